@@ -1,0 +1,1205 @@
+// refinputs.cpp -- host-side builders for the *inputs* of the per-pixel pass (C ABI: include/fs_inputs.h).
+//
+// The MI355X renderer consumes what FractalShark's host code already produces: a view (bounding box ->
+// dx/dy/centre), a reference orbit (PerturbationResults layout) and an LAv2 table (LAReference layout).
+// On a FractalShark host these come from Fractal.cpp / RefOrbitCalc.cpp / LAReference.cpp; this file is
+// the stand-alone equivalent used by bench.py, the tests and the oracle harness, so that the whole
+// pipeline can run where FractalShark itself is not built.  It is upstream of the hot path (SURVEY.md
+// section 8(f) rows 1-3), host-only, single-threaded, and follows the reference call-for-call on GMP's
+// mpf_t so the extracted float/double values are the reference's:
+//
+//   view      FractalViewPresets.cpp GetViewPreset, PointZoomBBConverter.cpp:26-53,100-117,271-330,
+//             PrecisionCalculator.cpp:58-108, Fractal.cpp:264-307,591-629
+//   coords    Fractal.cpp:2118-2119 (direct), :2230-2238 / :2513-2521 (perturbation)
+//   orbit     RefOrbitCalc.cpp:244-249,423-647 (ST / STPeriodicity), PerturbationResults.cpp:812-884
+//   LA table  LAReference.cpp:28-210 (stage 0, single-threaded), :215-770 (stage 0, multi-threaded
+//             hand-off, replayed sequentially), :774-966 (higher stages), :971-1013, :1050-1074 (AT);
+//             LAInfoDeep.h:108-391,456-506; LAParameters.h:66-75
+#include <gmp.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../csrc/hdr_math.hpp"
+#include "../../include/fs_inputs.h"
+
+using namespace fs;
+
+namespace {
+
+// ------------------------------------------------------------------ mpf wrapper (HighPrecision.h)
+// Mirrors HighPrecisionT: values carry their own precision; binary operators produce a result with the
+// precision of the left operand (HighPrecision.h:262-300); default-constructed values use
+// mpf_get_default_prec().
+struct Mp {
+    mpf_t v;
+    Mp() { mpf_init(v); }
+    explicit Mp(uint64_t prec_bits, int) { mpf_init2(v, prec_bits); }
+    Mp(const Mp &o)
+    {
+        mpf_init2(v, mpf_get_prec(o.v));
+        mpf_set(v, o.v);
+    }
+    Mp &operator=(const Mp &o)
+    {
+        if (this != &o) {
+            mpf_set_prec(v, mpf_get_prec(o.v));
+            mpf_set(v, o.v);
+        }
+        return *this;
+    }
+    ~Mp() { mpf_clear(v); }
+    static Mp from_str(const char *s)
+    {
+        Mp r;
+        mpf_set_str(r.v, s, 10);
+        return r;
+    }
+    static Mp from_ui(uint64_t x)
+    {
+        Mp r;
+        mpf_set_ui(r.v, x);
+        return r;
+    }
+    uint64_t prec() const { return (uint32_t)mpf_get_prec(v); }
+    void set_prec(uint64_t p) { mpf_set_prec(v, p); }
+};
+
+Mp operator+(const Mp &a, const Mp &b)
+{
+    Mp r(a.prec(), 0);
+    mpf_add(r.v, a.v, b.v);
+    return r;
+}
+Mp operator-(const Mp &a, const Mp &b)
+{
+    Mp r(a.prec(), 0);
+    mpf_sub(r.v, a.v, b.v);
+    return r;
+}
+Mp operator/(const Mp &a, const Mp &b)
+{
+    Mp r(a.prec(), 0);
+    mpf_div(r.v, a.v, b.v);
+    return r;
+}
+Mp mp_abs(const Mp &a)
+{
+    Mp r(a.prec(), 0);
+    mpf_abs(r.v, a.v);
+    return r;
+}
+
+// HDRFloat(const mpf_t) -- HDRFloat.h:366-389: mantissa in [0.5,1) as returned by mpf_get_d_2exp, cast
+// to F; NOT reduced.  Zero -> default.
+template <class F> hreal<F> hr_from_mpf(const mpf_t x)
+{
+    if (mpf_cmp_ui(x, 0) == 0)
+        return hr_zero<F>();
+    long e;
+    const double d = mpf_get_d_2exp(&e, x);
+    return hreal<F>{(F)d, (int32_t)e};
+}
+
+} // namespace
+
+// ------------------------------------------------------------------ view
+struct fsh_view {
+    Mp minX, minY, maxX, maxY, ptX, ptY, zoom;
+    uint64_t prec_bits = 0;
+    uint32_t width = 0, height = 0;
+};
+
+namespace {
+
+// PointZoomBBConverter::SquareAspectRatio, PointZoomBBConverter.cpp:271-330.
+void square_aspect(fsh_view &vw, size_t scrnWidth, size_t scrnHeight)
+{
+    if (scrnWidth == 0 || scrnHeight == 0)
+        return;
+    const uint64_t prec = vw.ptX.prec();
+    Mp ratio(prec, 0), mwidth(prec, 0), height(prec, 0), tmp(prec, 0);
+    {
+        Mp w = Mp::from_ui(scrnWidth);
+        Mp h = Mp::from_ui(scrnHeight);
+        mpf_div(ratio.v, w.v, h.v);
+    }
+    mpf_sub(mwidth.v, vw.maxX.v, vw.minX.v);
+    mpf_div(mwidth.v, mwidth.v, ratio.v);
+    mpf_sub(height.v, vw.maxY.v, vw.minY.v);
+
+    if (mpf_cmp(height.v, mwidth.v) > 0) {
+        mpf_sub(tmp.v, height.v, mwidth.v);
+        mpf_mul(tmp.v, ratio.v, tmp.v);
+        mpf_div_ui(tmp.v, tmp.v, 2);
+        mpf_sub(vw.minX.v, vw.minX.v, tmp.v);
+        mpf_add(vw.maxX.v, vw.maxX.v, tmp.v);
+    } else if (mpf_cmp(height.v, mwidth.v) < 0) {
+        mpf_sub(tmp.v, mwidth.v, height.v);
+        mpf_div_ui(tmp.v, tmp.v, 2);
+        mpf_sub(vw.minY.v, vw.minY.v, tmp.v);
+        mpf_add(vw.maxY.v, vw.maxY.v, tmp.v);
+    }
+    mpf_add(vw.ptX.v, vw.minX.v, vw.maxX.v);
+    mpf_div_ui(vw.ptX.v, vw.ptX.v, 2);
+    mpf_add(vw.ptY.v, vw.minY.v, vw.maxY.v);
+    mpf_div_ui(vw.ptY.v, vw.ptY.v, 2);
+
+    Mp deltaY(prec, 0);
+    mpf_sub(deltaY.v, vw.maxY.v, vw.minY.v);
+    if (mpf_cmp_ui(deltaY.v, 0) == 0) {
+        vw.zoom = Mp::from_ui(1);
+    } else {
+        Mp two = Mp::from_ui(2);
+        mpf_div(vw.zoom.v, two.v, deltaY.v);
+        mpf_mul_ui(vw.zoom.v, vw.zoom.v, 2);
+    }
+}
+
+} // namespace
+
+extern "C" fsh_view *fsh_view_create(const char *minX, const char *minY, const char *maxX, const char *maxY,
+                                     uint32_t width, uint32_t height)
+{
+    // GetViewPreset: coordinates are parsed at 1,000,000 bits (FractalViewPresets.cpp:11-12).
+    mpf_set_default_prec(1000000);
+    auto vw = std::make_unique<fsh_view>();
+    vw->width = width;
+    vw->height = height;
+    vw->minX = Mp::from_str(minX);
+    vw->minY = Mp::from_str(minY);
+    vw->maxX = Mp::from_str(maxX);
+    vw->maxY = Mp::from_str(maxY);
+    // PointZoomBBConverter(minX,minY,maxX,maxY), PointZoomBBConverter.cpp:26-53
+    {
+        Mp two = Mp::from_ui(2);
+        vw->ptX = (vw->minX + vw->maxX) / two;
+        vw->ptY = (vw->minY + vw->maxY) / two;
+        Mp deltaY = vw->maxY - vw->minY;
+        if (mpf_cmp_ui(deltaY.v, 0) == 0) {
+            vw->zoom = Mp::from_ui(1);
+        } else {
+            Mp zf = Mp::from_ui(2) / deltaY;
+            Mp zf2(zf.prec(), 0);
+            mpf_mul(zf2.v, zf.v, two.v);
+            vw->zoom = zf2;
+        }
+    }
+    // Fractal::SetPrecision -> PrecisionCalculator::GetPrecision (PrecisionCalculator.cpp:21-107);
+    // RequiresReuse() is false for the ST algorithms this file implements.
+    {
+        Mp dX = mp_abs(vw->maxX - vw->minX);
+        Mp dY = mp_abs(vw->maxY - vw->minY);
+        const hreal<double> tx = hr_from_mpf<double>(dX.v);
+        const hreal<double> ty = hr_from_mpf<double>(dY.v);
+        uint64_t larger = (uint64_t)std::max(std::abs(tx.e), std::abs(ty.e));
+        larger += 120; // AuthoritativeMinExtraPrecisionInBits, HighPrecision.h
+        vw->prec_bits = larger;
+    }
+    // PointZoomBBConverter::SetPrecision, PointZoomBBConverter.cpp:100-117
+    mpf_set_default_prec(vw->prec_bits);
+    vw->minX.set_prec(vw->prec_bits);
+    vw->minY.set_prec(vw->prec_bits);
+    vw->maxX.set_prec(vw->prec_bits);
+    vw->maxY.set_prec(vw->prec_bits);
+    vw->ptX.set_prec(vw->prec_bits);
+    vw->ptY.set_prec(vw->prec_bits);
+    vw->zoom.set_prec(vw->prec_bits);
+    square_aspect(*vw, width, height);
+    return vw.release();
+}
+
+extern "C" void fsh_view_destroy(fsh_view *v) { delete v; }
+extern "C" uint64_t fsh_view_precision_bits(const fsh_view *v) { return v->prec_bits; }
+
+extern "C" int fsh_view_bbox_str(const fsh_view *v, int which, char *buf, size_t buflen)
+{
+    const Mp *p = which == 0 ? &v->minX : which == 1 ? &v->minY : which == 2 ? &v->maxX : &v->maxY;
+    return gmp_snprintf(buf, buflen, "%.Fe", p->v);
+}
+
+// Cpu64 / direct kernels: dx, dy, minX, maxY as doubles -- Fractal.cpp:2118-2119,2148-2151
+// (T(HighPrecision) for T=double is mpf_get_d, HighPrecision.h:497-501).
+extern "C" void fsh_view_coords_direct_f64(const fsh_view *v, uint32_t w_aa, uint32_t h_aa, double out[4])
+{
+    mpf_set_default_prec(v->prec_bits);
+    Mp dx = (v->maxX - v->minX) / Mp::from_ui(w_aa);
+    Mp dy = (v->maxY - v->minY) / Mp::from_ui(h_aa);
+    out[0] = mpf_get_d(dx.v);
+    out[1] = mpf_get_d(dy.v);
+    out[2] = mpf_get_d(v->minX.v);
+    out[3] = mpf_get_d(v->maxY.v);
+}
+
+// ------------------------------------------------------------------ reference orbit
+template <class F> struct OrbitT {
+    std::vector<hreal<F>> x, y; // entry 0 is the explicit zero entry
+    uint64_t period = 0;
+    hreal<F> maxRadius{};
+    hreal<F> orbitXLow{}, orbitYLow{};
+    Mp cx, cy; // reference point (m_OrbitX / m_OrbitY)
+    uint64_t prec_bits = 0;
+    // packed copies in the ABI layout, built lazily
+    std::vector<fs_orbit_hdr32> packed32;
+    std::vector<fs_orbit_hdr64> packed64;
+};
+
+struct fsh_orbit {
+    int is64 = 0;
+    OrbitT<float> f;
+    OrbitT<double> d;
+};
+
+namespace {
+
+// AddPerturbationReferencePointST<..., Periodicity, ...>, RefOrbitCalc.cpp:423-647, for T = HDRFloat<F>,
+// PerturbExtras::Disable, ReuseMode::DontSaveForReuse.
+template <class F> void build_orbit(const fsh_view &vw, uint64_t max_iter, bool periodicity, OrbitT<F> &ob)
+{
+    mpf_set_default_prec(vw.prec_bits);
+    ob.prec_bits = vw.prec_bits;
+    // RefOrbitCalc.cpp:244-249: guess = bbox midpoint
+    {
+        Mp two = Mp::from_ui(2);
+        ob.cx = (vw.maxX + vw.minX) / two;
+        ob.cy = (vw.maxY + vw.minY) / two;
+    }
+    // PerturbationResults::InitResults, PerturbationResults.cpp:812-884
+    {
+        Mp delta = vw.maxY - vw.minY;
+        const hreal<F> radiusY = hr_div(hr_from_mpf<F>(delta.v), hr_from_mant<F>(F(2)));
+        ob.maxRadius = hr_reduced(radiusY);
+        ob.orbitXLow = hr_from_mpf<F>(ob.cx.v);
+        ob.orbitYLow = hr_from_mpf<F>(ob.cy.v);
+    }
+    ob.x.clear();
+    ob.y.clear();
+    ob.x.push_back(hr_zero<F>());
+    ob.y.push_back(hr_zero<F>());
+    ob.period = 0;
+
+    mpf_t cx, cy, zx, zy, zx2, t1, t2;
+    mpf_init(cx);
+    mpf_set(cx, ob.cx.v);
+    mpf_init(cy);
+    mpf_set(cy, ob.cy.v);
+    mpf_init(zx);
+    mpf_init(zy);
+    mpf_init(zx2);
+    mpf_init(t1);
+    mpf_init(t2);
+
+    hreal<F> dzdcX = hr_from_number<F>(F(1));
+    hreal<F> dzdcY = hr_from_number<F>(F(0));
+    hreal<F> cx_cast, cy_cast;
+    {
+        long e;
+        double m = mpf_get_d_2exp(&e, cx);
+        cx_cast = hr_raw<F>((int32_t)e, (F)m);
+        m = mpf_get_d_2exp(&e, cy);
+        cy_cast = hr_raw<F>((int32_t)e, (F)m);
+    }
+    const hreal<F> HighOne = hr_from_number<F>(F(1));
+    const hreal<F> HighTwo = hr_from_number<F>(F(2));
+    const hreal<F> TwoFiftySix = hr_from_number<F>(F(256));
+
+    mpf_set(zx, cx);
+    mpf_set(zy, cy);
+
+    for (uint64_t i = 0; i < max_iter; i++) {
+        mpf_mul_2exp(zx2, zx, 1);
+        hreal<F> double_zx = hr_from_mpf<F>(zx);
+        hreal<F> double_zy = hr_from_mpf<F>(zy);
+        ob.x.push_back(double_zx);
+        ob.y.push_back(double_zy);
+
+        if (periodicity) {
+            hr_reduce(dzdcX);
+            const hreal<F> dzdcX1 = hr_abs(dzdcX);
+            hr_reduce(dzdcY);
+            const hreal<F> dzdcY1 = hr_abs(dzdcY);
+            hr_reduce(double_zx);
+            const hreal<F> zxCopy1 = hr_abs(double_zx);
+            hr_reduce(double_zy);
+            const hreal<F> zyCopy1 = hr_abs(double_zy);
+            const hreal<F> n2 = hr_max_pos(zxCopy1, zyCopy1); // HdrMaxPositiveReduced
+            const hreal<F> r0 = hr_max_pos(dzdcX1, dzdcY1);
+            hreal<F> n3 = hr_mul(hr_mul(ob.maxRadius, r0), HighTwo);
+            hr_reduce(n3);
+            if (hr_cmp_pos(n2, n3) < 0) {
+                ob.period = ob.x.size(); // GetCountOrbitEntries()
+                break;
+            } else {
+                const hreal<F> dzdcXOrig = dzdcX;
+                dzdcX = hr_add(hr_mul(HighTwo, hr_sub(hr_mul(double_zx, dzdcX), hr_mul(double_zy, dzdcY))), HighOne);
+                dzdcY = hr_mul(HighTwo, hr_add(hr_mul(double_zx, dzdcY), hr_mul(double_zy, dzdcXOrig)));
+            }
+        }
+
+        mpf_mul(t1, zx, zx);
+        mpf_mul(t2, zy, zy);
+        mpf_sub(zx, t1, t2);
+        mpf_add(zx, zx, cx);
+        mpf_mul(zy, zx2, zy);
+        mpf_add(zy, zy, cy);
+
+        // RefOrbitCalc.cpp:616-622: tests z_i + c (not z_{i+1}), unreduced, against 256.
+        const hreal<F> tempZX = hr_add(double_zx, cx_cast);
+        const hreal<F> tempZY = hr_add(double_zy, cy_cast);
+        const hreal<F> zn = hr_add(hr_mul(tempZX, tempZX), hr_mul(tempZY, tempZY));
+        if (hr_cmp_pos(zn, TwoFiftySix) > 0)
+            break;
+    }
+    mpf_clear(cx);
+    mpf_clear(cy);
+    mpf_clear(zx);
+    mpf_clear(zy);
+    mpf_clear(zx2);
+    mpf_clear(t1);
+    mpf_clear(t2);
+}
+
+} // namespace
+
+extern "C" fsh_orbit *fsh_orbit_create(const fsh_view *v, int is64, uint64_t max_iter, int periodicity)
+{
+    auto ob = std::make_unique<fsh_orbit>();
+    ob->is64 = is64;
+    if (is64)
+        build_orbit<double>(*v, max_iter, periodicity != 0, ob->d);
+    else
+        build_orbit<float>(*v, max_iter, periodicity != 0, ob->f);
+    return ob.release();
+}
+extern "C" void fsh_orbit_destroy(fsh_orbit *o) { delete o; }
+extern "C" uint64_t fsh_orbit_count(const fsh_orbit *o) { return o->is64 ? o->d.x.size() : o->f.x.size(); }
+extern "C" uint64_t fsh_orbit_period(const fsh_orbit *o) { return o->is64 ? o->d.period : o->f.period; }
+
+extern "C" const fs_orbit_hdr32 *fsh_orbit_data_hdr32(fsh_orbit *o)
+{
+    if (o->is64)
+        return nullptr;
+    auto &ob = o->f;
+    if (ob.packed32.size() != ob.x.size()) {
+        ob.packed32.resize(ob.x.size());
+        for (size_t i = 0; i < ob.x.size(); i++)
+            ob.packed32[i] = fs_orbit_hdr32{ob.x[i].m, ob.x[i].e, ob.y[i].e, ob.y[i].m};
+    }
+    return ob.packed32.data();
+}
+
+extern "C" const fs_orbit_hdr64 *fsh_orbit_data_hdr64(fsh_orbit *o)
+{
+    if (!o->is64)
+        return nullptr;
+    auto &ob = o->d;
+    if (ob.packed64.size() != ob.x.size()) {
+        ob.packed64.resize(ob.x.size());
+        for (size_t i = 0; i < ob.x.size(); i++)
+            ob.packed64[i] = fs_orbit_hdr64{ob.x[i].m, ob.x[i].e, 0, ob.y[i].e, 0, ob.y[i].m};
+    }
+    return ob.packed64.data();
+}
+
+extern "C" void fsh_orbit_max_radius_hdr32(const fsh_orbit *o, fs_real_hdr32 *out)
+{
+    out->m = o->f.maxRadius.m;
+    out->e = o->f.maxRadius.e;
+}
+
+// dx, dy, centerX, centerY for the perturbation paths -- Fractal.cpp:2230-2238 / 2513-2521:
+//   dx = Reduce(T((maxX-minX)/HP(W*AA))), centerX = Reduce(T(refX - minX)), centerY = Reduce(T(refY - maxY)).
+template <class F> static void perturb_coords(const fsh_view &v, const OrbitT<F> &ob, uint32_t w_aa, uint32_t h_aa,
+                                              hreal<F> out[4])
+{
+    mpf_set_default_prec(v.prec_bits);
+    Mp dx = (v.maxX - v.minX) / Mp::from_ui(w_aa);
+    Mp dy = (v.maxY - v.minY) / Mp::from_ui(h_aa);
+    Mp cX = ob.cx - v.minX;
+    Mp cY = ob.cy - v.maxY;
+    out[0] = hr_reduced(hr_from_mpf<F>(dx.v));
+    out[1] = hr_reduced(hr_from_mpf<F>(dy.v));
+    out[2] = hr_reduced(hr_from_mpf<F>(cX.v));
+    out[3] = hr_reduced(hr_from_mpf<F>(cY.v));
+}
+
+extern "C" void fsh_view_coords_perturb_hdr32(const fsh_view *v, const fsh_orbit *o, uint32_t w_aa, uint32_t h_aa,
+                                              fs_real_hdr32 out[4])
+{
+    hreal<float> t[4];
+    perturb_coords<float>(*v, o->f, w_aa, h_aa, t);
+    for (int i = 0; i < 4; i++)
+        out[i] = fs_real_hdr32{t[i].m, t[i].e};
+}
+
+extern "C" void fsh_view_coords_perturb_hdr64(const fsh_view *v, const fsh_orbit *o, uint32_t w_aa, uint32_t h_aa,
+                                              fs_real_hdr64 out[4])
+{
+    hreal<double> t[4];
+    perturb_coords<double>(*v, o->d, w_aa, h_aa, t);
+    for (int i = 0; i < 4; i++)
+        out[i] = fs_real_hdr64{t[i].m, t[i].e, 0};
+}
+
+// ------------------------------------------------------------------ LAv2 table
+namespace {
+
+// LAParameters defaults, LAParameters.h:66-75 / LAParameters.cpp:61-71 (floats are exp2 of the exponents).
+struct LAParams {
+    int detectionMethod = 1;
+    int laThresholdScaleExp = -24;
+    int laThresholdCScaleExp = -24;
+    int stage0PeriodDetectionThreshold2Exp = -6;
+    int periodDetectionThreshold2Exp = -3;
+    int stage0PeriodDetectionThresholdExp = -10;
+    int periodDetectionThresholdExp = -10;
+};
+
+// `HDRFloat * float` for a power-of-two float goes through HDRFloat(T mant) -> {1.0, exp}.
+template <class F> hreal<F> pow2_hr(int e) { return hreal<F>{F(1), e}; }
+
+template <class F> struct LAInfo {
+    hcplx<F> Ref = hc_zero<F>();
+    hcplx<F> ZCoeff = hc_zero<F>();
+    hcplx<F> CCoeff = hc_zero<F>();
+    hreal<F> LAThreshold = hr_zero<F>();
+    hreal<F> LAThresholdC = hr_zero<F>();
+    hreal<F> MinMag = hr_zero<F>();
+    uint32_t StepLength = 0;
+    uint32_t NextStageLAIndex = 0;
+};
+
+// LAInfoDeep(la_parameters, z), LAInfoDeep.h:108-131
+template <class F> LAInfo<F> la_init(const LAParams &p, hcplx<F> z)
+{
+    LAInfo<F> r;
+    r.Ref = z;
+    r.ZCoeff = hc_from_native<F>(F(1), F(0));
+    r.CCoeff = hc_from_native<F>(F(1), F(0));
+    r.LAThreshold = hr_from_number<F>(F(1));
+    r.LAThresholdC = hr_from_number<F>(F(1));
+    if (p.detectionMethod == 1)
+        r.MinMag = hr_from_number<F>(F(4));
+    return r;
+}
+
+// LAInfoDeep::Step(params, out, z), LAInfoDeep.h:178-246 -- `out` keeps whatever it held in the fields
+// Step does not write (LAi; MinMag when detectionMethod != 1).
+template <class F> bool la_step(const LAParams &p, const LAInfo<F> &self, LAInfo<F> &out, hcplx<F> z)
+{
+    const hreal<F> ChebyMagz = hc_cheb(z);
+    const hreal<F> ChebyMagZCoeff = hc_cheb(self.ZCoeff);
+    const hreal<F> ChebyMagCCoeff = hc_cheb(self.CCoeff);
+    if (p.detectionMethod == 1)
+        out.MinMag = hr_min_pos(ChebyMagz, self.MinMag);
+
+    hreal<F> temp1 = hr_mul(hr_div(ChebyMagz, ChebyMagZCoeff), pow2_hr<F>(p.laThresholdScaleExp));
+    hr_reduce(temp1);
+    hreal<F> temp2 = hr_mul(hr_div(ChebyMagz, ChebyMagCCoeff), pow2_hr<F>(p.laThresholdCScaleExp));
+    hr_reduce(temp2);
+    out.LAThreshold = hr_min_pos(self.LAThreshold, temp1);
+    out.LAThresholdC = hr_min_pos(self.LAThresholdC, temp2);
+
+    const hcplx<F> z2 = hc_mul_real(z, hr_from_number<F>(F(2)));
+    out.ZCoeff = hc_reduced(hc_mul(z2, self.ZCoeff));
+    out.CCoeff = hc_reduced(hc_add_real(hc_mul(z2, self.CCoeff), hr_from_number<F>(F(1))));
+    out.Ref = self.Ref;
+
+    if (p.detectionMethod == 1)
+        return hr_cmp_pos(out.MinMag, hr_mul(self.MinMag, pow2_hr<F>(p.stage0PeriodDetectionThreshold2Exp))) < 0;
+    return hr_cmp_pos(out.LAThreshold, hr_mul(self.LAThreshold, pow2_hr<F>(p.stage0PeriodDetectionThresholdExp))) < 0;
+}
+
+// LAInfoDeep::Step(params, z) returning a fresh record, LAInfoDeep.h:268-277
+template <class F> LAInfo<F> la_step_new(const LAParams &p, const LAInfo<F> &self, hcplx<F> z)
+{
+    LAInfo<F> r;
+    la_step(p, self, r, z);
+    return r;
+}
+
+// LAInfoDeep::DetectPeriod, LAInfoDeep.h:133-155
+template <class F> bool la_detect_period(const LAParams &p, const LAInfo<F> &self, hcplx<F> z)
+{
+    if (p.detectionMethod == 1)
+        return hr_cmp_pos(hc_cheb(z), hr_mul(self.MinMag, pow2_hr<F>(p.periodDetectionThreshold2Exp))) < 0;
+    const hreal<F> lhs =
+        hr_mul(hr_div(hc_cheb(z), hc_cheb(self.ZCoeff)), pow2_hr<F>(p.laThresholdScaleExp));
+    return hr_cmp_pos(lhs, hr_mul(self.LAThreshold, pow2_hr<F>(p.periodDetectionThresholdExp))) < 0;
+}
+
+// LAInfoDeep::Composite(params, out, LA), LAInfoDeep.h:279-369
+template <class F> bool la_composite(const LAParams &p, const LAInfo<F> &self, LAInfo<F> &out, const LAInfo<F> &LA)
+{
+    const hcplx<F> z = LA.Ref;
+    const hreal<F> ChebyMagz = hc_cheb(z);
+    hreal<F> ChebyMagZCoeff = hc_cheb(self.ZCoeff);
+    hreal<F> ChebyMagCCoeff = hc_cheb(self.CCoeff);
+
+    hreal<F> temp1 = hr_mul(hr_div(ChebyMagz, ChebyMagZCoeff), pow2_hr<F>(p.laThresholdScaleExp));
+    hr_reduce(temp1);
+    hreal<F> temp2 = hr_mul(hr_div(ChebyMagz, ChebyMagCCoeff), pow2_hr<F>(p.laThresholdCScaleExp));
+    hr_reduce(temp2);
+    hreal<F> outLAThreshold = hr_min_pos(self.LAThreshold, temp1);
+    hreal<F> outLAThresholdC = hr_min_pos(self.LAThresholdC, temp2);
+
+    const hcplx<F> z2 = hc_mul_real(z, hr_from_number<F>(F(2)));
+    hcplx<F> outZCoeff = hc_reduced(hc_mul(z2, self.ZCoeff));
+    hcplx<F> outCCoeff = hc_reduced(hc_mul(z2, self.CCoeff));
+    ChebyMagZCoeff = hc_cheb(outZCoeff);
+    ChebyMagCCoeff = hc_cheb(outCCoeff);
+    hreal<F> temp = outLAThreshold;
+
+    temp1 = hr_div(LA.LAThreshold, ChebyMagZCoeff);
+    hr_reduce(temp1);
+    temp2 = hr_div(LA.LAThreshold, ChebyMagCCoeff);
+    hr_reduce(temp2);
+    outLAThreshold = hr_min_pos(outLAThreshold, temp1);
+    outLAThresholdC = hr_min_pos(outLAThresholdC, temp2);
+    outZCoeff = hc_reduced(hc_mul(outZCoeff, LA.ZCoeff));
+    outCCoeff = hc_reduced(hc_add(hc_mul(outCCoeff, LA.ZCoeff), LA.CCoeff));
+
+    out.LAThreshold = outLAThreshold;
+    out.LAThresholdC = outLAThresholdC;
+    out.ZCoeff = outZCoeff;
+    out.CCoeff = outCCoeff;
+    out.Ref = self.Ref;
+
+    if (p.detectionMethod == 1) {
+        temp = hr_min_pos(ChebyMagz, self.MinMag);
+        out.MinMag = hr_min_pos(temp, LA.MinMag);
+        return hr_cmp_pos(temp, hr_mul(self.MinMag, pow2_hr<F>(p.periodDetectionThreshold2Exp))) < 0;
+    }
+    return hr_cmp_pos(temp, hr_mul(self.LAThreshold, pow2_hr<F>(p.periodDetectionThresholdExp))) < 0;
+}
+template <class F> LAInfo<F> la_composite_new(const LAParams &p, const LAInfo<F> &self, const LAInfo<F> &LA)
+{
+    LAInfo<F> r;
+    la_composite(p, self, r, LA);
+    return r;
+}
+
+template <class F> struct ATInfoT {
+    uint32_t StepLength = 0;
+    hreal<F> ThresholdC = hr_zero<F>(), SqrEscapeRadius = hr_zero<F>();
+    hcplx<F> RefC = hc_zero<F>(), ZCoeff = hc_zero<F>(), CCoeff = hc_zero<F>(), InvZCoeff = hc_zero<F>();
+    hcplx<F> CCoeffSqrInvZCoeff = hc_zero<F>(), CCoeffInvZCoeff = hc_zero<F>();
+    hreal<F> CCoeffNormSqr = hr_zero<F>(), RefCNormSqr = hr_zero<F>();
+    hreal<F> factor = hr_from_number<F>(F(4294967296.0)); // HDRFloat(0x1.0p32), ATInfo.h:132
+};
+
+// LAInfoDeep::CreateAT, LAInfoDeep.h:456-506 (IsHDR branch; UseSmallExponents only matters for double).
+template <class F> void la_create_at(const LAInfo<F> &self, ATInfoT<F> &R, const LAInfo<F> &Next, bool useSmallExponents)
+{
+    R.ZCoeff = self.ZCoeff;
+    R.CCoeff = hc_reduced(hc_mul(self.ZCoeff, self.CCoeff));
+    R.InvZCoeff = hc_reduced(hc_recip(self.ZCoeff));
+    R.CCoeffSqrInvZCoeff = hc_reduced(hc_mul(hc_mul(R.CCoeff, R.CCoeff), R.InvZCoeff));
+    R.CCoeffInvZCoeff = hc_reduced(hc_mul(R.CCoeff, R.InvZCoeff));
+    R.RefC = hc_reduced(hc_mul(Next.Ref, self.ZCoeff));
+    R.CCoeffNormSqr = hr_reduced(hc_norm2(R.CCoeff));
+    R.RefCNormSqr = hr_reduced(hc_norm2(R.RefC));
+
+    hreal<F> lim = hr_raw<F>(32, F(1));
+    if (sizeof(F) == 8 && !useSmallExponents)
+        lim.e = 256;
+    hr_reduce(lim);
+    R.SqrEscapeRadius = hr_reduced(hr_min_pos(hr_mul(hc_norm2(self.ZCoeff), self.LAThreshold), lim));
+    R.ThresholdC = hr_min_pos(self.LAThresholdC, hr_div(lim, hc_cheb(R.CCoeff)));
+}
+
+// ATInfo::Usable, ATInfo.h:101-116
+template <class F> bool at_usable(const ATInfoT<F> &at, hreal<F> SqrRadius)
+{
+    const hreal<F> result = hr_reduced(hr_mul(hr_mul(at.CCoeffNormSqr, SqrRadius), at.factor));
+    const hreal<F> Four = hr_from_mant<F>(F(4));
+    return hr_cmp_pos(result, at.RefCNormSqr) > 0 && hr_cmp_pos(at.SqrEscapeRadius, Four) > 0;
+}
+
+template <class F> struct LATable {
+    std::vector<LAInfo<F>> las;
+    std::vector<fs_la_stage_u32> stages; // only [0, stageCount) meaningful
+    uint32_t stageCount = 0;
+    bool useAT = false;
+    bool isValid = false;
+    ATInfoT<F> at;
+    std::vector<fs_la_hdr32_u32> packed32;
+    std::vector<fs_la_stage_u32> packedStages;
+};
+
+constexpr uint32_t kLowBound = 64;   // LAReference.h:56
+constexpr int kPeriodDivisor = 2;    // LAReference.cpp:18-19 (PerturbExtras::Disable)
+constexpr uint32_t kMaxLAStages = 1024;
+
+template <class F> struct LABuilder {
+    const LAParams p;
+    const OrbitT<F> &ob;
+    LATable<F> &T;
+    LABuilder(const OrbitT<F> &o, LATable<F> &t) : p{}, ob(o), T(t) {}
+
+    hcplx<F> Z(uint64_t i) const { return hc_from_hr(ob.x[i], ob.y[i]); } // GetComplex<SubType>()
+
+    uint32_t la_size() const { return (uint32_t)T.las.size(); }
+
+    // Shared prologue of CreateLAFromOrbit / CreateLAFromOrbitMT (LAReference.cpp:40-151 == :256-352).
+    // Returns 0 = finished with `false`, 1 = continue into the main scan.
+    int stage0_prologue(uint32_t maxRef, LAInfo<F> &LA, uint32_t &i, uint32_t &Period, uint32_t &PeriodBegin,
+                        uint32_t &PeriodEnd, uint32_t &nextStageLAIndex)
+    {
+        T.isValid = false;
+        T.stages.assign(kMaxLAStages, fs_la_stage_u32{0, 0});
+        T.useAT = false;
+        T.stageCount = 0;
+        T.stages[0].LAIndex = 0;
+
+        Period = 0;
+        LA = la_init<F>(p, hc_zero<F>());
+        LA = la_step_new(p, LA, Z(1));
+        nextStageLAIndex = 0;
+        if (LA.ZCoeff.re == F(0) && LA.ZCoeff.im == F(0)) // isZCoeffZero
+            return 0;
+
+        for (i = 2; i < maxRef; i++) {
+            LAInfo<F> NewLA;
+            const bool PeriodDetected = la_step(p, LA, NewLA, Z(i));
+            if (!PeriodDetected) {
+                LA = NewLA;
+                continue;
+            }
+            Period = i;
+            LA.StepLength = Period;
+            LA.NextStageLAIndex = nextStageLAIndex;
+            T.las.push_back(LA);
+            nextStageLAIndex = i;
+            if (i + 1 < maxRef) {
+                LA = la_step_new(p, la_init<F>(p, Z(i)), Z(i + 1));
+                i += 2;
+            } else {
+                LA = la_init<F>(p, Z(i));
+                i += 1;
+            }
+            break;
+        }
+        T.stageCount = 1;
+        PeriodBegin = Period;
+        PeriodEnd = PeriodBegin + Period;
+
+        if (Period == 0) {
+            if (maxRef > kLowBound) {
+                LA = la_step_new(p, la_init<F>(p, Z(0)), Z(1));
+                nextStageLAIndex = 0;
+                i = 2;
+                const double NthRoot = std::round(std::log2((double)maxRef) / kPeriodDivisor);
+                Period = (uint32_t)std::round(std::pow((double)maxRef, 1.0 / NthRoot));
+                PeriodBegin = 0;
+                PeriodEnd = Period;
+            } else {
+                LA.StepLength = maxRef;
+                LA.NextStageLAIndex = nextStageLAIndex;
+                T.las.push_back(LA);
+                T.las.push_back(la_init<F>(p, Z(maxRef)));
+                T.stages[0].MacroItCount = 1;
+                return 0;
+            }
+        } else if (Period > kLowBound) {
+            T.las.pop_back();
+            LA = la_step_new(p, la_init<F>(p, Z(0)), Z(1));
+            nextStageLAIndex = 0;
+            i = 2;
+            const double NthRoot = std::round(std::log2((double)maxRef) / kPeriodDivisor);
+            Period = (uint32_t)std::round(std::pow((double)maxRef, 1.0 / NthRoot));
+            PeriodBegin = 0;
+            PeriodEnd = Period;
+        }
+        return 1;
+    }
+
+    // CreateLAFromOrbit, LAReference.cpp:28-210
+    bool create_stage0_st(uint32_t maxRef)
+    {
+        LAInfo<F> LA;
+        uint32_t i, Period, PeriodBegin, PeriodEnd, nextIdx;
+        if (!stage0_prologue(maxRef, LA, i, Period, PeriodBegin, PeriodEnd, nextIdx))
+            return false;
+        for (; i < maxRef; i++) {
+            LAInfo<F> NewLA;
+            const bool PeriodDetected = la_step(p, LA, NewLA, Z(i));
+            if (!PeriodDetected && i < PeriodEnd) {
+                LA = NewLA;
+                continue;
+            }
+            LA.StepLength = i - PeriodBegin;
+            LA.NextStageLAIndex = nextIdx;
+            T.las.push_back(LA);
+            nextIdx = i;
+            PeriodBegin = i;
+            PeriodEnd = PeriodBegin + Period;
+            const uint32_t ip1 = i + 1;
+            const bool detected = la_detect_period(p, NewLA, Z(ip1));
+            if (detected || ip1 >= maxRef) {
+                LA = la_init<F>(p, Z(i));
+            } else {
+                LA = la_step_new(p, la_init<F>(p, Z(i)), Z(ip1));
+                i++;
+            }
+        }
+        LA.StepLength = i - PeriodBegin;
+        LA.NextStageLAIndex = nextIdx;
+        T.las.push_back(LA);
+        T.stages[0].MacroItCount = la_size();
+        LAInfo<F> LA2 = la_init<F>(p, Z(maxRef));
+        T.las.push_back(LA2);
+        return true;
+    }
+
+    // CreateNewLAStage, LAReference.cpp:774-966
+    bool create_new_stage(uint32_t maxRef)
+    {
+        LAInfo<F> LA;
+        uint32_t liStep = 0, liNext = 0; // LAI
+        uint32_t i, PeriodBegin, PeriodEnd;
+        const uint32_t PrevStage = T.stageCount - 1;
+        const uint32_t CurrentStage = T.stageCount;
+        const uint32_t PrevStageLAIndex = T.stages[PrevStage].LAIndex;
+        const uint32_t PrevStageMacroItCount = T.stages[PrevStage].MacroItCount;
+        const LAInfo<F> PrevStageLA = T.las[PrevStageLAIndex];
+        const uint32_t PrevStageLAI_Step = PrevStageLA.StepLength;
+        const LAInfo<F> PrevStageLAp1 = T.las[PrevStageLAIndex + 1];
+        const uint32_t PrevStageLAIp1_Step = PrevStageLAp1.StepLength;
+        uint32_t Period = 0;
+
+        if (CurrentStage >= kMaxLAStages)
+            return false;
+        T.stages[CurrentStage].LAIndex = la_size();
+
+        LA = la_composite_new(p, PrevStageLA, PrevStageLAp1);
+        liNext = 0;
+        i = PrevStageLAI_Step + PrevStageLAIp1_Step;
+        uint32_t j;
+        for (j = 2; j < PrevStageMacroItCount; j++) {
+            LAInfo<F> NewLA;
+            const uint32_t idxj = PrevStageLAIndex + j;
+            const LAInfo<F> PrevStageLAj = T.las[idxj];
+            const bool PeriodDetected = la_composite(p, LA, NewLA, PrevStageLAj);
+            if (PeriodDetected) {
+                if (PrevStageLAj.LAThreshold.m == F(0)) // isLAThresholdZero
+                    break;
+                Period = i;
+                liStep = Period;
+                LA.StepLength = liStep;
+                LA.NextStageLAIndex = liNext;
+                T.las.push_back(LA);
+                liNext = j;
+                const LAInfo<F> PrevStageLAjp1 = T.las[idxj + 1];
+                if (la_detect_period(p, NewLA, PrevStageLAjp1.Ref) || j + 1 >= PrevStageMacroItCount) {
+                    LA = PrevStageLAj;
+                    i += PrevStageLAj.StepLength;
+                    j++;
+                } else {
+                    LA = la_composite_new(p, PrevStageLAj, PrevStageLAjp1);
+                    i += PrevStageLAj.StepLength + PrevStageLAjp1.StepLength;
+                    j += 2;
+                }
+                break;
+            }
+            LA = NewLA;
+            i += T.las[PrevStageLAIndex + j].StepLength;
+        }
+        T.stageCount++;
+
+        PeriodBegin = Period;
+        PeriodEnd = PeriodBegin + Period;
+
+        if (Period == 0) {
+            if (maxRef > PrevStageLAI_Step * kLowBound) {
+                LA = la_composite_new(p, PrevStageLA, PrevStageLAp1);
+                i = PrevStageLAI_Step + PrevStageLAIp1_Step;
+                liNext = 0;
+                j = 2;
+                const double Ratio = ((double)maxRef) / PrevStageLAI_Step;
+                const double NthRoot = std::round(std::log2((double)maxRef) / kPeriodDivisor);
+                Period = PrevStageLAI_Step * (uint32_t)std::round(std::pow(Ratio, 1.0 / NthRoot));
+                PeriodBegin = 0;
+                PeriodEnd = Period;
+            } else {
+                liStep = maxRef;
+                LA.StepLength = liStep;
+                LA.NextStageLAIndex = liNext;
+                T.las.push_back(LA);
+                LAInfo<F> LA2 = la_init<F>(p, Z(maxRef));
+                T.las.push_back(LA2);
+                T.stages[CurrentStage].MacroItCount = 1;
+                return false;
+            }
+        } else if (Period > PrevStageLAI_Step * kLowBound) {
+            T.las.pop_back();
+            LA = la_composite_new(p, PrevStageLA, PrevStageLAp1);
+            i = PrevStageLAI_Step + PrevStageLAIp1_Step;
+            liNext = 0;
+            j = 2;
+            const double Ratio = ((double)Period) / PrevStageLAI_Step;
+            const double NthRoot = std::round(std::log2((double)maxRef) / kPeriodDivisor);
+            Period = PrevStageLAI_Step * ((uint32_t)std::round(std::pow(Ratio, 1.0 / NthRoot)));
+            PeriodBegin = 0;
+            PeriodEnd = Period;
+        }
+
+        for (; j < PrevStageMacroItCount; j++) {
+            LAInfo<F> NewLA;
+            const uint32_t idxj = PrevStageLAIndex + j;
+            const LAInfo<F> PrevStageLAj = T.las[idxj];
+            const bool PeriodDetected = la_composite(p, LA, NewLA, PrevStageLAj);
+            if (PeriodDetected || i >= PeriodEnd) {
+                liStep = i - PeriodBegin;
+                LA.StepLength = liStep;
+                LA.NextStageLAIndex = liNext;
+                T.las.push_back(LA);
+                liNext = j;
+                PeriodBegin = i;
+                PeriodEnd = PeriodBegin + Period;
+                const LAInfo<F> PrevStageLAjp1 = T.las[idxj + 1];
+                if (la_detect_period(p, NewLA, PrevStageLAjp1.Ref) || j + 1 >= PrevStageMacroItCount) {
+                    LA = PrevStageLAj;
+                } else {
+                    LA = la_composite_new(p, PrevStageLAj, PrevStageLAjp1);
+                    i += T.las[idxj].StepLength;
+                    j++;
+                }
+            } else {
+                LA = NewLA;
+            }
+            i += T.las[PrevStageLAIndex + j].StepLength;
+        }
+        liStep = i - PeriodBegin;
+        LA.StepLength = liStep;
+        LA.NextStageLAIndex = liNext;
+        T.las.push_back(LA);
+        T.stages[CurrentStage].MacroItCount = la_size() - T.stages[CurrentStage].LAIndex;
+        LA = la_init<F>(p, Z(maxRef));
+        T.las.push_back(LA);
+        return true;
+    }
+
+    // CreateATFromLA, LAReference.cpp:1050-1074
+    void create_at(hreal<F> radius, bool useSmallExponents)
+    {
+        const hreal<F> SqrRadius = hr_reduced(hr_square(radius));
+        for (uint32_t Stage = T.stageCount; Stage > 0;) {
+            Stage--;
+            const uint32_t LAIndex = T.stages[Stage].LAIndex;
+            la_create_at(T.las[LAIndex], T.at, T.las[LAIndex + 1], useSmallExponents);
+            T.at.StepLength = T.las[LAIndex].StepLength;
+            if (T.at.StepLength > 0 && at_usable(T.at, SqrRadius)) {
+                T.useAT = true;
+                return;
+            }
+        }
+        T.useAT = false;
+    }
+
+    // GenerateApproximationData, LAReference.cpp:971-1013
+    void generate(int threads)
+    {
+        T.las.clear();
+        const uint32_t maxRef = (uint32_t)ob.x.size() - 1;
+        if (maxRef == 0) {
+            T.isValid = false;
+            return;
+        }
+        bool PeriodDetected;
+        // CreateLAFromOrbitMT falls back to the single-threaded scan when
+        // maxRefIteration / 50000 (capped by hardware_concurrency) is < 2 (LAReference.cpp:236-251).
+        size_t threadCount = maxRef / 50000;
+        if (threadCount > (size_t)threads)
+            threadCount = threads;
+        if (threadCount <= 1) {
+            PeriodDetected = create_stage0_st(maxRef);
+        } else {
+            PeriodDetected = create_stage0_mt(maxRef, threadCount);
+        }
+        if (!PeriodDetected)
+            return;
+        while (create_new_stage(maxRef)) {
+        }
+        create_at(ob.maxRadius, false);
+        T.isValid = true;
+    }
+
+    bool create_stage0_mt(uint32_t maxRef, size_t threadCount);
+};
+
+// CreateLAFromOrbitMT, LAReference.cpp:215-770, replayed sequentially.  The reference runs a "Starter"
+// (thread 0, continues the scan from the prologue) and Workers 1..N-1 that each begin at a fixed orbit
+// index, find their first period boundary, publish it (StartIndexPromise) and scan on until they pass
+// the *next* worker's published start.  All cross-thread values are futures, so the outcome does not
+// depend on timing: replaying the workers from last to first and the starter last reproduces it.
+template <class F> bool LABuilder<F>::create_stage0_mt(uint32_t maxRef, size_t ThreadCount)
+{
+    LAInfo<F> LA;
+    uint32_t i, Period, PeriodBegin, PeriodEnd, nextIdx;
+    if (!stage0_prologue(maxRef, LA, i, Period, PeriodBegin, PeriodEnd, nextIdx))
+        return false;
+
+    std::vector<int64_t> StartIndex(ThreadCount, 0);
+    std::vector<int64_t> FinishIndex(ThreadCount, 0);
+    std::vector<std::vector<LAInfo<F>>> LAsPerThread(ThreadCount);
+    std::vector<LAInfo<F>> LastLAPerThread(ThreadCount);
+
+    // Workers, last first (each only waits on StartIndexFuture of higher thread ids).
+    for (size_t ThreadID = ThreadCount - 1; ThreadID >= 1; ThreadID--) {
+        size_t NextThread = ThreadID + 1;
+        const size_t LastThread = ThreadCount - 1;
+        const uint32_t Begin = (uint32_t)((uint64_t)maxRef * ThreadID / ThreadCount);
+        uint32_t j = Begin;
+        const uint32_t End = (uint32_t)((uint64_t)maxRef * NextThread / ThreadCount);
+
+        uint32_t liNext = j;
+        LAInfo<F> LA_2 = la_step_new(p, la_init<F>(p, Z(j)), Z(j + 1));
+        uint32_t j2 = j + 2;
+        LAInfo<F> LA_ = la_step_new(p, la_init<F>(p, Z(j - 1)), Z(j));
+        uint32_t j1 = j + 1;
+
+        uint32_t wPeriodBegin = 0, wPeriodEnd = 0;
+        bool PeriodDetected = false, PeriodDetected2 = false;
+
+        for (; j2 < maxRef || j1 < maxRef; j1++, j2++) {
+            LAInfo<F> NewLA;
+            PeriodDetected = la_step(p, LA_, NewLA, Z(j1));
+            if (PeriodDetected) {
+                liNext = j1;
+                wPeriodBegin = j1;
+                wPeriodEnd = wPeriodBegin + Period;
+                if (j1 + 1 >= maxRef) {
+                    LA_ = la_init<F>(p, Z(j1));
+                    j1 += 1;
+                } else {
+                    LA_ = la_step_new(p, la_init<F>(p, Z(j1)), Z(j1 + 1));
+                    j1 += 2;
+                }
+                break;
+            }
+            LA_ = NewLA;
+            if (j2 < maxRef) {
+                LAInfo<F> NewLA2;
+                PeriodDetected2 = la_step(p, LA_2, NewLA2, Z(j2));
+                if (PeriodDetected2) {
+                    liNext = j2;
+                    wPeriodBegin = j2;
+                    wPeriodEnd = wPeriodBegin + Period;
+                    const uint32_t jp1 = j2 + 1;
+                    if (jp1 >= maxRef) {
+                        LA_2 = la_init<F>(p, Z(j2));
+                        j2++;
+                    } else {
+                        LA_2 = la_step_new(p, la_init<F>(p, Z(j2)), Z(jp1));
+                        j2 += 2;
+                    }
+                    break;
+                }
+                LA_2 = NewLA2;
+            }
+        }
+        if (PeriodDetected2) {
+            LA_ = LA_2;
+            j = j2;
+        } else if (PeriodDetected) {
+            j = j1;
+        } else {
+            j = maxRef;
+        }
+
+        if (ThreadID == LastThread || (j >= Begin && j < End)) {
+            StartIndex[ThreadID] = j;
+        } else {
+            const int64_t nextStart = StartIndex[NextThread];
+            StartIndex[ThreadID] = nextStart;
+            FinishIndex[ThreadID] = -1;
+            continue;
+        }
+
+        bool returned = false;
+        for (; j < maxRef; j++) {
+            LAInfo<F> NewLA;
+            PeriodDetected = la_step(p, LA_, NewLA, Z(j));
+            if (!PeriodDetected && j < wPeriodEnd) {
+                LA_ = NewLA;
+                continue;
+            }
+            LA_.StepLength = j - wPeriodBegin;
+            LA_.NextStageLAIndex = liNext;
+            LAsPerThread[ThreadID].push_back(LA_);
+            liNext = j;
+            wPeriodBegin = j;
+            wPeriodEnd = wPeriodBegin + Period;
+            const uint32_t jp1 = j + 1;
+            const bool detected = la_detect_period(p, NewLA, Z(jp1));
+            if (detected || jp1 >= maxRef) {
+                LA_ = la_init<F>(p, Z(j));
+            } else {
+                LA_ = la_step_new(p, la_init<F>(p, Z(j)), Z(jp1));
+                j++;
+            }
+            if (j > End) {
+                if (j >= maxRef)
+                    break;
+                if (NextThread < ThreadCount) {
+                    const int64_t nextStart = StartIndex[NextThread];
+                    if (nextStart < 0) {
+                        returned = true;
+                        break;
+                    }
+                    if ((int64_t)j == nextStart - 1) {
+                        j++;
+                        break;
+                    } else if ((int64_t)j >= nextStart) {
+                        NextThread++;
+                    }
+                }
+            }
+        }
+        if (returned)
+            continue;
+        FinishIndex[ThreadID] = (int64_t)j;
+        LA_.StepLength = j - wPeriodBegin;
+        LA_.NextStageLAIndex = liNext;
+        LastLAPerThread[ThreadID] = LA_;
+    }
+
+    // Starter (thread 0), LAReference.cpp:392-484.
+    {
+        const uint32_t threadBoundary = maxRef / (uint32_t)ThreadCount;
+        size_t NextThread = 1;
+        bool returned = false;
+        for (; i < maxRef; i++) {
+            LAInfo<F> NewLA;
+            const bool PeriodDetected = la_step(p, LA, NewLA, Z(i));
+            if (!PeriodDetected && i < PeriodEnd) {
+                LA = NewLA;
+                continue;
+            }
+            LA.StepLength = i - PeriodBegin;
+            LA.NextStageLAIndex = nextIdx;
+            T.las.push_back(LA);
+            nextIdx = i;
+            PeriodBegin = i;
+            PeriodEnd = PeriodBegin + Period;
+            const uint32_t ip1 = i + 1;
+            const bool detected = la_detect_period(p, NewLA, Z(ip1));
+            if (detected || ip1 >= maxRef) {
+                LA = la_init<F>(p, Z(i));
+            } else {
+                LA = la_step_new(p, la_init<F>(p, Z(i)), Z(ip1));
+                i++;
+            }
+            if (i > threadBoundary) {
+                if (i >= maxRef)
+                    break;
+                if (NextThread < ThreadCount) {
+                    const int64_t nextStart = StartIndex[NextThread];
+                    if (nextStart < 0) {
+                        returned = true;
+                        break;
+                    }
+                    if ((int64_t)i == nextStart - 1) {
+                        i++;
+                        break;
+                    } else if ((int64_t)i >= nextStart) {
+                        NextThread++;
+                    }
+                }
+            }
+        }
+        if (!returned) {
+            FinishIndex[0] = (int64_t)i;
+            LA.StepLength = i - PeriodBegin;
+            LA.NextStageLAIndex = nextIdx;
+            LastLAPerThread[0] = LA;
+        }
+    }
+
+    // Stitch, LAReference.cpp:711-760.
+    {
+        size_t lastThreadToAdd = 0;
+        size_t index = 0;
+        size_t j = index;
+        while ((index < ThreadCount - 1) && (FinishIndex[j] > StartIndex[index + 1]))
+            index++;
+        index++;
+        for (; index < ThreadCount; index++) {
+            const auto &threadData = LAsPerThread[index];
+            T.las.insert(T.las.end(), threadData.begin(), threadData.end());
+            if (FinishIndex[index] > StartIndex[index])
+                lastThreadToAdd = index;
+            j = index;
+            while ((index < ThreadCount - 1) && (FinishIndex[j] > StartIndex[index + 1]))
+                index++;
+        }
+        T.las.push_back(LastLAPerThread[lastThreadToAdd]);
+    }
+    T.stages[0].MacroItCount = la_size();
+    T.las.push_back(la_init<F>(p, Z(maxRef)));
+    return true;
+}
+
+} // namespace
+
+struct fsh_la {
+    LATable<float> t;
+};
+
+extern "C" fsh_la *fsh_la_create_hdr32(const fsh_orbit *o, int host_threads)
+{
+    if (o->is64)
+        return nullptr;
+    auto la = std::make_unique<fsh_la>();
+    LABuilder<float> b(o->f, la->t);
+    b.generate(host_threads < 1 ? 1 : host_threads);
+    auto &t = la->t;
+    t.packed32.resize(t.las.size());
+    for (size_t k = 0; k < t.las.size(); k++) {
+        const auto &s = t.las[k];
+        fs_la_hdr32_u32 r;
+        r.Ref = fs_cplx_hdr32{s.Ref.re, s.Ref.im, s.Ref.e};
+        r.ZCoeff = fs_cplx_hdr32{s.ZCoeff.re, s.ZCoeff.im, s.ZCoeff.e};
+        r.CCoeff = fs_cplx_hdr32{s.CCoeff.re, s.CCoeff.im, s.CCoeff.e};
+        r.LAThreshold = fs_real_hdr32{s.LAThreshold.m, s.LAThreshold.e};
+        r.LAThresholdC = fs_real_hdr32{s.LAThresholdC.m, s.LAThresholdC.e};
+        r.MinMag = fs_real_hdr32{s.MinMag.m, s.MinMag.e};
+        r.StepLength = s.StepLength;
+        r.NextStageLAIndex = s.NextStageLAIndex;
+        t.packed32[k] = r;
+    }
+    t.packedStages.assign(t.stages.begin(), t.stages.begin() + std::min<size_t>(t.stages.size(), t.stageCount));
+    return la.release();
+}
+extern "C" void fsh_la_destroy(fsh_la *l) { delete l; }
+extern "C" uint32_t fsh_la_count(const fsh_la *l) { return (uint32_t)l->t.packed32.size(); }
+extern "C" const fs_la_hdr32_u32 *fsh_la_data(const fsh_la *l) { return l->t.packed32.data(); }
+extern "C" uint32_t fsh_la_stage_count(const fsh_la *l) { return l->t.stageCount; }
+extern "C" const fs_la_stage_u32 *fsh_la_stages(const fsh_la *l) { return l->t.packedStages.data(); }
+extern "C" int fsh_la_is_valid(const fsh_la *l) { return l->t.isValid ? 1 : 0; }
+extern "C" int fsh_la_use_at(const fsh_la *l) { return l->t.useAT ? 1 : 0; }
+extern "C" void fsh_la_at(const fsh_la *l, fs_at_hdr32_u32 *out)
+{
+    const auto &a = l->t.at;
+    auto R = [](hreal<float> h) { return fs_real_hdr32{h.m, h.e}; };
+    auto C = [](hcplx<float> c) { return fs_cplx_hdr32{c.re, c.im, c.e}; };
+    out->StepLength = a.StepLength;
+    out->ThresholdC = R(a.ThresholdC);
+    out->SqrEscapeRadius = R(a.SqrEscapeRadius);
+    out->RefC = C(a.RefC);
+    out->ZCoeff = C(a.ZCoeff);
+    out->CCoeff = C(a.CCoeff);
+    out->InvZCoeff = C(a.InvZCoeff);
+    out->CCoeffSqrInvZCoeff = C(a.CCoeffSqrInvZCoeff);
+    out->CCoeffInvZCoeff = C(a.CCoeffInvZCoeff);
+    out->CCoeffNormSqr = R(a.CCoeffNormSqr);
+    out->RefCNormSqr = R(a.RefCNormSqr);
+    out->factor = R(a.factor);
+}

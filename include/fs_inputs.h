@@ -1,0 +1,72 @@
+/* fs_inputs.h -- C ABI of libfsinputs.so: host-side builders for the inputs of the per-pixel pass.
+ *
+ * These stand in for the parts of FractalShark that sit *upstream* of GPURenderer when FractalShark itself
+ * is not built (bench.py, tests, the oracle harness): view geometry, the GMP reference orbit and the LAv2
+ * table.  Inside FractalShark none of this is needed -- Fractal.cpp hands the renderer its own
+ * PerturbationResults / LAReference buffers, which have the layouts in fs_layout.h.
+ *
+ * Reference code each entry point follows is cited in fractalshark_amd/host/refinputs.cpp.
+ */
+#ifndef FS_INPUTS_H
+#define FS_INPUTS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "fs_layout.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fsh_view fsh_view;
+typedef struct fsh_orbit fsh_orbit;
+typedef struct fsh_la fsh_la;
+typedef struct fsh_bla fsh_bla;
+
+/* Fractal::View(n) for a window of width x height: parse the bounding box at 1e6 bits, pick the working
+ * precision, square the box to the window aspect ratio. */
+fsh_view *fsh_view_create(const char *minX, const char *minY, const char *maxX, const char *maxY,
+                          uint32_t width, uint32_t height);
+void fsh_view_destroy(fsh_view *v);
+uint64_t fsh_view_precision_bits(const fsh_view *v);
+/* which: 0=minX 1=minY 2=maxX 3=maxY; printf("%.Fe") of the squared bounding box. */
+int fsh_view_bbox_str(const fsh_view *v, int which, char *buf, size_t buflen);
+
+/* out = {dx, dy, minX, maxY} as doubles (Cpu64 / direct kernels). */
+void fsh_view_coords_direct_f64(const fsh_view *v, uint32_t w_aa, uint32_t h_aa, double out[4]);
+
+/* Reference orbit at the bounding-box centre. is64: 0 = HDRFloat<float>, 1 = HDRFloat<double>.
+ * periodicity: 1 = STPeriodicity (what PerturbationAlg::Auto picks below 1e150), 0 = ST. */
+fsh_orbit *fsh_orbit_create(const fsh_view *v, int is64, uint64_t max_iter, int periodicity);
+void fsh_orbit_destroy(fsh_orbit *o);
+uint64_t fsh_orbit_count(const fsh_orbit *o);  /* GetCountOrbitEntries(), includes the zero entry */
+uint64_t fsh_orbit_period(const fsh_orbit *o); /* GetPeriodMaybeZero() */
+const fs_orbit_hdr32 *fsh_orbit_data_hdr32(fsh_orbit *o);
+const fs_orbit_hdr64 *fsh_orbit_data_hdr64(fsh_orbit *o);
+void fsh_orbit_max_radius_hdr32(const fsh_orbit *o, fs_real_hdr32 *out);
+
+/* out = {dx, dy, centerX, centerY}, each reduced (perturbation paths). */
+void fsh_view_coords_perturb_hdr32(const fsh_view *v, const fsh_orbit *o, uint32_t w_aa, uint32_t h_aa,
+                                   fs_real_hdr32 out[4]);
+void fsh_view_coords_perturb_hdr64(const fsh_view *v, const fsh_orbit *o, uint32_t w_aa, uint32_t h_aa,
+                                   fs_real_hdr64 out[4]);
+
+/* LAv2 table (LAReference::GenerateApproximationData).  host_threads = std::thread::hardware_concurrency()
+ * of the machine being mirrored: the reference's multi-threaded stage-0 scan splits the orbit into
+ * min(count/50000, host_threads) chunks and the chunking can move record boundaries. */
+fsh_la *fsh_la_create_hdr32(const fsh_orbit *o, int host_threads);
+void fsh_la_destroy(fsh_la *l);
+uint32_t fsh_la_count(const fsh_la *l);
+const fs_la_hdr32_u32 *fsh_la_data(const fsh_la *l);
+uint32_t fsh_la_stage_count(const fsh_la *l);
+const fs_la_stage_u32 *fsh_la_stages(const fsh_la *l);
+int fsh_la_is_valid(const fsh_la *l);
+int fsh_la_use_at(const fsh_la *l);
+void fsh_la_at(const fsh_la *l, fs_at_hdr32_u32 *out);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* FS_INPUTS_H */

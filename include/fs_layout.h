@@ -1,0 +1,132 @@
+/* fs_layout.h -- plain-C record layouts that cross the fsmi355 C ABI.
+ *
+ * Every struct here is byte-for-byte the host layout FractalShark already keeps in memory for the
+ * per-pixel pass, so a maintainer can hand the existing buffers over without conversion:
+ *
+ *   fs_orbit_hdr32      = GPUReferenceIter<HDRFloat<float>, PerturbExtras::Disable>
+ *                         (HpSharkFloatLib/GPU_ReferenceIter.h:52-127; x is {mantissa,exp}, y is
+ *                          HDROrder::Right = {exp,mantissa}; 16 B)
+ *   fs_orbit_hdr64      = GPUReferenceIter<HDRFloat<double>, Disable>              (32 B)
+ *   fs_la_hdr32_u32     = LAInfoDeep<uint32_t, HDRFloat<float>, float, Disable>
+ *                         (HpSharkFloatLib/LAInfoDeep.h:36-43; 68 B, static-asserted against the GPU twin
+ *                          at FractalSharkLib/GPU_LAReference.h:118-133)
+ *   fs_la_stage_u32     = LAStageInfo<uint32_t>  (HpSharkFloatLib/LAInfoI.h:5-16; 8 B)
+ *   fs_at_hdr32_u32     = ATInfo<uint32_t, HDRFloat<float>, float> (HpSharkFloatLib/ATInfo.h:84-99; 116 B)
+ *   fs_bla_hdr32        = BLA<HDRFloat<float>>   (FractalSharkLib/BLA.h:9-16; 44 B)
+ *   fs_color16, fs_reduction = Color16 / ReductionResults (FractalSharkLib/GPU_Types.h:14-16,40-50)
+ */
+#ifndef FS_LAYOUT_H
+#define FS_LAYOUT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fs_real_hdr32 {
+    float m;
+    int32_t e;
+} fs_real_hdr32;
+
+typedef struct fs_cplx_hdr32 {
+    float re;
+    float im;
+    int32_t e;
+} fs_cplx_hdr32;
+
+typedef struct fs_real_hdr64 {
+    double m;
+    int32_t e;
+    int32_t pad_;
+} fs_real_hdr64;
+
+typedef struct fs_cplx_hdr64 {
+    double re;
+    double im;
+    int32_t e;
+    int32_t pad_;
+} fs_cplx_hdr64;
+
+typedef struct fs_orbit_hdr32 {
+    float mx;
+    int32_t ex;
+    int32_t ey;
+    float my;
+} fs_orbit_hdr32;
+
+typedef struct fs_orbit_hdr64 {
+    double mx;
+    int32_t ex;
+    int32_t pad0_;
+    int32_t ey;
+    int32_t pad1_;
+    double my;
+} fs_orbit_hdr64;
+
+typedef struct fs_orbit_f64 {
+    double x;
+    double y;
+} fs_orbit_f64;
+
+typedef struct fs_la_hdr32_u32 {
+    fs_cplx_hdr32 Ref;
+    fs_cplx_hdr32 ZCoeff;
+    fs_cplx_hdr32 CCoeff;
+    fs_real_hdr32 LAThreshold;
+    fs_real_hdr32 LAThresholdC;
+    fs_real_hdr32 MinMag;
+    uint32_t StepLength;
+    uint32_t NextStageLAIndex;
+} fs_la_hdr32_u32;
+
+typedef struct fs_la_stage_u32 {
+    uint32_t LAIndex;
+    uint32_t MacroItCount;
+} fs_la_stage_u32;
+
+typedef struct fs_at_hdr32_u32 {
+    uint32_t StepLength;
+    fs_real_hdr32 ThresholdC;
+    fs_real_hdr32 SqrEscapeRadius;
+    fs_cplx_hdr32 RefC;
+    fs_cplx_hdr32 ZCoeff;
+    fs_cplx_hdr32 CCoeff;
+    fs_cplx_hdr32 InvZCoeff;
+    fs_cplx_hdr32 CCoeffSqrInvZCoeff;
+    fs_cplx_hdr32 CCoeffInvZCoeff;
+    fs_real_hdr32 CCoeffNormSqr;
+    fs_real_hdr32 RefCNormSqr;
+    fs_real_hdr32 factor;
+} fs_at_hdr32_u32;
+
+typedef struct fs_bla_hdr32 {
+    fs_real_hdr32 r2;
+    fs_real_hdr32 Ax;
+    fs_real_hdr32 Ay;
+    fs_real_hdr32 Bx;
+    fs_real_hdr32 By;
+    int32_t l;
+} fs_bla_hdr32;
+
+typedef struct fs_color16 {
+    uint16_t r, g, b, a;
+} fs_color16;
+
+typedef struct fs_reduction {
+    uint64_t Min;
+    uint64_t Max;
+    uint64_t Sum;
+} fs_reduction;
+
+#ifdef __cplusplus
+}
+static_assert(sizeof(fs_orbit_hdr32) == 16, "orbit entry");
+static_assert(sizeof(fs_orbit_hdr64) == 32, "orbit entry (double)");
+static_assert(sizeof(fs_la_hdr32_u32) == 68, "LA record");
+static_assert(sizeof(fs_at_hdr32_u32) == 116, "AT record");
+static_assert(sizeof(fs_bla_hdr32) == 44, "BLA record");
+static_assert(sizeof(fs_real_hdr64) == 16 && sizeof(fs_cplx_hdr64) == 24, "double HDR");
+#endif
+
+#endif /* FS_LAYOUT_H */
