@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: Mpix/s of the iteration buffer, View #5 at 3840x2160, HDRx32 LAv2.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" = one full frame: the LAv2 iteration kernel over every (sub)pixel; for N > 1 each rank renders its
+interleaved 8-row bands and the slices are gathered to every rank with one RCCL all-gather (fractalshark_amd/
+tiling.py).  Inputs (reference orbit, LA table) are generated on the host with GMP *before* the timed region
+and are resident in HBM when it starts; `value` = W*H*K / t with t = max over ranks of the barrier-bracketed
+wall time.  Prints ONE JSON line on rank 0.
+
+Extra objects (round contract):
+  roofline      dominant kernel = k_lav2_hdr32.  It is VALU-bound (scalar complex arithmetic, no dense
+                contraction; orbit + table are L2 resident), so `bound` is "valu": achieved = executed
+                pixel-steps x 18 FP32 flop / average kernel duration measured with HIP
+                events on the renderer's compute stream; peak = 157.3 TFLOP/s FP32 vector (MI355X_MICROARCH.md).
+  cpu_baseline  the CPU oracle (restatement of the reference's multithreaded CPU RenderAlgorithm, same row-claiming
+                thread pool) timed on this host's cores over a bounded sample of rows of the same frame.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+FLOP_PER_STEP = 18            # complex dz*(2Z+dz)+dc, |Z+dz|^2, |dz|^2
+PEAK_FP32_VECTOR_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--view", type=int, default=5)
+    ap.add_argument("--parity", choices=["cpu", "cpu_gpustage"], default="cpu",
+                    help="cpu = literal reference CPU function (bit-exact vs Cpu32PerturbedBLAV2HDR); "
+                         "cpu_gpustage = same arithmetic, LA stage test in the GPU/FractalZoomer direction")
+    ap.add_argument("--cpu-sample-rows", type=int, default=16, help="rows of the frame timed on the CPU")
+    ap.add_argument("--no-cpu", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+
+    from fractalshark_amd import (GPURenderer, LAV2_FULL, PARITY_CPU, PARITY_CPU_GPUSTAGE, T_HDR32, _build, inputs,
+                                  tiling)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl")
+    else:
+        torch.cuda.set_device(0)
+    if rank == 0:
+        _build.build_all()
+    if distributed:
+        dist.barrier()
+
+    if GPURenderer.TestCudaIsWorking() == 0:
+        raise RuntimeError("no usable HIP device; there is no CPU fallback")
+
+    # ---- inputs (host, outside the timed region)
+    t0 = time.time()
+    view = inputs.View.builtin(args.view, args.width, args.height, antialiasing=1)
+    orbit = inputs.Orbit(view)
+    la = inputs.LATable(orbit)
+    t_inputs = time.time() - t0
+    W, H = view.width, view.height
+    n_iter = view.num_iterations
+    parity = PARITY_CPU if args.parity == "cpu" else PARITY_CPU_GPUSTAGE
+    coords = [(float(c["m"]), int(c["e"])) for c in view.coords_perturb_hdr32(orbit)]
+
+    r = GPURenderer(local_rank)
+    err = r.InitializeMemory(W, H, 1, None, 0, 0, 0, False)
+    assert err == 0, GPURenderer.ConvertErrorToString(err)
+    assert r.InitializePerturb(1, orbit, 0, None, la) == 0
+    band = tiling.band_height(1)
+    rw = r.rounded_width
+    if distributed:
+        assert r.SetRowBands(rank * band, band, world * band) == 0
+        max_rows = tiling.max_local_rows(H, world, band)
+        local = torch.zeros((max_rows, rw), dtype=torch.int32, device="cuda")
+        gathered = torch.empty((world * max_rows, rw), dtype=torch.int32, device="cuda")
+        frame_index = torch.from_numpy(tiling.reassemble_index(H, world, band)).cuda()
+        assert r.SetExternalIterBuffer(local.data_ptr()) == 0
+    r.enable_step_count(True)
+
+    kernel_ms = []
+    steps_executed = []
+
+    def one_frame(record):
+        e = r.RenderPerturbLAv2(None, None, None, *coords, n_iter, T=T_HDR32, Mode=LAV2_FULL, parity=parity)
+        assert e == 0, GPURenderer.ConvertErrorToString(e)
+        assert r.SyncComputeStream() == 0
+        frame = None
+        if distributed:
+            dist.all_gather_into_tensor(gathered, local)
+            frame = gathered.index_select(0, frame_index)
+        torch.cuda.synchronize()
+        if record:
+            kernel_ms.append(r.last_kernel_ms())
+            steps_executed.append(r.read_step_count())
+        return frame
+
+    for _ in range(args.warmup):
+        one_frame(False)
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    frame = None
+    for _ in range(args.steps):
+        frame = one_frame(True)
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        # executed pixel-steps and kernel time summed / maxed over ranks for the roofline line
+        st = torch.tensor([sum(s["perturb_steps"] for s in steps_executed),
+                           sum(s["at_iterations"] for s in steps_executed),
+                           sum(s["la_steps"] for s in steps_executed)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(st, op=dist.ReduceOp.SUM)
+        km = torch.tensor([sum(kernel_ms)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(km, op=dist.ReduceOp.MAX)
+        perturb_steps, at_iters, la_steps = [float(x) / args.steps for x in st.tolist()]
+        avg_kernel_ms = float(km.item()) / args.steps
+    else:
+        perturb_steps = sum(s["perturb_steps"] for s in steps_executed) / args.steps
+        at_iters = sum(s["at_iterations"] for s in steps_executed) / args.steps
+        la_steps = sum(s["la_steps"] for s in steps_executed) / args.steps
+        avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
+
+    # ---- PCIe-inclusive number (never `value`): one frame incl. D2H of the padded iteration buffer
+    d2h_ms = None
+    checksum = None
+    if rank == 0:
+        if distributed:
+            host = frame.cpu().numpy().view(np.uint32)
+            checksum = int(host[:H, :W].astype(np.uint64).sum())
+        else:
+            out = r.new_iter_buffer()
+            t1 = time.perf_counter()
+            assert r.RenderCurrent(n_iter, out) == 0
+            assert r.SyncComputeStream() == 0
+            d2h_ms = (time.perf_counter() - t1) * 1e3
+            checksum = int(out[:H, :W].astype(np.uint64).sum())
+
+    # ---- CPU baseline on a bounded sample of rows (rank 0, N = 1 only)
+    cpu_baseline = None
+    parity_rows_ok = None
+    if rank == 0 and not distributed and not args.no_cpu:
+        import _oracle
+        threads = os.cpu_count() or 1
+        nrows = max(1, min(args.cpu_sample_rows, H))
+        step = max(1, H // nrows)
+        y0 = step // 2
+        rows = list(range(y0, H, step))
+        stage_test = 0 if args.parity == "cpu" else 1
+        _oracle.lib()  # build / load outside the timed window
+        _oracle.set_row_step(step)
+        t1 = time.perf_counter()
+        ref = _oracle.lav2_hdr32(view, orbit, la, rows=(y0, H), threads=threads, stage_test=stage_test)
+        cpu_t = time.perf_counter() - t1
+        _oracle.set_row_step(1)
+        refs = [(y, ref[y]) for y in rows]
+        nrows = len(rows)
+        parity_rows_ok = all(np.array_equal(out[y], ref) for y, ref in refs)
+        cpu_baseline = {"value": round(nrows * W / cpu_t / 1e6, 6), "unit": "Mpix/s", "cores": threads,
+                        "kind": "port",
+                        "sample": "%d of %d rows of the same %dx%d frame (rows spread evenly), %.1f s" %
+                                  (nrows, H, W, H, cpu_t)}
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = W * H * args.steps / elapsed / 1e6
+        achieved = perturb_steps * FLOP_PER_STEP / (avg_kernel_ms * 1e-3) / 1e12
+        line = {
+            "metric": "Mpix/s (iteration buffer), View #5 3840x2160 HDRx32 LAv2",
+            "value": round(value, 4), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32+i32exp", "data": "synthetic",
+            "config": {"workload": "view%d_%dx%d_hdrx32_lav2_full" % (args.view, W, H), "parity": args.parity,
+                       "n_iterations": n_iter, "orbit_entries": orbit.count, "la_records": la.count,
+                       "la_stages": la.stage_count, "tiling": "rows/8-row bands interleaved x%d" % world,
+                       "host_input_build_s": round(t_inputs, 3)},
+            "roofline": {"bound": "valu", "achieved": round(achieved, 4), "peak": PEAK_FP32_VECTOR_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 5), "traffic": None,
+                         "kernel": "k_lav2_hdr32", "kernel_ms": round(avg_kernel_ms, 3),
+                         "pixel_steps_per_launch": perturb_steps, "at_iterations_per_launch": at_iters,
+                         "la_steps_per_launch": la_steps, "flop_per_pixel_step": FLOP_PER_STEP},
+            "cpu_baseline": cpu_baseline,
+            "frame_checksum": checksum, "cpu_sample_rows_bit_exact": parity_rows_ok,
+            "d2h_inclusive_ms": None if d2h_ms is None else round(d2h_ms + avg_kernel_ms, 3),
+        }
+        print(json.dumps(line))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    r.close()
+
+
+if __name__ == "__main__":
+    main()

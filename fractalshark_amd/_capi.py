@@ -1,0 +1,136 @@
+"""ctypes declarations for the two native libraries.  No torch types cross these boundaries."""
+import ctypes as C
+import os
+
+from . import _build
+
+vp = C.c_void_p
+u32 = C.c_uint32
+u64 = C.c_uint64
+i32 = C.c_int32
+
+
+class RealHdr32(C.Structure):
+    _fields_ = [("m", C.c_float), ("e", C.c_int32)]
+
+
+class CplxHdr32(C.Structure):
+    _fields_ = [("re", C.c_float), ("im", C.c_float), ("e", C.c_int32)]
+
+
+class AtHdr32(C.Structure):
+    _fields_ = [("StepLength", u32), ("ThresholdC", RealHdr32), ("SqrEscapeRadius", RealHdr32),
+                ("RefC", CplxHdr32), ("ZCoeff", CplxHdr32), ("CCoeff", CplxHdr32), ("InvZCoeff", CplxHdr32),
+                ("CCoeffSqrInvZCoeff", CplxHdr32), ("CCoeffInvZCoeff", CplxHdr32),
+                ("CCoeffNormSqr", RealHdr32), ("RefCNormSqr", RealHdr32), ("factor", RealHdr32)]
+
+
+class Reduction(C.Structure):
+    _fields_ = [("Min", u64), ("Max", u64), ("Sum", u64)]
+
+
+assert C.sizeof(AtHdr32) == 116
+
+DONE_CB = C.CFUNCTYPE(None, vp)
+
+_render = None
+_inputs = None
+
+
+def _decl(lib, name, restype, argtypes):
+    fn = getattr(lib, name)
+    fn.restype = restype
+    fn.argtypes = argtypes
+    return fn
+
+
+def render_lib():
+    """libfsmi355.so.  Raises if the HIP library has not been built: there is no fallback."""
+    global _render
+    if _render is not None:
+        return _render
+    path = _build.LIB_RENDER
+    if not os.path.exists(path):
+        raise RuntimeError("libfsmi355.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'`"
+                           % path)
+    lib = C.CDLL(path)
+    _decl(lib, "fs_create", vp, [C.c_int])
+    _decl(lib, "fs_destroy", None, [vp])
+    _decl(lib, "fs_test_device_is_working", u32, [])
+    _decl(lib, "fs_error_string", C.c_char_p, [u32])
+    _decl(lib, "fs_init_memory", u32, [vp, u32, u32, u32, u32, vp, u32, u32, u64, C.c_int])
+    _decl(lib, "fs_set_row_bands", u32, [vp, u32, u32, u32])
+    _decl(lib, "fs_local_rows", u32, [vp])
+    _decl(lib, "fs_set_external_iter_buffer", u32, [vp, vp])
+    _decl(lib, "fs_device_iter_buffer", vp, [vp])
+    _decl(lib, "fs_rounded_width", u32, [vp])
+    _decl(lib, "fs_upload_orbit", u32, [vp, u64, C.c_int, u32, vp, u64, u64, u64])
+    _decl(lib, "fs_upload_la", u32, [vp, u64, C.c_int, u32, vp, u32, vp, u32, C.c_int, C.c_int, vp])
+    _decl(lib, "fs_upload_bla", u32, [vp, C.c_int, vp, vp, i32, i32])
+    _decl(lib, "fs_render_lav2", u32, [vp, C.c_int, C.c_int, C.c_int, vp, u64])
+    _decl(lib, "fs_render_bla", u32, [vp, C.c_int, vp, u64])
+    _decl(lib, "fs_render_direct", u32, [vp, C.c_int, vp, u64])
+    _decl(lib, "fs_clear", u32, [vp])
+    _decl(lib, "fs_render_current", u32, [vp, u64, vp, vp, vp, C.c_int])
+    _decl(lib, "fs_sync_compute", u32, [vp])
+    _decl(lib, "fs_sync_display", u32, [vp])
+    _decl(lib, "fs_query_compute", u32, [vp])
+    _decl(lib, "fs_enqueue_done_callback", u32, [vp, DONE_CB, vp])
+    _decl(lib, "fs_get_width", u32, [vp])
+    _decl(lib, "fs_get_height", u32, [vp])
+    _decl(lib, "fs_last_kernel_ms", C.c_float, [vp])
+    _decl(lib, "fs_enable_step_count", u32, [vp, C.c_int])
+    _decl(lib, "fs_read_step_count", u32, [vp, vp])
+    _render = lib
+    return lib
+
+
+RENDER_SYMBOLS = [
+    "fs_create", "fs_destroy", "fs_test_device_is_working", "fs_error_string", "fs_init_memory", "fs_set_row_bands",
+    "fs_local_rows", "fs_set_external_iter_buffer", "fs_device_iter_buffer", "fs_rounded_width", "fs_upload_orbit",
+    "fs_upload_la", "fs_upload_bla", "fs_render_lav2", "fs_render_bla", "fs_render_direct", "fs_clear",
+    "fs_render_current", "fs_sync_compute", "fs_sync_display", "fs_query_compute", "fs_enqueue_done_callback",
+    "fs_get_width", "fs_get_height", "fs_last_kernel_ms", "fs_enable_step_count", "fs_read_step_count",
+]
+
+
+def inputs_lib():
+    """libfsinputs.so (GMP host builders)."""
+    global _inputs
+    if _inputs is not None:
+        return _inputs
+    path = _build.LIB_INPUTS
+    if not os.path.exists(path):
+        raise RuntimeError("libfsinputs.so is missing (%s): run __graft_entry__.build()" % path)
+    lib = C.CDLL(path)
+    _decl(lib, "fsh_view_create", vp, [C.c_char_p] * 4 + [u32, u32])
+    _decl(lib, "fsh_view_destroy", None, [vp])
+    _decl(lib, "fsh_view_precision_bits", u64, [vp])
+    _decl(lib, "fsh_view_bbox_str", C.c_int, [vp, C.c_int, C.c_char_p, C.c_size_t])
+    _decl(lib, "fsh_view_coords_direct_f64", None, [vp, u32, u32, vp])
+    _decl(lib, "fsh_orbit_create", vp, [vp, C.c_int, u64, C.c_int])
+    _decl(lib, "fsh_orbit_destroy", None, [vp])
+    _decl(lib, "fsh_orbit_count", u64, [vp])
+    _decl(lib, "fsh_orbit_period", u64, [vp])
+    _decl(lib, "fsh_orbit_data_hdr32", vp, [vp])
+    _decl(lib, "fsh_orbit_data_hdr64", vp, [vp])
+    _decl(lib, "fsh_orbit_max_radius_hdr32", None, [vp, vp])
+    _decl(lib, "fsh_view_coords_perturb_hdr32", None, [vp, vp, u32, u32, vp])
+    _decl(lib, "fsh_view_coords_perturb_hdr64", None, [vp, vp, u32, u32, vp])
+    _decl(lib, "fsh_la_create_hdr32", vp, [vp, C.c_int])
+    _decl(lib, "fsh_la_destroy", None, [vp])
+    _decl(lib, "fsh_la_count", u32, [vp])
+    _decl(lib, "fsh_la_data", vp, [vp])
+    _decl(lib, "fsh_la_stage_count", u32, [vp])
+    _decl(lib, "fsh_la_stages", vp, [vp])
+    _decl(lib, "fsh_la_is_valid", C.c_int, [vp])
+    _decl(lib, "fsh_la_use_at", C.c_int, [vp])
+    _decl(lib, "fsh_la_at", None, [vp, vp])
+    _decl(lib, "fsh_bla_create_hdr32", vp, [vp])
+    _decl(lib, "fsh_bla_destroy", None, [vp])
+    _decl(lib, "fsh_bla_num_levels", i32, [vp])
+    _decl(lib, "fsh_bla_lm2", i32, [vp])
+    _decl(lib, "fsh_bla_level_ptrs", vp, [vp])
+    _decl(lib, "fsh_bla_level_sizes", vp, [vp])
+    _inputs = lib
+    return lib

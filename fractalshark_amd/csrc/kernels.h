@@ -1,0 +1,79 @@
+// kernels.h -- argument blocks and launch entry points shared by renderer.cpp (host) and kernels.hip.
+// Kernel arguments are plain PODs passed by value (well under the 4 KB kernarg limit), instead of the
+// reference's by-value copies of non-trivial classes (GPUPerturbSingleResults, GPU_LAReference incl. ATInfo,
+// GPU_BLAS -- SURVEY.md appendix B).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fs_layout.h"
+#include "hdr_math.hpp"
+
+enum { FS_MODE_FULL = 0, FS_MODE_PO = 1, FS_MODE_LAO = 2 };
+enum { FS_PARITY_LITERAL = 0, FS_PARITY_GPUSTAGE = 1 };
+
+// Frame geometry + the row-band layout of the local iteration buffer.
+struct FsFrame {
+    uint32_t width;         // full frame width  (incl. antialiasing)
+    uint32_t height;        // full frame height (incl. antialiasing)
+    uint32_t rounded_width; // row stride of the iteration buffer (multiple of 16, GPU_Render.cu:73-79)
+    uint32_t local_rows;    // rows held locally (before padding to 8)
+    uint32_t band_first;    // first global row of band 0
+    uint32_t band_rows;     // rows per band
+    uint32_t band_stride;   // global-row distance between consecutive owned bands
+};
+
+struct FsCoords32 {
+    fs::hreal32 dx, dy, centerX, centerY;
+};
+
+struct FsLav2Args32 {
+    uint32_t *out;
+    const float4 *zref; // prepared orbit {re, im, exp, -}
+    const fs_la_hdr32_u32 *las;
+    const fs_la_stage_u32 *stages;
+    uint64_t *stats;
+    FsFrame frame;
+    FsCoords32 coords;
+    fs_at_hdr32_u32 at;
+    uint32_t orbit_count;
+    uint32_t period;
+    uint32_t stage_count;
+    uint32_t n_iterations;
+    int la_valid;
+    int use_at;
+    int parity;
+};
+
+struct FsBlaArgs32 {
+    uint32_t *out;
+    const float4 *zref;
+    const fs_bla_hdr32 *const *levels; // device array of device pointers, indexed by level
+    uint64_t *stats;
+    FsFrame frame;
+    FsCoords32 coords;
+    uint32_t orbit_count;
+    uint32_t n_iterations;
+    int32_t lm2;
+};
+
+struct FsDirectArgs64 {
+    uint32_t *out;
+    double *cx_row; // [width] row prefix of cx
+    uint64_t *stats;
+    FsFrame frame;
+    double dy;
+    double maxY;
+    uint32_t n_iterations;
+};
+
+void fsk_prepare_orbit_hdr32(const fs_orbit_hdr32 *in, float4 *out, uint64_t n, hipStream_t s);
+void fsk_lav2_hdr32(const FsLav2Args32 &A, int mode, bool stats, hipStream_t s);
+void fsk_perturb_scalar_hdr32(const FsBlaArgs32 &A, bool use_bla, bool stats, hipStream_t s);
+void fsk_direct_f64(const FsDirectArgs64 &A, double minX, double dx, bool stats, hipStream_t s);
+void fsk_antialias_u32(const uint32_t *iters, uint32_t rounded_width, fs_color16 *colors, const fs_color16 *pal,
+                       uint32_t pal_iters, uint32_t aux_depth, uint32_t aa, uint32_t color_w, uint32_t color_h,
+                       uint32_t n_iterations, hipStream_t s);
+void fsk_reduce_u32(const uint32_t *iters, uint32_t rounded_width, uint32_t width, uint32_t rows, fs_reduction *out,
+                    hipStream_t s);

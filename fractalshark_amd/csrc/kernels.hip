@@ -1,0 +1,545 @@
+// kernels.hip -- gfx950 device code of libfsmi355.so.  Compiled with -ffp-contract=off (see hdr_math.hpp).
+//
+// Parity target of every iteration kernel is a reference *CPU* RenderAlgorithm function (cited per kernel);
+// the decomposition is this project's own: one lane per (sub)pixel, 64-wide wavefronts walking a row
+// segment, reference orbit pre-converted once per upload into the complex form the CPU loop rebuilds on
+// every access.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fs_layout.h"
+#include "hdr_math.hpp"
+#include "kernels.h"
+
+using namespace fs;
+
+namespace {
+
+__device__ __forceinline__ hreal32 ldr(const fs_real_hdr32 &r) { return hreal32{r.m, r.e}; }
+__device__ __forceinline__ hcplx32 ldc(const fs_cplx_hdr32 &c) { return hcplx32{c.re, c.im, c.e}; }
+
+// Reference-orbit entry in device form: PerturbationResults::GetComplex (PerturbationResults.h:174-185)
+// builds HDRFloatComplex{x, y} on *every* access; it is a pure function of the entry, so it is evaluated
+// once here.  .w is unused padding so one access is one 16-byte load.
+__device__ __forceinline__ hcplx32 zref_at(const float4 *__restrict__ z, uint32_t i)
+{
+    const float4 v = z[i];
+    return hcplx32{v.x, v.y, __float_as_int(v.z)};
+}
+
+// Global row of local row L under the band layout (fs_set_row_bands).
+__device__ __forceinline__ uint32_t global_row(const FsFrame &f, uint32_t L)
+{
+    const uint32_t k = L / f.band_rows;
+    const uint32_t rr = L - k * f.band_rows;
+    return f.band_first + k * f.band_stride + rr;
+}
+
+// Pixel -> delta c, Fractal.cpp:2553-2562 (== 2272-2281): `dx * (float)x` goes through HDRFloat(T mant).
+__device__ __forceinline__ void pixel_delta(const FsCoords32 &c, uint32_t x, uint32_t y, hreal32 &dRe, hreal32 &dIm)
+{
+    hreal32 a = hr_mul(c.dx, hr_from_mant<float>((float)x));
+    hr_reduce(a);
+    a = hr_sub(a, c.centerX);
+    hreal32 b = hr_mul(hr_neg(c.dy), hr_from_mant<float>((float)y));
+    hr_reduce(b);
+    b = hr_sub(b, c.centerY);
+    hr_reduce(a);
+    hr_reduce(b);
+    dRe = a;
+    dIm = b;
+}
+
+__device__ __forceinline__ void add_stats(uint64_t *stats, uint64_t at, uint64_t la, uint64_t pt, uint64_t px)
+{
+    // one atomic per wave per counter
+    for (int off = 32; off > 0; off >>= 1) {
+        at += __shfl_down(at, off);
+        la += __shfl_down(la, off);
+        pt += __shfl_down(pt, off);
+        px += __shfl_down(px, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd((unsigned long long *)&stats[0], (unsigned long long)at);
+        atomicAdd((unsigned long long *)&stats[1], (unsigned long long)la);
+        atomicAdd((unsigned long long *)&stats[2], (unsigned long long)pt);
+        atomicAdd((unsigned long long *)&stats[3], (unsigned long long)px);
+    }
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------
+// Orbit preparation: fs_orbit_hdr32 (reference layout) -> {re, im, exp, 0}.
+__global__ void k_prepare_orbit_hdr32(const fs_orbit_hdr32 *__restrict__ in, float4 *__restrict__ out, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const fs_orbit_hdr32 e = in[i];
+    const hcplx32 c = hc_from_hr(hreal32{e.mx, e.ex}, hreal32{e.my, e.ey});
+    out[i] = make_float4(c.re, c.im, __int_as_float(c.e), 0.0f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LAv2, T = HDRFloat<float>.  CPU twin: Fractal::CalcCpuPerturbationFractalLAV2<uint32_t,float,Disable>
+// (Fractal.cpp:2545-2678) with LAReference::getLA / isLAStageInvalid (LAReference.cpp:1076-1134),
+// LAInfoDeep::Prepare / Evaluate (LAInfoDeep.h:395-420), ATInfo::PerformAT (ATInfo.h:155-188).
+// Replaces mandel_1xHDR_float_perturb_lav2 (FractalSharkGpuLib/LAKernel.cuh:3-315).
+template <int Mode, bool kStats>
+__global__ void __launch_bounds__(256) k_lav2_hdr32(FsLav2Args32 A)
+{
+    const uint32_t X = blockIdx.x * 64u + (threadIdx.x & 63u);
+    const uint32_t L = blockIdx.y * 4u + (threadIdx.x >> 6);
+    uint64_t c_at = 0, c_la = 0, c_pt = 0, c_px = 0;
+    const uint32_t Y = global_row(A.frame, L);
+    const bool live = X < A.frame.width && L < A.frame.local_rows && Y < A.frame.height;
+    if (live) {
+        c_px = 1;
+        const uint32_t n_iterations = A.n_iterations;
+        hreal32 deltaReal, deltaImaginary;
+        pixel_delta(A.coords, X, Y, deltaReal, deltaImaginary);
+        const hcplx32 DeltaSub0 = hc_from_hr(deltaReal, deltaImaginary);
+        hcplx32 DeltaSubN = hc_from_native<float>(0.0f, 0.0f); // {0,0}: zero with exponent 0 (Fractal.cpp:2565)
+        uint32_t iterations = 0;
+
+        if (Mode != FS_MODE_PO) {
+            if (A.la_valid && A.use_at && hr_cmp_pos(hc_cheb(DeltaSub0), ldr(A.at.ThresholdC)) <= 0) {
+                const uint32_t ATMaxIt = n_iterations / A.at.StepLength;
+                hcplx32 c = hc_add(hc_mul(DeltaSub0, ldc(A.at.CCoeff)), ldc(A.at.RefC));
+                hc_reduce(c);
+                hcplx32 z = hc_zero<float>();
+                const hreal32 esc = ldr(A.at.SqrEscapeRadius);
+                uint32_t i;
+                for (i = 0; i < ATMaxIt; i++) {
+                    hreal32 nsq = hc_norm2(z);
+                    hr_reduce(nsq);
+                    if (hr_cmp_pos(nsq, esc) > 0)
+                        break;
+                    z = hc_add(hc_mul(z, z), c);
+                }
+                hcplx32 dz = hc_mul(z, ldc(A.at.InvZCoeff));
+                hc_reduce(dz);
+                DeltaSubN = dz;
+                iterations = i * A.at.StepLength;
+                if (kStats)
+                    c_at = i;
+            }
+        }
+
+        uint32_t RefIteration = 0;
+        const uint32_t MaxRefIteration = A.orbit_count - 1;
+        // complex0 before the LA stages is dead in the CPU function (only its norm was read, into a variable
+        // that is overwritten before use), so it is not materialised; the RefIteration %= period side effect
+        // (Fractal.cpp:2590-2591) is kept.
+        if (iterations != 0 && !(RefIteration < MaxRefIteration) && A.period != 0)
+            RefIteration = RefIteration % A.period;
+
+        if (Mode != FS_MODE_PO) {
+            uint32_t CurrentLAStage = A.la_valid ? A.stage_count : 0;
+            const hreal32 dcCheb = hc_cheb(DeltaSub0);
+            while (CurrentLAStage > 0) {
+                CurrentLAStage--;
+                const uint32_t LAIndex = A.stages[CurrentLAStage].LAIndex;
+                {
+                    const int cmp = hr_cmp_pos(dcCheb, ldr(A.las[LAIndex].LAThresholdC));
+                    const bool invalid = A.parity == FS_PARITY_LITERAL ? (cmp < 0) : (cmp >= 0);
+                    if (invalid)
+                        continue;
+                }
+                const uint32_t MacroItCount = A.stages[CurrentLAStage].MacroItCount;
+                uint32_t j = RefIteration;
+                while (iterations < n_iterations) {
+                    const fs_la_hdr32_u32 *LAj = &A.las[LAIndex + j];
+                    const uint32_t l = LAj->StepLength;
+                    bool unusable = true;
+                    hcplx32 newDz = hc_zero<float>();
+                    if (iterations + l <= n_iterations) {
+                        newDz = hc_mul(DeltaSubN, hc_add(hc_mul2(ldc(LAj->Ref)), DeltaSubN));
+                        hc_reduce(newDz);
+                        unusable = hr_cmp_pos(hc_cheb(newDz), ldr(LAj->LAThreshold)) >= 0;
+                    }
+                    if (unusable) {
+                        RefIteration = LAj->NextStageLAIndex;
+                        break;
+                    }
+                    iterations += l;
+                    if (kStats)
+                        c_la++;
+                    DeltaSubN = hc_add(hc_mul(newDz, ldc(LAj->ZCoeff)), hc_mul(DeltaSub0, ldc(LAj->CCoeff)));
+                    const hcplx32 complex0 = hc_add(ldc(LAj[1].Ref), DeltaSubN);
+                    j++;
+                    const hreal32 lhs = hr_reduced(hc_cheb(complex0));
+                    const hreal32 rhs = hr_reduced(hc_cheb(DeltaSubN));
+                    if (hr_cmp_pos(lhs, rhs) < 0 || j >= MacroItCount) {
+                        DeltaSubN = complex0;
+                        j = 0;
+                    }
+                }
+                if (iterations >= n_iterations)
+                    break;
+            }
+        }
+
+        if (Mode != FS_MODE_LAO) {
+            const hreal32 TwoFiftySix = hreal32{1.0f, 8};
+            const float4 *__restrict__ zr = A.zref;
+            for (; iterations < n_iterations; iterations++) {
+                hcplx32 cur = zref_at(zr, RefIteration);
+                cur = hc_mul2(cur);
+                cur = hc_add(cur, DeltaSubN);
+                DeltaSubN = hc_mul(DeltaSubN, cur);
+                DeltaSubN = hc_add(DeltaSubN, DeltaSub0);
+                hc_reduce(DeltaSubN);
+                if (kStats)
+                    c_pt++;
+                RefIteration++;
+                hcplx32 complex0 = hc_add(zref_at(zr, RefIteration), DeltaSubN);
+                hc_reduce(complex0);
+                const hreal32 normSquared = hr_reduced(hc_norm2(complex0));
+                const hreal32 DeltaNormSquared = hr_reduced(hc_norm2(DeltaSubN));
+                if (hr_cmp_pos(normSquared, TwoFiftySix) > 0)
+                    break;
+                if (hr_cmp_pos(normSquared, DeltaNormSquared) < 0 || RefIteration >= MaxRefIteration) {
+                    DeltaSubN = complex0;
+                    RefIteration = 0;
+                }
+            }
+        }
+        A.out[(size_t)L * A.frame.rounded_width + X] = iterations;
+    }
+    if (kStats)
+        add_stats(A.stats, c_at, c_la, c_pt, c_px);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Scalar-HDRFloat perturbation with optional BLA skipping, T = HDRFloat<float>.
+// CPU twin: Fractal::CalcCpuPerturbationFractalBLA<uint32_t,HDRFloat<float>,float> (Fractal.cpp:2266-2470),
+// BLAS::LookupBackwards (BLAS.cpp:256-310), BLA::getValue (BLA.cuh:21-38).  With kBla == false the lookup is
+// compiled out: that is the perturbation-only single-step branch (:2342-2466), the parity target of the
+// LAv2Mode::PO entry point.  Replaces mandel_1xHDR_float_perturb_bla
+// (FractalSharkGpuLib/BLAKernels.cuh:193-434) and the PO instantiation of the LAv2 kernel.
+namespace {
+
+__device__ __forceinline__ const fs_bla_hdr32 *bla_lookup(const FsBlaArgs32 &A, uint32_t m, hreal32 z2)
+{
+    if (m == 0)
+        return nullptr;
+    const int32_t k = (int32_t)m - 1;
+    if ((k & 1) == 1)
+        return nullptr;
+    int32_t zeros;
+    uint32_t ix;
+    if (k == 0) {
+        if (hr_cmp_pos(z2, ldr(A.levels[2][0].r2)) >= 0)
+            return nullptr;
+        zeros = 32;
+        ix = 0;
+    } else {
+        zeros = __ffs(k) - 1; // exponent of (float)(k & -k), BLAS.cpp:283-286
+        ix = (uint32_t)k >> zeros;
+    }
+    const int32_t startLevel = zeros <= A.lm2 ? zeros : A.lm2;
+    for (int32_t level = startLevel; level >= 2; --level) {
+        const fs_bla_hdr32 *t = &A.levels[level][ix];
+        if (hr_cmp_pos(z2, ldr(t->r2)) < 0)
+            return t;
+        ix <<= 1;
+    }
+    return nullptr;
+}
+
+} // namespace
+
+template <bool kBla, bool kStats>
+__global__ void __launch_bounds__(256) k_perturb_scalar_hdr32(FsBlaArgs32 A)
+{
+    const uint32_t X = blockIdx.x * 64u + (threadIdx.x & 63u);
+    const uint32_t L = blockIdx.y * 4u + (threadIdx.x >> 6);
+    uint64_t c_la = 0, c_pt = 0, c_px = 0;
+    const uint32_t Y = global_row(A.frame, L);
+    const bool live = X < A.frame.width && L < A.frame.local_rows && Y < A.frame.height;
+    if (live) {
+        c_px = 1;
+        const uint32_t n_iterations = A.n_iterations;
+        const uint32_t count = A.orbit_count;
+        const float4 *__restrict__ zr = A.zref;
+        uint32_t iter = 0;
+        uint32_t RefIteration = 0;
+        hreal32 DeltaSub0X, DeltaSub0Y;
+        pixel_delta(A.coords, X, Y, DeltaSub0X, DeltaSub0Y);
+        hreal32 DeltaSubNX = hr_zero<float>();
+        hreal32 DeltaSubNY = hr_zero<float>();
+        hreal32 DeltaNormSquared = hr_zero<float>();
+        const hreal32 TwoFiftySix = hreal32{1.0f, 8};
+
+        while (iter < n_iterations) {
+            if (kBla) {
+                const fs_bla_hdr32 *b;
+                while ((b = bla_lookup(A, RefIteration, DeltaNormSquared)) != nullptr) {
+                    const uint32_t l = (uint32_t)b->l;
+                    if (RefIteration + l >= count)
+                        break;
+                    if (iter + l >= n_iterations)
+                        break;
+                    iter += l;
+                    if (kStats)
+                        c_la++;
+                    {
+                        const hreal32 Ax = ldr(b->Ax), Ay = ldr(b->Ay), Bx = ldr(b->Bx), By = ldr(b->By);
+                        const hreal32 nx = hr_sub(
+                            hr_add(hr_sub(hr_mul(Ax, DeltaSubNX), hr_mul(Ay, DeltaSubNY)), hr_mul(Bx, DeltaSub0X)),
+                            hr_mul(By, DeltaSub0Y));
+                        const hreal32 ny = hr_add(
+                            hr_add(hr_add(hr_mul(Ax, DeltaSubNY), hr_mul(Ay, DeltaSubNX)), hr_mul(Bx, DeltaSub0Y)),
+                            hr_mul(By, DeltaSub0X));
+                        DeltaSubNX = nx;
+                        DeltaSubNY = ny;
+                    }
+                    RefIteration += l;
+                    const hcplx32 Z = zref_at(zr, RefIteration);
+                    const hreal32 tempZX = hr_add(hc_re(Z), DeltaSubNX);
+                    const hreal32 tempZY = hr_add(hc_im(Z), DeltaSubNY);
+                    const hreal32 normSquared = hr_reduced(hr_add(hr_mul(tempZX, tempZX), hr_mul(tempZY, tempZY)));
+                    DeltaNormSquared = hr_reduced(hr_add(hr_mul(DeltaSubNX, DeltaSubNX), hr_mul(DeltaSubNY, DeltaSubNY)));
+                    if (hr_cmp_pos(normSquared, TwoFiftySix) > 0)
+                        break;
+                    if (hr_cmp_pos(normSquared, DeltaNormSquared) < 0 || RefIteration >= count - 1) {
+                        DeltaSubNX = tempZX;
+                        DeltaSubNY = tempZY;
+                        DeltaNormSquared = normSquared;
+                        RefIteration = 0;
+                    }
+                }
+                if (iter >= n_iterations)
+                    break;
+            }
+
+            const hreal32 OX = DeltaSubNX, OY = DeltaSubNY;
+            const hcplx32 Z = zref_at(zr, RefIteration);
+            // Term4 == the inner sum of TermB1, Term3 == the inner sum of TermB2 (same operands, same order)
+            const hreal32 T4 = hr_add(hr_mul2(hc_re(Z)), OX);
+            const hreal32 T3 = hr_add(hr_mul2(hc_im(Z)), OY);
+            const hreal32 TermB1 = hr_mul(OX, T4);
+            const hreal32 TermB2 = hr_mul(OY, T3);
+            DeltaSubNX = hr_sub(TermB1, TermB2);
+            DeltaSubNX = hr_add(DeltaSubNX, DeltaSub0X);
+            hr_reduce(DeltaSubNX);
+            DeltaSubNY = hr_add(hr_mul(OX, T3), hr_mul(OY, T4));
+            DeltaSubNY = hr_add(DeltaSubNY, DeltaSub0Y);
+            hr_reduce(DeltaSubNY);
+            if (kStats)
+                c_pt++;
+
+            ++RefIteration;
+            if (RefIteration >= count)
+                break;
+
+            const hcplx32 Z2 = zref_at(zr, RefIteration);
+            const hreal32 tempZX = hr_add(hc_re(Z2), DeltaSubNX);
+            const hreal32 tempZY = hr_add(hc_im(Z2), DeltaSubNY);
+            const hreal32 normSquared = hr_reduced(hr_add(hr_mul(tempZX, tempZX), hr_mul(tempZY, tempZY)));
+            DeltaNormSquared = hr_reduced(hr_add(hr_mul(DeltaSubNX, DeltaSubNX), hr_mul(DeltaSubNY, DeltaSubNY)));
+            if (hr_cmp_pos(normSquared, TwoFiftySix) > 0)
+                break;
+            if (hr_cmp_pos(normSquared, DeltaNormSquared) < 0 || RefIteration >= count - 1) {
+                DeltaSubNX = tempZX;
+                DeltaSubNY = tempZY;
+                DeltaNormSquared = normSquared;
+                RefIteration = 0;
+            }
+            ++iter;
+        }
+        A.out[(size_t)L * A.frame.rounded_width + X] = iter;
+    }
+    if (kStats)
+        add_stats(A.stats, 0, c_la, c_pt, c_px);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Direct double-precision escape time.  CPU twin: Fractal::CalcCpuHDR<uint32_t,double,double>
+// (Fractal.cpp:2148-2183): cy = maxY - dy*(double)(float)y; cx starts at minX and is ACCUMULATED (cx += dx)
+// along the row, so a lane at column x replays x additions; z0 = c; bailout sum > 4.
+// Replaces mandel_1x_double (FractalSharkGpuLib/LowPrecisionKernels.cuh:79-171).
+template <bool kStats>
+__global__ void __launch_bounds__(256) k_direct_f64(FsDirectArgs64 A)
+{
+    const uint32_t X = blockIdx.x * 64u + (threadIdx.x & 63u);
+    const uint32_t L = blockIdx.y * 4u + (threadIdx.x >> 6);
+    uint64_t c_pt = 0, c_px = 0;
+    const uint32_t Y = global_row(A.frame, L);
+    const bool live = X < A.frame.width && L < A.frame.local_rows && Y < A.frame.height;
+    if (live) {
+        c_px = 1;
+        // Row prefix of cx: minX + dx + dx + ... (X times), rounded after every addition like the CPU loop.
+        // The prefix for the wave's first column comes from a table built once per frame (A.cx_row).
+        const double cx = A.cx_row[X];
+        const double cy = A.maxY - A.dy * (double)((float)Y);
+        double zx = cx, zy = cy;
+        uint32_t i;
+        for (i = 0; i < A.n_iterations; i++) {
+            const double zx2 = zx * zx;
+            const double zy2 = zy * zy;
+            const double sum = zx2 + zy2;
+            if (sum > 4.0)
+                break;
+            zy = 2.0 * zx * zy;
+            zx = zx2 - zy2;
+            zx += cx;
+            zy += cy;
+        }
+        if (kStats)
+            c_pt = i;
+        A.out[(size_t)L * A.frame.rounded_width + X] = i;
+    }
+    if (kStats)
+        add_stats(A.stats, 0, 0, c_pt, c_px);
+}
+
+// cx_row[x] = minX (+ dx) x times, sequentially rounded: a serial scan, done by one lane once per frame
+// (W <= 61440 additions).
+__global__ void k_direct_row_prefix_f64(double minX, double dx, uint32_t width, double *cx_row)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double cx = minX;
+        for (uint32_t x = 0; x < width; x++) {
+            cx_row[x] = cx;
+            cx += dx;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// RenderCurrent pieces.  Antialias + palette: same arithmetic as antialiasing_kernel
+// (FractalSharkGpuLib/AntialiasingKernel.cuh:3-71): integer box filter, interior pixels contribute black,
+// alpha 65535, colour rows are NOT padded.
+__global__ void __launch_bounds__(256) k_antialias_u32(const uint32_t *__restrict__ iters, uint32_t rounded_width,
+                                                       fs_color16 *__restrict__ colors, const fs_color16 *__restrict__ pal,
+                                                       uint32_t pal_iters, uint32_t aux_depth, uint32_t aa,
+                                                       uint32_t color_w, uint32_t color_h, uint32_t n_iterations)
+{
+    const uint32_t ox = blockIdx.x * 64u + (threadIdx.x & 63u);
+    const uint32_t oy = blockIdx.y * 4u + (threadIdx.x >> 6);
+    if (ox >= color_w || oy >= color_h)
+        return;
+    uint64_t acc_r = 0, acc_g = 0, acc_b = 0;
+    for (uint32_t ix = ox * aa; ix < (ox + 1) * aa; ix++) {
+        for (uint32_t iy = oy * aa; iy < (oy + 1) * aa; iy++) {
+            const uint32_t n = iters[(size_t)iy * rounded_width + ix];
+            if (n < n_iterations) {
+                const uint32_t p = (n >> aux_depth) % pal_iters;
+                const fs_color16 c = pal[p];
+                acc_r += c.r;
+                acc_g += c.g;
+                acc_b += c.b;
+            }
+        }
+    }
+    const uint32_t total = aa * aa;
+    fs_color16 o;
+    o.r = (uint16_t)(acc_r / total);
+    o.g = (uint16_t)(acc_g / total);
+    o.b = (uint16_t)(acc_b / total);
+    o.a = 65535;
+    colors[(size_t)oy * color_w + ox] = o;
+}
+
+// Min / max / sum of the valid (unpadded) part of the iteration buffer: max_kernel
+// (FractalSharkGpuLib/ReductionKernels.cuh:73-142) without its unsynchronised output reset -- the host
+// seeds {Min=UINT32_MAX, Max=0, Sum=0} on the stream before the launch.  Wave shuffles, one atomic triple
+// per wave.
+__global__ void __launch_bounds__(256) k_reduce_u32(const uint32_t *__restrict__ iters, uint32_t rounded_width,
+                                                    uint32_t width, uint32_t rows, fs_reduction *out)
+{
+    uint64_t mn = 0xFFFFFFFFull, mx = 0, sum = 0;
+    const uint64_t total = (uint64_t)rounded_width * rows;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t x = (uint32_t)(i % rounded_width);
+        if (x < width) {
+            const uint64_t v = iters[i];
+            mn = v < mn ? v : mn;
+            mx = v > mx ? v : mx;
+            sum += v;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint64_t omn = __shfl_down(mn, off), omx = __shfl_down(mx, off);
+        mn = omn < mn ? omn : mn;
+        mx = omx > mx ? omx : mx;
+        sum += __shfl_down(sum, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin((unsigned long long *)&out->Min, (unsigned long long)mn);
+        atomicMax((unsigned long long *)&out->Max, (unsigned long long)mx);
+        atomicAdd((unsigned long long *)&out->Sum, (unsigned long long)sum);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Host-callable launchers (called from renderer.cpp through kernels.h).
+static dim3 frame_grid(const FsFrame &f) { return dim3((f.width + 63) / 64, (f.local_rows + 3) / 4, 1); }
+
+void fsk_prepare_orbit_hdr32(const fs_orbit_hdr32 *in, float4 *out, uint64_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_prepare_orbit_hdr32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n);
+}
+
+void fsk_lav2_hdr32(const FsLav2Args32 &A, int mode, bool stats, hipStream_t s)
+{
+    const dim3 g = frame_grid(A.frame), b(256);
+#define FS_LAUNCH(M)                                                                                                \
+    do {                                                                                                            \
+        if (stats)                                                                                                  \
+            hipLaunchKernelGGL((k_lav2_hdr32<M, true>), g, b, 0, s, A);                                             \
+        else                                                                                                        \
+            hipLaunchKernelGGL((k_lav2_hdr32<M, false>), g, b, 0, s, A);                                            \
+    } while (0)
+    if (mode == FS_MODE_FULL)
+        FS_LAUNCH(FS_MODE_FULL);
+    else if (mode == FS_MODE_PO)
+        FS_LAUNCH(FS_MODE_PO);
+    else
+        FS_LAUNCH(FS_MODE_LAO);
+#undef FS_LAUNCH
+}
+
+void fsk_perturb_scalar_hdr32(const FsBlaArgs32 &A, bool use_bla, bool stats, hipStream_t s)
+{
+    const dim3 g = frame_grid(A.frame), b(256);
+    if (use_bla) {
+        if (stats)
+            hipLaunchKernelGGL((k_perturb_scalar_hdr32<true, true>), g, b, 0, s, A);
+        else
+            hipLaunchKernelGGL((k_perturb_scalar_hdr32<true, false>), g, b, 0, s, A);
+    } else {
+        if (stats)
+            hipLaunchKernelGGL((k_perturb_scalar_hdr32<false, true>), g, b, 0, s, A);
+        else
+            hipLaunchKernelGGL((k_perturb_scalar_hdr32<false, false>), g, b, 0, s, A);
+    }
+}
+
+void fsk_direct_f64(const FsDirectArgs64 &A, double minX, double dx, bool stats, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_direct_row_prefix_f64, dim3(1), dim3(64), 0, s, minX, dx, A.frame.width, A.cx_row);
+    const dim3 g = frame_grid(A.frame), b(256);
+    if (stats)
+        hipLaunchKernelGGL((k_direct_f64<true>), g, b, 0, s, A);
+    else
+        hipLaunchKernelGGL((k_direct_f64<false>), g, b, 0, s, A);
+}
+
+void fsk_antialias_u32(const uint32_t *iters, uint32_t rounded_width, fs_color16 *colors, const fs_color16 *pal,
+                       uint32_t pal_iters, uint32_t aux_depth, uint32_t aa, uint32_t color_w, uint32_t color_h,
+                       uint32_t n_iterations, hipStream_t s)
+{
+    const dim3 g((color_w + 63) / 64, (color_h + 3) / 4), b(256);
+    hipLaunchKernelGGL(k_antialias_u32, g, b, 0, s, iters, rounded_width, colors, pal, pal_iters, aux_depth, aa,
+                       color_w, color_h, n_iterations);
+}
+
+void fsk_reduce_u32(const uint32_t *iters, uint32_t rounded_width, uint32_t width, uint32_t rows, fs_reduction *out,
+                    hipStream_t s)
+{
+    hipLaunchKernelGGL(k_reduce_u32, dim3(1024), dim3(256), 0, s, iters, rounded_width, width, rows, out);
+}

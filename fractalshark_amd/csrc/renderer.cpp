@@ -1,0 +1,743 @@
+// renderer.cpp -- host side of libfsmi355.so: the C ABI of include/fsmi355.h.
+//
+// State machine of one reference GPURenderer (FractalSharkGpuLib/GPU_Render.cu:92-1823) re-expressed for
+// HIP: two non-blocking streams (compute = lowest priority, display = highest, GPU_Render.cu:247-267),
+// device buffers owned here, uploads cached by generation number (GPU_Render.cu:440-487), kernels launched
+// asynchronously on the compute stream.  There is NO CPU fallback: if no HIP device is usable every entry
+// point returns the HIP error.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/fsmi355.h"
+#include "kernels.h"
+
+#define FS_TRY(expr)                                                                                                  \
+    do {                                                                                                              \
+        hipError_t e_ = (expr);                                                                                       \
+        if (e_ != hipSuccess)                                                                                         \
+            return (uint32_t)e_;                                                                                      \
+    } while (0)
+
+struct fs_renderer {
+    int device = 0;
+    hipStream_t compute = nullptr;
+    hipStream_t display = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool timed = false;
+
+    // geometry
+    uint32_t width = 0, height = 0, aa = 0, iter_bytes = 0;
+    uint32_t w_block = 0, h_block = 0;
+    uint32_t color_w = 0, color_h = 0;
+    size_t n_cu = 0, n_color_cu = 0;
+    uint32_t band_first = 0, band_rows = 0, band_stride = 0; // 0 rows = whole frame
+    uint32_t local_rows = 0, local_rows_padded = 0;
+
+    // buffers
+    void *iters_internal = nullptr;
+    size_t iters_internal_elems = 0;
+    void *iters_external = nullptr;
+    fs_color16 *colors = nullptr;
+    fs_reduction *reduction = nullptr;
+    uint64_t *stats = nullptr;
+    bool stats_on = false;
+
+    // palette (GPU_Render.cu:270-304)
+    fs_color16 *pal = nullptr;
+    uint32_t pal_iters = 0, pal_aux_depth = 0;
+    const fs_color16 *pal_cached_host = nullptr;
+    uint64_t pal_cached_gen = 0;
+
+    // orbit (HDRFloat<float>)
+    uint64_t orbit_gen = 0;
+    bool orbit_ok = false;
+    float4 *zref = nullptr;
+    uint64_t orbit_size = 0, orbit_uncompressed = 0, orbit_period = 0;
+
+    // LA table
+    uint64_t la_gen = 0;
+    bool la_ok = false;
+    fs_la_hdr32_u32 *las = nullptr;
+    fs_la_stage_u32 *stages = nullptr;
+    uint32_t n_las = 0, n_stages = 0;
+    int la_valid = 0, use_at = 0;
+    fs_at_hdr32_u32 at{};
+
+    // BLA table
+    std::vector<void *> bla_level_mem;
+    const fs_bla_hdr32 **bla_levels_dev = nullptr;
+    int32_t bla_n_levels = 0, bla_lm2 = 0;
+
+    // direct kernels
+    double *cx_row = nullptr;
+    uint32_t cx_row_cap = 0;
+
+    void *iters() const { return iters_external ? iters_external : iters_internal; }
+    bool memory_initialized() const { return iters() != nullptr && width != 0; }
+};
+
+namespace {
+
+uint32_t use_device(const fs_renderer *r)
+{
+    FS_TRY(hipSetDevice(r->device));
+    return 0;
+}
+
+void compute_local_rows(fs_renderer *r)
+{
+    if (r->band_rows == 0 || r->band_rows >= r->height) {
+        r->band_first = 0;
+        r->band_rows = r->height;
+        r->band_stride = r->height ? r->height : 1;
+    }
+    // rows owned = sum over k of |[first + k*stride, +rows) intersect [0,height)|
+    uint64_t rows = 0;
+    for (uint64_t start = r->band_first; start < r->height; start += r->band_stride) {
+        const uint64_t end = start + r->band_rows < r->height ? start + r->band_rows : r->height;
+        rows += end - start;
+    }
+    r->local_rows = (uint32_t)rows;
+    r->local_rows_padded = (r->local_rows + 7u) / 8u * 8u;
+}
+
+FsFrame make_frame(const fs_renderer *r)
+{
+    FsFrame f;
+    f.width = r->width;
+    f.height = r->height;
+    f.rounded_width = r->w_block * 16u;
+    f.local_rows = r->local_rows;
+    f.band_first = r->band_first;
+    f.band_rows = r->band_rows;
+    f.band_stride = r->band_stride;
+    return f;
+}
+
+uint32_t ensure_iter_buffer(fs_renderer *r)
+{
+    const size_t need = (size_t)r->w_block * 16u * r->local_rows_padded;
+    if (r->iters_external)
+        return 0;
+    if (r->iters_internal && r->iters_internal_elems >= need)
+        return 0;
+    if (r->iters_internal) {
+        FS_TRY(hipFree(r->iters_internal));
+        r->iters_internal = nullptr;
+    }
+    FS_TRY(hipMalloc(&r->iters_internal, need * r->iter_bytes));
+    r->iters_internal_elems = need;
+    return 0;
+}
+
+void free_perturb(fs_renderer *r)
+{
+    if (r->zref)
+        hipFree(r->zref);
+    r->zref = nullptr;
+    r->orbit_ok = false;
+    r->orbit_gen = 0;
+    if (r->las)
+        hipFree(r->las);
+    if (r->stages)
+        hipFree(r->stages);
+    r->las = nullptr;
+    r->stages = nullptr;
+    r->la_ok = false;
+    r->la_gen = 0;
+    for (void *p : r->bla_level_mem)
+        if (p)
+            hipFree(p);
+    r->bla_level_mem.clear();
+    if (r->bla_levels_dev)
+        hipFree((void *)r->bla_levels_dev);
+    r->bla_levels_dev = nullptr;
+    r->bla_n_levels = 0;
+}
+
+void free_all(fs_renderer *r)
+{
+    free_perturb(r);
+    if (r->iters_internal)
+        hipFree(r->iters_internal);
+    if (r->colors)
+        hipFree(r->colors);
+    if (r->reduction)
+        hipFree(r->reduction);
+    if (r->stats)
+        hipFree(r->stats);
+    if (r->pal)
+        hipFree(r->pal);
+    if (r->cx_row)
+        hipFree(r->cx_row);
+    r->iters_internal = nullptr;
+    r->colors = nullptr;
+    r->reduction = nullptr;
+    r->stats = nullptr;
+    r->pal = nullptr;
+    r->cx_row = nullptr;
+    r->width = r->height = 0;
+}
+
+struct TimedLaunch {
+    fs_renderer *r;
+    explicit TimedLaunch(fs_renderer *rr) : r(rr)
+    {
+        if (r->ev_start)
+            hipEventRecord(r->ev_start, r->compute);
+        if (r->stats_on && r->stats)
+            hipMemsetAsync(r->stats, 0, 4 * sizeof(uint64_t), r->compute);
+    }
+    ~TimedLaunch()
+    {
+        if (r->ev_stop) {
+            hipEventRecord(r->ev_stop, r->compute);
+            r->timed = true;
+        }
+    }
+};
+
+} // namespace
+
+extern "C" {
+
+fs_renderer *fs_create(int device)
+{
+    fs_renderer *r = new (std::nothrow) fs_renderer();
+    if (r)
+        r->device = device;
+    return r;
+}
+
+void fs_destroy(fs_renderer *r)
+{
+    if (!r)
+        return;
+    if (hipSetDevice(r->device) == hipSuccess) {
+        if (r->compute)
+            hipStreamSynchronize(r->compute);
+        if (r->display)
+            hipStreamSynchronize(r->display);
+        free_all(r);
+        if (r->ev_start)
+            hipEventDestroy(r->ev_start);
+        if (r->ev_stop)
+            hipEventDestroy(r->ev_stop);
+        if (r->compute)
+            hipStreamDestroy(r->compute);
+        if (r->display)
+            hipStreamDestroy(r->display);
+    }
+    delete r;
+}
+
+uint32_t fs_test_device_is_working(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return 0;
+    if (hipSetDevice(0) != hipSuccess)
+        return 0;
+    if (hipFree(nullptr) != hipSuccess)
+        return 0;
+    return 1;
+}
+
+const char *fs_error_string(uint32_t err)
+{
+    switch (err) {
+        case FS_OK:
+            return "no error";
+        case FS_ERR_1:
+        case FS_ERR_2:
+            return "FractalSharkError: unused";
+        case FS_ERR_3:
+            return "FractalSharkError::Error3: antialiasing must be 1..4";
+        case FS_ERR_4:
+            return "FractalSharkError::Error4: width not divisible by antialiasing";
+        case FS_ERR_5:
+            return "FractalSharkError::Error5: height not divisible by antialiasing";
+        case FS_ERR_6:
+            return "FractalSharkError::Error6: no uploaded orbit/table for this type";
+        case FS_ERR_7:
+            return "FractalSharkError::Error7";
+        case FS_ERR_UNSUPPORTED:
+            return "fsmi355: numeric type / mode not built into this library";
+        default:
+            return hipGetErrorString((hipError_t)err);
+    }
+}
+
+uint32_t fs_init_memory(fs_renderer *r, uint32_t w, uint32_t h, uint32_t antialiasing, uint32_t iter_bytes,
+                        const fs_color16 *pal_interleaved, uint32_t pal_iters, uint32_t palette_aux_depth,
+                        uint64_t palette_generation, int expected_reuse)
+{
+    if (uint32_t e = use_device(r))
+        return e;
+    if (iter_bytes != 4)
+        return FS_ERR_UNSUPPORTED; // uint64_t IterType: later round
+    if (!r->compute) {
+        int lo = 0, hi = 0;
+        FS_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        FS_TRY(hipStreamCreateWithPriority(&r->compute, hipStreamNonBlocking, lo));
+        FS_TRY(hipStreamCreateWithPriority(&r->display, hipStreamNonBlocking, hi));
+        FS_TRY(hipEventCreate(&r->ev_start));
+        FS_TRY(hipEventCreate(&r->ev_stop));
+    }
+    // palette: re-upload when the host pointer or the generation changes (GPU_Render.cu:270-304)
+    r->pal_aux_depth = palette_aux_depth;
+    if (pal_interleaved && (r->pal_cached_host != pal_interleaved || r->pal_cached_gen != palette_generation ||
+                            r->pal_iters != pal_iters)) {
+        if (r->pal) {
+            FS_TRY(hipFree(r->pal));
+            r->pal = nullptr;
+        }
+        FS_TRY(hipMalloc((void **)&r->pal, sizeof(fs_color16) * (size_t)pal_iters));
+        FS_TRY(hipMemcpyAsync(r->pal, pal_interleaved, sizeof(fs_color16) * (size_t)pal_iters, hipMemcpyDefault,
+                              r->compute));
+        FS_TRY(hipStreamSynchronize(r->compute)); // host buffer is borrowed for the call only
+        r->pal_iters = pal_iters;
+        r->pal_cached_host = pal_interleaved;
+        r->pal_cached_gen = palette_generation;
+    }
+    if (r->width == w && r->height == h && r->aa == antialiasing && r->iter_bytes == iter_bytes && expected_reuse)
+        return 0;
+    if (antialiasing > 4 || antialiasing < 1)
+        return FS_ERR_3;
+    if (w % antialiasing != 0)
+        return FS_ERR_4;
+    if (h % antialiasing != 0)
+        return FS_ERR_5;
+
+    r->w_block = w / 16 + (w % 16 != 0);
+    r->h_block = h / 8 + (h % 8 != 0);
+    r->width = w;
+    r->height = h;
+    r->aa = antialiasing;
+    r->iter_bytes = iter_bytes;
+    r->n_cu = (size_t)r->w_block * 16 * r->h_block * 8;
+    r->color_w = w / antialiasing;
+    r->color_h = h / antialiasing;
+    const uint32_t wcb = r->color_w / 16 + (r->color_w % 16 != 0);
+    const uint32_t hcb = r->color_h / 8 + (r->color_h % 8 != 0);
+    r->n_color_cu = (size_t)wcb * 16 * hcb * 8;
+    r->band_rows = 0;
+    compute_local_rows(r);
+
+    // ResetMemory(..., ResetPerturb::Yes, ...) -- GPU_Render.cu:346
+    free_perturb(r);
+    if (uint32_t e = ensure_iter_buffer(r)) {
+        free_all(r);
+        return e;
+    }
+    if (r->colors) {
+        hipFree(r->colors);
+        r->colors = nullptr;
+    }
+    if (!r->reduction)
+        FS_TRY(hipMalloc((void **)&r->reduction, sizeof(fs_reduction)));
+    if (!r->stats)
+        FS_TRY(hipMalloc((void **)&r->stats, 4 * sizeof(uint64_t)));
+    FS_TRY(hipMalloc((void **)&r->colors, r->n_color_cu * sizeof(fs_color16)));
+    return fs_clear(r);
+}
+
+uint32_t fs_set_row_bands(fs_renderer *r, uint32_t band_first_row, uint32_t band_rows, uint32_t band_stride_rows)
+{
+    if (uint32_t e = use_device(r))
+        return e;
+    if (r->width == 0)
+        return FS_ERR_6;
+    if (band_rows != 0 && (band_stride_rows < band_rows))
+        return FS_ERR_7;
+    r->band_first = band_first_row;
+    r->band_rows = band_rows;
+    r->band_stride = band_stride_rows;
+    compute_local_rows(r);
+    return ensure_iter_buffer(r);
+}
+
+uint32_t fs_local_rows(const fs_renderer *r) { return r->local_rows_padded; }
+
+uint32_t fs_set_external_iter_buffer(fs_renderer *r, void *device_ptr)
+{
+    r->iters_external = device_ptr;
+    if (!device_ptr)
+        return ensure_iter_buffer(r);
+    return 0;
+}
+
+void *fs_device_iter_buffer(const fs_renderer *r) { return r->iters(); }
+uint32_t fs_rounded_width(const fs_renderer *r) { return r->w_block * 16u; }
+
+uint32_t fs_upload_orbit(fs_renderer *r, uint64_t generation, int type_tag, uint32_t iter_bytes, const void *entries,
+                         uint64_t orbit_size, uint64_t uncompressed_size, uint64_t period_maybe_zero)
+{
+    if (uint32_t e = use_device(r))
+        return e;
+    if (type_tag != FS_T_HDR32 || iter_bytes != 4)
+        return FS_ERR_UNSUPPORTED;
+    if (!r->compute)
+        return FS_ERR_6;
+    if (r->orbit_ok && r->orbit_gen == generation && generation != 0)
+        return 0; // cached by generation number (GPU_Render.cu:440-487)
+    if (r->zref) {
+        FS_TRY(hipFree(r->zref));
+        r->zref = nullptr;
+    }
+    r->orbit_ok = false;
+    fs_orbit_hdr32 *raw = nullptr;
+    FS_TRY(hipMalloc((void **)&raw, orbit_size * sizeof(fs_orbit_hdr32)));
+    hipError_t err = hipMalloc((void **)&r->zref, orbit_size * sizeof(float4));
+    if (err == hipSuccess)
+        err = hipMemcpyAsync(raw, entries, orbit_size * sizeof(fs_orbit_hdr32), hipMemcpyDefault, r->compute);
+    if (err == hipSuccess) {
+        fsk_prepare_orbit_hdr32(raw, r->zref, orbit_size, r->compute);
+        err = hipGetLastError();
+    }
+    if (err == hipSuccess)
+        err = hipStreamSynchronize(r->compute);
+    hipFree(raw);
+    if (err != hipSuccess)
+        return (uint32_t)err;
+    r->orbit_size = orbit_size;
+    r->orbit_uncompressed = uncompressed_size;
+    r->orbit_period = period_maybe_zero;
+    r->orbit_gen = generation;
+    r->orbit_ok = true;
+    return 0;
+}
+
+uint32_t fs_upload_la(fs_renderer *r, uint64_t generation, int type_tag, uint32_t iter_bytes, const void *las,
+                      uint32_t n_las, const void *stages, uint32_t n_stages, int is_valid, int use_at,
+                      const void *at_info)
+{
+    if (uint32_t e = use_device(r))
+        return e;
+    if (type_tag != FS_T_HDR32 || iter_bytes != 4)
+        return FS_ERR_UNSUPPORTED;
+    if (!r->compute)
+        return FS_ERR_6;
+    if (r->la_ok && r->la_gen == generation && generation != 0)
+        return 0;
+    if (r->las) {
+        FS_TRY(hipFree(r->las));
+        r->las = nullptr;
+    }
+    if (r->stages) {
+        FS_TRY(hipFree(r->stages));
+        r->stages = nullptr;
+    }
+    r->la_ok = false;
+    if (n_las) {
+        FS_TRY(hipMalloc((void **)&r->las, (size_t)n_las * sizeof(fs_la_hdr32_u32)));
+        FS_TRY(hipMemcpyAsync(r->las, las, (size_t)n_las * sizeof(fs_la_hdr32_u32), hipMemcpyDefault, r->compute));
+    }
+    if (n_stages) {
+        FS_TRY(hipMalloc((void **)&r->stages, (size_t)n_stages * sizeof(fs_la_stage_u32)));
+        FS_TRY(hipMemcpyAsync(r->stages, stages, (size_t)n_stages * sizeof(fs_la_stage_u32), hipMemcpyDefault,
+                              r->compute));
+    }
+    FS_TRY(hipStreamSynchronize(r->compute));
+    r->n_las = n_las;
+    r->n_stages = n_stages;
+    r->la_valid = is_valid;
+    r->use_at = use_at;
+    if (at_info)
+        memcpy(&r->at, at_info, sizeof(r->at));
+    else {
+        memset(&r->at, 0, sizeof(r->at));
+        r->use_at = 0;
+    }
+    r->la_gen = generation;
+    r->la_ok = true;
+    return 0;
+}
+
+uint32_t fs_upload_bla(fs_renderer *r, int type_tag, const void *const *levels, const uint64_t *level_sizes,
+                       int32_t n_levels, int32_t lm2)
+{
+    if (uint32_t e = use_device(r))
+        return e;
+    if (type_tag != FS_T_HDR32)
+        return FS_ERR_UNSUPPORTED;
+    if (!r->compute)
+        return FS_ERR_6;
+    for (void *p : r->bla_level_mem)
+        if (p)
+            hipFree(p);
+    r->bla_level_mem.clear();
+    if (r->bla_levels_dev) {
+        hipFree((void *)r->bla_levels_dev);
+        r->bla_levels_dev = nullptr;
+    }
+    r->bla_n_levels = 0;
+    if (n_levels <= 0)
+        return 0;
+    std::vector<const fs_bla_hdr32 *> ptrs((size_t)n_levels, nullptr);
+    for (int32_t l = 0; l < n_levels; l++) {
+        void *d = nullptr;
+        if (levels[l] && level_sizes[l]) {
+            FS_TRY(hipMalloc(&d, level_sizes[l] * sizeof(fs_bla_hdr32)));
+            FS_TRY(hipMemcpyAsync(d, levels[l], level_sizes[l] * sizeof(fs_bla_hdr32), hipMemcpyDefault, r->compute));
+        }
+        r->bla_level_mem.push_back(d);
+        ptrs[l] = (const fs_bla_hdr32 *)d;
+    }
+    FS_TRY(hipMalloc((void **)&r->bla_levels_dev, sizeof(void *) * (size_t)n_levels));
+    FS_TRY(hipMemcpyAsync((void *)r->bla_levels_dev, ptrs.data(), sizeof(void *) * (size_t)n_levels, hipMemcpyDefault,
+                          r->compute));
+    FS_TRY(hipStreamSynchronize(r->compute));
+    r->bla_n_levels = n_levels;
+    r->bla_lm2 = lm2;
+    return 0;
+}
+
+static void fill_coords32(FsCoords32 &c, const void *coords)
+{
+    const fs_real_hdr32 *p = (const fs_real_hdr32 *)coords;
+    c.dx = fs::hreal32{p[0].m, p[0].e};
+    c.dy = fs::hreal32{p[1].m, p[1].e};
+    c.centerX = fs::hreal32{p[2].m, p[2].e};
+    c.centerY = fs::hreal32{p[3].m, p[3].e};
+}
+
+uint32_t fs_render_bla(fs_renderer *r, int type_tag, const void *coords, uint64_t n_iterations);
+
+uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, const void *coords, uint64_t n_iterations)
+{
+    if (uint32_t e = use_device(r))
+        return e;
+    if (!r->memory_initialized())
+        return 0; // GPU_Render.cu:1007-1009
+    if (type_tag != FS_T_HDR32 || n_iterations > 0xFFFFFFFFull)
+        return FS_ERR_UNSUPPORTED;
+    if (!r->orbit_ok)
+        return FS_ERR_6; // GPU_Render.cu:1015-1022
+    if (mode == FS_LAV2_PO && parity == FS_PARITY_CPU) {
+        // No dispatched CPU RenderAlgorithm is perturbation-only in HDRFloatComplex arithmetic; the CPU parity
+        // target for PO is the single-step branch of CalcCpuPerturbationFractalBLA.
+        const int32_t saved = r->bla_n_levels;
+        r->bla_n_levels = 0;
+        const uint32_t e = fs_render_bla(r, type_tag, coords, n_iterations);
+        r->bla_n_levels = saved;
+        return e;
+    }
+    if (mode != FS_LAV2_PO && !r->la_ok)
+        return FS_ERR_6;
+    FsLav2Args32 A;
+    memset(&A, 0, sizeof(A));
+    A.out = (uint32_t *)r->iters();
+    A.zref = r->zref;
+    A.las = r->las;
+    A.stages = r->stages;
+    A.stats = r->stats;
+    A.frame = make_frame(r);
+    fill_coords32(A.coords, coords);
+    A.at = r->at;
+    A.orbit_count = (uint32_t)r->orbit_uncompressed;
+    A.period = (uint32_t)r->orbit_period;
+    A.stage_count = r->n_stages;
+    A.n_iterations = (uint32_t)n_iterations;
+    A.la_valid = r->la_ok ? r->la_valid : 0;
+    A.use_at = r->use_at;
+    A.parity = (parity == FS_PARITY_CPU_GPUSTAGE) ? FS_PARITY_GPUSTAGE : FS_PARITY_LITERAL;
+    {
+        TimedLaunch t(r);
+        fsk_lav2_hdr32(A, mode == FS_LAV2_FULL ? FS_MODE_FULL : (mode == FS_LAV2_PO ? FS_MODE_PO : FS_MODE_LAO),
+                       r->stats_on, r->compute);
+    }
+    return (uint32_t)hipGetLastError();
+}
+
+uint32_t fs_render_bla(fs_renderer *r, int type_tag, const void *coords, uint64_t n_iterations)
+{
+    if (uint32_t e = use_device(r))
+        return e;
+    if (!r->memory_initialized())
+        return 0;
+    if (type_tag != FS_T_HDR32 || n_iterations > 0xFFFFFFFFull)
+        return FS_ERR_UNSUPPORTED;
+    if (!r->orbit_ok)
+        return FS_ERR_6;
+    FsBlaArgs32 A;
+    memset(&A, 0, sizeof(A));
+    A.out = (uint32_t *)r->iters();
+    A.zref = r->zref;
+    A.levels = r->bla_levels_dev;
+    A.stats = r->stats;
+    A.frame = make_frame(r);
+    fill_coords32(A.coords, coords);
+    A.orbit_count = (uint32_t)r->orbit_uncompressed;
+    A.n_iterations = (uint32_t)n_iterations;
+    A.lm2 = r->bla_lm2;
+    {
+        TimedLaunch t(r);
+        fsk_perturb_scalar_hdr32(A, r->bla_n_levels > 2 && r->bla_levels_dev != nullptr, r->stats_on, r->compute);
+    }
+    return (uint32_t)hipGetLastError();
+}
+
+uint32_t fs_render_direct(fs_renderer *r, int type_tag, const void *coords, uint64_t n_iterations)
+{
+    if (uint32_t e = use_device(r))
+        return e;
+    if (!r->memory_initialized())
+        return 0; // GPU_Render.cu:626-628
+    if (type_tag != FS_T_F64 || n_iterations > 0xFFFFFFFFull)
+        return FS_ERR_UNSUPPORTED;
+    if (r->cx_row_cap < r->width) {
+        if (r->cx_row)
+            FS_TRY(hipFree(r->cx_row));
+        r->cx_row = nullptr;
+        FS_TRY(hipMalloc((void **)&r->cx_row, sizeof(double) * r->width));
+        r->cx_row_cap = r->width;
+    }
+    const double *c = (const double *)coords;
+    FsDirectArgs64 A;
+    memset(&A, 0, sizeof(A));
+    A.out = (uint32_t *)r->iters();
+    A.cx_row = r->cx_row;
+    A.stats = r->stats;
+    A.frame = make_frame(r);
+    A.dy = c[1];
+    A.maxY = c[3];
+    A.n_iterations = (uint32_t)n_iterations;
+    {
+        TimedLaunch t(r);
+        fsk_direct_f64(A, c[2], c[0], r->stats_on, r->compute);
+    }
+    return (uint32_t)hipGetLastError();
+}
+
+uint32_t fs_clear(fs_renderer *r)
+{
+    if (uint32_t e = use_device(r))
+        return e;
+    if (!r->memory_initialized())
+        return 0;
+    const size_t elems = (size_t)r->w_block * 16u * r->local_rows_padded;
+    FS_TRY(hipMemsetAsync(r->iters(), 0, elems * r->iter_bytes, r->compute));
+    if (r->colors)
+        FS_TRY(hipMemsetAsync(r->colors, 0, r->n_color_cu * sizeof(fs_color16), r->compute));
+    return 0;
+}
+
+uint32_t fs_render_current(fs_renderer *r, uint64_t n_iterations, void *iter_buffer, fs_color16 *color_buffer,
+                           fs_reduction *reduction, int progressive)
+{
+    if (uint32_t e = use_device(r))
+        return e;
+    if (!r->memory_initialized())
+        return 0; // GPU_Render.cu:564-566
+    hipStream_t s = progressive ? r->display : r->compute;
+    const uint32_t rw = r->w_block * 16u;
+    const bool whole_frame = r->local_rows == r->height;
+    if (color_buffer && r->pal && whole_frame) {
+        fsk_antialias_u32((const uint32_t *)r->iters(), rw, r->colors, r->pal, r->pal_iters, r->pal_aux_depth, r->aa,
+                          r->color_w, r->color_h, (uint32_t)n_iterations, s);
+        FS_TRY(hipGetLastError());
+    }
+    if (reduction) {
+        const fs_reduction seed{0xFFFFFFFFull, 0, 0};
+        FS_TRY(hipMemcpyAsync(r->reduction, &seed, sizeof(seed), hipMemcpyHostToDevice, s));
+        fsk_reduce_u32((const uint32_t *)r->iters(), rw, r->width, r->local_rows, r->reduction, s);
+        FS_TRY(hipGetLastError());
+    }
+    // ExtractItersAndColors, GPU_Render.cu:1759-1805: padding included.
+    if (iter_buffer)
+        FS_TRY(hipMemcpyAsync(iter_buffer, r->iters(), (size_t)rw * r->local_rows_padded * r->iter_bytes,
+                              hipMemcpyDefault, s));
+    if (color_buffer && whole_frame)
+        FS_TRY(hipMemcpyAsync(color_buffer, r->colors, r->n_color_cu * sizeof(fs_color16), hipMemcpyDefault, s));
+    if (reduction)
+        FS_TRY(hipMemcpyAsync(reduction, r->reduction, sizeof(fs_reduction), hipMemcpyDefault, s));
+    return 0;
+}
+
+uint32_t fs_sync_compute(fs_renderer *r)
+{
+    if (uint32_t e = use_device(r))
+        return e;
+    if (!r->compute)
+        return 0;
+    return (uint32_t)hipStreamSynchronize(r->compute);
+}
+
+uint32_t fs_sync_display(fs_renderer *r)
+{
+    if (uint32_t e = use_device(r))
+        return e;
+    if (!r->display)
+        return 0;
+    return (uint32_t)hipStreamSynchronize(r->display);
+}
+
+uint32_t fs_query_compute(fs_renderer *r)
+{
+    if (uint32_t e = use_device(r))
+        return e;
+    if (!r->compute)
+        return 0;
+    return (uint32_t)hipStreamQuery(r->compute);
+}
+
+struct DoneThunk {
+    fs_done_cb cb;
+    void *user;
+};
+
+static void done_trampoline(void *p)
+{
+    DoneThunk *t = (DoneThunk *)p;
+    t->cb(t->user);
+    delete t;
+}
+
+uint32_t fs_enqueue_done_callback(fs_renderer *r, fs_done_cb cb, void *user)
+{
+    if (uint32_t e = use_device(r))
+        return e;
+    if (!r->compute || !cb)
+        return FS_ERR_6;
+    DoneThunk *t = new DoneThunk{cb, user};
+    const hipError_t e = hipLaunchHostFunc(r->compute, done_trampoline, t);
+    if (e != hipSuccess)
+        delete t;
+    return (uint32_t)e;
+}
+
+uint32_t fs_get_width(const fs_renderer *r) { return r->width; }
+uint32_t fs_get_height(const fs_renderer *r) { return r->height; }
+
+float fs_last_kernel_ms(const fs_renderer *r)
+{
+    if (!r->timed)
+        return -1.0f;
+    float ms = -1.0f;
+    if (hipEventElapsedTime(&ms, r->ev_start, r->ev_stop) != hipSuccess)
+        return -1.0f;
+    return ms;
+}
+
+uint32_t fs_enable_step_count(fs_renderer *r, int enable)
+{
+    r->stats_on = enable != 0;
+    return 0;
+}
+
+uint32_t fs_read_step_count(fs_renderer *r, uint64_t counts[4])
+{
+    if (uint32_t e = use_device(r))
+        return e;
+    if (!r->stats)
+        return FS_ERR_6;
+    FS_TRY(hipMemcpy(counts, r->stats, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+} // extern "C"

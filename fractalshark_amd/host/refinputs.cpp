@@ -1203,3 +1203,152 @@ extern "C" void fsh_la_at(const fsh_la *l, fs_at_hdr32_u32 *out)
     out->RefCNormSqr = R(a.RefCNormSqr);
     out->factor = R(a.factor);
 }
+
+// ------------------------------------------------------------------ BLA table
+// BLAS<uint32_t, HDRFloat<float>>::Init, BLAS.cpp:25-255 with BLA<T> helpers BLA.cuh:7-110.  The reference
+// fills level 2 and merges upwards on several threads; every element is a pure function of the orbit, so a
+// sequential fill gives the same table.
+namespace {
+
+template <class F> struct BlaRec {
+    hreal<F> r2, Ax, Ay, Bx, By;
+    int32_t l;
+};
+
+template <class F> struct BlaBuilder {
+    const OrbitT<F> &ob;
+    std::vector<std::vector<BlaRec<F>>> B;
+    std::vector<size_t> elementsPerLevel;
+    int32_t LM2 = 0;
+    size_t L = 0;
+    static constexpr size_t kFirstLevel = 2; // BLAS.h:22
+
+    explicit BlaBuilder(const OrbitT<F> &o) : ob(o) {}
+
+    // BLA<T>::hypotA / hypotB, BLA.cuh:40-56
+    static hreal<F> hypot2(hreal<F> a, hreal<F> b) { return hr_reduced(hr_sqrt(hr_add(hr_mul(a, a), hr_mul(b, b)))); }
+
+    // BLAS::CreateOneStep, BLAS.cpp:74-93
+    BlaRec<F> one_step(size_t m, hreal<F> epsilon) const
+    {
+        const hcplx<F> z = hc_from_hr(ob.x[m], ob.y[m]);
+        const hreal<F> RealA = hr_mul2(hc_re(z));
+        const hreal<F> ImagA = hr_mul2(hc_im(z));
+        const hreal<F> mA = hr_sqrt(hr_add(hr_mul(RealA, RealA), hr_mul(ImagA, ImagA)));
+        const hreal<F> r = hr_mul(mA, epsilon);
+        const hreal<F> r2 = hr_mul(r, r);
+        return BlaRec<F>{r2, RealA, ImagA, hr_from_number<F>(F(1)), hr_from_number<F>(F(0)), 1};
+    }
+
+    // BLAS::MergeTwoBlas, BLAS.cpp:25-47
+    BlaRec<F> merge(const BlaRec<F> &x, const BlaRec<F> &y, hreal<F> blaSize) const
+    {
+        const int32_t l = x.l + y.l;
+        // getNewA / getNewB, BLA.cuh:65-91
+        const hreal<F> RealA = hr_reduced(hr_sub(hr_mul(y.Ax, x.Ax), hr_mul(y.Ay, x.Ay)));
+        const hreal<F> ImagA = hr_reduced(hr_add(hr_mul(y.Ax, x.Ay), hr_mul(y.Ay, x.Ax)));
+        const hreal<F> RealB = hr_reduced(hr_add(hr_sub(hr_mul(y.Ax, x.Bx), hr_mul(y.Ay, x.By)), y.Bx));
+        const hreal<F> ImagB = hr_reduced(hr_add(hr_add(hr_mul(y.Ax, x.By), hr_mul(y.Ay, x.Bx)), y.By));
+        const hreal<F> xA = hypot2(x.Ax, x.Ay);
+        const hreal<F> xB = hypot2(x.Bx, x.By);
+        const hreal<F> tempR = hr_reduced(hr_div(hr_sub(hr_sqrt(y.r2), hr_mul(xB, blaSize)), xA));
+        const hreal<F> zero = hr_from_number<F>(F(0));
+        const hreal<F> mx = hr_cmp(zero, tempR) > 0 ? zero : tempR; // HdrMaxReduced(T(0), tempR)
+        const hreal<F> sx = hr_sqrt(x.r2);
+        const hreal<F> r = hr_cmp_pos(sx, mx) < 0 ? sx : mx; // HdrMinPositiveReduced
+        const hreal<F> r2 = hr_mul(r, r);
+        return BlaRec<F>{r2, RealA, ImagA, RealB, ImagB, l};
+    }
+
+    // BLAS::CreateLStep, BLAS.cpp:49-72
+    BlaRec<F> l_step(size_t level, size_t m, hreal<F> blaSize, hreal<F> epsilon) const
+    {
+        if (level == 0)
+            return one_step(m, epsilon);
+        const size_t m2 = m << 1, mx = m2 - 1, my = m2, levelm1 = level - 1;
+        if (my <= elementsPerLevel[levelm1]) {
+            const BlaRec<F> x = l_step(levelm1, mx, blaSize, epsilon);
+            const BlaRec<F> y = l_step(levelm1, my, blaSize, epsilon);
+            return merge(x, y, blaSize);
+        }
+        return l_step(levelm1, mx, blaSize, epsilon);
+    }
+
+    // BLAS::Init, BLAS.cpp:212-255
+    void init(size_t InM, hreal<F> blaSize)
+    {
+        const hreal<F> precision = hr_div(hr_from_number<F>(F(1)), hr_from_mant<F>(F(8388608))); // T(1)/T{1L<<23}
+        size_t m = InM - 1;
+        if (InM == 0 || m == 0)
+            return;
+        elementsPerLevel.clear();
+        for (; m > 1; m = (m + 1) >> 1)
+            elementsPerLevel.push_back(m);
+        elementsPerLevel.push_back(m);
+        L = elementsPerLevel.size();
+        B.clear();
+        B.resize(L);
+        LM2 = (int32_t)L - 2;
+        if (LM2 < 0)
+            LM2 = 0;
+        if (kFirstLevel >= elementsPerLevel.size())
+            return;
+        for (size_t l = kFirstLevel; l < B.size(); l++)
+            B[l].resize(elementsPerLevel[l]);
+        // InitInternal, BLAS.cpp:97-139
+        const size_t elements = elementsPerLevel[kFirstLevel] + 1;
+        for (size_t mm = 1; mm < elements; mm++)
+            B[kFirstLevel][mm - 1] = l_step(kFirstLevel, mm, blaSize, precision);
+        // Merge, BLAS.cpp:141-210
+        size_t src = kFirstLevel;
+        const size_t maxLevel = elementsPerLevel.size() - 1;
+        for (size_t elementsSrc = elementsPerLevel[src]; src < maxLevel && elementsSrc > 1; src++) {
+            const size_t dst = src + 1;
+            const size_t elementsDst = elementsPerLevel[dst];
+            for (size_t k = 0; k < elementsDst; k++) {
+                const size_t mx = k << 1, my = mx + 1;
+                if (my < elementsSrc)
+                    B[dst][k] = merge(B[src][mx], B[src][my], blaSize);
+                else
+                    B[dst][k] = B[src][mx];
+            }
+            elementsSrc = elementsDst;
+        }
+    }
+};
+
+} // namespace
+
+struct fsh_bla {
+    std::vector<std::vector<fs_bla_hdr32>> levels;
+    std::vector<const fs_bla_hdr32 *> ptrs;
+    std::vector<uint64_t> sizes;
+    int32_t lm2 = 0;
+};
+
+extern "C" fsh_bla *fsh_bla_create_hdr32(const fsh_orbit *o)
+{
+    if (o->is64)
+        return nullptr;
+    BlaBuilder<float> b(o->f);
+    b.init(o->f.x.size(), o->f.maxRadius);
+    auto r = std::make_unique<fsh_bla>();
+    r->lm2 = b.LM2;
+    r->levels.resize(b.B.size());
+    for (size_t l = 0; l < b.B.size(); l++) {
+        r->levels[l].resize(b.B[l].size());
+        for (size_t k = 0; k < b.B[l].size(); k++) {
+            const auto &s = b.B[l][k];
+            auto R = [](hreal<float> h) { return fs_real_hdr32{h.m, h.e}; };
+            r->levels[l][k] = fs_bla_hdr32{R(s.r2), R(s.Ax), R(s.Ay), R(s.Bx), R(s.By), s.l};
+        }
+        r->ptrs.push_back(r->levels[l].empty() ? nullptr : r->levels[l].data());
+        r->sizes.push_back(r->levels[l].size());
+    }
+    return r.release();
+}
+extern "C" void fsh_bla_destroy(fsh_bla *b) { delete b; }
+extern "C" int32_t fsh_bla_num_levels(const fsh_bla *b) { return (int32_t)b->levels.size(); }
+extern "C" int32_t fsh_bla_lm2(const fsh_bla *b) { return b->lm2; }
+extern "C" const fs_bla_hdr32 *const *fsh_bla_level_ptrs(const fsh_bla *b) { return b->ptrs.data(); }
+extern "C" const uint64_t *fsh_bla_level_sizes(const fsh_bla *b) { return b->sizes.data(); }

@@ -1,0 +1,185 @@
+"""Host-side inputs of the per-pixel pass: view geometry, reference orbit, LAv2 table, BLA table.
+
+Thin Python handles over libfsinputs.so (include/fs_inputs.h).  Inside FractalShark these objects already
+exist (PointZoomBBConverter, PerturbationResults, LAReference, BLAS); here they are produced stand-alone so
+the renderer can be driven from bench.py and the tests.
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+
+from . import _capi
+
+_VIEWS = None
+
+ORBIT_HDR32_DTYPE = np.dtype([("mx", "<f4"), ("ex", "<i4"), ("ey", "<i4"), ("my", "<f4")])
+LA_HDR32_DTYPE = np.dtype([
+    ("Ref_re", "<f4"), ("Ref_im", "<f4"), ("Ref_e", "<i4"),
+    ("Z_re", "<f4"), ("Z_im", "<f4"), ("Z_e", "<i4"),
+    ("C_re", "<f4"), ("C_im", "<f4"), ("C_e", "<i4"),
+    ("LAThreshold_m", "<f4"), ("LAThreshold_e", "<i4"),
+    ("LAThresholdC_m", "<f4"), ("LAThresholdC_e", "<i4"),
+    ("MinMag_m", "<f4"), ("MinMag_e", "<i4"),
+    ("StepLength", "<u4"), ("NextStageLAIndex", "<u4")])
+BLA_HDR32_DTYPE = np.dtype([("r2_m", "<f4"), ("r2_e", "<i4"), ("Ax_m", "<f4"), ("Ax_e", "<i4"),
+                            ("Ay_m", "<f4"), ("Ay_e", "<i4"), ("Bx_m", "<f4"), ("Bx_e", "<i4"),
+                            ("By_m", "<f4"), ("By_e", "<i4"), ("l", "<i4")])
+assert ORBIT_HDR32_DTYPE.itemsize == 16 and LA_HDR32_DTYPE.itemsize == 68 and BLA_HDR32_DTYPE.itemsize == 44
+
+
+def builtin_views():
+    """Built-in view presets used by the BASELINE configs (data/views.json, see tools/extract_views.py)."""
+    global _VIEWS
+    if _VIEWS is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "views.json")
+        with open(path) as f:
+            _VIEWS = {int(k): v for k, v in json.load(f).items()}
+    return _VIEWS
+
+
+class View:
+    """Fractal::View(n) for a width x height window (aspect-squared bounding box + working precision)."""
+
+    def __init__(self, min_x, min_y, max_x, max_y, width, height, num_iterations=8192, antialiasing=1):
+        self._lib = _capi.inputs_lib()
+        self.width, self.height = int(width), int(height)
+        self.num_iterations = int(num_iterations)
+        self.antialiasing = int(antialiasing)
+        self._h = self._lib.fsh_view_create(min_x.encode(), min_y.encode(), max_x.encode(), max_y.encode(),
+                                            self.width, self.height)
+        if not self._h:
+            raise RuntimeError("fsh_view_create failed")
+
+    @classmethod
+    def builtin(cls, n, width, height, antialiasing=None):
+        v = builtin_views()[n]
+        aa = v["gpuAntialiasing"] if antialiasing is None else antialiasing
+        return cls(v["minX"], v["minY"], v["maxX"], v["maxY"], width, height, v["numIterations"], aa)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.fsh_view_destroy(self._h)
+            self._h = None
+
+    @property
+    def precision_bits(self):
+        return self._lib.fsh_view_precision_bits(self._h)
+
+    def bbox(self):
+        out = []
+        for k in range(4):
+            buf = C.create_string_buffer(1 << 16)
+            self._lib.fsh_view_bbox_str(self._h, k, buf, len(buf))
+            out.append(buf.value.decode())
+        return out
+
+    def coords_direct_f64(self, aa=None):
+        """{dx, dy, minX, maxY} as float64[4] (Cpu64 / direct kernels)."""
+        aa = self.antialiasing if aa is None else aa
+        out = np.zeros(4, np.float64)
+        self._lib.fsh_view_coords_direct_f64(self._h, self.width * aa, self.height * aa, out.ctypes.data)
+        return out
+
+    def coords_perturb_hdr32(self, orbit, aa=None):
+        """{dx, dy, centerX, centerY} as 4 x {float mantissa, int32 exp} (8 x 4 bytes)."""
+        aa = self.antialiasing if aa is None else aa
+        out = np.zeros(4, np.dtype([("m", "<f4"), ("e", "<i4")]))
+        self._lib.fsh_view_coords_perturb_hdr32(self._h, orbit._h, self.width * aa, self.height * aa, out.ctypes.data)
+        return out
+
+
+class Orbit:
+    """Reference orbit at the view centre (PerturbationResults<uint32_t, HDRFloat<float>, Disable> layout)."""
+
+    def __init__(self, view, max_iter=None, periodicity=True):
+        self._lib = _capi.inputs_lib()
+        self.view = view
+        n = view.num_iterations if max_iter is None else max_iter
+        self._h = self._lib.fsh_orbit_create(view._h, 0, n, 1 if periodicity else 0)
+        if not self._h:
+            raise RuntimeError("fsh_orbit_create failed")
+        self.count = self._lib.fsh_orbit_count(self._h)
+        self.period = self._lib.fsh_orbit_period(self._h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.fsh_orbit_destroy(self._h)
+            self._h = None
+
+    @property
+    def data_ptr(self):
+        return self._lib.fsh_orbit_data_hdr32(self._h)
+
+    def entries(self):
+        buf = (C.c_uint8 * (self.count * 16)).from_address(self.data_ptr)
+        return np.frombuffer(buf, dtype=ORBIT_HDR32_DTYPE)
+
+
+class LATable:
+    """LAv2 table (LAReference<uint32_t, HDRFloat<float>, float, Disable>)."""
+
+    def __init__(self, orbit, host_threads=8):
+        self._lib = _capi.inputs_lib()
+        self.orbit = orbit
+        self._h = self._lib.fsh_la_create_hdr32(orbit._h, host_threads)
+        if not self._h:
+            raise RuntimeError("fsh_la_create_hdr32 failed")
+        self.count = self._lib.fsh_la_count(self._h)
+        self.stage_count = self._lib.fsh_la_stage_count(self._h)
+        self.is_valid = bool(self._lib.fsh_la_is_valid(self._h))
+        self.use_at = bool(self._lib.fsh_la_use_at(self._h))
+        self.at = _capi.AtHdr32()
+        self._lib.fsh_la_at(self._h, C.addressof(self.at))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.fsh_la_destroy(self._h)
+            self._h = None
+
+    @property
+    def las_ptr(self):
+        return self._lib.fsh_la_data(self._h)
+
+    @property
+    def stages_ptr(self):
+        return self._lib.fsh_la_stages(self._h)
+
+    def records(self):
+        buf = (C.c_uint8 * (self.count * 68)).from_address(self.las_ptr)
+        return np.frombuffer(buf, dtype=LA_HDR32_DTYPE)
+
+    def stages(self):
+        buf = (C.c_uint32 * (self.stage_count * 2)).from_address(self.stages_ptr)
+        return np.frombuffer(buf, dtype=np.uint32).reshape(-1, 2)
+
+
+class BLATable:
+    """BLA table (BLAS<uint32_t, HDRFloat<float>>)."""
+
+    def __init__(self, orbit):
+        self._lib = _capi.inputs_lib()
+        self.orbit = orbit
+        self._h = self._lib.fsh_bla_create_hdr32(orbit._h)
+        if not self._h:
+            raise RuntimeError("fsh_bla_create_hdr32 failed")
+        self.num_levels = self._lib.fsh_bla_num_levels(self._h)
+        self.lm2 = self._lib.fsh_bla_lm2(self._h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.fsh_bla_destroy(self._h)
+            self._h = None
+
+    @property
+    def level_ptrs(self):
+        return self._lib.fsh_bla_level_ptrs(self._h)
+
+    @property
+    def level_sizes(self):
+        return self._lib.fsh_bla_level_sizes(self._h)
+
+    def sizes(self):
+        buf = (C.c_uint64 * self.num_levels).from_address(self.level_sizes)
+        return list(buf)

@@ -1,0 +1,180 @@
+"""Python mirror of the reference's `GPURenderer` (FractalSharkLib/GPU_Render.h:20-227) over the C ABI.
+
+Method names, argument order and error behaviour follow the reference class so the tests read like calls
+from Fractal.cpp (every method returns the uint32 error code, 0 = success; template parameters of the
+reference become the `T=`/`Mode=` keyword tags).  All compute happens in libfsmi355.so (hand-written HIP);
+this module owns no arithmetic and there is no CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+
+# numeric type tags (include/fsmi355.h)
+T_F32, T_F64, T_2X32, T_HDR32, T_HDR64, T_HDR2X32 = range(6)
+# LAv2Mode (RenderAlgorithm.h:12-17)
+LAV2_FULL, LAV2_PO, LAV2_LAO = range(3)
+# parity (include/fsmi355.h)
+PARITY_CPU, PARITY_CPU_GPUSTAGE = range(2)
+
+NB_THREADS_W = 16  # GPU_Render.h:116-120: part of the contract (ItersMemoryContainer pads with them)
+NB_THREADS_H = 8
+
+
+class GPURenderer:
+    def __init__(self, device=0):
+        self._lib = _capi.render_lib()
+        self._h = self._lib.fs_create(int(device))
+        if not self._h:
+            raise MemoryError("fs_create failed")
+        self._cbs = []
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.fs_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    # ---- static members
+    @staticmethod
+    def TestCudaIsWorking():
+        """Non-zero = working (GPU_Render.cu:100-123)."""
+        return _capi.render_lib().fs_test_device_is_working()
+
+    @staticmethod
+    def ConvertErrorToString(err):
+        return _capi.render_lib().fs_error_string(int(err)).decode()
+
+    # ---- memory
+    def InitializeMemory(self, w, h, antialiasing, palInterleaved, palIters, paletteAuxDepth, paletteGeneration,
+                         expectedReuse, iter_bytes=4):
+        """w, h already include antialiasing.  palInterleaved: uint16[palIters,4] RGBA or None."""
+        if palInterleaved is not None:
+            pal = np.ascontiguousarray(palInterleaved, dtype=np.uint16)
+            self._pal_keepalive = pal
+            pal_ptr = pal.ctypes.data
+        else:
+            pal_ptr = None
+        return self._lib.fs_init_memory(self._h, w, h, antialiasing, iter_bytes, pal_ptr, palIters, paletteAuxDepth,
+                                        paletteGeneration, 1 if expectedReuse else 0)
+
+    def ClearMemory(self):
+        return self._lib.fs_clear(self._h)
+
+    def SetRowBands(self, band_first_row, band_rows, band_stride_rows):
+        return self._lib.fs_set_row_bands(self._h, band_first_row, band_rows, band_stride_rows)
+
+    def SetExternalIterBuffer(self, device_ptr):
+        return self._lib.fs_set_external_iter_buffer(self._h, device_ptr)
+
+    def GetWidth(self):
+        return self._lib.fs_get_width(self._h)
+
+    def GetHeight(self):
+        return self._lib.fs_get_height(self._h)
+
+    @property
+    def rounded_width(self):
+        return self._lib.fs_rounded_width(self._h)
+
+    @property
+    def local_rows(self):
+        return self._lib.fs_local_rows(self._h)
+
+    @property
+    def device_iter_buffer(self):
+        return self._lib.fs_device_iter_buffer(self._h)
+
+    # ---- uploads
+    def InitializePerturb(self, GenerationNumber1, Perturb1, GenerationNumber2=0, Perturb2=None,
+                          LaReferenceHost=None, T=T_HDR32):
+        """Perturb1: inputs.Orbit (or anything with data_ptr/count/period); LaReferenceHost: inputs.LATable."""
+        err = self._lib.fs_upload_orbit(self._h, GenerationNumber1, T, 4, Perturb1.data_ptr, Perturb1.count,
+                                        Perturb1.count, Perturb1.period)
+        if err:
+            return err
+        if LaReferenceHost is not None:
+            la = LaReferenceHost
+            err = self._lib.fs_upload_la(self._h, GenerationNumber1, T, 4, la.las_ptr, la.count, la.stages_ptr,
+                                         la.stage_count, 1 if la.is_valid else 0, 1 if la.use_at else 0,
+                                         C.addressof(la.at))
+        return err
+
+    # ---- renders (asynchronous on the compute stream)
+    @staticmethod
+    def _coords_ptr(coords):
+        arr = np.ascontiguousarray(coords)
+        return arr, arr.ctypes.data
+
+    def RenderPerturbLAv2(self, algorithm, cx, cy, dx, dy, centerX, centerY, n_iterations, T=T_HDR32,
+                          Mode=LAV2_FULL, parity=PARITY_CPU):
+        """cx, cy are unused by the kernels (as in the reference).  dx..centerY: (mantissa, exp) pairs."""
+        co = np.array([tuple(dx), tuple(dy), tuple(centerX), tuple(centerY)],
+                      dtype=np.dtype([("m", "<f4"), ("e", "<i4")]))
+        return self._lib.fs_render_lav2(self._h, T, Mode, parity, co.ctypes.data, int(n_iterations))
+
+    def RenderPerturbBLA(self, algorithm, results, blas, cx, cy, dx, dy, centerX, centerY, n_iterations,
+                         iteration_precision=1, T=T_HDR32):
+        """Uploads orbit and table on every call, like the reference (GPU_Render.cu:1464-1479)."""
+        err = self._lib.fs_upload_orbit(self._h, 0, T, 4, results.data_ptr, results.count, results.count,
+                                        results.period)
+        if err:
+            return err
+        if blas is not None:
+            err = self._lib.fs_upload_bla(self._h, T, blas.level_ptrs, blas.level_sizes, blas.num_levels, blas.lm2)
+        else:
+            err = self._lib.fs_upload_bla(self._h, T, None, None, 0, 0)
+        if err:
+            return err
+        co = np.array([tuple(dx), tuple(dy), tuple(centerX), tuple(centerY)],
+                      dtype=np.dtype([("m", "<f4"), ("e", "<i4")]))
+        return self._lib.fs_render_bla(self._h, T, co.ctypes.data, int(n_iterations))
+
+    def Render(self, algorithm, cx, cy, dx, dy, n_iterations, iteration_precision=1, T=T_F64):
+        """Direct kernels.  cx = minX, cy = maxY (Fractal.cpp:1894-1915 passes the view corner)."""
+        co = np.array([dx, dy, cx, cy], dtype=np.float64)
+        return self._lib.fs_render_direct(self._h, T, co.ctypes.data, int(n_iterations))
+
+    def RenderCurrent(self, n_iterations, iter_buffer=None, color_buffer=None, reduction_results=None,
+                      progressive=False):
+        """iter_buffer: uint32[local_rows, rounded_width]; color_buffer: uint16[N_color_cu,4];
+        reduction_results: _capi.Reduction.  Any may be None."""
+        ip = iter_buffer.ctypes.data if iter_buffer is not None else None
+        cp = color_buffer.ctypes.data if color_buffer is not None else None
+        rp = C.addressof(reduction_results) if reduction_results is not None else None
+        return self._lib.fs_render_current(self._h, int(n_iterations), ip, cp, rp, 1 if progressive else 0)
+
+    # ---- streams
+    def SyncComputeStream(self):
+        return self._lib.fs_sync_compute(self._h)
+
+    def SyncDisplayStream(self):
+        return self._lib.fs_sync_display(self._h)
+
+    def QueryComputeStream(self):
+        return self._lib.fs_query_compute(self._h)
+
+    def EnqueueComputeDoneCallback(self, fn):
+        cb = _capi.DONE_CB(lambda user: fn())
+        self._cbs.append(cb)
+        return self._lib.fs_enqueue_done_callback(self._h, cb, None)
+
+    # ---- measurement
+    def last_kernel_ms(self):
+        return float(self._lib.fs_last_kernel_ms(self._h))
+
+    def enable_step_count(self, on=True):
+        return self._lib.fs_enable_step_count(self._h, 1 if on else 0)
+
+    def read_step_count(self):
+        out = (C.c_uint64 * 4)()
+        err = self._lib.fs_read_step_count(self._h, out)
+        if err:
+            raise RuntimeError(self.ConvertErrorToString(err))
+        return {"at_iterations": out[0], "la_steps": out[1], "perturb_steps": out[2], "pixels": out[3]}
+
+    def new_iter_buffer(self):
+        return np.zeros((self.local_rows, self.rounded_width), np.uint32)

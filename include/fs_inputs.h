@@ -65,6 +65,15 @@ int fsh_la_is_valid(const fsh_la *l);
 int fsh_la_use_at(const fsh_la *l);
 void fsh_la_at(const fsh_la *l, fs_at_hdr32_u32 *out);
 
+/* BLA table (BLAS<uint32_t,HDRFloat<float>>::Init with blaSize = orbit max radius).  Levels 0 and 1 are never
+ * materialised (m_FirstLevel = 2): their pointers are NULL and sizes 0. */
+fsh_bla *fsh_bla_create_hdr32(const fsh_orbit *o);
+void fsh_bla_destroy(fsh_bla *b);
+int32_t fsh_bla_num_levels(const fsh_bla *b); /* m_B.size() */
+int32_t fsh_bla_lm2(const fsh_bla *b);        /* m_LM2 */
+const fs_bla_hdr32 *const *fsh_bla_level_ptrs(const fsh_bla *b);
+const uint64_t *fsh_bla_level_sizes(const fsh_bla *b);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,161 @@
+/* fsmi355.h -- C ABI of libfsmi355.so, the MI355X (gfx950) per-pixel renderer for FractalShark.
+ *
+ * One opaque fs_renderer corresponds to one reference `GPURenderer` object
+ * (FractalSharkLib/GPU_Render.h:20-227, implemented by FractalSharkGpuLib/GPU_Render.cu).  Every entry
+ * point below names the GPURenderer member it replaces; fractalshark_amd/csrc/gpu_render_shim.hpp defines
+ * those members (same names, argument order and error behaviour) by forwarding here, so Fractal.cpp keeps
+ * compiling against GPU_Render.h unchanged.  INTEGRATION.md shows the binding.
+ *
+ * Conventions (same as the reference):
+ *   - every call returns uint32_t; 0 = success; non-zero = hipError_t value or FS_ERR_* (10000+);
+ *   - host pointers are borrowed for the duration of the call only; device memory is owned by the renderer;
+ *   - one renderer is used by one host thread at a time; different renderers may run concurrently;
+ *   - "memory not initialised" makes render calls return 0 without doing anything (GPU_Render.cu:564-566).
+ *
+ * Record layouts: fs_layout.h.  Type tags select the numeric type T of the reference templates.
+ */
+#ifndef FSMI355_H
+#define FSMI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "fs_layout.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fs_renderer fs_renderer;
+
+/* FractalSharkError, GPU_Render.cu:33-43 (enum starts at 10000). */
+enum {
+    FS_OK = 0,
+    FS_ERR_1 = 10000,
+    FS_ERR_2 = 10001,
+    FS_ERR_3 = 10002, /* bad antialiasing */
+    FS_ERR_4 = 10003, /* width not divisible by antialiasing */
+    FS_ERR_5 = 10004, /* height not divisible by antialiasing */
+    FS_ERR_6 = 10005, /* no uploaded orbit / table for this type */
+    FS_ERR_7 = 10006,
+    FS_ERR_UNSUPPORTED = 10100 /* type tag / mode not built into this library (this project's addition) */
+};
+
+/* Numeric type T of the reference's kernel templates. */
+enum {
+    FS_T_F32 = 0,       /* float                      (Gpu1x32*)   */
+    FS_T_F64 = 1,       /* double                     (Gpu1x64*)   */
+    FS_T_2X32 = 2,      /* CudaDblflt<dblflt>         (Gpu2x32*)   */
+    FS_T_HDR32 = 3,     /* HDRFloat<float>            (GpuHDRx32*) */
+    FS_T_HDR64 = 4,     /* HDRFloat<double>           (GpuHDRx64*) */
+    FS_T_HDR2X32 = 5    /* HDRFloat<CudaDblflt<..>>   (GpuHDRx2x32*) */
+};
+
+/* LAv2Mode, FractalSharkLib/RenderAlgorithm.h:12-17. */
+enum { FS_LAV2_FULL = 0, FS_LAV2_PO = 1, FS_LAV2_LAO = 2 };
+
+/* Which arithmetic the kernels restate.  The reference's CUDA kernels and its CPU RenderAlgorithm functions
+ * are not bit-identical to each other; the parity target of this project is the CPU
+ * functions, so FS_PARITY_CPU is the default everywhere.
+ *   FS_PARITY_CPU      : literal CPU functions, including LAReference::isLAStageInvalid as written
+ *                        (LAReference.cpp:1076-1081: stage skipped when cheb(dc) <  LAThresholdC).
+ *   FS_PARITY_CPU_GPUSTAGE : CPU arithmetic, but the stage-validity test in the direction the reference's GPU
+ *                        twin (and FractalZoomer) uses (GPU_LAReference.h:240-254: skipped when cheb(dc) >= ...).
+ */
+enum { FS_PARITY_CPU = 0, FS_PARITY_CPU_GPUSTAGE = 1 };
+
+/* GPURenderer::GPURenderer / ~GPURenderer.  `device` = HIP device ordinal (the reference hard-codes 0,
+ * GPU_Render.cu:113; the multi-GPU row tiler passes LOCAL_RANK). */
+fs_renderer *fs_create(int device);
+void fs_destroy(fs_renderer *r);
+
+/* GPURenderer::TestCudaIsWorking (GPU_Render.cu:100-123): NON-ZERO = a usable device exists. */
+uint32_t fs_test_device_is_working(void);
+
+/* GPURenderer::ConvertErrorToString (GPU_Render.cu:1820-1823). */
+const char *fs_error_string(uint32_t err);
+
+/* GPURenderer::InitializeMemory<IterType> (GPU_Render.cu:232-407).  w,h already include antialiasing.
+ * iter_bytes = sizeof(IterType) (4 or 8).  The iteration buffer is padded to 16 columns x 8 rows
+ * (GPU_Render.cu:334-344). */
+uint32_t fs_init_memory(fs_renderer *r, uint32_t w, uint32_t h, uint32_t antialiasing, uint32_t iter_bytes,
+                        const fs_color16 *pal_interleaved, uint32_t pal_iters, uint32_t palette_aux_depth,
+                        uint64_t palette_generation, int expected_reuse);
+
+/* Row band for multi-GPU tiling (this project's addition; the reference is single-device).  The renderer
+ * keeps the full-frame geometry for the pixel -> delta-c mapping (Y stays the global row so
+ * DeltaImaginary = -dy*T(Y) - centerY rounds identically) but only computes global rows
+ * [band_first_row + k*band_stride_rows, +band_rows) for k = 0,1,...  The local iteration buffer then holds
+ * the owned bands back to back.  Defaults: first 0, rows = h, stride = h (whole frame). */
+uint32_t fs_set_row_bands(fs_renderer *r, uint32_t band_first_row, uint32_t band_rows, uint32_t band_stride_rows);
+/* Number of rows the local buffer holds under the current banding (after padding to 8). */
+uint32_t fs_local_rows(const fs_renderer *r);
+
+/* Optional: render into caller-owned DEVICE memory (e.g. a torch tensor handed to RCCL) instead of the
+ * internal buffer.  Must hold fs_local_rows() x rounded-width elements.  NULL restores the internal buffer. */
+uint32_t fs_set_external_iter_buffer(fs_renderer *r, void *device_ptr);
+void *fs_device_iter_buffer(const fs_renderer *r);
+uint32_t fs_rounded_width(const fs_renderer *r);
+
+/* GPURenderer::InitializePerturb<IterType,T1,SubType,PExtras,T2> (GPU_Render.cu:431-501), split in two:
+ * orbit upload (GPUPerturbSingleResults ctor, Perturb.cuh:20-80) ... */
+uint32_t fs_upload_orbit(fs_renderer *r, uint64_t generation, int type_tag, uint32_t iter_bytes,
+                         const void *entries, uint64_t orbit_size, uint64_t uncompressed_size,
+                         uint64_t period_maybe_zero);
+/* ... and LA table upload (GPU_LAReference ctor, GPU_LAReference.h:79-160).  at_info may be NULL when
+ * use_at == 0. */
+uint32_t fs_upload_la(fs_renderer *r, uint64_t generation, int type_tag, uint32_t iter_bytes, const void *las,
+                      uint32_t n_las, const void *stages, uint32_t n_stages, int is_valid, int use_at,
+                      const void *at_info);
+
+/* BLA table upload (GPU_BLAS ctor, BLA.cuh:123-160); the reference does this inside RenderPerturbBLA. */
+uint32_t fs_upload_bla(fs_renderer *r, int type_tag, const void *const *levels, const uint64_t *level_sizes,
+                       int32_t n_levels, int32_t lm2);
+
+/* GPURenderer::RenderPerturbLAv2<IterType,T,SubType,Mode,PExtras> (GPU_Render.cu:995-1188).
+ * coords = {dx, dy, centerX, centerY} in the type selected by type_tag (fs_real_hdr32[4] for FS_T_HDR32).
+ * Asynchronous on the compute stream. */
+uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, const void *coords,
+                        uint64_t n_iterations);
+
+/* GPURenderer::RenderPerturbBLA<IterType,T> (GPU_Render.cu:1440-1607); uses the orbit of fs_upload_orbit and
+ * the table of fs_upload_bla (n_levels == 0 there = plain perturbation). */
+uint32_t fs_render_bla(fs_renderer *r, int type_tag, const void *coords, uint64_t n_iterations);
+
+/* GPURenderer::Render<IterType,T> (GPU_Render.cu:617-846), direct escape-time kernels.
+ * coords = {dx, dy, minX, maxY} (doubles for FS_T_F64), CPU twin Fractal::CalcCpuHDR (Fractal.cpp:2096-2206). */
+uint32_t fs_render_direct(fs_renderer *r, int type_tag, const void *coords, uint64_t n_iterations);
+
+/* GPURenderer::ClearMemory<IterType> (GPU_Render.cu:212-225). */
+uint32_t fs_clear(fs_renderer *r);
+
+/* GPURenderer::RenderCurrent<IterType> (GPU_Render.cu:556-581): antialias + palette, min/max/sum, D2H.
+ * Any of the three host pointers may be NULL.  progressive != 0 runs on the display stream. */
+uint32_t fs_render_current(fs_renderer *r, uint64_t n_iterations, void *iter_buffer, fs_color16 *color_buffer,
+                           fs_reduction *reduction, int progressive);
+
+/* SyncComputeStream / SyncDisplayStream / QueryComputeStream / EnqueueComputeDoneCallback
+ * (GPU_Render.cu:596-615).  The callback runs on a runtime thread after all prior compute-stream work. */
+uint32_t fs_sync_compute(fs_renderer *r);
+uint32_t fs_sync_display(fs_renderer *r);
+uint32_t fs_query_compute(fs_renderer *r);
+typedef void (*fs_done_cb)(void *user);
+uint32_t fs_enqueue_done_callback(fs_renderer *r, fs_done_cb cb, void *user);
+
+uint32_t fs_get_width(const fs_renderer *r);
+uint32_t fs_get_height(const fs_renderer *r);
+
+/* Measurement hooks (this project's addition; bench.py / profiles).
+ * fs_last_kernel_ms: duration of the most recent iteration-kernel launch measured with HIP events on the
+ * compute stream (valid after fs_sync_compute).
+ * fs_enable_step_count: when on, iteration kernels also accumulate the executed work per launch:
+ * counts[0] = AT iterations, [1] = LA steps, [2] = perturbation steps, [3] = pixels. */
+float fs_last_kernel_ms(const fs_renderer *r);
+uint32_t fs_enable_step_count(fs_renderer *r, int enable);
+uint32_t fs_read_step_count(fs_renderer *r, uint64_t counts[4]);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* FSMI355_H */

@@ -257,12 +257,16 @@ inline HC ld(const fs_cplx_hdr32 &c) { return HC{c.re, c.im, c.e}; }
 inline HC OrbitAt(const fs_orbit_hdr32 *orb, uint64_t i) { return CFromH(H{orb[i].mx, orb[i].ex}, H{orb[i].my, orb[i].ey}); }
 
 // Row-claiming thread pool, Fractal.cpp:2523-2543.
+// Rows y0, y0+g_row_step, ... < y1 (g_row_step = 1 is the reference; a larger step selects an evenly spread sample
+// of rows of the same frame for the bounded cpu_baseline timing, orc_set_row_step()).
+static uint32_t g_row_step = 1;
 template <class RowFn> void run_rows(uint32_t y0, uint32_t y1, int threads, RowFn fn)
 {
     std::deque<std::atomic_uint64_t> atomics;
     atomics.resize(y1);
+    const uint32_t step = g_row_step ? g_row_step : 1;
     auto one_thread = [&]() {
-        for (size_t y = y0; y < y1; y++) {
+        for (size_t y = y0; y < y1; y += step) {
             if (atomics[y] != 0)
                 continue;
             uint64_t expected = 0;
@@ -341,6 +345,8 @@ const fs_bla_hdr32 *LookupBackwards(const BlaTable &B, size_t m, H z2)
 } // namespace
 
 extern "C" {
+
+void orc_set_row_step(uint32_t step) { g_row_step = step ? step : 1; }
 
 // Fractal::CalcCpuHDR<uint32_t,double,double>, Fractal.cpp:2096-2206.  coords = {dx, dy, minX, maxY}.
 void orc_direct_f64(uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, const double coords[4],
@@ -488,14 +494,17 @@ void orc_lav2_hdr32(uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, c
                     uint64_t orbit_count, uint64_t period_maybe_zero, const fs_la_hdr32_u32 *las, uint32_t n_las,
                     const fs_la_stage_u32 *stages, uint32_t stage_count, int la_valid, int use_at,
                     const fs_at_hdr32_u32 *at, const fs_real_hdr32 coords[4], uint32_t n_iterations,
-                    int stage_test, int mode, uint32_t *out, uint32_t stride, int threads)
+                    int stage_test, int mode, uint32_t *out, uint32_t stride, int threads, uint64_t *stats)
 {
+    // stats (optional, 4 x uint64): [0] AT iterations, [1] LA steps taken, [2] perturbation steps, [3] pixels
     (void)height;
     (void)n_las;
+    std::atomic<uint64_t> st_at{0}, st_la{0}, st_pt{0}, st_px{0};
     const H dx = ld(coords[0]), dy = ld(coords[1]), centerX = ld(coords[2]), centerY = ld(coords[3]);
     const H TwoFiftySix = HFromInt(256);
     const H Two = HFromInt(2);
     run_rows(y0, y1, threads, [&](uint32_t y) {
+        uint64_t c_at = 0, c_la = 0, c_pt = 0;
         for (size_t x = 0; x < width; x++) {
             uint32_t BLA2SkippedIterations = 0;
             H deltaReal, deltaImaginary;
@@ -522,6 +531,7 @@ void orc_lav2_hdr32(uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, c
                 CReduce(dz);
                 DeltaSubN = dz;
                 BLA2SkippedIterations = i * at->StepLength;
+                c_at += i;
             }
 
             uint32_t iterations = 0;
@@ -568,6 +578,7 @@ void orc_lav2_hdr32(uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, c
                         break;
                     }
                     iterations += l;
+                    c_la++;
                     // LAInfoDeep::Evaluate, LAInfoDeep.h:416-420
                     DeltaSubN = CAdd(CMul(newDz, ld(LAj.ZCoeff)), CMul(DeltaSub0, ld(LAj.CCoeff)));
                     // LAstep::getZ, LAstep.h:116-120
@@ -594,6 +605,7 @@ void orc_lav2_hdr32(uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, c
                     DeltaSubN = CMul(DeltaSubN, curIter);
                     DeltaSubN = CAdd(DeltaSubN, DeltaSub0);
                     CReduce(DeltaSubN);
+                    c_pt++;
                     RefIteration++;
                     complex0 = CAdd(OrbitAt(orbit, RefIteration), DeltaSubN);
                     CReduce(complex0);
@@ -611,7 +623,17 @@ void orc_lav2_hdr32(uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, c
             }
             out[(size_t)y * stride + x] = iterations;
         }
+        st_at += c_at;
+        st_la += c_la;
+        st_pt += c_pt;
+        st_px += width;
     });
+    if (stats) {
+        stats[0] = st_at;
+        stats[1] = st_la;
+        stats[2] = st_pt;
+        stats[3] = st_px;
+    }
 }
 
 } // extern "C"

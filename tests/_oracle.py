@@ -1,0 +1,149 @@
+"""ctypes loader for the CPU oracle (oracle/liboracle.so) -- test infrastructure only.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "liboracle.so")
+PIN = os.path.join(ORACLE_DIR, "_ref", "libpngpin.so")
+
+vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32
+_lib = None
+_pin = None
+
+
+def build():
+    src = os.path.join(ORACLE_DIR, "cpu_ref.cpp")
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", ORACLE_DIR, "all"], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    # the golden-CRC pin needs the reference's WPngImage/lodepng sources: only buildable where /root/reference is
+    if not os.path.exists(PIN) and os.path.isdir("/root/reference/FractalSharkLib/WPngImage"):
+        subprocess.run(["make", "-C", ORACLE_DIR, "_ref"], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        l = C.CDLL(LIB)
+        l.orc_direct_f64.restype = None
+        l.orc_direct_f64.argtypes = [u32, u32, u32, u32, vp, u32, vp, u32, C.c_int]
+        l.orc_bla_hdr32.restype = None
+        l.orc_bla_hdr32.argtypes = [u32, u32, u32, u32, vp, u64, vp, u32, vp, vp, i32, i32, vp, u32, C.c_int]
+        l.orc_lav2_hdr32.restype = None
+        l.orc_lav2_hdr32.argtypes = [u32, u32, u32, u32, vp, u64, u64, vp, u32, vp, u32, C.c_int, C.c_int, vp, vp,
+                                     u32, C.c_int, C.c_int, vp, u32, C.c_int, vp]
+        l.orc_set_row_step.restype = None
+        l.orc_set_row_step.argtypes = [u32]
+        _lib = l
+    return _lib
+
+
+def set_row_step(step):
+    """Render only rows y0, y0+step, ... (evenly spread sample for the bounded cpu_baseline timing)."""
+    lib().orc_set_row_step(step)
+
+
+def pin_lib():
+    global _pin
+    if _pin is None:
+        build()
+        if not os.path.exists(PIN):
+            return None
+        p = C.CDLL(PIN)
+        p.pin_png_crc64.restype = u64
+        p.pin_png_crc64.argtypes = [vp, u32, u32, u32, u32, u64, u64, C.c_char_p]
+        p.pin_default_palette.restype = u32
+        p.pin_default_palette.argtypes = [C.c_int, vp, u32]
+        _pin = p
+    return _pin
+
+
+def rounded_width(w):
+    return (w + 15) // 16 * 16
+
+
+def new_buffer(w, h):
+    return np.zeros(((h + 7) // 8 * 8, rounded_width(w)), np.uint32)
+
+
+def direct_f64(view, aa=1, rows=None, threads=8):
+    w, h = view.width * aa, view.height * aa
+    out = new_buffer(w, h)
+    co = view.coords_direct_f64(aa)
+    y0, y1 = rows if rows else (0, h)
+    lib().orc_direct_f64(w, h, y0, y1, co.ctypes.data, view.num_iterations, out.ctypes.data, out.shape[1], threads)
+    return out
+
+
+def bla_hdr32(view, orbit, bla=None, aa=1, rows=None, threads=8, n_iterations=None):
+    """CalcCpuPerturbationFractalBLA<u32,HDRFloat<float>,float>; bla=None suppresses the lookup (C2 target)."""
+    w, h = view.width * aa, view.height * aa
+    out = new_buffer(w, h)
+    co = view.coords_perturb_hdr32(orbit, aa)
+    y0, y1 = rows if rows else (0, h)
+    n = view.num_iterations if n_iterations is None else n_iterations
+    if bla is None:
+        lib().orc_bla_hdr32(w, h, y0, y1, orbit.data_ptr, orbit.count, co.ctypes.data, n, None, None, 0, 0,
+                            out.ctypes.data, out.shape[1], threads)
+    else:
+        lib().orc_bla_hdr32(w, h, y0, y1, orbit.data_ptr, orbit.count, co.ctypes.data, n, bla.level_ptrs,
+                            bla.level_sizes, bla.num_levels, bla.lm2, out.ctypes.data, out.shape[1], threads)
+    return out
+
+
+def lav2_hdr32(view, orbit, la, aa=1, rows=None, threads=8, stage_test=0, mode=0, n_iterations=None, stats=False):
+    """CalcCpuPerturbationFractalLAV2<u32,float,Disable>. stage_test 0 = literal CPU, 1 = GPU direction."""
+    w, h = view.width * aa, view.height * aa
+    out = new_buffer(w, h)
+    co = view.coords_perturb_hdr32(orbit, aa)
+    y0, y1 = rows if rows else (0, h)
+    n = view.num_iterations if n_iterations is None else n_iterations
+    st = (u64 * 4)()
+    lib().orc_lav2_hdr32(w, h, y0, y1, orbit.data_ptr, orbit.count, orbit.period, la.las_ptr, la.count,
+                         la.stages_ptr, la.stage_count, 1 if la.is_valid else 0, 1 if la.use_at else 0,
+                         C.addressof(la.at), co.ctypes.data, n, stage_test, mode, out.ctypes.data, out.shape[1],
+                         threads, st)
+    if stats:
+        return out, {"at_iterations": st[0], "la_steps": st[1], "perturb_steps": st[2], "pixels": st[3]}
+    return out
+
+
+def png_crc64(iters, width, height, aa, num_iterations, save_path=None):
+    """CRC-64 of the PNG bytes the reference's headless render writes for this iteration buffer, or None when the
+    pin library (needs /root/reference at build time) is unavailable."""
+    p = pin_lib()
+    if p is None:
+        return None
+    it = np.ascontiguousarray(iters, np.uint32)
+    # GetMaxIterations<uint32_t>() = INT32_MAX - 1 (Fractal.h:118-123)
+    crc = p.pin_png_crc64(it.ctypes.data, it.shape[1], width, height, aa, num_iterations, 2 ** 31 - 2,
+                          save_path.encode() if save_path else None)
+    return "%016x" % crc
+
+
+def default_palette(depth=8):
+    """Default palette as uint16[N,4]; restated in oracle/png_pin.cpp, falls back to a local restatement."""
+    p = pin_lib()
+    n = 7 << depth
+    out = np.zeros((n, 4), np.uint16)
+    if p is not None:
+        p.pin_default_palette(depth, out.ctypes.data, n)
+        return out
+    # FractalPalette.cpp:27-46,147-174
+    pal = []
+    cur = (0, 0, 0)
+    mv = 65535
+    for tgt in ((mv, 0, 0), (mv, mv, 0), (0, mv, 0), (0, mv, mv), (0, 0, mv), (mv, 0, mv), (0, 0, 0)):
+        length = 1 << depth
+        d = [(tgt[k] - cur[k]) / length for k in range(3)]
+        for i in range(length):
+            pal.append(tuple(int(cur[k] + d[k] * (i + 1)) & 0xFFFF for k in range(3)) + (0,))
+        cur = pal[-1][:3]
+    return np.array(pal, np.uint16)

@@ -1,0 +1,201 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same inputs, against the
+committed fixtures, and through size-independent properties at larger sizes.  Iteration counts must be
+bit-identical (integer outputs: no tolerance)."""
+import os
+
+import numpy as np
+import pytest
+
+import _oracle
+from fractalshark_amd import (GPURenderer, LAV2_FULL, LAV2_LAO, LAV2_PO, PARITY_CPU, PARITY_CPU_GPUSTAGE, T_F64,
+                              T_HDR32, _capi, inputs)
+
+pytestmark = pytest.mark.gpu
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_small.npz"))
+
+
+def _pairs(co):
+    return [(float(c["m"]), int(c["e"])) for c in co]
+
+
+@pytest.fixture(scope="module")
+def renderer(native_libs):
+    assert GPURenderer.TestCudaIsWorking() != 0, "no usable HIP device: the product path has no CPU fallback"
+    r = GPURenderer(0)
+    yield r
+    r.close()
+
+
+@pytest.fixture(scope="module")
+def v5_small(native_libs):
+    v = inputs.View.builtin(5, 64, 36)
+    ob = inputs.Orbit(v)
+    return v, ob, inputs.LATable(ob), inputs.BLATable(ob)
+
+
+def _render_lav2(r, v, ob, la, mode, parity, n_iter=None):
+    w, h = v.width * v.antialiasing, v.height * v.antialiasing
+    assert r.InitializeMemory(w, h, v.antialiasing, None, 0, 0, 0, False) == 0
+    assert r.InitializePerturb(1, ob, 0, None, la) == 0
+    assert r.ClearMemory() == 0
+    dx, dy, cx, cy = _pairs(v.coords_perturb_hdr32(ob))
+    n = v.num_iterations if n_iter is None else n_iter
+    assert r.RenderPerturbLAv2(None, None, None, dx, dy, cx, cy, n, T=T_HDR32, Mode=mode, parity=parity) == 0
+    assert r.SyncComputeStream() == 0
+    out = r.new_iter_buffer()
+    red = _capi.Reduction()
+    assert r.RenderCurrent(n, out, None, red) == 0
+    assert r.SyncComputeStream() == 0
+    return out, red
+
+
+def test_lav2_full_cpu_parity_fixture_and_oracle(renderer, v5_small):
+    v, ob, la, _ = v5_small
+    out, red = _render_lav2(renderer, v, ob, la, LAV2_FULL, PARITY_CPU)
+    assert np.array_equal(out, GOLD["view5_lav2_cpu_64x36"])
+    assert np.array_equal(out, _oracle.lav2_hdr32(v, ob, la, stage_test=0))
+    valid = out[:36, :64].astype(np.uint64)
+    assert (red.Min, red.Max, red.Sum) == (int(valid.min()), int(valid.max()), int(valid.sum()))
+
+
+def test_lav2_full_gpustage_parity(renderer, v5_small):
+    v, ob, la, _ = v5_small
+    out, _ = _render_lav2(renderer, v, ob, la, LAV2_FULL, PARITY_CPU_GPUSTAGE)
+    assert np.array_equal(out, GOLD["view5_lav2_gpustage_64x36"])
+
+
+def test_lav2_lao_parity(renderer, v5_small):
+    v, ob, la, _ = v5_small
+    out, _ = _render_lav2(renderer, v, ob, la, LAV2_LAO, PARITY_CPU)
+    assert np.array_equal(out, GOLD["view5_lao_cpu_64x36"])
+
+
+def test_lav2_po_parity_is_bla_single_step_branch(renderer, v5_small):
+    """C2: LAv2Mode::PO <-> single-step branch of CalcCpuPerturbationFractalBLA."""
+    v, ob, la, _ = v5_small
+    out, _ = _render_lav2(renderer, v, ob, la, LAV2_PO, PARITY_CPU)
+    assert np.array_equal(out, GOLD["view5_po_64x36"])
+
+
+def test_bla_parity(renderer, v5_small):
+    v, ob, _, bla = v5_small
+    r = renderer
+    assert r.InitializeMemory(64, 36, 1, None, 0, 0, 0, False) == 0
+    dx, dy, cx, cy = _pairs(v.coords_perturb_hdr32(ob))
+    assert r.RenderPerturbBLA(None, ob, bla, None, None, dx, dy, cx, cy, v.num_iterations) == 0
+    out = r.new_iter_buffer()
+    assert r.RenderCurrent(v.num_iterations, out) == 0
+    assert r.SyncComputeStream() == 0
+    assert np.array_equal(out, GOLD["view5_bla_64x36"])
+
+
+def test_direct_f64_parity(renderer, native_libs):
+    v = inputs.View.builtin(0, 64, 48)
+    r = renderer
+    assert r.InitializeMemory(64, 48, 1, None, 0, 0, 0, False) == 0
+    dx, dy, minx, maxy = v.coords_direct_f64()
+    assert r.Render(None, minx, maxy, dx, dy, v.num_iterations, T=T_F64) == 0
+    out = r.new_iter_buffer()
+    assert r.RenderCurrent(v.num_iterations, out) == 0
+    assert r.SyncComputeStream() == 0
+    assert np.array_equal(out, GOLD["view0_direct_f64_64x48"])
+
+
+def test_ragged_size_and_padding(renderer, native_libs):
+    """Width/height not multiples of 16/8: padding stays zero, valid region matches the oracle."""
+    v = inputs.View.builtin(5, 37, 21)
+    ob = inputs.Orbit(v)
+    la = inputs.LATable(ob)
+    out, red = _render_lav2(renderer, v, ob, la, LAV2_FULL, PARITY_CPU_GPUSTAGE)
+    ref = _oracle.lav2_hdr32(v, ob, la, stage_test=1)
+    assert out.shape == ref.shape == (24, 48)
+    assert np.array_equal(out, ref)
+    assert not out[21:, :].any() and not out[:, 37:].any()
+    assert red.Sum == int(ref[:21, :37].astype(np.uint64).sum())
+
+
+def test_row_bands_reassemble_full_frame(renderer, v5_small):
+    """Multi-GPU tiling primitive: interleaved 8-row bands rendered separately equal the whole frame."""
+    v, ob, la, _ = v5_small
+    full, _ = _render_lav2(renderer, v, ob, la, LAV2_FULL, PARITY_CPU_GPUSTAGE)
+    r = renderer
+    dx, dy, cx, cy = _pairs(v.coords_perturb_hdr32(ob))
+    world = 3
+    got = np.zeros_like(full)
+    for rank in range(world):
+        assert r.SetRowBands(rank * 8, 8, world * 8) == 0
+        assert r.ClearMemory() == 0
+        assert r.RenderPerturbLAv2(None, None, None, dx, dy, cx, cy, v.num_iterations, Mode=LAV2_FULL,
+                                   parity=PARITY_CPU_GPUSTAGE) == 0
+        loc = r.new_iter_buffer()
+        assert r.RenderCurrent(v.num_iterations, loc) == 0
+        assert r.SyncComputeStream() == 0
+        k = 0
+        for start in range(rank * 8, 36, world * 8):
+            n = min(8, 36 - start)
+            got[start:start + n] = loc[k:k + n]
+            k += n
+    assert r.SetRowBands(0, 0, 0) == 0
+    assert np.array_equal(got[:36], full[:36])
+
+
+def test_antialias_colors_match_integer_box_filter(renderer, native_libs):
+    v = inputs.View.builtin(0, 32, 24, antialiasing=2)
+    pal = _oracle.default_palette(8)
+    r = renderer
+    assert r.InitializeMemory(64, 48, 2, pal, len(pal), 0, 1, False) == 0
+    dx, dy, minx, maxy = v.coords_direct_f64(2)
+    assert r.Render(None, minx, maxy, dx, dy, v.num_iterations, T=T_F64) == 0
+    it = r.new_iter_buffer()
+    colors = np.zeros((32 * 24, 4), np.uint16)  # N_color_cu = 32 x 24 here (multiples of 16 x 8)
+    assert r.RenderCurrent(v.num_iterations, it, colors) == 0
+    assert r.SyncComputeStream() == 0
+    assert np.array_equal(it, _oracle.direct_f64(v, aa=2))
+    exp = np.zeros((24, 32, 4), np.uint64)
+    for oy in range(24):
+        for ox in range(32):
+            acc = np.zeros(3, np.uint64)
+            for ix in range(2 * ox, 2 * ox + 2):
+                for iy in range(2 * oy, 2 * oy + 2):
+                    n = int(it[iy, ix])
+                    if n < v.num_iterations:
+                        acc += pal[n % len(pal), :3].astype(np.uint64)
+            exp[oy, ox, :3] = acc // 4
+            exp[oy, ox, 3] = 65535
+    assert np.array_equal(colors.reshape(24, 32, 4).astype(np.uint64), exp)
+
+
+def test_errors_and_uninitialised_behaviour(native_libs):
+    r = GPURenderer(0)
+    # "memory not initialised" returns 0 silently (GPU_Render.cu:564-566,1007-1009)
+    assert r.RenderCurrent(10, None) == 0
+    assert r.InitializeMemory(64, 36, 5, None, 0, 0, 0, False) == 10002
+    assert r.InitializeMemory(63, 36, 2, None, 0, 0, 0, False) == 10003
+    assert r.InitializeMemory(64, 35, 2, None, 0, 0, 0, False) == 10004
+    assert r.InitializeMemory(64, 36, 1, None, 0, 0, 0, False) == 0
+    # render without an uploaded orbit -> Error6 (GPU_Render.cu:1015-1022)
+    assert r.RenderPerturbLAv2(None, None, None, (1, 0), (1, 0), (1, 0), (1, 0), 10) == 10005
+    r.close()
+
+
+def test_done_callback_fires(renderer, v5_small):
+    import threading
+    ev = threading.Event()
+    assert renderer.EnqueueComputeDoneCallback(ev.set) == 0
+    assert renderer.SyncComputeStream() == 0
+    assert ev.wait(5.0)
+
+
+def test_larger_frame_properties(renderer, native_libs):
+    """320x180: whole-frame parity vs the oracle on a bounded set of rows + reduction identity + idempotence."""
+    v = inputs.View.builtin(5, 320, 180)
+    ob = inputs.Orbit(v)
+    la = inputs.LATable(ob)
+    out, red = _render_lav2(renderer, v, ob, la, LAV2_FULL, PARITY_CPU_GPUSTAGE)
+    rows = (60, 68)
+    ref = _oracle.lav2_hdr32(v, ob, la, stage_test=1, rows=rows)
+    assert np.array_equal(out[rows[0]:rows[1]], ref[rows[0]:rows[1]])
+    assert red.Sum == int(out[:180, :320].astype(np.uint64).sum())
+    out2, _ = _render_lav2(renderer, v, ob, la, LAV2_FULL, PARITY_CPU_GPUSTAGE)
+    assert np.array_equal(out, out2)
