@@ -114,7 +114,7 @@ class Orbit:
 
     def entries(self):
         buf = (C.c_uint8 * (self.count * 16)).from_address(self.data_ptr)
-        return np.frombuffer(buf, dtype=ORBIT_HDR32_DTYPE)
+        return np.frombuffer(buf, dtype=ORBIT_HDR32_DTYPE).copy()
 
 
 class LATable:
@@ -148,11 +148,11 @@ class LATable:
 
     def records(self):
         buf = (C.c_uint8 * (self.count * 68)).from_address(self.las_ptr)
-        return np.frombuffer(buf, dtype=LA_HDR32_DTYPE)
+        return np.frombuffer(buf, dtype=LA_HDR32_DTYPE).copy()
 
     def stages(self):
         buf = (C.c_uint32 * (self.stage_count * 2)).from_address(self.stages_ptr)
-        return np.frombuffer(buf, dtype=np.uint32).reshape(-1, 2)
+        return np.frombuffer(buf, dtype=np.uint32).reshape(-1, 2).copy()
 
 
 class BLATable:
