@@ -32,6 +32,19 @@ FLOP_PER_STEP = 18            # complex dz*(2Z+dz)+dc, |Z+dz|^2,
 PEAK_FP32_VECTOR_TFLOPS = 157.3
 
 
+def effective_cpus():
+    """Usable host threads: the scheduler affinity capped by the cgroup CPU quota (the GPU boxes expose 256
+    logical CPUs but cap the container at a fraction of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -43,7 +56,8 @@ def parse():
     ap.add_argument("--parity", choices=["cpu", "cpu_gpustage"], default="cpu",
                     help="cpu = literal reference CPU function (bit-exact vs Cpu32PerturbedBLAV2HDR); "
                          "cpu_gpustage = same arithmetic, LA stage test in the GPU/FractalZoomer direction")
-    ap.add_argument("--cpu-sample-rows", type=int, default=16, help="rows of the frame timed on the CPU")
+    ap.add_argument("--cpu-sample-rows", type=int, default=0,
+                    help="rows of the frame timed on the CPU (0 = 2 x host cores, about 10-30 s of CPU work)")
     ap.add_argument("--no-cpu", action="store_true")
     return ap.parse_args()
 
@@ -149,6 +163,7 @@ def main():
         at_iters = sum(s["at_iterations"] for s in steps_executed) / args.steps
         la_steps = sum(s["la_steps"] for s in steps_executed) / args.steps
         avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
+    lane_slots = sum(s["lane_slots"] for s in steps_executed) / args.steps
 
     # ---- PCIe-inclusive number (never `value`): one frame incl. D2H of the padded iteration buffer
     d2h_ms = None
@@ -170,8 +185,8 @@ def main():
     parity_rows_ok = None
     if rank == 0 and not distributed and not args.no_cpu:
         import _oracle
-        threads = os.cpu_count() or 1
-        nrows = max(1, min(args.cpu_sample_rows, H))
+        threads = effective_cpus()
+        nrows = max(1, min(args.cpu_sample_rows if args.cpu_sample_rows > 0 else 2 * threads, H))
         step = max(1, H // nrows)
         y0 = step // 2
         rows = list(range(y0, H, step))
@@ -207,7 +222,8 @@ def main():
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 5), "traffic": None,
                          "kernel": "k_lav2_hdr32", "kernel_ms": round(avg_kernel_ms, 3),
                          "pixel_steps_per_launch": perturb_steps, "at_iterations_per_launch": at_iters,
-                         "la_steps_per_launch": la_steps, "flop_per_pixel_step": FLOP_PER_STEP},
+                         "la_steps_per_launch": la_steps, "flop_per_pixel_step": FLOP_PER_STEP,
+                         "lane_utilisation_rank0": round(perturb_steps / lane_slots, 4) if lane_slots and not distributed else None},
             "cpu_baseline": cpu_baseline,
             "frame_checksum": checksum, "cpu_sample_rows_bit_exact": parity_rows_ok,
             "d2h_inclusive_ms": None if d2h_ms is None else round(d2h_ms + avg_kernel_ms, 3),

@@ -1,0 +1,235 @@
+// gpu_render_shim.hpp -- the reference-side binding: `GPURenderer` member definitions that forward to the
+// C ABI of libfsmi355.so (include/fsmi355.h).
+//
+// How a FractalShark maintainer uses it:
+//   * keep FractalSharkLib/GPU_Render.h exactly as it is (class declaration, NB_THREADS_W/H constants);
+//   * replace FractalSharkGpuLib/GPU_Render.cu in the link by ONE translation unit that does
+//         #include "GPU_Render.h"
+//         #include "LAReference.h"
+//         #include "PerturbationResults.h"
+//         #include "gpu_render_shim.hpp"
+//     and link libfsmi355.so instead of FractalSharkGpuLib + cudart.
+//
+// The reference's class keeps its state in CUDA-typed private members (cudaStream_t == void* outside nvcc,
+// GPU_Types.h:26-28).  The shim stores the opaque `fs_renderer*` in `m_ComputeStream` (a void* it owns) and leaves
+// the other members untouched, so the class layout seen by Fractal.cpp does not change.
+//
+// Every template below is a *definition of a member the reference declares* (GPU_Render.h:25-158) with the
+// reference's explicit-instantiation list (GPU_Render.cu:227-230,409-429,503-537,583-594,849-991,1192-1300,
+// 1380-1436,1610-1692,1807-1818) reduced to the numeric types this library implements; calling an
+// instantiation that is not built returns FS_ERR_UNSUPPORTED (the caller then disables the GPU exactly as it
+// does for a CUDA error, Fractal.cpp:153-155).
+//
+// This header is also compiled stand-alone by tests/test_shim_compile.py against minimal stand-ins of the
+// reference types (FS_SHIM_SELFTEST), to keep the signatures honest without the reference tree.
+#pragma once
+
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "../../include/fsmi355.h"
+
+#ifndef FS_SHIM_SELFTEST
+// Provided by the including translation unit: GPU_Render.h, LAReference.h, PerturbationResults.h, BLAS.h.
+#endif
+
+namespace fsmi355_shim {
+
+inline fs_renderer *&handle(cudaStream_t &slot) { return reinterpret_cast<fs_renderer *&>(slot); }
+
+// Map the reference's numeric type T to a C-ABI tag.  Only HDRFloat<float> and double are built in round 1.
+template <class T> struct type_tag {
+    static constexpr int value = -1;
+};
+template <> struct type_tag<double> {
+    static constexpr int value = FS_T_F64;
+};
+template <> struct type_tag<::HDRFloat<float>> {
+    static constexpr int value = FS_T_HDR32;
+};
+
+// HDRFloat<float> has the layout {float mantissa; int32 exp} = fs_real_hdr32 (HDRFloat.h:61-69).
+inline fs_real_hdr32 to_abi(const ::HDRFloat<float> &v)
+{
+    fs_real_hdr32 r;
+    r.m = v.getMantissa();
+    r.e = v.getExp();
+    return r;
+}
+
+} // namespace fsmi355_shim
+
+inline GPURenderer::GPURenderer()
+{
+    // ClearLocals() equivalent: the handle is created lazily on the first InitializeMemory so that
+    // constructing the std::array<GPURenderer,4> in Fractal never touches the device (Fractal.h:496-508).
+    m_ComputeStream = nullptr;
+    m_DisplayStream = nullptr;
+    OutputIterMatrix = nullptr;
+    m_Width = m_Height = 0;
+}
+
+inline GPURenderer::~GPURenderer()
+{
+    if (m_ComputeStream)
+        fs_destroy(fsmi355_shim::handle(m_ComputeStream));
+    m_ComputeStream = nullptr;
+}
+
+inline uint32_t GPURenderer::TestCudaIsWorking() { return fs_test_device_is_working(); }
+inline const char *GPURenderer::ConvertErrorToString(uint32_t err) { return fs_error_string(err); }
+
+template <typename IterType>
+uint32_t GPURenderer::InitializeMemory(uint32_t w, uint32_t h, uint32_t antialiasing, const Color16 *palInterleaved,
+                                       uint32_t palIters, uint32_t paletteAuxDepth, uint64_t paletteGeneration,
+                                       bool expectedReuse)
+{
+    if (!m_ComputeStream) {
+        fsmi355_shim::handle(m_ComputeStream) = fs_create(0); // the reference hard-codes device 0
+        if (!m_ComputeStream)
+            return FS_ERR_1;
+    }
+    static_assert(sizeof(Color16) == sizeof(fs_color16), "Color16 layout");
+    const uint32_t err =
+        fs_init_memory(fsmi355_shim::handle(m_ComputeStream), w, h, antialiasing, (uint32_t)sizeof(IterType),
+                       reinterpret_cast<const fs_color16 *>(palInterleaved), palIters, paletteAuxDepth,
+                       paletteGeneration, expectedReuse ? 1 : 0);
+    if (err == 0) {
+        m_Width = w;
+        m_Height = h;
+        m_Antialiasing = antialiasing;
+        m_IterTypeSize = sizeof(IterType);
+    }
+    return err;
+}
+
+template <typename IterType> void GPURenderer::ClearMemory()
+{
+    if (m_ComputeStream)
+        fs_clear(fsmi355_shim::handle(m_ComputeStream));
+}
+
+template <typename IterType, class T1, class SubType, PerturbExtras PExtras, class T2>
+uint32_t GPURenderer::InitializePerturb(size_t GenerationNumber1, const GPUPerturbResults<IterType, T1, PExtras> *Perturb1,
+                                        size_t GenerationNumber2, const GPUPerturbResults<IterType, T2, PExtras> *Perturb2,
+                                        const LAReference<IterType, T1, SubType, PExtras> *LaReferenceHost)
+{
+    (void)GenerationNumber2;
+    (void)Perturb2; // second orbit: scaled kernels only (later round)
+    if (!m_ComputeStream)
+        return 0;
+    constexpr int tag = fsmi355_shim::type_tag<T1>::value;
+    if (tag < 0 || PExtras != PerturbExtras::Disable)
+        return FS_ERR_UNSUPPORTED;
+    fs_renderer *r = fsmi355_shim::handle(m_ComputeStream);
+    uint32_t err = fs_upload_orbit(r, GenerationNumber1, tag, (uint32_t)sizeof(IterType), Perturb1->GetFullOrbit(),
+                                   Perturb1->GetCompressedSize(), Perturb1->GetUncompressedSize(),
+                                   Perturb1->GetPeriodMaybeZero());
+    if (err || !LaReferenceHost)
+        return err;
+    // LAReference keeps LAInfoDeep / LAStageInfo in GrowableVectors whose element layout is fs_la_hdr32_u32 /
+    // fs_la_stage_u32 (static-asserted in the reference at GPU_LAReference.h:118-133).
+    const auto &at = LaReferenceHost->GetAT();
+    static_assert(sizeof(at) == sizeof(fs_at_hdr32_u32) || !std::is_same<T1, ::HDRFloat<float>>::value, "ATInfo layout");
+    return fs_upload_la(r, GenerationNumber1, tag, (uint32_t)sizeof(IterType), LaReferenceHost->GetLAs().GetData(),
+                        (uint32_t)LaReferenceHost->GetLAs().GetSize(), LaReferenceHost->GetLAStages().GetData(),
+                        (uint32_t)LaReferenceHost->GetLAStageCount(), LaReferenceHost->IsValid() ? 1 : 0,
+                        LaReferenceHost->UseAT() ? 1 : 0, &at);
+}
+
+template <typename IterType, class T, class SubType, LAv2Mode Mode, PerturbExtras PExtras>
+uint32_t GPURenderer::RenderPerturbLAv2(RenderAlgorithm /*algorithm*/, T /*cx*/, T /*cy*/, T dx, T dy, T centerX,
+                                        T centerY, IterType n_iterations)
+{
+    if (!m_ComputeStream)
+        return 0; // "memory not initialised" is silent, GPU_Render.cu:1007-1009
+    constexpr int tag = fsmi355_shim::type_tag<T>::value;
+    if (tag != FS_T_HDR32 || PExtras != PerturbExtras::Disable)
+        return FS_ERR_UNSUPPORTED;
+    const fs_real_hdr32 co[4] = {fsmi355_shim::to_abi(dx), fsmi355_shim::to_abi(dy), fsmi355_shim::to_abi(centerX),
+                                 fsmi355_shim::to_abi(centerY)};
+    const int mode = Mode == LAv2Mode::Full ? FS_LAV2_FULL : (Mode == LAv2Mode::PO ? FS_LAV2_PO : FS_LAV2_LAO);
+    return fs_render_lav2(fsmi355_shim::handle(m_ComputeStream), tag, mode, FS_PARITY_CPU, co, (uint64_t)n_iterations);
+}
+
+template <typename IterType, class T>
+uint32_t GPURenderer::RenderPerturbBLA(RenderAlgorithm /*algorithm*/,
+                                       const GPUPerturbResults<IterType, T, PerturbExtras::Disable> *results,
+                                       BLAS<IterType, T> *blas, T /*cx*/, T /*cy*/, T dx, T dy, T centerX, T centerY,
+                                       IterType n_iterations, int /*iteration_precision*/)
+{
+    if (!m_ComputeStream)
+        return 0;
+    constexpr int tag = fsmi355_shim::type_tag<T>::value;
+    if (tag != FS_T_HDR32)
+        return FS_ERR_UNSUPPORTED;
+    fs_renderer *r = fsmi355_shim::handle(m_ComputeStream);
+    // The reference re-uploads orbit and table on every call (GPU_Render.cu:1464-1479); so do we.
+    uint32_t err = fs_upload_orbit(r, 0, tag, (uint32_t)sizeof(IterType), results->GetFullOrbit(),
+                                   results->GetCompressedSize(), results->GetUncompressedSize(),
+                                   results->GetPeriodMaybeZero());
+    if (err)
+        return err;
+    const size_t n_levels = blas->m_B.size();
+    const void *levels[64] = {};
+    uint64_t sizes[64] = {};
+    for (size_t l = 0; l < n_levels && l < 64; l++) {
+        levels[l] = blas->m_B[l].empty() ? nullptr : blas->m_B[l].data();
+        sizes[l] = blas->m_B[l].size();
+    }
+    static_assert(sizeof(BLA<::HDRFloat<float>>) == sizeof(fs_bla_hdr32) || !std::is_same<T, ::HDRFloat<float>>::value,
+                  "BLA layout");
+    err = fs_upload_bla(r, tag, levels, sizes, (int32_t)n_levels, blas->m_LM2);
+    if (err)
+        return err;
+    const fs_real_hdr32 co[4] = {fsmi355_shim::to_abi(dx), fsmi355_shim::to_abi(dy), fsmi355_shim::to_abi(centerX),
+                                 fsmi355_shim::to_abi(centerY)};
+    return fs_render_bla(r, tag, co, (uint64_t)n_iterations);
+}
+
+template <typename IterType, class T>
+uint32_t GPURenderer::Render(RenderAlgorithm /*algorithm*/, T cx, T cy, T dx, T dy, IterType n_iterations,
+                             int /*iteration_precision*/)
+{
+    if (!m_ComputeStream)
+        return 0;
+    if (!std::is_same<T, double>::value)
+        return FS_ERR_UNSUPPORTED;
+    const double co[4] = {(double)dx, (double)dy, (double)cx, (double)cy};
+    return fs_render_direct(fsmi355_shim::handle(m_ComputeStream), FS_T_F64, co, (uint64_t)n_iterations);
+}
+
+template <typename IterType>
+uint32_t GPURenderer::RenderCurrent(IterType n_iterations, IterType *iter_buffer, Color16 *color_buffer,
+                                    ReductionResults *reduction_results, bool progressive)
+{
+    if (!m_ComputeStream)
+        return 0;
+    static_assert(sizeof(ReductionResults) == sizeof(fs_reduction), "ReductionResults layout");
+    return fs_render_current(fsmi355_shim::handle(m_ComputeStream), (uint64_t)n_iterations, iter_buffer,
+                             reinterpret_cast<fs_color16 *>(color_buffer),
+                             reinterpret_cast<fs_reduction *>(reduction_results), progressive ? 1 : 0);
+}
+
+inline uint32_t GPURenderer::SyncComputeStream()
+{
+    return m_ComputeStream ? fs_sync_compute(fsmi355_shim::handle(m_ComputeStream)) : 0;
+}
+inline uint32_t GPURenderer::SyncDisplayStream()
+{
+    return m_ComputeStream ? fs_sync_display(fsmi355_shim::handle(m_ComputeStream)) : 0;
+}
+inline uint32_t GPURenderer::QueryComputeStream()
+{
+    return m_ComputeStream ? fs_query_compute(fsmi355_shim::handle(m_ComputeStream)) : 0;
+}
+inline uint32_t GPURenderer::EnqueueComputeDoneCallback()
+{
+    if (!m_ComputeStream)
+        return 0;
+    // GPU_Render.cu:608-615: SignalComputeDone() runs on a runtime thread once prior compute work is done.
+    return fs_enqueue_done_callback(
+        fsmi355_shim::handle(m_ComputeStream), [](void *self) { static_cast<GPURenderer *>(self)->SignalComputeDone(); },
+        this);
+}

@@ -52,6 +52,13 @@ __device__ __forceinline__ void pixel_delta(const FsCoords32 &c, uint32_t x, uin
 
 __device__ __forceinline__ void add_stats(uint64_t *stats, uint64_t at, uint64_t la, uint64_t pt, uint64_t px)
 {
+    // stats[4]: lane slots the wave occupied in the perturbation loop = 64 x (longest lane); with [2] it gives
+    // the SIMD lane utilisation of the loop.
+    uint64_t mx = pt;
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint64_t o = __shfl_down(mx, off);
+        mx = o > mx ? o : mx;
+    }
     // one atomic per wave per counter
     for (int off = 32; off > 0; off >>= 1) {
         at += __shfl_down(at, off);
@@ -64,6 +71,7 @@ __device__ __forceinline__ void add_stats(uint64_t *stats, uint64_t at, uint64_t
         atomicAdd((unsigned long long *)&stats[1], (unsigned long long)la);
         atomicAdd((unsigned long long *)&stats[2], (unsigned long long)pt);
         atomicAdd((unsigned long long *)&stats[3], (unsigned long long)px);
+        atomicAdd((unsigned long long *)&stats[4], (unsigned long long)(mx * 64u));
     }
 }
 

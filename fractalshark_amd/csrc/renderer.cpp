@@ -190,7 +190,7 @@ struct TimedLaunch {
         if (r->ev_start)
             hipEventRecord(r->ev_start, r->compute);
         if (r->stats_on && r->stats)
-            hipMemsetAsync(r->stats, 0, 4 * sizeof(uint64_t), r->compute);
+            hipMemsetAsync(r->stats, 0, 8 * sizeof(uint64_t), r->compute);
     }
     ~TimedLaunch()
     {
@@ -341,7 +341,7 @@ uint32_t fs_init_memory(fs_renderer *r, uint32_t w, uint32_t h, uint32_t antiali
     if (!r->reduction)
         FS_TRY(hipMalloc((void **)&r->reduction, sizeof(fs_reduction)));
     if (!r->stats)
-        FS_TRY(hipMalloc((void **)&r->stats, 4 * sizeof(uint64_t)));
+        FS_TRY(hipMalloc((void **)&r->stats, 8 * sizeof(uint64_t)));
     FS_TRY(hipMalloc((void **)&r->colors, r->n_color_cu * sizeof(fs_color16)));
     return fs_clear(r);
 }
@@ -730,13 +730,13 @@ uint32_t fs_enable_step_count(fs_renderer *r, int enable)
     return 0;
 }
 
-uint32_t fs_read_step_count(fs_renderer *r, uint64_t counts[4])
+uint32_t fs_read_step_count(fs_renderer *r, uint64_t counts[5])
 {
     if (uint32_t e = use_device(r))
         return e;
     if (!r->stats)
         return FS_ERR_6;
-    FS_TRY(hipMemcpy(counts, r->stats, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    FS_TRY(hipMemcpy(counts, r->stats, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return 0;
 }
 

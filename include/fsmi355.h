@@ -149,10 +149,11 @@ uint32_t fs_get_height(const fs_renderer *r);
  * fs_last_kernel_ms: duration of the most recent iteration-kernel launch measured with HIP events on the
  * compute stream (valid after fs_sync_compute).
  * fs_enable_step_count: when on, iteration kernels also accumulate the executed work per launch:
- * counts[0] = AT iterations, [1] = LA steps, [2] = perturbation steps, [3] = pixels. */
+ * counts[0] = AT iterations, [1] = LA steps, [2] = perturbation steps, [3] = pixels,
+ * [4] = lane slots occupied in the perturbation loop (64 x longest lane, summed over waves). */
 float fs_last_kernel_ms(const fs_renderer *r);
 uint32_t fs_enable_step_count(fs_renderer *r, int enable);
-uint32_t fs_read_step_count(fs_renderer *r, uint64_t counts[4]);
+uint32_t fs_read_step_count(fs_renderer *r, uint64_t counts[5]);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,166 @@
+// Compile/link check of fractalshark_amd/csrc/gpu_render_shim.hpp WITHOUT the reference tree: minimal stand-ins
+// for the reference types the shim touches (same names, same member signatures as GPU_Render.h:20-227,
+// GPU_Types.h, LAReference.h:217-262, BLAS.h:13-24, HDRFloat.h getters), then the explicit instantiations a
+// maintainer's GPU_Render_hip.cpp would contain.  No arithmetic, nothing is executed on the CPU-only box.
+#include <stddef.h>
+#include <stdint.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <vector>
+
+#define FS_SHIM_SELFTEST 1
+
+using cudaStream_t = void *;
+enum class PerturbExtras { Disable, Bad, SimpleCompression, MaxCompression };
+enum class LAv2Mode { Full, PO, LAO };
+struct RenderAlgorithm {
+    int Algorithm;
+};
+struct Color16 {
+    uint16_t r, g, b, a;
+};
+struct ReductionResults {
+    uint64_t Min, Max, Sum;
+};
+struct AntialiasedColors {
+    Color16 *aa_colors;
+};
+struct Palette {
+    Color16 *local_pal;
+};
+struct PerturbResultsCollection {
+};
+template <class T> class HDRFloat {
+public:
+    T mantissa;
+    int32_t exp;
+    T getMantissa() const { return mantissa; }
+    int32_t getExp() const { return exp; }
+};
+template <class T, PerturbExtras P> struct GPUReferenceIter {
+    T x, y;
+};
+template <typename IterType, class T, PerturbExtras PExtras> class GPUPerturbResults {
+public:
+    const GPUReferenceIter<T, PExtras> *GetFullOrbit() const { return orb; }
+    IterType GetCompressedSize() const { return n; }
+    IterType GetUncompressedSize() const { return n; }
+    IterType GetPeriodMaybeZero() const { return period; }
+    const GPUReferenceIter<T, PExtras> *orb = nullptr;
+    IterType n = 0, period = 0;
+};
+template <class E> struct GrowableVector {
+    E *GetData() const { return nullptr; }
+    size_t GetSize() const { return 0; }
+};
+template <typename IterType, class F, class S> struct ATInfo {
+    unsigned char bytes[116];
+};
+template <typename IterType, class F, class S, PerturbExtras P> struct LAInfoDeep {
+    unsigned char bytes[68];
+};
+template <typename IterType> struct LAStageInfo {
+    IterType LAIndex, MacroItCount;
+};
+template <typename IterType, class Float, class SubType, PerturbExtras PExtras> class LAReference {
+public:
+    bool IsValid() const { return true; }
+    bool UseAT() const { return true; }
+    const ATInfo<IterType, Float, SubType> &GetAT() const { return at; }
+    IterType GetLAStageCount() const { return 0; }
+    const GrowableVector<LAInfoDeep<IterType, Float, SubType, PExtras>> &GetLAs() const { return las; }
+    const GrowableVector<LAStageInfo<IterType>> &GetLAStages() const { return stages; }
+    ATInfo<IterType, Float, SubType> at;
+    GrowableVector<LAInfoDeep<IterType, Float, SubType, PExtras>> las;
+    GrowableVector<LAStageInfo<IterType>> stages;
+};
+template <class T> struct BLA {
+    T r2, Ax, Ay, Bx, By;
+    int l;
+};
+template <typename IterType, class T, PerturbExtras PExtras = PerturbExtras::Disable> class BLAS {
+public:
+    std::vector<std::vector<BLA<T>>> m_B;
+    int32_t m_LM2 = 0;
+};
+struct MattDblflt {
+    float head, tail;
+};
+
+// Member list of the reference class (declarations only).
+class GPURenderer {
+public:
+    GPURenderer();
+    ~GPURenderer();
+    static uint32_t TestCudaIsWorking();
+    template <typename IterType, class T>
+    uint32_t Render(RenderAlgorithm algorithm, T cx, T cy, T dx, T dy, IterType n_iterations, int iteration_precision);
+    template <typename IterType, class T>
+    uint32_t RenderPerturbBLA(RenderAlgorithm algorithm,
+                              const GPUPerturbResults<IterType, T, PerturbExtras::Disable> *results,
+                              BLAS<IterType, T> *blas, T cx, T cy, T dx, T dy, T centerX, T centerY,
+                              IterType n_iterations, int iteration_precision);
+    template <typename IterType, class T, class SubType, LAv2Mode Mode, PerturbExtras PExtras>
+    uint32_t RenderPerturbLAv2(RenderAlgorithm algorithm, T cx, T cy, T dx, T dy, T centerX, T centerY,
+                               IterType n_iterations);
+    template <typename IterType>
+    uint32_t InitializeMemory(uint32_t w, uint32_t h, uint32_t antialiasing, const Color16 *palInterleaved,
+                              uint32_t palIters, uint32_t paletteAuxDepth, uint64_t paletteGeneration,
+                              bool expectedReuse);
+    template <typename IterType, class T1, class SubType, PerturbExtras PExtras, class T2>
+    uint32_t InitializePerturb(size_t GenerationNumber1, const GPUPerturbResults<IterType, T1, PExtras> *Perturb1,
+                               size_t GenerationNumber2, const GPUPerturbResults<IterType, T2, PExtras> *Perturb2,
+                               const LAReference<IterType, T1, SubType, PExtras> *LaReferenceHost);
+    template <typename IterType> void ClearMemory();
+    static const char *ConvertErrorToString(uint32_t err);
+    static const int32_t NB_THREADS_W = 16;
+    static const int32_t NB_THREADS_H = 8;
+    template <typename IterType>
+    uint32_t RenderCurrent(IterType n_iterations, IterType *iter_buffer, Color16 *color_buffer,
+                           ReductionResults *reduction_results, bool progressive = false);
+    uint32_t SyncComputeStream();
+    uint32_t SyncDisplayStream();
+    uint32_t QueryComputeStream();
+    uint32_t EnqueueComputeDoneCallback();
+    void SignalComputeDone() { m_ComputeDoneFlag.store(true, std::memory_order_release); }
+
+private:
+    void *OutputIterMatrix;
+    uint32_t m_Width, m_Height, m_Antialiasing, m_IterTypeSize;
+    cudaStream_t m_ComputeStream;
+    cudaStream_t m_DisplayStream;
+    std::atomic<bool> m_ComputeDoneFlag{false};
+};
+
+#include "../fractalshark_amd/csrc/gpu_render_shim.hpp"
+
+// What GPU_Render_hip.cpp instantiates (subset of GPU_Render.cu:227-230,409-429,503-537,1204-1300,1610-1692).
+using HDR32 = HDRFloat<float>;
+template uint32_t GPURenderer::InitializeMemory<uint32_t>(uint32_t, uint32_t, uint32_t, const Color16 *, uint32_t,
+                                                          uint32_t, uint64_t, bool);
+template void GPURenderer::ClearMemory<uint32_t>();
+template uint32_t GPURenderer::InitializePerturb<uint32_t, HDR32, float, PerturbExtras::Disable, HDR32>(
+    size_t, const GPUPerturbResults<uint32_t, HDR32, PerturbExtras::Disable> *, size_t,
+    const GPUPerturbResults<uint32_t, HDR32, PerturbExtras::Disable> *,
+    const LAReference<uint32_t, HDR32, float, PerturbExtras::Disable> *);
+template uint32_t GPURenderer::RenderPerturbLAv2<uint32_t, HDR32, float, LAv2Mode::Full, PerturbExtras::Disable>(
+    RenderAlgorithm, HDR32, HDR32, HDR32, HDR32, HDR32, HDR32, uint32_t);
+template uint32_t GPURenderer::RenderPerturbLAv2<uint32_t, HDR32, float, LAv2Mode::PO, PerturbExtras::Disable>(
+    RenderAlgorithm, HDR32, HDR32, HDR32, HDR32, HDR32, HDR32, uint32_t);
+template uint32_t GPURenderer::RenderPerturbLAv2<uint32_t, HDR32, float, LAv2Mode::LAO, PerturbExtras::Disable>(
+    RenderAlgorithm, HDR32, HDR32, HDR32, HDR32, HDR32, HDR32, uint32_t);
+template uint32_t GPURenderer::RenderPerturbBLA<uint32_t, HDR32>(RenderAlgorithm,
+                                                                 const GPUPerturbResults<uint32_t, HDR32, PerturbExtras::Disable> *,
+                                                                 BLAS<uint32_t, HDR32> *, HDR32, HDR32, HDR32, HDR32, HDR32,
+                                                                 HDR32, uint32_t, int);
+template uint32_t GPURenderer::Render<uint32_t, double>(RenderAlgorithm, double, double, double, double, uint32_t, int);
+template uint32_t GPURenderer::RenderCurrent<uint32_t>(uint32_t, uint32_t *, Color16 *, ReductionResults *, bool);
+
+int main()
+{
+    // Never executed by the CPU test (it only compiles and links); on a GPU box it is a tiny end-to-end call.
+    GPURenderer r;
+    return (int)r.SyncComputeStream();
+}
