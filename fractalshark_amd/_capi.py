@@ -79,6 +79,7 @@ def render_lib():
     _decl(lib, "fs_get_width", u32, [vp])
     _decl(lib, "fs_get_height", u32, [vp])
     _decl(lib, "fs_last_kernel_ms", C.c_float, [vp])
+    _decl(lib, "fs_set_kernel_variant", u32, [vp, C.c_int])
     _decl(lib, "fs_enable_step_count", u32, [vp, C.c_int])
     _decl(lib, "fs_read_step_count", u32, [vp, vp])
     _render = lib
@@ -90,7 +91,7 @@ RENDER_SYMBOLS = [
     "fs_local_rows", "fs_set_external_iter_buffer", "fs_device_iter_buffer", "fs_rounded_width", "fs_upload_orbit",
     "fs_upload_la", "fs_upload_bla", "fs_render_lav2", "fs_render_bla", "fs_render_direct", "fs_clear",
     "fs_render_current", "fs_sync_compute", "fs_sync_display", "fs_query_compute", "fs_enqueue_done_callback",
-    "fs_get_width", "fs_get_height", "fs_last_kernel_ms", "fs_enable_step_count", "fs_read_step_count",
+    "fs_get_width", "fs_get_height", "fs_last_kernel_ms", "fs_set_kernel_variant", "fs_enable_step_count", "fs_read_step_count",
 ]
 
 

@@ -12,6 +12,8 @@
 
 enum { FS_MODE_FULL = 0, FS_MODE_PO = 1, FS_MODE_LAO = 2 };
 enum { FS_PARITY_LITERAL = 0, FS_PARITY_GPUSTAGE = 1 };
+// kernel variant: 0 = tuned loop (default), 1 = literal operation-by-operation transcription (A/B reference)
+enum { FS_VARIANT_TUNED = 0, FS_VARIANT_LITERAL = 1 };
 
 // Frame geometry + the row-band layout of the local iteration buffer.
 struct FsFrame {
@@ -69,7 +71,7 @@ struct FsDirectArgs64 {
 };
 
 void fsk_prepare_orbit_hdr32(const fs_orbit_hdr32 *in, float4 *out, uint64_t n, hipStream_t s);
-void fsk_lav2_hdr32(const FsLav2Args32 &A, int mode, bool stats, hipStream_t s);
+void fsk_lav2_hdr32(const FsLav2Args32 &A, int mode, bool stats, int variant, hipStream_t s);
 void fsk_perturb_scalar_hdr32(const FsBlaArgs32 &A, bool use_bla, bool stats, hipStream_t s);
 void fsk_direct_f64(const FsDirectArgs64 &A, double minX, double dx, bool stats, hipStream_t s);
 void fsk_antialias_u32(const uint32_t *iters, uint32_t rounded_width, fs_color16 *colors, const fs_color16 *pal,

@@ -221,6 +221,220 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32(FsLav2Args32 A)
 }
 
 // ------------------------------------------------------------------------------------------------
+// LAv2, T = HDRFloat<float>: tuned perturbation loop.  Same prologue (AT + LA stages) and the same results, bit for
+// bit, as k_lav2_hdr32; the perturbation loop (>99.9 % of the executed work at View 5) is restructured around what
+// the CPU arithmetic actually does per step (measured with an instrumented oracle):
+//   * 2Z+dz and Z'+dz are "orbit bigger, 0 <= exponent gap < 120" in 99.9 % of lane-steps; dz*cur+dc is "dz bigger".
+//     A straight-line, branch-free step is executed speculatively under exactly those assumptions
+//     (no 4-way exponent-alignment branches, no operand swaps) and committed only if EVERY running lane of the wave
+//     met them (one ballot); otherwise the wave redoes that step with the generic functions of hdr_math.hpp.
+//   * Reduce(z) before |z|^2 is skipped on the fast path: scaling both parts by the same power of two commutes with
+//     IEEE multiply/add (no operand is near the denormal range there: the orbit part has |mantissa| >= 0.5), so
+//     Reduce(|z|^2) gives the same {mantissa, exponent}.  The reduced z is only materialised on a rebase.
+//   * Rebases (3.6e-4 per lane-step) and escapes leave the hot loop through cold branches.
+//   * (exp, mantissa) pairs of reduced non-negative values are compared as one signed 64-bit key, which is the
+//     lexicographic compareToBothPositiveReduced (HDRFloat.h:1150-1167) because IEEE bit patterns of non-negative
+//     floats order like integers.
+//   * The orbit entry of the *next* step is the Z' of this step: one 16-byte load per step instead of two.
+namespace {
+
+__device__ __forceinline__ float pow2_bits(int biased) { return __int_as_float(biased << 23); }
+
+__device__ __forceinline__ long long key_of(float m, int e)
+{
+    return ((long long)e << 32) | (long long)(unsigned)__float_as_int(m);
+}
+
+// Reduce(norm_squared(c)) as a key; c is any complex whose larger part is a normal float.
+__device__ __forceinline__ long long norm_key(float re, float im, int e)
+{
+    const float m = re * re + im * im; // >= +0
+    const int bits = __float_as_int(m);
+    const int fe = ((bits >> 23) & 0xff) - 127;
+    const bool z = m == 0.0f;
+    const int mm = z ? 0 : ((bits & 0x007FFFFF) | 0x3F800000);
+    const int ee = (e << 1) + (z ? 0 : fe);
+    return ((long long)ee << 32) | (long long)(unsigned)mm;
+}
+
+} // namespace
+
+template <int Mode, bool kStats>
+__global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
+{
+    const uint32_t X = blockIdx.x * 64u + (threadIdx.x & 63u);
+    const uint32_t L = blockIdx.y * 4u + (threadIdx.x >> 6);
+    uint64_t c_at = 0, c_la = 0, c_pt = 0, c_px = 0;
+    const uint32_t Y = global_row(A.frame, L);
+    const bool live = X < A.frame.width && L < A.frame.local_rows && Y < A.frame.height;
+    if (live) {
+        c_px = 1;
+        const uint32_t n_iterations = A.n_iterations;
+        hreal32 deltaReal, deltaImaginary;
+        pixel_delta(A.coords, X, Y, deltaReal, deltaImaginary);
+        const hcplx32 DeltaSub0 = hc_from_hr(deltaReal, deltaImaginary);
+        hcplx32 DeltaSubN = hc_from_native<float>(0.0f, 0.0f);
+        uint32_t iterations = 0;
+
+        if (Mode != FS_MODE_PO) {
+            if (A.la_valid && A.use_at && hr_cmp_pos(hc_cheb(DeltaSub0), ldr(A.at.ThresholdC)) <= 0) {
+                const uint32_t ATMaxIt = n_iterations / A.at.StepLength;
+                hcplx32 c = hc_add(hc_mul(DeltaSub0, ldc(A.at.CCoeff)), ldc(A.at.RefC));
+                hc_reduce(c);
+                hcplx32 z = hc_zero<float>();
+                const hreal32 esc = ldr(A.at.SqrEscapeRadius);
+                uint32_t i;
+                for (i = 0; i < ATMaxIt; i++) {
+                    hreal32 nsq = hc_norm2(z);
+                    hr_reduce(nsq);
+                    if (hr_cmp_pos(nsq, esc) > 0)
+                        break;
+                    z = hc_add(hc_mul(z, z), c);
+                }
+                hcplx32 dz = hc_mul(z, ldc(A.at.InvZCoeff));
+                hc_reduce(dz);
+                DeltaSubN = dz;
+                iterations = i * A.at.StepLength;
+                if (kStats)
+                    c_at = i;
+            }
+        }
+
+        uint32_t RefIteration = 0;
+        const uint32_t MaxRefIteration = A.orbit_count - 1;
+        if (iterations != 0 && !(RefIteration < MaxRefIteration) && A.period != 0)
+            RefIteration = RefIteration % A.period;
+
+        if (Mode != FS_MODE_PO) {
+            uint32_t CurrentLAStage = A.la_valid ? A.stage_count : 0;
+            const hreal32 dcCheb = hc_cheb(DeltaSub0);
+            while (CurrentLAStage > 0) {
+                CurrentLAStage--;
+                const uint32_t LAIndex = A.stages[CurrentLAStage].LAIndex;
+                {
+                    const int cmp = hr_cmp_pos(dcCheb, ldr(A.las[LAIndex].LAThresholdC));
+                    const bool invalid = A.parity == FS_PARITY_LITERAL ? (cmp < 0) : (cmp >= 0);
+                    if (invalid)
+                        continue;
+                }
+                const uint32_t MacroItCount = A.stages[CurrentLAStage].MacroItCount;
+                uint32_t j = RefIteration;
+                while (iterations < n_iterations) {
+                    const fs_la_hdr32_u32 *LAj = &A.las[LAIndex + j];
+                    const uint32_t l = LAj->StepLength;
+                    bool unusable = true;
+                    hcplx32 newDz = hc_zero<float>();
+                    if (iterations + l <= n_iterations) {
+                        newDz = hc_mul(DeltaSubN, hc_add(hc_mul2(ldc(LAj->Ref)), DeltaSubN));
+                        hc_reduce(newDz);
+                        unusable = hr_cmp_pos(hc_cheb(newDz), ldr(LAj->LAThreshold)) >= 0;
+                    }
+                    if (unusable) {
+                        RefIteration = LAj->NextStageLAIndex;
+                        break;
+                    }
+                    iterations += l;
+                    if (kStats)
+                        c_la++;
+                    DeltaSubN = hc_add(hc_mul(newDz, ldc(LAj->ZCoeff)), hc_mul(DeltaSub0, ldc(LAj->CCoeff)));
+                    const hcplx32 complex0 = hc_add(ldc(LAj[1].Ref), DeltaSubN);
+                    j++;
+                    const hreal32 lhs = hr_reduced(hc_cheb(complex0));
+                    const hreal32 rhs = hr_reduced(hc_cheb(DeltaSubN));
+                    if (hr_cmp_pos(lhs, rhs) < 0 || j >= MacroItCount) {
+                        DeltaSubN = complex0;
+                        j = 0;
+                    }
+                }
+                if (iterations >= n_iterations)
+                    break;
+            }
+        }
+
+        if (Mode != FS_MODE_LAO) {
+            const float4 *__restrict__ zr = A.zref;
+            const long long key256 = key_of(1.0f, 8);
+            hcplx32 dz = DeltaSubN;
+            const hcplx32 dc = DeltaSub0;
+            uint32_t ref = RefIteration;
+            hcplx32 Zc = zref_at(zr, ref);
+            bool running = iterations < n_iterations;
+            while (running) {
+                const hcplx32 Zn = zref_at(zr, ref + 1);
+                // ---- speculative straight-line step
+                // cur = 2Z + dz   (assume 0 <= gap < 120, orbit bigger)
+                const int e1 = Zc.e + 1;
+                const int d1 = e1 - dz.e;
+                const float m1 = pow2_bits(127 - d1);
+                const float cur_re = Zc.re + dz.re * m1;
+                const float cur_im = Zc.im + dz.im * m1;
+                // dz = dz * cur
+                const float p_re = (dz.re * cur_re) - (dz.im * cur_im);
+                const float p_im = (dz.re * cur_im) + (dz.im * cur_re);
+                const int p_e = clamp_exp(dz.e + e1);
+                // dz = dz + dc    (assume gap >= 0, dz bigger; gap >= 120 ignores dc)
+                const int d2 = p_e - dc.e;
+                const float m2 = (d2 < kExpDiffIgnored) ? pow2_bits(127 - d2) : 0.0f;
+                float q_re = p_re + dc.re * m2;
+                float q_im = p_im + dc.im * m2;
+                // Reduce(dz)      (assume not both zero)
+                const int fmax = imax(exp_field<float>(q_re), exp_field<float>(q_im));
+                const float m3 = pow2_bits(254 - fmax);
+                q_re *= m3;
+                q_im *= m3;
+                const int q_e = p_e + (fmax - 127);
+                // z = Z' + dz     (assume 0 <= gap < 120, orbit bigger)
+                const int d3 = Zn.e - q_e;
+                const float m4 = pow2_bits(127 - d3);
+                const float z_re = Zn.re + q_re * m4;
+                const float z_im = Zn.im + q_im * m4;
+                const bool ok = ((unsigned)d1 < (unsigned)kExpDiffIgnored) && (d2 >= 0) && (d2 <= 126 || d2 >= kExpDiffIgnored) &&
+                                ((unsigned)d3 < (unsigned)kExpDiffIgnored) && !(q_re == 0.0f && q_im == 0.0f) && fmax < 254;
+                hcplx32 ndz, z;
+                long long kn;
+                if (__ballot(!ok) == 0ull) {
+                    ndz = hcplx32{q_re, q_im, q_e};
+                    z = hcplx32{z_re, z_im, Zn.e};                 // NOT reduced (see header comment)
+                    kn = norm_key(z_re, z_im, Zn.e);
+                } else {
+                    // ---- generic step, literal order of Fractal.cpp:2646-2661
+                    hcplx32 cur = hc_mul2(Zc);
+                    cur = hc_add(cur, dz);
+                    ndz = hc_mul(dz, cur);
+                    ndz = hc_add(ndz, dc);
+                    hc_reduce(ndz);
+                    z = hc_add(Zn, ndz);
+                    hc_reduce(z);
+                    const hreal32 n = hr_reduced(hc_norm2(z));
+                    kn = key_of(n.m, n.e);
+                }
+                if (kStats)
+                    c_pt++;
+                ref++;
+                const long long kd = norm_key(ndz.re, ndz.im, ndz.e);
+                dz = ndz;
+                Zc = Zn;
+                if (kn > key256) {
+                    running = false; // escaped: `break` happens before iterations++ in the CPU loop
+                } else {
+                    if (kn < kd || ref >= MaxRefIteration) {
+                        hc_reduce(z); // idempotent on the generic path
+                        dz = z;
+                        ref = 0;
+                        Zc = zref_at(zr, 0);
+                    }
+                    iterations++;
+                    running = iterations < n_iterations;
+                }
+            }
+        }
+        A.out[(size_t)L * A.frame.rounded_width + X] = iterations;
+    }
+    if (kStats)
+        add_stats(A.stats, c_at, c_la, c_pt, c_px);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Scalar-HDRFloat perturbation with optional BLA skipping, T = HDRFloat<float>.
 // CPU twin: Fractal::CalcCpuPerturbationFractalBLA<uint32_t,HDRFloat<float>,float> (Fractal.cpp:2266-2470),
 // BLAS::LookupBackwards (BLAS.cpp:256-310), BLA::getValue (BLA.cuh:21-38).  With kBla == false the lookup is
@@ -492,15 +706,22 @@ void fsk_prepare_orbit_hdr32(const fs_orbit_hdr32 *in, float4 *out, uint64_t n, 
     hipLaunchKernelGGL(k_prepare_orbit_hdr32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n);
 }
 
-void fsk_lav2_hdr32(const FsLav2Args32 &A, int mode, bool stats, hipStream_t s)
+void fsk_lav2_hdr32(const FsLav2Args32 &A, int mode, bool stats, int variant, hipStream_t s)
 {
     const dim3 g = frame_grid(A.frame), b(256);
 #define FS_LAUNCH(M)                                                                                                \
     do {                                                                                                            \
-        if (stats)                                                                                                  \
-            hipLaunchKernelGGL((k_lav2_hdr32<M, true>), g, b, 0, s, A);                                             \
-        else                                                                                                        \
-            hipLaunchKernelGGL((k_lav2_hdr32<M, false>), g, b, 0, s, A);                                            \
+        if (variant == FS_VARIANT_LITERAL) {                                                                        \
+            if (stats)                                                                                              \
+                hipLaunchKernelGGL((k_lav2_hdr32<M, true>), g, b, 0, s, A);                                         \
+            else                                                                                                    \
+                hipLaunchKernelGGL((k_lav2_hdr32<M, false>), g, b, 0, s, A);                                        \
+        } else {                                                                                                    \
+            if (stats)                                                                                              \
+                hipLaunchKernelGGL((k_lav2_hdr32_fast<M, true>), g, b, 0, s, A);                                    \
+            else                                                                                                    \
+                hipLaunchKernelGGL((k_lav2_hdr32_fast<M, false>), g, b, 0, s, A);                                   \
+        }                                                                                                           \
     } while (0)
     if (mode == FS_MODE_FULL)
         FS_LAUNCH(FS_MODE_FULL);

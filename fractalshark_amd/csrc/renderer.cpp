@@ -45,6 +45,7 @@ struct fs_renderer {
     fs_reduction *reduction = nullptr;
     uint64_t *stats = nullptr;
     bool stats_on = false;
+    int variant = FS_VARIANT_TUNED;
 
     // palette (GPU_Render.cu:270-304)
     fs_color16 *pal = nullptr;
@@ -549,7 +550,7 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
     {
         TimedLaunch t(r);
         fsk_lav2_hdr32(A, mode == FS_LAV2_FULL ? FS_MODE_FULL : (mode == FS_LAV2_PO ? FS_MODE_PO : FS_MODE_LAO),
-                       r->stats_on, r->compute);
+                       r->stats_on, r->variant, r->compute);
     }
     return (uint32_t)hipGetLastError();
 }
@@ -722,6 +723,12 @@ float fs_last_kernel_ms(const fs_renderer *r)
     if (hipEventElapsedTime(&ms, r->ev_start, r->ev_stop) != hipSuccess)
         return -1.0f;
     return ms;
+}
+
+uint32_t fs_set_kernel_variant(fs_renderer *r, int variant)
+{
+    r->variant = variant ? FS_VARIANT_LITERAL : FS_VARIANT_TUNED;
+    return 0;
 }
 
 uint32_t fs_enable_step_count(fs_renderer *r, int enable)

@@ -166,6 +166,10 @@ class GPURenderer:
     def last_kernel_ms(self):
         return float(self._lib.fs_last_kernel_ms(self._h))
 
+    def set_kernel_variant(self, literal=False):
+        """False (default): tuned loops; True: literal transcription (A/B reference, identical results)."""
+        return self._lib.fs_set_kernel_variant(self._h, 1 if literal else 0)
+
     def enable_step_count(self, on=True):
         return self._lib.fs_enable_step_count(self._h, 1 if on else 0)
 

@@ -199,3 +199,40 @@ def test_larger_frame_properties(renderer, native_libs):
     assert red.Sum == int(out[:180, :320].astype(np.uint64).sum())
     out2, _ = _render_lav2(renderer, v, ob, la, LAV2_FULL, PARITY_CPU_GPUSTAGE)
     assert np.array_equal(out, out2)
+
+
+@pytest.mark.parametrize("parity", [PARITY_CPU, PARITY_CPU_GPUSTAGE])
+def test_tuned_loop_equals_literal_transcription_1080p(renderer, native_libs, parity):
+    """The tuned perturbation loop (speculative branch-free step + generic fallback) must give the same iteration
+    buffer as the literal operation-by-operation kernel on a full 1920x1080 frame (~5e10 executed pixel-steps),
+    and both must match the oracle on a sample of rows."""
+    v = inputs.View.builtin(5, 1920, 1080)
+    ob = inputs.Orbit(v)
+    la = inputs.LATable(ob)
+    r = renderer
+    try:
+        assert r.set_kernel_variant(literal=True) == 0
+        lit, red_l = _render_lav2(r, v, ob, la, LAV2_FULL, parity)
+        assert r.set_kernel_variant(literal=False) == 0
+        tun, red_t = _render_lav2(r, v, ob, la, LAV2_FULL, parity)
+    finally:
+        r.set_kernel_variant(literal=False)
+    assert np.array_equal(lit, tun)
+    assert (red_l.Min, red_l.Max, red_l.Sum) == (red_t.Min, red_t.Max, red_t.Sum)
+    _oracle.set_row_step(135)
+    try:
+        ref = _oracle.lav2_hdr32(v, ob, la, rows=(67, 1080), threads=16, stage_test=0 if parity == PARITY_CPU else 1)
+    finally:
+        _oracle.set_row_step(1)
+    for y in range(67, 1080, 135):
+        assert np.array_equal(tun[y], ref[y]), y
+
+
+def test_literal_variant_small_fixture(renderer, v5_small):
+    v, ob, la, _ = v5_small
+    try:
+        renderer.set_kernel_variant(literal=True)
+        out, _ = _render_lav2(renderer, v, ob, la, LAV2_FULL, PARITY_CPU)
+    finally:
+        renderer.set_kernel_variant(literal=False)
+    assert np.array_equal(out, GOLD["view5_lav2_cpu_64x36"])
