@@ -86,7 +86,9 @@ __global__ void k_prepare_orbit_hdr32(const fs_orbit_hdr32 *__restrict__ in, flo
         return;
     const fs_orbit_hdr32 e = in[i];
     const hcplx32 c = hc_from_hr(hreal32{e.mx, e.ex}, hreal32{e.my, e.ey});
-    out[i] = make_float4(c.re, c.im, __int_as_float(c.e), 0.0f);
+    // .w = 2^(8 - 2*exp): with z = Z + dz aligned to Z's exponent, |z|^2 > 256  <=>  re^2 + im^2 > .w  (tuned loop).
+    // Overflows to +inf for a tiny Z (never "escaped" there), cannot underflow (orbit values are < 2^9).
+    out[i] = make_float4(c.re, c.im, __int_as_float(c.e), ldexpf(1.0f, 8 - 2 * (c.e < -1000 ? -1000 : c.e)));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -257,6 +259,15 @@ __device__ __forceinline__ long long norm_key(float re, float im, int e)
     return ((long long)ee << 32) | (long long)(unsigned)mm;
 }
 
+// Same for a sum of squares already known to be a positive normal float (no zero special case).
+__device__ __forceinline__ long long norm_key_nz(float m, int e)
+{
+    const int bits = __float_as_int(m);
+    const int fe = ((bits >> 23) & 0xff) - 127;
+    const int mm = (bits & 0x007FFFFF) | 0x3F800000;
+    return ((long long)((e << 1) + fe) << 32) | (long long)(unsigned)mm;
+}
+
 } // namespace
 
 template <int Mode, bool kStats>
@@ -353,75 +364,99 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
 
         if (Mode != FS_MODE_LAO) {
             const float4 *__restrict__ zr = A.zref;
-            const long long key256 = key_of(1.0f, 8);
             hcplx32 dz = DeltaSubN;
             const hcplx32 dc = DeltaSub0;
             uint32_t ref = RefIteration;
             hcplx32 Zc = zref_at(zr, ref);
             bool running = iterations < n_iterations;
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            f2 dzm = {dz.re, dz.im};
+            int dze = dz.e;
+            const f2 dcm = {dc.re, dc.im};
+            const int dce = dc.e;
+            f2 Zcm = {Zc.re, Zc.im};
+            int Zce1 = Zc.e + 1; // exponent of 2Z
             while (running) {
-                const hcplx32 Zn = zref_at(zr, ref + 1);
-                // ---- speculative straight-line step
-                // cur = 2Z + dz   (assume 0 <= gap < 120, orbit bigger)
-                const int e1 = Zc.e + 1;
-                const int d1 = e1 - dz.e;
-                const float m1 = pow2_bits(127 - d1);
-                const float cur_re = Zc.re + dz.re * m1;
-                const float cur_im = Zc.im + dz.im * m1;
-                // dz = dz * cur
-                const float p_re = (dz.re * cur_re) - (dz.im * cur_im);
-                const float p_im = (dz.re * cur_im) + (dz.im * cur_re);
-                const int p_e = clamp_exp(dz.e + e1);
-                // dz = dz + dc    (assume gap >= 0, dz bigger; gap >= 120 ignores dc)
-                const int d2 = p_e - dc.e;
-                const float m2 = (d2 < kExpDiffIgnored) ? pow2_bits(127 - d2) : 0.0f;
-                float q_re = p_re + dc.re * m2;
-                float q_im = p_im + dc.im * m2;
-                // Reduce(dz)      (assume not both zero)
-                const int fmax = imax(exp_field<float>(q_re), exp_field<float>(q_im));
-                const float m3 = pow2_bits(254 - fmax);
-                q_re *= m3;
-                q_im *= m3;
-                const int q_e = p_e + (fmax - 127);
-                // z = Z' + dz     (assume 0 <= gap < 120, orbit bigger)
-                const int d3 = Zn.e - q_e;
-                const float m4 = pow2_bits(127 - d3);
-                const float z_re = Zn.re + q_re * m4;
-                const float z_im = Zn.im + q_im * m4;
-                const bool ok = ((unsigned)d1 < (unsigned)kExpDiffIgnored) && (d2 >= 0) && (d2 <= 126 || d2 >= kExpDiffIgnored) &&
-                                ((unsigned)d3 < (unsigned)kExpDiffIgnored) && !(q_re == 0.0f && q_im == 0.0f) && fmax < 254;
-                hcplx32 ndz, z;
-                long long kn;
-                if (__ballot(!ok) == 0ull) {
-                    ndz = hcplx32{q_re, q_im, q_e};
-                    z = hcplx32{z_re, z_im, Zn.e};                 // NOT reduced (see header comment)
-                    kn = norm_key(z_re, z_im, Zn.e);
-                } else {
+                const float4 zv = zr[ref + 1];
+                const f2 Znm = {zv.x, zv.y};
+                const int Zne = __float_as_int(zv.z);
+                // ---- speculative straight-line step; n* = NEGATED exponent gaps (<= 0 when the assumption holds)
+                // cur = 2Z + dz      (orbit bigger, gap in [0,120))
+                const int nd1 = dze - Zce1;
+                const f2 cur = Zcm + dzm * __int_as_float((nd1 << 23) + 0x3F800000);
+                // p = dz * cur       (re = dr*cr - di*ci, im = dr*ci + di*cr)
+                const f2 pa = dzm.xx * cur;
+                const f2 pb = dzm.yy * cur.yx;
+                f2 p;
+                asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(p) : "v"(pa), "v"(pb));
+                const int pe = imax(dze + Zce1, kMinBigExp);
+                // q = p + dc         (p bigger; gap >= 120 ignores dc)
+                const int nd2 = dce - pe;
+                const float m2 = nd2 > -kExpDiffIgnored ? __int_as_float((nd2 << 23) + 0x3F800000) : 0.0f;
+                f2 q = p + dcm * m2;
+                // Reduce(q)          (larger part a non-zero normal float)
+                const int fmax = imax((int)__builtin_amdgcn_ubfe(__float_as_int(q.x), 23, 8),
+                                      (int)__builtin_amdgcn_ubfe(__float_as_int(q.y), 23, 8));
+                q = q * __int_as_float(0x7F000000 - (fmax << 23));
+                const int qe = pe + fmax - 127;
+                // z = Z' + q         (orbit bigger, gap in [0,120)); z is NOT reduced (see header comment)
+                const int nd3 = qe - Zne;
+                const f2 zm = Znm + q * __int_as_float((nd3 << 23) + 0x3F800000);
+                const f2 zz = zm * zm;
+                const float zn2 = zz.x + zz.y;
+                const f2 qq = q * q;
+                const float dn2 = qq.x + qq.y; // in [1,8): q's larger part is in [1,2)
+                // With both norms positive normal floats, Reduce(|z|^2) > 256 and Reduce(|z|^2) < Reduce(|dz|^2)
+                // (lexicographic on (exp, mantissa in [1,2))) are plain value comparisons:
+                //   zn2 * 2^(2 Zne) > 2^8            <=>  zn2 > 2^(8 - 2 Zne)          (= zv.w, exact power of two)
+                //   zn2 * 2^(2 Zne) < dn2 * 2^(2 qe)  <=>  zn2 < dn2 * 2^(2 nd3)        (exact scaling; an underflow can
+                //                                                                       only make the rhs <= min normal <= zn2)
+                bool escaped = zn2 > zv.w;
+                bool rebase = zn2 < __builtin_amdgcn_ldexpf(dn2, nd3 + nd3);
+                const bool ok = imax(imax(nd1, nd3), nd2) <= 0 && (nd1 < nd3 ? nd1 : nd3) > -kExpDiffIgnored &&
+                                fmax != 0 && __builtin_amdgcn_classf(zn2, 0x100 /* +normal */);
+                hcplx32 z;
+                bool reduced_z = false;
+                if (__ballot(!ok) != 0ull) {
                     // ---- generic step, literal order of Fractal.cpp:2646-2661
-                    hcplx32 cur = hc_mul2(Zc);
-                    cur = hc_add(cur, dz);
-                    ndz = hc_mul(dz, cur);
+                    const hcplx32 Zc_g{Zcm.x, Zcm.y, Zce1 - 1};
+                    const hcplx32 dz_g{dzm.x, dzm.y, dze};
+                    hcplx32 curg = hc_mul2(Zc_g);
+                    curg = hc_add(curg, dz_g);
+                    hcplx32 ndz = hc_mul(dz_g, curg);
                     ndz = hc_add(ndz, dc);
                     hc_reduce(ndz);
-                    z = hc_add(Zn, ndz);
+                    z = hc_add(hcplx32{Znm.x, Znm.y, Zne}, ndz);
                     hc_reduce(z);
                     const hreal32 n = hr_reduced(hc_norm2(z));
-                    kn = key_of(n.m, n.e);
+                    const hreal32 dn = hr_reduced(hc_norm2(ndz));
+                    escaped = hr_cmp_pos(n, hreal32{1.0f, 8}) > 0;
+                    rebase = hr_cmp_pos(n, dn) < 0;
+                    q = (f2){ndz.re, ndz.im};
+                    dze = ndz.e;
+                    reduced_z = true;
+                } else {
+                    z = hcplx32{zm.x, zm.y, Zne};
+                    dze = qe;
                 }
                 if (kStats)
                     c_pt++;
                 ref++;
-                const long long kd = norm_key(ndz.re, ndz.im, ndz.e);
-                dz = ndz;
-                Zc = Zn;
-                if (kn > key256) {
-                    running = false; // escaped: `break` happens before iterations++ in the CPU loop
+                dzm = q;
+                Zcm = Znm;
+                Zce1 = Zne + 1;
+                if (escaped) {
+                    running = false; // `break` happens before iterations++ in the CPU loop
                 } else {
-                    if (kn < kd || ref >= MaxRefIteration) {
-                        hc_reduce(z); // idempotent on the generic path
-                        dz = z;
+                    if (rebase || ref >= MaxRefIteration) {
+                        if (!reduced_z)
+                            hc_reduce(z);
+                        dzm = (f2){z.re, z.im};
+                        dze = z.e;
                         ref = 0;
-                        Zc = zref_at(zr, 0);
+                        const float4 z0 = zr[0];
+                        Zcm = (f2){z0.x, z0.y};
+                        Zce1 = __float_as_int(z0.z) + 1;
                     }
                     iterations++;
                     running = iterations < n_iterations;
