@@ -73,7 +73,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # FS_FORCE_DIST=1 exercises the RCCL gather path with a single rank (1-GPU boxes)
+    distributed = world > 1 or os.environ.get("FS_FORCE_DIST") == "1"
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
