@@ -50,9 +50,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--width", type=int, default=3840)
-    ap.add_argument("--height", type=int, default=2160)
-    ap.add_argument("--view", type=int, default=5)
+    ap.add_argument("--workload", choices=["c3_lav2", "c2_po", "c5_bla"], default="c3_lav2",
+                    help="c3_lav2 (default, the headline config): View 5 3840x2160 HDRx32 LAv2 Full; "
+                         "c2_po: View 5 1920x1080 HDRx32 perturbation only; c5_bla: View 19 7680x4320 HDRx32 BLA")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--view", type=int, default=-1)
     ap.add_argument("--parity", choices=["cpu", "cpu_gpustage"], default="cpu",
                     help="cpu = literal reference CPU function (bit-exact vs Cpu32PerturbedBLAV2HDR); "
                          "cpu_gpustage = same arithmetic, LA stage test in the GPU/FractalZoomer direction")
@@ -91,20 +94,39 @@ def main():
         raise RuntimeError("no usable HIP device; there is no CPU fallback")
 
     # ---- inputs (host, outside the timed region)
+    defaults = {"c3_lav2": (5, 3840, 2160), "c2_po": (5, 1920, 1080), "c5_bla": (19, 7680, 4320)}[args.workload]
+    if args.view < 0:
+        args.view = defaults[0]
+    if args.width <= 0:
+        args.width = defaults[1]
+    if args.height <= 0:
+        args.height = defaults[2]
     t0 = time.time()
     view = inputs.View.builtin(args.view, args.width, args.height, antialiasing=1)
     orbit = inputs.Orbit(view)
-    la = inputs.LATable(orbit)
+    la = inputs.LATable(orbit, host_threads=effective_cpus()) if args.workload == "c3_lav2" else None
+    bla = inputs.BLATable(orbit) if args.workload == "c5_bla" else None
     t_inputs = time.time() - t0
     W, H = view.width, view.height
     n_iter = view.num_iterations
     parity = PARITY_CPU if args.parity == "cpu" else PARITY_CPU_GPUSTAGE
-    coords = [(float(c["m"]), int(c["e"])) for c in view.coords_perturb_hdr32(orbit)]
+    coords_arr = view.coords_perturb_hdr32(orbit)
+    coords = [(float(c["m"]), int(c["e"])) for c in coords_arr]
 
     r = GPURenderer(local_rank)
     err = r.InitializeMemory(W, H, 1, None, 0, 0, 0, False)
     assert err == 0, GPURenderer.ConvertErrorToString(err)
-    assert r.InitializePerturb(1, orbit, 0, None, la) == 0
+    if args.workload == "c3_lav2":
+        assert r.InitializePerturb(1, orbit, 0, None, la) == 0
+    else:
+        # the reference re-uploads orbit + BLA table inside every RenderPerturbBLA call (GPU_Render.cu:1464-1479);
+        # here they are uploaded once, outside the timed region (inputs resident in HBM)
+        lib = r._lib
+        assert lib.fs_upload_orbit(r._h, 1, T_HDR32, 4, orbit.data_ptr, orbit.count, orbit.count, orbit.period) == 0
+        if bla is not None:
+            assert lib.fs_upload_bla(r._h, T_HDR32, bla.level_ptrs, bla.level_sizes, bla.num_levels, bla.lm2) == 0
+        else:
+            assert lib.fs_upload_bla(r._h, T_HDR32, None, None, 0, 0) == 0
     band = tiling.band_height(1)
     rw = r.rounded_width
     if distributed:
@@ -118,7 +140,10 @@ def main():
     steps_executed = []
 
     def one_frame(record):
-        e = r.RenderPerturbLAv2(None, None, None, *coords, n_iter, T=T_HDR32, Mode=LAV2_FULL, parity=parity)
+        if args.workload == "c3_lav2":
+            e = r.RenderPerturbLAv2(None, None, None, *coords, n_iter, T=T_HDR32, Mode=LAV2_FULL, parity=parity)
+        else:
+            e = r._lib.fs_render_bla(r._h, T_HDR32, coords_arr.ctypes.data, n_iter)
         assert e == 0, GPURenderer.ConvertErrorToString(e)
         assert r.SyncComputeStream() == 0
         frame = None
@@ -198,7 +223,10 @@ def main():
         _oracle.lib()  # build / load outside the timed window
         _oracle.set_row_step(step)
         t1 = time.perf_counter()
-        ref = _oracle.lav2_hdr32(view, orbit, la, rows=(y0, H), threads=threads, stage_test=stage_test)
+        if args.workload == "c3_lav2":
+            ref = _oracle.lav2_hdr32(view, orbit, la, rows=(y0, H), threads=threads, stage_test=stage_test)
+        else:
+            ref = _oracle.bla_hdr32(view, orbit, bla, rows=(y0, H), threads=threads)
         cpu_t = time.perf_counter() - t1
         _oracle.set_row_step(1)
         refs = [(y, ref[y]) for y in rows]
@@ -214,17 +242,21 @@ def main():
         value = W * H * args.steps / elapsed / 1e6
         achieved = perturb_steps * FLOP_PER_STEP / (avg_kernel_ms * 1e-3) / 1e12
         line = {
-            "metric": "Mpix/s (iteration buffer), View #5 3840x2160 HDRx32 LAv2",
+            "metric": "Mpix/s (iteration buffer), View #5 3840x2160 HDRx32 LAv2" if args.workload == "c3_lav2"
+            else "Mpix/s (iteration buffer), " + args.workload,
             "value": round(value, 4), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32+i32exp", "data": "synthetic",
-            "config": {"workload": "view%d_%dx%d_hdrx32_lav2_full" % (args.view, W, H), "parity": args.parity,
-                       "n_iterations": n_iter, "orbit_entries": orbit.count, "la_records": la.count,
-                       "la_stages": la.stage_count, "tiling": "rows/8-row bands interleaved x%d" % world,
+            "config": {"workload": "view%d_%dx%d_hdrx32_%s" % (args.view, W, H, {"c3_lav2": "lav2_full", "c2_po": "po",
+                                                                                "c5_bla": "bla"}[args.workload]),
+                       "parity": args.parity, "n_iterations": n_iter, "orbit_entries": orbit.count,
+                       "la_records": la.count if la else 0, "la_stages": la.stage_count if la else 0,
+                       "bla_levels": bla.num_levels if bla else 0, "tiling": "rows/8-row bands interleaved x%d" % world,
                        "host_input_build_s": round(t_inputs, 3)},
             "roofline": {"bound": "valu", "achieved": round(achieved, 4), "peak": PEAK_FP32_VECTOR_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 5), "traffic": None,
-                         "kernel": "k_lav2_hdr32", "kernel_ms": round(avg_kernel_ms, 3),
+                         "kernel": "k_lav2_hdr32_fast" if args.workload == "c3_lav2" else "k_perturb_scalar_hdr32",
+                         "kernel_ms": round(avg_kernel_ms, 3),
                          "pixel_steps_per_launch": perturb_steps, "at_iterations_per_launch": at_iters,
                          "la_steps_per_launch": la_steps, "flop_per_pixel_step": FLOP_PER_STEP,
                          "lane_utilisation_rank0": round(perturb_steps / lane_slots, 4) if lane_slots and not distributed else None},

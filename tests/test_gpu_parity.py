@@ -236,3 +236,34 @@ def test_literal_variant_small_fixture(renderer, v5_small):
     finally:
         renderer.set_kernel_variant(literal=False)
     assert np.array_equal(out, GOLD["view5_lav2_cpu_64x36"])
+
+
+def test_view19_bla_parity_small(renderer, native_libs):
+    """C5 arithmetic: View 19 (zoom 1e158, 412 729-entry orbit, 113 M iterations, 20-level BLA table) at 64x36."""
+    v = inputs.View.builtin(19, 64, 36)
+    ob = inputs.Orbit(v)
+    bla = inputs.BLATable(ob)
+    r = renderer
+    assert r.InitializeMemory(64, 36, 1, None, 0, 0, 0, False) == 0
+    dx, dy, cx, cy = _pairs(v.coords_perturb_hdr32(ob))
+    assert r.RenderPerturbBLA(None, ob, bla, None, None, dx, dy, cx, cy, v.num_iterations) == 0
+    out = r.new_iter_buffer()
+    assert r.RenderCurrent(v.num_iterations, out) == 0
+    assert r.SyncComputeStream() == 0
+    assert np.array_equal(out, _oracle.bla_hdr32(v, ob, bla))
+
+
+def test_view5_po_parity_rows_1080p(renderer, native_libs):
+    """C2 at its BASELINE size (1920x1080): PO entry point vs the BLA function's single-step branch on sample rows."""
+    v = inputs.View.builtin(5, 1920, 1080)
+    ob = inputs.Orbit(v)
+    la = inputs.LATable(ob)
+    out, red = _render_lav2(renderer, v, ob, la, LAV2_PO, PARITY_CPU)
+    _oracle.set_row_step(270)
+    try:
+        ref = _oracle.bla_hdr32(v, ob, None, rows=(135, 1080), threads=16)
+    finally:
+        _oracle.set_row_step(1)
+    for y in range(135, 1080, 270):
+        assert np.array_equal(out[y], ref[y]), y
+    assert red.Sum == int(out[:1080, :1920].astype(np.uint64).sum())
