@@ -29,7 +29,22 @@ class Reduction(C.Structure):
     _fields_ = [("Min", u64), ("Max", u64), ("Sum", u64)]
 
 
-assert C.sizeof(AtHdr32) == 116
+class RealHdr64(C.Structure):
+    _fields_ = [("m", C.c_double), ("e", C.c_int32), ("pad_", C.c_int32)]
+
+
+class CplxHdr64(C.Structure):
+    _fields_ = [("re", C.c_double), ("im", C.c_double), ("e", C.c_int32), ("pad_", C.c_int32)]
+
+
+class AtHdr64(C.Structure):
+    _fields_ = [("StepLength", u32), ("pad_", u32), ("ThresholdC", RealHdr64), ("SqrEscapeRadius", RealHdr64),
+                ("RefC", CplxHdr64), ("ZCoeff", CplxHdr64), ("CCoeff", CplxHdr64), ("InvZCoeff", CplxHdr64),
+                ("CCoeffSqrInvZCoeff", CplxHdr64), ("CCoeffInvZCoeff", CplxHdr64),
+                ("CCoeffNormSqr", RealHdr64), ("RefCNormSqr", RealHdr64), ("factor", RealHdr64)]
+
+
+assert C.sizeof(AtHdr32) == 116 and C.sizeof(AtHdr64) == 232
 
 DONE_CB = C.CFUNCTYPE(None, vp)
 
@@ -109,6 +124,8 @@ def inputs_lib():
     _decl(lib, "fsh_view_precision_bits", u64, [vp])
     _decl(lib, "fsh_view_bbox_str", C.c_int, [vp, C.c_int, C.c_char_p, C.c_size_t])
     _decl(lib, "fsh_view_coords_direct_f64", None, [vp, u32, u32, vp])
+    _decl(lib, "fsh_view_coords_direct_hdr32", None, [vp, u32, u32, vp])
+    _decl(lib, "fsh_view_coords_direct_hdr64", None, [vp, u32, u32, vp])
     _decl(lib, "fsh_orbit_create", vp, [vp, C.c_int, u64, C.c_int])
     _decl(lib, "fsh_orbit_destroy", None, [vp])
     _decl(lib, "fsh_orbit_count", u64, [vp])
@@ -119,6 +136,8 @@ def inputs_lib():
     _decl(lib, "fsh_view_coords_perturb_hdr32", None, [vp, vp, u32, u32, vp])
     _decl(lib, "fsh_view_coords_perturb_hdr64", None, [vp, vp, u32, u32, vp])
     _decl(lib, "fsh_la_create_hdr32", vp, [vp, C.c_int])
+    _decl(lib, "fsh_la_create", vp, [vp, C.c_int])
+    _decl(lib, "fsh_la_is64", C.c_int, [vp])
     _decl(lib, "fsh_la_destroy", None, [vp])
     _decl(lib, "fsh_la_count", u32, [vp])
     _decl(lib, "fsh_la_data", vp, [vp])
@@ -128,6 +147,7 @@ def inputs_lib():
     _decl(lib, "fsh_la_use_at", C.c_int, [vp])
     _decl(lib, "fsh_la_at", None, [vp, vp])
     _decl(lib, "fsh_bla_create_hdr32", vp, [vp])
+    _decl(lib, "fsh_bla_create", vp, [vp])
     _decl(lib, "fsh_bla_destroy", None, [vp])
     _decl(lib, "fsh_bla_num_levels", i32, [vp])
     _decl(lib, "fsh_bla_lm2", i32, [vp])

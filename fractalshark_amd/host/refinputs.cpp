@@ -237,6 +237,33 @@ extern "C" void fsh_view_coords_direct_f64(const fsh_view *v, uint32_t w_aa, uin
     out[3] = mpf_get_d(v->maxY.v);
 }
 
+// CpuHDR32 / CpuHDR64 (CalcCpuHDR<.., HDRFloat<F>, F>): dx, dy, minX, maxY as HDRFloat built from mpf
+// (Fractal.cpp:2118-2119,2148-2151): mantissa in [0.5,1), NOT reduced.
+template <class F> static void direct_hdr_coords(const fsh_view &v, uint32_t w_aa, uint32_t h_aa, hreal<F> out[4])
+{
+    mpf_set_default_prec(v.prec_bits);
+    Mp dx = (v.maxX - v.minX) / Mp::from_ui(w_aa);
+    Mp dy = (v.maxY - v.minY) / Mp::from_ui(h_aa);
+    out[0] = hr_from_mpf<F>(dx.v);
+    out[1] = hr_from_mpf<F>(dy.v);
+    out[2] = hr_from_mpf<F>(v.minX.v);
+    out[3] = hr_from_mpf<F>(v.maxY.v);
+}
+extern "C" void fsh_view_coords_direct_hdr32(const fsh_view *v, uint32_t w_aa, uint32_t h_aa, fs_real_hdr32 out[4])
+{
+    hreal<float> t[4];
+    direct_hdr_coords<float>(*v, w_aa, h_aa, t);
+    for (int i = 0; i < 4; i++)
+        out[i] = fs_real_hdr32{t[i].m, t[i].e};
+}
+extern "C" void fsh_view_coords_direct_hdr64(const fsh_view *v, uint32_t w_aa, uint32_t h_aa, fs_real_hdr64 out[4])
+{
+    hreal<double> t[4];
+    direct_hdr_coords<double>(*v, w_aa, h_aa, t);
+    for (int i = 0; i < 4; i++)
+        out[i] = fs_real_hdr64{t[i].m, t[i].e, 0};
+}
+
 // ------------------------------------------------------------------ reference orbit
 template <class F> struct OrbitT {
     std::vector<hreal<F>> x, y; // entry 0 is the explicit zero entry
@@ -1150,58 +1177,125 @@ template <class F> bool LABuilder<F>::create_stage0_mt(uint32_t maxRef, size_t T
 } // namespace
 
 struct fsh_la {
-    LATable<float> t;
+    int is64 = 0;
+    LATable<float> t32;
+    LATable<double> t64;
+    std::vector<fs_la_hdr64_u32> packed64;
 };
 
-extern "C" fsh_la *fsh_la_create_hdr32(const fsh_orbit *o, int host_threads)
+namespace {
+template <class F> void pack_la(const LATable<F> &t, std::vector<fs_la_hdr32_u32> *o32, std::vector<fs_la_hdr64_u32> *o64)
 {
-    if (o->is64)
-        return nullptr;
-    auto la = std::make_unique<fsh_la>();
-    LABuilder<float> b(o->f, la->t);
-    b.generate(host_threads < 1 ? 1 : host_threads);
-    auto &t = la->t;
-    t.packed32.resize(t.las.size());
     for (size_t k = 0; k < t.las.size(); k++) {
         const auto &s = t.las[k];
-        fs_la_hdr32_u32 r;
-        r.Ref = fs_cplx_hdr32{s.Ref.re, s.Ref.im, s.Ref.e};
-        r.ZCoeff = fs_cplx_hdr32{s.ZCoeff.re, s.ZCoeff.im, s.ZCoeff.e};
-        r.CCoeff = fs_cplx_hdr32{s.CCoeff.re, s.CCoeff.im, s.CCoeff.e};
-        r.LAThreshold = fs_real_hdr32{s.LAThreshold.m, s.LAThreshold.e};
-        r.LAThresholdC = fs_real_hdr32{s.LAThresholdC.m, s.LAThresholdC.e};
-        r.MinMag = fs_real_hdr32{s.MinMag.m, s.MinMag.e};
-        r.StepLength = s.StepLength;
-        r.NextStageLAIndex = s.NextStageLAIndex;
-        t.packed32[k] = r;
+        if (o32) {
+            fs_la_hdr32_u32 r;
+            r.Ref = fs_cplx_hdr32{(float)s.Ref.re, (float)s.Ref.im, s.Ref.e};
+            r.ZCoeff = fs_cplx_hdr32{(float)s.ZCoeff.re, (float)s.ZCoeff.im, s.ZCoeff.e};
+            r.CCoeff = fs_cplx_hdr32{(float)s.CCoeff.re, (float)s.CCoeff.im, s.CCoeff.e};
+            r.LAThreshold = fs_real_hdr32{(float)s.LAThreshold.m, s.LAThreshold.e};
+            r.LAThresholdC = fs_real_hdr32{(float)s.LAThresholdC.m, s.LAThresholdC.e};
+            r.MinMag = fs_real_hdr32{(float)s.MinMag.m, s.MinMag.e};
+            r.StepLength = s.StepLength;
+            r.NextStageLAIndex = s.NextStageLAIndex;
+            o32->push_back(r);
+        } else {
+            fs_la_hdr64_u32 r;
+            memset(&r, 0, sizeof(r));
+            r.Ref = fs_cplx_hdr64{(double)s.Ref.re, (double)s.Ref.im, s.Ref.e, 0};
+            r.ZCoeff = fs_cplx_hdr64{(double)s.ZCoeff.re, (double)s.ZCoeff.im, s.ZCoeff.e, 0};
+            r.CCoeff = fs_cplx_hdr64{(double)s.CCoeff.re, (double)s.CCoeff.im, s.CCoeff.e, 0};
+            r.LAThreshold = fs_real_hdr64{(double)s.LAThreshold.m, s.LAThreshold.e, 0};
+            r.LAThresholdC = fs_real_hdr64{(double)s.LAThresholdC.m, s.LAThresholdC.e, 0};
+            r.MinMag = fs_real_hdr64{(double)s.MinMag.m, s.MinMag.e, 0};
+            r.StepLength = s.StepLength;
+            r.NextStageLAIndex = s.NextStageLAIndex;
+            o64->push_back(r);
+        }
     }
-    t.packedStages.assign(t.stages.begin(), t.stages.begin() + std::min<size_t>(t.stages.size(), t.stageCount));
+}
+} // namespace
+
+extern "C" fsh_la *fsh_la_create(const fsh_orbit *o, int host_threads)
+{
+    auto la = std::make_unique<fsh_la>();
+    la->is64 = o->is64;
+    const int th = host_threads < 1 ? 1 : host_threads;
+    if (o->is64) {
+        LABuilder<double> b(o->d, la->t64);
+        b.generate(th);
+        pack_la<double>(la->t64, nullptr, &la->packed64);
+        auto &t = la->t64;
+        t.packedStages.assign(t.stages.begin(), t.stages.begin() + std::min<size_t>(t.stages.size(), t.stageCount));
+    } else {
+        LABuilder<float> b(o->f, la->t32);
+        b.generate(th);
+        pack_la<float>(la->t32, &la->t32.packed32, nullptr);
+        auto &t = la->t32;
+        t.packedStages.assign(t.stages.begin(), t.stages.begin() + std::min<size_t>(t.stages.size(), t.stageCount));
+    }
     return la.release();
 }
-extern "C" void fsh_la_destroy(fsh_la *l) { delete l; }
-extern "C" uint32_t fsh_la_count(const fsh_la *l) { return (uint32_t)l->t.packed32.size(); }
-extern "C" const fs_la_hdr32_u32 *fsh_la_data(const fsh_la *l) { return l->t.packed32.data(); }
-extern "C" uint32_t fsh_la_stage_count(const fsh_la *l) { return l->t.stageCount; }
-extern "C" const fs_la_stage_u32 *fsh_la_stages(const fsh_la *l) { return l->t.packedStages.data(); }
-extern "C" int fsh_la_is_valid(const fsh_la *l) { return l->t.isValid ? 1 : 0; }
-extern "C" int fsh_la_use_at(const fsh_la *l) { return l->t.useAT ? 1 : 0; }
-extern "C" void fsh_la_at(const fsh_la *l, fs_at_hdr32_u32 *out)
+extern "C" fsh_la *fsh_la_create_hdr32(const fsh_orbit *o, int host_threads)
 {
-    const auto &a = l->t.at;
-    auto R = [](hreal<float> h) { return fs_real_hdr32{h.m, h.e}; };
-    auto C = [](hcplx<float> c) { return fs_cplx_hdr32{c.re, c.im, c.e}; };
-    out->StepLength = a.StepLength;
-    out->ThresholdC = R(a.ThresholdC);
-    out->SqrEscapeRadius = R(a.SqrEscapeRadius);
-    out->RefC = C(a.RefC);
-    out->ZCoeff = C(a.ZCoeff);
-    out->CCoeff = C(a.CCoeff);
-    out->InvZCoeff = C(a.InvZCoeff);
-    out->CCoeffSqrInvZCoeff = C(a.CCoeffSqrInvZCoeff);
-    out->CCoeffInvZCoeff = C(a.CCoeffInvZCoeff);
-    out->CCoeffNormSqr = R(a.CCoeffNormSqr);
-    out->RefCNormSqr = R(a.RefCNormSqr);
-    out->factor = R(a.factor);
+    return o->is64 ? nullptr : fsh_la_create(o, host_threads);
+}
+extern "C" void fsh_la_destroy(fsh_la *l) { delete l; }
+extern "C" int fsh_la_is64(const fsh_la *l) { return l->is64; }
+extern "C" uint32_t fsh_la_count(const fsh_la *l)
+{
+    return l->is64 ? (uint32_t)l->packed64.size() : (uint32_t)l->t32.packed32.size();
+}
+extern "C" const void *fsh_la_data(const fsh_la *l)
+{
+    return l->is64 ? (const void *)l->packed64.data() : (const void *)l->t32.packed32.data();
+}
+extern "C" uint32_t fsh_la_stage_count(const fsh_la *l) { return l->is64 ? l->t64.stageCount : l->t32.stageCount; }
+extern "C" const fs_la_stage_u32 *fsh_la_stages(const fsh_la *l)
+{
+    return l->is64 ? l->t64.packedStages.data() : l->t32.packedStages.data();
+}
+extern "C" int fsh_la_is_valid(const fsh_la *l) { return (l->is64 ? l->t64.isValid : l->t32.isValid) ? 1 : 0; }
+extern "C" int fsh_la_use_at(const fsh_la *l) { return (l->is64 ? l->t64.useAT : l->t32.useAT) ? 1 : 0; }
+// out: fs_at_hdr32_u32 (116 B) or fs_at_hdr64_u32 (232 B) depending on fsh_la_is64().
+extern "C" void fsh_la_at(const fsh_la *l, void *outp)
+{
+    if (!l->is64) {
+        const auto &a = l->t32.at;
+        fs_at_hdr32_u32 *out = (fs_at_hdr32_u32 *)outp;
+        auto R = [](hreal<float> h) { return fs_real_hdr32{h.m, h.e}; };
+        auto C = [](hcplx<float> c) { return fs_cplx_hdr32{c.re, c.im, c.e}; };
+        out->StepLength = a.StepLength;
+        out->ThresholdC = R(a.ThresholdC);
+        out->SqrEscapeRadius = R(a.SqrEscapeRadius);
+        out->RefC = C(a.RefC);
+        out->ZCoeff = C(a.ZCoeff);
+        out->CCoeff = C(a.CCoeff);
+        out->InvZCoeff = C(a.InvZCoeff);
+        out->CCoeffSqrInvZCoeff = C(a.CCoeffSqrInvZCoeff);
+        out->CCoeffInvZCoeff = C(a.CCoeffInvZCoeff);
+        out->CCoeffNormSqr = R(a.CCoeffNormSqr);
+        out->RefCNormSqr = R(a.RefCNormSqr);
+        out->factor = R(a.factor);
+    } else {
+        const auto &a = l->t64.at;
+        fs_at_hdr64_u32 *out = (fs_at_hdr64_u32 *)outp;
+        memset(out, 0, sizeof(*out));
+        auto R = [](hreal<double> h) { return fs_real_hdr64{h.m, h.e, 0}; };
+        auto C = [](hcplx<double> c) { return fs_cplx_hdr64{c.re, c.im, c.e, 0}; };
+        out->StepLength = a.StepLength;
+        out->ThresholdC = R(a.ThresholdC);
+        out->SqrEscapeRadius = R(a.SqrEscapeRadius);
+        out->RefC = C(a.RefC);
+        out->ZCoeff = C(a.ZCoeff);
+        out->CCoeff = C(a.CCoeff);
+        out->InvZCoeff = C(a.InvZCoeff);
+        out->CCoeffSqrInvZCoeff = C(a.CCoeffSqrInvZCoeff);
+        out->CCoeffInvZCoeff = C(a.CCoeffInvZCoeff);
+        out->CCoeffNormSqr = R(a.CCoeffNormSqr);
+        out->RefCNormSqr = R(a.RefCNormSqr);
+        out->factor = R(a.factor);
+    }
 }
 
 // ------------------------------------------------------------------ BLA table
@@ -1320,35 +1414,54 @@ template <class F> struct BlaBuilder {
 } // namespace
 
 struct fsh_bla {
-    std::vector<std::vector<fs_bla_hdr32>> levels;
-    std::vector<const fs_bla_hdr32 *> ptrs;
+    int is64 = 0;
+    std::vector<std::vector<fs_bla_hdr32>> levels32;
+    std::vector<std::vector<fs_bla_hdr64>> levels64;
+    std::vector<const void *> ptrs;
     std::vector<uint64_t> sizes;
     int32_t lm2 = 0;
 };
 
-extern "C" fsh_bla *fsh_bla_create_hdr32(const fsh_orbit *o)
+extern "C" fsh_bla *fsh_bla_create(const fsh_orbit *o)
 {
-    if (o->is64)
-        return nullptr;
-    BlaBuilder<float> b(o->f);
-    b.init(o->f.x.size(), o->f.maxRadius);
     auto r = std::make_unique<fsh_bla>();
-    r->lm2 = b.LM2;
-    r->levels.resize(b.B.size());
-    for (size_t l = 0; l < b.B.size(); l++) {
-        r->levels[l].resize(b.B[l].size());
-        for (size_t k = 0; k < b.B[l].size(); k++) {
-            const auto &s = b.B[l][k];
-            auto R = [](hreal<float> h) { return fs_real_hdr32{h.m, h.e}; };
-            r->levels[l][k] = fs_bla_hdr32{R(s.r2), R(s.Ax), R(s.Ay), R(s.Bx), R(s.By), s.l};
+    r->is64 = o->is64;
+    if (!o->is64) {
+        BlaBuilder<float> b(o->f);
+        b.init(o->f.x.size(), o->f.maxRadius);
+        r->lm2 = b.LM2;
+        r->levels32.resize(b.B.size());
+        for (size_t l = 0; l < b.B.size(); l++) {
+            r->levels32[l].resize(b.B[l].size());
+            for (size_t k = 0; k < b.B[l].size(); k++) {
+                const auto &s = b.B[l][k];
+                auto R = [](hreal<float> h) { return fs_real_hdr32{h.m, h.e}; };
+                r->levels32[l][k] = fs_bla_hdr32{R(s.r2), R(s.Ax), R(s.Ay), R(s.Bx), R(s.By), s.l};
+            }
+            r->ptrs.push_back(r->levels32[l].empty() ? nullptr : (const void *)r->levels32[l].data());
+            r->sizes.push_back(r->levels32[l].size());
         }
-        r->ptrs.push_back(r->levels[l].empty() ? nullptr : r->levels[l].data());
-        r->sizes.push_back(r->levels[l].size());
+    } else {
+        BlaBuilder<double> b(o->d);
+        b.init(o->d.x.size(), o->d.maxRadius);
+        r->lm2 = b.LM2;
+        r->levels64.resize(b.B.size());
+        for (size_t l = 0; l < b.B.size(); l++) {
+            r->levels64[l].resize(b.B[l].size());
+            for (size_t k = 0; k < b.B[l].size(); k++) {
+                const auto &s = b.B[l][k];
+                auto R = [](hreal<double> h) { return fs_real_hdr64{h.m, h.e, 0}; };
+                r->levels64[l][k] = fs_bla_hdr64{R(s.r2), R(s.Ax), R(s.Ay), R(s.Bx), R(s.By), s.l, 0};
+            }
+            r->ptrs.push_back(r->levels64[l].empty() ? nullptr : (const void *)r->levels64[l].data());
+            r->sizes.push_back(r->levels64[l].size());
+        }
     }
     return r.release();
 }
+extern "C" fsh_bla *fsh_bla_create_hdr32(const fsh_orbit *o) { return o->is64 ? nullptr : fsh_bla_create(o); }
 extern "C" void fsh_bla_destroy(fsh_bla *b) { delete b; }
-extern "C" int32_t fsh_bla_num_levels(const fsh_bla *b) { return (int32_t)b->levels.size(); }
+extern "C" int32_t fsh_bla_num_levels(const fsh_bla *b) { return (int32_t)b->ptrs.size(); }
 extern "C" int32_t fsh_bla_lm2(const fsh_bla *b) { return b->lm2; }
-extern "C" const fs_bla_hdr32 *const *fsh_bla_level_ptrs(const fsh_bla *b) { return b->ptrs.data(); }
+extern "C" const void *const *fsh_bla_level_ptrs(const fsh_bla *b) { return b->ptrs.data(); }
 extern "C" const uint64_t *fsh_bla_level_sizes(const fsh_bla *b) { return b->sizes.data(); }

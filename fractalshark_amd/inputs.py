@@ -26,6 +26,11 @@ LA_HDR32_DTYPE = np.dtype([
 BLA_HDR32_DTYPE = np.dtype([("r2_m", "<f4"), ("r2_e", "<i4"), ("Ax_m", "<f4"), ("Ax_e", "<i4"),
                             ("Ay_m", "<f4"), ("Ay_e", "<i4"), ("Bx_m", "<f4"), ("Bx_e", "<i4"),
                             ("By_m", "<f4"), ("By_e", "<i4"), ("l", "<i4")])
+ORBIT_HDR64_DTYPE = np.dtype([("mx", "<f8"), ("ex", "<i4"), ("pad0", "<i4"), ("ey", "<i4"), ("pad1", "<i4"),
+                              ("my", "<f8")])
+REAL_HDR32 = np.dtype([("m", "<f4"), ("e", "<i4")])
+REAL_HDR64 = np.dtype([("m", "<f8"), ("e", "<i4"), ("pad_", "<i4")])
+assert ORBIT_HDR64_DTYPE.itemsize == 32 and REAL_HDR64.itemsize == 16
 assert ORBIT_HDR32_DTYPE.itemsize == 16 and LA_HDR32_DTYPE.itemsize == 68 and BLA_HDR32_DTYPE.itemsize == 44
 
 
@@ -85,19 +90,37 @@ class View:
     def coords_perturb_hdr32(self, orbit, aa=None):
         """{dx, dy, centerX, centerY} as 4 x {float mantissa, int32 exp} (8 x 4 bytes)."""
         aa = self.antialiasing if aa is None else aa
-        out = np.zeros(4, np.dtype([("m", "<f4"), ("e", "<i4")]))
+        out = np.zeros(4, REAL_HDR32)
         self._lib.fsh_view_coords_perturb_hdr32(self._h, orbit._h, self.width * aa, self.height * aa, out.ctypes.data)
+        return out
+
+    def coords_perturb(self, orbit, aa=None):
+        """{dx, dy, centerX, centerY} in the orbit's type (hdr32 or hdr64 records)."""
+        if not orbit.is64:
+            return self.coords_perturb_hdr32(orbit, aa)
+        aa = self.antialiasing if aa is None else aa
+        out = np.zeros(4, REAL_HDR64)
+        self._lib.fsh_view_coords_perturb_hdr64(self._h, orbit._h, self.width * aa, self.height * aa, out.ctypes.data)
+        return out
+
+    def coords_direct_hdr(self, is64, aa=None):
+        """{dx, dy, minX, maxY} as un-reduced HDRFloat records (CpuHDR32 / CpuHDR64)."""
+        aa = self.antialiasing if aa is None else aa
+        out = np.zeros(4, REAL_HDR64 if is64 else REAL_HDR32)
+        fn = self._lib.fsh_view_coords_direct_hdr64 if is64 else self._lib.fsh_view_coords_direct_hdr32
+        fn(self._h, self.width * aa, self.height * aa, out.ctypes.data)
         return out
 
 
 class Orbit:
     """Reference orbit at the view centre (PerturbationResults<uint32_t, HDRFloat<float>, Disable> layout)."""
 
-    def __init__(self, view, max_iter=None, periodicity=True):
+    def __init__(self, view, max_iter=None, periodicity=True, is64=False):
         self._lib = _capi.inputs_lib()
         self.view = view
+        self.is64 = bool(is64)
         n = view.num_iterations if max_iter is None else max_iter
-        self._h = self._lib.fsh_orbit_create(view._h, 0, n, 1 if periodicity else 0)
+        self._h = self._lib.fsh_orbit_create(view._h, 1 if is64 else 0, n, 1 if periodicity else 0)
         if not self._h:
             raise RuntimeError("fsh_orbit_create failed")
         self.count = self._lib.fsh_orbit_count(self._h)
@@ -110,11 +133,12 @@ class Orbit:
 
     @property
     def data_ptr(self):
-        return self._lib.fsh_orbit_data_hdr32(self._h)
+        return self._lib.fsh_orbit_data_hdr64(self._h) if self.is64 else self._lib.fsh_orbit_data_hdr32(self._h)
 
     def entries(self):
-        buf = (C.c_uint8 * (self.count * 16)).from_address(self.data_ptr)
-        return np.frombuffer(buf, dtype=ORBIT_HDR32_DTYPE).copy()
+        dt = ORBIT_HDR64_DTYPE if self.is64 else ORBIT_HDR32_DTYPE
+        buf = (C.c_uint8 * (self.count * dt.itemsize)).from_address(self.data_ptr)
+        return np.frombuffer(buf, dtype=dt).copy()
 
 
 class LATable:
@@ -123,14 +147,15 @@ class LATable:
     def __init__(self, orbit, host_threads=8):
         self._lib = _capi.inputs_lib()
         self.orbit = orbit
-        self._h = self._lib.fsh_la_create_hdr32(orbit._h, host_threads)
+        self.is64 = orbit.is64
+        self._h = self._lib.fsh_la_create(orbit._h, host_threads)
         if not self._h:
-            raise RuntimeError("fsh_la_create_hdr32 failed")
+            raise RuntimeError("fsh_la_create failed")
         self.count = self._lib.fsh_la_count(self._h)
         self.stage_count = self._lib.fsh_la_stage_count(self._h)
         self.is_valid = bool(self._lib.fsh_la_is_valid(self._h))
         self.use_at = bool(self._lib.fsh_la_use_at(self._h))
-        self.at = _capi.AtHdr32()
+        self.at = _capi.AtHdr64() if self.is64 else _capi.AtHdr32()
         self._lib.fsh_la_at(self._h, C.addressof(self.at))
 
     def __del__(self):
@@ -147,6 +172,9 @@ class LATable:
         return self._lib.fsh_la_stages(self._h)
 
     def records(self):
+        if self.is64:
+            buf = (C.c_uint8 * (self.count * 128)).from_address(self.las_ptr)
+            return np.frombuffer(buf, dtype=np.uint8).reshape(-1, 128).copy()
         buf = (C.c_uint8 * (self.count * 68)).from_address(self.las_ptr)
         return np.frombuffer(buf, dtype=LA_HDR32_DTYPE).copy()
 
@@ -161,9 +189,10 @@ class BLATable:
     def __init__(self, orbit):
         self._lib = _capi.inputs_lib()
         self.orbit = orbit
-        self._h = self._lib.fsh_bla_create_hdr32(orbit._h)
+        self.is64 = orbit.is64
+        self._h = self._lib.fsh_bla_create(orbit._h)
         if not self._h:
-            raise RuntimeError("fsh_bla_create_hdr32 failed")
+            raise RuntimeError("fsh_bla_create failed")
         self.num_levels = self._lib.fsh_bla_num_levels(self._h)
         self.lm2 = self._lib.fsh_bla_lm2(self._h)
 

@@ -33,6 +33,10 @@ uint64_t fsh_view_precision_bits(const fsh_view *v);
 /* which: 0=minX 1=minY 2=maxX 3=maxY; printf("%.Fe") of the squared bounding box. */
 int fsh_view_bbox_str(const fsh_view *v, int which, char *buf, size_t buflen);
 
+/* out = {dx, dy, minX, maxY} as un-reduced HDRFloat (CpuHDR32 / CpuHDR64 direct kernels). */
+void fsh_view_coords_direct_hdr32(const fsh_view *v, uint32_t w_aa, uint32_t h_aa, fs_real_hdr32 out[4]);
+void fsh_view_coords_direct_hdr64(const fsh_view *v, uint32_t w_aa, uint32_t h_aa, fs_real_hdr64 out[4]);
+
 /* out = {dx, dy, minX, maxY} as doubles (Cpu64 / direct kernels). */
 void fsh_view_coords_direct_f64(const fsh_view *v, uint32_t w_aa, uint32_t h_aa, double out[4]);
 
@@ -55,23 +59,26 @@ void fsh_view_coords_perturb_hdr64(const fsh_view *v, const fsh_orbit *o, uint32
 /* LAv2 table (LAReference::GenerateApproximationData).  host_threads = std::thread::hardware_concurrency()
  * of the machine being mirrored: the reference's multi-threaded stage-0 scan splits the orbit into
  * min(count/50000, host_threads) chunks and the chunking can move record boundaries. */
-fsh_la *fsh_la_create_hdr32(const fsh_orbit *o, int host_threads);
+fsh_la *fsh_la_create(const fsh_orbit *o, int host_threads);       /* type follows the orbit (hdr32 / hdr64) */
+fsh_la *fsh_la_create_hdr32(const fsh_orbit *o, int host_threads); /* NULL for an hdr64 orbit */
 void fsh_la_destroy(fsh_la *l);
+int fsh_la_is64(const fsh_la *l);
 uint32_t fsh_la_count(const fsh_la *l);
-const fs_la_hdr32_u32 *fsh_la_data(const fsh_la *l);
+const void *fsh_la_data(const fsh_la *l); /* fs_la_hdr32_u32[] or fs_la_hdr64_u32[] */
 uint32_t fsh_la_stage_count(const fsh_la *l);
 const fs_la_stage_u32 *fsh_la_stages(const fsh_la *l);
 int fsh_la_is_valid(const fsh_la *l);
 int fsh_la_use_at(const fsh_la *l);
-void fsh_la_at(const fsh_la *l, fs_at_hdr32_u32 *out);
+void fsh_la_at(const fsh_la *l, void *out); /* fs_at_hdr32_u32 or fs_at_hdr64_u32 */
 
 /* BLA table (BLAS<uint32_t,HDRFloat<float>>::Init with blaSize = orbit max radius).  Levels 0 and 1 are never
  * materialised (m_FirstLevel = 2): their pointers are NULL and sizes 0. */
-fsh_bla *fsh_bla_create_hdr32(const fsh_orbit *o);
+fsh_bla *fsh_bla_create(const fsh_orbit *o);       /* type follows the orbit */
+fsh_bla *fsh_bla_create_hdr32(const fsh_orbit *o); /* NULL for an hdr64 orbit */
 void fsh_bla_destroy(fsh_bla *b);
 int32_t fsh_bla_num_levels(const fsh_bla *b); /* m_B.size() */
 int32_t fsh_bla_lm2(const fsh_bla *b);        /* m_LM2 */
-const fs_bla_hdr32 *const *fsh_bla_level_ptrs(const fsh_bla *b);
+const void *const *fsh_bla_level_ptrs(const fsh_bla *b); /* fs_bla_hdr32[] / fs_bla_hdr64[] per level */
 const uint64_t *fsh_bla_level_sizes(const fsh_bla *b);
 
 #ifdef __cplusplus

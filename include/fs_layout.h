@@ -109,6 +109,45 @@ typedef struct fs_bla_hdr32 {
     int32_t l;
 } fs_bla_hdr32;
 
+/* HDRFloat<double> twins: LAInfoDeep<uint32_t,HDRFloat<double>,double,Disable> (128 B), ATInfo (232 B),
+ * BLA<HDRFloat<double>> (88 B). */
+typedef struct fs_la_hdr64_u32 {
+    fs_cplx_hdr64 Ref;
+    fs_cplx_hdr64 ZCoeff;
+    fs_cplx_hdr64 CCoeff;
+    fs_real_hdr64 LAThreshold;
+    fs_real_hdr64 LAThresholdC;
+    fs_real_hdr64 MinMag;
+    uint32_t StepLength;
+    uint32_t NextStageLAIndex;
+} fs_la_hdr64_u32;
+
+typedef struct fs_at_hdr64_u32 {
+    uint32_t StepLength;
+    uint32_t pad_;
+    fs_real_hdr64 ThresholdC;
+    fs_real_hdr64 SqrEscapeRadius;
+    fs_cplx_hdr64 RefC;
+    fs_cplx_hdr64 ZCoeff;
+    fs_cplx_hdr64 CCoeff;
+    fs_cplx_hdr64 InvZCoeff;
+    fs_cplx_hdr64 CCoeffSqrInvZCoeff;
+    fs_cplx_hdr64 CCoeffInvZCoeff;
+    fs_real_hdr64 CCoeffNormSqr;
+    fs_real_hdr64 RefCNormSqr;
+    fs_real_hdr64 factor;
+} fs_at_hdr64_u32;
+
+typedef struct fs_bla_hdr64 {
+    fs_real_hdr64 r2;
+    fs_real_hdr64 Ax;
+    fs_real_hdr64 Ay;
+    fs_real_hdr64 Bx;
+    fs_real_hdr64 By;
+    int32_t l;
+    int32_t pad_;
+} fs_bla_hdr64;
+
 typedef struct fs_color16 {
     uint16_t r, g, b, a;
 } fs_color16;
@@ -127,6 +166,9 @@ static_assert(sizeof(fs_la_hdr32_u32) == 68, "LA record");
 static_assert(sizeof(fs_at_hdr32_u32) == 116, "AT record");
 static_assert(sizeof(fs_bla_hdr32) == 44, "BLA record");
 static_assert(sizeof(fs_real_hdr64) == 16 && sizeof(fs_cplx_hdr64) == 24, "double HDR");
+static_assert(sizeof(fs_la_hdr64_u32) == 128, "LA record (double)");
+static_assert(sizeof(fs_at_hdr64_u32) == 232, "AT record (double)");
+static_assert(sizeof(fs_bla_hdr64) == 88, "BLA record (double)");
 #endif
 
 #endif /* FS_LAYOUT_H */

@@ -16,7 +16,9 @@
 //                         (+ LAReference::getLA/isLAStageInvalid LAReference.cpp:1076-1134,
 //                          LAInfoDeep::Prepare/Evaluate LAInfoDeep.h:395-420, LAstep::getZ LAstep.h:116-120,
 //                          ATInfo::isValid/getC/getDZ/PerformAT ATInfo.h:126-188)
-// Numeric types: a self-contained restatement of HDRFloat<float> (HpSharkFloatLib/HDRFloat.h) and
+// Every perturbation function is a template over F in {float, double} = HDRFloat<float> / HDRFloat<double>
+// (Cpu32* / Cpu64* algorithms); orc_direct_hdr{32,64} restate CalcCpuHDR<uint32_t,HDRFloat<F>,F> (CpuHDR32/64).
+// Numeric types: a self-contained restatement of HDRFloat<F> (HpSharkFloatLib/HDRFloat.h) and
 // HDRFloatComplex<float> (HDRFloatComplex.h), written independently of fractalshark_amd/csrc/hdr_math.hpp
 // (this one calls libm's scalbnf exactly like the reference; the product builds powers of two from bits).
 //
@@ -44,128 +46,147 @@ namespace {
 constexpr int32_t MINEXP = INT32_MIN >> 3; // HDRFloat.h:50-58
 constexpr int32_t DIFF_IGNORED = 120;      // HDRFloat.h:122
 
-struct H {
-    float m;
+template <class F> struct Bits;
+template <> struct Bits<float> {
+    using U = uint32_t;
+    static constexpr U EXPMASK = 0x7F800000u, KEEP = 0x807FFFFFu, ONE = 0x3F800000u;
+    static constexpr int SHIFT = 23, BIAS = 127, MULMAX = 128;
+    static float maxval() { return 3.402823466e+38f; }
+    static float scalb(int s) { return scalbnf(1.0f, s); }
+};
+template <> struct Bits<double> {
+    using U = uint64_t;
+    static constexpr U EXPMASK = 0x7FF0000000000000ull, KEEP = 0x800FFFFFFFFFFFFFull, ONE = 0x3FF0000000000000ull;
+    static constexpr int SHIFT = 52, BIAS = 1023, MULMAX = 1024;
+    static double maxval() { return 1.7976931348623157e+308; }
+    static double scalb(int s) { return scalbn(1.0, s); }
+};
+
+template <class F> struct HT {
+    F m;
     int32_t e;
 };
-struct HC {
-    float re, im;
+template <class F> struct HCT {
+    F re, im;
     int32_t e;
 };
 
-inline uint32_t f2u(float f)
+template <class F> inline typename Bits<F>::U f2u(F f)
 {
-    uint32_t u;
-    memcpy(&u, &f, 4);
+    typename Bits<F>::U u;
+    memcpy(&u, &f, sizeof(u));
     return u;
 }
-inline float u2f(uint32_t u)
+template <class F> inline F u2f(typename Bits<F>::U u)
 {
-    float f;
-    memcpy(&f, &u, 4);
+    F f;
+    memcpy(&f, &u, sizeof(f));
     return f;
 }
+template <class F> inline int32_t expField(F v) { return (int32_t)((f2u<F>(v) & Bits<F>::EXPMASK) >> Bits<F>::SHIFT); }
 
 // HDRFloat.h:497-521
-inline float getMultiplier(int32_t s)
+template <class F> inline F getMultiplier(int32_t s)
 {
-    if (s <= -127)
-        return 0.0f;
-    if (s >= 128)
-        return 3.402823466e+38f;
-    return scalbnf(1.0f, s);
+    if (s <= -Bits<F>::BIAS)
+        return F(0);
+    if (s >= Bits<F>::MULMAX)
+        return Bits<F>::maxval();
+    return Bits<F>::scalb(s);
 }
 // HDRFloat.h:523-551
-inline float getMultiplierNeg(int32_t s)
+template <class F> inline F getMultiplierNeg(int32_t s)
 {
-    if (s <= -127)
-        return 0.0f;
-    return scalbnf(1.0f, s);
+    if (s <= -Bits<F>::BIAS)
+        return F(0);
+    return Bits<F>::scalb(s);
 }
 
-// HDRFloat.h:438-457
-inline void Reduce(H &a)
+// HDRFloat.h:414-457
+template <class F> inline void Reduce(HT<F> &a)
 {
     if (a.m == 0)
         return;
-    const uint32_t bits = f2u(a.m);
-    const int32_t f_exp = (int32_t)((bits & 0x7F800000u) >> 23) - 127;
-    a.m = u2f((bits & 0x807FFFFFu) | 0x3F800000u);
+    const auto bits = f2u<F>(a.m);
+    const int32_t f_exp = (int32_t)((bits & Bits<F>::EXPMASK) >> Bits<F>::SHIFT) - Bits<F>::BIAS;
+    a.m = u2f<F>((bits & Bits<F>::KEEP) | Bits<F>::ONE);
     a.e += f_exp;
 }
-inline H Reduced(H a)
+template <class F> inline HT<F> Reduced(HT<F> a)
 {
     Reduce(a);
     return a;
 }
 // HDRFloat.h:200-204
-inline H HZero() { return H{0.0f, MINEXP}; }
+template <class F> inline HT<F> HZero() { return HT<F>{F(0), MINEXP}; }
 // HDRFloat.h:206-212 HDRFloat(T mant)
-inline H HFromMant(float v)
+template <class F> inline HT<F> HFromMant(F v)
 {
-    H r{v, 0};
+    HT<F> r{v, 0};
     Reduce(r);
     return r;
 }
-// HDRFloat.h:295-363 HDRFloat(U number), U=int
-inline H HFromInt(int n)
+// HDRFloat.h:295-363 HDRFloat(U number), U in {int, float, double}
+template <class F> inline HT<F> HFromNumber(F n)
 {
-    if (n == 0)
-        return HZero();
-    const uint32_t bits = f2u((float)n);
-    return H{u2f((bits & 0x807FFFFFu) | 0x3F800000u), (int32_t)((bits & 0x7F800000u) >> 23) - 127};
+    if (n == F(0))
+        return HZero<F>();
+    const auto bits = f2u<F>(n);
+    return HT<F>{u2f<F>((bits & Bits<F>::KEEP) | Bits<F>::ONE),
+                 (int32_t)((bits & Bits<F>::EXPMASK) >> Bits<F>::SHIFT) - Bits<F>::BIAS};
 }
+template <class F> inline HT<F> HFromInt(int n) { return HFromNumber<F>((F)n); }
 inline int32_t clampE(int32_t e) { return e < MINEXP ? MINEXP : e; }
 // HDRFloat.h:829-840
-inline H Mul(H a, H b) { return H{a.m * b.m, clampE(a.e + b.e)}; }
-// operator*(HDRFloat, const T&) with the literal 2: HDRFloat(2.0f) = {1.0f, 1}
-inline H MulBy2(H a) { return Mul(a, HFromMant(2.0f)); }
-inline H MulByFloat(H a, float f) { return Mul(a, HFromMant(f)); }
+template <class F> inline HT<F> Mul(HT<F> a, HT<F> b) { return HT<F>{a.m * b.m, clampE(a.e + b.e)}; }
+// operator*(HDRFloat, const T&): the scalar goes through HDRFloat(T mant)
+template <class F> inline HT<F> MulBy2(HT<F> a) { return Mul(a, HFromMant<F>(F(2))); }
+template <class F> inline HT<F> MulByScalar(HT<F> a, F f) { return Mul(a, HFromMant<F>(f)); }
 // HDRFloat.h:974-1000
-inline H Add(H a, H b)
+template <class F> inline HT<F> Add(HT<F> a, HT<F> b)
 {
     const int32_t expDiff = a.e - b.e;
     if (expDiff >= DIFF_IGNORED) {
         return a;
     } else if (expDiff >= 0) {
-        const float mul = getMultiplierNeg(-expDiff);
+        const F mul = getMultiplierNeg<F>(-expDiff);
         a.m = a.m + b.m * mul;
     } else if (expDiff > -DIFF_IGNORED) {
-        const float mul = getMultiplierNeg(expDiff);
+        const F mul = getMultiplierNeg<F>(expDiff);
         a.e = b.e;
         a.m = a.m * mul + b.m;
     } else {
         a.e = b.e;
         a.m = b.m;
     }
-    if (a.m == 0.0f)
+    if (a.m == F(0))
         a.e = MINEXP;
     return a;
 }
 // HDRFloat.h:1039-1065
-inline H Sub(H a, H b)
+template <class F> inline HT<F> Sub(HT<F> a, HT<F> b)
 {
     const int32_t expDiff = a.e - b.e;
     if (expDiff >= DIFF_IGNORED) {
         return a;
     } else if (expDiff >= 0) {
-        const float mul = getMultiplierNeg(-expDiff);
+        const F mul = getMultiplierNeg<F>(-expDiff);
         a.m = a.m - b.m * mul;
     } else if (expDiff > -DIFF_IGNORED) {
-        const float mul = getMultiplierNeg(expDiff);
+        const F mul = getMultiplierNeg<F>(expDiff);
         a.e = b.e;
         a.m = a.m * mul - b.m;
     } else {
         a.e = b.e;
         a.m = -b.m;
     }
-    if (a.m == 0.0f)
+    if (a.m == F(0))
         a.e = MINEXP;
     return a;
 }
-inline H Neg(H a) { return H{-a.m, a.e}; }
+template <class F> inline HT<F> Neg(HT<F> a) { return HT<F>{-a.m, a.e}; }
 // HDRFloat.h:1150-1167
-inline int CmpPosReduced(H a, H b)
+template <class F> inline int CmpPosReduced(HT<F> a, HT<F> b)
 {
     if (a.e > b.e)
         return 1;
@@ -181,31 +202,31 @@ inline int CmpPosReduced(H a, H b)
 }
 
 // HDRFloatComplex.h:166-173
-inline HC CFromH(H re, H im)
+template <class F> inline HCT<F> CFromH(HT<F> re, HT<F> im)
 {
-    HC c;
+    HCT<F> c;
     c.e = re.e > im.e ? re.e : im.e;
-    c.re = re.m * getMultiplier(re.e - c.e);
-    c.im = im.m * getMultiplier(im.e - c.e);
+    c.re = re.m * getMultiplier<F>(re.e - c.e);
+    c.im = im.m * getMultiplier<F>(im.e - c.e);
     return c;
 }
 // HDRFloatComplex.h:160-163
-inline HC CFromFloats(float re, float im) { return CFromH(HFromMant(re), HFromMant(im)); }
-inline HC CZero() { return HC{0.0f, 0.0f, MINEXP}; }
-inline H CRe(HC c) { return H{c.re, c.e}; }
-inline H CIm(HC c) { return H{c.im, c.e}; }
+template <class F> inline HCT<F> CFromScalars(F re, F im) { return CFromH(HFromMant<F>(re), HFromMant<F>(im)); }
+template <class F> inline HCT<F> CZero() { return HCT<F>{F(0), F(0), MINEXP}; }
+template <class F> inline HT<F> CRe(HCT<F> c) { return HT<F>{c.re, c.e}; }
+template <class F> inline HT<F> CIm(HCT<F> c) { return HT<F>{c.im, c.e}; }
 // HDRFloatComplex.h:219-247
-inline HC CAdd(HC a, HC v)
+template <class F> inline HCT<F> CAdd(HCT<F> a, HCT<F> v)
 {
     const int32_t expDiff = a.e - v.e;
     if (expDiff >= DIFF_IGNORED) {
         return a;
     } else if (expDiff >= 0) {
-        const float mul = getMultiplier(-expDiff);
+        const F mul = getMultiplier<F>(-expDiff);
         a.re = a.re + v.re * mul;
         a.im = a.im + v.im * mul;
     } else if (expDiff > -DIFF_IGNORED) {
-        const float mul = getMultiplier(expDiff);
+        const F mul = getMultiplier<F>(expDiff);
         a.e = v.e;
         a.re = a.re * mul + v.re;
         a.im = a.im * mul + v.im;
@@ -217,44 +238,71 @@ inline HC CAdd(HC a, HC v)
     return a;
 }
 // HDRFloatComplex.h:267-283
-inline HC CMul(HC a, HC f)
+template <class F> inline HCT<F> CMul(HCT<F> a, HCT<F> f)
 {
-    const float re = (a.re * f.re) - (a.im * f.im);
-    const float im = (a.re * f.im) + (a.im * f.re);
-    return HC{re, im, clampE(a.e + f.e)};
+    const F re = (a.re * f.re) - (a.im * f.im);
+    const F im = (a.re * f.im) + (a.im * f.re);
+    return HCT<F>{re, im, clampE(a.e + f.e)};
 }
 // HDRFloatComplex.h:334-348
-inline HC CMulH(HC a, H f) { return HC{a.re * f.m, a.im * f.m, clampE(a.e + f.e)}; }
+template <class F> inline HCT<F> CMulH(HCT<F> a, HT<F> f) { return HCT<F>{a.re * f.m, a.im * f.m, clampE(a.e + f.e)}; }
 // HDRFloatComplex.h:473-510
-inline void CReduce(HC &a)
+template <class F> inline void CReduce(HCT<F> &a)
 {
-    if (a.re == 0.0f && a.im == 0.0f)
+    if (a.re == F(0) && a.im == F(0))
         return;
-    const int32_t f_expReal = (int32_t)((f2u(a.re) & 0x7F800000u) >> 23);
-    const int32_t f_expImag = (int32_t)((f2u(a.im) & 0x7F800000u) >> 23);
-    const int32_t expDiff = (f_expReal > f_expImag ? f_expReal : f_expImag) + (-127);
+    const int32_t f_expReal = expField<F>(a.re);
+    const int32_t f_expImag = expField<F>(a.im);
+    const int32_t expDiff = (f_expReal > f_expImag ? f_expReal : f_expImag) + (-Bits<F>::BIAS);
     const int32_t expCombined = a.e + expDiff;
-    const float mul = getMultiplier(-expDiff);
+    const F mul = getMultiplier<F>(-expDiff);
     a.re *= mul;
     a.im *= mul;
     a.e = expCombined;
 }
 // HDRFloatComplex.h:544-548
-inline H CNormSq(HC a) { return H{a.re * a.re + a.im * a.im, a.e << 1}; }
+template <class F> inline HT<F> CNormSq(HCT<F> a) { return HT<F>{a.re * a.re + a.im * a.im, a.e << 1}; }
 // HDRFloatComplex.h:691-695 with HdrAbs (HDRFloat.h:1385-1404) and maxBothPositiveReduced
-inline H CCheb(HC a)
+template <class F> inline HT<F> CCheb(HCT<F> a)
 {
-    const H x{fabsf(a.re), a.e};
-    const H y{fabsf(a.im), a.e};
+    const HT<F> x{(F)fabs(a.re), a.e};
+    const HT<F> y{(F)fabs(a.im), a.e};
     return CmpPosReduced(x, y) > 0 ? x : y;
 }
 
-inline H ld(const fs_real_hdr32 &r) { return H{r.m, r.e}; }
-inline HC ld(const fs_cplx_hdr32 &c) { return HC{c.re, c.im, c.e}; }
+// Record access for the two ABI layouts (include/fs_layout.h).
+template <class F> struct Rec;
+template <> struct Rec<float> {
+    using Real = fs_real_hdr32;
+    using Cplx = fs_cplx_hdr32;
+    using Orbit = fs_orbit_hdr32;
+    using LA = fs_la_hdr32_u32;
+    using AT = fs_at_hdr32_u32;
+    using BLA = fs_bla_hdr32;
+};
+template <> struct Rec<double> {
+    using Real = fs_real_hdr64;
+    using Cplx = fs_cplx_hdr64;
+    using Orbit = fs_orbit_hdr64;
+    using LA = fs_la_hdr64_u32;
+    using AT = fs_at_hdr64_u32;
+    using BLA = fs_bla_hdr64;
+};
+inline HT<float> ld(const fs_real_hdr32 &r) { return HT<float>{r.m, r.e}; }
+inline HCT<float> ld(const fs_cplx_hdr32 &c) { return HCT<float>{c.re, c.im, c.e}; }
+inline HT<double> ld(const fs_real_hdr64 &r) { return HT<double>{r.m, r.e}; }
+inline HCT<double> ld(const fs_cplx_hdr64 &c) { return HCT<double>{c.re, c.im, c.e}; }
 
-// PerturbationResults::GetComplex<float>, PerturbationResults.h:174-185: complex built from the stored
+// PerturbationResults::GetComplex<SubType>, PerturbationResults.h:174-185: complex built from the stored
 // (un-reduced) x and y.
-inline HC OrbitAt(const fs_orbit_hdr32 *orb, uint64_t i) { return CFromH(H{orb[i].mx, orb[i].ex}, H{orb[i].my, orb[i].ey}); }
+inline HCT<float> OrbitAt(const fs_orbit_hdr32 *orb, uint64_t i)
+{
+    return CFromH(HT<float>{orb[i].mx, orb[i].ex}, HT<float>{orb[i].my, orb[i].ey});
+}
+inline HCT<double> OrbitAt(const fs_orbit_hdr64 *orb, uint64_t i)
+{
+    return CFromH(HT<double>{orb[i].mx, orb[i].ex}, HT<double>{orb[i].my, orb[i].ey});
+}
 
 // Row-claiming thread pool, Fractal.cpp:2523-2543.
 // Rows y0, y0+g_row_step, ... < y1 (g_row_step = 1 is the reference; a larger step selects an evenly spread sample
@@ -287,12 +335,14 @@ template <class RowFn> void run_rows(uint32_t y0, uint32_t y1, int threads, RowF
 }
 
 // Pixel -> delta c, Fractal.cpp:2272-2281 == 2553-2562.
-inline void pixel_delta(const H dx, const H dy, const H centerX, const H centerY, size_t x, size_t y, H &dRe, H &dIm)
+template <class F>
+inline void pixel_delta(const HT<F> dx, const HT<F> dy, const HT<F> centerX, const HT<F> centerY, size_t x, size_t y,
+                        HT<F> &dRe, HT<F> &dIm)
 {
-    H deltaReal = MulByFloat(dx, (float)x);
+    HT<F> deltaReal = MulByScalar<F>(dx, (F)x);
     Reduce(deltaReal);
     deltaReal = Sub(deltaReal, centerX);
-    H deltaImaginary = MulByFloat(Neg(dy), (float)y);
+    HT<F> deltaImaginary = MulByScalar<F>(Neg(dy), (F)y);
     Reduce(deltaImaginary);
     deltaImaginary = Sub(deltaImaginary, centerY);
     Reduce(deltaReal);
@@ -301,8 +351,8 @@ inline void pixel_delta(const H dx, const H dy, const H centerX, const H centerY
     dIm = deltaImaginary;
 }
 
-struct BlaTable {
-    const fs_bla_hdr32 *const *levels; // indexed by level; entries below firstLevel are null
+template <class F> struct BlaTable {
+    const typename Rec<F>::BLA *const *levels; // indexed by level; entries below firstLevel are null
     const uint64_t *sizes;
     int32_t n_levels; // m_B.size(); 0 = lookup suppressed
     int32_t lm2;
@@ -310,7 +360,7 @@ struct BlaTable {
 };
 
 // BLAS::LookupBackwards, BLAS.cpp:256-310
-const fs_bla_hdr32 *LookupBackwards(const BlaTable &B, size_t m, H z2)
+template <class F> const typename Rec<F>::BLA *LookupBackwards(const BlaTable<F> &B, size_t m, HT<F> z2)
 {
     if (B.n_levels == 0)
         return nullptr;
@@ -328,13 +378,13 @@ const fs_bla_hdr32 *LookupBackwards(const BlaTable &B, size_t m, H z2)
         ix = 0;
     } else {
         const float v = (float)(k & -k);
-        const uint32_t bits = f2u(v);
+        const uint32_t bits = f2u<float>(v);
         zeros = (int32_t)(bits >> 23) - 0x7f;
         ix = (uint32_t)k >> zeros;
     }
     const int32_t startLevel = (zeros <= B.lm2) ? zeros : B.lm2;
     for (int32_t level = startLevel; level >= B.firstLevel; --level) {
-        const fs_bla_hdr32 *t = &B.levels[level][ix];
+        const typename Rec<F>::BLA *t = &B.levels[level][ix];
         if (CmpPosReduced(z2, ld(t->r2)) < 0)
             return t;
         ix = ix << 1;
@@ -342,69 +392,75 @@ const fs_bla_hdr32 *LookupBackwards(const BlaTable &B, size_t m, H z2)
     return nullptr;
 }
 
-} // namespace
-
-extern "C" {
-
-void orc_set_row_step(uint32_t step) { g_row_step = step ? step : 1; }
-
-// Fractal::CalcCpuHDR<uint32_t,double,double>, Fractal.cpp:2096-2206.  coords = {dx, dy, minX, maxY}.
-void orc_direct_f64(uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, const double coords[4],
-                    uint32_t n_iterations, uint32_t *out, uint32_t stride, int threads)
+// Fractal::CalcCpuHDR<uint32_t,HDRFloat<F>,F>, Fractal.cpp:2096-2206 (CpuHDR32 / CpuHDR64).
+// coords = {dx, dy, minX, maxY} as HDRFloat built from mpf (mantissa in [0.5,1), NOT reduced).
+template <class F>
+void direct_hdr_impl(uint32_t width, uint32_t y0, uint32_t y1, const typename Rec<F>::Real coords[4],
+                     uint32_t n_iterations, uint32_t *out, uint32_t stride, int threads)
 {
-    (void)height;
-    const double dx = coords[0], dy = coords[1], minX = coords[2], maxY = coords[3];
-    const double Four = 4, Two = 2;
+    using H = HT<F>;
+    const H dx = ld(coords[0]), dy = ld(coords[1]), minX = ld(coords[2]), maxY = ld(coords[3]);
+    const H Four = HFromInt<F>(4);
+    const H Two = HFromInt<F>(2);
     run_rows(y0, y1, threads, [&](uint32_t y) {
-        double cx = minX;
-        const double cy = maxY - dy * (double)((float)y);
-        double zx, zy, zx2, zy2, sum;
+        H cx = minX;
+        // T{static_cast<float>(y)}: HDRFloat<float> takes the non-template HDRFloat(T mant) ctor ({0,0} for y = 0),
+        // HDRFloat<double> the templated one with U = float ({0, MINEXP} for y = 0).
+        const H yh = sizeof(F) == 4 ? HFromMant<F>((F)(float)y) : HFromNumber<F>((F)(float)y);
+        const H cy = Sub(maxY, Mul(dy, yh));
+        H zx, zy, zx2, zy2, sum;
         unsigned int i;
         for (size_t x = 0; x < width; x++) {
             zx = cx;
             zy = cy;
             for (i = 0; i < n_iterations; i++) {
-                zx2 = zx * zx;
-                zy2 = zy * zy;
-                sum = zx2 + zy2;
-                if (sum > Four)
+                zx2 = Mul(zx, zx);
+                zy2 = Mul(zy, zy);
+                sum = Add(zx2, zy2);
+                Reduce(sum);
+                if (CmpPosReduced(sum, Four) > 0)
                     break;
-                zy = Two * zx * zy;
-                zx = zx2 - zy2;
-                zx += cx;
-                zy += cy;
+                zy = Mul(Mul(Two, zx), zy);
+                zx = Sub(zx2, zy2);
+                zx = Add(zx, cx);
+                zy = Add(zy, cy);
+                Reduce(zx);
+                Reduce(zy);
             }
-            cx += dx;
+            cx = Add(cx, dx);
             out[(size_t)y * stride + x] = i;
         }
     });
 }
 
-// Fractal::CalcCpuPerturbationFractalBLA<uint32_t,HDRFloat<float>,float>, Fractal.cpp:2208-2483.
+// Fractal::CalcCpuPerturbationFractalBLA<uint32_t,HDRFloat<F>,F>, Fractal.cpp:2208-2483.
 // coords = {dx, dy, centerX, centerY} (already reduced).
-void orc_bla_hdr32(uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, const fs_orbit_hdr32 *orbit,
-                   uint64_t orbit_count, const fs_real_hdr32 coords[4], uint32_t n_iterations,
-                   const fs_bla_hdr32 *const *bla_levels, const uint64_t *bla_level_sizes, int32_t bla_n_levels,
-                   int32_t bla_lm2, uint32_t *out, uint32_t stride, int threads)
+template <class F>
+void bla_impl(uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, const typename Rec<F>::Orbit *orbit,
+              uint64_t orbit_count, const typename Rec<F>::Real coords[4], uint32_t n_iterations,
+              const typename Rec<F>::BLA *const *bla_levels, const uint64_t *bla_level_sizes, int32_t bla_n_levels,
+              int32_t bla_lm2, uint32_t *out, uint32_t stride, int threads)
 {
+    using H = HT<F>;
+    using HC = HCT<F>;
     (void)height;
     const H dx = ld(coords[0]), dy = ld(coords[1]), centerX = ld(coords[2]), centerY = ld(coords[3]);
-    const BlaTable blas{bla_levels, bla_level_sizes, bla_n_levels, bla_lm2};
+    const BlaTable<F> blas{bla_levels, bla_level_sizes, bla_n_levels, bla_lm2};
     const uint32_t count = (uint32_t)orbit_count;
-    const H TwoFiftySix = HFromInt(256);
+    const H TwoFiftySix = HFromInt<F>(256);
     run_rows(y0, y1, threads, [&](uint32_t y) {
         for (size_t x = 0; x < width; x++) {
             uint32_t iter = 0;
             uint32_t RefIteration = 0;
             H DeltaSub0X, DeltaSub0Y;
-            pixel_delta(dx, dy, centerX, centerY, x, y, DeltaSub0X, DeltaSub0Y);
-            H DeltaSubNX = HFromInt(0);
-            H DeltaSubNY = HFromInt(0);
-            H DeltaNormSquared = HFromInt(0);
+            pixel_delta<F>(dx, dy, centerX, centerY, x, y, DeltaSub0X, DeltaSub0Y);
+            H DeltaSubNX = HFromInt<F>(0);
+            H DeltaSubNY = HFromInt<F>(0);
+            H DeltaNormSquared = HFromInt<F>(0);
 
             while (iter < n_iterations) {
-                const fs_bla_hdr32 *b = nullptr;
-                while ((b = LookupBackwards(blas, RefIteration, DeltaNormSquared)) != nullptr) {
+                const typename Rec<F>::BLA *b = nullptr;
+                while ((b = LookupBackwards<F>(blas, RefIteration, DeltaNormSquared)) != nullptr) {
                     const int l = b->l;
                     if (RefIteration + l >= count)
                         break; // "Out of bounds! :("
@@ -485,32 +541,35 @@ void orc_bla_hdr32(uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, co
     });
 }
 
-// Fractal::CalcCpuPerturbationFractalLAV2<uint32_t,float,PerturbExtras::Disable>, Fractal.cpp:2485-2691.
+// Fractal::CalcCpuPerturbationFractalLAV2<uint32_t,F,PerturbExtras::Disable>, Fractal.cpp:2485-2691.
 // stage_test: 0 = literal CPU LAReference::isLAStageInvalid (cheb(dc) <  LAThresholdC, LAReference.cpp:1076-1081)
 //             1 = the direction the GPU twin uses      (cheb(dc) >= LAThresholdC, GPU_LAReference.h:240-254)
 // mode: 0 = Full, 1 = PO (skip AT + LA stages), 2 = LAO (skip the perturbation loop) -- LAv2Mode of the GPU
 //       path (RenderAlgorithm.h:12-17); the CPU function is always Full.
-void orc_lav2_hdr32(uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, const fs_orbit_hdr32 *orbit,
-                    uint64_t orbit_count, uint64_t period_maybe_zero, const fs_la_hdr32_u32 *las, uint32_t n_las,
-                    const fs_la_stage_u32 *stages, uint32_t stage_count, int la_valid, int use_at,
-                    const fs_at_hdr32_u32 *at, const fs_real_hdr32 coords[4], uint32_t n_iterations,
-                    int stage_test, int mode, uint32_t *out, uint32_t stride, int threads, uint64_t *stats)
+template <class F>
+void lav2_impl(uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, const typename Rec<F>::Orbit *orbit,
+               uint64_t orbit_count, uint64_t period_maybe_zero, const typename Rec<F>::LA *las, uint32_t n_las,
+               const fs_la_stage_u32 *stages, uint32_t stage_count, int la_valid, int use_at,
+               const typename Rec<F>::AT *at, const typename Rec<F>::Real coords[4], uint32_t n_iterations,
+               int stage_test, int mode, uint32_t *out, uint32_t stride, int threads, uint64_t *stats)
 {
+    using H = HT<F>;
+    using HC = HCT<F>;
     // stats (optional, 4 x uint64): [0] AT iterations, [1] LA steps taken, [2] perturbation steps, [3] pixels
     (void)height;
     (void)n_las;
     std::atomic<uint64_t> st_at{0}, st_la{0}, st_pt{0}, st_px{0};
     const H dx = ld(coords[0]), dy = ld(coords[1]), centerX = ld(coords[2]), centerY = ld(coords[3]);
-    const H TwoFiftySix = HFromInt(256);
-    const H Two = HFromInt(2);
+    const H TwoFiftySix = HFromInt<F>(256);
+    const H Two = HFromInt<F>(2);
     run_rows(y0, y1, threads, [&](uint32_t y) {
         uint64_t c_at = 0, c_la = 0, c_pt = 0;
         for (size_t x = 0; x < width; x++) {
             uint32_t BLA2SkippedIterations = 0;
             H deltaReal, deltaImaginary;
-            pixel_delta(dx, dy, centerX, centerY, x, y, deltaReal, deltaImaginary);
+            pixel_delta<F>(dx, dy, centerX, centerY, x, y, deltaReal, deltaImaginary);
             const HC DeltaSub0 = CFromH(deltaReal, deltaImaginary);
-            HC DeltaSubN = CFromFloats(0.0f, 0.0f); // {0, 0}: zero with exponent 0, SURVEY 0.11
+            HC DeltaSubN = CFromScalars<F>(F(0), F(0)); // {0, 0}: zero with exponent 0, SURVEY 0.11
 
             if (mode != 1 && la_valid && use_at &&
                 CmpPosReduced(CCheb(DeltaSub0), ld(at->ThresholdC)) <= 0) { // ATInfo::isValid
@@ -518,7 +577,7 @@ void orc_lav2_hdr32(uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, c
                 const uint32_t ATMaxIt = n_iterations / at->StepLength;
                 HC c = CAdd(CMul(DeltaSub0, ld(at->CCoeff)), ld(at->RefC)); // getC
                 CReduce(c);
-                HC z = CZero();
+                HC z = CZero<F>();
                 uint32_t i;
                 for (i = 0; i < ATMaxIt; i++) {
                     H nsq = CNormSq(z);
@@ -562,11 +621,11 @@ void orc_lav2_hdr32(uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, c
                 while (iterations < n_iterations) {
                     // LAReference::getLA, LAReference.cpp:1097-1134
                     const uint32_t LAIndexj = LAIndex + j;
-                    const fs_la_hdr32_u32 &LAj = las[LAIndexj];
+                    const typename Rec<F>::LA &LAj = las[LAIndexj];
                     const uint32_t l = LAj.StepLength;
                     const bool usable = iterations + l <= n_iterations;
                     bool unusable = true;
-                    HC newDz = CZero();
+                    HC newDz = CZero<F>();
                     if (usable) {
                         // LAInfoDeep::Prepare, LAInfoDeep.h:395-414
                         newDz = CMul(DeltaSubN, CAdd(CMulH(ld(LAj.Ref), Two), DeltaSubN));
@@ -634,6 +693,95 @@ void orc_lav2_hdr32(uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, c
         stats[2] = st_pt;
         stats[3] = st_px;
     }
+}
+
+} // namespace
+
+extern "C" {
+
+void orc_set_row_step(uint32_t step) { g_row_step = step ? step : 1; }
+
+// Fractal::CalcCpuHDR<uint32_t,double,double>, Fractal.cpp:2096-2206.  coords = {dx, dy, minX, maxY}.
+void orc_direct_f64(uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, const double coords[4],
+                    uint32_t n_iterations, uint32_t *out, uint32_t stride, int threads)
+{
+    (void)height;
+    const double dx = coords[0], dy = coords[1], minX = coords[2], maxY = coords[3];
+    const double Four = 4, Two = 2;
+    run_rows(y0, y1, threads, [&](uint32_t y) {
+        double cx = minX;
+        const double cy = maxY - dy * (double)((float)y);
+        double zx, zy, zx2, zy2, sum;
+        unsigned int i;
+        for (size_t x = 0; x < width; x++) {
+            zx = cx;
+            zy = cy;
+            for (i = 0; i < n_iterations; i++) {
+                zx2 = zx * zx;
+                zy2 = zy * zy;
+                sum = zx2 + zy2;
+                if (sum > Four)
+                    break;
+                zy = Two * zx * zy;
+                zx = zx2 - zy2;
+                zx += cx;
+                zy += cy;
+            }
+            cx += dx;
+            out[(size_t)y * stride + x] = i;
+        }
+    });
+}
+
+
+void orc_direct_hdr32(uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, const fs_real_hdr32 coords[4],
+                      uint32_t n_iterations, uint32_t *out, uint32_t stride, int threads)
+{
+    (void)height;
+    direct_hdr_impl<float>(width, y0, y1, coords, n_iterations, out, stride, threads);
+}
+void orc_direct_hdr64(uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, const fs_real_hdr64 coords[4],
+                      uint32_t n_iterations, uint32_t *out, uint32_t stride, int threads)
+{
+    (void)height;
+    direct_hdr_impl<double>(width, y0, y1, coords, n_iterations, out, stride, threads);
+}
+
+void orc_bla_hdr32(uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, const fs_orbit_hdr32 *orbit,
+                   uint64_t orbit_count, const fs_real_hdr32 coords[4], uint32_t n_iterations,
+                   const fs_bla_hdr32 *const *bla_levels, const uint64_t *bla_level_sizes, int32_t bla_n_levels,
+                   int32_t bla_lm2, uint32_t *out, uint32_t stride, int threads)
+{
+    bla_impl<float>(width, height, y0, y1, orbit, orbit_count, coords, n_iterations, bla_levels, bla_level_sizes,
+                    bla_n_levels, bla_lm2, out, stride, threads);
+}
+void orc_bla_hdr64(uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, const fs_orbit_hdr64 *orbit,
+                   uint64_t orbit_count, const fs_real_hdr64 coords[4], uint32_t n_iterations,
+                   const fs_bla_hdr64 *const *bla_levels, const uint64_t *bla_level_sizes, int32_t bla_n_levels,
+                   int32_t bla_lm2, uint32_t *out, uint32_t stride, int threads)
+{
+    bla_impl<double>(width, height, y0, y1, orbit, orbit_count, coords, n_iterations, bla_levels, bla_level_sizes,
+                     bla_n_levels, bla_lm2, out, stride, threads);
+}
+
+// stage_test / mode / stats: see lav2_impl.
+void orc_lav2_hdr32(uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, const fs_orbit_hdr32 *orbit,
+                    uint64_t orbit_count, uint64_t period_maybe_zero, const fs_la_hdr32_u32 *las, uint32_t n_las,
+                    const fs_la_stage_u32 *stages, uint32_t stage_count, int la_valid, int use_at,
+                    const fs_at_hdr32_u32 *at, const fs_real_hdr32 coords[4], uint32_t n_iterations,
+                    int stage_test, int mode, uint32_t *out, uint32_t stride, int threads, uint64_t *stats)
+{
+    lav2_impl<float>(width, height, y0, y1, orbit, orbit_count, period_maybe_zero, las, n_las, stages, stage_count,
+                     la_valid, use_at, at, coords, n_iterations, stage_test, mode, out, stride, threads, stats);
+}
+void orc_lav2_hdr64(uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, const fs_orbit_hdr64 *orbit,
+                    uint64_t orbit_count, uint64_t period_maybe_zero, const fs_la_hdr64_u32 *las, uint32_t n_las,
+                    const fs_la_stage_u32 *stages, uint32_t stage_count, int la_valid, int use_at,
+                    const fs_at_hdr64_u32 *at, const fs_real_hdr64 coords[4], uint32_t n_iterations,
+                    int stage_test, int mode, uint32_t *out, uint32_t stride, int threads, uint64_t *stats)
+{
+    lav2_impl<double>(width, height, y0, y1, orbit, orbit_count, period_maybe_zero, las, n_las, stages, stage_count,
+                      la_valid, use_at, at, coords, n_iterations, stage_test, mode, out, stride, threads, stats);
 }
 
 } // extern "C"

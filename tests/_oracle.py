@@ -39,6 +39,12 @@ def lib():
         l.orc_lav2_hdr32.restype = None
         l.orc_lav2_hdr32.argtypes = [u32, u32, u32, u32, vp, u64, u64, vp, u32, vp, u32, C.c_int, C.c_int, vp, vp,
                                      u32, C.c_int, C.c_int, vp, u32, C.c_int, vp]
+        for name in ("orc_bla_hdr64", "orc_lav2_hdr64", "orc_direct_hdr32", "orc_direct_hdr64"):
+            getattr(l, name).restype = None
+        l.orc_bla_hdr64.argtypes = l.orc_bla_hdr32.argtypes
+        l.orc_lav2_hdr64.argtypes = l.orc_lav2_hdr32.argtypes
+        l.orc_direct_hdr32.argtypes = [u32, u32, u32, u32, vp, u32, vp, u32, C.c_int]
+        l.orc_direct_hdr64.argtypes = l.orc_direct_hdr32.argtypes
         l.orc_set_row_step.restype = None
         l.orc_set_row_step.argtypes = [u32]
         _lib = l
@@ -82,13 +88,34 @@ def direct_f64(view, aa=1, rows=None, threads=8):
     return out
 
 
-def bla_hdr32(view, orbit, bla=None, aa=1, rows=None, threads=8, n_iterations=None):
-    """CalcCpuPerturbationFractalBLA<u32,HDRFloat<float>,float>; bla=None suppresses the lookup (C2 target)."""
+def direct_hdr(view, is64, aa=1, rows=None, threads=8):
+    """CalcCpuHDR<u32,HDRFloat<F>,F> (CpuHDR32 / CpuHDR64)."""
     w, h = view.width * aa, view.height * aa
     out = new_buffer(w, h)
-    co = view.coords_perturb_hdr32(orbit, aa)
+    co = view.coords_direct_hdr(is64, aa)
+    y0, y1 = rows if rows else (0, h)
+    fn = lib().orc_direct_hdr64 if is64 else lib().orc_direct_hdr32
+    fn(w, h, y0, y1, co.ctypes.data, view.num_iterations, out.ctypes.data, out.shape[1], threads)
+    return out
+
+
+def bla_hdr32(view, orbit, bla=None, aa=1, rows=None, threads=8, n_iterations=None):
+    """CalcCpuPerturbationFractalBLA<u32,HDRFloat<F>,F> (F follows the orbit); bla=None suppresses the lookup
+    (C2 target)."""
+    w, h = view.width * aa, view.height * aa
+    out = new_buffer(w, h)
+    co = view.coords_perturb(orbit, aa)
     y0, y1 = rows if rows else (0, h)
     n = view.num_iterations if n_iterations is None else n_iterations
+    if orbit.is64:
+        fn = lib().orc_bla_hdr64
+        if bla is None:
+            fn(w, h, y0, y1, orbit.data_ptr, orbit.count, co.ctypes.data, n, None, None, 0, 0, out.ctypes.data,
+               out.shape[1], threads)
+        else:
+            fn(w, h, y0, y1, orbit.data_ptr, orbit.count, co.ctypes.data, n, bla.level_ptrs, bla.level_sizes,
+               bla.num_levels, bla.lm2, out.ctypes.data, out.shape[1], threads)
+        return out
     if bla is None:
         lib().orc_bla_hdr32(w, h, y0, y1, orbit.data_ptr, orbit.count, co.ctypes.data, n, None, None, 0, 0,
                             out.ctypes.data, out.shape[1], threads)
@@ -102,11 +129,12 @@ def lav2_hdr32(view, orbit, la, aa=1, rows=None, threads=8, stage_test=0, mode=0
     """CalcCpuPerturbationFractalLAV2<u32,float,Disable>. stage_test 0 = literal CPU, 1 = GPU direction."""
     w, h = view.width * aa, view.height * aa
     out = new_buffer(w, h)
-    co = view.coords_perturb_hdr32(orbit, aa)
+    co = view.coords_perturb(orbit, aa)
     y0, y1 = rows if rows else (0, h)
     n = view.num_iterations if n_iterations is None else n_iterations
     st = (u64 * 4)()
-    lib().orc_lav2_hdr32(w, h, y0, y1, orbit.data_ptr, orbit.count, orbit.period, la.las_ptr, la.count,
+    fn = lib().orc_lav2_hdr64 if orbit.is64 else lib().orc_lav2_hdr32
+    fn(w, h, y0, y1, orbit.data_ptr, orbit.count, orbit.period, la.las_ptr, la.count,
                          la.stages_ptr, la.stage_count, 1 if la.is_valid else 0, 1 if la.use_at else 0,
                          C.addressof(la.at), co.ctypes.data, n, stage_test, mode, out.ctypes.data, out.shape[1],
                          threads, st)

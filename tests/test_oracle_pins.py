@@ -96,3 +96,39 @@ def test_la_table_threading_replay_equivalent(native_libs):
     a = inputs.LATable(ob, host_threads=1).records().tobytes()
     b = inputs.LATable(ob, host_threads=8).records().tobytes()
     assert a == b
+
+
+# ---- HDRFloat<double> family and the HDR direct functions: five more of the reference's golden CRCs
+@needs_pin
+def test_golden_view5_cpu64_perturbed_blav2_hdr(native_libs):
+    v = inputs.View.builtin(5, W, H)
+    ob = inputs.Orbit(v, is64=True)
+    la = inputs.LATable(ob)
+    it = _oracle.lav2_hdr32(v, ob, la, stage_test=0)
+    assert _oracle.png_crc64(it, W, H, 1, v.num_iterations) == "ca7ad7c5f9cf750e"
+
+
+@needs_pin
+def test_golden_view5_cpu64_perturbed_bla_hdr(native_libs):
+    v = inputs.View.builtin(5, W, H)
+    ob = inputs.Orbit(v, is64=True)
+    bla = inputs.BLATable(ob)
+    it = _oracle.bla_hdr32(v, ob, bla)
+    assert _oracle.png_crc64(it, W, H, 1, v.num_iterations) == "c91e33c3eb85b33d"
+
+
+@needs_pin
+def test_golden_view1_cpu64_perturbed_bla_hdr(native_libs):
+    v = inputs.View.builtin(1, W, H)
+    ob = inputs.Orbit(v, is64=True)
+    bla = inputs.BLATable(ob)
+    it = _oracle.bla_hdr32(v, ob, bla)
+    assert _oracle.png_crc64(it, W, H, 1, v.num_iterations) == "d0c8921c878f6dc3"
+
+
+@needs_pin
+@pytest.mark.parametrize("is64,expected", [(False, "66ba2caaaa7f8013"), (True, "1275500d639ad02e")])
+def test_golden_view0_cpuhdr(native_libs, is64, expected):
+    v = inputs.View.builtin(0, W, H)
+    it = _oracle.direct_hdr(v, is64)
+    assert _oracle.png_crc64(it, W, H, 1, v.num_iterations) == expected
