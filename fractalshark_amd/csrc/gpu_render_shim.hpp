@@ -48,8 +48,12 @@ template <> struct type_tag<double> {
 template <> struct type_tag<::HDRFloat<float>> {
     static constexpr int value = FS_T_HDR32;
 };
+template <> struct type_tag<::HDRFloat<double>> {
+    static constexpr int value = FS_T_HDR64;
+};
 
-// HDRFloat<float> has the layout {float mantissa; int32 exp} = fs_real_hdr32 (HDRFloat.h:61-69).
+// HDRFloat<float> has the layout {float mantissa; int32 exp} = fs_real_hdr32 (HDRFloat.h:61-69);
+// HDRFloat<double> = {double mantissa; int32 exp; pad} = fs_real_hdr64.
 inline fs_real_hdr32 to_abi(const ::HDRFloat<float> &v)
 {
     fs_real_hdr32 r;
@@ -57,6 +61,21 @@ inline fs_real_hdr32 to_abi(const ::HDRFloat<float> &v)
     r.e = v.getExp();
     return r;
 }
+inline fs_real_hdr64 to_abi(const ::HDRFloat<double> &v)
+{
+    fs_real_hdr64 r;
+    r.m = v.getMantissa();
+    r.e = v.getExp();
+    r.pad_ = 0;
+    return r;
+}
+template <class T> struct abi_real;
+template <> struct abi_real<::HDRFloat<float>> {
+    using type = fs_real_hdr32;
+};
+template <> struct abi_real<::HDRFloat<double>> {
+    using type = fs_real_hdr64;
+};
 
 } // namespace fsmi355_shim
 
@@ -145,12 +164,16 @@ uint32_t GPURenderer::RenderPerturbLAv2(RenderAlgorithm /*algorithm*/, T /*cx*/,
     if (!m_ComputeStream)
         return 0; // "memory not initialised" is silent, GPU_Render.cu:1007-1009
     constexpr int tag = fsmi355_shim::type_tag<T>::value;
-    if (tag != FS_T_HDR32 || PExtras != PerturbExtras::Disable)
+    if constexpr (tag != FS_T_HDR32 && tag != FS_T_HDR64) {
         return FS_ERR_UNSUPPORTED;
-    const fs_real_hdr32 co[4] = {fsmi355_shim::to_abi(dx), fsmi355_shim::to_abi(dy), fsmi355_shim::to_abi(centerX),
-                                 fsmi355_shim::to_abi(centerY)};
+    } else {
+    if (PExtras != PerturbExtras::Disable)
+        return FS_ERR_UNSUPPORTED;
+    const typename fsmi355_shim::abi_real<T>::type co[4] = {fsmi355_shim::to_abi(dx), fsmi355_shim::to_abi(dy),
+                                                            fsmi355_shim::to_abi(centerX), fsmi355_shim::to_abi(centerY)};
     const int mode = Mode == LAv2Mode::Full ? FS_LAV2_FULL : (Mode == LAv2Mode::PO ? FS_LAV2_PO : FS_LAV2_LAO);
     return fs_render_lav2(fsmi355_shim::handle(m_ComputeStream), tag, mode, FS_PARITY_CPU, co, (uint64_t)n_iterations);
+    }
 }
 
 template <typename IterType, class T>
@@ -162,8 +185,9 @@ uint32_t GPURenderer::RenderPerturbBLA(RenderAlgorithm /*algorithm*/,
     if (!m_ComputeStream)
         return 0;
     constexpr int tag = fsmi355_shim::type_tag<T>::value;
-    if (tag != FS_T_HDR32)
+    if constexpr (tag != FS_T_HDR32 && tag != FS_T_HDR64) {
         return FS_ERR_UNSUPPORTED;
+    } else {
     fs_renderer *r = fsmi355_shim::handle(m_ComputeStream);
     // The reference re-uploads orbit and table on every call (GPU_Render.cu:1464-1479); so do we.
     uint32_t err = fs_upload_orbit(r, 0, tag, (uint32_t)sizeof(IterType), results->GetFullOrbit(),
@@ -183,9 +207,10 @@ uint32_t GPURenderer::RenderPerturbBLA(RenderAlgorithm /*algorithm*/,
     err = fs_upload_bla(r, tag, levels, sizes, (int32_t)n_levels, blas->m_LM2);
     if (err)
         return err;
-    const fs_real_hdr32 co[4] = {fsmi355_shim::to_abi(dx), fsmi355_shim::to_abi(dy), fsmi355_shim::to_abi(centerX),
-                                 fsmi355_shim::to_abi(centerY)};
+    const typename fsmi355_shim::abi_real<T>::type co[4] = {fsmi355_shim::to_abi(dx), fsmi355_shim::to_abi(dy),
+                                                            fsmi355_shim::to_abi(centerX), fsmi355_shim::to_abi(centerY)};
     return fs_render_bla(r, tag, co, (uint64_t)n_iterations);
+    }
 }
 
 template <typename IterType, class T>
@@ -194,10 +219,17 @@ uint32_t GPURenderer::Render(RenderAlgorithm /*algorithm*/, T cx, T cy, T dx, T 
 {
     if (!m_ComputeStream)
         return 0;
-    if (!std::is_same<T, double>::value)
+    if constexpr (std::is_same<T, double>::value) {
+        const double co[4] = {(double)dx, (double)dy, (double)cx, (double)cy};
+        return fs_render_direct(fsmi355_shim::handle(m_ComputeStream), FS_T_F64, co, (uint64_t)n_iterations);
+    } else if constexpr (fsmi355_shim::type_tag<T>::value == FS_T_HDR32 || fsmi355_shim::type_tag<T>::value == FS_T_HDR64) {
+        const typename fsmi355_shim::abi_real<T>::type co[4] = {fsmi355_shim::to_abi(dx), fsmi355_shim::to_abi(dy),
+                                                                fsmi355_shim::to_abi(cx), fsmi355_shim::to_abi(cy)};
+        return fs_render_direct(fsmi355_shim::handle(m_ComputeStream), fsmi355_shim::type_tag<T>::value, co,
+                                (uint64_t)n_iterations);
+    } else {
         return FS_ERR_UNSUPPORTED;
-    const double co[4] = {(double)dx, (double)dy, (double)cx, (double)cy};
-    return fs_render_direct(fsmi355_shim::handle(m_ComputeStream), FS_T_F64, co, (uint64_t)n_iterations);
+    }
 }
 
 template <typename IterType>

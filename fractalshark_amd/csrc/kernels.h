@@ -26,19 +26,48 @@ struct FsFrame {
     uint32_t band_stride;   // global-row distance between consecutive owned bands
 };
 
-struct FsCoords32 {
-    fs::hreal32 dx, dy, centerX, centerY;
+// Per-numeric-type device records.  F = float -> HDRFloat<float> (hdr32 ABI records), F = double -> HDRFloat<double>.
+struct FsZ64 { // prepared orbit entry for double: {re, im, exp, -, 2^(8-2exp)}; 32 B
+    double re;
+    double im;
+    int32_t e;
+    int32_t pad_;
+    double w;
+};
+template <class F> struct FsDev;
+template <> struct FsDev<float> {
+    using Z = float4; // {re, im, bitcast(exp), 2^(8-2exp)}
+    using Orbit = fs_orbit_hdr32;
+    using Real = fs_real_hdr32;
+    using Cplx = fs_cplx_hdr32;
+    using LA = fs_la_hdr32_u32;
+    using AT = fs_at_hdr32_u32;
+    using BLA = fs_bla_hdr32;
+};
+template <> struct FsDev<double> {
+    using Z = FsZ64;
+    using Orbit = fs_orbit_hdr64;
+    using Real = fs_real_hdr64;
+    using Cplx = fs_cplx_hdr64;
+    using LA = fs_la_hdr64_u32;
+    using AT = fs_at_hdr64_u32;
+    using BLA = fs_bla_hdr64;
 };
 
-struct FsLav2Args32 {
+template <class F> struct FsCoordsT {
+    fs::hreal<F> dx, dy, centerX, centerY;
+};
+using FsCoords32 = FsCoordsT<float>;
+
+template <class F> struct FsLav2ArgsT {
     uint32_t *out;
-    const float4 *zref; // prepared orbit {re, im, exp, -}
-    const fs_la_hdr32_u32 *las;
+    const typename FsDev<F>::Z *zref; // prepared orbit
+    const typename FsDev<F>::LA *las;
     const fs_la_stage_u32 *stages;
     uint64_t *stats;
     FsFrame frame;
-    FsCoords32 coords;
-    fs_at_hdr32_u32 at;
+    FsCoordsT<F> coords;
+    typename FsDev<F>::AT at;
     uint32_t orbit_count;
     uint32_t period;
     uint32_t stage_count;
@@ -47,17 +76,30 @@ struct FsLav2Args32 {
     int use_at;
     int parity;
 };
+using FsLav2Args32 = FsLav2ArgsT<float>;
 
-struct FsBlaArgs32 {
+template <class F> struct FsBlaArgsT {
     uint32_t *out;
-    const float4 *zref;
-    const fs_bla_hdr32 *const *levels; // device array of device pointers, indexed by level
+    const typename FsDev<F>::Z *zref;
+    const typename FsDev<F>::BLA *const *levels; // device array of device pointers, indexed by level
     uint64_t *stats;
     FsFrame frame;
-    FsCoords32 coords;
+    FsCoordsT<F> coords;
     uint32_t orbit_count;
     uint32_t n_iterations;
     int32_t lm2;
+};
+using FsBlaArgs32 = FsBlaArgsT<float>;
+
+// CalcCpuHDR<.., HDRFloat<F>, F> direct kernels: cx_row[x] = the CPU's accumulated cx (hreal<F>), dy/maxY un-reduced.
+template <class F> struct FsDirectHdrArgsT {
+    uint32_t *out;
+    fs::hreal<F> *cx_row;
+    uint64_t *stats;
+    FsFrame frame;
+    fs::hreal<F> dy;
+    fs::hreal<F> maxY;
+    uint32_t n_iterations;
 };
 
 struct FsDirectArgs64 {
@@ -71,8 +113,14 @@ struct FsDirectArgs64 {
 };
 
 void fsk_prepare_orbit_hdr32(const fs_orbit_hdr32 *in, float4 *out, uint64_t n, hipStream_t s);
+void fsk_prepare_orbit_hdr64(const fs_orbit_hdr64 *in, FsZ64 *out, uint64_t n, hipStream_t s);
 void fsk_lav2_hdr32(const FsLav2Args32 &A, int mode, bool stats, int variant, hipStream_t s);
+void fsk_lav2_hdr64(const FsLav2ArgsT<double> &A, int mode, bool stats, hipStream_t s);
 void fsk_perturb_scalar_hdr32(const FsBlaArgs32 &A, bool use_bla, bool stats, hipStream_t s);
+void fsk_perturb_scalar_hdr64(const FsBlaArgsT<double> &A, bool use_bla, bool stats, hipStream_t s);
+void fsk_direct_hdr32(const FsDirectHdrArgsT<float> &A, fs::hreal<float> minX, fs::hreal<float> dx, bool stats, hipStream_t s);
+void fsk_direct_hdr64(const FsDirectHdrArgsT<double> &A, fs::hreal<double> minX, fs::hreal<double> dx, bool stats,
+                      hipStream_t s);
 void fsk_direct_f64(const FsDirectArgs64 &A, double minX, double dx, bool stats, hipStream_t s);
 void fsk_antialias_u32(const uint32_t *iters, uint32_t rounded_width, fs_color16 *colors, const fs_color16 *pal,
                        uint32_t pal_iters, uint32_t aux_depth, uint32_t aa, uint32_t color_w, uint32_t color_h,

@@ -17,6 +17,8 @@ namespace {
 
 __device__ __forceinline__ hreal32 ldr(const fs_real_hdr32 &r) { return hreal32{r.m, r.e}; }
 __device__ __forceinline__ hcplx32 ldc(const fs_cplx_hdr32 &c) { return hcplx32{c.re, c.im, c.e}; }
+__device__ __forceinline__ hreal64 ldr(const fs_real_hdr64 &r) { return hreal64{r.m, r.e}; }
+__device__ __forceinline__ hcplx64 ldc(const fs_cplx_hdr64 &c) { return hcplx64{c.re, c.im, c.e}; }
 
 // Reference-orbit entry in device form: PerturbationResults::GetComplex (PerturbationResults.h:174-185)
 // builds HDRFloatComplex{x, y} on *every* access; it is a pure function of the entry, so it is evaluated
@@ -25,6 +27,10 @@ __device__ __forceinline__ hcplx32 zref_at(const float4 *__restrict__ z, uint32_
 {
     const float4 v = z[i];
     return hcplx32{v.x, v.y, __float_as_int(v.z)};
+}
+__device__ __forceinline__ hcplx64 zref_at(const FsZ64 *__restrict__ z, uint32_t i)
+{
+    return hcplx64{z[i].re, z[i].im, z[i].e};
 }
 
 // Global row of local row L under the band layout (fs_set_row_bands).
@@ -36,12 +42,13 @@ __device__ __forceinline__ uint32_t global_row(const FsFrame &f, uint32_t L)
 }
 
 // Pixel -> delta c, Fractal.cpp:2553-2562 (== 2272-2281): `dx * (float)x` goes through HDRFloat(T mant).
-__device__ __forceinline__ void pixel_delta(const FsCoords32 &c, uint32_t x, uint32_t y, hreal32 &dRe, hreal32 &dIm)
+template <class F>
+__device__ __forceinline__ void pixel_delta(const FsCoordsT<F> &c, uint32_t x, uint32_t y, hreal<F> &dRe, hreal<F> &dIm)
 {
-    hreal32 a = hr_mul(c.dx, hr_from_mant<float>((float)x));
+    hreal<F> a = hr_mul(c.dx, hr_from_mant<F>((F)x)); // `dx * (SubType)x`
     hr_reduce(a);
     a = hr_sub(a, c.centerX);
-    hreal32 b = hr_mul(hr_neg(c.dy), hr_from_mant<float>((float)y));
+    hreal<F> b = hr_mul(hr_neg(c.dy), hr_from_mant<F>((F)y));
     hr_reduce(b);
     b = hr_sub(b, c.centerY);
     hr_reduce(a);
@@ -96,8 +103,8 @@ __global__ void k_prepare_orbit_hdr32(const fs_orbit_hdr32 *__restrict__ in, flo
 // (Fractal.cpp:2545-2678) with LAReference::getLA / isLAStageInvalid (LAReference.cpp:1076-1134),
 // LAInfoDeep::Prepare / Evaluate (LAInfoDeep.h:395-420), ATInfo::PerformAT (ATInfo.h:155-188).
 // Replaces mandel_1xHDR_float_perturb_lav2 (FractalSharkGpuLib/LAKernel.cuh:3-315).
-template <int Mode, bool kStats>
-__global__ void __launch_bounds__(256) k_lav2_hdr32(FsLav2Args32 A)
+template <class F, int Mode, bool kStats>
+__global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
 {
     const uint32_t X = blockIdx.x * 64u + (threadIdx.x & 63u);
     const uint32_t L = blockIdx.y * 4u + (threadIdx.x >> 6);
@@ -107,28 +114,28 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32(FsLav2Args32 A)
     if (live) {
         c_px = 1;
         const uint32_t n_iterations = A.n_iterations;
-        hreal32 deltaReal, deltaImaginary;
-        pixel_delta(A.coords, X, Y, deltaReal, deltaImaginary);
-        const hcplx32 DeltaSub0 = hc_from_hr(deltaReal, deltaImaginary);
-        hcplx32 DeltaSubN = hc_from_native<float>(0.0f, 0.0f); // {0,0}: zero with exponent 0 (Fractal.cpp:2565)
+        hreal<F> deltaReal, deltaImaginary;
+        pixel_delta<F>(A.coords, X, Y, deltaReal, deltaImaginary);
+        const hcplx<F> DeltaSub0 = hc_from_hr(deltaReal, deltaImaginary);
+        hcplx<F> DeltaSubN = hc_from_native<F>(F(0), F(0)); // {0,0}: zero with exponent 0 (Fractal.cpp:2565)
         uint32_t iterations = 0;
 
         if (Mode != FS_MODE_PO) {
             if (A.la_valid && A.use_at && hr_cmp_pos(hc_cheb(DeltaSub0), ldr(A.at.ThresholdC)) <= 0) {
                 const uint32_t ATMaxIt = n_iterations / A.at.StepLength;
-                hcplx32 c = hc_add(hc_mul(DeltaSub0, ldc(A.at.CCoeff)), ldc(A.at.RefC));
+                hcplx<F> c = hc_add(hc_mul(DeltaSub0, ldc(A.at.CCoeff)), ldc(A.at.RefC));
                 hc_reduce(c);
-                hcplx32 z = hc_zero<float>();
-                const hreal32 esc = ldr(A.at.SqrEscapeRadius);
+                hcplx<F> z = hc_zero<F>();
+                const hreal<F> esc = ldr(A.at.SqrEscapeRadius);
                 uint32_t i;
                 for (i = 0; i < ATMaxIt; i++) {
-                    hreal32 nsq = hc_norm2(z);
+                    hreal<F> nsq = hc_norm2(z);
                     hr_reduce(nsq);
                     if (hr_cmp_pos(nsq, esc) > 0)
                         break;
                     z = hc_add(hc_mul(z, z), c);
                 }
-                hcplx32 dz = hc_mul(z, ldc(A.at.InvZCoeff));
+                hcplx<F> dz = hc_mul(z, ldc(A.at.InvZCoeff));
                 hc_reduce(dz);
                 DeltaSubN = dz;
                 iterations = i * A.at.StepLength;
@@ -147,7 +154,7 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32(FsLav2Args32 A)
 
         if (Mode != FS_MODE_PO) {
             uint32_t CurrentLAStage = A.la_valid ? A.stage_count : 0;
-            const hreal32 dcCheb = hc_cheb(DeltaSub0);
+            const hreal<F> dcCheb = hc_cheb(DeltaSub0);
             while (CurrentLAStage > 0) {
                 CurrentLAStage--;
                 const uint32_t LAIndex = A.stages[CurrentLAStage].LAIndex;
@@ -160,10 +167,10 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32(FsLav2Args32 A)
                 const uint32_t MacroItCount = A.stages[CurrentLAStage].MacroItCount;
                 uint32_t j = RefIteration;
                 while (iterations < n_iterations) {
-                    const fs_la_hdr32_u32 *LAj = &A.las[LAIndex + j];
+                    const typename FsDev<F>::LA *LAj = &A.las[LAIndex + j];
                     const uint32_t l = LAj->StepLength;
                     bool unusable = true;
-                    hcplx32 newDz = hc_zero<float>();
+                    hcplx<F> newDz = hc_zero<F>();
                     if (iterations + l <= n_iterations) {
                         newDz = hc_mul(DeltaSubN, hc_add(hc_mul2(ldc(LAj->Ref)), DeltaSubN));
                         hc_reduce(newDz);
@@ -177,10 +184,10 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32(FsLav2Args32 A)
                     if (kStats)
                         c_la++;
                     DeltaSubN = hc_add(hc_mul(newDz, ldc(LAj->ZCoeff)), hc_mul(DeltaSub0, ldc(LAj->CCoeff)));
-                    const hcplx32 complex0 = hc_add(ldc(LAj[1].Ref), DeltaSubN);
+                    const hcplx<F> complex0 = hc_add(ldc(LAj[1].Ref), DeltaSubN);
                     j++;
-                    const hreal32 lhs = hr_reduced(hc_cheb(complex0));
-                    const hreal32 rhs = hr_reduced(hc_cheb(DeltaSubN));
+                    const hreal<F> lhs = hr_reduced(hc_cheb(complex0));
+                    const hreal<F> rhs = hr_reduced(hc_cheb(DeltaSubN));
                     if (hr_cmp_pos(lhs, rhs) < 0 || j >= MacroItCount) {
                         DeltaSubN = complex0;
                         j = 0;
@@ -192,10 +199,10 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32(FsLav2Args32 A)
         }
 
         if (Mode != FS_MODE_LAO) {
-            const hreal32 TwoFiftySix = hreal32{1.0f, 8};
-            const float4 *__restrict__ zr = A.zref;
+            const hreal<F> TwoFiftySix = hreal<F>{F(1), 8};
+            const typename FsDev<F>::Z *__restrict__ zr = A.zref;
             for (; iterations < n_iterations; iterations++) {
-                hcplx32 cur = zref_at(zr, RefIteration);
+                hcplx<F> cur = zref_at(zr, RefIteration);
                 cur = hc_mul2(cur);
                 cur = hc_add(cur, DeltaSubN);
                 DeltaSubN = hc_mul(DeltaSubN, cur);
@@ -204,10 +211,10 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32(FsLav2Args32 A)
                 if (kStats)
                     c_pt++;
                 RefIteration++;
-                hcplx32 complex0 = hc_add(zref_at(zr, RefIteration), DeltaSubN);
+                hcplx<F> complex0 = hc_add(zref_at(zr, RefIteration), DeltaSubN);
                 hc_reduce(complex0);
-                const hreal32 normSquared = hr_reduced(hc_norm2(complex0));
-                const hreal32 DeltaNormSquared = hr_reduced(hc_norm2(DeltaSubN));
+                const hreal<F> normSquared = hr_reduced(hc_norm2(complex0));
+                const hreal<F> DeltaNormSquared = hr_reduced(hc_norm2(DeltaSubN));
                 if (hr_cmp_pos(normSquared, TwoFiftySix) > 0)
                     break;
                 if (hr_cmp_pos(normSquared, DeltaNormSquared) < 0 || RefIteration >= MaxRefIteration) {
@@ -282,7 +289,7 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
         c_px = 1;
         const uint32_t n_iterations = A.n_iterations;
         hreal32 deltaReal, deltaImaginary;
-        pixel_delta(A.coords, X, Y, deltaReal, deltaImaginary);
+        pixel_delta<float>(A.coords, X, Y, deltaReal, deltaImaginary);
         const hcplx32 DeltaSub0 = hc_from_hr(deltaReal, deltaImaginary);
         hcplx32 DeltaSubN = hc_from_native<float>(0.0f, 0.0f);
         uint32_t iterations = 0;
@@ -478,7 +485,8 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
 // (FractalSharkGpuLib/BLAKernels.cuh:193-434) and the PO instantiation of the LAv2 kernel.
 namespace {
 
-__device__ __forceinline__ const fs_bla_hdr32 *bla_lookup(const FsBlaArgs32 &A, uint32_t m, hreal32 z2)
+template <class F>
+__device__ __forceinline__ const typename FsDev<F>::BLA *bla_lookup(const FsBlaArgsT<F> &A, uint32_t m, hreal<F> z2)
 {
     if (m == 0)
         return nullptr;
@@ -498,7 +506,7 @@ __device__ __forceinline__ const fs_bla_hdr32 *bla_lookup(const FsBlaArgs32 &A, 
     }
     const int32_t startLevel = zeros <= A.lm2 ? zeros : A.lm2;
     for (int32_t level = startLevel; level >= 2; --level) {
-        const fs_bla_hdr32 *t = &A.levels[level][ix];
+        const typename FsDev<F>::BLA *t = &A.levels[level][ix];
         if (hr_cmp_pos(z2, ldr(t->r2)) < 0)
             return t;
         ix <<= 1;
@@ -508,8 +516,8 @@ __device__ __forceinline__ const fs_bla_hdr32 *bla_lookup(const FsBlaArgs32 &A, 
 
 } // namespace
 
-template <bool kBla, bool kStats>
-__global__ void __launch_bounds__(256) k_perturb_scalar_hdr32(FsBlaArgs32 A)
+template <class F, bool kBla, bool kStats>
+__global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
 {
     const uint32_t X = blockIdx.x * 64u + (threadIdx.x & 63u);
     const uint32_t L = blockIdx.y * 4u + (threadIdx.x >> 6);
@@ -520,22 +528,22 @@ __global__ void __launch_bounds__(256) k_perturb_scalar_hdr32(FsBlaArgs32 A)
         c_px = 1;
         const uint32_t n_iterations = A.n_iterations;
         const uint32_t count = A.orbit_count;
-        const float4 *__restrict__ zr = A.zref;
+        const typename FsDev<F>::Z *__restrict__ zr = A.zref;
         uint32_t iter = 0;
         uint32_t RefIteration = 0;
-        hreal32 DeltaSub0X, DeltaSub0Y;
-        pixel_delta(A.coords, X, Y, DeltaSub0X, DeltaSub0Y);
-        hreal32 DeltaSubNX = hr_zero<float>();
-        hreal32 DeltaSubNY = hr_zero<float>();
-        hreal32 DeltaNormSquared = hr_zero<float>();
-        const hreal32 TwoFiftySix = hreal32{1.0f, 8};
-        hcplx32 Zcached = hc_zero<float>();
+        hreal<F> DeltaSub0X, DeltaSub0Y;
+        pixel_delta<F>(A.coords, X, Y, DeltaSub0X, DeltaSub0Y);
+        hreal<F> DeltaSubNX = hr_zero<F>();
+        hreal<F> DeltaSubNY = hr_zero<F>();
+        hreal<F> DeltaNormSquared = hr_zero<F>();
+        const hreal<F> TwoFiftySix = hreal<F>{F(1), 8};
+        hcplx<F> Zcached = hc_zero<F>();
         uint32_t Zcached_at = 0xFFFFFFFFu;
 
         while (iter < n_iterations) {
             if (kBla) {
-                const fs_bla_hdr32 *b;
-                while ((b = bla_lookup(A, RefIteration, DeltaNormSquared)) != nullptr) {
+                const typename FsDev<F>::BLA *b;
+                while ((b = bla_lookup<F>(A, RefIteration, DeltaNormSquared)) != nullptr) {
                     const uint32_t l = (uint32_t)b->l;
                     if (RefIteration + l >= count)
                         break;
@@ -545,21 +553,21 @@ __global__ void __launch_bounds__(256) k_perturb_scalar_hdr32(FsBlaArgs32 A)
                     if (kStats)
                         c_la++;
                     {
-                        const hreal32 Ax = ldr(b->Ax), Ay = ldr(b->Ay), Bx = ldr(b->Bx), By = ldr(b->By);
-                        const hreal32 nx = hr_sub(
+                        const hreal<F> Ax = ldr(b->Ax), Ay = ldr(b->Ay), Bx = ldr(b->Bx), By = ldr(b->By);
+                        const hreal<F> nx = hr_sub(
                             hr_add(hr_sub(hr_mul(Ax, DeltaSubNX), hr_mul(Ay, DeltaSubNY)), hr_mul(Bx, DeltaSub0X)),
                             hr_mul(By, DeltaSub0Y));
-                        const hreal32 ny = hr_add(
+                        const hreal<F> ny = hr_add(
                             hr_add(hr_add(hr_mul(Ax, DeltaSubNY), hr_mul(Ay, DeltaSubNX)), hr_mul(Bx, DeltaSub0Y)),
                             hr_mul(By, DeltaSub0X));
                         DeltaSubNX = nx;
                         DeltaSubNY = ny;
                     }
                     RefIteration += l;
-                    const hcplx32 Z = zref_at(zr, RefIteration);
-                    const hreal32 tempZX = hr_add(hc_re(Z), DeltaSubNX);
-                    const hreal32 tempZY = hr_add(hc_im(Z), DeltaSubNY);
-                    const hreal32 normSquared = hr_reduced(hr_add(hr_mul(tempZX, tempZX), hr_mul(tempZY, tempZY)));
+                    const hcplx<F> Z = zref_at(zr, RefIteration);
+                    const hreal<F> tempZX = hr_add(hc_re(Z), DeltaSubNX);
+                    const hreal<F> tempZY = hr_add(hc_im(Z), DeltaSubNY);
+                    const hreal<F> normSquared = hr_reduced(hr_add(hr_mul(tempZX, tempZX), hr_mul(tempZY, tempZY)));
                     DeltaNormSquared = hr_reduced(hr_add(hr_mul(DeltaSubNX, DeltaSubNX), hr_mul(DeltaSubNY, DeltaSubNY)));
                     if (hr_cmp_pos(normSquared, TwoFiftySix) > 0)
                         break;
@@ -574,15 +582,15 @@ __global__ void __launch_bounds__(256) k_perturb_scalar_hdr32(FsBlaArgs32 A)
                     break;
             }
 
-            const hreal32 OX = DeltaSubNX, OY = DeltaSubNY;
+            const hreal<F> OX = DeltaSubNX, OY = DeltaSubNY;
             // The orbit entry read for the escape test of the previous step is the Z of this step unless a rebase or a
             // BLA jump moved RefIteration: one dependent 16-byte load per step instead of two.
-            const hcplx32 Z = (Zcached_at == RefIteration) ? Zcached : zref_at(zr, RefIteration);
+            const hcplx<F> Z = (Zcached_at == RefIteration) ? Zcached : zref_at(zr, RefIteration);
             // Term4 == the inner sum of TermB1, Term3 == the inner sum of TermB2 (same operands, same order)
-            const hreal32 T4 = hr_add(hr_mul2(hc_re(Z)), OX);
-            const hreal32 T3 = hr_add(hr_mul2(hc_im(Z)), OY);
-            const hreal32 TermB1 = hr_mul(OX, T4);
-            const hreal32 TermB2 = hr_mul(OY, T3);
+            const hreal<F> T4 = hr_add(hr_mul2(hc_re(Z)), OX);
+            const hreal<F> T3 = hr_add(hr_mul2(hc_im(Z)), OY);
+            const hreal<F> TermB1 = hr_mul(OX, T4);
+            const hreal<F> TermB2 = hr_mul(OY, T3);
             DeltaSubNX = hr_sub(TermB1, TermB2);
             DeltaSubNX = hr_add(DeltaSubNX, DeltaSub0X);
             hr_reduce(DeltaSubNX);
@@ -596,12 +604,12 @@ __global__ void __launch_bounds__(256) k_perturb_scalar_hdr32(FsBlaArgs32 A)
             if (RefIteration >= count)
                 break;
 
-            const hcplx32 Z2 = zref_at(zr, RefIteration);
+            const hcplx<F> Z2 = zref_at(zr, RefIteration);
             Zcached = Z2;
             Zcached_at = RefIteration;
-            const hreal32 tempZX = hr_add(hc_re(Z2), DeltaSubNX);
-            const hreal32 tempZY = hr_add(hc_im(Z2), DeltaSubNY);
-            const hreal32 normSquared = hr_reduced(hr_add(hr_mul(tempZX, tempZX), hr_mul(tempZY, tempZY)));
+            const hreal<F> tempZX = hr_add(hc_re(Z2), DeltaSubNX);
+            const hreal<F> tempZY = hr_add(hc_im(Z2), DeltaSubNY);
+            const hreal<F> normSquared = hr_reduced(hr_add(hr_mul(tempZX, tempZX), hr_mul(tempZY, tempZY)));
             DeltaNormSquared = hr_reduced(hr_add(hr_mul(DeltaSubNX, DeltaSubNX), hr_mul(DeltaSubNY, DeltaSubNY)));
             if (hr_cmp_pos(normSquared, TwoFiftySix) > 0)
                 break;
@@ -738,6 +746,78 @@ __global__ void __launch_bounds__(256) k_reduce_u32(const uint32_t *__restrict__
     }
 }
 
+// Orbit preparation for HDRFloat<double>.
+__global__ void k_prepare_orbit_hdr64(const fs_orbit_hdr64 *__restrict__ in, FsZ64 *__restrict__ out, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const fs_orbit_hdr64 e = in[i];
+    const hcplx64 c = hc_from_hr(hreal64{e.mx, e.ex}, hreal64{e.my, e.ey});
+    FsZ64 z;
+    z.re = c.re;
+    z.im = c.im;
+    z.e = c.e;
+    z.pad_ = 0;
+    z.w = ldexp(1.0, 8 - 2 * (c.e < -500 ? -500 : c.e));
+    out[i] = z;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Direct escape time in HDRFloat<F>.  CPU twin: Fractal::CalcCpuHDR<uint32_t,HDRFloat<F>,F> (Fractal.cpp:2148-2183;
+// CpuHDR32 / CpuHDR64): z0 = c, bailout Reduce(zx^2+zy^2) > 4, zy = (2*zx)*zy, zx = zx2 - zy2, += c, Reduce both.
+// cx is the CPU's accumulated `cx += dx` (un-reduced HDR adds) from a 1-lane serial scan, like k_direct_f64.
+// Replaces mandel_hdr_float (FractalSharkGpuLib/LowPrecisionKernels.cuh:682-777).
+template <class F, bool kStats>
+__global__ void __launch_bounds__(256) k_direct_hdr(FsDirectHdrArgsT<F> A)
+{
+    const uint32_t X = blockIdx.x * 64u + (threadIdx.x & 63u);
+    const uint32_t L = blockIdx.y * 4u + (threadIdx.x >> 6);
+    uint64_t c_pt = 0, c_px = 0;
+    const uint32_t Y = global_row(A.frame, L);
+    const bool live = X < A.frame.width && L < A.frame.local_rows && Y < A.frame.height;
+    if (live) {
+        c_px = 1;
+        const hreal<F> cx = A.cx_row[X];
+        // T{static_cast<float>(y)}: non-template HDRFloat(T mant) for float, templated (U = float) ctor for double
+        const hreal<F> yh = sizeof(F) == 4 ? hr_from_mant<F>((F)(float)Y) : hr_from_number<F>((F)(float)Y);
+        const hreal<F> cy = hr_sub(A.maxY, hr_mul(A.dy, yh));
+        const hreal<F> Four{F(1), 2};
+        const hreal<F> Two{F(1), 1};
+        hreal<F> zx = cx, zy = cy;
+        uint32_t i;
+        for (i = 0; i < A.n_iterations; i++) {
+            const hreal<F> zx2 = hr_mul(zx, zx);
+            const hreal<F> zy2 = hr_mul(zy, zy);
+            const hreal<F> sum = hr_reduced(hr_add(zx2, zy2));
+            if (hr_cmp_pos(sum, Four) > 0)
+                break;
+            zy = hr_mul(hr_mul(Two, zx), zy);
+            zx = hr_sub(zx2, zy2);
+            zx = hr_add(zx, cx);
+            zy = hr_add(zy, cy);
+            hr_reduce(zx);
+            hr_reduce(zy);
+        }
+        if (kStats)
+            c_pt = i;
+        A.out[(size_t)L * A.frame.rounded_width + X] = i;
+    }
+    if (kStats)
+        add_stats(A.stats, 0, 0, c_pt, c_px);
+}
+
+template <class F> __global__ void k_direct_row_prefix_hdr(hreal<F> minX, hreal<F> dx, uint32_t width, hreal<F> *cx_row)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        hreal<F> cx = minX;
+        for (uint32_t x = 0; x < width; x++) {
+            cx_row[x] = cx;
+            cx = hr_add(cx, dx);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Host-callable launchers (called from renderer.cpp through kernels.h).
 static dim3 frame_grid(const FsFrame &f) { return dim3((f.width + 63) / 64, (f.local_rows + 3) / 4, 1); }
@@ -754,9 +834,9 @@ void fsk_lav2_hdr32(const FsLav2Args32 &A, int mode, bool stats, int variant, hi
     do {                                                                                                            \
         if (variant == FS_VARIANT_LITERAL) {                                                                        \
             if (stats)                                                                                              \
-                hipLaunchKernelGGL((k_lav2_hdr32<M, true>), g, b, 0, s, A);                                         \
+                hipLaunchKernelGGL((k_lav2_lit<float, M, true>), g, b, 0, s, A);                                         \
             else                                                                                                    \
-                hipLaunchKernelGGL((k_lav2_hdr32<M, false>), g, b, 0, s, A);                                        \
+                hipLaunchKernelGGL((k_lav2_lit<float, M, false>), g, b, 0, s, A);                                        \
         } else {                                                                                                    \
             if (stats)                                                                                              \
                 hipLaunchKernelGGL((k_lav2_hdr32_fast<M, true>), g, b, 0, s, A);                                    \
@@ -778,15 +858,74 @@ void fsk_perturb_scalar_hdr32(const FsBlaArgs32 &A, bool use_bla, bool stats, hi
     const dim3 g = frame_grid(A.frame), b(256);
     if (use_bla) {
         if (stats)
-            hipLaunchKernelGGL((k_perturb_scalar_hdr32<true, true>), g, b, 0, s, A);
+            hipLaunchKernelGGL((k_perturb_scalar<float, true, true>), g, b, 0, s, A);
         else
-            hipLaunchKernelGGL((k_perturb_scalar_hdr32<true, false>), g, b, 0, s, A);
+            hipLaunchKernelGGL((k_perturb_scalar<float, true, false>), g, b, 0, s, A);
     } else {
         if (stats)
-            hipLaunchKernelGGL((k_perturb_scalar_hdr32<false, true>), g, b, 0, s, A);
+            hipLaunchKernelGGL((k_perturb_scalar<float, false, true>), g, b, 0, s, A);
         else
-            hipLaunchKernelGGL((k_perturb_scalar_hdr32<false, false>), g, b, 0, s, A);
+            hipLaunchKernelGGL((k_perturb_scalar<float, false, false>), g, b, 0, s, A);
     }
+}
+
+void fsk_prepare_orbit_hdr64(const fs_orbit_hdr64 *in, FsZ64 *out, uint64_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_prepare_orbit_hdr64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n);
+}
+
+void fsk_lav2_hdr64(const FsLav2ArgsT<double> &A, int mode, bool stats, hipStream_t s)
+{
+    const dim3 g = frame_grid(A.frame), b(256);
+#define FS_LAUNCH64(M)                                                                                              \
+    do {                                                                                                            \
+        if (stats)                                                                                                  \
+            hipLaunchKernelGGL((k_lav2_lit<double, M, true>), g, b, 0, s, A);                                       \
+        else                                                                                                        \
+            hipLaunchKernelGGL((k_lav2_lit<double, M, false>), g, b, 0, s, A);                                      \
+    } while (0)
+    if (mode == FS_MODE_FULL)
+        FS_LAUNCH64(FS_MODE_FULL);
+    else if (mode == FS_MODE_PO)
+        FS_LAUNCH64(FS_MODE_PO);
+    else
+        FS_LAUNCH64(FS_MODE_LAO);
+#undef FS_LAUNCH64
+}
+
+void fsk_perturb_scalar_hdr64(const FsBlaArgsT<double> &A, bool use_bla, bool stats, hipStream_t s)
+{
+    const dim3 g = frame_grid(A.frame), b(256);
+    if (use_bla) {
+        if (stats)
+            hipLaunchKernelGGL((k_perturb_scalar<double, true, true>), g, b, 0, s, A);
+        else
+            hipLaunchKernelGGL((k_perturb_scalar<double, true, false>), g, b, 0, s, A);
+    } else {
+        if (stats)
+            hipLaunchKernelGGL((k_perturb_scalar<double, false, true>), g, b, 0, s, A);
+        else
+            hipLaunchKernelGGL((k_perturb_scalar<double, false, false>), g, b, 0, s, A);
+    }
+}
+
+template <class F>
+static void launch_direct_hdr(const FsDirectHdrArgsT<F> &A, hreal<F> minX, hreal<F> dx, bool stats, hipStream_t s)
+{
+    hipLaunchKernelGGL((k_direct_row_prefix_hdr<F>), dim3(1), dim3(64), 0, s, minX, dx, A.frame.width, A.cx_row);
+    const dim3 g = frame_grid(A.frame), b(256);
+    if (stats)
+        hipLaunchKernelGGL((k_direct_hdr<F, true>), g, b, 0, s, A);
+    else
+        hipLaunchKernelGGL((k_direct_hdr<F, false>), g, b, 0, s, A);
+}
+void fsk_direct_hdr32(const FsDirectHdrArgsT<float> &A, hreal<float> minX, hreal<float> dx, bool stats, hipStream_t s)
+{
+    launch_direct_hdr<float>(A, minX, dx, stats, s);
+}
+void fsk_direct_hdr64(const FsDirectHdrArgsT<double> &A, hreal<double> minX, hreal<double> dx, bool stats, hipStream_t s)
+{
+    launch_direct_hdr<double>(A, minX, dx, stats, s);
 }
 
 void fsk_direct_f64(const FsDirectArgs64 &A, double minX, double dx, bool stats, hipStream_t s)

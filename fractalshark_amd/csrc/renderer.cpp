@@ -56,25 +56,30 @@ struct fs_renderer {
     // orbit (HDRFloat<float>)
     uint64_t orbit_gen = 0;
     bool orbit_ok = false;
+    int orbit_type = -1; // FS_T_HDR32 or FS_T_HDR64
     float4 *zref = nullptr;
+    FsZ64 *zref64 = nullptr;
     uint64_t orbit_size = 0, orbit_uncompressed = 0, orbit_period = 0;
 
     // LA table
     uint64_t la_gen = 0;
     bool la_ok = false;
-    fs_la_hdr32_u32 *las = nullptr;
+    int la_type = -1;
+    void *las = nullptr; // fs_la_hdr32_u32[] or fs_la_hdr64_u32[]
     fs_la_stage_u32 *stages = nullptr;
     uint32_t n_las = 0, n_stages = 0;
     int la_valid = 0, use_at = 0;
     fs_at_hdr32_u32 at{};
+    fs_at_hdr64_u32 at64{};
 
     // BLA table
     std::vector<void *> bla_level_mem;
-    const fs_bla_hdr32 **bla_levels_dev = nullptr;
+    const void **bla_levels_dev = nullptr;
+    int bla_type = -1;
     int32_t bla_n_levels = 0, bla_lm2 = 0;
 
     // direct kernels
-    double *cx_row = nullptr;
+    void *cx_row = nullptr; // double[] / hreal<float>[] / hreal<double>[] (16 B per column is enough for all)
     uint32_t cx_row_cap = 0;
 
     void *iters() const { return iters_external ? iters_external : iters_internal; }
@@ -139,7 +144,10 @@ void free_perturb(fs_renderer *r)
 {
     if (r->zref)
         hipFree(r->zref);
+    if (r->zref64)
+        hipFree(r->zref64);
     r->zref = nullptr;
+    r->zref64 = nullptr;
     r->orbit_ok = false;
     r->orbit_gen = 0;
     if (r->las)
@@ -203,6 +211,42 @@ struct TimedLaunch {
 };
 
 } // namespace
+
+static void fill_coords(FsCoordsT<float> &c, const void *coords)
+{
+    const fs_real_hdr32 *p = (const fs_real_hdr32 *)coords;
+    c.dx = fs::hreal32{p[0].m, p[0].e};
+    c.dy = fs::hreal32{p[1].m, p[1].e};
+    c.centerX = fs::hreal32{p[2].m, p[2].e};
+    c.centerY = fs::hreal32{p[3].m, p[3].e};
+}
+static void fill_coords(FsCoordsT<double> &c, const void *coords)
+{
+    const fs_real_hdr64 *p = (const fs_real_hdr64 *)coords;
+    c.dx = fs::hreal64{p[0].m, p[0].e};
+    c.dy = fs::hreal64{p[1].m, p[1].e};
+    c.centerX = fs::hreal64{p[2].m, p[2].e};
+    c.centerY = fs::hreal64{p[3].m, p[3].e};
+}
+
+template <class F> static void fill_lav2(fs_renderer *r, FsLav2ArgsT<F> &A, const void *coords, uint64_t n_iterations, int parity)
+{
+    memset(&A, 0, sizeof(A));
+    A.out = (uint32_t *)r->iters();
+    A.las = (const typename FsDev<F>::LA *)r->las;
+    A.stages = r->stages;
+    A.stats = r->stats;
+    A.frame = make_frame(r);
+    fill_coords(A.coords, coords);
+    A.orbit_count = (uint32_t)r->orbit_uncompressed;
+    A.period = (uint32_t)r->orbit_period;
+    A.stage_count = r->n_stages;
+    A.n_iterations = (uint32_t)n_iterations;
+    A.la_valid = r->la_ok ? r->la_valid : 0;
+    A.use_at = r->use_at;
+    A.parity = (parity == FS_PARITY_CPU_GPUSTAGE) ? FS_PARITY_GPUSTAGE : FS_PARITY_LITERAL;
+}
+
 
 extern "C" {
 
@@ -380,35 +424,50 @@ uint32_t fs_upload_orbit(fs_renderer *r, uint64_t generation, int type_tag, uint
 {
     if (uint32_t e = use_device(r))
         return e;
-    if (type_tag != FS_T_HDR32 || iter_bytes != 4)
+    if ((type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64) || iter_bytes != 4)
         return FS_ERR_UNSUPPORTED;
     if (!r->compute)
         return FS_ERR_6;
-    if (r->orbit_ok && r->orbit_gen == generation && generation != 0)
+    if (r->orbit_ok && r->orbit_gen == generation && generation != 0 && r->orbit_type == type_tag)
         return 0; // cached by generation number (GPU_Render.cu:440-487)
     if (r->zref) {
         FS_TRY(hipFree(r->zref));
         r->zref = nullptr;
     }
+    if (r->zref64) {
+        FS_TRY(hipFree(r->zref64));
+        r->zref64 = nullptr;
+    }
     r->orbit_ok = false;
-    fs_orbit_hdr32 *raw = nullptr;
-    FS_TRY(hipMalloc((void **)&raw, orbit_size * sizeof(fs_orbit_hdr32)));
-    hipError_t err = hipMalloc((void **)&r->zref, orbit_size * sizeof(float4));
+    const size_t in_bytes = type_tag == FS_T_HDR32 ? sizeof(fs_orbit_hdr32) : sizeof(fs_orbit_hdr64);
+    void *raw = nullptr;
+    FS_TRY(hipMalloc(&raw, orbit_size * in_bytes));
+    // two spare entries: the tuned loops may prefetch one entry past the end
+    hipError_t err = type_tag == FS_T_HDR32 ? hipMalloc((void **)&r->zref, (orbit_size + 2) * sizeof(float4))
+                                            : hipMalloc((void **)&r->zref64, (orbit_size + 2) * sizeof(FsZ64));
     if (err == hipSuccess)
-        err = hipMemcpyAsync(raw, entries, orbit_size * sizeof(fs_orbit_hdr32), hipMemcpyDefault, r->compute);
+        err = hipMemcpyAsync(raw, entries, orbit_size * in_bytes, hipMemcpyDefault, r->compute);
     if (err == hipSuccess) {
-        fsk_prepare_orbit_hdr32(raw, r->zref, orbit_size, r->compute);
-        err = hipGetLastError();
+        if (type_tag == FS_T_HDR32) {
+            err = hipMemsetAsync(r->zref + orbit_size, 0, 2 * sizeof(float4), r->compute);
+            fsk_prepare_orbit_hdr32((const fs_orbit_hdr32 *)raw, r->zref, orbit_size, r->compute);
+        } else {
+            err = hipMemsetAsync(r->zref64 + orbit_size, 0, 2 * sizeof(FsZ64), r->compute);
+            fsk_prepare_orbit_hdr64((const fs_orbit_hdr64 *)raw, r->zref64, orbit_size, r->compute);
+        }
+        if (err == hipSuccess)
+            err = hipGetLastError();
     }
     if (err == hipSuccess)
         err = hipStreamSynchronize(r->compute);
-    hipFree(raw);
+    (void)hipFree(raw);
     if (err != hipSuccess)
         return (uint32_t)err;
     r->orbit_size = orbit_size;
     r->orbit_uncompressed = uncompressed_size;
     r->orbit_period = period_maybe_zero;
     r->orbit_gen = generation;
+    r->orbit_type = type_tag;
     r->orbit_ok = true;
     return 0;
 }
@@ -419,12 +478,13 @@ uint32_t fs_upload_la(fs_renderer *r, uint64_t generation, int type_tag, uint32_
 {
     if (uint32_t e = use_device(r))
         return e;
-    if (type_tag != FS_T_HDR32 || iter_bytes != 4)
+    if ((type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64) || iter_bytes != 4)
         return FS_ERR_UNSUPPORTED;
     if (!r->compute)
         return FS_ERR_6;
-    if (r->la_ok && r->la_gen == generation && generation != 0)
+    if (r->la_ok && r->la_gen == generation && generation != 0 && r->la_type == type_tag)
         return 0;
+    const size_t la_bytes = type_tag == FS_T_HDR32 ? sizeof(fs_la_hdr32_u32) : sizeof(fs_la_hdr64_u32);
     if (r->las) {
         FS_TRY(hipFree(r->las));
         r->las = nullptr;
@@ -435,8 +495,8 @@ uint32_t fs_upload_la(fs_renderer *r, uint64_t generation, int type_tag, uint32_
     }
     r->la_ok = false;
     if (n_las) {
-        FS_TRY(hipMalloc((void **)&r->las, (size_t)n_las * sizeof(fs_la_hdr32_u32)));
-        FS_TRY(hipMemcpyAsync(r->las, las, (size_t)n_las * sizeof(fs_la_hdr32_u32), hipMemcpyDefault, r->compute));
+        FS_TRY(hipMalloc((void **)&r->las, (size_t)n_las * la_bytes));
+        FS_TRY(hipMemcpyAsync(r->las, las, (size_t)n_las * la_bytes, hipMemcpyDefault, r->compute));
     }
     if (n_stages) {
         FS_TRY(hipMalloc((void **)&r->stages, (size_t)n_stages * sizeof(fs_la_stage_u32)));
@@ -448,12 +508,15 @@ uint32_t fs_upload_la(fs_renderer *r, uint64_t generation, int type_tag, uint32_
     r->n_stages = n_stages;
     r->la_valid = is_valid;
     r->use_at = use_at;
-    if (at_info)
+    memset(&r->at, 0, sizeof(r->at));
+    memset(&r->at64, 0, sizeof(r->at64));
+    if (at_info && type_tag == FS_T_HDR32)
         memcpy(&r->at, at_info, sizeof(r->at));
-    else {
-        memset(&r->at, 0, sizeof(r->at));
+    else if (at_info)
+        memcpy(&r->at64, at_info, sizeof(r->at64));
+    else
         r->use_at = 0;
-    }
+    r->la_type = type_tag;
     r->la_gen = generation;
     r->la_ok = true;
     return 0;
@@ -464,10 +527,12 @@ uint32_t fs_upload_bla(fs_renderer *r, int type_tag, const void *const *levels, 
 {
     if (uint32_t e = use_device(r))
         return e;
-    if (type_tag != FS_T_HDR32)
+    if (type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64)
         return FS_ERR_UNSUPPORTED;
     if (!r->compute)
         return FS_ERR_6;
+    const size_t rec_bytes = type_tag == FS_T_HDR32 ? sizeof(fs_bla_hdr32) : sizeof(fs_bla_hdr64);
+    r->bla_type = type_tag;
     for (void *p : r->bla_level_mem)
         if (p)
             hipFree(p);
@@ -479,15 +544,15 @@ uint32_t fs_upload_bla(fs_renderer *r, int type_tag, const void *const *levels, 
     r->bla_n_levels = 0;
     if (n_levels <= 0)
         return 0;
-    std::vector<const fs_bla_hdr32 *> ptrs((size_t)n_levels, nullptr);
+    std::vector<const void *> ptrs((size_t)n_levels, nullptr);
     for (int32_t l = 0; l < n_levels; l++) {
         void *d = nullptr;
         if (levels[l] && level_sizes[l]) {
-            FS_TRY(hipMalloc(&d, level_sizes[l] * sizeof(fs_bla_hdr32)));
-            FS_TRY(hipMemcpyAsync(d, levels[l], level_sizes[l] * sizeof(fs_bla_hdr32), hipMemcpyDefault, r->compute));
+            FS_TRY(hipMalloc(&d, level_sizes[l] * rec_bytes));
+            FS_TRY(hipMemcpyAsync(d, levels[l], level_sizes[l] * rec_bytes, hipMemcpyDefault, r->compute));
         }
         r->bla_level_mem.push_back(d);
-        ptrs[l] = (const fs_bla_hdr32 *)d;
+        ptrs[l] = d;
     }
     FS_TRY(hipMalloc((void **)&r->bla_levels_dev, sizeof(void *) * (size_t)n_levels));
     FS_TRY(hipMemcpyAsync((void *)r->bla_levels_dev, ptrs.data(), sizeof(void *) * (size_t)n_levels, hipMemcpyDefault,
@@ -498,15 +563,6 @@ uint32_t fs_upload_bla(fs_renderer *r, int type_tag, const void *const *levels, 
     return 0;
 }
 
-static void fill_coords32(FsCoords32 &c, const void *coords)
-{
-    const fs_real_hdr32 *p = (const fs_real_hdr32 *)coords;
-    c.dx = fs::hreal32{p[0].m, p[0].e};
-    c.dy = fs::hreal32{p[1].m, p[1].e};
-    c.centerX = fs::hreal32{p[2].m, p[2].e};
-    c.centerY = fs::hreal32{p[3].m, p[3].e};
-}
-
 uint32_t fs_render_bla(fs_renderer *r, int type_tag, const void *coords, uint64_t n_iterations);
 
 uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, const void *coords, uint64_t n_iterations)
@@ -515,9 +571,9 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
         return e;
     if (!r->memory_initialized())
         return 0; // GPU_Render.cu:1007-1009
-    if (type_tag != FS_T_HDR32 || n_iterations > 0xFFFFFFFFull)
+    if ((type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64) || n_iterations > 0xFFFFFFFFull)
         return FS_ERR_UNSUPPORTED;
-    if (!r->orbit_ok)
+    if (!r->orbit_ok || r->orbit_type != type_tag)
         return FS_ERR_6; // GPU_Render.cu:1015-1022
     if (mode == FS_LAV2_PO && parity == FS_PARITY_CPU) {
         // No dispatched CPU RenderAlgorithm is perturbation-only in HDRFloatComplex arithmetic; the CPU parity
@@ -528,29 +584,23 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
         r->bla_n_levels = saved;
         return e;
     }
-    if (mode != FS_LAV2_PO && !r->la_ok)
+    if (mode != FS_LAV2_PO && (!r->la_ok || r->la_type != type_tag))
         return FS_ERR_6;
-    FsLav2Args32 A;
-    memset(&A, 0, sizeof(A));
-    A.out = (uint32_t *)r->iters();
-    A.zref = r->zref;
-    A.las = r->las;
-    A.stages = r->stages;
-    A.stats = r->stats;
-    A.frame = make_frame(r);
-    fill_coords32(A.coords, coords);
-    A.at = r->at;
-    A.orbit_count = (uint32_t)r->orbit_uncompressed;
-    A.period = (uint32_t)r->orbit_period;
-    A.stage_count = r->n_stages;
-    A.n_iterations = (uint32_t)n_iterations;
-    A.la_valid = r->la_ok ? r->la_valid : 0;
-    A.use_at = r->use_at;
-    A.parity = (parity == FS_PARITY_CPU_GPUSTAGE) ? FS_PARITY_GPUSTAGE : FS_PARITY_LITERAL;
-    {
+    const int kmode = mode == FS_LAV2_FULL ? FS_MODE_FULL : (mode == FS_LAV2_PO ? FS_MODE_PO : FS_MODE_LAO);
+    if (type_tag == FS_T_HDR32) {
+        FsLav2ArgsT<float> A;
+        fill_lav2<float>(r, A, coords, n_iterations, parity);
+        A.zref = r->zref;
+        A.at = r->at;
         TimedLaunch t(r);
-        fsk_lav2_hdr32(A, mode == FS_LAV2_FULL ? FS_MODE_FULL : (mode == FS_LAV2_PO ? FS_MODE_PO : FS_MODE_LAO),
-                       r->stats_on, r->variant, r->compute);
+        fsk_lav2_hdr32(A, kmode, r->stats_on, r->variant, r->compute);
+    } else {
+        FsLav2ArgsT<double> A;
+        fill_lav2<double>(r, A, coords, n_iterations, parity);
+        A.zref = r->zref64;
+        A.at = r->at64;
+        TimedLaunch t(r);
+        fsk_lav2_hdr64(A, kmode, r->stats_on, r->compute);
     }
     return (uint32_t)hipGetLastError();
 }
@@ -561,24 +611,39 @@ uint32_t fs_render_bla(fs_renderer *r, int type_tag, const void *coords, uint64_
         return e;
     if (!r->memory_initialized())
         return 0;
-    if (type_tag != FS_T_HDR32 || n_iterations > 0xFFFFFFFFull)
+    if ((type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64) || n_iterations > 0xFFFFFFFFull)
         return FS_ERR_UNSUPPORTED;
-    if (!r->orbit_ok)
+    if (!r->orbit_ok || r->orbit_type != type_tag)
         return FS_ERR_6;
-    FsBlaArgs32 A;
-    memset(&A, 0, sizeof(A));
-    A.out = (uint32_t *)r->iters();
-    A.zref = r->zref;
-    A.levels = r->bla_levels_dev;
-    A.stats = r->stats;
-    A.frame = make_frame(r);
-    fill_coords32(A.coords, coords);
-    A.orbit_count = (uint32_t)r->orbit_uncompressed;
-    A.n_iterations = (uint32_t)n_iterations;
-    A.lm2 = r->bla_lm2;
-    {
+    const bool use_bla = r->bla_n_levels > 2 && r->bla_levels_dev != nullptr && r->bla_type == type_tag;
+    if (type_tag == FS_T_HDR32) {
+        FsBlaArgsT<float> A;
+        memset(&A, 0, sizeof(A));
+        A.out = (uint32_t *)r->iters();
+        A.zref = r->zref;
+        A.levels = (const fs_bla_hdr32 *const *)r->bla_levels_dev;
+        A.stats = r->stats;
+        A.frame = make_frame(r);
+        fill_coords(A.coords, coords);
+        A.orbit_count = (uint32_t)r->orbit_uncompressed;
+        A.n_iterations = (uint32_t)n_iterations;
+        A.lm2 = r->bla_lm2;
         TimedLaunch t(r);
-        fsk_perturb_scalar_hdr32(A, r->bla_n_levels > 2 && r->bla_levels_dev != nullptr, r->stats_on, r->compute);
+        fsk_perturb_scalar_hdr32(A, use_bla, r->stats_on, r->compute);
+    } else {
+        FsBlaArgsT<double> A;
+        memset(&A, 0, sizeof(A));
+        A.out = (uint32_t *)r->iters();
+        A.zref = r->zref64;
+        A.levels = (const fs_bla_hdr64 *const *)r->bla_levels_dev;
+        A.stats = r->stats;
+        A.frame = make_frame(r);
+        fill_coords(A.coords, coords);
+        A.orbit_count = (uint32_t)r->orbit_uncompressed;
+        A.n_iterations = (uint32_t)n_iterations;
+        A.lm2 = r->bla_lm2;
+        TimedLaunch t(r);
+        fsk_perturb_scalar_hdr64(A, use_bla, r->stats_on, r->compute);
     }
     return (uint32_t)hipGetLastError();
 }
@@ -589,28 +654,54 @@ uint32_t fs_render_direct(fs_renderer *r, int type_tag, const void *coords, uint
         return e;
     if (!r->memory_initialized())
         return 0; // GPU_Render.cu:626-628
-    if (type_tag != FS_T_F64 || n_iterations > 0xFFFFFFFFull)
+    if ((type_tag != FS_T_F64 && type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64) || n_iterations > 0xFFFFFFFFull)
         return FS_ERR_UNSUPPORTED;
     if (r->cx_row_cap < r->width) {
         if (r->cx_row)
             FS_TRY(hipFree(r->cx_row));
         r->cx_row = nullptr;
-        FS_TRY(hipMalloc((void **)&r->cx_row, sizeof(double) * r->width));
+        FS_TRY(hipMalloc(&r->cx_row, (size_t)16 * r->width));
         r->cx_row_cap = r->width;
     }
-    const double *c = (const double *)coords;
-    FsDirectArgs64 A;
-    memset(&A, 0, sizeof(A));
-    A.out = (uint32_t *)r->iters();
-    A.cx_row = r->cx_row;
-    A.stats = r->stats;
-    A.frame = make_frame(r);
-    A.dy = c[1];
-    A.maxY = c[3];
-    A.n_iterations = (uint32_t)n_iterations;
-    {
+    if (type_tag == FS_T_F64) {
+        const double *c = (const double *)coords;
+        FsDirectArgs64 A;
+        memset(&A, 0, sizeof(A));
+        A.out = (uint32_t *)r->iters();
+        A.cx_row = (double *)r->cx_row;
+        A.stats = r->stats;
+        A.frame = make_frame(r);
+        A.dy = c[1];
+        A.maxY = c[3];
+        A.n_iterations = (uint32_t)n_iterations;
         TimedLaunch t(r);
         fsk_direct_f64(A, c[2], c[0], r->stats_on, r->compute);
+    } else if (type_tag == FS_T_HDR32) {
+        const fs_real_hdr32 *c = (const fs_real_hdr32 *)coords;
+        FsDirectHdrArgsT<float> A;
+        memset(&A, 0, sizeof(A));
+        A.out = (uint32_t *)r->iters();
+        A.cx_row = (fs::hreal<float> *)r->cx_row;
+        A.stats = r->stats;
+        A.frame = make_frame(r);
+        A.dy = fs::hreal32{c[1].m, c[1].e};
+        A.maxY = fs::hreal32{c[3].m, c[3].e};
+        A.n_iterations = (uint32_t)n_iterations;
+        TimedLaunch t(r);
+        fsk_direct_hdr32(A, fs::hreal32{c[2].m, c[2].e}, fs::hreal32{c[0].m, c[0].e}, r->stats_on, r->compute);
+    } else {
+        const fs_real_hdr64 *c = (const fs_real_hdr64 *)coords;
+        FsDirectHdrArgsT<double> A;
+        memset(&A, 0, sizeof(A));
+        A.out = (uint32_t *)r->iters();
+        A.cx_row = (fs::hreal<double> *)r->cx_row;
+        A.stats = r->stats;
+        A.frame = make_frame(r);
+        A.dy = fs::hreal64{c[1].m, c[1].e};
+        A.maxY = fs::hreal64{c[3].m, c[3].e};
+        A.n_iterations = (uint32_t)n_iterations;
+        TimedLaunch t(r);
+        fsk_direct_hdr64(A, fs::hreal64{c[2].m, c[2].e}, fs::hreal64{c[0].m, c[0].e}, r->stats_on, r->compute);
     }
     return (uint32_t)hipGetLastError();
 }

@@ -90,8 +90,11 @@ class GPURenderer:
 
     # ---- uploads
     def InitializePerturb(self, GenerationNumber1, Perturb1, GenerationNumber2=0, Perturb2=None,
-                          LaReferenceHost=None, T=T_HDR32):
-        """Perturb1: inputs.Orbit (or anything with data_ptr/count/period); LaReferenceHost: inputs.LATable."""
+                          LaReferenceHost=None, T=None):
+        """Perturb1: inputs.Orbit (or anything with data_ptr/count/period); LaReferenceHost: inputs.LATable.
+        T defaults to the orbit's type (T_HDR32 / T_HDR64)."""
+        if T is None:
+            T = T_HDR64 if getattr(Perturb1, "is64", False) else T_HDR32
         err = self._lib.fs_upload_orbit(self._h, GenerationNumber1, T, 4, Perturb1.data_ptr, Perturb1.count,
                                         Perturb1.count, Perturb1.period)
         if err:
@@ -105,20 +108,25 @@ class GPURenderer:
 
     # ---- renders (asynchronous on the compute stream)
     @staticmethod
-    def _coords_ptr(coords):
-        arr = np.ascontiguousarray(coords)
-        return arr, arr.ctypes.data
+    def _pack_coords(T, vals):
+        """vals: 4 x (mantissa, exp) pairs -> ABI records of the numeric type T."""
+        if T == T_HDR64:
+            dt = np.dtype([("m", "<f8"), ("e", "<i4"), ("pad_", "<i4")])
+            return np.array([(float(m), int(e), 0) for m, e in vals], dtype=dt)
+        dt = np.dtype([("m", "<f4"), ("e", "<i4")])
+        return np.array([(float(m), int(e)) for m, e in vals], dtype=dt)
 
     def RenderPerturbLAv2(self, algorithm, cx, cy, dx, dy, centerX, centerY, n_iterations, T=T_HDR32,
                           Mode=LAV2_FULL, parity=PARITY_CPU):
         """cx, cy are unused by the kernels (as in the reference).  dx..centerY: (mantissa, exp) pairs."""
-        co = np.array([tuple(dx), tuple(dy), tuple(centerX), tuple(centerY)],
-                      dtype=np.dtype([("m", "<f4"), ("e", "<i4")]))
+        co = self._pack_coords(T, [dx, dy, centerX, centerY])
         return self._lib.fs_render_lav2(self._h, T, Mode, parity, co.ctypes.data, int(n_iterations))
 
     def RenderPerturbBLA(self, algorithm, results, blas, cx, cy, dx, dy, centerX, centerY, n_iterations,
-                         iteration_precision=1, T=T_HDR32):
+                         iteration_precision=1, T=None):
         """Uploads orbit and table on every call, like the reference (GPU_Render.cu:1464-1479)."""
+        if T is None:
+            T = T_HDR64 if getattr(results, "is64", False) else T_HDR32
         err = self._lib.fs_upload_orbit(self._h, 0, T, 4, results.data_ptr, results.count, results.count,
                                         results.period)
         if err:
@@ -129,13 +137,16 @@ class GPURenderer:
             err = self._lib.fs_upload_bla(self._h, T, None, None, 0, 0)
         if err:
             return err
-        co = np.array([tuple(dx), tuple(dy), tuple(centerX), tuple(centerY)],
-                      dtype=np.dtype([("m", "<f4"), ("e", "<i4")]))
+        co = self._pack_coords(T, [dx, dy, centerX, centerY])
         return self._lib.fs_render_bla(self._h, T, co.ctypes.data, int(n_iterations))
 
     def Render(self, algorithm, cx, cy, dx, dy, n_iterations, iteration_precision=1, T=T_F64):
-        """Direct kernels.  cx = minX, cy = maxY (Fractal.cpp:1894-1915 passes the view corner)."""
-        co = np.array([dx, dy, cx, cy], dtype=np.float64)
+        """Direct kernels.  cx = minX, cy = maxY (Fractal.cpp:1894-1915 passes the view corner).  For T_F64 the
+        arguments are doubles, for T_HDR32 / T_HDR64 (mantissa, exp) pairs of the un-reduced HDRFloat values."""
+        if T == T_F64:
+            co = np.array([dx, dy, cx, cy], dtype=np.float64)
+        else:
+            co = self._pack_coords(T, [dx, dy, cx, cy])
         return self._lib.fs_render_direct(self._h, T, co.ctypes.data, int(n_iterations))
 
     def RenderCurrent(self, n_iterations, iter_buffer=None, color_buffer=None, reduction_results=None,

@@ -156,6 +156,14 @@ template uint32_t GPURenderer::RenderPerturbBLA<uint32_t, HDR32>(RenderAlgorithm
                                                                  BLAS<uint32_t, HDR32> *, HDR32, HDR32, HDR32, HDR32, HDR32,
                                                                  HDR32, uint32_t, int);
 template uint32_t GPURenderer::Render<uint32_t, double>(RenderAlgorithm, double, double, double, double, uint32_t, int);
+using HDR64 = HDRFloat<double>;
+template uint32_t GPURenderer::Render<uint32_t, HDR32>(RenderAlgorithm, HDR32, HDR32, HDR32, HDR32, uint32_t, int);
+template uint32_t GPURenderer::RenderPerturbLAv2<uint32_t, HDR64, double, LAv2Mode::Full, PerturbExtras::Disable>(
+    RenderAlgorithm, HDR64, HDR64, HDR64, HDR64, HDR64, HDR64, uint32_t);
+template uint32_t GPURenderer::RenderPerturbBLA<uint32_t, HDR64>(RenderAlgorithm,
+                                                                 const GPUPerturbResults<uint32_t, HDR64, PerturbExtras::Disable> *,
+                                                                 BLAS<uint32_t, HDR64> *, HDR64, HDR64, HDR64, HDR64, HDR64,
+                                                                 HDR64, uint32_t, int);
 template uint32_t GPURenderer::RenderCurrent<uint32_t>(uint32_t, uint32_t *, Color16 *, ReductionResults *, bool);
 
 int main()

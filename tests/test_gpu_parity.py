@@ -8,7 +8,7 @@ import pytest
 
 import _oracle
 from fractalshark_amd import (GPURenderer, LAV2_FULL, LAV2_LAO, LAV2_PO, PARITY_CPU, PARITY_CPU_GPUSTAGE, T_F64,
-                              T_HDR32, _capi, inputs)
+                              T_HDR32, T_HDR64, _capi, inputs)
 
 pytestmark = pytest.mark.gpu
 
@@ -39,9 +39,10 @@ def _render_lav2(r, v, ob, la, mode, parity, n_iter=None):
     assert r.InitializeMemory(w, h, v.antialiasing, None, 0, 0, 0, False) == 0
     assert r.InitializePerturb(1, ob, 0, None, la) == 0
     assert r.ClearMemory() == 0
-    dx, dy, cx, cy = _pairs(v.coords_perturb_hdr32(ob))
+    dx, dy, cx, cy = _pairs(v.coords_perturb(ob))
     n = v.num_iterations if n_iter is None else n_iter
-    assert r.RenderPerturbLAv2(None, None, None, dx, dy, cx, cy, n, T=T_HDR32, Mode=mode, parity=parity) == 0
+    T = T_HDR64 if ob.is64 else T_HDR32
+    assert r.RenderPerturbLAv2(None, None, None, dx, dy, cx, cy, n, T=T, Mode=mode, parity=parity) == 0
     assert r.SyncComputeStream() == 0
     out = r.new_iter_buffer()
     red = _capi.Reduction()
@@ -267,3 +268,47 @@ def test_view5_po_parity_rows_1080p(renderer, native_libs):
     for y in range(135, 1080, 270):
         assert np.array_equal(out[y], ref[y]), y
     assert red.Sum == int(out[:1080, :1920].astype(np.uint64).sum())
+
+
+# ---- HDRFloat<double> family (GpuHDRx64* <-> Cpu64Perturbed*HDR) and HDR direct kernels (GpuHDRx32 <-> CpuHDR32/64)
+@pytest.fixture(scope="module")
+def v5_small_64(native_libs):
+    v = inputs.View.builtin(5, 64, 36)
+    ob = inputs.Orbit(v, is64=True)
+    return v, ob, inputs.LATable(ob), inputs.BLATable(ob)
+
+
+@pytest.mark.parametrize("mode,parity,st,omode", [(LAV2_FULL, PARITY_CPU, 0, 0), (LAV2_FULL, PARITY_CPU_GPUSTAGE, 1, 0),
+                                                  (LAV2_LAO, PARITY_CPU, 0, 2)])
+def test_hdr64_lav2_parity(renderer, v5_small_64, mode, parity, st, omode):
+    v, ob, la, _ = v5_small_64
+    out, red = _render_lav2(renderer, v, ob, la, mode, parity)
+    ref = _oracle.lav2_hdr32(v, ob, la, stage_test=st, mode=omode)
+    assert np.array_equal(out, ref)
+    assert red.Sum == int(ref[:36, :64].astype(np.uint64).sum())
+
+
+def test_hdr64_po_and_bla_parity(renderer, v5_small_64):
+    v, ob, la, bla = v5_small_64
+    out, _ = _render_lav2(renderer, v, ob, la, LAV2_PO, PARITY_CPU)
+    assert np.array_equal(out, _oracle.bla_hdr32(v, ob, None))
+    r = renderer
+    dx, dy, cx, cy = _pairs(v.coords_perturb(ob))
+    assert r.RenderPerturbBLA(None, ob, bla, None, None, dx, dy, cx, cy, v.num_iterations) == 0
+    out = r.new_iter_buffer()
+    assert r.RenderCurrent(v.num_iterations, out) == 0
+    assert r.SyncComputeStream() == 0
+    assert np.array_equal(out, _oracle.bla_hdr32(v, ob, bla))
+
+
+@pytest.mark.parametrize("is64", [False, True])
+def test_direct_hdr_parity(renderer, native_libs, is64):
+    v = inputs.View.builtin(0, 64, 48)
+    r = renderer
+    assert r.InitializeMemory(64, 48, 1, None, 0, 0, 0, False) == 0
+    dx, dy, minx, maxy = _pairs(v.coords_direct_hdr(is64))
+    assert r.Render(None, minx, maxy, dx, dy, v.num_iterations, T=T_HDR64 if is64 else T_HDR32) == 0
+    out = r.new_iter_buffer()
+    assert r.RenderCurrent(v.num_iterations, out) == 0
+    assert r.SyncComputeStream() == 0
+    assert np.array_equal(out, _oracle.direct_hdr(v, is64))
