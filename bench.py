@@ -60,7 +60,7 @@ def parse():
                     help="cpu = literal reference CPU function (bit-exact vs Cpu32PerturbedBLAV2HDR); "
                          "cpu_gpustage = same arithmetic, LA stage test in the GPU/FractalZoomer direction")
     ap.add_argument("--cpu-sample-rows", type=int, default=0,
-                    help="rows of the frame timed on the CPU (0 = 2 x host cores, about 10-30 s of CPU work)")
+                    help="rows of the frame timed on the CPU (0 = 8 x usable host threads, about 10-30 s of CPU work)")
     ap.add_argument("--no-cpu", action="store_true")
     return ap.parse_args()
 
@@ -215,7 +215,7 @@ def main():
     if rank == 0 and not distributed and not args.no_cpu:
         import _oracle
         threads = effective_cpus()
-        nrows = max(1, min(args.cpu_sample_rows if args.cpu_sample_rows > 0 else 2 * threads, H))
+        nrows = max(1, min(args.cpu_sample_rows if args.cpu_sample_rows > 0 else 8 * threads, H))
         step = max(1, H // nrows)
         y0 = step // 2
         rows = list(range(y0, H, step))
@@ -237,6 +237,18 @@ def main():
                         "sample": "%d of %d rows of the same %dx%d frame (rows spread evenly), %.1f s" %
                                   (nrows, H, W, H, cpu_t)}
 
+    traffic = None
+    if rank == 0:
+        # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (collected in separate
+        # --pmc runs, see profiles/r01_traffic.json); null for workloads that have not been profiled.
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            key = "view%d_%dx%d_hdrx32_%s" % (args.view, W, H, {"c3_lav2": "lav2_full", "c2_po": "po",
+                                                                 "c5_bla": "bla"}[args.workload])
+            if key in tj and not distributed and args.parity == "cpu":
+                traffic = tj[key]["traffic_bytes"]
+        except (OSError, ValueError, KeyError):
+            traffic = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = W * H * args.steps / elapsed / 1e6
@@ -254,7 +266,7 @@ def main():
                        "bla_levels": bla.num_levels if bla else 0, "tiling": "rows/8-row bands interleaved x%d" % world,
                        "host_input_build_s": round(t_inputs, 3)},
             "roofline": {"bound": "valu", "achieved": round(achieved, 4), "peak": PEAK_FP32_VECTOR_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 5), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 5), "traffic": traffic,
                          "kernel": "k_lav2_hdr32_fast" if args.workload == "c3_lav2" else "k_perturb_scalar_hdr32",
                          "kernel_ms": round(avg_kernel_ms, 3),
                          "pixel_steps_per_launch": perturb_steps, "at_iterations_per_launch": at_iters,
