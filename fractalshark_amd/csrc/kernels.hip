@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/fs_layout.h"
 #include "hdr_math.hpp"
 #include "kernels.h"
@@ -586,6 +588,103 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
             // The orbit entry read for the escape test of the previous step is the Z of this step unless a rebase or a
             // BLA jump moved RefIteration: one dependent 16-byte load per step instead of two.
             const hcplx<F> Z = (Zcached_at == RefIteration) ? Zcached : zref_at(zr, RefIteration);
+
+            // ---- tuned single step (float only): speculative straight-line evaluation under the exponent-alignment
+            // cases that hold in > 99.9 % of lane-steps (measured with an instrumented oracle):
+            //   2Z+O, +dc, Z'+n : left operand (orbit / accumulated value) has the larger exponent (far case allowed);
+            //   B1-B2, C1+C2     : one swap decision, OX.e >= OY.e, because T3 and T4 share the exponent of 2Z;
+            //   zx^2+zy^2        : equal exponents.
+            // Committed only when every running lane of the wave met the assumptions (one ballot); otherwise the
+            // wave takes the generic step below, which is the literal CPU order.
+            bool done_fast = false;
+            if constexpr (std::is_same<F, float>::value) {
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                const auto zn4 = zr[RefIteration + 1]; // in bounds: the prepared orbit has two spare entries
+                const int Ze1 = Z.e + 1;
+                const f2 O = {OX.m, OY.m};
+                const int n4 = OX.e - Ze1, n3 = OY.e - Ze1; // negated gaps, <= 0 expected
+                const f2 tsc = {n4 > -kExpDiffIgnored ? __int_as_float((n4 << 23) + 0x3F800000) : 0.0f,
+                                n3 > -kExpDiffIgnored ? __int_as_float((n3 << 23) + 0x3F800000) : 0.0f};
+                const f2 T = (f2){Z.re, Z.im} + O * tsc; // (T4.m, T3.m), both with exponent Ze1
+                const f2 P1 = O.xx * T;                  // (B1.m, C1.m) exponent e1 = OX.e + Ze1
+                const f2 P2 = O.yy * T.yx;               // (B2.m, C2.m) exponent e2 = OY.e + Ze1
+                const int dxy = OX.e - OY.e;
+                const bool xbig = dxy >= 0;
+                const int nad = xbig ? -dxy : dxy;
+                const float ms = nad > -kExpDiffIgnored ? __int_as_float((nad << 23) + 0x3F800000) : 0.0f;
+                const f2 P1s = P1 * (xbig ? 1.0f : ms);
+                const f2 P2s = P2 * (xbig ? ms : 1.0f);
+                f2 N; // (B1' - B2', C1' + C2')
+                asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(N) : "v"(P1s), "v"(P2s));
+                const int E = (xbig ? OX.e : OY.e) + Ze1;
+                const int ncx = DeltaSub0X.e - E, ncy = DeltaSub0Y.e - E;
+                const f2 dsc = {ncx > -kExpDiffIgnored ? __int_as_float((ncx << 23) + 0x3F800000) : 0.0f,
+                                ncy > -kExpDiffIgnored ? __int_as_float((ncy << 23) + 0x3F800000) : 0.0f};
+                const f2 Q = N + (f2){DeltaSub0X.m, DeltaSub0Y.m} * dsc;
+                // scalar Reduce of each part
+                const int qxb = __float_as_int(Q.x), qyb = __float_as_int(Q.y);
+                const int fx = (int)__builtin_amdgcn_ubfe(qxb, 23, 8), fy = (int)__builtin_amdgcn_ubfe(qyb, 23, 8);
+                const float nxm = __int_as_float((qxb & 0x807FFFFF) | 0x3F800000);
+                const float nym = __int_as_float((qyb & 0x807FFFFF) | 0x3F800000);
+                const int nxe = E + fx - 127, nye = E + fy - 127;
+                // z = Z' + n
+                const int Zne = __float_as_int(zn4.z);
+                const int nzx = nxe - Zne, nzy = nye - Zne;
+                const f2 zsc = {nzx > -kExpDiffIgnored ? __int_as_float((nzx << 23) + 0x3F800000) : 0.0f,
+                                nzy > -kExpDiffIgnored ? __int_as_float((nzy << 23) + 0x3F800000) : 0.0f};
+                const f2 Zt = (f2){zn4.x, zn4.y} + (f2){nxm, nym} * zsc; // (tempZX.m, tempZY.m), exponent Zne
+                const f2 ZZ = Zt * Zt;
+                const float nm = ZZ.x + ZZ.y; // exponent 2*Zne
+                // dn = nx^2 + ny^2
+                const f2 SQ = (f2){nxm, nym} * (f2){nxm, nym};
+                const int dd = (nxe - nye) << 1;
+                const bool sxbig = dd >= 0;
+                const int nadd = sxbig ? -dd : dd;
+                const float md = nadd > -kExpDiffIgnored ? __int_as_float((nadd << 23) + 0x3F800000) : 0.0f;
+                const float dnm = SQ.x * (sxbig ? 1.0f : md) + SQ.y * (sxbig ? md : 1.0f);
+                const int dne = (sxbig ? nxe : nye) << 1;
+                // assumptions
+                const int gmax = imax(imax(imax(n4, n3), imax(ncx, ncy)), imax(nzx, nzy));
+                const float tiny = fminf(fminf(fminf(fabsf(T.x), fabsf(T.y)), fminf(fabsf(N.x), fabsf(N.y))),
+                                         fminf(fabsf(Zt.x), fabsf(Zt.y)));
+                const bool ok = gmax <= 0 && (OX.e < OY.e ? OX.e : OY.e) > -(1 << 26) && tiny > 0.0f &&
+                                __builtin_amdgcn_classf(Q.x, 0x108 /* +-normal */) &&
+                                __builtin_amdgcn_classf(Q.y, 0x108) && __builtin_amdgcn_classf(nm, 0x100) &&
+                                RefIteration + 1 < count;
+                if (__ballot(!ok) == 0ull) {
+                    done_fast = true;
+                    if (kStats)
+                        c_pt++;
+                    ++RefIteration;
+                    Zcached = hcplx<F>{zn4.x, zn4.y, Zne};
+                    Zcached_at = RefIteration;
+                    DeltaSubNX = hreal<F>{nxm, nxe};
+                    DeltaSubNY = hreal<F>{nym, nye};
+                    // Reduce(dn): dnm is in [1, 8]
+                    {
+                        const int db = __float_as_int(dnm);
+                        DeltaNormSquared = hreal<F>{__int_as_float((db & 0x007FFFFF) | 0x3F800000),
+                                                    dne + (int)__builtin_amdgcn_ubfe(db, 23, 8) - 127};
+                    }
+                    // Reduce(n) > 256 <=> nm * 2^(2 Zne) > 2^8 (nm a positive normal float); zn4.w = 2^(8 - 2 Zne)
+                    if (nm > zn4.w)
+                        break;
+                    // Reduce(n) < Reduce(dn) <=> nm * 2^(2 Zne) < dnm * 2^dne
+                    if (nm < __builtin_amdgcn_ldexpf(dnm, dne - (Zne << 1)) || RefIteration >= count - 1) {
+                        DeltaSubNX = hreal<F>{Zt.x, Zne};
+                        DeltaSubNY = hreal<F>{Zt.y, Zne};
+                        const int nb = __float_as_int(nm);
+                        DeltaNormSquared = hreal<F>{__int_as_float((nb & 0x007FFFFF) | 0x3F800000),
+                                                    (Zne << 1) + (int)__builtin_amdgcn_ubfe(nb, 23, 8) - 127};
+                        RefIteration = 0;
+                    }
+                    ++iter;
+                }
+            }
+            if (done_fast)
+                continue;
+
+            // ---- generic single step, literal order of Fractal.cpp:2342-2466
             // Term4 == the inner sum of TermB1, Term3 == the inner sum of TermB2 (same operands, same order)
             const hreal<F> T4 = hr_add(hr_mul2(hc_re(Z)), OX);
             const hreal<F> T3 = hr_add(hr_mul2(hc_im(Z)), OY);
