@@ -127,6 +127,11 @@ def inputs_lib():
     _decl(lib, "fsh_view_coords_direct_hdr32", None, [vp, u32, u32, vp])
     _decl(lib, "fsh_view_coords_direct_hdr64", None, [vp, u32, u32, vp])
     _decl(lib, "fsh_orbit_create", vp, [vp, C.c_int, u64, C.c_int])
+    _decl(lib, "fsh_orbit_create_ex", vp, [vp, C.c_int, u64, C.c_int, C.c_int])
+    _decl(lib, "fsh_orbit_is_compressed", C.c_int, [vp])
+    _decl(lib, "fsh_orbit_compressed_count", u64, [vp])
+    _decl(lib, "fsh_orbit_compressed_data_hdr32", vp, [vp])
+    _decl(lib, "fsh_orbit_low_hdr32", None, [vp, vp])
     _decl(lib, "fsh_orbit_destroy", None, [vp])
     _decl(lib, "fsh_orbit_count", u64, [vp])
     _decl(lib, "fsh_orbit_period", u64, [vp])

@@ -275,6 +275,12 @@ template <class F> struct OrbitT {
     // packed copies in the ABI layout, built lazily
     std::vector<fs_orbit_hdr32> packed32;
     std::vector<fs_orbit_hdr64> packed64;
+    // PerturbExtras::SimpleCompression: waypoints (m_FullOrbit of the compressed PerturbationResults); x / y above
+    // then hold the orbit as RuntimeDecompressor reproduces it.
+    bool compressed = false;
+    std::vector<uint64_t> wp_index;
+    std::vector<hreal<F>> wp_x, wp_y;
+    std::vector<fs_orbit_hdr32_rc> packed_rc32;
 };
 
 struct fsh_orbit {
@@ -287,7 +293,22 @@ namespace {
 
 // AddPerturbationReferencePointST<..., Periodicity, ...>, RefOrbitCalc.cpp:423-647, for T = HDRFloat<F>,
 // PerturbExtras::Disable, ReuseMode::DontSaveForReuse.
-template <class F> void build_orbit(const fsh_view &vw, uint64_t max_iter, bool periodicity, OrbitT<F> &ob)
+// RuntimeDecompressor::GetCompressedComplex's runOneIter, PerturbationResultsHelpers.h:51-58 (== the compressor's own
+// advance, PerturbationResults.cpp:2374-2378).
+template <class F> void rc_one_iter(hreal<F> &zx, hreal<F> &zy, hreal<F> cxLow, hreal<F> cyLow)
+{
+    const hreal<F> zx_old = zx;
+    zx = hr_add(hr_sub(hr_mul(zx, zx), hr_mul(zy, zy)), cxLow);
+    hr_reduce(zx);
+    zy = hr_add(hr_mul(hr_mul(hr_from_number<F>(F(2)), zx_old), zy), cyLow);
+    hr_reduce(zy);
+}
+
+// compression_exp < 0: PerturbExtras::Disable.  Otherwise PerturbExtras::SimpleCompression with
+// CompressionError = T(10^compression_exp) (RefOrbitCompressor, PerturbationResults.cpp:2334-2381; default exponent 20,
+// Fractal.h:138-141).
+template <class F>
+void build_orbit(const fsh_view &vw, uint64_t max_iter, bool periodicity, OrbitT<F> &ob, int compression_exp = -1)
 {
     mpf_set_default_prec(vw.prec_bits);
     ob.prec_bits = vw.prec_bits;
@@ -310,6 +331,13 @@ template <class F> void build_orbit(const fsh_view &vw, uint64_t max_iter, bool 
     ob.x.push_back(hr_zero<F>());
     ob.y.push_back(hr_zero<F>());
     ob.period = 0;
+    ob.compressed = compression_exp >= 0;
+    ob.wp_index.assign(1, 0);
+    ob.wp_x.assign(1, hr_zero<F>());
+    ob.wp_y.assign(1, hr_zero<F>());
+    uint64_t count = 1; // m_UncompressedItersInOrbit
+    hreal<F> rc_zx = ob.orbitXLow, rc_zy = ob.orbitYLow;
+    const hreal<F> rc_err = hr_from_number<F>((F)std::pow(10.0, compression_exp));
 
     mpf_t cx, cy, zx, zy, zx2, t1, t2;
     mpf_init(cx);
@@ -343,8 +371,25 @@ template <class F> void build_orbit(const fsh_view &vw, uint64_t max_iter, bool 
         mpf_mul_2exp(zx2, zx, 1);
         hreal<F> double_zx = hr_from_mpf<F>(zx);
         hreal<F> double_zy = hr_from_mpf<F>(zy);
-        ob.x.push_back(double_zx);
-        ob.y.push_back(double_zy);
+        if (!ob.compressed) {
+            ob.x.push_back(double_zx);
+            ob.y.push_back(double_zy);
+        } else {
+            // MaybeAddCompressedIteration({double_zx, double_zy, i + 1})
+            const hreal<F> errX = hr_sub(rc_zx, double_zx);
+            const hreal<F> errY = hr_sub(rc_zy, double_zy);
+            const hreal<F> norm_z = hr_reduced(hr_add(hr_mul(double_zx, double_zx), hr_mul(double_zy, double_zy)));
+            const hreal<F> err = hr_reduced(hr_mul(hr_add(hr_mul(errX, errX), hr_mul(errY, errY)), rc_err));
+            if (hr_cmp_pos(err, norm_z) >= 0) {
+                ob.wp_index.push_back(i + 1);
+                ob.wp_x.push_back(double_zx);
+                ob.wp_y.push_back(double_zy);
+                rc_zx = double_zx;
+                rc_zy = double_zy;
+            }
+            rc_one_iter(rc_zx, rc_zy, ob.orbitXLow, ob.orbitYLow);
+        }
+        count++;
 
         if (periodicity) {
             hr_reduce(dzdcX);
@@ -360,7 +405,7 @@ template <class F> void build_orbit(const fsh_view &vw, uint64_t max_iter, bool 
             hreal<F> n3 = hr_mul(hr_mul(ob.maxRadius, r0), HighTwo);
             hr_reduce(n3);
             if (hr_cmp_pos(n2, n3) < 0) {
-                ob.period = ob.x.size(); // GetCountOrbitEntries()
+                ob.period = count; // GetCountOrbitEntries()
                 break;
             } else {
                 const hreal<F> dzdcXOrig = dzdcX;
@@ -390,19 +435,66 @@ template <class F> void build_orbit(const fsh_view &vw, uint64_t max_iter, bool 
     mpf_clear(zx2);
     mpf_clear(t1);
     mpf_clear(t2);
+
+    if (ob.compressed) {
+        // What every consumer of a compressed orbit sees through RuntimeDecompressor::GetCompressedComplex
+        // (PerturbationResultsHelpers.h:46-161): the waypoint at or below the index, advanced with runOneIter.  The
+        // cache in that function only avoids recomputation; the value at an index is a pure function of the waypoints.
+        ob.x.assign(count, hr_zero<F>());
+        ob.y.assign(count, hr_zero<F>());
+        for (size_t k = 0; k < ob.wp_index.size(); k++) {
+            const uint64_t i0 = ob.wp_index[k];
+            const uint64_t i1 = k + 1 < ob.wp_index.size() ? ob.wp_index[k + 1] : count;
+            hreal<F> zx_ = ob.wp_x[k], zy_ = ob.wp_y[k];
+            for (uint64_t i = i0; i < i1; i++) {
+                ob.x[i] = zx_;
+                ob.y[i] = zy_;
+                rc_one_iter(zx_, zy_, ob.orbitXLow, ob.orbitYLow);
+            }
+        }
+    }
 }
 
 } // namespace
 
-extern "C" fsh_orbit *fsh_orbit_create(const fsh_view *v, int is64, uint64_t max_iter, int periodicity)
+extern "C" fsh_orbit *fsh_orbit_create_ex(const fsh_view *v, int is64, uint64_t max_iter, int periodicity,
+                                          int compression_exp)
 {
     auto ob = std::make_unique<fsh_orbit>();
     ob->is64 = is64;
     if (is64)
-        build_orbit<double>(*v, max_iter, periodicity != 0, ob->d);
+        build_orbit<double>(*v, max_iter, periodicity != 0, ob->d, compression_exp);
     else
-        build_orbit<float>(*v, max_iter, periodicity != 0, ob->f);
+        build_orbit<float>(*v, max_iter, periodicity != 0, ob->f, compression_exp);
     return ob.release();
+}
+extern "C" fsh_orbit *fsh_orbit_create(const fsh_view *v, int is64, uint64_t max_iter, int periodicity)
+{
+    return fsh_orbit_create_ex(v, is64, max_iter, periodicity, -1);
+}
+extern "C" int fsh_orbit_is_compressed(const fsh_orbit *o) { return (o->is64 ? o->d.compressed : o->f.compressed) ? 1 : 0; }
+extern "C" uint64_t fsh_orbit_compressed_count(const fsh_orbit *o)
+{
+    return o->is64 ? o->d.wp_index.size() : o->f.wp_index.size();
+}
+// GPUReferenceIter<HDRFloat<float>, SimpleCompression>[] (24 B: index, x, y) -- what FractalShark's compressed
+// PerturbationResults holds and what fs_upload_orbit_compressed consumes.
+extern "C" const fs_orbit_hdr32_rc *fsh_orbit_compressed_data_hdr32(fsh_orbit *o)
+{
+    if (o->is64 || !o->f.compressed)
+        return nullptr;
+    auto &ob = o->f;
+    if (ob.packed_rc32.size() != ob.wp_index.size()) {
+        ob.packed_rc32.resize(ob.wp_index.size());
+        for (size_t k = 0; k < ob.wp_index.size(); k++)
+            ob.packed_rc32[k] = fs_orbit_hdr32_rc{ob.wp_index[k], ob.wp_x[k].m, ob.wp_x[k].e, ob.wp_y[k].e, ob.wp_y[k].m};
+    }
+    return ob.packed_rc32.data();
+}
+extern "C" void fsh_orbit_low_hdr32(const fsh_orbit *o, fs_real_hdr32 out[2])
+{
+    out[0] = fs_real_hdr32{o->f.orbitXLow.m, o->f.orbitXLow.e};
+    out[1] = fs_real_hdr32{o->f.orbitYLow.m, o->f.orbitYLow.e};
 }
 extern "C" void fsh_orbit_destroy(fsh_orbit *o) { delete o; }
 extern "C" uint64_t fsh_orbit_count(const fsh_orbit *o) { return o->is64 ? o->d.x.size() : o->f.x.size(); }
@@ -661,14 +753,15 @@ template <class F> struct LATable {
 };
 
 constexpr uint32_t kLowBound = 64;   // LAReference.h:56
-constexpr int kPeriodDivisor = 2;    // LAReference.cpp:18-19 (PerturbExtras::Disable)
+// periodDivisor: 2 for PerturbExtras::Disable, 8 for SimpleCompression (LAReference.cpp:12-19)
 constexpr uint32_t kMaxLAStages = 1024;
 
 template <class F> struct LABuilder {
     const LAParams p;
     const OrbitT<F> &ob;
     LATable<F> &T;
-    LABuilder(const OrbitT<F> &o, LATable<F> &t) : p{}, ob(o), T(t) {}
+    const int kPeriodDivisor;
+    LABuilder(const OrbitT<F> &o, LATable<F> &t) : p{}, ob(o), T(t), kPeriodDivisor(o.compressed ? 8 : 2) {}
 
     hcplx<F> Z(uint64_t i) const { return hc_from_hr(ob.x[i], ob.y[i]); } // GetComplex<SubType>()
 

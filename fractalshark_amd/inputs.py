@@ -115,12 +115,15 @@ class View:
 class Orbit:
     """Reference orbit at the view centre (PerturbationResults<uint32_t, HDRFloat<float>, Disable> layout)."""
 
-    def __init__(self, view, max_iter=None, periodicity=True, is64=False):
+    def __init__(self, view, max_iter=None, periodicity=True, is64=False, compression_exp=None):
+        """compression_exp: None = PerturbExtras::Disable; an int (reference default 20) = SimpleCompression."""
         self._lib = _capi.inputs_lib()
         self.view = view
         self.is64 = bool(is64)
+        self.compressed = compression_exp is not None
         n = view.num_iterations if max_iter is None else max_iter
-        self._h = self._lib.fsh_orbit_create(view._h, 1 if is64 else 0, n, 1 if periodicity else 0)
+        self._h = self._lib.fsh_orbit_create_ex(view._h, 1 if is64 else 0, n, 1 if periodicity else 0,
+                                                -1 if compression_exp is None else int(compression_exp))
         if not self._h:
             raise RuntimeError("fsh_orbit_create failed")
         self.count = self._lib.fsh_orbit_count(self._h)
@@ -134,6 +137,19 @@ class Orbit:
     @property
     def data_ptr(self):
         return self._lib.fsh_orbit_data_hdr64(self._h) if self.is64 else self._lib.fsh_orbit_data_hdr32(self._h)
+
+    @property
+    def compressed_count(self):
+        return self._lib.fsh_orbit_compressed_count(self._h)
+
+    @property
+    def compressed_data_ptr(self):
+        return self._lib.fsh_orbit_compressed_data_hdr32(self._h)
+
+    def orbit_low(self):
+        out = np.zeros(2, REAL_HDR32)
+        self._lib.fsh_orbit_low_hdr32(self._h, out.ctypes.data)
+        return out
 
     def entries(self):
         dt = ORBIT_HDR64_DTYPE if self.is64 else ORBIT_HDR32_DTYPE

@@ -43,6 +43,13 @@ void fsh_view_coords_direct_f64(const fsh_view *v, uint32_t w_aa, uint32_t h_aa,
 /* Reference orbit at the bounding-box centre. is64: 0 = HDRFloat<float>, 1 = HDRFloat<double>.
  * periodicity: 1 = STPeriodicity (what PerturbationAlg::Auto picks below 1e150), 0 = ST. */
 fsh_orbit *fsh_orbit_create(const fsh_view *v, int is64, uint64_t max_iter, int periodicity);
+/* compression_exp < 0: uncompressed; >= 0: PerturbExtras::SimpleCompression with CompressionError 10^exp (default 20).
+ * The uncompressed accessors (fsh_orbit_data_*, count) then expose the orbit as RuntimeDecompressor reproduces it. */
+fsh_orbit *fsh_orbit_create_ex(const fsh_view *v, int is64, uint64_t max_iter, int periodicity, int compression_exp);
+int fsh_orbit_is_compressed(const fsh_orbit *o);
+uint64_t fsh_orbit_compressed_count(const fsh_orbit *o);
+const fs_orbit_hdr32_rc *fsh_orbit_compressed_data_hdr32(fsh_orbit *o);
+void fsh_orbit_low_hdr32(const fsh_orbit *o, fs_real_hdr32 out[2]); /* {OrbitXLow, OrbitYLow} */
 void fsh_orbit_destroy(fsh_orbit *o);
 uint64_t fsh_orbit_count(const fsh_orbit *o);  /* GetCountOrbitEntries(), includes the zero entry */
 uint64_t fsh_orbit_period(const fsh_orbit *o); /* GetPeriodMaybeZero() */

@@ -55,6 +55,16 @@ typedef struct fs_orbit_hdr32 {
     float my;
 } fs_orbit_hdr32;
 
+/* GPUReferenceIter<HDRFloat<float>, PerturbExtras::SimpleCompression>: the CompressionIndexField base
+ * (63-bit uncompressed index + 1 rebase bit, GPU_ReferenceIter.h:26-49) comes first, then x, y; 24 B. */
+typedef struct fs_orbit_hdr32_rc {
+    uint64_t index_and_rebase; /* bits 0..62 CompressionIndex, bit 63 Rebase */
+    float mx;
+    int32_t ex;
+    int32_t ey;
+    float my;
+} fs_orbit_hdr32_rc;
+
 typedef struct fs_orbit_hdr64 {
     double mx;
     int32_t ex;
@@ -161,6 +171,7 @@ typedef struct fs_reduction {
 #ifdef __cplusplus
 }
 static_assert(sizeof(fs_orbit_hdr32) == 16, "orbit entry");
+static_assert(sizeof(fs_orbit_hdr32_rc) == 24, "compressed orbit entry");
 static_assert(sizeof(fs_orbit_hdr64) == 32, "orbit entry (double)");
 static_assert(sizeof(fs_la_hdr32_u32) == 68, "LA record");
 static_assert(sizeof(fs_at_hdr32_u32) == 116, "AT record");

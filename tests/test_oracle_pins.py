@@ -132,3 +132,15 @@ def test_golden_view0_cpuhdr(native_libs, is64, expected):
     v = inputs.View.builtin(0, W, H)
     it = _oracle.direct_hdr(v, is64)
     assert _oracle.png_crc64(it, W, H, 1, v.num_iterations) == expected
+
+
+# ---- PerturbExtras::SimpleCompression ("RC" algorithms): compressed reference orbit + runtime decompression
+@needs_pin
+@pytest.mark.parametrize("is64,expected", [(False, "b956600cfdfe431a"), (True, "68df9ceecaf1a667")])
+def test_golden_view5_rc_blav2_hdr(native_libs, is64, expected):
+    v = inputs.View.builtin(5, W, H)
+    ob = inputs.Orbit(v, is64=is64, compression_exp=20)
+    assert ob.compressed_count < ob.count
+    la = inputs.LATable(ob)
+    it = _oracle.lav2_hdr32(v, ob, la, stage_test=0)
+    assert _oracle.png_crc64(it, W, H, 1, v.num_iterations) == expected
