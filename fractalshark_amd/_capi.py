@@ -80,6 +80,7 @@ def render_lib():
     _decl(lib, "fs_device_iter_buffer", vp, [vp])
     _decl(lib, "fs_rounded_width", u32, [vp])
     _decl(lib, "fs_upload_orbit", u32, [vp, u64, C.c_int, u32, vp, u64, u64, u64])
+    _decl(lib, "fs_upload_orbit_compressed", u32, [vp, u64, C.c_int, u32, vp, u64, u64, u64, vp, vp])
     _decl(lib, "fs_upload_la", u32, [vp, u64, C.c_int, u32, vp, u32, vp, u32, C.c_int, C.c_int, vp])
     _decl(lib, "fs_upload_bla", u32, [vp, C.c_int, vp, vp, i32, i32])
     _decl(lib, "fs_render_lav2", u32, [vp, C.c_int, C.c_int, C.c_int, vp, u64])
@@ -103,7 +104,7 @@ def render_lib():
 
 RENDER_SYMBOLS = [
     "fs_create", "fs_destroy", "fs_test_device_is_working", "fs_error_string", "fs_init_memory", "fs_set_row_bands",
-    "fs_local_rows", "fs_set_external_iter_buffer", "fs_device_iter_buffer", "fs_rounded_width", "fs_upload_orbit",
+    "fs_local_rows", "fs_set_external_iter_buffer", "fs_device_iter_buffer", "fs_rounded_width", "fs_upload_orbit", "fs_upload_orbit_compressed",
     "fs_upload_la", "fs_upload_bla", "fs_render_lav2", "fs_render_bla", "fs_render_direct", "fs_clear",
     "fs_render_current", "fs_sync_compute", "fs_sync_display", "fs_query_compute", "fs_enqueue_done_callback",
     "fs_get_width", "fs_get_height", "fs_last_kernel_ms", "fs_set_kernel_variant", "fs_enable_step_count", "fs_read_step_count",
@@ -158,5 +159,15 @@ def inputs_lib():
     _decl(lib, "fsh_bla_lm2", i32, [vp])
     _decl(lib, "fsh_bla_level_ptrs", vp, [vp])
     _decl(lib, "fsh_bla_level_sizes", vp, [vp])
+    _decl(lib, "fsh_orbit_f64_create", vp, [vp, u64, C.c_int])
+    _decl(lib, "fsh_orbit_f64_destroy", None, [vp])
+    _decl(lib, "fsh_orbit_f64_count", u64, [vp])
+    _decl(lib, "fsh_orbit_f64_period", u64, [vp])
+    _decl(lib, "fsh_orbit_f64_data", vp, [vp])
+    _decl(lib, "fsh_orbit_f64_bla_num_levels", i32, [vp])
+    _decl(lib, "fsh_orbit_f64_bla_lm2", i32, [vp])
+    _decl(lib, "fsh_orbit_f64_bla_level_ptrs", vp, [vp])
+    _decl(lib, "fsh_orbit_f64_bla_level_sizes", vp, [vp])
+    _decl(lib, "fsh_view_coords_perturb_f64", None, [vp, vp, u32, u32, vp])
     _inputs = lib
     return lib

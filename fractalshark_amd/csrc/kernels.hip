@@ -918,6 +918,37 @@ template <class F> __global__ void k_direct_row_prefix_hdr(hreal<F> minX, hreal<
 }
 
 // ------------------------------------------------------------------------------------------------
+// PerturbExtras::SimpleCompression: expand a compressed reference orbit into the prepared form.
+// The reference decompresses on the fly in every thread (GPUPerturbSingleResults::GetCompressedComplex*,
+// FractalSharkGpuLib/Perturb.cuh:160-326; CPU twin RuntimeDecompressor, PerturbationResultsHelpers.h:46-161): the
+// waypoint at or below the wanted index is advanced with z <- z^2 + c in HDRFloat arithmetic.  The value at an index is
+// a pure function of the waypoints, and an MI355X has 288 GB of HBM, so the orbit is expanded ONCE per upload --
+// one lane per waypoint segment, segments are independent -- and the iteration kernels stay the uncompressed ones.
+__global__ void k_decompress_orbit_hdr32(const fs_orbit_hdr32_rc *__restrict__ wp, uint64_t n_wp, uint64_t n_uncompressed,
+                                         fs_real_hdr32 cxLow, fs_real_hdr32 cyLow, float4 *__restrict__ out)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_wp)
+        return;
+    const uint64_t kIndexMask = 0x7FFFFFFFFFFFFFFFull;
+    const uint64_t i0 = wp[k].index_and_rebase & kIndexMask;
+    const uint64_t i1 = k + 1 < n_wp ? (wp[k + 1].index_and_rebase & kIndexMask) : n_uncompressed;
+    hreal32 zx{wp[k].mx, wp[k].ex}, zy{wp[k].my, wp[k].ey};
+    const hreal32 cx = ldr(cxLow), cy = ldr(cyLow);
+    const hreal32 Two{1.0f, 1};
+    for (uint64_t i = i0; i < i1 && i < n_uncompressed; i++) {
+        const hcplx32 c = hc_from_hr(zx, zy);
+        out[i] = make_float4(c.re, c.im, __int_as_float(c.e), ldexpf(1.0f, 8 - 2 * (c.e < -1000 ? -1000 : c.e)));
+        // runOneIter, PerturbationResultsHelpers.h:51-58
+        const hreal32 zx_old = zx;
+        zx = hr_add(hr_sub(hr_mul(zx, zx), hr_mul(zy, zy)), cx);
+        hr_reduce(zx);
+        zy = hr_add(hr_mul(hr_mul(Two, zx_old), zy), cy);
+        hr_reduce(zy);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Host-callable launchers (called from renderer.cpp through kernels.h).
 static dim3 frame_grid(const FsFrame &f) { return dim3((f.width + 63) / 64, (f.local_rows + 3) / 4, 1); }
 
@@ -966,6 +997,13 @@ void fsk_perturb_scalar_hdr32(const FsBlaArgs32 &A, bool use_bla, bool stats, hi
         else
             hipLaunchKernelGGL((k_perturb_scalar<float, false, false>), g, b, 0, s, A);
     }
+}
+
+void fsk_decompress_orbit_hdr32(const fs_orbit_hdr32_rc *wp, uint64_t n_wp, uint64_t n_uncompressed, fs_real_hdr32 cxLow,
+                                fs_real_hdr32 cyLow, float4 *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_decompress_orbit_hdr32, dim3((unsigned)((n_wp + 63) / 64)), dim3(64), 0, s, wp, n_wp,
+                       n_uncompressed, cxLow, cyLow, out);
 }
 
 void fsk_prepare_orbit_hdr64(const fs_orbit_hdr64 *in, FsZ64 *out, uint64_t n, hipStream_t s)

@@ -472,6 +472,53 @@ uint32_t fs_upload_orbit(fs_renderer *r, uint64_t generation, int type_tag, uint
     return 0;
 }
 
+uint32_t fs_upload_orbit_compressed(fs_renderer *r, uint64_t generation, int type_tag, uint32_t iter_bytes,
+                                    const void *entries, uint64_t compressed_size, uint64_t uncompressed_size,
+                                    uint64_t period_maybe_zero, const void *orbit_x_low, const void *orbit_y_low)
+{
+    if (uint32_t e = use_device(r))
+        return e;
+    if (type_tag != FS_T_HDR32 || iter_bytes != 4)
+        return FS_ERR_UNSUPPORTED;
+    if (!r->compute)
+        return FS_ERR_6;
+    if (r->orbit_ok && r->orbit_gen == generation && generation != 0 && r->orbit_type == type_tag)
+        return 0;
+    if (r->zref) {
+        FS_TRY(hipFree(r->zref));
+        r->zref = nullptr;
+    }
+    if (r->zref64) {
+        FS_TRY(hipFree(r->zref64));
+        r->zref64 = nullptr;
+    }
+    r->orbit_ok = false;
+    fs_orbit_hdr32_rc *raw = nullptr;
+    FS_TRY(hipMalloc((void **)&raw, compressed_size * sizeof(fs_orbit_hdr32_rc)));
+    hipError_t err = hipMalloc((void **)&r->zref, (uncompressed_size + 2) * sizeof(float4));
+    if (err == hipSuccess)
+        err = hipMemcpyAsync(raw, entries, compressed_size * sizeof(fs_orbit_hdr32_rc), hipMemcpyDefault, r->compute);
+    if (err == hipSuccess)
+        err = hipMemsetAsync(r->zref + uncompressed_size, 0, 2 * sizeof(float4), r->compute);
+    if (err == hipSuccess) {
+        fsk_decompress_orbit_hdr32(raw, compressed_size, uncompressed_size, *(const fs_real_hdr32 *)orbit_x_low,
+                                   *(const fs_real_hdr32 *)orbit_y_low, r->zref, r->compute);
+        err = hipGetLastError();
+    }
+    if (err == hipSuccess)
+        err = hipStreamSynchronize(r->compute);
+    (void)hipFree(raw);
+    if (err != hipSuccess)
+        return (uint32_t)err;
+    r->orbit_size = compressed_size;
+    r->orbit_uncompressed = uncompressed_size;
+    r->orbit_period = period_maybe_zero;
+    r->orbit_gen = generation;
+    r->orbit_type = type_tag;
+    r->orbit_ok = true;
+    return 0;
+}
+
 uint32_t fs_upload_la(fs_renderer *r, uint64_t generation, int type_tag, uint32_t iter_bytes, const void *las,
                       uint32_t n_las, const void *stages, uint32_t n_stages, int is_valid, int use_at,
                       const void *at_info)

@@ -22,6 +22,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <string>
 #include <vector>
@@ -1558,3 +1559,171 @@ extern "C" int32_t fsh_bla_num_levels(const fsh_bla *b) { return (int32_t)b->ptr
 extern "C" int32_t fsh_bla_lm2(const fsh_bla *b) { return b->lm2; }
 extern "C" const void *const *fsh_bla_level_ptrs(const fsh_bla *b) { return b->ptrs.data(); }
 extern "C" const uint64_t *fsh_bla_level_sizes(const fsh_bla *b) { return b->sizes.data(); }
+
+// ------------------------------------------------------------------ plain double (Cpu64PerturbedBLA / Gpu1x64PerturbedBLA)
+// PerturbationResults<uint32_t,double,Disable> + BLAS<uint32_t,double>: the floatOrDouble branches of
+// AddPerturbationReferencePointST (RefOrbitCalc.cpp:481-488,524-530,564-604,617-622) and BLAS.cpp with T = double.
+struct fsh_orbit_f64 {
+    std::vector<fs_orbit_f64> z; // entry 0 = {0,0}
+    uint64_t period = 0;
+    double maxRadius = 0;
+    Mp cx, cy;
+    std::vector<std::vector<fs_bla_f64>> levels;
+    std::vector<const void *> ptrs;
+    std::vector<uint64_t> sizes;
+    int32_t lm2 = 0;
+};
+
+extern "C" fsh_orbit_f64 *fsh_orbit_f64_create(const fsh_view *vwp, uint64_t max_iter, int periodicity)
+{
+    const fsh_view &vw = *vwp;
+    auto ob = std::make_unique<fsh_orbit_f64>();
+    mpf_set_default_prec(vw.prec_bits);
+    {
+        Mp two = Mp::from_ui(2);
+        ob->cx = (vw.maxX + vw.minX) / two;
+        ob->cy = (vw.maxY + vw.minY) / two;
+        Mp delta = vw.maxY - vw.minY;
+        ob->maxRadius = mpf_get_d(delta.v) / 2.0; // T{delta} / T{2.0f}
+    }
+    ob->z.push_back(fs_orbit_f64{0.0, 0.0});
+    mpf_t cx, cy, zx, zy, zx2, t1, t2;
+    mpf_init(cx);
+    mpf_set(cx, ob->cx.v);
+    mpf_init(cy);
+    mpf_set(cy, ob->cy.v);
+    mpf_init(zx);
+    mpf_init(zy);
+    mpf_init(zx2);
+    mpf_init(t1);
+    mpf_init(t2);
+    double dzdcX = 1.0, dzdcY = 0.0;
+    const double cx_cast = mpf_get_d(cx), cy_cast = mpf_get_d(cy);
+    mpf_set(zx, cx);
+    mpf_set(zy, cy);
+    for (uint64_t i = 0; i < max_iter; i++) {
+        mpf_mul_2exp(zx2, zx, 1);
+        const double double_zx = mpf_get_d(zx), double_zy = mpf_get_d(zy);
+        ob->z.push_back(fs_orbit_f64{double_zx, double_zy});
+        if (periodicity) {
+            const double n2 = std::max(std::fabs(double_zx), std::fabs(double_zy));
+            const double r0 = std::max(std::fabs(dzdcX), std::fabs(dzdcY));
+            const double n3 = ob->maxRadius * r0 * 2.0;
+            if (n2 < n3) {
+                ob->period = ob->z.size();
+                break;
+            } else {
+                const double dzdcXOrig = dzdcX;
+                dzdcX = 2.0 * (double_zx * dzdcX - double_zy * dzdcY) + 1.0;
+                dzdcY = 2.0 * (double_zx * dzdcY + double_zy * dzdcXOrig);
+            }
+        }
+        mpf_mul(t1, zx, zx);
+        mpf_mul(t2, zy, zy);
+        mpf_sub(zx, t1, t2);
+        mpf_add(zx, zx, cx);
+        mpf_mul(zy, zx2, zy);
+        mpf_add(zy, zy, cy);
+        const double tempZX = double_zx + cx_cast, tempZY = double_zy + cy_cast;
+        const double zn = tempZX * tempZX + tempZY * tempZY;
+        if (zn > 256.0)
+            break;
+    }
+    mpf_clear(cx);
+    mpf_clear(cy);
+    mpf_clear(zx);
+    mpf_clear(zy);
+    mpf_clear(zx2);
+    mpf_clear(t1);
+    mpf_clear(t2);
+
+    // BLAS<uint32_t,double>::Init(count, maxRadius), BLAS.cpp:25-255 with plain double (BLA.cuh:40-91)
+    {
+        const auto &Z = ob->z;
+        const double blaSize = ob->maxRadius;
+        const double epsilon = 1.0 / 8388608.0; // T(1) / T{1L << 23}
+        std::vector<size_t> epl;
+        size_t m = Z.size() - 1;
+        if (Z.size() != 0 && m != 0) {
+            for (; m > 1; m = (m + 1) >> 1)
+                epl.push_back(m);
+            epl.push_back(m);
+            const size_t L = epl.size();
+            ob->levels.resize(L);
+            ob->lm2 = (int32_t)L - 2 < 0 ? 0 : (int32_t)L - 2;
+            auto one_step = [&](size_t mm) {
+                const double RealA = Z[mm].x * 2, ImagA = Z[mm].y * 2;
+                const double mA = std::sqrt(RealA * RealA + ImagA * ImagA);
+                const double r = mA * epsilon;
+                return fs_bla_f64{r * r, RealA, ImagA, 1.0, 0.0, 1, 0};
+            };
+            auto merge = [&](const fs_bla_f64 &x, const fs_bla_f64 &y) {
+                const int32_t l = x.l + y.l;
+                const double RealA = y.Ax * x.Ax - y.Ay * x.Ay;
+                const double ImagA = y.Ax * x.Ay + y.Ay * x.Ax;
+                const double RealB = y.Ax * x.Bx - y.Ay * x.By + y.Bx;
+                const double ImagB = y.Ax * x.By + y.Ay * x.Bx + y.By;
+                const double xA = std::sqrt(x.Ax * x.Ax + x.Ay * x.Ay);
+                const double xB = std::sqrt(x.Bx * x.Bx + x.By * x.By);
+                const double tempR = (std::sqrt(y.r2) - xB * blaSize) / xA;
+                const double mx = (0.0 > tempR) ? 0.0 : tempR;           // HdrMaxReduced(T(0), tempR)
+                const double sx = std::sqrt(x.r2);
+                const double r = (sx < mx) ? sx : mx;                    // HdrMinPositiveReduced
+                return fs_bla_f64{r * r, RealA, ImagA, RealB, ImagB, l, 0};
+            };
+            std::function<fs_bla_f64(size_t, size_t)> l_step = [&](size_t level, size_t mm) -> fs_bla_f64 {
+                if (level == 0)
+                    return one_step(mm);
+                const size_t m2 = mm << 1, mx = m2 - 1, my = m2;
+                if (my <= epl[level - 1])
+                    return merge(l_step(level - 1, mx), l_step(level - 1, my));
+                return l_step(level - 1, mx);
+            };
+            if (2 < epl.size()) {
+                for (size_t l = 2; l < L; l++)
+                    ob->levels[l].resize(epl[l]);
+                const size_t elements = epl[2] + 1;
+                for (size_t mm = 1; mm < elements; mm++)
+                    ob->levels[2][mm - 1] = l_step(2, mm);
+                size_t src = 2;
+                const size_t maxLevel = epl.size() - 1;
+                for (size_t elementsSrc = epl[src]; src < maxLevel && elementsSrc > 1; src++) {
+                    const size_t dst = src + 1, elementsDst = epl[dst];
+                    for (size_t k = 0; k < elementsDst; k++) {
+                        const size_t mx = k << 1, my = mx + 1;
+                        ob->levels[dst][k] = my < elementsSrc ? merge(ob->levels[src][mx], ob->levels[src][my])
+                                                              : ob->levels[src][mx];
+                    }
+                    elementsSrc = elementsDst;
+                }
+            }
+        }
+        for (auto &lv : ob->levels) {
+            ob->ptrs.push_back(lv.empty() ? nullptr : (const void *)lv.data());
+            ob->sizes.push_back(lv.size());
+        }
+    }
+    return ob.release();
+}
+extern "C" void fsh_orbit_f64_destroy(fsh_orbit_f64 *o) { delete o; }
+extern "C" uint64_t fsh_orbit_f64_count(const fsh_orbit_f64 *o) { return o->z.size(); }
+extern "C" uint64_t fsh_orbit_f64_period(const fsh_orbit_f64 *o) { return o->period; }
+extern "C" const fs_orbit_f64 *fsh_orbit_f64_data(const fsh_orbit_f64 *o) { return o->z.data(); }
+extern "C" int32_t fsh_orbit_f64_bla_num_levels(const fsh_orbit_f64 *o) { return (int32_t)o->ptrs.size(); }
+extern "C" int32_t fsh_orbit_f64_bla_lm2(const fsh_orbit_f64 *o) { return o->lm2; }
+extern "C" const void *const *fsh_orbit_f64_bla_level_ptrs(const fsh_orbit_f64 *o) { return o->ptrs.data(); }
+extern "C" const uint64_t *fsh_orbit_f64_bla_level_sizes(const fsh_orbit_f64 *o) { return o->sizes.data(); }
+// {dx, dy, centerX, centerY} as doubles (Fractal.cpp:2230-2238 with T = double: mpf_get_d, no reduction).
+extern "C" void fsh_view_coords_perturb_f64(const fsh_view *v, const fsh_orbit_f64 *o, uint32_t w_aa, uint32_t h_aa,
+                                            double out[4])
+{
+    mpf_set_default_prec(v->prec_bits);
+    Mp dx = (v->maxX - v->minX) / Mp::from_ui(w_aa);
+    Mp dy = (v->maxY - v->minY) / Mp::from_ui(h_aa);
+    Mp cX = o->cx - v->minX;
+    Mp cY = o->cy - v->maxY;
+    out[0] = mpf_get_d(dx.v);
+    out[1] = mpf_get_d(dy.v);
+    out[2] = mpf_get_d(cX.v);
+    out[3] = mpf_get_d(cY.v);
+}

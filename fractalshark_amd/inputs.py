@@ -228,3 +228,42 @@ class BLATable:
     def sizes(self):
         buf = (C.c_uint64 * self.num_levels).from_address(self.level_sizes)
         return list(buf)
+
+
+class OrbitF64:
+    """Plain-double reference orbit + its BLA table (PerturbationResults<uint32_t,double,Disable>, BLAS<uint32_t,double>):
+    the inputs of Cpu64PerturbedBLA / Gpu1x64PerturbedBLA."""
+
+    def __init__(self, view, max_iter=None, periodicity=True):
+        self._lib = _capi.inputs_lib()
+        self.view = view
+        n = view.num_iterations if max_iter is None else max_iter
+        self._h = self._lib.fsh_orbit_f64_create(view._h, n, 1 if periodicity else 0)
+        self.count = self._lib.fsh_orbit_f64_count(self._h)
+        self.period = self._lib.fsh_orbit_f64_period(self._h)
+        self.num_levels = self._lib.fsh_orbit_f64_bla_num_levels(self._h)
+        self.lm2 = self._lib.fsh_orbit_f64_bla_lm2(self._h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.fsh_orbit_f64_destroy(self._h)
+            self._h = None
+
+    @property
+    def data_ptr(self):
+        return self._lib.fsh_orbit_f64_data(self._h)
+
+    @property
+    def level_ptrs(self):
+        return self._lib.fsh_orbit_f64_bla_level_ptrs(self._h)
+
+    @property
+    def level_sizes(self):
+        return self._lib.fsh_orbit_f64_bla_level_sizes(self._h)
+
+    def coords(self, aa=None):
+        aa = self.view.antialiasing if aa is None else aa
+        out = np.zeros(4, np.float64)
+        self._lib.fsh_view_coords_perturb_f64(self.view._h, self._h, self.view.width * aa, self.view.height * aa,
+                                              out.ctypes.data)
+        return out

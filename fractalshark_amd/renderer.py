@@ -95,8 +95,15 @@ class GPURenderer:
         T defaults to the orbit's type (T_HDR32 / T_HDR64)."""
         if T is None:
             T = T_HDR64 if getattr(Perturb1, "is64", False) else T_HDR32
-        err = self._lib.fs_upload_orbit(self._h, GenerationNumber1, T, 4, Perturb1.data_ptr, Perturb1.count,
-                                        Perturb1.count, Perturb1.period)
+        if getattr(Perturb1, "compressed", False):
+            # PerturbExtras::SimpleCompression: hand over the waypoints, like the reference's *RC* algorithms
+            low = Perturb1.orbit_low()
+            err = self._lib.fs_upload_orbit_compressed(self._h, GenerationNumber1, T, 4, Perturb1.compressed_data_ptr,
+                                                       Perturb1.compressed_count, Perturb1.count, Perturb1.period,
+                                                       low[0:1].ctypes.data, low[1:2].ctypes.data)
+        else:
+            err = self._lib.fs_upload_orbit(self._h, GenerationNumber1, T, 4, Perturb1.data_ptr, Perturb1.count,
+                                            Perturb1.count, Perturb1.period)
         if err:
             return err
         if LaReferenceHost is not None:

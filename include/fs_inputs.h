@@ -88,6 +88,20 @@ int32_t fsh_bla_lm2(const fsh_bla *b);        /* m_LM2 */
 const void *const *fsh_bla_level_ptrs(const fsh_bla *b); /* fs_bla_hdr32[] / fs_bla_hdr64[] per level */
 const uint64_t *fsh_bla_level_sizes(const fsh_bla *b);
 
+/* Plain double orbit + BLA table (PerturbationResults<uint32_t,double,Disable>, BLAS<uint32_t,double>):
+ * Cpu64PerturbedBLA / Gpu1x64PerturbedBLA. */
+typedef struct fsh_orbit_f64 fsh_orbit_f64;
+fsh_orbit_f64 *fsh_orbit_f64_create(const fsh_view *v, uint64_t max_iter, int periodicity);
+void fsh_orbit_f64_destroy(fsh_orbit_f64 *o);
+uint64_t fsh_orbit_f64_count(const fsh_orbit_f64 *o);
+uint64_t fsh_orbit_f64_period(const fsh_orbit_f64 *o);
+const fs_orbit_f64 *fsh_orbit_f64_data(const fsh_orbit_f64 *o);
+int32_t fsh_orbit_f64_bla_num_levels(const fsh_orbit_f64 *o);
+int32_t fsh_orbit_f64_bla_lm2(const fsh_orbit_f64 *o);
+const void *const *fsh_orbit_f64_bla_level_ptrs(const fsh_orbit_f64 *o); /* fs_bla_f64[] per level */
+const uint64_t *fsh_orbit_f64_bla_level_sizes(const fsh_orbit_f64 *o);
+void fsh_view_coords_perturb_f64(const fsh_view *v, const fsh_orbit_f64 *o, uint32_t w_aa, uint32_t h_aa, double out[4]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -158,6 +158,17 @@ typedef struct fs_bla_hdr64 {
     int32_t pad_;
 } fs_bla_hdr64;
 
+/* BLA<double> (FractalSharkLib/BLA.h:9-16): 48 B. */
+typedef struct fs_bla_f64 {
+    double r2;
+    double Ax;
+    double Ay;
+    double Bx;
+    double By;
+    int32_t l;
+    int32_t pad_;
+} fs_bla_f64;
+
 typedef struct fs_color16 {
     uint16_t r, g, b, a;
 } fs_color16;
@@ -180,6 +191,7 @@ static_assert(sizeof(fs_real_hdr64) == 16 && sizeof(fs_cplx_hdr64) == 24, "doubl
 static_assert(sizeof(fs_la_hdr64_u32) == 128, "LA record (double)");
 static_assert(sizeof(fs_at_hdr64_u32) == 232, "AT record (double)");
 static_assert(sizeof(fs_bla_hdr64) == 88, "BLA record (double)");
+static_assert(sizeof(fs_bla_f64) == 48 && sizeof(fs_orbit_f64) == 16, "plain double records");
 #endif
 
 #endif /* FS_LAYOUT_H */

@@ -102,6 +102,13 @@ uint32_t fs_rounded_width(const fs_renderer *r);
 uint32_t fs_upload_orbit(fs_renderer *r, uint64_t generation, int type_tag, uint32_t iter_bytes,
                          const void *entries, uint64_t orbit_size, uint64_t uncompressed_size,
                          uint64_t period_maybe_zero);
+/* The same for PerturbExtras::SimpleCompression orbits: `entries` = GPUReferenceIter<T, SimpleCompression>[compressed_size]
+ * (fs_orbit_hdr32_rc), orbit_x_low / orbit_y_low = GPUPerturbResults::OrbitXLow / OrbitYLow (the constant c of the runtime
+ * decompressor, Perturb.cuh:300-326).  The orbit is expanded once on the device; all render calls then behave exactly as
+ * the reference's *RC* algorithms (bit-identical to its CPU RuntimeDecompressor). */
+uint32_t fs_upload_orbit_compressed(fs_renderer *r, uint64_t generation, int type_tag, uint32_t iter_bytes,
+                                    const void *entries, uint64_t compressed_size, uint64_t uncompressed_size,
+                                    uint64_t period_maybe_zero, const void *orbit_x_low, const void *orbit_y_low);
 /* ... and LA table upload (GPU_LAReference ctor, GPU_LAReference.h:79-160).  at_info may be NULL when
  * use_at == 0. */
 uint32_t fs_upload_la(fs_renderer *r, uint64_t generation, int type_tag, uint32_t iter_bytes, const void *las,

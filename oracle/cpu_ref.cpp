@@ -747,6 +747,121 @@ void orc_direct_hdr64(uint32_t width, uint32_t height, uint32_t y0, uint32_t y1,
     direct_hdr_impl<double>(width, y0, y1, coords, n_iterations, out, stride, threads);
 }
 
+// Fractal::CalcCpuPerturbationFractalBLA<uint32_t,double,double> (Cpu64PerturbedBLA), Fractal.cpp:2208-2483 with
+// T = double: every HdrReduce is a no-op, comparisons are plain, GetComplex returns FloatComplex<double>.
+// coords = {dx, dy, centerX, centerY} as doubles.
+void orc_bla_f64(uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, const fs_orbit_f64 *orbit,
+                 uint64_t orbit_count, const double coords[4], uint32_t n_iterations,
+                 const fs_bla_f64 *const *B, const uint64_t *sizes, int32_t n_levels, int32_t lm2, uint32_t *out,
+                 uint32_t stride, int threads)
+{
+    (void)height;
+    (void)sizes;
+    const double dx = coords[0], dy = coords[1], centerX = coords[2], centerY = coords[3];
+    const uint32_t count = (uint32_t)orbit_count;
+    auto Lookup = [&](size_t m, double z2) -> const fs_bla_f64 * { // BLAS::LookupBackwards, BLAS.cpp:256-310
+        if (n_levels == 0 || m == 0)
+            return nullptr;
+        const int32_t k = (int32_t)m - 1;
+        if ((k & 1) == 1)
+            return nullptr;
+        int32_t zeros;
+        uint32_t ix;
+        if (k == 0) {
+            if (z2 >= B[2][0].r2)
+                return nullptr;
+            zeros = 32;
+            ix = 0;
+        } else {
+            const float v = (float)(k & -k);
+            uint32_t bits;
+            memcpy(&bits, &v, 4);
+            zeros = (int32_t)(bits >> 23) - 0x7f;
+            ix = (uint32_t)k >> zeros;
+        }
+        const int32_t startLevel = zeros <= lm2 ? zeros : lm2;
+        for (int32_t level = startLevel; level >= 2; --level) {
+            const fs_bla_f64 *t = &B[level][ix];
+            if (z2 < t->r2)
+                return t;
+            ix = ix << 1;
+        }
+        return nullptr;
+    };
+    run_rows(y0, y1, threads, [&](uint32_t y) {
+        for (size_t x = 0; x < width; x++) {
+            uint32_t iter = 0, RefIteration = 0;
+            double deltaReal = dx * (double)x;
+            deltaReal -= centerX;
+            double deltaImaginary = -dy * (double)y;
+            deltaImaginary -= centerY;
+            const double DeltaSub0X = deltaReal, DeltaSub0Y = deltaImaginary;
+            double DeltaSubNX = 0, DeltaSubNY = 0, DeltaNormSquared = 0;
+            while (iter < n_iterations) {
+                const fs_bla_f64 *b = nullptr;
+                while ((b = Lookup(RefIteration, DeltaNormSquared)) != nullptr) {
+                    const int l = b->l;
+                    if (RefIteration + l >= count)
+                        break;
+                    if (iter + l >= n_iterations)
+                        break;
+                    iter += l;
+                    {
+                        const double nx = b->Ax * DeltaSubNX - b->Ay * DeltaSubNY + b->Bx * DeltaSub0X - b->By * DeltaSub0Y;
+                        const double ny = b->Ax * DeltaSubNY + b->Ay * DeltaSubNX + b->Bx * DeltaSub0Y + b->By * DeltaSub0X;
+                        DeltaSubNX = nx;
+                        DeltaSubNY = ny;
+                    }
+                    RefIteration += l;
+                    const double tempZX = orbit[RefIteration].x + DeltaSubNX;
+                    const double tempZY = orbit[RefIteration].y + DeltaSubNY;
+                    const double normSquared = tempZX * tempZX + tempZY * tempZY;
+                    DeltaNormSquared = DeltaSubNX * DeltaSubNX + DeltaSubNY * DeltaSubNY;
+                    if (normSquared > 256.0)
+                        break;
+                    if (normSquared < DeltaNormSquared || RefIteration >= count - 1) {
+                        DeltaSubNX = tempZX;
+                        DeltaSubNY = tempZY;
+                        DeltaNormSquared = normSquared;
+                        RefIteration = 0;
+                    }
+                }
+                if (iter >= n_iterations)
+                    break;
+                const double OX = DeltaSubNX, OY = DeltaSubNY;
+                const double Zre = orbit[RefIteration].x, Zim = orbit[RefIteration].y;
+                const double TermB1 = OX * (Zre * 2 + OX);
+                const double TermB2 = OY * (Zim * 2 + OY);
+                DeltaSubNX = TermB1 - TermB2;
+                DeltaSubNX += DeltaSub0X;
+                const double Term3 = Zim * 2 + OY;
+                const double Term4 = Zre * 2 + OX;
+                DeltaSubNY = OX * Term3 + OY * Term4;
+                DeltaSubNY += DeltaSub0Y;
+                ++RefIteration;
+                if (RefIteration >= count)
+                    break;
+                const double tempZX = orbit[RefIteration].x + DeltaSubNX;
+                const double tempZY = orbit[RefIteration].y + DeltaSubNY;
+                const double nT1 = tempZX * tempZX;
+                const double nT2 = tempZY * tempZY;
+                const double normSquared = nT1 + nT2;
+                DeltaNormSquared = DeltaSubNX * DeltaSubNX + DeltaSubNY * DeltaSubNY;
+                if (normSquared > 256.0)
+                    break;
+                if (normSquared < DeltaNormSquared || RefIteration >= count - 1) {
+                    DeltaSubNX = tempZX;
+                    DeltaSubNY = tempZY;
+                    DeltaNormSquared = normSquared;
+                    RefIteration = 0;
+                }
+                ++iter;
+            }
+            out[(size_t)y * stride + x] = iter;
+        }
+    });
+}
+
 void orc_bla_hdr32(uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, const fs_orbit_hdr32 *orbit,
                    uint64_t orbit_count, const fs_real_hdr32 coords[4], uint32_t n_iterations,
                    const fs_bla_hdr32 *const *bla_levels, const uint64_t *bla_level_sizes, int32_t bla_n_levels,

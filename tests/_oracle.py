@@ -45,6 +45,8 @@ def lib():
         l.orc_lav2_hdr64.argtypes = l.orc_lav2_hdr32.argtypes
         l.orc_direct_hdr32.argtypes = [u32, u32, u32, u32, vp, u32, vp, u32, C.c_int]
         l.orc_direct_hdr64.argtypes = l.orc_direct_hdr32.argtypes
+        l.orc_bla_f64.restype = None
+        l.orc_bla_f64.argtypes = [u32, u32, u32, u32, vp, u64, vp, u32, vp, vp, i32, i32, vp, u32, C.c_int]
         l.orc_set_row_step.restype = None
         l.orc_set_row_step.argtypes = [u32]
         _lib = l
@@ -140,6 +142,22 @@ def lav2_hdr32(view, orbit, la, aa=1, rows=None, threads=8, stage_test=0, mode=0
                          threads, st)
     if stats:
         return out, {"at_iterations": st[0], "la_steps": st[1], "perturb_steps": st[2], "pixels": st[3]}
+    return out
+
+
+def bla_f64(view, orbit, use_bla=True, aa=1, rows=None, threads=8):
+    """CalcCpuPerturbationFractalBLA<u32,double,double> (Cpu64PerturbedBLA); orbit: inputs.OrbitF64."""
+    w, h = view.width * aa, view.height * aa
+    out = new_buffer(w, h)
+    co = orbit.coords(aa)
+    y0, y1 = rows if rows else (0, h)
+    if use_bla:
+        lib().orc_bla_f64(w, h, y0, y1, orbit.data_ptr, orbit.count, co.ctypes.data, view.num_iterations,
+                          orbit.level_ptrs, orbit.level_sizes, orbit.num_levels, orbit.lm2, out.ctypes.data,
+                          out.shape[1], threads)
+    else:
+        lib().orc_bla_f64(w, h, y0, y1, orbit.data_ptr, orbit.count, co.ctypes.data, view.num_iterations, None, None,
+                          0, 0, out.ctypes.data, out.shape[1], threads)
     return out
 
 

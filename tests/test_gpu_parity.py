@@ -312,3 +312,19 @@ def test_direct_hdr_parity(renderer, native_libs, is64):
     assert r.RenderCurrent(v.num_iterations, out) == 0
     assert r.SyncComputeStream() == 0
     assert np.array_equal(out, _oracle.direct_hdr(v, is64))
+
+
+def test_simple_compression_orbit_parity(renderer, native_libs):
+    """GpuHDRx32PerturbedRCLAv2 <-> Cpu32PerturbedRCBLAV2HDR: the waypoints are expanded on the device; the frame must
+    equal the CPU function reading the orbit through RuntimeDecompressor (golden CRC b956600cfdfe431a pins that chain)."""
+    v = inputs.View.builtin(5, 64, 36)
+    ob = inputs.Orbit(v, compression_exp=20)
+    assert ob.compressed and ob.compressed_count < ob.count
+    la = inputs.LATable(ob)
+    out, _ = _render_lav2(renderer, v, ob, la, LAV2_FULL, PARITY_CPU)
+    assert np.array_equal(out, _oracle.lav2_hdr32(v, ob, la, stage_test=0))
+    # and it is NOT the uncompressed frame (the decompressed orbit differs in the last bits)
+    ob_u = inputs.Orbit(v)
+    la_u = inputs.LATable(ob_u)
+    out_u, _ = _render_lav2(renderer, v, ob_u, la_u, LAV2_FULL, PARITY_CPU)
+    assert np.array_equal(out_u, GOLD["view5_lav2_cpu_64x36"])

@@ -144,3 +144,12 @@ def test_golden_view5_rc_blav2_hdr(native_libs, is64, expected):
     la = inputs.LATable(ob)
     it = _oracle.lav2_hdr32(v, ob, la, stage_test=0)
     assert _oracle.png_crc64(it, W, H, 1, v.num_iterations) == expected
+
+
+@needs_pin
+def test_golden_view5_cpu64_perturbed_bla_plain_double(native_libs):
+    """The twelfth golden: plain-double perturbation + BLA (Cpu64PerturbedBLA)."""
+    v = inputs.View.builtin(5, W, H)
+    ob = inputs.OrbitF64(v)
+    it = _oracle.bla_f64(v, ob)
+    assert _oracle.png_crc64(it, W, H, 1, v.num_iterations) == "f201db00ade569fc"
