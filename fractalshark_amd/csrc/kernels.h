@@ -91,6 +91,19 @@ template <class F> struct FsBlaArgsT {
 };
 using FsBlaArgs32 = FsBlaArgsT<float>;
 
+// Plain double perturbation + BLA (Gpu1x64PerturbedBLA <-> Cpu64PerturbedBLA).
+struct FsBlaArgsF64 {
+    uint32_t *out;
+    const fs_orbit_f64 *orbit;
+    const fs_bla_f64 *const *levels;
+    uint64_t *stats;
+    FsFrame frame;
+    double dx, dy, centerX, centerY;
+    uint32_t orbit_count;
+    uint32_t n_iterations;
+    int32_t lm2;
+};
+
 // CalcCpuHDR<.., HDRFloat<F>, F> direct kernels: cx_row[x] = the CPU's accumulated cx (hreal<F>), dy/maxY un-reduced.
 template <class F> struct FsDirectHdrArgsT {
     uint32_t *out;
@@ -120,6 +133,7 @@ void fsk_lav2_hdr32(const FsLav2Args32 &A, int mode, bool stats, int variant, hi
 void fsk_lav2_hdr64(const FsLav2ArgsT<double> &A, int mode, bool stats, hipStream_t s);
 void fsk_perturb_scalar_hdr32(const FsBlaArgs32 &A, bool use_bla, bool stats, hipStream_t s);
 void fsk_perturb_scalar_hdr64(const FsBlaArgsT<double> &A, bool use_bla, bool stats, hipStream_t s);
+void fsk_perturb_bla_f64(const FsBlaArgsF64 &A, bool use_bla, bool stats, hipStream_t s);
 void fsk_direct_hdr32(const FsDirectHdrArgsT<float> &A, fs::hreal<float> minX, fs::hreal<float> dx, bool stats, hipStream_t s);
 void fsk_direct_hdr64(const FsDirectHdrArgsT<double> &A, fs::hreal<double> minX, fs::hreal<double> dx, bool stats,
                       hipStream_t s);

@@ -949,6 +949,135 @@ __global__ void k_decompress_orbit_hdr32(const fs_orbit_hdr32_rc *__restrict__ w
 }
 
 // ------------------------------------------------------------------------------------------------
+// Plain double perturbation with BLA skipping.  CPU twin: Fractal::CalcCpuPerturbationFractalBLA<uint32_t,double,double>
+// (Cpu64PerturbedBLA, Fractal.cpp:2266-2470 with T = double: no reductions, plain comparisons).
+// Replaces mandel_1x_double_perturb_bla (FractalSharkGpuLib/BLAKernels.cuh:17-168).
+namespace {
+__device__ __forceinline__ const fs_bla_f64 *bla_lookup_f64(const FsBlaArgsF64 &A, uint32_t m, double z2)
+{
+    if (m == 0)
+        return nullptr;
+    const int32_t k = (int32_t)m - 1;
+    if ((k & 1) == 1)
+        return nullptr;
+    int32_t zeros;
+    uint32_t ix;
+    if (k == 0) {
+        if (z2 >= A.levels[2][0].r2)
+            return nullptr;
+        zeros = 32;
+        ix = 0;
+    } else {
+        zeros = __ffs(k) - 1;
+        ix = (uint32_t)k >> zeros;
+    }
+    const int32_t startLevel = zeros <= A.lm2 ? zeros : A.lm2;
+    for (int32_t level = startLevel; level >= 2; --level) {
+        const fs_bla_f64 *t = &A.levels[level][ix];
+        if (z2 < t->r2)
+            return t;
+        ix <<= 1;
+    }
+    return nullptr;
+}
+} // namespace
+
+template <bool kBla, bool kStats>
+__global__ void __launch_bounds__(256) k_perturb_bla_f64(FsBlaArgsF64 A)
+{
+    const uint32_t X = blockIdx.x * 64u + (threadIdx.x & 63u);
+    const uint32_t L = blockIdx.y * 4u + (threadIdx.x >> 6);
+    uint64_t c_la = 0, c_pt = 0, c_px = 0;
+    const uint32_t Y = global_row(A.frame, L);
+    const bool live = X < A.frame.width && L < A.frame.local_rows && Y < A.frame.height;
+    if (live) {
+        c_px = 1;
+        const uint32_t n_iterations = A.n_iterations;
+        const uint32_t count = A.orbit_count;
+        const fs_orbit_f64 *__restrict__ orbit = A.orbit;
+        uint32_t iter = 0, RefIteration = 0;
+        double deltaReal = A.dx * (double)X;
+        deltaReal -= A.centerX;
+        double deltaImaginary = -A.dy * (double)Y;
+        deltaImaginary -= A.centerY;
+        const double DeltaSub0X = deltaReal, DeltaSub0Y = deltaImaginary;
+        double DeltaSubNX = 0, DeltaSubNY = 0, DeltaNormSquared = 0;
+        while (iter < n_iterations) {
+            if (kBla) {
+                const fs_bla_f64 *b;
+                while ((b = bla_lookup_f64(A, RefIteration, DeltaNormSquared)) != nullptr) {
+                    const uint32_t l = (uint32_t)b->l;
+                    if (RefIteration + l >= count)
+                        break;
+                    if (iter + l >= n_iterations)
+                        break;
+                    iter += l;
+                    if (kStats)
+                        c_la++;
+                    {
+                        const double Ax = b->Ax, Ay = b->Ay, Bx = b->Bx, By = b->By;
+                        const double nx = Ax * DeltaSubNX - Ay * DeltaSubNY + Bx * DeltaSub0X - By * DeltaSub0Y;
+                        const double ny = Ax * DeltaSubNY + Ay * DeltaSubNX + Bx * DeltaSub0Y + By * DeltaSub0X;
+                        DeltaSubNX = nx;
+                        DeltaSubNY = ny;
+                    }
+                    RefIteration += l;
+                    const fs_orbit_f64 Z = orbit[RefIteration];
+                    const double tempZX = Z.x + DeltaSubNX;
+                    const double tempZY = Z.y + DeltaSubNY;
+                    const double normSquared = tempZX * tempZX + tempZY * tempZY;
+                    DeltaNormSquared = DeltaSubNX * DeltaSubNX + DeltaSubNY * DeltaSubNY;
+                    if (normSquared > 256.0)
+                        break;
+                    if (normSquared < DeltaNormSquared || RefIteration >= count - 1) {
+                        DeltaSubNX = tempZX;
+                        DeltaSubNY = tempZY;
+                        DeltaNormSquared = normSquared;
+                        RefIteration = 0;
+                    }
+                }
+                if (iter >= n_iterations)
+                    break;
+            }
+            const double OX = DeltaSubNX, OY = DeltaSubNY;
+            const fs_orbit_f64 Z = orbit[RefIteration];
+            const double TermB1 = OX * (Z.x * 2 + OX);
+            const double TermB2 = OY * (Z.y * 2 + OY);
+            DeltaSubNX = TermB1 - TermB2;
+            DeltaSubNX += DeltaSub0X;
+            const double Term3 = Z.y * 2 + OY;
+            const double Term4 = Z.x * 2 + OX;
+            DeltaSubNY = OX * Term3 + OY * Term4;
+            DeltaSubNY += DeltaSub0Y;
+            if (kStats)
+                c_pt++;
+            ++RefIteration;
+            if (RefIteration >= count)
+                break;
+            const fs_orbit_f64 Z2 = orbit[RefIteration];
+            const double tempZX = Z2.x + DeltaSubNX;
+            const double tempZY = Z2.y + DeltaSubNY;
+            const double nT1 = tempZX * tempZX;
+            const double nT2 = tempZY * tempZY;
+            const double normSquared = nT1 + nT2;
+            DeltaNormSquared = DeltaSubNX * DeltaSubNX + DeltaSubNY * DeltaSubNY;
+            if (normSquared > 256.0)
+                break;
+            if (normSquared < DeltaNormSquared || RefIteration >= count - 1) {
+                DeltaSubNX = tempZX;
+                DeltaSubNY = tempZY;
+                DeltaNormSquared = normSquared;
+                RefIteration = 0;
+            }
+            ++iter;
+        }
+        A.out[(size_t)L * A.frame.rounded_width + X] = iter;
+    }
+    if (kStats)
+        add_stats(A.stats, 0, c_la, c_pt, c_px);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Host-callable launchers (called from renderer.cpp through kernels.h).
 static dim3 frame_grid(const FsFrame &f) { return dim3((f.width + 63) / 64, (f.local_rows + 3) / 4, 1); }
 
@@ -1043,6 +1172,22 @@ void fsk_perturb_scalar_hdr64(const FsBlaArgsT<double> &A, bool use_bla, bool st
             hipLaunchKernelGGL((k_perturb_scalar<double, false, true>), g, b, 0, s, A);
         else
             hipLaunchKernelGGL((k_perturb_scalar<double, false, false>), g, b, 0, s, A);
+    }
+}
+
+void fsk_perturb_bla_f64(const FsBlaArgsF64 &A, bool use_bla, bool stats, hipStream_t s)
+{
+    const dim3 g = frame_grid(A.frame), b(256);
+    if (use_bla) {
+        if (stats)
+            hipLaunchKernelGGL((k_perturb_bla_f64<true, true>), g, b, 0, s, A);
+        else
+            hipLaunchKernelGGL((k_perturb_bla_f64<true, false>), g, b, 0, s, A);
+    } else {
+        if (stats)
+            hipLaunchKernelGGL((k_perturb_bla_f64<false, true>), g, b, 0, s, A);
+        else
+            hipLaunchKernelGGL((k_perturb_bla_f64<false, false>), g, b, 0, s, A);
     }
 }
 

@@ -59,6 +59,7 @@ struct fs_renderer {
     int orbit_type = -1; // FS_T_HDR32 or FS_T_HDR64
     float4 *zref = nullptr;
     FsZ64 *zref64 = nullptr;
+    fs_orbit_f64 *orbit_f64 = nullptr; // plain double orbit (FS_T_F64), used as uploaded
     uint64_t orbit_size = 0, orbit_uncompressed = 0, orbit_period = 0;
 
     // LA table
@@ -146,8 +147,11 @@ void free_perturb(fs_renderer *r)
         hipFree(r->zref);
     if (r->zref64)
         hipFree(r->zref64);
+    if (r->orbit_f64)
+        hipFree(r->orbit_f64);
     r->zref = nullptr;
     r->zref64 = nullptr;
+    r->orbit_f64 = nullptr;
     r->orbit_ok = false;
     r->orbit_gen = 0;
     if (r->las)
@@ -424,12 +428,29 @@ uint32_t fs_upload_orbit(fs_renderer *r, uint64_t generation, int type_tag, uint
 {
     if (uint32_t e = use_device(r))
         return e;
-    if ((type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64) || iter_bytes != 4)
+    if ((type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64 && type_tag != FS_T_F64) || iter_bytes != 4)
         return FS_ERR_UNSUPPORTED;
     if (!r->compute)
         return FS_ERR_6;
     if (r->orbit_ok && r->orbit_gen == generation && generation != 0 && r->orbit_type == type_tag)
         return 0; // cached by generation number (GPU_Render.cu:440-487)
+    if (type_tag == FS_T_F64) {
+        if (r->orbit_f64) {
+            FS_TRY(hipFree(r->orbit_f64));
+            r->orbit_f64 = nullptr;
+        }
+        r->orbit_ok = false;
+        FS_TRY(hipMalloc((void **)&r->orbit_f64, orbit_size * sizeof(fs_orbit_f64)));
+        FS_TRY(hipMemcpyAsync(r->orbit_f64, entries, orbit_size * sizeof(fs_orbit_f64), hipMemcpyDefault, r->compute));
+        FS_TRY(hipStreamSynchronize(r->compute));
+        r->orbit_size = orbit_size;
+        r->orbit_uncompressed = uncompressed_size;
+        r->orbit_period = period_maybe_zero;
+        r->orbit_gen = generation;
+        r->orbit_type = type_tag;
+        r->orbit_ok = true;
+        return 0;
+    }
     if (r->zref) {
         FS_TRY(hipFree(r->zref));
         r->zref = nullptr;
@@ -574,11 +595,12 @@ uint32_t fs_upload_bla(fs_renderer *r, int type_tag, const void *const *levels, 
 {
     if (uint32_t e = use_device(r))
         return e;
-    if (type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64)
+    if (type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64 && type_tag != FS_T_F64)
         return FS_ERR_UNSUPPORTED;
     if (!r->compute)
         return FS_ERR_6;
-    const size_t rec_bytes = type_tag == FS_T_HDR32 ? sizeof(fs_bla_hdr32) : sizeof(fs_bla_hdr64);
+    const size_t rec_bytes = type_tag == FS_T_HDR32 ? sizeof(fs_bla_hdr32)
+                                                    : (type_tag == FS_T_HDR64 ? sizeof(fs_bla_hdr64) : sizeof(fs_bla_f64));
     r->bla_type = type_tag;
     for (void *p : r->bla_level_mem)
         if (p)
@@ -658,12 +680,30 @@ uint32_t fs_render_bla(fs_renderer *r, int type_tag, const void *coords, uint64_
         return e;
     if (!r->memory_initialized())
         return 0;
-    if ((type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64) || n_iterations > 0xFFFFFFFFull)
+    if ((type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64 && type_tag != FS_T_F64) || n_iterations > 0xFFFFFFFFull)
         return FS_ERR_UNSUPPORTED;
     if (!r->orbit_ok || r->orbit_type != type_tag)
         return FS_ERR_6;
     const bool use_bla = r->bla_n_levels > 2 && r->bla_levels_dev != nullptr && r->bla_type == type_tag;
-    if (type_tag == FS_T_HDR32) {
+    if (type_tag == FS_T_F64) {
+        const double *c = (const double *)coords;
+        FsBlaArgsF64 A;
+        memset(&A, 0, sizeof(A));
+        A.out = (uint32_t *)r->iters();
+        A.orbit = r->orbit_f64;
+        A.levels = (const fs_bla_f64 *const *)r->bla_levels_dev;
+        A.stats = r->stats;
+        A.frame = make_frame(r);
+        A.dx = c[0];
+        A.dy = c[1];
+        A.centerX = c[2];
+        A.centerY = c[3];
+        A.orbit_count = (uint32_t)r->orbit_uncompressed;
+        A.n_iterations = (uint32_t)n_iterations;
+        A.lm2 = r->bla_lm2;
+        TimedLaunch t(r);
+        fsk_perturb_bla_f64(A, use_bla, r->stats_on, r->compute);
+    } else if (type_tag == FS_T_HDR32) {
         FsBlaArgsT<float> A;
         memset(&A, 0, sizeof(A));
         A.out = (uint32_t *)r->iters();

@@ -328,3 +328,24 @@ def test_simple_compression_orbit_parity(renderer, native_libs):
     la_u = inputs.LATable(ob_u)
     out_u, _ = _render_lav2(renderer, v, ob_u, la_u, LAV2_FULL, PARITY_CPU)
     assert np.array_equal(out_u, GOLD["view5_lav2_cpu_64x36"])
+
+
+def test_plain_double_bla_parity(renderer, native_libs):
+    """Gpu1x64PerturbedBLA <-> Cpu64PerturbedBLA (golden CRC f201db00ade569fc pins the CPU chain)."""
+    v = inputs.View.builtin(5, 64, 36)
+    ob = inputs.OrbitF64(v)
+    r = renderer
+    lib = r._lib
+    assert r.InitializeMemory(64, 36, 1, None, 0, 0, 0, False) == 0
+    assert lib.fs_upload_orbit(r._h, 0, T_F64, 4, ob.data_ptr, ob.count, ob.count, ob.period) == 0
+    co = ob.coords()
+    for use_bla in (True, False):
+        if use_bla:
+            assert lib.fs_upload_bla(r._h, T_F64, ob.level_ptrs, ob.level_sizes, ob.num_levels, ob.lm2) == 0
+        else:
+            assert lib.fs_upload_bla(r._h, T_F64, None, None, 0, 0) == 0
+        assert lib.fs_render_bla(r._h, T_F64, co.ctypes.data, v.num_iterations) == 0
+        out = r.new_iter_buffer()
+        assert r.RenderCurrent(v.num_iterations, out) == 0
+        assert r.SyncComputeStream() == 0
+        assert np.array_equal(out, _oracle.bla_f64(v, ob, use_bla=use_bla))
