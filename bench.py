@@ -50,9 +50,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["c3_lav2", "c2_po", "c5_bla"], default="c3_lav2",
+    ap.add_argument("--workload", choices=["c3_lav2", "c2_po", "c5_bla", "c4_hdr64"], default="c3_lav2",
                     help="c3_lav2 (default, the headline config): View 5 3840x2160 HDRx32 LAv2 Full; "
-                         "c2_po: View 5 1920x1080 HDRx32 perturbation only; c5_bla: View 19 7680x4320 HDRx32 BLA")
+                         "c2_po: View 5 1920x1080 HDRx32 perturbation only; c5_bla: View 19 7680x4320 HDRx32 BLA; "
+                         "c4_hdr64: View 14 (zoom 2^-21645) 3840x2160 x AA4 = 15360x8640 with HDRFloat<double> LAv2 -- the "
+                         "CPU-twinned stand-in for C4 until the 2x32 type exists (use --parity cpu_gpustage: the literal "
+                         "CPU function needs ~6e5 perturbation steps per pixel there)")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--view", type=int, default=-1)
@@ -70,8 +73,8 @@ def main():
     import numpy as np
     import torch
 
-    from fractalshark_amd import (GPURenderer, LAV2_FULL, PARITY_CPU, PARITY_CPU_GPUSTAGE, T_HDR32, _build, inputs,
-                                  tiling)
+    from fractalshark_amd import (GPURenderer, LAV2_FULL, PARITY_CPU, PARITY_CPU_GPUSTAGE, T_HDR32, T_HDR64, _build,
+                                  inputs, tiling)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -94,7 +97,8 @@ def main():
         raise RuntimeError("no usable HIP device; there is no CPU fallback")
 
     # ---- inputs (host, outside the timed region)
-    defaults = {"c3_lav2": (5, 3840, 2160), "c2_po": (5, 1920, 1080), "c5_bla": (19, 7680, 4320)}[args.workload]
+    defaults = {"c3_lav2": (5, 3840, 2160), "c2_po": (5, 1920, 1080), "c5_bla": (19, 7680, 4320),
+                "c4_hdr64": (14, 3840, 2160)}[args.workload]
     if args.view < 0:
         args.view = defaults[0]
     if args.width <= 0:
@@ -102,21 +106,25 @@ def main():
     if args.height <= 0:
         args.height = defaults[2]
     t0 = time.time()
-    view = inputs.View.builtin(args.view, args.width, args.height, antialiasing=1)
-    orbit = inputs.Orbit(view)
-    la = inputs.LATable(orbit, host_threads=effective_cpus()) if args.workload == "c3_lav2" else None
+    is_lav2 = args.workload in ("c3_lav2", "c4_hdr64")
+    is64 = args.workload == "c4_hdr64"
+    view = inputs.View.builtin(args.view, args.width, args.height, antialiasing=None if is64 else 1)
+    orbit = inputs.Orbit(view, is64=is64)
+    la = inputs.LATable(orbit, host_threads=effective_cpus()) if is_lav2 else None
     bla = inputs.BLATable(orbit) if args.workload == "c5_bla" else None
     t_inputs = time.time() - t0
-    W, H = view.width, view.height
+    AA = view.antialiasing
+    W, H = view.width * AA, view.height * AA
     n_iter = view.num_iterations
     parity = PARITY_CPU if args.parity == "cpu" else PARITY_CPU_GPUSTAGE
-    coords_arr = view.coords_perturb_hdr32(orbit)
+    coords_arr = view.coords_perturb(orbit)
     coords = [(float(c["m"]), int(c["e"])) for c in coords_arr]
 
     r = GPURenderer(local_rank)
-    err = r.InitializeMemory(W, H, 1, None, 0, 0, 0, False)
+    err = r.InitializeMemory(W, H, AA, None, 0, 0, 0, False)
     assert err == 0, GPURenderer.ConvertErrorToString(err)
-    if args.workload == "c3_lav2":
+    T_TAG = T_HDR64 if is64 else T_HDR32
+    if is_lav2:
         assert r.InitializePerturb(1, orbit, 0, None, la) == 0
     else:
         # the reference re-uploads orbit + BLA table inside every RenderPerturbBLA call (GPU_Render.cu:1464-1479);
@@ -140,8 +148,8 @@ def main():
     steps_executed = []
 
     def one_frame(record):
-        if args.workload == "c3_lav2":
-            e = r.RenderPerturbLAv2(None, None, None, *coords, n_iter, T=T_HDR32, Mode=LAV2_FULL, parity=parity)
+        if is_lav2:
+            e = r.RenderPerturbLAv2(None, None, None, *coords, n_iter, T=T_TAG, Mode=LAV2_FULL, parity=parity)
         else:
             e = r._lib.fs_render_bla(r._h, T_HDR32, coords_arr.ctypes.data, n_iter)
         assert e == 0, GPURenderer.ConvertErrorToString(e)
@@ -223,10 +231,10 @@ def main():
         _oracle.lib()  # build / load outside the timed window
         _oracle.set_row_step(step)
         t1 = time.perf_counter()
-        if args.workload == "c3_lav2":
-            ref = _oracle.lav2_hdr32(view, orbit, la, rows=(y0, H), threads=threads, stage_test=stage_test)
+        if is_lav2:
+            ref = _oracle.lav2_hdr32(view, orbit, la, aa=AA, rows=(y0, H), threads=threads, stage_test=stage_test)
         else:
-            ref = _oracle.bla_hdr32(view, orbit, bla, rows=(y0, H), threads=threads)
+            ref = _oracle.bla_hdr32(view, orbit, bla, aa=AA, rows=(y0, H), threads=threads)
         cpu_t = time.perf_counter() - t1
         _oracle.set_row_step(1)
         refs = [(y, ref[y]) for y in rows]
@@ -243,8 +251,8 @@ def main():
         # --pmc runs, see profiles/r01_traffic.json); null for workloads that have not been profiled.
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            key = "view%d_%dx%d_hdrx32_%s" % (args.view, W, H, {"c3_lav2": "lav2_full", "c2_po": "po",
-                                                                 "c5_bla": "bla"}[args.workload])
+            key = "view%d_%dx%d_%s" % (args.view, W, H, {"c3_lav2": "hdrx32_lav2_full", "c2_po": "hdrx32_po", "c5_bla": "hdrx32_bla",
+                                                                 "c4_hdr64": "hdrx64_lav2_full_aa4"}[args.workload])
             if key in tj and not distributed and args.parity == "cpu":
                 traffic = tj[key]["traffic_bytes"]
         except (OSError, ValueError, KeyError):
@@ -258,16 +266,17 @@ def main():
             else "Mpix/s (iteration buffer), " + args.workload,
             "value": round(value, 4), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32+i32exp", "data": "synthetic",
-            "config": {"workload": "view%d_%dx%d_hdrx32_%s" % (args.view, W, H, {"c3_lav2": "lav2_full", "c2_po": "po",
-                                                                                "c5_bla": "bla"}[args.workload]),
+            "vs_baseline": None, "dtype": "f64+i32exp" if is64 else "f32+i32exp", "data": "synthetic",
+            "config": {"workload": "view%d_%dx%d_%s" % (args.view, W, H, {"c3_lav2": "hdrx32_lav2_full", "c2_po": "hdrx32_po",
+                                                                                "c5_bla": "hdrx32_bla",
+                                                                                "c4_hdr64": "hdrx64_lav2_full_aa4"}[args.workload]),
                        "parity": args.parity, "n_iterations": n_iter, "orbit_entries": orbit.count,
                        "la_records": la.count if la else 0, "la_stages": la.stage_count if la else 0,
                        "bla_levels": bla.num_levels if bla else 0, "tiling": "rows/8-row bands interleaved x%d" % world,
                        "host_input_build_s": round(t_inputs, 3)},
             "roofline": {"bound": "valu", "achieved": round(achieved, 4), "peak": PEAK_FP32_VECTOR_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 5), "traffic": traffic,
-                         "kernel": "k_lav2_hdr32_fast" if args.workload == "c3_lav2" else "k_perturb_scalar_hdr32",
+                         "kernel": {"c3_lav2": "k_lav2_hdr32_fast", "c4_hdr64": "k_lav2_lit<double>"}.get(args.workload, "k_perturb_scalar"),
                          "kernel_ms": round(avg_kernel_ms, 3),
                          "pixel_steps_per_launch": perturb_steps, "at_iterations_per_launch": at_iters,
                          "la_steps_per_launch": la_steps, "flop_per_pixel_step": FLOP_PER_STEP,

@@ -133,6 +133,8 @@ def inputs_lib():
     _decl(lib, "fsh_orbit_compressed_count", u64, [vp])
     _decl(lib, "fsh_orbit_compressed_data_hdr32", vp, [vp])
     _decl(lib, "fsh_orbit_low_hdr32", None, [vp, vp])
+    _decl(lib, "fsh_orbit_compressed_data_hdr64", vp, [vp])
+    _decl(lib, "fsh_orbit_low_hdr64", None, [vp, vp])
     _decl(lib, "fsh_orbit_destroy", None, [vp])
     _decl(lib, "fsh_orbit_count", u64, [vp])
     _decl(lib, "fsh_orbit_period", u64, [vp])

@@ -128,6 +128,8 @@ struct FsDirectArgs64 {
 void fsk_prepare_orbit_hdr32(const fs_orbit_hdr32 *in, float4 *out, uint64_t n, hipStream_t s);
 void fsk_decompress_orbit_hdr32(const fs_orbit_hdr32_rc *wp, uint64_t n_wp, uint64_t n_uncompressed, fs_real_hdr32 cxLow,
                                 fs_real_hdr32 cyLow, float4 *out, hipStream_t s);
+void fsk_decompress_orbit_hdr64(const fs_orbit_hdr64_rc *wp, uint64_t n_wp, uint64_t n_uncompressed, fs_real_hdr64 cxLow,
+                                fs_real_hdr64 cyLow, FsZ64 *out, hipStream_t s);
 void fsk_prepare_orbit_hdr64(const fs_orbit_hdr64 *in, FsZ64 *out, uint64_t n, hipStream_t s);
 void fsk_lav2_hdr32(const FsLav2Args32 &A, int mode, bool stats, int variant, hipStream_t s);
 void fsk_lav2_hdr64(const FsLav2ArgsT<double> &A, int mode, bool stats, hipStream_t s);

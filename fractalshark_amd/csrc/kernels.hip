@@ -1128,6 +1128,42 @@ void fsk_perturb_scalar_hdr32(const FsBlaArgs32 &A, bool use_bla, bool stats, hi
     }
 }
 
+__global__ void k_decompress_orbit_hdr64(const fs_orbit_hdr64_rc *__restrict__ wp, uint64_t n_wp, uint64_t n_uncompressed,
+                                         fs_real_hdr64 cxLow, fs_real_hdr64 cyLow, FsZ64 *__restrict__ out)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_wp)
+        return;
+    const uint64_t kIndexMask = 0x7FFFFFFFFFFFFFFFull;
+    const uint64_t i0 = wp[k].index_and_rebase & kIndexMask;
+    const uint64_t i1 = k + 1 < n_wp ? (wp[k + 1].index_and_rebase & kIndexMask) : n_uncompressed;
+    hreal64 zx{wp[k].mx, wp[k].ex}, zy{wp[k].my, wp[k].ey};
+    const hreal64 cx = ldr(cxLow), cy = ldr(cyLow);
+    const hreal64 Two{1.0, 1};
+    for (uint64_t i = i0; i < i1 && i < n_uncompressed; i++) {
+        const hcplx64 c = hc_from_hr(zx, zy);
+        FsZ64 z;
+        z.re = c.re;
+        z.im = c.im;
+        z.e = c.e;
+        z.pad_ = 0;
+        z.w = ldexp(1.0, 8 - 2 * (c.e < -500 ? -500 : c.e));
+        out[i] = z;
+        const hreal64 zx_old = zx;
+        zx = hr_add(hr_sub(hr_mul(zx, zx), hr_mul(zy, zy)), cx);
+        hr_reduce(zx);
+        zy = hr_add(hr_mul(hr_mul(Two, zx_old), zy), cy);
+        hr_reduce(zy);
+    }
+}
+
+void fsk_decompress_orbit_hdr64(const fs_orbit_hdr64_rc *wp, uint64_t n_wp, uint64_t n_uncompressed, fs_real_hdr64 cxLow,
+                                fs_real_hdr64 cyLow, FsZ64 *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_decompress_orbit_hdr64, dim3((unsigned)((n_wp + 63) / 64)), dim3(64), 0, s, wp, n_wp,
+                       n_uncompressed, cxLow, cyLow, out);
+}
+
 void fsk_decompress_orbit_hdr32(const fs_orbit_hdr32_rc *wp, uint64_t n_wp, uint64_t n_uncompressed, fs_real_hdr32 cxLow,
                                 fs_real_hdr32 cyLow, float4 *out, hipStream_t s)
 {

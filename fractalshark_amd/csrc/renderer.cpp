@@ -499,7 +499,7 @@ uint32_t fs_upload_orbit_compressed(fs_renderer *r, uint64_t generation, int typ
 {
     if (uint32_t e = use_device(r))
         return e;
-    if (type_tag != FS_T_HDR32 || iter_bytes != 4)
+    if ((type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64) || iter_bytes != 4)
         return FS_ERR_UNSUPPORTED;
     if (!r->compute)
         return FS_ERR_6;
@@ -514,17 +514,27 @@ uint32_t fs_upload_orbit_compressed(fs_renderer *r, uint64_t generation, int typ
         r->zref64 = nullptr;
     }
     r->orbit_ok = false;
-    fs_orbit_hdr32_rc *raw = nullptr;
-    FS_TRY(hipMalloc((void **)&raw, compressed_size * sizeof(fs_orbit_hdr32_rc)));
-    hipError_t err = hipMalloc((void **)&r->zref, (uncompressed_size + 2) * sizeof(float4));
+    const size_t in_bytes = type_tag == FS_T_HDR32 ? sizeof(fs_orbit_hdr32_rc) : sizeof(fs_orbit_hdr64_rc);
+    void *raw = nullptr;
+    FS_TRY(hipMalloc(&raw, compressed_size * in_bytes));
+    hipError_t err = type_tag == FS_T_HDR32 ? hipMalloc((void **)&r->zref, (uncompressed_size + 2) * sizeof(float4))
+                                            : hipMalloc((void **)&r->zref64, (uncompressed_size + 2) * sizeof(FsZ64));
     if (err == hipSuccess)
-        err = hipMemcpyAsync(raw, entries, compressed_size * sizeof(fs_orbit_hdr32_rc), hipMemcpyDefault, r->compute);
-    if (err == hipSuccess)
-        err = hipMemsetAsync(r->zref + uncompressed_size, 0, 2 * sizeof(float4), r->compute);
+        err = hipMemcpyAsync(raw, entries, compressed_size * in_bytes, hipMemcpyDefault, r->compute);
     if (err == hipSuccess) {
-        fsk_decompress_orbit_hdr32(raw, compressed_size, uncompressed_size, *(const fs_real_hdr32 *)orbit_x_low,
-                                   *(const fs_real_hdr32 *)orbit_y_low, r->zref, r->compute);
-        err = hipGetLastError();
+        if (type_tag == FS_T_HDR32) {
+            err = hipMemsetAsync(r->zref + uncompressed_size, 0, 2 * sizeof(float4), r->compute);
+            fsk_decompress_orbit_hdr32((const fs_orbit_hdr32_rc *)raw, compressed_size, uncompressed_size,
+                                       *(const fs_real_hdr32 *)orbit_x_low, *(const fs_real_hdr32 *)orbit_y_low, r->zref,
+                                       r->compute);
+        } else {
+            err = hipMemsetAsync(r->zref64 + uncompressed_size, 0, 2 * sizeof(FsZ64), r->compute);
+            fsk_decompress_orbit_hdr64((const fs_orbit_hdr64_rc *)raw, compressed_size, uncompressed_size,
+                                       *(const fs_real_hdr64 *)orbit_x_low, *(const fs_real_hdr64 *)orbit_y_low, r->zref64,
+                                       r->compute);
+        }
+        if (err == hipSuccess)
+            err = hipGetLastError();
     }
     if (err == hipSuccess)
         err = hipStreamSynchronize(r->compute);

@@ -282,6 +282,7 @@ template <class F> struct OrbitT {
     std::vector<uint64_t> wp_index;
     std::vector<hreal<F>> wp_x, wp_y;
     std::vector<fs_orbit_hdr32_rc> packed_rc32;
+    std::vector<fs_orbit_hdr64_rc> packed_rc64;
 };
 
 struct fsh_orbit {
@@ -491,6 +492,24 @@ extern "C" const fs_orbit_hdr32_rc *fsh_orbit_compressed_data_hdr32(fsh_orbit *o
             ob.packed_rc32[k] = fs_orbit_hdr32_rc{ob.wp_index[k], ob.wp_x[k].m, ob.wp_x[k].e, ob.wp_y[k].e, ob.wp_y[k].m};
     }
     return ob.packed_rc32.data();
+}
+extern "C" const fs_orbit_hdr64_rc *fsh_orbit_compressed_data_hdr64(fsh_orbit *o)
+{
+    if (!o->is64 || !o->d.compressed)
+        return nullptr;
+    auto &ob = o->d;
+    if (ob.packed_rc64.size() != ob.wp_index.size()) {
+        ob.packed_rc64.resize(ob.wp_index.size());
+        for (size_t k = 0; k < ob.wp_index.size(); k++)
+            ob.packed_rc64[k] =
+                fs_orbit_hdr64_rc{ob.wp_index[k], ob.wp_x[k].m, ob.wp_x[k].e, 0, ob.wp_y[k].e, 0, ob.wp_y[k].m};
+    }
+    return ob.packed_rc64.data();
+}
+extern "C" void fsh_orbit_low_hdr64(const fsh_orbit *o, fs_real_hdr64 out[2])
+{
+    out[0] = fs_real_hdr64{o->d.orbitXLow.m, o->d.orbitXLow.e, 0};
+    out[1] = fs_real_hdr64{o->d.orbitYLow.m, o->d.orbitYLow.e, 0};
 }
 extern "C" void fsh_orbit_low_hdr32(const fsh_orbit *o, fs_real_hdr32 out[2])
 {

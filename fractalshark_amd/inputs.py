@@ -144,11 +144,13 @@ class Orbit:
 
     @property
     def compressed_data_ptr(self):
+        if self.is64:
+            return self._lib.fsh_orbit_compressed_data_hdr64(self._h)
         return self._lib.fsh_orbit_compressed_data_hdr32(self._h)
 
     def orbit_low(self):
-        out = np.zeros(2, REAL_HDR32)
-        self._lib.fsh_orbit_low_hdr32(self._h, out.ctypes.data)
+        out = np.zeros(2, REAL_HDR64 if self.is64 else REAL_HDR32)
+        (self._lib.fsh_orbit_low_hdr64 if self.is64 else self._lib.fsh_orbit_low_hdr32)(self._h, out.ctypes.data)
         return out
 
     def entries(self):

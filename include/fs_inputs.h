@@ -50,6 +50,8 @@ int fsh_orbit_is_compressed(const fsh_orbit *o);
 uint64_t fsh_orbit_compressed_count(const fsh_orbit *o);
 const fs_orbit_hdr32_rc *fsh_orbit_compressed_data_hdr32(fsh_orbit *o);
 void fsh_orbit_low_hdr32(const fsh_orbit *o, fs_real_hdr32 out[2]); /* {OrbitXLow, OrbitYLow} */
+const fs_orbit_hdr64_rc *fsh_orbit_compressed_data_hdr64(fsh_orbit *o);
+void fsh_orbit_low_hdr64(const fsh_orbit *o, fs_real_hdr64 out[2]);
 void fsh_orbit_destroy(fsh_orbit *o);
 uint64_t fsh_orbit_count(const fsh_orbit *o);  /* GetCountOrbitEntries(), includes the zero entry */
 uint64_t fsh_orbit_period(const fsh_orbit *o); /* GetPeriodMaybeZero() */

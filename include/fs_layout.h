@@ -65,6 +65,17 @@ typedef struct fs_orbit_hdr32_rc {
     float my;
 } fs_orbit_hdr32_rc;
 
+/* GPUReferenceIter<HDRFloat<double>, PerturbExtras::SimpleCompression>: 40 B. */
+typedef struct fs_orbit_hdr64_rc {
+    uint64_t index_and_rebase;
+    double mx;
+    int32_t ex;
+    int32_t pad0_;
+    int32_t ey;
+    int32_t pad1_;
+    double my;
+} fs_orbit_hdr64_rc;
+
 typedef struct fs_orbit_hdr64 {
     double mx;
     int32_t ex;
@@ -182,7 +193,7 @@ typedef struct fs_reduction {
 #ifdef __cplusplus
 }
 static_assert(sizeof(fs_orbit_hdr32) == 16, "orbit entry");
-static_assert(sizeof(fs_orbit_hdr32_rc) == 24, "compressed orbit entry");
+static_assert(sizeof(fs_orbit_hdr32_rc) == 24 && sizeof(fs_orbit_hdr64_rc) == 40, "compressed orbit entry");
 static_assert(sizeof(fs_orbit_hdr64) == 32, "orbit entry (double)");
 static_assert(sizeof(fs_la_hdr32_u32) == 68, "LA record");
 static_assert(sizeof(fs_at_hdr32_u32) == 116, "AT record");

@@ -314,6 +314,15 @@ def test_direct_hdr_parity(renderer, native_libs, is64):
     assert np.array_equal(out, _oracle.direct_hdr(v, is64))
 
 
+def test_simple_compression_orbit_parity_hdr64(renderer, native_libs):
+    """GpuHDRx64PerturbedRCLAv2 <-> Cpu64PerturbedRCBLAV2HDR (golden CRC 68df9ceecaf1a667 pins the CPU chain)."""
+    v = inputs.View.builtin(5, 64, 36)
+    ob = inputs.Orbit(v, is64=True, compression_exp=20)
+    la = inputs.LATable(ob)
+    out, _ = _render_lav2(renderer, v, ob, la, LAV2_FULL, PARITY_CPU)
+    assert np.array_equal(out, _oracle.lav2_hdr32(v, ob, la, stage_test=0))
+
+
 def test_simple_compression_orbit_parity(renderer, native_libs):
     """GpuHDRx32PerturbedRCLAv2 <-> Cpu32PerturbedRCBLAV2HDR: the waypoints are expanded on the device; the frame must
     equal the CPU function reading the orbit through RuntimeDecompressor (golden CRC b956600cfdfe431a pins that chain)."""
