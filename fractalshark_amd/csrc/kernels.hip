@@ -408,45 +408,58 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                                       (int)__builtin_amdgcn_ubfe(__float_as_int(q.y), 23, 8));
                 q = q * __int_as_float(0x7F000000 - (fmax << 23));
                 const int qe = pe + fmax - 127;
-                // z = Z' + q         (orbit bigger, gap in [0,120)); z is NOT reduced (see header comment)
                 const int nd3 = qe - Zne;
-                const f2 zm = Znm + q * __int_as_float((nd3 << 23) + 0x3F800000);
-                const f2 zz = zm * zm;
-                const float zn2 = zz.x + zz.y;
-                const f2 qq = q * q;
-                const float dn2 = qq.x + qq.y; // in [1,8): q's larger part is in [1,2)
-                // With both norms positive normal floats, Reduce(|z|^2) > 256 and Reduce(|z|^2) < Reduce(|dz|^2)
-                // (lexicographic on (exp, mantissa in [1,2))) are plain value comparisons:
-                //   zn2 * 2^(2 Zne) > 2^8            <=>  zn2 > 2^(8 - 2 Zne)          (= zv.w, exact power of two)
-                //   zn2 * 2^(2 Zne) < dn2 * 2^(2 qe)  <=>  zn2 < dn2 * 2^(2 nd3)        (exact scaling; an underflow can
-                //                                                                       only make the rhs <= min normal <= zn2)
-                bool escaped = zn2 > zv.w;
-                bool rebase = zn2 < __builtin_amdgcn_ldexpf(dn2, nd3 + nd3);
-                const bool ok = imax(imax(nd1, nd3), nd2) <= 0 && (nd1 < nd3 ? nd1 : nd3) > -kExpDiffIgnored &&
-                                fmax != 0 && __builtin_amdgcn_classf(zn2, 0x100 /* +normal */);
-                hcplx32 z;
-                bool reduced_z = false;
-                if (__ballot(!ok) != 0ull) {
-                    // ---- generic step, literal order of Fractal.cpp:2646-2661
-                    const hcplx32 Zc_g{Zcm.x, Zcm.y, Zce1 - 1};
-                    const hcplx32 dz_g{dzm.x, dzm.y, dze};
-                    hcplx32 curg = hc_mul2(Zc_g);
-                    curg = hc_add(curg, dz_g);
-                    hcplx32 ndz = hc_mul(dz_g, curg);
-                    ndz = hc_add(ndz, dc);
-                    hc_reduce(ndz);
-                    z = hc_add(hcplx32{Znm.x, Znm.y, Zne}, ndz);
-                    hc_reduce(z);
-                    const hreal32 n = hr_reduced(hc_norm2(z));
-                    const hreal32 dn = hr_reduced(hc_norm2(ndz));
-                    escaped = hr_cmp_pos(n, hreal32{1.0f, 8}) > 0;
-                    rebase = hr_cmp_pos(n, dn) < 0;
-                    q = (f2){ndz.re, ndz.im};
-                    dze = ndz.e;
-                    reduced_z = true;
-                } else {
-                    z = hcplx32{zm.x, zm.y, Zne};
+                const bool ok_core = imax(imax(nd1, nd3), nd2) <= 0 && (nd1 < nd3 ? nd1 : nd3) > -kExpDiffIgnored &&
+                                     (unsigned)(fmax - 1) < 254u; // larger part of q: non-zero, finite, normal
+                // ---- "quiet" step: when dz is at least 2^4 below the orbit value and the orbit value is < 8, neither
+                // exit test can fire and z itself is not needed:
+                //   |Z'| in [0.5, 2.83) 2^Zne (larger part of an orbit entry is in [0.5, 2)),  |dz| < 2.83 * 2^qe
+                //   qe <= Zne - 4  =>  |dz| < 0.18 * 2^Zne,  |z| = |Z' + dz| in (0.32, 3.01) * 2^Zne
+                //   => |z| > 1.8 |dz|  (no rebase: Reduce(|z|^2) < Reduce(|dz|^2) is false with a 3x margin in the squares)
+                //   => |z| < 12.1 for Zne <= 2 (no escape: |z|^2 > 256 is false with a 1.7x margin)
+                // float rounding moves these norms by < 1e-6 relative, so the CPU function takes the same decisions.
+                const bool quiet = nd3 <= -4 && Zne <= 2 && ref + 2 < MaxRefIteration + 1;
+                bool escaped = false, rebase = false, reduced_z = false;
+                hcplx32 z = hcplx32{0.0f, 0.0f, 0};
+                if (__ballot(!(ok_core && quiet)) == 0ull) {
                     dze = qe;
+                } else {
+                    // z = Z' + q         (orbit bigger, gap in [0,120)); z is NOT reduced (see header comment)
+                    const f2 zm = Znm + q * __int_as_float((nd3 << 23) + 0x3F800000);
+                    const f2 zz = zm * zm;
+                    const float zn2 = zz.x + zz.y;
+                    const f2 qq = q * q;
+                    const float dn2 = qq.x + qq.y; // in [1,8): q's larger part is in [1,2)
+                    // With both norms positive normal floats, Reduce(|z|^2) > 256 and Reduce(|z|^2) < Reduce(|dz|^2)
+                    // (lexicographic on (exp, mantissa in [1,2))) are plain value comparisons:
+                    //   zn2 * 2^(2 Zne) > 2^8            <=>  zn2 > 2^(8 - 2 Zne)      (= zv.w, exact power of two)
+                    //   zn2 * 2^(2 Zne) < dn2 * 2^(2 qe)  <=>  zn2 < dn2 * 2^(2 nd3)    (exact scaling; an underflow can
+                    //                                                                   only make the rhs <= min normal <= zn2)
+                    escaped = zn2 > zv.w;
+                    rebase = zn2 < __builtin_amdgcn_ldexpf(dn2, nd3 + nd3);
+                    const bool ok = ok_core && __builtin_amdgcn_classf(zn2, 0x100 /* +normal */);
+                    if (__ballot(!ok) != 0ull) {
+                        // ---- generic step, literal order of Fractal.cpp:2646-2661
+                        const hcplx32 Zc_g{Zcm.x, Zcm.y, Zce1 - 1};
+                        const hcplx32 dz_g{dzm.x, dzm.y, dze};
+                        hcplx32 curg = hc_mul2(Zc_g);
+                        curg = hc_add(curg, dz_g);
+                        hcplx32 ndz = hc_mul(dz_g, curg);
+                        ndz = hc_add(ndz, dc);
+                        hc_reduce(ndz);
+                        z = hc_add(hcplx32{Znm.x, Znm.y, Zne}, ndz);
+                        hc_reduce(z);
+                        const hreal32 n = hr_reduced(hc_norm2(z));
+                        const hreal32 dn = hr_reduced(hc_norm2(ndz));
+                        escaped = hr_cmp_pos(n, hreal32{1.0f, 8}) > 0;
+                        rebase = hr_cmp_pos(n, dn) < 0;
+                        q = (f2){ndz.re, ndz.im};
+                        dze = ndz.e;
+                        reduced_z = true;
+                    } else {
+                        z = hcplx32{zm.x, zm.y, Zne};
+                        dze = qe;
+                    }
                 }
                 if (kStats)
                     c_pt++;
