@@ -385,81 +385,108 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
             const int dce = dc.e;
             f2 Zcm = {Zc.re, Zc.im};
             int Zce1 = Zc.e + 1; // exponent of 2Z
+            // One speculative straight-line step from (dzm, dze, Zcm, Zce1) against the orbit entry zv.
+            // n* = NEGATED exponent gaps (<= 0 when the assumption holds).
+#define FS_LAV2_STEP_HEAD()                                                                                         \
+    const f2 Znm = {zv.x, zv.y};                                                                                    \
+    const int Zne = __float_as_int(zv.z);                                                                           \
+    /* cur = 2Z + dz      (orbit bigger, gap in [0,120)) */                                                        \
+    const int nd1 = dze - Zce1;                                                                                     \
+    const f2 cur = Zcm + dzm * __int_as_float((nd1 << 23) + 0x3F800000);                                            \
+    /* p = dz * cur       (re = dr*cr - di*ci, im = dr*ci + di*cr) */                                              \
+    const f2 pa = dzm.xx * cur;                                                                                     \
+    const f2 pb = dzm.yy * cur.yx;                                                                                  \
+    f2 p;                                                                                                           \
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(p) : "v"(pa), "v"(pb));                          \
+    const int pe = imax(dze + Zce1, kMinBigExp);                                                                    \
+    /* q = p + dc         (p bigger; gap >= 120 ignores dc) */                                                     \
+    const int nd2 = dce - pe;                                                                                       \
+    const float m2 = nd2 > -kExpDiffIgnored ? __int_as_float((nd2 << 23) + 0x3F800000) : 0.0f;                      \
+    f2 q = p + dcm * m2;                                                                                            \
+    /* Reduce(q)          (larger part a non-zero normal float) */                                                 \
+    const int fmax = imax((int)__builtin_amdgcn_ubfe(__float_as_int(q.x), 23, 8),                                   \
+                          (int)__builtin_amdgcn_ubfe(__float_as_int(q.y), 23, 8));                                  \
+    q = q * __int_as_float(0x7F000000 - (fmax << 23));                                                              \
+    const int qe = pe + fmax - 127;                                                                                 \
+    const int nd3 = qe - Zne;                                                                                       \
+    const bool ok_core = imax(imax(nd1, nd3), nd2) <= 0 && (nd1 < nd3 ? nd1 : nd3) > -kExpDiffIgnored &&            \
+                         (unsigned)(fmax - 1) < 254u /* larger part of q: non-zero, finite, normal */
+
             while (running) {
-                const float4 zv = zr[ref + 1];
-                const f2 Znm = {zv.x, zv.y};
-                const int Zne = __float_as_int(zv.z);
-                // ---- speculative straight-line step; n* = NEGATED exponent gaps (<= 0 when the assumption holds)
-                // cur = 2Z + dz      (orbit bigger, gap in [0,120))
-                const int nd1 = dze - Zce1;
-                const f2 cur = Zcm + dzm * __int_as_float((nd1 << 23) + 0x3F800000);
-                // p = dz * cur       (re = dr*cr - di*ci, im = dr*ci + di*cr)
-                const f2 pa = dzm.xx * cur;
-                const f2 pb = dzm.yy * cur.yx;
-                f2 p;
-                asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(p) : "v"(pa), "v"(pb));
-                const int pe = imax(dze + Zce1, kMinBigExp);
-                // q = p + dc         (p bigger; gap >= 120 ignores dc)
-                const int nd2 = dce - pe;
-                const float m2 = nd2 > -kExpDiffIgnored ? __int_as_float((nd2 << 23) + 0x3F800000) : 0.0f;
-                f2 q = p + dcm * m2;
-                // Reduce(q)          (larger part a non-zero normal float)
-                const int fmax = imax((int)__builtin_amdgcn_ubfe(__float_as_int(q.x), 23, 8),
-                                      (int)__builtin_amdgcn_ubfe(__float_as_int(q.y), 23, 8));
-                q = q * __int_as_float(0x7F000000 - (fmax << 23));
-                const int qe = pe + fmax - 127;
-                const int nd3 = qe - Zne;
-                const bool ok_core = imax(imax(nd1, nd3), nd2) <= 0 && (nd1 < nd3 ? nd1 : nd3) > -kExpDiffIgnored &&
-                                     (unsigned)(fmax - 1) < 254u; // larger part of q: non-zero, finite, normal
-                // ---- "quiet" step: when dz is at least 2^4 below the orbit value and the orbit value is < 8, neither
-                // exit test can fire and z itself is not needed:
+                // ---- run of "quiet" steps: when dz is at least 2^4 below the orbit value and the orbit value is < 8,
+                // neither exit test can fire and z itself is not needed:
                 //   |Z'| in [0.5, 2.83) 2^Zne (larger part of an orbit entry is in [0.5, 2)),  |dz| < 2.83 * 2^qe
                 //   qe <= Zne - 4  =>  |dz| < 0.18 * 2^Zne,  |z| = |Z' + dz| in (0.32, 3.01) * 2^Zne
                 //   => |z| > 1.8 |dz|  (no rebase: Reduce(|z|^2) < Reduce(|dz|^2) is false with a 3x margin in the squares)
                 //   => |z| < 12.1 for Zne <= 2 (no escape: |z|^2 > 256 is false with a 1.7x margin)
                 // float rounding moves these norms by < 1e-6 relative, so the CPU function takes the same decisions.
-                const bool quiet = nd3 <= -4 && Zne <= 2 && ref + 2 < MaxRefIteration + 1;
-                bool escaped = false, rebase = false, reduced_z = false;
-                hcplx32 z = hcplx32{0.0f, 0.0f, 0};
-                if (__ballot(!(ok_core && quiet)) == 0ull) {
-                    dze = qe;
-                } else {
-                    // z = Z' + q         (orbit bigger, gap in [0,120)); z is NOT reduced (see header comment)
-                    const f2 zm = Znm + q * __int_as_float((nd3 << 23) + 0x3F800000);
-                    const f2 zz = zm * zm;
-                    const float zn2 = zz.x + zz.y;
-                    const f2 qq = q * q;
-                    const float dn2 = qq.x + qq.y; // in [1,8): q's larger part is in [1,2)
-                    // With both norms positive normal floats, Reduce(|z|^2) > 256 and Reduce(|z|^2) < Reduce(|dz|^2)
-                    // (lexicographic on (exp, mantissa in [1,2))) are plain value comparisons:
-                    //   zn2 * 2^(2 Zne) > 2^8            <=>  zn2 > 2^(8 - 2 Zne)      (= zv.w, exact power of two)
-                    //   zn2 * 2^(2 Zne) < dn2 * 2^(2 qe)  <=>  zn2 < dn2 * 2^(2 nd3)    (exact scaling; an underflow can
-                    //                                                                   only make the rhs <= min normal <= zn2)
-                    escaped = zn2 > zv.w;
-                    rebase = zn2 < __builtin_amdgcn_ldexpf(dn2, nd3 + nd3);
-                    const bool ok = ok_core && __builtin_amdgcn_classf(zn2, 0x100 /* +normal */);
-                    if (__ballot(!ok) != 0ull) {
-                        // ---- generic step, literal order of Fractal.cpp:2646-2661
-                        const hcplx32 Zc_g{Zcm.x, Zcm.y, Zce1 - 1};
-                        const hcplx32 dz_g{dzm.x, dzm.y, dze};
-                        hcplx32 curg = hc_mul2(Zc_g);
-                        curg = hc_add(curg, dz_g);
-                        hcplx32 ndz = hc_mul(dz_g, curg);
-                        ndz = hc_add(ndz, dc);
-                        hc_reduce(ndz);
-                        z = hc_add(hcplx32{Znm.x, Znm.y, Zne}, ndz);
-                        hc_reduce(z);
-                        const hreal32 n = hr_reduced(hc_norm2(z));
-                        const hreal32 dn = hr_reduced(hc_norm2(ndz));
-                        escaped = hr_cmp_pos(n, hreal32{1.0f, 8}) > 0;
-                        rebase = hr_cmp_pos(n, dn) < 0;
-                        q = (f2){ndz.re, ndz.im};
-                        dze = ndz.e;
-                        reduced_z = true;
-                    } else {
-                        z = hcplx32{zm.x, zm.y, Zne};
+                // The run continues while EVERY running lane of the wave is quiet; `left` keeps a lane away from the
+                // orbit end and from its iteration limit (both need the careful step below).
+                {
+                    const uint32_t left_ref = ref + 1 < MaxRefIteration ? MaxRefIteration - 1 - ref : 0u;
+                    const uint32_t left_it = n_iterations - 1 - iterations; // running => iterations < n_iterations
+                    uint32_t left = left_ref < left_it ? left_ref : left_it;
+                    const float4 *zp = zr + ref + 1;
+                    uint32_t done = 0;
+                    for (;;) {
+                        const float4 zv = *zp;
+                        FS_LAV2_STEP_HEAD();
+                        const bool quiet = ok_core && nd3 <= -4 && Zne <= 2 && left != 0;
+                        if (__builtin_amdgcn_ballot_w64(!quiet) != 0ull)
+                            break;
+                        dzm = q;
                         dze = qe;
+                        Zcm = Znm;
+                        Zce1 = Zne + 1;
+                        zp++;
+                        left--;
+                        done++;
                     }
+                    ref += done;
+                    iterations += done;
+                    if (kStats)
+                        c_pt += done;
+                }
+                // ---- one careful step: full exit tests; generic CPU-order fallback when an assumption fails
+                const float4 zv = zr[ref + 1];
+                FS_LAV2_STEP_HEAD();
+                // z = Z' + q         (orbit bigger, gap in [0,120)); z is NOT reduced (see header comment)
+                const f2 zm = Znm + q * __int_as_float((nd3 << 23) + 0x3F800000);
+                const f2 zz = zm * zm;
+                const float zn2 = zz.x + zz.y;
+                const f2 qq = q * q;
+                const float dn2 = qq.x + qq.y; // in [1,8): q's larger part is in [1,2)
+                // With both norms positive normal floats, Reduce(|z|^2) > 256 and Reduce(|z|^2) < Reduce(|dz|^2)
+                // (lexicographic on (exp, mantissa in [1,2))) are plain value comparisons:
+                //   zn2 * 2^(2 Zne) > 2^8            <=>  zn2 > 2^(8 - 2 Zne)          (= zv.w, exact power of two)
+                //   zn2 * 2^(2 Zne) < dn2 * 2^(2 qe)  <=>  zn2 < dn2 * 2^(2 nd3)        (exact scaling; an underflow can
+                //                                                                       only make the rhs <= min normal <= zn2)
+                bool escaped = zn2 > zv.w;
+                bool rebase = zn2 < __builtin_amdgcn_ldexpf(dn2, nd3 + nd3);
+                const bool ok = ok_core && __builtin_amdgcn_classf(zn2, 0x100 /* +normal */);
+                hcplx32 z;
+                bool reduced_z = false;
+                if (__builtin_amdgcn_ballot_w64(!ok) != 0ull) {
+                    // ---- generic step, literal order of Fractal.cpp:2646-2661
+                    const hcplx32 Zc_g{Zcm.x, Zcm.y, Zce1 - 1};
+                    const hcplx32 dz_g{dzm.x, dzm.y, dze};
+                    hcplx32 curg = hc_mul2(Zc_g);
+                    curg = hc_add(curg, dz_g);
+                    hcplx32 ndz = hc_mul(dz_g, curg);
+                    ndz = hc_add(ndz, dc);
+                    hc_reduce(ndz);
+                    z = hc_add(hcplx32{Znm.x, Znm.y, Zne}, ndz);
+                    hc_reduce(z);
+                    const hreal32 n = hr_reduced(hc_norm2(z));
+                    const hreal32 dn = hr_reduced(hc_norm2(ndz));
+                    escaped = hr_cmp_pos(n, hreal32{1.0f, 8}) > 0;
+                    rebase = hr_cmp_pos(n, dn) < 0;
+                    q = (f2){ndz.re, ndz.im};
+                    dze = ndz.e;
+                    reduced_z = true;
+                } else {
+                    z = hcplx32{zm.x, zm.y, Zne};
+                    dze = qe;
                 }
                 if (kStats)
                     c_pt++;
@@ -484,6 +511,7 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                     running = iterations < n_iterations;
                 }
             }
+#undef FS_LAV2_STEP_HEAD
         }
         A.out[(size_t)L * A.frame.rounded_width + X] = iterations;
     }
@@ -664,7 +692,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                                 __builtin_amdgcn_classf(Q.x, 0x108 /* +-normal */) &&
                                 __builtin_amdgcn_classf(Q.y, 0x108) && __builtin_amdgcn_classf(nm, 0x100) &&
                                 RefIteration + 1 < count;
-                if (__ballot(!ok) == 0ull) {
+                if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) {
                     done_fast = true;
                     if (kStats)
                         c_pt++;
