@@ -280,6 +280,8 @@ def main():
                          "kernel_ms": round(avg_kernel_ms, 3),
                          "pixel_steps_per_launch": perturb_steps, "at_iterations_per_launch": at_iters,
                          "la_steps_per_launch": la_steps, "flop_per_pixel_step": FLOP_PER_STEP,
+                         "careful_step_fraction_rank0": round(steps_executed[0].get("careful_steps", 0) /
+                                                              max(1, steps_executed[0]["perturb_steps"]), 5),
                          "lane_utilisation_rank0": round(perturb_steps / lane_slots, 4) if lane_slots and not distributed else None},
             "cpu_baseline": cpu_baseline,
             "frame_checksum": checksum, "cpu_sample_rows_bit_exact": parity_rows_ok,

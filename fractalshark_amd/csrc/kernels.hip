@@ -285,6 +285,7 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
     const uint32_t X = blockIdx.x * 64u + (threadIdx.x & 63u);
     const uint32_t L = blockIdx.y * 4u + (threadIdx.x >> 6);
     uint64_t c_at = 0, c_la = 0, c_pt = 0, c_px = 0;
+    uint64_t c_careful = 0;
     const uint32_t Y = global_row(A.frame, L);
     const bool live = X < A.frame.width && L < A.frame.local_rows && Y < A.frame.height;
     if (live) {
@@ -488,8 +489,10 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                     z = hcplx32{zm.x, zm.y, Zne};
                     dze = qe;
                 }
-                if (kStats)
+                if (kStats) {
                     c_pt++;
+                    c_careful++;
+                }
                 ref++;
                 dzm = q;
                 Zcm = Znm;
@@ -515,8 +518,14 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
         }
         A.out[(size_t)L * A.frame.rounded_width + X] = iterations;
     }
-    if (kStats)
+    if (kStats) {
         add_stats(A.stats, c_at, c_la, c_pt, c_px);
+        // stats[5]: lane-steps taken through the careful path (the rest of [2] ran in quiet runs)
+        for (int off = 32; off > 0; off >>= 1)
+            c_careful += __shfl_down(c_careful, off);
+        if ((threadIdx.x & 63) == 0)
+            atomicAdd((unsigned long long *)&A.stats[5], (unsigned long long)c_careful);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

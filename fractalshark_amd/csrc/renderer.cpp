@@ -925,13 +925,13 @@ uint32_t fs_enable_step_count(fs_renderer *r, int enable)
     return 0;
 }
 
-uint32_t fs_read_step_count(fs_renderer *r, uint64_t counts[5])
+uint32_t fs_read_step_count(fs_renderer *r, uint64_t counts[6])
 {
     if (uint32_t e = use_device(r))
         return e;
     if (!r->stats)
         return FS_ERR_6;
-    FS_TRY(hipMemcpy(counts, r->stats, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    FS_TRY(hipMemcpy(counts, r->stats, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return 0;
 }
 

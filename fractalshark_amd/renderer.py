@@ -192,12 +192,12 @@ class GPURenderer:
         return self._lib.fs_enable_step_count(self._h, 1 if on else 0)
 
     def read_step_count(self):
-        out = (C.c_uint64 * 5)()
+        out = (C.c_uint64 * 6)()
         err = self._lib.fs_read_step_count(self._h, out)
         if err:
             raise RuntimeError(self.ConvertErrorToString(err))
         return {"at_iterations": out[0], "la_steps": out[1], "perturb_steps": out[2], "pixels": out[3],
-                "lane_slots": out[4]}
+                "lane_slots": out[4], "careful_steps": out[5]}
 
     def new_iter_buffer(self):
         return np.zeros((self.local_rows, self.rounded_width), np.uint32)

@@ -157,13 +157,14 @@ uint32_t fs_get_height(const fs_renderer *r);
  * compute stream (valid after fs_sync_compute).
  * fs_enable_step_count: when on, iteration kernels also accumulate the executed work per launch:
  * counts[0] = AT iterations, [1] = LA steps, [2] = perturbation steps, [3] = pixels,
- * [4] = lane slots occupied in the perturbation loop (64 x longest lane, summed over waves). */
+ * [4] = lane slots occupied in the perturbation loop (64 x longest lane, summed over waves),
+ * [5] = perturbation steps that went through the careful (exit-tested) path of the tuned LAv2 loop. */
 float fs_last_kernel_ms(const fs_renderer *r);
 /* 0 (default) = tuned iteration loops; 1 = literal operation-by-operation transcription of the CPU function
  * (slower; kept as the in-library A/B reference for the tuned loops -- results are identical). */
 uint32_t fs_set_kernel_variant(fs_renderer *r, int variant);
 uint32_t fs_enable_step_count(fs_renderer *r, int enable);
-uint32_t fs_read_step_count(fs_renderer *r, uint64_t counts[5]);
+uint32_t fs_read_step_count(fs_renderer *r, uint64_t counts[6]);
 
 #ifdef __cplusplus
 }
