@@ -50,12 +50,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["c3_lav2", "c2_po", "c5_bla", "c4_hdr64"], default="c3_lav2",
+    ap.add_argument("--workload", choices=["c3_lav2", "c2_po", "c5_bla", "c4_hdr64", "c4_2x32"], default="c3_lav2",
                     help="c3_lav2 (default, the headline config): View 5 3840x2160 HDRx32 LAv2 Full; "
                          "c2_po: View 5 1920x1080 HDRx32 perturbation only; c5_bla: View 19 7680x4320 HDRx32 BLA; "
                          "c4_hdr64: View 14 (zoom 2^-21645) 3840x2160 x AA4 = 15360x8640 with HDRFloat<double> LAv2 -- the "
-                         "CPU-twinned stand-in for C4 until the 2x32 type exists (use --parity cpu_gpustage: the literal "
-                         "CPU function needs ~6e5 perturbation steps per pixel there)")
+                         "CPU-twinned form of C4 (use --parity cpu_gpustage: the literal CPU function needs ~6e5 "
+                         "perturbation steps per pixel there); c4_2x32: the same frame with HDRFloat<CudaDblflt> "
+                         "(GpuHDRx2x32PerturbedLAv2), checked against the restated CUDA kernel (no CPU twin exists)")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--view", type=int, default=-1)
@@ -73,8 +74,8 @@ def main():
     import numpy as np
     import torch
 
-    from fractalshark_amd import (GPURenderer, LAV2_FULL, PARITY_CPU, PARITY_CPU_GPUSTAGE, T_HDR32, T_HDR64, _build,
-                                  inputs, tiling)
+    from fractalshark_amd import (GPURenderer, LAV2_FULL, PARITY_CPU, PARITY_CPU_GPUSTAGE, T_HDR2X32, T_HDR32, T_HDR64,
+                                  _build, inputs, tiling)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -98,7 +99,7 @@ def main():
 
     # ---- inputs (host, outside the timed region)
     defaults = {"c3_lav2": (5, 3840, 2160), "c2_po": (5, 1920, 1080), "c5_bla": (19, 7680, 4320),
-                "c4_hdr64": (14, 3840, 2160)}[args.workload]
+                "c4_hdr64": (14, 3840, 2160), "c4_2x32": (14, 3840, 2160)}[args.workload]
     if args.view < 0:
         args.view = defaults[0]
     if args.width <= 0:
@@ -106,25 +107,34 @@ def main():
     if args.height <= 0:
         args.height = defaults[2]
     t0 = time.time()
-    is_lav2 = args.workload in ("c3_lav2", "c4_hdr64")
-    is64 = args.workload == "c4_hdr64"
+    is_lav2 = args.workload in ("c3_lav2", "c4_hdr64", "c4_2x32")
+    is2x32 = args.workload == "c4_2x32"
+    is64 = args.workload in ("c4_hdr64", "c4_2x32")  # the 2x32 inputs are derived from the HDRFloat<double> ones
     view = inputs.View.builtin(args.view, args.width, args.height, antialiasing=None if is64 else 1)
     orbit = inputs.Orbit(view, is64=is64)
-    la = inputs.LATable(orbit, host_threads=effective_cpus()) if is_lav2 else None
+    la = inputs.LATable(orbit, host_threads=effective_cpus(), use_small_exponents=is2x32) if is_lav2 else None
+    orbit2 = inputs.Orbit2x32(orbit) if is2x32 else None
+    la2 = inputs.LATable2x32(la) if is2x32 else None
     bla = inputs.BLATable(orbit) if args.workload == "c5_bla" else None
     t_inputs = time.time() - t0
     AA = view.antialiasing
     W, H = view.width * AA, view.height * AA
     n_iter = view.num_iterations
     parity = PARITY_CPU if args.parity == "cpu" else PARITY_CPU_GPUSTAGE
-    coords_arr = view.coords_perturb(orbit)
-    coords = [(float(c["m"]), int(c["e"])) for c in coords_arr]
+    if is2x32:
+        coords_arr = view.coords_perturb_2x32(orbit2)
+        coords = [(float(c["head"]), float(c["tail"]), int(c["e"])) for c in coords_arr]
+    else:
+        coords_arr = view.coords_perturb(orbit)
+        coords = [(float(c["m"]), int(c["e"])) for c in coords_arr]
 
     r = GPURenderer(local_rank)
     err = r.InitializeMemory(W, H, AA, None, 0, 0, 0, False)
     assert err == 0, GPURenderer.ConvertErrorToString(err)
-    T_TAG = T_HDR64 if is64 else T_HDR32
-    if is_lav2:
+    T_TAG = T_HDR2X32 if is2x32 else (T_HDR64 if is64 else T_HDR32)
+    if is2x32:
+        assert r.InitializePerturb(1, orbit2, 0, None, la2) == 0
+    elif is_lav2:
         assert r.InitializePerturb(1, orbit, 0, None, la) == 0
     else:
         # the reference re-uploads orbit + BLA table inside every RenderPerturbBLA call (GPU_Render.cu:1464-1479);
@@ -223,7 +233,7 @@ def main():
     if rank == 0 and not distributed and not args.no_cpu:
         import _oracle
         threads = effective_cpus()
-        nrows = max(1, min(args.cpu_sample_rows if args.cpu_sample_rows > 0 else 8 * threads, H))
+        nrows = max(1, min(args.cpu_sample_rows if args.cpu_sample_rows > 0 else (4 if is2x32 else 8) * threads, H))
         step = max(1, H // nrows)
         y0 = step // 2
         rows = list(range(y0, H, step))
@@ -231,7 +241,9 @@ def main():
         _oracle.lib()  # build / load outside the timed window
         _oracle.set_row_step(step)
         t1 = time.perf_counter()
-        if is_lav2:
+        if is2x32:
+            ref = _oracle.gpu_lav2_2x32(view, orbit2, la2, aa=AA, rows=(y0, H), threads=threads)
+        elif is_lav2:
             ref = _oracle.lav2_hdr32(view, orbit, la, aa=AA, rows=(y0, H), threads=threads, stage_test=stage_test)
         else:
             ref = _oracle.bla_hdr32(view, orbit, bla, aa=AA, rows=(y0, H), threads=threads)
@@ -252,7 +264,8 @@ def main():
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
             key = "view%d_%dx%d_%s" % (args.view, W, H, {"c3_lav2": "hdrx32_lav2_full", "c2_po": "hdrx32_po", "c5_bla": "hdrx32_bla",
-                                                                 "c4_hdr64": "hdrx64_lav2_full_aa4"}[args.workload])
+                                                                 "c4_hdr64": "hdrx64_lav2_full_aa4",
+                                                                 "c4_2x32": "hdrx2x32_lav2_full_aa4"}[args.workload])
             if key in tj and not distributed and args.parity == "cpu":
                 traffic = tj[key]["traffic_bytes"]
         except (OSError, ValueError, KeyError):
@@ -260,23 +273,32 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = W * H * args.steps / elapsed / 1e6
-        achieved = perturb_steps * FLOP_PER_STEP / (avg_kernel_ms * 1e-3) / 1e12
+        if is2x32:
+            # binary32 operations of the double-float sequences: product = 12 flop (1 mul, 4 fma, 3 add),
+            # sum = 20 flop; AT iteration = 8 products + 5 sums, perturbation step = 12 products + 10 sums + 6 exact
+            # power-of-two scalings (another 6 products), LA step = 22 products + 12 sums.
+            flops = at_iters * 196.0 + perturb_steps * 416.0 + la_steps * 504.0
+        else:
+            flops = perturb_steps * FLOP_PER_STEP
+        achieved = flops / (avg_kernel_ms * 1e-3) / 1e12
         line = {
             "metric": "Mpix/s (iteration buffer), View #5 3840x2160 HDRx32 LAv2" if args.workload == "c3_lav2"
             else "Mpix/s (iteration buffer), " + args.workload,
             "value": round(value, 4), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f64+i32exp" if is64 else "f32+i32exp", "data": "synthetic",
+            "vs_baseline": None, "dtype": "2xf32+i32exp" if is2x32 else ("f64+i32exp" if is64 else "f32+i32exp"), "data": "synthetic",
             "config": {"workload": "view%d_%dx%d_%s" % (args.view, W, H, {"c3_lav2": "hdrx32_lav2_full", "c2_po": "hdrx32_po",
                                                                                 "c5_bla": "hdrx32_bla",
-                                                                                "c4_hdr64": "hdrx64_lav2_full_aa4"}[args.workload]),
+                                                                                "c4_hdr64": "hdrx64_lav2_full_aa4",
+                                                                                "c4_2x32": "hdrx2x32_lav2_full_aa4"}[args.workload]),
                        "parity": args.parity, "n_iterations": n_iter, "orbit_entries": orbit.count,
                        "la_records": la.count if la else 0, "la_stages": la.stage_count if la else 0,
                        "bla_levels": bla.num_levels if bla else 0, "tiling": "rows/8-row bands interleaved x%d" % world,
                        "host_input_build_s": round(t_inputs, 3)},
             "roofline": {"bound": "valu", "achieved": round(achieved, 4), "peak": PEAK_FP32_VECTOR_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 5), "traffic": traffic,
-                         "kernel": {"c3_lav2": "k_lav2_hdr32_fast", "c4_hdr64": "k_lav2_lit<double>"}.get(args.workload, "k_perturb_scalar"),
+                         "kernel": {"c3_lav2": "k_lav2_hdr32_fast", "c4_hdr64": "k_lav2_lit<double>",
+                                    "c4_2x32": "k_lav2_2x32"}.get(args.workload, "k_perturb_scalar"),
                          "kernel_ms": round(avg_kernel_ms, 3),
                          "pixel_steps_per_launch": perturb_steps, "at_iterations_per_launch": at_iters,
                          "la_steps_per_launch": la_steps, "flop_per_pixel_step": FLOP_PER_STEP,

@@ -44,7 +44,23 @@ class AtHdr64(C.Structure):
                 ("CCoeffNormSqr", RealHdr64), ("RefCNormSqr", RealHdr64), ("factor", RealHdr64)]
 
 
-assert C.sizeof(AtHdr32) == 116 and C.sizeof(AtHdr64) == 232
+class Real2x32(C.Structure):
+    _fields_ = [("head", C.c_float), ("tail", C.c_float), ("e", C.c_int32)]
+
+
+class Cplx2x32(C.Structure):
+    _fields_ = [("re_head", C.c_float), ("re_tail", C.c_float), ("im_head", C.c_float), ("im_tail", C.c_float),
+                ("e", C.c_int32)]
+
+
+class At2x32(C.Structure):
+    _fields_ = [("StepLength", u32), ("ThresholdC", Real2x32), ("SqrEscapeRadius", Real2x32),
+                ("RefC", Cplx2x32), ("ZCoeff", Cplx2x32), ("CCoeff", Cplx2x32), ("InvZCoeff", Cplx2x32),
+                ("CCoeffSqrInvZCoeff", Cplx2x32), ("CCoeffInvZCoeff", Cplx2x32),
+                ("CCoeffNormSqr", Real2x32), ("RefCNormSqr", Real2x32), ("factor", Real2x32)]
+
+
+assert C.sizeof(AtHdr32) == 116 and C.sizeof(AtHdr64) == 232 and C.sizeof(At2x32) == 184
 
 DONE_CB = C.CFUNCTYPE(None, vp)
 
@@ -143,8 +159,13 @@ def inputs_lib():
     _decl(lib, "fsh_orbit_max_radius_hdr32", None, [vp, vp])
     _decl(lib, "fsh_view_coords_perturb_hdr32", None, [vp, vp, u32, u32, vp])
     _decl(lib, "fsh_view_coords_perturb_hdr64", None, [vp, vp, u32, u32, vp])
+    _decl(lib, "fsh_convert_orbit_hdr64_to_2x32", None, [vp, u64, vp])
+    _decl(lib, "fsh_convert_la_hdr64_to_2x32", None, [vp, u64, vp])
+    _decl(lib, "fsh_convert_at_hdr64_to_2x32", None, [vp, vp])
+    _decl(lib, "fsh_view_coords_perturb_2x32", None, [vp, vp, u32, u32, vp])
     _decl(lib, "fsh_la_create_hdr32", vp, [vp, C.c_int])
     _decl(lib, "fsh_la_create", vp, [vp, C.c_int])
+    _decl(lib, "fsh_la_create_ex", vp, [vp, C.c_int, C.c_int])
     _decl(lib, "fsh_la_is64", C.c_int, [vp])
     _decl(lib, "fsh_la_destroy", None, [vp])
     _decl(lib, "fsh_la_count", u32, [vp])

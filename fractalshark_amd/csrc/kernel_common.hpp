@@ -1,0 +1,44 @@
+// kernel_common.hpp -- small device helpers shared by the kernel translation units (kernels.hip, kernels_2x32.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+namespace {
+
+// Global row of local row L under the band layout (fs_set_row_bands).
+__device__ __forceinline__ uint32_t global_row(const FsFrame &f, uint32_t L)
+{
+    const uint32_t k = L / f.band_rows;
+    const uint32_t rr = L - k * f.band_rows;
+    return f.band_first + k * f.band_stride + rr;
+}
+
+__device__ __forceinline__ void add_stats(uint64_t *stats, uint64_t at, uint64_t la, uint64_t pt, uint64_t px)
+{
+    // stats[4]: lane slots the wave occupied in the perturbation loop = 64 x (longest lane); with [2] it gives
+    // the SIMD lane utilisation of the loop.
+    uint64_t mx = pt;
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint64_t o = __shfl_down(mx, off);
+        mx = o > mx ? o : mx;
+    }
+    // one atomic per wave per counter
+    for (int off = 32; off > 0; off >>= 1) {
+        at += __shfl_down(at, off);
+        la += __shfl_down(la, off);
+        pt += __shfl_down(pt, off);
+        px += __shfl_down(px, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd((unsigned long long *)&stats[0], (unsigned long long)at);
+        atomicAdd((unsigned long long *)&stats[1], (unsigned long long)la);
+        atomicAdd((unsigned long long *)&stats[2], (unsigned long long)pt);
+        atomicAdd((unsigned long long *)&stats[3], (unsigned long long)px);
+        atomicAdd((unsigned long long *)&stats[4], (unsigned long long)(mx * 64u));
+    }
+}
+
+} // namespace

@@ -115,6 +115,24 @@ template <class F> struct FsDirectHdrArgsT {
     uint32_t n_iterations;
 };
 
+// LAv2 for HDRFloat<CudaDblflt> (2x32): the reference records are used as they are (24-B orbit entries, 104-B LA
+// records, the 184-B ATInfo in the argument block).
+struct FsLav2Args2x32 {
+    uint32_t *out;
+    const fs_orbit_2x32 *orbit;
+    const fs_la_2x32_u32 *las;
+    const fs_la_stage_u32 *stages;
+    uint64_t *stats;
+    FsFrame frame;
+    fs_real_2x32 coords[4]; // dx, dy, centerX, centerY
+    fs_at_2x32_u32 at;
+    uint32_t orbit_count;
+    uint32_t stage_count;
+    uint32_t n_iterations;
+    int la_valid;
+    int use_at;
+};
+
 struct FsDirectArgs64 {
     uint32_t *out;
     double *cx_row; // [width] row prefix of cx
@@ -133,6 +151,7 @@ void fsk_decompress_orbit_hdr64(const fs_orbit_hdr64_rc *wp, uint64_t n_wp, uint
 void fsk_prepare_orbit_hdr64(const fs_orbit_hdr64 *in, FsZ64 *out, uint64_t n, hipStream_t s);
 void fsk_lav2_hdr32(const FsLav2Args32 &A, int mode, bool stats, int variant, hipStream_t s);
 void fsk_lav2_hdr64(const FsLav2ArgsT<double> &A, int mode, bool stats, hipStream_t s);
+void fsk_lav2_2x32(const FsLav2Args2x32 &A, int mode, bool stats, hipStream_t s);
 void fsk_perturb_scalar_hdr32(const FsBlaArgs32 &A, bool use_bla, bool stats, hipStream_t s);
 void fsk_perturb_scalar_hdr64(const FsBlaArgsT<double> &A, bool use_bla, bool stats, hipStream_t s);
 void fsk_perturb_bla_f64(const FsBlaArgsF64 &A, bool use_bla, bool stats, hipStream_t s);

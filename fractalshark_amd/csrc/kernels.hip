@@ -12,6 +12,7 @@
 #include "../../include/fs_layout.h"
 #include "hdr_math.hpp"
 #include "kernels.h"
+#include "kernel_common.hpp"
 
 using namespace fs;
 
@@ -35,14 +36,6 @@ __device__ __forceinline__ hcplx64 zref_at(const FsZ64 *__restrict__ z, uint32_t
     return hcplx64{z[i].re, z[i].im, z[i].e};
 }
 
-// Global row of local row L under the band layout (fs_set_row_bands).
-__device__ __forceinline__ uint32_t global_row(const FsFrame &f, uint32_t L)
-{
-    const uint32_t k = L / f.band_rows;
-    const uint32_t rr = L - k * f.band_rows;
-    return f.band_first + k * f.band_stride + rr;
-}
-
 // Pixel -> delta c, Fractal.cpp:2553-2562 (== 2272-2281): `dx * (float)x` goes through HDRFloat(T mant).
 template <class F>
 __device__ __forceinline__ void pixel_delta(const FsCoordsT<F> &c, uint32_t x, uint32_t y, hreal<F> &dRe, hreal<F> &dIm)
@@ -57,31 +50,6 @@ __device__ __forceinline__ void pixel_delta(const FsCoordsT<F> &c, uint32_t x, u
     hr_reduce(b);
     dRe = a;
     dIm = b;
-}
-
-__device__ __forceinline__ void add_stats(uint64_t *stats, uint64_t at, uint64_t la, uint64_t pt, uint64_t px)
-{
-    // stats[4]: lane slots the wave occupied in the perturbation loop = 64 x (longest lane); with [2] it gives
-    // the SIMD lane utilisation of the loop.
-    uint64_t mx = pt;
-    for (int off = 32; off > 0; off >>= 1) {
-        const uint64_t o = __shfl_down(mx, off);
-        mx = o > mx ? o : mx;
-    }
-    // one atomic per wave per counter
-    for (int off = 32; off > 0; off >>= 1) {
-        at += __shfl_down(at, off);
-        la += __shfl_down(la, off);
-        pt += __shfl_down(pt, off);
-        px += __shfl_down(px, off);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd((unsigned long long *)&stats[0], (unsigned long long)at);
-        atomicAdd((unsigned long long *)&stats[1], (unsigned long long)la);
-        atomicAdd((unsigned long long *)&stats[2], (unsigned long long)pt);
-        atomicAdd((unsigned long long *)&stats[3], (unsigned long long)px);
-        atomicAdd((unsigned long long *)&stats[4], (unsigned long long)(mx * 64u));
-    }
 }
 
 } // namespace

@@ -1,0 +1,207 @@
+// kernels_2x32.hip -- LAv2 for T = HDRFloat<CudaDblflt> ("2x32 + exponent"): RenderAlgorithm
+// GpuHDRx2x32PerturbedLAv2[PO|LAO] (GPU_Render.cu:1152-1185).  Compiled with -ffp-contract=off (df32_math.hpp).
+//
+// This numeric type has no CPU RenderAlgorithm in the reference, so the semantics restated here are those of the
+// CUDA kernel itself, mandel_1xHDR_float_perturb_lav2<.., HDRFloat<CudaDblflt<dblflt>>, ..>
+// (FractalSharkGpuLib/LAKernel.cuh:3-315): scalar-HDR perturbation step (HDRFloat::custom_perturb3,
+// HDRFloat.h:797-812), escape when the reduced |z|^2 has exponent >= 2 (compareToBothPositiveReducedTemplate<256>,
+// HDRFloat.h:1169-1184), GPU direction of the LA stage-validity test (GPU_LAReference.h:238-254), delta-c built
+// without intermediate Reduce (LAKernel.cuh:41-42).  The checker is oracle/gpu_ref_2x32.cpp (parity unpinned: see
+// its header).
+//
+// Decomposition is the same as the other iteration kernels: one lane per (sub)pixel, block = 4 waves x 64 lanes over
+// a 64-pixel row segment x 4 rows, orbit / LA table read straight from L2 (every lane of a wave reads the same or a
+// neighbouring entry).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fs_layout.h"
+#include "df32_math.hpp"
+#include "kernels.h"
+#include "kernel_common.hpp"
+
+using namespace fs;
+
+namespace {
+
+using HR = hreal<df32>;
+using HC = hcplx<df32>;
+
+__device__ __forceinline__ HR ldr(const fs_real_2x32 &r) { return HR{df32(r.head, r.tail), r.e}; }
+__device__ __forceinline__ HC ldc(const fs_cplx_2x32 &c)
+{
+    return HC{df32(c.re_head, c.re_tail), df32(c.im_head, c.im_tail), c.e};
+}
+__device__ __forceinline__ HR orbit_x(const fs_orbit_2x32 *__restrict__ o, uint32_t i)
+{
+    return HR{df32(o[i].x_head, o[i].x_tail), o[i].ex};
+}
+__device__ __forceinline__ HR orbit_y(const fs_orbit_2x32 *__restrict__ o, uint32_t i)
+{
+    return HR{df32(o[i].y_head, o[i].y_tail), o[i].ey};
+}
+
+// `T(X)` for an int, HDRFloat.h:293-363.
+__device__ __forceinline__ HR hr2_from_int(int v) { return hr2_from_float((float)v); }
+
+// compareToBothPositiveReducedTemplate<256>() < 0, HDRFloat.h:1169-1184
+__device__ __forceinline__ bool below_bailout(HR n)
+{
+    if (n.e > 1)
+        return false;
+    if (n.e < 1)
+        return true;
+    return !(n.m >= df32(256.0f));
+}
+
+template <int Mode, bool kStats> __global__ void __launch_bounds__(256) k_lav2_2x32(FsLav2Args2x32 A)
+{
+    const uint32_t X = blockIdx.x * 64u + (threadIdx.x & 63u);
+    const uint32_t L = blockIdx.y * 4u + (threadIdx.x >> 6);
+    uint64_t c_at = 0, c_la = 0, c_pt = 0, c_px = 0;
+    const uint32_t Y = global_row(A.frame, L);
+    const bool live = X < A.frame.width && L < A.frame.local_rows && Y < A.frame.height;
+    if (live) {
+        c_px = 1;
+        const uint32_t n_iterations = A.n_iterations;
+        // LAKernel.cuh:39-63
+        const HR DeltaSub0X = hr_sub(hr_mul(ldr(A.coords[0]), hr2_from_int((int)X)), ldr(A.coords[2]));
+        const HR DeltaSub0Y = hr_sub(hr_mul(hr_neg(ldr(A.coords[1])), hr2_from_int((int)Y)), ldr(A.coords[3]));
+        const HC DeltaSub0 = hc_from_hr(DeltaSub0X, DeltaSub0Y);
+        HC DeltaSubN = hc_from_hr(hr2_from_int(0), hr2_from_int(0));
+        uint32_t iter = 0, RefIteration = 0;
+
+        if (Mode != FS_MODE_PO) {
+            // :66-71 + ATInfo::isValid / PerformAT, ATInfo.h:126-188
+            if (A.la_valid && A.use_at && hr_cmp_pos(hc_cheb(DeltaSub0), ldr(A.at.ThresholdC)) <= 0) {
+                const uint32_t ATMaxIt = n_iterations / A.at.StepLength;
+                HC c = hc_add(hc_mul(DeltaSub0, ldc(A.at.CCoeff)), ldc(A.at.RefC));
+                hc_reduce(c);
+                HC z = hc_zero<df32>();
+                const HR esc = ldr(A.at.SqrEscapeRadius);
+                uint32_t i;
+                for (i = 0; i < ATMaxIt; i++) {
+                    HR nsq = hc_norm2(z);
+                    hr_reduce(nsq);
+                    if (hr_cmp_pos(nsq, esc) > 0)
+                        break;
+                    z = hc_add(hc_mul(z, z), c);
+                }
+                HC dz = hc_mul(z, ldc(A.at.InvZCoeff));
+                hc_reduce(dz);
+                DeltaSubN = dz;
+                iter = i * A.at.StepLength;
+                if (kStats)
+                    c_at = i;
+            }
+            // :73-131 (complex0's value before the stage loop is dead)
+            uint32_t CurrentLAStage = A.la_valid ? A.stage_count : 0;
+            const HR dcCheb = hc_cheb(DeltaSub0);
+            while (CurrentLAStage > 0) {
+                CurrentLAStage--;
+                const uint32_t LAIndex = A.stages[CurrentLAStage].LAIndex;
+                if (hr_cmp_pos(dcCheb, ldr(A.las[LAIndex].LAThresholdC)) >= 0) // GPU_LAReference.h:238-254
+                    continue;
+                const uint32_t MacroItCount = A.stages[CurrentLAStage].MacroItCount;
+                uint32_t j = RefIteration;
+                while (iter < n_iterations) {
+                    const fs_la_2x32_u32 *LAj = &A.las[LAIndex + j]; // getLA, GPU_LAReference.h:271-303
+                    const uint32_t l = LAj->StepLength;
+                    bool unusable = true;
+                    HC newDz = hc_zero<df32>();
+                    if (iter + l <= n_iterations) {
+                        // Prepare, GPU_LAInfoDeep.h:90-106
+                        newDz = hc_mul(DeltaSubN, hc_add(hc_mul2(ldc(LAj->Ref)), DeltaSubN));
+                        hc_reduce(newDz);
+                        unusable = hr_cmp_pos(hc_cheb(newDz), ldr(LAj->LAThreshold)) >= 0;
+                    }
+                    if (unusable) {
+                        RefIteration = LAj->NextStageLAIndex;
+                        break;
+                    }
+                    iter += l;
+                    if (kStats)
+                        c_la++;
+                    // Evaluate GPU_LAInfoDeep.h:120-124, getZ LAstep.h:181-185
+                    DeltaSubN = hc_add(hc_mul(newDz, ldc(LAj->ZCoeff)), hc_mul(DeltaSub0, ldc(LAj->CCoeff)));
+                    const HC complex0 = hc_add(ldc(LAj[1].Ref), DeltaSubN);
+                    j++;
+                    const HR lhs = hr_reduced(hc_cheb(complex0));
+                    const HR rhs = hr_reduced(hc_cheb(DeltaSubN));
+                    if (hr_cmp_pos(lhs, rhs) < 0 || j >= MacroItCount) {
+                        DeltaSubN = complex0;
+                        j = 0;
+                    }
+                }
+                if (iter >= n_iterations)
+                    break;
+            }
+        }
+
+        if (Mode != FS_MODE_LAO) {
+            // :133-235.  perturbLoop(maxRefIteration) at :254-276 reads the block's previous results, which are zero on
+            // the cleared buffer every caller passes (Fractal.cpp:2822), so only perturbLoop(n_iterations) runs.
+            const fs_orbit_2x32 *__restrict__ orb = A.orbit;
+            const uint32_t MaxRef = A.orbit_count - 1;
+            HR dX = hc_re(DeltaSubN), dY = hc_im(DeltaSubN);
+            HR zx = orbit_x(orb, RefIteration), zy = orbit_y(orb, RefIteration);
+            for (;;) {
+                const HR sumY = hr_add(hr_mul2(zy), dY); // tempSum1
+                const HR sumX = hr_add(hr_mul2(zx), dX); // tempSum2
+                ++RefIteration;
+                // custom_perturb3 (its tempSum1 parameter is bound to tempSum2 and vice versa)
+                HR nX = hr_add(hr_sub(hr_mul(dX, sumX), hr_mul(dY, sumY)), DeltaSub0X);
+                hr_reduce(nX);
+                HR nY = hr_add(hr_add(hr_mul(dX, sumY), hr_mul(dY, sumX)), DeltaSub0Y);
+                hr_reduce(nY);
+                dX = nX;
+                dY = nY;
+                if (kStats)
+                    c_pt++;
+                zx = orbit_x(orb, RefIteration);
+                zy = orbit_y(orb, RefIteration);
+                const HR tX = hr_add(zx, dX);
+                const HR tY = hr_add(zy, dY);
+                const HR normSquared = hr_reduced(hr_add(hr_square(tX), hr_square(tY)));
+                if (below_bailout(normSquared) && iter < n_iterations) {
+                    const HR DeltaNormSquared = hr_reduced(hr_add(hr_square(dX), hr_square(dY)));
+                    if (hr_cmp_pos(normSquared, DeltaNormSquared) < 0 || RefIteration >= MaxRef) {
+                        dX = tX;
+                        dY = tY;
+                        RefIteration = 0;
+                        zx = orbit_x(orb, 0);
+                        zy = orbit_y(orb, 0);
+                    }
+                    ++iter;
+                } else {
+                    break;
+                }
+            }
+        }
+        A.out[(size_t)L * A.frame.rounded_width + X] = iter;
+    }
+    if (kStats)
+        add_stats(A.stats, c_at, c_la, c_pt, c_px);
+}
+
+} // namespace
+
+void fsk_lav2_2x32(const FsLav2Args2x32 &A, int mode, bool stats, hipStream_t s)
+{
+    const dim3 b(256);
+    const dim3 g((A.frame.width + 63) / 64, (A.frame.local_rows + 3) / 4);
+#define FS_LAUNCH(M)                                                                                                    \
+    do {                                                                                                                \
+        if (stats)                                                                                                      \
+            hipLaunchKernelGGL((k_lav2_2x32<M, true>), g, b, 0, s, A);                                                  \
+        else                                                                                                            \
+            hipLaunchKernelGGL((k_lav2_2x32<M, false>), g, b, 0, s, A);                                                 \
+    } while (0)
+    if (mode == FS_MODE_PO)
+        FS_LAUNCH(FS_MODE_PO);
+    else if (mode == FS_MODE_LAO)
+        FS_LAUNCH(FS_MODE_LAO);
+    else
+        FS_LAUNCH(FS_MODE_FULL);
+#undef FS_LAUNCH
+}

@@ -56,7 +56,8 @@ struct fs_renderer {
     // orbit (HDRFloat<float>)
     uint64_t orbit_gen = 0;
     bool orbit_ok = false;
-    int orbit_type = -1; // FS_T_HDR32 or FS_T_HDR64
+    int orbit_type = -1; // FS_T_HDR32 / FS_T_HDR64 / FS_T_HDR2X32 / FS_T_F64
+    fs_orbit_2x32 *orbit_2x32 = nullptr; // HDRFloat<CudaDblflt> orbit (FS_T_HDR2X32), used as uploaded
     float4 *zref = nullptr;
     FsZ64 *zref64 = nullptr;
     fs_orbit_f64 *orbit_f64 = nullptr; // plain double orbit (FS_T_F64), used as uploaded
@@ -72,6 +73,7 @@ struct fs_renderer {
     int la_valid = 0, use_at = 0;
     fs_at_hdr32_u32 at{};
     fs_at_hdr64_u32 at64{};
+    fs_at_2x32_u32 at2x32{};
 
     // BLA table
     std::vector<void *> bla_level_mem;
@@ -149,6 +151,9 @@ void free_perturb(fs_renderer *r)
         hipFree(r->zref64);
     if (r->orbit_f64)
         hipFree(r->orbit_f64);
+    if (r->orbit_2x32)
+        hipFree(r->orbit_2x32);
+    r->orbit_2x32 = nullptr;
     r->zref = nullptr;
     r->zref64 = nullptr;
     r->orbit_f64 = nullptr;
@@ -428,12 +433,30 @@ uint32_t fs_upload_orbit(fs_renderer *r, uint64_t generation, int type_tag, uint
 {
     if (uint32_t e = use_device(r))
         return e;
-    if ((type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64 && type_tag != FS_T_F64) || iter_bytes != 4)
+    if ((type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64 && type_tag != FS_T_F64 && type_tag != FS_T_HDR2X32) ||
+        iter_bytes != 4)
         return FS_ERR_UNSUPPORTED;
     if (!r->compute)
         return FS_ERR_6;
     if (r->orbit_ok && r->orbit_gen == generation && generation != 0 && r->orbit_type == type_tag)
         return 0; // cached by generation number (GPU_Render.cu:440-487)
+    if (type_tag == FS_T_HDR2X32) {
+        if (r->orbit_2x32) {
+            FS_TRY(hipFree(r->orbit_2x32));
+            r->orbit_2x32 = nullptr;
+        }
+        r->orbit_ok = false;
+        FS_TRY(hipMalloc((void **)&r->orbit_2x32, orbit_size * sizeof(fs_orbit_2x32)));
+        FS_TRY(hipMemcpyAsync(r->orbit_2x32, entries, orbit_size * sizeof(fs_orbit_2x32), hipMemcpyDefault, r->compute));
+        FS_TRY(hipStreamSynchronize(r->compute));
+        r->orbit_size = orbit_size;
+        r->orbit_uncompressed = uncompressed_size;
+        r->orbit_period = period_maybe_zero;
+        r->orbit_gen = generation;
+        r->orbit_type = type_tag;
+        r->orbit_ok = true;
+        return 0;
+    }
     if (type_tag == FS_T_F64) {
         if (r->orbit_f64) {
             FS_TRY(hipFree(r->orbit_f64));
@@ -556,13 +579,15 @@ uint32_t fs_upload_la(fs_renderer *r, uint64_t generation, int type_tag, uint32_
 {
     if (uint32_t e = use_device(r))
         return e;
-    if ((type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64) || iter_bytes != 4)
+    if ((type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64 && type_tag != FS_T_HDR2X32) || iter_bytes != 4)
         return FS_ERR_UNSUPPORTED;
     if (!r->compute)
         return FS_ERR_6;
     if (r->la_ok && r->la_gen == generation && generation != 0 && r->la_type == type_tag)
         return 0;
-    const size_t la_bytes = type_tag == FS_T_HDR32 ? sizeof(fs_la_hdr32_u32) : sizeof(fs_la_hdr64_u32);
+    const size_t la_bytes = type_tag == FS_T_HDR32
+                                ? sizeof(fs_la_hdr32_u32)
+                                : (type_tag == FS_T_HDR64 ? sizeof(fs_la_hdr64_u32) : sizeof(fs_la_2x32_u32));
     if (r->las) {
         FS_TRY(hipFree(r->las));
         r->las = nullptr;
@@ -588,8 +613,11 @@ uint32_t fs_upload_la(fs_renderer *r, uint64_t generation, int type_tag, uint32_
     r->use_at = use_at;
     memset(&r->at, 0, sizeof(r->at));
     memset(&r->at64, 0, sizeof(r->at64));
+    memset(&r->at2x32, 0, sizeof(r->at2x32));
     if (at_info && type_tag == FS_T_HDR32)
         memcpy(&r->at, at_info, sizeof(r->at));
+    else if (at_info && type_tag == FS_T_HDR2X32)
+        memcpy(&r->at2x32, at_info, sizeof(r->at2x32));
     else if (at_info)
         memcpy(&r->at64, at_info, sizeof(r->at64));
     else
@@ -650,10 +678,35 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
         return e;
     if (!r->memory_initialized())
         return 0; // GPU_Render.cu:1007-1009
-    if ((type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64) || n_iterations > 0xFFFFFFFFull)
+    if ((type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64 && type_tag != FS_T_HDR2X32) || n_iterations > 0xFFFFFFFFull)
         return FS_ERR_UNSUPPORTED;
     if (!r->orbit_ok || r->orbit_type != type_tag)
         return FS_ERR_6; // GPU_Render.cu:1015-1022
+    if (type_tag == FS_T_HDR2X32) {
+        // No CPU RenderAlgorithm exists for this type: the kernel restates the reference's CUDA kernel and ignores
+        // `parity` (coords are fs_real_2x32[4]).
+        if (mode != FS_LAV2_PO && (!r->la_ok || r->la_type != type_tag))
+            return FS_ERR_6;
+        FsLav2Args2x32 A;
+        memset(&A, 0, sizeof(A));
+        A.out = (uint32_t *)r->iters();
+        A.orbit = r->orbit_2x32;
+        A.las = (const fs_la_2x32_u32 *)r->las;
+        A.stages = r->stages;
+        A.stats = r->stats;
+        A.frame = make_frame(r);
+        memcpy(A.coords, coords, sizeof(A.coords));
+        A.at = r->at2x32;
+        A.orbit_count = (uint32_t)r->orbit_uncompressed;
+        A.stage_count = r->n_stages;
+        A.n_iterations = (uint32_t)n_iterations;
+        A.la_valid = (r->la_ok && r->la_type == type_tag) ? r->la_valid : 0;
+        A.use_at = r->use_at;
+        TimedLaunch t(r);
+        fsk_lav2_2x32(A, mode == FS_LAV2_FULL ? FS_MODE_FULL : (mode == FS_LAV2_PO ? FS_MODE_PO : FS_MODE_LAO),
+                      r->stats_on, r->compute);
+        return (uint32_t)hipGetLastError();
+    }
     if (mode == FS_LAV2_PO && parity == FS_PARITY_CPU) {
         // No dispatched CPU RenderAlgorithm is perturbation-only in HDRFloatComplex arithmetic; the CPU parity
         // target for PO is the single-step branch of CalcCpuPerturbationFractalBLA.

@@ -586,6 +586,111 @@ extern "C" void fsh_view_coords_perturb_hdr64(const fsh_view *v, const fsh_orbit
         out[i] = fs_real_hdr64{t[i].m, t[i].e, 0};
 }
 
+// ------------------------------------------------------------------ 2x32 (HDRFloat<CudaDblflt<MattDblflt>>) inputs
+// The reference never computes 2x32 inputs directly: RefOrbitCalc builds the HDRFloat<double> orbit and LA table
+// (ConditionalT, HDRFloat.h:1734-1760; Fractal.cpp:2771-2806) and PerturbationResults::CopyPerturbationResults /
+// LAReference::CopyLAReference convert them field by field (PerturbationResults.cpp:239-347, RefOrbitCalc.cpp:2490-2513,
+// LAReference.h:163-213, LAInfoDeep.h:94-107, ATInfo.h:18-30).  Each mantissa goes through MattDblflt(double)
+// (dblflt.h:37-52): split into (float)d and the float remainder, then one two-sum; exponents are carried over.
+namespace {
+
+inline void df_from_double(double other, float &head, float &tail)
+{
+    const float a = (float)other;
+    const float b = (float)(other - (double)a);
+    head = a + b;
+    float t1 = head - a;
+    float t2 = head - t1;
+    t1 = b - t1;
+    t2 = a - t2;
+    tail = t1 + t2;
+}
+inline fs_real_2x32 real_2x32(const fs_real_hdr64 &r)
+{
+    fs_real_2x32 o;
+    df_from_double(r.m, o.head, o.tail);
+    o.e = r.e;
+    return o;
+}
+inline fs_cplx_2x32 cplx_2x32(const fs_cplx_hdr64 &c)
+{
+    fs_cplx_2x32 o;
+    df_from_double(c.re, o.re_head, o.re_tail);
+    df_from_double(c.im, o.im_head, o.im_tail);
+    o.e = c.e;
+    return o;
+}
+
+} // namespace
+
+extern "C" void fsh_convert_orbit_hdr64_to_2x32(const fs_orbit_hdr64 *in, uint64_t n, fs_orbit_2x32 *out)
+{
+    for (uint64_t i = 0; i < n; i++) {
+        fs_orbit_2x32 o;
+        df_from_double(in[i].mx, o.x_head, o.x_tail);
+        o.ex = in[i].ex;
+        df_from_double(in[i].my, o.y_head, o.y_tail);
+        o.ey = in[i].ey;
+        out[i] = o;
+    }
+}
+
+extern "C" void fsh_convert_la_hdr64_to_2x32(const fs_la_hdr64_u32 *in, uint64_t n, fs_la_2x32_u32 *out)
+{
+    for (uint64_t i = 0; i < n; i++) {
+        fs_la_2x32_u32 o;
+        o.Ref = cplx_2x32(in[i].Ref);
+        o.ZCoeff = cplx_2x32(in[i].ZCoeff);
+        o.CCoeff = cplx_2x32(in[i].CCoeff);
+        o.LAThreshold = real_2x32(in[i].LAThreshold);
+        o.LAThresholdC = real_2x32(in[i].LAThresholdC);
+        o.MinMag = real_2x32(in[i].MinMag);
+        o.StepLength = in[i].StepLength;
+        o.NextStageLAIndex = in[i].NextStageLAIndex;
+        out[i] = o;
+    }
+}
+
+extern "C" void fsh_convert_at_hdr64_to_2x32(const fs_at_hdr64_u32 *in, fs_at_2x32_u32 *out)
+{
+    out->StepLength = in->StepLength;
+    out->ThresholdC = real_2x32(in->ThresholdC);
+    out->SqrEscapeRadius = real_2x32(in->SqrEscapeRadius);
+    out->RefC = cplx_2x32(in->RefC);
+    out->ZCoeff = cplx_2x32(in->ZCoeff);
+    out->CCoeff = cplx_2x32(in->CCoeff);
+    out->InvZCoeff = cplx_2x32(in->InvZCoeff);
+    out->CCoeffSqrInvZCoeff = cplx_2x32(in->CCoeffSqrInvZCoeff);
+    out->CCoeffInvZCoeff = cplx_2x32(in->CCoeffInvZCoeff);
+    out->CCoeffNormSqr = real_2x32(in->CCoeffNormSqr);
+    out->RefCNormSqr = real_2x32(in->RefCNormSqr);
+    out->factor = real_2x32(in->factor);
+}
+
+// FillGpuCoords / FillCoord(HighPrecision, HDRFloat<CudaDblflt<MattDblflt>>&), Fractal.cpp:1826-1844,2834-2840:
+// HDRFloat(const mpf_t) (HDRFloat.h:366-391) -- mantissa from mpf_get_d_2exp in [0.5,1), head = (float)m,
+// tail = (float)(m - head), *not* reduced and not re-normalised.
+extern "C" void fsh_view_coords_perturb_2x32(const fsh_view *v, const fsh_orbit *o, uint32_t w_aa, uint32_t h_aa,
+                                             fs_real_2x32 out[4])
+{
+    mpf_set_default_prec(v->prec_bits);
+    const Mp dx = (v->maxX - v->minX) / Mp::from_ui(w_aa);
+    const Mp dy = (v->maxY - v->minY) / Mp::from_ui(h_aa);
+    const Mp cX = (o->is64 ? o->d.cx : o->f.cx) - v->minX;
+    const Mp cY = (o->is64 ? o->d.cy : o->f.cy) - v->maxY;
+    const Mp *src[4] = {&dx, &dy, &cX, &cY};
+    for (int i = 0; i < 4; i++) {
+        if (mpf_cmp_ui(src[i]->v, 0) == 0) {
+            out[i] = fs_real_2x32{0.0f, 0.0f, fs::kMinBigExp};
+            continue;
+        }
+        long e;
+        const double m = mpf_get_d_2exp(&e, src[i]->v);
+        const float head = (float)m;
+        out[i] = fs_real_2x32{head, (float)(m - (double)head), (int32_t)e};
+    }
+}
+
 // ------------------------------------------------------------------ LAv2 table
 namespace {
 
@@ -1027,6 +1132,9 @@ template <class F> struct LABuilder {
     }
 
     // CreateATFromLA, LAReference.cpp:1050-1074
+    // UseSmallExponents = UsingDblflt (RefOrbitCalc.cpp:2346): true when the HDRFloat<double> table is built to be
+    // converted to 2x32, so that the AT escape radius fits a binary32 mantissa (lim = 2^32 instead of 2^256).
+    bool useSmallExponents = false;
     void create_at(hreal<F> radius, bool useSmallExponents)
     {
         const hreal<F> SqrRadius = hr_reduced(hr_square(radius));
@@ -1067,7 +1175,7 @@ template <class F> struct LABuilder {
             return;
         while (create_new_stage(maxRef)) {
         }
-        create_at(ob.maxRadius, false);
+        create_at(ob.maxRadius, useSmallExponents);
         T.isValid = true;
     }
 
@@ -1329,13 +1437,16 @@ template <class F> void pack_la(const LATable<F> &t, std::vector<fs_la_hdr32_u32
 }
 } // namespace
 
-extern "C" fsh_la *fsh_la_create(const fsh_orbit *o, int host_threads)
+extern "C" fsh_la *fsh_la_create_ex(const fsh_orbit *o, int host_threads, int use_small_exponents);
+extern "C" fsh_la *fsh_la_create(const fsh_orbit *o, int host_threads) { return fsh_la_create_ex(o, host_threads, 0); }
+extern "C" fsh_la *fsh_la_create_ex(const fsh_orbit *o, int host_threads, int use_small_exponents)
 {
     auto la = std::make_unique<fsh_la>();
     la->is64 = o->is64;
     const int th = host_threads < 1 ? 1 : host_threads;
     if (o->is64) {
         LABuilder<double> b(o->d, la->t64);
+        b.useSmallExponents = use_small_exponents != 0;
         b.generate(th);
         pack_la<double>(la->t64, nullptr, &la->packed64);
         auto &t = la->t64;

@@ -30,7 +30,11 @@ ORBIT_HDR64_DTYPE = np.dtype([("mx", "<f8"), ("ex", "<i4"), ("pad0", "<i4"), ("e
                               ("my", "<f8")])
 REAL_HDR32 = np.dtype([("m", "<f4"), ("e", "<i4")])
 REAL_HDR64 = np.dtype([("m", "<f8"), ("e", "<i4"), ("pad_", "<i4")])
+REAL_2X32 = np.dtype([("head", "<f4"), ("tail", "<f4"), ("e", "<i4")])
+ORBIT_2X32_DTYPE = np.dtype([("x_head", "<f4"), ("x_tail", "<f4"), ("ex", "<i4"), ("ey", "<i4"),
+                             ("y_head", "<f4"), ("y_tail", "<f4")])
 assert ORBIT_HDR64_DTYPE.itemsize == 32 and REAL_HDR64.itemsize == 16
+assert REAL_2X32.itemsize == 12 and ORBIT_2X32_DTYPE.itemsize == 24
 assert ORBIT_HDR32_DTYPE.itemsize == 16 and LA_HDR32_DTYPE.itemsize == 68 and BLA_HDR32_DTYPE.itemsize == 44
 
 
@@ -103,6 +107,14 @@ class View:
         self._lib.fsh_view_coords_perturb_hdr64(self._h, orbit._h, self.width * aa, self.height * aa, out.ctypes.data)
         return out
 
+    def coords_perturb_2x32(self, orbit, aa=None):
+        """{dx, dy, centerX, centerY} as HDRFloat<CudaDblflt> records (head, tail, exp), mantissas in [0.5,1)."""
+        aa = self.antialiasing if aa is None else aa
+        out = np.zeros(4, REAL_2X32)
+        o = orbit.source if isinstance(orbit, Orbit2x32) else orbit
+        self._lib.fsh_view_coords_perturb_2x32(self._h, o._h, self.width * aa, self.height * aa, out.ctypes.data)
+        return out
+
     def coords_direct_hdr(self, is64, aa=None):
         """{dx, dy, minX, maxY} as un-reduced HDRFloat records (CpuHDR32 / CpuHDR64)."""
         aa = self.antialiasing if aa is None else aa
@@ -159,14 +171,76 @@ class Orbit:
         return np.frombuffer(buf, dtype=dt).copy()
 
 
+class Orbit2x32:
+    """The HDRFloat<CudaDblflt> twin of an HDRFloat<double> orbit, converted entry by entry the way
+    PerturbationResults::CopyPerturbationResults does (PerturbationResults.cpp:239-347)."""
+
+    is64 = False
+    compressed = False
+
+    def __init__(self, orbit64):
+        if not orbit64.is64:
+            raise ValueError("the 2x32 orbit is derived from the HDRFloat<double> orbit")
+        lib = _capi.inputs_lib()
+        self.source = orbit64
+        self.view = orbit64.view
+        self.count, self.period = orbit64.count, orbit64.period
+        self._data = np.zeros(self.count, ORBIT_2X32_DTYPE)
+        lib.fsh_convert_orbit_hdr64_to_2x32(orbit64.data_ptr, self.count, self._data.ctypes.data)
+
+    @property
+    def data_ptr(self):
+        return self._data.ctypes.data
+
+    def entries(self):
+        return self._data.copy()
+
+
+class LATable2x32:
+    """The HDRFloat<CudaDblflt> twin of an HDRFloat<double> LAv2 table (LAReference::CopyLAReference,
+    LAReference.h:163-213): 104-byte records, the stages unchanged, ATInfo converted field by field."""
+
+    def __init__(self, la64):
+        if not la64.is64:
+            raise ValueError("the 2x32 LA table is derived from the HDRFloat<double> table")
+        if not la64.use_small_exponents:
+            raise ValueError("build the source table with use_small_exponents=True (RefOrbitCalc.cpp:2346)")
+        lib = _capi.inputs_lib()
+        self.source = la64
+        self.count, self.stage_count = la64.count, la64.stage_count
+        self.is_valid, self.use_at = la64.is_valid, la64.use_at
+        self._las = np.zeros((max(self.count, 1), 104), np.uint8)
+        lib.fsh_convert_la_hdr64_to_2x32(la64.las_ptr, self.count, self._las.ctypes.data)
+        self._stages = la64.stages()
+        self.at = _capi.At2x32()
+        lib.fsh_convert_at_hdr64_to_2x32(C.addressof(la64.at), C.addressof(self.at))
+
+    @property
+    def las_ptr(self):
+        return self._las.ctypes.data
+
+    @property
+    def stages_ptr(self):
+        return self._stages.ctypes.data
+
+    def records(self):
+        return self._las[: self.count].copy()
+
+    def stages(self):
+        return self._stages.copy()
+
+
 class LATable:
     """LAv2 table (LAReference<uint32_t, HDRFloat<float>, float, Disable>)."""
 
-    def __init__(self, orbit, host_threads=8):
+    def __init__(self, orbit, host_threads=8, use_small_exponents=False):
+        """use_small_exponents: the reference's UsingDblflt flag -- set it for a table that will be converted to
+        2x32 (LATable2x32); it caps the AT escape radius at 2^32 (LAInfoDeep.h:484-496)."""
         self._lib = _capi.inputs_lib()
         self.orbit = orbit
         self.is64 = orbit.is64
-        self._h = self._lib.fsh_la_create(orbit._h, host_threads)
+        self.use_small_exponents = bool(use_small_exponents)
+        self._h = self._lib.fsh_la_create_ex(orbit._h, host_threads, 1 if use_small_exponents else 0)
         if not self._h:
             raise RuntimeError("fsh_la_create failed")
         self.count = self._lib.fsh_la_count(self._h)

@@ -94,7 +94,10 @@ class GPURenderer:
         """Perturb1: inputs.Orbit (or anything with data_ptr/count/period); LaReferenceHost: inputs.LATable.
         T defaults to the orbit's type (T_HDR32 / T_HDR64)."""
         if T is None:
-            T = T_HDR64 if getattr(Perturb1, "is64", False) else T_HDR32
+            if type(Perturb1).__name__ == "Orbit2x32":
+                T = T_HDR2X32
+            else:
+                T = T_HDR64 if getattr(Perturb1, "is64", False) else T_HDR32
         if getattr(Perturb1, "compressed", False):
             # PerturbExtras::SimpleCompression: hand over the waypoints, like the reference's *RC* algorithms
             low = Perturb1.orbit_low()
@@ -120,6 +123,9 @@ class GPURenderer:
         if T == T_HDR64:
             dt = np.dtype([("m", "<f8"), ("e", "<i4"), ("pad_", "<i4")])
             return np.array([(float(m), int(e), 0) for m, e in vals], dtype=dt)
+        if T == T_HDR2X32:  # (head, tail, exp) triples
+            dt = np.dtype([("head", "<f4"), ("tail", "<f4"), ("e", "<i4")])
+            return np.array([(float(h), float(t), int(e)) for h, t, e in vals], dtype=dt)
         dt = np.dtype([("m", "<f4"), ("e", "<i4")])
         return np.array([(float(m), int(e)) for m, e in vals], dtype=dt)
 

@@ -65,10 +65,23 @@ void fsh_view_coords_perturb_hdr32(const fsh_view *v, const fsh_orbit *o, uint32
 void fsh_view_coords_perturb_hdr64(const fsh_view *v, const fsh_orbit *o, uint32_t w_aa, uint32_t h_aa,
                                    fs_real_hdr64 out[4]);
 
+/* 2x32 (HDRFloat<CudaDblflt<MattDblflt>>) inputs.  FractalShark derives them from the HDRFloat<double> orbit / LA
+ * table by field-wise conversion (PerturbationResults::CopyPerturbationResults, LAReference::CopyLAReference);
+ * these restate that conversion.  Coordinates come straight from the high-precision view (orbit must be hdr64). */
+void fsh_convert_orbit_hdr64_to_2x32(const fs_orbit_hdr64 *in, uint64_t n, fs_orbit_2x32 *out);
+void fsh_convert_la_hdr64_to_2x32(const fs_la_hdr64_u32 *in, uint64_t n, fs_la_2x32_u32 *out);
+void fsh_convert_at_hdr64_to_2x32(const fs_at_hdr64_u32 *in, fs_at_2x32_u32 *out);
+/* out = {dx, dy, centerX, centerY}; mantissas in [0.5,1), not reduced (FillCoord, Fractal.cpp:1826-1832). */
+void fsh_view_coords_perturb_2x32(const fsh_view *v, const fsh_orbit *o, uint32_t w_aa, uint32_t h_aa,
+                                  fs_real_2x32 out[4]);
+
 /* LAv2 table (LAReference::GenerateApproximationData).  host_threads = std::thread::hardware_concurrency()
  * of the machine being mirrored: the reference's multi-threaded stage-0 scan splits the orbit into
  * min(count/50000, host_threads) chunks and the chunking can move record boundaries. */
 fsh_la *fsh_la_create(const fsh_orbit *o, int host_threads);       /* type follows the orbit (hdr32 / hdr64) */
+/* use_small_exponents = the reference's UsingDblflt flag (RefOrbitCalc.cpp:2346): set it when the hdr64 table is
+ * built to be converted to 2x32; it caps the AT escape radius at 2^32 instead of 2^256 (LAInfoDeep.h:484-496). */
+fsh_la *fsh_la_create_ex(const fsh_orbit *o, int host_threads, int use_small_exponents);
 fsh_la *fsh_la_create_hdr32(const fsh_orbit *o, int host_threads); /* NULL for an hdr64 orbit */
 void fsh_la_destroy(fsh_la *l);
 int fsh_la_is64(const fsh_la *l);

@@ -13,6 +13,7 @@
  *   fs_la_stage_u32     = LAStageInfo<uint32_t>  (HpSharkFloatLib/LAInfoI.h:5-16; 8 B)
  *   fs_at_hdr32_u32     = ATInfo<uint32_t, HDRFloat<float>, float> (HpSharkFloatLib/ATInfo.h:84-99; 116 B)
  *   fs_bla_hdr32        = BLA<HDRFloat<float>>   (FractalSharkLib/BLA.h:9-16; 44 B)
+ *   fs_orbit_2x32 / fs_la_2x32_u32 / fs_at_2x32_u32 = the HDRFloat<CudaDblflt<MattDblflt>> twins (24 / 104 / 184 B)
  *   fs_color16, fs_reduction = Color16 / ReductionResults (FractalSharkLib/GPU_Types.h:14-16,40-50)
  */
 #ifndef FS_LAYOUT_H
@@ -180,6 +181,61 @@ typedef struct fs_bla_f64 {
     int32_t pad_;
 } fs_bla_f64;
 
+/* ---- 2x32 ("float-float + exponent") records: HDRFloat<CudaDblflt<MattDblflt>> family.
+ * MattDblflt is {head, tail} under #pragma pack(4) (HpSharkFloatLib/dblflt.h:5-62), CudaDblflt wraps it
+ * (CudaDblflt.h:24-28), so HDRFloat<CudaDblflt> is 12 B {head, tail, exp}, HDROrder::Right is {exp, head, tail},
+ * HDRFloatComplex<CudaDblflt> is 20 B and the orbit entry GPUReferenceIter<HDRFloat<CudaDblflt>,Disable> 24 B. */
+typedef struct fs_real_2x32 {
+    float head;
+    float tail;
+    int32_t e;
+} fs_real_2x32;
+
+typedef struct fs_cplx_2x32 {
+    float re_head;
+    float re_tail;
+    float im_head;
+    float im_tail;
+    int32_t e;
+} fs_cplx_2x32;
+
+typedef struct fs_orbit_2x32 {
+    float x_head;
+    float x_tail;
+    int32_t ex;
+    int32_t ey;
+    float y_head;
+    float y_tail;
+} fs_orbit_2x32;
+
+/* LAInfoDeep<uint32_t, HDRFloat<CudaDblflt<MattDblflt>>, CudaDblflt<MattDblflt>, Disable>: 104 B. */
+typedef struct fs_la_2x32_u32 {
+    fs_cplx_2x32 Ref;
+    fs_cplx_2x32 ZCoeff;
+    fs_cplx_2x32 CCoeff;
+    fs_real_2x32 LAThreshold;
+    fs_real_2x32 LAThresholdC;
+    fs_real_2x32 MinMag;
+    uint32_t StepLength;
+    uint32_t NextStageLAIndex;
+} fs_la_2x32_u32;
+
+/* ATInfo<uint32_t, HDRFloat<CudaDblflt<MattDblflt>>, CudaDblflt<MattDblflt>>: 184 B. */
+typedef struct fs_at_2x32_u32 {
+    uint32_t StepLength;
+    fs_real_2x32 ThresholdC;
+    fs_real_2x32 SqrEscapeRadius;
+    fs_cplx_2x32 RefC;
+    fs_cplx_2x32 ZCoeff;
+    fs_cplx_2x32 CCoeff;
+    fs_cplx_2x32 InvZCoeff;
+    fs_cplx_2x32 CCoeffSqrInvZCoeff;
+    fs_cplx_2x32 CCoeffInvZCoeff;
+    fs_real_2x32 CCoeffNormSqr;
+    fs_real_2x32 RefCNormSqr;
+    fs_real_2x32 factor;
+} fs_at_2x32_u32;
+
 typedef struct fs_color16 {
     uint16_t r, g, b, a;
 } fs_color16;
@@ -202,6 +258,8 @@ static_assert(sizeof(fs_real_hdr64) == 16 && sizeof(fs_cplx_hdr64) == 24, "doubl
 static_assert(sizeof(fs_la_hdr64_u32) == 128, "LA record (double)");
 static_assert(sizeof(fs_at_hdr64_u32) == 232, "AT record (double)");
 static_assert(sizeof(fs_bla_hdr64) == 88, "BLA record (double)");
+static_assert(sizeof(fs_real_2x32) == 12 && sizeof(fs_cplx_2x32) == 20 && sizeof(fs_orbit_2x32) == 24, "2x32 records");
+static_assert(sizeof(fs_la_2x32_u32) == 104 && sizeof(fs_at_2x32_u32) == 184, "2x32 LA / AT records");
 static_assert(sizeof(fs_bla_f64) == 48 && sizeof(fs_orbit_f64) == 16, "plain double records");
 #endif
 

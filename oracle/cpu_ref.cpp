@@ -700,6 +700,7 @@ void lav2_impl(uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, const 
 extern "C" {
 
 void orc_set_row_step(uint32_t step) { g_row_step = step ? step : 1; }
+uint32_t orc_get_row_step(void) { return g_row_step; } // shared with gpu_ref_2x32.cpp
 
 // Fractal::CalcCpuHDR<uint32_t,double,double>, Fractal.cpp:2096-2206.  coords = {dx, dy, minX, maxY}.
 void orc_direct_f64(uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, const double coords[4],

@@ -19,8 +19,8 @@ _pin = None
 
 
 def build():
-    src = os.path.join(ORACLE_DIR, "cpu_ref.cpp")
-    if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("cpu_ref.cpp", "gpu_ref_2x32.cpp")]
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(s) for s in srcs):
         subprocess.run(["make", "-C", ORACLE_DIR, "all"], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     # the golden-CRC pin needs the reference's WPngImage/lodepng sources: only buildable where /root/reference is
     if not os.path.exists(PIN) and os.path.isdir("/root/reference/FractalSharkLib/WPngImage"):
@@ -47,6 +47,14 @@ def lib():
         l.orc_direct_hdr64.argtypes = l.orc_direct_hdr32.argtypes
         l.orc_bla_f64.restype = None
         l.orc_bla_f64.argtypes = [u32, u32, u32, u32, vp, u64, vp, u32, vp, vp, i32, i32, vp, u32, C.c_int]
+        l.orc_gpu_lav2_2x32.restype = None
+        l.orc_gpu_lav2_2x32.argtypes = [vp, u32, u32, u32, u32, vp, u32, vp, vp, u32, C.c_int, C.c_int, vp, vp, u32,
+                                        C.c_int, C.c_int, vp]
+        for name in ("orc_df_add", "orc_df_sub", "orc_df_mul"):
+            getattr(l, name).restype = None
+            getattr(l, name).argtypes = [vp, vp, vp]
+        l.orc_h2_reduce.restype = None
+        l.orc_h2_reduce.argtypes = [vp]
         l.orc_set_row_step.restype = None
         l.orc_set_row_step.argtypes = [u32]
         _lib = l
@@ -142,6 +150,27 @@ def lav2_hdr32(view, orbit, la, aa=1, rows=None, threads=8, stage_test=0, mode=0
                          threads, st)
     if stats:
         return out, {"at_iterations": st[0], "la_steps": st[1], "perturb_steps": st[2], "pixels": st[3]}
+    return out
+
+
+def gpu_lav2_2x32(view, orbit2, la2, aa=1, rows=None, threads=8, mode=0, n_iterations=None, stats=False):
+    """Restated CUDA kernel mandel_1xHDR_float_perturb_lav2<.., HDRFloat<CudaDblflt>, ..> (oracle/gpu_ref_2x32.cpp).
+    orbit2: inputs.Orbit2x32; la2: inputs.LATable2x32 or None (mode 1 = perturbation only)."""
+    w, h = view.width * aa, view.height * aa
+    out = new_buffer(w, h)
+    co = view.coords_perturb_2x32(orbit2, aa)
+    y0, y1 = rows if rows else (0, h)
+    n = view.num_iterations if n_iterations is None else n_iterations
+    st = (u64 * 3)()
+    if la2 is not None:
+        lib().orc_gpu_lav2_2x32(out.ctypes.data, out.shape[1], w, y0, y1, orbit2.data_ptr, orbit2.count, la2.las_ptr,
+                                la2.stages_ptr, la2.stage_count, 1 if la2.is_valid else 0, 1 if la2.use_at else 0,
+                                C.addressof(la2.at), co.ctypes.data, n, mode, threads, st)
+    else:
+        lib().orc_gpu_lav2_2x32(out.ctypes.data, out.shape[1], w, y0, y1, orbit2.data_ptr, orbit2.count, None, None, 0,
+                                0, 0, None, co.ctypes.data, n, mode, threads, st)
+    if stats:
+        return out, {"at_iterations": st[0], "la_steps": st[1], "perturb_steps": st[2]}
     return out
 
 

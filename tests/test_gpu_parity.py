@@ -358,3 +358,63 @@ def test_plain_double_bla_parity(renderer, native_libs):
         assert r.RenderCurrent(v.num_iterations, out) == 0
         assert r.SyncComputeStream() == 0
         assert np.array_equal(out, _oracle.bla_f64(v, ob, use_bla=use_bla))
+
+
+# ---- HDRFloat<CudaDblflt> ("2x32 + exponent", GpuHDRx2x32PerturbedLAv2*): no CPU twin in the reference; the checker
+# restates the CUDA kernel (oracle/gpu_ref_2x32.cpp, parity unpinned -- see its header and tests/test_2x32_oracle.py)
+def _render_2x32(r, v, o2, la2, mode, n_iter=None, bands=None):
+    from fractalshark_amd import T_HDR2X32
+    w, h = v.width * v.antialiasing, v.height * v.antialiasing
+    assert r.InitializeMemory(w, h, v.antialiasing, None, 0, 0, 0, False) == 0
+    if bands:
+        assert r.SetRowBands(*bands) == 0
+    assert r.InitializePerturb(0, o2, 0, None, la2) == 0
+    assert r.ClearMemory() == 0
+    co = v.coords_perturb_2x32(o2)
+    tr = [(float(c["head"]), float(c["tail"]), int(c["e"])) for c in co]
+    n = v.num_iterations if n_iter is None else n_iter
+    assert r.RenderPerturbLAv2(None, None, None, tr[0], tr[1], tr[2], tr[3], n, T=T_HDR2X32, Mode=mode) == 0
+    assert r.SyncComputeStream() == 0
+    out = r.new_iter_buffer()
+    red = _capi.Reduction()
+    assert r.RenderCurrent(n, out, None, red) == 0
+    assert r.SyncComputeStream() == 0
+    return out, red
+
+
+@pytest.fixture(scope="module")
+def v5_2x32(native_libs):
+    v = inputs.View.builtin(5, 64, 36)
+    o = inputs.Orbit(v, is64=True)
+    la = inputs.LATable(o, use_small_exponents=True)
+    return v, inputs.Orbit2x32(o), inputs.LATable2x32(la)
+
+
+@pytest.mark.parametrize("mode,omode", [(LAV2_FULL, 0), (LAV2_LAO, 2)])
+def test_2x32_lav2_matches_restated_cuda_kernel(renderer, v5_2x32, mode, omode):
+    v, o2, la2 = v5_2x32
+    out, red = _render_2x32(renderer, v, o2, la2, mode)
+    ref = _oracle.gpu_lav2_2x32(v, o2, la2, mode=omode)
+    assert np.array_equal(out, ref)
+    assert red.Sum == int(ref[:36, :64].astype(np.uint64).sum())
+
+
+def test_2x32_perturbation_only_rows(renderer, v5_2x32):
+    v, o2, la2 = v5_2x32
+    # rows 8..11 only: perturbation-only runs ~8e4 double-float steps per pixel
+    out, _ = _render_2x32(renderer, v, o2, None, LAV2_PO, bands=(8, 4, 36))
+    ref = _oracle.gpu_lav2_2x32(v, o2, None, mode=1, rows=(8, 12))
+    assert np.array_equal(out[:4, :64], ref[8:12, :64])
+    assert renderer.SetRowBands(0, 0, 0) == 0
+
+
+def test_2x32_view14_deep_zoom_rows(renderer, native_libs):
+    """BASELINE config C4's view (2^-21645) at a small size: 116 695-entry orbit, AT-dominated."""
+    v = inputs.View.builtin(14, 64, 36, antialiasing=1)
+    o = inputs.Orbit(v, is64=True)
+    la = inputs.LATable(o, use_small_exponents=True)
+    o2, la2 = inputs.Orbit2x32(o), inputs.LATable2x32(la)
+    out, _ = _render_2x32(renderer, v, o2, la2, LAV2_FULL)
+    ref = _oracle.gpu_lav2_2x32(v, o2, la2, mode=0)
+    assert np.array_equal(out, ref)
+    assert len(np.unique(out[:36, :64])) > 16
