@@ -38,7 +38,7 @@ namespace fsmi355_shim {
 
 inline fs_renderer *&handle(cudaStream_t &slot) { return reinterpret_cast<fs_renderer *&>(slot); }
 
-// Map the reference's numeric type T to a C-ABI tag.  Only HDRFloat<float> and double are built in round 1.
+// Map the reference's numeric type T to a C-ABI tag (types this library implements; -1 = FS_ERR_UNSUPPORTED).
 template <class T> struct type_tag {
     static constexpr int value = -1;
 };
@@ -50,6 +50,9 @@ template <> struct type_tag<::HDRFloat<float>> {
 };
 template <> struct type_tag<::HDRFloat<double>> {
     static constexpr int value = FS_T_HDR64;
+};
+template <> struct type_tag<::HDRFloat<::CudaDblflt<::MattDblflt>>> {
+    static constexpr int value = FS_T_HDR2X32;
 };
 
 // HDRFloat<float> has the layout {float mantissa; int32 exp} = fs_real_hdr32 (HDRFloat.h:61-69);
@@ -69,7 +72,19 @@ inline fs_real_hdr64 to_abi(const ::HDRFloat<double> &v)
     r.pad_ = 0;
     return r;
 }
+// HDRFloat<CudaDblflt<MattDblflt>> = {head, tail, exp} = fs_real_2x32 (CudaDblflt.h:24-28, dblflt.h:5-62).
+inline fs_real_2x32 to_abi(const ::HDRFloat<::CudaDblflt<::MattDblflt>> &v)
+{
+    fs_real_2x32 r;
+    r.head = v.getMantissa().head();
+    r.tail = v.getMantissa().tail();
+    r.e = v.getExp();
+    return r;
+}
 template <class T> struct abi_real;
+template <> struct abi_real<::HDRFloat<::CudaDblflt<::MattDblflt>>> {
+    using type = fs_real_2x32;
+};
 template <> struct abi_real<::HDRFloat<float>> {
     using type = fs_real_hdr32;
 };
@@ -135,26 +150,42 @@ uint32_t GPURenderer::InitializePerturb(size_t GenerationNumber1, const GPUPertu
                                         const LAReference<IterType, T1, SubType, PExtras> *LaReferenceHost)
 {
     (void)GenerationNumber2;
-    (void)Perturb2; // second orbit: scaled kernels only (later round)
+    (void)Perturb2; // second orbit: scaled kernels only (not built)
     if (!m_ComputeStream)
         return 0;
     constexpr int tag = fsmi355_shim::type_tag<T1>::value;
-    if (tag < 0 || PExtras != PerturbExtras::Disable)
+    if constexpr (tag < 0 || (PExtras != PerturbExtras::Disable && PExtras != PerturbExtras::SimpleCompression)) {
         return FS_ERR_UNSUPPORTED;
+    } else {
     fs_renderer *r = fsmi355_shim::handle(m_ComputeStream);
-    uint32_t err = fs_upload_orbit(r, GenerationNumber1, tag, (uint32_t)sizeof(IterType), Perturb1->GetFullOrbit(),
-                                   Perturb1->GetCompressedSize(), Perturb1->GetUncompressedSize(),
-                                   Perturb1->GetPeriodMaybeZero());
+    uint32_t err;
+    if constexpr (PExtras == PerturbExtras::SimpleCompression) {
+        // the waypoints + the constant c of the runtime decompressor (Perturb.cuh:300-326)
+        const auto xlow = fsmi355_shim::to_abi(Perturb1->GetOrbitXLow());
+        const auto ylow = fsmi355_shim::to_abi(Perturb1->GetOrbitYLow());
+        err = fs_upload_orbit_compressed(r, GenerationNumber1, tag, (uint32_t)sizeof(IterType), Perturb1->GetFullOrbit(),
+                                         Perturb1->GetCompressedSize(), Perturb1->GetUncompressedSize(),
+                                         Perturb1->GetPeriodMaybeZero(), &xlow, &ylow);
+    } else {
+        err = fs_upload_orbit(r, GenerationNumber1, tag, (uint32_t)sizeof(IterType), Perturb1->GetFullOrbit(),
+                              Perturb1->GetCompressedSize(), Perturb1->GetUncompressedSize(),
+                              Perturb1->GetPeriodMaybeZero());
+    }
     if (err || !LaReferenceHost)
         return err;
-    // LAReference keeps LAInfoDeep / LAStageInfo in GrowableVectors whose element layout is fs_la_hdr32_u32 /
-    // fs_la_stage_u32 (static-asserted in the reference at GPU_LAReference.h:118-133).
+    // LAReference keeps LAInfoDeep / LAStageInfo in GrowableVectors whose element layouts are the fs_la_* /
+    // fs_la_stage_* records of fs_layout.h (the reference static-asserts host == device layout at
+    // GPU_LAReference.h:118-133); sizeof(IterType) selects the _u32 or _u64 family.
     const auto &at = LaReferenceHost->GetAT();
-    static_assert(sizeof(at) == sizeof(fs_at_hdr32_u32) || !std::is_same<T1, ::HDRFloat<float>>::value, "ATInfo layout");
+    static_assert(sizeof(IterType) != 4 || !std::is_same<T1, ::HDRFloat<float>>::value || sizeof(at) == sizeof(fs_at_hdr32_u32),
+                  "ATInfo layout");
+    static_assert(sizeof(IterType) != 8 || !std::is_same<T1, ::HDRFloat<float>>::value || sizeof(at) == sizeof(fs_at_hdr32_u64),
+                  "ATInfo layout (uint64_t IterType)");
     return fs_upload_la(r, GenerationNumber1, tag, (uint32_t)sizeof(IterType), LaReferenceHost->GetLAs().GetData(),
                         (uint32_t)LaReferenceHost->GetLAs().GetSize(), LaReferenceHost->GetLAStages().GetData(),
                         (uint32_t)LaReferenceHost->GetLAStageCount(), LaReferenceHost->IsValid() ? 1 : 0,
                         LaReferenceHost->UseAT() ? 1 : 0, &at);
+    }
 }
 
 template <typename IterType, class T, class SubType, LAv2Mode Mode, PerturbExtras PExtras>
@@ -164,10 +195,11 @@ uint32_t GPURenderer::RenderPerturbLAv2(RenderAlgorithm /*algorithm*/, T /*cx*/,
     if (!m_ComputeStream)
         return 0; // "memory not initialised" is silent, GPU_Render.cu:1007-1009
     constexpr int tag = fsmi355_shim::type_tag<T>::value;
-    if constexpr (tag != FS_T_HDR32 && tag != FS_T_HDR64) {
+    if constexpr (tag != FS_T_HDR32 && tag != FS_T_HDR64 && tag != FS_T_HDR2X32) {
         return FS_ERR_UNSUPPORTED;
     } else {
-    if (PExtras != PerturbExtras::Disable)
+    // PExtras only changes how the orbit was uploaded (InitializePerturb); the 2x32 kernel reads uncompressed orbits only
+    if (PExtras != PerturbExtras::Disable && (PExtras != PerturbExtras::SimpleCompression || tag == FS_T_HDR2X32))
         return FS_ERR_UNSUPPORTED;
     const typename fsmi355_shim::abi_real<T>::type co[4] = {fsmi355_shim::to_abi(dx), fsmi355_shim::to_abi(dy),
                                                             fsmi355_shim::to_abi(centerX), fsmi355_shim::to_abi(centerY)};

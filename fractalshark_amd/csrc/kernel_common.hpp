@@ -16,6 +16,17 @@ __device__ __forceinline__ uint32_t global_row(const FsFrame &f, uint32_t L)
     return f.band_first + k * f.band_stride + rr;
 }
 
+// One result into the iteration buffer: OutputIterMatrix[ConvertLocToIndex(X, Y, width)] (GPU_Render.cu:73-79) for
+// IterType = uint32_t or uint64_t.  Counts are computed in 32 bits (the ABI refuses n_iterations >= 2^32).
+__device__ __forceinline__ void store_iter(uint32_t *out, const FsFrame &f, uint32_t L, uint32_t X, uint32_t v)
+{
+    const size_t idx = (size_t)L * f.rounded_width + X;
+    if (f.iter_u64)
+        reinterpret_cast<uint64_t *>(out)[idx] = v;
+    else
+        out[idx] = v;
+}
+
 __device__ __forceinline__ void add_stats(uint64_t *stats, uint64_t at, uint64_t la, uint64_t pt, uint64_t px)
 {
     // stats[4]: lane slots the wave occupied in the perturbation loop = 64 x (longest lane); with [2] it gives

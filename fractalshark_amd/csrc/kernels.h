@@ -24,6 +24,7 @@ struct FsFrame {
     uint32_t band_first;    // first global row of band 0
     uint32_t band_rows;     // rows per band
     uint32_t band_stride;   // global-row distance between consecutive owned bands
+    uint32_t iter_u64;      // 1: the iteration buffer holds uint64_t elements (IterType = uint64_t), 0: uint32_t
 };
 
 // Per-numeric-type device records.  F = float -> HDRFloat<float> (hdr32 ABI records), F = double -> HDRFloat<double>.
@@ -159,8 +160,9 @@ void fsk_direct_hdr32(const FsDirectHdrArgsT<float> &A, fs::hreal<float> minX, f
 void fsk_direct_hdr64(const FsDirectHdrArgsT<double> &A, fs::hreal<double> minX, fs::hreal<double> dx, bool stats,
                       hipStream_t s);
 void fsk_direct_f64(const FsDirectArgs64 &A, double minX, double dx, bool stats, hipStream_t s);
-void fsk_antialias_u32(const uint32_t *iters, uint32_t rounded_width, fs_color16 *colors, const fs_color16 *pal,
-                       uint32_t pal_iters, uint32_t aux_depth, uint32_t aa, uint32_t color_w, uint32_t color_h,
-                       uint32_t n_iterations, hipStream_t s);
-void fsk_reduce_u32(const uint32_t *iters, uint32_t rounded_width, uint32_t width, uint32_t rows, fs_reduction *out,
-                    hipStream_t s);
+// iter_u64: element type of the iteration buffer (see FsFrame)
+void fsk_antialias(const void *iters, int iter_u64, uint32_t rounded_width, fs_color16 *colors, const fs_color16 *pal,
+                   uint32_t pal_iters, uint32_t aux_depth, uint32_t aa, uint32_t color_w, uint32_t color_h,
+                   uint32_t n_iterations, hipStream_t s);
+void fsk_reduce(const void *iters, int iter_u64, uint32_t rounded_width, uint32_t width, uint32_t rows,
+                fs_reduction *out, hipStream_t s);

@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
                 }
             }
         }
-        A.out[(size_t)L * A.frame.rounded_width + X] = iterations;
+        store_iter(A.out, A.frame, L, X, iterations);
     }
     if (kStats)
         add_stats(A.stats, c_at, c_la, c_pt, c_px);
@@ -484,7 +484,7 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
             }
 #undef FS_LAV2_STEP_HEAD
         }
-        A.out[(size_t)L * A.frame.rounded_width + X] = iterations;
+        store_iter(A.out, A.frame, L, X, iterations);
     }
     if (kStats) {
         add_stats(A.stats, c_at, c_la, c_pt, c_px);
@@ -738,7 +738,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
             }
             ++iter;
         }
-        A.out[(size_t)L * A.frame.rounded_width + X] = iter;
+        store_iter(A.out, A.frame, L, X, iter);
     }
     if (kStats)
         add_stats(A.stats, 0, c_la, c_pt, c_px);
@@ -778,7 +778,7 @@ __global__ void __launch_bounds__(256) k_direct_f64(FsDirectArgs64 A)
         }
         if (kStats)
             c_pt = i;
-        A.out[(size_t)L * A.frame.rounded_width + X] = i;
+        store_iter(A.out, A.frame, L, X, i);
     }
     if (kStats)
         add_stats(A.stats, 0, 0, c_pt, c_px);
@@ -801,10 +801,11 @@ __global__ void k_direct_row_prefix_f64(double minX, double dx, uint32_t width, 
 // RenderCurrent pieces.  Antialias + palette: same arithmetic as antialiasing_kernel
 // (FractalSharkGpuLib/AntialiasingKernel.cuh:3-71): integer box filter, interior pixels contribute black,
 // alpha 65535, colour rows are NOT padded.
-__global__ void __launch_bounds__(256) k_antialias_u32(const uint32_t *__restrict__ iters, uint32_t rounded_width,
-                                                       fs_color16 *__restrict__ colors, const fs_color16 *__restrict__ pal,
-                                                       uint32_t pal_iters, uint32_t aux_depth, uint32_t aa,
-                                                       uint32_t color_w, uint32_t color_h, uint32_t n_iterations)
+template <class IterT>
+__global__ void __launch_bounds__(256) k_antialias(const IterT *__restrict__ iters, uint32_t rounded_width,
+                                                   fs_color16 *__restrict__ colors, const fs_color16 *__restrict__ pal,
+                                                   uint32_t pal_iters, uint32_t aux_depth, uint32_t aa,
+                                                   uint32_t color_w, uint32_t color_h, uint32_t n_iterations)
 {
     const uint32_t ox = blockIdx.x * 64u + (threadIdx.x & 63u);
     const uint32_t oy = blockIdx.y * 4u + (threadIdx.x >> 6);
@@ -813,9 +814,9 @@ __global__ void __launch_bounds__(256) k_antialias_u32(const uint32_t *__restric
     uint64_t acc_r = 0, acc_g = 0, acc_b = 0;
     for (uint32_t ix = ox * aa; ix < (ox + 1) * aa; ix++) {
         for (uint32_t iy = oy * aa; iy < (oy + 1) * aa; iy++) {
-            const uint32_t n = iters[(size_t)iy * rounded_width + ix];
+            const IterT n = iters[(size_t)iy * rounded_width + ix];
             if (n < n_iterations) {
-                const uint32_t p = (n >> aux_depth) % pal_iters;
+                const uint32_t p = (uint32_t)((n >> aux_depth) % pal_iters);
                 const fs_color16 c = pal[p];
                 acc_r += c.r;
                 acc_g += c.g;
@@ -834,12 +835,13 @@ __global__ void __launch_bounds__(256) k_antialias_u32(const uint32_t *__restric
 
 // Min / max / sum of the valid (unpadded) part of the iteration buffer: max_kernel
 // (FractalSharkGpuLib/ReductionKernels.cuh:73-142) without its unsynchronised output reset -- the host
-// seeds {Min=UINT32_MAX, Max=0, Sum=0} on the stream before the launch.  Wave shuffles, one atomic triple
-// per wave.
-__global__ void __launch_bounds__(256) k_reduce_u32(const uint32_t *__restrict__ iters, uint32_t rounded_width,
-                                                    uint32_t width, uint32_t rows, fs_reduction *out)
+// seeds {Min=numeric_limits<IterType>::max(), Max=0, Sum=0} on the stream before the launch.  Wave shuffles, one
+// atomic triple per wave.
+template <class IterT>
+__global__ void __launch_bounds__(256) k_reduce(const IterT *__restrict__ iters, uint32_t rounded_width,
+                                                uint32_t width, uint32_t rows, fs_reduction *out)
 {
-    uint64_t mn = 0xFFFFFFFFull, mx = 0, sum = 0;
+    uint64_t mn = (uint64_t)(IterT)~(IterT)0, mx = 0, sum = 0;
     const uint64_t total = (uint64_t)rounded_width * rows;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t x = (uint32_t)(i % rounded_width);
@@ -918,7 +920,7 @@ __global__ void __launch_bounds__(256) k_direct_hdr(FsDirectHdrArgsT<F> A)
         }
         if (kStats)
             c_pt = i;
-        A.out[(size_t)L * A.frame.rounded_width + X] = i;
+        store_iter(A.out, A.frame, L, X, i);
     }
     if (kStats)
         add_stats(A.stats, 0, 0, c_pt, c_px);
@@ -1089,7 +1091,7 @@ __global__ void __launch_bounds__(256) k_perturb_bla_f64(FsBlaArgsF64 A)
             }
             ++iter;
         }
-        A.out[(size_t)L * A.frame.rounded_width + X] = iter;
+        store_iter(A.out, A.frame, L, X, iter);
     }
     if (kStats)
         add_stats(A.stats, 0, c_la, c_pt, c_px);
@@ -1274,17 +1276,26 @@ void fsk_direct_f64(const FsDirectArgs64 &A, double minX, double dx, bool stats,
         hipLaunchKernelGGL((k_direct_f64<false>), g, b, 0, s, A);
 }
 
-void fsk_antialias_u32(const uint32_t *iters, uint32_t rounded_width, fs_color16 *colors, const fs_color16 *pal,
-                       uint32_t pal_iters, uint32_t aux_depth, uint32_t aa, uint32_t color_w, uint32_t color_h,
-                       uint32_t n_iterations, hipStream_t s)
+void fsk_antialias(const void *iters, int iter_u64, uint32_t rounded_width, fs_color16 *colors, const fs_color16 *pal,
+                   uint32_t pal_iters, uint32_t aux_depth, uint32_t aa, uint32_t color_w, uint32_t color_h,
+                   uint32_t n_iterations, hipStream_t s)
 {
     const dim3 g((color_w + 63) / 64, (color_h + 3) / 4), b(256);
-    hipLaunchKernelGGL(k_antialias_u32, g, b, 0, s, iters, rounded_width, colors, pal, pal_iters, aux_depth, aa,
-                       color_w, color_h, n_iterations);
+    if (iter_u64)
+        hipLaunchKernelGGL(k_antialias<uint64_t>, g, b, 0, s, (const uint64_t *)iters, rounded_width, colors, pal,
+                           pal_iters, aux_depth, aa, color_w, color_h, n_iterations);
+    else
+        hipLaunchKernelGGL(k_antialias<uint32_t>, g, b, 0, s, (const uint32_t *)iters, rounded_width, colors, pal,
+                           pal_iters, aux_depth, aa, color_w, color_h, n_iterations);
 }
 
-void fsk_reduce_u32(const uint32_t *iters, uint32_t rounded_width, uint32_t width, uint32_t rows, fs_reduction *out,
-                    hipStream_t s)
+void fsk_reduce(const void *iters, int iter_u64, uint32_t rounded_width, uint32_t width, uint32_t rows,
+                fs_reduction *out, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_reduce_u32, dim3(1024), dim3(256), 0, s, iters, rounded_width, width, rows, out);
+    if (iter_u64)
+        hipLaunchKernelGGL(k_reduce<uint64_t>, dim3(1024), dim3(256), 0, s, (const uint64_t *)iters, rounded_width,
+                           width, rows, out);
+    else
+        hipLaunchKernelGGL(k_reduce<uint32_t>, dim3(1024), dim3(256), 0, s, (const uint32_t *)iters, rounded_width,
+                           width, rows, out);
 }

@@ -178,7 +178,7 @@ template <int Mode, bool kStats> __global__ void __launch_bounds__(256) k_lav2_2
                 }
             }
         }
-        A.out[(size_t)L * A.frame.rounded_width + X] = iter;
+        store_iter(A.out, A.frame, L, X, iter);
     }
     if (kStats)
         add_stats(A.stats, c_at, c_la, c_pt, c_px);

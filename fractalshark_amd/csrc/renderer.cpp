@@ -124,6 +124,7 @@ FsFrame make_frame(const fs_renderer *r)
     f.band_first = r->band_first;
     f.band_rows = r->band_rows;
     f.band_stride = r->band_stride;
+    f.iter_u64 = r->iter_bytes == 8 ? 1u : 0u;
     return f;
 }
 
@@ -257,6 +258,23 @@ template <class F> static void fill_lav2(fs_renderer *r, FsLav2ArgsT<F> &A, cons
 }
 
 
+// uint64_t IterType tables (fs_la_*_u64 / fs_la_stage_u64 / fs_at_*_u64) are narrowed to the uint32_t device records.
+template <class R64, class R32> static bool narrow_la(const void *in, uint32_t n, std::vector<uint8_t> &out)
+{
+    out.resize((size_t)n * sizeof(R32));
+    const R64 *src = (const R64 *)in;
+    R32 *dst = (R32 *)out.data();
+    for (uint32_t i = 0; i < n; i++) {
+        if (src[i].StepLength > 0xFFFFFFFFull || src[i].NextStageLAIndex > 0xFFFFFFFFull)
+            return false;
+        memcpy(&dst[i], &src[i], offsetof(R32, StepLength)); // Ref .. MinMag are laid out identically
+        dst[i].StepLength = (uint32_t)src[i].StepLength;
+        dst[i].NextStageLAIndex = (uint32_t)src[i].NextStageLAIndex;
+    }
+    return true;
+}
+
+
 extern "C" {
 
 fs_renderer *fs_create(int device)
@@ -332,8 +350,8 @@ uint32_t fs_init_memory(fs_renderer *r, uint32_t w, uint32_t h, uint32_t antiali
 {
     if (uint32_t e = use_device(r))
         return e;
-    if (iter_bytes != 4)
-        return FS_ERR_UNSUPPORTED; // uint64_t IterType: later round
+    if (iter_bytes != 4 && iter_bytes != 8)
+        return FS_ERR_UNSUPPORTED;
     if (!r->compute) {
         int lo = 0, hi = 0;
         FS_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -433,8 +451,9 @@ uint32_t fs_upload_orbit(fs_renderer *r, uint64_t generation, int type_tag, uint
 {
     if (uint32_t e = use_device(r))
         return e;
+    // orbit entries do not depend on IterType (GPU_ReferenceIter.h:52-127); counts must fit the 32-bit device counters
     if ((type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64 && type_tag != FS_T_F64 && type_tag != FS_T_HDR2X32) ||
-        iter_bytes != 4)
+        (iter_bytes != 4 && iter_bytes != 8) || uncompressed_size > 0xFFFFFFFFull)
         return FS_ERR_UNSUPPORTED;
     if (!r->compute)
         return FS_ERR_6;
@@ -522,7 +541,8 @@ uint32_t fs_upload_orbit_compressed(fs_renderer *r, uint64_t generation, int typ
 {
     if (uint32_t e = use_device(r))
         return e;
-    if ((type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64) || iter_bytes != 4)
+    if ((type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64) || (iter_bytes != 4 && iter_bytes != 8) ||
+        uncompressed_size > 0xFFFFFFFFull)
         return FS_ERR_UNSUPPORTED;
     if (!r->compute)
         return FS_ERR_6;
@@ -579,7 +599,8 @@ uint32_t fs_upload_la(fs_renderer *r, uint64_t generation, int type_tag, uint32_
 {
     if (uint32_t e = use_device(r))
         return e;
-    if ((type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64 && type_tag != FS_T_HDR2X32) || iter_bytes != 4)
+    if ((type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64 && type_tag != FS_T_HDR2X32) ||
+        (iter_bytes != 4 && iter_bytes != 8))
         return FS_ERR_UNSUPPORTED;
     if (!r->compute)
         return FS_ERR_6;
@@ -588,6 +609,39 @@ uint32_t fs_upload_la(fs_renderer *r, uint64_t generation, int type_tag, uint32_
     const size_t la_bytes = type_tag == FS_T_HDR32
                                 ? sizeof(fs_la_hdr32_u32)
                                 : (type_tag == FS_T_HDR64 ? sizeof(fs_la_hdr64_u32) : sizeof(fs_la_2x32_u32));
+    std::vector<uint8_t> las32, stages32;
+    uint8_t at32[sizeof(fs_at_hdr64_u32)] = {0};
+    if (iter_bytes == 8) {
+        bool ok = true;
+        if (n_las)
+            ok = type_tag == FS_T_HDR32   ? narrow_la<fs_la_hdr32_u64, fs_la_hdr32_u32>(las, n_las, las32)
+                 : type_tag == FS_T_HDR64 ? narrow_la<fs_la_hdr64_u64, fs_la_hdr64_u32>(las, n_las, las32)
+                                          : narrow_la<fs_la_2x32_u64, fs_la_2x32_u32>(las, n_las, las32);
+        stages32.resize((size_t)n_stages * sizeof(fs_la_stage_u32));
+        for (uint32_t i = 0; ok && i < n_stages; i++) {
+            const fs_la_stage_u64 &sg = ((const fs_la_stage_u64 *)stages)[i];
+            ok = sg.LAIndex <= 0xFFFFFFFFull && sg.MacroItCount <= 0xFFFFFFFFull;
+            ((fs_la_stage_u32 *)stages32.data())[i] = fs_la_stage_u32{(uint32_t)sg.LAIndex, (uint32_t)sg.MacroItCount};
+        }
+        if (ok && at_info) {
+            uint64_t step;
+            memcpy(&step, at_info, 8);
+            ok = step <= 0xFFFFFFFFull;
+            const uint32_t step32 = (uint32_t)step;
+            memcpy(at32, &step32, 4);
+            if (type_tag == FS_T_HDR32)
+                memcpy(at32 + 4, (const uint8_t *)at_info + 8, sizeof(fs_at_hdr32_u32) - 4);
+            else if (type_tag == FS_T_HDR64)
+                memcpy(at32 + 8, (const uint8_t *)at_info + 8, sizeof(fs_at_hdr64_u32) - 8);
+            else
+                memcpy(at32 + 4, (const uint8_t *)at_info + 8, sizeof(fs_at_2x32_u32) - 4);
+            at_info = at32;
+        }
+        if (!ok)
+            return FS_ERR_UNSUPPORTED; // a step length / index that does not fit the 32-bit device counters
+        las = las32.data();
+        stages = stages32.data();
+    }
     if (r->las) {
         FS_TRY(hipFree(r->las));
         r->las = nullptr;
@@ -880,14 +934,14 @@ uint32_t fs_render_current(fs_renderer *r, uint64_t n_iterations, void *iter_buf
     const uint32_t rw = r->w_block * 16u;
     const bool whole_frame = r->local_rows == r->height;
     if (color_buffer && r->pal && whole_frame) {
-        fsk_antialias_u32((const uint32_t *)r->iters(), rw, r->colors, r->pal, r->pal_iters, r->pal_aux_depth, r->aa,
-                          r->color_w, r->color_h, (uint32_t)n_iterations, s);
+        fsk_antialias(r->iters(), r->iter_bytes == 8, rw, r->colors, r->pal, r->pal_iters, r->pal_aux_depth, r->aa,
+                      r->color_w, r->color_h, (uint32_t)n_iterations, s);
         FS_TRY(hipGetLastError());
     }
     if (reduction) {
-        const fs_reduction seed{0xFFFFFFFFull, 0, 0};
+        const fs_reduction seed{r->iter_bytes == 8 ? ~0ull : 0xFFFFFFFFull, 0, 0}; // ReductionKernels.cuh:99-104
         FS_TRY(hipMemcpyAsync(r->reduction, &seed, sizeof(seed), hipMemcpyHostToDevice, s));
-        fsk_reduce_u32((const uint32_t *)r->iters(), rw, r->width, r->local_rows, r->reduction, s);
+        fsk_reduce(r->iters(), r->iter_bytes == 8, rw, r->width, r->local_rows, r->reduction, s);
         FS_TRY(hipGetLastError());
     }
     // ExtractItersAndColors, GPU_Render.cu:1759-1805: padding included.

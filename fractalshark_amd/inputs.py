@@ -230,6 +230,42 @@ class LATable2x32:
         return self._stages.copy()
 
 
+class LATableU64:
+    """The IterType = uint64_t form of an LAv2 table (LAInfoDeep<uint64_t,..>, LAStageInfo<uint64_t>, ATInfo<uint64_t,..>):
+    what a FractalShark build with 64-bit iteration counts hands to InitializePerturb<uint64_t,...>.  Built by widening
+    the counts of a uint32_t table; the coefficient fields are byte-identical (include/fs_layout.h)."""
+
+    def __init__(self, la):
+        self.source = la
+        self.count, self.stage_count = la.count, la.stage_count
+        self.is_valid, self.use_at = la.is_valid, la.use_at
+        rec32 = np.ascontiguousarray(la.records()).view(np.uint8).reshape(la.count, -1)
+        w32 = rec32.shape[1]                      # 68 / 128 / 104
+        coeff = w32 - 8                           # bytes before StepLength
+        w64 = (coeff + 7) // 8 * 8 + 16           # 80 / 136 / 112
+        out = np.zeros((max(la.count, 1), w64), np.uint8)
+        out[: la.count, :coeff] = rec32[:, :coeff]
+        steps = rec32[:, coeff:].copy().view(np.uint32).astype(np.uint64)
+        out[: la.count, w64 - 16:] = steps.view(np.uint8).reshape(la.count, 16)
+        self._las = out
+        self._stages = la.stages().astype(np.uint64)
+        at32 = bytes(la.at)
+        step_bytes = 8 if len(at32) == 232 else 4  # the double record pads StepLength to 8 already
+        at64 = np.zeros((len(at32) - step_bytes + 8 + 7) // 8 * 8, np.uint8)
+        at64[:8] = np.frombuffer(np.uint64(la.at.StepLength).tobytes(), np.uint8)
+        at64[8:8 + len(at32) - step_bytes] = np.frombuffer(at32[step_bytes:], np.uint8)
+        self._at = at64
+        self.at = (C.c_uint8 * len(at64)).from_buffer(self._at)
+
+    @property
+    def las_ptr(self):
+        return self._las.ctypes.data
+
+    @property
+    def stages_ptr(self):
+        return self._stages.ctypes.data
+
+
 class LATable:
     """LAv2 table (LAReference<uint32_t, HDRFloat<float>, float, Disable>)."""
 

@@ -58,6 +58,7 @@ class GPURenderer:
             pal_ptr = pal.ctypes.data
         else:
             pal_ptr = None
+        self._iter_bytes = int(iter_bytes)
         return self._lib.fs_init_memory(self._h, w, h, antialiasing, iter_bytes, pal_ptr, palIters, paletteAuxDepth,
                                         paletteGeneration, 1 if expectedReuse else 0)
 
@@ -90,9 +91,10 @@ class GPURenderer:
 
     # ---- uploads
     def InitializePerturb(self, GenerationNumber1, Perturb1, GenerationNumber2=0, Perturb2=None,
-                          LaReferenceHost=None, T=None):
+                          LaReferenceHost=None, T=None, iter_bytes=4):
         """Perturb1: inputs.Orbit (or anything with data_ptr/count/period); LaReferenceHost: inputs.LATable.
-        T defaults to the orbit's type (T_HDR32 / T_HDR64)."""
+        T defaults to the orbit's type (T_HDR32 / T_HDR64 / T_HDR2X32).  iter_bytes = sizeof(IterType): with 8,
+        LaReferenceHost must be an inputs.LATableU64."""
         if T is None:
             if type(Perturb1).__name__ == "Orbit2x32":
                 T = T_HDR2X32
@@ -101,17 +103,20 @@ class GPURenderer:
         if getattr(Perturb1, "compressed", False):
             # PerturbExtras::SimpleCompression: hand over the waypoints, like the reference's *RC* algorithms
             low = Perturb1.orbit_low()
-            err = self._lib.fs_upload_orbit_compressed(self._h, GenerationNumber1, T, 4, Perturb1.compressed_data_ptr,
+            err = self._lib.fs_upload_orbit_compressed(self._h, GenerationNumber1, T, iter_bytes,
+                                                       Perturb1.compressed_data_ptr,
                                                        Perturb1.compressed_count, Perturb1.count, Perturb1.period,
                                                        low[0:1].ctypes.data, low[1:2].ctypes.data)
         else:
-            err = self._lib.fs_upload_orbit(self._h, GenerationNumber1, T, 4, Perturb1.data_ptr, Perturb1.count,
+            err = self._lib.fs_upload_orbit(self._h, GenerationNumber1, T, iter_bytes, Perturb1.data_ptr, Perturb1.count,
                                             Perturb1.count, Perturb1.period)
         if err:
             return err
         if LaReferenceHost is not None:
             la = LaReferenceHost
-            err = self._lib.fs_upload_la(self._h, GenerationNumber1, T, 4, la.las_ptr, la.count, la.stages_ptr,
+            if (iter_bytes == 8) != (type(la).__name__ == "LATableU64"):
+                raise ValueError("iter_bytes=8 needs an inputs.LATableU64 (and only then)")
+            err = self._lib.fs_upload_la(self._h, GenerationNumber1, T, iter_bytes, la.las_ptr, la.count, la.stages_ptr,
                                          la.stage_count, 1 if la.is_valid else 0, 1 if la.use_at else 0,
                                          C.addressof(la.at))
         return err
@@ -206,4 +211,5 @@ class GPURenderer:
                 "lane_slots": out[4], "careful_steps": out[5]}
 
     def new_iter_buffer(self):
-        return np.zeros((self.local_rows, self.rounded_width), np.uint32)
+        dt = np.uint64 if getattr(self, "_iter_bytes", 4) == 8 else np.uint32
+        return np.zeros((self.local_rows, self.rounded_width), dt)

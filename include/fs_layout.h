@@ -236,6 +236,64 @@ typedef struct fs_at_2x32_u32 {
     fs_real_2x32 factor;
 } fs_at_2x32_u32;
 
+/* ---- IterType = uint64_t twins of the records that embed iteration counts (LAInfoI<uint64_t>, LAStageInfo<uint64_t>,
+ * ATInfo<uint64_t,..>::StepLength; natural alignment, no packing pragma in the reference).  The device works with the
+ * uint32_t records: fs_upload_la converts these on upload and refuses tables whose counts do not fit 32 bits. */
+typedef struct fs_la_stage_u64 {
+    uint64_t LAIndex;
+    uint64_t MacroItCount;
+} fs_la_stage_u64;
+
+typedef struct fs_la_hdr32_u64 {
+    fs_cplx_hdr32 Ref;
+    fs_cplx_hdr32 ZCoeff;
+    fs_cplx_hdr32 CCoeff;
+    fs_real_hdr32 LAThreshold;
+    fs_real_hdr32 LAThresholdC;
+    fs_real_hdr32 MinMag;
+    uint32_t pad_;
+    uint64_t StepLength;
+    uint64_t NextStageLAIndex;
+} fs_la_hdr32_u64;
+
+typedef struct fs_la_hdr64_u64 {
+    fs_cplx_hdr64 Ref;
+    fs_cplx_hdr64 ZCoeff;
+    fs_cplx_hdr64 CCoeff;
+    fs_real_hdr64 LAThreshold;
+    fs_real_hdr64 LAThresholdC;
+    fs_real_hdr64 MinMag;
+    uint64_t StepLength;
+    uint64_t NextStageLAIndex;
+} fs_la_hdr64_u64;
+
+typedef struct fs_la_2x32_u64 {
+    fs_cplx_2x32 Ref;
+    fs_cplx_2x32 ZCoeff;
+    fs_cplx_2x32 CCoeff;
+    fs_real_2x32 LAThreshold;
+    fs_real_2x32 LAThresholdC;
+    fs_real_2x32 MinMag;
+    uint64_t StepLength;
+    uint64_t NextStageLAIndex;
+} fs_la_2x32_u64;
+
+/* ATInfo<uint64_t, ..>: StepLength is 8 bytes, everything after it is laid out like the uint32_t record after its
+ * StepLength (+ pad for the double type). */
+typedef struct fs_at_hdr32_u64 {
+    uint64_t StepLength;
+    uint8_t rest[sizeof(fs_at_hdr32_u32) - 4]; /* ThresholdC .. factor */
+} fs_at_hdr32_u64;
+typedef struct fs_at_hdr64_u64 {
+    uint64_t StepLength;
+    uint8_t rest[sizeof(fs_at_hdr64_u32) - 8];
+} fs_at_hdr64_u64;
+typedef struct fs_at_2x32_u64 {
+    uint64_t StepLength;
+    uint8_t rest[sizeof(fs_at_2x32_u32) - 4];
+    uint32_t pad_;
+} fs_at_2x32_u64;
+
 typedef struct fs_color16 {
     uint16_t r, g, b, a;
 } fs_color16;
@@ -260,6 +318,11 @@ static_assert(sizeof(fs_at_hdr64_u32) == 232, "AT record (double)");
 static_assert(sizeof(fs_bla_hdr64) == 88, "BLA record (double)");
 static_assert(sizeof(fs_real_2x32) == 12 && sizeof(fs_cplx_2x32) == 20 && sizeof(fs_orbit_2x32) == 24, "2x32 records");
 static_assert(sizeof(fs_la_2x32_u32) == 104 && sizeof(fs_at_2x32_u32) == 184, "2x32 LA / AT records");
+static_assert(sizeof(fs_la_stage_u64) == 16 && sizeof(fs_la_hdr32_u64) == 80 && sizeof(fs_la_hdr64_u64) == 136 &&
+                  sizeof(fs_la_2x32_u64) == 112,
+              "uint64_t IterType LA records");
+static_assert(sizeof(fs_at_hdr32_u64) == 120 && sizeof(fs_at_hdr64_u64) == 232 && sizeof(fs_at_2x32_u64) == 192,
+              "uint64_t IterType AT records");
 static_assert(sizeof(fs_bla_f64) == 48 && sizeof(fs_orbit_f64) == 16, "plain double records");
 #endif
 

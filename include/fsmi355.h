@@ -77,7 +77,11 @@ const char *fs_error_string(uint32_t err);
 
 /* GPURenderer::InitializeMemory<IterType> (GPU_Render.cu:232-407).  w,h already include antialiasing.
  * iter_bytes = sizeof(IterType) (4 or 8).  The iteration buffer is padded to 16 columns x 8 rows
- * (GPU_Render.cu:334-344). */
+ * (GPU_Render.cu:334-344).
+ * IterType = uint64_t: the iteration buffer, RenderCurrent and ReductionResults work on uint64_t elements and the
+ * uint64_t record layouts (fs_la_*_u64, fs_la_stage_u64, fs_at_*_u64) are accepted, but the device counts in 32 bits:
+ * render calls with n_iterations >= 2^32 and tables whose step lengths / indices do not fit 32 bits return
+ * FS_ERR_UNSUPPORTED (every built-in view selects Bits32, FractalViewPresets.cpp:19). */
 uint32_t fs_init_memory(fs_renderer *r, uint32_t w, uint32_t h, uint32_t antialiasing, uint32_t iter_bytes,
                         const fs_color16 *pal_interleaved, uint32_t pal_iters, uint32_t palette_aux_depth,
                         uint64_t palette_generation, int expected_reuse);
@@ -110,7 +114,8 @@ uint32_t fs_upload_orbit_compressed(fs_renderer *r, uint64_t generation, int typ
                                     const void *entries, uint64_t compressed_size, uint64_t uncompressed_size,
                                     uint64_t period_maybe_zero, const void *orbit_x_low, const void *orbit_y_low);
 /* ... and LA table upload (GPU_LAReference ctor, GPU_LAReference.h:79-160).  at_info may be NULL when
- * use_at == 0. */
+ * use_at == 0.  iter_bytes selects the record family: 4 -> fs_la_*_u32 / fs_la_stage_u32 / fs_at_*_u32,
+ * 8 -> fs_la_*_u64 / fs_la_stage_u64 / fs_at_*_u64 (narrowed on upload). */
 uint32_t fs_upload_la(fs_renderer *r, uint64_t generation, int type_tag, uint32_t iter_bytes, const void *las,
                       uint32_t n_las, const void *stages, uint32_t n_stages, int is_valid, int use_at,
                       const void *at_info);

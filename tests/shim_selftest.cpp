@@ -39,6 +39,15 @@ public:
     T getMantissa() const { return mantissa; }
     int32_t getExp() const { return exp; }
 };
+struct MattDblflt {
+    float head, tail;
+};
+template <class T = MattDblflt> class CudaDblflt {
+public:
+    T d;
+    float head() const { return d.head; }
+    float tail() const { return d.tail; }
+};
 template <class T, PerturbExtras P> struct GPUReferenceIter {
     T x, y;
 };
@@ -48,15 +57,18 @@ public:
     IterType GetCompressedSize() const { return n; }
     IterType GetUncompressedSize() const { return n; }
     IterType GetPeriodMaybeZero() const { return period; }
+    T GetOrbitXLow() const { return xlow; }
+    T GetOrbitYLow() const { return ylow; }
     const GPUReferenceIter<T, PExtras> *orb = nullptr;
     IterType n = 0, period = 0;
+    T xlow{}, ylow{};
 };
 template <class E> struct GrowableVector {
     E *GetData() const { return nullptr; }
     size_t GetSize() const { return 0; }
 };
 template <typename IterType, class F, class S> struct ATInfo {
-    unsigned char bytes[116];
+    unsigned char bytes[sizeof(IterType) == 4 ? 116 : 120];
 };
 template <typename IterType, class F, class S, PerturbExtras P> struct LAInfoDeep {
     unsigned char bytes[68];
@@ -85,10 +97,6 @@ public:
     std::vector<std::vector<BLA<T>>> m_B;
     int32_t m_LM2 = 0;
 };
-struct MattDblflt {
-    float head, tail;
-};
-
 // Member list of the reference class (declarations only).
 class GPURenderer {
 public:
@@ -165,6 +173,30 @@ template uint32_t GPURenderer::RenderPerturbBLA<uint32_t, HDR64>(RenderAlgorithm
                                                                  BLAS<uint32_t, HDR64> *, HDR64, HDR64, HDR64, HDR64, HDR64,
                                                                  HDR64, uint32_t, int);
 template uint32_t GPURenderer::RenderCurrent<uint32_t>(uint32_t, uint32_t *, Color16 *, ReductionResults *, bool);
+// SimpleCompression orbits (Gpu*RC* algorithms), the 2x32 type and IterType = uint64_t
+template uint32_t GPURenderer::InitializePerturb<uint32_t, HDR32, float, PerturbExtras::SimpleCompression, HDR32>(
+    size_t, const GPUPerturbResults<uint32_t, HDR32, PerturbExtras::SimpleCompression> *, size_t,
+    const GPUPerturbResults<uint32_t, HDR32, PerturbExtras::SimpleCompression> *,
+    const LAReference<uint32_t, HDR32, float, PerturbExtras::SimpleCompression> *);
+template uint32_t GPURenderer::RenderPerturbLAv2<uint32_t, HDR32, float, LAv2Mode::Full, PerturbExtras::SimpleCompression>(
+    RenderAlgorithm, HDR32, HDR32, HDR32, HDR32, HDR32, HDR32, uint32_t);
+using HDR2x32 = HDRFloat<CudaDblflt<MattDblflt>>;
+template uint32_t GPURenderer::InitializePerturb<uint32_t, HDR2x32, CudaDblflt<MattDblflt>, PerturbExtras::Disable, HDR2x32>(
+    size_t, const GPUPerturbResults<uint32_t, HDR2x32, PerturbExtras::Disable> *, size_t,
+    const GPUPerturbResults<uint32_t, HDR2x32, PerturbExtras::Disable> *,
+    const LAReference<uint32_t, HDR2x32, CudaDblflt<MattDblflt>, PerturbExtras::Disable> *);
+template uint32_t GPURenderer::RenderPerturbLAv2<uint32_t, HDR2x32, CudaDblflt<MattDblflt>, LAv2Mode::Full, PerturbExtras::Disable>(
+    RenderAlgorithm, HDR2x32, HDR2x32, HDR2x32, HDR2x32, HDR2x32, HDR2x32, uint32_t);
+template uint32_t GPURenderer::InitializeMemory<uint64_t>(uint32_t, uint32_t, uint32_t, const Color16 *, uint32_t,
+                                                          uint32_t, uint64_t, bool);
+template void GPURenderer::ClearMemory<uint64_t>();
+template uint32_t GPURenderer::InitializePerturb<uint64_t, HDR32, float, PerturbExtras::Disable, HDR32>(
+    size_t, const GPUPerturbResults<uint64_t, HDR32, PerturbExtras::Disable> *, size_t,
+    const GPUPerturbResults<uint64_t, HDR32, PerturbExtras::Disable> *,
+    const LAReference<uint64_t, HDR32, float, PerturbExtras::Disable> *);
+template uint32_t GPURenderer::RenderPerturbLAv2<uint64_t, HDR32, float, LAv2Mode::Full, PerturbExtras::Disable>(
+    RenderAlgorithm, HDR32, HDR32, HDR32, HDR32, HDR32, HDR32, uint64_t);
+template uint32_t GPURenderer::RenderCurrent<uint64_t>(uint64_t, uint64_t *, Color16 *, ReductionResults *, bool);
 
 int main()
 {

@@ -418,3 +418,35 @@ def test_2x32_view14_deep_zoom_rows(renderer, native_libs):
     ref = _oracle.gpu_lav2_2x32(v, o2, la2, mode=0)
     assert np.array_equal(out, ref)
     assert len(np.unique(out[:36, :64])) > 16
+
+
+# ---- IterType = uint64_t: 64-bit iteration buffer / record layouts over the 32-bit device counters
+def test_uint64_itertype_matches_uint32(renderer, v5_small):
+    v, ob, la, _ = v5_small
+    r = renderer
+    pal = (np.arange(64 * 4, dtype=np.uint32).reshape(64, 4) * 257 % 65536).astype(np.uint16)
+    n = v.num_iterations
+    dx, dy, cx, cy = _pairs(v.coords_perturb(ob))
+    results = {}
+    for ib in (4, 8):
+        assert r.InitializeMemory(64, 36, 1, pal, 64, 0, 7 + ib, False, iter_bytes=ib) == 0
+        la_in = inputs.LATableU64(la) if ib == 8 else la
+        assert r.InitializePerturb(0, ob, 0, None, la_in, iter_bytes=ib) == 0
+        assert r.ClearMemory() == 0
+        assert r.RenderPerturbLAv2(None, None, None, dx, dy, cx, cy, n, Mode=LAV2_FULL, parity=PARITY_CPU_GPUSTAGE) == 0
+        out = r.new_iter_buffer()
+        colors = np.zeros((64 * 40, 4), np.uint16)
+        red = _capi.Reduction()
+        assert r.RenderCurrent(n, out, colors, red) == 0
+        assert r.SyncComputeStream() == 0
+        results[ib] = (out, colors, (red.Min, red.Max, red.Sum))
+    assert results[8][0].dtype == np.uint64 and results[8][0].itemsize == 8
+    assert np.array_equal(results[8][0], results[4][0].astype(np.uint64))
+    assert np.array_equal(results[8][1], results[4][1])
+    assert results[8][2] == results[4][2]
+    # counts that do not fit the 32-bit device counters are refused, not truncated
+    big = inputs.LATableU64(la)
+    big._stages[0, 1] = 1 << 33
+    assert r.InitializePerturb(0, ob, 0, None, big, iter_bytes=8) == 10100
+    assert r.RenderPerturbLAv2(None, None, None, dx, dy, cx, cy, 1 << 32, Mode=LAV2_FULL) == 10100
+    assert r.InitializeMemory(64, 36, 1, None, 0, 0, 0, False, iter_bytes=4) == 0
