@@ -102,6 +102,8 @@ def render_lib():
     _decl(lib, "fs_render_lav2", u32, [vp, C.c_int, C.c_int, C.c_int, vp, u64])
     _decl(lib, "fs_render_bla", u32, [vp, C.c_int, vp, u64])
     _decl(lib, "fs_render_direct", u32, [vp, C.c_int, vp, u64])
+    _decl(lib, "fs_upload_orbit_scaled", u32, [vp, C.c_int, u32, vp, vp, u64, u64])
+    _decl(lib, "fs_render_scaled", u32, [vp, C.c_int, vp, u64])
     _decl(lib, "fs_clear", u32, [vp])
     _decl(lib, "fs_render_current", u32, [vp, u64, vp, vp, vp, C.c_int])
     _decl(lib, "fs_sync_compute", u32, [vp])
@@ -121,7 +123,8 @@ def render_lib():
 RENDER_SYMBOLS = [
     "fs_create", "fs_destroy", "fs_test_device_is_working", "fs_error_string", "fs_init_memory", "fs_set_row_bands",
     "fs_local_rows", "fs_set_external_iter_buffer", "fs_device_iter_buffer", "fs_rounded_width", "fs_upload_orbit", "fs_upload_orbit_compressed",
-    "fs_upload_la", "fs_upload_bla", "fs_render_lav2", "fs_render_bla", "fs_render_direct", "fs_clear",
+    "fs_upload_la", "fs_upload_bla", "fs_render_lav2", "fs_render_bla", "fs_render_direct", "fs_upload_orbit_scaled",
+    "fs_render_scaled", "fs_clear",
     "fs_render_current", "fs_sync_compute", "fs_sync_display", "fs_query_compute", "fs_enqueue_done_callback",
     "fs_get_width", "fs_get_height", "fs_last_kernel_ms", "fs_set_kernel_variant", "fs_enable_step_count", "fs_read_step_count",
 ]
@@ -157,6 +160,9 @@ def inputs_lib():
     _decl(lib, "fsh_orbit_data_hdr32", vp, [vp])
     _decl(lib, "fsh_orbit_data_hdr64", vp, [vp])
     _decl(lib, "fsh_orbit_max_radius_hdr32", None, [vp, vp])
+    _decl(lib, "fsh_orbit_data_hdr32_bad", vp, [vp])
+    _decl(lib, "fsh_orbit_data_f32_bad", vp, [vp])
+    _decl(lib, "fsh_orbit_bad_count", u64, [vp])
     _decl(lib, "fsh_view_coords_perturb_hdr32", None, [vp, vp, u32, u32, vp])
     _decl(lib, "fsh_view_coords_perturb_hdr64", None, [vp, vp, u32, u32, vp])
     _decl(lib, "fsh_convert_orbit_hdr64_to_2x32", None, [vp, u64, vp])

@@ -246,6 +246,32 @@ uint32_t GPURenderer::RenderPerturbBLA(RenderAlgorithm /*algorithm*/,
 }
 
 template <typename IterType, class T>
+uint32_t GPURenderer::RenderPerturbBLAScaled(RenderAlgorithm /*algorithm*/,
+                                             const GPUPerturbResults<IterType, T, PerturbExtras::Bad> *double_perturb,
+                                             const GPUPerturbResults<IterType, float, PerturbExtras::Bad> *float_perturb,
+                                             T /*cx*/, T /*cy*/, T dx, T dy, T centerX, T centerY, IterType n_iterations,
+                                             int /*iteration_precision*/)
+{
+    if (!m_ComputeStream)
+        return 0; // GPU_Render.cu:1317-1319
+    constexpr int tag = fsmi355_shim::type_tag<T>::value;
+    if constexpr (tag != FS_T_HDR32) {
+        return FS_ERR_UNSUPPORTED; // Gpu1x32PerturbedScaled (T = double) is not built
+    } else {
+    fs_renderer *r = fsmi355_shim::handle(m_ComputeStream);
+    // both orbits are uploaded inside the call, like the reference (GPU_Render.cu:1324-1345)
+    uint32_t err = fs_upload_orbit_scaled(r, tag, (uint32_t)sizeof(IterType), double_perturb->GetFullOrbit(),
+                                          float_perturb->GetFullOrbit(), double_perturb->GetUncompressedSize(),
+                                          float_perturb->GetPeriodMaybeZero());
+    if (err)
+        return err;
+    const fs_real_hdr32 co[4] = {fsmi355_shim::to_abi(dx), fsmi355_shim::to_abi(dy), fsmi355_shim::to_abi(centerX),
+                                 fsmi355_shim::to_abi(centerY)};
+    return fs_render_scaled(r, tag, co, (uint64_t)n_iterations);
+    }
+}
+
+template <typename IterType, class T>
 uint32_t GPURenderer::Render(RenderAlgorithm /*algorithm*/, T cx, T cy, T dx, T dy, IterType n_iterations,
                              int /*iteration_precision*/)
 {

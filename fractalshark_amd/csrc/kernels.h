@@ -134,6 +134,20 @@ struct FsLav2Args2x32 {
     int use_at;
 };
 
+// Scaled perturbation (GpuHDRx32PerturbedScaled): the HDRFloat<float> orbit with `bad` flags and its binary32 copy,
+// both in the reference layouts.
+struct FsScaledArgs32 {
+    uint32_t *out;
+    const fs_orbit_hdr32_bad *orbit_t;
+    const fs_orbit_f32_bad *orbit_f;
+    uint64_t *stats;
+    FsFrame frame;
+    FsCoordsT<float> coords;
+    uint32_t orbit_count;
+    uint32_t n_iterations;
+    float w2threshold; // exp(log(1e30f) / 2), ScaledKernels.cuh:21,66
+};
+
 struct FsDirectArgs64 {
     uint32_t *out;
     double *cx_row; // [width] row prefix of cx
@@ -153,6 +167,7 @@ void fsk_prepare_orbit_hdr64(const fs_orbit_hdr64 *in, FsZ64 *out, uint64_t n, h
 void fsk_lav2_hdr32(const FsLav2Args32 &A, int mode, bool stats, int variant, hipStream_t s);
 void fsk_lav2_hdr64(const FsLav2ArgsT<double> &A, int mode, bool stats, hipStream_t s);
 void fsk_lav2_2x32(const FsLav2Args2x32 &A, int mode, bool stats, hipStream_t s);
+void fsk_scaled_hdr32(const FsScaledArgs32 &A, bool stats, hipStream_t s);
 void fsk_perturb_scalar_hdr32(const FsBlaArgs32 &A, bool use_bla, bool stats, hipStream_t s);
 void fsk_perturb_scalar_hdr64(const FsBlaArgsT<double> &A, bool use_bla, bool stats, hipStream_t s);
 void fsk_perturb_bla_f64(const FsBlaArgsF64 &A, bool use_bla, bool stats, hipStream_t s);

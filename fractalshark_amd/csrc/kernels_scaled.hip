@@ -1,0 +1,178 @@
+// kernels_scaled.hip -- scaled perturbation, T = HDRFloat<float>: RenderAlgorithm GpuHDRx32PerturbedScaled
+// (GPURenderer::RenderPerturbBLAScaled, GPU_Render.cu:1302-1376).  Compiled with -ffp-contract=off.
+//
+// Restates the reference's CUDA kernel mandel_1x_float_perturb_scaled<IterType, HDRFloat<float>>
+// (FractalSharkGpuLib/ScaledKernels.cuh:3-239): the perturbation w = dz / S is iterated in plain binary32 against a
+// binary32 copy of the orbit; when |w|^2 grows past sqrt(1e30), when the pixel rebases, or when the orbit entry is
+// flagged `bad` (its binary32 form underflows), the step is finished in HDRFloat<float> and the scale S renewed.
+// There is no CPU RenderAlgorithm for this algorithm and the reference's binary32 expressions are open to nvcc's FMA
+// contraction, so the rounding behaviour is fixed here by convention: source order, one IEEE operation per operator.
+// Checker: orc_gpu_scaled_hdr32 (oracle/cpu_ref.cpp), parity unpinned.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fs_layout.h"
+#include "hdr_math.hpp"
+#include "kernels.h"
+#include "kernel_common.hpp"
+
+using namespace fs;
+
+namespace {
+
+using H = hreal<float>;
+
+// HdrSqrt, HDRFloat.h:1358-1383 (binary32 sqrt is correctly rounded: hipcc's default)
+__device__ __forceinline__ H hr_sqrt_dev(H a)
+{
+    const bool odd = (a.e & 1) != 0;
+    return H{__builtin_sqrtf(odd ? 2.0f * a.m : a.m), odd ? (a.e - 1) / 2 : a.e / 2};
+}
+__device__ __forceinline__ H orb_x(const fs_orbit_hdr32_bad *__restrict__ o, uint32_t i) { return H{o[i].mx, o[i].ex}; }
+__device__ __forceinline__ H orb_y(const fs_orbit_hdr32_bad *__restrict__ o, uint32_t i) { return H{o[i].my, o[i].ey}; }
+
+template <bool kStats> __global__ void __launch_bounds__(256) k_scaled_hdr32(FsScaledArgs32 A)
+{
+    const uint32_t X = blockIdx.x * 64u + (threadIdx.x & 63u);
+    const uint32_t L = blockIdx.y * 4u + (threadIdx.x >> 6);
+    uint64_t c_rescale = 0, c_full = 0, c_float = 0, c_px = 0;
+    const uint32_t Y = global_row(A.frame, L);
+    const bool live = X < A.frame.width && L < A.frame.local_rows && Y < A.frame.height;
+    if (live) {
+        c_px = 1;
+        const uint32_t n_iterations = A.n_iterations;
+        const uint32_t MaxRefIteration = A.orbit_count - 1;
+        const fs_orbit_hdr32_bad *__restrict__ ot = A.orbit_t;
+        const fs_orbit_f32_bad *__restrict__ of = A.orbit_f;
+        uint32_t iter = 0, RefIteration = 0;
+        // :35-39  `dx * X`: the int becomes a float and goes through HDRFloat(T mant)
+        H DeltaReal = hr_sub(hr_mul(A.coords.dx, hr_from_mant<float>((float)(int)X)), A.coords.centerX);
+        hr_reduce(DeltaReal);
+        H DeltaImaginary = hr_sub(hr_mul(hr_neg(A.coords.dy), hr_from_mant<float>((float)(int)Y)), A.coords.centerY);
+        hr_reduce(DeltaImaginary);
+        H S = hr_sqrt_dev(hr_add(hr_mul(DeltaReal, DeltaReal), hr_mul(DeltaImaginary, DeltaImaginary)));
+        hr_reduce(S);
+        float DeltaSub0DX = hr_to_native(hr_div(DeltaReal, S));
+        float DeltaSub0DY = hr_to_native(hr_div(DeltaImaginary, S));
+        float wX = 0.0f, wY = 0.0f;
+        float s = hr_to_native(S);
+        float twos = 2 * s;
+        const float w2threshold = A.w2threshold;
+        const H Two = hr_from_mant<float>(2.0f);
+
+#define FS_RESCALE(NX, NY)                                                                                              \
+    do {                                                                                                                \
+        S = hr_sqrt_dev(hr_add(hr_mul((NX), (NX)), hr_mul((NY), (NY))));                                                \
+        hr_reduce(S);                                                                                                   \
+        s = hr_to_native(S);                                                                                            \
+        twos = 2 * s;                                                                                                   \
+        DeltaSub0DX = hr_to_native(hr_div(DeltaReal, S));                                                               \
+        DeltaSub0DY = hr_to_native(hr_div(DeltaImaginary, S));                                                          \
+        wX = hr_to_native(hr_div((NX), S));                                                                             \
+        wY = hr_to_native(hr_div((NY), S));                                                                             \
+    } while (0)
+
+        while (iter < n_iterations) {
+            const fs_orbit_f32_bad cf = of[RefIteration];
+            if (cf.bad == 0) {
+                // :78-94 binary32 step
+                const float ox = wX, oy = wY;
+                wX = ox * cf.x * 2 - oy * cf.y * 2 + s * ox * ox - s * oy * oy + DeltaSub0DX;
+                wY = ox * (cf.y * 2 + twos * oy) + oy * cf.x * 2 + DeltaSub0DY;
+                if (kStats)
+                    c_float++;
+                ++RefIteration;
+                const fs_orbit_f32_bad nf = of[RefIteration];
+                const float tempZX = nf.x + wX * s;
+                const float tempZY = nf.y + wY * s;
+                const float zn_size = tempZX * tempZX + tempZY * tempZY;
+                const float w2 = wX * wX + wY * wY;
+                const float normDeltaSubN = w2 * s * s;
+                const bool zn_size_OK = zn_size < 256.0f;
+                const bool test1a = zn_size < normDeltaSubN;
+                const bool test1b = RefIteration == MaxRefIteration;
+                const bool test1ab = test1a || (test1b && zn_size_OK);
+                const bool testw2 = (w2 >= w2threshold) && zn_size_OK;
+                const bool none = !test1ab && !testw2 && zn_size_OK;
+                if (none) {
+                    ++iter;
+                    continue;
+                } else if (test1ab) {
+                    const H ZX = hr_add(orb_x(ot, RefIteration), hr_mul(hr_from_mant<float>(wX), S));
+                    const H ZY = hr_add(orb_y(ot, RefIteration), hr_mul(hr_from_mant<float>(wY), S));
+                    RefIteration = 0;
+                    FS_RESCALE(ZX, ZY);
+                    if (kStats)
+                        c_rescale++;
+                    ++iter;
+                    continue;
+                } else if (testw2) {
+                    const H ZX = hr_mul(hr_from_mant<float>(wX), S);
+                    const H ZY = hr_mul(hr_from_mant<float>(wY), S);
+                    FS_RESCALE(ZX, ZY);
+                    if (kStats)
+                        c_rescale++;
+                    ++iter;
+                    continue;
+                } else {
+                    break;
+                }
+            } else {
+                // :160-233 the whole step in T
+                const H ox = hr_from_mant<float>(wX), oy = hr_from_mant<float>(wY);
+                const H cxr = orb_x(ot, RefIteration), cyr = orb_y(ot, RefIteration);
+                H nX = hr_mul(hr_mul(ox, cxr), Two);
+                nX = hr_sub(nX, hr_mul(hr_mul(oy, cyr), Two));
+                nX = hr_add(nX, hr_mul(hr_mul(S, ox), ox));
+                nX = hr_sub(nX, hr_mul(hr_mul(S, oy), oy));
+                nX = hr_add(nX, hr_div(DeltaReal, S));
+                hr_reduce(nX);
+                H nY = hr_mul(ox, hr_add(hr_mul(cyr, Two), hr_mul(hr_mul(hr_from_number<float>(2.0f), S), oy)));
+                nY = hr_add(nY, hr_mul(hr_mul(oy, cxr), Two));
+                nY = hr_add(nY, hr_div(DeltaImaginary, S));
+                hr_reduce(nY);
+                if (kStats)
+                    c_full++;
+                ++RefIteration;
+                const H tempZX = hr_add(orb_x(ot, RefIteration), hr_mul(nX, S));
+                const H tempZY = hr_add(orb_y(ot, RefIteration), hr_mul(nY, S));
+                H zn_size = hr_add(hr_mul(tempZX, tempZX), hr_mul(tempZY, tempZY));
+                hr_reduce(zn_size);
+                // !HdrCompareToBothPositiveReducedLT<T,256>(zn_size), HDRFloat.h:1169-1184
+                const bool below = zn_size.e < 1 || (zn_size.e == 1 && !(zn_size.m >= 256.0f));
+                if (!below)
+                    break;
+                const H TwoS = hr_mul(S, S);
+                H normDeltaSubN = hr_add(hr_mul(hr_mul(nX, nX), TwoS), hr_mul(hr_mul(nY, nY), TwoS));
+                hr_reduce(normDeltaSubN);
+                H NewX, NewY;
+                if (hr_cmp_pos(zn_size, normDeltaSubN) < 0 || RefIteration == MaxRefIteration) {
+                    NewX = hr_add(orb_x(ot, RefIteration), hr_mul(nX, S));
+                    NewY = hr_add(orb_y(ot, RefIteration), hr_mul(nY, S));
+                    RefIteration = 0;
+                } else {
+                    NewX = hr_mul(nX, S);
+                    NewY = hr_mul(nY, S);
+                }
+                FS_RESCALE(NewX, NewY);
+            }
+            ++iter;
+        }
+#undef FS_RESCALE
+        store_iter(A.out, A.frame, L, X, iter);
+    }
+    if (kStats)
+        add_stats(A.stats, c_rescale, c_full, c_float, c_px);
+}
+
+} // namespace
+
+void fsk_scaled_hdr32(const FsScaledArgs32 &A, bool stats, hipStream_t s)
+{
+    const dim3 b(256);
+    const dim3 g((A.frame.width + 63) / 64, (A.frame.local_rows + 3) / 4);
+    if (stats)
+        hipLaunchKernelGGL((k_scaled_hdr32<true>), g, b, 0, s, A);
+    else
+        hipLaunchKernelGGL((k_scaled_hdr32<false>), g, b, 0, s, A);
+}

@@ -7,6 +7,7 @@
 // point returns the HIP error.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -58,6 +59,9 @@ struct fs_renderer {
     bool orbit_ok = false;
     int orbit_type = -1; // FS_T_HDR32 / FS_T_HDR64 / FS_T_HDR2X32 / FS_T_F64
     fs_orbit_2x32 *orbit_2x32 = nullptr; // HDRFloat<CudaDblflt> orbit (FS_T_HDR2X32), used as uploaded
+    fs_orbit_hdr32_bad *scaled_t = nullptr; // PerturbExtras::Bad orbits of the scaled kernel
+    fs_orbit_f32_bad *scaled_f = nullptr;
+    uint64_t scaled_count = 0;
     float4 *zref = nullptr;
     FsZ64 *zref64 = nullptr;
     fs_orbit_f64 *orbit_f64 = nullptr; // plain double orbit (FS_T_F64), used as uploaded
@@ -155,6 +159,13 @@ void free_perturb(fs_renderer *r)
     if (r->orbit_2x32)
         hipFree(r->orbit_2x32);
     r->orbit_2x32 = nullptr;
+    if (r->scaled_t)
+        hipFree(r->scaled_t);
+    if (r->scaled_f)
+        hipFree(r->scaled_f);
+    r->scaled_t = nullptr;
+    r->scaled_f = nullptr;
+    r->scaled_count = 0;
     r->zref = nullptr;
     r->zref64 = nullptr;
     r->orbit_f64 = nullptr;
@@ -907,6 +918,60 @@ uint32_t fs_render_direct(fs_renderer *r, int type_tag, const void *coords, uint
         TimedLaunch t(r);
         fsk_direct_hdr64(A, fs::hreal64{c[2].m, c[2].e}, fs::hreal64{c[0].m, c[0].e}, r->stats_on, r->compute);
     }
+    return (uint32_t)hipGetLastError();
+}
+
+uint32_t fs_upload_orbit_scaled(fs_renderer *r, int type_tag, uint32_t iter_bytes, const void *entries_t,
+                                const void *entries_f32, uint64_t orbit_size, uint64_t period_maybe_zero)
+{
+    (void)period_maybe_zero;
+    if (uint32_t e = use_device(r))
+        return e;
+    if (type_tag != FS_T_HDR32 || (iter_bytes != 4 && iter_bytes != 8) || orbit_size > 0xFFFFFFFFull || orbit_size < 2)
+        return FS_ERR_UNSUPPORTED;
+    if (!r->compute)
+        return FS_ERR_6;
+    if (r->scaled_t) {
+        FS_TRY(hipFree(r->scaled_t));
+        r->scaled_t = nullptr;
+    }
+    if (r->scaled_f) {
+        FS_TRY(hipFree(r->scaled_f));
+        r->scaled_f = nullptr;
+    }
+    r->scaled_count = 0;
+    FS_TRY(hipMalloc((void **)&r->scaled_t, orbit_size * sizeof(fs_orbit_hdr32_bad)));
+    FS_TRY(hipMalloc((void **)&r->scaled_f, orbit_size * sizeof(fs_orbit_f32_bad)));
+    FS_TRY(hipMemcpyAsync(r->scaled_t, entries_t, orbit_size * sizeof(fs_orbit_hdr32_bad), hipMemcpyDefault, r->compute));
+    FS_TRY(hipMemcpyAsync(r->scaled_f, entries_f32, orbit_size * sizeof(fs_orbit_f32_bad), hipMemcpyDefault, r->compute));
+    FS_TRY(hipStreamSynchronize(r->compute)); // host buffers are borrowed for the call only
+    r->scaled_count = orbit_size;
+    return 0;
+}
+
+uint32_t fs_render_scaled(fs_renderer *r, int type_tag, const void *coords, uint64_t n_iterations)
+{
+    if (uint32_t e = use_device(r))
+        return e;
+    if (!r->memory_initialized())
+        return 0; // GPU_Render.cu:1317-1319
+    if (type_tag != FS_T_HDR32 || n_iterations > 0xFFFFFFFFull)
+        return FS_ERR_UNSUPPORTED;
+    if (!r->scaled_t || !r->scaled_f || r->scaled_count < 2)
+        return FS_ERR_6;
+    FsScaledArgs32 A;
+    memset(&A, 0, sizeof(A));
+    A.out = (uint32_t *)r->iters();
+    A.orbit_t = r->scaled_t;
+    A.orbit_f = r->scaled_f;
+    A.stats = r->stats;
+    A.frame = make_frame(r);
+    fill_coords(A.coords, coords);
+    A.orbit_count = (uint32_t)r->scaled_count;
+    A.n_iterations = (uint32_t)n_iterations;
+    A.w2threshold = (float)exp(log((double)1e30f) / 2.0);
+    TimedLaunch t(r);
+    fsk_scaled_hdr32(A, r->stats_on, r->compute);
     return (uint32_t)hipGetLastError();
 }
 

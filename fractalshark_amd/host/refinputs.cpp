@@ -273,9 +273,14 @@ template <class F> struct OrbitT {
     hreal<F> orbitXLow{}, orbitYLow{};
     Mp cx, cy; // reference point (m_OrbitX / m_OrbitY)
     uint64_t prec_bits = 0;
+    // PerturbExtras::Bad flag per entry (RefOrbitCalc.cpp:550-562,625-627); computed for every orbit, only the scaled
+    // kernels read it
+    std::vector<uint8_t> bad;
     // packed copies in the ABI layout, built lazily
     std::vector<fs_orbit_hdr32> packed32;
     std::vector<fs_orbit_hdr64> packed64;
+    std::vector<fs_orbit_hdr32_bad> packed32_bad;
+    std::vector<fs_orbit_f32_bad> packed_f32_bad;
     // PerturbExtras::SimpleCompression: waypoints (m_FullOrbit of the compressed PerturbationResults); x / y above
     // then hold the orbit as RuntimeDecompressor reproduces it.
     bool compressed = false;
@@ -332,6 +337,9 @@ void build_orbit(const fsh_view &vw, uint64_t max_iter, bool periodicity, OrbitT
     ob.y.clear();
     ob.x.push_back(hr_zero<F>());
     ob.y.push_back(hr_zero<F>());
+    ob.bad.assign(1, 0);
+    const hreal<F> small_float = hr_from_mant<F>((F)1.1754944e-38); // T((SubType)1.1754944e-38), :472
+    const F glitch = (F)0.0000001;                                  // :474
     ob.period = 0;
     ob.compressed = compression_exp >= 0;
     ob.wp_index.assign(1, 0);
@@ -392,6 +400,27 @@ void build_orbit(const fsh_view &vw, uint64_t max_iter, bool periodicity, OrbitT
             rc_one_iter(rc_zx, rc_zy, ob.orbitXLow, ob.orbitYLow);
         }
         count++;
+        {
+            // PerturbExtras::Bad, RefOrbitCalc.cpp:550-562: entries whose parts or norm underflow a binary32
+            const hreal<F> sq_x = hr_mul(double_zx, double_zx);
+            const hreal<F> sq_y = hr_mul(double_zy, double_zy);
+            const hreal<F> norm = hr_reduced(hr_mul(hr_add(sq_x, sq_y), hr_from_mant<F>(glitch)));
+            // (T)mpf_get_d(z): templated HDRFloat(const U) with U = double -- the zero test is on the double, the
+            // normalisation on its cast to SubType (HDRFloat.h:295-326)
+            auto from_double = [](double d) {
+                if (d == 0.0)
+                    return hr_zero<F>();
+                const F v = (F)d;
+                const auto bits = to_bits<F>(v);
+                const int32_t fe = (int32_t)((bits & fbits<F>::kExpMask) >> fbits<F>::kShift) - fbits<F>::kBias;
+                return hreal<F>{from_bits<F>((bits & fbits<F>::kKeepMask) | fbits<F>::kOneExp), fe};
+            };
+            const hreal<F> zx_reduced = hr_reduced(hr_abs(from_double(mpf_get_d(zx))));
+            const hreal<F> zy_reduced = hr_reduced(hr_abs(from_double(mpf_get_d(zy))));
+            const bool underflow = hr_cmp_pos(zx_reduced, small_float) <= 0 || hr_cmp_pos(zy_reduced, small_float) <= 0 ||
+                                   hr_cmp_pos(norm, small_float) <= 0;
+            ob.bad.push_back(underflow ? 1 : 0);
+        }
 
         if (periodicity) {
             hr_reduce(dzdcX);
@@ -437,6 +466,7 @@ void build_orbit(const fsh_view &vw, uint64_t max_iter, bool periodicity, OrbitT
     mpf_clear(zx2);
     mpf_clear(t1);
     mpf_clear(t2);
+    ob.bad.back() = 0; // results->SetBad(false), RefOrbitCalc.cpp:625-627
 
     if (ob.compressed) {
         // What every consumer of a compressed orbit sees through RuntimeDecompressor::GetCompressedComplex
@@ -544,6 +574,41 @@ extern "C" const fs_orbit_hdr64 *fsh_orbit_data_hdr64(fsh_orbit *o)
             ob.packed64[i] = fs_orbit_hdr64{ob.x[i].m, ob.x[i].e, 0, ob.y[i].e, 0, ob.y[i].m};
     }
     return ob.packed64.data();
+}
+
+// PerturbExtras::Bad orbits for the scaled kernel (GpuHDRx32PerturbedScaled): the HDRFloat<float> orbit with its flags,
+// and its binary32 copy (RefOrbitCalc::CopyUsefulPerturbationResults -> CopyFullOrbitVector, PerturbationResults.cpp:
+// 239-262: (float)x = HDRFloat::operator T() = mantissa * getMultiplier(exp), HDRFloat.h:557-568).
+extern "C" const fs_orbit_hdr32_bad *fsh_orbit_data_hdr32_bad(fsh_orbit *o)
+{
+    if (o->is64)
+        return nullptr;
+    auto &ob = o->f;
+    if (ob.packed32_bad.size() != ob.x.size()) {
+        ob.packed32_bad.resize(ob.x.size());
+        for (size_t i = 0; i < ob.x.size(); i++)
+            ob.packed32_bad[i] = fs_orbit_hdr32_bad{ob.bad[i], 0u, ob.x[i].m, ob.x[i].e, ob.y[i].e, ob.y[i].m};
+    }
+    return ob.packed32_bad.data();
+}
+extern "C" const fs_orbit_f32_bad *fsh_orbit_data_f32_bad(fsh_orbit *o)
+{
+    if (o->is64)
+        return nullptr;
+    auto &ob = o->f;
+    if (ob.packed_f32_bad.size() != ob.x.size()) {
+        ob.packed_f32_bad.resize(ob.x.size());
+        for (size_t i = 0; i < ob.x.size(); i++)
+            ob.packed_f32_bad[i] = fs_orbit_f32_bad{ob.bad[i] != 0 ? 1u : 0u, 0u, hr_to_native(ob.x[i]), hr_to_native(ob.y[i])};
+    }
+    return ob.packed_f32_bad.data();
+}
+extern "C" uint64_t fsh_orbit_bad_count(const fsh_orbit *o)
+{
+    uint64_t n = 0;
+    for (uint8_t b : (o->is64 ? o->d.bad : o->f.bad))
+        n += b;
+    return n;
 }
 
 extern "C" void fsh_orbit_max_radius_hdr32(const fsh_orbit *o, fs_real_hdr32 *out)

@@ -165,6 +165,19 @@ class Orbit:
         (self._lib.fsh_orbit_low_hdr64 if self.is64 else self._lib.fsh_orbit_low_hdr32)(self._h, out.ctypes.data)
         return out
 
+    # PerturbExtras::Bad form (scaled kernels): the HDRFloat<float> orbit with its flags + its binary32 copy
+    @property
+    def bad_data_ptr(self):
+        return self._lib.fsh_orbit_data_hdr32_bad(self._h)
+
+    @property
+    def bad_f32_data_ptr(self):
+        return self._lib.fsh_orbit_data_f32_bad(self._h)
+
+    @property
+    def bad_count(self):
+        return self._lib.fsh_orbit_bad_count(self._h)
+
     def entries(self):
         dt = ORBIT_HDR64_DTYPE if self.is64 else ORBIT_HDR32_DTYPE
         buf = (C.c_uint8 * (self.count * dt.itemsize)).from_address(self.data_ptr)

@@ -158,6 +158,19 @@ class GPURenderer:
         co = self._pack_coords(T, [dx, dy, centerX, centerY])
         return self._lib.fs_render_bla(self._h, T, co.ctypes.data, int(n_iterations))
 
+    def RenderPerturbBLAScaled(self, algorithm, double_perturb, float_perturb, cx, cy, dx, dy, centerX, centerY,
+                               n_iterations, iteration_precision=1, T=T_HDR32):
+        """GpuHDRx32PerturbedScaled.  double_perturb / float_perturb: the same inputs.Orbit (hdr32) -- its
+        PerturbExtras::Bad form and the binary32 copy are taken from it; uploaded on every call like the reference
+        (GPU_Render.cu:1324-1345)."""
+        ob = double_perturb
+        err = self._lib.fs_upload_orbit_scaled(self._h, T, 4, ob.bad_data_ptr, (float_perturb or ob).bad_f32_data_ptr,
+                                               ob.count, ob.period)
+        if err:
+            return err
+        co = self._pack_coords(T, [dx, dy, centerX, centerY])
+        return self._lib.fs_render_scaled(self._h, T, co.ctypes.data, int(n_iterations))
+
     def Render(self, algorithm, cx, cy, dx, dy, n_iterations, iteration_precision=1, T=T_F64):
         """Direct kernels.  cx = minX, cy = maxY (Fractal.cpp:1894-1915 passes the view corner).  For T_F64 the
         arguments are doubles, for T_HDR32 / T_HDR64 (mantissa, exp) pairs of the un-reduced HDRFloat values."""

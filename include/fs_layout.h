@@ -86,6 +86,24 @@ typedef struct fs_orbit_hdr64 {
     double my;
 } fs_orbit_hdr64;
 
+/* PerturbExtras::Bad orbit entries (scaled kernels): the BadField base {uint32 bad; uint32 padding}
+ * (GPU_ReferenceIter.h:10-24) comes first.  GPUReferenceIter<HDRFloat<float>,Bad> = 24 B, <float,Bad> = 16 B. */
+typedef struct fs_orbit_hdr32_bad {
+    uint32_t bad;
+    uint32_t padding;
+    float mx;
+    int32_t ex;
+    int32_t ey;
+    float my;
+} fs_orbit_hdr32_bad;
+
+typedef struct fs_orbit_f32_bad {
+    uint32_t bad;
+    uint32_t padding;
+    float x;
+    float y;
+} fs_orbit_f32_bad;
+
 typedef struct fs_orbit_f64 {
     double x;
     double y;
@@ -309,6 +327,7 @@ typedef struct fs_reduction {
 static_assert(sizeof(fs_orbit_hdr32) == 16, "orbit entry");
 static_assert(sizeof(fs_orbit_hdr32_rc) == 24 && sizeof(fs_orbit_hdr64_rc) == 40, "compressed orbit entry");
 static_assert(sizeof(fs_orbit_hdr64) == 32, "orbit entry (double)");
+static_assert(sizeof(fs_orbit_hdr32_bad) == 24 && sizeof(fs_orbit_f32_bad) == 16, "PerturbExtras::Bad orbit entries");
 static_assert(sizeof(fs_la_hdr32_u32) == 68, "LA record");
 static_assert(sizeof(fs_at_hdr32_u32) == 116, "AT record");
 static_assert(sizeof(fs_bla_hdr32) == 44, "BLA record");

@@ -138,6 +138,16 @@ uint32_t fs_render_bla(fs_renderer *r, int type_tag, const void *coords, uint64_
  * coords = {dx, dy, minX, maxY} (doubles for FS_T_F64), CPU twin Fractal::CalcCpuHDR (Fractal.cpp:2096-2206). */
 uint32_t fs_render_direct(fs_renderer *r, int type_tag, const void *coords, uint64_t n_iterations);
 
+/* GPURenderer::RenderPerturbBLAScaled<IterType,T> (GPU_Render.cu:1302-1376) -> mandel_1x_float_perturb_scaled
+ * (ScaledKernels.cuh:3-239), T = HDRFloat<float> (FS_T_HDR32, RenderAlgorithm GpuHDRx32PerturbedScaled).
+ * fs_upload_orbit_scaled takes the two PerturbExtras::Bad orbits the reference passes into the render call:
+ * entries_t = GPUReferenceIter<HDRFloat<float>,Bad>[n] (fs_orbit_hdr32_bad), entries_f32 = GPUReferenceIter<float,Bad>[n]
+ * (fs_orbit_f32_bad).  coords = fs_real_hdr32{dx, dy, centerX, centerY}.  No CPU RenderAlgorithm exists for this path:
+ * the kernel restates the reference's CUDA kernel with un-contracted IEEE binary32 arithmetic. */
+uint32_t fs_upload_orbit_scaled(fs_renderer *r, int type_tag, uint32_t iter_bytes, const void *entries_t,
+                                const void *entries_f32, uint64_t orbit_size, uint64_t period_maybe_zero);
+uint32_t fs_render_scaled(fs_renderer *r, int type_tag, const void *coords, uint64_t n_iterations);
+
 /* GPURenderer::ClearMemory<IterType> (GPU_Render.cu:212-225). */
 uint32_t fs_clear(fs_renderer *r);
 

@@ -901,3 +901,151 @@ void orc_lav2_hdr64(uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, c
 }
 
 } // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// Scaled perturbation, T = HDRFloat<float>: restated CUDA kernel
+//   mandel_1x_float_perturb_scaled<uint32_t, HDRFloat<float>>      FractalSharkGpuLib/ScaledKernels.cuh:3-239
+// behind RenderAlgorithm GpuHDRx32PerturbedScaled (GPU_Render.cu:1302-1376).  PARITY UNPINNED: the reference has no CPU
+// twin of this algorithm and no golden for it, and its binary32 expressions are subject to nvcc's FMA contraction,
+// which the source does not determine.  This restatement evaluates every expression in source order with one IEEE
+// operation per operator (no contraction), like the HIP kernel it checks.  w2threshold = exp(log(1e30f)/2) is passed in
+// (the caller evaluates it once in double precision) instead of relying on a particular libm.
+//   HDRFloat pieces used here only: divide_mutable HDRFloat.h:624-636, HdrSqrt :1358-1383, operator T() :557-568,
+//   compareToBothPositiveReducedTemplate<256> :1169-1184.
+namespace {
+inline HT<float> HDiv(HT<float> a, HT<float> b) { return HT<float>{a.m / b.m, clampE(a.e - b.e)}; }
+inline HT<float> HSqrt(HT<float> a)
+{
+    const bool odd = (a.e & 1) != 0;
+    return HT<float>{std::sqrt(odd ? 2.0f * a.m : a.m), odd ? (a.e - 1) / 2 : a.e / 2};
+}
+inline float HToFloat(HT<float> a) { return a.m * getMultiplier<float>(a.e); }
+} // namespace
+
+extern "C" void orc_gpu_scaled_hdr32(uint32_t *out, uint32_t pitch, uint32_t width, uint32_t y0, uint32_t y1,
+                                     const fs_orbit_hdr32_bad *orbT, const fs_orbit_f32_bad *orbF, uint32_t count,
+                                     const fs_real_hdr32 coords[4], uint32_t n_iterations, float w2threshold, int threads,
+                                     uint64_t *stats)
+{
+    using H = HT<float>;
+    const H dx = ld(coords[0]), dy = ld(coords[1]), centerX = ld(coords[2]), centerY = ld(coords[3]);
+    std::atomic<uint64_t> s_rescale{0}, s_full{0}, s_float{0};
+    const uint32_t MaxRefIteration = count - 1;
+    auto TX = [&](uint32_t i) { return H{orbT[i].mx, orbT[i].ex}; };
+    auto TY = [&](uint32_t i) { return H{orbT[i].my, orbT[i].ey}; };
+    const H Two = HFromMant<float>(2.0f);
+    run_rows(y0, y1, threads, [&](uint32_t Y) {
+        uint64_t c_rescale = 0, c_full = 0, c_float = 0;
+        for (uint32_t X = 0; X < width; X++) {
+            uint32_t iter = 0, RefIteration = 0;
+            H DeltaReal = Sub(MulByScalar<float>(dx, (float)(int)X), centerX);
+            Reduce(DeltaReal);
+            H DeltaImaginary = Sub(MulByScalar<float>(Neg(dy), (float)(int)Y), centerY);
+            Reduce(DeltaImaginary);
+            H S = HSqrt(Add(Mul(DeltaReal, DeltaReal), Mul(DeltaImaginary, DeltaImaginary)));
+            Reduce(S);
+            float DeltaSub0DX = HToFloat(HDiv(DeltaReal, S));
+            float DeltaSub0DY = HToFloat(HDiv(DeltaImaginary, S));
+            float DeltaSubNWX = 0, DeltaSubNWY = 0;
+            float s = HToFloat(S);
+            float twos = 2 * s;
+            auto rescale = [&](H NewX, H NewY) {
+                S = HSqrt(Add(Mul(NewX, NewX), Mul(NewY, NewY)));
+                Reduce(S);
+                s = HToFloat(S);
+                twos = 2 * s;
+                DeltaSub0DX = HToFloat(HDiv(DeltaReal, S));
+                DeltaSub0DY = HToFloat(HDiv(DeltaImaginary, S));
+                DeltaSubNWX = HToFloat(HDiv(NewX, S));
+                DeltaSubNWY = HToFloat(HDiv(NewY, S));
+            };
+            while (iter < n_iterations) {
+                if (orbF[RefIteration].bad == 0) {
+                    const float fx = orbF[RefIteration].x, fy = orbF[RefIteration].y;
+                    const float wx = DeltaSubNWX, wy = DeltaSubNWY;
+                    DeltaSubNWX = wx * fx * 2 - wy * fy * 2 + s * wx * wx - s * wy * wy + DeltaSub0DX;
+                    DeltaSubNWY = wx * (fy * 2 + twos * wy) + wy * fx * 2 + DeltaSub0DY;
+                    c_float++;
+                    ++RefIteration;
+                    const float tempZX = orbF[RefIteration].x + DeltaSubNWX * s;
+                    const float tempZY = orbF[RefIteration].y + DeltaSubNWY * s;
+                    const float zn_size = tempZX * tempZX + tempZY * tempZY;
+                    const float w2 = DeltaSubNWX * DeltaSubNWX + DeltaSubNWY * DeltaSubNWY;
+                    const float normDeltaSubN = w2 * s * s;
+                    const bool zn_size_OK = zn_size < 256.0f;
+                    const bool test1a = zn_size < normDeltaSubN;
+                    const bool test1b = RefIteration == MaxRefIteration;
+                    const bool test1ab = test1a || (test1b && zn_size_OK);
+                    const bool testw2 = (w2 >= w2threshold) && zn_size_OK;
+                    const bool none = !test1ab && !testw2 && zn_size_OK;
+                    if (none) {
+                        ++iter;
+                        continue;
+                    } else if (test1ab) {
+                        const H ZX = Add(TX(RefIteration), Mul(HFromMant<float>(DeltaSubNWX), S));
+                        const H ZY = Add(TY(RefIteration), Mul(HFromMant<float>(DeltaSubNWY), S));
+                        RefIteration = 0;
+                        rescale(ZX, ZY);
+                        c_rescale++;
+                        ++iter;
+                        continue;
+                    } else if (testw2) {
+                        rescale(Mul(HFromMant<float>(DeltaSubNWX), S), Mul(HFromMant<float>(DeltaSubNWY), S));
+                        c_rescale++;
+                        ++iter;
+                        continue;
+                    } else {
+                        break;
+                    }
+                } else {
+                    // full iteration in T
+                    const H wx = HFromMant<float>(DeltaSubNWX), wy = HFromMant<float>(DeltaSubNWY);
+                    const H cxr = TX(RefIteration), cyr = TY(RefIteration);
+                    H nX = Mul(Mul(wx, cxr), Two);
+                    nX = Sub(nX, Mul(Mul(wy, cyr), Two));
+                    nX = Add(nX, Mul(Mul(S, wx), wx));
+                    nX = Sub(nX, Mul(Mul(S, wy), wy));
+                    nX = Add(nX, HDiv(DeltaReal, S));
+                    Reduce(nX);
+                    H nY = Mul(wx, Add(Mul(cyr, Two), Mul(Mul(HFromNumber<float>(2.0f), S), wy)));
+                    nY = Add(nY, Mul(Mul(wy, cxr), Two));
+                    nY = Add(nY, HDiv(DeltaImaginary, S));
+                    Reduce(nY);
+                    c_full++;
+                    ++RefIteration;
+                    const H tempZX = Add(TX(RefIteration), Mul(nX, S));
+                    const H tempZY = Add(TY(RefIteration), Mul(nY, S));
+                    H zn_size = Add(Mul(tempZX, tempZX), Mul(tempZY, tempZY));
+                    Reduce(zn_size);
+                    // !HdrCompareToBothPositiveReducedLT<T,256>(zn_size)
+                    const int c256 = zn_size.e > 1 ? 1 : (zn_size.e < 1 ? -1 : (zn_size.m >= 256.0f ? 1 : -1));
+                    if (!(c256 < 0))
+                        break;
+                    const H TwoS = Mul(S, S);
+                    H normDeltaSubN = Add(Mul(Mul(nX, nX), TwoS), Mul(Mul(nY, nY), TwoS));
+                    Reduce(normDeltaSubN);
+                    H NewX, NewY;
+                    if (CmpPosReduced(zn_size, normDeltaSubN) < 0 || RefIteration == MaxRefIteration) {
+                        NewX = Add(TX(RefIteration), Mul(nX, S));
+                        NewY = Add(TY(RefIteration), Mul(nY, S));
+                        RefIteration = 0;
+                    } else {
+                        NewX = Mul(nX, S);
+                        NewY = Mul(nY, S);
+                    }
+                    rescale(NewX, NewY);
+                }
+                ++iter;
+            }
+            out[(size_t)Y * pitch + X] = iter;
+        }
+        s_rescale += c_rescale;
+        s_full += c_full;
+        s_float += c_float;
+    });
+    if (stats) {
+        stats[0] = s_rescale;
+        stats[1] = s_full;
+        stats[2] = s_float;
+    }
+}

@@ -110,6 +110,11 @@ public:
                               const GPUPerturbResults<IterType, T, PerturbExtras::Disable> *results,
                               BLAS<IterType, T> *blas, T cx, T cy, T dx, T dy, T centerX, T centerY,
                               IterType n_iterations, int iteration_precision);
+    template <typename IterType, class T>
+    uint32_t RenderPerturbBLAScaled(RenderAlgorithm algorithm,
+                                    const GPUPerturbResults<IterType, T, PerturbExtras::Bad> *double_perturb,
+                                    const GPUPerturbResults<IterType, float, PerturbExtras::Bad> *float_perturb, T cx, T cy,
+                                    T dx, T dy, T centerX, T centerY, IterType n_iterations, int iteration_precision);
     template <typename IterType, class T, class SubType, LAv2Mode Mode, PerturbExtras PExtras>
     uint32_t RenderPerturbLAv2(RenderAlgorithm algorithm, T cx, T cy, T dx, T dy, T centerX, T centerY,
                                IterType n_iterations);
@@ -187,6 +192,9 @@ template uint32_t GPURenderer::InitializePerturb<uint32_t, HDR2x32, CudaDblflt<M
     const LAReference<uint32_t, HDR2x32, CudaDblflt<MattDblflt>, PerturbExtras::Disable> *);
 template uint32_t GPURenderer::RenderPerturbLAv2<uint32_t, HDR2x32, CudaDblflt<MattDblflt>, LAv2Mode::Full, PerturbExtras::Disable>(
     RenderAlgorithm, HDR2x32, HDR2x32, HDR2x32, HDR2x32, HDR2x32, HDR2x32, uint32_t);
+template uint32_t GPURenderer::RenderPerturbBLAScaled<uint32_t, HDR32>(
+    RenderAlgorithm, const GPUPerturbResults<uint32_t, HDR32, PerturbExtras::Bad> *,
+    const GPUPerturbResults<uint32_t, float, PerturbExtras::Bad> *, HDR32, HDR32, HDR32, HDR32, HDR32, HDR32, uint32_t, int);
 template uint32_t GPURenderer::InitializeMemory<uint64_t>(uint32_t, uint32_t, uint32_t, const Color16 *, uint32_t,
                                                           uint32_t, uint64_t, bool);
 template void GPURenderer::ClearMemory<uint64_t>();

@@ -450,3 +450,28 @@ def test_uint64_itertype_matches_uint32(renderer, v5_small):
     assert r.InitializePerturb(0, ob, 0, None, big, iter_bytes=8) == 10100
     assert r.RenderPerturbLAv2(None, None, None, dx, dy, cx, cy, 1 << 32, Mode=LAV2_FULL) == 10100
     assert r.InitializeMemory(64, 36, 1, None, 0, 0, 0, False, iter_bytes=4) == 0
+
+
+# ---- scaled perturbation (GpuHDRx32PerturbedScaled): no CPU twin; checker = restated CUDA kernel, parity unpinned
+def test_scaled_hdr32_matches_restated_cuda_kernel(renderer, v5_small):
+    v, ob, _, _ = v5_small
+    r = renderer
+    assert r.InitializeMemory(64, 36, 1, None, 0, 0, 0, False) == 0
+    assert r.ClearMemory() == 0
+    dx, dy, cx, cy = _pairs(v.coords_perturb(ob))
+    r.enable_step_count(True)
+    assert r.RenderPerturbBLAScaled(None, ob, ob, None, None, dx, dy, cx, cy, v.num_iterations) == 0
+    out = r.new_iter_buffer()
+    assert r.RenderCurrent(v.num_iterations, out) == 0
+    assert r.SyncComputeStream() == 0
+    st = r.read_step_count()
+    r.enable_step_count(False)
+    ref, rst = _oracle.gpu_scaled_hdr32(v, ob, stats=True)
+    assert np.array_equal(out, ref)
+    # same work: rescales / full-precision steps / binary32 steps
+    assert (st["at_iterations"], st["la_steps"], st["perturb_steps"]) == (rst["rescales"], rst["full_steps"],
+                                                                         rst["float_steps"])
+    # and it is the same picture as the HDRFloat<float> perturbation path up to binary32 glitches
+    hdr = _oracle.bla_hdr32(v, ob, None)
+    d = np.abs(out[:36, :64].astype(np.int64) - hdr[:36, :64].astype(np.int64))
+    assert (d <= 2).mean() > 0.3 and np.median(d) <= 4
