@@ -168,6 +168,11 @@ void fsk_lav2_hdr32(const FsLav2Args32 &A, int mode, bool stats, int variant, hi
 void fsk_lav2_hdr64(const FsLav2ArgsT<double> &A, int mode, bool stats, hipStream_t s);
 void fsk_lav2_2x32(const FsLav2Args2x32 &A, int mode, bool stats, hipStream_t s);
 void fsk_scaled_hdr32(const FsScaledArgs32 &A, bool stats, hipStream_t s);
+// BLA table build on the device: levels[l] = device memory for epl[l] records (NULL below the first materialised level 2)
+void fsk_bla_build_hdr32(const float4 *zref, void *const *levels, const uint64_t *epl, int n_levels, fs_real_hdr32 bla_size,
+                         hipStream_t s);
+void fsk_bla_build_hdr64(const FsZ64 *zref, void *const *levels, const uint64_t *epl, int n_levels, fs_real_hdr64 bla_size,
+                         hipStream_t s);
 void fsk_perturb_scalar_hdr32(const FsBlaArgs32 &A, bool use_bla, bool stats, hipStream_t s);
 void fsk_perturb_scalar_hdr64(const FsBlaArgsT<double> &A, bool use_bla, bool stats, hipStream_t s);
 void fsk_perturb_bla_f64(const FsBlaArgsF64 &A, bool use_bla, bool stats, hipStream_t s);

@@ -1,0 +1,178 @@
+// kernels_tables.hip -- BLA table construction on the device.
+//
+// Replaces the host-side BLAS<IterType,T>::Init (FractalSharkLib/BLAS.cpp:212-255), which the reference re-runs on the
+// CPU for every BLA render (Fractal.cpp:2739-2740) and then copies to the GPU.  Here the table is built in HBM straight
+// from the uploaded orbit and never crosses PCIe.  Results are bit-identical to the host builder
+// (fractalshark_amd/host/refinputs.cpp BlaBuilder, itself pinned through the golden CRCs of the Cpu*PerturbedBLAHDR
+// algorithms): same operations in the same order, -ffp-contract=off, correctly rounded sqrt and divide.
+//
+//   first materialised level (m_FirstLevel = 2, BLAS.h:22): element m = CreateLStep(2, m) (BLAS.cpp:49-72) = the merge
+//       tree over up to four single-step records CreateOneStep (BLAS.cpp:74-93) -- one lane per element;
+//   every further level: element k = MergeTwoBlas(src[2k], src[2k+1]) or a copy of src[2k] at a ragged end
+//       (BLAS.cpp:141-210) -- one lane per element, one launch per level (log2(orbit) launches, each at least halving).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fs_layout.h"
+#include "hdr_math.hpp"
+#include "kernels.h"
+
+using namespace fs;
+
+namespace {
+
+template <class F> struct Rec {
+    hreal<F> r2, Ax, Ay, Bx, By;
+    int32_t l;
+};
+
+template <class F> __device__ __forceinline__ F sqrt_rn(F v);
+template <> __device__ __forceinline__ float sqrt_rn<float>(float v) { return __builtin_sqrtf(v); }
+template <> __device__ __forceinline__ double sqrt_rn<double>(double v) { return __builtin_sqrt(v); }
+
+// HdrSqrt, HDRFloat.h:1358-1383
+template <class F> __device__ __forceinline__ hreal<F> hsqrt(hreal<F> a)
+{
+    const bool odd = (a.e & 1) != 0;
+    return hreal<F>{sqrt_rn<F>(odd ? F(2) * a.m : a.m), odd ? (a.e - 1) / 2 : a.e / 2};
+}
+
+// BLA<T>::hypotA / hypotB, BLA.cuh:40-56
+template <class F> __device__ __forceinline__ hreal<F> hypot2(hreal<F> a, hreal<F> b)
+{
+    return hr_reduced(hsqrt(hr_add(hr_mul(a, a), hr_mul(b, b))));
+}
+
+__device__ __forceinline__ hcplx<float> zat(const float4 *__restrict__ z, uint32_t i)
+{
+    const float4 v = z[i];
+    return hcplx<float>{v.x, v.y, __float_as_int(v.z)};
+}
+__device__ __forceinline__ hcplx<double> zat(const FsZ64 *__restrict__ z, uint32_t i)
+{
+    return hcplx<double>{z[i].re, z[i].im, z[i].e};
+}
+
+// BLAS::CreateOneStep, BLAS.cpp:74-93
+template <class F, class Z> __device__ __forceinline__ Rec<F> one_step(const Z *__restrict__ zref, uint32_t m, hreal<F> epsilon)
+{
+    const hcplx<F> z = zat(zref, m);
+    const hreal<F> RealA = hr_mul2(hc_re(z));
+    const hreal<F> ImagA = hr_mul2(hc_im(z));
+    const hreal<F> mA = hsqrt(hr_add(hr_mul(RealA, RealA), hr_mul(ImagA, ImagA)));
+    const hreal<F> r = hr_mul(mA, epsilon);
+    return Rec<F>{hr_mul(r, r), RealA, ImagA, hr_from_number<F>(F(1)), hr_from_number<F>(F(0)), 1};
+}
+
+// BLAS::MergeTwoBlas, BLAS.cpp:25-47 with BLA::getNewA / getNewB, BLA.cuh:65-91
+template <class F> __device__ __forceinline__ Rec<F> merge(const Rec<F> &x, const Rec<F> &y, hreal<F> blaSize)
+{
+    Rec<F> o;
+    o.l = x.l + y.l;
+    o.Ax = hr_reduced(hr_sub(hr_mul(y.Ax, x.Ax), hr_mul(y.Ay, x.Ay)));
+    o.Ay = hr_reduced(hr_add(hr_mul(y.Ax, x.Ay), hr_mul(y.Ay, x.Ax)));
+    o.Bx = hr_reduced(hr_add(hr_sub(hr_mul(y.Ax, x.Bx), hr_mul(y.Ay, x.By)), y.Bx));
+    o.By = hr_reduced(hr_add(hr_add(hr_mul(y.Ax, x.By), hr_mul(y.Ay, x.Bx)), y.By));
+    const hreal<F> xA = hypot2(x.Ax, x.Ay);
+    const hreal<F> xB = hypot2(x.Bx, x.By);
+    const hreal<F> tempR = hr_reduced(hr_div(hr_sub(hsqrt(y.r2), hr_mul(xB, blaSize)), xA));
+    const hreal<F> zero = hr_from_number<F>(F(0));
+    const hreal<F> mx = hr_cmp(zero, tempR) > 0 ? zero : tempR; // HdrMaxReduced(T(0), tempR)
+    const hreal<F> sx = hsqrt(x.r2);
+    const hreal<F> r = hr_cmp_pos(sx, mx) < 0 ? sx : mx; // HdrMinPositiveReduced
+    o.r2 = hr_mul(r, r);
+    return o;
+}
+
+template <class F> __device__ __forceinline__ Rec<F> ld_rec(const typename FsDev<F>::BLA &b)
+{
+    return Rec<F>{hreal<F>{b.r2.m, b.r2.e}, hreal<F>{b.Ax.m, b.Ax.e}, hreal<F>{b.Ay.m, b.Ay.e}, hreal<F>{b.Bx.m, b.Bx.e},
+                  hreal<F>{b.By.m, b.By.e}, b.l};
+}
+template <class F> __device__ __forceinline__ void st_rec(typename FsDev<F>::BLA *dst, const Rec<F> &s)
+{
+    typename FsDev<F>::BLA o;
+    memset(&o, 0, sizeof(o)); // the double record has padding: keep it deterministic
+    o.r2.m = s.r2.m, o.r2.e = s.r2.e;
+    o.Ax.m = s.Ax.m, o.Ax.e = s.Ax.e;
+    o.Ay.m = s.Ay.m, o.Ay.e = s.Ay.e;
+    o.Bx.m = s.Bx.m, o.Bx.e = s.Bx.e;
+    o.By.m = s.By.m, o.By.e = s.By.e;
+    o.l = s.l;
+    *dst = o;
+}
+
+// level-1 element k (1-based), BLAS::CreateLStep(1, k)
+template <class F, class Z>
+__device__ __forceinline__ Rec<F> level1(const Z *__restrict__ zref, uint64_t k, uint64_t epl0, hreal<F> blaSize, hreal<F> eps)
+{
+    const uint64_t m2 = k << 1;
+    const Rec<F> x = one_step<F>(zref, (uint32_t)(m2 - 1), eps);
+    if (m2 <= epl0)
+        return merge(x, one_step<F>(zref, (uint32_t)m2, eps), blaSize);
+    return x;
+}
+
+// first materialised level: dst[m-1] = CreateLStep(2, m), m = 1..n
+template <class F, class Z>
+__global__ void __launch_bounds__(256) k_bla_first_level(const Z *__restrict__ zref, typename FsDev<F>::BLA *__restrict__ dst,
+                                                         uint64_t n, uint64_t epl0, uint64_t epl1, hreal<F> blaSize,
+                                                         hreal<F> eps)
+{
+    const uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + 1;
+    if (m > n)
+        return;
+    const uint64_t m2 = m << 1;
+    Rec<F> x = level1<F>(zref, m2 - 1, epl0, blaSize, eps);
+    if (m2 <= epl1)
+        x = merge(x, level1<F>(zref, m2, epl0, blaSize, eps), blaSize);
+    st_rec<F>(&dst[m - 1], x);
+}
+
+// BLAS::Merge, BLAS.cpp:141-210: dst[k] = merge(src[2k], src[2k+1]) or src[2k] at the ragged end
+template <class F>
+__global__ void __launch_bounds__(256) k_bla_merge(const typename FsDev<F>::BLA *__restrict__ src, uint64_t n_src,
+                                                   typename FsDev<F>::BLA *__restrict__ dst, uint64_t n_dst, hreal<F> blaSize)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_dst)
+        return;
+    const uint64_t mx = k << 1, my = mx + 1;
+    if (my < n_src)
+        st_rec<F>(&dst[k], merge(ld_rec<F>(src[mx]), ld_rec<F>(src[my]), blaSize));
+    else
+        dst[k] = src[mx];
+}
+
+} // namespace
+
+template <class F, class Z>
+static void build_levels(const Z *zref, void *const *levels, const uint64_t *epl, int n_levels, hreal<F> blaSize,
+                         hipStream_t s)
+{
+    using B = typename FsDev<F>::BLA;
+    // T(1) / T{1L << 23}: templated ctor for the int, HDRFloat(T mant) for the scalar (BLAS.cpp:216)
+    const hreal<F> eps = hr_div(hr_from_number<F>(F(1)), hr_from_mant<F>(F(8388608)));
+    const int first = 2;
+    if (n_levels <= first)
+        return;
+    const uint64_t n = epl[first];
+    hipLaunchKernelGGL((k_bla_first_level<F, Z>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, zref, (B *)levels[first],
+                       n, epl[0], epl[1], blaSize, eps);
+    for (int src = first; src + 1 < n_levels && epl[src] > 1; src++) {
+        const uint64_t nd = epl[src + 1];
+        hipLaunchKernelGGL((k_bla_merge<F>), dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, s, (const B *)levels[src],
+                           epl[src], (B *)levels[src + 1], nd, blaSize);
+    }
+}
+
+void fsk_bla_build_hdr32(const float4 *zref, void *const *levels, const uint64_t *epl, int n_levels, fs_real_hdr32 bla_size,
+                         hipStream_t s)
+{
+    build_levels<float>(zref, levels, epl, n_levels, hreal<float>{bla_size.m, bla_size.e}, s);
+}
+void fsk_bla_build_hdr64(const FsZ64 *zref, void *const *levels, const uint64_t *epl, int n_levels, fs_real_hdr64 bla_size,
+                         hipStream_t s)
+{
+    build_levels<double>(zref, levels, epl, n_levels, hreal<double>{bla_size.m, bla_size.e}, s);
+}

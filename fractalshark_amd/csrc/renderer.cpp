@@ -81,6 +81,7 @@ struct fs_renderer {
 
     // BLA table
     std::vector<void *> bla_level_mem;
+    std::vector<uint64_t> bla_level_sizes;
     const void **bla_levels_dev = nullptr;
     int bla_type = -1;
     int32_t bla_n_levels = 0, bla_lm2 = 0;
@@ -709,6 +710,7 @@ uint32_t fs_upload_bla(fs_renderer *r, int type_tag, const void *const *levels, 
         if (p)
             hipFree(p);
     r->bla_level_mem.clear();
+    r->bla_level_sizes.clear();
     if (r->bla_levels_dev) {
         hipFree((void *)r->bla_levels_dev);
         r->bla_levels_dev = nullptr;
@@ -724,6 +726,7 @@ uint32_t fs_upload_bla(fs_renderer *r, int type_tag, const void *const *levels, 
             FS_TRY(hipMemcpyAsync(d, levels[l], level_sizes[l] * rec_bytes, hipMemcpyDefault, r->compute));
         }
         r->bla_level_mem.push_back(d);
+        r->bla_level_sizes.push_back(d ? level_sizes[l] : 0);
         ptrs[l] = d;
     }
     FS_TRY(hipMalloc((void **)&r->bla_levels_dev, sizeof(void *) * (size_t)n_levels));
@@ -733,6 +736,84 @@ uint32_t fs_upload_bla(fs_renderer *r, int type_tag, const void *const *levels, 
     r->bla_n_levels = n_levels;
     r->bla_lm2 = lm2;
     return 0;
+}
+
+uint32_t fs_build_bla(fs_renderer *r, int type_tag, const void *bla_size)
+{
+    if (uint32_t e = use_device(r))
+        return e;
+    if (type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64)
+        return FS_ERR_UNSUPPORTED;
+    if (!r->compute || !r->orbit_ok || r->orbit_type != type_tag)
+        return FS_ERR_6;
+    const size_t rec_bytes = type_tag == FS_T_HDR32 ? sizeof(fs_bla_hdr32) : sizeof(fs_bla_hdr64);
+    for (void *p : r->bla_level_mem)
+        if (p)
+            (void)hipFree(p);
+    r->bla_level_mem.clear();
+    r->bla_level_sizes.clear();
+    if (r->bla_levels_dev) {
+        (void)hipFree((void *)r->bla_levels_dev);
+        r->bla_levels_dev = nullptr;
+    }
+    r->bla_n_levels = 0;
+    r->bla_type = type_tag;
+    // BLAS::Init, BLAS.cpp:218-241: elements per level halve (rounding up) from count-1 down to 1
+    const uint64_t InM = r->orbit_uncompressed;
+    uint64_t m = InM ? InM - 1 : 0;
+    if (InM == 0 || m == 0)
+        return 0;
+    std::vector<uint64_t> epl;
+    for (; m > 1; m = (m + 1) >> 1)
+        epl.push_back(m);
+    epl.push_back(m);
+    const int n_levels = (int)epl.size();
+    int32_t lm2 = n_levels - 2;
+    if (lm2 < 0)
+        lm2 = 0;
+    std::vector<void *> ptrs((size_t)n_levels, nullptr);
+    std::vector<uint64_t> sizes((size_t)n_levels, 0);
+    for (int l = 2; l < n_levels; l++) { // m_FirstLevel = 2: levels 0 and 1 are never materialised
+        FS_TRY(hipMalloc(&ptrs[l], epl[l] * rec_bytes));
+        sizes[l] = epl[l];
+    }
+    r->bla_level_mem = ptrs;
+    r->bla_level_sizes = sizes;
+    FS_TRY(hipMalloc((void **)&r->bla_levels_dev, sizeof(void *) * (size_t)n_levels));
+    FS_TRY(hipMemcpyAsync((void *)r->bla_levels_dev, ptrs.data(), sizeof(void *) * (size_t)n_levels, hipMemcpyDefault,
+                          r->compute));
+    {
+        TimedLaunch t(r);
+        if (type_tag == FS_T_HDR32)
+            fsk_bla_build_hdr32(r->zref, ptrs.data(), epl.data(), n_levels, *(const fs_real_hdr32 *)bla_size, r->compute);
+        else
+            fsk_bla_build_hdr64(r->zref64, ptrs.data(), epl.data(), n_levels, *(const fs_real_hdr64 *)bla_size, r->compute);
+    }
+    FS_TRY(hipGetLastError());
+    FS_TRY(hipStreamSynchronize(r->compute)); // ptrs / epl are host temporaries of this call
+    r->bla_n_levels = n_levels;
+    r->bla_lm2 = lm2;
+    return 0;
+}
+
+int32_t fs_bla_num_levels(const fs_renderer *r) { return r->bla_n_levels; }
+int32_t fs_bla_lm2(const fs_renderer *r) { return r->bla_lm2; }
+uint64_t fs_bla_level_size(const fs_renderer *r, int32_t level)
+{
+    return level >= 0 && (size_t)level < r->bla_level_sizes.size() ? r->bla_level_sizes[(size_t)level] : 0;
+}
+uint32_t fs_read_bla_level(fs_renderer *r, int32_t level, void *out, uint64_t max_records)
+{
+    if (uint32_t e = use_device(r))
+        return e;
+    if (level < 0 || (size_t)level >= r->bla_level_mem.size())
+        return FS_ERR_7;
+    const size_t rec_bytes = r->bla_type == FS_T_HDR32 ? sizeof(fs_bla_hdr32)
+                                                       : (r->bla_type == FS_T_HDR64 ? sizeof(fs_bla_hdr64) : sizeof(fs_bla_f64));
+    const uint64_t n = r->bla_level_sizes[(size_t)level] < max_records ? r->bla_level_sizes[(size_t)level] : max_records;
+    if (n && r->bla_level_mem[(size_t)level])
+        FS_TRY(hipMemcpyAsync(out, r->bla_level_mem[(size_t)level], n * rec_bytes, hipMemcpyDefault, r->compute));
+    return (uint32_t)hipStreamSynchronize(r->compute);
 }
 
 uint32_t fs_render_bla(fs_renderer *r, int type_tag, const void *coords, uint64_t n_iterations);

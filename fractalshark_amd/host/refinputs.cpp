@@ -611,6 +611,12 @@ extern "C" uint64_t fsh_orbit_bad_count(const fsh_orbit *o)
     return n;
 }
 
+extern "C" void fsh_orbit_max_radius_hdr64(const fsh_orbit *o, fs_real_hdr64 *out)
+{
+    out->m = o->d.maxRadius.m;
+    out->e = o->d.maxRadius.e;
+    out->pad_ = 0;
+}
 extern "C" void fsh_orbit_max_radius_hdr32(const fsh_orbit *o, fs_real_hdr32 *out)
 {
     out->m = o->f.maxRadius.m;

@@ -165,6 +165,13 @@ class Orbit:
         (self._lib.fsh_orbit_low_hdr64 if self.is64 else self._lib.fsh_orbit_low_hdr32)(self._h, out.ctypes.data)
         return out
 
+    def max_radius(self):
+        """PerturbationResults::GetMaxRadius() as an ABI record (the blaSize argument of BLAS::Init)."""
+        out = np.zeros(1, REAL_HDR64 if self.is64 else REAL_HDR32)
+        (self._lib.fsh_orbit_max_radius_hdr64 if self.is64 else self._lib.fsh_orbit_max_radius_hdr32)(
+            self._h, out.ctypes.data)
+        return out
+
     # PerturbExtras::Bad form (scaled kernels): the HDRFloat<float> orbit with its flags + its binary32 copy
     @property
     def bad_data_ptr(self):
@@ -353,6 +360,16 @@ class BLATable:
     def sizes(self):
         buf = (C.c_uint64 * self.num_levels).from_address(self.level_sizes)
         return list(buf)
+
+    def level(self, l):
+        """Records of level l as raw bytes (n, 44) / (n, 88)."""
+        n = self.sizes()[l]
+        rec = 88 if self.is64 else 44
+        if n == 0:
+            return np.zeros((0, rec), np.uint8)
+        ptrs = (C.c_void_p * self.num_levels).from_address(self.level_ptrs)
+        buf = (C.c_uint8 * (n * rec)).from_address(ptrs[l])
+        return np.frombuffer(buf, dtype=np.uint8).reshape(n, rec).copy()
 
 
 class OrbitF64:

@@ -171,6 +171,26 @@ class GPURenderer:
         co = self._pack_coords(T, [dx, dy, centerX, centerY])
         return self._lib.fs_render_scaled(self._h, T, co.ctypes.data, int(n_iterations))
 
+    def BuildBLAOnDevice(self, orbit, T=None):
+        """BLAS::Init(count, maxRadius) on the device for the orbit last uploaded (fs_build_bla): the table stays in HBM."""
+        if T is None:
+            T = T_HDR64 if orbit.is64 else T_HDR32
+        mr = orbit.max_radius()
+        return self._lib.fs_build_bla(self._h, T, mr.ctypes.data)
+
+    def read_bla_levels(self, is64=False):
+        """Device-resident BLA table -> list of (n, 44|88) uint8 arrays per level (tests / tools)."""
+        rec = 88 if is64 else 44
+        out = []
+        for l in range(self._lib.fs_bla_num_levels(self._h)):
+            n = self._lib.fs_bla_level_size(self._h, l)
+            a = np.zeros((n, rec), np.uint8)
+            err = self._lib.fs_read_bla_level(self._h, l, a.ctypes.data if n else None, n)
+            if err:
+                raise RuntimeError(self.ConvertErrorToString(err))
+            out.append(a)
+        return out
+
     def Render(self, algorithm, cx, cy, dx, dy, n_iterations, iteration_precision=1, T=T_F64):
         """Direct kernels.  cx = minX, cy = maxY (Fractal.cpp:1894-1915 passes the view corner).  For T_F64 the
         arguments are doubles, for T_HDR32 / T_HDR64 (mantissa, exp) pairs of the un-reduced HDRFloat values."""

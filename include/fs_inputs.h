@@ -58,6 +58,7 @@ uint64_t fsh_orbit_period(const fsh_orbit *o); /* GetPeriodMaybeZero() */
 const fs_orbit_hdr32 *fsh_orbit_data_hdr32(fsh_orbit *o);
 const fs_orbit_hdr64 *fsh_orbit_data_hdr64(fsh_orbit *o);
 void fsh_orbit_max_radius_hdr32(const fsh_orbit *o, fs_real_hdr32 *out);
+void fsh_orbit_max_radius_hdr64(const fsh_orbit *o, fs_real_hdr64 *out);
 /* PerturbExtras::Bad form of an hdr32 orbit + its binary32 copy (inputs of RenderPerturbBLAScaled). */
 const fs_orbit_hdr32_bad *fsh_orbit_data_hdr32_bad(fsh_orbit *o);
 const fs_orbit_f32_bad *fsh_orbit_data_f32_bad(fsh_orbit *o);

@@ -124,6 +124,19 @@ uint32_t fs_upload_la(fs_renderer *r, uint64_t generation, int type_tag, uint32_
 uint32_t fs_upload_bla(fs_renderer *r, int type_tag, const void *const *levels, const uint64_t *level_sizes,
                        int32_t n_levels, int32_t lm2);
 
+/* BLAS<IterType,T>::Init(count, blaSize) (FractalSharkLib/BLAS.cpp:212-255) executed on the device instead of the host:
+ * builds the BLA table of the orbit last uploaded with fs_upload_orbit (type_tag FS_T_HDR32 / FS_T_HDR64) directly in
+ * HBM and installs it as the renderer's table, bit-identical to the host builder.  bla_size = the orbit's max radius
+ * (fs_real_hdr32 / fs_real_hdr64, PerturbationResults::GetMaxRadius, Fractal.cpp:2739-2740).  Asynchronous on the compute
+ * stream.  The reference rebuilds this table on the CPU and copies it over PCIe on every BLA render. */
+uint32_t fs_build_bla(fs_renderer *r, int type_tag, const void *bla_size);
+/* Table geometry / contents after fs_build_bla or fs_upload_bla (tests, tools): number of levels (m_B.size()), m_LM2,
+ * records per level; fs_read_bla_level copies one level to the host (synchronises the compute stream). */
+int32_t fs_bla_num_levels(const fs_renderer *r);
+int32_t fs_bla_lm2(const fs_renderer *r);
+uint64_t fs_bla_level_size(const fs_renderer *r, int32_t level);
+uint32_t fs_read_bla_level(fs_renderer *r, int32_t level, void *out, uint64_t max_records);
+
 /* GPURenderer::RenderPerturbLAv2<IterType,T,SubType,Mode,PExtras> (GPU_Render.cu:995-1188).
  * coords = {dx, dy, centerX, centerY} in the type selected by type_tag (fs_real_hdr32[4] for FS_T_HDR32).
  * Asynchronous on the compute stream. */

@@ -475,3 +475,29 @@ def test_scaled_hdr32_matches_restated_cuda_kernel(renderer, v5_small):
     hdr = _oracle.bla_hdr32(v, ob, None)
     d = np.abs(out[:36, :64].astype(np.int64) - hdr[:36, :64].astype(np.int64))
     assert (d <= 2).mean() > 0.3 and np.median(d) <= 4
+
+
+# ---- BLA table built on the device (BLAS::Init) == the golden-pinned host builder, bit for bit
+@pytest.mark.parametrize("view_n,is64", [(5, False), (19, False), (5, True)])
+def test_bla_table_built_on_device_equals_host_builder(renderer, native_libs, view_n, is64):
+    v = inputs.View.builtin(view_n, 64, 36, antialiasing=1)
+    ob = inputs.Orbit(v, is64=is64)
+    host = inputs.BLATable(ob)
+    r = renderer
+    T = T_HDR64 if is64 else T_HDR32
+    assert r.InitializeMemory(64, 36, 1, None, 0, 0, 0, False) == 0
+    assert r._lib.fs_upload_orbit(r._h, 0, T, 4, ob.data_ptr, ob.count, ob.count, ob.period) == 0
+    assert r.BuildBLAOnDevice(ob) == 0
+    assert r._lib.fs_bla_num_levels(r._h) == host.num_levels and r._lib.fs_bla_lm2(r._h) == host.lm2
+    dev = r.read_bla_levels(is64)
+    assert [len(a) for a in dev] == host.sizes()
+    for l, a in enumerate(dev):
+        assert np.array_equal(a, host.level(l)), "level %d differs" % l
+    # and a render with the device-built table is the oracle's render
+    co = v.coords_perturb(ob)
+    assert r.ClearMemory() == 0
+    assert r._lib.fs_render_bla(r._h, T, co.ctypes.data, v.num_iterations) == 0
+    out = r.new_iter_buffer()
+    assert r.RenderCurrent(v.num_iterations, out) == 0
+    assert r.SyncComputeStream() == 0
+    assert np.array_equal(out, _oracle.bla_hdr32(v, ob, host))
