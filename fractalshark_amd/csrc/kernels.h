@@ -63,6 +63,7 @@ using FsCoords32 = FsCoordsT<float>;
 template <class F> struct FsLav2ArgsT {
     uint32_t *out;
     const typename FsDev<F>::Z *zref; // prepared orbit
+    const float4 *zq;                 // tuned HDRFloat<float> loop only: {re, im, ~exp | poison, -} (k_make_quiet_orbit)
     const typename FsDev<F>::LA *las;
     const fs_la_stage_u32 *stages;
     uint64_t *stats;
@@ -164,6 +165,7 @@ void fsk_decompress_orbit_hdr32(const fs_orbit_hdr32_rc *wp, uint64_t n_wp, uint
 void fsk_decompress_orbit_hdr64(const fs_orbit_hdr64_rc *wp, uint64_t n_wp, uint64_t n_uncompressed, fs_real_hdr64 cxLow,
                                 fs_real_hdr64 cyLow, FsZ64 *out, hipStream_t s);
 void fsk_prepare_orbit_hdr64(const fs_orbit_hdr64 *in, FsZ64 *out, uint64_t n, hipStream_t s);
+void fsk_make_quiet_orbit(const float4 *zref, float4 *zq, uint64_t n, hipStream_t s);
 void fsk_lav2_hdr32(const FsLav2Args32 &A, int mode, bool stats, int variant, hipStream_t s);
 void fsk_lav2_hdr64(const FsLav2ArgsT<double> &A, int mode, bool stats, hipStream_t s);
 void fsk_lav2_2x32(const FsLav2Args2x32 &A, int mode, bool stats, hipStream_t s);

@@ -68,6 +68,18 @@ __global__ void k_prepare_orbit_hdr32(const fs_orbit_hdr32 *__restrict__ in, flo
     out[i] = make_float4(c.re, c.im, __int_as_float(c.e), ldexpf(1.0f, 8 - 2 * (c.e < -1000 ? -1000 : c.e)));
 }
 
+// Companion array of the tuned LAv2 loop: {re, im, s, -} with s = ~exp (so that -s = exp + 1 = the exponent of 2Z) for
+// orbit values below 8, and a large positive poison for larger ones, which makes the loop's range test fail there.
+__global__ void k_make_quiet_orbit(const float4 *__restrict__ zref, float4 *__restrict__ zq, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const float4 v = zref[i];
+    const int e = __float_as_int(v.z);
+    zq[i] = make_float4(v.x, v.y, __int_as_float(e <= 2 ? ~e : (1 << 24)), 0.0f);
+}
+
 // ------------------------------------------------------------------------------------------------
 // LAv2, T = HDRFloat<float>.  CPU twin: Fractal::CalcCpuPerturbationFractalLAV2<uint32_t,float,Disable>
 // (Fractal.cpp:2545-2678) with LAReference::getLA / isLAStageInvalid (LAReference.cpp:1076-1134),
@@ -353,7 +365,6 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
             const f2 dcm = {dc.re, dc.im};
             const int dce = dc.e;
             f2 Zcm = {Zc.re, Zc.im};
-            int Zce1 = Zc.e + 1; // exponent of 2Z
             // One speculative straight-line step from (dzm, dze, Zcm, Zce1) against the orbit entry zv.
             // n* = NEGATED exponent gaps (<= 0 when the assumption holds).
 #define FS_LAV2_STEP_HEAD()                                                                                         \
@@ -381,6 +392,9 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
     const bool ok_core = imax(imax(nd1, nd3), nd2) <= 0 && (nd1 < nd3 ? nd1 : nd3) > -kExpDiffIgnored &&            \
                          (unsigned)(fmax - 1) < 254u /* larger part of q: non-zero, finite, normal */
 
+            // Quiet-run state: sC = ~(exponent of Zc) for an orbit value below 8, a large positive poison otherwise
+            // (zq[i].z, written by k_make_quiet_orbit), so that 2Z's exponent is -sC and every use below is one add.
+            const float4 *__restrict__ zq = A.zq;
             while (running) {
                 // ---- run of "quiet" steps: when dz is at least 2^4 below the orbit value and the orbit value is < 8,
                 // neither exit test can fire and z itself is not needed:
@@ -389,33 +403,88 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                 //   => |z| > 1.8 |dz|  (no rebase: Reduce(|z|^2) < Reduce(|dz|^2) is false with a 3x margin in the squares)
                 //   => |z| < 12.1 for Zne <= 2 (no escape: |z|^2 > 256 is false with a 1.7x margin)
                 // float rounding moves these norms by < 1e-6 relative, so the CPU function takes the same decisions.
-                // The run continues while EVERY running lane of the wave is quiet; `left` keeps a lane away from the
-                // orbit end and from its iteration limit (both need the careful step below).
+                // The run continues while EVERY running lane of the wave is quiet.  The conditions are *sufficient*
+                // ones (a lane that fails them takes the careful step below, which decides exactly):
+                //   t1 = max(nd1, nd2, nd3 + 4) <= 0   (orbit bigger than dz / p bigger than dc / dz' 2^4 below Z')
+                //   t2 = min(nd1, nd3 + 4) >= -115      (both alignment gaps inside the reference's 120 window)
+                //   larger part of q a finite normal float; orbit value below 8 (poisoned sN fails t1 otherwise).
+                // A lane must also stay clear of the orbit end and of its iteration limit (`left`); runs are cut into
+                // chunks of 64 steps so that this is a per-chunk wave vote instead of a per-step, per-lane counter.
+#define FS_QUIET_HEAD()                                                                                             \
+    const f2 Znm = {zx2.x, zx2.y};                                                                                  \
+    const int nd1 = dze + sC;                                                                                       \
+    const int pe = imax(dze - sC, kMinBigExp);                                                                      \
+    const f2 cur = Zcm + dzm * __int_as_float((nd1 << 23) + 0x3F800000);                                            \
+    const f2 pa = dzm.xx * cur;                                                                                     \
+    const f2 pb = dzm.yy * cur.yx;                                                                                  \
+    f2 p;                                                                                                           \
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(p) : "v"(pa), "v"(pb));                          \
+    const int nd2 = dce - pe;                                                                                       \
+    const float m2 = nd2 > -kExpDiffIgnored ? __int_as_float((nd2 << 23) + 0x3F800000) : 0.0f;                      \
+    const f2 q = p + dcm * m2;                                                                                      \
+    const int fmax = imax((int)__builtin_amdgcn_ubfe(__float_as_int(q.x), 23, 8),                                   \
+                          (int)__builtin_amdgcn_ubfe(__float_as_int(q.y), 23, 8));                                  \
+    const int qe = pe + fmax - 127;                                                                                 \
+    const int nd3p4 = qe + sN + 5; /* = qe - Zne + 4 */                                                             \
+    const int t1 = imax(imax(nd1, nd2), nd3p4);                                                                     \
+    const int t2 = nd1 < nd3p4 ? nd1 : nd3p4;                                                                       \
+    const uint64_t viol = __builtin_amdgcn_ballot_w64(t1 > 0) | __builtin_amdgcn_ballot_w64(t2 < -115) |            \
+                          __builtin_amdgcn_ballot_w64((unsigned)(fmax - 1) >= 254u)
+#define FS_QUIET_COMMIT()                                                                                           \
+    dzm = q * __int_as_float(__mul24(fmax, -8388608) + 0x7F000000); /* 2^(127 - fmax) */                            \
+    dze = qe;                                                                                                       \
+    Zcm = Znm;                                                                                                      \
+    sC = sN;                                                                                                        \
+    zp++
                 {
-                    const uint32_t left_ref = ref + 1 < MaxRefIteration ? MaxRefIteration - 1 - ref : 0u;
-                    const uint32_t left_it = n_iterations - 1 - iterations; // running => iterations < n_iterations
-                    uint32_t left = left_ref < left_it ? left_ref : left_it;
-                    const float4 *zp = zr + ref + 1;
+                    int sC = __float_as_int(zq[ref].z);
+                    const float4 *zp = zq + ref + 1;
                     uint32_t done = 0;
                     for (;;) {
-                        const float4 zv = *zp;
-                        FS_LAV2_STEP_HEAD();
-                        const bool quiet = ok_core && nd3 <= -4 && Zne <= 2 && left != 0;
-                        if (__builtin_amdgcn_ballot_w64(!quiet) != 0ull)
+                        const uint32_t r0 = ref + done, i0 = iterations + done;
+                        const uint32_t left_ref = r0 + 1 < MaxRefIteration ? MaxRefIteration - 1 - r0 : 0u;
+                        const uint32_t left_it = n_iterations - 1 - i0; // running => iterations < n_iterations
+                        uint32_t left = left_ref < left_it ? left_ref : left_it;
+                        bool stop = false;
+                        if (__builtin_amdgcn_ballot_w64(left < 64u) == 0ull) {
+                            // every running lane has at least 64 quiet-eligible steps ahead: no per-step counter
+                            uint32_t c = 0;
+                            for (; c < 64u; c++) {
+                                const int sN = __float_as_int(zp->z);
+                                const float2 zx2 = *reinterpret_cast<const float2 *>(zp);
+                                FS_QUIET_HEAD();
+                                if (viol != 0ull) {
+                                    stop = true;
+                                    break;
+                                }
+                                FS_QUIET_COMMIT();
+                            }
+                            done += c;
+                        } else {
+                            for (;;) {
+                                const int sN = __float_as_int(zp->z);
+                                const float2 zx2 = *reinterpret_cast<const float2 *>(zp);
+                                FS_QUIET_HEAD();
+                                if ((viol | __builtin_amdgcn_ballot_w64(left == 0u)) != 0ull)
+                                    break;
+                                FS_QUIET_COMMIT();
+                                left--;
+                                done++;
+                            }
+                            stop = true;
+                        }
+                        if (stop)
                             break;
-                        dzm = q;
-                        dze = qe;
-                        Zcm = Znm;
-                        Zce1 = Zne + 1;
-                        zp++;
-                        left--;
-                        done++;
                     }
                     ref += done;
                     iterations += done;
                     if (kStats)
                         c_pt += done;
                 }
+#undef FS_QUIET_HEAD
+#undef FS_QUIET_COMMIT
+                // the careful step works with the true exponent of Zc (sC may be the poison value)
+                int Zce1 = __float_as_int(zr[ref].z) + 1;
                 // ---- one careful step: full exit tests; generic CPU-order fallback when an assumption fails
                 const float4 zv = zr[ref + 1];
                 FS_LAV2_STEP_HEAD();
@@ -464,7 +533,6 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                 ref++;
                 dzm = q;
                 Zcm = Znm;
-                Zce1 = Zne + 1;
                 if (escaped) {
                     running = false; // `break` happens before iterations++ in the CPU loop
                 } else {
@@ -476,7 +544,6 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                         ref = 0;
                         const float4 z0 = zr[0];
                         Zcm = (f2){z0.x, z0.y};
-                        Zce1 = __float_as_int(z0.z) + 1;
                     }
                     iterations++;
                     running = iterations < n_iterations;
@@ -1104,6 +1171,11 @@ static dim3 frame_grid(const FsFrame &f) { return dim3((f.width + 63) / 64, (f.l
 void fsk_prepare_orbit_hdr32(const fs_orbit_hdr32 *in, float4 *out, uint64_t n, hipStream_t s)
 {
     hipLaunchKernelGGL(k_prepare_orbit_hdr32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n);
+}
+
+void fsk_make_quiet_orbit(const float4 *zref, float4 *zq, uint64_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_make_quiet_orbit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, zref, zq, n);
 }
 
 void fsk_lav2_hdr32(const FsLav2Args32 &A, int mode, bool stats, int variant, hipStream_t s)

@@ -63,6 +63,7 @@ struct fs_renderer {
     fs_orbit_f32_bad *scaled_f = nullptr;
     uint64_t scaled_count = 0;
     float4 *zref = nullptr;
+    float4 *zq = nullptr; // companion of zref for the tuned LAv2 loop
     FsZ64 *zref64 = nullptr;
     fs_orbit_f64 *orbit_f64 = nullptr; // plain double orbit (FS_T_F64), used as uploaded
     uint64_t orbit_size = 0, orbit_uncompressed = 0, orbit_period = 0;
@@ -133,6 +134,20 @@ FsFrame make_frame(const fs_renderer *r)
     return f;
 }
 
+// zq: the tuned LAv2 loop's view of the prepared orbit (same length incl. the two spare entries)
+hipError_t make_quiet_orbit(fs_renderer *r, uint64_t n)
+{
+    if (r->zq) {
+        (void)hipFree(r->zq);
+        r->zq = nullptr;
+    }
+    hipError_t err = hipMalloc((void **)&r->zq, (n + 2) * sizeof(float4));
+    if (err != hipSuccess)
+        return err;
+    fsk_make_quiet_orbit(r->zref, r->zq, n + 2, r->compute);
+    return hipGetLastError();
+}
+
 uint32_t ensure_iter_buffer(fs_renderer *r)
 {
     const size_t need = (size_t)r->w_block * 16u * r->local_rows_padded;
@@ -153,6 +168,9 @@ void free_perturb(fs_renderer *r)
 {
     if (r->zref)
         hipFree(r->zref);
+    if (r->zq)
+        hipFree(r->zq);
+    r->zq = nullptr;
     if (r->zref64)
         hipFree(r->zref64);
     if (r->orbit_f64)
@@ -526,6 +544,8 @@ uint32_t fs_upload_orbit(fs_renderer *r, uint64_t generation, int type_tag, uint
         if (type_tag == FS_T_HDR32) {
             err = hipMemsetAsync(r->zref + orbit_size, 0, 2 * sizeof(float4), r->compute);
             fsk_prepare_orbit_hdr32((const fs_orbit_hdr32 *)raw, r->zref, orbit_size, r->compute);
+            if (err == hipSuccess)
+                err = make_quiet_orbit(r, orbit_size);
         } else {
             err = hipMemsetAsync(r->zref64 + orbit_size, 0, 2 * sizeof(FsZ64), r->compute);
             fsk_prepare_orbit_hdr64((const fs_orbit_hdr64 *)raw, r->zref64, orbit_size, r->compute);
@@ -582,6 +602,8 @@ uint32_t fs_upload_orbit_compressed(fs_renderer *r, uint64_t generation, int typ
             fsk_decompress_orbit_hdr32((const fs_orbit_hdr32_rc *)raw, compressed_size, uncompressed_size,
                                        *(const fs_real_hdr32 *)orbit_x_low, *(const fs_real_hdr32 *)orbit_y_low, r->zref,
                                        r->compute);
+            if (err == hipSuccess)
+                err = make_quiet_orbit(r, uncompressed_size);
         } else {
             err = hipMemsetAsync(r->zref64 + uncompressed_size, 0, 2 * sizeof(FsZ64), r->compute);
             fsk_decompress_orbit_hdr64((const fs_orbit_hdr64_rc *)raw, compressed_size, uncompressed_size,
@@ -869,6 +891,7 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
         FsLav2ArgsT<float> A;
         fill_lav2<float>(r, A, coords, n_iterations, parity);
         A.zref = r->zref;
+        A.zq = r->zq;
         A.at = r->at;
         TimedLaunch t(r);
         fsk_lav2_hdr32(A, kmode, r->stats_on, r->variant, r->compute);
