@@ -248,6 +248,21 @@ __device__ __forceinline__ long long norm_key(float re, float im, int e)
     return ((long long)ee << 32) | (long long)(unsigned)mm;
 }
 
+__device__ __forceinline__ int imin3(int a, int b, int c)
+{
+    const int m = a < b ? a : b;
+    return m < c ? m : c;
+}
+
+// 0x7F000000 - (f << 23) = the bits of 2^(127 - f), as one v_mad_i32_i24 (f < 2^8)
+__device__ __forceinline__ int mad24_scale(int f)
+{
+    int r;
+    const int k = -8388608;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(k), "s"(0x7F000000));
+    return r;
+}
+
 // Same for a sum of squares already known to be a positive normal float (no zero special case).
 __device__ __forceinline__ long long norm_key_nz(float m, int e)
 {
@@ -427,11 +442,12 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
     const int qe = pe + fmax - 127;                                                                                 \
     const int nd3p4 = qe + sN + 5; /* = qe - Zne + 4 */                                                             \
     const int t1 = imax(imax(nd1, nd2), nd3p4);                                                                     \
-    const int t2 = nd1 < nd3p4 ? nd1 : nd3p4;                                                                       \
-    const uint64_t viol = __builtin_amdgcn_ballot_w64(t1 > 0) | __builtin_amdgcn_ballot_w64(t2 < -115) |            \
-                          __builtin_amdgcn_ballot_w64((unsigned)(fmax - 1) >= 254u)
+    /* fmax == 0 (q zero or denormal) fails t2 too; fmax == 255 needs an infinite input, which the bounded mantissas   \
+       of this loop cannot produce (|p| < 32) */                                                                    \
+    const int t2 = imin3(nd1, nd3p4, fmax - 116);                                                                   \
+    const uint64_t viol = __builtin_amdgcn_ballot_w64(t1 > 0) | __builtin_amdgcn_ballot_w64(t2 < -115)
 #define FS_QUIET_COMMIT()                                                                                           \
-    dzm = q * __int_as_float(__mul24(fmax, -8388608) + 0x7F000000); /* 2^(127 - fmax) */                            \
+    dzm = q * __int_as_float(mad24_scale(fmax)); /* 2^(127 - fmax) */                                               \
     dze = qe;                                                                                                       \
     Zcm = Znm;                                                                                                      \
     sC = sN;                                                                                                        \
