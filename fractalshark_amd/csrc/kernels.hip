@@ -248,6 +248,7 @@ __device__ __forceinline__ long long norm_key(float re, float im, int e)
     return ((long long)ee << 32) | (long long)(unsigned)mm;
 }
 
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imin3(int a, int b, int c)
 {
     const int m = a < b ? a : b;
@@ -428,17 +429,20 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
 #define FS_QUIET_HEAD()                                                                                             \
     const f2 Znm = {zx2.x, zx2.y};                                                                                  \
     const int nd1 = dze + sC;                                                                                       \
-    const int pe = imax(dze - sC, kMinBigExp);                                                                      \
+    /* no clamp at kMinBigExp: an exponent that far down fails t2 (nd1 >= -115 and sC < 2^10 bound pe below) */      \
+    const int pe = dze - sC;                                                                                        \
     const f2 cur = Zcm + dzm * __int_as_float((nd1 << 23) + 0x3F800000);                                            \
     const f2 pa = dzm.xx * cur;                                                                                     \
     const f2 pb = dzm.yy * cur.yx;                                                                                  \
     f2 p;                                                                                                           \
     asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(p) : "v"(pa), "v"(pb));                          \
     const int nd2 = dce - pe;                                                                                       \
-    const float m2 = nd2 > -kExpDiffIgnored ? __int_as_float((nd2 << 23) + 0x3F800000) : 0.0f;                      \
-    const f2 q = p + dcm * m2;                                                                                      \
-    const int fmax = imax((int)__builtin_amdgcn_ubfe(__float_as_int(q.x), 23, 8),                                   \
-                          (int)__builtin_amdgcn_ubfe(__float_as_int(q.y), 23, 8));                                  \
+    /* dc * 2^nd2 for nd2 > -120, 0 otherwise, as (dc * 2^7) * 2^(nd2 - 7): the clamped exponent field is 0 exactly at \
+       the cut-off, and both factors stay normal */                                                                 \
+    const float m2 = __int_as_float((imax(imin(nd2, 0), -kExpDiffIgnored) << 23) + (kExpDiffIgnored << 23));        \
+    const f2 q = p + dcm128 * m2;                                                                                   \
+    const int fmax = (int)__builtin_amdgcn_ubfe(__float_as_int(__builtin_fmaxf(__builtin_fabsf(q.x),                \
+                                                                               __builtin_fabsf(q.y))), 23, 8);      \
     const int qe = pe + fmax - 127;                                                                                 \
     const int nd3p4 = qe + sN + 5; /* = qe - Zne + 4 */                                                             \
     const int t1 = imax(imax(nd1, nd2), nd3p4);                                                                     \
@@ -450,11 +454,13 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
     dzm = q * __int_as_float(mad24_scale(fmax)); /* 2^(127 - fmax) */                                               \
     dze = qe;                                                                                                       \
     Zcm = Znm;                                                                                                      \
-    sC = sN;                                                                                                        \
-    zp++
+    sC = sN
                 {
                     int sC = __float_as_int(zq[ref].z);
-                    const float4 *zp = zq + ref + 1;
+                    // entry of step k of this run = zq[done_k][lane_idx]: a wave-uniform base advanced on the scalar unit
+                    // plus a per-lane offset that is fixed for the whole run
+                    const uint32_t lane_idx = ref + 1;
+                    const f2 dcm128 = dcm * 128.0f;
                     uint32_t done = 0;
                     for (;;) {
                         const uint32_t r0 = ref + done, i0 = iterations + done;
@@ -466,8 +472,9 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                             // every running lane has at least 64 quiet-eligible steps ahead: no per-step counter
                             uint32_t c = 0;
                             for (; c < 64u; c++) {
-                                const int sN = __float_as_int(zp->z);
-                                const float2 zx2 = *reinterpret_cast<const float2 *>(zp);
+                                const float4 *zc = zq + (done + c);
+                                const int sN = __float_as_int(zc[lane_idx].z);
+                                const float2 zx2 = *reinterpret_cast<const float2 *>(&zc[lane_idx]);
                                 FS_QUIET_HEAD();
                                 if (viol != 0ull) {
                                     stop = true;
@@ -478,8 +485,9 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                             done += c;
                         } else {
                             for (;;) {
-                                const int sN = __float_as_int(zp->z);
-                                const float2 zx2 = *reinterpret_cast<const float2 *>(zp);
+                                const float4 *zc = zq + done;
+                                const int sN = __float_as_int(zc[lane_idx].z);
+                                const float2 zx2 = *reinterpret_cast<const float2 *>(&zc[lane_idx]);
                                 FS_QUIET_HEAD();
                                 if ((viol | __builtin_amdgcn_ballot_w64(left == 0u)) != 0ull)
                                     break;
