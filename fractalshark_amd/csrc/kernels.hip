@@ -426,40 +426,50 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                 //   larger part of q a finite normal float; orbit value below 8 (poisoned sN fails t1 otherwise).
                 // A lane must also stay clear of the orbit end and of its iteration limit (`left`); runs are cut into
                 // chunks of 64 steps so that this is a per-chunk wave vote instead of a per-step, per-lane counter.
-#define FS_QUIET_HEAD()                                                                                             \
-    const f2 Znm = {zx2.x, zx2.y};                                                                                  \
-    const int nd1 = dze + sC;                                                                                       \
+                // One quiet step from state (DZM, DZE, ZCM, SC) into (NDZM, NDZE, NZCM, NSC) against entry K of the run.
+                // The orbit entry {re, im, s} is fetched with one 12-byte load in the scalar-base + per-lane-offset
+                // addressing mode (issued by hand: the compiler folds the offset into a 64-bit per-lane pointer and then
+                // spends a vector instruction per step on advancing it); the wait is tied to the loaded registers.
+#define FS_QUIET_STEP(DZM, DZE, ZCM, SC, NDZM, NDZE, NZCM, NSC, K, VIOL)                                            \
+    f3 ent_##VIOL;                                                                                                  \
+    {                                                                                                               \
+        const float4 *zc_ = zq + (K);                                                                               \
+        /* "+v"(DZE): nothing is written, it only pins the load ahead of the arithmetic that reads DZE */           \
+        asm volatile("global_load_dwordx3 %0, %2, %3" : "=v"(ent_##VIOL), "+v"(DZE) : "v"(lane_off), "s"(zc_));     \
+    }                                                                                                               \
+    const int nd1_##VIOL = DZE + SC;                                                                                \
     /* no clamp at kMinBigExp: an exponent that far down fails t2 (nd1 >= -115 and sC < 2^10 bound pe below) */      \
-    const int pe = dze - sC;                                                                                        \
-    const f2 cur = Zcm + dzm * __int_as_float((nd1 << 23) + 0x3F800000);                                            \
-    const f2 pa = dzm.xx * cur;                                                                                     \
-    const f2 pb = dzm.yy * cur.yx;                                                                                  \
-    f2 p;                                                                                                           \
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(p) : "v"(pa), "v"(pb));                          \
-    const int nd2 = dce - pe;                                                                                       \
+    const int pe_##VIOL = DZE - SC;                                                                                 \
+    const f2 cur_##VIOL = ZCM + DZM * __int_as_float((nd1_##VIOL << 23) + 0x3F800000);                              \
+    const f2 pa_##VIOL = DZM.xx * cur_##VIOL;                                                                       \
+    const f2 pb_##VIOL = DZM.yy * cur_##VIOL.yx;                                                                    \
+    f2 p_##VIOL;                                                                                                    \
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(p_##VIOL) : "v"(pa_##VIOL), "v"(pb_##VIOL));     \
+    const int nd2_##VIOL = dce - pe_##VIOL;                                                                         \
     /* dc * 2^nd2 for nd2 > -120, 0 otherwise, as (dc * 2^7) * 2^(nd2 - 7): the clamped exponent field is 0 exactly at \
        the cut-off, and both factors stay normal */                                                                 \
-    const float m2 = __int_as_float((imax(imin(nd2, 0), -kExpDiffIgnored) << 23) + (kExpDiffIgnored << 23));        \
-    const f2 q = p + dcm128 * m2;                                                                                   \
-    const int fmax = (int)__builtin_amdgcn_ubfe(__float_as_int(__builtin_fmaxf(__builtin_fabsf(q.x),                \
-                                                                               __builtin_fabsf(q.y))), 23, 8);      \
-    const int qe = pe + fmax - 127;                                                                                 \
-    const int nd3p4 = qe + sN + 5; /* = qe - Zne + 4 */                                                             \
-    const int t1 = imax(imax(nd1, nd2), nd3p4);                                                                     \
+    const float m2_##VIOL =                                                                                         \
+        __int_as_float((imax(imin(nd2_##VIOL, 0), -kExpDiffIgnored) << 23) + (kExpDiffIgnored << 23));              \
+    const f2 q_##VIOL = p_##VIOL + dcm128 * m2_##VIOL;                                                              \
+    const int fmax_##VIOL = (int)__builtin_amdgcn_ubfe(                                                             \
+        __float_as_int(__builtin_fmaxf(__builtin_fabsf(q_##VIOL.x), __builtin_fabsf(q_##VIOL.y))), 23, 8);          \
+    NDZE = pe_##VIOL + fmax_##VIOL - 127;                                                                           \
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ent_##VIOL));                                                          \
+    NSC = __float_as_int(ent_##VIOL.z);                                                                             \
+    NZCM = (f2){ent_##VIOL.x, ent_##VIOL.y};                                                                        \
+    const int nd3p4_##VIOL = NDZE + NSC + 5; /* = qe - Zne + 4 */                                                   \
+    const int t1_##VIOL = imax(imax(nd1_##VIOL, nd2_##VIOL), nd3p4_##VIOL);                                         \
     /* fmax == 0 (q zero or denormal) fails t2 too; fmax == 255 needs an infinite input, which the bounded mantissas   \
        of this loop cannot produce (|p| < 32) */                                                                    \
-    const int t2 = imin3(nd1, nd3p4, fmax - 116);                                                                   \
-    const uint64_t viol = __builtin_amdgcn_ballot_w64(t1 > 0) | __builtin_amdgcn_ballot_w64(t2 < -115)
-#define FS_QUIET_COMMIT()                                                                                           \
-    dzm = q * __int_as_float(mad24_scale(fmax)); /* 2^(127 - fmax) */                                               \
-    dze = qe;                                                                                                       \
-    Zcm = Znm;                                                                                                      \
-    sC = sN
+    const int t2_##VIOL = imin3(nd1_##VIOL, nd3p4_##VIOL, fmax_##VIOL - 116);                                       \
+    const uint64_t VIOL = __builtin_amdgcn_ballot_w64(t1_##VIOL > 0) | __builtin_amdgcn_ballot_w64(t2_##VIOL < -115); \
+    NDZM = q_##VIOL * __int_as_float(mad24_scale(fmax_##VIOL)) /* 2^(127 - fmax) */
                 {
+                    typedef float f3 __attribute__((ext_vector_type(3)));
                     int sC = __float_as_int(zq[ref].z);
-                    // entry of step k of this run = zq[done_k][lane_idx]: a wave-uniform base advanced on the scalar unit
-                    // plus a per-lane offset that is fixed for the whole run
-                    const uint32_t lane_idx = ref + 1;
+                    // entry of step k of this run = zq[done_k] + lane_off: a wave-uniform base advanced on the scalar unit
+                    // plus a per-lane byte offset that is fixed for the whole run
+                    const uint32_t lane_off = (ref + 1) * 16u;
                     const f2 dcm128 = dcm * 128.0f;
                     uint32_t done = 0;
                     for (;;) {
@@ -469,29 +479,37 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                         uint32_t left = left_ref < left_it ? left_ref : left_it;
                         bool stop = false;
                         if (__builtin_amdgcn_ballot_w64(left < 64u) == 0ull) {
-                            // every running lane has at least 64 quiet-eligible steps ahead: no per-step counter
+                            // every running lane has at least 64 quiet-eligible steps ahead: no per-step counter; two
+                            // steps per trip so that the state ping-pongs between two register sets without copies
                             uint32_t c = 0;
-                            for (; c < 64u; c++) {
-                                const float4 *zc = zq + (done + c);
-                                const int sN = __float_as_int(zc[lane_idx].z);
-                                const float2 zx2 = *reinterpret_cast<const float2 *>(&zc[lane_idx]);
-                                FS_QUIET_HEAD();
-                                if (viol != 0ull) {
+                            for (; c < 64u; c += 2) {
+                                f2 dzmB, ZcmB;
+                                int dzeB, sB;
+                                FS_QUIET_STEP(dzm, dze, Zcm, sC, dzmB, dzeB, ZcmB, sB, done + c, vA);
+                                if (vA != 0ull) {
                                     stop = true;
                                     break;
                                 }
-                                FS_QUIET_COMMIT();
+                                f2 dzmA, ZcmA;
+                                int dzeA, sA;
+                                FS_QUIET_STEP(dzmB, dzeB, ZcmB, sB, dzmA, dzeA, ZcmA, sA, done + c + 1, vB);
+                                if (vB != 0ull) {
+                                    dzm = dzmB, dze = dzeB, Zcm = ZcmB, sC = sB;
+                                    c++;
+                                    stop = true;
+                                    break;
+                                }
+                                dzm = dzmA, dze = dzeA, Zcm = ZcmA, sC = sA;
                             }
                             done += c;
                         } else {
                             for (;;) {
-                                const float4 *zc = zq + done;
-                                const int sN = __float_as_int(zc[lane_idx].z);
-                                const float2 zx2 = *reinterpret_cast<const float2 *>(&zc[lane_idx]);
-                                FS_QUIET_HEAD();
-                                if ((viol | __builtin_amdgcn_ballot_w64(left == 0u)) != 0ull)
+                                f2 dzmN, ZcmN;
+                                int dzeN, sN;
+                                FS_QUIET_STEP(dzm, dze, Zcm, sC, dzmN, dzeN, ZcmN, sN, done, vT);
+                                if ((vT | __builtin_amdgcn_ballot_w64(left == 0u)) != 0ull)
                                     break;
-                                FS_QUIET_COMMIT();
+                                dzm = dzmN, dze = dzeN, Zcm = ZcmN, sC = sN;
                                 left--;
                                 done++;
                             }
@@ -505,8 +523,7 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                     if (kStats)
                         c_pt += done;
                 }
-#undef FS_QUIET_HEAD
-#undef FS_QUIET_COMMIT
+#undef FS_QUIET_STEP
                 // the careful step works with the true exponent of Zc (sC may be the poison value)
                 int Zce1 = __float_as_int(zr[ref].z) + 1;
                 // ---- one careful step: full exit tests; generic CPU-order fallback when an assumption fails
