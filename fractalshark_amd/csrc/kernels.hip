@@ -68,8 +68,9 @@ __global__ void k_prepare_orbit_hdr32(const fs_orbit_hdr32 *__restrict__ in, flo
     out[i] = make_float4(c.re, c.im, __int_as_float(c.e), ldexpf(1.0f, 8 - 2 * (c.e < -1000 ? -1000 : c.e)));
 }
 
-// Companion array of the tuned LAv2 loop: {re, im, s, -} with s = ~exp (so that -s = exp + 1 = the exponent of 2Z) for
-// orbit values below 8, and a large positive poison for larger ones, which makes the loop's range test fail there.
+// Companion array of the tuned LAv2 loop: {re, im, s, -} with s = ~exp + 116 (-(s - 116) = exp + 1 = the exponent of 2Z;
+// the bias turns the loop's range tests into comparisons against constants) for orbit values below 8, and a large
+// positive poison for larger ones, which makes the range test fail there.
 __global__ void k_make_quiet_orbit(const float4 *__restrict__ zref, float4 *__restrict__ zq, uint64_t n)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -77,7 +78,7 @@ __global__ void k_make_quiet_orbit(const float4 *__restrict__ zref, float4 *__re
         return;
     const float4 v = zref[i];
     const int e = __float_as_int(v.z);
-    zq[i] = make_float4(v.x, v.y, __int_as_float(e <= 2 ? ~e : (1 << 24)), 0.0f);
+    zq[i] = make_float4(v.x, v.y, __int_as_float(e <= 2 ? ~e + 116 : (1 << 24)), 0.0f);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -408,8 +409,8 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
     const bool ok_core = imax(imax(nd1, nd3), nd2) <= 0 && (nd1 < nd3 ? nd1 : nd3) > -kExpDiffIgnored &&            \
                          (unsigned)(fmax - 1) < 254u /* larger part of q: non-zero, finite, normal */
 
-            // Quiet-run state: sC = ~(exponent of Zc) for an orbit value below 8, a large positive poison otherwise
-            // (zq[i].z, written by k_make_quiet_orbit), so that 2Z's exponent is -sC and every use below is one add.
+            // Quiet-run state: sC = ~(exponent of Zc) + 116 for an orbit value below 8, a large positive poison otherwise
+            // (zq[i].z, written by k_make_quiet_orbit).
             const float4 *__restrict__ zq = A.zq;
             while (running) {
                 // ---- run of "quiet" steps: when dz is at least 2^4 below the orbit value and the orbit value is < 8,
@@ -426,97 +427,99 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                 //   larger part of q a finite normal float; orbit value below 8 (poisoned sN fails t1 otherwise).
                 // A lane must also stay clear of the orbit end and of its iteration limit (`left`); runs are cut into
                 // chunks of 64 steps so that this is a per-chunk wave vote instead of a per-step, per-lane counter.
-                // One quiet step from state (DZM, DZE, ZCM, SC) into (NDZM, NDZE, NZCM, NSC) against entry K of the run.
+                // One quiet step from state (DZM, DZE, ZCM, SC, W) into (NDZM, NDZE, NZCM, NSC, NW) against entry K of the run.
+                // Exponent bookkeeping is biased so that every range test is against a constant that needs no extra add:
+                //   SC = ~exp(Zc) + 116 (zq[].z; poison 2^24 for an orbit value >= 8),  W = DZE + SC = nd1 + 116,
+                //   pe' = DZE - SC = pe - 116,  nd2B = (dce - 5) - pe' = nd2 + 111,  NW = qe + NSC = nd3 + 115.
+                // NW is next step's W: nd1 of a step is nd3 of the previous one minus 1, so only nd3 (and the first nd1 of
+                // a run) needs a range test:  nd3 in [-114, -4]  <=>  NW in [1, 111];  nd2 <= 0  <=>  nd2B <= 111;
+                // the larger part of q non-zero and normal  <=>  fmax >= 1  (fmax = 255 needs an infinite input, which
+                // the bounded mantissas of this loop cannot produce: |p| < 32).
                 // The orbit entry {re, im, s} is fetched with one 12-byte load in the scalar-base + per-lane-offset
                 // addressing mode (issued by hand: the compiler folds the offset into a 64-bit per-lane pointer and then
                 // spends a vector instruction per step on advancing it); the wait is tied to the loaded registers.
-#define FS_QUIET_STEP(DZM, DZE, ZCM, SC, NDZM, NDZE, NZCM, NSC, K, VIOL)                                            \
+#define FS_QUIET_STEP(DZM, DZE, ZCM, SC, W, NDZM, NDZE, NZCM, NSC, NW, K, VIOL)                                     \
     f3 ent_##VIOL;                                                                                                  \
     {                                                                                                               \
         const float4 *zc_ = zq + (K);                                                                               \
         /* "+v"(DZE): nothing is written, it only pins the load ahead of the arithmetic that reads DZE */           \
         asm volatile("global_load_dwordx3 %0, %2, %3" : "=v"(ent_##VIOL), "+v"(DZE) : "v"(lane_off), "s"(zc_));     \
     }                                                                                                               \
-    const int nd1_##VIOL = DZE + SC;                                                                                \
-    /* no clamp at kMinBigExp: an exponent that far down fails t2 (nd1 >= -115 and sC < 2^10 bound pe below) */      \
-    const int pe_##VIOL = DZE - SC;                                                                                 \
-    const f2 cur_##VIOL = ZCM + DZM * __int_as_float((nd1_##VIOL << 23) + 0x3F800000);                              \
+    const int pe_##VIOL = DZE - SC; /* pe - 116; no clamp at kMinBigExp: an exponent that far down fails the W test */ \
+    const f2 cur_##VIOL = ZCM + DZM * __int_as_float((W << 23) + (0x3F800000 - (116 << 23)));                       \
     const f2 pa_##VIOL = DZM.xx * cur_##VIOL;                                                                       \
     const f2 pb_##VIOL = DZM.yy * cur_##VIOL.yx;                                                                    \
     f2 p_##VIOL;                                                                                                    \
     asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(p_##VIOL) : "v"(pa_##VIOL), "v"(pb_##VIOL));     \
-    const int nd2_##VIOL = dce - pe_##VIOL;                                                                         \
+    const int nd2_##VIOL = dceB - pe_##VIOL; /* nd2 + 111 */                                                        \
     /* dc * 2^nd2 for nd2 > -120, 0 otherwise, as (dc * 2^7) * 2^(nd2 - 7): the clamped exponent field is 0 exactly at \
        the cut-off, and both factors stay normal */                                                                 \
-    const float m2_##VIOL =                                                                                         \
-        __int_as_float((imax(imin(nd2_##VIOL, 0), -kExpDiffIgnored) << 23) + (kExpDiffIgnored << 23));              \
+    const float m2_##VIOL = __int_as_float((imax(imin(nd2_##VIOL, 111), -9) << 23) + (9 << 23));                    \
     const f2 q_##VIOL = p_##VIOL + dcm128 * m2_##VIOL;                                                              \
-    const int fmax_##VIOL = (int)__builtin_amdgcn_ubfe(                                                             \
-        __float_as_int(__builtin_fmaxf(__builtin_fabsf(q_##VIOL.x), __builtin_fabsf(q_##VIOL.y))), 23, 8);          \
-    NDZE = pe_##VIOL + fmax_##VIOL - 127;                                                                           \
+    const int fmax_##VIOL =                                                                                         \
+        __float_as_int(__builtin_fmaxf(__builtin_fabsf(q_##VIOL.x), __builtin_fabsf(q_##VIOL.y))) >> 23;            \
+    NDZE = pe_##VIOL + fmax_##VIOL - 11; /* pe + fmax - 127 */                                                      \
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(ent_##VIOL));                                                          \
     NSC = __float_as_int(ent_##VIOL.z);                                                                             \
     NZCM = (f2){ent_##VIOL.x, ent_##VIOL.y};                                                                        \
-    const int nd3p4_##VIOL = NDZE + NSC + 5; /* = qe - Zne + 4 */                                                   \
-    const int t1_##VIOL = imax(imax(nd1_##VIOL, nd2_##VIOL), nd3p4_##VIOL);                                         \
-    /* fmax == 0 (q zero or denormal) fails t2 too; fmax == 255 needs an infinite input, which the bounded mantissas   \
-       of this loop cannot produce (|p| < 32) */                                                                    \
-    const int t2_##VIOL = imin3(nd1_##VIOL, nd3p4_##VIOL, fmax_##VIOL - 116);                                       \
-    const uint64_t VIOL = __builtin_amdgcn_ballot_w64(t1_##VIOL > 0) | __builtin_amdgcn_ballot_w64(t2_##VIOL < -115); \
+    NW = NDZE + NSC;                                                                                                \
+    const uint64_t VIOL = __builtin_amdgcn_ballot_w64(imax(NW, nd2_##VIOL) > 111) |                                 \
+                          __builtin_amdgcn_ballot_w64(imin(NW, fmax_##VIOL) < 1);                                   \
     NDZM = q_##VIOL * __int_as_float(mad24_scale(fmax_##VIOL)) /* 2^(127 - fmax) */
                 {
                     typedef float f3 __attribute__((ext_vector_type(3)));
                     int sC = __float_as_int(zq[ref].z);
+                    int W = dze + sC;
                     // entry of step k of this run = zq[done_k] + lane_off: a wave-uniform base advanced on the scalar unit
                     // plus a per-lane byte offset that is fixed for the whole run
                     const uint32_t lane_off = (ref + 1) * 16u;
                     const f2 dcm128 = dcm * 128.0f;
+                    const int dceB = dce - 5;
                     uint32_t done = 0;
-                    for (;;) {
+                    // first step of the run: nd1 in [-115, 0] is not implied by a previous quiet step
+                    bool stop = __builtin_amdgcn_ballot_w64((unsigned)(W - 1) > 115u) != 0ull;
+                    while (!stop) {
                         const uint32_t r0 = ref + done, i0 = iterations + done;
                         const uint32_t left_ref = r0 + 1 < MaxRefIteration ? MaxRefIteration - 1 - r0 : 0u;
                         const uint32_t left_it = n_iterations - 1 - i0; // running => iterations < n_iterations
                         uint32_t left = left_ref < left_it ? left_ref : left_it;
-                        bool stop = false;
                         if (__builtin_amdgcn_ballot_w64(left < 64u) == 0ull) {
                             // every running lane has at least 64 quiet-eligible steps ahead: no per-step counter; two
                             // steps per trip so that the state ping-pongs between two register sets without copies
                             uint32_t c = 0;
                             for (; c < 64u; c += 2) {
                                 f2 dzmB, ZcmB;
-                                int dzeB, sB;
-                                FS_QUIET_STEP(dzm, dze, Zcm, sC, dzmB, dzeB, ZcmB, sB, done + c, vA);
+                                int dzeB, sB, WB;
+                                FS_QUIET_STEP(dzm, dze, Zcm, sC, W, dzmB, dzeB, ZcmB, sB, WB, done + c, vA);
                                 if (vA != 0ull) {
                                     stop = true;
                                     break;
                                 }
                                 f2 dzmA, ZcmA;
-                                int dzeA, sA;
-                                FS_QUIET_STEP(dzmB, dzeB, ZcmB, sB, dzmA, dzeA, ZcmA, sA, done + c + 1, vB);
+                                int dzeA, sA, WA;
+                                FS_QUIET_STEP(dzmB, dzeB, ZcmB, sB, WB, dzmA, dzeA, ZcmA, sA, WA, done + c + 1, vB);
                                 if (vB != 0ull) {
-                                    dzm = dzmB, dze = dzeB, Zcm = ZcmB, sC = sB;
+                                    dzm = dzmB, dze = dzeB, Zcm = ZcmB, sC = sB, W = WB;
                                     c++;
                                     stop = true;
                                     break;
                                 }
-                                dzm = dzmA, dze = dzeA, Zcm = ZcmA, sC = sA;
+                                dzm = dzmA, dze = dzeA, Zcm = ZcmA, sC = sA, W = WA;
                             }
                             done += c;
                         } else {
                             for (;;) {
                                 f2 dzmN, ZcmN;
-                                int dzeN, sN;
-                                FS_QUIET_STEP(dzm, dze, Zcm, sC, dzmN, dzeN, ZcmN, sN, done, vT);
+                                int dzeN, sN, WN;
+                                FS_QUIET_STEP(dzm, dze, Zcm, sC, W, dzmN, dzeN, ZcmN, sN, WN, done, vT);
                                 if ((vT | __builtin_amdgcn_ballot_w64(left == 0u)) != 0ull)
                                     break;
-                                dzm = dzmN, dze = dzeN, Zcm = ZcmN, sC = sN;
+                                dzm = dzmN, dze = dzeN, Zcm = ZcmN, sC = sN, W = WN;
                                 left--;
                                 done++;
                             }
                             stop = true;
                         }
-                        if (stop)
-                            break;
                     }
                     ref += done;
                     iterations += done;
