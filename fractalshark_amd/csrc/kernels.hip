@@ -82,6 +82,70 @@ __global__ void k_make_quiet_orbit(const float4 *__restrict__ zref, float4 *__re
 }
 
 // ------------------------------------------------------------------------------------------------
+// ATInfo::PerformAT (ATInfo.h:155-188): i = number of iterations z = z*z + c taken before |z|^2 > SqrEscapeRadius.
+// The literal loop is HDRFloatComplex arithmetic with a 4-way exponent alignment per add and a Reduce + lexicographic
+// compare per norm.  After the first iteration (0*0 + c = c) z carries c's exponent k, and for -120 < k <= 0 every later
+// iteration takes the same alignment branch (z*z has exponent 2k, gap k to c): z' = (z*z) * 2^k + c with exponent k
+// again.  The steady state below executes exactly those IEEE operations -- same operands, same order; re*im + im*re is
+// computed as ri + ri, which is the same value -- on bare mantissas, and replaces Reduce + compare by a value comparison
+// against T = esc.m * 2^(esc.e - 2k) (exact power-of-two scaling; +inf when it overflows), which is equivalent for a
+// positive normal |z|^2.  Anything else (k outside the window, a zero / denormal norm) runs the literal loop.
+template <class F>
+__device__ __forceinline__ void at_perform(const hcplx<F> c, const hreal<F> esc, const uint32_t ATMaxIt, hcplx<F> &z_out,
+                                           uint32_t &i_out)
+{
+    hcplx<F> z = hc_zero<F>();
+    uint32_t i = 0;
+    const int k = c.e;
+    if (k <= 0 && k > -kExpDiffIgnored && ATMaxIt > 1) {
+        // iteration 0 literally: the norm of the zero start never exceeds the radius; z becomes c
+        z = hc_add(hc_mul(z, z), c);
+        i = 1;
+        if (z.e == k) {
+            F re = z.re, im = z.im;
+            const F P = pow2_normal<F>(k);
+            const int te = esc.e - 2 * k;
+            F T;
+            if (te >= fbits<F>::kMaxMulExp)
+                T = type_max<F>() * F(2); // +inf: the scaled radius is >= 2^128 (2^1024), above every finite norm
+            else
+                T = esc.m * pow2_normal<F>(te < -fbits<F>::kBias + 2 ? -fbits<F>::kBias + 2 : te);
+            const F min_normal = pow2_normal<F>(-fbits<F>::kBias + 1);
+            bool literal = te < -fbits<F>::kBias + 2;
+            while (!literal && i < ATMaxIt) {
+                const F rr = re * re, ii = im * im;
+                const F m = rr + ii;
+                if (!(m >= min_normal)) {
+                    literal = true;
+                    break;
+                }
+                if (m > T)
+                    break;
+                const F ri = re * im;
+                re = (rr - ii) * P + c.re;
+                im = (ri + ri) * P + c.im;
+                i++;
+            }
+            z = hcplx<F>{re, im, k};
+            if (!literal) {
+                z_out = z;
+                i_out = i;
+                return;
+            }
+        }
+    }
+    for (; i < ATMaxIt; i++) {
+        hreal<F> nsq = hc_norm2(z);
+        hr_reduce(nsq);
+        if (hr_cmp_pos(nsq, esc) > 0)
+            break;
+        z = hc_add(hc_mul(z, z), c);
+    }
+    z_out = z;
+    i_out = i;
+}
+
+// ------------------------------------------------------------------------------------------------
 // LAv2, T = HDRFloat<float>.  CPU twin: Fractal::CalcCpuPerturbationFractalLAV2<uint32_t,float,Disable>
 // (Fractal.cpp:2545-2678) with LAReference::getLA / isLAStageInvalid (LAReference.cpp:1076-1134),
 // LAInfoDeep::Prepare / Evaluate (LAInfoDeep.h:395-420), ATInfo::PerformAT (ATInfo.h:155-188).
@@ -89,6 +153,9 @@ __global__ void k_make_quiet_orbit(const float4 *__restrict__ zref, float4 *__re
 template <class F, int Mode, bool kStats>
 __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
 {
+    // The float instantiation is the operation-by-operation A/B reference of the tuned kernel and keeps the literal AT
+    // loop; the double instantiation is the production HDRFloat<double> kernel and uses the steady-state AT loop.
+    constexpr bool kFastAT = sizeof(F) == 8;
     const uint32_t X = blockIdx.x * 64u + (threadIdx.x & 63u);
     const uint32_t L = blockIdx.y * 4u + (threadIdx.x >> 6);
     uint64_t c_at = 0, c_la = 0, c_pt = 0, c_px = 0;
@@ -108,15 +175,20 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
                 const uint32_t ATMaxIt = n_iterations / A.at.StepLength;
                 hcplx<F> c = hc_add(hc_mul(DeltaSub0, ldc(A.at.CCoeff)), ldc(A.at.RefC));
                 hc_reduce(c);
-                hcplx<F> z = hc_zero<F>();
-                const hreal<F> esc = ldr(A.at.SqrEscapeRadius);
+                hcplx<F> z;
                 uint32_t i;
-                for (i = 0; i < ATMaxIt; i++) {
-                    hreal<F> nsq = hc_norm2(z);
-                    hr_reduce(nsq);
-                    if (hr_cmp_pos(nsq, esc) > 0)
-                        break;
-                    z = hc_add(hc_mul(z, z), c);
+                if (kFastAT) {
+                    at_perform<F>(c, ldr(A.at.SqrEscapeRadius), ATMaxIt, z, i);
+                } else {
+                    z = hc_zero<F>();
+                    const hreal<F> esc = ldr(A.at.SqrEscapeRadius);
+                    for (i = 0; i < ATMaxIt; i++) {
+                        hreal<F> nsq = hc_norm2(z);
+                        hr_reduce(nsq);
+                        if (hr_cmp_pos(nsq, esc) > 0)
+                            break;
+                        z = hc_add(hc_mul(z, z), c);
+                    }
                 }
                 hcplx<F> dz = hc_mul(z, ldc(A.at.InvZCoeff));
                 hc_reduce(dz);
@@ -299,16 +371,9 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                 const uint32_t ATMaxIt = n_iterations / A.at.StepLength;
                 hcplx32 c = hc_add(hc_mul(DeltaSub0, ldc(A.at.CCoeff)), ldc(A.at.RefC));
                 hc_reduce(c);
-                hcplx32 z = hc_zero<float>();
-                const hreal32 esc = ldr(A.at.SqrEscapeRadius);
+                hcplx32 z;
                 uint32_t i;
-                for (i = 0; i < ATMaxIt; i++) {
-                    hreal32 nsq = hc_norm2(z);
-                    hr_reduce(nsq);
-                    if (hr_cmp_pos(nsq, esc) > 0)
-                        break;
-                    z = hc_add(hc_mul(z, z), c);
-                }
+                at_perform<float>(c, ldr(A.at.SqrEscapeRadius), ATMaxIt, z, i);
                 hcplx32 dz = hc_mul(z, ldc(A.at.InvZCoeff));
                 hc_reduce(dz);
                 DeltaSubN = dz;
