@@ -501,3 +501,46 @@ def test_bla_table_built_on_device_equals_host_builder(renderer, native_libs, vi
     assert r.RenderCurrent(v.num_iterations, out) == 0
     assert r.SyncComputeStream() == 0
     assert np.array_equal(out, _oracle.bla_hdr32(v, ob, host))
+
+
+# ---- threading contract: four renderers on one device driven from four threads, and a progressive
+# RenderCurrent on the display stream while an iteration kernel is in flight on the compute stream
+def test_four_renderers_concurrently_and_progressive_readback(native_libs, v5_small):
+    import threading
+    v, ob, la, _ = v5_small
+    ref = _oracle.lav2_hdr32(v, ob, la, stage_test=0)
+    dx, dy, cx, cy = _pairs(v.coords_perturb(ob))
+    results, errors = [None] * 4, []
+
+    def worker(i):
+        try:
+            r = GPURenderer(0)
+            assert r.InitializeMemory(64, 36, 1, None, 0, 0, 0, False) == 0
+            assert r.InitializePerturb(i + 1, ob, 0, None, la) == 0
+            for _ in range(3):
+                assert r.ClearMemory() == 0
+                assert r.RenderPerturbLAv2(None, None, None, dx, dy, cx, cy, v.num_iterations, Mode=LAV2_FULL,
+                                           parity=PARITY_CPU) == 0
+                # progressive read-back on the display stream while the kernel may still be running: must not fail and
+                # must return either untouched (0) or final values, never garbage
+                part = r.new_iter_buffer()
+                assert r.RenderCurrent(v.num_iterations, part, None, None, progressive=True) == 0
+                assert r.SyncDisplayStream() == 0
+                assert np.all((part == 0) | (part == ref))
+                assert r.SyncComputeStream() == 0
+            out = r.new_iter_buffer()
+            assert r.RenderCurrent(v.num_iterations, out) == 0
+            assert r.SyncComputeStream() == 0
+            results[i] = out
+            r.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    for out in results:
+        assert np.array_equal(out, ref)

@@ -1,0 +1,10 @@
+#!/bin/bash
+# rocprofv3 PMC passes for one bench.py workload (separate runs per counter group, no trace domains; see
+# MI355X_MICROARCH.md "HBM / rocprofv3").  Usage: tools/pmc_passes.sh <tag> <bench.py args...>
+# Results land in gpurun_out/pmc_<tag>_<group>/ as CSV.
+tag=$1; shift
+export TMPDIR=/tmp
+for grp in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_WAVES" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+  name=$(echo $grp | tr ' ' '_' | cut -c1-40)
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d gpurun_out/pmc_${tag}_${name} -- python3 bench.py "$@" --steps 2 --warmup 0 --no-cpu > gpurun_out/pmc_${tag}_${name}.log 2>&1
+done
