@@ -40,7 +40,7 @@ struct fs_renderer {
 
     // buffers
     void *iters_internal = nullptr;
-    size_t iters_internal_elems = 0;
+    size_t iters_internal_bytes = 0;
     void *iters_external = nullptr;
     fs_color16 *colors = nullptr;
     fs_reduction *reduction = nullptr;
@@ -150,17 +150,19 @@ hipError_t make_quiet_orbit(fs_renderer *r, uint64_t n)
 
 uint32_t ensure_iter_buffer(fs_renderer *r)
 {
-    const size_t need = (size_t)r->w_block * 16u * r->local_rows_padded;
+    // capacity is tracked in BYTES: the same frame needs twice the memory with IterType = uint64_t
+    const size_t need = (size_t)r->w_block * 16u * r->local_rows_padded * r->iter_bytes;
     if (r->iters_external)
         return 0;
-    if (r->iters_internal && r->iters_internal_elems >= need)
+    if (r->iters_internal && r->iters_internal_bytes >= need)
         return 0;
     if (r->iters_internal) {
         FS_TRY(hipFree(r->iters_internal));
         r->iters_internal = nullptr;
+        r->iters_internal_bytes = 0;
     }
-    FS_TRY(hipMalloc(&r->iters_internal, need * r->iter_bytes));
-    r->iters_internal_elems = need;
+    FS_TRY(hipMalloc(&r->iters_internal, need));
+    r->iters_internal_bytes = need;
     return 0;
 }
 
