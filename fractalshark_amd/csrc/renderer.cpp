@@ -1169,9 +1169,11 @@ uint32_t fs_enqueue_done_callback(fs_renderer *r, fs_done_cb cb, void *user)
 {
     if (uint32_t e = use_device(r))
         return e;
-    if (!r->compute || !cb)
+    if (!cb)
         return FS_ERR_6;
     DoneThunk *t = new DoneThunk{cb, user};
+    // before InitializeMemory the reference's m_ComputeStream is the null stream and the callback still fires
+    // (GPU_Render.cu:613-615); r->compute == nullptr behaves the same way
     const hipError_t e = hipLaunchHostFunc(r->compute, done_trampoline, t);
     if (e != hipSuccess)
         delete t;
