@@ -83,6 +83,7 @@ using FsLav2Args32 = FsLav2ArgsT<float>;
 template <class F> struct FsBlaArgsT {
     uint32_t *out;
     const typename FsDev<F>::Z *zref;
+    const float4 *zq;                            // float, perturbation-only: quiet-run companion of zref
     const typename FsDev<F>::BLA *const *levels; // device array of device pointers, indexed by level
     uint64_t *stats;
     FsFrame frame;

@@ -778,6 +778,116 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                     break;
             }
 
+            // ---- perturbation-only mode, float: runs of "quiet" steps (same idea as the tuned LAv2 loop, in the scalar
+            // HDRFloat arithmetic of Fractal.cpp:2342-2361).  A step is quiet when both parts of the new dz are at least
+            // 2^4 below the next orbit value and that value is below 8: then neither the escape test nor the rebase test
+            // can fire (|Z'| in [0.5, 1.42) 2^Zne, |dz| < 2.83 * 2^(Zne-4): |z| > 1.8 |dz| and |z|^2 < 41), z and the two
+            // norms are not needed, and the step reduces to the dz update under the alignment cases listed at the tuned
+            // single step below -- evaluated with the same IEEE operations in the same order.  Everything is wave-voted;
+            // a lane that fails a condition sends the wave to the single step, which decides exactly.
+            //   orbit companion zq[i] = {re, im, s = ~exp + 116 | poison};  aX = OXe + sC = n4 + 116 (n4 = OXe - exp(2Z));
+            //   E' = max(OXe, OYe) - sC = E - 116;  ncB = (dce - 5) - E' = nc + 111.
+            //   The "gap >= 120: smaller operand ignored" rule of the reference's add is a clamped exponent field that is 0
+            //   exactly at the cut-off; the 2^-7 this costs is pre-paid by carrying dz's mantissas times 128 (O128), and it
+            //   is consumed once on the way to N: T = Z + O128 * 2^(n-7), P = O128 * T = 128 * (O * T), N = P * 2^(e-7).
+            //   valid: aX', aY' <= 111 (new dz 2^4 below Z'), ncB <= 111 (N bigger than dc), both parts of Q normal
+            //   non-zero, no exact zero in T or N (the literal adds reset the exponent there).
+            if constexpr (!kBla && std::is_same<F, float>::value) {
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                typedef float f3 __attribute__((ext_vector_type(3)));
+                const float4 *__restrict__ zq = A.zq;
+                f2 O128 = (f2){DeltaSubNX.m, DeltaSubNY.m} * 128.0f;
+                int OXe = DeltaSubNX.e, OYe = DeltaSubNY.e;
+                const float4 zc0 = zq[RefIteration];
+                f2 Zc = {zc0.x, zc0.y};
+                int sC = __float_as_int(zc0.z);
+                int aX = OXe + sC, aY = OYe + sC;
+                // entry: both parts reduced (mantissa in [1,2)) and at least 2^4 below the orbit value
+                const bool entry_ok = (__float_as_int(DeltaSubNX.m) & 0x7F800000) == 0x3F800000 &&
+                                      (__float_as_int(DeltaSubNY.m) & 0x7F800000) == 0x3F800000 && aX <= 111 && aY <= 111;
+                bool stop = __builtin_amdgcn_ballot_w64(!entry_ok) != 0ull;
+                const uint32_t lane_off = (RefIteration + 1) * 16u;
+                const f2 dcm128 = (f2){DeltaSub0X.m, DeltaSub0Y.m} * 128.0f;
+                const int dcXB = DeltaSub0X.e - 5, dcYB = DeltaSub0Y.e - 5;
+                const uint32_t MaxRef = count - 1;
+                uint32_t done = 0;
+#define FS_SQ_STEP(VIOL, K)                                                                                         \
+    f3 ent_;                                                                                                        \
+    {                                                                                                               \
+        const float4 *zc_ = zq + (K);                                                                               \
+        asm volatile("global_load_dwordx3 %0, %2, %3" : "=v"(ent_), "+v"(OXe) : "v"(lane_off), "s"(zc_));           \
+    }                                                                                                               \
+    const f2 tsc_ = {__int_as_float((imax(imin(aX, 116), -4) << 23) + (4 << 23)),                                   \
+                     __int_as_float((imax(imin(aY, 116), -4) << 23) + (4 << 23))};                                  \
+    const f2 T_ = Zc + O128 * tsc_;               /* (T4.m, T3.m), exponent of 2Z */                               \
+    const int dxy_ = aX - aY, dyx_ = aY - aX;                                                                       \
+    const f2 P1_ = O128.xx * T_;                  /* 128 * (B1.m, C1.m), exponent OXe + exp(2Z) */                 \
+    const f2 P2_ = O128.yy * T_.yx;               /* 128 * (B2.m, C2.m), exponent OYe + exp(2Z) */                 \
+    const f2 P1s_ = P1_ * __int_as_float((imax(imin(dxy_, 0), -kExpDiffIgnored) << 23) + (kExpDiffIgnored << 23));  \
+    const f2 P2s_ = P2_ * __int_as_float((imax(imin(dyx_, 0), -kExpDiffIgnored) << 23) + (kExpDiffIgnored << 23));  \
+    f2 N_;                                        /* (B1' - B2', C1' + C2'), exponent E */                          \
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(N_) : "v"(P1s_), "v"(P2s_));                     \
+    const int Ep_ = imax(OXe, OYe) - sC;          /* E - 116 */                                                    \
+    const int ncx_ = dcXB - Ep_, ncy_ = dcYB - Ep_;                                                                 \
+    const int cx_ = imax(imin(ncx_, 112), -9), cy_ = imax(imin(ncy_, 112), -9);                                     \
+    const f2 dsc_ = {__int_as_float((cx_ << 23) + (9 << 23)), __int_as_float((cy_ << 23) + (9 << 23))};             \
+    const f2 Q_ = N_ + dcm128 * dsc_;                                                                               \
+    const int qxb_ = __float_as_int(Q_.x), qyb_ = __float_as_int(Q_.y);                                             \
+    const int fx_ = (int)__builtin_amdgcn_ubfe(qxb_, 23, 8), fy_ = (int)__builtin_amdgcn_ubfe(qyb_, 23, 8);         \
+    const int nxe_ = Ep_ + fx_ - 11, nye_ = Ep_ + fy_ - 11;                                                         \
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ent_));                                                                \
+    const int sN_ = __float_as_int(ent_.z);                                                                         \
+    const int aXn_ = nxe_ + sN_, aYn_ = nye_ + sN_;                                                                 \
+    const int hi_ = imax(imax(imax(aXn_, aYn_), cx_), cy_);                                                         \
+    const float tiny_ = __builtin_fminf(__builtin_fminf(__builtin_fabsf(T_.x), __builtin_fabsf(T_.y)),              \
+                                        __builtin_fminf(__builtin_fabsf(N_.x), __builtin_fabsf(N_.y)));             \
+    const uint64_t VIOL = __builtin_amdgcn_ballot_w64(imin(fx_, fy_) < 1) | __builtin_amdgcn_ballot_w64(hi_ > 111) | \
+                          __builtin_amdgcn_ballot_w64(!(tiny_ > 0.0f))
+#define FS_SQ_COMMIT()                                                                                              \
+    O128 = (f2){__int_as_float((qxb_ & 0x807FFFFF) | 0x43000000), __int_as_float((qyb_ & 0x807FFFFF) | 0x43000000)}; \
+    OXe = nxe_, OYe = nye_, aX = aXn_, aY = aYn_, sC = sN_;                                                         \
+    Zc = (f2){ent_.x, ent_.y}
+                while (!stop) {
+                    const uint32_t r0 = RefIteration + done, i0 = iter + done;
+                    const uint32_t left_ref = r0 + 1 < MaxRef ? MaxRef - 1 - r0 : 0u;
+                    const uint32_t left_it = n_iterations - 1 - i0; // iter < n_iterations here
+                    uint32_t left = left_ref < left_it ? left_ref : left_it;
+                    if (__builtin_amdgcn_ballot_w64(left < 64u) == 0ull) {
+                        uint32_t c = 0;
+                        for (; c < 64u; c++) {
+                            FS_SQ_STEP(vA, done + c);
+                            if (vA != 0ull) {
+                                stop = true;
+                                break;
+                            }
+                            FS_SQ_COMMIT();
+                        }
+                        done += c;
+                    } else {
+                        for (;;) {
+                            FS_SQ_STEP(vT, done);
+                            if ((vT | __builtin_amdgcn_ballot_w64(left == 0u)) != 0ull)
+                                break;
+                            FS_SQ_COMMIT();
+                            left--;
+                            done++;
+                        }
+                        stop = true;
+                    }
+                }
+#undef FS_SQ_STEP
+#undef FS_SQ_COMMIT
+                if (done != 0) {
+                    RefIteration += done;
+                    iter += done;
+                    if (kStats)
+                        c_pt += done;
+                    DeltaSubNX = hreal<F>{O128.x * 0.0078125f, OXe};
+                    DeltaSubNY = hreal<F>{O128.y * 0.0078125f, OYe};
+                    Zcached_at = 0xFFFFFFFFu;
+                }
+            }
+
             const hreal<F> OX = DeltaSubNX, OY = DeltaSubNY;
             // The orbit entry read for the escape test of the previous step is the Z of this step unless a rebase or a
             // BLA jump moved RefIteration: one dependent 16-byte load per step instead of two.
