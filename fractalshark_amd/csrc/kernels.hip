@@ -811,12 +811,16 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                 const int dcXB = DeltaSub0X.e - 5, dcYB = DeltaSub0Y.e - 5;
                 const uint32_t MaxRef = count - 1;
                 uint32_t done = 0;
-#define FS_SQ_STEP(VIOL, K)                                                                                         \
-    f3 ent_;                                                                                                        \
+#define FS_SQ_WAIT_ZERO(E) asm volatile("s_waitcnt vmcnt(0)" : "+v"(E))
+#define FS_SQ_WAIT_NONE(E)
+#define FS_SQ_LOAD(ENT, K)                                                                                          \
     {                                                                                                               \
         const float4 *zc_ = zq + (K);                                                                               \
-        asm volatile("global_load_dwordx3 %0, %2, %3" : "=v"(ent_), "+v"(OXe) : "v"(lane_off), "s"(zc_));           \
-    }                                                                                                               \
+        /* "+v"(OXe): nothing is written, it only pins the load ahead of the arithmetic that reads OXe */           \
+        asm volatile("global_load_dwordx3 %0, %2, %3" : "=v"(ENT), "+v"(OXe) : "v"(lane_off), "s"(zc_));            \
+    }
+                // WAIT is ZERO (entry loaded by hand in this step) or NONE (entry came through an ordinary load)
+#define FS_SQ_STEP(VIOL, ent_, WAIT)                                                                                \
     const f2 tsc_ = {__int_as_float((imax(imin(aX, 116), -4) << 23) + (4 << 23)),                                   \
                      __int_as_float((imax(imin(aY, 116), -4) << 23) + (4 << 23))};                                  \
     const f2 T_ = Zc + O128 * tsc_;               /* (T4.m, T3.m), exponent of 2Z */                               \
@@ -835,7 +839,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
     const int qxb_ = __float_as_int(Q_.x), qyb_ = __float_as_int(Q_.y);                                             \
     const int fx_ = (int)__builtin_amdgcn_ubfe(qxb_, 23, 8), fy_ = (int)__builtin_amdgcn_ubfe(qyb_, 23, 8);         \
     const int nxe_ = Ep_ + fx_ - 11, nye_ = Ep_ + fy_ - 11;                                                         \
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ent_));                                                                \
+    FS_SQ_WAIT_##WAIT(ent_);                                                                                        \
     const int sN_ = __float_as_int(ent_.z);                                                                         \
     const int aXn_ = nxe_ + sN_, aYn_ = nye_ + sN_;                                                                 \
     const int hi_ = imax(imax(imax(aXn_, aYn_), cx_), cy_);                                                         \
@@ -843,7 +847,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                                         __builtin_fminf(__builtin_fabsf(N_.x), __builtin_fabsf(N_.y)));             \
     const uint64_t VIOL = __builtin_amdgcn_ballot_w64(imin(fx_, fy_) < 1) | __builtin_amdgcn_ballot_w64(hi_ > 111) | \
                           __builtin_amdgcn_ballot_w64(!(tiny_ > 0.0f))
-#define FS_SQ_COMMIT()                                                                                              \
+#define FS_SQ_COMMIT(ent_)                                                                                          \
     O128 = (f2){__int_as_float((qxb_ & 0x807FFFFF) | 0x43000000), __int_as_float((qyb_ & 0x807FFFFF) | 0x43000000)}; \
     OXe = nxe_, OYe = nye_, aX = aXn_, aY = aYn_, sC = sN_;                                                         \
     Zc = (f2){ent_.x, ent_.y}
@@ -852,29 +856,44 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                     const uint32_t left_ref = r0 + 1 < MaxRef ? MaxRef - 1 - r0 : 0u;
                     const uint32_t left_it = n_iterations - 1 - i0; // iter < n_iterations here
                     uint32_t left = left_ref < left_it ? left_ref : left_it;
-                    if (__builtin_amdgcn_ballot_w64(left < 64u) == 0ull) {
+                    if (__builtin_amdgcn_ballot_w64(left < 66u) == 0ull) {
+                        // every running lane has more than 64 quiet-eligible steps ahead: no per-step counter.  The orbit
+                        // entry of step k+1 is requested while step k computes (a wave that is alone on its SIMD -- the
+                        // long interior chains -- would otherwise sit out the full load latency every step).  These are
+                        // ordinary loads: a hand-issued load may not stay in flight across the loop's back edge (the
+                        // register allocator is free to copy its destination before the data has arrived).
                         uint32_t c = 0;
+                        const float4 *zl = zq + (RefIteration + 1 + done);
+                        float4 nxt = zl[0];
                         for (; c < 64u; c++) {
-                            FS_SQ_STEP(vA, done + c);
+                            const float4 cur = nxt;
+                            nxt = zl[c + 1];
+                            f3 entC = {cur.x, cur.y, cur.z};
+                            FS_SQ_STEP(vA, entC, NONE);
                             if (vA != 0ull) {
                                 stop = true;
                                 break;
                             }
-                            FS_SQ_COMMIT();
+                            FS_SQ_COMMIT(entC);
                         }
                         done += c;
                     } else {
                         for (;;) {
-                            FS_SQ_STEP(vT, done);
+                            f3 entT;
+                            FS_SQ_LOAD(entT, done);
+                            FS_SQ_STEP(vT, entT, ZERO);
                             if ((vT | __builtin_amdgcn_ballot_w64(left == 0u)) != 0ull)
                                 break;
-                            FS_SQ_COMMIT();
+                            FS_SQ_COMMIT(entT);
                             left--;
                             done++;
                         }
                         stop = true;
                     }
                 }
+#undef FS_SQ_LOAD
+#undef FS_SQ_WAIT_ZERO
+#undef FS_SQ_WAIT_NONE
 #undef FS_SQ_STEP
 #undef FS_SQ_COMMIT
                 if (done != 0) {
