@@ -233,7 +233,9 @@ def main():
     if rank == 0 and not distributed and not args.no_cpu:
         import _oracle
         threads = effective_cpus()
-        nrows = max(1, min(args.cpu_sample_rows if args.cpu_sample_rows > 0 else (4 if is2x32 else 8) * threads, H))
+        # rows per host thread chosen per workload so that the sample is 10-30 s of CPU work on the box's 16 threads
+        per_thread = {"c3_lav2": 8, "c2_po": 3, "c5_bla": 32, "c4_hdr64": 64, "c4_2x32": 8}[args.workload]
+        nrows = max(1, min(args.cpu_sample_rows if args.cpu_sample_rows > 0 else per_thread * threads, H))
         step = max(1, H // nrows)
         y0 = step // 2
         rows = list(range(y0, H, step))
