@@ -109,6 +109,7 @@ def render_lib():
     _decl(lib, "fs_bla_lm2", i32, [vp])
     _decl(lib, "fs_bla_level_size", u64, [vp, i32])
     _decl(lib, "fs_read_bla_level", u32, [vp, i32, vp, u64])
+    _decl(lib, "fs_render_direct_lp", u32, [vp, C.c_int, vp, u64, C.c_int])
     _decl(lib, "fs_clear", u32, [vp])
     _decl(lib, "fs_render_current", u32, [vp, u64, vp, vp, vp, C.c_int])
     _decl(lib, "fs_sync_compute", u32, [vp])
@@ -130,7 +131,7 @@ RENDER_SYMBOLS = [
     "fs_local_rows", "fs_set_external_iter_buffer", "fs_device_iter_buffer", "fs_rounded_width", "fs_upload_orbit", "fs_upload_orbit_compressed",
     "fs_upload_la", "fs_upload_bla", "fs_render_lav2", "fs_render_bla", "fs_render_direct", "fs_upload_orbit_scaled",
     "fs_render_scaled", "fs_build_bla", "fs_bla_num_levels", "fs_bla_lm2", "fs_bla_level_size", "fs_read_bla_level",
-    "fs_clear",
+    "fs_render_direct_lp", "fs_clear",
     "fs_render_current", "fs_sync_compute", "fs_sync_display", "fs_query_compute", "fs_enqueue_done_callback",
     "fs_get_width", "fs_get_height", "fs_last_kernel_ms", "fs_set_kernel_variant", "fs_enable_step_count", "fs_read_step_count",
 ]
@@ -170,6 +171,7 @@ def inputs_lib():
     _decl(lib, "fsh_orbit_data_hdr32_bad", vp, [vp])
     _decl(lib, "fsh_orbit_data_f32_bad", vp, [vp])
     _decl(lib, "fsh_orbit_bad_count", u64, [vp])
+    _decl(lib, "fsh_view_coords_direct_lp", None, [vp, u32, u32, C.c_int, vp])
     _decl(lib, "fsh_view_coords_perturb_hdr32", None, [vp, vp, u32, u32, vp])
     _decl(lib, "fsh_view_coords_perturb_hdr64", None, [vp, vp, u32, u32, vp])
     _decl(lib, "fsh_convert_orbit_hdr64_to_2x32", None, [vp, u64, vp])

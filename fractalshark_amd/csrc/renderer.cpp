@@ -1082,6 +1082,33 @@ uint32_t fs_render_scaled(fs_renderer *r, int type_tag, const void *coords, uint
     return (uint32_t)hipGetLastError();
 }
 
+uint32_t fs_render_direct_lp(fs_renderer *r, int type_tag, const void *coords, uint64_t n_iterations,
+                             int iteration_precision)
+{
+    if (uint32_t e = use_device(r))
+        return e;
+    if (!r->memory_initialized())
+        return 0; // GPU_Render.cu:626-628
+    if ((type_tag != FS_T_F32 && type_tag != FS_T_2X32 && type_tag != FS_T_2X64) || n_iterations > 0xFFFFFFFFull)
+        return FS_ERR_UNSUPPORTED;
+    FsDirectLpArgs A;
+    memset(&A, 0, sizeof(A));
+    A.out = (uint32_t *)r->iters();
+    A.stats = r->stats;
+    A.frame = make_frame(r);
+    A.n_iterations = (uint32_t)n_iterations;
+    if (type_tag == FS_T_F32)
+        memcpy(A.c32, coords, 4 * sizeof(float));
+    else if (type_tag == FS_T_2X32)
+        memcpy(A.c32, coords, 8 * sizeof(float));
+    else
+        memcpy(A.c64, coords, 8 * sizeof(double));
+    TimedLaunch t(r);
+    (void)fsk_direct_lp(A, type_tag == FS_T_F32 ? 0 : (type_tag == FS_T_2X32 ? 1 : 2), iteration_precision, r->stats_on,
+                        r->compute);
+    return (uint32_t)hipGetLastError();
+}
+
 uint32_t fs_clear(fs_renderer *r)
 {
     if (uint32_t e = use_device(r))

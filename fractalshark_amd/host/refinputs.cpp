@@ -238,6 +238,37 @@ extern "C" void fsh_view_coords_direct_f64(const fsh_view *v, uint32_t w_aa, uin
     out[3] = mpf_get_d(v->maxY.v);
 }
 
+// Gpu1x32 / Gpu2x32 / Gpu2x64 (Fractal::CalcGpuFractal<IterType, float | MattDblflt | MattDbldbl>, Fractal.cpp:1896-1915):
+// FillGpuCoords (:1833-1844) = {MinX, MinY, dx, dy} through FillCoord: float = (float)mpf_get_d (:1813-1818, Convert,
+// HighPrecision.h:516-519); MattDblflt = head (float)src, tail (float)(src - HighPrecision{head}) (:1805-1811);
+// MattDbldbl the same in double (:1774-1780).  kind: 0 = float[4], 1 = float[8], 2 = double[8], order cx, cy, dx, dy.
+extern "C" void fsh_view_coords_direct_lp(const fsh_view *v, uint32_t w_aa, uint32_t h_aa, int kind, void *out)
+{
+    mpf_set_default_prec(v->prec_bits);
+    const Mp dx = (v->maxX - v->minX) / Mp::from_ui(w_aa);
+    const Mp dy = (v->maxY - v->minY) / Mp::from_ui(h_aa);
+    const Mp *src[4] = {&v->minX, &v->minY, &dx, &dy};
+    for (int i = 0; i < 4; i++) {
+        if (kind == 0) {
+            ((float *)out)[i] = (float)mpf_get_d(src[i]->v);
+        } else if (kind == 1) {
+            const float head = (float)mpf_get_d(src[i]->v);
+            Mp h;
+            mpf_set_d(h.v, (double)head);
+            const Mp rest = *src[i] - h;
+            ((float *)out)[2 * i] = head;
+            ((float *)out)[2 * i + 1] = (float)mpf_get_d(rest.v);
+        } else {
+            const double head = mpf_get_d(src[i]->v);
+            Mp h;
+            mpf_set_d(h.v, head);
+            const Mp rest = *src[i] - h;
+            ((double *)out)[2 * i] = head;
+            ((double *)out)[2 * i + 1] = mpf_get_d(rest.v);
+        }
+    }
+}
+
 // CpuHDR32 / CpuHDR64 (CalcCpuHDR<.., HDRFloat<F>, F>): dx, dy, minX, maxY as HDRFloat built from mpf
 // (Fractal.cpp:2118-2119,2148-2151): mantissa in [0.5,1), NOT reduced.
 template <class F> static void direct_hdr_coords(const fsh_view &v, uint32_t w_aa, uint32_t h_aa, hreal<F> out[4])

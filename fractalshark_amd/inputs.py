@@ -91,6 +91,15 @@ class View:
         self._lib.fsh_view_coords_direct_f64(self._h, self.width * aa, self.height * aa, out.ctypes.data)
         return out
 
+    def coords_direct_lp(self, kind, aa=None):
+        """{cx = minX, cy = minY, dx, dy} for the Gpu1x32 ("1x32": float32[4]), Gpu2x32 ("2x32": float32[8] head/tail
+        pairs) and Gpu2x64 ("2x64": float64[8]) direct kernels."""
+        aa = self.antialiasing if aa is None else aa
+        k = {"1x32": 0, "2x32": 1, "2x64": 2}[kind]
+        out = np.zeros(4 if k == 0 else 8, np.float64 if k == 2 else np.float32)
+        self._lib.fsh_view_coords_direct_lp(self._h, self.width * aa, self.height * aa, k, out.ctypes.data)
+        return out
+
     def coords_perturb_hdr32(self, orbit, aa=None):
         """{dx, dy, centerX, centerY} as 4 x {float mantissa, int32 exp} (8 x 4 bytes)."""
         aa = self.antialiasing if aa is None else aa

@@ -19,7 +19,7 @@ _pin = None
 
 
 def build():
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("cpu_ref.cpp", "gpu_ref_2x32.cpp")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("cpu_ref.cpp", "gpu_ref_2x32.cpp", "gpu_ref_lp.cpp")]
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(s) for s in srcs):
         subprocess.run(["make", "-C", ORACLE_DIR, "all"], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     # the golden-CRC pin needs the reference's WPngImage/lodepng sources: only buildable where /root/reference is
@@ -55,6 +55,11 @@ def lib():
             getattr(l, name).argtypes = [vp, vp, vp]
         l.orc_h2_reduce.restype = None
         l.orc_h2_reduce.argtypes = [vp]
+        for name in ("orc_gpu_direct_1x32", "orc_gpu_direct_2x32"):
+            getattr(l, name).restype = None
+            getattr(l, name).argtypes = [vp, u32, u32, u32, u32, u32, vp, u32, C.c_int]
+        l.orc_gpu_direct_2x64.restype = None
+        l.orc_gpu_direct_2x64.argtypes = [vp, u32, u32, u32, u32, u32, vp, u32]
         l.orc_gpu_scaled_hdr32.restype = None
         l.orc_gpu_scaled_hdr32.argtypes = [vp, u32, u32, u32, u32, vp, vp, u32, vp, u32, C.c_float, C.c_int, vp]
         l.orc_set_row_step.restype = None
@@ -190,6 +195,21 @@ def gpu_scaled_hdr32(view, orbit, aa=1, rows=None, threads=8, n_iterations=None,
                                orbit.count, co.ctypes.data, n, w2, threads, st)
     if stats:
         return out, {"rescales": st[0], "full_steps": st[1], "float_steps": st[2]}
+    return out
+
+
+def gpu_direct_lp(view, kind, iteration_precision=1, aa=1, rows=None, n_iterations=None):
+    """Restated CUDA direct kernels without a CPU twin (oracle/gpu_ref_lp.cpp).  kind: "1x32" | "2x32" | "2x64"."""
+    w, h = view.width * aa, view.height * aa
+    out = new_buffer(w, h)
+    co = view.coords_direct_lp(kind, aa)
+    y0, y1 = rows if rows else (0, h)
+    n = view.num_iterations if n_iterations is None else n_iterations
+    if kind == "2x64":
+        lib().orc_gpu_direct_2x64(out.ctypes.data, out.shape[1], w, h, y0, y1, co.ctypes.data, n)
+    else:
+        fn = lib().orc_gpu_direct_1x32 if kind == "1x32" else lib().orc_gpu_direct_2x32
+        fn(out.ctypes.data, out.shape[1], w, h, y0, y1, co.ctypes.data, n, iteration_precision)
     return out
 
 

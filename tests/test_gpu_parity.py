@@ -544,3 +544,33 @@ def test_four_renderers_concurrently_and_progressive_readback(native_libs, v5_sm
     assert not errors, errors
     for out in results:
         assert np.array_equal(out, ref)
+
+
+# ---- Gpu1x32 / Gpu2x32 / Gpu2x64 direct kernels (no CPU twin; checker = restated CUDA kernels, oracle/gpu_ref_lp.cpp)
+@pytest.mark.parametrize("kind,ip", [("1x32", 1), ("1x32", 4), ("1x32", 16), ("2x32", 1), ("2x32", 8), ("2x64", 1)])
+def test_low_precision_direct_kernels(renderer, native_libs, kind, ip):
+    from fractalshark_amd import T_2X32, T_2X64, T_F32
+    v = inputs.View.builtin(0, 70, 37)  # ragged size: padding columns / rows stay zero
+    r = renderer
+    assert r.InitializeMemory(70, 37, 1, None, 0, 0, 0, False) == 0
+    assert r.ClearMemory() == 0
+    T = {"1x32": T_F32, "2x32": T_2X32, "2x64": T_2X64}[kind]
+    assert r.RenderLowPrecision(None, v.coords_direct_lp(kind), v.num_iterations, ip, T=T) == 0
+    out = r.new_iter_buffer()
+    assert r.RenderCurrent(v.num_iterations, out) == 0
+    assert r.SyncComputeStream() == 0
+    ref = _oracle.gpu_direct_lp(v, kind, ip)
+    assert np.array_equal(out, ref)
+    # same picture as the pinned Cpu64 render: the GPU kernels sample row R at maxY - dy*(R+1) and start from z = 0
+    # (one extra iteration, rounded up to a multiple of iteration_precision)
+    cpu = _oracle.direct_f64(v)[:37, :70].astype(np.int64)
+    a = out[:36, :70].astype(np.int64)
+    d = a - np.minimum(cpu[1:37] + 1, v.num_iterations)
+    assert ((d >= 0) & (d < ip + 1)).mean() > 0.97
+    if kind != "2x64":  # iteration_precision values the reference does not instantiate launch nothing
+        assert r.ClearMemory() == 0
+        assert r.RenderLowPrecision(None, v.coords_direct_lp(kind), v.num_iterations, 3, T=T) == 0
+        z = r.new_iter_buffer()
+        assert r.RenderCurrent(v.num_iterations, z) == 0
+        assert r.SyncComputeStream() == 0
+        assert not z.any()
