@@ -273,20 +273,35 @@ uint32_t GPURenderer::RenderPerturbBLAScaled(RenderAlgorithm /*algorithm*/,
 
 template <typename IterType, class T>
 uint32_t GPURenderer::Render(RenderAlgorithm /*algorithm*/, T cx, T cy, T dx, T dy, IterType n_iterations,
-                             int /*iteration_precision*/)
+                             int iteration_precision)
 {
     if (!m_ComputeStream)
         return 0;
-    if constexpr (std::is_same<T, double>::value) {
-        const double co[4] = {(double)dx, (double)dy, (double)cx, (double)cy};
-        return fs_render_direct(fsmi355_shim::handle(m_ComputeStream), FS_T_F64, co, (uint64_t)n_iterations);
+    fs_renderer *r = fsmi355_shim::handle(m_ComputeStream);
+    // Fractal::FillGpuCoords hands over the view's MIN corner (Fractal.cpp:1833-1844).
+    if constexpr (std::is_same<T, float>::value) { // Gpu1x32
+        const float co[4] = {cx, cy, dx, dy};
+        return fs_render_direct_lp(r, FS_T_F32, co, (uint64_t)n_iterations, iteration_precision);
+    } else if constexpr (std::is_same<T, ::MattDblflt>::value) { // Gpu2x32
+        const float co[8] = {cx.head, cx.tail, cy.head, cy.tail, dx.head, dx.tail, dy.head, dy.tail};
+        return fs_render_direct_lp(r, FS_T_2X32, co, (uint64_t)n_iterations, iteration_precision);
+    } else if constexpr (std::is_same<T, ::MattDbldbl>::value) { // Gpu2x64
+        const double co[8] = {cx.head, cx.tail, cy.head, cy.tail, dx.head, dx.tail, dy.head, dy.tail};
+        return fs_render_direct_lp(r, FS_T_2X64, co, (uint64_t)n_iterations, iteration_precision);
+    } else if constexpr (std::is_same<T, double>::value) {
+        // Gpu1x64 is built as the twin of the CPU algorithm Cpu64 (rows from maxY downwards, Fractal.cpp:2148-2183).
+        // maxY is not part of this interface: it is rebuilt from the min corner, which rounds differently from
+        // T(ptz.GetMaxY()) in the last place; pass maxY through fs_render_direct directly for bit-equality with Cpu64.
+        const double maxY = (double)cy + (double)dy * (double)m_Height;
+        const double co[4] = {(double)dx, (double)dy, (double)cx, maxY};
+        return fs_render_direct(r, FS_T_F64, co, (uint64_t)n_iterations);
     } else if constexpr (fsmi355_shim::type_tag<T>::value == FS_T_HDR32 || fsmi355_shim::type_tag<T>::value == FS_T_HDR64) {
+        const T maxY = cy + dy * T((float)m_Height);
         const typename fsmi355_shim::abi_real<T>::type co[4] = {fsmi355_shim::to_abi(dx), fsmi355_shim::to_abi(dy),
-                                                                fsmi355_shim::to_abi(cx), fsmi355_shim::to_abi(cy)};
-        return fs_render_direct(fsmi355_shim::handle(m_ComputeStream), fsmi355_shim::type_tag<T>::value, co,
-                                (uint64_t)n_iterations);
+                                                                fsmi355_shim::to_abi(cx), fsmi355_shim::to_abi(maxY)};
+        return fs_render_direct(r, fsmi355_shim::type_tag<T>::value, co, (uint64_t)n_iterations);
     } else {
-        return FS_ERR_UNSUPPORTED;
+        return FS_ERR_UNSUPPORTED; // the 4x (quad-float / quad-double) kernels
     }
 }
 

@@ -36,8 +36,16 @@ template <class T> class HDRFloat {
 public:
     T mantissa;
     int32_t exp;
+    HDRFloat() = default;
+    explicit HDRFloat(float v) : mantissa(T(v)), exp(0) {}
     T getMantissa() const { return mantissa; }
     int32_t getExp() const { return exp; }
+    // arithmetic is the reference's; the stand-in only needs the operators to exist
+    friend HDRFloat operator+(HDRFloat a, const HDRFloat &) { return a; }
+    friend HDRFloat operator*(HDRFloat a, const HDRFloat &) { return a; }
+};
+struct MattDbldbl {
+    double head, tail;
 };
 struct MattDblflt {
     float head, tail;
@@ -195,6 +203,11 @@ template uint32_t GPURenderer::RenderPerturbLAv2<uint32_t, HDR2x32, CudaDblflt<M
 template uint32_t GPURenderer::RenderPerturbBLAScaled<uint32_t, HDR32>(
     RenderAlgorithm, const GPUPerturbResults<uint32_t, HDR32, PerturbExtras::Bad> *,
     const GPUPerturbResults<uint32_t, float, PerturbExtras::Bad> *, HDR32, HDR32, HDR32, HDR32, HDR32, HDR32, uint32_t, int);
+template uint32_t GPURenderer::Render<uint32_t, float>(RenderAlgorithm, float, float, float, float, uint32_t, int);
+template uint32_t GPURenderer::Render<uint32_t, MattDblflt>(RenderAlgorithm, MattDblflt, MattDblflt, MattDblflt, MattDblflt,
+                                                            uint32_t, int);
+template uint32_t GPURenderer::Render<uint32_t, MattDbldbl>(RenderAlgorithm, MattDbldbl, MattDbldbl, MattDbldbl, MattDbldbl,
+                                                            uint32_t, int);
 template uint32_t GPURenderer::InitializeMemory<uint64_t>(uint32_t, uint32_t, uint32_t, const Color16 *, uint32_t,
                                                           uint32_t, uint64_t, bool);
 template void GPURenderer::ClearMemory<uint64_t>();
