@@ -202,6 +202,8 @@ def inputs_lib():
     _decl(lib, "fsh_orbit_f64_count", u64, [vp])
     _decl(lib, "fsh_orbit_f64_period", u64, [vp])
     _decl(lib, "fsh_orbit_f64_data", vp, [vp])
+    _decl(lib, "fsh_orbit_f64_data_bad", vp, [vp])
+    _decl(lib, "fsh_orbit_f64_data_f32_bad", vp, [vp])
     _decl(lib, "fsh_orbit_f64_bla_num_levels", i32, [vp])
     _decl(lib, "fsh_orbit_f64_bla_lm2", i32, [vp])
     _decl(lib, "fsh_orbit_f64_bla_level_ptrs", vp, [vp])

@@ -255,8 +255,8 @@ uint32_t GPURenderer::RenderPerturbBLAScaled(RenderAlgorithm /*algorithm*/,
     if (!m_ComputeStream)
         return 0; // GPU_Render.cu:1317-1319
     constexpr int tag = fsmi355_shim::type_tag<T>::value;
-    if constexpr (tag != FS_T_HDR32) {
-        return FS_ERR_UNSUPPORTED; // Gpu1x32PerturbedScaled (T = double) is not built
+    if constexpr (tag != FS_T_HDR32 && tag != FS_T_F64) {
+        return FS_ERR_UNSUPPORTED;
     } else {
     fs_renderer *r = fsmi355_shim::handle(m_ComputeStream);
     // both orbits are uploaded inside the call, like the reference (GPU_Render.cu:1324-1345)
@@ -265,9 +265,14 @@ uint32_t GPURenderer::RenderPerturbBLAScaled(RenderAlgorithm /*algorithm*/,
                                           float_perturb->GetPeriodMaybeZero());
     if (err)
         return err;
-    const fs_real_hdr32 co[4] = {fsmi355_shim::to_abi(dx), fsmi355_shim::to_abi(dy), fsmi355_shim::to_abi(centerX),
-                                 fsmi355_shim::to_abi(centerY)};
-    return fs_render_scaled(r, tag, co, (uint64_t)n_iterations);
+    if constexpr (tag == FS_T_F64) { // Gpu1x32PerturbedScaled
+        const double co[4] = {(double)dx, (double)dy, (double)centerX, (double)centerY};
+        return fs_render_scaled(r, tag, co, (uint64_t)n_iterations);
+    } else { // GpuHDRx32PerturbedScaled
+        const fs_real_hdr32 co[4] = {fsmi355_shim::to_abi(dx), fsmi355_shim::to_abi(dy), fsmi355_shim::to_abi(centerX),
+                                     fsmi355_shim::to_abi(centerY)};
+        return fs_render_scaled(r, tag, co, (uint64_t)n_iterations);
+    }
     }
 }
 

@@ -150,6 +150,18 @@ struct FsScaledArgs32 {
     float w2threshold; // exp(log(1e30f) / 2), ScaledKernels.cuh:21,66
 };
 
+struct FsScaledArgsF64 { // Gpu1x32PerturbedScaled: T = double
+    uint32_t *out;
+    const fs_orbit_f64_bad *orbit_t;
+    const fs_orbit_f32_bad *orbit_f;
+    uint64_t *stats;
+    FsFrame frame;
+    double dx, dy, centerX, centerY;
+    uint32_t orbit_count;
+    uint32_t n_iterations;
+    float w2threshold;
+};
+
 // Gpu1x32 / Gpu2x32 / Gpu2x64 direct kernels: c32 = {cx, cy, dx, dy} (1x32) or {cx.head, cx.tail, cy.., dx.., dy..} (2x32);
 // c64 = the same eight values as doubles (2x64).  cx / cy are the view's min corner.
 struct FsDirectLpArgs {
@@ -184,6 +196,7 @@ void fsk_lav2_2x32(const FsLav2Args2x32 &A, int mode, bool stats, hipStream_t s)
 // kind: 0 = Gpu1x32, 1 = Gpu2x32, 2 = Gpu2x64; false = iteration_precision the reference does not instantiate
 bool fsk_direct_lp(const FsDirectLpArgs &A, int kind, int iteration_precision, bool stats, hipStream_t s);
 void fsk_scaled_hdr32(const FsScaledArgs32 &A, bool stats, hipStream_t s);
+void fsk_scaled_f64(const FsScaledArgsF64 &A, bool stats, hipStream_t s);
 // BLA table build on the device: levels[l] = device memory for epl[l] records (NULL below the first materialised level 2)
 void fsk_bla_build_hdr32(const float4 *zref, void *const *levels, const uint64_t *epl, int n_levels, fs_real_hdr32 bla_size,
                          hipStream_t s);

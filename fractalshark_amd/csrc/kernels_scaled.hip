@@ -165,6 +165,130 @@ template <bool kStats> __global__ void __launch_bounds__(256) k_scaled_hdr32(FsS
         add_stats(A.stats, c_rescale, c_full, c_float, c_px);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same kernel for T = double (RenderAlgorithm Gpu1x32PerturbedScaled): HdrReduce / HdrSqrt / the HDR comparisons
+// collapse to plain double arithmetic (ScaledKernels.cuh:3-239 with T = double; HdrCompareToBothPositiveReducedLT<T,256>
+// is `zn_size < 256.0`, HDRFloat.h:1584).
+template <bool kStats> __global__ void __launch_bounds__(256) k_scaled_f64(FsScaledArgsF64 A)
+{
+    const uint32_t X = blockIdx.x * 64u + (threadIdx.x & 63u);
+    const uint32_t L = blockIdx.y * 4u + (threadIdx.x >> 6);
+    uint64_t c_rescale = 0, c_full = 0, c_float = 0, c_px = 0;
+    const uint32_t Y = global_row(A.frame, L);
+    const bool live = X < A.frame.width && L < A.frame.local_rows && Y < A.frame.height;
+    if (live) {
+        c_px = 1;
+        const uint32_t n_iterations = A.n_iterations;
+        const uint32_t MaxRefIteration = A.orbit_count - 1;
+        const fs_orbit_f64_bad *__restrict__ ot = A.orbit_t;
+        const fs_orbit_f32_bad *__restrict__ of = A.orbit_f;
+        uint32_t iter = 0, RefIteration = 0;
+        const double DeltaReal = A.dx * (double)(int)X - A.centerX;
+        const double DeltaImaginary = -A.dy * (double)(int)Y - A.centerY;
+        double S = __builtin_sqrt(DeltaReal * DeltaReal + DeltaImaginary * DeltaImaginary);
+        float DeltaSub0DX = (float)(DeltaReal / S);
+        float DeltaSub0DY = (float)(DeltaImaginary / S);
+        float wX = 0.0f, wY = 0.0f;
+        float s = (float)S;
+        float twos = 2 * s;
+        const float w2threshold = A.w2threshold;
+
+#define FS_RESCALE64(NX, NY)                                                                                            \
+    do {                                                                                                                \
+        S = __builtin_sqrt((NX) * (NX) + (NY) * (NY));                                                                  \
+        s = (float)S;                                                                                                   \
+        twos = 2 * s;                                                                                                   \
+        DeltaSub0DX = (float)(DeltaReal / S);                                                                           \
+        DeltaSub0DY = (float)(DeltaImaginary / S);                                                                      \
+        wX = (float)((NX) / S);                                                                                         \
+        wY = (float)((NY) / S);                                                                                         \
+    } while (0)
+
+        while (iter < n_iterations) {
+            const fs_orbit_f32_bad cf = of[RefIteration];
+            if (cf.bad == 0) {
+                const float ox = wX, oy = wY;
+                wX = ox * cf.x * 2 - oy * cf.y * 2 + s * ox * ox - s * oy * oy + DeltaSub0DX;
+                wY = ox * (cf.y * 2 + twos * oy) + oy * cf.x * 2 + DeltaSub0DY;
+                if (kStats)
+                    c_float++;
+                ++RefIteration;
+                const fs_orbit_f32_bad nf = of[RefIteration];
+                const float tempZX = nf.x + wX * s;
+                const float tempZY = nf.y + wY * s;
+                const float zn_size = tempZX * tempZX + tempZY * tempZY;
+                const float w2 = wX * wX + wY * wY;
+                const float normDeltaSubN = w2 * s * s;
+                const bool zn_size_OK = zn_size < 256.0f;
+                const bool test1a = zn_size < normDeltaSubN;
+                const bool test1b = RefIteration == MaxRefIteration;
+                const bool test1ab = test1a || (test1b && zn_size_OK);
+                const bool testw2 = (w2 >= w2threshold) && zn_size_OK;
+                const bool none = !test1ab && !testw2 && zn_size_OK;
+                if (none) {
+                    ++iter;
+                    continue;
+                } else if (test1ab) {
+                    const double ZX = ot[RefIteration].x + (double)wX * S;
+                    const double ZY = ot[RefIteration].y + (double)wY * S;
+                    RefIteration = 0;
+                    FS_RESCALE64(ZX, ZY);
+                    if (kStats)
+                        c_rescale++;
+                    ++iter;
+                    continue;
+                } else if (testw2) {
+                    const double ZX = (double)wX * S;
+                    const double ZY = (double)wY * S;
+                    FS_RESCALE64(ZX, ZY);
+                    if (kStats)
+                        c_rescale++;
+                    ++iter;
+                    continue;
+                } else {
+                    break;
+                }
+            } else {
+                const double ox = (double)wX, oy = (double)wY;
+                const double cxr = ot[RefIteration].x, cyr = ot[RefIteration].y;
+                double nX = ox * cxr * 2;
+                nX -= oy * cyr * 2;
+                nX += S * ox * ox;
+                nX -= S * oy * oy;
+                nX += DeltaReal / S;
+                double nY = ox * (cyr * 2 + 2.0 * S * oy);
+                nY += oy * cxr * 2;
+                nY += DeltaImaginary / S;
+                if (kStats)
+                    c_full++;
+                ++RefIteration;
+                const double tempZX = ot[RefIteration].x + nX * S;
+                const double tempZY = ot[RefIteration].y + nY * S;
+                const double zn_size = tempZX * tempZX + tempZY * tempZY;
+                if (!(zn_size < 256.0))
+                    break;
+                const double TwoS = S * S;
+                const double normDeltaSubN = nX * nX * TwoS + nY * nY * TwoS;
+                double NewX, NewY;
+                if (zn_size < normDeltaSubN || RefIteration == MaxRefIteration) {
+                    NewX = ot[RefIteration].x + nX * S;
+                    NewY = ot[RefIteration].y + nY * S;
+                    RefIteration = 0;
+                } else {
+                    NewX = nX * S;
+                    NewY = nY * S;
+                }
+                FS_RESCALE64(NewX, NewY);
+            }
+            ++iter;
+        }
+#undef FS_RESCALE64
+        store_iter(A.out, A.frame, L, X, iter);
+    }
+    if (kStats)
+        add_stats(A.stats, c_rescale, c_full, c_float, c_px);
+}
+
 } // namespace
 
 void fsk_scaled_hdr32(const FsScaledArgs32 &A, bool stats, hipStream_t s)
@@ -175,4 +299,14 @@ void fsk_scaled_hdr32(const FsScaledArgs32 &A, bool stats, hipStream_t s)
         hipLaunchKernelGGL((k_scaled_hdr32<true>), g, b, 0, s, A);
     else
         hipLaunchKernelGGL((k_scaled_hdr32<false>), g, b, 0, s, A);
+}
+
+void fsk_scaled_f64(const FsScaledArgsF64 &A, bool stats, hipStream_t s)
+{
+    const dim3 b(256);
+    const dim3 g((A.frame.width + 63) / 64, (A.frame.local_rows + 3) / 4);
+    if (stats)
+        hipLaunchKernelGGL((k_scaled_f64<true>), g, b, 0, s, A);
+    else
+        hipLaunchKernelGGL((k_scaled_f64<false>), g, b, 0, s, A);
 }

@@ -59,7 +59,8 @@ struct fs_renderer {
     bool orbit_ok = false;
     int orbit_type = -1; // FS_T_HDR32 / FS_T_HDR64 / FS_T_HDR2X32 / FS_T_F64
     fs_orbit_2x32 *orbit_2x32 = nullptr; // HDRFloat<CudaDblflt> orbit (FS_T_HDR2X32), used as uploaded
-    fs_orbit_hdr32_bad *scaled_t = nullptr; // PerturbExtras::Bad orbits of the scaled kernel
+    int scaled_type = -1;
+    void *scaled_t = nullptr; // PerturbExtras::Bad orbits of the scaled kernel (fs_orbit_hdr32_bad[] or fs_orbit_f64_bad[])
     fs_orbit_f32_bad *scaled_f = nullptr;
     uint64_t scaled_count = 0;
     float4 *zref = nullptr;
@@ -1034,7 +1035,8 @@ uint32_t fs_upload_orbit_scaled(fs_renderer *r, int type_tag, uint32_t iter_byte
     (void)period_maybe_zero;
     if (uint32_t e = use_device(r))
         return e;
-    if (type_tag != FS_T_HDR32 || (iter_bytes != 4 && iter_bytes != 8) || orbit_size > 0xFFFFFFFFull || orbit_size < 2)
+    if ((type_tag != FS_T_HDR32 && type_tag != FS_T_F64) || (iter_bytes != 4 && iter_bytes != 8) ||
+        orbit_size > 0xFFFFFFFFull || orbit_size < 2)
         return FS_ERR_UNSUPPORTED;
     if (!r->compute)
         return FS_ERR_6;
@@ -1047,12 +1049,14 @@ uint32_t fs_upload_orbit_scaled(fs_renderer *r, int type_tag, uint32_t iter_byte
         r->scaled_f = nullptr;
     }
     r->scaled_count = 0;
-    FS_TRY(hipMalloc((void **)&r->scaled_t, orbit_size * sizeof(fs_orbit_hdr32_bad)));
+    const size_t t_bytes = type_tag == FS_T_HDR32 ? sizeof(fs_orbit_hdr32_bad) : sizeof(fs_orbit_f64_bad);
+    FS_TRY(hipMalloc(&r->scaled_t, orbit_size * t_bytes));
     FS_TRY(hipMalloc((void **)&r->scaled_f, orbit_size * sizeof(fs_orbit_f32_bad)));
-    FS_TRY(hipMemcpyAsync(r->scaled_t, entries_t, orbit_size * sizeof(fs_orbit_hdr32_bad), hipMemcpyDefault, r->compute));
+    FS_TRY(hipMemcpyAsync(r->scaled_t, entries_t, orbit_size * t_bytes, hipMemcpyDefault, r->compute));
     FS_TRY(hipMemcpyAsync(r->scaled_f, entries_f32, orbit_size * sizeof(fs_orbit_f32_bad), hipMemcpyDefault, r->compute));
     FS_TRY(hipStreamSynchronize(r->compute)); // host buffers are borrowed for the call only
     r->scaled_count = orbit_size;
+    r->scaled_type = type_tag;
     return 0;
 }
 
@@ -1062,21 +1066,39 @@ uint32_t fs_render_scaled(fs_renderer *r, int type_tag, const void *coords, uint
         return e;
     if (!r->memory_initialized())
         return 0; // GPU_Render.cu:1317-1319
-    if (type_tag != FS_T_HDR32 || n_iterations > 0xFFFFFFFFull)
+    if ((type_tag != FS_T_HDR32 && type_tag != FS_T_F64) || n_iterations > 0xFFFFFFFFull)
         return FS_ERR_UNSUPPORTED;
-    if (!r->scaled_t || !r->scaled_f || r->scaled_count < 2)
+    if (!r->scaled_t || !r->scaled_f || r->scaled_count < 2 || r->scaled_type != type_tag)
         return FS_ERR_6;
+    const float w2threshold = (float)exp(log((double)1e30f) / 2.0);
+    if (type_tag == FS_T_F64) {
+        FsScaledArgsF64 A;
+        memset(&A, 0, sizeof(A));
+        A.out = (uint32_t *)r->iters();
+        A.orbit_t = (const fs_orbit_f64_bad *)r->scaled_t;
+        A.orbit_f = r->scaled_f;
+        A.stats = r->stats;
+        A.frame = make_frame(r);
+        const double *c = (const double *)coords;
+        A.dx = c[0], A.dy = c[1], A.centerX = c[2], A.centerY = c[3];
+        A.orbit_count = (uint32_t)r->scaled_count;
+        A.n_iterations = (uint32_t)n_iterations;
+        A.w2threshold = w2threshold;
+        TimedLaunch t(r);
+        fsk_scaled_f64(A, r->stats_on, r->compute);
+        return (uint32_t)hipGetLastError();
+    }
     FsScaledArgs32 A;
     memset(&A, 0, sizeof(A));
     A.out = (uint32_t *)r->iters();
-    A.orbit_t = r->scaled_t;
+    A.orbit_t = (const fs_orbit_hdr32_bad *)r->scaled_t;
     A.orbit_f = r->scaled_f;
     A.stats = r->stats;
     A.frame = make_frame(r);
     fill_coords(A.coords, coords);
     A.orbit_count = (uint32_t)r->scaled_count;
     A.n_iterations = (uint32_t)n_iterations;
-    A.w2threshold = (float)exp(log((double)1e30f) / 2.0);
+    A.w2threshold = w2threshold;
     TimedLaunch t(r);
     fsk_scaled_hdr32(A, r->stats_on, r->compute);
     return (uint32_t)hipGetLastError();

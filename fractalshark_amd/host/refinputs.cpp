@@ -1797,6 +1797,9 @@ extern "C" const uint64_t *fsh_bla_level_sizes(const fsh_bla *b) { return b->siz
 // AddPerturbationReferencePointST (RefOrbitCalc.cpp:481-488,524-530,564-604,617-622) and BLAS.cpp with T = double.
 struct fsh_orbit_f64 {
     std::vector<fs_orbit_f64> z; // entry 0 = {0,0}
+    std::vector<uint8_t> bad;    // PerturbExtras::Bad flag per entry (RefOrbitCalc.cpp:550-562,625-627)
+    std::vector<fs_orbit_f64_bad> packed_bad;
+    std::vector<fs_orbit_f32_bad> packed_f32_bad;
     uint64_t period = 0;
     double maxRadius = 0;
     Mp cx, cy;
@@ -1819,6 +1822,7 @@ extern "C" fsh_orbit_f64 *fsh_orbit_f64_create(const fsh_view *vwp, uint64_t max
         ob->maxRadius = mpf_get_d(delta.v) / 2.0; // T{delta} / T{2.0f}
     }
     ob->z.push_back(fs_orbit_f64{0.0, 0.0});
+    ob->bad.push_back(0);
     mpf_t cx, cy, zx, zy, zx2, t1, t2;
     mpf_init(cx);
     mpf_set(cx, ob->cx.v);
@@ -1837,6 +1841,14 @@ extern "C" fsh_orbit_f64 *fsh_orbit_f64_create(const fsh_view *vwp, uint64_t max
         mpf_mul_2exp(zx2, zx, 1);
         const double double_zx = mpf_get_d(zx), double_zy = mpf_get_d(zy);
         ob->z.push_back(fs_orbit_f64{double_zx, double_zy});
+        {
+            const double small_float = 1.1754944e-38, glitch = 0.0000001;
+            const double norm = (double_zx * double_zx + double_zy * double_zy) * glitch;
+            ob->bad.push_back((std::fabs(double_zx) <= small_float || std::fabs(double_zy) <= small_float ||
+                               norm <= small_float)
+                                  ? 1
+                                  : 0);
+        }
         if (periodicity) {
             const double n2 = std::max(std::fabs(double_zx), std::fabs(double_zy));
             const double r0 = std::max(std::fabs(dzdcX), std::fabs(dzdcY));
@@ -1868,6 +1880,8 @@ extern "C" fsh_orbit_f64 *fsh_orbit_f64_create(const fsh_view *vwp, uint64_t max
     mpf_clear(zx2);
     mpf_clear(t1);
     mpf_clear(t2);
+
+    ob->bad.back() = 0; // results->SetBad(false), RefOrbitCalc.cpp:625-627
 
     // BLAS<uint32_t,double>::Init(count, maxRadius), BLAS.cpp:25-255 with plain double (BLA.cuh:40-91)
     {
@@ -1937,6 +1951,26 @@ extern "C" fsh_orbit_f64 *fsh_orbit_f64_create(const fsh_view *vwp, uint64_t max
     }
     return ob.release();
 }
+// PerturbExtras::Bad form of the double orbit + its binary32 copy (Gpu1x32PerturbedScaled)
+extern "C" const fs_orbit_f64_bad *fsh_orbit_f64_data_bad(fsh_orbit_f64 *o)
+{
+    if (o->packed_bad.size() != o->z.size()) {
+        o->packed_bad.resize(o->z.size());
+        for (size_t i = 0; i < o->z.size(); i++)
+            o->packed_bad[i] = fs_orbit_f64_bad{o->bad[i], 0u, o->z[i].x, o->z[i].y};
+    }
+    return o->packed_bad.data();
+}
+extern "C" const fs_orbit_f32_bad *fsh_orbit_f64_data_f32_bad(fsh_orbit_f64 *o)
+{
+    if (o->packed_f32_bad.size() != o->z.size()) {
+        o->packed_f32_bad.resize(o->z.size());
+        for (size_t i = 0; i < o->z.size(); i++)
+            o->packed_f32_bad[i] = fs_orbit_f32_bad{o->bad[i] != 0 ? 1u : 0u, 0u, (float)o->z[i].x, (float)o->z[i].y};
+    }
+    return o->packed_f32_bad.data();
+}
+
 extern "C" void fsh_orbit_f64_destroy(fsh_orbit_f64 *o) { delete o; }
 extern "C" uint64_t fsh_orbit_f64_count(const fsh_orbit_f64 *o) { return o->z.size(); }
 extern "C" uint64_t fsh_orbit_f64_period(const fsh_orbit_f64 *o) { return o->period; }

@@ -405,6 +405,14 @@ class OrbitF64:
         return self._lib.fsh_orbit_f64_data(self._h)
 
     @property
+    def bad_data_ptr(self):
+        return self._lib.fsh_orbit_f64_data_bad(self._h)
+
+    @property
+    def bad_f32_data_ptr(self):
+        return self._lib.fsh_orbit_f64_data_f32_bad(self._h)
+
+    @property
     def level_ptrs(self):
         return self._lib.fsh_orbit_f64_bla_level_ptrs(self._h)
 

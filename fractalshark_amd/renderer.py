@@ -160,15 +160,19 @@ class GPURenderer:
 
     def RenderPerturbBLAScaled(self, algorithm, double_perturb, float_perturb, cx, cy, dx, dy, centerX, centerY,
                                n_iterations, iteration_precision=1, T=T_HDR32):
-        """GpuHDRx32PerturbedScaled.  double_perturb / float_perturb: the same inputs.Orbit (hdr32) -- its
-        PerturbExtras::Bad form and the binary32 copy are taken from it; uploaded on every call like the reference
+        """GpuHDRx32PerturbedScaled (T_HDR32: double_perturb = inputs.Orbit, coords (mantissa, exp) pairs) or
+        Gpu1x32PerturbedScaled (T_F64: double_perturb = inputs.OrbitF64, coords doubles).  The PerturbExtras::Bad form of
+        the orbit and its binary32 copy are taken from it; uploaded on every call like the reference
         (GPU_Render.cu:1324-1345)."""
         ob = double_perturb
         err = self._lib.fs_upload_orbit_scaled(self._h, T, 4, ob.bad_data_ptr, (float_perturb or ob).bad_f32_data_ptr,
                                                ob.count, ob.period)
         if err:
             return err
-        co = self._pack_coords(T, [dx, dy, centerX, centerY])
+        if T == T_F64:
+            co = np.array([dx, dy, centerX, centerY], dtype=np.float64)
+        else:
+            co = self._pack_coords(T, [dx, dy, centerX, centerY])
         return self._lib.fs_render_scaled(self._h, T, co.ctypes.data, int(n_iterations))
 
     def BuildBLAOnDevice(self, orbit, T=None):

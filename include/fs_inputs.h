@@ -120,6 +120,8 @@ void fsh_orbit_f64_destroy(fsh_orbit_f64 *o);
 uint64_t fsh_orbit_f64_count(const fsh_orbit_f64 *o);
 uint64_t fsh_orbit_f64_period(const fsh_orbit_f64 *o);
 const fs_orbit_f64 *fsh_orbit_f64_data(const fsh_orbit_f64 *o);
+const fs_orbit_f64_bad *fsh_orbit_f64_data_bad(fsh_orbit_f64 *o);         /* PerturbExtras::Bad form ... */
+const fs_orbit_f32_bad *fsh_orbit_f64_data_f32_bad(fsh_orbit_f64 *o);     /* ... and its binary32 copy */
 int32_t fsh_orbit_f64_bla_num_levels(const fsh_orbit_f64 *o);
 int32_t fsh_orbit_f64_bla_lm2(const fsh_orbit_f64 *o);
 const void *const *fsh_orbit_f64_bla_level_ptrs(const fsh_orbit_f64 *o); /* fs_bla_f64[] per level */

@@ -97,6 +97,14 @@ typedef struct fs_orbit_hdr32_bad {
     float my;
 } fs_orbit_hdr32_bad;
 
+/* GPUReferenceIter<double, Bad>: 24 B */
+typedef struct fs_orbit_f64_bad {
+    uint32_t bad;
+    uint32_t padding;
+    double x;
+    double y;
+} fs_orbit_f64_bad;
+
 typedef struct fs_orbit_f32_bad {
     uint32_t bad;
     uint32_t padding;
@@ -327,7 +335,8 @@ typedef struct fs_reduction {
 static_assert(sizeof(fs_orbit_hdr32) == 16, "orbit entry");
 static_assert(sizeof(fs_orbit_hdr32_rc) == 24 && sizeof(fs_orbit_hdr64_rc) == 40, "compressed orbit entry");
 static_assert(sizeof(fs_orbit_hdr64) == 32, "orbit entry (double)");
-static_assert(sizeof(fs_orbit_hdr32_bad) == 24 && sizeof(fs_orbit_f32_bad) == 16, "PerturbExtras::Bad orbit entries");
+static_assert(sizeof(fs_orbit_hdr32_bad) == 24 && sizeof(fs_orbit_f32_bad) == 16 && sizeof(fs_orbit_f64_bad) == 24,
+              "PerturbExtras::Bad orbit entries");
 static_assert(sizeof(fs_la_hdr32_u32) == 68, "LA record");
 static_assert(sizeof(fs_at_hdr32_u32) == 116, "AT record");
 static_assert(sizeof(fs_bla_hdr32) == 44, "BLA record");

@@ -1049,3 +1049,113 @@ extern "C" void orc_gpu_scaled_hdr32(uint32_t *out, uint32_t pitch, uint32_t wid
         stats[2] = s_float;
     }
 }
+
+// The same kernel for T = double (Gpu1x32PerturbedScaled): plain double arithmetic.  PARITY UNPINNED, same conventions.
+extern "C" void orc_gpu_scaled_f64(uint32_t *out, uint32_t pitch, uint32_t width, uint32_t y0, uint32_t y1,
+                                   const fs_orbit_f64_bad *orbT, const fs_orbit_f32_bad *orbF, uint32_t count,
+                                   const double coords[4], uint32_t n_iterations, float w2threshold, int threads,
+                                   uint64_t *stats)
+{
+    const double dx = coords[0], dy = coords[1], centerX = coords[2], centerY = coords[3];
+    std::atomic<uint64_t> s_rescale{0}, s_full{0}, s_float{0};
+    const uint32_t MaxRefIteration = count - 1;
+    run_rows(y0, y1, threads, [&](uint32_t Y) {
+        uint64_t c_rescale = 0, c_full = 0, c_float = 0;
+        for (uint32_t X = 0; X < width; X++) {
+            uint32_t iter = 0, RefIteration = 0;
+            const double DeltaReal = dx * (double)(int)X - centerX;
+            const double DeltaImaginary = -dy * (double)(int)Y - centerY;
+            double S = std::sqrt(DeltaReal * DeltaReal + DeltaImaginary * DeltaImaginary);
+            float DeltaSub0DX = (float)(DeltaReal / S), DeltaSub0DY = (float)(DeltaImaginary / S);
+            float DeltaSubNWX = 0, DeltaSubNWY = 0;
+            float s = (float)S, twos = 2 * s;
+            auto rescale = [&](double NewX, double NewY) {
+                S = std::sqrt(NewX * NewX + NewY * NewY);
+                s = (float)S;
+                twos = 2 * s;
+                DeltaSub0DX = (float)(DeltaReal / S);
+                DeltaSub0DY = (float)(DeltaImaginary / S);
+                DeltaSubNWX = (float)(NewX / S);
+                DeltaSubNWY = (float)(NewY / S);
+            };
+            while (iter < n_iterations) {
+                if (orbF[RefIteration].bad == 0) {
+                    const float fx = orbF[RefIteration].x, fy = orbF[RefIteration].y;
+                    const float wx = DeltaSubNWX, wy = DeltaSubNWY;
+                    DeltaSubNWX = wx * fx * 2 - wy * fy * 2 + s * wx * wx - s * wy * wy + DeltaSub0DX;
+                    DeltaSubNWY = wx * (fy * 2 + twos * wy) + wy * fx * 2 + DeltaSub0DY;
+                    c_float++;
+                    ++RefIteration;
+                    const float tempZX = orbF[RefIteration].x + DeltaSubNWX * s;
+                    const float tempZY = orbF[RefIteration].y + DeltaSubNWY * s;
+                    const float zn_size = tempZX * tempZX + tempZY * tempZY;
+                    const float w2 = DeltaSubNWX * DeltaSubNWX + DeltaSubNWY * DeltaSubNWY;
+                    const float normDeltaSubN = w2 * s * s;
+                    const bool zn_size_OK = zn_size < 256.0f;
+                    const bool test1ab = (zn_size < normDeltaSubN) || ((RefIteration == MaxRefIteration) && zn_size_OK);
+                    const bool testw2 = (w2 >= w2threshold) && zn_size_OK;
+                    const bool none = !test1ab && !testw2 && zn_size_OK;
+                    if (none) {
+                        ++iter;
+                        continue;
+                    } else if (test1ab) {
+                        const double ZX = orbT[RefIteration].x + (double)DeltaSubNWX * S;
+                        const double ZY = orbT[RefIteration].y + (double)DeltaSubNWY * S;
+                        RefIteration = 0;
+                        rescale(ZX, ZY);
+                        c_rescale++;
+                        ++iter;
+                        continue;
+                    } else if (testw2) {
+                        rescale((double)DeltaSubNWX * S, (double)DeltaSubNWY * S);
+                        c_rescale++;
+                        ++iter;
+                        continue;
+                    } else {
+                        break;
+                    }
+                } else {
+                    const double wx = (double)DeltaSubNWX, wy = (double)DeltaSubNWY;
+                    const double cxr = orbT[RefIteration].x, cyr = orbT[RefIteration].y;
+                    double nX = wx * cxr * 2;
+                    nX -= wy * cyr * 2;
+                    nX += S * wx * wx;
+                    nX -= S * wy * wy;
+                    nX += DeltaReal / S;
+                    double nY = wx * (cyr * 2 + 2.0 * S * wy);
+                    nY += wy * cxr * 2;
+                    nY += DeltaImaginary / S;
+                    c_full++;
+                    ++RefIteration;
+                    const double tempZX = orbT[RefIteration].x + nX * S;
+                    const double tempZY = orbT[RefIteration].y + nY * S;
+                    const double zn_size = tempZX * tempZX + tempZY * tempZY;
+                    if (!(zn_size < 256.0))
+                        break;
+                    const double TwoS = S * S;
+                    const double normDeltaSubN = nX * nX * TwoS + nY * nY * TwoS;
+                    double NewX, NewY;
+                    if (zn_size < normDeltaSubN || RefIteration == MaxRefIteration) {
+                        NewX = orbT[RefIteration].x + nX * S;
+                        NewY = orbT[RefIteration].y + nY * S;
+                        RefIteration = 0;
+                    } else {
+                        NewX = nX * S;
+                        NewY = nY * S;
+                    }
+                    rescale(NewX, NewY);
+                }
+                ++iter;
+            }
+            out[(size_t)Y * pitch + X] = iter;
+        }
+        s_rescale += c_rescale;
+        s_full += c_full;
+        s_float += c_float;
+    });
+    if (stats) {
+        stats[0] = s_rescale;
+        stats[1] = s_full;
+        stats[2] = s_float;
+    }
+}

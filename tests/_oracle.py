@@ -62,6 +62,8 @@ def lib():
         l.orc_gpu_direct_2x64.argtypes = [vp, u32, u32, u32, u32, u32, vp, u32]
         l.orc_gpu_scaled_hdr32.restype = None
         l.orc_gpu_scaled_hdr32.argtypes = [vp, u32, u32, u32, u32, vp, vp, u32, vp, u32, C.c_float, C.c_int, vp]
+        l.orc_gpu_scaled_f64.restype = None
+        l.orc_gpu_scaled_f64.argtypes = [vp, u32, u32, u32, u32, vp, vp, u32, vp, u32, C.c_float, C.c_int, vp]
         l.orc_set_row_step.restype = None
         l.orc_set_row_step.argtypes = [u32]
         _lib = l
@@ -193,6 +195,23 @@ def gpu_scaled_hdr32(view, orbit, aa=1, rows=None, threads=8, n_iterations=None,
     w2 = float(np.float32(math.exp(math.log(float(np.float32(1e30))) / 2.0)))
     lib().orc_gpu_scaled_hdr32(out.ctypes.data, out.shape[1], w, y0, y1, orbit.bad_data_ptr, orbit.bad_f32_data_ptr,
                                orbit.count, co.ctypes.data, n, w2, threads, st)
+    if stats:
+        return out, {"rescales": st[0], "full_steps": st[1], "float_steps": st[2]}
+    return out
+
+
+def gpu_scaled_f64(view, orbit, aa=1, rows=None, threads=8, n_iterations=None, stats=False):
+    """Restated CUDA kernel mandel_1x_float_perturb_scaled<.., double> (oracle/cpu_ref.cpp); orbit: inputs.OrbitF64."""
+    import math
+    w, h = view.width * aa, view.height * aa
+    out = new_buffer(w, h)
+    co = orbit.coords(aa)
+    y0, y1 = rows if rows else (0, h)
+    n = view.num_iterations if n_iterations is None else n_iterations
+    st = (u64 * 3)()
+    w2 = float(np.float32(math.exp(math.log(float(np.float32(1e30))) / 2.0)))
+    lib().orc_gpu_scaled_f64(out.ctypes.data, out.shape[1], w, y0, y1, orbit.bad_data_ptr, orbit.bad_f32_data_ptr,
+                             orbit.count, co.ctypes.data, n, w2, threads, st)
     if stats:
         return out, {"rescales": st[0], "full_steps": st[1], "float_steps": st[2]}
     return out

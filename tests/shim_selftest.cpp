@@ -208,6 +208,9 @@ template uint32_t GPURenderer::Render<uint32_t, MattDblflt>(RenderAlgorithm, Mat
                                                             uint32_t, int);
 template uint32_t GPURenderer::Render<uint32_t, MattDbldbl>(RenderAlgorithm, MattDbldbl, MattDbldbl, MattDbldbl, MattDbldbl,
                                                             uint32_t, int);
+template uint32_t GPURenderer::RenderPerturbBLAScaled<uint32_t, double>(
+    RenderAlgorithm, const GPUPerturbResults<uint32_t, double, PerturbExtras::Bad> *,
+    const GPUPerturbResults<uint32_t, float, PerturbExtras::Bad> *, double, double, double, double, double, double, uint32_t, int);
 template uint32_t GPURenderer::InitializeMemory<uint64_t>(uint32_t, uint32_t, uint32_t, const Color16 *, uint32_t,
                                                           uint32_t, uint64_t, bool);
 template void GPURenderer::ClearMemory<uint64_t>();

@@ -574,3 +574,23 @@ def test_low_precision_direct_kernels(renderer, native_libs, kind, ip):
         assert r.RenderCurrent(v.num_iterations, z) == 0
         assert r.SyncComputeStream() == 0
         assert not z.any()
+
+
+def test_scaled_f64_matches_restated_cuda_kernel(renderer, native_libs):
+    """Gpu1x32PerturbedScaled (T = double): View 5 is in double range (2^-148), so the plain-double orbit works."""
+    v = inputs.View.builtin(5, 64, 36)
+    ob = inputs.OrbitF64(v)
+    r = renderer
+    assert r.InitializeMemory(64, 36, 1, None, 0, 0, 0, False) == 0
+    assert r.ClearMemory() == 0
+    co = ob.coords()
+    assert r.RenderPerturbBLAScaled(None, ob, ob, None, None, co[0], co[1], co[2], co[3], v.num_iterations, T=T_F64) == 0
+    out = r.new_iter_buffer()
+    assert r.RenderCurrent(v.num_iterations, out) == 0
+    assert r.SyncComputeStream() == 0
+    ref = _oracle.gpu_scaled_f64(v, ob)
+    assert np.array_equal(out, ref)
+    # same picture as the plain-double perturbation path (Cpu64PerturbedBLA without BLA) up to binary32 glitches
+    dbl = _oracle.bla_f64(v, ob, use_bla=False)
+    d = np.abs(out[:36, :64].astype(np.int64) - dbl[:36, :64].astype(np.int64))
+    assert np.median(d) <= 16 and (d <= 2).mean() > 0.25
