@@ -174,6 +174,10 @@ def inputs_lib():
     _decl(lib, "fsh_view_coords_direct_lp", None, [vp, u32, u32, C.c_int, vp])
     _decl(lib, "fsh_view_coords_perturb_hdr32", None, [vp, vp, u32, u32, vp])
     _decl(lib, "fsh_view_coords_perturb_hdr64", None, [vp, vp, u32, u32, vp])
+    _decl(lib, "fsh_df32_op", None, [C.c_int, vp, vp, vp])
+    _decl(lib, "fsh_hr2_reduce", None, [vp])
+    _decl(lib, "fsh_hr2_add", None, [vp, vp, C.c_int, vp])
+    _decl(lib, "fsh_hc2_reduce", None, [vp])
     _decl(lib, "fsh_convert_orbit_hdr64_to_2x32", None, [vp, u64, vp])
     _decl(lib, "fsh_convert_la_hdr64_to_2x32", None, [vp, u64, vp])
     _decl(lib, "fsh_convert_at_hdr64_to_2x32", None, [vp, vp])

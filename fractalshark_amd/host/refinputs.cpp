@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "../csrc/hdr_math.hpp"
+#include "../csrc/df32_math.hpp"
 #include "../../include/fs_inputs.h"
 
 using namespace fs;
@@ -724,6 +725,34 @@ inline fs_cplx_2x32 cplx_2x32(const fs_cplx_hdr64 &c)
 }
 
 } // namespace
+
+// Host-side entry points into the product's 2x32 arithmetic (csrc/df32_math.hpp is one header for host and device): the
+// CPU test-suite cross-checks them bit for bit against the oracle's independent restatement.
+extern "C" void fsh_df32_op(int op, const float a[2], const float b[2], float out[2])
+{
+    const fs::df32 x(a[0], a[1]), y(b[0], b[1]);
+    const fs::df32 r = op == 0 ? x + y : (op == 1 ? x - y : x * y);
+    out[0] = r.head;
+    out[1] = r.tail;
+}
+extern "C" void fsh_hr2_reduce(fs_real_2x32 *v)
+{
+    fs::hreal<fs::df32> h{fs::df32(v->head, v->tail), v->e};
+    fs::hr_reduce(h);
+    *v = fs_real_2x32{h.m.head, h.m.tail, h.e};
+}
+extern "C" void fsh_hr2_add(const fs_real_2x32 *a, const fs_real_2x32 *b, int subtract, fs_real_2x32 *out)
+{
+    const fs::hreal<fs::df32> x{fs::df32(a->head, a->tail), a->e}, y{fs::df32(b->head, b->tail), b->e};
+    const fs::hreal<fs::df32> r = subtract ? fs::hr_sub(x, y) : fs::hr_add(x, y);
+    *out = fs_real_2x32{r.m.head, r.m.tail, r.e};
+}
+extern "C" void fsh_hc2_reduce(fs_cplx_2x32 *v)
+{
+    fs::hcplx<fs::df32> c{fs::df32(v->re_head, v->re_tail), fs::df32(v->im_head, v->im_tail), v->e};
+    fs::hc_reduce(c);
+    *v = fs_cplx_2x32{c.re.head, c.re.tail, c.im.head, c.im.tail, c.e};
+}
 
 extern "C" void fsh_convert_orbit_hdr64_to_2x32(const fs_orbit_hdr64 *in, uint64_t n, fs_orbit_2x32 *out)
 {

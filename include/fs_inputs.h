@@ -84,6 +84,13 @@ void fsh_convert_at_hdr64_to_2x32(const fs_at_hdr64_u32 *in, fs_at_2x32_u32 *out
 void fsh_view_coords_perturb_2x32(const fsh_view *v, const fsh_orbit *o, uint32_t w_aa, uint32_t h_aa,
                                   fs_real_2x32 out[4]);
 
+/* Host instantiation of the product's 2x32 arithmetic (fractalshark_amd/csrc/df32_math.hpp), for CPU-side cross-checks.
+ * op: 0 add, 1 sub, 2 mul on (head, tail) pairs. */
+void fsh_df32_op(int op, const float a[2], const float b[2], float out[2]);
+void fsh_hr2_reduce(fs_real_2x32 *v);
+void fsh_hr2_add(const fs_real_2x32 *a, const fs_real_2x32 *b, int subtract, fs_real_2x32 *out);
+void fsh_hc2_reduce(fs_cplx_2x32 *v);
+
 /* LAv2 table (LAReference::GenerateApproximationData).  host_threads = std::thread::hardware_concurrency()
  * of the machine being mirrored: the reference's multi-threaded stage-0 scan splits the orbit into
  * min(count/50000, host_threads) chunks and the chunking can move record boundaries. */

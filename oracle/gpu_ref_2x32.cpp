@@ -421,6 +421,18 @@ void orc_h2_reduce(fs_real_2x32 *v)
     *v = fs_real_2x32{h.m.head, h.m.tail, h.e};
 }
 
+void orc_h2_add(const fs_real_2x32 *a, const fs_real_2x32 *b, int subtract, fs_real_2x32 *out)
+{
+    const H2 r = subtract ? H2Sub(RealOf(*a), RealOf(*b)) : H2Add(RealOf(*a), RealOf(*b));
+    *out = fs_real_2x32{r.m.head, r.m.tail, r.e};
+}
+void orc_c2_reduce(fs_cplx_2x32 *v)
+{
+    C2 c = CplxOf(*v);
+    C2Reduce(c);
+    *v = fs_cplx_2x32{c.re.head, c.re.tail, c.im.head, c.im.tail, c.e};
+}
+
 // mode: 0 = Full, 1 = PO, 2 = LAO (RenderAlgorithm.h:12-17).  stats (optional, [3]): AT iterations, LA steps,
 // perturbation steps summed over the rendered rows.
 void orc_gpu_lav2_2x32(uint32_t *out, uint32_t pitch, uint32_t width, uint32_t y0, uint32_t y1,

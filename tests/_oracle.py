@@ -55,6 +55,10 @@ def lib():
             getattr(l, name).argtypes = [vp, vp, vp]
         l.orc_h2_reduce.restype = None
         l.orc_h2_reduce.argtypes = [vp]
+        l.orc_h2_add.restype = None
+        l.orc_h2_add.argtypes = [vp, vp, C.c_int, vp]
+        l.orc_c2_reduce.restype = None
+        l.orc_c2_reduce.argtypes = [vp]
         for name in ("orc_gpu_direct_1x32", "orc_gpu_direct_2x32"):
             getattr(l, name).restype = None
             getattr(l, name).argtypes = [vp, u32, u32, u32, u32, u32, vp, u32, C.c_int]

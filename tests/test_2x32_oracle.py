@@ -120,3 +120,56 @@ def test_2x32_render_tracks_the_pinned_hdr64_oracle(view5_2x32):
     assert stpo["at_iterations"] == 0 and stpo["la_steps"] == 0
     # perturbation-only agrees with the approximated render except at a few chaotic pixels
     assert (np.abs(po[:2, : v.width].astype(np.int64) - a[:2]) <= 2).mean() > 0.8
+
+
+def test_product_df32_host_build_matches_oracle_bitwise(native_libs):
+    """fractalshark_amd/csrc/df32_math.hpp (the header the HIP kernel is built from, instantiated for the host in
+    libfsinputs.so) against the oracle's independent restatement: double-float primitives, HDR add/sub with its 4-way
+    exponent alignment, real and complex Reduce -- bit for bit on random and edge-case operands."""
+    from fractalshark_amd import _capi
+    hl = _capi.inputs_lib()
+    ol = _oracle.lib()
+    rng = np.random.default_rng(99)
+
+    def pair(scale_exp):
+        p = _norm_pair(rng, 2.0 ** scale_exp)
+        return np.float32(p[0]), np.float32(p[1])
+
+    for k in range(3000):
+        a, b = pair(int(rng.integers(-30, 30))), pair(int(rng.integers(-30, 30)))
+        for op, name in ((0, "orc_df_add"), (1, "orc_df_sub"), (2, "orc_df_mul")):
+            o1, o2 = (C.c_float * 2)(), (C.c_float * 2)()
+            hl.fsh_df32_op(op, _df(a), _df(b), o1)
+            getattr(ol, name)(_df(a), _df(b), o2)
+            assert bytes(o1) == bytes(o2), (op, a, b)
+    recs = []
+    for k in range(3000):
+        ea, eb = int(rng.integers(-300, 300)), 0
+        eb = ea + int(rng.choice([0, 1, -1, 5, -5, 119, -119, 120, -120, 121, -121, 126, -127, 200, -200]))
+        a, b = pair(0), pair(0)
+        recs.append(((a[0], a[1], ea), (b[0], b[1], eb)))
+    recs.append(((0.0, 0.0, -268435456), (1.5, 1e-9, -3)))      # zero + x
+    recs.append(((1.5, 1e-9, -3), (0.0, 0.0, -268435456)))      # x + zero
+    recs.append(((1.25, 0.0, 7), (-1.25, 0.0, 7)))              # exact cancellation: exponent reset to MIN
+    for ra, rb in recs:
+        A = np.array([ra], inputs.REAL_2X32)
+        B = np.array([rb], inputs.REAL_2X32)
+        for sub in (0, 1):
+            o1, o2 = np.zeros(1, inputs.REAL_2X32), np.zeros(1, inputs.REAL_2X32)
+            hl.fsh_hr2_add(A.ctypes.data, B.ctypes.data, sub, o1.ctypes.data)
+            ol.orc_h2_add(A.ctypes.data, B.ctypes.data, sub, o2.ctypes.data)
+            assert o1.tobytes() == o2.tobytes(), (ra, rb, sub)
+        r1, r2 = A.copy(), A.copy()
+        hl.fsh_hr2_reduce(r1.ctypes.data)
+        ol.orc_h2_reduce(r2.ctypes.data)
+        assert r1.tobytes() == r2.tobytes()
+    cdt = np.dtype([("re_head", "<f4"), ("re_tail", "<f4"), ("im_head", "<f4"), ("im_tail", "<f4"), ("e", "<i4")])
+    for k in range(2000):
+        re, im = pair(int(rng.integers(-40, 40))), pair(int(rng.integers(-40, 40)))
+        if k % 50 == 0:
+            im = (np.float32(0.0), np.float32(0.0))
+        c1 = np.array([(re[0], re[1], im[0], im[1], int(rng.integers(-500, 500)))], cdt)
+        c2 = c1.copy()
+        hl.fsh_hc2_reduce(c1.ctypes.data)
+        ol.orc_c2_reduce(c2.ctypes.data)
+        assert c1.tobytes() == c2.tobytes()
