@@ -16,6 +16,16 @@ __device__ __forceinline__ uint32_t global_row(const FsFrame &f, uint32_t L)
     return f.band_first + k * f.band_stride + rr;
 }
 
+// Pixel of this lane under the square-tile mapping: a wave covers an 8 x 8 pixel tile (4 tiles side by side per 256-thread
+// block) instead of 64 pixels of one row.  Iteration counts are correlated in two dimensions, so a compact tile keeps the
+// lanes of a wave closer together in how long they run and in which orbit position they read.
+__device__ __forceinline__ void tile_pixel(uint32_t &X, uint32_t &L)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    X = blockIdx.x * 32u + wave * 8u + (lane & 7u);
+    L = blockIdx.y * 8u + (lane >> 3);
+}
+
 // One result into the iteration buffer: OutputIterMatrix[ConvertLocToIndex(X, Y, width)] (GPU_Render.cu:73-79) for
 // IterType = uint32_t or uint64_t.  Counts are computed in 32 bits (the ABI refuses n_iterations >= 2^32).
 __device__ __forceinline__ void store_iter(uint32_t *out, const FsFrame &f, uint32_t L, uint32_t X, uint32_t v)

@@ -715,8 +715,8 @@ __device__ __forceinline__ const typename FsDev<F>::BLA *bla_lookup(const FsBlaA
 template <class F, bool kBla, bool kStats>
 __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
 {
-    const uint32_t X = blockIdx.x * 64u + (threadIdx.x & 63u);
-    const uint32_t L = blockIdx.y * 4u + (threadIdx.x >> 6);
+    uint32_t X, L;
+    tile_pixel(X, L);
     uint64_t c_la = 0, c_pt = 0, c_px = 0;
     const uint32_t Y = global_row(A.frame, L);
     const bool live = X < A.frame.width && L < A.frame.local_rows && Y < A.frame.height;
@@ -1405,6 +1405,7 @@ __global__ void __launch_bounds__(256) k_perturb_bla_f64(FsBlaArgsF64 A)
 // ------------------------------------------------------------------------------------------------
 // Host-callable launchers (called from renderer.cpp through kernels.h).
 static dim3 frame_grid(const FsFrame &f) { return dim3((f.width + 63) / 64, (f.local_rows + 3) / 4, 1); }
+static dim3 tile_grid(const FsFrame &f) { return dim3((f.width + 31) / 32, (f.local_rows + 7) / 8, 1); } // tile_pixel()
 
 void fsk_prepare_orbit_hdr32(const fs_orbit_hdr32 *in, float4 *out, uint64_t n, hipStream_t s)
 {
@@ -1444,7 +1445,7 @@ void fsk_lav2_hdr32(const FsLav2Args32 &A, int mode, bool stats, int variant, hi
 
 void fsk_perturb_scalar_hdr32(const FsBlaArgs32 &A, bool use_bla, bool stats, hipStream_t s)
 {
-    const dim3 g = frame_grid(A.frame), b(256);
+    const dim3 g = tile_grid(A.frame), b(256);
     if (use_bla) {
         if (stats)
             hipLaunchKernelGGL((k_perturb_scalar<float, true, true>), g, b, 0, s, A);
@@ -1527,7 +1528,7 @@ void fsk_lav2_hdr64(const FsLav2ArgsT<double> &A, int mode, bool stats, hipStrea
 
 void fsk_perturb_scalar_hdr64(const FsBlaArgsT<double> &A, bool use_bla, bool stats, hipStream_t s)
 {
-    const dim3 g = frame_grid(A.frame), b(256);
+    const dim3 g = tile_grid(A.frame), b(256);
     if (use_bla) {
         if (stats)
             hipLaunchKernelGGL((k_perturb_scalar<double, true, true>), g, b, 0, s, A);
