@@ -156,8 +156,8 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
     // The float instantiation is the operation-by-operation A/B reference of the tuned kernel and keeps the literal AT
     // loop; the double instantiation is the production HDRFloat<double> kernel and uses the steady-state AT loop.
     constexpr bool kFastAT = sizeof(F) == 8;
-    const uint32_t X = blockIdx.x * 64u + (threadIdx.x & 63u);
-    const uint32_t L = blockIdx.y * 4u + (threadIdx.x >> 6);
+    uint32_t X, L;
+    tile_pixel(X, L);
     uint64_t c_at = 0, c_la = 0, c_pt = 0, c_px = 0;
     const uint32_t Y = global_row(A.frame, L);
     const bool live = X < A.frame.width && L < A.frame.local_rows && Y < A.frame.height;
@@ -351,8 +351,8 @@ __device__ __forceinline__ long long norm_key_nz(float m, int e)
 template <int Mode, bool kStats>
 __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
 {
-    const uint32_t X = blockIdx.x * 64u + (threadIdx.x & 63u);
-    const uint32_t L = blockIdx.y * 4u + (threadIdx.x >> 6);
+    uint32_t X, L;
+    tile_pixel(X, L);
     uint64_t c_at = 0, c_la = 0, c_pt = 0, c_px = 0;
     uint64_t c_careful = 0;
     const uint32_t Y = global_row(A.frame, L);
@@ -1419,7 +1419,7 @@ void fsk_make_quiet_orbit(const float4 *zref, float4 *zq, uint64_t n, hipStream_
 
 void fsk_lav2_hdr32(const FsLav2Args32 &A, int mode, bool stats, int variant, hipStream_t s)
 {
-    const dim3 g = frame_grid(A.frame), b(256);
+    const dim3 g = tile_grid(A.frame), b(256);
 #define FS_LAUNCH(M)                                                                                                \
     do {                                                                                                            \
         if (variant == FS_VARIANT_LITERAL) {                                                                        \
@@ -1509,7 +1509,7 @@ void fsk_prepare_orbit_hdr64(const fs_orbit_hdr64 *in, FsZ64 *out, uint64_t n, h
 
 void fsk_lav2_hdr64(const FsLav2ArgsT<double> &A, int mode, bool stats, hipStream_t s)
 {
-    const dim3 g = frame_grid(A.frame), b(256);
+    const dim3 g = tile_grid(A.frame), b(256);
 #define FS_LAUNCH64(M)                                                                                              \
     do {                                                                                                            \
         if (stats)                                                                                                  \

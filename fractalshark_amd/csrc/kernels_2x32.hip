@@ -56,8 +56,8 @@ __device__ __forceinline__ bool below_bailout(HR n)
 
 template <int Mode, bool kStats> __global__ void __launch_bounds__(256) k_lav2_2x32(FsLav2Args2x32 A)
 {
-    const uint32_t X = blockIdx.x * 64u + (threadIdx.x & 63u);
-    const uint32_t L = blockIdx.y * 4u + (threadIdx.x >> 6);
+    uint32_t X, L;
+    tile_pixel(X, L);
     uint64_t c_at = 0, c_la = 0, c_pt = 0, c_px = 0;
     const uint32_t Y = global_row(A.frame, L);
     const bool live = X < A.frame.width && L < A.frame.local_rows && Y < A.frame.height;
@@ -189,7 +189,7 @@ template <int Mode, bool kStats> __global__ void __launch_bounds__(256) k_lav2_2
 void fsk_lav2_2x32(const FsLav2Args2x32 &A, int mode, bool stats, hipStream_t s)
 {
     const dim3 b(256);
-    const dim3 g((A.frame.width + 63) / 64, (A.frame.local_rows + 3) / 4);
+    const dim3 g((A.frame.width + 31) / 32, (A.frame.local_rows + 7) / 8); // tile_pixel()
 #define FS_LAUNCH(M)                                                                                                    \
     do {                                                                                                                \
         if (stats)                                                                                                      \
