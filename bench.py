@@ -280,8 +280,13 @@ def main():
             # sum = 20 flop; AT iteration = 8 products + 5 sums, perturbation step = 12 products + 10 sums + 6 exact
             # power-of-two scalings (another 6 products), LA step = 22 products + 12 sums.
             flops = at_iters * 196.0 + perturb_steps * 416.0 + la_steps * 504.0
+        elif is64:
+            # HDRFloat<double>: FP64 operations; AT iteration = 5 mul + 5 add (z*z + c on bare mantissas + the norm),
+            # perturbation step = 18, LA step = 2 complex mul-adds + 2 norms = 40
+            flops = at_iters * 10.0 + perturb_steps * FLOP_PER_STEP + la_steps * 40.0
         else:
             flops = perturb_steps * FLOP_PER_STEP
+        peak = PEAK_FP64_VECTOR_TFLOPS if (is64 and not is2x32) else PEAK_FP32_VECTOR_TFLOPS
         achieved = flops / (avg_kernel_ms * 1e-3) / 1e12
         line = {
             "metric": "Mpix/s (iteration buffer), View #5 3840x2160 HDRx32 LAv2" if args.workload == "c3_lav2"
@@ -297,8 +302,8 @@ def main():
                        "la_records": la.count if la else 0, "la_stages": la.stage_count if la else 0,
                        "bla_levels": bla.num_levels if bla else 0, "tiling": "rows/8-row bands interleaved x%d" % world,
                        "host_input_build_s": round(t_inputs, 3)},
-            "roofline": {"bound": "valu", "achieved": round(achieved, 4), "peak": PEAK_FP32_VECTOR_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 5), "traffic": traffic,
+            "roofline": {"bound": "valu", "achieved": round(achieved, 4), "peak": peak,
+                         "unit": "TFLOP/s", "frac": round(achieved / peak, 5), "traffic": traffic,
                          "kernel": {"c3_lav2": "k_lav2_hdr32_fast", "c4_hdr64": "k_lav2_lit<double>",
                                     "c4_2x32": "k_lav2_2x32"}.get(args.workload, "k_perturb_scalar"),
                          "kernel_ms": round(avg_kernel_ms, 3),
