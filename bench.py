@@ -30,6 +30,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 FLOP_PER_STEP = 18            # complex dz*(2Z+dz)+dc, |Z+dz|^2, |dz|^2
 PEAK_FP32_VECTOR_TFLOPS = 157.3
+PEAK_FP64_VECTOR_TFLOPS = 78.6
 
 
 def effective_cpus():
@@ -60,9 +61,11 @@ def parse():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--view", type=int, default=-1)
-    ap.add_argument("--parity", choices=["cpu", "cpu_gpustage"], default="cpu",
+    ap.add_argument("--parity", choices=["cpu", "cpu_gpustage"], default=None,
                     help="cpu = literal reference CPU function (bit-exact vs Cpu32PerturbedBLAV2HDR); "
-                         "cpu_gpustage = same arithmetic, LA stage test in the GPU/FractalZoomer direction")
+                         "cpu_gpustage = same arithmetic, LA stage test in the GPU/FractalZoomer direction. "
+                         "Default: cpu, except c4_hdr64 (cpu_gpustage: the literal CPU direction skips every LA "
+                         "stage at View 14 and iterates towards the 2^31 cap)")
     ap.add_argument("--cpu-sample-rows", type=int, default=0,
                     help="rows of the frame timed on the CPU (0 = 8 x usable host threads, about 10-30 s of CPU work)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -106,6 +109,8 @@ def main():
         args.width = defaults[1]
     if args.height <= 0:
         args.height = defaults[2]
+    if args.parity is None:
+        args.parity = "cpu_gpustage" if args.workload == "c4_hdr64" else "cpu"
     t0 = time.time()
     is_lav2 = args.workload in ("c3_lav2", "c4_hdr64", "c4_2x32")
     is2x32 = args.workload == "c4_2x32"

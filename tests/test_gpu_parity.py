@@ -594,3 +594,38 @@ def test_scaled_f64_matches_restated_cuda_kernel(renderer, native_libs):
     dbl = _oracle.bla_f64(v, ob, use_bla=False)
     d = np.abs(out[:36, :64].astype(np.int64) - dbl[:36, :64].astype(np.int64))
     assert np.median(d) <= 16 and (d <= 2).mean() > 0.25
+
+
+# ---- more built-in views: different depths (2^-60 ... 2^-2400), periods (59 ... 52 860), stage counts (1 ... 12)
+@pytest.mark.parametrize("view_n", [2, 3, 9, 11])
+@pytest.mark.parametrize("is64", [False, True])
+def test_other_views_lav2_and_bla_parity(renderer, native_libs, view_n, is64):
+    v = inputs.View.builtin(view_n, 64, 36, antialiasing=1)
+    ob = inputs.Orbit(v, is64=is64)
+    la = inputs.LATable(ob)
+    for parity, st in ((PARITY_CPU, 0), (PARITY_CPU_GPUSTAGE, 1)):
+        out, red = _render_lav2(renderer, v, ob, la, LAV2_FULL, parity)
+        ref = _oracle.lav2_hdr32(v, ob, la, stage_test=st)
+        assert np.array_equal(out, ref), (view_n, is64, parity)
+        assert red.Sum == int(ref[:36, :64].astype(np.uint64).sum())
+    if view_n != 9:  # perturbation only / BLA (view 9 needs 2e7 literal steps on the CPU side: covered by LAv2 above)
+        out, _ = _render_lav2(renderer, v, ob, la, LAV2_PO, PARITY_CPU)
+        assert np.array_equal(out, _oracle.bla_hdr32(v, ob, None))
+        bla = inputs.BLATable(ob)
+        r = renderer
+        dx, dy, cx, cy = _pairs(v.coords_perturb(ob))
+        assert r.RenderPerturbBLA(None, ob, bla, None, None, dx, dy, cx, cy, v.num_iterations) == 0
+        out = r.new_iter_buffer()
+        assert r.RenderCurrent(v.num_iterations, out) == 0
+        assert r.SyncComputeStream() == 0
+        assert np.array_equal(out, _oracle.bla_hdr32(v, ob, bla))
+
+
+def test_other_views_2x32(renderer, native_libs):
+    for view_n in (3, 11):
+        v = inputs.View.builtin(view_n, 64, 36, antialiasing=1)
+        o = inputs.Orbit(v, is64=True)
+        la = inputs.LATable(o, use_small_exponents=True)
+        o2, la2 = inputs.Orbit2x32(o), inputs.LATable2x32(la)
+        out, _ = _render_2x32(renderer, v, o2, la2, LAV2_FULL)
+        assert np.array_equal(out, _oracle.gpu_lav2_2x32(v, o2, la2, mode=0)), view_n

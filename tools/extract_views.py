@@ -11,7 +11,7 @@ import re
 import sys
 
 SRC = "/root/reference/FractalSharkLib/FractalViewPresets.cpp"
-WANT = [1, 5, 14, 19]
+WANT = [1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 14, 15, 17, 19, 22]
 
 
 def main():
