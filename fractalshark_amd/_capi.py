@@ -201,6 +201,24 @@ def inputs_lib():
     _decl(lib, "fsh_bla_lm2", i32, [vp])
     _decl(lib, "fsh_bla_level_ptrs", vp, [vp])
     _decl(lib, "fsh_bla_level_sizes", vp, [vp])
+    _decl(lib, "fsh_plain_create", vp, [vp, C.c_int, u64, C.c_int, C.c_int])
+    _decl(lib, "fsh_plain_destroy", None, [vp])
+    _decl(lib, "fsh_plain_kind", C.c_int, [vp])
+    _decl(lib, "fsh_plain_orbit_count", u64, [vp])
+    _decl(lib, "fsh_plain_orbit_period", u64, [vp])
+    _decl(lib, "fsh_plain_orbit_data", vp, [vp])
+    _decl(lib, "fsh_plain_la_count", u32, [vp])
+    _decl(lib, "fsh_plain_la_data", vp, [vp])
+    _decl(lib, "fsh_plain_la_stage_count", u32, [vp])
+    _decl(lib, "fsh_plain_la_stages", vp, [vp])
+    _decl(lib, "fsh_plain_la_is_valid", C.c_int, [vp])
+    _decl(lib, "fsh_plain_la_use_at", C.c_int, [vp])
+    _decl(lib, "fsh_plain_la_at", None, [vp, vp])
+    _decl(lib, "fsh_plain_coords", None, [vp, vp, u32, u32, vp])
+    _decl(lib, "fsh_convert_orbit_f64_to_p2x32", None, [vp, u64, vp])
+    _decl(lib, "fsh_convert_la_f64_to_p2x32", None, [vp, u64, vp])
+    _decl(lib, "fsh_convert_at_f64_to_p2x32", None, [vp, vp])
+    _decl(lib, "fsh_convert_coords_f64_to_p2x32", None, [vp, vp])
     _decl(lib, "fsh_orbit_f64_create", vp, [vp, u64, C.c_int])
     _decl(lib, "fsh_orbit_f64_destroy", None, [vp])
     _decl(lib, "fsh_orbit_f64_count", u64, [vp])

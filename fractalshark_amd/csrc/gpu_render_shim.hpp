@@ -45,6 +45,12 @@ template <class T> struct type_tag {
 template <> struct type_tag<double> {
     static constexpr int value = FS_T_F64;
 };
+template <> struct type_tag<float> {
+    static constexpr int value = FS_T_F32;
+};
+template <> struct type_tag<::CudaDblflt<::MattDblflt>> {
+    static constexpr int value = FS_T_2X32;
+};
 template <> struct type_tag<::HDRFloat<float>> {
     static constexpr int value = FS_T_HDR32;
 };
@@ -81,7 +87,26 @@ inline fs_real_2x32 to_abi(const ::HDRFloat<::CudaDblflt<::MattDblflt>> &v)
     r.e = v.getExp();
     return r;
 }
+// the plain (non-HDR) types cross the ABI as themselves; CudaDblflt<MattDblflt> = {head, tail} = fs_real_p2x32
+inline float to_abi(float v) { return v; }
+inline double to_abi(double v) { return v; }
+inline fs_real_p2x32 to_abi(const ::CudaDblflt<::MattDblflt> &v)
+{
+    fs_real_p2x32 r;
+    r.head = v.head();
+    r.tail = v.tail();
+    return r;
+}
 template <class T> struct abi_real;
+template <> struct abi_real<float> {
+    using type = float;
+};
+template <> struct abi_real<double> {
+    using type = double;
+};
+template <> struct abi_real<::CudaDblflt<::MattDblflt>> {
+    using type = fs_real_p2x32;
+};
 template <> struct abi_real<::HDRFloat<::CudaDblflt<::MattDblflt>>> {
     using type = fs_real_2x32;
 };
@@ -195,11 +220,13 @@ uint32_t GPURenderer::RenderPerturbLAv2(RenderAlgorithm /*algorithm*/, T /*cx*/,
     if (!m_ComputeStream)
         return 0; // "memory not initialised" is silent, GPU_Render.cu:1007-1009
     constexpr int tag = fsmi355_shim::type_tag<T>::value;
-    if constexpr (tag != FS_T_HDR32 && tag != FS_T_HDR64 && tag != FS_T_HDR2X32) {
+    if constexpr (tag < 0) {
         return FS_ERR_UNSUPPORTED;
     } else {
-    // PExtras only changes how the orbit was uploaded (InitializePerturb); the 2x32 kernel reads uncompressed orbits only
-    if (PExtras != PerturbExtras::Disable && (PExtras != PerturbExtras::SimpleCompression || tag == FS_T_HDR2X32))
+    // PExtras only changes how the orbit was uploaded (InitializePerturb); the 2x32 and the non-HDR kernels read
+    // uncompressed orbits only
+    if (PExtras != PerturbExtras::Disable &&
+        (PExtras != PerturbExtras::SimpleCompression || (tag != FS_T_HDR32 && tag != FS_T_HDR64)))
         return FS_ERR_UNSUPPORTED;
     const typename fsmi355_shim::abi_real<T>::type co[4] = {fsmi355_shim::to_abi(dx), fsmi355_shim::to_abi(dy),
                                                             fsmi355_shim::to_abi(centerX), fsmi355_shim::to_abi(centerY)};

@@ -136,6 +136,24 @@ struct FsLav2Args2x32 {
     int use_at;
 };
 
+// Non-HDR LAv2 (Gpu1x32 / Gpu1x64 / Gpu2x32 PerturbedLAv2*): records in the reference layouts of the selected type
+// (fs_layout.h "plain" families); `at` and `coords` hold the ATInfo record / the four coordinates of that type.
+struct FsLav2ArgsPlain {
+    uint32_t *out;
+    const void *orbit;
+    const void *las;
+    const fs_la_stage_u32 *stages;
+    uint64_t *stats;
+    FsFrame frame;
+    alignas(8) uint8_t at[sizeof(fs_at_f64_u32)];
+    alignas(8) uint8_t coords[4 * sizeof(double)];
+    uint32_t orbit_count;
+    uint32_t stage_count;
+    uint32_t n_iterations;
+    int la_valid;
+    int use_at;
+};
+
 // Scaled perturbation (GpuHDRx32PerturbedScaled): the HDRFloat<float> orbit with `bad` flags and its binary32 copy,
 // both in the reference layouts.
 struct FsScaledArgs32 {
@@ -193,6 +211,8 @@ void fsk_make_quiet_orbit(const float4 *zref, float4 *zq, uint64_t n, hipStream_
 void fsk_lav2_hdr32(const FsLav2Args32 &A, int mode, bool stats, int variant, hipStream_t s);
 void fsk_lav2_hdr64(const FsLav2ArgsT<double> &A, int mode, bool stats, hipStream_t s);
 void fsk_lav2_2x32(const FsLav2Args2x32 &A, int mode, bool stats, hipStream_t s);
+// kind: 0 = float, 1 = double, 2 = CudaDblflt
+void fsk_lav2_plain(const FsLav2ArgsPlain &A, int kind, int mode, bool stats, hipStream_t s);
 // kind: 0 = Gpu1x32, 1 = Gpu2x32, 2 = Gpu2x64; false = iteration_precision the reference does not instantiate
 bool fsk_direct_lp(const FsDirectLpArgs &A, int kind, int iteration_precision, bool stats, hipStream_t s);
 void fsk_scaled_hdr32(const FsScaledArgs32 &A, bool stats, hipStream_t s);

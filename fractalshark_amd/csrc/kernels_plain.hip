@@ -1,0 +1,250 @@
+// kernels_plain.hip -- LAv2 for the non-HDR numeric types: T = float (RenderAlgorithm Gpu1x32PerturbedLAv2[PO|LAO],
+// GPU_Render.cu:1025-1043), double (Gpu1x64PerturbedLAv2*, :1077-1100) and CudaDblflt (Gpu2x32PerturbedLAv2*, :1044-1076).
+// Fractal's AUTO mode renders zoom factors 1e4 .. 1e34 with the float kernel (Fractal.cpp:958-966).
+// Compiled with -ffp-contract=off: every operation below is one IEEE operation, as written.
+//
+// No CPU RenderAlgorithm runs LAv2 on a plain T, so the semantics restated here are those of the CUDA kernel itself,
+// mandel_1xHDR_float_perturb_lav2<IterType, T, T, Mode, PExtras> (FractalSharkGpuLib/LAKernel.cuh:3-315) with its
+// `else` arms for non-HDR types: FloatComplex<T> arithmetic (FloatComplex.h:188-268,327-331,413-419), HdrReduce a no-op,
+// compares by operator< / >= (HDRFloat.h:1536-1586; GPU_LAReference.h:238-254; GPU_LAInfoDeep.h:90-106), bailout
+// |z|^2 < T(256), the AT shortcut of ATInfo.h:126-188.  The checker is oracle/gpu_ref_plain.cpp (parity unpinned: see
+// its header).
+//
+// Decomposition: one lane per (sub)pixel, a wave covers an 8 x 8 pixel tile (kernel_common.hpp), the orbit and the LA
+// table are read straight from L2 (the lanes of a wave read the same or neighbouring entries).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fs_layout.h"
+#include "df32_math.hpp"
+#include "kernels.h"
+#include "kernel_common.hpp"
+
+using namespace fs;
+
+namespace {
+
+template <class T> struct Plain;
+template <> struct Plain<float> {
+    using Orbit = fs_orbit_f32;
+    using LA = fs_la_f32_u32;
+    using AT = fs_at_f32_u32;
+    using Real = float;
+    static __device__ __forceinline__ float from_int(int v) { return (float)v; }
+};
+template <> struct Plain<double> {
+    using Orbit = fs_orbit_f64;
+    using LA = fs_la_f64_u32;
+    using AT = fs_at_f64_u32;
+    using Real = double;
+    static __device__ __forceinline__ double from_int(int v) { return (double)v; }
+};
+template <> struct Plain<df32> {
+    using Orbit = fs_orbit_p2x32;
+    using LA = fs_la_p2x32_u32;
+    using AT = fs_at_p2x32_u32;
+    using Real = fs_real_p2x32;
+    // on the device only CudaDblflt(float) is viable for T(X) with an int X (CudaDblflt.h:52-68)
+    static __device__ __forceinline__ df32 from_int(int v) { return df32((float)v); }
+};
+
+template <class T> struct cx {
+    T re, im;
+};
+template <class T> __device__ __forceinline__ cx<T> operator+(cx<T> a, cx<T> b) { return cx<T>{a.re + b.re, a.im + b.im}; }
+// times_mutable(FloatComplex), FloatComplex.h:198-211
+template <class T> __device__ __forceinline__ cx<T> operator*(cx<T> a, cx<T> b)
+{
+    const T re = (a.re * b.re) - (a.im * b.im);
+    const T im = (a.re * b.im) + (a.im * b.re);
+    return cx<T>{re, im};
+}
+template <class T> __device__ __forceinline__ cx<T> mul_real(cx<T> a, T f) { return cx<T>{a.re * f, a.im * f}; }
+template <class T> __device__ __forceinline__ T norm2(cx<T> a) { return a.re * a.re + a.im * a.im; }
+template <class T> __device__ __forceinline__ T cheb(cx<T> a)
+{
+    const T ar = fabs_bits<T>(a.re), ai = fabs_bits<T>(a.im);
+    return ar > ai ? ar : ai;
+}
+
+__device__ __forceinline__ float ld(float v) { return v; }
+__device__ __forceinline__ double ld(double v) { return v; }
+__device__ __forceinline__ df32 ld(const fs_real_p2x32 &v) { return df32(v.head, v.tail); }
+__device__ __forceinline__ cx<float> ld(const fs_cplx_f32 &c) { return cx<float>{c.re, c.im}; }
+__device__ __forceinline__ cx<double> ld(const fs_cplx_f64 &c) { return cx<double>{c.re, c.im}; }
+__device__ __forceinline__ cx<df32> ld(const fs_cplx_p2x32 &c)
+{
+    return cx<df32>{df32(c.re_head, c.re_tail), df32(c.im_head, c.im_tail)};
+}
+__device__ __forceinline__ cx<float> ldz(const fs_orbit_f32 *__restrict__ o, uint32_t i)
+{
+    const float2 v = *reinterpret_cast<const float2 *>(o + i);
+    return cx<float>{v.x, v.y};
+}
+__device__ __forceinline__ cx<double> ldz(const fs_orbit_f64 *__restrict__ o, uint32_t i)
+{
+    const double2 v = *reinterpret_cast<const double2 *>(o + i);
+    return cx<double>{v.x, v.y};
+}
+__device__ __forceinline__ cx<df32> ldz(const fs_orbit_p2x32 *__restrict__ o, uint32_t i)
+{
+    const float4 v = *reinterpret_cast<const float4 *>(o + i);
+    return cx<df32>{df32(v.x, v.y), df32(v.z, v.w)};
+}
+
+template <class T, int Mode, bool kStats> __global__ void __launch_bounds__(256) k_lav2_plain(FsLav2ArgsPlain A)
+{
+    using P = Plain<T>;
+    uint32_t X, L;
+    tile_pixel(X, L);
+    uint64_t c_at = 0, c_la = 0, c_pt = 0, c_px = 0;
+    const uint32_t Y = global_row(A.frame, L);
+    const bool live = X < A.frame.width && L < A.frame.local_rows && Y < A.frame.height;
+    if (live) {
+        c_px = 1;
+        const uint32_t n_iterations = A.n_iterations;
+        const typename P::Real *co = reinterpret_cast<const typename P::Real *>(A.coords);
+        const typename P::AT &at = *reinterpret_cast<const typename P::AT *>(A.at);
+        const typename P::LA *__restrict__ las = reinterpret_cast<const typename P::LA *>(A.las);
+        const typename P::Orbit *__restrict__ orb = reinterpret_cast<const typename P::Orbit *>(A.orbit);
+        const T Two = P::from_int(2);
+        // LAKernel.cuh:39-63
+        const T DeltaSub0X = ld(co[0]) * P::from_int((int)X) - ld(co[2]);
+        const T DeltaSub0Y = -ld(co[1]) * P::from_int((int)Y) - ld(co[3]);
+        const cx<T> DeltaSub0{DeltaSub0X, DeltaSub0Y};
+        cx<T> DeltaSubN{P::from_int(0), P::from_int(0)};
+        uint32_t iter = 0, RefIteration = 0;
+
+        if (Mode != FS_MODE_PO) {
+            // :66-71 + ATInfo::isValid / PerformAT (plain arms), ATInfo.h:126-188.  For T = CudaDblflt `<=` is the
+            // reference's operator as written (CudaDblflt.h:218-222, df32_math.hpp).
+            if (A.la_valid && A.use_at && cheb(DeltaSub0) <= ld(at.ThresholdC)) {
+                const uint32_t ATMaxIt = n_iterations / at.StepLength;
+                const cx<T> c = DeltaSub0 * ld(at.CCoeff) + ld(at.RefC);
+                cx<T> z{P::from_int(0), P::from_int(0)};
+                const T esc = ld(at.SqrEscapeRadius);
+                uint32_t i;
+                for (i = 0; i < ATMaxIt; i++) {
+                    if (norm2(z) > esc)
+                        break;
+                    z = z * z + c;
+                }
+                DeltaSubN = z * ld(at.InvZCoeff);
+                iter = i * at.StepLength;
+                if (kStats)
+                    c_at = i;
+            }
+            // :73-131 (complex0's value before the stage loop is dead)
+            uint32_t CurrentLAStage = A.la_valid ? A.stage_count : 0;
+            const T dcCheb = cheb(DeltaSub0);
+            while (CurrentLAStage > 0) {
+                CurrentLAStage--;
+                const uint32_t LAIndex = A.stages[CurrentLAStage].LAIndex;
+                if (dcCheb >= ld(las[LAIndex].LAThresholdC)) // GPU_LAReference.h:238-254
+                    continue;
+                const uint32_t MacroItCount = A.stages[CurrentLAStage].MacroItCount;
+                uint32_t j = RefIteration;
+                while (iter < n_iterations) {
+                    const typename P::LA *LAj = &las[LAIndex + j]; // getLA, GPU_LAReference.h:271-303
+                    const uint32_t l = LAj->StepLength;
+                    bool unusable = true;
+                    cx<T> newDz{P::from_int(0), P::from_int(0)};
+                    if (iter + l <= n_iterations) {
+                        // Prepare, GPU_LAInfoDeep.h:90-106
+                        newDz = DeltaSubN * (mul_real(ld(LAj->Ref), Two) + DeltaSubN);
+                        unusable = cheb(newDz) >= ld(LAj->LAThreshold);
+                    }
+                    if (unusable) {
+                        RefIteration = LAj->NextStageLAIndex;
+                        break;
+                    }
+                    iter += l;
+                    if (kStats)
+                        c_la++;
+                    // Evaluate GPU_LAInfoDeep.h:120-124, getZ LAstep.h:181-185
+                    DeltaSubN = newDz * ld(LAj->ZCoeff) + DeltaSub0 * ld(LAj->CCoeff);
+                    const cx<T> complex0 = ld(LAj[1].Ref) + DeltaSubN;
+                    j++;
+                    if (cheb(complex0) < cheb(DeltaSubN) || j >= MacroItCount) {
+                        DeltaSubN = complex0;
+                        j = 0;
+                    }
+                }
+                if (iter >= n_iterations)
+                    break;
+            }
+        }
+
+        if (Mode != FS_MODE_LAO) {
+            // :133-235.  perturbLoop(maxRefIteration) at :254-276 reads the block's previous results, which are zero on
+            // the cleared buffer every caller passes (Fractal.cpp:2822), so only perturbLoop(n_iterations) runs.
+            const uint32_t MaxRef = A.orbit_count - 1;
+            const T TwoFiftySix = P::from_int(256);
+            T dX = DeltaSubN.re, dY = DeltaSubN.im;
+            cx<T> z = ldz(orb, RefIteration);
+            for (;;) {
+                const T sumY = z.im * Two + dY; // tempSum1
+                const T sumX = z.re * Two + dX; // tempSum2
+                ++RefIteration;
+                const T nX = dX * sumX - dY * sumY + DeltaSub0X;
+                const T nY = dX * sumY + dY * sumX + DeltaSub0Y;
+                dX = nX;
+                dY = nY;
+                if (kStats)
+                    c_pt++;
+                z = ldz(orb, RefIteration);
+                const T tX = z.re + dX;
+                const T tY = z.im + dY;
+                const T normSquared = tX * tX + tY * tY;
+                if (normSquared < TwoFiftySix && iter < n_iterations) {
+                    const T DeltaNormSquared = dX * dX + dY * dY;
+                    if (normSquared < DeltaNormSquared || RefIteration >= MaxRef) {
+                        dX = tX;
+                        dY = tY;
+                        RefIteration = 0;
+                        z = ldz(orb, 0);
+                    }
+                    ++iter;
+                } else {
+                    break;
+                }
+            }
+        }
+        store_iter(A.out, A.frame, L, X, iter);
+    }
+    if (kStats)
+        add_stats(A.stats, c_at, c_la, c_pt, c_px);
+}
+
+template <class T> void launch(const FsLav2ArgsPlain &A, int mode, bool stats, hipStream_t s)
+{
+    const dim3 b(256);
+    const dim3 g((A.frame.width + 31) / 32, (A.frame.local_rows + 7) / 8); // tile_pixel()
+#define FS_LAUNCH(M)                                                                                                    \
+    do {                                                                                                                \
+        if (stats)                                                                                                      \
+            hipLaunchKernelGGL((k_lav2_plain<T, M, true>), g, b, 0, s, A);                                              \
+        else                                                                                                            \
+            hipLaunchKernelGGL((k_lav2_plain<T, M, false>), g, b, 0, s, A);                                             \
+    } while (0)
+    if (mode == FS_MODE_PO)
+        FS_LAUNCH(FS_MODE_PO);
+    else if (mode == FS_MODE_LAO)
+        FS_LAUNCH(FS_MODE_LAO);
+    else
+        FS_LAUNCH(FS_MODE_FULL);
+#undef FS_LAUNCH
+}
+
+} // namespace
+
+// kind: 0 = float, 1 = double, 2 = CudaDblflt
+void fsk_lav2_plain(const FsLav2ArgsPlain &A, int kind, int mode, bool stats, hipStream_t s)
+{
+    if (kind == 0)
+        launch<float>(A, mode, stats, s);
+    else if (kind == 1)
+        launch<double>(A, mode, stats, s);
+    else
+        launch<df32>(A, mode, stats, s);
+}

@@ -67,6 +67,8 @@ struct fs_renderer {
     float4 *zq = nullptr; // companion of zref for the tuned LAv2 loop
     FsZ64 *zref64 = nullptr;
     fs_orbit_f64 *orbit_f64 = nullptr; // plain double orbit (FS_T_F64), used as uploaded
+    void *orbit_plain = nullptr;       // plain float / CudaDblflt orbit (FS_T_F32 / FS_T_2X32), used as uploaded
+    alignas(8) uint8_t at_plain[sizeof(fs_at_f64_u32)] = {0}; // ATInfo of the plain LA table (type = la_type)
     uint64_t orbit_size = 0, orbit_uncompressed = 0, orbit_period = 0;
 
     // LA table
@@ -178,6 +180,9 @@ void free_perturb(fs_renderer *r)
         hipFree(r->zref64);
     if (r->orbit_f64)
         hipFree(r->orbit_f64);
+    if (r->orbit_plain)
+        hipFree(r->orbit_plain);
+    r->orbit_plain = nullptr;
     if (r->orbit_2x32)
         hipFree(r->orbit_2x32);
     r->orbit_2x32 = nullptr;
@@ -485,13 +490,33 @@ uint32_t fs_upload_orbit(fs_renderer *r, uint64_t generation, int type_tag, uint
     if (uint32_t e = use_device(r))
         return e;
     // orbit entries do not depend on IterType (GPU_ReferenceIter.h:52-127); counts must fit the 32-bit device counters
-    if ((type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64 && type_tag != FS_T_F64 && type_tag != FS_T_HDR2X32) ||
+    if ((type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64 && type_tag != FS_T_F64 && type_tag != FS_T_HDR2X32 &&
+         type_tag != FS_T_F32 && type_tag != FS_T_2X32) ||
         (iter_bytes != 4 && iter_bytes != 8) || uncompressed_size > 0xFFFFFFFFull)
         return FS_ERR_UNSUPPORTED;
     if (!r->compute)
         return FS_ERR_6;
     if (r->orbit_ok && r->orbit_gen == generation && generation != 0 && r->orbit_type == type_tag)
         return 0; // cached by generation number (GPU_Render.cu:440-487)
+    if (type_tag == FS_T_F32 || type_tag == FS_T_2X32) {
+        // GPUReferenceIter<float,Disable> (8 B) / GPUReferenceIter<CudaDblflt,Disable> (16 B), used as uploaded
+        const size_t eb = type_tag == FS_T_F32 ? sizeof(fs_orbit_f32) : sizeof(fs_orbit_p2x32);
+        if (r->orbit_plain) {
+            FS_TRY(hipFree(r->orbit_plain));
+            r->orbit_plain = nullptr;
+        }
+        r->orbit_ok = false;
+        FS_TRY(hipMalloc(&r->orbit_plain, (orbit_size + 1) * eb));
+        FS_TRY(hipMemcpyAsync(r->orbit_plain, entries, orbit_size * eb, hipMemcpyDefault, r->compute));
+        FS_TRY(hipStreamSynchronize(r->compute));
+        r->orbit_size = orbit_size;
+        r->orbit_uncompressed = uncompressed_size;
+        r->orbit_period = period_maybe_zero;
+        r->orbit_gen = generation;
+        r->orbit_type = type_tag;
+        r->orbit_ok = true;
+        return 0;
+    }
     if (type_tag == FS_T_HDR2X32) {
         if (r->orbit_2x32) {
             FS_TRY(hipFree(r->orbit_2x32));
@@ -636,16 +661,28 @@ uint32_t fs_upload_la(fs_renderer *r, uint64_t generation, int type_tag, uint32_
 {
     if (uint32_t e = use_device(r))
         return e;
-    if ((type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64 && type_tag != FS_T_HDR2X32) ||
+    const bool plain = type_tag == FS_T_F32 || type_tag == FS_T_F64 || type_tag == FS_T_2X32;
+    if ((type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64 && type_tag != FS_T_HDR2X32 && !plain) ||
         (iter_bytes != 4 && iter_bytes != 8))
         return FS_ERR_UNSUPPORTED;
     if (!r->compute)
         return FS_ERR_6;
     if (r->la_ok && r->la_gen == generation && generation != 0 && r->la_type == type_tag)
         return 0;
-    const size_t la_bytes = type_tag == FS_T_HDR32
-                                ? sizeof(fs_la_hdr32_u32)
-                                : (type_tag == FS_T_HDR64 ? sizeof(fs_la_hdr64_u32) : sizeof(fs_la_2x32_u32));
+    const size_t la_bytes = type_tag == FS_T_HDR32   ? sizeof(fs_la_hdr32_u32)
+                            : type_tag == FS_T_HDR64 ? sizeof(fs_la_hdr64_u32)
+                            : type_tag == FS_T_F32   ? sizeof(fs_la_f32_u32)
+                            : type_tag == FS_T_F64   ? sizeof(fs_la_f64_u32)
+                            : type_tag == FS_T_2X32  ? sizeof(fs_la_p2x32_u32)
+                                                     : sizeof(fs_la_2x32_u32);
+    // size of the uint32_t ATInfo record and the offset of its second field in the uint32_t / uint64_t records
+    const size_t at_bytes = type_tag == FS_T_HDR32   ? sizeof(fs_at_hdr32_u32)
+                            : type_tag == FS_T_HDR64 ? sizeof(fs_at_hdr64_u32)
+                            : type_tag == FS_T_F32   ? sizeof(fs_at_f32_u32)
+                            : type_tag == FS_T_F64   ? sizeof(fs_at_f64_u32)
+                            : type_tag == FS_T_2X32  ? sizeof(fs_at_p2x32_u32)
+                                                     : sizeof(fs_at_2x32_u32);
+    const size_t at_rest32 = (type_tag == FS_T_HDR64 || type_tag == FS_T_F64) ? 8 : 4;
     std::vector<uint8_t> las32, stages32;
     uint8_t at32[sizeof(fs_at_hdr64_u32)] = {0};
     if (iter_bytes == 8) {
@@ -653,6 +690,9 @@ uint32_t fs_upload_la(fs_renderer *r, uint64_t generation, int type_tag, uint32_
         if (n_las)
             ok = type_tag == FS_T_HDR32   ? narrow_la<fs_la_hdr32_u64, fs_la_hdr32_u32>(las, n_las, las32)
                  : type_tag == FS_T_HDR64 ? narrow_la<fs_la_hdr64_u64, fs_la_hdr64_u32>(las, n_las, las32)
+                 : type_tag == FS_T_F32   ? narrow_la<fs_la_f32_u64, fs_la_f32_u32>(las, n_las, las32)
+                 : type_tag == FS_T_F64   ? narrow_la<fs_la_f64_u64, fs_la_f64_u32>(las, n_las, las32)
+                 : type_tag == FS_T_2X32  ? narrow_la<fs_la_p2x32_u64, fs_la_p2x32_u32>(las, n_las, las32)
                                           : narrow_la<fs_la_2x32_u64, fs_la_2x32_u32>(las, n_las, las32);
         stages32.resize((size_t)n_stages * sizeof(fs_la_stage_u32));
         for (uint32_t i = 0; ok && i < n_stages; i++) {
@@ -666,12 +706,8 @@ uint32_t fs_upload_la(fs_renderer *r, uint64_t generation, int type_tag, uint32_
             ok = step <= 0xFFFFFFFFull;
             const uint32_t step32 = (uint32_t)step;
             memcpy(at32, &step32, 4);
-            if (type_tag == FS_T_HDR32)
-                memcpy(at32 + 4, (const uint8_t *)at_info + 8, sizeof(fs_at_hdr32_u32) - 4);
-            else if (type_tag == FS_T_HDR64)
-                memcpy(at32 + 8, (const uint8_t *)at_info + 8, sizeof(fs_at_hdr64_u32) - 8);
-            else
-                memcpy(at32 + 4, (const uint8_t *)at_info + 8, sizeof(fs_at_2x32_u32) - 4);
+            // everything after StepLength is laid out identically; it starts at offset 8 in the uint64_t record
+            memcpy(at32 + at_rest32, (const uint8_t *)at_info + 8, at_bytes - at_rest32);
             at_info = at32;
         }
         if (!ok)
@@ -705,7 +741,10 @@ uint32_t fs_upload_la(fs_renderer *r, uint64_t generation, int type_tag, uint32_
     memset(&r->at, 0, sizeof(r->at));
     memset(&r->at64, 0, sizeof(r->at64));
     memset(&r->at2x32, 0, sizeof(r->at2x32));
-    if (at_info && type_tag == FS_T_HDR32)
+    memset(r->at_plain, 0, sizeof(r->at_plain));
+    if (at_info && plain)
+        memcpy(r->at_plain, at_info, at_bytes);
+    else if (at_info && type_tag == FS_T_HDR32)
         memcpy(&r->at, at_info, sizeof(r->at));
     else if (at_info && type_tag == FS_T_HDR2X32)
         memcpy(&r->at2x32, at_info, sizeof(r->at2x32));
@@ -849,10 +888,38 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
         return e;
     if (!r->memory_initialized())
         return 0; // GPU_Render.cu:1007-1009
-    if ((type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64 && type_tag != FS_T_HDR2X32) || n_iterations > 0xFFFFFFFFull)
+    const bool plain = type_tag == FS_T_F32 || type_tag == FS_T_F64 || type_tag == FS_T_2X32;
+    if ((type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64 && type_tag != FS_T_HDR2X32 && !plain) ||
+        n_iterations > 0xFFFFFFFFull)
         return FS_ERR_UNSUPPORTED;
     if (!r->orbit_ok || r->orbit_type != type_tag)
         return FS_ERR_6; // GPU_Render.cu:1015-1022
+    if (plain) {
+        // Gpu1x32 / Gpu1x64 / Gpu2x32 PerturbedLAv2*: no CPU RenderAlgorithm exists for LAv2 on a plain type, the kernel
+        // restates the reference's CUDA kernel and ignores `parity`.  coords = float[4] / double[4] / fs_real_p2x32[4].
+        if (mode != FS_LAV2_PO && (!r->la_ok || r->la_type != type_tag))
+            return FS_ERR_6;
+        FsLav2ArgsPlain A;
+        memset(&A, 0, sizeof(A));
+        A.out = (uint32_t *)r->iters();
+        A.orbit = type_tag == FS_T_F64 ? (const void *)r->orbit_f64 : (const void *)r->orbit_plain;
+        A.las = r->las;
+        A.stages = r->stages;
+        A.stats = r->stats;
+        A.frame = make_frame(r);
+        memcpy(A.coords, coords, type_tag == FS_T_F32 ? 4 * sizeof(float) : 4 * sizeof(double));
+        memcpy(A.at, r->at_plain, sizeof(A.at));
+        A.orbit_count = (uint32_t)r->orbit_uncompressed;
+        A.stage_count = r->n_stages;
+        A.n_iterations = (uint32_t)n_iterations;
+        A.la_valid = (r->la_ok && r->la_type == type_tag) ? r->la_valid : 0;
+        A.use_at = r->use_at;
+        TimedLaunch t(r);
+        fsk_lav2_plain(A, type_tag == FS_T_F32 ? 0 : (type_tag == FS_T_F64 ? 1 : 2),
+                       mode == FS_LAV2_FULL ? FS_MODE_FULL : (mode == FS_LAV2_PO ? FS_MODE_PO : FS_MODE_LAO), r->stats_on,
+                       r->compute);
+        return (uint32_t)hipGetLastError();
+    }
     if (type_tag == FS_T_HDR2X32) {
         // No CPU RenderAlgorithm exists for this type: the kernel restates the reference's CUDA kernel and ignores
         // `parity` (coords are fs_real_2x32[4]).

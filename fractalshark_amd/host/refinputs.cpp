@@ -836,54 +836,140 @@ struct LAParams {
     int periodDetectionThresholdExp = -10;
 };
 
-// `HDRFloat * float` for a power-of-two float goes through HDRFloat(T mant) -> {1.0, exp}.
-template <class F> hreal<F> pow2_hr(int e) { return hreal<F>{F(1), e}; }
+// ---- number families.  The LA builder below is written once against real_t<F> / cplx_t<F>:
+//   F = float | double           T = HDRFloat<F>, complex = HDRFloatComplex<F>   (hdr_math.hpp)
+//   F = plain<float|double>      T = float | double itself, complex = FloatComplex<T> (FloatComplex.h:7-420): the
+//                                `else` arms of every `if constexpr (IsHDR)` in LAInfoDeep.h / ATInfo.h, HdrReduce
+//                                a no-op (HDRFloat.h:1406-1419), min = std::min, compare = operator<.
+template <class T> struct plain {};
+template <class T> struct preal {
+    T m; // named like hreal's mantissa so that `x.m == 0` reads the same for both families
+};
+template <class T> struct pcplx {
+    T re, im;
+};
+template <class F> struct num {
+    using R = hreal<F>;
+    using C = hcplx<F>;
+    using S = F;
+    static constexpr bool is_plain = false;
+};
+template <class T> struct num<plain<T>> {
+    using R = preal<T>;
+    using C = pcplx<T>;
+    using S = T;
+    static constexpr bool is_plain = true;
+};
+template <class F> using real_t = typename num<F>::R;
+template <class F> using cplx_t = typename num<F>::C;
+template <class F> using scalar_t = typename num<F>::S;
+
+template <class T> preal<T> hr_mul(preal<T> a, preal<T> b) { return preal<T>{a.m * b.m}; }
+template <class T> preal<T> hr_div(preal<T> a, preal<T> b) { return preal<T>{a.m / b.m}; }
+template <class T> preal<T> hr_square(preal<T> a) { return preal<T>{a.m * a.m}; }
+template <class T> void hr_reduce(preal<T> &) {}
+template <class T> preal<T> hr_reduced(preal<T> a) { return a; }
+template <class T> preal<T> hr_min_pos(preal<T> a, preal<T> b) { return preal<T>{std::min(a.m, b.m)}; }
+template <class T> int hr_cmp_pos(preal<T> a, preal<T> b) { return a.m < b.m ? -1 : (a.m > b.m ? 1 : 0); }
+template <class T> pcplx<T> hc_from_hr(preal<T> re, preal<T> im) { return pcplx<T>{re.m, im.m}; }
+template <class T> pcplx<T> hc_reduced(pcplx<T> a) { return a; }
+// chebychevNorm, FloatComplex.h:413-419
+template <class T> preal<T> hc_cheb(pcplx<T> a)
+{
+    const T ar = std::fabs(a.re), ai = std::fabs(a.im);
+    return preal<T>{ar > ai ? ar : ai};
+}
+// times_mutable(FloatComplex), FloatComplex.h:198-211
+template <class T> pcplx<T> hc_mul(pcplx<T> a, pcplx<T> b)
+{
+    const T re = (a.re * b.re) - (a.im * b.im);
+    const T im = (a.re * b.im) + (a.im * b.re);
+    return pcplx<T>{re, im};
+}
+template <class T> pcplx<T> hc_mul_real(pcplx<T> a, preal<T> f) { return pcplx<T>{a.re * f.m, a.im * f.m}; } // :245-251
+template <class T> pcplx<T> hc_add(pcplx<T> a, pcplx<T> b) { return pcplx<T>{a.re + b.re, a.im + b.im}; }  // :188-195
+template <class T> pcplx<T> hc_add_real(pcplx<T> a, preal<T> r) { return pcplx<T>{a.re + r.m, a.im}; }      // :263-268
+template <class T> preal<T> hc_norm2(pcplx<T> a) { return preal<T>{a.re * a.re + a.im * a.im}; }            // :327-331
+// reciprocal(), FloatComplex.h:339-344
+template <class T> pcplx<T> hc_recip(pcplx<T> a)
+{
+    const T temp = T(1) / (a.re * a.re + a.im * a.im);
+    return pcplx<T>{a.re * temp, -a.im * temp};
+}
+
+// constructors spelled per family
+template <class F> struct mk {
+    static hreal<F> zero() { return hr_zero<F>(); }
+    static hcplx<F> czero() { return hc_zero<F>(); }
+    static hcplx<F> cnative(double re, double im) { return hc_from_native<F>(F(re), F(im)); }
+    static hreal<F> number(double v) { return hr_from_number<F>(F(v)); }
+    static hreal<F> mant(double v) { return hr_from_mant<F>(F(v)); }
+    static hreal<F> raw_pow2(int e) { return hr_raw<F>(e, F(1)); }
+};
+template <class T> struct mk<plain<T>> {
+    static preal<T> zero() { return preal<T>{T(0)}; }
+    static pcplx<T> czero() { return pcplx<T>{T(0), T(0)}; }
+    static pcplx<T> cnative(double re, double im) { return pcplx<T>{T(re), T(im)}; }
+    static preal<T> number(double v) { return preal<T>{T(v)}; }
+    static preal<T> mant(double v) { return preal<T>{T(v)}; }
+    static preal<T> raw_pow2(int e) { return preal<T>{T(std::ldexp(1.0, e))}; }
+};
+
+// `HDRFloat * float` for a power-of-two float goes through HDRFloat(T mant) -> {1.0, exp}; for a plain T it is the
+// float constant itself (LAParameters.cpp:61-71), exact in either width.
+template <class F> real_t<F> pow2_hr(int e)
+{
+    if constexpr (num<F>::is_plain)
+        return real_t<F>{scalar_t<F>(std::ldexp(1.0f, e))};
+    else
+        return real_t<F>{F(1), e};
+}
 
 template <class F> struct LAInfo {
-    hcplx<F> Ref = hc_zero<F>();
-    hcplx<F> ZCoeff = hc_zero<F>();
-    hcplx<F> CCoeff = hc_zero<F>();
-    hreal<F> LAThreshold = hr_zero<F>();
-    hreal<F> LAThresholdC = hr_zero<F>();
-    hreal<F> MinMag = hr_zero<F>();
+    cplx_t<F> Ref = mk<F>::czero();
+    cplx_t<F> ZCoeff = mk<F>::czero();
+    cplx_t<F> CCoeff = mk<F>::czero();
+    real_t<F> LAThreshold = mk<F>::zero();
+    real_t<F> LAThresholdC = mk<F>::zero();
+    real_t<F> MinMag = mk<F>::zero();
     uint32_t StepLength = 0;
     uint32_t NextStageLAIndex = 0;
 };
 
 // LAInfoDeep(la_parameters, z), LAInfoDeep.h:108-131
-template <class F> LAInfo<F> la_init(const LAParams &p, hcplx<F> z)
+template <class F> LAInfo<F> la_init(const LAParams &p, cplx_t<F> z)
 {
     LAInfo<F> r;
     r.Ref = z;
-    r.ZCoeff = hc_from_native<F>(F(1), F(0));
-    r.CCoeff = hc_from_native<F>(F(1), F(0));
-    r.LAThreshold = hr_from_number<F>(F(1));
-    r.LAThresholdC = hr_from_number<F>(F(1));
+    r.ZCoeff = mk<F>::cnative(1, 0);
+    r.CCoeff = mk<F>::cnative(1, 0);
+    r.LAThreshold = mk<F>::number(1);
+    r.LAThresholdC = mk<F>::number(1);
     if (p.detectionMethod == 1)
-        r.MinMag = hr_from_number<F>(F(4));
+        r.MinMag = mk<F>::number(4);
     return r;
 }
 
 // LAInfoDeep::Step(params, out, z), LAInfoDeep.h:178-246 -- `out` keeps whatever it held in the fields
 // Step does not write (LAi; MinMag when detectionMethod != 1).
-template <class F> bool la_step(const LAParams &p, const LAInfo<F> &self, LAInfo<F> &out, hcplx<F> z)
+template <class F> bool la_step(const LAParams &p, const LAInfo<F> &self, LAInfo<F> &out, cplx_t<F> z)
 {
-    const hreal<F> ChebyMagz = hc_cheb(z);
-    const hreal<F> ChebyMagZCoeff = hc_cheb(self.ZCoeff);
-    const hreal<F> ChebyMagCCoeff = hc_cheb(self.CCoeff);
+    const real_t<F> ChebyMagz = hc_cheb(z);
+    const real_t<F> ChebyMagZCoeff = hc_cheb(self.ZCoeff);
+    const real_t<F> ChebyMagCCoeff = hc_cheb(self.CCoeff);
     if (p.detectionMethod == 1)
         out.MinMag = hr_min_pos(ChebyMagz, self.MinMag);
 
-    hreal<F> temp1 = hr_mul(hr_div(ChebyMagz, ChebyMagZCoeff), pow2_hr<F>(p.laThresholdScaleExp));
+    real_t<F> temp1 = hr_mul(hr_div(ChebyMagz, ChebyMagZCoeff), pow2_hr<F>(p.laThresholdScaleExp));
     hr_reduce(temp1);
-    hreal<F> temp2 = hr_mul(hr_div(ChebyMagz, ChebyMagCCoeff), pow2_hr<F>(p.laThresholdCScaleExp));
+    real_t<F> temp2 = hr_mul(hr_div(ChebyMagz, ChebyMagCCoeff), pow2_hr<F>(p.laThresholdCScaleExp));
     hr_reduce(temp2);
     out.LAThreshold = hr_min_pos(self.LAThreshold, temp1);
     out.LAThresholdC = hr_min_pos(self.LAThresholdC, temp2);
 
-    const hcplx<F> z2 = hc_mul_real(z, hr_from_number<F>(F(2)));
+    const cplx_t<F> z2 = hc_mul_real(z, mk<F>::number(2));
     out.ZCoeff = hc_reduced(hc_mul(z2, self.ZCoeff));
-    out.CCoeff = hc_reduced(hc_add_real(hc_mul(z2, self.CCoeff), hr_from_number<F>(F(1))));
+    out.CCoeff = hc_reduced(hc_add_real(hc_mul(z2, self.CCoeff), mk<F>::number(1)));
     out.Ref = self.Ref;
 
     if (p.detectionMethod == 1)
@@ -892,7 +978,7 @@ template <class F> bool la_step(const LAParams &p, const LAInfo<F> &self, LAInfo
 }
 
 // LAInfoDeep::Step(params, z) returning a fresh record, LAInfoDeep.h:268-277
-template <class F> LAInfo<F> la_step_new(const LAParams &p, const LAInfo<F> &self, hcplx<F> z)
+template <class F> LAInfo<F> la_step_new(const LAParams &p, const LAInfo<F> &self, cplx_t<F> z)
 {
     LAInfo<F> r;
     la_step(p, self, r, z);
@@ -900,11 +986,11 @@ template <class F> LAInfo<F> la_step_new(const LAParams &p, const LAInfo<F> &sel
 }
 
 // LAInfoDeep::DetectPeriod, LAInfoDeep.h:133-155
-template <class F> bool la_detect_period(const LAParams &p, const LAInfo<F> &self, hcplx<F> z)
+template <class F> bool la_detect_period(const LAParams &p, const LAInfo<F> &self, cplx_t<F> z)
 {
     if (p.detectionMethod == 1)
         return hr_cmp_pos(hc_cheb(z), hr_mul(self.MinMag, pow2_hr<F>(p.periodDetectionThreshold2Exp))) < 0;
-    const hreal<F> lhs =
+    const real_t<F> lhs =
         hr_mul(hr_div(hc_cheb(z), hc_cheb(self.ZCoeff)), pow2_hr<F>(p.laThresholdScaleExp));
     return hr_cmp_pos(lhs, hr_mul(self.LAThreshold, pow2_hr<F>(p.periodDetectionThresholdExp))) < 0;
 }
@@ -912,24 +998,24 @@ template <class F> bool la_detect_period(const LAParams &p, const LAInfo<F> &sel
 // LAInfoDeep::Composite(params, out, LA), LAInfoDeep.h:279-369
 template <class F> bool la_composite(const LAParams &p, const LAInfo<F> &self, LAInfo<F> &out, const LAInfo<F> &LA)
 {
-    const hcplx<F> z = LA.Ref;
-    const hreal<F> ChebyMagz = hc_cheb(z);
-    hreal<F> ChebyMagZCoeff = hc_cheb(self.ZCoeff);
-    hreal<F> ChebyMagCCoeff = hc_cheb(self.CCoeff);
+    const cplx_t<F> z = LA.Ref;
+    const real_t<F> ChebyMagz = hc_cheb(z);
+    real_t<F> ChebyMagZCoeff = hc_cheb(self.ZCoeff);
+    real_t<F> ChebyMagCCoeff = hc_cheb(self.CCoeff);
 
-    hreal<F> temp1 = hr_mul(hr_div(ChebyMagz, ChebyMagZCoeff), pow2_hr<F>(p.laThresholdScaleExp));
+    real_t<F> temp1 = hr_mul(hr_div(ChebyMagz, ChebyMagZCoeff), pow2_hr<F>(p.laThresholdScaleExp));
     hr_reduce(temp1);
-    hreal<F> temp2 = hr_mul(hr_div(ChebyMagz, ChebyMagCCoeff), pow2_hr<F>(p.laThresholdCScaleExp));
+    real_t<F> temp2 = hr_mul(hr_div(ChebyMagz, ChebyMagCCoeff), pow2_hr<F>(p.laThresholdCScaleExp));
     hr_reduce(temp2);
-    hreal<F> outLAThreshold = hr_min_pos(self.LAThreshold, temp1);
-    hreal<F> outLAThresholdC = hr_min_pos(self.LAThresholdC, temp2);
+    real_t<F> outLAThreshold = hr_min_pos(self.LAThreshold, temp1);
+    real_t<F> outLAThresholdC = hr_min_pos(self.LAThresholdC, temp2);
 
-    const hcplx<F> z2 = hc_mul_real(z, hr_from_number<F>(F(2)));
-    hcplx<F> outZCoeff = hc_reduced(hc_mul(z2, self.ZCoeff));
-    hcplx<F> outCCoeff = hc_reduced(hc_mul(z2, self.CCoeff));
+    const cplx_t<F> z2 = hc_mul_real(z, mk<F>::number(2));
+    cplx_t<F> outZCoeff = hc_reduced(hc_mul(z2, self.ZCoeff));
+    cplx_t<F> outCCoeff = hc_reduced(hc_mul(z2, self.CCoeff));
     ChebyMagZCoeff = hc_cheb(outZCoeff);
     ChebyMagCCoeff = hc_cheb(outCCoeff);
-    hreal<F> temp = outLAThreshold;
+    real_t<F> temp = outLAThreshold;
 
     temp1 = hr_div(LA.LAThreshold, ChebyMagZCoeff);
     hr_reduce(temp1);
@@ -962,11 +1048,11 @@ template <class F> LAInfo<F> la_composite_new(const LAParams &p, const LAInfo<F>
 
 template <class F> struct ATInfoT {
     uint32_t StepLength = 0;
-    hreal<F> ThresholdC = hr_zero<F>(), SqrEscapeRadius = hr_zero<F>();
-    hcplx<F> RefC = hc_zero<F>(), ZCoeff = hc_zero<F>(), CCoeff = hc_zero<F>(), InvZCoeff = hc_zero<F>();
-    hcplx<F> CCoeffSqrInvZCoeff = hc_zero<F>(), CCoeffInvZCoeff = hc_zero<F>();
-    hreal<F> CCoeffNormSqr = hr_zero<F>(), RefCNormSqr = hr_zero<F>();
-    hreal<F> factor = hr_from_number<F>(F(4294967296.0)); // HDRFloat(0x1.0p32), ATInfo.h:132
+    real_t<F> ThresholdC = mk<F>::zero(), SqrEscapeRadius = mk<F>::zero();
+    cplx_t<F> RefC = mk<F>::czero(), ZCoeff = mk<F>::czero(), CCoeff = mk<F>::czero(), InvZCoeff = mk<F>::czero();
+    cplx_t<F> CCoeffSqrInvZCoeff = mk<F>::czero(), CCoeffInvZCoeff = mk<F>::czero();
+    real_t<F> CCoeffNormSqr = mk<F>::zero(), RefCNormSqr = mk<F>::zero();
+    real_t<F> factor = mk<F>::number(4294967296.0); // HDRFloat(0x1.0p32), ATInfo.h:132
 };
 
 // LAInfoDeep::CreateAT, LAInfoDeep.h:456-506 (IsHDR branch; UseSmallExponents only matters for double).
@@ -981,19 +1067,21 @@ template <class F> void la_create_at(const LAInfo<F> &self, ATInfoT<F> &R, const
     R.CCoeffNormSqr = hr_reduced(hc_norm2(R.CCoeff));
     R.RefCNormSqr = hr_reduced(hc_norm2(R.RefC));
 
-    hreal<F> lim = hr_raw<F>(32, F(1));
-    if (sizeof(F) == 8 && !useSmallExponents)
-        lim.e = 256;
+    real_t<F> lim = mk<F>::raw_pow2(32); // plain T: lim = 4294967296.0f, LAInfoDeep.h:499
+    if constexpr (!num<F>::is_plain) {
+        if (sizeof(F) == 8 && !useSmallExponents)
+            lim.e = 256;
+    }
     hr_reduce(lim);
     R.SqrEscapeRadius = hr_reduced(hr_min_pos(hr_mul(hc_norm2(self.ZCoeff), self.LAThreshold), lim));
     R.ThresholdC = hr_min_pos(self.LAThresholdC, hr_div(lim, hc_cheb(R.CCoeff)));
 }
 
 // ATInfo::Usable, ATInfo.h:101-116
-template <class F> bool at_usable(const ATInfoT<F> &at, hreal<F> SqrRadius)
+template <class F> bool at_usable(const ATInfoT<F> &at, real_t<F> SqrRadius)
 {
-    const hreal<F> result = hr_reduced(hr_mul(hr_mul(at.CCoeffNormSqr, SqrRadius), at.factor));
-    const hreal<F> Four = hr_from_mant<F>(F(4));
+    const real_t<F> result = hr_reduced(hr_mul(hr_mul(at.CCoeffNormSqr, SqrRadius), at.factor));
+    const real_t<F> Four = mk<F>::mant(4);
     return hr_cmp_pos(result, at.RefCNormSqr) > 0 && hr_cmp_pos(at.SqrEscapeRadius, Four) > 0;
 }
 
@@ -1012,14 +1100,29 @@ constexpr uint32_t kLowBound = 64;   // LAReference.h:56
 // periodDivisor: 2 for PerturbExtras::Disable, 8 for SimpleCompression (LAReference.cpp:12-19)
 constexpr uint32_t kMaxLAStages = 1024;
 
+template <class F> struct orbit_of {
+    using type = OrbitT<F>;
+};
+// PerturbationResults<uint32_t, T, Disable> for a plain T (only what the LA builder reads)
+template <class T> struct PlainOrbit {
+    std::vector<preal<T>> x, y; // entry 0 = {0, 0}
+    uint64_t period = 0;
+    preal<T> maxRadius{};
+    Mp cx, cy;
+    bool compressed = false;
+};
+template <class T> struct orbit_of<plain<T>> {
+    using type = PlainOrbit<T>;
+};
 template <class F> struct LABuilder {
+    using Orb = typename orbit_of<F>::type;
     const LAParams p;
-    const OrbitT<F> &ob;
+    const Orb &ob;
     LATable<F> &T;
     const int kPeriodDivisor;
-    LABuilder(const OrbitT<F> &o, LATable<F> &t) : p{}, ob(o), T(t), kPeriodDivisor(o.compressed ? 8 : 2) {}
+    LABuilder(const Orb &o, LATable<F> &t) : p{}, ob(o), T(t), kPeriodDivisor(o.compressed ? 8 : 2) {}
 
-    hcplx<F> Z(uint64_t i) const { return hc_from_hr(ob.x[i], ob.y[i]); } // GetComplex<SubType>()
+    cplx_t<F> Z(uint64_t i) const { return hc_from_hr(ob.x[i], ob.y[i]); } // GetComplex<SubType>()
 
     uint32_t la_size() const { return (uint32_t)T.las.size(); }
 
@@ -1035,10 +1138,10 @@ template <class F> struct LABuilder {
         T.stages[0].LAIndex = 0;
 
         Period = 0;
-        LA = la_init<F>(p, hc_zero<F>());
+        LA = la_init<F>(p, mk<F>::czero());
         LA = la_step_new(p, LA, Z(1));
         nextStageLAIndex = 0;
-        if (LA.ZCoeff.re == F(0) && LA.ZCoeff.im == F(0)) // isZCoeffZero
+        if (LA.ZCoeff.re == scalar_t<F>(0) && LA.ZCoeff.im == scalar_t<F>(0)) // isZCoeffZero
             return 0;
 
         for (i = 2; i < maxRef; i++) {
@@ -1164,7 +1267,7 @@ template <class F> struct LABuilder {
             const LAInfo<F> PrevStageLAj = T.las[idxj];
             const bool PeriodDetected = la_composite(p, LA, NewLA, PrevStageLAj);
             if (PeriodDetected) {
-                if (PrevStageLAj.LAThreshold.m == F(0)) // isLAThresholdZero
+                if (PrevStageLAj.LAThreshold.m == scalar_t<F>(0)) // isLAThresholdZero
                     break;
                 Period = i;
                 liStep = Period;
@@ -1266,9 +1369,9 @@ template <class F> struct LABuilder {
     // UseSmallExponents = UsingDblflt (RefOrbitCalc.cpp:2346): true when the HDRFloat<double> table is built to be
     // converted to 2x32, so that the AT escape radius fits a binary32 mantissa (lim = 2^32 instead of 2^256).
     bool useSmallExponents = false;
-    void create_at(hreal<F> radius, bool useSmallExponents)
+    void create_at(real_t<F> radius, bool useSmallExponents)
     {
-        const hreal<F> SqrRadius = hr_reduced(hr_square(radius));
+        const real_t<F> SqrRadius = hr_reduced(hr_square(radius));
         for (uint32_t Stage = T.stageCount; Stage > 0;) {
             Stage--;
             const uint32_t LAIndex = T.stages[Stage].LAIndex;
@@ -2021,4 +2124,267 @@ extern "C" void fsh_view_coords_perturb_f64(const fsh_view *v, const fsh_orbit_f
     out[1] = mpf_get_d(dy.v);
     out[2] = mpf_get_d(cX.v);
     out[3] = mpf_get_d(cY.v);
+}
+
+// ------------------------------------------------------------------ plain float / double orbit + LAv2 table
+// Inputs of Gpu1x32PerturbedLAv2* (T = float), Gpu1x64PerturbedLAv2* (T = double) and, converted field-wise,
+// Gpu2x32PerturbedLAv2* (T = CudaDblflt<MattDblflt>, built as double: DoubleTo2x32Converter, Fractal.cpp:2771-2772).
+// Orbit: the floatOrDouble arms of AddPerturbationReferencePointST (RefOrbitCalc.cpp:481-488,524-530,564-604,617-622)
+// with T = float | double; table: LAReference<uint32_t,T,T,Disable> through the builder above with F = plain<T>.
+namespace {
+template <class T> void build_plain_orbit(const fsh_view &vw, uint64_t max_iter, int periodicity, PlainOrbit<T> &ob)
+{
+    mpf_set_default_prec(vw.prec_bits);
+    {
+        Mp two = Mp::from_ui(2);
+        ob.cx = (vw.maxX + vw.minX) / two;
+        ob.cy = (vw.maxY + vw.minY) / two;
+        Mp delta = vw.maxY - vw.minY;
+        ob.maxRadius = preal<T>{(T)((T)mpf_get_d(delta.v) / T(2.0f))}; // T{delta} / T{2.0f}, PerturbationResults.cpp:823-824
+    }
+    ob.x.push_back(preal<T>{T(0)});
+    ob.y.push_back(preal<T>{T(0)});
+    mpf_t cx, cy, zx, zy, zx2, t1, t2;
+    mpf_init(cx);
+    mpf_set(cx, ob.cx.v);
+    mpf_init(cy);
+    mpf_set(cy, ob.cy.v);
+    mpf_init(zx);
+    mpf_init(zy);
+    mpf_init(zx2);
+    mpf_init(t1);
+    mpf_init(t2);
+    T dzdcX = T(1), dzdcY = T(0);
+    const T cx_cast = (T)mpf_get_d(cx), cy_cast = (T)mpf_get_d(cy);
+    mpf_set(zx, cx);
+    mpf_set(zy, cy);
+    for (uint64_t i = 0; i < max_iter; i++) {
+        mpf_mul_2exp(zx2, zx, 1);
+        const T double_zx = (T)mpf_get_d(zx), double_zy = (T)mpf_get_d(zy);
+        ob.x.push_back(preal<T>{double_zx});
+        ob.y.push_back(preal<T>{double_zy});
+        if (periodicity) {
+            const T n2 = std::max(std::fabs(double_zx), std::fabs(double_zy));
+            const T r0 = std::max(std::fabs(dzdcX), std::fabs(dzdcY));
+            const T n3 = ob.maxRadius.m * r0 * T(2);
+            if (n2 < n3) {
+                ob.period = ob.x.size();
+                break;
+            } else {
+                const T dzdcXOrig = dzdcX;
+                dzdcX = T(2) * (double_zx * dzdcX - double_zy * dzdcY) + T(1);
+                dzdcY = T(2) * (double_zx * dzdcY + double_zy * dzdcXOrig);
+            }
+        }
+        mpf_mul(t1, zx, zx);
+        mpf_mul(t2, zy, zy);
+        mpf_sub(zx, t1, t2);
+        mpf_add(zx, zx, cx);
+        mpf_mul(zy, zx2, zy);
+        mpf_add(zy, zy, cy);
+        const T tempZX = double_zx + cx_cast, tempZY = double_zy + cy_cast;
+        const T zn = tempZX * tempZX + tempZY * tempZY;
+        if (zn > T(256))
+            break;
+    }
+    mpf_clear(cx);
+    mpf_clear(cy);
+    mpf_clear(zx);
+    mpf_clear(zy);
+    mpf_clear(zx2);
+    mpf_clear(t1);
+    mpf_clear(t2);
+}
+
+template <class T> struct plain_recs;
+template <> struct plain_recs<float> {
+    using orbit = fs_orbit_f32;
+    using la = fs_la_f32_u32;
+    using at = fs_at_f32_u32;
+    using cplx = fs_cplx_f32;
+};
+template <> struct plain_recs<double> {
+    using orbit = fs_orbit_f64;
+    using la = fs_la_f64_u32;
+    using at = fs_at_f64_u32;
+    using cplx = fs_cplx_f64;
+};
+
+template <class T> struct PlainInputs {
+    PlainOrbit<T> ob;
+    LATable<plain<T>> t;
+    std::vector<typename plain_recs<T>::orbit> orbit_packed;
+    std::vector<typename plain_recs<T>::la> la_packed;
+    typename plain_recs<T>::at at_packed;
+
+    void build(const fsh_view &vw, uint64_t max_iter, int periodicity, int host_threads)
+    {
+        using R = plain_recs<T>;
+        build_plain_orbit<T>(vw, max_iter, periodicity, ob);
+        orbit_packed.resize(ob.x.size());
+        for (size_t i = 0; i < ob.x.size(); i++)
+            orbit_packed[i] = typename R::orbit{ob.x[i].m, ob.y[i].m};
+        LABuilder<plain<T>> b(ob, t);
+        b.generate(host_threads < 1 ? 1 : host_threads);
+        auto C = [](pcplx<T> c) { return typename R::cplx{c.re, c.im}; };
+        la_packed.resize(t.las.size());
+        for (size_t k = 0; k < t.las.size(); k++) {
+            const auto &s = t.las[k];
+            typename R::la r;
+            memset(&r, 0, sizeof(r));
+            r.Ref = C(s.Ref);
+            r.ZCoeff = C(s.ZCoeff);
+            r.CCoeff = C(s.CCoeff);
+            r.LAThreshold = s.LAThreshold.m;
+            r.LAThresholdC = s.LAThresholdC.m;
+            r.MinMag = s.MinMag.m;
+            r.StepLength = s.StepLength;
+            r.NextStageLAIndex = s.NextStageLAIndex;
+            la_packed[k] = r;
+        }
+        t.packedStages.assign(t.stages.begin(), t.stages.begin() + std::min<size_t>(t.stages.size(), t.stageCount));
+        const auto &a = t.at;
+        memset(&at_packed, 0, sizeof(at_packed));
+        at_packed.StepLength = a.StepLength;
+        at_packed.ThresholdC = a.ThresholdC.m;
+        at_packed.SqrEscapeRadius = a.SqrEscapeRadius.m;
+        at_packed.RefC = C(a.RefC);
+        at_packed.ZCoeff = C(a.ZCoeff);
+        at_packed.CCoeff = C(a.CCoeff);
+        at_packed.InvZCoeff = C(a.InvZCoeff);
+        at_packed.CCoeffSqrInvZCoeff = C(a.CCoeffSqrInvZCoeff);
+        at_packed.CCoeffInvZCoeff = C(a.CCoeffInvZCoeff);
+        at_packed.CCoeffNormSqr = a.CCoeffNormSqr.m;
+        at_packed.RefCNormSqr = a.RefCNormSqr.m;
+        at_packed.factor = a.factor.m;
+    }
+};
+} // namespace
+
+struct fsh_plain {
+    int kind = 0; // 0 float, 1 double
+    PlainInputs<float> f;
+    PlainInputs<double> d;
+};
+
+extern "C" fsh_plain *fsh_plain_create(const fsh_view *v, int kind, uint64_t max_iter, int periodicity, int host_threads)
+{
+    if (kind != 0 && kind != 1)
+        return nullptr;
+    auto h = std::make_unique<fsh_plain>();
+    h->kind = kind;
+    if (kind == 0)
+        h->f.build(*v, max_iter, periodicity, host_threads);
+    else
+        h->d.build(*v, max_iter, periodicity, host_threads);
+    return h.release();
+}
+extern "C" void fsh_plain_destroy(fsh_plain *h) { delete h; }
+extern "C" int fsh_plain_kind(const fsh_plain *h) { return h->kind; }
+#define FS_PLAIN_GET(EXPR_F, EXPR_D) (h->kind == 0 ? (EXPR_F) : (EXPR_D))
+extern "C" uint64_t fsh_plain_orbit_count(const fsh_plain *h) { return FS_PLAIN_GET(h->f.ob.x.size(), h->d.ob.x.size()); }
+extern "C" uint64_t fsh_plain_orbit_period(const fsh_plain *h) { return FS_PLAIN_GET(h->f.ob.period, h->d.ob.period); }
+extern "C" const void *fsh_plain_orbit_data(const fsh_plain *h)
+{
+    return FS_PLAIN_GET((const void *)h->f.orbit_packed.data(), (const void *)h->d.orbit_packed.data());
+}
+extern "C" uint32_t fsh_plain_la_count(const fsh_plain *h)
+{
+    return (uint32_t)FS_PLAIN_GET(h->f.la_packed.size(), h->d.la_packed.size());
+}
+extern "C" const void *fsh_plain_la_data(const fsh_plain *h)
+{
+    return FS_PLAIN_GET((const void *)h->f.la_packed.data(), (const void *)h->d.la_packed.data());
+}
+extern "C" uint32_t fsh_plain_la_stage_count(const fsh_plain *h) { return FS_PLAIN_GET(h->f.t.stageCount, h->d.t.stageCount); }
+extern "C" const fs_la_stage_u32 *fsh_plain_la_stages(const fsh_plain *h)
+{
+    return FS_PLAIN_GET(h->f.t.packedStages.data(), h->d.t.packedStages.data());
+}
+extern "C" int fsh_plain_la_is_valid(const fsh_plain *h) { return FS_PLAIN_GET(h->f.t.isValid, h->d.t.isValid) ? 1 : 0; }
+extern "C" int fsh_plain_la_use_at(const fsh_plain *h) { return FS_PLAIN_GET(h->f.t.useAT, h->d.t.useAT) ? 1 : 0; }
+extern "C" void fsh_plain_la_at(const fsh_plain *h, void *out)
+{
+    if (h->kind == 0)
+        memcpy(out, &h->f.at_packed, sizeof(h->f.at_packed));
+    else
+        memcpy(out, &h->d.at_packed, sizeof(h->d.at_packed));
+}
+#undef FS_PLAIN_GET
+// {dx, dy, centerX, centerY} (FillGpuCoords / FillCoord, Fractal.cpp:1782-1786,1813-1817,1833-1844, :2828-2832):
+// float[4] for kind 0, double[4] for kind 1.
+extern "C" void fsh_plain_coords(const fsh_view *v, const fsh_plain *h, uint32_t w_aa, uint32_t h_aa, void *out)
+{
+    mpf_set_default_prec(v->prec_bits);
+    Mp dx = (v->maxX - v->minX) / Mp::from_ui(w_aa);
+    Mp dy = (v->maxY - v->minY) / Mp::from_ui(h_aa);
+    const Mp &ocx = h->kind == 0 ? h->f.ob.cx : h->d.ob.cx;
+    const Mp &ocy = h->kind == 0 ? h->f.ob.cy : h->d.ob.cy;
+    Mp cX = ocx - v->minX;
+    Mp cY = ocy - v->maxY;
+    const double d[4] = {mpf_get_d(dx.v), mpf_get_d(dy.v), mpf_get_d(cX.v), mpf_get_d(cY.v)};
+    for (int i = 0; i < 4; i++) {
+        if (h->kind == 0)
+            ((float *)out)[i] = (float)d[i];
+        else
+            ((double *)out)[i] = d[i];
+    }
+}
+// field-wise double -> CudaDblflt conversions (CudaDblflt(double) = MattDblflt(double), dblflt.h:13-23)
+namespace {
+fs_real_p2x32 real_p2x32(double v)
+{
+    fs_real_p2x32 r;
+    df_from_double(v, r.head, r.tail);
+    return r;
+}
+fs_cplx_p2x32 cplx_p2x32(fs_cplx_f64 c)
+{
+    fs_cplx_p2x32 r;
+    df_from_double(c.re, r.re_head, r.re_tail);
+    df_from_double(c.im, r.im_head, r.im_tail);
+    return r;
+}
+} // namespace
+extern "C" void fsh_convert_orbit_f64_to_p2x32(const fs_orbit_f64 *in, uint64_t n, fs_orbit_p2x32 *out)
+{
+    for (uint64_t i = 0; i < n; i++) {
+        df_from_double(in[i].x, out[i].x_head, out[i].x_tail);
+        df_from_double(in[i].y, out[i].y_head, out[i].y_tail);
+    }
+}
+extern "C" void fsh_convert_la_f64_to_p2x32(const fs_la_f64_u32 *in, uint64_t n, fs_la_p2x32_u32 *out)
+{
+    for (uint64_t i = 0; i < n; i++) {
+        fs_la_p2x32_u32 o;
+        o.Ref = cplx_p2x32(in[i].Ref);
+        o.ZCoeff = cplx_p2x32(in[i].ZCoeff);
+        o.CCoeff = cplx_p2x32(in[i].CCoeff);
+        o.LAThreshold = real_p2x32(in[i].LAThreshold);
+        o.LAThresholdC = real_p2x32(in[i].LAThresholdC);
+        o.MinMag = real_p2x32(in[i].MinMag);
+        o.StepLength = in[i].StepLength;
+        o.NextStageLAIndex = in[i].NextStageLAIndex;
+        out[i] = o;
+    }
+}
+extern "C" void fsh_convert_at_f64_to_p2x32(const fs_at_f64_u32 *in, fs_at_p2x32_u32 *out)
+{
+    out->StepLength = in->StepLength;
+    out->ThresholdC = real_p2x32(in->ThresholdC);
+    out->SqrEscapeRadius = real_p2x32(in->SqrEscapeRadius);
+    out->RefC = cplx_p2x32(in->RefC);
+    out->ZCoeff = cplx_p2x32(in->ZCoeff);
+    out->CCoeff = cplx_p2x32(in->CCoeff);
+    out->InvZCoeff = cplx_p2x32(in->InvZCoeff);
+    out->CCoeffSqrInvZCoeff = cplx_p2x32(in->CCoeffSqrInvZCoeff);
+    out->CCoeffInvZCoeff = cplx_p2x32(in->CCoeffInvZCoeff);
+    out->CCoeffNormSqr = real_p2x32(in->CCoeffNormSqr);
+    out->RefCNormSqr = real_p2x32(in->RefCNormSqr);
+    out->factor = real_p2x32(in->factor);
+}
+extern "C" void fsh_convert_coords_f64_to_p2x32(const double in[4], fs_real_p2x32 out[4])
+{
+    for (int i = 0; i < 4; i++)
+        out[i] = real_p2x32(in[i]);
 }

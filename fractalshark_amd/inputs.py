@@ -426,3 +426,103 @@ class OrbitF64:
         self._lib.fsh_view_coords_perturb_f64(self.view._h, self._h, self.view.width * aa, self.view.height * aa,
                                               out.ctypes.data)
         return out
+
+
+# ---- plain (non-HDR) LAv2 inputs: Gpu1x32 / Gpu1x64 / Gpu2x32 PerturbedLAv2*
+def _plain_dtypes(kind):
+    f = {"f32": "<f4", "f64": "<f8"}.get(kind)
+    if kind == "2x32":
+        real = [("head", "<f4"), ("tail", "<f4")]
+        cplx = np.dtype([("re_head", "<f4"), ("re_tail", "<f4"), ("im_head", "<f4"), ("im_tail", "<f4")])
+        orbit = np.dtype([("x_head", "<f4"), ("x_tail", "<f4"), ("y_head", "<f4"), ("y_tail", "<f4")])
+        real = np.dtype(real)
+    else:
+        real = np.dtype(f)
+        cplx = np.dtype([("re", f), ("im", f)])
+        orbit = np.dtype([("x", f), ("y", f)])
+    la = np.dtype([("Ref", cplx), ("ZCoeff", cplx), ("CCoeff", cplx), ("LAThreshold", real), ("LAThresholdC", real),
+                   ("MinMag", real), ("StepLength", "<u4"), ("NextStageLAIndex", "<u4")])
+    at = np.dtype([("StepLength", "<u4"), ("ThresholdC", real), ("SqrEscapeRadius", real), ("RefC", cplx),
+                   ("ZCoeff", cplx), ("CCoeff", cplx), ("InvZCoeff", cplx), ("CCoeffSqrInvZCoeff", cplx),
+                   ("CCoeffInvZCoeff", cplx), ("CCoeffNormSqr", real), ("RefCNormSqr", real), ("factor", real)],
+                  align=(kind == "f64"))
+    return orbit, la, at, real
+
+
+class PlainInputs:
+    """Orbit + LAv2 table + coordinates for the non-HDR LAv2 algorithms.
+
+    kind "f32": PerturbationResults<u32,float,Disable> + LAReference<u32,float,float,Disable> built in binary32
+    (Gpu1x32PerturbedLAv2*); "f64": the same in binary64 (Gpu1x64PerturbedLAv2*); "2x32": the binary64 inputs converted
+    field by field to CudaDblflt<MattDblflt> (Gpu2x32PerturbedLAv2*, Fractal.cpp:2771-2772)."""
+
+    def __init__(self, view, kind, host_threads=1, periodicity=True, max_iter=None):
+        assert kind in ("f32", "f64", "2x32")
+        lib = self._lib = _capi.inputs_lib()
+        self.view, self.kind = view, kind
+        self._h = lib.fsh_plain_create(view._h, 0 if kind == "f32" else 1,
+                                       view.num_iterations if max_iter is None else max_iter,
+                                       1 if periodicity else 0, host_threads)
+        if not self._h:
+            raise RuntimeError("fsh_plain_create failed")
+        src_kind = "f32" if kind == "f32" else "f64"
+        o_dt, la_dt, at_dt, real_dt = _plain_dtypes(src_kind)
+        self.count = int(lib.fsh_plain_orbit_count(self._h))
+        self.period = int(lib.fsh_plain_orbit_period(self._h))
+        self.la_count = int(lib.fsh_plain_la_count(self._h))
+        self.stage_count = int(lib.fsh_plain_la_stage_count(self._h))
+        self.is_valid = bool(lib.fsh_plain_la_is_valid(self._h))
+        self.use_at = bool(lib.fsh_plain_la_use_at(self._h))
+
+        def grab(ptr, n, dt):
+            if n == 0 or not ptr:
+                return np.zeros(0, dt)
+            return np.frombuffer((C.c_uint8 * (n * dt.itemsize)).from_address(ptr), dtype=dt).copy()
+
+        orbit = grab(lib.fsh_plain_orbit_data(self._h), self.count, o_dt)
+        las = grab(lib.fsh_plain_la_data(self._h), self.la_count, la_dt)
+        self._stages = grab(lib.fsh_plain_la_stages(self._h), self.stage_count, np.dtype([("LAIndex", "<u4"),
+                                                                                          ("MacroItCount", "<u4")]))
+        at = np.zeros(1, at_dt)
+        lib.fsh_plain_la_at(self._h, at.ctypes.data)
+        aa = view.antialiasing
+        coords = np.zeros(4, real_dt)
+        lib.fsh_plain_coords(view._h, self._h, view.width * aa, view.height * aa, coords.ctypes.data)
+        if kind == "2x32":
+            o2, la2, at2, real2 = _plain_dtypes("2x32")
+            self._orbit = np.zeros(self.count, o2)
+            lib.fsh_convert_orbit_f64_to_p2x32(orbit.ctypes.data, self.count, self._orbit.ctypes.data)
+            self._las = np.zeros(max(self.la_count, 1), la2)
+            lib.fsh_convert_la_f64_to_p2x32(las.ctypes.data, self.la_count, self._las.ctypes.data)
+            self._at = np.zeros(1, at2)
+            lib.fsh_convert_at_f64_to_p2x32(at.ctypes.data, self._at.ctypes.data)
+            self._coords = np.zeros(4, real2)
+            lib.fsh_convert_coords_f64_to_p2x32(coords.ctypes.data, self._coords.ctypes.data)
+        else:
+            self._orbit, self._las, self._at, self._coords = orbit, (las if self.la_count else np.zeros(1, la_dt)), at, coords
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.fsh_plain_destroy(self._h)
+            self._h = None
+
+    orbit_ptr = property(lambda self: self._orbit.ctypes.data)
+    las_ptr = property(lambda self: self._las.ctypes.data)
+    stages_ptr = property(lambda self: self._stages.ctypes.data if self.stage_count else None)
+    at_ptr = property(lambda self: self._at.ctypes.data)
+    coords_ptr = property(lambda self: self._coords.ctypes.data)
+
+    def orbit(self):
+        return self._orbit.copy()
+
+    def las(self):
+        return self._las[: self.la_count].copy()
+
+    def stages(self):
+        return self._stages.copy()
+
+    def at(self):
+        return self._at.copy()
+
+    def coords(self):
+        return self._coords.copy()

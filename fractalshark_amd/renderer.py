@@ -121,6 +121,23 @@ class GPURenderer:
                                          C.addressof(la.at))
         return err
 
+    def InitializePerturbPlain(self, GenerationNumber1, plain, with_la=True):
+        """InitializePerturb<IterType, T, T, Disable, T> for a non-HDR T: plain = inputs.PlainInputs (kind f32 -> float,
+        f64 -> double, 2x32 -> CudaDblflt<MattDblflt>), i.e. the inputs of Gpu1x32 / Gpu1x64 / Gpu2x32 PerturbedLAv2*."""
+        T = {"f32": T_F32, "f64": T_F64, "2x32": T_2X32}[plain.kind]
+        err = self._lib.fs_upload_orbit(self._h, GenerationNumber1, T, 4, plain.orbit_ptr, plain.count, plain.count,
+                                        plain.period)
+        if err or not with_la:
+            return err
+        return self._lib.fs_upload_la(self._h, GenerationNumber1, T, 4, plain.las_ptr, plain.la_count,
+                                      plain.stages_ptr, plain.stage_count, 1 if plain.is_valid else 0,
+                                      1 if plain.use_at else 0, plain.at_ptr)
+
+    def RenderPerturbLAv2Plain(self, plain, n_iterations, Mode=LAV2_FULL):
+        """RenderPerturbLAv2<IterType, T, T, Mode, Disable> for the type of `plain` (see InitializePerturbPlain)."""
+        T = {"f32": T_F32, "f64": T_F64, "2x32": T_2X32}[plain.kind]
+        return self._lib.fs_render_lav2(self._h, T, Mode, PARITY_CPU, plain.coords_ptr, int(n_iterations))
+
     # ---- renders (asynchronous on the compute stream)
     @staticmethod
     def _pack_coords(T, vals):

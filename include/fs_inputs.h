@@ -135,6 +135,30 @@ const void *const *fsh_orbit_f64_bla_level_ptrs(const fsh_orbit_f64 *o); /* fs_b
 const uint64_t *fsh_orbit_f64_bla_level_sizes(const fsh_orbit_f64 *o);
 void fsh_view_coords_perturb_f64(const fsh_view *v, const fsh_orbit_f64 *o, uint32_t w_aa, uint32_t h_aa, double out[4]);
 
+/* Plain float / double orbit + LAv2 table: PerturbationResults<uint32_t,T,Disable> + LAReference<uint32_t,T,T,Disable>
+ * for T = float (kind 0: Gpu1x32PerturbedLAv2*) or double (kind 1: Gpu1x64PerturbedLAv2*, and the source of the
+ * Gpu2x32PerturbedLAv2* inputs, which FractalShark converts field-wise from the double ones). */
+typedef struct fsh_plain fsh_plain;
+fsh_plain *fsh_plain_create(const fsh_view *v, int kind, uint64_t max_iter, int periodicity, int host_threads);
+void fsh_plain_destroy(fsh_plain *h);
+int fsh_plain_kind(const fsh_plain *h);
+uint64_t fsh_plain_orbit_count(const fsh_plain *h);
+uint64_t fsh_plain_orbit_period(const fsh_plain *h);
+const void *fsh_plain_orbit_data(const fsh_plain *h); /* fs_orbit_f32[] / fs_orbit_f64[] */
+uint32_t fsh_plain_la_count(const fsh_plain *h);
+const void *fsh_plain_la_data(const fsh_plain *h);    /* fs_la_f32_u32[] / fs_la_f64_u32[] */
+uint32_t fsh_plain_la_stage_count(const fsh_plain *h);
+const fs_la_stage_u32 *fsh_plain_la_stages(const fsh_plain *h);
+int fsh_plain_la_is_valid(const fsh_plain *h);
+int fsh_plain_la_use_at(const fsh_plain *h);
+void fsh_plain_la_at(const fsh_plain *h, void *out);  /* fs_at_f32_u32 / fs_at_f64_u32 */
+/* out = {dx, dy, centerX, centerY}: float[4] (kind 0) or double[4] (kind 1) */
+void fsh_plain_coords(const fsh_view *v, const fsh_plain *h, uint32_t w_aa, uint32_t h_aa, void *out);
+void fsh_convert_orbit_f64_to_p2x32(const fs_orbit_f64 *in, uint64_t n, fs_orbit_p2x32 *out);
+void fsh_convert_la_f64_to_p2x32(const fs_la_f64_u32 *in, uint64_t n, fs_la_p2x32_u32 *out);
+void fsh_convert_at_f64_to_p2x32(const fs_at_f64_u32 *in, fs_at_p2x32_u32 *out);
+void fsh_convert_coords_f64_to_p2x32(const double in[4], fs_real_p2x32 out[4]);
+
 #ifdef __cplusplus
 }
 #endif

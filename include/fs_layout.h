@@ -320,6 +320,84 @@ typedef struct fs_at_2x32_u64 {
     uint32_t pad_;
 } fs_at_2x32_u64;
 
+/* ---- plain (non-HDR) LAv2 families: T = float (Gpu1x32PerturbedLAv2*), double (Gpu1x64PerturbedLAv2*) and
+ * CudaDblflt<MattDblflt> (Gpu2x32PerturbedLAv2*).  The complex type is FloatComplex<T> = {re, im}
+ * (HpSharkFloatLib/FloatComplex.h:7-12), records are LAInfoDeep<uint32_t,T,T,Disable> (LAInfoDeep.h:35-41),
+ * ATInfo<uint32_t,T,T> (ATInfo.h:84-95) and GPUReferenceIter<T,Disable> = {x, y} (GPU_ReferenceIter.h:56-127);
+ * CudaDblflt is {head, tail} under #pragma pack(4). */
+typedef struct fs_orbit_f32 {
+    float x;
+    float y;
+} fs_orbit_f32;
+
+typedef struct fs_orbit_p2x32 {
+    float x_head;
+    float x_tail;
+    float y_head;
+    float y_tail;
+} fs_orbit_p2x32;
+
+typedef struct fs_cplx_f32 {
+    float re;
+    float im;
+} fs_cplx_f32;
+
+typedef struct fs_cplx_f64 {
+    double re;
+    double im;
+} fs_cplx_f64;
+
+typedef struct fs_real_p2x32 {
+    float head;
+    float tail;
+} fs_real_p2x32;
+
+typedef struct fs_cplx_p2x32 {
+    float re_head;
+    float re_tail;
+    float im_head;
+    float im_tail;
+} fs_cplx_p2x32;
+
+#define FS_DECL_PLAIN_LA(NAME, CPLX, REAL, ITER)                                                                        \
+    typedef struct NAME {                                                                                               \
+        CPLX Ref;                                                                                                       \
+        CPLX ZCoeff;                                                                                                    \
+        CPLX CCoeff;                                                                                                    \
+        REAL LAThreshold;                                                                                               \
+        REAL LAThresholdC;                                                                                              \
+        REAL MinMag;                                                                                                    \
+        ITER StepLength;                                                                                                \
+        ITER NextStageLAIndex;                                                                                          \
+    } NAME
+#define FS_DECL_PLAIN_AT(NAME, CPLX, REAL, ITER)                                                                        \
+    typedef struct NAME {                                                                                               \
+        ITER StepLength;                                                                                                \
+        REAL ThresholdC;                                                                                                \
+        REAL SqrEscapeRadius;                                                                                           \
+        CPLX RefC;                                                                                                      \
+        CPLX ZCoeff;                                                                                                    \
+        CPLX CCoeff;                                                                                                    \
+        CPLX InvZCoeff;                                                                                                 \
+        CPLX CCoeffSqrInvZCoeff;                                                                                        \
+        CPLX CCoeffInvZCoeff;                                                                                           \
+        REAL CCoeffNormSqr;                                                                                             \
+        REAL RefCNormSqr;                                                                                               \
+        REAL factor;                                                                                                    \
+    } NAME
+FS_DECL_PLAIN_LA(fs_la_f32_u32, fs_cplx_f32, float, uint32_t);           /* 44 B */
+FS_DECL_PLAIN_LA(fs_la_f64_u32, fs_cplx_f64, double, uint32_t);          /* 80 B */
+FS_DECL_PLAIN_LA(fs_la_p2x32_u32, fs_cplx_p2x32, fs_real_p2x32, uint32_t); /* 80 B */
+FS_DECL_PLAIN_LA(fs_la_f32_u64, fs_cplx_f32, float, uint64_t);           /* 56 B */
+FS_DECL_PLAIN_LA(fs_la_f64_u64, fs_cplx_f64, double, uint64_t);          /* 88 B */
+FS_DECL_PLAIN_LA(fs_la_p2x32_u64, fs_cplx_p2x32, fs_real_p2x32, uint64_t); /* 88 B */
+FS_DECL_PLAIN_AT(fs_at_f32_u32, fs_cplx_f32, float, uint32_t);           /* 72 B */
+FS_DECL_PLAIN_AT(fs_at_f64_u32, fs_cplx_f64, double, uint32_t);          /* 144 B */
+FS_DECL_PLAIN_AT(fs_at_p2x32_u32, fs_cplx_p2x32, fs_real_p2x32, uint32_t); /* 140 B */
+FS_DECL_PLAIN_AT(fs_at_f32_u64, fs_cplx_f32, float, uint64_t);           /* 80 B */
+FS_DECL_PLAIN_AT(fs_at_f64_u64, fs_cplx_f64, double, uint64_t);          /* 144 B */
+FS_DECL_PLAIN_AT(fs_at_p2x32_u64, fs_cplx_p2x32, fs_real_p2x32, uint64_t); /* 144 B */
+
 typedef struct fs_color16 {
     uint16_t r, g, b, a;
 } fs_color16;
@@ -352,6 +430,13 @@ static_assert(sizeof(fs_la_stage_u64) == 16 && sizeof(fs_la_hdr32_u64) == 80 && 
 static_assert(sizeof(fs_at_hdr32_u64) == 120 && sizeof(fs_at_hdr64_u64) == 232 && sizeof(fs_at_2x32_u64) == 192,
               "uint64_t IterType AT records");
 static_assert(sizeof(fs_bla_f64) == 48 && sizeof(fs_orbit_f64) == 16, "plain double records");
+static_assert(sizeof(fs_orbit_f32) == 8 && sizeof(fs_orbit_p2x32) == 16, "plain orbit entries");
+static_assert(sizeof(fs_la_f32_u32) == 44 && sizeof(fs_la_f64_u32) == 80 && sizeof(fs_la_p2x32_u32) == 80 &&
+                  sizeof(fs_la_f32_u64) == 56 && sizeof(fs_la_f64_u64) == 88 && sizeof(fs_la_p2x32_u64) == 88,
+              "plain LA records");
+static_assert(sizeof(fs_at_f32_u32) == 72 && sizeof(fs_at_f64_u32) == 144 && sizeof(fs_at_p2x32_u32) == 140 &&
+                  sizeof(fs_at_f32_u64) == 80 && sizeof(fs_at_f64_u64) == 144 && sizeof(fs_at_p2x32_u64) == 144,
+              "plain AT records");
 #endif
 
 #endif /* FS_LAYOUT_H */

@@ -138,9 +138,13 @@ int32_t fs_bla_lm2(const fs_renderer *r);
 uint64_t fs_bla_level_size(const fs_renderer *r, int32_t level);
 uint32_t fs_read_bla_level(fs_renderer *r, int32_t level, void *out, uint64_t max_records);
 
-/* GPURenderer::RenderPerturbLAv2<IterType,T,SubType,Mode,PExtras> (GPU_Render.cu:995-1188).
- * coords = {dx, dy, centerX, centerY} in the type selected by type_tag (fs_real_hdr32[4] for FS_T_HDR32).
- * Asynchronous on the compute stream. */
+/* GPURenderer::RenderPerturbLAv2<IterType,T,SubType,Mode,PExtras> (GPU_Render.cu:995-1188) for all six numeric types of
+ * its instantiation list (:1204-1300): FS_T_HDR32 / FS_T_HDR64 / FS_T_HDR2X32 (GpuHDRx32 / x64 / x2x32 PerturbedLAv2*)
+ * and the non-HDR FS_T_F32 / FS_T_F64 / FS_T_2X32 (Gpu1x32 / Gpu1x64 / Gpu2x32 PerturbedLAv2*; orbit, table and ATInfo
+ * in the "plain" record families of fs_layout.h, uploaded with the same type_tag).
+ * coords = {dx, dy, centerX, centerY} in the type selected by type_tag (fs_real_hdr32[4], fs_real_hdr64[4],
+ * fs_real_2x32[4], float[4], double[4], fs_real_p2x32[4]).  `parity` only applies to FS_T_HDR32 / FS_T_HDR64 (the types
+ * with a CPU twin).  Asynchronous on the compute stream. */
 uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, const void *coords,
                         uint64_t n_iterations);
 

@@ -50,6 +50,9 @@ def lib():
         l.orc_gpu_lav2_2x32.restype = None
         l.orc_gpu_lav2_2x32.argtypes = [vp, u32, u32, u32, u32, vp, u32, vp, vp, u32, C.c_int, C.c_int, vp, vp, u32,
                                         C.c_int, C.c_int, vp]
+        l.orc_gpu_lav2_plain.restype = None
+        l.orc_gpu_lav2_plain.argtypes = [C.c_int, vp, u32, u32, u32, u32, vp, u32, vp, vp, u32, C.c_int, C.c_int, vp, vp,
+                                         u32, C.c_int, C.c_int, vp]
         for name in ("orc_df_add", "orc_df_sub", "orc_df_mul"):
             getattr(l, name).restype = None
             getattr(l, name).argtypes = [vp, vp, vp]
@@ -182,6 +185,23 @@ def gpu_lav2_2x32(view, orbit2, la2, aa=1, rows=None, threads=8, mode=0, n_itera
     else:
         lib().orc_gpu_lav2_2x32(out.ctypes.data, out.shape[1], w, y0, y1, orbit2.data_ptr, orbit2.count, None, None, 0,
                                 0, 0, None, co.ctypes.data, n, mode, threads, st)
+    if stats:
+        return out, {"at_iterations": st[0], "la_steps": st[1], "perturb_steps": st[2]}
+    return out
+
+
+def gpu_lav2_plain(view, pin, aa=1, rows=None, threads=8, mode=0, n_iterations=None, stats=False):
+    """Restated CUDA kernel mandel_1xHDR_float_perturb_lav2<.., T, T, ..> for T = float / double / CudaDblflt
+    (oracle/gpu_ref_plain.cpp).  pin: inputs.PlainInputs (its kind selects T); mode 0 Full, 1 PO, 2 LAO."""
+    w, h = view.width * aa, view.height * aa
+    out = new_buffer(w, h)
+    y0, y1 = rows if rows else (0, h)
+    n = view.num_iterations if n_iterations is None else n_iterations
+    st = (u64 * 3)()
+    kind = {"f32": 0, "f64": 1, "2x32": 2}[pin.kind]
+    lib().orc_gpu_lav2_plain(kind, out.ctypes.data, out.shape[1], w, y0, y1, pin.orbit_ptr, pin.count, pin.las_ptr,
+                             pin.stages_ptr, pin.stage_count, 1 if pin.is_valid else 0, 1 if pin.use_at else 0,
+                             pin.at_ptr, pin.coords_ptr, n, mode, threads, st)
     if stats:
         return out, {"at_iterations": st[0], "la_steps": st[1], "perturb_steps": st[2]}
     return out

@@ -200,6 +200,23 @@ template uint32_t GPURenderer::InitializePerturb<uint32_t, HDR2x32, CudaDblflt<M
     const LAReference<uint32_t, HDR2x32, CudaDblflt<MattDblflt>, PerturbExtras::Disable> *);
 template uint32_t GPURenderer::RenderPerturbLAv2<uint32_t, HDR2x32, CudaDblflt<MattDblflt>, LAv2Mode::Full, PerturbExtras::Disable>(
     RenderAlgorithm, HDR2x32, HDR2x32, HDR2x32, HDR2x32, HDR2x32, HDR2x32, uint32_t);
+// the non-HDR LAv2 types: Gpu1x32 / Gpu1x64 / Gpu2x32 PerturbedLAv2* (GPU_Render.cu:511-537,1204-1300)
+using P2x32 = CudaDblflt<MattDblflt>;
+#define FS_INST_PLAIN(T, IT)                                                                                            \
+    template uint32_t GPURenderer::InitializePerturb<IT, T, T, PerturbExtras::Disable, T>(                              \
+        size_t, const GPUPerturbResults<IT, T, PerturbExtras::Disable> *, size_t,                                       \
+        const GPUPerturbResults<IT, T, PerturbExtras::Disable> *, const LAReference<IT, T, T, PerturbExtras::Disable> *); \
+    template uint32_t GPURenderer::RenderPerturbLAv2<IT, T, T, LAv2Mode::Full, PerturbExtras::Disable>(                 \
+        RenderAlgorithm, T, T, T, T, T, T, IT);                                                                         \
+    template uint32_t GPURenderer::RenderPerturbLAv2<IT, T, T, LAv2Mode::PO, PerturbExtras::Disable>(                   \
+        RenderAlgorithm, T, T, T, T, T, T, IT);                                                                         \
+    template uint32_t GPURenderer::RenderPerturbLAv2<IT, T, T, LAv2Mode::LAO, PerturbExtras::Disable>(                  \
+        RenderAlgorithm, T, T, T, T, T, T, IT)
+FS_INST_PLAIN(float, uint32_t);
+FS_INST_PLAIN(double, uint32_t);
+FS_INST_PLAIN(P2x32, uint32_t);
+FS_INST_PLAIN(float, uint64_t);
+#undef FS_INST_PLAIN
 template uint32_t GPURenderer::RenderPerturbBLAScaled<uint32_t, HDR32>(
     RenderAlgorithm, const GPUPerturbResults<uint32_t, HDR32, PerturbExtras::Bad> *,
     const GPUPerturbResults<uint32_t, float, PerturbExtras::Bad> *, HDR32, HDR32, HDR32, HDR32, HDR32, HDR32, uint32_t, int);

@@ -629,3 +629,45 @@ def test_other_views_2x32(renderer, native_libs):
         o2, la2 = inputs.Orbit2x32(o), inputs.LATable2x32(la)
         out, _ = _render_2x32(renderer, v, o2, la2, LAV2_FULL)
         assert np.array_equal(out, _oracle.gpu_lav2_2x32(v, o2, la2, mode=0)), view_n
+
+
+# ---- non-HDR LAv2: Gpu1x32 / Gpu1x64 / Gpu2x32 PerturbedLAv2[PO|LAO] (Fractal's AUTO choice for zoom 1e4 .. 1e34)
+def _render_plain(r, v, pin, mode, n_iter=None, bands=None):
+    w, h = v.width * v.antialiasing, v.height * v.antialiasing
+    assert r.InitializeMemory(w, h, v.antialiasing, None, 0, 0, 0, False) == 0
+    if bands:
+        assert r.SetRowBands(*bands) == 0
+    assert r.InitializePerturbPlain(0, pin) == 0
+    assert r.ClearMemory() == 0
+    n = v.num_iterations if n_iter is None else n_iter
+    assert r.RenderPerturbLAv2Plain(pin, n, Mode=mode) == 0
+    assert r.SyncComputeStream() == 0
+    out = r.new_iter_buffer()
+    red = _capi.Reduction()
+    assert r.RenderCurrent(n, out, None, red) == 0
+    assert r.SyncComputeStream() == 0
+    return out, red
+
+
+@pytest.mark.parametrize("kind", ["f32", "f64", "2x32"])
+@pytest.mark.parametrize("width", ["1e-6", "1e-12", "1e-20", "1e-28"])
+def test_plain_lav2_parity(renderer, native_libs, kind, width):
+    from test_plain_oracle import shallow_view
+    v = shallow_view(width)
+    pin = inputs.PlainInputs(v, kind)
+    for mode, omode in ((LAV2_FULL, 0), (LAV2_PO, 1), (LAV2_LAO, 2)):
+        out, red = _render_plain(renderer, v, pin, mode)
+        ref = _oracle.gpu_lav2_plain(v, pin, mode=omode)
+        assert np.array_equal(out, ref), (kind, width, mode, int((out != ref).sum()))
+        assert red.Sum == int(ref[:36, :64].astype(np.uint64).sum())
+
+
+def test_plain_lav2_odd_sizes_bands_and_antialiasing(renderer, native_libs):
+    from test_plain_oracle import shallow_view
+    v = shallow_view("1e-12", W=37, H=21)
+    v.antialiasing = 2
+    for kind in ("f32", "2x32"):
+        pin = inputs.PlainInputs(v, kind)
+        out, _ = _render_plain(renderer, v, pin, LAV2_FULL)
+        ref = _oracle.gpu_lav2_plain(v, pin, aa=2, mode=0)
+        assert np.array_equal(out, ref), kind
