@@ -15,6 +15,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/fs_layout.h"
 #include "df32_math.hpp"
 #include "kernels.h"
@@ -67,6 +69,13 @@ template <class T> __device__ __forceinline__ T cheb(cx<T> a)
     return ar > ai ? ar : ai;
 }
 
+// zx * T{2} + d (LAKernel.cuh:143-149).  For binary32 / binary64 the product by two is exact, so the fused form performs
+// the same single rounding of 2z + d as the separate multiply and add: identical bits, one instruction.  (Orbit values
+// are bounded by the bailout radius, far from overflow.)
+template <class T> __device__ __forceinline__ T twice_plus(T z, T d, T Two) { return z * Two + d; }
+template <> __device__ __forceinline__ float twice_plus<float>(float z, float d, float) { return __builtin_fmaf(z, 2.0f, d); }
+template <> __device__ __forceinline__ double twice_plus<double>(double z, double d, double) { return __builtin_fma(z, 2.0, d); }
+
 __device__ __forceinline__ float ld(float v) { return v; }
 __device__ __forceinline__ double ld(double v) { return v; }
 __device__ __forceinline__ df32 ld(const fs_real_p2x32 &v) { return df32(v.head, v.tail); }
@@ -90,6 +99,67 @@ __device__ __forceinline__ cx<df32> ldz(const fs_orbit_p2x32 *__restrict__ o, ui
 {
     const float4 v = *reinterpret_cast<const float4 *>(o + i);
     return cx<df32>{df32(v.x, v.y), df32(v.z, v.w)};
+}
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// The perturbation loop of LAKernel.cuh:133-235 for T = float, on packed binary32 pairs.  Same IEEE operations as the
+// generic loop below, in the same association:
+//   s  = 2z + d                         one v_pk_fma_f32 (exact doubling, see twice_plus)
+//   pa = dX * (sX, sY), pb = dY * (sY, sX)
+//   n  = (pa.x - pb.x, pa.y + pb.y) + d0   one v_pk_add_f32 with a lane-wise negate, one v_pk_add_f32
+//   t  = z' + n, |t|^2, |n|^2
+// Per-lane state is {d, z, byte offset of the orbit entry, iter}; the select block that rebases is skipped with one
+// wave-uniform branch on the steps where no lane of the wave rebases.
+template <bool kStats>
+__device__ __forceinline__ void perturb_f32(const fs_orbit_f32 *__restrict__ orb, uint32_t orbit_count, f2 d, f2 d0,
+                                            uint32_t &RefIteration, uint32_t &iter, uint32_t n_iterations,
+                                            uint64_t &c_pt)
+{
+    const char *base = reinterpret_cast<const char *>(orb);
+    const uint32_t max_off = (orbit_count - 1) * 8u;
+    uint32_t off = RefIteration * 8u;
+    const f2 z0 = *reinterpret_cast<const f2 *>(base);
+    f2 z = *reinterpret_cast<const f2 *>(base + off);
+    const f2 two = {2.0f, 2.0f};
+    // one step: state (D, Z) -> (ND, NZ); two copies with the names swapped make the loop body, so that no step ends in
+    // register copies
+#define FS_PLAIN_STEP(D, Z, ND, NZ)                                                                                     \
+    {                                                                                                                   \
+        const f2 s_ = __builtin_elementwise_fma(Z, two, D);                                                             \
+        off += 8u;                                                                                                      \
+        NZ = *reinterpret_cast<const f2 *>(base + off); /* the entry this step ends on */                               \
+        const f2 pa_ = D.xx * s_;                                                                                       \
+        const f2 pb_ = D.yy * s_.yx;                                                                                    \
+        f2 r_;                                                                                                          \
+        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(r_) : "v"(pa_), "v"(pb_));                       \
+        ND = r_ + d0;                                                                                                   \
+        if (kStats)                                                                                                     \
+            c_pt++;                                                                                                     \
+        const f2 t_ = NZ + ND;                                                                                          \
+        const f2 tt_ = t_ * t_;                                                                                         \
+        const float normSquared_ = tt_.x + tt_.y;                                                                       \
+        if (!(normSquared_ < 256.0f && iter < n_iterations))                                                            \
+            break;                                                                                                      \
+        const f2 nn_ = ND * ND;                                                                                         \
+        const float DeltaNormSquared_ = nn_.x + nn_.y;                                                                  \
+        const bool rebase_ = normSquared_ < DeltaNormSquared_ || off >= max_off;                                        \
+        if (__builtin_amdgcn_ballot_w64(rebase_) != 0) {                                                                \
+            /* the empty volatile asm keeps this a real (wave-uniform) branch instead of unconditional selects */       \
+            asm volatile("" : "+v"(ND), "+v"(NZ), "+v"(off));                                                           \
+            ND = rebase_ ? t_ : ND;                                                                                     \
+            NZ = rebase_ ? z0 : NZ;                                                                                     \
+            off = rebase_ ? 0u : off;                                                                                   \
+        }                                                                                                               \
+        ++iter;                                                                                                         \
+    }
+    f2 d2, z2;
+    for (;;) {
+        FS_PLAIN_STEP(d, z, d2, z2)
+        FS_PLAIN_STEP(d2, z2, d, z)
+    }
+#undef FS_PLAIN_STEP
+    RefIteration = off >> 3;
 }
 
 template <class T, int Mode, bool kStats> __global__ void __launch_bounds__(256) k_lav2_plain(FsLav2ArgsPlain A)
@@ -178,36 +248,45 @@ template <class T, int Mode, bool kStats> __global__ void __launch_bounds__(256)
         if (Mode != FS_MODE_LAO) {
             // :133-235.  perturbLoop(maxRefIteration) at :254-276 reads the block's previous results, which are zero on
             // the cleared buffer every caller passes (Fractal.cpp:2822), so only perturbLoop(n_iterations) runs.
+            if constexpr (std::is_same<T, float>::value) {
+                perturb_f32<kStats>(orb, A.orbit_count, f2{DeltaSubN.re, DeltaSubN.im}, f2{DeltaSub0X, DeltaSub0Y},
+                                    RefIteration, iter, n_iterations, c_pt);
+            } else {
             const uint32_t MaxRef = A.orbit_count - 1;
             const T TwoFiftySix = P::from_int(256);
             T dX = DeltaSubN.re, dY = DeltaSubN.im;
+            const cx<T> z0 = ldz(orb, 0);
             cx<T> z = ldz(orb, RefIteration);
             for (;;) {
-                const T sumY = z.im * Two + dY; // tempSum1
-                const T sumX = z.re * Two + dX; // tempSum2
+                const T sumY = twice_plus(z.im, dY, Two); // tempSum1 = zy * T{2} + dY
+                const T sumX = twice_plus(z.re, dX, Two); // tempSum2
                 ++RefIteration;
+                z = ldz(orb, RefIteration); // GetIterSeq: the entry this step ends on, requested before the arithmetic
                 const T nX = dX * sumX - dY * sumY + DeltaSub0X;
                 const T nY = dX * sumY + dY * sumX + DeltaSub0Y;
-                dX = nX;
-                dY = nY;
                 if (kStats)
                     c_pt++;
-                z = ldz(orb, RefIteration);
-                const T tX = z.re + dX;
-                const T tY = z.im + dY;
+                const T tX = z.re + nX;
+                const T tY = z.im + nY;
                 const T normSquared = tX * tX + tY * tY;
-                if (normSquared < TwoFiftySix && iter < n_iterations) {
-                    const T DeltaNormSquared = dX * dX + dY * dY;
-                    if (normSquared < DeltaNormSquared || RefIteration >= MaxRef) {
-                        dX = tX;
-                        dY = tY;
-                        RefIteration = 0;
-                        z = ldz(orb, 0);
-                    }
-                    ++iter;
-                } else {
+                if (!(normSquared < TwoFiftySix && iter < n_iterations))
                     break;
+                const T DeltaNormSquared = nX * nX + nY * nY;
+                const bool rebase = normSquared < DeltaNormSquared || RefIteration >= MaxRef;
+                dX = nX;
+                dY = nY;
+                if (__builtin_amdgcn_ballot_w64(rebase) != 0) {
+                    // (the empty volatile asm keeps this a real wave-uniform branch, skipped on the steps where no lane
+                    // of the wave rebases, instead of unconditional selects)
+                    asm volatile("" : "+v"(RefIteration));
+                    dX = rebase ? tX : dX;
+                    dY = rebase ? tY : dY;
+                    RefIteration = rebase ? 0u : RefIteration;
+                    z.re = rebase ? z0.re : z.re;
+                    z.im = rebase ? z0.im : z.im;
                 }
+                ++iter;
+            }
             }
         }
         store_iter(A.out, A.frame, L, X, iter);
