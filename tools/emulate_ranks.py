@@ -1,0 +1,46 @@
+"""Per-rank kernel time at N GPUs, measured on one GPU: renders each rank's interleaved row bands (fs_set_row_bands)
+of the C3 frame in turn.  max over ranks = the kernel part of the N-GPU frame time.
+Usage: python tools/emulate_ranks.py [--world 8] [--parity cpu|cpu_gpustage]"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from fractalshark_amd import (GPURenderer, LAV2_FULL, PARITY_CPU, PARITY_CPU_GPUSTAGE, T_HDR32, inputs, tiling)  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--world", type=int, default=8)
+    ap.add_argument("--parity", default="cpu")
+    ap.add_argument("--band", type=int, default=0)
+    a = ap.parse_args()
+    v = inputs.View.builtin(5, 3840, 2160, antialiasing=1)
+    o = inputs.Orbit(v)
+    la = inputs.LATable(o, host_threads=16)
+    co = [(float(c["m"]), int(c["e"])) for c in v.coords_perturb(o)]
+    parity = PARITY_CPU if a.parity == "cpu" else PARITY_CPU_GPUSTAGE
+    r = GPURenderer(0)
+    assert r.InitializeMemory(3840, 2160, 1, None, 0, 0, 0, False) == 0
+    assert r.InitializePerturb(1, o, 0, None, la) == 0
+    band = a.band or tiling.band_height(1)
+    for world in sorted({1, a.world}):
+        times = []
+        for rank in range(world):
+            assert r.SetRowBands(rank * band, band, world * band) == 0
+            best = 1e9
+            for _ in range(2):
+                assert r.RenderPerturbLAv2(None, None, None, *co, v.num_iterations, T=T_HDR32, Mode=LAV2_FULL,
+                                           parity=parity) == 0
+                assert r.SyncComputeStream() == 0
+                best = min(best, r.last_kernel_ms())
+            times.append(round(best, 3))
+        print(json.dumps({"world": world, "band_rows": band, "parity": a.parity, "kernel_ms_per_rank": times,
+                          "max_ms": max(times), "sum_ms": round(sum(times), 3)}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
