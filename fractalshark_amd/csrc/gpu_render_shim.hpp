@@ -320,6 +320,12 @@ uint32_t GPURenderer::Render(RenderAlgorithm /*algorithm*/, T cx, T cy, T dx, T 
     } else if constexpr (std::is_same<T, ::MattDbldbl>::value) { // Gpu2x64
         const double co[8] = {cx.head, cx.tail, cy.head, cy.tail, dx.head, dx.tail, dy.head, dy.tail};
         return fs_render_direct_lp(r, FS_T_2X64, co, (uint64_t)n_iterations, iteration_precision);
+    } else if constexpr (std::is_same<T, ::MattQFltflt>::value) { // Gpu4x32
+        const float co[16] = {cx.x, cx.y, cx.z, cx.w, cy.x, cy.y, cy.z, cy.w, dx.x, dx.y, dx.z, dx.w, dy.x, dy.y, dy.z, dy.w};
+        return fs_render_direct_lp(r, FS_T_4X32, co, (uint64_t)n_iterations, iteration_precision);
+    } else if constexpr (std::is_same<T, ::MattQDbldbl>::value) { // Gpu4x64
+        const double co[16] = {cx.x, cx.y, cx.z, cx.w, cy.x, cy.y, cy.z, cy.w, dx.x, dx.y, dx.z, dx.w, dy.x, dy.y, dy.z, dy.w};
+        return fs_render_direct_lp(r, FS_T_4X64, co, (uint64_t)n_iterations, iteration_precision);
     } else if constexpr (std::is_same<T, double>::value) {
         // Gpu1x64 is built as the twin of the CPU algorithm Cpu64 (rows from maxY downwards, Fractal.cpp:2148-2183).
         // maxY is not part of this interface: it is rebuilt from the min corner, which rounds differently from
@@ -333,7 +339,7 @@ uint32_t GPURenderer::Render(RenderAlgorithm /*algorithm*/, T cx, T cy, T dx, T 
                                                                 fsmi355_shim::to_abi(cx), fsmi355_shim::to_abi(maxY)};
         return fs_render_direct(r, fsmi355_shim::type_tag<T>::value, co, (uint64_t)n_iterations);
     } else {
-        return FS_ERR_UNSUPPORTED; // the 4x (quad-float / quad-double) kernels
+        return FS_ERR_UNSUPPORTED;
     }
 }
 

@@ -186,8 +186,8 @@ struct FsDirectLpArgs {
     uint32_t *out;
     uint64_t *stats;
     FsFrame frame;
-    float c32[8];
-    double c64[8];
+    float c32[16];  // 1x32: 4, 2x32: 8, 4x32: 16 values
+    double c64[16]; // 2x64: 8, 4x64: 16 values
     uint32_t n_iterations;
 };
 

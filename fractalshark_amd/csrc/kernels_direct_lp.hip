@@ -1,6 +1,7 @@
 // kernels_direct_lp.hip -- the direct (no reference orbit) low-precision kernels of LowPrecisionKernels.cuh that have no
 // CPU RenderAlgorithm twin: Gpu1x32 (mandel_1x_float, :682-...), Gpu2x32 (mandel_2x_float, :384-555, float-float) and
-// Gpu2x64 (mandel_2x_double, :171-290, double-double).  Compiled with -ffp-contract=off.
+// Gpu2x64 (mandel_2x_double, :171-290, double-double), plus Gpu4x32 (mandel_4x_float, :5-75, quad-float) and Gpu4x64
+// (mandel_4x_double, :77-140, quad-double) on the expansion arithmetic of qd_math.hpp.  Compiled with -ffp-contract=off.
 //
 // These restate the CUDA kernels' source semantics: every __f*_rn / __d*_rn intrinsic is one IEEE operation, __fmaf_rd is
 // a fused multiply-add rounded toward -infinity (OCML's rtn variant sets the hardware rounding mode around one v_fma),
@@ -13,8 +14,13 @@
 
 #include "../../include/fs_layout.h"
 #include "hdr_math.hpp"
+#include "qd_math.hpp"
 #include "kernels.h"
 #include "kernel_common.hpp"
+
+using fs::q4;
+using fs::q_mul_pwr2;
+using fs::q_sqr;
 
 extern "C" __device__ __attribute__((const)) float __ocml_fma_rtn_f32(float, float, float);
 
@@ -224,6 +230,75 @@ template <bool kStats> __global__ void __launch_bounds__(256) k_direct_2x64(FsDi
         add_stats(A.stats, 0, 0, c_pt, c_px);
 }
 
+// mandel_4x_float (Gpu4x32), LowPrecisionKernels.cuh:5-75: quad-float; the pixel index enters as make_qf(X, 0, 0, 0), the
+// doubling is mul_pwr2, squares use sqr(), the bailout compares two quads
+template <bool kStats> __global__ void __launch_bounds__(256) k_direct_4x32(FsDirectLpArgs A)
+{
+    using Q = q4<float>;
+    uint32_t X, L;
+    int Y;
+    uint64_t c_pt = 0, c_px = 0;
+    if (lp_pixel(A.frame, X, L, Y)) {
+        c_px = 1;
+        const Q cx{A.c32[0], A.c32[1], A.c32[2], A.c32[3]}, cy{A.c32[4], A.c32[5], A.c32[6], A.c32[7]};
+        const Q dx{A.c32[8], A.c32[9], A.c32[10], A.c32[11]}, dy{A.c32[12], A.c32[13], A.c32[14], A.c32[15]};
+        const Q y0 = cy + dy * Q{(float)Y, 0.0f, 0.0f, 0.0f};
+        const Q x0 = cx + dx * Q{(float)(int)X, 0.0f, 0.0f, 0.0f};
+        const Q four{4.0f, 0.0f, 0.0f, 0.0f};
+        Q x{0.0f, 0.0f, 0.0f, 0.0f}, y = x;
+        Q zrsqr = q_sqr(x), zisqr = q_sqr(y);
+        uint32_t iter = 0;
+        while (zrsqr + zisqr <= four && iter < A.n_iterations) {
+            y = x * y;
+            y = q_mul_pwr2(y, 2.0f);
+            y = y + y0;
+            x = zrsqr - zisqr + x0;
+            zrsqr = q_sqr(x);
+            zisqr = q_sqr(y);
+            iter++;
+        }
+        if (kStats)
+            c_pt = iter;
+        store_iter(A.out, A.frame, L, X, iter);
+    }
+    if (kStats)
+        add_stats(A.stats, 0, 0, c_pt, c_px);
+}
+
+// mandel_4x_double (Gpu4x64), LowPrecisionKernels.cuh:77-140: quad-double; the pixel index and the factor two are scalars
+// (quad * double), squares are full products, the bailout compares against the scalar 4.0
+template <bool kStats> __global__ void __launch_bounds__(256) k_direct_4x64(FsDirectLpArgs A)
+{
+    using Q = q4<double>;
+    uint32_t X, L;
+    int Y;
+    uint64_t c_pt = 0, c_px = 0;
+    if (lp_pixel(A.frame, X, L, Y)) {
+        c_px = 1;
+        const Q cx{A.c64[0], A.c64[1], A.c64[2], A.c64[3]}, cy{A.c64[4], A.c64[5], A.c64[6], A.c64[7]};
+        const Q dx{A.c64[8], A.c64[9], A.c64[10], A.c64[11]}, dy{A.c64[12], A.c64[13], A.c64[14], A.c64[15]};
+        const Q y0 = cy + dy * (double)Y;
+        const Q x0 = cx + dx * (double)(int)X;
+        Q x{0.0, 0.0, 0.0, 0.0}, y = x;
+        Q zrsqr = x * x, zisqr = y * y;
+        uint32_t iter = 0;
+        while (zrsqr + zisqr <= 4.0 && iter < A.n_iterations) {
+            y = x * y;
+            y = y * 2.0;
+            y = y + y0;
+            x = zrsqr - zisqr + x0;
+            zrsqr = x * x;
+            zisqr = y * y;
+            iter++;
+        }
+        if (kStats)
+            c_pt = iter;
+        store_iter(A.out, A.frame, L, X, iter);
+    }
+    if (kStats)
+        add_stats(A.stats, 0, 0, c_pt, c_px);
+}
+
 } // namespace
 
 bool fsk_direct_lp(const FsDirectLpArgs &A, int kind, int iteration_precision, bool stats, hipStream_t s)
@@ -255,11 +330,23 @@ bool fsk_direct_lp(const FsDirectLpArgs &A, int kind, int iteration_precision, b
         default:
             return false;
         }
-    } else {
+    } else if (kind == 2) {
         if (stats)
             hipLaunchKernelGGL((k_direct_2x64<true>), g, b, 0, s, A);
         else
             hipLaunchKernelGGL((k_direct_2x64<false>), g, b, 0, s, A);
+        return true;
+    } else if (kind == 3) { // Gpu4x32
+        if (stats)
+            hipLaunchKernelGGL((k_direct_4x32<true>), g, b, 0, s, A);
+        else
+            hipLaunchKernelGGL((k_direct_4x32<false>), g, b, 0, s, A);
+        return true;
+    } else { // Gpu4x64
+        if (stats)
+            hipLaunchKernelGGL((k_direct_4x64<true>), g, b, 0, s, A);
+        else
+            hipLaunchKernelGGL((k_direct_4x64<false>), g, b, 0, s, A);
         return true;
     }
 #undef FS_LP_IP

@@ -1178,7 +1178,9 @@ uint32_t fs_render_direct_lp(fs_renderer *r, int type_tag, const void *coords, u
         return e;
     if (!r->memory_initialized())
         return 0; // GPU_Render.cu:626-628
-    if ((type_tag != FS_T_F32 && type_tag != FS_T_2X32 && type_tag != FS_T_2X64) || n_iterations > 0xFFFFFFFFull)
+    if ((type_tag != FS_T_F32 && type_tag != FS_T_2X32 && type_tag != FS_T_2X64 && type_tag != FS_T_4X32 &&
+         type_tag != FS_T_4X64) ||
+        n_iterations > 0xFFFFFFFFull)
         return FS_ERR_UNSUPPORTED;
     FsDirectLpArgs A;
     memset(&A, 0, sizeof(A));
@@ -1190,11 +1192,19 @@ uint32_t fs_render_direct_lp(fs_renderer *r, int type_tag, const void *coords, u
         memcpy(A.c32, coords, 4 * sizeof(float));
     else if (type_tag == FS_T_2X32)
         memcpy(A.c32, coords, 8 * sizeof(float));
+    else if (type_tag == FS_T_4X32)
+        memcpy(A.c32, coords, 16 * sizeof(float));
+    else if (type_tag == FS_T_4X64)
+        memcpy(A.c64, coords, 16 * sizeof(double));
     else
         memcpy(A.c64, coords, 8 * sizeof(double));
+    const int kind = type_tag == FS_T_F32    ? 0
+                     : type_tag == FS_T_2X32 ? 1
+                     : type_tag == FS_T_2X64 ? 2
+                     : type_tag == FS_T_4X32 ? 3
+                                             : 4;
     TimedLaunch t(r);
-    (void)fsk_direct_lp(A, type_tag == FS_T_F32 ? 0 : (type_tag == FS_T_2X32 ? 1 : 2), iteration_precision, r->stats_on,
-                        r->compute);
+    (void)fsk_direct_lp(A, kind, iteration_precision, r->stats_on, r->compute);
     return (uint32_t)hipGetLastError();
 }
 

@@ -259,13 +259,27 @@ extern "C" void fsh_view_coords_direct_lp(const fsh_view *v, uint32_t w_aa, uint
             const Mp rest = *src[i] - h;
             ((float *)out)[2 * i] = head;
             ((float *)out)[2 * i + 1] = (float)mpf_get_d(rest.v);
-        } else {
+        } else if (kind == 2) {
             const double head = mpf_get_d(src[i]->v);
             Mp h;
             mpf_set_d(h.v, head);
             const Mp rest = *src[i] - h;
             ((double *)out)[2 * i] = head;
             ((double *)out)[2 * i + 1] = mpf_get_d(rest.v);
+        } else {
+            // FillCoord(MattQFltflt / MattQDbldbl), Fractal.cpp:1751-1771: each component converts what is left after
+            // subtracting the previous ones (left to right, in the precision of the source)
+            Mp rest = *src[i];
+            for (int k = 0; k < 4; k++) {
+                const double part = kind == 3 ? (double)(float)mpf_get_d(rest.v) : mpf_get_d(rest.v);
+                if (kind == 3)
+                    ((float *)out)[4 * i + k] = (float)part;
+                else
+                    ((double *)out)[4 * i + k] = part;
+                Mp h;
+                mpf_set_d(h.v, part);
+                rest = rest - h;
+            }
         }
     }
 }

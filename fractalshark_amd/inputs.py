@@ -93,10 +93,11 @@ class View:
 
     def coords_direct_lp(self, kind, aa=None):
         """{cx = minX, cy = minY, dx, dy} for the Gpu1x32 ("1x32": float32[4]), Gpu2x32 ("2x32": float32[8] head/tail
-        pairs) and Gpu2x64 ("2x64": float64[8]) direct kernels."""
+        pairs), Gpu2x64 ("2x64": float64[8]), Gpu4x32 ("4x32": float32[16], x..w quadruples) and Gpu4x64 ("4x64":
+        float64[16]) direct kernels."""
         aa = self.antialiasing if aa is None else aa
-        k = {"1x32": 0, "2x32": 1, "2x64": 2}[kind]
-        out = np.zeros(4 if k == 0 else 8, np.float64 if k == 2 else np.float32)
+        k = {"1x32": 0, "2x32": 1, "2x64": 2, "4x32": 3, "4x64": 4}[kind]
+        out = np.zeros((4, 8, 8, 16, 16)[k], np.float64 if k in (2, 4) else np.float32)
         self._lib.fsh_view_coords_direct_lp(self._h, self.width * aa, self.height * aa, k, out.ctypes.data)
         return out
 

@@ -12,7 +12,7 @@ import numpy as np
 from . import _capi
 
 # numeric type tags (include/fsmi355.h)
-T_F32, T_F64, T_2X32, T_HDR32, T_HDR64, T_HDR2X32, T_2X64 = range(7)
+T_F32, T_F64, T_2X32, T_HDR32, T_HDR64, T_HDR2X32, T_2X64, T_4X32, T_4X64 = range(9)
 # LAv2Mode (RenderAlgorithm.h:12-17)
 LAV2_FULL, LAV2_PO, LAV2_LAO = range(3)
 # parity (include/fsmi355.h)
@@ -222,7 +222,8 @@ class GPURenderer:
         return self._lib.fs_render_direct(self._h, T, co.ctypes.data, int(n_iterations))
 
     def RenderLowPrecision(self, algorithm, coords, n_iterations, iteration_precision=1, T=T_F32):
-        """Gpu1x32 (T_F32), Gpu2x32 (T_2X32), Gpu2x64 (T_2X64): coords from inputs.View.coords_direct_lp."""
+        """Gpu1x32 (T_F32), Gpu2x32 (T_2X32), Gpu2x64 (T_2X64), Gpu4x32 (T_4X32), Gpu4x64 (T_4X64): coords from
+        inputs.View.coords_direct_lp."""
         co = np.ascontiguousarray(coords)
         return self._lib.fs_render_direct_lp(self._h, T, co.ctypes.data, int(n_iterations), int(iteration_precision))
 

@@ -37,8 +37,9 @@ int fsh_view_bbox_str(const fsh_view *v, int which, char *buf, size_t buflen);
 void fsh_view_coords_direct_hdr32(const fsh_view *v, uint32_t w_aa, uint32_t h_aa, fs_real_hdr32 out[4]);
 void fsh_view_coords_direct_hdr64(const fsh_view *v, uint32_t w_aa, uint32_t h_aa, fs_real_hdr64 out[4]);
 
-/* Gpu1x32 / Gpu2x32 / Gpu2x64 direct kernels: {cx = minX, cy = minY, dx, dy} (Fractal::FillGpuCoords).
- * kind 0: float[4]; kind 1: float[8] = (head, tail) pairs (MattDblflt); kind 2: double[8] (MattDbldbl). */
+/* Gpu1x32 / Gpu2x32 / Gpu2x64 / Gpu4x32 / Gpu4x64 direct kernels: {cx = minX, cy = minY, dx, dy} (Fractal::FillGpuCoords).
+ * kind 0: float[4]; kind 1: float[8] = (head, tail) pairs (MattDblflt); kind 2: double[8] (MattDbldbl); kind 3: float[16]
+ * = (x, y, z, w) quadruples, most significant first (MattQFltflt); kind 4: double[16] (MattQDbldbl). */
 void fsh_view_coords_direct_lp(const fsh_view *v, uint32_t w_aa, uint32_t h_aa, int kind, void *out);
 
 /* out = {dx, dy, minX, maxY} as doubles (Cpu64 / direct kernels). */

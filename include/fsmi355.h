@@ -49,7 +49,9 @@ enum {
     FS_T_HDR32 = 3,     /* HDRFloat<float>            (GpuHDRx32*) */
     FS_T_HDR64 = 4,     /* HDRFloat<double>           (GpuHDRx64*) */
     FS_T_HDR2X32 = 5,   /* HDRFloat<CudaDblflt<..>>   (GpuHDRx2x32*) */
-    FS_T_2X64 = 6       /* MattDbldbl (double-double) (Gpu2x64)      */
+    FS_T_2X64 = 6,      /* MattDbldbl (double-double) (Gpu2x64)      */
+    FS_T_4X32 = 7,      /* MattQFltflt (quad-float)   (Gpu4x32)      */
+    FS_T_4X64 = 8       /* MattQDbldbl (quad-double)  (Gpu4x64)      */
 };
 
 /* LAv2Mode, FractalSharkLib/RenderAlgorithm.h:12-17. */
@@ -169,9 +171,11 @@ uint32_t fs_render_scaled(fs_renderer *r, int type_tag, const void *coords, uint
 /* GPURenderer::Render<IterType,T> for the direct kernels that have no CPU RenderAlgorithm twin (LowPrecisionKernels.cuh):
  * FS_T_F32 -> mandel_1x_float (Gpu1x32), coords = float{cx, cy, dx, dy};  FS_T_2X32 -> mandel_2x_float (Gpu2x32),
  * coords = float{cx.head, cx.tail, cy.head, cy.tail, dx.head, dx.tail, dy.head, dy.tail} (MattDblflt);  FS_T_2X64 ->
- * mandel_2x_double (Gpu2x64), the same eight values as doubles (MattDbldbl).  cx / cy = the view's MIN corner
+ * mandel_2x_double (Gpu2x64), the same eight values as doubles (MattDbldbl);  FS_T_4X32 -> mandel_4x_float (Gpu4x32),
+ * coords = float{cx.x..w, cy.x..w, dx.x..w, dy.x..w} (MattQFltflt, most significant first);  FS_T_4X64 -> mandel_4x_double
+ * (Gpu4x64), the same sixteen values as doubles (MattQDbldbl).  cx / cy = the view's MIN corner
  * (Fractal::FillGpuCoords, Fractal.cpp:1833-1844); rows are written flipped like the reference.  iteration_precision in
- * {1, 4, 8, 16} (ignored by Gpu2x64); other values launch nothing and return 0, like the reference's switch.  The kernels
+ * {1, 4, 8, 16} (ignored by Gpu2x64 / Gpu4x32 / Gpu4x64); other values launch nothing and return 0, like the reference's switch.  The kernels
  * restate the CUDA kernels (no CPU twin exists; un-contracted IEEE arithmetic, __fmaf_rd = fma rounded toward -inf). */
 uint32_t fs_render_direct_lp(fs_renderer *r, int type_tag, const void *coords, uint64_t n_iterations,
                              int iteration_precision);

@@ -65,8 +65,9 @@ def lib():
         for name in ("orc_gpu_direct_1x32", "orc_gpu_direct_2x32"):
             getattr(l, name).restype = None
             getattr(l, name).argtypes = [vp, u32, u32, u32, u32, u32, vp, u32, C.c_int]
-        l.orc_gpu_direct_2x64.restype = None
-        l.orc_gpu_direct_2x64.argtypes = [vp, u32, u32, u32, u32, u32, vp, u32]
+        for name in ("orc_gpu_direct_2x64", "orc_gpu_direct_4x32", "orc_gpu_direct_4x64"):
+            getattr(l, name).restype = None
+            getattr(l, name).argtypes = [vp, u32, u32, u32, u32, u32, vp, u32]
         l.orc_gpu_scaled_hdr32.restype = None
         l.orc_gpu_scaled_hdr32.argtypes = [vp, u32, u32, u32, u32, vp, vp, u32, vp, u32, C.c_float, C.c_int, vp]
         l.orc_gpu_scaled_f64.restype = None
@@ -242,14 +243,16 @@ def gpu_scaled_f64(view, orbit, aa=1, rows=None, threads=8, n_iterations=None, s
 
 
 def gpu_direct_lp(view, kind, iteration_precision=1, aa=1, rows=None, n_iterations=None):
-    """Restated CUDA direct kernels without a CPU twin (oracle/gpu_ref_lp.cpp).  kind: "1x32" | "2x32" | "2x64"."""
+    """Restated CUDA direct kernels without a CPU twin (oracle/gpu_ref_lp.cpp).  kind: "1x32" | "2x32" | "2x64", and
+    "4x32" | "4x64" (oracle/gpu_ref_qd.cpp)."""
     w, h = view.width * aa, view.height * aa
     out = new_buffer(w, h)
     co = view.coords_direct_lp(kind, aa)
     y0, y1 = rows if rows else (0, h)
     n = view.num_iterations if n_iterations is None else n_iterations
-    if kind == "2x64":
-        lib().orc_gpu_direct_2x64(out.ctypes.data, out.shape[1], w, h, y0, y1, co.ctypes.data, n)
+    if kind in ("2x64", "4x32", "4x64"):
+        fn = {"2x64": lib().orc_gpu_direct_2x64, "4x32": lib().orc_gpu_direct_4x32, "4x64": lib().orc_gpu_direct_4x64}[kind]
+        fn(out.ctypes.data, out.shape[1], w, h, y0, y1, co.ctypes.data, n)
     else:
         fn = lib().orc_gpu_direct_1x32 if kind == "1x32" else lib().orc_gpu_direct_2x32
         fn(out.ctypes.data, out.shape[1], w, h, y0, y1, co.ctypes.data, n, iteration_precision)

@@ -50,6 +50,12 @@ struct MattDbldbl {
 struct MattDblflt {
     float head, tail;
 };
+struct MattQFltflt {
+    float x, y, z, w;
+};
+struct MattQDbldbl {
+    double x, y, z, w;
+};
 template <class T = MattDblflt> class CudaDblflt {
 public:
     T d;
@@ -223,6 +229,10 @@ template uint32_t GPURenderer::RenderPerturbBLAScaled<uint32_t, HDR32>(
 template uint32_t GPURenderer::Render<uint32_t, float>(RenderAlgorithm, float, float, float, float, uint32_t, int);
 template uint32_t GPURenderer::Render<uint32_t, MattDblflt>(RenderAlgorithm, MattDblflt, MattDblflt, MattDblflt, MattDblflt,
                                                             uint32_t, int);
+template uint32_t GPURenderer::Render<uint32_t, MattQFltflt>(RenderAlgorithm, MattQFltflt, MattQFltflt, MattQFltflt,
+                                                             MattQFltflt, uint32_t, int);
+template uint32_t GPURenderer::Render<uint32_t, MattQDbldbl>(RenderAlgorithm, MattQDbldbl, MattQDbldbl, MattQDbldbl,
+                                                             MattQDbldbl, uint32_t, int);
 template uint32_t GPURenderer::Render<uint32_t, MattDbldbl>(RenderAlgorithm, MattDbldbl, MattDbldbl, MattDbldbl, MattDbldbl,
                                                             uint32_t, int);
 template uint32_t GPURenderer::RenderPerturbBLAScaled<uint32_t, double>(

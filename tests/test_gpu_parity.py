@@ -547,14 +547,15 @@ def test_four_renderers_concurrently_and_progressive_readback(native_libs, v5_sm
 
 
 # ---- Gpu1x32 / Gpu2x32 / Gpu2x64 direct kernels (no CPU twin; checker = restated CUDA kernels, oracle/gpu_ref_lp.cpp)
-@pytest.mark.parametrize("kind,ip", [("1x32", 1), ("1x32", 4), ("1x32", 16), ("2x32", 1), ("2x32", 8), ("2x64", 1)])
+@pytest.mark.parametrize("kind,ip", [("1x32", 1), ("1x32", 4), ("1x32", 16), ("2x32", 1), ("2x32", 8), ("2x64", 1),
+                                     ("4x32", 1), ("4x64", 1)])
 def test_low_precision_direct_kernels(renderer, native_libs, kind, ip):
-    from fractalshark_amd import T_2X32, T_2X64, T_F32
+    from fractalshark_amd import T_2X32, T_2X64, T_4X32, T_4X64, T_F32
     v = inputs.View.builtin(0, 70, 37)  # ragged size: padding columns / rows stay zero
     r = renderer
     assert r.InitializeMemory(70, 37, 1, None, 0, 0, 0, False) == 0
     assert r.ClearMemory() == 0
-    T = {"1x32": T_F32, "2x32": T_2X32, "2x64": T_2X64}[kind]
+    T = {"1x32": T_F32, "2x32": T_2X32, "2x64": T_2X64, "4x32": T_4X32, "4x64": T_4X64}[kind]
     assert r.RenderLowPrecision(None, v.coords_direct_lp(kind), v.num_iterations, ip, T=T) == 0
     out = r.new_iter_buffer()
     assert r.RenderCurrent(v.num_iterations, out) == 0
@@ -566,8 +567,8 @@ def test_low_precision_direct_kernels(renderer, native_libs, kind, ip):
     cpu = _oracle.direct_f64(v)[:37, :70].astype(np.int64)
     a = out[:36, :70].astype(np.int64)
     d = a - np.minimum(cpu[1:37] + 1, v.num_iterations)
-    assert ((d >= 0) & (d < ip + 1)).mean() > 0.97
-    if kind != "2x64":  # iteration_precision values the reference does not instantiate launch nothing
+    assert ((d >= 0) & (d < ip + 1)).mean() > 0.97, np.unique(d, return_counts=True)
+    if kind in ("1x32", "2x32"):  # iteration_precision values the reference does not instantiate launch nothing
         assert r.ClearMemory() == 0
         assert r.RenderLowPrecision(None, v.coords_direct_lp(kind), v.num_iterations, 3, T=T) == 0
         z = r.new_iter_buffer()
@@ -671,3 +672,23 @@ def test_plain_lav2_odd_sizes_bands_and_antialiasing(renderer, native_libs):
         out, _ = _render_plain(renderer, v, pin, LAV2_FULL)
         ref = _oracle.gpu_lav2_plain(v, pin, aa=2, mode=0)
         assert np.array_equal(out, ref), kind
+
+
+def test_quad_direct_kernels_on_a_deep_view(renderer, native_libs):
+    """Gpu4x32 / Gpu4x64 where the extra words matter: a 1e-20-wide view (beyond binary64, inside quad-float's ~29 digits)."""
+    from fractalshark_amd import T_4X32, T_4X64
+    from test_plain_oracle import shallow_view
+    v = shallow_view("1e-20", n_iter=12000, W=32, H=16)
+    r = renderer
+    assert r.InitializeMemory(32, 16, 1, None, 0, 0, 0, False) == 0
+    outs = {}
+    for kind, T in (("4x32", T_4X32), ("4x64", T_4X64)):
+        assert r.ClearMemory() == 0
+        assert r.RenderLowPrecision(None, v.coords_direct_lp(kind), v.num_iterations, 1, T=T) == 0
+        out = r.new_iter_buffer()
+        assert r.RenderCurrent(v.num_iterations, out) == 0
+        assert r.SyncComputeStream() == 0
+        assert np.array_equal(out, _oracle.gpu_direct_lp(v, kind, 1)), kind
+        outs[kind] = out[:16, :32].astype(np.int64)
+    assert len(np.unique(outs["4x64"])) > 20  # a real picture, not a constant
+    assert (np.abs(outs["4x32"] - outs["4x64"]) <= 2).mean() > 0.9
