@@ -13,7 +13,7 @@
 enum { FS_MODE_FULL = 0, FS_MODE_PO = 1, FS_MODE_LAO = 2 };
 enum { FS_PARITY_LITERAL = 0, FS_PARITY_GPUSTAGE = 1 };
 // kernel variant: 0 = tuned loop (default), 1 = literal operation-by-operation transcription (A/B reference)
-enum { FS_VARIANT_TUNED = 0, FS_VARIANT_LITERAL = 1 };
+enum { FS_VARIANT_TUNED = 0, FS_VARIANT_LITERAL = 1, FS_VARIANT_TUNED_NOSCALE = 2 };
 
 // Frame geometry + the row-band layout of the local iteration buffer.
 struct FsFrame {
@@ -64,6 +64,7 @@ template <class F> struct FsLav2ArgsT {
     uint32_t *out;
     const typename FsDev<F>::Z *zref; // prepared orbit
     const float4 *zq;                 // tuned HDRFloat<float> loop only: {re, im, ~exp | poison, -} (k_make_quiet_orbit)
+    const float4 *zs;                 // ... and its scaled runs: {2Z.re, 2Z.im, 2^-5 max|Z| | -1, -} in true scale
     const typename FsDev<F>::LA *las;
     const fs_la_stage_u32 *stages;
     uint64_t *stats;

@@ -70,7 +70,7 @@ __global__ void k_prepare_orbit_hdr32(const fs_orbit_hdr32 *__restrict__ in, flo
 
 // Companion array of the tuned LAv2 loop: {re, im, s, -} with s = ~exp + 116 (-(s - 116) = exp + 1 = the exponent of 2Z;
 // the bias turns the loop's range tests into comparisons against constants) for orbit values below 8, and a large
-// positive poison for larger ones, which makes the range test fail there.
+// positive poison for larger ones, which makes the range test fail there.  zq must hold 2 n entries.
 __global__ void k_make_quiet_orbit(const float4 *__restrict__ zref, float4 *__restrict__ zq, uint64_t n)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -79,6 +79,16 @@ __global__ void k_make_quiet_orbit(const float4 *__restrict__ zref, float4 *__re
     const float4 v = zref[i];
     const int e = __float_as_int(v.z);
     zq[i] = make_float4(v.x, v.y, __int_as_float(e <= 2 ? ~e + 116 : (1 << 24)), 0.0f);
+    // second companion, zq[n + i], for the scaled runs: {2Z.re, 2Z.im, 2^-3 * max(|Z.re|, |Z.im|)} as plain floats (true
+    // scale), the bound negative (= "never quiet") unless 2^-40 <= max part < 5.6 (|Z| < 8) and the smaller part is within
+    // 2^40 of the larger one.  (Packing the entry into 8 bytes and deriving the bound from 2Z costs one more vector
+    // instruction per step and was measured slower: the loop is not bound by its loads.)
+    const float hi = __builtin_fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y));
+    const float lo = __builtin_fminf(__builtin_fabsf(v.x), __builtin_fabsf(v.y));
+    const float zmax = __builtin_amdgcn_ldexpf(hi, e < -200 ? -200 : (e > 100 ? 100 : e));
+    const bool usable = zmax >= 0x1p-40f && zmax < 5.6f && lo >= hi * 0x1p-40f;
+    zq[n + i] = make_float4(__builtin_amdgcn_ldexpf(v.x, e + 1), __builtin_amdgcn_ldexpf(v.y, e + 1),
+                            usable ? zmax * 0x1p-3f : -1.0f, 0.0f);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -348,13 +358,13 @@ __device__ __forceinline__ long long norm_key_nz(float m, int e)
 
 } // namespace
 
-template <int Mode, bool kStats>
+template <int Mode, bool kStats, bool kScaled>
 __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
 {
     uint32_t X, L;
     tile_pixel(X, L);
     uint64_t c_at = 0, c_la = 0, c_pt = 0, c_px = 0;
-    uint64_t c_careful = 0;
+    uint64_t c_careful = 0, c_scaled = 0, c_runs = 0;
     const uint32_t Y = global_row(A.frame, L);
     const bool live = X < A.frame.width && L < A.frame.local_rows && Y < A.frame.height;
     if (live) {
@@ -477,7 +487,119 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
             // Quiet-run state: sC = ~(exponent of Zc) + 116 for an orbit value below 8, a large positive poison otherwise
             // (zq[i].z, written by k_make_quiet_orbit).
             const float4 *__restrict__ zq = A.zq;
+            const float4 *__restrict__ zs = A.zs;
             while (running) {
+                // ---- run of "scaled" quiet steps.  HDRFloat addition and multiplication are the correctly rounded binary32
+                // operations on the represented values (an exponent gap >= 120 drops an addend that is far below half an
+                // ulp of the other; Reduce only re-labels a value), so as long as nothing leaves binary32's normal range the
+                // reference's step  dz' = dz (2Z + dz) + dc  can be carried out on plain floats under one fixed power-of-two
+                // scale per lane:  w = dz 2^-E,  s = fma(w, 2^E, 2Z),  q = w s + dc 2^-E  -- the same IEEE operations on the
+                // same (scaled) operands, hence the same bits.  A step is accepted when (all lanes of the wave)
+                //   max|q| 2^E <= 2^-3 max|Z'|   |dz'| <= 0.18 |Z'|: neither exit test of the CPU loop can fire (|z| > 4.6 |dz'|,
+                //                                |z|^2 < 87 with |Z'| < 8), and Z' passed the companion's range test;
+                //   min|q| >= 2^-40 max|q|       no part of a product that matters is lost below 2^-126 in either
+                //                                representation (a dropped term is >= 2^40 below what it is added to);
+                //   2^-20 <= max|q| <= 2^40      the scale still fits.  Tested on every second step: a value cannot come back
+                //                                from below in one step (it grows by at most |2Z + dz| < 2^5), and the whole
+                //                                two-step trip is dropped when its second step fails.
+                // Anything else leaves the state of the last accepted step to the exponent-tracking loop below.
+                bool sc_stopped = false; // a scaled run ended on a step it could not take: that step goes to the careful path
+                if (kScaled) {
+                    typedef float f3 __attribute__((ext_vector_type(3)));
+                    for (;;) {
+                        const float4 e0 = zs[ref];
+                        const int E = dze;
+                        const float sE = __builtin_amdgcn_ldexpf(1.0f, E); // 0 / denormal below 2^-126: dz then cannot matter
+                        const int dsh = dce - E;
+                        const f2 dcs = {__builtin_amdgcn_ldexpf(dcm.x, dsh), __builtin_amdgcn_ldexpf(dcm.y, dsh)};
+                        const float mx0 = __builtin_fmaxf(__builtin_fabsf(dzm.x), __builtin_fabsf(dzm.y));
+                        const float mn0 = __builtin_fminf(__builtin_fabsf(dzm.x), __builtin_fabsf(dzm.y));
+                        const uint32_t left_ref = ref + 1 < MaxRefIteration ? MaxRefIteration - 1 - ref : 0u;
+                        const uint32_t left_it = n_iterations - 1 - iterations;
+                        const uint32_t left = left_ref < left_it ? left_ref : left_it;
+                        const bool start_ok = mx0 * sE <= e0.z && mn0 >= mx0 * 0x1p-40f && mx0 >= 1.0f && mx0 < 2.0f &&
+                                              dsh <= 30 && left >= 64u;
+                        if (__builtin_amdgcn_ballot_w64(!start_ok) != 0ull)
+                            break;
+                        const f2 sE2 = {sE, sE};
+                        const uint32_t lane_off = (ref + 1) * 16u;
+                        // One step from (W_, Z_) into (NW_, NZ_); OFS = byte offset of the arrival entry from the body's
+                        // base pointer (an immediate of the load).  The wait is tied to the step's results so that it stays
+                        // behind the arithmetic.  V accumulates the lanes that fail a test.
+#define FS_SCALED_STEP(W_, Z_, NW_, NZ_, OFS, T, V, DRIFT)                                                               \
+    f3 ent_##T;                                                                                                     \
+    asm volatile("global_load_dwordx3 %0, %2, %3 offset:" OFS : "=v"(ent_##T), "+v"(W_) : "v"(lane_off), "s"(zp)); \
+    const f2 s_##T = __builtin_elementwise_fma(W_, sE2, Z_);                                                        \
+    const f2 pa_##T = W_.xx * s_##T;                                                                                \
+    const f2 pb_##T = W_.yy * s_##T.yx;                                                                             \
+    f2 p_##T;                                                                                                       \
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(p_##T) : "v"(pa_##T), "v"(pb_##T));              \
+    NW_ = p_##T + dcs;                                                                                              \
+    float mx_##T = __builtin_fmaxf(__builtin_fabsf(NW_.x), __builtin_fabsf(NW_.y));                                 \
+    float mn_##T = __builtin_fminf(__builtin_fabsf(NW_.x), __builtin_fabsf(NW_.y));                                 \
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ent_##T), "+v"(mx_##T), "+v"(mn_##T));                                 \
+    NZ_ = (f2){ent_##T.x, ent_##T.y};                                                                               \
+    V |= __builtin_amdgcn_ballot_w64(!(mx_##T * sE <= ent_##T.z)) |                                                 \
+         __builtin_amdgcn_ballot_w64(!(mn_##T >= mx_##T * 0x1p-40f));                                               \
+    if (DRIFT)                                                                                                      \
+    V |= __builtin_amdgcn_ballot_w64((uint32_t)(__float_as_int(mx_##T) - (107 << 23)) >= (uint32_t)(60 << 23))
+                        // Two steps are tested together and the state ping-pongs between two register sets over two such
+                        // trips, so neither the back-edge nor the roll-back of a failed trip needs a register copy: a
+                        // trip that contains a failing step is dropped as a whole and its first step goes to the
+                        // careful path.  (The scalar unit is shared by the four SIMDs of a CU, so the tests' ORs and the
+                        // loop control are kept as few as the vector instructions allow.)
+                        const float4 *zp = zs; // wave-uniform; the per-lane part of the address is lane_off
+                        f2 w0 = dzm, z0 = {e0.x, e0.y}, w2, z2, wO, zO;
+                        uint32_t c = 0;
+                        bool failed;
+                        for (;;) {
+                            f2 t1, u1;
+                            uint64_t v1 = 0;
+                            FS_SCALED_STEP(w0, z0, t1, u1, "0", a, v1, false);
+                            FS_SCALED_STEP(t1, u1, w2, z2, "16", b, v1, true);
+                            if (v1 != 0ull) {
+                                wO = w0, zO = z0, failed = true;
+                                break;
+                            }
+                            c += 2;
+                            f2 t3, u3;
+                            uint64_t v2 = 0;
+                            FS_SCALED_STEP(w2, z2, t3, u3, "32", c_, v2, false);
+                            FS_SCALED_STEP(t3, u3, w0, z0, "48", d, v2, true);
+                            if (v2 != 0ull) {
+                                wO = w2, zO = z2, failed = true;
+                                break;
+                            }
+                            c += 2;
+                            zp += 4;
+                            if (c >= 64u) {
+                                wO = w0, zO = z0, failed = false;
+                                break;
+                            }
+                        }
+#undef FS_SCALED_STEP
+                        // back to the reduced form: the larger part's exponent moves into dze (exact)
+                        if (c != 0u) {
+                            const float mxw = __builtin_fmaxf(__builtin_fabsf(wO.x), __builtin_fabsf(wO.y));
+                            const int k = (int)((uint32_t)__float_as_int(mxw) >> 23) - 127;
+                            dzm = (f2){__builtin_amdgcn_ldexpf(wO.x, -k), __builtin_amdgcn_ldexpf(wO.y, -k)};
+                            dze = E + k;
+                            ref += c;
+                            iterations += c;
+                            if (kStats) {
+                                c_pt += c;
+                                c_scaled += c;
+                                c_runs++;
+                            }
+                            const float4 zc = zq[ref];
+                            Zcm = (f2){zc.x, zc.y};
+                        }
+                        if (failed) {
+                            sc_stopped = true;
+                            break;
+                        }
+                    }
+                }
                 // ---- run of "quiet" steps: when dz is at least 2^4 below the orbit value and the orbit value is < 8,
                 // neither exit test can fire and z itself is not needed:
                 //   |Z'| in [0.5, 2.83) 2^Zne (larger part of an orbit entry is in [0.5, 2)),  |dz| < 2.83 * 2^qe
@@ -531,6 +653,7 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
     const uint64_t VIOL = __builtin_amdgcn_ballot_w64(imax(NW, nd2_##VIOL) > 111) |                                 \
                           __builtin_amdgcn_ballot_w64(imin(NW, fmax_##VIOL) < 1);                                   \
     NDZM = q_##VIOL * __int_as_float(mad24_scale(fmax_##VIOL)) /* 2^(127 - fmax) */
+                if (!sc_stopped)
                 {
                     typedef float f3 __attribute__((ext_vector_type(3)));
                     int sC = __float_as_int(zq[ref].z);
@@ -665,10 +788,16 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
     if (kStats) {
         add_stats(A.stats, c_at, c_la, c_pt, c_px);
         // stats[5]: lane-steps taken through the careful path (the rest of [2] ran in quiet runs)
-        for (int off = 32; off > 0; off >>= 1)
+        for (int off = 32; off > 0; off >>= 1) {
             c_careful += __shfl_down(c_careful, off);
-        if ((threadIdx.x & 63) == 0)
+            c_scaled += __shfl_down(c_scaled, off);
+            c_runs += __shfl_down(c_runs, off);
+        }
+        if ((threadIdx.x & 63) == 0) {
             atomicAdd((unsigned long long *)&A.stats[5], (unsigned long long)c_careful);
+            atomicAdd((unsigned long long *)&A.stats[6], (unsigned long long)c_scaled);
+            atomicAdd((unsigned long long *)&A.stats[7], (unsigned long long)c_runs);
+        }
     }
 }
 
@@ -1428,10 +1557,15 @@ void fsk_lav2_hdr32(const FsLav2Args32 &A, int mode, bool stats, int variant, hi
             else                                                                                                    \
                 hipLaunchKernelGGL((k_lav2_lit<float, M, false>), g, b, 0, s, A);                                        \
         } else {                                                                                                    \
-            if (stats)                                                                                              \
-                hipLaunchKernelGGL((k_lav2_hdr32_fast<M, true>), g, b, 0, s, A);                                    \
+            if (variant == FS_VARIANT_TUNED_NOSCALE) {                                                              \
+                if (stats)                                                                                          \
+                    hipLaunchKernelGGL((k_lav2_hdr32_fast<M, true, false>), g, b, 0, s, A);                         \
+                else                                                                                                \
+                    hipLaunchKernelGGL((k_lav2_hdr32_fast<M, false, false>), g, b, 0, s, A);                        \
+            } else if (stats)                                                                                       \
+                hipLaunchKernelGGL((k_lav2_hdr32_fast<M, true, true>), g, b, 0, s, A);                              \
             else                                                                                                    \
-                hipLaunchKernelGGL((k_lav2_hdr32_fast<M, false>), g, b, 0, s, A);                                   \
+                hipLaunchKernelGGL((k_lav2_hdr32_fast<M, false, true>), g, b, 0, s, A);                             \
         }                                                                                                           \
     } while (0)
     if (mode == FS_MODE_FULL)

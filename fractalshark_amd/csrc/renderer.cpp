@@ -64,7 +64,8 @@ struct fs_renderer {
     fs_orbit_f32_bad *scaled_f = nullptr;
     uint64_t scaled_count = 0;
     float4 *zref = nullptr;
-    float4 *zq = nullptr; // companion of zref for the tuned LAv2 loop
+    float4 *zq = nullptr; // companions of zref for the tuned LAv2 loop (2 x zq_n entries)
+    uint64_t zq_n = 0;
     FsZ64 *zref64 = nullptr;
     fs_orbit_f64 *orbit_f64 = nullptr; // plain double orbit (FS_T_F64), used as uploaded
     void *orbit_plain = nullptr;       // plain float / CudaDblflt orbit (FS_T_F32 / FS_T_2X32), used as uploaded
@@ -144,9 +145,10 @@ hipError_t make_quiet_orbit(fs_renderer *r, uint64_t n)
         (void)hipFree(r->zq);
         r->zq = nullptr;
     }
-    hipError_t err = hipMalloc((void **)&r->zq, (n + 2) * sizeof(float4));
+    hipError_t err = hipMalloc((void **)&r->zq, 2 * (n + 2) * sizeof(float4)); // two companions back to back
     if (err != hipSuccess)
         return err;
+    r->zq_n = n + 2;
     fsk_make_quiet_orbit(r->zref, r->zq, n + 2, r->compute);
     return hipGetLastError();
 }
@@ -962,6 +964,7 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
         fill_lav2<float>(r, A, coords, n_iterations, parity);
         A.zref = r->zref;
         A.zq = r->zq;
+        A.zs = r->zq + r->zq_n;
         A.at = r->at;
         TimedLaunch t(r);
         fsk_lav2_hdr32(A, kmode, r->stats_on, r->variant, r->compute);
@@ -1322,7 +1325,7 @@ float fs_last_kernel_ms(const fs_renderer *r)
 
 uint32_t fs_set_kernel_variant(fs_renderer *r, int variant)
 {
-    r->variant = variant ? FS_VARIANT_LITERAL : FS_VARIANT_TUNED;
+    r->variant = variant == 1 ? FS_VARIANT_LITERAL : (variant == 2 ? FS_VARIANT_TUNED_NOSCALE : FS_VARIANT_TUNED);
     return 0;
 }
 
@@ -1332,13 +1335,13 @@ uint32_t fs_enable_step_count(fs_renderer *r, int enable)
     return 0;
 }
 
-uint32_t fs_read_step_count(fs_renderer *r, uint64_t counts[6])
+uint32_t fs_read_step_count(fs_renderer *r, uint64_t counts[8])
 {
     if (uint32_t e = use_device(r))
         return e;
     if (!r->stats)
         return FS_ERR_6;
-    FS_TRY(hipMemcpy(counts, r->stats, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    FS_TRY(hipMemcpy(counts, r->stats, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return 0;
 }
 

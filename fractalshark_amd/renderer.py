@@ -256,19 +256,20 @@ class GPURenderer:
         return float(self._lib.fs_last_kernel_ms(self._h))
 
     def set_kernel_variant(self, literal=False):
-        """False (default): tuned loops; True: literal transcription (A/B reference, identical results)."""
-        return self._lib.fs_set_kernel_variant(self._h, 1 if literal else 0)
+        """False / 0 (default): tuned loops; True / 1: literal transcription; 2: tuned loops without the scaled runs
+        (A/B references, identical results)."""
+        return self._lib.fs_set_kernel_variant(self._h, int(literal))
 
     def enable_step_count(self, on=True):
         return self._lib.fs_enable_step_count(self._h, 1 if on else 0)
 
     def read_step_count(self):
-        out = (C.c_uint64 * 6)()
+        out = (C.c_uint64 * 8)()
         err = self._lib.fs_read_step_count(self._h, out)
         if err:
             raise RuntimeError(self.ConvertErrorToString(err))
         return {"at_iterations": out[0], "la_steps": out[1], "perturb_steps": out[2], "pixels": out[3],
-                "lane_slots": out[4], "careful_steps": out[5]}
+                "lane_slots": out[4], "careful_steps": out[5], "scaled_steps": out[6], "scaled_runs": out[7]}
 
     def new_iter_buffer(self):
         dt = np.uint64 if getattr(self, "_iter_bytes", 4) == 8 else np.uint32

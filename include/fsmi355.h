@@ -205,13 +205,15 @@ uint32_t fs_get_height(const fs_renderer *r);
  * fs_enable_step_count: when on, iteration kernels also accumulate the executed work per launch:
  * counts[0] = AT iterations, [1] = LA steps, [2] = perturbation steps, [3] = pixels,
  * [4] = lane slots occupied in the perturbation loop (64 x longest lane, summed over waves),
- * [5] = perturbation steps that went through the careful (exit-tested) path of the tuned LAv2 loop. */
+ * [5] = perturbation steps that went through the careful (exit-tested) path of the tuned LAv2 loop, [6] = steps taken in
+ * its scaled runs, [7] = scaled runs started (both per lane). */
 float fs_last_kernel_ms(const fs_renderer *r);
-/* 0 (default) = tuned iteration loops; 1 = literal operation-by-operation transcription of the CPU function
- * (slower; kept as the in-library A/B reference for the tuned loops -- results are identical). */
+/* 0 (default) = tuned iteration loops; 1 = literal operation-by-operation transcription of the CPU function; 2 = tuned
+ * loops without the scaled runs of the HDRFloat<float> LAv2 kernel (slower; kept as in-library A/B references for the
+ * tuned loops -- results are identical). */
 uint32_t fs_set_kernel_variant(fs_renderer *r, int variant);
 uint32_t fs_enable_step_count(fs_renderer *r, int enable);
-uint32_t fs_read_step_count(fs_renderer *r, uint64_t counts[6]);
+uint32_t fs_read_step_count(fs_renderer *r, uint64_t counts[8]);
 
 #ifdef __cplusplus
 }
