@@ -80,15 +80,15 @@ __global__ void k_make_quiet_orbit(const float4 *__restrict__ zref, float4 *__re
     const int e = __float_as_int(v.z);
     zq[i] = make_float4(v.x, v.y, __int_as_float(e <= 2 ? ~e + 116 : (1 << 24)), 0.0f);
     // second companion, zq[n + i], for the scaled runs: {2Z.re, 2Z.im, 2^-3 * max(|Z.re|, |Z.im|)} as plain floats (true
-    // scale), the bound negative (= "never quiet") unless 2^-40 <= max part < 5.6 (|Z| < 8) and the smaller part is within
-    // 2^40 of the larger one.  (Packing the entry into 8 bytes and deriving the bound from 2Z costs one more vector
+    // scale), the bound -0.0 (bit pattern INT_MIN = "never quiet": the loop compares bit patterns as integers) unless
+    // 2^-40 <= max part < 5.6 (|Z| < 8) and the smaller part is within 2^40 of the larger one.  (Packing the entry into 8 bytes and deriving the bound from 2Z costs one more vector
     // instruction per step and was measured slower: the loop is not bound by its loads.)
     const float hi = __builtin_fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y));
     const float lo = __builtin_fminf(__builtin_fabsf(v.x), __builtin_fabsf(v.y));
     const float zmax = __builtin_amdgcn_ldexpf(hi, e < -200 ? -200 : (e > 100 ? 100 : e));
     const bool usable = zmax >= 0x1p-40f && zmax < 5.6f && lo >= hi * 0x1p-40f;
     zq[n + i] = make_float4(__builtin_amdgcn_ldexpf(v.x, e + 1), __builtin_amdgcn_ldexpf(v.y, e + 1),
-                            usable ? zmax * 0x1p-3f : -1.0f, 0.0f);
+                            usable ? zmax * 0x1p-3f : -0.0f, 0.0f);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -499,9 +499,12 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                 //                                |z|^2 < 87 with |Z'| < 8), and Z' passed the companion's range test;
                 //   min|q| >= 2^-40 max|q|       no part of a product that matters is lost below 2^-126 in either
                 //                                representation (a dropped term is >= 2^40 below what it is added to);
-                //   2^-20 <= max|q| <= 2^40      the scale still fits.  Tested on every second step: a value cannot come back
-                //                                from below in one step (it grows by at most |2Z + dz| < 2^5), and the whole
-                //                                two-step trip is dropped when its second step fails.
+                //   2^-20 <= max|q| <= 2^40      the scale still fits.
+                // The last two are tested on every second step, and a two-step trip is dropped as a whole when either of
+                // its steps fails: the first step of a trip starts from a state that passed them, so its own products are
+                // exact; a part of its result that is out of proportion (or a result that left the window -- it cannot come
+                // back from below in one step, the factor |2Z + dz| is < 2^5) either shows in the second step's result or
+                // sits >= 2^80 below everything that result is made of.
                 // Anything else leaves the state of the last accepted step to the exponent-tracking loop below.
                 bool sc_stopped = false; // a scaled run ended on a step it could not take: that step goes to the careful path
                 if (kScaled) {
@@ -517,18 +520,19 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                         const uint32_t left_ref = ref + 1 < MaxRefIteration ? MaxRefIteration - 1 - ref : 0u;
                         const uint32_t left_it = n_iterations - 1 - iterations;
                         const uint32_t left = left_ref < left_it ? left_ref : left_it;
-                        const bool start_ok = mx0 * sE <= e0.z && mn0 >= mx0 * 0x1p-40f && mx0 >= 1.0f && mx0 < 2.0f &&
-                                              dsh <= 30 && left >= 64u;
+                        // max|w| 2^E <= bound, on the bit patterns: for positive floats the exponent shift is an integer add,
+                        // a result below the normal range turns negative (dz far too small to matter: passes), NaN is huge
+                        // (E < 0 in every run: the start test needs max|dz| in [2^E, 2^(E+1)) below a bound < 0.7)
+                        const int Esh = (E < -254 ? -254 : (E > 0 ? 0 : E)) * (1 << 23);
+                        const bool start_ok = __float_as_int(mx0) + Esh <= __float_as_int(e0.z) && mn0 >= mx0 * 0x1p-40f &&
+                                              mx0 >= 1.0f && mx0 < 2.0f && dsh <= 30 && left >= 64u;
                         if (__builtin_amdgcn_ballot_w64(!start_ok) != 0ull)
                             break;
                         const f2 sE2 = {sE, sE};
-                        const uint32_t lane_off = (ref + 1) * 16u;
-                        // One step from (W_, Z_) into (NW_, NZ_); OFS = byte offset of the arrival entry from the body's
-                        // base pointer (an immediate of the load).  The wait is tied to the step's results so that it stays
-                        // behind the arithmetic.  V accumulates the lanes that fail a test.
-#define FS_SCALED_STEP(W_, Z_, NW_, NZ_, OFS, T, V, DRIFT)                                                               \
-    f3 ent_##T;                                                                                                     \
-    asm volatile("global_load_dwordx3 %0, %2, %3 offset:" OFS : "=v"(ent_##T), "+v"(W_) : "v"(lane_off), "s"(zp)); \
+                        // One step from (W_, Z_) into (NW_, NZ_); V accumulates the lanes that fail a test.
+                        // AFTER_ARITH is the statement that waits for the entry (tied to the step's results so that it stays
+                        // behind the arithmetic); EX / EY / EB name the arrival entry's 2Z and bound.
+#define FS_SCALED_STEP(W_, Z_, NW_, NZ_, T, V, FULL, AFTER_ARITH, EX, EY, EB)                                       \
     const f2 s_##T = __builtin_elementwise_fma(W_, sE2, Z_);                                                        \
     const f2 pa_##T = W_.xx * s_##T;                                                                                \
     const f2 pb_##T = W_.yy * s_##T.yx;                                                                             \
@@ -536,46 +540,110 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
     asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(p_##T) : "v"(pa_##T), "v"(pb_##T));              \
     NW_ = p_##T + dcs;                                                                                              \
     float mx_##T = __builtin_fmaxf(__builtin_fabsf(NW_.x), __builtin_fabsf(NW_.y));                                 \
-    float mn_##T = __builtin_fminf(__builtin_fabsf(NW_.x), __builtin_fabsf(NW_.y));                                 \
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ent_##T), "+v"(mx_##T), "+v"(mn_##T));                                 \
-    NZ_ = (f2){ent_##T.x, ent_##T.y};                                                                               \
-    V |= __builtin_amdgcn_ballot_w64(!(mx_##T * sE <= ent_##T.z)) |                                                 \
-         __builtin_amdgcn_ballot_w64(!(mn_##T >= mx_##T * 0x1p-40f));                                               \
-    if (DRIFT)                                                                                                      \
-    V |= __builtin_amdgcn_ballot_w64((uint32_t)(__float_as_int(mx_##T) - (107 << 23)) >= (uint32_t)(60 << 23))
+    AFTER_ARITH;                                                                                                    \
+    NZ_ = (f2){EX, EY};                                                                                             \
+    V |= __builtin_amdgcn_ballot_w64(__float_as_int(mx_##T) + Esh > __float_as_int(EB));                            \
+    if (FULL) {                                                                                                     \
+        const float mn_##T = __builtin_fminf(__builtin_fabsf(NW_.x), __builtin_fabsf(NW_.y));                       \
+        V |= __builtin_amdgcn_ballot_w64(!(mn_##T >= mx_##T * 0x1p-40f)) |                                          \
+             __builtin_amdgcn_ballot_w64((uint32_t)(__float_as_int(mx_##T) - (107 << 23)) >= (uint32_t)(60 << 23)); \
+    }
                         // Two steps are tested together and the state ping-pongs between two register sets over two such
                         // trips, so neither the back-edge nor the roll-back of a failed trip needs a register copy: a
                         // trip that contains a failing step is dropped as a whole and its first step goes to the
-                        // careful path.  (The scalar unit is shared by the four SIMDs of a CU, so the tests' ORs and the
-                        // loop control are kept as few as the vector instructions allow.)
-                        const float4 *zp = zs; // wave-uniform; the per-lane part of the address is lane_off
+                        // careful path.
                         f2 w0 = dzm, z0 = {e0.x, e0.y}, w2, z2, wO, zO;
                         uint32_t c = 0;
                         bool failed;
-                        for (;;) {
-                            f2 t1, u1;
-                            uint64_t v1 = 0;
-                            FS_SCALED_STEP(w0, z0, t1, u1, "0", a, v1, false);
-                            FS_SCALED_STEP(t1, u1, w2, z2, "16", b, v1, true);
-                            if (v1 != 0ull) {
-                                wO = w0, zO = z0, failed = true;
-                                break;
+                        const uint32_t ref_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)ref);
+                        if (__builtin_amdgcn_ballot_w64(ref != ref_u) == 0ull) {
+                            // Every lane of the wave reads the same orbit entries (the usual case: neighbouring pixels
+                            // rebase on the same step): the entries come through the scalar cache into scalar registers,
+                            // four per body, and the vector memory path -- whose 12-byte returns cost the SIMD about as
+                            // much as four vector instructions per step -- stays idle.
+                            typedef float f4 __attribute__((ext_vector_type(4)));
+                            const float4 *zpu = zs + ref_u + 1;
+                            for (;;) {
+                                f4 ua, ub, uc, ud;
+                                asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(ua) : "s"(zpu));
+                                asm volatile("s_load_dwordx4 %0, %1, 0x10" : "=s"(ub) : "s"(zpu));
+                                asm volatile("s_load_dwordx4 %0, %1, 0x20" : "=s"(uc) : "s"(zpu));
+                                asm volatile("s_load_dwordx4 %0, %1, 0x30" : "=s"(ud) : "s"(zpu));
+                                f2 t1, u1;
+                                uint64_t v1 = 0;
+                                FS_SCALED_STEP(w0, z0, t1, u1, a, v1, false,
+                                               asm volatile("s_waitcnt lgkmcnt(0)"
+                                                            : "+s"(ua), "+s"(ub), "+s"(uc), "+s"(ud), "+v"(mx_a)),
+                                               ua.x, ua.y, ua.z);
+                                FS_SCALED_STEP(t1, u1, w2, z2, b, v1, true, (void)0, ub.x, ub.y, ub.z);
+                                if (v1 != 0ull) {
+                                    wO = w0, zO = z0, failed = true;
+                                    break;
+                                }
+                                c += 2;
+                                f2 t3, u3;
+                                uint64_t v2 = 0;
+                                FS_SCALED_STEP(w2, z2, t3, u3, c_, v2, false, (void)0, uc.x, uc.y, uc.z);
+                                FS_SCALED_STEP(t3, u3, w0, z0, d, v2, true, (void)0, ud.x, ud.y, ud.z);
+                                if (v2 != 0ull) {
+                                    wO = w2, zO = z2, failed = true;
+                                    break;
+                                }
+                                c += 2;
+                                zpu += 4;
+                                if (c >= 64u) {
+                                    wO = w0, zO = z0, failed = false;
+                                    break;
+                                }
                             }
-                            c += 2;
-                            f2 t3, u3;
-                            uint64_t v2 = 0;
-                            FS_SCALED_STEP(w2, z2, t3, u3, "32", c_, v2, false);
-                            FS_SCALED_STEP(t3, u3, w0, z0, "48", d, v2, true);
-                            if (v2 != 0ull) {
-                                wO = w2, zO = z2, failed = true;
-                                break;
+                        } else {
+                            // per-lane orbit positions: one 12-byte vector load per step from a wave-uniform base plus a
+                            // per-lane byte offset that is fixed for the run; the four loads of a body are requested up
+                            // front and arrive in order
+                            const uint32_t lane_off = (ref + 1) * 16u;
+                            const float4 *zp = zs;
+#define FS_SCALED_LOAD(OFS, T, PIN)                                                                                 \
+    f3 ent_##T;                                                                                                     \
+    asm volatile("global_load_dwordx3 %0, %2, %3 offset:" OFS : "=v"(ent_##T), "+v"(PIN) : "v"(lane_off), "s"(zp));
+                            for (;;) {
+                                FS_SCALED_LOAD("0", a, w0)
+                                FS_SCALED_LOAD("16", b, w0)
+                                FS_SCALED_LOAD("32", c_, w0)
+                                FS_SCALED_LOAD("48", d, w0)
+                                f2 t1, u1;
+                                uint64_t v1 = 0;
+                                FS_SCALED_STEP(w0, z0, t1, u1, a, v1, false,
+                                               asm volatile("s_waitcnt vmcnt(3)" : "+v"(ent_a), "+v"(mx_a)), ent_a.x,
+                                               ent_a.y, ent_a.z);
+                                FS_SCALED_STEP(t1, u1, w2, z2, b, v1, true,
+                                               asm volatile("s_waitcnt vmcnt(2)" : "+v"(ent_b), "+v"(mx_b)), ent_b.x,
+                                               ent_b.y, ent_b.z);
+                                if (v1 != 0ull) {
+                                    asm volatile("s_waitcnt vmcnt(0)" ::"v"(ent_c_), "v"(ent_d)); // nothing stays in flight
+                                    wO = w0, zO = z0, failed = true;
+                                    break;
+                                }
+                                c += 2;
+                                f2 t3, u3;
+                                uint64_t v2 = 0;
+                                FS_SCALED_STEP(w2, z2, t3, u3, c_, v2, false,
+                                               asm volatile("s_waitcnt vmcnt(1)" : "+v"(ent_c_), "+v"(mx_c_)), ent_c_.x,
+                                               ent_c_.y, ent_c_.z);
+                                FS_SCALED_STEP(t3, u3, w0, z0, d, v2, true,
+                                               asm volatile("s_waitcnt vmcnt(0)" : "+v"(ent_d), "+v"(mx_d)), ent_d.x,
+                                               ent_d.y, ent_d.z);
+                                if (v2 != 0ull) {
+                                    wO = w2, zO = z2, failed = true;
+                                    break;
+                                }
+                                c += 2;
+                                zp += 4;
+                                if (c >= 64u) {
+                                    wO = w0, zO = z0, failed = false;
+                                    break;
+                                }
                             }
-                            c += 2;
-                            zp += 4;
-                            if (c >= 64u) {
-                                wO = w0, zO = z0, failed = false;
-                                break;
-                            }
+#undef FS_SCALED_LOAD
                         }
 #undef FS_SCALED_STEP
                         // back to the reduced form: the larger part's exponent moves into dze (exact)
