@@ -85,6 +85,7 @@ template <class F> struct FsBlaArgsT {
     uint32_t *out;
     const typename FsDev<F>::Z *zref;
     const float4 *zq;                            // float, perturbation-only: quiet-run companion of zref
+    const float4 *zs;                            // ... and the scaled runs' companion (see FsLav2ArgsT)
     const typename FsDev<F>::BLA *const *levels; // device array of device pointers, indexed by level
     uint64_t *stats;
     FsFrame frame;

@@ -989,7 +989,162 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
             //   is consumed once on the way to N: T = Z + O128 * 2^(n-7), P = O128 * T = 128 * (O * T), N = P * 2^(e-7).
             //   valid: aX', aY' <= 111 (new dz 2^4 below Z'), ncB <= 111 (N bigger than dc), both parts of Q normal
             //   non-zero, no exact zero in T or N (the literal adds reset the exponent there).
+            // ---- first chance: runs of *scaled* quiet steps (see k_lav2_hdr32_fast: HDRFloat operations are the correctly
+            // rounded binary32 operations on the represented values, so while nothing leaves binary32's normal range the
+            // step can run on plain floats under one power-of-two scale per lane).  The scalar-HDRFloat step of
+            // Fractal.cpp:2342-2361 -- X' = X (2Zx + X) - Y (2Zy + Y) + cX,  Y' = X (2Zy + Y) + Y (2Zx + X) + cY, each part
+            // with its own exponent -- is the same sequence of roundings as the complex one: s = fma(w, 2^E, 2Z),
+            // q = (w.x s.x - w.y s.y, w.x s.y + w.y s.x) + c 2^-E.  Same acceptance tests, same companion array.
+            bool sc_stopped = false;
             if constexpr (!kBla && std::is_same<F, float>::value) {
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                typedef float f3 __attribute__((ext_vector_type(3)));
+                typedef float f4 __attribute__((ext_vector_type(4)));
+                const float4 *__restrict__ zs = A.zs;
+                const uint32_t MaxRefS = count - 1;
+                for (;;) {
+                    const float4 e0 = zs[RefIteration];
+                    const int E = imax(DeltaSubNX.e, DeltaSubNY.e);
+                    const f2 dzs = {__builtin_amdgcn_ldexpf(DeltaSubNX.m, imax(DeltaSubNX.e - E, -200)),
+                                    __builtin_amdgcn_ldexpf(DeltaSubNY.m, imax(DeltaSubNY.e - E, -200))};
+                    const float sE = __builtin_amdgcn_ldexpf(1.0f, E);
+                    const int dshx = DeltaSub0X.e - E, dshy = DeltaSub0Y.e - E;
+                    const f2 dcs = {__builtin_amdgcn_ldexpf(DeltaSub0X.m, imax(imin(dshx, 100), -200)),
+                                    __builtin_amdgcn_ldexpf(DeltaSub0Y.m, imax(imin(dshy, 100), -200))};
+                    const float mx0 = __builtin_fmaxf(__builtin_fabsf(dzs.x), __builtin_fabsf(dzs.y));
+                    const float mn0 = __builtin_fminf(__builtin_fabsf(dzs.x), __builtin_fabsf(dzs.y));
+                    const uint32_t left_ref = RefIteration + 1 < MaxRefS ? MaxRefS - 1 - RefIteration : 0u;
+                    const uint32_t left_it = n_iterations - 1 - iter; // iter < n_iterations here
+                    const uint32_t left = left_ref < left_it ? left_ref : left_it;
+                    const int Esh = (E < -254 ? -254 : (E > 0 ? 0 : E)) * (1 << 23);
+                    const bool start_ok = __float_as_int(mx0) + Esh <= __float_as_int(e0.z) && mn0 >= mx0 * 0x1p-40f &&
+                                          mx0 >= 1.0f && mx0 < 2.0f && imax(dshx, dshy) <= 30 && left >= 64u;
+                    if (__builtin_amdgcn_ballot_w64(!start_ok) != 0ull)
+                        break;
+                    const f2 sE2 = {sE, sE};
+#define FS_SCALED_STEP(W_, Z_, NW_, NZ_, T, V, FULL, AFTER_ARITH, EX, EY, EB)                                       \
+    const f2 s_##T = __builtin_elementwise_fma(W_, sE2, Z_);                                                        \
+    const f2 pa_##T = W_.xx * s_##T;                                                                                \
+    const f2 pb_##T = W_.yy * s_##T.yx;                                                                             \
+    f2 p_##T;                                                                                                       \
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(p_##T) : "v"(pa_##T), "v"(pb_##T));              \
+    NW_ = p_##T + dcs;                                                                                              \
+    float mx_##T = __builtin_fmaxf(__builtin_fabsf(NW_.x), __builtin_fabsf(NW_.y));                                 \
+    AFTER_ARITH;                                                                                                    \
+    NZ_ = (f2){EX, EY};                                                                                             \
+    V |= __builtin_amdgcn_ballot_w64(__float_as_int(mx_##T) + Esh > __float_as_int(EB));                            \
+    if (FULL) {                                                                                                     \
+        const float mn_##T = __builtin_fminf(__builtin_fabsf(NW_.x), __builtin_fabsf(NW_.y));                       \
+        V |= __builtin_amdgcn_ballot_w64(!(mn_##T >= mx_##T * 0x1p-40f)) |                                          \
+             __builtin_amdgcn_ballot_w64((uint32_t)(__float_as_int(mx_##T) - (107 << 23)) >= (uint32_t)(60 << 23)); \
+    }
+                    f2 w0 = dzs, z0 = {e0.x, e0.y}, w2, z2, wO, zO;
+                    uint32_t c = 0;
+                    bool failed;
+                    const uint32_t ref_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)RefIteration);
+                    if (__builtin_amdgcn_ballot_w64(RefIteration != ref_u) == 0ull) {
+                        const float4 *zpu = zs + ref_u + 1; // entries through the scalar cache: all lanes read the same ones
+                        for (;;) {
+                            f4 ua, ub, uc, ud;
+                            asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(ua) : "s"(zpu));
+                            asm volatile("s_load_dwordx4 %0, %1, 0x10" : "=s"(ub) : "s"(zpu));
+                            asm volatile("s_load_dwordx4 %0, %1, 0x20" : "=s"(uc) : "s"(zpu));
+                            asm volatile("s_load_dwordx4 %0, %1, 0x30" : "=s"(ud) : "s"(zpu));
+                            f2 t1, u1;
+                            uint64_t v1 = 0;
+                            FS_SCALED_STEP(w0, z0, t1, u1, a, v1, false,
+                                           asm volatile("s_waitcnt lgkmcnt(0)"
+                                                        : "+s"(ua), "+s"(ub), "+s"(uc), "+s"(ud), "+v"(mx_a)),
+                                           ua.x, ua.y, ua.z);
+                            FS_SCALED_STEP(t1, u1, w2, z2, b, v1, true, (void)0, ub.x, ub.y, ub.z);
+                            if (v1 != 0ull) {
+                                wO = w0, zO = z0, failed = true;
+                                break;
+                            }
+                            c += 2;
+                            f2 t3, u3;
+                            uint64_t v2 = 0;
+                            FS_SCALED_STEP(w2, z2, t3, u3, c_, v2, false, (void)0, uc.x, uc.y, uc.z);
+                            FS_SCALED_STEP(t3, u3, w0, z0, d, v2, true, (void)0, ud.x, ud.y, ud.z);
+                            if (v2 != 0ull) {
+                                wO = w2, zO = z2, failed = true;
+                                break;
+                            }
+                            c += 2;
+                            zpu += 4;
+                            if (c >= 64u) {
+                                wO = w0, zO = z0, failed = false;
+                                break;
+                            }
+                        }
+                    } else {
+                        const uint32_t lane_off = (RefIteration + 1) * 16u;
+                        const float4 *zp = zs;
+#define FS_SCALED_LOAD(OFS, T, PIN)                                                                                 \
+    f3 ent_##T;                                                                                                     \
+    asm volatile("global_load_dwordx3 %0, %2, %3 offset:" OFS : "=v"(ent_##T), "+v"(PIN) : "v"(lane_off), "s"(zp));
+                        for (;;) {
+                            FS_SCALED_LOAD("0", a, w0)
+                            FS_SCALED_LOAD("16", b, w0)
+                            FS_SCALED_LOAD("32", c_, w0)
+                            FS_SCALED_LOAD("48", d, w0)
+                            f2 t1, u1;
+                            uint64_t v1 = 0;
+                            FS_SCALED_STEP(w0, z0, t1, u1, a, v1, false,
+                                           asm volatile("s_waitcnt vmcnt(3)" : "+v"(ent_a), "+v"(mx_a)), ent_a.x, ent_a.y,
+                                           ent_a.z);
+                            FS_SCALED_STEP(t1, u1, w2, z2, b, v1, true,
+                                           asm volatile("s_waitcnt vmcnt(2)" : "+v"(ent_b), "+v"(mx_b)), ent_b.x, ent_b.y,
+                                           ent_b.z);
+                            if (v1 != 0ull) {
+                                asm volatile("s_waitcnt vmcnt(0)" ::"v"(ent_c_), "v"(ent_d)); // nothing stays in flight
+                                wO = w0, zO = z0, failed = true;
+                                break;
+                            }
+                            c += 2;
+                            f2 t3, u3;
+                            uint64_t v2 = 0;
+                            FS_SCALED_STEP(w2, z2, t3, u3, c_, v2, false,
+                                           asm volatile("s_waitcnt vmcnt(1)" : "+v"(ent_c_), "+v"(mx_c_)), ent_c_.x,
+                                           ent_c_.y, ent_c_.z);
+                            FS_SCALED_STEP(t3, u3, w0, z0, d, v2, true,
+                                           asm volatile("s_waitcnt vmcnt(0)" : "+v"(ent_d), "+v"(mx_d)), ent_d.x, ent_d.y,
+                                           ent_d.z);
+                            if (v2 != 0ull) {
+                                wO = w2, zO = z2, failed = true;
+                                break;
+                            }
+                            c += 2;
+                            zp += 4;
+                            if (c >= 64u) {
+                                wO = w0, zO = z0, failed = false;
+                                break;
+                            }
+                        }
+#undef FS_SCALED_LOAD
+                    }
+#undef FS_SCALED_STEP
+                    if (c != 0u) {
+                        // back to two reduced HDRFloats: each part's own exponent moves out of the float (exact; an accepted
+                        // state has no zero part)
+                        const int kx = (int)(((uint32_t)__float_as_int(wO.x) >> 23) & 0xFFu) - 127;
+                        const int ky = (int)(((uint32_t)__float_as_int(wO.y) >> 23) & 0xFFu) - 127;
+                        DeltaSubNX = hreal<F>{__builtin_amdgcn_ldexpf(wO.x, -kx), E + kx};
+                        DeltaSubNY = hreal<F>{__builtin_amdgcn_ldexpf(wO.y, -ky), E + ky};
+                        RefIteration += c;
+                        iter += c;
+                        if (kStats)
+                            c_pt += c;
+                        Zcached_at = 0xFFFFFFFFu;
+                    }
+                    if (failed) {
+                        sc_stopped = true;
+                        break;
+                    }
+                }
+            }
+            if constexpr (!kBla && std::is_same<F, float>::value) {
+              if (!sc_stopped) {
                 typedef float f2 __attribute__((ext_vector_type(2)));
                 typedef float f3 __attribute__((ext_vector_type(3)));
                 const float4 *__restrict__ zq = A.zq;
@@ -1102,6 +1257,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                     DeltaSubNY = hreal<F>{O128.y * 0.0078125f, OYe};
                     Zcached_at = 0xFFFFFFFFu;
                 }
+              }
             }
 
             const hreal<F> OX = DeltaSubNX, OY = DeltaSubNY;

@@ -1014,6 +1014,7 @@ uint32_t fs_render_bla(fs_renderer *r, int type_tag, const void *coords, uint64_
         A.out = (uint32_t *)r->iters();
         A.zref = r->zref;
         A.zq = r->zq;
+        A.zs = r->zq + r->zq_n;
         A.levels = (const fs_bla_hdr32 *const *)r->bla_levels_dev;
         A.stats = r->stats;
         A.frame = make_frame(r);
