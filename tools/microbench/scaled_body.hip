@@ -7,7 +7,8 @@
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f3 __attribute__((ext_vector_type(3)));
 
-// VARIANT bits: 1 = loads, 2 = scalar ORs + compare + branch, 4 = checks (max/add/cmp ...), 8 = per-lane different addresses
+// VARIANT bits: 1 = vector loads, 2 = scalar ORs + compare + branch, 4 = checks (max/add/cmp ...), 8 = per-lane different
+// addresses, 16 = entries through the scalar cache (four s_load_dwordx4 per body, one wait) instead of vector loads
 template <int V> __global__ void __launch_bounds__(256) k(const float4 *__restrict__ tab, float *out, int iters, int n)
 {
     f2 w = {1.0f + threadIdx.x * 1e-3f, 0.5f}, z = {0.3f, -0.2f};
@@ -16,6 +17,7 @@ template <int V> __global__ void __launch_bounds__(256) k(const float4 *__restri
     uint32_t lane_off = (V & 8) ? ((threadIdx.x * 37u) % 1024u) * 16u : 16u;
     uint32_t c = 0;
     const float4 *zp = tab + (blockIdx.x % 7) * 64;
+    const float4 *zp0 = zp;
     uint64_t acc = 0;
     for (int it = 0; it < iters; it++) {
 #define STEP(W_, Z_, NW_, NZ_, OFS, FULL)                                                                               \
@@ -44,6 +46,16 @@ template <int V> __global__ void __launch_bounds__(256) k(const float4 *__restri
     }
         f2 t1, u1, w2, z2, t3, u3;
         uint64_t viol = 0;
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        f4 ua, ub, uc, ud;
+        if (V & 16) {
+            asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(ua) : "s"(zp));
+            asm volatile("s_load_dwordx4 %0, %1, 0x10" : "=s"(ub) : "s"(zp));
+            asm volatile("s_load_dwordx4 %0, %1, 0x20" : "=s"(uc) : "s"(zp));
+            asm volatile("s_load_dwordx4 %0, %1, 0x30" : "=s"(ud) : "s"(zp));
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ua), "+s"(ub), "+s"(uc), "+s"(ud), "+v"(w));
+            z = (f2){z.x + ua.x * 1e-30f, z.y + ub.y * 1e-30f + uc.x * 1e-30f + ud.x * 1e-30f};
+        }
         STEP(w, z, t1, u1, "0", false)
         STEP(t1, u1, w2, z2, "16", true)
         if ((V & 2) && viol != 0ull) {
@@ -60,9 +72,9 @@ template <int V> __global__ void __launch_bounds__(256) k(const float4 *__restri
             acc |= viol;
         c += 4;
         zp += 4;
-        if (c >= 64u) {
+        if (c >= 16384u) { // walk 256 KB so that scalar-cache lines are new ones, as in the kernel
             c = 0;
-            zp -= 64;
+            zp = zp0;
             // keep the values in range
             w = (f2){1.0f + w.x * 1e-30f, 0.5f + w.y * 1e-30f};
         }
@@ -70,11 +82,11 @@ template <int V> __global__ void __launch_bounds__(256) k(const float4 *__restri
     out[blockIdx.x * blockDim.x + threadIdx.x] = w.x + w.y + z.x + z.y + (float)acc;
 }
 
-template <int V> void run(const char *name)
+template <int V> void run(const char *name, int waves_per_simd = 8)
 {
     float *out;
     float4 *tab;
-    const int blocks = 256 * 8, n = 4096;
+    const int blocks = 256 * waves_per_simd, n = 1 << 16;
     hipMalloc(&out, blocks * 256 * sizeof(float));
     hipMalloc(&tab, n * sizeof(float4));
     float4 *h = new float4[n];
@@ -93,9 +105,10 @@ template <int V> void run(const char *name)
     hipEventSynchronize(e1);
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
-    const double steps_per_simd = (double)iters * 4 * 8; // 8 waves per SIMD, 4 steps per trip
-    printf("{\"variant\": \"%s\", \"ms\": %.3f, \"ns_per_wave_step_per_simd\": %.2f, \"cycles_at_2.4GHz\": %.1f}\n", name, ms,
-           ms * 1e6 / steps_per_simd, ms * 1e-3 * 2.4e9 / steps_per_simd);
+    const double steps_per_simd = (double)iters * 4 * waves_per_simd; // 4 steps per trip
+    printf("{\"variant\": \"%s\", \"waves_per_simd\": %d, \"ms\": %.3f, \"ns_per_wave_step_per_simd\": %.2f, "
+           "\"cycles_at_2.4GHz\": %.1f}\n",
+           name, waves_per_simd, ms, ms * 1e6 / steps_per_simd, ms * 1e-3 * 2.4e9 / steps_per_simd);
     hipFree(out);
     hipFree(tab);
     delete[] h;
@@ -110,5 +123,12 @@ int main()
     run<7>("everything, same address in every lane");
     run<15>("everything, per-lane addresses");
     run<9>("arithmetic + loads, per-lane addresses");
+    run<22>("checks + scalar OR / branch + scalar-cache entries");
+    // one wave per SIMD: the dependent chain, nothing to hide it behind
+    run<0>("arithmetic only (5 packed + max)", 1);
+    run<4>("+ checks", 1);
+    run<6>("+ checks + scalar OR / branch", 1);
+    run<7>("everything, vector loads, same address in every lane", 1);
+    run<22>("checks + scalar OR / branch + scalar-cache entries", 1);
     return 0;
 }
