@@ -561,19 +561,26 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                             // rebase on the same step): the entries come through the scalar cache into scalar registers,
                             // four per body, and the vector memory path -- whose 12-byte returns cost the SIMD about as
                             // much as four vector instructions per step -- stays idle.
+                            // Eight entries (two 64-byte lines) per body, one wait: a scalar-cache miss is an L2 round trip,
+                            // and these loads cannot be waited for one at a time.
                             typedef float f4 __attribute__((ext_vector_type(4)));
                             const float4 *zpu = zs + ref_u + 1;
                             for (;;) {
-                                f4 ua, ub, uc, ud;
+                                f4 ua, ub, uc, ud, ue, uf, ug, uh;
                                 asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(ua) : "s"(zpu));
                                 asm volatile("s_load_dwordx4 %0, %1, 0x10" : "=s"(ub) : "s"(zpu));
                                 asm volatile("s_load_dwordx4 %0, %1, 0x20" : "=s"(uc) : "s"(zpu));
                                 asm volatile("s_load_dwordx4 %0, %1, 0x30" : "=s"(ud) : "s"(zpu));
+                                asm volatile("s_load_dwordx4 %0, %1, 0x40" : "=s"(ue) : "s"(zpu));
+                                asm volatile("s_load_dwordx4 %0, %1, 0x50" : "=s"(uf) : "s"(zpu));
+                                asm volatile("s_load_dwordx4 %0, %1, 0x60" : "=s"(ug) : "s"(zpu));
+                                asm volatile("s_load_dwordx4 %0, %1, 0x70" : "=s"(uh) : "s"(zpu));
                                 f2 t1, u1;
                                 uint64_t v1 = 0;
                                 FS_SCALED_STEP(w0, z0, t1, u1, a, v1, false,
                                                asm volatile("s_waitcnt lgkmcnt(0)"
-                                                            : "+s"(ua), "+s"(ub), "+s"(uc), "+s"(ud), "+v"(mx_a)),
+                                                            : "+s"(ua), "+s"(ub), "+s"(uc), "+s"(ud), "+s"(ue), "+s"(uf),
+                                                              "+s"(ug), "+s"(uh), "+v"(mx_a)),
                                                ua.x, ua.y, ua.z);
                                 FS_SCALED_STEP(t1, u1, w2, z2, b, v1, true, (void)0, ub.x, ub.y, ub.z);
                                 if (v1 != 0ull) {
@@ -590,7 +597,25 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                                     break;
                                 }
                                 c += 2;
-                                zpu += 4;
+                                f2 t5, u5;
+                                uint64_t v3 = 0;
+                                FS_SCALED_STEP(w0, z0, t5, u5, e, v3, false, (void)0, ue.x, ue.y, ue.z);
+                                FS_SCALED_STEP(t5, u5, w2, z2, f, v3, true, (void)0, uf.x, uf.y, uf.z);
+                                if (v3 != 0ull) {
+                                    wO = w0, zO = z0, failed = true;
+                                    break;
+                                }
+                                c += 2;
+                                f2 t7, u7;
+                                uint64_t v4 = 0;
+                                FS_SCALED_STEP(w2, z2, t7, u7, g, v4, false, (void)0, ug.x, ug.y, ug.z);
+                                FS_SCALED_STEP(t7, u7, w0, z0, h, v4, true, (void)0, uh.x, uh.y, uh.z);
+                                if (v4 != 0ull) {
+                                    wO = w2, zO = z2, failed = true;
+                                    break;
+                                }
+                                c += 2;
+                                zpu += 8;
                                 if (c >= 64u) {
                                     wO = w0, zO = z0, failed = false;
                                     break;
