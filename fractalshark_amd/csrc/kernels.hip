@@ -524,8 +524,10 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                         // a result below the normal range turns negative (dz far too small to matter: passes), NaN is huge
                         // (E < 0 in every run: the start test needs max|dz| in [2^E, 2^(E+1)) below a bound < 0.7)
                         const int Esh = (E < -254 ? -254 : (E > 0 ? 0 : E)) * (1 << 23);
-                        const bool start_ok = __float_as_int(mx0) + Esh <= __float_as_int(e0.z) && mn0 >= mx0 * 0x1p-40f &&
-                                              mx0 >= 1.0f && mx0 < 2.0f && dsh <= 30 && left >= 64u;
+                        // (the state a run starts from has passed the CPU loop's tests already: only the entry it starts at
+                        // must be one the companion vouches for -- a NaN-free 2Z, bound not the "never" pattern)
+                        const bool start_ok = __float_as_int(e0.z) > 0 && mn0 >= mx0 * 0x1p-40f && mx0 >= 1.0f && mx0 < 2.0f &&
+                                              dsh <= 30 && left >= 64u;
                         if (__builtin_amdgcn_ballot_w64(!start_ok) != 0ull)
                             break;
                         const f2 sE2 = {sE, sE};
@@ -1042,8 +1044,8 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                     const uint32_t left_it = n_iterations - 1 - iter; // iter < n_iterations here
                     const uint32_t left = left_ref < left_it ? left_ref : left_it;
                     const int Esh = (E < -254 ? -254 : (E > 0 ? 0 : E)) * (1 << 23);
-                    const bool start_ok = __float_as_int(mx0) + Esh <= __float_as_int(e0.z) && mn0 >= mx0 * 0x1p-40f &&
-                                          mx0 >= 1.0f && mx0 < 2.0f && imax(dshx, dshy) <= 30 && left >= 64u;
+                    const bool start_ok = __float_as_int(e0.z) > 0 && mn0 >= mx0 * 0x1p-40f && mx0 >= 1.0f && mx0 < 2.0f &&
+                                          imax(dshx, dshy) <= 30 && left >= 64u;
                     if (__builtin_amdgcn_ballot_w64(!start_ok) != 0ull)
                         break;
                     const f2 sE2 = {sE, sE};
