@@ -214,11 +214,14 @@ def test_tuned_loop_equals_literal_transcription_1080p(renderer, native_libs, pa
     try:
         assert r.set_kernel_variant(literal=True) == 0
         lit, red_l = _render_lav2(r, v, ob, la, LAV2_FULL, parity)
-        assert r.set_kernel_variant(literal=False) == 0
+        assert r.set_kernel_variant(2) == 0  # exponent-tracking quiet runs only
+        mid, _ = _render_lav2(r, v, ob, la, LAV2_FULL, parity)
+        assert r.set_kernel_variant(literal=False) == 0  # scaled runs first (default)
         tun, red_t = _render_lav2(r, v, ob, la, LAV2_FULL, parity)
     finally:
         r.set_kernel_variant(literal=False)
     assert np.array_equal(lit, tun)
+    assert np.array_equal(lit, mid)
     assert (red_l.Min, red_l.Max, red_l.Sum) == (red_t.Min, red_t.Max, red_t.Sum)
     _oracle.set_row_step(135)
     try:
@@ -692,3 +695,42 @@ def test_quad_direct_kernels_on_a_deep_view(renderer, native_libs):
         outs[kind] = out[:16, :32].astype(np.int64)
     assert len(np.unique(outs["4x64"])) > 20  # a real picture, not a constant
     assert (np.abs(outs["4x32"] - outs["4x64"]) <= 2).mean() > 0.9
+
+
+# ---- the scaled quiet runs on inputs that stress their acceptance tests
+def _axis_view(width, W=64, H=36, n_iter=60000):
+    """A view centred ON the real axis (imaginary centre exactly 0, orbit and part of dz purely real): parts of dz and
+    of the orbit are exact zeros, which the scaled runs must leave to the exponent-tracking path."""
+    from decimal import Decimal, getcontext
+    getcontext().prec = 80
+    cx = Decimal("-1.7865720822115618956924187301180679424")  # a real-axis minibrot neighbourhood
+    w = Decimal(width)
+    h = w * H / W
+    return inputs.View(str(cx - w / 2), str(-h / 2), str(cx + w / 2), str(h / 2), W, H, num_iterations=n_iter)
+
+
+@pytest.mark.parametrize("width", ["1e-20", "1e-30"])
+def test_scaled_runs_on_a_real_axis_view(renderer, native_libs, width):
+    v = _axis_view(width)
+    ob = inputs.Orbit(v)
+    la = inputs.LATable(ob)
+    for parity, st in ((PARITY_CPU, 0), (PARITY_CPU_GPUSTAGE, 1)):
+        out, _ = _render_lav2(renderer, v, ob, la, LAV2_FULL, parity)
+        assert np.array_equal(out, _oracle.lav2_hdr32(v, ob, la, stage_test=st)), (width, parity)
+    out, _ = _render_lav2(renderer, v, ob, la, LAV2_PO, PARITY_CPU)  # scalar-HDRFloat kernel
+    assert np.array_equal(out, _oracle.bla_hdr32(v, ob, None)), width
+
+
+@pytest.mark.parametrize("view_n", [3, 9, 11])
+def test_three_variants_agree_on_other_views(renderer, native_libs, view_n):
+    v = inputs.View.builtin(view_n, 96, 54, antialiasing=1)
+    ob = inputs.Orbit(v)
+    la = inputs.LATable(ob)
+    outs = []
+    try:
+        for variant in (1, 2, 0):
+            assert renderer.set_kernel_variant(variant) == 0
+            outs.append(_render_lav2(renderer, v, ob, la, LAV2_FULL, PARITY_CPU)[0])
+    finally:
+        renderer.set_kernel_variant(0)
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
