@@ -35,7 +35,7 @@ def _run(cmd):
 
 
 def build_render(force=False):
-    srcs = [os.path.join(CSRC, f) for f in ("kernels.hip", "kernels_2x32.hip", "kernels_scaled.hip", "kernels_tables.hip", "kernels_direct_lp.hip", "kernels_plain.hip", "renderer.cpp", "kernels.h", "kernel_common.hpp",
+    srcs = [os.path.join(CSRC, f) for f in ("kernels.hip", "kernels_2x32.hip", "kernels_scaled.hip", "kernels_tables.hip", "kernels_direct_lp.hip", "kernels_plain.hip", "kernels_decompress.hip", "renderer.cpp", "kernels.h", "kernel_common.hpp",
                                             "hdr_math.hpp", "df32_math.hpp")]
     srcs += [os.path.join(ROOT, "include", f) for f in ("fsmi355.h", "fs_layout.h")]
     if not force and _newer(LIB_RENDER, srcs):
@@ -44,7 +44,7 @@ def build_render(force=False):
     _run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
           "-o", LIB_RENDER, os.path.join(CSRC, "kernels.hip"), os.path.join(CSRC, "kernels_2x32.hip"),
           os.path.join(CSRC, "kernels_scaled.hip"), os.path.join(CSRC, "kernels_tables.hip"),
-          os.path.join(CSRC, "kernels_direct_lp.hip"), os.path.join(CSRC, "kernels_plain.hip"),
+          os.path.join(CSRC, "kernels_direct_lp.hip"), os.path.join(CSRC, "kernels_plain.hip"), os.path.join(CSRC, "kernels_decompress.hip"),
           os.path.join(CSRC, "renderer.cpp")])
     return LIB_RENDER
 

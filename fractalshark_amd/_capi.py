@@ -202,6 +202,14 @@ def inputs_lib():
     _decl(lib, "fsh_bla_level_ptrs", vp, [vp])
     _decl(lib, "fsh_bla_level_sizes", vp, [vp])
     _decl(lib, "fsh_plain_create", vp, [vp, C.c_int, u64, C.c_int, C.c_int])
+    _decl(lib, "fsh_plain_create_ex", vp, [vp, C.c_int, u64, C.c_int, C.c_int, C.c_int])
+    _decl(lib, "fsh_plain_is_compressed", C.c_int, [vp])
+    _decl(lib, "fsh_plain_compressed_count", u64, [vp])
+    _decl(lib, "fsh_plain_compressed_data", vp, [vp])
+    _decl(lib, "fsh_plain_orbit_low", None, [vp, vp])
+    _decl(lib, "fsh_convert_orbit_rc_f64_to_p2x32", None, [vp, u64, vp])
+    _decl(lib, "fsh_convert_orbit_rc_hdr64_to_2x32", None, [vp, u64, vp])
+    _decl(lib, "fsh_orbit_low_2x32", None, [vp, vp])
     _decl(lib, "fsh_plain_destroy", None, [vp])
     _decl(lib, "fsh_plain_kind", C.c_int, [vp])
     _decl(lib, "fsh_plain_orbit_count", u64, [vp])

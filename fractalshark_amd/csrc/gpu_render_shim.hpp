@@ -223,10 +223,9 @@ uint32_t GPURenderer::RenderPerturbLAv2(RenderAlgorithm /*algorithm*/, T /*cx*/,
     if constexpr (tag < 0) {
         return FS_ERR_UNSUPPORTED;
     } else {
-    // PExtras only changes how the orbit was uploaded (InitializePerturb); the 2x32 and the non-HDR kernels read
-    // uncompressed orbits only
-    if (PExtras != PerturbExtras::Disable &&
-        (PExtras != PerturbExtras::SimpleCompression || (tag != FS_T_HDR32 && tag != FS_T_HDR64)))
+    // PExtras only changes how the orbit was uploaded (InitializePerturb): SimpleCompression waypoints are expanded on
+    // the device at upload, for every numeric type
+    if (PExtras != PerturbExtras::Disable && PExtras != PerturbExtras::SimpleCompression)
         return FS_ERR_UNSUPPORTED;
     const typename fsmi355_shim::abi_real<T>::type co[4] = {fsmi355_shim::to_abi(dx), fsmi355_shim::to_abi(dy),
                                                             fsmi355_shim::to_abi(centerX), fsmi355_shim::to_abi(centerY)};

@@ -22,7 +22,7 @@ __device__ __forceinline__ uint32_t global_row(const FsFrame &f, uint32_t L)
 __device__ __forceinline__ void tile_pixel(uint32_t &X, uint32_t &L)
 {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    X = blockIdx.x * 32u + wave * 8u + (lane & 7u);
+    X = (blockIdx.x * (blockDim.x >> 6) + wave) * 8u + (lane & 7u);
     L = blockIdx.y * 8u + (lane >> 3);
 }
 

@@ -204,6 +204,10 @@ struct FsDirectArgs64 {
 };
 
 void fsk_prepare_orbit_hdr32(const fs_orbit_hdr32 *in, float4 *out, uint64_t n, hipStream_t s);
+// type_tag = FS_T_F32 | FS_T_F64 | FS_T_2X32 | FS_T_HDR2X32; wp / out / cxLow are the records of that type
+// (fs_orbit_*_rc -> fs_orbit_*; float / double / fs_real_p2x32 / fs_real_2x32), kernels_decompress.hip
+void fsk_decompress_orbit_plain(int type_tag, const void *wp, uint64_t n_wp, uint64_t n_uncompressed, const void *cxLow,
+                                const void *cyLow, void *out, hipStream_t s);
 void fsk_decompress_orbit_hdr32(const fs_orbit_hdr32_rc *wp, uint64_t n_wp, uint64_t n_uncompressed, fs_real_hdr32 cxLow,
                                 fs_real_hdr32 cyLow, float4 *out, hipStream_t s);
 void fsk_decompress_orbit_hdr64(const fs_orbit_hdr64_rc *wp, uint64_t n_wp, uint64_t n_uncompressed, fs_real_hdr64 cxLow,

@@ -12,6 +12,7 @@
 #include "../../include/fs_layout.h"
 #include "hdr_math.hpp"
 #include "kernels.h"
+#include <cstdlib>
 #include "kernel_common.hpp"
 
 using namespace fs;
@@ -1797,9 +1798,23 @@ void fsk_make_quiet_orbit(const float4 *zref, float4 *zq, uint64_t n, hipStream_
     hipLaunchKernelGGL(k_make_quiet_orbit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, zref, zq, n);
 }
 
+static unsigned lds_pad()
+{
+    static const unsigned v = [] {
+        const char *e = getenv("FSMI355_LDS_PAD");
+        return e ? (unsigned)atoi(e) : 0u;
+    }();
+    return v;
+}
+
 void fsk_lav2_hdr32(const FsLav2Args32 &A, int mode, bool stats, int variant, hipStream_t s)
 {
-    const dim3 g = tile_grid(A.frame), b(256);
+    const unsigned pad = lds_pad();
+    static const unsigned bs = [] {
+        const char *e = getenv("FSMI355_BLOCK");
+        return e ? (unsigned)atoi(e) : 256u;
+    }();
+    const dim3 b(bs), g((A.frame.width + bs / 8 - 1) / (bs / 8), (A.frame.local_rows + 7) / 8, 1);
 #define FS_LAUNCH(M)                                                                                                \
     do {                                                                                                            \
         if (variant == FS_VARIANT_LITERAL) {                                                                        \
@@ -1810,13 +1825,13 @@ void fsk_lav2_hdr32(const FsLav2Args32 &A, int mode, bool stats, int variant, hi
         } else {                                                                                                    \
             if (variant == FS_VARIANT_TUNED_NOSCALE) {                                                              \
                 if (stats)                                                                                          \
-                    hipLaunchKernelGGL((k_lav2_hdr32_fast<M, true, false>), g, b, 0, s, A);                         \
+                    hipLaunchKernelGGL((k_lav2_hdr32_fast<M, true, false>), g, b, pad, s, A);                         \
                 else                                                                                                \
-                    hipLaunchKernelGGL((k_lav2_hdr32_fast<M, false, false>), g, b, 0, s, A);                        \
+                    hipLaunchKernelGGL((k_lav2_hdr32_fast<M, false, false>), g, b, pad, s, A);                        \
             } else if (stats)                                                                                       \
-                hipLaunchKernelGGL((k_lav2_hdr32_fast<M, true, true>), g, b, 0, s, A);                              \
+                hipLaunchKernelGGL((k_lav2_hdr32_fast<M, true, true>), g, b, pad, s, A);                              \
             else                                                                                                    \
-                hipLaunchKernelGGL((k_lav2_hdr32_fast<M, false, true>), g, b, 0, s, A);                             \
+                hipLaunchKernelGGL((k_lav2_hdr32_fast<M, false, true>), g, b, pad, s, A);                             \
         }                                                                                                           \
     } while (0)
     if (mode == FS_MODE_FULL)

@@ -603,13 +603,63 @@ uint32_t fs_upload_orbit_compressed(fs_renderer *r, uint64_t generation, int typ
 {
     if (uint32_t e = use_device(r))
         return e;
-    if ((type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64) || (iter_bytes != 4 && iter_bytes != 8) ||
-        uncompressed_size > 0xFFFFFFFFull)
+    if ((type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64 && type_tag != FS_T_F32 && type_tag != FS_T_F64 &&
+         type_tag != FS_T_2X32 && type_tag != FS_T_HDR2X32) ||
+        (iter_bytes != 4 && iter_bytes != 8) || uncompressed_size > 0xFFFFFFFFull || !orbit_x_low || !orbit_y_low)
         return FS_ERR_UNSUPPORTED;
     if (!r->compute)
         return FS_ERR_6;
     if (r->orbit_ok && r->orbit_gen == generation && generation != 0 && r->orbit_type == type_tag)
         return 0;
+    if (type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64) {
+        // float / double / CudaDblflt / HDRFloat<CudaDblflt>: expanded into the record array the uncompressed upload
+        // of that type fills (kernels_decompress.hip)
+        size_t in_b, out_b;
+        void **slot;
+        switch (type_tag) {
+        case FS_T_F32:
+            in_b = sizeof(fs_orbit_f32_rc), out_b = sizeof(fs_orbit_f32), slot = &r->orbit_plain;
+            break;
+        case FS_T_2X32:
+            in_b = sizeof(fs_orbit_p2x32_rc), out_b = sizeof(fs_orbit_p2x32), slot = &r->orbit_plain;
+            break;
+        case FS_T_F64:
+            in_b = sizeof(fs_orbit_f64_rc), out_b = sizeof(fs_orbit_f64), slot = (void **)&r->orbit_f64;
+            break;
+        default:
+            in_b = sizeof(fs_orbit_2x32_rc), out_b = sizeof(fs_orbit_2x32), slot = (void **)&r->orbit_2x32;
+            break;
+        }
+        if (*slot) {
+            FS_TRY(hipFree(*slot));
+            *slot = nullptr;
+        }
+        r->orbit_ok = false;
+        void *raw = nullptr;
+        FS_TRY(hipMalloc(&raw, compressed_size * in_b));
+        hipError_t err = hipMalloc(slot, (uncompressed_size + 1) * out_b);
+        if (err == hipSuccess)
+            err = hipMemcpyAsync(raw, entries, compressed_size * in_b, hipMemcpyDefault, r->compute);
+        if (err == hipSuccess)
+            err = hipMemsetAsync((char *)*slot + uncompressed_size * out_b, 0, out_b, r->compute);
+        if (err == hipSuccess) {
+            fsk_decompress_orbit_plain(type_tag, raw, compressed_size, uncompressed_size, orbit_x_low, orbit_y_low, *slot,
+                                       r->compute);
+            err = hipGetLastError();
+        }
+        if (err == hipSuccess)
+            err = hipStreamSynchronize(r->compute);
+        (void)hipFree(raw);
+        if (err != hipSuccess)
+            return (uint32_t)err;
+        r->orbit_size = compressed_size;
+        r->orbit_uncompressed = uncompressed_size;
+        r->orbit_period = period_maybe_zero;
+        r->orbit_gen = generation;
+        r->orbit_type = type_tag;
+        r->orbit_ok = true;
+        return 0;
+    }
     if (r->zref) {
         FS_TRY(hipFree(r->zref));
         r->zref = nullptr;

@@ -780,6 +780,42 @@ extern "C" void fsh_convert_orbit_hdr64_to_2x32(const fs_orbit_hdr64 *in, uint64
     }
 }
 
+extern "C" void fsh_convert_orbit_rc_hdr64_to_2x32(const fs_orbit_hdr64_rc *in, uint64_t n, fs_orbit_2x32_rc *out)
+{
+    for (uint64_t i = 0; i < n; i++) {
+        fs_orbit_2x32_rc o;
+        o.index_and_rebase = in[i].index_and_rebase & 0x7FFFFFFFFFFFFFFFull;
+        df_from_double(in[i].mx, o.x_head, o.x_tail);
+        o.ex = in[i].ex;
+        df_from_double(in[i].my, o.y_head, o.y_tail);
+        o.ey = in[i].ey;
+        out[i] = o;
+    }
+}
+
+// m_OrbitXLow / m_OrbitYLow of the converted results: static_cast<T>(Convert<HighPrecision, double>(m_OrbitX))
+// (PerturbationResults.cpp:306-307), T = HDRFloat<CudaDblflt>: the double is split into exponent and a mantissa in
+// [1, 2), the mantissa into head + tail (HDRFloat.h:341-349).
+extern "C" void fsh_orbit_low_2x32(const fsh_orbit *o, fs_real_2x32 out[2])
+{
+    const Mp *c[2] = {o->is64 ? &o->d.cx : &o->f.cx, o->is64 ? &o->d.cy : &o->f.cy};
+    for (int k = 0; k < 2; k++) {
+        const double number = mpf_get_d(c[k]->v);
+        fs_real_2x32 r{0.0f, 0.0f, fs::kMinBigExp};
+        if (number != 0.0) {
+            uint64_t bits;
+            memcpy(&bits, &number, 8);
+            const int64_t f_exp = (int64_t)((bits & 0x7FF0000000000000ull) >> 52) - 1023;
+            const uint64_t val = (bits & 0x800FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
+            double f_val;
+            memcpy(&f_val, &val, 8);
+            df_from_double(f_val, r.head, r.tail);
+            r.e = (int32_t)f_exp;
+        }
+        out[k] = r;
+    }
+}
+
 extern "C" void fsh_convert_la_hdr64_to_2x32(const fs_la_hdr64_u32 *in, uint64_t n, fs_la_2x32_u32 *out)
 {
     for (uint64_t i = 0; i < n; i++) {
@@ -1123,7 +1159,11 @@ template <class T> struct PlainOrbit {
     uint64_t period = 0;
     preal<T> maxRadius{};
     Mp cx, cy;
+    // PerturbExtras::SimpleCompression: waypoints; x / y then hold the orbit as RuntimeDecompressor reproduces it
     bool compressed = false;
+    std::vector<uint64_t> wp_index;
+    std::vector<T> wp_x, wp_y;
+    T orbitXLow{}, orbitYLow{};
 };
 template <class T> struct orbit_of<plain<T>> {
     using type = PlainOrbit<T>;
@@ -2146,7 +2186,18 @@ extern "C" void fsh_view_coords_perturb_f64(const fsh_view *v, const fsh_orbit_f
 // Orbit: the floatOrDouble arms of AddPerturbationReferencePointST (RefOrbitCalc.cpp:481-488,524-530,564-604,617-622)
 // with T = float | double; table: LAReference<uint32_t,T,T,Disable> through the builder above with F = plain<T>.
 namespace {
-template <class T> void build_plain_orbit(const fsh_view &vw, uint64_t max_iter, int periodicity, PlainOrbit<T> &ob)
+// runOneIter for a plain T (PerturbationResultsHelpers.h:51-58; HdrReduce is the identity)
+template <class T> void rc_one_iter_plain(T &zx, T &zy, T cxLow, T cyLow)
+{
+    const T zx_old = zx;
+    zx = zx * zx - zy * zy + cxLow;
+    zy = T(2.0f) * zx_old * zy + cyLow;
+}
+
+// compression_exp >= 0: PerturbExtras::SimpleCompression through RefOrbitCompressor<IterType, T, SimpleCompression>
+// (PerturbationResults.cpp:2334-2381) in plain T arithmetic.
+template <class T>
+void build_plain_orbit(const fsh_view &vw, uint64_t max_iter, int periodicity, PlainOrbit<T> &ob, int compression_exp = -1)
 {
     mpf_set_default_prec(vw.prec_bits);
     {
@@ -2170,19 +2221,44 @@ template <class T> void build_plain_orbit(const fsh_view &vw, uint64_t max_iter,
     mpf_init(t2);
     T dzdcX = T(1), dzdcY = T(0);
     const T cx_cast = (T)mpf_get_d(cx), cy_cast = (T)mpf_get_d(cy);
+    ob.orbitXLow = cx_cast; // m_OrbitXLow = T{cx}, PerturbationResults.cpp:852-853
+    ob.orbitYLow = cy_cast;
+    ob.compressed = compression_exp >= 0;
+    ob.wp_index.assign(1, 0);
+    ob.wp_x.assign(1, T(0));
+    ob.wp_y.assign(1, T(0));
+    uint64_t count = 1; // m_UncompressedItersInOrbit
+    T rc_zx = ob.orbitXLow, rc_zy = ob.orbitYLow;
+    const T rc_err = static_cast<T>(std::pow(10, compression_exp));
     mpf_set(zx, cx);
     mpf_set(zy, cy);
     for (uint64_t i = 0; i < max_iter; i++) {
         mpf_mul_2exp(zx2, zx, 1);
         const T double_zx = (T)mpf_get_d(zx), double_zy = (T)mpf_get_d(zy);
-        ob.x.push_back(preal<T>{double_zx});
-        ob.y.push_back(preal<T>{double_zy});
+        if (!ob.compressed) {
+            ob.x.push_back(preal<T>{double_zx});
+            ob.y.push_back(preal<T>{double_zy});
+        } else {
+            // MaybeAddCompressedIteration({double_zx, double_zy, i + 1})
+            const T errX = rc_zx - double_zx, errY = rc_zy - double_zy;
+            const T norm_z = double_zx * double_zx + double_zy * double_zy;
+            const T err = (errX * errX + errY * errY) * rc_err;
+            if (err >= norm_z) {
+                ob.wp_index.push_back(i + 1);
+                ob.wp_x.push_back(double_zx);
+                ob.wp_y.push_back(double_zy);
+                rc_zx = double_zx;
+                rc_zy = double_zy;
+            }
+            rc_one_iter_plain(rc_zx, rc_zy, ob.orbitXLow, ob.orbitYLow);
+        }
+        count++;
         if (periodicity) {
             const T n2 = std::max(std::fabs(double_zx), std::fabs(double_zy));
             const T r0 = std::max(std::fabs(dzdcX), std::fabs(dzdcY));
             const T n3 = ob.maxRadius.m * r0 * T(2);
             if (n2 < n3) {
-                ob.period = ob.x.size();
+                ob.period = count;
                 break;
             } else {
                 const T dzdcXOrig = dzdcX;
@@ -2208,16 +2284,33 @@ template <class T> void build_plain_orbit(const fsh_view &vw, uint64_t max_iter,
     mpf_clear(zx2);
     mpf_clear(t1);
     mpf_clear(t2);
+    if (ob.compressed) {
+        // the orbit every host consumer (the LA builder) sees: RuntimeDecompressor::GetCompressedComplex
+        ob.x.assign(count, preal<T>{T(0)});
+        ob.y.assign(count, preal<T>{T(0)});
+        for (size_t k = 0; k < ob.wp_index.size(); k++) {
+            const uint64_t i0 = ob.wp_index[k];
+            const uint64_t i1 = k + 1 < ob.wp_index.size() ? ob.wp_index[k + 1] : count;
+            T zx_ = ob.wp_x[k], zy_ = ob.wp_y[k];
+            for (uint64_t i = i0; i < i1; i++) {
+                ob.x[i] = preal<T>{zx_};
+                ob.y[i] = preal<T>{zy_};
+                rc_one_iter_plain(zx_, zy_, ob.orbitXLow, ob.orbitYLow);
+            }
+        }
+    }
 }
 
 template <class T> struct plain_recs;
 template <> struct plain_recs<float> {
+    using orbit_rc = fs_orbit_f32_rc;
     using orbit = fs_orbit_f32;
     using la = fs_la_f32_u32;
     using at = fs_at_f32_u32;
     using cplx = fs_cplx_f32;
 };
 template <> struct plain_recs<double> {
+    using orbit_rc = fs_orbit_f64_rc;
     using orbit = fs_orbit_f64;
     using la = fs_la_f64_u32;
     using at = fs_at_f64_u32;
@@ -2228,16 +2321,22 @@ template <class T> struct PlainInputs {
     PlainOrbit<T> ob;
     LATable<plain<T>> t;
     std::vector<typename plain_recs<T>::orbit> orbit_packed;
+    std::vector<typename plain_recs<T>::orbit_rc> rc_packed; // GPUReferenceIter<T, SimpleCompression>[]
     std::vector<typename plain_recs<T>::la> la_packed;
     typename plain_recs<T>::at at_packed;
 
-    void build(const fsh_view &vw, uint64_t max_iter, int periodicity, int host_threads)
+    void build(const fsh_view &vw, uint64_t max_iter, int periodicity, int host_threads, int compression_exp)
     {
         using R = plain_recs<T>;
-        build_plain_orbit<T>(vw, max_iter, periodicity, ob);
+        build_plain_orbit<T>(vw, max_iter, periodicity, ob, compression_exp);
         orbit_packed.resize(ob.x.size());
         for (size_t i = 0; i < ob.x.size(); i++)
             orbit_packed[i] = typename R::orbit{ob.x[i].m, ob.y[i].m};
+        if (ob.compressed) {
+            rc_packed.resize(ob.wp_index.size());
+            for (size_t k = 0; k < ob.wp_index.size(); k++)
+                rc_packed[k] = typename R::orbit_rc{ob.wp_index[k], ob.wp_x[k], ob.wp_y[k]};
+        }
         LABuilder<plain<T>> b(ob, t);
         b.generate(host_threads < 1 ? 1 : host_threads);
         auto C = [](pcplx<T> c) { return typename R::cplx{c.re, c.im}; };
@@ -2281,17 +2380,22 @@ struct fsh_plain {
     PlainInputs<double> d;
 };
 
-extern "C" fsh_plain *fsh_plain_create(const fsh_view *v, int kind, uint64_t max_iter, int periodicity, int host_threads)
+extern "C" fsh_plain *fsh_plain_create_ex(const fsh_view *v, int kind, uint64_t max_iter, int periodicity, int host_threads,
+                                          int compression_exp)
 {
     if (kind != 0 && kind != 1)
         return nullptr;
     auto h = std::make_unique<fsh_plain>();
     h->kind = kind;
     if (kind == 0)
-        h->f.build(*v, max_iter, periodicity, host_threads);
+        h->f.build(*v, max_iter, periodicity, host_threads, compression_exp);
     else
-        h->d.build(*v, max_iter, periodicity, host_threads);
+        h->d.build(*v, max_iter, periodicity, host_threads, compression_exp);
     return h.release();
+}
+extern "C" fsh_plain *fsh_plain_create(const fsh_view *v, int kind, uint64_t max_iter, int periodicity, int host_threads)
+{
+    return fsh_plain_create_ex(v, kind, max_iter, periodicity, host_threads, -1);
 }
 extern "C" void fsh_plain_destroy(fsh_plain *h) { delete h; }
 extern "C" int fsh_plain_kind(const fsh_plain *h) { return h->kind; }
@@ -2301,6 +2405,25 @@ extern "C" uint64_t fsh_plain_orbit_period(const fsh_plain *h) { return FS_PLAIN
 extern "C" const void *fsh_plain_orbit_data(const fsh_plain *h)
 {
     return FS_PLAIN_GET((const void *)h->f.orbit_packed.data(), (const void *)h->d.orbit_packed.data());
+}
+extern "C" int fsh_plain_is_compressed(const fsh_plain *h) { return FS_PLAIN_GET(h->f.ob.compressed, h->d.ob.compressed) ? 1 : 0; }
+extern "C" uint64_t fsh_plain_compressed_count(const fsh_plain *h)
+{
+    return FS_PLAIN_GET(h->f.rc_packed.size(), h->d.rc_packed.size());
+}
+extern "C" const void *fsh_plain_compressed_data(const fsh_plain *h)
+{
+    return FS_PLAIN_GET((const void *)h->f.rc_packed.data(), (const void *)h->d.rc_packed.data());
+}
+extern "C" void fsh_plain_orbit_low(const fsh_plain *h, void *out)
+{
+    if (h->kind == 0) {
+        ((float *)out)[0] = h->f.ob.orbitXLow;
+        ((float *)out)[1] = h->f.ob.orbitYLow;
+    } else {
+        ((double *)out)[0] = h->d.ob.orbitXLow;
+        ((double *)out)[1] = h->d.ob.orbitYLow;
+    }
 }
 extern "C" uint32_t fsh_plain_la_count(const fsh_plain *h)
 {
@@ -2363,6 +2486,15 @@ fs_cplx_p2x32 cplx_p2x32(fs_cplx_f64 c)
 extern "C" void fsh_convert_orbit_f64_to_p2x32(const fs_orbit_f64 *in, uint64_t n, fs_orbit_p2x32 *out)
 {
     for (uint64_t i = 0; i < n; i++) {
+        df_from_double(in[i].x, out[i].x_head, out[i].x_tail);
+        df_from_double(in[i].y, out[i].y_head, out[i].y_tail);
+    }
+}
+// CopyFullOrbitVector's SimpleCompression arm (PerturbationResults.cpp:265-268): x, y converted, index kept
+extern "C" void fsh_convert_orbit_rc_f64_to_p2x32(const fs_orbit_f64_rc *in, uint64_t n, fs_orbit_p2x32_rc *out)
+{
+    for (uint64_t i = 0; i < n; i++) {
+        out[i].index_and_rebase = in[i].index_and_rebase & 0x7FFFFFFFFFFFFFFFull;
         df_from_double(in[i].x, out[i].x_head, out[i].x_tail);
         df_from_double(in[i].y, out[i].y_head, out[i].y_tail);
     }

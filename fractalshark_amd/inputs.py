@@ -34,7 +34,9 @@ REAL_2X32 = np.dtype([("head", "<f4"), ("tail", "<f4"), ("e", "<i4")])
 ORBIT_2X32_DTYPE = np.dtype([("x_head", "<f4"), ("x_tail", "<f4"), ("ex", "<i4"), ("ey", "<i4"),
                              ("y_head", "<f4"), ("y_tail", "<f4")])
 assert ORBIT_HDR64_DTYPE.itemsize == 32 and REAL_HDR64.itemsize == 16
-assert REAL_2X32.itemsize == 12 and ORBIT_2X32_DTYPE.itemsize == 24
+ORBIT_2X32_RC_DTYPE = np.dtype([("index", "<u8"), ("x_head", "<f4"), ("x_tail", "<f4"), ("ex", "<i4"), ("ey", "<i4"),
+                                ("y_head", "<f4"), ("y_tail", "<f4")])
+assert REAL_2X32.itemsize == 12 and ORBIT_2X32_DTYPE.itemsize == 24 and ORBIT_2X32_RC_DTYPE.itemsize == 32
 assert ORBIT_HDR32_DTYPE.itemsize == 16 and LA_HDR32_DTYPE.itemsize == 68 and BLA_HDR32_DTYPE.itemsize == 44
 
 
@@ -203,26 +205,51 @@ class Orbit:
 
 class Orbit2x32:
     """The HDRFloat<CudaDblflt> twin of an HDRFloat<double> orbit, converted entry by entry the way
-    PerturbationResults::CopyPerturbationResults does (PerturbationResults.cpp:239-347)."""
+    PerturbationResults::CopyPerturbationResults does (PerturbationResults.cpp:239-347).  From a SimpleCompression
+    source the waypoints are what is converted (:265-268); the full orbit then only exists on the GPU, where it is
+    rebuilt in 2x32 arithmetic."""
 
     is64 = False
-    compressed = False
 
     def __init__(self, orbit64):
         if not orbit64.is64:
             raise ValueError("the 2x32 orbit is derived from the HDRFloat<double> orbit")
-        lib = _capi.inputs_lib()
+        lib = self._lib = _capi.inputs_lib()
         self.source = orbit64
         self.view = orbit64.view
         self.count, self.period = orbit64.count, orbit64.period
-        self._data = np.zeros(self.count, ORBIT_2X32_DTYPE)
-        lib.fsh_convert_orbit_hdr64_to_2x32(orbit64.data_ptr, self.count, self._data.ctypes.data)
+        self.compressed = orbit64.compressed
+        if self.compressed:
+            self.compressed_count = orbit64.compressed_count
+            self._rc = np.zeros(self.compressed_count, ORBIT_2X32_RC_DTYPE)
+            lib.fsh_convert_orbit_rc_hdr64_to_2x32(orbit64.compressed_data_ptr, self.compressed_count,
+                                                   self._rc.ctypes.data)
+            self._data = None
+        else:
+            self._data = np.zeros(self.count, ORBIT_2X32_DTYPE)
+            lib.fsh_convert_orbit_hdr64_to_2x32(orbit64.data_ptr, self.count, self._data.ctypes.data)
 
     @property
     def data_ptr(self):
+        if self._data is None:
+            raise ValueError("a SimpleCompression 2x32 orbit has no host-side uncompressed form")
         return self._data.ctypes.data
 
+    @property
+    def compressed_data_ptr(self):
+        return self._rc.ctypes.data
+
+    def waypoints(self):
+        return self._rc.copy()
+
+    def orbit_low(self):
+        out = np.zeros(2, REAL_2X32)
+        self._lib.fsh_orbit_low_2x32(self.source._h, out.ctypes.data)
+        return out
+
     def entries(self):
+        if self._data is None:
+            raise ValueError("a SimpleCompression 2x32 orbit has no host-side uncompressed form")
         return self._data.copy()
 
 
@@ -457,13 +484,18 @@ class PlainInputs:
     (Gpu1x32PerturbedLAv2*); "f64": the same in binary64 (Gpu1x64PerturbedLAv2*); "2x32": the binary64 inputs converted
     field by field to CudaDblflt<MattDblflt> (Gpu2x32PerturbedLAv2*, Fractal.cpp:2771-2772)."""
 
-    def __init__(self, view, kind, host_threads=1, periodicity=True, max_iter=None):
+    def __init__(self, view, kind, host_threads=1, periodicity=True, max_iter=None, compression_exp=None):
+        """compression_exp: None = PerturbExtras::Disable; an int (reference default 20) = SimpleCompression (the
+        Gpu*PerturbedRCLAv2* algorithms): `waypoints()` is then what is uploaded, `orbit()` what the host's
+        RuntimeDecompressor makes of it (for "2x32": of the binary64 source; the GPU rebuilds its own in 2x32)."""
         assert kind in ("f32", "f64", "2x32")
         lib = self._lib = _capi.inputs_lib()
         self.view, self.kind = view, kind
-        self._h = lib.fsh_plain_create(view._h, 0 if kind == "f32" else 1,
-                                       view.num_iterations if max_iter is None else max_iter,
-                                       1 if periodicity else 0, host_threads)
+        self.compressed = compression_exp is not None
+        self._h = lib.fsh_plain_create_ex(view._h, 0 if kind == "f32" else 1,
+                                          view.num_iterations if max_iter is None else max_iter,
+                                          1 if periodicity else 0, host_threads,
+                                          -1 if compression_exp is None else int(compression_exp))
         if not self._h:
             raise RuntimeError("fsh_plain_create failed")
         src_kind = "f32" if kind == "f32" else "f64"
@@ -489,6 +521,20 @@ class PlainInputs:
         aa = view.antialiasing
         coords = np.zeros(4, real_dt)
         lib.fsh_plain_coords(view._h, self._h, view.width * aa, view.height * aa, coords.ctypes.data)
+        if self.compressed:
+            self.compressed_count = int(lib.fsh_plain_compressed_count(self._h))
+            rc_dt = np.dtype([("index", "<u8")] + [(n, o_dt.fields[n][0]) for n in o_dt.names])
+            rc = grab(lib.fsh_plain_compressed_data(self._h), self.compressed_count, rc_dt)
+            low = np.zeros(4, real_dt)  # {OrbitXLow, OrbitYLow, -, -}
+            lib.fsh_plain_orbit_low(self._h, low.ctypes.data)
+            if kind == "2x32":
+                o2 = _plain_dtypes("2x32")[0]
+                self._rc = np.zeros(self.compressed_count, np.dtype([("index", "<u8")] + [(n, "<f4") for n in o2.names]))
+                lib.fsh_convert_orbit_rc_f64_to_p2x32(rc.ctypes.data, self.compressed_count, self._rc.ctypes.data)
+                self._low = np.zeros(4, _plain_dtypes("2x32")[3])
+                lib.fsh_convert_coords_f64_to_p2x32(low.ctypes.data, self._low.ctypes.data)
+            else:
+                self._rc, self._low = rc, low
         if kind == "2x32":
             o2, la2, at2, real2 = _plain_dtypes("2x32")
             self._orbit = np.zeros(self.count, o2)
@@ -512,6 +558,14 @@ class PlainInputs:
     stages_ptr = property(lambda self: self._stages.ctypes.data if self.stage_count else None)
     at_ptr = property(lambda self: self._at.ctypes.data)
     coords_ptr = property(lambda self: self._coords.ctypes.data)
+    compressed_data_ptr = property(lambda self: self._rc.ctypes.data)
+
+    def waypoints(self):
+        return self._rc.copy()
+
+    def orbit_low(self):
+        """{OrbitXLow, OrbitYLow} in the type of `kind`."""
+        return self._low[:2].copy()
 
     def orbit(self):
         return self._orbit.copy()

@@ -125,8 +125,14 @@ class GPURenderer:
         """InitializePerturb<IterType, T, T, Disable, T> for a non-HDR T: plain = inputs.PlainInputs (kind f32 -> float,
         f64 -> double, 2x32 -> CudaDblflt<MattDblflt>), i.e. the inputs of Gpu1x32 / Gpu1x64 / Gpu2x32 PerturbedLAv2*."""
         T = {"f32": T_F32, "f64": T_F64, "2x32": T_2X32}[plain.kind]
-        err = self._lib.fs_upload_orbit(self._h, GenerationNumber1, T, 4, plain.orbit_ptr, plain.count, plain.count,
-                                        plain.period)
+        if getattr(plain, "compressed", False):  # PerturbExtras::SimpleCompression: Gpu*PerturbedRCLAv2*
+            low = plain.orbit_low()
+            err = self._lib.fs_upload_orbit_compressed(self._h, GenerationNumber1, T, 4, plain.compressed_data_ptr,
+                                                       plain.compressed_count, plain.count, plain.period,
+                                                       low[0:1].ctypes.data, low[1:2].ctypes.data)
+        else:
+            err = self._lib.fs_upload_orbit(self._h, GenerationNumber1, T, 4, plain.orbit_ptr, plain.count, plain.count,
+                                            plain.period)
         if err or not with_la:
             return err
         return self._lib.fs_upload_la(self._h, GenerationNumber1, T, 4, plain.las_ptr, plain.la_count,

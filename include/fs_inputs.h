@@ -79,6 +79,10 @@ void fsh_view_coords_perturb_hdr64(const fsh_view *v, const fsh_orbit *o, uint32
  * table by field-wise conversion (PerturbationResults::CopyPerturbationResults, LAReference::CopyLAReference);
  * these restate that conversion.  Coordinates come straight from the high-precision view (orbit must be hdr64). */
 void fsh_convert_orbit_hdr64_to_2x32(const fs_orbit_hdr64 *in, uint64_t n, fs_orbit_2x32 *out);
+/* SimpleCompression form: waypoints converted, indices kept (CopyFullOrbitVector, PerturbationResults.cpp:265-268);
+ * out[2] = {OrbitXLow, OrbitYLow} of the converted results (the double cast of the reference point). */
+void fsh_convert_orbit_rc_hdr64_to_2x32(const fs_orbit_hdr64_rc *in, uint64_t n, fs_orbit_2x32_rc *out);
+void fsh_orbit_low_2x32(const fsh_orbit *o, fs_real_2x32 out[2]);
 void fsh_convert_la_hdr64_to_2x32(const fs_la_hdr64_u32 *in, uint64_t n, fs_la_2x32_u32 *out);
 void fsh_convert_at_hdr64_to_2x32(const fs_at_hdr64_u32 *in, fs_at_2x32_u32 *out);
 /* out = {dx, dy, centerX, centerY}; mantissas in [0.5,1), not reduced (FillCoord, Fractal.cpp:1826-1832). */
@@ -141,6 +145,14 @@ void fsh_view_coords_perturb_f64(const fsh_view *v, const fsh_orbit_f64 *o, uint
  * Gpu2x32PerturbedLAv2* inputs, which FractalShark converts field-wise from the double ones). */
 typedef struct fsh_plain fsh_plain;
 fsh_plain *fsh_plain_create(const fsh_view *v, int kind, uint64_t max_iter, int periodicity, int host_threads);
+/* compression_exp >= 0: PerturbExtras::SimpleCompression (see fsh_orbit_create_ex); the LA table is then built from
+ * the orbit as RuntimeDecompressor reproduces it, with the SimpleCompression period divisor. */
+fsh_plain *fsh_plain_create_ex(const fsh_view *v, int kind, uint64_t max_iter, int periodicity, int host_threads,
+                               int compression_exp);
+int fsh_plain_is_compressed(const fsh_plain *h);
+uint64_t fsh_plain_compressed_count(const fsh_plain *h);
+const void *fsh_plain_compressed_data(const fsh_plain *h); /* fs_orbit_f32_rc[] / fs_orbit_f64_rc[] */
+void fsh_plain_orbit_low(const fsh_plain *h, void *out);   /* {OrbitXLow, OrbitYLow}: float[2] / double[2] */
 void fsh_plain_destroy(fsh_plain *h);
 int fsh_plain_kind(const fsh_plain *h);
 uint64_t fsh_plain_orbit_count(const fsh_plain *h);
@@ -156,6 +168,7 @@ void fsh_plain_la_at(const fsh_plain *h, void *out);  /* fs_at_f32_u32 / fs_at_f
 /* out = {dx, dy, centerX, centerY}: float[4] (kind 0) or double[4] (kind 1) */
 void fsh_plain_coords(const fsh_view *v, const fsh_plain *h, uint32_t w_aa, uint32_t h_aa, void *out);
 void fsh_convert_orbit_f64_to_p2x32(const fs_orbit_f64 *in, uint64_t n, fs_orbit_p2x32 *out);
+void fsh_convert_orbit_rc_f64_to_p2x32(const fs_orbit_f64_rc *in, uint64_t n, fs_orbit_p2x32_rc *out);
 void fsh_convert_la_f64_to_p2x32(const fs_la_f64_u32 *in, uint64_t n, fs_la_p2x32_u32 *out);
 void fsh_convert_at_f64_to_p2x32(const fs_at_f64_u32 *in, fs_at_p2x32_u32 *out);
 void fsh_convert_coords_f64_to_p2x32(const double in[4], fs_real_p2x32 out[4]);

@@ -337,6 +337,38 @@ typedef struct fs_orbit_p2x32 {
     float y_tail;
 } fs_orbit_p2x32;
 
+/* GPUReferenceIter<T, PerturbExtras::SimpleCompression> for the non-HDR types and for HDRFloat<CudaDblflt>: the
+ * CompressionIndexField base first (GPU_ReferenceIter.h:26-49), then x, y. */
+typedef struct fs_orbit_f32_rc {
+    uint64_t index_and_rebase;
+    float x;
+    float y;
+} fs_orbit_f32_rc;
+
+typedef struct fs_orbit_f64_rc {
+    uint64_t index_and_rebase;
+    double x;
+    double y;
+} fs_orbit_f64_rc;
+
+typedef struct fs_orbit_p2x32_rc {
+    uint64_t index_and_rebase;
+    float x_head;
+    float x_tail;
+    float y_head;
+    float y_tail;
+} fs_orbit_p2x32_rc;
+
+typedef struct fs_orbit_2x32_rc {
+    uint64_t index_and_rebase;
+    float x_head;
+    float x_tail;
+    int32_t ex;
+    int32_t ey;
+    float y_head;
+    float y_tail;
+} fs_orbit_2x32_rc;
+
 typedef struct fs_cplx_f32 {
     float re;
     float im;
@@ -412,6 +444,9 @@ typedef struct fs_reduction {
 }
 static_assert(sizeof(fs_orbit_hdr32) == 16, "orbit entry");
 static_assert(sizeof(fs_orbit_hdr32_rc) == 24 && sizeof(fs_orbit_hdr64_rc) == 40, "compressed orbit entry");
+static_assert(sizeof(fs_orbit_f32_rc) == 16 && sizeof(fs_orbit_f64_rc) == 24 && sizeof(fs_orbit_p2x32_rc) == 24 &&
+                  sizeof(fs_orbit_2x32_rc) == 32,
+              "compressed orbit entry");
 static_assert(sizeof(fs_orbit_hdr64) == 32, "orbit entry (double)");
 static_assert(sizeof(fs_orbit_hdr32_bad) == 24 && sizeof(fs_orbit_f32_bad) == 16 && sizeof(fs_orbit_f64_bad) == 24,
               "PerturbExtras::Bad orbit entries");

@@ -110,9 +110,11 @@ uint32_t fs_upload_orbit(fs_renderer *r, uint64_t generation, int type_tag, uint
                          const void *entries, uint64_t orbit_size, uint64_t uncompressed_size,
                          uint64_t period_maybe_zero);
 /* The same for PerturbExtras::SimpleCompression orbits: `entries` = GPUReferenceIter<T, SimpleCompression>[compressed_size]
- * (fs_orbit_hdr32_rc), orbit_x_low / orbit_y_low = GPUPerturbResults::OrbitXLow / OrbitYLow (the constant c of the runtime
- * decompressor, Perturb.cuh:300-326).  The orbit is expanded once on the device; all render calls then behave exactly as
- * the reference's *RC* algorithms (bit-identical to its CPU RuntimeDecompressor). */
+ * (fs_orbit_hdr32_rc / _hdr64_rc / _f32_rc / _f64_rc / _p2x32_rc / _2x32_rc by type_tag), orbit_x_low / orbit_y_low =
+ * GPUPerturbResults::OrbitXLow / OrbitYLow in the same numeric type (fs_real_hdr32 / fs_real_hdr64 / float / double /
+ * fs_real_p2x32 / fs_real_2x32): the constant c of the runtime decompressor, Perturb.cuh:272-326.  The orbit is expanded
+ * once on the device, in T arithmetic; all render calls then behave exactly as the reference's *RC* algorithms (for
+ * HDRFloat<float|double>, float and double bit-identical to its CPU RuntimeDecompressor too).  All six numeric types. */
 uint32_t fs_upload_orbit_compressed(fs_renderer *r, uint64_t generation, int type_tag, uint32_t iter_bytes,
                                     const void *entries, uint64_t compressed_size, uint64_t uncompressed_size,
                                     uint64_t period_maybe_zero, const void *orbit_x_low, const void *orbit_y_low);

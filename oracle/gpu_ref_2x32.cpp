@@ -482,4 +482,52 @@ void orc_gpu_lav2_2x32(uint32_t *out, uint32_t pitch, uint32_t width, uint32_t y
     }
 }
 
+
+// PerturbExtras::SimpleCompression orbits as the reference's *RC* kernels see them, entry by entry:
+// GPUPerturbSingleResults::GetCompressedComplexSeq (Perturb.cuh:300-326) walked from index 0 -- the next waypoint when
+// its CompressionIndex is reached, otherwise z <- z*z + OrbitLow in the kernel's number type (Type{2} * zx_old * zy).
+void orc_decompress_p2x32(const fs_orbit_p2x32_rc *wp, uint64_t n_wp, uint64_t n_uncompressed, const fs_real_p2x32 low[2],
+                          fs_orbit_p2x32 *out)
+{
+    const DF cx{low[0].head, low[0].tail}, cy{low[1].head, low[1].tail};
+    const DF two = DFFromFloat(2.0f);
+    DF zx = DFZero(), zy = DFZero();
+    uint64_t next = 0;
+    for (uint64_t i = 0; i < n_uncompressed; i++) {
+        if (next < n_wp && (wp[next].index_and_rebase & 0x7FFFFFFFFFFFFFFFull) == i) {
+            zx = DF{wp[next].x_head, wp[next].x_tail};
+            zy = DF{wp[next].y_head, wp[next].y_tail};
+            next++;
+        } else {
+            const DF zx_old = zx;
+            zx = DFAdd(DFSub(DFMul(zx, zx), DFMul(zy, zy)), cx);
+            zy = DFAdd(DFMul(DFMul(two, zx_old), zy), cy);
+        }
+        out[i] = fs_orbit_p2x32{zx.head, zx.tail, zy.head, zy.tail};
+    }
+}
+
+void orc_decompress_hdr2x32(const fs_orbit_2x32_rc *wp, uint64_t n_wp, uint64_t n_uncompressed, const fs_real_2x32 low[2],
+                            fs_orbit_2x32 *out)
+{
+    const H2 cx = RealOf(low[0]), cy = RealOf(low[1]);
+    const H2 two = H2FromInt(2);
+    H2 zx = H2Zero(), zy = H2Zero();
+    uint64_t next = 0;
+    for (uint64_t i = 0; i < n_uncompressed; i++) {
+        if (next < n_wp && (wp[next].index_and_rebase & 0x7FFFFFFFFFFFFFFFull) == i) {
+            zx = H2{DF{wp[next].x_head, wp[next].x_tail}, wp[next].ex};
+            zy = H2{DF{wp[next].y_head, wp[next].y_tail}, wp[next].ey};
+            next++;
+        } else {
+            const H2 zx_old = zx;
+            zx = H2Add(H2Sub(H2Mul(zx, zx), H2Mul(zy, zy)), cx);
+            H2Reduce(zx);
+            zy = H2Add(H2Mul(H2Mul(two, zx_old), zy), cy);
+            H2Reduce(zy);
+        }
+        out[i] = fs_orbit_2x32{zx.m.head, zx.m.tail, zx.e, zy.e, zy.m.head, zy.m.tail};
+    }
+}
+
 } // extern "C"

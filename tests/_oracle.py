@@ -170,15 +170,43 @@ def lav2_hdr32(view, orbit, la, aa=1, rows=None, threads=8, stage_test=0, mode=0
     return out
 
 
-def gpu_lav2_2x32(view, orbit2, la2, aa=1, rows=None, threads=8, mode=0, n_iterations=None, stats=False):
+def decompress_hdr2x32(orbit2):
+    """The full orbit the reference's GPU rebuilds from a SimpleCompression HDRFloat<CudaDblflt> waypoint list
+    (GetCompressedComplexSeq in 2x32 arithmetic, oracle/gpu_ref_2x32.cpp).  orbit2: a compressed inputs.Orbit2x32."""
+    from fractalshark_amd.inputs import ORBIT_2X32_DTYPE
+    wp, low = orbit2.waypoints(), orbit2.orbit_low()
+    out = np.zeros(orbit2.count, ORBIT_2X32_DTYPE)
+    fn = lib().orc_decompress_hdr2x32
+    fn.restype, fn.argtypes = None, [C.c_void_p, u64, u64, C.c_void_p, C.c_void_p]
+    fn(wp.ctypes.data, len(wp), orbit2.count, low.ctypes.data, out.ctypes.data)
+    return out
+
+
+def decompress_p2x32(pin):
+    """The same for CudaDblflt (Gpu2x32PerturbedRCLAv2*).  pin: a compressed inputs.PlainInputs of kind "2x32"."""
+    wp, low = pin.waypoints(), pin.orbit_low()
+    out = np.zeros(pin.count, pin._orbit.dtype)
+    fn = lib().orc_decompress_p2x32
+    fn.restype, fn.argtypes = None, [C.c_void_p, u64, u64, C.c_void_p, C.c_void_p]
+    fn(wp.ctypes.data, len(wp), pin.count, low.ctypes.data, out.ctypes.data)
+    return out
+
+
+def gpu_lav2_2x32(view, orbit2, la2, aa=1, rows=None, threads=8, mode=0, n_iterations=None, stats=False,
+                  orbit_entries=None):
     """Restated CUDA kernel mandel_1xHDR_float_perturb_lav2<.., HDRFloat<CudaDblflt>, ..> (oracle/gpu_ref_2x32.cpp).
-    orbit2: inputs.Orbit2x32; la2: inputs.LATable2x32 or None (mode 1 = perturbation only)."""
+    orbit2: inputs.Orbit2x32; la2: inputs.LATable2x32 or None (mode 1 = perturbation only).  orbit_entries: the
+    uncompressed entries to use instead of orbit2's own (decompress_hdr2x32 for a SimpleCompression orbit)."""
     w, h = view.width * aa, view.height * aa
     out = new_buffer(w, h)
     co = view.coords_perturb_2x32(orbit2, aa)
     y0, y1 = rows if rows else (0, h)
     n = view.num_iterations if n_iterations is None else n_iterations
     st = (u64 * 3)()
+    if orbit_entries is not None:
+        class _O:
+            data_ptr, count = orbit_entries.ctypes.data, len(orbit_entries)
+        orbit2 = _O
     if la2 is not None:
         lib().orc_gpu_lav2_2x32(out.ctypes.data, out.shape[1], w, y0, y1, orbit2.data_ptr, orbit2.count, la2.las_ptr,
                                 la2.stages_ptr, la2.stage_count, 1 if la2.is_valid else 0, 1 if la2.use_at else 0,
@@ -191,7 +219,7 @@ def gpu_lav2_2x32(view, orbit2, la2, aa=1, rows=None, threads=8, mode=0, n_itera
     return out
 
 
-def gpu_lav2_plain(view, pin, aa=1, rows=None, threads=8, mode=0, n_iterations=None, stats=False):
+def gpu_lav2_plain(view, pin, aa=1, rows=None, threads=8, mode=0, n_iterations=None, stats=False, orbit_entries=None):
     """Restated CUDA kernel mandel_1xHDR_float_perturb_lav2<.., T, T, ..> for T = float / double / CudaDblflt
     (oracle/gpu_ref_plain.cpp).  pin: inputs.PlainInputs (its kind selects T); mode 0 Full, 1 PO, 2 LAO."""
     w, h = view.width * aa, view.height * aa
@@ -200,7 +228,8 @@ def gpu_lav2_plain(view, pin, aa=1, rows=None, threads=8, mode=0, n_iterations=N
     n = view.num_iterations if n_iterations is None else n_iterations
     st = (u64 * 3)()
     kind = {"f32": 0, "f64": 1, "2x32": 2}[pin.kind]
-    lib().orc_gpu_lav2_plain(kind, out.ctypes.data, out.shape[1], w, y0, y1, pin.orbit_ptr, pin.count, pin.las_ptr,
+    orbit_ptr = pin.orbit_ptr if orbit_entries is None else orbit_entries.ctypes.data
+    lib().orc_gpu_lav2_plain(kind, out.ctypes.data, out.shape[1], w, y0, y1, orbit_ptr, pin.count, pin.las_ptr,
                              pin.stages_ptr, pin.stage_count, 1 if pin.is_valid else 0, 1 if pin.use_at else 0,
                              pin.at_ptr, pin.coords_ptr, n, mode, threads, st)
     if stats:

@@ -223,6 +223,19 @@ FS_INST_PLAIN(double, uint32_t);
 FS_INST_PLAIN(P2x32, uint32_t);
 FS_INST_PLAIN(float, uint64_t);
 #undef FS_INST_PLAIN
+// ... and their SimpleCompression forms (Gpu1x32 / Gpu1x64 / Gpu2x32 / GpuHDRx2x32 PerturbedRCLAv2*)
+#define FS_INST_RC(T, S)                                                                                                \
+    template uint32_t GPURenderer::InitializePerturb<uint32_t, T, S, PerturbExtras::SimpleCompression, T>(              \
+        size_t, const GPUPerturbResults<uint32_t, T, PerturbExtras::SimpleCompression> *, size_t,                       \
+        const GPUPerturbResults<uint32_t, T, PerturbExtras::SimpleCompression> *,                                       \
+        const LAReference<uint32_t, T, S, PerturbExtras::SimpleCompression> *);                                         \
+    template uint32_t GPURenderer::RenderPerturbLAv2<uint32_t, T, S, LAv2Mode::Full, PerturbExtras::SimpleCompression>( \
+        RenderAlgorithm, T, T, T, T, T, T, uint32_t)
+FS_INST_RC(float, float);
+FS_INST_RC(double, double);
+FS_INST_RC(P2x32, P2x32);
+FS_INST_RC(HDR2x32, P2x32);
+#undef FS_INST_RC
 template uint32_t GPURenderer::RenderPerturbBLAScaled<uint32_t, HDR32>(
     RenderAlgorithm, const GPUPerturbResults<uint32_t, HDR32, PerturbExtras::Bad> *,
     const GPUPerturbResults<uint32_t, float, PerturbExtras::Bad> *, HDR32, HDR32, HDR32, HDR32, HDR32, HDR32, uint32_t, int);

@@ -734,3 +734,50 @@ def test_three_variants_agree_on_other_views(renderer, native_libs, view_n):
     finally:
         renderer.set_kernel_variant(0)
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
+# ---- PerturbExtras::SimpleCompression for the remaining numeric types (Gpu1x32 / Gpu1x64 / Gpu2x32 / GpuHDRx2x32
+# PerturbedRCLAv2*): waypoints are expanded on the device in the kernel's own arithmetic (kernels_decompress.hip)
+@pytest.mark.parametrize("kind,width,cexp", [("f32", "1e-6", 10), ("f64", "1e-12", 20), ("f64", "1e-28", 20),
+                                             ("2x32", "1e-12", 20), ("2x32", "1e-20", 16)])
+def test_plain_simple_compression_parity(renderer, native_libs, kind, width, cexp):
+    from test_plain_oracle import shallow_view
+    v = shallow_view(width)
+    pin = inputs.PlainInputs(v, kind, compression_exp=cexp)
+    assert pin.compressed and 1 < pin.compressed_count < pin.count
+    # what the reference's kernel rebuilds: for float / double the host RuntimeDecompressor's orbit, for CudaDblflt the
+    # double-float rebuild of the converted waypoints
+    full = _oracle.decompress_p2x32(pin) if kind == "2x32" else pin.orbit()
+    for mode, omode in ((LAV2_FULL, 0), (LAV2_PO, 1), (LAV2_LAO, 2)):
+        out, red = _render_plain(renderer, v, pin, mode)
+        ref = _oracle.gpu_lav2_plain(v, pin, mode=omode, orbit_entries=full)
+        assert np.array_equal(out, ref), (kind, width, mode, int((out != ref).sum()))
+        assert red.Sum == int(ref[:36, :64].astype(np.uint64).sum())
+    # the compressed upload is a different orbit from the uncompressed one (last bits), and the frames can tell
+    if kind == "f32":
+        u = inputs.PlainInputs(v, kind)
+        assert not np.array_equal(u.orbit()["x"], full["x"])
+
+
+@pytest.mark.parametrize("view_n", [5, 14])
+def test_hdr2x32_simple_compression_parity(renderer, native_libs, view_n):
+    v = inputs.View.builtin(view_n, 64, 36, antialiasing=1)
+    o = inputs.Orbit(v, is64=True, compression_exp=20)
+    la = inputs.LATable(o, use_small_exponents=True)
+    o2, la2 = inputs.Orbit2x32(o), inputs.LATable2x32(la)
+    assert o2.compressed and o2.compressed_count < o2.count
+    full = _oracle.decompress_hdr2x32(o2)
+    out, _ = _render_2x32(renderer, v, o2, la2, LAV2_FULL)
+    ref = _oracle.gpu_lav2_2x32(v, o2, la2, mode=0, orbit_entries=full)
+    assert np.array_equal(out, ref)
+    assert len(np.unique(out[:36, :64])) > 16
+
+
+def test_compressed_upload_rejects_missing_constants(renderer, native_libs):
+    from test_plain_oracle import shallow_view
+    from fractalshark_amd import T_F32
+    pin = inputs.PlainInputs(shallow_view("1e-6"), "f32", compression_exp=10)
+    assert renderer.InitializeMemory(64, 36, 1, None, 0, 0, 0, False) == 0
+    e = renderer._lib.fs_upload_orbit_compressed(renderer._h, 0, T_F32, 4, pin.compressed_data_ptr, pin.compressed_count,
+                                                 pin.count, pin.period, None, None)
+    assert e != 0

@@ -111,3 +111,82 @@ def test_2x32_at_validity_uses_the_reference_operator_as_written(native_libs):
     _, s64 = _oracle.gpu_lav2_plain(v, p64, mode=2, stats=True)
     _, s2 = _oracle.gpu_lav2_plain(v, p2, mode=2, stats=True)
     assert s64["at_iterations"] <= 4 and s2["at_iterations"] >= 2000
+
+
+# ---- PerturbExtras::SimpleCompression for the non-HDR types (Gpu1x32 / Gpu1x64 / Gpu2x32 PerturbedRCLAv2*)
+@pytest.mark.parametrize("width", ["1e-6", "1e-12", "1e-20"])
+def test_plain_double_compression_equals_the_pinned_hdr64_compression(native_libs, width):
+    """The HDRFloat<double> compressor / RuntimeDecompressor chain is pinned by a golden CRC (Cpu64PerturbedRCBLAV2HDR);
+    in binary64 range the plain-double chain must pick the same waypoints and rebuild the same orbit."""
+    v = shallow_view(width)
+    p = inputs.PlainInputs(v, "f64", compression_exp=20)
+    o = inputs.Orbit(v, is64=True, compression_exp=20)
+    assert p.compressed and p.count == o.count and p.period == o.period
+    assert 1 < p.compressed_count == o.compressed_count < p.count
+    wp = p.waypoints()
+    assert wp["index"][0] == 0 and wp["x"][0] == 0 and wp["y"][0] == 0 and (np.diff(wp["index"].astype(np.int64)) > 0).all()
+    e, po = o.entries(), p.orbit()
+    assert np.array_equal(np.ldexp(e["mx"], e["ex"]), po["x"]) and np.array_equal(np.ldexp(e["my"], e["ey"]), po["y"])
+    # waypoints are orbit entries; everything between them is rebuilt
+    assert np.array_equal(po["x"][wp["index"]], wp["x"]) and np.array_equal(po["y"][wp["index"]], wp["y"])
+    u = inputs.PlainInputs(v, "f64").orbit()
+    assert np.array_equal(u["x"][wp["index"]], wp["x"])
+    err2 = (po["x"] - u["x"]) ** 2 + (po["y"] - u["y"]) ** 2
+    assert (err2[1:] * 1e20 <= (u["x"] ** 2 + u["y"] ** 2)[1:] * 1.001).all()  # the compressor's own bound
+    assert (err2 > 0).any()
+
+
+def test_plain_float_compression_bound_and_table(native_libs):
+    v = shallow_view("1e-6")
+    # binary32 carries ~7 digits: an error bound of 10^-(exp/2) = 1e-5 relative is the tightest that still compresses
+    p = inputs.PlainInputs(v, "f32", compression_exp=10)
+    u = inputs.PlainInputs(v, "f32")
+    assert 1 < p.compressed_count < p.count == u.count
+    po, uo, wp = p.orbit(), u.orbit(), p.waypoints()
+    assert wp.dtype.itemsize == 16
+    assert np.array_equal(uo["x"][wp["index"]], wp["x"]) and np.array_equal(po["y"][wp["index"]], wp["y"])
+    err2 = (po["x"].astype(np.float64) - uo["x"]) ** 2 + (po["y"].astype(np.float64) - uo["y"]) ** 2
+    assert (err2[1:] * 1e10 <= (uo["x"].astype(np.float64) ** 2 + uo["y"].astype(np.float64) ** 2)[1:] * 1.01).all()
+    # LAReference over a SimpleCompression orbit uses period divisor 8 instead of 2 (LAReference.cpp:12-19)
+    assert p.is_valid and p.la_count > 0
+    low = p.orbit_low()
+    assert low.dtype == np.float32 and abs(float(low[0]) + 0.5482057) < 1e-6
+
+
+def test_2x32_compressed_orbit_is_rebuilt_in_2x32_arithmetic(native_libs):
+    """CudaDblflt waypoints are the converted binary64 ones (CopyFullOrbitVector); the GPU-side rebuild runs in
+    double-float arithmetic, so it tracks -- but is not -- the converted binary64 rebuild."""
+    v = shallow_view("1e-12")
+    p2 = inputs.PlainInputs(v, "2x32", compression_exp=20)
+    p64 = inputs.PlainInputs(v, "f64", compression_exp=20)
+    wp2, wp64 = p2.waypoints(), p64.waypoints()
+    assert wp2.dtype.itemsize == 24 and np.array_equal(wp2["index"], wp64["index"])
+    assert np.array_equal(np.float32(wp64["x"]), wp2["x_head"])
+    full = _oracle.decompress_p2x32(p2)
+    assert np.array_equal(full["x_head"][wp2["index"]], wp2["x_head"])
+    assert np.array_equal(full["y_tail"][wp2["index"]], wp2["y_tail"])
+    x = full["x_head"].astype(np.float64) + full["x_tail"]
+    ref = p64.orbit()["x"]
+    big = np.abs(ref) > 1e-3
+    rel = np.abs(x - ref)[big] / np.abs(ref)[big]
+    assert rel.max() < 1e-8 and (x != ref).any()
+
+
+def test_hdr2x32_compressed_orbit_is_rebuilt_in_2x32_arithmetic(native_libs):
+    v = inputs.View.builtin(5, 64, 36)
+    o = inputs.Orbit(v, is64=True, compression_exp=20)
+    o2 = inputs.Orbit2x32(o)
+    assert o2.compressed and o2.compressed_count == o.compressed_count
+    wp = o2.waypoints()
+    assert wp.dtype.itemsize == 32 and wp["index"][0] == 0
+    low = o2.orbit_low()
+    # HDRFloat<CudaDblflt>(double): mantissa in [1, 2) (HDRFloat.h:341-349)
+    assert 1.0 <= abs(float(low["head"][0])) < 2.0 and int(low["e"][0]) == -1
+    assert abs((float(low["head"][0]) + float(low["tail"][0])) * 0.5 + 0.548205748070475708) < 1e-13
+    full = _oracle.decompress_hdr2x32(o2)
+    assert np.array_equal(full["x_head"][wp["index"]], wp["x_head"]) and np.array_equal(full["ey"][wp["index"]], wp["ey"])
+    e = o.entries()
+    x = np.ldexp(full["x_head"].astype(np.float64) + full["x_tail"], full["ex"])
+    ref = np.ldexp(e["mx"], e["ex"])
+    big = np.abs(ref) > 1e-3
+    assert (np.abs(x - ref)[big] / np.abs(ref)[big]).max() < 1e-8
