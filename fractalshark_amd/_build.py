@@ -41,7 +41,10 @@ def build_render(force=False):
     if not force and _newer(LIB_RENDER, srcs):
         return LIB_RENDER
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    _run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+    # FS_PROFILE_CYCLES=1: the instrumented (step-counting) kernel variants also report shader-clock cycles per phase
+    # (tools/cycle_probe.py); never set for the product build
+    extra = ["-DFS_PROFILE_CYCLES"] if os.environ.get("FS_PROFILE_CYCLES") == "1" else []
+    _run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", *extra,
           "-o", LIB_RENDER, os.path.join(CSRC, "kernels.hip"), os.path.join(CSRC, "kernels_2x32.hip"),
           os.path.join(CSRC, "kernels_scaled.hip"), os.path.join(CSRC, "kernels_tables.hip"),
           os.path.join(CSRC, "kernels_direct_lp.hip"), os.path.join(CSRC, "kernels_plain.hip"), os.path.join(CSRC, "kernels_decompress.hip"),

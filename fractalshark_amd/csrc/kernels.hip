@@ -366,6 +366,12 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
     tile_pixel(X, L);
     uint64_t c_at = 0, c_la = 0, c_pt = 0, c_px = 0;
     uint64_t c_careful = 0, c_scaled = 0, c_runs = 0;
+#ifdef FS_PROFILE_CYCLES
+    uint64_t cyc_loop = 0, cyc_run = 0, cyc_body = 0, cyc_t0 = 0, cyc_t1 = 0, cyc_t2 = 0;
+#define FS_CYC(stmt) do { if (kStats) { stmt; } } while (0)
+#else
+#define FS_CYC(stmt) do { } while (0)
+#endif
     const uint32_t Y = global_row(A.frame, L);
     const bool live = X < A.frame.width && L < A.frame.local_rows && Y < A.frame.height;
     if (live) {
@@ -489,6 +495,7 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
             // (zq[i].z, written by k_make_quiet_orbit).
             const float4 *__restrict__ zq = A.zq;
             const float4 *__restrict__ zs = A.zs;
+            FS_CYC(cyc_t0 = __builtin_readcyclecounter());
             while (running) {
                 // ---- run of "scaled" quiet steps.  HDRFloat addition and multiplication are the correctly rounded binary32
                 // operations on the represented values (an exponent gap >= 120 drops an addend that is far below half an
@@ -510,6 +517,7 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                 bool sc_stopped = false; // a scaled run ended on a step it could not take: that step goes to the careful path
                 if (kScaled) {
                     typedef float f3 __attribute__((ext_vector_type(3)));
+                    FS_CYC(cyc_t1 = __builtin_readcyclecounter());
                     for (;;) {
                         const float4 e0 = zs[ref];
                         const int E = dze;
@@ -558,6 +566,7 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                         f2 w0 = dzm, z0 = {e0.x, e0.y}, w2, z2, wO, zO;
                         uint32_t c = 0;
                         bool failed;
+                        FS_CYC(cyc_t2 = __builtin_readcyclecounter());
                         const uint32_t ref_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)ref);
                         if (__builtin_amdgcn_ballot_w64(ref != ref_u) == 0ull) {
                             // Every lane of the wave reads the same orbit entries (the usual case: neighbouring pixels
@@ -631,8 +640,8 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                             const uint32_t lane_off = (ref + 1) * 16u;
                             const float4 *zp = zs;
 #define FS_SCALED_LOAD(OFS, T, PIN)                                                                                 \
-    f3 ent_##T;                                                                                                     \
     asm volatile("global_load_dwordx3 %0, %2, %3 offset:" OFS : "=v"(ent_##T), "+v"(PIN) : "v"(lane_off), "s"(zp));
+                            f3 ent_a, ent_b, ent_c_, ent_d;
                             for (;;) {
                                 FS_SCALED_LOAD("0", a, w0)
                                 FS_SCALED_LOAD("16", b, w0)
@@ -647,7 +656,6 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                                                asm volatile("s_waitcnt vmcnt(2)" : "+v"(ent_b), "+v"(mx_b)), ent_b.x,
                                                ent_b.y, ent_b.z);
                                 if (v1 != 0ull) {
-                                    asm volatile("s_waitcnt vmcnt(0)" ::"v"(ent_c_), "v"(ent_d)); // nothing stays in flight
                                     wO = w0, zO = z0, failed = true;
                                     break;
                                 }
@@ -671,9 +679,12 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                                     break;
                                 }
                             }
+                            // a run that ends in its first trip leaves the loads of the second in flight: they land before anything else happens
+                            asm volatile("s_waitcnt vmcnt(0) ; scaled run, loop exit" ::"v"(ent_a), "v"(ent_b), "v"(ent_c_), "v"(ent_d));
 #undef FS_SCALED_LOAD
                         }
 #undef FS_SCALED_STEP
+                        FS_CYC(cyc_body += __builtin_readcyclecounter() - cyc_t2);
                         // back to the reduced form: the larger part's exponent moves into dze (exact)
                         if (c != 0u) {
                             const float mxw = __builtin_fmaxf(__builtin_fabsf(wO.x), __builtin_fabsf(wO.y));
@@ -695,6 +706,7 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                             break;
                         }
                     }
+                    FS_CYC(cyc_run += __builtin_readcyclecounter() - cyc_t1);
                 }
                 // ---- run of "quiet" steps: when dz is at least 2^4 below the orbit value and the orbit value is < 8,
                 // neither exit test can fire and z itself is not needed:
@@ -877,10 +889,21 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                     running = iterations < n_iterations;
                 }
             }
+            FS_CYC(cyc_loop += __builtin_readcyclecounter() - cyc_t0);
 #undef FS_LAV2_STEP_HEAD
         }
         store_iter(A.out, A.frame, L, X, iterations);
     }
+#ifdef FS_PROFILE_CYCLES
+    if (kStats) {
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd((unsigned long long *)&A.stats[0], (unsigned long long)cyc_loop);
+            atomicAdd((unsigned long long *)&A.stats[1], (unsigned long long)cyc_run);
+            atomicAdd((unsigned long long *)&A.stats[3], (unsigned long long)cyc_body);
+        }
+        c_at = c_la = c_px = 0;
+    }
+#endif
     if (kStats) {
         add_stats(A.stats, c_at, c_la, c_pt, c_px);
         // stats[5]: lane-steps taken through the careful path (the rest of [2] ran in quiet runs)
@@ -1109,8 +1132,8 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                         const uint32_t lane_off = (RefIteration + 1) * 16u;
                         const float4 *zp = zs;
 #define FS_SCALED_LOAD(OFS, T, PIN)                                                                                 \
-    f3 ent_##T;                                                                                                     \
     asm volatile("global_load_dwordx3 %0, %2, %3 offset:" OFS : "=v"(ent_##T), "+v"(PIN) : "v"(lane_off), "s"(zp));
+                        f3 ent_a, ent_b, ent_c_, ent_d;
                         for (;;) {
                             FS_SCALED_LOAD("0", a, w0)
                             FS_SCALED_LOAD("16", b, w0)
@@ -1149,6 +1172,8 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                                 break;
                             }
                         }
+                        // a run that ends in its first trip leaves the loads of the second in flight: they land before anything else happens
+                        asm volatile("s_waitcnt vmcnt(0) ; scaled run, loop exit" ::"v"(ent_a), "v"(ent_b), "v"(ent_c_), "v"(ent_d));
 #undef FS_SCALED_LOAD
                     }
 #undef FS_SCALED_STEP
