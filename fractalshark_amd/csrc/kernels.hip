@@ -80,7 +80,7 @@ __global__ void k_make_quiet_orbit(const float4 *__restrict__ zref, float4 *__re
     const float4 v = zref[i];
     const int e = __float_as_int(v.z);
     zq[i] = make_float4(v.x, v.y, __int_as_float(e <= 2 ? ~e + 116 : (1 << 24)), 0.0f);
-    // second companion, zq[n + i], for the scaled runs: {2Z.re, 2Z.im, 2^-3 * max(|Z.re|, |Z.im|)} as plain floats (true
+    // second companion, zq[n + i], for the scaled runs: {2Z.re, 2Z.im, 2^-2 * max(|Z.re|, |Z.im|)} as plain floats (true
     // scale), the bound -0.0 (bit pattern INT_MIN = "never quiet": the loop compares bit patterns as integers) unless
     // 2^-40 <= max part < 5.6 (|Z| < 8) and the smaller part is within 2^40 of the larger one.  (Packing the entry into 8 bytes and deriving the bound from 2Z costs one more vector
     // instruction per step and was measured slower: the loop is not bound by its loads.)
@@ -89,7 +89,7 @@ __global__ void k_make_quiet_orbit(const float4 *__restrict__ zref, float4 *__re
     const float zmax = __builtin_amdgcn_ldexpf(hi, e < -200 ? -200 : (e > 100 ? 100 : e));
     const bool usable = zmax >= 0x1p-40f && zmax < 5.6f && lo >= hi * 0x1p-40f;
     zq[n + i] = make_float4(__builtin_amdgcn_ldexpf(v.x, e + 1), __builtin_amdgcn_ldexpf(v.y, e + 1),
-                            usable ? zmax * 0x1p-3f : -0.0f, 0.0f);
+                            usable ? zmax * 0x1p-2f : -0.0f, 0.0f);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -503,8 +503,10 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                 // reference's step  dz' = dz (2Z + dz) + dc  can be carried out on plain floats under one fixed power-of-two
                 // scale per lane:  w = dz 2^-E,  s = fma(w, 2^E, 2Z),  q = w s + dc 2^-E  -- the same IEEE operations on the
                 // same (scaled) operands, hence the same bits.  A step is accepted when (all lanes of the wave)
-                //   max|q| 2^E <= 2^-3 max|Z'|   |dz'| <= 0.18 |Z'|: neither exit test of the CPU loop can fire (|z| > 4.6 |dz'|,
-                //                                |z|^2 < 87 with |Z'| < 8), and Z' passed the companion's range test;
+                //   max|q| 2^E <= 2^-2 max|Z'|   |dz'| <= 0.354 |Z'| in the 2-norm: neither exit test of the CPU loop can fire
+                //                                (|z| >= 0.646 |Z'| > 1.8 |dz'|: a 3.3x margin in the squares the rebase test
+                //                                compares; |z|^2 < 115 with max|Z'| < 5.6), and Z' passed the companion's range
+                //                                test.  (2^-3 was the first choice; 2^-2 loses fewer runs: -1.5 % frame time on View 5);
                 //   min|q| >= 2^-40 max|q|       no part of a product that matters is lost below 2^-126 in either
                 //                                representation (a dropped term is >= 2^40 below what it is added to);
                 //   2^-20 <= max|q| <= 2^40      the scale still fits.
@@ -563,7 +565,26 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                         // trips, so neither the back-edge nor the roll-back of a failed trip needs a register copy: a
                         // trip that contains a failing step is dropped as a whole and its first step goes to the
                         // careful path.
-                        f2 w0 = dzm, z0 = {e0.x, e0.y}, w2, z2, wO, zO;
+                        // A trip that fails is rolled back to its start -- unless its first step is good on its own: the
+                        // bound test it passed in the loop plus, now, the two tests the loop only applies to second steps.
+                        // Then the first step's result is the exit state and only the second step goes to the careful path
+                        // (a near-zero orbit entry otherwise costs two careful steps and two run entries when it sits second).
+#define FS_TRIP_FAILED(T, NW_, EB, WSTART)                                                                         \
+    {                                                                                                               \
+        const float mn_s = __builtin_fminf(__builtin_fabsf(NW_.x), __builtin_fabsf(NW_.y));                         \
+        const uint64_t bad_s =                                                                                      \
+            __builtin_amdgcn_ballot_w64(__float_as_int(mx_##T) + Esh > __float_as_int(EB)) |                        \
+            __builtin_amdgcn_ballot_w64(!(mn_s >= mx_##T * 0x1p-40f)) |                                             \
+            __builtin_amdgcn_ballot_w64((uint32_t)(__float_as_int(mx_##T) - (107 << 23)) >= (uint32_t)(60 << 23)); \
+        if (bad_s == 0ull) {                                                                                        \
+            wO = NW_;                                                                                               \
+            c += 1;                                                                                                 \
+        } else {                                                                                                    \
+            wO = WSTART;                                                                                            \
+        }                                                                                                           \
+        failed = true;                                                                                              \
+    }
+                        f2 w0 = dzm, z0 = {e0.x, e0.y}, w2, z2, wO;
                         uint32_t c = 0;
                         bool failed;
                         FS_CYC(cyc_t2 = __builtin_readcyclecounter());
@@ -596,7 +617,7 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                                                ua.x, ua.y, ua.z);
                                 FS_SCALED_STEP(t1, u1, w2, z2, b, v1, true, (void)0, ub.x, ub.y, ub.z);
                                 if (v1 != 0ull) {
-                                    wO = w0, zO = z0, failed = true;
+                                    FS_TRIP_FAILED(a, t1, ua.z, w0)
                                     break;
                                 }
                                 c += 2;
@@ -605,7 +626,7 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                                 FS_SCALED_STEP(w2, z2, t3, u3, c_, v2, false, (void)0, uc.x, uc.y, uc.z);
                                 FS_SCALED_STEP(t3, u3, w0, z0, d, v2, true, (void)0, ud.x, ud.y, ud.z);
                                 if (v2 != 0ull) {
-                                    wO = w2, zO = z2, failed = true;
+                                    FS_TRIP_FAILED(c_, t3, uc.z, w2)
                                     break;
                                 }
                                 c += 2;
@@ -614,7 +635,7 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                                 FS_SCALED_STEP(w0, z0, t5, u5, e, v3, false, (void)0, ue.x, ue.y, ue.z);
                                 FS_SCALED_STEP(t5, u5, w2, z2, f, v3, true, (void)0, uf.x, uf.y, uf.z);
                                 if (v3 != 0ull) {
-                                    wO = w0, zO = z0, failed = true;
+                                    FS_TRIP_FAILED(e, t5, ue.z, w0)
                                     break;
                                 }
                                 c += 2;
@@ -623,13 +644,13 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                                 FS_SCALED_STEP(w2, z2, t7, u7, g, v4, false, (void)0, ug.x, ug.y, ug.z);
                                 FS_SCALED_STEP(t7, u7, w0, z0, h, v4, true, (void)0, uh.x, uh.y, uh.z);
                                 if (v4 != 0ull) {
-                                    wO = w2, zO = z2, failed = true;
+                                    FS_TRIP_FAILED(g, t7, ug.z, w2)
                                     break;
                                 }
                                 c += 2;
                                 zpu += 8;
                                 if (c >= 64u) {
-                                    wO = w0, zO = z0, failed = false;
+                                    wO = w0, failed = false;
                                     break;
                                 }
                             }
@@ -656,7 +677,7 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                                                asm volatile("s_waitcnt vmcnt(2)" : "+v"(ent_b), "+v"(mx_b)), ent_b.x,
                                                ent_b.y, ent_b.z);
                                 if (v1 != 0ull) {
-                                    wO = w0, zO = z0, failed = true;
+                                    FS_TRIP_FAILED(a, t1, ent_a.z, w0)
                                     break;
                                 }
                                 c += 2;
@@ -669,13 +690,13 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                                                asm volatile("s_waitcnt vmcnt(0)" : "+v"(ent_d), "+v"(mx_d)), ent_d.x,
                                                ent_d.y, ent_d.z);
                                 if (v2 != 0ull) {
-                                    wO = w2, zO = z2, failed = true;
+                                    FS_TRIP_FAILED(c_, t3, ent_c_.z, w2)
                                     break;
                                 }
                                 c += 2;
                                 zp += 4;
                                 if (c >= 64u) {
-                                    wO = w0, zO = z0, failed = false;
+                                    wO = w0, failed = false;
                                     break;
                                 }
                             }
@@ -683,6 +704,7 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                             asm volatile("s_waitcnt vmcnt(0) ; scaled run, loop exit" ::"v"(ent_a), "v"(ent_b), "v"(ent_c_), "v"(ent_d));
 #undef FS_SCALED_LOAD
                         }
+#undef FS_TRIP_FAILED
 #undef FS_SCALED_STEP
                         FS_CYC(cyc_body += __builtin_readcyclecounter() - cyc_t2);
                         // back to the reduced form: the larger part's exponent moves into dze (exact)
@@ -1089,27 +1111,34 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
         V |= __builtin_amdgcn_ballot_w64(!(mn_##T >= mx_##T * 0x1p-40f)) |                                          \
              __builtin_amdgcn_ballot_w64((uint32_t)(__float_as_int(mx_##T) - (107 << 23)) >= (uint32_t)(60 << 23)); \
     }
-                    f2 w0 = dzs, z0 = {e0.x, e0.y}, w2, z2, wO, zO;
+                    // (keeping the first step of a failed trip, as k_lav2_hdr32_fast does, loses here: the exit conversion drops
+                    // the cached orbit value the careful step would reuse; measured 437 -> 453 ms on C2)
+                    f2 w0 = dzs, z0 = {e0.x, e0.y}, w2, z2, wO;
                     uint32_t c = 0;
                     bool failed;
                     const uint32_t ref_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)RefIteration);
                     if (__builtin_amdgcn_ballot_w64(RefIteration != ref_u) == 0ull) {
                         const float4 *zpu = zs + ref_u + 1; // entries through the scalar cache: all lanes read the same ones
                         for (;;) {
-                            f4 ua, ub, uc, ud;
+                            f4 ua, ub, uc, ud, ue, uf, ug, uh; // eight entries (two 64-byte lines) per body, one wait
                             asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(ua) : "s"(zpu));
                             asm volatile("s_load_dwordx4 %0, %1, 0x10" : "=s"(ub) : "s"(zpu));
                             asm volatile("s_load_dwordx4 %0, %1, 0x20" : "=s"(uc) : "s"(zpu));
                             asm volatile("s_load_dwordx4 %0, %1, 0x30" : "=s"(ud) : "s"(zpu));
+                            asm volatile("s_load_dwordx4 %0, %1, 0x40" : "=s"(ue) : "s"(zpu));
+                            asm volatile("s_load_dwordx4 %0, %1, 0x50" : "=s"(uf) : "s"(zpu));
+                            asm volatile("s_load_dwordx4 %0, %1, 0x60" : "=s"(ug) : "s"(zpu));
+                            asm volatile("s_load_dwordx4 %0, %1, 0x70" : "=s"(uh) : "s"(zpu));
                             f2 t1, u1;
                             uint64_t v1 = 0;
                             FS_SCALED_STEP(w0, z0, t1, u1, a, v1, false,
                                            asm volatile("s_waitcnt lgkmcnt(0)"
-                                                        : "+s"(ua), "+s"(ub), "+s"(uc), "+s"(ud), "+v"(mx_a)),
+                                                        : "+s"(ua), "+s"(ub), "+s"(uc), "+s"(ud), "+s"(ue), "+s"(uf),
+                                                          "+s"(ug), "+s"(uh), "+v"(mx_a)),
                                            ua.x, ua.y, ua.z);
                             FS_SCALED_STEP(t1, u1, w2, z2, b, v1, true, (void)0, ub.x, ub.y, ub.z);
                             if (v1 != 0ull) {
-                                wO = w0, zO = z0, failed = true;
+                                wO = w0, failed = true;
                                 break;
                             }
                             c += 2;
@@ -1118,13 +1147,31 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                             FS_SCALED_STEP(w2, z2, t3, u3, c_, v2, false, (void)0, uc.x, uc.y, uc.z);
                             FS_SCALED_STEP(t3, u3, w0, z0, d, v2, true, (void)0, ud.x, ud.y, ud.z);
                             if (v2 != 0ull) {
-                                wO = w2, zO = z2, failed = true;
+                                wO = w2, failed = true;
                                 break;
                             }
                             c += 2;
-                            zpu += 4;
+                            f2 t5, u5;
+                            uint64_t v3 = 0;
+                            FS_SCALED_STEP(w0, z0, t5, u5, e, v3, false, (void)0, ue.x, ue.y, ue.z);
+                            FS_SCALED_STEP(t5, u5, w2, z2, f, v3, true, (void)0, uf.x, uf.y, uf.z);
+                            if (v3 != 0ull) {
+                                wO = w0, failed = true;
+                                break;
+                            }
+                            c += 2;
+                            f2 t7, u7;
+                            uint64_t v4 = 0;
+                            FS_SCALED_STEP(w2, z2, t7, u7, g, v4, false, (void)0, ug.x, ug.y, ug.z);
+                            FS_SCALED_STEP(t7, u7, w0, z0, h, v4, true, (void)0, uh.x, uh.y, uh.z);
+                            if (v4 != 0ull) {
+                                wO = w2, failed = true;
+                                break;
+                            }
+                            c += 2;
+                            zpu += 8;
                             if (c >= 64u) {
-                                wO = w0, zO = z0, failed = false;
+                                wO = w0, failed = false;
                                 break;
                             }
                         }
@@ -1149,7 +1196,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                                            ent_b.z);
                             if (v1 != 0ull) {
                                 asm volatile("s_waitcnt vmcnt(0)" ::"v"(ent_c_), "v"(ent_d)); // nothing stays in flight
-                                wO = w0, zO = z0, failed = true;
+                                wO = w0, failed = true;
                                 break;
                             }
                             c += 2;
@@ -1162,13 +1209,13 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                                            asm volatile("s_waitcnt vmcnt(0)" : "+v"(ent_d), "+v"(mx_d)), ent_d.x, ent_d.y,
                                            ent_d.z);
                             if (v2 != 0ull) {
-                                wO = w2, zO = z2, failed = true;
+                                wO = w2, failed = true;
                                 break;
                             }
                             c += 2;
                             zp += 4;
                             if (c >= 64u) {
-                                wO = w0, zO = z0, failed = false;
+                                wO = w0, failed = false;
                                 break;
                             }
                         }
