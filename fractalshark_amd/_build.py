@@ -44,6 +44,8 @@ def build_render(force=False):
     # FS_PROFILE_CYCLES=1: the instrumented (step-counting) kernel variants also report shader-clock cycles per phase
     # (tools/cycle_probe.py); never set for the product build
     extra = ["-DFS_PROFILE_CYCLES"] if os.environ.get("FS_PROFILE_CYCLES") == "1" else []
+    if os.environ.get("FS_SCALED_CHUNK"):  # tuning experiments only
+        extra.append("-DFS_SCALED_CHUNK=" + str(int(os.environ["FS_SCALED_CHUNK"])))
     _run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", *extra,
           "-o", LIB_RENDER, os.path.join(CSRC, "kernels.hip"), os.path.join(CSRC, "kernels_2x32.hip"),
           os.path.join(CSRC, "kernels_scaled.hip"), os.path.join(CSRC, "kernels_tables.hip"),

@@ -88,8 +88,12 @@ __global__ void k_make_quiet_orbit(const float4 *__restrict__ zref, float4 *__re
     const float lo = __builtin_fminf(__builtin_fabsf(v.x), __builtin_fabsf(v.y));
     const float zmax = __builtin_amdgcn_ldexpf(hi, e < -200 ? -200 : (e > 100 ? 100 : e));
     const bool usable = zmax >= 0x1p-40f && zmax < 5.6f && lo >= hi * 0x1p-40f;
+    // .w: a run may START at this entry (its 2Z is exact in true scale): every usable entry, and an exact zero -- entry 0,
+    // where every rebase lands; 2Z + dz is then dz itself in either arithmetic.  (Nothing arrives at a zero entry: its bound
+    // is the "never" pattern.)
+    const bool startable = usable || (v.x == 0.0f && v.y == 0.0f);
     zq[n + i] = make_float4(__builtin_amdgcn_ldexpf(v.x, e + 1), __builtin_amdgcn_ldexpf(v.y, e + 1),
-                            usable ? zmax * 0x1p-2f : -0.0f, 0.0f);
+                            usable ? zmax * 0x1p-2f : -0.0f, startable ? 1.0f : 0.0f);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -359,6 +363,14 @@ __device__ __forceinline__ long long norm_key_nz(float m, int e)
 
 } // namespace
 
+// Steps per scaled run (a multiple of the 8-step body): a run's scale is fixed, and its lanes must have this many
+// steps left before the orbit ends and before their iteration limit.  Measured on View 5 (C3 / C2, ms): 64: 69.9 / 385,
+// 128: 68.6 / 390, 256: 68.0 / 372, 512: 68.2 / 380, 1024: 68.0 / 380, 4096: 78.9 / 561 (too few lanes qualify).
+#ifndef FS_SCALED_CHUNK
+#define FS_SCALED_CHUNK 256
+#endif
+constexpr uint32_t kScaledChunk = FS_SCALED_CHUNK;
+
 template <int Mode, bool kStats, bool kScaled>
 __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
 {
@@ -536,9 +548,9 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                         // (E < 0 in every run: the start test needs max|dz| in [2^E, 2^(E+1)) below a bound < 0.7)
                         const int Esh = (E < -254 ? -254 : (E > 0 ? 0 : E)) * (1 << 23);
                         // (the state a run starts from has passed the CPU loop's tests already: only the entry it starts at
-                        // must be one the companion vouches for -- a NaN-free 2Z, bound not the "never" pattern)
-                        const bool start_ok = __float_as_int(e0.z) > 0 && mn0 >= mx0 * 0x1p-40f && mx0 >= 1.0f && mx0 < 2.0f &&
-                                              dsh <= 30 && left >= 64u;
+                        // must be one the companion vouches for -- its .w: 2Z exact in true scale)
+                        const bool start_ok = e0.w != 0.0f && mn0 >= mx0 * 0x1p-40f && mx0 >= 1.0f && mx0 < 2.0f &&
+                                              dsh <= 30 && left >= kScaledChunk;
                         if (__builtin_amdgcn_ballot_w64(!start_ok) != 0ull)
                             break;
                         const f2 sE2 = {sE, sE};
@@ -649,7 +661,7 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                                 }
                                 c += 2;
                                 zpu += 8;
-                                if (c >= 64u) {
+                                if (c >= kScaledChunk) {
                                     wO = w0, failed = false;
                                     break;
                                 }
@@ -695,7 +707,7 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                                 }
                                 c += 2;
                                 zp += 4;
-                                if (c >= 64u) {
+                                if (c >= kScaledChunk) {
                                     wO = w0, failed = false;
                                     break;
                                 }
@@ -743,7 +755,7 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                 //   t2 = min(nd1, nd3 + 4) >= -115      (both alignment gaps inside the reference's 120 window)
                 //   larger part of q a finite normal float; orbit value below 8 (poisoned sN fails t1 otherwise).
                 // A lane must also stay clear of the orbit end and of its iteration limit (`left`); runs are cut into
-                // chunks of 64 steps so that this is a per-chunk wave vote instead of a per-step, per-lane counter.
+                // chunks of 64 steps (this loop; kScaledChunk in the scaled runs) so that this is a per-chunk wave vote instead of a per-step, per-lane counter.
                 // One quiet step from state (DZM, DZE, ZCM, SC, W) into (NDZM, NDZE, NZCM, NSC, NW) against entry K of the run.
                 // Exponent bookkeeping is biased so that every range test is against a constant that needs no extra add:
                 //   SC = ~exp(Zc) + 116 (zq[].z; poison 2^24 for an orbit value >= 8),  W = DZE + SC = nd1 + 116,
@@ -1090,8 +1102,8 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                     const uint32_t left_it = n_iterations - 1 - iter; // iter < n_iterations here
                     const uint32_t left = left_ref < left_it ? left_ref : left_it;
                     const int Esh = (E < -254 ? -254 : (E > 0 ? 0 : E)) * (1 << 23);
-                    const bool start_ok = __float_as_int(e0.z) > 0 && mn0 >= mx0 * 0x1p-40f && mx0 >= 1.0f && mx0 < 2.0f &&
-                                          imax(dshx, dshy) <= 30 && left >= 64u;
+                    const bool start_ok = e0.w != 0.0f && mn0 >= mx0 * 0x1p-40f && mx0 >= 1.0f && mx0 < 2.0f &&
+                                          imax(dshx, dshy) <= 30 && left >= kScaledChunk;
                     if (__builtin_amdgcn_ballot_w64(!start_ok) != 0ull)
                         break;
                     const f2 sE2 = {sE, sE};
@@ -1170,7 +1182,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                             }
                             c += 2;
                             zpu += 8;
-                            if (c >= 64u) {
+                            if (c >= kScaledChunk) {
                                 wO = w0, failed = false;
                                 break;
                             }
@@ -1214,7 +1226,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                             }
                             c += 2;
                             zp += 4;
-                            if (c >= 64u) {
+                            if (c >= kScaledChunk) {
                                 wO = w0, failed = false;
                                 break;
                             }
