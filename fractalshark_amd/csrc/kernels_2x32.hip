@@ -81,6 +81,46 @@ template <int Mode, bool kStats> __global__ void __launch_bounds__(256) k_lav2_2
                 const HR esc = ldr(A.at.SqrEscapeRadius);
                 uint32_t i;
                 for (i = 0; i < ATMaxIt; i++) {
+                    // Steady state.  z starts as {0, 0, kMinBigExp}; the first z*z + c returns c itself (its exponent gap is
+                    // beyond the 120 window), and from then on z carries c's exponent E whenever E <= 0 (|c| < 2): z*z has
+                    // exponent 2E, the gap d = 2E - E = E selects the same arm of the complex addition in every iteration
+                    // (E = 0: z*z + c * 2^0;  -120 < E < 0: (z*z) * 2^E + c, HDRFloatComplex.h plus_mutable), and the sum
+                    // keeps exponent E.  The iteration is then plain double-float arithmetic on the mantissas -- the same
+                    // operations in the same order as the general form below, minus its exponent bookkeeping and its
+                    // three-way (divergent) addition; the constant c * 2^0 is computed once.
+                    if (z.e == c.e && c.e <= 0 && c.e > -kExpDiffIgnored) {
+                        const int32_t E = c.e;
+                        const int32_t nsq_e = E << 1;
+                        df32 re = z.re, im = z.im;
+                        if (E == 0) {
+                            const df32 mul0 = multiplier<df32>(0);
+                            const df32 cre = c.re * mul0, cim = c.im * mul0;
+                            for (; i < ATMaxIt; i++) {
+                                const df32 rr = re * re, ii = im * im;
+                                HR nsq{rr + ii, nsq_e};
+                                hr_reduce(nsq);
+                                if (hr_cmp_pos(nsq, esc) > 0)
+                                    break;
+                                const df32 im2 = (re * im) + (im * re);
+                                re = (rr - ii) + cre;
+                                im = im2 + cim;
+                            }
+                        } else {
+                            const df32 mul = multiplier<df32>(E);
+                            for (; i < ATMaxIt; i++) {
+                                const df32 rr = re * re, ii = im * im;
+                                HR nsq{rr + ii, nsq_e};
+                                hr_reduce(nsq);
+                                if (hr_cmp_pos(nsq, esc) > 0)
+                                    break;
+                                const df32 im2 = (re * im) + (im * re);
+                                re = (rr - ii) * mul + c.re;
+                                im = im2 * mul + c.im;
+                            }
+                        }
+                        z = HC{re, im, E};
+                        break;
+                    }
                     HR nsq = hc_norm2(z);
                     hr_reduce(nsq);
                     if (hr_cmp_pos(nsq, esc) > 0)
