@@ -1885,8 +1885,9 @@ void fsk_make_quiet_orbit(const float4 *zref, float4 *zq, uint64_t n, hipStream_
 static unsigned lds_pad()
 {
     static const unsigned v = [] {
-        const char *e = getenv("FSMI355_LDS_PAD");
-        return e ? (unsigned)atoi(e) : 0u;
+        const char *e = getenv("FSMI355_LDS_PAD"); // occupancy-cap experiment: dynamic LDS bytes
+        const unsigned v = e ? (unsigned)atoi(e) : 0u;
+        return v <= 65536u ? v : 0u;
     }();
     return v;
 }
@@ -1895,8 +1896,9 @@ void fsk_lav2_hdr32(const FsLav2Args32 &A, int mode, bool stats, int variant, hi
 {
     const unsigned pad = lds_pad();
     static const unsigned bs = [] {
-        const char *e = getenv("FSMI355_BLOCK");
-        return e ? (unsigned)atoi(e) : 256u;
+        const char *e = getenv("FSMI355_BLOCK"); // launch-shape experiment: 64, 128 or 256
+        const unsigned v = e ? (unsigned)atoi(e) : 256u;
+        return v == 64u || v == 128u ? v : 256u;
     }();
     const dim3 b(bs), g((A.frame.width + bs / 8 - 1) / (bs / 8), (A.frame.local_rows + 7) / 8, 1);
 #define FS_LAUNCH(M)                                                                                                \
