@@ -159,6 +159,7 @@ def main():
         gathered = torch.empty((world * max_rows, rw), dtype=torch.int32, device="cuda")
         frame_index = torch.from_numpy(tiling.reassemble_index(H, world, band)).cuda()
         assert r.SetExternalIterBuffer(local.data_ptr()) == 0
+        render_stream = torch.cuda.ExternalStream(r.compute_stream)
     kernel_ms = []
     steps_executed = []
 
@@ -168,11 +169,14 @@ def main():
         else:
             e = r._lib.fs_render_bla(r._h, T_HDR32, coords_arr.ctypes.data, n_iter)
         assert e == 0, GPURenderer.ConvertErrorToString(e)
-        assert r.SyncComputeStream() == 0
         frame = None
         if distributed:
+            # the gather waits for the render on the device (stream-to-stream), not through the host
+            torch.cuda.current_stream().wait_stream(render_stream)
             dist.all_gather_into_tensor(gathered, local)
             frame = gathered.index_select(0, frame_index)
+        else:
+            assert r.SyncComputeStream() == 0
         torch.cuda.synchronize()
         if record:
             kernel_ms.append(r.last_kernel_ms())

@@ -113,6 +113,7 @@ def render_lib():
     _decl(lib, "fs_clear", u32, [vp])
     _decl(lib, "fs_render_current", u32, [vp, u64, vp, vp, vp, C.c_int])
     _decl(lib, "fs_sync_compute", u32, [vp])
+    _decl(lib, "fs_compute_stream", vp, [vp])
     _decl(lib, "fs_sync_display", u32, [vp])
     _decl(lib, "fs_query_compute", u32, [vp])
     _decl(lib, "fs_enqueue_done_callback", u32, [vp, DONE_CB, vp])
@@ -132,7 +133,7 @@ RENDER_SYMBOLS = [
     "fs_upload_la", "fs_upload_bla", "fs_render_lav2", "fs_render_bla", "fs_render_direct", "fs_upload_orbit_scaled",
     "fs_render_scaled", "fs_build_bla", "fs_bla_num_levels", "fs_bla_lm2", "fs_bla_level_size", "fs_read_bla_level",
     "fs_render_direct_lp", "fs_clear",
-    "fs_render_current", "fs_sync_compute", "fs_sync_display", "fs_query_compute", "fs_enqueue_done_callback",
+    "fs_render_current", "fs_sync_compute", "fs_compute_stream", "fs_sync_display", "fs_query_compute", "fs_enqueue_done_callback",
     "fs_get_width", "fs_get_height", "fs_last_kernel_ms", "fs_set_kernel_variant", "fs_enable_step_count", "fs_read_step_count",
 ]
 

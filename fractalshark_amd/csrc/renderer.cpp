@@ -1316,6 +1316,8 @@ uint32_t fs_sync_compute(fs_renderer *r)
     return (uint32_t)hipStreamSynchronize(r->compute);
 }
 
+void *fs_compute_stream(const fs_renderer *r) { return (void *)r->compute; }
+
 uint32_t fs_sync_display(fs_renderer *r)
 {
     if (uint32_t e = use_device(r))

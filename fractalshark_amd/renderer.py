@@ -68,6 +68,11 @@ class GPURenderer:
     def SetRowBands(self, band_first_row, band_rows, band_stride_rows):
         return self._lib.fs_set_row_bands(self._h, band_first_row, band_rows, band_stride_rows)
 
+    @property
+    def compute_stream(self):
+        """The renderer's compute stream as a raw hipStream_t (int), e.g. for torch.cuda.ExternalStream."""
+        return self._lib.fs_compute_stream(self._h) or 0
+
     def SetExternalIterBuffer(self, device_ptr):
         return self._lib.fs_set_external_iter_buffer(self._h, device_ptr)
 

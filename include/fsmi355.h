@@ -194,6 +194,10 @@ uint32_t fs_render_current(fs_renderer *r, uint64_t n_iterations, void *iter_buf
  * (GPU_Render.cu:596-615).  The callback runs on a runtime thread after all prior compute-stream work. */
 uint32_t fs_sync_compute(fs_renderer *r);
 uint32_t fs_sync_display(fs_renderer *r);
+/* The compute stream itself (a hipStream_t; GPURenderer::m_ComputeStream, GPU_Render.h), NULL before fs_init_memory.  For a
+ * host that chains its own device work behind a render without a host round trip (the multi-GPU gather of bench.py waits
+ * on it from its own stream).  Owned by the renderer. */
+void *fs_compute_stream(const fs_renderer *r);
 uint32_t fs_query_compute(fs_renderer *r);
 typedef void (*fs_done_cb)(void *user);
 uint32_t fs_enqueue_done_callback(fs_renderer *r, fs_done_cb cb, void *user);
