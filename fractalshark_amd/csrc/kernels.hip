@@ -370,6 +370,19 @@ __device__ __forceinline__ long long norm_key_nz(float m, int e)
 #define FS_SCALED_CHUNK 256
 #endif
 constexpr uint32_t kScaledChunk = FS_SCALED_CHUNK;
+static_assert(kScaledChunk % 8 == 0 && kScaledChunk >= 64, "a run is a whole number of 8-step bodies");
+
+// Steps of the next scaled run: kScaledChunk when every (active) lane has that many left, else 64, else 16, else none --
+// without the shorter runs the last 256 steps of every pass over the orbit (1.6 % of View 5's 16 046-entry orbit) fall to
+// the exponent-tracking loop.
+__device__ __forceinline__ uint32_t scaled_run_length(uint32_t left)
+{
+    if (__builtin_amdgcn_ballot_w64(left < kScaledChunk) == 0ull)
+        return kScaledChunk;
+    if (__builtin_amdgcn_ballot_w64(left < 64u) == 0ull)
+        return 64u;
+    return __builtin_amdgcn_ballot_w64(left < 16u) == 0ull ? 16u : 0u;
+}
 
 template <int Mode, bool kStats, bool kScaled>
 __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
@@ -550,8 +563,11 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                         // (the state a run starts from has passed the CPU loop's tests already: only the entry it starts at
                         // must be one the companion vouches for -- its .w: 2Z exact in true scale)
                         const bool start_ok = e0.w != 0.0f && mn0 >= mx0 * 0x1p-40f && mx0 >= 1.0f && mx0 < 2.0f &&
-                                              dsh <= 30 && left >= kScaledChunk;
-                        if (__builtin_amdgcn_ballot_w64(!start_ok) != 0ull)
+                                              dsh <= 30;
+                        // run length: the longest of 256 / 64 / 16 steps that every lane still has before the orbit ends
+                        // and before its iteration limit (three votes per run, not a counter per step)
+                        const uint32_t run_len = scaled_run_length(left);
+                        if (__builtin_amdgcn_ballot_w64(!start_ok) != 0ull || run_len == 0u)
                             break;
                         const f2 sE2 = {sE, sE};
                         // One step from (W_, Z_) into (NW_, NZ_); V accumulates the lanes that fail a test.
@@ -661,7 +677,7 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                                 }
                                 c += 2;
                                 zpu += 8;
-                                if (c >= kScaledChunk) {
+                                if (c >= run_len) {
                                     wO = w0, failed = false;
                                     break;
                                 }
@@ -707,7 +723,7 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                                 }
                                 c += 2;
                                 zp += 4;
-                                if (c >= kScaledChunk) {
+                                if (c >= run_len) {
                                     wO = w0, failed = false;
                                     break;
                                 }
@@ -1103,8 +1119,9 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                     const uint32_t left = left_ref < left_it ? left_ref : left_it;
                     const int Esh = (E < -254 ? -254 : (E > 0 ? 0 : E)) * (1 << 23);
                     const bool start_ok = e0.w != 0.0f && mn0 >= mx0 * 0x1p-40f && mx0 >= 1.0f && mx0 < 2.0f &&
-                                          imax(dshx, dshy) <= 30 && left >= kScaledChunk;
-                    if (__builtin_amdgcn_ballot_w64(!start_ok) != 0ull)
+                                          imax(dshx, dshy) <= 30;
+                    const uint32_t run_len = scaled_run_length(left);
+                    if (__builtin_amdgcn_ballot_w64(!start_ok) != 0ull || run_len == 0u)
                         break;
                     const f2 sE2 = {sE, sE};
 #define FS_SCALED_STEP(W_, Z_, NW_, NZ_, T, V, FULL, AFTER_ARITH, EX, EY, EB)                                       \
@@ -1182,7 +1199,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                             }
                             c += 2;
                             zpu += 8;
-                            if (c >= kScaledChunk) {
+                            if (c >= run_len) {
                                 wO = w0, failed = false;
                                 break;
                             }
@@ -1226,7 +1243,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                             }
                             c += 2;
                             zp += 4;
-                            if (c >= kScaledChunk) {
+                            if (c >= run_len) {
                                 wO = w0, failed = false;
                                 break;
                             }
