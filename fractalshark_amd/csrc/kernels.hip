@@ -824,6 +824,7 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                     uint32_t done = 0;
                     // first step of the run: nd1 in [-115, 0] is not implied by a previous quiet step
                     bool stop = __builtin_amdgcn_ballot_w64((unsigned)(W - 1) > 115u) != 0ull;
+                    bool retry_scaled = false;
                     while (!stop) {
                         const uint32_t r0 = ref + done, i0 = iterations + done;
                         const uint32_t left_ref = r0 + 1 < MaxRefIteration ? MaxRefIteration - 1 - r0 : 0u;
@@ -853,6 +854,12 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                                 dzm = dzmA, dze = dzeA, Zcm = ZcmA, sC = sA, W = WA;
                             }
                             done += c;
+                            if (kScaled && !stop) {
+                                // a clean chunk: hand the state back so that a scaled run can start from it (this loop is
+                                // the second chance, and once in it a wave would otherwise stay for as long as it is quiet)
+                                retry_scaled = true;
+                                break;
+                            }
                         } else {
                             for (;;) {
                                 f2 dzmN, ZcmN;
@@ -871,6 +878,8 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                     iterations += done;
                     if (kStats)
                         c_pt += done;
+                    if (retry_scaled)
+                        continue; // (every lane of the chunk had >= 64 steps left: still running)
                 }
 #undef FS_QUIET_STEP
                 // the careful step works with the true exponent of Zc (sC may be the poison value)
