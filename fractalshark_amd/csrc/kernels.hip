@@ -1296,6 +1296,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                 const bool entry_ok = (__float_as_int(DeltaSubNX.m) & 0x7F800000) == 0x3F800000 &&
                                       (__float_as_int(DeltaSubNY.m) & 0x7F800000) == 0x3F800000 && aX <= 111 && aY <= 111;
                 bool stop = __builtin_amdgcn_ballot_w64(!entry_ok) != 0ull;
+                bool retry_scaled = false; // a clean chunk goes back to the scaled runs (see k_lav2_hdr32_fast)
                 const uint32_t lane_off = (RefIteration + 1) * 16u;
                 const f2 dcm128 = (f2){DeltaSub0X.m, DeltaSub0Y.m} * 128.0f;
                 const int dcXB = DeltaSub0X.e - 5, dcYB = DeltaSub0Y.e - 5;
@@ -1367,6 +1368,10 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                             FS_SQ_COMMIT(entC);
                         }
                         done += c;
+                        if (!stop) {
+                            retry_scaled = true;
+                            break;
+                        }
                     } else {
                         for (;;) {
                             f3 entT;
@@ -1395,6 +1400,8 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                     DeltaSubNY = hreal<F>{O128.y * 0.0078125f, OYe};
                     Zcached_at = 0xFFFFFFFFu;
                 }
+                if (retry_scaled)
+                    continue;
               }
             }
 
