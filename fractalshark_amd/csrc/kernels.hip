@@ -978,6 +978,7 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
         }
     }
 }
+#undef FS_CYC
 
 // ------------------------------------------------------------------------------------------------
 // Scalar-HDRFloat perturbation with optional BLA skipping, T = HDRFloat<float>.
