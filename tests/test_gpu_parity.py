@@ -781,3 +781,28 @@ def test_compressed_upload_rejects_missing_constants(renderer, native_libs):
     e = renderer._lib.fs_upload_orbit_compressed(renderer._h, 0, T_F32, 4, pin.compressed_data_ptr, pin.compressed_count,
                                                  pin.count, pin.period, None, None)
     assert e != 0
+
+
+def test_short_orbit_runs_and_oracle(renderer, native_libs):
+    """An orbit shorter than a full scaled run (122 entries < 256): run lengths fall back to 64 / 16 by wave vote.  The
+    three kernel variants agree and equal the CPU oracle."""
+    from decimal import Decimal, getcontext
+    getcontext().prec = 60
+    cx, cy = Decimal("-0.1528465308235274786391493323577"), Decimal("1.0397032701234428320367513768879")
+    w = Decimal("1e-22")
+    h = w * 36 / 64
+    v = inputs.View(str(cx - w / 2), str(cy - h / 2), str(cx + w / 2), str(cy + h / 2), 64, 36, num_iterations=50000)
+    ob = inputs.Orbit(v)
+    assert ob.count < 256
+    la = inputs.LATable(ob)
+    outs = []
+    try:
+        for mode in (LAV2_FULL, LAV2_PO):
+            for variant in (1, 2, 0):
+                assert renderer.set_kernel_variant(variant) == 0
+                outs.append(_render_lav2(renderer, v, ob, la, mode, PARITY_CPU)[0])
+    finally:
+        renderer.set_kernel_variant(0)
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    assert np.array_equal(outs[3], outs[4]) and np.array_equal(outs[3], outs[5])
+    assert np.array_equal(outs[0], _oracle.lav2_hdr32(v, ob, la, stage_test=0))
