@@ -127,6 +127,23 @@ __device__ __forceinline__ void at_perform(const hcplx<F> c, const hreal<F> esc,
                 T = esc.m * pow2_normal<F>(te < -fbits<F>::kBias + 2 ? -fbits<F>::kBias + 2 : te);
             const F min_normal = pow2_normal<F>(-fbits<F>::kBias + 1);
             bool literal = te < -fbits<F>::kBias + 2;
+            if (__builtin_amdgcn_ballot_w64(k != 0) == 0ull) {
+                // every lane of the wave has 1 <= |c| < 2: P is 1 and x * 1 is x, bit for bit -- two multiplications less
+                while (!literal && i < ATMaxIt) {
+                    const F rr = re * re, ii = im * im;
+                    const F m = rr + ii;
+                    if (!(m >= min_normal)) {
+                        literal = true;
+                        break;
+                    }
+                    if (m > T)
+                        break;
+                    const F ri = re * im;
+                    re = (rr - ii) + c.re;
+                    im = (ri + ri) + c.im;
+                    i++;
+                }
+            }
             while (!literal && i < ATMaxIt) {
                 const F rr = re * re, ii = im * im;
                 const F m = rr + ii;
