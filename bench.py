@@ -69,6 +69,8 @@ def parse():
     ap.add_argument("--cpu-sample-rows", type=int, default=0,
                     help="rows of the frame timed on the CPU (0 = 8 x usable host threads, about 10-30 s of CPU work)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-build", action="store_true",
+                    help="never spawn a compiler (same as FS_NO_BUILD=1): required under rocprofv3, see tools/pmc_passes.sh")
     return ap.parse_args()
 
 
@@ -93,7 +95,14 @@ def main():
     else:
         torch.cuda.set_device(0)
     if rank == 0:
-        _build.build_all()
+        if os.environ.get("FS_NO_BUILD") == "1" or args.no_build:
+            # under a profiler (rocprofv3 preloads a library that has initialised the GPU) no compiler may be spawned:
+            # a stale or missing library is an error, not a rebuild
+            if not _build.up_to_date():
+                raise RuntimeError("native libraries are missing or stale and --no-build / FS_NO_BUILD=1 forbids "
+                                   "compiling: run `python -c 'from fractalshark_amd import _build; _build.build_all()'` first")
+        else:
+            _build.build_all()
     if distributed:
         dist.barrier()
 
@@ -158,7 +167,7 @@ def main():
         local = torch.zeros((max_rows, rw), dtype=torch.int32, device="cuda")
         gathered = torch.empty((world * max_rows, rw), dtype=torch.int32, device="cuda")
         frame_index = torch.from_numpy(tiling.reassemble_index(H, world, band)).cuda()
-        assert r.SetExternalIterBuffer(local.data_ptr()) == 0
+        assert r.SetExternalIterBuffer(local.data_ptr(), local.numel() * local.element_size()) == 0
         render_stream = torch.cuda.ExternalStream(r.compute_stream)
     kernel_ms = []
     steps_executed = []

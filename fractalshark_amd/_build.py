@@ -5,63 +5,136 @@
 
 `-ffp-contract=off` is part of the numerical contract (see csrc/hdr_math.hpp): the parity target is the
 reference's CPU build, which has no FMA.
+
+Up-to-date checks compare a CONTENT hash of the sources + flags with a stamp written next to each output (file
+times do not survive the snapshot that carries the tree to the GPU box; a stale time there would start a compiler
+under a profiler).  Translation units are compiled to objects in parallel and only the changed ones are rebuilt.
 """
+import glob
+import hashlib
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 HOST = os.path.join(HERE, "host")
+OBJ = os.path.join(CSRC, "build")
 LIB_RENDER = os.path.join(CSRC, "libfsmi355.so")
 LIB_INPUTS = os.path.join(HOST, "libfsinputs.so")
 
 GMP_PREFIX = os.environ.get("FS_GMP_PREFIX", "/opt/conda")
 
 
-def _newer(target, sources):
-    if not os.path.exists(target):
-        return False
-    t = os.path.getmtime(target)
-    return all(os.path.getmtime(s) <= t for s in sources)
-
-
 def _run(cmd):
-    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    # compilers never inherit a profiler's preload (rocprofv3 injects a library that initialises the GPU; exec'ing
+    # clang / cc1plus / ld from such a process tree is what the GPU pool forbids)
+    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(("ROCP_", "ROCPROF"))}
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
     if p.returncode != 0:
         raise RuntimeError("build failed: %s\n%s" % (" ".join(cmd), p.stdout))
     return p.stdout
 
 
-def build_render(force=False):
-    srcs = [os.path.join(CSRC, f) for f in ("kernels.hip", "kernels_2x32.hip", "kernels_scaled.hip", "kernels_tables.hip", "kernels_direct_lp.hip", "kernels_plain.hip", "kernels_decompress.hip", "renderer.cpp", "kernels.h", "kernel_common.hpp",
-                                            "hdr_math.hpp", "df32_math.hpp")]
-    srcs += [os.path.join(ROOT, "include", f) for f in ("fsmi355.h", "fs_layout.h")]
-    if not force and _newer(LIB_RENDER, srcs):
-        return LIB_RENDER
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+def _digest(paths, flags):
+    h = hashlib.sha256()
+    h.update("\0".join(flags).encode())
+    for p in sorted(paths):
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _stamp_ok(target, digest):
+    try:
+        return os.path.exists(target) and open(target + ".stamp").read().strip() == digest
+    except OSError:
+        return False
+
+
+def _write_stamp(target, digest):
+    with open(target + ".stamp", "w") as f:
+        f.write(digest + "\n")
+
+
+def _render_units():
+    """Translation units of libfsmi355.so: every csrc/*.hip plus the host side of the C ABI."""
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip"))) + [os.path.join(CSRC, "renderer.cpp"),
+                                                             os.path.join(CSRC, "group.cpp")]
+
+
+def _render_headers():
+    return sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hpp")) +
+                  [os.path.join(ROOT, "include", f) for f in ("fsmi355.h", "fs_layout.h")])
+
+
+def _render_flags():
     # FS_PROFILE_CYCLES=1: the instrumented (step-counting) kernel variants also report shader-clock cycles per phase
     # (tools/cycle_probe.py); never set for the product build
     extra = ["-DFS_PROFILE_CYCLES"] if os.environ.get("FS_PROFILE_CYCLES") == "1" else []
     if os.environ.get("FS_SCALED_CHUNK"):  # tuning experiments only
         extra.append("-DFS_SCALED_CHUNK=" + str(int(os.environ["FS_SCALED_CHUNK"])))
-    _run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", *extra,
-          "-o", LIB_RENDER, os.path.join(CSRC, "kernels.hip"), os.path.join(CSRC, "kernels_2x32.hip"),
-          os.path.join(CSRC, "kernels_scaled.hip"), os.path.join(CSRC, "kernels_tables.hip"),
-          os.path.join(CSRC, "kernels_direct_lp.hip"), os.path.join(CSRC, "kernels_plain.hip"), os.path.join(CSRC, "kernels_decompress.hip"),
-          os.path.join(CSRC, "renderer.cpp")])
+    return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", *extra]
+
+
+def _inputs_sources():
+    return [os.path.join(HOST, "refinputs.cpp"), os.path.join(CSRC, "hdr_math.hpp"),
+            os.path.join(ROOT, "include", "fs_inputs.h"), os.path.join(ROOT, "include", "fs_layout.h")]
+
+
+_INPUTS_FLAGS = ["-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+
+
+def up_to_date():
+    """True when both libraries exist and were built from the current sources (no compiler is started)."""
+    units = [u for u in _render_units() if os.path.exists(u)]
+    return (_stamp_ok(LIB_RENDER, _digest(units + _render_headers(), _render_flags())) and
+            _stamp_ok(LIB_INPUTS, _digest(_inputs_sources(), _INPUTS_FLAGS)))
+
+
+def build_render(force=False):
+    units = [u for u in _render_units() if os.path.exists(u)]
+    headers = _render_headers()
+    flags = _render_flags()
+    digest = _digest(units + headers, flags)
+    if not force and _stamp_ok(LIB_RENDER, digest):
+        return LIB_RENDER
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    os.makedirs(OBJ, exist_ok=True)
+    hdr_digest = _digest(headers, flags)
+
+    def compile_unit(src):
+        obj = os.path.join(OBJ, os.path.basename(src) + ".o")
+        d = _digest([src], [hdr_digest])
+        if force or not _stamp_ok(obj, d):
+            # renderer.cpp / group.cpp are host-only C++ that include HIP runtime headers: compiled by hipcc as HIP so
+            # that <hip/hip_runtime.h> types (float4, hipStream_t) match the kernels' launchers
+            lang = [] if src.endswith(".hip") else ["-x", "hip"]
+            _run([hipcc, *flags, "-c", *lang, src, "-o", obj])
+            _write_stamp(obj, d)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_unit, units))
+    # RCCL (the multi-GPU gather behind fs_group_*) is resolved at run time with dlopen, so the library loads on hosts
+    # without it; -ldl only
+    _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_RENDER, *objs, "-ldl", "-lpthread"])
+    _write_stamp(LIB_RENDER, digest)
     return LIB_RENDER
 
 
 def build_inputs(force=False):
-    srcs = [os.path.join(HOST, "refinputs.cpp"), os.path.join(CSRC, "hdr_math.hpp"),
-            os.path.join(ROOT, "include", "fs_inputs.h"), os.path.join(ROOT, "include", "fs_layout.h")]
-    if not force and _newer(LIB_INPUTS, srcs):
+    srcs = _inputs_sources()
+    digest = _digest(srcs, _INPUTS_FLAGS)
+    if not force and _stamp_ok(LIB_INPUTS, digest):
         return LIB_INPUTS
-    _run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-          "-I" + os.path.join(GMP_PREFIX, "include"), "-o", LIB_INPUTS, os.path.join(HOST, "refinputs.cpp"),
-          "-L" + os.path.join(GMP_PREFIX, "lib"), "-lgmp", "-Wl,-rpath," + os.path.join(GMP_PREFIX, "lib")])
+    _run(["g++", *_INPUTS_FLAGS, "-I" + os.path.join(GMP_PREFIX, "include"), "-o", LIB_INPUTS,
+          os.path.join(HOST, "refinputs.cpp"), "-L" + os.path.join(GMP_PREFIX, "lib"), "-lgmp",
+          "-Wl,-rpath," + os.path.join(GMP_PREFIX, "lib")])
+    _write_stamp(LIB_INPUTS, digest)
     return LIB_INPUTS
 
 

@@ -92,7 +92,7 @@ def render_lib():
     _decl(lib, "fs_init_memory", u32, [vp, u32, u32, u32, u32, vp, u32, u32, u64, C.c_int])
     _decl(lib, "fs_set_row_bands", u32, [vp, u32, u32, u32])
     _decl(lib, "fs_local_rows", u32, [vp])
-    _decl(lib, "fs_set_external_iter_buffer", u32, [vp, vp])
+    _decl(lib, "fs_set_external_iter_buffer", u32, [vp, vp, u64])
     _decl(lib, "fs_device_iter_buffer", vp, [vp])
     _decl(lib, "fs_rounded_width", u32, [vp])
     _decl(lib, "fs_upload_orbit", u32, [vp, u64, C.c_int, u32, vp, u64, u64, u64])

@@ -42,6 +42,8 @@ struct fs_renderer {
     void *iters_internal = nullptr;
     size_t iters_internal_bytes = 0;
     void *iters_external = nullptr;
+    size_t iters_external_bytes = 0;
+    fs_reduction reduce_seed{}; // source of the stream-ordered seed copy in fs_render_current (must outlive the call)
     fs_color16 *colors = nullptr;
     fs_reduction *reduction = nullptr;
     uint64_t *stats = nullptr;
@@ -158,7 +160,7 @@ uint32_t ensure_iter_buffer(fs_renderer *r)
     // capacity is tracked in BYTES: the same frame needs twice the memory with IterType = uint64_t
     const size_t need = (size_t)r->w_block * 16u * r->local_rows_padded * r->iter_bytes;
     if (r->iters_external)
-        return 0;
+        return r->iters_external_bytes >= need ? 0 : (uint32_t)hipErrorInvalidValue; // never write past a caller's buffer
     if (r->iters_internal && r->iters_internal_bytes >= need)
         return 0;
     if (r->iters_internal) {
@@ -352,7 +354,10 @@ uint32_t fs_test_device_is_working(void)
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
         return 0;
-    if (hipSetDevice(0) != hipSuccess)
+    // probe the caller's current device and leave it current (the reference hard-codes device 0 because it only ever
+    // uses that one, GPU_Render.cu:113; a multi-GPU host has already selected its own)
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess || hipSetDevice(cur) != hipSuccess)
         return 0;
     if (hipFree(nullptr) != hipSuccess)
         return 0;
@@ -439,6 +444,9 @@ uint32_t fs_init_memory(fs_renderer *r, uint32_t w, uint32_t h, uint32_t antiali
     r->n_color_cu = (size_t)wcb * 16 * hcb * 8;
     r->band_rows = 0;
     compute_local_rows(r);
+    // a caller-owned iteration buffer was sized for the previous geometry: drop it (fs_set_external_iter_buffer again)
+    r->iters_external = nullptr;
+    r->iters_external_bytes = 0;
 
     // ResetMemory(..., ResetPerturb::Yes, ...) -- GPU_Render.cu:346
     free_perturb(r);
@@ -470,17 +478,32 @@ uint32_t fs_set_row_bands(fs_renderer *r, uint32_t band_first_row, uint32_t band
     r->band_rows = band_rows;
     r->band_stride = band_stride_rows;
     compute_local_rows(r);
-    return ensure_iter_buffer(r);
+    const uint32_t e = ensure_iter_buffer(r);
+    if (e && r->iters_external) { // the caller's buffer does not hold the new banding: fall back to the internal one
+        r->iters_external = nullptr;
+        r->iters_external_bytes = 0;
+        (void)ensure_iter_buffer(r);
+    }
+    return e;
 }
 
 uint32_t fs_local_rows(const fs_renderer *r) { return r->local_rows_padded; }
 
-uint32_t fs_set_external_iter_buffer(fs_renderer *r, void *device_ptr)
+uint32_t fs_set_external_iter_buffer(fs_renderer *r, void *device_ptr, uint64_t capacity_bytes)
 {
+    if (uint32_t e = use_device(r))
+        return e;
+    if (r->width == 0)
+        return FS_ERR_6;
     r->iters_external = device_ptr;
-    if (!device_ptr)
-        return ensure_iter_buffer(r);
-    return 0;
+    r->iters_external_bytes = device_ptr ? (size_t)capacity_bytes : 0;
+    const uint32_t e = ensure_iter_buffer(r); // too small for the current geometry: rejected, internal buffer restored
+    if (e && device_ptr) {
+        r->iters_external = nullptr;
+        r->iters_external_bytes = 0;
+        (void)ensure_iter_buffer(r);
+    }
+    return e;
 }
 
 void *fs_device_iter_buffer(const fs_renderer *r) { return r->iters(); }
@@ -887,14 +910,14 @@ uint32_t fs_build_bla(fs_renderer *r, int type_tag, const void *bla_size)
     int32_t lm2 = n_levels - 2;
     if (lm2 < 0)
         lm2 = 0;
-    std::vector<void *> ptrs((size_t)n_levels, nullptr);
-    std::vector<uint64_t> sizes((size_t)n_levels, 0);
+    // the renderer owns each level from the moment it is allocated (freed by the next build / upload / free_perturb)
+    r->bla_level_mem.assign((size_t)n_levels, nullptr);
+    r->bla_level_sizes.assign((size_t)n_levels, 0);
     for (int l = 2; l < n_levels; l++) { // m_FirstLevel = 2: levels 0 and 1 are never materialised
-        FS_TRY(hipMalloc(&ptrs[l], epl[l] * rec_bytes));
-        sizes[l] = epl[l];
+        FS_TRY(hipMalloc(&r->bla_level_mem[(size_t)l], epl[l] * rec_bytes));
+        r->bla_level_sizes[(size_t)l] = epl[l];
     }
-    r->bla_level_mem = ptrs;
-    r->bla_level_sizes = sizes;
+    const std::vector<void *> &ptrs = r->bla_level_mem;
     FS_TRY(hipMalloc((void **)&r->bla_levels_dev, sizeof(void *) * (size_t)n_levels));
     FS_TRY(hipMemcpyAsync((void *)r->bla_levels_dev, ptrs.data(), sizeof(void *) * (size_t)n_levels, hipMemcpyDefault,
                           r->compute));
@@ -1291,8 +1314,8 @@ uint32_t fs_render_current(fs_renderer *r, uint64_t n_iterations, void *iter_buf
         FS_TRY(hipGetLastError());
     }
     if (reduction) {
-        const fs_reduction seed{r->iter_bytes == 8 ? ~0ull : 0xFFFFFFFFull, 0, 0}; // ReductionKernels.cuh:99-104
-        FS_TRY(hipMemcpyAsync(r->reduction, &seed, sizeof(seed), hipMemcpyHostToDevice, s));
+        r->reduce_seed = fs_reduction{r->iter_bytes == 8 ? ~0ull : 0xFFFFFFFFull, 0, 0}; // ReductionKernels.cuh:99-104
+        FS_TRY(hipMemcpyAsync(r->reduction, &r->reduce_seed, sizeof(fs_reduction), hipMemcpyHostToDevice, s));
         fsk_reduce(r->iters(), r->iter_bytes == 8, rw, r->width, r->local_rows, r->reduction, s);
         FS_TRY(hipGetLastError());
     }
@@ -1394,7 +1417,9 @@ uint32_t fs_read_step_count(fs_renderer *r, uint64_t counts[8])
         return e;
     if (!r->stats)
         return FS_ERR_6;
-    FS_TRY(hipMemcpy(counts, r->stats, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    // ordered behind the kernels of the (non-blocking) compute stream, which the null stream is not
+    FS_TRY(hipMemcpyAsync(counts, r->stats, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, r->compute));
+    FS_TRY(hipStreamSynchronize(r->compute));
     return 0;
 }
 

@@ -73,8 +73,8 @@ class GPURenderer:
         """The renderer's compute stream as a raw hipStream_t (int), e.g. for torch.cuda.ExternalStream."""
         return self._lib.fs_compute_stream(self._h) or 0
 
-    def SetExternalIterBuffer(self, device_ptr):
-        return self._lib.fs_set_external_iter_buffer(self._h, device_ptr)
+    def SetExternalIterBuffer(self, device_ptr, capacity_bytes=0):
+        return self._lib.fs_set_external_iter_buffer(self._h, device_ptr, int(capacity_bytes))
 
     def GetWidth(self):
         return self._lib.fs_get_width(self._h)

@@ -99,8 +99,11 @@ uint32_t fs_set_row_bands(fs_renderer *r, uint32_t band_first_row, uint32_t band
 uint32_t fs_local_rows(const fs_renderer *r);
 
 /* Optional: render into caller-owned DEVICE memory (e.g. a torch tensor handed to RCCL) instead of the
- * internal buffer.  Must hold fs_local_rows() x rounded-width elements.  NULL restores the internal buffer. */
-uint32_t fs_set_external_iter_buffer(fs_renderer *r, void *device_ptr);
+ * internal buffer.  capacity_bytes = size of the caller's allocation: it must hold fs_local_rows() x rounded-width
+ * elements of sizeof(IterType), otherwise hipErrorInvalidValue is returned and the internal buffer stays in use.
+ * fs_init_memory with a new geometry drops the pointer; fs_set_row_bands re-validates it against the new banding
+ * (and falls back to the internal buffer with an error when it is too small).  NULL restores the internal buffer. */
+uint32_t fs_set_external_iter_buffer(fs_renderer *r, void *device_ptr, uint64_t capacity_bytes);
 void *fs_device_iter_buffer(const fs_renderer *r);
 uint32_t fs_rounded_width(const fs_renderer *r);
 
