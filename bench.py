@@ -4,19 +4,24 @@
   python bench.py --gpus N --steps K --warmup W
   (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-One "step" = one full frame: the LAv2 iteration kernel over every (sub)pixel; for N > 1 each rank renders its
-interleaved 8-row bands and the slices are gathered to every rank with one RCCL all-gather (fractalshark_amd/
-tiling.py).  Inputs (reference orbit, LA table) are generated on the host with GMP *before* the timed region
-and are resident in HBM when it starts; `value` = W*H*K / t with t = max over ranks of the barrier-bracketed
-wall time.  Prints ONE JSON line on rank 0.
+One "step" = one full frame in the window SURVEY.md section 8(d) defines (the reference's m_PerPixel timer,
+Fractal.cpp:2842 -> :1539): launch of the iteration kernel -> iteration buffer resident in HOST memory.  For N > 1
+each rank renders its interleaved 8-row bands, the slices are gathered with one RCCL all-gather
+(fractalshark_amd/tiling.py), and rank 0 copies the reassembled frame to the host.  Inputs (reference orbit, LA
+table) are generated on the host with GMP *before* the timed region and are resident in HBM when it starts;
+`value` = W*H*K / t with t = max over ranks of the barrier-bracketed wall time.  Prints ONE JSON line on rank 0.
 
 Extra objects (round contract):
-  roofline      dominant kernel = k_lav2_hdr32.  It is VALU-bound (scalar complex arithmetic, no dense
-                contraction; orbit + table are L2 resident), so `bound` is "valu": achieved = executed
+  roofline      dominant kernel of the workload.  The perturbation kernels are VALU-bound (scalar complex arithmetic,
+                no dense contraction; orbit + table are L2 resident), so `bound` is "valu": achieved = executed
                 pixel-steps x 18 FP32 flop / average kernel duration measured with HIP
                 events on the renderer's compute stream; peak = 157.3 TFLOP/s FP32 vector (MI355X_MICROARCH.md).
   cpu_baseline  the CPU oracle (restatement of the reference's multithreaded CPU RenderAlgorithm, same row-claiming
-                thread pool) timed on this host's cores over a bounded sample of rows of the same frame.
+                thread pool) timed on this host's cores over a bounded sample of rows of the same frame -- the
+                UNMODIFIED function; `cpu_baseline_patched` is the same with the LA stage test in the GPU direction
+                (SURVEY.md section 0.1 / 8(d) asks for both).
+  secondary     (c3_lav2 only) the same frame with FS_PARITY_CPU_GPUSTAGE, timed the same way: the configuration in
+                which the LA stages are actually used (the literal CPU stage test skips every stage at View 5).
 """
 import argparse
 import json
@@ -31,6 +36,15 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 FLOP_PER_STEP = 18            # complex dz*(2Z+dz)+dc, |Z+dz|^2, |dz|^2
 PEAK_FP32_VECTOR_TFLOPS = 157.3
 PEAK_FP64_VECTOR_TFLOPS = 78.6
+
+WORKLOADS = {  # name: (view, width, height, tag in config.workload, dominant kernel)
+    "c3_lav2": (5, 3840, 2160, "hdrx32_lav2_full", "k_lav2_hdr32_fast"),
+    "c2_po": (5, 1920, 1080, "hdrx32_po", "k_perturb_scalar"),
+    "c5_bla": (19, 7680, 4320, "hdrx32_bla", "k_perturb_scalar"),
+    "c4_hdr64": (14, 3840, 2160, "hdrx64_lav2_full_aa4", "k_lav2_lit<double>"),
+    "c4_2x32": (14, 3840, 2160, "hdrx2x32_lav2_full_aa4", "k_lav2_2x32"),
+    "c4_scaled": (14, 3840, 2160, "hdrx32_scaled_aa1_itercap", "k_scaled_hdr32"),
+}
 
 
 def effective_cpus():
@@ -51,24 +65,31 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["c3_lav2", "c2_po", "c5_bla", "c4_hdr64", "c4_2x32"], default="c3_lav2",
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3_lav2",
                     help="c3_lav2 (default, the headline config): View 5 3840x2160 HDRx32 LAv2 Full; "
                          "c2_po: View 5 1920x1080 HDRx32 perturbation only; c5_bla: View 19 7680x4320 HDRx32 BLA; "
                          "c4_hdr64: View 14 (zoom 2^-21645) 3840x2160 x AA4 = 15360x8640 with HDRFloat<double> LAv2 -- the "
                          "CPU-twinned form of C4 (use --parity cpu_gpustage: the literal CPU function needs ~6e5 "
                          "perturbation steps per pixel there); c4_2x32: the same frame with HDRFloat<CudaDblflt> "
-                         "(GpuHDRx2x32PerturbedLAv2), checked against the restated CUDA kernel (no CPU twin exists)")
+                         "(GpuHDRx2x32PerturbedLAv2), checked against the restated CUDA kernel (no CPU twin exists); "
+                         "c4_scaled: View 14 at 3840x2160 (AA 1) through GpuHDRx32PerturbedScaled with the iteration cap "
+                         "lowered to --iter-cap (perturbation-only rendering of this view needs the full 2^31 steps for "
+                         "almost every pixel), checked against the restated CUDA kernel")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--view", type=int, default=-1)
+    ap.add_argument("--iter-cap", type=int, default=0,
+                    help="override the view's iteration cap (default: the view's own; 65536 for c4_scaled)")
     ap.add_argument("--parity", choices=["cpu", "cpu_gpustage"], default=None,
                     help="cpu = literal reference CPU function (bit-exact vs Cpu32PerturbedBLAV2HDR); "
                          "cpu_gpustage = same arithmetic, LA stage test in the GPU/FractalZoomer direction. "
                          "Default: cpu, except c4_hdr64 (cpu_gpustage: the literal CPU direction skips every LA "
                          "stage at View 14 and iterates towards the 2^31 cap)")
     ap.add_argument("--cpu-sample-rows", type=int, default=0,
-                    help="rows of the frame timed on the CPU (0 = 8 x usable host threads, about 10-30 s of CPU work)")
+                    help="rows of the frame timed on the CPU (0 = a per-workload multiple of the usable host threads, "
+                         "about 10-30 s of CPU work)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-build", action="store_true",
                     help="never spawn a compiler (same as FS_NO_BUILD=1): required under rocprofv3, see tools/pmc_passes.sh")
     return ap.parse_args()
@@ -87,6 +108,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # FS_FORCE_DIST=1 exercises the RCCL gather path with a single rank (1-GPU boxes)
     distributed = world > 1 or os.environ.get("FS_FORCE_DIST") == "1"
+    no_build = args.no_build or os.environ.get("FS_NO_BUILD") == "1"
+    if no_build:
+        os.environ["FS_NO_BUILD"] = "1"
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -95,7 +119,7 @@ def main():
     else:
         torch.cuda.set_device(0)
     if rank == 0:
-        if os.environ.get("FS_NO_BUILD") == "1" or args.no_build:
+        if no_build:
             # under a profiler (rocprofv3 preloads a library that has initialised the GPU) no compiler may be spawned:
             # a stale or missing library is an error, not a rebuild
             if not _build.up_to_date():
@@ -110,30 +134,35 @@ def main():
         raise RuntimeError("no usable HIP device; there is no CPU fallback")
 
     # ---- inputs (host, outside the timed region)
-    defaults = {"c3_lav2": (5, 3840, 2160), "c2_po": (5, 1920, 1080), "c5_bla": (19, 7680, 4320),
-                "c4_hdr64": (14, 3840, 2160), "c4_2x32": (14, 3840, 2160)}[args.workload]
+    wl = args.workload
+    dview, dw, dh, wl_tag, wl_kernel = WORKLOADS[wl]
     if args.view < 0:
-        args.view = defaults[0]
+        args.view = dview
     if args.width <= 0:
-        args.width = defaults[1]
+        args.width = dw
     if args.height <= 0:
-        args.height = defaults[2]
+        args.height = dh
     if args.parity is None:
-        args.parity = "cpu_gpustage" if args.workload == "c4_hdr64" else "cpu"
+        args.parity = "cpu_gpustage" if wl == "c4_hdr64" else "cpu"
     t0 = time.time()
-    is_lav2 = args.workload in ("c3_lav2", "c4_hdr64", "c4_2x32")
-    is2x32 = args.workload == "c4_2x32"
-    is64 = args.workload in ("c4_hdr64", "c4_2x32")  # the 2x32 inputs are derived from the HDRFloat<double> ones
+    is_lav2 = wl in ("c3_lav2", "c4_hdr64", "c4_2x32")
+    is2x32 = wl == "c4_2x32"
+    is_scaled = wl == "c4_scaled"
+    is64 = wl in ("c4_hdr64", "c4_2x32")  # the 2x32 inputs are derived from the HDRFloat<double> ones
     view = inputs.View.builtin(args.view, args.width, args.height, antialiasing=None if is64 else 1)
     orbit = inputs.Orbit(view, is64=is64)
     la = inputs.LATable(orbit, host_threads=effective_cpus(), use_small_exponents=is2x32) if is_lav2 else None
     orbit2 = inputs.Orbit2x32(orbit) if is2x32 else None
     la2 = inputs.LATable2x32(la) if is2x32 else None
-    bla = inputs.BLATable(orbit) if args.workload == "c5_bla" else None
+    bla = inputs.BLATable(orbit) if wl == "c5_bla" else None
     t_inputs = time.time() - t0
     AA = view.antialiasing
     W, H = view.width * AA, view.height * AA
     n_iter = view.num_iterations
+    if args.iter_cap > 0:
+        n_iter = args.iter_cap
+    elif is_scaled:
+        n_iter = 65536
     parity = PARITY_CPU if args.parity == "cpu" else PARITY_CPU_GPUSTAGE
     if is2x32:
         coords_arr = view.coords_perturb_2x32(orbit2)
@@ -146,14 +175,19 @@ def main():
     err = r.InitializeMemory(W, H, AA, None, 0, 0, 0, False)
     assert err == 0, GPURenderer.ConvertErrorToString(err)
     T_TAG = T_HDR2X32 if is2x32 else (T_HDR64 if is64 else T_HDR32)
+    lib = r._lib
     if is2x32:
         assert r.InitializePerturb(1, orbit2, 0, None, la2) == 0
     elif is_lav2:
         assert r.InitializePerturb(1, orbit, 0, None, la) == 0
+    elif is_scaled:
+        # the reference re-uploads both PerturbExtras::Bad orbits inside every RenderPerturbBLAScaled call
+        # (GPU_Render.cu:1324-1345); here once, outside the timed region (inputs resident in HBM)
+        assert lib.fs_upload_orbit_scaled(r._h, T_HDR32, 4, orbit.bad_data_ptr, orbit.bad_f32_data_ptr, orbit.count,
+                                          orbit.period) == 0
     else:
         # the reference re-uploads orbit + BLA table inside every RenderPerturbBLA call (GPU_Render.cu:1464-1479);
         # here they are uploaded once, outside the timed region (inputs resident in HBM)
-        lib = r._lib
         assert lib.fs_upload_orbit(r._h, 1, T_HDR32, 4, orbit.data_ptr, orbit.count, orbit.count, orbit.period) == 0
         if bla is not None:
             assert lib.fs_upload_bla(r._h, T_HDR32, bla.level_ptrs, bla.level_sizes, bla.num_levels, bla.lm2) == 0
@@ -161,6 +195,10 @@ def main():
             assert lib.fs_upload_bla(r._h, T_HDR32, None, None, 0, 0) == 0
     band = tiling.band_height(1)
     rw = r.rounded_width
+    # the host copy of the frame (the reference's ItersMemoryContainer): page-locked so the D2H is one DMA
+    rows_padded = (H + 7) // 8 * 8
+    host_frame_t = torch.zeros((rows_padded, rw), dtype=torch.int32, pin_memory=True) if rank == 0 else None
+    host_frame = host_frame_t.numpy().view(np.uint32) if rank == 0 else None
     if distributed:
         assert r.SetRowBands(rank * band, band, world * band) == 0
         max_rows = tiling.max_local_rows(H, world, band)
@@ -170,126 +208,159 @@ def main():
         assert r.SetExternalIterBuffer(local.data_ptr(), local.numel() * local.element_size()) == 0
         render_stream = torch.cuda.ExternalStream(r.compute_stream)
     kernel_ms = []
-    steps_executed = []
 
-    def one_frame(record):
+    def one_frame(record, par):
+        """Launch -> iteration buffer in host memory (rank 0)."""
         if is_lav2:
-            e = r.RenderPerturbLAv2(None, None, None, *coords, n_iter, T=T_TAG, Mode=LAV2_FULL, parity=parity)
+            e = r.RenderPerturbLAv2(None, None, None, *coords, n_iter, T=T_TAG, Mode=LAV2_FULL, parity=par)
+        elif is_scaled:
+            e = lib.fs_render_scaled(r._h, T_HDR32, coords_arr.ctypes.data, n_iter)
         else:
-            e = r._lib.fs_render_bla(r._h, T_HDR32, coords_arr.ctypes.data, n_iter)
+            e = lib.fs_render_bla(r._h, T_HDR32, coords_arr.ctypes.data, n_iter)
         assert e == 0, GPURenderer.ConvertErrorToString(e)
-        frame = None
         if distributed:
             # the gather waits for the render on the device (stream-to-stream), not through the host
             torch.cuda.current_stream().wait_stream(render_stream)
             dist.all_gather_into_tensor(gathered, local)
-            frame = gathered.index_select(0, frame_index)
+            if rank == 0:
+                frame = gathered.index_select(0, frame_index)
+                host_frame_t[:frame.shape[0]].copy_(frame, non_blocking=True)
         else:
+            # RenderCurrent: D2H of the padded buffer on the compute stream, behind the kernel (GPU_Render.cu:1759-1805)
+            assert r.RenderCurrent(n_iter, host_frame) == 0
             assert r.SyncComputeStream() == 0
         torch.cuda.synchronize()
-        if record:
-            kernel_ms.append(r.last_kernel_ms())
-        return frame
+        if record is not None:
+            record.append(r.last_kernel_ms())
 
-    # Executed work per frame is a pure function of the inputs: count it once in an untimed launch with the
-    # instrumented kernel build (wave-reduced atomics), then time the uninstrumented kernel.
-    r.enable_step_count(True)
-    one_frame(False)
-    steps_executed = [r.read_step_count()] * args.steps
-    r.enable_step_count(False)
+    def timed(par, record):
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_frame(record, par)
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if distributed:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    def count_steps(par):
+        # Executed work per frame is a pure function of the inputs: count it once in an untimed launch with the
+        # instrumented kernel build (wave-reduced atomics); the timed launches run the uninstrumented kernel.
+        r.enable_step_count(True)
+        one_frame(None, par)
+        st = r.read_step_count()
+        r.enable_step_count(False)
+        if distributed:
+            keys = ("perturb_steps", "at_iterations", "la_steps")
+            t = torch.tensor([st[k] for k in keys], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            st = dict(st)
+            st.update({k: float(x) for k, x in zip(keys, t.tolist())})
+        return st
+
+    st = count_steps(parity)
     for _ in range(args.warmup):
-        one_frame(False)
+        one_frame(None, parity)
+    elapsed = timed(parity, kernel_ms)
     if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    frame = None
-    for _ in range(args.steps):
-        frame = one_frame(True)
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        # executed pixel-steps and kernel time summed / maxed over ranks for the roofline line
-        st = torch.tensor([sum(s["perturb_steps"] for s in steps_executed),
-                           sum(s["at_iterations"] for s in steps_executed),
-                           sum(s["la_steps"] for s in steps_executed)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(st, op=dist.ReduceOp.SUM)
         km = torch.tensor([sum(kernel_ms)], dtype=torch.float64, device="cuda")
         dist.all_reduce(km, op=dist.ReduceOp.MAX)
-        perturb_steps, at_iters, la_steps = [float(x) / args.steps for x in st.tolist()]
         avg_kernel_ms = float(km.item()) / args.steps
     else:
-        perturb_steps = sum(s["perturb_steps"] for s in steps_executed) / args.steps
-        at_iters = sum(s["at_iterations"] for s in steps_executed) / args.steps
-        la_steps = sum(s["la_steps"] for s in steps_executed) / args.steps
         avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
-    lane_slots = sum(s["lane_slots"] for s in steps_executed) / args.steps
+    perturb_steps, at_iters, la_steps = float(st["perturb_steps"]), float(st["at_iterations"]), float(st["la_steps"])
+    lane_slots = st["lane_slots"]
+    checksum = int(host_frame[:H, :W].astype(np.uint64).sum()) if rank == 0 else None
+    frame_main = host_frame.copy() if rank == 0 else None
 
-    # ---- PCIe-inclusive number (never `value`): one frame incl. D2H of the padded iteration buffer
-    d2h_ms = None
-    checksum = None
-    if rank == 0:
-        if distributed:
-            host = frame.cpu().numpy().view(np.uint32)
-            checksum = int(host[:H, :W].astype(np.uint64).sum())
-        else:
-            out = r.new_iter_buffer()
-            t1 = time.perf_counter()
-            assert r.RenderCurrent(n_iter, out) == 0
-            assert r.SyncComputeStream() == 0
-            d2h_ms = (time.perf_counter() - t1) * 1e3
-            checksum = int(out[:H, :W].astype(np.uint64).sum())
+    # ---- secondary: the same frame with the LA stages in use (GPU-direction stage test), driver-timed like `value`
+    secondary = None
+    frame_secondary = None
+    if wl == "c3_lav2" and args.parity == "cpu" and not args.no_secondary:
+        st2 = count_steps(PARITY_CPU_GPUSTAGE)
+        one_frame(None, PARITY_CPU_GPUSTAGE)
+        km2 = []
+        el2 = timed(PARITY_CPU_GPUSTAGE, km2)
+        if rank == 0:
+            secondary = {"what": "same frame, FS_PARITY_CPU_GPUSTAGE: CPU arithmetic with the LA stage test in the "
+                                 "direction of GPU_LAReference.h:240-254 (the LA stages are used)",
+                         "ms_per_step": round(el2 / args.steps * 1e3, 3),
+                         "value": round(W * H * args.steps / el2 / 1e6, 4), "unit": "Mpix/s",
+                         "kernel_ms_rank0": round(sum(km2) / len(km2), 3),
+                         "la_steps_per_launch": float(st2["la_steps"]),
+                         "at_iterations_per_launch": float(st2["at_iterations"]),
+                         "pixel_steps_per_launch": float(st2["perturb_steps"]),
+                         "frame_checksum": int(host_frame[:H, :W].astype(np.uint64).sum())}
+            frame_secondary = host_frame.copy()
 
     # ---- CPU baseline on a bounded sample of rows (rank 0, N = 1 only)
     cpu_baseline = None
+    cpu_baseline_patched = None
     parity_rows_ok = None
     if rank == 0 and not distributed and not args.no_cpu:
         import _oracle
         threads = effective_cpus()
         # rows per host thread chosen per workload so that the sample is 10-30 s of CPU work on the box's 16 threads
-        per_thread = {"c3_lav2": 8, "c2_po": 3, "c5_bla": 32, "c4_hdr64": 64, "c4_2x32": 8}[args.workload]
+        per_thread = {"c3_lav2": 8, "c2_po": 3, "c5_bla": 32, "c4_hdr64": 64, "c4_2x32": 8, "c4_scaled": 4}[wl]
         nrows = max(1, min(args.cpu_sample_rows if args.cpu_sample_rows > 0 else per_thread * threads, H))
         step = max(1, H // nrows)
         y0 = step // 2
         rows = list(range(y0, H, step))
-        stage_test = 0 if args.parity == "cpu" else 1
         _oracle.lib()  # build / load outside the timed window
-        _oracle.set_row_step(step)
-        t1 = time.perf_counter()
-        if is2x32:
-            ref = _oracle.gpu_lav2_2x32(view, orbit2, la2, aa=AA, rows=(y0, H), threads=threads)
-        elif is_lav2:
-            ref = _oracle.lav2_hdr32(view, orbit, la, aa=AA, rows=(y0, H), threads=threads, stage_test=stage_test)
-        else:
-            ref = _oracle.bla_hdr32(view, orbit, bla, aa=AA, rows=(y0, H), threads=threads)
-        cpu_t = time.perf_counter() - t1
-        _oracle.set_row_step(1)
-        refs = [(y, ref[y]) for y in rows]
-        nrows = len(rows)
-        parity_rows_ok = all(np.array_equal(out[y], ref) for y, ref in refs)
-        cpu_baseline = {"value": round(nrows * W / cpu_t / 1e6, 6), "unit": "Mpix/s", "cores": threads,
-                        "kind": "port",
-                        "sample": "%d of %d rows of the same %dx%d frame (rows spread evenly), %.1f s" %
-                                  (nrows, H, W, H, cpu_t)}
+
+        def cpu_run(stage_test):
+            _oracle.set_row_step(step)
+            t1 = time.perf_counter()
+            if is2x32:
+                ref = _oracle.gpu_lav2_2x32(view, orbit2, la2, aa=AA, rows=(y0, H), threads=threads)
+            elif is_lav2:
+                ref = _oracle.lav2_hdr32(view, orbit, la, aa=AA, rows=(y0, H), threads=threads, stage_test=stage_test)
+            elif is_scaled:
+                ref = _oracle.gpu_scaled_hdr32(view, orbit, aa=AA, rows=(y0, H), threads=threads, n_iterations=n_iter)
+            else:
+                ref = _oracle.bla_hdr32(view, orbit, bla, aa=AA, rows=(y0, H), threads=threads)
+            dt = time.perf_counter() - t1
+            _oracle.set_row_step(1)
+            return ref, dt
+
+        def line(dt, what):
+            return {"value": round(len(rows) * W / dt / 1e6, 6), "unit": "Mpix/s", "cores": threads,
+                    "kind": "port", "what": what,
+                    "sample": "%d of %d rows of the same %dx%d frame (rows spread evenly), %.1f s" %
+                              (len(rows), H, W, H, dt)}
+
+        ref, cpu_t = cpu_run(0 if args.parity == "cpu" else 1)
+        parity_rows_ok = all(np.array_equal(frame_main[y], ref[y]) for y in rows)
+        twin = {"c3_lav2": "Cpu32PerturbedBLAV2HDR", "c4_hdr64": "Cpu64PerturbedBLAV2HDR",
+                "c2_po": "Cpu32PerturbedBLAHDR (single-step branch)",
+                "c5_bla": "Cpu32PerturbedBLAHDR"}.get(wl, "the CUDA kernel (no CPU twin exists)")
+        cpu_baseline = line(cpu_t, "oracle restatement of " + twin +
+                            (", unmodified" if args.parity == "cpu" else ", LA stage test patched to the GPU direction"))
+        if secondary is not None:
+            ref2, cpu_t2 = cpu_run(1)
+            secondary["cpu_sample_rows_bit_exact"] = all(np.array_equal(frame_secondary[y], ref2[y]) for y in rows)
+            cpu_baseline_patched = line(cpu_t2, "the same function with LAReference::isLAStageInvalid in the GPU direction")
 
     traffic = None
     if rank == 0:
         # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (collected in separate
-        # --pmc runs, see profiles/r01_traffic.json); null for workloads that have not been profiled.
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            key = "view%d_%dx%d_%s" % (args.view, W, H, {"c3_lav2": "hdrx32_lav2_full", "c2_po": "hdrx32_po", "c5_bla": "hdrx32_bla",
-                                                                 "c4_hdr64": "hdrx64_lav2_full_aa4",
-                                                                 "c4_2x32": "hdrx2x32_lav2_full_aa4"}[args.workload])
-            if key in tj and not distributed and args.parity == "cpu":
-                traffic = tj[key]["traffic_bytes"]
-        except (OSError, ValueError, KeyError):
-            traffic = None
+        # --pmc runs by tools/pmc_passes.sh); null for workloads that have not been profiled.
+        key = "view%d_%dx%d_%s" % (args.view, W, H, wl_tag)
+        for tf in ("r02_traffic.json", "r01_traffic.json"):
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
+                if key in tj and not distributed and args.parity == "cpu" and args.iter_cap == 0:
+                    traffic = tj[key]["traffic_bytes"]
+                    break
+            except (OSError, ValueError, KeyError):
+                pass
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = W * H * args.steps / elapsed / 1e6
@@ -302,39 +373,42 @@ def main():
             # HDRFloat<double>: FP64 operations; AT iteration = 5 mul + 5 add (z*z + c on bare mantissas + the norm),
             # perturbation step = 18, LA step = 2 complex mul-adds + 2 norms = 40
             flops = at_iters * 10.0 + perturb_steps * FLOP_PER_STEP + la_steps * 40.0
+        elif is_scaled:
+            # scaled kernel counters: [0] rescales, [1] full-precision (HDRFloat) steps, [2] binary32 steps; every step is
+            # the 18-flop perturbation step of SURVEY 8(d)
+            flops = (perturb_steps + la_steps) * FLOP_PER_STEP
         else:
             flops = perturb_steps * FLOP_PER_STEP
         peak = PEAK_FP64_VECTOR_TFLOPS if (is64 and not is2x32) else PEAK_FP32_VECTOR_TFLOPS
         achieved = flops / (avg_kernel_ms * 1e-3) / 1e12
-        line = {
-            "metric": "Mpix/s (iteration buffer), View #5 3840x2160 HDRx32 LAv2" if args.workload == "c3_lav2"
-            else "Mpix/s (iteration buffer), " + args.workload,
+        out = {
+            "metric": "Mpix/s (iteration buffer), View #5 3840x2160 HDRx32 LAv2" if wl == "c3_lav2"
+            else "Mpix/s (iteration buffer), " + wl,
             "value": round(value, 4), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "2xf32+i32exp" if is2x32 else ("f64+i32exp" if is64 else "f32+i32exp"), "data": "synthetic",
-            "config": {"workload": "view%d_%dx%d_%s" % (args.view, W, H, {"c3_lav2": "hdrx32_lav2_full", "c2_po": "hdrx32_po",
-                                                                                "c5_bla": "hdrx32_bla",
-                                                                                "c4_hdr64": "hdrx64_lav2_full_aa4",
-                                                                                "c4_2x32": "hdrx2x32_lav2_full_aa4"}[args.workload]),
+            "vs_baseline": None, "dtype": "2xf32+i32exp" if is2x32 else ("f64+i32exp" if is64 else "f32+i32exp"),
+            "data": "built-in view %d of the reference (deterministic: no dataset or randomness on this path)" % args.view,
+            "window": "kernel launch -> iteration buffer in (page-locked) host memory, SURVEY.md 8(d)",
+            "config": {"workload": "view%d_%dx%d_%s" % (args.view, W, H, wl_tag),
                        "parity": args.parity, "n_iterations": n_iter, "orbit_entries": orbit.count,
                        "la_records": la.count if la else 0, "la_stages": la.stage_count if la else 0,
                        "bla_levels": bla.num_levels if bla else 0, "tiling": "rows/8-row bands interleaved x%d" % world,
                        "host_input_build_s": round(t_inputs, 3)},
             "roofline": {"bound": "valu", "achieved": round(achieved, 4), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(achieved / peak, 5), "traffic": traffic,
-                         "kernel": {"c3_lav2": "k_lav2_hdr32_fast", "c4_hdr64": "k_lav2_lit<double>",
-                                    "c4_2x32": "k_lav2_2x32"}.get(args.workload, "k_perturb_scalar"),
-                         "kernel_ms": round(avg_kernel_ms, 3),
+                         "kernel": wl_kernel, "kernel_ms": round(avg_kernel_ms, 3),
                          "pixel_steps_per_launch": perturb_steps, "at_iterations_per_launch": at_iters,
                          "la_steps_per_launch": la_steps, "flop_per_pixel_step": FLOP_PER_STEP,
-                         "careful_step_fraction_rank0": round(steps_executed[0].get("careful_steps", 0) /
-                                                              max(1, steps_executed[0]["perturb_steps"]), 5),
-                         "lane_utilisation_rank0": round(perturb_steps / lane_slots, 4) if lane_slots and not distributed else None},
-            "cpu_baseline": cpu_baseline,
+                         "careful_step_fraction_rank0": round(st.get("careful_steps", 0) / max(1.0, perturb_steps), 5)
+                         if not distributed else None,
+                         "lane_utilisation_rank0": round(perturb_steps / lane_slots, 4)
+                         if lane_slots and not distributed else None},
+            "cpu_baseline": cpu_baseline, "cpu_baseline_patched": cpu_baseline_patched, "secondary": secondary,
             "frame_checksum": checksum, "cpu_sample_rows_bit_exact": parity_rows_ok,
-            "d2h_inclusive_ms": None if d2h_ms is None else round(d2h_ms + avg_kernel_ms, 3),
+            "device_resident_ms": round(avg_kernel_ms, 3),
+            "device_resident_mpix_s": round(W * H / avg_kernel_ms / 1e3, 4),
         }
-        print(json.dumps(line))
+        print(json.dumps(out))
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

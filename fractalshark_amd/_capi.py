@@ -123,6 +123,7 @@ def render_lib():
     _decl(lib, "fs_set_kernel_variant", u32, [vp, C.c_int])
     _decl(lib, "fs_enable_step_count", u32, [vp, C.c_int])
     _decl(lib, "fs_read_step_count", u32, [vp, vp])
+    _decl(lib, "fs_time_render_current", u32, [vp, u64, u32, vp])
     _render = lib
     return lib
 
@@ -135,6 +136,7 @@ RENDER_SYMBOLS = [
     "fs_render_direct_lp", "fs_clear",
     "fs_render_current", "fs_sync_compute", "fs_compute_stream", "fs_sync_display", "fs_query_compute", "fs_enqueue_done_callback",
     "fs_get_width", "fs_get_height", "fs_last_kernel_ms", "fs_set_kernel_variant", "fs_enable_step_count", "fs_read_step_count",
+    "fs_time_render_current",
 ]
 
 

@@ -238,6 +238,6 @@ void fsk_direct_f64(const FsDirectArgs64 &A, double minX, double dx, bool stats,
 // iter_u64: element type of the iteration buffer (see FsFrame)
 void fsk_antialias(const void *iters, int iter_u64, uint32_t rounded_width, fs_color16 *colors, const fs_color16 *pal,
                    uint32_t pal_iters, uint32_t aux_depth, uint32_t aa, uint32_t color_w, uint32_t color_h,
-                   uint32_t n_iterations, hipStream_t s);
+                   uint64_t n_iterations, hipStream_t s);
 void fsk_reduce(const void *iters, int iter_u64, uint32_t rounded_width, uint32_t width, uint32_t rows,
                 fs_reduction *out, hipStream_t s);

@@ -1618,74 +1618,6 @@ __global__ void k_direct_row_prefix_f64(double minX, double dx, uint32_t width, 
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// RenderCurrent pieces.  Antialias + palette: same arithmetic as antialiasing_kernel
-// (FractalSharkGpuLib/AntialiasingKernel.cuh:3-71): integer box filter, interior pixels contribute black,
-// alpha 65535, colour rows are NOT padded.
-template <class IterT>
-__global__ void __launch_bounds__(256) k_antialias(const IterT *__restrict__ iters, uint32_t rounded_width,
-                                                   fs_color16 *__restrict__ colors, const fs_color16 *__restrict__ pal,
-                                                   uint32_t pal_iters, uint32_t aux_depth, uint32_t aa,
-                                                   uint32_t color_w, uint32_t color_h, uint32_t n_iterations)
-{
-    const uint32_t ox = blockIdx.x * 64u + (threadIdx.x & 63u);
-    const uint32_t oy = blockIdx.y * 4u + (threadIdx.x >> 6);
-    if (ox >= color_w || oy >= color_h)
-        return;
-    uint64_t acc_r = 0, acc_g = 0, acc_b = 0;
-    for (uint32_t ix = ox * aa; ix < (ox + 1) * aa; ix++) {
-        for (uint32_t iy = oy * aa; iy < (oy + 1) * aa; iy++) {
-            const IterT n = iters[(size_t)iy * rounded_width + ix];
-            if (n < n_iterations) {
-                const uint32_t p = (uint32_t)((n >> aux_depth) % pal_iters);
-                const fs_color16 c = pal[p];
-                acc_r += c.r;
-                acc_g += c.g;
-                acc_b += c.b;
-            }
-        }
-    }
-    const uint32_t total = aa * aa;
-    fs_color16 o;
-    o.r = (uint16_t)(acc_r / total);
-    o.g = (uint16_t)(acc_g / total);
-    o.b = (uint16_t)(acc_b / total);
-    o.a = 65535;
-    colors[(size_t)oy * color_w + ox] = o;
-}
-
-// Min / max / sum of the valid (unpadded) part of the iteration buffer: max_kernel
-// (FractalSharkGpuLib/ReductionKernels.cuh:73-142) without its unsynchronised output reset -- the host
-// seeds {Min=numeric_limits<IterType>::max(), Max=0, Sum=0} on the stream before the launch.  Wave shuffles, one
-// atomic triple per wave.
-template <class IterT>
-__global__ void __launch_bounds__(256) k_reduce(const IterT *__restrict__ iters, uint32_t rounded_width,
-                                                uint32_t width, uint32_t rows, fs_reduction *out)
-{
-    uint64_t mn = (uint64_t)(IterT)~(IterT)0, mx = 0, sum = 0;
-    const uint64_t total = (uint64_t)rounded_width * rows;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t x = (uint32_t)(i % rounded_width);
-        if (x < width) {
-            const uint64_t v = iters[i];
-            mn = v < mn ? v : mn;
-            mx = v > mx ? v : mx;
-            sum += v;
-        }
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        const uint64_t omn = __shfl_down(mn, off), omx = __shfl_down(mx, off);
-        mn = omn < mn ? omn : mn;
-        mx = omx > mx ? omx : mx;
-        sum += __shfl_down(sum, off);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        atomicMin((unsigned long long *)&out->Min, (unsigned long long)mn);
-        atomicMax((unsigned long long *)&out->Max, (unsigned long long)mx);
-        atomicAdd((unsigned long long *)&out->Sum, (unsigned long long)sum);
-    }
-}
-
 // Orbit preparation for HDRFloat<double>.
 __global__ void k_prepare_orbit_hdr64(const fs_orbit_hdr64 *__restrict__ in, FsZ64 *__restrict__ out, uint64_t n)
 {
@@ -2124,26 +2056,3 @@ void fsk_direct_f64(const FsDirectArgs64 &A, double minX, double dx, bool stats,
         hipLaunchKernelGGL((k_direct_f64<false>), g, b, 0, s, A);
 }
 
-void fsk_antialias(const void *iters, int iter_u64, uint32_t rounded_width, fs_color16 *colors, const fs_color16 *pal,
-                   uint32_t pal_iters, uint32_t aux_depth, uint32_t aa, uint32_t color_w, uint32_t color_h,
-                   uint32_t n_iterations, hipStream_t s)
-{
-    const dim3 g((color_w + 63) / 64, (color_h + 3) / 4), b(256);
-    if (iter_u64)
-        hipLaunchKernelGGL(k_antialias<uint64_t>, g, b, 0, s, (const uint64_t *)iters, rounded_width, colors, pal,
-                           pal_iters, aux_depth, aa, color_w, color_h, n_iterations);
-    else
-        hipLaunchKernelGGL(k_antialias<uint32_t>, g, b, 0, s, (const uint32_t *)iters, rounded_width, colors, pal,
-                           pal_iters, aux_depth, aa, color_w, color_h, n_iterations);
-}
-
-void fsk_reduce(const void *iters, int iter_u64, uint32_t rounded_width, uint32_t width, uint32_t rows,
-                fs_reduction *out, hipStream_t s)
-{
-    if (iter_u64)
-        hipLaunchKernelGGL(k_reduce<uint64_t>, dim3(1024), dim3(256), 0, s, (const uint64_t *)iters, rounded_width,
-                           width, rows, out);
-    else
-        hipLaunchKernelGGL(k_reduce<uint32_t>, dim3(1024), dim3(256), 0, s, (const uint32_t *)iters, rounded_width,
-                           width, rows, out);
-}

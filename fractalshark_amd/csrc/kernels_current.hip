@@ -1,0 +1,229 @@
+// kernels_current.hip -- the device half of GPURenderer::RenderCurrent (FractalSharkGpuLib/GPU_Render.cu:556-581):
+// antialias + palette (antialiasing_kernel, AntialiasingKernel.cuh:3-71) and min / max / sum of the iteration buffer
+// (max_kernel, ReductionKernels.cuh:73-142).  Both are one pass over the iteration buffer and HBM-bound: 4*AA^2 B read +
+// 8 B written per colour pixel, 4 B read per iteration-buffer element (8 B for IterType = uint64_t).  The shape of both
+// kernels is therefore "every lane issues the widest aligned load its row segment allows and nothing else gets in the
+// way": one 16-byte load per AA row for AA = 4 (rows are multiples of 16 elements, so a 4-element group never
+// straddles an alignment boundary), no per-element 64-bit division anywhere.
+#include "kernel_common.hpp"
+
+namespace {
+
+// n % d for a 32-bit n and 2^8 <= d < 2^24, with the quotient estimated in binary32 and finished with integer
+// compare-free corrections (all full-rate instructions; the compiler's generic 32-bit remainder costs about twice as
+// much and the 64-bit one an order of magnitude more).
+//   q_est = trunc(float(n) * float(1/d)): relative error <= 3 * 2^-24, q <= 2^32 / 2^8 = 2^24, so q_est is within
+//   {q-2 .. q+1}.  With q' = max(q_est, 2) - 2 the remainder candidate n - q'*d lies in [0, 5d) subset of [0, 8d), and
+//   three "r = min(r, r - k*d)" steps (unsigned: r - k*d wraps above r exactly when r < k*d) bring it into [0, d).
+//   q' < 2^24 and d < 2^24, so the low 32 bits of q'*d come from the 24-bit multiplier.
+struct FastMod {
+    uint32_t d;
+    float inv;
+    uint32_t usable; // 1: the bounds above hold
+};
+
+__device__ __forceinline__ uint32_t fast_mod(uint32_t n, const FastMod &m)
+{
+    uint32_t q = (uint32_t)((float)n * m.inv);
+    q = (q > 2u ? q : 2u) - 2u;
+    uint32_t r = n - __umul24(q, m.d);
+    uint32_t t = r - 4u * m.d;
+    r = t < r ? t : r;
+    t = r - 2u * m.d;
+    r = t < r ? t : r;
+    t = r - m.d;
+    r = t < r ? t : r;
+    return r;
+}
+
+template <class IterT> struct Vec;
+template <> struct Vec<uint32_t> {
+    using V4 = uint4;
+    using V2 = uint2;
+};
+template <> struct Vec<uint64_t> {
+    using V4 = ulonglong4;
+    using V2 = ulonglong2;
+};
+
+// One colour pixel per lane, 64 consecutive pixels of a colour row per wave: with AA = 4 a wave reads 1 KiB of
+// consecutive bytes per AA row (64 x uint4), fully coalesced.  Integer sums, so the order of accumulation is free.
+template <class IterT, uint32_t AA, bool kFast>
+__global__ void __launch_bounds__(256) k_antialias(const IterT *__restrict__ iters, uint32_t rounded_width,
+                                                   fs_color16 *__restrict__ colors, const fs_color16 *__restrict__ pal,
+                                                   uint32_t pal_iters, FastMod fm, uint32_t aux_depth, uint32_t color_w,
+                                                   uint32_t color_h, uint64_t n_iterations)
+{
+    const uint32_t ox = blockIdx.x * 64u + (threadIdx.x & 63u);
+    const uint32_t oy = blockIdx.y * 4u + (threadIdx.x >> 6);
+    if (ox >= color_w || oy >= color_h)
+        return;
+    uint32_t acc_r = 0, acc_g = 0, acc_b = 0; // <= 16 x 65535 fits 32 bits
+    const IterT *row = iters + (size_t)(oy * AA) * rounded_width + (size_t)ox * AA;
+#pragma unroll
+    for (uint32_t iy = 0; iy < AA; iy++, row += rounded_width) {
+        IterT v[AA];
+        if constexpr (AA == 4) {
+            const auto q = *reinterpret_cast<const typename Vec<IterT>::V4 *>(row);
+            v[0] = q.x, v[1] = q.y, v[2] = q.z, v[3] = q.w;
+        } else if constexpr (AA == 2) {
+            const auto q = *reinterpret_cast<const typename Vec<IterT>::V2 *>(row);
+            v[0] = q.x, v[1] = q.y;
+        } else {
+#pragma unroll
+            for (uint32_t k = 0; k < AA; k++)
+                v[k] = row[k];
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < AA; k++) {
+            const IterT n = v[k];
+            if (n < n_iterations) {
+                uint32_t p;
+                if constexpr (kFast)
+                    p = fast_mod((uint32_t)(n >> aux_depth), fm);
+                else
+                    p = (uint32_t)((n >> aux_depth) % pal_iters);
+                const uint2 c = *reinterpret_cast<const uint2 *>(pal + p); // one 8-byte gather {r|g<<16, b|a<<16}
+                acc_r += c.x & 0xFFFFu;
+                acc_g += c.x >> 16;
+                acc_b += c.y & 0xFFFFu;
+            }
+        }
+    }
+    constexpr uint32_t total = AA * AA;
+    uint2 o;
+    o.x = (acc_r / total) | ((acc_g / total) << 16);
+    o.y = (acc_b / total) | (65535u << 16);
+    *reinterpret_cast<uint2 *>(colors + (size_t)oy * color_w + ox) = o;
+}
+
+// Min / max / sum of the valid (unpadded) part of the iteration buffer: max_kernel (ReductionKernels.cuh:73-142)
+// without its unsynchronised output reset -- the host seeds {Min = numeric_limits<IterType>::max(), Max = 0, Sum = 0} on
+// the stream before the launch.  2-D: x walks 4-element groups of a row (rows are multiples of 16 elements), y strides
+// rows -- no division; wave shuffles, then one LDS hop so that a workgroup issues a single atomic triple.
+template <class IterT>
+__global__ void __launch_bounds__(256) k_reduce(const IterT *__restrict__ iters, uint32_t rounded_width, uint32_t width,
+                                                uint32_t rows, fs_reduction *out)
+{
+    uint64_t mn = (uint64_t)(IterT)~(IterT)0, mx = 0, sum = 0;
+    const uint32_t x0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
+    if (x0 < width) {
+        const uint32_t nvalid = width - x0 < 4u ? width - x0 : 4u;
+        const IterT *p = iters + (size_t)blockIdx.y * rounded_width + x0;
+        const size_t stride = (size_t)gridDim.y * rounded_width;
+        auto fold = [&](const typename Vec<IterT>::V4 &q) {
+            const uint64_t v[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++)
+                if (k < nvalid) {
+                    mn = v[k] < mn ? v[k] : mn;
+                    mx = v[k] > mx ? v[k] : mx;
+                    sum += v[k];
+                }
+        };
+        using V4 = typename Vec<IterT>::V4;
+        uint32_t y = blockIdx.y;
+        // four rows per trip: four independent 16-byte loads in flight per lane
+        for (; y + 3u * gridDim.y < rows; y += 4u * gridDim.y, p += 4u * stride) {
+            const V4 q0 = *reinterpret_cast<const V4 *>(p);
+            const V4 q1 = *reinterpret_cast<const V4 *>(p + stride);
+            const V4 q2 = *reinterpret_cast<const V4 *>(p + 2u * stride);
+            const V4 q3 = *reinterpret_cast<const V4 *>(p + 3u * stride);
+            fold(q0);
+            fold(q1);
+            fold(q2);
+            fold(q3);
+        }
+        for (; y < rows; y += gridDim.y, p += stride)
+            fold(*reinterpret_cast<const V4 *>(p));
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint64_t omn = __shfl_down(mn, off), omx = __shfl_down(mx, off);
+        mn = omn < mn ? omn : mn;
+        mx = omx > mx ? omx : mx;
+        sum += __shfl_down(sum, off);
+    }
+    __shared__ uint64_t part[3][4];
+    const uint32_t wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63u) == 0) {
+        part[0][wave] = mn;
+        part[1][wave] = mx;
+        part[2][wave] = sum;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (uint32_t w = 1; w < 4; w++) {
+            mn = part[0][w] < mn ? part[0][w] : mn;
+            mx = part[1][w] > mx ? part[1][w] : mx;
+            sum += part[2][w];
+        }
+        atomicMin((unsigned long long *)&out->Min, (unsigned long long)mn);
+        atomicMax((unsigned long long *)&out->Max, (unsigned long long)mx);
+        atomicAdd((unsigned long long *)&out->Sum, (unsigned long long)sum);
+    }
+}
+
+template <class IterT, bool kFast>
+void launch_antialias(const void *iters, uint32_t rounded_width, fs_color16 *colors, const fs_color16 *pal,
+                      uint32_t pal_iters, FastMod fm, uint32_t aux_depth, uint32_t aa, uint32_t color_w, uint32_t color_h,
+                      uint64_t n_iterations, hipStream_t s)
+{
+    const dim3 g((color_w + 63) / 64, (color_h + 3) / 4), b(256);
+    const IterT *it = (const IterT *)iters;
+    switch (aa) {
+    case 1:
+        hipLaunchKernelGGL((k_antialias<IterT, 1, kFast>), g, b, 0, s, it, rounded_width, colors, pal, pal_iters, fm,
+                           aux_depth, color_w, color_h, n_iterations);
+        break;
+    case 2:
+        hipLaunchKernelGGL((k_antialias<IterT, 2, kFast>), g, b, 0, s, it, rounded_width, colors, pal, pal_iters, fm,
+                           aux_depth, color_w, color_h, n_iterations);
+        break;
+    case 3:
+        hipLaunchKernelGGL((k_antialias<IterT, 3, kFast>), g, b, 0, s, it, rounded_width, colors, pal, pal_iters, fm,
+                           aux_depth, color_w, color_h, n_iterations);
+        break;
+    default:
+        hipLaunchKernelGGL((k_antialias<IterT, 4, kFast>), g, b, 0, s, it, rounded_width, colors, pal, pal_iters, fm,
+                           aux_depth, color_w, color_h, n_iterations);
+        break;
+    }
+}
+
+} // namespace
+
+void fsk_antialias(const void *iters, int iter_u64, uint32_t rounded_width, fs_color16 *colors, const fs_color16 *pal,
+                   uint32_t pal_iters, uint32_t aux_depth, uint32_t aa, uint32_t color_w, uint32_t color_h,
+                   uint64_t n_iterations, hipStream_t s)
+{
+    FastMod fm;
+    fm.d = pal_iters;
+    fm.inv = pal_iters ? (float)(1.0 / (double)pal_iters) : 0.0f;
+    fm.usable = pal_iters >= 256u && pal_iters < (1u << 24);
+    if (iter_u64) // 64-bit counts: the shifted value may exceed 32 bits, generic remainder
+        launch_antialias<uint64_t, false>(iters, rounded_width, colors, pal, pal_iters, fm, aux_depth, aa, color_w, color_h,
+                                          n_iterations, s);
+    else if (fm.usable)
+        launch_antialias<uint32_t, true>(iters, rounded_width, colors, pal, pal_iters, fm, aux_depth, aa, color_w, color_h,
+                                         n_iterations, s);
+    else
+        launch_antialias<uint32_t, false>(iters, rounded_width, colors, pal, pal_iters, fm, aux_depth, aa, color_w, color_h,
+                                          n_iterations, s);
+}
+
+void fsk_reduce(const void *iters, int iter_u64, uint32_t rounded_width, uint32_t width, uint32_t rows,
+                fs_reduction *out, hipStream_t s)
+{
+    if (!rows || !width)
+        return;
+    const uint32_t gx = (width + 1023u) / 1024u;
+    // enough workgroups to fill 256 CUs several times over, few enough that the atomics (one triple per workgroup) stay
+    // in the low thousands
+    uint32_t gy = (2048u + gx - 1u) / gx;
+    gy = gy < rows ? gy : rows;
+    const dim3 g(gx, gy), b(256);
+    if (iter_u64)
+        hipLaunchKernelGGL(k_reduce<uint64_t>, g, b, 0, s, (const uint64_t *)iters, rounded_width, width, rows, out);
+    else
+        hipLaunchKernelGGL(k_reduce<uint32_t>, g, b, 0, s, (const uint32_t *)iters, rounded_width, width, rows, out);
+}

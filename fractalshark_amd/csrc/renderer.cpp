@@ -1310,7 +1310,7 @@ uint32_t fs_render_current(fs_renderer *r, uint64_t n_iterations, void *iter_buf
     const bool whole_frame = r->local_rows == r->height;
     if (color_buffer && r->pal && whole_frame) {
         fsk_antialias(r->iters(), r->iter_bytes == 8, rw, r->colors, r->pal, r->pal_iters, r->pal_aux_depth, r->aa,
-                      r->color_w, r->color_h, (uint32_t)n_iterations, s);
+                      r->color_w, r->color_h, n_iterations, s);
         FS_TRY(hipGetLastError());
     }
     if (reduction) {
@@ -1327,6 +1327,41 @@ uint32_t fs_render_current(fs_renderer *r, uint64_t n_iterations, void *iter_buf
         FS_TRY(hipMemcpyAsync(color_buffer, r->colors, r->n_color_cu * sizeof(fs_color16), hipMemcpyDefault, s));
     if (reduction)
         FS_TRY(hipMemcpyAsync(reduction, r->reduction, sizeof(fs_reduction), hipMemcpyDefault, s));
+    return 0;
+}
+
+uint32_t fs_time_render_current(fs_renderer *r, uint64_t n_iterations, uint32_t repeats, float ms_out[2])
+{
+    if (uint32_t e = use_device(r))
+        return e;
+    if (!r->memory_initialized() || !r->pal || r->local_rows != r->height || !repeats)
+        return FS_ERR_6;
+    const uint32_t rw = r->w_block * 16u;
+    hipEvent_t a, b;
+    FS_TRY(hipEventCreate(&a));
+    FS_TRY(hipEventCreate(&b));
+    // the kernels only (the 24-byte seed copy of fs_render_current is not part of what is measured; min / max are
+    // idempotent and the accumulated sum of the repeats is discarded)
+    r->reduce_seed = fs_reduction{r->iter_bytes == 8 ? ~0ull : 0xFFFFFFFFull, 0, 0};
+    FS_TRY(hipMemcpyAsync(r->reduction, &r->reduce_seed, sizeof(fs_reduction), hipMemcpyHostToDevice, r->compute));
+    for (int which = 0; which < 2; which++) {
+        FS_TRY(hipEventRecord(a, r->compute));
+        for (uint32_t i = 0; i < repeats; i++) {
+            if (which == 0)
+                fsk_antialias(r->iters(), r->iter_bytes == 8, rw, r->colors, r->pal, r->pal_iters, r->pal_aux_depth, r->aa,
+                              r->color_w, r->color_h, n_iterations, r->compute);
+            else
+                fsk_reduce(r->iters(), r->iter_bytes == 8, rw, r->width, r->local_rows, r->reduction, r->compute);
+        }
+        FS_TRY(hipEventRecord(b, r->compute));
+        FS_TRY(hipEventSynchronize(b));
+        FS_TRY(hipGetLastError());
+        float ms = 0;
+        FS_TRY(hipEventElapsedTime(&ms, a, b));
+        ms_out[which] = ms / (float)repeats;
+    }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
     return 0;
 }
 

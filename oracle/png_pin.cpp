@@ -139,4 +139,21 @@ uint64_t pin_png_crc64(const uint32_t *iters, uint32_t stride, uint32_t width, u
         image.saveImage(std::string(save_path), WPngImage::kPngFileFormat_RGBA16);
     return Crc64(bytes.data(), bytes.size());
 }
+
+// The same PNG bytes from an RGBA16 colour buffer that is already antialiased and palette-mapped (the Color16 buffer
+// GPURenderer::RenderCurrent hands back, row stride = `stride` pixels, GPU_Render.cu:1759-1805): pins the colour half of
+// the path (antialiasing_kernel + palette lookup) against the same golden CRCs.  Alpha is taken as Pixel16's default
+// (opaque), like the pixels written above.
+uint64_t pin_png_crc64_rgba16(const uint16_t *rgba, uint32_t stride, uint32_t width, uint32_t height)
+{
+    WPngImage image((int)width, (int)height, WPngImage::Pixel16(0, 0, 0));
+    for (size_t oy = 0; oy < height; oy++)
+        for (size_t ox = 0; ox < width; ox++) {
+            const uint16_t *px = rgba + 4 * (oy * stride + ox);
+            image.set((int)ox, (int)oy, WPngImage::Pixel16(px[0], px[1], px[2]));
+        }
+    std::vector<unsigned char> bytes;
+    image.saveImageToRAM(bytes, WPngImage::kPngFileFormat_RGBA16);
+    return Crc64(bytes.data(), bytes.size());
+}
 }

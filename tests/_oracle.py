@@ -4,7 +4,6 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use thi
 """
 import ctypes as C
 import os
-import subprocess
 
 import numpy as np
 
@@ -19,12 +18,27 @@ _pin = None
 
 
 def build():
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("cpu_ref.cpp", "gpu_ref_2x32.cpp", "gpu_ref_lp.cpp")]
-    if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(s) for s in srcs):
-        subprocess.run(["make", "-C", ORACLE_DIR, "all"], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    """make the oracle (and, where /root/reference exists, the golden-CRC pin).  Up-to-date checks are content hashes
+    (fractalshark_amd._build), not file times; with FS_NO_BUILD=1 (profiler runs) nothing is ever compiled."""
+    import glob
+
+    from fractalshark_amd import _build
+    no_build = os.environ.get("FS_NO_BUILD") == "1"
+    srcs = sorted(glob.glob(os.path.join(ORACLE_DIR, "*.cpp")) + glob.glob(os.path.join(ORACLE_DIR, "*.hpp")) +
+                  [os.path.join(ORACLE_DIR, "Makefile"), os.path.join(ROOT, "include", "fs_layout.h")])
+    lib_srcs = [s for s in srcs if not s.endswith("png_pin.cpp")]
+    d = _build._digest(lib_srcs, ["oracle"])
+    if not _build._stamp_ok(LIB, d):
+        if no_build:
+            raise RuntimeError("oracle/liboracle.so is missing or stale and FS_NO_BUILD=1 forbids compiling")
+        _build._run(["make", "-C", ORACLE_DIR, "-B", "all"])
+        _build._write_stamp(LIB, d)
     # the golden-CRC pin needs the reference's WPngImage/lodepng sources: only buildable where /root/reference is
-    if not os.path.exists(PIN) and os.path.isdir("/root/reference/FractalSharkLib/WPngImage"):
-        subprocess.run(["make", "-C", ORACLE_DIR, "_ref"], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    pin_srcs = [os.path.join(ORACLE_DIR, "png_pin.cpp"), os.path.join(ORACLE_DIR, "Makefile")]
+    d = _build._digest(pin_srcs, ["pin"])
+    if not _build._stamp_ok(PIN, d) and not no_build and os.path.isdir("/root/reference/FractalSharkLib/WPngImage"):
+        _build._run(["make", "-C", ORACLE_DIR, "-B", "_ref"])
+        _build._write_stamp(PIN, d)
 
 
 def lib():
@@ -92,6 +106,8 @@ def pin_lib():
         p = C.CDLL(PIN)
         p.pin_png_crc64.restype = u64
         p.pin_png_crc64.argtypes = [vp, u32, u32, u32, u32, u64, u64, C.c_char_p]
+        p.pin_png_crc64_rgba16.restype = u64
+        p.pin_png_crc64_rgba16.argtypes = [vp, u32, u32, u32]
         p.pin_default_palette.restype = u32
         p.pin_default_palette.argtypes = [C.c_int, vp, u32]
         _pin = p
@@ -315,6 +331,16 @@ def png_crc64(iters, width, height, aa, num_iterations, save_path=None):
     crc = p.pin_png_crc64(it.ctypes.data, it.shape[1], width, height, aa, num_iterations, 2 ** 31 - 2,
                           save_path.encode() if save_path else None)
     return "%016x" % crc
+
+
+def png_crc64_rgba16(colors, width, height):
+    """CRC-64 of the PNG the reference writes for an RGBA16 colour buffer (uint16[rows, width, 4], already antialiased
+    and palette-mapped: GPURenderer::RenderCurrent's Color16 output), or None without the pin library."""
+    p = pin_lib()
+    if p is None:
+        return None
+    c = np.ascontiguousarray(colors, np.uint16)
+    return "%016x" % p.pin_png_crc64_rgba16(c.ctypes.data, width, width, height)
 
 
 def default_palette(depth=8):

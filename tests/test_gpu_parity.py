@@ -480,6 +480,33 @@ def test_scaled_hdr32_matches_restated_cuda_kernel(renderer, v5_small):
     assert (d <= 2).mean() > 0.3 and np.median(d) <= 4
 
 
+@pytest.mark.parametrize("w,h,aa", [(64, 36, 1), (16, 12, 4)])
+def test_scaled_hdr32_view14_deep_zoom(renderer, native_libs, w, h, aa):
+    """BASELINE config C4's other form: View 14 (2^-21645) through GpuHDRx32PerturbedScaled (fs_render_scaled), with
+    the PerturbExtras::Bad orbit pair of that view (116 695 entries, `bad` entries present) -- at AA 1 and in C4's AA 4
+    geometry.  The iteration cap is lowered to 1.8 M: with the view's own cap (2^31 - 2) perturbation-only rendering
+    needs 2.1e9 steps for almost every pixel of this view (the first escapes are at 1.53 M), on any hardware."""
+    v = inputs.View.builtin(14, w, h, antialiasing=aa)
+    ob = inputs.Orbit(v)
+    n = 1800000
+    r = renderer
+    assert r.InitializeMemory(w * aa, h * aa, aa, None, 0, 0, 0, False) == 0
+    assert r.ClearMemory() == 0
+    dx, dy, cx, cy = _pairs(v.coords_perturb(ob, aa))
+    r.enable_step_count(True)
+    assert r.RenderPerturbBLAScaled(None, ob, ob, None, None, dx, dy, cx, cy, n) == 0
+    out = r.new_iter_buffer()
+    assert r.RenderCurrent(n, out) == 0
+    assert r.SyncComputeStream() == 0
+    st = r.read_step_count()
+    r.enable_step_count(False)
+    ref, rst = _oracle.gpu_scaled_hdr32(v, ob, aa=aa, stats=True, n_iterations=n)
+    assert np.array_equal(out, ref)
+    assert rst["rescales"] > 0 and rst["full_steps"] > 0  # the rescale and the `bad`-entry paths are both exercised
+    assert (st["at_iterations"], st["la_steps"], st["perturb_steps"]) == (rst["rescales"], rst["full_steps"],
+                                                                         rst["float_steps"])
+
+
 # ---- SURVEY 8(f) row 2: BLA table built on the device (BLAS::Init) == the golden-pinned host builder, bit for bit
 @pytest.mark.parametrize("view_n,is64", [(5, False), (19, False), (5, True)])
 def test_bla_table_built_on_device_equals_host_builder(renderer, native_libs, view_n, is64):
