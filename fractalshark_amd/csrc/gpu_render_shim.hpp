@@ -243,7 +243,8 @@ uint32_t GPURenderer::RenderPerturbBLA(RenderAlgorithm /*algorithm*/,
     if (!m_ComputeStream)
         return 0;
     constexpr int tag = fsmi355_shim::type_tag<T>::value;
-    if constexpr (tag != FS_T_HDR32 && tag != FS_T_HDR64) {
+    // GPU_Render.cu:1610-1692: T = double (Gpu1x64PerturbedBLA), HDRFloat<float>, HDRFloat<double>
+    if constexpr (tag != FS_T_HDR32 && tag != FS_T_HDR64 && tag != FS_T_F64) {
         return FS_ERR_UNSUPPORTED;
     } else {
     fs_renderer *r = fsmi355_shim::handle(m_ComputeStream);
@@ -262,6 +263,7 @@ uint32_t GPURenderer::RenderPerturbBLA(RenderAlgorithm /*algorithm*/,
     }
     static_assert(sizeof(BLA<::HDRFloat<float>>) == sizeof(fs_bla_hdr32) || !std::is_same<T, ::HDRFloat<float>>::value,
                   "BLA layout");
+    static_assert(sizeof(BLA<double>) == sizeof(fs_bla_f64) || !std::is_same<T, double>::value, "BLA layout (double)");
     err = fs_upload_bla(r, tag, levels, sizes, (int32_t)n_levels, blas->m_LM2);
     if (err)
         return err;
@@ -337,6 +339,10 @@ uint32_t GPURenderer::Render(RenderAlgorithm /*algorithm*/, T cx, T cy, T dx, T 
         const typename fsmi355_shim::abi_real<T>::type co[4] = {fsmi355_shim::to_abi(dx), fsmi355_shim::to_abi(dy),
                                                                 fsmi355_shim::to_abi(cx), fsmi355_shim::to_abi(maxY)};
         return fs_render_direct(r, fsmi355_shim::type_tag<T>::value, co, (uint64_t)n_iterations);
+    } else if constexpr (std::is_same<T, ::CudaDblflt<::MattDblflt>>::value) {
+        // instantiated by the reference (GPU_Render.cu:905-912,977-984) but no branch of its Render launches anything
+        // for this T: it returns cudaSuccess (:843)
+        return 0;
     } else {
         return FS_ERR_UNSUPPORTED;
     }
