@@ -401,6 +401,7 @@ def main():
                          "la_steps_per_launch": la_steps, "flop_per_pixel_step": FLOP_PER_STEP,
                          "careful_step_fraction_rank0": round(st.get("careful_steps", 0) / max(1.0, perturb_steps), 5)
                          if not distributed else None,
+                         "stat6_rank0": st.get("scaled_steps"), "stat7_rank0": st.get("scaled_runs"),
                          "lane_utilisation_rank0": round(perturb_steps / lane_slots, 4)
                          if lane_slots and not distributed else None},
             "cpu_baseline": cpu_baseline, "cpu_baseline_patched": cpu_baseline_patched, "secondary": secondary,

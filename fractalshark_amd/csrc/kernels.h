@@ -88,6 +88,7 @@ template <class F> struct FsBlaArgsT {
     const float4 *zs;                            // ... and the scaled runs' companion (see FsLav2ArgsT)
     const typename FsDev<F>::BLA *const *levels; // device array of device pointers, indexed by level
     uint64_t *stats;
+    uint32_t *queue; // frame-wide pixel counter of the persistent (lane-refilling) launch, zeroed before each launch
     FsFrame frame;
     FsCoordsT<F> coords;
     uint32_t orbit_count;

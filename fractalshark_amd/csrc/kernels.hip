@@ -1006,9 +1006,15 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
 // (FractalSharkGpuLib/BLAKernels.cuh:193-434) and the PO instantiation of the LAv2 kernel.
 namespace {
 
+// BLAS::LookupBackwards (BLAS.cpp:256-310).  `levels` is the workgroup's LDS copy of the level pointer table (a
+// ds_read instead of a global load in front of every probe).  The (level, index) pairs a lookup visits depend only on m,
+// so the r2 values of the first four levels are requested together -- one memory round trip instead of up to four
+// dependent ones -- and then tested in the reference's order (highest level first).
 template <class F>
-__device__ __forceinline__ const typename FsDev<F>::BLA *bla_lookup(const FsBlaArgsT<F> &A, uint32_t m, hreal<F> z2)
+__device__ __forceinline__ const typename FsDev<F>::BLA *bla_lookup(const typename FsDev<F>::BLA *const *levels, int32_t lm2,
+                                                                     uint32_t m, hreal<F> z2)
 {
+    using B = typename FsDev<F>::BLA;
     if (m == 0)
         return nullptr;
     const int32_t k = (int32_t)m - 1;
@@ -1017,7 +1023,7 @@ __device__ __forceinline__ const typename FsDev<F>::BLA *bla_lookup(const FsBlaA
     int32_t zeros;
     uint32_t ix;
     if (k == 0) {
-        if (hr_cmp_pos(z2, ldr(A.levels[2][0].r2)) >= 0)
+        if (hr_cmp_pos(z2, ldr(levels[2][0].r2)) >= 0)
             return nullptr;
         zeros = 32;
         ix = 0;
@@ -1025,9 +1031,35 @@ __device__ __forceinline__ const typename FsDev<F>::BLA *bla_lookup(const FsBlaA
         zeros = __ffs(k) - 1; // exponent of (float)(k & -k), BLAS.cpp:283-286
         ix = (uint32_t)k >> zeros;
     }
-    const int32_t startLevel = zeros <= A.lm2 ? zeros : A.lm2;
-    for (int32_t level = startLevel; level >= 2; --level) {
-        const typename FsDev<F>::BLA *t = &A.levels[level][ix];
+    const int32_t startLevel = zeros <= lm2 ? zeros : lm2;
+    if (startLevel < 2)
+        return nullptr;
+    const int32_t np = startLevel - 1 < 4 ? startLevel - 1 : 4; // levels startLevel .. startLevel - np + 1 (>= 2)
+    const B *t0 = levels[startLevel] + ix, *t1 = nullptr, *t2 = nullptr, *t3 = nullptr;
+    hreal<F> r0 = ldr(t0->r2), r1 = r0, r2 = r0, r3 = r0;
+    if (np > 1) {
+        t1 = levels[startLevel - 1] + (ix << 1);
+        r1 = ldr(t1->r2);
+    }
+    if (np > 2) {
+        t2 = levels[startLevel - 2] + (ix << 2);
+        r2 = ldr(t2->r2);
+    }
+    if (np > 3) {
+        t3 = levels[startLevel - 3] + (ix << 3);
+        r3 = ldr(t3->r2);
+    }
+    if (hr_cmp_pos(z2, r0) < 0)
+        return t0;
+    if (np > 1 && hr_cmp_pos(z2, r1) < 0)
+        return t1;
+    if (np > 2 && hr_cmp_pos(z2, r2) < 0)
+        return t2;
+    if (np > 3 && hr_cmp_pos(z2, r3) < 0)
+        return t3;
+    ix <<= 4;
+    for (int32_t level = startLevel - 4; level >= 2; --level) {
+        const B *t = &levels[level][ix];
         if (hr_cmp_pos(z2, ldr(t->r2)) < 0)
             return t;
         ix <<= 1;
@@ -1037,44 +1069,192 @@ __device__ __forceinline__ const typename FsDev<F>::BLA *bla_lookup(const FsBlaA
 
 } // namespace
 
-template <class F, bool kBla, bool kStats>
+// With a table (kBla) the kernel is PERSISTENT and lanes are re-packed: pixels of one wave finish at very different
+// times (BLA jumps and rebases make iteration counts of neighbours differ by orders of magnitude; a third of the lane
+// slots of a one-tile-per-wave launch idle behind the longest pixel of their tile), and nothing in this loop needs the
+// lanes of a wave to be neighbours -- with a table they sit at different orbit positions after the first jump anyway.
+// So a wave keeps its 64 lanes fed from a frame-wide pixel queue: every kRefillEvery outer iterations the idle lanes
+// are found with one ballot, the wave takes popcount(idle) consecutive pixel numbers with ONE atomic (lane prefix =
+// mbcnt over the ballot) and the idle lanes start those pixels.  Pixel numbers run in 8 x 8-tile order, so a wave
+// starts on one tile like the non-persistent launch.  Without a table (perturbation only) the scaled runs want all
+// lanes of a wave at the same orbit position (scalar-cache entries), so that launch stays one tile per wave.
+constexpr uint32_t kRefillEvery = 24;
+
+template <class F, bool kBla, bool kStats, bool kRefill>
 __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
 {
-    uint32_t X, L;
-    tile_pixel(X, L);
+    __shared__ const typename FsDev<F>::BLA *s_levels[kBla ? 64 : 1];
+    if constexpr (kBla) {
+        if (threadIdx.x < 64u)
+            s_levels[threadIdx.x] = (int32_t)threadIdx.x < A.lm2 + 2 ? A.levels[threadIdx.x] : nullptr;
+        __syncthreads();
+    }
+    uint32_t X = 0, L = 0;
     uint64_t c_la = 0, c_pt = 0, c_px = 0;
-    const uint32_t Y = global_row(A.frame, L);
-    const bool live = X < A.frame.width && L < A.frame.local_rows && Y < A.frame.height;
-    if (live) {
-        c_px = 1;
-        const uint32_t n_iterations = A.n_iterations;
-        const uint32_t count = A.orbit_count;
-        const typename FsDev<F>::Z *__restrict__ zr = A.zref;
-        uint32_t iter = 0;
-        uint32_t RefIteration = 0;
-        hreal<F> DeltaSub0X, DeltaSub0Y;
-        pixel_delta<F>(A.coords, X, Y, DeltaSub0X, DeltaSub0Y);
-        hreal<F> DeltaSubNX = hr_zero<F>();
-        hreal<F> DeltaSubNY = hr_zero<F>();
-        hreal<F> DeltaNormSquared = hr_zero<F>();
-        const hreal<F> TwoFiftySix = hreal<F>{F(1), 8};
-        hcplx<F> Zcached = hc_zero<F>();
-        uint32_t Zcached_at = 0xFFFFFFFFu;
-
+    const uint32_t n_iterations = A.n_iterations;
+    const uint32_t count = A.orbit_count;
+    const typename FsDev<F>::Z *__restrict__ zr = A.zref;
+    const hreal<F> TwoFiftySix = hreal<F>{F(1), 8};
+    // per-pixel state (lives across refill rounds)
+    bool have = false;
+    uint32_t iter = 0;
+    uint32_t RefIteration = 0;
+    hreal<F> DeltaSub0X = hr_zero<F>(), DeltaSub0Y = hr_zero<F>();
+    hreal<F> DeltaSubNX = hr_zero<F>();
+    hreal<F> DeltaSubNY = hr_zero<F>();
+    hreal<F> DeltaNormSquared = hr_zero<F>();
+    hcplx<F> Zcached = hc_zero<F>();
+    uint32_t Zcached_at = 0xFFFFFFFFu;
+    // frame-wide pixel queue (kRefill)
+    const uint32_t tiles_x = (A.frame.width + 7u) >> 3;
+    const uint32_t total = tiles_x * ((A.frame.local_rows + 7u) >> 3) * 64u;
+    bool queue_empty = false;
+    auto start_pixel = [&](uint32_t x, uint32_t l) {
+        X = x, L = l;
+        const uint32_t Y = global_row(A.frame, l);
+        have = x < A.frame.width && l < A.frame.local_rows && Y < A.frame.height;
+        if (have) {
+            c_px++;
+            iter = 0;
+            RefIteration = 0;
+            pixel_delta<F>(A.coords, x, Y, DeltaSub0X, DeltaSub0Y);
+            DeltaSubNX = hr_zero<F>();
+            DeltaSubNY = hr_zero<F>();
+            DeltaNormSquared = hr_zero<F>();
+            Zcached = hc_zero<F>();
+            Zcached_at = 0xFFFFFFFFu;
+        }
+    };
+    if constexpr (!kRefill) {
+        uint32_t x, l;
+        tile_pixel(x, l);
+        start_pixel(x, l);
+    }
+    for (;;) {
+        if constexpr (kRefill) {
+            const uint64_t idle = __builtin_amdgcn_ballot_w64(!have);
+            if (idle != 0ull && !queue_empty) {
+                const uint32_t want = (uint32_t)__popcll(idle);
+                uint32_t base = 0;
+                if ((threadIdx.x & 63u) == 0u)
+                    base = atomicAdd(A.queue, want);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                queue_empty = base + want >= total;
+                // rank of this lane among the idle lanes = number of idle lanes below it
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                const uint32_t idx = base + rank;
+                if (!have && idx < total) {
+                    const uint32_t t = idx >> 6, ln = idx & 63u;
+                    const uint32_t ty = t / tiles_x, tx = t - ty * tiles_x;
+                    start_pixel(tx * 8u + (ln & 7u), ty * 8u + (ln >> 3));
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(have) == 0ull) {
+                if (queue_empty)
+                    break;
+                continue;
+            }
+        }
+    if (have) {
+        bool finished = true;
+        uint32_t budget = kRefillEvery;
         while (iter < n_iterations) {
+            if constexpr (kRefill) {
+                // every lane counts the same trips (a SIMT loop runs its trips jointly), so the wave leaves together
+                if (budget == 0u) {
+                    finished = false;
+                    break;
+                }
+                budget--;
+            }
             if (kBla) {
                 const typename FsDev<F>::BLA *b;
-                while ((b = bla_lookup<F>(A, RefIteration, DeltaNormSquared)) != nullptr) {
+                while ((b = bla_lookup<F>(s_levels, A.lm2, RefIteration, DeltaNormSquared)) != nullptr) {
                     const uint32_t l = (uint32_t)b->l;
                     if (RefIteration + l >= count)
                         break;
                     if (iter + l >= n_iterations)
                         break;
                     iter += l;
-                    if (kStats)
+                    if (kStats) {
                         c_la++;
+                        // histogram probe (tools): jumps of >= 1024 / >= 256 orbit steps
+                        if (l >= 1024u)
+                            atomicAdd((unsigned long long *)&A.stats[6], 1ull);
+                        if (l >= 256u)
+                            atomicAdd((unsigned long long *)&A.stats[7], 1ull);
+                    }
+                    const hreal<F> Ax = ldr(b->Ax), Ay = ldr(b->Ay), Bx = ldr(b->Bx), By = ldr(b->By);
+                    const hcplx<F> Z = zref_at(zr, RefIteration + l);
+                    bool applied = false;
+                    if constexpr (std::is_same<F, float>::value) {
+                        // ---- BLA::getValue + the two norms in ONE straight-line evaluation for every exponent alignment
+                        // (see the tuned single step below for why this is the same arithmetic): the four products of each
+                        // part are summed, in the reference's order, under the maximum of their four exponents; z = Z + dz
+                        // under the maximum of the three exponents involved.  A lane whose sums leave [2^-60, 2^60] or
+                        // hit an exact zero on the way takes the literal code below (per lane: a jump is per lane anyway).
+                        typedef float f2 __attribute__((ext_vector_type(2)));
+                        auto p2 = [](int n) { return n > -kExpDiffIgnored ? __int_as_float((n << 23) + 0x3F800000) : 0.0f; };
+                        const f2 D = {DeltaSubNX.m, DeltaSubNY.m}, D0 = {DeltaSub0X.m, DeltaSub0Y.m};
+                        // nx = ((Ax DX - Ay DY) + Bx D0X) - By D0Y;  ny = ((Ax DY + Ay DX) + Bx D0Y) + By D0X
+                        const f2 pA = (f2){Ax.m, Ax.m} * D;         // (Ax DX, Ax DY)   exps Ax.e + (DX.e, DY.e)
+                        const f2 pB = (f2){Ay.m, Ay.m} * D.yx;      // (Ay DY, Ay DX)   exps Ay.e + (DY.e, DX.e)
+                        const f2 pC = (f2){Bx.m, Bx.m} * D0;        // (Bx D0X, Bx D0Y) exps Bx.e + (D0X.e, D0Y.e)
+                        const f2 pD = (f2){By.m, By.m} * D0.yx;     // (By D0Y, By D0X) exps By.e + (D0Y.e, D0X.e)
+                        const int eAx = Ax.e + DeltaSubNX.e, eAy = Ax.e + DeltaSubNY.e;
+                        const int eBx = Ay.e + DeltaSubNY.e, eBy = Ay.e + DeltaSubNX.e;
+                        const int eCx = Bx.e + DeltaSub0X.e, eCy = Bx.e + DeltaSub0Y.e;
+                        const int eDx = By.e + DeltaSub0Y.e, eDy = By.e + DeltaSub0X.e;
+                        const int Ex = imax(imax(eAx, eBx), imax(eCx, eDx)), Ey = imax(imax(eAy, eBy), imax(eCy, eDy));
+                        const f2 tA = pA * (f2){p2(eAx - Ex), p2(eAy - Ey)};
+                        const f2 tB = pB * (f2){p2(eBx - Ex), p2(eBy - Ey)};
+                        const f2 tC = pC * (f2){p2(eCx - Ex), p2(eCy - Ey)};
+                        const f2 tD = pD * (f2){p2(eDx - Ex), p2(eDy - Ey)};
+                        f2 s1, s3;
+                        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(s1) : "v"(tA), "v"(tB));
+                        const f2 s2 = s1 + tC;
+                        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(s3) : "v"(s2), "v"(tD));
+                        // z = Z + dz under ez; the norms
+                        const int ez = imax(imax(Z.e, Ex), Ey);
+                        const float zsZ = p2(Z.e - ez);
+                        const f2 Zt = (f2){Z.re, Z.im} * (f2){zsZ, zsZ} + s3 * (f2){p2(Ex - ez), p2(Ey - ez)};
+                        const f2 ZZ = Zt * Zt;
+                        const float nm = ZZ.x + ZZ.y; // exponent 2 ez
+                        const f2 SQ = s3 * s3;
+                        const int dd = (Ex - Ey) << 1;
+                        const bool sxbig = dd >= 0;
+                        const float md = p2(sxbig ? -dd : dd);
+                        const float dnm = SQ.x * (sxbig ? 1.0f : md) + SQ.y * (sxbig ? md : 1.0f);
+                        const int dne = (sxbig ? Ex : Ey) << 1;
+                        const float smx = fmaxf(fmaxf(fabsf(s3.x), fabsf(s3.y)), fmaxf(fabsf(Zt.x), fabsf(Zt.y)));
+                        const float smn = fminf(fminf(fabsf(s3.x), fabsf(s3.y)), fminf(fabsf(Zt.x), fabsf(Zt.y)));
+                        const float zmn = fminf(fminf(fabsf(s1.x), fabsf(s1.y)), fminf(fabsf(s2.x), fabsf(s2.y)));
+                        const int emin = imin(imin(imin(DeltaSubNX.e, DeltaSubNY.e), imin(DeltaSub0X.e, DeltaSub0Y.e)),
+                                              imin(imin(Ax.e, Ay.e), imin(imin(Bx.e, By.e), Z.e)));
+                        if (smn >= 0x1p-60f && smx <= 0x1p60f && zmn > 0.0f && emin > -(1 << 26)) {
+                            applied = true;
+                            RefIteration += l;
+                            DeltaSubNX = hreal<F>{s3.x, Ex};
+                            DeltaSubNY = hreal<F>{s3.y, Ey};
+                            const int db = __float_as_int(dnm);
+                            DeltaNormSquared = hreal<F>{__int_as_float((db & 0x007FFFFF) | 0x3F800000),
+                                                        dne + (int)__builtin_amdgcn_ubfe(db, 23, 8) - 127};
+                            if (__builtin_amdgcn_ldexpf(nm, imax((ez << 1) - 8, -400)) > 1.0f)
+                                break;
+                            if (nm < __builtin_amdgcn_ldexpf(dnm, imax(dne - (ez << 1), -400)) || RefIteration >= count - 1) {
+                                const int ex = imax(Z.e, Ex), ey = imax(Z.e, Ey);
+                                DeltaSubNX = hreal<F>{__builtin_amdgcn_ldexpf(Zt.x, ez - ex), ex};
+                                DeltaSubNY = hreal<F>{__builtin_amdgcn_ldexpf(Zt.y, ez - ey), ey};
+                                const int nb = __float_as_int(nm);
+                                DeltaNormSquared = hreal<F>{__int_as_float((nb & 0x007FFFFF) | 0x3F800000),
+                                                            (ez << 1) + (int)__builtin_amdgcn_ubfe(nb, 23, 8) - 127};
+                                RefIteration = 0;
+                            }
+                        }
+                    }
+                    if (applied)
+                        continue;
                     {
-                        const hreal<F> Ax = ldr(b->Ax), Ay = ldr(b->Ay), Bx = ldr(b->Bx), By = ldr(b->By);
                         const hreal<F> nx = hr_sub(
                             hr_add(hr_sub(hr_mul(Ax, DeltaSubNX), hr_mul(Ay, DeltaSubNY)), hr_mul(Bx, DeltaSub0X)),
                             hr_mul(By, DeltaSub0Y));
@@ -1085,7 +1265,6 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                         DeltaSubNY = ny;
                     }
                     RefIteration += l;
-                    const hcplx<F> Z = zref_at(zr, RefIteration);
                     const hreal<F> tempZX = hr_add(hc_re(Z), DeltaSubNX);
                     const hreal<F> tempZY = hr_add(hc_im(Z), DeltaSubNY);
                     const hreal<F> normSquared = hr_reduced(hr_add(hr_mul(tempZX, tempZX), hr_mul(tempZY, tempZY)));
@@ -1428,68 +1607,84 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
             // BLA jump moved RefIteration: one dependent 16-byte load per step instead of two.
             const hcplx<F> Z = (Zcached_at == RefIteration) ? Zcached : zref_at(zr, RefIteration);
 
-            // ---- tuned single step (float only): speculative straight-line evaluation under the exponent-alignment
-            // cases that hold in > 99.9 % of lane-steps (measured with an instrumented oracle):
-            //   2Z+O, +dc, Z'+n : left operand (orbit / accumulated value) has the larger exponent (far case allowed);
-            //   B1-B2, C1+C2     : one swap decision, OX.e >= OY.e, because T3 and T4 share the exponent of 2Z;
-            //   zx^2+zy^2        : equal exponents.
-            // Committed only when every running lane of the wave met the assumptions (one ballot); otherwise the
-            // wave takes the generic step below, which is the literal CPU order.
+            // ---- tuned single step (float only): ONE straight-line evaluation for every exponent alignment.
+            // HDRFloat addition and multiplication are the correctly rounded binary32 operations on the represented
+            // values (a product is the float product of the mantissas, an aligned sum the float sum after an exact
+            // power-of-two scaling; the "gap >= 120: smaller operand ignored" rule only drops what a float sum absorbs
+            // anyway), so a sum may be formed under ANY common exponent that keeps both addends inside binary32's
+            // normal range -- not only the one the literal code picks by comparing the operands' exponents.  Each of
+            // the four sums of a step (2Z + dz, B1 - B2 / C1 + C2, + dc, Z' + dz') is therefore aligned to the MAXIMUM
+            // of the exponents involved (v_max3), every operand gets the exact factor 2^(its exponent - that maximum)
+            // (0 from a gap of 120 on, like the reference), and no branch asks which operand was the larger.  This
+            // covers, with the same instructions, the three cases the first version of this step (orbit value bigger
+            // than dz everywhere) had to hand to the literal code: the step from orbit entry 0 (Z = 0 exactly, every
+            // rebase lands there), the step that rebases (Z' + dz' cancels) and dc bigger than dz (pixel start).
+            //   What is NOT covered -- and is voted out to the literal step below, which decides exactly: a sum that
+            //   is exactly zero (the literal add then resets the exponent), and a sum whose float leaves
+            //   [2^-60, 2^60] (a component more than 2^60 below its sibling, or cancellation that deep: the products
+            //   built from it could leave the normal range).  Every sum is tested, so products of two sums stay
+            //   inside 2^+-120.
+            // Committed only when every running lane of the wave passed (one ballot): the fall-back is the literal CPU
+            // order.  With lanes re-packed from the pixel queue a wave nearly always holds a lane that is rebasing,
+            // which is why the step must not care.
             bool done_fast = false;
             if constexpr (std::is_same<F, float>::value) {
                 typedef float f2 __attribute__((ext_vector_type(2)));
                 const auto zn4 = zr[RefIteration + 1]; // in bounds: the prepared orbit has two spare entries
                 const int Ze1 = Z.e + 1;
                 const f2 O = {OX.m, OY.m};
-                const int n4 = OX.e - Ze1, n3 = OY.e - Ze1; // negated gaps, <= 0 expected
-                const f2 tsc = {n4 > -kExpDiffIgnored ? __int_as_float((n4 << 23) + 0x3F800000) : 0.0f,
-                                n3 > -kExpDiffIgnored ? __int_as_float((n3 << 23) + 0x3F800000) : 0.0f};
-                const f2 T = (f2){Z.re, Z.im} + O * tsc; // (T4.m, T3.m), both with exponent Ze1
-                const f2 P1 = O.xx * T;                  // (B1.m, C1.m) exponent e1 = OX.e + Ze1
-                const f2 P2 = O.yy * T.yx;               // (B2.m, C2.m) exponent e2 = OY.e + Ze1
+                // exact 2^n for -120 < n <= 0, else 0 (n <= 0 by construction: n = exponent - maximum)
+                auto p2 = [](int n) { return n > -kExpDiffIgnored ? __int_as_float((n << 23) + 0x3F800000) : 0.0f; };
+                // T = 2Z + O under eT
+                const int eT = imax(imax(Ze1, OX.e), OY.e);
+                const float zsT = p2(Ze1 - eT);
+                const f2 tsc = {p2(OX.e - eT), p2(OY.e - eT)};
+                const f2 T = (f2){Z.re, Z.im} * (f2){zsT, zsT} + O * tsc; // (T4.m, T3.m), exponent eT
+                const f2 P1 = O.xx * T;                                  // (B1.m, C1.m) exponent OX.e + eT
+                const f2 P2 = O.yy * T.yx;                               // (B2.m, C2.m) exponent OY.e + eT
                 const int dxy = OX.e - OY.e;
                 const bool xbig = dxy >= 0;
                 const int nad = xbig ? -dxy : dxy;
-                const float ms = nad > -kExpDiffIgnored ? __int_as_float((nad << 23) + 0x3F800000) : 0.0f;
+                const float ms = p2(nad);
                 const f2 P1s = P1 * (xbig ? 1.0f : ms);
                 const f2 P2s = P2 * (xbig ? ms : 1.0f);
-                f2 N; // (B1' - B2', C1' + C2')
+                f2 N; // (B1' - B2', C1' + C2'), exponent E
                 asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(N) : "v"(P1s), "v"(P2s));
-                const int E = (xbig ? OX.e : OY.e) + Ze1;
-                const int ncx = DeltaSub0X.e - E, ncy = DeltaSub0Y.e - E;
-                const f2 dsc = {ncx > -kExpDiffIgnored ? __int_as_float((ncx << 23) + 0x3F800000) : 0.0f,
-                                ncy > -kExpDiffIgnored ? __int_as_float((ncy << 23) + 0x3F800000) : 0.0f};
-                const f2 Q = N + (f2){DeltaSub0X.m, DeltaSub0Y.m} * dsc;
+                const int E = (xbig ? OX.e : OY.e) + eT;
+                // Q = N + dc under EQ
+                const int EQ = imax(imax(E, DeltaSub0X.e), DeltaSub0Y.e);
+                const float nsQ = p2(E - EQ);
+                const f2 dsc = {p2(DeltaSub0X.e - EQ), p2(DeltaSub0Y.e - EQ)};
+                const f2 Q = N * (f2){nsQ, nsQ} + (f2){DeltaSub0X.m, DeltaSub0Y.m} * dsc;
                 // scalar Reduce of each part
                 const int qxb = __float_as_int(Q.x), qyb = __float_as_int(Q.y);
                 const int fx = (int)__builtin_amdgcn_ubfe(qxb, 23, 8), fy = (int)__builtin_amdgcn_ubfe(qyb, 23, 8);
                 const float nxm = __int_as_float((qxb & 0x807FFFFF) | 0x3F800000);
                 const float nym = __int_as_float((qyb & 0x807FFFFF) | 0x3F800000);
-                const int nxe = E + fx - 127, nye = E + fy - 127;
-                // z = Z' + n
+                const int nxe = EQ + fx - 127, nye = EQ + fy - 127;
+                // z = Z' + n under ez
                 const int Zne = __float_as_int(zn4.z);
-                const int nzx = nxe - Zne, nzy = nye - Zne;
-                const f2 zsc = {nzx > -kExpDiffIgnored ? __int_as_float((nzx << 23) + 0x3F800000) : 0.0f,
-                                nzy > -kExpDiffIgnored ? __int_as_float((nzy << 23) + 0x3F800000) : 0.0f};
-                const f2 Zt = (f2){zn4.x, zn4.y} + (f2){nxm, nym} * zsc; // (tempZX.m, tempZY.m), exponent Zne
+                const int ez = imax(imax(Zne, nxe), nye);
+                const float zsZ = p2(Zne - ez);
+                const f2 zsc = {p2(nxe - ez), p2(nye - ez)};
+                const f2 Zt = (f2){zn4.x, zn4.y} * (f2){zsZ, zsZ} + (f2){nxm, nym} * zsc; // (tempZX.m, tempZY.m), exponent ez
                 const f2 ZZ = Zt * Zt;
-                const float nm = ZZ.x + ZZ.y; // exponent 2*Zne
+                const float nm = ZZ.x + ZZ.y; // exponent 2*ez
                 // dn = nx^2 + ny^2
                 const f2 SQ = (f2){nxm, nym} * (f2){nxm, nym};
                 const int dd = (nxe - nye) << 1;
                 const bool sxbig = dd >= 0;
                 const int nadd = sxbig ? -dd : dd;
-                const float md = nadd > -kExpDiffIgnored ? __int_as_float((nadd << 23) + 0x3F800000) : 0.0f;
+                const float md = p2(nadd);
                 const float dnm = SQ.x * (sxbig ? 1.0f : md) + SQ.y * (sxbig ? md : 1.0f);
                 const int dne = (sxbig ? nxe : nye) << 1;
-                // assumptions
-                const int gmax = imax(imax(imax(n4, n3), imax(ncx, ncy)), imax(nzx, nzy));
-                const float tiny = fminf(fminf(fminf(fabsf(T.x), fabsf(T.y)), fminf(fabsf(N.x), fabsf(N.y))),
-                                         fminf(fabsf(Zt.x), fabsf(Zt.y)));
-                const bool ok = gmax <= 0 && (OX.e < OY.e ? OX.e : OY.e) > -(1 << 26) && tiny > 0.0f &&
-                                __builtin_amdgcn_classf(Q.x, 0x108 /* +-normal */) &&
-                                __builtin_amdgcn_classf(Q.y, 0x108) && __builtin_amdgcn_classf(nm, 0x100) &&
-                                RefIteration + 1 < count;
+                // every sum inside [2^-60, 2^60] (also excludes zeros, denormals, infinities and NaNs)
+                const float smx = fmaxf(fmaxf(fmaxf(fabsf(T.x), fabsf(T.y)), fmaxf(fabsf(N.x), fabsf(N.y))),
+                                        fmaxf(fmaxf(fabsf(Q.x), fabsf(Q.y)), fmaxf(fabsf(Zt.x), fabsf(Zt.y))));
+                const float smn = fminf(fminf(fminf(fabsf(T.x), fabsf(T.y)), fminf(fabsf(N.x), fabsf(N.y))),
+                                        fminf(fminf(fabsf(Q.x), fabsf(Q.y)), fminf(fabsf(Zt.x), fabsf(Zt.y))));
+                const bool ok = smn >= 0x1p-60f && smx <= 0x1p60f && (OX.e < OY.e ? OX.e : OY.e) > -(1 << 26) &&
+                                Zne > -(1 << 26) && RefIteration + 1 < count;
                 if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) {
                     done_fast = true;
                     if (kStats)
@@ -1505,16 +1700,19 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                         DeltaNormSquared = hreal<F>{__int_as_float((db & 0x007FFFFF) | 0x3F800000),
                                                     dne + (int)__builtin_amdgcn_ubfe(db, 23, 8) - 127};
                     }
-                    // Reduce(n) > 256 <=> nm * 2^(2 Zne) > 2^8 (nm a positive normal float); zn4.w = 2^(8 - 2 Zne)
-                    if (nm > zn4.w)
+                    // Reduce(n) > 256 <=> nm * 2^(2 ez) > 2^8 (nm a positive normal float; ldexp saturates both ways)
+                    if (__builtin_amdgcn_ldexpf(nm, imax((ez << 1) - 8, -400)) > 1.0f)
                         break;
-                    // Reduce(n) < Reduce(dn) <=> nm * 2^(2 Zne) < dnm * 2^dne
-                    if (nm < __builtin_amdgcn_ldexpf(dnm, dne - (Zne << 1)) || RefIteration >= count - 1) {
-                        DeltaSubNX = hreal<F>{Zt.x, Zne};
-                        DeltaSubNY = hreal<F>{Zt.y, Zne};
+                    // Reduce(n) < Reduce(dn) <=> nm * 2^(2 ez) < dnm * 2^dne  (dne <= 2 ez)
+                    if (nm < __builtin_amdgcn_ldexpf(dnm, imax(dne - (ez << 1), -400)) || RefIteration >= count - 1) {
+                        // dz = z in the literal representation: each part carries max(exponent of Z', exponent of its
+                        // own dz' part) (exact rescaling of the sum formed under ez)
+                        const int ex = imax(Zne, nxe), ey = imax(Zne, nye);
+                        DeltaSubNX = hreal<F>{__builtin_amdgcn_ldexpf(Zt.x, ez - ex), ex};
+                        DeltaSubNY = hreal<F>{__builtin_amdgcn_ldexpf(Zt.y, ez - ey), ey};
                         const int nb = __float_as_int(nm);
                         DeltaNormSquared = hreal<F>{__int_as_float((nb & 0x007FFFFF) | 0x3F800000),
-                                                    (Zne << 1) + (int)__builtin_amdgcn_ubfe(nb, 23, 8) - 127};
+                                                    (ez << 1) + (int)__builtin_amdgcn_ubfe(nb, 23, 8) - 127};
                         RefIteration = 0;
                     }
                     ++iter;
@@ -1524,6 +1722,9 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                 continue;
 
             // ---- generic single step, literal order of Fractal.cpp:2342-2466
+            if (kStats && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) ==
+                              (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true)))
+                atomicAdd((unsigned long long *)&A.stats[5], 1ull); // wave-trips through the literal step
             // Term4 == the inner sum of TermB1, Term3 == the inner sum of TermB2 (same operands, same order)
             const hreal<F> T4 = hr_add(hr_mul2(hc_re(Z)), OX);
             const hreal<F> T3 = hr_add(hr_mul2(hc_im(Z)), OY);
@@ -1559,7 +1760,13 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
             }
             ++iter;
         }
-        store_iter(A.out, A.frame, L, X, iter);
+        if (finished) {
+            store_iter(A.out, A.frame, L, X, iter);
+            have = false;
+        }
+    }
+        if constexpr (!kRefill)
+            break;
     }
     if (kStats)
         add_stats(A.stats, 0, c_la, c_pt, c_px);
@@ -1912,20 +2119,62 @@ void fsk_lav2_hdr32(const FsLav2Args32 &A, int mode, bool stats, int variant, hi
 #undef FS_LAUNCH
 }
 
-void fsk_perturb_scalar_hdr32(const FsBlaArgs32 &A, bool use_bla, bool stats, hipStream_t s)
+// Grid of the persistent (lane-refilling) launch: as many workgroups as the device holds at once, never more than one
+// wave per tile.  The pixel queue counter is zeroed on the stream right before the launch.
+template <class K> static dim3 persistent_grid(K kernel, const FsFrame &f)
+{
+    int dev = 0, cus = 256, per_cu = 2;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1)
+        per_cu = 2;
+    if (const char *e = getenv("FSMI355_PERSIST_PER_CU")) // launch-shape experiment
+        per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
+    const uint64_t tiles = (uint64_t)((f.width + 7u) >> 3) * ((f.local_rows + 7u) >> 3);
+    uint64_t blocks = (uint64_t)cus * (uint64_t)per_cu;
+    const uint64_t need = (tiles + 3u) / 4u;
+    if (blocks > need)
+        blocks = need;
+    return dim3((unsigned)(blocks ? blocks : 1u), 1, 1);
+}
+
+static bool refill_enabled()
+{
+    // A/B switch: FSMI355_REFILL=1 selects the persistent, lane-refilling launch.  It is OFF by
+    // default: measured on C5 it raises the loop's lane utilisation from 0.71 to 0.97 and still loses (127.6 vs 72.4 ms
+    // on the 3840x2160 quarter frame) -- re-packed lanes sit at unrelated orbit and table positions, every per-lane load
+    // of a wave then touches 64 different cache lines, and the kernel turns from VALU-bound into L1/L2-request-bound.
+    static const bool on = getenv("FSMI355_REFILL") != nullptr && atoi(getenv("FSMI355_REFILL")) != 0;
+    return on;
+}
+
+template <class F> static void launch_perturb_scalar(const FsBlaArgsT<F> &A, bool use_bla, bool stats, hipStream_t s)
 {
     const dim3 g = tile_grid(A.frame), b(256);
-    if (use_bla) {
+    if (use_bla && refill_enabled()) {
+        (void)hipMemsetAsync(A.queue, 0, sizeof(uint32_t), s);
         if (stats)
-            hipLaunchKernelGGL((k_perturb_scalar<float, true, true>), g, b, 0, s, A);
+            hipLaunchKernelGGL((k_perturb_scalar<F, true, true, true>),
+                               persistent_grid(k_perturb_scalar<F, true, true, true>, A.frame), b, 0, s, A);
         else
-            hipLaunchKernelGGL((k_perturb_scalar<float, true, false>), g, b, 0, s, A);
+            hipLaunchKernelGGL((k_perturb_scalar<F, true, false, true>),
+                               persistent_grid(k_perturb_scalar<F, true, false, true>, A.frame), b, 0, s, A);
+    } else if (use_bla) {
+        if (stats)
+            hipLaunchKernelGGL((k_perturb_scalar<F, true, true, false>), g, b, 0, s, A);
+        else
+            hipLaunchKernelGGL((k_perturb_scalar<F, true, false, false>), g, b, 0, s, A);
     } else {
         if (stats)
-            hipLaunchKernelGGL((k_perturb_scalar<float, false, true>), g, b, 0, s, A);
+            hipLaunchKernelGGL((k_perturb_scalar<F, false, true, false>), g, b, 0, s, A);
         else
-            hipLaunchKernelGGL((k_perturb_scalar<float, false, false>), g, b, 0, s, A);
+            hipLaunchKernelGGL((k_perturb_scalar<F, false, false, false>), g, b, 0, s, A);
     }
+}
+
+void fsk_perturb_scalar_hdr32(const FsBlaArgs32 &A, bool use_bla, bool stats, hipStream_t s)
+{
+    launch_perturb_scalar<float>(A, use_bla, stats, s);
 }
 
 __global__ void k_decompress_orbit_hdr64(const fs_orbit_hdr64_rc *__restrict__ wp, uint64_t n_wp, uint64_t n_uncompressed,
@@ -1997,18 +2246,7 @@ void fsk_lav2_hdr64(const FsLav2ArgsT<double> &A, int mode, bool stats, hipStrea
 
 void fsk_perturb_scalar_hdr64(const FsBlaArgsT<double> &A, bool use_bla, bool stats, hipStream_t s)
 {
-    const dim3 g = tile_grid(A.frame), b(256);
-    if (use_bla) {
-        if (stats)
-            hipLaunchKernelGGL((k_perturb_scalar<double, true, true>), g, b, 0, s, A);
-        else
-            hipLaunchKernelGGL((k_perturb_scalar<double, true, false>), g, b, 0, s, A);
-    } else {
-        if (stats)
-            hipLaunchKernelGGL((k_perturb_scalar<double, false, true>), g, b, 0, s, A);
-        else
-            hipLaunchKernelGGL((k_perturb_scalar<double, false, false>), g, b, 0, s, A);
-    }
+    launch_perturb_scalar<double>(A, use_bla, stats, s);
 }
 
 void fsk_perturb_bla_f64(const FsBlaArgsF64 &A, bool use_bla, bool stats, hipStream_t s)

@@ -47,6 +47,7 @@ struct fs_renderer {
     fs_color16 *colors = nullptr;
     fs_reduction *reduction = nullptr;
     uint64_t *stats = nullptr;
+    uint32_t *queue = nullptr; // pixel counter of the persistent launches (kernels.hip, k_perturb_scalar)
     bool stats_on = false;
     int variant = FS_VARIANT_TUNED;
 
@@ -231,6 +232,9 @@ void free_all(fs_renderer *r)
         hipFree(r->reduction);
     if (r->stats)
         hipFree(r->stats);
+    if (r->queue)
+        hipFree(r->queue);
+    r->queue = nullptr;
     if (r->pal)
         hipFree(r->pal);
     if (r->cx_row)
@@ -462,6 +466,8 @@ uint32_t fs_init_memory(fs_renderer *r, uint32_t w, uint32_t h, uint32_t antiali
         FS_TRY(hipMalloc((void **)&r->reduction, sizeof(fs_reduction)));
     if (!r->stats)
         FS_TRY(hipMalloc((void **)&r->stats, 8 * sizeof(uint64_t)));
+    if (!r->queue)
+        FS_TRY(hipMalloc((void **)&r->queue, 64));
     FS_TRY(hipMalloc((void **)&r->colors, r->n_color_cu * sizeof(fs_color16)));
     return fs_clear(r);
 }
@@ -1090,6 +1096,7 @@ uint32_t fs_render_bla(fs_renderer *r, int type_tag, const void *coords, uint64_
         A.zs = r->zq + r->zq_n;
         A.levels = (const fs_bla_hdr32 *const *)r->bla_levels_dev;
         A.stats = r->stats;
+        A.queue = r->queue;
         A.frame = make_frame(r);
         fill_coords(A.coords, coords);
         A.orbit_count = (uint32_t)r->orbit_uncompressed;
@@ -1104,6 +1111,7 @@ uint32_t fs_render_bla(fs_renderer *r, int type_tag, const void *coords, uint64_
         A.zref = r->zref64;
         A.levels = (const fs_bla_hdr64 *const *)r->bla_levels_dev;
         A.stats = r->stats;
+        A.queue = r->queue;
         A.frame = make_frame(r);
         fill_coords(A.coords, coords);
         A.orbit_count = (uint32_t)r->orbit_uncompressed;
