@@ -5,7 +5,7 @@ modules here are plumbing: `renderer.GPURenderer` mirrors the reference's GPURen
 builds views / reference orbits / LA / BLA tables with GMP, `tiling` row-tiles a frame over the GPUs of one node.
 """
 from . import inputs  # noqa: F401
-from .renderer import (GPURenderer, LAV2_FULL, LAV2_LAO, LAV2_PO, PARITY_CPU, PARITY_CPU_GPUSTAGE,  # noqa: F401
+from .renderer import (GPURendererGroup, GPURenderer, LAV2_FULL, LAV2_LAO, LAV2_PO, PARITY_CPU, PARITY_CPU_GPUSTAGE,  # noqa: F401
                        T_2X32, T_2X64, T_4X32, T_4X64, T_F32, T_F64, T_HDR2X32, T_HDR32, T_HDR64)
 
 __all__ = ["GPURenderer", "inputs", "LAV2_FULL", "LAV2_PO", "LAV2_LAO", "PARITY_CPU", "PARITY_CPU_GPUSTAGE",

@@ -124,6 +124,26 @@ def render_lib():
     _decl(lib, "fs_enable_step_count", u32, [vp, C.c_int])
     _decl(lib, "fs_read_step_count", u32, [vp, vp])
     _decl(lib, "fs_time_render_current", u32, [vp, u64, u32, vp])
+    _decl(lib, "fs_group_create", vp, [vp, C.c_int, C.c_int])
+    _decl(lib, "fs_group_destroy", None, [vp])
+    _decl(lib, "fs_group_size", C.c_int, [vp])
+    _decl(lib, "fs_group_transport", C.c_int, [vp])
+    _decl(lib, "fs_group_renderer", vp, [vp, C.c_int])
+    _decl(lib, "fs_group_init_memory", u32, [vp, u32, u32, u32, u32, vp, u32, u32, u64])
+    _decl(lib, "fs_group_upload_orbit", u32, [vp, u64, C.c_int, u32, vp, u64, u64, u64])
+    _decl(lib, "fs_group_upload_orbit_compressed", u32, [vp, u64, C.c_int, u32, vp, u64, u64, u64, vp, vp])
+    _decl(lib, "fs_group_upload_la", u32, [vp, u64, C.c_int, u32, vp, u32, vp, u32, C.c_int, C.c_int, vp])
+    _decl(lib, "fs_group_upload_bla", u32, [vp, C.c_int, vp, vp, i32, i32])
+    _decl(lib, "fs_group_upload_orbit_scaled", u32, [vp, C.c_int, u32, vp, vp, u64, u64])
+    _decl(lib, "fs_group_render_lav2", u32, [vp, C.c_int, C.c_int, C.c_int, vp, u64])
+    _decl(lib, "fs_group_render_bla", u32, [vp, C.c_int, vp, u64])
+    _decl(lib, "fs_group_render_scaled", u32, [vp, C.c_int, vp, u64])
+    _decl(lib, "fs_group_render_direct", u32, [vp, C.c_int, vp, u64])
+    _decl(lib, "fs_group_clear", u32, [vp])
+    _decl(lib, "fs_group_render_current", u32, [vp, u64, vp, vp])
+    _decl(lib, "fs_group_sync", u32, [vp])
+    _decl(lib, "fs_group_gather_ms", C.c_float, [vp])
+    _decl(lib, "fs_group_plan", None, [u32, u32, u32, u32, vp, vp, vp])
     _render = lib
     return lib
 
@@ -137,6 +157,11 @@ RENDER_SYMBOLS = [
     "fs_render_current", "fs_sync_compute", "fs_compute_stream", "fs_sync_display", "fs_query_compute", "fs_enqueue_done_callback",
     "fs_get_width", "fs_get_height", "fs_last_kernel_ms", "fs_set_kernel_variant", "fs_enable_step_count", "fs_read_step_count",
     "fs_time_render_current",
+    "fs_group_create", "fs_group_destroy", "fs_group_size", "fs_group_transport", "fs_group_renderer", "fs_group_init_memory",
+    "fs_group_upload_orbit", "fs_group_upload_orbit_compressed", "fs_group_upload_la", "fs_group_upload_bla",
+    "fs_group_upload_orbit_scaled", "fs_group_render_lav2", "fs_group_render_bla", "fs_group_render_scaled",
+    "fs_group_render_direct", "fs_group_clear", "fs_group_render_current", "fs_group_sync", "fs_group_gather_ms",
+    "fs_group_plan",
 ]
 
 

@@ -1,0 +1,399 @@
+// group.cpp -- fs_group_*: one frame row-tiled over the GPUs of one node behind the C ABI (include/fsmi355.h).
+//
+// The reference is single-device (GPU_Render.cu:113 hard-codes device 0); north_star asks for "frames row-tiled across
+// the 8 GPUs of one node with a RCCL gather over xGMI of the iteration buffer".  A C++ host that links libfsmi355.so
+// (the FractalShark drop-in of INTEGRATION.md) is ONE process, so the group is single-process multi-GPU: one fs_renderer
+// per device, one RCCL communicator per device from ncclCommInitAll, and the gather is N-1 ncclSend / one rank-0
+// ncclRecv per peer inside a single ncclGroupStart / ncclGroupEnd, enqueued on the members' own compute streams (so it
+// is ordered behind each member's kernel without a host round trip).  Only rank 0 needs the frame (it is what
+// RenderCurrent hands to the host), so this moves (N-1)/N of the frame once over the point-to-point xGMI links into
+// device 0 -- an all-gather would move N times as much for nothing.
+//
+// Partitioning = fractalshark_amd/tiling.py: rank r owns the 8-row bands k*N + r (fine interleaving: slow pixels cluster
+// spatially), the kernels keep the GLOBAL row in the pixel -> delta-c mapping (fs_set_row_bands), slices are padded to
+// equal size, and one HBM-bound kernel on device 0 restores row order (k_gather_rows).
+//
+// RCCL is resolved at run time (dlopen "librccl.so.1"): the library has no link-time dependency on it and a one-GPU
+// host never loads it.  transport: 0 = RCCL (default for distinct devices), 1 = hipMemcpyPeerAsync (members that share
+// a device -- the one-GPU test box -- and hosts without RCCL).
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/fsmi355.h"
+#include "kernels.h"
+
+namespace {
+
+// the few RCCL entry points used, with the signatures of rccl.h (ncclResult_t and ncclDataType_t are ints there)
+struct Rccl {
+    void *lib = nullptr;
+    int (*CommInitAll)(void **comms, int ndev, const int *devlist) = nullptr;
+    int (*CommDestroy)(void *comm) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *buf, size_t count, int dtype, int peer, void *comm, hipStream_t s) = nullptr;
+    int (*Recv)(void *buf, size_t count, int dtype, int peer, void *comm, hipStream_t s) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+
+Rccl &rccl()
+{
+    static Rccl r = [] {
+        Rccl q;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            q.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (q.lib)
+                break;
+        }
+        if (!q.lib)
+            return q;
+        q.CommInitAll = (decltype(q.CommInitAll))dlsym(q.lib, "ncclCommInitAll");
+        q.CommDestroy = (decltype(q.CommDestroy))dlsym(q.lib, "ncclCommDestroy");
+        q.GroupStart = (decltype(q.GroupStart))dlsym(q.lib, "ncclGroupStart");
+        q.GroupEnd = (decltype(q.GroupEnd))dlsym(q.lib, "ncclGroupEnd");
+        q.Send = (decltype(q.Send))dlsym(q.lib, "ncclSend");
+        q.Recv = (decltype(q.Recv))dlsym(q.lib, "ncclRecv");
+        q.GetErrorString = (decltype(q.GetErrorString))dlsym(q.lib, "ncclGetErrorString");
+        q.ok = q.CommInitAll && q.CommDestroy && q.GroupStart && q.GroupEnd && q.Send && q.Recv;
+        return q;
+    }();
+    return r;
+}
+
+constexpr int kNcclUint8 = 1; // ncclUint8, rccl.h
+
+} // namespace
+
+struct fs_group {
+    std::vector<int> devices;
+    std::vector<fs_renderer *> members;
+    std::vector<void *> comms;     // ncclComm_t per member (RCCL transport)
+    std::vector<void *> slices;    // per member: its slice buffer on its own device (external iteration buffer)
+    int transport = 0;
+    uint32_t width = 0, height = 0, band = 8, iter_bytes = 4, rounded_width = 0, max_rows = 0;
+    void *gathered = nullptr;      // device 0: N slices back to back
+    void *frame = nullptr;         // device 0: rows in order, padded to 8
+    uint32_t *index = nullptr;     // device 0: frame row -> gathered row
+    fs_reduction *reduction = nullptr;
+    fs_reduction reduce_seed{};
+    float last_gather_ms = -1.0f;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    size_t slice_bytes() const { return (size_t)max_rows * rounded_width * iter_bytes; }
+};
+
+extern "C" {
+
+void fs_group_plan(uint32_t height, uint32_t world, uint32_t band, uint32_t rank, uint32_t *local_rows,
+                   uint32_t *max_local_rows, uint32_t *frame_index)
+{
+    // rows of `rank` in local-buffer order, and the slot every rank's slice is padded to (rank 0 owns the most)
+    auto rows_of = [&](uint32_t r) {
+        uint32_t n = 0;
+        for (uint64_t s = (uint64_t)r * band; s < height; s += (uint64_t)world * band)
+            n += (uint32_t)((s + band < height ? s + band : height) - s);
+        return n;
+    };
+    const uint32_t m = (rows_of(0) + 7u) / 8u * 8u;
+    if (local_rows)
+        *local_rows = rows_of(rank);
+    if (max_local_rows)
+        *max_local_rows = m;
+    if (frame_index)
+        for (uint32_t r = 0; r < world; r++) {
+            uint32_t k = 0;
+            for (uint64_t s = (uint64_t)r * band; s < height; s += (uint64_t)world * band)
+                for (uint64_t y = s; y < s + band && y < height; y++)
+                    frame_index[y] = r * m + k++;
+        }
+}
+
+fs_group *fs_group_create(const int *devices, int n_devices, int transport)
+{
+    if (!devices || n_devices < 1 || n_devices > 64)
+        return nullptr;
+    fs_group *g = new (std::nothrow) fs_group();
+    if (!g)
+        return nullptr;
+    g->devices.assign(devices, devices + n_devices);
+    bool distinct = true;
+    for (int i = 0; i < n_devices; i++)
+        for (int j = 0; j < i; j++)
+            distinct = distinct && devices[i] != devices[j];
+    g->transport = (transport == 1 || !distinct || n_devices == 1) ? 1 : 0;
+    for (int i = 0; i < n_devices; i++) {
+        fs_renderer *r = fs_create(devices[i]);
+        if (!r) {
+            fs_group_destroy(g);
+            return nullptr;
+        }
+        g->members.push_back(r);
+    }
+    if (g->transport == 0) {
+        Rccl &q = rccl();
+        g->comms.assign((size_t)n_devices, nullptr);
+        if (!q.ok || q.CommInitAll(g->comms.data(), n_devices, devices) != 0) {
+            fprintf(stderr, "fsmi355: RCCL unavailable or ncclCommInitAll failed; the group falls back to peer copies\n");
+            g->comms.clear();
+            g->transport = 1;
+        }
+    }
+    return g;
+}
+
+static void group_free_buffers(fs_group *g)
+{
+    for (size_t i = 0; i < g->slices.size(); i++)
+        if (g->slices[i] && hipSetDevice(g->devices[i]) == hipSuccess) {
+            (void)fs_set_external_iter_buffer(g->members[i], nullptr, 0);
+            (void)hipFree(g->slices[i]);
+        }
+    g->slices.clear();
+    if (!g->devices.empty() && hipSetDevice(g->devices[0]) == hipSuccess) {
+        if (g->gathered)
+            (void)hipFree(g->gathered);
+        if (g->frame)
+            (void)hipFree(g->frame);
+        if (g->index)
+            (void)hipFree(g->index);
+        if (g->reduction)
+            (void)hipFree(g->reduction);
+    }
+    g->gathered = g->frame = nullptr;
+    g->index = nullptr;
+    g->reduction = nullptr;
+}
+
+void fs_group_destroy(fs_group *g)
+{
+    if (!g)
+        return;
+    (void)fs_group_sync(g);
+    group_free_buffers(g);
+    if (g->ev_a)
+        (void)hipEventDestroy(g->ev_a);
+    if (g->ev_b)
+        (void)hipEventDestroy(g->ev_b);
+    for (void *c : g->comms)
+        if (c)
+            rccl().CommDestroy(c);
+    for (fs_renderer *r : g->members)
+        fs_destroy(r);
+    delete g;
+}
+
+int fs_group_size(const fs_group *g) { return (int)g->members.size(); }
+fs_renderer *fs_group_renderer(fs_group *g, int rank)
+{
+    return rank >= 0 && (size_t)rank < g->members.size() ? g->members[(size_t)rank] : nullptr;
+}
+int fs_group_transport(const fs_group *g) { return g->transport; }
+
+#define FSG_TRY(expr)                                                                                                 \
+    do {                                                                                                              \
+        const uint32_t e_ = (uint32_t)(expr);                                                                         \
+        if (e_ != 0)                                                                                                  \
+            return e_;                                                                                                \
+    } while (0)
+
+uint32_t fs_group_init_memory(fs_group *g, uint32_t w, uint32_t h, uint32_t antialiasing, uint32_t iter_bytes,
+                              const fs_color16 *pal_interleaved, uint32_t pal_iters, uint32_t palette_aux_depth,
+                              uint64_t palette_generation)
+{
+    const uint32_t world = (uint32_t)g->members.size();
+    group_free_buffers(g);
+    g->band = antialiasing == 3 ? 24u : 8u; // a band never splits an antialiasing row group (tiling.py)
+    for (uint32_t r = 0; r < world; r++) {
+        FSG_TRY(fs_init_memory(g->members[r], w, h, antialiasing, iter_bytes, pal_interleaved, pal_iters, palette_aux_depth,
+                               palette_generation, 0));
+        FSG_TRY(fs_set_row_bands(g->members[r], r * g->band, g->band, world * g->band));
+    }
+    g->width = w;
+    g->height = h;
+    g->iter_bytes = iter_bytes;
+    g->rounded_width = fs_rounded_width(g->members[0]);
+    std::vector<uint32_t> idx(h);
+    fs_group_plan(h, world, g->band, 0, nullptr, &g->max_rows, idx.data());
+    // device 0: the gather target (N padded slices), the ordered frame, the row index, the reduction cell
+    FSG_TRY(hipSetDevice(g->devices[0]));
+    const size_t sb = g->slice_bytes();
+    FSG_TRY(hipMalloc(&g->gathered, sb * world));
+    FSG_TRY(hipMemset(g->gathered, 0, sb * world));
+    const size_t frame_rows = ((size_t)h + 7u) / 8u * 8u;
+    FSG_TRY(hipMalloc(&g->frame, frame_rows * g->rounded_width * iter_bytes));
+    FSG_TRY(hipMemset(g->frame, 0, frame_rows * g->rounded_width * iter_bytes));
+    FSG_TRY(hipMalloc((void **)&g->index, sizeof(uint32_t) * h));
+    FSG_TRY(hipMemcpy(g->index, idx.data(), sizeof(uint32_t) * h, hipMemcpyHostToDevice));
+    FSG_TRY(hipMalloc((void **)&g->reduction, sizeof(fs_reduction)));
+    if (!g->ev_a) {
+        FSG_TRY(hipEventCreate(&g->ev_a));
+        FSG_TRY(hipEventCreate(&g->ev_b));
+    }
+    // every member renders into a slice buffer of the common (padded) size; member 0 straight into its gather slot
+    g->slices.assign(world, nullptr);
+    for (uint32_t r = 0; r < world; r++) {
+        void *buf = nullptr;
+        if (r == 0) {
+            buf = g->gathered;
+        } else {
+            FSG_TRY(hipSetDevice(g->devices[r]));
+            FSG_TRY(hipMalloc(&buf, sb));
+            FSG_TRY(hipMemset(buf, 0, sb));
+            g->slices[r] = buf;
+        }
+        FSG_TRY(fs_set_external_iter_buffer(g->members[r], buf, sb));
+    }
+    return 0;
+}
+
+// ---- replicated uploads (inputs are small next to the frame: 257 KB at C3; the host pointer is read once per member)
+uint32_t fs_group_upload_orbit(fs_group *g, uint64_t generation, int type_tag, uint32_t iter_bytes, const void *entries,
+                               uint64_t orbit_size, uint64_t uncompressed_size, uint64_t period_maybe_zero)
+{
+    for (fs_renderer *r : g->members)
+        FSG_TRY(fs_upload_orbit(r, generation, type_tag, iter_bytes, entries, orbit_size, uncompressed_size, period_maybe_zero));
+    return 0;
+}
+uint32_t fs_group_upload_orbit_compressed(fs_group *g, uint64_t generation, int type_tag, uint32_t iter_bytes,
+                                          const void *entries, uint64_t compressed_size, uint64_t uncompressed_size,
+                                          uint64_t period_maybe_zero, const void *orbit_x_low, const void *orbit_y_low)
+{
+    for (fs_renderer *r : g->members)
+        FSG_TRY(fs_upload_orbit_compressed(r, generation, type_tag, iter_bytes, entries, compressed_size, uncompressed_size,
+                                           period_maybe_zero, orbit_x_low, orbit_y_low));
+    return 0;
+}
+uint32_t fs_group_upload_la(fs_group *g, uint64_t generation, int type_tag, uint32_t iter_bytes, const void *las,
+                            uint32_t n_las, const void *stages, uint32_t n_stages, int is_valid, int use_at,
+                            const void *at_info)
+{
+    for (fs_renderer *r : g->members)
+        FSG_TRY(fs_upload_la(r, generation, type_tag, iter_bytes, las, n_las, stages, n_stages, is_valid, use_at, at_info));
+    return 0;
+}
+uint32_t fs_group_upload_bla(fs_group *g, int type_tag, const void *const *levels, const uint64_t *level_sizes,
+                             int32_t n_levels, int32_t lm2)
+{
+    for (fs_renderer *r : g->members)
+        FSG_TRY(fs_upload_bla(r, type_tag, levels, level_sizes, n_levels, lm2));
+    return 0;
+}
+uint32_t fs_group_upload_orbit_scaled(fs_group *g, int type_tag, uint32_t iter_bytes, const void *entries_t,
+                                      const void *entries_f32, uint64_t orbit_size, uint64_t period_maybe_zero)
+{
+    for (fs_renderer *r : g->members)
+        FSG_TRY(fs_upload_orbit_scaled(r, type_tag, iter_bytes, entries_t, entries_f32, orbit_size, period_maybe_zero));
+    return 0;
+}
+
+// ---- renders: one asynchronous launch per member, each on its own device and compute stream
+uint32_t fs_group_render_lav2(fs_group *g, int type_tag, int mode, int parity, const void *coords, uint64_t n_iterations)
+{
+    for (fs_renderer *r : g->members)
+        FSG_TRY(fs_render_lav2(r, type_tag, mode, parity, coords, n_iterations));
+    return 0;
+}
+uint32_t fs_group_render_bla(fs_group *g, int type_tag, const void *coords, uint64_t n_iterations)
+{
+    for (fs_renderer *r : g->members)
+        FSG_TRY(fs_render_bla(r, type_tag, coords, n_iterations));
+    return 0;
+}
+uint32_t fs_group_render_scaled(fs_group *g, int type_tag, const void *coords, uint64_t n_iterations)
+{
+    for (fs_renderer *r : g->members)
+        FSG_TRY(fs_render_scaled(r, type_tag, coords, n_iterations));
+    return 0;
+}
+uint32_t fs_group_render_direct(fs_group *g, int type_tag, const void *coords, uint64_t n_iterations)
+{
+    for (fs_renderer *r : g->members)
+        FSG_TRY(fs_render_direct(r, type_tag, coords, n_iterations));
+    return 0;
+}
+uint32_t fs_group_clear(fs_group *g)
+{
+    for (fs_renderer *r : g->members)
+        FSG_TRY(fs_clear(r));
+    return 0;
+}
+
+uint32_t fs_group_sync(fs_group *g)
+{
+    for (fs_renderer *r : g->members)
+        FSG_TRY(fs_sync_compute(r));
+    return 0;
+}
+
+// Gather + RenderCurrent: slices -> device 0 over xGMI, row order restored, min / max / sum, D2H of the padded frame.
+// Asynchronous on member 0's compute stream (fs_group_sync waits); iter_buffer / reduction may be NULL.
+uint32_t fs_group_render_current(fs_group *g, uint64_t n_iterations, void *iter_buffer, fs_reduction *reduction)
+{
+    (void)n_iterations;
+    const uint32_t world = (uint32_t)g->members.size();
+    if (!g->gathered)
+        return 0; // memory not initialised: silent, like GPURenderer::RenderCurrent
+    const size_t sb = g->slice_bytes();
+    hipStream_t s0 = (hipStream_t)fs_compute_stream(g->members[0]);
+    FSG_TRY(hipSetDevice(g->devices[0]));
+    FSG_TRY(hipEventRecord(g->ev_a, s0));
+    if (world > 1 && g->transport == 0) {
+        Rccl &q = rccl();
+        if (q.GroupStart() != 0)
+            return FS_ERR_7;
+        for (uint32_t r = 1; r < world; r++) {
+            // rank 0 receives slice r behind its own kernel; rank r sends behind ITS kernel (its compute stream)
+            if (q.Recv((char *)g->gathered + sb * r, sb, kNcclUint8, (int)r, g->comms[0], s0) != 0)
+                return FS_ERR_7;
+            if (q.Send(g->slices[r], sb, kNcclUint8, 0, g->comms[r], (hipStream_t)fs_compute_stream(g->members[r])) != 0)
+                return FS_ERR_7;
+        }
+        if (q.GroupEnd() != 0)
+            return FS_ERR_7;
+    } else if (world > 1) {
+        for (uint32_t r = 1; r < world; r++) {
+            // the copy runs on the SENDER's stream (ordered behind its kernel); rank 0 then waits for it on the device
+            hipStream_t sr = (hipStream_t)fs_compute_stream(g->members[r]);
+            FSG_TRY(hipSetDevice(g->devices[r]));
+            FSG_TRY(hipMemcpyPeerAsync((char *)g->gathered + sb * r, g->devices[0], g->slices[r], g->devices[r], sb, sr));
+            hipEvent_t done;
+            FSG_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+            FSG_TRY(hipEventRecord(done, sr));
+            FSG_TRY(hipSetDevice(g->devices[0]));
+            FSG_TRY(hipStreamWaitEvent(s0, done, 0));
+            FSG_TRY(hipEventDestroy(done)); // released once the recorded work has completed
+        }
+    }
+    FSG_TRY(hipSetDevice(g->devices[0]));
+    fsk_gather_rows(g->gathered, g->frame, g->index, g->rounded_width * g->iter_bytes, g->height, s0);
+    FSG_TRY(hipGetLastError());
+    FSG_TRY(hipEventRecord(g->ev_b, s0));
+    if (reduction) {
+        g->reduce_seed = fs_reduction{g->iter_bytes == 8 ? ~0ull : 0xFFFFFFFFull, 0, 0};
+        FSG_TRY(hipMemcpyAsync(g->reduction, &g->reduce_seed, sizeof(fs_reduction), hipMemcpyHostToDevice, s0));
+        fsk_reduce(g->frame, g->iter_bytes == 8, g->rounded_width, g->width, g->height, g->reduction, s0);
+        FSG_TRY(hipGetLastError());
+        FSG_TRY(hipMemcpyAsync(reduction, g->reduction, sizeof(fs_reduction), hipMemcpyDefault, s0));
+    }
+    if (iter_buffer) {
+        const size_t frame_rows = ((size_t)g->height + 7u) / 8u * 8u;
+        FSG_TRY(hipMemcpyAsync(iter_buffer, g->frame, frame_rows * g->rounded_width * g->iter_bytes, hipMemcpyDefault, s0));
+    }
+    return 0;
+}
+
+float fs_group_gather_ms(fs_group *g)
+{
+    float ms = -1.0f;
+    if (g->ev_a && hipSetDevice(g->devices[0]) == hipSuccess && hipEventSynchronize(g->ev_b) == hipSuccess &&
+        hipEventElapsedTime(&ms, g->ev_a, g->ev_b) == hipSuccess)
+        g->last_gather_ms = ms;
+    return g->last_gather_ms;
+}
+
+} // extern "C"

@@ -37,6 +37,12 @@ __device__ __forceinline__ void store_iter(uint32_t *out, const FsFrame &f, uint
         out[idx] = v;
 }
 
+// IterType = uint64_t with 64-bit counting: the full value (the buffer holds uint64_t elements)
+__device__ __forceinline__ void store_iter(uint32_t *out, const FsFrame &f, uint32_t L, uint32_t X, uint64_t v)
+{
+    reinterpret_cast<uint64_t *>(out)[(size_t)L * f.rounded_width + X] = v;
+}
+
 __device__ __forceinline__ void add_stats(uint64_t *stats, uint64_t at, uint64_t la, uint64_t pt, uint64_t px)
 {
     // stats[4]: lane slots the wave occupied in the perturbation loop = 64 x (longest lane); with [2] it gives

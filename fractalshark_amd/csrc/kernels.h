@@ -74,7 +74,8 @@ template <class F> struct FsLav2ArgsT {
     uint32_t orbit_count;
     uint32_t period;
     uint32_t stage_count;
-    uint32_t n_iterations;
+    uint32_t n_iterations;    // low 32 bits of the iteration cap
+    uint32_t n_iterations_hi; // high 32 bits: non-zero only for the IterType = uint64_t kernels (k_lav2_lit<.., uint64_t>)
     int la_valid;
     int use_at;
     int parity;
@@ -217,6 +218,9 @@ void fsk_prepare_orbit_hdr64(const fs_orbit_hdr64 *in, FsZ64 *out, uint64_t n, h
 void fsk_make_quiet_orbit(const float4 *zref, float4 *zq, uint64_t n, hipStream_t s);
 void fsk_lav2_hdr32(const FsLav2Args32 &A, int mode, bool stats, int variant, hipStream_t s);
 void fsk_lav2_hdr64(const FsLav2ArgsT<double> &A, int mode, bool stats, hipStream_t s);
+// IterType = uint64_t with 64-bit iteration counting (iteration caps of 2^32 and above): the literal kernel instantiated
+// with a 64-bit counter; needs a uint64_t iteration buffer (frame.iter_u64)
+void fsk_lav2_wide(const FsLav2Args32 *A32, const FsLav2ArgsT<double> *A64, int mode, bool stats, hipStream_t s);
 void fsk_lav2_2x32(const FsLav2Args2x32 &A, int mode, bool stats, hipStream_t s);
 // kind: 0 = float, 1 = double, 2 = CudaDblflt
 void fsk_lav2_plain(const FsLav2ArgsPlain &A, int kind, int mode, bool stats, hipStream_t s);
@@ -242,3 +246,5 @@ void fsk_antialias(const void *iters, int iter_u64, uint32_t rounded_width, fs_c
                    uint64_t n_iterations, hipStream_t s);
 void fsk_reduce(const void *iters, int iter_u64, uint32_t rounded_width, uint32_t width, uint32_t rows,
                 fs_reduction *out, hipStream_t s);
+// multi-GPU tiler: out row y = in row index[y] (row_bytes a multiple of 16)
+void fsk_gather_rows(const void *in, void *out, const uint32_t *index, uint32_t row_bytes, uint32_t rows, hipStream_t s);

@@ -105,12 +105,12 @@ __global__ void k_make_quiet_orbit(const float4 *__restrict__ zref, float4 *__re
 // computed as ri + ri, which is the same value -- on bare mantissas, and replaces Reduce + compare by a value comparison
 // against T = esc.m * 2^(esc.e - 2k) (exact power-of-two scaling; +inf when it overflows), which is equivalent for a
 // positive normal |z|^2.  Anything else (k outside the window, a zero / denormal norm) runs the literal loop.
-template <class F>
-__device__ __forceinline__ void at_perform(const hcplx<F> c, const hreal<F> esc, const uint32_t ATMaxIt, hcplx<F> &z_out,
-                                           uint32_t &i_out)
+template <class F, class IterT = uint32_t>
+__device__ __forceinline__ void at_perform(const hcplx<F> c, const hreal<F> esc, const IterT ATMaxIt, hcplx<F> &z_out,
+                                           IterT &i_out)
 {
     hcplx<F> z = hc_zero<F>();
-    uint32_t i = 0;
+    IterT i = 0;
     const int k = c.e;
     if (k <= 0 && k > -kExpDiffIgnored && ATMaxIt > 1) {
         // iteration 0 literally: the norm of the zero start never exceeds the radius; z becomes c
@@ -182,7 +182,10 @@ __device__ __forceinline__ void at_perform(const hcplx<F> c, const hreal<F> esc,
 // (Fractal.cpp:2545-2678) with LAReference::getLA / isLAStageInvalid (LAReference.cpp:1076-1134),
 // LAInfoDeep::Prepare / Evaluate (LAInfoDeep.h:395-420), ATInfo::PerformAT (ATInfo.h:155-188).
 // Replaces mandel_1xHDR_float_perturb_lav2 (FractalSharkGpuLib/LAKernel.cuh:3-315).
-template <class F, int Mode, bool kStats>
+// IterT = the reference's IterType for the COUNTERS (LAKernel.cuh:3): uint32_t, or uint64_t for iteration caps of 2^32 and
+// above (iterations, the cap, the AT iteration count and the skipped-iteration product are then 64-bit; table step
+// lengths and indices stay 32-bit -- an orbit or table with 2^32 entries would not fit any device).
+template <class F, int Mode, bool kStats, class IterT = uint32_t>
 __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
 {
     // The float instantiation is the operation-by-operation A/B reference of the tuned kernel and keeps the literal AT
@@ -195,22 +198,23 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
     const bool live = X < A.frame.width && L < A.frame.local_rows && Y < A.frame.height;
     if (live) {
         c_px = 1;
-        const uint32_t n_iterations = A.n_iterations;
+        const IterT n_iterations = sizeof(IterT) == 8 ? (IterT)(((uint64_t)A.n_iterations_hi << 32) | A.n_iterations)
+                                                      : (IterT)A.n_iterations;
         hreal<F> deltaReal, deltaImaginary;
         pixel_delta<F>(A.coords, X, Y, deltaReal, deltaImaginary);
         const hcplx<F> DeltaSub0 = hc_from_hr(deltaReal, deltaImaginary);
         hcplx<F> DeltaSubN = hc_from_native<F>(F(0), F(0)); // {0,0}: zero with exponent 0 (Fractal.cpp:2565)
-        uint32_t iterations = 0;
+        IterT iterations = 0;
 
         if (Mode != FS_MODE_PO) {
             if (A.la_valid && A.use_at && hr_cmp_pos(hc_cheb(DeltaSub0), ldr(A.at.ThresholdC)) <= 0) {
-                const uint32_t ATMaxIt = n_iterations / A.at.StepLength;
+                const IterT ATMaxIt = n_iterations / A.at.StepLength;
                 hcplx<F> c = hc_add(hc_mul(DeltaSub0, ldc(A.at.CCoeff)), ldc(A.at.RefC));
                 hc_reduce(c);
                 hcplx<F> z;
-                uint32_t i;
+                IterT i;
                 if (kFastAT) {
-                    at_perform<F>(c, ldr(A.at.SqrEscapeRadius), ATMaxIt, z, i);
+                    at_perform<F, IterT>(c, ldr(A.at.SqrEscapeRadius), ATMaxIt, z, i);
                 } else {
                     z = hc_zero<F>();
                     const hreal<F> esc = ldr(A.at.SqrEscapeRadius);
@@ -2242,6 +2246,32 @@ void fsk_lav2_hdr64(const FsLav2ArgsT<double> &A, int mode, bool stats, hipStrea
     else
         FS_LAUNCH64(FS_MODE_LAO);
 #undef FS_LAUNCH64
+}
+
+void fsk_lav2_wide(const FsLav2Args32 *A32, const FsLav2ArgsT<double> *A64, int mode, bool stats, hipStream_t s)
+{
+    const dim3 b(256), g = tile_grid(A32 ? A32->frame : A64->frame);
+#define FS_LAUNCH_WIDE(M)                                                                                           \
+    do {                                                                                                            \
+        if (A32) {                                                                                                  \
+            if (stats)                                                                                              \
+                hipLaunchKernelGGL((k_lav2_lit<float, M, true, uint64_t>), g, b, 0, s, *A32);                       \
+            else                                                                                                    \
+                hipLaunchKernelGGL((k_lav2_lit<float, M, false, uint64_t>), g, b, 0, s, *A32);                      \
+        } else {                                                                                                    \
+            if (stats)                                                                                              \
+                hipLaunchKernelGGL((k_lav2_lit<double, M, true, uint64_t>), g, b, 0, s, *A64);                      \
+            else                                                                                                    \
+                hipLaunchKernelGGL((k_lav2_lit<double, M, false, uint64_t>), g, b, 0, s, *A64);                     \
+        }                                                                                                           \
+    } while (0)
+    if (mode == FS_MODE_FULL)
+        FS_LAUNCH_WIDE(FS_MODE_FULL);
+    else if (mode == FS_MODE_PO)
+        FS_LAUNCH_WIDE(FS_MODE_PO);
+    else
+        FS_LAUNCH_WIDE(FS_MODE_LAO);
+#undef FS_LAUNCH_WIDE
 }
 
 void fsk_perturb_scalar_hdr64(const FsBlaArgsT<double> &A, bool use_bla, bool stats, hipStream_t s)

@@ -227,3 +227,29 @@ void fsk_reduce(const void *iters, int iter_u64, uint32_t rounded_width, uint32_
     else
         hipLaunchKernelGGL(k_reduce<uint32_t>, g, b, 0, s, (const uint32_t *)iters, rounded_width, width, rows, out);
 }
+
+// ------------------------------------------------------------------------------------------------
+// Row reassembly of the multi-GPU tiler (csrc/group.cpp): out row y = gathered row index[y].  One 16-byte vector per
+// lane, rows are multiples of 16 elements: a pure HBM copy (read + write of the frame once).
+namespace {
+__global__ void __launch_bounds__(256) k_gather_rows(const uint4 *__restrict__ in, uint4 *__restrict__ out,
+                                                     const uint32_t *__restrict__ index, uint32_t row_vec4, uint32_t rows)
+{
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x;
+    if (x >= row_vec4)
+        return;
+    for (uint32_t y = blockIdx.y; y < rows; y += gridDim.y)
+        out[(size_t)y * row_vec4 + x] = in[(size_t)index[y] * row_vec4 + x];
+}
+} // namespace
+
+void fsk_gather_rows(const void *in, void *out, const uint32_t *index, uint32_t row_bytes, uint32_t rows, hipStream_t s)
+{
+    const uint32_t v4 = row_bytes / 16u;
+    if (!v4 || !rows)
+        return;
+    const uint32_t gx = (v4 + 255u) / 256u;
+    uint32_t gy = (4096u + gx - 1u) / gx;
+    gy = gy < rows ? gy : rows;
+    hipLaunchKernelGGL(k_gather_rows, dim3(gx, gy), dim3(256), 0, s, (const uint4 *)in, (uint4 *)out, index, v4, rows);
+}

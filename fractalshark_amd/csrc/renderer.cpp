@@ -298,6 +298,7 @@ template <class F> static void fill_lav2(fs_renderer *r, FsLav2ArgsT<F> &A, cons
     A.period = (uint32_t)r->orbit_period;
     A.stage_count = r->n_stages;
     A.n_iterations = (uint32_t)n_iterations;
+    A.n_iterations_hi = (uint32_t)(n_iterations >> 32);
     A.la_valid = r->la_ok ? r->la_valid : 0;
     A.use_at = r->use_at;
     A.parity = (parity == FS_PARITY_CPU_GPUSTAGE) ? FS_PARITY_GPUSTAGE : FS_PARITY_LITERAL;
@@ -970,11 +971,37 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
     if (!r->memory_initialized())
         return 0; // GPU_Render.cu:1007-1009
     const bool plain = type_tag == FS_T_F32 || type_tag == FS_T_F64 || type_tag == FS_T_2X32;
+    // iteration caps of 2^32 and above: IterType = uint64_t (8-byte buffer) and the types with a 64-bit counting kernel
+    const bool wide = n_iterations > 0xFFFFFFFFull;
     if ((type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64 && type_tag != FS_T_HDR2X32 && !plain) ||
-        n_iterations > 0xFFFFFFFFull)
+        (wide && (r->iter_bytes != 8 || (type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64))))
         return FS_ERR_UNSUPPORTED;
     if (!r->orbit_ok || r->orbit_type != type_tag)
         return FS_ERR_6; // GPU_Render.cu:1015-1022
+    if (wide) {
+        // GPURenderer::RenderPerturbLAv2<uint64_t, ...> with a cap the 32-bit counters cannot hold: the literal kernel
+        // instantiated with 64-bit counters (all three modes; the reference's arithmetic, operation by operation)
+        if (mode != FS_LAV2_PO && (!r->la_ok || r->la_type != type_tag))
+            return FS_ERR_6;
+        const int kmode = mode == FS_LAV2_FULL ? FS_MODE_FULL : (mode == FS_LAV2_PO ? FS_MODE_PO : FS_MODE_LAO);
+        TimedLaunch t(r);
+        if (type_tag == FS_T_HDR32) {
+            FsLav2ArgsT<float> A;
+            fill_lav2<float>(r, A, coords, n_iterations, parity);
+            A.zref = r->zref;
+            A.zq = r->zq;
+            A.zs = r->zq + r->zq_n;
+            A.at = r->at;
+            fsk_lav2_wide(&A, nullptr, kmode, r->stats_on, r->compute);
+        } else {
+            FsLav2ArgsT<double> A;
+            fill_lav2<double>(r, A, coords, n_iterations, parity);
+            A.zref = r->zref64;
+            A.at = r->at64;
+            fsk_lav2_wide(nullptr, &A, kmode, r->stats_on, r->compute);
+        }
+        return (uint32_t)hipGetLastError();
+    }
     if (plain) {
         // Gpu1x32 / Gpu1x64 / Gpu2x32 PerturbedLAv2*: no CPU RenderAlgorithm exists for LAv2 on a plain type, the kernel
         // restates the reference's CUDA kernel and ignores `parity`.  coords = float[4] / double[4] / fs_real_p2x32[4].

@@ -285,3 +285,86 @@ class GPURenderer:
     def new_iter_buffer(self):
         dt = np.uint64 if getattr(self, "_iter_bytes", 4) == 8 else np.uint32
         return np.zeros((self.local_rows, self.rounded_width), dt)
+
+
+class GPURendererGroup:
+    """One frame row-tiled over several GPUs of one node behind the C ABI (fs_group_*, csrc/group.cpp): the multi-GPU
+    form of GPURenderer for a single-process C++ host.  devices: HIP ordinals (repeats allowed: members then share a
+    device and the gather uses peer copies -- how the one-GPU test box exercises the tiler).  transport: 0 = RCCL,
+    1 = hipMemcpyPeerAsync."""
+
+    def __init__(self, devices, transport=0):
+        self._lib = _capi.render_lib()
+        arr = (C.c_int * len(devices))(*devices)
+        self._h = self._lib.fs_group_create(arr, len(devices), int(transport))
+        if not self._h:
+            raise MemoryError("fs_group_create failed")
+        self._iter_bytes = 4
+        self._shape = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.fs_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    @property
+    def size(self):
+        return self._lib.fs_group_size(self._h)
+
+    @property
+    def transport(self):
+        return self._lib.fs_group_transport(self._h)
+
+    def InitializeMemory(self, w, h, antialiasing, palInterleaved=None, palIters=0, paletteAuxDepth=0, paletteGeneration=0,
+                         iter_bytes=4):
+        pal_ptr = None
+        if palInterleaved is not None:
+            self._pal = np.ascontiguousarray(palInterleaved, dtype=np.uint16)
+            pal_ptr = self._pal.ctypes.data
+        self._iter_bytes = int(iter_bytes)
+        self._shape = ((h + 7) // 8 * 8, (w + 15) // 16 * 16)
+        return self._lib.fs_group_init_memory(self._h, w, h, antialiasing, iter_bytes, pal_ptr, palIters, paletteAuxDepth,
+                                              paletteGeneration)
+
+    def InitializePerturb(self, GenerationNumber1, Perturb1, LaReferenceHost=None, T=T_HDR32):
+        err = self._lib.fs_group_upload_orbit(self._h, GenerationNumber1, T, 4, Perturb1.data_ptr, Perturb1.count,
+                                              Perturb1.count, Perturb1.period)
+        if err or LaReferenceHost is None:
+            return err
+        la = LaReferenceHost
+        return self._lib.fs_group_upload_la(self._h, GenerationNumber1, T, 4, la.las_ptr, la.count, la.stages_ptr,
+                                            la.stage_count, 1 if la.is_valid else 0, 1 if la.use_at else 0,
+                                            C.addressof(la.at))
+
+    def UploadBLA(self, blas, T=T_HDR32):
+        if blas is None:
+            return self._lib.fs_group_upload_bla(self._h, T, None, None, 0, 0)
+        return self._lib.fs_group_upload_bla(self._h, T, blas.level_ptrs, blas.level_sizes, blas.num_levels, blas.lm2)
+
+    def RenderPerturbLAv2(self, dx, dy, centerX, centerY, n_iterations, T=T_HDR32, Mode=LAV2_FULL, parity=PARITY_CPU):
+        co = GPURenderer._pack_coords(T, [dx, dy, centerX, centerY])
+        return self._lib.fs_group_render_lav2(self._h, T, Mode, parity, co.ctypes.data, int(n_iterations))
+
+    def RenderPerturbBLA(self, dx, dy, centerX, centerY, n_iterations, T=T_HDR32):
+        co = GPURenderer._pack_coords(T, [dx, dy, centerX, centerY])
+        return self._lib.fs_group_render_bla(self._h, T, co.ctypes.data, int(n_iterations))
+
+    def ClearMemory(self):
+        return self._lib.fs_group_clear(self._h)
+
+    def RenderCurrent(self, n_iterations, iter_buffer=None, reduction_results=None):
+        ip = iter_buffer.ctypes.data if iter_buffer is not None else None
+        rp = C.addressof(reduction_results) if reduction_results is not None else None
+        return self._lib.fs_group_render_current(self._h, int(n_iterations), ip, rp)
+
+    def Sync(self):
+        return self._lib.fs_group_sync(self._h)
+
+    def gather_ms(self):
+        return float(self._lib.fs_group_gather_ms(self._h))
+
+    def new_iter_buffer(self):
+        return np.zeros(self._shape, np.uint64 if self._iter_bytes == 8 else np.uint32)

@@ -82,9 +82,11 @@ const char *fs_error_string(uint32_t err);
  * iter_bytes = sizeof(IterType) (4 or 8).  The iteration buffer is padded to 16 columns x 8 rows
  * (GPU_Render.cu:334-344).
  * IterType = uint64_t: the iteration buffer, RenderCurrent and ReductionResults work on uint64_t elements and the
- * uint64_t record layouts (fs_la_*_u64, fs_la_stage_u64, fs_at_*_u64) are accepted, but the device counts in 32 bits:
- * render calls with n_iterations >= 2^32 and tables whose step lengths / indices do not fit 32 bits return
- * FS_ERR_UNSUPPORTED (every built-in view selects Bits32, FractalViewPresets.cpp:19). */
+ * uint64_t record layouts (fs_la_*_u64, fs_la_stage_u64, fs_at_*_u64) are accepted (table step lengths / indices must
+ * fit 32 bits -- a table that large would not fit any device -- else FS_ERR_UNSUPPORTED).  Iteration caps of 2^32 and
+ * above are served by kernels that count in 64 bits for fs_render_lav2 with FS_T_HDR32 / FS_T_HDR64 (all three modes);
+ * the other entry points return FS_ERR_UNSUPPORTED for such a cap, as does every entry point with a 4-byte buffer
+ * (every built-in view selects Bits32, FractalViewPresets.cpp:19). */
 uint32_t fs_init_memory(fs_renderer *r, uint32_t w, uint32_t h, uint32_t antialiasing, uint32_t iter_bytes,
                         const fs_color16 *pal_interleaved, uint32_t pal_iters, uint32_t palette_aux_depth,
                         uint64_t palette_generation, int expected_reuse);
@@ -227,6 +229,53 @@ uint32_t fs_read_step_count(fs_renderer *r, uint64_t counts[8]);
  * kernels over the current iteration buffer: ms_out[0] = antialias + palette, ms_out[1] = min / max / sum.  Needs a
  * palette (fs_init_memory) and the whole frame on this renderer.  tools/bench_render_current.py turns them into GB/s. */
 uint32_t fs_time_render_current(fs_renderer *r, uint64_t n_iterations, uint32_t repeats, float ms_out[2]);
+
+/* ---- Multi-GPU: one frame row-tiled over the GPUs of one node, gathered over xGMI with RCCL (this project's addition;
+ * the reference is single-device, GPU_Render.cu:113).  A group = one fs_renderer per device inside ONE process (the C++
+ * drop-in of INTEGRATION.md is one process), RCCL communicators from ncclCommInitAll.  Rank r renders the 8-row bands
+ * k*N + r (24-row bands for antialiasing 3) with the global-row delta-c mapping of fs_set_row_bands; slices are sent to
+ * device 0 with ncclSend / ncclRecv in one ncclGroup on the members' compute streams, one kernel restores row order.
+ * transport: 0 = RCCL (resolved with dlopen at first use; falls back to 1 with a message on stderr if unavailable),
+ * 1 = hipMemcpyPeerAsync (also chosen automatically when members share a device, e.g. tests on a one-GPU box).
+ * Every fs_group_* upload / render call is the fs_* call of the same name applied to every member; renders are
+ * asynchronous.  fs_group_render_current = gather + row reassembly + min / max / sum + D2H of the padded iteration buffer
+ * (same layout as fs_render_current of a single renderer on the whole frame), asynchronous on member 0's compute stream;
+ * fs_group_sync waits for everything.  Colour output stays per renderer (fs_group_renderer + fs_render_current). */
+typedef struct fs_group fs_group;
+fs_group *fs_group_create(const int *devices, int n_devices, int transport);
+void fs_group_destroy(fs_group *g);
+int fs_group_size(const fs_group *g);
+int fs_group_transport(const fs_group *g);
+fs_renderer *fs_group_renderer(fs_group *g, int rank);
+uint32_t fs_group_init_memory(fs_group *g, uint32_t w, uint32_t h, uint32_t antialiasing, uint32_t iter_bytes,
+                              const fs_color16 *pal_interleaved, uint32_t pal_iters, uint32_t palette_aux_depth,
+                              uint64_t palette_generation);
+uint32_t fs_group_upload_orbit(fs_group *g, uint64_t generation, int type_tag, uint32_t iter_bytes, const void *entries,
+                               uint64_t orbit_size, uint64_t uncompressed_size, uint64_t period_maybe_zero);
+uint32_t fs_group_upload_orbit_compressed(fs_group *g, uint64_t generation, int type_tag, uint32_t iter_bytes,
+                                          const void *entries, uint64_t compressed_size, uint64_t uncompressed_size,
+                                          uint64_t period_maybe_zero, const void *orbit_x_low, const void *orbit_y_low);
+uint32_t fs_group_upload_la(fs_group *g, uint64_t generation, int type_tag, uint32_t iter_bytes, const void *las,
+                            uint32_t n_las, const void *stages, uint32_t n_stages, int is_valid, int use_at,
+                            const void *at_info);
+uint32_t fs_group_upload_bla(fs_group *g, int type_tag, const void *const *levels, const uint64_t *level_sizes,
+                             int32_t n_levels, int32_t lm2);
+uint32_t fs_group_upload_orbit_scaled(fs_group *g, int type_tag, uint32_t iter_bytes, const void *entries_t,
+                                      const void *entries_f32, uint64_t orbit_size, uint64_t period_maybe_zero);
+uint32_t fs_group_render_lav2(fs_group *g, int type_tag, int mode, int parity, const void *coords, uint64_t n_iterations);
+uint32_t fs_group_render_bla(fs_group *g, int type_tag, const void *coords, uint64_t n_iterations);
+uint32_t fs_group_render_scaled(fs_group *g, int type_tag, const void *coords, uint64_t n_iterations);
+uint32_t fs_group_render_direct(fs_group *g, int type_tag, const void *coords, uint64_t n_iterations);
+uint32_t fs_group_clear(fs_group *g);
+uint32_t fs_group_render_current(fs_group *g, uint64_t n_iterations, void *iter_buffer, fs_reduction *reduction);
+uint32_t fs_group_sync(fs_group *g);
+/* Duration of the last gather + reassembly on device 0 (HIP events; synchronises member 0's stream). */
+float fs_group_gather_ms(fs_group *g);
+/* The tiler's plan as a pure host function (tests; equals fractalshark_amd/tiling.py): rows rank `rank` owns, the
+ * common padded slice height, and frame_index[y] = row of the gathered buffer (N slices back to back) that holds frame
+ * row y.  Any output pointer may be NULL. */
+void fs_group_plan(uint32_t height, uint32_t world, uint32_t band, uint32_t rank, uint32_t *local_rows,
+                   uint32_t *max_local_rows, uint32_t *frame_index);
 
 #ifdef __cplusplus
 }

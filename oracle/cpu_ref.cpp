@@ -546,12 +546,14 @@ void bla_impl(uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, const t
 //             1 = the direction the GPU twin uses      (cheb(dc) >= LAThresholdC, GPU_LAReference.h:240-254)
 // mode: 0 = Full, 1 = PO (skip AT + LA stages), 2 = LAO (skip the perturbation loop) -- LAv2Mode of the GPU
 //       path (RenderAlgorithm.h:12-17); the CPU function is always Full.
-template <class F>
+// IterT = the reference's IterType for the counters (uint32_t, or uint64_t for iteration caps of 2^32 and above); table
+// fields stay 32-bit like the product's device records.
+template <class F, class IterT = uint32_t>
 void lav2_impl(uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, const typename Rec<F>::Orbit *orbit,
                uint64_t orbit_count, uint64_t period_maybe_zero, const typename Rec<F>::LA *las, uint32_t n_las,
                const fs_la_stage_u32 *stages, uint32_t stage_count, int la_valid, int use_at,
-               const typename Rec<F>::AT *at, const typename Rec<F>::Real coords[4], uint32_t n_iterations,
-               int stage_test, int mode, uint32_t *out, uint32_t stride, int threads, uint64_t *stats)
+               const typename Rec<F>::AT *at, const typename Rec<F>::Real coords[4], IterT n_iterations,
+               int stage_test, int mode, IterT *out, uint32_t stride, int threads, uint64_t *stats)
 {
     using H = HT<F>;
     using HC = HCT<F>;
@@ -565,7 +567,7 @@ void lav2_impl(uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, const 
     run_rows(y0, y1, threads, [&](uint32_t y) {
         uint64_t c_at = 0, c_la = 0, c_pt = 0;
         for (size_t x = 0; x < width; x++) {
-            uint32_t BLA2SkippedIterations = 0;
+            IterT BLA2SkippedIterations = 0;
             H deltaReal, deltaImaginary;
             pixel_delta<F>(dx, dy, centerX, centerY, x, y, deltaReal, deltaImaginary);
             const HC DeltaSub0 = CFromH(deltaReal, deltaImaginary);
@@ -574,11 +576,11 @@ void lav2_impl(uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, const 
             if (mode != 1 && la_valid && use_at &&
                 CmpPosReduced(CCheb(DeltaSub0), ld(at->ThresholdC)) <= 0) { // ATInfo::isValid
                 // ATInfo::PerformAT, ATInfo.h:155-188
-                const uint32_t ATMaxIt = n_iterations / at->StepLength;
+                const IterT ATMaxIt = n_iterations / at->StepLength;
                 HC c = CAdd(CMul(DeltaSub0, ld(at->CCoeff)), ld(at->RefC)); // getC
                 CReduce(c);
                 HC z = CZero<F>();
-                uint32_t i;
+                IterT i;
                 for (i = 0; i < ATMaxIt; i++) {
                     H nsq = CNormSq(z);
                     Reduce(nsq);
@@ -593,7 +595,7 @@ void lav2_impl(uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, const 
                 c_at += i;
             }
 
-            uint32_t iterations = 0;
+            IterT iterations = 0;
             uint32_t RefIteration = 0;
             const uint32_t MaxRefIteration = (uint32_t)orbit_count - 1;
             iterations = BLA2SkippedIterations;
@@ -898,6 +900,28 @@ void orc_lav2_hdr64(uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, c
 {
     lav2_impl<double>(width, height, y0, y1, orbit, orbit_count, period_maybe_zero, las, n_las, stages, stage_count,
                       la_valid, use_at, at, coords, n_iterations, stage_test, mode, out, stride, threads, stats);
+}
+
+// IterType = uint64_t (iteration caps of 2^32 and above): the same functions with 64-bit counters and a uint64_t buffer
+void orc_lav2_hdr32_u64(uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, const fs_orbit_hdr32 *orbit,
+                        uint64_t orbit_count, uint64_t period_maybe_zero, const fs_la_hdr32_u32 *las, uint32_t n_las,
+                        const fs_la_stage_u32 *stages, uint32_t stage_count, int la_valid, int use_at,
+                        const fs_at_hdr32_u32 *at, const fs_real_hdr32 coords[4], uint64_t n_iterations, int stage_test,
+                        int mode, uint64_t *out, uint32_t stride, int threads, uint64_t *stats)
+{
+    lav2_impl<float, uint64_t>(width, height, y0, y1, orbit, orbit_count, period_maybe_zero, las, n_las, stages,
+                               stage_count, la_valid, use_at, at, coords, n_iterations, stage_test, mode, out, stride,
+                               threads, stats);
+}
+void orc_lav2_hdr64_u64(uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, const fs_orbit_hdr64 *orbit,
+                        uint64_t orbit_count, uint64_t period_maybe_zero, const fs_la_hdr64_u32 *las, uint32_t n_las,
+                        const fs_la_stage_u32 *stages, uint32_t stage_count, int la_valid, int use_at,
+                        const fs_at_hdr64_u32 *at, const fs_real_hdr64 coords[4], uint64_t n_iterations, int stage_test,
+                        int mode, uint64_t *out, uint32_t stride, int threads, uint64_t *stats)
+{
+    lav2_impl<double, uint64_t>(width, height, y0, y1, orbit, orbit_count, period_maybe_zero, las, n_las, stages,
+                                stage_count, la_valid, use_at, at, coords, n_iterations, stage_test, mode, out, stride,
+                                threads, stats);
 }
 
 } // extern "C"

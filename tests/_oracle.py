@@ -59,6 +59,10 @@ def lib():
         l.orc_lav2_hdr64.argtypes = l.orc_lav2_hdr32.argtypes
         l.orc_direct_hdr32.argtypes = [u32, u32, u32, u32, vp, u32, vp, u32, C.c_int]
         l.orc_direct_hdr64.argtypes = l.orc_direct_hdr32.argtypes
+        for name in ("orc_lav2_hdr32_u64", "orc_lav2_hdr64_u64"):
+            getattr(l, name).restype = None
+            getattr(l, name).argtypes = [u32, u32, u32, u32, vp, u64, u64, vp, u32, vp, u32, C.c_int, C.c_int, vp, vp,
+                                         u64, C.c_int, C.c_int, vp, u32, C.c_int, vp]
         l.orc_bla_f64.restype = None
         l.orc_bla_f64.argtypes = [u32, u32, u32, u32, vp, u64, vp, u32, vp, vp, i32, i32, vp, u32, C.c_int]
         l.orc_gpu_lav2_2x32.restype = None
@@ -183,6 +187,20 @@ def lav2_hdr32(view, orbit, la, aa=1, rows=None, threads=8, stage_test=0, mode=0
                          threads, st)
     if stats:
         return out, {"at_iterations": st[0], "la_steps": st[1], "perturb_steps": st[2], "pixels": st[3]}
+    return out
+
+
+def lav2_u64(view, orbit, la, n_iterations, aa=1, rows=None, threads=8, stage_test=0, mode=0):
+    """CalcCpuPerturbationFractalLAV2<uint64_t, ...>: 64-bit counters and a uint64 buffer (iteration caps >= 2^32)."""
+    w, h = view.width * aa, view.height * aa
+    out = np.zeros(((h + 7) // 8 * 8, rounded_width(w)), np.uint64)
+    co = view.coords_perturb(orbit, aa)
+    y0, y1 = rows if rows else (0, h)
+    st = (u64 * 4)()
+    fn = lib().orc_lav2_hdr64_u64 if orbit.is64 else lib().orc_lav2_hdr32_u64
+    fn(w, h, y0, y1, orbit.data_ptr, orbit.count, orbit.period, la.las_ptr, la.count, la.stages_ptr, la.stage_count,
+       1 if la.is_valid else 0, 1 if la.use_at else 0, C.addressof(la.at), co.ctypes.data, int(n_iterations), stage_test,
+       mode, out.ctypes.data, out.shape[1], threads, st)
     return out
 
 

@@ -451,7 +451,39 @@ def test_uint64_itertype_matches_uint32(renderer, v5_small):
     big = inputs.LATableU64(la)
     big._stages[0, 1] = 1 << 33
     assert r.InitializePerturb(0, ob, 0, None, big, iter_bytes=8) == 10100
+    # an iteration cap of 2^32 needs IterType = uint64_t: refused with a 4-byte buffer (see the next test for 8 bytes)
+    assert r.InitializeMemory(64, 36, 1, None, 0, 0, 0, False, iter_bytes=4) == 0
+    assert r.InitializePerturb(0, ob, 0, None, la) == 0
     assert r.RenderPerturbLAv2(None, None, None, dx, dy, cx, cy, 1 << 32, Mode=LAV2_FULL) == 10100
+
+
+@pytest.mark.parametrize("is64", [False, True])
+def test_uint64_itertype_counts_past_2_to_32(renderer, native_libs, is64):
+    """GPURenderer::RenderPerturbLAv2<uint64_t, ...> with an iteration cap above 2^32 (LAKernel.cuh:3 is templated on
+    IterType; GPU_Render.cu:1204-1300 instantiates uint64_t): 64-bit counters in the kernel.  Interior pixels must come
+    back with exactly the cap, which no 32-bit counter can hold; everything is compared with the CPU function
+    instantiated for uint64_t (oracle)."""
+    v = inputs.View.builtin(5, 64, 36)
+    ob = inputs.Orbit(v, is64=is64)
+    la = inputs.LATable(ob)
+    n = (1 << 32) + 12345
+    r = renderer
+    T = T_HDR64 if is64 else T_HDR32
+    assert r.InitializeMemory(64, 36, 1, None, 0, 0, 0, False, iter_bytes=8) == 0
+    assert r.InitializePerturb(0, ob, 0, None, inputs.LATableU64(la), iter_bytes=8) == 0
+    dx, dy, cx, cy = _pairs(v.coords_perturb(ob))
+    for mode, omode in ((LAV2_FULL, 0), (LAV2_LAO, 2)):
+        assert r.ClearMemory() == 0
+        assert r.RenderPerturbLAv2(None, None, None, dx, dy, cx, cy, n, T=T, Mode=mode, parity=PARITY_CPU_GPUSTAGE) == 0
+        out = r.new_iter_buffer()
+        red = _capi.Reduction()
+        assert r.RenderCurrent(n, out, None, red) == 0
+        assert r.SyncComputeStream() == 0
+        ref = _oracle.lav2_u64(v, ob, la, n, stage_test=1, mode=omode)
+        assert out.dtype == np.uint64 and np.array_equal(out, ref)
+        if mode == LAV2_FULL:
+            assert int(out.max()) == n and int((out[:36, :64] == n).sum()) >= 1  # interior pixels sit at the cap
+        assert red.Max == int(ref[:36, :64].max()) and red.Sum == int(ref[:36, :64].sum())
     assert r.InitializeMemory(64, 36, 1, None, 0, 0, 0, False, iter_bytes=4) == 0
 
 
