@@ -970,6 +970,8 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
         return e;
     if (!r->memory_initialized())
         return 0; // GPU_Render.cu:1007-1009
+    if (r->local_rows == 0)
+        return 0; // this renderer owns no row of the frame (a rank beyond the last band)
     const bool plain = type_tag == FS_T_F32 || type_tag == FS_T_F64 || type_tag == FS_T_2X32;
     // iteration caps of 2^32 and above: IterType = uint64_t (8-byte buffer) and the types with a 64-bit counting kernel
     const bool wide = n_iterations > 0xFFFFFFFFull;
@@ -1091,6 +1093,8 @@ uint32_t fs_render_bla(fs_renderer *r, int type_tag, const void *coords, uint64_
         return e;
     if (!r->memory_initialized())
         return 0;
+    if (r->local_rows == 0)
+        return 0; // this renderer owns no row of the frame (a rank beyond the last band)
     if ((type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64 && type_tag != FS_T_F64) || n_iterations > 0xFFFFFFFFull)
         return FS_ERR_UNSUPPORTED;
     if (!r->orbit_ok || r->orbit_type != type_tag)
@@ -1156,6 +1160,8 @@ uint32_t fs_render_direct(fs_renderer *r, int type_tag, const void *coords, uint
         return e;
     if (!r->memory_initialized())
         return 0; // GPU_Render.cu:626-628
+    if (r->local_rows == 0)
+        return 0; // this renderer owns no row of the frame (a rank beyond the last band)
     if ((type_tag != FS_T_F64 && type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64) || n_iterations > 0xFFFFFFFFull)
         return FS_ERR_UNSUPPORTED;
     if (r->cx_row_cap < r->width) {
@@ -1245,6 +1251,8 @@ uint32_t fs_render_scaled(fs_renderer *r, int type_tag, const void *coords, uint
         return e;
     if (!r->memory_initialized())
         return 0; // GPU_Render.cu:1317-1319
+    if (r->local_rows == 0)
+        return 0; // this renderer owns no row of the frame (a rank beyond the last band)
     if ((type_tag != FS_T_HDR32 && type_tag != FS_T_F64) || n_iterations > 0xFFFFFFFFull)
         return FS_ERR_UNSUPPORTED;
     if (!r->scaled_t || !r->scaled_f || r->scaled_count < 2 || r->scaled_type != type_tag)
@@ -1290,6 +1298,8 @@ uint32_t fs_render_direct_lp(fs_renderer *r, int type_tag, const void *coords, u
         return e;
     if (!r->memory_initialized())
         return 0; // GPU_Render.cu:626-628
+    if (r->local_rows == 0)
+        return 0; // this renderer owns no row of the frame (a rank beyond the last band)
     if ((type_tag != FS_T_F32 && type_tag != FS_T_2X32 && type_tag != FS_T_2X64 && type_tag != FS_T_4X32 &&
          type_tag != FS_T_4X64) ||
         n_iterations > 0xFFFFFFFFull)
