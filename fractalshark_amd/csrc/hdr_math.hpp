@@ -408,8 +408,8 @@ template <class F> FS_HD hreal<F> hc_cheb(hcplx<F> a)
     return hreal<F>{ar > ai ? ar : ai, a.e};
 }
 
-// HDRFloatComplex.h:556-561 reciprocal (host builders only).
-template <class F> inline hcplx<F> hc_recip(hcplx<F> a)
+// HDRFloatComplex.h:556-561 reciprocal.
+template <class F> FS_HD hcplx<F> hc_recip(hcplx<F> a)
 {
     const F t = F(1) / (a.re * a.re + a.im * a.im);
     return hcplx<F>{a.re * t, -a.im * t, -a.e};

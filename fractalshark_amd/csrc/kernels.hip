@@ -405,9 +405,17 @@ __device__ __forceinline__ uint32_t scaled_run_length(uint32_t left)
     return __builtin_amdgcn_ballot_w64(left < 16u) == 0ull ? 16u : 0u;
 }
 
-template <int Mode, bool kStats, bool kScaled>
+// kLds (A/B variant, north_star "LDS staging of orbit segments shared across a wavefront"): in the scaled runs whose
+// lanes share their orbit position, the entries reach the wave through LDS instead of the scalar cache.  Each wave owns
+// two 1-KiB LDS buffers; one global_load_lds_dwordx4 (LDS-DMA: no VGPR destination, counted by vmcnt) brings the 64
+// entries of the NEXT 64 steps while the current 64 are consumed with broadcast ds_read_b128 (every lane the same
+// address; counted by lgkmcnt).  Two counters, in-order returns: a true software pipeline, which the scalar loads (one
+// out-of-order counter) cannot be.  What it costs: the entries live in VGPRs (8 x 4 per body) and every ds_read writes
+// 1 KiB of registers.  Measured against the scalar-cache path in DESIGN.md section 5.
+template <int Mode, bool kStats, bool kScaled, bool kLds = false>
 __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
 {
+    __shared__ float4 s_zs_lds[kLds ? 4 * 2 * 64 : 1];
     uint32_t X, L;
     tile_pixel(X, L);
     uint64_t c_at = 0, c_la = 0, c_pt = 0, c_px = 0;
@@ -645,6 +653,107 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                             // much as four vector instructions per step -- stays idle.
                             // Eight entries (two 64-byte lines) per body, one wait: a scalar-cache miss is an L2 round trip,
                             // and these loads cannot be waited for one at a time.
+                            if constexpr (kLds) {
+                                // ---- entries through LDS (see the kernel's header comment)
+                                float4 *wbuf = s_zs_lds + (threadIdx.x >> 6) * 128u;
+                                const uint32_t lds_base = (uint32_t)__builtin_amdgcn_readfirstlane(
+                                    (int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) float4 *)wbuf);
+                                const uint32_t last_entry = A.orbit_count + 1u; // the prepared arrays hold count + 2 entries
+                                const uint32_t nchunks = (run_len + 63u) >> 6;
+// ALL 64 lanes take part in the LDS-DMA whatever the loop's EXEC mask is (lanes whose pixel has finished are masked
+// off here, and a masked lane would leave its 16-byte slot of the chunk unwritten): EXEC is widened for the one
+// instruction, the lane number and the (clamped) entry offset are rebuilt inside the widened region, then EXEC and M0
+// are restored.  vaddr = 32-bit byte offset from the scalar base (the orbit arrays are far below 4 GiB).
+#define FS_GLDS_CHUNK(CH)                                                                                           \
+    {                                                                                                               \
+        const uint32_t idx0_ = ref_u + 1u + (CH) * 64u;                                                             \
+        const uint32_t dst_ = lds_base + (((CH) & 1u) << 10);                                                       \
+        uint32_t keep_, voff_;                                                                                      \
+        uint64_t exec_;                                                                                             \
+        asm volatile("s_or_saveexec_b64 %0, -1\n\t"                                                               \
+                     "v_mbcnt_lo_u32_b32 %2, -1, 0\n\t"                                                           \
+                     "v_mbcnt_hi_u32_b32 %2, -1, %2\n\t"                                                          \
+                     "v_add_u32 %2, %3, %2\n\t"                                                                   \
+                     "v_min_u32 %2, %4, %2\n\t"                                                                   \
+                     "v_lshlrev_b32 %2, 4, %2\n\t"                                                                \
+                     "s_mov_b32 %1, m0\n\t"                                                                       \
+                     "s_mov_b32 m0, %5\n\t"                                                                       \
+                     "s_nop 0\n\t"                                                                                \
+                     "global_load_lds_dwordx4 %2, %6\n\t"                                                         \
+                     "s_mov_b32 m0, %1\n\t"                                                                       \
+                     "s_mov_b64 exec, %0"                                                                           \
+                     : "=&s"(exec_), "=&s"(keep_), "=&v"(voff_)                                                     \
+                     : "s"(idx0_), "s"(last_entry), "s"(dst_), "s"(zs)                                              \
+                     : "memory");                                                                                   \
+    }
+                                FS_GLDS_CHUNK(0u)
+                                uint32_t chunk = 0;
+                                bool run_over = false;
+                                while (!run_over) {
+                                    if (chunk + 1u < nchunks) {
+                                        FS_GLDS_CHUNK(chunk + 1u)
+                                        asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); // this chunk has landed, the next flies
+                                    } else {
+                                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                                    }
+                                    const float4 *cb = wbuf + ((chunk & 1u) << 6);
+                                    const uint32_t steps_here = run_len - (chunk << 6) < 64u ? run_len - (chunk << 6) : 64u;
+                                    for (uint32_t e8 = 0; e8 < steps_here; e8 += 8u) {
+                                        const float4 ua = cb[e8], ub = cb[e8 + 1], uc = cb[e8 + 2], ud = cb[e8 + 3];
+                                        const float4 ue = cb[e8 + 4], uf = cb[e8 + 5], ug = cb[e8 + 6], uh = cb[e8 + 7];
+                                        f2 t1, u1;
+                                        uint64_t v1 = 0;
+                                        FS_SCALED_STEP(w0, z0, t1, u1, a, v1, false, (void)0, ua.x, ua.y, ua.z);
+                                        FS_SCALED_STEP(t1, u1, w2, z2, b, v1, true, (void)0, ub.x, ub.y, ub.z);
+                                        if (v1 != 0ull) {
+                                            FS_TRIP_FAILED(a, t1, ua.z, w0)
+                                            run_over = true;
+                                            break;
+                                        }
+                                        c += 2;
+                                        f2 t3, u3;
+                                        uint64_t v2 = 0;
+                                        FS_SCALED_STEP(w2, z2, t3, u3, c_, v2, false, (void)0, uc.x, uc.y, uc.z);
+                                        FS_SCALED_STEP(t3, u3, w0, z0, d, v2, true, (void)0, ud.x, ud.y, ud.z);
+                                        if (v2 != 0ull) {
+                                            FS_TRIP_FAILED(c_, t3, uc.z, w2)
+                                            run_over = true;
+                                            break;
+                                        }
+                                        c += 2;
+                                        f2 t5, u5;
+                                        uint64_t v3 = 0;
+                                        FS_SCALED_STEP(w0, z0, t5, u5, e, v3, false, (void)0, ue.x, ue.y, ue.z);
+                                        FS_SCALED_STEP(t5, u5, w2, z2, f, v3, true, (void)0, uf.x, uf.y, uf.z);
+                                        if (v3 != 0ull) {
+                                            FS_TRIP_FAILED(e, t5, ue.z, w0)
+                                            run_over = true;
+                                            break;
+                                        }
+                                        c += 2;
+                                        f2 t7, u7;
+                                        uint64_t v4 = 0;
+                                        FS_SCALED_STEP(w2, z2, t7, u7, g, v4, false, (void)0, ug.x, ug.y, ug.z);
+                                        FS_SCALED_STEP(t7, u7, w0, z0, h, v4, true, (void)0, uh.x, uh.y, uh.z);
+                                        if (v4 != 0ull) {
+                                            FS_TRIP_FAILED(g, t7, ug.z, w2)
+                                            run_over = true;
+                                            break;
+                                        }
+                                        c += 2;
+                                    }
+                                    if (run_over)
+                                        break;
+                                    chunk++;
+                                    if (c >= run_len) {
+                                        wO = w0, failed = false;
+                                        run_over = true;
+                                    }
+                                }
+                                // a run that stopped early may have left its prefetch in flight: it lands before the buffers are reused
+                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef FS_GLDS_CHUNK
+                            } else {
                             typedef float f4 __attribute__((ext_vector_type(4)));
                             const float4 *zpu = zs + ref_u + 1;
                             for (;;) {
@@ -702,6 +811,7 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                                     wO = w0, failed = false;
                                     break;
                                 }
+                            }
                             }
                         } else {
                             // per-lane orbit positions: one 12-byte vector load per step from a wave-uniform base plus a
@@ -2094,6 +2204,8 @@ void fsk_lav2_hdr32(const FsLav2Args32 &A, int mode, bool stats, int variant, hi
         const unsigned v = e ? (unsigned)atoi(e) : 256u;
         return v == 64u || v == 128u ? v : 256u;
     }();
+    // A/B switch: FSMI355_LDS_ORBIT=1 routes the wave-uniform scaled runs' orbit entries through LDS (see the kernel)
+    static const bool lds_orbit = getenv("FSMI355_LDS_ORBIT") != nullptr && atoi(getenv("FSMI355_LDS_ORBIT")) != 0;
     const dim3 b(bs), g((A.frame.width + bs / 8 - 1) / (bs / 8), (A.frame.local_rows + 7) / 8, 1);
 #define FS_LAUNCH(M)                                                                                                \
     do {                                                                                                            \
@@ -2108,6 +2220,11 @@ void fsk_lav2_hdr32(const FsLav2Args32 &A, int mode, bool stats, int variant, hi
                     hipLaunchKernelGGL((k_lav2_hdr32_fast<M, true, false>), g, b, pad, s, A);                         \
                 else                                                                                                \
                     hipLaunchKernelGGL((k_lav2_hdr32_fast<M, false, false>), g, b, pad, s, A);                        \
+            } else if (lds_orbit) {                                                                                 \
+                if (stats)                                                                                          \
+                    hipLaunchKernelGGL((k_lav2_hdr32_fast<M, true, true, true>), g, b, pad, s, A);                    \
+                else                                                                                                \
+                    hipLaunchKernelGGL((k_lav2_hdr32_fast<M, false, true, true>), g, b, pad, s, A);                   \
             } else if (stats)                                                                                       \
                 hipLaunchKernelGGL((k_lav2_hdr32_fast<M, true, true>), g, b, pad, s, A);                              \
             else                                                                                                    \

@@ -31,10 +31,16 @@ __device__ __forceinline__ H hr_sqrt_dev(H a)
 __device__ __forceinline__ H orb_x(const fs_orbit_hdr32_bad *__restrict__ o, uint32_t i) { return H{o[i].mx, o[i].ex}; }
 __device__ __forceinline__ H orb_y(const fs_orbit_hdr32_bad *__restrict__ o, uint32_t i) { return H{o[i].my, o[i].ey}; }
 
+// MI355X shape of the loop (the arithmetic is the reference's, operation by operation -- there is no CPU twin to pin a
+// re-association against): a wave covers an 8 x 8 pixel tile like the other perturbation kernels (neighbours in two
+// dimensions stay on the same orbit entry longer than 64 pixels of a row do, so the per-lane 16-byte entry loads of a
+// wave mostly hit one cache line); the binary32 orbit entry a step tests against is the entry the next step multiplies
+// by, so it is carried in registers instead of being loaded twice (one load per binary32 step); the common outcome of a
+// step ("none": no rebase, no rescale, no escape) is the fall-through, everything else is cold.
 template <bool kStats> __global__ void __launch_bounds__(256) k_scaled_hdr32(FsScaledArgs32 A)
 {
-    const uint32_t X = blockIdx.x * 64u + (threadIdx.x & 63u);
-    const uint32_t L = blockIdx.y * 4u + (threadIdx.x >> 6);
+    uint32_t X, L;
+    tile_pixel(X, L);
     uint64_t c_rescale = 0, c_full = 0, c_float = 0, c_px = 0;
     const uint32_t Y = global_row(A.frame, L);
     const bool live = X < A.frame.width && L < A.frame.local_rows && Y < A.frame.height;
@@ -72,8 +78,13 @@ template <bool kStats> __global__ void __launch_bounds__(256) k_scaled_hdr32(FsS
         wY = hr_to_native(hr_div((NY), S));                                                                             \
     } while (0)
 
+        fs_orbit_f32_bad cf = of[0];
+        uint32_t cf_at = 0; // orbit index cf was loaded from
         while (iter < n_iterations) {
-            const fs_orbit_f32_bad cf = of[RefIteration];
+            if (cf_at != RefIteration) {
+                cf = of[RefIteration];
+                cf_at = RefIteration;
+            }
             if (cf.bad == 0) {
                 // :78-94 binary32 step
                 const float ox = wX, oy = wY;
@@ -83,6 +94,8 @@ template <bool kStats> __global__ void __launch_bounds__(256) k_scaled_hdr32(FsS
                     c_float++;
                 ++RefIteration;
                 const fs_orbit_f32_bad nf = of[RefIteration];
+                cf = nf; // the entry of the next step (unless this step rebases: cf_at then no longer matches)
+                cf_at = RefIteration;
                 const float tempZX = nf.x + wX * s;
                 const float tempZY = nf.y + wY * s;
                 const float zn_size = tempZX * tempZX + tempZY * tempZY;
@@ -294,7 +307,7 @@ template <bool kStats> __global__ void __launch_bounds__(256) k_scaled_f64(FsSca
 void fsk_scaled_hdr32(const FsScaledArgs32 &A, bool stats, hipStream_t s)
 {
     const dim3 b(256);
-    const dim3 g((A.frame.width + 63) / 64, (A.frame.local_rows + 3) / 4);
+    const dim3 g((A.frame.width + 31) / 32, (A.frame.local_rows + 7) / 8); // tile_pixel(): four 8 x 8 tiles per workgroup
     if (stats)
         hipLaunchKernelGGL((k_scaled_hdr32<true>), g, b, 0, s, A);
     else

@@ -68,6 +68,11 @@ def step(state, ins, report=None):
     if op in ("s_endpgm", "s_setpc_b64", "s_swappc_b64"):
         return frozenset(), ()
     is_load, is_vm_other = op.startswith(VM_LOAD), op.startswith(VM_OTHER)
+    # LDS-DMA (global_load_lds_*, buffer_load_* ... lds): counted by vmcnt like a load, but its destination is LDS -- every
+    # register operand is an address that is read at issue, and no register is written when it lands
+    is_lds_dma = op.startswith("global_load_lds_") or (op.startswith("buffer_load_") and ops.rstrip().endswith(" lds"))
+    if is_lds_dma:
+        is_load, is_vm_other = False, True
     dst_text, _, src_text = ops.partition(",")
     # vector memory operations complete in order: a load may write a register an older load also writes; only its
     # address operands must have arrived
@@ -88,7 +93,7 @@ def step(state, ins, report=None):
     elif is_load:
         vector = vector + (frozenset((r, here) for r in regs_of(dst_text)),)
     elif is_vm_other:
-        returns = "_atomic_" in op and (" glc" in ops or " sc0" in ops)
+        returns = not is_lds_dma and "_atomic_" in op and (" glc" in ops or " sc0" in ops)
         vector = vector + (frozenset((r, here) for r in regs_of(dst_text)) if returns else frozenset(),)
     return scalar, vector
 
