@@ -248,3 +248,24 @@ void fsk_reduce(const void *iters, int iter_u64, uint32_t rounded_width, uint32_
                 fs_reduction *out, hipStream_t s);
 // multi-GPU tiler: out row y = in row index[y] (row_bytes a multiple of 16)
 void fsk_gather_rows(const void *in, void *out, const uint32_t *index, uint32_t row_bytes, uint32_t rows, hipStream_t s);
+
+// ---- LAv2 table construction on the device (kernels_la.hip; host orchestration: fs_build_la in renderer.cpp).
+// F = float | double.  Work arrays are raw device pointers (hreal<F> / LAInfo<F> of csrc/la_math.hpp).
+template <class F> void fsk_la_src_orbit(const void *zref, uint32_t n, void *chebv, hipStream_t s);
+template <class F> void fsk_la_src_stage(const void *P, uint32_t n, void *chebv, void *mm, uint32_t *steps, hipStream_t s);
+void fsk_scan_u32(const uint32_t *in, uint32_t *out, uint32_t n, hipStream_t s); // exclusive; out[n] = total
+template <class F> void fsk_la_first(bool stage0, const void *chebv, const void *mm, uint32_t limit, uint32_t *out, hipStream_t s);
+template <class F>
+void fsk_la_next(bool stage0, const void *chebv, const void *mm, const uint32_t *pos, uint32_t limit, uint32_t period,
+                 uint32_t *next, hipStream_t s);
+void fsk_la_reach(const uint32_t *jin, uint32_t *jout, uint32_t *reach, uint32_t nstates, hipStream_t s);
+template <class F>
+void fsk_la_records(bool stage0, const void *zref, const void *P, const uint32_t *pos, const uint32_t *next,
+                    const uint32_t *reach, const uint32_t *rank, uint32_t limit, uint32_t rank_offset, void *out, hipStream_t s);
+template <class F>
+void fsk_la_one_record(bool stage0, const void *zref, const void *P, uint32_t e, uint32_t step_length, void *out, hipStream_t s);
+template <class F> void fsk_la_tail(const void *zref, uint32_t max_ref, void *out, uint32_t *zcoeff_zero, hipStream_t s);
+template <class F>
+void fsk_la_at(const void *las, const uint32_t *stage_la_index, uint32_t stage_count, const void *radius,
+               int use_small_exponents, void *at_out, uint32_t *use_at, hipStream_t s);
+void fsk_la_pack(bool is64, const void *in, void *out, uint32_t n, hipStream_t s);

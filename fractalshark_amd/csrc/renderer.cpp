@@ -9,12 +9,14 @@
 
 #include <cmath>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <vector>
 
 #include "../../include/fsmi355.h"
 #include "kernels.h"
+#include "la_math.hpp"
 
 #define FS_TRY(expr)                                                                                                  \
     do {                                                                                                              \
@@ -939,6 +941,320 @@ uint32_t fs_build_bla(fs_renderer *r, int type_tag, const void *bla_size)
     FS_TRY(hipStreamSynchronize(r->compute)); // ptrs / epl are host temporaries of this call
     r->bla_n_levels = n_levels;
     r->bla_lm2 = lm2;
+    return 0;
+}
+
+} // extern "C" (the builder below is a template)
+
+// ---- LAv2 table built on the device (kernels_la.hip): the scalar decisions of LAReference.cpp on the host, everything
+// that touches the orbit or a record on the device.  See the header of kernels_la.hip for the algorithm.
+namespace {
+
+struct DevBuf { // hipFree on scope exit
+    void *p = nullptr;
+    ~DevBuf()
+    {
+        if (p)
+            (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    template <class T> T *as() const { return (T *)p; }
+};
+
+template <class F> void pack_at(const fs::la::ATInfoT<F> &a, fs_renderer *r);
+template <> void pack_at<float>(const fs::la::ATInfoT<float> &a, fs_renderer *r)
+{
+    auto R = [](fs::hreal<float> h) { return fs_real_hdr32{h.m, h.e}; };
+    auto C = [](fs::hcplx<float> c) { return fs_cplx_hdr32{c.re, c.im, c.e}; };
+    fs_at_hdr32_u32 &o = r->at;
+    memset(&o, 0, sizeof(o));
+    o.StepLength = a.StepLength;
+    o.ThresholdC = R(a.ThresholdC), o.SqrEscapeRadius = R(a.SqrEscapeRadius);
+    o.RefC = C(a.RefC), o.ZCoeff = C(a.ZCoeff), o.CCoeff = C(a.CCoeff), o.InvZCoeff = C(a.InvZCoeff);
+    o.CCoeffSqrInvZCoeff = C(a.CCoeffSqrInvZCoeff), o.CCoeffInvZCoeff = C(a.CCoeffInvZCoeff);
+    o.CCoeffNormSqr = R(a.CCoeffNormSqr), o.RefCNormSqr = R(a.RefCNormSqr), o.factor = R(a.factor);
+}
+template <> void pack_at<double>(const fs::la::ATInfoT<double> &a, fs_renderer *r)
+{
+    auto R = [](fs::hreal<double> h) { return fs_real_hdr64{h.m, h.e, 0}; };
+    auto C = [](fs::hcplx<double> c) { return fs_cplx_hdr64{c.re, c.im, c.e, 0}; };
+    fs_at_hdr64_u32 &o = r->at64;
+    memset(&o, 0, sizeof(o));
+    o.StepLength = a.StepLength;
+    o.ThresholdC = R(a.ThresholdC), o.SqrEscapeRadius = R(a.SqrEscapeRadius);
+    o.RefC = C(a.RefC), o.ZCoeff = C(a.ZCoeff), o.CCoeff = C(a.CCoeff), o.InvZCoeff = C(a.InvZCoeff);
+    o.CCoeffSqrInvZCoeff = C(a.CCoeffSqrInvZCoeff), o.CCoeffInvZCoeff = C(a.CCoeffInvZCoeff);
+    o.CCoeffNormSqr = R(a.CCoeffNormSqr), o.RefCNormSqr = R(a.RefCNormSqr), o.factor = R(a.factor);
+}
+
+constexpr uint32_t kLaLowBound = 64;    // LAReference.h:56
+constexpr uint32_t kLaMaxStages = 1024; // LAReference.h
+constexpr uint32_t kLaTerm = 0xFFFFFFFFu;
+
+template <class F> uint32_t build_la(fs_renderer *r, const void *max_radius, int use_small_exponents)
+{
+    using Rec = fs::la::LAInfo<F>;
+    using HR = fs::hreal<F>;
+    hipStream_t s = r->compute;
+    const void *zref = sizeof(F) == 4 ? (const void *)r->zref : (const void *)r->zref64;
+    const uint32_t maxRef = (uint32_t)r->orbit_uncompressed - 1u; // entries 0 .. maxRef
+    const int periodDivisor = r->orbit_size != r->orbit_uncompressed ? 8 : 2; // LAReference.cpp:12-19
+    if (r->orbit_uncompressed < 2 || maxRef <= kLaLowBound)
+        return FS_ERR_UNSUPPORTED; // degenerate tables (orbits of <= 64 entries) are left to the host builder
+    // capacity: a stage never holds more records than elements it was folded from (+ its tail record)
+    const size_t cap_states = 2u * ((size_t)maxRef + 2u);
+    DevBuf chebv, mm, steps, pos, nextA, nextB, reach, rank, table, small, stage_idx, atbuf;
+    FS_TRY(chebv.alloc(sizeof(HR) * (maxRef + 2u)));
+    FS_TRY(mm.alloc(sizeof(HR) * (maxRef + 2u)));
+    FS_TRY(steps.alloc(4u * (maxRef + 2u)));
+    FS_TRY(pos.alloc(4u * (maxRef + 3u)));
+    FS_TRY(nextA.alloc(4u * cap_states));
+    FS_TRY(nextB.alloc(4u * cap_states));
+    FS_TRY(nextA.p && nextB.p ? hipSuccess : hipErrorOutOfMemory);
+    FS_TRY(reach.alloc(4u * cap_states));
+    FS_TRY(rank.alloc(4u * (cap_states + 1u)));
+    // all stages: stage k+1 holds at most half of stage k (+2), so 2 * maxRef + slack bounds the sum
+    const size_t cap_recs = 2u * (size_t)maxRef + 64u * kLaLowBound;
+    FS_TRY(table.alloc(sizeof(Rec) * cap_recs));
+    FS_TRY(small.alloc(64));
+    FS_TRY(stage_idx.alloc(4u * kLaMaxStages));
+    FS_TRY(atbuf.alloc(sizeof(fs::la::ATInfoT<F>)));
+    uint32_t *d_small = small.as<uint32_t>();
+    Rec *d_table = table.as<Rec>();
+
+    std::vector<fs_la_stage_u32> stages;
+    uint32_t la_size = 0;
+    uint32_t h[4];
+
+    // isZCoeffZero of the first step (LAReference.cpp:52-56)
+    fsk_la_tail<F>(zref, maxRef, nullptr, d_small, s);
+    FS_TRY(hipMemcpyAsync(h, d_small, 4, hipMemcpyDeviceToHost, s));
+    FS_TRY(hipStreamSynchronize(s));
+    if (h[0])
+        return FS_ERR_UNSUPPORTED;
+
+    // one stage: elements 0 .. limit-1 (+ the sentinel element `limit`), period / first record decided by the caller
+    auto run_chain = [&](bool stage0, const Rec *P, uint32_t limit, uint32_t period, bool have_first, uint32_t first_end,
+                         uint32_t first_step, uint32_t x_start, uint32_t &n_records) -> uint32_t {
+        const uint32_t nstates = 2u * limit;
+        uint32_t offset = 0;
+        if (have_first) {
+            fsk_la_one_record<F>(stage0, zref, P, first_end, first_step, d_table + la_size, s);
+            offset = 1;
+        }
+        n_records = offset;
+        if (x_start != kLaTerm && (x_start >> 1) < limit) {
+            fsk_la_next<F>(stage0, chebv.p, mm.p, pos.as<uint32_t>(), limit, period, nextA.as<uint32_t>(), s);
+            FS_TRY(hipMemsetAsync(reach.p, 0, 4u * nstates, s));
+            const uint32_t one = 1;
+            FS_TRY(hipMemcpyAsync(reach.as<uint32_t>() + x_start, &one, 4, hipMemcpyHostToDevice, s));
+            // jump tables: nextB is the doubling scratch; the original next stays in nextA for the record kernel
+            DevBuf j0, j1;
+            FS_TRY(j0.alloc(4u * nstates));
+            FS_TRY(j1.alloc(4u * nstates));
+            FS_TRY(hipMemcpyAsync(j0.p, nextA.p, 4u * nstates, hipMemcpyDeviceToDevice, s));
+            uint32_t *jin = j0.as<uint32_t>(), *jout = j1.as<uint32_t>();
+            for (uint32_t span = 1; span < limit + 1u; span <<= 1) {
+                fsk_la_reach(jin, jout, reach.as<uint32_t>(), nstates, s);
+                std::swap(jin, jout);
+            }
+            fsk_scan_u32(reach.as<uint32_t>(), rank.as<uint32_t>(), nstates, s);
+            FS_TRY(hipMemcpyAsync(h, rank.as<uint32_t>() + nstates, 4, hipMemcpyDeviceToHost, s));
+            FS_TRY(hipStreamSynchronize(s)); // also keeps j0 / j1 alive until the rounds have run
+            if ((size_t)la_size + offset + h[0] + 2u > cap_recs)
+                return FS_ERR_7;
+            fsk_la_records<F>(stage0, zref, P, pos.as<uint32_t>(), nextA.as<uint32_t>(), reach.as<uint32_t>(),
+                              rank.as<uint32_t>(), limit, offset, d_table + la_size, s);
+            FS_TRY(hipStreamSynchronize(s));
+            n_records = offset + h[0];
+        }
+        return (uint32_t)hipGetLastError();
+    };
+
+    // ---------------- stage 0: CreateLAFromOrbit, LAReference.cpp:28-210
+    {
+        const uint32_t limit = maxRef;
+        fsk_la_src_orbit<F>(zref, maxRef + 1u, chebv.p, s);
+        fsk_la_first<F>(true, chebv.p, mm.p, limit, d_small, s);
+        FS_TRY(hipMemcpyAsync(h, d_small, 8, hipMemcpyDeviceToHost, s));
+        FS_TRY(hipStreamSynchronize(s));
+        uint32_t Period = h[0] == kLaTerm ? 0u : h[0];
+        bool have_first = false;
+        uint32_t x_start;
+        const double NthRoot = std::round(std::log2((double)maxRef) / periodDivisor);
+        if (Period == 0 || Period > kLaLowBound) {
+            Period = (uint32_t)std::round(std::pow((double)maxRef, 1.0 / NthRoot)); // :128-134 / :141-147
+            x_start = 1u;                                                            // (0, flavour 1)
+        } else {
+            have_first = true; // the record that ended at the first detection stays (:97-101)
+            const uint32_t i = Period;
+            x_start = i + 1u < maxRef ? 2u * i + 1u : 2u * i; // :105-111: step z[i+1] at once unless that is the end
+        }
+        stages.push_back(fs_la_stage_u32{0u, 0u});
+        uint32_t n = 0;
+        if (uint32_t e = run_chain(true, nullptr, limit, Period, have_first, have_first ? Period : 0u,
+                                   have_first ? Period : 0u, x_start, n))
+            return e;
+        stages[0].MacroItCount = n;
+        la_size = n;
+        fsk_la_tail<F>(zref, maxRef, d_table + la_size, nullptr, s);
+        la_size++;
+    }
+
+    // ---------------- higher stages: CreateNewLAStage, LAReference.cpp:774-966
+    for (;;) {
+        const uint32_t PrevStage = (uint32_t)stages.size() - 1u, CurrentStage = (uint32_t)stages.size();
+        if (CurrentStage >= kLaMaxStages)
+            break;
+        const uint32_t PrevIdx = stages[PrevStage].LAIndex, Count = stages[PrevStage].MacroItCount;
+        const Rec *P = d_table + PrevIdx;
+        fsk_la_src_stage<F>(P, Count + 1u, chebv.p, mm.p, steps.as<uint32_t>(), s);
+        fsk_scan_u32(steps.as<uint32_t>(), pos.as<uint32_t>(), Count + 1u, s);
+        fsk_la_first<F>(false, chebv.p, mm.p, Count, d_small, s);
+        FS_TRY(hipMemcpyAsync(h, d_small, 8, hipMemcpyDeviceToHost, s));
+        FS_TRY(hipStreamSynchronize(s));
+        uint32_t jd = h[0], fd = h[1];
+        uint32_t step0 = 0, posjd = 0;
+        FS_TRY(hipMemcpy(&step0, steps.as<uint32_t>(), 4, hipMemcpyDeviceToHost));
+        uint32_t Period = 0;
+        if (jd != kLaTerm) {
+            Rec pj;
+            FS_TRY(hipMemcpy(&pj, P + jd, sizeof(Rec), hipMemcpyDeviceToHost));
+            if (pj.LAThreshold.m == F(0)) { // isLAThresholdZero: the prologue breaks without a period (:815-817)
+                jd = kLaTerm;
+            } else {
+                FS_TRY(hipMemcpy(&posjd, pos.as<uint32_t>() + jd, 4, hipMemcpyDeviceToHost));
+                Period = posjd;
+            }
+        }
+        stages.push_back(fs_la_stage_u32{la_size, 0u});
+        const double NthRoot = std::round(std::log2((double)maxRef) / periodDivisor);
+        bool have_first = false, last_stage = false;
+        uint32_t x_start = 1u, first_end = 0, first_step = 0;
+        if (Period == 0) {
+            if ((uint64_t)maxRef > (uint64_t)step0 * kLaLowBound) {
+                const double Ratio = ((double)maxRef) / step0;
+                Period = step0 * (uint32_t)std::round(std::pow(Ratio, 1.0 / NthRoot)); // :861-869
+            } else {
+                // :870-881: one record over the whole previous stage, and this is the last stage
+                last_stage = true;
+                have_first = true;
+                first_end = Count;
+                first_step = maxRef;
+                x_start = kLaTerm;
+            }
+        } else if ((uint64_t)Period > (uint64_t)step0 * kLaLowBound) {
+            const double Ratio = ((double)Period) / step0;
+            Period = step0 * ((uint32_t)std::round(std::pow(Ratio, 1.0 / NthRoot))); // :882-893
+        } else {
+            have_first = true;
+            first_end = jd;
+            first_step = Period;
+            x_start = 2u * jd + fd;
+        }
+        uint32_t n = 0;
+        if (uint32_t e = run_chain(false, P, Count, Period, have_first, first_end, first_step, x_start, n))
+            return e;
+        stages[CurrentStage].MacroItCount = last_stage ? 1u : n;
+        la_size += n;
+        fsk_la_tail<F>(zref, maxRef, d_table + la_size, nullptr, s);
+        la_size++;
+        if (last_stage)
+            break;
+    }
+
+    // ---------------- CreateATFromLA + install
+    const uint32_t stage_count = (uint32_t)stages.size();
+    std::vector<uint32_t> idx(stage_count);
+    for (uint32_t k = 0; k < stage_count; k++)
+        idx[k] = stages[k].LAIndex;
+    FS_TRY(hipMemcpyAsync(stage_idx.p, idx.data(), 4u * stage_count, hipMemcpyHostToDevice, s));
+    fsk_la_at<F>(d_table, stage_idx.as<uint32_t>(), stage_count, max_radius, use_small_exponents, atbuf.p, d_small, s);
+    fs::la::ATInfoT<F> at;
+    FS_TRY(hipMemcpyAsync(&at, atbuf.p, sizeof(at), hipMemcpyDeviceToHost, s));
+    FS_TRY(hipMemcpyAsync(h, d_small, 4, hipMemcpyDeviceToHost, s));
+    FS_TRY(hipStreamSynchronize(s));
+
+    if (r->las) {
+        FS_TRY(hipFree(r->las));
+        r->las = nullptr;
+    }
+    if (r->stages) {
+        FS_TRY(hipFree(r->stages));
+        r->stages = nullptr;
+    }
+    r->la_ok = false;
+    const size_t rec_bytes = sizeof(F) == 4 ? sizeof(fs_la_hdr32_u32) : sizeof(fs_la_hdr64_u32);
+    FS_TRY(hipMalloc(&r->las, rec_bytes * la_size));
+    fsk_la_pack(sizeof(F) == 8, d_table, r->las, la_size, s);
+    FS_TRY(hipMalloc((void **)&r->stages, sizeof(fs_la_stage_u32) * stage_count));
+    FS_TRY(hipMemcpyAsync(r->stages, stages.data(), sizeof(fs_la_stage_u32) * stage_count, hipMemcpyHostToDevice, s));
+    FS_TRY(hipStreamSynchronize(s));
+    FS_TRY(hipGetLastError());
+    r->n_las = la_size;
+    r->n_stages = stage_count;
+    r->la_valid = 1;
+    r->use_at = h[0] ? 1 : 0;
+    memset(&r->at, 0, sizeof(r->at));
+    memset(&r->at64, 0, sizeof(r->at64));
+    pack_at<F>(at, r);
+    r->la_type = sizeof(F) == 4 ? FS_T_HDR32 : FS_T_HDR64;
+    r->la_gen = 0;
+    r->la_ok = true;
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+uint32_t fs_build_la(fs_renderer *r, int type_tag, const void *max_radius, int use_small_exponents)
+{
+    if (uint32_t e = use_device(r))
+        return e;
+    if (type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64)
+        return FS_ERR_UNSUPPORTED;
+    if (!r->compute || !r->orbit_ok || r->orbit_type != type_tag || !max_radius)
+        return FS_ERR_6;
+    TimedLaunch t(r);
+    return type_tag == FS_T_HDR32 ? build_la<float>(r, max_radius, use_small_exponents)
+                                  : build_la<double>(r, max_radius, use_small_exponents);
+}
+
+uint32_t fs_la_counts(const fs_renderer *r, uint32_t *n_las, uint32_t *n_stages, int *use_at, int *is_valid)
+{
+    if (!r->la_ok)
+        return FS_ERR_6;
+    if (n_las)
+        *n_las = r->n_las;
+    if (n_stages)
+        *n_stages = r->n_stages;
+    if (use_at)
+        *use_at = r->use_at;
+    if (is_valid)
+        *is_valid = r->la_valid;
+    return 0;
+}
+
+uint32_t fs_read_la(fs_renderer *r, void *las_out, uint32_t max_las, void *stages_out, uint32_t max_stages, void *at_out)
+{
+    if (uint32_t e = use_device(r))
+        return e;
+    if (!r->la_ok || (r->la_type != FS_T_HDR32 && r->la_type != FS_T_HDR64))
+        return FS_ERR_6;
+    const size_t rec_bytes = r->la_type == FS_T_HDR32 ? sizeof(fs_la_hdr32_u32) : sizeof(fs_la_hdr64_u32);
+    const uint32_t nl = r->n_las < max_las ? r->n_las : max_las, ns = r->n_stages < max_stages ? r->n_stages : max_stages;
+    if (las_out && nl)
+        FS_TRY(hipMemcpyAsync(las_out, r->las, rec_bytes * nl, hipMemcpyDeviceToHost, r->compute));
+    if (stages_out && ns)
+        FS_TRY(hipMemcpyAsync(stages_out, r->stages, sizeof(fs_la_stage_u32) * ns, hipMemcpyDeviceToHost, r->compute));
+    FS_TRY(hipStreamSynchronize(r->compute));
+    if (at_out) {
+        if (r->la_type == FS_T_HDR32)
+            memcpy(at_out, &r->at, sizeof(r->at));
+        else
+            memcpy(at_out, &r->at64, sizeof(r->at64));
+    }
     return 0;
 }
 

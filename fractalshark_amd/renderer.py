@@ -210,6 +210,29 @@ class GPURenderer:
         mr = orbit.max_radius()
         return self._lib.fs_build_bla(self._h, T, mr.ctypes.data)
 
+    def BuildLAOnDevice(self, orbit, use_small_exponents=False, T=None):
+        """LAReference::GenerateApproximationData on the device for the orbit last uploaded (fs_build_la): all stages and
+        the ATInfo stay in HBM, installed as the renderer's table."""
+        if T is None:
+            T = T_HDR64 if orbit.is64 else T_HDR32
+        mr = orbit.max_radius()
+        return self._lib.fs_build_la(self._h, T, mr.ctypes.data, 1 if use_small_exponents else 0)
+
+    def read_la(self, is64=False):
+        """Device-resident LA table -> (records uint8[n, 68|128], stages uint32[k, 2], at bytes, use_at, is_valid)."""
+        n, k, ua, iv = C.c_uint32(0), C.c_uint32(0), C.c_int(0), C.c_int(0)
+        err = self._lib.fs_la_counts(self._h, C.byref(n), C.byref(k), C.byref(ua), C.byref(iv))
+        if err:
+            raise RuntimeError(self.ConvertErrorToString(err))
+        rec = 128 if is64 else 68
+        las = np.zeros((n.value, rec), np.uint8)
+        stages = np.zeros((k.value, 2), np.uint32)
+        at = _capi.AtHdr64() if is64 else _capi.AtHdr32()
+        err = self._lib.fs_read_la(self._h, las.ctypes.data, n.value, stages.ctypes.data, k.value, C.addressof(at))
+        if err:
+            raise RuntimeError(self.ConvertErrorToString(err))
+        return las, stages, bytes(at), bool(ua.value), bool(iv.value)
+
     def read_bla_levels(self, is64=False):
         """Device-resident BLA table -> list of (n, 44|88) uint8 arrays per level (tests / tools)."""
         rec = 88 if is64 else 44

@@ -147,6 +147,19 @@ int32_t fs_bla_lm2(const fs_renderer *r);
 uint64_t fs_bla_level_size(const fs_renderer *r, int32_t level);
 uint32_t fs_read_bla_level(fs_renderer *r, int32_t level, void *out, uint64_t max_records);
 
+/* LAReference::GenerateApproximationData (FractalSharkLib/LAReference.cpp:971-1013: CreateLAFromOrbit :28-210,
+ * CreateNewLAStage :774-966, CreateATFromLA :1050-1074) executed on the DEVICE instead of the host: builds the LAv2 table
+ * (all stages + ATInfo) of the orbit last uploaded with fs_upload_orbit / fs_upload_orbit_compressed (type_tag FS_T_HDR32 /
+ * FS_T_HDR64) directly in HBM and installs it as the renderer's table, as fs_upload_la would.  max_radius =
+ * PerturbationResults::GetMaxRadius (fs_real_hdr32 / fs_real_hdr64); use_small_exponents = the UseSmallExponents flag of
+ * CreateATFromLA (RefOrbitCalc.cpp:2346).  The table is bit-identical to the reference's SINGLE-THREADED builder (what
+ * LAReference produces when hardware_concurrency() < 2 * 50000-entry chunks, :236-251; the multi-threaded stage-0 variant
+ * yields a thread-count-dependent table, which stays with the host).  Orbits of <= 64 entries: FS_ERR_UNSUPPORTED (use
+ * fs_upload_la).  Synchronous.  fs_la_counts / fs_read_la read the installed table back (tests, tools). */
+uint32_t fs_build_la(fs_renderer *r, int type_tag, const void *max_radius, int use_small_exponents);
+uint32_t fs_la_counts(const fs_renderer *r, uint32_t *n_las, uint32_t *n_stages, int *use_at, int *is_valid);
+uint32_t fs_read_la(fs_renderer *r, void *las_out, uint32_t max_las, void *stages_out, uint32_t max_stages, void *at_out);
+
 /* GPURenderer::RenderPerturbLAv2<IterType,T,SubType,Mode,PExtras> (GPU_Render.cu:995-1188) for all six numeric types of
  * its instantiation list (:1204-1300): FS_T_HDR32 / FS_T_HDR64 / FS_T_HDR2X32 (GpuHDRx32 / x64 / x2x32 PerturbedLAv2*)
  * and the non-HDR FS_T_F32 / FS_T_F64 / FS_T_2X32 (Gpu1x32 / Gpu1x64 / Gpu2x32 PerturbedLAv2*; orbit, table and ATInfo

@@ -539,6 +539,64 @@ def test_scaled_hdr32_view14_deep_zoom(renderer, native_libs, w, h, aa):
                                                                          rst["float_steps"])
 
 
+# ---- LA table built on the device (fs_build_la) == the golden-pinned host builder in its
+# single-threaded form (LAReference.cpp:28-210,774-966,1050-1074), bit for bit: every record of every stage, the stage
+# table, ATInfo and the UseAT decision -- and the frame rendered from the device-built table equals the fixture
+@pytest.mark.parametrize("view_n,is64,small", [(5, False, False), (5, True, False), (1, False, False), (3, True, False),
+                                                (3, False, False), (4, False, False), (9, False, False), (9, True, False),
+                                                (11, True, False), (11, False, False), (14, True, True),
+                                                (14, False, False), (19, False, False), (19, True, False),
+                                                (6, False, False)])
+def test_la_table_built_on_device_equals_host_builder(renderer, native_libs, view_n, is64, small):
+    import ctypes as C
+    v = inputs.View.builtin(view_n, 64, 36, antialiasing=1)
+    ob = inputs.Orbit(v, is64=is64)
+    la = inputs.LATable(ob, host_threads=1, use_small_exponents=small)
+    r = renderer
+    T = T_HDR64 if is64 else T_HDR32
+    assert r.InitializeMemory(64, 36, 1, None, 0, 0, 0, False) == 0
+    assert r._lib.fs_upload_orbit(r._h, 0, T, 4, ob.data_ptr, ob.count, ob.count, ob.period) == 0
+    assert r.BuildLAOnDevice(ob, use_small_exponents=small) == 0
+    las, stages, at, use_at, is_valid = r.read_la(is64)
+    assert is_valid and la.is_valid
+    assert stages.shape[0] == la.stage_count and np.array_equal(stages, la.stages())
+    assert las.shape[0] == la.count
+    host = la.records()
+    host = host.view(np.uint8).reshape(la.count, -1)
+    bad = np.nonzero((las != host).any(axis=1))[0]
+    assert len(bad) == 0, "first differing record %d of %d" % (int(bad[0]), la.count)
+    assert use_at == la.use_at
+    assert at == bytes((C.c_char * C.sizeof(la.at)).from_address(C.addressof(la.at)))
+
+
+def test_la_build_on_device_leaves_tiny_orbits_to_the_host(renderer, native_libs):
+    """View 2's orbit has 59 entries (<= LowBound 64): the degenerate one-record table is not built on the device."""
+    v = inputs.View.builtin(2, 64, 36, antialiasing=1)
+    ob = inputs.Orbit(v)
+    assert ob.count <= 64
+    r = renderer
+    assert r.InitializeMemory(64, 36, 1, None, 0, 0, 0, False) == 0
+    assert r._lib.fs_upload_orbit(r._h, 0, T_HDR32, 4, ob.data_ptr, ob.count, ob.count, ob.period) == 0
+    assert r.BuildLAOnDevice(ob) == 10100
+
+
+def test_frame_from_device_built_la_table(renderer, v5_small):
+    """View 5 64x36 rendered from the device-built table == the golden fixture (host table, golden-pinned oracle)."""
+    v, ob, la, _ = v5_small
+    r = renderer
+    assert r.InitializeMemory(64, 36, 1, None, 0, 0, 0, False) == 0
+    assert r._lib.fs_upload_orbit(r._h, 0, T_HDR32, 4, ob.data_ptr, ob.count, ob.count, ob.period) == 0
+    assert r.BuildLAOnDevice(ob) == 0
+    dx, dy, cx, cy = _pairs(v.coords_perturb(ob))
+    for parity, key in ((PARITY_CPU, "view5_lav2_cpu_64x36"), (PARITY_CPU_GPUSTAGE, "view5_lav2_gpustage_64x36")):
+        assert r.ClearMemory() == 0
+        assert r.RenderPerturbLAv2(None, None, None, dx, dy, cx, cy, v.num_iterations, Mode=LAV2_FULL, parity=parity) == 0
+        out = r.new_iter_buffer()
+        assert r.RenderCurrent(v.num_iterations, out) == 0
+        assert r.SyncComputeStream() == 0
+        assert np.array_equal(out, GOLD[key])
+
+
 # ---- SURVEY 8(f) row 2: BLA table built on the device (BLAS::Init) == the golden-pinned host builder, bit for bit
 @pytest.mark.parametrize("view_n,is64", [(5, False), (19, False), (5, True)])
 def test_bla_table_built_on_device_equals_host_builder(renderer, native_libs, view_n, is64):
