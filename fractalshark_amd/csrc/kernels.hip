@@ -412,7 +412,10 @@ __device__ __forceinline__ uint32_t scaled_run_length(uint32_t left)
 // address; counted by lgkmcnt).  Two counters, in-order returns: a true software pipeline, which the scalar loads (one
 // out-of-order counter) cannot be.  What it costs: the entries live in VGPRs (8 x 4 per body) and every ds_read writes
 // 1 KiB of registers.  Measured against the scalar-cache path in DESIGN.md section 5.
-template <int Mode, bool kStats, bool kScaled, bool kLds = false>
+// kGpuStage: the LA stage-validity test in the direction of the reference's GPU twin (FS_PARITY_CPU_GPUSTAGE) instead of
+// the CPU function's (FS_PARITY_CPU) -- a template parameter so that the two parity modes are two kernels (they do very
+// different work per frame, and a kernel trace then lists them separately).
+template <int Mode, bool kStats, bool kScaled, bool kLds = false, bool kGpuStage = false>
 __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
 {
     __shared__ float4 s_zs_lds[kLds ? 4 * 2 * 64 : 1];
@@ -467,7 +470,7 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                 const uint32_t LAIndex = A.stages[CurrentLAStage].LAIndex;
                 {
                     const int cmp = hr_cmp_pos(dcCheb, ldr(A.las[LAIndex].LAThresholdC));
-                    const bool invalid = A.parity == FS_PARITY_LITERAL ? (cmp < 0) : (cmp >= 0);
+                    const bool invalid = kGpuStage ? (cmp >= 0) : (cmp < 0);
                     if (invalid)
                         continue;
                 }
@@ -1219,6 +1222,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
     hreal<F> DeltaNormSquared = hr_zero<F>();
     hcplx<F> Zcached = hc_zero<F>();
     uint32_t Zcached_at = 0xFFFFFFFFu;
+    bool force_step = false; // (action loop) the BLA loop of the reference was left by its escape test: step next, no lookup
     // frame-wide pixel queue (kRefill)
     const uint32_t tiles_x = (A.frame.width + 7u) >> 3;
     const uint32_t total = tiles_x * ((A.frame.local_rows + 7u) >> 3) * 64u;
@@ -1237,6 +1241,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
             DeltaNormSquared = hr_zero<F>();
             Zcached = hc_zero<F>();
             Zcached_at = 0xFFFFFFFFu;
+            force_step = false;
         }
     };
     if constexpr (!kRefill) {
@@ -1281,7 +1286,186 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                 }
                 budget--;
             }
-            if (kBla) {
+            // ---- kBla, float: the ACTION loop.  The reference's "while (a table entry applies) jump; then one
+            // perturbation step" is, per pixel, a sequence of actions -- JUMP (BLA::getValue) or STEP -- that both end
+            // in the same tail: z = Z[next] + dz', the two norms, the escape test, the rebase test.  Lanes of a wave are
+            // rarely due for the same action, so each trip of this loop lets EVERY lane take ONE action: a short
+            // divergent part that only forms the new dz (four aligned products for a jump, dz (2Z + dz) + dc for a
+            // step, both in the alignment-free form described at the tuned single step below), then the shared
+            // tail at full width.  (The first version ran a per-lane `while` of jumps followed by a wave-voted step:
+            // lanes waited for each other's jump chains, 38 % of the vector lane-cycles did work.)  The order of
+            // actions of every pixel is the reference's: a jump whose escape test fires leaves the reference's inner
+            // loop, so that pixel's next action is a STEP without a lookup (force_step).
+            bool act_literal_step = false;
+            // Measured on C5: with one 8 x 8 tile per wave the lanes' actions are correlated and the
+            // reference-shaped loop below (a per-lane chain of jumps, then a wave-voted step) is the faster one
+            // (263 vs 302 ms); with lanes re-packed from the pixel queue (kRefill) actions are uncorrelated and this
+            // loop is (333 vs 505 ms).  So the action loop is the persistent launch's loop.
+            if constexpr (kBla && kRefill && std::is_same<F, float>::value) {
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                auto p2 = [](int n) { return n > -kExpDiffIgnored ? __int_as_float((n << 23) + 0x3F800000) : 0.0f; };
+                const typename FsDev<F>::BLA *b =
+                    force_step ? nullptr : bla_lookup<F>(s_levels, A.lm2, RefIteration, DeltaNormSquared);
+                force_step = false;
+                uint32_t l = 0;
+                if (b != nullptr) {
+                    l = (uint32_t)b->l;
+                    if (RefIteration + l >= count || iter + l >= n_iterations)
+                        b = nullptr; // the reference leaves its jump loop here and takes a step
+                }
+                const bool jump = b != nullptr;
+                const uint32_t nref = RefIteration + (jump ? l : 1u);
+                // Both actions are  dz' = A dz + B dc  with complex A, B given as four extended-exponent reals:
+                //   JUMP: (Ax, Ay, Bx, By) = the table record (BLA::getValue, BLA.cuh:21-38);
+                //   STEP: A = 2Z + dz (formed here under one exponent, as at the tuned single step), B = 1 -- the
+                //         reference's (B1 - B2) + dcX and (C1 + C2) + dcY are the first three of the four terms below, in
+                //         the same order, and the fourth is an exact zero.
+                // So only the few instructions that produce (A, B) diverge; the four aligned products, the sums and the
+                // tail run at full width for every lane.
+                hreal<F> Ax, Ay, Bx, By;
+                bool ok = true;
+                if (jump) {
+                    Ax = ldr(b->Ax), Ay = ldr(b->Ay), Bx = ldr(b->Bx), By = ldr(b->By);
+                } else {
+                    const hcplx<F> Z = (Zcached_at == RefIteration) ? Zcached : zref_at(zr, RefIteration);
+                    const int Ze1 = Z.e + 1;
+                    const int eT = imax(imax(Ze1, DeltaSubNX.e), DeltaSubNY.e);
+                    const float zsT = p2(Ze1 - eT);
+                    const f2 T = (f2){Z.re, Z.im} * (f2){zsT, zsT} +
+                                 (f2){DeltaSubNX.m, DeltaSubNY.m} * (f2){p2(DeltaSubNX.e - eT), p2(DeltaSubNY.e - eT)};
+                    Ax = hreal<F>{T.x, eT};
+                    Ay = hreal<F>{T.y, eT};
+                    Bx = hreal<F>{1.0f, 0};
+                    By = hreal<F>{0.0f, -(1 << 25)}; // an exact zero that never sets the common exponent
+                    const float tmx_ = fmaxf(fabsf(T.x), fabsf(T.y)), tmn_ = fminf(fabsf(T.x), fabsf(T.y));
+                    ok = tmn_ >= 0x1p-60f && tmx_ <= 0x1p60f && nref < count;
+                }
+                f2 cm;        // new dz, mantissas
+                int cex, cey; // ... and exponents (per part)
+                {
+                    const f2 D = {DeltaSubNX.m, DeltaSubNY.m}, D0 = {DeltaSub0X.m, DeltaSub0Y.m};
+                    // nx = ((Ax DX - Ay DY) + Bx D0X) - By D0Y;  ny = ((Ax DY + Ay DX) + Bx D0Y) + By D0X
+                    const f2 pA = (f2){Ax.m, Ax.m} * D, pB = (f2){Ay.m, Ay.m} * D.yx;
+                    const f2 pC = (f2){Bx.m, Bx.m} * D0, pD = (f2){By.m, By.m} * D0.yx;
+                    const int eAx = Ax.e + DeltaSubNX.e, eAy = Ax.e + DeltaSubNY.e;
+                    const int eBx = Ay.e + DeltaSubNY.e, eBy = Ay.e + DeltaSubNX.e;
+                    const int eCx = Bx.e + DeltaSub0X.e, eCy = Bx.e + DeltaSub0Y.e;
+                    const int eDx = By.e + DeltaSub0Y.e, eDy = By.e + DeltaSub0X.e;
+                    cex = imax(imax(eAx, eBx), imax(eCx, eDx)), cey = imax(imax(eAy, eBy), imax(eCy, eDy));
+                    const f2 tA = pA * (f2){p2(eAx - cex), p2(eAy - cey)}, tB = pB * (f2){p2(eBx - cex), p2(eBy - cey)};
+                    const f2 tC = pC * (f2){p2(eCx - cex), p2(eCy - cey)}, tD = pD * (f2){p2(eDx - cex), p2(eDy - cey)};
+                    f2 s1;
+                    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(s1) : "v"(tA), "v"(tB));
+                    const f2 s2 = s1 + tC;
+                    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(cm) : "v"(s2), "v"(tD));
+                    const float zmn = fminf(fminf(fabsf(s1.x), fabsf(s1.y)), fminf(fabsf(s2.x), fabsf(s2.y)));
+                    const int emin = imin(imin(imin(DeltaSubNX.e, DeltaSubNY.e), imin(DeltaSub0X.e, DeltaSub0Y.e)),
+                                          imin(imin(Ax.e, Ay.e), imin(Bx.e, By.e)));
+                    ok = ok && zmn > 0.0f && emin > -(1 << 26);
+                    if (!jump) { // a step ends with Reduce of both parts (Fractal.cpp:2353,2360); a jump does not
+                        const int qxb = __float_as_int(cm.x), qyb = __float_as_int(cm.y);
+                        ok = ok && fminf(fabsf(cm.x), fabsf(cm.y)) >= 0x1p-60f && fmaxf(fabsf(cm.x), fabsf(cm.y)) <= 0x1p60f;
+                        cm = (f2){__int_as_float((qxb & 0x807FFFFF) | 0x3F800000), __int_as_float((qyb & 0x807FFFFF) | 0x3F800000)};
+                        cex += (int)__builtin_amdgcn_ubfe(qxb, 23, 8) - 127;
+                        cey += (int)__builtin_amdgcn_ubfe(qyb, 23, 8) - 127;
+                    }
+                }
+                // ---- shared tail: z = Z[nref] + dz' under ez, |z|^2, |dz'|^2
+                const auto zn4 = zr[nref]; // in bounds: nref <= count (two spare entries)
+                const int Zne = __float_as_int(zn4.z);
+                const int ez = imax(imax(Zne, cex), cey);
+                const float zsZ = p2(Zne - ez);
+                const f2 Zt = (f2){zn4.x, zn4.y} * (f2){zsZ, zsZ} + cm * (f2){p2(cex - ez), p2(cey - ez)};
+                const f2 ZZ = Zt * Zt;
+                const float nm = ZZ.x + ZZ.y; // exponent 2 ez
+                const f2 SQ = cm * cm;
+                const int dd = (cex - cey) << 1;
+                const bool sxbig = dd >= 0;
+                const float md = p2(sxbig ? -dd : dd);
+                const float dnm = SQ.x * (sxbig ? 1.0f : md) + SQ.y * (sxbig ? md : 1.0f);
+                const int dne = (sxbig ? cex : cey) << 1;
+                const float tmx = fmaxf(fmaxf(fabsf(cm.x), fabsf(cm.y)), fmaxf(fabsf(Zt.x), fabsf(Zt.y)));
+                const float tmn = fminf(fminf(fabsf(cm.x), fabsf(cm.y)), fminf(fabsf(Zt.x), fabsf(Zt.y)));
+                ok = ok && tmn >= 0x1p-60f && tmx <= 0x1p60f && Zne > -(1 << 26);
+                if (ok) {
+                    if (jump) {
+                        iter += l;
+                        if (kStats) {
+                            c_la++;
+                            if (l >= 1024u)
+                                atomicAdd((unsigned long long *)&A.stats[6], 1ull);
+                            if (l >= 256u)
+                                atomicAdd((unsigned long long *)&A.stats[7], 1ull);
+                        }
+                    } else if (kStats) {
+                        c_pt++;
+                    }
+                    RefIteration = nref;
+                    Zcached = hcplx<F>{zn4.x, zn4.y, Zne};
+                    Zcached_at = nref;
+                    DeltaSubNX = hreal<F>{cm.x, cex};
+                    DeltaSubNY = hreal<F>{cm.y, cey};
+                    {
+                        const int db = __float_as_int(dnm);
+                        DeltaNormSquared = hreal<F>{__int_as_float((db & 0x007FFFFF) | 0x3F800000),
+                                                    dne + (int)__builtin_amdgcn_ubfe(db, 23, 8) - 127};
+                    }
+                    if (__builtin_amdgcn_ldexpf(nm, imax((ez << 1) - 8, -400)) > 1.0f) {
+                        if (jump) {
+                            force_step = true; // the reference leaves its jump loop; the pixel's next action is a step
+                            continue;
+                        }
+                        break; // a step escaped: the pixel is done (no ++iter, like the reference)
+                    }
+                    if (nm < __builtin_amdgcn_ldexpf(dnm, imax(dne - (ez << 1), -400)) || RefIteration >= count - 1) {
+                        const int ex = imax(Zne, cex), ey = imax(Zne, cey);
+                        DeltaSubNX = hreal<F>{__builtin_amdgcn_ldexpf(Zt.x, ez - ex), ex};
+                        DeltaSubNY = hreal<F>{__builtin_amdgcn_ldexpf(Zt.y, ez - ey), ey};
+                        const int nb = __float_as_int(nm);
+                        DeltaNormSquared = hreal<F>{__int_as_float((nb & 0x007FFFFF) | 0x3F800000),
+                                                    (ez << 1) + (int)__builtin_amdgcn_ubfe(nb, 23, 8) - 127};
+                        RefIteration = 0;
+                    }
+                    if (!jump)
+                        ++iter;
+                    continue;
+                }
+                // ---- a sum left [2^-60, 2^60] or hit an exact zero: this lane's action in the literal order
+                if (jump) {
+                    iter += l;
+                    if (kStats)
+                        c_la++;
+                    const hcplx<F> Z = zref_at(zr, nref);
+                    {
+                        const hreal<F> nx = hr_sub(
+                            hr_add(hr_sub(hr_mul(Ax, DeltaSubNX), hr_mul(Ay, DeltaSubNY)), hr_mul(Bx, DeltaSub0X)),
+                            hr_mul(By, DeltaSub0Y));
+                        const hreal<F> ny = hr_add(
+                            hr_add(hr_add(hr_mul(Ax, DeltaSubNY), hr_mul(Ay, DeltaSubNX)), hr_mul(Bx, DeltaSub0Y)),
+                            hr_mul(By, DeltaSub0X));
+                        DeltaSubNX = nx;
+                        DeltaSubNY = ny;
+                    }
+                    RefIteration = nref;
+                    const hreal<F> tempZX = hr_add(hc_re(Z), DeltaSubNX);
+                    const hreal<F> tempZY = hr_add(hc_im(Z), DeltaSubNY);
+                    const hreal<F> normSquared = hr_reduced(hr_add(hr_mul(tempZX, tempZX), hr_mul(tempZY, tempZY)));
+                    DeltaNormSquared = hr_reduced(hr_add(hr_mul(DeltaSubNX, DeltaSubNX), hr_mul(DeltaSubNY, DeltaSubNY)));
+                    if (hr_cmp_pos(normSquared, TwoFiftySix) > 0) {
+                        force_step = true;
+                        continue;
+                    }
+                    if (hr_cmp_pos(normSquared, DeltaNormSquared) < 0 || RefIteration >= count - 1) {
+                        DeltaSubNX = tempZX;
+                        DeltaSubNY = tempZY;
+                        DeltaNormSquared = normSquared;
+                        RefIteration = 0;
+                    }
+                    continue;
+                }
+                act_literal_step = true; // falls through to the literal step at the bottom of the loop
+            }
+            if (kBla && !(kRefill && std::is_same<F, float>::value)) {
                 const typename FsDev<F>::BLA *b;
                 while ((b = bla_lookup<F>(s_levels, A.lm2, RefIteration, DeltaNormSquared)) != nullptr) {
                     const uint32_t l = (uint32_t)b->l;
@@ -1742,7 +1926,8 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
             // order.  With lanes re-packed from the pixel queue a wave nearly always holds a lane that is rebasing,
             // which is why the step must not care.
             bool done_fast = false;
-            if constexpr (std::is_same<F, float>::value) {
+            (void)act_literal_step;
+            if constexpr (std::is_same<F, float>::value && !(kBla && kRefill)) {
                 typedef float f2 __attribute__((ext_vector_type(2)));
                 const auto zn4 = zr[RefIteration + 1]; // in bounds: the prepared orbit has two spare entries
                 const int Ze1 = Z.e + 1;
@@ -2207,6 +2392,18 @@ void fsk_lav2_hdr32(const FsLav2Args32 &A, int mode, bool stats, int variant, hi
     // A/B switch: FSMI355_LDS_ORBIT=1 routes the wave-uniform scaled runs' orbit entries through LDS (see the kernel)
     static const bool lds_orbit = getenv("FSMI355_LDS_ORBIT") != nullptr && atoi(getenv("FSMI355_LDS_ORBIT")) != 0;
     const dim3 b(bs), g((A.frame.width + bs / 8 - 1) / (bs / 8), (A.frame.local_rows + 7) / 8, 1);
+#define FS_LAUNCH_FAST(M, SC, LDS)                                                                                  \
+    if (stats) {                                                                                                    \
+        if (gs)                                                                                                     \
+            hipLaunchKernelGGL((k_lav2_hdr32_fast<M, true, SC, LDS, true>), g, b, pad, s, A);                       \
+        else                                                                                                        \
+            hipLaunchKernelGGL((k_lav2_hdr32_fast<M, true, SC, LDS, false>), g, b, pad, s, A);                      \
+    } else {                                                                                                        \
+        if (gs)                                                                                                     \
+            hipLaunchKernelGGL((k_lav2_hdr32_fast<M, false, SC, LDS, true>), g, b, pad, s, A);                      \
+        else                                                                                                        \
+            hipLaunchKernelGGL((k_lav2_hdr32_fast<M, false, SC, LDS, false>), g, b, pad, s, A);                     \
+    }
 #define FS_LAUNCH(M)                                                                                                \
     do {                                                                                                            \
         if (variant == FS_VARIANT_LITERAL) {                                                                        \
@@ -2215,20 +2412,14 @@ void fsk_lav2_hdr32(const FsLav2Args32 &A, int mode, bool stats, int variant, hi
             else                                                                                                    \
                 hipLaunchKernelGGL((k_lav2_lit<float, M, false>), g, b, 0, s, A);                                        \
         } else {                                                                                                    \
+            const bool gs = A.parity == FS_PARITY_GPUSTAGE;                                                         \
             if (variant == FS_VARIANT_TUNED_NOSCALE) {                                                              \
-                if (stats)                                                                                          \
-                    hipLaunchKernelGGL((k_lav2_hdr32_fast<M, true, false>), g, b, pad, s, A);                         \
-                else                                                                                                \
-                    hipLaunchKernelGGL((k_lav2_hdr32_fast<M, false, false>), g, b, pad, s, A);                        \
+                FS_LAUNCH_FAST(M, false, false)                                                                     \
             } else if (lds_orbit) {                                                                                 \
-                if (stats)                                                                                          \
-                    hipLaunchKernelGGL((k_lav2_hdr32_fast<M, true, true, true>), g, b, pad, s, A);                    \
-                else                                                                                                \
-                    hipLaunchKernelGGL((k_lav2_hdr32_fast<M, false, true, true>), g, b, pad, s, A);                   \
-            } else if (stats)                                                                                       \
-                hipLaunchKernelGGL((k_lav2_hdr32_fast<M, true, true>), g, b, pad, s, A);                              \
-            else                                                                                                    \
-                hipLaunchKernelGGL((k_lav2_hdr32_fast<M, false, true>), g, b, pad, s, A);                             \
+                FS_LAUNCH_FAST(M, true, true)                                                                       \
+            } else {                                                                                                \
+                FS_LAUNCH_FAST(M, true, false)                                                                      \
+            }                                                                                                       \
         }                                                                                                           \
     } while (0)
     if (mode == FS_MODE_FULL)
@@ -2238,6 +2429,7 @@ void fsk_lav2_hdr32(const FsLav2Args32 &A, int mode, bool stats, int variant, hi
     else
         FS_LAUNCH(FS_MODE_LAO);
 #undef FS_LAUNCH
+#undef FS_LAUNCH_FAST
 }
 
 // Grid of the persistent (lane-refilling) launch: as many workgroups as the device holds at once, never more than one
@@ -2262,9 +2454,11 @@ template <class K> static dim3 persistent_grid(K kernel, const FsFrame &f)
 static bool refill_enabled()
 {
     // A/B switch: FSMI355_REFILL=1 selects the persistent, lane-refilling launch.  It is OFF by
-    // default: measured on C5 it raises the loop's lane utilisation from 0.71 to 0.97 and still loses (127.6 vs 72.4 ms
-    // on the 3840x2160 quarter frame) -- re-packed lanes sit at unrelated orbit and table positions, every per-lane load
-    // of a wave then touches 64 different cache lines, and the kernel turns from VALU-bound into L1/L2-request-bound.
+    // default: measured on C5 (7680x4320) it raises the loop's lane utilisation from 0.74 to 0.98 and still loses, 333 ms
+    // against 263 ms -- re-packed lanes are due for different actions (jump / step) and sit at unrelated orbit and table
+    // positions: rocprofv3 counts 1.8x the vector instructions at 37 % active lanes with the reference-shaped loop
+    // (505 ms), and with the action loop, which removes that divergence, 2.5x the L2 requests remain (every per-lane
+    // load of a wave touches 64 different lines).
     static const bool on = getenv("FSMI355_REFILL") != nullptr && atoi(getenv("FSMI355_REFILL")) != 0;
     return on;
 }
