@@ -97,6 +97,12 @@ def parse():
 
 def main():
     args = parse()
+    # stdout carries exactly ONE JSON line.  Libraries write banners there (RCCL prints its version block to stdout when the
+    # first communicator comes up), so for the whole run file descriptor 1 is pointed at stderr and the real stdout is kept
+    # for the result line only.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import numpy as np
     import torch
 
@@ -409,11 +415,14 @@ def main():
             "device_resident_ms": round(avg_kernel_ms, 3),
             "device_resident_mpix_s": round(W * H / avg_kernel_ms / 1e3, 4),
         }
-        print(json.dumps(out))
+        result_line = json.dumps(out)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
     r.close()
+    if rank == 0:
+        sys.stdout.flush()
+        os.write(real_stdout, (result_line + "\n").encode())
 
 
 if __name__ == "__main__":

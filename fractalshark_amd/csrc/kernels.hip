@@ -1223,6 +1223,27 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
     hcplx<F> Zcached = hc_zero<F>();
     uint32_t Zcached_at = 0xFFFFFFFFu;
     bool force_step = false; // (action loop) the BLA loop of the reference was left by its escape test: step next, no lookup
+    // Exact cycle detection for pixels that never escape (perturbation only).  After a rebase the whole future of a pixel
+    // is a pure function of its dz (RefIteration is 0, dc is fixed, the arithmetic is deterministic; the iteration counter
+    // only decides where the loop stops).  So if the dz of a rebase equals, bit for bit, the dz of an earlier rebase, the
+    // pixel's states repeat forever, none of them escaped, and the reference's loop would run on to the iteration cap and
+    // return exactly n_iterations -- which is returned here at once.  Brent's scheme: the dz of rebase number 1, 2, 4, 8 ...
+    // is kept, every later rebase compares against it (four integer compares on a path taken once per ~60 steps).
+    // Interior pixels of C2 run 4.7 M steps each in the reference; their dz locks into an exact cycle long before that.
+    hreal<F> cycX = hreal<F>{F(0), INT32_MIN}, cycY = cycX;
+    uint32_t cyc_n = 0, cyc_next = 1;
+#define FS_CYCLE_CHECK()                                                                                            \
+    if constexpr (!kBla && std::is_same<F, float>::value) {                                                         \
+        if (__float_as_int(DeltaSubNX.m) == __float_as_int(cycX.m) && DeltaSubNX.e == cycX.e &&                     \
+            __float_as_int(DeltaSubNY.m) == __float_as_int(cycY.m) && DeltaSubNY.e == cycY.e) {                     \
+            iter = n_iterations - 1u; /* the ++iter that follows makes it the cap */                                \
+            if (kStats)                                                                                             \
+                atomicAdd((unsigned long long *)&A.stats[5], 1ull); /* probe: pixels ended by the cycle test */      \
+        } else if (++cyc_n == cyc_next) {                                                                           \
+            cycX = DeltaSubNX, cycY = DeltaSubNY;                                                                   \
+            cyc_next <<= 1;                                                                                         \
+        }                                                                                                           \
+    }
     // frame-wide pixel queue (kRefill)
     const uint32_t tiles_x = (A.frame.width + 7u) >> 3;
     const uint32_t total = tiles_x * ((A.frame.local_rows + 7u) >> 3) * 64u;
@@ -1242,6 +1263,8 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
             Zcached = hc_zero<F>();
             Zcached_at = 0xFFFFFFFFu;
             force_step = false;
+            cycX = hreal<F>{F(0), INT32_MIN}, cycY = cycX;
+            cyc_n = 0, cyc_next = 1;
         }
     };
     if constexpr (!kRefill) {
@@ -2013,6 +2036,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                         DeltaNormSquared = hreal<F>{__int_as_float((nb & 0x007FFFFF) | 0x3F800000),
                                                     (ez << 1) + (int)__builtin_amdgcn_ubfe(nb, 23, 8) - 127};
                         RefIteration = 0;
+                        FS_CYCLE_CHECK()
                     }
                     ++iter;
                 }
@@ -2056,10 +2080,14 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                 DeltaSubNY = tempZY;
                 DeltaNormSquared = normSquared;
                 RefIteration = 0;
+                FS_CYCLE_CHECK()
             }
             ++iter;
         }
+#undef FS_CYCLE_CHECK
         if (finished) {
+            if (kStats && !kBla && iter >= n_iterations)
+                atomicAdd((unsigned long long *)&A.stats[6], 1ull); // probe: pixels that came back with the cap
             store_iter(A.out, A.frame, L, X, iter);
             have = false;
         }

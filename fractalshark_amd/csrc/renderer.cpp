@@ -1003,14 +1003,14 @@ template <class F> uint32_t build_la(fs_renderer *r, const void *max_radius, int
         return FS_ERR_UNSUPPORTED; // degenerate tables (orbits of <= 64 entries) are left to the host builder
     // capacity: a stage never holds more records than elements it was folded from (+ its tail record)
     const size_t cap_states = 2u * ((size_t)maxRef + 2u);
-    DevBuf chebv, mm, steps, pos, nextA, nextB, reach, rank, table, small, stage_idx, atbuf;
+    DevBuf chebv, mm, steps, pos, nextA, nextB, nextC, reach, rank, table, small, stage_idx, atbuf;
     FS_TRY(chebv.alloc(sizeof(HR) * (maxRef + 2u)));
     FS_TRY(mm.alloc(sizeof(HR) * (maxRef + 2u)));
     FS_TRY(steps.alloc(4u * (maxRef + 2u)));
     FS_TRY(pos.alloc(4u * (maxRef + 3u)));
     FS_TRY(nextA.alloc(4u * cap_states));
     FS_TRY(nextB.alloc(4u * cap_states));
-    FS_TRY(nextA.p && nextB.p ? hipSuccess : hipErrorOutOfMemory);
+    FS_TRY(nextC.alloc(4u * cap_states));
     FS_TRY(reach.alloc(4u * cap_states));
     FS_TRY(rank.alloc(4u * (cap_states + 1u)));
     // all stages: stage k+1 holds at most half of stage k (+2), so 2 * maxRef + slack bounds the sum
@@ -1048,24 +1048,20 @@ template <class F> uint32_t build_la(fs_renderer *r, const void *max_radius, int
             FS_TRY(hipMemsetAsync(reach.p, 0, 4u * nstates, s));
             const uint32_t one = 1;
             FS_TRY(hipMemcpyAsync(reach.as<uint32_t>() + x_start, &one, 4, hipMemcpyHostToDevice, s));
-            // jump tables: nextB is the doubling scratch; the original next stays in nextA for the record kernel
-            DevBuf j0, j1;
-            FS_TRY(j0.alloc(4u * nstates));
-            FS_TRY(j1.alloc(4u * nstates));
-            FS_TRY(hipMemcpyAsync(j0.p, nextA.p, 4u * nstates, hipMemcpyDeviceToDevice, s));
-            uint32_t *jin = j0.as<uint32_t>(), *jout = j1.as<uint32_t>();
+            // jump tables ping-pong between nextB and nextC; the original next stays in nextA for the record kernel
+            uint32_t *jin = nextA.as<uint32_t>(), *jout = nextB.as<uint32_t>();
             for (uint32_t span = 1; span < limit + 1u; span <<= 1) {
                 fsk_la_reach(jin, jout, reach.as<uint32_t>(), nstates, s);
-                std::swap(jin, jout);
+                jin = jout;
+                jout = jout == nextB.as<uint32_t>() ? nextC.as<uint32_t>() : nextB.as<uint32_t>();
             }
             fsk_scan_u32(reach.as<uint32_t>(), rank.as<uint32_t>(), nstates, s);
             FS_TRY(hipMemcpyAsync(h, rank.as<uint32_t>() + nstates, 4, hipMemcpyDeviceToHost, s));
-            FS_TRY(hipStreamSynchronize(s)); // also keeps j0 / j1 alive until the rounds have run
+            FS_TRY(hipStreamSynchronize(s));
             if ((size_t)la_size + offset + h[0] + 2u > cap_recs)
                 return FS_ERR_7;
             fsk_la_records<F>(stage0, zref, P, pos.as<uint32_t>(), nextA.as<uint32_t>(), reach.as<uint32_t>(),
                               rank.as<uint32_t>(), limit, offset, d_table + la_size, s);
-            FS_TRY(hipStreamSynchronize(s));
             n_records = offset + h[0];
         }
         return (uint32_t)hipGetLastError();
@@ -1115,17 +1111,18 @@ template <class F> uint32_t build_la(fs_renderer *r, const void *max_radius, int
         FS_TRY(hipStreamSynchronize(s));
         uint32_t jd = h[0], fd = h[1];
         uint32_t step0 = 0, posjd = 0;
-        FS_TRY(hipMemcpy(&step0, steps.as<uint32_t>(), 4, hipMemcpyDeviceToHost));
+        FS_TRY(hipMemcpyAsync(&step0, steps.as<uint32_t>(), 4, hipMemcpyDeviceToHost, s));
+        FS_TRY(hipStreamSynchronize(s));
         uint32_t Period = 0;
         if (jd != kLaTerm) {
             Rec pj;
-            FS_TRY(hipMemcpy(&pj, P + jd, sizeof(Rec), hipMemcpyDeviceToHost));
-            if (pj.LAThreshold.m == F(0)) { // isLAThresholdZero: the prologue breaks without a period (:815-817)
+            FS_TRY(hipMemcpyAsync(&pj, P + jd, sizeof(Rec), hipMemcpyDeviceToHost, s));
+            FS_TRY(hipMemcpyAsync(&posjd, pos.as<uint32_t>() + jd, 4, hipMemcpyDeviceToHost, s));
+            FS_TRY(hipStreamSynchronize(s));
+            if (pj.LAThreshold.m == F(0)) // isLAThresholdZero: the prologue breaks without a period (:815-817)
                 jd = kLaTerm;
-            } else {
-                FS_TRY(hipMemcpy(&posjd, pos.as<uint32_t>() + jd, 4, hipMemcpyDeviceToHost));
+            else
                 Period = posjd;
-            }
         }
         stages.push_back(fs_la_stage_u32{la_size, 0u});
         const double NthRoot = std::round(std::log2((double)maxRef) / periodDivisor);
