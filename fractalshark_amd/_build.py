@@ -75,6 +75,8 @@ def _render_flags():
     # FS_PROFILE_CYCLES=1: the instrumented (step-counting) kernel variants also report shader-clock cycles per phase
     # (tools/cycle_probe.py); never set for the product build
     extra = ["-DFS_PROFILE_CYCLES"] if os.environ.get("FS_PROFILE_CYCLES") == "1" else []
+    if os.environ.get("FS_TRACE_WAVES") == "1":  # tools/wave_trace.py: per-wave start / end / SIMD records
+        extra.append("-DFS_TRACE_WAVES")
     if os.environ.get("FS_SCALED_CHUNK"):  # tuning experiments only
         extra.append("-DFS_SCALED_CHUNK=" + str(int(os.environ["FS_SCALED_CHUNK"])))
     return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", *extra]

@@ -124,6 +124,7 @@ def render_lib():
     _decl(lib, "fs_enable_step_count", u32, [vp, C.c_int])
     _decl(lib, "fs_read_step_count", u32, [vp, vp])
     _decl(lib, "fs_time_render_current", u32, [vp, u64, u32, vp])
+    _decl(lib, "fs_read_stats_raw", u32, [vp, vp, u64])
     _decl(lib, "fs_build_la", u32, [vp, C.c_int, vp, C.c_int])
     _decl(lib, "fs_la_counts", u32, [vp, vp, vp, vp, vp])
     _decl(lib, "fs_read_la", u32, [vp, vp, u32, vp, u32, vp])
@@ -159,7 +160,7 @@ RENDER_SYMBOLS = [
     "fs_render_direct_lp", "fs_clear",
     "fs_render_current", "fs_sync_compute", "fs_compute_stream", "fs_sync_display", "fs_query_compute", "fs_enqueue_done_callback",
     "fs_get_width", "fs_get_height", "fs_last_kernel_ms", "fs_set_kernel_variant", "fs_enable_step_count", "fs_read_step_count",
-    "fs_time_render_current", "fs_build_la", "fs_la_counts", "fs_read_la",
+    "fs_time_render_current", "fs_read_stats_raw", "fs_build_la", "fs_la_counts", "fs_read_la",
     "fs_group_create", "fs_group_destroy", "fs_group_size", "fs_group_transport", "fs_group_renderer", "fs_group_init_memory",
     "fs_group_upload_orbit", "fs_group_upload_orbit_compressed", "fs_group_upload_la", "fs_group_upload_bla",
     "fs_group_upload_orbit_scaled", "fs_group_render_lav2", "fs_group_render_bla", "fs_group_render_scaled",

@@ -421,6 +421,10 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
     __shared__ float4 s_zs_lds[kLds ? 4 * 2 * 64 : 1];
     uint32_t X, L;
     tile_pixel(X, L);
+#ifdef FS_TRACE_WAVES
+    // measurement build (tools/wave_trace.py): every wave records when and where it ran.  100 MHz constant clock.
+    const uint64_t trace_t0 = wall_clock64();
+#endif
     uint64_t c_at = 0, c_la = 0, c_pt = 0, c_px = 0;
     uint64_t c_careful = 0, c_scaled = 0, c_runs = 0;
 #ifdef FS_PROFILE_CYCLES
@@ -1087,6 +1091,26 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
         }
         store_iter(A.out, A.frame, L, X, iterations);
     }
+#ifdef FS_TRACE_WAVES
+    if (kStats && A.stats) {
+        uint64_t steps = c_pt;
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint64_t o = __shfl_down(steps, off);
+            steps = o > steps ? o : steps;
+        }
+        if ((threadIdx.x & 63) == 0) {
+            uint32_t hw_id, xcc_id;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+            const uint64_t wave = ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+            uint64_t *t = A.stats + 16 + 4 * wave;
+            t[0] = trace_t0;
+            t[1] = wall_clock64();
+            t[2] = ((uint64_t)xcc_id << 32) | hw_id;
+            t[3] = steps; // longest lane of the wave, perturbation steps
+        }
+    }
+#endif
 #ifdef FS_PROFILE_CYCLES
     if (kStats) {
         if ((threadIdx.x & 63) == 0) {

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -49,6 +50,8 @@ struct fs_renderer {
     fs_color16 *colors = nullptr;
     fs_reduction *reduction = nullptr;
     uint64_t *stats = nullptr;
+    size_t stats_words = 8;
+
     uint32_t *queue = nullptr; // pixel counter of the persistent launches (kernels.hip, k_perturb_scalar)
     bool stats_on = false;
     int variant = FS_VARIANT_TUNED;
@@ -237,6 +240,7 @@ void free_all(fs_renderer *r)
     if (r->queue)
         hipFree(r->queue);
     r->queue = nullptr;
+
     if (r->pal)
         hipFree(r->pal);
     if (r->cx_row)
@@ -467,8 +471,14 @@ uint32_t fs_init_memory(fs_renderer *r, uint32_t w, uint32_t h, uint32_t antiali
     }
     if (!r->reduction)
         FS_TRY(hipMalloc((void **)&r->reduction, sizeof(fs_reduction)));
-    if (!r->stats)
-        FS_TRY(hipMalloc((void **)&r->stats, 8 * sizeof(uint64_t)));
+    if (!r->stats) {
+        // 8 counters; a measurement build (FS_TRACE_WAVES) appends four words per wave of the largest frame it will see
+        r->stats_words = 8;
+        if (const char *e = getenv("FSMI355_TRACE_WAVES"))
+            r->stats_words = 16 + 4 * (size_t)atoll(e);
+        FS_TRY(hipMalloc((void **)&r->stats, r->stats_words * sizeof(uint64_t)));
+        FS_TRY(hipMemset(r->stats, 0, r->stats_words * sizeof(uint64_t)));
+    }
     if (!r->queue)
         FS_TRY(hipMalloc((void **)&r->queue, 64));
     FS_TRY(hipMalloc((void **)&r->colors, r->n_color_cu * sizeof(fs_color16)));
@@ -1801,6 +1811,18 @@ uint32_t fs_set_kernel_variant(fs_renderer *r, int variant)
 uint32_t fs_enable_step_count(fs_renderer *r, int enable)
 {
     r->stats_on = enable != 0;
+    return 0;
+}
+
+uint32_t fs_read_stats_raw(fs_renderer *r, uint64_t *out, uint64_t max_words)
+{
+    if (uint32_t e = use_device(r))
+        return e;
+    if (!r->stats)
+        return FS_ERR_6;
+    const size_t n = r->stats_words < max_words ? r->stats_words : (size_t)max_words;
+    FS_TRY(hipMemcpyAsync(out, r->stats, n * sizeof(uint64_t), hipMemcpyDeviceToHost, r->compute));
+    FS_TRY(hipStreamSynchronize(r->compute));
     return 0;
 }
 

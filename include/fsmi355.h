@@ -238,6 +238,9 @@ float fs_last_kernel_ms(const fs_renderer *r);
 uint32_t fs_set_kernel_variant(fs_renderer *r, int variant);
 uint32_t fs_enable_step_count(fs_renderer *r, int enable);
 uint32_t fs_read_step_count(fs_renderer *r, uint64_t counts[8]);
+/* The whole statistics buffer (measurement builds append per-wave trace records behind the 8 counters: library built
+ * with FS_TRACE_WAVES=1 and FSMI355_TRACE_WAVES=<max waves> in the environment; tools/wave_trace.py). */
+uint32_t fs_read_stats_raw(fs_renderer *r, uint64_t *out, uint64_t max_words);
 /* Average duration (HIP events on the compute stream, `repeats` back-to-back launches, no D2H) of the two RenderCurrent
  * kernels over the current iteration buffer: ms_out[0] = antialias + palette, ms_out[1] = min / max / sum.  Needs a
  * palette (fs_init_memory) and the whole frame on this renderer.  tools/bench_render_current.py turns them into GB/s. */
