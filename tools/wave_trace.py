@@ -39,6 +39,8 @@ n = 16 + 4 * waves
 buf = np.zeros(n, np.uint64)
 assert r._lib.fs_read_stats_raw(r._h, buf.ctypes.data, n) == 0
 t = buf[16:].reshape(-1, 4)
+# waves are numbered (blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave: 480 tiles per 8-row band
+band_of = (np.arange(len(t)) // 480)[t[:, 1] > 0]
 t = t[t[:, 1] > 0]
 t0 = t[:, 0].min()
 start = (t[:, 0] - t0).astype(np.float64) / 100.0  # us (100 MHz)
@@ -61,6 +63,10 @@ for s_, e_ in zip(start, end):
     occ[b0:b1 + 1] += 1
 nsimd = len(np.unique(key))
 per = np.bincount(np.unique(key, return_inverse=True)[1])
+band_cost = np.bincount(band_of, weights=dur)
+band_steps = np.bincount(band_of, weights=steps)
+print(json.dumps({"band_wave_ms_sum": [round(float(x) / 1e3, 1) for x in band_cost],
+                  "band_wave_steps_sum_k": [int(x / 1e3) for x in band_steps]}))
 print(json.dumps({"world": a.world, "rank": a.rank, "kernel_ms_with_trace_build": round(ms, 3), "waves": int(len(t)),
                   "simds_seen": int(nsimd), "waves_per_simd_min_mean_max": [int(per.min()), round(float(per.mean()), 2), int(per.max())],
                   "span_us": round(float(total), 1),
