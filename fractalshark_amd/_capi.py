@@ -180,6 +180,8 @@ def inputs_lib():
     lib = C.CDLL(path)
     _decl(lib, "fsh_view_create", vp, [C.c_char_p] * 4 + [u32, u32])
     _decl(lib, "fsh_view_destroy", None, [vp])
+    _decl(lib, "fsh_view_save_im", C.c_int, [vp, u64, C.c_char_p, C.c_int])
+    _decl(lib, "fsh_view_load_im", vp, [C.c_char_p, u32, u32, C.POINTER(u64), C.POINTER(C.c_int), C.POINTER(C.c_int)])
     _decl(lib, "fsh_view_precision_bits", u64, [vp])
     _decl(lib, "fsh_view_bbox_str", C.c_int, [vp, C.c_int, C.c_char_p, C.c_size_t])
     _decl(lib, "fsh_view_coords_direct_f64", None, [vp, u32, u32, vp])

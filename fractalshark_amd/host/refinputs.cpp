@@ -168,6 +168,10 @@ void square_aspect(fsh_view &vw, size_t scrnWidth, size_t scrnHeight)
 
 } // namespace
 
+namespace {
+fsh_view *finish_view(std::unique_ptr<fsh_view> vw, bool from_box);
+}
+
 extern "C" fsh_view *fsh_view_create(const char *minX, const char *minY, const char *maxX, const char *maxY,
                                      uint32_t width, uint32_t height)
 {
@@ -180,8 +184,18 @@ extern "C" fsh_view *fsh_view_create(const char *minX, const char *minY, const c
     vw->minY = Mp::from_str(minY);
     vw->maxX = Mp::from_str(maxX);
     vw->maxY = Mp::from_str(maxY);
+    return finish_view(std::move(vw), true);
+}
+
+namespace {
+
+// The rest of what the reference does to a new view: the box form of PointZoomBBConverter (from_box; the point + zoom form
+// has set ptX / ptY / zoom already), Fractal::SetPrecision, SquareAspectRatio.
+fsh_view *finish_view(std::unique_ptr<fsh_view> vw, bool from_box)
+{
+    const uint32_t width = vw->width, height = vw->height;
     // PointZoomBBConverter(minX,minY,maxX,maxY), PointZoomBBConverter.cpp:26-53
-    {
+    if (from_box) {
         Mp two = Mp::from_ui(2);
         vw->ptX = (vw->minX + vw->maxX) / two;
         vw->ptY = (vw->minY + vw->maxY) / two;
@@ -217,6 +231,203 @@ extern "C" fsh_view *fsh_view_create(const char *minX, const char *minY, const c
     vw->zoom.set_prec(vw->prec_bits);
     square_aspect(*vw, width, height);
     return vw.release();
+}
+
+} // namespace
+
+// ------------------------------------------------------------------ Imagina ".im" files, location form
+// The reference saves / loads a view as an Imagina location file (RefOrbitCalc::SaveOrbitResults(filename),
+// RefOrbitCalc.cpp:3117-3166; LoadOrbitConstInternal, :3425-3520; ImaginaOrbit.h:10-24):
+//   IMFileHeader { u64 Magic = 0x000A0D56504D49FF ("\xFFIMPV\r\n\0"; "Sharks:)" = 0x536861726b733a29 for the reference's own
+//                  variant), u64 Reserved = 0, u64 LocationOffset = 32, u64 ReferenceOffset = 0 (no orbit stored) }
+//   at LocationOffset: HRReal halfH  = HDRFloat<double, Left, int64_t>{ double mantissa; int64 exp } = half the view's height
+//                      u64 iterationLimit
+//                      mpf orbitX, mpf orbitY  (the view's centre) in the MPIR raw stream form of MpirSerialization.cpp:157-187:
+//                          long _mp_exp (limbs), then the limbs as one integer: int32 big-endian signed byte count +
+//                          magnitude bytes, most significant first
+// Files that also carry a reference orbit (ReferenceOffset != 0: the reference's MaxCompression intermediate form) are
+// recognised and loaded as locations; the stored orbit is ignored (it is not needed to render: the orbit is recomputed).
+namespace {
+
+constexpr uint64_t kImMagic = 0x000A0D56504D49FFull, kSharksMagic = 0x536861726b733a29ull;
+
+// exp_bytes = sizeof(long) of the build that wrote the file: 4 for the reference's Windows (MSVC) build and Imagina itself,
+// 8 for the reference built on Linux.  Limbs are 64-bit in both (MPIR x64 / GMP), so only the field width differs.
+void im_write_mpf(FILE *f, mpf_srcptr X, int exp_bytes)
+{
+    const int64_t expt = X->_mp_exp;
+    if (exp_bytes == 4) {
+        const int32_t e32 = (int32_t)expt;
+        fwrite(&e32, 4, 1, f);
+    } else {
+        fwrite(&expt, 8, 1, f);
+    }
+    mpz_t Z; // non-owning view of X's limbs, like the reference
+    const int nz = X->_mp_size;
+    Z->_mp_alloc = std::abs(nz);
+    Z->_mp_size = nz;
+    Z->_mp_d = X->_mp_d;
+    size_t byte_count = 0;
+    const int sign = mpz_sgn(Z);
+    if (sign != 0)
+        byte_count = (mpz_sizeinbase(Z, 2) + 7) / 8;
+    const int32_t header = sign == 0 ? 0 : (sign < 0 ? -1 : 1) * (int32_t)byte_count;
+    const uint32_t u = (uint32_t)header;
+    const unsigned char hdr[4] = {(unsigned char)(u >> 24), (unsigned char)(u >> 16), (unsigned char)(u >> 8), (unsigned char)u};
+    fwrite(hdr, 1, 4, f);
+    if (byte_count) {
+        std::vector<unsigned char> buf(byte_count);
+        size_t n = 0;
+        mpz_export(buf.data(), &n, 1, 1, 1, 0, Z);
+        fwrite(buf.data(), 1, byte_count, f);
+    }
+}
+
+bool im_read_mpf(FILE *f, mpf_ptr X, int exp_bytes)
+{
+    int64_t expt = 0;
+    unsigned char hdr[4];
+    if (exp_bytes == 4) {
+        int32_t e32;
+        if (fread(&e32, 4, 1, f) != 1)
+            return false;
+        expt = e32;
+    } else if (fread(&expt, 8, 1, f) != 1) {
+        return false;
+    }
+    if (fread(hdr, 1, 4, f) != 4)
+        return false;
+    const int32_t raw = (int32_t)(((uint32_t)hdr[0] << 24) | ((uint32_t)hdr[1] << 16) | ((uint32_t)hdr[2] << 8) | hdr[3]);
+    mpz_t Z;
+    mpz_init(Z);
+    if (raw != 0) {
+        const size_t n = (size_t)std::abs((int64_t)raw);
+        if (n > (1u << 24)) { // 128 Mbit of mantissa: not a location anyone saved; the wrong exponent width reads such counts
+            mpz_clear(Z);
+            return false;
+        }
+        std::vector<unsigned char> buf(n);
+        if (fread(buf.data(), 1, n, f) != n) {
+            mpz_clear(Z);
+            return false;
+        }
+        mpz_import(Z, n, 1, 1, 1, 0, buf.data());
+        if (raw < 0)
+            mpz_neg(Z, Z);
+    }
+    mpf_set_z(X, Z);
+    if (raw != 0)
+        X->_mp_exp = (mp_exp_t)expt;
+    mpz_clear(Z);
+    return true;
+}
+
+struct ImHalfH { // Imagina::HRReal
+    double mantissa;
+    int64_t exp;
+};
+
+} // namespace
+
+extern "C" int fsh_view_save_im(const fsh_view *v, uint64_t iteration_limit, const char *path, int exp_bytes)
+{
+    if (exp_bytes != 4 && exp_bytes != 8)
+        return -1;
+    FILE *f = fopen(path, "wb");
+    if (!f)
+        return -1;
+    const uint64_t header[4] = {kImMagic, 0, 32, 0};
+    fwrite(header, 8, 4, f);
+    // radiusY = double{maxY - minY} / 2.0; halfH = HRReal{radiusY}: the templated HDRFloat(number) constructor
+    // (HDRFloat.h:295-363): zero -> {0, MIN_BIG_EXPONENT}, else mantissa in [1, 2) and the exponent beside it
+    mpf_set_default_prec(v->prec_bits);
+    Mp dY = v->maxY - v->minY;
+    const double radiusY = mpf_get_d(dY.v) / 2.0;
+    ImHalfH hh;
+    if (radiusY == 0.0) {
+        hh.mantissa = 0.0;
+        hh.exp = INT16_MIN >> 3; // GenericHdrBase::MIN_BIG_EXPONENT for a TExp that is neither int32_t nor float
+    } else {
+        // the same bit surgery (HDRFloat.h:307-316), so that subnormal radii come out the way the reference writes them
+        uint64_t bits;
+        memcpy(&bits, &radiusY, 8);
+        const uint64_t val = (bits & 0x800FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
+        memcpy(&hh.mantissa, &val, 8);
+        hh.exp = (int64_t)((bits & 0x7FF0000000000000ull) >> 52) - 1023;
+    }
+    fwrite(&hh, sizeof(hh), 1, f);
+    fwrite(&iteration_limit, 8, 1, f);
+    im_write_mpf(f, v->ptX.v, exp_bytes);
+    im_write_mpf(f, v->ptY.v, exp_bytes);
+    const bool ok = !ferror(f);
+    fclose(f);
+    return ok ? 0 : -1;
+}
+
+extern "C" fsh_view *fsh_view_load_im(const char *path, uint32_t width, uint32_t height, uint64_t *iteration_limit,
+                                     int *has_orbit, int *exp_bytes_out)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f)
+        return nullptr;
+    uint64_t header[4];
+    ImHalfH hh;
+    uint64_t limit = 0;
+    fsh_view *out = nullptr;
+    if (fread(header, 8, 4, f) == 4 && (header[0] == kImMagic || header[0] == kSharksMagic) &&
+        fseek(f, (long)header[2], SEEK_SET) == 0 && fread(&hh, sizeof(hh), 1, f) == 1 && fread(&limit, 8, 1, f) == 1) {
+        // precision = -min(0, halfH.exp) + AuthoritativeMinExtraPrecisionInBits (RefOrbitCalc.cpp:3458-3460)
+        const uint64_t precision = (uint64_t)(-std::min<int64_t>(0, hh.exp)) + 120u;
+        mpf_set_default_prec(precision);
+        Mp X(precision, 0), Y(precision, 0), H(precision, 0);
+        // which `long` wrote the file: the two values must end exactly where the location section ends (the reference
+        // orbit's offset, or the end of the file)
+        const long at = ftell(f);
+        fseek(f, 0, SEEK_END);
+        const long section_end = header[3] > header[2] ? (long)header[3] : ftell(f);
+        int width_ok = 0;
+        for (int exp_bytes : {4, 8}) {
+            fseek(f, at, SEEK_SET);
+            if (im_read_mpf(f, X.v, exp_bytes) && im_read_mpf(f, Y.v, exp_bytes) && ftell(f) == section_end) {
+                width_ok = exp_bytes;
+                break;
+            }
+        }
+        // halfH == 0 is what the writer stores for a view too deep for a double radius; there is no box to load
+        // (the reference divides by it)
+        if (width_ok && hh.mantissa != 0.0) {
+            // halfH.GetHighPrecision (HDRFloat.h:396-412); the box is pt -+ Factor / zoomFactor = pt -+ halfH
+            mpf_set_d(H.v, hh.mantissa);
+            if (hh.exp >= 0)
+                mpf_mul_2exp(H.v, H.v, (mp_bitcnt_t)hh.exp);
+            else
+                mpf_div_2exp(H.v, H.v, (mp_bitcnt_t)(-hh.exp));
+            // zoomFactor = 2 / halfH (:3462-3465), then PointZoomBBConverter(ptX, ptY, zoomFactor): the box is
+            // pt -+ Factor / zoomFactor (PointZoomBBConverter.cpp:9-24), every operation rounded at `precision`
+            const Mp two = Mp::from_ui(2);
+            const Mp zoom = two / H;
+            const Mp r = two / zoom;
+            auto vw = std::make_unique<fsh_view>();
+            vw->width = width;
+            vw->height = height;
+            vw->ptX = X;
+            vw->ptY = Y;
+            vw->zoom = zoom;
+            vw->minX = X - r;
+            vw->minY = Y - r;
+            vw->maxX = X + r;
+            vw->maxY = Y + r;
+            out = finish_view(std::move(vw), false);
+            if (iteration_limit)
+                *iteration_limit = limit;
+            if (has_orbit)
+                *has_orbit = header[3] != 0;
+            if (exp_bytes_out)
+                *exp_bytes_out = width_ok;
+        }
+    }
+    fclose(f);
+    return out;
 }
 
 extern "C" void fsh_view_destroy(fsh_view *v) { delete v; }

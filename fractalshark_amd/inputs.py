@@ -69,6 +69,31 @@ class View:
         aa = v["gpuAntialiasing"] if antialiasing is None else antialiasing
         return cls(v["minX"], v["minY"], v["maxX"], v["maxY"], width, height, v["numIterations"], aa)
 
+    @classmethod
+    def load_im(cls, path, width, height, antialiasing=1):
+        """A view from an Imagina ".im" location file (Fractal::LoadRefOrbit's location half: RefOrbitCalc.cpp:3425-3520,
+        then RecenterViewCalc on {orbitX, orbitY, 2 / halfH}).  `.im_has_orbit` says whether the file also carried a
+        reference orbit (not read: the orbit is recomputed), `.im_exp_bytes` which `long` wrote it."""
+        lib = _capi.inputs_lib()
+        limit, has_orbit, exp_bytes = C.c_uint64(0), C.c_int(0), C.c_int(0)
+        h = lib.fsh_view_load_im(os.fsencode(path), int(width), int(height), C.byref(limit), C.byref(has_orbit),
+                                 C.byref(exp_bytes))
+        if not h:
+            raise ValueError("%s: not an Imagina location file" % (path,))
+        self = cls.__new__(cls)
+        self._lib, self._h = lib, h
+        self.width, self.height = int(width), int(height)
+        self.num_iterations = int(limit.value)
+        self.antialiasing = int(antialiasing)
+        self.im_has_orbit, self.im_exp_bytes = bool(has_orbit.value), exp_bytes.value
+        return self
+
+    def save_im(self, path, exp_bytes=4):
+        """The view as an Imagina location file, RefOrbitCalc::SaveOrbitResults(filename) (RefOrbitCalc.cpp:3117-3166).
+        exp_bytes=4 writes what the reference's Windows build and Imagina write, 8 the reference's Linux build."""
+        if self._lib.fsh_view_save_im(self._h, self.num_iterations, os.fsencode(path), int(exp_bytes)) != 0:
+            raise OSError("could not write %s" % (path,))
+
     def __del__(self):
         if getattr(self, "_h", None):
             self._lib.fsh_view_destroy(self._h)

@@ -30,6 +30,17 @@ fsh_view *fsh_view_create(const char *minX, const char *minY, const char *maxX, 
                           uint32_t width, uint32_t height);
 void fsh_view_destroy(fsh_view *v);
 uint64_t fsh_view_precision_bits(const fsh_view *v);
+/* Imagina ".im" location files, the form the reference writes for a view without a stored orbit
+ * (RefOrbitCalc::SaveOrbitResults(filename), RefOrbitCalc.cpp:3117-3166) and reads back in LoadOrbitConstInternal
+ * (:3425-3520): IMFileHeader, halfH (HDRFloat<double, Left, int64_t>), iteration limit, the centre as two MPIR raw-stream
+ * mpf values (MpirSerialization.cpp:157-187).  fsh_view_load_im also accepts files that carry a reference orbit
+ * (*has_orbit = 1) and loads their location; the stored orbit (the reference's MaxCompression intermediate form) is
+ * not read.  exp_bytes is sizeof(long) of the build whose files are meant: 4 = the reference's Windows build and Imagina,
+ * 8 = the reference built on Linux (the mpf exponent field is a raw `long`); the loader finds it from the section's
+ * length and reports it.  Returns 0 / a view, or -1 / NULL. */
+int fsh_view_save_im(const fsh_view *v, uint64_t iteration_limit, const char *path, int exp_bytes);
+fsh_view *fsh_view_load_im(const char *path, uint32_t width, uint32_t height, uint64_t *iteration_limit, int *has_orbit,
+                           int *exp_bytes_out);
 /* which: 0=minX 1=minY 2=maxX 3=maxY; printf("%.Fe") of the squared bounding box. */
 int fsh_view_bbox_str(const fsh_view *v, int which, char *buf, size_t buflen);
 

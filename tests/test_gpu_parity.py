@@ -569,6 +569,32 @@ def test_la_table_built_on_device_equals_host_builder(renderer, native_libs, vie
     assert at == bytes((C.c_char * C.sizeof(la.at)).from_address(C.addressof(la.at)))
 
 
+@pytest.mark.parametrize("is64", [False, True])
+def test_la_table_built_on_device_from_a_compressed_orbit(renderer, native_libs, is64):
+    """PerturbExtras::SimpleCompression: the orbit is expanded on the device at upload and the table built from it uses
+    periodDivisor 8 (LAReference.cpp:12-19) -- must equal the host builder's table for the same compressed orbit, and the
+    frame rendered from it the oracle's (golden-pinned chain b956... / 68df...)."""
+    v = inputs.View.builtin(5, 64, 36)
+    ob = inputs.Orbit(v, is64=is64, compression_exp=20)
+    assert ob.compressed
+    la = inputs.LATable(ob, host_threads=1)
+    r = renderer
+    assert r.InitializeMemory(64, 36, 1, None, 0, 0, 0, False) == 0
+    assert r.InitializePerturb(1, ob, 0, None, None) == 0  # waypoints only, no table
+    assert r.BuildLAOnDevice(ob) == 0
+    las, stages, at, use_at, is_valid = r.read_la(is64)
+    assert np.array_equal(stages, la.stages()) and las.shape[0] == la.count
+    assert las.tobytes() == la.records().tobytes() and use_at == la.use_at
+    dx, dy, cx, cy = _pairs(v.coords_perturb(ob))
+    T = T_HDR64 if is64 else T_HDR32
+    assert r.ClearMemory() == 0
+    assert r.RenderPerturbLAv2(None, None, None, dx, dy, cx, cy, v.num_iterations, T=T, Mode=LAV2_FULL, parity=PARITY_CPU) == 0
+    out = r.new_iter_buffer()
+    assert r.RenderCurrent(v.num_iterations, out) == 0
+    assert r.SyncComputeStream() == 0
+    assert np.array_equal(out, _oracle.lav2_hdr32(v, ob, la, stage_test=0))
+
+
 def test_la_build_on_device_leaves_tiny_orbits_to_the_host(renderer, native_libs):
     """View 2's orbit has 59 entries (<= LowBound 64): the degenerate one-record table is not built on the device."""
     v = inputs.View.builtin(2, 64, 36, antialiasing=1)
