@@ -1232,6 +1232,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
     }
     uint32_t X = 0, L = 0;
     uint64_t c_la = 0, c_pt = 0, c_px = 0;
+    uint64_t c_single = 0, c_runs = 0; // probes of the perturbation-only float path (tools/c2_probe.py)
     const uint32_t n_iterations = A.n_iterations;
     const uint32_t count = A.orbit_count;
     const typename FsDev<F>::Z *__restrict__ zr = A.zref;
@@ -1698,63 +1699,79 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                     bool failed;
                     const uint32_t ref_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)RefIteration);
                     if (__builtin_amdgcn_ballot_w64(RefIteration != ref_u) == 0ull) {
-                        const float4 *zpu = zs + ref_u + 1; // entries through the scalar cache: all lanes read the same ones
+                        // Entries through the scalar cache (all lanes read the same ones), eight (two 64-byte lines) per
+                        // body.  Scalar loads return out of order, so the only wait there is waits for all of them -- the
+                        // next body's eight are therefore requested right AFTER this body's wait, into a second register
+                        // set, and have the whole body to arrive (two bodies per loop trip, sets A and B).  A wave that is
+                        // alone on its SIMD -- the interior pixels' 4.7 M-step chains that decide C2's frame time -- no
+                        // longer stalls on an L2 round trip every eight steps.
+                        // The exit test of a trip is branched on one trip late (its two steps' tests then overlap the next
+                        // trip's arithmetic instead of standing between two dependent chains); a failing trip costs one
+                        // wasted trip, and the states are named per trip so the roll-back needs no copy.
+                        const float4 *zpu = zs + ref_u + 1;
+                        f4 a0, a1, a2, a3, a4, a5, a6, a7, b0, b1, b2, b3, b4, b5, b6, b7;
+#define FS_SLOAD8(S, P)                                                                                             \
+    asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(S##0) : "s"(P));                                               \
+    asm volatile("s_load_dwordx4 %0, %1, 0x10" : "=s"(S##1) : "s"(P));                                              \
+    asm volatile("s_load_dwordx4 %0, %1, 0x20" : "=s"(S##2) : "s"(P));                                              \
+    asm volatile("s_load_dwordx4 %0, %1, 0x30" : "=s"(S##3) : "s"(P));                                              \
+    asm volatile("s_load_dwordx4 %0, %1, 0x40" : "=s"(S##4) : "s"(P));                                              \
+    asm volatile("s_load_dwordx4 %0, %1, 0x50" : "=s"(S##5) : "s"(P));                                              \
+    asm volatile("s_load_dwordx4 %0, %1, 0x60" : "=s"(S##6) : "s"(P));                                              \
+    asm volatile("s_load_dwordx4 %0, %1, 0x70" : "=s"(S##7) : "s"(P));
+#define FS_SWAIT8(S)                                                                                                \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                                             \
+                 : "+s"(S##0), "+s"(S##1), "+s"(S##2), "+s"(S##3), "+s"(S##4), "+s"(S##5), "+s"(S##6), "+s"(S##7));
+#define FS_SBODY(S, NEXT)                                                                                           \
+    {                                                                                                               \
+        FS_SWAIT8(S)                                                                                                \
+        FS_SLOAD8(NEXT, zpu + 8)                                                                                    \
+        f2 t1, u1, w2_, z2_, t3, u3, w4_, z4_, t5, u5, w6_, z6_, t7, u7, w8_, z8_;                                  \
+        uint64_t v1 = 0, v2 = 0, v3 = 0, v4 = 0;                                                                    \
+        FS_SCALED_STEP(w0, z0, t1, u1, a##S, v1, false, (void)0, (S##0).x, (S##0).y, (S##0).z);                           \
+        FS_SCALED_STEP(t1, u1, w2_, z2_, b##S, v1, true, (void)0, (S##1).x, (S##1).y, (S##1).z);                          \
+        FS_SCALED_STEP(w2_, z2_, t3, u3, c##S, v2, false, (void)0, (S##2).x, (S##2).y, (S##2).z);                         \
+        FS_SCALED_STEP(t3, u3, w4_, z4_, d##S, v2, true, (void)0, (S##3).x, (S##3).y, (S##3).z);                          \
+        if (v1 != 0ull) {                                                                                           \
+            wO = w0, failed = true;                                                                                 \
+            break;                                                                                                  \
+        }                                                                                                           \
+        FS_SCALED_STEP(w4_, z4_, t5, u5, e##S, v3, false, (void)0, (S##4).x, (S##4).y, (S##4).z);                         \
+        FS_SCALED_STEP(t5, u5, w6_, z6_, f##S, v3, true, (void)0, (S##5).x, (S##5).y, (S##5).z);                          \
+        if (v2 != 0ull) {                                                                                           \
+            wO = w2_, failed = true, c += 2;                                                                        \
+            break;                                                                                                  \
+        }                                                                                                           \
+        FS_SCALED_STEP(w6_, z6_, t7, u7, g##S, v4, false, (void)0, (S##6).x, (S##6).y, (S##6).z);                         \
+        FS_SCALED_STEP(t7, u7, w8_, z8_, h##S, v4, true, (void)0, (S##7).x, (S##7).y, (S##7).z);                          \
+        if (v3 != 0ull) {                                                                                           \
+            wO = w4_, failed = true, c += 4;                                                                        \
+            break;                                                                                                  \
+        }                                                                                                           \
+        if (v4 != 0ull) {                                                                                           \
+            wO = w6_, failed = true, c += 6;                                                                        \
+            break;                                                                                                  \
+        }                                                                                                           \
+        c += 8;                                                                                                     \
+        zpu += 8;                                                                                                   \
+        w0 = w8_, z0 = z8_;                                                                                         \
+        if (c >= run_len) {                                                                                         \
+            wO = w0, failed = false;                                                                                \
+            break;                                                                                                  \
+        }                                                                                                           \
+    }
+                        FS_SLOAD8(a, zpu)
                         for (;;) {
-                            f4 ua, ub, uc, ud, ue, uf, ug, uh; // eight entries (two 64-byte lines) per body, one wait
-                            asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(ua) : "s"(zpu));
-                            asm volatile("s_load_dwordx4 %0, %1, 0x10" : "=s"(ub) : "s"(zpu));
-                            asm volatile("s_load_dwordx4 %0, %1, 0x20" : "=s"(uc) : "s"(zpu));
-                            asm volatile("s_load_dwordx4 %0, %1, 0x30" : "=s"(ud) : "s"(zpu));
-                            asm volatile("s_load_dwordx4 %0, %1, 0x40" : "=s"(ue) : "s"(zpu));
-                            asm volatile("s_load_dwordx4 %0, %1, 0x50" : "=s"(uf) : "s"(zpu));
-                            asm volatile("s_load_dwordx4 %0, %1, 0x60" : "=s"(ug) : "s"(zpu));
-                            asm volatile("s_load_dwordx4 %0, %1, 0x70" : "=s"(uh) : "s"(zpu));
-                            f2 t1, u1;
-                            uint64_t v1 = 0;
-                            FS_SCALED_STEP(w0, z0, t1, u1, a, v1, false,
-                                           asm volatile("s_waitcnt lgkmcnt(0)"
-                                                        : "+s"(ua), "+s"(ub), "+s"(uc), "+s"(ud), "+s"(ue), "+s"(uf),
-                                                          "+s"(ug), "+s"(uh), "+v"(mx_a)),
-                                           ua.x, ua.y, ua.z);
-                            FS_SCALED_STEP(t1, u1, w2, z2, b, v1, true, (void)0, ub.x, ub.y, ub.z);
-                            if (v1 != 0ull) {
-                                wO = w0, failed = true;
-                                break;
-                            }
-                            c += 2;
-                            f2 t3, u3;
-                            uint64_t v2 = 0;
-                            FS_SCALED_STEP(w2, z2, t3, u3, c_, v2, false, (void)0, uc.x, uc.y, uc.z);
-                            FS_SCALED_STEP(t3, u3, w0, z0, d, v2, true, (void)0, ud.x, ud.y, ud.z);
-                            if (v2 != 0ull) {
-                                wO = w2, failed = true;
-                                break;
-                            }
-                            c += 2;
-                            f2 t5, u5;
-                            uint64_t v3 = 0;
-                            FS_SCALED_STEP(w0, z0, t5, u5, e, v3, false, (void)0, ue.x, ue.y, ue.z);
-                            FS_SCALED_STEP(t5, u5, w2, z2, f, v3, true, (void)0, uf.x, uf.y, uf.z);
-                            if (v3 != 0ull) {
-                                wO = w0, failed = true;
-                                break;
-                            }
-                            c += 2;
-                            f2 t7, u7;
-                            uint64_t v4 = 0;
-                            FS_SCALED_STEP(w2, z2, t7, u7, g, v4, false, (void)0, ug.x, ug.y, ug.z);
-                            FS_SCALED_STEP(t7, u7, w0, z0, h, v4, true, (void)0, uh.x, uh.y, uh.z);
-                            if (v4 != 0ull) {
-                                wO = w2, failed = true;
-                                break;
-                            }
-                            c += 2;
-                            zpu += 8;
-                            if (c >= run_len) {
-                                wO = w0, failed = false;
-                                break;
-                            }
+                            FS_SBODY(a, b)
+                            FS_SBODY(b, a)
                         }
+                        // whichever body the run left from, the other set's request may still be in flight: it lands
+                        // before its registers are used for anything else
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(a5), "s"(a6),
+                                     "s"(a7), "s"(b0), "s"(b1), "s"(b2), "s"(b3), "s"(b4), "s"(b5), "s"(b6), "s"(b7));
+#undef FS_SBODY
+#undef FS_SWAIT8
+#undef FS_SLOAD8
                     } else {
                         const uint32_t lane_off = (RefIteration + 1) * 16u;
                         const float4 *zp = zs;
@@ -1813,8 +1830,11 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                         DeltaSubNY = hreal<F>{__builtin_amdgcn_ldexpf(wO.y, -ky), E + ky};
                         RefIteration += c;
                         iter += c;
-                        if (kStats)
+                        if (kStats) {
                             c_pt += c;
+                            c_la += c; // (no BLA on this path: the slot carries the scaled steps)
+                            c_runs++;
+                        }
                         Zcached_at = 0xFFFFFFFFu;
                     }
                     if (failed) {
@@ -2033,8 +2053,10 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                                 Zne > -(1 << 26) && RefIteration + 1 < count;
                 if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) {
                     done_fast = true;
-                    if (kStats)
+                    if (kStats) {
                         c_pt++;
+                        c_single++;
+                    }
                     ++RefIteration;
                     Zcached = hcplx<F>{zn4.x, zn4.y, Zne};
                     Zcached_at = RefIteration;
@@ -2119,8 +2141,11 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
         if constexpr (!kRefill)
             break;
     }
-    if (kStats)
-        add_stats(A.stats, 0, c_la, c_pt, c_px);
+    if (kStats) {
+        add_stats(A.stats, c_single, c_la, c_pt, c_px);
+        if (!kBla)
+            atomicAdd((unsigned long long *)&A.stats[7], (unsigned long long)c_runs);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -153,7 +153,9 @@ hipError_t make_quiet_orbit(fs_renderer *r, uint64_t n)
         (void)hipFree(r->zq);
         r->zq = nullptr;
     }
-    hipError_t err = hipMalloc((void **)&r->zq, 2 * (n + 2) * sizeof(float4)); // two companions back to back
+    // two companions back to back; the scaled runs request their entries one 8-entry body ahead, so the second one may be
+    // read up to 16 entries past its end (never used)
+    hipError_t err = hipMalloc((void **)&r->zq, (2 * (n + 2) + 16) * sizeof(float4));
     if (err != hipSuccess)
         return err;
     r->zq_n = n + 2;
