@@ -1705,9 +1705,11 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                         // set, and have the whole body to arrive (two bodies per loop trip, sets A and B).  A wave that is
                         // alone on its SIMD -- the interior pixels' 4.7 M-step chains that decide C2's frame time -- no
                         // longer stalls on an L2 round trip every eight steps.
-                        // The exit test of a trip is branched on one trip late (its two steps' tests then overlap the next
-                        // trip's arithmetic instead of standing between two dependent chains); a failing trip costs one
-                        // wasted trip, and the states are named per trip so the roll-back needs no copy.
+                        // The exit tests of a body's four trips are branched on ONCE, after the body (their compares and votes
+                        // then sit between the arithmetic of later steps instead of standing, with a branch each, between
+                        // two dependent chains); the states are named per trip, so the roll-back to the first failing
+                        // trip's start needs no copy, and a failing body costs at most six wasted steps -- runs of the
+                        // pixels this loop is shaped for average 227 steps.
                         const float4 *zpu = zs + ref_u + 1;
                         f4 a0, a1, a2, a3, a4, a5, a6, a7, b0, b1, b2, b3, b4, b5, b6, b7;
 #define FS_SLOAD8(S, P)                                                                                             \
@@ -1728,35 +1730,32 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
         FS_SLOAD8(NEXT, zpu + 8)                                                                                    \
         f2 t1, u1, w2_, z2_, t3, u3, w4_, z4_, t5, u5, w6_, z6_, t7, u7, w8_, z8_;                                  \
         uint64_t v1 = 0, v2 = 0, v3 = 0, v4 = 0;                                                                    \
-        FS_SCALED_STEP(w0, z0, t1, u1, a##S, v1, false, (void)0, (S##0).x, (S##0).y, (S##0).z);                           \
-        FS_SCALED_STEP(t1, u1, w2_, z2_, b##S, v1, true, (void)0, (S##1).x, (S##1).y, (S##1).z);                          \
-        FS_SCALED_STEP(w2_, z2_, t3, u3, c##S, v2, false, (void)0, (S##2).x, (S##2).y, (S##2).z);                         \
-        FS_SCALED_STEP(t3, u3, w4_, z4_, d##S, v2, true, (void)0, (S##3).x, (S##3).y, (S##3).z);                          \
-        if (v1 != 0ull) {                                                                                           \
-            wO = w0, failed = true;                                                                                 \
-            break;                                                                                                  \
-        }                                                                                                           \
-        FS_SCALED_STEP(w4_, z4_, t5, u5, e##S, v3, false, (void)0, (S##4).x, (S##4).y, (S##4).z);                         \
-        FS_SCALED_STEP(t5, u5, w6_, z6_, f##S, v3, true, (void)0, (S##5).x, (S##5).y, (S##5).z);                          \
-        if (v2 != 0ull) {                                                                                           \
-            wO = w2_, failed = true, c += 2;                                                                        \
-            break;                                                                                                  \
-        }                                                                                                           \
-        FS_SCALED_STEP(w6_, z6_, t7, u7, g##S, v4, false, (void)0, (S##6).x, (S##6).y, (S##6).z);                         \
-        FS_SCALED_STEP(t7, u7, w8_, z8_, h##S, v4, true, (void)0, (S##7).x, (S##7).y, (S##7).z);                          \
-        if (v3 != 0ull) {                                                                                           \
-            wO = w4_, failed = true, c += 4;                                                                        \
-            break;                                                                                                  \
-        }                                                                                                           \
-        if (v4 != 0ull) {                                                                                           \
-            wO = w6_, failed = true, c += 6;                                                                        \
+        FS_SCALED_STEP(w0, z0, t1, u1, a##S, v1, false, (void)0, (S##0).x, (S##0).y, (S##0).z);                     \
+        FS_SCALED_STEP(t1, u1, w2_, z2_, b##S, v1, true, (void)0, (S##1).x, (S##1).y, (S##1).z);                    \
+        FS_SCALED_STEP(w2_, z2_, t3, u3, c##S, v2, false, (void)0, (S##2).x, (S##2).y, (S##2).z);                   \
+        FS_SCALED_STEP(t3, u3, w4_, z4_, d##S, v2, true, (void)0, (S##3).x, (S##3).y, (S##3).z);                    \
+        FS_SCALED_STEP(w4_, z4_, t5, u5, e##S, v3, false, (void)0, (S##4).x, (S##4).y, (S##4).z);                   \
+        FS_SCALED_STEP(t5, u5, w6_, z6_, f##S, v3, true, (void)0, (S##5).x, (S##5).y, (S##5).z);                    \
+        FS_SCALED_STEP(w6_, z6_, t7, u7, g##S, v4, false, (void)0, (S##6).x, (S##6).y, (S##6).z);                   \
+        FS_SCALED_STEP(t7, u7, w8_, z8_, h##S, v4, true, (void)0, (S##7).x, (S##7).y, (S##7).z);                    \
+        if (((v1 | v2) | (v3 | v4)) != 0ull) {                                                                      \
+            /* the first failing trip ends the run at its start state (later trips ran on whatever it produced) */  \
+            failed = true;                                                                                          \
+            if (v1 != 0ull)                                                                                         \
+                wO = w0;                                                                                            \
+            else if (v2 != 0ull)                                                                                    \
+                wO = w2_, c += 2;                                                                                   \
+            else if (v3 != 0ull)                                                                                    \
+                wO = w4_, c += 4;                                                                                   \
+            else                                                                                                    \
+                wO = w6_, c += 6;                                                                                   \
             break;                                                                                                  \
         }                                                                                                           \
         c += 8;                                                                                                     \
         zpu += 8;                                                                                                   \
         w0 = w8_, z0 = z8_;                                                                                         \
         if (c >= run_len) {                                                                                         \
-            wO = w0, failed = false;                                                                                \
+            failed = false;                                                                                         \
             break;                                                                                                  \
         }                                                                                                           \
     }
@@ -1765,6 +1764,8 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                             FS_SBODY(a, b)
                             FS_SBODY(b, a)
                         }
+                        if (!failed)
+                            wO = w0;
                         // whichever body the run left from, the other set's request may still be in flight: it lands
                         // before its registers are used for anything else
                         asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(a5), "s"(a6),
