@@ -82,6 +82,12 @@ def _render_flags():
     return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", *extra]
 
 
+# Per-unit flags.  kernels_scaled.hip: the scalar float expressions of the reference's scaled kernel are written out
+# operation by operation; the SLP vectorizer pairs them into packed instructions with register shuffles around them, which
+# costs more than the two-operand scalar forms it replaces (the pairs that pay are written as float2 in the source).
+_UNIT_FLAGS = {"kernels_scaled.hip": ["-fno-slp-vectorize"]}
+
+
 def _inputs_sources():
     return [os.path.join(HOST, "refinputs.cpp"), os.path.join(CSRC, "hdr_math.hpp"), os.path.join(CSRC, "la_math.hpp"),
             os.path.join(CSRC, "df32_math.hpp"),
@@ -94,7 +100,7 @@ _INPUTS_FLAGS = ["-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 def up_to_date():
     """True when both libraries exist and were built from the current sources (no compiler is started)."""
     units = [u for u in _render_units() if os.path.exists(u)]
-    return (_stamp_ok(LIB_RENDER, _digest(units + _render_headers(), _render_flags())) and
+    return (_stamp_ok(LIB_RENDER, _digest(units + _render_headers(), _render_flags() + [repr(sorted(_UNIT_FLAGS.items()))])) and
             _stamp_ok(LIB_INPUTS, _digest(_inputs_sources(), _INPUTS_FLAGS)))
 
 
@@ -102,7 +108,7 @@ def build_render(force=False):
     units = [u for u in _render_units() if os.path.exists(u)]
     headers = _render_headers()
     flags = _render_flags()
-    digest = _digest(units + headers, flags)
+    digest = _digest(units + headers, flags + [repr(sorted(_UNIT_FLAGS.items()))])
     if not force and _stamp_ok(LIB_RENDER, digest):
         return LIB_RENDER
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -111,12 +117,13 @@ def build_render(force=False):
 
     def compile_unit(src):
         obj = os.path.join(OBJ, os.path.basename(src) + ".o")
-        d = _digest([src], [hdr_digest])
+        unit_flags = _UNIT_FLAGS.get(os.path.basename(src), [])
+        d = _digest([src], [hdr_digest, *unit_flags])
         if force or not _stamp_ok(obj, d):
             # renderer.cpp / group.cpp are host-only C++ that include HIP runtime headers: compiled by hipcc as HIP so
             # that <hip/hip_runtime.h> types (float4, hipStream_t) match the kernels' launchers
             lang = [] if src.endswith(".hip") else ["-x", "hip"]
-            _run([hipcc, *flags, "-c", *lang, src, "-o", obj])
+            _run([hipcc, *flags, *unit_flags, "-c", *lang, src, "-o", obj])
             _write_stamp(obj, d)
         return obj
 

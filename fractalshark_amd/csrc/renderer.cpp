@@ -1561,9 +1561,12 @@ uint32_t fs_upload_orbit_scaled(fs_renderer *r, int type_tag, uint32_t iter_byte
     r->scaled_count = 0;
     const size_t t_bytes = type_tag == FS_T_HDR32 ? sizeof(fs_orbit_hdr32_bad) : sizeof(fs_orbit_f64_bad);
     FS_TRY(hipMalloc(&r->scaled_t, orbit_size * t_bytes));
-    FS_TRY(hipMalloc((void **)&r->scaled_f, orbit_size * sizeof(fs_orbit_f32_bad)));
+    // (the tuned kernel requests its binary32 entries four steps ahead: up to three entries past the end are read, never used)
+    FS_TRY(hipMalloc((void **)&r->scaled_f, (orbit_size + 8) * sizeof(fs_orbit_f32_bad)));
+    FS_TRY(hipMemsetAsync(r->scaled_f + orbit_size, 0, 8 * sizeof(fs_orbit_f32_bad), r->compute));
     FS_TRY(hipMemcpyAsync(r->scaled_t, entries_t, orbit_size * t_bytes, hipMemcpyDefault, r->compute));
     FS_TRY(hipMemcpyAsync(r->scaled_f, entries_f32, orbit_size * sizeof(fs_orbit_f32_bad), hipMemcpyDefault, r->compute));
+    fsk_scaled_bounds(r->scaled_f, orbit_size, r->compute); // the tuned kernel's per-entry bound, in the padding word
     FS_TRY(hipStreamSynchronize(r->compute)); // host buffers are borrowed for the call only
     r->scaled_count = orbit_size;
     r->scaled_type = type_tag;
@@ -1612,7 +1615,7 @@ uint32_t fs_render_scaled(fs_renderer *r, int type_tag, const void *coords, uint
     A.n_iterations = (uint32_t)n_iterations;
     A.w2threshold = w2threshold;
     TimedLaunch t(r);
-    fsk_scaled_hdr32(A, r->stats_on, r->compute);
+    fsk_scaled_hdr32(A, r->stats_on, r->variant, r->compute);
     return (uint32_t)hipGetLastError();
 }
 

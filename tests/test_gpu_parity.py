@@ -539,6 +539,38 @@ def test_scaled_hdr32_view14_deep_zoom(renderer, native_libs, w, h, aa):
                                                                          rst["float_steps"])
 
 
+@pytest.mark.parametrize("view_n,w,h,n", [(5, 320, 180, None), (14, 96, 54, 1800000), (3, 128, 72, None)])
+def test_scaled_hdr32_tuned_equals_literal(renderer, native_libs, view_n, w, h, n):
+    """The tuned scaled kernel (runs of binary32 steps whose outcome tests are implied by a per-entry bound) against the
+    statement-for-statement kernel (FS_VARIANT_LITERAL) on larger frames than the oracle is run on: same frame, same
+    rescale / full-precision / binary32 step counts."""
+    v = inputs.View.builtin(view_n, w, h, antialiasing=1)
+    ob = inputs.Orbit(v)
+    n = v.num_iterations if n is None else n
+    r = renderer
+    assert r.InitializeMemory(w, h, 1, None, 0, 0, 0, False) == 0
+    dx, dy, cx, cy = _pairs(v.coords_perturb(ob))
+    outs, stats = [], []
+    try:
+        for variant in (1, 0):  # literal, tuned
+            assert r.set_kernel_variant(variant) == 0
+            assert r.ClearMemory() == 0
+            r.enable_step_count(True)
+            assert r.RenderPerturbBLAScaled(None, ob, ob, None, None, dx, dy, cx, cy, n) == 0
+            out = r.new_iter_buffer()
+            assert r.RenderCurrent(n, out) == 0
+            assert r.SyncComputeStream() == 0
+            st = r.read_step_count()
+            r.enable_step_count(False)
+            outs.append(out)
+            stats.append((st["at_iterations"], st["la_steps"], st["perturb_steps"]))
+    finally:
+        r.set_kernel_variant(0)
+    assert np.array_equal(outs[0], outs[1])
+    assert stats[0] == stats[1]
+    assert stats[0][2] > 0
+
+
 # ---- SURVEY 8(f) row 1: LA table built on the device (fs_build_la) == the golden-pinned host builder in its
 # single-threaded form (LAReference.cpp:28-210,774-966,1050-1074), bit for bit: every record of every stage, the stage
 # table, ATInfo and the UseAT decision -- and the frame rendered from the device-built table equals the fixture
