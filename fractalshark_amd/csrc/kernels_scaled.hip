@@ -209,7 +209,9 @@ template <bool kStats> __global__ void __launch_bounds__(256) k_scaled_hdr32(FsS
 // whole wave and every lane takes one step through the literal code, which decides exactly.  Lanes whose iteration limit
 // is near are kept out of the runs by a vote on the steps left (runs of 256 / 64 / 16 steps, scaled_run_length in
 // kernels.hip does the same).  The entry of a step is one 16-byte load per lane, requested four steps ahead from a
-// wave-uniform base plus a per-lane byte offset that is fixed for the run.
+// wave-uniform base plus a per-lane byte offset that is fixed for the run.  (Entries through the scalar cache when the lanes
+// share their orbit position, which pays in k_lav2_hdr32_fast, does not here: 325 vs 315 ms on View 14, whose runs
+// average 37 steps -- profiles/patches/r02_t_*.)
 template <bool kStats> __global__ void __launch_bounds__(256) k_scaled_hdr32_fast(FsScaledArgs32 A)
 {
     typedef float f4 __attribute__((ext_vector_type(4)));
