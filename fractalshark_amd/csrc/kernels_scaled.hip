@@ -427,8 +427,11 @@ template <bool kStats> __global__ void __launch_bounds__(256) k_scaled_hdr32_fas
 #undef FS_RESCALE
         store_iter(A.out, A.frame, L, X, iter);
     }
-    if (kStats)
+    if (kStats) {
         add_stats(A.stats, c_rescale, c_full, c_float, c_px);
+        atomicAdd((unsigned long long *)&A.stats[6], (unsigned long long)c_fast); // probes (tools/scaled_kernel_probe.py):
+        atomicAdd((unsigned long long *)&A.stats[7], (unsigned long long)c_runs); // lane-steps inside runs, runs
+    }
         atomicAdd((unsigned long long *)&A.stats[6], (unsigned long long)c_fast); // probes: lane-steps inside runs, runs
         atomicAdd((unsigned long long *)&A.stats[7], (unsigned long long)c_runs);
         (void)0;
@@ -454,7 +457,7 @@ template <bool kStats> __global__ void __launch_bounds__(256) k_scaled_f64(FsSca
 {
     const uint32_t X = blockIdx.x * 64u + (threadIdx.x & 63u);
     const uint32_t L = blockIdx.y * 4u + (threadIdx.x >> 6);
-    uint64_t c_rescale = 0, c_full = 0, c_float = 0, c_px = 0;
+    uint64_t c_rescale = 0, c_full = 0, c_float = 0, c_px = 0, c_fast = 0, c_runs = 0;
     const uint32_t Y = global_row(A.frame, L);
     const bool live = X < A.frame.width && L < A.frame.local_rows && Y < A.frame.height;
     if (live) {
