@@ -228,7 +228,7 @@ void fsk_lav2_plain(const FsLav2ArgsPlain &A, int kind, int mode, bool stats, hi
 bool fsk_direct_lp(const FsDirectLpArgs &A, int kind, int iteration_precision, bool stats, hipStream_t s);
 void fsk_scaled_hdr32(const FsScaledArgs32 &A, bool stats, int variant, hipStream_t s);
 void fsk_scaled_bounds(fs_orbit_f32_bad *of, uint64_t n, hipStream_t s); // tuned kernel: per-entry bound into .padding
-void fsk_scaled_f64(const FsScaledArgsF64 &A, bool stats, hipStream_t s);
+void fsk_scaled_f64(const FsScaledArgsF64 &A, bool stats, int variant, hipStream_t s);
 // BLA table build on the device: levels[l] = device memory for epl[l] records (NULL below the first materialised level 2)
 void fsk_bla_build_hdr32(const float4 *zref, void *const *levels, const uint64_t *epl, int n_levels, fs_real_hdr32 bla_size,
                          hipStream_t s);

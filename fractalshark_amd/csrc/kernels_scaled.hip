@@ -189,6 +189,76 @@ template <bool kStats> __global__ void __launch_bounds__(256) k_scaled_hdr32(FsS
         add_stats(A.stats, c_rescale, c_full, c_float, c_px);
 }
 
+// One wave-voted run of binary32 steps (see the tuned kernel below): from orbit entry `ref` (whose binary32 value is
+// cfx, cfy) at most run_len steps, stopping before the first step that ANY running lane of the wave fails.  Returns the
+// number of steps taken; w and the entry values are advanced.  Every running lane of the wave must call it together.
+__device__ __forceinline__ uint32_t scaled_run(const fs_orbit_f32_bad *__restrict__ of, uint32_t ref, uint32_t run_len,
+                                               float &wX, float &wY, float &cfx, float &cfy, float s, float twos, float dcX,
+                                               float dcY)
+{
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const uint32_t lane_off = (ref + 1u) * 16u;
+    const f4 *zp = (const f4 *)of;
+    uint32_t c = 0;
+    f2 o = {wX, wY}, e = {cfx, cfy};
+    const f2 two2 = {2.0f, 2.0f}, s2 = {s, s}, dc2 = {dcX, dcY};
+#define FS_SC_LOAD(OFS, T, PIN)                                                                                     \
+    asm volatile("global_load_dwordx4 %0, %2, %3 offset:" OFS : "=v"(ent_##T), "+v"(PIN) : "v"(lane_off), "s"(zp));
+    // One step from O against entry E into N; WAIT orders the arrival entry's load.  The reference's expressions,
+    // operation by operation, with the operations that come in pairs issued as packed ones (the same IEEE operation on
+    // each half):
+    //   wX' = ((ox ex) 2 - (oy ey) 2 + (s ox) ox - (s oy) oy) + dX      wY' = (ox (ey 2 + twos oy) + (oy ex) 2) + dY
+    //   P = (o * e) * 2 = (t1, t2),  Q = (s * o) * o = (t3, t4),  wX' = ((t1 - t2) + t3) - t4 + dX
+#define FS_SC_STEP(O, E, N, T, WAIT)                                                                                 \
+    const f2 P_##T = (O * E) * two2;                                                                                 \
+    const f2 Q_##T = (s2 * O) * O;                                                                                   \
+    const float c_##T = ((P_##T.x - P_##T.y) + Q_##T.x) - Q_##T.y;                                                   \
+    const float u_##T = O.x * (E.y * 2 + twos * O.y) + O.y * E.x * 2;                                                \
+    const f2 N = (f2){c_##T, u_##T} + dc2;                                                                           \
+    float mx_##T = __builtin_fmaxf(__builtin_fabsf(N.x), __builtin_fabsf(N.y));                                      \
+    WAIT;                                                                                                            \
+    const bool ok_##T = mx_##T * s <= ent_##T.y && mx_##T < 0x1p24f;
+    f4 ent_a, ent_b, ent_c, ent_d; // {bad, bound, x, y}
+    for (;;) {
+        FS_SC_LOAD("0", a, o.x)
+        FS_SC_LOAD("16", b, o.x)
+        FS_SC_LOAD("32", c, o.x)
+        FS_SC_LOAD("48", d, o.x)
+        FS_SC_STEP(o, e, n1, a, asm volatile("s_waitcnt vmcnt(3)" : "+v"(ent_a), "+v"(mx_a)))
+        if (__builtin_amdgcn_ballot_w64(!ok_a) != 0ull)
+            break;
+        const f2 e1 = {ent_a.z, ent_a.w};
+        FS_SC_STEP(n1, e1, n2, b, asm volatile("s_waitcnt vmcnt(2)" : "+v"(ent_b), "+v"(mx_b)))
+        if (__builtin_amdgcn_ballot_w64(!ok_b) != 0ull) {
+            o = n1, e = e1, c += 1;
+            break;
+        }
+        const f2 e2 = {ent_b.z, ent_b.w};
+        FS_SC_STEP(n2, e2, n3, c, asm volatile("s_waitcnt vmcnt(1)" : "+v"(ent_c), "+v"(mx_c)))
+        if (__builtin_amdgcn_ballot_w64(!ok_c) != 0ull) {
+            o = n2, e = e2, c += 2;
+            break;
+        }
+        const f2 e3 = {ent_c.z, ent_c.w};
+        FS_SC_STEP(n3, e3, n4, d, asm volatile("s_waitcnt vmcnt(0)" : "+v"(ent_d), "+v"(mx_d)))
+        if (__builtin_amdgcn_ballot_w64(!ok_d) != 0ull) {
+            o = n3, e = e3, c += 3;
+            break;
+        }
+        o = n4, e = (f2){ent_d.z, ent_d.w}, c += 4;
+        zp += 4;
+        if (c >= run_len)
+            break;
+    }
+    // a run that ends early leaves loads in flight: they land before anything else happens
+    asm volatile("s_waitcnt vmcnt(0) ; scaled-kernel run, loop exit" ::"v"(ent_a), "v"(ent_b), "v"(ent_c), "v"(ent_d));
+#undef FS_SC_STEP
+#undef FS_SC_LOAD
+    wX = o.x, wY = o.y, cfx = e.x, cfy = e.y;
+    return c;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Tuned form of the same kernel (the default; the kernel above stays as FS_VARIANT_LITERAL, the A/B reference).
 //
@@ -214,7 +284,6 @@ template <bool kStats> __global__ void __launch_bounds__(256) k_scaled_hdr32(FsS
 // average 37 steps -- profiles/patches/r02_t_*.)
 template <bool kStats> __global__ void __launch_bounds__(256) k_scaled_hdr32_fast(FsScaledArgs32 A)
 {
-    typedef float f4 __attribute__((ext_vector_type(4)));
     uint32_t X, L;
     tile_pixel(X, L);
     uint64_t c_rescale = 0, c_full = 0, c_float = 0, c_px = 0, c_fast = 0, c_runs = 0;
@@ -266,67 +335,9 @@ template <bool kStats> __global__ void __launch_bounds__(256) k_scaled_hdr32_fas
             {
                 const uint32_t run_len = scaled_run_length_dev(n_iterations - iter);
                 if (__builtin_amdgcn_ballot_w64(cf_bad != 0u) == 0ull && run_len != 0u) {
-                    const uint32_t lane_off = (RefIteration + 1u) * 16u;
-                    const f4 *zp = (const f4 *)of;
-                    uint32_t c = 0;
-                    typedef float f2 __attribute__((ext_vector_type(2)));
-                    f2 o = {wX, wY}, e = {cfx, cfy};
-                    const f2 two2 = {2.0f, 2.0f}, s2 = {s, s}, dc2 = {DeltaSub0DX, DeltaSub0DY};
-#define FS_SC_LOAD(OFS, T, PIN)                                                                                     \
-    asm volatile("global_load_dwordx4 %0, %2, %3 offset:" OFS : "=v"(ent_##T), "+v"(PIN) : "v"(lane_off), "s"(zp));
-                    // one step from (OX, OY) against entry (EX, EY) into (NX, NY); WAIT orders the arrival entry's load
-                    // The reference's expressions, operation by operation, with the operations that come in pairs issued as
-                    // packed ones (same IEEE operation on each half):
-                    //   wX' = ((ox ex) 2 - (oy ey) 2 + (s ox) ox - (s oy) oy) + dX      wY' = (ox (ey 2 + twos oy) + (oy ex) 2) + dY
-                    //   P = (o * e) * 2 = (t1, t2),  Q = (s * o) * o = (t3, t4),  wX' = ((t1 - t2) + t3) - t4 + dX
-#define FS_SC_STEP(O, E, N, T, WAIT)                                                                                 \
-    const f2 P_##T = (O * E) * two2;                                                                                 \
-    const f2 Q_##T = (s2 * O) * O;                                                                                   \
-    const float c_##T = ((P_##T.x - P_##T.y) + Q_##T.x) - Q_##T.y;                                                   \
-    const float u_##T = O.x * (E.y * 2 + twos * O.y) + O.y * E.x * 2;                                                \
-    const f2 N = (f2){c_##T, u_##T} + dc2;                                                                           \
-    float mx_##T = __builtin_fmaxf(__builtin_fabsf(N.x), __builtin_fabsf(N.y));                                      \
-    WAIT;                                                                                                            \
-    const bool ok_##T = mx_##T * s <= ent_##T.y && mx_##T < 0x1p24f;
-                    f4 ent_a, ent_b, ent_c, ent_d; // {bad, bound, x, y}
-                    for (;;) {
-                        FS_SC_LOAD("0", a, o.x)
-                        FS_SC_LOAD("16", b, o.x)
-                        FS_SC_LOAD("32", c, o.x)
-                        FS_SC_LOAD("48", d, o.x)
-                        FS_SC_STEP(o, e, n1, a, asm volatile("s_waitcnt vmcnt(3)" : "+v"(ent_a), "+v"(mx_a)))
-                        if (__builtin_amdgcn_ballot_w64(!ok_a) != 0ull)
-                            break;
-                        const f2 e1 = {ent_a.z, ent_a.w};
-                        FS_SC_STEP(n1, e1, n2, b, asm volatile("s_waitcnt vmcnt(2)" : "+v"(ent_b), "+v"(mx_b)))
-                        if (__builtin_amdgcn_ballot_w64(!ok_b) != 0ull) {
-                            o = n1, e = e1, c += 1;
-                            break;
-                        }
-                        const f2 e2 = {ent_b.z, ent_b.w};
-                        FS_SC_STEP(n2, e2, n3, c, asm volatile("s_waitcnt vmcnt(1)" : "+v"(ent_c), "+v"(mx_c)))
-                        if (__builtin_amdgcn_ballot_w64(!ok_c) != 0ull) {
-                            o = n2, e = e2, c += 2;
-                            break;
-                        }
-                        const f2 e3 = {ent_c.z, ent_c.w};
-                        FS_SC_STEP(n3, e3, n4, d, asm volatile("s_waitcnt vmcnt(0)" : "+v"(ent_d), "+v"(mx_d)))
-                        if (__builtin_amdgcn_ballot_w64(!ok_d) != 0ull) {
-                            o = n3, e = e3, c += 3;
-                            break;
-                        }
-                        o = n4, e = (f2){ent_d.z, ent_d.w}, c += 4;
-                        zp += 4;
-                        if (c >= run_len)
-                            break;
-                    }
-                    // a run that ends early leaves loads in flight: they land before anything else happens
-                    asm volatile("s_waitcnt vmcnt(0) ; scaled-kernel run, loop exit" ::"v"(ent_a), "v"(ent_b), "v"(ent_c), "v"(ent_d));
-#undef FS_SC_STEP
-#undef FS_SC_LOAD
+                    const uint32_t c = scaled_run(of, RefIteration, run_len, wX, wY, cfx, cfy, s, twos, DeltaSub0DX, DeltaSub0DY);
                     if (c != 0u) {
-                        wX = o.x, wY = o.y;
-                        cfx = e.x, cfy = e.y, cf_bad = 0u; // an entry a run arrived at is not `bad`
+                        cf_bad = 0u; // an entry a run arrived at is not `bad`
                         RefIteration += c;
                         cf_at = RefIteration;
                         iter += c;
@@ -573,6 +584,155 @@ template <bool kStats> __global__ void __launch_bounds__(256) k_scaled_f64(FsSca
         add_stats(A.stats, c_rescale, c_full, c_float, c_px);
 }
 
+// Tuned form of k_scaled_f64: the same wave-voted runs of binary32 steps as k_scaled_hdr32_fast (the binary32 step does not
+// depend on T), 8 x 8 pixel tiles per wave; the literal kernel above stays as FS_VARIANT_LITERAL.
+template <bool kStats> __global__ void __launch_bounds__(256) k_scaled_f64_fast(FsScaledArgsF64 A)
+{
+    uint32_t X, L;
+    tile_pixel(X, L);
+    uint64_t c_rescale = 0, c_full = 0, c_float = 0, c_px = 0, c_fast = 0, c_runs = 0;
+    const uint32_t Y = global_row(A.frame, L);
+    const bool live = X < A.frame.width && L < A.frame.local_rows && Y < A.frame.height;
+    if (live) {
+        c_px = 1;
+        const uint32_t n_iterations = A.n_iterations;
+        const uint32_t MaxRefIteration = A.orbit_count - 1;
+        const fs_orbit_f64_bad *__restrict__ ot = A.orbit_t;
+        const fs_orbit_f32_bad *__restrict__ of = A.orbit_f;
+        uint32_t iter = 0, RefIteration = 0;
+        const double DeltaReal = A.dx * (double)(int)X - A.centerX;
+        const double DeltaImaginary = -A.dy * (double)(int)Y - A.centerY;
+        double S = __builtin_sqrt(DeltaReal * DeltaReal + DeltaImaginary * DeltaImaginary);
+        float DeltaSub0DX = (float)(DeltaReal / S);
+        float DeltaSub0DY = (float)(DeltaImaginary / S);
+        float wX = 0.0f, wY = 0.0f;
+        float s = (float)S;
+        float twos = 2 * s;
+        const float w2threshold = A.w2threshold;
+
+#define FS_RESCALE64(NX, NY)                                                                                            \
+    do {                                                                                                                \
+        S = __builtin_sqrt((NX) * (NX) + (NY) * (NY));                                                                  \
+        s = (float)S;                                                                                                   \
+        twos = 2 * s;                                                                                                   \
+        DeltaSub0DX = (float)(DeltaReal / S);                                                                           \
+        DeltaSub0DY = (float)(DeltaImaginary / S);                                                                      \
+        wX = (float)((NX) / S);                                                                                         \
+        wY = (float)((NY) / S);                                                                                         \
+    } while (0)
+
+        float cfx = of[0].x, cfy = of[0].y; // the entry the next step multiplies by ...
+        uint32_t cf_bad = of[0].bad;
+        uint32_t cf_at = 0;                 // ... and the orbit index it was loaded from
+        while (iter < n_iterations) {
+            if (cf_at != RefIteration) {
+                const fs_orbit_f32_bad e = of[RefIteration];
+                cfx = e.x, cfy = e.y, cf_bad = e.bad;
+                cf_at = RefIteration;
+            }
+            // ---- runs of binary32 steps whose tests are implied (k_scaled_hdr32_fast)
+            {
+                const uint32_t run_len = scaled_run_length_dev(n_iterations - iter);
+                if (__builtin_amdgcn_ballot_w64(cf_bad != 0u) == 0ull && run_len != 0u) {
+                    const uint32_t c = scaled_run(of, RefIteration, run_len, wX, wY, cfx, cfy, s, twos, DeltaSub0DX, DeltaSub0DY);
+                    if (c != 0u) {
+                        cf_bad = 0u;
+                        RefIteration += c;
+                        cf_at = RefIteration;
+                        iter += c;
+                        if (kStats)
+                            c_float += c;
+                        if (iter >= n_iterations)
+                            break;
+                    }
+                }
+            }
+            // ---- one step through the literal code
+            if (cf_bad == 0) {
+                const float ox = wX, oy = wY;
+                wX = ox * cfx * 2 - oy * cfy * 2 + s * ox * ox - s * oy * oy + DeltaSub0DX;
+                wY = ox * (cfy * 2 + twos * oy) + oy * cfx * 2 + DeltaSub0DY;
+                if (kStats)
+                    c_float++;
+                ++RefIteration;
+                const fs_orbit_f32_bad nf = of[RefIteration];
+                cfx = nf.x, cfy = nf.y, cf_bad = nf.bad;
+                cf_at = RefIteration;
+                const float tempZX = nf.x + wX * s;
+                const float tempZY = nf.y + wY * s;
+                const float zn_size = tempZX * tempZX + tempZY * tempZY;
+                const float w2 = wX * wX + wY * wY;
+                const float normDeltaSubN = w2 * s * s;
+                const bool zn_size_OK = zn_size < 256.0f;
+                const bool test1a = zn_size < normDeltaSubN;
+                const bool test1b = RefIteration == MaxRefIteration;
+                const bool test1ab = test1a || (test1b && zn_size_OK);
+                const bool testw2 = (w2 >= w2threshold) && zn_size_OK;
+                const bool none = !test1ab && !testw2 && zn_size_OK;
+                if (none) {
+                    ++iter;
+                    continue;
+                } else if (test1ab) {
+                    const double ZX = ot[RefIteration].x + (double)wX * S;
+                    const double ZY = ot[RefIteration].y + (double)wY * S;
+                    RefIteration = 0;
+                    FS_RESCALE64(ZX, ZY);
+                    if (kStats)
+                        c_rescale++;
+                    ++iter;
+                    continue;
+                } else if (testw2) {
+                    const double ZX = (double)wX * S;
+                    const double ZY = (double)wY * S;
+                    FS_RESCALE64(ZX, ZY);
+                    if (kStats)
+                        c_rescale++;
+                    ++iter;
+                    continue;
+                } else {
+                    break;
+                }
+            } else {
+                const double ox = (double)wX, oy = (double)wY;
+                const double cxr = ot[RefIteration].x, cyr = ot[RefIteration].y;
+                double nX = ox * cxr * 2;
+                nX -= oy * cyr * 2;
+                nX += S * ox * ox;
+                nX -= S * oy * oy;
+                nX += DeltaReal / S;
+                double nY = ox * (cyr * 2 + 2.0 * S * oy);
+                nY += oy * cxr * 2;
+                nY += DeltaImaginary / S;
+                if (kStats)
+                    c_full++;
+                ++RefIteration;
+                const double tempZX = ot[RefIteration].x + nX * S;
+                const double tempZY = ot[RefIteration].y + nY * S;
+                const double zn_size = tempZX * tempZX + tempZY * tempZY;
+                if (!(zn_size < 256.0))
+                    break;
+                const double TwoS = S * S;
+                const double normDeltaSubN = nX * nX * TwoS + nY * nY * TwoS;
+                double NewX, NewY;
+                if (zn_size < normDeltaSubN || RefIteration == MaxRefIteration) {
+                    NewX = ot[RefIteration].x + nX * S;
+                    NewY = ot[RefIteration].y + nY * S;
+                    RefIteration = 0;
+                } else {
+                    NewX = nX * S;
+                    NewY = nY * S;
+                }
+                FS_RESCALE64(NewX, NewY);
+            }
+            ++iter;
+        }
+#undef FS_RESCALE64
+        store_iter(A.out, A.frame, L, X, iter);
+    }
+    if (kStats)
+        add_stats(A.stats, c_rescale, c_full, c_float, c_px);
+}
+
 } // namespace
 
 void fsk_scaled_hdr32(const FsScaledArgs32 &A, bool stats, int variant, hipStream_t s)
@@ -597,12 +757,20 @@ void fsk_scaled_bounds(fs_orbit_f32_bad *of, uint64_t n, hipStream_t s)
     hipLaunchKernelGGL(k_scaled_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, of, n);
 }
 
-void fsk_scaled_f64(const FsScaledArgsF64 &A, bool stats, hipStream_t s)
+void fsk_scaled_f64(const FsScaledArgsF64 &A, bool stats, int variant, hipStream_t s)
 {
     const dim3 b(256);
-    const dim3 g((A.frame.width + 63) / 64, (A.frame.local_rows + 3) / 4);
-    if (stats)
-        hipLaunchKernelGGL((k_scaled_f64<true>), g, b, 0, s, A);
-    else
-        hipLaunchKernelGGL((k_scaled_f64<false>), g, b, 0, s, A);
+    if (variant == FS_VARIANT_LITERAL) {
+        const dim3 g((A.frame.width + 63) / 64, (A.frame.local_rows + 3) / 4);
+        if (stats)
+            hipLaunchKernelGGL((k_scaled_f64<true>), g, b, 0, s, A);
+        else
+            hipLaunchKernelGGL((k_scaled_f64<false>), g, b, 0, s, A);
+    } else {
+        const dim3 g((A.frame.width + 31) / 32, (A.frame.local_rows + 7) / 8); // tile_pixel()
+        if (stats)
+            hipLaunchKernelGGL((k_scaled_f64_fast<true>), g, b, 0, s, A);
+        else
+            hipLaunchKernelGGL((k_scaled_f64_fast<false>), g, b, 0, s, A);
+    }
 }

@@ -1600,7 +1600,7 @@ uint32_t fs_render_scaled(fs_renderer *r, int type_tag, const void *coords, uint
         A.n_iterations = (uint32_t)n_iterations;
         A.w2threshold = w2threshold;
         TimedLaunch t(r);
-        fsk_scaled_f64(A, r->stats_on, r->compute);
+        fsk_scaled_f64(A, r->stats_on, r->variant, r->compute);
         return (uint32_t)hipGetLastError();
     }
     FsScaledArgs32 A;

@@ -775,6 +775,28 @@ def test_scaled_f64_matches_restated_cuda_kernel(renderer, native_libs):
     assert np.median(d) <= 16 and (d <= 2).mean() > 0.25
 
 
+def test_scaled_f64_tuned_equals_literal(renderer, native_libs):
+    v = inputs.View.builtin(5, 320, 180)
+    ob = inputs.OrbitF64(v)
+    r = renderer
+    assert r.InitializeMemory(320, 180, 1, None, 0, 0, 0, False) == 0
+    co = ob.coords()
+    outs = []
+    try:
+        for variant in (1, 0):  # literal, tuned
+            assert r.set_kernel_variant(variant) == 0
+            assert r.ClearMemory() == 0
+            assert r.RenderPerturbBLAScaled(None, ob, ob, None, None, co[0], co[1], co[2], co[3], v.num_iterations,
+                                            T=T_F64) == 0
+            out = r.new_iter_buffer()
+            assert r.RenderCurrent(v.num_iterations, out) == 0
+            assert r.SyncComputeStream() == 0
+            outs.append(out)
+    finally:
+        r.set_kernel_variant(0)
+    assert np.array_equal(outs[0], outs[1]) and outs[0].any()
+
+
 # ---- more built-in views: different depths (2^-60 ... 2^-2400), periods (59 ... 52 860), stage counts (1 ... 12)
 @pytest.mark.parametrize("view_n", [2, 3, 9, 11])
 @pytest.mark.parametrize("is64", [False, True])
