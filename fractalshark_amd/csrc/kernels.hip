@@ -127,36 +127,51 @@ __device__ __forceinline__ void at_perform(const hcplx<F> c, const hreal<F> esc,
                 T = esc.m * pow2_normal<F>(te < -fbits<F>::kBias + 2 ? -fbits<F>::kBias + 2 : te);
             const F min_normal = pow2_normal<F>(-fbits<F>::kBias + 1);
             bool literal = te < -fbits<F>::kBias + 2;
-            if (__builtin_amdgcn_ballot_w64(k != 0) == 0ull) {
-                // every lane of the wave has 1 <= |c| < 2: P is 1 and x * 1 is x, bit for bit -- two multiplications less
-                while (!literal && i < ATMaxIt) {
-                    const F rr = re * re, ii = im * im;
-                    const F m = rr + ii;
-                    if (!(m >= min_normal)) {
-                        literal = true;
-                        break;
-                    }
-                    if (m > T)
-                        break;
-                    const F ri = re * im;
-                    re = (rr - ii) + c.re;
-                    im = (ri + ri) + c.im;
-                    i++;
+            // Loop shape.  The lanes that are in this loop all entered it at i = 1 and take one iteration per trip, so the
+            // iteration number is ONE wave-uniform counter on the scalar unit.  A lane that is done (its norm left the
+            // normal range or passed the radius) is NOT masked off: the wave keeps iterating all its lanes -- a finished
+            // lane's z runs on into infinity or NaN, which nothing reads -- and the lane's state is recorded once, on the
+            // trip it finishes (a wave-uniform branch on the vote of the lanes finishing now: at most 64 such trips per
+            // wave against thousands of iterations).  Per iteration that leaves 8 arithmetic instructions, two compares and
+            // a handful of scalar ones; the first form of this loop -- the two tests as divergent breaks, a per-lane
+            // counter -- spent 17 scalar instructions per iteration on EXEC bookkeeping.
+            if (!literal && i < ATMaxIt) {
+                IterT it = 1;                                               // wave-uniform
+                uint64_t pending = __builtin_amdgcn_ballot_w64(true);       // lanes still iterating (a lane mask, scalar)
+                F xre = re, xim = im, xm = min_normal;
+                IterT xi = ATMaxIt;
+#define FS_AT_LOOP(SCALE)                                                                                           \
+    for (;;) {                                                                                                      \
+        const F rr = re * re, ii = im * im;                                                                         \
+        const F m = rr + ii;                                                                                        \
+        const uint64_t fin = (__builtin_amdgcn_ballot_w64(!(m >= min_normal)) | __builtin_amdgcn_ballot_w64(m > T)) \
+                             & pending;                                                                             \
+        if (fin != 0ull) {                                                                                          \
+            if (__builtin_amdgcn_inverse_ballot_w64(fin))                                                           \
+                xre = re, xim = im, xm = m, xi = it;                                                                \
+            pending &= ~fin;                                                                                        \
+            if (pending == 0ull)                                                                                    \
+                break;                                                                                              \
+        }                                                                                                           \
+        const F ri = re * im;                                                                                       \
+        re = (rr - ii) SCALE + c.re;                                                                                \
+        im = (ri + ri) SCALE + c.im;                                                                                \
+        if (++it >= ATMaxIt) {                                                                                      \
+            if (__builtin_amdgcn_inverse_ballot_w64(pending))                                                       \
+                xre = re, xim = im, xi = ATMaxIt; /* took its last iteration (xm stays normal: not literal) */      \
+            break;                                                                                                  \
+        }                                                                                                           \
+    }
+                if (__builtin_amdgcn_ballot_w64(k != 0) == 0ull) {
+                    // every lane of the wave has 1 <= |c| < 2: P is 1 and x * 1 is x, bit for bit -- two multiplications less
+                    FS_AT_LOOP()
+                } else {
+                    FS_AT_LOOP(*P)
                 }
-            }
-            while (!literal && i < ATMaxIt) {
-                const F rr = re * re, ii = im * im;
-                const F m = rr + ii;
-                if (!(m >= min_normal)) {
-                    literal = true;
-                    break;
-                }
-                if (m > T)
-                    break;
-                const F ri = re * im;
-                re = (rr - ii) * P + c.re;
-                im = (ri + ri) * P + c.im;
-                i++;
+#undef FS_AT_LOOP
+                re = xre, im = xim, i = xi;
+                // finished through the norm test with a norm that is not a normal number: the literal loop continues from here
+                literal = i < ATMaxIt && !(xm >= min_normal);
             }
             z = hcplx<F>{re, im, k};
             if (!literal) {
