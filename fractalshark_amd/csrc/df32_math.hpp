@@ -162,6 +162,58 @@ template <> FS_HD void hc_reduce<df32>(hcplx<df32> &a)
     a.e += old;
 }
 
+
+#if defined(__HIPCC__)
+// Two double-floats side by side (device code only): the SAME operation sequences as df32's operators above, applied to both
+// halves of packed binary32 registers (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 are the IEEE operations of their scalar
+// forms on each half), so .lo() / .hi() of a result are bit for bit what the df32 operator gives for the corresponding
+// operands.  Used where the reference's arithmetic has two independent double-float operations of the same kind next to
+// each other -- the real and imaginary part of a complex step.
+struct df32x2 {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 head, tail;
+    __device__ __forceinline__ df32x2() = default;
+    __device__ __forceinline__ df32x2(f2 h, f2 t) : head(h), tail(t) {}
+    __device__ __forceinline__ df32x2(df32 a, df32 b) : head{a.head, b.head}, tail{a.tail, b.tail} {}
+    __device__ __forceinline__ df32 lo() const { return df32(head.x, tail.x); }
+    __device__ __forceinline__ df32 hi() const { return df32(head.y, tail.y); }
+    __device__ __forceinline__ df32x2 swapped() const { return df32x2(head.yx, tail.yx); }
+    // (-lo, hi): negation of a double-float is exact, and `x - y` is the IEEE operation `x + (-y)` (operator- above)
+    __device__ __forceinline__ df32x2 neg_lo() const { return df32x2((f2){-head.x, head.y}, (f2){-tail.x, tail.y}); }
+};
+
+// add_dblflt on both halves (operator+ above, line for line)
+__device__ __forceinline__ df32x2 operator+(df32x2 a, df32x2 b)
+{
+    typedef df32x2::f2 f2;
+    f2 t1 = a.head + b.head;
+    f2 t2 = t1 - a.head;
+    f2 t3 = (a.head + (t2 - t1)) + (b.head - t2);
+    f2 t4 = a.tail + b.tail;
+    t2 = t4 - a.tail;
+    const f2 t5 = (a.tail + (t2 - t4)) + (b.tail - t2);
+    t3 = t3 + t4;
+    t4 = t1 + t3;
+    t3 = (t1 - t4) + t3;
+    t3 = t3 + t5;
+    const f2 e = t4 + t3;
+    return df32x2(e, (t4 - e) + t3);
+}
+
+// mul_dblflt on both halves (operator* above, line for line)
+__device__ __forceinline__ df32x2 operator*(df32x2 a, df32x2 b)
+{
+    typedef df32x2::f2 f2;
+    const f2 th = a.head * b.head;
+    f2 tt = __builtin_elementwise_fma(a.head, b.head, -th);
+    tt = __builtin_elementwise_fma(a.tail, b.tail, tt);
+    tt = __builtin_elementwise_fma(a.head, b.tail, tt);
+    tt = __builtin_elementwise_fma(a.tail, b.head, tt);
+    const f2 e = th + tt;
+    return df32x2(e, (th - e) + tt);
+}
+#endif
+
 using hreal2x32 = hreal<df32>;
 using hcplx2x32 = hcplx<df32>;
 static_assert(sizeof(hreal2x32) == 12 && sizeof(hcplx2x32) == 20, "2x32 records");

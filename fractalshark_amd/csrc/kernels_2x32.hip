@@ -92,32 +92,41 @@ template <int Mode, bool kStats> __global__ void __launch_bounds__(256) k_lav2_2
                         const int32_t E = c.e;
                         const int32_t nsq_e = E << 1;
                         df32 re = z.re, im = z.im;
+                        // Real and imaginary part side by side in packed registers (df32x2: the same operation sequences on
+                        // both halves): (rr, ii) is one packed product, (re im, im re) another, (rr - ii, re im + im re) one
+                        // packed sum with the first half's second operand negated, (+ c.re, + c.im) another -- 56 packed
+                        // instructions and the 35 scalar ones of the norm test instead of 147 scalar ones per iteration.
+                        df32x2 zz(re, im);
                         if (E == 0) {
                             const df32 mul0 = multiplier<df32>(0);
-                            const df32 cre = c.re * mul0, cim = c.im * mul0;
+                            const df32x2 cc(c.re * mul0, c.im * mul0);
                             for (; i < ATMaxIt; i++) {
-                                const df32 rr = re * re, ii = im * im;
-                                HR nsq{rr + ii, nsq_e};
+                                const df32x2 sq = zz * zz; // (rr, ii)
+                                HR nsq{sq.lo() + sq.hi(), nsq_e};
                                 hr_reduce(nsq);
                                 if (hr_cmp_pos(nsq, esc) > 0)
                                     break;
-                                const df32 im2 = (re * im) + (im * re);
-                                re = (rr - ii) + cre;
-                                im = im2 + cim;
+                                const df32x2 cr = zz * zz.swapped();                            // (re im, im re)
+                                const df32x2 lhs(df32x2::f2{sq.head.x, cr.head.x}, df32x2::f2{sq.tail.x, cr.tail.x}); // (rr, re im)
+                                const df32x2 rhs(df32x2::f2{sq.head.y, cr.head.y}, df32x2::f2{sq.tail.y, cr.tail.y}); // (ii, im re)
+                                zz = (lhs + rhs.neg_lo()) + cc; // ((rr - ii) + cre, (re im + im re) + cim)
                             }
                         } else {
                             const df32 mul = multiplier<df32>(E);
+                            const df32x2 mm(mul, mul), cc(c.re, c.im);
                             for (; i < ATMaxIt; i++) {
-                                const df32 rr = re * re, ii = im * im;
-                                HR nsq{rr + ii, nsq_e};
+                                const df32x2 sq = zz * zz;
+                                HR nsq{sq.lo() + sq.hi(), nsq_e};
                                 hr_reduce(nsq);
                                 if (hr_cmp_pos(nsq, esc) > 0)
                                     break;
-                                const df32 im2 = (re * im) + (im * re);
-                                re = (rr - ii) * mul + c.re;
-                                im = im2 * mul + c.im;
+                                const df32x2 cr = zz * zz.swapped();
+                                const df32x2 lhs(df32x2::f2{sq.head.x, cr.head.x}, df32x2::f2{sq.tail.x, cr.tail.x});
+                                const df32x2 rhs(df32x2::f2{sq.head.y, cr.head.y}, df32x2::f2{sq.tail.y, cr.tail.y});
+                                zz = (lhs + rhs.neg_lo()) * mm + cc;
                             }
                         }
+                        re = zz.lo(), im = zz.hi();
                         z = HC{re, im, E};
                         break;
                     }
