@@ -43,7 +43,7 @@ WORKLOADS = {  # name: (view, width, height, tag in config.workload, dominant ke
     "c5_bla": (19, 7680, 4320, "hdrx32_bla", "k_perturb_scalar"),
     "c4_hdr64": (14, 3840, 2160, "hdrx64_lav2_full_aa4", "k_lav2_lit<double>"),
     "c4_2x32": (14, 3840, 2160, "hdrx2x32_lav2_full_aa4", "k_lav2_2x32"),
-    "c4_scaled": (14, 3840, 2160, "hdrx32_scaled_aa1_itercap", "k_scaled_hdr32"),
+    "c4_scaled": (14, 3840, 2160, "hdrx32_scaled_aa1_itercap", "k_scaled_hdr32_fast"),
 }
 
 
