@@ -2044,15 +2044,8 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                 const float nxm = __int_as_float((qxb & 0x807FFFFF) | 0x3F800000);
                 const float nym = __int_as_float((qyb & 0x807FFFFF) | 0x3F800000);
                 const int nxe = EQ + fx - 127, nye = EQ + fy - 127;
-                // z = Z' + n under ez
-                const int Zne = __float_as_int(zn4.z);
-                const int ez = imax(imax(Zne, nxe), nye);
-                const float zsZ = p2(Zne - ez);
-                const f2 zsc = {p2(nxe - ez), p2(nye - ez)};
-                const f2 Zt = (f2){zn4.x, zn4.y} * (f2){zsZ, zsZ} + (f2){nxm, nym} * zsc; // (tempZX.m, tempZY.m), exponent ez
-                const f2 ZZ = Zt * Zt;
-                const float nm = ZZ.x + ZZ.y; // exponent 2*ez
                 // dn = nx^2 + ny^2
+                const int Zne = __float_as_int(zn4.z);
                 const f2 SQ = (f2){nxm, nym} * (f2){nxm, nym};
                 const int dd = (nxe - nye) << 1;
                 const bool sxbig = dd >= 0;
@@ -2060,13 +2053,48 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                 const float md = p2(nadd);
                 const float dnm = SQ.x * (sxbig ? 1.0f : md) + SQ.y * (sxbig ? md : 1.0f);
                 const int dne = (sxbig ? nxe : nye) << 1;
-                // every sum inside [2^-60, 2^60] (also excludes zeros, denormals, infinities and NaNs)
-                const float smx = fmaxf(fmaxf(fmaxf(fabsf(T.x), fabsf(T.y)), fmaxf(fabsf(N.x), fabsf(N.y))),
-                                        fmaxf(fmaxf(fabsf(Q.x), fabsf(Q.y)), fmaxf(fabsf(Zt.x), fabsf(Zt.y))));
-                const float smn = fminf(fminf(fminf(fabsf(T.x), fabsf(T.y)), fminf(fabsf(N.x), fabsf(N.y))),
-                                        fminf(fminf(fabsf(Q.x), fabsf(Q.y)), fminf(fabsf(Zt.x), fabsf(Zt.y))));
-                const bool ok = smn >= 0x1p-60f && smx <= 0x1p60f && (OX.e < OY.e ? OX.e : OY.e) > -(1 << 26) &&
-                                Zne > -(1 << 26) && RefIteration + 1 < count;
+                // the sums of the dz update inside [2^-60, 2^60] (also excludes zeros, denormals, infinities and NaNs)
+                const float dmx = fmaxf(fmaxf(fmaxf(fabsf(T.x), fabsf(T.y)), fmaxf(fabsf(N.x), fabsf(N.y))),
+                                        fmaxf(fabsf(Q.x), fabsf(Q.y)));
+                const float dmn = fminf(fminf(fminf(fabsf(T.x), fabsf(T.y)), fminf(fabsf(N.x), fabsf(N.y))),
+                                        fminf(fabsf(Q.x), fabsf(Q.y)));
+                const bool ok_dz = dmn >= 0x1p-60f && dmx <= 0x1p60f && (OX.e < OY.e ? OX.e : OY.e) > -(1 << 26) &&
+                                   Zne > -(1 << 26) && RefIteration + 1 < count;
+                // Quiet step: both parts of the new dz at least four binades below the orbit value it arrives at (whose
+                // larger part is in [0.5, 2) 2^Zne), and that value below 4: |dz'| < 2^(Zne - 2.5) = 0.177 * 2^Zne <=
+                // 0.354 |Z'|, so |z| = |Z' + dz'| is in [0.646, 1.354] |Z'| -- |z|^2 >= 3.3 |dz'|^2 (the rebase test cannot
+                // fire) and |z|^2 < 59 for Zne <= 1 (nor the escape test).  z and its norm are then not formed at all; when
+                // every stepping lane of the wave is in this state that is a quarter of the step's instructions.
+                const bool quiet = imax(nxe, nye) <= Zne - 4 && Zne <= 1 && Zne >= -40 && RefIteration + 2 < count;
+                if (__builtin_amdgcn_ballot_w64(!(ok_dz && quiet)) == 0ull) {
+                    done_fast = true;
+                    if (kStats) {
+                        c_pt++;
+                        c_single++;
+                    }
+                    ++RefIteration;
+                    Zcached = hcplx<F>{zn4.x, zn4.y, Zne};
+                    Zcached_at = RefIteration;
+                    DeltaSubNX = hreal<F>{nxm, nxe};
+                    DeltaSubNY = hreal<F>{nym, nye};
+                    {
+                        const int db = __float_as_int(dnm);
+                        DeltaNormSquared = hreal<F>{__int_as_float((db & 0x007FFFFF) | 0x3F800000),
+                                                    dne + (int)__builtin_amdgcn_ubfe(db, 23, 8) - 127};
+                    }
+                    ++iter;
+                    continue;
+                }
+                // z = Z' + n under ez
+                const int ez = imax(imax(Zne, nxe), nye);
+                const float zsZ = p2(Zne - ez);
+                const f2 zsc = {p2(nxe - ez), p2(nye - ez)};
+                const f2 Zt = (f2){zn4.x, zn4.y} * (f2){zsZ, zsZ} + (f2){nxm, nym} * zsc; // (tempZX.m, tempZY.m), exponent ez
+                const f2 ZZ = Zt * Zt;
+                const float nm = ZZ.x + ZZ.y; // exponent 2*ez
+                const float smx = fmaxf(fabsf(Zt.x), fabsf(Zt.y));
+                const float smn = fminf(fabsf(Zt.x), fabsf(Zt.y));
+                const bool ok = ok_dz && smn >= 0x1p-60f && smx <= 0x1p60f;
                 if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) {
                     done_fast = true;
                     if (kStats) {
