@@ -54,6 +54,40 @@ __device__ __forceinline__ bool below_bailout(HR n)
     return !(n.m >= df32(256.0f));
 }
 
+
+// The complex operations of the LA step with the real and the imaginary part side by side in packed registers (df32x2:
+// the df32 operation sequences on both halves at once).  Same operations in the same order per part as hc_mul / hc_add /
+// hc_mul2 of hdr_math.hpp with F = df32 (a double-float difference is the sum with the negated operand, df32_math.hpp).
+__device__ __forceinline__ HC hc_mul_pk(HC a, HC b)
+{
+    const df32x2 P = df32x2(a.re, a.re) * df32x2(b.re, b.im); // (a.re b.re, a.re b.im)
+    const df32x2 Q = df32x2(a.im, a.im) * df32x2(b.im, b.re); // (a.im b.im, a.im b.re)
+    const df32x2 R = P + Q.neg_lo();                          // (a.re b.re - a.im b.im, a.re b.im + a.im b.re)
+    return HC{R.lo(), R.hi(), clamp_exp(a.e + b.e)};
+}
+__device__ __forceinline__ HC hc_add_pk(HC a, HC b)
+{
+    const int32_t d = a.e - b.e;
+    if (d >= kExpDiffIgnored) {
+        return a;
+    } else if (d >= 0) {
+        const df32 mul = multiplier<df32>(-d);
+        const df32x2 R = df32x2(a.re, a.im) + df32x2(b.re, b.im) * df32x2(mul, mul);
+        return HC{R.lo(), R.hi(), a.e};
+    } else if (d > -kExpDiffIgnored) {
+        const df32 mul = multiplier<df32>(d);
+        const df32x2 R = df32x2(a.re, a.im) * df32x2(mul, mul) + df32x2(b.re, b.im);
+        return HC{R.lo(), R.hi(), b.e};
+    }
+    return b;
+}
+__device__ __forceinline__ HC hc_mul2_pk(HC a)
+{
+    const df32 one(1.0f);
+    const df32x2 R = df32x2(a.re, a.im) * df32x2(one, one);
+    return HC{R.lo(), R.hi(), clamp_exp(a.e + 1)};
+}
+
 template <int Mode, bool kStats> __global__ void __launch_bounds__(256) k_lav2_2x32(FsLav2Args2x32 A)
 {
     uint32_t X, L;
@@ -97,15 +131,27 @@ template <int Mode, bool kStats> __global__ void __launch_bounds__(256) k_lav2_2
                         // packed sum with the first half's second operand negated, (+ c.re, + c.im) another -- 56 packed
                         // instructions and the 35 scalar ones of the norm test instead of 147 scalar ones per iteration.
                         df32x2 zz(re, im);
+                        // The bailout test -- a double-float sum of the two squares, Reduce, a lexicographic compare: as many
+                        // instructions as the rest of the iteration -- only decides "norm above the radius or not", and the
+                        // norm is not used otherwise.  The float sum of the squares' heads is within 2^-21 (relative) of the
+                        // double-float norm, so when it is below the radius by more than that (esc_low: the radius in the
+                        // norm's scale, times 1 - 2^-16) the exact test would say "not above" and is skipped; otherwise
+                        // (close to the radius, or not a number) the exact test runs and decides as before.
+                        const int32_t esc_sh = esc.e - nsq_e;
+                        const float esc_low = esc_sh > 120 ? __builtin_inff()
+                                              : esc_sh < -120 ? 0.0f
+                                                              : __builtin_amdgcn_ldexpf(esc.m.head, esc_sh) * 0.9999847412109375f;
                         if (E == 0) {
                             const df32 mul0 = multiplier<df32>(0);
                             const df32x2 cc(c.re * mul0, c.im * mul0);
                             for (; i < ATMaxIt; i++) {
                                 const df32x2 sq = zz * zz; // (rr, ii)
-                                HR nsq{sq.lo() + sq.hi(), nsq_e};
-                                hr_reduce(nsq);
-                                if (hr_cmp_pos(nsq, esc) > 0)
-                                    break;
+                                if (!(sq.head.x + sq.head.y < esc_low)) { // (see esc_low)
+                                    HR nsq{sq.lo() + sq.hi(), nsq_e};
+                                    hr_reduce(nsq);
+                                    if (hr_cmp_pos(nsq, esc) > 0)
+                                        break;
+                                }
                                 const df32x2 cr = zz * zz.swapped();                            // (re im, im re)
                                 const df32x2 lhs(df32x2::f2{sq.head.x, cr.head.x}, df32x2::f2{sq.tail.x, cr.tail.x}); // (rr, re im)
                                 const df32x2 rhs(df32x2::f2{sq.head.y, cr.head.y}, df32x2::f2{sq.tail.y, cr.tail.y}); // (ii, im re)
@@ -116,10 +162,12 @@ template <int Mode, bool kStats> __global__ void __launch_bounds__(256) k_lav2_2
                             const df32x2 mm(mul, mul), cc(c.re, c.im);
                             for (; i < ATMaxIt; i++) {
                                 const df32x2 sq = zz * zz;
-                                HR nsq{sq.lo() + sq.hi(), nsq_e};
-                                hr_reduce(nsq);
-                                if (hr_cmp_pos(nsq, esc) > 0)
-                                    break;
+                                if (!(sq.head.x + sq.head.y < esc_low)) {
+                                    HR nsq{sq.lo() + sq.hi(), nsq_e};
+                                    hr_reduce(nsq);
+                                    if (hr_cmp_pos(nsq, esc) > 0)
+                                        break;
+                                }
                                 const df32x2 cr = zz * zz.swapped();
                                 const df32x2 lhs(df32x2::f2{sq.head.x, cr.head.x}, df32x2::f2{sq.tail.x, cr.tail.x});
                                 const df32x2 rhs(df32x2::f2{sq.head.y, cr.head.y}, df32x2::f2{sq.tail.y, cr.tail.y});
@@ -160,7 +208,7 @@ template <int Mode, bool kStats> __global__ void __launch_bounds__(256) k_lav2_2
                     HC newDz = hc_zero<df32>();
                     if (iter + l <= n_iterations) {
                         // Prepare, GPU_LAInfoDeep.h:90-106
-                        newDz = hc_mul(DeltaSubN, hc_add(hc_mul2(ldc(LAj->Ref)), DeltaSubN));
+                        newDz = hc_mul_pk(DeltaSubN, hc_add_pk(hc_mul2_pk(ldc(LAj->Ref)), DeltaSubN));
                         hc_reduce(newDz);
                         unusable = hr_cmp_pos(hc_cheb(newDz), ldr(LAj->LAThreshold)) >= 0;
                     }
@@ -172,8 +220,8 @@ template <int Mode, bool kStats> __global__ void __launch_bounds__(256) k_lav2_2
                     if (kStats)
                         c_la++;
                     // Evaluate GPU_LAInfoDeep.h:120-124, getZ LAstep.h:181-185
-                    DeltaSubN = hc_add(hc_mul(newDz, ldc(LAj->ZCoeff)), hc_mul(DeltaSub0, ldc(LAj->CCoeff)));
-                    const HC complex0 = hc_add(ldc(LAj[1].Ref), DeltaSubN);
+                    DeltaSubN = hc_add_pk(hc_mul_pk(newDz, ldc(LAj->ZCoeff)), hc_mul_pk(DeltaSub0, ldc(LAj->CCoeff)));
+                    const HC complex0 = hc_add_pk(ldc(LAj[1].Ref), DeltaSubN);
                     j++;
                     const HR lhs = hr_reduced(hc_cheb(complex0));
                     const HR rhs = hr_reduced(hc_cheb(DeltaSubN));
