@@ -195,6 +195,9 @@ def inputs_lib():
     _decl(lib, "fsh_orbit_low_hdr32", None, [vp, vp])
     _decl(lib, "fsh_orbit_compressed_data_hdr64", vp, [vp])
     _decl(lib, "fsh_orbit_low_hdr64", None, [vp, vp])
+    _decl(lib, "fsh_orbit_save_im", C.c_int, [vp, u64, C.c_int, C.c_char_p, C.c_int])
+    _decl(lib, "fsh_orbit_load_im", vp, [C.c_char_p, C.POINTER(u64)])
+    _decl(lib, "fsh_orbit_is64", C.c_int, [vp])
     _decl(lib, "fsh_orbit_destroy", None, [vp])
     _decl(lib, "fsh_orbit_count", u64, [vp])
     _decl(lib, "fsh_orbit_period", u64, [vp])

@@ -748,6 +748,371 @@ void build_orbit(const fsh_view &vw, uint64_t max_iter, bool periodicity, OrbitT
 
 } // namespace
 
+// ------------------------------------------------------------------ Imagina ".im" files that carry a reference orbit
+// RefOrbitCalc::SaveOrbitResults(results, filename) (RefOrbitCalc.cpp:3039-3115) writes, after the location section
+// (header, halfH = the orbit's MaxRadius, iteration limit = MaxIterations - 1, centre), at ReferenceOffset:
+//   ReferenceHeader { bool ExtendedRange }                                                     1 B
+//   ReferenceTrivialContent { HRReal AbsolutePrecision {2, -precisionInBits}, RelativePrecision {}, ValidRadius = MaxRadius }   48 B
+//   LAReferenceTrivialContent { complex<double> Refc; size_t RefIt = count - 1, MaxIt = MaxIterations - 2; bool x4
+//                               (IsPeriodic = period != 0); ImaginaATInfo AT {}; size_t LAStageCount = 0 }                     192 B
+//   size_t n; n x { HRReal x, HRReal y, CompressionIndexField (63-bit orbit index, 1 rebase bit) }                            40 B each
+//   size_t r; r x uint64 rebase indices
+// (PerturbationResults::SaveOrbitBin, PerturbationResults.cpp:2013-2082; sizes and offsets checked against the reference's
+// headers in tests/test_im_orbit.py).  The waypoints are the orbit under "max compression" (PerturbationResults::
+// CompressMax, :1347-1640 -- the waypoint scheme of Imagina: the orbit is re-derived by perturbing it against its own
+// beginning, and a waypoint is stored where that drifts by more than sqrt(10^-CompressionErrorExp) relative, Chebyshev norm);
+// the reader rebuilds the full orbit from them (LoadOrbitBin :2104-2211, DecompressMax :1660-1840, with the backwards
+// Newton correction of every stretch between two waypoints).  Restated here for T = HDRFloat<float> ("Sharks:)" magic) and
+// HDRFloat<double> (Imagina's magic), ExtendedRange = true.
+namespace {
+
+template <class F> struct MaxWaypoints {
+    std::vector<hreal<F>> x, y;
+    std::vector<uint64_t> index;
+    std::vector<uint8_t> rebase;
+    std::vector<uint64_t> rebases;
+};
+
+template <class F> hreal<F> mc_norm(hreal<F> x, hreal<F> y)
+{
+    // HdrMaxReduced(HdrAbs(x), HdrAbs(y)) (HDRFloat.h:1477-1500: `one.compareTo(two) > 0 ? one : two`), HdrReduce
+    const hreal<F> ax = hr_abs(x), ay = hr_abs(y);
+    return hr_reduced(hr_cmp(ax, ay) > 0 ? ax : ay);
+}
+template <class F> hreal<F> mc_norm_times(hreal<F> x, hreal<F> y, hreal<F> t)
+{
+    const hreal<F> ax = hr_abs(x), ay = hr_abs(y);
+    return hr_reduced(hr_mul(hr_cmp(ax, ay) > 0 ? ax : ay, t));
+}
+// dz' = (2 Z + dz) dz in the reference's operand order (PerturbationResults.cpp:1489-1493, 1610-1614, 1842-1848)
+template <class F> void mc_dz_step(hreal<F> &dzX, hreal<F> &dzY, hreal<F> Zx, hreal<F> Zy)
+{
+    const hreal<F> Two = hr_from_number<F>(F(2));
+    const hreal<F> old = dzX;
+    dzX = hr_sub(hr_add(hr_sub(hr_mul(hr_mul(Two, Zx), dzX), hr_mul(hr_mul(Two, Zy), dzY)), hr_mul(dzX, dzX)), hr_mul(dzY, dzY));
+    hr_reduce(dzX);
+    dzY = hr_add(hr_add(hr_mul(hr_mul(Two, Zx), dzY), hr_mul(hr_mul(Two, Zy), old)), hr_mul(hr_mul(Two, old), dzY));
+    hr_reduce(dzY);
+}
+
+// PerturbationResults::CompressMax, PerturbationResults.cpp:1347-1640 (includeDummy = false)
+template <class F> MaxWaypoints<F> compress_max(const OrbitT<F> &ob, int compression_exp)
+{
+    MaxWaypoints<F> w;
+    const uint64_t count = ob.x.size();
+    const hreal<F> threshold2 = hr_from_number<F>((F)std::sqrt(std::pow(10.0, compression_exp)));
+    const hreal<F> constant1 = hr_reduced(hr_from_number<F>((F)0x1.0p-4));
+    const hreal<F> constant2 = hr_reduced(hr_from_number<F>((F)0x1.000001p0));
+    hreal<F> zx = ob.orbitXLow, zy = ob.orbitYLow;
+    auto push = [&](hreal<F> x, hreal<F> y, uint64_t i, bool rebase) {
+        w.x.push_back(x), w.y.push_back(y), w.index.push_back(i), w.rebase.push_back(rebase ? 1 : 0);
+    };
+    uint64_t i = 1;
+    for (; i < count; i++) {
+        const hreal<F> outX = ob.x[i], outY = ob.y[i];
+        const hreal<F> norm_z = mc_norm(outX, outY);
+        if (hr_cmp_pos(norm_z, constant1) < 0) {
+            zx = outX, zy = outY;
+            push(outX, outY, i, true);
+            break;
+        } else {
+            const hreal<F> err = mc_norm_times(hr_sub(zx, outX), hr_sub(zy, outY), threshold2);
+            if (hr_cmp_pos(err, norm_z) >= 0) {
+                zx = outX, zy = outY;
+                push(outX, outY, i, false);
+            }
+        }
+        rc_one_iter(zx, zy, ob.orbitXLow, ob.orbitYLow);
+    }
+    hreal<F> dzX = zx, dzY = zy;
+    uint64_t prev_waypoint = i;
+    mc_dz_step(dzX, dzY, ob.x[0], ob.y[0]);
+    i++;
+    uint64_t j = 1;
+    for (; i < count; i++, j++) {
+        const hreal<F> outXi = ob.x[i], outYi = ob.y[i];
+        hreal<F> outXj = ob.x[j], outYj = ob.y[j];
+        zx = hr_add(dzX, outXj);
+        zy = hr_add(dzY, outYj);
+        const hreal<F> norm_z_orig = mc_norm(zx, zy);
+        const hreal<F> norm_dz_orig = mc_norm_times(dzX, dzY, constant2);
+        const hreal<F> err = mc_norm_times(hr_sub(zx, outXi), hr_sub(zy, outYi), threshold2);
+        const bool condition1 = j >= prev_waypoint;
+        const bool condition2 = hr_cmp_pos(err, norm_z_orig) >= 0;
+        if (condition1 || condition2) {
+            prev_waypoint = i;
+            zx = outXi, zy = outYi;
+            dzX = hr_sub(zx, outXj);
+            dzY = hr_sub(zy, outYj);
+            const hreal<F> norm_z = mc_norm(zx, zy), norm_dz = mc_norm(dzX, dzY);
+            if (hr_cmp_pos(norm_z, norm_dz) < 0 || (i - j) * 4 < i) {
+                dzX = zx, dzY = zy;
+                j = 0;
+                push(dzX, dzY, i, true);
+            } else {
+                push(dzX, dzY, i, false);
+            }
+        } else if (hr_cmp_pos(norm_z_orig, norm_dz_orig) < 0) {
+            dzX = zx, dzY = zy;
+            j = 0;
+            if (!w.rebases.empty() && !w.index.empty() && w.rebases.back() > w.index.back())
+                w.rebases.back() = i;
+            else
+                w.rebases.push_back(i);
+        }
+        outXj = ob.x[j], outYj = ob.y[j]; // j may have changed
+        mc_dz_step(dzX, dzY, outXj, outYj);
+    }
+    return w;
+}
+
+// PerturbationResults::DecompressMax<Disable>, PerturbationResults.cpp:1660-1850.  The waypoint and rebase lists carry the
+// reader's terminators (index ~0) at their ends (LoadOrbitBin :2208-2210).
+template <class F>
+void decompress_max(const MaxWaypoints<F> &w, hreal<F> cxLow, hreal<F> cyLow, uint64_t target, std::vector<hreal<F>> &ox,
+                    std::vector<hreal<F>> &oy)
+{
+    ox.clear(), oy.clear();
+    ox.reserve(target), oy.reserve(target);
+    const hreal<F> Two = hr_from_number<F>(F(2));
+    // CorrectOrbit, :1712-1760: the stretch [begin, end) is pulled onto the waypoint by a backwards Newton step per entry
+    auto correct = [&](uint64_t begin, uint64_t end, hreal<F> diffX, hreal<F> diffY) {
+        hreal<F> dzdcX = hr_from_number<F>(F(1)), dzdcY = hr_from_number<F>(F(0));
+        hr_reduce(diffX);
+        hr_reduce(diffY);
+        for (uint64_t i = end; i > begin;) {
+            i--;
+            const hreal<F> old = dzdcX;
+            // dzdcX * Z.x * 2 - dzdcY * Z.y * 2 ; `* 2` is HDRFloat * int -> HDRFloat(int 2) = {1.0, 1}
+            dzdcX = hr_sub(hr_mul(hr_mul(dzdcX, ox[i]), Two), hr_mul(hr_mul(dzdcY, oy[i]), Two));
+            hr_reduce(dzdcX);
+            dzdcY = hr_add(hr_mul(hr_mul(old, oy[i]), Two), hr_mul(hr_mul(dzdcY, ox[i]), Two));
+            hr_reduce(dzdcY);
+            const hreal<F> den = hr_add(hr_mul(dzdcX, dzdcX), hr_mul(dzdcY, dzdcY));
+            hreal<F> resultReal = hr_div(hr_add(hr_mul(diffX, dzdcX), hr_mul(diffY, dzdcY)), den);
+            hr_reduce(resultReal);
+            hreal<F> resultImag = hr_div(hr_sub(hr_mul(diffY, dzdcX), hr_mul(diffX, dzdcY)), den);
+            hr_reduce(resultImag);
+            ox[i] = hr_reduced(hr_add(ox[i], resultReal));
+            oy[i] = hr_reduced(hr_add(oy[i], resultImag));
+        }
+    };
+    hreal<F> zx = hr_zero<F>(), zy = hr_zero<F>(); // T zx{}, zy{}
+    uint64_t wp = 0, rb = 0;
+    uint64_t next_index = w.index[0];
+    uint64_t next_rebase = w.rebases[0];
+    uint64_t i = 0, uncorrected_begin = 1;
+    for (; i < target; i++) {
+        if (i == next_index) {
+            correct(uncorrected_begin, i, hr_sub(w.x[wp], zx), hr_sub(w.y[wp], zy));
+            uncorrected_begin = i + 1;
+            zx = w.x[wp], zy = w.y[wp];
+            const bool rebase = w.rebase[wp] != 0;
+            wp++;
+            next_index = w.index[wp];
+            if (rebase)
+                break;
+        }
+        ox.push_back(zx), oy.push_back(zy);
+        rc_one_iter(zx, zy, cxLow, cyLow);
+    }
+    uint64_t j = 0;
+    hreal<F> dzX = zx, dzY = zy;
+    for (; i < target; i++, j++) {
+        zx = hr_add(dzX, ox[j]);
+        zy = hr_add(dzY, oy[j]);
+        if (i == next_index) {
+            if (w.rebase[wp]) {
+                dzX = zx, dzY = zy;
+                j = 0;
+            }
+            correct(uncorrected_begin, i, hr_sub(w.x[wp], dzX), hr_sub(w.y[wp], dzY));
+            uncorrected_begin = i + 1;
+            dzX = w.x[wp], dzY = w.y[wp];
+            zx = hr_add(dzX, ox[j]);
+            zy = hr_add(dzY, oy[j]);
+            wp++;
+            next_index = w.index[wp];
+        } else if (i == next_rebase) {
+            rb++;
+            next_rebase = w.rebases[rb];
+            dzX = zx, dzY = zy;
+            j = 0;
+        } else {
+            const hreal<F> norm_z = mc_norm(zx, zy), norm_dz = mc_norm(dzX, dzY);
+            if (hr_cmp_pos(norm_z, norm_dz) < 0) {
+                dzX = zx, dzY = zy;
+                j = 0;
+            }
+        }
+        ox.push_back(zx), oy.push_back(zy);
+        mc_dz_step(dzX, dzY, ox[j], oy[j]);
+    }
+}
+
+struct ImHR { // Imagina::HRReal = HDRFloat<double, Left, int64_t>
+    double mantissa;
+    int64_t exp;
+};
+static_assert(sizeof(ImHR) == 16, "HRReal");
+
+template <class F> ImHR im_hr(hreal<F> v) { return ImHR{(double)v.m, (int64_t)v.e}; }
+
+template <class F>
+int save_im_orbit(const OrbitT<F> &ob, uint64_t num_iterations, int compression_exp, const char *path, int exp_bytes)
+{
+    if ((exp_bytes != 4 && exp_bytes != 8) || ob.x.size() < 2)
+        return -1;
+    FILE *f = fopen(path, "wb");
+    if (!f)
+        return -1;
+    uint64_t header[4] = {sizeof(F) == 4 ? kSharksMagic : kImMagic, 0, 32, 0};
+    fwrite(header, 8, 4, f);
+    const ImHR halfH = im_hr(ob.maxRadius); // Imagina::HRReal{results.GetMaxRadius()}
+    fwrite(&halfH, sizeof(halfH), 1, f);
+    const uint64_t iteration_limit = num_iterations; // GetMaxIterations() - 1, MaxIterations = NumIterations + 1 (:859)
+    fwrite(&iteration_limit, 8, 1, f);
+    im_write_mpf(f, ob.cx.v, exp_bytes);
+    im_write_mpf(f, ob.cy.v, exp_bytes);
+    const uint64_t reference_offset = (uint64_t)ftell(f);
+    const MaxWaypoints<F> w = compress_max(ob, compression_exp);
+    const uint8_t extended_range = 1; // results.IsHDR
+    fwrite(&extended_range, 1, 1, f);
+    // ReferenceTrivialContent
+    const ImHR trivial[3] = {ImHR{2.0, -(int64_t)mpf_get_prec(ob.cx.v)}, ImHR{0.0, 0}, im_hr(ob.maxRadius)};
+    fwrite(trivial, sizeof(ImHR), 3, f);
+    // LAReferenceTrivialContent, 192 bytes: Refc @0, RefIt @16, MaxIt @24, bools @32..35 (IsPeriodic @34), AT @40, LAStageCount @184
+    unsigned char la[192];
+    memset(la, 0, sizeof(la));
+    const double refc[2] = {mpf_get_d(ob.cx.v), mpf_get_d(ob.cy.v)};
+    memcpy(la + 0, refc, 16);
+    const uint64_t ref_it = ob.x.size() - 1, max_it = num_iterations + 1 - 2;
+    memcpy(la + 16, &ref_it, 8);
+    memcpy(la + 24, &max_it, 8);
+    la[34] = ob.period != 0 ? 1 : 0;
+    fwrite(la, 1, sizeof(la), f);
+    const uint64_t n = w.x.size();
+    fwrite(&n, 8, 1, f);
+    for (uint64_t k = 0; k < n; k++) {
+        const ImHR xy[2] = {im_hr(w.x[k]), im_hr(w.y[k])};
+        fwrite(xy, sizeof(ImHR), 2, f);
+        const uint64_t field = (w.index[k] & 0x7FFFFFFFFFFFFFFFull) | ((uint64_t)w.rebase[k] << 63);
+        fwrite(&field, 8, 1, f);
+    }
+    const uint64_t r = w.rebases.size();
+    fwrite(&r, 8, 1, f);
+    if (r)
+        fwrite(w.rebases.data(), 8, r, f);
+    header[3] = reference_offset;
+    fseek(f, 0, SEEK_SET);
+    fwrite(header, 8, 4, f);
+    const bool ok = !ferror(f);
+    fclose(f);
+    return ok ? 0 : -1;
+}
+
+// the stored orbit of an open file (positioned anywhere), into ob: LoadOrbitBin + DecompressMax<Disable>
+template <class F>
+bool load_im_orbit(FILE *f, uint64_t reference_offset, OrbitT<F> &ob, uint64_t file_iteration_limit, ImHR halfH)
+{
+    if (fseek(f, (long)reference_offset, SEEK_SET) != 0)
+        return false;
+    uint8_t extended_range = 0;
+    ImHR trivial[3];
+    unsigned char la[192];
+    uint64_t n = 0;
+    if (fread(&extended_range, 1, 1, f) != 1 || fread(trivial, sizeof(ImHR), 3, f) != 3 || fread(la, 1, sizeof(la), f) != sizeof(la) ||
+        fread(&n, 8, 1, f) != 1 || !extended_range || n == 0 || n > (1ull << 32))
+        return false;
+    uint64_t ref_it;
+    memcpy(&ref_it, la + 16, 8);
+    const bool periodic = la[34] != 0;
+    MaxWaypoints<F> w;
+    for (uint64_t k = 0; k < n; k++) {
+        ImHR xy[2];
+        uint64_t field;
+        if (fread(xy, sizeof(ImHR), 2, f) != 2 || fread(&field, 8, 1, f) != 1)
+            return false;
+        w.x.push_back(hreal<F>{(F)xy[0].mantissa, (int32_t)xy[0].exp});
+        w.y.push_back(hreal<F>{(F)xy[1].mantissa, (int32_t)xy[1].exp});
+        w.index.push_back(field & 0x7FFFFFFFFFFFFFFFull);
+        w.rebase.push_back((uint8_t)(field >> 63));
+    }
+    uint64_t r = 0;
+    if (fread(&r, 8, 1, f) != 1 || r > (1ull << 32))
+        return false;
+    w.rebases.resize(r);
+    if (r && fread(w.rebases.data(), 8, r, f) != r)
+        return false;
+    // the reader's terminators (:2208-2210): {{}, {}, ~0ull, false} and ~0ull
+    w.x.push_back(hr_zero<F>()), w.y.push_back(hr_zero<F>()), w.index.push_back(0x7FFFFFFFFFFFFFFFull), w.rebase.push_back(0);
+    w.rebases.push_back(~0ull);
+    // InitResults(DontSaveForReuse, orbitX, orbitY, radius, fileProvidedIters - 1, 0), :2125-2134
+    ob.maxRadius = hr_reduced(hreal<F>{(F)halfH.mantissa, (int32_t)halfH.exp});
+    ob.orbitXLow = hr_from_mpf<F>(ob.cx.v);
+    ob.orbitYLow = hr_from_mpf<F>(ob.cy.v);
+    const uint64_t count = ref_it + 1; // m_UncompressedItersInOrbit
+    ob.period = periodic ? ref_it + 1 : 0;
+    (void)file_iteration_limit;
+    decompress_max(w, ob.orbitXLow, ob.orbitYLow, count, ob.x, ob.y);
+    ob.bad.assign(ob.x.size(), 0);
+    ob.compressed = false;
+    return ob.x.size() == count;
+}
+
+} // namespace
+
+extern "C" int fsh_orbit_save_im(const fsh_orbit *o, uint64_t num_iterations, int compression_exp, const char *path,
+                                 int exp_bytes)
+{
+    return o->is64 ? save_im_orbit<double>(o->d, num_iterations, compression_exp, path, exp_bytes)
+                   : save_im_orbit<float>(o->f, num_iterations, compression_exp, path, exp_bytes);
+}
+
+extern "C" fsh_orbit *fsh_orbit_load_im(const char *path, uint64_t *iteration_limit)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f)
+        return nullptr;
+    uint64_t header[4];
+    ImHR hh;
+    uint64_t limit = 0;
+    std::unique_ptr<fsh_orbit> out;
+    if (fread(header, 8, 4, f) == 4 && (header[0] == kImMagic || header[0] == kSharksMagic) && header[3] != 0 &&
+        fseek(f, (long)header[2], SEEK_SET) == 0 && fread(&hh, sizeof(hh), 1, f) == 1 && fread(&limit, 8, 1, f) == 1) {
+        const uint64_t precision = (uint64_t)(-std::min<int64_t>(0, hh.exp)) + 120u;
+        mpf_set_default_prec(precision);
+        Mp X(precision, 0), Y(precision, 0);
+        const long at = ftell(f);
+        int width_ok = 0;
+        for (int exp_bytes : {4, 8}) {
+            fseek(f, at, SEEK_SET);
+            if (im_read_mpf(f, X.v, exp_bytes) && im_read_mpf(f, Y.v, exp_bytes) && (uint64_t)ftell(f) == header[3]) {
+                width_ok = exp_bytes;
+                break;
+            }
+        }
+        if (width_ok) {
+            out = std::make_unique<fsh_orbit>();
+            out->is64 = header[0] == kImMagic ? 1 : 0; // SubType double <-> Imagina's magic, float <-> "Sharks:)" (:3052-3058)
+            bool ok;
+            if (out->is64) {
+                out->d.cx = X, out->d.cy = Y, out->d.prec_bits = precision;
+                ok = load_im_orbit<double>(f, header[3], out->d, limit, ImHR{hh.mantissa, hh.exp});
+            } else {
+                out->f.cx = X, out->f.cy = Y, out->f.prec_bits = precision;
+                ok = load_im_orbit<float>(f, header[3], out->f, limit, ImHR{hh.mantissa, hh.exp});
+            }
+            if (!ok)
+                out.reset();
+            else if (iteration_limit)
+                *iteration_limit = limit;
+        }
+    }
+    fclose(f);
+    return out.release();
+}
+
 extern "C" fsh_orbit *fsh_orbit_create_ex(const fsh_view *v, int is64, uint64_t max_iter, int periodicity,
                                           int compression_exp)
 {
@@ -763,6 +1128,7 @@ extern "C" fsh_orbit *fsh_orbit_create(const fsh_view *v, int is64, uint64_t max
 {
     return fsh_orbit_create_ex(v, is64, max_iter, periodicity, -1);
 }
+extern "C" int fsh_orbit_is64(const fsh_orbit *o) { return o->is64; }
 extern "C" int fsh_orbit_is_compressed(const fsh_orbit *o) { return (o->is64 ? o->d.compressed : o->f.compressed) ? 1 : 0; }
 extern "C" uint64_t fsh_orbit_compressed_count(const fsh_orbit *o)
 {

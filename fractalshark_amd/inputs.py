@@ -178,6 +178,34 @@ class Orbit:
         self.count = self._lib.fsh_orbit_count(self._h)
         self.period = self._lib.fsh_orbit_period(self._h)
 
+    @classmethod
+    def load_im(cls, path, view):
+        """The reference orbit stored in an Imagina ".im" file (RefOrbitCalc::LoadOrbitConst, RefOrbitCalc.cpp:3318-3423:
+        LoadOrbitBin + DecompressMax): rebuilt from the file's waypoints, no high-precision iteration.  `view` is the
+        view the orbit belongs to -- normally View.load_im(path, width, height).  HDRFloat<double> orbits come from
+        files with Imagina's magic, HDRFloat<float> ones from "Sharks:)" files."""
+        lib = _capi.inputs_lib()
+        limit = C.c_uint64(0)
+        h = lib.fsh_orbit_load_im(os.fsencode(path), C.byref(limit))
+        if not h:
+            raise ValueError("%s: no reference orbit this reader takes" % (path,))
+        self = cls.__new__(cls)
+        self._lib, self._h, self.view = lib, h, view
+        self.is64 = bool(lib.fsh_orbit_is64(h))
+        self.compressed = False
+        self.count = lib.fsh_orbit_count(h)
+        self.period = lib.fsh_orbit_period(h)
+        self.im_iteration_limit = int(limit.value)
+        return self
+
+    def save_im(self, path, compression_exp=20, exp_bytes=4):
+        """The view's location and this orbit under "max compression" as an Imagina ".im" file
+        (RefOrbitCalc::SaveOrbitResults(results, filename), RefOrbitCalc.cpp:3039-3115).  compression_exp: the
+        reference's Fractal::CompressionError::Low default."""
+        if self._lib.fsh_orbit_save_im(self._h, self.view.num_iterations, int(compression_exp), os.fsencode(path),
+                                       int(exp_bytes)) != 0:
+            raise OSError("could not write %s" % (path,))
+
     def __del__(self):
         if getattr(self, "_h", None):
             self._lib.fsh_orbit_destroy(self._h)

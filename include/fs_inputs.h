@@ -41,6 +41,14 @@ uint64_t fsh_view_precision_bits(const fsh_view *v);
 int fsh_view_save_im(const fsh_view *v, uint64_t iteration_limit, const char *path, int exp_bytes);
 fsh_view *fsh_view_load_im(const char *path, uint32_t width, uint32_t height, uint64_t *iteration_limit, int *has_orbit,
                            int *exp_bytes_out);
+/* ".im" files WITH a reference orbit (RefOrbitCalc::SaveOrbitResults(results, filename), RefOrbitCalc.cpp:3039-3115; the
+ * reader: LoadOrbitConst :3318-3423 -> LoadOrbitBin + DecompressMax, PerturbationResults.cpp:2104-2211,1660-1850): the
+ * location section as above, then the orbit under "max compression" (CompressMax, PerturbationResults.cpp:1347-1640;
+ * compression_exp: the reference's default is 20).  HDRFloat<float> orbits carry the "Sharks:)" magic, HDRFloat<double>
+ * ones Imagina's; ExtendedRange = true.  fsh_orbit_load_im rebuilds the full orbit from the file (no GMP iteration);
+ * files without the ExtendedRange flag (plain float / double orbits) are refused (NULL). */
+int fsh_orbit_save_im(const fsh_orbit *o, uint64_t num_iterations, int compression_exp, const char *path, int exp_bytes);
+fsh_orbit *fsh_orbit_load_im(const char *path, uint64_t *iteration_limit);
 /* which: 0=minX 1=minY 2=maxX 3=maxY; printf("%.Fe") of the squared bounding box. */
 int fsh_view_bbox_str(const fsh_view *v, int which, char *buf, size_t buflen);
 
@@ -62,6 +70,7 @@ fsh_orbit *fsh_orbit_create(const fsh_view *v, int is64, uint64_t max_iter, int 
 /* compression_exp < 0: uncompressed; >= 0: PerturbExtras::SimpleCompression with CompressionError 10^exp (default 20).
  * The uncompressed accessors (fsh_orbit_data_*, count) then expose the orbit as RuntimeDecompressor reproduces it. */
 fsh_orbit *fsh_orbit_create_ex(const fsh_view *v, int is64, uint64_t max_iter, int periodicity, int compression_exp);
+int fsh_orbit_is64(const fsh_orbit *o); /* 1: HDRFloat<double> entries, 0: HDRFloat<float> */
 int fsh_orbit_is_compressed(const fsh_orbit *o);
 uint64_t fsh_orbit_compressed_count(const fsh_orbit *o);
 const fs_orbit_hdr32_rc *fsh_orbit_compressed_data_hdr32(fsh_orbit *o);
