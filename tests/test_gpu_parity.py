@@ -775,6 +775,33 @@ def test_scaled_f64_matches_restated_cuda_kernel(renderer, native_libs):
     assert np.median(d) <= 16 and (d <= 2).mean() > 0.25
 
 
+@pytest.mark.parametrize("w,h,cap", [(70, 37, 15), (70, 37, 17), (33, 9, 300), (64, 36, 1)])
+def test_scaled_hdr32_tuned_equals_literal_small_caps_and_ragged_frames(renderer, native_libs, w, h, cap):
+    """Iteration limits around the shortest run (16 steps) and frames that are not a multiple of the 8 x 8 tile: the
+    tuned scaled kernel's run-length votes and its four-entries-ahead loads against the statement-for-statement kernel
+    and the oracle."""
+    v = inputs.View.builtin(5, w, h, antialiasing=1)
+    ob = inputs.Orbit(v)
+    r = renderer
+    assert r.InitializeMemory(w, h, 1, None, 0, 0, 0, False) == 0
+    dx, dy, cx, cy = _pairs(v.coords_perturb(ob))
+    outs = []
+    try:
+        for variant in (1, 0):
+            assert r.set_kernel_variant(variant) == 0
+            assert r.ClearMemory() == 0
+            assert r.RenderPerturbBLAScaled(None, ob, ob, None, None, dx, dy, cx, cy, cap) == 0
+            out = r.new_iter_buffer()
+            assert r.RenderCurrent(cap, out) == 0
+            assert r.SyncComputeStream() == 0
+            outs.append(out)
+    finally:
+        r.set_kernel_variant(0)
+    assert np.array_equal(outs[0], outs[1])
+    assert np.array_equal(outs[1], _oracle.gpu_scaled_hdr32(v, ob, n_iterations=cap))
+    assert not outs[1][h:, :].any() and not outs[1][:, w:].any()  # padding rows / columns stay zero
+
+
 def test_scaled_f64_tuned_equals_literal(renderer, native_libs):
     v = inputs.View.builtin(5, 320, 180)
     ob = inputs.OrbitF64(v)
