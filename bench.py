@@ -1,13 +1,19 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark: Mpix/s of the iteration buffer, View #5 at 3840x2160, HDRx32 LAv2.
 
-  python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W [--workload c3_lav2|c2_po|c5_bla|c4_hdr64|c4_2x32|c4_scaled]
+
+N > 1 is one rank per GPU under torch.distributed (backend "nccl" = RCCL).  When bench.py is started WITHOUT a launcher
+(no WORLD_SIZE / RANK in the environment) and --gpus N > 1, it starts `python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1 bench.py <same arguments>` itself, as a CHILD process, before torch is imported
+or any HIP call is made, relays the child's JSON line and exits with its code.  Started under a launcher (the driver's
+torchrun command) it is a rank.  Every workload runs at every N.
 
 One "step" = one full frame in the window SURVEY.md section 8(d) defines (the reference's m_PerPixel timer,
 Fractal.cpp:2842 -> :1539): launch of the iteration kernel -> iteration buffer resident in HOST memory.  For N > 1
-each rank renders its interleaved 8-row bands, the slices are gathered with one RCCL all-gather
-(fractalshark_amd/tiling.py), and rank 0 copies the reassembled frame to the host.  Inputs (reference orbit, LA
+each rank renders its interleaved 8-row bands, the slices are gathered to rank 0 with one RCCL gather over xGMI
+(fractalshark_amd/tiling.py: grouped send / recv, only rank 0 receives), rank 0 restores row order on the device and copies
+the frame to the host.  Inputs (reference orbit, LA
 table) are generated on the host with GMP *before* the timed region and are resident in HBM when it starts;
 `value` = W*H*K / t with t = max over ranks of the barrier-bracketed wall time.  Prints ONE JSON line on rank 0.
 
@@ -36,6 +42,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 FLOP_PER_STEP = 18            # complex dz*(2Z+dz)+dc, |Z+dz|^2, |dz|^2
 PEAK_FP32_VECTOR_TFLOPS = 157.3
 PEAK_FP64_VECTOR_TFLOPS = 78.6
+PEAK_HBM_GBS = 8000.0
+FLOP_PER_BLA_JUMP = 22
 
 WORKLOADS = {  # name: (view, width, height, tag in config.workload, dominant kernel)
     "c3_lav2": (5, 3840, 2160, "hdrx32_lav2_full", "k_lav2_hdr32_fast"),
@@ -58,6 +66,20 @@ def effective_cpus():
     except (OSError, ValueError):
         pass
     return n
+
+
+def cpu_model():
+    """Model string of the host CPU (/proc/cpuinfo) and the logical CPUs the OS reports -- the CPU baseline is only
+    interpretable next to them (boxes of the pool differ, and the container is capped well below the logical count)."""
+    model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return model, os.cpu_count() or 1
 
 
 def parse():
@@ -88,6 +110,9 @@ def parse():
     ap.add_argument("--cpu-sample-rows", type=int, default=0,
                     help="rows of the frame timed on the CPU (0 = a per-workload multiple of the usable host threads, "
                          "about 10-30 s of CPU work)")
+    ap.add_argument("--variant", default="",
+                    help="comma-separated A/B selections of fs_set_kernel_variant: literal | noscale, lds_orbit, refill "
+                         "(default: the tuned kernels)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-build", action="store_true",
@@ -95,8 +120,44 @@ def parse():
     return ap.parse_args()
 
 
+def rank_launch_command(gpus, argv, script=None, port=None):
+    """The command that runs `script` (default: this file) with `argv` as `gpus` ranks of one node, or None when this
+    process is a rank already (a launcher set WORLD_SIZE / RANK) or one rank is asked for.  Pure: no torch, no HIP."""
+    if gpus <= 1 or "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return None
+    if port is None:
+        import socket
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % gpus,
+            "--master-addr", "127.0.0.1", "--master-port", str(port), script or os.path.abspath(__file__), *argv]
+
+
+def launch_ranks(cmd):
+    """Run the rank launcher as a child and relay it: its stdout (the ONE JSON line of rank 0) goes to our stdout, its
+    stderr passes through, its exit code is ours.  The parent never imports torch nor touches the GPU (replacing a process
+    that has initialised the GPU is forbidden on the GPU pool; a child of a clean parent is always fine)."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # RCCL / IPC between the ranks needs dmabuf IPC on these hosts
+    env.setdefault("OMP_NUM_THREADS", "1")
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    lines = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.strip()]
+    json_lines = [ln for ln in lines if ln.lstrip().startswith("{")]
+    for ln in lines:
+        if ln not in json_lines:
+            print(ln, file=sys.stderr)
+    if json_lines:
+        print(json_lines[-1], flush=True)
+    return p.returncode if p.returncode != 0 or json_lines else 1
+
+
 def main():
     args = parse()
+    cmd = rank_launch_command(args.gpus, sys.argv[1:])
+    if cmd is not None:
+        sys.exit(launch_ranks(cmd))
     # stdout carries exactly ONE JSON line.  Libraries write banners there (RCCL prints its version block to stdout when the
     # first communicator comes up), so for the whole run file descriptor 1 is pointed at stderr and the real stdout is kept
     # for the result line only.
@@ -181,6 +242,13 @@ def main():
     err = r.InitializeMemory(W, H, AA, None, 0, 0, 0, False)
     assert err == 0, GPURenderer.ConvertErrorToString(err)
     T_TAG = T_HDR2X32 if is2x32 else (T_HDR64 if is64 else T_HDR32)
+    vsel = [x for x in args.variant.split(",") if x]
+    if vsel:
+        unknown = set(vsel) - {"literal", "noscale", "lds_orbit", "refill"}
+        assert not unknown, "unknown --variant entries: %s" % sorted(unknown)
+        e = r.set_kernel_variant(1 if "literal" in vsel else (2 if "noscale" in vsel else 0),
+                                 lds_orbit="lds_orbit" in vsel, refill="refill" in vsel)
+        assert e == 0, GPURenderer.ConvertErrorToString(e)
     lib = r._lib
     if is2x32:
         assert r.InitializePerturb(1, orbit2, 0, None, la2) == 0
@@ -206,7 +274,7 @@ def main():
         if r.BuildLAOnDevice(orbit) == 0:
             la_device_ms = round((time.perf_counter() - t1) * 1e3, 3)
         assert r.InitializePerturb(2, orbit, 0, None, la) == 0  # the timed frames use the uploaded host table
-    band = tiling.band_height(1)
+    band = tiling.band_height(AA)
     rw = r.rounded_width
     # the host copy of the frame (the reference's ItersMemoryContainer): page-locked so the D2H is one DMA
     rows_padded = (H + 7) // 8 * 8
@@ -216,8 +284,8 @@ def main():
         assert r.SetRowBands(rank * band, band, world * band) == 0
         max_rows = tiling.max_local_rows(H, world, band)
         local = torch.zeros((max_rows, rw), dtype=torch.int32, device="cuda")
-        gathered = torch.empty((world * max_rows, rw), dtype=torch.int32, device="cuda")
-        frame_index = torch.from_numpy(tiling.reassemble_index(H, world, band)).cuda()
+        gathered = torch.empty((world * max_rows, rw), dtype=torch.int32, device="cuda") if rank == 0 else None
+        frame_index = torch.from_numpy(tiling.reassemble_index(H, world, band)).cuda() if rank == 0 else None
         assert r.SetExternalIterBuffer(local.data_ptr(), local.numel() * local.element_size()) == 0
         render_stream = torch.cuda.ExternalStream(r.compute_stream)
     kernel_ms = []
@@ -234,9 +302,8 @@ def main():
         if distributed:
             # the gather waits for the render on the device (stream-to-stream), not through the host
             torch.cuda.current_stream().wait_stream(render_stream)
-            dist.all_gather_into_tensor(gathered, local)
+            frame = tiling.gather_frame(local, gathered, frame_index, rank, world)
             if rank == 0:
-                frame = gathered.index_select(0, frame_index)
                 host_frame_t[:frame.shape[0]].copy_(frame, non_blocking=True)
         else:
             # RenderCurrent: D2H of the padded buffer on the compute stream, behind the kernel (GPU_Render.cu:1759-1805)
@@ -343,9 +410,11 @@ def main():
             _oracle.set_row_step(1)
             return ref, dt
 
+        model, nproc = cpu_model()
+
         def line(dt, what):
             return {"value": round(len(rows) * W / dt / 1e6, 6), "unit": "Mpix/s", "cores": threads,
-                    "kind": "port", "what": what,
+                    "cpu_model": model, "nproc": nproc, "kind": "port", "what": what,
                     "sample": "%d of %d rows of the same %dx%d frame (rows spread evenly), %.1f s" %
                               (len(rows), H, W, H, dt)}
 
@@ -390,10 +459,29 @@ def main():
             # scaled kernel counters: [0] rescales, [1] full-precision (HDRFloat) steps, [2] binary32 steps; every step is
             # the 18-flop perturbation step of SURVEY 8(d)
             flops = (perturb_steps + la_steps) * FLOP_PER_STEP
+        elif wl == "c5_bla":
+            # a BLA jump = dz' = A dz + B dc (two complex products, 6 flop each, + one complex sum, 2), z = Z + dz' (2),
+            # |z|^2 (3), |dz'|^2 (3) = 22 flop; the kernel's la_steps counter holds the jumps
+            flops = perturb_steps * FLOP_PER_STEP + la_steps * FLOP_PER_BLA_JUMP
         else:
             flops = perturb_steps * FLOP_PER_STEP
         peak = PEAK_FP64_VECTOR_TFLOPS if (is64 and not is2x32) else PEAK_FP32_VECTOR_TFLOPS
         achieved = flops / (avg_kernel_ms * 1e-3) / 1e12
+        roof = {"bound": "valu", "achieved": round(achieved, 4), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 5), "traffic": traffic}
+        if wl == "c5_bla":
+            # C5 is priced against HBM: achieved = ALGORITHMIC bytes per launch (compulsory traffic: the
+            # prepared orbit once, the table once, the iteration buffer written once) / kernel time against 8 TB/s, with the
+            # counter bytes beside it (`traffic`; traffic >> algorithmic = re-reads from L2 misses).  The vector-issue view
+            # of the same launch is kept under "valu".
+            alg_bytes = orbit.count * 16 + sum(bla.sizes()) * 44 + rows_padded * rw * 4
+            gbs = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": round(gbs, 3), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(gbs / PEAK_HBM_GBS, 6), "traffic": traffic, "algorithmic_bytes": alg_bytes,
+                    "traffic_gbs": round(traffic / (avg_kernel_ms * 1e-3) / 1e9, 2) if traffic else None,
+                    "valu": {"achieved": round(achieved, 4), "peak": peak, "unit": "TFLOP/s",
+                             "frac": round(achieved / peak, 5), "flop_per_bla_jump": FLOP_PER_BLA_JUMP,
+                             "bla_jumps_per_launch": la_steps}}
         out = {
             "metric": "Mpix/s (iteration buffer), View #5 3840x2160 HDRx32 LAv2" if wl == "c3_lav2"
             else "Mpix/s (iteration buffer), " + wl,
@@ -403,12 +491,11 @@ def main():
             "data": "built-in view %d of the reference (deterministic: no dataset or randomness on this path)" % args.view,
             "window": "kernel launch -> iteration buffer in (page-locked) host memory, SURVEY.md 8(d)",
             "config": {"workload": "view%d_%dx%d_%s" % (args.view, W, H, wl_tag),
-                       "parity": args.parity, "n_iterations": n_iter, "orbit_entries": orbit.count,
+                       "parity": args.parity, "kernel_variant": args.variant or "tuned", "n_iterations": n_iter, "orbit_entries": orbit.count,
                        "la_records": la.count if la else 0, "la_stages": la.stage_count if la else 0,
                        "bla_levels": bla.num_levels if bla else 0, "tiling": "rows/8-row bands interleaved x%d" % world,
                        "host_input_build_s": round(t_inputs, 3), "la_build_on_device_ms": la_device_ms},
-            "roofline": {"bound": "valu", "achieved": round(achieved, 4), "peak": peak,
-                         "unit": "TFLOP/s", "frac": round(achieved / peak, 5), "traffic": traffic,
+            "roofline": {**roof,
                          "kernel": wl_kernel, "kernel_ms": round(avg_kernel_ms, 3),
                          "pixel_steps_per_launch": perturb_steps, "at_iterations_per_launch": at_iters,
                          "la_steps_per_launch": la_steps, "flop_per_pixel_step": FLOP_PER_STEP,

@@ -88,6 +88,7 @@ def render_lib():
     _decl(lib, "fs_create", vp, [C.c_int])
     _decl(lib, "fs_destroy", None, [vp])
     _decl(lib, "fs_test_device_is_working", u32, [])
+    _decl(lib, "fs_device_count", C.c_int, [])
     _decl(lib, "fs_error_string", C.c_char_p, [u32])
     _decl(lib, "fs_init_memory", u32, [vp, u32, u32, u32, u32, vp, u32, u32, u64, C.c_int])
     _decl(lib, "fs_set_row_bands", u32, [vp, u32, u32, u32])
@@ -153,7 +154,7 @@ def render_lib():
 
 
 RENDER_SYMBOLS = [
-    "fs_create", "fs_destroy", "fs_test_device_is_working", "fs_error_string", "fs_init_memory", "fs_set_row_bands",
+    "fs_create", "fs_destroy", "fs_test_device_is_working", "fs_device_count", "fs_error_string", "fs_init_memory", "fs_set_row_bands",
     "fs_local_rows", "fs_set_external_iter_buffer", "fs_device_iter_buffer", "fs_rounded_width", "fs_upload_orbit", "fs_upload_orbit_compressed",
     "fs_upload_la", "fs_upload_bla", "fs_render_lav2", "fs_render_bla", "fs_render_direct", "fs_upload_orbit_scaled",
     "fs_render_scaled", "fs_build_bla", "fs_bla_num_levels", "fs_bla_lm2", "fs_bla_level_size", "fs_read_bla_level",

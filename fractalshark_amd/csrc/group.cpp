@@ -84,6 +84,7 @@ struct fs_group {
     fs_reduction reduce_seed{};
     float last_gather_ms = -1.0f;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    hipEvent_t ev_consumed = nullptr; // recorded on member 0's stream once k_gather_rows has read the gather slots
     size_t slice_bytes() const { return (size_t)max_rows * rounded_width * iter_bytes; }
 };
 
@@ -154,6 +155,9 @@ static void group_free_buffers(fs_group *g)
             (void)hipFree(g->slices[i]);
         }
     g->slices.clear();
+    // member 0 renders straight into its gather slot (no slice of its own): detach it before that memory goes away
+    if (g->gathered && !g->members.empty())
+        (void)fs_set_external_iter_buffer(g->members[0], nullptr, 0);
     if (!g->devices.empty() && hipSetDevice(g->devices[0]) == hipSuccess) {
         if (g->gathered)
             (void)hipFree(g->gathered);
@@ -179,6 +183,8 @@ void fs_group_destroy(fs_group *g)
         (void)hipEventDestroy(g->ev_a);
     if (g->ev_b)
         (void)hipEventDestroy(g->ev_b);
+    if (g->ev_consumed)
+        (void)hipEventDestroy(g->ev_consumed);
     for (void *c : g->comms)
         if (c)
             rccl().CommDestroy(c);
@@ -233,6 +239,7 @@ uint32_t fs_group_init_memory(fs_group *g, uint32_t w, uint32_t h, uint32_t anti
     if (!g->ev_a) {
         FSG_TRY(hipEventCreate(&g->ev_a));
         FSG_TRY(hipEventCreate(&g->ev_b));
+        FSG_TRY(hipEventCreateWithFlags(&g->ev_consumed, hipEventDisableTiming));
     }
     // every member renders into a slice buffer of the common (padded) size; member 0 straight into its gather slot
     g->slices.assign(world, nullptr);
@@ -346,20 +353,25 @@ uint32_t fs_group_render_current(fs_group *g, uint64_t n_iterations, void *iter_
         Rccl &q = rccl();
         if (q.GroupStart() != 0)
             return FS_ERR_7;
-        for (uint32_t r = 1; r < world; r++) {
-            // rank 0 receives slice r behind its own kernel; rank r sends behind ITS kernel (its compute stream)
-            if (q.Recv((char *)g->gathered + sb * r, sb, kNcclUint8, (int)r, g->comms[0], s0) != 0)
-                return FS_ERR_7;
-            if (q.Send(g->slices[r], sb, kNcclUint8, 0, g->comms[r], (hipStream_t)fs_compute_stream(g->members[r])) != 0)
-                return FS_ERR_7;
+        // (every exit below closes the group: a thread left inside an open ncclGroup corrupts its later RCCL calls)
+        bool ok = true;
+        for (uint32_t r = 1; r < world && ok; r++) {
+            // rank 0 receives slice r behind its own kernel -- and, being on s0, behind the k_gather_rows of the previous
+            // frame, so a slot is never overwritten while it is still being read; rank r sends behind ITS kernel
+            ok = q.Recv((char *)g->gathered + sb * r, sb, kNcclUint8, (int)r, g->comms[0], s0) == 0 &&
+                 q.Send(g->slices[r], sb, kNcclUint8, 0, g->comms[r], (hipStream_t)fs_compute_stream(g->members[r])) == 0;
         }
-        if (q.GroupEnd() != 0)
+        if (q.GroupEnd() != 0 || !ok)
             return FS_ERR_7;
     } else if (world > 1) {
         for (uint32_t r = 1; r < world; r++) {
-            // the copy runs on the SENDER's stream (ordered behind its kernel); rank 0 then waits for it on the device
+            // the copy runs on the SENDER's stream (ordered behind its kernel); rank 0 then waits for it on the device.
+            // The copy writes rank 0's gather slot r, which the k_gather_rows of the PREVIOUS frame may still be reading
+            // (this call is asynchronous; a fast member can be a whole frame ahead of a slow one): the sender first waits
+            // for ev_consumed, recorded on s0 behind that kernel (a never-recorded event does not wait).
             hipStream_t sr = (hipStream_t)fs_compute_stream(g->members[r]);
             FSG_TRY(hipSetDevice(g->devices[r]));
+            FSG_TRY(hipStreamWaitEvent(sr, g->ev_consumed, 0));
             FSG_TRY(hipMemcpyPeerAsync((char *)g->gathered + sb * r, g->devices[0], g->slices[r], g->devices[r], sb, sr));
             hipEvent_t done;
             FSG_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
@@ -372,6 +384,7 @@ uint32_t fs_group_render_current(fs_group *g, uint64_t n_iterations, void *iter_
     FSG_TRY(hipSetDevice(g->devices[0]));
     fsk_gather_rows(g->gathered, g->frame, g->index, g->rounded_width * g->iter_bytes, g->height, s0);
     FSG_TRY(hipGetLastError());
+    FSG_TRY(hipEventRecord(g->ev_consumed, s0)); // the gather slots may be written again
     FSG_TRY(hipEventRecord(g->ev_b, s0));
     if (reduction) {
         g->reduce_seed = fs_reduction{g->iter_bytes == 8 ? ~0ull : 0xFFFFFFFFull, 0, 0};

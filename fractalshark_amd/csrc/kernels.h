@@ -13,7 +13,10 @@
 enum { FS_MODE_FULL = 0, FS_MODE_PO = 1, FS_MODE_LAO = 2 };
 enum { FS_PARITY_LITERAL = 0, FS_PARITY_GPUSTAGE = 1 };
 // kernel variant: 0 = tuned loop (default), 1 = literal operation-by-operation transcription (A/B reference)
-enum { FS_VARIANT_TUNED = 0, FS_VARIANT_LITERAL = 1, FS_VARIANT_TUNED_NOSCALE = 2 };
+enum { FS_VARIANT_TUNED = 0, FS_VARIANT_LITERAL = 1, FS_VARIANT_TUNED_NOSCALE = 2, FS_VARIANT_BASE_MASK = 0xff };
+// ... ORed with the A/B flags of fs_set_kernel_variant (include/fsmi355.h): orbit entries of the scaled runs through LDS
+// (k_lav2_hdr32_fast<kLds>), persistent lane-refilling launch of the BLA kernel (k_perturb_scalar<kRefill>)
+enum { FS_VARIANT_FLAG_LDS_ORBIT = 0x100, FS_VARIANT_FLAG_REFILL = 0x200 };
 
 // Frame geometry + the row-band layout of the local iteration buffer.
 struct FsFrame {
@@ -234,8 +237,8 @@ void fsk_bla_build_hdr32(const float4 *zref, void *const *levels, const uint64_t
                          hipStream_t s);
 void fsk_bla_build_hdr64(const FsZ64 *zref, void *const *levels, const uint64_t *epl, int n_levels, fs_real_hdr64 bla_size,
                          hipStream_t s);
-void fsk_perturb_scalar_hdr32(const FsBlaArgs32 &A, bool use_bla, bool stats, hipStream_t s);
-void fsk_perturb_scalar_hdr64(const FsBlaArgsT<double> &A, bool use_bla, bool stats, hipStream_t s);
+void fsk_perturb_scalar_hdr32(const FsBlaArgs32 &A, bool use_bla, bool stats, int variant, hipStream_t s);
+void fsk_perturb_scalar_hdr64(const FsBlaArgsT<double> &A, bool use_bla, bool stats, int variant, hipStream_t s);
 void fsk_perturb_bla_f64(const FsBlaArgsF64 &A, bool use_bla, bool stats, hipStream_t s);
 void fsk_direct_hdr32(const FsDirectHdrArgsT<float> &A, fs::hreal<float> minX, fs::hreal<float> dx, bool stats, hipStream_t s);
 void fsk_direct_hdr64(const FsDirectHdrArgsT<double> &A, fs::hreal<double> minX, fs::hreal<double> dx, bool stats,

@@ -2510,8 +2510,9 @@ void fsk_lav2_hdr32(const FsLav2Args32 &A, int mode, bool stats, int variant, hi
         const unsigned v = e ? (unsigned)atoi(e) : 256u;
         return v == 64u || v == 128u ? v : 256u;
     }();
-    // A/B switch: FSMI355_LDS_ORBIT=1 routes the wave-uniform scaled runs' orbit entries through LDS (see the kernel)
-    static const bool lds_orbit = getenv("FSMI355_LDS_ORBIT") != nullptr && atoi(getenv("FSMI355_LDS_ORBIT")) != 0;
+    // A/B flag of fs_set_kernel_variant: the wave-uniform scaled runs' orbit entries through LDS (see the kernel)
+    const bool lds_orbit = (variant & FS_VARIANT_FLAG_LDS_ORBIT) != 0;
+    variant &= FS_VARIANT_BASE_MASK;
     const dim3 b(bs), g((A.frame.width + bs / 8 - 1) / (bs / 8), (A.frame.local_rows + 7) / 8, 1);
 #define FS_LAUNCH_FAST(M, SC, LDS)                                                                                  \
     if (stats) {                                                                                                    \
@@ -2572,22 +2573,17 @@ template <class K> static dim3 persistent_grid(K kernel, const FsFrame &f)
     return dim3((unsigned)(blocks ? blocks : 1u), 1, 1);
 }
 
-static bool refill_enabled()
-{
-    // A/B switch: FSMI355_REFILL=1 selects the persistent, lane-refilling launch.  It is OFF by
-    // default: measured on C5 (7680x4320) it raises the loop's lane utilisation from 0.74 to 0.98 and still loses, 333 ms
-    // against 263 ms -- re-packed lanes are due for different actions (jump / step) and sit at unrelated orbit and table
-    // positions: rocprofv3 counts 1.8x the vector instructions at 37 % active lanes with the reference-shaped loop
-    // (505 ms), and with the action loop, which removes that divergence, 2.5x the L2 requests remain (every per-lane
-    // load of a wave touches 64 different lines).
-    static const bool on = getenv("FSMI355_REFILL") != nullptr && atoi(getenv("FSMI355_REFILL")) != 0;
-    return on;
-}
-
-template <class F> static void launch_perturb_scalar(const FsBlaArgsT<F> &A, bool use_bla, bool stats, hipStream_t s)
+// FS_VARIANT_FLAG_REFILL (fs_set_kernel_variant; A/B) selects the persistent, lane-refilling launch.
+// It is OFF by default: measured on C5 (7680x4320) it raises the loop's lane utilisation from 0.74 to 0.98 and still
+// loses, 333 ms against 263 ms -- re-packed lanes are due for different actions (jump / step) and sit at unrelated orbit
+// and table positions: rocprofv3 counts 1.8x the vector instructions at 37 % active lanes with the reference-shaped
+// loop (505 ms), and with the action loop, which removes that divergence, 2.5x the L2 requests remain (every per-lane
+// load of a wave touches 64 different lines).
+template <class F>
+static void launch_perturb_scalar(const FsBlaArgsT<F> &A, bool use_bla, bool stats, int variant, hipStream_t s)
 {
     const dim3 g = tile_grid(A.frame), b(256);
-    if (use_bla && refill_enabled()) {
+    if (use_bla && (variant & FS_VARIANT_FLAG_REFILL) != 0) {
         (void)hipMemsetAsync(A.queue, 0, sizeof(uint32_t), s);
         if (stats)
             hipLaunchKernelGGL((k_perturb_scalar<F, true, true, true>),
@@ -2608,9 +2604,9 @@ template <class F> static void launch_perturb_scalar(const FsBlaArgsT<F> &A, boo
     }
 }
 
-void fsk_perturb_scalar_hdr32(const FsBlaArgs32 &A, bool use_bla, bool stats, hipStream_t s)
+void fsk_perturb_scalar_hdr32(const FsBlaArgs32 &A, bool use_bla, bool stats, int variant, hipStream_t s)
 {
-    launch_perturb_scalar<float>(A, use_bla, stats, s);
+    launch_perturb_scalar<float>(A, use_bla, stats, variant, s);
 }
 
 __global__ void k_decompress_orbit_hdr64(const fs_orbit_hdr64_rc *__restrict__ wp, uint64_t n_wp, uint64_t n_uncompressed,
@@ -2706,9 +2702,9 @@ void fsk_lav2_wide(const FsLav2Args32 *A32, const FsLav2ArgsT<double> *A64, int 
 #undef FS_LAUNCH_WIDE
 }
 
-void fsk_perturb_scalar_hdr64(const FsBlaArgsT<double> &A, bool use_bla, bool stats, hipStream_t s)
+void fsk_perturb_scalar_hdr64(const FsBlaArgsT<double> &A, bool use_bla, bool stats, int variant, hipStream_t s)
 {
-    launch_perturb_scalar<double>(A, use_bla, stats, s);
+    launch_perturb_scalar<double>(A, use_bla, stats, variant, s);
 }
 
 void fsk_perturb_bla_f64(const FsBlaArgsF64 &A, bool use_bla, bool stats, hipStream_t s)

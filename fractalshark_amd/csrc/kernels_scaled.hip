@@ -443,9 +443,6 @@ template <bool kStats> __global__ void __launch_bounds__(256) k_scaled_hdr32_fas
         atomicAdd((unsigned long long *)&A.stats[6], (unsigned long long)c_fast); // probes (tools/scaled_kernel_probe.py):
         atomicAdd((unsigned long long *)&A.stats[7], (unsigned long long)c_runs); // lane-steps inside runs, runs
     }
-        atomicAdd((unsigned long long *)&A.stats[6], (unsigned long long)c_fast); // probes: lane-steps inside runs, runs
-        atomicAdd((unsigned long long *)&A.stats[7], (unsigned long long)c_runs);
-        (void)0;
 }
 
 // The bound word of the binary32 orbit entries (their padding field): M / 4, or -1 where no run may arrive.

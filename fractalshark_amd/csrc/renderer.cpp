@@ -377,6 +377,12 @@ uint32_t fs_test_device_is_working(void)
     return 1;
 }
 
+int fs_device_count(void)
+{
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess && n > 0 ? n : 0;
+}
+
 const char *fs_error_string(uint32_t err)
 {
     switch (err) {
@@ -1009,6 +1015,10 @@ template <class F> uint32_t build_la(fs_renderer *r, const void *max_radius, int
     using HR = fs::hreal<F>;
     hipStream_t s = r->compute;
     const void *zref = sizeof(F) == 4 ? (const void *)r->zref : (const void *)r->zref64;
+    // state numbers (2 per element) and record indices are 32-bit on the device: an orbit of 2^31 entries does not fit
+    // (its prepared form alone would be 32 GiB of float4); refuse instead of truncating
+    if (r->orbit_uncompressed >= (1ull << 31))
+        return FS_ERR_UNSUPPORTED;
     const uint32_t maxRef = (uint32_t)r->orbit_uncompressed - 1u; // entries 0 .. maxRef
     const int periodDivisor = r->orbit_size != r->orbit_uncompressed ? 8 : 2; // LAReference.cpp:12-19
     if (r->orbit_uncompressed < 2 || maxRef <= kLaLowBound)
@@ -1048,8 +1058,11 @@ template <class F> uint32_t build_la(fs_renderer *r, const void *max_radius, int
     // one stage: elements 0 .. limit-1 (+ the sentinel element `limit`), period / first record decided by the caller
     auto run_chain = [&](bool stage0, const Rec *P, uint32_t limit, uint32_t period, bool have_first, uint32_t first_end,
                          uint32_t first_step, uint32_t x_start, uint32_t &n_records) -> uint32_t {
-        const uint32_t nstates = 2u * limit;
+        const uint32_t nstates = 2u * limit; // limit <= maxRef < 2^31 - 1
         uint32_t offset = 0;
+        // room for this stage's first record and its tail record before anything is written
+        if ((size_t)la_size + 2u > cap_recs)
+            return FS_ERR_7;
         if (have_first) {
             fsk_la_one_record<F>(stage0, zref, P, first_end, first_step, d_table + la_size, s);
             offset = 1;
@@ -1459,7 +1472,7 @@ uint32_t fs_render_bla(fs_renderer *r, int type_tag, const void *coords, uint64_
         A.n_iterations = (uint32_t)n_iterations;
         A.lm2 = r->bla_lm2;
         TimedLaunch t(r);
-        fsk_perturb_scalar_hdr32(A, use_bla, r->stats_on, r->compute);
+        fsk_perturb_scalar_hdr32(A, use_bla, r->stats_on, r->variant, r->compute);
     } else {
         FsBlaArgsT<double> A;
         memset(&A, 0, sizeof(A));
@@ -1474,7 +1487,7 @@ uint32_t fs_render_bla(fs_renderer *r, int type_tag, const void *coords, uint64_
         A.n_iterations = (uint32_t)n_iterations;
         A.lm2 = r->bla_lm2;
         TimedLaunch t(r);
-        fsk_perturb_scalar_hdr64(A, use_bla, r->stats_on, r->compute);
+        fsk_perturb_scalar_hdr64(A, use_bla, r->stats_on, r->variant, r->compute);
     }
     return (uint32_t)hipGetLastError();
 }
@@ -1600,7 +1613,7 @@ uint32_t fs_render_scaled(fs_renderer *r, int type_tag, const void *coords, uint
         A.n_iterations = (uint32_t)n_iterations;
         A.w2threshold = w2threshold;
         TimedLaunch t(r);
-        fsk_scaled_f64(A, r->stats_on, r->variant, r->compute);
+        fsk_scaled_f64(A, r->stats_on, r->variant & FS_VARIANT_BASE_MASK, r->compute);
         return (uint32_t)hipGetLastError();
     }
     FsScaledArgs32 A;
@@ -1615,7 +1628,7 @@ uint32_t fs_render_scaled(fs_renderer *r, int type_tag, const void *coords, uint
     A.n_iterations = (uint32_t)n_iterations;
     A.w2threshold = w2threshold;
     TimedLaunch t(r);
-    fsk_scaled_hdr32(A, r->stats_on, r->variant, r->compute);
+    fsk_scaled_hdr32(A, r->stats_on, r->variant & FS_VARIANT_BASE_MASK, r->compute);
     return (uint32_t)hipGetLastError();
 }
 
@@ -1809,7 +1822,10 @@ float fs_last_kernel_ms(const fs_renderer *r)
 
 uint32_t fs_set_kernel_variant(fs_renderer *r, int variant)
 {
-    r->variant = variant == 1 ? FS_VARIANT_LITERAL : (variant == 2 ? FS_VARIANT_TUNED_NOSCALE : FS_VARIANT_TUNED);
+    const int base = variant & FS_VARIANT_BASE_MASK, flags = variant & ~FS_VARIANT_BASE_MASK;
+    if (base > FS_VARIANT_TUNED_NOSCALE || (flags & ~(FS_VARIANT_FLAG_LDS_ORBIT | FS_VARIANT_FLAG_REFILL)) != 0)
+        return hipErrorInvalidValue;
+    r->variant = base | flags;
     return 0;
 }
 

@@ -1026,13 +1026,27 @@ bool load_im_orbit(FILE *f, uint64_t reference_offset, OrbitT<F> &ob, uint64_t f
         return false;
     uint64_t ref_it;
     memcpy(&ref_it, la + 16, 8);
+    // a file is untrusted input: the orbit it announces must fit the device-side 32-bit indices and may not be longer than
+    // the iteration limit it was computed for (a crafted RefIt would otherwise size the vectors below)
+    if (ref_it >= (1ull << 32) || (file_iteration_limit != 0 && ref_it > file_iteration_limit))
+        return false;
     const bool periodic = la[34] != 0;
     MaxWaypoints<F> w;
+    auto exp_fits = [](const ImHR &h) { return h.exp >= INT32_MIN && h.exp <= INT32_MAX; };
+    if (!exp_fits(halfH))
+        return false;
+    uint64_t prev_index = 0;
     for (uint64_t k = 0; k < n; k++) {
         ImHR xy[2];
         uint64_t field;
         if (fread(xy, sizeof(ImHR), 2, f) != 2 || fread(&field, 8, 1, f) != 1)
             return false;
+        // waypoints are strictly increasing orbit positions >= 1 (entry 0 is the implicit zero start; DecompressMax reads the
+        // entry BEFORE a rebasing waypoint), inside the announced orbit, with exponents that fit HDRFloat's int32
+        const uint64_t idx = field & 0x7FFFFFFFFFFFFFFFull;
+        if (idx == 0 || idx <= prev_index || idx > ref_it || !exp_fits(xy[0]) || !exp_fits(xy[1]))
+            return false;
+        prev_index = idx;
         w.x.push_back(hreal<F>{(F)xy[0].mantissa, (int32_t)xy[0].exp});
         w.y.push_back(hreal<F>{(F)xy[1].mantissa, (int32_t)xy[1].exp});
         w.index.push_back(field & 0x7FFFFFFFFFFFFFFFull);
@@ -1053,7 +1067,6 @@ bool load_im_orbit(FILE *f, uint64_t reference_offset, OrbitT<F> &ob, uint64_t f
     ob.orbitYLow = hr_from_mpf<F>(ob.cy.v);
     const uint64_t count = ref_it + 1; // m_UncompressedItersInOrbit
     ob.period = periodic ? ref_it + 1 : 0;
-    (void)file_iteration_limit;
     decompress_max(w, ob.orbitXLow, ob.orbitYLow, count, ob.x, ob.y);
     ob.bad.assign(ob.x.size(), 0);
     ob.compressed = false;
@@ -1069,11 +1082,26 @@ extern "C" int fsh_orbit_save_im(const fsh_orbit *o, uint64_t num_iterations, in
                    : save_im_orbit<float>(o->f, num_iterations, compression_exp, path, exp_bytes);
 }
 
+static fsh_orbit *orbit_load_im(FILE *f, uint64_t *iteration_limit);
+
 extern "C" fsh_orbit *fsh_orbit_load_im(const char *path, uint64_t *iteration_limit)
 {
     FILE *f = fopen(path, "rb");
     if (!f)
         return nullptr;
+    // nothing may unwind through the C boundary (a corrupt file can still make a vector throw): NULL, like any other refusal
+    fsh_orbit *out = nullptr;
+    try {
+        out = orbit_load_im(f, iteration_limit);
+    } catch (...) {
+        out = nullptr;
+    }
+    fclose(f);
+    return out;
+}
+
+static fsh_orbit *orbit_load_im(FILE *f, uint64_t *iteration_limit)
+{
     uint64_t header[4];
     ImHR hh;
     uint64_t limit = 0;
@@ -1109,7 +1137,6 @@ extern "C" fsh_orbit *fsh_orbit_load_im(const char *path, uint64_t *iteration_li
                 *iteration_limit = limit;
         }
     }
-    fclose(f);
     return out.release();
 }
 

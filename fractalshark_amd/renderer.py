@@ -17,6 +17,9 @@ T_F32, T_F64, T_2X32, T_HDR32, T_HDR64, T_HDR2X32, T_2X64, T_4X32, T_4X64 = rang
 LAV2_FULL, LAV2_PO, LAV2_LAO = range(3)
 # parity (include/fsmi355.h)
 PARITY_CPU, PARITY_CPU_GPUSTAGE = range(2)
+FS_ERR_UNSUPPORTED = 10100
+# A/B flags of fs_set_kernel_variant (include/fsmi355.h)
+VARIANT_LDS_ORBIT, VARIANT_REFILL = 0x100, 0x200
 
 NB_THREADS_W = 16  # GPU_Render.h:116-120: part of the contract (ItersMemoryContainer pads with them)
 NB_THREADS_H = 8
@@ -39,6 +42,11 @@ class GPURenderer:
         self.close()
 
     # ---- static members
+    @staticmethod
+    def device_count():
+        """HIP devices visible to this process (fs_device_count)."""
+        return int(_capi.render_lib().fs_device_count())
+
     @staticmethod
     def TestCudaIsWorking():
         """Non-zero = working (GPU_Render.cu:100-123)."""
@@ -210,13 +218,22 @@ class GPURenderer:
         mr = orbit.max_radius()
         return self._lib.fs_build_bla(self._h, T, mr.ctypes.data)
 
-    def BuildLAOnDevice(self, orbit, use_small_exponents=False, T=None):
+    def BuildLAOnDevice(self, orbit, use_small_exponents=False, T=None, host_fallback=True):
         """LAReference::GenerateApproximationData on the device for the orbit last uploaded (fs_build_la): all stages and
-        the ATInfo stay in HBM, installed as the renderer's table."""
+        the ATInfo stay in HBM, installed as the renderer's table.  The degenerate inputs the device builder leaves to the
+        host (FS_ERR_UNSUPPORTED: orbits of <= 64 entries, a first step with a zero ZCoeff -- microseconds of host work)
+        are built by the host builder and uploaded with fs_upload_la, which is what FractalShark itself does for every
+        table (host_fallback=False returns the error code instead)."""
         if T is None:
             T = T_HDR64 if orbit.is64 else T_HDR32
         mr = orbit.max_radius()
-        return self._lib.fs_build_la(self._h, T, mr.ctypes.data, 1 if use_small_exponents else 0)
+        err = self._lib.fs_build_la(self._h, T, mr.ctypes.data, 1 if use_small_exponents else 0)
+        if err == FS_ERR_UNSUPPORTED and host_fallback:
+            from . import inputs
+            la = inputs.LATable(orbit, use_small_exponents=use_small_exponents)
+            err = self._lib.fs_upload_la(self._h, 0, T, 4, la.las_ptr, la.count, la.stages_ptr, la.stage_count,
+                                         1 if la.is_valid else 0, 1 if la.use_at else 0, C.addressof(la.at))
+        return err
 
     def read_la(self, is64=False):
         """Device-resident LA table -> (records uint8[n, 68|128], stages uint32[k, 2], at bytes, use_at, is_valid)."""
@@ -289,10 +306,12 @@ class GPURenderer:
     def last_kernel_ms(self):
         return float(self._lib.fs_last_kernel_ms(self._h))
 
-    def set_kernel_variant(self, literal=False):
+    def set_kernel_variant(self, literal=False, lds_orbit=False, refill=False):
         """False / 0 (default): tuned loops; True / 1: literal transcription; 2: tuned loops without the scaled runs
-        (A/B references, identical results)."""
-        return self._lib.fs_set_kernel_variant(self._h, int(literal))
+        (A/B references, identical results).  lds_orbit / refill: the A/B flags FS_VARIANT_LDS_ORBIT / FS_VARIANT_REFILL
+        of include/fsmi355.h (orbit entries through LDS; persistent lane-refilling BLA launch)."""
+        v = int(literal) | (VARIANT_LDS_ORBIT if lds_orbit else 0) | (VARIANT_REFILL if refill else 0)
+        return self._lib.fs_set_kernel_variant(self._h, v)
 
     def enable_step_count(self, on=True):
         return self._lib.fs_enable_step_count(self._h, 1 if on else 0)

@@ -6,8 +6,10 @@ cluster spatially and equal contiguous bands would be badly imbalanced.  Band he
 never splits a padding block, and it is a multiple of every legal antialiasing factor's row group only for
 AA in {1,2,4} (AA=3 frames use band height 24).
 
-The only data-path exchange is the gather of the iteration-buffer slices to rank 0: one RCCL all-gather of
-equal-sized (padded) slices over xGMI, ~33 MB total at 3840x2160 -- latency-dominated next to the kernels.
+The only data-path exchange is the gather of the iteration-buffer slices to rank 0 (gather_frame): one RCCL gather
+of equal-sized (padded) slices -- a group of point-to-point sends, so each slice crosses its own xGMI link to GPU 0 once
+and only rank 0 receives ((N-1)/N of the frame in total; an all-gather would deliver N times as much).  ~33 MB at
+3840x2160 (latency-dominated next to the kernels), 531 MB at C4's 15360x8640.
 """
 import numpy as np
 
@@ -61,3 +63,16 @@ def reassemble_index(height, world, band=8):
             idx[a:b] = rank * m + k + np.arange(b - a)
             k += b - a
     return idx
+
+
+def gather_frame(local, gathered, frame_index, rank, world):
+    """The data-path collective: every rank's padded slice `local` [max_rows, W] goes to rank 0 (torch.distributed.gather:
+    with the nccl backend one ncclGroup of send / recv pairs), where `gathered` [world * max_rows, W] receives them back to
+    back and one index_select with `frame_index` (reassemble_index) restores row order.  Returns the frame [height, W] on
+    rank 0, None elsewhere.  `gathered` / `frame_index` are only needed on rank 0.  Works on any backend (gloo in the tests)."""
+    import torch.distributed as dist
+    chunks = list(gathered.view(world, local.shape[0], local.shape[1]).unbind(0)) if rank == 0 else None
+    dist.gather(local, gather_list=chunks, dst=0)
+    if rank != 0:
+        return None
+    return gathered.index_select(0, frame_index)

@@ -75,6 +75,10 @@ void fs_destroy(fs_renderer *r);
 /* GPURenderer::TestCudaIsWorking (GPU_Render.cu:100-123): NON-ZERO = a usable device exists. */
 uint32_t fs_test_device_is_working(void);
 
+/* Number of HIP devices this process can see (0 when there is none or the runtime fails): what a multi-GPU host sizes
+ * fs_group_create with.  This project's addition (the reference is single-device). */
+int fs_device_count(void);
+
 /* GPURenderer::ConvertErrorToString (GPU_Render.cu:1820-1823). */
 const char *fs_error_string(uint32_t err);
 
@@ -232,9 +236,16 @@ uint32_t fs_get_height(const fs_renderer *r);
  * [5] = perturbation steps that went through the careful (exit-tested) path of the tuned LAv2 loop, [6] = steps taken in
  * its scaled runs, [7] = scaled runs started (both per lane). */
 float fs_last_kernel_ms(const fs_renderer *r);
-/* 0 (default) = tuned iteration loops; 1 = literal operation-by-operation transcription of the CPU function; 2 = tuned
- * loops without the scaled runs of the HDRFloat<float> LAv2 kernel (slower; kept as in-library A/B references for the
- * tuned loops -- results are identical). */
+/* Low byte: 0 (default) = tuned iteration loops; 1 = literal operation-by-operation transcription of the CPU function;
+ * 2 = tuned loops without the scaled runs of the HDRFloat<float> LAv2 kernel (slower; kept as in-library A/B references
+ * for the tuned loops -- results are identical).  ORed with A/B flags, both off by default because they measure slower
+ * (DESIGN.md 4.3 / 5.2), both bit-identical to the default and under test (tests/test_gpu_variants.py):
+ *   FS_VARIANT_LDS_ORBIT  the scaled runs of the tuned HDRFloat<float> LAv2 kernel take their orbit entries through LDS
+ *                         (LDS-DMA double buffer per wave) instead of the scalar cache;
+ *   FS_VARIANT_REFILL     the HDRFloat<float|double> BLA kernel runs as a persistent launch whose waves refill finished
+ *                         lanes from a frame-wide pixel queue (wave-ballot compaction).
+ * Unknown values: hipErrorInvalidValue, the selection stays as it was. */
+enum { FS_VARIANT_LDS_ORBIT = 0x100, FS_VARIANT_REFILL = 0x200 };
 uint32_t fs_set_kernel_variant(fs_renderer *r, int variant);
 uint32_t fs_enable_step_count(fs_renderer *r, int enable);
 uint32_t fs_read_step_count(fs_renderer *r, uint64_t counts[8]);

@@ -68,3 +68,76 @@ def test_group_bla_path(native_libs):
     assert g.Sync() == 0
     assert np.array_equal(out, gold["view5_bla_64x36"])
     g.close()
+
+
+def _single_frames(v, ob, la, parities):
+    dx, dy, cx, cy = _pairs(v.coords_perturb_hdr32(ob))
+    r = GPURenderer(0)
+    assert r.InitializeMemory(v.width, v.height, 1, None, 0, 0, 0, False) == 0
+    assert r.InitializePerturb(1, ob, 0, None, la) == 0
+    out = []
+    for parity in parities:
+        assert r.RenderPerturbLAv2(None, None, None, dx, dy, cx, cy, v.num_iterations, Mode=LAV2_FULL, parity=parity) == 0
+        buf = r.new_iter_buffer()
+        assert r.RenderCurrent(v.num_iterations, buf) == 0
+        assert r.SyncComputeStream() == 0
+        out.append(buf)
+    r.close()
+    return out
+
+
+@pytest.mark.parametrize("world", [2, 5])
+def test_group_frames_issued_back_to_back_without_a_sync(native_libs, world):
+    """fs_group_render_current is asynchronous: a host may issue frame N+1 before frame N has been gathered.  Two DIFFERENT
+    frames (the two parity modes give different counts) are rendered and gathered back to back into separate host buffers
+    with a single sync at the end; a sender that overwrote a gather slot the previous reassembly was still reading would mix
+    them (the peer-copy transport orders the copy behind that reassembly with an event)."""
+    v = inputs.View.builtin(5, 320, 180)
+    ob = inputs.Orbit(v)
+    la = inputs.LATable(ob)
+    dx, dy, cx, cy = _pairs(v.coords_perturb_hdr32(ob))
+    order = [PARITY_CPU, PARITY_CPU_GPUSTAGE] * 3
+    refs = _single_frames(v, ob, la, order[:2])
+    assert not np.array_equal(refs[0], refs[1])
+    g = GPURendererGroup([0] * world)
+    assert g.InitializeMemory(320, 180, 1) == 0
+    assert g.InitializePerturb(1, ob, la) == 0
+    outs = [g.new_iter_buffer() for _ in order]
+    for parity, out in zip(order, outs):
+        assert g.RenderPerturbLAv2(dx, dy, cx, cy, v.num_iterations, Mode=LAV2_FULL, parity=parity) == 0
+        assert g.RenderCurrent(v.num_iterations, out) == 0
+    assert g.Sync() == 0
+    for k, out in enumerate(outs):
+        assert np.array_equal(out, refs[k % 2]), k
+    g.close()
+
+
+@pytest.mark.parametrize("transport", [0, 1])
+def test_group_over_distinct_devices(native_libs, transport):
+    """The group on real, distinct GPUs: transport 0 = RCCL (ncclCommInitAll, grouped ncclSend / ncclRecv on the members'
+    compute streams over xGMI), transport 1 = hipMemcpyPeerAsync.  Needs >= 2 devices in this process; the round's test box
+    has one, the driver's 8-GPU node has eight."""
+    n = GPURenderer.device_count()
+    if n < 2:
+        pytest.skip("needs >= 2 HIP devices (this box has %d)" % n)
+    world = min(n, 8)
+    v = inputs.View.builtin(5, 320, 180)
+    ob = inputs.Orbit(v)
+    la = inputs.LATable(ob)
+    dx, dy, cx, cy = _pairs(v.coords_perturb_hdr32(ob))
+    order = [PARITY_CPU, PARITY_CPU_GPUSTAGE, PARITY_CPU]
+    refs = _single_frames(v, ob, la, order[:2])
+    g = GPURendererGroup(list(range(world)), transport=transport)
+    assert g.size == world
+    assert g.transport == transport, "RCCL did not come up (ncclCommInitAll) -- the group fell back to peer copies"
+    assert g.InitializeMemory(320, 180, 1) == 0
+    assert g.InitializePerturb(1, ob, la) == 0
+    outs = [g.new_iter_buffer() for _ in order]
+    for parity, out in zip(order, outs):
+        assert g.RenderPerturbLAv2(dx, dy, cx, cy, v.num_iterations, Mode=LAV2_FULL, parity=parity) == 0
+        assert g.RenderCurrent(v.num_iterations, out) == 0
+    assert g.Sync() == 0
+    for k, out in enumerate(outs):
+        assert np.array_equal(out, refs[k % 2]), (transport, k)
+    assert g.gather_ms() >= 0.0
+    g.close()

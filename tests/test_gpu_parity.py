@@ -635,7 +635,18 @@ def test_la_build_on_device_leaves_tiny_orbits_to_the_host(renderer, native_libs
     r = renderer
     assert r.InitializeMemory(64, 36, 1, None, 0, 0, 0, False) == 0
     assert r._lib.fs_upload_orbit(r._h, 0, T_HDR32, 4, ob.data_ptr, ob.count, ob.count, ob.period) == 0
-    assert r.BuildLAOnDevice(ob) == 10100
+    assert r.BuildLAOnDevice(ob, host_fallback=False) == 10100
+    # the wrapper's default: the host builder's table is uploaded instead (what FractalShark does for every table), and the
+    # frame rendered from it is the oracle's
+    assert r.BuildLAOnDevice(ob) == 0
+    la = inputs.LATable(ob)
+    assert r.ClearMemory() == 0
+    assert r.RenderPerturbLAv2(None, None, None, *_pairs(v.coords_perturb(ob)), v.num_iterations, T=T_HDR32,
+                               Mode=LAV2_FULL, parity=PARITY_CPU) == 0
+    out = r.new_iter_buffer()
+    assert r.RenderCurrent(v.num_iterations, out) == 0
+    assert r.SyncComputeStream() == 0
+    assert np.array_equal(out, _oracle.lav2_hdr32(v, ob, la, stage_test=0))
 
 
 def test_frame_from_device_built_la_table(renderer, v5_small):

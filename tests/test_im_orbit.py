@@ -134,6 +134,43 @@ def test_files_without_extended_range_or_without_an_orbit_are_refused(tmp_path):
         inputs.Orbit.load_im(loc_only, v)
 
 
+@pytest.mark.parametrize("is64", [True, False])
+def test_corrupt_or_crafted_orbit_sections_are_refused_not_fatal(tmp_path, is64):
+    """A file is untrusted input: an orbit length that does not fit (it sizes the reader's vectors), a waypoint at index 0
+    with the rebase bit (the reader would look at the entry before it), waypoints out of order or past the orbit, and
+    exponents beyond int32 all come back as a refusal -- the process survives and a good file still loads afterwards."""
+    v = inputs.View.builtin(5, 32, 32)
+    o = inputs.Orbit(v, is64=is64)
+    p = tmp_path / "o.im"
+    o.save_im(p)
+    raw = bytearray(open(p, "rb").read())
+    info = parse(p)
+    ref = info["ref"]
+    assert len(info["waypoints"]) >= 2
+    la_at = ref + 1 + 48            # ReferenceHeader: ExtendedRange byte, three HRReal, then the LA block
+    refit_at = la_at + 16
+    wp0 = la_at + 192 + 8           # first waypoint: x (16 B), y (16 B), index | rebase << 63
+    assert struct.unpack("<Q", raw[refit_at:refit_at + 8])[0] == info["ref_it"] == o.count - 1
+
+    def refused(name, patch):
+        b = bytearray(raw)
+        patch(b)
+        q = tmp_path / (name + ".im")
+        q.write_bytes(bytes(b))
+        with pytest.raises(ValueError):
+            inputs.Orbit.load_im(q, v)
+
+    refused("refit_huge", lambda b: b.__setitem__(slice(refit_at, refit_at + 8), struct.pack("<Q", 2 ** 40)))
+    refused("refit_all_ones", lambda b: b.__setitem__(slice(refit_at, refit_at + 8), struct.pack("<Q", 2 ** 64 - 1)))
+    refused("refit_past_limit", lambda b: b.__setitem__(slice(refit_at, refit_at + 8), struct.pack("<Q", info["limit"] + 1)))
+    refused("wp_index0_rebase", lambda b: b.__setitem__(slice(wp0 + 32, wp0 + 40), struct.pack("<Q", 1 << 63)))
+    refused("wp_not_increasing", lambda b: b.__setitem__(slice(wp0 + 40 + 32, wp0 + 80), b[wp0 + 32:wp0 + 40]))
+    refused("wp_past_orbit", lambda b: b.__setitem__(slice(wp0 + 32, wp0 + 40), struct.pack("<Q", info["ref_it"] + 5)))
+    refused("exp_beyond_int32", lambda b: b.__setitem__(slice(wp0 + 8, wp0 + 16), struct.pack("<q", 2 ** 40)))
+    q = inputs.Orbit.load_im(p, v)
+    assert q.count == o.count
+
+
 LAYOUT_PROBE = r"""
 #include <cstddef>
 #include <cstdio>

@@ -19,12 +19,12 @@ run_stats c3_default
 run_stats c5_bla --workload c5_bla --steps 3 --warmup 1 --no-cpu
 run_stats c2_po --workload c2_po --steps 2 --warmup 1 --no-cpu
 run_stats c4_scaled --workload c4_scaled --steps 2 --warmup 1 --no-cpu
-FSMI355_LDS_ORBIT=1 run_stats c3_lds_orbit --steps 5 --warmup 1 --no-cpu --no-secondary
-FSMI355_REFILL=1 run_stats c5_refill --workload c5_bla --steps 3 --warmup 1 --no-cpu
+run_stats c3_lds_orbit --variant lds_orbit --steps 5 --warmup 1 --no-cpu --no-secondary
+run_stats c5_refill --workload c5_bla --variant refill --steps 3 --warmup 1 --no-cpu
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_render_current -- python3 tools/bench_render_current.py > gpurun_out/prof_${tag}_render_current.json 2> gpurun_out/prof_${tag}_render_current.err
 bash tools/pmc_passes.sh ${tag}_c3 --no-secondary
 bash tools/pmc_passes.sh ${tag}_c5 --workload c5_bla
-FSMI355_REFILL=1 bash tools/pmc_passes.sh ${tag}_c5_refill --workload c5_bla
+bash tools/pmc_passes.sh ${tag}_c5_refill --workload c5_bla --variant refill
 # keep only the small summaries
 find gpurun_out -name "*_kernel_trace.csv" -size +2M -delete
 find gpurun_out -name "*.db" -delete
