@@ -1248,6 +1248,16 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
     uint32_t X = 0, L = 0;
     uint64_t c_la = 0, c_pt = 0, c_px = 0;
     uint64_t c_single = 0, c_runs = 0; // probes of the perturbation-only float path (tools/c2_probe.py)
+#ifdef FS_PROFILE_CYCLES
+    // measurement build (tools/c5_phase_probe.py): shader-clock cycles and wave-passes per phase of the BLA loop, per wave.
+    // The clock is read on the scalar unit, i.e. once per pass of the WAVE through the code, whatever the lane mask is.
+    uint64_t ph_lookup = 0, ph_jump = 0, ph_step = 0, ph_literal = 0, ph_t = 0;
+    uint64_t ph_n_lookup = 0, ph_n_jump = 0, ph_n_step = 0, ph_n_literal = 0, ph_n_outer = 0;
+    uint64_t ph_lanes_jump = 0, ph_lanes_step = 0;
+#define FS_PH(stmt) do { if (kStats && kBla) { stmt; } } while (0)
+#else
+#define FS_PH(stmt) do { } while (0)
+#endif
     const uint32_t n_iterations = A.n_iterations;
     const uint32_t count = A.orbit_count;
     const typename FsDev<F>::Z *__restrict__ zr = A.zref;
@@ -1530,12 +1540,20 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
             }
             if (kBla && !(kRefill && std::is_same<F, float>::value)) {
                 const typename FsDev<F>::BLA *b;
-                while ((b = bla_lookup<F>(s_levels, A.lm2, RefIteration, DeltaNormSquared)) != nullptr) {
+                FS_PH(ph_n_outer++);
+                for (;;) {
+                    FS_PH(ph_t = __builtin_readcyclecounter());
+                    b = bla_lookup<F>(s_levels, A.lm2, RefIteration, DeltaNormSquared);
+                    FS_PH(ph_lookup += __builtin_readcyclecounter() - ph_t; ph_n_lookup++);
+                    if (b == nullptr)
+                        break;
                     const uint32_t l = (uint32_t)b->l;
                     if (RefIteration + l >= count)
                         break;
                     if (iter + l >= n_iterations)
                         break;
+                    FS_PH(ph_t = __builtin_readcyclecounter(); ph_n_jump++;
+                          ph_lanes_jump += (uint64_t)__popcll(__builtin_amdgcn_ballot_w64(true)));
                     iter += l;
                     if (kStats) {
                         c_la++;
@@ -1613,8 +1631,10 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                             }
                         }
                     }
+                    FS_PH(ph_jump += __builtin_readcyclecounter() - ph_t);
                     if (applied)
                         continue;
+                    FS_PH(ph_t = __builtin_readcyclecounter(); ph_n_literal++);
                     {
                         const hreal<F> nx = hr_sub(
                             hr_add(hr_sub(hr_mul(Ax, DeltaSubNX), hr_mul(Ay, DeltaSubNY)), hr_mul(Bx, DeltaSub0X)),
@@ -1638,6 +1658,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                         DeltaNormSquared = normSquared;
                         RefIteration = 0;
                     }
+                    FS_PH(ph_literal += __builtin_readcyclecounter() - ph_t);
                 }
                 if (iter >= n_iterations)
                     break;
@@ -1983,6 +2004,8 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
               }
             }
 
+            FS_PH(ph_t = __builtin_readcyclecounter(); ph_n_step++;
+                  ph_lanes_step += (uint64_t)__popcll(__builtin_amdgcn_ballot_w64(true)));
             const hreal<F> OX = DeltaSubNX, OY = DeltaSubNY;
             // The orbit entry read for the escape test of the previous step is the Z of this step unless a rebase or a
             // BLA jump moved RefIteration: one dependent 16-byte load per step instead of two.
@@ -2083,6 +2106,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                                                     dne + (int)__builtin_amdgcn_ubfe(db, 23, 8) - 127};
                     }
                     ++iter;
+                    FS_PH(ph_step += __builtin_readcyclecounter() - ph_t);
                     continue;
                 }
                 // z = Z' + n under ez
@@ -2131,8 +2155,11 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                     ++iter;
                 }
             }
-            if (done_fast)
+            if (done_fast) {
+                FS_PH(ph_step += __builtin_readcyclecounter() - ph_t);
                 continue;
+            }
+            FS_PH(ph_n_literal++);
 
             // ---- generic single step, literal order of Fractal.cpp:2342-2466
             if (kStats && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) ==
@@ -2173,6 +2200,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                 FS_CYCLE_CHECK()
             }
             ++iter;
+            FS_PH(ph_literal += __builtin_readcyclecounter() - ph_t);
         }
 #undef FS_CYCLE_CHECK
         if (finished) {
@@ -2190,6 +2218,16 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
         if (!kBla)
             atomicAdd((unsigned long long *)&A.stats[7], (unsigned long long)c_runs);
     }
+#ifdef FS_PROFILE_CYCLES
+    if (kStats && kBla && (threadIdx.x & 63) == 0) {
+        // slots 16.. of the statistics buffer (fs_read_stats_raw; the renderer allocates them in this build)
+        const uint64_t v[12] = {ph_lookup, ph_jump, ph_step, ph_literal, ph_n_lookup, ph_n_jump,
+                                ph_n_step, ph_n_literal, ph_n_outer, ph_lanes_jump, ph_lanes_step, 1};
+        for (int i = 0; i < 12; i++)
+            atomicAdd((unsigned long long *)&A.stats[16 + i], (unsigned long long)v[i]);
+    }
+#endif
+#undef FS_PH
 }
 
 // ------------------------------------------------------------------------------------------------

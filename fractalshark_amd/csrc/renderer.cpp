@@ -50,7 +50,7 @@ struct fs_renderer {
     fs_color16 *colors = nullptr;
     fs_reduction *reduction = nullptr;
     uint64_t *stats = nullptr;
-    size_t stats_words = 8;
+    size_t stats_words = 32;
 
     uint32_t *queue = nullptr; // pixel counter of the persistent launches (kernels.hip, k_perturb_scalar)
     bool stats_on = false;
@@ -103,6 +103,16 @@ struct fs_renderer {
     void *cx_row = nullptr; // double[] / hreal<float>[] / hreal<double>[] (16 B per column is enough for all)
     uint32_t cx_row_cap = 0;
 
+    // memory management (r_alloc / r_free below)
+    std::vector<void *> host_allocs; // input tables that live in page-locked HOST memory (device out of memory)
+    size_t host_alloc_bytes = 0;
+    bool inject_input_oom = false;   // fault injection: FSMI355_FAIL_INPUT_ALLOC=1 at fs_create time
+    void *arena = nullptr;           // work memory of fs_build_la (kept between calls, grown on demand)
+    size_t arena_cap = 0;
+    void *bla_block = nullptr;       // ONE allocation for the BLA table: the level pointer table, then the levels
+    size_t bla_block_cap = 0;
+    size_t las_cap = 0, stages_cap = 0; // bytes behind `las` / `stages` (reused by the next table when they fit)
+
     void *iters() const { return iters_external ? iters_external : iters_internal; }
     bool memory_initialized() const { return iters() != nullptr && width != 0; }
 };
@@ -113,6 +123,92 @@ uint32_t use_device(const fs_renderer *r)
 {
     FS_TRY(hipSetDevice(r->device));
     return 0;
+}
+
+// ---- Device memory of a renderer.
+// Stream-ordered on the compute stream once it exists (hipMallocAsync / hipFreeAsync: no device-wide synchronisation per
+// allocation, and memory is handed back in stream order -- the reference does the same, GPU_Render.cu:127,142-153,362-395);
+// everything that touches such memory is enqueued on the compute stream or behind a synchronisation of it.
+// kInput allocations -- reference orbit, LA table, BLA table, their upload staging -- fall back to page-locked HOST memory
+// when the device allocation fails, and the kernels then read them over the bus: slow, but the frame still renders
+// (GPUPerturbSingleResults, Perturb.cuh:51-61; GPU_LAReference, GPU_LAReference.h:93-113).  Frame buffers (kFrame) do not.
+enum AllocKind { kFrame = 0, kInput = 1 };
+
+hipError_t r_alloc(fs_renderer *r, void **out, size_t bytes, AllocKind kind)
+{
+    if (bytes == 0)
+        bytes = 16;
+    *out = nullptr;
+    hipError_t e = hipErrorOutOfMemory;
+    if (!(kind == kInput && r->inject_input_oom))
+        e = r->compute ? hipMallocAsync(out, bytes, r->compute) : hipMalloc(out, bytes);
+    if (e == hipSuccess || kind != kInput)
+        return e;
+    (void)hipGetLastError(); // the failed device allocation is handled here, not reported by a later launch check
+    e = hipHostMalloc(out, bytes, hipHostMallocDefault); // mapped into the device's address space at the same address
+    if (e == hipSuccess) {
+        r->host_allocs.push_back(*out);
+        r->host_alloc_bytes += bytes;
+    }
+    return e;
+}
+template <class T> hipError_t r_alloc(fs_renderer *r, T **out, size_t bytes, AllocKind kind)
+{
+    return r_alloc(r, (void **)out, bytes, kind);
+}
+
+hipError_t r_free(fs_renderer *r, const void *cp)
+{
+    void *p = const_cast<void *>(cp);
+    if (!p)
+        return hipSuccess;
+    for (size_t i = 0; i < r->host_allocs.size(); i++)
+        if (r->host_allocs[i] == p) {
+            r->host_allocs.erase(r->host_allocs.begin() + (long)i);
+            if (r->compute)
+                (void)hipStreamSynchronize(r->compute); // a kernel may still be reading it
+            return hipHostFree(p);
+        }
+    return r->compute ? hipFreeAsync(p, r->compute) : hipFree(p);
+}
+
+// The installed LA table (records + stages): the buffers of the previous table are kept when the new one fits.
+hipError_t la_reserve(fs_renderer *r, size_t las_bytes, size_t stages_bytes)
+{
+    if (!r->las || r->las_cap < las_bytes) {
+        (void)r_free(r, r->las);
+        r->las = nullptr;
+        r->las_cap = 0;
+        hipError_t e = r_alloc(r, &r->las, las_bytes, kInput);
+        if (e != hipSuccess)
+            return e;
+        r->las_cap = las_bytes ? las_bytes : 16;
+    }
+    if (!r->stages || r->stages_cap < stages_bytes) {
+        (void)r_free(r, r->stages);
+        r->stages = nullptr;
+        r->stages_cap = 0;
+        hipError_t e = r_alloc(r, (void **)&r->stages, stages_bytes, kInput);
+        if (e != hipSuccess)
+            return e;
+        r->stages_cap = stages_bytes ? stages_bytes : 16;
+    }
+    return hipSuccess;
+}
+
+// Work memory that outlives a call: grown, never shrunk, handed out from the start on every use.
+hipError_t arena_reserve(fs_renderer *r, size_t bytes)
+{
+    if (r->arena_cap >= bytes)
+        return hipSuccess;
+    (void)r_free(r, r->arena);
+    r->arena = nullptr;
+    r->arena_cap = 0;
+    const size_t want = bytes + bytes / 4; // some slack: the next orbit of a zoom sequence is usually a little longer
+    hipError_t e = r_alloc(r, &r->arena, want, kInput);
+    if (e == hipSuccess)
+        r->arena_cap = want;
+    return e;
 }
 
 void compute_local_rows(fs_renderer *r)
@@ -150,12 +246,12 @@ FsFrame make_frame(const fs_renderer *r)
 hipError_t make_quiet_orbit(fs_renderer *r, uint64_t n)
 {
     if (r->zq) {
-        (void)hipFree(r->zq);
+        (void)r_free(r, r->zq);
         r->zq = nullptr;
     }
     // two companions back to back; the scaled runs request their entries one 8-entry body ahead, so the second one may be
     // read up to 16 entries past its end (never used)
-    hipError_t err = hipMalloc((void **)&r->zq, (2 * (n + 2) + 16) * sizeof(float4));
+    hipError_t err = r_alloc(r, (void **)&r->zq, (2 * (n + 2) + 16) * sizeof(float4), kInput);
     if (err != hipSuccess)
         return err;
     r->zq_n = n + 2;
@@ -172,36 +268,88 @@ uint32_t ensure_iter_buffer(fs_renderer *r)
     if (r->iters_internal && r->iters_internal_bytes >= need)
         return 0;
     if (r->iters_internal) {
-        FS_TRY(hipFree(r->iters_internal));
+        if (r->display)
+            FS_TRY(hipStreamSynchronize(r->display)); // a progressive RenderCurrent may still be reading it
+        FS_TRY(r_free(r, r->iters_internal));
         r->iters_internal = nullptr;
         r->iters_internal_bytes = 0;
     }
-    FS_TRY(hipMalloc(&r->iters_internal, need));
+    FS_TRY(r_alloc(r, &r->iters_internal, need, kFrame));
     r->iters_internal_bytes = need;
+    if (r->compute)
+        FS_TRY(hipStreamSynchronize(r->compute)); // usable from any stream from here on
     return 0;
+}
+
+// The BLA table lives in ONE allocation: 64 level pointers (the device-side pointer table the kernels index by level), then
+// the levels back to back, each 256-byte aligned; kept and reused when the next table fits (the reference re-allocates
+// and re-uploads every level on every BLA render, GPU_Render.cu:1464-1479).
+constexpr size_t kBlaPtrTableBytes = 64 * sizeof(void *);
+
+void bla_release(fs_renderer *r)
+{
+    (void)r_free(r, r->bla_block);
+    r->bla_block = nullptr;
+    r->bla_block_cap = 0;
+    r->bla_level_mem.clear();
+    r->bla_level_sizes.clear();
+    r->bla_levels_dev = nullptr;
+    r->bla_n_levels = 0;
+}
+
+// Lays out n_levels levels of sizes[l] records of rec_bytes in the block (growing it if needed) and uploads the pointer
+// table on the compute stream.  A level of size 0 gets a NULL pointer.
+hipError_t bla_layout(fs_renderer *r, const uint64_t *sizes, int32_t n_levels, size_t rec_bytes)
+{
+    if (n_levels > 64)
+        return hipErrorInvalidValue;
+    size_t total = kBlaPtrTableBytes;
+    for (int32_t l = 0; l < n_levels; l++)
+        total += (sizes[l] * rec_bytes + 255u) & ~(size_t)255u;
+    r->bla_n_levels = 0;
+    if (!r->bla_block || r->bla_block_cap < total) {
+        bla_release(r);
+        hipError_t e = r_alloc(r, &r->bla_block, total, kInput);
+        if (e != hipSuccess)
+            return e;
+        r->bla_block_cap = total;
+    }
+    r->bla_level_mem.assign((size_t)n_levels, nullptr);
+    r->bla_level_sizes.assign((size_t)n_levels, 0);
+    size_t at = kBlaPtrTableBytes;
+    for (int32_t l = 0; l < n_levels; l++) {
+        if (sizes[l] == 0)
+            continue;
+        r->bla_level_mem[(size_t)l] = (char *)r->bla_block + at;
+        r->bla_level_sizes[(size_t)l] = sizes[l];
+        at += (sizes[l] * rec_bytes + 255u) & ~(size_t)255u;
+    }
+    r->bla_levels_dev = (const void **)r->bla_block;
+    return hipMemcpyAsync(r->bla_block, r->bla_level_mem.data(), sizeof(void *) * (size_t)n_levels, hipMemcpyHostToDevice,
+                          r->compute);
 }
 
 void free_perturb(fs_renderer *r)
 {
     if (r->zref)
-        hipFree(r->zref);
+        r_free(r, r->zref);
     if (r->zq)
-        hipFree(r->zq);
+        r_free(r, r->zq);
     r->zq = nullptr;
     if (r->zref64)
-        hipFree(r->zref64);
+        r_free(r, r->zref64);
     if (r->orbit_f64)
-        hipFree(r->orbit_f64);
+        r_free(r, r->orbit_f64);
     if (r->orbit_plain)
-        hipFree(r->orbit_plain);
+        r_free(r, r->orbit_plain);
     r->orbit_plain = nullptr;
     if (r->orbit_2x32)
-        hipFree(r->orbit_2x32);
+        r_free(r, r->orbit_2x32);
     r->orbit_2x32 = nullptr;
     if (r->scaled_t)
-        hipFree(r->scaled_t);
+        r_free(r, r->scaled_t);
     if (r->scaled_f)
-        hipFree(r->scaled_f);
+        r_free(r, r->scaled_f);
     r->scaled_t = nullptr;
     r->scaled_f = nullptr;
     r->scaled_count = 0;
@@ -211,42 +359,39 @@ void free_perturb(fs_renderer *r)
     r->orbit_ok = false;
     r->orbit_gen = 0;
     if (r->las)
-        hipFree(r->las);
+        r_free(r, r->las);
     if (r->stages)
-        hipFree(r->stages);
+        r_free(r, r->stages);
     r->las = nullptr;
     r->stages = nullptr;
+    r->las_cap = r->stages_cap = 0;
     r->la_ok = false;
     r->la_gen = 0;
-    for (void *p : r->bla_level_mem)
-        if (p)
-            hipFree(p);
-    r->bla_level_mem.clear();
-    if (r->bla_levels_dev)
-        hipFree((void *)r->bla_levels_dev);
-    r->bla_levels_dev = nullptr;
-    r->bla_n_levels = 0;
+    bla_release(r);
 }
 
 void free_all(fs_renderer *r)
 {
     free_perturb(r);
     if (r->iters_internal)
-        hipFree(r->iters_internal);
+        r_free(r, r->iters_internal);
     if (r->colors)
-        hipFree(r->colors);
+        r_free(r, r->colors);
     if (r->reduction)
-        hipFree(r->reduction);
+        r_free(r, r->reduction);
     if (r->stats)
-        hipFree(r->stats);
+        r_free(r, r->stats);
     if (r->queue)
-        hipFree(r->queue);
+        r_free(r, r->queue);
     r->queue = nullptr;
 
     if (r->pal)
-        hipFree(r->pal);
+        r_free(r, r->pal);
     if (r->cx_row)
-        hipFree(r->cx_row);
+        r_free(r, r->cx_row);
+    (void)r_free(r, r->arena);
+    r->arena = nullptr;
+    r->arena_cap = 0;
     r->iters_internal = nullptr;
     r->colors = nullptr;
     r->reduction = nullptr;
@@ -263,7 +408,7 @@ struct TimedLaunch {
         if (r->ev_start)
             hipEventRecord(r->ev_start, r->compute);
         if (r->stats_on && r->stats)
-            hipMemsetAsync(r->stats, 0, 8 * sizeof(uint64_t), r->compute);
+            hipMemsetAsync(r->stats, 0, (r->stats_words == 32 ? 32 : 8) * sizeof(uint64_t), r->compute);
     }
     ~TimedLaunch()
     {
@@ -335,8 +480,13 @@ extern "C" {
 fs_renderer *fs_create(int device)
 {
     fs_renderer *r = new (std::nothrow) fs_renderer();
-    if (r)
+    if (r) {
         r->device = device;
+        // fault injection for the out-of-memory path (tests): every input-table allocation of this renderer behaves as if
+        // the device were full and lands in page-locked host memory
+        const char *e = getenv("FSMI355_FAIL_INPUT_ALLOC");
+        r->inject_input_oom = e != nullptr && atoi(e) != 0;
+    }
     return r;
 }
 
@@ -350,6 +500,8 @@ void fs_destroy(fs_renderer *r)
         if (r->display)
             hipStreamSynchronize(r->display);
         free_all(r);
+        if (r->compute)
+            hipStreamSynchronize(r->compute); // the stream-ordered frees have run before their stream goes away
         if (r->ev_start)
             hipEventDestroy(r->ev_start);
         if (r->ev_stop)
@@ -423,16 +575,24 @@ uint32_t fs_init_memory(fs_renderer *r, uint32_t w, uint32_t h, uint32_t antiali
         FS_TRY(hipStreamCreateWithPriority(&r->display, hipStreamNonBlocking, hi));
         FS_TRY(hipEventCreate(&r->ev_start));
         FS_TRY(hipEventCreate(&r->ev_stop));
+        // the stream-ordered allocator keeps freed memory for the next allocation instead of returning it to the driver at
+        // every synchronisation (uploads synchronise: their host buffers are borrowed for the call only)
+        hipMemPool_t pool = nullptr;
+        if (hipDeviceGetDefaultMemPool(&pool, r->device) == hipSuccess && pool) {
+            uint64_t keep = ~0ull;
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+        }
+        (void)hipGetLastError();
     }
     // palette: re-upload when the host pointer or the generation changes (GPU_Render.cu:270-304)
     r->pal_aux_depth = palette_aux_depth;
     if (pal_interleaved && (r->pal_cached_host != pal_interleaved || r->pal_cached_gen != palette_generation ||
                             r->pal_iters != pal_iters)) {
         if (r->pal) {
-            FS_TRY(hipFree(r->pal));
+            FS_TRY(r_free(r, r->pal));
             r->pal = nullptr;
         }
-        FS_TRY(hipMalloc((void **)&r->pal, sizeof(fs_color16) * (size_t)pal_iters));
+        FS_TRY(r_alloc(r, (void **)&r->pal, sizeof(fs_color16) * (size_t)pal_iters, kFrame));
         FS_TRY(hipMemcpyAsync(r->pal, pal_interleaved, sizeof(fs_color16) * (size_t)pal_iters, hipMemcpyDefault,
                               r->compute));
         FS_TRY(hipStreamSynchronize(r->compute)); // host buffer is borrowed for the call only
@@ -467,30 +627,39 @@ uint32_t fs_init_memory(fs_renderer *r, uint32_t w, uint32_t h, uint32_t antiali
     r->iters_external = nullptr;
     r->iters_external_bytes = 0;
 
-    // ResetMemory(..., ResetPerturb::Yes, ...) -- GPU_Render.cu:346
+    // ResetMemory(..., ResetPerturb::Yes, ...) -- GPU_Render.cu:346.  Frees are ordered on the compute stream; the display
+    // stream (progressive RenderCurrent) may still be reading the buffers that are about to go
+    FS_TRY(hipStreamSynchronize(r->display));
     free_perturb(r);
     if (uint32_t e = ensure_iter_buffer(r)) {
         free_all(r);
         return e;
     }
     if (r->colors) {
-        hipFree(r->colors);
+        r_free(r, r->colors);
         r->colors = nullptr;
     }
     if (!r->reduction)
-        FS_TRY(hipMalloc((void **)&r->reduction, sizeof(fs_reduction)));
+        FS_TRY(r_alloc(r, (void **)&r->reduction, sizeof(fs_reduction), kFrame));
     if (!r->stats) {
         // 8 counters; a measurement build (FS_TRACE_WAVES) appends four words per wave of the largest frame it will see
-        r->stats_words = 8;
+        // (words 16..27: per-phase cycle counters of the FS_PROFILE_CYCLES build of the BLA kernel, tools/c5_phase_probe.py;
+        // the two measurement builds are not combined)
+        r->stats_words = 32;
         if (const char *e = getenv("FSMI355_TRACE_WAVES"))
             r->stats_words = 16 + 4 * (size_t)atoll(e);
-        FS_TRY(hipMalloc((void **)&r->stats, r->stats_words * sizeof(uint64_t)));
-        FS_TRY(hipMemset(r->stats, 0, r->stats_words * sizeof(uint64_t)));
+        FS_TRY(r_alloc(r, (void **)&r->stats, r->stats_words * sizeof(uint64_t), kFrame));
+        FS_TRY(hipMemsetAsync(r->stats, 0, r->stats_words * sizeof(uint64_t), r->compute));
     }
     if (!r->queue)
-        FS_TRY(hipMalloc((void **)&r->queue, 64));
-    FS_TRY(hipMalloc((void **)&r->colors, r->n_color_cu * sizeof(fs_color16)));
-    return fs_clear(r);
+        FS_TRY(r_alloc(r, (void **)&r->queue, 64, kFrame));
+    FS_TRY(r_alloc(r, (void **)&r->colors, r->n_color_cu * sizeof(fs_color16), kFrame));
+    if (uint32_t e = fs_clear(r))
+        return e;
+    // the frame buffers were allocated in compute-stream order; the display stream (and the caller's own streams, through
+    // fs_device_iter_buffer) may use them from here on
+    FS_TRY(hipStreamSynchronize(r->compute));
+    return 0;
 }
 
 uint32_t fs_set_row_bands(fs_renderer *r, uint32_t band_first_row, uint32_t band_rows, uint32_t band_stride_rows)
@@ -554,11 +723,11 @@ uint32_t fs_upload_orbit(fs_renderer *r, uint64_t generation, int type_tag, uint
         // GPUReferenceIter<float,Disable> (8 B) / GPUReferenceIter<CudaDblflt,Disable> (16 B), used as uploaded
         const size_t eb = type_tag == FS_T_F32 ? sizeof(fs_orbit_f32) : sizeof(fs_orbit_p2x32);
         if (r->orbit_plain) {
-            FS_TRY(hipFree(r->orbit_plain));
+            FS_TRY(r_free(r, r->orbit_plain));
             r->orbit_plain = nullptr;
         }
         r->orbit_ok = false;
-        FS_TRY(hipMalloc(&r->orbit_plain, (orbit_size + 1) * eb));
+        FS_TRY(r_alloc(r, &r->orbit_plain, (orbit_size + 1) * eb, kInput));
         FS_TRY(hipMemcpyAsync(r->orbit_plain, entries, orbit_size * eb, hipMemcpyDefault, r->compute));
         FS_TRY(hipStreamSynchronize(r->compute));
         r->orbit_size = orbit_size;
@@ -571,11 +740,11 @@ uint32_t fs_upload_orbit(fs_renderer *r, uint64_t generation, int type_tag, uint
     }
     if (type_tag == FS_T_HDR2X32) {
         if (r->orbit_2x32) {
-            FS_TRY(hipFree(r->orbit_2x32));
+            FS_TRY(r_free(r, r->orbit_2x32));
             r->orbit_2x32 = nullptr;
         }
         r->orbit_ok = false;
-        FS_TRY(hipMalloc((void **)&r->orbit_2x32, orbit_size * sizeof(fs_orbit_2x32)));
+        FS_TRY(r_alloc(r, (void **)&r->orbit_2x32, orbit_size * sizeof(fs_orbit_2x32), kInput));
         FS_TRY(hipMemcpyAsync(r->orbit_2x32, entries, orbit_size * sizeof(fs_orbit_2x32), hipMemcpyDefault, r->compute));
         FS_TRY(hipStreamSynchronize(r->compute));
         r->orbit_size = orbit_size;
@@ -588,11 +757,11 @@ uint32_t fs_upload_orbit(fs_renderer *r, uint64_t generation, int type_tag, uint
     }
     if (type_tag == FS_T_F64) {
         if (r->orbit_f64) {
-            FS_TRY(hipFree(r->orbit_f64));
+            FS_TRY(r_free(r, r->orbit_f64));
             r->orbit_f64 = nullptr;
         }
         r->orbit_ok = false;
-        FS_TRY(hipMalloc((void **)&r->orbit_f64, orbit_size * sizeof(fs_orbit_f64)));
+        FS_TRY(r_alloc(r, (void **)&r->orbit_f64, orbit_size * sizeof(fs_orbit_f64), kInput));
         FS_TRY(hipMemcpyAsync(r->orbit_f64, entries, orbit_size * sizeof(fs_orbit_f64), hipMemcpyDefault, r->compute));
         FS_TRY(hipStreamSynchronize(r->compute));
         r->orbit_size = orbit_size;
@@ -604,20 +773,20 @@ uint32_t fs_upload_orbit(fs_renderer *r, uint64_t generation, int type_tag, uint
         return 0;
     }
     if (r->zref) {
-        FS_TRY(hipFree(r->zref));
+        FS_TRY(r_free(r, r->zref));
         r->zref = nullptr;
     }
     if (r->zref64) {
-        FS_TRY(hipFree(r->zref64));
+        FS_TRY(r_free(r, r->zref64));
         r->zref64 = nullptr;
     }
     r->orbit_ok = false;
     const size_t in_bytes = type_tag == FS_T_HDR32 ? sizeof(fs_orbit_hdr32) : sizeof(fs_orbit_hdr64);
     void *raw = nullptr;
-    FS_TRY(hipMalloc(&raw, orbit_size * in_bytes));
+    FS_TRY(r_alloc(r, &raw, orbit_size * in_bytes, kInput));
     // two spare entries: the tuned loops may prefetch one entry past the end
-    hipError_t err = type_tag == FS_T_HDR32 ? hipMalloc((void **)&r->zref, (orbit_size + 2) * sizeof(float4))
-                                            : hipMalloc((void **)&r->zref64, (orbit_size + 2) * sizeof(FsZ64));
+    hipError_t err = type_tag == FS_T_HDR32 ? r_alloc(r, (void **)&r->zref, (orbit_size + 2) * sizeof(float4), kInput)
+                                            : r_alloc(r, (void **)&r->zref64, (orbit_size + 2) * sizeof(FsZ64), kInput);
     if (err == hipSuccess)
         err = hipMemcpyAsync(raw, entries, orbit_size * in_bytes, hipMemcpyDefault, r->compute);
     if (err == hipSuccess) {
@@ -635,7 +804,7 @@ uint32_t fs_upload_orbit(fs_renderer *r, uint64_t generation, int type_tag, uint
     }
     if (err == hipSuccess)
         err = hipStreamSynchronize(r->compute);
-    (void)hipFree(raw);
+    (void)r_free(r, raw);
     if (err != hipSuccess)
         return (uint32_t)err;
     r->orbit_size = orbit_size;
@@ -681,13 +850,13 @@ uint32_t fs_upload_orbit_compressed(fs_renderer *r, uint64_t generation, int typ
             break;
         }
         if (*slot) {
-            FS_TRY(hipFree(*slot));
+            FS_TRY(r_free(r, *slot));
             *slot = nullptr;
         }
         r->orbit_ok = false;
         void *raw = nullptr;
-        FS_TRY(hipMalloc(&raw, compressed_size * in_b));
-        hipError_t err = hipMalloc(slot, (uncompressed_size + 1) * out_b);
+        FS_TRY(r_alloc(r, &raw, compressed_size * in_b, kInput));
+        hipError_t err = r_alloc(r, slot, (uncompressed_size + 1) * out_b, kInput);
         if (err == hipSuccess)
             err = hipMemcpyAsync(raw, entries, compressed_size * in_b, hipMemcpyDefault, r->compute);
         if (err == hipSuccess)
@@ -699,7 +868,7 @@ uint32_t fs_upload_orbit_compressed(fs_renderer *r, uint64_t generation, int typ
         }
         if (err == hipSuccess)
             err = hipStreamSynchronize(r->compute);
-        (void)hipFree(raw);
+        (void)r_free(r, raw);
         if (err != hipSuccess)
             return (uint32_t)err;
         r->orbit_size = compressed_size;
@@ -711,19 +880,19 @@ uint32_t fs_upload_orbit_compressed(fs_renderer *r, uint64_t generation, int typ
         return 0;
     }
     if (r->zref) {
-        FS_TRY(hipFree(r->zref));
+        FS_TRY(r_free(r, r->zref));
         r->zref = nullptr;
     }
     if (r->zref64) {
-        FS_TRY(hipFree(r->zref64));
+        FS_TRY(r_free(r, r->zref64));
         r->zref64 = nullptr;
     }
     r->orbit_ok = false;
     const size_t in_bytes = type_tag == FS_T_HDR32 ? sizeof(fs_orbit_hdr32_rc) : sizeof(fs_orbit_hdr64_rc);
     void *raw = nullptr;
-    FS_TRY(hipMalloc(&raw, compressed_size * in_bytes));
-    hipError_t err = type_tag == FS_T_HDR32 ? hipMalloc((void **)&r->zref, (uncompressed_size + 2) * sizeof(float4))
-                                            : hipMalloc((void **)&r->zref64, (uncompressed_size + 2) * sizeof(FsZ64));
+    FS_TRY(r_alloc(r, &raw, compressed_size * in_bytes, kInput));
+    hipError_t err = type_tag == FS_T_HDR32 ? r_alloc(r, (void **)&r->zref, (uncompressed_size + 2) * sizeof(float4), kInput)
+                                            : r_alloc(r, (void **)&r->zref64, (uncompressed_size + 2) * sizeof(FsZ64), kInput);
     if (err == hipSuccess)
         err = hipMemcpyAsync(raw, entries, compressed_size * in_bytes, hipMemcpyDefault, r->compute);
     if (err == hipSuccess) {
@@ -745,7 +914,7 @@ uint32_t fs_upload_orbit_compressed(fs_renderer *r, uint64_t generation, int typ
     }
     if (err == hipSuccess)
         err = hipStreamSynchronize(r->compute);
-    (void)hipFree(raw);
+    (void)r_free(r, raw);
     if (err != hipSuccess)
         return (uint32_t)err;
     r->orbit_size = compressed_size;
@@ -817,24 +986,13 @@ uint32_t fs_upload_la(fs_renderer *r, uint64_t generation, int type_tag, uint32_
         las = las32.data();
         stages = stages32.data();
     }
-    if (r->las) {
-        FS_TRY(hipFree(r->las));
-        r->las = nullptr;
-    }
-    if (r->stages) {
-        FS_TRY(hipFree(r->stages));
-        r->stages = nullptr;
-    }
     r->la_ok = false;
-    if (n_las) {
-        FS_TRY(hipMalloc((void **)&r->las, (size_t)n_las * la_bytes));
+    FS_TRY(la_reserve(r, (size_t)n_las * la_bytes, (size_t)n_stages * sizeof(fs_la_stage_u32)));
+    if (n_las)
         FS_TRY(hipMemcpyAsync(r->las, las, (size_t)n_las * la_bytes, hipMemcpyDefault, r->compute));
-    }
-    if (n_stages) {
-        FS_TRY(hipMalloc((void **)&r->stages, (size_t)n_stages * sizeof(fs_la_stage_u32)));
+    if (n_stages)
         FS_TRY(hipMemcpyAsync(r->stages, stages, (size_t)n_stages * sizeof(fs_la_stage_u32), hipMemcpyDefault,
                               r->compute));
-    }
     FS_TRY(hipStreamSynchronize(r->compute));
     r->n_las = n_las;
     r->n_stages = n_stages;
@@ -872,33 +1030,18 @@ uint32_t fs_upload_bla(fs_renderer *r, int type_tag, const void *const *levels, 
     const size_t rec_bytes = type_tag == FS_T_HDR32 ? sizeof(fs_bla_hdr32)
                                                     : (type_tag == FS_T_HDR64 ? sizeof(fs_bla_hdr64) : sizeof(fs_bla_f64));
     r->bla_type = type_tag;
-    for (void *p : r->bla_level_mem)
-        if (p)
-            hipFree(p);
-    r->bla_level_mem.clear();
-    r->bla_level_sizes.clear();
-    if (r->bla_levels_dev) {
-        hipFree((void *)r->bla_levels_dev);
-        r->bla_levels_dev = nullptr;
-    }
     r->bla_n_levels = 0;
     if (n_levels <= 0)
         return 0;
-    std::vector<const void *> ptrs((size_t)n_levels, nullptr);
-    for (int32_t l = 0; l < n_levels; l++) {
-        void *d = nullptr;
-        if (levels[l] && level_sizes[l]) {
-            FS_TRY(hipMalloc(&d, level_sizes[l] * rec_bytes));
-            FS_TRY(hipMemcpyAsync(d, levels[l], level_sizes[l] * rec_bytes, hipMemcpyDefault, r->compute));
-        }
-        r->bla_level_mem.push_back(d);
-        r->bla_level_sizes.push_back(d ? level_sizes[l] : 0);
-        ptrs[l] = d;
-    }
-    FS_TRY(hipMalloc((void **)&r->bla_levels_dev, sizeof(void *) * (size_t)n_levels));
-    FS_TRY(hipMemcpyAsync((void *)r->bla_levels_dev, ptrs.data(), sizeof(void *) * (size_t)n_levels, hipMemcpyDefault,
-                          r->compute));
-    FS_TRY(hipStreamSynchronize(r->compute));
+    std::vector<uint64_t> sizes((size_t)n_levels, 0);
+    for (int32_t l = 0; l < n_levels; l++)
+        sizes[(size_t)l] = levels[l] ? level_sizes[l] : 0;
+    FS_TRY(bla_layout(r, sizes.data(), n_levels, rec_bytes));
+    for (int32_t l = 0; l < n_levels; l++)
+        if (sizes[(size_t)l])
+            FS_TRY(hipMemcpyAsync(r->bla_level_mem[(size_t)l], levels[l], sizes[(size_t)l] * rec_bytes, hipMemcpyDefault,
+                                  r->compute));
+    FS_TRY(hipStreamSynchronize(r->compute)); // the host levels are borrowed for the call only
     r->bla_n_levels = n_levels;
     r->bla_lm2 = lm2;
     return 0;
@@ -913,15 +1056,6 @@ uint32_t fs_build_bla(fs_renderer *r, int type_tag, const void *bla_size)
     if (!r->compute || !r->orbit_ok || r->orbit_type != type_tag)
         return FS_ERR_6;
     const size_t rec_bytes = type_tag == FS_T_HDR32 ? sizeof(fs_bla_hdr32) : sizeof(fs_bla_hdr64);
-    for (void *p : r->bla_level_mem)
-        if (p)
-            (void)hipFree(p);
-    r->bla_level_mem.clear();
-    r->bla_level_sizes.clear();
-    if (r->bla_levels_dev) {
-        (void)hipFree((void *)r->bla_levels_dev);
-        r->bla_levels_dev = nullptr;
-    }
     r->bla_n_levels = 0;
     r->bla_type = type_tag;
     // BLAS::Init, BLAS.cpp:218-241: elements per level halve (rounding up) from count-1 down to 1
@@ -937,17 +1071,12 @@ uint32_t fs_build_bla(fs_renderer *r, int type_tag, const void *bla_size)
     int32_t lm2 = n_levels - 2;
     if (lm2 < 0)
         lm2 = 0;
-    // the renderer owns each level from the moment it is allocated (freed by the next build / upload / free_perturb)
-    r->bla_level_mem.assign((size_t)n_levels, nullptr);
-    r->bla_level_sizes.assign((size_t)n_levels, 0);
-    for (int l = 2; l < n_levels; l++) { // m_FirstLevel = 2: levels 0 and 1 are never materialised
-        FS_TRY(hipMalloc(&r->bla_level_mem[(size_t)l], epl[l] * rec_bytes));
-        r->bla_level_sizes[(size_t)l] = epl[l];
-    }
+    std::vector<uint64_t> materialised(epl); // m_FirstLevel = 2: levels 0 and 1 get no memory (NULL pointers)
+    materialised[0] = 0;
+    if (n_levels > 1)
+        materialised[1] = 0;
+    FS_TRY(bla_layout(r, materialised.data(), n_levels, rec_bytes));
     const std::vector<void *> &ptrs = r->bla_level_mem;
-    FS_TRY(hipMalloc((void **)&r->bla_levels_dev, sizeof(void *) * (size_t)n_levels));
-    FS_TRY(hipMemcpyAsync((void *)r->bla_levels_dev, ptrs.data(), sizeof(void *) * (size_t)n_levels, hipMemcpyDefault,
-                          r->compute));
     {
         TimedLaunch t(r);
         if (type_tag == FS_T_HDR32)
@@ -968,15 +1097,23 @@ uint32_t fs_build_bla(fs_renderer *r, int type_tag, const void *bla_size)
 // that touches the orbit or a record on the device.  See the header of kernels_la.hip for the algorithm.
 namespace {
 
-struct DevBuf { // hipFree on scope exit
-    void *p = nullptr;
-    ~DevBuf()
-    {
-        if (p)
-            (void)hipFree(p);
-    }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+// Work arrays of one fs_build_la call, carved out of the renderer's arena (no allocation once the arena has grown to the
+// largest orbit seen): 256-byte aligned slices handed out front to back.
+struct ArenaSlice {
+    void *p;
     template <class T> T *as() const { return (T *)p; }
+};
+struct ArenaCarver {
+    char *base;
+    size_t used = 0;
+    explicit ArenaCarver(void *b) : base((char *)b) {}
+    static size_t padded(size_t bytes) { return (bytes + 255u) & ~(size_t)255u; }
+    template <class T> T *take(size_t bytes)
+    {
+        T *p = (T *)(base + used);
+        used += padded(bytes ? bytes : 16);
+        return p;
+    }
 };
 
 template <class F> void pack_at(const fs::la::ATInfoT<F> &a, fs_renderer *r);
@@ -1025,22 +1162,22 @@ template <class F> uint32_t build_la(fs_renderer *r, const void *max_radius, int
         return FS_ERR_UNSUPPORTED; // degenerate tables (orbits of <= 64 entries) are left to the host builder
     // capacity: a stage never holds more records than elements it was folded from (+ its tail record)
     const size_t cap_states = 2u * ((size_t)maxRef + 2u);
-    DevBuf chebv, mm, steps, pos, nextA, nextB, nextC, reach, rank, table, small, stage_idx, atbuf;
-    FS_TRY(chebv.alloc(sizeof(HR) * (maxRef + 2u)));
-    FS_TRY(mm.alloc(sizeof(HR) * (maxRef + 2u)));
-    FS_TRY(steps.alloc(4u * (maxRef + 2u)));
-    FS_TRY(pos.alloc(4u * (maxRef + 3u)));
-    FS_TRY(nextA.alloc(4u * cap_states));
-    FS_TRY(nextB.alloc(4u * cap_states));
-    FS_TRY(nextC.alloc(4u * cap_states));
-    FS_TRY(reach.alloc(4u * cap_states));
-    FS_TRY(rank.alloc(4u * (cap_states + 1u)));
     // all stages: stage k+1 holds at most half of stage k (+2), so 2 * maxRef + slack bounds the sum
     const size_t cap_recs = 2u * (size_t)maxRef + 64u * kLaLowBound;
-    FS_TRY(table.alloc(sizeof(Rec) * cap_recs));
-    FS_TRY(small.alloc(64));
-    FS_TRY(stage_idx.alloc(4u * kLaMaxStages));
-    FS_TRY(atbuf.alloc(sizeof(fs::la::ATInfoT<F>)));
+    const size_t sizes[13] = {sizeof(HR) * (maxRef + 2u), sizeof(HR) * (maxRef + 2u), 4u * (maxRef + 2u), 4u * (maxRef + 3u),
+                              4u * cap_states,            4u * cap_states,            4u * cap_states,     4u * cap_states,
+                              4u * (cap_states + 1u),     sizeof(Rec) * cap_recs,     64,                  4u * kLaMaxStages,
+                              sizeof(fs::la::ATInfoT<F>)};
+    size_t total = 0;
+    for (size_t b : sizes)
+        total += ArenaCarver::padded(b);
+    FS_TRY(arena_reserve(r, total));
+    ArenaCarver carve(r->arena);
+    ArenaSlice chebv{carve.take<char>(sizes[0])}, mm{carve.take<char>(sizes[1])}, steps{carve.take<char>(sizes[2])},
+        pos{carve.take<char>(sizes[3])}, nextA{carve.take<char>(sizes[4])}, nextB{carve.take<char>(sizes[5])},
+        nextC{carve.take<char>(sizes[6])}, reach{carve.take<char>(sizes[7])}, rank{carve.take<char>(sizes[8])},
+        table{carve.take<char>(sizes[9])}, small{carve.take<char>(sizes[10])}, stage_idx{carve.take<char>(sizes[11])},
+        atbuf{carve.take<char>(sizes[12])};
     uint32_t *d_small = small.as<uint32_t>();
     Rec *d_table = table.as<Rec>();
 
@@ -1197,19 +1334,10 @@ template <class F> uint32_t build_la(fs_renderer *r, const void *max_radius, int
     FS_TRY(hipMemcpyAsync(h, d_small, 4, hipMemcpyDeviceToHost, s));
     FS_TRY(hipStreamSynchronize(s));
 
-    if (r->las) {
-        FS_TRY(hipFree(r->las));
-        r->las = nullptr;
-    }
-    if (r->stages) {
-        FS_TRY(hipFree(r->stages));
-        r->stages = nullptr;
-    }
     r->la_ok = false;
     const size_t rec_bytes = sizeof(F) == 4 ? sizeof(fs_la_hdr32_u32) : sizeof(fs_la_hdr64_u32);
-    FS_TRY(hipMalloc(&r->las, rec_bytes * la_size));
+    FS_TRY(la_reserve(r, rec_bytes * la_size, sizeof(fs_la_stage_u32) * stage_count));
     fsk_la_pack(sizeof(F) == 8, d_table, r->las, la_size, s);
-    FS_TRY(hipMalloc((void **)&r->stages, sizeof(fs_la_stage_u32) * stage_count));
     FS_TRY(hipMemcpyAsync(r->stages, stages.data(), sizeof(fs_la_stage_u32) * stage_count, hipMemcpyHostToDevice, s));
     FS_TRY(hipStreamSynchronize(s));
     FS_TRY(hipGetLastError());
@@ -1504,9 +1632,9 @@ uint32_t fs_render_direct(fs_renderer *r, int type_tag, const void *coords, uint
         return FS_ERR_UNSUPPORTED;
     if (r->cx_row_cap < r->width) {
         if (r->cx_row)
-            FS_TRY(hipFree(r->cx_row));
+            FS_TRY(r_free(r, r->cx_row));
         r->cx_row = nullptr;
-        FS_TRY(hipMalloc(&r->cx_row, (size_t)16 * r->width));
+        FS_TRY(r_alloc(r, &r->cx_row, (size_t)16 * r->width, kFrame));
         r->cx_row_cap = r->width;
     }
     if (type_tag == FS_T_F64) {
@@ -1564,18 +1692,18 @@ uint32_t fs_upload_orbit_scaled(fs_renderer *r, int type_tag, uint32_t iter_byte
     if (!r->compute)
         return FS_ERR_6;
     if (r->scaled_t) {
-        FS_TRY(hipFree(r->scaled_t));
+        FS_TRY(r_free(r, r->scaled_t));
         r->scaled_t = nullptr;
     }
     if (r->scaled_f) {
-        FS_TRY(hipFree(r->scaled_f));
+        FS_TRY(r_free(r, r->scaled_f));
         r->scaled_f = nullptr;
     }
     r->scaled_count = 0;
     const size_t t_bytes = type_tag == FS_T_HDR32 ? sizeof(fs_orbit_hdr32_bad) : sizeof(fs_orbit_f64_bad);
-    FS_TRY(hipMalloc(&r->scaled_t, orbit_size * t_bytes));
+    FS_TRY(r_alloc(r, &r->scaled_t, orbit_size * t_bytes, kInput));
     // (the tuned kernel requests its binary32 entries four steps ahead: up to three entries past the end are read, never used)
-    FS_TRY(hipMalloc((void **)&r->scaled_f, (orbit_size + 8) * sizeof(fs_orbit_f32_bad)));
+    FS_TRY(r_alloc(r, (void **)&r->scaled_f, (orbit_size + 8) * sizeof(fs_orbit_f32_bad), kInput));
     FS_TRY(hipMemsetAsync(r->scaled_f + orbit_size, 0, 8 * sizeof(fs_orbit_f32_bad), r->compute));
     FS_TRY(hipMemcpyAsync(r->scaled_t, entries_t, orbit_size * t_bytes, hipMemcpyDefault, r->compute));
     FS_TRY(hipMemcpyAsync(r->scaled_f, entries_f32, orbit_size * sizeof(fs_orbit_f32_bad), hipMemcpyDefault, r->compute));
@@ -1806,6 +1934,8 @@ uint32_t fs_enqueue_done_callback(fs_renderer *r, fs_done_cb cb, void *user)
         delete t;
     return (uint32_t)e;
 }
+
+uint64_t fs_host_fallback_bytes(const fs_renderer *r) { return r->host_alloc_bytes; }
 
 uint32_t fs_get_width(const fs_renderer *r) { return r->width; }
 uint32_t fs_get_height(const fs_renderer *r) { return r->height; }

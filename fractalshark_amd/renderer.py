@@ -302,6 +302,11 @@ class GPURenderer:
         self._cbs.append(cb)
         return self._lib.fs_enqueue_done_callback(self._h, cb, None)
 
+    @property
+    def host_fallback_bytes(self):
+        """Bytes of input tables this renderer had to place in page-locked host memory (fs_host_fallback_bytes)."""
+        return int(self._lib.fs_host_fallback_bytes(self._h))
+
     # ---- measurement
     def last_kernel_ms(self):
         return float(self._lib.fs_last_kernel_ms(self._h))

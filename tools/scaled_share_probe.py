@@ -1,0 +1,34 @@
+"""Share of the perturbation steps of the tuned LAv2 kernel that run inside scaled runs, by frame size (View 5).
+Usage: python tools/scaled_share_probe.py"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fractalshark_amd import GPURenderer, LAV2_FULL, PARITY_CPU, T_HDR32, inputs  # noqa: E402
+
+r = GPURenderer(0)
+for w, h in ((480, 270), (960, 540), (1920, 1080), (3840, 2160)):
+    v = inputs.View.builtin(5, w, h, antialiasing=1)
+    o = inputs.Orbit(v)
+    la = inputs.LATable(o)
+    co = [(float(c["m"]), int(c["e"])) for c in v.coords_perturb(o)]
+    assert r.InitializeMemory(w, h, 1, None, 0, 0, 0, False) == 0
+    assert r.InitializePerturb(1, o, 0, None, la) == 0
+    for lds in (False, True):
+        r.set_kernel_variant(0, lds_orbit=lds)
+        r.enable_step_count(True)
+        assert r.RenderPerturbLAv2(None, None, None, *co, v.num_iterations, T=T_HDR32, Mode=LAV2_FULL, parity=PARITY_CPU) == 0
+        assert r.SyncComputeStream() == 0
+        st = r.read_step_count()
+        ms_stats = r.last_kernel_ms()
+        r.enable_step_count(False)
+        assert r.RenderPerturbLAv2(None, None, None, *co, v.num_iterations, T=T_HDR32, Mode=LAV2_FULL, parity=PARITY_CPU) == 0
+        assert r.SyncComputeStream() == 0
+        print(json.dumps({"size": "%dx%d" % (w, h), "lds": lds, "kernel_ms": round(r.last_kernel_ms(), 3), "kernel_ms_counting_build": round(ms_stats, 3),
+                          "steps_per_pixel": round(st["perturb_steps"] / (w * h), 1),
+                          "scaled_share": round(st["scaled_steps"] / max(1, st["perturb_steps"]), 4),
+                          "careful_share": round(st["careful_steps"] / max(1, st["perturb_steps"]), 4),
+                          "steps_per_run": round(st["scaled_steps"] / max(1, st["scaled_runs"]), 1),
+                          "lane_utilisation": round(st["perturb_steps"] / max(1, st["lane_slots"]), 4)}), flush=True)
+r.set_kernel_variant(0)
