@@ -85,6 +85,24 @@ template <class F> struct FsLav2ArgsT {
 };
 using FsLav2Args32 = FsLav2ArgsT<float>;
 
+// Device-native BLA table of the HDRFloat<float> kernel (k_bla_make_native, kernels_tables.hip), built once per table next to
+// the reference-layout levels.  All levels >= 2 back to back; position of element ix of level L = level_off[L] + ix.
+//   FsBlaRec  (48 B, 16-byte aligned): what a jump needs, in the order it is used -- the four mantissas as one 16-byte load,
+//             the four exponents as another, then the step count (the reference record is 44 B: it straddles alignment
+//             boundaries and interleaves mantissas with exponents).
+//   ladder    (32 B per position): the r2 of this element and of the first elements of its left sub-trees on the three
+//             levels below -- exactly the (level, index) pairs BLAS::LookupBackwards probes next when this one fails
+//             (BLAS.cpp:256-310) -- as four 64-bit keys (exponent << 32 | mantissa bits): for reduced non-negative values
+//             the reference's lexicographic (exponent, mantissa) compare is ONE signed 64-bit integer compare, and a whole
+//             round of four probes is two 16-byte loads.  Levels below 2 carry INT64_MIN ("never valid").
+struct FsBlaRec {
+    float Axm, Aym, Bxm, Bym;
+    int32_t Axe, Aye, Bxe, Bye;
+    uint32_t l;
+    uint32_t pad_[3];
+};
+constexpr int kBlaMaxLevels = 40;
+
 template <class F> struct FsBlaArgsT {
     uint32_t *out;
     const typename FsDev<F>::Z *zref;
@@ -98,6 +116,10 @@ template <class F> struct FsBlaArgsT {
     uint32_t orbit_count;
     uint32_t n_iterations;
     int32_t lm2;
+    // HDRFloat<float> only: the device-native table (NULL = use `levels`, the reference-layout records)
+    const FsBlaRec *nrec;
+    const int4 *nlad; // two int4 per position
+    uint32_t level_off[kBlaMaxLevels];
 };
 using FsBlaArgs32 = FsBlaArgsT<float>;
 
@@ -237,6 +259,10 @@ void fsk_bla_build_hdr32(const float4 *zref, void *const *levels, const uint64_t
                          hipStream_t s);
 void fsk_bla_build_hdr64(const FsZ64 *zref, void *const *levels, const uint64_t *epl, int n_levels, fs_real_hdr64 bla_size,
                          hipStream_t s);
+// levels: device pointer table of the reference-layout levels; level_off / epl: host arrays [n_levels]; bad: device word that
+// is set when an r2 is not a reduced non-negative finite value (the caller then keeps using the reference-layout table)
+void fsk_bla_make_native(const fs_bla_hdr32 *const *levels, const uint32_t *level_off, const uint64_t *epl, int n_levels,
+                         FsBlaRec *rec, int4 *lad, uint32_t *bad, hipStream_t s);
 void fsk_perturb_scalar_hdr32(const FsBlaArgs32 &A, bool use_bla, bool stats, int variant, hipStream_t s);
 void fsk_perturb_scalar_hdr64(const FsBlaArgsT<double> &A, bool use_bla, bool stats, int variant, hipStream_t s);
 void fsk_perturb_bla_f64(const FsBlaArgsF64 &A, bool use_bla, bool stats, hipStream_t s);

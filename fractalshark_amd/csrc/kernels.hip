@@ -706,7 +706,7 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                      "s_mov_b64 exec, %0"                                                                           \
                      : "=&s"(exec_), "=&s"(keep_), "=&v"(voff_)                                                     \
                      : "s"(idx0_), "s"(last_entry), "s"(dst_), "s"(zs)                                              \
-                     : "memory");                                                                                   \
+                     : "memory", "scc");                                                                                   \
     }
                                 FS_GLDS_CHUNK(0u)
                                 uint32_t chunk = 0;
@@ -1223,6 +1223,49 @@ __device__ __forceinline__ const typename FsDev<F>::BLA *bla_lookup(const typena
     return nullptr;
 }
 
+// The same lookup on the device-native table (FsBlaRec / ladder, kernels.h): returns the POSITION of the record that applies,
+// or ~0u.  One round = the four probes BLAS::LookupBackwards would make next, fetched as two 16-byte loads from one ladder
+// entry and decided with four signed 64-bit compares (key = exponent << 32 | mantissa bits == the reference's
+// lexicographic compare for reduced non-negative values); the first probe that holds, in the reference's order (highest
+// level first), wins -- no assumption about the r2 being monotone along the ladder.  Levels below 2 carry keys that never
+// hold.  No branch per probe, no 64-bit pointer per level: level offsets come from LDS (`off`), positions are 32-bit.
+// 15 of 16 lookups start at level <= 5 and finish in their first round; deeper ones loop (another four levels per round).
+__device__ __forceinline__ uint32_t bla_lookup_native(const int4 *__restrict__ lad, const uint32_t *off, int32_t lm2,
+                                                      uint32_t m, long long zkey, long long key20)
+{
+    const int32_t k = (int32_t)m - 1;
+    const bool first = k == 0;
+    const int32_t zeros = first ? 32 : (int32_t)__ffs(k) - 1; // exponent of (float)(k & -k), BLAS.cpp:283-286
+    uint32_t ix = first ? 0u : (uint32_t)k >> (zeros & 31);
+    int32_t L = zeros <= lm2 ? zeros : lm2;
+    // m == 0: no table entry; odd k: level 0; k == 0: only when the first element of level 2 applies (BLAS.cpp:270-281)
+    bool live = m != 0u && (k & 1) == 0 && L >= 2 && (!first || zkey < key20);
+    uint32_t hit = 0xFFFFFFFFu;
+    while (__builtin_amdgcn_ballot_w64(live) != 0ull) {
+        if (live) {
+            const uint32_t p = off[L] + ix;
+            const int4 a = lad[2u * (size_t)p], b = lad[2u * (size_t)p + 1u];
+            const long long k0 = (long long)(((unsigned long long)(unsigned)a.y << 32) | (unsigned)a.x);
+            const long long k1 = (long long)(((unsigned long long)(unsigned)a.w << 32) | (unsigned)a.z);
+            const long long k2 = (long long)(((unsigned long long)(unsigned)b.y << 32) | (unsigned)b.x);
+            const long long k3 = (long long)(((unsigned long long)(unsigned)b.w << 32) | (unsigned)b.z);
+            int32_t nf = zkey < k3 ? 3 : 4;
+            nf = zkey < k2 ? 2 : nf;
+            nf = zkey < k1 ? 1 : nf;
+            nf = zkey < k0 ? 0 : nf;
+            if (nf < 4) {
+                hit = off[L - nf] + (ix << nf);
+                live = false;
+            } else {
+                L -= 4;
+                ix <<= 4;
+                live = L >= 2;
+            }
+        }
+    }
+    return hit;
+}
+
 } // namespace
 
 // With a table (kBla) the kernel is PERSISTENT and lanes are re-packed: pixels of one wave finish at very different
@@ -1236,14 +1279,25 @@ __device__ __forceinline__ const typename FsDev<F>::BLA *bla_lookup(const typena
 // lanes of a wave at the same orbit position (scalar-cache entries), so that launch stays one tile per wave.
 constexpr uint32_t kRefillEvery = 24;
 
-template <class F, bool kBla, bool kStats, bool kRefill>
+// kNat (HDRFloat<float>, kBla, one tile per wave): the table is read in its device-native form (FsBlaRec + ladder).
+template <class F, bool kBla, bool kStats, bool kRefill, bool kNat = false>
 __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
 {
-    __shared__ const typename FsDev<F>::BLA *s_levels[kBla ? 64 : 1];
-    if constexpr (kBla) {
+    __shared__ const typename FsDev<F>::BLA *s_levels[kBla && !kNat ? 64 : 1];
+    __shared__ uint32_t s_off[kNat ? 64 : 1];
+    if constexpr (kBla && !kNat) {
         if (threadIdx.x < 64u)
             s_levels[threadIdx.x] = (int32_t)threadIdx.x < A.lm2 + 2 ? A.levels[threadIdx.x] : nullptr;
         __syncthreads();
+    }
+    long long nat_key20 = 0;
+    if constexpr (kNat) {
+        if (threadIdx.x < 64u)
+            s_off[threadIdx.x] = threadIdx.x < (uint32_t)kBlaMaxLevels ? A.level_off[threadIdx.x] : 0u;
+        __syncthreads();
+        // key of the first element of level 2 (the k == 0 pre-test): wave-uniform, one scalar load
+        const int4 e20 = A.nlad[2u * (size_t)A.level_off[2]];
+        nat_key20 = (long long)(((unsigned long long)(unsigned)e20.y << 32) | (unsigned)e20.x);
     }
     uint32_t X = 0, L = 0;
     uint64_t c_la = 0, c_pt = 0, c_px = 0;
@@ -1543,15 +1597,38 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                 FS_PH(ph_n_outer++);
                 for (;;) {
                     FS_PH(ph_t = __builtin_readcyclecounter());
-                    b = bla_lookup<F>(s_levels, A.lm2, RefIteration, DeltaNormSquared);
-                    FS_PH(ph_lookup += __builtin_readcyclecounter() - ph_t; ph_n_lookup++);
-                    if (b == nullptr)
-                        break;
-                    const uint32_t l = (uint32_t)b->l;
-                    if (RefIteration + l >= count)
-                        break;
-                    if (iter + l >= n_iterations)
-                        break;
+                    uint32_t l;
+                    hreal<F> Ax, Ay, Bx, By;
+                    if constexpr (kNat) {
+                        const long long zkey = (long long)(((unsigned long long)(unsigned)DeltaNormSquared.e << 32) |
+                                                           (unsigned)__float_as_int(DeltaNormSquared.m));
+                        const uint32_t pos = bla_lookup_native(A.nlad, s_off, A.lm2, RefIteration, zkey, nat_key20);
+                        FS_PH(ph_lookup += __builtin_readcyclecounter() - ph_t; ph_n_lookup++);
+                        if (pos == 0xFFFFFFFFu)
+                            break;
+                        const FsBlaRec *nb = A.nrec + pos;
+                        l = nb->l;
+                        if (RefIteration + l >= count)
+                            break;
+                        if (iter + l >= n_iterations)
+                            break;
+                        const float4 mant = *reinterpret_cast<const float4 *>(&nb->Axm);
+                        const int4 exps = *reinterpret_cast<const int4 *>(&nb->Axe);
+                        Ax = hreal<F>{mant.x, exps.x}, Ay = hreal<F>{mant.y, exps.y};
+                        Bx = hreal<F>{mant.z, exps.z}, By = hreal<F>{mant.w, exps.w};
+                        b = nullptr;
+                    } else {
+                        b = bla_lookup<F>(s_levels, A.lm2, RefIteration, DeltaNormSquared);
+                        FS_PH(ph_lookup += __builtin_readcyclecounter() - ph_t; ph_n_lookup++);
+                        if (b == nullptr)
+                            break;
+                        l = (uint32_t)b->l;
+                        if (RefIteration + l >= count)
+                            break;
+                        if (iter + l >= n_iterations)
+                            break;
+                        Ax = ldr(b->Ax), Ay = ldr(b->Ay), Bx = ldr(b->Bx), By = ldr(b->By);
+                    }
                     FS_PH(ph_t = __builtin_readcyclecounter(); ph_n_jump++;
                           ph_lanes_jump += (uint64_t)__popcll(__builtin_amdgcn_ballot_w64(true)));
                     iter += l;
@@ -1563,7 +1640,6 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                         if (l >= 256u)
                             atomicAdd((unsigned long long *)&A.stats[7], 1ull);
                     }
-                    const hreal<F> Ax = ldr(b->Ax), Ay = ldr(b->Ay), Bx = ldr(b->Bx), By = ldr(b->By);
                     const hcplx<F> Z = zref_at(zr, RefIteration + l);
                     bool applied = false;
                     if constexpr (std::is_same<F, float>::value) {
@@ -2630,6 +2706,15 @@ static void launch_perturb_scalar(const FsBlaArgsT<F> &A, bool use_bla, bool sta
             hipLaunchKernelGGL((k_perturb_scalar<F, true, false, true>),
                                persistent_grid(k_perturb_scalar<F, true, false, true>, A.frame), b, 0, s, A);
     } else if (use_bla) {
+        if constexpr (std::is_same<F, float>::value) {
+            if (A.nrec != nullptr && (variant & FS_VARIANT_BASE_MASK) != FS_VARIANT_LITERAL) {
+                if (stats)
+                    hipLaunchKernelGGL((k_perturb_scalar<F, true, true, false, true>), g, b, 0, s, A);
+                else
+                    hipLaunchKernelGGL((k_perturb_scalar<F, true, false, false, true>), g, b, 0, s, A);
+                return;
+            }
+        }
         if (stats)
             hipLaunchKernelGGL((k_perturb_scalar<F, true, true, false>), g, b, 0, s, A);
         else

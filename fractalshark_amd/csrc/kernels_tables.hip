@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstring>
+
 #include "../../include/fs_layout.h"
 #include "hdr_math.hpp"
 #include "kernels.h"
@@ -164,6 +166,78 @@ static void build_levels(const Z *zref, void *const *levels, const uint64_t *epl
         hipLaunchKernelGGL((k_bla_merge<F>), dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, s, (const B *)levels[src],
                            epl[src], (B *)levels[src + 1], nd, blaSize);
     }
+}
+
+// ---- device-native form of an HDRFloat<float> table (see FsBlaRec in kernels.h)
+namespace {
+
+struct NativeGeom {
+    uint32_t level_off[kBlaMaxLevels];
+    uint32_t level_n[kBlaMaxLevels];
+    int32_t n_levels;
+    uint32_t total;
+};
+
+__device__ __forceinline__ long long r2_key(fs_real_hdr32 r2, uint32_t *bad)
+{
+    const int bits = __float_as_int(r2.m);
+    // the integer compare equals the reference's float compare of the mantissas only for non-negative, non-NaN values
+    if (bits < 0 || (bits & 0x7F800000) == 0x7F800000) {
+        atomicOr(bad, 1u);
+        return (long long)0x8000000000000000ull;
+    }
+    return (long long)(((unsigned long long)(unsigned)r2.e << 32) | (unsigned)bits);
+}
+
+__global__ void __launch_bounds__(256) k_bla_make_native(const fs_bla_hdr32 *const *__restrict__ levels, NativeGeom G,
+                                                         FsBlaRec *__restrict__ rec, int4 *__restrict__ lad,
+                                                         uint32_t *__restrict__ bad)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= G.total)
+        return;
+    int32_t L = 2;
+    for (int32_t l = 3; l < G.n_levels; l++)
+        if (G.level_n[l] != 0u && p >= G.level_off[l])
+            L = l;
+    const uint32_t ix = p - G.level_off[L];
+    const fs_bla_hdr32 b = levels[L][ix];
+    FsBlaRec o;
+    o.Axm = b.Ax.m, o.Aym = b.Ay.m, o.Bxm = b.Bx.m, o.Bym = b.By.m;
+    o.Axe = b.Ax.e, o.Aye = b.Ay.e, o.Bxe = b.Bx.e, o.Bye = b.By.e;
+    o.l = (uint32_t)b.l;
+    o.pad_[0] = o.pad_[1] = o.pad_[2] = 0u;
+    rec[p] = o;
+    long long k[4];
+    for (int j = 0; j < 4; j++) {
+        const int32_t Lj = L - j;
+        // (Lj, ix << j) is the first element of the left sub-tree j levels down: it exists whenever (L, ix) does
+        k[j] = Lj >= 2 ? r2_key(levels[Lj][(size_t)ix << j].r2, bad) : (long long)0x8000000000000000ull;
+    }
+    lad[2 * (size_t)p] = make_int4((int)(unsigned long long)k[0], (int)((unsigned long long)k[0] >> 32),
+                                   (int)(unsigned long long)k[1], (int)((unsigned long long)k[1] >> 32));
+    lad[2 * (size_t)p + 1] = make_int4((int)(unsigned long long)k[2], (int)((unsigned long long)k[2] >> 32),
+                                       (int)(unsigned long long)k[3], (int)((unsigned long long)k[3] >> 32));
+}
+
+} // namespace
+
+void fsk_bla_make_native(const fs_bla_hdr32 *const *levels, const uint32_t *level_off, const uint64_t *epl, int n_levels,
+                         FsBlaRec *rec, int4 *lad, uint32_t *bad, hipStream_t s)
+{
+    NativeGeom G;
+    memset(&G, 0, sizeof(G));
+    G.n_levels = n_levels;
+    uint32_t total = 0;
+    for (int l = 2; l < n_levels && l < kBlaMaxLevels; l++) {
+        G.level_off[l] = level_off[l];
+        G.level_n[l] = (uint32_t)epl[l];
+        total = level_off[l] + (uint32_t)epl[l];
+    }
+    G.total = total;
+    if (total == 0)
+        return;
+    hipLaunchKernelGGL(k_bla_make_native, dim3((total + 255u) / 256u), dim3(256), 0, s, levels, G, rec, lad, bad);
 }
 
 void fsk_bla_build_hdr32(const float4 *zref, void *const *levels, const uint64_t *epl, int n_levels, fs_real_hdr32 bla_size,

@@ -112,6 +112,12 @@ struct fs_renderer {
     void *bla_block = nullptr;       // ONE allocation for the BLA table: the level pointer table, then the levels
     size_t bla_block_cap = 0;
     size_t las_cap = 0, stages_cap = 0; // bytes behind `las` / `stages` (reused by the next table when they fit)
+    // device-native form of an HDRFloat<float> BLA table (FsBlaRec + ladder, kernels.h): [flag word | records | ladder]
+    void *bla_native = nullptr;
+    size_t bla_native_cap = 0;
+    bool bla_native_ok = false;
+    uint32_t bla_native_total = 0;
+    uint32_t bla_level_off[kBlaMaxLevels] = {0};
 
     void *iters() const { return iters_external ? iters_external : iters_internal; }
     bool memory_initialized() const { return iters() != nullptr && width != 0; }
@@ -288,6 +294,10 @@ constexpr size_t kBlaPtrTableBytes = 64 * sizeof(void *);
 
 void bla_release(fs_renderer *r)
 {
+    (void)r_free(r, r->bla_native);
+    r->bla_native = nullptr;
+    r->bla_native_cap = 0;
+    r->bla_native_ok = false;
     (void)r_free(r, r->bla_block);
     r->bla_block = nullptr;
     r->bla_block_cap = 0;
@@ -327,6 +337,48 @@ hipError_t bla_layout(fs_renderer *r, const uint64_t *sizes, int32_t n_levels, s
     r->bla_levels_dev = (const void **)r->bla_block;
     return hipMemcpyAsync(r->bla_block, r->bla_level_mem.data(), sizeof(void *) * (size_t)n_levels, hipMemcpyHostToDevice,
                           r->compute);
+}
+
+// Device-native form of the HDRFloat<float> table just installed in the block (see FsBlaRec, kernels.h).  Leaves
+// bla_native_ok = false -- the kernels then read the reference-layout records -- when the table has more than
+// kBlaMaxLevels levels or 2^32 records, when memory for it cannot be had, or when an r2 is not a reduced non-negative finite
+// value (the integer-key compare would then differ from the reference's float compare).  Synchronises the compute stream.
+uint32_t bla_make_native(fs_renderer *r, int32_t n_levels)
+{
+    r->bla_native_ok = false;
+    if (n_levels <= 2 || n_levels > kBlaMaxLevels)
+        return 0;
+    uint64_t total = 0;
+    for (int32_t l = 2; l < n_levels; l++) {
+        r->bla_level_off[l] = (uint32_t)total;
+        total += r->bla_level_sizes[(size_t)l];
+    }
+    if (total == 0 || total > 0xFFFFFFF0ull)
+        return 0;
+    const size_t need = 256 + (size_t)total * (sizeof(FsBlaRec) + 2 * sizeof(int4));
+    if (!r->bla_native || r->bla_native_cap < need) {
+        (void)r_free(r, r->bla_native);
+        r->bla_native = nullptr;
+        r->bla_native_cap = 0;
+        if (r_alloc(r, &r->bla_native, need, kInput) != hipSuccess) {
+            (void)hipGetLastError();
+            return 0; // not an error: the reference-layout table serves
+        }
+        r->bla_native_cap = need;
+    }
+    uint32_t *bad = (uint32_t *)r->bla_native;
+    FsBlaRec *rec = (FsBlaRec *)((char *)r->bla_native + 256);
+    int4 *lad = (int4 *)((char *)rec + (size_t)total * sizeof(FsBlaRec));
+    FS_TRY(hipMemsetAsync(bad, 0, 256, r->compute));
+    fsk_bla_make_native((const fs_bla_hdr32 *const *)r->bla_levels_dev, r->bla_level_off, r->bla_level_sizes.data(), n_levels,
+                        rec, lad, bad, r->compute);
+    FS_TRY(hipGetLastError());
+    uint32_t flag = 1;
+    FS_TRY(hipMemcpyAsync(&flag, bad, 4, hipMemcpyDeviceToHost, r->compute));
+    FS_TRY(hipStreamSynchronize(r->compute));
+    r->bla_native_total = (uint32_t)total;
+    r->bla_native_ok = flag == 0;
+    return 0;
 }
 
 void free_perturb(fs_renderer *r)
@@ -1044,6 +1096,9 @@ uint32_t fs_upload_bla(fs_renderer *r, int type_tag, const void *const *levels, 
     FS_TRY(hipStreamSynchronize(r->compute)); // the host levels are borrowed for the call only
     r->bla_n_levels = n_levels;
     r->bla_lm2 = lm2;
+    r->bla_native_ok = false;
+    if (type_tag == FS_T_HDR32)
+        return bla_make_native(r, n_levels);
     return 0;
 }
 
@@ -1088,6 +1143,9 @@ uint32_t fs_build_bla(fs_renderer *r, int type_tag, const void *bla_size)
     FS_TRY(hipStreamSynchronize(r->compute)); // ptrs / epl are host temporaries of this call
     r->bla_n_levels = n_levels;
     r->bla_lm2 = lm2;
+    r->bla_native_ok = false;
+    if (type_tag == FS_T_HDR32)
+        return bla_make_native(r, n_levels);
     return 0;
 }
 
@@ -1599,6 +1657,11 @@ uint32_t fs_render_bla(fs_renderer *r, int type_tag, const void *coords, uint64_
         A.orbit_count = (uint32_t)r->orbit_uncompressed;
         A.n_iterations = (uint32_t)n_iterations;
         A.lm2 = r->bla_lm2;
+        if (use_bla && r->bla_native_ok) {
+            A.nrec = (const FsBlaRec *)((const char *)r->bla_native + 256);
+            A.nlad = (const int4 *)((const char *)A.nrec + (size_t)r->bla_native_total * sizeof(FsBlaRec));
+            memcpy(A.level_off, r->bla_level_off, sizeof(A.level_off));
+        }
         TimedLaunch t(r);
         fsk_perturb_scalar_hdr32(A, use_bla, r->stats_on, r->variant, r->compute);
     } else {

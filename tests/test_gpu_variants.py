@@ -213,3 +213,42 @@ def test_lav2_hdr32_step_counters_equal_the_oracles(renderer, native_libs, parit
         at_len = int(la.at.StepLength)
         if la.use_at:
             assert int(out[:256, :256].astype(np.uint64).sum()) == got["at_iterations"] * at_len + got["perturb_steps"] - escaped
+
+
+# ---- the device-native BLA table (FsBlaRec + ladder keys) against the reference-layout lookup
+@pytest.mark.parametrize("view_n,w,h", [(19, 64, 36), (19, 203, 117), (5, 64, 36), (1, 96, 54), (9, 96, 54)])
+def test_native_bla_table_equals_reference_layout_lookup(renderer, native_libs, view_n, w, h):
+    """The HDRFloat<float> BLA kernel reads its table in a device-native form by default (48-byte records, the four r2 a
+    lookup probes next as 64-bit integer keys in one ladder entry); variant 1 keeps the lookup on the reference-layout
+    records (44-byte AoS, extended-exponent compares).  Same frames, same jumps, same steps -- with the host-built table
+    and with the table built on the device."""
+    v = inputs.View.builtin(view_n, w, h, antialiasing=1)
+    ob = inputs.Orbit(v)
+    bla = inputs.BLATable(ob)
+    r = renderer
+    got = {}
+    try:
+        for name, variant in (("native", 0), ("reference_layout", 1)):
+            assert r.set_kernel_variant(variant) == 0
+            r.enable_step_count(True)
+            out = _bla(r, v, ob, bla)
+            got[name] = (out, r.read_step_count())
+            r.enable_step_count(False)
+        # device-built table (fs_build_bla), native form made from it
+        assert r.set_kernel_variant(0) == 0
+        assert r.InitializeMemory(w, h, 1, None, 0, 0, 0, False) == 0
+        assert r._lib.fs_upload_orbit(r._h, 0, T_HDR32, 4, ob.data_ptr, ob.count, ob.count, ob.period) == 0
+        assert r.BuildBLAOnDevice(ob) == 0
+        assert r._lib.fs_render_bla(r._h, T_HDR32, v.coords_perturb(ob).ctypes.data, v.num_iterations) == 0
+        dev = r.new_iter_buffer()
+        assert r.RenderCurrent(v.num_iterations, dev) == 0
+        assert r.SyncComputeStream() == 0
+    finally:
+        r.enable_step_count(False)
+        r.set_kernel_variant(0)
+    assert np.array_equal(got["native"][0], got["reference_layout"][0]), int((got["native"][0] != got["reference_layout"][0]).sum())
+    assert np.array_equal(dev, got["native"][0])
+    for k in ("perturb_steps", "la_steps", "pixels"):
+        assert got["native"][1][k] == got["reference_layout"][1][k], k
+    if w * h <= 64 * 36:
+        assert np.array_equal(got["native"][0], _oracle.bla_hdr32(v, ob, bla))
