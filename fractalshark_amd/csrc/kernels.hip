@@ -1307,7 +1307,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
     // The clock is read on the scalar unit, i.e. once per pass of the WAVE through the code, whatever the lane mask is.
     uint64_t ph_lookup = 0, ph_jump = 0, ph_step = 0, ph_literal = 0, ph_t = 0;
     uint64_t ph_n_lookup = 0, ph_n_jump = 0, ph_n_step = 0, ph_n_literal = 0, ph_n_outer = 0;
-    uint64_t ph_lanes_jump = 0, ph_lanes_step = 0;
+    uint64_t ph_lanes_jump = 0, ph_lanes_step = 0, ph_n_scaled = 0;
 #define FS_PH(stmt) do { if (kStats && kBla) { stmt; } } while (0)
 #else
 #define FS_PH(stmt) do { } while (0)
@@ -2082,6 +2082,71 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
 
             FS_PH(ph_t = __builtin_readcyclecounter(); ph_n_step++;
                   ph_lanes_step += (uint64_t)__popcll(__builtin_amdgcn_ballot_w64(true)));
+            // ---- with a table, float: the step between two lookups as ONE scaled step (a scaled run of length one, see the
+            // perturbation-only path above and k_lav2_hdr32_fast): the lane's dz under the power-of-two scale 2^E of its
+            // larger part, dz' 2^-E = w (2Z + w 2^E) + dc 2^-E on plain floats -- the reference's roundings, no exponent
+            // bookkeeping -- accepted when the start entry vouches for an exact 2Z (companion .w), the start state and the
+            // result have their parts within 2^40 of each other and inside the scale's window, and the result is at most a
+            // quarter of the orbit value it arrives at (then neither exit test of the reference's loop can fire, so z and
+            // its norm are not formed).  Lanes sit at unrelated orbit positions here (every lane has jumped on its own), so
+            // each lane has its own E and reads its own two companion entries; the vote is over the stepping lanes, and a
+            // wave with a lane that does not qualify takes the straight-line HDRFloat step below, which decides exactly.
+            // About a third of that step's instructions.
+            if constexpr (kBla && !kRefill && std::is_same<F, float>::value) {
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                const float4 *__restrict__ zs = A.zs;
+                const float4 e0 = zs[RefIteration];
+                const float4 e1 = zs[RefIteration + 1]; // in bounds: the companions hold count + 2 entries
+                // a jump leaves dz's parts un-reduced: E is the exponent of the larger part's VALUE
+                const int kx = (int)__builtin_amdgcn_ubfe(__float_as_int(DeltaSubNX.m), 23, 8) - 127;
+                const int ky = (int)__builtin_amdgcn_ubfe(__float_as_int(DeltaSubNY.m), 23, 8) - 127;
+                const int E = imax(DeltaSubNX.e + kx, DeltaSubNY.e + ky);
+                const f2 w = {__builtin_amdgcn_ldexpf(DeltaSubNX.m, imax(DeltaSubNX.e - E, -200)),
+                              __builtin_amdgcn_ldexpf(DeltaSubNY.m, imax(DeltaSubNY.e - E, -200))};
+                const float sE = __builtin_amdgcn_ldexpf(1.0f, E);
+                const int dshx = DeltaSub0X.e - E, dshy = DeltaSub0Y.e - E;
+                const f2 dcs = {__builtin_amdgcn_ldexpf(DeltaSub0X.m, imax(imin(dshx, 100), -200)),
+                                __builtin_amdgcn_ldexpf(DeltaSub0Y.m, imax(imin(dshy, 100), -200))};
+                const float mx0 = __builtin_fmaxf(__builtin_fabsf(w.x), __builtin_fabsf(w.y));
+                const float mn0 = __builtin_fminf(__builtin_fabsf(w.x), __builtin_fabsf(w.y));
+                const int Esh = (E < -254 ? -254 : (E > 0 ? 0 : E)) * (1 << 23);
+                const bool start_ok = e0.w != 0.0f && mn0 >= mx0 * 0x1p-40f && mx0 >= 1.0f && mx0 < 2.0f &&
+                                      imax(dshx, dshy) <= 30 && RefIteration + 2 < count;
+                const f2 sE2 = {sE, sE};
+                const f2 s_ = __builtin_elementwise_fma(w, sE2, (f2){e0.x, e0.y});
+                const f2 pa_ = w.xx * s_;
+                const f2 pb_ = w.yy * s_.yx;
+                f2 p_;
+                asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(p_) : "v"(pa_), "v"(pb_));
+                const f2 nw = p_ + dcs;
+                const float mx1 = __builtin_fmaxf(__builtin_fabsf(nw.x), __builtin_fabsf(nw.y));
+                const float mn1 = __builtin_fminf(__builtin_fabsf(nw.x), __builtin_fabsf(nw.y));
+                const bool step_ok = start_ok && !(__float_as_int(mx1) + Esh > __float_as_int(e1.z)) &&
+                                     mn1 >= mx1 * 0x1p-40f &&
+                                     (uint32_t)(__float_as_int(mx1) - (107 << 23)) < (uint32_t)(60 << 23);
+                if (__builtin_amdgcn_ballot_w64(!step_ok) == 0ull) {
+                    // back to two reduced HDRFloats (exact: no part of an accepted state is zero), and |dz'|^2 for the
+                    // next lookup: the float sum of the float squares under the same scale, i.e. the reference's
+                    // Reduce(X X + Y Y) (parts at most 2^40 apart: its alignment rule drops nothing)
+                    const int nkx = (int)__builtin_amdgcn_ubfe(__float_as_int(nw.x), 23, 8) - 127;
+                    const int nky = (int)__builtin_amdgcn_ubfe(__float_as_int(nw.y), 23, 8) - 127;
+                    DeltaSubNX = hreal<F>{__builtin_amdgcn_ldexpf(nw.x, -nkx), E + nkx};
+                    DeltaSubNY = hreal<F>{__builtin_amdgcn_ldexpf(nw.y, -nky), E + nky};
+                    const f2 sq = nw * nw;
+                    const int nb = __float_as_int(sq.x + sq.y);
+                    DeltaNormSquared = hreal<F>{__int_as_float((nb & 0x007FFFFF) | 0x3F800000),
+                                                (E << 1) + (int)__builtin_amdgcn_ubfe(nb, 23, 8) - 127};
+                    ++RefIteration;
+                    ++iter;
+                    Zcached_at = 0xFFFFFFFFu;
+                    if (kStats) {
+                        c_pt++;
+                        c_single++;
+                    }
+                    FS_PH(ph_step += __builtin_readcyclecounter() - ph_t; ph_n_scaled++);
+                    continue;
+                }
+            }
             const hreal<F> OX = DeltaSubNX, OY = DeltaSubNY;
             // The orbit entry read for the escape test of the previous step is the Z of this step unless a rebase or a
             // BLA jump moved RefIteration: one dependent 16-byte load per step instead of two.
@@ -2297,9 +2362,9 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
 #ifdef FS_PROFILE_CYCLES
     if (kStats && kBla && (threadIdx.x & 63) == 0) {
         // slots 16.. of the statistics buffer (fs_read_stats_raw; the renderer allocates them in this build)
-        const uint64_t v[12] = {ph_lookup, ph_jump, ph_step, ph_literal, ph_n_lookup, ph_n_jump,
-                                ph_n_step, ph_n_literal, ph_n_outer, ph_lanes_jump, ph_lanes_step, 1};
-        for (int i = 0; i < 12; i++)
+        const uint64_t v[13] = {ph_lookup, ph_jump, ph_step, ph_literal, ph_n_lookup, ph_n_jump,
+                                ph_n_step, ph_n_literal, ph_n_outer, ph_lanes_jump, ph_lanes_step, 1, ph_n_scaled};
+        for (int i = 0; i < 13; i++)
             atomicAdd((unsigned long long *)&A.stats[16 + i], (unsigned long long)v[i]);
     }
 #endif

@@ -39,7 +39,7 @@ for _ in range(2):
 raw = (C.c_uint64 * 32)()
 assert lib.fs_read_stats_raw(r._h, raw, 32) == 0
 st = r.read_step_count()
-ph = list(raw)[16:28]
+ph = list(raw)[16:29]
 names = ["lookup", "jump", "step", "literal"]
 cyc = dict(zip(names, ph[0:4]))
 n = dict(zip(names, ph[4:8]))
@@ -53,5 +53,6 @@ out = {"frame": "%dx%d" % (W, H), "kernel_ms_instrumented": round(r.last_kernel_
        "active_lanes_per_jump_pass": round(lanes_jump / max(1, n["jump"]), 2),
        "active_lanes_per_step_pass": round(lanes_step / max(1, n["step"]), 2),
        "lookup_passes_per_outer_trip": round(n["lookup"] / max(1, outer), 3),
-       "jump_passes_per_outer_trip": round(n["jump"] / max(1, outer), 3)}
+       "jump_passes_per_outer_trip": round(n["jump"] / max(1, outer), 3),
+       "step_passes_taken_as_one_scaled_step": round(ph[12] / max(1, n["step"]), 4)}
 print(json.dumps(out))
