@@ -1223,36 +1223,53 @@ __device__ __forceinline__ const typename FsDev<F>::BLA *bla_lookup(const typena
     return nullptr;
 }
 
-// The same lookup on the device-native table (FsBlaRec / ladder, kernels.h): returns the POSITION of the record that applies,
-// or ~0u.  One round = the four probes BLAS::LookupBackwards would make next, fetched as two 16-byte loads from one ladder
-// entry and decided with four signed 64-bit compares (key = exponent << 32 | mantissa bits == the reference's
-// lexicographic compare for reduced non-negative values); the first probe that holds, in the reference's order (highest
-// level first), wins -- no assumption about the r2 being monotone along the ladder.  Levels below 2 carry keys that never
-// hold.  No branch per probe, no 64-bit pointer per level: level offsets come from LDS (`off`), positions are 32-bit.
+// The same lookup on the device-native table (FsBlaRec, kernels.h): returns the POSITION of the record that applies, or ~0u.
+// One round = the four probes BLAS::LookupBackwards would make next, fetched as ONE 16-byte load (the ladder of the start
+// element) and decided with integer compares of 32-bit order keys; the first probe that holds, in the reference's order
+// (highest level first), wins -- no assumption about the r2 being monotone along the ladder.  A probe whose keys are EQUAL
+// is undecided (the key drops low mantissa bits): that lane decides its round exactly, on the reference-layout records
+// (`levels`), with the reference's compare -- about one round in 2^16, so the exact code is a cold branch.  No branch per
+// probe, no 64-bit pointer per level: level offsets come from LDS (`off`), positions are 32-bit.
 // 15 of 16 lookups start at level <= 5 and finish in their first round; deeper ones loop (another four levels per round).
-__device__ __forceinline__ uint32_t bla_lookup_native(const int4 *__restrict__ lad, const uint32_t *off, int32_t lm2,
-                                                      uint32_t m, long long zkey, long long key20)
+__device__ __forceinline__ uint32_t bla_lookup_native(const FsBlaRec *__restrict__ rec, const fs_bla_hdr32 *const *levels,
+                                                      const uint32_t *off, int32_t lm2, uint32_t m, hreal<float> z2,
+                                                      FsBlaKeyFormat fmt, uint32_t key20)
 {
     const int32_t k = (int32_t)m - 1;
     const bool first = k == 0;
     const int32_t zeros = first ? 32 : (int32_t)__ffs(k) - 1; // exponent of (float)(k & -k), BLAS.cpp:283-286
     uint32_t ix = first ? 0u : (uint32_t)k >> (zeros & 31);
     int32_t L = zeros <= lm2 ? zeros : lm2;
-    // m == 0: no table entry; odd k: level 0; k == 0: only when the first element of level 2 applies (BLAS.cpp:270-281)
-    bool live = m != 0u && (k & 1) == 0 && L >= 2 && (!first || zkey < key20);
+    const uint32_t zc = fs_bla_order_key(z2.e, __float_as_int(z2.m), fmt);
+    // m == 0: no table entry; odd k: level 0; k == 0: only when the first element of level 2 applies (BLAS.cpp:270-281;
+    // equal keys: decided exactly)
+    bool pre = !first || zc < key20;
+    if (__builtin_expect(first && zc == key20, 0))
+        pre = hr_cmp_pos(z2, ldr(levels[2][0].r2)) < 0;
+    bool live = m != 0u && (k & 1) == 0 && L >= 2 && pre;
     uint32_t hit = 0xFFFFFFFFu;
     while (__builtin_amdgcn_ballot_w64(live) != 0ull) {
         if (live) {
             const uint32_t p = off[L] + ix;
-            const int4 a = lad[2u * (size_t)p], b = lad[2u * (size_t)p + 1u];
-            const long long k0 = (long long)(((unsigned long long)(unsigned)a.y << 32) | (unsigned)a.x);
-            const long long k1 = (long long)(((unsigned long long)(unsigned)a.w << 32) | (unsigned)a.z);
-            const long long k2 = (long long)(((unsigned long long)(unsigned)b.y << 32) | (unsigned)b.x);
-            const long long k3 = (long long)(((unsigned long long)(unsigned)b.w << 32) | (unsigned)b.z);
-            int32_t nf = zkey < k3 ? 3 : 4;
-            nf = zkey < k2 ? 2 : nf;
-            nf = zkey < k1 ? 1 : nf;
-            nf = zkey < k0 ? 0 : nf;
+            const uint4 q = *reinterpret_cast<const uint4 *>(rec[p].lad);
+            int32_t nf = zc < q.w ? 3 : 4;
+            nf = zc < q.z ? 2 : nf;
+            nf = zc < q.y ? 1 : nf;
+            nf = zc < q.x ? 0 : nf;
+            // undecided: an equal key at a probe that comes before the first proven one
+            const bool tie = (zc == q.x) || (zc == q.y && nf > 1) || (zc == q.z && nf > 2) || (zc == q.w && nf > 3);
+            if (__builtin_expect(tie, 0)) {
+                nf = 4;
+                for (int32_t j = 0; j < 4; j++) {
+                    const int32_t Lj = L - j;
+                    if (Lj < 2)
+                        break;
+                    if (hr_cmp_pos(z2, ldr(levels[Lj][(size_t)ix << j].r2)) < 0) {
+                        nf = j;
+                        break;
+                    }
+                }
+            }
             if (nf < 4) {
                 hit = off[L - nf] + (ix << nf);
                 live = false;
@@ -1290,14 +1307,13 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
             s_levels[threadIdx.x] = (int32_t)threadIdx.x < A.lm2 + 2 ? A.levels[threadIdx.x] : nullptr;
         __syncthreads();
     }
-    long long nat_key20 = 0;
+    uint32_t nat_key20 = 0;
     if constexpr (kNat) {
         if (threadIdx.x < 64u)
             s_off[threadIdx.x] = threadIdx.x < (uint32_t)kBlaMaxLevels ? A.level_off[threadIdx.x] : 0u;
         __syncthreads();
         // key of the first element of level 2 (the k == 0 pre-test): wave-uniform, one scalar load
-        const int4 e20 = A.nlad[2u * (size_t)A.level_off[2]];
-        nat_key20 = (long long)(((unsigned long long)(unsigned)e20.y << 32) | (unsigned)e20.x);
+        nat_key20 = A.nrec[A.level_off[2]].lad[0];
     }
     uint32_t X = 0, L = 0;
     uint64_t c_la = 0, c_pt = 0, c_px = 0;
@@ -1307,7 +1323,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
     // The clock is read on the scalar unit, i.e. once per pass of the WAVE through the code, whatever the lane mask is.
     uint64_t ph_lookup = 0, ph_jump = 0, ph_step = 0, ph_literal = 0, ph_t = 0;
     uint64_t ph_n_lookup = 0, ph_n_jump = 0, ph_n_step = 0, ph_n_literal = 0, ph_n_outer = 0;
-    uint64_t ph_lanes_jump = 0, ph_lanes_step = 0, ph_n_scaled = 0;
+    uint64_t ph_lanes_jump = 0, ph_lanes_step = 0, ph_n_scaled = 0; // (ph_n_scaled: step passes taken by a cheap form)
 #define FS_PH(stmt) do { if (kStats && kBla) { stmt; } } while (0)
 #else
 #define FS_PH(stmt) do { } while (0)
@@ -1599,15 +1615,16 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                     FS_PH(ph_t = __builtin_readcyclecounter());
                     uint32_t l;
                     hreal<F> Ax, Ay, Bx, By;
+                    hcplx<F> Znat = hc_zero<F>(); // (kNat) the orbit entry the jump arrives at, from the record
                     if constexpr (kNat) {
-                        const long long zkey = (long long)(((unsigned long long)(unsigned)DeltaNormSquared.e << 32) |
-                                                           (unsigned)__float_as_int(DeltaNormSquared.m));
-                        const uint32_t pos = bla_lookup_native(A.nlad, s_off, A.lm2, RefIteration, zkey, nat_key20);
+                        const uint32_t pos = bla_lookup_native(A.nrec, A.levels, s_off, A.lm2, RefIteration, DeltaNormSquared,
+                                                               A.nkey, nat_key20);
                         FS_PH(ph_lookup += __builtin_readcyclecounter() - ph_t; ph_n_lookup++);
                         if (pos == 0xFFFFFFFFu)
                             break;
                         const FsBlaRec *nb = A.nrec + pos;
-                        l = nb->l;
+                        const float4 tail = *reinterpret_cast<const float4 *>(&nb->Zre); // {Z.re, Z.im, Z.exp, l}
+                        l = (uint32_t)__float_as_int(tail.w);
                         if (RefIteration + l >= count)
                             break;
                         if (iter + l >= n_iterations)
@@ -1616,6 +1633,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                         const int4 exps = *reinterpret_cast<const int4 *>(&nb->Axe);
                         Ax = hreal<F>{mant.x, exps.x}, Ay = hreal<F>{mant.y, exps.y};
                         Bx = hreal<F>{mant.z, exps.z}, By = hreal<F>{mant.w, exps.w};
+                        Znat = hcplx<F>{tail.x, tail.y, __float_as_int(tail.z)};
                         b = nullptr;
                     } else {
                         b = bla_lookup<F>(s_levels, A.lm2, RefIteration, DeltaNormSquared);
@@ -1640,7 +1658,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                         if (l >= 256u)
                             atomicAdd((unsigned long long *)&A.stats[7], 1ull);
                     }
-                    const hcplx<F> Z = zref_at(zr, RefIteration + l);
+                    const hcplx<F> Z = kNat ? Znat : zref_at(zr, RefIteration + l);
                     bool applied = false;
                     if constexpr (std::is_same<F, float>::value) {
                         // ---- BLA::getValue + the two norms in ONE straight-line evaluation for every exponent alignment
@@ -2082,71 +2100,6 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
 
             FS_PH(ph_t = __builtin_readcyclecounter(); ph_n_step++;
                   ph_lanes_step += (uint64_t)__popcll(__builtin_amdgcn_ballot_w64(true)));
-            // ---- with a table, float: the step between two lookups as ONE scaled step (a scaled run of length one, see the
-            // perturbation-only path above and k_lav2_hdr32_fast): the lane's dz under the power-of-two scale 2^E of its
-            // larger part, dz' 2^-E = w (2Z + w 2^E) + dc 2^-E on plain floats -- the reference's roundings, no exponent
-            // bookkeeping -- accepted when the start entry vouches for an exact 2Z (companion .w), the start state and the
-            // result have their parts within 2^40 of each other and inside the scale's window, and the result is at most a
-            // quarter of the orbit value it arrives at (then neither exit test of the reference's loop can fire, so z and
-            // its norm are not formed).  Lanes sit at unrelated orbit positions here (every lane has jumped on its own), so
-            // each lane has its own E and reads its own two companion entries; the vote is over the stepping lanes, and a
-            // wave with a lane that does not qualify takes the straight-line HDRFloat step below, which decides exactly.
-            // About a third of that step's instructions.
-            if constexpr (kBla && !kRefill && std::is_same<F, float>::value) {
-                typedef float f2 __attribute__((ext_vector_type(2)));
-                const float4 *__restrict__ zs = A.zs;
-                const float4 e0 = zs[RefIteration];
-                const float4 e1 = zs[RefIteration + 1]; // in bounds: the companions hold count + 2 entries
-                // a jump leaves dz's parts un-reduced: E is the exponent of the larger part's VALUE
-                const int kx = (int)__builtin_amdgcn_ubfe(__float_as_int(DeltaSubNX.m), 23, 8) - 127;
-                const int ky = (int)__builtin_amdgcn_ubfe(__float_as_int(DeltaSubNY.m), 23, 8) - 127;
-                const int E = imax(DeltaSubNX.e + kx, DeltaSubNY.e + ky);
-                const f2 w = {__builtin_amdgcn_ldexpf(DeltaSubNX.m, imax(DeltaSubNX.e - E, -200)),
-                              __builtin_amdgcn_ldexpf(DeltaSubNY.m, imax(DeltaSubNY.e - E, -200))};
-                const float sE = __builtin_amdgcn_ldexpf(1.0f, E);
-                const int dshx = DeltaSub0X.e - E, dshy = DeltaSub0Y.e - E;
-                const f2 dcs = {__builtin_amdgcn_ldexpf(DeltaSub0X.m, imax(imin(dshx, 100), -200)),
-                                __builtin_amdgcn_ldexpf(DeltaSub0Y.m, imax(imin(dshy, 100), -200))};
-                const float mx0 = __builtin_fmaxf(__builtin_fabsf(w.x), __builtin_fabsf(w.y));
-                const float mn0 = __builtin_fminf(__builtin_fabsf(w.x), __builtin_fabsf(w.y));
-                const int Esh = (E < -254 ? -254 : (E > 0 ? 0 : E)) * (1 << 23);
-                const bool start_ok = e0.w != 0.0f && mn0 >= mx0 * 0x1p-40f && mx0 >= 1.0f && mx0 < 2.0f &&
-                                      imax(dshx, dshy) <= 30 && RefIteration + 2 < count;
-                const f2 sE2 = {sE, sE};
-                const f2 s_ = __builtin_elementwise_fma(w, sE2, (f2){e0.x, e0.y});
-                const f2 pa_ = w.xx * s_;
-                const f2 pb_ = w.yy * s_.yx;
-                f2 p_;
-                asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(p_) : "v"(pa_), "v"(pb_));
-                const f2 nw = p_ + dcs;
-                const float mx1 = __builtin_fmaxf(__builtin_fabsf(nw.x), __builtin_fabsf(nw.y));
-                const float mn1 = __builtin_fminf(__builtin_fabsf(nw.x), __builtin_fabsf(nw.y));
-                const bool step_ok = start_ok && !(__float_as_int(mx1) + Esh > __float_as_int(e1.z)) &&
-                                     mn1 >= mx1 * 0x1p-40f &&
-                                     (uint32_t)(__float_as_int(mx1) - (107 << 23)) < (uint32_t)(60 << 23);
-                if (__builtin_amdgcn_ballot_w64(!step_ok) == 0ull) {
-                    // back to two reduced HDRFloats (exact: no part of an accepted state is zero), and |dz'|^2 for the
-                    // next lookup: the float sum of the float squares under the same scale, i.e. the reference's
-                    // Reduce(X X + Y Y) (parts at most 2^40 apart: its alignment rule drops nothing)
-                    const int nkx = (int)__builtin_amdgcn_ubfe(__float_as_int(nw.x), 23, 8) - 127;
-                    const int nky = (int)__builtin_amdgcn_ubfe(__float_as_int(nw.y), 23, 8) - 127;
-                    DeltaSubNX = hreal<F>{__builtin_amdgcn_ldexpf(nw.x, -nkx), E + nkx};
-                    DeltaSubNY = hreal<F>{__builtin_amdgcn_ldexpf(nw.y, -nky), E + nky};
-                    const f2 sq = nw * nw;
-                    const int nb = __float_as_int(sq.x + sq.y);
-                    DeltaNormSquared = hreal<F>{__int_as_float((nb & 0x007FFFFF) | 0x3F800000),
-                                                (E << 1) + (int)__builtin_amdgcn_ubfe(nb, 23, 8) - 127};
-                    ++RefIteration;
-                    ++iter;
-                    Zcached_at = 0xFFFFFFFFu;
-                    if (kStats) {
-                        c_pt++;
-                        c_single++;
-                    }
-                    FS_PH(ph_step += __builtin_readcyclecounter() - ph_t; ph_n_scaled++);
-                    continue;
-                }
-            }
             const hreal<F> OX = DeltaSubNX, OY = DeltaSubNY;
             // The orbit entry read for the escape test of the previous step is the Z of this step unless a rebase or a
             // BLA jump moved RefIteration: one dependent 16-byte load per step instead of two.

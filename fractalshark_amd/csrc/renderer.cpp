@@ -116,8 +116,10 @@ struct fs_renderer {
     void *bla_native = nullptr;
     size_t bla_native_cap = 0;
     bool bla_native_ok = false;
+    bool bla_native_stale = false; // table or orbit changed since the native form was made: remade by the next BLA render
     uint32_t bla_native_total = 0;
     uint32_t bla_level_off[kBlaMaxLevels] = {0};
+    FsBlaKeyFormat bla_key{};
 
     void *iters() const { return iters_external ? iters_external : iters_internal; }
     bool memory_initialized() const { return iters() != nullptr && width != 0; }
@@ -346,7 +348,9 @@ hipError_t bla_layout(fs_renderer *r, const uint64_t *sizes, int32_t n_levels, s
 uint32_t bla_make_native(fs_renderer *r, int32_t n_levels)
 {
     r->bla_native_ok = false;
-    if (n_levels <= 2 || n_levels > kBlaMaxLevels)
+    r->bla_native_stale = false;
+    if (n_levels <= 2 || n_levels > kBlaMaxLevels || r->bla_type != FS_T_HDR32 || !r->orbit_ok ||
+        r->orbit_type != FS_T_HDR32 || !r->zref)
         return 0;
     uint64_t total = 0;
     for (int32_t l = 2; l < n_levels; l++) {
@@ -355,7 +359,7 @@ uint32_t bla_make_native(fs_renderer *r, int32_t n_levels)
     }
     if (total == 0 || total > 0xFFFFFFF0ull)
         return 0;
-    const size_t need = 256 + (size_t)total * (sizeof(FsBlaRec) + 2 * sizeof(int4));
+    const size_t need = 256 + (size_t)total * sizeof(FsBlaRec);
     if (!r->bla_native || r->bla_native_cap < need) {
         (void)r_free(r, r->bla_native);
         r->bla_native = nullptr;
@@ -366,19 +370,52 @@ uint32_t bla_make_native(fs_renderer *r, int32_t n_levels)
         }
         r->bla_native_cap = need;
     }
-    uint32_t *bad = (uint32_t *)r->bla_native;
-    FsBlaRec *rec = (FsBlaRec *)((char *)r->bla_native + 256);
-    int4 *lad = (int4 *)((char *)rec + (size_t)total * sizeof(FsBlaRec));
-    FS_TRY(hipMemsetAsync(bad, 0, 256, r->compute));
-    fsk_bla_make_native((const fs_bla_hdr32 *const *)r->bla_levels_dev, r->bla_level_off, r->bla_level_sizes.data(), n_levels,
-                        rec, lad, bad, r->compute);
+    // pass 1: exponent range of the r2 (and whether they are all reduced non-negative values)
+    uint32_t *range = (uint32_t *)r->bla_native;
+    const uint32_t seed[4] = {0xFFFFFFFFu, 0u, 0u, 0u};
+    FS_TRY(hipMemcpyAsync(range, seed, sizeof(seed), hipMemcpyHostToDevice, r->compute));
+    const fs_bla_hdr32 *const *levels = (const fs_bla_hdr32 *const *)r->bla_levels_dev;
+    fsk_bla_r2_range(levels, r->bla_level_off, r->bla_level_sizes.data(), n_levels, range, r->compute);
     FS_TRY(hipGetLastError());
-    uint32_t flag = 1;
-    FS_TRY(hipMemcpyAsync(&flag, bad, 4, hipMemcpyDeviceToHost, r->compute));
+    uint32_t got[4] = {0, 0, 1, 0};
+    FS_TRY(hipMemcpyAsync(got, range, sizeof(got), hipMemcpyDeviceToHost, r->compute));
+    FS_TRY(hipStreamSynchronize(r->compute));
+    if (got[2] != 0u || got[0] > got[1])
+        return 0; // a non-canonical r2, or no non-zero r2 at all: the reference-layout lookup serves
+    const int64_t emin = (int64_t)got[0] - 0x80000000ll, emax = (int64_t)got[1] - 0x80000000ll;
+    // key format: table exponents land in fields [1, span], 0 is "below every r2" and span + 1 "above every r2"
+    const int64_t span = emax - emin + 1;
+    int field_bits = 2;
+    while (((int64_t)1 << field_bits) < span + 2)
+        field_bits++;
+    if (field_bits > 24)
+        return 0; // exponents spread over more than 2^24 binades: keep the exact compares
+    FsBlaKeyFormat fmt;
+    fmt.ebase = (int32_t)(emin - 1);
+    fmt.emax_field = (int32_t)(span + 1);
+    fmt.mant_bits = 32 - field_bits > 23 ? 23 : 32 - field_bits;
+    // tests: fewer mantissa bits make equal keys (the exactly-decided cold path of the lookup) frequent
+    if (const char *e = getenv("FSMI355_BLA_KEY_MANT_BITS")) {
+        const int v = atoi(e);
+        if (v >= 1 && v < fmt.mant_bits)
+            fmt.mant_bits = v;
+    }
+    r->bla_key = fmt;
+    FsBlaRec *rec = (FsBlaRec *)((char *)r->bla_native + 256);
+    fsk_bla_make_native(levels, r->bla_level_off, r->bla_level_sizes.data(), n_levels, r->zref, (uint32_t)r->orbit_uncompressed,
+                        fmt, rec, r->compute);
+    FS_TRY(hipGetLastError());
     FS_TRY(hipStreamSynchronize(r->compute));
     r->bla_native_total = (uint32_t)total;
-    r->bla_native_ok = flag == 0;
+    r->bla_native_ok = true;
     return 0;
+}
+
+// A new orbit is in place: the native BLA table carries arrival entries of the previous one.
+void orbit_changed(fs_renderer *r)
+{
+    r->bla_native_ok = false;
+    r->bla_native_stale = r->bla_n_levels > 0 && r->bla_type == FS_T_HDR32;
 }
 
 void free_perturb(fs_renderer *r)
@@ -788,6 +825,7 @@ uint32_t fs_upload_orbit(fs_renderer *r, uint64_t generation, int type_tag, uint
         r->orbit_gen = generation;
         r->orbit_type = type_tag;
         r->orbit_ok = true;
+        orbit_changed(r);
         return 0;
     }
     if (type_tag == FS_T_HDR2X32) {
@@ -805,6 +843,7 @@ uint32_t fs_upload_orbit(fs_renderer *r, uint64_t generation, int type_tag, uint
         r->orbit_gen = generation;
         r->orbit_type = type_tag;
         r->orbit_ok = true;
+        orbit_changed(r);
         return 0;
     }
     if (type_tag == FS_T_F64) {
@@ -822,6 +861,7 @@ uint32_t fs_upload_orbit(fs_renderer *r, uint64_t generation, int type_tag, uint
         r->orbit_gen = generation;
         r->orbit_type = type_tag;
         r->orbit_ok = true;
+        orbit_changed(r);
         return 0;
     }
     if (r->zref) {
@@ -865,6 +905,7 @@ uint32_t fs_upload_orbit(fs_renderer *r, uint64_t generation, int type_tag, uint
     r->orbit_gen = generation;
     r->orbit_type = type_tag;
     r->orbit_ok = true;
+    orbit_changed(r);
     return 0;
 }
 
@@ -929,6 +970,7 @@ uint32_t fs_upload_orbit_compressed(fs_renderer *r, uint64_t generation, int typ
         r->orbit_gen = generation;
         r->orbit_type = type_tag;
         r->orbit_ok = true;
+        orbit_changed(r);
         return 0;
     }
     if (r->zref) {
@@ -975,6 +1017,7 @@ uint32_t fs_upload_orbit_compressed(fs_renderer *r, uint64_t generation, int typ
     r->orbit_gen = generation;
     r->orbit_type = type_tag;
     r->orbit_ok = true;
+    orbit_changed(r);
     return 0;
 }
 
@@ -1097,8 +1140,7 @@ uint32_t fs_upload_bla(fs_renderer *r, int type_tag, const void *const *levels, 
     r->bla_n_levels = n_levels;
     r->bla_lm2 = lm2;
     r->bla_native_ok = false;
-    if (type_tag == FS_T_HDR32)
-        return bla_make_native(r, n_levels);
+    r->bla_native_stale = type_tag == FS_T_HDR32; // made by the next BLA render: it also needs the orbit of that render
     return 0;
 }
 
@@ -1144,8 +1186,7 @@ uint32_t fs_build_bla(fs_renderer *r, int type_tag, const void *bla_size)
     r->bla_n_levels = n_levels;
     r->bla_lm2 = lm2;
     r->bla_native_ok = false;
-    if (type_tag == FS_T_HDR32)
-        return bla_make_native(r, n_levels);
+    r->bla_native_stale = type_tag == FS_T_HDR32; // made by the next BLA render: it also needs the orbit of that render
     return 0;
 }
 
@@ -1657,9 +1698,12 @@ uint32_t fs_render_bla(fs_renderer *r, int type_tag, const void *coords, uint64_
         A.orbit_count = (uint32_t)r->orbit_uncompressed;
         A.n_iterations = (uint32_t)n_iterations;
         A.lm2 = r->bla_lm2;
+        if (use_bla && r->bla_native_stale)
+            if (uint32_t e = bla_make_native(r, r->bla_n_levels))
+                return e;
         if (use_bla && r->bla_native_ok) {
             A.nrec = (const FsBlaRec *)((const char *)r->bla_native + 256);
-            A.nlad = (const int4 *)((const char *)A.nrec + (size_t)r->bla_native_total * sizeof(FsBlaRec));
+            A.nkey = r->bla_key;
             memcpy(A.level_off, r->bla_level_off, sizeof(A.level_off));
         }
         TimedLaunch t(r);
