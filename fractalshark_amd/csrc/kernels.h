@@ -82,47 +82,40 @@ template <class F> struct FsLav2ArgsT {
     int la_valid;
     int use_at;
     int parity;
+    // SimpleCompression orbit kept compressed in HBM and decompressed by the kernel as it walks it (fsk_lav2_seq): the
+    // waypoints in the reference layout (fs_orbit_hdr32_rc / fs_orbit_hdr64_rc), their number, and the constant c of the
+    // runtime decompressor (GPUPerturbResults::OrbitXLow / OrbitYLow); zref is NULL then
+    const void *wp;
+    uint32_t n_wp;
+    typename FsDev<F>::Real cxLow, cyLow;
 };
 using FsLav2Args32 = FsLav2ArgsT<float>;
 
 // Device-native BLA table of the HDRFloat<float> kernel (k_bla_make_native, kernels_tables.hip), built once per (table,
 // orbit) pair next to the reference-layout levels.  All levels >= 2 back to back; position of element ix of level L =
-// level_off[L] + ix.  One 64-byte record (half a cache line, 16-byte aligned) per element:
-//   lad   the r2 of this element and of the first elements of its left sub-trees on the three levels below -- exactly the
-//         (level, index) pairs BLAS::LookupBackwards probes next when this one fails (BLAS.cpp:256-310) -- as four 32-bit
-//         ORDER KEYS: (exponent - ebase) in the upper bits, the leading mantissa bits below (FsBlaKeyFormat; the split is
-//         chosen per table from the exponent range of its r2).  key(z2) < key(r2) proves z2 < r2 and key(z2) > key(r2)
-//         proves z2 >= r2 in the reference's lexicographic (exponent, mantissa) order; equal keys (one compare in ~2^16 or
-//         rarer) are decided exactly on the reference-layout record.  A whole round of four probes is ONE 16-byte load and
-//         four integer compares.  Levels below 2 and r2 == 0 carry key 0 ("never valid").
-//   the four mantissas, the four exponents (one 16-byte load each: the reference record is 44 B, straddles alignment
-//         boundaries and interleaves mantissas with exponents);
-//   Z, l  the step count AND the orbit value the jump arrives at: element ix of level L only ever applies at orbit index
-//         (ix << L) + 1, so its arrival entry Z[(ix << L) + 1 + l] is a property of the record, and the dependent orbit
-//         load behind every jump (its index is known only once l has arrived) disappears.  Stale once table or orbit change.
+// level_off[L] + ix.
+//   FsBlaRec  (48 B, three 16-byte loads that never straddle a cache line): the four mantissas, the four exponents (the
+//             reference record is 44 B, straddles alignment boundaries and interleaves mantissas with exponents), then the
+//             step count AND the orbit value the jump arrives at: element ix of level L only ever applies at orbit index
+//             (ix << L) + 1, so its arrival entry Z[(ix << L) + 1 + l] is a property of the record, and the dependent
+//             orbit load behind every jump (its index is known only once l has arrived) disappears.  Stale once table or
+//             orbit change.
+//   ladder    (32 B per position): the r2 of this element and of the first elements of its left sub-trees on the three
+//             levels below -- exactly the (level, index) pairs BLAS::LookupBackwards probes next when this one fails
+//             (BLAS.cpp:256-310) -- as four 64-bit keys (exponent << 32 | mantissa bits): for reduced non-negative values
+//             the reference's lexicographic (exponent, mantissa) compare is ONE signed 64-bit integer compare, and a whole
+//             round of four probes is two 16-byte loads.  Levels below 2 carry INT64_MIN ("never valid").
+//   (Measured and dropped, round 3: the ladder as four 32-bit order keys inside a 64-byte record -- one load per round,
+//   equal keys decided exactly on the reference-layout record: 253 vs 229 ms on C5; the tie bookkeeping costs more vector
+//   instructions than the second load, and this kernel is bound by vector issue, profiles/r03_c5_*.)
 struct FsBlaRec {
-    uint32_t lad[4];
     float Axm, Aym, Bxm, Bym;
     int32_t Axe, Aye, Bxe, Bye;
     float Zre, Zim; // prepared orbit entry at the arrival index (zeros when the jump would leave the orbit: never taken)
     int32_t Ze;
     uint32_t l;
 };
-static_assert(sizeof(FsBlaRec) == 64, "device-native BLA record");
-struct FsBlaKeyFormat {
-    int32_t ebase;    // key exponent field = clamp(e - ebase, 0, emax_field); table values land in [1, emax_field - 1]
-    int32_t emax_field;
-    int32_t mant_bits; // leading mantissa-fraction bits kept (<= 23)
-};
-// The order key of a reduced non-negative value {mantissa bits, exponent} (zero: any mantissa bits 0 with the exponent of
-// HDRFloat's zero, far below every ebase):  field = clamp(e - ebase, 0, emax_field),  key = field << mant_bits | leading
-// mant_bits of the fraction.  Exponents are within +-2^29, so the difference cannot wrap.
-__host__ __device__ inline uint32_t fs_bla_order_key(int32_t e, int32_t mbits, FsBlaKeyFormat f)
-{
-    const int32_t d = e - f.ebase;
-    const uint32_t field = d < 0 ? 0u : (d > f.emax_field ? (uint32_t)f.emax_field : (uint32_t)d);
-    return (field << f.mant_bits) | (((uint32_t)mbits & 0x007FFFFFu) >> (23 - f.mant_bits));
-}
+static_assert(sizeof(FsBlaRec) == 48, "device-native BLA record");
 constexpr int kBlaMaxLevels = 40;
 
 template <class F> struct FsBlaArgsT {
@@ -140,7 +133,7 @@ template <class F> struct FsBlaArgsT {
     int32_t lm2;
     // HDRFloat<float> only: the device-native table (NULL = use `levels`, the reference-layout records)
     const FsBlaRec *nrec;
-    FsBlaKeyFormat nkey;
+    const int4 *nlad; // two int4 per position
     uint32_t level_off[kBlaMaxLevels];
 };
 using FsBlaArgs32 = FsBlaArgsT<float>;
@@ -268,6 +261,9 @@ void fsk_lav2_hdr64(const FsLav2ArgsT<double> &A, int mode, bool stats, hipStrea
 // IterType = uint64_t with 64-bit iteration counting (iteration caps of 2^32 and above): the literal kernel instantiated
 // with a 64-bit counter; needs a uint64_t iteration buffer (frame.iter_u64)
 void fsk_lav2_wide(const FsLav2Args32 *A32, const FsLav2ArgsT<double> *A64, int mode, bool stats, hipStream_t s);
+// PerturbExtras::SimpleCompression with the orbit decompressed IN the kernel (GPUPerturbSingleResults::SeqWorkspace /
+// GetIterSeq / BinarySearch, Perturb.cuh:146-326): only the waypoints are resident (A.wp); the literal kernel walks them
+void fsk_lav2_seq(const FsLav2Args32 *A32, const FsLav2ArgsT<double> *A64, int mode, bool stats, hipStream_t s);
 void fsk_lav2_2x32(const FsLav2Args2x32 &A, int mode, bool stats, hipStream_t s);
 // kind: 0 = float, 1 = double, 2 = CudaDblflt
 void fsk_lav2_plain(const FsLav2ArgsPlain &A, int kind, int mode, bool stats, hipStream_t s);
@@ -281,14 +277,10 @@ void fsk_bla_build_hdr32(const float4 *zref, void *const *levels, const uint64_t
                          hipStream_t s);
 void fsk_bla_build_hdr64(const FsZ64 *zref, void *const *levels, const uint64_t *epl, int n_levels, fs_real_hdr64 bla_size,
                          hipStream_t s);
-// levels: device pointer table of the reference-layout levels; level_off / epl: host arrays [n_levels].
-// fsk_bla_r2_range: range[0] = min, range[1] = max exponent over the non-zero r2 of all levels >= 2 (as biased uint32: e +
-// 2^31), range[2] = 1 when an r2 is not a reduced non-negative finite value (the caller then keeps the reference-layout
-// lookup); range must hold {0xFFFFFFFF, 0, 0} on entry.
-void fsk_bla_r2_range(const fs_bla_hdr32 *const *levels, const uint32_t *level_off, const uint64_t *epl, int n_levels,
-                      uint32_t *range, hipStream_t s);
+// levels: device pointer table of the reference-layout levels; level_off / epl: host arrays [n_levels]; bad: device word that
+// is set when an r2 is not a reduced non-negative finite value (the caller then keeps using the reference-layout table)
 void fsk_bla_make_native(const fs_bla_hdr32 *const *levels, const uint32_t *level_off, const uint64_t *epl, int n_levels,
-                         const float4 *zref, uint32_t orbit_count, FsBlaKeyFormat fmt, FsBlaRec *rec, hipStream_t s);
+                         const float4 *zref, uint32_t orbit_count, FsBlaRec *rec, int4 *lad, uint32_t *bad, hipStream_t s);
 void fsk_perturb_scalar_hdr32(const FsBlaArgs32 &A, bool use_bla, bool stats, int variant, hipStream_t s);
 void fsk_perturb_scalar_hdr64(const FsBlaArgsT<double> &A, bool use_bla, bool stats, int variant, hipStream_t s);
 void fsk_perturb_bla_f64(const FsBlaArgsF64 &A, bool use_bla, bool stats, hipStream_t s);

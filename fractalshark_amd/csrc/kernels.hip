@@ -193,6 +193,82 @@ __device__ __forceinline__ void at_perform(const hcplx<F> c, const hreal<F> esc,
 }
 
 // ------------------------------------------------------------------------------------------------
+// Sequential access to a PerturbExtras::SimpleCompression orbit that stays compressed in HBM: the device twin of
+// GPUPerturbSingleResults::SeqWorkspace / GetIterSeq / BinarySearch (Perturb.cuh:160-326) and of the CPU
+// RuntimeDecompressor (PerturbationResultsHelpers.h:35-199).  A cursor holds one orbit value; seek() starts from the
+// last waypoint at or before the index and iterates z = z^2 + c forward in T arithmetic (c = OrbitXLow / OrbitYLow),
+// step() moves one index on: the next waypoint when its index comes up, one iteration otherwise.  Same operations in
+// the same order as k_decompress_orbit_* (which expand the same waypoints once per upload), so both modes see the same
+// orbit bit for bit; this one trades ~60 vector instructions per step for an orbit that occupies only its waypoints.
+namespace {
+
+template <class F> struct FsWaypoints;
+template <> struct FsWaypoints<float> {
+    using Rec = fs_orbit_hdr32_rc;
+};
+template <> struct FsWaypoints<double> {
+    using Rec = fs_orbit_hdr64_rc;
+};
+
+template <class F> struct SeqOrbit {
+    const typename FsWaypoints<F>::Rec *__restrict__ wp;
+    uint32_t n_wp;
+    hreal<F> cx, cy;
+    // cursor
+    uint32_t idx;        // orbit index of (zx, zy)
+    uint32_t next;       // number of the first waypoint behind the cursor
+    uint32_t next_index; // ... and its orbit index (~0u: none left)
+    hreal<F> zx, zy;
+
+    __device__ __forceinline__ uint32_t index_of(uint32_t k) const
+    {
+        return (uint32_t)(wp[k].index_and_rebase & 0x7FFFFFFFFFFFFFFFull);
+    }
+    __device__ __forceinline__ void load(uint32_t k)
+    {
+        zx = hreal<F>{wp[k].mx, wp[k].ex};
+        zy = hreal<F>{wp[k].my, wp[k].ey};
+    }
+    __device__ __forceinline__ void step()
+    {
+        idx++;
+        if (idx == next_index) { // GetCompressedComplexSeq, Perturb.cuh:303-326
+            load(next);
+            next++;
+            next_index = next < n_wp ? index_of(next) : 0xFFFFFFFFu;
+        } else { // runOneIter, PerturbationResultsHelpers.h:51-58
+            const hreal<F> zx_old = zx;
+            zx = hr_add(hr_sub(hr_mul(zx, zx), hr_mul(zy, zy)), cx);
+            hr_reduce(zx);
+            zy = hr_add(hr_mul(hr_mul(hreal<F>{F(1), 1}, zx_old), zy), cy);
+            hr_reduce(zy);
+        }
+    }
+    __device__ __forceinline__ void seek(uint32_t i)
+    {
+        // BinarySearch, Perturb.cuh:241-263: the last waypoint whose index is <= i (waypoint 0 sits at index 0)
+        uint32_t lo = 0, hi = n_wp;
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (index_of(mid) <= i)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        load(lo);
+        idx = index_of(lo);
+        next = lo + 1u;
+        next_index = next < n_wp ? index_of(next) : 0xFFFFFFFFu;
+        while (idx < i)
+            step();
+    }
+    // PerturbationResults::GetComplex on the cursor's value
+    __device__ __forceinline__ hcplx<F> value() const { return hc_from_hr(zx, zy); }
+};
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------
 // LAv2, T = HDRFloat<float>.  CPU twin: Fractal::CalcCpuPerturbationFractalLAV2<uint32_t,float,Disable>
 // (Fractal.cpp:2545-2678) with LAReference::getLA / isLAStageInvalid (LAReference.cpp:1076-1134),
 // LAInfoDeep::Prepare / Evaluate (LAInfoDeep.h:395-420), ATInfo::PerformAT (ATInfo.h:155-188).
@@ -200,7 +276,8 @@ __device__ __forceinline__ void at_perform(const hcplx<F> c, const hreal<F> esc,
 // IterT = the reference's IterType for the COUNTERS (LAKernel.cuh:3): uint32_t, or uint64_t for iteration caps of 2^32 and
 // above (iterations, the cap, the AT iteration count and the skipped-iteration product are then 64-bit; table step
 // lengths and indices stay 32-bit -- an orbit or table with 2^32 entries would not fit any device).
-template <class F, int Mode, bool kStats, class IterT = uint32_t>
+// kSeq: the orbit is a compressed one that stays compressed (A.wp): every orbit value comes from a SeqOrbit cursor.
+template <class F, int Mode, bool kStats, class IterT = uint32_t, bool kSeq = false>
 __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
 {
     // The float instantiation is the operation-by-operation A/B reference of the tuned kernel and keeps the literal AT
@@ -307,8 +384,20 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
         if (Mode != FS_MODE_LAO) {
             const hreal<F> TwoFiftySix = hreal<F>{F(1), 8};
             const typename FsDev<F>::Z *__restrict__ zr = A.zref;
+            SeqOrbit<F> seq;
+            if constexpr (kSeq) {
+                seq.wp = (const typename FsWaypoints<F>::Rec *)A.wp;
+                seq.n_wp = A.n_wp;
+                seq.cx = ldr(A.cxLow), seq.cy = ldr(A.cyLow);
+                if (iterations < n_iterations)
+                    seq.seek(RefIteration); // SeqWorkspace(results, RefIteration)
+            }
             for (; iterations < n_iterations; iterations++) {
-                hcplx<F> cur = zref_at(zr, RefIteration);
+                hcplx<F> cur;
+                if constexpr (kSeq)
+                    cur = seq.value();
+                else
+                    cur = zref_at(zr, RefIteration);
                 cur = hc_mul2(cur);
                 cur = hc_add(cur, DeltaSubN);
                 DeltaSubN = hc_mul(DeltaSubN, cur);
@@ -317,7 +406,14 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
                 if (kStats)
                     c_pt++;
                 RefIteration++;
-                hcplx<F> complex0 = hc_add(zref_at(zr, RefIteration), DeltaSubN);
+                hcplx<F> Znext;
+                if constexpr (kSeq) {
+                    seq.step(); // GetIterSeq
+                    Znext = seq.value();
+                } else {
+                    Znext = zref_at(zr, RefIteration);
+                }
+                hcplx<F> complex0 = hc_add(Znext, DeltaSubN);
                 hc_reduce(complex0);
                 const hreal<F> normSquared = hr_reduced(hc_norm2(complex0));
                 const hreal<F> DeltaNormSquared = hr_reduced(hc_norm2(DeltaSubN));
@@ -326,6 +422,8 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
                 if (hr_cmp_pos(normSquared, DeltaNormSquared) < 0 || RefIteration >= MaxRefIteration) {
                     DeltaSubN = complex0;
                     RefIteration = 0;
+                    if constexpr (kSeq)
+                        seq.seek(0); // a new SeqWorkspace at the start of the orbit
                 }
             }
         }
@@ -1223,53 +1321,40 @@ __device__ __forceinline__ const typename FsDev<F>::BLA *bla_lookup(const typena
     return nullptr;
 }
 
-// The same lookup on the device-native table (FsBlaRec, kernels.h): returns the POSITION of the record that applies, or ~0u.
-// One round = the four probes BLAS::LookupBackwards would make next, fetched as ONE 16-byte load (the ladder of the start
-// element) and decided with integer compares of 32-bit order keys; the first probe that holds, in the reference's order
-// (highest level first), wins -- no assumption about the r2 being monotone along the ladder.  A probe whose keys are EQUAL
-// is undecided (the key drops low mantissa bits): that lane decides its round exactly, on the reference-layout records
-// (`levels`), with the reference's compare -- about one round in 2^16, so the exact code is a cold branch.  No branch per
-// probe, no 64-bit pointer per level: level offsets come from LDS (`off`), positions are 32-bit.
+// The same lookup on the device-native table (FsBlaRec / ladder, kernels.h): returns the POSITION of the record that applies,
+// or ~0u.  One round = the four probes BLAS::LookupBackwards would make next, fetched as two 16-byte loads from one ladder
+// entry and decided with four signed 64-bit compares (key = exponent << 32 | mantissa bits == the reference's
+// lexicographic compare for reduced non-negative values); the first probe that holds, in the reference's order (highest
+// level first), wins -- no assumption about the r2 being monotone along the ladder.  Levels below 2 carry keys that never
+// hold.  No branch per probe, no 64-bit pointer per level: level offsets come from LDS (`off`), positions are 32-bit.
 // 15 of 16 lookups start at level <= 5 and finish in their first round; deeper ones loop (another four levels per round).
-__device__ __forceinline__ uint32_t bla_lookup_native(const FsBlaRec *__restrict__ rec, const fs_bla_hdr32 *const *levels,
-                                                      const uint32_t *off, int32_t lm2, uint32_t m, hreal<float> z2,
-                                                      FsBlaKeyFormat fmt, uint32_t key20)
+// A table entry can only apply at orbit indices m = 1 (mod 4) (level >= 2 needs k = m - 1 divisible by 4): when no lane
+// of the wave sits at one, the lookup is one vote.
+__device__ __forceinline__ uint32_t bla_lookup_native(const int4 *__restrict__ lad, const uint32_t *off, int32_t lm2,
+                                                      uint32_t m, long long zkey, long long key20)
 {
+    if (__builtin_amdgcn_ballot_w64((m & 3u) == 1u) == 0ull)
+        return 0xFFFFFFFFu;
     const int32_t k = (int32_t)m - 1;
     const bool first = k == 0;
     const int32_t zeros = first ? 32 : (int32_t)__ffs(k) - 1; // exponent of (float)(k & -k), BLAS.cpp:283-286
     uint32_t ix = first ? 0u : (uint32_t)k >> (zeros & 31);
     int32_t L = zeros <= lm2 ? zeros : lm2;
-    const uint32_t zc = fs_bla_order_key(z2.e, __float_as_int(z2.m), fmt);
-    // m == 0: no table entry; odd k: level 0; k == 0: only when the first element of level 2 applies (BLAS.cpp:270-281;
-    // equal keys: decided exactly)
-    bool pre = !first || zc < key20;
-    if (__builtin_expect(first && zc == key20, 0))
-        pre = hr_cmp_pos(z2, ldr(levels[2][0].r2)) < 0;
-    bool live = m != 0u && (k & 1) == 0 && L >= 2 && pre;
+    // m == 0: no table entry; odd k: level 0; k == 0: only when the first element of level 2 applies (BLAS.cpp:270-281)
+    bool live = m != 0u && (k & 1) == 0 && L >= 2 && (!first || zkey < key20);
     uint32_t hit = 0xFFFFFFFFu;
     while (__builtin_amdgcn_ballot_w64(live) != 0ull) {
         if (live) {
             const uint32_t p = off[L] + ix;
-            const uint4 q = *reinterpret_cast<const uint4 *>(rec[p].lad);
-            int32_t nf = zc < q.w ? 3 : 4;
-            nf = zc < q.z ? 2 : nf;
-            nf = zc < q.y ? 1 : nf;
-            nf = zc < q.x ? 0 : nf;
-            // undecided: an equal key at a probe that comes before the first proven one
-            const bool tie = (zc == q.x) || (zc == q.y && nf > 1) || (zc == q.z && nf > 2) || (zc == q.w && nf > 3);
-            if (__builtin_expect(tie, 0)) {
-                nf = 4;
-                for (int32_t j = 0; j < 4; j++) {
-                    const int32_t Lj = L - j;
-                    if (Lj < 2)
-                        break;
-                    if (hr_cmp_pos(z2, ldr(levels[Lj][(size_t)ix << j].r2)) < 0) {
-                        nf = j;
-                        break;
-                    }
-                }
-            }
+            const int4 a = lad[2u * (size_t)p], b = lad[2u * (size_t)p + 1u];
+            const long long k0 = (long long)(((unsigned long long)(unsigned)a.y << 32) | (unsigned)a.x);
+            const long long k1 = (long long)(((unsigned long long)(unsigned)a.w << 32) | (unsigned)a.z);
+            const long long k2 = (long long)(((unsigned long long)(unsigned)b.y << 32) | (unsigned)b.x);
+            const long long k3 = (long long)(((unsigned long long)(unsigned)b.w << 32) | (unsigned)b.z);
+            int32_t nf = zkey < k3 ? 3 : 4;
+            nf = zkey < k2 ? 2 : nf;
+            nf = zkey < k1 ? 1 : nf;
+            nf = zkey < k0 ? 0 : nf;
             if (nf < 4) {
                 hit = off[L - nf] + (ix << nf);
                 live = false;
@@ -1307,13 +1392,14 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
             s_levels[threadIdx.x] = (int32_t)threadIdx.x < A.lm2 + 2 ? A.levels[threadIdx.x] : nullptr;
         __syncthreads();
     }
-    uint32_t nat_key20 = 0;
+    long long nat_key20 = 0;
     if constexpr (kNat) {
         if (threadIdx.x < 64u)
             s_off[threadIdx.x] = threadIdx.x < (uint32_t)kBlaMaxLevels ? A.level_off[threadIdx.x] : 0u;
         __syncthreads();
         // key of the first element of level 2 (the k == 0 pre-test): wave-uniform, one scalar load
-        nat_key20 = A.nrec[A.level_off[2]].lad[0];
+        const int4 e20 = A.nlad[2u * (size_t)A.level_off[2]];
+        nat_key20 = (long long)(((unsigned long long)(unsigned)e20.y << 32) | (unsigned)e20.x);
     }
     uint32_t X = 0, L = 0;
     uint64_t c_la = 0, c_pt = 0, c_px = 0;
@@ -1617,8 +1703,9 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                     hreal<F> Ax, Ay, Bx, By;
                     hcplx<F> Znat = hc_zero<F>(); // (kNat) the orbit entry the jump arrives at, from the record
                     if constexpr (kNat) {
-                        const uint32_t pos = bla_lookup_native(A.nrec, A.levels, s_off, A.lm2, RefIteration, DeltaNormSquared,
-                                                               A.nkey, nat_key20);
+                        const long long zkey = (long long)(((unsigned long long)(unsigned)DeltaNormSquared.e << 32) |
+                                                           (unsigned)__float_as_int(DeltaNormSquared.m));
+                        const uint32_t pos = bla_lookup_native(A.nlad, s_off, A.lm2, RefIteration, zkey, nat_key20);
                         FS_PH(ph_lookup += __builtin_readcyclecounter() - ph_t; ph_n_lookup++);
                         if (pos == 0xFFFFFFFFu)
                             break;
@@ -2841,6 +2928,33 @@ void fsk_lav2_wide(const FsLav2Args32 *A32, const FsLav2ArgsT<double> *A64, int 
     else
         FS_LAUNCH_WIDE(FS_MODE_LAO);
 #undef FS_LAUNCH_WIDE
+}
+
+void fsk_lav2_seq(const FsLav2Args32 *A32, const FsLav2ArgsT<double> *A64, int mode, bool stats, hipStream_t s)
+{
+    const FsFrame &f = A32 ? A32->frame : A64->frame;
+    const dim3 g = tile_grid(f), b(256);
+#define FS_LAUNCH_SEQ(M)                                                                                             \
+    do {                                                                                                            \
+        if (A32) {                                                                                                  \
+            if (stats)                                                                                              \
+                hipLaunchKernelGGL((k_lav2_lit<float, M, true, uint32_t, true>), g, b, 0, s, *A32);                  \
+            else                                                                                                    \
+                hipLaunchKernelGGL((k_lav2_lit<float, M, false, uint32_t, true>), g, b, 0, s, *A32);                 \
+        } else {                                                                                                    \
+            if (stats)                                                                                              \
+                hipLaunchKernelGGL((k_lav2_lit<double, M, true, uint32_t, true>), g, b, 0, s, *A64);                 \
+            else                                                                                                    \
+                hipLaunchKernelGGL((k_lav2_lit<double, M, false, uint32_t, true>), g, b, 0, s, *A64);                \
+        }                                                                                                           \
+    } while (0)
+    if (mode == FS_MODE_FULL)
+        FS_LAUNCH_SEQ(FS_MODE_FULL);
+    else if (mode == FS_MODE_PO)
+        FS_LAUNCH_SEQ(FS_MODE_PO);
+    else
+        FS_LAUNCH_SEQ(FS_MODE_LAO);
+#undef FS_LAUNCH_SEQ
 }
 
 void fsk_perturb_scalar_hdr64(const FsBlaArgsT<double> &A, bool use_bla, bool stats, int variant, hipStream_t s)

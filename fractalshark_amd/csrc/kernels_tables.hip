@@ -178,68 +178,32 @@ struct NativeGeom {
     uint32_t total;
 };
 
-__device__ __forceinline__ int32_t level_of(const NativeGeom &G, uint32_t p)
+__device__ __forceinline__ long long r2_key(fs_real_hdr32 r2, uint32_t *bad)
 {
+    const int bits = __float_as_int(r2.m);
+    // the integer compare equals the reference's float compare of the mantissas only for non-negative, non-NaN values
+    if (bits < 0 || (bits & 0x7F800000) == 0x7F800000) {
+        atomicOr(bad, 1u);
+        return (long long)0x8000000000000000ull;
+    }
+    return (long long)(((unsigned long long)(unsigned)r2.e << 32) | (unsigned)bits);
+}
+
+__global__ void __launch_bounds__(256) k_bla_make_native(const fs_bla_hdr32 *const *__restrict__ levels, NativeGeom G,
+                                                         const float4 *__restrict__ zref, uint32_t orbit_count,
+                                                         FsBlaRec *__restrict__ rec, int4 *__restrict__ lad,
+                                                         uint32_t *__restrict__ bad)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= G.total)
+        return;
     int32_t L = 2;
     for (int32_t l = 3; l < G.n_levels; l++)
         if (G.level_n[l] != 0u && p >= G.level_off[l])
             L = l;
-    return L;
-}
-
-// r2 is "canonical" when it is an exact zero or a reduced positive value (mantissa in [1, 2)): what BLA construction
-// produces.  Only then does the order key below order like the reference's compare.
-__device__ __forceinline__ bool r2_is_zero(fs_real_hdr32 r2) { return r2.m == 0.0f; }
-__device__ __forceinline__ bool r2_canonical(fs_real_hdr32 r2)
-{
-    return r2.m == 0.0f || (__float_as_int(r2.m) & 0xFF800000) == 0x3F800000;
-}
-
-__global__ void __launch_bounds__(256) k_bla_r2_range(const fs_bla_hdr32 *const *__restrict__ levels, NativeGeom G,
-                                                      uint32_t *__restrict__ range)
-{
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= G.total)
-        return;
-    const int32_t L = level_of(G, p);
-    const fs_real_hdr32 r2 = levels[L][p - G.level_off[L]].r2;
-    if (!r2_canonical(r2)) {
-        atomicOr(&range[2], 1u);
-        return;
-    }
-    if (r2_is_zero(r2))
-        return;
-    const uint32_t be = (uint32_t)r2.e + 0x80000000u;
-    atomicMin(&range[0], be);
-    atomicMax(&range[1], be);
-}
-
-} // namespace
-
-namespace {
-
-__global__ void __launch_bounds__(256) k_bla_make_native(const fs_bla_hdr32 *const *__restrict__ levels, NativeGeom G,
-                                                         const float4 *__restrict__ zref, uint32_t orbit_count,
-                                                         FsBlaKeyFormat fmt, FsBlaRec *__restrict__ rec)
-{
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= G.total)
-        return;
-    const int32_t L = level_of(G, p);
     const uint32_t ix = p - G.level_off[L];
     const fs_bla_hdr32 b = levels[L][ix];
     FsBlaRec o;
-    for (int j = 0; j < 4; j++) {
-        const int32_t Lj = L - j;
-        uint32_t key = 0u; // never valid: levels below 2, and r2 == 0 (nothing is smaller than zero)
-        if (Lj >= 2) {
-            // (Lj, ix << j) is the first element of the left sub-tree j levels down: it exists whenever (L, ix) does
-            const fs_real_hdr32 r2 = levels[Lj][(size_t)ix << j].r2;
-            if (!r2_is_zero(r2))
-                key = fs_bla_order_key(r2.e, __float_as_int(r2.m), fmt);
-        }
-        o.lad[j] = key;
-    }
     o.Axm = b.Ax.m, o.Aym = b.Ay.m, o.Bxm = b.Bx.m, o.Bym = b.By.m;
     o.Axe = b.Ax.e, o.Aye = b.Ay.e, o.Bxe = b.Bx.e, o.Bye = b.By.e;
     o.l = (uint32_t)b.l;
@@ -249,9 +213,22 @@ __global__ void __launch_bounds__(256) k_bla_make_native(const fs_bla_hdr32 *con
     const float4 z = arrive < orbit_count ? zref[arrive] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     o.Zre = z.x, o.Zim = z.y, o.Ze = __float_as_int(z.z);
     rec[p] = o;
+    long long k[4];
+    for (int j = 0; j < 4; j++) {
+        const int32_t Lj = L - j;
+        // (Lj, ix << j) is the first element of the left sub-tree j levels down: it exists whenever (L, ix) does
+        k[j] = Lj >= 2 ? r2_key(levels[Lj][(size_t)ix << j].r2, bad) : (long long)0x8000000000000000ull;
+    }
+    lad[2 * (size_t)p] = make_int4((int)(unsigned long long)k[0], (int)((unsigned long long)k[0] >> 32),
+                                   (int)(unsigned long long)k[1], (int)((unsigned long long)k[1] >> 32));
+    lad[2 * (size_t)p + 1] = make_int4((int)(unsigned long long)k[2], (int)((unsigned long long)k[2] >> 32),
+                                       (int)(unsigned long long)k[3], (int)((unsigned long long)k[3] >> 32));
 }
 
-NativeGeom make_geom(const uint32_t *level_off, const uint64_t *epl, int n_levels)
+} // namespace
+
+void fsk_bla_make_native(const fs_bla_hdr32 *const *levels, const uint32_t *level_off, const uint64_t *epl, int n_levels,
+                         const float4 *zref, uint32_t orbit_count, FsBlaRec *rec, int4 *lad, uint32_t *bad, hipStream_t s)
 {
     NativeGeom G;
     memset(&G, 0, sizeof(G));
@@ -263,28 +240,10 @@ NativeGeom make_geom(const uint32_t *level_off, const uint64_t *epl, int n_level
         total = level_off[l] + (uint32_t)epl[l];
     }
     G.total = total;
-    return G;
-}
-
-} // namespace
-
-void fsk_bla_r2_range(const fs_bla_hdr32 *const *levels, const uint32_t *level_off, const uint64_t *epl, int n_levels,
-                      uint32_t *range, hipStream_t s)
-{
-    const NativeGeom G = make_geom(level_off, epl, n_levels);
-    if (G.total == 0)
+    if (total == 0)
         return;
-    hipLaunchKernelGGL(k_bla_r2_range, dim3((G.total + 255u) / 256u), dim3(256), 0, s, levels, G, range);
-}
-
-void fsk_bla_make_native(const fs_bla_hdr32 *const *levels, const uint32_t *level_off, const uint64_t *epl, int n_levels,
-                         const float4 *zref, uint32_t orbit_count, FsBlaKeyFormat fmt, FsBlaRec *rec, hipStream_t s)
-{
-    const NativeGeom G = make_geom(level_off, epl, n_levels);
-    if (G.total == 0)
-        return;
-    hipLaunchKernelGGL(k_bla_make_native, dim3((G.total + 255u) / 256u), dim3(256), 0, s, levels, G, zref, orbit_count, fmt,
-                       rec);
+    hipLaunchKernelGGL(k_bla_make_native, dim3((total + 255u) / 256u), dim3(256), 0, s, levels, G, zref, orbit_count, rec, lad,
+                       bad);
 }
 
 void fsk_bla_build_hdr32(const float4 *zref, void *const *levels, const uint64_t *epl, int n_levels, fs_real_hdr32 bla_size,

@@ -79,6 +79,13 @@ struct fs_renderer {
     void *orbit_plain = nullptr;       // plain float / CudaDblflt orbit (FS_T_F32 / FS_T_2X32), used as uploaded
     alignas(8) uint8_t at_plain[sizeof(fs_at_f64_u32)] = {0}; // ATInfo of the plain LA table (type = la_type)
     uint64_t orbit_size = 0, orbit_uncompressed = 0, orbit_period = 0;
+    // PerturbExtras::SimpleCompression orbits: 0 = expanded once on upload (default), 1 = kept compressed, decompressed by
+    // the kernel as it walks the orbit (fs_set_compressed_orbit_mode)
+    int compressed_mode = 0;
+    bool orbit_seq = false; // the resident orbit is a compressed one (wp_raw); zref / zref64 are NULL
+    void *wp_raw = nullptr; // fs_orbit_hdr32_rc[] / fs_orbit_hdr64_rc[]
+    fs_real_hdr32 c_low32[2] = {};
+    fs_real_hdr64 c_low64[2] = {};
 
     // LA table
     uint64_t la_gen = 0;
@@ -119,7 +126,6 @@ struct fs_renderer {
     bool bla_native_stale = false; // table or orbit changed since the native form was made: remade by the next BLA render
     uint32_t bla_native_total = 0;
     uint32_t bla_level_off[kBlaMaxLevels] = {0};
-    FsBlaKeyFormat bla_key{};
 
     void *iters() const { return iters_external ? iters_external : iters_internal; }
     bool memory_initialized() const { return iters() != nullptr && width != 0; }
@@ -359,7 +365,7 @@ uint32_t bla_make_native(fs_renderer *r, int32_t n_levels)
     }
     if (total == 0 || total > 0xFFFFFFF0ull)
         return 0;
-    const size_t need = 256 + (size_t)total * sizeof(FsBlaRec);
+    const size_t need = 256 + (size_t)total * (sizeof(FsBlaRec) + 2 * sizeof(int4));
     if (!r->bla_native || r->bla_native_cap < need) {
         (void)r_free(r, r->bla_native);
         r->bla_native = nullptr;
@@ -370,44 +376,18 @@ uint32_t bla_make_native(fs_renderer *r, int32_t n_levels)
         }
         r->bla_native_cap = need;
     }
-    // pass 1: exponent range of the r2 (and whether they are all reduced non-negative values)
-    uint32_t *range = (uint32_t *)r->bla_native;
-    const uint32_t seed[4] = {0xFFFFFFFFu, 0u, 0u, 0u};
-    FS_TRY(hipMemcpyAsync(range, seed, sizeof(seed), hipMemcpyHostToDevice, r->compute));
-    const fs_bla_hdr32 *const *levels = (const fs_bla_hdr32 *const *)r->bla_levels_dev;
-    fsk_bla_r2_range(levels, r->bla_level_off, r->bla_level_sizes.data(), n_levels, range, r->compute);
-    FS_TRY(hipGetLastError());
-    uint32_t got[4] = {0, 0, 1, 0};
-    FS_TRY(hipMemcpyAsync(got, range, sizeof(got), hipMemcpyDeviceToHost, r->compute));
-    FS_TRY(hipStreamSynchronize(r->compute));
-    if (got[2] != 0u || got[0] > got[1])
-        return 0; // a non-canonical r2, or no non-zero r2 at all: the reference-layout lookup serves
-    const int64_t emin = (int64_t)got[0] - 0x80000000ll, emax = (int64_t)got[1] - 0x80000000ll;
-    // key format: table exponents land in fields [1, span], 0 is "below every r2" and span + 1 "above every r2"
-    const int64_t span = emax - emin + 1;
-    int field_bits = 2;
-    while (((int64_t)1 << field_bits) < span + 2)
-        field_bits++;
-    if (field_bits > 24)
-        return 0; // exponents spread over more than 2^24 binades: keep the exact compares
-    FsBlaKeyFormat fmt;
-    fmt.ebase = (int32_t)(emin - 1);
-    fmt.emax_field = (int32_t)(span + 1);
-    fmt.mant_bits = 32 - field_bits > 23 ? 23 : 32 - field_bits;
-    // tests: fewer mantissa bits make equal keys (the exactly-decided cold path of the lookup) frequent
-    if (const char *e = getenv("FSMI355_BLA_KEY_MANT_BITS")) {
-        const int v = atoi(e);
-        if (v >= 1 && v < fmt.mant_bits)
-            fmt.mant_bits = v;
-    }
-    r->bla_key = fmt;
+    uint32_t *bad = (uint32_t *)r->bla_native;
     FsBlaRec *rec = (FsBlaRec *)((char *)r->bla_native + 256);
-    fsk_bla_make_native(levels, r->bla_level_off, r->bla_level_sizes.data(), n_levels, r->zref, (uint32_t)r->orbit_uncompressed,
-                        fmt, rec, r->compute);
+    int4 *lad = (int4 *)((char *)rec + (size_t)total * sizeof(FsBlaRec));
+    FS_TRY(hipMemsetAsync(bad, 0, 256, r->compute));
+    fsk_bla_make_native((const fs_bla_hdr32 *const *)r->bla_levels_dev, r->bla_level_off, r->bla_level_sizes.data(), n_levels,
+                        r->zref, (uint32_t)r->orbit_uncompressed, rec, lad, bad, r->compute);
     FS_TRY(hipGetLastError());
+    uint32_t flag = 1;
+    FS_TRY(hipMemcpyAsync(&flag, bad, 4, hipMemcpyDeviceToHost, r->compute));
     FS_TRY(hipStreamSynchronize(r->compute));
     r->bla_native_total = (uint32_t)total;
-    r->bla_native_ok = true;
+    r->bla_native_ok = flag == 0;
     return 0;
 }
 
@@ -416,6 +396,14 @@ void orbit_changed(fs_renderer *r)
 {
     r->bla_native_ok = false;
     r->bla_native_stale = r->bla_n_levels > 0 && r->bla_type == FS_T_HDR32;
+}
+
+// The compressed-resident form of the orbit (runtime decompression) goes whenever another orbit is about to come in.
+void drop_seq(fs_renderer *r)
+{
+    (void)r_free(r, r->wp_raw);
+    r->wp_raw = nullptr;
+    r->orbit_seq = false;
 }
 
 void free_perturb(fs_renderer *r)
@@ -427,6 +415,7 @@ void free_perturb(fs_renderer *r)
     r->zq = nullptr;
     if (r->zref64)
         r_free(r, r->zref64);
+    drop_seq(r);
     if (r->orbit_f64)
         r_free(r, r->orbit_f64);
     if (r->orbit_plain)
@@ -446,6 +435,7 @@ void free_perturb(fs_renderer *r)
     r->zref64 = nullptr;
     r->orbit_f64 = nullptr;
     r->orbit_ok = false;
+    drop_seq(r);
     r->orbit_gen = 0;
     if (r->las)
         r_free(r, r->las);
@@ -816,6 +806,7 @@ uint32_t fs_upload_orbit(fs_renderer *r, uint64_t generation, int type_tag, uint
             r->orbit_plain = nullptr;
         }
         r->orbit_ok = false;
+        drop_seq(r);
         FS_TRY(r_alloc(r, &r->orbit_plain, (orbit_size + 1) * eb, kInput));
         FS_TRY(hipMemcpyAsync(r->orbit_plain, entries, orbit_size * eb, hipMemcpyDefault, r->compute));
         FS_TRY(hipStreamSynchronize(r->compute));
@@ -834,6 +825,7 @@ uint32_t fs_upload_orbit(fs_renderer *r, uint64_t generation, int type_tag, uint
             r->orbit_2x32 = nullptr;
         }
         r->orbit_ok = false;
+        drop_seq(r);
         FS_TRY(r_alloc(r, (void **)&r->orbit_2x32, orbit_size * sizeof(fs_orbit_2x32), kInput));
         FS_TRY(hipMemcpyAsync(r->orbit_2x32, entries, orbit_size * sizeof(fs_orbit_2x32), hipMemcpyDefault, r->compute));
         FS_TRY(hipStreamSynchronize(r->compute));
@@ -852,6 +844,7 @@ uint32_t fs_upload_orbit(fs_renderer *r, uint64_t generation, int type_tag, uint
             r->orbit_f64 = nullptr;
         }
         r->orbit_ok = false;
+        drop_seq(r);
         FS_TRY(r_alloc(r, (void **)&r->orbit_f64, orbit_size * sizeof(fs_orbit_f64), kInput));
         FS_TRY(hipMemcpyAsync(r->orbit_f64, entries, orbit_size * sizeof(fs_orbit_f64), hipMemcpyDefault, r->compute));
         FS_TRY(hipStreamSynchronize(r->compute));
@@ -873,6 +866,7 @@ uint32_t fs_upload_orbit(fs_renderer *r, uint64_t generation, int type_tag, uint
         r->zref64 = nullptr;
     }
     r->orbit_ok = false;
+    drop_seq(r);
     const size_t in_bytes = type_tag == FS_T_HDR32 ? sizeof(fs_orbit_hdr32) : sizeof(fs_orbit_hdr64);
     void *raw = nullptr;
     FS_TRY(r_alloc(r, &raw, orbit_size * in_bytes, kInput));
@@ -921,7 +915,8 @@ uint32_t fs_upload_orbit_compressed(fs_renderer *r, uint64_t generation, int typ
         return FS_ERR_UNSUPPORTED;
     if (!r->compute)
         return FS_ERR_6;
-    if (r->orbit_ok && r->orbit_gen == generation && generation != 0 && r->orbit_type == type_tag)
+    const bool want_seq = r->compressed_mode == 1 && (type_tag == FS_T_HDR32 || type_tag == FS_T_HDR64);
+    if (r->orbit_ok && r->orbit_gen == generation && generation != 0 && r->orbit_type == type_tag && r->orbit_seq == want_seq)
         return 0;
     if (type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64) {
         // float / double / CudaDblflt / HDRFloat<CudaDblflt>: expanded into the record array the uncompressed upload
@@ -947,6 +942,7 @@ uint32_t fs_upload_orbit_compressed(fs_renderer *r, uint64_t generation, int typ
             *slot = nullptr;
         }
         r->orbit_ok = false;
+        drop_seq(r);
         void *raw = nullptr;
         FS_TRY(r_alloc(r, &raw, compressed_size * in_b, kInput));
         hipError_t err = r_alloc(r, slot, (uncompressed_size + 1) * out_b, kInput);
@@ -982,7 +978,33 @@ uint32_t fs_upload_orbit_compressed(fs_renderer *r, uint64_t generation, int typ
         r->zref64 = nullptr;
     }
     r->orbit_ok = false;
+    drop_seq(r);
     const size_t in_bytes = type_tag == FS_T_HDR32 ? sizeof(fs_orbit_hdr32_rc) : sizeof(fs_orbit_hdr64_rc);
+    if (r->compressed_mode == 1) {
+        // keep the waypoints, nothing else: the kernel decompresses as it goes (GPUPerturbSingleResults for
+        // PerturbExtras::SimpleCompression uploads exactly this array, Perturb.cuh:51-80)
+        if (compressed_size == 0 || compressed_size > 0xFFFFFFFFull)
+            return FS_ERR_UNSUPPORTED;
+        FS_TRY(r_alloc(r, &r->wp_raw, compressed_size * in_bytes, kInput));
+        FS_TRY(hipMemcpyAsync(r->wp_raw, entries, compressed_size * in_bytes, hipMemcpyDefault, r->compute));
+        FS_TRY(hipStreamSynchronize(r->compute));
+        if (type_tag == FS_T_HDR32) {
+            r->c_low32[0] = *(const fs_real_hdr32 *)orbit_x_low;
+            r->c_low32[1] = *(const fs_real_hdr32 *)orbit_y_low;
+        } else {
+            r->c_low64[0] = *(const fs_real_hdr64 *)orbit_x_low;
+            r->c_low64[1] = *(const fs_real_hdr64 *)orbit_y_low;
+        }
+        r->orbit_seq = true;
+        r->orbit_size = compressed_size;
+        r->orbit_uncompressed = uncompressed_size;
+        r->orbit_period = period_maybe_zero;
+        r->orbit_gen = generation;
+        r->orbit_type = type_tag;
+        r->orbit_ok = true;
+        orbit_changed(r);
+        return 0;
+    }
     void *raw = nullptr;
     FS_TRY(r_alloc(r, &raw, compressed_size * in_bytes, kInput));
     hipError_t err = type_tag == FS_T_HDR32 ? r_alloc(r, (void **)&r->zref, (uncompressed_size + 2) * sizeof(float4), kInput)
@@ -1152,6 +1174,8 @@ uint32_t fs_build_bla(fs_renderer *r, int type_tag, const void *bla_size)
         return FS_ERR_UNSUPPORTED;
     if (!r->compute || !r->orbit_ok || r->orbit_type != type_tag)
         return FS_ERR_6;
+    if (r->orbit_seq)
+        return FS_ERR_UNSUPPORTED; // needs the expanded orbit (fs_set_compressed_orbit_mode 0)
     const size_t rec_bytes = type_tag == FS_T_HDR32 ? sizeof(fs_bla_hdr32) : sizeof(fs_bla_hdr64);
     r->bla_n_levels = 0;
     r->bla_type = type_tag;
@@ -1465,6 +1489,8 @@ uint32_t fs_build_la(fs_renderer *r, int type_tag, const void *max_radius, int u
         return FS_ERR_UNSUPPORTED;
     if (!r->compute || !r->orbit_ok || r->orbit_type != type_tag || !max_radius)
         return FS_ERR_6;
+    if (r->orbit_seq)
+        return FS_ERR_UNSUPPORTED; // needs the expanded orbit (fs_set_compressed_orbit_mode 0)
     TimedLaunch t(r);
     return type_tag == FS_T_HDR32 ? build_la<float>(r, max_radius, use_small_exponents)
                                   : build_la<double>(r, max_radius, use_small_exponents);
@@ -1545,6 +1571,33 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
         return FS_ERR_UNSUPPORTED;
     if (!r->orbit_ok || r->orbit_type != type_tag)
         return FS_ERR_6; // GPU_Render.cu:1015-1022
+    if (r->orbit_seq) {
+        // the orbit is resident as waypoints only (fs_set_compressed_orbit_mode 1): the literal kernel with a sequential
+        // decompression cursor per pixel.  Perturbation-only with CPU parity has its twin in the scalar kernel, which reads
+        // an expanded orbit: not served in this mode, like iteration caps of 2^32 and above.
+        if (wide || (mode == FS_LAV2_PO && parity == FS_PARITY_CPU))
+            return FS_ERR_UNSUPPORTED;
+        if (mode != FS_LAV2_PO && (!r->la_ok || r->la_type != type_tag))
+            return FS_ERR_6;
+        const int kmode = mode == FS_LAV2_FULL ? FS_MODE_FULL : (mode == FS_LAV2_PO ? FS_MODE_PO : FS_MODE_LAO);
+        TimedLaunch t(r);
+        if (type_tag == FS_T_HDR32) {
+            FsLav2ArgsT<float> A;
+            fill_lav2<float>(r, A, coords, n_iterations, parity);
+            A.at = r->at;
+            A.wp = r->wp_raw, A.n_wp = (uint32_t)r->orbit_size;
+            A.cxLow = r->c_low32[0], A.cyLow = r->c_low32[1];
+            fsk_lav2_seq(&A, nullptr, kmode, r->stats_on, r->compute);
+        } else {
+            FsLav2ArgsT<double> A;
+            fill_lav2<double>(r, A, coords, n_iterations, parity);
+            A.at = r->at64;
+            A.wp = r->wp_raw, A.n_wp = (uint32_t)r->orbit_size;
+            A.cxLow = r->c_low64[0], A.cyLow = r->c_low64[1];
+            fsk_lav2_seq(nullptr, &A, kmode, r->stats_on, r->compute);
+        }
+        return (uint32_t)hipGetLastError();
+    }
     if (wide) {
         // GPURenderer::RenderPerturbLAv2<uint64_t, ...> with a cap the 32-bit counters cannot hold: the literal kernel
         // instantiated with 64-bit counters (all three modes; the reference's arithmetic, operation by operation)
@@ -1664,6 +1717,8 @@ uint32_t fs_render_bla(fs_renderer *r, int type_tag, const void *coords, uint64_
         return FS_ERR_UNSUPPORTED;
     if (!r->orbit_ok || r->orbit_type != type_tag)
         return FS_ERR_6;
+    if (r->orbit_seq)
+        return FS_ERR_UNSUPPORTED; // needs the expanded orbit (fs_set_compressed_orbit_mode 0)
     const bool use_bla = r->bla_n_levels > 2 && r->bla_levels_dev != nullptr && r->bla_type == type_tag;
     if (type_tag == FS_T_F64) {
         const double *c = (const double *)coords;
@@ -1703,7 +1758,7 @@ uint32_t fs_render_bla(fs_renderer *r, int type_tag, const void *coords, uint64_
                 return e;
         if (use_bla && r->bla_native_ok) {
             A.nrec = (const FsBlaRec *)((const char *)r->bla_native + 256);
-            A.nkey = r->bla_key;
+            A.nlad = (const int4 *)((const char *)A.nrec + (size_t)r->bla_native_total * sizeof(FsBlaRec));
             memcpy(A.level_off, r->bla_level_off, sizeof(A.level_off));
         }
         TimedLaunch t(r);
@@ -2043,6 +2098,39 @@ uint32_t fs_enqueue_done_callback(fs_renderer *r, fs_done_cb cb, void *user)
 }
 
 uint64_t fs_host_fallback_bytes(const fs_renderer *r) { return r->host_alloc_bytes; }
+
+uint32_t fs_set_compressed_orbit_mode(fs_renderer *r, int mode)
+{
+    if (mode != 0 && mode != 1)
+        return hipErrorInvalidValue;
+    r->compressed_mode = mode;
+    return 0;
+}
+
+uint64_t fs_orbit_device_bytes(const fs_renderer *r)
+{
+    if (!r->orbit_ok)
+        return 0;
+    const uint64_t n = r->orbit_uncompressed;
+    if (r->orbit_seq)
+        return r->orbit_size * (r->orbit_type == FS_T_HDR32 ? sizeof(fs_orbit_hdr32_rc) : sizeof(fs_orbit_hdr64_rc));
+    switch (r->orbit_type) {
+        case FS_T_HDR32: // prepared entries + the two companion arrays of the tuned loops
+            return (n + 2) * sizeof(float4) + (2 * (n + 2) + 16) * sizeof(float4);
+        case FS_T_HDR64:
+            return (n + 2) * sizeof(FsZ64);
+        case FS_T_F64:
+            return n * sizeof(fs_orbit_f64);
+        case FS_T_HDR2X32:
+            return n * sizeof(fs_orbit_2x32);
+        case FS_T_F32:
+            return (n + 1) * sizeof(fs_orbit_f32);
+        case FS_T_2X32:
+            return (n + 1) * sizeof(fs_orbit_p2x32);
+        default:
+            return 0;
+    }
+}
 
 uint32_t fs_get_width(const fs_renderer *r) { return r->width; }
 uint32_t fs_get_height(const fs_renderer *r) { return r->height; }

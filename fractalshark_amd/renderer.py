@@ -302,6 +302,15 @@ class GPURenderer:
         self._cbs.append(cb)
         return self._lib.fs_enqueue_done_callback(self._h, cb, None)
 
+    def set_compressed_orbit_mode(self, runtime_decompression):
+        """False / 0: SimpleCompression orbits are expanded on upload; True / 1: only the waypoints stay in HBM and the
+        kernel decompresses as it walks the orbit (fs_set_compressed_orbit_mode).  Applies to the next upload."""
+        return self._lib.fs_set_compressed_orbit_mode(self._h, 1 if runtime_decompression else 0)
+
+    @property
+    def orbit_device_bytes(self):
+        return int(self._lib.fs_orbit_device_bytes(self._h))
+
     @property
     def host_fallback_bytes(self):
         """Bytes of input tables this renderer had to place in page-locked host memory (fs_host_fallback_bytes)."""

@@ -127,6 +127,17 @@ uint32_t fs_upload_orbit(fs_renderer *r, uint64_t generation, int type_tag, uint
 uint32_t fs_upload_orbit_compressed(fs_renderer *r, uint64_t generation, int type_tag, uint32_t iter_bytes,
                                     const void *entries, uint64_t compressed_size, uint64_t uncompressed_size,
                                     uint64_t period_maybe_zero, const void *orbit_x_low, const void *orbit_y_low);
+/* How fs_upload_orbit_compressed keeps an HDRFloat<float|double> orbit in HBM (set it before the upload):
+ *   0 (default)  expanded once on upload into the full orbit (fastest kernels; costs uncompressed_size entries of HBM);
+ *   1            only the waypoints stay resident and every pixel decompresses the orbit as it walks it, with a sequential
+ *                cursor -- GPUPerturbSingleResults::SeqWorkspace / GetIterSeq / BinarySearch (Perturb.cuh:146-326), the
+ *                reason the format exists: orbits too long to hold expanded.  Same orbit values bit for bit, hence the same
+ *                frames.  Served by fs_render_lav2 (all modes except perturbation-only with FS_PARITY_CPU, whose twin is the
+ *                scalar kernel; iteration caps below 2^32); fs_render_bla / fs_build_la / fs_build_bla need the expanded orbit
+ *                and return FS_ERR_UNSUPPORTED.  Other numeric types are always expanded.
+ * fs_orbit_device_bytes: HBM bytes the resident orbit occupies in all its device forms (0 without an orbit). */
+uint32_t fs_set_compressed_orbit_mode(fs_renderer *r, int mode);
+uint64_t fs_orbit_device_bytes(const fs_renderer *r);
 /* ... and LA table upload (GPU_LAReference ctor, GPU_LAReference.h:79-160).  at_info may be NULL when
  * use_at == 0.  iter_bytes selects the record family: 4 -> fs_la_*_u32 / fs_la_stage_u32 / fs_at_*_u32,
  * 8 -> fs_la_*_u64 / fs_la_stage_u64 / fs_at_*_u64 (narrowed on upload). */

@@ -84,3 +84,77 @@ def test_hip_render_reproduces_reference_golden_crc(renderer, native_libs, name,
     assert _oracle.png_crc64(it, gc.W, gc.H, aa, v.num_iterations) == crc64, name
     # (3) the HIP colour path (antialiasing_kernel + palette, AntialiasingKernel.cuh:3-71) through the same writer
     assert _oracle.png_crc64_rgba16(colors, gc.W, gc.H) == crc64, name
+
+
+# ---- the same RC golden cases with the orbit kept COMPRESSED in HBM and decompressed inside the kernel
+RC_CASES = [c for c in gc.CASES if "RC" in c[2]]
+
+
+@pytest.mark.parametrize("name,view_n,alg,aa,crc64", RC_CASES, ids=[c[0] + "-runtime-decompression" for c in RC_CASES])
+def test_rc_goldens_with_in_kernel_decompression(renderer, native_libs, name, view_n, alg, aa, crc64):
+    """PerturbExtras::SimpleCompression as the reference's GPU runs it (Perturb.cuh:146-326): only the waypoints are
+    uploaded and every pixel walks the orbit with a sequential decompression cursor.  The frames must be the golden ones,
+    and the resident orbit must be the waypoints only."""
+    assert len(RC_CASES) == 2
+    v, ob, table = gc.build_inputs(inputs, view_n, alg, aa)
+    assert ob.compressed and ob.compressed_count < ob.count
+    r = renderer
+    try:
+        assert r.set_compressed_orbit_mode(True) == 0
+        it, colors, red = _hip_render(r, alg, v, ob, table, aa)
+        resident = r.orbit_device_bytes
+    finally:
+        r.set_compressed_orbit_mode(False)
+    assert resident == ob.compressed_count * (40 if ob.is64 else 24)
+    assert gc.buffer_crc32(it) == GOLD[name]["iter_buffer_crc32"], name
+    assert red.Sum == GOLD[name]["iter_sum"]
+    assert _oracle.pin_lib() is not None
+    assert _oracle.png_crc64(it, gc.W, gc.H, aa, v.num_iterations) == crc64, name
+    assert _oracle.png_crc64_rgba16(colors, gc.W, gc.H) == crc64, name
+    # the expanding mode on the same renderer afterwards: same frame, the whole orbit resident
+    it2, _, _ = _hip_render(r, alg, v, ob, table, aa)
+    assert np.array_equal(it, it2)
+    assert r.orbit_device_bytes >= ob.count * (32 if ob.is64 else 16) > 10 * resident
+
+
+@pytest.mark.parametrize("is64", [False, True])
+def test_in_kernel_decompression_modes_bands_and_refusals(renderer, native_libs, is64):
+    """All LAv2 modes and both parities on a ragged frame, as the middle rank of a three-way row split, with the LA stages
+    in use (they hand the perturbation loop an orbit index in the MIDDLE of the orbit: the cursor starts with a binary
+    search); entry points that need the expanded orbit say so."""
+    from fractalshark_amd import LAV2_LAO, LAV2_PO, PARITY_CPU_GPUSTAGE
+    v = inputs.View.builtin(5, 70, 37)
+    ob = inputs.Orbit(v, is64=is64, compression_exp=20)
+    la = inputs.LATable(ob)
+    T = T_HDR64 if is64 else T_HDR32
+    co = _pairs(v.coords_perturb(ob))
+    r = renderer
+    frames = {}
+    try:
+        for seq in (False, True):
+            assert r.set_compressed_orbit_mode(seq) == 0
+            assert r.InitializeMemory(70, 37, 1, None, 0, 0, 0, False) == 0
+            assert r.SetRowBands(8, 8, 24) == 0
+            assert r.InitializePerturb(0, ob, 0, None, la) == 0
+            for mode, parity in ((LAV2_FULL, PARITY_CPU), (LAV2_FULL, PARITY_CPU_GPUSTAGE), (LAV2_LAO, PARITY_CPU_GPUSTAGE),
+                                 (LAV2_PO, PARITY_CPU_GPUSTAGE)):
+                assert r.ClearMemory() == 0
+                assert r.RenderPerturbLAv2(None, None, None, *co, v.num_iterations, T=T, Mode=mode, parity=parity) == 0
+                out = r.new_iter_buffer()
+                assert r.RenderCurrent(v.num_iterations, out) == 0
+                assert r.SyncComputeStream() == 0
+                frames[(seq, mode, parity)] = out
+            if seq:
+                assert r.RenderPerturbLAv2(None, None, None, *co, v.num_iterations, T=T, Mode=LAV2_PO, parity=PARITY_CPU) == 10100
+                assert r._lib.fs_render_bla(r._h, T, v.coords_perturb(ob).ctypes.data, v.num_iterations) == 10100
+                assert r.BuildLAOnDevice(ob, host_fallback=False) == 10100
+                assert r.BuildBLAOnDevice(ob) == 10100
+    finally:
+        r.set_compressed_orbit_mode(False)
+    for (seq, mode, parity), out in frames.items():
+        if seq:
+            assert np.array_equal(out, frames[(False, mode, parity)]), (mode, parity)
+    full = _oracle.lav2_hdr32(v, ob, la, stage_test=1)
+    got = frames[(True, LAV2_FULL, PARITY_CPU_GPUSTAGE)]
+    for k, y in enumerate(range(8, 16)):  # the band this "rank" owns first
+        assert np.array_equal(got[k, :70], full[y, :70])

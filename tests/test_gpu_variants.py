@@ -252,31 +252,3 @@ def test_native_bla_table_equals_reference_layout_lookup(renderer, native_libs, 
         assert got["native"][1][k] == got["reference_layout"][1][k], k
     if w * h <= 64 * 36:
         assert np.array_equal(got["native"][0], _oracle.bla_hdr32(v, ob, bla))
-
-
-@pytest.mark.parametrize("bits", [1, 3, 8])
-def test_native_bla_lookup_decides_equal_keys_exactly(renderer, native_libs, monkeypatch, bits):
-    """The 32-bit order keys of the native table drop low mantissa bits; a probe whose keys are equal is decided on the
-    reference-layout record with the reference's compare.  With only a few mantissa bits kept (test switch read when the
-    native form is made) that path is taken for a large share of the probes instead of one in 2^21: frames and counters
-    must not move."""
-    v = inputs.View.builtin(19, 203, 117, antialiasing=1)
-    ob = inputs.Orbit(v)
-    bla = inputs.BLATable(ob)
-    r = renderer
-    try:
-        assert r.set_kernel_variant(1) == 0
-        r.enable_step_count(True)
-        ref = _bla(r, v, ob, bla)
-        st_ref = r.read_step_count()
-        assert r.set_kernel_variant(0) == 0
-        monkeypatch.setenv("FSMI355_BLA_KEY_MANT_BITS", str(bits))
-        out = _bla(r, v, ob, bla)  # uploads orbit and table again: the native form is remade with the short keys
-        st = r.read_step_count()
-        monkeypatch.delenv("FSMI355_BLA_KEY_MANT_BITS")
-    finally:
-        r.enable_step_count(False)
-        r.set_kernel_variant(0)
-    assert np.array_equal(out, ref), int((out != ref).sum())
-    for k in ("perturb_steps", "la_steps", "pixels"):
-        assert st[k] == st_ref[k], k
