@@ -1754,7 +1754,12 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                         // under the maximum of the three exponents involved.  A lane whose sums leave [2^-60, 2^60] or
                         // hit an exact zero on the way takes the literal code below (per lane: a jump is per lane anyway).
                         typedef float f2 __attribute__((ext_vector_type(2)));
-                        auto p2 = [](int n) { return n > -kExpDiffIgnored ? __int_as_float((n << 23) + 0x3F800000) : 0.0f; };
+                        // exact 2^n for -150 < n <= 0, else 0.  The reference ignores an operand from a gap of 120 on
+                        // (kExpDiffIgnored); between 120 and 149 this factor is still a tiny power of two instead of 0 --
+                        // the same thing once every sum has passed the window test below: an operand that far under
+                        // the sum's leading term is absorbed by the float addition either way (one v_ldexp_f32 instead of
+                        // shift-add, compare and select; there are twelve of these per jump)
+                        auto p2 = [](int n) { return __builtin_amdgcn_ldexpf(1.0f, n); };
                         const f2 D = {DeltaSubNX.m, DeltaSubNY.m}, D0 = {DeltaSub0X.m, DeltaSub0Y.m};
                         // nx = ((Ax DX - Ay DY) + Bx D0X) - By D0Y;  ny = ((Ax DY + Ay DX) + Bx D0Y) + By D0X
                         const f2 pA = (f2){Ax.m, Ax.m} * D;         // (Ax DX, Ax DY)   exps Ax.e + (DX.e, DY.e)
@@ -1791,7 +1796,11 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                         const float zmn = fminf(fminf(fabsf(s1.x), fabsf(s1.y)), fminf(fabsf(s2.x), fabsf(s2.y)));
                         const int emin = imin(imin(imin(DeltaSubNX.e, DeltaSubNY.e), imin(DeltaSub0X.e, DeltaSub0Y.e)),
                                               imin(imin(Ax.e, Ay.e), imin(imin(Bx.e, By.e), Z.e)));
-                        if (smn >= 0x1p-60f && smx <= 0x1p60f && zmn > 0.0f && emin > -(1 << 26)) {
+                        // (window 2^+-30 on every sum and 2^30 on the record's mantissas: an operand the reference would
+                        // ignore -- 120 binades under the leading term -- is then at least 2^30 below half an ulp of any sum
+                        // it could be added to, so the power-of-two factor above may stay non-zero there)
+                        const float amx = fmaxf(fmaxf(fabsf(Ax.m), fabsf(Ay.m)), fmaxf(fabsf(Bx.m), fabsf(By.m)));
+                        if (smn >= 0x1p-30f && smx <= 0x1p30f && zmn > 0.0f && emin > -(1 << 26) && amx <= 0x1p30f) {
                             applied = true;
                             RefIteration += l;
                             DeltaSubNX = hreal<F>{s3.x, Ex};
@@ -2220,7 +2229,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                 const int Ze1 = Z.e + 1;
                 const f2 O = {OX.m, OY.m};
                 // exact 2^n for -120 < n <= 0, else 0 (n <= 0 by construction: n = exponent - maximum)
-                auto p2 = [](int n) { return n > -kExpDiffIgnored ? __int_as_float((n << 23) + 0x3F800000) : 0.0f; };
+                auto p2 = [](int n) { return __builtin_amdgcn_ldexpf(1.0f, n); }; // (see the jump above)
                 // T = 2Z + O under eT
                 const int eT = imax(imax(Ze1, OX.e), OY.e);
                 const float zsT = p2(Ze1 - eT);
@@ -2257,12 +2266,12 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                 const float md = p2(nadd);
                 const float dnm = SQ.x * (sxbig ? 1.0f : md) + SQ.y * (sxbig ? md : 1.0f);
                 const int dne = (sxbig ? nxe : nye) << 1;
-                // the sums of the dz update inside [2^-60, 2^60] (also excludes zeros, denormals, infinities and NaNs)
+                // the sums of the dz update inside [2^-30, 2^30] (also excludes zeros, denormals, infinities and NaNs)
                 const float dmx = fmaxf(fmaxf(fmaxf(fabsf(T.x), fabsf(T.y)), fmaxf(fabsf(N.x), fabsf(N.y))),
                                         fmaxf(fabsf(Q.x), fabsf(Q.y)));
                 const float dmn = fminf(fminf(fminf(fabsf(T.x), fabsf(T.y)), fminf(fabsf(N.x), fabsf(N.y))),
                                         fminf(fabsf(Q.x), fabsf(Q.y)));
-                const bool ok_dz = dmn >= 0x1p-60f && dmx <= 0x1p60f && (OX.e < OY.e ? OX.e : OY.e) > -(1 << 26) &&
+                const bool ok_dz = dmn >= 0x1p-30f && dmx <= 0x1p30f && (OX.e < OY.e ? OX.e : OY.e) > -(1 << 26) &&
                                    Zne > -(1 << 26) && RefIteration + 1 < count;
                 // Quiet step: both parts of the new dz at least four binades below the orbit value it arrives at (whose
                 // larger part is in [0.5, 2) 2^Zne), and that value below 4: |dz'| < 2^(Zne - 2.5) = 0.177 * 2^Zne <=
@@ -2299,7 +2308,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                 const float nm = ZZ.x + ZZ.y; // exponent 2*ez
                 const float smx = fmaxf(fabsf(Zt.x), fabsf(Zt.y));
                 const float smn = fminf(fabsf(Zt.x), fabsf(Zt.y));
-                const bool ok = ok_dz && smn >= 0x1p-60f && smx <= 0x1p60f;
+                const bool ok = ok_dz && smn >= 0x1p-30f && smx <= 0x1p30f;
                 if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) {
                     done_fast = true;
                     if (kStats) {
