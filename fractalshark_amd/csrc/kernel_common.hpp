@@ -37,10 +37,23 @@ __device__ __forceinline__ void store_iter(uint32_t *out, const FsFrame &f, uint
         out[idx] = v;
 }
 
-// IterType = uint64_t with 64-bit counting: the full value (the buffer holds uint64_t elements)
+// 64-bit counting: the full value into a uint64_t buffer (IterType = uint64_t); a 4-byte buffer can only be paired with
+// these kernels through the FS_VARIANT_FLAG_WIDE test switch at caps below 2^32, where the low word is the whole count
 __device__ __forceinline__ void store_iter(uint32_t *out, const FsFrame &f, uint32_t L, uint32_t X, uint64_t v)
 {
-    reinterpret_cast<uint64_t *>(out)[(size_t)L * f.rounded_width + X] = v;
+    const size_t idx = (size_t)L * f.rounded_width + X;
+    if (f.iter_u64)
+        reinterpret_cast<uint64_t *>(out)[idx] = v;
+    else
+        out[idx] = (uint32_t)v;
+}
+
+// The iteration cap as the kernel's counter type: IterT = uint32_t takes the low word (the host only launches such a kernel
+// for caps below 2^32), IterT = uint64_t the full value (IterType = uint64_t of the reference's templates with a cap the
+// 32-bit counters cannot hold; the iteration buffer then holds uint64_t elements).
+template <class IterT> __device__ __forceinline__ IterT iter_cap(uint32_t lo, uint32_t hi)
+{
+    return sizeof(IterT) == 8 ? (IterT)(((uint64_t)hi << 32) | lo) : (IterT)lo;
 }
 
 __device__ __forceinline__ void add_stats(uint64_t *stats, uint64_t at, uint64_t la, uint64_t pt, uint64_t px)

@@ -16,7 +16,7 @@ enum { FS_PARITY_LITERAL = 0, FS_PARITY_GPUSTAGE = 1 };
 enum { FS_VARIANT_TUNED = 0, FS_VARIANT_LITERAL = 1, FS_VARIANT_TUNED_NOSCALE = 2, FS_VARIANT_BASE_MASK = 0xff };
 // ... ORed with the A/B flags of fs_set_kernel_variant (include/fsmi355.h): orbit entries of the scaled runs through LDS
 // (k_lav2_hdr32_fast<kLds>), persistent lane-refilling launch of the BLA kernel (k_perturb_scalar<kRefill>)
-enum { FS_VARIANT_FLAG_LDS_ORBIT = 0x100, FS_VARIANT_FLAG_REFILL = 0x200 };
+enum { FS_VARIANT_FLAG_LDS_ORBIT = 0x100, FS_VARIANT_FLAG_REFILL = 0x200, FS_VARIANT_FLAG_WIDE = 0x400 };
 
 // Frame geometry + the row-band layout of the local iteration buffer.
 struct FsFrame {
@@ -28,6 +28,8 @@ struct FsFrame {
     uint32_t band_rows;     // rows per band
     uint32_t band_stride;   // global-row distance between consecutive owned bands
     uint32_t iter_u64;      // 1: the iteration buffer holds uint64_t elements (IterType = uint64_t), 0: uint32_t
+    uint32_t wide;          // 1: launch the instantiation that COUNTS in 64 bits (iteration cap >= 2^32, or the
+                            // FS_VARIANT_FLAG_WIDE test switch), 0: 32-bit counters
 };
 
 // Per-numeric-type device records.  F = float -> HDRFloat<float> (hdr32 ABI records), F = double -> HDRFloat<double>.
@@ -129,7 +131,8 @@ template <class F> struct FsBlaArgsT {
     FsFrame frame;
     FsCoordsT<F> coords;
     uint32_t orbit_count;
-    uint32_t n_iterations;
+    uint32_t n_iterations;    // low 32 bits of the iteration cap
+    uint32_t n_iterations_hi; // high 32 bits: non-zero only for the 64-bit counting instantiation
     int32_t lm2;
     // HDRFloat<float> only: the device-native table (NULL = use `levels`, the reference-layout records)
     const FsBlaRec *nrec;
@@ -148,6 +151,7 @@ struct FsBlaArgsF64 {
     double dx, dy, centerX, centerY;
     uint32_t orbit_count;
     uint32_t n_iterations;
+    uint32_t n_iterations_hi;
     int32_t lm2;
 };
 
@@ -160,6 +164,7 @@ template <class F> struct FsDirectHdrArgsT {
     fs::hreal<F> dy;
     fs::hreal<F> maxY;
     uint32_t n_iterations;
+    uint32_t n_iterations_hi; // high word of the cap: non-zero selects the 64-bit counting instantiation
 };
 
 // LAv2 for HDRFloat<CudaDblflt> (2x32): the reference records are used as they are (24-B orbit entries, 104-B LA
@@ -176,6 +181,7 @@ struct FsLav2Args2x32 {
     uint32_t orbit_count;
     uint32_t stage_count;
     uint32_t n_iterations;
+    uint32_t n_iterations_hi; // high word of the cap: non-zero selects the 64-bit counting instantiation
     int la_valid;
     int use_at;
 };
@@ -194,6 +200,7 @@ struct FsLav2ArgsPlain {
     uint32_t orbit_count;
     uint32_t stage_count;
     uint32_t n_iterations;
+    uint32_t n_iterations_hi;
     int la_valid;
     int use_at;
 };
@@ -209,6 +216,7 @@ struct FsScaledArgs32 {
     FsCoordsT<float> coords;
     uint32_t orbit_count;
     uint32_t n_iterations;
+    uint32_t n_iterations_hi; // high word of the cap: non-zero selects the 64-bit counting instantiation (literal kernel)
     float w2threshold; // exp(log(1e30f) / 2), ScaledKernels.cuh:21,66
 };
 
@@ -221,6 +229,7 @@ struct FsScaledArgsF64 { // Gpu1x32PerturbedScaled: T = double
     double dx, dy, centerX, centerY;
     uint32_t orbit_count;
     uint32_t n_iterations;
+    uint32_t n_iterations_hi;
     float w2threshold;
 };
 
@@ -233,6 +242,7 @@ struct FsDirectLpArgs {
     float c32[16];  // 1x32: 4, 2x32: 8, 4x32: 16 values
     double c64[16]; // 2x64: 8, 4x64: 16 values
     uint32_t n_iterations;
+    uint32_t n_iterations_hi;
 };
 
 struct FsDirectArgs64 {
@@ -243,6 +253,7 @@ struct FsDirectArgs64 {
     double dy;
     double maxY;
     uint32_t n_iterations;
+    uint32_t n_iterations_hi;
 };
 
 void fsk_prepare_orbit_hdr32(const fs_orbit_hdr32 *in, float4 *out, uint64_t n, hipStream_t s);

@@ -1382,9 +1382,13 @@ __device__ __forceinline__ uint32_t bla_lookup_native(const int4 *__restrict__ l
 constexpr uint32_t kRefillEvery = 24;
 
 // kNat (HDRFloat<float>, kBla, one tile per wave): the table is read in its device-native form (FsBlaRec + ladder).
-template <class F, bool kBla, bool kStats, bool kRefill, bool kNat = false>
+// IterT: the reference's IterType for the counters (BLAKernels.cuh:193 is templated on it the same way): uint32_t, or
+// uint64_t for iteration caps of 2^32 and above (one tile per wave, reference-layout lookup; the runs of the perturbation-only
+// float path, whose step budgets are 32-bit, are compiled out -- the single steps and the jumps count in IterT).
+template <class F, bool kBla, bool kStats, bool kRefill, bool kNat = false, class IterT = uint32_t>
 __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
 {
+    constexpr bool kRuns = sizeof(IterT) == 4;
     __shared__ const typename FsDev<F>::BLA *s_levels[kBla && !kNat ? 64 : 1];
     __shared__ uint32_t s_off[kNat ? 64 : 1];
     if constexpr (kBla && !kNat) {
@@ -1414,13 +1418,13 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
 #else
 #define FS_PH(stmt) do { } while (0)
 #endif
-    const uint32_t n_iterations = A.n_iterations;
+    const IterT n_iterations = iter_cap<IterT>(A.n_iterations, A.n_iterations_hi);
     const uint32_t count = A.orbit_count;
     const typename FsDev<F>::Z *__restrict__ zr = A.zref;
     const hreal<F> TwoFiftySix = hreal<F>{F(1), 8};
     // per-pixel state (lives across refill rounds)
     bool have = false;
-    uint32_t iter = 0;
+    IterT iter = 0;
     uint32_t RefIteration = 0;
     hreal<F> DeltaSub0X = hr_zero<F>(), DeltaSub0Y = hr_zero<F>();
     hreal<F> DeltaSubNX = hr_zero<F>();
@@ -1875,7 +1879,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
             // with its own exponent -- is the same sequence of roundings as the complex one: s = fma(w, 2^E, 2Z),
             // q = (w.x s.x - w.y s.y, w.x s.y + w.y s.x) + c 2^-E.  Same acceptance tests, same companion array.
             bool sc_stopped = false;
-            if constexpr (!kBla && std::is_same<F, float>::value) {
+            if constexpr (kRuns && !kBla && std::is_same<F, float>::value) {
                 typedef float f2 __attribute__((ext_vector_type(2)));
                 typedef float f3 __attribute__((ext_vector_type(3)));
                 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -2070,7 +2074,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                     }
                 }
             }
-            if constexpr (!kBla && std::is_same<F, float>::value) {
+            if constexpr (kRuns && !kBla && std::is_same<F, float>::value) {
               if (!sc_stopped) {
                 typedef float f2 __attribute__((ext_vector_type(2)));
                 typedef float f3 __attribute__((ext_vector_type(3)));
@@ -2425,7 +2429,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
 // (Fractal.cpp:2148-2183): cy = maxY - dy*(double)(float)y; cx starts at minX and is ACCUMULATED (cx += dx)
 // along the row, so a lane at column x replays x additions; z0 = c; bailout sum > 4.
 // Replaces mandel_1x_double (FractalSharkGpuLib/LowPrecisionKernels.cuh:79-171).
-template <bool kStats>
+template <bool kStats, class IterT = uint32_t>
 __global__ void __launch_bounds__(256) k_direct_f64(FsDirectArgs64 A)
 {
     const uint32_t X = blockIdx.x * 64u + (threadIdx.x & 63u);
@@ -2440,8 +2444,9 @@ __global__ void __launch_bounds__(256) k_direct_f64(FsDirectArgs64 A)
         const double cx = A.cx_row[X];
         const double cy = A.maxY - A.dy * (double)((float)Y);
         double zx = cx, zy = cy;
-        uint32_t i;
-        for (i = 0; i < A.n_iterations; i++) {
+        const IterT n_iterations = iter_cap<IterT>(A.n_iterations, A.n_iterations_hi);
+        IterT i;
+        for (i = 0; i < n_iterations; i++) {
             const double zx2 = zx * zx;
             const double zy2 = zy * zy;
             const double sum = zx2 + zy2;
@@ -2495,7 +2500,7 @@ __global__ void k_prepare_orbit_hdr64(const fs_orbit_hdr64 *__restrict__ in, FsZ
 // CpuHDR32 / CpuHDR64): z0 = c, bailout Reduce(zx^2+zy^2) > 4, zy = (2*zx)*zy, zx = zx2 - zy2, += c, Reduce both.
 // cx is the CPU's accumulated `cx += dx` (un-reduced HDR adds) from a 1-lane serial scan, like k_direct_f64.
 // Replaces mandel_hdr_float (FractalSharkGpuLib/LowPrecisionKernels.cuh:682-777).
-template <class F, bool kStats>
+template <class F, bool kStats, class IterT = uint32_t>
 __global__ void __launch_bounds__(256) k_direct_hdr(FsDirectHdrArgsT<F> A)
 {
     const uint32_t X = blockIdx.x * 64u + (threadIdx.x & 63u);
@@ -2512,8 +2517,9 @@ __global__ void __launch_bounds__(256) k_direct_hdr(FsDirectHdrArgsT<F> A)
         const hreal<F> Four{F(1), 2};
         const hreal<F> Two{F(1), 1};
         hreal<F> zx = cx, zy = cy;
-        uint32_t i;
-        for (i = 0; i < A.n_iterations; i++) {
+        const IterT n_iterations = iter_cap<IterT>(A.n_iterations, A.n_iterations_hi);
+        IterT i;
+        for (i = 0; i < n_iterations; i++) {
             const hreal<F> zx2 = hr_mul(zx, zx);
             const hreal<F> zy2 = hr_mul(zy, zy);
             const hreal<F> sum = hr_reduced(hr_add(zx2, zy2));
@@ -2610,7 +2616,7 @@ __device__ __forceinline__ const fs_bla_f64 *bla_lookup_f64(const FsBlaArgsF64 &
 }
 } // namespace
 
-template <bool kBla, bool kStats>
+template <bool kBla, bool kStats, class IterT = uint32_t>
 __global__ void __launch_bounds__(256) k_perturb_bla_f64(FsBlaArgsF64 A)
 {
     const uint32_t X = blockIdx.x * 64u + (threadIdx.x & 63u);
@@ -2620,10 +2626,11 @@ __global__ void __launch_bounds__(256) k_perturb_bla_f64(FsBlaArgsF64 A)
     const bool live = X < A.frame.width && L < A.frame.local_rows && Y < A.frame.height;
     if (live) {
         c_px = 1;
-        const uint32_t n_iterations = A.n_iterations;
+        const IterT n_iterations = iter_cap<IterT>(A.n_iterations, A.n_iterations_hi);
         const uint32_t count = A.orbit_count;
         const fs_orbit_f64 *__restrict__ orbit = A.orbit;
-        uint32_t iter = 0, RefIteration = 0;
+        IterT iter = 0;
+        uint32_t RefIteration = 0;
         double deltaReal = A.dx * (double)X;
         deltaReal -= A.centerX;
         double deltaImaginary = -A.dy * (double)Y;
@@ -2811,6 +2818,20 @@ template <class F>
 static void launch_perturb_scalar(const FsBlaArgsT<F> &A, bool use_bla, bool stats, int variant, hipStream_t s)
 {
     const dim3 g = tile_grid(A.frame), b(256);
+    if (A.frame.wide != 0u) { // iteration cap of 2^32 or above: the instantiation that counts in 64 bits
+        if (use_bla) {
+            if (stats)
+                hipLaunchKernelGGL((k_perturb_scalar<F, true, true, false, false, uint64_t>), g, b, 0, s, A);
+            else
+                hipLaunchKernelGGL((k_perturb_scalar<F, true, false, false, false, uint64_t>), g, b, 0, s, A);
+        } else {
+            if (stats)
+                hipLaunchKernelGGL((k_perturb_scalar<F, false, true, false, false, uint64_t>), g, b, 0, s, A);
+            else
+                hipLaunchKernelGGL((k_perturb_scalar<F, false, false, false, false, uint64_t>), g, b, 0, s, A);
+        }
+        return;
+    }
     if (use_bla && (variant & FS_VARIANT_FLAG_REFILL) != 0) {
         (void)hipMemsetAsync(A.queue, 0, sizeof(uint32_t), s);
         if (stats)
@@ -2943,9 +2964,15 @@ void fsk_lav2_seq(const FsLav2Args32 *A32, const FsLav2ArgsT<double> *A64, int m
 {
     const FsFrame &f = A32 ? A32->frame : A64->frame;
     const dim3 g = tile_grid(f), b(256);
+    const bool wide = (A32 ? A32->frame.wide : A64->frame.wide) != 0u;
 #define FS_LAUNCH_SEQ(M)                                                                                             \
     do {                                                                                                            \
-        if (A32) {                                                                                                  \
+        if (wide) {                                                                                                 \
+            if (A32)                                                                                                \
+                hipLaunchKernelGGL((k_lav2_lit<float, M, false, uint64_t, true>), g, b, 0, s, *A32);                 \
+            else                                                                                                    \
+                hipLaunchKernelGGL((k_lav2_lit<double, M, false, uint64_t, true>), g, b, 0, s, *A64);                \
+        } else if (A32) {                                                                                           \
             if (stats)                                                                                              \
                 hipLaunchKernelGGL((k_lav2_lit<float, M, true, uint32_t, true>), g, b, 0, s, *A32);                  \
             else                                                                                                    \
@@ -2974,6 +3001,13 @@ void fsk_perturb_scalar_hdr64(const FsBlaArgsT<double> &A, bool use_bla, bool st
 void fsk_perturb_bla_f64(const FsBlaArgsF64 &A, bool use_bla, bool stats, hipStream_t s)
 {
     const dim3 g = frame_grid(A.frame), b(256);
+    if (A.frame.wide != 0u) { // 64-bit counting (iteration caps of 2^32 and above)
+        if (use_bla)
+            hipLaunchKernelGGL((k_perturb_bla_f64<true, false, uint64_t>), g, b, 0, s, A);
+        else
+            hipLaunchKernelGGL((k_perturb_bla_f64<false, false, uint64_t>), g, b, 0, s, A);
+        return;
+    }
     if (use_bla) {
         if (stats)
             hipLaunchKernelGGL((k_perturb_bla_f64<true, true>), g, b, 0, s, A);
@@ -2992,7 +3026,9 @@ static void launch_direct_hdr(const FsDirectHdrArgsT<F> &A, hreal<F> minX, hreal
 {
     hipLaunchKernelGGL((k_direct_row_prefix_hdr<F>), dim3(1), dim3(64), 0, s, minX, dx, A.frame.width, A.cx_row);
     const dim3 g = frame_grid(A.frame), b(256);
-    if (stats)
+    if (A.frame.wide != 0u)
+        hipLaunchKernelGGL((k_direct_hdr<F, false, uint64_t>), g, b, 0, s, A);
+    else if (stats)
         hipLaunchKernelGGL((k_direct_hdr<F, true>), g, b, 0, s, A);
     else
         hipLaunchKernelGGL((k_direct_hdr<F, false>), g, b, 0, s, A);
@@ -3010,7 +3046,9 @@ void fsk_direct_f64(const FsDirectArgs64 &A, double minX, double dx, bool stats,
 {
     hipLaunchKernelGGL(k_direct_row_prefix_f64, dim3(1), dim3(64), 0, s, minX, dx, A.frame.width, A.cx_row);
     const dim3 g = frame_grid(A.frame), b(256);
-    if (stats)
+    if (A.frame.wide != 0u)
+        hipLaunchKernelGGL((k_direct_f64<false, uint64_t>), g, b, 0, s, A);
+    else if (stats)
         hipLaunchKernelGGL((k_direct_f64<true>), g, b, 0, s, A);
     else
         hipLaunchKernelGGL((k_direct_f64<false>), g, b, 0, s, A);

@@ -88,7 +88,10 @@ __device__ __forceinline__ HC hc_mul2_pk(HC a)
     return HC{R.lo(), R.hi(), clamp_exp(a.e + 1)};
 }
 
-template <int Mode, bool kStats> __global__ void __launch_bounds__(256) k_lav2_2x32(FsLav2Args2x32 A)
+// IterT: the reference's IterType for the counters (LAKernel.cuh:3): uint32_t, or uint64_t for iteration caps of 2^32 and
+// above (iterations, the cap, the AT iteration count and the i x StepLength product in 64 bits).
+template <int Mode, bool kStats, class IterT = uint32_t>
+__global__ void __launch_bounds__(256) k_lav2_2x32(FsLav2Args2x32 A)
 {
     uint32_t X, L;
     tile_pixel(X, L);
@@ -97,23 +100,24 @@ template <int Mode, bool kStats> __global__ void __launch_bounds__(256) k_lav2_2
     const bool live = X < A.frame.width && L < A.frame.local_rows && Y < A.frame.height;
     if (live) {
         c_px = 1;
-        const uint32_t n_iterations = A.n_iterations;
+        const IterT n_iterations = iter_cap<IterT>(A.n_iterations, A.n_iterations_hi);
         // LAKernel.cuh:39-63
         const HR DeltaSub0X = hr_sub(hr_mul(ldr(A.coords[0]), hr2_from_int((int)X)), ldr(A.coords[2]));
         const HR DeltaSub0Y = hr_sub(hr_mul(hr_neg(ldr(A.coords[1])), hr2_from_int((int)Y)), ldr(A.coords[3]));
         const HC DeltaSub0 = hc_from_hr(DeltaSub0X, DeltaSub0Y);
         HC DeltaSubN = hc_from_hr(hr2_from_int(0), hr2_from_int(0));
-        uint32_t iter = 0, RefIteration = 0;
+        IterT iter = 0;
+        uint32_t RefIteration = 0;
 
         if (Mode != FS_MODE_PO) {
             // :66-71 + ATInfo::isValid / PerformAT, ATInfo.h:126-188
             if (A.la_valid && A.use_at && hr_cmp_pos(hc_cheb(DeltaSub0), ldr(A.at.ThresholdC)) <= 0) {
-                const uint32_t ATMaxIt = n_iterations / A.at.StepLength;
+                const IterT ATMaxIt = n_iterations / A.at.StepLength;
                 HC c = hc_add(hc_mul(DeltaSub0, ldc(A.at.CCoeff)), ldc(A.at.RefC));
                 hc_reduce(c);
                 HC z = hc_zero<df32>();
                 const HR esc = ldr(A.at.SqrEscapeRadius);
-                uint32_t i;
+                IterT i;
                 for (i = 0; i < ATMaxIt; i++) {
                     // Steady state.  z starts as {0, 0, kMinBigExp}; the first z*z + c returns c itself (its exponent gap is
                     // beyond the 120 window), and from then on z carries c's exponent E whenever E <= 0 (|c| < 2): z*z has
@@ -289,7 +293,9 @@ void fsk_lav2_2x32(const FsLav2Args2x32 &A, int mode, bool stats, hipStream_t s)
     const dim3 g((A.frame.width + 31) / 32, (A.frame.local_rows + 7) / 8); // tile_pixel()
 #define FS_LAUNCH(M)                                                                                                    \
     do {                                                                                                                \
-        if (stats)                                                                                                      \
+        if (A.frame.wide != 0u)                                                                                    \
+            hipLaunchKernelGGL((k_lav2_2x32<M, false, uint64_t>), g, b, 0, s, A);                                       \
+        else if (stats)                                                                                                 \
             hipLaunchKernelGGL((k_lav2_2x32<M, true>), g, b, 0, s, A);                                                  \
         else                                                                                                            \
             hipLaunchKernelGGL((k_lav2_2x32<M, false>), g, b, 0, s, A);                                                 \

@@ -130,7 +130,7 @@ __device__ __forceinline__ bool lp_pixel(const FsFrame &f, uint32_t &X, uint32_t
 }
 
 // mandel_1x_float<IterType, iteration_precision>
-template <int IP, bool kStats> __global__ void __launch_bounds__(256) k_direct_1x32(FsDirectLpArgs A)
+template <int IP, bool kStats, class IterT = uint32_t> __global__ void __launch_bounds__(256) k_direct_1x32(FsDirectLpArgs A)
 {
     uint32_t X, L;
     int Y;
@@ -141,8 +141,8 @@ template <int IP, bool kStats> __global__ void __launch_bounds__(256) k_direct_1
         const float x0 = cx + dx * (float)(int)X;
         const float y0 = cy + dy * (float)Y;
         float x = 0.0f, y = 0.0f;
-        const uint32_t n = A.n_iterations - (uint32_t)(IP - 1);
-        uint32_t iter = 0;
+        const IterT n = iter_cap<IterT>(A.n_iterations, A.n_iterations_hi) - (IterT)(IP - 1);
+        IterT iter = 0;
         while (x * x + y * y < 4.0f && iter < n) {
 #pragma unroll
             for (int k = 0; k < IP; k++) {
@@ -163,7 +163,7 @@ template <int IP, bool kStats> __global__ void __launch_bounds__(256) k_direct_1
 }
 
 // mandel_2x_float<IterType, iteration_precision>
-template <int IP, bool kStats> __global__ void __launch_bounds__(256) k_direct_2x32(FsDirectLpArgs A)
+template <int IP, bool kStats, class IterT = uint32_t> __global__ void __launch_bounds__(256) k_direct_2x32(FsDirectLpArgs A)
 {
     uint32_t X, L;
     int Y;
@@ -176,8 +176,9 @@ template <int IP, bool kStats> __global__ void __launch_bounds__(256) k_direct_2
         const dw<float> x0 = dw_add(cx2, dw_mul(dx2, X2));
         const dw<float> y0 = dw_add(cy2, dw_mul(dy2, Y2));
         dw<float> x{0.0f, 0.0f}, y{0.0f, 0.0f}, zrsqr{0.0f, 0.0f}, zisqr{0.0f, 0.0f};
-        uint32_t iter = 0;
-        while (zrsqr.h + zisqr.h < 4.0f && iter < A.n_iterations) {
+        const IterT n_iterations = iter_cap<IterT>(A.n_iterations, A.n_iterations_hi);
+        IterT iter = 0;
+        while (zrsqr.h + zisqr.h < 4.0f && iter < n_iterations) {
 #pragma unroll
             for (int k = 0; k < IP; k++) {
                 y = dw_mul2x(x, y);
@@ -198,7 +199,7 @@ template <int IP, bool kStats> __global__ void __launch_bounds__(256) k_direct_2
 }
 
 // mandel_2x_double<IterType>
-template <bool kStats> __global__ void __launch_bounds__(256) k_direct_2x64(FsDirectLpArgs A)
+template <bool kStats, class IterT = uint32_t> __global__ void __launch_bounds__(256) k_direct_2x64(FsDirectLpArgs A)
 {
     uint32_t X, L;
     int Y;
@@ -213,8 +214,9 @@ template <bool kStats> __global__ void __launch_bounds__(256) k_direct_2x64(FsDi
         dw<double> x = two_sum(0.0, 0.0), y = two_sum(0.0, 0.0);
         const dw<double> two = two_sum(2.0, 0.0);
         dw<double> zrsqr = dw_sqr(x), zisqr = dw_sqr(y);
-        uint32_t iter = 0;
-        while (zrsqr.h + zisqr.h < 4.0 && iter < A.n_iterations) {
+        const IterT n_iterations = iter_cap<IterT>(A.n_iterations, A.n_iterations_hi);
+        IterT iter = 0;
+        while (zrsqr.h + zisqr.h < 4.0 && iter < n_iterations) {
             const dw<double> xtemp = dw_add(dw_sub(zrsqr, zisqr), x0);
             y = dw_add(dw_mul(two, dw_mul(x, y)), y0);
             x = xtemp;
@@ -232,7 +234,7 @@ template <bool kStats> __global__ void __launch_bounds__(256) k_direct_2x64(FsDi
 
 // mandel_4x_float (Gpu4x32), LowPrecisionKernels.cuh:5-75: quad-float; the pixel index enters as make_qf(X, 0, 0, 0), the
 // doubling is mul_pwr2, squares use sqr(), the bailout compares two quads
-template <bool kStats> __global__ void __launch_bounds__(256) k_direct_4x32(FsDirectLpArgs A)
+template <bool kStats, class IterT = uint32_t> __global__ void __launch_bounds__(256) k_direct_4x32(FsDirectLpArgs A)
 {
     using Q = q4<float>;
     uint32_t X, L;
@@ -247,8 +249,9 @@ template <bool kStats> __global__ void __launch_bounds__(256) k_direct_4x32(FsDi
         const Q four{4.0f, 0.0f, 0.0f, 0.0f};
         Q x{0.0f, 0.0f, 0.0f, 0.0f}, y = x;
         Q zrsqr = q_sqr(x), zisqr = q_sqr(y);
-        uint32_t iter = 0;
-        while (zrsqr + zisqr <= four && iter < A.n_iterations) {
+        const IterT n_iterations = iter_cap<IterT>(A.n_iterations, A.n_iterations_hi);
+        IterT iter = 0;
+        while (zrsqr + zisqr <= four && iter < n_iterations) {
             y = x * y;
             y = q_mul_pwr2(y, 2.0f);
             y = y + y0;
@@ -267,7 +270,7 @@ template <bool kStats> __global__ void __launch_bounds__(256) k_direct_4x32(FsDi
 
 // mandel_4x_double (Gpu4x64), LowPrecisionKernels.cuh:77-140: quad-double; the pixel index and the factor two are scalars
 // (quad * double), squares are full products, the bailout compares against the scalar 4.0
-template <bool kStats> __global__ void __launch_bounds__(256) k_direct_4x64(FsDirectLpArgs A)
+template <bool kStats, class IterT = uint32_t> __global__ void __launch_bounds__(256) k_direct_4x64(FsDirectLpArgs A)
 {
     using Q = q4<double>;
     uint32_t X, L;
@@ -281,8 +284,9 @@ template <bool kStats> __global__ void __launch_bounds__(256) k_direct_4x64(FsDi
         const Q x0 = cx + dx * (double)(int)X;
         Q x{0.0, 0.0, 0.0, 0.0}, y = x;
         Q zrsqr = x * x, zisqr = y * y;
-        uint32_t iter = 0;
-        while (zrsqr + zisqr <= 4.0 && iter < A.n_iterations) {
+        const IterT n_iterations = iter_cap<IterT>(A.n_iterations, A.n_iterations_hi);
+        IterT iter = 0;
+        while (zrsqr + zisqr <= 4.0 && iter < n_iterations) {
             y = x * y;
             y = y * 2.0;
             y = y + y0;
@@ -305,9 +309,12 @@ bool fsk_direct_lp(const FsDirectLpArgs &A, int kind, int iteration_precision, b
 {
     const dim3 b(256);
     const dim3 g((A.frame.width + 63) / 64, (A.frame.local_rows + 3) / 4);
+    const bool wide = A.frame.wide != 0u; // iteration cap of 2^32 or above: the instantiations counting in 64 bits
 #define FS_LP_IP(K, IPV)                                                                                            \
     case IPV:                                                                                                       \
-        if (stats)                                                                                                  \
+        if (wide)                                                                                                   \
+            hipLaunchKernelGGL((K<IPV, false, uint64_t>), g, b, 0, s, A);                                           \
+        else if (stats)                                                                                             \
             hipLaunchKernelGGL((K<IPV, true>), g, b, 0, s, A);                                                      \
         else                                                                                                        \
             hipLaunchKernelGGL((K<IPV, false>), g, b, 0, s, A);                                                     \
@@ -331,19 +338,25 @@ bool fsk_direct_lp(const FsDirectLpArgs &A, int kind, int iteration_precision, b
             return false;
         }
     } else if (kind == 2) {
-        if (stats)
+        if (wide)
+            hipLaunchKernelGGL((k_direct_2x64<false, uint64_t>), g, b, 0, s, A);
+        else if (stats)
             hipLaunchKernelGGL((k_direct_2x64<true>), g, b, 0, s, A);
         else
             hipLaunchKernelGGL((k_direct_2x64<false>), g, b, 0, s, A);
         return true;
     } else if (kind == 3) { // Gpu4x32
-        if (stats)
+        if (wide)
+            hipLaunchKernelGGL((k_direct_4x32<false, uint64_t>), g, b, 0, s, A);
+        else if (stats)
             hipLaunchKernelGGL((k_direct_4x32<true>), g, b, 0, s, A);
         else
             hipLaunchKernelGGL((k_direct_4x32<false>), g, b, 0, s, A);
         return true;
     } else { // Gpu4x64
-        if (stats)
+        if (wide)
+            hipLaunchKernelGGL((k_direct_4x64<false, uint64_t>), g, b, 0, s, A);
+        else if (stats)
             hipLaunchKernelGGL((k_direct_4x64<true>), g, b, 0, s, A);
         else
             hipLaunchKernelGGL((k_direct_4x64<false>), g, b, 0, s, A);

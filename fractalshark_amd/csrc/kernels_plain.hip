@@ -111,10 +111,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 //   t  = z' + n, |t|^2, |n|^2
 // Per-lane state is {d, z, byte offset of the orbit entry, iter}; the select block that rebases is skipped with one
 // wave-uniform branch on the steps where no lane of the wave rebases.
-template <bool kStats>
+template <bool kStats, class IterT>
 __device__ __forceinline__ void perturb_f32(const fs_orbit_f32 *__restrict__ orb, uint32_t orbit_count, f2 d, f2 d0,
-                                            uint32_t &RefIteration, uint32_t &iter, uint32_t n_iterations,
-                                            uint64_t &c_pt)
+                                            uint32_t &RefIteration, IterT &iter, IterT n_iterations, uint64_t &c_pt)
 {
     const char *base = reinterpret_cast<const char *>(orb);
     const uint32_t max_off = (orbit_count - 1) * 8u;
@@ -162,7 +161,9 @@ __device__ __forceinline__ void perturb_f32(const fs_orbit_f32 *__restrict__ orb
     RefIteration = off >> 3;
 }
 
-template <class T, int Mode, bool kStats> __global__ void __launch_bounds__(256) k_lav2_plain(FsLav2ArgsPlain A)
+// IterT: the reference's IterType for the counters (LAKernel.cuh:3): uint32_t, or uint64_t for caps of 2^32 and above.
+template <class T, int Mode, bool kStats, class IterT = uint32_t>
+__global__ void __launch_bounds__(256) k_lav2_plain(FsLav2ArgsPlain A)
 {
     using P = Plain<T>;
     uint32_t X, L;
@@ -172,7 +173,7 @@ template <class T, int Mode, bool kStats> __global__ void __launch_bounds__(256)
     const bool live = X < A.frame.width && L < A.frame.local_rows && Y < A.frame.height;
     if (live) {
         c_px = 1;
-        const uint32_t n_iterations = A.n_iterations;
+        const IterT n_iterations = iter_cap<IterT>(A.n_iterations, A.n_iterations_hi);
         const typename P::Real *co = reinterpret_cast<const typename P::Real *>(A.coords);
         const typename P::AT &at = *reinterpret_cast<const typename P::AT *>(A.at);
         const typename P::LA *__restrict__ las = reinterpret_cast<const typename P::LA *>(A.las);
@@ -183,17 +184,18 @@ template <class T, int Mode, bool kStats> __global__ void __launch_bounds__(256)
         const T DeltaSub0Y = -ld(co[1]) * P::from_int((int)Y) - ld(co[3]);
         const cx<T> DeltaSub0{DeltaSub0X, DeltaSub0Y};
         cx<T> DeltaSubN{P::from_int(0), P::from_int(0)};
-        uint32_t iter = 0, RefIteration = 0;
+        IterT iter = 0;
+        uint32_t RefIteration = 0;
 
         if (Mode != FS_MODE_PO) {
             // :66-71 + ATInfo::isValid / PerformAT (plain arms), ATInfo.h:126-188.  For T = CudaDblflt `<=` is the
             // reference's operator as written (CudaDblflt.h:218-222, df32_math.hpp).
             if (A.la_valid && A.use_at && cheb(DeltaSub0) <= ld(at.ThresholdC)) {
-                const uint32_t ATMaxIt = n_iterations / at.StepLength;
+                const IterT ATMaxIt = n_iterations / at.StepLength;
                 const cx<T> c = DeltaSub0 * ld(at.CCoeff) + ld(at.RefC);
                 cx<T> z{P::from_int(0), P::from_int(0)};
                 const T esc = ld(at.SqrEscapeRadius);
-                uint32_t i;
+                IterT i;
                 for (i = 0; i < ATMaxIt; i++) {
                     if (norm2(z) > esc)
                         break;
@@ -249,7 +251,7 @@ template <class T, int Mode, bool kStats> __global__ void __launch_bounds__(256)
             // :133-235.  perturbLoop(maxRefIteration) at :254-276 reads the block's previous results, which are zero on
             // the cleared buffer every caller passes (Fractal.cpp:2822), so only perturbLoop(n_iterations) runs.
             if constexpr (std::is_same<T, float>::value) {
-                perturb_f32<kStats>(orb, A.orbit_count, f2{DeltaSubN.re, DeltaSubN.im}, f2{DeltaSub0X, DeltaSub0Y},
+                perturb_f32<kStats, IterT>(orb, A.orbit_count, f2{DeltaSubN.re, DeltaSubN.im}, f2{DeltaSub0X, DeltaSub0Y},
                                     RefIteration, iter, n_iterations, c_pt);
             } else {
             const uint32_t MaxRef = A.orbit_count - 1;
@@ -301,7 +303,9 @@ template <class T> void launch(const FsLav2ArgsPlain &A, int mode, bool stats, h
     const dim3 g((A.frame.width + 31) / 32, (A.frame.local_rows + 7) / 8); // tile_pixel()
 #define FS_LAUNCH(M)                                                                                                    \
     do {                                                                                                                \
-        if (stats)                                                                                                      \
+        if (A.frame.wide != 0u)                                                                                    \
+            hipLaunchKernelGGL((k_lav2_plain<T, M, false, uint64_t>), g, b, 0, s, A);                                   \
+        else if (stats)                                                                                                 \
             hipLaunchKernelGGL((k_lav2_plain<T, M, true>), g, b, 0, s, A);                                              \
         else                                                                                                            \
             hipLaunchKernelGGL((k_lav2_plain<T, M, false>), g, b, 0, s, A);                                             \

@@ -48,7 +48,7 @@ __device__ __forceinline__ uint32_t scaled_run_length_dev(uint32_t left)
 // wave mostly hit one cache line); the binary32 orbit entry a step tests against is the entry the next step multiplies
 // by, so it is carried in registers instead of being loaded twice (one load per binary32 step); the common outcome of a
 // step ("none": no rebase, no rescale, no escape) is the fall-through, everything else is cold.
-template <bool kStats> __global__ void __launch_bounds__(256) k_scaled_hdr32(FsScaledArgs32 A)
+template <bool kStats, class IterT = uint32_t> __global__ void __launch_bounds__(256) k_scaled_hdr32(FsScaledArgs32 A)
 {
     uint32_t X, L;
     tile_pixel(X, L);
@@ -57,11 +57,12 @@ template <bool kStats> __global__ void __launch_bounds__(256) k_scaled_hdr32(FsS
     const bool live = X < A.frame.width && L < A.frame.local_rows && Y < A.frame.height;
     if (live) {
         c_px = 1;
-        const uint32_t n_iterations = A.n_iterations;
+        const IterT n_iterations = iter_cap<IterT>(A.n_iterations, A.n_iterations_hi);
         const uint32_t MaxRefIteration = A.orbit_count - 1;
         const fs_orbit_hdr32_bad *__restrict__ ot = A.orbit_t;
         const fs_orbit_f32_bad *__restrict__ of = A.orbit_f;
-        uint32_t iter = 0, RefIteration = 0;
+        IterT iter = 0;
+        uint32_t RefIteration = 0;
         // :35-39  `dx * X`: the int becomes a float and goes through HDRFloat(T mant)
         H DeltaReal = hr_sub(hr_mul(A.coords.dx, hr_from_mant<float>((float)(int)X)), A.coords.centerX);
         hr_reduce(DeltaReal);
@@ -461,7 +462,7 @@ __global__ void k_scaled_bounds(fs_orbit_f32_bad *__restrict__ of, uint64_t n)
 // The same kernel for T = double (RenderAlgorithm Gpu1x32PerturbedScaled): HdrReduce / HdrSqrt / the HDR comparisons
 // collapse to plain double arithmetic (ScaledKernels.cuh:3-239 with T = double; HdrCompareToBothPositiveReducedLT<T,256>
 // is `zn_size < 256.0`, HDRFloat.h:1584).
-template <bool kStats> __global__ void __launch_bounds__(256) k_scaled_f64(FsScaledArgsF64 A)
+template <bool kStats, class IterT = uint32_t> __global__ void __launch_bounds__(256) k_scaled_f64(FsScaledArgsF64 A)
 {
     const uint32_t X = blockIdx.x * 64u + (threadIdx.x & 63u);
     const uint32_t L = blockIdx.y * 4u + (threadIdx.x >> 6);
@@ -470,11 +471,12 @@ template <bool kStats> __global__ void __launch_bounds__(256) k_scaled_f64(FsSca
     const bool live = X < A.frame.width && L < A.frame.local_rows && Y < A.frame.height;
     if (live) {
         c_px = 1;
-        const uint32_t n_iterations = A.n_iterations;
+        const IterT n_iterations = iter_cap<IterT>(A.n_iterations, A.n_iterations_hi);
         const uint32_t MaxRefIteration = A.orbit_count - 1;
         const fs_orbit_f64_bad *__restrict__ ot = A.orbit_t;
         const fs_orbit_f32_bad *__restrict__ of = A.orbit_f;
-        uint32_t iter = 0, RefIteration = 0;
+        IterT iter = 0;
+        uint32_t RefIteration = 0;
         const double DeltaReal = A.dx * (double)(int)X - A.centerX;
         const double DeltaImaginary = -A.dy * (double)(int)Y - A.centerY;
         double S = __builtin_sqrt(DeltaReal * DeltaReal + DeltaImaginary * DeltaImaginary);
@@ -736,6 +738,10 @@ void fsk_scaled_hdr32(const FsScaledArgs32 &A, bool stats, int variant, hipStrea
 {
     const dim3 b(256);
     const dim3 g((A.frame.width + 31) / 32, (A.frame.local_rows + 7) / 8); // tile_pixel(): four 8 x 8 tiles per workgroup
+    if (A.frame.wide != 0u) { // iteration cap of 2^32 or above: the literal kernel counting in 64 bits
+        hipLaunchKernelGGL((k_scaled_hdr32<false, uint64_t>), g, b, 0, s, A);
+        return;
+    }
     if (variant == FS_VARIANT_LITERAL) {
         if (stats)
             hipLaunchKernelGGL((k_scaled_hdr32<true>), g, b, 0, s, A);
@@ -757,6 +763,11 @@ void fsk_scaled_bounds(fs_orbit_f32_bad *of, uint64_t n, hipStream_t s)
 void fsk_scaled_f64(const FsScaledArgsF64 &A, bool stats, int variant, hipStream_t s)
 {
     const dim3 b(256);
+    if (A.frame.wide != 0u) {
+        const dim3 g((A.frame.width + 63) / 64, (A.frame.local_rows + 3) / 4);
+        hipLaunchKernelGGL((k_scaled_f64<false, uint64_t>), g, b, 0, s, A);
+        return;
+    }
     if (variant == FS_VARIANT_LITERAL) {
         const dim3 g((A.frame.width + 63) / 64, (A.frame.local_rows + 3) / 4);
         if (stats)

@@ -253,6 +253,7 @@ FsFrame make_frame(const fs_renderer *r)
     f.band_rows = r->band_rows;
     f.band_stride = r->band_stride;
     f.iter_u64 = r->iter_bytes == 8 ? 1u : 0u;
+    f.wide = (r->variant & FS_VARIANT_FLAG_WIDE) != 0 ? 1u : 0u; // (|= cap >= 2^32 where the cap is known)
     return f;
 }
 
@@ -531,6 +532,7 @@ template <class F> static void fill_lav2(fs_renderer *r, FsLav2ArgsT<F> &A, cons
     A.stage_count = r->n_stages;
     A.n_iterations = (uint32_t)n_iterations;
     A.n_iterations_hi = (uint32_t)(n_iterations >> 32);
+        A.frame.wide |= A.n_iterations_hi != 0u ? 1u : 0u;
     A.la_valid = r->la_ok ? r->la_valid : 0;
     A.use_at = r->use_at;
     A.parity = (parity == FS_PARITY_CPU_GPUSTAGE) ? FS_PARITY_GPUSTAGE : FS_PARITY_LITERAL;
@@ -1564,18 +1566,21 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
     if (r->local_rows == 0)
         return 0; // this renderer owns no row of the frame (a rank beyond the last band)
     const bool plain = type_tag == FS_T_F32 || type_tag == FS_T_F64 || type_tag == FS_T_2X32;
-    // iteration caps of 2^32 and above: IterType = uint64_t (8-byte buffer) and the types with a 64-bit counting kernel
-    const bool wide = n_iterations > 0xFFFFFFFFull;
-    if ((type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64 && type_tag != FS_T_HDR2X32 && !plain) ||
-        (wide && (r->iter_bytes != 8 || (type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64))))
+    // iteration caps of 2^32 and above need IterType = uint64_t (an 8-byte buffer): every type then runs an instantiation
+    // of its kernel that counts in 64 bits (the literal one for HDRFloat<float|double>)
+    if (type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64 && type_tag != FS_T_HDR2X32 && !plain)
         return FS_ERR_UNSUPPORTED;
+    if (n_iterations > 0xFFFFFFFFull && r->iter_bytes != 8)
+        return (uint32_t)hipErrorInvalidValue; // a 4-byte IterType cannot hold such a count
+    // (the 64-bit counting kernels can also be forced at small caps: FS_VARIANT_WIDE_COUNTERS, a test switch)
+    const bool wide = n_iterations > 0xFFFFFFFFull || (r->variant & FS_VARIANT_FLAG_WIDE) != 0;
     if (!r->orbit_ok || r->orbit_type != type_tag)
         return FS_ERR_6; // GPU_Render.cu:1015-1022
     if (r->orbit_seq) {
         // the orbit is resident as waypoints only (fs_set_compressed_orbit_mode 1): the literal kernel with a sequential
         // decompression cursor per pixel.  Perturbation-only with CPU parity has its twin in the scalar kernel, which reads
-        // an expanded orbit: not served in this mode, like iteration caps of 2^32 and above.
-        if (wide || (mode == FS_LAV2_PO && parity == FS_PARITY_CPU))
+        // an expanded orbit: not served in this mode.
+        if (mode == FS_LAV2_PO && parity == FS_PARITY_CPU)
             return FS_ERR_UNSUPPORTED;
         if (mode != FS_LAV2_PO && (!r->la_ok || r->la_type != type_tag))
             return FS_ERR_6;
@@ -1598,7 +1603,7 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
         }
         return (uint32_t)hipGetLastError();
     }
-    if (wide) {
+    if (wide && (type_tag == FS_T_HDR32 || type_tag == FS_T_HDR64) && !(mode == FS_LAV2_PO && parity == FS_PARITY_CPU)) {
         // GPURenderer::RenderPerturbLAv2<uint64_t, ...> with a cap the 32-bit counters cannot hold: the literal kernel
         // instantiated with 64-bit counters (all three modes; the reference's arithmetic, operation by operation)
         if (mode != FS_LAV2_PO && (!r->la_ok || r->la_type != type_tag))
@@ -1640,6 +1645,8 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
         A.orbit_count = (uint32_t)r->orbit_uncompressed;
         A.stage_count = r->n_stages;
         A.n_iterations = (uint32_t)n_iterations;
+        A.n_iterations_hi = (uint32_t)(n_iterations >> 32);
+        A.frame.wide |= A.n_iterations_hi != 0u ? 1u : 0u;
         A.la_valid = (r->la_ok && r->la_type == type_tag) ? r->la_valid : 0;
         A.use_at = r->use_at;
         TimedLaunch t(r);
@@ -1666,6 +1673,8 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
         A.orbit_count = (uint32_t)r->orbit_uncompressed;
         A.stage_count = r->n_stages;
         A.n_iterations = (uint32_t)n_iterations;
+        A.n_iterations_hi = (uint32_t)(n_iterations >> 32);
+        A.frame.wide |= A.n_iterations_hi != 0u ? 1u : 0u;
         A.la_valid = (r->la_ok && r->la_type == type_tag) ? r->la_valid : 0;
         A.use_at = r->use_at;
         TimedLaunch t(r);
@@ -1713,8 +1722,10 @@ uint32_t fs_render_bla(fs_renderer *r, int type_tag, const void *coords, uint64_
         return 0;
     if (r->local_rows == 0)
         return 0; // this renderer owns no row of the frame (a rank beyond the last band)
-    if ((type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64 && type_tag != FS_T_F64) || n_iterations > 0xFFFFFFFFull)
+    if (type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64 && type_tag != FS_T_F64)
         return FS_ERR_UNSUPPORTED;
+    if (n_iterations > 0xFFFFFFFFull && r->iter_bytes != 8)
+        return (uint32_t)hipErrorInvalidValue; // a 4-byte IterType cannot hold such a count
     if (!r->orbit_ok || r->orbit_type != type_tag)
         return FS_ERR_6;
     if (r->orbit_seq)
@@ -1735,6 +1746,8 @@ uint32_t fs_render_bla(fs_renderer *r, int type_tag, const void *coords, uint64_
         A.centerY = c[3];
         A.orbit_count = (uint32_t)r->orbit_uncompressed;
         A.n_iterations = (uint32_t)n_iterations;
+        A.n_iterations_hi = (uint32_t)(n_iterations >> 32);
+        A.frame.wide |= A.n_iterations_hi != 0u ? 1u : 0u;
         A.lm2 = r->bla_lm2;
         TimedLaunch t(r);
         fsk_perturb_bla_f64(A, use_bla, r->stats_on, r->compute);
@@ -1752,6 +1765,8 @@ uint32_t fs_render_bla(fs_renderer *r, int type_tag, const void *coords, uint64_
         fill_coords(A.coords, coords);
         A.orbit_count = (uint32_t)r->orbit_uncompressed;
         A.n_iterations = (uint32_t)n_iterations;
+        A.n_iterations_hi = (uint32_t)(n_iterations >> 32);
+        A.frame.wide |= A.n_iterations_hi != 0u ? 1u : 0u;
         A.lm2 = r->bla_lm2;
         if (use_bla && r->bla_native_stale)
             if (uint32_t e = bla_make_native(r, r->bla_n_levels))
@@ -1775,6 +1790,8 @@ uint32_t fs_render_bla(fs_renderer *r, int type_tag, const void *coords, uint64_
         fill_coords(A.coords, coords);
         A.orbit_count = (uint32_t)r->orbit_uncompressed;
         A.n_iterations = (uint32_t)n_iterations;
+        A.n_iterations_hi = (uint32_t)(n_iterations >> 32);
+        A.frame.wide |= A.n_iterations_hi != 0u ? 1u : 0u;
         A.lm2 = r->bla_lm2;
         TimedLaunch t(r);
         fsk_perturb_scalar_hdr64(A, use_bla, r->stats_on, r->variant, r->compute);
@@ -1790,8 +1807,10 @@ uint32_t fs_render_direct(fs_renderer *r, int type_tag, const void *coords, uint
         return 0; // GPU_Render.cu:626-628
     if (r->local_rows == 0)
         return 0; // this renderer owns no row of the frame (a rank beyond the last band)
-    if ((type_tag != FS_T_F64 && type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64) || n_iterations > 0xFFFFFFFFull)
+    if (type_tag != FS_T_F64 && type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64)
         return FS_ERR_UNSUPPORTED;
+    if (n_iterations > 0xFFFFFFFFull && r->iter_bytes != 8)
+        return (uint32_t)hipErrorInvalidValue;
     if (r->cx_row_cap < r->width) {
         if (r->cx_row)
             FS_TRY(r_free(r, r->cx_row));
@@ -1810,6 +1829,8 @@ uint32_t fs_render_direct(fs_renderer *r, int type_tag, const void *coords, uint
         A.dy = c[1];
         A.maxY = c[3];
         A.n_iterations = (uint32_t)n_iterations;
+        A.n_iterations_hi = (uint32_t)(n_iterations >> 32);
+        A.frame.wide |= A.n_iterations_hi != 0u ? 1u : 0u;
         TimedLaunch t(r);
         fsk_direct_f64(A, c[2], c[0], r->stats_on, r->compute);
     } else if (type_tag == FS_T_HDR32) {
@@ -1823,6 +1844,8 @@ uint32_t fs_render_direct(fs_renderer *r, int type_tag, const void *coords, uint
         A.dy = fs::hreal32{c[1].m, c[1].e};
         A.maxY = fs::hreal32{c[3].m, c[3].e};
         A.n_iterations = (uint32_t)n_iterations;
+        A.n_iterations_hi = (uint32_t)(n_iterations >> 32);
+        A.frame.wide |= A.n_iterations_hi != 0u ? 1u : 0u;
         TimedLaunch t(r);
         fsk_direct_hdr32(A, fs::hreal32{c[2].m, c[2].e}, fs::hreal32{c[0].m, c[0].e}, r->stats_on, r->compute);
     } else {
@@ -1836,6 +1859,8 @@ uint32_t fs_render_direct(fs_renderer *r, int type_tag, const void *coords, uint
         A.dy = fs::hreal64{c[1].m, c[1].e};
         A.maxY = fs::hreal64{c[3].m, c[3].e};
         A.n_iterations = (uint32_t)n_iterations;
+        A.n_iterations_hi = (uint32_t)(n_iterations >> 32);
+        A.frame.wide |= A.n_iterations_hi != 0u ? 1u : 0u;
         TimedLaunch t(r);
         fsk_direct_hdr64(A, fs::hreal64{c[2].m, c[2].e}, fs::hreal64{c[0].m, c[0].e}, r->stats_on, r->compute);
     }
@@ -1884,8 +1909,10 @@ uint32_t fs_render_scaled(fs_renderer *r, int type_tag, const void *coords, uint
         return 0; // GPU_Render.cu:1317-1319
     if (r->local_rows == 0)
         return 0; // this renderer owns no row of the frame (a rank beyond the last band)
-    if ((type_tag != FS_T_HDR32 && type_tag != FS_T_F64) || n_iterations > 0xFFFFFFFFull)
+    if (type_tag != FS_T_HDR32 && type_tag != FS_T_F64)
         return FS_ERR_UNSUPPORTED;
+    if (n_iterations > 0xFFFFFFFFull && r->iter_bytes != 8)
+        return (uint32_t)hipErrorInvalidValue;
     if (!r->scaled_t || !r->scaled_f || r->scaled_count < 2 || r->scaled_type != type_tag)
         return FS_ERR_6;
     const float w2threshold = (float)exp(log((double)1e30f) / 2.0);
@@ -1901,6 +1928,8 @@ uint32_t fs_render_scaled(fs_renderer *r, int type_tag, const void *coords, uint
         A.dx = c[0], A.dy = c[1], A.centerX = c[2], A.centerY = c[3];
         A.orbit_count = (uint32_t)r->scaled_count;
         A.n_iterations = (uint32_t)n_iterations;
+        A.n_iterations_hi = (uint32_t)(n_iterations >> 32);
+        A.frame.wide |= A.n_iterations_hi != 0u ? 1u : 0u;
         A.w2threshold = w2threshold;
         TimedLaunch t(r);
         fsk_scaled_f64(A, r->stats_on, r->variant & FS_VARIANT_BASE_MASK, r->compute);
@@ -1916,6 +1945,8 @@ uint32_t fs_render_scaled(fs_renderer *r, int type_tag, const void *coords, uint
     fill_coords(A.coords, coords);
     A.orbit_count = (uint32_t)r->scaled_count;
     A.n_iterations = (uint32_t)n_iterations;
+    A.n_iterations_hi = (uint32_t)(n_iterations >> 32);
+        A.frame.wide |= A.n_iterations_hi != 0u ? 1u : 0u;
     A.w2threshold = w2threshold;
     TimedLaunch t(r);
     fsk_scaled_hdr32(A, r->stats_on, r->variant & FS_VARIANT_BASE_MASK, r->compute);
@@ -1931,16 +1962,19 @@ uint32_t fs_render_direct_lp(fs_renderer *r, int type_tag, const void *coords, u
         return 0; // GPU_Render.cu:626-628
     if (r->local_rows == 0)
         return 0; // this renderer owns no row of the frame (a rank beyond the last band)
-    if ((type_tag != FS_T_F32 && type_tag != FS_T_2X32 && type_tag != FS_T_2X64 && type_tag != FS_T_4X32 &&
-         type_tag != FS_T_4X64) ||
-        n_iterations > 0xFFFFFFFFull)
+    if (type_tag != FS_T_F32 && type_tag != FS_T_2X32 && type_tag != FS_T_2X64 && type_tag != FS_T_4X32 &&
+        type_tag != FS_T_4X64)
         return FS_ERR_UNSUPPORTED;
+    if (n_iterations > 0xFFFFFFFFull && r->iter_bytes != 8)
+        return (uint32_t)hipErrorInvalidValue;
     FsDirectLpArgs A;
     memset(&A, 0, sizeof(A));
     A.out = (uint32_t *)r->iters();
     A.stats = r->stats;
     A.frame = make_frame(r);
     A.n_iterations = (uint32_t)n_iterations;
+    A.n_iterations_hi = (uint32_t)(n_iterations >> 32);
+        A.frame.wide |= A.n_iterations_hi != 0u ? 1u : 0u;
     if (type_tag == FS_T_F32)
         memcpy(A.c32, coords, 4 * sizeof(float));
     else if (type_tag == FS_T_2X32)
@@ -2148,7 +2182,8 @@ float fs_last_kernel_ms(const fs_renderer *r)
 uint32_t fs_set_kernel_variant(fs_renderer *r, int variant)
 {
     const int base = variant & FS_VARIANT_BASE_MASK, flags = variant & ~FS_VARIANT_BASE_MASK;
-    if (base > FS_VARIANT_TUNED_NOSCALE || (flags & ~(FS_VARIANT_FLAG_LDS_ORBIT | FS_VARIANT_FLAG_REFILL)) != 0)
+    if (base > FS_VARIANT_TUNED_NOSCALE ||
+        (flags & ~(FS_VARIANT_FLAG_LDS_ORBIT | FS_VARIANT_FLAG_REFILL | FS_VARIANT_FLAG_WIDE)) != 0)
         return hipErrorInvalidValue;
     r->variant = base | flags;
     return 0;

@@ -88,9 +88,11 @@ const char *fs_error_string(uint32_t err);
  * IterType = uint64_t: the iteration buffer, RenderCurrent and ReductionResults work on uint64_t elements and the
  * uint64_t record layouts (fs_la_*_u64, fs_la_stage_u64, fs_at_*_u64) are accepted (table step lengths / indices must
  * fit 32 bits -- a table that large would not fit any device -- else FS_ERR_UNSUPPORTED).  Iteration caps of 2^32 and
- * above are served by kernels that count in 64 bits for fs_render_lav2 with FS_T_HDR32 / FS_T_HDR64 (all three modes);
- * the other entry points return FS_ERR_UNSUPPORTED for such a cap, as does every entry point with a 4-byte buffer
- * (every built-in view selects Bits32, FractalViewPresets.cpp:19). */
+ * above are served by every render entry point and numeric type: each kernel is also instantiated with 64-bit counters, as
+ * the reference's kernels are templated on IterType (GPU_Render.cu:849-991, 1204-1300, 1380-1436, 1610-1692) -- for the
+ * HDRFloat<float> perturbation kernels the literal form (the tuned runs budget their steps in 32 bits).  Such a cap with a
+ * 4-byte buffer is a caller error (hipErrorInvalidValue): a uint32_t IterType cannot hold the count (every built-in view
+ * selects Bits32, FractalViewPresets.cpp:19). */
 uint32_t fs_init_memory(fs_renderer *r, uint32_t w, uint32_t h, uint32_t antialiasing, uint32_t iter_bytes,
                         const fs_color16 *pal_interleaved, uint32_t pal_iters, uint32_t palette_aux_depth,
                         uint64_t palette_generation, int expected_reuse);
@@ -264,8 +266,12 @@ float fs_last_kernel_ms(const fs_renderer *r);
  *                         (LDS-DMA double buffer per wave) instead of the scalar cache;
  *   FS_VARIANT_REFILL     the HDRFloat<float|double> BLA kernel runs as a persistent launch whose waves refill finished
  *                         lanes from a frame-wide pixel queue (wave-ballot compaction).
- * Unknown values: hipErrorInvalidValue, the selection stays as it was. */
-enum { FS_VARIANT_LDS_ORBIT = 0x100, FS_VARIANT_REFILL = 0x200 };
+ * Unknown values: hipErrorInvalidValue, the selection stays as it was.
+ *   FS_VARIANT_WIDE_COUNTERS  (test switch) every entry point launches the instantiation of its kernel that counts
+ *                         iterations in 64 bits -- the ones an iteration cap of 2^32 or above selects -- whatever the cap is:
+ *                         lets the 64-bit kernels be compared with the CPU functions at caps a test can afford.
+ */
+enum { FS_VARIANT_LDS_ORBIT = 0x100, FS_VARIANT_REFILL = 0x200, FS_VARIANT_WIDE_COUNTERS = 0x400 };
 uint32_t fs_set_kernel_variant(fs_renderer *r, int variant);
 uint32_t fs_enable_step_count(fs_renderer *r, int enable);
 uint32_t fs_read_step_count(fs_renderer *r, uint64_t counts[8]);

@@ -17,6 +17,10 @@ def main():
     ap.add_argument("--world", type=int, default=8)
     ap.add_argument("--parity", default="cpu")
     ap.add_argument("--band", type=int, default=0)
+    ap.add_argument("--repeats", type=int, default=4,
+                    help="launches per rank; the minimum is reported (kernel time on an otherwise idle GPU: run-to-run "
+                         "differences of +-3 %% between identical launches are clock / placement noise, and on a real "
+                         "8-GPU node every rank runs alone on its own GPU)")
     a = ap.parse_args()
     v = inputs.View.builtin(5, 3840, 2160, antialiasing=1)
     o = inputs.Orbit(v)
@@ -29,17 +33,22 @@ def main():
     band = a.band or tiling.band_height(1)
     for world in sorted({1, a.world}):
         times = []
+        spreads = []
         for rank in range(world):
             assert r.SetRowBands(rank * band, band, world * band) == 0
             best = 1e9
-            for _ in range(2):
+            samples = []
+            for _ in range(max(1, a.repeats)):
                 assert r.RenderPerturbLAv2(None, None, None, *co, v.num_iterations, T=T_HDR32, Mode=LAV2_FULL,
                                            parity=parity) == 0
                 assert r.SyncComputeStream() == 0
-                best = min(best, r.last_kernel_ms())
+                samples.append(r.last_kernel_ms())
+                best = min(best, samples[-1])
             times.append(round(best, 3))
+            spreads.append(round(max(samples) - min(samples), 3))
         print(json.dumps({"world": world, "band_rows": band, "parity": a.parity, "kernel_ms_per_rank": times,
-                          "max_ms": max(times), "sum_ms": round(sum(times), 3)}), flush=True)
+                          "max_ms": max(times), "mean_ms": round(sum(times) / len(times), 3), "sum_ms": round(sum(times), 3),
+                          "repeats": a.repeats, "max_spread_between_repeats_ms": max(spreads)}), flush=True)
 
 
 if __name__ == "__main__":
