@@ -451,10 +451,11 @@ def test_uint64_itertype_matches_uint32(renderer, v5_small):
     big = inputs.LATableU64(la)
     big._stages[0, 1] = 1 << 33
     assert r.InitializePerturb(0, ob, 0, None, big, iter_bytes=8) == 10100
-    # an iteration cap of 2^32 needs IterType = uint64_t: refused with a 4-byte buffer (see the next test for 8 bytes)
+    # an iteration cap of 2^32 needs IterType = uint64_t: a caller error (hipErrorInvalidValue) with a 4-byte buffer (see the
+    # next test and tests/test_gpu_wide_counters.py for 8 bytes)
     assert r.InitializeMemory(64, 36, 1, None, 0, 0, 0, False, iter_bytes=4) == 0
     assert r.InitializePerturb(0, ob, 0, None, la) == 0
-    assert r.RenderPerturbLAv2(None, None, None, dx, dy, cx, cy, 1 << 32, Mode=LAV2_FULL) == 10100
+    assert r.RenderPerturbLAv2(None, None, None, dx, dy, cx, cy, 1 << 32, Mode=LAV2_FULL) == 1
 
 
 @pytest.mark.parametrize("is64", [False, True])
