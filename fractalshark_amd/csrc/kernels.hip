@@ -877,22 +877,20 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                             typedef float f4 __attribute__((ext_vector_type(4)));
                             const float4 *zpu = zs + ref_u + 1;
                             for (;;) {
-                                f4 ua, ub, uc, ud, ue, uf, ug, uh;
-                                asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(ua) : "s"(zpu));
-                                asm volatile("s_load_dwordx4 %0, %1, 0x10" : "=s"(ub) : "s"(zpu));
-                                asm volatile("s_load_dwordx4 %0, %1, 0x20" : "=s"(uc) : "s"(zpu));
-                                asm volatile("s_load_dwordx4 %0, %1, 0x30" : "=s"(ud) : "s"(zpu));
-                                asm volatile("s_load_dwordx4 %0, %1, 0x40" : "=s"(ue) : "s"(zpu));
-                                asm volatile("s_load_dwordx4 %0, %1, 0x50" : "=s"(uf) : "s"(zpu));
-                                asm volatile("s_load_dwordx4 %0, %1, 0x60" : "=s"(ug) : "s"(zpu));
-                                asm volatile("s_load_dwordx4 %0, %1, 0x70" : "=s"(uh) : "s"(zpu));
+                                // the body's eight 16-byte entries as TWO 64-byte scalar loads (s_load_dwordx16 takes any
+                                // dword-aligned address): the scalar unit is shared by the CU's four SIMDs, and six issue slots
+                                // less per body is what is saved there
+                                typedef float f16 __attribute__((ext_vector_type(16)));
+                                f16 U, V;
+                                asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(U) : "s"(zpu));
+                                asm volatile("s_load_dwordx16 %0, %1, 0x40" : "=s"(V) : "s"(zpu));
                                 f2 t1, u1;
                                 uint64_t v1 = 0;
                                 FS_SCALED_STEP(w0, z0, t1, u1, a, v1, false,
-                                               asm volatile("s_waitcnt lgkmcnt(0)"
-                                                            : "+s"(ua), "+s"(ub), "+s"(uc), "+s"(ud), "+s"(ue), "+s"(uf),
-                                                              "+s"(ug), "+s"(uh), "+v"(mx_a)),
-                                               ua.x, ua.y, ua.z);
+                                               asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(U), "+s"(V), "+v"(mx_a)), U.s0, U.s1,
+                                               U.s2);
+                                const f4 ua = U.s0123, ub = U.s4567, uc = U.s89ab, ud = U.scdef;
+                                const f4 ue = V.s0123, uf = V.s4567, ug = V.s89ab, uh = V.scdef;
                                 FS_SCALED_STEP(t1, u1, w2, z2, b, v1, true, (void)0, ub.x, ub.y, ub.z);
                                 if (v1 != 0ull) {
                                     FS_TRIP_FAILED(a, t1, ua.z, w0)
@@ -1941,23 +1939,20 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                         // trip's start needs no copy, and a failing body costs at most six wasted steps -- runs of the
                         // pixels this loop is shaped for average 227 steps.
                         const float4 *zpu = zs + ref_u + 1;
-                        f4 a0, a1, a2, a3, a4, a5, a6, a7, b0, b1, b2, b3, b4, b5, b6, b7;
+                        // (each set of eight 16-byte entries as two 64-byte scalar loads: s_load_dwordx16 takes any
+                        // dword-aligned address, and the lone wave this loop is shaped for pays per instruction issued)
+                        typedef float f16 __attribute__((ext_vector_type(16)));
+                        f16 aL, aH, bL, bH;
 #define FS_SLOAD8(S, P)                                                                                             \
-    asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(S##0) : "s"(P));                                               \
-    asm volatile("s_load_dwordx4 %0, %1, 0x10" : "=s"(S##1) : "s"(P));                                              \
-    asm volatile("s_load_dwordx4 %0, %1, 0x20" : "=s"(S##2) : "s"(P));                                              \
-    asm volatile("s_load_dwordx4 %0, %1, 0x30" : "=s"(S##3) : "s"(P));                                              \
-    asm volatile("s_load_dwordx4 %0, %1, 0x40" : "=s"(S##4) : "s"(P));                                              \
-    asm volatile("s_load_dwordx4 %0, %1, 0x50" : "=s"(S##5) : "s"(P));                                              \
-    asm volatile("s_load_dwordx4 %0, %1, 0x60" : "=s"(S##6) : "s"(P));                                              \
-    asm volatile("s_load_dwordx4 %0, %1, 0x70" : "=s"(S##7) : "s"(P));
-#define FS_SWAIT8(S)                                                                                                \
-    asm volatile("s_waitcnt lgkmcnt(0)"                                                                             \
-                 : "+s"(S##0), "+s"(S##1), "+s"(S##2), "+s"(S##3), "+s"(S##4), "+s"(S##5), "+s"(S##6), "+s"(S##7));
+    asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(S##L) : "s"(P));                                              \
+    asm volatile("s_load_dwordx16 %0, %1, 0x40" : "=s"(S##H) : "s"(P));
+#define FS_SWAIT8(S) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(S##L), "+s"(S##H));
 #define FS_SBODY(S, NEXT)                                                                                           \
     {                                                                                                               \
         FS_SWAIT8(S)                                                                                                \
         FS_SLOAD8(NEXT, zpu + 8)                                                                                    \
+        const f4 S##0 = S##L.s0123, S##1 = S##L.s4567, S##2 = S##L.s89ab, S##3 = S##L.scdef;                        \
+        const f4 S##4 = S##H.s0123, S##5 = S##H.s4567, S##6 = S##H.s89ab, S##7 = S##H.scdef;                        \
         f2 t1, u1, w2_, z2_, t3, u3, w4_, z4_, t5, u5, w6_, z6_, t7, u7, w8_, z8_;                                  \
         uint64_t v1 = 0, v2 = 0, v3 = 0, v4 = 0;                                                                    \
         FS_SCALED_STEP(w0, z0, t1, u1, a##S, v1, false, (void)0, (S##0).x, (S##0).y, (S##0).z);                     \
@@ -1998,8 +1993,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                             wO = w0;
                         // whichever body the run left from, the other set's request may still be in flight: it lands
                         // before its registers are used for anything else
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(a5), "s"(a6),
-                                     "s"(a7), "s"(b0), "s"(b1), "s"(b2), "s"(b3), "s"(b4), "s"(b5), "s"(b6), "s"(b7));
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(aL), "s"(aH), "s"(bL), "s"(bH));
 #undef FS_SBODY
 #undef FS_SWAIT8
 #undef FS_SLOAD8
