@@ -565,6 +565,12 @@ def test_scaled_hdr32_tuned_equals_literal(renderer, native_libs, view_n, w, h, 
             r.enable_step_count(False)
             outs.append(out)
             stats.append((st["at_iterations"], st["la_steps"], st["perturb_steps"]))
+            # probes of the tuned kernel (tools/scaled_kernel_probe.py): the binary32 steps taken INSIDE wave-voted runs are
+            # a subset of the binary32 steps, and runs exist only where steps do (each probe is counted once)
+            assert st["scaled_steps"] <= st["perturb_steps"], (variant, st)
+            assert st["scaled_runs"] <= st["scaled_steps"] or st["scaled_steps"] == 0
+            if variant == 1:
+                assert st["scaled_steps"] == 0 and st["scaled_runs"] == 0  # the literal kernel has no runs
     finally:
         r.set_kernel_variant(0)
     assert np.array_equal(outs[0], outs[1])
