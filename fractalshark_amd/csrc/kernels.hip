@@ -69,6 +69,25 @@ __global__ void k_prepare_orbit_hdr32(const fs_orbit_hdr32 *__restrict__ in, flo
     out[i] = make_float4(c.re, c.im, __int_as_float(c.e), ldexpf(1.0f, 8 - 2 * (c.e < -1000 ? -1000 : c.e)));
 }
 
+// Bound of a scaled-run arrival at orbit entry v = {re, im, exp}: 2^-2 * max(|Z.re|, |Z.im|) in true scale, or -0.0 (bit
+// pattern INT_MIN = "never": the loops compare bit patterns as integers) unless 2^-40 <= max part < 5.6 (|Z| < 8) and the
+// smaller part is within 2^40 of the larger one.
+__device__ __forceinline__ float scaled_bound(const float4 v)
+{
+    const int e = __float_as_int(v.z);
+    const float hi = __builtin_fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y));
+    const float lo = __builtin_fminf(__builtin_fabsf(v.x), __builtin_fabsf(v.y));
+    const float zmax = __builtin_amdgcn_ldexpf(hi, e < -200 ? -200 : (e > 100 ? 100 : e));
+    const bool usable = zmax >= 0x1p-40f && zmax < 5.6f && lo >= hi * 0x1p-40f;
+    return usable ? zmax * 0x1p-2f : -0.0f;
+}
+
+// A scaled run may start at entry e of the second companion array: a usable entry (bound not "never") or an exact zero.
+__device__ __forceinline__ bool scaled_startable(const float4 e)
+{
+    return __float_as_int(e.z) != (int)0x80000000 || (e.x == 0.0f && e.y == 0.0f);
+}
+
 // Companion array of the tuned LAv2 loop: {re, im, s, -} with s = ~exp + 116 (-(s - 116) = exp + 1 = the exponent of 2Z;
 // the bias turns the loop's range tests into comparisons against constants) for orbit values below 8, and a large
 // positive poison for larger ones, which makes the range test fail there.  zq must hold 2 n entries.
@@ -80,20 +99,27 @@ __global__ void k_make_quiet_orbit(const float4 *__restrict__ zref, float4 *__re
     const float4 v = zref[i];
     const int e = __float_as_int(v.z);
     zq[i] = make_float4(v.x, v.y, __int_as_float(e <= 2 ? ~e + 116 : (1 << 24)), 0.0f);
-    // second companion, zq[n + i], for the scaled runs: {2Z.re, 2Z.im, 2^-2 * max(|Z.re|, |Z.im|)} as plain floats (true
-    // scale), the bound -0.0 (bit pattern INT_MIN = "never quiet": the loop compares bit patterns as integers) unless
-    // 2^-40 <= max part < 5.6 (|Z| < 8) and the smaller part is within 2^40 of the larger one.  (Packing the entry into 8 bytes and deriving the bound from 2Z costs one more vector
+    // second companion, zq[n + i], for the scaled runs: {2Z.re, 2Z.im, scaled_bound(Z), block bound} as plain floats (true
+    // scale).  (Packing the entry into 8 bytes and deriving the bound from 2Z costs one more vector
     // instruction per step and was measured slower: the loop is not bound by its loads.)
-    const float hi = __builtin_fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y));
-    const float lo = __builtin_fminf(__builtin_fabsf(v.x), __builtin_fabsf(v.y));
-    const float zmax = __builtin_amdgcn_ldexpf(hi, e < -200 ? -200 : (e > 100 ? 100 : e));
-    const bool usable = zmax >= 0x1p-40f && zmax < 5.6f && lo >= hi * 0x1p-40f;
-    // .w: a run may START at this entry (its 2Z is exact in true scale): every usable entry, and an exact zero -- entry 0,
-    // where every rebase lands; 2Z + dz is then dz itself in either arithmetic.  (Nothing arrives at a zero entry: its bound
-    // is the "never" pattern.)
-    const bool startable = usable || (v.x == 0.0f && v.y == 0.0f);
-    zq[n + i] = make_float4(__builtin_amdgcn_ldexpf(v.x, e + 1), __builtin_amdgcn_ldexpf(v.y, e + 1),
-                            usable ? zmax * 0x1p-2f : -0.0f, startable ? 1.0f : 0.0f);
+    const float b0 = scaled_bound(v);
+    // .w: the BLOCK bound of the four entries after this one, min(bound[i+1..i+4]) * 2^-18 ("never" if one of them is):
+    // with G = max(max|dz|, max|dc|) at this entry, |dz'|_2 <= |dz|_2 |2Z + dz|_2 + |dc|_2 and |2Z + dz|_2 < 20 while the
+    // per-step bound holds (|Z|_2 < 7.92, |dz|_inf < 2.9), so four steps multiply G by less than
+    // ((20 * 21 + 1) * 20 + 1) * 20 + 1 = 168421 times sqrt 2 < 2^18: G <= .w implies that each of the four arrivals passes
+    // its own bound test, and the scalar-cache path of the scaled runs then skips those tests (same accepted steps).
+    // (A run may START at every usable entry and at an exact zero -- entry 0, where every rebase lands; 2Z + dz is then dz
+    // itself in either arithmetic -- the kernels read that off .z and .xy.  Nothing arrives at a zero entry: its bound is
+    // the "never" pattern.)
+    float bm = 0x1p60f;
+    bool all4 = true;
+    for (uint32_t k = 1; k <= 4; k++) {
+        const float bk = i + k < n ? scaled_bound(zref[i + k]) : -0.0f;
+        all4 = all4 && __float_as_int(bk) != (int)0x80000000;
+        bm = __builtin_fminf(bm, bk);
+    }
+    zq[n + i] = make_float4(__builtin_amdgcn_ldexpf(v.x, e + 1), __builtin_amdgcn_ldexpf(v.y, e + 1), b0,
+                            all4 ? bm * 0x1p-18f : -0.0f);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -529,7 +555,7 @@ __device__ __forceinline__ uint32_t scaled_run_length(uint32_t left)
 // the CPU function's (FS_PARITY_CPU) -- a template parameter so that the two parity modes are two kernels (they do very
 // different work per frame, and a kernel trace then lists them separately).
 template <int Mode, bool kStats, bool kScaled, bool kLds = false, bool kGpuStage = false>
-__global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) k_lav2_hdr32_fast(FsLav2Args32 A)
 {
     __shared__ float4 s_zs_lds[kLds ? 4 * 2 * 64 : 1];
     uint32_t X, L;
@@ -540,6 +566,7 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
 #endif
     uint64_t c_at = 0, c_la = 0, c_pt = 0, c_px = 0;
     uint64_t c_careful = 0, c_scaled = 0, c_runs = 0;
+    uint32_t c_blk_free = 0, c_blk_tested = 0; // 4-step blocks of the scalar-cache scaled path without / with bound tests (per wave)
 #ifdef FS_PROFILE_CYCLES
     uint64_t cyc_loop = 0, cyc_run = 0, cyc_body = 0, cyc_t0 = 0, cyc_t1 = 0, cyc_t2 = 0;
 #define FS_CYC(stmt) do { if (kStats) { stmt; } } while (0)
@@ -710,8 +737,8 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                         // (E < 0 in every run: the start test needs max|dz| in [2^E, 2^(E+1)) below a bound < 0.7)
                         const int Esh = (E < -254 ? -254 : (E > 0 ? 0 : E)) * (1 << 23);
                         // (the state a run starts from has passed the CPU loop's tests already: only the entry it starts at
-                        // must be one the companion vouches for -- its .w: 2Z exact in true scale)
-                        const bool start_ok = e0.w != 0.0f && mn0 >= mx0 * 0x1p-40f && mx0 >= 1.0f && mx0 < 2.0f &&
+                        // must be one the companion vouches for -- scaled_startable: 2Z exact in true scale)
+                        const bool start_ok = scaled_startable(e0) && mn0 >= mx0 * 0x1p-40f && mx0 >= 1.0f && mx0 < 2.0f &&
                                               dsh <= 30;
                         // run length: the longest of 256 / 64 / 16 steps that every lane still has before the orbit ends
                         // and before its iteration limit (three votes per run, not a counter per step)
@@ -753,6 +780,22 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
             __builtin_amdgcn_ballot_w64(__float_as_int(mx_##T) + Esh > __float_as_int(EB)) |                        \
             __builtin_amdgcn_ballot_w64(!(mn_s >= mx_##T * 0x1p-40f)) |                                             \
             __builtin_amdgcn_ballot_w64((uint32_t)(__float_as_int(mx_##T) - (107 << 23)) >= (uint32_t)(60 << 23)); \
+        if (bad_s == 0ull) {                                                                                        \
+            wO = NW_;                                                                                               \
+            c += 1;                                                                                                 \
+        } else {                                                                                                    \
+            wO = WSTART;                                                                                            \
+        }                                                                                                           \
+        failed = true;                                                                                              \
+    }
+#define FS_TRIP_FAILED_NB(T, NW_, EB, WSTART)                                                                      \
+    {                                                                                                               \
+        const float mx_s = __builtin_fmaxf(__builtin_fabsf(NW_.x), __builtin_fabsf(NW_.y));                         \
+        const float mn_s = __builtin_fminf(__builtin_fabsf(NW_.x), __builtin_fabsf(NW_.y));                         \
+        const uint64_t bad_s =                                                                                      \
+            __builtin_amdgcn_ballot_w64(__float_as_int(mx_s) + Esh > __float_as_int(EB)) |                        \
+            __builtin_amdgcn_ballot_w64(!(mn_s >= mx_s * 0x1p-40f)) |                                             \
+            __builtin_amdgcn_ballot_w64((uint32_t)(__float_as_int(mx_s) - (107 << 23)) >= (uint32_t)(60 << 23)); \
         if (bad_s == 0ull) {                                                                                        \
             wO = NW_;                                                                                               \
             c += 1;                                                                                                 \
@@ -876,60 +919,233 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
                             } else {
                             typedef float f4 __attribute__((ext_vector_type(4)));
                             const float4 *zpu = zs + ref_u + 1;
+                            // Block test (k_make_quiet_orbit's .w): when max(max|w|, max|dc|) at a block's first entry is
+                            // within that entry's block bound, its four arrivals pass their bound tests whatever else
+                            // happens, and the block runs without them -- as the hand-scheduled body below (eight steps;
+                            // it stops after four when the second block needs its bound tests).  Blocks that need them run
+                            // the tested C++ form, four steps at a time.
+                            const int imdc = __float_as_int(__builtin_fmaxf(__builtin_fabsf(dcs.x), __builtin_fabsf(dcs.y)));
+                            float mxS = mx0;
+                            int pwi = __builtin_amdgcn_readfirstlane(__float_as_int(e0.w));
+                            // (all lanes sit at the same entry here: 2Z of the entry the state is at lives in scalar registers)
+                            f2 zS = {__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(e0.x))),
+                                     __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(e0.y)))};
+#define FS_STEP_ARITH(W_, Z_, NW_, T)                                                                               \
+    const f2 s_##T = __builtin_elementwise_fma(W_, sE2, Z_);                                                        \
+    const f2 pa_##T = W_.xx * s_##T;                                                                                \
+    const f2 pb_##T = W_.yy * s_##T.yx;                                                                             \
+    f2 p_##T;                                                                                                       \
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(p_##T) : "v"(pa_##T), "v"(pb_##T));              \
+    NW_ = p_##T + dcs;
+#define FS_STEP_BOUND(NW_, T, V, EB)                                                                                \
+    const float mx_##T = __builtin_fmaxf(__builtin_fabsf(NW_.x), __builtin_fabsf(NW_.y));                           \
+    V |= __builtin_amdgcn_ballot_w64(__float_as_int(mx_##T) + Esh > __float_as_int(EB));
+#define FS_STEP_SHAPE(NW_, T, V)                                                                                    \
+    {                                                                                                               \
+        const float mn_ = __builtin_fminf(__builtin_fabsf(NW_.x), __builtin_fabsf(NW_.y));                          \
+        V |= __builtin_amdgcn_ballot_w64(!(mn_ >= mx_##T * 0x1p-40f)) |                                             \
+             __builtin_amdgcn_ballot_w64((uint32_t)(__float_as_int(mx_##T) - (107 << 23)) >= (uint32_t)(60 << 23)); \
+    }
+// The untested body.  Registers are named (the halves of a packed pair have no operand syntax): the state w in v[48:49];
+// four state pairs v[48:55] in rotation (a trip = two steps: start state, first step, and the next trip's two while the
+// verdict is pending); the entries in s[36:67].  A packed result cannot be read by the next instruction, so each trip's
+// tests run in the wait states of the following trip's packed arithmetic, and its verdict arrives just before that trip's
+// second step is written over the failed trip's start state: everything a failed trip needs is still in its registers,
+// and what was computed past it is dropped.
+// The loop runs inside the statement: bodies of eight steps while the block test passes and eight steps are left
+// (status 0 on the way out: state in v[48:49], max|w| in v60, counters advanced); status 1 / 2: the first / second trip
+// of a block failed (start state / first step: v48 / v50, v52 / v54; `pw` = the first arrival's bound then).
+#define FS_PK_F(W, Z) "v_pk_fma_f32 v[56:57], " W ", %[se], " Z "\n\t"
+#define FS_PK_MA(W) "v_pk_mul_f32 v[58:59], " W ", v[56:57] op_sel_hi:[0,1]\n\t"
+#define FS_PK_MB(W) "v_pk_mul_f32 v[56:57], " W ", v[56:57] op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+#define FS_PK_P "v_pk_add_f32 v[58:59], v[58:59], v[56:57] neg_lo:[0,1] neg_hi:[0,0]\n\t"
+#define FS_PK_A(NW) "v_pk_add_f32 " NW ", v[58:59], %[dc]\n\t"
+#define FS_R0 "v[48:49]"
+#define FS_R1 "v[50:51]"
+#define FS_R2 "v[52:53]"
+#define FS_R3 "v[54:55]"
+#define FS_T_X(A, B) "v_max_f32_e64 v60, |" A "|, |" B "|\n\t"
+#define FS_T_N(A, B) "v_min_f32_e64 v61, |" A "|, |" B "|\n\t"
+#define FS_T_L "v_mul_f32_e32 v62, 0x2b800000, v60\n\t"          /* 2^-40 max */
+#define FS_T_C1 "v_cmp_nge_f32_e64 %[m], v61, v62\n\t"
+#define FS_T_W "v_add_u32_e32 v61, 0xca800000, v60\n\t"          /* bits(max) - (107 << 23) */
+#define FS_T_C2 "v_cmp_le_u32_e32 vcc, 0x1e000000, v61\n\t" /* >= 60 << 23 */
+#define FS_T_O "s_or_b64 %[m], %[m], vcc\n\t"
+#define FS_NOP "s_nop 0\n\t"
+#define FS_FAST_LOOP                                                                                                \
+    asm volatile(                                                                                                   \
+        ".Lfs_loop_%=:\n\t" /* eight steps left?  the first block's test: max(max|w|, max|dc|) against .w */        \
+        "v_max_i32_e32 v62, v60, %[imdc]\n\t"                                                                       \
+        "s_add_u32 %[st], %[c], 8\n\t"                                                                              \
+        "v_add_u32_e32 v62, v62, %[esh]\n\t"                                                                        \
+        "s_cmp_gt_u32 %[st], %[rl]\n\t"                                                                             \
+        "s_cbranch_scc1 .Lfs_out_%=\n\t"                                                                            \
+        "v_cmp_lt_i32_e64 %[m], %[pw], v62\n\t"                                                                     \
+        "s_cmp_lg_u64 %[m], 0\n\t"                                                                                  \
+        "s_cbranch_scc1 .Lfs_out_%=\n\t"                                                                            \
+        "s_load_dwordx16 s[36:51], s[68:69], 0x0\n\t"                                                               \
+        "s_load_dwordx16 s[52:67], s[68:69], 0x40\n\t" /* step 1: needs the previous entry only */                  \
+        FS_PK_F(FS_R0, "%[z0]") FS_NOP FS_PK_MA(FS_R0) FS_PK_MB(FS_R0) FS_NOP FS_PK_P FS_NOP FS_PK_A(FS_R1)         \
+        "s_waitcnt lgkmcnt(0)\n\t" /* step 2 */                                                                     \
+        FS_PK_F(FS_R1, "s[36:37]") FS_NOP FS_PK_MA(FS_R1) FS_PK_MB(FS_R1) FS_NOP FS_PK_P FS_NOP FS_PK_A(FS_R2)      \
+        FS_NOP /* steps 3, 4 + the tests of w2 = the verdict of trip 1 */                                           \
+        FS_PK_F(FS_R2, "s[40:41]") FS_T_X("v52", "v53") FS_PK_MA(FS_R2) FS_PK_MB(FS_R2) FS_T_N("v52", "v53")        \
+        FS_PK_P FS_T_L FS_PK_A(FS_R3) FS_T_C1                                                                       \
+        FS_PK_F(FS_R3, "s[44:45]") FS_T_W FS_PK_MA(FS_R3) FS_PK_MB(FS_R3) FS_T_C2 FS_PK_P FS_T_O                    \
+        "s_cbranch_scc1 .Lfs_f1_%=\n\t" FS_PK_A(FS_R0) FS_NOP /* steps 5, 6 + the tests of w4 (trip 2) */           \
+        FS_PK_F(FS_R0, "s[48:49]") FS_T_X("v48", "v49") FS_PK_MA(FS_R0) FS_PK_MB(FS_R0) FS_T_N("v48", "v49")        \
+        FS_PK_P FS_T_L FS_PK_A(FS_R1) FS_T_C1                                                                       \
+        FS_PK_F(FS_R1, "s[52:53]") FS_T_W FS_PK_MA(FS_R1) FS_PK_MB(FS_R1) FS_T_C2 FS_PK_P FS_T_O                    \
+        "s_cbranch_scc1 .Lfs_f2_%=\n\t" /* the second block's test: max(max|w4|, max|dc|) against entry 4's .w */   \
+        "v_max_i32_e32 v62, v60, %[imdc]\n\t" FS_PK_A(FS_R2) "v_add_u32_e32 v62, v62, %[esh]\n\t"                   \
+        /* steps 7, 8 + the tests of w6 (trip 3) */                                                                 \
+        FS_PK_F(FS_R2, "s[56:57]") "v_cmp_lt_i32_e64 %[m], s51, v62\n\t" FS_PK_MA(FS_R2) FS_PK_MB(FS_R2)            \
+        "s_cmp_lg_u64 %[m], 0\n\t" FS_PK_P "s_cbranch_scc1 .Lfs_blk_%=\n\t" FS_PK_A(FS_R3) FS_T_X("v52", "v53")     \
+        FS_PK_F(FS_R3, "s[60:61]") FS_T_N("v52", "v53") FS_PK_MA(FS_R3) FS_PK_MB(FS_R3) FS_T_L FS_PK_P FS_T_C1      \
+        FS_T_W FS_T_C2 FS_T_O "s_cbranch_scc1 .Lfs_f3_%=\n\t" FS_PK_A(FS_R0)                                        \
+        "s_mov_b64 %[z0], s[64:65]\n\t" /* the tests of w8 (trip 4) */                                              \
+        FS_T_X("v48", "v49") FS_T_N("v48", "v49") FS_T_L FS_T_C1 FS_T_W FS_T_C2 FS_T_O                              \
+        "s_cbranch_scc1 .Lfs_f4_%=\n\t"                                                                             \
+        "s_mov_b32 %[pw], s67\n\t"                                                                                  \
+        "s_add_u32 %[c], %[c], 8\n\t"                                                                               \
+        "s_add_u32 s68, s68, 0x80\n\t"                                                                              \
+        "s_addc_u32 s69, s69, 0\n\t"                                                                                \
+        "s_branch .Lfs_loop_%=\n"                                                                                   \
+        ".Lfs_out_%=:\n\t" /* the block at the current position needs its tests, or fewer than 8 steps are left */  \
+        "s_mov_b32 %[st], 0\n\t"                                                                                    \
+        "s_branch .Lfs_end_%=\n"                                                                                    \
+        ".Lfs_blk_%=:\n\t" /* the same after the first block */                                                     \
+        "s_mov_b32 %[st], 0\n\t"                                                                                    \
+        "s_mov_b64 %[z0], s[48:49]\n\t"                                                                             \
+        "s_mov_b32 %[pw], s51\n\t"                                                                                  \
+        "s_add_u32 %[c], %[c], 4\n\t"                                                                               \
+        "s_add_u32 s68, s68, 0x40\n\t"                                                                              \
+        "s_addc_u32 s69, s69, 0\n\t"                                                                                \
+        "s_branch .Lfs_end_%=\n"                                                                                    \
+        ".Lfs_f1_%=:\n\t"                                                                                           \
+        "s_mov_b32 %[st], 1\n\t"                                                                                    \
+        "s_mov_b32 %[pw], s38\n\t"                                                                                  \
+        "s_branch .Lfs_end_%=\n"                                                                                    \
+        ".Lfs_f2_%=:\n\t"                                                                                           \
+        "s_mov_b32 %[st], 2\n\t"                                                                                    \
+        "s_mov_b32 %[pw], s46\n\t"                                                                                  \
+        "s_add_u32 %[c], %[c], 2\n\t"                                                                               \
+        "s_branch .Lfs_end_%=\n"                                                                                    \
+        ".Lfs_f3_%=:\n\t"                                                                                           \
+        "s_mov_b32 %[st], 1\n\t"                                                                                    \
+        "s_mov_b32 %[pw], s54\n\t"                                                                                  \
+        "s_add_u32 %[c], %[c], 4\n\t"                                                                               \
+        "s_branch .Lfs_end_%=\n"                                                                                    \
+        ".Lfs_f4_%=:\n\t"                                                                                           \
+        "s_mov_b32 %[st], 2\n\t"                                                                                    \
+        "s_mov_b32 %[pw], s62\n\t"                                                                                  \
+        "s_add_u32 %[c], %[c], 6\n"                                                                                 \
+        ".Lfs_end_%=:"                                                                                              \
+        : "+{v[48:49]}"(wv), "={v[50:51]}"(r1), "={v[52:53]}"(r2), "={v[54:55]}"(r3), "={v[56:57]}"(ts_),           \
+          "={v[58:59]}"(ta_), "+{v60}"(mxS), "={v61}"(tn_), "={v62}"(tl_), [m] "=&s"(msk_), [st] "=&s"(st),         \
+          [pw] "+s"(pwi), [z0] "+s"(zS), [c] "+s"(cs), "+{s[68:69]}"(zpu)                                           \
+        : [se] "v"(sE2), [dc] "v"(dcs), [esh] "v"(Esh), [imdc] "v"(imdc), [rl] "s"(rl)                              \
+        : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50",  \
+          "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65",  \
+          "s66", "s67", "vcc", "scc")
+                            f2 wv = w0;
+                            uint32_t cs = 0;
+                            const uint32_t rl = (uint32_t)__builtin_amdgcn_readfirstlane((int)run_len);
                             for (;;) {
-                                // the body's eight 16-byte entries as TWO 64-byte scalar loads (s_load_dwordx16 takes any
-                                // dword-aligned address): the scalar unit is shared by the CU's four SIMDs, and six issue slots
-                                // less per body is what is saved there
+                                {
+                                    // the untested bodies, as long as they last: status 0 = stopped in front of a block
+                                    // that needs its tests or of the last four steps (or at the end of the run); 1 / 2 =
+                                    // the first / second trip of a block failed (start state, first step: wv / r1,
+                                    // r2 / r3; pwi = the first arrival's bound; cs counts the steps before the trip)
+                                    f2 r1, r2, r3, ts_, ta_;
+                                    float tn_, tl_;
+                                    uint64_t msk_;
+                                    int st;
+                                    const uint32_t c_in = cs;
+                                    FS_FAST_LOOP;
+                                    st = __builtin_amdgcn_readfirstlane(st); // (asm results count as divergent)
+                                    cs = (uint32_t)__builtin_amdgcn_readfirstlane((int)cs);
+                                    pwi = __builtin_amdgcn_readfirstlane(pwi);
+                                    if (kStats)
+                                        c_blk_free += (cs - c_in) >> 2;
+                                    if (st != 0) {
+                                        const float ebf = __int_as_float(pwi);
+                                        c = cs;
+                                        if (st == 1) {
+                                            FS_TRIP_FAILED_NB(a, r1, ebf, wv)
+                                        } else {
+                                            FS_TRIP_FAILED_NB(a, r3, ebf, r2)
+                                        }
+                                        break;
+                                    }
+                                }
+                                if (cs >= rl) {
+                                    c = cs, wO = wv, failed = false;
+                                    break;
+                                }
+                                // a block with its bound tests: four entries as one 64-byte scalar load (s_load_dwordx16
+                                // takes any dword-aligned address)
+                                if (kStats)
+                                    c_blk_tested++;
                                 typedef float f16 __attribute__((ext_vector_type(16)));
-                                f16 U, V;
+                                f16 U;
                                 asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(U) : "s"(zpu));
-                                asm volatile("s_load_dwordx16 %0, %1, 0x40" : "=s"(V) : "s"(zpu));
-                                f2 t1, u1;
-                                uint64_t v1 = 0;
-                                FS_SCALED_STEP(w0, z0, t1, u1, a, v1, false,
-                                               asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(U), "+s"(V), "+v"(mx_a)), U.s0, U.s1,
-                                               U.s2);
+                                f2 tp_, tq_;
+                                FS_STEP_ARITH(wv, zS, tp_, a)
+                                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(U), "+v"(tp_));
                                 const f4 ua = U.s0123, ub = U.s4567, uc = U.s89ab, ud = U.scdef;
-                                const f4 ue = V.s0123, uf = V.s4567, ug = V.s89ab, uh = V.scdef;
-                                FS_SCALED_STEP(t1, u1, w2, z2, b, v1, true, (void)0, ub.x, ub.y, ub.z);
-                                if (v1 != 0ull) {
-                                    FS_TRIP_FAILED(a, t1, ua.z, w0)
+                                const f2 up_ = {ua.x, ua.y}, uq_ = {uc.x, uc.y};
+                                uint64_t vp_ = 0, vq_ = 0;
+                                c = cs;
+                                FS_STEP_BOUND(tp_, a, vp_, ua.z)
+                                FS_STEP_ARITH(tp_, up_, w2, b)
+                                FS_STEP_BOUND(w2, b, vp_, ub.z)
+                                FS_STEP_SHAPE(w2, b, vp_)
+                                if (vp_ != 0ull) {
+                                    FS_TRIP_FAILED(a, tp_, ua.z, wv)
                                     break;
                                 }
+                                z2 = (f2){ub.x, ub.y};
                                 c += 2;
-                                f2 t3, u3;
-                                uint64_t v2 = 0;
-                                FS_SCALED_STEP(w2, z2, t3, u3, c_, v2, false, (void)0, uc.x, uc.y, uc.z);
-                                FS_SCALED_STEP(t3, u3, w0, z0, d, v2, true, (void)0, ud.x, ud.y, ud.z);
-                                if (v2 != 0ull) {
-                                    FS_TRIP_FAILED(c_, t3, uc.z, w2)
+                                FS_STEP_ARITH(w2, z2, tq_, c_)
+                                FS_STEP_BOUND(tq_, c_, vq_, uc.z)
+                                f2 w4;
+                                FS_STEP_ARITH(tq_, uq_, w4, d)
+                                FS_STEP_BOUND(w4, d, vq_, ud.z)
+                                FS_STEP_SHAPE(w4, d, vq_)
+                                if (vq_ != 0ull) {
+                                    FS_TRIP_FAILED(c_, tq_, uc.z, w2)
                                     break;
                                 }
-                                c += 2;
-                                f2 t5, u5;
-                                uint64_t v3 = 0;
-                                FS_SCALED_STEP(w0, z0, t5, u5, e, v3, false, (void)0, ue.x, ue.y, ue.z);
-                                FS_SCALED_STEP(t5, u5, w2, z2, f, v3, true, (void)0, uf.x, uf.y, uf.z);
-                                if (v3 != 0ull) {
-                                    FS_TRIP_FAILED(e, t5, ue.z, w0)
-                                    break;
-                                }
-                                c += 2;
-                                f2 t7, u7;
-                                uint64_t v4 = 0;
-                                FS_SCALED_STEP(w2, z2, t7, u7, g, v4, false, (void)0, ug.x, ug.y, ug.z);
-                                FS_SCALED_STEP(t7, u7, w0, z0, h, v4, true, (void)0, uh.x, uh.y, uh.z);
-                                if (v4 != 0ull) {
-                                    FS_TRIP_FAILED(g, t7, ug.z, w2)
-                                    break;
-                                }
-                                c += 2;
-                                zpu += 8;
-                                if (c >= run_len) {
-                                    wO = w0, failed = false;
+                                cs += 4;
+                                zpu += 4;
+                                wv = w4, mxS = mx_d, zS = (f2){ud.x, ud.y}, pwi = __float_as_int(ud.w);
+                                if (cs >= rl) {
+                                    c = cs, wO = wv, failed = false;
                                     break;
                                 }
                             }
+#undef FS_FAST_LOOP
+#undef FS_PK_F
+#undef FS_PK_MA
+#undef FS_PK_MB
+#undef FS_PK_P
+#undef FS_PK_A
+#undef FS_R0
+#undef FS_R1
+#undef FS_R2
+#undef FS_R3
+#undef FS_T_X
+#undef FS_T_N
+#undef FS_T_L
+#undef FS_T_W
+#undef FS_T_C1
+#undef FS_T_C2
+#undef FS_T_O
+#undef FS_NOP
+#undef FS_STEP_ARITH
+#undef FS_STEP_BOUND
+#undef FS_STEP_SHAPE
                             }
                         } else {
                             // per-lane orbit positions: one 12-byte vector load per step from a wave-uniform base plus a
@@ -982,6 +1198,7 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
 #undef FS_SCALED_LOAD
                         }
 #undef FS_TRIP_FAILED
+#undef FS_TRIP_FAILED_NB
 #undef FS_SCALED_STEP
                         FS_CYC(cyc_body += __builtin_readcyclecounter() - cyc_t2);
                         // back to the reduced form: the larger part's exponent moves into dze (exact)
@@ -1239,11 +1456,16 @@ __global__ void __launch_bounds__(256) k_lav2_hdr32_fast(FsLav2Args32 A)
             c_careful += __shfl_down(c_careful, off);
             c_scaled += __shfl_down(c_scaled, off);
             c_runs += __shfl_down(c_runs, off);
+            const uint32_t bf = __shfl_down(c_blk_free, off), bt = __shfl_down(c_blk_tested, off);
+            c_blk_free = bf > c_blk_free ? bf : c_blk_free; // wave-uniform while a lane is in the loop: the longest lane's
+            c_blk_tested = bt > c_blk_tested ? bt : c_blk_tested;
         }
         if ((threadIdx.x & 63) == 0) {
             atomicAdd((unsigned long long *)&A.stats[5], (unsigned long long)c_careful);
             atomicAdd((unsigned long long *)&A.stats[6], (unsigned long long)c_scaled);
             atomicAdd((unsigned long long *)&A.stats[7], (unsigned long long)c_runs);
+            atomicAdd((unsigned long long *)&A.stats[8], (unsigned long long)c_blk_free);
+            atomicAdd((unsigned long long *)&A.stats[9], (unsigned long long)c_blk_tested);
         }
     }
 }
@@ -1898,7 +2120,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                     const uint32_t left_it = n_iterations - 1 - iter; // iter < n_iterations here
                     const uint32_t left = left_ref < left_it ? left_ref : left_it;
                     const int Esh = (E < -254 ? -254 : (E > 0 ? 0 : E)) * (1 << 23);
-                    const bool start_ok = e0.w != 0.0f && mn0 >= mx0 * 0x1p-40f && mx0 >= 1.0f && mx0 < 2.0f &&
+                    const bool start_ok = scaled_startable(e0) && mn0 >= mx0 * 0x1p-40f && mx0 >= 1.0f && mx0 < 2.0f &&
                                           imax(dshx, dshy) <= 30;
                     const uint32_t run_len = scaled_run_length(left);
                     if (__builtin_amdgcn_ballot_w64(!start_ok) != 0ull || run_len == 0u)

@@ -1,5 +1,6 @@
 """Share of the perturbation steps of the tuned LAv2 kernel that run inside scaled runs, by frame size (View 5).
 Usage: python tools/scaled_share_probe.py"""
+import ctypes as C
 import json
 import os
 import sys
@@ -21,6 +22,9 @@ for w, h in ((480, 270), (960, 540), (1920, 1080), (3840, 2160)):
         assert r.RenderPerturbLAv2(None, None, None, *co, v.num_iterations, T=T_HDR32, Mode=LAV2_FULL, parity=PARITY_CPU) == 0
         assert r.SyncComputeStream() == 0
         st = r.read_step_count()
+        raw = (C.c_uint64 * 32)()
+        assert r._lib.fs_read_stats_raw(r._h, raw, 32) == 0
+        blk_free, blk_tested = raw[8], raw[9]
         ms_stats = r.last_kernel_ms()
         r.enable_step_count(False)
         assert r.RenderPerturbLAv2(None, None, None, *co, v.num_iterations, T=T_HDR32, Mode=LAV2_FULL, parity=PARITY_CPU) == 0
@@ -30,5 +34,7 @@ for w, h in ((480, 270), (960, 540), (1920, 1080), (3840, 2160)):
                           "scaled_share": round(st["scaled_steps"] / max(1, st["perturb_steps"]), 4),
                           "careful_share": round(st["careful_steps"] / max(1, st["perturb_steps"]), 4),
                           "steps_per_run": round(st["scaled_steps"] / max(1, st["scaled_runs"]), 1),
+                          "blocks_without_bound_tests": round(blk_free / max(1, blk_free + blk_tested), 4),
+                          "wave_blocks": blk_free + blk_tested,
                           "lane_utilisation": round(st["perturb_steps"] / max(1, st["lane_slots"]), 4)}), flush=True)
 r.set_kernel_variant(0)
