@@ -566,6 +566,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
 #endif
     uint64_t c_at = 0, c_la = 0, c_pt = 0, c_px = 0;
     uint64_t c_careful = 0, c_scaled = 0, c_runs = 0;
+    uint32_t c_pass = 0, c_generic = 0; // careful passes of the wave / those that took the generic step
     uint32_t c_blk_free = 0, c_blk_tested = 0; // 4-step blocks of the scalar-cache scaled path without / with bound tests (per wave)
 #ifdef FS_PROFILE_CYCLES
     uint64_t cyc_loop = 0, cyc_run = 0, cyc_body = 0, cyc_t0 = 0, cyc_t1 = 0, cyc_t2 = 0;
@@ -665,33 +666,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
             const f2 dcm = {dc.re, dc.im};
             const int dce = dc.e;
             f2 Zcm = {Zc.re, Zc.im};
-            // One speculative straight-line step from (dzm, dze, Zcm, Zce1) against the orbit entry zv.
-            // n* = NEGATED exponent gaps (<= 0 when the assumption holds).
-#define FS_LAV2_STEP_HEAD()                                                                                         \
-    const f2 Znm = {zv.x, zv.y};                                                                                    \
-    const int Zne = __float_as_int(zv.z);                                                                           \
-    /* cur = 2Z + dz      (orbit bigger, gap in [0,120)) */                                                        \
-    const int nd1 = dze - Zce1;                                                                                     \
-    const f2 cur = Zcm + dzm * __int_as_float((nd1 << 23) + 0x3F800000);                                            \
-    /* p = dz * cur       (re = dr*cr - di*ci, im = dr*ci + di*cr) */                                              \
-    const f2 pa = dzm.xx * cur;                                                                                     \
-    const f2 pb = dzm.yy * cur.yx;                                                                                  \
-    f2 p;                                                                                                           \
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(p) : "v"(pa), "v"(pb));                          \
-    const int pe = imax(dze + Zce1, kMinBigExp);                                                                    \
-    /* q = p + dc         (p bigger; gap >= 120 ignores dc) */                                                     \
-    const int nd2 = dce - pe;                                                                                       \
-    const float m2 = nd2 > -kExpDiffIgnored ? __int_as_float((nd2 << 23) + 0x3F800000) : 0.0f;                      \
-    f2 q = p + dcm * m2;                                                                                            \
-    /* Reduce(q)          (larger part a non-zero normal float) */                                                 \
-    const int fmax = imax((int)__builtin_amdgcn_ubfe(__float_as_int(q.x), 23, 8),                                   \
-                          (int)__builtin_amdgcn_ubfe(__float_as_int(q.y), 23, 8));                                  \
-    q = q * __int_as_float(0x7F000000 - (fmax << 23));                                                              \
-    const int qe = pe + fmax - 127;                                                                                 \
-    const int nd3 = qe - Zne;                                                                                       \
-    const bool ok_core = imax(imax(nd1, nd3), nd2) <= 0 && (nd1 < nd3 ? nd1 : nd3) > -kExpDiffIgnored &&            \
-                         (unsigned)(fmax - 1) < 254u /* larger part of q: non-zero, finite, normal */
-
+            // The careful step as straight-line code for EVERY exponent order of its three sums.  plus_mutable
+            // (HDRFloatComplex.h:219-247, hc_add) keeps the operand with the larger exponent and adds the other one scaled
+            // by 2^-gap -- or not at all from a gap of 120 on: with f(g) = 2^g for g > -120 and 0 below,
+            //   sum = a f(a.e - e) + b f(b.e - e),  e = max(a.e, b.e)
+            // is the same two IEEE operations per part in each of its four arms (one factor is 1, the product by it exact;
+            // a product by 0 adds a zero), up to the sign of a zero part, which no later operation can see.
+            auto pow2_or_zero = [](int g) -> float {
+                return g > -kExpDiffIgnored ? __int_as_float((int)(((uint32_t)g << 23) + 0x3F800000u)) : 0.0f; // g <= 0
+            };
             // Quiet-run state: sC = ~(exponent of Zc) + 116 for an orbit value below 8, a large positive poison otherwise
             // (zq[i].z, written by k_make_quiet_orbit).
             const float4 *__restrict__ zq = A.zq;
@@ -1348,28 +1331,53 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                         continue; // (every lane of the chunk had >= 64 steps left: still running)
                 }
 #undef FS_QUIET_STEP
-                // the careful step works with the true exponent of Zc (sC may be the poison value)
-                int Zce1 = __float_as_int(zr[ref].z) + 1;
-                // ---- one careful step: full exit tests; generic CPU-order fallback when an assumption fails
+                // ---- one careful step: full exit tests (Fractal.cpp:2646-2661); the literal transcription takes over when a
+                // value leaves the range the straight-line form is proven for
+                const int Zce1 = __float_as_int(zr[ref].z) + 1; // the true exponent of 2 Zc (sC may be the poison value)
                 const float4 zv = zr[ref + 1];
-                FS_LAV2_STEP_HEAD();
-                // z = Z' + q         (orbit bigger, gap in [0,120)); z is NOT reduced (see header comment)
-                const f2 zm = Znm + q * __int_as_float((nd3 << 23) + 0x3F800000);
+                const f2 Znm = {zv.x, zv.y};
+                const int Zne = __float_as_int(zv.z);
+                // cur = 2Z + dz
+                const int e_cur = imax(Zce1, dze);
+                const f2 cur = Zcm * pow2_or_zero(Zce1 - e_cur) + dzm * pow2_or_zero(dze - e_cur);
+                // p = dz * cur       (re = dr*cr - di*ci, im = dr*ci + di*cr)
+                const f2 pa = dzm.xx * cur;
+                const f2 pb = dzm.yy * cur.yx;
+                f2 p;
+                asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(p) : "v"(pa), "v"(pb));
+                const int pe = imax(dze + e_cur, kMinBigExp);
+                // q = p + dc, then Reduce (the larger part a non-zero float: checked below)
+                const int e_q = imax(pe, dce);
+                f2 q = p * pow2_or_zero(pe - e_q) + dcm * pow2_or_zero(dce - e_q);
+                const int fmax = imax((int)__builtin_amdgcn_ubfe(__float_as_int(q.x), 23, 8),
+                                      (int)__builtin_amdgcn_ubfe(__float_as_int(q.y), 23, 8));
+                q = q * __int_as_float(0x7F000000 - (fmax << 23));
+                const int qe = e_q + fmax - 127;
+                // z = Z' + q; z is NOT reduced (see header comment)
+                const int e_z = imax(Zne, qe);
+                const int gq = qe - e_z;
+                const f2 zm = Znm * pow2_or_zero(Zne - e_z) + q * pow2_or_zero(gq);
                 const f2 zz = zm * zm;
                 const float zn2 = zz.x + zz.y;
                 const f2 qq = q * q;
                 const float dn2 = qq.x + qq.y; // in [1,8): q's larger part is in [1,2)
                 // With both norms positive normal floats, Reduce(|z|^2) > 256 and Reduce(|z|^2) < Reduce(|dz|^2)
                 // (lexicographic on (exp, mantissa in [1,2))) are plain value comparisons:
-                //   zn2 * 2^(2 Zne) > 2^8            <=>  zn2 > 2^(8 - 2 Zne)          (= zv.w, exact power of two)
-                //   zn2 * 2^(2 Zne) < dn2 * 2^(2 qe)  <=>  zn2 < dn2 * 2^(2 nd3)        (exact scaling; an underflow can
+                //   zn2 * 2^(2 e_z) > 2^8             <=>  zn2 > 2^(8 - 2 e_z)          (exact power of two, +inf / 0 beyond the range)
+                //   zn2 * 2^(2 e_z) < dn2 * 2^(2 qe)  <=>  zn2 < dn2 * 2^(2 (qe - e_z))  (exact scaling; an underflow can
                 //                                                                       only make the rhs <= min normal <= zn2)
-                bool escaped = zn2 > zv.w;
-                bool rebase = zn2 < __builtin_amdgcn_ldexpf(dn2, nd3 + nd3);
-                const bool ok = ok_core && __builtin_amdgcn_classf(zn2, 0x100 /* +normal */);
+                const int esc_e = 8 - 2 * (e_z < -100 ? -100 : (e_z > 100 ? 100 : e_z));
+                bool escaped = zn2 > __builtin_amdgcn_ldexpf(1.0f, esc_e);
+                bool rebase = zn2 < __builtin_amdgcn_ldexpf(dn2, gq + gq);
+                // larger part of q: non-zero, finite, normal (a NaN or an infinity anywhere above ends up in q or zn2)
+                const bool ok = (unsigned)(fmax - 1) < 254u && __builtin_amdgcn_classf(zn2, 0x100 /* +normal */);
                 hcplx32 z;
                 bool reduced_z = false;
+                if (kStats)
+                    c_pass++;
                 if (__builtin_amdgcn_ballot_w64(!ok) != 0ull) {
+                    if (kStats)
+                        c_generic++;
                     // ---- generic step, literal order of Fractal.cpp:2646-2661
                     const hcplx32 Zc_g{Zcm.x, Zcm.y, Zce1 - 1};
                     const hcplx32 dz_g{dzm.x, dzm.y, dze};
@@ -1388,7 +1396,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                     dze = ndz.e;
                     reduced_z = true;
                 } else {
-                    z = hcplx32{zm.x, zm.y, Zne};
+                    z = hcplx32{zm.x, zm.y, e_z};
                     dze = qe;
                 }
                 if (kStats) {
@@ -1415,7 +1423,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                 }
             }
             FS_CYC(cyc_loop += __builtin_readcyclecounter() - cyc_t0);
-#undef FS_LAV2_STEP_HEAD
         }
         store_iter(A.out, A.frame, L, X, iterations);
     }
@@ -1459,6 +1466,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
             const uint32_t bf = __shfl_down(c_blk_free, off), bt = __shfl_down(c_blk_tested, off);
             c_blk_free = bf > c_blk_free ? bf : c_blk_free; // wave-uniform while a lane is in the loop: the longest lane's
             c_blk_tested = bt > c_blk_tested ? bt : c_blk_tested;
+            const uint32_t cp = __shfl_down(c_pass, off), cg = __shfl_down(c_generic, off);
+            c_pass = cp > c_pass ? cp : c_pass;
+            c_generic = cg > c_generic ? cg : c_generic;
         }
         if ((threadIdx.x & 63) == 0) {
             atomicAdd((unsigned long long *)&A.stats[5], (unsigned long long)c_careful);
@@ -1466,6 +1476,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
             atomicAdd((unsigned long long *)&A.stats[7], (unsigned long long)c_runs);
             atomicAdd((unsigned long long *)&A.stats[8], (unsigned long long)c_blk_free);
             atomicAdd((unsigned long long *)&A.stats[9], (unsigned long long)c_blk_tested);
+            atomicAdd((unsigned long long *)&A.stats[10], (unsigned long long)c_pass);
+            atomicAdd((unsigned long long *)&A.stats[11], (unsigned long long)c_generic);
         }
     }
 }

@@ -36,5 +36,7 @@ for w, h in ((480, 270), (960, 540), (1920, 1080), (3840, 2160)):
                           "steps_per_run": round(st["scaled_steps"] / max(1, st["scaled_runs"]), 1),
                           "blocks_without_bound_tests": round(blk_free / max(1, blk_free + blk_tested), 4),
                           "wave_blocks": blk_free + blk_tested,
+                          "careful_passes_per_wave": round(raw[10] / (w * h / 64), 1),
+                          "generic_step_share_of_passes": round(raw[11] / max(1, raw[10]), 4),
                           "lane_utilisation": round(st["perturb_steps"] / max(1, st["lane_slots"]), 4)}), flush=True)
 r.set_kernel_variant(0)
