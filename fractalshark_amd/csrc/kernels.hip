@@ -460,6 +460,139 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
 }
 
 // ------------------------------------------------------------------------------------------------
+// The scalar-cache path of the scaled runs (k_lav2_hdr32_fast and the perturbation-only float path of k_perturb_scalar):
+// step pieces of the tested C++ block and the hand-scheduled untested loop.  Names used from the enclosing scope: sE2, dcs,
+// Esh, imdc, wv, mxS, pwi, zS, cs, zpu, rl.
+// PF of FS_FAST_LOOP: FS_PF_NONE, or FS_PF_NEXT_BODY = one dword of each 64-byte line of the NEXT body's entries (three:
+// entries are 16-byte aligned only), requested right after this body's wait, so that the next body's loads hit the scalar
+// cache -- for waves that run alone on their SIMD (C2's interior pixels), where the L2 round trip per body is not hidden.
+#define FS_PF_NONE ""
+#define FS_PF_NEXT_BODY                                                                                             \
+    "s_load_dword %[pf], s[68:69], 0x80\n\t"                                                                        \
+    "s_load_dword %[pg], s[68:69], 0xc0\n\t"                                                                        \
+    "s_load_dword %[ph], s[68:69], 0xfc\n\t"
+#define FS_STEP_ARITH(W_, Z_, NW_, T)                                                                               \
+    const f2 s_##T = __builtin_elementwise_fma(W_, sE2, Z_);                                                        \
+    const f2 pa_##T = W_.xx * s_##T;                                                                                \
+    const f2 pb_##T = W_.yy * s_##T.yx;                                                                             \
+    f2 p_##T;                                                                                                       \
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(p_##T) : "v"(pa_##T), "v"(pb_##T));              \
+    NW_ = p_##T + dcs;
+#define FS_STEP_BOUND(NW_, T, V, EB)                                                                                \
+    const float mx_##T = __builtin_fmaxf(__builtin_fabsf(NW_.x), __builtin_fabsf(NW_.y));                           \
+    V |= __builtin_amdgcn_ballot_w64(__float_as_int(mx_##T) + Esh > __float_as_int(EB));
+#define FS_STEP_SHAPE(NW_, T, V)                                                                                    \
+    {                                                                                                               \
+        const float mn_ = __builtin_fminf(__builtin_fabsf(NW_.x), __builtin_fabsf(NW_.y));                          \
+        V |= __builtin_amdgcn_ballot_w64(!(mn_ >= mx_##T * 0x1p-40f)) |                                             \
+             __builtin_amdgcn_ballot_w64((uint32_t)(__float_as_int(mx_##T) - (107 << 23)) >= (uint32_t)(60 << 23)); \
+    }
+// The untested body.  Registers are named (the halves of a packed pair have no operand syntax): the state w in v[48:49];
+// four state pairs v[48:55] in rotation (a trip = two steps: start state, first step, and the next trip's two while the
+// verdict is pending); the entries in s[36:67].  A packed result cannot be read by the next instruction, so each trip's
+// tests run in the wait states of the following trip's packed arithmetic, and its verdict arrives just before that trip's
+// second step is written over the failed trip's start state: everything a failed trip needs is still in its registers,
+// and what was computed past it is dropped.
+// The loop runs inside the statement: bodies of eight steps while the block test passes and eight steps are left
+// (status 0 on the way out: state in v[48:49], max|w| in v60, counters advanced); status 1 / 2: the first / second trip
+// of a block failed (start state / first step: v48 / v50, v52 / v54; `pw` = the first arrival's bound then).
+#define FS_PK_F(W, Z) "v_pk_fma_f32 v[56:57], " W ", %[se], " Z "\n\t"
+#define FS_PK_MA(W) "v_pk_mul_f32 v[58:59], " W ", v[56:57] op_sel_hi:[0,1]\n\t"
+#define FS_PK_MB(W) "v_pk_mul_f32 v[56:57], " W ", v[56:57] op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+#define FS_PK_P "v_pk_add_f32 v[58:59], v[58:59], v[56:57] neg_lo:[0,1] neg_hi:[0,0]\n\t"
+#define FS_PK_A(NW) "v_pk_add_f32 " NW ", v[58:59], %[dc]\n\t"
+#define FS_R0 "v[48:49]"
+#define FS_R1 "v[50:51]"
+#define FS_R2 "v[52:53]"
+#define FS_R3 "v[54:55]"
+#define FS_T_X(A, B) "v_max_f32_e64 v60, |" A "|, |" B "|\n\t"
+#define FS_T_N(A, B) "v_min_f32_e64 v61, |" A "|, |" B "|\n\t"
+#define FS_T_L "v_mul_f32_e32 v62, 0x2b800000, v60\n\t"          /* 2^-40 max */
+#define FS_T_C1 "v_cmp_nge_f32_e64 %[m], v61, v62\n\t"
+#define FS_T_W "v_add_u32_e32 v61, 0xca800000, v60\n\t"          /* bits(max) - (107 << 23) */
+#define FS_T_C2 "v_cmp_le_u32_e32 vcc, 0x1e000000, v61\n\t" /* >= 60 << 23 */
+#define FS_T_O "s_or_b64 %[m], %[m], vcc\n\t"
+#define FS_NOP "s_nop 0\n\t"
+#define FS_FAST_LOOP(PF)                                                                                              \
+    asm volatile(                                                                                                   \
+        ".Lfs_loop_%=:\n\t" /* eight steps left?  the first block's test: max(max|w|, max|dc|) against .w */        \
+        "v_max_i32_e32 v62, v60, %[imdc]\n\t"                                                                       \
+        "s_add_u32 %[st], %[c], 8\n\t"                                                                              \
+        "v_add_u32_e32 v62, v62, %[esh]\n\t"                                                                        \
+        "s_cmp_gt_u32 %[st], %[rl]\n\t"                                                                             \
+        "s_cbranch_scc1 .Lfs_out_%=\n\t"                                                                            \
+        "v_cmp_lt_i32_e64 %[m], %[pw], v62\n\t"                                                                     \
+        "s_cmp_lg_u64 %[m], 0\n\t"                                                                                  \
+        "s_cbranch_scc1 .Lfs_out_%=\n\t"                                                                            \
+        "s_load_dwordx16 s[36:51], s[68:69], 0x0\n\t"                                                               \
+        "s_load_dwordx16 s[52:67], s[68:69], 0x40\n\t" /* step 1: needs the previous entry only */                  \
+        FS_PK_F(FS_R0, "%[z0]") FS_NOP FS_PK_MA(FS_R0) FS_PK_MB(FS_R0) FS_NOP FS_PK_P FS_NOP FS_PK_A(FS_R1)         \
+        "s_waitcnt lgkmcnt(0)\n\t" PF /* step 2 */                                                                  \
+        FS_PK_F(FS_R1, "s[36:37]") FS_NOP FS_PK_MA(FS_R1) FS_PK_MB(FS_R1) FS_NOP FS_PK_P FS_NOP FS_PK_A(FS_R2)      \
+        FS_NOP /* steps 3, 4 + the tests of w2 = the verdict of trip 1 */                                           \
+        FS_PK_F(FS_R2, "s[40:41]") FS_T_X("v52", "v53") FS_PK_MA(FS_R2) FS_PK_MB(FS_R2) FS_T_N("v52", "v53")        \
+        FS_PK_P FS_T_L FS_PK_A(FS_R3) FS_T_C1                                                                       \
+        FS_PK_F(FS_R3, "s[44:45]") FS_T_W FS_PK_MA(FS_R3) FS_PK_MB(FS_R3) FS_T_C2 FS_PK_P FS_T_O                    \
+        "s_cbranch_scc1 .Lfs_f1_%=\n\t" FS_PK_A(FS_R0) FS_NOP /* steps 5, 6 + the tests of w4 (trip 2) */           \
+        FS_PK_F(FS_R0, "s[48:49]") FS_T_X("v48", "v49") FS_PK_MA(FS_R0) FS_PK_MB(FS_R0) FS_T_N("v48", "v49")        \
+        FS_PK_P FS_T_L FS_PK_A(FS_R1) FS_T_C1                                                                       \
+        FS_PK_F(FS_R1, "s[52:53]") FS_T_W FS_PK_MA(FS_R1) FS_PK_MB(FS_R1) FS_T_C2 FS_PK_P FS_T_O                    \
+        "s_cbranch_scc1 .Lfs_f2_%=\n\t" /* the second block's test: max(max|w4|, max|dc|) against entry 4's .w */   \
+        "v_max_i32_e32 v62, v60, %[imdc]\n\t" FS_PK_A(FS_R2) "v_add_u32_e32 v62, v62, %[esh]\n\t"                   \
+        /* steps 7, 8 + the tests of w6 (trip 3) */                                                                 \
+        FS_PK_F(FS_R2, "s[56:57]") "v_cmp_lt_i32_e64 %[m], s51, v62\n\t" FS_PK_MA(FS_R2) FS_PK_MB(FS_R2)            \
+        "s_cmp_lg_u64 %[m], 0\n\t" FS_PK_P "s_cbranch_scc1 .Lfs_blk_%=\n\t" FS_PK_A(FS_R3) FS_T_X("v52", "v53")     \
+        FS_PK_F(FS_R3, "s[60:61]") FS_T_N("v52", "v53") FS_PK_MA(FS_R3) FS_PK_MB(FS_R3) FS_T_L FS_PK_P FS_T_C1      \
+        FS_T_W FS_T_C2 FS_T_O "s_cbranch_scc1 .Lfs_f3_%=\n\t" FS_PK_A(FS_R0)                                        \
+        "s_mov_b64 %[z0], s[64:65]\n\t" /* the tests of w8 (trip 4) */                                              \
+        FS_T_X("v48", "v49") FS_T_N("v48", "v49") FS_T_L FS_T_C1 FS_T_W FS_T_C2 FS_T_O                              \
+        "s_cbranch_scc1 .Lfs_f4_%=\n\t"                                                                             \
+        "s_mov_b32 %[pw], s67\n\t"                                                                                  \
+        "s_add_u32 %[c], %[c], 8\n\t"                                                                               \
+        "s_add_u32 s68, s68, 0x80\n\t"                                                                              \
+        "s_addc_u32 s69, s69, 0\n\t"                                                                                \
+        "s_branch .Lfs_loop_%=\n"                                                                                   \
+        ".Lfs_out_%=:\n\t" /* the block at the current position needs its tests, or fewer than 8 steps are left */  \
+        "s_mov_b32 %[st], 0\n\t"                                                                                    \
+        "s_branch .Lfs_end_%=\n"                                                                                    \
+        ".Lfs_blk_%=:\n\t" /* the same after the first block */                                                     \
+        "s_mov_b32 %[st], 0\n\t"                                                                                    \
+        "s_mov_b64 %[z0], s[48:49]\n\t"                                                                             \
+        "s_mov_b32 %[pw], s51\n\t"                                                                                  \
+        "s_add_u32 %[c], %[c], 4\n\t"                                                                               \
+        "s_add_u32 s68, s68, 0x40\n\t"                                                                              \
+        "s_addc_u32 s69, s69, 0\n\t"                                                                                \
+        "s_branch .Lfs_end_%=\n"                                                                                    \
+        ".Lfs_f1_%=:\n\t"                                                                                           \
+        "s_mov_b32 %[st], 1\n\t"                                                                                    \
+        "s_mov_b32 %[pw], s38\n\t"                                                                                  \
+        "s_branch .Lfs_end_%=\n"                                                                                    \
+        ".Lfs_f2_%=:\n\t"                                                                                           \
+        "s_mov_b32 %[st], 2\n\t"                                                                                    \
+        "s_mov_b32 %[pw], s46\n\t"                                                                                  \
+        "s_add_u32 %[c], %[c], 2\n\t"                                                                               \
+        "s_branch .Lfs_end_%=\n"                                                                                    \
+        ".Lfs_f3_%=:\n\t"                                                                                           \
+        "s_mov_b32 %[st], 1\n\t"                                                                                    \
+        "s_mov_b32 %[pw], s54\n\t"                                                                                  \
+        "s_add_u32 %[c], %[c], 4\n\t"                                                                               \
+        "s_branch .Lfs_end_%=\n"                                                                                    \
+        ".Lfs_f4_%=:\n\t"                                                                                           \
+        "s_mov_b32 %[st], 2\n\t"                                                                                    \
+        "s_mov_b32 %[pw], s62\n\t"                                                                                  \
+        "s_add_u32 %[c], %[c], 6\n"                                                                                 \
+        ".Lfs_end_%=:\n\t"                                                                                           \
+        "s_waitcnt lgkmcnt(0)" /* (PF: nothing stays in flight) */                                                  \
+        : "+{v[48:49]}"(wv), "={v[50:51]}"(r1), "={v[52:53]}"(r2), "={v[54:55]}"(r3), "={v[56:57]}"(ts_),           \
+          "={v[58:59]}"(ta_), "+{v60}"(mxS), "={v61}"(tn_), "={v62}"(tl_), [m] "=&s"(msk_), [st] "=&s"(st),         \
+          [pw] "+s"(pwi), [z0] "+s"(zS), [c] "+s"(cs), "+{s[68:69]}"(zpu), [pf] "=&s"(pf_),                         \
+          [pg] "=&s"(pg_), [ph] "=&s"(ph_)                                                                          \
+        : [se] "v"(sE2), [dc] "v"(dcs), [esh] "v"(Esh), [imdc] "v"(imdc), [rl] "s"(rl)                              \
+        : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50",  \
+          "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65",  \
+          "s66", "s67", "vcc", "scc")
+
+// ------------------------------------------------------------------------------------------------
 // LAv2, T = HDRFloat<float>: tuned perturbation loop.  Same prologue (AT + LA stages) and the same results, bit for
 // bit, as k_lav2_hdr32; the perturbation loop (>99.9 % of the executed work at View 5) is restructured around what
 // the CPU arithmetic actually does per step (measured with an instrumented oracle):
@@ -566,6 +699,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
 #endif
     uint64_t c_at = 0, c_la = 0, c_pt = 0, c_px = 0;
     uint64_t c_careful = 0, c_scaled = 0, c_runs = 0;
+    uint32_t c_why[4] = {0, 0, 0, 0};
+    uint32_t c_wentry = 0, c_wstart = 0, c_wshort = 0; // run entries tried / runs started / runs of fewer than 8 steps (per wave)
     uint32_t c_pass = 0, c_generic = 0; // careful passes of the wave / those that took the generic step
     uint32_t c_blk_free = 0, c_blk_tested = 0; // 4-step blocks of the scalar-cache scaled path without / with bound tests (per wave)
 #ifdef FS_PROFILE_CYCLES
@@ -726,6 +861,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                         // run length: the longest of 256 / 64 / 16 steps that every lane still has before the orbit ends
                         // and before its iteration limit (three votes per run, not a counter per step)
                         const uint32_t run_len = scaled_run_length(left);
+                        if (kStats) {
+                            c_wentry++;
+                            // why an entry fails (wave votes; tools/scaled_share_probe.py)
+                            if (run_len == 0u)
+                                c_why[0]++;
+                            else if (__builtin_amdgcn_ballot_w64(!scaled_startable(e0)) != 0ull)
+                                c_why[1]++;
+                            else if (__builtin_amdgcn_ballot_w64(dsh > 30) != 0ull)
+                                c_why[2]++;
+                            else if (__builtin_amdgcn_ballot_w64(!start_ok) != 0ull)
+                                c_why[3]++;
+                        }
                         if (__builtin_amdgcn_ballot_w64(!start_ok) != 0ull || run_len == 0u)
                             break;
                         const f2 sE2 = {sE, sE};
@@ -913,124 +1060,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                             // (all lanes sit at the same entry here: 2Z of the entry the state is at lives in scalar registers)
                             f2 zS = {__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(e0.x))),
                                      __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(e0.y)))};
-#define FS_STEP_ARITH(W_, Z_, NW_, T)                                                                               \
-    const f2 s_##T = __builtin_elementwise_fma(W_, sE2, Z_);                                                        \
-    const f2 pa_##T = W_.xx * s_##T;                                                                                \
-    const f2 pb_##T = W_.yy * s_##T.yx;                                                                             \
-    f2 p_##T;                                                                                                       \
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(p_##T) : "v"(pa_##T), "v"(pb_##T));              \
-    NW_ = p_##T + dcs;
-#define FS_STEP_BOUND(NW_, T, V, EB)                                                                                \
-    const float mx_##T = __builtin_fmaxf(__builtin_fabsf(NW_.x), __builtin_fabsf(NW_.y));                           \
-    V |= __builtin_amdgcn_ballot_w64(__float_as_int(mx_##T) + Esh > __float_as_int(EB));
-#define FS_STEP_SHAPE(NW_, T, V)                                                                                    \
-    {                                                                                                               \
-        const float mn_ = __builtin_fminf(__builtin_fabsf(NW_.x), __builtin_fabsf(NW_.y));                          \
-        V |= __builtin_amdgcn_ballot_w64(!(mn_ >= mx_##T * 0x1p-40f)) |                                             \
-             __builtin_amdgcn_ballot_w64((uint32_t)(__float_as_int(mx_##T) - (107 << 23)) >= (uint32_t)(60 << 23)); \
-    }
-// The untested body.  Registers are named (the halves of a packed pair have no operand syntax): the state w in v[48:49];
-// four state pairs v[48:55] in rotation (a trip = two steps: start state, first step, and the next trip's two while the
-// verdict is pending); the entries in s[36:67].  A packed result cannot be read by the next instruction, so each trip's
-// tests run in the wait states of the following trip's packed arithmetic, and its verdict arrives just before that trip's
-// second step is written over the failed trip's start state: everything a failed trip needs is still in its registers,
-// and what was computed past it is dropped.
-// The loop runs inside the statement: bodies of eight steps while the block test passes and eight steps are left
-// (status 0 on the way out: state in v[48:49], max|w| in v60, counters advanced); status 1 / 2: the first / second trip
-// of a block failed (start state / first step: v48 / v50, v52 / v54; `pw` = the first arrival's bound then).
-#define FS_PK_F(W, Z) "v_pk_fma_f32 v[56:57], " W ", %[se], " Z "\n\t"
-#define FS_PK_MA(W) "v_pk_mul_f32 v[58:59], " W ", v[56:57] op_sel_hi:[0,1]\n\t"
-#define FS_PK_MB(W) "v_pk_mul_f32 v[56:57], " W ", v[56:57] op_sel:[1,1] op_sel_hi:[1,0]\n\t"
-#define FS_PK_P "v_pk_add_f32 v[58:59], v[58:59], v[56:57] neg_lo:[0,1] neg_hi:[0,0]\n\t"
-#define FS_PK_A(NW) "v_pk_add_f32 " NW ", v[58:59], %[dc]\n\t"
-#define FS_R0 "v[48:49]"
-#define FS_R1 "v[50:51]"
-#define FS_R2 "v[52:53]"
-#define FS_R3 "v[54:55]"
-#define FS_T_X(A, B) "v_max_f32_e64 v60, |" A "|, |" B "|\n\t"
-#define FS_T_N(A, B) "v_min_f32_e64 v61, |" A "|, |" B "|\n\t"
-#define FS_T_L "v_mul_f32_e32 v62, 0x2b800000, v60\n\t"          /* 2^-40 max */
-#define FS_T_C1 "v_cmp_nge_f32_e64 %[m], v61, v62\n\t"
-#define FS_T_W "v_add_u32_e32 v61, 0xca800000, v60\n\t"          /* bits(max) - (107 << 23) */
-#define FS_T_C2 "v_cmp_le_u32_e32 vcc, 0x1e000000, v61\n\t" /* >= 60 << 23 */
-#define FS_T_O "s_or_b64 %[m], %[m], vcc\n\t"
-#define FS_NOP "s_nop 0\n\t"
-#define FS_FAST_LOOP                                                                                                \
-    asm volatile(                                                                                                   \
-        ".Lfs_loop_%=:\n\t" /* eight steps left?  the first block's test: max(max|w|, max|dc|) against .w */        \
-        "v_max_i32_e32 v62, v60, %[imdc]\n\t"                                                                       \
-        "s_add_u32 %[st], %[c], 8\n\t"                                                                              \
-        "v_add_u32_e32 v62, v62, %[esh]\n\t"                                                                        \
-        "s_cmp_gt_u32 %[st], %[rl]\n\t"                                                                             \
-        "s_cbranch_scc1 .Lfs_out_%=\n\t"                                                                            \
-        "v_cmp_lt_i32_e64 %[m], %[pw], v62\n\t"                                                                     \
-        "s_cmp_lg_u64 %[m], 0\n\t"                                                                                  \
-        "s_cbranch_scc1 .Lfs_out_%=\n\t"                                                                            \
-        "s_load_dwordx16 s[36:51], s[68:69], 0x0\n\t"                                                               \
-        "s_load_dwordx16 s[52:67], s[68:69], 0x40\n\t" /* step 1: needs the previous entry only */                  \
-        FS_PK_F(FS_R0, "%[z0]") FS_NOP FS_PK_MA(FS_R0) FS_PK_MB(FS_R0) FS_NOP FS_PK_P FS_NOP FS_PK_A(FS_R1)         \
-        "s_waitcnt lgkmcnt(0)\n\t" /* step 2 */                                                                     \
-        FS_PK_F(FS_R1, "s[36:37]") FS_NOP FS_PK_MA(FS_R1) FS_PK_MB(FS_R1) FS_NOP FS_PK_P FS_NOP FS_PK_A(FS_R2)      \
-        FS_NOP /* steps 3, 4 + the tests of w2 = the verdict of trip 1 */                                           \
-        FS_PK_F(FS_R2, "s[40:41]") FS_T_X("v52", "v53") FS_PK_MA(FS_R2) FS_PK_MB(FS_R2) FS_T_N("v52", "v53")        \
-        FS_PK_P FS_T_L FS_PK_A(FS_R3) FS_T_C1                                                                       \
-        FS_PK_F(FS_R3, "s[44:45]") FS_T_W FS_PK_MA(FS_R3) FS_PK_MB(FS_R3) FS_T_C2 FS_PK_P FS_T_O                    \
-        "s_cbranch_scc1 .Lfs_f1_%=\n\t" FS_PK_A(FS_R0) FS_NOP /* steps 5, 6 + the tests of w4 (trip 2) */           \
-        FS_PK_F(FS_R0, "s[48:49]") FS_T_X("v48", "v49") FS_PK_MA(FS_R0) FS_PK_MB(FS_R0) FS_T_N("v48", "v49")        \
-        FS_PK_P FS_T_L FS_PK_A(FS_R1) FS_T_C1                                                                       \
-        FS_PK_F(FS_R1, "s[52:53]") FS_T_W FS_PK_MA(FS_R1) FS_PK_MB(FS_R1) FS_T_C2 FS_PK_P FS_T_O                    \
-        "s_cbranch_scc1 .Lfs_f2_%=\n\t" /* the second block's test: max(max|w4|, max|dc|) against entry 4's .w */   \
-        "v_max_i32_e32 v62, v60, %[imdc]\n\t" FS_PK_A(FS_R2) "v_add_u32_e32 v62, v62, %[esh]\n\t"                   \
-        /* steps 7, 8 + the tests of w6 (trip 3) */                                                                 \
-        FS_PK_F(FS_R2, "s[56:57]") "v_cmp_lt_i32_e64 %[m], s51, v62\n\t" FS_PK_MA(FS_R2) FS_PK_MB(FS_R2)            \
-        "s_cmp_lg_u64 %[m], 0\n\t" FS_PK_P "s_cbranch_scc1 .Lfs_blk_%=\n\t" FS_PK_A(FS_R3) FS_T_X("v52", "v53")     \
-        FS_PK_F(FS_R3, "s[60:61]") FS_T_N("v52", "v53") FS_PK_MA(FS_R3) FS_PK_MB(FS_R3) FS_T_L FS_PK_P FS_T_C1      \
-        FS_T_W FS_T_C2 FS_T_O "s_cbranch_scc1 .Lfs_f3_%=\n\t" FS_PK_A(FS_R0)                                        \
-        "s_mov_b64 %[z0], s[64:65]\n\t" /* the tests of w8 (trip 4) */                                              \
-        FS_T_X("v48", "v49") FS_T_N("v48", "v49") FS_T_L FS_T_C1 FS_T_W FS_T_C2 FS_T_O                              \
-        "s_cbranch_scc1 .Lfs_f4_%=\n\t"                                                                             \
-        "s_mov_b32 %[pw], s67\n\t"                                                                                  \
-        "s_add_u32 %[c], %[c], 8\n\t"                                                                               \
-        "s_add_u32 s68, s68, 0x80\n\t"                                                                              \
-        "s_addc_u32 s69, s69, 0\n\t"                                                                                \
-        "s_branch .Lfs_loop_%=\n"                                                                                   \
-        ".Lfs_out_%=:\n\t" /* the block at the current position needs its tests, or fewer than 8 steps are left */  \
-        "s_mov_b32 %[st], 0\n\t"                                                                                    \
-        "s_branch .Lfs_end_%=\n"                                                                                    \
-        ".Lfs_blk_%=:\n\t" /* the same after the first block */                                                     \
-        "s_mov_b32 %[st], 0\n\t"                                                                                    \
-        "s_mov_b64 %[z0], s[48:49]\n\t"                                                                             \
-        "s_mov_b32 %[pw], s51\n\t"                                                                                  \
-        "s_add_u32 %[c], %[c], 4\n\t"                                                                               \
-        "s_add_u32 s68, s68, 0x40\n\t"                                                                              \
-        "s_addc_u32 s69, s69, 0\n\t"                                                                                \
-        "s_branch .Lfs_end_%=\n"                                                                                    \
-        ".Lfs_f1_%=:\n\t"                                                                                           \
-        "s_mov_b32 %[st], 1\n\t"                                                                                    \
-        "s_mov_b32 %[pw], s38\n\t"                                                                                  \
-        "s_branch .Lfs_end_%=\n"                                                                                    \
-        ".Lfs_f2_%=:\n\t"                                                                                           \
-        "s_mov_b32 %[st], 2\n\t"                                                                                    \
-        "s_mov_b32 %[pw], s46\n\t"                                                                                  \
-        "s_add_u32 %[c], %[c], 2\n\t"                                                                               \
-        "s_branch .Lfs_end_%=\n"                                                                                    \
-        ".Lfs_f3_%=:\n\t"                                                                                           \
-        "s_mov_b32 %[st], 1\n\t"                                                                                    \
-        "s_mov_b32 %[pw], s54\n\t"                                                                                  \
-        "s_add_u32 %[c], %[c], 4\n\t"                                                                               \
-        "s_branch .Lfs_end_%=\n"                                                                                    \
-        ".Lfs_f4_%=:\n\t"                                                                                           \
-        "s_mov_b32 %[st], 2\n\t"                                                                                    \
-        "s_mov_b32 %[pw], s62\n\t"                                                                                  \
-        "s_add_u32 %[c], %[c], 6\n"                                                                                 \
-        ".Lfs_end_%=:"                                                                                              \
-        : "+{v[48:49]}"(wv), "={v[50:51]}"(r1), "={v[52:53]}"(r2), "={v[54:55]}"(r3), "={v[56:57]}"(ts_),           \
-          "={v[58:59]}"(ta_), "+{v60}"(mxS), "={v61}"(tn_), "={v62}"(tl_), [m] "=&s"(msk_), [st] "=&s"(st),         \
-          [pw] "+s"(pwi), [z0] "+s"(zS), [c] "+s"(cs), "+{s[68:69]}"(zpu)                                           \
-        : [se] "v"(sE2), [dc] "v"(dcs), [esh] "v"(Esh), [imdc] "v"(imdc), [rl] "s"(rl)                              \
-        : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50",  \
-          "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65",  \
-          "s66", "s67", "vcc", "scc")
                             f2 wv = w0;
                             uint32_t cs = 0;
                             const uint32_t rl = (uint32_t)__builtin_amdgcn_readfirstlane((int)run_len);
@@ -1043,9 +1072,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                                     f2 r1, r2, r3, ts_, ta_;
                                     float tn_, tl_;
                                     uint64_t msk_;
-                                    int st;
+                                    int st, pf_, pg_, ph_;
                                     const uint32_t c_in = cs;
-                                    FS_FAST_LOOP;
+                                    FS_FAST_LOOP(FS_PF_NONE);
                                     st = __builtin_amdgcn_readfirstlane(st); // (asm results count as divergent)
                                     cs = (uint32_t)__builtin_amdgcn_readfirstlane((int)cs);
                                     pwi = __builtin_amdgcn_readfirstlane(pwi);
@@ -1108,27 +1137,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                                     break;
                                 }
                             }
-#undef FS_FAST_LOOP
-#undef FS_PK_F
-#undef FS_PK_MA
-#undef FS_PK_MB
-#undef FS_PK_P
-#undef FS_PK_A
-#undef FS_R0
-#undef FS_R1
-#undef FS_R2
-#undef FS_R3
-#undef FS_T_X
-#undef FS_T_N
-#undef FS_T_L
-#undef FS_T_W
-#undef FS_T_C1
-#undef FS_T_C2
-#undef FS_T_O
-#undef FS_NOP
-#undef FS_STEP_ARITH
-#undef FS_STEP_BOUND
-#undef FS_STEP_SHAPE
                             }
                         } else {
                             // per-lane orbit positions: one 12-byte vector load per step from a wave-uniform base plus a
@@ -1196,6 +1204,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                                 c_pt += c;
                                 c_scaled += c;
                                 c_runs++;
+                                c_wstart++;
+                                if (c < 8u)
+                                    c_wshort++;
                             }
                             const float4 zc = zq[ref];
                             Zcm = (f2){zc.x, zc.y};
@@ -1469,6 +1480,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
             const uint32_t cp = __shfl_down(c_pass, off), cg = __shfl_down(c_generic, off);
             c_pass = cp > c_pass ? cp : c_pass;
             c_generic = cg > c_generic ? cg : c_generic;
+            const uint32_t we = __shfl_down(c_wentry, off), ws = __shfl_down(c_wstart, off), wh = __shfl_down(c_wshort, off);
+            c_wentry = we > c_wentry ? we : c_wentry;
+            c_wstart = ws > c_wstart ? ws : c_wstart;
+            c_wshort = wh > c_wshort ? wh : c_wshort;
+            for (int i = 0; i < 4; i++) {
+                const uint32_t y = __shfl_down(c_why[i], off);
+                c_why[i] = y > c_why[i] ? y : c_why[i];
+            }
         }
         if ((threadIdx.x & 63) == 0) {
             atomicAdd((unsigned long long *)&A.stats[5], (unsigned long long)c_careful);
@@ -1478,6 +1497,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
             atomicAdd((unsigned long long *)&A.stats[9], (unsigned long long)c_blk_tested);
             atomicAdd((unsigned long long *)&A.stats[10], (unsigned long long)c_pass);
             atomicAdd((unsigned long long *)&A.stats[11], (unsigned long long)c_generic);
+            atomicAdd((unsigned long long *)&A.stats[12], (unsigned long long)c_wentry);
+            atomicAdd((unsigned long long *)&A.stats[13], (unsigned long long)c_wstart);
+            atomicAdd((unsigned long long *)&A.stats[14], (unsigned long long)c_wshort);
+            for (int i = 0; i < 4; i++)
+                atomicAdd((unsigned long long *)&A.stats[16 + i], (unsigned long long)c_why[i]);
         }
     }
 }
@@ -2161,76 +2185,75 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                     bool failed;
                     const uint32_t ref_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)RefIteration);
                     if (__builtin_amdgcn_ballot_w64(RefIteration != ref_u) == 0ull) {
-                        // Entries through the scalar cache (all lanes read the same ones), eight (two 64-byte lines) per
-                        // body.  Scalar loads return out of order, so the only wait there is waits for all of them -- the
-                        // next body's eight are therefore requested right AFTER this body's wait, into a second register
-                        // set, and have the whole body to arrive (two bodies per loop trip, sets A and B).  A wave that is
-                        // alone on its SIMD -- the interior pixels' 4.7 M-step chains that decide C2's frame time -- no
-                        // longer stalls on an L2 round trip every eight steps.
-                        // The exit tests of a body's four trips are branched on ONCE, after the body (their compares and votes
-                        // then sit between the arithmetic of later steps instead of standing, with a branch each, between
-                        // two dependent chains); the states are named per trip, so the roll-back to the first failing
-                        // trip's start needs no copy, and a failing body costs at most six wasted steps -- runs of the
-                        // pixels this loop is shaped for average 227 steps.
+                        // Entries through the scalar cache (all lanes read the same ones): the hand-scheduled untested loop
+                        // of k_lav2_hdr32_fast (FS_FAST_LOOP; here with the next body's cache lines requested a body ahead:
+                        // a wave that is alone on its SIMD -- the interior pixels' 4.7 M-step chains that decide C2's frame
+                        // time -- pays per instruction issued and for every L2 round trip it waits out), and four-step
+                        // blocks with their bound tests where the block test fails.  A failed trip ends the run at its start
+                        // state (keeping its first step loses here, see above).
                         const float4 *zpu = zs + ref_u + 1;
-                        // (each set of eight 16-byte entries as two 64-byte scalar loads: s_load_dwordx16 takes any
-                        // dword-aligned address, and the lone wave this loop is shaped for pays per instruction issued)
-                        typedef float f16 __attribute__((ext_vector_type(16)));
-                        f16 aL, aH, bL, bH;
-#define FS_SLOAD8(S, P)                                                                                             \
-    asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(S##L) : "s"(P));                                              \
-    asm volatile("s_load_dwordx16 %0, %1, 0x40" : "=s"(S##H) : "s"(P));
-#define FS_SWAIT8(S) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(S##L), "+s"(S##H));
-#define FS_SBODY(S, NEXT)                                                                                           \
-    {                                                                                                               \
-        FS_SWAIT8(S)                                                                                                \
-        FS_SLOAD8(NEXT, zpu + 8)                                                                                    \
-        const f4 S##0 = S##L.s0123, S##1 = S##L.s4567, S##2 = S##L.s89ab, S##3 = S##L.scdef;                        \
-        const f4 S##4 = S##H.s0123, S##5 = S##H.s4567, S##6 = S##H.s89ab, S##7 = S##H.scdef;                        \
-        f2 t1, u1, w2_, z2_, t3, u3, w4_, z4_, t5, u5, w6_, z6_, t7, u7, w8_, z8_;                                  \
-        uint64_t v1 = 0, v2 = 0, v3 = 0, v4 = 0;                                                                    \
-        FS_SCALED_STEP(w0, z0, t1, u1, a##S, v1, false, (void)0, (S##0).x, (S##0).y, (S##0).z);                     \
-        FS_SCALED_STEP(t1, u1, w2_, z2_, b##S, v1, true, (void)0, (S##1).x, (S##1).y, (S##1).z);                    \
-        FS_SCALED_STEP(w2_, z2_, t3, u3, c##S, v2, false, (void)0, (S##2).x, (S##2).y, (S##2).z);                   \
-        FS_SCALED_STEP(t3, u3, w4_, z4_, d##S, v2, true, (void)0, (S##3).x, (S##3).y, (S##3).z);                    \
-        FS_SCALED_STEP(w4_, z4_, t5, u5, e##S, v3, false, (void)0, (S##4).x, (S##4).y, (S##4).z);                   \
-        FS_SCALED_STEP(t5, u5, w6_, z6_, f##S, v3, true, (void)0, (S##5).x, (S##5).y, (S##5).z);                    \
-        FS_SCALED_STEP(w6_, z6_, t7, u7, g##S, v4, false, (void)0, (S##6).x, (S##6).y, (S##6).z);                   \
-        FS_SCALED_STEP(t7, u7, w8_, z8_, h##S, v4, true, (void)0, (S##7).x, (S##7).y, (S##7).z);                    \
-        if (((v1 | v2) | (v3 | v4)) != 0ull) {                                                                      \
-            /* the first failing trip ends the run at its start state (later trips ran on whatever it produced) */  \
-            failed = true;                                                                                          \
-            if (v1 != 0ull)                                                                                         \
-                wO = w0;                                                                                            \
-            else if (v2 != 0ull)                                                                                    \
-                wO = w2_, c += 2;                                                                                   \
-            else if (v3 != 0ull)                                                                                    \
-                wO = w4_, c += 4;                                                                                   \
-            else                                                                                                    \
-                wO = w6_, c += 6;                                                                                   \
-            break;                                                                                                  \
-        }                                                                                                           \
-        c += 8;                                                                                                     \
-        zpu += 8;                                                                                                   \
-        w0 = w8_, z0 = z8_;                                                                                         \
-        if (c >= run_len) {                                                                                         \
-            failed = false;                                                                                         \
-            break;                                                                                                  \
-        }                                                                                                           \
-    }
-                        FS_SLOAD8(a, zpu)
+                        const int imdc = __float_as_int(__builtin_fmaxf(__builtin_fabsf(dcs.x), __builtin_fabsf(dcs.y)));
+                        float mxS = mx0;
+                        int pwi = __builtin_amdgcn_readfirstlane(__float_as_int(e0.w));
+                        f2 zS = {__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(e0.x))),
+                                 __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(e0.y)))};
+                        f2 wv = w0;
+                        uint32_t cs = 0;
+                        const uint32_t rl = (uint32_t)__builtin_amdgcn_readfirstlane((int)run_len);
                         for (;;) {
-                            FS_SBODY(a, b)
-                            FS_SBODY(b, a)
+                            {
+                                f2 r1, r2, r3, ts_, ta_;
+                                float tn_, tl_;
+                                uint64_t msk_;
+                                int st, pf_, pg_, ph_;
+                                FS_FAST_LOOP(FS_PF_NEXT_BODY);
+                                st = __builtin_amdgcn_readfirstlane(st); // (asm results count as divergent)
+                                cs = (uint32_t)__builtin_amdgcn_readfirstlane((int)cs);
+                                pwi = __builtin_amdgcn_readfirstlane(pwi);
+                                if (st != 0) {
+                                    c = cs, wO = st == 1 ? wv : r2, failed = true;
+                                    break;
+                                }
+                            }
+                            if (cs >= rl) {
+                                c = cs, wO = wv, failed = false;
+                                break;
+                            }
+                            typedef float f16 __attribute__((ext_vector_type(16)));
+                            f16 U;
+                            asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(U) : "s"(zpu));
+                            f2 tp_, tq_, w4;
+                            FS_STEP_ARITH(wv, zS, tp_, a)
+                            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(U), "+v"(tp_));
+                            const f4 ua = U.s0123, ub = U.s4567, uc = U.s89ab, ud = U.scdef;
+                            const f2 up_ = {ua.x, ua.y}, uq_ = {uc.x, uc.y};
+                            uint64_t vp_ = 0, vq_ = 0;
+                            FS_STEP_BOUND(tp_, a, vp_, ua.z)
+                            FS_STEP_ARITH(tp_, up_, w2, b)
+                            FS_STEP_BOUND(w2, b, vp_, ub.z)
+                            FS_STEP_SHAPE(w2, b, vp_)
+                            if (vp_ != 0ull) {
+                                c = cs, wO = wv, failed = true;
+                                break;
+                            }
+                            z2 = (f2){ub.x, ub.y};
+                            FS_STEP_ARITH(w2, z2, tq_, c_)
+                            FS_STEP_BOUND(tq_, c_, vq_, uc.z)
+                            FS_STEP_ARITH(tq_, uq_, w4, d)
+                            FS_STEP_BOUND(w4, d, vq_, ud.z)
+                            FS_STEP_SHAPE(w4, d, vq_)
+                            if (vq_ != 0ull) {
+                                c = cs + 2, wO = w2, failed = true;
+                                break;
+                            }
+                            cs += 4;
+                            zpu += 4;
+                            wv = w4, mxS = mx_d, zS = (f2){ud.x, ud.y}, pwi = __float_as_int(ud.w);
+                            if (cs >= rl) {
+                                c = cs, wO = wv, failed = false;
+                                break;
+                            }
                         }
-                        if (!failed)
-                            wO = w0;
-                        // whichever body the run left from, the other set's request may still be in flight: it lands
-                        // before its registers are used for anything else
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(aL), "s"(aH), "s"(bL), "s"(bH));
-#undef FS_SBODY
-#undef FS_SWAIT8
-#undef FS_SLOAD8
                     } else {
                         const uint32_t lane_off = (RefIteration + 1) * 16u;
                         const float4 *zp = zs;
