@@ -462,15 +462,15 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
 // ------------------------------------------------------------------------------------------------
 // The scalar-cache path of the scaled runs (k_lav2_hdr32_fast and the perturbation-only float path of k_perturb_scalar):
 // step pieces of the tested C++ block and the hand-scheduled untested loop.  Names used from the enclosing scope: sE2, dcs,
-// Esh, imdc, wv, mxS, pwi, zS, cs, zpu, rl.
+// Esh, imdc, wv, mxS, pwi, zS, off, zpb, lim8 (and the asm's outputs).
 // PF of FS_FAST_LOOP: FS_PF_NONE, or FS_PF_NEXT_BODY = one dword of each 64-byte line of the NEXT body's entries (three:
 // entries are 16-byte aligned only), requested right after this body's wait, so that the next body's loads hit the scalar
 // cache -- for waves that run alone on their SIMD (C2's interior pixels), where the L2 round trip per body is not hidden.
 #define FS_PF_NONE ""
 #define FS_PF_NEXT_BODY                                                                                             \
-    "s_load_dword %[pf], s[68:69], 0x80\n\t"                                                                        \
-    "s_load_dword %[pg], s[68:69], 0xc0\n\t"                                                                        \
-    "s_load_dword %[ph], s[68:69], 0xfc\n\t"
+    "s_load_dword %[pf], s[68:69], %[off] offset:0x80\n\t"                                                          \
+    "s_load_dword %[pg], s[68:69], %[off] offset:0xc0\n\t"                                                          \
+    "s_load_dword %[ph], s[68:69], %[off] offset:0xfc\n\t"
 #define FS_STEP_ARITH(W_, Z_, NW_, T)                                                                               \
     const f2 s_##T = __builtin_elementwise_fma(W_, sE2, Z_);                                                        \
     const f2 pa_##T = W_.xx * s_##T;                                                                                \
@@ -494,8 +494,10 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
 // second step is written over the failed trip's start state: everything a failed trip needs is still in its registers,
 // and what was computed past it is dropped.
 // The loop runs inside the statement: bodies of eight steps while the block test passes and eight steps are left
-// (status 0 on the way out: state in v[48:49], max|w| in v60, counters advanced); status 1 / 2: the first / second trip
-// of a block failed (start state / first step: v48 / v50, v52 / v54; `pw` = the first arrival's bound then).
+// (status 0 on the way out: state in v[48:49], max|w| in v60, `off` = 16 bytes per step taken so far, s[64:65] / s67 =
+// 2Z / block bound of the entry the state is at); status 1 / 2: the first / second trip of a block failed (start state /
+// first step: v48 / v50, v52 / v54; `off` counts the steps before the trip, `eb` = the first arrival's bound).  The
+// tests of a body's LAST trip run in the wait states of the next body's first two steps -- or on the way out.
 #define FS_PK_F(W, Z) "v_pk_fma_f32 v[56:57], " W ", %[se], " Z "\n\t"
 #define FS_PK_MA(W) "v_pk_mul_f32 v[58:59], " W ", v[56:57] op_sel_hi:[0,1]\n\t"
 #define FS_PK_MB(W) "v_pk_mul_f32 v[56:57], " W ", v[56:57] op_sel:[1,1] op_sel_hi:[1,0]\n\t"
@@ -515,21 +517,23 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
 #define FS_NOP "s_nop 0\n\t"
 #define FS_FAST_LOOP(PF)                                                                                              \
     asm volatile(                                                                                                   \
-        ".Lfs_loop_%=:\n\t" /* eight steps left?  the first block's test: max(max|w|, max|dc|) against .w */        \
+        ".Lfs_loop_%=:\n\t" /* eight steps left?  the first block's test: max(max|w|, max|dc|) against .w (s67) */  \
         "v_max_i32_e32 v62, v60, %[imdc]\n\t"                                                                       \
-        "s_add_u32 %[st], %[c], 8\n\t"                                                                              \
+        "s_cmp_gt_u32 %[off], %[lim8]\n\t"                                                                          \
         "v_add_u32_e32 v62, v62, %[esh]\n\t"                                                                        \
-        "s_cmp_gt_u32 %[st], %[rl]\n\t"                                                                             \
         "s_cbranch_scc1 .Lfs_out_%=\n\t"                                                                            \
-        "v_cmp_lt_i32_e64 %[m], %[pw], v62\n\t"                                                                     \
+        "v_cmp_lt_i32_e64 %[m], s67, v62\n\t"                                                                       \
         "s_cmp_lg_u64 %[m], 0\n\t"                                                                                  \
-        "s_cbranch_scc1 .Lfs_out_%=\n\t"                                                                            \
-        "s_load_dwordx16 s[36:51], s[68:69], 0x0\n\t"                                                               \
-        "s_load_dwordx16 s[52:67], s[68:69], 0x40\n\t" /* step 1: needs the previous entry only */                  \
-        FS_PK_F(FS_R0, "%[z0]") FS_NOP FS_PK_MA(FS_R0) FS_PK_MB(FS_R0) FS_NOP FS_PK_P FS_NOP FS_PK_A(FS_R1)         \
-        "s_waitcnt lgkmcnt(0)\n\t" PF /* step 2 */                                                                  \
-        FS_PK_F(FS_R1, "s[36:37]") FS_NOP FS_PK_MA(FS_R1) FS_PK_MB(FS_R1) FS_NOP FS_PK_P FS_NOP FS_PK_A(FS_R2)      \
-        FS_NOP /* steps 3, 4 + the tests of w2 = the verdict of trip 1 */                                           \
+        "s_cbranch_scc1 .Lfs_out_%=\n\t" /* steps 1, 2 (the first needs the previous entry only: s[64:65], read      \
+           before the loads that replace it are issued) + the pending tests of the state itself = the verdict of    \
+           the previous body's last trip, whose registers are written over only after it */                         \
+        FS_PK_F(FS_R0, "s[64:65]") "s_mov_b32 %[eb], s62\n\t"                                                       \
+        "s_load_dwordx16 s[36:51], s[68:69], %[off]\n\t"                                                            \
+        "s_load_dwordx16 s[52:67], s[68:69], %[off] offset:0x40\n\t"                                                \
+        FS_PK_MA(FS_R0) FS_PK_MB(FS_R0) FS_T_N("v48", "v49") FS_PK_P FS_T_L FS_PK_A(FS_R1) FS_T_C1                  \
+        "s_waitcnt lgkmcnt(0)\n\t" PF                                                                               \
+        FS_PK_F(FS_R1, "s[36:37]") FS_T_W FS_PK_MA(FS_R1) FS_PK_MB(FS_R1) FS_T_C2 FS_PK_P FS_T_O                    \
+        "s_cbranch_scc1 .Lfs_fp_%=\n\t" FS_PK_A(FS_R2) FS_NOP /* steps 3, 4 + the tests of w2 = trip 1 */           \
         FS_PK_F(FS_R2, "s[40:41]") FS_T_X("v52", "v53") FS_PK_MA(FS_R2) FS_PK_MB(FS_R2) FS_T_N("v52", "v53")        \
         FS_PK_P FS_T_L FS_PK_A(FS_R3) FS_T_C1                                                                       \
         FS_PK_F(FS_R3, "s[44:45]") FS_T_W FS_PK_MA(FS_R3) FS_PK_MB(FS_R3) FS_T_C2 FS_PK_P FS_T_O                    \
@@ -544,53 +548,46 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
         "s_cmp_lg_u64 %[m], 0\n\t" FS_PK_P "s_cbranch_scc1 .Lfs_blk_%=\n\t" FS_PK_A(FS_R3) FS_T_X("v52", "v53")     \
         FS_PK_F(FS_R3, "s[60:61]") FS_T_N("v52", "v53") FS_PK_MA(FS_R3) FS_PK_MB(FS_R3) FS_T_L FS_PK_P FS_T_C1      \
         FS_T_W FS_T_C2 FS_T_O "s_cbranch_scc1 .Lfs_f3_%=\n\t" FS_PK_A(FS_R0)                                        \
-        "s_mov_b64 %[z0], s[64:65]\n\t" /* the tests of w8 (trip 4) */                                              \
-        FS_T_X("v48", "v49") FS_T_N("v48", "v49") FS_T_L FS_T_C1 FS_T_W FS_T_C2 FS_T_O                              \
-        "s_cbranch_scc1 .Lfs_f4_%=\n\t"                                                                             \
-        "s_mov_b32 %[pw], s67\n\t"                                                                                  \
-        "s_add_u32 %[c], %[c], 8\n\t"                                                                               \
-        "s_add_u32 s68, s68, 0x80\n\t"                                                                              \
-        "s_addc_u32 s69, s69, 0\n\t"                                                                                \
-        "s_branch .Lfs_loop_%=\n"                                                                                   \
-        ".Lfs_out_%=:\n\t" /* the block at the current position needs its tests, or fewer than 8 steps are left */  \
+        "s_add_u32 %[off], %[off], 0x80\n\t" /* max|w8| for the next block test; its other tests ride in the next body */ \
+        FS_T_X("v48", "v49") "s_branch .Lfs_loop_%=\n"                                                              \
+        ".Lfs_out_%=:\n\t" /* the block here needs its bound tests, or fewer than 8 steps are left: the pending tests */ \
+        "s_mov_b32 %[eb], s62\n\t" FS_T_N("v48", "v49") FS_T_L FS_T_C1 FS_T_W FS_T_C2 FS_T_O                        \
+        "s_cbranch_scc1 .Lfs_fp_%=\n\t"                                                                             \
         "s_mov_b32 %[st], 0\n\t"                                                                                    \
         "s_branch .Lfs_end_%=\n"                                                                                    \
-        ".Lfs_blk_%=:\n\t" /* the same after the first block */                                                     \
+        ".Lfs_blk_%=:\n\t" /* the same after the first block (no verdict is pending there) */                       \
         "s_mov_b32 %[st], 0\n\t"                                                                                    \
-        "s_mov_b64 %[z0], s[48:49]\n\t"                                                                             \
-        "s_mov_b32 %[pw], s51\n\t"                                                                                  \
-        "s_add_u32 %[c], %[c], 4\n\t"                                                                               \
-        "s_add_u32 s68, s68, 0x40\n\t"                                                                              \
-        "s_addc_u32 s69, s69, 0\n\t"                                                                                \
+        "s_mov_b64 s[64:65], s[48:49]\n\t"                                                                          \
+        "s_mov_b32 s67, s51\n\t"                                                                                    \
+        "s_add_u32 %[off], %[off], 0x40\n\t"                                                                        \
+        "s_branch .Lfs_end_%=\n"                                                                                    \
+        ".Lfs_fp_%=:\n\t" /* the previous body's last trip: start state v[52:53], first step v[54:55] */            \
+        "s_mov_b32 %[st], 2\n\t"                                                                                    \
+        "s_sub_u32 %[off], %[off], 0x20\n\t"                                                                        \
         "s_branch .Lfs_end_%=\n"                                                                                    \
         ".Lfs_f1_%=:\n\t"                                                                                           \
         "s_mov_b32 %[st], 1\n\t"                                                                                    \
-        "s_mov_b32 %[pw], s38\n\t"                                                                                  \
+        "s_mov_b32 %[eb], s38\n\t"                                                                                  \
         "s_branch .Lfs_end_%=\n"                                                                                    \
         ".Lfs_f2_%=:\n\t"                                                                                           \
         "s_mov_b32 %[st], 2\n\t"                                                                                    \
-        "s_mov_b32 %[pw], s46\n\t"                                                                                  \
-        "s_add_u32 %[c], %[c], 2\n\t"                                                                               \
+        "s_mov_b32 %[eb], s46\n\t"                                                                                  \
+        "s_add_u32 %[off], %[off], 0x20\n\t"                                                                        \
         "s_branch .Lfs_end_%=\n"                                                                                    \
         ".Lfs_f3_%=:\n\t"                                                                                           \
         "s_mov_b32 %[st], 1\n\t"                                                                                    \
-        "s_mov_b32 %[pw], s54\n\t"                                                                                  \
-        "s_add_u32 %[c], %[c], 4\n\t"                                                                               \
-        "s_branch .Lfs_end_%=\n"                                                                                    \
-        ".Lfs_f4_%=:\n\t"                                                                                           \
-        "s_mov_b32 %[st], 2\n\t"                                                                                    \
-        "s_mov_b32 %[pw], s62\n\t"                                                                                  \
-        "s_add_u32 %[c], %[c], 6\n"                                                                                 \
-        ".Lfs_end_%=:\n\t"                                                                                           \
-        "s_waitcnt lgkmcnt(0)" /* (PF: nothing stays in flight) */                                                  \
+        "s_mov_b32 %[eb], s54\n\t"                                                                                  \
+        "s_add_u32 %[off], %[off], 0x40\n"                                                                          \
+        ".Lfs_end_%=:\n\t"                                                                                          \
+        "s_waitcnt lgkmcnt(0)" /* (a failed pending trip leaves after the loads: nothing stays in flight) */        \
         : "+{v[48:49]}"(wv), "={v[50:51]}"(r1), "={v[52:53]}"(r2), "={v[54:55]}"(r3), "={v[56:57]}"(ts_),           \
           "={v[58:59]}"(ta_), "+{v60}"(mxS), "={v61}"(tn_), "={v62}"(tl_), [m] "=&s"(msk_), [st] "=&s"(st),         \
-          [pw] "+s"(pwi), [z0] "+s"(zS), [c] "+s"(cs), "+{s[68:69]}"(zpu), [pf] "=&s"(pf_),                         \
-          [pg] "=&s"(pg_), [ph] "=&s"(ph_)                                                                          \
-        : [se] "v"(sE2), [dc] "v"(dcs), [esh] "v"(Esh), [imdc] "v"(imdc), [rl] "s"(rl)                              \
+          [eb] "=&s"(ebo), "+{s67}"(pwi), "+{s[64:65]}"(zS), [off] "+s"(off), [pf] "=&s"(pf_), [pg] "=&s"(pg_),     \
+          [ph] "=&s"(ph_)                                                                                           \
+        : [se] "v"(sE2), [dc] "v"(dcs), [esh] "v"(Esh), [imdc] "v"(imdc), [lim8] "s"(lim8), "{s[68:69]}"(zpb)       \
         : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50",  \
-          "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65",  \
-          "s66", "s67", "vcc", "scc")
+          "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s66", "vcc",  \
+          "scc")
 
 // ------------------------------------------------------------------------------------------------
 // LAv2, T = HDRFloat<float>: tuned perturbation loop.  Same prologue (AT + LA stages) and the same results, bit for
@@ -1063,6 +1060,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                             f2 wv = w0;
                             uint32_t cs = 0;
                             const uint32_t rl = (uint32_t)__builtin_amdgcn_readfirstlane((int)run_len);
+                            const uint32_t lim8 = (rl << 4) - 0x80u; // run lengths are 16 / 64 / 256 steps
+                            const float4 *const zpb = zpu;
                             for (;;) {
                                 {
                                     // the untested bodies, as long as they last: status 0 = stopped in front of a block
@@ -1072,16 +1071,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                                     f2 r1, r2, r3, ts_, ta_;
                                     float tn_, tl_;
                                     uint64_t msk_;
-                                    int st, pf_, pg_, ph_;
+                                    int st, ebo, pf_, pg_, ph_;
                                     const uint32_t c_in = cs;
+                                    uint32_t off = cs << 4;
                                     FS_FAST_LOOP(FS_PF_NONE);
                                     st = __builtin_amdgcn_readfirstlane(st); // (asm results count as divergent)
-                                    cs = (uint32_t)__builtin_amdgcn_readfirstlane((int)cs);
+                                    cs = (uint32_t)__builtin_amdgcn_readfirstlane((int)off) >> 4;
                                     pwi = __builtin_amdgcn_readfirstlane(pwi);
                                     if (kStats)
                                         c_blk_free += (cs - c_in) >> 2;
                                     if (st != 0) {
-                                        const float ebf = __int_as_float(pwi);
+                                        const float ebf = __int_as_float(__builtin_amdgcn_readfirstlane(ebo));
                                         c = cs;
                                         if (st == 1) {
                                             FS_TRIP_FAILED_NB(a, r1, ebf, wv)
@@ -1101,7 +1101,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                                     c_blk_tested++;
                                 typedef float f16 __attribute__((ext_vector_type(16)));
                                 f16 U;
-                                asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(U) : "s"(zpu));
+                                asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(U) : "s"(zpb + cs));
                                 f2 tp_, tq_;
                                 FS_STEP_ARITH(wv, zS, tp_, a)
                                 asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(U), "+v"(tp_));
@@ -1130,7 +1130,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                                     break;
                                 }
                                 cs += 4;
-                                zpu += 4;
                                 wv = w4, mxS = mx_d, zS = (f2){ud.x, ud.y}, pwi = __float_as_int(ud.w);
                                 if (cs >= rl) {
                                     c = cs, wO = wv, failed = false;
@@ -2200,15 +2199,18 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                         f2 wv = w0;
                         uint32_t cs = 0;
                         const uint32_t rl = (uint32_t)__builtin_amdgcn_readfirstlane((int)run_len);
+                        const uint32_t lim8 = (rl << 4) - 0x80u; // run lengths are 16 / 64 / 256 steps
+                        const float4 *const zpb = zpu;
                         for (;;) {
                             {
                                 f2 r1, r2, r3, ts_, ta_;
                                 float tn_, tl_;
                                 uint64_t msk_;
-                                int st, pf_, pg_, ph_;
+                                int st, ebo, pf_, pg_, ph_;
+                                uint32_t off = cs << 4;
                                 FS_FAST_LOOP(FS_PF_NEXT_BODY);
                                 st = __builtin_amdgcn_readfirstlane(st); // (asm results count as divergent)
-                                cs = (uint32_t)__builtin_amdgcn_readfirstlane((int)cs);
+                                cs = (uint32_t)__builtin_amdgcn_readfirstlane((int)off) >> 4;
                                 pwi = __builtin_amdgcn_readfirstlane(pwi);
                                 if (st != 0) {
                                     c = cs, wO = st == 1 ? wv : r2, failed = true;
@@ -2221,7 +2223,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                             }
                             typedef float f16 __attribute__((ext_vector_type(16)));
                             f16 U;
-                            asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(U) : "s"(zpu));
+                            asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(U) : "s"(zpb + cs));
                             f2 tp_, tq_, w4;
                             FS_STEP_ARITH(wv, zS, tp_, a)
                             asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(U), "+v"(tp_));
@@ -2247,7 +2249,6 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                                 break;
                             }
                             cs += 4;
-                            zpu += 4;
                             wv = w4, mxS = mx_d, zS = (f2){ud.x, ud.y}, pwi = __float_as_int(ud.w);
                             if (cs >= rl) {
                                 c = cs, wO = wv, failed = false;
