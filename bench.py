@@ -111,7 +111,7 @@ def parse():
                     help="rows of the frame timed on the CPU (0 = a per-workload multiple of the usable host threads, "
                          "about 10-30 s of CPU work)")
     ap.add_argument("--variant", default="",
-                    help="comma-separated A/B selections of fs_set_kernel_variant: literal | noscale, lds_orbit, refill "
+                    help="comma-separated A/B selections of fs_set_kernel_variant: literal | noscale, lds_orbit, refill, natural_tile_order "
                          "(default: the tuned kernels)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
@@ -244,10 +244,11 @@ def main():
     T_TAG = T_HDR2X32 if is2x32 else (T_HDR64 if is64 else T_HDR32)
     vsel = [x for x in args.variant.split(",") if x]
     if vsel:
-        unknown = set(vsel) - {"literal", "noscale", "lds_orbit", "refill"}
+        unknown = set(vsel) - {"literal", "noscale", "lds_orbit", "refill", "natural_tile_order"}
         assert not unknown, "unknown --variant entries: %s" % sorted(unknown)
         e = r.set_kernel_variant(1 if "literal" in vsel else (2 if "noscale" in vsel else 0),
-                                 lds_orbit="lds_orbit" in vsel, refill="refill" in vsel)
+                                 lds_orbit="lds_orbit" in vsel, refill="refill" in vsel,
+                                 natural_tile_order="natural_tile_order" in vsel)
         assert e == 0, GPURenderer.ConvertErrorToString(e)
     lib = r._lib
     if is2x32:

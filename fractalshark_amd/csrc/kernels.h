@@ -16,7 +16,8 @@ enum { FS_PARITY_LITERAL = 0, FS_PARITY_GPUSTAGE = 1 };
 enum { FS_VARIANT_TUNED = 0, FS_VARIANT_LITERAL = 1, FS_VARIANT_TUNED_NOSCALE = 2, FS_VARIANT_BASE_MASK = 0xff };
 // ... ORed with the A/B flags of fs_set_kernel_variant (include/fsmi355.h): orbit entries of the scaled runs through LDS
 // (k_lav2_hdr32_fast<kLds>), persistent lane-refilling launch of the BLA kernel (k_perturb_scalar<kRefill>)
-enum { FS_VARIANT_FLAG_LDS_ORBIT = 0x100, FS_VARIANT_FLAG_REFILL = 0x200, FS_VARIANT_FLAG_WIDE = 0x400 };
+enum { FS_VARIANT_FLAG_LDS_ORBIT = 0x100, FS_VARIANT_FLAG_REFILL = 0x200, FS_VARIANT_FLAG_WIDE = 0x400,
+       FS_VARIANT_FLAG_NATURAL_ORDER = 0x800 };
 
 // Frame geometry + the row-band layout of the local iteration buffer.
 struct FsFrame {
@@ -128,6 +129,13 @@ template <class F> struct FsBlaArgsT {
     const typename FsDev<F>::BLA *const *levels; // device array of device pointers, indexed by level
     uint64_t *stats;
     uint32_t *queue; // frame-wide pixel counter of the persistent (lane-refilling) launch, zeroed before each launch
+    // "long tiles first" (fsk_tile_order, perturbation only): wave w of the launch renders the 8 x 8 tile tile_order[w]
+    // (row-major tile number, 0xFFFFFFFF = none) instead of the one its block index names; null = natural order
+    const uint32_t *tile_order;
+    // probe launch: lane (x, l) runs the CENTRE pixel (8x + 4, 8l + 4) of tile (x, l) and stores its count at
+    // probe_out[l * probe_pitch + x]; the frame fields describe the real frame
+    uint32_t *probe_out;
+    uint32_t probe_pitch;
     FsFrame frame;
     FsCoordsT<F> coords;
     uint32_t orbit_count;
@@ -267,6 +275,10 @@ void fsk_decompress_orbit_hdr64(const fs_orbit_hdr64_rc *wp, uint64_t n_wp, uint
                                 fs_real_hdr64 cyLow, FsZ64 *out, hipStream_t s);
 void fsk_prepare_orbit_hdr64(const fs_orbit_hdr64 *in, FsZ64 *out, uint64_t n, hipStream_t s);
 void fsk_make_quiet_orbit(const float4 *zref, float4 *zq, uint64_t n, hipStream_t s);
+// Launch order for "long tiles first": order[0 .. n_slots) = the tiles whose probe count (their own centre's or a
+// neighbour's) reached `threshold`, in tile order, then the others, then 0xFFFFFFFF.  probe: tiles_y rows of tiles_x counts.
+void fsk_tile_order(const uint32_t *probe, uint32_t probe_pitch, uint32_t tiles_x, uint32_t tiles_y, uint32_t threshold,
+                    uint32_t *order, uint32_t n_slots, hipStream_t s);
 void fsk_lav2_hdr32(const FsLav2Args32 &A, int mode, bool stats, int variant, hipStream_t s);
 void fsk_lav2_hdr64(const FsLav2ArgsT<double> &A, int mode, bool stats, hipStream_t s);
 // IterType = uint64_t with 64-bit iteration counting (iteration caps of 2^32 and above): the literal kernel instantiated

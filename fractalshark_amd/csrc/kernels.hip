@@ -1663,6 +1663,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
     uint32_t X = 0, L = 0;
     uint64_t c_la = 0, c_pt = 0, c_px = 0;
     uint64_t c_single = 0, c_runs = 0; // probes of the perturbation-only float path (tools/c2_probe.py)
+    uint64_t c_free_steps = 0, c_tested_blocks = 0; // lane-steps inside the untested loop / tested four-step blocks (per lane)
 #ifdef FS_PROFILE_CYCLES
     // measurement build (tools/c5_phase_probe.py): shader-clock cycles and wave-passes per phase of the BLA loop, per wave.
     // The clock is read on the scalar unit, i.e. once per pass of the WAVE through the code, whatever the lane mask is.
@@ -1715,6 +1716,10 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
     bool queue_empty = false;
     auto start_pixel = [&](uint32_t x, uint32_t l) {
         X = x, L = l;
+        if (A.probe_out) { // probe launch: the centre pixel of tile (x, l)
+            x = x < 0x10000000u ? (x << 3) + 4u : 0xFFFFFFFFu;
+            l = (l << 3) + 4u;
+        }
         const uint32_t Y = global_row(A.frame, l);
         have = x < A.frame.width && l < A.frame.local_rows && Y < A.frame.height;
         if (have) {
@@ -1734,7 +1739,14 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
     };
     if constexpr (!kRefill) {
         uint32_t x, l;
-        tile_pixel(x, l);
+        if (A.tile_order) {
+            const uint32_t w = (blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+            const uint32_t t = A.tile_order[w], lane = threadIdx.x & 63u;
+            x = t != 0xFFFFFFFFu ? (t % tiles_x) * 8u + (lane & 7u) : 0xFFFFFFFFu;
+            l = (t / tiles_x) * 8u + (lane >> 3);
+        } else {
+            tile_pixel(x, l);
+        }
         start_pixel(x, l);
     }
     for (;;) {
@@ -2208,9 +2220,12 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                                 uint64_t msk_;
                                 int st, ebo, pf_, pg_, ph_;
                                 uint32_t off = cs << 4;
+                                const uint32_t c_in = cs;
                                 FS_FAST_LOOP(FS_PF_NEXT_BODY);
                                 st = __builtin_amdgcn_readfirstlane(st); // (asm results count as divergent)
                                 cs = (uint32_t)__builtin_amdgcn_readfirstlane((int)off) >> 4;
+                                if (kStats)
+                                    c_free_steps += cs - c_in;
                                 pwi = __builtin_amdgcn_readfirstlane(pwi);
                                 if (st != 0) {
                                     c = cs, wO = st == 1 ? wv : r2, failed = true;
@@ -2221,6 +2236,8 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                                 c = cs, wO = wv, failed = false;
                                 break;
                             }
+                            if (kStats)
+                                c_tested_blocks++;
                             typedef float f16 __attribute__((ext_vector_type(16)));
                             f16 U;
                             asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(U) : "s"(zpb + cs));
@@ -2652,7 +2669,10 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
         if (finished) {
             if (kStats && !kBla && iter >= n_iterations)
                 atomicAdd((unsigned long long *)&A.stats[6], 1ull); // probe: pixels that came back with the cap
-            store_iter(A.out, A.frame, L, X, iter);
+            if (A.probe_out)
+                A.probe_out[(size_t)L * A.probe_pitch + X] = (uint32_t)iter;
+            else
+                store_iter(A.out, A.frame, L, X, iter);
             have = false;
         }
     }
@@ -2661,8 +2681,11 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
     }
     if (kStats) {
         add_stats(A.stats, c_single, c_la, c_pt, c_px);
-        if (!kBla)
+        if (!kBla) {
             atomicAdd((unsigned long long *)&A.stats[7], (unsigned long long)c_runs);
+            atomicAdd((unsigned long long *)&A.stats[8], (unsigned long long)c_free_steps);
+            atomicAdd((unsigned long long *)&A.stats[9], (unsigned long long)c_tested_blocks);
+        }
     }
 #ifdef FS_PROFILE_CYCLES
     if (kStats && kBla && (threadIdx.x & 63) == 0) {
@@ -3067,9 +3090,12 @@ template <class K> static dim3 persistent_grid(K kernel, const FsFrame &f)
 // loop (505 ms), and with the action loop, which removes that divergence, 2.5x the L2 requests remain (every per-lane
 // load of a wave touches 64 different lines).
 template <class F>
-static void launch_perturb_scalar(const FsBlaArgsT<F> &A, bool use_bla, bool stats, int variant, hipStream_t s)
+static void launch_perturb_scalar(const FsBlaArgsT<F> &A_in, bool use_bla, bool stats, int variant, hipStream_t s)
 {
-    const dim3 g = tile_grid(A.frame), b(256);
+    const FsBlaArgsT<F> &A = A_in;
+    // a probe launch covers one lane per tile of the frame
+    const uint32_t ptx = (A.frame.width + 7u) >> 3, pty = (A.frame.local_rows + 7u) >> 3;
+    const dim3 g = A.probe_out ? dim3((ptx + 31) / 32, (pty + 7) / 8, 1) : tile_grid(A.frame), b(256);
     if (A.frame.wide != 0u) { // iteration cap of 2^32 or above: the instantiation that counts in 64 bits
         if (use_bla) {
             if (stats)

@@ -253,3 +253,59 @@ void fsk_gather_rows(const void *in, void *out, const uint32_t *index, uint32_t 
     gy = gy < rows ? gy : rows;
     hipLaunchKernelGGL(k_gather_rows, dim3(gx, gy), dim3(256), 0, s, (const uint4 *)in, (uint4 *)out, index, v4, rows);
 }
+
+// ------------------------------------------------------------------------------------------------
+// "Long tiles first": the launch order of a frame's 8 x 8 tiles from a probe of their centre pixels (fs_render_bla).
+// One workgroup: every thread counts the long tiles of its contiguous chunk, an LDS scan ranks the chunks, then the long
+// tiles are written in tile order, followed by the others in tile order (a stable two-way partition), followed by the
+// "no tile" filler for the launch's surplus waves.
+namespace {
+__global__ void __launch_bounds__(1024) k_tile_order(const uint32_t *__restrict__ probe, uint32_t pitch, uint32_t tiles_x,
+                                                     uint32_t tiles_y, uint32_t threshold, uint32_t *__restrict__ order,
+                                                     uint32_t n_slots)
+{
+    __shared__ uint32_t s_cnt[1024];
+    const uint32_t n = tiles_x * tiles_y, chunk = (n + 1023u) / 1024u;
+    const uint32_t lo = threadIdx.x * chunk < n ? threadIdx.x * chunk : n, hi = lo + chunk < n ? lo + chunk : n;
+    // a tile counts as long when its own centre or a neighbour's is still running: the set's boundary is ragged, and a
+    // tile next to an interior one often holds interior pixels away from its centre
+    auto is_long = [&](uint32_t i) {
+        const uint32_t tx = i % tiles_x, ty = i / tiles_x;
+        const uint32_t x0 = tx ? tx - 1 : 0, x1 = tx + 1 < tiles_x ? tx + 1 : tx, y0 = ty ? ty - 1 : 0,
+                       y1 = ty + 1 < tiles_y ? ty + 1 : ty;
+        for (uint32_t y = y0; y <= y1; y++)
+            for (uint32_t x = x0; x <= x1; x++)
+                if (probe[(size_t)y * pitch + x] >= threshold)
+                    return true;
+        return false;
+    };
+    uint32_t mine = 0;
+    for (uint32_t i = lo; i < hi; i++)
+        mine += is_long(i) ? 1u : 0u;
+    s_cnt[threadIdx.x] = mine;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) { // inclusive Hillis-Steele scan
+        const uint32_t v = threadIdx.x >= d ? s_cnt[threadIdx.x - d] : 0u;
+        __syncthreads();
+        s_cnt[threadIdx.x] += v;
+        __syncthreads();
+    }
+    const uint32_t total_long = s_cnt[1023];
+    uint32_t at_long = s_cnt[threadIdx.x] - mine; // long tiles before this chunk
+    uint32_t at_short = total_long + (lo - at_long);
+    for (uint32_t i = lo; i < hi; i++) {
+        if (is_long(i))
+            order[at_long++] = i;
+        else
+            order[at_short++] = i;
+    }
+    for (uint32_t i = n + threadIdx.x; i < n_slots; i += 1024u)
+        order[i] = 0xFFFFFFFFu;
+}
+} // namespace
+
+void fsk_tile_order(const uint32_t *probe, uint32_t probe_pitch, uint32_t tiles_x, uint32_t tiles_y, uint32_t threshold,
+                    uint32_t *order, uint32_t n_slots, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, probe, probe_pitch, tiles_x, tiles_y, threshold, order, n_slots);
+}

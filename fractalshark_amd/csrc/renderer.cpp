@@ -53,6 +53,8 @@ struct fs_renderer {
     size_t stats_words = 32;
 
     uint32_t *queue = nullptr; // pixel counter of the persistent launches (kernels.hip, k_perturb_scalar)
+    uint32_t *tile_probe = nullptr, *tile_order = nullptr; // "long tiles first" (fs_render_bla): probe counts, launch order
+    size_t tile_probe_cap = 0, tile_order_cap = 0;           // in elements
     bool stats_on = false;
     int variant = FS_VARIANT_TUNED;
 
@@ -256,6 +258,13 @@ FsFrame make_frame(const fs_renderer *r)
     f.wide = (r->variant & FS_VARIANT_FLAG_WIDE) != 0 ? 1u : 0u; // (|= cap >= 2^32 where the cap is known)
     return f;
 }
+
+// "long tiles first" (fs_render_bla, perturbation only): the probe runs each tile's centre pixel for n_iterations /
+// kTileProbeDivisor steps; on by default for an iteration limit far above the bulk of a frame's pixels and enough tiles
+// for an order to matter
+constexpr uint64_t kTileProbeDivisor = 32;
+constexpr uint64_t kTileOrderMinIterations = 1ull << 18;
+constexpr uint32_t kTileOrderMinTiles = 4096;
 
 // zq: the tuned LAv2 loop's view of the prepared orbit (same length incl. the two spare entries)
 hipError_t make_quiet_orbit(fs_renderer *r, uint64_t n)
@@ -464,6 +473,12 @@ void free_all(fs_renderer *r)
     if (r->queue)
         r_free(r, r->queue);
     r->queue = nullptr;
+    if (r->tile_probe)
+        r_free(r, r->tile_probe);
+    if (r->tile_order)
+        r_free(r, r->tile_order);
+    r->tile_probe = r->tile_order = nullptr;
+    r->tile_probe_cap = r->tile_order_cap = 0;
 
     if (r->pal)
         r_free(r, r->pal);
@@ -1776,7 +1791,45 @@ uint32_t fs_render_bla(fs_renderer *r, int type_tag, const void *coords, uint64_
             A.nlad = (const int4 *)((const char *)A.nrec + (size_t)r->bla_native_total * sizeof(FsBlaRec));
             memcpy(A.level_off, r->bla_level_off, sizeof(A.level_off));
         }
+        // Long tiles first.  A perturbation-only frame with a high iteration limit is bounded by the few waves that hold
+        // never-escaping pixels: each runs its millions of steps at the pace of a wave that is alone on its SIMD, and the
+        // frame ends that long after the LAST of them was dispatched -- later still where two of them share a SIMD.  A
+        // probe launch runs the centre pixel of every 8 x 8 tile for n_iterations / 32 steps (one lane per tile), the
+        // tiles whose centre (or a neighbour's) is still running then are launched first -- one per SIMD while there are
+        // no more of them than SIMDs -- the rest in their natural order.  Which wave renders which tile changes no pixel.
+        const uint32_t tiles_x = (r->width + 7u) / 8u, tiles_y = (r->local_rows + 7u) / 8u;
+        const uint32_t n_slots = ((tiles_x + 3u) / 4u) * 4u * tiles_y; // waves of the launch (tile_grid: 4 tiles per block)
+        const bool reorder = !use_bla && !r->stats_on && A.frame.wide == 0u && n_iterations >= kTileOrderMinIterations &&
+                             n_slots >= kTileOrderMinTiles && (r->variant & FS_VARIANT_FLAG_NATURAL_ORDER) == 0 &&
+                             (r->variant & FS_VARIANT_BASE_MASK) == FS_VARIANT_TUNED;
+        if (reorder) {
+            if (r->tile_probe_cap < (size_t)tiles_x * tiles_y) {
+                if (r->tile_probe)
+                    FS_TRY(r_free(r, r->tile_probe));
+                r->tile_probe = nullptr;
+                r->tile_probe_cap = 0;
+                FS_TRY(r_alloc(r, (void **)&r->tile_probe, (size_t)tiles_x * tiles_y * sizeof(uint32_t), kFrame));
+                r->tile_probe_cap = (size_t)tiles_x * tiles_y;
+            }
+            if (r->tile_order_cap < n_slots) {
+                if (r->tile_order)
+                    FS_TRY(r_free(r, r->tile_order));
+                r->tile_order = nullptr;
+                r->tile_order_cap = 0;
+                FS_TRY(r_alloc(r, (void **)&r->tile_order, (size_t)n_slots * sizeof(uint32_t), kFrame));
+                r->tile_order_cap = n_slots;
+            }
+        }
         TimedLaunch t(r);
+        if (reorder) {
+            FsBlaArgsT<float> P = A;
+            P.probe_out = r->tile_probe;
+            P.probe_pitch = tiles_x;
+            P.n_iterations = (uint32_t)(n_iterations / kTileProbeDivisor);
+            fsk_perturb_scalar_hdr32(P, use_bla, false, r->variant, r->compute);
+            fsk_tile_order(r->tile_probe, tiles_x, tiles_x, tiles_y, P.n_iterations, r->tile_order, n_slots, r->compute);
+            A.tile_order = r->tile_order;
+        }
         fsk_perturb_scalar_hdr32(A, use_bla, r->stats_on, r->variant, r->compute);
     } else {
         FsBlaArgsT<double> A;
@@ -2183,7 +2236,7 @@ uint32_t fs_set_kernel_variant(fs_renderer *r, int variant)
 {
     const int base = variant & FS_VARIANT_BASE_MASK, flags = variant & ~FS_VARIANT_BASE_MASK;
     if (base > FS_VARIANT_TUNED_NOSCALE ||
-        (flags & ~(FS_VARIANT_FLAG_LDS_ORBIT | FS_VARIANT_FLAG_REFILL | FS_VARIANT_FLAG_WIDE)) != 0)
+        (flags & ~(FS_VARIANT_FLAG_LDS_ORBIT | FS_VARIANT_FLAG_REFILL | FS_VARIANT_FLAG_WIDE | FS_VARIANT_FLAG_NATURAL_ORDER)) != 0)
         return hipErrorInvalidValue;
     r->variant = base | flags;
     return 0;

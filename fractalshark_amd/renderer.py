@@ -19,7 +19,7 @@ LAV2_FULL, LAV2_PO, LAV2_LAO = range(3)
 PARITY_CPU, PARITY_CPU_GPUSTAGE = range(2)
 FS_ERR_UNSUPPORTED = 10100
 # A/B flags of fs_set_kernel_variant (include/fsmi355.h)
-VARIANT_LDS_ORBIT, VARIANT_REFILL, VARIANT_WIDE_COUNTERS = 0x100, 0x200, 0x400
+VARIANT_LDS_ORBIT, VARIANT_REFILL, VARIANT_WIDE_COUNTERS, VARIANT_NATURAL_TILE_ORDER = 0x100, 0x200, 0x400, 0x800
 
 NB_THREADS_W = 16  # GPU_Render.h:116-120: part of the contract (ItersMemoryContainer pads with them)
 NB_THREADS_H = 8
@@ -320,12 +320,15 @@ class GPURenderer:
     def last_kernel_ms(self):
         return float(self._lib.fs_last_kernel_ms(self._h))
 
-    def set_kernel_variant(self, literal=False, lds_orbit=False, refill=False, wide_counters=False):
+    def set_kernel_variant(self, literal=False, lds_orbit=False, refill=False, wide_counters=False,
+                           natural_tile_order=False):
         """False / 0 (default): tuned loops; True / 1: literal transcription; 2: tuned loops without the scaled runs
         (A/B references, identical results).  lds_orbit / refill: the A/B flags FS_VARIANT_LDS_ORBIT / FS_VARIANT_REFILL
-        of include/fsmi355.h (orbit entries through LDS; persistent lane-refilling BLA launch)."""
+        of include/fsmi355.h (orbit entries through LDS; persistent lane-refilling BLA launch); natural_tile_order:
+        FS_VARIANT_NATURAL_TILE_ORDER (no "long tiles first" in the perturbation-only launch)."""
         v = (int(literal) | (VARIANT_LDS_ORBIT if lds_orbit else 0) | (VARIANT_REFILL if refill else 0) |
-             (VARIANT_WIDE_COUNTERS if wide_counters else 0))  # wide_counters: 64-bit counting kernels at any cap (tests)
+             (VARIANT_WIDE_COUNTERS if wide_counters else 0) |  # wide_counters: 64-bit counting kernels at any cap (tests)
+             (VARIANT_NATURAL_TILE_ORDER if natural_tile_order else 0))
         return self._lib.fs_set_kernel_variant(self._h, v)
 
     def enable_step_count(self, on=True):

@@ -270,8 +270,14 @@ float fs_last_kernel_ms(const fs_renderer *r);
  *   FS_VARIANT_WIDE_COUNTERS  (test switch) every entry point launches the instantiation of its kernel that counts
  *                         iterations in 64 bits -- the ones an iteration cap of 2^32 or above selects -- whatever the cap is:
  *                         lets the 64-bit kernels be compared with the CPU functions at caps a test can afford.
+ *   FS_VARIANT_NATURAL_TILE_ORDER  fs_render_bla without BLA (perturbation only, HDRFloat<float>) launches a frame's 8 x 8
+ *                         tiles in their natural order.  Default for frames with an iteration limit of 2^18 or more and
+ *                         at least 4096 tiles: the tiles that hold long-running pixels first (a probe launch runs every
+ *                         tile's centre pixel for n_iterations / 32 steps) -- which wave renders which tile
+ *                         changes no pixel.
  */
-enum { FS_VARIANT_LDS_ORBIT = 0x100, FS_VARIANT_REFILL = 0x200, FS_VARIANT_WIDE_COUNTERS = 0x400 };
+enum { FS_VARIANT_LDS_ORBIT = 0x100, FS_VARIANT_REFILL = 0x200, FS_VARIANT_WIDE_COUNTERS = 0x400,
+       FS_VARIANT_NATURAL_TILE_ORDER = 0x800 };
 uint32_t fs_set_kernel_variant(fs_renderer *r, int variant);
 uint32_t fs_enable_step_count(fs_renderer *r, int enable);
 uint32_t fs_read_step_count(fs_renderer *r, uint64_t counts[8]);

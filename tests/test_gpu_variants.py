@@ -60,7 +60,8 @@ def _bla(r, v, ob, bla, n_iter=None):
 def test_variant_selection_is_validated(renderer):
     r = renderer
     assert r._lib.fs_set_kernel_variant(r._h, 3) != 0            # no such base variant
-    assert r._lib.fs_set_kernel_variant(r._h, 0x800) != 0        # no such flag
+    assert r._lib.fs_set_kernel_variant(r._h, 0x1000) != 0       # no such flag
+    assert r._lib.fs_set_kernel_variant(r._h, 0x800) == 0        # FS_VARIANT_NATURAL_TILE_ORDER
     assert r._lib.fs_set_kernel_variant(r._h, 0x100 | 0x200) == 0
     assert r._lib.fs_set_kernel_variant(r._h, 0) == 0
 
@@ -179,6 +180,42 @@ def test_refill_variant_counts_every_pixel_once(renderer, native_libs):
             assert got["tiles"][1][k] == got["refill"][1][k]
     finally:
         r.enable_step_count(False)
+        r.set_kernel_variant(0)
+
+
+# ---- long tiles first (perturbation only)
+@pytest.mark.parametrize("w,h,bands", [(512, 512, None), (520, 517, None), (512, 1024, (8, 8, 16))])
+def test_long_tiles_first_changes_no_pixel(renderer, native_libs, w, h, bands):
+    """fs_render_bla without BLA reorders the launch of a frame's 8 x 8 tiles from a probe of their centre pixels once the
+    frame has 4096 tiles and the iteration limit is 2^18 or more (C2's regime).  Same frame with the reordering on (default)
+    and off (FS_VARIANT_NATURAL_TILE_ORDER): identical buffers, pixels at the limit included, on a square frame, a ragged
+    one and one rank's row bands; the rows around the frame's busiest tile against the oracle."""
+    v = inputs.View.builtin(5, w, h, antialiasing=1)
+    ob = inputs.Orbit(v)
+    n = 300000  # above every pixel's escape time that escapes below it; the interior pixels stop here
+    r = renderer
+    got = {}
+    try:
+        for name, natural in (("reordered", False), ("natural", True)):
+            assert r.set_kernel_variant(0, natural_tile_order=natural) == 0
+            assert r.InitializeMemory(w, h, 1, None, 0, 0, 0, False) == 0
+            if bands:
+                assert r.SetRowBands(*bands) == 0
+            assert r.ClearMemory() == 0
+            assert r.RenderPerturbBLA(None, ob, None, None, None, *_pairs(v.coords_perturb(ob)), n) == 0
+            out = r.new_iter_buffer()
+            assert r.RenderCurrent(n, out) == 0
+            assert r.SyncComputeStream() == 0
+            got[name] = out.copy()
+        assert np.array_equal(got["reordered"], got["natural"])
+        img = got["reordered"][:r.local_rows, :w]
+        assert img.max() <= n
+        if not bands:
+            y = int(np.unravel_index(int(img.argmax()), img.shape)[0])
+            y0, y1 = max(0, y - 1), min(h, y + 2)
+            ref = _oracle.bla_hdr32(v, ob, None, rows=(y0, y1), n_iterations=n)
+            assert np.array_equal(img[y0:y1], ref[y0:y1, :w])
+    finally:
         r.set_kernel_variant(0)
 
 

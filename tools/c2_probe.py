@@ -2,6 +2,7 @@
 steps alone on its SIMD.  This probe renders the frame, picks the 8-row band with the most pixels at the cap, renders
 that band alone (every wave of it is alone on its SIMD) and reports what such a wave's steps are made of:
 ns per step of the longest chain, steps per scaled run, single (careful) steps and literal wave-trips per run."""
+import ctypes as C
 import json
 import os
 import sys
@@ -40,6 +41,9 @@ for stats in (False, True):
     d = {"band_kernel_ms": round(ms, 2), "instrumented": stats, "ns_per_step_of_longest_chain": round(ms * 1e6 / v.num_iterations, 2)}
     if stats:
         st = r.read_step_count()
+        raw = (C.c_uint64 * 32)()
+        assert lib.fs_read_stats_raw(r._h, raw, 32) == 0
+        d.update({"lane_steps_in_the_untested_loop": raw[8], "lane_steps_in_tested_blocks": 4 * raw[9]})
         runs = max(1, st["scaled_runs"])
         d.update({"steps": st["perturb_steps"], "scaled_steps": st["la_steps"], "scaled_runs": st["scaled_runs"],
                   "single_steps": st["at_iterations"], "literal_wave_trips": st["careful_steps"],
