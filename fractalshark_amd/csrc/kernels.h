@@ -276,7 +276,8 @@ void fsk_decompress_orbit_hdr64(const fs_orbit_hdr64_rc *wp, uint64_t n_wp, uint
 void fsk_prepare_orbit_hdr64(const fs_orbit_hdr64 *in, FsZ64 *out, uint64_t n, hipStream_t s);
 void fsk_make_quiet_orbit(const float4 *zref, float4 *zq, uint64_t n, hipStream_t s);
 // Launch order for "long tiles first": order[0 .. n_slots) = the tiles whose probe count (their own centre's or a
-// neighbour's) reached `threshold`, in tile order, then the others, then 0xFFFFFFFF.  probe: tiles_y rows of tiles_x counts.
+// neighbour's) reached `threshold`, in tile order, then the others, then 0xFFFFFFFF; order[n_slots] = the number of long
+// tiles.  probe: tiles_y rows of tiles_x counts.
 void fsk_tile_order(const uint32_t *probe, uint32_t probe_pitch, uint32_t tiles_x, uint32_t tiles_y, uint32_t threshold,
                     uint32_t *order, uint32_t n_slots, hipStream_t s);
 void fsk_lav2_hdr32(const FsLav2Args32 &A, int mode, bool stats, int variant, hipStream_t s);

@@ -1744,6 +1744,10 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
             const uint32_t t = A.tile_order[w], lane = threadIdx.x & 63u;
             x = t != 0xFFFFFFFFu ? (t % tiles_x) * 8u + (lane & 7u) : 0xFFFFFFFFu;
             l = (t / tiles_x) * 8u + (lane >> 3);
+            // the waves of the long tiles decide when the frame ends: they ask the instruction arbiter for priority over
+            // the waves they share their SIMD with while the bulk of the frame is still being rendered
+            if (w < A.tile_order[gridDim.x * gridDim.y * (blockDim.x >> 6)] )
+                __builtin_amdgcn_s_setprio(3);
         } else {
             tile_pixel(x, l);
         }

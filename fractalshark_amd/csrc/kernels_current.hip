@@ -301,6 +301,8 @@ __global__ void __launch_bounds__(1024) k_tile_order(const uint32_t *__restrict_
     }
     for (uint32_t i = n + threadIdx.x; i < n_slots; i += 1024u)
         order[i] = 0xFFFFFFFFu;
+    if (threadIdx.x == 0)
+        order[n_slots] = total_long; // the waves below this number hold the long tiles (they ask for issue priority)
 }
 } // namespace
 

@@ -1816,7 +1816,7 @@ uint32_t fs_render_bla(fs_renderer *r, int type_tag, const void *coords, uint64_
                     FS_TRY(r_free(r, r->tile_order));
                 r->tile_order = nullptr;
                 r->tile_order_cap = 0;
-                FS_TRY(r_alloc(r, (void **)&r->tile_order, (size_t)n_slots * sizeof(uint32_t), kFrame));
+                FS_TRY(r_alloc(r, (void **)&r->tile_order, ((size_t)n_slots + 1) * sizeof(uint32_t), kFrame));
                 r->tile_order_cap = n_slots;
             }
         }
