@@ -860,15 +860,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                         const uint32_t run_len = scaled_run_length(left);
                         if (kStats) {
                             c_wentry++;
-                            // why an entry fails (wave votes; tools/scaled_share_probe.py)
-                            if (run_len == 0u)
+                            // entries that fail (wave votes; tools/scaled_share_probe.py)
+                            if (run_len == 0u || __builtin_amdgcn_ballot_w64(!start_ok) != 0ull)
                                 c_why[0]++;
-                            else if (__builtin_amdgcn_ballot_w64(!scaled_startable(e0)) != 0ull)
-                                c_why[1]++;
-                            else if (__builtin_amdgcn_ballot_w64(dsh > 30) != 0ull)
-                                c_why[2]++;
-                            else if (__builtin_amdgcn_ballot_w64(!start_ok) != 0ull)
-                                c_why[3]++;
                         }
                         if (__builtin_amdgcn_ballot_w64(!start_ok) != 0ull || run_len == 0u)
                             break;
@@ -1412,6 +1406,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                 if (kStats) {
                     c_pt++;
                     c_careful++;
+                    // what a careful pass of the wave finds (tools/scaled_share_probe.py): a rebase / an escape in some lane,
+                    // a rebase in every running lane
+                    const uint64_t act = __builtin_amdgcn_ballot_w64(true);
+                    const uint64_t rb = __builtin_amdgcn_ballot_w64(!escaped && (rebase || ref + 1 >= MaxRefIteration));
+                    if (rb != 0ull)
+                        c_why[1]++;
+                    if (rb == act)
+                        c_why[2]++;
+                    if (__builtin_amdgcn_ballot_w64(escaped) != 0ull)
+                        c_why[3]++;
                 }
                 ref++;
                 dzm = q;

@@ -40,10 +40,10 @@ for w, h in ((480, 270), (960, 540), (1920, 1080), (3840, 2160)):
                           "run_entries_tried_per_wave": round(raw[12] / (w * h / 64), 1),
                           "runs_started_per_wave": round(raw[13] / (w * h / 64), 1),
                           "runs_shorter_than_8_per_wave": round(raw[14] / (w * h / 64), 1),
-                          "entry_failures_per_wave": {"fewer_than_16_steps_left": round(raw[16] / (w * h / 64), 1),
-                                                      "entry_not_startable": round(raw[17] / (w * h / 64), 1),
-                                                      "dc_more_than_2^30_above_dz": round(raw[18] / (w * h / 64), 1),
-                                                      "ratio_of_parts": round(raw[19] / (w * h / 64), 1)},
+                          "entry_failures_per_wave": round(raw[16] / (w * h / 64), 1),
+                          "careful_passes_per_wave_with": {"a_rebase_in_some_lane": round(raw[17] / (w * h / 64), 1),
+                                                           "a_rebase_in_every_running_lane": round(raw[18] / (w * h / 64), 1),
+                                                           "an_escape": round(raw[19] / (w * h / 64), 1)},
                           "generic_step_share_of_passes": round(raw[11] / max(1, raw[10]), 4),
                           "lane_utilisation": round(st["perturb_steps"] / max(1, st["lane_slots"]), 4)}), flush=True)
 r.set_kernel_variant(0)
