@@ -108,6 +108,8 @@ __global__ void k_make_quiet_orbit(const float4 *__restrict__ zref, float4 *__re
     // per-step bound holds (|Z|_2 < 7.92, |dz|_inf < 2.9), so four steps multiply G by less than
     // ((20 * 21 + 1) * 20 + 1) * 20 + 1 = 168421 times sqrt 2 < 2^18: G <= .w implies that each of the four arrivals passes
     // its own bound test, and the scalar-cache path of the scaled runs then skips those tests (same accepted steps).
+    // (Eight entries with 2^-36 -- one test per loop body -- pass for 67 % of C3's blocks instead of 93.6 %: 63.5 instead of
+    // 55.8 ms.)
     // (A run may START at every usable entry and at an exact zero -- entry 0, where every rebase lands; 2Z + dz is then dz
     // itself in either arithmetic -- the kernels read that off .z and .xy.  Nothing arrives at a zero entry: its bound is
     // the "never" pattern.)
