@@ -142,13 +142,30 @@ uint32_t use_device(const fs_renderer *r)
 }
 
 // ---- Device memory of a renderer.
-// Stream-ordered on the compute stream once it exists (hipMallocAsync / hipFreeAsync: no device-wide synchronisation per
-// allocation, and memory is handed back in stream order -- the reference does the same, GPU_Render.cu:127,142-153,362-395);
-// everything that touches such memory is enqueued on the compute stream or behind a synchronisation of it.
+// hipMalloc / hipFree behind a synchronisation of the compute stream (everything that touches such memory is enqueued on
+// the compute stream or behind a synchronisation of it); optionally stream-ordered (hipMallocAsync / hipFreeAsync, as the
+// reference does, GPU_Render.cu:127,142-153,362-395) -- see async_alloc_enabled() for why that is not the default.
 // kInput allocations -- reference orbit, LA table, BLA table, their upload staging -- fall back to page-locked HOST memory
 // when the device allocation fails, and the kernels then read them over the bus: slow, but the frame still renders
 // (GPUPerturbSingleResults, Perturb.cuh:51-61; GPU_LAReference, GPU_LAReference.h:93-113).  Frame buffers (kFrame) do not.
 enum AllocKind { kFrame = 0, kInput = 1 };
+
+// The stream-ordered allocator (round 3: hipMallocAsync / hipFreeAsync on the compute stream) is OFF by default: on this
+// ROCm (7.2.0) a block that the pool hands out again is not reliably the memory the next copy and the next kernel agree on
+// -- tools/microbench/async_alloc_probe.hip (upload, transform, check, free, four rounds) finds stale or zero data from
+// the second round on with blocks of 32 MiB and more, whatever the release threshold, the stream type or the kind of host
+// memory, and none with hipMalloc / hipFree (profiles/r03zz_async_alloc_probe.txt).  In this library it showed as wrong
+// frames from the SECOND orbit upload of a renderer when the orbit has tens of millions of entries (Views 10, 15, 22).
+// FSMI355_ASYNC_ALLOC=1 switches the stream-ordered path back on.  What keeps allocation off the frame path either way:
+// buffers are kept and reused when the next table fits (LA table, BLA table block, work arena, iteration buffers).
+static bool async_alloc_enabled()
+{
+    static const bool on = [] {
+        const char *e = getenv("FSMI355_ASYNC_ALLOC");
+        return e != nullptr && atoi(e) != 0;
+    }();
+    return on;
+}
 
 hipError_t r_alloc(fs_renderer *r, void **out, size_t bytes, AllocKind kind)
 {
@@ -157,7 +174,7 @@ hipError_t r_alloc(fs_renderer *r, void **out, size_t bytes, AllocKind kind)
     *out = nullptr;
     hipError_t e = hipErrorOutOfMemory;
     if (!(kind == kInput && r->inject_input_oom))
-        e = r->compute ? hipMallocAsync(out, bytes, r->compute) : hipMalloc(out, bytes);
+        e = r->compute && async_alloc_enabled() ? hipMallocAsync(out, bytes, r->compute) : hipMalloc(out, bytes);
     if (e == hipSuccess || kind != kInput)
         return e;
     (void)hipGetLastError(); // the failed device allocation is handled here, not reported by a later launch check
@@ -185,7 +202,11 @@ hipError_t r_free(fs_renderer *r, const void *cp)
                 (void)hipStreamSynchronize(r->compute); // a kernel may still be reading it
             return hipHostFree(p);
         }
-    return r->compute ? hipFreeAsync(p, r->compute) : hipFree(p);
+    if (r->compute && async_alloc_enabled())
+        return hipFreeAsync(p, r->compute);
+    if (r->compute)
+        (void)hipStreamSynchronize(r->compute); // work that uses the block has been enqueued on this stream only
+    return hipFree(p);
 }
 
 // The installed LA table (records + stages): the buffers of the previous table are kept when the new one fits.

@@ -238,7 +238,8 @@ typedef void (*fs_done_cb)(void *user);
 uint32_t fs_enqueue_done_callback(fs_renderer *r, fs_done_cb cb, void *user);
 
 /* Memory behaviour (GPU_Render.cu:127,142-153,362-395; Perturb.cuh:51-61; GPU_LAReference.h:93-113): device memory is
- * allocated and freed in compute-stream order (hipMallocAsync / hipFreeAsync); the work memory of fs_build_la, the installed
+ * allocated with hipMalloc / hipFree behind a synchronisation of the compute stream (FSMI355_ASYNC_ALLOC=1 in the environment
+ * selects hipMallocAsync / hipFreeAsync in compute-stream order instead -- off by default); the work memory of fs_build_la, the installed
  * LA table and the BLA table (one allocation for all levels) are kept and reused when the next one fits.  When the device
  * cannot hold an INPUT table (reference orbit, LA table, BLA table) it is placed in page-locked host memory instead and the
  * kernels read it over the bus, as the reference does -- the frame still renders, slowly.  fs_host_fallback_bytes = bytes
