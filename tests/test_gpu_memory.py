@@ -111,3 +111,33 @@ def test_a_normal_renderer_never_touches_the_fallback_and_reuses_its_table_memor
         assert r.host_fallback_bytes == 0
     finally:
         r.close()
+
+
+def test_second_upload_of_a_large_orbit_renders_the_same_frame(native_libs):
+    """Round 3's regression: with the stream-ordered allocator (hipMallocAsync / hipFreeAsync) the blocks of the SECOND upload
+    of a large orbit came back from the pool with stale contents under ROCm 7.2.0 (tools/microbench/async_alloc_probe.hip;
+    DESIGN.md 3.2) and every pixel of the second frame was wrong -- whatever the kernel variant.  View 17's 1.5-million-entry
+    orbit (25 MB prepared + 49 MB of companions + its LA table) uploaded three times into one renderer: the tuned, the
+    no-scaled-runs and the literal kernel give one and the same frame, in LAv2 Full and perturbation only."""
+    r = GPURenderer(0)
+    try:
+        v = inputs.View.builtin(17, 64, 36)
+        ob = inputs.Orbit(v)
+        assert ob.count > 1 << 20
+        la = inputs.LATable(ob)
+        co = _pairs(v.coords_perturb(ob))
+        frames = {}
+        for mode, n in ((LAV2_FULL, v.num_iterations), (LAV2_PO, min(v.num_iterations, 20000))):
+            for k, variant in enumerate((1, 0, 2, 0)):
+                assert r.set_kernel_variant(variant) == 0
+                assert r.InitializeMemory(64, 36, 1, None, 0, 0, 0, False) == 0
+                assert r.InitializePerturb(0, ob, 0, None, la) == 0  # generation 0: uploaded again every time
+                assert r.ClearMemory() == 0
+                assert r.RenderPerturbLAv2(None, None, None, *co, n, T=T_HDR32, Mode=mode, parity=PARITY_CPU) == 0
+                out, _ = _frame(r, n)
+                frames.setdefault(mode, out.copy())
+                assert np.array_equal(out, frames[mode]), (mode, k, variant)
+        assert r.host_fallback_bytes == 0
+    finally:
+        r.set_kernel_variant(0)
+        r.close()
