@@ -114,6 +114,13 @@ struct fs_renderer {
 
     // memory management (r_alloc / r_free below)
     std::vector<void *> host_allocs; // input tables that live in page-locked HOST memory (device out of memory)
+    // device blocks of this renderer (synchronous allocation): every live block with its size, and the released ones that
+    // are kept for the next request of a similar size (r_alloc / r_free)
+    struct Block {
+        void *p;
+        size_t bytes;
+    };
+    std::vector<Block> live_blocks, kept_blocks;
     size_t host_alloc_bytes = 0;
     bool inject_input_oom = false;   // fault injection: FSMI355_FAIL_INPUT_ALLOC=1 at fs_create time
     void *arena = nullptr;           // work memory of fs_build_la (kept between calls, grown on demand)
@@ -167,14 +174,50 @@ static bool async_alloc_enabled()
     return on;
 }
 
+constexpr size_t kKeptBlocks = 16;
+constexpr size_t kKeptBytes = (size_t)2 << 30;
+
+static void release_kept_blocks(fs_renderer *r)
+{
+    for (const auto &k : r->kept_blocks)
+        (void)hipFree(k.p);
+    r->kept_blocks.clear();
+}
+
 hipError_t r_alloc(fs_renderer *r, void **out, size_t bytes, AllocKind kind)
 {
     if (bytes == 0)
         bytes = 16;
     *out = nullptr;
     hipError_t e = hipErrorOutOfMemory;
-    if (!(kind == kInput && r->inject_input_oom))
-        e = r->compute && async_alloc_enabled() ? hipMallocAsync(out, bytes, r->compute) : hipMalloc(out, bytes);
+    if (!(kind == kInput && r->inject_input_oom)) {
+        if (r->compute && async_alloc_enabled()) {
+            e = hipMallocAsync(out, bytes, r->compute);
+        } else {
+            // a kept block that fits (best fit, at most twice the size asked for) before a new allocation: a host that uploads
+            // an orbit and its tables for every frame allocates nothing in the steady state
+            size_t best = r->kept_blocks.size();
+            for (size_t i = 0; i < r->kept_blocks.size(); i++) {
+                const size_t b = r->kept_blocks[i].bytes;
+                if (b >= bytes && b <= 2 * bytes + (1u << 16) && (best == r->kept_blocks.size() || b < r->kept_blocks[best].bytes))
+                    best = i;
+            }
+            if (best != r->kept_blocks.size()) {
+                *out = r->kept_blocks[best].p;
+                r->live_blocks.push_back(r->kept_blocks[best]);
+                r->kept_blocks.erase(r->kept_blocks.begin() + (long)best);
+                return hipSuccess;
+            }
+            e = hipMalloc(out, bytes);
+            if (e != hipSuccess && !r->kept_blocks.empty()) { // the kept blocks may be what is in the way
+                (void)hipGetLastError();
+                release_kept_blocks(r);
+                e = hipMalloc(out, bytes);
+            }
+            if (e == hipSuccess)
+                r->live_blocks.push_back(fs_renderer::Block{*out, bytes});
+        }
+    }
     if (e == hipSuccess || kind != kInput)
         return e;
     (void)hipGetLastError(); // the failed device allocation is handled here, not reported by a later launch check
@@ -206,7 +249,23 @@ hipError_t r_free(fs_renderer *r, const void *cp)
         return hipFreeAsync(p, r->compute);
     if (r->compute)
         (void)hipStreamSynchronize(r->compute); // work that uses the block has been enqueued on this stream only
-    return hipFree(p);
+    for (size_t i = 0; i < r->live_blocks.size(); i++)
+        if (r->live_blocks[i].p == p) {
+            const fs_renderer::Block b = r->live_blocks[i];
+            r->live_blocks.erase(r->live_blocks.begin() + (long)i);
+            // kept for the next request -- up to kKeptBlocks of them and kKeptBytes in total (the oldest go first)
+            r->kept_blocks.push_back(b);
+            size_t total = 0;
+            for (const auto &k : r->kept_blocks)
+                total += k.bytes;
+            while (!r->kept_blocks.empty() && (r->kept_blocks.size() > kKeptBlocks || total > kKeptBytes)) {
+                total -= r->kept_blocks.front().bytes;
+                (void)hipFree(r->kept_blocks.front().p);
+                r->kept_blocks.erase(r->kept_blocks.begin());
+            }
+            return hipSuccess;
+        }
+    return hipFree(p); // (not one of ours: allocated before the compute stream existed, or by the stream-ordered path)
 }
 
 // The installed LA table (records + stages): the buffers of the previous table are kept when the new one fits.
@@ -515,6 +574,7 @@ void free_all(fs_renderer *r)
     r->pal = nullptr;
     r->cx_row = nullptr;
     r->width = r->height = 0;
+    release_kept_blocks(r);
 }
 
 struct TimedLaunch {
