@@ -672,7 +672,8 @@ static_assert(kScaledChunk % 8 == 0 && kScaledChunk >= 64, "a run is a whole num
 // thirds of the attempts of a wave (300 of 460) ended that way -- lanes near their escape, where dz is never small against
 // the orbit -- each for the price of an entry, a trip and an exit.  Measured (C3 kernel ms / emulated 8-rank maximum): cap 0
 // (no back-off) 60.3 / 10.27, 1: 57.7 / 9.81, 3: 56.5 / 9.41, 7: 55.8 / 9.36, 15: 55.5 / 9.13, 31: 56.1 / 9.28, 63: 55.4 / 9.17;
-// doubling instead of counting up: no better.  Which steps run scaled changes no result.
+// doubling instead of counting up: no better; neither is waiting for a careful step that leaves every lane's dz 1 .. 4 binades
+// below the orbit value it arrived at (57.3 .. 58.7).  Which steps run scaled changes no result.
 #ifndef FS_BACKOFF_CAP
 #define FS_BACKOFF_CAP 15
 #endif
