@@ -712,6 +712,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
     uint64_t c_careful = 0, c_scaled = 0, c_runs = 0;
     uint32_t c_why[4] = {0, 0, 0, 0};
     uint32_t c_wentry = 0, c_wstart = 0, c_wshort = 0; // run entries tried / runs started / runs of fewer than 8 steps (per wave)
+    uint32_t c_blk_violation = 0; // (verification build) blocks that passed the block test and failed a bound test: must stay 0
     uint32_t c_pass = 0, c_generic = 0; // careful passes of the wave / those that took the generic step
     uint32_t c_blk_free = 0, c_blk_tested = 0; // 4-step blocks of the scalar-cache scaled path without / with bound tests (per wave)
 #ifdef FS_PROFILE_CYCLES
@@ -1078,6 +1079,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                             const uint32_t lim8 = (rl << 4) - 0x80u; // run lengths are 16 / 64 / 256 steps
                             const float4 *const zpb = zpu;
                             for (;;) {
+#ifdef FS_VERIFY_BLOCK_BOUND
+                                // VERIFICATION BUILD (tools/block_bound_check.py): every block runs the tested form, and a block
+                                // whose block test passes while one of its four arrivals fails its own bound test is counted
+                                const int vg_ = __float_as_int(mxS) > imdc ? __float_as_int(mxS) : imdc;
+                                const bool bt_pass = __builtin_amdgcn_ballot_w64(vg_ + Esh > pwi) == 0ull;
+                                if (kStats && bt_pass)
+                                    c_blk_free++;
+#else
                                 {
                                     // the untested bodies, as long as they last: status 0 = stopped in front of a block
                                     // that needs its tests or of the last four steps (or at the end of the run); 1 / 2 =
@@ -1106,7 +1115,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                                         break;
                                     }
                                 }
-                                if (cs >= rl) {
+#endif
+                                if (cs + 4u > rl) {
                                     c = cs, wO = wv, failed = false;
                                     break;
                                 }
@@ -1128,6 +1138,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                                 FS_STEP_ARITH(tp_, up_, w2, b)
                                 FS_STEP_BOUND(w2, b, vp_, ub.z)
                                 FS_STEP_SHAPE(w2, b, vp_)
+#ifdef FS_VERIFY_BLOCK_BOUND
+                                if (kStats && bt_pass &&
+                                    (__builtin_amdgcn_ballot_w64(__float_as_int(mx_a) + Esh > __float_as_int(ua.z)) |
+                                     __builtin_amdgcn_ballot_w64(__float_as_int(mx_b) + Esh > __float_as_int(ub.z))) != 0ull)
+                                    c_blk_violation++;
+#endif
                                 if (vp_ != 0ull) {
                                     FS_TRIP_FAILED(a, tp_, ua.z, wv)
                                     break;
@@ -1140,6 +1156,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                                 FS_STEP_ARITH(tq_, uq_, w4, d)
                                 FS_STEP_BOUND(w4, d, vq_, ud.z)
                                 FS_STEP_SHAPE(w4, d, vq_)
+#ifdef FS_VERIFY_BLOCK_BOUND
+                                if (kStats && bt_pass &&
+                                    (__builtin_amdgcn_ballot_w64(__float_as_int(mx_c_) + Esh > __float_as_int(uc.z)) |
+                                     __builtin_amdgcn_ballot_w64(__float_as_int(mx_d) + Esh > __float_as_int(ud.z))) != 0ull)
+                                    c_blk_violation++;
+#endif
                                 if (vq_ != 0ull) {
                                     FS_TRIP_FAILED(c_, tq_, uc.z, w2)
                                     break;
@@ -1514,6 +1536,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
             c_wentry = we > c_wentry ? we : c_wentry;
             c_wstart = ws > c_wstart ? ws : c_wstart;
             c_wshort = wh > c_wshort ? wh : c_wshort;
+            const uint32_t bv = __shfl_down(c_blk_violation, off);
+            c_blk_violation = bv > c_blk_violation ? bv : c_blk_violation;
             for (int i = 0; i < 4; i++) {
                 const uint32_t y = __shfl_down(c_why[i], off);
                 c_why[i] = y > c_why[i] ? y : c_why[i];
@@ -1530,6 +1554,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
             atomicAdd((unsigned long long *)&A.stats[12], (unsigned long long)c_wentry);
             atomicAdd((unsigned long long *)&A.stats[13], (unsigned long long)c_wstart);
             atomicAdd((unsigned long long *)&A.stats[14], (unsigned long long)c_wshort);
+            atomicAdd((unsigned long long *)&A.stats[15], (unsigned long long)c_blk_violation);
             for (int i = 0; i < 4; i++)
                 atomicAdd((unsigned long long *)&A.stats[16 + i], (unsigned long long)c_why[i]);
         }
@@ -1694,6 +1719,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
     uint32_t X = 0, L = 0;
     uint64_t c_la = 0, c_pt = 0, c_px = 0;
     uint64_t c_single = 0, c_runs = 0; // probes of the perturbation-only float path (tools/c2_probe.py)
+    uint64_t c_blk_violation = 0; // (verification build) must stay 0
     uint64_t c_free_steps = 0, c_tested_blocks = 0; // lane-steps inside the untested loop / tested four-step blocks (per lane)
 #ifdef FS_PROFILE_CYCLES
     // measurement build (tools/c5_phase_probe.py): shader-clock cycles and wave-passes per phase of the BLA loop, per wave.
@@ -2249,6 +2275,13 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                         const uint32_t lim8 = (rl << 4) - 0x80u; // run lengths are 16 / 64 / 256 steps
                         const float4 *const zpb = zpu;
                         for (;;) {
+#ifdef FS_VERIFY_BLOCK_BOUND
+                            // VERIFICATION BUILD (tools/block_bound_check.py), as in k_lav2_hdr32_fast
+                            const int vg_ = __float_as_int(mxS) > imdc ? __float_as_int(mxS) : imdc;
+                            const bool bt_pass = __builtin_amdgcn_ballot_w64(vg_ + Esh > pwi) == 0ull;
+                            if (kStats && bt_pass)
+                                c_free_steps += 4;
+#else
                             {
                                 f2 r1, r2, r3, ts_, ta_;
                                 float tn_, tl_;
@@ -2267,7 +2300,8 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                                     break;
                                 }
                             }
-                            if (cs >= rl) {
+#endif
+                            if (cs + 4u > rl) {
                                 c = cs, wO = wv, failed = false;
                                 break;
                             }
@@ -2286,6 +2320,12 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                             FS_STEP_ARITH(tp_, up_, w2, b)
                             FS_STEP_BOUND(w2, b, vp_, ub.z)
                             FS_STEP_SHAPE(w2, b, vp_)
+#ifdef FS_VERIFY_BLOCK_BOUND
+                            if (kStats && bt_pass &&
+                                (__builtin_amdgcn_ballot_w64(__float_as_int(mx_a) + Esh > __float_as_int(ua.z)) |
+                                 __builtin_amdgcn_ballot_w64(__float_as_int(mx_b) + Esh > __float_as_int(ub.z))) != 0ull)
+                                c_blk_violation++;
+#endif
                             if (vp_ != 0ull) {
                                 c = cs, wO = wv, failed = true;
                                 break;
@@ -2296,6 +2336,12 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                             FS_STEP_ARITH(tq_, uq_, w4, d)
                             FS_STEP_BOUND(w4, d, vq_, ud.z)
                             FS_STEP_SHAPE(w4, d, vq_)
+#ifdef FS_VERIFY_BLOCK_BOUND
+                            if (kStats && bt_pass &&
+                                (__builtin_amdgcn_ballot_w64(__float_as_int(mx_c_) + Esh > __float_as_int(uc.z)) |
+                                 __builtin_amdgcn_ballot_w64(__float_as_int(mx_d) + Esh > __float_as_int(ud.z))) != 0ull)
+                                c_blk_violation++;
+#endif
                             if (vq_ != 0ull) {
                                 c = cs + 2, wO = w2, failed = true;
                                 break;
@@ -2720,6 +2766,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
             atomicAdd((unsigned long long *)&A.stats[7], (unsigned long long)c_runs);
             atomicAdd((unsigned long long *)&A.stats[8], (unsigned long long)c_free_steps);
             atomicAdd((unsigned long long *)&A.stats[9], (unsigned long long)c_tested_blocks);
+            atomicAdd((unsigned long long *)&A.stats[10], (unsigned long long)c_blk_violation);
         }
     }
 #ifdef FS_PROFILE_CYCLES
