@@ -82,6 +82,17 @@ def cpu_model():
     return model, os.cpu_count() or 1
 
 
+def checksum_vs_committed(workload_key, parity, n_iterations, checksum):
+    """True / False when tests/golden/frame_checksums.json holds the sum of this frame's iteration counts as one GPU
+    rendered it, None when it holds none."""
+    try:
+        table = json.load(open(os.path.join(ROOT, "tests", "golden", "frame_checksums.json")))
+    except (OSError, ValueError):
+        return None
+    want = table.get("%s|%s|%d" % (workload_key, parity, n_iterations))
+    return None if want is None or checksum is None else bool(int(want) == int(checksum))
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,6 +125,9 @@ def parse():
                     help="comma-separated A/B selections of fs_set_kernel_variant: literal | noscale, lds_orbit, refill, natural_tile_order "
                          "(default: the tuned kernels)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-cold", action="store_true", help="skip the cold-frame (natural tile order) latency measurement")
+    ap.add_argument("--natural-tile-order", action="store_true",
+                    help="FS_VARIANT_NATURAL_TILE_ORDER: every frame in natural tile order (no self-recorded longest-first)")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-build", action="store_true",
                     help="never spawn a compiler (same as FS_NO_BUILD=1): required under rocprofv3, see tools/pmc_passes.sh")
@@ -157,6 +171,16 @@ def main():
     args = parse()
     cmd = rank_launch_command(args.gpus, sys.argv[1:])
     if cmd is not None:
+        # under a profiler the preloaded tool library has initialised the GPU in THIS process already: starting the
+        # launcher from here would be the fork + exec of a GPU-initialised process that the pool forbids
+        # (tools/pmc_passes.sh) -- profile one rank (--gpus 1), or start the ranks under the profiler yourself
+        traced = [k for k in os.environ if k.startswith(("ROCP_", "ROCPROF", "ROCPROFILER"))] + \
+                 (["LD_PRELOAD"] if os.environ.get("LD_PRELOAD") else [])
+        if traced:
+            print("bench.py: --gpus %d without a launcher under a profiler / preload (%s): refusing to start the rank "
+                  "launcher from a process that may have initialised the GPU" % (args.gpus, ", ".join(sorted(traced))),
+                  file=sys.stderr)
+            sys.exit(2)
         sys.exit(launch_ranks(cmd))
     # stdout carries exactly ONE JSON line.  Libraries write banners there (RCCL prints its version block to stdout when the
     # first communicator comes up), so for the whole run file descriptor 1 is pointed at stderr and the real stdout is kept
@@ -181,6 +205,10 @@ def main():
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:  # FS_FORCE_DIST=1 without a launcher: a one-rank job
+            os.environ.setdefault("MASTER_PORT", "29541")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl")
     else:
@@ -277,22 +305,46 @@ def main():
         assert r.InitializePerturb(2, orbit, 0, None, la) == 0  # the timed frames use the uploaded host table
     band = tiling.band_height(AA)
     rw = r.rounded_width
-    # the host copy of the frame (the reference's ItersMemoryContainer): page-locked so the D2H is one DMA
     rows_padded = (H + 7) // 8 * 8
-    host_frame_t = torch.zeros((rows_padded, rw), dtype=torch.int32, pin_memory=True) if rank == 0 else None
-    host_frame = host_frame_t.numpy().view(np.uint32) if rank == 0 else None
+    # ---- buffers of the frame pipeline.  TWO of everything a frame passes through, in rotation, so that
+    # frame k+1's kernel runs while frame k is gathered, put back in row order and copied to the host:
+    #   local[b]     the rank's iteration buffer (caller-owned: fs_set_external_iter_buffer), written by the kernel
+    #   gathered[b]  rank 0, N > 1: the ranks' padded slices back to back (one RCCL gather)
+    #   frame_dev[b] rank 0, N > 1: the frame in row order (one index_select into a fixed buffer)
+    #   host[b]      rank 0: the frame in page-locked host memory (the reference's ItersMemoryContainer) -- one DMA
+    # Streams: the renderer's compute stream (kernel), `post` (gather + row order), `copy` (D2H); events order them and
+    # the HOST waits on the D2H event of a frame, never on the device.
+    NB = 2
     if distributed:
         assert r.SetRowBands(rank * band, band, world * band) == 0
-        max_rows = tiling.max_local_rows(H, world, band)
-        local = torch.zeros((max_rows, rw), dtype=torch.int32, device="cuda")
-        gathered = torch.empty((world * max_rows, rw), dtype=torch.int32, device="cuda") if rank == 0 else None
-        frame_index = torch.from_numpy(tiling.reassemble_index(H, world, band)).cuda() if rank == 0 else None
-        assert r.SetExternalIterBuffer(local.data_ptr(), local.numel() * local.element_size()) == 0
-        render_stream = torch.cuda.ExternalStream(r.compute_stream)
-    kernel_ms = []
+        local_rows = tiling.max_local_rows(H, world, band)
+    else:
+        local_rows = rows_padded
+    local = [torch.zeros((local_rows, rw), dtype=torch.int32, device="cuda") for _ in range(NB)]
+    local_bytes = local[0].numel() * local[0].element_size()
+    host_t = [torch.zeros((rows_padded, rw), dtype=torch.int32, pin_memory=True) for _ in range(NB)] if rank == 0 else None
+    host_np = [t.numpy().view(np.uint32) for t in host_t] if rank == 0 else None
+    gathered = frame_dev = frame_index = None
+    if distributed and rank == 0:
+        gathered = [torch.empty((world * local_rows, rw), dtype=torch.int32, device="cuda") for _ in range(NB)]
+        frame_dev = [torch.empty((H, rw), dtype=torch.int32, device="cuda") for _ in range(NB)]
+        frame_index = torch.from_numpy(tiling.reassemble_index(H, world, band)).cuda()
+    render_stream = torch.cuda.ExternalStream(r.compute_stream)
+    post_stream = torch.cuda.Stream()
+    copy_stream = torch.cuda.Stream()
+    ev_render = [torch.cuda.Event() for _ in range(NB)]
+    ev_consumed = [torch.cuda.Event() for _ in range(NB)]  # local[b] has been read by everything that reads it
+    ev_host = [torch.cuda.Event() for _ in range(NB)]      # host[b] holds the frame
+    used = [False] * NB
+    state = {"k": 0, "last": None}
 
-    def one_frame(record, par):
-        """Launch -> iteration buffer in host memory (rank 0)."""
+    def enqueue_frame(par):
+        """Launch one frame and everything behind it (asynchronous).  Returns the buffer index it lands in."""
+        b = state["k"] % NB
+        state["k"] += 1
+        if used[b]:
+            render_stream.wait_event(ev_consumed[b])  # the kernel must not overwrite local[b] before it has been read
+        assert r.SetExternalIterBuffer(local[b].data_ptr(), local_bytes) == 0
         if is_lav2:
             e = r.RenderPerturbLAv2(None, None, None, *coords, n_iter, T=T_TAG, Mode=LAV2_FULL, parity=par)
         elif is_scaled:
@@ -300,42 +352,89 @@ def main():
         else:
             e = lib.fs_render_bla(r._h, T_HDR32, coords_arr.ctypes.data, n_iter)
         assert e == 0, GPURenderer.ConvertErrorToString(e)
+        ev_render[b].record(render_stream)
+        src = local[b]
         if distributed:
-            # the gather waits for the render on the device (stream-to-stream), not through the host
-            torch.cuda.current_stream().wait_stream(render_stream)
-            frame = tiling.gather_frame(local, gathered, frame_index, rank, world)
-            if rank == 0:
-                host_frame_t[:frame.shape[0]].copy_(frame, non_blocking=True)
-        else:
-            # RenderCurrent: D2H of the padded buffer on the compute stream, behind the kernel (GPU_Render.cu:1759-1805)
-            assert r.RenderCurrent(n_iter, host_frame) == 0
-            assert r.SyncComputeStream() == 0
-        torch.cuda.synchronize()
-        if record is not None:
-            record.append(r.last_kernel_ms())
+            with torch.cuda.stream(post_stream):
+                post_stream.wait_event(ev_render[b])  # device-side: the gather waits for the kernel, not the host
+                if rank == 0 and used[b]:
+                    post_stream.wait_event(ev_host[b])  # gathered[b] / frame_dev[b] are still being copied out (frame k - NB)
+                tiling.gather_slices(local[b], gathered[b] if rank == 0 else None, rank, world)
+                ev_consumed[b].record(post_stream)
+                if rank == 0:
+                    torch.index_select(gathered[b], 0, frame_index, out=frame_dev[b])
+                    src = frame_dev[b]
+        if rank == 0:
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(ev_render[b])
+                if distributed:
+                    copy_stream.wait_stream(post_stream)
+                host_t[b][:src.shape[0]].copy_(src, non_blocking=True)
+                ev_host[b].record(copy_stream)
+                if not distributed:
+                    ev_consumed[b].record(copy_stream)
+        elif not distributed:
+            ev_consumed[b].record(render_stream)
+        used[b] = True
+        state["last"] = b
+        return b
 
-    def timed(par, record):
+    def wait_frame(b):
+        """Host waits until frame in buffer b is where it has to be (rank 0: in host memory)."""
+        (ev_host[b] if rank == 0 else ev_consumed[b]).synchronize()
+
+    def one_frame(par):
+        """One frame, launch -> iteration buffer in host memory (rank 0), synchronously: the frame LATENCY."""
+        b = enqueue_frame(par)
+        wait_frame(b)
+        return b
+
+    def barrier_sync():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if not distributed:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed(par):
+        """EXACTLY args.steps frames between barrier + synchronize on both sides, pipelined: while frame k's slices are
+        gathered and copied out, frame k+1's kernel runs; the host waits for frame k-1's host buffer before it launches
+        frame k+1.  -> (seconds, max over ranks; kernel ms of this rank's frames)"""
+        barrier_sync()
         t0 = time.perf_counter()
+        prev = None
         for _ in range(args.steps):
-            one_frame(record, par)
-        torch.cuda.synchronize()
-        if distributed:
-            dist.barrier()
-        el = time.perf_counter() - t0
-        if distributed:
-            t = torch.tensor([el], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
-        return el
+            b = enqueue_frame(par)
+            if prev is not None:
+                wait_frame(prev)
+            prev = b
+        wait_frame(prev)
+        barrier_sync()
+        el = max_over_ranks(time.perf_counter() - t0)
+        return el, r.kernel_ms_history(min(args.steps, 64))
+
+    def latency(par, frames, cold=False):
+        """`frames` frames one at a time (nothing overlaps): mean wall ms launch -> host, max over ranks; kernel ms."""
+        barrier_sync()
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            if cold:
+                r.forget_tile_costs()
+            one_frame(par)
+        barrier_sync()
+        el = max_over_ranks(time.perf_counter() - t0)
+        return el / frames * 1e3, r.kernel_ms_history(min(frames, 64))
 
     def count_steps(par):
         # Executed work per frame is a pure function of the inputs: count it once in an untimed launch with the
         # instrumented kernel build (wave-reduced atomics); the timed launches run the uninstrumented kernel.
         r.enable_step_count(True)
-        one_frame(None, par)
+        one_frame(par)
         st = r.read_step_count()
         r.enable_step_count(False)
         if distributed:
@@ -346,50 +445,81 @@ def main():
             st.update({k: float(x) for k, x in zip(keys, t.tolist())})
         return st
 
+    tile_order_on = "natural_tile_order" not in vsel and not args.natural_tile_order
+    if not tile_order_on:
+        r.set_kernel_variant(1 if "literal" in vsel else (2 if "noscale" in vsel else 0), lds_orbit="lds_orbit" in vsel,
+                             refill="refill" in vsel, natural_tile_order=True)
     st = count_steps(parity)
     for _ in range(args.warmup):
-        one_frame(None, parity)
-    elapsed = timed(parity, kernel_ms)
-    if distributed:
-        km = torch.tensor([sum(kernel_ms)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(km, op=dist.ReduceOp.MAX)
-        avg_kernel_ms = float(km.item()) / args.steps
-    else:
-        avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
+        one_frame(parity)
+    # the frame the steady state starts from: a frame in natural order has run (count_steps), its recorded costs order the
+    # frames that follow ("warm": every timed frame, like every frame after the first of a real sequence of frames)
+    elapsed, kernel_ms = timed(parity)
+    avg_kernel_ms = max_over_ranks(sum(kernel_ms) / len(kernel_ms))
+    ordered_frames = bool(r.last_frame_tile_ordered()) if is_lav2 and not is64 else False
     perturb_steps, at_iters, la_steps = float(st["perturb_steps"]), float(st["at_iterations"]), float(st["la_steps"])
     lane_slots = st["lane_slots"]
-    checksum = int(host_frame[:H, :W].astype(np.uint64).sum()) if rank == 0 else None
-    frame_main = host_frame.copy() if rank == 0 else None
+    b_main = state["last"]
+    checksum = int(host_np[b_main][:H, :W].astype(np.uint64).sum()) if rank == 0 else None
+    frame_main = host_np[b_main].copy() if rank == 0 else None
+    # latency of ONE frame (launch -> host, nothing overlapped), warm and cold (natural tile order: what the FIRST frame of a
+    # view costs; fs_forget_tile_costs before every frame)
+    n_lat = max(1, min(args.steps, 5))
+    lat_warm_ms, lat_warm_k = latency(parity, n_lat)
+    lat_cold_ms = lat_cold_k = None
+    if ordered_frames and not args.no_cold:
+        lat_cold_ms, lat_cold_k = latency(parity, n_lat, cold=True)
+        one_frame(parity)  # (leave the renderer warm again)
+    frame_timing = None
+    if rank == 0:
+        frame_timing = {
+            "sustained_ms_per_frame": round(elapsed / args.steps * 1e3, 3),
+            "latency_ms_warm": round(lat_warm_ms, 3), "latency_kernel_ms_warm": round(sum(lat_warm_k) / len(lat_warm_k), 3),
+            "latency_ms_cold": round(lat_cold_ms, 3) if lat_cold_ms is not None else None,
+            "latency_kernel_ms_cold": round(sum(lat_cold_k) / len(lat_cold_k), 3) if lat_cold_k else None,
+            "value_cold": round(W * H / lat_cold_ms / 1e3, 4) if lat_cold_ms is not None else None,
+            "tile_order": ("longest first, recorded by the previous frame (warm)" if ordered_frames
+                           else "natural"),
+            "what": "value / ms_per_step = sustained: frames back to back, frame k+1's kernel runs while frame k is gathered and "
+                    "copied to the host (two buffers in rotation, copy stream, the host waits on the copy's event).  latency = one "
+                    "frame, launch -> host, nothing overlapped.  cold = natural tile order (the first frame of a view), warm = "
+                    "tiles launched longest first from the costs the previous frame recorded."}
 
     # ---- secondary: the same frame with the LA stages in use (GPU-direction stage test), driver-timed like `value`
     secondary = None
     frame_secondary = None
     if wl == "c3_lav2" and args.parity == "cpu" and not args.no_secondary:
         st2 = count_steps(PARITY_CPU_GPUSTAGE)
-        one_frame(None, PARITY_CPU_GPUSTAGE)
-        km2 = []
-        el2 = timed(PARITY_CPU_GPUSTAGE, km2)
+        one_frame(PARITY_CPU_GPUSTAGE)
+        el2, km2 = timed(PARITY_CPU_GPUSTAGE)
+        lat2_ms, _ = latency(PARITY_CPU_GPUSTAGE, n_lat)
         if rank == 0:
+            b2 = state["last"]
             secondary = {"what": "same frame, FS_PARITY_CPU_GPUSTAGE: CPU arithmetic with the LA stage test in the "
                                  "direction of GPU_LAReference.h:240-254 (the LA stages are used)",
                          "ms_per_step": round(el2 / args.steps * 1e3, 3),
                          "value": round(W * H * args.steps / el2 / 1e6, 4), "unit": "Mpix/s",
+                         "latency_ms_warm": round(lat2_ms, 3),
                          "kernel_ms_rank0": round(sum(km2) / len(km2), 3),
                          "la_steps_per_launch": float(st2["la_steps"]),
                          "at_iterations_per_launch": float(st2["at_iterations"]),
                          "pixel_steps_per_launch": float(st2["perturb_steps"]),
-                         "frame_checksum": int(host_frame[:H, :W].astype(np.uint64).sum())}
-            frame_secondary = host_frame.copy()
+                         "frame_checksum": int(host_np[b2][:H, :W].astype(np.uint64).sum())}
+            frame_secondary = host_np[b2].copy()
 
     # ---- CPU baseline on a bounded sample of rows (rank 0, N = 1 only)
     cpu_baseline = None
     cpu_baseline_patched = None
     parity_rows_ok = None
-    if rank == 0 and not distributed and not args.no_cpu:
+    if rank == 0 and not args.no_cpu:
         import _oracle
         threads = effective_cpus()
-        # rows per host thread chosen per workload so that the sample is 10-30 s of CPU work on the box's 16 threads
-        per_thread = {"c3_lav2": 8, "c2_po": 3, "c5_bla": 32, "c4_hdr64": 64, "c4_2x32": 8, "c4_scaled": 4}[wl]
+        # rows per host thread chosen per workload so that the sample is about 10 s of CPU work on the box's 16 threads (the
+        # GPU part of the default run is ~2 s: a longer CPU leg hides it from a utilisation sampler); at N > 1 the same
+        # check runs on rank 0 with one row per thread: the line of an N-GPU run carries its own parity verdict
+        per_thread = {"c3_lav2": 2, "c2_po": 1, "c5_bla": 12, "c4_hdr64": 24, "c4_2x32": 3, "c4_scaled": 2}[wl]
+        if distributed:
+            per_thread = 1
         nrows = max(1, min(args.cpu_sample_rows if args.cpu_sample_rows > 0 else per_thread * threads, H))
         step = max(1, H // nrows)
         y0 = step // 2
@@ -424,9 +554,10 @@ def main():
         twin = {"c3_lav2": "Cpu32PerturbedBLAV2HDR", "c4_hdr64": "Cpu64PerturbedBLAV2HDR",
                 "c2_po": "Cpu32PerturbedBLAHDR (single-step branch)",
                 "c5_bla": "Cpu32PerturbedBLAHDR"}.get(wl, "the CUDA kernel (no CPU twin exists)")
-        cpu_baseline = line(cpu_t, "oracle restatement of " + twin +
-                            (", unmodified" if args.parity == "cpu" else ", LA stage test patched to the GPU direction"))
-        if secondary is not None:
+        if not distributed:  # (a reported baseline at N = 1 only; at N > 1 the rows are the line's parity check)
+            cpu_baseline = line(cpu_t, "oracle restatement of " + twin +
+                                (", unmodified" if args.parity == "cpu" else ", LA stage test patched to the GPU direction"))
+        if secondary is not None and not distributed:
             ref2, cpu_t2 = cpu_run(1)
             secondary["cpu_sample_rows_bit_exact"] = all(np.array_equal(frame_secondary[y], ref2[y]) for y in rows)
             cpu_baseline_patched = line(cpu_t2, "the same function with LAReference::isLAStageInvalid in the GPU direction")
@@ -483,6 +614,7 @@ def main():
                     "valu": {"achieved": round(achieved, 4), "peak": peak, "unit": "TFLOP/s",
                              "frac": round(achieved / peak, 5), "flop_per_bla_jump": FLOP_PER_BLA_JUMP,
                              "bla_jumps_per_launch": la_steps}}
+        wl_key = "view%d_%dx%d_%s" % (args.view, W, H, wl_tag)
         out = {
             "metric": "Mpix/s (iteration buffer), View #5 3840x2160 HDRx32 LAv2" if wl == "c3_lav2"
             else "Mpix/s (iteration buffer), " + wl,
@@ -490,7 +622,8 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "2xf32+i32exp" if is2x32 else ("f64+i32exp" if is64 else "f32+i32exp"),
             "data": "built-in view %d of the reference (deterministic: no dataset or randomness on this path)" % args.view,
-            "window": "kernel launch -> iteration buffer in (page-locked) host memory, SURVEY.md 8(d)",
+            "window": "kernel launch -> iteration buffer in (page-locked) host memory, SURVEY.md 8(d); K frames back to back "
+                      "(sustained, see frame_timing for the latency of one frame)",
             "config": {"workload": "view%d_%dx%d_%s" % (args.view, W, H, wl_tag),
                        "parity": args.parity, "kernel_variant": args.variant or "tuned", "n_iterations": n_iter, "orbit_entries": orbit.count,
                        "la_records": la.count if la else 0, "la_stages": la.stage_count if la else 0,
@@ -507,6 +640,10 @@ def main():
                          if lane_slots and not distributed else None},
             "cpu_baseline": cpu_baseline, "cpu_baseline_patched": cpu_baseline_patched, "secondary": secondary,
             "frame_checksum": checksum, "cpu_sample_rows_bit_exact": parity_rows_ok,
+            # the same frame rendered by one GPU (tests/golden/frame_checksums.json, written from N = 1 runs whose sampled rows
+            # were bit-exact): null when no checksum is committed for this workload / parity / cap
+            "frame_checksum_equals_committed_n1": checksum_vs_committed(wl_key, args.parity, n_iter, checksum),
+            "frame_timing": frame_timing,
             "device_resident_ms": round(avg_kernel_ms, 3),
             "device_resident_mpix_s": round(W * H / avg_kernel_ms / 1e3, 4),
         }

@@ -91,6 +91,13 @@ template <class F> struct FsLav2ArgsT {
     const void *wp;
     uint32_t n_wp;
     typename FsDev<F>::Real cxLow, cyLow;
+    // "longest tiles first" from the costs the previous frame recorded (k_lav2_hdr32_fast; fsk_tile_order_by_cost): wave w
+    // of the launch renders the 8 x 8 tile tile_order[w] (row-major tile number of the LOCAL buffer, tiles_x per row,
+    // 0xFFFFFFFF = none) instead of the one its block index names; null = natural order.  tile_cost (null = not recorded):
+    // one word per tile, written by the wave that rendered it = the longest lane's perturbation steps (+ 8 per LA step).
+    const uint32_t *tile_order;
+    uint32_t *tile_cost;
+    uint32_t tiles_x;
 };
 using FsLav2Args32 = FsLav2ArgsT<float>;
 
@@ -280,6 +287,15 @@ void fsk_make_quiet_orbit(const float4 *zref, float4 *zq, uint64_t n, hipStream_
 // tiles.  probe: tiles_y rows of tiles_x counts.
 void fsk_tile_order(const uint32_t *probe, uint32_t probe_pitch, uint32_t tiles_x, uint32_t tiles_y, uint32_t threshold,
                     uint32_t *order, uint32_t n_slots, hipStream_t s);
+// Launch order "longest tiles first" from recorded costs: order[0 .. n_tiles) = the tile numbers sorted by cost, highest
+// first, in 64 cost classes between the frame's minimum and maximum, tile order kept inside a class (neighbours keep
+// starting together: they walk the same stretch of the orbit); order[n_tiles .. n_slots) = 0xFFFFFFFF; order[n_slots] = 0.
+// tmp: n_tiles words of work memory.
+void fsk_tile_order_by_cost(const uint32_t *cost, uint32_t n_tiles, uint32_t *tmp, uint32_t *order, uint32_t n_slots,
+                            hipStream_t s);
+// wave slots of the fsk_lav2_hdr32 launch for this frame (>= its number of 8 x 8 tiles), 0 = the launch shape is not the
+// default one (FSMI355_BLOCK experiment): no tile order then
+uint32_t fsk_lav2_hdr32_slots(const FsFrame &f);
 void fsk_lav2_hdr32(const FsLav2Args32 &A, int mode, bool stats, int variant, hipStream_t s);
 void fsk_lav2_hdr64(const FsLav2ArgsT<double> &A, int mode, bool stats, hipStream_t s);
 // IterType = uint64_t with 64-bit iteration counting (iteration caps of 2^32 and above): the literal kernel instantiated

@@ -702,8 +702,34 @@ template <int Mode, bool kStats, bool kScaled, bool kLds = false, bool kGpuStage
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) k_lav2_hdr32_fast(FsLav2Args32 A)
 {
     __shared__ float4 s_zs_lds[kLds ? 4 * 2 * 64 : 1];
+    // cost recording (A.tile_cost): a lane parks its count at the start of the perturbation loop here, so that nothing
+    // extra stays in a register across the loop
+    __shared__ uint32_t s_it0[256];
+    // The tile this wave renders, as two wave-uniform numbers: named by the launch order when there is one (longest tiles
+    // first, from the costs the previous frame recorded), by the block index otherwise.  The pixel is tile + lane, and
+    // it is worked out twice -- here, and again for the store at the end from the scalar tile numbers and a freshly
+    // computed lane number -- so that neither the pixel position nor the thread index occupies vector registers across the
+    // perturbation loop (they used to be spilled to scratch around it: 64 registers at 8 waves per SIMD, 15 of them
+    // named by the hand-scheduled loop).
+    uint32_t tile_x, tile_y;
+    const uint32_t wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (A.tile_order) {
+        const uint32_t w = (blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + wave_in_block;
+        const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.tile_order[w]);
+        tile_y = tile != 0xFFFFFFFFu ? tile / A.tiles_x : 0u;
+        tile_x = tile != 0xFFFFFFFFu ? tile - tile_y * A.tiles_x : 0xFFFFFFFu; // (no tile: a column beyond every frame)
+    } else {
+        tile_x = blockIdx.x * (blockDim.x >> 6) + wave_in_block;
+        tile_y = blockIdx.y;
+    }
     uint32_t X, L;
-    tile_pixel(X, L);
+    {
+        uint32_t lane; // (opaque, so that no later use of the lane number is served from a register kept since here)
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+        X = tile_x * 8u + (lane & 7u);
+        L = tile_y * 8u + (lane >> 3);
+    }
+    uint32_t lane_cost = 0;
 #ifdef FS_TRACE_WAVES
     // measurement build (tools/wave_trace.py): every wave records when and where it ran.  100 MHz constant clock.
     const uint64_t trace_t0 = wall_clock64();
@@ -731,6 +757,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         const hcplx32 DeltaSub0 = hc_from_hr(deltaReal, deltaImaginary);
         hcplx32 DeltaSubN = hc_from_native<float>(0.0f, 0.0f);
         uint32_t iterations = 0;
+        uint32_t la_cost = 0; // what ran before the perturbation loop, in units of a perturbation step (tile cost only)
 
         if (Mode != FS_MODE_PO) {
             if (A.la_valid && A.use_at && hr_cmp_pos(hc_cheb(DeltaSub0), ldr(A.at.ThresholdC)) <= 0) {
@@ -744,6 +771,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                 hc_reduce(dz);
                 DeltaSubN = dz;
                 iterations = i * A.at.StepLength;
+                la_cost = i;
                 if (kStats)
                     c_at = i;
             }
@@ -783,6 +811,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                         break;
                     }
                     iterations += l;
+                    la_cost += 8u;
                     if (kStats)
                         c_la++;
                     DeltaSubN = hc_add(hc_mul(newDz, ldc(LAj->ZCoeff)), hc_mul(DeltaSub0, ldc(LAj->CCoeff)));
@@ -805,6 +834,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
             hcplx32 dz = DeltaSubN;
             const hcplx32 dc = DeltaSub0;
             uint32_t ref = RefIteration;
+            {
+                uint32_t lane_s;
+                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_s));
+                s_it0[wave_in_block * 64u + lane_s] = iterations - la_cost;
+            }
             hcplx32 Zc = zref_at(zr, ref);
             bool running = iterations < n_iterations;
             typedef float f2 __attribute__((ext_vector_type(2)));
@@ -1486,8 +1520,31 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                 }
             }
             FS_CYC(cyc_loop += __builtin_readcyclecounter() - cyc_t0);
+            {
+                uint32_t lane_e;
+                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+                lane_cost = iterations - s_it0[wave_in_block * 64u + lane_e];
+            }
+        } else {
+            lane_cost = la_cost;
         }
-        store_iter(A.out, A.frame, L, X, iterations);
+        {
+            // (the pixel again, see the top of the kernel)
+            uint32_t lane_e;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+            store_iter(A.out, A.frame, tile_y * 8u + (lane_e >> 3), tile_x * 8u + (lane_e & 7u), iterations);
+        }
+    }
+    if (A.tile_cost && tile_x < A.tiles_x) {
+        // the tile's cost = its longest lane (the wave runs until that one is done)
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t o = __shfl_down(lane_cost, off);
+            lane_cost = o > lane_cost ? o : lane_cost;
+        }
+        uint32_t lane_e;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+        if (lane_e == 0u)
+            A.tile_cost[tile_y * A.tiles_x + tile_x] = lane_cost;
     }
 #ifdef FS_TRACE_WAVES
     if (kStats && A.stats) {
@@ -3094,14 +3151,27 @@ static unsigned lds_pad()
     return v;
 }
 
-void fsk_lav2_hdr32(const FsLav2Args32 &A, int mode, bool stats, int variant, hipStream_t s)
+static unsigned lav2_block_size()
 {
-    const unsigned pad = lds_pad();
     static const unsigned bs = [] {
         const char *e = getenv("FSMI355_BLOCK"); // launch-shape experiment: 64, 128 or 256
         const unsigned v = e ? (unsigned)atoi(e) : 256u;
         return v == 64u || v == 128u ? v : 256u;
     }();
+    return bs;
+}
+
+uint32_t fsk_lav2_hdr32_slots(const FsFrame &f)
+{
+    if (lav2_block_size() != 256u)
+        return 0;
+    return ((f.width + 31u) / 32u) * 4u * ((f.local_rows + 7u) / 8u);
+}
+
+void fsk_lav2_hdr32(const FsLav2Args32 &A, int mode, bool stats, int variant, hipStream_t s)
+{
+    const unsigned pad = lds_pad();
+    const unsigned bs = lav2_block_size();
     // A/B flag of fs_set_kernel_variant: the wave-uniform scaled runs' orbit entries through LDS (see the kernel)
     const bool lds_orbit = (variant & FS_VARIANT_FLAG_LDS_ORBIT) != 0;
     variant &= FS_VARIANT_BASE_MASK;

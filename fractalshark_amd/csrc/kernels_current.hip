@@ -311,3 +311,123 @@ void fsk_tile_order(const uint32_t *probe, uint32_t probe_pitch, uint32_t tiles_
 {
     hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, probe, probe_pitch, tiles_x, tiles_y, threshold, order, n_slots);
 }
+
+// ------------------------------------------------------------------------------------------------
+// "Longest tiles first" from recorded costs (k_lav2_hdr32_fast writes one word per 8 x 8 tile: its longest lane's step
+// count; the next frame of the same geometry is launched in this order, fs_render_lav2).  A frame ends one long wave after
+// its LAST wave was dispatched, and the waves of one frame differ 2.5x in length: started first,
+// the long ones finish while the chip is still full.
+// One workgroup.  The costs are cut into 64 classes between the frame's minimum and maximum, highest first, and the tiles
+// are sorted by class with two stable 8-way counting passes (low three bits, then high three bits), so tiles of one class
+// keep their raster order: neighbours (whose costs are alike) still start together and walk the same stretch of the orbit.
+namespace {
+constexpr uint32_t kSortThreads = 1024;
+
+__device__ __forceinline__ uint32_t cost_class(uint32_t c, uint32_t mn, uint32_t span)
+{
+    // 63 - floor(64 (c - mn) / span), span = max - min + 1 (the product stays below 2^38)
+    return 63u - (uint32_t)(((uint64_t)(c - mn) << 6) / span);
+}
+
+// one stable 8-way pass over the sequence seq[0 .. n) (seq == nullptr: the identity) by digit (class >> shift) & 7
+__device__ void tile_sort_pass(const uint32_t *__restrict__ cost, const uint32_t *__restrict__ seq, uint32_t *__restrict__ out,
+                               uint32_t n, uint32_t shift, uint32_t mn, uint32_t span, uint32_t (*s_cnt)[kSortThreads],
+                               uint32_t *s_scan)
+{
+    const uint32_t t = threadIdx.x, chunk = (n + kSortThreads - 1u) / kSortThreads;
+    const uint32_t lo = t * chunk < n ? t * chunk : n, hi = lo + chunk < n ? lo + chunk : n;
+    uint32_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t i = lo; i < hi; i++) {
+        const uint32_t tile = seq ? seq[i] : i;
+        const uint32_t d = (cost_class(cost[tile], mn, span) >> shift) & 7u;
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++)
+            c[k] += d == k ? 1u : 0u;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++)
+        s_cnt[k][t] = c[k];
+    __syncthreads();
+    // exclusive scan of the 8192 counters in (digit, thread) order: thread t owns positions 8t .. 8t + 7
+    uint32_t *flat = &s_cnt[0][0];
+    uint32_t mine = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++)
+        mine += flat[8u * t + k];
+    s_scan[t] = mine;
+    __syncthreads();
+    for (uint32_t d = 1; d < kSortThreads; d <<= 1) {
+        const uint32_t v = t >= d ? s_scan[t - d] : 0u;
+        __syncthreads();
+        s_scan[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_scan[t] - mine;
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++) {
+        const uint32_t v = flat[8u * t + k];
+        flat[8u * t + k] = run;
+        run += v;
+    }
+    __syncthreads();
+    uint32_t at[8];
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++)
+        at[k] = s_cnt[k][t];
+    for (uint32_t i = lo; i < hi; i++) {
+        const uint32_t tile = seq ? seq[i] : i;
+        const uint32_t d = (cost_class(cost[tile], mn, span) >> shift) & 7u;
+        uint32_t pos = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
+            pos = d == k ? at[k] : pos;
+            at[k] += d == k ? 1u : 0u;
+        }
+        out[pos] = tile;
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(kSortThreads) k_tile_order_by_cost(const uint32_t *__restrict__ cost, uint32_t n,
+                                                                     uint32_t *__restrict__ tmp, uint32_t *__restrict__ order,
+                                                                     uint32_t n_slots)
+{
+    __shared__ uint32_t s_cnt[8][kSortThreads];
+    __shared__ uint32_t s_scan[kSortThreads];
+    __shared__ uint32_t s_mn[kSortThreads / 64], s_mx[kSortThreads / 64];
+    const uint32_t t = threadIdx.x;
+    uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+    for (uint32_t i = t; i < n; i += kSortThreads) {
+        const uint32_t c = cost[i];
+        mn = c < mn ? c : mn;
+        mx = c > mx ? c : mx;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t a = __shfl_down(mn, off), b = __shfl_down(mx, off);
+        mn = a < mn ? a : mn;
+        mx = b > mx ? b : mx;
+    }
+    if ((t & 63u) == 0u)
+        s_mn[t >> 6] = mn, s_mx[t >> 6] = mx;
+    __syncthreads();
+    mn = s_mn[0], mx = s_mx[0];
+    for (uint32_t k = 1; k < kSortThreads / 64; k++) {
+        mn = s_mn[k] < mn ? s_mn[k] : mn;
+        mx = s_mx[k] > mx ? s_mx[k] : mx;
+    }
+    const uint32_t span = mx - mn + 1u; // (mx - mn <= 2^32 - 2: costs are step counts below the iteration cap)
+    tile_sort_pass(cost, nullptr, tmp, n, 0u, mn, span, s_cnt, s_scan);
+    __threadfence_block();
+    tile_sort_pass(cost, tmp, order, n, 3u, mn, span, s_cnt, s_scan);
+    for (uint32_t i = n + t; i < n_slots; i += kSortThreads)
+        order[i] = 0xFFFFFFFFu;
+    if (t == 0)
+        order[n_slots] = 0u;
+}
+} // namespace
+
+void fsk_tile_order_by_cost(const uint32_t *cost, uint32_t n_tiles, uint32_t *tmp, uint32_t *order, uint32_t n_slots,
+                            hipStream_t s)
+{
+    hipLaunchKernelGGL(k_tile_order_by_cost, dim3(1), dim3(kSortThreads), 0, s, cost, n_tiles, tmp, order, n_slots);
+}

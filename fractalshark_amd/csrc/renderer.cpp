@@ -30,8 +30,11 @@ struct fs_renderer {
     int device = 0;
     hipStream_t compute = nullptr;
     hipStream_t display = nullptr;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
-    bool timed = false;
+    // HIP events around the iteration-kernel launches, a ring of pairs: fs_last_kernel_ms reads the newest one,
+    // fs_kernel_ms_history the last few (frames that are in flight together, e.g. a pipelined bench loop, each keep theirs)
+    static constexpr uint32_t kTimingRing = 64;
+    hipEvent_t ev_start[kTimingRing] = {}, ev_stop[kTimingRing] = {};
+    uint64_t timed_launches = 0; // launches recorded so far; launch i uses pair i % kTimingRing
 
     // geometry
     uint32_t width = 0, height = 0, aa = 0, iter_bytes = 0;
@@ -55,6 +58,22 @@ struct fs_renderer {
     uint32_t *queue = nullptr; // pixel counter of the persistent launches (kernels.hip, k_perturb_scalar)
     uint32_t *tile_probe = nullptr, *tile_order = nullptr; // "long tiles first" (fs_render_bla): probe counts, launch order
     size_t tile_probe_cap = 0, tile_order_cap = 0;           // in elements
+    // "longest tiles first" of the tuned LAv2 kernel (fs_render_lav2): the costs the last frame recorded per 8 x 8 tile, the
+    // launch order made from them, work memory of the sort; and what the costs belong to (a frame of another geometry, band
+    // layout or orbit generation starts cold: natural order, costs recorded)
+    uint32_t *lav2_cost = nullptr, *lav2_order = nullptr, *lav2_sort_tmp = nullptr;
+    size_t lav2_cost_cap = 0, lav2_order_cap = 0; // in elements
+    bool lav2_cost_valid = false;
+    struct CostKey {
+        uint32_t width, local_rows, band_first, band_rows, band_stride;
+        uint64_t orbit_gen;
+        bool operator==(const CostKey &o) const
+        {
+            return width == o.width && local_rows == o.local_rows && band_first == o.band_first && band_rows == o.band_rows &&
+                   band_stride == o.band_stride && orbit_gen == o.orbit_gen;
+        }
+    } lav2_cost_key{};
+    bool last_frame_ordered = false; // the last fs_render_lav2 launch used a recorded order (fs_last_frame_tile_ordered)
     bool stats_on = false;
     int variant = FS_VARIANT_TUNED;
 
@@ -345,6 +364,8 @@ FsFrame make_frame(const fs_renderer *r)
 constexpr uint64_t kTileProbeDivisor = 32;
 constexpr uint64_t kTileOrderMinIterations = 1ull << 18;
 constexpr uint32_t kTileOrderMinTiles = 4096;
+// the same for the self-recorded order of the tuned LAv2 kernel: below this many tiles the chip is not full anyway
+constexpr uint32_t kLav2OrderMinTiles = 2048;
 
 // zq: the tuned LAv2 loop's view of the prepared orbit (same length incl. the two spare entries)
 hipError_t make_quiet_orbit(fs_renderer *r, uint64_t n)
@@ -559,6 +580,12 @@ void free_all(fs_renderer *r)
         r_free(r, r->tile_order);
     r->tile_probe = r->tile_order = nullptr;
     r->tile_probe_cap = r->tile_order_cap = 0;
+    (void)r_free(r, r->lav2_cost);
+    (void)r_free(r, r->lav2_order);
+    (void)r_free(r, r->lav2_sort_tmp);
+    r->lav2_cost = r->lav2_order = r->lav2_sort_tmp = nullptr;
+    r->lav2_cost_cap = r->lav2_order_cap = 0;
+    r->lav2_cost_valid = false;
 
     if (r->pal)
         r_free(r, r->pal);
@@ -581,16 +608,16 @@ struct TimedLaunch {
     fs_renderer *r;
     explicit TimedLaunch(fs_renderer *rr) : r(rr)
     {
-        if (r->ev_start)
-            hipEventRecord(r->ev_start, r->compute);
+        if (r->ev_start[0])
+            hipEventRecord(r->ev_start[r->timed_launches % fs_renderer::kTimingRing], r->compute);
         if (r->stats_on && r->stats)
             hipMemsetAsync(r->stats, 0, (r->stats_words == 32 ? 32 : 8) * sizeof(uint64_t), r->compute);
     }
     ~TimedLaunch()
     {
-        if (r->ev_stop) {
-            hipEventRecord(r->ev_stop, r->compute);
-            r->timed = true;
+        if (r->ev_stop[0]) {
+            hipEventRecord(r->ev_stop[r->timed_launches % fs_renderer::kTimingRing], r->compute);
+            r->timed_launches++;
         }
     }
 };
@@ -679,10 +706,12 @@ void fs_destroy(fs_renderer *r)
         free_all(r);
         if (r->compute)
             hipStreamSynchronize(r->compute); // the stream-ordered frees have run before their stream goes away
-        if (r->ev_start)
-            hipEventDestroy(r->ev_start);
-        if (r->ev_stop)
-            hipEventDestroy(r->ev_stop);
+        for (uint32_t i = 0; i < fs_renderer::kTimingRing; i++) {
+            if (r->ev_start[i])
+                hipEventDestroy(r->ev_start[i]);
+            if (r->ev_stop[i])
+                hipEventDestroy(r->ev_stop[i]);
+        }
         if (r->compute)
             hipStreamDestroy(r->compute);
         if (r->display)
@@ -750,8 +779,10 @@ uint32_t fs_init_memory(fs_renderer *r, uint32_t w, uint32_t h, uint32_t antiali
         FS_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
         FS_TRY(hipStreamCreateWithPriority(&r->compute, hipStreamNonBlocking, lo));
         FS_TRY(hipStreamCreateWithPriority(&r->display, hipStreamNonBlocking, hi));
-        FS_TRY(hipEventCreate(&r->ev_start));
-        FS_TRY(hipEventCreate(&r->ev_stop));
+        for (uint32_t i = 0; i < fs_renderer::kTimingRing; i++) {
+            FS_TRY(hipEventCreate(&r->ev_start[i]));
+            FS_TRY(hipEventCreate(&r->ev_stop[i]));
+        }
         // the stream-ordered allocator keeps freed memory for the next allocation instead of returning it to the driver at
         // every synchronisation (uploads synchronise: their host buffers are borrowed for the call only)
         hipMemPool_t pool = nullptr;
@@ -766,6 +797,10 @@ uint32_t fs_init_memory(fs_renderer *r, uint32_t w, uint32_t h, uint32_t antiali
     if (pal_interleaved && (r->pal_cached_host != pal_interleaved || r->pal_cached_gen != palette_generation ||
                             r->pal_iters != pal_iters)) {
         if (r->pal) {
+            // a progressive RenderCurrent on the display stream may still be reading the old palette, and r_free parks the
+            // block where the r_alloc below finds it again: the display stream must have drained before the block is reused
+            // (hipFree used to synchronise the whole device here)
+            FS_TRY(hipStreamSynchronize(r->display));
             FS_TRY(r_free(r, r->pal));
             r->pal = nullptr;
         }
@@ -1797,8 +1832,52 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
         A.zq = r->zq;
         A.zs = r->zq + r->zq_n;
         A.at = r->at;
+        // Longest tiles first, self-recorded.  Every frame of the tuned kernel stores one cost word per 8 x 8 tile (its
+        // longest lane's step count); the NEXT frame of the same geometry, band layout and orbit generation is launched in
+        // descending cost order (64 classes, raster order inside a class).  A frame ends one long wave after its last wave
+        // was dispatched and the waves differ 2.5x in length, so the drain at the end of the launch shrinks from the longest
+        // wave's duration towards the shortest's.  Which wave renders which tile changes no pixel; the first frame (and
+        // every frame after fs_forget_tile_costs, or with FS_VARIANT_NATURAL_TILE_ORDER) runs in natural order.
+        const uint32_t tiles_x = (r->width + 7u) / 8u, tiles_y = (r->local_rows + 7u) / 8u;
+        const uint32_t n_tiles = tiles_x * tiles_y;
+        const uint32_t n_slots = fsk_lav2_hdr32_slots(A.frame);
+        const bool tuned = (r->variant & FS_VARIANT_BASE_MASK) != FS_VARIANT_LITERAL;
+        const bool record = tuned && n_slots != 0u && n_tiles >= kLav2OrderMinTiles &&
+                            (r->variant & FS_VARIANT_FLAG_NATURAL_ORDER) == 0;
+        r->last_frame_ordered = false;
+        if (record) {
+            if (r->lav2_cost_cap < n_tiles) {
+                (void)r_free(r, r->lav2_cost);
+                (void)r_free(r, r->lav2_sort_tmp);
+                r->lav2_cost = r->lav2_sort_tmp = nullptr;
+                r->lav2_cost_cap = 0;
+                r->lav2_cost_valid = false;
+                FS_TRY(r_alloc(r, (void **)&r->lav2_cost, (size_t)n_tiles * sizeof(uint32_t), kFrame));
+                FS_TRY(r_alloc(r, (void **)&r->lav2_sort_tmp, (size_t)n_tiles * sizeof(uint32_t), kFrame));
+                r->lav2_cost_cap = n_tiles;
+            }
+            if (r->lav2_order_cap < n_slots) {
+                (void)r_free(r, r->lav2_order);
+                r->lav2_order = nullptr;
+                r->lav2_order_cap = 0;
+                FS_TRY(r_alloc(r, (void **)&r->lav2_order, ((size_t)n_slots + 1) * sizeof(uint32_t), kFrame));
+                r->lav2_order_cap = n_slots;
+            }
+            const fs_renderer::CostKey key{r->width, r->local_rows, A.frame.band_first, A.frame.band_rows,
+                                           A.frame.band_stride, r->orbit_gen};
+            A.tile_cost = r->lav2_cost;
+            A.tiles_x = tiles_x;
+            if (r->lav2_cost_valid && r->lav2_cost_key == key)
+                A.tile_order = r->lav2_order;
+            r->lav2_cost_key = key;
+        }
+        if (A.tile_order) {
+            fsk_tile_order_by_cost(r->lav2_cost, n_tiles, r->lav2_sort_tmp, r->lav2_order, n_slots, r->compute);
+            r->last_frame_ordered = true;
+        }
         TimedLaunch t(r);
         fsk_lav2_hdr32(A, kmode, r->stats_on, r->variant, r->compute);
+        r->lav2_cost_valid = record;
     } else {
         FsLav2ArgsT<double> A;
         fill_lav2<double>(r, A, coords, n_iterations, parity);
@@ -2305,12 +2384,25 @@ uint32_t fs_get_height(const fs_renderer *r) { return r->height; }
 
 float fs_last_kernel_ms(const fs_renderer *r)
 {
-    if (!r->timed)
+    if (r->timed_launches == 0)
         return -1.0f;
     float ms = -1.0f;
-    if (hipEventElapsedTime(&ms, r->ev_start, r->ev_stop) != hipSuccess)
+    const uint32_t i = (uint32_t)((r->timed_launches - 1) % fs_renderer::kTimingRing);
+    if (hipEventElapsedTime(&ms, r->ev_start[i], r->ev_stop[i]) != hipSuccess)
         return -1.0f;
     return ms;
+}
+
+uint32_t fs_kernel_ms_history(const fs_renderer *r, float *ms_out, uint32_t n)
+{
+    // the last n launches, oldest first; they must have completed (fs_sync_compute)
+    if (n > fs_renderer::kTimingRing || n > r->timed_launches)
+        return (uint32_t)hipErrorInvalidValue;
+    for (uint32_t k = 0; k < n; k++) {
+        const uint32_t i = (uint32_t)((r->timed_launches - n + k) % fs_renderer::kTimingRing);
+        FS_TRY(hipEventElapsedTime(&ms_out[k], r->ev_start[i], r->ev_stop[i]));
+    }
+    return 0;
 }
 
 uint32_t fs_set_kernel_variant(fs_renderer *r, int variant)
@@ -2320,6 +2412,44 @@ uint32_t fs_set_kernel_variant(fs_renderer *r, int variant)
         (flags & ~(FS_VARIANT_FLAG_LDS_ORBIT | FS_VARIANT_FLAG_REFILL | FS_VARIANT_FLAG_WIDE | FS_VARIANT_FLAG_NATURAL_ORDER)) != 0)
         return hipErrorInvalidValue;
     r->variant = base | flags;
+    return 0;
+}
+
+uint32_t fs_forget_tile_costs(fs_renderer *r)
+{
+    r->lav2_cost_valid = false;
+    return 0;
+}
+
+int fs_last_frame_tile_ordered(fs_renderer *r) { return r->last_frame_ordered ? 1 : 0; }
+
+uint32_t fs_read_tile_costs(fs_renderer *r, uint32_t *out, uint64_t max_words, uint64_t *n_tiles)
+{
+    if (uint32_t e = use_device(r))
+        return e;
+    if (!r->lav2_cost || !r->lav2_cost_valid)
+        return FS_ERR_6;
+    const uint64_t n = (uint64_t)((r->lav2_cost_key.width + 7u) / 8u) * ((r->lav2_cost_key.local_rows + 7u) / 8u);
+    if (n_tiles)
+        *n_tiles = n;
+    const uint64_t m = n < max_words ? n : max_words;
+    if (out && m) {
+        FS_TRY(hipMemcpyAsync(out, r->lav2_cost, m * sizeof(uint32_t), hipMemcpyDeviceToHost, r->compute));
+        FS_TRY(hipStreamSynchronize(r->compute));
+    }
+    return 0;
+}
+
+uint32_t fs_read_tile_order(fs_renderer *r, uint32_t *out, uint64_t max_words)
+{
+    if (uint32_t e = use_device(r))
+        return e;
+    if (!r->lav2_order || !r->last_frame_ordered)
+        return FS_ERR_6;
+    const uint64_t n = (uint64_t)((r->lav2_cost_key.width + 7u) / 8u) * ((r->lav2_cost_key.local_rows + 7u) / 8u);
+    const uint64_t m = n < max_words ? n : max_words;
+    FS_TRY(hipMemcpyAsync(out, r->lav2_order, m * sizeof(uint32_t), hipMemcpyDeviceToHost, r->compute));
+    FS_TRY(hipStreamSynchronize(r->compute));
     return 0;
 }
 

@@ -320,6 +320,14 @@ class GPURenderer:
     def last_kernel_ms(self):
         return float(self._lib.fs_last_kernel_ms(self._h))
 
+    def kernel_ms_history(self, n):
+        """Durations (ms) of the last n iteration-kernel launches, oldest first (after SyncComputeStream)."""
+        out = (C.c_float * int(n))()
+        err = self._lib.fs_kernel_ms_history(self._h, out, int(n))
+        if err:
+            raise RuntimeError("fs_kernel_ms_history: %s" % self.ConvertErrorToString(err))
+        return [float(x) for x in out]
+
     def set_kernel_variant(self, literal=False, lds_orbit=False, refill=False, wide_counters=False,
                            natural_tile_order=False):
         """False / 0 (default): tuned loops; True / 1: literal transcription; 2: tuned loops without the scaled runs
@@ -330,6 +338,30 @@ class GPURenderer:
              (VARIANT_WIDE_COUNTERS if wide_counters else 0) |  # wide_counters: 64-bit counting kernels at any cap (tests)
              (VARIANT_NATURAL_TILE_ORDER if natural_tile_order else 0))
         return self._lib.fs_set_kernel_variant(self._h, v)
+
+    def forget_tile_costs(self):
+        """The next RenderPerturbLAv2 frame of the tuned HDRFloat<float> kernel starts cold: natural tile order (it
+        records costs again; the one after it runs longest tiles first)."""
+        return self._lib.fs_forget_tile_costs(self._h)
+
+    def last_frame_tile_ordered(self):
+        return bool(self._lib.fs_last_frame_tile_ordered(self._h))
+
+    def read_tile_costs(self):
+        """Costs the last tuned LAv2 frame recorded, one per 8 x 8 tile of the local buffer (row-major), or None."""
+        n = C.c_uint64(0)
+        if self._lib.fs_read_tile_costs(self._h, None, 0, C.byref(n)) != 0:
+            return None
+        out = np.zeros(int(n.value), np.uint32)
+        assert self._lib.fs_read_tile_costs(self._h, out.ctypes.data, out.size, C.byref(n)) == 0
+        return out
+
+    def read_tile_order(self, n_tiles):
+        """Launch order of the last frame when it was an ordered one (a permutation of range(n_tiles)), else None."""
+        out = np.zeros(int(n_tiles), np.uint32)
+        if self._lib.fs_read_tile_order(self._h, out.ctypes.data, out.size) != 0:
+            return None
+        return out
 
     def enable_step_count(self, on=True):
         return self._lib.fs_enable_step_count(self._h, 1 if on else 0)

@@ -65,6 +65,15 @@ def reassemble_index(height, world, band=8):
     return idx
 
 
+def gather_slices(local, gathered, rank, world):
+    """The collective alone: every rank's padded slice `local` [max_rows, W] to rank 0's `gathered` [world * max_rows, W]
+    (needed on rank 0 only), enqueued on the caller's current stream.  bench.py's pipelined loop restores row order into
+    a buffer of its own (torch.index_select(..., out=...)) so that no tensor is allocated per frame."""
+    import torch.distributed as dist
+    chunks = list(gathered.view(world, local.shape[0], local.shape[1]).unbind(0)) if rank == 0 else None
+    dist.gather(local, gather_list=chunks, dst=0)
+
+
 def gather_frame(local, gathered, frame_index, rank, world):
     """The data-path collective: every rank's padded slice `local` [max_rows, W] goes to rank 0 (torch.distributed.gather:
     with the nccl backend one ncclGroup of send / recv pairs), where `gathered` [world * max_rows, W] receives them back to

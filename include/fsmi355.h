@@ -259,6 +259,9 @@ uint32_t fs_get_height(const fs_renderer *r);
  * [5] = perturbation steps that went through the careful (exit-tested) path of the tuned LAv2 loop, [6] = steps taken in
  * its scaled runs, [7] = scaled runs started (both per lane). */
 float fs_last_kernel_ms(const fs_renderer *r);
+/* The durations of the last n (<= 64) iteration-kernel launches, oldest first (each launch keeps its own pair of HIP
+ * events, so frames that were in flight together can be read after the fact); valid after fs_sync_compute. */
+uint32_t fs_kernel_ms_history(const fs_renderer *r, float *ms_out, uint32_t n);
 /* Low byte: 0 (default) = tuned iteration loops; 1 = literal operation-by-operation transcription of the CPU function;
  * 2 = tuned loops without the scaled runs of the HDRFloat<float> LAv2 kernel (slower; kept as in-library A/B references
  * for the tuned loops -- results are identical).  ORed with A/B flags, both off by default because they measure slower
@@ -271,7 +274,8 @@ float fs_last_kernel_ms(const fs_renderer *r);
  *   FS_VARIANT_WIDE_COUNTERS  (test switch) every entry point launches the instantiation of its kernel that counts
  *                         iterations in 64 bits -- the ones an iteration cap of 2^32 or above selects -- whatever the cap is:
  *                         lets the 64-bit kernels be compared with the CPU functions at caps a test can afford.
- *   FS_VARIANT_NATURAL_TILE_ORDER  fs_render_bla without BLA (perturbation only, HDRFloat<float>) launches a frame's 8 x 8
+ *   FS_VARIANT_NATURAL_TILE_ORDER  fs_render_bla without BLA (perturbation only, HDRFloat<float>) and the tuned
+ *                         HDRFloat<float> fs_render_lav2 (self-recorded order, see fs_forget_tile_costs) launch a frame's 8 x 8
  *                         tiles in their natural order.  Default for frames with an iteration limit of 2^18 or more and
  *                         at least 4096 tiles: the tiles that hold long-running pixels first (a probe launch runs every
  *                         tile's centre pixel for n_iterations / 32 steps) -- which wave renders which tile
@@ -280,6 +284,20 @@ float fs_last_kernel_ms(const fs_renderer *r);
 enum { FS_VARIANT_LDS_ORBIT = 0x100, FS_VARIANT_REFILL = 0x200, FS_VARIANT_WIDE_COUNTERS = 0x400,
        FS_VARIANT_NATURAL_TILE_ORDER = 0x800 };
 uint32_t fs_set_kernel_variant(fs_renderer *r, int variant);
+/* Longest tiles first, self-recorded (this project's addition).  Every fs_render_lav2 frame of the tuned
+ * HDRFloat<float> kernel records one cost word per 8 x 8 tile (its longest lane's step count); the next frame with the
+ * same geometry, row bands and orbit generation is launched in descending cost order -- "warm".  The first frame, a frame
+ * after any of those changed or after fs_forget_tile_costs, and every frame under FS_VARIANT_NATURAL_TILE_ORDER run in
+ * natural order -- "cold".  The order changes which wave renders which tile, never a pixel.
+ * fs_last_frame_tile_ordered: 1 when the most recent fs_render_lav2 launch used a recorded order.
+ * fs_read_tile_costs: the costs the last frame recorded (row-major tiles of the LOCAL buffer, (width + 7) / 8 per row);
+ * *n_tiles = their number; out may be NULL.  FractalSharkError 10006 when nothing has been recorded. */
+uint32_t fs_forget_tile_costs(fs_renderer *r);
+int fs_last_frame_tile_ordered(fs_renderer *r);
+uint32_t fs_read_tile_costs(fs_renderer *r, uint32_t *out, uint64_t max_words, uint64_t *n_tiles);
+/* The launch order of the most recent frame when it was an ordered one (its first n_tiles words: a permutation of the tile
+ * numbers, highest cost class first); 10006 otherwise.  For tests. */
+uint32_t fs_read_tile_order(fs_renderer *r, uint32_t *out, uint64_t max_words);
 uint32_t fs_enable_step_count(fs_renderer *r, int enable);
 uint32_t fs_read_step_count(fs_renderer *r, uint64_t counts[8]);
 /* The whole statistics buffer (measurement builds append per-wave trace records behind the 8 counters: library built
