@@ -155,6 +155,7 @@ def render_lib():
     _decl(lib, "fs_group_clear", u32, [vp])
     _decl(lib, "fs_group_render_current", u32, [vp, u64, vp, vp])
     _decl(lib, "fs_group_sync", u32, [vp])
+    _decl(lib, "fs_group_wait_current", u32, [vp, u32])
     _decl(lib, "fs_group_gather_ms", C.c_float, [vp])
     _decl(lib, "fs_group_plan", None, [u32, u32, u32, u32, vp, vp, vp])
     _render = lib
@@ -173,7 +174,7 @@ RENDER_SYMBOLS = [
     "fs_group_create", "fs_group_destroy", "fs_group_size", "fs_group_transport", "fs_group_renderer", "fs_group_init_memory",
     "fs_group_upload_orbit", "fs_group_upload_orbit_compressed", "fs_group_upload_la", "fs_group_upload_bla",
     "fs_group_upload_orbit_scaled", "fs_group_render_lav2", "fs_group_render_bla", "fs_group_render_scaled",
-    "fs_group_render_direct", "fs_group_clear", "fs_group_render_current", "fs_group_sync", "fs_group_gather_ms",
+    "fs_group_render_direct", "fs_group_clear", "fs_group_render_current", "fs_group_sync", "fs_group_wait_current", "fs_group_gather_ms",
     "fs_group_plan",
 ]
 

@@ -77,14 +77,23 @@ struct fs_group {
     std::vector<void *> slices;    // per member: its slice buffer on its own device (external iteration buffer)
     int transport = 0;
     uint32_t width = 0, height = 0, band = 8, iter_bytes = 4, rounded_width = 0, max_rows = 0;
-    void *gathered = nullptr;      // device 0: N slices back to back
-    void *frame = nullptr;         // device 0: rows in order, padded to 8
+    // Two frames can be in flight: while frame k is received, put in row order, reduced and copied to the
+    // host on device 0's POST stream, the members render frame k+1.  Everything frame k's post-processing reads or writes
+    // on device 0 therefore exists twice, used in rotation (`cur` = the set the frame being rendered lands in):
+    static constexpr int kSets = 2;
+    void *gathered[kSets] = {};    // device 0: N slices back to back (member 0 renders straight into slot 0)
+    void *frame[kSets] = {};       // device 0: rows in order, padded to 8
     uint32_t *index = nullptr;     // device 0: frame row -> gathered row
     fs_reduction *reduction = nullptr;
     fs_reduction reduce_seed{};
     float last_gather_ms = -1.0f;
+    int cur = 0;
+    uint64_t frames_posted = 0;         // fs_group_render_current calls so far
+    hipStream_t post = nullptr;         // device 0: receive + row order + reduction + D2H of a finished frame
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
-    hipEvent_t ev_consumed = nullptr; // recorded on member 0's stream once k_gather_rows has read the gather slots
+    hipEvent_t ev_rendered[kSets] = {}; // member 0's kernel of the frame in set b has finished (recorded on its compute stream)
+    hipEvent_t ev_consumed[kSets] = {}; // k_gather_rows has read gathered[b]: its slots may be written again
+    hipEvent_t ev_done[kSets] = {};     // the frame of set b is in the caller's host buffer
     size_t slice_bytes() const { return (size_t)max_rows * rounded_width * iter_bytes; }
 };
 
@@ -156,21 +165,26 @@ static void group_free_buffers(fs_group *g)
         }
     g->slices.clear();
     // member 0 renders straight into its gather slot (no slice of its own): detach it before that memory goes away
-    if (g->gathered && !g->members.empty())
+    if (g->gathered[0] && !g->members.empty())
         (void)fs_set_external_iter_buffer(g->members[0], nullptr, 0);
     if (!g->devices.empty() && hipSetDevice(g->devices[0]) == hipSuccess) {
-        if (g->gathered)
-            (void)hipFree(g->gathered);
-        if (g->frame)
-            (void)hipFree(g->frame);
+        if (g->post)
+            (void)hipStreamSynchronize(g->post);
+        for (int b = 0; b < fs_group::kSets; b++) {
+            if (g->gathered[b])
+                (void)hipFree(g->gathered[b]);
+            if (g->frame[b])
+                (void)hipFree(g->frame[b]);
+            g->gathered[b] = g->frame[b] = nullptr;
+        }
         if (g->index)
             (void)hipFree(g->index);
         if (g->reduction)
             (void)hipFree(g->reduction);
     }
-    g->gathered = g->frame = nullptr;
     g->index = nullptr;
     g->reduction = nullptr;
+    g->cur = 0;
 }
 
 void fs_group_destroy(fs_group *g)
@@ -183,8 +197,16 @@ void fs_group_destroy(fs_group *g)
         (void)hipEventDestroy(g->ev_a);
     if (g->ev_b)
         (void)hipEventDestroy(g->ev_b);
-    if (g->ev_consumed)
-        (void)hipEventDestroy(g->ev_consumed);
+    for (int b = 0; b < fs_group::kSets; b++) {
+        if (g->ev_rendered[b])
+            (void)hipEventDestroy(g->ev_rendered[b]);
+        if (g->ev_consumed[b])
+            (void)hipEventDestroy(g->ev_consumed[b]);
+        if (g->ev_done[b])
+            (void)hipEventDestroy(g->ev_done[b]);
+    }
+    if (g->post && !g->devices.empty() && hipSetDevice(g->devices[0]) == hipSuccess)
+        (void)hipStreamDestroy(g->post);
     for (void *c : g->comms)
         if (c)
             rccl().CommDestroy(c);
@@ -228,25 +250,37 @@ uint32_t fs_group_init_memory(fs_group *g, uint32_t w, uint32_t h, uint32_t anti
     // device 0: the gather target (N padded slices), the ordered frame, the row index, the reduction cell
     FSG_TRY(hipSetDevice(g->devices[0]));
     const size_t sb = g->slice_bytes();
-    FSG_TRY(hipMalloc(&g->gathered, sb * world));
-    FSG_TRY(hipMemset(g->gathered, 0, sb * world));
     const size_t frame_rows = ((size_t)h + 7u) / 8u * 8u;
-    FSG_TRY(hipMalloc(&g->frame, frame_rows * g->rounded_width * iter_bytes));
-    FSG_TRY(hipMemset(g->frame, 0, frame_rows * g->rounded_width * iter_bytes));
+    for (int b = 0; b < fs_group::kSets; b++) {
+        FSG_TRY(hipMalloc(&g->gathered[b], sb * world));
+        FSG_TRY(hipMemset(g->gathered[b], 0, sb * world));
+        FSG_TRY(hipMalloc(&g->frame[b], frame_rows * g->rounded_width * iter_bytes));
+        FSG_TRY(hipMemset(g->frame[b], 0, frame_rows * g->rounded_width * iter_bytes));
+    }
     FSG_TRY(hipMalloc((void **)&g->index, sizeof(uint32_t) * h));
     FSG_TRY(hipMemcpy(g->index, idx.data(), sizeof(uint32_t) * h, hipMemcpyHostToDevice));
     FSG_TRY(hipMalloc((void **)&g->reduction, sizeof(fs_reduction)));
     if (!g->ev_a) {
         FSG_TRY(hipEventCreate(&g->ev_a));
         FSG_TRY(hipEventCreate(&g->ev_b));
-        FSG_TRY(hipEventCreateWithFlags(&g->ev_consumed, hipEventDisableTiming));
+        for (int b = 0; b < fs_group::kSets; b++) {
+            FSG_TRY(hipEventCreateWithFlags(&g->ev_rendered[b], hipEventDisableTiming));
+            FSG_TRY(hipEventCreateWithFlags(&g->ev_consumed[b], hipEventDisableTiming));
+            FSG_TRY(hipEventCreateWithFlags(&g->ev_done[b], hipEventDisableTiming));
+        }
+        // highest priority: when a finished frame's slices arrive, device 0 is already rendering the next frame on its
+        // (lowest-priority) compute stream, and the row-order kernel takes the first wave slots that come free
+        int prio_least = 0, prio_greatest = 0;
+        FSG_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+        FSG_TRY(hipStreamCreateWithPriority(&g->post, hipStreamNonBlocking, prio_greatest));
     }
+    g->cur = 0;
     // every member renders into a slice buffer of the common (padded) size; member 0 straight into its gather slot
     g->slices.assign(world, nullptr);
     for (uint32_t r = 0; r < world; r++) {
         void *buf = nullptr;
         if (r == 0) {
-            buf = g->gathered;
+            buf = g->gathered[0];
         } else {
             FSG_TRY(hipSetDevice(g->devices[r]));
             FSG_TRY(hipMalloc(&buf, sb));
@@ -334,21 +368,46 @@ uint32_t fs_group_sync(fs_group *g)
 {
     for (fs_renderer *r : g->members)
         FSG_TRY(fs_sync_compute(r));
+    if (g->post) {
+        FSG_TRY(hipSetDevice(g->devices[0]));
+        FSG_TRY(hipStreamSynchronize(g->post));
+    }
     return 0;
 }
 
+// Host waits until the fs_group_render_current issued `frames_back` calls ago (0 = the latest, 1 = the one before) has
+// delivered its frame (and reduction) to the caller's buffers.  A pipelined host loop: render k, render_current k,
+// wait_current(1) -- frame k-1 is complete while frame k is still being rendered.
+uint32_t fs_group_wait_current(fs_group *g, uint32_t frames_back)
+{
+    if (frames_back >= (uint32_t)fs_group::kSets || frames_back >= g->frames_posted)
+        return frames_back >= g->frames_posted ? 0u : (uint32_t)hipErrorInvalidValue;
+    const int b = (int)((g->frames_posted - 1 - frames_back) % fs_group::kSets);
+    FSG_TRY(hipSetDevice(g->devices[0]));
+    return (uint32_t)hipEventSynchronize(g->ev_done[b]);
+}
+
 // Gather + RenderCurrent: slices -> device 0 over xGMI, row order restored, min / max / sum, D2H of the padded frame.
-// Asynchronous on member 0's compute stream (fs_group_sync waits); iter_buffer / reduction may be NULL.
+// Asynchronous: on device 0's POST stream, behind the members' kernels on the device (events, no host round trip), so the
+// members' NEXT frame can be launched right away and runs while this one is delivered (fs_group_wait_current /
+// fs_group_sync wait); iter_buffer / reduction may be NULL.
 uint32_t fs_group_render_current(fs_group *g, uint64_t n_iterations, void *iter_buffer, fs_reduction *reduction)
 {
     (void)n_iterations;
     const uint32_t world = (uint32_t)g->members.size();
-    if (!g->gathered)
+    if (!g->gathered[0])
         return 0; // memory not initialised: silent, like GPURenderer::RenderCurrent
     const size_t sb = g->slice_bytes();
+    const int b = g->cur;
+    void *const gathered = g->gathered[b];
+    void *const frame = g->frame[b];
     hipStream_t s0 = (hipStream_t)fs_compute_stream(g->members[0]);
+    hipStream_t p0 = g->post;
     FSG_TRY(hipSetDevice(g->devices[0]));
-    FSG_TRY(hipEventRecord(g->ev_a, s0));
+    // member 0's slice is in slot 0 once its kernel has finished
+    FSG_TRY(hipEventRecord(g->ev_rendered[b], s0));
+    FSG_TRY(hipStreamWaitEvent(p0, g->ev_rendered[b], 0));
+    FSG_TRY(hipEventRecord(g->ev_a, p0));
     if (world > 1 && g->transport == 0) {
         Rccl &q = rccl();
         if (q.GroupStart() != 0)
@@ -356,47 +415,54 @@ uint32_t fs_group_render_current(fs_group *g, uint64_t n_iterations, void *iter_
         // (every exit below closes the group: a thread left inside an open ncclGroup corrupts its later RCCL calls)
         bool ok = true;
         for (uint32_t r = 1; r < world && ok; r++) {
-            // rank 0 receives slice r behind its own kernel -- and, being on s0, behind the k_gather_rows of the previous
-            // frame, so a slot is never overwritten while it is still being read; rank r sends behind ITS kernel
-            ok = q.Recv((char *)g->gathered + sb * r, sb, kNcclUint8, (int)r, g->comms[0], s0) == 0 &&
+            // rank 0 receives slice r on the post stream -- behind the k_gather_rows that last read this set's slots (same
+            // stream), so a slot is never overwritten while it is still being read; rank r sends behind ITS kernel
+            ok = q.Recv((char *)gathered + sb * r, sb, kNcclUint8, (int)r, g->comms[0], p0) == 0 &&
                  q.Send(g->slices[r], sb, kNcclUint8, 0, g->comms[r], (hipStream_t)fs_compute_stream(g->members[r])) == 0;
         }
         if (q.GroupEnd() != 0 || !ok)
             return FS_ERR_7;
     } else if (world > 1) {
         for (uint32_t r = 1; r < world; r++) {
-            // the copy runs on the SENDER's stream (ordered behind its kernel); rank 0 then waits for it on the device.
-            // The copy writes rank 0's gather slot r, which the k_gather_rows of the PREVIOUS frame may still be reading
-            // (this call is asynchronous; a fast member can be a whole frame ahead of a slow one): the sender first waits
-            // for ev_consumed, recorded on s0 behind that kernel (a never-recorded event does not wait).
+            // the copy runs on the SENDER's stream (ordered behind its kernel); the post stream then waits for it on the
+            // device.  The copy writes gather slot r of this set, which the k_gather_rows of the frame that used the set
+            // last may still be reading (this call is asynchronous; a fast member can be frames ahead of a slow one): the
+            // sender first waits for that set's ev_consumed (a never-recorded event does not wait).
             hipStream_t sr = (hipStream_t)fs_compute_stream(g->members[r]);
             FSG_TRY(hipSetDevice(g->devices[r]));
-            FSG_TRY(hipStreamWaitEvent(sr, g->ev_consumed, 0));
-            FSG_TRY(hipMemcpyPeerAsync((char *)g->gathered + sb * r, g->devices[0], g->slices[r], g->devices[r], sb, sr));
+            FSG_TRY(hipStreamWaitEvent(sr, g->ev_consumed[b], 0));
+            FSG_TRY(hipMemcpyPeerAsync((char *)gathered + sb * r, g->devices[0], g->slices[r], g->devices[r], sb, sr));
             hipEvent_t done;
             FSG_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
             FSG_TRY(hipEventRecord(done, sr));
             FSG_TRY(hipSetDevice(g->devices[0]));
-            FSG_TRY(hipStreamWaitEvent(s0, done, 0));
+            FSG_TRY(hipStreamWaitEvent(p0, done, 0));
             FSG_TRY(hipEventDestroy(done)); // released once the recorded work has completed
         }
     }
     FSG_TRY(hipSetDevice(g->devices[0]));
-    fsk_gather_rows(g->gathered, g->frame, g->index, g->rounded_width * g->iter_bytes, g->height, s0);
+    fsk_gather_rows(gathered, frame, g->index, g->rounded_width * g->iter_bytes, g->height, p0);
     FSG_TRY(hipGetLastError());
-    FSG_TRY(hipEventRecord(g->ev_consumed, s0)); // the gather slots may be written again
-    FSG_TRY(hipEventRecord(g->ev_b, s0));
+    FSG_TRY(hipEventRecord(g->ev_consumed[b], p0)); // this set's gather slots may be written again
+    FSG_TRY(hipEventRecord(g->ev_b, p0));
     if (reduction) {
         g->reduce_seed = fs_reduction{g->iter_bytes == 8 ? ~0ull : 0xFFFFFFFFull, 0, 0};
-        FSG_TRY(hipMemcpyAsync(g->reduction, &g->reduce_seed, sizeof(fs_reduction), hipMemcpyHostToDevice, s0));
-        fsk_reduce(g->frame, g->iter_bytes == 8, g->rounded_width, g->width, g->height, g->reduction, s0);
+        FSG_TRY(hipMemcpyAsync(g->reduction, &g->reduce_seed, sizeof(fs_reduction), hipMemcpyHostToDevice, p0));
+        fsk_reduce(frame, g->iter_bytes == 8, g->rounded_width, g->width, g->height, g->reduction, p0);
         FSG_TRY(hipGetLastError());
-        FSG_TRY(hipMemcpyAsync(reduction, g->reduction, sizeof(fs_reduction), hipMemcpyDefault, s0));
+        FSG_TRY(hipMemcpyAsync(reduction, g->reduction, sizeof(fs_reduction), hipMemcpyDefault, p0));
     }
     if (iter_buffer) {
         const size_t frame_rows = ((size_t)g->height + 7u) / 8u * 8u;
-        FSG_TRY(hipMemcpyAsync(iter_buffer, g->frame, frame_rows * g->rounded_width * g->iter_bytes, hipMemcpyDefault, s0));
+        FSG_TRY(hipMemcpyAsync(iter_buffer, frame, frame_rows * g->rounded_width * g->iter_bytes, hipMemcpyDefault, p0));
     }
+    FSG_TRY(hipEventRecord(g->ev_done[b], p0));
+    g->frames_posted++;
+    // the next frame lands in the other set: member 0 renders into ITS slot 0 -- once the frame that used that set last has
+    // been put in row order (its gather slots are free then)
+    g->cur = (b + 1) % fs_group::kSets;
+    FSG_TRY(hipStreamWaitEvent(s0, g->ev_consumed[g->cur], 0));
+    FSG_TRY(fs_set_external_iter_buffer(g->members[0], g->gathered[g->cur], sb));
     return 0;
 }
 

@@ -287,10 +287,11 @@ void fsk_make_quiet_orbit(const float4 *zref, float4 *zq, uint64_t n, hipStream_
 // tiles.  probe: tiles_y rows of tiles_x counts.
 void fsk_tile_order(const uint32_t *probe, uint32_t probe_pitch, uint32_t tiles_x, uint32_t tiles_y, uint32_t threshold,
                     uint32_t *order, uint32_t n_slots, hipStream_t s);
-// Launch order "longest tiles first" from recorded costs: order[0 .. n_tiles) = the tile numbers sorted by cost, highest
-// first, in 64 cost classes between the frame's minimum and maximum, tile order kept inside a class (neighbours keep
-// starting together: they walk the same stretch of the orbit); order[n_tiles .. n_slots) = 0xFFFFFFFF; order[n_slots] = 0.
-// tmp: n_tiles words of work memory.
+// Launch order "longest tiles first" from recorded costs: order[0 .. n_tiles) = the tile numbers sorted by cost class,
+// highest first -- 256 classes, 8 per octave of the cost (exponent and three mantissa bits of the cost as a float) -- tile
+// order kept inside a class (neighbours keep starting together: they walk the same stretch of the orbit);
+// order[n_tiles .. n_slots) = 0xFFFFFFFF; order[n_slots] = 0.  tmp: fsk_tile_order_work_words() words of work memory.
+uint32_t fsk_tile_order_work_words(uint32_t n_tiles);
 void fsk_tile_order_by_cost(const uint32_t *cost, uint32_t n_tiles, uint32_t *tmp, uint32_t *order, uint32_t n_slots,
                             hipStream_t s);
 // wave slots of the fsk_lav2_hdr32 launch for this frame (>= its number of 8 x 8 tiles), 0 = the launch shape is not the

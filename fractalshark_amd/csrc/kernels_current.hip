@@ -317,117 +317,131 @@ void fsk_tile_order(const uint32_t *probe, uint32_t probe_pitch, uint32_t tiles_
 // count; the next frame of the same geometry is launched in this order, fs_render_lav2).  A frame ends one long wave after
 // its LAST wave was dispatched, and the waves of one frame differ 2.5x in length: started first,
 // the long ones finish while the chip is still full.
-// One workgroup.  The costs are cut into 64 classes between the frame's minimum and maximum, highest first, and the tiles
-// are sorted by class with two stable 8-way counting passes (low three bits, then high three bits), so tiles of one class
-// keep their raster order: neighbours (whose costs are alike) still start together and walk the same stretch of the orbit.
+// A stable counting sort into 256 cost classes, highest first: class = 255 - (exponent and three mantissa bits of the cost
+// as a float) -- 8 classes per octave over the whole 32-bit range, so no pass over the costs is needed to find their
+// range.  Tiles of one class keep their raster order: neighbours (whose costs are alike) still start together and walk the
+// same stretch of the orbit.  Three small launches (the first version was ONE workgroup and took 0.65 ms at 129 600 tiles
+// -- a serial chain of dependent loads per thread -- in front of every frame):
+//   k_cost_hist     kSortWaves waves, each over a contiguous chunk of tiles: tiles per class, per wave
+//   k_cost_scan     one workgroup: exclusive scan of the (class, wave) counts in class-major order
+//   k_cost_scatter  the same waves: every tile to  offset[class][wave] + its rank among the wave's earlier tiles of the class
+// Inside a wave a group of 64 tiles is ranked with ballots: eight votes give each lane the mask of the lanes that share
+// its class (its rank = the set bits below it), and an LDS word per class hands that mask to the lane that keeps the
+// class's running offset.
 namespace {
-constexpr uint32_t kSortThreads = 1024;
+constexpr uint32_t kSortWaves = 128;  // waves over the tile array (4 per workgroup)
+constexpr uint32_t kCostClasses = 256;
 
-__device__ __forceinline__ uint32_t cost_class(uint32_t c, uint32_t mn, uint32_t span)
+__device__ __forceinline__ uint32_t cost_class(uint32_t c)
 {
-    // 63 - floor(64 (c - mn) / span), span = max - min + 1 (the product stays below 2^38)
-    return 63u - (uint32_t)(((uint64_t)(c - mn) << 6) / span);
+    // monotone in c: 0 -> 255 (last), 1 -> 255, 2 -> 247, ..., 2^32 - 1 -> 0 (float conversion rounds to nearest: monotone)
+    const uint32_t q = c ? (__float_as_uint((float)c) >> 20) - (127u << 3) : 0u;
+    return kCostClasses - 1u - (q < kCostClasses ? q : kCostClasses - 1u);
 }
 
-// one stable 8-way pass over the sequence seq[0 .. n) (seq == nullptr: the identity) by digit (class >> shift) & 7
-__device__ void tile_sort_pass(const uint32_t *__restrict__ cost, const uint32_t *__restrict__ seq, uint32_t *__restrict__ out,
-                               uint32_t n, uint32_t shift, uint32_t mn, uint32_t span, uint32_t (*s_cnt)[kSortThreads],
-                               uint32_t *s_scan)
+__device__ __forceinline__ uint32_t sort_chunk(uint32_t n) // tiles per wave: a whole number of 64-tile groups
 {
-    const uint32_t t = threadIdx.x, chunk = (n + kSortThreads - 1u) / kSortThreads;
-    const uint32_t lo = t * chunk < n ? t * chunk : n, hi = lo + chunk < n ? lo + chunk : n;
-    uint32_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (uint32_t i = lo; i < hi; i++) {
-        const uint32_t tile = seq ? seq[i] : i;
-        const uint32_t d = (cost_class(cost[tile], mn, span) >> shift) & 7u;
+    return ((n + kSortWaves - 1u) / kSortWaves + 63u) / 64u * 64u;
+}
+
+// mask of the lanes (of the 64 active ones) whose 8-bit class equals this lane's
+__device__ __forceinline__ uint64_t class_peers(uint32_t cls)
+{
+    uint64_t peers = ~0ull;
 #pragma unroll
-        for (uint32_t k = 0; k < 8; k++)
-            c[k] += d == k ? 1u : 0u;
+    for (uint32_t bit = 0; bit < 8; bit++) {
+        const uint64_t b = __builtin_amdgcn_ballot_w64(((cls >> bit) & 1u) != 0u);
+        peers &= ((cls >> bit) & 1u) ? b : ~b;
     }
+    return peers;
+}
+
+// One pass of a wave over its chunk.  kScatter == false: counts[class * kSortWaves + wave] = tiles of the class in the
+// chunk; true: order[offsets[class * kSortWaves + wave] + rank] = tile.
+template <bool kScatter>
+__global__ void __launch_bounds__(256) k_cost_pass(const uint32_t *__restrict__ cost, uint32_t n, uint32_t *__restrict__ table,
+                                                   uint32_t *__restrict__ order, uint32_t n_slots)
+{
+    __shared__ uint64_t s_mask[4][kCostClasses];
+    __shared__ uint32_t s_base[4][kCostClasses];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, w = blockIdx.x * 4u + wv;
+    // (volatile: the lanes of a wave talk to each other through these words; a wave's LDS operations execute in order)
+    volatile uint64_t *mask = s_mask[wv];
+    volatile uint32_t *base = s_base[wv];
 #pragma unroll
-    for (uint32_t k = 0; k < 8; k++)
-        s_cnt[k][t] = c[k];
-    __syncthreads();
-    // exclusive scan of the 8192 counters in (digit, thread) order: thread t owns positions 8t .. 8t + 7
-    uint32_t *flat = &s_cnt[0][0];
-    uint32_t mine = 0;
+    for (uint32_t j = 0; j < 4; j++)
+        base[lane + 64u * j] = kScatter ? table[(lane + 64u * j) * kSortWaves + w] : 0u;
+    const uint32_t chunk = sort_chunk(n);
+    const uint32_t lo = w * chunk < n ? w * chunk : n, hi = lo + chunk < n ? lo + chunk : n;
+    for (uint32_t g = lo; g < hi; g += 64u) {
+        const uint32_t tile = g + lane;
+        const bool have = tile < hi;
+        // (a lane beyond the end votes in a class of its own kind: class 0 with the `have` bit cleared never matches a tile)
+        const uint32_t cls = have ? cost_class(cost[tile]) : 0u;
 #pragma unroll
-    for (uint32_t k = 0; k < 8; k++)
-        mine += flat[8u * t + k];
+        for (uint32_t j = 0; j < 4; j++)
+            mask[lane + 64u * j] = 0ull;
+        const uint64_t live = __builtin_amdgcn_ballot_w64(have);
+        const uint64_t peers = class_peers(cls) & live;
+        if (have)
+            mask[cls] = peers; // (every lane of a class writes the same word)
+        if (kScatter && have) {
+            const uint64_t below = peers & ((1ull << lane) - 1ull);
+            order[base[cls] + (uint32_t)__popcll(below)] = tile;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++)
+            base[lane + 64u * j] = base[lane + 64u * j] + (uint32_t)__popcll(mask[lane + 64u * j]);
+    }
+    if (!kScatter) {
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++)
+            table[(lane + 64u * j) * kSortWaves + w] = base[lane + 64u * j];
+    } else {
+        // the launch's surplus waves render nothing
+        for (uint32_t i = n + blockIdx.x * 256u + threadIdx.x; i < n_slots; i += gridDim.x * 256u)
+            order[i] = 0xFFFFFFFFu;
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+            order[n_slots] = 0u;
+    }
+}
+
+// exclusive scan of the kCostClasses x kSortWaves counts, in place (class-major: all of class 0, then class 1, ...)
+__global__ void __launch_bounds__(1024) k_cost_scan(uint32_t *__restrict__ table)
+{
+    constexpr uint32_t kPer = kCostClasses * kSortWaves / 1024u;
+    __shared__ uint32_t s_scan[1024];
+    const uint32_t t = threadIdx.x;
+    uint32_t v[kPer], mine = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kPer; k++) {
+        v[k] = table[t * kPer + k];
+        mine += v[k];
+    }
     s_scan[t] = mine;
     __syncthreads();
-    for (uint32_t d = 1; d < kSortThreads; d <<= 1) {
-        const uint32_t v = t >= d ? s_scan[t - d] : 0u;
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {
+        const uint32_t a = t >= d ? s_scan[t - d] : 0u;
         __syncthreads();
-        s_scan[t] += v;
+        s_scan[t] += a;
         __syncthreads();
     }
     uint32_t run = s_scan[t] - mine;
 #pragma unroll
-    for (uint32_t k = 0; k < 8; k++) {
-        const uint32_t v = flat[8u * t + k];
-        flat[8u * t + k] = run;
-        run += v;
+    for (uint32_t k = 0; k < kPer; k++) {
+        table[t * kPer + k] = run;
+        run += v[k];
     }
-    __syncthreads();
-    uint32_t at[8];
-#pragma unroll
-    for (uint32_t k = 0; k < 8; k++)
-        at[k] = s_cnt[k][t];
-    for (uint32_t i = lo; i < hi; i++) {
-        const uint32_t tile = seq ? seq[i] : i;
-        const uint32_t d = (cost_class(cost[tile], mn, span) >> shift) & 7u;
-        uint32_t pos = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < 8; k++) {
-            pos = d == k ? at[k] : pos;
-            at[k] += d == k ? 1u : 0u;
-        }
-        out[pos] = tile;
-    }
-    __syncthreads();
 }
-
-__global__ void __launch_bounds__(kSortThreads) k_tile_order_by_cost(const uint32_t *__restrict__ cost, uint32_t n,
-                                                                     uint32_t *__restrict__ tmp, uint32_t *__restrict__ order,
-                                                                     uint32_t n_slots)
-{
-    __shared__ uint32_t s_cnt[8][kSortThreads];
-    __shared__ uint32_t s_scan[kSortThreads];
-    __shared__ uint32_t s_mn[kSortThreads / 64], s_mx[kSortThreads / 64];
-    const uint32_t t = threadIdx.x;
-    uint32_t mn = 0xFFFFFFFFu, mx = 0u;
-    for (uint32_t i = t; i < n; i += kSortThreads) {
-        const uint32_t c = cost[i];
-        mn = c < mn ? c : mn;
-        mx = c > mx ? c : mx;
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        const uint32_t a = __shfl_down(mn, off), b = __shfl_down(mx, off);
-        mn = a < mn ? a : mn;
-        mx = b > mx ? b : mx;
-    }
-    if ((t & 63u) == 0u)
-        s_mn[t >> 6] = mn, s_mx[t >> 6] = mx;
-    __syncthreads();
-    mn = s_mn[0], mx = s_mx[0];
-    for (uint32_t k = 1; k < kSortThreads / 64; k++) {
-        mn = s_mn[k] < mn ? s_mn[k] : mn;
-        mx = s_mx[k] > mx ? s_mx[k] : mx;
-    }
-    const uint32_t span = mx - mn + 1u; // (mx - mn <= 2^32 - 2: costs are step counts below the iteration cap)
-    tile_sort_pass(cost, nullptr, tmp, n, 0u, mn, span, s_cnt, s_scan);
-    __threadfence_block();
-    tile_sort_pass(cost, tmp, order, n, 3u, mn, span, s_cnt, s_scan);
-    for (uint32_t i = n + t; i < n_slots; i += kSortThreads)
-        order[i] = 0xFFFFFFFFu;
-    if (t == 0)
-        order[n_slots] = 0u;
-}
+static_assert(kCostClasses * kSortWaves % 1024u == 0, "the scan gives every thread the same number of counters");
 } // namespace
+
+uint32_t fsk_tile_order_work_words(uint32_t) { return kCostClasses * kSortWaves; }
 
 void fsk_tile_order_by_cost(const uint32_t *cost, uint32_t n_tiles, uint32_t *tmp, uint32_t *order, uint32_t n_slots,
                             hipStream_t s)
 {
-    hipLaunchKernelGGL(k_tile_order_by_cost, dim3(1), dim3(kSortThreads), 0, s, cost, n_tiles, tmp, order, n_slots);
+    hipLaunchKernelGGL(k_cost_pass<false>, dim3(kSortWaves / 4), dim3(256), 0, s, cost, n_tiles, tmp, order, n_slots);
+    hipLaunchKernelGGL(k_cost_scan, dim3(1), dim3(1024), 0, s, tmp);
+    hipLaunchKernelGGL(k_cost_pass<true>, dim3(kSortWaves / 4), dim3(256), 0, s, cost, n_tiles, tmp, order, n_slots);
 }

@@ -1853,7 +1853,7 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
                 r->lav2_cost_cap = 0;
                 r->lav2_cost_valid = false;
                 FS_TRY(r_alloc(r, (void **)&r->lav2_cost, (size_t)n_tiles * sizeof(uint32_t), kFrame));
-                FS_TRY(r_alloc(r, (void **)&r->lav2_sort_tmp, (size_t)n_tiles * sizeof(uint32_t), kFrame));
+                FS_TRY(r_alloc(r, (void **)&r->lav2_sort_tmp, (size_t)fsk_tile_order_work_words(n_tiles) * sizeof(uint32_t), kFrame));
                 r->lav2_cost_cap = n_tiles;
             }
             if (r->lav2_order_cap < n_slots) {

@@ -35,7 +35,8 @@ class GPURenderer:
 
     def close(self):
         if getattr(self, "_h", None):
-            self._lib.fs_destroy(self._h)
+            if not getattr(self, "_borrowed", False):  # (a member of a GPURendererGroup belongs to the group)
+                self._lib.fs_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -454,6 +455,19 @@ class GPURendererGroup:
 
     def Sync(self):
         return self._lib.fs_group_sync(self._h)
+
+    def WaitCurrent(self, frames_back=0):
+        """Host waits for the RenderCurrent issued `frames_back` calls ago (0 = latest, 1 = the one before): two frames may
+        be in flight (render k+1 while frame k is gathered and copied out)."""
+        return self._lib.fs_group_wait_current(self._h, int(frames_back))
+
+    def renderer(self, rank):
+        """Borrowed GPURenderer view of member `rank` (fs_group_renderer): measurement hooks only."""
+        m = GPURenderer.__new__(GPURenderer)
+        m._lib = self._lib
+        m._h = self._lib.fs_group_renderer(self._h, int(rank))
+        m._borrowed = True
+        return m
 
     def gather_ms(self):
         return float(self._lib.fs_group_gather_ms(self._h))

@@ -347,7 +347,15 @@ uint32_t fs_group_render_direct(fs_group *g, int type_tag, const void *coords, u
 uint32_t fs_group_clear(fs_group *g);
 uint32_t fs_group_render_current(fs_group *g, uint64_t n_iterations, void *iter_buffer, fs_reduction *reduction);
 uint32_t fs_group_sync(fs_group *g);
-/* Duration of the last gather + reassembly on device 0 (HIP events; synchronises member 0's stream). */
+/* Two frames may be in flight: fs_group_render_current runs on a stream of its own on device 0 (receive, row order,
+ * reduction, D2H) behind the members' kernels, over one of TWO sets of gather / frame buffers used in rotation, so the
+ * members' next frame can be launched right away and renders while this one is delivered.  fs_group_wait_current: the host
+ * waits until the fs_group_render_current issued `frames_back` calls ago (0 = the latest, 1 = the one before) has filled
+ * the caller's buffers -- the pipelined loop is  render k; render_current k (host buffer k % 2); wait_current(1).
+ * The caller owns the host buffers: one per frame in flight.  (After fs_group_render_current member 0's own iteration
+ * buffer is the OTHER set's slot: per-renderer colour output of a frame is taken before that call.) */
+uint32_t fs_group_wait_current(fs_group *g, uint32_t frames_back);
+/* Duration of the last gather + reassembly on device 0 (HIP events; synchronises device 0's post stream). */
 float fs_group_gather_ms(fs_group *g);
 /* The tiler's plan as a pure host function (tests; equals fractalshark_amd/tiling.py): rows rank `rank` owns, the
  * common padded slice height, and frame_index[y] = row of the gathered buffer (N slices back to back) that holds frame

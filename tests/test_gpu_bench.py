@@ -1,0 +1,71 @@
+"""GPU: bench.py end to end at a small frame -- the one-rank run, the RCCL path with a single rank (FS_FORCE_DIST=1: process
+group, gather, row order, pipelined delivery) and, where the box has two GPUs, two torchrun ranks over nccl.  Every run must
+print exactly one JSON line whose frame checksum equals the plain one-GPU run's and whose oracle rows are bit-exact."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from fractalshark_amd import GPURenderer
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--width", "960", "--height", "544", "--steps", "3", "--warmup", "1", "--no-secondary", "--cpu-sample-rows", "4"]
+
+
+def _run(extra_args, extra_env=None, timeout=900):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["FS_NO_BUILD"] = "1"
+    env.update(extra_env or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *SMALL, *extra_args], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, env=env, timeout=timeout, cwd=ROOT)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    return json.loads(lines[0])
+
+
+@pytest.fixture(scope="module")
+def single(native_libs):
+    return _run([])
+
+
+def test_one_rank_line(single):
+    d = single
+    assert d["n_gpus"] == 1 and d["steps"] == 3
+    assert d["cpu_sample_rows_bit_exact"] is True
+    assert d["roofline"]["frac"] > 0 and d["cpu_baseline"]["value"] > 0
+    ft = d["frame_timing"]
+    assert ft["tile_order"].startswith("longest first")
+    assert ft["latency_ms_cold"] is not None and ft["latency_ms_warm"] > 0
+    # sustained frames overlap the copy-out of the previous frame: never slower than one frame at a time (10 % slack for
+    # a 3-frame sample)
+    assert ft["sustained_ms_per_frame"] <= ft["latency_ms_warm"] * 1.1
+
+
+def test_forced_process_group_one_rank(single):
+    d = _run([], {"FS_FORCE_DIST": "1", "MASTER_PORT": "29547"})
+    assert d["frame_checksum"] == single["frame_checksum"]
+    assert d["cpu_sample_rows_bit_exact"] is True  # the N > 1 line carries its own parity verdict
+    assert d["cpu_baseline"] is None               # ... and no CPU baseline (N = 1 only)
+    assert d["roofline"]["pixel_steps_per_launch"] == single["roofline"]["pixel_steps_per_launch"]
+
+
+def test_natural_tile_order_flag(single):
+    d = _run(["--natural-tile-order", "--no-cpu"])
+    assert d["frame_checksum"] == single["frame_checksum"]
+    assert d["frame_timing"]["tile_order"] == "natural" and d["frame_timing"]["latency_ms_cold"] is None
+
+
+def test_two_ranks_over_nccl(single):
+    n = GPURenderer.device_count()
+    if n < 2:
+        pytest.skip("needs >= 2 HIP devices (this box has %d)" % n)
+    d = _run(["--gpus", "2"])
+    assert d["n_gpus"] == 2
+    assert d["frame_checksum"] == single["frame_checksum"]
+    assert d["cpu_sample_rows_bit_exact"] is True
+    assert d["roofline"]["pixel_steps_per_launch"] == single["roofline"]["pixel_steps_per_launch"]

@@ -112,6 +112,42 @@ def test_group_frames_issued_back_to_back_without_a_sync(native_libs, world):
     g.close()
 
 
+@pytest.mark.parametrize("world", [2, 8])
+def test_group_pipelined_loop_two_frames_in_flight(native_libs, world):
+    """The pipelined host loop of include/fsmi355.h: render k; render_current k into host buffer k % 2; wait_current(1).
+    When wait_current(1) returns, frame k-1 must be complete in ITS host buffer although frame k is still in flight; the
+    frames alternate between two different results, and the members run longest-tiles-first from their second frame on."""
+    w, h = 960, 544
+    v = inputs.View.builtin(5, w, h)
+    ob = inputs.Orbit(v)
+    la = inputs.LATable(ob)
+    dx, dy, cx, cy = _pairs(v.coords_perturb_hdr32(ob))
+    order = [PARITY_CPU, PARITY_CPU_GPUSTAGE] * 4
+    refs = _single_frames(v, ob, la, order[:2])
+    assert not np.array_equal(refs[0], refs[1])
+    g = GPURendererGroup([0] * world)
+    assert g.InitializeMemory(w, h, 1) == 0
+    assert g.InitializePerturb(1, ob, la) == 0
+    host = [g.new_iter_buffer() for _ in range(2)]
+    reds = [_capi.Reduction(), _capi.Reduction()]
+    assert g.WaitCurrent(0) == 0  # nothing posted yet: returns at once
+    for k, parity in enumerate(order):
+        assert g.RenderPerturbLAv2(dx, dy, cx, cy, v.num_iterations, Mode=LAV2_FULL, parity=parity) == 0
+        assert g.RenderCurrent(v.num_iterations, host[k % 2], reds[k % 2]) == 0
+        assert g.WaitCurrent(1) == 0
+        if k >= 1:
+            got = host[(k - 1) % 2]
+            assert np.array_equal(got, refs[(k - 1) % 2]), "frame %d was not complete when wait_current(1) returned" % (k - 1)
+            assert reds[(k - 1) % 2].Sum == int(refs[(k - 1) % 2][:h, :w].astype(np.uint64).sum())
+    assert g.WaitCurrent(0) == 0
+    assert np.array_equal(host[(len(order) - 1) % 2], refs[(len(order) - 1) % 2])
+    assert g.WaitCurrent(2) != 0  # only two frames are tracked
+    if world == 2:  # (with 8 members a member's share of this frame is below the tile-order threshold)
+        assert g.renderer(1).last_frame_tile_ordered()
+    assert g.Sync() == 0
+    g.close()
+
+
 @pytest.mark.parametrize("transport", [0, 1])
 def test_group_over_distinct_devices(native_libs, transport):
     """The group on real, distinct GPUs: transport 0 = RCCL (ncclCommInitAll, grouped ncclSend / ncclRecv on the members'

@@ -44,10 +44,12 @@ def _setup(r, v, ob, la, bands=None, gen=1):
 
 
 def _host_order(cost):
-    """The order the device sort must produce: 64 cost classes between min and max, highest first, stable inside a class."""
-    mn, mx = int(cost.min()), int(cost.max())
-    span = mx - mn + 1
-    cls = 63 - ((cost.astype(np.uint64) - mn) * 64 // span).astype(np.int64)
+    """The order the device sort must produce: 256 cost classes (exponent and three mantissa bits of the cost as a float, 8
+    per octave), highest first, stable inside a class."""
+    f = cost.astype(np.float32)
+    q = (f.view(np.uint32) >> 20).astype(np.int64) - (127 << 3)
+    q = np.where(cost == 0, 0, np.clip(q, 0, 255))
+    cls = 255 - q
     return np.argsort(cls, kind="stable").astype(np.uint32)
 
 
