@@ -592,6 +592,121 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
           "scc")
 
 // ------------------------------------------------------------------------------------------------
+// Round 4: the FLOOR form of the scaled runs' acceptance tests (k_lav2_hdr32_fast; the scalar-HDRFloat kernel keeps the
+// form above).  Scale of a run: w = dz 2^-E with E = dz's exponent + 24, i.e. max|w| starts in [2^-24, 2^-23).
+//
+// Why a scaled step can differ from the reference's HDRFloatComplex step at all (Fractal.cpp:2646-2661: cur = 2Z + dz,
+// p = dz cur, q = p + dc, Reduce): both carry out the same IEEE operations on the same real operands (the scale is a
+// power of two), so the results agree bit for bit UNLESS
+//   (u) an operation underflows -- its result is below 2^-126 in the units it is carried out in and loses bits -- in one
+//       of the two arithmetics: the scaled one (units 2^E), or the reference's mantissa arithmetic (products in units of
+//       2^(dz.e + cur.e), the aligned operand of an addition in the units of the larger one, Reduce's re-scaling by up to
+//       2^-4).  Such an event injects an absolute error below 2^-126 in ITS units; in the run's units that is below
+//       2^(-126 + 35): the exponent of a product's units is that of max|w| (kept below 29, see H) plus that of 2Z + dz
+//       (< 5), and dc's units are at most 2^7 (start condition).  Two roundings lie between the event and a part of the
+//       new state (p = a - b, q = p + dc), each amplifies the error by at most 2^26 relative to the result it rounds, so a
+//       part of q that is wrong because of it is smaller than 2^(-91 + 29.2) < 2^-61;
+//   (d) the reference DROPS the smaller operand of q = p + dc when the exponents are 120 or more apart
+//       (HDRFloatComplex::plus_mutable) while the scaled step adds it: a part of q can differ only where the dropped
+//       operand is within 2^26 of the kept one's part, and then that part of q is below 2^(28 + exponent of the kept
+//       operand's units - 120) <= 2^-57 (dc dropped: units of p, < 2^35) or far below (p dropped: dc's units <= 2^7).
+//       (cur = 2Z + dz: a dropped dz is more than 2^79 below either part of a usable orbit entry -- the companion's
+//       "usable" test -- and changes no bit.)
+// Hence: a new state whose TWO parts are both at least 2^-56 in magnitude (the floor, F) is the reference's state, bit for
+// bit, provided the state it was stepped from was (induction) and had max|w| < 2^29 (H).  Every state is tested against
+// the floor (one v_min / v_min3 per state, one compare per two states); H is tested where a block starts (max|w| < 2^14:
+// a step multiplies max|w| by less than 25.2 and adds at most 2^7, so the block's other three states stay below 2^29).
+// The form above tests every SECOND state and therefore needs a test relative to the state's size (part ratio 2^-40 and a
+// 60-binade window: six vector instructions per two states instead of three).  Exact zero parts fail the floor (pixels on
+// the axes go to the exponent-tracking loop, as before).
+constexpr int kScaleShift = 24;
+#define FS_FL_FLOOR 0x1p-56f
+#define FS_FL_HIGH 0x1p14f   /* max|w| where a 4-step block starts */
+#define FS_FL_HIGH_TRIP 0x1p24f /* the per-lane paths test H once per two-step trip: 25.2 * 2^24 + 2^7 < 2^29 */
+#define FS_FL_N1(A, B) "v_min_f32_e64 v61, |" A "|, |" B "|\n\t"
+#define FS_FL_N2(A, B) "v_min3_f32 v61, |" A "|, |" B "|, v61\n\t"
+#define FS_FL_C "v_cmp_gt_f32_e32 vcc, 0x23800000, v61\n\t"   /* 2^-56 > the smallest part of the trip's two states */
+#define FS_FL_H "v_cmp_lt_f32_e32 vcc, 0x46800000, v60\n\t"   /* 2^14 < max|w| at a block's first state */
+#define FS_STEP_FLOOR(NW_, V)                                                                                       \
+    V |= __builtin_amdgcn_ballot_w64(!(__builtin_fminf(__builtin_fabsf(NW_.x), __builtin_fabsf(NW_.y)) >= FS_FL_FLOOR));
+// The untested body, floor form.  Same registers, same rotation of the four state pairs, same exits as FS_FAST_LOOP; a
+// trip's two states (first step, second step) are tested together while the next trip's packed arithmetic is in flight,
+// the verdict arrives before that trip's second step overwrites the failed trip's start state.  On entry the pending
+// "previous trip" is (v[54:55], v[48:49]): the caller passes the entering state in both.
+#define FS_FAST_LOOP_FL(PF)                                                                                           \
+    asm volatile(                                                                                                   \
+        ".Lfl_loop_%=:\n\t" /* eight steps left?  the first block's tests: max(max|w|, max|dc|) against .w (s67), H */ \
+        "v_max_i32_e32 v62, v60, %[imdc]\n\t"                                                                       \
+        "s_cmp_gt_u32 %[off], %[lim8]\n\t"                                                                          \
+        "v_add_u32_e32 v62, v62, %[esh]\n\t"                                                                        \
+        "s_cbranch_scc1 .Lfl_out_%=\n\t"                                                                            \
+        "v_cmp_lt_i32_e64 %[m], s67, v62\n\t" FS_FL_H                                                               \
+        "s_or_b64 %[m], %[m], vcc\n\t"                                                                              \
+        "s_cbranch_scc1 .Lfl_out_%=\n\t" /* steps 1, 2 + the pending tests (previous body's last trip) */           \
+        FS_PK_F(FS_R0, "s[64:65]") "s_mov_b32 %[eb], s62\n\t"                                                       \
+        "s_load_dwordx16 s[36:51], s[68:69], %[off]\n\t"                                                            \
+        "s_load_dwordx16 s[52:67], s[68:69], %[off] offset:0x40\n\t"                                                \
+        FS_PK_MA(FS_R0) FS_FL_N1("v54", "v55") FS_PK_MB(FS_R0) FS_FL_N2("v48", "v49") FS_PK_P FS_FL_C FS_PK_A(FS_R1) \
+        "s_waitcnt lgkmcnt(0)\n\t" PF                                                                               \
+        FS_PK_F(FS_R1, "s[36:37]") FS_PK_MA(FS_R1) FS_PK_MB(FS_R1) FS_PK_P                                          \
+        "s_cbranch_vccnz .Lfl_fp_%=\n\t" FS_PK_A(FS_R2) /* steps 3, 4 + the tests of trip 1 (v[50:51], v[52:53]) */ \
+        FS_PK_F(FS_R2, "s[40:41]") FS_FL_N1("v50", "v51") FS_PK_MA(FS_R2) FS_PK_MB(FS_R2) FS_FL_N2("v52", "v53")    \
+        FS_PK_P FS_FL_C FS_PK_A(FS_R3)                                                                              \
+        FS_PK_F(FS_R3, "s[44:45]") FS_PK_MA(FS_R3) FS_PK_MB(FS_R3) FS_PK_P                                          \
+        "s_cbranch_vccnz .Lfl_f1_%=\n\t" FS_PK_A(FS_R0) /* steps 5, 6 + the tests of trip 2 (v[54:55], v[48:49]) */ \
+        FS_PK_F(FS_R0, "s[48:49]") FS_FL_N1("v54", "v55") FS_PK_MA(FS_R0) FS_PK_MB(FS_R0) FS_FL_N2("v48", "v49")    \
+        FS_PK_P FS_FL_C FS_PK_A(FS_R1) FS_T_X("v48", "v49")                                                         \
+        FS_PK_F(FS_R1, "s[52:53]") FS_PK_MA(FS_R1) FS_PK_MB(FS_R1) FS_PK_P                                          \
+        "s_cbranch_vccnz .Lfl_f2_%=\n\t" /* the second block's tests: max(max|w4|, max|dc|) against entry 3's .w, H */ \
+        "v_max_i32_e32 v62, v60, %[imdc]\n\t" FS_PK_A(FS_R2) "v_add_u32_e32 v62, v62, %[esh]\n\t"                   \
+        /* steps 7, 8 + the tests of trip 3 (v[50:51], v[52:53]) */                                                 \
+        FS_PK_F(FS_R2, "s[56:57]") "v_cmp_lt_i32_e64 %[m], s51, v62\n\t" FS_FL_H FS_PK_MA(FS_R2)                    \
+        "s_or_b64 %[m], %[m], vcc\n\t" FS_PK_MB(FS_R2) FS_PK_P "s_cbranch_scc1 .Lfl_blk_%=\n\t" FS_PK_A(FS_R3)      \
+        FS_FL_N1("v50", "v51")                                                                                      \
+        FS_PK_F(FS_R3, "s[60:61]") FS_FL_N2("v52", "v53") FS_PK_MA(FS_R3) FS_PK_MB(FS_R3) FS_FL_C FS_PK_P           \
+        "s_cbranch_vccnz .Lfl_f3_%=\n\t" FS_PK_A(FS_R0)                                                             \
+        "s_add_u32 %[off], %[off], 0x80\n\t" /* max|w8| for the next block test; its floor test rides in the next body */ \
+        FS_T_X("v48", "v49") "s_branch .Lfl_loop_%=\n"                                                              \
+        ".Lfl_out_%=:\n\t" /* the block here needs its bound tests, or fewer than 8 steps are left: the pending tests */ \
+        "s_mov_b32 %[eb], s62\n\t" FS_FL_N1("v54", "v55") FS_FL_N2("v48", "v49") FS_FL_C                            \
+        "s_cbranch_vccnz .Lfl_fp_%=\n\t"                                                                            \
+        "s_mov_b32 %[st], 0\n\t"                                                                                    \
+        "s_branch .Lfl_end_%=\n"                                                                                    \
+        ".Lfl_blk_%=:\n\t" /* the same after the first block (no verdict is pending there) */                       \
+        "s_mov_b32 %[st], 0\n\t"                                                                                    \
+        "s_mov_b64 s[64:65], s[48:49]\n\t"                                                                          \
+        "s_mov_b32 s67, s51\n\t"                                                                                    \
+        "s_add_u32 %[off], %[off], 0x40\n\t"                                                                        \
+        "s_branch .Lfl_end_%=\n"                                                                                    \
+        ".Lfl_fp_%=:\n\t" /* the previous body's last trip: start state v[52:53], first step v[54:55] */            \
+        "s_mov_b32 %[st], 2\n\t"                                                                                    \
+        "s_sub_u32 %[off], %[off], 0x20\n\t"                                                                        \
+        "s_branch .Lfl_end_%=\n"                                                                                    \
+        ".Lfl_f1_%=:\n\t"                                                                                           \
+        "s_mov_b32 %[st], 1\n\t"                                                                                    \
+        "s_mov_b32 %[eb], s38\n\t"                                                                                  \
+        "s_branch .Lfl_end_%=\n"                                                                                    \
+        ".Lfl_f2_%=:\n\t"                                                                                           \
+        "s_mov_b32 %[st], 2\n\t"                                                                                    \
+        "s_mov_b32 %[eb], s46\n\t"                                                                                  \
+        "s_add_u32 %[off], %[off], 0x20\n\t"                                                                        \
+        "s_branch .Lfl_end_%=\n"                                                                                    \
+        ".Lfl_f3_%=:\n\t"                                                                                           \
+        "s_mov_b32 %[st], 1\n\t"                                                                                    \
+        "s_mov_b32 %[eb], s54\n\t"                                                                                  \
+        "s_add_u32 %[off], %[off], 0x40\n"                                                                          \
+        ".Lfl_end_%=:\n\t"                                                                                          \
+        "s_waitcnt lgkmcnt(0)" /* (a failed pending trip leaves after the loads: nothing stays in flight) */        \
+        : "+{v[48:49]}"(wv), "={v[50:51]}"(r1), "={v[52:53]}"(r2), "+{v[54:55]}"(r3), "={v[56:57]}"(ts_),           \
+          "={v[58:59]}"(ta_), "+{v60}"(mxS), "={v61}"(tn_), "={v62}"(tl_), [m] "=&s"(msk_), [st] "=&s"(st),         \
+          [eb] "=&s"(ebo), "+{s67}"(pwi), "+{s[64:65]}"(zS), [off] "+s"(off), [pf] "=&s"(pf_), [pg] "=&s"(pg_),     \
+          [ph] "=&s"(ph_)                                                                                           \
+        : [se] "v"(sE2), [dc] "v"(dcs), [esh] "v"(Esh), [imdc] "v"(imdc), [lim8] "s"(lim8), "{s[68:69]}"(zpb)       \
+        : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50",  \
+          "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s66", "vcc",  \
+          "scc")
+
+// ------------------------------------------------------------------------------------------------
 // LAv2, T = HDRFloat<float>: tuned perturbation loop.  Same prologue (AT + LA stages) and the same results, bit for
 // bit, as k_lav2_hdr32; the perturbation loop (>99.9 % of the executed work at View 5) is restructured around what
 // the CPU arithmetic actually does per step (measured with an instrumented oracle):
@@ -894,7 +1009,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                     FS_CYC(cyc_t1 = __builtin_readcyclecounter());
                     for (;;) {
                         const float4 e0 = zs[ref];
-                        const int E = dze;
+                        // (floor form, see FS_FAST_LOOP_FL: the run's scale puts max|w| at 2^-24)
+                        const int E = dze + kScaleShift;
                         const float sE = __builtin_amdgcn_ldexpf(1.0f, E); // 0 / denormal below 2^-126: dz then cannot matter
                         const int dsh = dce - E;
                         const f2 dcs = {__builtin_amdgcn_ldexpf(dcm.x, dsh), __builtin_amdgcn_ldexpf(dcm.y, dsh)};
@@ -905,12 +1021,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                         const uint32_t left = left_ref < left_it ? left_ref : left_it;
                         // max|w| 2^E <= bound, on the bit patterns: for positive floats the exponent shift is an integer add,
                         // a result below the normal range turns negative (dz far too small to matter: passes), NaN is huge
-                        // (E < 0 in every run: the start test needs max|dz| in [2^E, 2^(E+1)) below a bound < 0.7)
-                        const int Esh = (E < -254 ? -254 : (E > 0 ? 0 : E)) * (1 << 23);
+                        // (max|w| < 2^29 and |dz| = |w| 2^E < 4: the sum of the two exponent fields stays inside a float's)
+                        const int Esh = (E < -254 ? -254 : (E > 127 ? 127 : E)) * (1 << 23);
                         // (the state a run starts from has passed the CPU loop's tests already: only the entry it starts at
                         // must be one the companion vouches for -- scaled_startable: 2Z exact in true scale)
-                        const bool start_ok = scaled_startable(e0) && mn0 >= mx0 * 0x1p-40f && mx0 >= 1.0f && mx0 < 2.0f &&
-                                              dsh <= 30;
+                        // dz 2^-E is exact and above the floor; dc 2^-E <= 2^7 (the same dc <= 2^30 dz as before)
+                        const bool start_ok = scaled_startable(e0) && mn0 >= 0x1p-32f && mx0 >= 1.0f && mx0 < 2.0f &&
+                                              dsh <= 30 - kScaleShift;
                         // run length: the longest of 256 / 64 / 16 steps that every lane still has before the orbit ends
                         // and before its iteration limit (three votes per run, not a counter per step)
                         const uint32_t run_len = scaled_run_length(left);
@@ -937,11 +1054,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
     AFTER_ARITH;                                                                                                    \
     NZ_ = (f2){EX, EY};                                                                                             \
     V |= __builtin_amdgcn_ballot_w64(__float_as_int(mx_##T) + Esh > __float_as_int(EB));                            \
-    if (FULL) {                                                                                                     \
-        const float mn_##T = __builtin_fminf(__builtin_fabsf(NW_.x), __builtin_fabsf(NW_.y));                       \
-        V |= __builtin_amdgcn_ballot_w64(!(mn_##T >= mx_##T * 0x1p-40f)) |                                          \
-             __builtin_amdgcn_ballot_w64((uint32_t)(__float_as_int(mx_##T) - (107 << 23)) >= (uint32_t)(60 << 23)); \
-    }
+    FS_STEP_FLOOR(NW_, V)                                                                                           \
+    if (FULL)                                                                                                       \
+        V |= __builtin_amdgcn_ballot_w64(!(mx_##T < FS_FL_HIGH_TRIP));
                         // Two steps are tested together and the state ping-pongs between two register sets over two such
                         // trips, so neither the back-edge nor the roll-back of a failed trip needs a register copy: a
                         // trip that contains a failing step is dropped as a whole and its first step goes to the
@@ -955,8 +1070,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         const float mn_s = __builtin_fminf(__builtin_fabsf(NW_.x), __builtin_fabsf(NW_.y));                         \
         const uint64_t bad_s =                                                                                      \
             __builtin_amdgcn_ballot_w64(__float_as_int(mx_##T) + Esh > __float_as_int(EB)) |                        \
-            __builtin_amdgcn_ballot_w64(!(mn_s >= mx_##T * 0x1p-40f)) |                                             \
-            __builtin_amdgcn_ballot_w64((uint32_t)(__float_as_int(mx_##T) - (107 << 23)) >= (uint32_t)(60 << 23)); \
+            __builtin_amdgcn_ballot_w64(!(mn_s >= FS_FL_FLOOR));                                                    \
         if (bad_s == 0ull) {                                                                                        \
             wO = NW_;                                                                                               \
             c += 1;                                                                                                 \
@@ -971,8 +1085,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         const float mn_s = __builtin_fminf(__builtin_fabsf(NW_.x), __builtin_fabsf(NW_.y));                         \
         const uint64_t bad_s =                                                                                      \
             __builtin_amdgcn_ballot_w64(__float_as_int(mx_s) + Esh > __float_as_int(EB)) |                        \
-            __builtin_amdgcn_ballot_w64(!(mn_s >= mx_s * 0x1p-40f)) |                                             \
-            __builtin_amdgcn_ballot_w64((uint32_t)(__float_as_int(mx_s) - (107 << 23)) >= (uint32_t)(60 << 23)); \
+            __builtin_amdgcn_ballot_w64(!(mn_s >= FS_FL_FLOOR));                                                  \
         if (bad_s == 0ull) {                                                                                        \
             wO = NW_;                                                                                               \
             c += 1;                                                                                                 \
@@ -981,7 +1094,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         }                                                                                                           \
         failed = true;                                                                                              \
     }
-                        f2 w0 = dzm, z0 = {e0.x, e0.y}, w2, z2, wO;
+                        f2 w0 = dzm * 0x1p-24f, z0 = {e0.x, e0.y}, w2, z2, wO; // (kScaleShift)
                         uint32_t c = 0;
                         bool failed;
                         FS_CYC(cyc_t2 = __builtin_readcyclecounter());
@@ -1102,7 +1215,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                             // it stops after four when the second block needs its bound tests).  Blocks that need them run
                             // the tested C++ form, four steps at a time.
                             const int imdc = __float_as_int(__builtin_fmaxf(__builtin_fabsf(dcs.x), __builtin_fabsf(dcs.y)));
-                            float mxS = mx0;
+                            float mxS = mx0 * 0x1p-24f;
                             int pwi = __builtin_amdgcn_readfirstlane(__float_as_int(e0.w));
                             // (all lanes sit at the same entry here: 2Z of the entry the state is at lives in scalar registers)
                             f2 zS = {__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(e0.x))),
@@ -1126,13 +1239,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                                     // that needs its tests or of the last four steps (or at the end of the run); 1 / 2 =
                                     // the first / second trip of a block failed (start state, first step: wv / r1,
                                     // r2 / r3; pwi = the first arrival's bound; cs counts the steps before the trip)
-                                    f2 r1, r2, r3, ts_, ta_;
+                                    f2 r1, r2, r3 = wv, ts_, ta_; // (r3 = wv: the pending pair on entry is the state itself)
                                     float tn_, tl_;
                                     uint64_t msk_;
                                     int st, ebo, pf_, pg_, ph_;
                                     const uint32_t c_in = cs;
                                     uint32_t off = cs << 4;
-                                    FS_FAST_LOOP(FS_PF_NONE);
+                                    FS_FAST_LOOP_FL(FS_PF_NONE);
                                     st = __builtin_amdgcn_readfirstlane(st); // (asm results count as divergent)
                                     cs = (uint32_t)__builtin_amdgcn_readfirstlane((int)off) >> 4;
                                     pwi = __builtin_amdgcn_readfirstlane(pwi);
@@ -1154,6 +1267,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                                     c = cs, wO = wv, failed = false;
                                     break;
                                 }
+                                // H where a block starts (the untested loop leaves here for it too): the run ends and the next
+                                // one re-centres the scale
+                                if (__builtin_amdgcn_ballot_w64(!(mxS < FS_FL_HIGH)) != 0ull) {
+                                    c = cs, wO = wv, failed = false;
+                                    break;
+                                }
                                 // a block with its bound tests: four entries as one 64-byte scalar load (s_load_dwordx16
                                 // takes any dword-aligned address)
                                 if (kStats)
@@ -1169,9 +1288,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                                 uint64_t vp_ = 0, vq_ = 0;
                                 c = cs;
                                 FS_STEP_BOUND(tp_, a, vp_, ua.z)
+                                FS_STEP_FLOOR(tp_, vp_)
                                 FS_STEP_ARITH(tp_, up_, w2, b)
                                 FS_STEP_BOUND(w2, b, vp_, ub.z)
-                                FS_STEP_SHAPE(w2, b, vp_)
+                                FS_STEP_FLOOR(w2, vp_)
 #ifdef FS_VERIFY_BLOCK_BOUND
                                 if (kStats && bt_pass &&
                                     (__builtin_amdgcn_ballot_w64(__float_as_int(mx_a) + Esh > __float_as_int(ua.z)) |
@@ -1186,10 +1306,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                                 c += 2;
                                 FS_STEP_ARITH(w2, z2, tq_, c_)
                                 FS_STEP_BOUND(tq_, c_, vq_, uc.z)
+                                FS_STEP_FLOOR(tq_, vq_)
                                 f2 w4;
                                 FS_STEP_ARITH(tq_, uq_, w4, d)
                                 FS_STEP_BOUND(w4, d, vq_, ud.z)
-                                FS_STEP_SHAPE(w4, d, vq_)
+                                FS_STEP_FLOOR(w4, vq_)
 #ifdef FS_VERIFY_BLOCK_BOUND
                                 if (kStats && bt_pass &&
                                     (__builtin_amdgcn_ballot_w64(__float_as_int(mx_c_) + Esh > __float_as_int(uc.z)) |
