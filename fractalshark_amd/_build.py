@@ -94,7 +94,7 @@ _UNIT_FLAGS = {"kernels_scaled.hip": ["-fno-slp-vectorize"]}
 
 def _inputs_sources():
     return [os.path.join(HOST, "refinputs.cpp"), os.path.join(CSRC, "hdr_math.hpp"), os.path.join(CSRC, "la_math.hpp"),
-            os.path.join(CSRC, "df32_math.hpp"),
+            os.path.join(CSRC, "df32_math.hpp"), os.path.join(CSRC, "bla_math.hpp"),
             os.path.join(ROOT, "include", "fs_inputs.h"), os.path.join(ROOT, "include", "fs_layout.h")]
 
 

@@ -235,6 +235,9 @@ template <class F> FS_HD hreal<F> hr_sub(hreal<F> a, hreal<F> b)
     return a;
 }
 
+// HDRFloat.h:606-613 reciprocal(): raw, not reduced.
+template <class F> FS_HD hreal<F> hr_recip(hreal<F> a) { return hreal<F>{F(1) / a.m, -a.e}; }
+
 template <class F> FS_HD hreal<F> hr_neg(hreal<F> a) { return hreal<F>{-a.m, a.e}; }
 // HDRFloat.h:1385-1404 HdrAbs.
 template <class F> FS_HD F fabs_bits(F v)
@@ -406,6 +409,22 @@ template <class F> FS_HD hreal<F> hc_cheb(hcplx<F> a)
     const F ar = fabs_bits<F>(a.re);
     const F ai = fabs_bits<F>(a.im);
     return hreal<F>{ar > ai ? ar : ai, a.e};
+}
+
+// HDRFloatComplex.h:551-555 norm(): the mantissas' Euclidean length under the shared exponent.
+template <class F> FS_HD hreal<F> hc_norm(hcplx<F> a)
+{
+    const F n2 = a.re * a.re + a.im * a.im;
+    return hreal<F>{sizeof(F) == 4 ? (F)__builtin_sqrtf((float)n2) : (F)__builtin_sqrt((double)n2), a.e};
+}
+
+// HDRFloatComplex.h:574-594 divide_mutable(complex).
+template <class F> FS_HD hcplx<F> hc_div(hcplx<F> a, hcplx<F> b)
+{
+    const F t = F(1) / (b.re * b.re + b.im * b.im);
+    const F re = (a.re * b.re + a.im * b.im) * t;
+    const F im = (a.im * b.re - a.re * b.im) * t;
+    return hcplx<F>{re, im, clamp_exp(a.e - b.e)};
 }
 
 // HDRFloatComplex.h:556-561 reciprocal.

@@ -17,33 +17,14 @@
 
 #include "../../include/fs_layout.h"
 #include "hdr_math.hpp"
+#include "bla_math.hpp"
 #include "kernels.h"
 
 using namespace fs;
 
 namespace {
 
-template <class F> struct Rec {
-    hreal<F> r2, Ax, Ay, Bx, By;
-    int32_t l;
-};
-
-template <class F> __device__ __forceinline__ F sqrt_rn(F v);
-template <> __device__ __forceinline__ float sqrt_rn<float>(float v) { return __builtin_sqrtf(v); }
-template <> __device__ __forceinline__ double sqrt_rn<double>(double v) { return __builtin_sqrt(v); }
-
-// HdrSqrt, HDRFloat.h:1358-1383
-template <class F> __device__ __forceinline__ hreal<F> hsqrt(hreal<F> a)
-{
-    const bool odd = (a.e & 1) != 0;
-    return hreal<F>{sqrt_rn<F>(odd ? F(2) * a.m : a.m), odd ? (a.e - 1) / 2 : a.e / 2};
-}
-
-// BLA<T>::hypotA / hypotB, BLA.cuh:40-56
-template <class F> __device__ __forceinline__ hreal<F> hypot2(hreal<F> a, hreal<F> b)
-{
-    return hr_reduced(hsqrt(hr_add(hr_mul(a, a), hr_mul(b, b))));
-}
+template <class F> using Rec = BlaRec<F>;
 
 __device__ __forceinline__ hcplx<float> zat(const float4 *__restrict__ z, uint32_t i)
 {
@@ -55,35 +36,15 @@ __device__ __forceinline__ hcplx<double> zat(const FsZ64 *__restrict__ z, uint32
     return hcplx<double>{z[i].re, z[i].im, z[i].e};
 }
 
-// BLAS::CreateOneStep, BLAS.cpp:74-93
+// The record arithmetic itself is csrc/bla_math.hpp (shared with the host builder and the known-answer harness):
+// BLAS::CreateOneStep (BLAS.cpp:74-93) at orbit entry m, BLAS::MergeTwoBlas (BLAS.cpp:25-47).
 template <class F, class Z> __device__ __forceinline__ Rec<F> one_step(const Z *__restrict__ zref, uint32_t m, hreal<F> epsilon)
 {
-    const hcplx<F> z = zat(zref, m);
-    const hreal<F> RealA = hr_mul2(hc_re(z));
-    const hreal<F> ImagA = hr_mul2(hc_im(z));
-    const hreal<F> mA = hsqrt(hr_add(hr_mul(RealA, RealA), hr_mul(ImagA, ImagA)));
-    const hreal<F> r = hr_mul(mA, epsilon);
-    return Rec<F>{hr_mul(r, r), RealA, ImagA, hr_from_number<F>(F(1)), hr_from_number<F>(F(0)), 1};
+    return bla_one_step<F>(zat(zref, m), epsilon);
 }
-
-// BLAS::MergeTwoBlas, BLAS.cpp:25-47 with BLA::getNewA / getNewB, BLA.cuh:65-91
 template <class F> __device__ __forceinline__ Rec<F> merge(const Rec<F> &x, const Rec<F> &y, hreal<F> blaSize)
 {
-    Rec<F> o;
-    o.l = x.l + y.l;
-    o.Ax = hr_reduced(hr_sub(hr_mul(y.Ax, x.Ax), hr_mul(y.Ay, x.Ay)));
-    o.Ay = hr_reduced(hr_add(hr_mul(y.Ax, x.Ay), hr_mul(y.Ay, x.Ax)));
-    o.Bx = hr_reduced(hr_add(hr_sub(hr_mul(y.Ax, x.Bx), hr_mul(y.Ay, x.By)), y.Bx));
-    o.By = hr_reduced(hr_add(hr_add(hr_mul(y.Ax, x.By), hr_mul(y.Ay, x.Bx)), y.By));
-    const hreal<F> xA = hypot2(x.Ax, x.Ay);
-    const hreal<F> xB = hypot2(x.Bx, x.By);
-    const hreal<F> tempR = hr_reduced(hr_div(hr_sub(hsqrt(y.r2), hr_mul(xB, blaSize)), xA));
-    const hreal<F> zero = hr_from_number<F>(F(0));
-    const hreal<F> mx = hr_cmp(zero, tempR) > 0 ? zero : tempR; // HdrMaxReduced(T(0), tempR)
-    const hreal<F> sx = hsqrt(x.r2);
-    const hreal<F> r = hr_cmp_pos(sx, mx) < 0 ? sx : mx; // HdrMinPositiveReduced
-    o.r2 = hr_mul(r, r);
-    return o;
+    return bla_merge<F>(x, y, blaSize);
 }
 
 template <class F> __device__ __forceinline__ Rec<F> ld_rec(const typename FsDev<F>::BLA &b)

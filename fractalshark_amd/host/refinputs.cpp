@@ -30,6 +30,7 @@
 #include "../csrc/hdr_math.hpp"
 #include "../csrc/df32_math.hpp"
 #include "../csrc/la_math.hpp"
+#include "../csrc/bla_math.hpp"
 #include "../../include/fs_inputs.h"
 
 using namespace fs;
@@ -2164,10 +2165,7 @@ extern "C" void fsh_la_at(const fsh_la *l, void *outp)
 // sequential fill gives the same table.
 namespace {
 
-template <class F> struct BlaRec {
-    hreal<F> r2, Ax, Ay, Bx, By;
-    int32_t l;
-};
+// (BlaRec<F> and the record arithmetic: csrc/bla_math.hpp, shared with the device builder)
 
 template <class F> struct BlaBuilder {
     const OrbitT<F> &ob;
@@ -2179,40 +2177,11 @@ template <class F> struct BlaBuilder {
 
     explicit BlaBuilder(const OrbitT<F> &o) : ob(o) {}
 
-    // BLA<T>::hypotA / hypotB, BLA.cuh:40-56
-    static hreal<F> hypot2(hreal<F> a, hreal<F> b) { return hr_reduced(hr_sqrt(hr_add(hr_mul(a, a), hr_mul(b, b)))); }
-
     // BLAS::CreateOneStep, BLAS.cpp:74-93
-    BlaRec<F> one_step(size_t m, hreal<F> epsilon) const
-    {
-        const hcplx<F> z = hc_from_hr(ob.x[m], ob.y[m]);
-        const hreal<F> RealA = hr_mul2(hc_re(z));
-        const hreal<F> ImagA = hr_mul2(hc_im(z));
-        const hreal<F> mA = hr_sqrt(hr_add(hr_mul(RealA, RealA), hr_mul(ImagA, ImagA)));
-        const hreal<F> r = hr_mul(mA, epsilon);
-        const hreal<F> r2 = hr_mul(r, r);
-        return BlaRec<F>{r2, RealA, ImagA, hr_from_number<F>(F(1)), hr_from_number<F>(F(0)), 1};
-    }
+    BlaRec<F> one_step(size_t m, hreal<F> epsilon) const { return bla_one_step<F>(hc_from_hr(ob.x[m], ob.y[m]), epsilon); }
 
     // BLAS::MergeTwoBlas, BLAS.cpp:25-47
-    BlaRec<F> merge(const BlaRec<F> &x, const BlaRec<F> &y, hreal<F> blaSize) const
-    {
-        const int32_t l = x.l + y.l;
-        // getNewA / getNewB, BLA.cuh:65-91
-        const hreal<F> RealA = hr_reduced(hr_sub(hr_mul(y.Ax, x.Ax), hr_mul(y.Ay, x.Ay)));
-        const hreal<F> ImagA = hr_reduced(hr_add(hr_mul(y.Ax, x.Ay), hr_mul(y.Ay, x.Ax)));
-        const hreal<F> RealB = hr_reduced(hr_add(hr_sub(hr_mul(y.Ax, x.Bx), hr_mul(y.Ay, x.By)), y.Bx));
-        const hreal<F> ImagB = hr_reduced(hr_add(hr_add(hr_mul(y.Ax, x.By), hr_mul(y.Ay, x.Bx)), y.By));
-        const hreal<F> xA = hypot2(x.Ax, x.Ay);
-        const hreal<F> xB = hypot2(x.Bx, x.By);
-        const hreal<F> tempR = hr_reduced(hr_div(hr_sub(hr_sqrt(y.r2), hr_mul(xB, blaSize)), xA));
-        const hreal<F> zero = hr_from_number<F>(F(0));
-        const hreal<F> mx = hr_cmp(zero, tempR) > 0 ? zero : tempR; // HdrMaxReduced(T(0), tempR)
-        const hreal<F> sx = hr_sqrt(x.r2);
-        const hreal<F> r = hr_cmp_pos(sx, mx) < 0 ? sx : mx; // HdrMinPositiveReduced
-        const hreal<F> r2 = hr_mul(r, r);
-        return BlaRec<F>{r2, RealA, ImagA, RealB, ImagB, l};
-    }
+    BlaRec<F> merge(const BlaRec<F> &x, const BlaRec<F> &y, hreal<F> blaSize) const { return bla_merge<F>(x, y, blaSize); }
 
     // BLAS::CreateLStep, BLAS.cpp:49-72
     BlaRec<F> l_step(size_t level, size_t m, hreal<F> blaSize, hreal<F> epsilon) const
