@@ -98,8 +98,19 @@ template <class F> struct FsLav2ArgsT {
     const uint32_t *tile_order;
     uint32_t *tile_cost;
     uint32_t tiles_x;
+    // IterType = uint64_t POSITIONS (the waypoint-resident kernel with 64-bit counters, fsk_lav2_seq `wide`): high words of
+    // the orbit's uncompressed length, of its period and of the AT step length; la_u64 = 1: `las` holds the reference's
+    // uint64_t records (fs_la_hdr32_u64 / fs_la_hdr64_u64: 64-bit StepLength / NextStageLAIndex) instead of the narrowed ones
+    uint32_t orbit_count_hi, period_hi, at_step_hi, la_u64;
 };
 using FsLav2Args32 = FsLav2ArgsT<float>;
+template <class F> struct FsLaU64;
+template <> struct FsLaU64<float> {
+    using T = fs_la_hdr32_u64;
+};
+template <> struct FsLaU64<double> {
+    using T = fs_la_hdr64_u64;
+};
 
 // Device-native BLA table of the HDRFloat<float> kernel (k_bla_make_native, kernels_tables.hip), built once per (table,
 // orbit) pair next to the reference-layout levels.  All levels >= 2 back to back; position of element ix of level L =
@@ -305,6 +316,10 @@ void fsk_lav2_wide(const FsLav2Args32 *A32, const FsLav2ArgsT<double> *A64, int 
 // PerturbExtras::SimpleCompression with the orbit decompressed IN the kernel (GPUPerturbSingleResults::SeqWorkspace /
 // GetIterSeq / BinarySearch, Perturb.cuh:146-326): only the waypoints are resident (A.wp); the literal kernel walks them
 void fsk_lav2_seq(const FsLav2Args32 *A32, const FsLav2ArgsT<double> *A64, int mode, bool stats, hipStream_t s);
+// test hook: one lane's SeqOrbit cursor (32- or 64-bit positions) seeks to `start` and walks n entries on; out[k] = the
+// orbit value at start + k as hcplx<float> (12 B) / hcplx<double> (24 B)
+void fsk_seq_cursor_probe(bool is64, bool wide_pos, const void *wp, uint32_t n_wp, const void *cx, const void *cy,
+                          uint64_t start, uint32_t n, void *out, hipStream_t s);
 void fsk_lav2_2x32(const FsLav2Args2x32 &A, int mode, bool stats, hipStream_t s);
 // kind: 0 = float, 1 = double, 2 = CudaDblflt
 void fsk_lav2_plain(const FsLav2ArgsPlain &A, int kind, int mode, bool stats, hipStream_t s);

@@ -143,19 +143,22 @@ template <> struct FsWaypoints<double> {
     using Rec = fs_orbit_hdr64_rc;
 };
 
-template <class F> struct SeqOrbit {
+// PosT = the reference's IterType for orbit POSITIONS: uint32_t, or uint64_t in the instantiation that counts in 64 bits --
+// a compressed orbit can have 2^32 and more uncompressed entries (its waypoints are what is resident), and waypoint
+// indices, the cursor, RefIteration and the period are then 64-bit like the reference's (Perturb.cuh:21-23,202-203,247-271).
+template <class F, class PosT = uint32_t> struct SeqOrbit {
     const typename FsWaypoints<F>::Rec *__restrict__ wp;
     uint32_t n_wp;
     hreal<F> cx, cy;
     // cursor
-    uint32_t idx;        // orbit index of (zx, zy)
-    uint32_t next;       // number of the first waypoint behind the cursor
-    uint32_t next_index; // ... and its orbit index (~0u: none left)
+    PosT idx;        // orbit index of (zx, zy)
+    uint32_t next;   // number of the first waypoint behind the cursor
+    PosT next_index; // ... and its orbit index (all ones: none left)
     hreal<F> zx, zy;
 
-    __device__ __forceinline__ uint32_t index_of(uint32_t k) const
+    __device__ __forceinline__ PosT index_of(uint32_t k) const
     {
-        return (uint32_t)(wp[k].index_and_rebase & 0x7FFFFFFFFFFFFFFFull);
+        return (PosT)(wp[k].index_and_rebase & 0x7FFFFFFFFFFFFFFFull);
     }
     __device__ __forceinline__ void load(uint32_t k)
     {
@@ -168,7 +171,7 @@ template <class F> struct SeqOrbit {
         if (idx == next_index) { // GetCompressedComplexSeq, Perturb.cuh:303-326
             load(next);
             next++;
-            next_index = next < n_wp ? index_of(next) : 0xFFFFFFFFu;
+            next_index = next < n_wp ? index_of(next) : ~(PosT)0;
         } else { // runOneIter, PerturbationResultsHelpers.h:51-58
             const hreal<F> zx_old = zx;
             zx = hr_add(hr_sub(hr_mul(zx, zx), hr_mul(zy, zy)), cx);
@@ -177,7 +180,7 @@ template <class F> struct SeqOrbit {
             hr_reduce(zy);
         }
     }
-    __device__ __forceinline__ void seek(uint32_t i)
+    __device__ __forceinline__ void seek(PosT i)
     {
         // BinarySearch, Perturb.cuh:241-263: the last waypoint whose index is <= i (waypoint 0 sits at index 0)
         uint32_t lo = 0, hi = n_wp;
@@ -191,13 +194,31 @@ template <class F> struct SeqOrbit {
         load(lo);
         idx = index_of(lo);
         next = lo + 1u;
-        next_index = next < n_wp ? index_of(next) : 0xFFFFFFFFu;
+        next_index = next < n_wp ? index_of(next) : ~(PosT)0;
         while (idx < i)
             step();
     }
     // PerturbationResults::GetComplex on the cursor's value
     __device__ __forceinline__ hcplx<F> value() const { return hc_from_hr(zx, zy); }
 };
+
+// test hook (fs_seq_cursor_probe): one lane seeks to `start` and walks n entries on; out[k] = the value at start + k
+template <class F, class PosT>
+__global__ void k_seq_cursor_probe(const void *wp, uint32_t n_wp, hreal<F> cx, hreal<F> cy, uint64_t start, uint32_t n,
+                                   hcplx<F> *out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0)
+        return;
+    SeqOrbit<F, PosT> seq;
+    seq.wp = (const typename FsWaypoints<F>::Rec *)wp;
+    seq.n_wp = n_wp;
+    seq.cx = cx, seq.cy = cy;
+    seq.seek((PosT)start);
+    for (uint32_t k = 0; k < n; k++) {
+        out[k] = seq.value();
+        seq.step();
+    }
+}
 
 } // namespace
 
@@ -216,6 +237,24 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
     // The float instantiation is the operation-by-operation A/B reference of the tuned kernel and keeps the literal AT
     // loop; the double instantiation is the production HDRFloat<double> kernel and uses the steady-state AT loop.
     constexpr bool kFastAT = sizeof(F) == 8;
+    // 64-bit POSITIONS go with the waypoint-resident orbit and 64-bit counters (see SeqOrbit); every other instantiation
+    // keeps 32-bit ones (an expanded orbit of 2^32 entries does not fit a device)
+    constexpr bool kWidePos = kSeq && sizeof(IterT) == 8;
+    using PosT = std::conditional_t<kWidePos, uint64_t, uint32_t>;
+    using LaRec = typename FsDev<F>::LA;
+    using LaRec64 = typename FsLaU64<F>::T;
+    // the table's records: the narrowed (uint32_t) ones, or the reference's uint64_t records as they are (A.la_u64) -- the
+    // two layouts agree up to StepLength, so the coefficients are read through the narrow type either way
+    const bool la64 = kWidePos && A.la_u64 != 0u;
+    auto la_rec = [&](uint64_t idx) -> const LaRec * {
+        return la64 ? (const LaRec *)((const LaRec64 *)(const void *)A.las + idx) : A.las + idx;
+    };
+    auto la_step_length = [&](const LaRec *p) -> IterT {
+        return la64 ? (IterT)((const LaRec64 *)(const void *)p)->StepLength : (IterT)p->StepLength;
+    };
+    auto la_next_stage = [&](const LaRec *p) -> PosT {
+        return la64 ? (PosT)((const LaRec64 *)(const void *)p)->NextStageLAIndex : (PosT)p->NextStageLAIndex;
+    };
     uint32_t X, L;
     tile_pixel(X, L);
     uint64_t c_at = 0, c_la = 0, c_pt = 0, c_px = 0;
@@ -233,7 +272,8 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
 
         if (Mode != FS_MODE_PO) {
             if (A.la_valid && A.use_at && hr_cmp_pos(hc_cheb(DeltaSub0), ldr(A.at.ThresholdC)) <= 0) {
-                const IterT ATMaxIt = n_iterations / A.at.StepLength;
+                const IterT at_step = kWidePos ? (IterT)(((uint64_t)A.at_step_hi << 32) | A.at.StepLength) : (IterT)A.at.StepLength;
+                const IterT ATMaxIt = n_iterations / at_step;
                 hcplx<F> c = hc_add(hc_mul(DeltaSub0, ldc(A.at.CCoeff)), ldc(A.at.RefC));
                 hc_reduce(c);
                 hcplx<F> z;
@@ -254,19 +294,20 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
                 hcplx<F> dz = hc_mul(z, ldc(A.at.InvZCoeff));
                 hc_reduce(dz);
                 DeltaSubN = dz;
-                iterations = i * A.at.StepLength;
+                iterations = i * at_step;
                 if (kStats)
                     c_at = i;
             }
         }
 
-        uint32_t RefIteration = 0;
-        const uint32_t MaxRefIteration = A.orbit_count - 1;
+        PosT RefIteration = 0;
+        const PosT MaxRefIteration = (kWidePos ? (PosT)(((uint64_t)A.orbit_count_hi << 32) | A.orbit_count) : (PosT)A.orbit_count) - 1;
+        const PosT period = kWidePos ? (PosT)(((uint64_t)A.period_hi << 32) | A.period) : (PosT)A.period;
         // complex0 before the LA stages is dead in the CPU function (only its norm was read, into a variable
         // that is overwritten before use), so it is not materialised; the RefIteration %= period side effect
         // (Fractal.cpp:2590-2591) is kept.
-        if (iterations != 0 && !(RefIteration < MaxRefIteration) && A.period != 0)
-            RefIteration = RefIteration % A.period;
+        if (iterations != 0 && !(RefIteration < MaxRefIteration) && period != 0)
+            RefIteration = RefIteration % period;
 
         if (Mode != FS_MODE_PO) {
             uint32_t CurrentLAStage = A.la_valid ? A.stage_count : 0;
@@ -275,16 +316,16 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
                 CurrentLAStage--;
                 const uint32_t LAIndex = A.stages[CurrentLAStage].LAIndex;
                 {
-                    const int cmp = hr_cmp_pos(dcCheb, ldr(A.las[LAIndex].LAThresholdC));
+                    const int cmp = hr_cmp_pos(dcCheb, ldr(la_rec(LAIndex)->LAThresholdC));
                     const bool invalid = A.parity == FS_PARITY_LITERAL ? (cmp < 0) : (cmp >= 0);
                     if (invalid)
                         continue;
                 }
                 const uint32_t MacroItCount = A.stages[CurrentLAStage].MacroItCount;
-                uint32_t j = RefIteration;
+                PosT j = RefIteration;
                 while (iterations < n_iterations) {
-                    const typename FsDev<F>::LA *LAj = &A.las[LAIndex + j];
-                    const uint32_t l = LAj->StepLength;
+                    const LaRec *LAj = la_rec((uint64_t)LAIndex + j);
+                    const IterT l = la_step_length(LAj);
                     bool unusable = true;
                     hcplx<F> newDz = hc_zero<F>();
                     if (iterations + l <= n_iterations) {
@@ -293,14 +334,14 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
                         unusable = hr_cmp_pos(hc_cheb(newDz), ldr(LAj->LAThreshold)) >= 0;
                     }
                     if (unusable) {
-                        RefIteration = LAj->NextStageLAIndex;
+                        RefIteration = la_next_stage(LAj);
                         break;
                     }
                     iterations += l;
                     if (kStats)
                         c_la++;
                     DeltaSubN = hc_add(hc_mul(newDz, ldc(LAj->ZCoeff)), hc_mul(DeltaSub0, ldc(LAj->CCoeff)));
-                    const hcplx<F> complex0 = hc_add(ldc(LAj[1].Ref), DeltaSubN);
+                    const hcplx<F> complex0 = hc_add(ldc(la_rec((uint64_t)LAIndex + j + 1)->Ref), DeltaSubN);
                     j++;
                     const hreal<F> lhs = hr_reduced(hc_cheb(complex0));
                     const hreal<F> rhs = hr_reduced(hc_cheb(DeltaSubN));
@@ -317,7 +358,7 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
         if (Mode != FS_MODE_LAO) {
             const hreal<F> TwoFiftySix = hreal<F>{F(1), 8};
             const typename FsDev<F>::Z *__restrict__ zr = A.zref;
-            SeqOrbit<F> seq;
+            SeqOrbit<F, PosT> seq;
             if constexpr (kSeq) {
                 seq.wp = (const typename FsWaypoints<F>::Rec *)A.wp;
                 seq.n_wp = A.n_wp;
@@ -330,7 +371,7 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
                 if constexpr (kSeq)
                     cur = seq.value();
                 else
-                    cur = zref_at(zr, RefIteration);
+                    cur = zref_at(zr, (uint32_t)RefIteration);
                 cur = hc_mul2(cur);
                 cur = hc_add(cur, DeltaSubN);
                 DeltaSubN = hc_mul(DeltaSubN, cur);
@@ -344,7 +385,7 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
                     seq.step(); // GetIterSeq
                     Znext = seq.value();
                 } else {
-                    Znext = zref_at(zr, RefIteration);
+                    Znext = zref_at(zr, (uint32_t)RefIteration);
                 }
                 hcplx<F> complex0 = hc_add(Znext, DeltaSubN);
                 hc_reduce(complex0);
@@ -3447,6 +3488,30 @@ void fsk_lav2_seq(const FsLav2Args32 *A32, const FsLav2ArgsT<double> *A64, int m
     else
         FS_LAUNCH_SEQ(FS_MODE_LAO);
 #undef FS_LAUNCH_SEQ
+}
+
+void fsk_seq_cursor_probe(bool is64, bool wide_pos, const void *wp, uint32_t n_wp, const void *cx, const void *cy,
+                          uint64_t start, uint32_t n, void *out, hipStream_t s)
+{
+    if (is64) {
+        const fs_real_hdr64 *x = (const fs_real_hdr64 *)cx, *y = (const fs_real_hdr64 *)cy;
+        const hreal<double> hx{x->m, x->e}, hy{y->m, y->e};
+        if (wide_pos)
+            hipLaunchKernelGGL((k_seq_cursor_probe<double, uint64_t>), dim3(1), dim3(64), 0, s, wp, n_wp, hx, hy, start, n,
+                               (hcplx<double> *)out);
+        else
+            hipLaunchKernelGGL((k_seq_cursor_probe<double, uint32_t>), dim3(1), dim3(64), 0, s, wp, n_wp, hx, hy, start, n,
+                               (hcplx<double> *)out);
+    } else {
+        const fs_real_hdr32 *x = (const fs_real_hdr32 *)cx, *y = (const fs_real_hdr32 *)cy;
+        const hreal<float> hx{x->m, x->e}, hy{y->m, y->e};
+        if (wide_pos)
+            hipLaunchKernelGGL((k_seq_cursor_probe<float, uint64_t>), dim3(1), dim3(64), 0, s, wp, n_wp, hx, hy, start, n,
+                               (hcplx<float> *)out);
+        else
+            hipLaunchKernelGGL((k_seq_cursor_probe<float, uint32_t>), dim3(1), dim3(64), 0, s, wp, n_wp, hx, hy, start, n,
+                               (hcplx<float> *)out);
+    }
 }
 
 void fsk_perturb_scalar_hdr64(const FsBlaArgsT<double> &A, bool use_bla, bool stats, int variant, hipStream_t s)

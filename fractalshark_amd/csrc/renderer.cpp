@@ -116,6 +116,8 @@ struct fs_renderer {
     fs_la_stage_u32 *stages = nullptr;
     uint32_t n_las = 0, n_stages = 0;
     int la_valid = 0, use_at = 0;
+    bool la_u64 = false;     // `las` holds the reference's uint64_t records (only the waypoint-resident wide kernel reads them)
+    uint32_t at_step_hi = 0; // high word of the AT step length of a uint64_t table
     fs_at_hdr32_u32 at{};
     fs_at_hdr64_u32 at64{};
     fs_at_2x32_u32 at2x32{};
@@ -659,6 +661,10 @@ template <class F> static void fill_lav2(fs_renderer *r, FsLav2ArgsT<F> &A, cons
     A.la_valid = r->la_ok ? r->la_valid : 0;
     A.use_at = r->use_at;
     A.parity = (parity == FS_PARITY_CPU_GPUSTAGE) ? FS_PARITY_GPUSTAGE : FS_PARITY_LITERAL;
+    A.orbit_count_hi = (uint32_t)(r->orbit_uncompressed >> 32);
+    A.period_hi = (uint32_t)(r->orbit_period >> 32);
+    A.at_step_hi = r->at_step_hi;
+    A.la_u64 = r->la_u64 ? 1u : 0u;
 }
 
 
@@ -1044,11 +1050,15 @@ uint32_t fs_upload_orbit_compressed(fs_renderer *r, uint64_t generation, int typ
         return e;
     if ((type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64 && type_tag != FS_T_F32 && type_tag != FS_T_F64 &&
          type_tag != FS_T_2X32 && type_tag != FS_T_HDR2X32) ||
-        (iter_bytes != 4 && iter_bytes != 8) || uncompressed_size > 0xFFFFFFFFull || !orbit_x_low || !orbit_y_low)
+        (iter_bytes != 4 && iter_bytes != 8) || !orbit_x_low || !orbit_y_low)
         return FS_ERR_UNSUPPORTED;
     if (!r->compute)
         return FS_ERR_6;
     const bool want_seq = r->compressed_mode == 1 && (type_tag == FS_T_HDR32 || type_tag == FS_T_HDR64);
+    // an EXPANDED orbit must fit the 32-bit positions of the kernels that read it (and the device: 2^32 entries are 64 GiB
+    // and more); a waypoint-resident one may be any length -- its positions are 64-bit in the kernel that walks it
+    if (!want_seq && uncompressed_size > 0xFFFFFFFFull)
+        return FS_ERR_UNSUPPORTED; // (fs_set_compressed_orbit_mode(1) serves such an orbit)
     if (r->orbit_ok && r->orbit_gen == generation && generation != 0 && r->orbit_type == type_tag && r->orbit_seq == want_seq)
         return 0;
     if (type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64) {
@@ -1206,25 +1216,41 @@ uint32_t fs_upload_la(fs_renderer *r, uint64_t generation, int type_tag, uint32_
     const size_t at_rest32 = (type_tag == FS_T_HDR64 || type_tag == FS_T_F64) ? 8 : 4;
     std::vector<uint8_t> las32, stages32;
     uint8_t at32[sizeof(fs_at_hdr64_u32)] = {0};
+    bool keep_u64 = false; // the LA records stay in the reference's uint64_t layout
+    uint32_t at_step_hi = 0;
+    size_t la_bytes_up = la_bytes;
     if (iter_bytes == 8) {
         bool ok = true;
-        if (n_las)
+        // HDRFloat<float | double> tables under fs_set_compressed_orbit_mode(1) are read by the waypoint-resident kernel,
+        // whose wide instantiation takes the uint64_t records as they are: kept whenever a step length or index does not fit
+        // 32 bits (an orbit of 2^32 and more uncompressed entries), and under the FS_VARIANT_WIDE_COUNTERS test switch
+        const bool can_keep = (type_tag == FS_T_HDR32 || type_tag == FS_T_HDR64) && r->compressed_mode == 1;
+        keep_u64 = can_keep && (r->variant & FS_VARIANT_FLAG_WIDE) != 0;
+        if (n_las && !keep_u64) {
             ok = type_tag == FS_T_HDR32   ? narrow_la<fs_la_hdr32_u64, fs_la_hdr32_u32>(las, n_las, las32)
                  : type_tag == FS_T_HDR64 ? narrow_la<fs_la_hdr64_u64, fs_la_hdr64_u32>(las, n_las, las32)
                  : type_tag == FS_T_F32   ? narrow_la<fs_la_f32_u64, fs_la_f32_u32>(las, n_las, las32)
                  : type_tag == FS_T_F64   ? narrow_la<fs_la_f64_u64, fs_la_f64_u32>(las, n_las, las32)
                  : type_tag == FS_T_2X32  ? narrow_la<fs_la_p2x32_u64, fs_la_p2x32_u32>(las, n_las, las32)
                                           : narrow_la<fs_la_2x32_u64, fs_la_2x32_u32>(las, n_las, las32);
+            if (!ok && can_keep)
+                keep_u64 = ok = true;
+        }
         stages32.resize((size_t)n_stages * sizeof(fs_la_stage_u32));
         for (uint32_t i = 0; ok && i < n_stages; i++) {
+            // (a stage's first record and its record count index the table itself, whose size is a uint32_t)
             const fs_la_stage_u64 &sg = ((const fs_la_stage_u64 *)stages)[i];
-            ok = sg.LAIndex <= 0xFFFFFFFFull && sg.MacroItCount <= 0xFFFFFFFFull;
+            if (sg.LAIndex > 0xFFFFFFFFull || sg.MacroItCount > 0xFFFFFFFFull)
+                return (uint32_t)hipErrorInvalidValue;
             ((fs_la_stage_u32 *)stages32.data())[i] = fs_la_stage_u32{(uint32_t)sg.LAIndex, (uint32_t)sg.MacroItCount};
         }
         if (ok && at_info) {
             uint64_t step;
             memcpy(&step, at_info, 8);
-            ok = step <= 0xFFFFFFFFull;
+            if (keep_u64)
+                at_step_hi = (uint32_t)(step >> 32);
+            else
+                ok = step <= 0xFFFFFFFFull;
             const uint32_t step32 = (uint32_t)step;
             memcpy(at32, &step32, 4);
             // everything after StepLength is laid out identically; it starts at offset 8 in the uint64_t record
@@ -1232,14 +1258,19 @@ uint32_t fs_upload_la(fs_renderer *r, uint64_t generation, int type_tag, uint32_
             at_info = at32;
         }
         if (!ok)
-            return FS_ERR_UNSUPPORTED; // a step length / index that does not fit the 32-bit device counters
-        las = las32.data();
+            return FS_ERR_UNSUPPORTED; // a step length / index beyond 32 bits for a kernel that reads an EXPANDED orbit
+        if (keep_u64)
+            la_bytes_up = type_tag == FS_T_HDR32 ? sizeof(fs_la_hdr32_u64) : sizeof(fs_la_hdr64_u64);
+        else
+            las = las32.data();
         stages = stages32.data();
     }
     r->la_ok = false;
-    FS_TRY(la_reserve(r, (size_t)n_las * la_bytes, (size_t)n_stages * sizeof(fs_la_stage_u32)));
+    FS_TRY(la_reserve(r, (size_t)n_las * la_bytes_up, (size_t)n_stages * sizeof(fs_la_stage_u32)));
     if (n_las)
-        FS_TRY(hipMemcpyAsync(r->las, las, (size_t)n_las * la_bytes, hipMemcpyDefault, r->compute));
+        FS_TRY(hipMemcpyAsync(r->las, las, (size_t)n_las * la_bytes_up, hipMemcpyDefault, r->compute));
+    r->la_u64 = keep_u64;
+    r->at_step_hi = at_step_hi;
     if (n_stages)
         FS_TRY(hipMemcpyAsync(r->stages, stages, (size_t)n_stages * sizeof(fs_la_stage_u32), hipMemcpyDefault,
                               r->compute));
@@ -1716,10 +1747,14 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
         if (mode != FS_LAV2_PO && (!r->la_ok || r->la_type != type_tag))
             return FS_ERR_6;
         const int kmode = mode == FS_LAV2_FULL ? FS_MODE_FULL : (mode == FS_LAV2_PO ? FS_MODE_PO : FS_MODE_LAO);
+        // 64-bit POSITIONS (and counters) whenever something does not fit 32 bits: the orbit's uncompressed length or period,
+        // a table kept in the uint64_t layout -- besides the iteration cap and the test switch
+        const bool wide_pos = wide || r->la_u64 || r->orbit_uncompressed > 0xFFFFFFFFull || r->orbit_period > 0xFFFFFFFFull;
         TimedLaunch t(r);
         if (type_tag == FS_T_HDR32) {
             FsLav2ArgsT<float> A;
             fill_lav2<float>(r, A, coords, n_iterations, parity);
+            A.frame.wide |= wide_pos ? 1u : 0u;
             A.at = r->at;
             A.wp = r->wp_raw, A.n_wp = (uint32_t)r->orbit_size;
             A.cxLow = r->c_low32[0], A.cyLow = r->c_low32[1];
@@ -1727,6 +1762,7 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
         } else {
             FsLav2ArgsT<double> A;
             fill_lav2<double>(r, A, coords, n_iterations, parity);
+            A.frame.wide |= wide_pos ? 1u : 0u;
             A.at = r->at64;
             A.wp = r->wp_raw, A.n_wp = (uint32_t)r->orbit_size;
             A.cxLow = r->c_low64[0], A.cyLow = r->c_low64[1];
@@ -1734,6 +1770,8 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
         }
         return (uint32_t)hipGetLastError();
     }
+    if (r->la_u64 && mode != FS_LAV2_PO)
+        return FS_ERR_UNSUPPORTED; // the table is in the uint64_t layout: only the waypoint-resident kernel reads it
     if (wide && (type_tag == FS_T_HDR32 || type_tag == FS_T_HDR64) && !(mode == FS_LAV2_PO && parity == FS_PARITY_CPU)) {
         // GPURenderer::RenderPerturbLAv2<uint64_t, ...> with a cap the 32-bit counters cannot hold: the literal kernel
         // instantiated with 64-bit counters (all three modes; the reference's arithmetic, operation by operation)
@@ -2438,6 +2476,28 @@ uint32_t fs_read_tile_costs(fs_renderer *r, uint32_t *out, uint64_t max_words, u
         FS_TRY(hipStreamSynchronize(r->compute));
     }
     return 0;
+}
+
+uint32_t fs_seq_cursor_probe(fs_renderer *r, int wide_positions, uint64_t start, uint32_t n, void *out)
+{
+    if (uint32_t e = use_device(r))
+        return e;
+    if (!r->orbit_ok || !r->orbit_seq || !r->wp_raw || !out)
+        return FS_ERR_6;
+    const bool is64 = r->orbit_type == FS_T_HDR64;
+    const size_t rec = is64 ? sizeof(fs::hcplx<double>) : sizeof(fs::hcplx<float>);
+    void *dev = nullptr;
+    FS_TRY(r_alloc(r, &dev, (size_t)n * rec, kFrame));
+    fsk_seq_cursor_probe(is64, wide_positions != 0, r->wp_raw, (uint32_t)r->orbit_size,
+                         is64 ? (const void *)&r->c_low64[0] : (const void *)&r->c_low32[0],
+                         is64 ? (const void *)&r->c_low64[1] : (const void *)&r->c_low32[1], start, n, dev, r->compute);
+    hipError_t err = hipGetLastError();
+    if (err == hipSuccess)
+        err = hipMemcpyAsync(out, dev, (size_t)n * rec, hipMemcpyDeviceToHost, r->compute);
+    if (err == hipSuccess)
+        err = hipStreamSynchronize(r->compute);
+    (void)r_free(r, dev);
+    return (uint32_t)err;
 }
 
 uint32_t fs_read_tile_order(fs_renderer *r, uint32_t *out, uint64_t max_words)

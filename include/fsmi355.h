@@ -135,14 +135,20 @@ uint32_t fs_upload_orbit_compressed(fs_renderer *r, uint64_t generation, int typ
  *                cursor -- GPUPerturbSingleResults::SeqWorkspace / GetIterSeq / BinarySearch (Perturb.cuh:146-326), the
  *                reason the format exists: orbits too long to hold expanded.  Same orbit values bit for bit, hence the same
  *                frames.  Served by fs_render_lav2 (all modes except perturbation-only with FS_PARITY_CPU, whose twin is the
- *                scalar kernel; iteration caps below 2^32); fs_render_bla / fs_build_la / fs_build_bla need the expanded orbit
- *                and return FS_ERR_UNSUPPORTED.  Other numeric types are always expanded.
+ *                scalar kernel; every iteration cap -- 2^32 and above with a uint64_t iteration buffer); fs_render_bla /
+ *                fs_build_la / fs_build_bla need the expanded orbit and return FS_ERR_UNSUPPORTED.  Other numeric types are
+ *                always expanded.  In this mode orbit POSITIONS are IterType-wide like the reference's (Perturb.cuh:21-23,
+ *                202-203,247-271; LAInfoI.h:5-19): an orbit of 2^32 and more uncompressed entries (only its waypoints are
+ *                resident), a period, LA step lengths / next-stage indices and an AT step length beyond 32 bits are accepted
+ *                -- fs_upload_la then keeps the uint64_t records as they are -- and the kernel walks them with 64-bit
+ *                positions.  (Expanded orbits are limited to 2^32 - 1 entries: FS_ERR_UNSUPPORTED above that.)
  * fs_orbit_device_bytes: HBM bytes the resident orbit occupies in all its device forms (0 without an orbit). */
 uint32_t fs_set_compressed_orbit_mode(fs_renderer *r, int mode);
 uint64_t fs_orbit_device_bytes(const fs_renderer *r);
 /* ... and LA table upload (GPU_LAReference ctor, GPU_LAReference.h:79-160).  at_info may be NULL when
  * use_at == 0.  iter_bytes selects the record family: 4 -> fs_la_*_u32 / fs_la_stage_u32 / fs_at_*_u32,
- * 8 -> fs_la_*_u64 / fs_la_stage_u64 / fs_at_*_u64 (narrowed on upload). */
+ * 8 -> fs_la_*_u64 / fs_la_stage_u64 / fs_at_*_u64 (narrowed on upload; kept as they are for HDRFloat<float | double> under
+ * fs_set_compressed_orbit_mode(1) when a step length or index does not fit 32 bits). */
 uint32_t fs_upload_la(fs_renderer *r, uint64_t generation, int type_tag, uint32_t iter_bytes, const void *las,
                       uint32_t n_las, const void *stages, uint32_t n_stages, int is_valid, int use_at,
                       const void *at_info);
@@ -295,6 +301,11 @@ uint32_t fs_set_kernel_variant(fs_renderer *r, int variant);
 uint32_t fs_forget_tile_costs(fs_renderer *r);
 int fs_last_frame_tile_ordered(fs_renderer *r);
 uint32_t fs_read_tile_costs(fs_renderer *r, uint32_t *out, uint64_t max_words, uint64_t *n_tiles);
+/* Test hook for the waypoint-resident orbit (fs_set_compressed_orbit_mode(1), HDRFloat<float | double>): one lane's
+ * decompression cursor -- with 32-bit positions, or the 64-bit ones the wide kernel uses -- seeks to orbit index `start`
+ * and walks n entries on; out[k] = the orbit value at start + k as {float re, im; int32 e} (12 B) or
+ * {double re, im; int32 e; pad} (24 B).  Indices of 2^32 and above need wide_positions = 1. */
+uint32_t fs_seq_cursor_probe(fs_renderer *r, int wide_positions, uint64_t start, uint32_t n, void *out);
 /* The launch order of the most recent frame when it was an ordered one (its first n_tiles words: a permutation of the tile
  * numbers, highest cost class first); 10006 otherwise.  For tests. */
 uint32_t fs_read_tile_order(fs_renderer *r, uint32_t *out, uint64_t max_words);
