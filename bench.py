@@ -567,7 +567,7 @@ def main():
         # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (collected in separate
         # --pmc runs by tools/pmc_passes.sh); null for workloads that have not been profiled.
         key = "view%d_%dx%d_%s" % (args.view, W, H, wl_tag)
-        for tf in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+        for tf in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
                 if key in tj and not distributed and args.parity == "cpu" and args.iter_cap == 0:
