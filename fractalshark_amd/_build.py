@@ -81,6 +81,11 @@ def _render_flags():
         extra.append("-DFS_BACKOFF_CAP=%d" % int(os.environ["FS_BACKOFF_CAP"]))
     if os.environ.get("FS_TRACE_WAVES") == "1":  # tools/wave_trace.py: per-wave start / end / SIMD records
         extra.append("-DFS_TRACE_WAVES")
+    if os.environ.get("FS_VERIFY_FLOOR") == "1":  # tools/floor_check.py: trips whose untested first state is below the every-state floor
+        extra.append("-DFS_VERIFY_FLOOR")
+    for name in ("FS_FL_EVERY", "FS_FL_SHIFT", "FS_FL_FLOOR_EXP"):  # A/B: form and scale of the scaled runs' floor tests (kernels.hip)
+        if os.environ.get(name):
+            extra.append("-D%s=%d" % (name, int(os.environ[name])))
     if os.environ.get("FS_SCALED_CHUNK"):  # tuning experiments only
         extra.append("-DFS_SCALED_CHUNK=" + str(int(os.environ["FS_SCALED_CHUNK"])))
     return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", *extra]
