@@ -704,6 +704,72 @@ constexpr int kFloorBits = (127 - FS_FL_FLOOR_EXP) << 23;
           "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s66", "vcc",  \
           "scc")
 
+// The untested body with the floor verdict DEFERRED (every-state form only): one v_min3 per state accumulates the smallest
+// part of every state the invocation passes through (v61, +inf on entry: the entering state has been certified by whoever
+// made it), no compare and no branch per trip; the verdict is taken once, on the way out -- status 3 = some state fell below
+// the floor: the caller discards the whole run attempt (nothing has been committed) and repeats it with FS_FAST_LOOP_FL,
+// whose per-trip verdicts stop at the failing trip.  A state below the floor is rare (about 1 in 10^4 wave-trips on C3), the
+// repeat costs next to nothing, and each state of an accepted invocation has been tested exactly as in the per-trip form --
+// every-state rigour at the price of the every-second-state form.  H and the block bounds are tested where a block starts,
+// as in FS_FAST_LOOP_FL (they guard the steps that follow, so they cannot be deferred).
+#define FS_FL_ACC(A, B) "v_min3_f32 v61, |" A "|, |" B "|, v61\n\t"
+// The block test's pieces are macro parameters (BMAX / BADD / HCMP / HOR): a second and third copy of the loop without the dc half
+// (max|dc| 2^E within the smallest block bound of the whole orbit) and without H (E >= -26 in every lane) were written and would
+// save about 1 ms on C3, but more than one copy of this statement per kernel makes the backend fail ("illegal VGPR to SGPR copy":
+// the statement's scalar in/out operands meet in phis it treats as divergent) -- one copy, the general one, is instantiated.
+#define FS_BT_DC_MAX "v_max_i32_e32 v62, v60, %[imdc]\n\t"
+#define FS_BT_DC_ADD "v_add_u32_e32 v62, v62, %[esh]\n\t"
+#define FS_BT_NODC_MAX ""
+#define FS_BT_NODC_ADD "v_add_u32_e32 v62, v60, %[esh]\n\t"
+#define FS_BT_H_CMP FS_FL_H
+#define FS_BT_H_OR "s_or_b64 %[m], %[m], vcc\n\t"
+#define FS_BT_NOH_CMP ""
+#define FS_BT_NOH_OR "s_cmp_lg_u64 %[m], 0\n\t"
+#define FS_FAST_LOOP_FD(PF, BMAX, BADD, HCMP, HOR)                                                                                          \
+    asm volatile(                                                                                                   \
+        "v_mov_b32_e32 v61, 0x7f800000\n"                                                                           \
+        ".Lfd_loop_%=:\n\t" /* eight steps left?  the first block's tests: max(max|w|, max|dc|) against .w (s67), H */ \
+        BMAX "s_cmp_gt_u32 %[off], %[lim8]\n\t" BADD                                                                \
+        "s_cbranch_scc1 .Lfd_out_%=\n\t"                                                                            \
+        "v_cmp_lt_i32_e64 %[m], s67, v62\n\t" HCMP HOR                                                              \
+        "s_cbranch_scc1 .Lfd_out_%=\n\t" /* steps 1 .. 4 */                                                         \
+        FS_PK_F(FS_R0, "s[64:65]")                                                                                  \
+        "s_load_dwordx16 s[36:51], s[68:69], %[off]\n\t"                                                            \
+        "s_load_dwordx16 s[52:67], s[68:69], %[off] offset:0x40\n\t"                                                \
+        FS_PK_MA(FS_R0) FS_PK_MB(FS_R0) FS_PK_P FS_PK_A(FS_R1)                                                      \
+        "s_waitcnt lgkmcnt(0)\n\t" PF                                                                               \
+        FS_PK_F(FS_R1, "s[36:37]") FS_FL_ACC("v50", "v51") FS_PK_MA(FS_R1) FS_PK_MB(FS_R1) FS_PK_P FS_PK_A(FS_R2)   \
+        FS_PK_F(FS_R2, "s[40:41]") FS_FL_ACC("v52", "v53") FS_PK_MA(FS_R2) FS_PK_MB(FS_R2) FS_PK_P FS_PK_A(FS_R3)   \
+        FS_PK_F(FS_R3, "s[44:45]") FS_FL_ACC("v54", "v55") FS_PK_MA(FS_R3) FS_PK_MB(FS_R3) FS_PK_P FS_PK_A(FS_R0)   \
+        /* step 5 + w4's floor part and max; the second block's tests in step 6, before anything of block 2 is counted */ \
+        FS_PK_F(FS_R0, "s[48:49]") FS_FL_ACC("v48", "v49") FS_PK_MA(FS_R0) FS_T_X("v48", "v49") FS_PK_MB(FS_R0)     \
+        FS_PK_P BMAX FS_PK_A(FS_R1) BADD                                                                            \
+        FS_PK_F(FS_R1, "s[52:53]") "v_cmp_lt_i32_e64 %[m], s51, v62\n\t" HCMP FS_PK_MA(FS_R1)                       \
+        HOR FS_PK_MB(FS_R1) FS_PK_P "s_cbranch_scc1 .Lfd_blk_%=\n\t" FS_PK_A(FS_R2)                                 \
+        FS_PK_F(FS_R2, "s[56:57]") FS_FL_ACC("v50", "v51") FS_PK_MA(FS_R2) FS_FL_ACC("v52", "v53") FS_PK_MB(FS_R2)  \
+        FS_PK_P FS_PK_A(FS_R3)                                                                                      \
+        FS_PK_F(FS_R3, "s[60:61]") FS_FL_ACC("v54", "v55") FS_PK_MA(FS_R3) FS_PK_MB(FS_R3) FS_PK_P FS_PK_A(FS_R0)   \
+        "s_add_u32 %[off], %[off], 0x80\n\t"                                                                        \
+        FS_T_X("v48", "v49") FS_FL_ACC("v48", "v49") "s_branch .Lfd_loop_%=\n"                                      \
+        ".Lfd_blk_%=:\n\t" /* the second block needs its bound tests (or H): the state is w4 in v[48:49] */         \
+        "s_mov_b64 s[64:65], s[48:49]\n\t"                                                                          \
+        "s_mov_b32 s67, s51\n\t"                                                                                    \
+        "s_add_u32 %[off], %[off], 0x40\n"                                                                          \
+        ".Lfd_out_%=:\n\t" /* the verdict over every state of this invocation */                                    \
+        "s_mov_b32 %[st], 0\n\t" FS_FL_C                                                                            \
+        "s_cbranch_vccz .Lfd_end_%=\n\t"                                                                            \
+        "s_mov_b32 %[st], 3\n"                                                                                      \
+        ".Lfd_end_%=:\n\t"                                                                                          \
+        "s_waitcnt lgkmcnt(0)"                                                                                      \
+        : "+{v[48:49]}"(wv), "={v[50:51]}"(r1), "={v[52:53]}"(r2), "={v[54:55]}"(r3), "={v[56:57]}"(ts_),           \
+          "={v[58:59]}"(ta_), "+{v60}"(mxS), "={v61}"(tn_), "={v62}"(tl_), [m] "=&s"(msk_), [st] "=&s"(st),         \
+          "+{s67}"(pwi), "+{s[64:65]}"(zS), [off] "+s"(off), [pf] "=&s"(pf_), [pg] "=&s"(pg_), [ph] "=&s"(ph_)      \
+        : [se] "v"(sE2), [dc] "v"(dcs), [esh] "v"(Esh), [imdc] "v"(imdc), [lim8] "s"(lim8), "{s[68:69]}"(zpb),      \
+          [flr] "s"(kFloorBits)                                                                                     \
+        : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50",  \
+          "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s66", "vcc",  \
+          "scc")
+
 // ------------------------------------------------------------------------------------------------
 // LAv2, T = HDRFloat<float>: tuned perturbation loop.  Same prologue (AT + LA stages) and the same results, bit for
 // bit, as k_lav2_hdr32; the perturbation loop (>99.9 % of the executed work at View 5) is restructured around what
@@ -975,6 +1041,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
             const float4 *__restrict__ zs = A.zs;
             FS_CYC(cyc_t0 = __builtin_readcyclecounter());
             uint32_t sc_skip = 0, sc_penalty = 0; // (wave-uniform) back-off of the scaled-run attempts, see below
+            bool fl_per_trip = false; // (wave-uniform) the next run attempt uses the per-trip floor verdicts (FS_FAST_LOOP_FD)
             while (running) {
                 // ---- run of "scaled" quiet steps.  HDRFloat addition and multiplication are the correctly rounded binary32
                 // operations on the represented values (an exponent gap >= 120 drops an addend that is far below half an
@@ -1099,6 +1166,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                         uint32_t c = 0;
                         bool failed;
                         FS_CYC(cyc_t2 = __builtin_readcyclecounter());
+                        bool fl_redo = false;
                         const uint32_t ref_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)ref);
                         if (__builtin_amdgcn_ballot_w64(ref != ref_u) == 0ull) {
                             // Every lane of the wave reads the same orbit entries (the usual case: neighbouring pixels
@@ -1247,12 +1315,30 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                                     int st, ebo, pf_, pg_, ph_;
                                     const uint32_t c_in = cs;
                                     uint32_t off = cs << 4;
-                                    FS_FAST_LOOP_FL(FS_PF_NONE);
+#if FS_FL_EVERY && !defined(FS_VERIFY_FLOOR)
+                                    if (!fl_per_trip) {
+                                        {
+                                            FS_FAST_LOOP_FD(FS_PF_NONE, FS_BT_DC_MAX, FS_BT_DC_ADD, FS_BT_H_CMP, FS_BT_H_OR);
+                                        }
+                                        ebo = 0;
+                                    } else
+#endif
+                                    {
+                                        FS_FAST_LOOP_FL(FS_PF_NONE);
+                                    }
 #ifdef FS_VERIFY_FLOOR
                                     if (kStats && xacc_ != 0ull)
                                         c_blk_violation++;
 #endif
                                     st = __builtin_amdgcn_readfirstlane(st); // (asm results count as divergent)
+                                    zS = (f2){__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(zS.x))),
+                                              __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(zS.y)))};
+                                    if (st == 3) {
+                                        // a state of this invocation fell below the floor (deferred verdict): nothing of the run
+                                        // has been committed -- the same run again, with the per-trip verdicts
+                                        fl_redo = true;
+                                        break;
+                                    }
                                     cs = (uint32_t)__builtin_amdgcn_readfirstlane((int)off) >> 4;
                                     pwi = __builtin_amdgcn_readfirstlane(pwi);
                                     if (kStats)
@@ -1389,6 +1475,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
 #undef FS_TRIP_FAILED_NB
 #undef FS_SCALED_STEP
                         FS_CYC(cyc_body += __builtin_readcyclecounter() - cyc_t2);
+                        if (fl_redo) {
+                            fl_per_trip = true;
+                            continue;
+                        }
+                        fl_per_trip = false;
                         // back to the reduced form: the larger part's exponent moves into dze (exact)
                         if (c != 0u) {
                             const float mxw = __builtin_fmaxf(__builtin_fabsf(wO.x), __builtin_fabsf(wO.y));
