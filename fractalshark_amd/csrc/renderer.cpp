@@ -74,6 +74,7 @@ struct fs_renderer {
         }
     } lav2_cost_key{};
     bool last_frame_ordered = false; // the last fs_render_lav2 launch used a recorded order (fs_last_frame_tile_ordered)
+    bool last_launch_wide = false;   // the last render launched a 64-bit counting kernel: those carry no step counters
     bool stats_on = false;
     int variant = FS_VARIANT_TUNED;
 
@@ -658,6 +659,7 @@ template <class F> static void fill_lav2(fs_renderer *r, FsLav2ArgsT<F> &A, cons
     A.n_iterations = (uint32_t)n_iterations;
     A.n_iterations_hi = (uint32_t)(n_iterations >> 32);
         A.frame.wide |= A.n_iterations_hi != 0u ? 1u : 0u;
+        r->last_launch_wide = A.frame.wide != 0u;
     A.la_valid = r->la_ok ? r->la_valid : 0;
     A.use_at = r->use_at;
     A.parity = (parity == FS_PARITY_CPU_GPUSTAGE) ? FS_PARITY_GPUSTAGE : FS_PARITY_LITERAL;
@@ -1755,6 +1757,7 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
             FsLav2ArgsT<float> A;
             fill_lav2<float>(r, A, coords, n_iterations, parity);
             A.frame.wide |= wide_pos ? 1u : 0u;
+            r->last_launch_wide = A.frame.wide != 0u;
             A.at = r->at;
             A.wp = r->wp_raw, A.n_wp = (uint32_t)r->orbit_size;
             A.cxLow = r->c_low32[0], A.cyLow = r->c_low32[1];
@@ -1763,6 +1766,7 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
             FsLav2ArgsT<double> A;
             fill_lav2<double>(r, A, coords, n_iterations, parity);
             A.frame.wide |= wide_pos ? 1u : 0u;
+            r->last_launch_wide = A.frame.wide != 0u;
             A.at = r->at64;
             A.wp = r->wp_raw, A.n_wp = (uint32_t)r->orbit_size;
             A.cxLow = r->c_low64[0], A.cyLow = r->c_low64[1];
@@ -1816,6 +1820,7 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
         A.n_iterations = (uint32_t)n_iterations;
         A.n_iterations_hi = (uint32_t)(n_iterations >> 32);
         A.frame.wide |= A.n_iterations_hi != 0u ? 1u : 0u;
+        r->last_launch_wide = A.frame.wide != 0u;
         A.la_valid = (r->la_ok && r->la_type == type_tag) ? r->la_valid : 0;
         A.use_at = r->use_at;
         TimedLaunch t(r);
@@ -1844,6 +1849,7 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
         A.n_iterations = (uint32_t)n_iterations;
         A.n_iterations_hi = (uint32_t)(n_iterations >> 32);
         A.frame.wide |= A.n_iterations_hi != 0u ? 1u : 0u;
+        r->last_launch_wide = A.frame.wide != 0u;
         A.la_valid = (r->la_ok && r->la_type == type_tag) ? r->la_valid : 0;
         A.use_at = r->use_at;
         TimedLaunch t(r);
@@ -1961,6 +1967,7 @@ uint32_t fs_render_bla(fs_renderer *r, int type_tag, const void *coords, uint64_
         A.n_iterations = (uint32_t)n_iterations;
         A.n_iterations_hi = (uint32_t)(n_iterations >> 32);
         A.frame.wide |= A.n_iterations_hi != 0u ? 1u : 0u;
+        r->last_launch_wide = A.frame.wide != 0u;
         A.lm2 = r->bla_lm2;
         TimedLaunch t(r);
         fsk_perturb_bla_f64(A, use_bla, r->stats_on, r->compute);
@@ -1980,6 +1987,7 @@ uint32_t fs_render_bla(fs_renderer *r, int type_tag, const void *coords, uint64_
         A.n_iterations = (uint32_t)n_iterations;
         A.n_iterations_hi = (uint32_t)(n_iterations >> 32);
         A.frame.wide |= A.n_iterations_hi != 0u ? 1u : 0u;
+        r->last_launch_wide = A.frame.wide != 0u;
         A.lm2 = r->bla_lm2;
         if (use_bla && r->bla_native_stale)
             if (uint32_t e = bla_make_native(r, r->bla_n_levels))
@@ -2043,6 +2051,7 @@ uint32_t fs_render_bla(fs_renderer *r, int type_tag, const void *coords, uint64_
         A.n_iterations = (uint32_t)n_iterations;
         A.n_iterations_hi = (uint32_t)(n_iterations >> 32);
         A.frame.wide |= A.n_iterations_hi != 0u ? 1u : 0u;
+        r->last_launch_wide = A.frame.wide != 0u;
         A.lm2 = r->bla_lm2;
         TimedLaunch t(r);
         fsk_perturb_scalar_hdr64(A, use_bla, r->stats_on, r->variant, r->compute);
@@ -2082,6 +2091,7 @@ uint32_t fs_render_direct(fs_renderer *r, int type_tag, const void *coords, uint
         A.n_iterations = (uint32_t)n_iterations;
         A.n_iterations_hi = (uint32_t)(n_iterations >> 32);
         A.frame.wide |= A.n_iterations_hi != 0u ? 1u : 0u;
+        r->last_launch_wide = A.frame.wide != 0u;
         TimedLaunch t(r);
         fsk_direct_f64(A, c[2], c[0], r->stats_on, r->compute);
     } else if (type_tag == FS_T_HDR32) {
@@ -2097,6 +2107,7 @@ uint32_t fs_render_direct(fs_renderer *r, int type_tag, const void *coords, uint
         A.n_iterations = (uint32_t)n_iterations;
         A.n_iterations_hi = (uint32_t)(n_iterations >> 32);
         A.frame.wide |= A.n_iterations_hi != 0u ? 1u : 0u;
+        r->last_launch_wide = A.frame.wide != 0u;
         TimedLaunch t(r);
         fsk_direct_hdr32(A, fs::hreal32{c[2].m, c[2].e}, fs::hreal32{c[0].m, c[0].e}, r->stats_on, r->compute);
     } else {
@@ -2112,6 +2123,7 @@ uint32_t fs_render_direct(fs_renderer *r, int type_tag, const void *coords, uint
         A.n_iterations = (uint32_t)n_iterations;
         A.n_iterations_hi = (uint32_t)(n_iterations >> 32);
         A.frame.wide |= A.n_iterations_hi != 0u ? 1u : 0u;
+        r->last_launch_wide = A.frame.wide != 0u;
         TimedLaunch t(r);
         fsk_direct_hdr64(A, fs::hreal64{c[2].m, c[2].e}, fs::hreal64{c[0].m, c[0].e}, r->stats_on, r->compute);
     }
@@ -2181,6 +2193,7 @@ uint32_t fs_render_scaled(fs_renderer *r, int type_tag, const void *coords, uint
         A.n_iterations = (uint32_t)n_iterations;
         A.n_iterations_hi = (uint32_t)(n_iterations >> 32);
         A.frame.wide |= A.n_iterations_hi != 0u ? 1u : 0u;
+        r->last_launch_wide = A.frame.wide != 0u;
         A.w2threshold = w2threshold;
         TimedLaunch t(r);
         fsk_scaled_f64(A, r->stats_on, r->variant & FS_VARIANT_BASE_MASK, r->compute);
@@ -2198,6 +2211,7 @@ uint32_t fs_render_scaled(fs_renderer *r, int type_tag, const void *coords, uint
     A.n_iterations = (uint32_t)n_iterations;
     A.n_iterations_hi = (uint32_t)(n_iterations >> 32);
         A.frame.wide |= A.n_iterations_hi != 0u ? 1u : 0u;
+        r->last_launch_wide = A.frame.wide != 0u;
     A.w2threshold = w2threshold;
     TimedLaunch t(r);
     fsk_scaled_hdr32(A, r->stats_on, r->variant & FS_VARIANT_BASE_MASK, r->compute);
@@ -2226,6 +2240,7 @@ uint32_t fs_render_direct_lp(fs_renderer *r, int type_tag, const void *coords, u
     A.n_iterations = (uint32_t)n_iterations;
     A.n_iterations_hi = (uint32_t)(n_iterations >> 32);
         A.frame.wide |= A.n_iterations_hi != 0u ? 1u : 0u;
+        r->last_launch_wide = A.frame.wide != 0u;
     if (type_tag == FS_T_F32)
         memcpy(A.c32, coords, 4 * sizeof(float));
     else if (type_tag == FS_T_2X32)
@@ -2537,6 +2552,9 @@ uint32_t fs_read_step_count(fs_renderer *r, uint64_t counts[8])
         return e;
     if (!r->stats)
         return FS_ERR_6;
+    // the 64-bit counting instantiations are not built with the step counters: zeros would read as "no work was done"
+    if (r->last_launch_wide)
+        return FS_ERR_UNSUPPORTED;
     // ordered behind the kernels of the (non-blocking) compute stream, which the null stream is not
     FS_TRY(hipMemcpyAsync(counts, r->stats, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, r->compute));
     FS_TRY(hipStreamSynchronize(r->compute));

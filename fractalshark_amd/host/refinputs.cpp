@@ -251,6 +251,11 @@ fsh_view *finish_view(std::unique_ptr<fsh_view> vw, bool from_box)
 namespace {
 
 constexpr uint64_t kImMagic = 0x000A0D56504D49FFull, kSharksMagic = 0x536861726b733a29ull;
+// precision a location file may ask for (bits): the view must still be expressible with int32 exponents, and GMP aborts
+// (it does not throw) when asked for more than it can allocate
+constexpr uint64_t kMaxImPrecisionBits = 1ull << 26;
+// orbit entries a file may announce (32 bytes each while it is expanded on the host: 16 GiB)
+constexpr uint64_t kMaxImOrbitEntries = 1ull << 29;
 
 // exp_bytes = sizeof(long) of the build that wrote the file: 4 for the reference's Windows (MSVC) build and Imagina itself,
 // 8 for the reference built on Linux.  Limbs are 64-bit in both (MPIR x64 / GMP), so only the field width differs.
@@ -378,6 +383,10 @@ extern "C" fsh_view *fsh_view_load_im(const char *path, uint32_t width, uint32_t
     if (fread(header, 8, 4, f) == 4 && (header[0] == kImMagic || header[0] == kSharksMagic) &&
         fseek(f, (long)header[2], SEEK_SET) == 0 && fread(&hh, sizeof(hh), 1, f) == 1 && fread(&limit, 8, 1, f) == 1) {
         // precision = -min(0, halfH.exp) + AuthoritativeMinExtraPrecisionInBits (RefOrbitCalc.cpp:3458-3460)
+        if (hh.exp < -(int64_t)kMaxImPrecisionBits) {
+            fclose(f);
+            return nullptr;
+        }
         const uint64_t precision = (uint64_t)(-std::min<int64_t>(0, hh.exp)) + 120u;
         mpf_set_default_prec(precision);
         Mp X(precision, 0), Y(precision, 0), H(precision, 0);
@@ -1031,6 +1040,10 @@ bool load_im_orbit(FILE *f, uint64_t reference_offset, OrbitT<F> &ob, uint64_t f
     // the iteration limit it was computed for (a crafted RefIt would otherwise size the vectors below)
     if (ref_it >= (1ull << 32) || (file_iteration_limit != 0 && ref_it > file_iteration_limit))
         return false;
+    // ... nor longer than this host can expand (the iteration limit comes from the same file): DecompressMax sizes its vectors
+    // for ref_it entries of 2 x 16 bytes, and with overcommit a crafted length ends in an OOM kill rather than a bad_alloc
+    if (ref_it > kMaxImOrbitEntries)
+        return false;
     const bool periodic = la[34] != 0;
     MaxWaypoints<F> w;
     auto exp_fits = [](const ImHR &h) { return h.exp >= INT32_MIN && h.exp <= INT32_MAX; };
@@ -1109,6 +1122,10 @@ static fsh_orbit *orbit_load_im(FILE *f, uint64_t *iteration_limit)
     std::unique_ptr<fsh_orbit> out;
     if (fread(header, 8, 4, f) == 4 && (header[0] == kImMagic || header[0] == kSharksMagic) && header[3] != 0 &&
         fseek(f, (long)header[2], SEEK_SET) == 0 && fread(&hh, sizeof(hh), 1, f) == 1 && fread(&limit, 8, 1, f) == 1) {
+        // (a file is untrusted input: GMP aborts on an absurd precision, it does not throw -- the deepest view the renderer's
+        // int32 exponents can express needs 2^31 bits)
+        if (hh.exp < -(int64_t)kMaxImPrecisionBits)
+            return nullptr;
         const uint64_t precision = (uint64_t)(-std::min<int64_t>(0, hh.exp)) + 120u;
         mpf_set_default_prec(precision);
         Mp X(precision, 0), Y(precision, 0);

