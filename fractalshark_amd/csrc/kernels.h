@@ -210,6 +210,11 @@ struct FsLav2Args2x32 {
     uint32_t n_iterations_hi; // high word of the cap: non-zero selects the 64-bit counting instantiation
     int la_valid;
     int use_at;
+    // SimpleCompression orbit kept compressed (fs_set_compressed_orbit_mode 1): the waypoints (fs_orbit_2x32_rc), their
+    // number and the decompressor's constant c; `orbit` is NULL then and every entry comes from a per-pixel cursor
+    const fs_orbit_2x32_rc *wp;
+    uint32_t n_wp;
+    fs_real_2x32 cxLow, cyLow;
 };
 
 // Non-HDR LAv2 (Gpu1x32 / Gpu1x64 / Gpu2x32 PerturbedLAv2*): records in the reference layouts of the selected type
@@ -229,6 +234,11 @@ struct FsLav2ArgsPlain {
     uint32_t n_iterations_hi;
     int la_valid;
     int use_at;
+    // SimpleCompression orbit kept compressed: waypoints in the type's reference layout (fs_orbit_f32_rc / _f64_rc / _p2x32_rc),
+    // their number, the decompressor's constant c (float / double / fs_real_p2x32, 8 bytes each at most); `orbit` is NULL then
+    const void *wp;
+    uint32_t n_wp;
+    alignas(8) uint8_t c_low[2][8];
 };
 
 // Scaled perturbation (GpuHDRx32PerturbedScaled): the HDRFloat<float> orbit with `bad` flags and its binary32 copy,

@@ -41,6 +41,55 @@ __device__ __forceinline__ HR orbit_y(const fs_orbit_2x32 *__restrict__ o, uint3
     return HR{df32(o[i].y_head, o[i].y_tail), o[i].ey};
 }
 
+// Sequential access to a SimpleCompression orbit that stays compressed in HBM (fs_set_compressed_orbit_mode 1): the
+// HDRFloat<CudaDblflt> twin of SeqOrbit in kernels.hip (Perturb.cuh:160-326); same operations in the same order as
+// k_decompress_hdr2x32, which expands the same waypoints once per upload.
+struct Seq2x32 {
+    const fs_orbit_2x32_rc *__restrict__ wp;
+    uint32_t n_wp;
+    HR cx, cy;
+    uint32_t idx, next, next_index;
+    HR zx, zy;
+    __device__ __forceinline__ uint32_t index_of(uint32_t k) const { return (uint32_t)(wp[k].index_and_rebase & 0x7FFFFFFFFFFFFFFFull); }
+    __device__ __forceinline__ void load(uint32_t k)
+    {
+        zx = HR{df32(wp[k].x_head, wp[k].x_tail), wp[k].ex};
+        zy = HR{df32(wp[k].y_head, wp[k].y_tail), wp[k].ey};
+    }
+    __device__ __forceinline__ void step()
+    {
+        idx++;
+        if (idx == next_index) {
+            load(next);
+            next++;
+            next_index = next < n_wp ? index_of(next) : 0xFFFFFFFFu;
+        } else {
+            const HR zx_old = zx;
+            zx = hr_add(hr_sub(hr_mul(zx, zx), hr_mul(zy, zy)), cx);
+            hr_reduce(zx);
+            zy = hr_add(hr_mul(hr_mul(hr2_from_float(2.0f), zx_old), zy), cy);
+            hr_reduce(zy);
+        }
+    }
+    __device__ __forceinline__ void seek(uint32_t i)
+    {
+        uint32_t lo = 0, hi = n_wp;
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (index_of(mid) <= i)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        load(lo);
+        idx = index_of(lo);
+        next = lo + 1u;
+        next_index = next < n_wp ? index_of(next) : 0xFFFFFFFFu;
+        while (idx < i)
+            step();
+    }
+};
+
 // `T(X)` for an int, HDRFloat.h:293-363.
 __device__ __forceinline__ HR hr2_from_int(int v) { return hr2_from_float((float)v); }
 
@@ -90,7 +139,8 @@ __device__ __forceinline__ HC hc_mul2_pk(HC a)
 
 // IterT: the reference's IterType for the counters (LAKernel.cuh:3): uint32_t, or uint64_t for iteration caps of 2^32 and
 // above (iterations, the cap, the AT iteration count and the i x StepLength product in 64 bits).
-template <int Mode, bool kStats, class IterT = uint32_t>
+// kSeq: the orbit stays compressed (A.wp): every entry comes from a Seq2x32 cursor.
+template <int Mode, bool kStats, class IterT = uint32_t, bool kSeq = false>
 __global__ void __launch_bounds__(256) k_lav2_2x32(FsLav2Args2x32 A)
 {
     uint32_t X, L;
@@ -245,7 +295,17 @@ __global__ void __launch_bounds__(256) k_lav2_2x32(FsLav2Args2x32 A)
             const fs_orbit_2x32 *__restrict__ orb = A.orbit;
             const uint32_t MaxRef = A.orbit_count - 1;
             HR dX = hc_re(DeltaSubN), dY = hc_im(DeltaSubN);
-            HR zx = orbit_x(orb, RefIteration), zy = orbit_y(orb, RefIteration);
+            Seq2x32 seq;
+            HR zx, zy;
+            if constexpr (kSeq) {
+                seq.wp = A.wp;
+                seq.n_wp = A.n_wp;
+                seq.cx = ldr(A.cxLow), seq.cy = ldr(A.cyLow);
+                seq.seek(RefIteration);
+                zx = seq.zx, zy = seq.zy;
+            } else {
+                zx = orbit_x(orb, RefIteration), zy = orbit_y(orb, RefIteration);
+            }
             for (;;) {
                 const HR sumY = hr_add(hr_mul2(zy), dY); // tempSum1
                 const HR sumX = hr_add(hr_mul2(zx), dX); // tempSum2
@@ -259,8 +319,13 @@ __global__ void __launch_bounds__(256) k_lav2_2x32(FsLav2Args2x32 A)
                 dY = nY;
                 if (kStats)
                     c_pt++;
-                zx = orbit_x(orb, RefIteration);
-                zy = orbit_y(orb, RefIteration);
+                if constexpr (kSeq) {
+                    seq.step();
+                    zx = seq.zx, zy = seq.zy;
+                } else {
+                    zx = orbit_x(orb, RefIteration);
+                    zy = orbit_y(orb, RefIteration);
+                }
                 const HR tX = hr_add(zx, dX);
                 const HR tY = hr_add(zy, dY);
                 const HR normSquared = hr_reduced(hr_add(hr_square(tX), hr_square(tY)));
@@ -270,8 +335,13 @@ __global__ void __launch_bounds__(256) k_lav2_2x32(FsLav2Args2x32 A)
                         dX = tX;
                         dY = tY;
                         RefIteration = 0;
-                        zx = orbit_x(orb, 0);
-                        zy = orbit_y(orb, 0);
+                        if constexpr (kSeq) {
+                            seq.seek(0); // a new SeqWorkspace at the start of the orbit
+                            zx = seq.zx, zy = seq.zy;
+                        } else {
+                            zx = orbit_x(orb, 0);
+                            zy = orbit_y(orb, 0);
+                        }
                     }
                     ++iter;
                 } else {
@@ -293,7 +363,11 @@ void fsk_lav2_2x32(const FsLav2Args2x32 &A, int mode, bool stats, hipStream_t s)
     const dim3 g((A.frame.width + 31) / 32, (A.frame.local_rows + 7) / 8); // tile_pixel()
 #define FS_LAUNCH(M)                                                                                                    \
     do {                                                                                                                \
-        if (A.frame.wide != 0u)                                                                                    \
+        if (A.wp != nullptr && A.frame.wide != 0u)                                                                      \
+            hipLaunchKernelGGL((k_lav2_2x32<M, false, uint64_t, true>), g, b, 0, s, A);                                 \
+        else if (A.wp != nullptr)                                                                                       \
+            hipLaunchKernelGGL((k_lav2_2x32<M, false, uint32_t, true>), g, b, 0, s, A);                                 \
+        else if (A.frame.wide != 0u)                                                                                    \
             hipLaunchKernelGGL((k_lav2_2x32<M, false, uint64_t>), g, b, 0, s, A);                                       \
         else if (stats)                                                                                                 \
             hipLaunchKernelGGL((k_lav2_2x32<M, true>), g, b, 0, s, A);                                                  \

@@ -101,6 +101,74 @@ __device__ __forceinline__ cx<df32> ldz(const fs_orbit_p2x32 *__restrict__ o, ui
     return cx<df32>{df32(v.x, v.y), df32(v.z, v.w)};
 }
 
+// Sequential access to a SimpleCompression orbit that stays compressed in HBM (fs_set_compressed_orbit_mode 1), T = float /
+// double / CudaDblflt: the plain-type twin of SeqOrbit in kernels.hip (GPUPerturbSingleResults::SeqWorkspace / GetIterSeq /
+// BinarySearch, Perturb.cuh:160-326).  seek() starts at the last waypoint at or before the index and iterates z = z^2 + c
+// forward in T arithmetic, step() moves one index on: the next waypoint when its index comes up, one iteration otherwise --
+// the operations, in the order, of k_decompress_plain / k_decompress_p2x32, which expand the same waypoints once per upload.
+template <class T> struct PlainRc;
+template <> struct PlainRc<float> {
+    using Rc = fs_orbit_f32_rc;
+    static __device__ __forceinline__ void load(const Rc &w, float &x, float &y) { x = w.x, y = w.y; }
+    static __device__ __forceinline__ float low(const uint8_t *p) { return *reinterpret_cast<const float *>(p); }
+};
+template <> struct PlainRc<double> {
+    using Rc = fs_orbit_f64_rc;
+    static __device__ __forceinline__ void load(const Rc &w, double &x, double &y) { x = w.x, y = w.y; }
+    static __device__ __forceinline__ double low(const uint8_t *p) { return *reinterpret_cast<const double *>(p); }
+};
+template <> struct PlainRc<df32> {
+    using Rc = fs_orbit_p2x32_rc;
+    static __device__ __forceinline__ void load(const Rc &w, df32 &x, df32 &y)
+    {
+        x = df32(w.x_head, w.x_tail), y = df32(w.y_head, w.y_tail);
+    }
+    static __device__ __forceinline__ df32 low(const uint8_t *p)
+    {
+        const fs_real_p2x32 *r = reinterpret_cast<const fs_real_p2x32 *>(p);
+        return df32(r->head, r->tail);
+    }
+};
+
+template <class T> struct SeqPlain {
+    const typename PlainRc<T>::Rc *__restrict__ wp;
+    uint32_t n_wp;
+    T cx, cy;
+    uint32_t idx, next, next_index;
+    T zx, zy;
+    __device__ __forceinline__ uint32_t index_of(uint32_t k) const { return (uint32_t)(wp[k].index_and_rebase & 0x7FFFFFFFFFFFFFFFull); }
+    __device__ __forceinline__ void step()
+    {
+        idx++;
+        if (idx == next_index) {
+            PlainRc<T>::load(wp[next], zx, zy);
+            next++;
+            next_index = next < n_wp ? index_of(next) : 0xFFFFFFFFu;
+        } else {
+            const T zx_old = zx;
+            zx = zx * zx - zy * zy + cx;
+            zy = T(2.0f) * zx_old * zy + cy;
+        }
+    }
+    __device__ __forceinline__ void seek(uint32_t i)
+    {
+        uint32_t lo = 0, hi = n_wp;
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (index_of(mid) <= i)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        PlainRc<T>::load(wp[lo], zx, zy);
+        idx = index_of(lo);
+        next = lo + 1u;
+        next_index = next < n_wp ? index_of(next) : 0xFFFFFFFFu;
+        while (idx < i)
+            step();
+    }
+};
+
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 // The perturbation loop of LAKernel.cuh:133-235 for T = float, on packed binary32 pairs.  Same IEEE operations as the
@@ -162,7 +230,8 @@ __device__ __forceinline__ void perturb_f32(const fs_orbit_f32 *__restrict__ orb
 }
 
 // IterT: the reference's IterType for the counters (LAKernel.cuh:3): uint32_t, or uint64_t for caps of 2^32 and above.
-template <class T, int Mode, bool kStats, class IterT = uint32_t>
+// kSeq: the orbit stays compressed (A.wp): every entry comes from a SeqPlain cursor (the generic loop for all three types).
+template <class T, int Mode, bool kStats, class IterT = uint32_t, bool kSeq = false>
 __global__ void __launch_bounds__(256) k_lav2_plain(FsLav2ArgsPlain A)
 {
     using P = Plain<T>;
@@ -250,20 +319,38 @@ __global__ void __launch_bounds__(256) k_lav2_plain(FsLav2ArgsPlain A)
         if (Mode != FS_MODE_LAO) {
             // :133-235.  perturbLoop(maxRefIteration) at :254-276 reads the block's previous results, which are zero on
             // the cleared buffer every caller passes (Fractal.cpp:2822), so only perturbLoop(n_iterations) runs.
-            if constexpr (std::is_same<T, float>::value) {
+            if constexpr (std::is_same<T, float>::value && !kSeq) {
                 perturb_f32<kStats, IterT>(orb, A.orbit_count, f2{DeltaSubN.re, DeltaSubN.im}, f2{DeltaSub0X, DeltaSub0Y},
                                     RefIteration, iter, n_iterations, c_pt);
             } else {
             const uint32_t MaxRef = A.orbit_count - 1;
             const T TwoFiftySix = P::from_int(256);
             T dX = DeltaSubN.re, dY = DeltaSubN.im;
-            const cx<T> z0 = ldz(orb, 0);
-            cx<T> z = ldz(orb, RefIteration);
+            SeqPlain<T> seq;
+            cx<T> z0, z;
+            if constexpr (kSeq) {
+                seq.wp = reinterpret_cast<const typename PlainRc<T>::Rc *>(A.wp);
+                seq.n_wp = A.n_wp;
+                seq.cx = PlainRc<T>::low(A.c_low[0]), seq.cy = PlainRc<T>::low(A.c_low[1]);
+                seq.seek(0);
+                z0 = cx<T>{seq.zx, seq.zy};
+                if (RefIteration != 0)
+                    seq.seek(RefIteration);
+                z = cx<T>{seq.zx, seq.zy};
+            } else {
+                z0 = ldz(orb, 0);
+                z = ldz(orb, RefIteration);
+            }
             for (;;) {
                 const T sumY = twice_plus(z.im, dY, Two); // tempSum1 = zy * T{2} + dY
                 const T sumX = twice_plus(z.re, dX, Two); // tempSum2
                 ++RefIteration;
-                z = ldz(orb, RefIteration); // GetIterSeq: the entry this step ends on, requested before the arithmetic
+                if constexpr (kSeq) {
+                    seq.step();
+                    z = cx<T>{seq.zx, seq.zy};
+                } else {
+                    z = ldz(orb, RefIteration); // GetIterSeq: the entry this step ends on, requested before the arithmetic
+                }
                 const T nX = dX * sumX - dY * sumY + DeltaSub0X;
                 const T nY = dX * sumY + dY * sumX + DeltaSub0Y;
                 if (kStats)
@@ -286,6 +373,10 @@ __global__ void __launch_bounds__(256) k_lav2_plain(FsLav2ArgsPlain A)
                     RefIteration = rebase ? 0u : RefIteration;
                     z.re = rebase ? z0.re : z.re;
                     z.im = rebase ? z0.im : z.im;
+                    if constexpr (kSeq) {
+                        if (rebase)
+                            seq.seek(0); // a new SeqWorkspace at the start of the orbit
+                    }
                 }
                 ++iter;
             }
@@ -303,7 +394,11 @@ template <class T> void launch(const FsLav2ArgsPlain &A, int mode, bool stats, h
     const dim3 g((A.frame.width + 31) / 32, (A.frame.local_rows + 7) / 8); // tile_pixel()
 #define FS_LAUNCH(M)                                                                                                    \
     do {                                                                                                                \
-        if (A.frame.wide != 0u)                                                                                    \
+        if (A.wp != nullptr && A.frame.wide != 0u)                                                                      \
+            hipLaunchKernelGGL((k_lav2_plain<T, M, false, uint64_t, true>), g, b, 0, s, A);                             \
+        else if (A.wp != nullptr)                                                                                       \
+            hipLaunchKernelGGL((k_lav2_plain<T, M, false, uint32_t, true>), g, b, 0, s, A);                             \
+        else if (A.frame.wide != 0u)                                                                                    \
             hipLaunchKernelGGL((k_lav2_plain<T, M, false, uint64_t>), g, b, 0, s, A);                                   \
         else if (stats)                                                                                                 \
             hipLaunchKernelGGL((k_lav2_plain<T, M, true>), g, b, 0, s, A);                                              \

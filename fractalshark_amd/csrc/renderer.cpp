@@ -108,6 +108,7 @@ struct fs_renderer {
     void *wp_raw = nullptr; // fs_orbit_hdr32_rc[] / fs_orbit_hdr64_rc[]
     fs_real_hdr32 c_low32[2] = {};
     fs_real_hdr64 c_low64[2] = {};
+    alignas(8) uint8_t c_low_plain[2][16] = {}; // ... of a float / double / CudaDblflt / HDRFloat<CudaDblflt> orbit (as uploaded)
 
     // LA table
     uint64_t la_gen = 0;
@@ -1056,7 +1057,7 @@ uint32_t fs_upload_orbit_compressed(fs_renderer *r, uint64_t generation, int typ
         return FS_ERR_UNSUPPORTED;
     if (!r->compute)
         return FS_ERR_6;
-    const bool want_seq = r->compressed_mode == 1 && (type_tag == FS_T_HDR32 || type_tag == FS_T_HDR64);
+    const bool want_seq = r->compressed_mode == 1;
     // an EXPANDED orbit must fit the 32-bit positions of the kernels that read it (and the device: 2^32 entries are 64 GiB
     // and more); a waypoint-resident one may be any length -- its positions are 64-bit in the kernel that walks it
     if (!want_seq && uncompressed_size > 0xFFFFFFFFull)
@@ -1088,6 +1089,28 @@ uint32_t fs_upload_orbit_compressed(fs_renderer *r, uint64_t generation, int typ
         }
         r->orbit_ok = false;
         drop_seq(r);
+        if (want_seq) {
+            // keep the waypoints, nothing else: k_lav2_plain / k_lav2_2x32 walk them with a cursor per pixel (same values as
+            // the expansion below, entry for entry)
+            if (compressed_size == 0 || compressed_size > 0xFFFFFFFFull || uncompressed_size > 0xFFFFFFFFull)
+                return FS_ERR_UNSUPPORTED; // (these kernels keep 32-bit positions)
+            const size_t low_b = type_tag == FS_T_F32 ? sizeof(float) : (type_tag == FS_T_HDR2X32 ? sizeof(fs_real_2x32) : 8u);
+            FS_TRY(r_alloc(r, &r->wp_raw, compressed_size * in_b, kInput));
+            FS_TRY(hipMemcpyAsync(r->wp_raw, entries, compressed_size * in_b, hipMemcpyDefault, r->compute));
+            FS_TRY(hipStreamSynchronize(r->compute));
+            memset(r->c_low_plain, 0, sizeof(r->c_low_plain));
+            memcpy(r->c_low_plain[0], orbit_x_low, low_b);
+            memcpy(r->c_low_plain[1], orbit_y_low, low_b);
+            r->orbit_seq = true;
+            r->orbit_size = compressed_size;
+            r->orbit_uncompressed = uncompressed_size;
+            r->orbit_period = period_maybe_zero;
+            r->orbit_gen = generation;
+            r->orbit_type = type_tag;
+            r->orbit_ok = true;
+            orbit_changed(r);
+            return 0;
+        }
         void *raw = nullptr;
         FS_TRY(r_alloc(r, &raw, compressed_size * in_b, kInput));
         hipError_t err = r_alloc(r, slot, (uncompressed_size + 1) * out_b, kInput);
@@ -1740,7 +1763,7 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
     const bool wide = n_iterations > 0xFFFFFFFFull || (r->variant & FS_VARIANT_FLAG_WIDE) != 0;
     if (!r->orbit_ok || r->orbit_type != type_tag)
         return FS_ERR_6; // GPU_Render.cu:1015-1022
-    if (r->orbit_seq) {
+    if (r->orbit_seq && (type_tag == FS_T_HDR32 || type_tag == FS_T_HDR64)) {
         // the orbit is resident as waypoints only (fs_set_compressed_orbit_mode 1): the literal kernel with a sequential
         // decompression cursor per pixel.  Perturbation-only with CPU parity has its twin in the scalar kernel, which reads
         // an expanded orbit: not served in this mode.
@@ -1823,6 +1846,13 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
         r->last_launch_wide = A.frame.wide != 0u;
         A.la_valid = (r->la_ok && r->la_type == type_tag) ? r->la_valid : 0;
         A.use_at = r->use_at;
+        if (r->orbit_seq) { // waypoint-resident orbit: a cursor per pixel (k_lav2_plain<.., kSeq>)
+            A.orbit = nullptr;
+            A.wp = r->wp_raw;
+            A.n_wp = (uint32_t)r->orbit_size;
+            memcpy(A.c_low[0], r->c_low_plain[0], 8);
+            memcpy(A.c_low[1], r->c_low_plain[1], 8);
+        }
         TimedLaunch t(r);
         fsk_lav2_plain(A, type_tag == FS_T_F32 ? 0 : (type_tag == FS_T_F64 ? 1 : 2),
                        mode == FS_LAV2_FULL ? FS_MODE_FULL : (mode == FS_LAV2_PO ? FS_MODE_PO : FS_MODE_LAO), r->stats_on,
@@ -1852,6 +1882,13 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
         r->last_launch_wide = A.frame.wide != 0u;
         A.la_valid = (r->la_ok && r->la_type == type_tag) ? r->la_valid : 0;
         A.use_at = r->use_at;
+        if (r->orbit_seq) { // waypoint-resident orbit: a cursor per pixel (k_lav2_2x32<.., kSeq>)
+            A.orbit = nullptr;
+            A.wp = (const fs_orbit_2x32_rc *)r->wp_raw;
+            A.n_wp = (uint32_t)r->orbit_size;
+            memcpy(&A.cxLow, r->c_low_plain[0], sizeof(fs_real_2x32));
+            memcpy(&A.cyLow, r->c_low_plain[1], sizeof(fs_real_2x32));
+        }
         TimedLaunch t(r);
         fsk_lav2_2x32(A, mode == FS_LAV2_FULL ? FS_MODE_FULL : (mode == FS_LAV2_PO ? FS_MODE_PO : FS_MODE_LAO),
                       r->stats_on, r->compute);
@@ -2412,8 +2449,16 @@ uint64_t fs_orbit_device_bytes(const fs_renderer *r)
     if (!r->orbit_ok)
         return 0;
     const uint64_t n = r->orbit_uncompressed;
-    if (r->orbit_seq)
-        return r->orbit_size * (r->orbit_type == FS_T_HDR32 ? sizeof(fs_orbit_hdr32_rc) : sizeof(fs_orbit_hdr64_rc));
+    if (r->orbit_seq) {
+        switch (r->orbit_type) {
+            case FS_T_HDR32: return r->orbit_size * sizeof(fs_orbit_hdr32_rc);
+            case FS_T_HDR64: return r->orbit_size * sizeof(fs_orbit_hdr64_rc);
+            case FS_T_F32: return r->orbit_size * sizeof(fs_orbit_f32_rc);
+            case FS_T_F64: return r->orbit_size * sizeof(fs_orbit_f64_rc);
+            case FS_T_2X32: return r->orbit_size * sizeof(fs_orbit_p2x32_rc);
+            default: return r->orbit_size * sizeof(fs_orbit_2x32_rc);
+        }
+    }
     switch (r->orbit_type) {
         case FS_T_HDR32: // prepared entries + the two companion arrays of the tuned loops
             return (n + 2) * sizeof(float4) + (2 * (n + 2) + 16) * sizeof(float4);

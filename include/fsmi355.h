@@ -129,16 +129,17 @@ uint32_t fs_upload_orbit(fs_renderer *r, uint64_t generation, int type_tag, uint
 uint32_t fs_upload_orbit_compressed(fs_renderer *r, uint64_t generation, int type_tag, uint32_t iter_bytes,
                                     const void *entries, uint64_t compressed_size, uint64_t uncompressed_size,
                                     uint64_t period_maybe_zero, const void *orbit_x_low, const void *orbit_y_low);
-/* How fs_upload_orbit_compressed keeps an HDRFloat<float|double> orbit in HBM (set it before the upload):
+/* How fs_upload_orbit_compressed keeps an orbit in HBM (set it before the upload; all six numeric types):
  *   0 (default)  expanded once on upload into the full orbit (fastest kernels; costs uncompressed_size entries of HBM);
  *   1            only the waypoints stay resident and every pixel decompresses the orbit as it walks it, with a sequential
  *                cursor -- GPUPerturbSingleResults::SeqWorkspace / GetIterSeq / BinarySearch (Perturb.cuh:146-326), the
  *                reason the format exists: orbits too long to hold expanded.  Same orbit values bit for bit, hence the same
  *                frames.  Served by fs_render_lav2 (all modes except perturbation-only with FS_PARITY_CPU, whose twin is the
  *                scalar kernel; every iteration cap -- 2^32 and above with a uint64_t iteration buffer); fs_render_bla /
- *                fs_build_la / fs_build_bla need the expanded orbit and return FS_ERR_UNSUPPORTED.  Other numeric types are
- *                always expanded.  In this mode orbit POSITIONS are IterType-wide like the reference's (Perturb.cuh:21-23,
- *                202-203,247-271; LAInfoI.h:5-19): an orbit of 2^32 and more uncompressed entries (only its waypoints are
+ *                fs_build_la / fs_build_bla need the expanded orbit and return FS_ERR_UNSUPPORTED.  float / double / CudaDblflt /
+ *                HDRFloat<CudaDblflt> orbits are walked the same way by their LAv2 kernels (GPU_Render.cu:518-523,532-537
+ *                instantiates SimpleCompression for them too), with 32-bit positions.  For HDRFloat<float | double> orbit
+ *                POSITIONS are IterType-wide like the reference's (Perturb.cuh:21-23,202-203,247-271; LAInfoI.h:5-19): an orbit of 2^32 and more uncompressed entries (only its waypoints are
  *                resident), a period, LA step lengths / next-stage indices and an AT step length beyond 32 bits are accepted
  *                -- fs_upload_la then keeps the uint64_t records as they are -- and the kernel walks them with 64-bit
  *                positions.  (Expanded orbits are limited to 2^32 - 1 entries: FS_ERR_UNSUPPORTED above that.)

@@ -169,3 +169,60 @@ def test_la_table_with_step_lengths_beyond_32_bits_is_accepted(renderer, native_
     finally:
         rec[0] = saved
         r.set_compressed_orbit_mode(False)
+
+
+def test_waypoint_resident_mode_for_the_plain_types_and_hdr2x32(renderer, native_libs):
+    """fs_set_compressed_orbit_mode(1) for float / double / CudaDblflt / HDRFloat<CudaDblflt> (GPU_Render.cu:518-523,532-537
+    instantiates SimpleCompression for them too): only the waypoints are resident and the LAv2 kernels walk them with a cursor
+    per pixel.  Same frames as the expanding mode (whose kernels are checked against the restated CUDA kernels), all modes;
+    the resident orbit is the waypoints."""
+    from fractalshark_amd import LAV2_PO, T_2X32, T_F32, T_F64, T_HDR2X32
+    from test_plain_oracle import shallow_view
+    r = renderer
+    vs = shallow_view("1e-12")
+    w, h = 70, 37
+    try:
+        for kind, T, rc_bytes in (("f32", T_F32, 16), ("f64", T_F64, 24), ("2x32", T_2X32, 24)):
+            pin = inputs.PlainInputs(vs, kind, compression_exp=20)
+            assert pin.compressed and 1 < pin.compressed_count < pin.count
+            frames = {}
+            for seq in (False, True):
+                assert r.set_compressed_orbit_mode(seq) == 0
+                assert r.InitializeMemory(64, 36, 1, None, 0, 0, 0, False) == 0
+                assert r.InitializePerturbPlain(0, pin) == 0
+                if seq:
+                    assert r.orbit_device_bytes == pin.compressed_count * rc_bytes
+                for mode in (LAV2_FULL, LAV2_PO, LAV2_LAO):
+                    assert r.ClearMemory() == 0
+                    assert r.RenderPerturbLAv2Plain(pin, vs.num_iterations, Mode=mode) == 0
+                    out = r.new_iter_buffer()
+                    assert r.RenderCurrent(vs.num_iterations, out) == 0
+                    assert r.SyncComputeStream() == 0
+                    frames[(seq, mode)] = out
+            for mode in (LAV2_FULL, LAV2_PO, LAV2_LAO):
+                assert np.array_equal(frames[(True, mode)], frames[(False, mode)]), (kind, mode)
+            assert frames[(True, LAV2_FULL)].max() > 0
+        # HDRFloat<CudaDblflt>
+        v = inputs.View.builtin(5, 64, 36)
+        o = inputs.Orbit(v, is64=True, compression_exp=20)
+        la = inputs.LATable(o, use_small_exponents=True)
+        o2, la2 = inputs.Orbit2x32(o), inputs.LATable2x32(la)
+        tr = [(float(c["head"]), float(c["tail"]), int(c["e"])) for c in v.coords_perturb_2x32(o2)]
+        frames = {}
+        for seq in (False, True):
+            assert r.set_compressed_orbit_mode(seq) == 0
+            assert r.InitializeMemory(64, 36, 1, None, 0, 0, 0, False) == 0
+            assert r.InitializePerturb(0, o2, 0, None, la2) == 0
+            if seq:
+                assert r.orbit_device_bytes == o2.compressed_count * 32
+            for mode in (LAV2_FULL, LAV2_LAO):
+                assert r.ClearMemory() == 0
+                assert r.RenderPerturbLAv2(None, None, None, *tr, v.num_iterations, T=T_HDR2X32, Mode=mode) == 0
+                out = r.new_iter_buffer()
+                assert r.RenderCurrent(v.num_iterations, out) == 0
+                assert r.SyncComputeStream() == 0
+                frames[(seq, mode)] = out
+        for mode in (LAV2_FULL, LAV2_LAO):
+            assert np.array_equal(frames[(True, mode)], frames[(False, mode)]), mode
+    finally:
+        r.set_compressed_orbit_mode(False)
