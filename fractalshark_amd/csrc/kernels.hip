@@ -2488,11 +2488,21 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                 typedef float f4 __attribute__((ext_vector_type(4)));
                 const float4 *__restrict__ zs = A.zs;
                 const uint32_t MaxRefS = count - 1;
+                bool fl_per_trip = false; // (wave-uniform) the next run attempt uses the per-trip floor verdicts
                 for (;;) {
                     const float4 e0 = zs[RefIteration];
-                    const int E = imax(DeltaSubNX.e, DeltaSubNY.e);
-                    const f2 dzs = {__builtin_amdgcn_ldexpf(DeltaSubNX.m, imax(DeltaSubNX.e - E, -200)),
-                                    __builtin_amdgcn_ldexpf(DeltaSubNY.m, imax(DeltaSubNY.e - E, -200))};
+                    // Floor form of the acceptance tests (round 4; derivation above FS_FL_EVERY).  It is the simpler case here:
+                    // the reference's arithmetic is scalar HDRFloat -- every operand reduced, a mantissa product in [1, 4),
+                    // an aligned sum (sums have no underflow error) -- so the reference itself never loses bits to
+                    // underflow, and its "gap >= 120: addend ignored" rule acts per part, where an addend 2^120 below the
+                    // other is absorbed by the IEEE sum as well.  What is left is (u) on the scaled side: a product below
+                    // 2^-126 in the run's units.  Such a product is either absorbed by the term it is added to (>= 2^-100: the
+                    // same sum in both arithmetics) or leaves a part of the new state below 2^-72 -- under the floor.
+                    // Scale: E = larger exponent + 24 (max|w| starts at 2^-24); dzs = the state with max part in [1, 2).
+                    const int E0 = imax(DeltaSubNX.e, DeltaSubNY.e);
+                    const int E = E0 + kScaleShift;
+                    const f2 dzs = {__builtin_amdgcn_ldexpf(DeltaSubNX.m, imax(DeltaSubNX.e - E0, -200)),
+                                    __builtin_amdgcn_ldexpf(DeltaSubNY.m, imax(DeltaSubNY.e - E0, -200))};
                     const float sE = __builtin_amdgcn_ldexpf(1.0f, E);
                     const int dshx = DeltaSub0X.e - E, dshy = DeltaSub0Y.e - E;
                     const f2 dcs = {__builtin_amdgcn_ldexpf(DeltaSub0X.m, imax(imin(dshx, 100), -200)),
@@ -2502,9 +2512,10 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                     const uint32_t left_ref = RefIteration + 1 < MaxRefS ? MaxRefS - 1 - RefIteration : 0u;
                     const uint32_t left_it = n_iterations - 1 - iter; // iter < n_iterations here
                     const uint32_t left = left_ref < left_it ? left_ref : left_it;
-                    const int Esh = (E < -254 ? -254 : (E > 0 ? 0 : E)) * (1 << 23);
-                    const bool start_ok = scaled_startable(e0) && mn0 >= mx0 * 0x1p-40f && mx0 >= 1.0f && mx0 < 2.0f &&
-                                          imax(dshx, dshy) <= 30;
+                    const int Esh = (E < -254 ? -254 : (E > 127 ? 127 : E)) * (1 << 23);
+                    // dz 2^-E exact and above the floor; |dc| 2^-E < 2^7
+                    const bool start_ok = scaled_startable(e0) && mn0 >= FS_FL_FLOOR * __builtin_amdgcn_ldexpf(1.0f, kScaleShift) &&
+                                          mx0 >= 1.0f && mx0 < 2.0f && imax(dshx, dshy) <= 30 - kScaleShift;
                     const uint32_t run_len = scaled_run_length(left);
                     if (__builtin_amdgcn_ballot_w64(!start_ok) != 0ull || run_len == 0u)
                         break;
@@ -2521,15 +2532,17 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
     NZ_ = (f2){EX, EY};                                                                                             \
     V |= __builtin_amdgcn_ballot_w64(__float_as_int(mx_##T) + Esh > __float_as_int(EB));                            \
     if (FULL) {                                                                                                     \
-        const float mn_##T = __builtin_fminf(__builtin_fabsf(NW_.x), __builtin_fabsf(NW_.y));                       \
-        V |= __builtin_amdgcn_ballot_w64(!(mn_##T >= mx_##T * 0x1p-40f)) |                                          \
-             __builtin_amdgcn_ballot_w64((uint32_t)(__float_as_int(mx_##T) - (107 << 23)) >= (uint32_t)(60 << 23)); \
+        FS_STEP_FLOOR(NW_, V)                                                                                       \
+        V |= __builtin_amdgcn_ballot_w64(!(mx_##T < FS_FL_HIGH_TRIP));                                              \
+    } else {                                                                                                        \
+        FS_STEP_FLOOR_FIRST(NW_, V)                                                                                 \
     }
                     // (keeping the first step of a failed trip, as k_lav2_hdr32_fast does, loses here: the exit conversion drops
                     // the cached orbit value the careful step would reuse; measured 437 -> 453 ms on C2)
-                    f2 w0 = dzs, z0 = {e0.x, e0.y}, w2, z2, wO;
+                    f2 w0 = dzs * __builtin_amdgcn_ldexpf(1.0f, -kScaleShift), z0 = {e0.x, e0.y}, w2, z2, wO;
                     uint32_t c = 0;
                     bool failed;
+                    bool fl_redo = false;
                     const uint32_t ref_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)RefIteration);
                     if (__builtin_amdgcn_ballot_w64(RefIteration != ref_u) == 0ull) {
                         // Entries through the scalar cache (all lanes read the same ones): the hand-scheduled untested loop
@@ -2540,7 +2553,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                         // state (keeping its first step loses here, see above).
                         const float4 *zpu = zs + ref_u + 1;
                         const int imdc = __float_as_int(__builtin_fmaxf(__builtin_fabsf(dcs.x), __builtin_fabsf(dcs.y)));
-                        float mxS = mx0;
+                        float mxS = mx0 * __builtin_amdgcn_ldexpf(1.0f, -kScaleShift);
                         int pwi = __builtin_amdgcn_readfirstlane(__float_as_int(e0.w));
                         f2 zS = {__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(e0.x))),
                                  __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(e0.y)))};
@@ -2558,14 +2571,37 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                                 c_free_steps += 4;
 #else
                             {
-                                f2 r1, r2, r3, ts_, ta_;
+                                f2 r1, r2, r3 = wv, ts_, ta_; // (r3 = wv: the pending pair on entry is the state itself)
+                                uint64_t xacc_ = 0;           // (verification build only)
                                 float tn_, tl_;
                                 uint64_t msk_;
                                 int st, ebo, pf_, pg_, ph_;
                                 uint32_t off = cs << 4;
                                 const uint32_t c_in = cs;
-                                FS_FAST_LOOP(FS_PF_NEXT_BODY);
+#if FS_FL_EVERY && !defined(FS_VERIFY_FLOOR)
+                                if (!fl_per_trip) {
+                                    {
+                                        FS_FAST_LOOP_FD(FS_PF_NEXT_BODY, FS_BT_DC_MAX, FS_BT_DC_ADD, FS_BT_H_CMP, FS_BT_H_OR);
+                                    }
+                                    ebo = 0;
+                                } else
+#endif
+                                {
+                                    FS_FAST_LOOP_FL(FS_PF_NEXT_BODY);
+                                }
+#ifdef FS_VERIFY_FLOOR
+                                if (kStats && xacc_ != 0ull)
+                                    c_blk_violation++;
+#endif
                                 st = __builtin_amdgcn_readfirstlane(st); // (asm results count as divergent)
+                                zS = (f2){__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(zS.x))),
+                                          __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(zS.y)))};
+                                if (st == 3) {
+                                    // (deferred verdict) a state of this invocation fell below the floor: nothing of the run
+                                    // has been committed -- the same run again with the per-trip verdicts
+                                    fl_redo = true;
+                                    break;
+                                }
                                 cs = (uint32_t)__builtin_amdgcn_readfirstlane((int)off) >> 4;
                                 if (kStats)
                                     c_free_steps += cs - c_in;
@@ -2577,6 +2613,11 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                             }
 #endif
                             if (cs + 4u > rl) {
+                                c = cs, wO = wv, failed = false;
+                                break;
+                            }
+                            // H where a block starts: the run ends and the next one re-centres the scale
+                            if (__builtin_amdgcn_ballot_w64(!(mxS < FS_FL_HIGH)) != 0ull) {
                                 c = cs, wO = wv, failed = false;
                                 break;
                             }
@@ -2592,9 +2633,10 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                             const f2 up_ = {ua.x, ua.y}, uq_ = {uc.x, uc.y};
                             uint64_t vp_ = 0, vq_ = 0;
                             FS_STEP_BOUND(tp_, a, vp_, ua.z)
+                            FS_STEP_FLOOR_FIRST(tp_, vp_)
                             FS_STEP_ARITH(tp_, up_, w2, b)
                             FS_STEP_BOUND(w2, b, vp_, ub.z)
-                            FS_STEP_SHAPE(w2, b, vp_)
+                            FS_STEP_FLOOR(w2, vp_)
 #ifdef FS_VERIFY_BLOCK_BOUND
                             if (kStats && bt_pass &&
                                 (__builtin_amdgcn_ballot_w64(__float_as_int(mx_a) + Esh > __float_as_int(ua.z)) |
@@ -2608,9 +2650,10 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                             z2 = (f2){ub.x, ub.y};
                             FS_STEP_ARITH(w2, z2, tq_, c_)
                             FS_STEP_BOUND(tq_, c_, vq_, uc.z)
+                            FS_STEP_FLOOR_FIRST(tq_, vq_)
                             FS_STEP_ARITH(tq_, uq_, w4, d)
                             FS_STEP_BOUND(w4, d, vq_, ud.z)
-                            FS_STEP_SHAPE(w4, d, vq_)
+                            FS_STEP_FLOOR(w4, vq_)
 #ifdef FS_VERIFY_BLOCK_BOUND
                             if (kStats && bt_pass &&
                                 (__builtin_amdgcn_ballot_w64(__float_as_int(mx_c_) + Esh > __float_as_int(uc.z)) |
@@ -2677,6 +2720,11 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
 #undef FS_SCALED_LOAD
                     }
 #undef FS_SCALED_STEP
+                    if (fl_redo) {
+                        fl_per_trip = true;
+                        continue;
+                    }
+                    fl_per_trip = false;
                     if (c != 0u) {
                         // back to two reduced HDRFloats: each part's own exponent moves out of the float (exact; an accepted
                         // state has no zero part)
