@@ -411,7 +411,7 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
 // The scalar-cache path of the scaled runs (k_lav2_hdr32_fast and the perturbation-only float path of k_perturb_scalar):
 // step pieces of the tested C++ block and the hand-scheduled untested loop.  Names used from the enclosing scope: sE2, dcs,
 // Esh, imdc, wv, mxS, pwi, zS, off, zpb, lim8 (and the asm's outputs).
-// PF of FS_FAST_LOOP: FS_PF_NONE, or FS_PF_NEXT_BODY = one dword of each 64-byte line of the NEXT body's entries (three:
+// PF of the loops (FS_FAST_LOOP_FL / _FD below): FS_PF_NONE, or FS_PF_NEXT_BODY = one dword of each 64-byte line of the NEXT body's entries (three:
 // entries are 16-byte aligned only), requested right after this body's wait, so that the next body's loads hit the scalar
 // cache -- for waves that run alone on their SIMD (C2's interior pixels), where the L2 round trip per body is not hidden.
 #define FS_PF_NONE ""
@@ -429,12 +429,6 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
 #define FS_STEP_BOUND(NW_, T, V, EB)                                                                                \
     const float mx_##T = __builtin_fmaxf(__builtin_fabsf(NW_.x), __builtin_fabsf(NW_.y));                           \
     V |= __builtin_amdgcn_ballot_w64(__float_as_int(mx_##T) + Esh > __float_as_int(EB));
-#define FS_STEP_SHAPE(NW_, T, V)                                                                                    \
-    {                                                                                                               \
-        const float mn_ = __builtin_fminf(__builtin_fabsf(NW_.x), __builtin_fabsf(NW_.y));                          \
-        V |= __builtin_amdgcn_ballot_w64(!(mn_ >= mx_##T * 0x1p-40f)) |                                             \
-             __builtin_amdgcn_ballot_w64((uint32_t)(__float_as_int(mx_##T) - (107 << 23)) >= (uint32_t)(60 << 23)); \
-    }
 // The untested body.  Registers are named (the halves of a packed pair have no operand syntax): the state w in v[48:49];
 // four state pairs v[48:55] in rotation (a trip = two steps: start state, first step, and the next trip's two while the
 // verdict is pending); the entries in s[36:67].  A packed result cannot be read by the next instruction, so each trip's
@@ -456,90 +450,10 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
 #define FS_R2 "v[52:53]"
 #define FS_R3 "v[54:55]"
 #define FS_T_X(A, B) "v_max_f32_e64 v60, |" A "|, |" B "|\n\t"
-#define FS_T_N(A, B) "v_min_f32_e64 v61, |" A "|, |" B "|\n\t"
-#define FS_T_L "v_mul_f32_e32 v62, 0x2b800000, v60\n\t"          /* 2^-40 max */
-#define FS_T_C1 "v_cmp_nge_f32_e64 %[m], v61, v62\n\t"
-#define FS_T_W "v_add_u32_e32 v61, 0xca800000, v60\n\t"          /* bits(max) - (107 << 23) */
-#define FS_T_C2 "v_cmp_le_u32_e32 vcc, 0x1e000000, v61\n\t" /* >= 60 << 23 */
-#define FS_T_O "s_or_b64 %[m], %[m], vcc\n\t"
-#define FS_NOP "s_nop 0\n\t"
-#define FS_FAST_LOOP(PF)                                                                                              \
-    asm volatile(                                                                                                   \
-        ".Lfs_loop_%=:\n\t" /* eight steps left?  the first block's test: max(max|w|, max|dc|) against .w (s67) */  \
-        "v_max_i32_e32 v62, v60, %[imdc]\n\t"                                                                       \
-        "s_cmp_gt_u32 %[off], %[lim8]\n\t"                                                                          \
-        "v_add_u32_e32 v62, v62, %[esh]\n\t"                                                                        \
-        "s_cbranch_scc1 .Lfs_out_%=\n\t"                                                                            \
-        "v_cmp_lt_i32_e64 %[m], s67, v62\n\t"                                                                       \
-        "s_cmp_lg_u64 %[m], 0\n\t"                                                                                  \
-        "s_cbranch_scc1 .Lfs_out_%=\n\t" /* steps 1, 2 (the first needs the previous entry only: s[64:65], read      \
-           before the loads that replace it are issued) + the pending tests of the state itself = the verdict of    \
-           the previous body's last trip, whose registers are written over only after it */                         \
-        FS_PK_F(FS_R0, "s[64:65]") "s_mov_b32 %[eb], s62\n\t"                                                       \
-        "s_load_dwordx16 s[36:51], s[68:69], %[off]\n\t"                                                            \
-        "s_load_dwordx16 s[52:67], s[68:69], %[off] offset:0x40\n\t"                                                \
-        FS_PK_MA(FS_R0) FS_PK_MB(FS_R0) FS_T_N("v48", "v49") FS_PK_P FS_T_L FS_PK_A(FS_R1) FS_T_C1                  \
-        "s_waitcnt lgkmcnt(0)\n\t" PF                                                                               \
-        FS_PK_F(FS_R1, "s[36:37]") FS_T_W FS_PK_MA(FS_R1) FS_PK_MB(FS_R1) FS_T_C2 FS_PK_P FS_T_O                    \
-        "s_cbranch_scc1 .Lfs_fp_%=\n\t" FS_PK_A(FS_R2) FS_NOP /* steps 3, 4 + the tests of w2 = trip 1 */           \
-        FS_PK_F(FS_R2, "s[40:41]") FS_T_X("v52", "v53") FS_PK_MA(FS_R2) FS_PK_MB(FS_R2) FS_T_N("v52", "v53")        \
-        FS_PK_P FS_T_L FS_PK_A(FS_R3) FS_T_C1                                                                       \
-        FS_PK_F(FS_R3, "s[44:45]") FS_T_W FS_PK_MA(FS_R3) FS_PK_MB(FS_R3) FS_T_C2 FS_PK_P FS_T_O                    \
-        "s_cbranch_scc1 .Lfs_f1_%=\n\t" FS_PK_A(FS_R0) FS_NOP /* steps 5, 6 + the tests of w4 (trip 2) */           \
-        FS_PK_F(FS_R0, "s[48:49]") FS_T_X("v48", "v49") FS_PK_MA(FS_R0) FS_PK_MB(FS_R0) FS_T_N("v48", "v49")        \
-        FS_PK_P FS_T_L FS_PK_A(FS_R1) FS_T_C1                                                                       \
-        FS_PK_F(FS_R1, "s[52:53]") FS_T_W FS_PK_MA(FS_R1) FS_PK_MB(FS_R1) FS_T_C2 FS_PK_P FS_T_O                    \
-        "s_cbranch_scc1 .Lfs_f2_%=\n\t" /* the second block's test: max(max|w4|, max|dc|) against entry 4's .w */   \
-        "v_max_i32_e32 v62, v60, %[imdc]\n\t" FS_PK_A(FS_R2) "v_add_u32_e32 v62, v62, %[esh]\n\t"                   \
-        /* steps 7, 8 + the tests of w6 (trip 3) */                                                                 \
-        FS_PK_F(FS_R2, "s[56:57]") "v_cmp_lt_i32_e64 %[m], s51, v62\n\t" FS_PK_MA(FS_R2) FS_PK_MB(FS_R2)            \
-        "s_cmp_lg_u64 %[m], 0\n\t" FS_PK_P "s_cbranch_scc1 .Lfs_blk_%=\n\t" FS_PK_A(FS_R3) FS_T_X("v52", "v53")     \
-        FS_PK_F(FS_R3, "s[60:61]") FS_T_N("v52", "v53") FS_PK_MA(FS_R3) FS_PK_MB(FS_R3) FS_T_L FS_PK_P FS_T_C1      \
-        FS_T_W FS_T_C2 FS_T_O "s_cbranch_scc1 .Lfs_f3_%=\n\t" FS_PK_A(FS_R0)                                        \
-        "s_add_u32 %[off], %[off], 0x80\n\t" /* max|w8| for the next block test; its other tests ride in the next body */ \
-        FS_T_X("v48", "v49") "s_branch .Lfs_loop_%=\n"                                                              \
-        ".Lfs_out_%=:\n\t" /* the block here needs its bound tests, or fewer than 8 steps are left: the pending tests */ \
-        "s_mov_b32 %[eb], s62\n\t" FS_T_N("v48", "v49") FS_T_L FS_T_C1 FS_T_W FS_T_C2 FS_T_O                        \
-        "s_cbranch_scc1 .Lfs_fp_%=\n\t"                                                                             \
-        "s_mov_b32 %[st], 0\n\t"                                                                                    \
-        "s_branch .Lfs_end_%=\n"                                                                                    \
-        ".Lfs_blk_%=:\n\t" /* the same after the first block (no verdict is pending there) */                       \
-        "s_mov_b32 %[st], 0\n\t"                                                                                    \
-        "s_mov_b64 s[64:65], s[48:49]\n\t"                                                                          \
-        "s_mov_b32 s67, s51\n\t"                                                                                    \
-        "s_add_u32 %[off], %[off], 0x40\n\t"                                                                        \
-        "s_branch .Lfs_end_%=\n"                                                                                    \
-        ".Lfs_fp_%=:\n\t" /* the previous body's last trip: start state v[52:53], first step v[54:55] */            \
-        "s_mov_b32 %[st], 2\n\t"                                                                                    \
-        "s_sub_u32 %[off], %[off], 0x20\n\t"                                                                        \
-        "s_branch .Lfs_end_%=\n"                                                                                    \
-        ".Lfs_f1_%=:\n\t"                                                                                           \
-        "s_mov_b32 %[st], 1\n\t"                                                                                    \
-        "s_mov_b32 %[eb], s38\n\t"                                                                                  \
-        "s_branch .Lfs_end_%=\n"                                                                                    \
-        ".Lfs_f2_%=:\n\t"                                                                                           \
-        "s_mov_b32 %[st], 2\n\t"                                                                                    \
-        "s_mov_b32 %[eb], s46\n\t"                                                                                  \
-        "s_add_u32 %[off], %[off], 0x20\n\t"                                                                        \
-        "s_branch .Lfs_end_%=\n"                                                                                    \
-        ".Lfs_f3_%=:\n\t"                                                                                           \
-        "s_mov_b32 %[st], 1\n\t"                                                                                    \
-        "s_mov_b32 %[eb], s54\n\t"                                                                                  \
-        "s_add_u32 %[off], %[off], 0x40\n"                                                                          \
-        ".Lfs_end_%=:\n\t"                                                                                          \
-        "s_waitcnt lgkmcnt(0)" /* (a failed pending trip leaves after the loads: nothing stays in flight) */        \
-        : "+{v[48:49]}"(wv), "={v[50:51]}"(r1), "={v[52:53]}"(r2), "={v[54:55]}"(r3), "={v[56:57]}"(ts_),           \
-          "={v[58:59]}"(ta_), "+{v60}"(mxS), "={v61}"(tn_), "={v62}"(tl_), [m] "=&s"(msk_), [st] "=&s"(st),         \
-          [eb] "=&s"(ebo), "+{s67}"(pwi), "+{s[64:65]}"(zS), [off] "+s"(off), [pf] "=&s"(pf_), [pg] "=&s"(pg_),     \
-          [ph] "=&s"(ph_)                                                                                           \
-        : [se] "v"(sE2), [dc] "v"(dcs), [esh] "v"(Esh), [imdc] "v"(imdc), [lim8] "s"(lim8), "{s[68:69]}"(zpb)       \
-        : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50",  \
-          "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s66", "vcc",  \
-          "scc")
 
 // ------------------------------------------------------------------------------------------------
-// Round 4: the FLOOR form of the scaled runs' acceptance tests (k_lav2_hdr32_fast; the scalar-HDRFloat kernel keeps the
-// form above).  Scale of a run: w = dz 2^-E with E = dz's exponent + 24, i.e. max|w| starts in [2^-24, 2^-23).
+// Round 4: the FLOOR form of the scaled runs' acceptance tests (k_lav2_hdr32_fast, and k_perturb_scalar's float path -- whose
+// simpler version of the argument is given there).  Scale of a run: w = dz 2^-E with E = dz's exponent + 24, i.e. max|w| starts in [2^-24, 2^-23).
 //
 // Why a scaled step can differ from the reference's HDRFloatComplex step at all (Fractal.cpp:2646-2661: cur = 2Z + dz,
 // p = dz cur, q = p + dc, Reduce): both carry out the same IEEE operations on the same real operands (the scale is a
@@ -626,7 +540,8 @@ constexpr int kFloorBits = (127 - FS_FL_FLOOR_EXP) << 23;
 #else
 #define FS_STEP_FLOOR_FIRST(NW_, V)
 #endif
-// The untested body, floor form.  Same registers, same rotation of the four state pairs, same exits as FS_FAST_LOOP; a
+// The untested body, floor form (round 3's form of this statement tested every second state against a ratio and a window:
+// six vector instructions per two states).  Registers, rotation of the four state pairs and exits as described above; a
 // trip's two states (first step, second step) are tested together while the next trip's packed arithmetic is in flight,
 // the verdict arrives before that trip's second step overwrites the failed trip's start state.  On entry the pending
 // "previous trip" is (v[54:55], v[48:49]): the caller passes the entering state in both.
@@ -2546,7 +2461,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                     const uint32_t ref_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)RefIteration);
                     if (__builtin_amdgcn_ballot_w64(RefIteration != ref_u) == 0ull) {
                         // Entries through the scalar cache (all lanes read the same ones): the hand-scheduled untested loop
-                        // of k_lav2_hdr32_fast (FS_FAST_LOOP; here with the next body's cache lines requested a body ahead:
+                        // of k_lav2_hdr32_fast (FS_FAST_LOOP_FD / _FL; here with the next body's cache lines requested a body ahead:
                         // a wave that is alone on its SIMD -- the interior pixels' 4.7 M-step chains that decide C2's frame
                         // time -- pays per instruction issued and for every L2 round trip it waits out), and four-step
                         // blocks with their bound tests where the block test fails.  A failed trip ends the run at its start

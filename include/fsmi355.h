@@ -296,7 +296,11 @@ uint32_t fs_set_kernel_variant(fs_renderer *r, int variant);
  * same geometry, row bands and orbit generation is launched in descending cost order -- "warm".  The first frame, a frame
  * after any of those changed or after fs_forget_tile_costs, and every frame under FS_VARIANT_NATURAL_TILE_ORDER run in
  * natural order -- "cold".  The order changes which wave renders which tile, never a pixel.
- * fs_last_frame_tile_ordered: 1 when the most recent fs_render_lav2 launch used a recorded order.
+ * fs_render_bla's probe order (FS_VARIANT_NATURAL_TILE_ORDER above) is kept the same way: a frame with the same geometry, row
+ * bands, orbit (generation, or for generation 0 a sampled fingerprint of the entries -- RenderPerturbBLA re-uploads per call),
+ * coordinates and iteration limit as the one before reuses the order and skips the probe launch; fs_forget_tile_costs drops it.
+ * fs_last_frame_tile_ordered: 1 when the most recent fs_render_lav2 launch used a recorded order / the most recent
+ * perturbation-only fs_render_bla launch reused its probe order.
  * fs_read_tile_costs: the costs the last frame recorded (row-major tiles of the LOCAL buffer, (width + 7) / 8 per row);
  * *n_tiles = their number; out may be NULL.  FractalSharkError 10006 when nothing has been recorded. */
 uint32_t fs_forget_tile_costs(fs_renderer *r);

@@ -176,3 +176,56 @@ def test_lao_mode_records_and_reuses(renderer, native_libs):
     b = _frame(r, v, ob, PARITY_CPU_GPUSTAGE, mode=LAV2_LAO)
     assert r.last_frame_tile_ordered()
     assert np.array_equal(a, b)
+
+
+def test_perturbation_only_probe_order_is_reused_for_a_repeated_frame(renderer, native_libs):
+    """fs_render_bla without a table (C2's path): the probe launch's tile order is a pure function of its inputs, so a
+    repeated frame reuses it -- also when the orbit is re-uploaded with generation 0, as RenderPerturbBLA does on every
+    call -- and anything that changes the inputs (coordinates, iteration limit, orbit, fs_forget_tile_costs) probes again.
+    Every frame equals the first and the CPU function's rows."""
+    r = renderer
+    w, h = 640, 416  # 80 x 52 = 4160 tiles: enough for the reordering to switch on
+    v = inputs.View.builtin(5, w, h)
+    n = (1 << 18) + 8192  # the reordering needs a limit of 2^18 or more, for both limits used below
+    ob = inputs.Orbit(v)
+    co = _pairs(v.coords_perturb(ob))
+    assert r.InitializeMemory(w, h, 1, None, 0, 0, 0, False) == 0
+    assert r.forget_tile_costs() == 0
+
+    def frame(coords=co, cap=n, orbit=ob):
+        assert r.ClearMemory() == 0
+        assert r.RenderPerturbBLA(None, orbit, None, None, None, *coords, cap) == 0
+        out = r.new_iter_buffer()
+        assert r.RenderCurrent(cap, out) == 0
+        assert r.SyncComputeStream() == 0
+        return out[:h, :w].copy()
+
+    first = frame()
+    assert not r.last_frame_tile_ordered()
+    second = frame()  # same orbit uploaded again (generation 0): recognised by its fingerprint
+    assert r.last_frame_tile_ordered()
+    assert np.array_equal(first, second)
+    ref = _oracle.bla_hdr32(v, ob, None, rows=(204, 212), n_iterations=n)
+    assert np.array_equal(first[204:212], ref[204:212, :w])
+    # a lower iteration limit, other coordinates, a forgotten order: each probes again, and the frame after is warm
+    frame(cap=n - 4096)
+    assert not r.last_frame_tile_ordered()
+    frame(cap=n - 4096)
+    assert r.last_frame_tile_ordered()
+    moved = [co[0], co[1], (co[2][0] * 1.0000001, co[2][1]), co[3]]
+    frame(coords=moved)
+    assert not r.last_frame_tile_ordered()
+    assert np.array_equal(frame(), first)
+    assert not r.last_frame_tile_ordered()  # the coordinates changed back: probed again
+    assert np.array_equal(frame(), first) and r.last_frame_tile_ordered()
+    assert r.forget_tile_costs() == 0
+    assert np.array_equal(frame(), first) and not r.last_frame_tile_ordered()
+    # another orbit (View 3) at the same geometry: probed again
+    v3 = inputs.View.builtin(3, w, h)
+    ob3 = inputs.Orbit(v3)
+    frame(coords=_pairs(v3.coords_perturb(ob3)), orbit=ob3)
+    assert not r.last_frame_tile_ordered()
+    # natural order: no probe, never "ordered"; same pixels
+    r.set_kernel_variant(0x800)
+    assert np.array_equal(frame(), first) and not r.last_frame_tile_ordered()
+    r.set_kernel_variant(0)
