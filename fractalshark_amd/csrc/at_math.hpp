@@ -64,16 +64,40 @@ __device__ __forceinline__ void at_perform(const hcplx<F> c, const hreal<F> esc,
             // wave against thousands of iterations).  Per iteration that leaves 8 arithmetic instructions, two compares and
             // a handful of scalar ones; the first form of this loop -- the two tests as divergent breaks, a per-lane
             // counter -- spent 17 scalar instructions per iteration on EXEC bookkeeping.
+            // Round 4, F = double: the loop in TRUE values.  With Z = z 2^k (the value z represents) and C = c 2^k the
+            // iteration z' = (z*z) 2^k + c is Z' = Z*Z + C: a power-of-two scaling commutes with every IEEE operation
+            // that neither underflows nor overflows, so the same bits come out with the two multiplications by P gone
+            // (10 instead of 12 vector instructions per iteration).  What can differ is an underflow in ONE of the two
+            // domains: a product below 2^-1022 in true values (rr, ii, ri), or (z*z) 2^k below it in the reference's.
+            // rr / ii: the iteration is only taken while |Z|^2 >= 2^-782 (`floor_t`; the reference's own norm is then
+            // normal too), so an underflowed square is 2^239 below the other one and absorbed by both sums that read
+            // it.  ri: added to C.im, which absorbs it when |c.im| >= 2^-800 (the ratio is the same in both domains);
+            // c.im == 0 keeps im at exactly 0 (z starts at 0).  Hence the wave-uniform precondition below; a wave with
+            // a lane outside it (a pixel within 2^-800 of the real axis in relative terms, an escape radius outside
+            // 2^+-900) takes the loop in the reference's units.  Below the floor the literal loop continues, as before.
+            bool true_domain = false;
+            F thr = min_normal, cre = c.re, cim = c.im;
+            if constexpr (sizeof(F) == 8) {
+                const F acim = c.im < F(0) ? -c.im : c.im;
+                const bool lane_ok = !literal && te < fbits<F>::kMaxMulExp && (c.im == F(0) || acim >= pow2_normal<F>(-800)) &&
+                                     esc.e > -900 && esc.e < 900;
+                if (__builtin_amdgcn_ballot_w64(!lane_ok) == 0ull) {
+                    true_domain = true;
+                    re *= P, im *= P, cre *= P, cim *= P; // exact: |parts| are 0 or >= 2^-920
+                    T = esc.m * pow2_normal<F>(esc.e);
+                    thr = pow2_normal<F>(-782);
+                }
+            }
             if (!literal && i < ATMaxIt) {
                 IterT it = 1;                                               // wave-uniform
                 uint64_t pending = __builtin_amdgcn_ballot_w64(true);       // lanes still iterating (a lane mask, scalar)
-                F xre = re, xim = im, xm = min_normal;
+                F xre = re, xim = im, xm = thr;
                 IterT xi = ATMaxIt;
 #define FS_AT_LOOP(SCALE)                                                                                           \
     for (;;) {                                                                                                      \
         const F rr = re * re, ii = im * im;                                                                         \
         const F m = rr + ii;                                                                                        \
-        const uint64_t fin = (__builtin_amdgcn_ballot_w64(!(m >= min_normal)) | __builtin_amdgcn_ballot_w64(m > T)) \
+        const uint64_t fin = (__builtin_amdgcn_ballot_w64(!(m >= thr)) | __builtin_amdgcn_ballot_w64(m > T))      \
                              & pending;                                                                             \
         if (fin != 0ull) {                                                                                          \
             if (__builtin_amdgcn_inverse_ballot_w64(fin))                                                           \
@@ -83,24 +107,29 @@ __device__ __forceinline__ void at_perform(const hcplx<F> c, const hreal<F> esc,
                 break;                                                                                              \
         }                                                                                                           \
         const F ri = re * im;                                                                                       \
-        re = (rr - ii) SCALE + c.re;                                                                                \
-        im = (ri + ri) SCALE + c.im;                                                                                \
+        re = (rr - ii) SCALE + cre;                                                                                 \
+        im = (ri + ri) SCALE + cim;                                                                                 \
         if (++it >= ATMaxIt) {                                                                                      \
             if (__builtin_amdgcn_inverse_ballot_w64(pending))                                                       \
                 xre = re, xim = im, xi = ATMaxIt; /* took its last iteration (xm stays normal: not literal) */      \
             break;                                                                                                  \
         }                                                                                                           \
     }
-                if (__builtin_amdgcn_ballot_w64(k != 0) == 0ull) {
-                    // every lane of the wave has 1 <= |c| < 2: P is 1 and x * 1 is x, bit for bit -- two multiplications less
+                if (true_domain || __builtin_amdgcn_ballot_w64(k != 0) == 0ull) {
+                    // true values -- or every lane of the wave has 1 <= |c| < 2: P is 1 and x * 1 is x, bit for bit
                     FS_AT_LOOP()
                 } else {
                     FS_AT_LOOP(*P)
                 }
 #undef FS_AT_LOOP
                 re = xre, im = xim, i = xi;
-                // finished through the norm test with a norm that is not a normal number: the literal loop continues from here
-                literal = i < ATMaxIt && !(xm >= min_normal);
+                // finished through the norm test with a norm below the floor (not a normal number in the reference's units,
+                // or too close to it for the true-value loop): the literal loop continues from here
+                literal = i < ATMaxIt && !(xm >= thr);
+            }
+            if (true_domain) {
+                const F Pinv = pow2_normal<F>(-k); // back to the reference's units: exact
+                re *= Pinv, im *= Pinv;
             }
             z = hcplx<F>{re, im, k};
             if (!literal) {
