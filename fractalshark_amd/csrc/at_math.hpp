@@ -74,13 +74,13 @@ __device__ __forceinline__ void at_perform(const hcplx<F> c, const hreal<F> esc,
             // it.  ri: added to C.im, which absorbs it when |c.im| >= 2^-800 (the ratio is the same in both domains);
             // c.im == 0 keeps im at exactly 0 (z starts at 0).  Hence the wave-uniform precondition below; a wave with
             // a lane outside it (a pixel within 2^-800 of the real axis in relative terms, an escape radius outside
-            // 2^+-900) takes the loop in the reference's units.  Below the floor the literal loop continues, as before.
+            // 2^-700 .. 2^900) takes the loop in the reference's units.  Below the floor the literal loop continues, as before.
             bool true_domain = false;
             F thr = min_normal, cre = c.re, cim = c.im;
             if constexpr (sizeof(F) == 8) {
                 const F acim = c.im < F(0) ? -c.im : c.im;
                 const bool lane_ok = !literal && te < fbits<F>::kMaxMulExp && (c.im == F(0) || acim >= pow2_normal<F>(-800)) &&
-                                     esc.e > -900 && esc.e < 900;
+                                     esc.e > -700 && esc.e < 900;
                 if (__builtin_amdgcn_ballot_w64(!lane_ok) == 0ull) {
                     true_domain = true;
                     re *= P, im *= P, cre *= P, cim *= P; // exact: |parts| are 0 or >= 2^-920
@@ -115,8 +115,87 @@ __device__ __forceinline__ void at_perform(const hcplx<F> c, const hreal<F> esc,
             break;                                                                                                  \
         }                                                                                                           \
     }
-                if (true_domain || __builtin_amdgcn_ballot_w64(k != 0) == 0ull) {
-                    // true values -- or every lane of the wave has 1 <= |c| < 2: P is 1 and x * 1 is x, bit for bit
+                if constexpr (sizeof(F) == 8) {
+                    if (true_domain) {
+                        // The true-value loop by hand: what the compiler makes of FS_AT_LOOP() is 10 vector and 11 scalar
+                        // instructions per iteration, and the scalar unit (shared by the CU's four SIMDs) is then as busy as
+                        // the vector pipes.  Here: the eight arithmetic operations, ONE test -- the high word of |Z|^2 inside
+                        // [high word of the floor, high word of T): two 32-bit instructions that flag a superset of the
+                        // lanes that finish (equal high words are decided exactly, outside) -- and four scalar instructions
+                        // (vote, branch, count, branch).  The statement leaves when a pending lane is flagged, with the state
+                        // NOT advanced, or after its iteration budget; recording, the exact test and that one iteration are
+                        // C++ (a lane finishes once, a wave leaves the statement a few dozen times in thousands of iterations).
+                        const uint32_t thr_hi = (uint32_t)(to_bits<F>(thr) >> 32);
+                        const uint32_t range = (uint32_t)(to_bits<F>(T) >> 32) - thr_hi; // (T >= 2^-700 > floor: precondition)
+                        for (;;) {
+                            const IterT left = ATMaxIt - it; // >= 1
+                            const uint32_t n = left > (IterT)0x40000000u ? 0x40000000u : (uint32_t)left;
+                            uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n - 1u));
+                            F rr, ii, ri, m;
+                            uint32_t t_;
+                            uint64_t tmp_;
+                            int st;
+                            asm volatile("s_mov_b32 %[st], 0\n"
+                                         ".Lat_loop_%=:\n\t"
+                                         "v_mul_f64 %[rr], %[re], %[re]\n\t"
+                                         "v_mul_f64 %[ii], %[im], %[im]\n\t"
+                                         "v_mul_f64 %[ri], %[re], %[im]\n\t"
+                                         "v_add_f64 v[62:63], %[rr], %[ii]\n\t"
+                                         "v_add_f64 %[rr], %[rr], -%[ii]\n\t"
+                                         "v_add_f64 %[ri], %[ri], %[ri]\n\t"
+                                         "v_subrev_u32_e32 %[t], %[thi], v63\n\t"
+                                         "v_cmp_le_u32_e32 vcc, %[rng], %[t]\n\t"
+                                         "s_and_b64 %[tmp], vcc, %[pend]\n\t"
+                                         "s_cbranch_scc1 .Lat_flag_%=\n\t"
+                                         "v_add_f64 %[re], %[rr], %[cre]\n\t"
+                                         "v_add_f64 %[im], %[ri], %[cim]\n\t"
+                                         "s_sub_u32 %[cnt], %[cnt], 1\n\t"
+                                         "s_cbranch_scc0 .Lat_loop_%=\n\t"
+                                         "s_branch .Lat_end_%=\n"
+                                         ".Lat_flag_%=:\n\t"
+                                         "s_mov_b32 %[st], 1\n"
+                                         ".Lat_end_%=:"
+                                         : [re] "+v"(re), [im] "+v"(im), [rr] "=&v"(rr), [ii] "=&v"(ii), [ri] "=&v"(ri),
+                                           "={v[62:63]}"(m), [t] "=&v"(t_), [tmp] "=&s"(tmp_), [st] "=&s"(st), [cnt] "+s"(cnt)
+                                         : [cre] "v"(cre), [cim] "v"(cim), [rng] "v"(range), [pend] "s"(pending),
+                                           [thi] "s"(thr_hi)
+                                         : "vcc", "scc");
+                            st = __builtin_amdgcn_readfirstlane(st);
+                            cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt);
+                            if (st == 0) {
+                                it += (IterT)n;
+                                if (it >= ATMaxIt) {
+                                    if (__builtin_amdgcn_inverse_ballot_w64(pending))
+                                        xre = re, xim = im, xi = ATMaxIt;
+                                    break;
+                                }
+                                continue;
+                            }
+                            it += (IterT)(n - 1u - cnt);
+                            // the state is at iteration `it`, its norm in m, rr - ii and ri + ri in rr / ri: the exact test
+                            const uint64_t fin =
+                                (__builtin_amdgcn_ballot_w64(!(m >= thr)) | __builtin_amdgcn_ballot_w64(m > T)) & pending;
+                            if (fin != 0ull) {
+                                if (__builtin_amdgcn_inverse_ballot_w64(fin))
+                                    xre = re, xim = im, xm = m, xi = it;
+                                pending &= ~fin;
+                                if (pending == 0ull)
+                                    break;
+                            }
+                            re = rr + cre;
+                            im = ri + cim;
+                            if (++it >= ATMaxIt) {
+                                if (__builtin_amdgcn_inverse_ballot_w64(pending))
+                                    xre = re, xim = im, xi = ATMaxIt;
+                                break;
+                            }
+                        }
+                    }
+                }
+                if (true_domain) {
+                    // (done above)
+                } else if (__builtin_amdgcn_ballot_w64(k != 0) == 0ull) {
+                    // every lane of the wave has 1 <= |c| < 2: P is 1 and x * 1 is x, bit for bit -- two multiplications less
                     FS_AT_LOOP()
                 } else {
                     FS_AT_LOOP(*P)
