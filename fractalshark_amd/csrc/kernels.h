@@ -163,6 +163,7 @@ template <class F> struct FsBlaArgsT {
     // HDRFloat<float> only: the device-native table (NULL = use `levels`, the reference-layout records)
     const FsBlaRec *nrec;
     const int4 *nlad; // two int4 per position
+    const long long *nkmax; // per orbit index m = 4 q + 1: the largest r2 key LookupBackwards can meet there (pre-test), [q]
     uint32_t level_off[kBlaMaxLevels];
 };
 using FsBlaArgs32 = FsBlaArgsT<float>;
@@ -346,7 +347,7 @@ void fsk_bla_build_hdr64(const FsZ64 *zref, void *const *levels, const uint64_t 
 // levels: device pointer table of the reference-layout levels; level_off / epl: host arrays [n_levels]; bad: device word that
 // is set when an r2 is not a reduced non-negative finite value (the caller then keeps using the reference-layout table)
 void fsk_bla_make_native(const fs_bla_hdr32 *const *levels, const uint32_t *level_off, const uint64_t *epl, int n_levels,
-                         const float4 *zref, uint32_t orbit_count, FsBlaRec *rec, int4 *lad, uint32_t *bad, hipStream_t s);
+                         const float4 *zref, uint32_t orbit_count, FsBlaRec *rec, int4 *lad, uint32_t *bad, int32_t lm2, long long *kmax, uint32_t n_kmax, hipStream_t s);
 void fsk_perturb_scalar_hdr32(const FsBlaArgs32 &A, bool use_bla, bool stats, int variant, hipStream_t s);
 void fsk_perturb_scalar_hdr64(const FsBlaArgsT<double> &A, bool use_bla, bool stats, int variant, hipStream_t s);
 void fsk_perturb_bla_f64(const FsBlaArgsF64 &A, bool use_bla, bool stats, hipStream_t s);

@@ -1831,8 +1831,12 @@ __device__ __forceinline__ const typename FsDev<F>::BLA *bla_lookup(const typena
 // 15 of 16 lookups start at level <= 5 and finish in their first round; deeper ones loop (another four levels per round).
 // A table entry can only apply at orbit indices m = 1 (mod 4) (level >= 2 needs k = m - 1 divisible by 4): when no lane
 // of the wave sits at one, the lookup is one vote.
-__device__ __forceinline__ uint32_t bla_lookup_native(const int4 *__restrict__ lad, const uint32_t *off, int32_t lm2,
-                                                      uint32_t m, long long zkey, long long key20)
+// Round 4: before the walk, one key per orbit index -- kmax[(m - 1) / 4] = the largest key the walk at m can meet
+// (k_bla_make_kmax) -- decides the lookups that find nothing, which is how every outer trip of the kernel ends (741 of a
+// wave's 1061 lookup passes on C5): one 8-byte load and one compare instead of two to three rounds of the ladder.
+__device__ __forceinline__ uint32_t bla_lookup_native(const int4 *__restrict__ lad, const long long *__restrict__ kmax,
+                                                      const uint32_t *off, int32_t lm2, uint32_t m, long long zkey,
+                                                      long long key20)
 {
     if (__builtin_amdgcn_ballot_w64((m & 3u) == 1u) == 0ull)
         return 0xFFFFFFFFu;
@@ -1843,6 +1847,8 @@ __device__ __forceinline__ uint32_t bla_lookup_native(const int4 *__restrict__ l
     int32_t L = zeros <= lm2 ? zeros : lm2;
     // m == 0: no table entry; odd k: level 0; k == 0: only when the first element of level 2 applies (BLAS.cpp:270-281)
     bool live = m != 0u && (k & 1) == 0 && L >= 2 && (!first || zkey < key20);
+    if (live)
+        live = zkey < kmax[(uint32_t)k >> 2];
     uint32_t hit = 0xFFFFFFFFu;
     while (__builtin_amdgcn_ballot_w64(live) != 0ull) {
         if (live) {
@@ -2227,7 +2233,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                     if constexpr (kNat) {
                         const long long zkey = (long long)(((unsigned long long)(unsigned)DeltaNormSquared.e << 32) |
                                                            (unsigned)__float_as_int(DeltaNormSquared.m));
-                        const uint32_t pos = bla_lookup_native(A.nlad, s_off, A.lm2, RefIteration, zkey, nat_key20);
+                        const uint32_t pos = bla_lookup_native(A.nlad, A.nkmax, s_off, A.lm2, RefIteration, zkey, nat_key20);
                         FS_PH(ph_lookup += __builtin_readcyclecounter() - ph_t; ph_n_lookup++);
                         if (pos == 0xFFFFFFFFu)
                             break;

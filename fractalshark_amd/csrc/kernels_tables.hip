@@ -186,10 +186,39 @@ __global__ void __launch_bounds__(256) k_bla_make_native(const fs_bla_hdr32 *con
                                        (int)(unsigned long long)k[3], (int)((unsigned long long)k[3] >> 32));
 }
 
+// Pre-test of the lookup: kmax[q] = the largest key among the elements BLAS::LookupBackwards probes at orbit index
+// m = 4 q + 1 (k = 4 q: start level min(zeros(k), lm2), element index k >> zeros(k) -- from zeros, not from the capped level,
+// as BLAS.cpp:283-300 has it -- then one level down and the index doubled, until level 2).  |dz|^2 >= kmax[q] means that
+// no probe of that walk can hold: the lookup is over after one 8-byte load and one compare, for every lane of a wave whose
+// lookup finds nothing -- which is how every outer trip of the kernel ends.  An element index outside its level (the walk
+// would read beyond the table) disables the pre-test for that q (INT64_MAX: never rejects).
+__global__ void __launch_bounds__(256) k_bla_make_kmax(const int4 *__restrict__ lad, NativeGeom G, int32_t lm2,
+                                                       long long *__restrict__ kmax, uint32_t n)
+{
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n)
+        return;
+    const uint32_t k = q << 2;
+    const int32_t zeros = k == 0u ? 32 : (int32_t)__ffs((int)k) - 1;
+    uint32_t ix = k == 0u ? 0u : k >> zeros;
+    long long best = (long long)0x8000000000000000ull;
+    for (int32_t L = zeros <= lm2 ? zeros : lm2; L >= 2; L--, ix <<= 1) {
+        if (L >= G.n_levels || ix >= G.level_n[L]) {
+            best = 0x7FFFFFFFFFFFFFFFll;
+            break;
+        }
+        const int4 a = lad[2u * ((size_t)G.level_off[L] + ix)];
+        const long long key = (long long)(((unsigned long long)(unsigned)a.y << 32) | (unsigned)a.x);
+        best = key > best ? key : best;
+    }
+    kmax[q] = best;
+}
+
 } // namespace
 
 void fsk_bla_make_native(const fs_bla_hdr32 *const *levels, const uint32_t *level_off, const uint64_t *epl, int n_levels,
-                         const float4 *zref, uint32_t orbit_count, FsBlaRec *rec, int4 *lad, uint32_t *bad, hipStream_t s)
+                         const float4 *zref, uint32_t orbit_count, FsBlaRec *rec, int4 *lad, uint32_t *bad, int32_t lm2,
+                         long long *kmax, uint32_t n_kmax, hipStream_t s)
 {
     NativeGeom G;
     memset(&G, 0, sizeof(G));
@@ -205,6 +234,8 @@ void fsk_bla_make_native(const fs_bla_hdr32 *const *levels, const uint32_t *leve
         return;
     hipLaunchKernelGGL(k_bla_make_native, dim3((total + 255u) / 256u), dim3(256), 0, s, levels, G, zref, orbit_count, rec, lad,
                        bad);
+    if (n_kmax != 0u)
+        hipLaunchKernelGGL(k_bla_make_kmax, dim3((n_kmax + 255u) / 256u), dim3(256), 0, s, lad, G, lm2, kmax, n_kmax);
 }
 
 void fsk_bla_build_hdr32(const float4 *zref, void *const *levels, const uint64_t *epl, int n_levels, fs_real_hdr32 bla_size,

@@ -491,7 +491,9 @@ uint32_t bla_make_native(fs_renderer *r, int32_t n_levels)
     }
     if (total == 0 || total > 0xFFFFFFF0ull)
         return 0;
-    const size_t need = 256 + (size_t)total * (sizeof(FsBlaRec) + 2 * sizeof(int4));
+    // (+ the lookup's pre-test keys, one per orbit index 4 q + 1)
+    const uint32_t n_kmax = (uint32_t)(r->orbit_uncompressed / 4u) + 2u;
+    const size_t need = 256 + (size_t)total * (sizeof(FsBlaRec) + 2 * sizeof(int4)) + (size_t)n_kmax * sizeof(long long);
     if (!r->bla_native || r->bla_native_cap < need) {
         (void)r_free(r, r->bla_native);
         r->bla_native = nullptr;
@@ -507,7 +509,8 @@ uint32_t bla_make_native(fs_renderer *r, int32_t n_levels)
     int4 *lad = (int4 *)((char *)rec + (size_t)total * sizeof(FsBlaRec));
     FS_TRY(hipMemsetAsync(bad, 0, 256, r->compute));
     fsk_bla_make_native((const fs_bla_hdr32 *const *)r->bla_levels_dev, r->bla_level_off, r->bla_level_sizes.data(), n_levels,
-                        r->zref, (uint32_t)r->orbit_uncompressed, rec, lad, bad, r->compute);
+                        r->zref, (uint32_t)r->orbit_uncompressed, rec, lad, bad, r->bla_lm2,
+                        (long long *)(lad + 2 * (size_t)total), n_kmax, r->compute);
     FS_TRY(hipGetLastError());
     uint32_t flag = 1;
     FS_TRY(hipMemcpyAsync(&flag, bad, 4, hipMemcpyDeviceToHost, r->compute));
@@ -2081,6 +2084,7 @@ uint32_t fs_render_bla(fs_renderer *r, int type_tag, const void *coords, uint64_
         if (use_bla && r->bla_native_ok) {
             A.nrec = (const FsBlaRec *)((const char *)r->bla_native + 256);
             A.nlad = (const int4 *)((const char *)A.nrec + (size_t)r->bla_native_total * sizeof(FsBlaRec));
+            A.nkmax = (const long long *)(A.nlad + 2 * (size_t)r->bla_native_total);
             memcpy(A.level_off, r->bla_level_off, sizeof(A.level_off));
         }
         // Long tiles first.  A perturbation-only frame with a high iteration limit is bounded by the few waves that hold
