@@ -831,6 +831,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
     uint64_t c_at = 0, c_la = 0, c_pt = 0, c_px = 0;
     uint64_t c_careful = 0, c_scaled = 0, c_runs = 0;
     uint32_t c_why[4] = {0, 0, 0, 0};
+    uint32_t c_nz[4] = {0, 0, 0, 0}; // (counting build) careful passes by the kind of entry they arrive at, see below
+    bool was_skip = false;
     uint32_t c_wentry = 0, c_wstart = 0, c_wshort = 0; // run entries tried / runs started / runs of fewer than 8 steps (per wave)
     uint32_t c_blk_violation = 0; // (verification build) blocks that passed the block test and failed a bound test: must stay 0
     uint32_t c_pass = 0, c_generic = 0; // careful passes of the wave / those that took the generic step
@@ -984,6 +986,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                     // entry, a trip and an exit, so a few careful steps are taken before the next one
                     sc_skip--;
                     sc_stopped = true;
+                    was_skip = true;
                 } else if (kScaled) {
                     typedef float f3 __attribute__((ext_vector_type(3)));
                     FS_CYC(cyc_t1 = __builtin_readcyclecounter());
@@ -1632,7 +1635,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                         c_why[2]++;
                     if (__builtin_amdgcn_ballot_w64(escaped) != 0ull)
                         c_why[3]++;
+                    // the entry this pass arrives at is one no scaled step may arrive at ("never" bound: near zero, or out of
+                    // the companion's range) for every lane / and nothing happens there / nothing happens at another kind of
+                    // entry / the pass is a back-off wait
+                    const bool nz = __builtin_amdgcn_ballot_w64(__float_as_int(zs[ref + 1].z) != (int)0x80000000) == 0ull;
+                    const bool quiet_pass = rb == 0ull && __builtin_amdgcn_ballot_w64(escaped) == 0ull;
+                    if (nz)
+                        c_nz[0]++;
+                    if (nz && quiet_pass)
+                        c_nz[1]++;
+                    if (!nz && quiet_pass)
+                        c_nz[2]++;
+                    if (was_skip)
+                        c_nz[3]++;
                 }
+                was_skip = false;
                 ref++;
                 dzm = q;
                 Zcm = Znm;
@@ -1731,6 +1748,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
             for (int i = 0; i < 4; i++) {
                 const uint32_t y = __shfl_down(c_why[i], off);
                 c_why[i] = y > c_why[i] ? y : c_why[i];
+                const uint32_t y2 = __shfl_down(c_nz[i], off);
+                c_nz[i] = y2 > c_nz[i] ? y2 : c_nz[i];
             }
         }
         if ((threadIdx.x & 63) == 0) {
@@ -1745,8 +1764,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
             atomicAdd((unsigned long long *)&A.stats[13], (unsigned long long)c_wstart);
             atomicAdd((unsigned long long *)&A.stats[14], (unsigned long long)c_wshort);
             atomicAdd((unsigned long long *)&A.stats[15], (unsigned long long)c_blk_violation);
-            for (int i = 0; i < 4; i++)
+            for (int i = 0; i < 4; i++) {
                 atomicAdd((unsigned long long *)&A.stats[16 + i], (unsigned long long)c_why[i]);
+                atomicAdd((unsigned long long *)&A.stats[20 + i], (unsigned long long)c_nz[i]);
+            }
         }
     }
 }

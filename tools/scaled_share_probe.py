@@ -44,6 +44,10 @@ for w, h in ((480, 270), (960, 540), (1920, 1080), (3840, 2160)):
                           "careful_passes_per_wave_with": {"a_rebase_in_some_lane": round(raw[17] / (w * h / 64), 1),
                                                            "a_rebase_in_every_running_lane": round(raw[18] / (w * h / 64), 1),
                                                            "an_escape": round(raw[19] / (w * h / 64), 1)},
+                          "careful_passes_per_wave_arriving_at": {"an_entry_no_scaled_step_may_arrive_at": round(raw[20] / (w * h / 64), 1),
+                                                                   "such_an_entry_and_nothing_happens": round(raw[21] / (w * h / 64), 1),
+                                                                   "another_entry_and_nothing_happens": round(raw[22] / (w * h / 64), 1),
+                                                                   "as_a_back_off_wait": round(raw[23] / (w * h / 64), 1)},
                           "generic_step_share_of_passes": round(raw[11] / max(1, raw[10]), 4),
                           "lane_utilisation": round(st["perturb_steps"] / max(1, st["lane_slots"]), 4)}), flush=True)
 r.set_kernel_variant(0)
