@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -155,6 +156,7 @@ struct fs_renderer {
         size_t bytes;
     };
     std::vector<Block> live_blocks, kept_blocks;
+    std::mutex kept_mu; // kept_blocks only: another renderer of the same device may drain them when IT runs out of memory
     size_t host_alloc_bytes = 0;
     bool inject_input_oom = false;   // fault injection: FSMI355_FAIL_INPUT_ALLOC=1 at fs_create time
     void *arena = nullptr;           // work memory of fs_build_la (kept between calls, grown on demand)
@@ -211,11 +213,32 @@ static bool async_alloc_enabled()
 constexpr size_t kKeptBlocks = 16;
 constexpr size_t kKeptBytes = (size_t)2 << 30;
 
-static void release_kept_blocks(fs_renderer *r)
+static uint64_t release_kept_blocks(fs_renderer *r)
 {
-    for (const auto &k : r->kept_blocks)
+    std::lock_guard<std::mutex> g(r->kept_mu);
+    uint64_t bytes = 0;
+    for (const auto &k : r->kept_blocks) {
         (void)hipFree(k.p);
+        bytes += k.bytes;
+    }
     r->kept_blocks.clear();
+    return bytes;
+}
+
+// Every renderer of the process, so that one that runs out of device memory can take back what the OTHERS of its device keep
+// idle (FractalShark holds four GPURenderers on one device; a kept block is idle by construction -- its owner parked it
+// after draining its stream -- so any thread may free it).
+static std::mutex g_renderers_mu;
+static std::vector<fs_renderer *> g_renderers;
+
+static uint64_t release_idle_memory_of_device(int device)
+{
+    std::lock_guard<std::mutex> g(g_renderers_mu);
+    uint64_t bytes = 0;
+    for (fs_renderer *o : g_renderers)
+        if (o->device == device)
+            bytes += release_kept_blocks(o);
+    return bytes;
 }
 
 hipError_t r_alloc(fs_renderer *r, void **out, size_t bytes, AllocKind kind)
@@ -230,23 +253,32 @@ hipError_t r_alloc(fs_renderer *r, void **out, size_t bytes, AllocKind kind)
         } else {
             // a kept block that fits (best fit, at most twice the size asked for) before a new allocation: a host that uploads
             // an orbit and its tables for every frame allocates nothing in the steady state
-            size_t best = r->kept_blocks.size();
-            for (size_t i = 0; i < r->kept_blocks.size(); i++) {
-                const size_t b = r->kept_blocks[i].bytes;
-                if (b >= bytes && b <= 2 * bytes + (1u << 16) && (best == r->kept_blocks.size() || b < r->kept_blocks[best].bytes))
-                    best = i;
-            }
-            if (best != r->kept_blocks.size()) {
-                *out = r->kept_blocks[best].p;
-                r->live_blocks.push_back(r->kept_blocks[best]);
-                r->kept_blocks.erase(r->kept_blocks.begin() + (long)best);
-                return hipSuccess;
+            {
+                std::lock_guard<std::mutex> g(r->kept_mu);
+                size_t best = r->kept_blocks.size();
+                for (size_t i = 0; i < r->kept_blocks.size(); i++) {
+                    const size_t b = r->kept_blocks[i].bytes;
+                    if (b >= bytes && b <= 2 * bytes + (1u << 16) &&
+                        (best == r->kept_blocks.size() || b < r->kept_blocks[best].bytes))
+                        best = i;
+                }
+                if (best != r->kept_blocks.size()) {
+                    *out = r->kept_blocks[best].p;
+                    r->live_blocks.push_back(r->kept_blocks[best]);
+                    r->kept_blocks.erase(r->kept_blocks.begin() + (long)best);
+                    return hipSuccess;
+                }
             }
             e = hipMalloc(out, bytes);
-            if (e != hipSuccess && !r->kept_blocks.empty()) { // the kept blocks may be what is in the way
+            if (e != hipSuccess) { // idle blocks may be what is in the way: this renderer's, then every renderer's of the device
                 (void)hipGetLastError();
-                release_kept_blocks(r);
-                e = hipMalloc(out, bytes);
+                if (release_kept_blocks(r) != 0u)
+                    e = hipMalloc(out, bytes);
+                if (e != hipSuccess) {
+                    (void)hipGetLastError();
+                    if (release_idle_memory_of_device(r->device) != 0u)
+                        e = hipMalloc(out, bytes);
+                }
             }
             if (e == hipSuccess)
                 r->live_blocks.push_back(fs_renderer::Block{*out, bytes});
@@ -288,6 +320,7 @@ hipError_t r_free(fs_renderer *r, const void *cp)
             const fs_renderer::Block b = r->live_blocks[i];
             r->live_blocks.erase(r->live_blocks.begin() + (long)i);
             // kept for the next request -- up to kKeptBlocks of them and kKeptBytes in total (the oldest go first)
+            std::lock_guard<std::mutex> g(r->kept_mu);
             r->kept_blocks.push_back(b);
             size_t total = 0;
             for (const auto &k : r->kept_blocks)
@@ -714,6 +747,8 @@ fs_renderer *fs_create(int device)
         // the device were full and lands in page-locked host memory
         const char *e = getenv("FSMI355_FAIL_INPUT_ALLOC");
         r->inject_input_oom = e != nullptr && atoi(e) != 0;
+        std::lock_guard<std::mutex> g(g_renderers_mu);
+        g_renderers.push_back(r);
     }
     return r;
 }
@@ -722,6 +757,10 @@ void fs_destroy(fs_renderer *r)
 {
     if (!r)
         return;
+    {
+        std::lock_guard<std::mutex> g(g_renderers_mu);
+        g_renderers.erase(std::remove(g_renderers.begin(), g_renderers.end(), r), g_renderers.end());
+    }
     if (hipSetDevice(r->device) == hipSuccess) {
         if (r->compute)
             hipStreamSynchronize(r->compute);
@@ -2504,6 +2543,17 @@ uint32_t fs_enqueue_done_callback(fs_renderer *r, fs_done_cb cb, void *user)
 }
 
 uint64_t fs_host_fallback_bytes(const fs_renderer *r) { return r->host_alloc_bytes; }
+
+uint64_t fs_idle_device_bytes(fs_renderer *r)
+{
+    std::lock_guard<std::mutex> g(r->kept_mu);
+    uint64_t b = 0;
+    for (const auto &k : r->kept_blocks)
+        b += k.bytes;
+    return b;
+}
+
+uint64_t fs_release_idle_device_memory(int device) { return release_idle_memory_of_device(device); }
 
 uint32_t fs_set_compressed_orbit_mode(fs_renderer *r, int mode)
 {

@@ -317,6 +317,15 @@ class GPURenderer:
         """Bytes of input tables this renderer had to place in page-locked host memory (fs_host_fallback_bytes)."""
         return int(self._lib.fs_host_fallback_bytes(self._h))
 
+    def idle_device_bytes(self):
+        """Device memory this renderer keeps idle for its next allocation (fs_idle_device_bytes)."""
+        return int(self._lib.fs_idle_device_bytes(self._h))
+
+    @staticmethod
+    def release_idle_device_memory(device=0):
+        """Frees the idle blocks of every renderer of this process on `device` (fs_release_idle_device_memory)."""
+        return int(_capi.render_lib().fs_release_idle_device_memory(int(device)))
+
     # ---- measurement
     def last_kernel_ms(self):
         return float(self._lib.fs_last_kernel_ms(self._h))

@@ -253,6 +253,13 @@ uint32_t fs_enqueue_done_callback(fs_renderer *r, fs_done_cb cb, void *user);
  * ever placed there by this renderer (0 in normal operation).  FSMI355_FAIL_INPUT_ALLOC=1 in the environment when
  * fs_create runs makes every input allocation of that renderer take the fallback (fault injection for tests). */
 uint64_t fs_host_fallback_bytes(const fs_renderer *r);
+/* Device memory a renderer keeps idle for its next allocation (blocks it has freed: at most 16 blocks / 2 GiB, reused when
+ * the next request fits).  A renderer whose allocation fails frees its own idle blocks, then those of EVERY renderer of the
+ * process on the same device (FractalShark holds four GPURenderers on one device), and only then takes the page-locked
+ * fallback or reports the error.  fs_idle_device_bytes: what `r` holds idle now; fs_release_idle_device_memory: frees the idle
+ * blocks of all renderers on `device` (what the out-of-memory path does), returns the bytes freed.  Thread-safe. */
+uint64_t fs_idle_device_bytes(fs_renderer *r);
+uint64_t fs_release_idle_device_memory(int device);
 
 uint32_t fs_get_width(const fs_renderer *r);
 uint32_t fs_get_height(const fs_renderer *r);

@@ -141,3 +141,39 @@ def test_second_upload_of_a_large_orbit_renders_the_same_frame(native_libs):
     finally:
         r.set_kernel_variant(0)
         r.close()
+
+
+def test_idle_blocks_of_every_renderer_on_the_device_can_be_taken_back(native_libs):
+    """A renderer keeps the blocks it frees for its next request (fs_idle_device_bytes).  What the out-of-memory path of ANY
+    renderer on the device does before it gives up -- free the idle blocks of all of them (fs_release_idle_device_memory) --
+    is run here by hand between two frames of two renderers: the idle bytes go to zero, both renderers keep rendering the
+    right frame (nothing that is in use was touched), and the blocks come back with the next round of uploads."""
+    a, b = GPURenderer(0), GPURenderer(0)
+    try:
+        v = inputs.View.builtin(5, 64, 36)
+        ob = inputs.Orbit(v)
+        la = inputs.LATable(ob)
+        co = _pairs(v.coords_perturb(ob))
+        want = _oracle.lav2_hdr32(v, ob, la, stage_test=0)
+
+        def frame(r, gen):
+            assert r.InitializeMemory(64, 36, 1, None, 0, 0, 0, True) == 0
+            assert r.InitializePerturb(gen, ob, 0, None, la) == 0
+            assert r.RenderPerturbLAv2(None, None, None, *co, v.num_iterations, T=T_HDR32, Mode=LAV2_FULL,
+                                       parity=PARITY_CPU) == 0
+            return _frame(r, v.num_iterations)[0]
+
+        for gen in (1, 2, 3):  # new generations: orbit and table are uploaded again, the old buffers are freed -> kept idle
+            assert np.array_equal(frame(a, gen), want)
+            assert np.array_equal(frame(b, gen), want)
+        idle = a.idle_device_bytes() + b.idle_device_bytes()
+        assert idle > 0
+        assert GPURenderer.release_idle_device_memory(0) >= idle
+        assert a.idle_device_bytes() == 0 and b.idle_device_bytes() == 0
+        assert np.array_equal(frame(a, 3), want)  # (cached generation: renders from what is resident)
+        assert np.array_equal(frame(b, 4), want)
+        assert np.array_equal(frame(a, 5), want)
+        assert a.host_fallback_bytes == 0 and b.host_fallback_bytes == 0
+    finally:
+        a.close()
+        b.close()
