@@ -57,11 +57,18 @@ def _worker(rank, world, port, q):
         index = torch.from_numpy(tiling.reassemble_index(H, world, band)) if rank == 0 else None
         frame = tiling.gather_frame(lt, gathered, index, rank, world)
         assert (frame is None) == (rank != 0)
+        # ... and the form bench.py's pipelined loop uses: the collective alone into a buffer that is reused from frame to
+        # frame (gather_slices), row order restored with index_select(out=...) into another one
+        gathered2 = torch.full((world * max_rows, rw), -1, dtype=torch.int32) if rank == 0 else None
+        tiling.gather_slices(lt, gathered2, rank, world)
         if rank == 0:
             frame2 = tiling.reassemble(gathered.view(world, max_rows, rw), H, world, band)
+            frame3 = torch.empty((H, rw), dtype=torch.int32)
+            torch.index_select(gathered2, 0, index, out=frame3)
             full = _oracle.lav2_hdr32(v, ob, la, threads=2, stage_test=1)
             ok = np.array_equal(frame.numpy().view(np.uint32), full[:H]) and \
-                np.array_equal(frame2.numpy().view(np.uint32), full[:H])
+                np.array_equal(frame2.numpy().view(np.uint32), full[:H]) and \
+                np.array_equal(frame3.numpy().view(np.uint32), full[:H])
             q.put(bool(ok))
         dist.barrier()
     finally:
