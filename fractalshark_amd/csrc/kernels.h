@@ -71,6 +71,8 @@ template <class F> struct FsLav2ArgsT {
     const typename FsDev<F>::Z *zref; // prepared orbit
     const float4 *zq;                 // tuned HDRFloat<float> loop only: {re, im, ~exp | poison, -} (k_make_quiet_orbit)
     const float4 *zs;                 // ... and its scaled runs: {2Z.re, 2Z.im, 2^-5 max|Z| | -1, -} in true scale
+    const float2 *zs2;                // the same 2Z alone, 8 B per entry, and
+    const float4 *zqb;                // the block bounds of entries i + 3, + 7, + 11, + 15: what a 16-step body of the untested loop reads
     const typename FsDev<F>::LA *las;
     const fs_la_stage_u32 *stages;
     uint64_t *stats;
@@ -144,6 +146,8 @@ template <class F> struct FsBlaArgsT {
     const typename FsDev<F>::Z *zref;
     const float4 *zq;                            // float, perturbation-only: quiet-run companion of zref
     const float4 *zs;                            // ... and the scaled runs' companion (see FsLav2ArgsT)
+    const float2 *zs2;                           // ... in the compact form of the 16-step body (see FsLav2ArgsT)
+    const float4 *zqb;
     const typename FsDev<F>::BLA *const *levels; // device array of device pointers, indexed by level
     uint64_t *stats;
     uint32_t *queue; // frame-wide pixel counter of the persistent (lane-refilling) launch, zeroed before each launch
@@ -303,7 +307,7 @@ void fsk_decompress_orbit_hdr32(const fs_orbit_hdr32_rc *wp, uint64_t n_wp, uint
 void fsk_decompress_orbit_hdr64(const fs_orbit_hdr64_rc *wp, uint64_t n_wp, uint64_t n_uncompressed, fs_real_hdr64 cxLow,
                                 fs_real_hdr64 cyLow, FsZ64 *out, hipStream_t s);
 void fsk_prepare_orbit_hdr64(const fs_orbit_hdr64 *in, FsZ64 *out, uint64_t n, hipStream_t s);
-void fsk_make_quiet_orbit(const float4 *zref, float4 *zq, uint64_t n, hipStream_t s);
+void fsk_make_quiet_orbit(const float4 *zref, float4 *zq, float2 *zs2, float4 *zqb, uint64_t n, hipStream_t s);
 // Launch order for "long tiles first": order[0 .. n_slots) = the tiles whose probe count (their own centre's or a
 // neighbour's) reached `threshold`, in tile order, then the others, then 0xFFFFFFFF; order[n_slots] = the number of long
 // tiles.  probe: tiles_y rows of tiles_x counts.

@@ -92,7 +92,23 @@ __device__ __forceinline__ bool scaled_startable(const float4 e)
 // Companion array of the tuned LAv2 loop: {re, im, s, -} with s = ~exp + 116 (-(s - 116) = exp + 1 = the exponent of 2Z;
 // the bias turns the loop's range tests into comparisons against constants) for orbit values below 8, and a large
 // positive poison for larger ones, which makes the range test fail there.  zq must hold 2 n entries.
-__global__ void k_make_quiet_orbit(const float4 *__restrict__ zref, float4 *__restrict__ zq, uint64_t n)
+// Block bound of entry j (the .w of the second companion, see below): min(bound[j+1 .. j+4]) 2^-18, "never" if one of them is.
+__device__ __forceinline__ float scaled_block_bound(const float4 *__restrict__ zref, uint64_t j, uint64_t n)
+{
+    if (j >= n)
+        return -0.0f;
+    float bm = 0x1p60f;
+    bool all4 = true;
+    for (uint32_t k = 1; k <= 4; k++) {
+        const float bk = j + k < n ? scaled_bound(zref[j + k]) : -0.0f;
+        all4 = all4 && __float_as_int(bk) != (int)0x80000000;
+        bm = __builtin_fminf(bm, bk);
+    }
+    return all4 ? bm * 0x1p-18f : -0.0f;
+}
+
+__global__ void k_make_quiet_orbit(const float4 *__restrict__ zref, float4 *__restrict__ zq, float2 *__restrict__ zs2,
+                                   float4 *__restrict__ zqb, uint64_t n)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
@@ -123,6 +139,12 @@ __global__ void k_make_quiet_orbit(const float4 *__restrict__ zref, float4 *__re
     }
     zq[n + i] = make_float4(__builtin_amdgcn_ldexpf(v.x, e + 1), __builtin_amdgcn_ldexpf(v.y, e + 1), b0,
                             all4 ? bm * 0x1p-18f : -0.0f);
+    // the compact form for the 16-step body of the untested loop (FS_FAST_LOOP_FD16): 2Z alone, and the block bounds a body
+    // whose first arrival is entry i needs -- those of its entries 3, 7, 11 (the states its second to fourth blocks start
+    // from) and 15 (the state the NEXT body starts from)
+    zs2[i] = make_float2(__builtin_amdgcn_ldexpf(v.x, e + 1), __builtin_amdgcn_ldexpf(v.y, e + 1));
+    zqb[i] = make_float4(scaled_block_bound(zref, i + 3, n), scaled_block_bound(zref, i + 7, n),
+                         scaled_block_bound(zref, i + 11, n), scaled_block_bound(zref, i + 15, n));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -685,6 +707,90 @@ constexpr int kFloorBits = (127 - FS_FL_FLOOR_EXP) << 23;
           "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s66", "vcc",  \
           "scc")
 
+// The untested body with the deferred verdict, SIXTEEN steps per body (round 4).  A wave that is alone on its SIMD -- the
+// never-escaping pixels that decide C2's frame time, the last waves of a rank of an N-GPU split -- pays one L2 round trip per
+// body: scalar loads return out of order, so the entries of a body can only be waited for all together, and the loads that
+// warm the scalar cache for the next body are waited for with them.  Twice the steps per round trip: the body reads its
+// entries in the COMPACT form -- 2Z alone, 8 bytes per entry (zs2: two s_load_dwordx16 for sixteen entries), and ONE
+// 16-byte record (zqb) with the block bounds of its entries 3, 7, 11 and 15 -- instead of sixteen bytes per entry.
+// Registers: entries E0 .. E15 in s[36:67] (E15 = s[66:67] is the entry the state is at when the body ends: the next
+// body's first step reads it BEFORE the loads overwrite it), the four block bounds in s[72:75] (s75 = the bound of the
+// state's entry at the loop's top), bases s[68:69] (zs2) and s[70:71] (zqb), `off` = 16 bytes per step as everywhere.
+// State pairs, temporaries, the floor accumulator and the statuses as in FS_FAST_LOOP_FD: 0 = stopped in front of a block
+// that needs its tests / fewer than 16 steps left, 3 = a state below the floor (the caller repeats the run attempt with
+// FS_FAST_LOOP_FL).  Blocks 2 .. 4 are tested in the second step of the block, before anything of the block is counted.
+#define FS_FD16_PAIR(EA, EB_, BW, LBL)                                                                              \
+    FS_PK_F(FS_R0, EA) FS_FL_ACC("v48", "v49") FS_PK_MA(FS_R0) FS_T_X("v48", "v49") FS_PK_MB(FS_R0)                 \
+    FS_PK_P FS_BT_DC_MAX FS_PK_A(FS_R1) FS_BT_DC_ADD                                                                \
+    FS_PK_F(FS_R1, EB_) "v_cmp_lt_i32_e64 %[m], " BW ", v62\n\t" FS_BT_H_CMP FS_PK_MA(FS_R1)                         \
+    FS_BT_H_OR FS_PK_MB(FS_R1) FS_PK_P "s_cbranch_scc1 " LBL "\n\t" FS_PK_A(FS_R2)
+#define FS_FD16_TAIL(EC, ED)                                                                                        \
+    FS_PK_F(FS_R2, EC) FS_FL_ACC("v50", "v51") FS_PK_MA(FS_R2) FS_FL_ACC("v52", "v53") FS_PK_MB(FS_R2)              \
+    FS_PK_P FS_PK_A(FS_R3)                                                                                          \
+    FS_PK_F(FS_R3, ED) FS_FL_ACC("v54", "v55") FS_PK_MA(FS_R3) FS_PK_MB(FS_R3) FS_PK_P FS_PK_A(FS_R0)
+#define FS_PF16_NONE ""
+#define FS_PF16_NEXT_BODY                                                                                           \
+    "s_load_dword %[pf], s[68:69], %[oc] offset:0x80\n\t"                                                           \
+    "s_load_dword %[pg], s[68:69], %[oc] offset:0xc0\n\t"                                                           \
+    "s_load_dword %[ph], s[68:69], %[oc] offset:0xfc\n\t"                                                           \
+    "s_load_dword %[pi], s[70:71], %[off] offset:0x100\n\t"                                                         \
+    "s_load_dword %[pj], s[70:71], %[off] offset:0x10c\n\t"
+#define FS_FAST_LOOP_FD16(PF)                                                                                       \
+    asm volatile(                                                                                                   \
+        "v_mov_b32_e32 v61, 0x7f800000\n"                                                                           \
+        ".Lfe_loop_%=:\n\t" /* sixteen steps left?  the first block's tests: max(max|w|, max|dc|) against s75, H */  \
+        FS_BT_DC_MAX "s_cmp_gt_u32 %[off], %[lim16]\n\t" FS_BT_DC_ADD                                               \
+        "s_cbranch_scc1 .Lfe_out_%=\n\t"                                                                            \
+        "v_cmp_lt_i32_e64 %[m], s75, v62\n\t" FS_BT_H_CMP FS_BT_H_OR                                                \
+        "s_cbranch_scc1 .Lfe_out_%=\n\t" /* steps 1 .. 4 */                                                         \
+        FS_PK_F(FS_R0, "s[66:67]")                                                                                  \
+        "s_lshr_b32 %[oc], %[off], 1\n\t"                                                                           \
+        "s_load_dwordx16 s[36:51], s[68:69], %[oc]\n\t"                                                             \
+        "s_load_dwordx16 s[52:67], s[68:69], %[oc] offset:0x40\n\t"                                                 \
+        "s_load_dwordx4 s[72:75], s[70:71], %[off]\n\t"                                                             \
+        FS_PK_MA(FS_R0) FS_PK_MB(FS_R0) FS_PK_P FS_PK_A(FS_R1)                                                      \
+        "s_waitcnt lgkmcnt(0)\n\t" PF                                                                               \
+        FS_PK_F(FS_R1, "s[36:37]") FS_FL_ACC("v50", "v51") FS_PK_MA(FS_R1) FS_PK_MB(FS_R1) FS_PK_P FS_PK_A(FS_R2)   \
+        FS_PK_F(FS_R2, "s[38:39]") FS_FL_ACC("v52", "v53") FS_PK_MA(FS_R2) FS_PK_MB(FS_R2) FS_PK_P FS_PK_A(FS_R3)   \
+        FS_PK_F(FS_R3, "s[40:41]") FS_FL_ACC("v54", "v55") FS_PK_MA(FS_R3) FS_PK_MB(FS_R3) FS_PK_P FS_PK_A(FS_R0)   \
+        /* steps 5 .. 8: w4's floor part and max in step 5, the second block's tests in step 6 */                   \
+        FS_FD16_PAIR("s[42:43]", "s[44:45]", "s72", ".Lfe_b1_%=") FS_FD16_TAIL("s[46:47]", "s[48:49]")              \
+        /* steps 9 .. 12 */                                                                                         \
+        FS_FD16_PAIR("s[50:51]", "s[52:53]", "s73", ".Lfe_b2_%=") FS_FD16_TAIL("s[54:55]", "s[56:57]")              \
+        /* steps 13 .. 16 */                                                                                        \
+        FS_FD16_PAIR("s[58:59]", "s[60:61]", "s74", ".Lfe_b3_%=") FS_FD16_TAIL("s[62:63]", "s[64:65]")              \
+        "s_add_u32 %[off], %[off], 0x100\n\t"                                                                       \
+        FS_T_X("v48", "v49") FS_FL_ACC("v48", "v49") "s_branch .Lfe_loop_%=\n"                                      \
+        ".Lfe_b1_%=:\n\t" /* block 2 needs its bound tests (or H): the state is w4 in v[48:49], at entry 3 */       \
+        "s_mov_b64 s[66:67], s[42:43]\n\t"                                                                          \
+        "s_mov_b32 s75, s72\n\t"                                                                                    \
+        "s_add_u32 %[off], %[off], 0x40\n\t"                                                                        \
+        "s_branch .Lfe_out_%=\n"                                                                                    \
+        ".Lfe_b2_%=:\n\t" /* block 3: w8, entry 7 */                                                                \
+        "s_mov_b64 s[66:67], s[50:51]\n\t"                                                                          \
+        "s_mov_b32 s75, s73\n\t"                                                                                    \
+        "s_add_u32 %[off], %[off], 0x80\n\t"                                                                        \
+        "s_branch .Lfe_out_%=\n"                                                                                    \
+        ".Lfe_b3_%=:\n\t" /* block 4: w12, entry 11 */                                                              \
+        "s_mov_b64 s[66:67], s[58:59]\n\t"                                                                          \
+        "s_mov_b32 s75, s74\n\t"                                                                                    \
+        "s_add_u32 %[off], %[off], 0xc0\n"                                                                          \
+        ".Lfe_out_%=:\n\t" /* the verdict over every state of this invocation */                                    \
+        "s_mov_b32 %[st], 0\n\t" FS_FL_C                                                                            \
+        "s_cbranch_vccz .Lfe_end_%=\n\t"                                                                            \
+        "s_mov_b32 %[st], 3\n"                                                                                      \
+        ".Lfe_end_%=:\n\t"                                                                                          \
+        "s_waitcnt lgkmcnt(0)"                                                                                      \
+        : "+{v[48:49]}"(wv), "={v[50:51]}"(r1), "={v[52:53]}"(r2), "={v[54:55]}"(r3), "={v[56:57]}"(ts_),           \
+          "={v[58:59]}"(ta_), "+{v60}"(mxS), "={v61}"(tn_), "={v62}"(tl_), [m] "=&s"(msk_), [st] "=&s"(st),         \
+          "+{s75}"(pwi), "+{s[66:67]}"(zS), [off] "+s"(off), [oc] "=&s"(oc_), [pf] "=&s"(pf_), [pg] "=&s"(pg_),     \
+          [ph] "=&s"(ph_), [pi] "=&s"(pi_), [pj] "=&s"(pj_)                                                         \
+        : [se] "v"(sE2), [dc] "v"(dcs), [esh] "v"(Esh), [imdc] "v"(imdc), [lim16] "s"(lim16), "{s[68:69]}"(zpb2),   \
+          "{s[70:71]}"(zqbp), [flr] "s"(kFloorBits)                                                                 \
+        : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50",  \
+          "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65",  \
+          "s72", "s73", "s74", "vcc", "scc")
+
 // ------------------------------------------------------------------------------------------------
 // LAv2, T = HDRFloat<float>: tuned perturbation loop.  Same prologue (AT + LA stages) and the same results, bit for
 // bit, as k_lav2_hdr32; the perturbation loop (>99.9 % of the executed work at View 5) is restructured around what
@@ -1236,6 +1342,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
 #if FS_FL_EVERY && !defined(FS_VERIFY_FLOOR)
                                     if (!fl_per_trip) {
                                         {
+                                            // (the 16-step body of k_perturb_scalar, FS_FAST_LOOP_FD16, measures 1 - 2 % slower
+                                            // here -- 51.6 against 50.6 ms at N = 1, the same 7.5 ms on the slowest of eight
+                                            // emulated ranks: with eight waves per SIMD the round trip it halves is hidden)
                                             FS_FAST_LOOP_FD(FS_PF_NONE, FS_BT_DC_MAX, FS_BT_DC_ADD, FS_BT_H_CMP, FS_BT_H_OR);
                                         }
                                         ebo = 0;
@@ -2503,7 +2612,10 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                         uint32_t cs = 0;
                         const uint32_t rl = (uint32_t)__builtin_amdgcn_readfirstlane((int)run_len);
                         const uint32_t lim8 = (rl << 4) - 0x80u; // run lengths are 16 / 64 / 256 steps
+                        const uint32_t lim16 = (rl << 4) - 0x100u;
                         const float4 *const zpb = zpu;
+                        const float2 *const zpb2 = A.zs2 + ref_u + 1; // the same entries in the 16-step body's compact form
+                        const float4 *const zqbp = A.zqb + ref_u + 1;
                         for (;;) {
 #ifdef FS_VERIFY_BLOCK_BOUND
                             // VERIFICATION BUILD (tools/block_bound_check.py), as in k_lav2_hdr32_fast
@@ -2517,13 +2629,14 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                                 uint64_t xacc_ = 0;           // (verification build only)
                                 float tn_, tl_;
                                 uint64_t msk_;
-                                int st, ebo, pf_, pg_, ph_;
+                                int st, ebo, pf_, pg_, ph_, pi_, pj_;
+                                uint32_t oc_;
                                 uint32_t off = cs << 4;
                                 const uint32_t c_in = cs;
 #if FS_FL_EVERY && !defined(FS_VERIFY_FLOOR)
                                 if (!fl_per_trip) {
                                     {
-                                        FS_FAST_LOOP_FD(FS_PF_NEXT_BODY, FS_BT_DC_MAX, FS_BT_DC_ADD, FS_BT_H_CMP, FS_BT_H_OR);
+                                        FS_FAST_LOOP_FD16(FS_PF16_NEXT_BODY);
                                     }
                                     ebo = 0;
                                 } else
@@ -3344,9 +3457,9 @@ void fsk_prepare_orbit_hdr32(const fs_orbit_hdr32 *in, float4 *out, uint64_t n, 
     hipLaunchKernelGGL(k_prepare_orbit_hdr32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n);
 }
 
-void fsk_make_quiet_orbit(const float4 *zref, float4 *zq, uint64_t n, hipStream_t s)
+void fsk_make_quiet_orbit(const float4 *zref, float4 *zq, float2 *zs2, float4 *zqb, uint64_t n, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_make_quiet_orbit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, zref, zq, n);
+    hipLaunchKernelGGL(k_make_quiet_orbit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, zref, zq, zs2, zqb, n);
 }
 
 static unsigned lds_pad()

@@ -108,6 +108,8 @@ struct fs_renderer {
     float4 *zref = nullptr;
     float4 *zq = nullptr; // companions of zref for the tuned LAv2 loop (2 x zq_n entries)
     uint64_t zq_n = 0;
+    float2 *zs2 = nullptr; // (inside the zq block) compact companions of the 16-step body
+    float4 *zqb = nullptr;
     FsZ64 *zref64 = nullptr;
     fs_orbit_f64 *orbit_f64 = nullptr; // plain double orbit (FS_T_F64), used as uploaded
     void *orbit_plain = nullptr;       // plain float / CudaDblflt orbit (FS_T_F32 / FS_T_2X32), used as uploaded
@@ -424,11 +426,21 @@ hipError_t make_quiet_orbit(fs_renderer *r, uint64_t n)
     }
     // two companions back to back; the scaled runs request their entries one 8-entry body ahead, so the second one may be
     // read up to 16 entries past its end (never used)
-    hipError_t err = r_alloc(r, (void **)&r->zq, (2 * (n + 2) + 16) * sizeof(float4), kInput);
+    // ... followed by the compact form the 16-step body of the untested loop reads: 2Z alone (8 B per entry) and, per entry, the
+    // block bounds of the entries 3, 7, 11 and 15 further on (16 B); 32 entries of slack each (the body after the last is
+    // requested ahead, never used)
+    const uint64_t m = n + 2, slack = 32;
+    const uint64_t units = 2 * m + 16 + (m + slack + 1) / 2 + (m + slack);
+    hipError_t err = r_alloc(r, (void **)&r->zq, units * sizeof(float4), kInput);
     if (err != hipSuccess)
         return err;
-    r->zq_n = n + 2;
-    fsk_make_quiet_orbit(r->zref, r->zq, n + 2, r->compute);
+    r->zq_n = m;
+    r->zs2 = (float2 *)(r->zq + 2 * m + 16);
+    r->zqb = r->zq + 2 * m + 16 + (m + slack + 1) / 2;
+    err = hipMemsetAsync(r->zs2, 0, ((m + slack + 1) / 2 + (m + slack)) * sizeof(float4), r->compute);
+    if (err != hipSuccess)
+        return err;
+    fsk_make_quiet_orbit(r->zref, r->zq, r->zs2, r->zqb, m, r->compute);
     return hipGetLastError();
 }
 
@@ -1903,6 +1915,8 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
             A.zref = r->zref;
             A.zq = r->zq;
             A.zs = r->zq + r->zq_n;
+        A.zs2 = r->zs2;
+        A.zqb = r->zqb;
             A.at = r->at;
             fsk_lav2_wide(&A, nullptr, kmode, r->stats_on, r->compute);
         } else {
@@ -2003,6 +2017,8 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
         A.zref = r->zref;
         A.zq = r->zq;
         A.zs = r->zq + r->zq_n;
+        A.zs2 = r->zs2;
+        A.zqb = r->zqb;
         A.at = r->at;
         // Longest tiles first, self-recorded.  Every frame of the tuned kernel stores one cost word per 8 x 8 tile (its
         // longest lane's step count); the NEXT frame of the same geometry, band layout and orbit generation is launched in
@@ -2106,6 +2122,8 @@ uint32_t fs_render_bla(fs_renderer *r, int type_tag, const void *coords, uint64_
         A.zref = r->zref;
         A.zq = r->zq;
         A.zs = r->zq + r->zq_n;
+        A.zs2 = r->zs2;
+        A.zqb = r->zqb;
         A.levels = (const fs_bla_hdr32 *const *)r->bla_levels_dev;
         A.stats = r->stats;
         A.queue = r->queue;

@@ -1,0 +1,33 @@
+"""C4 through HDRFloat<double>: where the frame's time goes, by LAv2 mode (View 14, 15360x8640 = 3840x2160 x AA 4, GPU-direction
+stage test): Full (AT + LA stages + perturbation steps) against LA only (AT + LA stages), with the step counters of the Full
+frame.  Usage: python tools/c4_phase_split.py"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fractalshark_amd import GPURenderer, LAV2_FULL, LAV2_LAO, PARITY_CPU_GPUSTAGE, T_HDR64, inputs  # noqa: E402
+
+r = GPURenderer(0)
+v = inputs.View.builtin(14, 3840, 2160, antialiasing=None)
+ob = inputs.Orbit(v, is64=True)
+la = inputs.LATable(ob)
+AA = v.antialiasing
+W, H = v.width * AA, v.height * AA
+co = [(float(c["m"]), int(c["e"])) for c in v.coords_perturb(ob)]
+assert r.InitializeMemory(W, H, AA, None, 0, 0, 0, False) == 0
+assert r.InitializePerturb(1, ob, 0, None, la) == 0
+out = {"frame": "%dx%d" % (W, H)}
+for name, mode in (("full", LAV2_FULL), ("la_only", LAV2_LAO)):
+    ms = []
+    for _ in range(3):
+        assert r.RenderPerturbLAv2(None, None, None, *co, v.num_iterations, T=T_HDR64, Mode=mode, parity=PARITY_CPU_GPUSTAGE) == 0
+        assert r.SyncComputeStream() == 0
+        ms.append(r.last_kernel_ms())
+    out["kernel_ms_" + name] = round(min(ms), 3)
+r.enable_step_count(True)
+assert r.RenderPerturbLAv2(None, None, None, *co, v.num_iterations, T=T_HDR64, Mode=LAV2_FULL, parity=PARITY_CPU_GPUSTAGE) == 0
+assert r.SyncComputeStream() == 0
+st = r.read_step_count()
+out.update({k: int(st[k]) for k in ("perturb_steps", "at_iterations", "la_steps", "lane_slots") if k in st})
+print(json.dumps(out))

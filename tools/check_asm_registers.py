@@ -1,6 +1,6 @@
 """Static check of the hand-scheduled loops' register ownership (gfx950 code objects of libfsmi355.so; CPU only).
 
-FS_FAST_LOOP / FS_FAST_LOOP_FL / FS_FAST_LOOP_FD are single `asm` statements that NAME their registers: the state pairs
+FS_FAST_LOOP_FL / FS_FAST_LOOP_FD / FS_FAST_LOOP_FD16 are single `asm` statements that NAME their registers: the state pairs
 v[48:55], the temporaries v[56:59], v61, v62, the entries s[36:63] and s66, with s[64:65], s67, s[68:69] and v60 as in/out
 operands.  The compiler allocates everything else around the statement and honours the clobber list -- this check makes a
 break of that contract visible in the BUILT code instead of in a frame:
@@ -22,8 +22,10 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import check_inflight_loads as chk  # noqa: E402
 
 SCRATCH = {("v", i) for i in (56, 57, 58, 59, 61, 62)} | {("s", i) for i in list(range(36, 64)) + [66]}
-NAMED = {("v", i) for i in range(48, 63)} | {("s", i) for i in range(36, 70)}
-FIRST = re.compile(r"^v_pk_fma_f32 v\[56:57\], v\[48:49\], v\[\d+:\d+\], s\[64:65\]")
+# the 16-step body (FS_FAST_LOOP_FD16): entries in s[36:67] with s[66:67] an in/out operand, block bounds in s[72:75] with s75 in/out
+SCRATCH16 = {("v", i) for i in (56, 57, 58, 59, 61, 62)} | {("s", i) for i in list(range(36, 66)) + [72, 73, 74]}
+NAMED = {("v", i) for i in range(48, 63)} | {("s", i) for i in range(36, 76)}
+FIRST = re.compile(r"^v_pk_fma_f32 v\[56:57\], v\[48:49\], v\[\d+:\d+\], s\[6(4:65|6:67)\]")
 
 
 def successors(instrs):
@@ -67,7 +69,7 @@ def defs_uses(ins):
 
 
 def regions(instrs):
-    """[(first index, last index)] of the hand-scheduled loops of a function."""
+    """[(first index, last index, scratch set)] of the hand-scheduled loops of a function."""
     out = []
     i = 0
     while i < len(instrs):
@@ -91,7 +93,7 @@ def regions(instrs):
                         last_target = max(last_target, t)
                 if ins["op"] == "s_waitcnt" and "lgkmcnt(0)" in ins["ops"] and b >= last_target and b - i > 60:
                     break
-            out.append((a, b))
+            out.append((a, b, SCRATCH16 if "s[66:67]" in instrs[i]["text"] else SCRATCH))
             i = b + 1
         else:
             i += 1
@@ -107,10 +109,11 @@ def check_function(name, instrs):
     du = [defs_uses(ins) for ins in instrs]
     # the loop's own reads of its scratch registers are not uses the surrounding code is responsible for (e.g. `s_mov eb, s62`
     # at the loop's head reads what the previous body loaded -- or, on entry, a value nothing depends on)
-    inside = set()
-    for a, b in regs:
-        inside |= set(range(a, b + 1))
-    du = [(d, (u - SCRATCH) if i in inside else u) for i, (d, u) in enumerate(du)]
+    inside = {}
+    for a, b, scr in regs:
+        for i in range(a, b + 1):
+            inside[i] = scr
+    du = [(d, (u - inside[i]) if i in inside else u) for i, (d, u) in enumerate(du)]
     live_in = [set() for _ in instrs]
     changed = True
     while changed:  # backward liveness, to a fixed point
@@ -124,14 +127,14 @@ def check_function(name, instrs):
             if new != live_in[i]:
                 live_in[i] = new
                 changed = True
-    for a, b in regs:
+    for a, b, scr in regs:
         # exits of the region: successors outside [a, b]
         live_out = set()
         for i in range(a, b + 1):
             for j in succ[i]:
                 if j < a or j > b:
                     live_out |= live_in[j]
-        bad = sorted(live_out & SCRATCH)
+        bad = sorted(live_out & scr)
         if bad:
             findings.append((name, "scratch registers of the hand-scheduled loop live on its exit", bad))
         written = set()
