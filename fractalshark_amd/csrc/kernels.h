@@ -376,8 +376,11 @@ void fsk_scan_u32(const uint32_t *in, uint32_t *out, uint32_t n, hipStream_t s);
 template <class F> void fsk_la_first(bool stage0, const void *chebv, const void *mm, uint32_t limit, uint32_t *out, hipStream_t s);
 template <class F>
 void fsk_la_next(bool stage0, const void *chebv, const void *mm, const uint32_t *pos, uint32_t limit, uint32_t period,
-                 uint32_t *next, hipStream_t s);
+                 uint32_t *next, uint32_t *reach, uint32_t x_start, hipStream_t s); // also writes the chain's start mark into reach
+template <class F> void fsk_la_stage_info(const void *P, const uint32_t *steps, const uint32_t *pos, uint32_t *out, hipStream_t s);
 void fsk_la_reach(const uint32_t *jin, uint32_t *jout, uint32_t *reach, uint32_t nstates, hipStream_t s);
+void fsk_la_reach_all(const uint32_t *next, uint32_t *bufB, uint32_t *bufC, uint32_t *reach, uint32_t nstates, uint32_t rounds,
+                      hipStream_t s); // every round in one launch (one workgroup): stages of at most 2^16 states
 template <class F>
 void fsk_la_records(bool stage0, const void *zref, const void *P, const uint32_t *pos, const uint32_t *next,
                     const uint32_t *reach, const uint32_t *rank, uint32_t limit, uint32_t rank_offset, void *out, hipStream_t s);

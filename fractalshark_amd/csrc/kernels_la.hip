@@ -81,17 +81,17 @@ __global__ void __launch_bounds__(1024) k_scan_u32(const uint32_t *in, uint32_t 
         s += in[i];
     part[t] = s;
     __syncthreads();
-    if (t == 0) {
-        uint32_t run = 0;
-        for (uint32_t k = 0; k < 1024u; k++) {
-            const uint32_t v = part[k];
-            part[k] = run;
-            run += v;
-        }
-        out[n] = run;
+    // inclusive scan of the 1024 partials in ten rounds (round 4: lane 0 alone took 1024 dependent LDS round trips here --
+    // 10 to 57 us of every stage of fs_build_la)
+    for (uint32_t off = 1; off < 1024u; off <<= 1) {
+        const uint32_t v = t >= off ? part[t - off] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
     }
-    __syncthreads();
-    uint32_t run = part[t];
+    if (t == 1023u)
+        out[n] = part[t];
+    uint32_t run = t == 0u ? 0u : part[t - 1u];
     for (uint32_t i = a; i < b; i++) {
         const uint32_t v = in[i];
         out[i] = run;
@@ -133,13 +133,22 @@ __global__ void __launch_bounds__(1024) k_la_first(const hreal<F> *chebv, const 
     if (t == 0)
         found = kTerm;
     __syncthreads();
-    if (t == 0) {
-        hreal<F> run = start_min<F, kStage0>(chebv, mm, 0u, 1u);
-        for (uint32_t k = 0; k < 1024u; k++) {
-            const hreal<F> v = part[k];
-            part[k] = run;
-            run = hr_min_pos(v, run);
-        }
+    // exclusive prefix minimum over the 1024 chunk minima, seeded with the record's start value: ten rounds instead of lane 0
+    // walking all of them (round 4: that walk was 58 us of every stage).  min over a total order: associative, and equal
+    // values are identical, so the order of the operands changes nothing
+    for (uint32_t off = 1; off < 1024u; off <<= 1) {
+        hreal<F> v = part[t];
+        if (t >= off)
+            v = hr_min_pos(part[t - off], v);
+        __syncthreads();
+        part[t] = v;
+        __syncthreads();
+    }
+    {
+        const hreal<F> start = start_min<F, kStage0>(chebv, mm, 0u, 1u);
+        const hreal<F> excl = t == 0u ? start : hr_min_pos(part[t - 1u], start);
+        __syncthreads();
+        part[t] = excl;
     }
     __syncthreads();
     hreal<F> run = part[t];
@@ -167,14 +176,26 @@ __global__ void __launch_bounds__(1024) k_la_first(const hreal<F> *chebv, const 
     }
 }
 
+// What the host decides a higher stage's period from, next to the first detection (out[0] = jd, out[1] = flavour): the first
+// element's step length, the orbit position of element jd and whether its record's LAThreshold is zero (LAReference.cpp:
+// 811-852) -- one read-back instead of three.
+template <class F> __global__ void k_la_stage_info(const LAInfo<F> *P, const uint32_t *steps, const uint32_t *pos, uint32_t *out)
+{
+    const uint32_t jd = out[0];
+    out[2] = steps[0];
+    out[3] = jd != kTerm ? pos[jd] : 0u;
+    out[4] = jd != kTerm && P[jd].LAThreshold.m == F(0) ? 1u : 0u;
+}
+
 // ---- 3. next(b, f) for every state; shift = the stage's in-loop detection threshold exponent (-6 stage 0, -3 above)
 template <class F, bool kStage0>
 __global__ void k_la_next(const hreal<F> *chebv, const hreal<F> *mm, const uint32_t *pos, uint32_t limit, uint32_t period,
-                          int shift, uint32_t *next)
+                          int shift, uint32_t *next, uint32_t *reach, uint32_t x_start)
 {
     const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= 2u * limit)
         return;
+    reach[x] = x == x_start ? 1u : 0u; // the chain's start mark (round 4: was a memset and a 4-byte upload per stage)
     const uint32_t b = x >> 1, f = x & 1u;
     if (f && b + 1u >= limit) {
         next[x] = kTerm; // never reached: flavour 1 needs the element after the boundary
@@ -208,6 +229,28 @@ __global__ void k_la_reach(const uint32_t *jin, uint32_t *jout, uint32_t *reach,
     if (reach[x] && j != kTerm)
         reach[j] = 1u; // idempotent stores from several lanes
     jout[x] = j == kTerm ? kTerm : jin[j];
+}
+
+// The same for a stage of at most 2^16 states, all rounds in ONE launch (round 4): one workgroup walks the states in strides,
+// a barrier between rounds (a workgroup-scope fence: the waves of a workgroup share their CU's L1, what one round stored is
+// what the next one loads).  The launches of the per-round form -- fourteen for View 5's first stage, ~9 us apart -- were
+// most of what fs_build_la took on a small orbit.  Returns with the final jump table in whichever buffer the last round wrote.
+__global__ void __launch_bounds__(1024) k_la_reach_all(const uint32_t *next, uint32_t *bufB, uint32_t *bufC, uint32_t *reach,
+                                                       uint32_t nstates, uint32_t rounds)
+{
+    const uint32_t *jin = next;
+    uint32_t *jout = bufB;
+    for (uint32_t r = 0; r < rounds; r++) {
+        for (uint32_t x = threadIdx.x; x < nstates; x += 1024u) {
+            const uint32_t j = jin[x];
+            if (reach[x] && j != kTerm)
+                reach[j] = 1u;
+            jout[x] = j == kTerm ? kTerm : jin[j];
+        }
+        __syncthreads();
+        jin = jout;
+        jout = jout == bufB ? bufC : bufB;
+    }
 }
 
 // ---- 5. records
@@ -367,18 +410,28 @@ template <class F> void fsk_la_first(bool stage0, const void *chebv, const void 
 }
 template <class F>
 void fsk_la_next(bool stage0, const void *chebv, const void *mm, const uint32_t *pos, uint32_t limit, uint32_t period,
-                 uint32_t *next, hipStream_t s)
+                 uint32_t *next, uint32_t *reach, uint32_t x_start, hipStream_t s)
 {
     if (stage0)
         hipLaunchKernelGGL((k_la_next<F, true>), dim3(nblk(2u * limit)), dim3(256), 0, s, (const hreal<F> *)chebv,
-                           (const hreal<F> *)mm, pos, limit, period, LAParams{}.stage0PeriodDetectionThreshold2Exp, next);
+                           (const hreal<F> *)mm, pos, limit, period, LAParams{}.stage0PeriodDetectionThreshold2Exp, next, reach,
+                           x_start);
     else
         hipLaunchKernelGGL((k_la_next<F, false>), dim3(nblk(2u * limit)), dim3(256), 0, s, (const hreal<F> *)chebv,
-                           (const hreal<F> *)mm, pos, limit, period, LAParams{}.periodDetectionThreshold2Exp, next);
+                           (const hreal<F> *)mm, pos, limit, period, LAParams{}.periodDetectionThreshold2Exp, next, reach, x_start);
+}
+template <class F> void fsk_la_stage_info(const void *P, const uint32_t *steps, const uint32_t *pos, uint32_t *out, hipStream_t s)
+{
+    hipLaunchKernelGGL((k_la_stage_info<F>), dim3(1), dim3(1), 0, s, (const LAInfo<F> *)P, steps, pos, out);
 }
 void fsk_la_reach(const uint32_t *jin, uint32_t *jout, uint32_t *reach, uint32_t nstates, hipStream_t s)
 {
     hipLaunchKernelGGL(k_la_reach, dim3(nblk(nstates)), dim3(256), 0, s, jin, jout, reach, nstates);
+}
+void fsk_la_reach_all(const uint32_t *next, uint32_t *bufB, uint32_t *bufC, uint32_t *reach, uint32_t nstates, uint32_t rounds,
+                      hipStream_t s)
+{
+    hipLaunchKernelGGL(k_la_reach_all, dim3(1), dim3(1024), 0, s, next, bufB, bufC, reach, nstates, rounds);
 }
 template <class F>
 void fsk_la_records(bool stage0, const void *zref, const void *P, const uint32_t *pos, const uint32_t *next,
@@ -426,7 +479,8 @@ void fsk_la_pack(bool is64, const void *in, void *out, uint32_t n, hipStream_t s
     template void fsk_la_src_stage<F>(const void *, uint32_t, void *, void *, uint32_t *, hipStream_t);             \
     template void fsk_la_first<F>(bool, const void *, const void *, uint32_t, uint32_t *, hipStream_t);             \
     template void fsk_la_next<F>(bool, const void *, const void *, const uint32_t *, uint32_t, uint32_t, uint32_t *, \
-                                 hipStream_t);                                                                      \
+                                 uint32_t *, uint32_t, hipStream_t);                                                \
+    template void fsk_la_stage_info<F>(const void *, const uint32_t *, const uint32_t *, uint32_t *, hipStream_t);  \
     template void fsk_la_records<F>(bool, const void *, const void *, const uint32_t *, const uint32_t *,            \
                                     const uint32_t *, const uint32_t *, uint32_t, uint32_t, void *, hipStream_t);   \
     template void fsk_la_one_record<F>(bool, const void *, const void *, uint32_t, uint32_t, void *, hipStream_t);  \

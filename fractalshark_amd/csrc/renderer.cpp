@@ -1600,12 +1600,9 @@ template <class F> uint32_t build_la(fs_renderer *r, const void *max_radius, int
     uint32_t la_size = 0;
     uint32_t h[4];
 
-    // isZCoeffZero of the first step (LAReference.cpp:52-56)
-    fsk_la_tail<F>(zref, maxRef, nullptr, d_small, s);
-    FS_TRY(hipMemcpyAsync(h, d_small, 4, hipMemcpyDeviceToHost, s));
-    FS_TRY(hipStreamSynchronize(s));
-    if (h[0])
-        return FS_ERR_UNSUPPORTED;
+    // isZCoeffZero of the first step (LAReference.cpp:52-56): word 8 of the scratch words, read back with stage 0's first
+    // detection below (one round trip less)
+    fsk_la_tail<F>(zref, maxRef, nullptr, d_small + 8, s);
 
     // one stage: elements 0 .. limit-1 (+ the sentinel element `limit`), period / first record decided by the caller
     auto run_chain = [&](bool stage0, const Rec *P, uint32_t limit, uint32_t period, bool have_first, uint32_t first_end,
@@ -1621,16 +1618,23 @@ template <class F> uint32_t build_la(fs_renderer *r, const void *max_radius, int
         }
         n_records = offset;
         if (x_start != kLaTerm && (x_start >> 1) < limit) {
-            fsk_la_next<F>(stage0, chebv.p, mm.p, pos.as<uint32_t>(), limit, period, nextA.as<uint32_t>(), s);
-            FS_TRY(hipMemsetAsync(reach.p, 0, 4u * nstates, s));
-            const uint32_t one = 1;
-            FS_TRY(hipMemcpyAsync(reach.as<uint32_t>() + x_start, &one, 4, hipMemcpyHostToDevice, s));
+            fsk_la_next<F>(stage0, chebv.p, mm.p, pos.as<uint32_t>(), limit, period, nextA.as<uint32_t>(), reach.as<uint32_t>(),
+                           x_start, s); // (also zeroes reach and marks the chain's start)
             // jump tables ping-pong between nextB and nextC; the original next stays in nextA for the record kernel
-            uint32_t *jin = nextA.as<uint32_t>(), *jout = nextB.as<uint32_t>();
-            for (uint32_t span = 1; span < limit + 1u; span <<= 1) {
-                fsk_la_reach(jin, jout, reach.as<uint32_t>(), nstates, s);
-                jin = jout;
-                jout = jout == nextB.as<uint32_t>() ? nextC.as<uint32_t>() : nextB.as<uint32_t>();
+            if (nstates <= (1u << 16)) {
+                // a small stage: every round in one launch (the launches were most of the time on a small orbit)
+                uint32_t rounds = 0;
+                for (uint32_t span = 1; span < limit + 1u; span <<= 1)
+                    rounds++;
+                fsk_la_reach_all(nextA.as<uint32_t>(), nextB.as<uint32_t>(), nextC.as<uint32_t>(), reach.as<uint32_t>(), nstates,
+                                 rounds, s);
+            } else {
+                uint32_t *jin = nextA.as<uint32_t>(), *jout = nextB.as<uint32_t>();
+                for (uint32_t span = 1; span < limit + 1u; span <<= 1) {
+                    fsk_la_reach(jin, jout, reach.as<uint32_t>(), nstates, s);
+                    jin = jout;
+                    jout = jout == nextB.as<uint32_t>() ? nextC.as<uint32_t>() : nextB.as<uint32_t>();
+                }
             }
             fsk_scan_u32(reach.as<uint32_t>(), rank.as<uint32_t>(), nstates, s);
             FS_TRY(hipMemcpyAsync(h, rank.as<uint32_t>() + nstates, 4, hipMemcpyDeviceToHost, s));
@@ -1649,8 +1653,12 @@ template <class F> uint32_t build_la(fs_renderer *r, const void *max_radius, int
         const uint32_t limit = maxRef;
         fsk_la_src_orbit<F>(zref, maxRef + 1u, chebv.p, s);
         fsk_la_first<F>(true, chebv.p, mm.p, limit, d_small, s);
-        FS_TRY(hipMemcpyAsync(h, d_small, 8, hipMemcpyDeviceToHost, s));
+        uint32_t h0[9];
+        FS_TRY(hipMemcpyAsync(h0, d_small, sizeof(h0), hipMemcpyDeviceToHost, s));
         FS_TRY(hipStreamSynchronize(s));
+        if (h0[8])
+            return FS_ERR_UNSUPPORTED; // the first step's ZCoeff is zero
+        h[0] = h0[0], h[1] = h0[1];
         uint32_t Period = h[0] == kLaTerm ? 0u : h[0];
         bool have_first = false;
         uint32_t x_start;
@@ -1684,22 +1692,19 @@ template <class F> uint32_t build_la(fs_renderer *r, const void *max_radius, int
         fsk_la_src_stage<F>(P, Count + 1u, chebv.p, mm.p, steps.as<uint32_t>(), s);
         fsk_scan_u32(steps.as<uint32_t>(), pos.as<uint32_t>(), Count + 1u, s);
         fsk_la_first<F>(false, chebv.p, mm.p, Count, d_small, s);
-        FS_TRY(hipMemcpyAsync(h, d_small, 8, hipMemcpyDeviceToHost, s));
+        // everything the period decision reads, in one read-back (round 4: three round trips per stage before)
+        fsk_la_stage_info<F>(P, steps.as<uint32_t>(), pos.as<uint32_t>(), d_small, s);
+        uint32_t hs[5];
+        FS_TRY(hipMemcpyAsync(hs, d_small, sizeof(hs), hipMemcpyDeviceToHost, s));
         FS_TRY(hipStreamSynchronize(s));
-        uint32_t jd = h[0], fd = h[1];
-        uint32_t step0 = 0, posjd = 0;
-        FS_TRY(hipMemcpyAsync(&step0, steps.as<uint32_t>(), 4, hipMemcpyDeviceToHost, s));
-        FS_TRY(hipStreamSynchronize(s));
+        uint32_t jd = hs[0], fd = hs[1];
+        const uint32_t step0 = hs[2];
         uint32_t Period = 0;
         if (jd != kLaTerm) {
-            Rec pj;
-            FS_TRY(hipMemcpyAsync(&pj, P + jd, sizeof(Rec), hipMemcpyDeviceToHost, s));
-            FS_TRY(hipMemcpyAsync(&posjd, pos.as<uint32_t>() + jd, 4, hipMemcpyDeviceToHost, s));
-            FS_TRY(hipStreamSynchronize(s));
-            if (pj.LAThreshold.m == F(0)) // isLAThresholdZero: the prologue breaks without a period (:815-817)
+            if (hs[4]) // isLAThresholdZero: the prologue breaks without a period (:815-817)
                 jd = kLaTerm;
             else
-                Period = posjd;
+                Period = hs[3];
         }
         stages.push_back(fs_la_stage_u32{la_size, 0u});
         const double NthRoot = std::round(std::log2((double)maxRef) / periodDivisor);
@@ -1745,16 +1750,14 @@ template <class F> uint32_t build_la(fs_renderer *r, const void *max_radius, int
     FS_TRY(hipMemcpyAsync(stage_idx.p, idx.data(), 4u * stage_count, hipMemcpyHostToDevice, s));
     fsk_la_at<F>(d_table, stage_idx.as<uint32_t>(), stage_count, max_radius, use_small_exponents, atbuf.p, d_small, s);
     fs::la::ATInfoT<F> at;
-    FS_TRY(hipMemcpyAsync(&at, atbuf.p, sizeof(at), hipMemcpyDeviceToHost, s));
-    FS_TRY(hipMemcpyAsync(h, d_small, 4, hipMemcpyDeviceToHost, s));
-    FS_TRY(hipStreamSynchronize(s));
-
     r->la_ok = false;
     const size_t rec_bytes = sizeof(F) == 4 ? sizeof(fs_la_hdr32_u32) : sizeof(fs_la_hdr64_u32);
     FS_TRY(la_reserve(r, rec_bytes * la_size, sizeof(fs_la_stage_u32) * stage_count));
     fsk_la_pack(sizeof(F) == 8, d_table, r->las, la_size, s);
     FS_TRY(hipMemcpyAsync(r->stages, stages.data(), sizeof(fs_la_stage_u32) * stage_count, hipMemcpyHostToDevice, s));
-    FS_TRY(hipStreamSynchronize(s));
+    FS_TRY(hipMemcpyAsync(&at, atbuf.p, sizeof(at), hipMemcpyDeviceToHost, s));
+    FS_TRY(hipMemcpyAsync(h, d_small, 4, hipMemcpyDeviceToHost, s));
+    FS_TRY(hipStreamSynchronize(s)); // (one round trip for the AT record, its flag, and the host temporaries above)
     FS_TRY(hipGetLastError());
     r->n_las = la_size;
     r->n_stages = stage_count;
