@@ -377,13 +377,17 @@ template <class F> void fsk_la_first(bool stage0, const void *chebv, const void 
 template <class F>
 void fsk_la_next(bool stage0, const void *chebv, const void *mm, const uint32_t *pos, uint32_t limit, uint32_t period,
                  uint32_t *next, uint32_t *reach, uint32_t x_start, hipStream_t s); // also writes the chain's start mark into reach
-template <class F> void fsk_la_stage_info(const void *P, const uint32_t *steps, const uint32_t *pos, uint32_t *out, hipStream_t s);
 void fsk_la_reach(const uint32_t *jin, uint32_t *jout, uint32_t *reach, uint32_t nstates, hipStream_t s);
 void fsk_la_reach_all(const uint32_t *next, uint32_t *bufB, uint32_t *bufC, uint32_t *reach, uint32_t nstates, uint32_t rounds,
                       hipStream_t s); // every round in one launch (one workgroup): stages of at most 2^16 states
 template <class F>
 void fsk_la_records(bool stage0, const void *zref, const void *P, const uint32_t *pos, const uint32_t *next,
-                    const uint32_t *reach, const uint32_t *rank, uint32_t limit, uint32_t rank_offset, void *out, hipStream_t s);
+                    const uint32_t *reach, const uint32_t *rank, uint32_t limit, uint32_t rank_offset, void *out, void *tail_out,
+                    uint32_t max_ref, hipStream_t s); // tail_out: the stage's tail record in the same launch (or null)
+// a higher stage's prologue in one launch: scan of the step lengths, first detection, the words the period decision reads
+template <class F>
+void fsk_la_stage_prologue(const void *P, const void *chebv, const void *mm, const uint32_t *steps, uint32_t *pos, uint32_t count,
+                           uint32_t *out, hipStream_t s);
 template <class F>
 void fsk_la_one_record(bool stage0, const void *zref, const void *P, uint32_t e, uint32_t step_length, void *out, hipStream_t s);
 template <class F> void fsk_la_tail(const void *zref, uint32_t max_ref, void *out, uint32_t *zcoeff_zero, hipStream_t s);

@@ -71,9 +71,8 @@ __global__ void k_la_src_stage(const LAInfo<F> *P, uint32_t n, hreal<F> *chebv, 
 }
 
 // exclusive prefix sum, one workgroup of 1024 lanes over contiguous chunks; out[n] = total
-__global__ void __launch_bounds__(1024) k_scan_u32(const uint32_t *in, uint32_t *out, uint32_t n)
+__device__ __forceinline__ void scan_u32_body(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *part)
 {
-    __shared__ uint32_t part[1024];
     const uint32_t t = threadIdx.x, chunk = (n + 1023u) / 1024u;
     const uint32_t a = t * chunk, b = a + chunk < n ? a + chunk : n;
     uint32_t s = 0;
@@ -98,6 +97,11 @@ __global__ void __launch_bounds__(1024) k_scan_u32(const uint32_t *in, uint32_t 
         run += v;
     }
 }
+__global__ void __launch_bounds__(1024) k_scan_u32(const uint32_t *in, uint32_t *out, uint32_t n)
+{
+    __shared__ uint32_t part[1024];
+    scan_u32_body(in, out, n, part);
+}
 
 // What one element contributes to the running minimum once it has been folded into the record.
 template <class F, bool kStage0> __device__ __forceinline__ hreal<F> contrib(const hreal<F> *chebv, const hreal<F> *mm, uint32_t j)
@@ -118,10 +122,9 @@ template <class F, bool kStage0> __device__ __forceinline__ hreal<F> start_min(c
 // ---- 2. first detection of the prologue: the uncapped scan from (0, 1), test elements 2 .. limit-1.
 // out[0] = index of the first detection (kTerm if none), out[1] = the flavour that follows it by the DetectPeriod rule.
 template <class F, bool kStage0>
-__global__ void __launch_bounds__(1024) k_la_first(const hreal<F> *chebv, const hreal<F> *mm, uint32_t limit, int shift, uint32_t *out)
+__device__ __forceinline__ void la_first_body(const hreal<F> *chebv, const hreal<F> *mm, uint32_t limit, int shift, uint32_t *out,
+                                              hreal<F> *part, uint32_t &found)
 {
-    __shared__ hreal<F> part[1024];
-    __shared__ uint32_t found;
     const uint32_t t = threadIdx.x;
     const uint32_t n = limit > 2u ? limit - 2u : 0u, chunk = (n + 1023u) / 1024u;
     const uint32_t a = 2u + t * chunk, b = (a + chunk < limit ? a + chunk : limit);
@@ -175,16 +178,35 @@ __global__ void __launch_bounds__(1024) k_la_first(const hreal<F> *chebv, const 
         out[1] = (detect || found + 1u >= limit) ? 0u : 1u;
     }
 }
-
-// What the host decides a higher stage's period from, next to the first detection (out[0] = jd, out[1] = flavour): the first
-// element's step length, the orbit position of element jd and whether its record's LAThreshold is zero (LAReference.cpp:
-// 811-852) -- one read-back instead of three.
-template <class F> __global__ void k_la_stage_info(const LAInfo<F> *P, const uint32_t *steps, const uint32_t *pos, uint32_t *out)
+template <class F, bool kStage0>
+__global__ void __launch_bounds__(1024) k_la_first(const hreal<F> *chebv, const hreal<F> *mm, uint32_t limit, int shift, uint32_t *out)
 {
-    const uint32_t jd = out[0];
-    out[2] = steps[0];
-    out[3] = jd != kTerm ? pos[jd] : 0u;
-    out[4] = jd != kTerm && P[jd].LAThreshold.m == F(0) ? 1u : 0u;
+    __shared__ hreal<F> part[1024];
+    __shared__ uint32_t found;
+    la_first_body<F, kStage0>(chebv, mm, limit, shift, out, part, found);
+}
+// A higher stage's prologue in ONE launch (round 4): the exclusive scan of the step lengths (orbit positions), the first
+// detection, and the words the host decides the stage's period from next to it (the first element's step length, the orbit
+// position of the detecting element, whether its record's LAThreshold is zero: LAReference.cpp:811-852) -- three launches and
+// three read-backs before.
+template <class F>
+__global__ void __launch_bounds__(1024) k_la_stage_prologue(const LAInfo<F> *P, const hreal<F> *chebv, const hreal<F> *mm,
+                                                            const uint32_t *steps, uint32_t *pos, uint32_t count, int shift,
+                                                            uint32_t *out)
+{
+    __shared__ hreal<F> part[1024];
+    __shared__ uint32_t upart[1024];
+    __shared__ uint32_t found;
+    scan_u32_body(steps, pos, count + 1u, upart);
+    __syncthreads();
+    la_first_body<F, false>(chebv, mm, count, shift, out, part, found);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t jd = found;
+        out[2] = steps[0];
+        out[3] = jd != kTerm ? pos[jd] : 0u;
+        out[4] = jd != kTerm && P[jd].LAThreshold.m == F(0) ? 1u : 0u;
+    }
 }
 
 // ---- 3. next(b, f) for every state; shift = the stage's in-loop detection threshold exponent (-6 stage 0, -3 above)
@@ -257,12 +279,14 @@ __global__ void __launch_bounds__(1024) k_la_reach_all(const uint32_t *next, uin
 template <class F, bool kStage0>
 __global__ void k_la_records(const void *zref, const LAInfo<F> *P, const uint32_t *pos, const uint32_t *next,
                              const uint32_t *reach, const uint32_t *rank, uint32_t limit, uint32_t nstates,
-                             uint32_t rank_offset, LAInfo<F> *out)
+                             uint32_t rank_offset, LAInfo<F> *out, LAInfo<F> *tail_out, uint32_t max_ref)
 {
     const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    const LAParams p{};
+    if (x == 0u && tail_out) // the stage's tail record (k_la_tail), in the same launch
+        *tail_out = la_init<F>(p, z_at<F>(zref, max_ref));
     if (x >= nstates || !reach[x])
         return;
-    const LAParams p{};
     const uint32_t b = x >> 1;
     const uint32_t e = next[x] == kTerm ? limit : next[x] >> 1;
     LAInfo<F> LA;
@@ -420,10 +444,6 @@ void fsk_la_next(bool stage0, const void *chebv, const void *mm, const uint32_t 
         hipLaunchKernelGGL((k_la_next<F, false>), dim3(nblk(2u * limit)), dim3(256), 0, s, (const hreal<F> *)chebv,
                            (const hreal<F> *)mm, pos, limit, period, LAParams{}.periodDetectionThreshold2Exp, next, reach, x_start);
 }
-template <class F> void fsk_la_stage_info(const void *P, const uint32_t *steps, const uint32_t *pos, uint32_t *out, hipStream_t s)
-{
-    hipLaunchKernelGGL((k_la_stage_info<F>), dim3(1), dim3(1), 0, s, (const LAInfo<F> *)P, steps, pos, out);
-}
 void fsk_la_reach(const uint32_t *jin, uint32_t *jout, uint32_t *reach, uint32_t nstates, hipStream_t s)
 {
     hipLaunchKernelGGL(k_la_reach, dim3(nblk(nstates)), dim3(256), 0, s, jin, jout, reach, nstates);
@@ -435,15 +455,23 @@ void fsk_la_reach_all(const uint32_t *next, uint32_t *bufB, uint32_t *bufC, uint
 }
 template <class F>
 void fsk_la_records(bool stage0, const void *zref, const void *P, const uint32_t *pos, const uint32_t *next,
-                    const uint32_t *reach, const uint32_t *rank, uint32_t limit, uint32_t rank_offset, void *out, hipStream_t s)
+                    const uint32_t *reach, const uint32_t *rank, uint32_t limit, uint32_t rank_offset, void *out, void *tail_out,
+                    uint32_t max_ref, hipStream_t s)
 {
     const uint32_t nstates = 2u * limit;
     if (stage0)
         hipLaunchKernelGGL((k_la_records<F, true>), dim3(nblk(nstates)), dim3(256), 0, s, zref, (const LAInfo<F> *)P, pos,
-                           next, reach, rank, limit, nstates, rank_offset, (LAInfo<F> *)out);
+                           next, reach, rank, limit, nstates, rank_offset, (LAInfo<F> *)out, (LAInfo<F> *)tail_out, max_ref);
     else
         hipLaunchKernelGGL((k_la_records<F, false>), dim3(nblk(nstates)), dim3(256), 0, s, zref, (const LAInfo<F> *)P, pos,
-                           next, reach, rank, limit, nstates, rank_offset, (LAInfo<F> *)out);
+                           next, reach, rank, limit, nstates, rank_offset, (LAInfo<F> *)out, (LAInfo<F> *)tail_out, max_ref);
+}
+template <class F>
+void fsk_la_stage_prologue(const void *P, const void *chebv, const void *mm, const uint32_t *steps, uint32_t *pos, uint32_t count,
+                           uint32_t *out, hipStream_t s)
+{
+    hipLaunchKernelGGL((k_la_stage_prologue<F>), dim3(1), dim3(1024), 0, s, (const LAInfo<F> *)P, (const hreal<F> *)chebv,
+                       (const hreal<F> *)mm, steps, pos, count, LAParams{}.periodDetectionThreshold2Exp, out);
 }
 template <class F>
 void fsk_la_one_record(bool stage0, const void *zref, const void *P, uint32_t e, uint32_t step_length, void *out, hipStream_t s)
@@ -480,9 +508,11 @@ void fsk_la_pack(bool is64, const void *in, void *out, uint32_t n, hipStream_t s
     template void fsk_la_first<F>(bool, const void *, const void *, uint32_t, uint32_t *, hipStream_t);             \
     template void fsk_la_next<F>(bool, const void *, const void *, const uint32_t *, uint32_t, uint32_t, uint32_t *, \
                                  uint32_t *, uint32_t, hipStream_t);                                                \
-    template void fsk_la_stage_info<F>(const void *, const uint32_t *, const uint32_t *, uint32_t *, hipStream_t);  \
     template void fsk_la_records<F>(bool, const void *, const void *, const uint32_t *, const uint32_t *,            \
-                                    const uint32_t *, const uint32_t *, uint32_t, uint32_t, void *, hipStream_t);   \
+                                    const uint32_t *, const uint32_t *, uint32_t, uint32_t, void *, void *, uint32_t,  \
+                                    hipStream_t);                                                                   \
+    template void fsk_la_stage_prologue<F>(const void *, const void *, const void *, const uint32_t *, uint32_t *,   \
+                                           uint32_t, uint32_t *, hipStream_t);                                      \
     template void fsk_la_one_record<F>(bool, const void *, const void *, uint32_t, uint32_t, void *, hipStream_t);  \
     template void fsk_la_tail<F>(const void *, uint32_t, void *, uint32_t *, hipStream_t);                          \
     template void fsk_la_at<F>(const void *, const uint32_t *, uint32_t, const void *, int, void *, uint32_t *, hipStream_t);

@@ -1605,9 +1605,11 @@ template <class F> uint32_t build_la(fs_renderer *r, const void *max_radius, int
     fsk_la_tail<F>(zref, maxRef, nullptr, d_small + 8, s);
 
     // one stage: elements 0 .. limit-1 (+ the sentinel element `limit`), period / first record decided by the caller
+    bool tail_written = false; // run_chain wrote the stage's tail record with its records
     auto run_chain = [&](bool stage0, const Rec *P, uint32_t limit, uint32_t period, bool have_first, uint32_t first_end,
                          uint32_t first_step, uint32_t x_start, uint32_t &n_records) -> uint32_t {
         const uint32_t nstates = 2u * limit; // limit <= maxRef < 2^31 - 1
+        tail_written = false;
         uint32_t offset = 0;
         // room for this stage's first record and its tail record before anything is written
         if ((size_t)la_size + 2u > cap_recs)
@@ -1641,9 +1643,11 @@ template <class F> uint32_t build_la(fs_renderer *r, const void *max_radius, int
             FS_TRY(hipStreamSynchronize(s));
             if ((size_t)la_size + offset + h[0] + 2u > cap_recs)
                 return FS_ERR_7;
+            // (the stage's tail record goes out with the same launch)
             fsk_la_records<F>(stage0, zref, P, pos.as<uint32_t>(), nextA.as<uint32_t>(), reach.as<uint32_t>(),
-                              rank.as<uint32_t>(), limit, offset, d_table + la_size, s);
+                              rank.as<uint32_t>(), limit, offset, d_table + la_size, d_table + la_size + offset + h[0], maxRef, s);
             n_records = offset + h[0];
+            tail_written = true;
         }
         return (uint32_t)hipGetLastError();
     };
@@ -1678,7 +1682,8 @@ template <class F> uint32_t build_la(fs_renderer *r, const void *max_radius, int
             return e;
         stages[0].MacroItCount = n;
         la_size = n;
-        fsk_la_tail<F>(zref, maxRef, d_table + la_size, nullptr, s);
+        if (!tail_written)
+            fsk_la_tail<F>(zref, maxRef, d_table + la_size, nullptr, s);
         la_size++;
     }
 
@@ -1690,10 +1695,9 @@ template <class F> uint32_t build_la(fs_renderer *r, const void *max_radius, int
         const uint32_t PrevIdx = stages[PrevStage].LAIndex, Count = stages[PrevStage].MacroItCount;
         const Rec *P = d_table + PrevIdx;
         fsk_la_src_stage<F>(P, Count + 1u, chebv.p, mm.p, steps.as<uint32_t>(), s);
-        fsk_scan_u32(steps.as<uint32_t>(), pos.as<uint32_t>(), Count + 1u, s);
-        fsk_la_first<F>(false, chebv.p, mm.p, Count, d_small, s);
-        // everything the period decision reads, in one read-back (round 4: three round trips per stage before)
-        fsk_la_stage_info<F>(P, steps.as<uint32_t>(), pos.as<uint32_t>(), d_small, s);
+        // scan of the step lengths, first detection and everything the period decision reads: one launch, one read-back
+        // (round 4: three launches and three round trips per stage before)
+        fsk_la_stage_prologue<F>(P, chebv.p, mm.p, steps.as<uint32_t>(), pos.as<uint32_t>(), Count, d_small, s);
         uint32_t hs[5];
         FS_TRY(hipMemcpyAsync(hs, d_small, sizeof(hs), hipMemcpyDeviceToHost, s));
         FS_TRY(hipStreamSynchronize(s));
@@ -1736,7 +1740,8 @@ template <class F> uint32_t build_la(fs_renderer *r, const void *max_radius, int
             return e;
         stages[CurrentStage].MacroItCount = last_stage ? 1u : n;
         la_size += n;
-        fsk_la_tail<F>(zref, maxRef, d_table + la_size, nullptr, s);
+        if (!tail_written)
+            fsk_la_tail<F>(zref, maxRef, d_table + la_size, nullptr, s);
         la_size++;
         if (last_stage)
             break;
