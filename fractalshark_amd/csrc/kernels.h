@@ -378,6 +378,7 @@ template <class F>
 void fsk_la_next(bool stage0, const void *chebv, const void *mm, const uint32_t *pos, uint32_t limit, uint32_t period,
                  uint32_t *next, uint32_t *reach, uint32_t x_start, hipStream_t s); // also writes the chain's start mark into reach
 void fsk_la_reach(const uint32_t *jin, uint32_t *jout, uint32_t *reach, uint32_t nstates, hipStream_t s);
+void fsk_la_mail(const uint32_t *src, uint32_t n, uint32_t *mail, uint32_t seq, hipStream_t s); // n <= 31 words -> host mailbox, then seq in word 31
 void fsk_la_reach_all(const uint32_t *next, uint32_t *bufB, uint32_t *bufC, uint32_t *reach, uint32_t nstates, uint32_t rounds,
                       hipStream_t s); // every round in one launch (one workgroup): stages of at most 2^16 states
 template <class F>

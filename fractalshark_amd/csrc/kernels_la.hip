@@ -275,6 +275,20 @@ __global__ void __launch_bounds__(1024) k_la_reach_all(const uint32_t *next, uin
     }
 }
 
+// A few words to the host without a stream synchronisation (round 4): `mail` is page-locked, coherent host memory that the
+// device writes directly; the words first, a system-scope fence, then the sequence number the host is spinning on.  A
+// hipStreamSynchronize behind a 4-byte copy costs 20 - 30 us of interrupt latency, and fs_build_la needs two such reads per
+// stage: on a small orbit they were half of its time.
+__global__ void k_la_mail(const uint32_t *src, uint32_t n, volatile uint32_t *mail, uint32_t seq)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0)
+        return;
+    for (uint32_t i = 0; i < n; i++)
+        mail[i] = src[i];
+    __threadfence_system();
+    mail[31] = seq;
+}
+
 // ---- 5. records
 template <class F, bool kStage0>
 __global__ void k_la_records(const void *zref, const LAInfo<F> *P, const uint32_t *pos, const uint32_t *next,
@@ -447,6 +461,10 @@ void fsk_la_next(bool stage0, const void *chebv, const void *mm, const uint32_t 
 void fsk_la_reach(const uint32_t *jin, uint32_t *jout, uint32_t *reach, uint32_t nstates, hipStream_t s)
 {
     hipLaunchKernelGGL(k_la_reach, dim3(nblk(nstates)), dim3(256), 0, s, jin, jout, reach, nstates);
+}
+void fsk_la_mail(const uint32_t *src, uint32_t n, uint32_t *mail, uint32_t seq, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_la_mail, dim3(1), dim3(1), 0, s, src, n, (volatile uint32_t *)mail, seq);
 }
 void fsk_la_reach_all(const uint32_t *next, uint32_t *bufB, uint32_t *bufC, uint32_t *reach, uint32_t nstates, uint32_t rounds,
                       hipStream_t s)

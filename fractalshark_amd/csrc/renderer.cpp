@@ -162,6 +162,8 @@ struct fs_renderer {
     size_t host_alloc_bytes = 0;
     bool inject_input_oom = false;   // fault injection: FSMI355_FAIL_INPUT_ALLOC=1 at fs_create time
     void *arena = nullptr;           // work memory of fs_build_la (kept between calls, grown on demand)
+    uint32_t *la_mail = nullptr;     // 32 words of coherent page-locked memory the build's kernels report through (k_la_mail)
+    uint32_t la_mail_seq = 0;
     size_t arena_cap = 0;
     void *bla_block = nullptr;       // ONE allocation for the BLA table: the level pointer table, then the levels
     size_t bla_block_cap = 0;
@@ -657,6 +659,9 @@ void free_all(fs_renderer *r)
         r_free(r, r->cx_row);
     (void)r_free(r, r->arena);
     r->arena = nullptr;
+    if (r->la_mail)
+        (void)hipHostFree(r->la_mail);
+    r->la_mail = nullptr;
     r->arena_cap = 0;
     r->iters_internal = nullptr;
     r->colors = nullptr;
@@ -1600,6 +1605,36 @@ template <class F> uint32_t build_la(fs_renderer *r, const void *max_radius, int
     uint32_t la_size = 0;
     uint32_t h[4];
 
+    // A few words from the device: through the mailbox (a tiny kernel writes them into coherent page-locked memory and then
+    // a sequence number; the host spins on that word) -- or, if the mailbox could not be had or stays silent, the plain way
+    if (!r->la_mail) {
+        if (hipHostMalloc((void **)&r->la_mail, 32 * sizeof(uint32_t), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
+            (void)hipGetLastError();
+            r->la_mail = nullptr;
+        } else {
+            memset(r->la_mail, 0, 32 * sizeof(uint32_t));
+        }
+    }
+    auto read_words = [&](const uint32_t *src, uint32_t n, uint32_t *out) -> hipError_t {
+        if (r->la_mail && n <= 31u) {
+            const uint32_t seq = ++r->la_mail_seq ? r->la_mail_seq : ++r->la_mail_seq; // never 0
+            fsk_la_mail(src, n, r->la_mail, seq, s);
+            volatile uint32_t *m = r->la_mail;
+            for (uint64_t spin = 0; spin < 400000000ull; spin++) { // (seconds; a launch error shows below)
+                if (m[31] == seq) {
+                    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+                    for (uint32_t i = 0; i < n; i++)
+                        out[i] = m[i];
+                    return hipSuccess;
+                }
+                if ((spin & 0xFFFFFu) == 0xFFFFFu && hipStreamQuery(s) != hipErrorNotReady)
+                    break; // the stream has drained (or failed) without the word arriving: read the plain way
+            }
+        }
+        hipError_t e = hipMemcpyAsync(out, src, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+        return e != hipSuccess ? e : hipStreamSynchronize(s);
+    };
+
     // isZCoeffZero of the first step (LAReference.cpp:52-56): word 8 of the scratch words, read back with stage 0's first
     // detection below (one round trip less)
     fsk_la_tail<F>(zref, maxRef, nullptr, d_small + 8, s);
@@ -1639,8 +1674,7 @@ template <class F> uint32_t build_la(fs_renderer *r, const void *max_radius, int
                 }
             }
             fsk_scan_u32(reach.as<uint32_t>(), rank.as<uint32_t>(), nstates, s);
-            FS_TRY(hipMemcpyAsync(h, rank.as<uint32_t>() + nstates, 4, hipMemcpyDeviceToHost, s));
-            FS_TRY(hipStreamSynchronize(s));
+            FS_TRY(read_words(rank.as<uint32_t>() + nstates, 1, h));
             if ((size_t)la_size + offset + h[0] + 2u > cap_recs)
                 return FS_ERR_7;
             // (the stage's tail record goes out with the same launch)
@@ -1658,8 +1692,7 @@ template <class F> uint32_t build_la(fs_renderer *r, const void *max_radius, int
         fsk_la_src_orbit<F>(zref, maxRef + 1u, chebv.p, s);
         fsk_la_first<F>(true, chebv.p, mm.p, limit, d_small, s);
         uint32_t h0[9];
-        FS_TRY(hipMemcpyAsync(h0, d_small, sizeof(h0), hipMemcpyDeviceToHost, s));
-        FS_TRY(hipStreamSynchronize(s));
+        FS_TRY(read_words(d_small, 9, h0));
         if (h0[8])
             return FS_ERR_UNSUPPORTED; // the first step's ZCoeff is zero
         h[0] = h0[0], h[1] = h0[1];
@@ -1699,8 +1732,7 @@ template <class F> uint32_t build_la(fs_renderer *r, const void *max_radius, int
         // (round 4: three launches and three round trips per stage before)
         fsk_la_stage_prologue<F>(P, chebv.p, mm.p, steps.as<uint32_t>(), pos.as<uint32_t>(), Count, d_small, s);
         uint32_t hs[5];
-        FS_TRY(hipMemcpyAsync(hs, d_small, sizeof(hs), hipMemcpyDeviceToHost, s));
-        FS_TRY(hipStreamSynchronize(s));
+        FS_TRY(read_words(d_small, 5, hs));
         uint32_t jd = hs[0], fd = hs[1];
         const uint32_t step0 = hs[2];
         uint32_t Period = 0;
