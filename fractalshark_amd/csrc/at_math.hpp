@@ -119,7 +119,8 @@ __device__ __forceinline__ void at_perform(const hcplx<F> c, const hreal<F> esc,
                     if (true_domain) {
                         // The true-value loop by hand: what the compiler makes of FS_AT_LOOP() is 10 vector and 11 scalar
                         // instructions per iteration, and the scalar unit (shared by the CU's four SIMDs) is then as busy as
-                        // the vector pipes.  Here: the eight arithmetic operations, ONE test -- the high word of |Z|^2 inside
+                        // the vector pipes.  Here: seven arithmetic operations -- (ri + ri) + C.im is ONE fused multiply-add by 2:
+                        // the doubling is exact, so the single rounding of the fma is the rounding of the sum --, ONE test -- the high word of |Z|^2 inside
                         // [high word of the floor, high word of T): two 32-bit instructions that flag a superset of the
                         // lanes that finish (equal high words are decided exactly, outside) -- and four scalar instructions
                         // (vote, branch, count, branch).  The statement leaves when a pending lane is flagged, with the state
@@ -142,13 +143,12 @@ __device__ __forceinline__ void at_perform(const hcplx<F> c, const hreal<F> esc,
                                          "v_mul_f64 %[ri], %[re], %[im]\n\t"
                                          "v_add_f64 v[62:63], %[rr], %[ii]\n\t"
                                          "v_add_f64 %[rr], %[rr], -%[ii]\n\t"
-                                         "v_add_f64 %[ri], %[ri], %[ri]\n\t"
                                          "v_subrev_u32_e32 %[t], %[thi], v63\n\t"
                                          "v_cmp_le_u32_e32 vcc, %[rng], %[t]\n\t"
                                          "s_and_b64 %[tmp], vcc, %[pend]\n\t"
                                          "s_cbranch_scc1 .Lat_flag_%=\n\t"
                                          "v_add_f64 %[re], %[rr], %[cre]\n\t"
-                                         "v_add_f64 %[im], %[ri], %[cim]\n\t"
+                                         "v_fma_f64 %[im], %[ri], 2.0, %[cim]\n\t" /* (ri + ri) + cim: doubling is exact */
                                          "s_sub_u32 %[cnt], %[cnt], 1\n\t"
                                          "s_cbranch_scc0 .Lat_loop_%=\n\t"
                                          "s_branch .Lat_end_%=\n"
@@ -172,7 +172,7 @@ __device__ __forceinline__ void at_perform(const hcplx<F> c, const hreal<F> esc,
                                 continue;
                             }
                             it += (IterT)(n - 1u - cnt);
-                            // the state is at iteration `it`, its norm in m, rr - ii and ri + ri in rr / ri: the exact test
+                            // the state is at iteration `it`, its norm in m, rr - ii and re * im in rr / ri: the exact test
                             const uint64_t fin =
                                 (__builtin_amdgcn_ballot_w64(!(m >= thr)) | __builtin_amdgcn_ballot_w64(m > T)) & pending;
                             if (fin != 0ull) {
@@ -183,7 +183,7 @@ __device__ __forceinline__ void at_perform(const hcplx<F> c, const hreal<F> esc,
                                     break;
                             }
                             re = rr + cre;
-                            im = ri + cim;
+                            im = (ri + ri) + cim;
                             if (++it >= ATMaxIt) {
                                 if (__builtin_amdgcn_inverse_ballot_w64(pending))
                                     xre = re, xim = im, xi = ATMaxIt;
