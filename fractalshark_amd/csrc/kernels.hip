@@ -388,12 +388,23 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
                 if (iterations < n_iterations)
                     seq.seek(RefIteration); // SeqWorkspace(results, RefIteration)
             }
+            // (round 4) Two things the reference's loop does per step are not done per step here, with the same results:
+            // the orbit entry a step arrives at is the entry the next step leaves from -- one load per step, not two, unless
+            // a rebase moved the index; and Reduce(z) before |z|^2 only re-labels z -- both parts scaled by the same power of
+            // two, which commutes with the squares and their sum (the larger part of z is an O(1) mantissa: nothing comes
+            // near the ends of the range) -- so the reduced norm is the same and z is reduced only where it is stored, on a
+            // rebase.
+            hcplx<F> Zhere = hc_zero<F>();
+            if constexpr (!kSeq) {
+                if (iterations < n_iterations)
+                    Zhere = zref_at(zr, (uint32_t)RefIteration);
+            }
             for (; iterations < n_iterations; iterations++) {
                 hcplx<F> cur;
                 if constexpr (kSeq)
                     cur = seq.value();
                 else
-                    cur = zref_at(zr, (uint32_t)RefIteration);
+                    cur = Zhere;
                 cur = hc_mul2(cur);
                 cur = hc_add(cur, DeltaSubN);
                 DeltaSubN = hc_mul(DeltaSubN, cur);
@@ -408,18 +419,21 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
                     Znext = seq.value();
                 } else {
                     Znext = zref_at(zr, (uint32_t)RefIteration);
+                    Zhere = Znext;
                 }
                 hcplx<F> complex0 = hc_add(Znext, DeltaSubN);
-                hc_reduce(complex0);
                 const hreal<F> normSquared = hr_reduced(hc_norm2(complex0));
                 const hreal<F> DeltaNormSquared = hr_reduced(hc_norm2(DeltaSubN));
                 if (hr_cmp_pos(normSquared, TwoFiftySix) > 0)
                     break;
                 if (hr_cmp_pos(normSquared, DeltaNormSquared) < 0 || RefIteration >= MaxRefIteration) {
+                    hc_reduce(complex0);
                     DeltaSubN = complex0;
                     RefIteration = 0;
                     if constexpr (kSeq)
                         seq.seek(0); // a new SeqWorkspace at the start of the orbit
+                    else
+                        Zhere = zref_at(zr, 0u);
                 }
             }
         }
