@@ -345,13 +345,18 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
                 }
                 const uint32_t MacroItCount = A.stages[CurrentLAStage].MacroItCount;
                 PosT j = RefIteration;
+                // (round 4) the Ref of record j + 1, read for the rebase test of step j, is the Ref step j + 1 starts from:
+                // one load of it per step, not two, unless the test reset j
+                hcplx<F> RefJ = hc_zero<F>();
+                if (iterations < n_iterations)
+                    RefJ = ldc(la_rec((uint64_t)LAIndex + j)->Ref);
                 while (iterations < n_iterations) {
                     const LaRec *LAj = la_rec((uint64_t)LAIndex + j);
                     const IterT l = la_step_length(LAj);
                     bool unusable = true;
                     hcplx<F> newDz = hc_zero<F>();
                     if (iterations + l <= n_iterations) {
-                        newDz = hc_mul(DeltaSubN, hc_add(hc_mul2(ldc(LAj->Ref)), DeltaSubN));
+                        newDz = hc_mul(DeltaSubN, hc_add(hc_mul2(RefJ), DeltaSubN));
                         hc_reduce(newDz);
                         unusable = hr_cmp_pos(hc_cheb(newDz), ldr(LAj->LAThreshold)) >= 0;
                     }
@@ -363,13 +368,17 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
                     if (kStats)
                         c_la++;
                     DeltaSubN = hc_add(hc_mul(newDz, ldc(LAj->ZCoeff)), hc_mul(DeltaSub0, ldc(LAj->CCoeff)));
-                    const hcplx<F> complex0 = hc_add(ldc(la_rec((uint64_t)LAIndex + j + 1)->Ref), DeltaSubN);
+                    const hcplx<F> RefN = ldc(la_rec((uint64_t)LAIndex + j + 1)->Ref);
+                    const hcplx<F> complex0 = hc_add(RefN, DeltaSubN);
                     j++;
                     const hreal<F> lhs = hr_reduced(hc_cheb(complex0));
                     const hreal<F> rhs = hr_reduced(hc_cheb(DeltaSubN));
                     if (hr_cmp_pos(lhs, rhs) < 0 || j >= MacroItCount) {
                         DeltaSubN = complex0;
                         j = 0;
+                        RefJ = ldc(la_rec((uint64_t)LAIndex)->Ref);
+                    } else {
+                        RefJ = RefN;
                     }
                 }
                 if (iterations >= n_iterations)
@@ -1012,13 +1021,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                 }
                 const uint32_t MacroItCount = A.stages[CurrentLAStage].MacroItCount;
                 uint32_t j = RefIteration;
+                // (the Ref of record j + 1, read for the rebase test of step j, is the Ref step j + 1 starts from: one load
+                // of it per step unless the test reset j)
+                hcplx32 RefJ = hc_zero<float>();
+                if (iterations < n_iterations)
+                    RefJ = ldc(A.las[LAIndex + j].Ref);
                 while (iterations < n_iterations) {
                     const fs_la_hdr32_u32 *LAj = &A.las[LAIndex + j];
                     const uint32_t l = LAj->StepLength;
                     bool unusable = true;
                     hcplx32 newDz = hc_zero<float>();
                     if (iterations + l <= n_iterations) {
-                        newDz = hc_mul(DeltaSubN, hc_add(hc_mul2(ldc(LAj->Ref)), DeltaSubN));
+                        newDz = hc_mul(DeltaSubN, hc_add(hc_mul2(RefJ), DeltaSubN));
                         hc_reduce(newDz);
                         unusable = hr_cmp_pos(hc_cheb(newDz), ldr(LAj->LAThreshold)) >= 0;
                     }
@@ -1031,13 +1045,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                     if (kStats)
                         c_la++;
                     DeltaSubN = hc_add(hc_mul(newDz, ldc(LAj->ZCoeff)), hc_mul(DeltaSub0, ldc(LAj->CCoeff)));
-                    const hcplx32 complex0 = hc_add(ldc(LAj[1].Ref), DeltaSubN);
+                    const hcplx32 RefN = ldc(LAj[1].Ref);
+                    const hcplx32 complex0 = hc_add(RefN, DeltaSubN);
                     j++;
                     const hreal32 lhs = hr_reduced(hc_cheb(complex0));
                     const hreal32 rhs = hr_reduced(hc_cheb(DeltaSubN));
                     if (hr_cmp_pos(lhs, rhs) < 0 || j >= MacroItCount) {
                         DeltaSubN = complex0;
                         j = 0;
+                        RefJ = ldc(A.las[LAIndex].Ref);
+                    } else {
+                        RefJ = RefN;
                     }
                 }
                 if (iterations >= n_iterations)
