@@ -901,6 +901,11 @@ static_assert(kScaledChunk % 8 == 0 && kScaledChunk >= 64, "a run is a whole num
 #define FS_BACKOFF_CAP 15
 #endif
 constexpr uint32_t kScaledBackoffCap = FS_BACKOFF_CAP;
+// Steps of a hot run (k_lav2_hdr32_fast, see there) before the scale is re-centred.
+#ifndef FS_HOT_RUN_STEPS
+#define FS_HOT_RUN_STEPS 64 /* measured on C3 (kernel ms): 8: 50.2, 16: 49.75, 32: 49.7, 64: 49.5, 128 .. 1024: 49.5 - 49.6 */
+#endif
+constexpr uint32_t kHotRunSteps = FS_HOT_RUN_STEPS;
 
 __device__ __forceinline__ uint32_t scaled_run_length(uint32_t left)
 {
@@ -1122,6 +1127,120 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                     // back-off: the last run attempts of this wave ended before their first step (a lane sits where dz is not
                     // small against the orbit -- near its escape, or between two near-zero orbit values): an attempt costs an
                     // entry, a trip and an exit, so a few careful steps are taken before the next one
+                    //
+                    // ---- HOT RUN (round 4).  What the wave is waiting for is a pixel on its way out: for its last half-dozen
+                    // steps its dz is no longer small against the orbit, it rebases every other step, and the 63 others
+                    // take careful steps with it (356 of a wave's 454 careful passes on C3).  Those steps run here on the
+                    // scaled form instead, PER LANE -- each lane at its own orbit position (entries through per-lane loads)
+                    // and with the CPU loop's two exit tests evaluated exactly, in true scale, on every step:
+                    //   z = Z' + q 2^E as one fma (the exact sum rounded once, like the reference's aligned sum; where dz is
+                    //   far below binary32's range the product vanishes inside the fma and z = Z', which is what the
+                    //   reference's sum rounds to as well: both parts of a usable entry are >= 2^-80);  |z|^2 and
+                    //   |q|^2 2^2E as sums of squares (the same roundings up to the scale; a square that underflows belongs
+                    //   to a part 2^40 below its sibling -- absorbed in both arithmetics -- or to a z that cancelled to below
+                    //   2^-62 against a dz' >= 2^-41: the rebase test fires either way);  escape |z|^2 > 256: the pixel is
+                    //   done;  rebase |z|^2 < |dz'|^2 (or the orbit's end): dz = z -- the rounded sum itself, scaled back --
+                    //   at orbit index 0.
+                    // The step is the reference's step while the floor form's conditions hold (both parts of every state,
+                    // a rebased one included, >= 2^-56; max|w| < 2^24; the arrival entry usable); a lane that misses one
+                    // ends the run for the wave before anything of that step is committed, and the careful step below
+                    // decides.  The run also ends when every lane has cooled down (its arrival passes the bound test
+                    // again: the fast paths resume) and after kHotRunSteps steps (the scale is re-centred).
+                    bool hot_progress = false, hot_cold = false;
+                    {
+                        const int E = dze + kScaleShift, E2 = E + E;
+                        const float sE = __builtin_amdgcn_ldexpf(1.0f, E);
+                        const f2 sE2 = {sE, sE};
+                        const int dsh = dce - E;
+                        const f2 dcs = {__builtin_amdgcn_ldexpf(dcm.x, dsh), __builtin_amdgcn_ldexpf(dcm.y, dsh)};
+                        const int Esh = (E < -254 ? -254 : (E > 127 ? 127 : E)) * (1 << 23);
+                        const float4 e0 = zs[ref];
+                        const float mx0 = __builtin_fmaxf(__builtin_fabsf(dzm.x), __builtin_fabsf(dzm.y));
+                        const float mn0 = __builtin_fminf(__builtin_fabsf(dzm.x), __builtin_fabsf(dzm.y));
+                        const bool start_ok = scaled_startable(e0) && mn0 >= FS_FL_FLOOR * __builtin_amdgcn_ldexpf(1.0f, kScaleShift) &&
+                                              mx0 >= 1.0f && mx0 < 2.0f && dsh <= 30 - kScaleShift;
+                        if (__builtin_amdgcn_ballot_w64(!start_ok) == 0ull) {
+                            f2 w = dzm * __builtin_amdgcn_ldexpf(1.0f, -kScaleShift), c2 = {e0.x, e0.y};
+                            bool live = true;
+                            for (uint32_t budget = kHotRunSteps; budget != 0u; budget--) {
+                                const float4 ent = zs[live ? ref + 1u : 0u];
+                                const f2 s_ = __builtin_elementwise_fma(w, sE2, c2);
+                                const f2 pa_ = w.xx * s_;
+                                const f2 pb_ = w.yy * s_.yx;
+                                f2 p_;
+                                asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(p_) : "v"(pa_), "v"(pb_));
+                                const f2 q_ = p_ + dcs;
+                                const float mxq = __builtin_fmaxf(__builtin_fabsf(q_.x), __builtin_fabsf(q_.y));
+                                const float mnq = __builtin_fminf(__builtin_fabsf(q_.x), __builtin_fabsf(q_.y));
+                                const f2 zt = __builtin_elementwise_fma(q_, sE2, (f2){ent.x, ent.y} * 0.5f);
+                                const f2 zz_ = zt * zt, qq_ = q_ * q_;
+                                const float nz = zz_.x + zz_.y;
+                                const float nq = __builtin_amdgcn_ldexpf(qq_.x + qq_.y, E2);
+                                const bool esc = nz > 256.0f;
+                                const bool reb = !esc && (nz < nq || ref + 1u >= MaxRefIteration);
+                                bool valid = mnq >= FS_FL_FLOOR && mxq < FS_FL_HIGH_TRIP && __float_as_int(ent.z) != (int)0x80000000 &&
+                                             nz == nz;
+                                // the rebased state dz = z in the run's scale (it would overflow where dz is tiny -- where no
+                                // rebase happens), formed only on the steps on which some lane rebases
+                                f2 wz = q_;
+                                if (__builtin_amdgcn_ballot_w64(live && reb) != 0ull) {
+                                    wz = (f2){__builtin_amdgcn_ldexpf(zt.x, -E), __builtin_amdgcn_ldexpf(zt.y, -E)};
+                                    const float mxz = __builtin_fmaxf(__builtin_fabsf(wz.x), __builtin_fabsf(wz.y));
+                                    const float mnz = __builtin_fminf(__builtin_fabsf(wz.x), __builtin_fabsf(wz.y));
+                                    valid = valid && (!reb || (mnz >= FS_FL_FLOOR && mxz < FS_FL_HIGH_TRIP));
+                                }
+                                if (__builtin_amdgcn_ballot_w64(live && !valid) != 0ull)
+                                    break;
+                                const bool cold = !(__float_as_int(mxq) + Esh > __float_as_int(ent.z)) && !reb;
+                                if (live) {
+                                    hot_progress = true;
+                                    if (kStats) {
+                                        c_pt++;
+                                        c_scaled++;
+                                    }
+                                    if (esc) {
+                                        live = false;
+                                        running = false; // `break` happens before iterations++ in the CPU loop
+                                    } else {
+                                        iterations++;
+                                        if (reb) {
+                                            w = wz;
+                                            ref = 0u;
+                                            c2 = (f2){0.0f, 0.0f}; // 2 Z[0]: the orbit starts at an exact zero
+                                        } else {
+                                            w = q_;
+                                            ref++;
+                                            c2 = (f2){ent.x, ent.y};
+                                        }
+                                        if (iterations >= n_iterations) {
+                                            live = false;
+                                            running = false;
+                                        }
+                                    }
+                                }
+                                if (__builtin_amdgcn_ballot_w64(live) == 0ull)
+                                    break;
+                                if (__builtin_amdgcn_ballot_w64(live && !cold) == 0ull) {
+                                    hot_cold = true;
+                                    break;
+                                }
+                            }
+                            if (hot_progress && running) {
+                                // back to the reduced form (exact; every accepted state has two non-zero parts)
+                                const float mxw = __builtin_fmaxf(__builtin_fabsf(w.x), __builtin_fabsf(w.y));
+                                const int k = (int)((uint32_t)__float_as_int(mxw) >> 23) - 127;
+                                dzm = (f2){__builtin_amdgcn_ldexpf(w.x, -k), __builtin_amdgcn_ldexpf(w.y, -k)};
+                                dze = E + k;
+                                const float4 zc = zq[ref];
+                                Zcm = (f2){zc.x, zc.y};
+                            }
+                        }
+                    }
+                    if (__builtin_amdgcn_ballot_w64(hot_progress) != 0ull) { // (wave-uniform: a lane that is done has progressed)
+                        if (hot_cold)
+                            sc_skip = 0u, sc_penalty = 0u;
+                        continue;
+                    }
                     sc_skip--;
                     sc_stopped = true;
                     was_skip = true;
