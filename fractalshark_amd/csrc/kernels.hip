@@ -927,12 +927,19 @@ __device__ __forceinline__ uint32_t scaled_run_length(uint32_t left)
 // the CPU function's (FS_PARITY_CPU) -- a template parameter so that the two parity modes are two kernels (they do very
 // different work per frame, and a kernel trace then lists them separately).
 template <int Mode, bool kStats, bool kScaled, bool kLds = false, bool kGpuStage = false>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) k_lav2_hdr32_fast(FsLav2Args32 A)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) k_lav2_hdr32_fast(FsLav2Args32 A)
 {
     __shared__ float4 s_zs_lds[kLds ? 4 * 2 * 64 : 1];
     // cost recording (A.tile_cost): a lane parks its count at the start of the perturbation loop here, so that nothing
     // extra stays in a register across the loop
     __shared__ uint32_t s_it0[256];
+    // dc of the wave's pixels (two mantissas, one exponent): constant over the perturbation loop and needed only where a run or
+    // a careful step starts, it is read back from here there instead of holding three registers across the loops (with the
+    // hot runs of round 4 the register allocator had none left and spilled to scratch -- 180 MB of writes per frame)
+    __shared__ float s_dcp[3 * 256];
+    // ... and the state a scaled run starts from (dz's mantissas), needed again only when a run is repeated with the per-trip
+    // verdicts: parked here for the run instead of held in two registers across it
+    __shared__ float s_dzp[2 * 256];
     // The tile this wave renders, as two wave-uniform numbers: named by the launch order when there is one (longest tiles
     // first, from the costs the previous frame recorded), by the block index otherwise.  The pixel is tile + lane, and
     // it is worked out twice -- here, and again for the store at the end from the scalar tile numbers and a freshly
@@ -951,11 +958,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         tile_y = blockIdx.y;
     }
     uint32_t X, L;
+    uint32_t lds_lane16 = 0; // (kLds) lane * 16, made here where all 64 lanes are active: see FS_GLDS_CHUNK
     {
         uint32_t lane; // (opaque, so that no later use of the lane number is served from a register kept since here)
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
         X = tile_x * 8u + (lane & 7u);
         L = tile_y * 8u + (lane >> 3);
+        if constexpr (kLds)
+            asm volatile("v_lshlrev_b32_e32 %0, 4, %1" : "=v"(lds_lane16) : "v"(lane));
     }
     uint32_t lane_cost = 0;
 #ifdef FS_TRACE_WAVES
@@ -1071,21 +1081,38 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         if (Mode != FS_MODE_LAO) {
             const float4 *__restrict__ zr = A.zref;
             hcplx32 dz = DeltaSubN;
-            const hcplx32 dc = DeltaSub0;
+            const hcplx32 dc = DeltaSub0; // (parked in LDS below; not used past that)
             uint32_t ref = RefIteration;
             {
                 uint32_t lane_s;
                 asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_s));
                 s_it0[wave_in_block * 64u + lane_s] = iterations - la_cost;
             }
-            hcplx32 Zc = zref_at(zr, ref);
             bool running = iterations < n_iterations;
             typedef float f2 __attribute__((ext_vector_type(2)));
             f2 dzm = {dz.re, dz.im};
             int dze = dz.e;
-            const f2 dcm = {dc.re, dc.im};
-            const int dce = dc.e;
-            f2 Zcm = {Zc.re, Zc.im};
+            {
+                uint32_t lane_s;
+                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_s));
+                volatile __attribute__((address_space(3))) float *pd =
+                    (volatile __attribute__((address_space(3))) float *)s_dcp + (wave_in_block * 64u + lane_s) * 3u;
+                pd[0] = dc.re, pd[1] = dc.im, pd[2] = __int_as_float(dc.e);
+            }
+            // (each use site reads dc back: FS_LOAD_DC declares dcm / dce in its scope)
+#define FS_LOAD_DC()                                                                                                \
+    f2 dcm;                                                                                                         \
+    int dce;                                                                                                        \
+    {                                                                                                               \
+        uint32_t lane_d;                                                                                            \
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_d));             \
+        const volatile __attribute__((address_space(3))) float *pd_ =                                               \
+            (const volatile __attribute__((address_space(3))) float *)s_dcp + (wave_in_block * 64u + lane_d) * 3u;  \
+        dcm = (f2){pd_[0], pd_[1]};                                                                                 \
+        dce = __float_as_int(pd_[2]);                                                                               \
+    }
+            // (the orbit value the pixel is at is read where a quiet run or a careful step starts -- zq / zr [ref] -- instead of
+            // being carried in registers across the runs)
             // The careful step as straight-line code for EVERY exponent order of its three sums.  plus_mutable
             // (HDRFloatComplex.h:219-247, hc_add) keeps the operand with the larger exponent and adds the other one scaled
             // by 2^-gap -- or not at all from a gap of 120 on: with f(g) = 2^g for g > -120 and 0 below,
@@ -1148,37 +1175,67 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                     // again: the fast paths resume) and after kHotRunSteps steps (the scale is re-centred).
                     bool hot_progress = false, hot_cold = false;
                     {
-                        const int E = dze + kScaleShift, E2 = E + E;
+                        FS_LOAD_DC()
+                        const int E = dze + kScaleShift;
                         const float sE = __builtin_amdgcn_ldexpf(1.0f, E);
                         const f2 sE2 = {sE, sE};
                         const int dsh = dce - E;
                         const f2 dcs = {__builtin_amdgcn_ldexpf(dcm.x, dsh), __builtin_amdgcn_ldexpf(dcm.y, dsh)};
-                        const int Esh = (E < -254 ? -254 : (E > 127 ? 127 : E)) * (1 << 23);
                         const float4 e0 = zs[ref];
                         const float mx0 = __builtin_fmaxf(__builtin_fabsf(dzm.x), __builtin_fabsf(dzm.y));
                         const float mn0 = __builtin_fminf(__builtin_fabsf(dzm.x), __builtin_fabsf(dzm.y));
                         const bool start_ok = scaled_startable(e0) && mn0 >= FS_FL_FLOOR * __builtin_amdgcn_ldexpf(1.0f, kScaleShift) &&
                                               mx0 >= 1.0f && mx0 < 2.0f && dsh <= 30 - kScaleShift;
                         if (__builtin_amdgcn_ballot_w64(!start_ok) == 0ull) {
-                            f2 w = dzm * __builtin_amdgcn_ldexpf(1.0f, -kScaleShift), c2 = {e0.x, e0.y};
+                            f2 w = dzm * __builtin_amdgcn_ldexpf(1.0f, -kScaleShift);
                             bool live = true;
+#pragma unroll 1
                             for (uint32_t budget = kHotRunSteps; budget != 0u; budget--) {
-                                const float4 ent = zs[live ? ref + 1u : 0u];
-                                const f2 s_ = __builtin_elementwise_fma(w, sE2, c2);
-                                const f2 pa_ = w.xx * s_;
-                                const f2 pb_ = w.yy * s_.yx;
-                                f2 p_;
-                                asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(p_) : "v"(pa_), "v"(pb_));
-                                const f2 q_ = p_ + dcs;
-                                const float mxq = __builtin_fmaxf(__builtin_fabsf(q_.x), __builtin_fabsf(q_.y));
-                                const float mnq = __builtin_fminf(__builtin_fabsf(q_.x), __builtin_fabsf(q_.y));
-                                const f2 zt = __builtin_elementwise_fma(q_, sE2, (f2){ent.x, ent.y} * 0.5f);
-                                const f2 zz_ = zt * zt, qq_ = q_ * q_;
-                                const float nz = zz_.x + zz_.y;
-                                const float nq = __builtin_amdgcn_ldexpf(qq_.x + qq_.y, E2);
+                                // One step, by hand, in the registers the hand-scheduled loops name (v[48:62] are free between
+                                // those loops): written in C++ the run took nine registers more than the kernel has at eight waves
+                                // per SIMD -- its temporaries, 64-bit per-lane addresses, and what the compiler hoists out of the
+                                // loop (2Z of the entry the lane is at, 2 E, the shifted exponent) -- and the allocator spilled to
+                                // scratch.  Here both orbit entries -- the one the lane is at, and the one it arrives at -- come
+                                // through a scalar base and a 32-bit per-lane offset (a finished lane reads entries 0 and 1):
+                                //   s = fma(w, 2^E, 2Z);  q = w s + dc 2^-E;  z = fma(q, 2^E, Z');  |z|^2;  |q|^2 2^2E;  max / min |q|;
+                                //   hb = bits(max|q|) + (E << 23, clamped): the bound test's left side
+                                // (a packed result read by the very next instruction needs one wait state: s_nop 0)
+                                f2 q_, zt;
+                                float nz, nq, mxq, mnq, entz;
+                                int hb;
+                                {
+                                    const uint32_t off_ = (live ? ref + 1u : 1u) << 4;
+                                    asm volatile("global_load_dwordx2 v[58:59], %[off], %[zs] offset:-16\n\t"
+                                                 "global_load_dwordx3 v[60:62], %[off], %[zs]\n\t"
+                                                 "s_waitcnt vmcnt(0)\n\t"
+                                                 "v_pk_fma_f32 v[56:57], %[w], %[se], v[58:59]\n\t"
+                                                 "v_mul_f32_e32 v50, 0.5, v60\n\t"
+                                                 "v_pk_mul_f32 v[58:59], %[w], v[56:57] op_sel_hi:[0,1]\n\t"
+                                                 "v_pk_mul_f32 v[56:57], %[w], v[56:57] op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+                                                 "v_mul_f32_e32 v51, 0.5, v61\n\t"
+                                                 "v_pk_add_f32 v[58:59], v[58:59], v[56:57] neg_lo:[0,1] neg_hi:[0,0]\n\t"
+                                                 "v_max_i32_e32 v60, 0xffffff02, %[e]\n\t" /* E clamped to -254 .. 127 */
+                                                 "v_min_i32_e32 v60, 0x7f, v60\n\t"
+                                                 "v_pk_add_f32 v[48:49], v[58:59], %[dc]\n\t"
+                                                 "v_lshlrev_b32_e32 v60, 23, v60\n\t"
+                                                 "v_pk_fma_f32 v[50:51], v[48:49], %[se], v[50:51]\n\t"
+                                                 "v_pk_mul_f32 v[58:59], v[48:49], v[48:49]\n\t"
+                                                 "v_max_f32_e64 v54, |v48|, |v49|\n\t"
+                                                 "v_pk_mul_f32 v[56:57], v[50:51], v[50:51]\n\t"
+                                                 "v_add_f32_e32 v53, v58, v59\n\t"
+                                                 "v_min_f32_e64 v55, |v48|, |v49|\n\t"
+                                                 "v_add_f32_e32 v52, v56, v57\n\t"
+                                                 "v_lshlrev_b32_e32 v61, 1, %[e]\n\t"
+                                                 "v_add_u32_e32 v56, v54, v60\n\t"
+                                                 "v_ldexp_f32 v53, v53, v61"
+                                                 : "=&{v[48:49]}"(q_), "=&{v[50:51]}"(zt), "=&{v52}"(nz), "=&{v53}"(nq), "=&{v54}"(mxq),
+                                                   "=&{v55}"(mnq), "=&{v56}"(hb), "=&{v62}"(entz) /* (early clobber: no input may share one) */
+                                                 : [w] "v"(w), [se] "v"(sE2), [dc] "v"(dcs), [e] "v"(E), [off] "v"(off_), [zs] "s"(zs)
+                                                 : "v57", "v58", "v59", "v60", "v61", "memory");
+                                }
                                 const bool esc = nz > 256.0f;
                                 const bool reb = !esc && (nz < nq || ref + 1u >= MaxRefIteration);
-                                bool valid = mnq >= FS_FL_FLOOR && mxq < FS_FL_HIGH_TRIP && __float_as_int(ent.z) != (int)0x80000000 &&
+                                bool valid = mnq >= FS_FL_FLOOR && mxq < FS_FL_HIGH_TRIP && __float_as_int(entz) != (int)0x80000000 &&
                                              nz == nz;
                                 // the rebased state dz = z in the run's scale (it would overflow where dz is tiny -- where no
                                 // rebase happens), formed only on the steps on which some lane rebases
@@ -1191,7 +1248,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                                 }
                                 if (__builtin_amdgcn_ballot_w64(live && !valid) != 0ull)
                                     break;
-                                const bool cold = !(__float_as_int(mxq) + Esh > __float_as_int(ent.z)) && !reb;
+                                const bool cold = !(hb > __float_as_int(entz)) && !reb;
                                 if (live) {
                                     hot_progress = true;
                                     if (kStats) {
@@ -1205,12 +1262,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                                         iterations++;
                                         if (reb) {
                                             w = wz;
-                                            ref = 0u;
-                                            c2 = (f2){0.0f, 0.0f}; // 2 Z[0]: the orbit starts at an exact zero
+                                            ref = 0u; // (2 Z[0] is an exact zero: the orbit starts there)
                                         } else {
                                             w = q_;
                                             ref++;
-                                            c2 = (f2){ent.x, ent.y};
                                         }
                                         if (iterations >= n_iterations) {
                                             live = false;
@@ -1225,14 +1280,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                                     break;
                                 }
                             }
-                            if (hot_progress && running) {
-                                // back to the reduced form (exact; every accepted state has two non-zero parts)
+                            {
+                                // back to the reduced form (exact; every accepted state has two non-zero parts) -- also for a
+                                // lane that took no step: its w is dz 2^-E still, and rebuilding dz, its exponent and the orbit
+                                // value from it means that none of the three has to stay in a register across the run
                                 const float mxw = __builtin_fmaxf(__builtin_fabsf(w.x), __builtin_fabsf(w.y));
                                 const int k = (int)((uint32_t)__float_as_int(mxw) >> 23) - 127;
                                 dzm = (f2){__builtin_amdgcn_ldexpf(w.x, -k), __builtin_amdgcn_ldexpf(w.y, -k)};
                                 dze = E + k;
-                                const float4 zc = zq[ref];
-                                Zcm = (f2){zc.x, zc.y};
                             }
                         }
                     }
@@ -1252,6 +1307,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                         // (floor form, see FS_FAST_LOOP_FL: the run's scale puts max|w| at 2^-24)
                         const int E = dze + kScaleShift;
                         const float sE = __builtin_amdgcn_ldexpf(1.0f, E); // 0 / denormal below 2^-126: dz then cannot matter
+                        FS_LOAD_DC()
                         const int dsh = dce - E;
                         const f2 dcs = {__builtin_amdgcn_ldexpf(dcm.x, dsh), __builtin_amdgcn_ldexpf(dcm.y, dsh)};
                         const float mx0 = __builtin_fmaxf(__builtin_fabsf(dzm.x), __builtin_fabsf(dzm.y));
@@ -1279,6 +1335,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                         }
                         if (__builtin_amdgcn_ballot_w64(!start_ok) != 0ull || run_len == 0u)
                             break;
+                        {
+                            uint32_t lane_p;
+                            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_p));
+                            volatile __attribute__((address_space(3))) float *pz =
+                                (volatile __attribute__((address_space(3))) float *)s_dzp + (wave_in_block * 64u + lane_p) * 2u;
+                            pz[0] = dzm.x, pz[1] = dzm.y;
+                        }
                         const f2 sE2 = {sE, sE};
                         // One step from (W_, Z_) into (NW_, NZ_); V accumulates the lanes that fail a test.
                         // AFTER_ARITH is the statement that waits for the entry (tied to the step's results so that it stays
@@ -1355,33 +1418,33 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                                 float4 *wbuf = s_zs_lds + (threadIdx.x >> 6) * 128u;
                                 const uint32_t lds_base = (uint32_t)__builtin_amdgcn_readfirstlane(
                                     (int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) float4 *)wbuf);
-                                const uint32_t last_entry = A.orbit_count + 1u; // the prepared arrays hold count + 2 entries
                                 const uint32_t nchunks = (run_len + 63u) >> 6;
+// (round 4) NOTHING may be written to a vector register while EXEC is widened: the register the compiler picks for a
+// temporary holds, in the lanes that are masked off, whatever those lanes' pixels still need -- the first form of this
+// statement built the per-lane offset there and, once the allocation had shifted, overwrote finished pixels' step counters
+// (tests/test_gpu_variants.py caught it).  The per-lane byte offset (lane * 16) is therefore made ONCE, at the top of the
+// kernel where every lane is active, kept for the kernel's lifetime and only read here; the chunk's first entry goes into
+// the wave-uniform base.  Entries past the orbit's end land in the arrays that follow zs in the same allocation.
 // ALL 64 lanes take part in the LDS-DMA whatever the loop's EXEC mask is (lanes whose pixel has finished are masked
 // off here, and a masked lane would leave its 16-byte slot of the chunk unwritten): EXEC is widened for the one
 // instruction, the lane number and the (clamped) entry offset are rebuilt inside the widened region, then EXEC and M0
 // are restored.  vaddr = 32-bit byte offset from the scalar base (the orbit arrays are far below 4 GiB).
 #define FS_GLDS_CHUNK(CH)                                                                                           \
     {                                                                                                               \
-        const uint32_t idx0_ = ref_u + 1u + (CH) * 64u;                                                             \
+        const float4 *src_ = zs + (ref_u + 1u + (CH) * 64u); /* wave-uniform; the arrays behind zs are the slack */  \
         const uint32_t dst_ = lds_base + (((CH) & 1u) << 10);                                                       \
-        uint32_t keep_, voff_;                                                                                      \
+        uint32_t keep_;                                                                                             \
         uint64_t exec_;                                                                                             \
         asm volatile("s_or_saveexec_b64 %0, -1\n\t"                                                               \
-                     "v_mbcnt_lo_u32_b32 %2, -1, 0\n\t"                                                           \
-                     "v_mbcnt_hi_u32_b32 %2, -1, %2\n\t"                                                          \
-                     "v_add_u32 %2, %3, %2\n\t"                                                                   \
-                     "v_min_u32 %2, %4, %2\n\t"                                                                   \
-                     "v_lshlrev_b32 %2, 4, %2\n\t"                                                                \
                      "s_mov_b32 %1, m0\n\t"                                                                       \
-                     "s_mov_b32 m0, %5\n\t"                                                                       \
+                     "s_mov_b32 m0, %3\n\t"                                                                       \
                      "s_nop 0\n\t"                                                                                \
-                     "global_load_lds_dwordx4 %2, %6\n\t"                                                         \
+                     "global_load_lds_dwordx4 %2, %4\n\t"                                                         \
                      "s_mov_b32 m0, %1\n\t"                                                                       \
                      "s_mov_b64 exec, %0"                                                                           \
-                     : "=&s"(exec_), "=&s"(keep_), "=&v"(voff_)                                                     \
-                     : "s"(idx0_), "s"(last_entry), "s"(dst_), "s"(zs)                                              \
-                     : "memory", "scc");                                                                                   \
+                     : "=&s"(exec_), "=&s"(keep_)                                                                   \
+                     : "v"(lds_lane16), "s"(dst_), "s"(src_)                                                        \
+                     : "memory", "scc");                                                                            \
     }
                                 FS_GLDS_CHUNK(0u)
                                 uint32_t chunk = 0;
@@ -1654,19 +1717,29 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
 #undef FS_SCALED_STEP
                         FS_CYC(cyc_body += __builtin_readcyclecounter() - cyc_t2);
                         if (fl_redo) {
+                            // the same run again from its start state: dz's mantissas come back from where they were parked
+                            uint32_t lane_p;
+                            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_p));
+                            const volatile __attribute__((address_space(3))) float *pz =
+                                (const volatile __attribute__((address_space(3))) float *)s_dzp + (wave_in_block * 64u + lane_p) * 2u;
+                            dzm = (f2){pz[0], pz[1]};
+                            dze = E - kScaleShift;
                             fl_per_trip = true;
                             continue;
                         }
                         fl_per_trip = false;
-                        // back to the reduced form: the larger part's exponent moves into dze (exact)
-                        if (c != 0u) {
+                        // back to the reduced form: the larger part's exponent moves into dze (exact).  Also when the run took
+                        // no step: wO is dz 2^-E then, and rebuilding dz, its exponent and the orbit value from what the run
+                        // ends with means that none of them has to survive the run in a register (round 4: with the hot runs
+                        // the allocator had spilled them to scratch around every run)
+                        {
                             const float mxw = __builtin_fmaxf(__builtin_fabsf(wO.x), __builtin_fabsf(wO.y));
                             const int k = (int)((uint32_t)__float_as_int(mxw) >> 23) - 127;
                             dzm = (f2){__builtin_amdgcn_ldexpf(wO.x, -k), __builtin_amdgcn_ldexpf(wO.y, -k)};
                             dze = E + k;
                             ref += c;
                             iterations += c;
-                            if (kStats) {
+                            if (kStats && c != 0u) {
                                 c_pt += c;
                                 c_scaled += c;
                                 c_runs++;
@@ -1674,8 +1747,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                                 if (c < 8u)
                                     c_wshort++;
                             }
-                            const float4 zc = zq[ref];
-                            Zcm = (f2){zc.x, zc.y};
                         }
                         if (failed) {
                             sc_stopped = true;
@@ -1746,11 +1817,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                 if (!sc_stopped)
                 {
                     typedef float f3 __attribute__((ext_vector_type(3)));
-                    int sC = __float_as_int(zq[ref].z);
+                    const float4 zq0 = zq[ref];
+                    f2 Zcm = {zq0.x, zq0.y};
+                    int sC = __float_as_int(zq0.z);
                     int W = dze + sC;
                     // entry of step k of this run = zq[done_k] + lane_off: a wave-uniform base advanced on the scalar unit
                     // plus a per-lane byte offset that is fixed for the whole run
                     const uint32_t lane_off = (ref + 1) * 16u;
+                    FS_LOAD_DC()
                     const f2 dcm128 = dcm * 128.0f;
                     const int dceB = dce - 5;
                     uint32_t done = 0;
@@ -1816,7 +1890,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
 #undef FS_QUIET_STEP
                 // ---- one careful step: full exit tests (Fractal.cpp:2646-2661); the literal transcription takes over when a
                 // value leaves the range the straight-line form is proven for
-                const int Zce1 = __float_as_int(zr[ref].z) + 1; // the true exponent of 2 Zc (sC may be the poison value)
+                const float4 zcur = zr[ref];
+                const f2 Zcm = {zcur.x, zcur.y};
+                const int Zce1 = __float_as_int(zcur.z) + 1; // the true exponent of 2 Zc (sC may be the poison value)
                 const float4 zv = zr[ref + 1];
                 const f2 Znm = {zv.x, zv.y};
                 const int Zne = __float_as_int(zv.z);
@@ -1830,6 +1906,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                 asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(p) : "v"(pa), "v"(pb));
                 const int pe = imax(dze + e_cur, kMinBigExp);
                 // q = p + dc, then Reduce (the larger part a non-zero float: checked below)
+                FS_LOAD_DC()
                 const int e_q = imax(pe, dce);
                 f2 q = p * pow2_or_zero(pe - e_q) + dcm * pow2_or_zero(dce - e_q);
                 const int fmax = imax((int)__builtin_amdgcn_ubfe(__float_as_int(q.x), 23, 8),
@@ -1867,7 +1944,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                     hcplx32 curg = hc_mul2(Zc_g);
                     curg = hc_add(curg, dz_g);
                     hcplx32 ndz = hc_mul(dz_g, curg);
-                    ndz = hc_add(ndz, dc);
+                    ndz = hc_add(ndz, hcplx32{dcm.x, dcm.y, dce});
                     hc_reduce(ndz);
                     z = hc_add(hcplx32{Znm.x, Znm.y, Zne}, ndz);
                     hc_reduce(z);
@@ -1912,7 +1989,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                 was_skip = false;
                 ref++;
                 dzm = q;
-                Zcm = Znm;
                 if (escaped) {
                     running = false; // `break` happens before iterations++ in the CPU loop
                 } else {
@@ -1922,8 +1998,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                         dzm = (f2){z.re, z.im};
                         dze = z.e;
                         ref = 0;
-                        const float4 z0 = zr[0];
-                        Zcm = (f2){z0.x, z0.y};
                     }
                     iterations++;
                     running = iterations < n_iterations;
