@@ -3134,6 +3134,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                 }
 #undef FS_SQ_LOAD
 #undef FS_SQ_WAIT_ZERO
+#undef FS_STEP_DN
 #undef FS_SQ_WAIT_NONE
 #undef FS_SQ_STEP
 #undef FS_SQ_COMMIT
@@ -3214,15 +3215,16 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                 const float nxm = __int_as_float((qxb & 0x807FFFFF) | 0x3F800000);
                 const float nym = __int_as_float((qyb & 0x807FFFFF) | 0x3F800000);
                 const int nxe = EQ + fx - 127, nye = EQ + fy - 127;
-                // dn = nx^2 + ny^2
+                // dn = nx^2 + ny^2 (formed where it is needed: see the quiet step below)
                 const int Zne = __float_as_int(zn4.z);
-                const f2 SQ = (f2){nxm, nym} * (f2){nxm, nym};
-                const int dd = (nxe - nye) << 1;
-                const bool sxbig = dd >= 0;
-                const int nadd = sxbig ? -dd : dd;
-                const float md = p2(nadd);
-                const float dnm = SQ.x * (sxbig ? 1.0f : md) + SQ.y * (sxbig ? md : 1.0f);
-                const int dne = (sxbig ? nxe : nye) << 1;
+#define FS_STEP_DN()                                                                                                \
+    const f2 SQ = (f2){nxm, nym} * (f2){nxm, nym};                                                                  \
+    const int dd = (nxe - nye) << 1;                                                                                \
+    const bool sxbig = dd >= 0;                                                                                     \
+    const int nadd = sxbig ? -dd : dd;                                                                              \
+    const float md = p2(nadd);                                                                                      \
+    const float dnm = SQ.x * (sxbig ? 1.0f : md) + SQ.y * (sxbig ? md : 1.0f);                                      \
+    const int dne = (sxbig ? nxe : nye) << 1;
                 // the sums of the dz update inside [2^-30, 2^30] (also excludes zeros, denormals, infinities and NaNs)
                 const float dmx = fmaxf(fmaxf(fmaxf(fabsf(T.x), fabsf(T.y)), fmaxf(fabsf(N.x), fabsf(N.y))),
                                         fmaxf(fabsf(Q.x), fabsf(Q.y)));
@@ -3247,7 +3249,10 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                     Zcached_at = RefIteration;
                     DeltaSubNX = hreal<F>{nxm, nxe};
                     DeltaSubNY = hreal<F>{nym, nye};
-                    {
+                    // |dz|^2 is read by the next table lookup only, and a table entry can only apply at orbit indices
+                    // m = 1 (mod 4): three quiet steps in four leave it unformed (round 4; without a table nothing reads it)
+                    if (kBla && __builtin_amdgcn_ballot_w64((RefIteration & 3u) == 1u) != 0ull) {
+                        FS_STEP_DN()
                         const int db = __float_as_int(dnm);
                         DeltaNormSquared = hreal<F>{__int_as_float((db & 0x007FFFFF) | 0x3F800000),
                                                     dne + (int)__builtin_amdgcn_ubfe(db, 23, 8) - 127};
@@ -3256,6 +3261,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                     FS_PH(ph_step += __builtin_readcyclecounter() - ph_t);
                     continue;
                 }
+                FS_STEP_DN()
                 // z = Z' + n under ez
                 const int ez = imax(imax(Zne, nxe), nye);
                 const float zsZ = p2(Zne - ez);
