@@ -3134,7 +3134,6 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                 }
 #undef FS_SQ_LOAD
 #undef FS_SQ_WAIT_ZERO
-#undef FS_STEP_DN
 #undef FS_SQ_WAIT_NONE
 #undef FS_SQ_STEP
 #undef FS_SQ_COMMIT
@@ -3262,6 +3261,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                     continue;
                 }
                 FS_STEP_DN()
+#undef FS_STEP_DN
                 // z = Z' + n under ez
                 const int ez = imax(imax(Zne, nxe), nye);
                 const float zsZ = p2(Zne - ez);
