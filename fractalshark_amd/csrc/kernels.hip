@@ -2662,6 +2662,40 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                         asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(s1) : "v"(tA), "v"(tB));
                         const f2 s2 = s1 + tC;
                         asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(s3) : "v"(s2), "v"(tD));
+                        // (window 2^+-30 on every sum and 2^30 on the record's mantissas: an operand the reference would
+                        // ignore -- 120 binades under the leading term -- is then at least 2^30 below half an ulp of any sum
+                        // it could be added to, so the power-of-two factor above may stay non-zero there)
+                        const float zmn = fminf(fminf(fabsf(s1.x), fabsf(s1.y)), fminf(fabsf(s2.x), fabsf(s2.y)));
+                        const int emin = imin(imin(imin(DeltaSubNX.e, DeltaSubNY.e), imin(DeltaSub0X.e, DeltaSub0Y.e)),
+                                              imin(imin(Ax.e, Ay.e), imin(imin(Bx.e, By.e), Z.e)));
+                        const float amx = fmaxf(fmaxf(fabsf(Ax.m), fabsf(Ay.m)), fmaxf(fabsf(Bx.m), fabsf(By.m)));
+                        const float dmx = fmaxf(fabsf(s3.x), fabsf(s3.y)), dmn = fminf(fabsf(s3.x), fabsf(s3.y));
+                        const bool sums_ok = dmn >= 0x1p-30f && dmx <= 0x1p30f && zmn > 0.0f && emin > -(1 << 26) && amx <= 0x1p30f;
+                        // (round 4) QUIET jump, the jump's form of the quiet step: both parts of the new dz at least four binades
+                        // below the orbit value the jump arrives at, and that value below 4 -- then |z| is within [0.646, 1.354] |Z|:
+                        // neither the escape nor the rebase test can fire, and z and the norms are not formed.  (|dz|^2 is formed
+                        // only when the index the jump lands on is one a table entry can apply at.)
+                        const int tex = Ex + (int)__builtin_amdgcn_ubfe(__float_as_int(s3.x), 23, 8) - 127;
+                        const int tey = Ey + (int)__builtin_amdgcn_ubfe(__float_as_int(s3.y), 23, 8) - 127;
+                        const bool quiet_j = sums_ok && imax(tex, tey) <= Z.e - 4 && Z.e <= 1 && Z.e >= -40 &&
+                                             RefIteration + l + 1u < count;
+                        if (quiet_j) {
+                            applied = true;
+                            RefIteration += l;
+                            DeltaSubNX = hreal<F>{s3.x, Ex};
+                            DeltaSubNY = hreal<F>{s3.y, Ey};
+                            if ((RefIteration & 3u) == 1u) {
+                                const f2 SQ = s3 * s3;
+                                const int dd = (Ex - Ey) << 1;
+                                const bool sxbig = dd >= 0;
+                                const float md = p2(sxbig ? -dd : dd);
+                                const float dnm = SQ.x * (sxbig ? 1.0f : md) + SQ.y * (sxbig ? md : 1.0f);
+                                const int dne = (sxbig ? Ex : Ey) << 1;
+                                const int db = __float_as_int(dnm);
+                                DeltaNormSquared = hreal<F>{__int_as_float((db & 0x007FFFFF) | 0x3F800000),
+                                                            dne + (int)__builtin_amdgcn_ubfe(db, 23, 8) - 127};
+                            }
+                        } else {
                         // z = Z + dz under ez; the norms
                         const int ez = imax(imax(Z.e, Ex), Ey);
                         const float zsZ = p2(Z.e - ez);
@@ -2674,15 +2708,8 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                         const float md = p2(sxbig ? -dd : dd);
                         const float dnm = SQ.x * (sxbig ? 1.0f : md) + SQ.y * (sxbig ? md : 1.0f);
                         const int dne = (sxbig ? Ex : Ey) << 1;
-                        const float smx = fmaxf(fmaxf(fabsf(s3.x), fabsf(s3.y)), fmaxf(fabsf(Zt.x), fabsf(Zt.y)));
-                        const float smn = fminf(fminf(fabsf(s3.x), fabsf(s3.y)), fminf(fabsf(Zt.x), fabsf(Zt.y)));
-                        const float zmn = fminf(fminf(fabsf(s1.x), fabsf(s1.y)), fminf(fabsf(s2.x), fabsf(s2.y)));
-                        const int emin = imin(imin(imin(DeltaSubNX.e, DeltaSubNY.e), imin(DeltaSub0X.e, DeltaSub0Y.e)),
-                                              imin(imin(Ax.e, Ay.e), imin(imin(Bx.e, By.e), Z.e)));
-                        // (window 2^+-30 on every sum and 2^30 on the record's mantissas: an operand the reference would
-                        // ignore -- 120 binades under the leading term -- is then at least 2^30 below half an ulp of any sum
-                        // it could be added to, so the power-of-two factor above may stay non-zero there)
-                        const float amx = fmaxf(fmaxf(fabsf(Ax.m), fabsf(Ay.m)), fmaxf(fabsf(Bx.m), fabsf(By.m)));
+                        const float smx = fmaxf(dmx, fmaxf(fabsf(Zt.x), fabsf(Zt.y)));
+                        const float smn = fminf(dmn, fminf(fabsf(Zt.x), fabsf(Zt.y)));
                         if (smn >= 0x1p-30f && smx <= 0x1p30f && zmn > 0.0f && emin > -(1 << 26) && amx <= 0x1p30f) {
                             applied = true;
                             RefIteration += l;
@@ -2702,6 +2729,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                                                             (ez << 1) + (int)__builtin_amdgcn_ubfe(nb, 23, 8) - 127};
                                 RefIteration = 0;
                             }
+                        }
                         }
                     }
                     FS_PH(ph_jump += __builtin_readcyclecounter() - ph_t);
