@@ -92,19 +92,36 @@ __device__ __forceinline__ bool scaled_startable(const float4 e)
 // Companion array of the tuned LAv2 loop: {re, im, s, -} with s = ~exp + 116 (-(s - 116) = exp + 1 = the exponent of 2Z;
 // the bias turns the loop's range tests into comparisons against constants) for orbit values below 8, and a large
 // positive poison for larger ones, which makes the range test fail there.  zq must hold 2 n entries.
-// Block bound of entry j (the .w of the second companion, see below): min(bound[j+1 .. j+4]) 2^-18, "never" if one of them is.
+// Block bound of entry j (the .w of the second companion, see below; "never" when one of the four entries after j has no
+// bound).  With G = max(max|dz|, max|dc|) at entry j (maximum norms of the parts, true scale) the block's four arrivals pass
+// their own bound tests whenever G <= this value:
+//   one step from entry k:  dz' = dz (2 Z_k + dz) + dc,  |a b|_inf <= 2 |a|_inf |b|_inf for complex a, b, so
+//   |dz'|_inf <= 2 G (2 M_k + G) + G <= G (4 M_k + 3.8)        M_k = max part of Z_k,  G <= 1.4 (every bound is <= 0.25 * 5.6)
+//   => G grows by at most g_k = 4 M_k + 3.8 per step (dc included: g_k > 1), and arrival j + m passes its test when
+//      G g_j g_(j+1) .. g_(j+m-1) <= bound[j + m]:   block bound = min over m = 1 .. 4 of bound[j + m] / (g_j .. g_(j+m-1)),
+//   by induction over the block's steps (arrival j + m - 1 has passed its test, so G <= 1.4 holds where step m starts; at
+//   entry j itself G <= bound[j + 1] / 3.8).  Rounding: the steps' own rounding errors are 2^-23 relative, each g carries
+//   a factor 1 + 2^-10.  (Round 3 used one constant for every step -- |2Z + dz| < 20, i.e. 2^-18 for four steps; the orbit's
+//   own |Z| gives 2^-9 .. 2^-12 for typical entries, and fewer blocks need their bound tests.)
 __device__ __forceinline__ float scaled_block_bound(const float4 *__restrict__ zref, uint64_t j, uint64_t n)
 {
     if (j >= n)
         return -0.0f;
-    float bm = 0x1p60f;
-    bool all4 = true;
-    for (uint32_t k = 1; k <= 4; k++) {
-        const float bk = j + k < n ? scaled_bound(zref[j + k]) : -0.0f;
-        all4 = all4 && __float_as_int(bk) != (int)0x80000000;
-        bm = __builtin_fminf(bm, bk);
+    float best = 0x1p60f, grow = 1.0f;
+    bool ok = true;
+    for (uint32_t k = 0; k < 4; k++) {
+        // growth of the step that leaves entry j + k
+        const float4 v = zref[j + k < n ? j + k : n - 1];
+        const int e = __float_as_int(v.z);
+        const float m = __builtin_amdgcn_ldexpf(__builtin_fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)),
+                                               e < -200 ? -200 : (e > 100 ? 100 : e));
+        ok = ok && m < 5.6f; // (a state never sits at an entry this large: its own bound is "never")
+        grow *= (4.0f * m + 3.8f) * (1.0f + 0x1p-10f);
+        const float bk = j + k + 1 < n ? scaled_bound(zref[j + k + 1]) : -0.0f;
+        ok = ok && __float_as_int(bk) != (int)0x80000000;
+        best = __builtin_fminf(best, bk / grow);
     }
-    return all4 ? bm * 0x1p-18f : -0.0f;
+    return ok ? best * (1.0f - 0x1p-10f) : -0.0f;
 }
 
 __global__ void k_make_quiet_orbit(const float4 *__restrict__ zref, float4 *__restrict__ zq, float2 *__restrict__ zs2,
@@ -120,25 +137,15 @@ __global__ void k_make_quiet_orbit(const float4 *__restrict__ zref, float4 *__re
     // scale).  (Packing the entry into 8 bytes and deriving the bound from 2Z costs one more vector
     // instruction per step and was measured slower: the loop is not bound by its loads.)
     const float b0 = scaled_bound(v);
-    // .w: the BLOCK bound of the four entries after this one, min(bound[i+1..i+4]) * 2^-18 ("never" if one of them is):
-    // with G = max(max|dz|, max|dc|) at this entry, |dz'|_2 <= |dz|_2 |2Z + dz|_2 + |dc|_2 and |2Z + dz|_2 < 20 while the
-    // per-step bound holds (|Z|_2 < 7.92, |dz|_inf < 2.9), so four steps multiply G by less than
-    // ((20 * 21 + 1) * 20 + 1) * 20 + 1 = 168421 times sqrt 2 < 2^18: G <= .w implies that each of the four arrivals passes
-    // its own bound test, and the scalar-cache path of the scaled runs then skips those tests (same accepted steps).
-    // (Eight entries with 2^-36 -- one test per loop body -- pass for 67 % of C3's blocks instead of 93.6 %: 63.5 instead of
-    // 55.8 ms.)
+    // .w: the BLOCK bound of the four entries after this one (scaled_block_bound above): G = max(max|dz|, max|dc|) <= .w at
+    // this entry implies that each of the four arrivals passes its own bound test, and the scalar-cache path of the scaled
+    // runs then skips those tests (same accepted steps).  (Eight entries per test -- one test per loop body -- passed for
+    // 67 % of C3's blocks instead of 93.6 % with round 3's constant-growth bound: 63.5 instead of 55.8 ms.)
     // (A run may START at every usable entry and at an exact zero -- entry 0, where every rebase lands; 2Z + dz is then dz
     // itself in either arithmetic -- the kernels read that off .z and .xy.  Nothing arrives at a zero entry: its bound is
     // the "never" pattern.)
-    float bm = 0x1p60f;
-    bool all4 = true;
-    for (uint32_t k = 1; k <= 4; k++) {
-        const float bk = i + k < n ? scaled_bound(zref[i + k]) : -0.0f;
-        all4 = all4 && __float_as_int(bk) != (int)0x80000000;
-        bm = __builtin_fminf(bm, bk);
-    }
     zq[n + i] = make_float4(__builtin_amdgcn_ldexpf(v.x, e + 1), __builtin_amdgcn_ldexpf(v.y, e + 1), b0,
-                            all4 ? bm * 0x1p-18f : -0.0f);
+                            scaled_block_bound(zref, i, n));
     // the compact form for the 16-step body of the untested loop (FS_FAST_LOOP_FD16): 2Z alone, and the block bounds a body
     // whose first arrival is entry i needs -- those of its entries 3, 7, 11 (the states its second to fourth blocks start
     // from) and 15 (the state the NEXT body starts from)
