@@ -1563,9 +1563,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
 #if FS_FL_EVERY && !defined(FS_VERIFY_FLOOR)
                                     if (!fl_per_trip) {
                                         {
-                                            // (the 16-step body of k_perturb_scalar, FS_FAST_LOOP_FD16, measures 1 - 2 % slower
-                                            // here -- 51.6 against 50.6 ms at N = 1, the same 7.5 ms on the slowest of eight
-                                            // emulated ranks: with eight waves per SIMD the round trip it halves is hidden)
+                                            // (the 16-step body of k_perturb_scalar, FS_FAST_LOOP_FD16, measures 2 % slower here --
+                                            // 47.8 - 48.1 against 46.6 - 47.0 ms at N = 1, 6.79 against 6.70 ms on the slowest of
+                                            // eight emulated ranks: with seven waves per SIMD the round trip it halves is hidden)
                                             FS_FAST_LOOP_FD(FS_PF_NONE, FS_BT_DC_MAX, FS_BT_DC_ADD, FS_BT_H_CMP, FS_BT_H_OR);
                                         }
                                         ebo = 0;
