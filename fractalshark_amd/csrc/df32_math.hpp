@@ -212,6 +212,77 @@ __device__ __forceinline__ df32x2 operator*(df32x2 a, df32x2 b)
     const f2 e = th + tt;
     return df32x2(e, (th - e) + tt);
 }
+
+// (a.lo - b.lo, a.hi + b.hi): sub_dblflt in the lower half and add_dblflt in the upper one, operation for operation (a
+// subtraction IS the addition of the negated operand, so each packed addition below with one negated half is the scalar
+// operation of the corresponding line of operator- / operator+ above).
+__device__ __forceinline__ df32x2 sub_lo_add_hi(df32x2 a, df32x2 b)
+{
+    typedef df32x2::f2 f2;
+    f2 t1 = a.head + (f2){-b.head.x, b.head.y};
+    f2 t2 = t1 - a.head;
+    const f2 v3 = b.head + (f2){t2.x, -t2.y};
+    f2 t3 = (a.head + (t2 - t1)) + (f2){-v3.x, v3.y};
+    f2 t4 = a.tail + (f2){-b.tail.x, b.tail.y};
+    t2 = t4 - a.tail;
+    const f2 v5 = b.tail + (f2){t2.x, -t2.y};
+    const f2 t5 = (a.tail + (t2 - t4)) + (f2){-v5.x, v5.y};
+    t3 = t3 + t4;
+    t4 = t1 + t3;
+    t3 = (t1 - t4) + t3;
+    t3 = t3 + t5;
+    const f2 e = t4 + t3;
+    return df32x2(e, (t4 - e) + t3);
+}
+
+// Two HDRFloat<CudaDblflt> side by side, each with its own exponent: the X and the Y part of the scalar-HDR perturbation
+// step (HDRFloat::custom_perturb3 and the norms around it), whose operations come in pairs of the same kind.
+struct hreal2 {
+    df32x2 m;
+    int32_t ex, ey;
+    __device__ __forceinline__ hreal2() = default;
+    __device__ __forceinline__ hreal2(df32x2 m_, int32_t ex_, int32_t ey_) : m(m_), ex(ex_), ey(ey_) {}
+    __device__ __forceinline__ hreal2(hreal<df32> x, hreal<df32> y) : m(x.m, y.m), ex(x.e), ey(y.e) {}
+    __device__ __forceinline__ hreal<df32> x() const { return hreal<df32>{m.lo(), ex}; }
+    __device__ __forceinline__ hreal<df32> y() const { return hreal<df32>{m.hi(), ey}; }
+};
+
+// (a.x - b.x, a.y + b.y) for kSubLo, else (a.x + b.x, a.y + b.y): add_mutable / subtract_mutable (hr_add / hr_sub,
+// hdr_math.hpp) of both pairs in one straight line.  The reference's four-way branch on the exponent gap d = a.e - b.e is,
+// for |d| < 120, "scale the operand with the smaller exponent by 2^-|d|, then add, first operand first"; which operand that
+// is is a per-lane select here and the scaling one packed double-float product for both parts.  That product has a
+// multiplier {2^-|d|, 0}: of mul_dblflt's four fused operations the two on the multiplier's zero tail return their addend
+// (x * 0 + t = t for finite x unless t is -0, and t -- the exact error of a product by a power of two, or what the next
+// fused operation made of it -- is never -0), so they are not issued.  From a gap of 120 on the reference returns the
+// operand with the larger exponent untouched (deep zooms live there: dz is hundreds of binades below the orbit): one more
+// select per word.  What the straight line does NOT cover is reported in `rare` and left to the caller's literal path: a
+// zero result (the reference resets the exponent) and non-finite values.
+template <bool kSubLo> __device__ __forceinline__ hreal2 hr_add2(hreal2 a, hreal2 b, bool &rare)
+{
+    typedef df32x2::f2 f2;
+    const int32_t dx = a.ex - b.ex, dy = a.ey - b.ey;
+    const bool nx = dx < 0, ny = dy < 0;
+    const int32_t gx = nx ? -dx : dx, gy = ny ? -dy : dy;
+    const f2 mul = {__builtin_amdgcn_ldexpf(1.0f, -gx), __builtin_amdgcn_ldexpf(1.0f, -gy)}; // multiplier_neg(-|d|), |d| < 120
+    const f2 sh = {nx ? a.m.head.x : b.m.head.x, ny ? a.m.head.y : b.m.head.y};
+    const f2 st = {nx ? a.m.tail.x : b.m.tail.x, ny ? a.m.tail.y : b.m.tail.y};
+    const f2 th = sh * mul;
+    f2 tt = __builtin_elementwise_fma(sh, mul, -th);
+    tt = __builtin_elementwise_fma(st, mul, tt);
+    const f2 se = th + tt;
+    const f2 sl = (th - se) + tt;
+    const df32x2 A((f2){nx ? se.x : a.m.head.x, ny ? se.y : a.m.head.y}, (f2){nx ? sl.x : a.m.tail.x, ny ? sl.y : a.m.tail.y});
+    const df32x2 B((f2){nx ? b.m.head.x : se.x, ny ? b.m.head.y : se.y}, (f2){nx ? b.m.tail.x : sl.x, ny ? b.m.tail.y : sl.y});
+    const df32x2 W = kSubLo ? sub_lo_add_hi(A, B) : A + B;
+    // a gap of 120 or more: the operand with the larger exponent, untouched (negated when it is the subtrahend)
+    const bool fx = gx >= kExpDiffIgnored, fy = gy >= kExpDiffIgnored;
+    const float uhx = nx ? (kSubLo ? -B.head.x : B.head.x) : A.head.x, utx = nx ? (kSubLo ? -B.tail.x : B.tail.x) : A.tail.x;
+    const float uhy = ny ? B.head.y : A.head.y, uty = ny ? B.tail.y : A.tail.y;
+    const df32x2 R((f2){fx ? uhx : W.head.x, fy ? uhy : W.head.y}, (f2){fx ? utx : W.tail.x, fy ? uty : W.tail.y});
+    // neither zero nor infinite nor a NaN (class mask: +-normal, +-denormal)
+    rare = rare || !__builtin_amdgcn_classf(R.head.x, 0x198) || !__builtin_amdgcn_classf(R.head.y, 0x198);
+    return hreal2(R, nx ? b.ex : a.ex, ny ? b.ey : a.ey);
+}
 #endif
 
 using hreal2x32 = hreal<df32>;

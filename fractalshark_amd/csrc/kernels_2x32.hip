@@ -137,6 +137,37 @@ __device__ __forceinline__ HC hc_mul2_pk(HC a)
     return HC{R.lo(), R.hi(), clamp_exp(a.e + 1)};
 }
 
+// One perturbation step of the scalar-HDR loop (HDRFloat::custom_perturb3, HDRFloat.h:797-812, and the norms of
+// LAKernel.cuh:170-200) with the X and the Y part side by side: its operations come in pairs of the same kind --
+// (2zx + dX, 2zy + dY), (dX sumX, dX sumY), (dY sumY, dY sumX), (P - Q, P + Q), (+ cX, + cY), (z'x + nX, z'y + nY),
+// (tX^2, nX^2) + (tY^2, nY^2) -- so every double-float product and sum is one packed operation for two (df32x2, hr_add2:
+// the same IEEE operations per half as the scalar code the literal loop below runs, in the same order).  Returns false for
+// a lane the straight line does not cover (hr_add2's `rare`, or a dz part that is an exact zero); the caller votes and runs
+// the literal step for the wave then.
+struct PkStep {
+    HR nX, nY, tX, tY, norm, dnorm;
+    bool covered;
+};
+__device__ __forceinline__ PkStep pt_step_pk(HR dX, HR dY, HR zx, HR zy, HR c0X, HR c0Y, HR zxn, HR zyn)
+{
+    // multiply_mutable clamps the sum of two exponents at kMinBigExp: that needs a factor that is an exact zero, and the only
+    // factors of this step whose exponent is not bounded below by dz's own are dX and dY themselves.  (An exact zero in the
+    // orbit -- entry 0, where every rebase lands -- or in delta-c only ever meets an addition, as the operand that is dropped.)
+    bool rare = (dX.e < dY.e ? dX.e : dY.e) <= -(1 << 26);
+    const df32 one(1.0f);
+    const hreal2 Z2(df32x2(zx.m, zy.m) * df32x2(one, one), zx.e + 1, zy.e + 1); // hr_mul2 of both
+    const hreal2 S = hr_add2<false>(Z2, hreal2(dX, dY), rare);                  // (sumX, sumY)
+    const hreal2 P(df32x2(dX.m, dX.m) * S.m, dX.e + S.ex, dX.e + S.ey);           // (dX sumX, dX sumY)
+    const hreal2 Q(df32x2(dY.m, dY.m) * S.m.swapped(), dY.e + S.ey, dY.e + S.ex); // (dY sumY, dY sumX)
+    const hreal2 R = hr_add2<true>(P, Q, rare);                                 // (dX sumX - dY sumY, dX sumY + dY sumX)
+    const hreal2 N = hr_add2<false>(R, hreal2(c0X, c0Y), rare);
+    const HR nX = hr_reduced(N.x()), nY = hr_reduced(N.y());
+    const hreal2 T = hr_add2<false>(hreal2(zxn, zyn), hreal2(nX, nY), rare);
+    const df32x2 a(df32(T.m.head.x, T.m.tail.x), nX.m), b(df32(T.m.head.y, T.m.tail.y), nY.m);
+    const hreal2 NN = hr_add2<false>(hreal2(a * a, T.ex * 2, nX.e * 2), hreal2(b * b, T.ey * 2, nY.e * 2), rare); // (|z|^2, |dz|^2)
+    return PkStep{nX, nY, T.x(), T.y(), hr_reduced(NN.x()), hr_reduced(NN.y()), !rare};
+}
+
 // IterT: the reference's IterType for the counters (LAKernel.cuh:3): uint32_t, or uint64_t for iteration caps of 2^32 and
 // above (iterations, the cap, the AT iteration count and the i x StepLength product in 64 bits).
 // kSeq: the orbit stays compressed (A.wp): every entry comes from a Seq2x32 cursor.
@@ -307,30 +338,52 @@ __global__ void __launch_bounds__(256) k_lav2_2x32(FsLav2Args2x32 A)
                 zx = orbit_x(orb, RefIteration), zy = orbit_y(orb, RefIteration);
             }
             for (;;) {
-                const HR sumY = hr_add(hr_mul2(zy), dY); // tempSum1
-                const HR sumX = hr_add(hr_mul2(zx), dX); // tempSum2
-                ++RefIteration;
-                // custom_perturb3 (its tempSum1 parameter is bound to tempSum2 and vice versa)
-                HR nX = hr_add(hr_sub(hr_mul(dX, sumX), hr_mul(dY, sumY)), DeltaSub0X);
-                hr_reduce(nX);
-                HR nY = hr_add(hr_add(hr_mul(dX, sumY), hr_mul(dY, sumX)), DeltaSub0Y);
-                hr_reduce(nY);
-                dX = nX;
-                dY = nY;
-                if (kStats)
-                    c_pt++;
-                if constexpr (kSeq) {
-                    seq.step();
-                    zx = seq.zx, zy = seq.zy;
-                } else {
-                    zx = orbit_x(orb, RefIteration);
-                    zy = orbit_y(orb, RefIteration);
+                HR tX, tY, normSquared, dnorm = HR{df32(0.0f), 0};
+                bool fast = false;
+                if constexpr (!kSeq) {
+                    // the packed straight-line step (pt_step_pk above); taken when every running lane of the wave is covered
+                    const HR zxn = orbit_x(orb, RefIteration + 1), zyn = orbit_y(orb, RefIteration + 1);
+                    const PkStep st = pt_step_pk(dX, dY, zx, zy, DeltaSub0X, DeltaSub0Y, zxn, zyn);
+                    if (__builtin_amdgcn_ballot_w64(!st.covered) == 0ull) {
+                        fast = true;
+                        ++RefIteration;
+                        dX = st.nX, dY = st.nY;
+                        zx = zxn, zy = zyn;
+                        tX = st.tX, tY = st.tY, normSquared = st.norm, dnorm = st.dnorm;
+                        if (kStats)
+                            c_pt++;
+                    }
                 }
-                const HR tX = hr_add(zx, dX);
-                const HR tY = hr_add(zy, dY);
-                const HR normSquared = hr_reduced(hr_add(hr_square(tX), hr_square(tY)));
+                if (!fast) {
+#ifdef FS_2X32_PROBE
+                    if (kStats)
+                        atomicAdd((unsigned long long *)&A.stats[12], 1ull); // probe: lane-steps through the literal step
+#endif
+                    const HR sumY = hr_add(hr_mul2(zy), dY); // tempSum1
+                    const HR sumX = hr_add(hr_mul2(zx), dX); // tempSum2
+                    ++RefIteration;
+                    // custom_perturb3 (its tempSum1 parameter is bound to tempSum2 and vice versa)
+                    HR nX = hr_add(hr_sub(hr_mul(dX, sumX), hr_mul(dY, sumY)), DeltaSub0X);
+                    hr_reduce(nX);
+                    HR nY = hr_add(hr_add(hr_mul(dX, sumY), hr_mul(dY, sumX)), DeltaSub0Y);
+                    hr_reduce(nY);
+                    dX = nX;
+                    dY = nY;
+                    if (kStats)
+                        c_pt++;
+                    if constexpr (kSeq) {
+                        seq.step();
+                        zx = seq.zx, zy = seq.zy;
+                    } else {
+                        zx = orbit_x(orb, RefIteration);
+                        zy = orbit_y(orb, RefIteration);
+                    }
+                    tX = hr_add(zx, dX);
+                    tY = hr_add(zy, dY);
+                    normSquared = hr_reduced(hr_add(hr_square(tX), hr_square(tY)));
+                }
                 if (below_bailout(normSquared) && iter < n_iterations) {
-                    const HR DeltaNormSquared = hr_reduced(hr_add(hr_square(dX), hr_square(dY)));
+                    const HR DeltaNormSquared = fast ? dnorm : hr_reduced(hr_add(hr_square(dX), hr_square(dY)));
                     if (hr_cmp_pos(normSquared, DeltaNormSquared) < 0 || RefIteration >= MaxRef) {
                         dX = tX;
                         dY = tY;

@@ -35,6 +35,27 @@ __global__ void k_check(const float4 *__restrict__ in, size_t n, unsigned long l
         atomicAdd(&bad[2], 1ull);
     if (!same(W.lo(), a1) || !same(W.hi(), a0))
         atomicAdd(&bad[3], 1ull);
+    const df32x2 D2 = sub_lo_add_hi(A, B);
+    if (!same(D2.lo(), a0 - b0) || !same(D2.hi(), a1 + b1))
+        atomicAdd(&bad[4], 1ull);
+    // hr_add2: two HDRFloat<CudaDblflt> additions (or a subtraction and an addition) side by side, against hr_add / hr_sub
+    // on each pair.  Exponents from the operands' low mantissa bits: gaps of -130 .. 130, mostly small.  Where the packed
+    // form reports `rare` nothing is claimed (the caller runs the literal code); everywhere else every bit must agree.
+    const int32_t k = (int32_t)(__float_as_uint(u.y) >> 3), q = (int32_t)(__float_as_uint(v.w) >> 5);
+    const int32_t ea0 = (k % 41) - 20, eb0 = ea0 + (((k >> 8) & 7) == 0 ? ((k >> 11) % 261) - 130 : ((k >> 11) % 49) - 24);
+    const int32_t ea1 = (q % 33) - 16, eb1 = ea1 + (((q >> 8) & 7) == 0 ? ((q >> 11) % 261) - 130 : ((q >> 11) % 49) - 24);
+    const hreal<df32> x0{a0, ea0}, y0{b0, eb0}, x1{a1, ea1}, y1{b1, eb1};
+    for (int sub = 0; sub < 2; sub++) {
+        bool rare = false;
+        const hreal2 r = sub ? hr_add2<true>(hreal2(x0, x1), hreal2(y0, y1), rare) : hr_add2<false>(hreal2(x0, x1), hreal2(y0, y1), rare);
+        if (rare) {
+            atomicAdd(&bad[6], 1ull);
+            continue;
+        }
+        const hreal<df32> w0 = sub ? hr_sub(x0, y0) : hr_add(x0, y0), w1 = hr_add(x1, y1);
+        if (!same(r.x().m, w0.m) || r.ex != w0.e || !same(r.y().m, w1.m) || r.ey != w1.e)
+            atomicAdd(&bad[5], 1ull);
+    }
 }
 
 static void two_sum(float a, float b, float &s, float &e)
@@ -72,7 +93,7 @@ int main()
         }
     }
     float4 *d_in;
-    unsigned long long *d_bad, bad[4] = {0, 0, 0, 0};
+    unsigned long long *d_bad, bad[7] = {0, 0, 0, 0, 0, 0, 0};
     if (hipMalloc((void **)&d_in, h.size() * sizeof(float)) != hipSuccess || hipMalloc((void **)&d_bad, sizeof(bad)) != hipSuccess)
         return 2;
     hipMemcpy(d_in, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice);
@@ -81,7 +102,8 @@ int main()
     if (hipDeviceSynchronize() != hipSuccess)
         return 2;
     hipMemcpy(bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost);
-    printf("{\"pairs\": %zu, \"add_mismatch\": %llu, \"mul_mismatch\": %llu, \"sub_mismatch\": %llu, \"swap_mismatch\": %llu}\n",
-           n / 2, bad[0], bad[1], bad[2], bad[3]);
-    return (bad[0] | bad[1] | bad[2] | bad[3]) ? 1 : 0;
+    printf("{\"pairs\": %zu, \"add_mismatch\": %llu, \"mul_mismatch\": %llu, \"sub_mismatch\": %llu, \"swap_mismatch\": %llu, "
+           "\"sub_lo_add_hi_mismatch\": %llu, \"hr_add2_mismatch\": %llu, \"hr_add2_rare\": %llu}\n",
+           n / 2, bad[0], bad[1], bad[2], bad[3], bad[4], bad[5], bad[6]);
+    return (bad[0] | bad[1] | bad[2] | bad[3] | bad[4] | bad[5]) ? 1 : 0;
 }
