@@ -1578,8 +1578,8 @@ template <class F> uint32_t build_la(fs_renderer *r, const void *max_radius, int
         return FS_ERR_UNSUPPORTED;
     const uint32_t maxRef = (uint32_t)r->orbit_uncompressed - 1u; // entries 0 .. maxRef
     const int periodDivisor = r->orbit_size != r->orbit_uncompressed ? 8 : 2; // LAReference.cpp:12-19
-    if (r->orbit_uncompressed < 2 || maxRef <= kLaLowBound)
-        return FS_ERR_UNSUPPORTED; // degenerate tables (orbits of <= 64 entries) are left to the host builder
+    if (r->orbit_uncompressed < 3)
+        return FS_ERR_UNSUPPORTED; // (maxRefIteration == 0: no table, LAReference.cpp:981-984; one step: left to the host builder)
     // capacity: a stage never holds more records than elements it was folded from (+ its tail record)
     const size_t cap_states = 2u * ((size_t)maxRef + 2u);
     // all stages: stage k+1 holds at most half of stage k (+2), so 2 * maxRef + slack bounds the sum
@@ -1687,6 +1687,7 @@ template <class F> uint32_t build_la(fs_renderer *r, const void *max_radius, int
     };
 
     // ---------------- stage 0: CreateLAFromOrbit, LAReference.cpp:28-210
+    bool no_table = false; // CreateLAFromOrbit returned false: the records stay, the table is not valid
     {
         const uint32_t limit = maxRef;
         fsk_la_src_orbit<F>(zref, maxRef + 1u, chebv.p, s);
@@ -1700,7 +1701,12 @@ template <class F> uint32_t build_la(fs_renderer *r, const void *max_radius, int
         bool have_first = false;
         uint32_t x_start;
         const double NthRoot = std::round(std::log2((double)maxRef) / periodDivisor);
-        if (Period == 0 || Period > kLaLowBound) {
+        if (Period == 0 && maxRef <= kLaLowBound) {
+            // :135-140: no period in an orbit of at most 64 steps -- one record over the whole orbit and the closing one,
+            // CreateLAFromOrbit returns false and the table stays invalid (GenerateApproximationData, :1002-1005)
+            no_table = true;
+            x_start = kLaTerm;
+        } else if (Period == 0 || Period > kLaLowBound) {
             Period = (uint32_t)std::round(std::pow((double)maxRef, 1.0 / NthRoot)); // :128-134 / :141-147
             x_start = 1u;                                                            // (0, flavour 1)
         } else {
@@ -1710,8 +1716,12 @@ template <class F> uint32_t build_la(fs_renderer *r, const void *max_radius, int
         }
         stages.push_back(fs_la_stage_u32{0u, 0u});
         uint32_t n = 0;
-        if (uint32_t e = run_chain(true, nullptr, limit, Period, have_first, have_first ? Period : 0u,
-                                   have_first ? Period : 0u, x_start, n))
+        if (no_table) {
+            fsk_la_one_record<F>(true, zref, nullptr, maxRef, maxRef, d_table, s);
+            n = 1;
+            tail_written = false;
+        } else if (uint32_t e = run_chain(true, nullptr, limit, Period, have_first, have_first ? Period : 0u,
+                                          have_first ? Period : 0u, x_start, n))
             return e;
         stages[0].MacroItCount = n;
         la_size = n;
@@ -1721,7 +1731,7 @@ template <class F> uint32_t build_la(fs_renderer *r, const void *max_radius, int
     }
 
     // ---------------- higher stages: CreateNewLAStage, LAReference.cpp:774-966
-    for (;;) {
+    while (!no_table) {
         const uint32_t PrevStage = (uint32_t)stages.size() - 1u, CurrentStage = (uint32_t)stages.size();
         if (CurrentStage >= kLaMaxStages)
             break;
@@ -1785,7 +1795,12 @@ template <class F> uint32_t build_la(fs_renderer *r, const void *max_radius, int
     for (uint32_t k = 0; k < stage_count; k++)
         idx[k] = stages[k].LAIndex;
     FS_TRY(hipMemcpyAsync(stage_idx.p, idx.data(), 4u * stage_count, hipMemcpyHostToDevice, s));
-    fsk_la_at<F>(d_table, stage_idx.as<uint32_t>(), stage_count, max_radius, use_small_exponents, atbuf.p, d_small, s);
+    if (!no_table)
+        fsk_la_at<F>(d_table, stage_idx.as<uint32_t>(), stage_count, max_radius, use_small_exponents, atbuf.p, d_small, s);
+    else { // (no CreateATFromLA: the ATInfo stays as constructed and is never used)
+        FS_TRY(hipMemsetAsync(atbuf.p, 0, sizeof(fs::la::ATInfoT<F>), s));
+        FS_TRY(hipMemsetAsync(d_small, 0, 4, s));
+    }
     fs::la::ATInfoT<F> at;
     r->la_ok = false;
     const size_t rec_bytes = sizeof(F) == 4 ? sizeof(fs_la_hdr32_u32) : sizeof(fs_la_hdr64_u32);
@@ -1798,11 +1813,12 @@ template <class F> uint32_t build_la(fs_renderer *r, const void *max_radius, int
     FS_TRY(hipGetLastError());
     r->n_las = la_size;
     r->n_stages = stage_count;
-    r->la_valid = 1;
-    r->use_at = h[0] ? 1 : 0;
+    r->la_valid = no_table ? 0 : 1;
+    r->use_at = !no_table && h[0] ? 1 : 0;
     memset(&r->at, 0, sizeof(r->at));
     memset(&r->at64, 0, sizeof(r->at64));
-    pack_at<F>(at, r);
+    if (!no_table)
+        pack_at<F>(at, r);
     r->la_type = sizeof(F) == 4 ? FS_T_HDR32 : FS_T_HDR64;
     r->la_gen = 0;
     r->la_ok = true;

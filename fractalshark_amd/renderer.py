@@ -221,10 +221,12 @@ class GPURenderer:
 
     def BuildLAOnDevice(self, orbit, use_small_exponents=False, T=None, host_fallback=True):
         """LAReference::GenerateApproximationData on the device for the orbit last uploaded (fs_build_la): all stages and
-        the ATInfo stay in HBM, installed as the renderer's table.  The degenerate inputs the device builder leaves to the
-        host (FS_ERR_UNSUPPORTED: orbits of <= 64 entries, a first step with a zero ZCoeff -- microseconds of host work)
-        are built by the host builder and uploaded with fs_upload_la, which is what FractalShark itself does for every
-        table (host_fallback=False returns the error code instead)."""
+        the ATInfo stay in HBM, installed as the renderer's table.  An orbit of at most 64 steps in which no period is
+        found gets the reference's two records and a table that is NOT valid (LAReference.cpp:135-140); the kernels ignore
+        it, as they do in FractalShark.  The degenerate inputs the device builder leaves to the host (FS_ERR_UNSUPPORTED: an
+        orbit of fewer than three entries, a first step with a zero ZCoeff -- microseconds of host work) are built by the
+        host builder and uploaded with fs_upload_la, which is what FractalShark itself does for every table
+        (host_fallback=False returns the error code instead)."""
         if T is None:
             T = T_HDR64 if orbit.is64 else T_HDR32
         mr = orbit.max_radius()

@@ -178,8 +178,11 @@ uint32_t fs_read_bla_level(fs_renderer *r, int32_t level, void *out, uint64_t ma
  * PerturbationResults::GetMaxRadius (fs_real_hdr32 / fs_real_hdr64); use_small_exponents = the UseSmallExponents flag of
  * CreateATFromLA (RefOrbitCalc.cpp:2346).  The table is bit-identical to the reference's SINGLE-THREADED builder (what
  * LAReference produces when hardware_concurrency() < 2 * 50000-entry chunks, :236-251; the multi-threaded stage-0 variant
- * yields a thread-count-dependent table, which stays with the host).  Orbits of <= 64 entries: FS_ERR_UNSUPPORTED (use
- * fs_upload_la).  Synchronous.  fs_la_counts / fs_read_la read the installed table back (tests, tools). */
+ * yields a thread-count-dependent table, which stays with the host).  An orbit of at most 64 steps (LowBound,
+ * LAReference.h:56) in which no period is found gets the reference's two records and a table that is not valid (:135-140,
+ * :1002-1005; fs_la_counts reports is_valid 0 and the kernels ignore the table); one in which periods are found gets its
+ * normal small table.  FS_ERR_UNSUPPORTED (use fs_upload_la): an orbit of fewer than three entries, a first step whose ZCoeff
+ * is zero.  Synchronous.  fs_la_counts / fs_read_la read the installed table back (tests, tools). */
 uint32_t fs_build_la(fs_renderer *r, int type_tag, const void *max_radius, int use_small_exponents);
 uint32_t fs_la_counts(const fs_renderer *r, uint32_t *n_las, uint32_t *n_stages, int *use_at, int *is_valid);
 uint32_t fs_read_la(fs_renderer *r, void *las_out, uint32_t max_las, void *stages_out, uint32_t max_stages, void *at_out);

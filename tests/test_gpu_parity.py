@@ -634,26 +634,51 @@ def test_la_table_built_on_device_from_a_compressed_orbit(renderer, native_libs,
     assert np.array_equal(out, _oracle.lav2_hdr32(v, ob, la, stage_test=0))
 
 
-def test_la_build_on_device_leaves_tiny_orbits_to_the_host(renderer, native_libs):
-    """View 2's orbit has 59 entries (<= LowBound 64): the degenerate one-record table is not built on the device."""
-    v = inputs.View.builtin(2, 64, 36, antialiasing=1)
-    ob = inputs.Orbit(v)
-    assert ob.count <= 64
+def _tiny_view(cx, cy, w, n, W=64, H=36):
+    from decimal import Decimal, getcontext
+    getcontext().prec = 50
+    cx, cy, w = Decimal(cx), Decimal(cy), Decimal(w)
+    h = w * H / W
+    return inputs.View(str(cx - w / 2), str(cy - h / 2), str(cx + w / 2), str(cy + h / 2), W, H, num_iterations=n)
+
+
+@pytest.mark.parametrize("name,args,is64", [
+    ("view2", None, False),                                                         # 59 entries, no period: two records, not valid
+    ("period3_bulb_50", ("-0.1225", "0.7448", "1e-4", 50), False),                  # 51 entries, periods found: a valid 2-stage table
+    ("period3_bulb_50", ("-0.1225", "0.7448", "1e-4", 50), True),
+    ("period3_centre", ("-0.122561166876654", "0.744861766619744", "1e-6", 60), False),  # 4 entries
+    ("period2_centre", ("-1.0", "0.0", "1e-5", 40), False),                         # 3 entries: the smallest orbit with a step to fold
+    ("main_cardioid_30", ("-0.2", "0.1", "1e-5", 30), True),                        # 31 entries, no period
+    ("seahorse_63", ("-0.75", "0.1", "1e-4", 63), False),                           # 36 entries (the orbit escapes)
+])
+def test_la_build_on_device_for_orbits_of_at_most_64_entries(renderer, native_libs, name, args, is64):
+    """LowBound = 64 (LAReference.h:56): an orbit this short either yields periods (a normal, small table) or CreateLAFromOrbit
+    keeps one record over the whole orbit plus the closing one and returns false -- the table is then NOT valid
+    (LAReference.cpp:135-140, :1002-1005) and the kernels ignore it.  Both outcomes on the device == the host builder's:
+    records, stage table, validity, UseAT -- and the frame rendered with the device's table == the oracle's with the host's."""
+    v = inputs.View.builtin(2, 64, 36, antialiasing=1) if args is None else _tiny_view(*args)
+    ob = inputs.Orbit(v, is64=is64)
+    assert 3 <= ob.count <= 65
+    la = inputs.LATable(ob, host_threads=1)
     r = renderer
+    T = T_HDR64 if is64 else T_HDR32
     assert r.InitializeMemory(64, 36, 1, None, 0, 0, 0, False) == 0
-    assert r._lib.fs_upload_orbit(r._h, 0, T_HDR32, 4, ob.data_ptr, ob.count, ob.count, ob.period) == 0
-    assert r.BuildLAOnDevice(ob, host_fallback=False) == 10100
-    # the wrapper's default: the host builder's table is uploaded instead (what FractalShark does for every table), and the
-    # frame rendered from it is the oracle's
-    assert r.BuildLAOnDevice(ob) == 0
-    la = inputs.LATable(ob)
+    assert r._lib.fs_upload_orbit(r._h, 0, T, 4, ob.data_ptr, ob.count, ob.count, ob.period) == 0
+    assert r.BuildLAOnDevice(ob, host_fallback=False) == 0
+    las, stages, at, use_at, is_valid = r.read_la(is64)
+    assert is_valid == la.is_valid and use_at == la.use_at
+    assert stages.shape[0] == la.stage_count and np.array_equal(stages, la.stages())
+    assert las.shape[0] == la.count and las.tobytes() == la.records().tobytes()
+    if la.is_valid:
+        import ctypes as C
+        assert at == bytes((C.c_char * C.sizeof(la.at)).from_address(C.addressof(la.at)))
     assert r.ClearMemory() == 0
-    assert r.RenderPerturbLAv2(None, None, None, *_pairs(v.coords_perturb(ob)), v.num_iterations, T=T_HDR32,
+    assert r.RenderPerturbLAv2(None, None, None, *_pairs(v.coords_perturb(ob)), v.num_iterations, T=T,
                                Mode=LAV2_FULL, parity=PARITY_CPU) == 0
     out = r.new_iter_buffer()
     assert r.RenderCurrent(v.num_iterations, out) == 0
     assert r.SyncComputeStream() == 0
-    assert np.array_equal(out, _oracle.lav2_hdr32(v, ob, la, stage_test=0))
+    assert np.array_equal(out, _oracle.lav2_hdr32(v, ob, la, stage_test=0))  # (dispatches on the orbit's type)
 
 
 def test_frame_from_device_built_la_table(renderer, v5_small):
