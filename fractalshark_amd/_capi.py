@@ -253,6 +253,8 @@ def inputs_lib():
     _decl(lib, "fsh_bla_level_sizes", vp, [vp])
     _decl(lib, "fsh_plain_create", vp, [vp, C.c_int, u64, C.c_int, C.c_int])
     _decl(lib, "fsh_plain_create_ex", vp, [vp, C.c_int, u64, C.c_int, C.c_int, C.c_int])
+    _decl(lib, "fsh_plain_save_im", C.c_int, [vp, u64, C.c_int, C.c_char_p, C.c_int])
+    _decl(lib, "fsh_plain_load_im", vp, [C.c_char_p, C.POINTER(u64), C.c_int])
     _decl(lib, "fsh_plain_is_compressed", C.c_int, [vp])
     _decl(lib, "fsh_plain_compressed_count", u64, [vp])
     _decl(lib, "fsh_plain_compressed_data", vp, [vp])

@@ -776,29 +776,43 @@ void build_orbit(const fsh_view &vw, uint64_t max_iter, bool periodicity, OrbitT
 // HDRFloat<double> (Imagina's magic), ExtendedRange = true.
 namespace {
 
+template <class T> void rc_one_iter_plain(T &zx, T &zy, T cxLow, T cyLow); // (defined with the plain orbit builder below)
+
+// (F is a number family of la_math.hpp: float / double = HDRFloat<F>, plain<float> / plain<double> = the type itself --
+// the reference's CompressMax / DecompressMax are one template over T, with HdrReduce a no-op, HdrAbs = fabs and
+// HdrMaxReduced = `(one > two) ? one : two` for a plain T, HDRFloat.h:1385-1500)
+template <class T> preal<T> hr_add(preal<T> a, preal<T> b) { return preal<T>{a.m + b.m}; }
+template <class T> preal<T> hr_sub(preal<T> a, preal<T> b) { return preal<T>{a.m - b.m}; }
+template <class T> preal<T> hr_abs(preal<T> a) { return preal<T>{std::fabs(a.m)}; }
+template <class T> int hr_cmp(preal<T> a, preal<T> b) { return a.m > b.m ? 1 : (a.m < b.m ? -1 : 0); }
+template <class T> void rc_one_iter(preal<T> &zx, preal<T> &zy, preal<T> cxLow, preal<T> cyLow)
+{
+    rc_one_iter_plain(zx.m, zy.m, cxLow.m, cyLow.m);
+}
+
 template <class F> struct MaxWaypoints {
-    std::vector<hreal<F>> x, y;
+    std::vector<real_t<F>> x, y;
     std::vector<uint64_t> index;
     std::vector<uint8_t> rebase;
     std::vector<uint64_t> rebases;
 };
 
-template <class F> hreal<F> mc_norm(hreal<F> x, hreal<F> y)
+template <class R> R mc_norm(R x, R y)
 {
     // HdrMaxReduced(HdrAbs(x), HdrAbs(y)) (HDRFloat.h:1477-1500: `one.compareTo(two) > 0 ? one : two`), HdrReduce
-    const hreal<F> ax = hr_abs(x), ay = hr_abs(y);
+    const R ax = hr_abs(x), ay = hr_abs(y);
     return hr_reduced(hr_cmp(ax, ay) > 0 ? ax : ay);
 }
-template <class F> hreal<F> mc_norm_times(hreal<F> x, hreal<F> y, hreal<F> t)
+template <class R> R mc_norm_times(R x, R y, R t)
 {
-    const hreal<F> ax = hr_abs(x), ay = hr_abs(y);
+    const R ax = hr_abs(x), ay = hr_abs(y);
     return hr_reduced(hr_mul(hr_cmp(ax, ay) > 0 ? ax : ay, t));
 }
 // dz' = (2 Z + dz) dz in the reference's operand order (PerturbationResults.cpp:1489-1493, 1610-1614, 1842-1848)
-template <class F> void mc_dz_step(hreal<F> &dzX, hreal<F> &dzY, hreal<F> Zx, hreal<F> Zy)
+template <class F> void mc_dz_step(real_t<F> &dzX, real_t<F> &dzY, real_t<F> Zx, real_t<F> Zy)
 {
-    const hreal<F> Two = hr_from_number<F>(F(2));
-    const hreal<F> old = dzX;
+    const real_t<F> Two = mk<F>::number(2.0);
+    const real_t<F> old = dzX;
     dzX = hr_sub(hr_add(hr_sub(hr_mul(hr_mul(Two, Zx), dzX), hr_mul(hr_mul(Two, Zy), dzY)), hr_mul(dzX, dzX)), hr_mul(dzY, dzY));
     hr_reduce(dzX);
     dzY = hr_add(hr_add(hr_mul(hr_mul(Two, Zx), dzY), hr_mul(hr_mul(Two, Zy), old)), hr_mul(hr_mul(Two, old), dzY));
@@ -806,47 +820,50 @@ template <class F> void mc_dz_step(hreal<F> &dzX, hreal<F> &dzY, hreal<F> Zx, hr
 }
 
 // PerturbationResults::CompressMax, PerturbationResults.cpp:1347-1640 (includeDummy = false)
-template <class F> MaxWaypoints<F> compress_max(const OrbitT<F> &ob, int compression_exp)
+template <class F, class Orb>
+MaxWaypoints<F> compress_max(const Orb &ob, real_t<F> orbitXLow, real_t<F> orbitYLow, int compression_exp)
 {
+    using hr = real_t<F>;
+    using S = scalar_t<F>;
     MaxWaypoints<F> w;
     const uint64_t count = ob.x.size();
-    const hreal<F> threshold2 = hr_from_number<F>((F)std::sqrt(std::pow(10.0, compression_exp)));
-    const hreal<F> constant1 = hr_reduced(hr_from_number<F>((F)0x1.0p-4));
-    const hreal<F> constant2 = hr_reduced(hr_from_number<F>((F)0x1.000001p0));
-    hreal<F> zx = ob.orbitXLow, zy = ob.orbitYLow;
-    auto push = [&](hreal<F> x, hreal<F> y, uint64_t i, bool rebase) {
+    const hr threshold2 = mk<F>::number((S)std::sqrt(std::pow(10.0, compression_exp)));
+    const hr constant1 = hr_reduced(mk<F>::number((S)0x1.0p-4));
+    const hr constant2 = hr_reduced(mk<F>::number((S)0x1.000001p0));
+    hr zx = orbitXLow, zy = orbitYLow;
+    auto push = [&](hr x, hr y, uint64_t i, bool rebase) {
         w.x.push_back(x), w.y.push_back(y), w.index.push_back(i), w.rebase.push_back(rebase ? 1 : 0);
     };
     uint64_t i = 1;
     for (; i < count; i++) {
-        const hreal<F> outX = ob.x[i], outY = ob.y[i];
-        const hreal<F> norm_z = mc_norm(outX, outY);
+        const hr outX = ob.x[i], outY = ob.y[i];
+        const hr norm_z = mc_norm(outX, outY);
         if (hr_cmp_pos(norm_z, constant1) < 0) {
             zx = outX, zy = outY;
             push(outX, outY, i, true);
             break;
         } else {
-            const hreal<F> err = mc_norm_times(hr_sub(zx, outX), hr_sub(zy, outY), threshold2);
+            const hr err = mc_norm_times(hr_sub(zx, outX), hr_sub(zy, outY), threshold2);
             if (hr_cmp_pos(err, norm_z) >= 0) {
                 zx = outX, zy = outY;
                 push(outX, outY, i, false);
             }
         }
-        rc_one_iter(zx, zy, ob.orbitXLow, ob.orbitYLow);
+        rc_one_iter(zx, zy, orbitXLow, orbitYLow);
     }
-    hreal<F> dzX = zx, dzY = zy;
+    hr dzX = zx, dzY = zy;
     uint64_t prev_waypoint = i;
-    mc_dz_step(dzX, dzY, ob.x[0], ob.y[0]);
+    mc_dz_step<F>(dzX, dzY, ob.x[0], ob.y[0]);
     i++;
     uint64_t j = 1;
     for (; i < count; i++, j++) {
-        const hreal<F> outXi = ob.x[i], outYi = ob.y[i];
-        hreal<F> outXj = ob.x[j], outYj = ob.y[j];
+        const hr outXi = ob.x[i], outYi = ob.y[i];
+        hr outXj = ob.x[j], outYj = ob.y[j];
         zx = hr_add(dzX, outXj);
         zy = hr_add(dzY, outYj);
-        const hreal<F> norm_z_orig = mc_norm(zx, zy);
-        const hreal<F> norm_dz_orig = mc_norm_times(dzX, dzY, constant2);
-        const hreal<F> err = mc_norm_times(hr_sub(zx, outXi), hr_sub(zy, outYi), threshold2);
+        const hr norm_z_orig = mc_norm(zx, zy);
+        const hr norm_dz_orig = mc_norm_times(dzX, dzY, constant2);
+        const hr err = mc_norm_times(hr_sub(zx, outXi), hr_sub(zy, outYi), threshold2);
         const bool condition1 = j >= prev_waypoint;
         const bool condition2 = hr_cmp_pos(err, norm_z_orig) >= 0;
         if (condition1 || condition2) {
@@ -854,7 +871,7 @@ template <class F> MaxWaypoints<F> compress_max(const OrbitT<F> &ob, int compres
             zx = outXi, zy = outYi;
             dzX = hr_sub(zx, outXj);
             dzY = hr_sub(zy, outYj);
-            const hreal<F> norm_z = mc_norm(zx, zy), norm_dz = mc_norm(dzX, dzY);
+            const hr norm_z = mc_norm(zx, zy), norm_dz = mc_norm(dzX, dzY);
             if (hr_cmp_pos(norm_z, norm_dz) < 0 || (i - j) * 4 < i) {
                 dzX = zx, dzY = zy;
                 j = 0;
@@ -871,7 +888,7 @@ template <class F> MaxWaypoints<F> compress_max(const OrbitT<F> &ob, int compres
                 w.rebases.push_back(i);
         }
         outXj = ob.x[j], outYj = ob.y[j]; // j may have changed
-        mc_dz_step(dzX, dzY, outXj, outYj);
+        mc_dz_step<F>(dzX, dzY, outXj, outYj);
     }
     return w;
 }
@@ -879,35 +896,36 @@ template <class F> MaxWaypoints<F> compress_max(const OrbitT<F> &ob, int compres
 // PerturbationResults::DecompressMax<Disable>, PerturbationResults.cpp:1660-1850.  The waypoint and rebase lists carry the
 // reader's terminators (index ~0) at their ends (LoadOrbitBin :2208-2210).
 template <class F>
-void decompress_max(const MaxWaypoints<F> &w, hreal<F> cxLow, hreal<F> cyLow, uint64_t target, std::vector<hreal<F>> &ox,
-                    std::vector<hreal<F>> &oy)
+void decompress_max(const MaxWaypoints<F> &w, real_t<F> cxLow, real_t<F> cyLow, uint64_t target, std::vector<real_t<F>> &ox,
+                    std::vector<real_t<F>> &oy)
 {
+    using hr = real_t<F>;
     ox.clear(), oy.clear();
     ox.reserve(target), oy.reserve(target);
-    const hreal<F> Two = hr_from_number<F>(F(2));
+    const hr Two = mk<F>::number(2.0);
     // CorrectOrbit, :1712-1760: the stretch [begin, end) is pulled onto the waypoint by a backwards Newton step per entry
-    auto correct = [&](uint64_t begin, uint64_t end, hreal<F> diffX, hreal<F> diffY) {
-        hreal<F> dzdcX = hr_from_number<F>(F(1)), dzdcY = hr_from_number<F>(F(0));
+    auto correct = [&](uint64_t begin, uint64_t end, hr diffX, hr diffY) {
+        hr dzdcX = mk<F>::number(1.0), dzdcY = mk<F>::number(0.0);
         hr_reduce(diffX);
         hr_reduce(diffY);
         for (uint64_t i = end; i > begin;) {
             i--;
-            const hreal<F> old = dzdcX;
+            const hr old = dzdcX;
             // dzdcX * Z.x * 2 - dzdcY * Z.y * 2 ; `* 2` is HDRFloat * int -> HDRFloat(int 2) = {1.0, 1}
             dzdcX = hr_sub(hr_mul(hr_mul(dzdcX, ox[i]), Two), hr_mul(hr_mul(dzdcY, oy[i]), Two));
             hr_reduce(dzdcX);
             dzdcY = hr_add(hr_mul(hr_mul(old, oy[i]), Two), hr_mul(hr_mul(dzdcY, ox[i]), Two));
             hr_reduce(dzdcY);
-            const hreal<F> den = hr_add(hr_mul(dzdcX, dzdcX), hr_mul(dzdcY, dzdcY));
-            hreal<F> resultReal = hr_div(hr_add(hr_mul(diffX, dzdcX), hr_mul(diffY, dzdcY)), den);
+            const hr den = hr_add(hr_mul(dzdcX, dzdcX), hr_mul(dzdcY, dzdcY));
+            hr resultReal = hr_div(hr_add(hr_mul(diffX, dzdcX), hr_mul(diffY, dzdcY)), den);
             hr_reduce(resultReal);
-            hreal<F> resultImag = hr_div(hr_sub(hr_mul(diffY, dzdcX), hr_mul(diffX, dzdcY)), den);
+            hr resultImag = hr_div(hr_sub(hr_mul(diffY, dzdcX), hr_mul(diffX, dzdcY)), den);
             hr_reduce(resultImag);
             ox[i] = hr_reduced(hr_add(ox[i], resultReal));
             oy[i] = hr_reduced(hr_add(oy[i], resultImag));
         }
     };
-    hreal<F> zx = hr_zero<F>(), zy = hr_zero<F>(); // T zx{}, zy{}
+    hr zx = mk<F>::zero(), zy = mk<F>::zero(); // T zx{}, zy{}
     uint64_t wp = 0, rb = 0;
     uint64_t next_index = w.index[0];
     uint64_t next_rebase = w.rebases[0];
@@ -927,7 +945,7 @@ void decompress_max(const MaxWaypoints<F> &w, hreal<F> cxLow, hreal<F> cyLow, ui
         rc_one_iter(zx, zy, cxLow, cyLow);
     }
     uint64_t j = 0;
-    hreal<F> dzX = zx, dzY = zy;
+    hr dzX = zx, dzY = zy;
     for (; i < target; i++, j++) {
         zx = hr_add(dzX, ox[j]);
         zy = hr_add(dzY, oy[j]);
@@ -949,14 +967,14 @@ void decompress_max(const MaxWaypoints<F> &w, hreal<F> cxLow, hreal<F> cyLow, ui
             dzX = zx, dzY = zy;
             j = 0;
         } else {
-            const hreal<F> norm_z = mc_norm(zx, zy), norm_dz = mc_norm(dzX, dzY);
+            const hr norm_z = mc_norm(zx, zy), norm_dz = mc_norm(dzX, dzY);
             if (hr_cmp_pos(norm_z, norm_dz) < 0) {
                 dzX = zx, dzY = zy;
                 j = 0;
             }
         }
         ox.push_back(zx), oy.push_back(zy);
-        mc_dz_step(dzX, dzY, ox[j], oy[j]);
+        mc_dz_step<F>(dzX, dzY, ox[j], oy[j]);
     }
 }
 
@@ -967,16 +985,26 @@ struct ImHR { // Imagina::HRReal = HDRFloat<double, Left, int64_t>
 static_assert(sizeof(ImHR) == 16, "HRReal");
 
 template <class F> ImHR im_hr(hreal<F> v) { return ImHR{(double)v.m, (int64_t)v.e}; }
+// Imagina::HRReal{T} for a plain T: the templated HDRFloat(const U number) constructor, which normalises (HDRFloat.h:295-363)
+template <class T> ImHR im_hr(preal<T> v)
+{
+    const hreal<double> h = hr_from_number<double>((double)v.m);
+    return ImHR{h.m, (int64_t)h.e};
+}
 
-template <class F>
-int save_im_orbit(const OrbitT<F> &ob, uint64_t num_iterations, int compression_exp, const char *path, int exp_bytes)
+// F: the number family (float / double: HDRFloat<F>, ExtendedRange = true, 40-byte waypoints of two HRReal and the index field;
+// plain<float> / plain<double>: ExtendedRange = false, 24-byte waypoints of two doubles and the index field,
+// PerturbationResults.cpp:2047-2075).  The magic follows the SubType (RefOrbitCalc.cpp:3052-3062).
+template <class F, class Orb>
+int save_im_orbit(const Orb &ob, real_t<F> orbitXLow, real_t<F> orbitYLow, uint64_t num_iterations, int compression_exp,
+                  const char *path, int exp_bytes)
 {
     if ((exp_bytes != 4 && exp_bytes != 8) || ob.x.size() < 2)
         return -1;
     FILE *f = fopen(path, "wb");
     if (!f)
         return -1;
-    uint64_t header[4] = {sizeof(F) == 4 ? kSharksMagic : kImMagic, 0, 32, 0};
+    uint64_t header[4] = {sizeof(scalar_t<F>) == 4 ? kSharksMagic : kImMagic, 0, 32, 0};
     fwrite(header, 8, 4, f);
     const ImHR halfH = im_hr(ob.maxRadius); // Imagina::HRReal{results.GetMaxRadius()}
     fwrite(&halfH, sizeof(halfH), 1, f);
@@ -985,8 +1013,8 @@ int save_im_orbit(const OrbitT<F> &ob, uint64_t num_iterations, int compression_
     im_write_mpf(f, ob.cx.v, exp_bytes);
     im_write_mpf(f, ob.cy.v, exp_bytes);
     const uint64_t reference_offset = (uint64_t)ftell(f);
-    const MaxWaypoints<F> w = compress_max(ob, compression_exp);
-    const uint8_t extended_range = 1; // results.IsHDR
+    const MaxWaypoints<F> w = compress_max<F>(ob, orbitXLow, orbitYLow, compression_exp);
+    const uint8_t extended_range = num<F>::is_plain ? 0 : 1; // results.IsHDR
     fwrite(&extended_range, 1, 1, f);
     // ReferenceTrivialContent
     const ImHR trivial[3] = {ImHR{2.0, -(int64_t)mpf_get_prec(ob.cx.v)}, ImHR{0.0, 0}, im_hr(ob.maxRadius)};
@@ -1004,8 +1032,13 @@ int save_im_orbit(const OrbitT<F> &ob, uint64_t num_iterations, int compression_
     const uint64_t n = w.x.size();
     fwrite(&n, 8, 1, f);
     for (uint64_t k = 0; k < n; k++) {
-        const ImHR xy[2] = {im_hr(w.x[k]), im_hr(w.y[k])};
-        fwrite(xy, sizeof(ImHR), 2, f);
+        if constexpr (num<F>::is_plain) {
+            const double xy[2] = {(double)w.x[k].m, (double)w.y[k].m};
+            fwrite(xy, sizeof(double), 2, f);
+        } else {
+            const ImHR xy[2] = {im_hr(w.x[k]), im_hr(w.y[k])};
+            fwrite(xy, sizeof(ImHR), 2, f);
+        }
         const uint64_t field = (w.index[k] & 0x7FFFFFFFFFFFFFFFull) | ((uint64_t)w.rebase[k] << 63);
         fwrite(&field, 8, 1, f);
     }
@@ -1022,8 +1055,8 @@ int save_im_orbit(const OrbitT<F> &ob, uint64_t num_iterations, int compression_
 }
 
 // the stored orbit of an open file (positioned anywhere), into ob: LoadOrbitBin + DecompressMax<Disable>
-template <class F>
-bool load_im_orbit(FILE *f, uint64_t reference_offset, OrbitT<F> &ob, uint64_t file_iteration_limit, ImHR halfH)
+template <class F, class Orb>
+bool load_im_orbit(FILE *f, uint64_t reference_offset, Orb &ob, uint64_t file_iteration_limit, ImHR halfH)
 {
     if (fseek(f, (long)reference_offset, SEEK_SET) != 0)
         return false;
@@ -1032,7 +1065,7 @@ bool load_im_orbit(FILE *f, uint64_t reference_offset, OrbitT<F> &ob, uint64_t f
     unsigned char la[192];
     uint64_t n = 0;
     if (fread(&extended_range, 1, 1, f) != 1 || fread(trivial, sizeof(ImHR), 3, f) != 3 || fread(la, 1, sizeof(la), f) != sizeof(la) ||
-        fread(&n, 8, 1, f) != 1 || !extended_range || n == 0 || n > (1ull << 32))
+        fread(&n, 8, 1, f) != 1 || (extended_range != 0) == num<F>::is_plain || n == 0 || n > (1ull << 32))
         return false;
     uint64_t ref_it;
     memcpy(&ref_it, la + 16, 8);
@@ -1052,17 +1085,29 @@ bool load_im_orbit(FILE *f, uint64_t reference_offset, OrbitT<F> &ob, uint64_t f
     uint64_t prev_index = 0;
     for (uint64_t k = 0; k < n; k++) {
         ImHR xy[2];
+        double pxy[2] = {0.0, 0.0};
         uint64_t field;
-        if (fread(xy, sizeof(ImHR), 2, f) != 2 || fread(&field, 8, 1, f) != 1)
-            return false;
+        if constexpr (num<F>::is_plain) {
+            if (fread(pxy, sizeof(double), 2, f) != 2 || fread(&field, 8, 1, f) != 1)
+                return false;
+            xy[0] = xy[1] = ImHR{0.0, 0};
+        } else {
+            if (fread(xy, sizeof(ImHR), 2, f) != 2 || fread(&field, 8, 1, f) != 1)
+                return false;
+        }
         // waypoints are strictly increasing orbit positions >= 1 (entry 0 is the implicit zero start; DecompressMax reads the
         // entry BEFORE a rebasing waypoint), inside the announced orbit, with exponents that fit HDRFloat's int32
         const uint64_t idx = field & 0x7FFFFFFFFFFFFFFFull;
         if (idx == 0 || idx <= prev_index || idx > ref_it || !exp_fits(xy[0]) || !exp_fits(xy[1]))
             return false;
         prev_index = idx;
-        w.x.push_back(hreal<F>{(F)xy[0].mantissa, (int32_t)xy[0].exp});
-        w.y.push_back(hreal<F>{(F)xy[1].mantissa, (int32_t)xy[1].exp});
+        if constexpr (num<F>::is_plain) {
+            w.x.push_back(real_t<F>{(scalar_t<F>)pxy[0]}); // static_cast<T>(x), PerturbationResults.cpp:2177-2183
+            w.y.push_back(real_t<F>{(scalar_t<F>)pxy[1]});
+        } else {
+            w.x.push_back(hreal<F>{(F)xy[0].mantissa, (int32_t)xy[0].exp});
+            w.y.push_back(hreal<F>{(F)xy[1].mantissa, (int32_t)xy[1].exp});
+        }
         w.index.push_back(field & 0x7FFFFFFFFFFFFFFFull);
         w.rebase.push_back((uint8_t)(field >> 63));
     }
@@ -1073,17 +1118,26 @@ bool load_im_orbit(FILE *f, uint64_t reference_offset, OrbitT<F> &ob, uint64_t f
     if (r && fread(w.rebases.data(), 8, r, f) != r)
         return false;
     // the reader's terminators (:2208-2210): {{}, {}, ~0ull, false} and ~0ull
-    w.x.push_back(hr_zero<F>()), w.y.push_back(hr_zero<F>()), w.index.push_back(0x7FFFFFFFFFFFFFFFull), w.rebase.push_back(0);
+    w.x.push_back(mk<F>::zero()), w.y.push_back(mk<F>::zero()), w.index.push_back(0x7FFFFFFFFFFFFFFFull), w.rebase.push_back(0);
     w.rebases.push_back(~0ull);
     // InitResults(DontSaveForReuse, orbitX, orbitY, radius, fileProvidedIters - 1, 0), :2125-2134
-    ob.maxRadius = hr_reduced(hreal<F>{(F)halfH.mantissa, (int32_t)halfH.exp});
-    ob.orbitXLow = hr_from_mpf<F>(ob.cx.v);
-    ob.orbitYLow = hr_from_mpf<F>(ob.cy.v);
     const uint64_t count = ref_it + 1; // m_UncompressedItersInOrbit
     ob.period = periodic ? ref_it + 1 : 0;
-    decompress_max(w, ob.orbitXLow, ob.orbitYLow, count, ob.x, ob.y);
-    ob.bad.assign(ob.x.size(), 0);
     ob.compressed = false;
+    if constexpr (num<F>::is_plain) {
+        using T = scalar_t<F>;
+        // static_cast<T>(halfH.toDouble()), :2136-2137; toDouble = mantissa * getMultiplier(exp), HDRFloat.h:553-557
+        ob.maxRadius = preal<T>{(T)(halfH.mantissa * multiplier<double>((int32_t)halfH.exp))};
+        ob.orbitXLow = (T)mpf_get_d(ob.cx.v);                                    // T{orbitX}
+        ob.orbitYLow = (T)mpf_get_d(ob.cy.v);
+        decompress_max(w, preal<T>{ob.orbitXLow}, preal<T>{ob.orbitYLow}, count, ob.x, ob.y);
+    } else {
+        ob.maxRadius = hr_reduced(hreal<F>{(F)halfH.mantissa, (int32_t)halfH.exp});
+        ob.orbitXLow = hr_from_mpf<F>(ob.cx.v);
+        ob.orbitYLow = hr_from_mpf<F>(ob.cy.v);
+        decompress_max(w, ob.orbitXLow, ob.orbitYLow, count, ob.x, ob.y);
+        ob.bad.assign(ob.x.size(), 0);
+    }
     return ob.x.size() == count;
 }
 
@@ -1092,8 +1146,8 @@ bool load_im_orbit(FILE *f, uint64_t reference_offset, OrbitT<F> &ob, uint64_t f
 extern "C" int fsh_orbit_save_im(const fsh_orbit *o, uint64_t num_iterations, int compression_exp, const char *path,
                                  int exp_bytes)
 {
-    return o->is64 ? save_im_orbit<double>(o->d, num_iterations, compression_exp, path, exp_bytes)
-                   : save_im_orbit<float>(o->f, num_iterations, compression_exp, path, exp_bytes);
+    return o->is64 ? save_im_orbit<double>(o->d, o->d.orbitXLow, o->d.orbitYLow, num_iterations, compression_exp, path, exp_bytes)
+                   : save_im_orbit<float>(o->f, o->f.orbitXLow, o->f.orbitYLow, num_iterations, compression_exp, path, exp_bytes);
 }
 
 static fsh_orbit *orbit_load_im(FILE *f, uint64_t *iteration_limit);
@@ -2661,8 +2715,13 @@ template <class T> struct PlainInputs {
 
     void build(const fsh_view &vw, uint64_t max_iter, int periodicity, int host_threads, int compression_exp)
     {
-        using R = plain_recs<T>;
         build_plain_orbit<T>(vw, max_iter, periodicity, ob, compression_exp);
+        finish(host_threads);
+    }
+    // everything derived from the orbit (packed records, LA table, ATInfo): also what a loaded ".im" orbit goes through
+    void finish(int host_threads)
+    {
+        using R = plain_recs<T>;
         orbit_packed.resize(ob.x.size());
         for (size_t i = 0; i < ob.x.size(); i++)
             orbit_packed[i] = typename R::orbit{ob.x[i].m, ob.y[i].m};
@@ -2732,6 +2791,79 @@ extern "C" fsh_plain *fsh_plain_create(const fsh_view *v, int kind, uint64_t max
     return fsh_plain_create_ex(v, kind, max_iter, periodicity, host_threads, -1);
 }
 extern "C" void fsh_plain_destroy(fsh_plain *h) { delete h; }
+
+// ".im" files with a reference orbit for the non-ExtendedRange types (float: "Sharks:)" magic, double: Imagina's;
+// ReferenceHeader::ExtendedRange = false; RefOrbitCalc.cpp:3039-3115 / :3386-3412, PerturbationResults.cpp:2047-2075, 2177-2183)
+extern "C" int fsh_plain_save_im(const fsh_plain *h, uint64_t num_iterations, int compression_exp, const char *path, int exp_bytes)
+{
+    if (h->kind == 0)
+        return save_im_orbit<plain<float>>(h->f.ob, preal<float>{h->f.ob.orbitXLow}, preal<float>{h->f.ob.orbitYLow},
+                                           num_iterations, compression_exp, path, exp_bytes);
+    return save_im_orbit<plain<double>>(h->d.ob, preal<double>{h->d.ob.orbitXLow}, preal<double>{h->d.ob.orbitYLow},
+                                        num_iterations, compression_exp, path, exp_bytes);
+}
+
+static fsh_plain *plain_load_im(FILE *f, uint64_t *iteration_limit, int host_threads)
+{
+    uint64_t header[4];
+    ImHR hh;
+    uint64_t limit = 0;
+    std::unique_ptr<fsh_plain> out;
+    if (fread(header, 8, 4, f) == 4 && (header[0] == kImMagic || header[0] == kSharksMagic) && header[3] != 0 &&
+        fseek(f, (long)header[2], SEEK_SET) == 0 && fread(&hh, sizeof(hh), 1, f) == 1 && fread(&limit, 8, 1, f) == 1) {
+        // (untrusted input, as in orbit_load_im: bound the precision GMP is asked for)
+        if (hh.exp < -(int64_t)kMaxImPrecisionBits)
+            return nullptr;
+        const uint64_t precision = (uint64_t)(-std::min<int64_t>(0, hh.exp)) + 120u;
+        mpf_set_default_prec(precision);
+        Mp X(precision, 0), Y(precision, 0);
+        const long at = ftell(f);
+        int width_ok = 0;
+        for (int exp_bytes : {4, 8}) {
+            fseek(f, at, SEEK_SET);
+            if (im_read_mpf(f, X.v, exp_bytes) && im_read_mpf(f, Y.v, exp_bytes) && (uint64_t)ftell(f) == header[3]) {
+                width_ok = exp_bytes;
+                break;
+            }
+        }
+        if (width_ok) {
+            out = std::make_unique<fsh_plain>();
+            out->kind = header[0] == kImMagic ? 1 : 0; // T double <-> Imagina's magic, float <-> "Sharks:)" (:3386-3412)
+            bool ok;
+            if (out->kind == 1) {
+                out->d.ob.cx = X, out->d.ob.cy = Y;
+                ok = load_im_orbit<plain<double>>(f, header[3], out->d.ob, limit, ImHR{hh.mantissa, hh.exp});
+                if (ok)
+                    out->d.finish(host_threads);
+            } else {
+                out->f.ob.cx = X, out->f.ob.cy = Y;
+                ok = load_im_orbit<plain<float>>(f, header[3], out->f.ob, limit, ImHR{hh.mantissa, hh.exp});
+                if (ok)
+                    out->f.finish(host_threads);
+            }
+            if (!ok)
+                out.reset();
+            else if (iteration_limit)
+                *iteration_limit = limit;
+        }
+    }
+    return out.release();
+}
+
+extern "C" fsh_plain *fsh_plain_load_im(const char *path, uint64_t *iteration_limit, int host_threads)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f)
+        return nullptr;
+    fsh_plain *out = nullptr;
+    try { // nothing may unwind through the C boundary
+        out = plain_load_im(f, iteration_limit, host_threads);
+    } catch (...) {
+        out = nullptr;
+    }
+    fclose(f);
+    return out;
+}
 extern "C" int fsh_plain_kind(const fsh_plain *h) { return h->kind; }
 #define FS_PLAIN_GET(EXPR_F, EXPR_D) (h->kind == 0 ? (EXPR_F) : (EXPR_D))
 extern "C" uint64_t fsh_plain_orbit_count(const fsh_plain *h) { return FS_PLAIN_GET(h->f.ob.x.size(), h->d.ob.x.size()); }

@@ -551,6 +551,41 @@ class PlainInputs:
                                           -1 if compression_exp is None else int(compression_exp))
         if not self._h:
             raise RuntimeError("fsh_plain_create failed")
+        self._adopt()
+
+    @classmethod
+    def load_im(cls, path, view, kind=None, host_threads=1):
+        """The reference orbit of an Imagina ".im" file written for a non-ExtendedRange type (ReferenceHeader::ExtendedRange
+        false; float for the "Sharks:)" magic, double for Imagina's -- RefOrbitCalc.cpp:3386-3412), rebuilt from the file's
+        waypoints (LoadOrbitBin + DecompressMax), with the LAv2 table built from it.  kind: None = the file's type
+        ("f32" / "f64"); "2x32" converts a double file's inputs to CudaDblflt like the constructor does."""
+        lib = _capi.inputs_lib()
+        limit = C.c_uint64(0)
+        h = lib.fsh_plain_load_im(os.fsencode(path), C.byref(limit), int(host_threads))
+        if not h:
+            raise ValueError("%s: no plain-type reference orbit this reader takes" % (path,))
+        file_kind = "f32" if lib.fsh_plain_kind(h) == 0 else "f64"
+        if kind is None:
+            kind = file_kind
+        if (kind == "f32") != (file_kind == "f32"):
+            lib.fsh_plain_destroy(h)
+            raise ValueError("%s holds a %s orbit" % (path, file_kind))
+        self = cls.__new__(cls)
+        self._lib, self._h, self.view, self.kind, self.compressed = lib, h, view, kind, False
+        self.im_iteration_limit = int(limit.value)
+        self._adopt()
+        return self
+
+    def save_im(self, path, compression_exp=20, exp_bytes=4):
+        """The view's location and this orbit under "max compression" as an Imagina ".im" file, the form
+        RefOrbitCalc::SaveOrbitResults(results, filename) writes for PerturbationResults<IterType, float | double, ...>
+        (RefOrbitCalc.cpp:3039-3115: ExtendedRange = false, waypoints as two doubles and the index field)."""
+        if self._lib.fsh_plain_save_im(self._h, self.view.num_iterations, int(compression_exp), os.fsencode(path),
+                                       int(exp_bytes)) != 0:
+            raise OSError("could not write %s" % (path,))
+
+    def _adopt(self):
+        lib, view, kind = self._lib, self.view, self.kind
         src_kind = "f32" if kind == "f32" else "f64"
         o_dt, la_dt, at_dt, real_dt = _plain_dtypes(src_kind)
         self.count = int(lib.fsh_plain_orbit_count(self._h))

@@ -169,6 +169,13 @@ fsh_plain *fsh_plain_create(const fsh_view *v, int kind, uint64_t max_iter, int 
  * the orbit as RuntimeDecompressor reproduces it, with the SimpleCompression period divisor. */
 fsh_plain *fsh_plain_create_ex(const fsh_view *v, int kind, uint64_t max_iter, int periodicity, int host_threads,
                                int compression_exp);
+/* ".im" files with a reference orbit for the non-ExtendedRange types (RefOrbitCalc::SaveOrbitResults(results, filename) /
+ * LoadOrbitConst for T = float | double, RefOrbitCalc.cpp:3039-3115, :3386-3412; SaveOrbitBin / LoadOrbitBin,
+ * PerturbationResults.cpp:2047-2075, :2177-2183): ReferenceHeader::ExtendedRange = false, waypoints of two doubles and the
+ * index field, "Sharks:)" magic for float and Imagina's for double.  fsh_plain_load_im rebuilds the orbit from the waypoints
+ * (DecompressMax) and builds the LAv2 table from it; NULL for anything else (an ExtendedRange file: fsh_orbit_load_im). */
+int fsh_plain_save_im(const fsh_plain *h, uint64_t num_iterations, int compression_exp, const char *path, int exp_bytes);
+fsh_plain *fsh_plain_load_im(const char *path, uint64_t *iteration_limit, int host_threads);
 int fsh_plain_is_compressed(const fsh_plain *h);
 uint64_t fsh_plain_compressed_count(const fsh_plain *h);
 const void *fsh_plain_compressed_data(const fsh_plain *h); /* fs_orbit_f32_rc[] / fs_orbit_f64_rc[] */

@@ -953,6 +953,26 @@ def test_plain_lav2_parity(renderer, native_libs, kind, width):
         assert red.Sum == int(ref[:36, :64].astype(np.uint64).sum())
 
 
+@pytest.mark.parametrize("kind,width", [("f32", "1e-5"), ("f64", "1e-10"), ("2x32", "1e-10")])
+def test_plain_lav2_from_an_im_file_orbit(renderer, native_libs, tmp_path, kind, width):
+    """Round 4: ".im" files of the non-ExtendedRange types.  The orbit rebuilt from a file's waypoints (and the table built from
+    it) renders to what the restated kernel makes of the same inputs -- and that frame is close to the saved orbit's."""
+    from test_plain_oracle import shallow_view
+    v = shallow_view(width)
+    src = inputs.PlainInputs(v, "f32" if kind == "f32" else "f64")
+    p = tmp_path / "plain.im"
+    src.save_im(p)
+    w = inputs.View.load_im(p, v.width, v.height)
+    pin = inputs.PlainInputs.load_im(p, w, kind=kind)
+    assert (pin.count, pin.period) == (src.count, src.period)
+    out, _ = _render_plain(renderer, w, pin, LAV2_FULL)
+    assert np.array_equal(out, _oracle.gpu_lav2_plain(w, pin, mode=0)), kind
+    direct, _ = _render_plain(renderer, v, inputs.PlainInputs(v, kind), LAV2_FULL)
+    a, b = out[:36, :64].astype(np.int64), direct[:36, :64].astype(np.int64)
+    # an orbit good to the compression tolerance (1e-10 relative in binary64, 1e-3 in binary32): the same picture
+    assert (np.abs(a - b) <= 2).mean() > (0.5 if kind == "f32" else 0.9)
+
+
 def test_plain_lav2_odd_sizes_bands_and_antialiasing(renderer, native_libs):
     from test_plain_oracle import shallow_view
     v = shallow_view("1e-12", W=37, H=21)

@@ -219,3 +219,104 @@ def test_layout_constants_against_the_reference_headers(tmp_path):
     assert [int(x) for x in out[:12]] == [32, 16, 1, 48, 144, 192, 16, 24, 34, 40, 184, 8]
     assert (float(out[12]), int(out[13])) == (2.0, -1234)  # HRReal{exp, mantissa}: the AbsolutePrecision field
     assert out[14] == "8000000000000005"                   # 63-bit index, rebase flag in the top bit
+
+
+# ---- the non-ExtendedRange forms: PerturbationResults<IterType, float | double, ...> (round 4)
+def parse_plain(path):
+    b = open(path, "rb").read()
+    magic, reserved, loc, ref = struct.unpack("<4Q", b[:32])
+    mant, e, limit = struct.unpack("<dqQ", b[loc:loc + 24])
+    at = ref
+    ext = b[at]
+    at += 1 + 48
+    la = b[at:at + 192]
+    at += 192
+    (n,) = struct.unpack("<Q", b[at:at + 8])
+    at += 8
+    wps = []
+    for _ in range(n):
+        x, y, field = struct.unpack("<ddQ", b[at:at + 24])  # double x, double y, CompressionIndexField
+        wps.append((x, y, field & (2 ** 63 - 1), field >> 63))
+        at += 24
+    (r,) = struct.unpack("<Q", b[at:at + 8])
+    at += 8 + 8 * r
+    return dict(magic=magic, loc=loc, ref=ref, halfH=(mant, e), limit=limit, ext=ext, ref_it=struct.unpack("<Q", la[16:24])[0],
+                max_it=struct.unpack("<Q", la[24:32])[0], flags=tuple(la[32:36]), waypoints=wps, end=at, size=len(b))
+
+
+def _shallow(width="1e-5", n_iter=20000):
+    from test_plain_oracle import shallow_view
+    return shallow_view(width, n_iter=n_iter)
+
+
+@pytest.mark.parametrize("kind", ["f32", "f64"])
+def test_plain_file_layout(tmp_path, kind):
+    v = _shallow()
+    pin = inputs.PlainInputs(v, kind)
+    p = tmp_path / "p.im"
+    pin.save_im(p)
+    f = parse_plain(p)
+    assert f["magic"] == (SHARKS_MAGIC if kind == "f32" else IM_MAGIC)  # the magic follows the SubType
+    assert f["ext"] == 0                                                 # ReferenceHeader::ExtendedRange = results.IsHDR
+    assert f["loc"] == 32 and f["end"] == f["size"]                      # 24-byte waypoints account for every byte
+    assert f["limit"] == v.num_iterations and f["ref_it"] == pin.count - 1 and f["max_it"] == v.num_iterations - 1
+    assert f["flags"][2] == (1 if pin.period else 0)
+    # halfH = Imagina::HRReal{T radius}: normalised mantissa in [1, 2)
+    assert 1.0 <= abs(f["halfH"][0]) < 2.0
+    idx = [w[2] for w in f["waypoints"]]
+    assert idx == sorted(idx) and idx[0] >= 1 and idx[-1] <= pin.count - 1
+    if kind == "f32":  # waypoints are floats widened to double: no bits below binary32
+        for x, y, _, _ in f["waypoints"]:
+            assert np.float64(np.float32(x)) == x and np.float64(np.float32(y)) == y
+
+
+@pytest.mark.parametrize("kind,width,tol", [("f64", "1e-5", 1e-9), ("f64", "1e-10", 1e-9), ("f32", "1e-4", 2e-3), ("f32", "1e-5", 2e-3)])
+def test_plain_round_trip_rebuilds_the_orbit_and_its_table(tmp_path, kind, width, tol):
+    v = _shallow(width)
+    pin = inputs.PlainInputs(v, kind)
+    p = tmp_path / "p.im"
+    pin.save_im(p)
+    w = inputs.View.load_im(p, v.width, v.height)
+    assert w.im_has_orbit
+    q = inputs.PlainInputs.load_im(p, w)
+    assert (q.kind, q.count, q.period) == (kind, pin.count, pin.period)
+    assert q.im_iteration_limit == v.num_iterations
+    a, b = pin.orbit(), q.orbit()
+    ax, ay, bx, by = (z.astype(np.float64) for z in (a["x"], a["y"], b["x"], b["y"]))
+    cheb = np.maximum(np.abs(ax), np.abs(ay))
+    err = np.maximum(np.abs(ax - bx), np.abs(ay - by))
+    assert (err[1:] <= tol * cheb[1:]).all(), float((err[1:] / cheb[1:]).max())
+    assert ax[0] == bx[0] == 0.0 and ay[0] == by[0] == 0.0
+    # a table comes with the loaded orbit (the same builder ran on it), of the same shape as the saved orbit's
+    assert q.is_valid == pin.is_valid and q.stage_count == pin.stage_count
+    assert abs(q.la_count - pin.la_count) <= max(2, pin.la_count // 50)
+
+
+def test_plain_and_extended_range_readers_refuse_each_other(tmp_path):
+    v = _shallow()
+    pin = inputs.PlainInputs(v, "f64")
+    p = tmp_path / "plain.im"
+    pin.save_im(p)
+    with pytest.raises(ValueError):
+        inputs.Orbit.load_im(p, v)  # ExtendedRange = false: not an HDRFloat orbit
+    with pytest.raises(ValueError):
+        inputs.PlainInputs.load_im(p, v, kind="f32")  # Imagina's magic: a double orbit
+    o = inputs.Orbit(v, is64=True)
+    h = tmp_path / "hdr.im"
+    o.save_im(h)
+    with pytest.raises(ValueError):
+        inputs.PlainInputs.load_im(h, v)  # ExtendedRange = true
+    raw = bytearray(open(p, "rb").read())
+    cut = tmp_path / "cut.im"
+    cut.write_bytes(bytes(raw[:-7]))
+    with pytest.raises(ValueError):
+        inputs.PlainInputs.load_im(cut, v)
+    # a crafted waypoint index past the announced orbit
+    ref = struct.unpack("<Q", raw[24:32])[0]
+    first = ref + 1 + 48 + 192 + 8
+    bad = bytearray(raw)
+    bad[first + 16:first + 24] = struct.pack("<Q", 2 ** 40)
+    b = tmp_path / "bad.im"
+    b.write_bytes(bytes(bad))
+    with pytest.raises(ValueError):
+        inputs.PlainInputs.load_im(b, v)
