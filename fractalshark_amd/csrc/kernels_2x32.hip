@@ -275,6 +275,18 @@ __global__ void __launch_bounds__(256) k_lav2_2x32(FsLav2Args2x32 A)
                 iter = i * A.at.StepLength;
                 if (kStats)
                     c_at = i;
+#ifdef FS_2X32_PROBE
+                if (kStats) { // probe: lane slots of the AT loop = 64 x the longest lane of the wave (statistics word 13)
+                    unsigned long long m = (unsigned long long)i;
+                    for (int d = 32; d >= 1; d >>= 1) {
+                        const unsigned long long o = __shfl_xor(m, d);
+                        m = o > m ? o : m;
+                    }
+                    const uint64_t act = __builtin_amdgcn_ballot_w64(true);
+                    if (__builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u)) == 0u)
+                        atomicAdd((unsigned long long *)&A.stats[13], m * 64ull);
+                }
+#endif
             }
             // :73-131 (complex0's value before the stage loop is dead)
             uint32_t CurrentLAStage = A.la_valid ? A.stage_count : 0;

@@ -38,6 +38,7 @@ for view, W, H, mode, name in ((14, 960, 540, LAV2_FULL, "view14_full_aa4"), (5,
     raw = (C.c_uint64 * 32)()
     assert r._lib.fs_read_stats_raw(r._h, raw, 32) == 0
     st = r.read_step_count()
-    out[name] = {"kernel_ms": round(min(ms), 3), "perturb_steps": int(st["perturb_steps"]), "literal_lane_steps": int(raw[12])}
+    out[name] = {"kernel_ms": round(min(ms), 3), "perturb_steps": int(st["perturb_steps"]), "literal_lane_steps": int(raw[12]),
+                 "at_iterations": int(st.get("at_iterations", 0)), "at_lane_slots_of_waves_that_enter_at": int(raw[13])}
     del r
 print(json.dumps(out))
