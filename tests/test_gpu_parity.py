@@ -922,6 +922,32 @@ def test_other_views_2x32(renderer, native_libs):
         assert np.array_equal(out, _oracle.gpu_lav2_2x32(v, o2, la2, mode=0)), view_n
 
 
+# ---- round 4: the packed X/Y perturbation step of k_lav2_2x32 (pt_step_pk) on orbits it has not seen: three centres (one ON
+# the real axis, where parts of dz and of the orbit are exact zeros and the step must hand over to the literal code), zoom
+# widths from 1e-8 to 1e-40 -- exponent gaps from a few binades to beyond the 120 at which an operand is dropped
+_X2_CENTRES = [("-0.5482057480704757084582125675467330293766992786373239", "-0.5775708389036038428051089822018505586755517268027721"),
+               ("-1.7685736563152709932817429153295447129341", "0.0"),
+               ("-0.1528465308235274786391493323577", "1.0397032701234428320367513768879")]
+
+
+@pytest.mark.parametrize("centre", [0, 1, 2])
+@pytest.mark.parametrize("width", ["1e-8", "1e-14", "1e-22", "1e-31", "1e-40"])
+def test_2x32_generated_views_full_and_perturbation_only(renderer, native_libs, centre, width):
+    from decimal import Decimal, getcontext
+    getcontext().prec = 80
+    W, H = 48, 27
+    cx, cy, w = Decimal(_X2_CENTRES[centre][0]), Decimal(_X2_CENTRES[centre][1]), Decimal(width)
+    h = w * H / W
+    v = inputs.View(str(cx - w / 2), str(cy - h / 2), str(cx + w / 2), str(cy + h / 2), W, H, num_iterations=30000)
+    o = inputs.Orbit(v, is64=True)
+    la = inputs.LATable(o, use_small_exponents=True)
+    o2, la2 = inputs.Orbit2x32(o), inputs.LATable2x32(la)
+    out, _ = _render_2x32(renderer, v, o2, la2, LAV2_FULL)
+    assert np.array_equal(out, _oracle.gpu_lav2_2x32(v, o2, la2, mode=0)), (centre, width, "full")
+    out, _ = _render_2x32(renderer, v, o2, None, LAV2_PO, n_iter=4000)
+    assert np.array_equal(out, _oracle.gpu_lav2_2x32(v, o2, None, mode=1, n_iterations=4000)), (centre, width, "po")
+
+
 # ---- non-HDR LAv2: Gpu1x32 / Gpu1x64 / Gpu2x32 PerturbedLAv2[PO|LAO] (Fractal's AUTO choice for zoom 1e4 .. 1e34)
 def _render_plain(r, v, pin, mode, n_iter=None, bands=None):
     w, h = v.width * v.antialiasing, v.height * v.antialiasing
