@@ -259,20 +259,11 @@ constexpr uint64_t kMaxImOrbitEntries = 1ull << 29;
 
 // exp_bytes = sizeof(long) of the build that wrote the file: 4 for the reference's Windows (MSVC) build and Imagina itself,
 // 8 for the reference built on Linux.  Limbs are 64-bit in both (MPIR x64 / GMP), so only the field width differs.
-void im_write_mpf(FILE *f, mpf_srcptr X, int exp_bytes)
+// The integer stream under the mpf one: MpirSerialization::mpz_out_raw_stream / mpz_inp_raw_stream (MPIR's mpz_out_raw):
+// a 4-byte big-endian signed header sign x byte-count, then the magnitude, most significant byte first.  Pinned by the
+// reference's own byte vectors (FractalSharkTest/TestMpirSerialization.cpp:236-308, :393-428; tests/test_mpir_wire_format.py).
+size_t im_write_mpz(FILE *f, mpz_srcptr Z)
 {
-    const int64_t expt = X->_mp_exp;
-    if (exp_bytes == 4) {
-        const int32_t e32 = (int32_t)expt;
-        fwrite(&e32, 4, 1, f);
-    } else {
-        fwrite(&expt, 8, 1, f);
-    }
-    mpz_t Z; // non-owning view of X's limbs, like the reference
-    const int nz = X->_mp_size;
-    Z->_mp_alloc = std::abs(nz);
-    Z->_mp_size = nz;
-    Z->_mp_d = X->_mp_d;
     size_t byte_count = 0;
     const int sign = mpz_sgn(Z);
     if (sign != 0)
@@ -287,12 +278,53 @@ void im_write_mpf(FILE *f, mpf_srcptr X, int exp_bytes)
         mpz_export(buf.data(), &n, 1, 1, 1, 0, Z);
         fwrite(buf.data(), 1, byte_count, f);
     }
+    return 4 + byte_count;
+}
+
+// Z must be initialised.  *nonzero: whether the header announced a magnitude.
+bool im_read_mpz(FILE *f, mpz_ptr Z, bool *nonzero)
+{
+    unsigned char hdr[4];
+    if (fread(hdr, 1, 4, f) != 4)
+        return false;
+    const int32_t raw = (int32_t)(((uint32_t)hdr[0] << 24) | ((uint32_t)hdr[1] << 16) | ((uint32_t)hdr[2] << 8) | hdr[3]);
+    mpz_set_ui(Z, 0);
+    if (raw != 0) {
+        const size_t n = (size_t)std::abs((int64_t)raw);
+        if (n > (1u << 24)) // 128 Mbit of mantissa: not a location anyone saved; the wrong exponent width reads such counts
+            return false;
+        std::vector<unsigned char> buf(n);
+        if (fread(buf.data(), 1, n, f) != n)
+            return false;
+        mpz_import(Z, n, 1, 1, 1, 0, buf.data());
+        if (raw < 0)
+            mpz_neg(Z, Z);
+    }
+    if (nonzero)
+        *nonzero = raw != 0;
+    return true;
+}
+
+void im_write_mpf(FILE *f, mpf_srcptr X, int exp_bytes)
+{
+    const int64_t expt = X->_mp_exp;
+    if (exp_bytes == 4) {
+        const int32_t e32 = (int32_t)expt;
+        fwrite(&e32, 4, 1, f);
+    } else {
+        fwrite(&expt, 8, 1, f);
+    }
+    mpz_t Z; // non-owning view of X's limbs, like the reference
+    const int nz = X->_mp_size;
+    Z->_mp_alloc = std::abs(nz);
+    Z->_mp_size = nz;
+    Z->_mp_d = X->_mp_d;
+    im_write_mpz(f, Z);
 }
 
 bool im_read_mpf(FILE *f, mpf_ptr X, int exp_bytes)
 {
     int64_t expt = 0;
-    unsigned char hdr[4];
     if (exp_bytes == 4) {
         int32_t e32;
         if (fread(&e32, 4, 1, f) != 1)
@@ -301,28 +333,15 @@ bool im_read_mpf(FILE *f, mpf_ptr X, int exp_bytes)
     } else if (fread(&expt, 8, 1, f) != 1) {
         return false;
     }
-    if (fread(hdr, 1, 4, f) != 4)
-        return false;
-    const int32_t raw = (int32_t)(((uint32_t)hdr[0] << 24) | ((uint32_t)hdr[1] << 16) | ((uint32_t)hdr[2] << 8) | hdr[3]);
     mpz_t Z;
     mpz_init(Z);
-    if (raw != 0) {
-        const size_t n = (size_t)std::abs((int64_t)raw);
-        if (n > (1u << 24)) { // 128 Mbit of mantissa: not a location anyone saved; the wrong exponent width reads such counts
-            mpz_clear(Z);
-            return false;
-        }
-        std::vector<unsigned char> buf(n);
-        if (fread(buf.data(), 1, n, f) != n) {
-            mpz_clear(Z);
-            return false;
-        }
-        mpz_import(Z, n, 1, 1, 1, 0, buf.data());
-        if (raw < 0)
-            mpz_neg(Z, Z);
+    bool nonzero = false;
+    if (!im_read_mpz(f, Z, &nonzero)) {
+        mpz_clear(Z);
+        return false;
     }
     mpf_set_z(X, Z);
-    if (raw != 0)
+    if (nonzero)
         X->_mp_exp = (mp_exp_t)expt;
     mpz_clear(Z);
     return true;
@@ -334,6 +353,51 @@ struct ImHalfH { // Imagina::HRReal
 };
 
 } // namespace
+
+// The integer stream on its own, memory to memory (tests: the reference's wire-format vectors).  fsh_mpz_raw_write: the
+// bytes of `value` (a number in `base`) into out[0 .. cap), returns their count (0: bad number or no room).
+// fsh_mpz_raw_read: one integer from in[0 .. n), its decimal text into out_decimal; returns the bytes consumed (0: error).
+extern "C" size_t fsh_mpz_raw_write(const char *value, int base, unsigned char *out, size_t cap)
+{
+    mpz_t z;
+    if (mpz_init_set_str(z, value, base) != 0) {
+        mpz_clear(z);
+        return 0;
+    }
+    char *mem = nullptr;
+    size_t len = 0;
+    FILE *f = open_memstream(&mem, &len);
+    size_t written = 0;
+    if (f) {
+        written = im_write_mpz(f, z);
+        fclose(f);
+        if (written != len || len > cap)
+            written = 0;
+        else
+            memcpy(out, mem, len);
+        free(mem);
+    }
+    mpz_clear(z);
+    return written;
+}
+extern "C" size_t fsh_mpz_raw_read(const unsigned char *in, size_t n, char *out_decimal, size_t cap)
+{
+    if (n == 0)
+        return 0;
+    FILE *f = fmemopen(const_cast<unsigned char *>(in), n, "rb");
+    if (!f)
+        return 0;
+    mpz_t z;
+    mpz_init(z);
+    size_t used = 0;
+    if (im_read_mpz(f, z, nullptr) && mpz_sizeinbase(z, 10) + 2 <= cap) {
+        mpz_get_str(out_decimal, 10, z);
+        used = (size_t)ftell(f);
+    }
+    mpz_clear(z);
+    fclose(f);
+    return used;
+}
 
 extern "C" int fsh_view_save_im(const fsh_view *v, uint64_t iteration_limit, const char *path, int exp_bytes)
 {

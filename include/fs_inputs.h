@@ -39,6 +39,11 @@ uint64_t fsh_view_precision_bits(const fsh_view *v);
  * 8 = the reference built on Linux (the mpf exponent field is a raw `long`); the loader finds it from the section's
  * length and reports it.  Returns 0 / a view, or -1 / NULL. */
 int fsh_view_save_im(const fsh_view *v, uint64_t iteration_limit, const char *path, int exp_bytes);
+/* The integer stream the two mpf values of an ".im" file are written in (MpirSerialization::mpz_out_raw_stream /
+ * mpz_inp_raw_stream = MPIR's mpz_out_raw: big-endian signed byte count, magnitude most significant byte first), memory to
+ * memory: what tests/test_mpir_wire_format.py pins to the byte vectors of the reference's own unit tests. */
+size_t fsh_mpz_raw_write(const char *value, int base, unsigned char *out, size_t cap);
+size_t fsh_mpz_raw_read(const unsigned char *in, size_t n, char *out_decimal, size_t cap);
 fsh_view *fsh_view_load_im(const char *path, uint32_t width, uint32_t height, uint64_t *iteration_limit, int *has_orbit,
                            int *exp_bytes_out);
 /* ".im" files WITH a reference orbit (RefOrbitCalc::SaveOrbitResults(results, filename), RefOrbitCalc.cpp:3039-3115; the

@@ -18,10 +18,10 @@ import re
 import sys
 
 REF = "/root/reference/FractalSharkTest"
-FILES = ["TestHDRFloat.cpp", "TestHDRFloatComplex.cpp", "TestATInfo.cpp", "TestBLA.cpp"]
+FILES = ["TestHDRFloat.cpp", "TestHDRFloatComplex.cpp", "TestATInfo.cpp", "TestBLA.cpp", "TestFloatComplex.cpp"]
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "known_answer_vectors.json")
 
-SKIP_IF = [("HighPrecision", "MPIR HighPrecision conversion: host-only, outside the per-pixel numeric core"),
+SKIP_IF = [("ostringstream", "text I/O of FloatComplex: not on the hot path"), ("HighPrecision", "MPIR HighPrecision conversion: host-only, outside the per-pixel numeric core"),
            ("ToString", "text I/O of HDRFloat: not on the hot path"),
            ("HDROrder::Right", "alternative member order of the reference's template: this repository has one layout"),
            ("HRReal", "64-bit exponent instantiation (Imagina::HRReal): the device types carry int32 exponents")]
@@ -40,7 +40,8 @@ def preprocess(body):
             (r"std::pow", "pow"), (r"HDRd::MIN_BIG_EXPONENT\(\)", "MIN_BIG_EXP"), (r"HDRd::getMultiplier", "getMultiplier_d"),
             (r"HDRf::getMultiplier", "getMultiplier_f"), (r"HDRd::HDRMax", "HDRMax"), (r"HDRd::HDRMin", "HDRMin"),
             (r"BLAd::getNewA", "getNewA"), (r"BLAd::getNewB", "getNewB"), (r"BLAd::getGenericStep", "BLAd"),
-            (r"\.Reduce<true>\(&(\w+)\)", r".ReduceGet(\1)"), (r"HDRFloatComplex<float>", "HDRCf")]
+            (r"\.Reduce<true>\(&(\w+)\)", r".ReduceGet(\1)"), (r"HDRFloatComplex<float>", "HDRCf"),
+            (r"FloatComplex<float>", "HDRCf"), (r"\bFCd\b", "FC")]
     for a, b in subs:
         body = re.sub(a, b, body)
     return body

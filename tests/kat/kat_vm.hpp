@@ -157,11 +157,12 @@ struct Machine {
                 default: return v_c(hc_div(a.c, b.c));
             }
         }
-        if (a.kind == K_C && b.kind == K_R) {
+        if (a.kind == K_C && (b.kind == K_R || is_num(b))) { // complex (+ | *) real; a plain scalar enters as HDRFloat(T mant)
+            const hreal<double> r = b.kind == K_R ? b.r : to_r(b);
             if (f == F_add)
-                return v_c(hc_add_real(a.c, b.r));
+                return v_c(hc_add_real(a.c, r));
             if (f == F_mul)
-                return v_c(hc_mul_real(a.c, b.r));
+                return v_c(hc_mul_real(a.c, r));
         }
         return v_dbl(0.0 / 0.0);
     }
@@ -262,6 +263,7 @@ struct Machine {
             // ---- HDRFloatComplex (FloatComplex<double> operands are carried as reduced HDR complex values)
             case F_ctor_HDRCd: case F_ctor_FC:
                 if (n == 0) push(v_c(hc_zero<double>()));
+                else if (n == 1 && a[0].kind == K_C) push(a[0]); // copy construction
                 else if (n == 1) push(v_c(hcplx<double>{(double)a[0].cf.re, (double)a[0].cf.im, a[0].cf.e}));
                 else if (a[0].kind == K_R) push(v_c(hc_from_hr(a[0].r, a[1].r)));
                 else push(v_c(hc_from_native<double>(num(a[0]), num(a[1]))));
