@@ -208,6 +208,7 @@ def inputs_lib():
     _decl(lib, "fsh_orbit_low_hdr32", None, [vp, vp])
     _decl(lib, "fsh_orbit_compressed_data_hdr64", vp, [vp])
     _decl(lib, "fsh_orbit_low_hdr64", None, [vp, vp])
+    _decl(lib, "fsh_la_default_params", None, [C.POINTER(C.c_int32)])
     _decl(lib, "fsh_mpz_raw_write", C.c_size_t, [C.c_char_p, C.c_int, C.c_char_p, C.c_size_t])
     _decl(lib, "fsh_mpz_raw_read", C.c_size_t, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t])
     _decl(lib, "fsh_orbit_save_im", C.c_int, [vp, u64, C.c_int, C.c_char_p, C.c_int])

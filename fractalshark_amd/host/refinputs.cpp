@@ -357,6 +357,17 @@ struct ImHalfH { // Imagina::HRReal
 // The integer stream on its own, memory to memory (tests: the reference's wire-format vectors).  fsh_mpz_raw_write: the
 // bytes of `value` (a number in `base`) into out[0 .. cap), returns their count (0: bad number or no room).
 // fsh_mpz_raw_read: one integer from in[0 .. n), its decimal text into out_decimal; returns the bytes consumed (0: error).
+// The LAParameters every table in this file is built with (la_math.hpp LAParams = the reference's defaults,
+// LAParameters.h:66-75): {detectionMethod, LAThresholdScaleExp, LAThresholdCScaleExp, Stage0PeriodDetectionThreshold2Exp,
+// PeriodDetectionThreshold2Exp, Stage0PeriodDetectionThresholdExp, PeriodDetectionThresholdExp}.
+extern "C" void fsh_la_default_params(int32_t out[7])
+{
+    const LAParams p{};
+    out[0] = p.detectionMethod, out[1] = p.laThresholdScaleExp, out[2] = p.laThresholdCScaleExp;
+    out[3] = p.stage0PeriodDetectionThreshold2Exp, out[4] = p.periodDetectionThreshold2Exp;
+    out[5] = p.stage0PeriodDetectionThresholdExp, out[6] = p.periodDetectionThresholdExp;
+}
+
 extern "C" size_t fsh_mpz_raw_write(const char *value, int base, unsigned char *out, size_t cap)
 {
     mpz_t z;

@@ -42,6 +42,9 @@ int fsh_view_save_im(const fsh_view *v, uint64_t iteration_limit, const char *pa
 /* The integer stream the two mpf values of an ".im" file are written in (MpirSerialization::mpz_out_raw_stream /
  * mpz_inp_raw_stream = MPIR's mpz_out_raw: big-endian signed byte count, magnitude most significant byte first), memory to
  * memory: what tests/test_mpir_wire_format.py pins to the byte vectors of the reference's own unit tests. */
+/* The LAParameters the LAv2 tables are built with (the reference's defaults, LAParameters.h:66-75; pinned by the values of its
+ * unit tests, tests/test_host_builder_vectors.py): detection method, then the six exponents in the order of the getters. */
+void fsh_la_default_params(int32_t out[7]);
 size_t fsh_mpz_raw_write(const char *value, int base, unsigned char *out, size_t cap);
 size_t fsh_mpz_raw_read(const unsigned char *in, size_t n, char *out_decimal, size_t cap);
 fsh_view *fsh_view_load_im(const char *path, uint32_t width, uint32_t height, uint64_t *iteration_limit, int *has_orbit,
