@@ -34,3 +34,26 @@ def test_view_precision(native_libs, case):
         x0, y0, x1, y1 = str(-h), str(-h), str(h), str(h)
     v = inputs.View(x0, y0, x1, y1, 64, 64, num_iterations=100)
     assert v.precision_bits == case["precision_bits"], case["source"]
+
+
+@pytest.mark.parametrize("case", VEC["double_float_split"], ids=[c["name"] for c in VEC["double_float_split"]])
+def test_double_to_double_float_split(native_libs, case):
+    """TestCudaDblflt.cpp: what MattDblflt(double) / CudaDblflt(double) must give back.  The product's converter is the one every
+    HDRFloat<CudaDblflt> / CudaDblflt orbit, table and coordinate goes through (fsh_convert_*_to_*2x32, host/refinputs.cpp)."""
+    import numpy as np
+    lib = _capi.inputs_lib()
+    src = np.zeros(1, np.dtype([("x", "<f8"), ("y", "<f8")]))
+    v = float(case["value"])
+    src["x"], src["y"] = v, -v
+    dst = np.zeros(1, np.dtype([("x_head", "<f4"), ("x_tail", "<f4"), ("y_head", "<f4"), ("y_tail", "<f4")]))
+    lib.fsh_convert_orbit_f64_to_p2x32(src.ctypes.data, 1, dst.ctypes.data)
+    head, tail = float(dst["x_head"][0]), float(dst["x_tail"][0])
+    assert (float(dst["y_head"][0]), float(dst["y_tail"][0])) == (-head, -tail)  # the split is odd
+    if "sum_tolerance" in case:
+        assert abs((head + tail) - v) <= case["sum_tolerance"]
+    if case.get("both_words_zero"):
+        assert head == 0.0 and tail == 0.0
+    if case.get("closer_than_the_head_alone"):
+        head_err = abs(v - float(np.float32(v)))
+        assert abs(v - (head + tail)) < head_err or head_err < 1e-15
+    assert abs(tail) <= abs(head) * 2.0 ** -23 or head == 0.0  # normalised: the tail is below the head's last place
