@@ -211,7 +211,7 @@ class Compiler:
                         self.emit("call", "to_float", 1)
                     self.store(name, typ)
             else:
-                if typ in ("HDRd", "HDRf", "HDRCd", "HDRCf", "BLAd", "ATInfoD", "ATResultD"):
+                if typ in ("HDRd", "HDRf", "HDRCd", "HDRCf", "BLAd", "ATInfoD", "ATResultD", "FC"):
                     self.construct(typ, 0)
                     self.store(name, typ)
                 else:
@@ -265,6 +265,15 @@ class Compiler:
                 if self.at("="):
                     self.take()
                     self.expression()
+                    self.store(name)
+                    return
+                # compound assignment  a op= b  ==  a = a op b
+                if self.peek()[0] == "op" and self.peek()[1] in ("+", "-", "*", "/") and self.peek(1) == ("op", "="):
+                    op = self.take()[1]
+                    self.take("op", "=")
+                    self.emit("load", self.vars[name])
+                    self.expression()
+                    self.emit("call", self.NAMES[op], 2)
                     self.store(name)
                     return
             except (SyntaxError, KeyError):
