@@ -7,6 +7,8 @@ Source (read where it lies, /root/reference; nothing of it is copied):
   FractalSharkTest/TestPrecisionCalculator.cpp   the bounding-box and converter cases: the MPIR precision a view is given
                                              (larger binary exponent of its width / height + 120 bits), which decides every bit of the
                                              reference orbit
+  FractalSharkTest/TestPointZoomBBConverter.cpp  SquareAspectRatio_AlreadySquare / _Wide / _Tall: how a view's box is widened to the
+                                             screen's aspect ratio before anything is rendered (every pixel's delta-c follows from it)
   FractalSharkTest/TestCudaDblflt.cpp        the double -> (head, tail) split of MattDblflt / CudaDblflt (construction from a double,
                                              copy, assignment): the conversion every HDRFloat<CudaDblflt> and CudaDblflt input goes through
 What is committed is DATA: getter names with expected integers, boxes (as decimal / power-of-two text) with the expected
@@ -77,10 +79,26 @@ def main():
             entry["closer_than_the_head_alone"] = True
         if len(entry) > 3:
             splits.append(entry)
+    pz = open(os.path.join(REF, "TestPointZoomBBConverter.cpp")).read()
+    aspect = []
+    for name in ("SquareAspectRatio_AlreadySquare", "SquareAspectRatio_Wide", "SquareAspectRatio_Tall"):
+        body, line = body_of(pz, name)
+        box = re.findall(r"HighPrecision\{(-?\d+)\}", body)[:4]
+        w, h = re.search(r"SquareAspectRatio\((\d+),\s*(\d+)\)", body).groups()
+        want = {}
+        for got, val, tol in re.findall(r"ASSERT_NEAR\((\w+),\s*([\w.]+),\s*([-\de.]+)\)", body):
+            key = "width" if "idth" in got else "height"
+            if re.fullmatch(r"[\d.]+", val):
+                want[key] = (float(val), float(tol))
+            else:  # compared with the box's own extent before the call
+                want[key] = (float(box[2 if key == "width" else 3]) - float(box[0 if key == "width" else 1]), float(tol))
+        aspect.append({"name": name, "source": "TestPointZoomBBConverter.cpp:%d" % line, "box": box, "screen": [int(w), int(h)],
+                       "width": want["width"][0], "height": want["height"][0], "tolerance": max(want["width"][1], want["height"][1])})
     out = {"_comment": "generated by tests/golden/make_host_builder_vectors.py from the reference's unit tests "
-                       "(TestLAParameters.cpp, TestPrecisionCalculator.cpp, TestCudaDblflt.cpp): names, operands, expected integers "
-                       "and tolerances only",
-           "la_parameters": {"sources": src, "defaults": params}, "precision": boxes, "double_float_split": splits}
+                       "(TestLAParameters.cpp, TestPrecisionCalculator.cpp, TestPointZoomBBConverter.cpp, TestCudaDblflt.cpp): names, "
+                       "operands, expected values and tolerances only",
+           "la_parameters": {"sources": src, "defaults": params}, "precision": boxes, "square_aspect_ratio": aspect,
+           "double_float_split": splits}
     with open(OUT, "w") as f:
         json.dump(out, f, indent=1)
         f.write("\n")

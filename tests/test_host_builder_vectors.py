@@ -57,3 +57,15 @@ def test_double_to_double_float_split(native_libs, case):
         head_err = abs(v - float(np.float32(v)))
         assert abs(v - (head + tail)) < head_err or head_err < 1e-15
     assert abs(tail) <= abs(head) * 2.0 ** -23 or head == 0.0  # normalised: the tail is below the head's last place
+
+
+@pytest.mark.parametrize("case", VEC["square_aspect_ratio"], ids=[c["name"] for c in VEC["square_aspect_ratio"]])
+def test_square_aspect_ratio(native_libs, case):
+    """TestPointZoomBBConverter.cpp: a view's box after PointZoomBBConverter::SquareAspectRatio(width, height) -- what inputs.View
+    applies to the box it is given, as Fractal does before it renders (every pixel's delta-c is a fraction of this box)."""
+    v = inputs.View(*case["box"], case["screen"][0], case["screen"][1], num_iterations=100)
+    x0, y0, x1, y1 = (float(t) for t in v.bbox())
+    assert abs((x1 - x0) - case["width"]) <= case["tolerance"]
+    assert abs((y1 - y0) - case["height"]) <= case["tolerance"]
+    # centred on the original box
+    assert abs((x0 + x1) / 2) <= case["tolerance"] and abs((y0 + y1) / 2) <= case["tolerance"]
