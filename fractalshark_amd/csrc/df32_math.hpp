@@ -213,6 +213,19 @@ __device__ __forceinline__ df32x2 operator*(df32x2 a, df32x2 b)
     return df32x2(e, (th - e) + tt);
 }
 
+// a * {m, 0} on both halves for a multiplier that is a plain float (a power of two wherever this is used): mul_dblflt with
+// the two fused operations on the multiplier's zero tail left out -- they return their addend: x * 0 + t = t for a finite x
+// unless t is -0, and t, the exact error of the head product (or what the previous fused operation made of it), is never -0.
+__device__ __forceinline__ df32x2 mul_by_float(df32x2 a, df32x2::f2 m)
+{
+    typedef df32x2::f2 f2;
+    const f2 th = a.head * m;
+    f2 tt = __builtin_elementwise_fma(a.head, m, -th);
+    tt = __builtin_elementwise_fma(a.tail, m, tt);
+    const f2 e = th + tt;
+    return df32x2(e, (th - e) + tt);
+}
+
 // (a.lo - b.lo, a.hi + b.hi): sub_dblflt in the lower half and add_dblflt in the upper one, operation for operation (a
 // subtraction IS the addition of the negated operand, so each packed addition below with one negated half is the scalar
 // operation of the corresponding line of operator- / operator+ above).
@@ -250,10 +263,8 @@ struct hreal2 {
 // (a.x - b.x, a.y + b.y) for kSubLo, else (a.x + b.x, a.y + b.y): add_mutable / subtract_mutable (hr_add / hr_sub,
 // hdr_math.hpp) of both pairs in one straight line.  The reference's four-way branch on the exponent gap d = a.e - b.e is,
 // for |d| < 120, "scale the operand with the smaller exponent by 2^-|d|, then add, first operand first"; which operand that
-// is is a per-lane select here and the scaling one packed double-float product for both parts.  That product has a
-// multiplier {2^-|d|, 0}: of mul_dblflt's four fused operations the two on the multiplier's zero tail return their addend
-// (x * 0 + t = t for finite x unless t is -0, and t -- the exact error of a product by a power of two, or what the next
-// fused operation made of it -- is never -0), so they are not issued.  From a gap of 120 on the reference returns the
+// is is a per-lane select here and the scaling one packed double-float product for both parts (mul_by_float: the
+// multiplier is {2^-|d|, 0}).  From a gap of 120 on the reference returns the
 // operand with the larger exponent untouched (deep zooms live there: dz is hundreds of binades below the orbit): one more
 // select per word.  What the straight line does NOT cover is reported in `rare` and left to the caller's literal path: a
 // zero result (the reference resets the exponent) and non-finite values.
@@ -266,11 +277,8 @@ template <bool kSubLo> __device__ __forceinline__ hreal2 hr_add2(hreal2 a, hreal
     const f2 mul = {__builtin_amdgcn_ldexpf(1.0f, -gx), __builtin_amdgcn_ldexpf(1.0f, -gy)}; // multiplier_neg(-|d|), |d| < 120
     const f2 sh = {nx ? a.m.head.x : b.m.head.x, ny ? a.m.head.y : b.m.head.y};
     const f2 st = {nx ? a.m.tail.x : b.m.tail.x, ny ? a.m.tail.y : b.m.tail.y};
-    const f2 th = sh * mul;
-    f2 tt = __builtin_elementwise_fma(sh, mul, -th);
-    tt = __builtin_elementwise_fma(st, mul, tt);
-    const f2 se = th + tt;
-    const f2 sl = (th - se) + tt;
+    const df32x2 S = mul_by_float(df32x2(sh, st), mul);
+    const f2 se = S.head, sl = S.tail;
     const df32x2 A((f2){nx ? se.x : a.m.head.x, ny ? se.y : a.m.head.y}, (f2){nx ? sl.x : a.m.tail.x, ny ? sl.y : a.m.tail.y});
     const df32x2 B((f2){nx ? b.m.head.x : se.x, ny ? b.m.head.y : se.y}, (f2){nx ? b.m.tail.x : sl.x, ny ? b.m.tail.y : sl.y});
     const df32x2 W = kSubLo ? sub_lo_add_hi(A, B) : A + B;

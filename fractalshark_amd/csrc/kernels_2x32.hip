@@ -243,8 +243,9 @@ __global__ void __launch_bounds__(256) k_lav2_2x32(FsLav2Args2x32 A)
                                 zz = (lhs + rhs.neg_lo()) + cc; // ((rr - ii) + cre, (re im + im re) + cim)
                             }
                         } else {
-                            const df32 mul = multiplier<df32>(E);
-                            const df32x2 mm(mul, mul), cc(c.re, c.im);
+                            const df32 mul = multiplier<df32>(E); // {2^E, 0} (-120 < E < 0)
+                            const df32x2::f2 mm = {mul.head, mul.head};
+                            const df32x2 cc(c.re, c.im);
                             for (; i < ATMaxIt; i++) {
                                 const df32x2 sq = zz * zz;
                                 if (!(sq.head.x + sq.head.y < esc_low)) {
@@ -256,7 +257,7 @@ __global__ void __launch_bounds__(256) k_lav2_2x32(FsLav2Args2x32 A)
                                 const df32x2 cr = zz * zz.swapped();
                                 const df32x2 lhs(df32x2::f2{sq.head.x, cr.head.x}, df32x2::f2{sq.tail.x, cr.tail.x});
                                 const df32x2 rhs(df32x2::f2{sq.head.y, cr.head.y}, df32x2::f2{sq.tail.y, cr.tail.y});
-                                zz = (lhs + rhs.neg_lo()) * mm + cc;
+                                zz = mul_by_float(lhs + rhs.neg_lo(), mm) + cc; // (x * {2^E, 0}: df32_math.hpp)
                             }
                         }
                         re = zz.lo(), im = zz.hi();

@@ -38,6 +38,14 @@ __global__ void k_check(const float4 *__restrict__ in, size_t n, unsigned long l
     const df32x2 D2 = sub_lo_add_hi(A, B);
     if (!same(D2.lo(), a0 - b0) || !same(D2.hi(), a1 + b1))
         atomicAdd(&bad[4], 1ull);
+    // mul_by_float: a * {2^k, 0} with the two fused operations on the zero tail left out == the full product
+    {
+        const float m0 = __builtin_amdgcn_ldexpf(1.0f, (int)((__float_as_uint(u.w) >> 2) % 121) - 120);
+        const float m1 = __builtin_amdgcn_ldexpf(1.0f, (int)((__float_as_uint(v.y) >> 2) % 121) - 120);
+        const df32x2 M = mul_by_float(A, (df32x2::f2){m0, m1});
+        if (!same(M.lo(), a0 * df32(m0)) || !same(M.hi(), a1 * df32(m1)))
+            atomicAdd(&bad[7], 1ull);
+    }
     // hr_add2: two HDRFloat<CudaDblflt> additions (or a subtraction and an addition) side by side, against hr_add / hr_sub
     // on each pair.  Exponents from the operands' low mantissa bits: gaps of -130 .. 130, mostly small.  Where the packed
     // form reports `rare` nothing is claimed (the caller runs the literal code); everywhere else every bit must agree.
@@ -93,7 +101,7 @@ int main()
         }
     }
     float4 *d_in;
-    unsigned long long *d_bad, bad[7] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned long long *d_bad, bad[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (hipMalloc((void **)&d_in, h.size() * sizeof(float)) != hipSuccess || hipMalloc((void **)&d_bad, sizeof(bad)) != hipSuccess)
         return 2;
     hipMemcpy(d_in, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice);
@@ -103,7 +111,7 @@ int main()
         return 2;
     hipMemcpy(bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost);
     printf("{\"pairs\": %zu, \"add_mismatch\": %llu, \"mul_mismatch\": %llu, \"sub_mismatch\": %llu, \"swap_mismatch\": %llu, "
-           "\"sub_lo_add_hi_mismatch\": %llu, \"hr_add2_mismatch\": %llu, \"hr_add2_rare\": %llu}\n",
-           n / 2, bad[0], bad[1], bad[2], bad[3], bad[4], bad[5], bad[6]);
-    return (bad[0] | bad[1] | bad[2] | bad[3] | bad[4] | bad[5]) ? 1 : 0;
+           "\"sub_lo_add_hi_mismatch\": %llu, \"hr_add2_mismatch\": %llu, \"hr_add2_rare\": %llu, \"mul_by_float_mismatch\": %llu}\n",
+           n / 2, bad[0], bad[1], bad[2], bad[3], bad[4], bad[5], bad[6], bad[7]);
+    return (bad[0] | bad[1] | bad[2] | bad[3] | bad[4] | bad[5] | bad[7]) ? 1 : 0;
 }
