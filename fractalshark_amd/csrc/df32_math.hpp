@@ -147,14 +147,14 @@ FS_HD hreal<df32> hr2_from_float(float v)
 }
 
 // HDRFloatComplex::Reduce(), CudaDblflt branch, HDRFloatComplex.h:472-500: each part through HDRFloat(T mant)
-// (mantissa, exponent 0, Reduce), Reduce again (no-op), setMantexp, then the old exponent is added back.
+// (mantissa, exponent 0, Reduce), Reduce again, setMantexp, then the old exponent is added back.  The second Reduce is
+// not issued: after the first one the head's exponent field is 127 (or head and tail are both zero and Reduce returns at
+// once), so it would shift by 0 binades -- head, tail and exponent come back bit for bit.
 template <> FS_HD void hc_reduce<df32>(hcplx<df32> &a)
 {
     if (a.re == df32(0.0f) && a.im == df32(0.0f))
         return;
     hreal<df32> tr{a.re, 0}, ti{a.im, 0};
-    hr_reduce(tr);
-    hr_reduce(ti);
     hr_reduce(tr);
     hr_reduce(ti);
     const int32_t old = a.e;

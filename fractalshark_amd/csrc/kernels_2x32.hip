@@ -120,20 +120,19 @@ __device__ __forceinline__ HC hc_add_pk(HC a, HC b)
     if (d >= kExpDiffIgnored) {
         return a;
     } else if (d >= 0) {
-        const df32 mul = multiplier<df32>(-d);
-        const df32x2 R = df32x2(a.re, a.im) + df32x2(b.re, b.im) * df32x2(mul, mul);
+        const float mul = multiplier<df32>(-d).head; // {2^-d, 0}: mul_by_float is the full product for it (df32_math.hpp)
+        const df32x2 R = df32x2(a.re, a.im) + mul_by_float(df32x2(b.re, b.im), (df32x2::f2){mul, mul});
         return HC{R.lo(), R.hi(), a.e};
     } else if (d > -kExpDiffIgnored) {
-        const df32 mul = multiplier<df32>(d);
-        const df32x2 R = df32x2(a.re, a.im) * df32x2(mul, mul) + df32x2(b.re, b.im);
+        const float mul = multiplier<df32>(d).head;
+        const df32x2 R = mul_by_float(df32x2(a.re, a.im), (df32x2::f2){mul, mul}) + df32x2(b.re, b.im);
         return HC{R.lo(), R.hi(), b.e};
     }
     return b;
 }
 __device__ __forceinline__ HC hc_mul2_pk(HC a)
 {
-    const df32 one(1.0f);
-    const df32x2 R = df32x2(a.re, a.im) * df32x2(one, one);
+    const df32x2 R = mul_by_float(df32x2(a.re, a.im), (df32x2::f2){1.0f, 1.0f}); // a * {1, 0}
     return HC{R.lo(), R.hi(), clamp_exp(a.e + 1)};
 }
 
