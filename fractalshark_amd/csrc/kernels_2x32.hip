@@ -153,8 +153,7 @@ __device__ __forceinline__ PkStep pt_step_pk(HR dX, HR dY, HR zx, HR zy, HR c0X,
     // factors of this step whose exponent is not bounded below by dz's own are dX and dY themselves.  (An exact zero in the
     // orbit -- entry 0, where every rebase lands -- or in delta-c only ever meets an addition, as the operand that is dropped.)
     bool rare = (dX.e < dY.e ? dX.e : dY.e) <= -(1 << 26);
-    const df32 one(1.0f);
-    const hreal2 Z2(df32x2(zx.m, zy.m) * df32x2(one, one), zx.e + 1, zy.e + 1); // hr_mul2 of both
+    const hreal2 Z2(mul_by_float(df32x2(zx.m, zy.m), (df32x2::f2){1.0f, 1.0f}), zx.e + 1, zy.e + 1); // hr_mul2 of both (m * {1, 0})
     const hreal2 S = hr_add2<false>(Z2, hreal2(dX, dY), rare);                  // (sumX, sumY)
     const hreal2 P(df32x2(dX.m, dX.m) * S.m, dX.e + S.ex, dX.e + S.ey);           // (dX sumX, dX sumY)
     const hreal2 Q(df32x2(dY.m, dY.m) * S.m.swapped(), dY.e + S.ey, dY.e + S.ex); // (dY sumY, dY sumX)
