@@ -272,6 +272,10 @@ template <bool kSubLo> __device__ __forceinline__ hreal2 hr_add2(hreal2 a, hreal
 {
     typedef df32x2::f2 f2;
     const int32_t dx = a.ex - b.ex, dy = a.ey - b.ey;
+    // every lane of the wave 120 binades or more above its second operand in both parts (a deep zoom's 2z + dz and z' + dz'):
+    // the reference returns the first operand as it is, and so does this -- one vote instead of the product and the sum
+    if (__builtin_amdgcn_ballot_w64(!(dx >= kExpDiffIgnored && dy >= kExpDiffIgnored)) == 0ull)
+        return a;
     const bool nx = dx < 0, ny = dy < 0;
     const int32_t gx = nx ? -dx : dx, gy = ny ? -dy : dy;
     const f2 mul = {__builtin_amdgcn_ldexpf(1.0f, -gx), __builtin_amdgcn_ldexpf(1.0f, -gy)}; // multiplier_neg(-|d|), |d| < 120
