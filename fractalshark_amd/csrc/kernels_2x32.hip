@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(256) k_lav2_2x32(FsLav2Args2x32 A)
                         const int32_t nsq_e = E << 1;
                         df32 re = z.re, im = z.im;
                         // Real and imaginary part side by side in packed registers (df32x2: the same operation sequences on
-                        // both halves): (rr, ii) is one packed product, (re im, im re) another, (rr - ii, re im + im re) one
+                        // both halves): (rr, re im) is one packed product, (ii, im re) another, (rr - ii, re im + im re) one
                         // packed sum with the first half's second operand negated, (+ c.re, + c.im) another -- 56 packed
                         // instructions and the 35 scalar ones of the norm test instead of 147 scalar ones per iteration.
                         df32x2 zz(re, im);
@@ -228,16 +228,17 @@ __global__ void __launch_bounds__(256) k_lav2_2x32(FsLav2Args2x32 A)
                             const df32 mul0 = multiplier<df32>(0);
                             const df32x2 cc(c.re * mul0, c.im * mul0);
                             for (; i < ATMaxIt; i++) {
-                                const df32x2 sq = zz * zz; // (rr, ii)
-                                if (!(sq.head.x + sq.head.y < esc_low)) { // (see esc_low)
-                                    HR nsq{sq.lo() + sq.hi(), nsq_e};
+                                // (re, re) * (re, im) and (im, im) * (im, re): the four products of z * z already paired the
+                                // way the sums want them (same operand order per product as HDRFloatComplex's times), so no
+                                // half of a result has to change registers
+                                const df32x2 lhs = df32x2(zz.head.xx, zz.tail.xx) * zz;           // (rr, re im)
+                                const df32x2 rhs = df32x2(zz.head.yy, zz.tail.yy) * zz.swapped(); // (ii, im re)
+                                if (!(lhs.head.x + rhs.head.x < esc_low)) { // (see esc_low)
+                                    HR nsq{lhs.lo() + rhs.lo(), nsq_e};
                                     hr_reduce(nsq);
                                     if (hr_cmp_pos(nsq, esc) > 0)
                                         break;
                                 }
-                                const df32x2 cr = zz * zz.swapped();                            // (re im, im re)
-                                const df32x2 lhs(df32x2::f2{sq.head.x, cr.head.x}, df32x2::f2{sq.tail.x, cr.tail.x}); // (rr, re im)
-                                const df32x2 rhs(df32x2::f2{sq.head.y, cr.head.y}, df32x2::f2{sq.tail.y, cr.tail.y}); // (ii, im re)
                                 zz = (lhs + rhs.neg_lo()) + cc; // ((rr - ii) + cre, (re im + im re) + cim)
                             }
                         } else {
@@ -245,16 +246,14 @@ __global__ void __launch_bounds__(256) k_lav2_2x32(FsLav2Args2x32 A)
                             const df32x2::f2 mm = {mul.head, mul.head};
                             const df32x2 cc(c.re, c.im);
                             for (; i < ATMaxIt; i++) {
-                                const df32x2 sq = zz * zz;
-                                if (!(sq.head.x + sq.head.y < esc_low)) {
-                                    HR nsq{sq.lo() + sq.hi(), nsq_e};
+                                const df32x2 lhs = df32x2(zz.head.xx, zz.tail.xx) * zz;
+                                const df32x2 rhs = df32x2(zz.head.yy, zz.tail.yy) * zz.swapped();
+                                if (!(lhs.head.x + rhs.head.x < esc_low)) {
+                                    HR nsq{lhs.lo() + rhs.lo(), nsq_e};
                                     hr_reduce(nsq);
                                     if (hr_cmp_pos(nsq, esc) > 0)
                                         break;
                                 }
-                                const df32x2 cr = zz * zz.swapped();
-                                const df32x2 lhs(df32x2::f2{sq.head.x, cr.head.x}, df32x2::f2{sq.tail.x, cr.tail.x});
-                                const df32x2 rhs(df32x2::f2{sq.head.y, cr.head.y}, df32x2::f2{sq.tail.y, cr.tail.y});
                                 zz = mul_by_float(lhs + rhs.neg_lo(), mm) + cc; // (x * {2^E, 0}: df32_math.hpp)
                             }
                         }
