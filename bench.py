@@ -93,6 +93,48 @@ def checksum_vs_committed(workload_key, parity, n_iterations, checksum):
     return None if want is None or checksum is None else bool(int(want) == int(checksum))
 
 
+def make_inputs(wl, view_id=-1, width=0, height=0, iter_cap=0, parity=None):
+    """Everything a workload's frame is a function of, built on the host the way main() hands it to the renderer: the view,
+    the reference orbit (GMP), the LA / BLA table, the pixel -> delta-c coefficients, the iteration cap and the parity mode.
+    Shared with tests/golden/make_frame_crcs.py, which renders the same frames with the CPU oracle.  No torch, no HIP.
+    (The LA builder's thread count only matters through min(orbit entries / 50000, threads), LAReference.cpp:236-251: 1 for
+    View 5's 16 046 entries and 2 for View 14's 116 695 on every host with two threads or more.)"""
+    from fractalshark_amd import inputs
+    dview, dw, dh = WORKLOADS[wl][:3]
+    view_id = dview if view_id < 0 else view_id
+    width = dw if width <= 0 else width
+    height = dh if height <= 0 else height
+    if parity is None:
+        parity = "cpu_gpustage" if wl == "c4_hdr64" else "cpu"
+    is_lav2 = wl in ("c3_lav2", "c4_hdr64", "c4_2x32")
+    is2x32 = wl == "c4_2x32"
+    is_scaled = wl == "c4_scaled"
+    is64 = wl in ("c4_hdr64", "c4_2x32")  # the 2x32 inputs are derived from the HDRFloat<double> ones
+    view = inputs.View.builtin(view_id, width, height, antialiasing=None if is64 else 1)
+    orbit = inputs.Orbit(view, is64=is64)
+    la = inputs.LATable(orbit, host_threads=max(2, effective_cpus()), use_small_exponents=is2x32) if is_lav2 else None
+    orbit2 = inputs.Orbit2x32(orbit) if is2x32 else None
+    la2 = inputs.LATable2x32(la) if is2x32 else None
+    bla = inputs.BLATable(orbit) if wl == "c5_bla" else None
+    AA = view.antialiasing
+    n_iter = view.num_iterations
+    if iter_cap > 0:
+        n_iter = iter_cap
+    elif is_scaled:
+        n_iter = 65536
+    if is2x32:
+        coords_arr = view.coords_perturb_2x32(orbit2)
+        coords = [(float(c["head"]), float(c["tail"]), int(c["e"])) for c in coords_arr]
+    else:
+        coords_arr = view.coords_perturb(orbit)
+        coords = [(float(c["m"]), int(c["e"])) for c in coords_arr]
+    return {"workload": wl, "view_id": view_id, "width": width, "height": height, "parity": parity, "is_lav2": is_lav2,
+            "is2x32": is2x32, "is_scaled": is_scaled, "is64": is64, "view": view, "orbit": orbit, "la": la, "orbit2": orbit2,
+            "la2": la2, "bla": bla, "AA": AA, "W": view.width * AA, "H": view.height * AA, "n_iter": n_iter,
+            "coords_arr": coords_arr, "coords": coords,
+            "key": "view%d_%dx%d_%s" % (view_id, view.width * AA, view.height * AA, WORKLOADS[wl][3])}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,6 +171,15 @@ def parse():
     ap.add_argument("--natural-tile-order", action="store_true",
                     help="FS_VARIANT_NATURAL_TILE_ORDER: every frame in natural tile order (no self-recorded longest-first)")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="nccl (default) = RCCL: the slices go to rank 0 over xGMI on the device.  gloo = the same N-rank program "
+                         "with a HOST-STAGED exchange (slice -> page-locked host -> gloo gather -> rank 0 puts the rows in order on "
+                         "the host): the functional N > 1 path where RCCL between the ranks cannot come up -- e.g. two rank "
+                         "processes sharing one device (--share-device), which is how a one-GPU box runs the whole of main() "
+                         "with a peer.  Not a performance path: the exchange blocks the host")
+    ap.add_argument("--share-device", action="store_true",
+                    help="every rank uses device 0 (tests on a one-GPU box; needs --dist-backend gloo: RCCL refuses two ranks "
+                         "on one device)")
     ap.add_argument("--no-build", action="store_true",
                     help="never spawn a compiler (same as FS_NO_BUILD=1): required under rocprofv3, see tools/pmc_passes.sh")
     return ap.parse_args()
@@ -188,6 +239,9 @@ def main():
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    # RCCL / IPC between the ranks needs dmabuf IPC on these hosts (hipIpcGetMemHandle: invalid argument without it).  Set in
+    # EVERY rank before the runtime comes up -- a rank started by somebody else's torchrun never passes through launch_ranks
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import numpy as np
     import torch
 
@@ -209,10 +263,15 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29541")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
+        if args.share_device:
+            assert args.dist_backend == "gloo", "--share-device needs --dist-backend gloo (RCCL refuses two ranks on one device)"
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl")
+        dist.init_process_group(args.dist_backend)
     else:
         torch.cuda.set_device(0)
+    host_staged = distributed and args.dist_backend == "gloo"
+    red_device = "cpu" if host_staged else "cuda"  # where the few scalars that cross ranks live
     if rank == 0:
         if no_build:
             # under a profiler (rocprofv3 preloads a library that has initialised the GPU) no compiler may be spawned:
@@ -230,41 +289,16 @@ def main():
 
     # ---- inputs (host, outside the timed region)
     wl = args.workload
-    dview, dw, dh, wl_tag, wl_kernel = WORKLOADS[wl]
-    if args.view < 0:
-        args.view = dview
-    if args.width <= 0:
-        args.width = dw
-    if args.height <= 0:
-        args.height = dh
-    if args.parity is None:
-        args.parity = "cpu_gpustage" if wl == "c4_hdr64" else "cpu"
+    wl_tag, wl_kernel = WORKLOADS[wl][3], WORKLOADS[wl][4]
     t0 = time.time()
-    is_lav2 = wl in ("c3_lav2", "c4_hdr64", "c4_2x32")
-    is2x32 = wl == "c4_2x32"
-    is_scaled = wl == "c4_scaled"
-    is64 = wl in ("c4_hdr64", "c4_2x32")  # the 2x32 inputs are derived from the HDRFloat<double> ones
-    view = inputs.View.builtin(args.view, args.width, args.height, antialiasing=None if is64 else 1)
-    orbit = inputs.Orbit(view, is64=is64)
-    la = inputs.LATable(orbit, host_threads=effective_cpus(), use_small_exponents=is2x32) if is_lav2 else None
-    orbit2 = inputs.Orbit2x32(orbit) if is2x32 else None
-    la2 = inputs.LATable2x32(la) if is2x32 else None
-    bla = inputs.BLATable(orbit) if wl == "c5_bla" else None
+    inp = make_inputs(wl, args.view, args.width, args.height, args.iter_cap, args.parity)
     t_inputs = time.time() - t0
-    AA = view.antialiasing
-    W, H = view.width * AA, view.height * AA
-    n_iter = view.num_iterations
-    if args.iter_cap > 0:
-        n_iter = args.iter_cap
-    elif is_scaled:
-        n_iter = 65536
+    args.view, args.width, args.height, args.parity = inp["view_id"], inp["width"], inp["height"], inp["parity"]
+    is_lav2, is2x32, is_scaled, is64 = inp["is_lav2"], inp["is2x32"], inp["is_scaled"], inp["is64"]
+    view, orbit, la, orbit2, la2, bla = inp["view"], inp["orbit"], inp["la"], inp["orbit2"], inp["la2"], inp["bla"]
+    AA, W, H, n_iter = inp["AA"], inp["W"], inp["H"], inp["n_iter"]
+    coords_arr, coords = inp["coords_arr"], inp["coords"]
     parity = PARITY_CPU if args.parity == "cpu" else PARITY_CPU_GPUSTAGE
-    if is2x32:
-        coords_arr = view.coords_perturb_2x32(orbit2)
-        coords = [(float(c["head"]), float(c["tail"]), int(c["e"])) for c in coords_arr]
-    else:
-        coords_arr = view.coords_perturb(orbit)
-        coords = [(float(c["m"]), int(c["e"])) for c in coords_arr]
 
     r = GPURenderer(local_rank)
     err = r.InitializeMemory(W, H, AA, None, 0, 0, 0, False)
@@ -324,8 +358,13 @@ def main():
     local_bytes = local[0].numel() * local[0].element_size()
     host_t = [torch.zeros((rows_padded, rw), dtype=torch.int32, pin_memory=True) for _ in range(NB)] if rank == 0 else None
     host_np = [t.numpy().view(np.uint32) for t in host_t] if rank == 0 else None
-    gathered = frame_dev = frame_index = None
-    if distributed and rank == 0:
+    gathered = frame_dev = frame_index = stage = None
+    if host_staged:
+        stage = torch.zeros((local_rows, rw), dtype=torch.int32, pin_memory=True)
+        if rank == 0:
+            gathered = [torch.empty((world * local_rows, rw), dtype=torch.int32)]
+            frame_index = torch.from_numpy(tiling.reassemble_index(H, world, band))
+    elif distributed and rank == 0:
         gathered = [torch.empty((world * local_rows, rw), dtype=torch.int32, device="cuda") for _ in range(NB)]
         frame_dev = [torch.empty((H, rw), dtype=torch.int32, device="cuda") for _ in range(NB)]
         frame_index = torch.from_numpy(tiling.reassemble_index(H, world, band)).cuda()
@@ -354,6 +393,19 @@ def main():
         assert e == 0, GPURenderer.ConvertErrorToString(e)
         ev_render[b].record(render_stream)
         src = local[b]
+        if host_staged:
+            # the same exchange through host memory: wait for the kernel, slice -> page-locked host, gloo gather, rank 0 puts
+            # the rows in order straight into the frame's host buffer.  Blocking: frames do not overlap in this mode
+            ev_render[b].synchronize()
+            stage.copy_(local[b])
+            tiling.gather_slices(stage, gathered[0] if rank == 0 else None, rank, world)
+            if rank == 0:
+                torch.index_select(gathered[0], 0, frame_index, out=host_t[b][:H])
+            ev_consumed[b].record(render_stream)
+            ev_host[b].record(render_stream)
+            used[b] = True
+            state["last"] = b
+            return b
         if distributed:
             with torch.cuda.stream(post_stream):
                 post_stream.wait_event(ev_render[b])  # device-side: the gather waits for the kernel, not the host
@@ -397,7 +449,7 @@ def main():
     def max_over_ranks(x):
         if not distributed:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        t = torch.tensor([x], dtype=torch.float64, device=red_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -439,7 +491,7 @@ def main():
         r.enable_step_count(False)
         if distributed:
             keys = ("perturb_steps", "at_iterations", "la_steps")
-            t = torch.tensor([st[k] for k in keys], dtype=torch.float64, device="cuda")
+            t = torch.tensor([st[k] for k in keys], dtype=torch.float64, device=red_device)
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             st = dict(st)
             st.update({k: float(x) for k, x in zip(keys, t.tolist())})
@@ -529,18 +581,9 @@ def main():
         _oracle.lib()  # build / load outside the timed window
 
         def cpu_run(stage_test):
-            _oracle.set_row_step(step)
             t1 = time.perf_counter()
-            if is2x32:
-                ref = _oracle.gpu_lav2_2x32(view, orbit2, la2, aa=AA, rows=(y0, H), threads=threads)
-            elif is_lav2:
-                ref = _oracle.lav2_hdr32(view, orbit, la, aa=AA, rows=(y0, H), threads=threads, stage_test=stage_test)
-            elif is_scaled:
-                ref = _oracle.gpu_scaled_hdr32(view, orbit, aa=AA, rows=(y0, H), threads=threads, n_iterations=n_iter)
-            else:
-                ref = _oracle.bla_hdr32(view, orbit, bla, aa=AA, rows=(y0, H), threads=threads)
+            ref = _oracle.workload_rows(inp, y0, H, threads=threads, stage_test=stage_test, row_step=step)
             dt = time.perf_counter() - t1
-            _oracle.set_row_step(1)
             return ref, dt
 
         model, nproc = cpu_model()
@@ -630,6 +673,8 @@ def main():
                        "parity": args.parity, "kernel_variant": args.variant or "tuned", "n_iterations": n_iter, "orbit_entries": orbit.count,
                        "la_records": la.count if la else 0, "la_stages": la.stage_count if la else 0,
                        "bla_levels": bla.num_levels if bla else 0, "tiling": "rows/8-row bands interleaved x%d" % world,
+                       "exchange": ("none" if not distributed else "gloo gather through host memory (functional path)" if host_staged
+                                    else "RCCL gather to rank 0 on the device"),
                        "host_input_build_s": round(t_inputs, 3), "la_build_on_device_ms": la_device_ms},
             "roofline": {**roof,
                          "kernel": wl_kernel, "kernel_ms": round(avg_kernel_ms, 3),

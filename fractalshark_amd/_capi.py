@@ -157,6 +157,11 @@ def render_lib():
     _decl(lib, "fs_group_render_direct", u32, [vp, C.c_int, vp, u64])
     _decl(lib, "fs_group_clear", u32, [vp])
     _decl(lib, "fs_group_render_current", u32, [vp, u64, vp, vp])
+    _decl(lib, "fs_group_render_current_colors", u32, [vp, u64, vp, vp, vp, C.c_int])
+    _decl(lib, "fs_group_sync_display", u32, [vp])
+    _decl(lib, "fs_display_stream", vp, [vp])
+    _decl(lib, "fs_colorize_frame", u32, [vp, vp, u64, vp, vp, vp])
+    _decl(lib, "fs_color_buffer_elements", u64, [vp])
     _decl(lib, "fs_group_sync", u32, [vp])
     _decl(lib, "fs_group_wait_current", u32, [vp, u32])
     _decl(lib, "fs_group_gather_ms", C.c_float, [vp])
@@ -177,7 +182,8 @@ RENDER_SYMBOLS = [
     "fs_group_create", "fs_group_destroy", "fs_group_size", "fs_group_transport", "fs_group_renderer", "fs_group_init_memory",
     "fs_group_upload_orbit", "fs_group_upload_orbit_compressed", "fs_group_upload_la", "fs_group_upload_bla",
     "fs_group_upload_orbit_scaled", "fs_group_render_lav2", "fs_group_render_bla", "fs_group_render_scaled",
-    "fs_group_render_direct", "fs_group_clear", "fs_group_render_current", "fs_group_sync", "fs_group_wait_current", "fs_group_gather_ms",
+    "fs_group_render_direct", "fs_group_clear", "fs_group_render_current", "fs_group_render_current_colors", "fs_group_sync_display", "fs_display_stream", "fs_colorize_frame",
+    "fs_color_buffer_elements", "fs_group_sync", "fs_group_wait_current", "fs_group_gather_ms",
     "fs_group_plan",
 ]
 

@@ -16,6 +16,7 @@
 // RCCL is resolved at run time (dlopen "librccl.so.1"): the library has no link-time dependency on it and a one-GPU
 // host never loads it.  transport: 0 = RCCL (default for distinct devices), 1 = hipMemcpyPeerAsync (members that share
 // a device -- the one-GPU test box -- and hosts without RCCL).
+#include <cstdlib>
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
@@ -41,6 +42,12 @@ struct Rccl {
     const char *(*GetErrorString)(int) = nullptr;
     bool ok = false;
 };
+
+// RCCL's intra-node transport shares buffers between devices through IPC handles, and the hosts of this pool only support the
+// dmabuf form (hipIpcGetMemHandle: invalid argument otherwise).  The ROCm runtime reads the switch once, when it comes up
+// (the first HIP call of the process), so it is set when THIS library is loaded -- before any call of ours can be that first
+// call -- and never over a value the host application has chosen itself.
+__attribute__((constructor)) void fs_env_defaults() { (void)setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", /*overwrite=*/0); }
 
 Rccl &rccl()
 {
@@ -94,6 +101,13 @@ struct fs_group {
     hipEvent_t ev_rendered[kSets] = {}; // member 0's kernel of the frame in set b has finished (recorded on its compute stream)
     hipEvent_t ev_consumed[kSets] = {}; // k_gather_rows has read gathered[b]: its slots may be written again
     hipEvent_t ev_done[kSets] = {};     // the frame of set b is in the caller's host buffer
+    // progressive RenderCurrent (a snapshot of the frame while the members' kernels are still writing it, GPU_Render.cu:556-581
+    // with progressive = true): a third set of device-0 buffers of its own, filled on the members' DISPLAY streams, so that
+    // it neither waits for a kernel nor touches what the two frames in flight use.  Allocated by the first progressive call.
+    void *prog_gathered = nullptr, *prog_frame = nullptr;
+    fs_color16 *prog_colors = nullptr;
+    fs_reduction *prog_reduction = nullptr;
+    fs_reduction prog_seed{};
     size_t slice_bytes() const { return (size_t)max_rows * rounded_width * iter_bytes; }
 };
 
@@ -158,6 +172,9 @@ fs_group *fs_group_create(const int *devices, int n_devices, int transport)
 
 static void group_free_buffers(fs_group *g)
 {
+    if (g->prog_gathered) // a progressive snapshot may still be copying out of the slices on the display streams
+        for (fs_renderer *m : g->members)
+            (void)fs_sync_display(m);
     for (size_t i = 0; i < g->slices.size(); i++)
         if (g->slices[i] && hipSetDevice(g->devices[i]) == hipSuccess) {
             (void)fs_set_external_iter_buffer(g->members[i], nullptr, 0);
@@ -181,10 +198,19 @@ static void group_free_buffers(fs_group *g)
             (void)hipFree(g->index);
         if (g->reduction)
             (void)hipFree(g->reduction);
+        if (!g->members.empty() && fs_display_stream(g->members[0]))
+            (void)hipStreamSynchronize((hipStream_t)fs_display_stream(g->members[0]));
+        for (void *p : {g->prog_gathered, g->prog_frame, (void *)g->prog_colors, (void *)g->prog_reduction})
+            if (p)
+                (void)hipFree(p);
     }
+    g->prog_gathered = g->prog_frame = nullptr;
+    g->prog_colors = nullptr;
+    g->prog_reduction = nullptr;
     g->index = nullptr;
     g->reduction = nullptr;
     g->cur = 0;
+    g->frames_posted = 0; // (fs_group_wait_current counts back from here: no frame of the new geometry has been posted)
 }
 
 void fs_group_destroy(fs_group *g)
@@ -382,7 +408,10 @@ uint32_t fs_group_wait_current(fs_group *g, uint32_t frames_back)
 {
     if (frames_back >= (uint32_t)fs_group::kSets || frames_back >= g->frames_posted)
         return frames_back >= g->frames_posted ? 0u : (uint32_t)hipErrorInvalidValue;
-    const int b = (int)((g->frames_posted - 1 - frames_back) % fs_group::kSets);
+    // the set the frame posted `frames_back` calls ago went through, counted back from the set the NEXT frame lands in (`cur`
+    // is what fs_group_render_current itself rotates, so the two can never disagree -- also after a second
+    // fs_group_init_memory, which starts again at set 0)
+    const int b = (g->cur + 2 * fs_group::kSets - 1 - (int)frames_back) % fs_group::kSets;
     FSG_TRY(hipSetDevice(g->devices[0]));
     return (uint32_t)hipEventSynchronize(g->ev_done[b]);
 }
@@ -391,12 +420,78 @@ uint32_t fs_group_wait_current(fs_group *g, uint32_t frames_back)
 // Asynchronous: on device 0's POST stream, behind the members' kernels on the device (events, no host round trip), so the
 // members' NEXT frame can be launched right away and runs while this one is delivered (fs_group_wait_current /
 // fs_group_sync wait); iter_buffer / reduction may be NULL.
+// The progressive form: a snapshot.  Nothing here waits for a kernel: every member's slice is copied AS IT IS NOW on that
+// member's display stream (high priority, GPU_Render.cu:247-267) into a buffer set of its own on device 0, where device 0's
+// display stream puts the rows in order, colours them (member 0's palette), reduces and copies to the host.  Peer copies
+// for every transport (an RCCL exchange on a second stream of the same communicator would queue behind the frame gather).
+static uint32_t group_current_progressive(fs_group *g, uint64_t n_iterations, void *iter_buffer, fs_color16 *color_buffer,
+                                          fs_reduction *reduction)
+{
+    const uint32_t world = (uint32_t)g->members.size();
+    const size_t sb = g->slice_bytes();
+    const size_t frame_rows = ((size_t)g->height + 7u) / 8u * 8u;
+    const size_t frame_bytes = frame_rows * g->rounded_width * g->iter_bytes;
+    hipStream_t d0 = (hipStream_t)fs_display_stream(g->members[0]);
+    FSG_TRY(hipSetDevice(g->devices[0]));
+    if (!g->prog_gathered) {
+        FSG_TRY(hipMalloc(&g->prog_gathered, sb * world));
+        FSG_TRY(hipMemset(g->prog_gathered, 0, sb * world));
+        FSG_TRY(hipMalloc(&g->prog_frame, frame_bytes));
+        FSG_TRY(hipMemset(g->prog_frame, 0, frame_bytes));
+        FSG_TRY(hipMalloc((void **)&g->prog_colors, fs_color_buffer_elements(g->members[0]) * sizeof(fs_color16)));
+        FSG_TRY(hipMalloc((void **)&g->prog_reduction, sizeof(fs_reduction)));
+    }
+    // member 0 renders straight into slot 0 of the set in rotation
+    FSG_TRY(hipMemcpyAsync(g->prog_gathered, g->gathered[g->cur], sb, hipMemcpyDeviceToDevice, d0));
+    for (uint32_t r = 1; r < world; r++) {
+        hipStream_t dr = (hipStream_t)fs_display_stream(g->members[r]);
+        FSG_TRY(hipSetDevice(g->devices[r]));
+        FSG_TRY(hipMemcpyPeerAsync((char *)g->prog_gathered + sb * r, g->devices[0], g->slices[r], g->devices[r], sb, dr));
+        hipEvent_t done;
+        FSG_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+        FSG_TRY(hipEventRecord(done, dr));
+        FSG_TRY(hipSetDevice(g->devices[0]));
+        FSG_TRY(hipStreamWaitEvent(d0, done, 0));
+        FSG_TRY(hipEventDestroy(done));
+    }
+    FSG_TRY(hipSetDevice(g->devices[0]));
+    fsk_gather_rows(g->prog_gathered, g->prog_frame, g->index, g->rounded_width * g->iter_bytes, g->height, d0);
+    FSG_TRY(hipGetLastError());
+    if (color_buffer)
+        FSG_TRY(fs_colorize_frame(g->members[0], g->prog_frame, n_iterations, g->prog_colors, color_buffer, d0));
+    if (reduction) {
+        g->prog_seed = fs_reduction{g->iter_bytes == 8 ? ~0ull : 0xFFFFFFFFull, 0, 0};
+        FSG_TRY(hipMemcpyAsync(g->prog_reduction, &g->prog_seed, sizeof(fs_reduction), hipMemcpyHostToDevice, d0));
+        fsk_reduce(g->prog_frame, g->iter_bytes == 8, g->rounded_width, g->width, g->height, g->prog_reduction, d0);
+        FSG_TRY(hipGetLastError());
+        FSG_TRY(hipMemcpyAsync(reduction, g->prog_reduction, sizeof(fs_reduction), hipMemcpyDefault, d0));
+    }
+    if (iter_buffer)
+        FSG_TRY(hipMemcpyAsync(iter_buffer, g->prog_frame, frame_bytes, hipMemcpyDefault, d0));
+    return 0;
+}
+
+uint32_t fs_group_sync_display(fs_group *g)
+{
+    // the members' display streams first (their copies feed device 0's), then device 0's
+    for (size_t r = g->members.size(); r-- > 0;)
+        FSG_TRY(fs_sync_display(g->members[r]));
+    return 0;
+}
+
 uint32_t fs_group_render_current(fs_group *g, uint64_t n_iterations, void *iter_buffer, fs_reduction *reduction)
 {
-    (void)n_iterations;
+    return fs_group_render_current_colors(g, n_iterations, iter_buffer, nullptr, reduction, 0);
+}
+
+uint32_t fs_group_render_current_colors(fs_group *g, uint64_t n_iterations, void *iter_buffer, fs_color16 *color_buffer,
+                                        fs_reduction *reduction, int progressive)
+{
     const uint32_t world = (uint32_t)g->members.size();
     if (!g->gathered[0])
         return 0; // memory not initialised: silent, like GPURenderer::RenderCurrent
+    if (progressive)
+        return group_current_progressive(g, n_iterations, iter_buffer, color_buffer, reduction);
     const size_t sb = g->slice_bytes();
     const int b = g->cur;
     void *const gathered = g->gathered[b];
@@ -445,6 +540,10 @@ uint32_t fs_group_render_current(fs_group *g, uint64_t n_iterations, void *iter_
     FSG_TRY(hipGetLastError());
     FSG_TRY(hipEventRecord(g->ev_consumed[b], p0)); // this set's gather slots may be written again
     FSG_TRY(hipEventRecord(g->ev_b, p0));
+    // colours of the whole frame (antialias + palette) on device 0, behind the row order: member 0 holds the palette and the
+    // whole-frame geometry; frames in flight share its colour buffer one after the other (one post stream)
+    if (color_buffer)
+        FSG_TRY(fs_colorize_frame(g->members[0], frame, n_iterations, nullptr, color_buffer, p0));
     if (reduction) {
         g->reduce_seed = fs_reduction{g->iter_bytes == 8 ? ~0ull : 0xFFFFFFFFull, 0, 0};
         FSG_TRY(hipMemcpyAsync(g->reduction, &g->reduce_seed, sizeof(fs_reduction), hipMemcpyHostToDevice, p0));

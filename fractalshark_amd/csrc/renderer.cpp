@@ -419,6 +419,14 @@ constexpr uint32_t kTileOrderMinTiles = 4096;
 // the same for the self-recorded order of the tuned LAv2 kernel: below this many tiles the chip is not full anyway
 constexpr uint32_t kLav2OrderMinTiles = 2048;
 
+// float4 units of the tuned loops' companion arrays of an n-entry HDRFloat<float> orbit (make_quiet_orbit lays them out;
+// fs_orbit_device_bytes reports them)
+constexpr uint64_t kQuietSlack = 32;
+constexpr uint64_t quiet_orbit_units(uint64_t n)
+{
+    return 2 * (n + 2) + 16 + ((n + 2) + kQuietSlack + 1) / 2 + ((n + 2) + kQuietSlack);
+}
+
 // zq: the tuned LAv2 loop's view of the prepared orbit (same length incl. the two spare entries)
 hipError_t make_quiet_orbit(fs_renderer *r, uint64_t n)
 {
@@ -431,8 +439,8 @@ hipError_t make_quiet_orbit(fs_renderer *r, uint64_t n)
     // ... followed by the compact form the 16-step body of the untested loop reads: 2Z alone (8 B per entry) and, per entry, the
     // block bounds of the entries 3, 7, 11 and 15 further on (16 B); 32 entries of slack each (the body after the last is
     // requested ahead, never used)
-    const uint64_t m = n + 2, slack = 32;
-    const uint64_t units = 2 * m + 16 + (m + slack + 1) / 2 + (m + slack);
+    const uint64_t m = n + 2, slack = kQuietSlack;
+    const uint64_t units = quiet_orbit_units(n);
     hipError_t err = r_alloc(r, (void **)&r->zq, units * sizeof(float4), kInput);
     if (err != hipSuccess)
         return err;
@@ -1821,6 +1829,8 @@ template <class F> uint32_t build_la(fs_renderer *r, const void *max_radius, int
         pack_at<F>(at, r);
     r->la_type = sizeof(F) == 4 ? FS_T_HDR32 : FS_T_HDR64;
     r->la_gen = 0;
+    r->la_u64 = false; // the table just installed has uint32 fields, whatever an earlier fs_upload_la left behind
+    r->at_step_hi = 0;
     r->la_ok = true;
     return 0;
 }
@@ -2004,7 +2014,9 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
         A.n_iterations = (uint32_t)n_iterations;
         A.n_iterations_hi = (uint32_t)(n_iterations >> 32);
         A.frame.wide |= A.n_iterations_hi != 0u ? 1u : 0u;
-        r->last_launch_wide = A.frame.wide != 0u;
+        // (the waypoint-resident instantiations are built without the step counters too: fs_read_step_count must refuse, not
+        // report zeros)
+        r->last_launch_wide = A.frame.wide != 0u || r->orbit_seq;
         A.la_valid = (r->la_ok && r->la_type == type_tag) ? r->la_valid : 0;
         A.use_at = r->use_at;
         if (r->orbit_seq) { // waypoint-resident orbit: a cursor per pixel (k_lav2_plain<.., kSeq>)
@@ -2040,7 +2052,7 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
         A.n_iterations = (uint32_t)n_iterations;
         A.n_iterations_hi = (uint32_t)(n_iterations >> 32);
         A.frame.wide |= A.n_iterations_hi != 0u ? 1u : 0u;
-        r->last_launch_wide = A.frame.wide != 0u;
+        r->last_launch_wide = A.frame.wide != 0u || r->orbit_seq; // (kSeq: no counters either)
         A.la_valid = (r->la_ok && r->la_type == type_tag) ? r->la_valid : 0;
         A.use_at = r->use_at;
         if (r->orbit_seq) { // waypoint-resident orbit: a cursor per pixel (k_lav2_2x32<.., kSeq>)
@@ -2570,6 +2582,29 @@ uint32_t fs_sync_compute(fs_renderer *r)
 }
 
 void *fs_compute_stream(const fs_renderer *r) { return (void *)r->compute; }
+void *fs_display_stream(const fs_renderer *r) { return (void *)r->display; }
+
+// RunAntialiasing (GPU_Render.cu:1695-1757) over a whole frame that lies somewhere else on this renderer's device (the frame
+// an fs_group has put back in row order), with this renderer's palette and geometry, on the caller's stream.
+uint32_t fs_colorize_frame(fs_renderer *r, const void *device_iters, uint64_t n_iterations, fs_color16 *device_colors,
+                           fs_color16 *color_buffer, void *stream)
+{
+    if (uint32_t e = use_device(r))
+        return e;
+    if (!r->memory_initialized() || !device_iters)
+        return 0;
+    if (!r->pal)
+        return 0; // no palette was ever uploaded: RenderCurrent leaves the colour buffer alone
+    hipStream_t s = (hipStream_t)stream;
+    fs_color16 *dst = device_colors ? device_colors : r->colors;
+    fsk_antialias(device_iters, r->iter_bytes == 8, r->w_block * 16u, dst, r->pal, r->pal_iters, r->pal_aux_depth, r->aa,
+                  r->color_w, r->color_h, n_iterations, s);
+    FS_TRY(hipGetLastError());
+    if (color_buffer)
+        FS_TRY(hipMemcpyAsync(color_buffer, dst, r->n_color_cu * sizeof(fs_color16), hipMemcpyDefault, s));
+    return 0;
+}
+uint64_t fs_color_buffer_elements(const fs_renderer *r) { return r->n_color_cu; }
 
 uint32_t fs_sync_display(fs_renderer *r)
 {
@@ -2654,7 +2689,7 @@ uint64_t fs_orbit_device_bytes(const fs_renderer *r)
     }
     switch (r->orbit_type) {
         case FS_T_HDR32: // prepared entries + the two companion arrays of the tuned loops
-            return (n + 2) * sizeof(float4) + (2 * (n + 2) + 16) * sizeof(float4);
+            return (n + 2) * sizeof(float4) + quiet_orbit_units(n) * sizeof(float4);
         case FS_T_HDR64:
             return (n + 2) * sizeof(FsZ64);
         case FS_T_F64:

@@ -1187,11 +1187,18 @@ bool load_im_orbit(FILE *f, uint64_t reference_offset, Orb &ob, uint64_t file_it
         w.rebase.push_back((uint8_t)(field >> 63));
     }
     uint64_t r = 0;
-    if (fread(&r, 8, 1, f) != 1 || r > (1ull << 32))
+    // every rebase is an orbit position, so a file that announces more of them than the (already bounded) orbit has entries
+    // is not one CompressMax wrote -- refused BEFORE anything is allocated for it; the list itself is read in chunks, so the
+    // memory that gets touched follows the bytes that are really there
+    if (fread(&r, 8, 1, f) != 1 || r > ref_it + 1)
         return false;
-    w.rebases.resize(r);
-    if (r && fread(w.rebases.data(), 8, r, f) != r)
-        return false;
+    for (uint64_t done = 0; done < r;) {
+        const uint64_t chunk = std::min<uint64_t>(r - done, 1u << 16);
+        w.rebases.resize(done + chunk);
+        if (fread(w.rebases.data() + done, 8, chunk, f) != chunk)
+            return false;
+        done += chunk;
+    }
     // the reader's terminators (:2208-2210): {{}, {}, ~0ull, false} and ~0ull
     w.x.push_back(mk<F>::zero()), w.y.push_back(mk<F>::zero()), w.index.push_back(0x7FFFFFFFFFFFFFFFull), w.rebase.push_back(0);
     w.rebases.push_back(~0ull);

@@ -456,16 +456,34 @@ class GPURendererGroup:
         co = GPURenderer._pack_coords(T, [dx, dy, centerX, centerY])
         return self._lib.fs_group_render_bla(self._h, T, co.ctypes.data, int(n_iterations))
 
+    def Render(self, cx, cy, dx, dy, n_iterations, T=T_F64):
+        """Direct kernels over the row-tiled frame (GPURenderer.Render: cx = minX, cy = maxY)."""
+        co = np.array([dx, dy, cx, cy], dtype=np.float64) if T == T_F64 else GPURenderer._pack_coords(T, [dx, dy, cx, cy])
+        return self._lib.fs_group_render_direct(self._h, T, co.ctypes.data, int(n_iterations))
+
     def ClearMemory(self):
         return self._lib.fs_group_clear(self._h)
 
-    def RenderCurrent(self, n_iterations, iter_buffer=None, reduction_results=None):
+    def RenderCurrent(self, n_iterations, iter_buffer=None, reduction_results=None, color_buffer=None, progressive=False):
+        """GPURenderer::RenderCurrent(n, iters, colors, reduction, progressive) for the row-tiled frame.  progressive: a
+        snapshot on the display streams (SyncDisplay waits for it)."""
         ip = iter_buffer.ctypes.data if iter_buffer is not None else None
         rp = C.addressof(reduction_results) if reduction_results is not None else None
-        return self._lib.fs_group_render_current(self._h, int(n_iterations), ip, rp)
+        cp = color_buffer.ctypes.data if color_buffer is not None else None
+        if cp is None and not progressive:
+            return self._lib.fs_group_render_current(self._h, int(n_iterations), ip, rp)
+        return self._lib.fs_group_render_current_colors(self._h, int(n_iterations), ip, cp, rp, 1 if progressive else 0)
+
+    def new_color_buffer(self):
+        """uint16[N_color_cu, 4]: the Color16 buffer RenderCurrent fills (padded to 16 x 8 blocks of colour pixels)."""
+        n = self._lib.fs_color_buffer_elements(self._lib.fs_group_renderer(self._h, 0))
+        return np.zeros((int(n), 4), np.uint16)
 
     def Sync(self):
         return self._lib.fs_group_sync(self._h)
+
+    def SyncDisplay(self):
+        return self._lib.fs_group_sync_display(self._h)
 
     def WaitCurrent(self, frames_back=0):
         """Host waits for the RenderCurrent issued `frames_back` calls ago (0 = latest, 1 = the one before): two frames may

@@ -235,6 +235,15 @@ uint32_t fs_clear(fs_renderer *r);
 uint32_t fs_render_current(fs_renderer *r, uint64_t n_iterations, void *iter_buffer, fs_color16 *color_buffer,
                            fs_reduction *reduction, int progressive);
 
+/* RenderCurrent's colour half (RunAntialiasing, GPU_Render.cu:1695-1757) over a whole frame that lies elsewhere on the
+ * renderer's device -- the frame an fs_group has gathered and put back in row order: antialias + palette with this renderer's
+ * palette and geometry into device_colors (NULL = the renderer's own colour buffer), then, if color_buffer is not NULL, the
+ * copy of N_color_cu Color16 to the host, all on `stream` (a hipStream_t of that device).  fs_color_buffer_elements =
+ * N_color_cu, the element count of a colour buffer (padded to 16 x 8 blocks like the reference's). */
+uint32_t fs_colorize_frame(fs_renderer *r, const void *device_iters, uint64_t n_iterations, fs_color16 *device_colors,
+                           fs_color16 *color_buffer, void *stream);
+uint64_t fs_color_buffer_elements(const fs_renderer *r);
+
 /* SyncComputeStream / SyncDisplayStream / QueryComputeStream / EnqueueComputeDoneCallback
  * (GPU_Render.cu:596-615).  The callback runs on a runtime thread after all prior compute-stream work. */
 uint32_t fs_sync_compute(fs_renderer *r);
@@ -243,6 +252,8 @@ uint32_t fs_sync_display(fs_renderer *r);
  * host that chains its own device work behind a render without a host round trip (the multi-GPU gather of bench.py waits
  * on it from its own stream).  Owned by the renderer. */
 void *fs_compute_stream(const fs_renderer *r);
+/* The display stream (GPURenderer::m_DisplayStream: high priority, where a progressive RenderCurrent runs). */
+void *fs_display_stream(const fs_renderer *r);
 uint32_t fs_query_compute(fs_renderer *r);
 typedef void (*fs_done_cb)(void *user);
 uint32_t fs_enqueue_done_callback(fs_renderer *r, fs_done_cb cb, void *user);
@@ -344,7 +355,7 @@ uint32_t fs_time_render_current(fs_renderer *r, uint64_t n_iterations, uint32_t 
  * Every fs_group_* upload / render call is the fs_* call of the same name applied to every member; renders are
  * asynchronous.  fs_group_render_current = gather + row reassembly + min / max / sum + D2H of the padded iteration buffer
  * (same layout as fs_render_current of a single renderer on the whole frame), asynchronous on member 0's compute stream;
- * fs_group_sync waits for everything.  Colour output stays per renderer (fs_group_renderer + fs_render_current). */
+ * fs_group_sync waits for everything.  Colours of the whole frame: fs_group_render_current_colors. */
 typedef struct fs_group fs_group;
 fs_group *fs_group_create(const int *devices, int n_devices, int transport);
 void fs_group_destroy(fs_group *g);
@@ -372,6 +383,16 @@ uint32_t fs_group_render_scaled(fs_group *g, int type_tag, const void *coords, u
 uint32_t fs_group_render_direct(fs_group *g, int type_tag, const void *coords, uint64_t n_iterations);
 uint32_t fs_group_clear(fs_group *g);
 uint32_t fs_group_render_current(fs_group *g, uint64_t n_iterations, void *iter_buffer, fs_reduction *reduction);
+/* GPURenderer::RenderCurrent<IterType>(n, iters, colors, reduction, progressive) (GPU_Render.cu:556-581) for the group: as
+ * fs_group_render_current, plus the Color16 buffer of the whole frame (antialias + palette on device 0 behind the row order,
+ * N_color_cu = fs_color_buffer_elements(fs_group_renderer(g, 0)) elements, same layout as fs_render_current's).  Any of the
+ * three host pointers may be NULL.  progressive != 0: a SNAPSHOT of the frame while the members' kernels are still writing it
+ * -- nothing waits for a kernel; the slices are copied as they are on the members' display streams into buffers of their own
+ * (it does not take part in the two-set rotation and does not count for fs_group_wait_current); fs_group_sync_display waits
+ * for it. */
+uint32_t fs_group_render_current_colors(fs_group *g, uint64_t n_iterations, void *iter_buffer, fs_color16 *color_buffer,
+                                        fs_reduction *reduction, int progressive);
+uint32_t fs_group_sync_display(fs_group *g);
 uint32_t fs_group_sync(fs_group *g);
 /* Two frames may be in flight: fs_group_render_current runs on a stream of its own on device 0 (receive, row order,
  * reduction, D2H) behind the members' kernels, over one of TWO sets of gather / frame buffers used in rotation, so the

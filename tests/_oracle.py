@@ -101,6 +101,27 @@ def set_row_step(step):
     lib().orc_set_row_step(step)
 
 
+def workload_rows(inp, y0, y1, threads=8, stage_test=None, row_step=1):
+    """Rows y0, y0 + row_step, ... < y1 of a bench workload's frame (inp = bench.make_inputs(...)) as the oracle renders them:
+    the ONE dispatch from workload to oracle function, shared by bench.py's cpu_baseline leg and
+    tests/golden/make_frame_crcs.py.  stage_test None follows inp["parity"] (cpu = 0: the literal CPU function)."""
+    if stage_test is None:
+        stage_test = 0 if inp["parity"] == "cpu" else 1
+    view, orbit, aa, n = inp["view"], inp["orbit"], inp["AA"], inp["n_iter"]
+    set_row_step(row_step)
+    try:
+        if inp["is2x32"]:
+            return gpu_lav2_2x32(view, inp["orbit2"], inp["la2"], aa=aa, rows=(y0, y1), threads=threads, n_iterations=n)
+        if inp["is_lav2"]:
+            return lav2_hdr32(view, orbit, inp["la"], aa=aa, rows=(y0, y1), threads=threads, stage_test=stage_test,
+                              n_iterations=n)
+        if inp["is_scaled"]:
+            return gpu_scaled_hdr32(view, orbit, aa=aa, rows=(y0, y1), threads=threads, n_iterations=n)
+        return bla_hdr32(view, orbit, inp["bla"], aa=aa, rows=(y0, y1), threads=threads, n_iterations=n)
+    finally:
+        set_row_step(1)
+
+
 def pin_lib():
     global _pin
     if _pin is None:

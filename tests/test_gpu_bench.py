@@ -69,3 +69,19 @@ def test_two_ranks_over_nccl(single):
     assert d["frame_checksum"] == single["frame_checksum"]
     assert d["cpu_sample_rows_bit_exact"] is True
     assert d["roofline"]["pixel_steps_per_launch"] == single["roofline"]["pixel_steps_per_launch"]
+
+
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_rank_processes_sharing_the_device_run_the_whole_of_main(single, ranks):
+    """Real rank PROCESSES through the whole of bench.py's main() on a one-GPU box: `--gpus N --dist-backend gloo --share-device`
+    starts N torchrun ranks that all use device 0 and exchange their slices through host memory (RCCL refuses two ranks on one
+    device) -- the barriers, the max over ranks, the all-reduced step counts, rank-0-only buffers and the row-band arithmetic
+    all run with a peer.  The line must carry the one-GPU frame (checksum), the oracle's rows and the summed step counts."""
+    d = _run(["--gpus", str(ranks), "--dist-backend", "gloo", "--share-device"], timeout=1500)
+    assert d["n_gpus"] == ranks
+    assert d["config"]["exchange"].startswith("gloo")
+    assert d["frame_checksum"] == single["frame_checksum"]
+    assert d["cpu_sample_rows_bit_exact"] is True
+    assert d["cpu_baseline"] is None
+    assert d["roofline"]["pixel_steps_per_launch"] == single["roofline"]["pixel_steps_per_launch"]
+    assert d["roofline"]["at_iterations_per_launch"] == single["roofline"]["at_iterations_per_launch"]

@@ -177,3 +177,153 @@ def test_group_over_distinct_devices(native_libs, transport):
         assert np.array_equal(out, refs[k % 2]), (transport, k)
     assert g.gather_ms() >= 0.0
     g.close()
+
+
+# ---- RenderCurrent's colour half and its progressive form through the group (GPU_Render.cu:556-581, 1695-1805)
+def _group_golden(world, name):
+    import golden_cases as gc
+    import _oracle
+    from fractalshark_amd import T_F64, T_HDR32
+    case = [c for c in gc.CASES if c[0] == name][0]
+    _, view_n, alg, aa, crc64 = case
+    v, ob, table = gc.build_inputs(inputs, view_n, alg, aa)
+    pal = _oracle.default_palette(8)
+    g = GPURendererGroup([0] * world)
+    assert g.InitializeMemory(gc.W * aa, gc.H * aa, aa, pal, len(pal), 0, 1) == 0
+    n = v.num_iterations
+    if alg == "Cpu64":
+        dx, dy, minx, maxy = v.coords_direct_f64(aa)
+
+        def render():
+            return g.Render(minx, maxy, dx, dy, n, T=T_F64)
+    elif "V2" in alg:
+        assert g.InitializePerturb(1, ob, table) == 0
+        co = _pairs(v.coords_perturb(ob))
+
+        def render():
+            return g.RenderPerturbLAv2(*co, n, T=T_HDR32, Mode=LAV2_FULL, parity=PARITY_CPU)
+    else:
+        assert g.InitializePerturb(0, ob, None) == 0
+        assert g.UploadBLA(table) == 0
+        co = _pairs(v.coords_perturb(ob))
+
+        def render():
+            return g.RenderPerturbBLA(*co, n)
+    return g, render, v, aa, crc64, gc
+
+
+@pytest.mark.parametrize("name", ["view5-cpu-bla-v2", "view5-cpu32-bla-hdr", "view0-cpu64-aa4"])
+def test_group_colours_reproduce_the_reference_golden_crc(native_libs, name):
+    """Three members row-tile a golden case; fs_group_render_current_colors returns the iteration buffer AND the Color16
+    buffer of the whole frame (antialias + palette on device 0 behind the row order).  Both must encode, through the
+    reference's own PNG writer, to the CRC-64 literal of FractalSharkTest/TestRenderGoldens.cpp:84-97 (AA 4: bands of 8 rows
+    never split an antialiasing group)."""
+    import json
+    import os
+    import _oracle
+    g, render, v, aa, crc64, gc = _group_golden(3, name)
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden_crc.json")))[name]
+    try:
+        for _ in range(2):  # twice: the second frame goes through the other buffer set
+            assert g.ClearMemory() == 0
+            assert render() == 0
+            it = g.new_iter_buffer()
+            colors = g.new_color_buffer()
+            assert len(colors) == gc.W * gc.H
+            red = _capi.Reduction()
+            assert g.RenderCurrent(v.num_iterations, it, red, color_buffer=colors) == 0
+            assert g.Sync() == 0
+            assert gc.buffer_crc32(it) == gold["iter_buffer_crc32"]
+            assert red.Sum == gold["iter_sum"]
+            assert _oracle.pin_lib() is not None
+            assert _oracle.png_crc64(it, gc.W, gc.H, aa, v.num_iterations) == crc64
+            assert _oracle.png_crc64_rgba16(colors.reshape(gc.H, gc.W, 4), gc.W, gc.H) == crc64
+    finally:
+        g.close()
+
+
+def test_group_progressive_snapshot(native_libs):
+    """progressive = true: a snapshot on the display streams that waits for no kernel and leaves the two frames in flight alone.
+    (1) taken after the frame has finished it IS the frame, colours included; (2) taken while a long frame is being rendered it
+    returns at once with a mixture of finished pixels and zeros, and the frame that was in flight is still delivered complete."""
+    import _oracle
+    g, render, v, aa, crc64, gc = _group_golden(3, "view5-cpu-bla-v2")
+    try:
+        assert g.ClearMemory() == 0
+        assert render() == 0
+        it = g.new_iter_buffer()
+        assert g.RenderCurrent(v.num_iterations, it) == 0
+        assert g.Sync() == 0
+        # (1) a snapshot of the finished frame.  After RenderCurrent member 0 renders into the OTHER set: render the frame
+        # again so that every member's current buffer holds it
+        assert render() == 0
+        assert g.Sync() == 0
+        snap, colors, red = g.new_iter_buffer(), g.new_color_buffer(), _capi.Reduction()
+        assert g.RenderCurrent(v.num_iterations, snap, red, color_buffer=colors, progressive=True) == 0
+        assert g.SyncDisplay() == 0
+        assert np.array_equal(snap, it)
+        assert red.Sum == int(it[:gc.H, :gc.W].astype(np.uint64).sum())
+        assert _oracle.png_crc64_rgba16(colors.reshape(gc.H, gc.W, 4), gc.W, gc.H) == crc64
+        assert g.WaitCurrent(0) == 0  # the snapshot did not count as a posted frame: still the first RenderCurrent
+    finally:
+        g.close()
+    # (2) in flight: a frame that takes long enough to be caught half way
+    w, h = 1920, 1080
+    v2 = inputs.View.builtin(5, w, h)
+    ob = inputs.Orbit(v2)
+    la = inputs.LATable(ob)
+    co = _pairs(v2.coords_perturb_hdr32(ob))
+    g = GPURendererGroup([0] * 3)
+    try:
+        assert g.InitializeMemory(w, h, 1) == 0
+        assert g.InitializePerturb(1, ob, la) == 0
+        assert g.ClearMemory() == 0
+        assert g.Sync() == 0
+        assert g.RenderPerturbLAv2(*co, v2.num_iterations, Mode=LAV2_FULL, parity=PARITY_CPU) == 0
+        full = g.new_iter_buffer()
+        snap = g.new_iter_buffer()
+        assert g.RenderCurrent(v2.num_iterations, snap, progressive=True) == 0
+        assert g.SyncDisplay() == 0
+        assert g.RenderCurrent(v2.num_iterations, full) == 0
+        assert g.Sync() == 0
+        done = snap[:h, :w] != 0
+        assert (full[:h, :w] != 0).all()
+        assert np.array_equal(snap[:h, :w][done], full[:h, :w][done])  # what the snapshot holds are final counts
+        assert not done.all(), "the snapshot waited for the kernels"
+    finally:
+        g.close()
+
+
+def test_group_reinitialised_after_an_odd_number_of_frames(native_libs):
+    """A second InitializeMemory (a resize) after ONE RenderCurrent: the buffer-set rotation starts again at set 0, and
+    fs_group_wait_current must wait on the set the frames of the new geometry actually go through (it used to count posted
+    frames across the re-initialisation and wait on the other set's never-recorded event)."""
+    v = inputs.View.builtin(5, 320, 180)
+    ob = inputs.Orbit(v)
+    la = inputs.LATable(ob)
+    co = _pairs(v.coords_perturb_hdr32(ob))
+    refs = _single_frames(v, ob, la, [PARITY_CPU, PARITY_CPU_GPUSTAGE])
+    g = GPURendererGroup([0] * 3)
+    try:
+        assert g.InitializeMemory(64, 36, 1) == 0
+        v0 = inputs.View.builtin(5, 64, 36)
+        ob0 = inputs.Orbit(v0)
+        assert g.InitializePerturb(1, ob0, inputs.LATable(ob0)) == 0
+        assert g.RenderPerturbLAv2(*_pairs(v0.coords_perturb_hdr32(ob0)), v0.num_iterations, Mode=LAV2_FULL, parity=PARITY_CPU) == 0
+        assert g.RenderCurrent(v0.num_iterations, g.new_iter_buffer()) == 0  # ONE frame: an odd count
+        assert g.Sync() == 0
+        assert g.InitializeMemory(320, 180, 1) == 0
+        assert g.WaitCurrent(0) == 0  # nothing of the new geometry posted yet
+        assert g.InitializePerturb(2, ob, la) == 0
+        host = [g.new_iter_buffer() for _ in range(2)]
+        order = [PARITY_CPU, PARITY_CPU_GPUSTAGE] * 3
+        for k, parity in enumerate(order):
+            assert g.RenderPerturbLAv2(*co, v.num_iterations, Mode=LAV2_FULL, parity=parity) == 0
+            assert g.RenderCurrent(v.num_iterations, host[k % 2]) == 0
+            assert g.WaitCurrent(1) == 0
+            if k >= 1:
+                assert np.array_equal(host[(k - 1) % 2], refs[(k - 1) % 2]), k - 1
+        assert g.WaitCurrent(0) == 0
+        assert np.array_equal(host[(len(order) - 1) % 2], refs[(len(order) - 1) % 2])
+    finally:
+        g.close()

@@ -167,6 +167,13 @@ def test_corrupt_or_crafted_orbit_sections_are_refused_not_fatal(tmp_path, is64)
     refused("wp_not_increasing", lambda b: b.__setitem__(slice(wp0 + 40 + 32, wp0 + 80), b[wp0 + 32:wp0 + 40]))
     refused("wp_past_orbit", lambda b: b.__setitem__(slice(wp0 + 32, wp0 + 40), struct.pack("<Q", info["ref_it"] + 5)))
     refused("exp_beyond_int32", lambda b: b.__setitem__(slice(wp0 + 8, wp0 + 16), struct.pack("<q", 2 ** 40)))
+    # the rebase count (8 bytes behind the last waypoint) sizes a vector too: 2^32 of them (32 GiB, zero-filled) used to be
+    # allocated before the short read was noticed; more rebases than orbit entries is refused before any allocation
+    reb_at = wp0 + 40 * len(info["waypoints"])
+    assert struct.unpack("<Q", raw[reb_at:reb_at + 8])[0] == len(info["rebases"])
+    refused("rebases_2_32", lambda b: b.__setitem__(slice(reb_at, reb_at + 8), struct.pack("<Q", 2 ** 32)))
+    refused("rebases_past_orbit", lambda b: b.__setitem__(slice(reb_at, reb_at + 8), struct.pack("<Q", info["ref_it"] + 2)))
+    refused("rebases_short_read", lambda b: b.__setitem__(slice(reb_at, reb_at + 8), struct.pack("<Q", len(info["rebases"]) + 3)))
     q = inputs.Orbit.load_im(p, v)
     assert q.count == o.count
 

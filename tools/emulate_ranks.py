@@ -1,63 +1,106 @@
-"""Per-rank kernel time at N GPUs, measured on one GPU: renders each rank's interleaved row bands (fs_set_row_bands)
-of the C3 frame in turn.  max over ranks = the kernel part of the N-GPU frame time.
-Usage: python tools/emulate_ranks.py [--world 8] [--parity cpu|cpu_gpustage]"""
+"""Per-rank kernel time at N GPUs, measured on ONE GPU: renders each rank's interleaved row bands (fs_set_row_bands) of a bench
+workload's frame in turn, every rank alone on the device as it would be on its own GPU.  max over ranks = the kernel part of
+the N-GPU frame time; next to it the bytes the gather moves to rank 0 and what they cost at a STATED xGMI rate (one link per
+peer into GPU 0: the slices arrive in parallel, so the gather time is one slice / one link).
+
+  python tools/emulate_ranks.py [--workload c3_lav2|c2_po|c5_bla|c4_hdr64|c4_2x32|c4_scaled] [--worlds 2,4,8] [--repeats 4]
+
+One JSON line per (tile order, world).  Per rank: median and max of the repeats (the minimum is kept for continuity with round
+4's lines, which reported it)."""
 import argparse
 import json
 import os
+import statistics
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from fractalshark_amd import (GPURenderer, LAV2_FULL, PARITY_CPU, PARITY_CPU_GPUSTAGE, T_HDR32, inputs, tiling)  # noqa: E402
+import bench  # noqa: E402
+from fractalshark_amd import (GPURenderer, LAV2_FULL, PARITY_CPU, PARITY_CPU_GPUSTAGE, T_HDR2X32, T_HDR32, T_HDR64, tiling)  # noqa: E402
+
+XGMI_LINK_GBS = 64.0  # ASSUMED, not measured (no 2-GPU box this round): one xGMI link, one direction, sustained; the link peak is
+                      # ~153 GB/s for both directions together, i.e. ~76 GB/s one way
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--world", type=int, default=8)
-    ap.add_argument("--parity", default="cpu")
+    ap.add_argument("--workload", default="c3_lav2", choices=sorted(bench.WORKLOADS))
+    ap.add_argument("--worlds", default="8")
+    ap.add_argument("--world", type=int, default=0, help="(round-4 spelling of --worlds N)")
+    ap.add_argument("--parity", default=None)
     ap.add_argument("--band", type=int, default=0)
     ap.add_argument("--tile-order", choices=["natural", "warm", "both"], default="both",
                     help="natural: FS_VARIANT_NATURAL_TILE_ORDER (every frame cold); warm: a rank's launches after its first "
-                         "run longest tiles first from the costs the previous one recorded")
-    ap.add_argument("--repeats", type=int, default=4,
-                    help="launches per rank; the minimum is reported (kernel time on an otherwise idle GPU: run-to-run "
-                         "differences of +-3 %% between identical launches are clock / placement noise, and on a real "
-                         "8-GPU node every rank runs alone on its own GPU)")
+                         "run longest tiles first from the costs the previous one recorded (kernels that record an order)")
+    ap.add_argument("--repeats", type=int, default=4)
     a = ap.parse_args()
-    v = inputs.View.builtin(5, 3840, 2160, antialiasing=1)
-    o = inputs.Orbit(v)
-    la = inputs.LATable(o, host_threads=16)
-    co = [(float(c["m"]), int(c["e"])) for c in v.coords_perturb(o)]
-    parity = PARITY_CPU if a.parity == "cpu" else PARITY_CPU_GPUSTAGE
+    worlds = [a.world] if a.world else [int(x) for x in a.worlds.split(",") if x]
+    inp = bench.make_inputs(a.workload, parity=a.parity)
+    W, H, AA, n_iter = inp["W"], inp["H"], inp["AA"], inp["n_iter"]
+    parity = PARITY_CPU if inp["parity"] == "cpu" else PARITY_CPU_GPUSTAGE
+    T = T_HDR2X32 if inp["is2x32"] else (T_HDR64 if inp["is64"] else T_HDR32)
+    orbit, la = inp["orbit"], inp["la"]
     r = GPURenderer(0)
-    assert r.InitializeMemory(3840, 2160, 1, None, 0, 0, 0, False) == 0
-    assert r.InitializePerturb(1, o, 0, None, la) == 0
-    band = a.band or tiling.band_height(1)
+    lib = r._lib
+    assert r.InitializeMemory(W, H, AA, None, 0, 0, 0, False) == 0
+    if inp["is2x32"]:
+        assert r.InitializePerturb(1, inp["orbit2"], 0, None, inp["la2"]) == 0
+    elif inp["is_lav2"]:
+        assert r.InitializePerturb(1, orbit, 0, None, la) == 0
+    elif inp["is_scaled"]:
+        assert lib.fs_upload_orbit_scaled(r._h, T_HDR32, 4, orbit.bad_data_ptr, orbit.bad_f32_data_ptr, orbit.count, orbit.period) == 0
+    else:
+        assert lib.fs_upload_orbit(r._h, 1, T_HDR32, 4, orbit.data_ptr, orbit.count, orbit.count, orbit.period) == 0
+        bla = inp["bla"]
+        if bla is not None:
+            assert lib.fs_upload_bla(r._h, T_HDR32, bla.level_ptrs, bla.level_sizes, bla.num_levels, bla.lm2) == 0
+        else:
+            assert lib.fs_upload_bla(r._h, T_HDR32, None, None, 0, 0) == 0
+    coords, coords_arr = inp["coords"], inp["coords_arr"]
+
+    def render():
+        if inp["is_lav2"]:
+            e = r.RenderPerturbLAv2(None, None, None, *coords, n_iter, T=T, Mode=LAV2_FULL, parity=parity)
+        elif inp["is_scaled"]:
+            e = lib.fs_render_scaled(r._h, T_HDR32, coords_arr.ctypes.data, n_iter)
+        else:
+            e = lib.fs_render_bla(r._h, T_HDR32, coords_arr.ctypes.data, n_iter)
+        assert e == 0, GPURenderer.ConvertErrorToString(e)
+        assert r.SyncComputeStream() == 0
+        return r.last_kernel_ms()
+
+    band = a.band or tiling.band_height(AA)
+    rw = r.rounded_width
     for order in (["natural", "warm"] if a.tile_order == "both" else [a.tile_order]):
         assert r.set_kernel_variant(0, natural_tile_order=(order == "natural")) == 0
-        for world in sorted({1, a.world}):
-            times = []
-            spreads = []
+        for world in sorted({1, *worlds}):
+            med, mx, mn = [], [], []
+            ordered = None
             for rank in range(world):
                 assert r.SetRowBands(rank * band, band, world * band) == 0
-                best = 1e9
                 samples = []
                 for i in range(max(1, a.repeats) + (1 if order == "warm" else 0)):
-                    assert r.RenderPerturbLAv2(None, None, None, *co, v.num_iterations, T=T_HDR32, Mode=LAV2_FULL,
-                                               parity=parity) == 0
-                    assert r.SyncComputeStream() == 0
+                    ms = render()
                     if order == "warm" and i == 0:
-                        continue  # the frame that records the costs
-                    assert r.last_frame_tile_ordered() == (order == "warm")
-                    samples.append(r.last_kernel_ms())
-                    best = min(best, samples[-1])
-                times.append(round(best, 3))
-                spreads.append(round(max(samples) - min(samples), 3))
-            print(json.dumps({"world": world, "tile_order": order, "band_rows": band, "parity": a.parity,
-                              "kernel_ms_per_rank": times, "max_ms": max(times), "mean_ms": round(sum(times) / len(times), 3),
-                              "sum_ms": round(sum(times), 3), "repeats": a.repeats,
-                              "max_spread_between_repeats_ms": max(spreads)}), flush=True)
+                        continue  # the frame that records the costs (or runs the probe)
+                    samples.append(ms)
+                ordered = bool(r.last_frame_tile_ordered())
+                med.append(round(statistics.median(samples), 3))
+                mx.append(round(max(samples), 3))
+                mn.append(round(min(samples), 3))
+            slice_bytes = tiling.max_local_rows(H, world, band) * rw * 4
+            gather_bytes = slice_bytes * (world - 1)
+            print(json.dumps({
+                "workload": inp["key"], "parity": inp["parity"], "world": world, "tile_order": order,
+                "tile_order_in_effect": ordered, "band_rows": band, "repeats": a.repeats,
+                "kernel_ms_per_rank_median": med, "kernel_ms_per_rank_max": mx, "kernel_ms_per_rank_min": mn,
+                "slowest_rank_median_ms": max(med), "slowest_rank_max_ms": max(mx), "mean_of_medians_ms": round(sum(med) / len(med), 3),
+                "sum_of_medians_ms": round(sum(med), 3),
+                "gather_bytes_to_rank0": gather_bytes, "slice_bytes": slice_bytes,
+                "gather_ms_at_stated_link_rate": round(slice_bytes / (XGMI_LINK_GBS * 1e9) * 1e3, 3) if world > 1 else 0.0,
+                "stated_xgmi_link_gbs": XGMI_LINK_GBS}), flush=True)
+    r.close()
 
 
 if __name__ == "__main__":
