@@ -225,8 +225,9 @@ def main():
         # under a profiler the preloaded tool library has initialised the GPU in THIS process already: starting the
         # launcher from here would be the fork + exec of a GPU-initialised process that the pool forbids
         # (tools/pmc_passes.sh) -- profile one rank (--gpus 1), or start the ranks under the profiler yourself
+        # (a preload by itself is not a profiler: the GPU boxes preload their own exec guard into every process)
         traced = [k for k in os.environ if k.startswith(("ROCP_", "ROCPROF", "ROCPROFILER"))] + \
-                 (["LD_PRELOAD"] if os.environ.get("LD_PRELOAD") else [])
+                 (["LD_PRELOAD"] if "rocprof" in os.environ.get("LD_PRELOAD", "").lower() else [])
         if traced:
             print("bench.py: --gpus %d without a launcher under a profiler / preload (%s): refusing to start the rank "
                   "launcher from a process that may have initialised the GPU" % (args.gpus, ", ".join(sorted(traced))),

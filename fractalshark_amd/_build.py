@@ -83,6 +83,8 @@ def _render_flags():
         extra.append("-DFS_TRACE_WAVES")
     if os.environ.get("FS_VERIFY_FLOOR") == "1":  # tools/floor_check.py: trips whose untested first state is below the every-state floor
         extra.append("-DFS_VERIFY_FLOOR")
+    if os.environ.get("FS_BLA_FAST_PROBE") == "1":  # tools/bla_fast_check.py: how often the hand-written BLA loop is left (statistics words 20..23)
+        extra.append("-DFS_BLA_FAST_PROBE")
     if os.environ.get("FS_2X32_PROBE") == "1":  # counts the 2x32 perturbation loop's literal steps (statistics word 12)
         extra.append("-DFS_2X32_PROBE")
     for name in ("FS_FL_EVERY", "FS_FL_SHIFT", "FS_FL_FLOOR_EXP", "FS_HOT_RUN_STEPS"):  # A/B: form and scale of the scaled runs' floor tests (kernels.hip)

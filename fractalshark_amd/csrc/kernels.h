@@ -169,6 +169,13 @@ template <class F> struct FsBlaArgsT {
     const int4 *nlad; // two int4 per position
     const long long *nkmax; // per orbit index m = 4 q + 1: the largest r2 key LookupBackwards can meet there (pre-test), [q]
     uint32_t level_off[kBlaMaxLevels];
+    // ... and its heap-numbered copy for the hand-written kernel (kernels_bla_fast.hip; NULL = not made): element ix of level L
+    // at position 2^(H - L) + ix of hrec / hlad; hq[q] = {pre-test key, start position, start level} per orbit index 4 q + 1;
+    // zb = the orbit with the quiet step's arrival bound in .w
+    const float4 *zb;
+    const int4 *hq;
+    const int4 *hlad;
+    const FsBlaRec *hrec;
 };
 using FsBlaArgs32 = FsBlaArgsT<float>;
 
@@ -353,6 +360,13 @@ void fsk_bla_build_hdr64(const FsZ64 *zref, void *const *levels, const uint64_t 
 void fsk_bla_make_native(const fs_bla_hdr32 *const *levels, const uint32_t *level_off, const uint64_t *epl, int n_levels,
                          const float4 *zref, uint32_t orbit_count, FsBlaRec *rec, int4 *lad, uint32_t *bad, int32_t lm2, long long *kmax, uint32_t n_kmax, hipStream_t s);
 void fsk_perturb_scalar_hdr32(const FsBlaArgs32 &A, bool use_bla, bool stats, int variant, hipStream_t s);
+// the hand-written HDRFloat<float> BLA kernel and its tables (kernels_bla_fast.hip).  fsk_bla_heap_positions: elements of hrec
+// (and pairs of hlad) a table with these level sizes needs, 0 = the table cannot be numbered that way.
+uint64_t fsk_bla_heap_positions(const uint64_t *epl, int n_levels);
+void fsk_bla_make_heap(const FsBlaRec *rec, const int4 *lad, const long long *kmax, uint32_t n_kmax, const uint32_t *level_off,
+                       const uint64_t *epl, int n_levels, int32_t lm2, const float4 *zref, uint32_t orbit_count, FsBlaRec *hrec,
+                       int4 *hlad, int4 *hq, float4 *zb, hipStream_t s);
+void fsk_bla_hdr32_fast(const FsBlaArgs32 &A, hipStream_t s);
 void fsk_perturb_scalar_hdr64(const FsBlaArgsT<double> &A, bool use_bla, bool stats, int variant, hipStream_t s);
 void fsk_perturb_bla_f64(const FsBlaArgsF64 &A, bool use_bla, bool stats, hipStream_t s);
 void fsk_direct_hdr32(const FsDirectHdrArgsT<float> &A, fs::hreal<float> minX, fs::hreal<float> dx, bool stats, hipStream_t s);

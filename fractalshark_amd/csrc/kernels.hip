@@ -2279,6 +2279,9 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
     uint64_t c_single = 0, c_runs = 0; // probes of the perturbation-only float path (tools/c2_probe.py)
     uint64_t c_blk_violation = 0; // (verification build) must stay 0
     uint64_t c_free_steps = 0, c_tested_blocks = 0; // lane-steps inside the untested loop / tested four-step blocks (per lane)
+    // (kBla probes, statistics words 8..12: lane-passes through the quiet step / the step with z / the literal step, the
+    // quiet jump / the jump with z -- which share of the actions the hand-written kernel's fast forms must cover)
+    uint64_t c_q_step = 0, c_z_step = 0, c_lit_step = 0, c_q_jump = 0, c_z_jump = 0;
 #ifdef FS_PROFILE_CYCLES
     // measurement build (tools/c5_phase_probe.py): shader-clock cycles and wave-passes per phase of the BLA loop, per wave.
     // The clock is read on the scalar unit, i.e. once per pass of the WAVE through the code, whatever the lane mask is.
@@ -2688,6 +2691,8 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                                              RefIteration + l + 1u < count;
                         if (quiet_j) {
                             applied = true;
+                            if (kStats)
+                                c_q_jump++;
                             RefIteration += l;
                             DeltaSubNX = hreal<F>{s3.x, Ex};
                             DeltaSubNY = hreal<F>{s3.y, Ey};
@@ -2719,6 +2724,8 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                         const float smn = fminf(dmn, fminf(fabsf(Zt.x), fabsf(Zt.y)));
                         if (smn >= 0x1p-30f && smx <= 0x1p30f && zmn > 0.0f && emin > -(1 << 26) && amx <= 0x1p30f) {
                             applied = true;
+                            if (kStats)
+                                c_z_jump++;
                             RefIteration += l;
                             DeltaSubNX = hreal<F>{s3.x, Ex};
                             DeltaSubNY = hreal<F>{s3.y, Ey};
@@ -3277,6 +3284,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                     if (kStats) {
                         c_pt++;
                         c_single++;
+                        c_q_step++;
                     }
                     ++RefIteration;
                     Zcached = hcplx<F>{zn4.x, zn4.y, Zne};
@@ -3312,6 +3320,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                     if (kStats) {
                         c_pt++;
                         c_single++;
+                        c_z_step++;
                     }
                     ++RefIteration;
                     Zcached = hcplx<F>{zn4.x, zn4.y, Zne};
@@ -3364,8 +3373,10 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
             DeltaSubNY = hr_add(hr_mul(OX, T3), hr_mul(OY, T4));
             DeltaSubNY = hr_add(DeltaSubNY, DeltaSub0Y);
             hr_reduce(DeltaSubNY);
-            if (kStats)
+            if (kStats) {
                 c_pt++;
+                c_lit_step++;
+            }
 
             ++RefIteration;
             if (RefIteration >= count)
@@ -3406,6 +3417,16 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
     }
     if (kStats) {
         add_stats(A.stats, c_single, c_la, c_pt, c_px);
+        if (kBla) {
+            const uint64_t v[5] = {c_q_step, c_z_step, c_lit_step, c_q_jump, c_z_jump};
+            for (int i = 0; i < 5; i++) {
+                uint64_t t = v[i];
+                for (int off = 32; off > 0; off >>= 1)
+                    t += __shfl_down(t, off);
+                if ((threadIdx.x & 63) == 0)
+                    atomicAdd((unsigned long long *)&A.stats[8 + i], (unsigned long long)t);
+            }
+        }
         if (!kBla) {
             atomicAdd((unsigned long long *)&A.stats[7], (unsigned long long)c_runs);
             atomicAdd((unsigned long long *)&A.stats[8], (unsigned long long)c_free_steps);
@@ -3881,6 +3902,13 @@ static void launch_perturb_scalar(const FsBlaArgsT<F> &A_in, bool use_bla, bool 
 
 void fsk_perturb_scalar_hdr32(const FsBlaArgs32 &A, bool use_bla, bool stats, int variant, hipStream_t s)
 {
+    // the default BLA frame: the hand-written kernel (kernels_bla_fast.hip).  The compiled kernel below keeps the step-counting
+    // launches, the 64-bit counters, the refill variant, probes, and variants 1 / 2 (A/B references).
+    if (use_bla && !stats && A.hrec != nullptr && A.frame.wide == 0u && variant == FS_VARIANT_TUNED && A.probe_out == nullptr &&
+        A.tile_order == nullptr && A.frame.iter_u64 == 0u) {
+        fsk_bla_hdr32_fast(A, s);
+        return;
+    }
     launch_perturb_scalar<float>(A, use_bla, stats, variant, s);
 }
 

@@ -174,6 +174,12 @@ struct fs_renderer {
     bool bla_native_ok = false;
     bool bla_native_stale = false; // table or orbit changed since the native form was made: remade by the next BLA render
     uint32_t bla_native_total = 0;
+    // the heap-numbered copy the hand-written kernel reads (kernels_bla_fast.hip), made with the native form
+    void *bla_heap = nullptr;
+    size_t bla_heap_cap = 0;
+    bool bla_heap_ok = false;
+    uint64_t bla_heap_positions = 0;
+    uint32_t bla_heap_nq = 0;
     uint32_t bla_level_off[kBlaMaxLevels] = {0};
 
     void *iters() const { return iters_external ? iters_external : iters_internal; }
@@ -487,6 +493,10 @@ void bla_release(fs_renderer *r)
     r->bla_native = nullptr;
     r->bla_native_cap = 0;
     r->bla_native_ok = false;
+    (void)r_free(r, r->bla_heap);
+    r->bla_heap = nullptr;
+    r->bla_heap_cap = 0;
+    r->bla_heap_ok = false;
     (void)r_free(r, r->bla_block);
     r->bla_block = nullptr;
     r->bla_block_cap = 0;
@@ -572,6 +582,36 @@ uint32_t bla_make_native(fs_renderer *r, int32_t n_levels)
     FS_TRY(hipStreamSynchronize(r->compute));
     r->bla_native_total = (uint32_t)total;
     r->bla_native_ok = flag == 0;
+    // ... and its heap-numbered copy for the hand-written kernel (not an error when it cannot be had: the compiled kernel serves)
+    r->bla_heap_ok = false;
+    const uint64_t hn = fsk_bla_heap_positions(r->bla_level_sizes.data(), n_levels);
+    if (r->bla_native_ok && hn != 0 && r->orbit_uncompressed < 0x0FFFFFF0ull) {
+        const size_t nz = (size_t)r->orbit_uncompressed + 2u;
+        const size_t hneed = (size_t)hn * (sizeof(FsBlaRec) + 2 * sizeof(int4)) + (size_t)n_kmax * sizeof(int4) + nz * sizeof(float4);
+        if (!r->bla_heap || r->bla_heap_cap < hneed) {
+            (void)r_free(r, r->bla_heap);
+            r->bla_heap = nullptr;
+            r->bla_heap_cap = 0;
+            if (r_alloc(r, &r->bla_heap, hneed, kInput) != hipSuccess) {
+                (void)hipGetLastError();
+                return 0;
+            }
+            r->bla_heap_cap = hneed;
+        }
+        FS_TRY(hipMemsetAsync(r->bla_heap, 0, hneed, r->compute));
+        FsBlaRec *hrec = (FsBlaRec *)r->bla_heap;
+        int4 *hlad = (int4 *)(hrec + hn);
+        int4 *hq = hlad + 2 * (size_t)hn;
+        float4 *zb = (float4 *)(hq + n_kmax);
+        fsk_bla_make_heap(rec, lad, (const long long *)(lad + 2 * (size_t)total), n_kmax, r->bla_level_off,
+                          r->bla_level_sizes.data(), n_levels, r->bla_lm2, r->zref, (uint32_t)r->orbit_uncompressed, hrec, hlad, hq,
+                          zb, r->compute);
+        FS_TRY(hipGetLastError());
+        FS_TRY(hipStreamSynchronize(r->compute));
+        r->bla_heap_positions = hn;
+        r->bla_heap_nq = n_kmax;
+        r->bla_heap_ok = true;
+    }
     return 0;
 }
 
@@ -2211,6 +2251,12 @@ uint32_t fs_render_bla(fs_renderer *r, int type_tag, const void *coords, uint64_
             A.nlad = (const int4 *)((const char *)A.nrec + (size_t)r->bla_native_total * sizeof(FsBlaRec));
             A.nkmax = (const long long *)(A.nlad + 2 * (size_t)r->bla_native_total);
             memcpy(A.level_off, r->bla_level_off, sizeof(A.level_off));
+            if (r->bla_heap_ok) {
+                A.hrec = (const FsBlaRec *)r->bla_heap;
+                A.hlad = (const int4 *)(A.hrec + r->bla_heap_positions);
+                A.hq = A.hlad + 2 * (size_t)r->bla_heap_positions;
+                A.zb = (const float4 *)(A.hq + r->bla_heap_nq);
+            }
         }
         // Long tiles first.  A perturbation-only frame with a high iteration limit is bounded by the few waves that hold
         // never-escaping pixels: each runs its millions of steps at the pace of a wave that is alone on its SIMD, and the

@@ -26,6 +26,9 @@ def main():
     ap.add_argument("--key", default=None)
     ap.add_argument("--algorithmic-bytes", type=int, default=None)
     ap.add_argument("--note", default="")
+    ap.add_argument("--largest-grid-only", action="store_true",
+                    help="keep only the launches with the largest Grid_Size among the matches (drops C2's tile-order probe launch, "
+                         "the same kernel over one pixel per tile)")
     a = ap.parse_args()
     sums, counts = {}, {}
     for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_%s_*" % a.tag))):
@@ -41,6 +44,9 @@ def main():
                         rows.append(row)
         if not rows:
             continue
+        if a.largest_grid_only:
+            big = max(int(row["Grid_Size"]) for row in rows)
+            rows = [row for row in rows if int(row["Grid_Size"]) == big]
         # one row per (dispatch, counter); a dispatch's value may be split over several rows (dimensions): sum per dispatch
         per = {}
         for row in rows:
