@@ -82,15 +82,25 @@ def cpu_model():
     return model, os.cpu_count() or 1
 
 
-def checksum_vs_committed(workload_key, parity, n_iterations, checksum):
-    """True / False when tests/golden/frame_checksums.json holds the sum of this frame's iteration counts as one GPU
-    rendered it, None when it holds none."""
+def oracle_frame_record(workload_key, parity, n_iterations):
+    """tests/golden/frame_crcs.json: the WHOLE frame of this workload as the CPU oracle renders it (tests/golden/make_frame_crcs.py,
+    build container, no GPU involved) -- {"crc32", "sum", "band_rows", "band_crc32", ...} or None when no oracle frame is committed
+    for this workload / parity / cap."""
     try:
-        table = json.load(open(os.path.join(ROOT, "tests", "golden", "frame_checksums.json")))
+        table = json.load(open(os.path.join(ROOT, "tests", "golden", "frame_crcs.json")))
     except (OSError, ValueError):
         return None
-    want = table.get("%s|%s|%d" % (workload_key, parity, n_iterations))
-    return None if want is None or checksum is None else bool(int(want) == int(checksum))
+    rec = table.get("%s|%s|%d" % (workload_key, parity, n_iterations))
+    return rec if isinstance(rec, dict) and rec.get("source") == "oracle" else None
+
+
+def frame_crc32(frame, H, W):
+    """zlib CRC-32 of rows 0..H-1 x columns 0..W-1 of the iteration buffer, uint32 little-endian, row-major: the value
+    tests/golden/frame_crcs.json holds for the oracle's frame."""
+    import zlib
+
+    import numpy as np
+    return "%08x" % (zlib.crc32(np.ascontiguousarray(frame[:H, :W]).astype("<u4", copy=False).tobytes()) & 0xFFFFFFFF)
 
 
 def make_inputs(wl, view_id=-1, width=0, height=0, iter_cap=0, parity=None):
@@ -516,6 +526,7 @@ def main():
     b_main = state["last"]
     checksum = int(host_np[b_main][:H, :W].astype(np.uint64).sum()) if rank == 0 else None
     frame_main = host_np[b_main].copy() if rank == 0 else None
+    crc_main = frame_crc32(frame_main, H, W) if rank == 0 else None
     # latency of ONE frame (launch -> host, nothing overlapped), warm and cold (natural tile order: what the FIRST frame of a
     # view costs; fs_forget_tile_costs before every frame)
     n_lat = max(1, min(args.steps, 5))
@@ -561,6 +572,10 @@ def main():
                          "pixel_steps_per_launch": float(st2["perturb_steps"]),
                          "frame_checksum": int(host_np[b2][:H, :W].astype(np.uint64).sum())}
             frame_secondary = host_np[b2].copy()
+            orc2 = oracle_frame_record(inp["key"], "cpu_gpustage", n_iter)
+            secondary["frame_crc32"] = frame_crc32(frame_secondary, H, W)
+            secondary["frame_crc32_equals_oracle_frame"] = (None if orc2 is None else
+                                                             bool(orc2["crc32"] == secondary["frame_crc32"]))
 
     # ---- CPU baseline on a bounded sample of rows (rank 0, N = 1 only)
     cpu_baseline = None
@@ -661,6 +676,7 @@ def main():
                              "frac": round(achieved / peak, 5), "flop_per_bla_jump": FLOP_PER_BLA_JUMP,
                              "bla_jumps_per_launch": la_steps}}
         wl_key = "view%d_%dx%d_%s" % (args.view, W, H, wl_tag)
+        orc = oracle_frame_record(wl_key, args.parity, n_iter)
         out = {
             "metric": "Mpix/s (iteration buffer), View #5 3840x2160 HDRx32 LAv2" if wl == "c3_lav2"
             else "Mpix/s (iteration buffer), " + wl,
@@ -688,9 +704,12 @@ def main():
                          if lane_slots and not distributed else None},
             "cpu_baseline": cpu_baseline, "cpu_baseline_patched": cpu_baseline_patched, "secondary": secondary,
             "frame_checksum": checksum, "cpu_sample_rows_bit_exact": parity_rows_ok,
-            # the same frame rendered by one GPU (tests/golden/frame_checksums.json, written from N = 1 runs whose sampled rows
-            # were bit-exact): null when no checksum is committed for this workload / parity / cap
-            "frame_checksum_equals_committed_n1": checksum_vs_committed(wl_key, args.parity, n_iter, checksum),
+            # the WHOLE frame against the CPU oracle's frame (tests/golden/frame_crcs.json: rendered by the oracle in the build
+            # container, no GPU involved): CRC-32 of the valid region; null when no oracle frame is committed for this
+            # workload / parity / cap
+            "frame_crc32": crc_main,
+            "frame_crc32_equals_oracle_frame": None if orc is None else bool(orc["crc32"] == crc_main),
+            "frame_checksum_equals_oracle_frame": None if orc is None else bool(int(orc["sum"]) == int(checksum)),
             "frame_timing": frame_timing,
             "device_resident_ms": round(avg_kernel_ms, 3),
             "device_resident_mpix_s": round(W * H / avg_kernel_ms / 1e3, 4),

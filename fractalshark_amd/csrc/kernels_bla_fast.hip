@@ -82,9 +82,12 @@ __global__ void __launch_bounds__(256) k_bla_make_heap(const FsBlaRec *__restric
     hlad[2 * (size_t)h + 1] = lad[2 * (size_t)p + 1];
 }
 
-// Q[q], one per orbit index m = 4 q + 1: {pre-test key (k_bla_make_kmax; for q = 0 also bounded by the key of the first element
-// of level 2, the gate of BLAS.cpp:270-281), heap position of the element the walk starts at, its level -- 0 when the walk
-// cannot be expressed here (an element index outside its level: the compiled lookup serves)}.
+// Q[q], one per orbit index m = 4 q + 1, 48 bytes: {pre-test key (k_bla_make_kmax; for q = 0 also bounded by the key of the first
+// element of level 2, the gate of BLAS.cpp:270-281), heap position of the element the walk starts at, its level -- 0 when the
+// walk cannot be expressed here (an element index outside its level: the compiled lookup serves)} and that element's ladder
+// entry (the four keys of the walk's first round), so that a lookup that ends in its first round -- 15 of 16 -- reads nothing
+// else before the record: the dependent chain of a lookup is Q -> record instead of key -> ladder -> record, and Q itself is
+// requested by the action that arrives at the index (a step or a jump), well before the lookup needs it.
 __global__ void __launch_bounds__(256) k_bla_make_q(const long long *__restrict__ kmax, const int4 *__restrict__ lad, HeapGeom G,
                                                     int32_t lm2, int4 *__restrict__ hq, uint32_t n)
 {
@@ -109,7 +112,10 @@ __global__ void __launch_bounds__(256) k_bla_make_q(const long long *__restrict_
             key = key20 < key ? key20 : key;
         }
     }
-    hq[q] = make_int4((int)(unsigned long long)key, (int)((unsigned long long)key >> 32), (int)pos, lvl);
+    hq[3 * (size_t)q] = make_int4((int)(unsigned long long)key, (int)((unsigned long long)key >> 32), (int)pos, lvl);
+    const int4 never = make_int4(0, (int)0x80000000u, 0, (int)0x80000000u);
+    hq[3 * (size_t)q + 1] = lvl ? lad[2 * ((size_t)G.level_off[L] + ix)] : never;
+    hq[3 * (size_t)q + 2] = lvl ? lad[2 * ((size_t)G.level_off[L] + ix) + 1] : never;
 }
 
 // The orbit as this kernel's steps read it: {re, im, exponent, exponent - 4 where the QUIET step may arrive}.  .w is poisoned
@@ -278,8 +284,22 @@ __device__ __forceinline__ bool step_literal(const FsBlaArgsT<float> &A, PixelSt
 #define FS_CNT(R) ""
 #define FS_CNT_ZERO ""
 #endif
+// Q[(m - 1) / 4] into v[22:33] for the lanes that have just arrived at an index m = 1 (mod 4) -- the only ones whose next
+// lookup can find anything; s57 = "requested" (the lookup then only waits).  48 bytes per record: (m - 1) * 12.
+#define FS_Q_LOADS                                                                                                      \
+    "v_mad_u32_u24 v16, v8, 12, -12\n\t"                                                                               \
+    "global_load_dwordx4 v[22:25], v16, %[hq]\n\t"                                                                      \
+    "global_load_dwordx4 v[26:29], v16, %[hq] offset:16\n\t"                                                            \
+    "global_load_dwordx4 v[30:33], v16, %[hq] offset:32\n\t"
+#define FS_Q_PREFETCH(N)                                                                                                \
+    "v_and_b32_e32 v16, 3, v8\n\t"                                                                                      \
+    "v_cmp_eq_u32_e32 vcc, 1, v16\n\t"                                                                                  \
+    "s_and_saveexec_b64 s[46:47], vcc\n\t"                                                                              \
+    "s_cbranch_execz .Lbf_pf" N "_%=\n\t" FS_Q_LOADS "s_mov_b32 s57, 1\n"                                               \
+    ".Lbf_pf" N "_%=:\n\t"                                                                                              \
+    "s_mov_b64 exec, s[46:47]\n\t"
 #define FS_BLA_ASM                                                                                                      \
-    FS_CNT_ZERO "s_mov_b64 s[48:49], exec\n\t"                                                                                      \
+    FS_CNT_ZERO "s_mov_b32 s57, 0\n\t" "s_mov_b64 s[48:49], exec\n\t"                                                                                      \
     "s_mov_b32 s50, 0x807fffff\n\t"                                                                                     \
     "s_mov_b32 s51, 0xffffff81\n\t"                                                                                     \
     "s_mov_b32 s52, 0x30800000\n\t"                                                                                     \
@@ -299,25 +319,29 @@ __device__ __forceinline__ bool step_literal(const FsBlaArgsT<float> &A, PixelSt
     "v_cmp_eq_u32_e32 vcc, 1, v16\n\t"                                                                                  \
     "s_and_b64 exec, exec, vcc\n\t"                                                                                     \
     "s_cbranch_scc0 .Lbf_step_%=\n\t"                                                                                   \
-    "v_lshl_add_u32 v16, v8, 2, -4\n\t" FS_CNT("s59")                                                                                 \
-    "global_load_dwordx4 v[18:21], v16, %[hq]\n\t"                                                                      \
+    "s_cmp_lg_u32 s57, 0\n\t"                                                                                           \
+    "s_cbranch_scc1 .Lbf_haveq_%=\n\t" FS_Q_LOADS                                                                       \
+    ".Lbf_haveq_%=:\n\t"                                                                                                \
+    "s_mov_b32 s57, 0\n\t"                                                                                              \
     "s_mov_b64 s[44:45], 0\n\t"                                                                                         \
     "s_waitcnt vmcnt(0)\n\t"                                                                                            \
-    "v_cmp_lt_i64_e32 vcc, v[10:11], v[18:19]\n\t"                                                                      \
+    "v_cmp_lt_i64_e32 vcc, v[10:11], v[22:23]\n\t"                                                                      \
     "s_and_b64 exec, exec, vcc\n\t"                                                                                     \
     "s_cbranch_scc0 .Lbf_step_%=\n\t"                                                                                   \
-    "v_cmp_eq_u32_e32 vcc, 0, v21\n\t"                                                                                  \
-    "s_cbranch_vccnz .Lbf_slowlk_%=\n"                                                                                  \
-    ".Lbf_round_%=:\n\t" FS_CNT("s60")                                                                                                \
-    "v_lshlrev_b32_e32 v16, 5, v20\n\t"                                                                                 \
-    "global_load_dwordx4 v[22:25], v16, %[hlad]\n\t"                                                                    \
-    "global_load_dwordx4 v[26:29], v16, %[hlad] offset:16\n\t"                                                          \
+    "v_cmp_eq_u32_e32 vcc, 0, v25\n\t"                                                                                  \
+    "s_cbranch_vccnz .Lbf_slowlk_%=\n\t"                                                                                \
+    "s_branch .Lbf_cmp_%=\n"                     /* (the first round's keys came with Q) */                            \
+    ".Lbf_round_%=:\n\t" FS_CNT("s60")                                                                                  \
+    "v_lshlrev_b32_e32 v16, 5, v24\n\t"                                                                                 \
+    "global_load_dwordx4 v[26:29], v16, %[hlad]\n\t"                                                                    \
+    "global_load_dwordx4 v[30:33], v16, %[hlad] offset:16\n\t"                                                          \
+    "s_waitcnt vmcnt(0)\n"                                                                                              \
+    ".Lbf_cmp_%=:\n\t"                                                                                                  \
     "v_mov_b32_e32 v17, 4\n\t"                                                                                          \
-    "s_waitcnt vmcnt(0)\n\t"                                                                                            \
-    "v_cmp_lt_i64_e64 s[42:43], v[10:11], v[28:29]\n\t"                                                                 \
-    "v_cmp_lt_i64_e64 s[40:41], v[10:11], v[26:27]\n\t"                                                                 \
-    "v_cmp_lt_i64_e64 s[38:39], v[10:11], v[24:25]\n\t"                                                                 \
-    "v_cmp_lt_i64_e64 s[36:37], v[10:11], v[22:23]\n\t"                                                                 \
+    "v_cmp_lt_i64_e64 s[42:43], v[10:11], v[32:33]\n\t"                                                                 \
+    "v_cmp_lt_i64_e64 s[40:41], v[10:11], v[30:31]\n\t"                                                                 \
+    "v_cmp_lt_i64_e64 s[38:39], v[10:11], v[28:29]\n\t"                                                                 \
+    "v_cmp_lt_i64_e64 s[36:37], v[10:11], v[26:27]\n\t"                                                                 \
     "v_cndmask_b32_e64 v17, v17, 3, s[42:43]\n\t"                                                                       \
     "v_cndmask_b32_e64 v17, v17, 2, s[40:41]\n\t"                                                                       \
     "v_cndmask_b32_e64 v17, v17, 1, s[38:39]\n\t"                                                                       \
@@ -325,16 +349,16 @@ __device__ __forceinline__ bool step_literal(const FsBlaArgsT<float> &A, PixelSt
     "s_or_b64 s[42:43], s[42:43], s[40:41]\n\t"                                                                         \
     "s_or_b64 s[38:39], s[38:39], s[36:37]\n\t"                                                                         \
     "s_or_b64 s[42:43], s[42:43], s[38:39]\n\t" /* lanes that found their element this round */                         \
-    "v_lshlrev_b32_e32 v20, v17, v20\n\t"       /* its position -- or, for the others, the next round's start */         \
-    "v_cmp_le_i32_e32 vcc, 6, v21\n\t"          /* four more levels down is still level 2 or above */                   \
-    "v_add_u32_e32 v21, -4, v21\n\t"                                                                                    \
+    "v_lshlrev_b32_e32 v24, v17, v24\n\t"       /* its position -- or, for the others, the next round's start */         \
+    "v_cmp_le_i32_e32 vcc, 6, v25\n\t"          /* four more levels down is still level 2 or above */                   \
+    "v_add_u32_e32 v25, -4, v25\n\t"                                                                                    \
     "s_or_b64 s[44:45], s[44:45], s[42:43]\n\t"                                                                         \
     "s_andn2_b64 exec, vcc, s[42:43]\n\t"                                                                               \
     "s_cbranch_scc1 .Lbf_round_%=\n\t"                                                                                  \
     "s_mov_b64 exec, s[44:45]\n\t"                                                                                      \
-    "s_cbranch_execz .Lbf_step_%=\n\t" FS_CNT("s61")                                                                                  \
+    "s_cbranch_execz .Lbf_step_%=\n\t" FS_CNT("s61")                                                                    \
     /* ---------------- jump: lanes that found an element (position v20) */                                             \
-    "v_mul_u32_u24_e32 v16, 48, v20\n\t"                                                                                \
+    "v_mul_u32_u24_e32 v16, 48, v24\n\t"                                                                                \
     "global_load_dwordx4 v[30:33], v16, %[hrec] offset:32\n\t" /* Z.re, Z.im, Z.exp (poisoned: not quiet), l */          \
     "global_load_dwordx4 v[22:25], v16, %[hrec]\n\t"           /* Ax, Ay, Bx, By mantissas */                            \
     "global_load_dwordx4 v[26:29], v16, %[hrec] offset:16\n\t" /* ... exponents */                                       \
@@ -401,14 +425,11 @@ __device__ __forceinline__ bool step_literal(const FsBlaArgsT<float> &A, PixelSt
     "s_and_b64 s[36:37], s[36:37], s[38:39]\n\t"                                                                        \
     "s_xor_b64 s[36:37], s[36:37], exec\n\t"                                                                            \
     "s_cbranch_scc1 .Lbf_slowlk_%=\n\t"         /* some lane's jump is not the quiet form: nothing committed */          \
-    "v_mov_b32_e32 v0, v40\n\t"                                                                                         \
-    "v_mov_b32_e32 v1, v41\n\t"                                                                                         \
-    "v_mov_b32_e32 v2, v42\n\t"                                                                                         \
-    "v_mov_b32_e32 v3, v43\n\t"                                                                                         \
+    "v_pk_mov_b32 v[0:1], v[40:41], v[40:41] op_sel:[0,1]\n\t"                                                         \
+    "v_pk_mov_b32 v[2:3], v[42:43], v[42:43] op_sel:[0,1]\n\t"                                                         \
     "v_add_u32_e32 v8, v8, v33\n\t"                                                                                     \
     "v_mov_b32_e32 v9, v17\n\t"                                                                                         \
-    "v_mov_b32_e32 v12, v30\n\t"                                                                                        \
-    "v_mov_b32_e32 v13, v31\n\t"                                                                                        \
+    "v_pk_mov_b32 v[12:13], v[30:31], v[30:31] op_sel:[0,1]\n\t"                                                       \
     "v_mov_b32_e32 v14, v32\n\t"                                                                                        \
     "v_pk_mul_f32 v[38:39], v[40:41], v[40:41]\n\t" /* |dz|^2 for the lookup that follows */                            \
     "v_max_i32_e32 v45, v42, v43\n\t"                                                                                   \
@@ -423,13 +444,15 @@ __device__ __forceinline__ bool step_literal(const FsBlaArgsT<float> &A, PixelSt
     "v_and_or_b32 v10, v38, s50, 1.0\n\t"                                                                               \
     "v_lshl_add_u32 v45, v45, 1, v39\n\t"                                                                               \
     "v_add_u32_e32 v11, s51, v45\n\t"                                                                                   \
-    "s_mov_b64 %[J], exec\n\t"                                                                                          \
+    "s_mov_b64 %[J], exec\n\t" FS_Q_PREFETCH("j")                                                                       \
     "s_branch .Lbf_lk_%=\n"                                                                                             \
     ".Lbf_jnone_%=:\n\t"                                                                                                \
     "s_waitcnt vmcnt(0)\n"                                                                                              \
     /* ---------------- step: every running lane */                                                                     \
     ".Lbf_step_%=:\n\t"                                                                                                 \
     "s_mov_b64 exec, %[R]\n\t"                                                                                          \
+    "s_waitcnt vmcnt(0)\n\t"                    /* (a requested Q that no lookup consumed) */                           \
+    "s_mov_b32 s57, 0\n\t"                                                                                              \
     "v_lshl_add_u32 v16, v8, 4, 16\n\t" FS_CNT("s62")                                                                                 \
     "global_load_dwordx4 v[18:21], v16, %[zb]\n\t" /* the entry the step arrives at: re, im, exponent, quiet bound */    \
     "v_add_u32_e32 v17, 1, v14\n\t"                                                                                     \
@@ -478,7 +501,6 @@ __device__ __forceinline__ bool step_literal(const FsBlaArgsT<float> &A, PixelSt
     "v_min_i32_e32 v46, v2, v3\n\t"                                                                                     \
     "v_cmp_lt_i32_e32 vcc, s54, v46\n\t"                                                                                \
     "s_and_b64 s[36:37], s[36:37], vcc\n\t"     /* ok_dz */                                                             \
-    "v_add_u32_e32 v17, 1, v9\n\t"                                                                                      \
     "v_max_i32_e32 v46, v36, v37\n\t"                                                                                   \
     "s_waitcnt vmcnt(0)\n\t"                                                                                            \
     "v_cmp_le_i32_e32 vcc, v46, v21\n\t"        /* quiet */                                                             \
@@ -488,13 +510,11 @@ __device__ __forceinline__ bool step_literal(const FsBlaArgsT<float> &A, PixelSt
     /* quiet commit */                                                                                                  \
     "v_and_or_b32 v0, v22, s50, 1.0\n\t"                                                                                \
     "v_and_or_b32 v1, v23, s50, 1.0\n\t"                                                                                \
-    "v_mov_b32_e32 v2, v36\n\t"                                                                                         \
-    "v_mov_b32_e32 v3, v37\n\t"                                                                                         \
-    "v_mov_b32_e32 v12, v18\n\t"                                                                                        \
-    "v_mov_b32_e32 v13, v19\n\t"                                                                                        \
+    "v_pk_mov_b32 v[2:3], v[36:37], v[36:37] op_sel:[0,1]\n\t"                                                         \
+    "v_pk_mov_b32 v[12:13], v[18:19], v[18:19] op_sel:[0,1]\n\t"                                                       \
     "v_mov_b32_e32 v14, v20\n\t"                                                                                        \
     "v_add_u32_e32 v8, 1, v8\n\t"                                                                                       \
-    "v_mov_b32_e32 v9, v17\n\t"                                                                                         \
+    "v_add_u32_e32 v9, 1, v9\n\t"                                                                                       \
     "v_cmp_gt_u32_e32 vcc, %[n], v9\n\t"        /* lanes at the cap leave with it */                                    \
     "s_mov_b64 %[R], vcc\n\t"                                                                                           \
     "v_and_b32_e32 v16, 3, v8\n\t"                                                                                      \
@@ -512,7 +532,7 @@ __device__ __forceinline__ bool step_literal(const FsBlaArgsT<float> &A, PixelSt
     "v_bfe_u32 v25, v24, 23, 8\n\t"                                                                                     \
     "v_and_or_b32 v10, v24, s50, 1.0\n\t"                                                                               \
     "v_lshl_add_u32 v43, v43, 1, v25\n\t"                                                                               \
-    "v_add_u32_e32 v11, s51, v43\n\t"                                                                                   \
+    "v_add_u32_e32 v11, s51, v43\n\t" FS_Q_PREFETCH("q")                                                                \
     "s_branch .Lbf_next_%=\n"                                                                                           \
     /* the step with z = Z' + dz' */                                                                                    \
     ".Lbf_wz_%=:\n\t" FS_CNT("s63")                                                                                                   \
@@ -548,12 +568,9 @@ __device__ __forceinline__ bool step_literal(const FsBlaArgsT<float> &A, PixelSt
     "s_and_b64 s[38:39], s[38:39], vcc\n\t"                                                                             \
     "s_xor_b64 s[46:47], s[38:39], exec\n\t"                                                                            \
     "s_cbranch_scc1 .Lbf_slowstep_%=\n\t"                                                                               \
-    "v_mov_b32_e32 v0, v22\n\t"                 /* commit */                                                            \
-    "v_mov_b32_e32 v1, v23\n\t"                                                                                         \
-    "v_mov_b32_e32 v2, v36\n\t"                                                                                         \
-    "v_mov_b32_e32 v3, v37\n\t"                                                                                         \
-    "v_mov_b32_e32 v12, v18\n\t"                                                                                        \
-    "v_mov_b32_e32 v13, v19\n\t"                                                                                        \
+    "v_pk_mov_b32 v[0:1], v[22:23], v[22:23] op_sel:[0,1]\n\t" /* commit */                                            \
+    "v_pk_mov_b32 v[2:3], v[36:37], v[36:37] op_sel:[0,1]\n\t"                                                         \
+    "v_pk_mov_b32 v[12:13], v[18:19], v[18:19] op_sel:[0,1]\n\t"                                                       \
     "v_mov_b32_e32 v14, v20\n\t"                                                                                        \
     "v_add_u32_e32 v8, 1, v8\n\t"                                                                                       \
     "v_bfe_u32 v25, v24, 23, 8\n\t"                                                                                     \
@@ -589,10 +606,11 @@ __device__ __forceinline__ bool step_literal(const FsBlaArgsT<float> &A, PixelSt
     "v_mov_b32_e32 v14, s56\n"                                                                                          \
     ".Lbf_norebase_%=:\n\t"                                                                                             \
     "s_mov_b64 exec, s[46:47]\n\t"                                                                                      \
-    "v_mov_b32_e32 v9, v17\n"                                                                                           \
+    "v_add_u32_e32 v9, 1, v9\n"                                                                                           \
     ".Lbf_wzdone_%=:\n\t"                                                                                               \
     "v_cmp_gt_u32_e32 vcc, %[n], v9\n\t"        /* (EXEC = the lanes that did not escape) */                            \
-    "s_mov_b64 %[R], vcc\n"                                                                                             \
+    "s_mov_b64 %[R], vcc\n\t" FS_Q_PREFETCH("z")                                                                        \
+    "s_nop 0\n"                                                                                             \
     ".Lbf_next_%=:\n\t"                                                                                                 \
     "s_cmp_lg_u64 %[R], 0\n\t"                                                                                          \
     "s_cbranch_scc1 .Lbf_top_%=\n\t"                                                                                    \
@@ -605,6 +623,7 @@ __device__ __forceinline__ bool step_literal(const FsBlaArgsT<float> &A, PixelSt
     "s_mov_b64 %[M], exec\n\t"                                                                                          \
     "s_mov_b32 %[st], 2\n"                                                                                              \
     ".Lbf_end_%=:\n\t"                                                                                                  \
+    "s_waitcnt vmcnt(0)\n\t"                    /* nothing stays in flight into registers the compiler owns again */    \
     "s_mov_b64 exec, s[48:49]"
 
 __global__ void __launch_bounds__(256) k_bla_hdr32_fast(FsBlaArgsT<float> A)
@@ -657,7 +676,7 @@ __global__ void __launch_bounds__(256) k_bla_hdr32_fast(FsBlaArgsT<float> A)
                      : "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30",
                        "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45",
                        "v46", "v47", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48",
-                       "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "vcc", "scc", "memory");
+                       "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "vcc", "scc", "memory");
         st = (uint32_t)__builtin_amdgcn_readfirstlane((int)st);
         R = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(R >> 32)) << 32) |
             (uint32_t)__builtin_amdgcn_readfirstlane((int)R);
@@ -756,7 +775,7 @@ void fsk_bla_make_heap(const FsBlaRec *rec, const int4 *lad, const long long *km
     if (G.H == 0 || total == 0)
         return;
     hipLaunchKernelGGL(k_bla_make_heap, dim3((total + 255u) / 256u), dim3(256), 0, s, rec, lad, G, orbit_count, hrec, hlad);
-    hipLaunchKernelGGL(k_bla_make_q, dim3((n_kmax + 255u) / 256u), dim3(256), 0, s, kmax, lad, G, lm2, hq, n_kmax);
+    hipLaunchKernelGGL(k_bla_make_q, dim3((n_kmax + 255u) / 256u), dim3(256), 0, s, kmax, lad, G, lm2, hq, n_kmax); // 3 int4 each
     const uint32_t nz = orbit_count + 2u;
     hipLaunchKernelGGL(k_bla_make_zb, dim3((nz + 255u) / 256u), dim3(256), 0, s, zref, orbit_count, zb, nz);
 }

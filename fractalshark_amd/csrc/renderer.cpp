@@ -585,9 +585,10 @@ uint32_t bla_make_native(fs_renderer *r, int32_t n_levels)
     // ... and its heap-numbered copy for the hand-written kernel (not an error when it cannot be had: the compiled kernel serves)
     r->bla_heap_ok = false;
     const uint64_t hn = fsk_bla_heap_positions(r->bla_level_sizes.data(), n_levels);
-    if (r->bla_native_ok && hn != 0 && r->orbit_uncompressed < 0x0FFFFFF0ull) {
+    // (orbit positions below 2^24: the kernel forms the address of Q[(m - 1) / 4] with one 24-bit multiply-add)
+    if (r->bla_native_ok && hn != 0 && r->orbit_uncompressed < 0x00FFFFF0ull) {
         const size_t nz = (size_t)r->orbit_uncompressed + 2u;
-        const size_t hneed = (size_t)hn * (sizeof(FsBlaRec) + 2 * sizeof(int4)) + (size_t)n_kmax * sizeof(int4) + nz * sizeof(float4);
+        const size_t hneed = (size_t)hn * (sizeof(FsBlaRec) + 2 * sizeof(int4)) + (size_t)n_kmax * 3 * sizeof(int4) + nz * sizeof(float4);
         if (!r->bla_heap || r->bla_heap_cap < hneed) {
             (void)r_free(r, r->bla_heap);
             r->bla_heap = nullptr;
@@ -602,7 +603,7 @@ uint32_t bla_make_native(fs_renderer *r, int32_t n_levels)
         FsBlaRec *hrec = (FsBlaRec *)r->bla_heap;
         int4 *hlad = (int4 *)(hrec + hn);
         int4 *hq = hlad + 2 * (size_t)hn;
-        float4 *zb = (float4 *)(hq + n_kmax);
+        float4 *zb = (float4 *)(hq + 3 * (size_t)n_kmax);
         fsk_bla_make_heap(rec, lad, (const long long *)(lad + 2 * (size_t)total), n_kmax, r->bla_level_off,
                           r->bla_level_sizes.data(), n_levels, r->bla_lm2, r->zref, (uint32_t)r->orbit_uncompressed, hrec, hlad, hq,
                           zb, r->compute);
@@ -2255,7 +2256,7 @@ uint32_t fs_render_bla(fs_renderer *r, int type_tag, const void *coords, uint64_
                 A.hrec = (const FsBlaRec *)r->bla_heap;
                 A.hlad = (const int4 *)(A.hrec + r->bla_heap_positions);
                 A.hq = A.hlad + 2 * (size_t)r->bla_heap_positions;
-                A.zb = (const float4 *)(A.hq + r->bla_heap_nq);
+                A.zb = (const float4 *)(A.hq + 3 * (size_t)r->bla_heap_nq);
             }
         }
         // Long tiles first.  A perturbation-only frame with a high iteration limit is bounded by the few waves that hold

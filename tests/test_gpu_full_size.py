@@ -1,8 +1,10 @@
 """GPU: the BASELINE configurations at their FULL sizes, end to end through bench.py (C-ABI renderer, pipelined frames, the copy
-to the host): the frame's checksum must equal the committed one-GPU checksum (tests/golden/frame_checksums.json, written from
-runs whose sampled rows were bit-exact) and a few rows of the same frame, spread over its height, must equal the CPU oracle
-bit for bit in the same run.  C3 3840x2160, C2 1920x1080, C5 7680x4320, C4 15360x8640 in its three forms.  One frame buffer
-of C4 is 531 MB; the oracle's share is bounded by --cpu-sample-rows."""
+to the host): the WHOLE frame must equal the frame the CPU oracle renders -- CRC-32 of the valid region and the sum of the
+counts against tests/golden/frame_crcs.json, which tests/golden/make_frame_crcs.py wrote in the build container from full
+oracle frames (hours of CPU, no GPU involved; the reference's own pattern: TestRenderGoldens.cpp:84-97 pins whole frames by a
+CRC) -- and a few rows of the same frame, spread over its height, must equal the oracle bit for bit in the same run.
+C3 3840x2160, C2 1920x1080, C5 7680x4320, C4 15360x8640 in its three forms.  One frame buffer of C4 is 531 MB; the oracle's
+share of a test run is bounded by --cpu-sample-rows."""
 import json
 import os
 import subprocess
@@ -40,8 +42,10 @@ def test_baseline_configuration_at_full_size(native_libs, workload, rows, name):
     assert d["config"]["workload"] == name
     assert d["n_gpus"] == 1
     assert d["cpu_sample_rows_bit_exact"] is True, d.get("cpu_baseline")
-    # the whole frame, not only the sampled rows: the sum of its iteration counts is the committed one
-    assert d["frame_checksum_equals_committed_n1"] is True, d["frame_checksum"]
+    # the whole frame, not only the sampled rows: its CRC-32 and its sum are those of the ORACLE's frame
+    assert d["frame_crc32_equals_oracle_frame"] is True, (d["frame_crc32"], "no oracle frame committed" if
+                                                         d["frame_crc32_equals_oracle_frame"] is None else "differs")
+    assert d["frame_checksum_equals_oracle_frame"] is True, d["frame_checksum"]
     assert d["roofline"]["kernel_ms"] > 0 and d["value"] > 0
 
 
@@ -49,11 +53,13 @@ def test_baseline_configuration_at_full_size(native_libs, workload, rows, name):
 def test_c3_full_size_row_tiled_over_a_group(native_libs, world):
     """The N > 1 data path at the BASELINE size: C3's 3840x2160 frame row-tiled over `world` members of an fs_group (they share
     this box's one device: interleaved bands rendered concurrently, gathered and re-ordered on the device), its reduction's sum
-    == the committed one-GPU checksum, twice (buffers and tile costs are reused by the second frame)."""
+    and CRC-32 == the oracle frame's, twice (buffers and tile costs are reused by the second frame)."""
     import numpy as np
     from fractalshark_amd import GPURendererGroup, LAV2_FULL, PARITY_CPU, _capi, inputs
-    want = json.load(open(os.path.join(ROOT, "tests", "golden", "frame_checksums.json")))[
-        "view5_3840x2160_hdrx32_lav2_full|cpu|4718592"]
+    import zlib
+    orc = json.load(open(os.path.join(ROOT, "tests", "golden", "frame_crcs.json")))["view5_3840x2160_hdrx32_lav2_full|cpu|4718592"]
+    assert orc["source"] == "oracle"
+    want, want_crc = int(orc["sum"]), orc["crc32"]
     v = inputs.View.builtin(5, 3840, 2160, antialiasing=1)
     ob = inputs.Orbit(v)
     la = inputs.LATable(ob)
@@ -72,5 +78,6 @@ def test_c3_full_size_row_tiled_over_a_group(native_libs, world):
             assert g.Sync() == 0
             assert int(out[:v.height, :v.width].astype(np.uint64).sum()) == want
             assert red.Sum == want
+            assert "%08x" % (zlib.crc32(np.ascontiguousarray(out[:v.height, :v.width]).astype("<u4").tobytes()) & 0xFFFFFFFF) == want_crc
     finally:
         g.close()
