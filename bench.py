@@ -44,6 +44,7 @@ PEAK_FP32_VECTOR_TFLOPS = 157.3
 PEAK_FP64_VECTOR_TFLOPS = 78.6
 PEAK_HBM_GBS = 8000.0
 FLOP_PER_BLA_JUMP = 22
+TRAFFIC_FILE = "r05_traffic.json"  # profiles/: PMC passes of THIS round's kernels (tools/profile_round5.sh + _collect.py)
 
 WORKLOADS = {  # name: (view, width, height, tag in config.workload, dominant kernel)
     "c3_lav2": (5, 3840, 2160, "hdrx32_lav2_full", "k_lav2_hdr32_fast"),
@@ -306,6 +307,7 @@ def main():
     t_inputs = time.time() - t0
     args.view, args.width, args.height, args.parity = inp["view_id"], inp["width"], inp["height"], inp["parity"]
     is_lav2, is2x32, is_scaled, is64 = inp["is_lav2"], inp["is2x32"], inp["is_scaled"], inp["is64"]
+    inp_default_parity = "cpu_gpustage" if wl == "c4_hdr64" else "cpu"  # (the parity the profiles were taken in)
     view, orbit, la, orbit2, la2, bla = inp["view"], inp["orbit"], inp["la"], inp["orbit2"], inp["la2"], inp["bla"]
     AA, W, H, n_iter = inp["AA"], inp["W"], inp["H"], inp["n_iter"]
     coords_arr, coords = inp["coords_arr"], inp["coords"]
@@ -607,6 +609,7 @@ def main():
         def line(dt, what):
             return {"value": round(len(rows) * W / dt / 1e6, 6), "unit": "Mpix/s", "cores": threads,
                     "cpu_model": model, "nproc": nproc, "kind": "port", "what": what,
+                    "compiler": _oracle.compiler_and_flags(),
                     "sample": "%d of %d rows of the same %dx%d frame (rows spread evenly), %.1f s" %
                               (len(rows), H, W, H, dt)}
 
@@ -628,22 +631,25 @@ def main():
         # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (collected in separate
         # --pmc runs by tools/pmc_passes.sh); null for workloads that have not been profiled.
         key = "view%d_%dx%d_%s" % (args.view, W, H, wl_tag)
-        for tf in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
-            try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
-                if key in tj and not distributed and args.parity == "cpu" and args.iter_cap == 0:
-                    traffic = tj[key]["traffic_bytes"]
-                    break
-            except (OSError, ValueError, KeyError):
-                pass
+        # this round's file only: a workload that has not been profiled with the kernels of this round prints null, never
+        # another round's number
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))
+            if key in tj and not distributed and args.parity == inp_default_parity and args.iter_cap == 0:
+                traffic = tj[key]["traffic_bytes"]
+        except (OSError, ValueError, KeyError):
+            pass
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = W * H * args.steps / elapsed / 1e6
+        flops_issued = None
         if is2x32:
-            # binary32 operations of the double-float sequences: product = 12 flop (1 mul, 4 fma, 3 add),
-            # sum = 20 flop; AT iteration = 8 products + 5 sums, perturbation step = 12 products + 10 sums + 6 exact
-            # power-of-two scalings (another 6 products), LA step = 22 products + 12 sums.
-            flops = at_iters * 196.0 + perturb_steps * 416.0 + la_steps * 504.0
+            # SURVEY.md 8(d)'s ALGORITHMIC count, the same for every numeric type: AT iteration 10, perturbation step 18, LA step
+            # 40 flop.  Beside it (frac_issued_ops) the binary32 operations the double-float sequences issue for them (DESIGN.md
+            # 4.4): product = 12 flop (1 mul, 4 fma, 3 add), sum = 20 flop; AT iteration = 8 products + 5 sums, perturbation
+            # step = 12 products + 10 sums + 6 exact power-of-two scalings (another 6 products), LA step = 22 products + 12 sums.
+            flops = at_iters * 10.0 + perturb_steps * FLOP_PER_STEP + la_steps * 40.0
+            flops_issued = at_iters * 196.0 + perturb_steps * 416.0 + la_steps * 504.0
         elif is64:
             # HDRFloat<double>: FP64 operations; AT iteration = 5 mul + 5 add (z*z + c on bare mantissas + the norm),
             # perturbation step = 18, LA step = 2 complex mul-adds + 2 norms = 40
@@ -662,6 +668,10 @@ def main():
         achieved = flops / (avg_kernel_ms * 1e-3) / 1e12
         roof = {"bound": "valu", "achieved": round(achieved, 4), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 5), "traffic": traffic}
+        if flops_issued is not None:
+            roof["frac_issued_ops"] = round(flops_issued / (avg_kernel_ms * 1e-3) / 1e12 / peak, 5)
+            roof["what"] = ("frac = algorithmic flop (SURVEY 8(d): AT 10 / step 18 / LA step 40) / kernel time / FP32 vector peak; "
+                            "frac_issued_ops = the binary32 operations of the double-float sequences that carry them out")
         if wl == "c5_bla":
             # C5 is priced against HBM: achieved = ALGORITHMIC bytes per launch (compulsory traffic: the
             # prepared orbit once, the table once, the iteration buffer written once) / kernel time against 8 TB/s, with the

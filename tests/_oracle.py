@@ -33,6 +33,12 @@ def build():
             raise RuntimeError("oracle/liboracle.so is missing or stale and FS_NO_BUILD=1 forbids compiling")
         _build._run(["make", "-C", ORACLE_DIR, "-B", "all"])
         _build._write_stamp(LIB, d)
+        try:  # what built it, for bench.py's cpu_baseline line (read back there: a timed process spawns nothing)
+            ver = _build._run(["g++", "--version"]).splitlines()[0].strip()
+        except Exception:
+            ver = "g++ (version unknown)"
+        with open(LIB + ".compiler", "w") as f:
+            f.write(ver + "\n")
     # the golden-CRC pin needs the reference's WPngImage/lodepng sources: only buildable where /root/reference is
     pin_srcs = [os.path.join(ORACLE_DIR, "png_pin.cpp"), os.path.join(ORACLE_DIR, "Makefile")]
     d = _build._digest(pin_srcs, ["pin"])
@@ -94,6 +100,23 @@ def lib():
         l.orc_set_row_step.argtypes = [u32]
         _lib = l
     return _lib
+
+
+def compiler_and_flags():
+    """Compiler and flags the oracle library was built with (oracle/Makefile: the reference's Linux release flags, -O3 and no
+    -march, build_linux.sh:20-23), for the cpu_baseline line."""
+    flags = "-O3 -std=c++17 -ffp-contract=off -fPIC -pthread"
+    try:
+        for ln in open(os.path.join(ORACLE_DIR, "Makefile")):
+            if ln.startswith("CXXFLAGS"):
+                flags = ln.split("=", 1)[1].strip()
+    except OSError:
+        pass
+    try:
+        ver = open(LIB + ".compiler").read().strip()
+    except OSError:
+        ver = "g++"
+    return "%s %s" % (ver, flags)
 
 
 def set_row_step(step):

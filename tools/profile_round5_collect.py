@@ -17,7 +17,7 @@ import bench  # noqa: E402
 
 # the instantiation the TIMED frames launch (the step-counting launch of every run is another instantiation: kStats = true)
 KERNEL = {"c3_lav2": "k_lav2_hdr32_fast<0, false, true, false, false", "c2_po": "k_perturb_scalar<float, false, false, false",
-          "c5_bla": "k_perturb_scalar<float, true, false, false, true", "c4_hdr64": "k_lav2_lit<double, 0, false",
+          "c5_bla": "k_bla_hdr32_fast", "c4_hdr64": "k_lav2_lit<double, 0, false",
           "c4_2x32": "k_lav2_2x32<0, false", "c4_scaled": "k_scaled_hdr32_fast<false>"}
 
 
