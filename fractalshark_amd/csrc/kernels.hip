@@ -481,6 +481,28 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
 #define FS_STEP_BOUND(NW_, T, V, EB)                                                                                \
     const float mx_##T = __builtin_fmaxf(__builtin_fabsf(NW_.x), __builtin_fabsf(NW_.y));                           \
     V |= __builtin_amdgcn_ballot_w64(__float_as_int(mx_##T) + Esh > __float_as_int(EB));
+// One scaled step with its acceptance tests, and the per-lane entry load of the runs whose lanes sit at different orbit
+// positions: shared by k_lav2_hdr32_fast and the perturbation-only float path of k_perturb_scalar (one definition; round 4 had
+// two identical copies).  Names from the enclosing scope as listed above, plus lane_off / zp for the load.
+#define FS_SCALED_STEP(W_, Z_, NW_, NZ_, T, V, FULL, AFTER_ARITH, EX, EY, EB)                                       \
+    const f2 s_##T = __builtin_elementwise_fma(W_, sE2, Z_);                                                        \
+    const f2 pa_##T = W_.xx * s_##T;                                                                                \
+    const f2 pb_##T = W_.yy * s_##T.yx;                                                                             \
+    f2 p_##T;                                                                                                       \
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(p_##T) : "v"(pa_##T), "v"(pb_##T));              \
+    NW_ = p_##T + dcs;                                                                                              \
+    float mx_##T = __builtin_fmaxf(__builtin_fabsf(NW_.x), __builtin_fabsf(NW_.y));                                 \
+    AFTER_ARITH;                                                                                                    \
+    NZ_ = (f2){EX, EY};                                                                                             \
+    V |= __builtin_amdgcn_ballot_w64(__float_as_int(mx_##T) + Esh > __float_as_int(EB));                            \
+    if (FULL) {                                                                                                     \
+        FS_STEP_FLOOR(NW_, V)                                                                                       \
+        V |= __builtin_amdgcn_ballot_w64(!(mx_##T < FS_FL_HIGH_TRIP));                                              \
+    } else {                                                                                                        \
+        FS_STEP_FLOOR_FIRST(NW_, V)                                                                                 \
+    }
+#define FS_SCALED_LOAD(OFS, T, PIN)                                                                                 \
+    asm volatile("global_load_dwordx3 %0, %2, %3 offset:" OFS : "=v"(ent_##T), "+v"(PIN) : "v"(lane_off), "s"(zp));
 // The untested body.  Registers are named (the halves of a packed pair have no operand syntax): the state w in v[48:49];
 // four state pairs v[48:55] in rotation (a trip = two steps: start state, first step, and the next trip's two while the
 // verdict is pending); the entries in s[36:67].  A packed result cannot be read by the next instruction, so each trip's
@@ -1353,23 +1375,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
                         // One step from (W_, Z_) into (NW_, NZ_); V accumulates the lanes that fail a test.
                         // AFTER_ARITH is the statement that waits for the entry (tied to the step's results so that it stays
                         // behind the arithmetic); EX / EY / EB name the arrival entry's 2Z and bound.
-#define FS_SCALED_STEP(W_, Z_, NW_, NZ_, T, V, FULL, AFTER_ARITH, EX, EY, EB)                                       \
-    const f2 s_##T = __builtin_elementwise_fma(W_, sE2, Z_);                                                        \
-    const f2 pa_##T = W_.xx * s_##T;                                                                                \
-    const f2 pb_##T = W_.yy * s_##T.yx;                                                                             \
-    f2 p_##T;                                                                                                       \
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(p_##T) : "v"(pa_##T), "v"(pb_##T));              \
-    NW_ = p_##T + dcs;                                                                                              \
-    float mx_##T = __builtin_fmaxf(__builtin_fabsf(NW_.x), __builtin_fabsf(NW_.y));                                 \
-    AFTER_ARITH;                                                                                                    \
-    NZ_ = (f2){EX, EY};                                                                                             \
-    V |= __builtin_amdgcn_ballot_w64(__float_as_int(mx_##T) + Esh > __float_as_int(EB));                            \
-    if (FULL) {                                                                                                     \
-        FS_STEP_FLOOR(NW_, V)                                                                                       \
-        V |= __builtin_amdgcn_ballot_w64(!(mx_##T < FS_FL_HIGH_TRIP));                                              \
-    } else {                                                                                                        \
-        FS_STEP_FLOOR_FIRST(NW_, V)                                                                                 \
-    }
                         // Two steps are tested together and the state ping-pongs between two register sets over two such
                         // trips, so neither the back-edge nor the roll-back of a failed trip needs a register copy: a
                         // trip that contains a failing step is dropped as a whole and its first step goes to the
@@ -1675,8 +1680,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
                             // front and arrive in order
                             const uint32_t lane_off = (ref + 1) * 16u;
                             const float4 *zp = zs;
-#define FS_SCALED_LOAD(OFS, T, PIN)                                                                                 \
-    asm volatile("global_load_dwordx3 %0, %2, %3 offset:" OFS : "=v"(ent_##T), "+v"(PIN) : "v"(lane_off), "s"(zp));
                             f3 ent_a, ent_b, ent_c_, ent_d;
                             for (;;) {
                                 FS_SCALED_LOAD("0", a, w0)
@@ -1717,11 +1720,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
                             }
                             // a run that ends in its first trip leaves the loads of the second in flight: they land before anything else happens
                             asm volatile("s_waitcnt vmcnt(0) ; scaled run, loop exit" ::"v"(ent_a), "v"(ent_b), "v"(ent_c_), "v"(ent_d));
-#undef FS_SCALED_LOAD
                         }
 #undef FS_TRIP_FAILED
 #undef FS_TRIP_FAILED_NB
-#undef FS_SCALED_STEP
                         FS_CYC(cyc_body += __builtin_readcyclecounter() - cyc_t2);
                         if (fl_redo) {
                             // the same run again from its start state: dz's mantissas come back from where they were parked
@@ -2838,23 +2839,6 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                     if (__builtin_amdgcn_ballot_w64(!start_ok) != 0ull || run_len == 0u)
                         break;
                     const f2 sE2 = {sE, sE};
-#define FS_SCALED_STEP(W_, Z_, NW_, NZ_, T, V, FULL, AFTER_ARITH, EX, EY, EB)                                       \
-    const f2 s_##T = __builtin_elementwise_fma(W_, sE2, Z_);                                                        \
-    const f2 pa_##T = W_.xx * s_##T;                                                                                \
-    const f2 pb_##T = W_.yy * s_##T.yx;                                                                             \
-    f2 p_##T;                                                                                                       \
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(p_##T) : "v"(pa_##T), "v"(pb_##T));              \
-    NW_ = p_##T + dcs;                                                                                              \
-    float mx_##T = __builtin_fmaxf(__builtin_fabsf(NW_.x), __builtin_fabsf(NW_.y));                                 \
-    AFTER_ARITH;                                                                                                    \
-    NZ_ = (f2){EX, EY};                                                                                             \
-    V |= __builtin_amdgcn_ballot_w64(__float_as_int(mx_##T) + Esh > __float_as_int(EB));                            \
-    if (FULL) {                                                                                                     \
-        FS_STEP_FLOOR(NW_, V)                                                                                       \
-        V |= __builtin_amdgcn_ballot_w64(!(mx_##T < FS_FL_HIGH_TRIP));                                              \
-    } else {                                                                                                        \
-        FS_STEP_FLOOR_FIRST(NW_, V)                                                                                 \
-    }
                     // (keeping the first step of a failed trip, as k_lav2_hdr32_fast does, loses here: the exit conversion drops
                     // the cached orbit value the careful step would reuse; measured 437 -> 453 ms on C2)
                     f2 w0 = dzs * __builtin_amdgcn_ldexpf(1.0f, -kScaleShift), z0 = {e0.x, e0.y}, w2, z2, wO;
@@ -2996,8 +2980,6 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                     } else {
                         const uint32_t lane_off = (RefIteration + 1) * 16u;
                         const float4 *zp = zs;
-#define FS_SCALED_LOAD(OFS, T, PIN)                                                                                 \
-    asm volatile("global_load_dwordx3 %0, %2, %3 offset:" OFS : "=v"(ent_##T), "+v"(PIN) : "v"(lane_off), "s"(zp));
                         f3 ent_a, ent_b, ent_c_, ent_d;
                         for (;;) {
                             FS_SCALED_LOAD("0", a, w0)
@@ -3039,9 +3021,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                         }
                         // a run that ends in its first trip leaves the loads of the second in flight: they land before anything else happens
                         asm volatile("s_waitcnt vmcnt(0) ; scaled run, loop exit" ::"v"(ent_a), "v"(ent_b), "v"(ent_c_), "v"(ent_d));
-#undef FS_SCALED_LOAD
                     }
-#undef FS_SCALED_STEP
                     if (fl_redo) {
                         fl_per_trip = true;
                         continue;
@@ -3904,7 +3884,8 @@ void fsk_perturb_scalar_hdr32(const FsBlaArgs32 &A, bool use_bla, bool stats, in
 {
     // the default BLA frame: the hand-written kernel (kernels_bla_fast.hip).  The compiled kernel below keeps the step-counting
     // launches, the 64-bit counters, the refill variant, probes, and variants 1 / 2 (A/B references).
-    if (use_bla && !stats && A.hrec != nullptr && A.frame.wide == 0u && variant == FS_VARIANT_TUNED && A.probe_out == nullptr &&
+    if (use_bla && !stats && A.hrec != nullptr && A.frame.wide == 0u && (variant & FS_VARIANT_BASE_MASK) == FS_VARIANT_TUNED &&
+        (variant & FS_VARIANT_FLAG_REFILL) == 0 && A.probe_out == nullptr &&
         A.tile_order == nullptr && A.frame.iter_u64 == 0u) {
         fsk_bla_hdr32_fast(A, s);
         return;

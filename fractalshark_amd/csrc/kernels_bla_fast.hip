@@ -30,6 +30,8 @@
 // inputs, not of the kernel), the 64-bit counting instantiation, the refill variant, and variant 2 (A/B reference).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
+#include <cstring>
 
 #include "../../include/fs_layout.h"
 #include "hdr_math.hpp"
@@ -279,9 +281,11 @@ __device__ __forceinline__ bool step_literal(const FsBlaArgsT<float> &A, PixelSt
 // others have finished theirs.
 #ifdef FS_BLA_FAST_PROBE
 #define FS_CNT(R) "s_add_u32 " R ", " R ", 1\n\t"
+#define FS_LANE_STEP "v_add_u32_e32 v48, 1, v48\n\t" /* steps this lane has taken (written out INSTEAD of the count) */
 #define FS_CNT_ZERO "s_mov_b32 s58, 0\n\ts_mov_b32 s59, 0\n\ts_mov_b32 s60, 0\n\ts_mov_b32 s61, 0\n\ts_mov_b32 s62, 0\n\ts_mov_b32 s63, 0\n\ts_mov_b32 s64, 0\n\t"
 #else
 #define FS_CNT(R) ""
+#define FS_LANE_STEP ""
 #define FS_CNT_ZERO ""
 #endif
 // Q[(m - 1) / 4] into v[22:33] for the lanes that have just arrived at an index m = 1 (mod 4) -- the only ones whose next
@@ -453,7 +457,7 @@ __device__ __forceinline__ bool step_literal(const FsBlaArgsT<float> &A, PixelSt
     "s_mov_b64 exec, %[R]\n\t"                                                                                          \
     "s_waitcnt vmcnt(0)\n\t"                    /* (a requested Q that no lookup consumed) */                           \
     "s_mov_b32 s57, 0\n\t"                                                                                              \
-    "v_lshl_add_u32 v16, v8, 4, 16\n\t" FS_CNT("s62")                                                                                 \
+    "v_lshl_add_u32 v16, v8, 4, 16\n\t" FS_CNT("s62") FS_LANE_STEP                                                                                 \
     "global_load_dwordx4 v[18:21], v16, %[zb]\n\t" /* the entry the step arrives at: re, im, exponent, quiet bound */    \
     "v_add_u32_e32 v17, 1, v14\n\t"                                                                                     \
     "v_max3_i32 v42, v17, v2, v3\n\t"           /* T = 2Z + dz under eT */                                              \
@@ -659,6 +663,7 @@ __global__ void __launch_bounds__(256) k_bla_hdr32_fast(FsBlaArgsT<float> A)
     uint32_t mode = 0;
 #ifdef FS_BLA_FAST_PROBE
     uint32_t n_enter = 0, n_slow_step = 0, n_slow_lk = 0; // (measurement build: how often the statement is left, per wave)
+    uint32_t lane_steps = 0;
     uint32_t pc[7] = {0, 0, 0, 0, 0, 0, 0}, pacc[7] = {0, 0, 0, 0, 0, 0, 0}; // passes: lookup, pre-test, ladder round, jump, step, step with z, rebase
 #endif
     while (R != 0ull) {
@@ -669,7 +674,7 @@ __global__ void __launch_bounds__(256) k_bla_hdr32_fast(FsBlaArgsT<float> A)
                        "+{v7}"(cYe), "+{v8}"(ref), "+{v9}"(iter), "+{v10}"(dnm), "+{v11}"(dne), "+{v12}"(Zre), "+{v13}"(Zim),
                        "+{v14}"(Ze), "+{v15}"(cemin), [R] "+s"(R), [J] "+s"(J), [st] "=&s"(st), [M] "=&s"(M)
 #ifdef FS_BLA_FAST_PROBE
-                       , "={s58}"(pc[0]), "={s59}"(pc[1]), "={s60}"(pc[2]), "={s61}"(pc[3]), "={s62}"(pc[4]), "={s63}"(pc[5]), "={s64}"(pc[6])
+                       , "+{v48}"(lane_steps), "={s58}"(pc[0]), "={s59}"(pc[1]), "={s60}"(pc[2]), "={s61}"(pc[3]), "={s62}"(pc[4]), "={s63}"(pc[5]), "={s64}"(pc[6])
 #endif
                      : [mode] "s"(__builtin_amdgcn_readfirstlane((int)mode)), [zb] "s"(A.zb), [hq] "s"(A.hq), [hlad] "s"(A.hlad), [hrec] "s"(A.hrec),
                        [n] "s"(n_iterations), [cm1] "s"(count - 1u)
@@ -717,6 +722,10 @@ __global__ void __launch_bounds__(256) k_bla_hdr32_fast(FsBlaArgsT<float> A)
             Zre = z.x, Zim = z.y, Ze = __float_as_int(z.z);
         }
     }
+#ifdef FS_BLA_FAST_PROBE
+    if (A.probe_pitch == 0x57E9u) // (probe switch FSMI355_BLA_STEPS_OUT=1: the buffer receives the STEPS each pixel took)
+        iter = lane_steps;
+#endif
     if (have)
         store_iter(A.out, A.frame, L, X, iter);
 #ifdef FS_BLA_FAST_PROBE
@@ -780,7 +789,12 @@ void fsk_bla_make_heap(const FsBlaRec *rec, const int4 *lad, const long long *km
     hipLaunchKernelGGL(k_bla_make_zb, dim3((nz + 255u) / 256u), dim3(256), 0, s, zref, orbit_count, zb, nz);
 }
 
-void fsk_bla_hdr32_fast(const FsBlaArgsT<float> &A, hipStream_t s)
+void fsk_bla_hdr32_fast(const FsBlaArgsT<float> &A_in, hipStream_t s)
 {
+    FsBlaArgsT<float> A = A_in;
+#ifdef FS_BLA_FAST_PROBE
+    if (getenv("FSMI355_BLA_STEPS_OUT"))
+        A.probe_pitch = 0x57E9u;
+#endif
     hipLaunchKernelGGL(k_bla_hdr32_fast, dim3((A.frame.width + 31) / 32, (A.frame.local_rows + 7) / 8, 1), dim3(256), 0, s, A);
 }
