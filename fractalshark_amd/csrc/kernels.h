@@ -17,7 +17,7 @@ enum { FS_VARIANT_TUNED = 0, FS_VARIANT_LITERAL = 1, FS_VARIANT_TUNED_NOSCALE = 
 // ... ORed with the A/B flags of fs_set_kernel_variant (include/fsmi355.h): orbit entries of the scaled runs through LDS
 // (k_lav2_hdr32_fast<kLds>), persistent lane-refilling launch of the BLA kernel (k_perturb_scalar<kRefill>)
 enum { FS_VARIANT_FLAG_LDS_ORBIT = 0x100, FS_VARIANT_FLAG_REFILL = 0x200, FS_VARIANT_FLAG_WIDE = 0x400,
-       FS_VARIANT_FLAG_NATURAL_ORDER = 0x800 };
+       FS_VARIANT_FLAG_NATURAL_ORDER = 0x800, FS_VARIANT_FLAG_BLA_POOL = 0x1000 };
 
 // Frame geometry + the row-band layout of the local iteration buffer.
 struct FsFrame {
@@ -366,7 +366,7 @@ uint64_t fsk_bla_heap_positions(const uint64_t *epl, int n_levels);
 void fsk_bla_make_heap(const FsBlaRec *rec, const int4 *lad, const long long *kmax, uint32_t n_kmax, const uint32_t *level_off,
                        const uint64_t *epl, int n_levels, int32_t lm2, const float4 *zref, uint32_t orbit_count, FsBlaRec *hrec,
                        int4 *hlad, int4 *hq, float4 *zb, hipStream_t s);
-void fsk_bla_hdr32_fast(const FsBlaArgs32 &A, hipStream_t s);
+void fsk_bla_hdr32_fast(const FsBlaArgs32 &A, bool pool, hipStream_t s);
 void fsk_perturb_scalar_hdr64(const FsBlaArgsT<double> &A, bool use_bla, bool stats, int variant, hipStream_t s);
 void fsk_perturb_bla_f64(const FsBlaArgsF64 &A, bool use_bla, bool stats, hipStream_t s);
 void fsk_direct_hdr32(const FsDirectHdrArgsT<float> &A, fs::hreal<float> minX, fs::hreal<float> dx, bool stats, hipStream_t s);

@@ -3887,7 +3887,7 @@ void fsk_perturb_scalar_hdr32(const FsBlaArgs32 &A, bool use_bla, bool stats, in
     if (use_bla && !stats && A.hrec != nullptr && A.frame.wide == 0u && (variant & FS_VARIANT_BASE_MASK) == FS_VARIANT_TUNED &&
         (variant & FS_VARIANT_FLAG_REFILL) == 0 && A.probe_out == nullptr &&
         A.tile_order == nullptr && A.frame.iter_u64 == 0u) {
-        fsk_bla_hdr32_fast(A, s);
+        fsk_bla_hdr32_fast(A, (variant & FS_VARIANT_FLAG_BLA_POOL) != 0, s);
         return;
     }
     launch_perturb_scalar<float>(A, use_bla, stats, variant, s);

@@ -617,7 +617,13 @@ __device__ __forceinline__ bool step_literal(const FsBlaArgsT<float> &A, PixelSt
     "s_nop 0\n"                                                                                             \
     ".Lbf_next_%=:\n\t"                                                                                                 \
     "s_cmp_lg_u64 %[R], 0\n\t"                                                                                          \
-    "s_cbranch_scc1 .Lbf_top_%=\n\t"                                                                                    \
+    "s_cbranch_scc0 .Lbf_done_%=\n\t"                                                                                   \
+    "s_add_u32 %[bud], %[bud], -1\n\t"          /* trips until the workgroup's next checkpoint (pooling) */             \
+    "s_cmp_eq_u32 %[bud], 0\n\t"                                                                                        \
+    "s_cbranch_scc0 .Lbf_top_%=\n\t"                                                                                    \
+    "s_mov_b32 %[st], 3\n\t"                                                                                            \
+    "s_branch .Lbf_end_%=\n"                                                                                             \
+    ".Lbf_done_%=:\n\t"                                                                                                 \
     "s_mov_b32 %[st], 0\n\t"                                                                                            \
     "s_branch .Lbf_end_%=\n"                                                                                            \
     ".Lbf_slowstep_%=:\n\t"                                                                                             \
@@ -630,8 +636,25 @@ __device__ __forceinline__ bool step_literal(const FsBlaArgsT<float> &A, PixelSt
     "s_waitcnt vmcnt(0)\n\t"                    /* nothing stays in flight into registers the compiler owns again */    \
     "s_mov_b64 exec, s[48:49]"
 
-__global__ void __launch_bounds__(256) k_bla_hdr32_fast(FsBlaArgsT<float> A)
+__device__ __forceinline__ uint64_t uniform64(uint64_t v)
 {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+           (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+
+// kPool: the running pixels of a workgroup's four waves (four 8 x 8 tiles side by side) are re-packed into as few waves as possible.
+// A wave runs until its slowest pixel is done -- 1038 trips on C5 against a mean of 741 steps per pixel -- and a pass costs the
+// same whatever EXEC holds (tools/microbench/exec_mask_rate.hip), so the tail of every tile runs at a fraction of the lanes.
+// Every kPoolEvery trips the waves of a workgroup meet: finished pixels are stored, the running lanes are counted, and when
+// they fit in fewer waves than hold them, every running lane writes its 17 words of state (the statement's sixteen registers and
+// the pixel it belongs to) to LDS at its rank and the lowest waves read them back densely; waves left without a lane end.
+constexpr uint32_t kPoolEvery = 32;
+constexpr uint32_t kPoolWords = 17;
+
+template <bool kPool> __global__ void __launch_bounds__(256) k_bla_hdr32_fast(FsBlaArgsT<float> A)
+{
+    __shared__ uint32_t s_cnt[kPool ? 8 : 1];
+    __shared__ uint32_t s_slot[kPool ? 256 * kPoolWords : 1];
     const uint32_t count = A.orbit_count;
     const uint32_t n_iterations = A.n_iterations;
     uint32_t X, L;
@@ -661,18 +684,26 @@ __global__ void __launch_bounds__(256) k_bla_hdr32_fast(FsBlaArgsT<float> A)
     uint64_t R = __builtin_amdgcn_ballot_w64(have && n_iterations != 0u);
     uint64_t J = 0;
     uint32_t mode = 0;
+    uint32_t budget = kPool ? kPoolEvery : 0x7FFFFFFFu;
+    uint32_t pix = threadIdx.x; // which pixel of the workgroup's 32 x 8 block this lane's state belongs to
+    bool mine = have;           // ... and whether it holds one at all
+    uint32_t round = 0;
 #ifdef FS_BLA_FAST_PROBE
     uint32_t n_enter = 0, n_slow_step = 0, n_slow_lk = 0; // (measurement build: how often the statement is left, per wave)
     uint32_t lane_steps = 0;
     uint32_t pc[7] = {0, 0, 0, 0, 0, 0, 0}, pacc[7] = {0, 0, 0, 0, 0, 0, 0}; // passes: lookup, pre-test, ladder round, jump, step, step with z, rebase
 #endif
-    while (R != 0ull) {
-        uint32_t st;
-        uint64_t M;
+    while (kPool || R != 0ull) {
+        uint32_t st = 0;
+        uint64_t M = 0;
+        // (scalar operands of the statement must be provably uniform where they enter it)
+        R = uniform64(R), J = uniform64(J);
+        budget = (uint32_t)__builtin_amdgcn_readfirstlane((int)budget);
+        if (!kPool || R != 0ull)
         asm volatile(FS_BLA_ASM
                      : "+{v0}"(dXm), "+{v1}"(dYm), "+{v2}"(dXe), "+{v3}"(dYe), "+{v4}"(cXm), "+{v5}"(cYm), "+{v6}"(cXe),
                        "+{v7}"(cYe), "+{v8}"(ref), "+{v9}"(iter), "+{v10}"(dnm), "+{v11}"(dne), "+{v12}"(Zre), "+{v13}"(Zim),
-                       "+{v14}"(Ze), "+{v15}"(cemin), [R] "+s"(R), [J] "+s"(J), [st] "=&s"(st), [M] "=&s"(M)
+                       "+{v14}"(Ze), "+{v15}"(cemin), [R] "+s"(R), [J] "+s"(J), [st] "=&s"(st), [M] "=&s"(M), [bud] "+s"(budget)
 #ifdef FS_BLA_FAST_PROBE
                        , "+{v48}"(lane_steps), "={s58}"(pc[0]), "={s59}"(pc[1]), "={s60}"(pc[2]), "={s61}"(pc[3]), "={s62}"(pc[4]), "={s63}"(pc[5]), "={s64}"(pc[6])
 #endif
@@ -683,8 +714,8 @@ __global__ void __launch_bounds__(256) k_bla_hdr32_fast(FsBlaArgsT<float> A)
                        "v46", "v47", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48",
                        "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "vcc", "scc", "memory");
         st = (uint32_t)__builtin_amdgcn_readfirstlane((int)st);
-        R = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(R >> 32)) << 32) |
-            (uint32_t)__builtin_amdgcn_readfirstlane((int)R);
+        R = uniform64(R), J = uniform64(J);
+        budget = (uint32_t)__builtin_amdgcn_readfirstlane((int)budget);
 #ifdef FS_BLA_FAST_PROBE
         n_enter++;
         for (int i = 0; i < 7; i++)
@@ -692,10 +723,62 @@ __global__ void __launch_bounds__(256) k_bla_hdr32_fast(FsBlaArgsT<float> A)
         n_slow_step += st == 1u;
         n_slow_lk += st == 2u;
 #endif
-        if (st == 0u)
+        if constexpr (kPool) {
+            if (st == 0u || st == 3u) {
+                // ---- checkpoint of the workgroup (every wave that is still alive passes here the same number of times)
+                const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+                bool running = ((R >> lane) & 1ull) != 0ull;
+                if (mine && !running) { // this lane's pixel is finished: its count goes out, the lane is free
+                    const uint32_t px = (blockIdx.x * 4u + (pix >> 6)) * 8u + (pix & 7u), pl = blockIdx.y * 8u + ((pix & 63u) >> 3);
+                    store_iter(A.out, A.frame, pl, px, iter);
+                    mine = false;
+                }
+                uint32_t *cnt = s_cnt + ((round & 1u) << 2); // (two sets in rotation: one barrier per checkpoint suffices)
+                round++;
+                if (lane == 0u)
+                    cnt[wave] = (uint32_t)__popcll(R);
+                __syncthreads();
+                const uint32_t c0 = cnt[0], c1 = cnt[1], c2 = cnt[2], c3 = cnt[3];
+                const uint32_t total = c0 + c1 + c2 + c3;
+                if (total == 0u)
+                    break;
+                const uint32_t holding = (c0 != 0u) + (c1 != 0u) + (c2 != 0u) + (c3 != 0u), needed = (total + 63u) >> 6;
+                if (needed < holding) {
+                    const uint32_t base = (wave > 0u ? c0 : 0u) + (wave > 1u ? c1 : 0u) + (wave > 2u ? c2 : 0u);
+                    const uint32_t rank = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(R >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)R, 0u));
+                    if (running) {
+                        uint32_t *d = s_slot + rank * kPoolWords;
+                        d[0] = __float_as_uint(dXm), d[1] = __float_as_uint(dYm), d[2] = (uint32_t)dXe, d[3] = (uint32_t)dYe;
+                        d[4] = __float_as_uint(cXm), d[5] = __float_as_uint(cYm), d[6] = (uint32_t)cXe, d[7] = (uint32_t)cYe;
+                        d[8] = ref, d[9] = iter, d[10] = __float_as_uint(dnm), d[11] = (uint32_t)dne;
+                        d[12] = __float_as_uint(Zre), d[13] = __float_as_uint(Zim), d[14] = (uint32_t)Ze, d[15] = (uint32_t)cemin;
+                        d[16] = pix;
+                    }
+                    __syncthreads();
+                    running = threadIdx.x < total;
+                    if (running) {
+                        const uint32_t *q = s_slot + threadIdx.x * kPoolWords;
+                        dXm = __uint_as_float(q[0]), dYm = __uint_as_float(q[1]), dXe = (int)q[2], dYe = (int)q[3];
+                        cXm = __uint_as_float(q[4]), cYm = __uint_as_float(q[5]), cXe = (int)q[6], cYe = (int)q[7];
+                        ref = q[8], iter = q[9], dnm = __uint_as_float(q[10]), dne = (int)q[11];
+                        Zre = __uint_as_float(q[12]), Zim = __uint_as_float(q[13]), Ze = (int)q[14], cemin = (int)q[15];
+                        pix = q[16];
+                    }
+                    mine = running;
+                    R = __builtin_amdgcn_ballot_w64(running);
+                    __syncthreads(); // (the slots are free for the next compaction)
+                    // (a wave left without a lane stays and keeps attending the checkpoints -- it waits at the barrier, which
+                    // costs nothing -- until the whole workgroup is done: letting it end here made the frame wrong on gfx950,
+                    // although a barrier is documented to wait for the surviving waves only)
+                }
+                budget = kPoolEvery;
+                mode = 0;
+                continue;
+            }
+        } else if (st == 0u) {
             break;
-        M = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(M >> 32)) << 32) |
-            (uint32_t)__builtin_amdgcn_readfirstlane((int)M);
+        }
+        M = uniform64(M);
         const uint32_t lane = threadIdx.x & 63u;
         const bool running = ((R >> lane) & 1ull) != 0ull;
         PixelState s{hreal32{dXm, dXe}, hreal32{dYm, dYe}, hreal32{cXm, cXe}, hreal32{cYm, cYe}, hreal32{dnm, dne}, ref, iter};
@@ -726,7 +809,7 @@ __global__ void __launch_bounds__(256) k_bla_hdr32_fast(FsBlaArgsT<float> A)
     if (A.probe_pitch == 0x57E9u) // (probe switch FSMI355_BLA_STEPS_OUT=1: the buffer receives the STEPS each pixel took)
         iter = lane_steps;
 #endif
-    if (have)
+    if (!kPool && have)
         store_iter(A.out, A.frame, L, X, iter);
 #ifdef FS_BLA_FAST_PROBE
     if ((threadIdx.x & 63u) == 0u && A.stats) {
@@ -789,12 +872,20 @@ void fsk_bla_make_heap(const FsBlaRec *rec, const int4 *lad, const long long *km
     hipLaunchKernelGGL(k_bla_make_zb, dim3((nz + 255u) / 256u), dim3(256), 0, s, zref, orbit_count, zb, nz);
 }
 
-void fsk_bla_hdr32_fast(const FsBlaArgsT<float> &A_in, hipStream_t s)
+void fsk_bla_hdr32_fast(const FsBlaArgsT<float> &A_in, bool pool, hipStream_t s)
 {
     FsBlaArgsT<float> A = A_in;
 #ifdef FS_BLA_FAST_PROBE
     if (getenv("FSMI355_BLA_STEPS_OUT"))
         A.probe_pitch = 0x57E9u;
 #endif
-    hipLaunchKernelGGL(k_bla_hdr32_fast, dim3((A.frame.width + 31) / 32, (A.frame.local_rows + 7) / 8, 1), dim3(256), 0, s, A);
+    // pool (FS_VARIANT_BLA_POOL, A/B, off by default): the running pixels of a workgroup's four waves re-packed every 32 trips.
+    // Measured on C5: 140.9 against 132.6 ms at 7680x4320, 39.4 against 37.4 ms at 3840x2160 -- the passes it saves (18 % of the
+    // step passes if it were free and perfect, tools/c5_pooling_potential.py) cost less than the checkpoints and the mixed waves
+    // (lanes of four tiles at unrelated orbit phases: more lookup and jump passes per trip, fewer all-quiet steps) add.
+    const dim3 g((A.frame.width + 31) / 32, (A.frame.local_rows + 7) / 8, 1), b(256);
+    if (pool)
+        hipLaunchKernelGGL(k_bla_hdr32_fast<true>, g, b, 0, s, A);
+    else
+        hipLaunchKernelGGL(k_bla_hdr32_fast<false>, g, b, 0, s, A);
 }

@@ -2782,7 +2782,8 @@ uint32_t fs_set_kernel_variant(fs_renderer *r, int variant)
 {
     const int base = variant & FS_VARIANT_BASE_MASK, flags = variant & ~FS_VARIANT_BASE_MASK;
     if (base > FS_VARIANT_TUNED_NOSCALE ||
-        (flags & ~(FS_VARIANT_FLAG_LDS_ORBIT | FS_VARIANT_FLAG_REFILL | FS_VARIANT_FLAG_WIDE | FS_VARIANT_FLAG_NATURAL_ORDER)) != 0)
+        (flags & ~(FS_VARIANT_FLAG_LDS_ORBIT | FS_VARIANT_FLAG_REFILL | FS_VARIANT_FLAG_WIDE | FS_VARIANT_FLAG_NATURAL_ORDER |
+                   FS_VARIANT_FLAG_BLA_POOL)) != 0)
         return hipErrorInvalidValue;
     r->variant = base | flags;
     return 0;

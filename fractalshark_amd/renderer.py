@@ -341,14 +341,14 @@ class GPURenderer:
         return [float(x) for x in out]
 
     def set_kernel_variant(self, literal=False, lds_orbit=False, refill=False, wide_counters=False,
-                           natural_tile_order=False):
+                           natural_tile_order=False, bla_pool=False):
         """False / 0 (default): tuned loops; True / 1: literal transcription; 2: tuned loops without the scaled runs
         (A/B references, identical results).  lds_orbit / refill: the A/B flags FS_VARIANT_LDS_ORBIT / FS_VARIANT_REFILL
         of include/fsmi355.h (orbit entries through LDS; persistent lane-refilling BLA launch); natural_tile_order:
         FS_VARIANT_NATURAL_TILE_ORDER (no "long tiles first" in the perturbation-only launch)."""
         v = (int(literal) | (VARIANT_LDS_ORBIT if lds_orbit else 0) | (VARIANT_REFILL if refill else 0) |
              (VARIANT_WIDE_COUNTERS if wide_counters else 0) |  # wide_counters: 64-bit counting kernels at any cap (tests)
-             (VARIANT_NATURAL_TILE_ORDER if natural_tile_order else 0))
+             (VARIANT_NATURAL_TILE_ORDER if natural_tile_order else 0) | (0x1000 if bla_pool else 0))  # FS_VARIANT_BLA_POOL
         return self._lib.fs_set_kernel_variant(self._h, v)
 
     def forget_tile_costs(self):

@@ -308,9 +308,12 @@ uint32_t fs_kernel_ms_history(const fs_renderer *r, float *ms_out, uint32_t n);
  *                         at least 4096 tiles: the tiles that hold long-running pixels first (a probe launch runs every
  *                         tile's centre pixel for n_iterations / 32 steps) -- which wave renders which tile
  *                         changes no pixel.
+ *   FS_VARIANT_BLA_POOL   the hand-written HDRFloat<float> BLA kernel (the default of fs_render_bla with a table) re-packs the
+ *                         running pixels of a workgroup's four waves into as few waves as possible every 32 trips (LDS exchange).
+ *                         A/B, off by default: measured slower; results identical.
  */
 enum { FS_VARIANT_LDS_ORBIT = 0x100, FS_VARIANT_REFILL = 0x200, FS_VARIANT_WIDE_COUNTERS = 0x400,
-       FS_VARIANT_NATURAL_TILE_ORDER = 0x800 };
+       FS_VARIANT_NATURAL_TILE_ORDER = 0x800, FS_VARIANT_BLA_POOL = 0x1000 };
 uint32_t fs_set_kernel_variant(fs_renderer *r, int variant);
 /* Longest tiles first, self-recorded (this project's addition).  Every fs_render_lav2 frame of the tuned
  * HDRFloat<float> kernel records one cost word per 8 x 8 tile (its longest lane's step count); the next frame with the

@@ -114,3 +114,34 @@ def test_1080p_equals_the_compiled_kernel_and_sampled_oracle_rows(renderer, nati
         _oracle.set_row_step(1)
     for y in range(100, 1080, 270):
         assert np.array_equal(f[0][y], ref[y]), y
+
+
+@pytest.mark.parametrize("view_n,w,h,n", [(19, 320, 180, 2_000_000), (5, 100, 75, None), (19, 33, 9, 300_000)])
+def test_workgroup_pooling_variant_is_identical(renderer, native_libs, view_n, w, h, n):
+    """FS_VARIANT_BLA_POOL (A/B, off by default because it measures slower): every 32 trips the running pixels of a workgroup's
+    four waves are re-packed into as few waves as possible through LDS -- a pixel's state moves between lanes and waves and its
+    count is written by whichever lane finishes it.  Same frame as the default kernel and the oracle, ragged frames included."""
+    v = inputs.View.builtin(view_n, w, h, antialiasing=1)
+    ob = inputs.Orbit(v)
+    bla = inputs.BLATable(ob)
+    n = v.num_iterations if n is None else n
+    r = renderer
+    assert r.InitializeMemory(w, h, 1, None, 0, 0, 0, False) == 0
+    lib = r._lib
+    assert lib.fs_upload_orbit(r._h, 1, T_HDR32, 4, ob.data_ptr, ob.count, ob.count, ob.period) == 0
+    assert lib.fs_upload_bla(r._h, T_HDR32, bla.level_ptrs, bla.level_sizes, bla.num_levels, bla.lm2) == 0
+    co = v.coords_perturb(ob)
+    frames = []
+    try:
+        for pool in (False, True):
+            assert r.set_kernel_variant(0, bla_pool=pool) == 0
+            assert r.ClearMemory() == 0
+            assert lib.fs_render_bla(r._h, T_HDR32, co.ctypes.data, n) == 0
+            buf = r.new_iter_buffer()
+            assert r.RenderCurrent(n, buf) == 0
+            assert r.SyncComputeStream() == 0
+            frames.append(buf)
+    finally:
+        r.set_kernel_variant(0)
+    assert np.array_equal(frames[0], frames[1])
+    assert np.array_equal(frames[1], _oracle.bla_hdr32(v, ob, bla, n_iterations=n))

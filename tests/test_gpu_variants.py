@@ -60,7 +60,8 @@ def _bla(r, v, ob, bla, n_iter=None):
 def test_variant_selection_is_validated(renderer):
     r = renderer
     assert r._lib.fs_set_kernel_variant(r._h, 3) != 0            # no such base variant
-    assert r._lib.fs_set_kernel_variant(r._h, 0x1000) != 0       # no such flag
+    assert r._lib.fs_set_kernel_variant(r._h, 0x2000) != 0       # no such flag
+    assert r._lib.fs_set_kernel_variant(r._h, 0x1000) == 0       # FS_VARIANT_BLA_POOL
     assert r._lib.fs_set_kernel_variant(r._h, 0x800) == 0        # FS_VARIANT_NATURAL_TILE_ORDER
     assert r._lib.fs_set_kernel_variant(r._h, 0x100 | 0x200) == 0
     assert r._lib.fs_set_kernel_variant(r._h, 0) == 0
