@@ -522,7 +522,7 @@ def main():
     elapsed, kernel_ms = timed(parity)
     avg_kernel_ms = max_over_ranks(sum(kernel_ms) / len(kernel_ms))
     is_po = wl == "c2_po"
-    ordered_frames = bool(r.last_frame_tile_ordered()) if ((is_lav2 and not is64 and not is2x32) or is_po) else False
+    ordered_frames = bool(r.last_frame_tile_ordered()) if (is_lav2 or is_po) else False
     perturb_steps, at_iters, la_steps = float(st["perturb_steps"]), float(st["at_iterations"]), float(st["la_steps"])
     lane_slots = st["lane_slots"]
     b_main = state["last"]
@@ -547,6 +547,8 @@ def main():
             "value_cold": round(W * H / lat_cold_ms / 1e3, 4) if lat_cold_ms is not None else None,
             "tile_order": (("long tiles first, from the probe launch of the first frame of the view (warm: the probe's order is "
                             "reused; cold: probe launch inside the frame)") if ordered_frames and is_po
+                           else ("pixels in the order of the previous frame's counts, longest first (warm: lane s of the launch renders "
+                                 "the pixel that ranked s-th; cold: 8 x 8 tiles)") if ordered_frames and (is64 or is2x32)
                            else "longest first, recorded by the previous frame (warm)" if ordered_frames else "natural"),
             "what": "value / ms_per_step = sustained: frames back to back, frame k+1's kernel runs while frame k is gathered and "
                     "copied to the host (two buffers in rotation, copy stream, the host waits on the copy's event).  latency = one "

@@ -26,6 +26,21 @@ __device__ __forceinline__ void tile_pixel(uint32_t &X, uint32_t &L)
     L = blockIdx.y * 8u + (lane >> 3);
 }
 
+// ... or, with a recorded pixel order (kernels_order.hip): lane s of the launch takes element order[s] of the local iteration
+// buffer.  Elements in the padding (column >= width, row >= local_rows) are not pixels: the caller's bounds test drops them.
+__device__ __forceinline__ void ordered_pixel(const FsFrame &f, const uint32_t *__restrict__ order, uint32_t &X, uint32_t &L)
+{
+    const uint32_t slot = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+    const uint32_t n = f.rounded_width * ((f.local_rows + 7u) & ~7u);
+    if (slot < n) {
+        const uint32_t id = order[slot];
+        L = id / f.rounded_width;
+        X = id - L * f.rounded_width;
+    } else {
+        X = 0xFFFFFFFFu, L = 0xFFFFFFFFu;
+    }
+}
+
 // One result into the iteration buffer: OutputIterMatrix[ConvertLocToIndex(X, Y, width)] (GPU_Render.cu:73-79) for
 // IterType = uint32_t or uint64_t.  Counts are computed in 32 bits (the ABI refuses n_iterations >= 2^32).
 __device__ __forceinline__ void store_iter(uint32_t *out, const FsFrame &f, uint32_t L, uint32_t X, uint32_t v)

@@ -100,6 +100,10 @@ template <class F> struct FsLav2ArgsT {
     const uint32_t *tile_order;
     uint32_t *tile_cost;
     uint32_t tiles_x;
+    // "pixels in the order of the previous frame's counts" (kernels_order.hip; k_lav2_lit only): lane s of the launch renders the
+    // element pixel_order[s] of the local iteration buffer (row * rounded_width + column) instead of its tile's pixel; null =
+    // the tile mapping
+    const uint32_t *pixel_order;
     // IterType = uint64_t POSITIONS (the waypoint-resident kernel with 64-bit counters, fsk_lav2_seq `wide`): high words of
     // the orbit's uncompressed length, of its period and of the AT step length; la_u64 = 1: `las` holds the reference's
     // uint64_t records (fs_la_hdr32_u64 / fs_la_hdr64_u64: 64-bit StepLength / NextStageLAIndex) instead of the narrowed ones
@@ -227,6 +231,7 @@ struct FsLav2Args2x32 {
     const fs_orbit_2x32_rc *wp;
     uint32_t n_wp;
     fs_real_2x32 cxLow, cyLow;
+    const uint32_t *pixel_order; // see FsLav2ArgsT
 };
 
 // Non-HDR LAv2 (Gpu1x32 / Gpu1x64 / Gpu2x32 PerturbedLAv2*): records in the reference layouts of the selected type
@@ -367,6 +372,10 @@ void fsk_bla_make_heap(const FsBlaRec *rec, const int4 *lad, const long long *km
                        const uint64_t *epl, int n_levels, int32_t lm2, const float4 *zref, uint32_t orbit_count, FsBlaRec *hrec,
                        int4 *hlad, int4 *hq, float4 *zb, hipStream_t s);
 void fsk_bla_hdr32_fast(const FsBlaArgs32 &A, bool pool, hipStream_t s);
+// pixel order from a frame's counts (kernels_order.hip): n = elements of the iteration buffer; work = 2 n words; order = n words
+size_t fsk_pixel_order_temp_bytes(uint32_t n);
+hipError_t fsk_pixel_order_build(const uint32_t *counts, uint32_t n, uint32_t *work, uint32_t *order, void *temp, size_t temp_bytes,
+                                 hipStream_t s);
 void fsk_perturb_scalar_hdr64(const FsBlaArgsT<double> &A, bool use_bla, bool stats, int variant, hipStream_t s);
 void fsk_perturb_bla_f64(const FsBlaArgsF64 &A, bool use_bla, bool stats, hipStream_t s);
 void fsk_direct_hdr32(const FsDirectHdrArgsT<float> &A, fs::hreal<float> minX, fs::hreal<float> dx, bool stats, hipStream_t s);

@@ -285,10 +285,14 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
         return la64 ? (PosT)((const LaRec64 *)(const void *)p)->NextStageLAIndex : (PosT)p->NextStageLAIndex;
     };
     uint32_t X, L;
-    tile_pixel(X, L);
+    if (A.pixel_order)
+        ordered_pixel(A.frame, A.pixel_order, X, L);
+    else
+        tile_pixel(X, L);
     uint64_t c_at = 0, c_la = 0, c_pt = 0, c_px = 0;
-    const uint32_t Y = global_row(A.frame, L);
-    const bool live = X < A.frame.width && L < A.frame.local_rows && Y < A.frame.height;
+    const bool in_buffer = X < A.frame.width && L < A.frame.local_rows;
+    const uint32_t Y = in_buffer ? global_row(A.frame, L) : 0xFFFFFFFFu;
+    const bool live = in_buffer && Y < A.frame.height;
     if (live) {
         c_px = 1;
         const IterT n_iterations = sizeof(IterT) == 8 ? (IterT)(((uint64_t)A.n_iterations_hi << 32) | A.n_iterations)

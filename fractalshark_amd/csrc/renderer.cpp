@@ -81,6 +81,19 @@ struct fs_renderer {
     uint64_t po_order_epoch = 0, po_order_iterations = 0;
     unsigned char po_order_coords[32] = {};
     bool last_frame_ordered = false; // the last fs_render_lav2 launch used a recorded order (fs_last_frame_tile_ordered)
+    // "pixels in the order of the previous frame's counts" (kernels_order.hip; HDRFloat<double> and HDRFloat<CudaDblflt> LAv2):
+    // the order, the sort's work memory, and what the order was made from
+    uint32_t *pix_order = nullptr, *pix_work = nullptr;
+    void *pix_temp = nullptr;
+    size_t pix_cap = 0, pix_temp_bytes = 0;
+    bool pix_valid = false;
+    struct PixKey {
+        uint32_t rounded_width, local_rows, band_first, band_rows, band_stride;
+        int type_tag, mode, parity;
+        uint64_t orbit_gen, orbit_epoch, n_iterations;
+        unsigned char coords[64];
+        bool operator==(const PixKey &o) const { return memcmp(this, &o, sizeof(*this)) == 0; }
+    } pix_key{};
     bool last_launch_wide = false;   // the last render launched a 64-bit counting kernel: those carry no step counters
     bool stats_on = false;
     int variant = FS_VARIANT_TUNED;
@@ -697,6 +710,13 @@ void free_all(fs_renderer *r)
     (void)r_free(r, r->lav2_cost);
     (void)r_free(r, r->lav2_order);
     (void)r_free(r, r->lav2_sort_tmp);
+    (void)r_free(r, r->pix_order);
+    (void)r_free(r, r->pix_work);
+    (void)r_free(r, r->pix_temp);
+    r->pix_order = r->pix_work = nullptr;
+    r->pix_temp = nullptr;
+    r->pix_cap = 0;
+    r->pix_valid = false;
     r->lav2_cost = r->lav2_order = r->lav2_sort_tmp = nullptr;
     r->lav2_cost_cap = r->lav2_order_cap = 0;
     r->lav2_cost_valid = false;
@@ -1954,6 +1974,77 @@ uint32_t fs_read_bla_level(fs_renderer *r, int32_t level, void *out, uint64_t ma
 
 uint32_t fs_render_bla(fs_renderer *r, int type_tag, const void *coords, uint64_t n_iterations);
 
+// Pixel order for the LAv2 kernels that wait for their slowest lane (see kernels_order.hip).  pix_order_for: the order to launch
+// this frame with, or nullptr (first frame of a view, small frames, 64-bit buffers, A/B switch, no memory); pix_order_after: called
+// behind the frame's kernel when it ran WITHOUT an order -- sorts the buffer it has just written and keeps the result for the next
+// frame with the same key.  Frames of fewer than kPixOrderMinPixels elements are not worth the sort.
+constexpr uint64_t kPixOrderMinPixels = 1u << 20;
+
+static fs_renderer::PixKey pix_key_of(fs_renderer *r, const FsFrame &f, int type_tag, int mode, int parity, const void *coords,
+                                      size_t coords_bytes, uint64_t n_iterations)
+{
+    fs_renderer::PixKey k;
+    memset(&k, 0, sizeof(k));
+    k.rounded_width = f.rounded_width, k.local_rows = f.local_rows, k.band_first = f.band_first, k.band_rows = f.band_rows;
+    k.band_stride = f.band_stride, k.type_tag = type_tag, k.mode = mode, k.parity = parity;
+    k.orbit_gen = r->orbit_gen, k.orbit_epoch = r->orbit_epoch, k.n_iterations = n_iterations;
+    memcpy(k.coords, coords, coords_bytes < sizeof(k.coords) ? coords_bytes : sizeof(k.coords));
+    return k;
+}
+
+static bool pix_order_wanted(fs_renderer *r, const FsFrame &f)
+{
+    const uint64_t n = (uint64_t)f.rounded_width * ((f.local_rows + 7u) & ~7u);
+    return r->iter_bytes == 4 && f.wide == 0u && !r->stats_on && n >= kPixOrderMinPixels && n < 0x7FFFFFFFull &&
+           (r->variant & FS_VARIANT_FLAG_NATURAL_ORDER) == 0 && (r->variant & FS_VARIANT_BASE_MASK) == FS_VARIANT_TUNED;
+}
+
+static const uint32_t *pix_order_for(fs_renderer *r, const FsFrame &f, const fs_renderer::PixKey &key)
+{
+    r->last_frame_ordered = false;
+    if (!pix_order_wanted(r, f) || !r->pix_valid || !(r->pix_key == key))
+        return nullptr;
+    r->last_frame_ordered = true;
+    return r->pix_order;
+}
+
+static void pix_order_after(fs_renderer *r, const FsFrame &f, const fs_renderer::PixKey &key, bool frame_was_ordered)
+{
+    if (frame_was_ordered || !pix_order_wanted(r, f))
+        return; // (an ordered frame's buffer equals the one the order was made from: nothing new to learn)
+    const uint32_t n = f.rounded_width * ((f.local_rows + 7u) & ~7u);
+    r->pix_valid = false;
+    if (r->pix_cap < n) {
+        (void)r_free(r, r->pix_order);
+        (void)r_free(r, r->pix_work);
+        (void)r_free(r, r->pix_temp);
+        r->pix_order = r->pix_work = nullptr;
+        r->pix_temp = nullptr;
+        r->pix_cap = 0;
+        const size_t tb = fsk_pixel_order_temp_bytes(n);
+        if (r_alloc(r, (void **)&r->pix_order, (size_t)n * sizeof(uint32_t), kFrame) != hipSuccess ||
+            r_alloc(r, (void **)&r->pix_work, (size_t)n * 2 * sizeof(uint32_t), kFrame) != hipSuccess ||
+            r_alloc(r, &r->pix_temp, tb ? tb : 16, kFrame) != hipSuccess) {
+            (void)hipGetLastError(); // no memory for it: frames keep the tile mapping
+            (void)r_free(r, r->pix_order);
+            (void)r_free(r, r->pix_work);
+            (void)r_free(r, r->pix_temp);
+            r->pix_order = r->pix_work = nullptr;
+            r->pix_temp = nullptr;
+            return;
+        }
+        r->pix_cap = n;
+        r->pix_temp_bytes = tb;
+    }
+    if (fsk_pixel_order_build((const uint32_t *)r->iters(), n, r->pix_work, r->pix_order, r->pix_temp, r->pix_temp_bytes, r->compute) !=
+        hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    r->pix_key = key;
+    r->pix_valid = true;
+}
+
 uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, const void *coords, uint64_t n_iterations)
 {
     if (uint32_t e = use_device(r))
@@ -2103,9 +2194,15 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
             memcpy(&A.cxLow, r->c_low_plain[0], sizeof(fs_real_2x32));
             memcpy(&A.cyLow, r->c_low_plain[1], sizeof(fs_real_2x32));
         }
-        TimedLaunch t(r);
-        fsk_lav2_2x32(A, mode == FS_LAV2_FULL ? FS_MODE_FULL : (mode == FS_LAV2_PO ? FS_MODE_PO : FS_MODE_LAO),
-                      r->stats_on, r->compute);
+        const fs_renderer::PixKey pk = pix_key_of(r, A.frame, type_tag, mode, 0, coords, sizeof(A.coords), n_iterations);
+        A.pixel_order = r->orbit_seq ? nullptr : pix_order_for(r, A.frame, pk);
+        {
+            TimedLaunch t(r);
+            fsk_lav2_2x32(A, mode == FS_LAV2_FULL ? FS_MODE_FULL : (mode == FS_LAV2_PO ? FS_MODE_PO : FS_MODE_LAO),
+                          r->stats_on, r->compute);
+        }
+        if (!r->orbit_seq)
+            pix_order_after(r, A.frame, pk, A.pixel_order != nullptr);
         return (uint32_t)hipGetLastError();
     }
     if (mode == FS_LAV2_PO && parity == FS_PARITY_CPU) {
@@ -2180,8 +2277,13 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
         fill_lav2<double>(r, A, coords, n_iterations, parity);
         A.zref = r->zref64;
         A.at = r->at64;
-        TimedLaunch t(r);
-        fsk_lav2_hdr64(A, kmode, r->stats_on, r->compute);
+        const fs_renderer::PixKey pk = pix_key_of(r, A.frame, type_tag, mode, parity, coords, 4 * sizeof(fs_real_hdr64), n_iterations);
+        A.pixel_order = pix_order_for(r, A.frame, pk);
+        {
+            TimedLaunch t(r);
+            fsk_lav2_hdr64(A, kmode, r->stats_on, r->compute);
+        }
+        pix_order_after(r, A.frame, pk, A.pixel_order != nullptr);
     }
     return (uint32_t)hipGetLastError();
 }
@@ -2793,6 +2895,7 @@ uint32_t fs_forget_tile_costs(fs_renderer *r)
 {
     r->lav2_cost_valid = false;
     r->po_order_valid = false;
+    r->pix_valid = false;
     return 0;
 }
 
