@@ -308,6 +308,12 @@ uint32_t fs_kernel_ms_history(const fs_renderer *r, float *ms_out, uint32_t n);
  *                         at least 4096 tiles: the tiles that hold long-running pixels first (a probe launch runs every
  *                         tile's centre pixel for n_iterations / 32 steps) -- which wave renders which tile
  *                         changes no pixel.
+ *                         The same switch keeps the HDRFloat<double> / HDRFloat<CudaDblflt> fs_render_lav2 frames in the tile
+ *                         mapping: by default, from the second frame of a view on (same geometry, row bands, orbit, coordinates,
+ *                         iteration limit, mode), lane s of the launch renders the pixel that ranked s-th by iteration count in
+ *                         the previous frame (device radix sort of the iteration buffer, once per view; frames of 2^20 elements
+ *                         and more) -- the lanes of a wave then run equally long (View 14: 107.6 -> 88.7 ms and 646 -> 553 ms) --
+ *                         which lane renders which pixel changes no pixel.
  *   FS_VARIANT_BLA_POOL   the hand-written HDRFloat<float> BLA kernel (the default of fs_render_bla with a table) re-packs the
  *                         running pixels of a workgroup's four waves into as few waves as possible every 32 trips (LDS exchange).
  *                         A/B, off by default: measured slower; results identical.
@@ -322,7 +328,8 @@ uint32_t fs_set_kernel_variant(fs_renderer *r, int variant);
  * natural order -- "cold".  The order changes which wave renders which tile, never a pixel.
  * fs_render_bla's probe order (FS_VARIANT_NATURAL_TILE_ORDER above) is kept the same way: a frame with the same geometry, row
  * bands, orbit (generation, or for generation 0 a sampled fingerprint of the entries -- RenderPerturbBLA re-uploads per call),
- * coordinates and iteration limit as the one before reuses the order and skips the probe launch; fs_forget_tile_costs drops it.
+ * coordinates and iteration limit as the one before reuses the order and skips the probe launch; fs_forget_tile_costs drops it
+ * -- and the pixel order of the HDRFloat<double> / HDRFloat<CudaDblflt> LAv2 frames (FS_VARIANT_NATURAL_TILE_ORDER above).
  * fs_last_frame_tile_ordered: 1 when the most recent fs_render_lav2 launch used a recorded order / the most recent
  * perturbation-only fs_render_bla launch reused its probe order.
  * fs_read_tile_costs: the costs the last frame recorded (row-major tiles of the LOCAL buffer, (width + 7) / 8 per row);

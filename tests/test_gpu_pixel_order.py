@@ -1,0 +1,112 @@
+"""GPU: "pixels in the order of the previous frame's counts" (csrc/kernels_order.hip) for the HDRFloat<double> and
+HDRFloat<CudaDblflt> LAv2 kernels: the second frame of a view is launched with lane s rendering the pixel that ranked s-th by
+count in the first -- a permutation of which lane renders which pixel, so every frame must be the first frame bit for bit (and
+the oracle's rows), with row bands, after a change of the inputs (the stale order is a permutation of another view's ranking:
+still every pixel exactly once), and with the A/B switch (FS_VARIANT_NATURAL_TILE_ORDER) or fs_forget_tile_costs the frames run
+in the tile mapping again."""
+import numpy as np
+import pytest
+
+import _oracle
+from fractalshark_amd import (GPURenderer, LAV2_FULL, PARITY_CPU, PARITY_CPU_GPUSTAGE, T_HDR2X32, T_HDR64, inputs)
+
+pytestmark = pytest.mark.gpu
+W = H = 1024  # 2^20 elements: the smallest frame the order is made for
+
+
+def _pairs(co):
+    return [(float(c["m"]), int(c["e"])) for c in co]
+
+
+@pytest.fixture(scope="module")
+def renderer(native_libs):
+    assert GPURenderer.TestCudaIsWorking() != 0, "no usable HIP device: the product path has no CPU fallback"
+    r = GPURenderer(0)
+    yield r
+    r.set_kernel_variant(0)
+    r.close()
+
+
+def _frame(r, co, n, T, parity):
+    assert r.ClearMemory() == 0
+    assert r.RenderPerturbLAv2(None, None, None, *co, n, T=T, Mode=LAV2_FULL, parity=parity) == 0
+    out = r.new_iter_buffer()
+    assert r.RenderCurrent(n, out) == 0
+    assert r.SyncComputeStream() == 0
+    return out, r.last_frame_tile_ordered()
+
+
+@pytest.mark.parametrize("view_n,parity,st", [(14, PARITY_CPU_GPUSTAGE, 1), (5, PARITY_CPU, 0)])
+def test_hdr64_frames_in_count_order_are_the_first_frame(renderer, native_libs, view_n, parity, st):
+    r = renderer
+    v = inputs.View.builtin(view_n, W, H, antialiasing=1)
+    ob = inputs.Orbit(v, is64=True)
+    la = inputs.LATable(ob)
+    co = _pairs(v.coords_perturb(ob))
+    n = v.num_iterations if view_n == 14 else 20000
+    assert r.InitializeMemory(W, H, 1, None, 0, 0, 0, False) == 0
+    assert r.InitializePerturb(1, ob, 0, None, la) == 0
+    assert r.forget_tile_costs() == 0
+    first, ordered0 = _frame(r, co, n, T_HDR64, parity)
+    second, ordered1 = _frame(r, co, n, T_HDR64, parity)
+    third, ordered2 = _frame(r, co, n, T_HDR64, parity)
+    assert (ordered0, ordered1, ordered2) == (False, True, True)
+    assert np.array_equal(second, first) and np.array_equal(third, first)
+    _oracle.set_row_step(255)
+    try:
+        ref = _oracle.lav2_hdr32(v, ob, la, rows=(3, H), stage_test=st, n_iterations=n)
+    finally:
+        _oracle.set_row_step(1)
+    for y in range(3, H, 255):
+        assert np.array_equal(second[y], ref[y]), y
+    # other coordinates with the same geometry: the recorded order does not match -> tile mapping, and a new order after it
+    co2 = list(co)
+    co2[2] = (co[2][0] * 0.5, co[2][1])
+    a, oa = _frame(r, co2, n, T_HDR64, parity)
+    b, ob_ = _frame(r, co2, n, T_HDR64, parity)
+    assert (oa, ob_) == (False, True) and np.array_equal(a, b)
+    # the A/B switch and fs_forget_tile_costs
+    assert r.set_kernel_variant(0, natural_tile_order=True) == 0
+    c, oc = _frame(r, co2, n, T_HDR64, parity)
+    assert r.set_kernel_variant(0) == 0
+    assert oc is False and np.array_equal(c, a)
+    assert r.forget_tile_costs() == 0
+    d, od = _frame(r, co2, n, T_HDR64, parity)
+    assert od is False and np.array_equal(d, a)
+
+
+def test_hdr64_count_order_with_row_bands(renderer, native_libs):
+    r = renderer
+    v = inputs.View.builtin(14, 2048, 1536, antialiasing=1)
+    ob = inputs.Orbit(v, is64=True)
+    la = inputs.LATable(ob)
+    co = _pairs(v.coords_perturb(ob))
+    n = v.num_iterations
+    assert r.InitializeMemory(2048, 1536, 1, None, 0, 0, 0, False) == 0
+    assert r.SetRowBands(8, 8, 16) == 0  # the second of two ranks: 768 rows x 2048 = 1.5 M elements
+    assert r.InitializePerturb(1, ob, 0, None, la) == 0
+    assert r.forget_tile_costs() == 0
+    first, o0 = _frame(r, co, n, T_HDR64, PARITY_CPU_GPUSTAGE)
+    second, o1 = _frame(r, co, n, T_HDR64, PARITY_CPU_GPUSTAGE)
+    assert (o0, o1) == (False, True)
+    assert np.array_equal(first, second)
+    ref = _oracle.lav2_hdr32(v, ob, la, rows=(8, 16), stage_test=1)
+    assert np.array_equal(second[0:8, :2048], ref[8:16, :2048])
+
+
+def test_2x32_frames_in_count_order_are_the_first_frame(renderer, native_libs):
+    r = renderer
+    v = inputs.View.builtin(14, W, H, antialiasing=1)
+    ob = inputs.Orbit(v, is64=True)
+    la = inputs.LATable(ob, use_small_exponents=True)
+    o2, la2 = inputs.Orbit2x32(ob), inputs.LATable2x32(la)
+    co = [(float(c["head"]), float(c["tail"]), int(c["e"])) for c in v.coords_perturb_2x32(o2)]
+    assert r.InitializeMemory(W, H, 1, None, 0, 0, 0, False) == 0
+    assert r.InitializePerturb(1, o2, 0, None, la2) == 0
+    assert r.forget_tile_costs() == 0
+    first, o0 = _frame(r, co, v.num_iterations, T_HDR2X32, PARITY_CPU)
+    second, o1 = _frame(r, co, v.num_iterations, T_HDR2X32, PARITY_CPU)
+    assert (o0, o1) == (False, True)
+    assert np.array_equal(first, second)
+    ref = _oracle.gpu_lav2_2x32(v, o2, la2, rows=(500, 504))
+    assert np.array_equal(second[500:504], ref[500:504])
