@@ -58,6 +58,22 @@ def defs_uses(ins):
     dst, _, src = ops.partition(",")
     d = chk.regs_of(dst)
     u = chk.regs_of(src)
+    if op.startswith("v_pk_") and "op_sel" in src:
+        # a packed operation reads, of each 64-bit source, only the halves op_sel (for the result's low half: 0 = low register)
+        # and op_sel_hi (for its high half: 1 = high register, the default) name -- `s[36:37] op_sel_hi:[1,0]` reads s36 twice
+        # and s37 not at all
+        m_lo = re.search(r"op_sel:\[([01,]+)\]", src)
+        m_hi = re.search(r"op_sel_hi:\[([01,]+)\]", src)
+        srcs = [x.strip() for x in re.split(r",\s*(?![^\[]*\])", src.split(" op_sel")[0].split(" neg_")[0]) if x.strip()]
+        lo = [int(x) for x in m_lo.group(1).split(",")] if m_lo else [0] * len(srcs)
+        hi = [int(x) for x in m_hi.group(1).split(",")] if m_hi else [1] * len(srcs)
+        u = set()
+        for k, operand in enumerate(srcs):
+            regs = sorted(chk.regs_of(operand))
+            if len(regs) == 2 and k < len(lo) and k < len(hi):
+                u |= {regs[h] for h in {lo[k], hi[k]}}
+            else:
+                u |= set(regs)
     if op.startswith(("v_readlane", "v_writelane", "v_mac", "v_fmac", "v_pk_fmac", "v_dot", "v_mfma", "v_cndmask")) or "_mov_rel" in op:
         u |= d if op.startswith(("v_writelane", "v_mac", "v_fmac", "v_pk_fmac")) else set()
     if op.startswith(("v_div_scale", "v_add_co", "v_sub_co", "v_addc_co", "v_subb_co", "v_mad_u64_u32", "v_mad_i64_i32")):
