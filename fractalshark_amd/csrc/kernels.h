@@ -397,6 +397,13 @@ template <class F> void fsk_la_src_orbit(const void *zref, uint32_t n, void *che
 template <class F> void fsk_la_src_stage(const void *P, uint32_t n, void *chebv, void *mm, uint32_t *steps, hipStream_t s);
 void fsk_scan_u32(const uint32_t *in, uint32_t *out, uint32_t n, hipStream_t s); // exclusive; out[n] = total
 template <class F> void fsk_la_first(bool stage0, const void *chebv, const void *mm, uint32_t limit, uint32_t *out, hipStream_t s);
+// stage 0, multi-threaded variant: first uncapped detection from state (bases[q], 1) for every query q; out[q] = index or ~0u
+template <class F>
+void fsk_la_first_from(const void *chebv, const uint32_t *bases, uint32_t n_queries, uint32_t limit, uint32_t *out, hipStream_t s);
+// stage-0 records from an explicit list of orbit segments seg[2k] .. seg[2k+1] (+ the stage's tail record when tail_out)
+template <class F>
+void fsk_la_records_list(const void *zref, const uint32_t *seg, uint32_t n, void *out, void *tail_out, uint32_t max_ref,
+                         hipStream_t s);
 template <class F>
 void fsk_la_next(bool stage0, const void *chebv, const void *mm, const uint32_t *pos, uint32_t limit, uint32_t period,
                  uint32_t *next, uint32_t *reach, uint32_t x_start, hipStream_t s); // also writes the chain's start mark into reach

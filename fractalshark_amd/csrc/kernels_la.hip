@@ -20,8 +20,11 @@
 //      source the golden-pinned host builder compiles too) and write the record at its rank.
 // The host (renderer.cpp, fs_build_la) keeps only the scalar decisions of LAReference.cpp (period from the prologue, the
 // low-bound rules, when the stage loop stops) and reads a few words back per stage.  Result: the table of the reference's
-// single-threaded builder, bit for bit (its multi-threaded stage-0 variant, :215-770, produces a table that depends on
-// the host's thread count; the host builder replays that one).
+// single-threaded builder, bit for bit.  Its multi-threaded stage-0 variant (CreateLAFromOrbitMT, :215-770) scans the orbit
+// in pieces -- each piece a stretch of one of the chains x -> next(x) above, begun where a worker's two uncapped trackers
+// first detect a period (k_la_first_from) and ended where it meets the next worker's published start -- and stitches them:
+// fs_build_la_mt computes next() and the first detections here, walks and stitches the chains on the host (indices only) and
+// folds the records of the resulting segment list with k_la_records_list.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -119,15 +122,16 @@ template <class F, bool kStage0> __device__ __forceinline__ hreal<F> start_min(c
     return r;
 }
 
-// ---- 2. first detection of the prologue: the uncapped scan from (0, 1), test elements 2 .. limit-1.
+// ---- 2. first detection of the prologue: the uncapped scan from (base, 1), test elements base+2 .. limit-1 (base = 0 for
+// a stage's prologue; the workers of the multi-threaded stage 0 begin elsewhere, see k_la_first_from).
 // out[0] = index of the first detection (kTerm if none), out[1] = the flavour that follows it by the DetectPeriod rule.
 template <class F, bool kStage0>
 __device__ __forceinline__ void la_first_body(const hreal<F> *chebv, const hreal<F> *mm, uint32_t limit, int shift, uint32_t *out,
-                                              hreal<F> *part, uint32_t &found)
+                                              hreal<F> *part, uint32_t &found, uint32_t base = 0u)
 {
     const uint32_t t = threadIdx.x;
-    const uint32_t n = limit > 2u ? limit - 2u : 0u, chunk = (n + 1023u) / 1024u;
-    const uint32_t a = 2u + t * chunk, b = (a + chunk < limit ? a + chunk : limit);
+    const uint32_t n = limit > base + 2u ? limit - (base + 2u) : 0u, chunk = (n + 1023u) / 1024u;
+    const uint32_t a0 = base + 2u + t * chunk, a = a0 < limit ? a0 : limit, b = (a + chunk < limit ? a + chunk : limit);
     const hreal<F> big = hreal<F>{F(1), 1 << 28};
     hreal<F> m = big;
     for (uint32_t j = a; j < b; j++)
@@ -148,7 +152,7 @@ __device__ __forceinline__ void la_first_body(const hreal<F> *chebv, const hreal
         __syncthreads();
     }
     {
-        const hreal<F> start = start_min<F, kStage0>(chebv, mm, 0u, 1u);
+        const hreal<F> start = start_min<F, kStage0>(chebv, mm, base, 1u);
         const hreal<F> excl = t == 0u ? start : hr_min_pos(part[t - 1u], start);
         __syncthreads();
         part[t] = excl;
@@ -184,6 +188,21 @@ __global__ void __launch_bounds__(1024) k_la_first(const hreal<F> *chebv, const 
     __shared__ hreal<F> part[1024];
     __shared__ uint32_t found;
     la_first_body<F, kStage0>(chebv, mm, limit, shift, out, part, found);
+}
+// CreateLAFromOrbitMT's workers (LAReference.cpp:486-560): each begins at a fixed orbit index with two trackers one element apart
+// and runs both, uncapped, until one detects a period.  A tracker is the scan from state (base, 1): one workgroup per tracker,
+// out[q] = index of its first detection (kTerm: none before the end of the orbit).  Which tracker wins is the host's decision.
+template <class F>
+__global__ void __launch_bounds__(1024) k_la_first_from(const hreal<F> *chebv, const uint32_t *bases, uint32_t limit, int shift,
+                                                        uint32_t *out)
+{
+    __shared__ hreal<F> part[1024];
+    __shared__ uint32_t found;
+    __shared__ uint32_t two[2];
+    la_first_body<F, true>(chebv, nullptr, limit, shift, two, part, found, bases[blockIdx.x]);
+    __syncthreads();
+    if (threadIdx.x == 0)
+        out[blockIdx.x] = found;
 }
 // A higher stage's prologue in ONE launch (round 4): the exclusive scan of the step lengths (orbit positions), the first
 // detection, and the words the host decides the stage's period from next to it (the first element's step length, the orbit
@@ -319,6 +338,27 @@ __global__ void k_la_records(const void *zref, const LAInfo<F> *P, const uint32_
     out[rank_offset + rank[x]] = LA;
 }
 
+// ... and from an explicit list of segments [b, e) of the orbit (the stitched chains of the multi-threaded stage 0: the host has
+// walked them, see build_la in renderer.cpp): record k = init(z[b]) stepped through z[b+1 .. e-1], StepLength e - b.
+template <class F>
+__global__ void k_la_records_list(const void *zref, const uint32_t *seg, uint32_t n, LAInfo<F> *out, LAInfo<F> *tail_out,
+                                  uint32_t max_ref)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    const LAParams p{};
+    if (k == 0u && tail_out)
+        *tail_out = la_init<F>(p, z_at<F>(zref, max_ref));
+    if (k >= n)
+        return;
+    const uint32_t b = seg[2u * k], e = seg[2u * k + 1u];
+    LAInfo<F> LA = la_init<F>(p, z_at<F>(zref, b));
+    for (uint32_t t = b + 1u; t < e; t++)
+        LA = la_step_new<F>(p, LA, z_at<F>(zref, t));
+    LA.StepLength = e - b;
+    LA.NextStageLAIndex = b;
+    out[k] = LA;
+}
+
 // one explicit segment [0, e) (the prologue's first record, or the single record of the last stage)
 template <class F, bool kStage0>
 __global__ void k_la_one_record(const void *zref, const LAInfo<F> *P, uint32_t e, uint32_t step_length, LAInfo<F> *out)
@@ -447,6 +487,19 @@ template <class F> void fsk_la_first(bool stage0, const void *chebv, const void 
                            (const hreal<F> *)mm, limit, LAParams{}.periodDetectionThreshold2Exp, out);
 }
 template <class F>
+void fsk_la_first_from(const void *chebv, const uint32_t *bases, uint32_t n_queries, uint32_t limit, uint32_t *out, hipStream_t s)
+{
+    hipLaunchKernelGGL((k_la_first_from<F>), dim3(n_queries), dim3(1024), 0, s, (const hreal<F> *)chebv, bases, limit,
+                       LAParams{}.stage0PeriodDetectionThreshold2Exp, out);
+}
+template <class F>
+void fsk_la_records_list(const void *zref, const uint32_t *seg, uint32_t n, void *out, void *tail_out, uint32_t max_ref,
+                         hipStream_t s)
+{
+    hipLaunchKernelGGL((k_la_records_list<F>), dim3(nblk(n ? n : 1u)), dim3(256), 0, s, zref, seg, n, (LAInfo<F> *)out,
+                       (LAInfo<F> *)tail_out, max_ref);
+}
+template <class F>
 void fsk_la_next(bool stage0, const void *chebv, const void *mm, const uint32_t *pos, uint32_t limit, uint32_t period,
                  uint32_t *next, uint32_t *reach, uint32_t x_start, hipStream_t s)
 {
@@ -524,6 +577,8 @@ void fsk_la_pack(bool is64, const void *in, void *out, uint32_t n, hipStream_t s
     template void fsk_la_src_orbit<F>(const void *, uint32_t, void *, hipStream_t);                                 \
     template void fsk_la_src_stage<F>(const void *, uint32_t, void *, void *, uint32_t *, hipStream_t);             \
     template void fsk_la_first<F>(bool, const void *, const void *, uint32_t, uint32_t *, hipStream_t);             \
+    template void fsk_la_first_from<F>(const void *, const uint32_t *, uint32_t, uint32_t, uint32_t *, hipStream_t); \
+    template void fsk_la_records_list<F>(const void *, const uint32_t *, uint32_t, void *, void *, uint32_t, hipStream_t); \
     template void fsk_la_next<F>(bool, const void *, const void *, const uint32_t *, uint32_t, uint32_t, uint32_t *, \
                                  uint32_t *, uint32_t, hipStream_t);                                                \
     template void fsk_la_records<F>(bool, const void *, const void *, const uint32_t *, const uint32_t *,            \

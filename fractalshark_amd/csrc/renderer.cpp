@@ -1635,7 +1635,7 @@ constexpr uint32_t kLaLowBound = 64;    // LAReference.h:56
 constexpr uint32_t kLaMaxStages = 1024; // LAReference.h
 constexpr uint32_t kLaTerm = 0xFFFFFFFFu;
 
-template <class F> uint32_t build_la(fs_renderer *r, const void *max_radius, int use_small_exponents)
+template <class F> uint32_t build_la(fs_renderer *r, const void *max_radius, int use_small_exponents, int host_threads)
 {
     using Rec = fs::la::LAInfo<F>;
     using HR = fs::hreal<F>;
@@ -1785,10 +1785,141 @@ template <class F> uint32_t build_la(fs_renderer *r, const void *max_radius, int
         }
         stages.push_back(fs_la_stage_u32{0u, 0u});
         uint32_t n = 0;
+        // CreateLAFromOrbitMT (:215-770) is what the reference runs when the orbit has two or more 50 000-entry chunks and the
+        // host two or more hardware threads (:236-251): the same prologue, then the scan in pieces
+        size_t thread_count = maxRef / 50000u;
+        if (thread_count > (size_t)(host_threads > 0 ? host_threads : 1))
+            thread_count = (size_t)(host_threads > 0 ? host_threads : 1);
         if (no_table) {
             fsk_la_one_record<F>(true, zref, nullptr, maxRef, maxRef, d_table, s);
             n = 1;
             tail_written = false;
+        } else if (thread_count > 1) {
+            // Every piece of the reference's multi-threaded scan is a stretch of one of the chains x -> next(x) of the
+            // single-threaded state machine: the Starter's from the prologue's state, Worker k's from the state its first
+            // period detection leaves (two uncapped trackers begun one element apart at maxRef * k / N, :486-560); a piece ends
+            // where its scan meets the start the next worker has published (:640-668, :440-470), and Stitch (:711-760) lines the
+            // pieces up.  All cross-thread values are futures in the reference, so none of this depends on timing.  On the
+            // device: next() for every state and the 2 (N - 1) first detections; the host walks the chains (indices only) and
+            // stitches; the device folds the records of the segments that came out.
+            const size_t TC = thread_count;
+            const uint32_t nstates = 2u * limit;
+            tail_written = false;
+            if (have_first)
+                fsk_la_one_record<F>(true, zref, nullptr, Period, Period, d_table, s);
+            const uint32_t offset = have_first ? 1u : 0u;
+            fsk_la_next<F>(true, chebv.p, mm.p, pos.as<uint32_t>(), limit, Period, nextA.as<uint32_t>(), reach.as<uint32_t>(), x_start, s);
+            std::vector<uint32_t> bases(2u * (TC - 1u)), firsts(2u * (TC - 1u));
+            for (size_t k = 1; k < TC; k++) {
+                const uint32_t Begin = (uint32_t)((uint64_t)maxRef * k / TC);
+                bases[2u * (k - 1u)] = Begin - 1u; // LA: z[Begin-1] stepped with z[Begin], tests from Begin + 1
+                bases[2u * (k - 1u) + 1u] = Begin; // LA2: z[Begin] stepped with z[Begin+1], tests from Begin + 2
+            }
+            uint32_t *d_bases = nextB.as<uint32_t>(), *d_firsts = nextC.as<uint32_t>();
+            FS_TRY(hipMemcpyAsync(d_bases, bases.data(), 4u * bases.size(), hipMemcpyHostToDevice, s));
+            fsk_la_first_from<F>(chebv.p, d_bases, (uint32_t)bases.size(), limit, d_firsts, s);
+            std::vector<uint32_t> hnext(nstates);
+            FS_TRY(hipMemcpyAsync(firsts.data(), d_firsts, 4u * firsts.size(), hipMemcpyDeviceToHost, s));
+            FS_TRY(hipMemcpyAsync(hnext.data(), nextA.p, 4u * (size_t)nstates, hipMemcpyDeviceToHost, s));
+            FS_TRY(hipStreamSynchronize(s));
+            FS_TRY(hipGetLastError());
+
+            struct Piece {
+                int64_t start = 0, finish = 0;
+                std::vector<uint32_t> states; // the records this piece pushed: segment of state x = [x >> 1, next(x) >> 1)
+                uint32_t last_b = 0, last_e = 0; // the record it was still accumulating when it stopped
+            };
+            std::vector<Piece> piece(TC);
+            // the main scan of a piece (:392-484 Starter, :600-690 Worker): from state x; once past `end`, each boundary is
+            // compared with the published start of the next piece
+            auto walk = [&](uint32_t x, uint32_t end, size_t next_thread, Piece &pc) {
+                for (;;) {
+                    const uint32_t nx = hnext[x];
+                    if (nx == kLaTerm) { // the scan ran to the end of the orbit: its open record covers the rest
+                        pc.finish = maxRef;
+                        pc.last_b = x >> 1, pc.last_e = maxRef;
+                        return;
+                    }
+                    pc.states.push_back(x);
+                    x = nx;
+                    const uint32_t c = (x >> 1) + (x & 1u); // the scan index when the reference tests `j > End`
+                    if (c > end && next_thread < TC) {
+                        const int64_t ns = piece[next_thread].start;
+                        if ((int64_t)c == ns - 1) { // joined: the open record is what the new state has taken so far
+                            pc.finish = (int64_t)c + 1;
+                            pc.last_b = x >> 1, pc.last_e = (x >> 1) + (x & 1u) + 1u;
+                            return;
+                        }
+                        if ((int64_t)c >= ns)
+                            next_thread++;
+                    }
+                }
+            };
+            for (size_t k = TC - 1u; k >= 1u; k--) {
+                const uint32_t Begin = (uint32_t)((uint64_t)maxRef * k / TC), End = (uint32_t)((uint64_t)maxRef * (k + 1u) / TC);
+                const uint32_t dA = firsts[2u * (k - 1u)], dB = firsts[2u * (k - 1u) + 1u];
+                // the loop tests LA at Begin + 1 + t, then LA2 at Begin + 2 + t: the first to fire wins, LA on a tie
+                uint32_t d = kLaTerm;
+                if (dA != kLaTerm && (dB == kLaTerm || (uint64_t)dA - (Begin + 1u) <= (uint64_t)dB - (Begin + 2u)))
+                    d = dA;
+                else if (dB != kLaTerm)
+                    d = dB;
+                uint32_t x = kLaTerm;
+                int64_t j = maxRef;
+                if (d != kLaTerm) {
+                    const uint32_t f = d + 1u < maxRef ? 1u : 0u; // :520-527, :541-549
+                    x = 2u * d + f;
+                    j = (int64_t)d + 1 + f;
+                }
+                Piece &pc = piece[k];
+                if (k == TC - 1u || (j >= (int64_t)Begin && j < (int64_t)End)) {
+                    pc.start = j;
+                } else { // no period boundary inside its own chunk: the worker adopts the next one's start and contributes nothing
+                    pc.start = piece[k + 1u].start;
+                    pc.finish = -1;
+                    continue;
+                }
+                if (x == kLaTerm) { // (last worker, nothing detected: no records, finish == start)
+                    pc.finish = maxRef;
+                    pc.last_b = Begin - 1u, pc.last_e = maxRef;
+                    continue;
+                }
+                walk(x, End, k + 1u, pc);
+            }
+            walk(x_start, maxRef / (uint32_t)TC, 1u, piece[0]);
+
+            // Stitch, :711-760
+            std::vector<uint32_t> seg;
+            auto append = [&](const Piece &pc) {
+                for (uint32_t x : pc.states) {
+                    seg.push_back(x >> 1);
+                    seg.push_back(hnext[x] >> 1);
+                }
+            };
+            append(piece[0]);
+            size_t last_to_add = 0, index = 0, jj = 0;
+            while (index < TC - 1u && piece[jj].finish > piece[index + 1u].start)
+                index++;
+            index++;
+            for (; index < TC; index++) {
+                append(piece[index]);
+                if (piece[index].finish > piece[index].start)
+                    last_to_add = index;
+                jj = index;
+                while (index < TC - 1u && piece[jj].finish > piece[index + 1u].start)
+                    index++;
+            }
+            seg.push_back(piece[last_to_add].last_b);
+            seg.push_back(piece[last_to_add].last_e);
+            const uint32_t nseg = (uint32_t)(seg.size() / 2u);
+            if ((size_t)offset + nseg + 2u > cap_recs || seg.size() > cap_states)
+                return FS_ERR_7;
+            FS_TRY(hipMemcpyAsync(nextB.p, seg.data(), 4u * seg.size(), hipMemcpyHostToDevice, s));
+            fsk_la_records_list<F>(zref, nextB.as<uint32_t>(), nseg, d_table + offset, d_table + offset + nseg, maxRef, s);
+            FS_TRY(hipStreamSynchronize(s)); // (seg lives on this stack frame)
+            FS_TRY(hipGetLastError());
+            n = offset + nseg;
+            tail_written = true;
         } else if (uint32_t e = run_chain(true, nullptr, limit, Period, have_first, have_first ? Period : 0u,
                                           have_first ? Period : 0u, x_start, n))
             return e;
@@ -1902,6 +2033,11 @@ extern "C" {
 
 uint32_t fs_build_la(fs_renderer *r, int type_tag, const void *max_radius, int use_small_exponents)
 {
+    return fs_build_la_mt(r, type_tag, max_radius, use_small_exponents, 1);
+}
+
+uint32_t fs_build_la_mt(fs_renderer *r, int type_tag, const void *max_radius, int use_small_exponents, int host_threads)
+{
     if (uint32_t e = use_device(r))
         return e;
     if (type_tag != FS_T_HDR32 && type_tag != FS_T_HDR64)
@@ -1911,8 +2047,8 @@ uint32_t fs_build_la(fs_renderer *r, int type_tag, const void *max_radius, int u
     if (r->orbit_seq)
         return FS_ERR_UNSUPPORTED; // needs the expanded orbit (fs_set_compressed_orbit_mode 0)
     TimedLaunch t(r);
-    return type_tag == FS_T_HDR32 ? build_la<float>(r, max_radius, use_small_exponents)
-                                  : build_la<double>(r, max_radius, use_small_exponents);
+    return type_tag == FS_T_HDR32 ? build_la<float>(r, max_radius, use_small_exponents, host_threads)
+                                  : build_la<double>(r, max_radius, use_small_exponents, host_threads);
 }
 
 uint32_t fs_la_counts(const fs_renderer *r, uint32_t *n_las, uint32_t *n_stages, int *use_at, int *is_valid)

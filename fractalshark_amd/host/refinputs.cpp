@@ -1354,6 +1354,31 @@ extern "C" void fsh_orbit_low_hdr32(const fsh_orbit *o, fs_real_hdr32 out[2])
 }
 extern "C" void fsh_orbit_destroy(fsh_orbit *o) { delete o; }
 extern "C" uint64_t fsh_orbit_count(const fsh_orbit *o) { return o->is64 ? o->d.x.size() : o->f.x.size(); }
+// Test hook: entries idx[k] of the (uncompressed) orbit scaled by 2^exp2[k].  The result is no longer the orbit of any view;
+// it is an orbit-shaped input with period boundaries where a test wants them (what the LA builders make of adjacent deep
+// minima, of a minimum right behind a worker's first index...).  Returns the number of entries changed.
+extern "C" uint64_t fsh_orbit_scale_entries(fsh_orbit *o, const uint64_t *idx, const int32_t *exp2, uint64_t n)
+{
+    uint64_t changed = 0;
+    auto apply = [&](auto &ob) {
+        if (ob.compressed)
+            return;
+        for (uint64_t k = 0; k < n; k++) {
+            if (idx[k] >= ob.x.size())
+                continue;
+            ob.x[idx[k]].e += exp2[k];
+            ob.y[idx[k]].e += exp2[k];
+            changed++;
+        }
+        ob.packed32.clear();
+        ob.packed64.clear();
+    };
+    if (o->is64)
+        apply(o->d);
+    else
+        apply(o->f);
+    return changed;
+}
 extern "C" uint64_t fsh_orbit_period(const fsh_orbit *o) { return o->is64 ? o->d.period : o->f.period; }
 
 extern "C" const fs_orbit_hdr32 *fsh_orbit_data_hdr32(fsh_orbit *o)

@@ -211,6 +211,14 @@ class Orbit:
             self._lib.fsh_orbit_destroy(self._h)
             self._h = None
 
+    def scale_entries(self, indices, exp2):
+        """Test hook (fsh_orbit_scale_entries): entries `indices` scaled by 2^exp2 -- an orbit-shaped input with period
+        boundaries where a test wants them; not the orbit of any view any more."""
+        idx = np.ascontiguousarray(indices, np.uint64)
+        ex = np.ascontiguousarray(exp2, np.int32)
+        assert idx.shape == ex.shape
+        return int(self._lib.fsh_orbit_scale_entries(self._h, idx.ctypes.data, ex.ctypes.data, idx.size))
+
     @property
     def data_ptr(self):
         return self._lib.fsh_orbit_data_hdr64(self._h) if self.is64 else self._lib.fsh_orbit_data_hdr32(self._h)

@@ -219,21 +219,22 @@ class GPURenderer:
         mr = orbit.max_radius()
         return self._lib.fs_build_bla(self._h, T, mr.ctypes.data)
 
-    def BuildLAOnDevice(self, orbit, use_small_exponents=False, T=None, host_fallback=True):
+    def BuildLAOnDevice(self, orbit, use_small_exponents=False, T=None, host_fallback=True, host_threads=1):
         """LAReference::GenerateApproximationData on the device for the orbit last uploaded (fs_build_la): all stages and
         the ATInfo stay in HBM, installed as the renderer's table.  An orbit of at most 64 steps in which no period is
         found gets the reference's two records and a table that is NOT valid (LAReference.cpp:135-140); the kernels ignore
         it, as they do in FractalShark.  The degenerate inputs the device builder leaves to the host (FS_ERR_UNSUPPORTED: an
         orbit of fewer than three entries, a first step with a zero ZCoeff -- microseconds of host work) are built by the
         host builder and uploaded with fs_upload_la, which is what FractalShark itself does for every table
-        (host_fallback=False returns the error code instead)."""
+        (host_fallback=False returns the error code instead).  host_threads > 1: stage 0 as CreateLAFromOrbitMT builds it on a
+        host with that many hardware threads (fs_build_la_mt)."""
         if T is None:
             T = T_HDR64 if orbit.is64 else T_HDR32
         mr = orbit.max_radius()
-        err = self._lib.fs_build_la(self._h, T, mr.ctypes.data, 1 if use_small_exponents else 0)
+        err = self._lib.fs_build_la_mt(self._h, T, mr.ctypes.data, 1 if use_small_exponents else 0, int(host_threads))
         if err == FS_ERR_UNSUPPORTED and host_fallback:
             from . import inputs
-            la = inputs.LATable(orbit, use_small_exponents=use_small_exponents)
+            la = inputs.LATable(orbit, host_threads=host_threads, use_small_exponents=use_small_exponents)
             err = self._lib.fs_upload_la(self._h, 0, T, 4, la.las_ptr, la.count, la.stages_ptr, la.stage_count,
                                          1 if la.is_valid else 0, 1 if la.use_at else 0, C.addressof(la.at))
         return err

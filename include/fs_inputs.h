@@ -87,6 +87,9 @@ const fs_orbit_hdr64_rc *fsh_orbit_compressed_data_hdr64(fsh_orbit *o);
 void fsh_orbit_low_hdr64(const fsh_orbit *o, fs_real_hdr64 out[2]);
 void fsh_orbit_destroy(fsh_orbit *o);
 uint64_t fsh_orbit_count(const fsh_orbit *o);  /* GetCountOrbitEntries(), includes the zero entry */
+/* Test hook: entries idx[k] of an uncompressed orbit scaled by 2^exp2[k] (period boundaries where a test of the LA builders
+ * wants them; the result is not the orbit of any view).  Returns the number of entries changed. */
+uint64_t fsh_orbit_scale_entries(fsh_orbit *o, const uint64_t *idx, const int32_t *exp2, uint64_t n);
 uint64_t fsh_orbit_period(const fsh_orbit *o); /* GetPeriodMaybeZero() */
 const fs_orbit_hdr32 *fsh_orbit_data_hdr32(fsh_orbit *o);
 const fs_orbit_hdr64 *fsh_orbit_data_hdr64(fsh_orbit *o);

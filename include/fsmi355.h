@@ -177,13 +177,22 @@ uint32_t fs_read_bla_level(fs_renderer *r, int32_t level, void *out, uint64_t ma
  * FS_T_HDR64) directly in HBM and installs it as the renderer's table, as fs_upload_la would.  max_radius =
  * PerturbationResults::GetMaxRadius (fs_real_hdr32 / fs_real_hdr64); use_small_exponents = the UseSmallExponents flag of
  * CreateATFromLA (RefOrbitCalc.cpp:2346).  The table is bit-identical to the reference's SINGLE-THREADED builder (what
- * LAReference produces when hardware_concurrency() < 2 * 50000-entry chunks, :236-251; the multi-threaded stage-0 variant
- * yields a thread-count-dependent table, which stays with the host).  An orbit of at most 64 steps (LowBound,
+ * LAReference produces when hardware_concurrency() < 2 or the orbit has fewer than 2 * 50000 entries, :236-251; the
+ * multi-threaded stage-0 variant yields a thread-count-dependent table: fs_build_la_mt below).  An orbit of at most 64 steps (LowBound,
  * LAReference.h:56) in which no period is found gets the reference's two records and a table that is not valid (:135-140,
  * :1002-1005; fs_la_counts reports is_valid 0 and the kernels ignore the table); one in which periods are found gets its
  * normal small table.  FS_ERR_UNSUPPORTED (use fs_upload_la): an orbit of fewer than three entries, a first step whose ZCoeff
  * is zero.  Synchronous.  fs_la_counts / fs_read_la read the installed table back (tests, tools). */
 uint32_t fs_build_la(fs_renderer *r, int type_tag, const void *max_radius, int use_small_exponents);
+/* ... and with stage 0 as LAReference::CreateLAFromOrbitMT (LAReference.cpp:215-770) builds it on a host with `host_threads`
+ * hardware threads (std::thread::hardware_concurrency(), :236-240): ThreadCount = min(maxRefIteration / 50000, host_threads)
+ * pieces -- the Starter from the prologue, Worker k from the first period boundary it finds after orbit index
+ * maxRefIteration * k / ThreadCount (:486-560), each until it meets the next published start (:640-668), stitched (:711-760) --
+ * so that the table is, bit for bit, the one FractalShark's own CPU builder makes on THAT host (it differs from the
+ * single-threaded table near every piece boundary).  ThreadCount < 2 (host_threads < 2 or an orbit below 100 000 entries) is
+ * fs_build_la.  The device computes next() for every state of the scan and the 2 (ThreadCount - 1) uncapped first detections;
+ * the host walks the chains (indices only: 8 bytes per orbit entry come back once) and stitches; the device folds the records. */
+uint32_t fs_build_la_mt(fs_renderer *r, int type_tag, const void *max_radius, int use_small_exponents, int host_threads);
 uint32_t fs_la_counts(const fs_renderer *r, uint32_t *n_las, uint32_t *n_stages, int *use_at, int *is_valid);
 uint32_t fs_read_la(fs_renderer *r, void *las_out, uint32_t max_las, void *stages_out, uint32_t max_stages, void *at_out);
 

@@ -634,6 +634,90 @@ def test_la_table_built_on_device_from_a_compressed_orbit(renderer, native_libs,
     assert np.array_equal(out, _oracle.lav2_hdr32(v, ob, la, stage_test=0))
 
 
+# ---- ... and in its MULTI-THREADED form (CreateLAFromOrbitMT, LAReference.cpp:215-770: what FractalShark's CPU builder makes of
+# an orbit of 100 000 entries and more on a host with two or more hardware threads): fs_build_la_mt(host_threads) == the host
+# builder's replay of that variant with the same thread count, bit for bit.  On the built-in views the pieces join cleanly and
+# the table equals the single-threaded one; the crafted orbits put two adjacent deep minima right behind a worker's first index
+# (Orbit.scale_entries), where the worker's first record and the scan arriving from the left disagree and the tables differ.
+def _check_la_mt(r, ob, is64, threads, expect_differs, compressed=False):
+    import ctypes as C
+    la = inputs.LATable(ob, host_threads=threads)
+    st = inputs.LATable(ob, host_threads=1)
+    differs = la.count != st.count or la.records().tobytes() != st.records().tobytes()
+    assert differs == expect_differs
+    T = T_HDR64 if is64 else T_HDR32
+    assert r.InitializeMemory(64, 36, 1, None, 0, 0, 0, False) == 0
+    if compressed:
+        assert r.InitializePerturb(1, ob, 0, None, None) == 0
+    else:
+        assert r._lib.fs_upload_orbit(r._h, 0, T, 4, ob.data_ptr, ob.count, ob.count, ob.period) == 0
+    assert r.BuildLAOnDevice(ob, host_threads=threads, host_fallback=False) == 0
+    las, stages, at, use_at, is_valid = r.read_la(is64)
+    assert is_valid and la.is_valid
+    assert stages.shape[0] == la.stage_count and np.array_equal(stages, la.stages())
+    assert las.shape[0] == la.count
+    host = la.records().view(np.uint8).reshape(la.count, -1)
+    bad = np.nonzero((las != host).any(axis=1))[0]
+    assert len(bad) == 0, "first differing record %d of %d" % (int(bad[0]), la.count)
+    assert use_at == la.use_at
+    assert at == bytes((C.c_char * C.sizeof(la.at)).from_address(C.addressof(la.at)))
+    # host_threads = 1 through the same entry point is the single-threaded table
+    assert r.BuildLAOnDevice(ob, host_threads=1, host_fallback=False) == 0
+    las1 = r.read_la(is64)[0]
+    assert las1.shape[0] == st.count and las1.tobytes() == st.records().tobytes()
+
+
+@pytest.mark.parametrize("view_n,is64,threads,compression", [
+    (14, False, 2, None),                                # 116 695 entries: two pieces whatever the host has
+    (19, False, 2, None), (19, False, 3, None), (19, False, 8, None), (19, True, 5, None), (19, True, 8, None),
+    (19, False, 64, None),                               # 412 729 entries: at most 8 pieces
+    (6, False, 4, None), (6, False, 16, None), (6, True, 9, None),  # 457 977 entries: at most 9
+    (19, False, 8, 20),                                  # SimpleCompression: expanded at upload, periodDivisor 8
+])
+def test_la_table_built_on_device_equals_host_builder_multithreaded(renderer, native_libs, view_n, is64, threads, compression):
+    v = inputs.View.builtin(view_n, 64, 36, antialiasing=1)
+    ob = inputs.Orbit(v, is64=is64) if compression is None else inputs.Orbit(v, is64=is64, compression_exp=compression)
+    _check_la_mt(renderer, ob, is64, threads, expect_differs=False, compressed=compression is not None)
+
+
+@pytest.mark.parametrize("is64,threads,edits", [
+    # (worker k, offset behind its first index, 2^e of that entry, 2^e of the next one)
+    (False, 3, [(2, 9, -30, -50)]),
+    (False, 8, [(1, 10, -30, -50)]),
+    (False, 8, [(1, 10, -20, -24)]),
+    (False, 8, [(3, 4, -30, -50)]),
+    (False, 8, [(6, 7, -20, -24)]),
+    (False, 8, [(1, 10, -30, -50), (3, 4, -20, -24), (6, 7, -30, -50)]),   # three joins off in one table
+    (True, 8, [(1, 10, -30, -50), (3, 4, -20, -24), (6, 7, -30, -50)]),
+])
+def test_la_multithreaded_table_where_it_differs_from_the_single_threaded_one(renderer, native_libs, is64, threads, edits):
+    v = inputs.View.builtin(19, 64, 36, antialiasing=1)
+    ob = inputs.Orbit(v, is64=is64)
+    max_ref = ob.count - 1
+    idx, ex = [], []
+    for k, a, ea, eb in edits:
+        begin = max_ref * k // threads
+        idx += [begin + a, begin + a + 1]
+        ex += [ea, eb]
+    assert ob.scale_entries(idx, ex) == len(idx)
+    _check_la_mt(renderer, ob, is64, threads, expect_differs=True)
+
+
+@pytest.mark.parametrize("seed,count,threads", [(5, 20000, 8), (2, 20000, 3), (1, 2000, 5)])
+def test_la_multithreaded_table_of_an_orbit_with_random_minima(renderer, native_libs, seed, count, threads):
+    """Thousands of artificial period boundaries (half of them in adjacent pairs): long chains, many stages."""
+    v = inputs.View.builtin(19, 64, 36, antialiasing=1)
+    ob = inputs.Orbit(v, is64=False)
+    rng = np.random.default_rng(seed)
+    idx = rng.integers(2, ob.count - 2, count).astype(np.uint64)
+    idx = np.concatenate([idx, idx[:count // 2] + 1])
+    ex = -rng.integers(5, 60, idx.size).astype(np.int32)
+    ob.scale_entries(idx, ex)
+    la = inputs.LATable(ob, host_threads=threads)
+    st = inputs.LATable(ob, host_threads=1)
+    _check_la_mt(renderer, ob, False, threads, expect_differs=la.records().tobytes() != st.records().tobytes())
+
+
 def _tiny_view(cx, cy, w, n, W=64, H=36):
     from decimal import Decimal, getcontext
     getcontext().prec = 50

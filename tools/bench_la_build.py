@@ -40,10 +40,17 @@ for n in args.views:
         best = min(best, time.perf_counter() - t0)
     las, stages, at, use_at, _ = r.read_la(args.is64)
     same = las.tobytes() == la1.records().tobytes()
+    best_mt = 1e9
+    for _ in range(3):  # stage 0 as CreateLAFromOrbitMT makes it on a 16-thread host (fs_build_la_mt)
+        t0 = time.perf_counter()
+        assert r.BuildLAOnDevice(ob, host_threads=16) == 0
+        best_mt = min(best_mt, time.perf_counter() - t0)
+    same_mt = r.read_la(args.is64)[0].tobytes() == la16.records().tobytes()
     print(json.dumps({"view": n, "type": "hdr64" if args.is64 else "hdr32", "orbit_entries": ob.count,
                       "la_records": int(las.shape[0]), "stages": int(stages.shape[0]),
                       "device_build_ms": round(best * 1e3, 3), "host_build_1thread_ms": round(t_host1 * 1e3, 3),
                       "host_build_16thread_replay_ms": round(t_host16 * 1e3, 3),
+                      "device_build_mt16_ms": round(best_mt * 1e3, 3), "bit_identical_to_host_16thread": bool(same_mt),
                       "gmp_orbit_s": round(t_orbit, 3), "bit_identical_to_host_1thread": bool(same),
                       "records_if_multithreaded_host": la16.count}), flush=True)
 r.close()
