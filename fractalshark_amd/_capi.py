@@ -80,7 +80,8 @@ def render_lib():
     global _render
     if _render is not None:
         return _render
-    path = _build.LIB_RENDER
+    # FSMI355_LIB: another build of the same library (A/B measurements against other build flags; tools/c2_ab.py)
+    path = os.environ.get("FSMI355_LIB") or _build.LIB_RENDER
     if not os.path.exists(path):
         raise RuntimeError("libfsmi355.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'`"
                            % path)

@@ -847,6 +847,97 @@ constexpr int kFloorBits = (127 - FS_FL_FLOOR_EXP) << 23;
           "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65",  \
           "s72", "s73", "s74", "vcc", "scc")
 
+// The sixteen-step body as a TWO-STAGE PIPELINE (round 5).  Scalar loads return out of order behind one counter, so a wait is a
+// wait for everything in flight -- but nothing says the wait has to follow the request: the body's entries live in two halves
+// (E0 .. E7 in s[36:51] with the bounds of the entries 3 and 7 in s[72:73]; E8 .. E15 in s[52:67] with those of 11 and 15 in
+// s[74:75]), and each half is requested while the OTHER one is being consumed -- the upper half at step 1 (right after the
+// instruction that reads E15 of the body before), the next body's lower half at step 10 (right after the instructions that read
+// E7 and the bound of entry 7) -- and waited for eight steps later, just before its first use, when it has long landed: the
+// only thing in flight at either wait is the half requested eight steps ago.  A wave that is alone on its SIMD no longer
+// stands still for an L2 round trip per body (C2's interior pixels: 4.7 M dependent steps; FS_FAST_LOOP_FD16 with its warming
+// loads measured ~30 ns per step against the ~19 ns of the step's dependent arithmetic).  Same registers as FS_FAST_LOOP_FD16,
+// same statuses, same exits; the exit taken at step 6 waits before it writes s[66:67] / s75 (the upper half is in flight
+// there).  The half requested past the end of a run is never used (the companion arrays carry 32 entries of slack).
+// The deferred floor verdict is taken PER BODY: the state a body starts from is kept (v[46:47], its step count in `cko`) once
+// the verdict over the body before has passed, and a state below the floor sends the statement back to that checkpoint with
+// status 3 -- the caller commits the certified steps and lets the per-trip loop (FS_FAST_LOOP_FL) find the failing trip in
+// the sixteen steps that follow, instead of repeating the whole run with it (a 2048-step run that ends on a floor failure,
+// which is how most runs of C2's never-escaping pixels end, was executed twice).
+#define FS_FD16P_PAIR(EA, EB_, BW, LBL, WAIT, LOADS)                                                                \
+    FS_PK_F(FS_R0, EA) FS_FL_ACC("v48", "v49") FS_PK_MA(FS_R0) FS_T_X("v48", "v49") FS_PK_MB(FS_R0)                 \
+    FS_PK_P FS_BT_DC_MAX FS_PK_A(FS_R1) FS_BT_DC_ADD WAIT                                                           \
+    FS_PK_F(FS_R1, EB_) "v_cmp_lt_i32_e64 %[m], " BW ", v62\n\t" FS_BT_H_CMP FS_PK_MA(FS_R1)                         \
+    FS_BT_H_OR FS_PK_MB(FS_R1) FS_PK_P "s_cbranch_scc1 " LBL "\n\t" LOADS FS_PK_A(FS_R2)
+#define FS_FAST_LOOP_FD16P                                                                                          \
+    asm volatile(                                                                                                   \
+        "v_mov_b32_e32 v61, 0x7f800000\n\t" /* the first body's lower half; every later body finds its own requested */ \
+        "s_lshr_b32 %[oc], %[off], 1\n\t"                                                                           \
+        "s_load_dwordx16 s[36:51], s[68:69], %[oc]\n\t"                                                             \
+        "s_load_dwordx2 s[72:73], s[70:71], %[off]\n"                                                               \
+        ".Lfp_loop_%=:\n\t" /* sixteen steps left?  the first block's tests: max(max|w|, max|dc|) against s75, H */  \
+        FS_BT_DC_MAX "s_cmp_gt_u32 %[off], %[lim16]\n\t" FS_BT_DC_ADD FS_FL_C                                       \
+        "s_cbranch_scc1 .Lfp_out_%=\n\t" /* the floor verdict over the body before: see the checkpoint below */     \
+        "s_cbranch_vccnz .Lfp_redo_%=\n\t"                                                                          \
+        "v_cmp_lt_i32_e64 %[m], s75, v62\n\t" FS_BT_H_CMP FS_BT_H_OR                                                \
+        "s_cbranch_scc1 .Lfp_out_%=\n\t" /* the checkpoint: every state up to here is certified */                  \
+        "v_mov_b32_e32 v46, v48\n\t"                                                                                \
+        "v_mov_b32_e32 v47, v49\n\t"                                                                                \
+        "s_mov_b32 %[cko], %[off]\n\t"                                                                              \
+        "v_mov_b32_e32 v61, 0x7f800000\n\t" /* steps 1 .. 4; the lower half has landed, the upper half is requested */ \
+        FS_PK_F(FS_R0, "s[66:67]")                                                                                  \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                                                  \
+        "s_lshr_b32 %[oc], %[off], 1\n\t"                                                                           \
+        "s_load_dwordx16 s[52:67], s[68:69], %[oc] offset:0x40\n\t"                                                 \
+        "s_load_dwordx2 s[74:75], s[70:71], %[off] offset:0x8\n\t"                                                  \
+        FS_PK_MA(FS_R0) FS_PK_MB(FS_R0) FS_PK_P FS_PK_A(FS_R1)                                                      \
+        FS_PK_F(FS_R1, "s[36:37]") FS_FL_ACC("v50", "v51") FS_PK_MA(FS_R1) FS_PK_MB(FS_R1) FS_PK_P FS_PK_A(FS_R2)   \
+        FS_PK_F(FS_R2, "s[38:39]") FS_FL_ACC("v52", "v53") FS_PK_MA(FS_R2) FS_PK_MB(FS_R2) FS_PK_P FS_PK_A(FS_R3)   \
+        FS_PK_F(FS_R3, "s[40:41]") FS_FL_ACC("v54", "v55") FS_PK_MA(FS_R3) FS_PK_MB(FS_R3) FS_PK_P FS_PK_A(FS_R0)   \
+        /* steps 5 .. 8 */                                                                                          \
+        FS_FD16P_PAIR("s[42:43]", "s[44:45]", "s72", ".Lfp_b1_%=", "", "") FS_FD16_TAIL("s[46:47]", "s[48:49]")     \
+        /* steps 9 .. 12: the upper half has landed (step 10 reads E8); the next body's lower half is requested */   \
+        FS_FD16P_PAIR("s[50:51]", "s[52:53]", "s73", ".Lfp_b2_%=", "s_waitcnt lgkmcnt(0)\n\t",                      \
+                      "s_load_dwordx16 s[36:51], s[68:69], %[oc] offset:0x80\n\t"                                   \
+                      "s_load_dwordx2 s[72:73], s[70:71], %[off] offset:0x100\n\t")                                 \
+        FS_FD16_TAIL("s[54:55]", "s[56:57]")                                                                        \
+        /* steps 13 .. 16 */                                                                                        \
+        FS_FD16P_PAIR("s[58:59]", "s[60:61]", "s74", ".Lfp_b3_%=", "", "") FS_FD16_TAIL("s[62:63]", "s[64:65]")     \
+        "s_add_u32 %[off], %[off], 0x100\n\t"                                                                       \
+        FS_T_X("v48", "v49") FS_FL_ACC("v48", "v49") "s_branch .Lfp_loop_%=\n"                                      \
+        ".Lfp_b1_%=:\n\t" /* block 2 needs its bound tests (or H): the state is w4 in v[48:49], at entry 3 */       \
+        "s_waitcnt lgkmcnt(0)\n\t" /* (the upper half is in flight: it must not land on what is written here) */    \
+        "s_mov_b64 s[66:67], s[42:43]\n\t"                                                                          \
+        "s_mov_b32 s75, s72\n\t"                                                                                    \
+        "s_add_u32 %[off], %[off], 0x40\n\t"                                                                        \
+        "s_branch .Lfp_out_%=\n"                                                                                    \
+        ".Lfp_b2_%=:\n\t" /* block 3: w8, entry 7 (nothing is in flight here) */                                   \
+        "s_mov_b64 s[66:67], s[50:51]\n\t"                                                                          \
+        "s_mov_b32 s75, s73\n\t"                                                                                    \
+        "s_add_u32 %[off], %[off], 0x80\n\t"                                                                        \
+        "s_branch .Lfp_out_%=\n"                                                                                    \
+        ".Lfp_b3_%=:\n\t" /* block 4: w12, entry 11 (the next lower half is in flight: other registers) */         \
+        "s_mov_b64 s[66:67], s[58:59]\n\t"                                                                          \
+        "s_mov_b32 s75, s74\n\t"                                                                                    \
+        "s_add_u32 %[off], %[off], 0xc0\n"                                                                          \
+        ".Lfp_out_%=:\n\t" /* the verdict over the states since the checkpoint */                                   \
+        "s_mov_b32 %[st], 0\n\t" FS_FL_C                                                                            \
+        "s_cbranch_vccz .Lfp_end_%=\n"                                                                              \
+        ".Lfp_redo_%=:\n\t" /* a state below the floor: back to the checkpoint (state and step count), status 3 */  \
+        "v_mov_b32_e32 v48, v46\n\t"                                                                                \
+        "v_mov_b32_e32 v49, v47\n\t"                                                                                \
+        "s_mov_b32 %[off], %[cko]\n\t"                                                                              \
+        "s_mov_b32 %[st], 3\n"                                                                                      \
+        ".Lfp_end_%=:\n\t"                                                                                          \
+        "s_waitcnt lgkmcnt(0)"                                                                                      \
+        : "+{v[48:49]}"(wv), "={v[50:51]}"(r1), "={v[52:53]}"(r2), "={v[54:55]}"(r3), "={v[56:57]}"(ts_),           \
+          "={v[58:59]}"(ta_), "+{v60}"(mxS), "={v61}"(tn_), "={v62}"(tl_), "={v[46:47]}"(ck_), [m] "=&s"(msk_),     \
+          [st] "=&s"(st), "+{s75}"(pwi), "+{s[66:67]}"(zS), [off] "+s"(off), [oc] "=&s"(oc_), [cko] "=&s"(cko_)     \
+        : [se] "v"(sE2), [dc] "v"(dcs), [esh] "v"(Esh), [imdc] "v"(imdc), [lim16] "s"(lim16), "{s[68:69]}"(zpb2),   \
+          "{s[70:71]}"(zqbp), [flr] "s"(kFloorBits)                                                                 \
+        : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50",  \
+          "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65",  \
+          "s72", "s73", "s74", "vcc", "scc")
+
 // ------------------------------------------------------------------------------------------------
 // LAv2, T = HDRFloat<float>: tuned perturbation loop.  Same prologue (AT + LA stages) and the same results, bit for
 // bit, as k_lav2_hdr32; the perturbation loop (>99.9 % of the executed work at View 5) is restructured around what
@@ -947,6 +1038,22 @@ __device__ __forceinline__ uint32_t scaled_run_length(uint32_t left)
     if (__builtin_amdgcn_ballot_w64(left < 64u) == 0ull)
         return 64u;
     return __builtin_amdgcn_ballot_w64(left < 16u) == 0ull ? 16u : 0u;
+}
+
+// ... and for the perturbation-only kernel (k_perturb_scalar): one longer tier in front.  A wave that is alone on its SIMD pays
+// for every instruction of a run's entry and exit (and waits out their vector loads): at 256 steps per run they were 40 % of the
+// time of C2's never-escaping pixels (tools/microbench/lone_pace.hip: the loop's own pace is 11.5 ns per step, the kernel's
+// 21 - 31).  A run still ends where it has to: H, a floor or bound failure, a block that needs its tests at the very end.
+#ifndef FS_PO_CHUNK
+#define FS_PO_CHUNK 2048
+#endif
+constexpr uint32_t kPoChunk = FS_PO_CHUNK;
+static_assert(kPoChunk % 16 == 0 && kPoChunk >= kScaledChunk && kPoChunk <= (1u << 20), "whole 16-step bodies; offsets stay 32-bit");
+__device__ __forceinline__ uint32_t scaled_run_length_po(uint32_t left)
+{
+    if (kPoChunk > kScaledChunk && __builtin_amdgcn_ballot_w64(left < kPoChunk) == 0ull)
+        return kPoChunk;
+    return scaled_run_length(left);
 }
 
 // kLds (A/B variant, north_star "LDS staging of orbit segments shared across a wavefront"): in the scaled runs whose
@@ -2263,6 +2370,10 @@ template <class F, bool kBla, bool kStats, bool kRefill, bool kNat = false, clas
 __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
 {
     constexpr bool kRuns = sizeof(IterT) == 4;
+#ifdef FS_TRACE_WAVES
+    const uint64_t ps_trace_t0 = wall_clock64();
+    const uint64_t ps_trace_c0 = __builtin_readcyclecounter(); // shader clock: with the constant 100 MHz clock, the wave's MHz
+#endif
     __shared__ const typename FsDev<F>::BLA *s_levels[kBla && !kNat ? 64 : 1];
     __shared__ uint32_t s_off[kNat ? 64 : 1];
     if constexpr (kBla && !kNat) {
@@ -2294,9 +2405,15 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
     uint64_t ph_n_lookup = 0, ph_n_jump = 0, ph_n_step = 0, ph_n_literal = 0, ph_n_outer = 0;
     uint64_t ph_lanes_jump = 0, ph_lanes_step = 0, ph_n_scaled = 0; // (ph_n_scaled: step passes taken by a cheap form)
 #define FS_PH(stmt) do { if (kStats && kBla) { stmt; } } while (0)
+    // ... and of the perturbation-only float path (tools/c2_phase_probe.py): the whole pixel loop, the scaled-run block, the
+    // hand-scheduled statement inside it, the exponent-tracking (second chance) block; the single steps are the rest
+    uint64_t po_total = 0, po_run = 0, po_asm = 0, po_quiet = 0, po_t0 = 0, po_t1 = 0, po_t2 = 0, po_n_run = 0, po_n_asm = 0;
+#define FS_PO(stmt) do { if (kStats && !kBla) { stmt; } } while (0)
 #else
 #define FS_PH(stmt) do { } while (0)
+#define FS_PO(stmt) do { } while (0)
 #endif
+    FS_PO(po_t0 = __builtin_readcyclecounter());
     const IterT n_iterations = iter_cap<IterT>(A.n_iterations, A.n_iterations_hi);
     const uint32_t count = A.orbit_count;
     const typename FsDev<F>::Z *__restrict__ zr = A.zref;
@@ -2369,7 +2486,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
             l = (t / tiles_x) * 8u + (lane >> 3);
             // the waves of the long tiles decide when the frame ends: they ask the instruction arbiter for priority over
             // the waves they share their SIMD with while the bulk of the frame is still being rendered
-            if (w < A.tile_order[gridDim.x * gridDim.y * (blockDim.x >> 6)] )
+            if (w < A.tile_order[gridDim.x * gridDim.y * (blockDim.x >> 6)])
                 __builtin_amdgcn_s_setprio(3);
         } else {
             tile_pixel(x, l);
@@ -2805,6 +2922,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
             // with its own exponent -- is the same sequence of roundings as the complex one: s = fma(w, 2^E, 2Z),
             // q = (w.x s.x - w.y s.y, w.x s.y + w.y s.x) + c 2^-E.  Same acceptance tests, same companion array.
             bool sc_stopped = false;
+            FS_PO(po_t1 = __builtin_readcyclecounter(); po_n_run++);
             if constexpr (kRuns && !kBla && std::is_same<F, float>::value) {
                 typedef float f2 __attribute__((ext_vector_type(2)));
                 typedef float f3 __attribute__((ext_vector_type(3)));
@@ -2839,7 +2957,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                     // dz 2^-E exact and above the floor; |dc| 2^-E < 2^7
                     const bool start_ok = scaled_startable(e0) && mn0 >= FS_FL_FLOOR * __builtin_amdgcn_ldexpf(1.0f, kScaleShift) &&
                                           mx0 >= 1.0f && mx0 < 2.0f && imax(dshx, dshy) <= 30 - kScaleShift;
-                    const uint32_t run_len = scaled_run_length(left);
+                    const uint32_t run_len = scaled_run_length_po(left);
                     if (__builtin_amdgcn_ballot_w64(!start_ok) != 0ull || run_len == 0u)
                         break;
                     const f2 sE2 = {sE, sE};
@@ -2848,7 +2966,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                     f2 w0 = dzs * __builtin_amdgcn_ldexpf(1.0f, -kScaleShift), z0 = {e0.x, e0.y}, w2, z2, wO;
                     uint32_t c = 0;
                     bool failed;
-                    bool fl_redo = false;
+                    bool fl_redo = false, fl_next = false;
                     const uint32_t ref_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)RefIteration);
                     if (__builtin_amdgcn_ballot_w64(RefIteration != ref_u) == 0ull) {
                         // Entries through the scalar cache (all lanes read the same ones): the hand-scheduled untested loop
@@ -2885,13 +3003,20 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                                 float tn_, tl_;
                                 uint64_t msk_;
                                 int st, ebo, pf_, pg_, ph_, pi_, pj_;
-                                uint32_t oc_;
+                                uint32_t oc_, cko_;
+                                f2 ck_;
                                 uint32_t off = cs << 4;
                                 const uint32_t c_in = cs;
 #if FS_FL_EVERY && !defined(FS_VERIFY_FLOOR)
                                 if (!fl_per_trip) {
                                     {
+                                        FS_PO(po_t2 = __builtin_readcyclecounter(); po_n_asm++);
+#ifdef FS_FD16_SERIAL /* A/B: round 4's body -- one wait right behind the request, the next body's lines warmed */
                                         FS_FAST_LOOP_FD16(FS_PF16_NEXT_BODY);
+#else
+                                        FS_FAST_LOOP_FD16P;
+#endif
+                                        FS_PO(po_asm += __builtin_readcyclecounter() - po_t2);
                                     }
                                     ebo = 0;
                                 } else
@@ -2907,10 +3032,25 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                                 zS = (f2){__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(zS.x))),
                                           __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(zS.y)))};
                                 if (st == 3) {
+#ifdef FS_FD16_SERIAL
                                     // (deferred verdict) a state of this invocation fell below the floor: nothing of the run
                                     // has been committed -- the same run again with the per-trip verdicts
                                     fl_redo = true;
                                     break;
+#else
+                                    // (deferred verdict, per body) a state of the last body fell below the floor: the statement
+                                    // is back at its checkpoint -- the steps up to there are certified and committed, the next
+                                    // run starts there with the per-trip verdicts
+                                    if (fl_per_trip) { // (the per-trip loop has no status 3)
+                                        fl_redo = true;
+                                        break;
+                                    }
+                                    cs = (uint32_t)__builtin_amdgcn_readfirstlane((int)off) >> 4;
+                                    if (kStats)
+                                        c_free_steps += cs - c_in;
+                                    c = cs, wO = wv, failed = false, fl_next = true;
+                                    break;
+#endif
                                 }
                                 cs = (uint32_t)__builtin_amdgcn_readfirstlane((int)off) >> 4;
                                 if (kStats)
@@ -3030,7 +3170,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                         fl_per_trip = true;
                         continue;
                     }
-                    fl_per_trip = false;
+                    fl_per_trip = fl_next;
                     if (c != 0u) {
                         // back to two reduced HDRFloats: each part's own exponent moves out of the float (exact; an accepted
                         // state has no zero part)
@@ -3053,6 +3193,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                     }
                 }
             }
+            FS_PO(po_t2 = __builtin_readcyclecounter(); po_run += po_t2 - po_t1);
             if constexpr (kRuns && !kBla && std::is_same<F, float>::value) {
               if (!sc_stopped) {
                 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -3172,11 +3313,14 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                     DeltaSubNY = hreal<F>{O128.y * 0.0078125f, OYe};
                     Zcached_at = 0xFFFFFFFFu;
                 }
-                if (retry_scaled)
+                if (retry_scaled) {
+                    FS_PO(po_quiet += __builtin_readcyclecounter() - po_t2);
                     continue;
+                }
               }
             }
 
+            FS_PO(po_quiet += __builtin_readcyclecounter() - po_t2);
             FS_PH(ph_t = __builtin_readcyclecounter(); ph_n_step++;
                   ph_lanes_step += (uint64_t)__popcll(__builtin_amdgcn_ballot_w64(true)));
             const hreal<F> OX = DeltaSubNX, OY = DeltaSubNY;
@@ -3418,7 +3562,41 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
             atomicAdd((unsigned long long *)&A.stats[10], (unsigned long long)c_blk_violation);
         }
     }
+#ifdef FS_TRACE_WAVES
+    // measurement build (tools/c2_wave_trace.py): when and where every wave of a perturbation-only launch ran
+    if (kStats && !kBla && !kRefill && A.stats) {
+        uint64_t steps = c_pt;
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint64_t o = __shfl_down(steps, off);
+            steps = o > steps ? o : steps;
+        }
+        if ((threadIdx.x & 63) == 0) {
+            uint32_t hw_id, xcc_id;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+            const uint64_t wave = ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+            uint64_t *t = A.stats + 16 + 4 * wave;
+            t[0] = ps_trace_t0;
+            t[1] = wall_clock64();
+            t[2] = ((uint64_t)xcc_id << 32) | hw_id;
+            t[3] = (steps & 0xFFFFFFFFull) | (((__builtin_readcyclecounter() - ps_trace_c0) >> 10) << 32);
+        }
+    }
+#endif
 #ifdef FS_PROFILE_CYCLES
+    if (kStats && !kBla && !kRefill) {
+        // (a lane accumulates while its pixel runs: the wave's figures are those of its longest-running lane)
+        po_total = __builtin_readcyclecounter() - po_t0;
+        uint64_t v[6] = {po_total, po_run, po_asm, po_quiet, po_n_run, po_n_asm};
+        for (int i = 1; i < 6; i++)
+            for (int off = 32; off > 0; off >>= 1) {
+                const uint64_t o = __shfl_xor(v[i], off);
+                v[i] = o > v[i] ? o : v[i];
+            }
+        if ((threadIdx.x & 63) == 0)
+            for (int i = 0; i < 6; i++)
+                atomicAdd((unsigned long long *)&A.stats[16 + i], (unsigned long long)v[i]);
+    }
     if (kStats && kBla && (threadIdx.x & 63) == 0) {
         // slots 16.. of the statistics buffer (fs_read_stats_raw; the renderer allocates them in this build)
         const uint64_t v[13] = {ph_lookup, ph_jump, ph_step, ph_literal, ph_n_lookup, ph_n_jump,

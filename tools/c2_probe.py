@@ -28,7 +28,7 @@ assert r.RenderCurrent(v.num_iterations, out) == 0
 r.SyncComputeStream()
 cap = out[:H, :W] >= v.num_iterations
 per_band = cap.reshape(H // 8, 8, W).sum(axis=(1, 2))
-band = int(per_band.argmax())
+band = int(os.environ.get("C2_BAND", per_band.argmax()))
 print(json.dumps({"frame_ms": round(frame_ms, 2), "pixels_at_cap": int(cap.sum()), "band": band,
                   "band_pixels_at_cap": int(per_band[band]), "bands_with_cap_pixels": int((per_band > 0).sum())}))
 assert r.SetRowBands(band * 8, 8, H) == 0

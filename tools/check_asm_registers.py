@@ -24,7 +24,7 @@ import check_inflight_loads as chk  # noqa: E402
 SCRATCH = {("v", i) for i in (56, 57, 58, 59, 61, 62)} | {("s", i) for i in list(range(36, 64)) + [66]}
 # the 16-step body (FS_FAST_LOOP_FD16): entries in s[36:67] with s[66:67] an in/out operand, block bounds in s[72:75] with s75 in/out
 SCRATCH16 = {("v", i) for i in (56, 57, 58, 59, 61, 62)} | {("s", i) for i in list(range(36, 66)) + [72, 73, 74]}
-NAMED = {("v", i) for i in range(48, 63)} | {("s", i) for i in range(36, 76)}
+NAMED = {("v", i) for i in range(46, 63)} | {("s", i) for i in range(36, 76)}  # (v[46:47]: FS_FAST_LOOP_FD16P's checkpoint)
 FIRST = re.compile(r"^v_pk_fma_f32 v\[56:57\], v\[48:49\], v\[\d+:\d+\], s\[6(4:65|6:67)\]")
 
 
@@ -91,9 +91,18 @@ def regions(instrs):
     while i < len(instrs):
         if FIRST.match(instrs[i]["text"]):
             # back to the loop's top: the nearest preceding write of v62 from v60 (block test) or of v61 (deferred form)
+            # (the pipelined 16-step body, FS_FAST_LOOP_FD16P, resets v61 a second time at its per-body checkpoint, right in front
+            # of the first packed instruction: its top is the EARLIER of the two, in front of the statement's first loads)
             a = i
             while a > 0 and i - a < 12 and not (instrs[a]["text"].startswith(("v_max_i32_e32 v62, v60", "v_mov_b32_e32 v61, 0x7f800000"))):
                 a -= 1
+            if instrs[a]["text"].startswith("v_mov_b32_e32 v61, 0x7f800000") and "s[66:67]" in instrs[i]["text"]:
+                k = a - 1
+                while k > 0 and a - k < 28:
+                    if instrs[k]["text"].startswith("v_mov_b32_e32 v61, 0x7f800000"):
+                        a = k
+                        break
+                    k -= 1
             # forward to the common end: the first s_waitcnt lgkmcnt(0) that no branch of the region jumps over
             b = i
             last_target = i
