@@ -856,82 +856,99 @@ constexpr int kFloorBits = (127 - FS_FL_FLOOR_EXP) << 23;
 // only thing in flight at either wait is the half requested eight steps ago.  A wave that is alone on its SIMD no longer
 // stands still for an L2 round trip per body (C2's interior pixels: 4.7 M dependent steps; FS_FAST_LOOP_FD16 with its warming
 // loads measured ~30 ns per step against the ~19 ns of the step's dependent arithmetic).  Same registers as FS_FAST_LOOP_FD16,
-// same statuses, same exits; the exit taken at step 6 waits before it writes s[66:67] / s75 (the upper half is in flight
-// there).  The half requested past the end of a run is never used (the companion arrays carry 32 entries of slack).
+// statuses 0 and 3 as there (4: below).  The half requested past the end of a run is never used (the companion arrays carry 32
+// entries of slack).
 // The deferred floor verdict is taken PER BODY: the state a body starts from is kept (v[46:47], its step count in `cko`) once
 // the verdict over the body before has passed, and a state below the floor sends the statement back to that checkpoint with
 // status 3 -- the caller commits the certified steps and lets the per-trip loop (FS_FAST_LOOP_FL) find the failing trip in
 // the sixteen steps that follow, instead of repeating the whole run with it (a 2048-step run that ends on a floor failure,
 // which is how most runs of C2's never-escaping pixels end, was executed twice).
-#define FS_FD16P_PAIR(EA, EB_, BW, LBL, WAIT, LOADS)                                                                \
-    FS_PK_F(FS_R0, EA) FS_FL_ACC("v48", "v49") FS_PK_MA(FS_R0) FS_T_X("v48", "v49") FS_PK_MB(FS_R0)                 \
-    FS_PK_P FS_BT_DC_MAX FS_PK_A(FS_R1) FS_BT_DC_ADD WAIT                                                           \
-    FS_PK_F(FS_R1, EB_) "v_cmp_lt_i32_e64 %[m], " BW ", v62\n\t" FS_BT_H_CMP FS_PK_MA(FS_R1)                         \
-    FS_BT_H_OR FS_PK_MB(FS_R1) FS_PK_P "s_cbranch_scc1 " LBL "\n\t" LOADS FS_PK_A(FS_R2)
+// The tests of the blocks INSIDE a body (its second to fourth) are deferred too (round 5): a wave that is alone on its SIMD
+// issues in order, and `compare -> scalar or -> branch` makes it wait for the vector pipeline to drain at every block -- measured
+// on the isolated loop (tools/microbench/lone_pace.hip) 20.7 ns per step with the three branches, 17.6 without, 11.0 for the
+// arithmetic alone.  Each of those blocks leaves its verdict in v63 instead (positive = violated; it only grows):
+//     max(max|w|, max|dc|) + Esh - bound, saturating (the "never" bound is the most negative integer),  and  max(..) - 2^14 (H;
+//     max|dc| 2^-E <= 2^7 by the start condition, so taking the maximum with it changes nothing there)
+// and the body's steps run on whatever comes.  ONE verdict per body, at the top of the next one (and on every way out): the floor
+// accumulator v61 and v63 together; a violation of either sends the statement back to the body's checkpoint -- status 3 (floor
+// alone: the caller commits the certified steps and lets the per-trip loop find the failing trip) or 4 (a block test: the
+// caller takes the block in front of it through the tested form, as it does for status 0; the entry values it needs it reads
+// itself).  What ran past a violated block test is discarded with the roll-back: nothing but registers was written.
+// The first block of a body is treated the same way (blocks that need their tests are 0.1 % of the steps of C2's long pixels:
+// a body run in vain in front of each costs nothing next to one more drain of the pipeline per body).
+#define FS_FD16D_PAIR(EA, EB_, BW, WAIT, LOADS)                                                                     \
+    FS_PK_F(FS_R0, EA) FS_FL_ACC("v48", "v49") FS_PK_MA(FS_R0)                                                      \
+    "v_max3_f32 v62, |v48|, |v49|, %[imdc]\n\t"                                                                     \
+    FS_PK_MB(FS_R0) FS_PK_P                                                                                         \
+    "v_subrev_u32_e32 v45, 0x46800000, v62\n\t"                                                                     \
+    FS_PK_A(FS_R1)                                                                                                  \
+    "v_add_u32_e32 v62, v62, %[esh]\n\t" WAIT                                                                       \
+    FS_PK_F(FS_R1, EB_)                                                                                             \
+    "v_sub_i32 v62, v62, " BW " clamp\n\t"                                                                          \
+    FS_PK_MA(FS_R1)                                                                                                 \
+    "v_max3_i32 v63, v63, v62, v45\n\t"                                                                             \
+    FS_PK_MB(FS_R1) FS_PK_P LOADS FS_PK_A(FS_R2)
 #define FS_FAST_LOOP_FD16P                                                                                          \
     asm volatile(                                                                                                   \
         "v_mov_b32_e32 v61, 0x7f800000\n\t" /* the first body's lower half; every later body finds its own requested */ \
+        "v_bfrev_b32_e32 v63, 1\n\t"                                                                                \
         "s_lshr_b32 %[oc], %[off], 1\n\t"                                                                           \
         "s_load_dwordx16 s[36:51], s[68:69], %[oc]\n\t"                                                             \
         "s_load_dwordx2 s[72:73], s[70:71], %[off]\n"                                                               \
-        ".Lfp_loop_%=:\n\t" /* sixteen steps left?  the first block's tests: max(max|w|, max|dc|) against s75, H */  \
-        FS_BT_DC_MAX "s_cmp_gt_u32 %[off], %[lim16]\n\t" FS_BT_DC_ADD FS_FL_C                                       \
-        "s_cbranch_scc1 .Lfp_out_%=\n\t" /* the floor verdict over the body before: see the checkpoint below */     \
-        "s_cbranch_vccnz .Lfp_redo_%=\n\t"                                                                          \
-        "v_cmp_lt_i32_e64 %[m], s75, v62\n\t" FS_BT_H_CMP FS_BT_H_OR                                                \
+        ".Lfp_loop_%=:\n\t" /* the verdict over the body before: floor (flr > the smallest part seen) or a block test */ \
+        "v_sub_u32_e32 v45, %[flr], v61\n\t"                                                                        \
+        FS_BT_DC_MAX "s_cmp_gt_u32 %[off], %[lim16]\n\t"                                                            \
+        "v_max_i32_e32 v45, v45, v63\n\t"                                                                           \
+        FS_BT_DC_ADD                                                                                                \
+        "v_cmp_lt_i32_e32 vcc, 0, v45\n\t"                                                                          \
+        "s_cbranch_vccnz .Lfp_redo_%=\n\t" /* sixteen steps left? */                                                \
         "s_cbranch_scc1 .Lfp_out_%=\n\t" /* the checkpoint: every state up to here is certified */                  \
         "v_mov_b32_e32 v46, v48\n\t"                                                                                \
         "v_mov_b32_e32 v47, v49\n\t"                                                                                \
         "s_mov_b32 %[cko], %[off]\n\t"                                                                              \
-        "v_mov_b32_e32 v61, 0x7f800000\n\t" /* steps 1 .. 4; the lower half has landed, the upper half is requested */ \
+        "v_mov_b32_e32 v61, 0x7f800000\n\t" /* steps 1 .. 4 + the first block's verdict (s75, H) into v63 */        \
         FS_PK_F(FS_R0, "s[66:67]")                                                                                  \
-        "s_waitcnt lgkmcnt(0)\n\t"                                                                                  \
+        "v_sub_i32 v62, v62, s75 clamp\n\t"                                                                         \
+        "v_subrev_u32_e32 v45, 0x46800000, v60\n\t"                                                                 \
+        "s_waitcnt lgkmcnt(0)\n\t" /* the lower half has landed, the upper half is requested */                     \
         "s_lshr_b32 %[oc], %[off], 1\n\t"                                                                           \
         "s_load_dwordx16 s[52:67], s[68:69], %[oc] offset:0x40\n\t"                                                 \
         "s_load_dwordx2 s[74:75], s[70:71], %[off] offset:0x8\n\t"                                                  \
-        FS_PK_MA(FS_R0) FS_PK_MB(FS_R0) FS_PK_P FS_PK_A(FS_R1)                                                      \
+        FS_PK_MA(FS_R0)                                                                                             \
+        "v_max_i32_e32 v63, v62, v45\n\t"                                                                           \
+        FS_PK_MB(FS_R0) FS_PK_P FS_PK_A(FS_R1)                                                                      \
         FS_PK_F(FS_R1, "s[36:37]") FS_FL_ACC("v50", "v51") FS_PK_MA(FS_R1) FS_PK_MB(FS_R1) FS_PK_P FS_PK_A(FS_R2)   \
         FS_PK_F(FS_R2, "s[38:39]") FS_FL_ACC("v52", "v53") FS_PK_MA(FS_R2) FS_PK_MB(FS_R2) FS_PK_P FS_PK_A(FS_R3)   \
         FS_PK_F(FS_R3, "s[40:41]") FS_FL_ACC("v54", "v55") FS_PK_MA(FS_R3) FS_PK_MB(FS_R3) FS_PK_P FS_PK_A(FS_R0)   \
         /* steps 5 .. 8 */                                                                                          \
-        FS_FD16P_PAIR("s[42:43]", "s[44:45]", "s72", ".Lfp_b1_%=", "", "") FS_FD16_TAIL("s[46:47]", "s[48:49]")     \
+        FS_FD16D_PAIR("s[42:43]", "s[44:45]", "s72", "", "") FS_FD16_TAIL("s[46:47]", "s[48:49]")                   \
         /* steps 9 .. 12: the upper half has landed (step 10 reads E8); the next body's lower half is requested */   \
-        FS_FD16P_PAIR("s[50:51]", "s[52:53]", "s73", ".Lfp_b2_%=", "s_waitcnt lgkmcnt(0)\n\t",                      \
+        FS_FD16D_PAIR("s[50:51]", "s[52:53]", "s73", "s_waitcnt lgkmcnt(0)\n\t",                                    \
                       "s_load_dwordx16 s[36:51], s[68:69], %[oc] offset:0x80\n\t"                                   \
                       "s_load_dwordx2 s[72:73], s[70:71], %[off] offset:0x100\n\t")                                 \
         FS_FD16_TAIL("s[54:55]", "s[56:57]")                                                                        \
         /* steps 13 .. 16 */                                                                                        \
-        FS_FD16P_PAIR("s[58:59]", "s[60:61]", "s74", ".Lfp_b3_%=", "", "") FS_FD16_TAIL("s[62:63]", "s[64:65]")     \
+        FS_FD16D_PAIR("s[58:59]", "s[60:61]", "s74", "", "") FS_FD16_TAIL("s[62:63]", "s[64:65]")                   \
         "s_add_u32 %[off], %[off], 0x100\n\t"                                                                       \
         FS_T_X("v48", "v49") FS_FL_ACC("v48", "v49") "s_branch .Lfp_loop_%=\n"                                      \
-        ".Lfp_b1_%=:\n\t" /* block 2 needs its bound tests (or H): the state is w4 in v[48:49], at entry 3 */       \
-        "s_waitcnt lgkmcnt(0)\n\t" /* (the upper half is in flight: it must not land on what is written here) */    \
-        "s_mov_b64 s[66:67], s[42:43]\n\t"                                                                          \
-        "s_mov_b32 s75, s72\n\t"                                                                                    \
-        "s_add_u32 %[off], %[off], 0x40\n\t"                                                                        \
-        "s_branch .Lfp_out_%=\n"                                                                                    \
-        ".Lfp_b2_%=:\n\t" /* block 3: w8, entry 7 (nothing is in flight here) */                                   \
-        "s_mov_b64 s[66:67], s[50:51]\n\t"                                                                          \
-        "s_mov_b32 s75, s73\n\t"                                                                                    \
-        "s_add_u32 %[off], %[off], 0x80\n\t"                                                                        \
-        "s_branch .Lfp_out_%=\n"                                                                                    \
-        ".Lfp_b3_%=:\n\t" /* block 4: w12, entry 11 (the next lower half is in flight: other registers) */         \
-        "s_mov_b64 s[66:67], s[58:59]\n\t"                                                                          \
-        "s_mov_b32 s75, s74\n\t"                                                                                    \
-        "s_add_u32 %[off], %[off], 0xc0\n"                                                                          \
-        ".Lfp_out_%=:\n\t" /* the verdict over the states since the checkpoint */                                   \
-        "s_mov_b32 %[st], 0\n\t" FS_FL_C                                                                            \
-        "s_cbranch_vccz .Lfp_end_%=\n"                                                                              \
-        ".Lfp_redo_%=:\n\t" /* a state below the floor: back to the checkpoint (state and step count), status 3 */  \
+        ".Lfp_redo_%=:\n\t" /* back to the checkpoint (state, its max, step count): status 3 (floor) or 4 (a block test) */ \
         "v_mov_b32_e32 v48, v46\n\t"                                                                                \
         "v_mov_b32_e32 v49, v47\n\t"                                                                                \
+        "v_cmp_lt_i32_e32 vcc, 0, v63\n\t"                                                                          \
         "s_mov_b32 %[off], %[cko]\n\t"                                                                              \
-        "s_mov_b32 %[st], 3\n"                                                                                      \
+        FS_T_X("v46", "v47")                                                                                        \
+        "s_mov_b32 %[st], 3\n\t"                                                                                    \
+        "s_cbranch_vccz .Lfp_end_%=\n\t"                                                                            \
+        "s_mov_b32 %[st], 4\n\t"                                                                                    \
+        "s_branch .Lfp_end_%=\n"                                                                                    \
+        ".Lfp_out_%=:\n\t" /* in front of a block that needs its tests, or of the last steps (the verdict has passed) */ \
+        "s_mov_b32 %[st], 0\n"                                                                                      \
         ".Lfp_end_%=:\n\t"                                                                                          \
         "s_waitcnt lgkmcnt(0)"                                                                                      \
         : "+{v[48:49]}"(wv), "={v[50:51]}"(r1), "={v[52:53]}"(r2), "={v[54:55]}"(r3), "={v[56:57]}"(ts_),           \
-          "={v[58:59]}"(ta_), "+{v60}"(mxS), "={v61}"(tn_), "={v62}"(tl_), "={v[46:47]}"(ck_), [m] "=&s"(msk_),     \
-          [st] "=&s"(st), "+{s75}"(pwi), "+{s[66:67]}"(zS), [off] "+s"(off), [oc] "=&s"(oc_), [cko] "=&s"(cko_)     \
+          "={v[58:59]}"(ta_), "+{v60}"(mxS), "={v61}"(tn_), "={v62}"(tl_), "={v[46:47]}"(ck_), "={v45}"(th_),       \
+          "={v63}"(va_), [st] "=&s"(st), "+{s75}"(pwi), "+{s[66:67]}"(zS), [off] "+s"(off), [oc] "=&s"(oc_),        \
+          [cko] "=&s"(cko_)                                                                                         \
         : [se] "v"(sE2), [dc] "v"(dcs), [esh] "v"(Esh), [imdc] "v"(imdc), [lim16] "s"(lim16), "{s[68:69]}"(zpb2),   \
           "{s[70:71]}"(zqbp), [flr] "s"(kFloorBits)                                                                 \
         : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50",  \
@@ -3005,6 +3022,8 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                                 int st, ebo, pf_, pg_, ph_, pi_, pj_;
                                 uint32_t oc_, cko_;
                                 f2 ck_;
+                                float th_;
+                                int va_;
                                 uint32_t off = cs << 4;
                                 const uint32_t c_in = cs;
 #if FS_FL_EVERY && !defined(FS_VERIFY_FLOOR)
@@ -3052,10 +3071,28 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                                     break;
 #endif
                                 }
-                                cs = (uint32_t)__builtin_amdgcn_readfirstlane((int)off) >> 4;
-                                if (kStats)
-                                    c_free_steps += cs - c_in;
-                                pwi = __builtin_amdgcn_readfirstlane(pwi);
+#ifndef FS_FD16_SERIAL
+                                if (st == 4) {
+                                    // a block test inside the last body failed: the statement is back at the body's checkpoint.  Its
+                                    // first block passed its test, so it runs once more -- through the tested form below, which is
+                                    // what every block in front of a failed test gets; 2Z and the block bound of the entry the state
+                                    // is at come from the companion array (the statement's copies are those of a later entry)
+                                    cs = (uint32_t)__builtin_amdgcn_readfirstlane((int)off) >> 4;
+                                    if (kStats)
+                                        c_free_steps += cs - c_in;
+                                    const float4 ez = zs[ref_u + cs];
+                                    zS = (f2){__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ez.x))),
+                                              __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ez.y)))};
+                                    pwi = __builtin_amdgcn_readfirstlane(__float_as_int(ez.w));
+                                    st = 0;
+                                } else
+#endif
+                                {
+                                    cs = (uint32_t)__builtin_amdgcn_readfirstlane((int)off) >> 4;
+                                    if (kStats)
+                                        c_free_steps += cs - c_in;
+                                    pwi = __builtin_amdgcn_readfirstlane(pwi);
+                                }
                                 if (st != 0) {
                                     c = cs, wO = st == 1 ? wv : r2, failed = true;
                                     break;

@@ -24,7 +24,7 @@ import check_inflight_loads as chk  # noqa: E402
 SCRATCH = {("v", i) for i in (56, 57, 58, 59, 61, 62)} | {("s", i) for i in list(range(36, 64)) + [66]}
 # the 16-step body (FS_FAST_LOOP_FD16): entries in s[36:67] with s[66:67] an in/out operand, block bounds in s[72:75] with s75 in/out
 SCRATCH16 = {("v", i) for i in (56, 57, 58, 59, 61, 62)} | {("s", i) for i in list(range(36, 66)) + [72, 73, 74]}
-NAMED = {("v", i) for i in range(46, 63)} | {("s", i) for i in range(36, 76)}  # (v[46:47]: FS_FAST_LOOP_FD16P's checkpoint)
+NAMED = {("v", i) for i in range(45, 64)} | {("s", i) for i in range(36, 76)}  # (v45 .. v47, v63: FS_FAST_LOOP_FD16P's checkpoint and deferred verdicts)
 FIRST = re.compile(r"^v_pk_fma_f32 v\[56:57\], v\[48:49\], v\[\d+:\d+\], s\[6(4:65|6:67)\]")
 
 
@@ -107,6 +107,14 @@ def regions(instrs):
             b = i
             last_target = i
             index = {ins["addr"]: k for k, ins in enumerate(instrs)}
+            for k in range(a, i):  # (the branches of the loop's top -- the verdict, the first block's test -- leave forwards too)
+                ins = instrs[k]
+                if ins["op"].startswith(chk.BRANCHES):
+                    imm = int(ins["ops"].split()[0])
+                    imm = imm - 65536 if imm >= 32768 else imm
+                    t = index.get(ins["addr"] + 4 + imm * 4)
+                    if t is not None and t > i:
+                        last_target = max(last_target, t)
             while b + 1 < len(instrs):
                 b += 1
                 ins = instrs[b]
