@@ -290,3 +290,43 @@ def test_native_bla_table_equals_reference_layout_lookup(renderer, native_libs, 
         assert got["native"][1][k] == got["reference_layout"][1][k], k
     if w * h <= 64 * 36:
         assert np.array_equal(got["native"][0], _oracle.bla_hdr32(v, ob, bla))
+
+
+# ---- the step-counting instantiation of the perturbation-only kernel (k_perturb_scalar<float, false, true>): the build
+# bench.py's roofline numerator for C2 is read from, and the one tests/test_isa_asm_registers.py's liveness analysis leaves out
+# (path-insensitive: it cannot rule out one compiler-allocated scalar).  Dynamic evidence instead: its frame is the plain
+# kernel's and the oracle's, its counts are those of the statement-for-statement variant, and they reconcile with the frame.
+@pytest.mark.parametrize("w,h", [(256, 144), (200, 120)])
+def test_counting_instantiation_of_the_perturbation_only_kernel(renderer, native_libs, w, h):
+    v = inputs.View.builtin(5, w, h, antialiasing=1)
+    ob = inputs.Orbit(v)
+    r = renderer
+    n = v.num_iterations
+    got = {}
+    try:
+        for name, variant, counting in (("plain", 0, False), ("counting", 0, True), ("literal_counting", 1, True)):
+            assert r.set_kernel_variant(variant) == 0
+            r.enable_step_count(counting)
+            out = _bla(r, v, ob, None)
+            got[name] = (out, r.read_step_count() if counting else None)
+            r.enable_step_count(False)
+    finally:
+        r.enable_step_count(False)
+        r.set_kernel_variant(0)
+    ref = _oracle.bla_hdr32(v, ob, None)
+    assert np.array_equal(got["plain"][0], ref)
+    assert np.array_equal(got["counting"][0], ref)
+    assert np.array_equal(got["literal_counting"][0], ref)
+    st, lit = got["counting"][1], got["literal_counting"][1]
+    assert st["pixels"] == lit["pixels"] == w * h
+    frame = ref[:h, :w].astype(np.uint64)
+    escaped = int((frame < n).sum())
+    capped = int((frame >= n).sum())
+    assert capped > 0  # interior pixels: the waves this kernel's frame time is made of
+    # every counted iteration is an executed step; an escaping pixel's last step is executed and not counted; a pixel the cycle
+    # test ends early (both variants: the test sits at the rebase, outside the parts that differ) has executed fewer steps than
+    # it reports -- so the two variants must agree with each other exactly and with the frame up to the capped pixels
+    total = int(frame.sum()) + escaped
+    assert st["perturb_steps"] == lit["perturb_steps"], (st["perturb_steps"], lit["perturb_steps"])
+    assert total - capped * n <= st["perturb_steps"] <= total
+    assert st["scaled_runs"] > 0 and st["la_steps"] > 0  # (this path's slot for the steps inside scaled runs)
