@@ -72,3 +72,42 @@ def test_perturbation_only_and_bla_against_the_oracle(renderer, native_libs, nam
         assert r.SyncComputeStream() == 0
         ref = _oracle.bla_hdr32(v, ob, bla, n_iterations=n)
         assert np.array_equal(out[:H, :W], ref[:H, :W]), (name, "bla" if bla is not None else "perturbation only")
+
+
+@pytest.mark.parametrize("name,builtin,gen", _views(), ids=[v[0] for v in _views()])
+def test_perturbation_only_long_runs_tuned_equals_literal(renderer, native_libs, name, builtin, gen):
+    """The same views at a cap that gives the tuned kernel its long scaled runs (2048-step runs, 16-step bodies with one
+    verdict per body and the roll-backs behind it: statuses 3 and 4 of FS_FAST_LOOP_FD16P): the tuned frame against the
+    statement-for-statement variant's, which the test above ties to the oracle."""
+    w, h, cap = 128, 72, 300000
+    if builtin is not None:
+        v = inputs.View.builtin(builtin, w, h, antialiasing=1)
+    else:
+        getcontext().prec = 80
+        (cx, cy), wd = gen
+        cxd, cyd, ww = Decimal(cx), Decimal(cy), Decimal(wd)
+        hh = ww * h / w
+        v = inputs.View(str(cxd - ww / 2), str(cyd - hh / 2), str(cxd + ww / 2), str(cyd + hh / 2), w, h, num_iterations=cap)
+    try:
+        ob = inputs.Orbit(v)
+    except Exception as e:
+        pytest.skip(str(e))
+    if ob.count > 2_000_000:
+        pytest.skip("orbit of %d entries" % ob.count)
+    n = min(v.num_iterations, cap)
+    r = renderer
+    co = _pairs(v.coords_perturb(ob))
+    frames = []
+    try:
+        for variant in (0, 1):
+            assert r.set_kernel_variant(variant) == 0
+            assert r.InitializeMemory(w, h, 1, None, 0, 0, 0, False) == 0
+            assert r.ClearMemory() == 0
+            assert r.RenderPerturbBLA(None, ob, None, None, None, *co, n) == 0
+            out = r.new_iter_buffer()
+            assert r.RenderCurrent(n, out) == 0
+            assert r.SyncComputeStream() == 0
+            frames.append(out[:h, :w].copy())
+    finally:
+        r.set_kernel_variant(0)
+    assert np.array_equal(frames[0], frames[1]), (name, int((frames[0] != frames[1]).sum()))
