@@ -2503,7 +2503,8 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
             l = (t / tiles_x) * 8u + (lane >> 3);
             // the waves of the long tiles decide when the frame ends: they ask the instruction arbiter for priority over
             // the waves they share their SIMD with while the bulk of the frame is still being rendered
-            if (w < A.tile_order[gridDim.x * gridDim.y * (blockDim.x >> 6)])
+            const uint32_t nl = A.tile_order[gridDim.x * gridDim.y * (blockDim.x >> 6)];
+            if ((nl >> 31) != 0u ? ((w & 3u) == 0u && (w >> 2) < (nl & 0x7FFFFFFFu)) : w < nl)
                 __builtin_amdgcn_s_setprio(3);
         } else {
             tile_pixel(x, l);

@@ -292,17 +292,25 @@ __global__ void __launch_bounds__(1024) k_tile_order(const uint32_t *__restrict_
     }
     const uint32_t total_long = s_cnt[1023];
     uint32_t at_long = s_cnt[threadIdx.x] - mine; // long tiles before this chunk
-    uint32_t at_short = total_long + (lo - at_long);
+    uint32_t at_short = lo - at_long;            // short tiles before this chunk
+    // One long tile per WORKGROUP while there are three short ones to go with each (round 5): the four waves of a workgroup
+    // share a CU, and never-escaping waves that share one were measured to slow each other down (tools/c2_cu_pace.py: the
+    // long waves of one workgroup speed up and slow down together from launch to launch).  Long tile k goes to slot 4 k,
+    // the first 3 k short tiles fill the slots next to them, the rest follow.  Otherwise: the long tiles first, as before.
+    const bool spread = 3u * total_long <= n - total_long;
     for (uint32_t i = lo; i < hi; i++) {
-        if (is_long(i))
-            order[at_long++] = i;
-        else
-            order[at_short++] = i;
+        if (is_long(i)) {
+            order[spread ? 4u * at_long : at_long] = i;
+            at_long++;
+        } else {
+            const uint32_t sidx = at_short++;
+            order[!spread ? total_long + sidx : (sidx < 3u * total_long ? 4u * (sidx / 3u) + 1u + sidx % 3u : total_long + sidx)] = i;
+        }
     }
     for (uint32_t i = n + threadIdx.x; i < n_slots; i += 1024u)
         order[i] = 0xFFFFFFFFu;
-    if (threadIdx.x == 0)
-        order[n_slots] = total_long; // the waves below this number hold the long tiles (they ask for issue priority)
+    if (threadIdx.x == 0) // the number of long tiles (their waves ask for issue priority); the top bit: one per workgroup
+        order[n_slots] = total_long | (spread ? 0x80000000u : 0u);
 }
 } // namespace
 
