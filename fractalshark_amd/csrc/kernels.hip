@@ -1066,10 +1066,18 @@ __device__ __forceinline__ uint32_t scaled_run_length(uint32_t left)
 #endif
 constexpr uint32_t kPoChunk = FS_PO_CHUNK;
 static_assert(kPoChunk % 16 == 0 && kPoChunk >= kScaledChunk && kPoChunk <= (1u << 20), "whole 16-step bodies; offsets stay 32-bit");
+// Between the tiers: when every lane has as many steps left as the first one (the lanes of a never-escaping tile walk the orbit
+// together), the run takes exactly those -- a pass over View 5's 16 046-entry orbit is then 8 runs instead of 17 (seven of 2048
+// and the tail in one piece instead of 256 + 256 + ... + 16 + 16).  Multiples of four: the tested form behind the statement
+// advances in four-step blocks.
 __device__ __forceinline__ uint32_t scaled_run_length_po(uint32_t left)
 {
-    if (kPoChunk > kScaledChunk && __builtin_amdgcn_ballot_w64(left < kPoChunk) == 0ull)
-        return kPoChunk;
+    if (kPoChunk > kScaledChunk) {
+        const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)left);
+        const uint32_t want = (first < kPoChunk ? first : kPoChunk) & ~3u;
+        if (want > kScaledChunk && __builtin_amdgcn_ballot_w64(left < want) == 0ull)
+            return want;
+    }
     return scaled_run_length(left);
 }
 
@@ -2412,6 +2420,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
     uint64_t c_single = 0, c_runs = 0; // probes of the perturbation-only float path (tools/c2_probe.py)
     uint64_t c_blk_violation = 0; // (verification build) must stay 0
     uint64_t c_free_steps = 0, c_tested_blocks = 0; // lane-steps inside the untested loop / tested four-step blocks (per lane)
+    uint32_t c_end[5] = {0, 0, 0, 0, 0}; // (counting build, per wave) why scaled runs of the perturbation-only path end: their length / H / a tested block failed / floor (status 3) -- and [4] roll-backs of a block test (status 4: not an end)
     // (kBla probes, statistics words 8..12: lane-passes through the quiet step / the step with z / the literal step, the
     // quiet jump / the jump with z -- which share of the actions the hand-written kernel's fast forms must cover)
     uint64_t c_q_step = 0, c_z_step = 0, c_lit_step = 0, c_q_jump = 0, c_z_jump = 0;
@@ -3069,6 +3078,8 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                                     if (kStats)
                                         c_free_steps += cs - c_in;
                                     c = cs, wO = wv, failed = false, fl_next = true;
+                                    if (kStats)
+                                        c_end[3]++;
                                     break;
 #endif
                                 }
@@ -3086,6 +3097,8 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                                               __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ez.y)))};
                                     pwi = __builtin_amdgcn_readfirstlane(__float_as_int(ez.w));
                                     st = 0;
+                                    if (kStats)
+                                        c_end[4]++;
                                 } else
 #endif
                                 {
@@ -3102,11 +3115,15 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
 #endif
                             if (cs + 4u > rl) {
                                 c = cs, wO = wv, failed = false;
+                                if (kStats)
+                                    c_end[0]++;
                                 break;
                             }
                             // H where a block starts: the run ends and the next one re-centres the scale
                             if (__builtin_amdgcn_ballot_w64(!(mxS < FS_FL_HIGH)) != 0ull) {
                                 c = cs, wO = wv, failed = false;
+                                if (kStats)
+                                    c_end[1]++;
                                 break;
                             }
                             if (kStats)
@@ -3133,6 +3150,8 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
 #endif
                             if (vp_ != 0ull) {
                                 c = cs, wO = wv, failed = true;
+                                if (kStats)
+                                    c_end[2]++;
                                 break;
                             }
                             z2 = (f2){ub.x, ub.y};
@@ -3150,12 +3169,16 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
 #endif
                             if (vq_ != 0ull) {
                                 c = cs + 2, wO = w2, failed = true;
+                                if (kStats)
+                                    c_end[2]++;
                                 break;
                             }
                             cs += 4;
                             wv = w4, mxS = mx_d, zS = (f2){ud.x, ud.y}, pwi = __float_as_int(ud.w);
                             if (cs >= rl) {
                                 c = cs, wO = wv, failed = false;
+                                if (kStats)
+                                    c_end[0]++;
                                 break;
                             }
                         }
@@ -3598,6 +3621,9 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
             atomicAdd((unsigned long long *)&A.stats[8], (unsigned long long)c_free_steps);
             atomicAdd((unsigned long long *)&A.stats[9], (unsigned long long)c_tested_blocks);
             atomicAdd((unsigned long long *)&A.stats[10], (unsigned long long)c_blk_violation);
+            if ((threadIdx.x & 63) == 0) // (per wave: lane 0 of a tile is there from the first step to the wave's last)
+                for (int i = 0; i < 5; i++)
+                    atomicAdd((unsigned long long *)&A.stats[11 + i], (unsigned long long)c_end[i]);
         }
     }
 #ifdef FS_TRACE_WAVES

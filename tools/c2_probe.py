@@ -43,7 +43,9 @@ for stats in (False, True):
         st = r.read_step_count()
         raw = (C.c_uint64 * 32)()
         assert lib.fs_read_stats_raw(r._h, raw, 32) == 0
-        d.update({"lane_steps_in_the_untested_loop": raw[8], "lane_steps_in_tested_blocks": 4 * raw[9]})
+        d.update({"lane_steps_in_the_untested_loop": raw[8], "lane_steps_in_tested_blocks": 4 * raw[9],
+                  "runs_ended_by (per wave, as lane 0 saw them)": {"their_length": raw[11], "H": raw[12], "a_tested_block_failing": raw[13],
+                                                                   "floor_status_3": raw[14]}, "block_test_roll_backs_status_4": raw[15]})
         runs = max(1, st["scaled_runs"])
         d.update({"steps": st["perturb_steps"], "scaled_steps": st["la_steps"], "scaled_runs": st["scaled_runs"],
                   "single_steps": st["at_iterations"], "literal_wave_trips": st["careful_steps"],
