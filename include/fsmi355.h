@@ -315,8 +315,9 @@ uint32_t fs_kernel_ms_history(const fs_renderer *r, float *ms_out, uint32_t n);
  *                         HDRFloat<float> fs_render_lav2 (self-recorded order, see fs_forget_tile_costs) launch a frame's 8 x 8
  *                         tiles in their natural order.  Default for frames with an iteration limit of 2^18 or more and
  *                         at least 4096 tiles: the tiles that hold long-running pixels first (a probe launch runs every
- *                         tile's centre pixel for n_iterations / 32 steps) -- which wave renders which tile
- *                         changes no pixel.
+ *                         tile's centre pixel for n_iterations / 32 steps), ONE to a workgroup with three
+ *                         short tiles beside it (never-escaping waves that share a CU slow each other down) --
+ *                         which wave renders which tile changes no pixel.
  *                         The same switch keeps the HDRFloat<double> / HDRFloat<CudaDblflt> fs_render_lav2 frames in the tile
  *                         mapping: by default, from the second frame of a view on (same geometry, row bands, orbit, coordinates,
  *                         iteration limit, mode), lane s of the launch renders the pixel that ranked s-th by iteration count in
