@@ -524,6 +524,10 @@ def main():
     is_po = wl == "c2_po"
     ordered_frames = bool(r.last_frame_tile_ordered()) if (is_lav2 or is_po) else False
     perturb_steps, at_iters, la_steps = float(st["perturb_steps"]), float(st["at_iterations"]), float(st["la_steps"])
+    # HDRFloat<double> / <CudaDblflt> LAv2: the AT iterations the launch actually RAN (statistics word 5 of k_lav2_lit / k_lav2_2x32: the AT loop's cycle search
+    # spares a pixel inside the set most of the iterations the limit asks of it -- same state, same count, same frame).  The
+    # roofline prices executed work; at_iterations_per_launch stays what the reference's loop would run.
+    at_iters_executed = float(st.get("careful_steps", 0)) if (wl in ("c4_hdr64", "c4_2x32") and st.get("careful_steps")) else at_iters
     lane_slots = st["lane_slots"]
     b_main = state["last"]
     checksum = int(host_np[b_main][:H, :W].astype(np.uint64).sum()) if rank == 0 else None
@@ -650,12 +654,12 @@ def main():
             # 40 flop.  Beside it (frac_issued_ops) the binary32 operations the double-float sequences issue for them (DESIGN.md
             # 4.4): product = 12 flop (1 mul, 4 fma, 3 add), sum = 20 flop; AT iteration = 8 products + 5 sums, perturbation
             # step = 12 products + 10 sums + 6 exact power-of-two scalings (another 6 products), LA step = 22 products + 12 sums.
-            flops = at_iters * 10.0 + perturb_steps * FLOP_PER_STEP + la_steps * 40.0
-            flops_issued = at_iters * 196.0 + perturb_steps * 416.0 + la_steps * 504.0
+            flops = at_iters_executed * 10.0 + perturb_steps * FLOP_PER_STEP + la_steps * 40.0
+            flops_issued = at_iters_executed * 196.0 + perturb_steps * 416.0 + la_steps * 504.0
         elif is64:
             # HDRFloat<double>: FP64 operations; AT iteration = 5 mul + 5 add (z*z + c on bare mantissas + the norm),
             # perturbation step = 18, LA step = 2 complex mul-adds + 2 norms = 40
-            flops = at_iters * 10.0 + perturb_steps * FLOP_PER_STEP + la_steps * 40.0
+            flops = at_iters_executed * 10.0 + perturb_steps * FLOP_PER_STEP + la_steps * 40.0
         elif is_scaled:
             # scaled kernel counters: [0] rescales, [1] full-precision (HDRFloat) steps, [2] binary32 steps; every step is
             # the 18-flop perturbation step of SURVEY 8(d)
@@ -670,6 +674,11 @@ def main():
         achieved = flops / (avg_kernel_ms * 1e-3) / 1e12
         roof = {"bound": "valu", "achieved": round(achieved, 4), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 5), "traffic": traffic}
+        if at_iters_executed != at_iters:
+            roof["at_iterations_executed_per_launch"] = at_iters_executed
+            roof["what"] = ("frac prices the work the launch RAN: at_iterations_executed (the cycle search of the AT loop spares pixels "
+                            "inside the set most of the at_iterations_per_launch the reference's loop runs for the same frame), "
+                            "perturbation and LA steps as counted")
         if flops_issued is not None:
             roof["frac_issued_ops"] = round(flops_issued / (avg_kernel_ms * 1e-3) / 1e12 / peak, 5)
             roof["what"] = ("frac = algorithmic flop (SURVEY 8(d): AT 10 / step 18 / LA step 40) / kernel time / FP32 vector peak; "

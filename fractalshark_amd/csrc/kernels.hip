@@ -289,7 +289,7 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
         ordered_pixel(A.frame, A.pixel_order, X, L);
     else
         tile_pixel(X, L);
-    uint64_t c_at = 0, c_la = 0, c_pt = 0, c_px = 0;
+    uint64_t c_at = 0, c_la = 0, c_pt = 0, c_px = 0, c_at_exec = 0; // (c_at_exec: AT iterations actually run -- the cycle search of at_perform spares the rest)
     const bool in_buffer = X < A.frame.width && L < A.frame.local_rows;
     const uint32_t Y = in_buffer ? global_row(A.frame, L) : 0xFFFFFFFFu;
     const bool live = in_buffer && Y < A.frame.height;
@@ -310,9 +310,9 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
                 hcplx<F> c = hc_add(hc_mul(DeltaSub0, ldc(A.at.CCoeff)), ldc(A.at.RefC));
                 hc_reduce(c);
                 hcplx<F> z;
-                IterT i;
+                IterT i, i_exec = 0;
                 if (kFastAT) {
-                    at_perform<F, IterT>(c, ldr(A.at.SqrEscapeRadius), ATMaxIt, z, i);
+                    at_perform<F, IterT>(c, ldr(A.at.SqrEscapeRadius), ATMaxIt, z, i, kStats ? &i_exec : nullptr);
                 } else {
                     z = hc_zero<F>();
                     const hreal<F> esc = ldr(A.at.SqrEscapeRadius);
@@ -328,8 +328,10 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
                 hc_reduce(dz);
                 DeltaSubN = dz;
                 iterations = i * at_step;
-                if (kStats)
+                if (kStats) {
                     c_at = i;
+                    c_at_exec = kFastAT ? (uint64_t)i_exec : (uint64_t)i;
+                }
             }
         }
 
@@ -459,8 +461,15 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
         }
         store_iter(A.out, A.frame, L, X, iterations);
     }
-    if (kStats)
+    if (kStats) {
         add_stats(A.stats, c_at, c_la, c_pt, c_px);
+        // statistics word 5 (this kernel has no careful steps to report there): AT iterations executed
+        uint64_t e = c_at_exec;
+        for (int off = 32; off > 0; off >>= 1)
+            e += __shfl_down(e, off);
+        if ((threadIdx.x & 63) == 0)
+            atomicAdd((unsigned long long *)&A.stats[5], (unsigned long long)e);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

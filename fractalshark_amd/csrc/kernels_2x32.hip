@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(256) k_lav2_2x32(FsLav2Args2x32 A)
         ordered_pixel(A.frame, A.pixel_order, X, L);
     else
         tile_pixel(X, L);
-    uint64_t c_at = 0, c_la = 0, c_pt = 0, c_px = 0;
+    uint64_t c_at = 0, c_la = 0, c_pt = 0, c_px = 0, c_at_skipped = 0; // (c_at_skipped: AT iterations the cycle search spared this lane)
     const bool in_buffer = X < A.frame.width && L < A.frame.local_rows;
     const uint32_t Y = in_buffer ? global_row(A.frame, L) : 0xFFFFFFFFu;
     const bool live = in_buffer && Y < A.frame.height;
@@ -228,38 +228,64 @@ __global__ void __launch_bounds__(256) k_lav2_2x32(FsLav2Args2x32 A)
                         const float esc_low = esc_sh > 120 ? __builtin_inff()
                                               : esc_sh < -120 ? 0.0f
                                                               : __builtin_amdgcn_ldexpf(esc.m.head, esc_sh) * 0.9999847412109375f;
+                        // CYCLE SEARCH (round 5; at_math.hpp has the HDRFloat<double> form and the argument): the loop is a pure
+                        // function of zz, so a state that comes back bit for bit -- looked for where i is a multiple of
+                        // kAtCycleChunk, against a state kept at doubling distances -- means the lane will go round that
+                        // cycle for good: it cannot escape, and its state after ATMaxIt iterations is the state
+                        // (ATMaxIt - i) mod P iterations further on.  The lane's loop limit drops to exactly that many.
+                        constexpr uint32_t kAtCycleChunk = 128u;
+                        IterT lim = ATMaxIt;      // this lane's loop limit: ATMaxIt, or where its remainder round the cycle ends
+                        IterT s_it = 0, s_next = (IterT)kAtCycleChunk;
+                        df32x2 s_zz(df32(__builtin_nanf(""), 0.0f), df32(0.0f, 0.0f)); // the kept state (a NaN equals nothing)
+                        bool cyc = false, out = false;
+#define FS_AT2_LOOP(UPDATE)                                                                                         \
+    while (i < lim && !out) {                                                                                       \
+        const IterT stop_ = (i | (IterT)(kAtCycleChunk - 1u)) + 1u;                                                 \
+        const IterT end_ = stop_ < lim ? stop_ : lim;                                                               \
+        for (; i < end_; i++) {                                                                                     \
+            const df32x2 lhs = df32x2(zz.head.xx, zz.tail.xx) * zz;           /* (rr, re im) */                     \
+            const df32x2 rhs = df32x2(zz.head.yy, zz.tail.yy) * zz.swapped(); /* (ii, im re) */                     \
+            if (!(lhs.head.x + rhs.head.x < esc_low)) { /* (see esc_low) */                                         \
+                HR nsq{lhs.lo() + rhs.lo(), nsq_e};                                                                 \
+                hr_reduce(nsq);                                                                                     \
+                if (hr_cmp_pos(nsq, esc) > 0) {                                                                     \
+                    out = true;                                                                                     \
+                    break;                                                                                          \
+                }                                                                                                   \
+            }                                                                                                       \
+            zz = UPDATE;                                                                                            \
+        }                                                                                                           \
+        if (!out && !cyc && i == stop_ && i < lim) {                                                                \
+            const bool same = __float_as_uint(zz.head.x) == __float_as_uint(s_zz.head.x) &&                         \
+                              __float_as_uint(zz.head.y) == __float_as_uint(s_zz.head.y) &&                         \
+                              __float_as_uint(zz.tail.x) == __float_as_uint(s_zz.tail.x) &&                         \
+                              __float_as_uint(zz.tail.y) == __float_as_uint(s_zz.tail.y);                           \
+            if (same) {                                                                                             \
+                cyc = true;                                                                                         \
+                lim = i + (ATMaxIt - i) % (i - s_it);                                                               \
+            } else if (i >= s_next) {                                                                               \
+                s_zz = zz, s_it = i, s_next = i + i;                                                                \
+            }                                                                                                       \
+        }                                                                                                           \
+    }
                         if (E == 0) {
                             const df32 mul0 = multiplier<df32>(0);
                             const df32x2 cc(c.re * mul0, c.im * mul0);
-                            for (; i < ATMaxIt; i++) {
-                                // (re, re) * (re, im) and (im, im) * (im, re): the four products of z * z already paired the
-                                // way the sums want them (same operand order per product as HDRFloatComplex's times), so no
-                                // half of a result has to change registers
-                                const df32x2 lhs = df32x2(zz.head.xx, zz.tail.xx) * zz;           // (rr, re im)
-                                const df32x2 rhs = df32x2(zz.head.yy, zz.tail.yy) * zz.swapped(); // (ii, im re)
-                                if (!(lhs.head.x + rhs.head.x < esc_low)) { // (see esc_low)
-                                    HR nsq{lhs.lo() + rhs.lo(), nsq_e};
-                                    hr_reduce(nsq);
-                                    if (hr_cmp_pos(nsq, esc) > 0)
-                                        break;
-                                }
-                                zz = (lhs + rhs.neg_lo()) + cc; // ((rr - ii) + cre, (re im + im re) + cim)
-                            }
+                            // (re, re) * (re, im) and (im, im) * (im, re): the four products of z * z already paired the way the
+                            // sums want them (same operand order per product as HDRFloatComplex's times), so no half of a result
+                            // has to change registers;  ((rr - ii) + cre, (re im + im re) + cim)
+                            FS_AT2_LOOP((lhs + rhs.neg_lo()) + cc)
                         } else {
                             const df32 mul = multiplier<df32>(E); // {2^E, 0} (-120 < E < 0)
                             const df32x2::f2 mm = {mul.head, mul.head};
                             const df32x2 cc(c.re, c.im);
-                            for (; i < ATMaxIt; i++) {
-                                const df32x2 lhs = df32x2(zz.head.xx, zz.tail.xx) * zz;
-                                const df32x2 rhs = df32x2(zz.head.yy, zz.tail.yy) * zz.swapped();
-                                if (!(lhs.head.x + rhs.head.x < esc_low)) {
-                                    HR nsq{lhs.lo() + rhs.lo(), nsq_e};
-                                    hr_reduce(nsq);
-                                    if (hr_cmp_pos(nsq, esc) > 0)
-                                        break;
-                                }
-                                zz = mul_by_float(lhs + rhs.neg_lo(), mm) + cc; // (x * {2^E, 0}: df32_math.hpp)
-                            }
+                            FS_AT2_LOOP(mul_by_float(lhs + rhs.neg_lo(), mm) + cc) // (x * {2^E, 0}: df32_math.hpp)
+                        }
+#undef FS_AT2_LOOP
+                        if (cyc && !out) {
+                            if (kStats)
+                                c_at_skipped = (uint64_t)(ATMaxIt - i);
+                            i = ATMaxIt; // (the state is the one ATMaxIt iterations produce: see above)
                         }
                         re = zz.lo(), im = zz.hi();
                         z = HC{re, im, E};
@@ -418,8 +444,15 @@ __global__ void __launch_bounds__(256) k_lav2_2x32(FsLav2Args2x32 A)
         }
         store_iter(A.out, A.frame, L, X, iter);
     }
-    if (kStats)
+    if (kStats) {
         add_stats(A.stats, c_at, c_la, c_pt, c_px);
+        // statistics word 5: AT iterations executed (= counted - spared by the cycle search)
+        uint64_t e = c_at - c_at_skipped;
+        for (int off = 32; off > 0; off >>= 1)
+            e += __shfl_down(e, off);
+        if ((threadIdx.x & 63) == 0)
+            atomicAdd((unsigned long long *)&A.stats[5], (unsigned long long)e);
+    }
 }
 
 } // namespace
