@@ -36,11 +36,12 @@ FS_HD void at_perform_literal(const hcplx<F> c, const hreal<F> esc, const IterT 
 // positive normal |z|^2.  Anything else (k outside the window, a zero / denormal norm) runs the literal loop.
 template <class F, class IterT = uint32_t>
 __device__ __forceinline__ void at_perform(const hcplx<F> c, const hreal<F> esc, const IterT ATMaxIt, hcplx<F> &z_out,
-                                           IterT &i_out, IterT *executed = nullptr)
+                                           IterT &i_out, IterT *executed = nullptr, IterT *own_cost = nullptr)
 {
     hcplx<F> z = hc_zero<F>();
     IterT i = 0;
     IterT skipped = 0; // iterations the cycle search spared this lane (counting builds: executed = i_out - skipped)
+    IterT own = 0;     // != 0: what this lane alone would have run (where ITS cycle showed + its remainder), for the pixel order
     const int k = c.e;
     if (k <= 0 && k > -kExpDiffIgnored && ATMaxIt > 1) {
         // iteration 0 literally: the norm of the zero start never exceeds the radius; z becomes c
@@ -142,7 +143,7 @@ __device__ __forceinline__ void at_perform(const hcplx<F> c, const hreal<F> esc,
                         // and each lane walks its remainder.  Same states, same iteration count, same results.
                         constexpr uint32_t kAtCycleChunk = 128u;
                         uint64_t s_re = ~0ull, s_im = ~0ull; // the kept state (bit patterns; all ones = a NaN no state equals)
-                        IterT s_it = 0, s_next = (IterT)kAtCycleChunk, cyc_p = 0; // cyc_p != 0: this lane has found its cycle
+                        IterT s_it = 0, s_next = (IterT)kAtCycleChunk, cyc_p = 0, cyc_at = 0; // cyc_p != 0: this lane has found its cycle (at iteration cyc_at)
                         bool all_cyclic = false;
                         for (;;) {
                             const IterT left = ATMaxIt - it; // >= 1
@@ -190,6 +191,7 @@ __device__ __forceinline__ void at_perform(const hcplx<F> c, const hreal<F> esc,
                                 if (cyc_p == 0) {
                                     if (b_re == s_re && b_im == s_im) {
                                         cyc_p = it - s_it;
+                                        cyc_at = it;
                                     } else if (it >= s_next) {
                                         s_re = b_re, s_im = b_im, s_it = it;
                                         s_next = it + it; // (it <= ATMaxIt / 2 matters only: beyond it no cycle can pay)
@@ -226,6 +228,7 @@ __device__ __forceinline__ void at_perform(const hcplx<F> c, const hreal<F> esc,
                             if (__builtin_amdgcn_inverse_ballot_w64(pending)) {
                                 IterT r = (ATMaxIt - it) % cyc_p;
                                 skipped = ATMaxIt - it - r;
+                                own = cyc_at + (ATMaxIt - cyc_at) % cyc_p;
                                 for (; r != 0; r--) {
                                     const F rr = re * re, ii = im * im, ri = re * im;
                                     re = (rr - ii) + cre;
@@ -260,6 +263,8 @@ __device__ __forceinline__ void at_perform(const hcplx<F> c, const hreal<F> esc,
                 i_out = i;
                 if (executed)
                     *executed = i - skipped;
+                if (own_cost)
+                    *own_cost = own != 0 ? own : i - skipped;
                 return;
             }
         }
@@ -275,6 +280,8 @@ __device__ __forceinline__ void at_perform(const hcplx<F> c, const hreal<F> esc,
     i_out = i;
     if (executed)
         *executed = i - skipped;
+    if (own_cost)
+        *own_cost = own != 0 ? own : i - skipped;
 }
 
 #endif // __HIPCC__

@@ -104,6 +104,11 @@ template <class F> struct FsLav2ArgsT {
     // element pixel_order[s] of the local iteration buffer (row * rounded_width + column) instead of its tile's pixel; null =
     // the tile mapping
     const uint32_t *pixel_order;
+    // (round 5) what the order is made from: when not null, every pixel records its COST -- the AT iterations it needs by itself
+    // (20 bits) above its perturbation steps (12 bits, saturating) -- at its own position of this buffer (same geometry as the iteration buffer); the next frames of the
+    // view are sorted by it.  (The count alone no longer tells: since the AT loop's cycle search a pixel inside the set costs
+    // what its cycle took to show, not what the iteration limit asks.)
+    uint32_t *pixel_cost;
     // IterType = uint64_t POSITIONS (the waypoint-resident kernel with 64-bit counters, fsk_lav2_seq `wide`): high words of
     // the orbit's uncompressed length, of its period and of the AT step length; la_u64 = 1: `las` holds the reference's
     // uint64_t records (fs_la_hdr32_u64 / fs_la_hdr64_u64: 64-bit StepLength / NextStageLAIndex) instead of the narrowed ones
@@ -232,6 +237,7 @@ struct FsLav2Args2x32 {
     uint32_t n_wp;
     fs_real_2x32 cxLow, cyLow;
     const uint32_t *pixel_order; // see FsLav2ArgsT
+    uint32_t *pixel_cost;        // see FsLav2ArgsT
 };
 
 // Non-HDR LAv2 (Gpu1x32 / Gpu1x64 / Gpu2x32 PerturbedLAv2*): records in the reference layouts of the selected type

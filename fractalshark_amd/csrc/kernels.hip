@@ -290,6 +290,7 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
     else
         tile_pixel(X, L);
     uint64_t c_at = 0, c_la = 0, c_pt = 0, c_px = 0, c_at_exec = 0; // (c_at_exec: AT iterations actually run -- the cycle search of at_perform spares the rest)
+    uint32_t px_cost = 0; // AT iterations this pixel ran (FsLav2ArgsT::pixel_cost)
     const bool in_buffer = X < A.frame.width && L < A.frame.local_rows;
     const uint32_t Y = in_buffer ? global_row(A.frame, L) : 0xFFFFFFFFu;
     const bool live = in_buffer && Y < A.frame.height;
@@ -310,9 +311,10 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
                 hcplx<F> c = hc_add(hc_mul(DeltaSub0, ldc(A.at.CCoeff)), ldc(A.at.RefC));
                 hc_reduce(c);
                 hcplx<F> z;
-                IterT i, i_exec = 0;
+                IterT i, i_exec = 0, i_own = 0;
                 if (kFastAT) {
-                    at_perform<F, IterT>(c, ldr(A.at.SqrEscapeRadius), ATMaxIt, z, i, kStats ? &i_exec : nullptr);
+                    at_perform<F, IterT>(c, ldr(A.at.SqrEscapeRadius), ATMaxIt, z, i, &i_exec, &i_own);
+                    px_cost = i_own > (IterT)0xFFFFFu ? 0xFFFFFu : (uint32_t)i_own;
                 } else {
                     z = hc_zero<F>();
                     const hreal<F> esc = ldr(A.at.SqrEscapeRadius);
@@ -399,6 +401,7 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
             }
         }
 
+        const IterT it_la = iterations; // (the perturbation steps of this pixel = its final count - this)
         if (Mode != FS_MODE_LAO) {
             const hreal<F> TwoFiftySix = hreal<F>{F(1), 8};
             const typename FsDev<F>::Z *__restrict__ zr = A.zref;
@@ -460,6 +463,13 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
             }
         }
         store_iter(A.out, A.frame, L, X, iterations);
+        if (A.pixel_cost) {
+            // AT iterations first, perturbation steps second: the two phases run one after the other and a wave pays the
+            // longest lane of each, so pixels should agree in both (a single sum puts a pixel that iterates long and steps
+            // little next to one that does the opposite)
+            const uint64_t pt = (uint64_t)(iterations - it_la);
+            A.pixel_cost[(size_t)L * A.frame.rounded_width + X] = (px_cost << 12) | (pt > 0xFFFull ? 0xFFFu : (uint32_t)pt);
+        }
     }
     if (kStats) {
         add_stats(A.stats, c_at, c_la, c_pt, c_px);

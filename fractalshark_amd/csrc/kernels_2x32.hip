@@ -178,6 +178,7 @@ __global__ void __launch_bounds__(256) k_lav2_2x32(FsLav2Args2x32 A)
     else
         tile_pixel(X, L);
     uint64_t c_at = 0, c_la = 0, c_pt = 0, c_px = 0, c_at_skipped = 0; // (c_at_skipped: AT iterations the cycle search spared this lane)
+    uint32_t px_cost = 0;
     const bool in_buffer = X < A.frame.width && L < A.frame.local_rows;
     const uint32_t Y = in_buffer ? global_row(A.frame, L) : 0xFFFFFFFFu;
     const bool live = in_buffer && Y < A.frame.height;
@@ -282,6 +283,7 @@ __global__ void __launch_bounds__(256) k_lav2_2x32(FsLav2Args2x32 A)
                             FS_AT2_LOOP(mul_by_float(lhs + rhs.neg_lo(), mm) + cc) // (x * {2^E, 0}: df32_math.hpp)
                         }
 #undef FS_AT2_LOOP
+                        px_cost = (uint32_t)i; // (AT iterations this pixel ran: FsLav2Args2x32::pixel_cost)
                         if (cyc && !out) {
                             if (kStats)
                                 c_at_skipped = (uint64_t)(ATMaxIt - i);
@@ -360,6 +362,7 @@ __global__ void __launch_bounds__(256) k_lav2_2x32(FsLav2Args2x32 A)
             }
         }
 
+        const IterT it_la = iter; // (the perturbation steps of this pixel = its final count - this)
         if (Mode != FS_MODE_LAO) {
             // :133-235.  perturbLoop(maxRefIteration) at :254-276 reads the block's previous results, which are zero on
             // the cleared buffer every caller passes (Fractal.cpp:2822), so only perturbLoop(n_iterations) runs.
@@ -443,6 +446,11 @@ __global__ void __launch_bounds__(256) k_lav2_2x32(FsLav2Args2x32 A)
             }
         }
         store_iter(A.out, A.frame, L, X, iter);
+        if (A.pixel_cost) {
+            const uint64_t pt = (uint64_t)(iter - it_la); // (AT iterations first, perturbation steps second: see k_lav2_lit)
+            A.pixel_cost[(size_t)L * A.frame.rounded_width + X] =
+                ((px_cost > 0xFFFFFu ? 0xFFFFFu : px_cost) << 12) | (pt > 0xFFFull ? 0xFFFu : (uint32_t)pt);
+        }
     }
     if (kStats) {
         add_stats(A.stats, c_at, c_la, c_pt, c_px);

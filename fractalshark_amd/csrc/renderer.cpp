@@ -83,6 +83,8 @@ struct fs_renderer {
     bool last_frame_ordered = false; // the last fs_render_lav2 launch used a recorded order (fs_last_frame_tile_ordered)
     // "pixels in the order of the previous frame's counts" (kernels_order.hip; HDRFloat<double> and HDRFloat<CudaDblflt> LAv2):
     // the order, the sort's work memory, and what the order was made from
+    uint32_t *pix_cost = nullptr; // per-pixel cost the unordered frame of a view records; what the order is sorted by
+    size_t pix_cost_cap = 0;
     uint32_t *pix_order = nullptr, *pix_work = nullptr;
     void *pix_temp = nullptr;
     size_t pix_cap = 0, pix_temp_bytes = 0;
@@ -710,6 +712,9 @@ void free_all(fs_renderer *r)
     (void)r_free(r, r->lav2_cost);
     (void)r_free(r, r->lav2_order);
     (void)r_free(r, r->lav2_sort_tmp);
+    (void)r_free(r, r->pix_cost);
+    r->pix_cost = nullptr;
+    r->pix_cost_cap = 0;
     (void)r_free(r, r->pix_order);
     (void)r_free(r, r->pix_work);
     (void)r_free(r, r->pix_temp);
@@ -2144,7 +2149,32 @@ static const uint32_t *pix_order_for(fs_renderer *r, const FsFrame &f, const fs_
     return r->pix_order;
 }
 
-static void pix_order_after(fs_renderer *r, const FsFrame &f, const fs_renderer::PixKey &key, bool frame_was_ordered)
+// The cost record of a frame that runs WITHOUT an order (the first of a view): a zeroed buffer in the iteration buffer's geometry
+// that the kernel fills pixel by pixel (padding stays 0 and sorts last), or nullptr (no order wanted, no memory).
+static uint32_t *pix_cost_for(fs_renderer *r, const FsFrame &f, bool frame_is_ordered)
+{
+    if (frame_is_ordered || !pix_order_wanted(r, f))
+        return nullptr;
+    const size_t n = (size_t)f.rounded_width * ((f.local_rows + 7u) & ~7u);
+    if (r->pix_cost_cap < n) {
+        (void)r_free(r, r->pix_cost);
+        r->pix_cost = nullptr;
+        r->pix_cost_cap = 0;
+        if (r_alloc(r, (void **)&r->pix_cost, n * sizeof(uint32_t), kFrame) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        r->pix_cost_cap = n;
+    }
+    if (hipMemsetAsync(r->pix_cost, 0, n * sizeof(uint32_t), r->compute) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return r->pix_cost;
+}
+
+static void pix_order_after(fs_renderer *r, const FsFrame &f, const fs_renderer::PixKey &key, bool frame_was_ordered,
+                            const uint32_t *cost = nullptr)
 {
     if (frame_was_ordered || !pix_order_wanted(r, f))
         return; // (an ordered frame's buffer equals the one the order was made from: nothing new to learn)
@@ -2172,7 +2202,8 @@ static void pix_order_after(fs_renderer *r, const FsFrame &f, const fs_renderer:
         r->pix_cap = n;
         r->pix_temp_bytes = tb;
     }
-    if (fsk_pixel_order_build((const uint32_t *)r->iters(), n, r->pix_work, r->pix_order, r->pix_temp, r->pix_temp_bytes, r->compute) !=
+    // sorted by the cost the frame recorded (round 5) -- or, without a record, by the counts as before
+    if (fsk_pixel_order_build(cost ? cost : (const uint32_t *)r->iters(), n, r->pix_work, r->pix_order, r->pix_temp, r->pix_temp_bytes, r->compute) !=
         hipSuccess) {
         (void)hipGetLastError();
         return;
@@ -2332,13 +2363,14 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
         }
         const fs_renderer::PixKey pk = pix_key_of(r, A.frame, type_tag, mode, 0, coords, sizeof(A.coords), n_iterations);
         A.pixel_order = r->orbit_seq ? nullptr : pix_order_for(r, A.frame, pk);
+        A.pixel_cost = r->orbit_seq ? nullptr : pix_cost_for(r, A.frame, A.pixel_order != nullptr);
         {
             TimedLaunch t(r);
             fsk_lav2_2x32(A, mode == FS_LAV2_FULL ? FS_MODE_FULL : (mode == FS_LAV2_PO ? FS_MODE_PO : FS_MODE_LAO),
                           r->stats_on, r->compute);
         }
         if (!r->orbit_seq)
-            pix_order_after(r, A.frame, pk, A.pixel_order != nullptr);
+            pix_order_after(r, A.frame, pk, A.pixel_order != nullptr, A.pixel_cost);
         return (uint32_t)hipGetLastError();
     }
     if (mode == FS_LAV2_PO && parity == FS_PARITY_CPU) {
@@ -2415,6 +2447,9 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
         A.at = r->at64;
         const fs_renderer::PixKey pk = pix_key_of(r, A.frame, type_tag, mode, parity, coords, 4 * sizeof(fs_real_hdr64), n_iterations);
         A.pixel_order = pix_order_for(r, A.frame, pk);
+        // (sorted by COUNT, not by a recorded cost as the 2x32 frames are: this kernel's steps are cheap enough for the loads of
+        // a wave whose lanes are scattered over the frame to cost more than the idle lanes they save -- 81 ms with the cost as
+        // the key, 68 with its binades, 53 with the counts, which keep the pixels inside the set side by side: DESIGN.md 7)
         {
             TimedLaunch t(r);
             fsk_lav2_hdr64(A, kmode, r->stats_on, r->compute);
