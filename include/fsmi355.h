@@ -320,10 +320,11 @@ uint32_t fs_kernel_ms_history(const fs_renderer *r, float *ms_out, uint32_t n);
  *                         which wave renders which tile changes no pixel.
  *                         The same switch keeps the HDRFloat<double> / HDRFloat<CudaDblflt> fs_render_lav2 frames in the tile
  *                         mapping: by default, from the second frame of a view on (same geometry, row bands, orbit, coordinates,
- *                         iteration limit, mode), lane s of the launch renders the pixel that ranked s-th by iteration count in
- *                         the previous frame (device radix sort of the iteration buffer, once per view; frames of 2^20 elements
- *                         and more) -- the lanes of a wave then run equally long (View 14: 107.6 -> 88.7 ms and 646 -> 553 ms) --
- *                         which lane renders which pixel changes no pixel.
+ *                         iteration limit, mode), lane s of the launch renders the pixel that ranked s-th in the previous
+ *                         frame -- by iteration count (HDRFloat<double>) or by the cost that frame recorded per pixel, its own AT
+ *                         iterations above its perturbation steps (HDRFloat<CudaDblflt>); a device radix sort, once per view;
+ *                         frames of 2^20 elements and more -- so that the lanes of a wave run equally long.  Which lane renders
+ *                         which pixel changes no pixel.
  *   FS_VARIANT_BLA_POOL   the hand-written HDRFloat<float> BLA kernel (the default of fs_render_bla with a table) re-packs the
  *                         running pixels of a workgroup's four waves into as few waves as possible every 32 trips (LDS exchange).
  *                         A/B, off by default: measured slower; results identical.
