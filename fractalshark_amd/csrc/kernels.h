@@ -66,6 +66,13 @@ template <class F> struct FsCoordsT {
 };
 using FsCoords32 = FsCoordsT<float>;
 
+// PerformAT's result for one pixel (HDRFloat<double>): dz = z * InvZCoeff, reduced, and the AT iterations taken; i = all ones:
+// the AT step does not apply to this pixel (ATInfo::isValid false).
+struct FsAtRes {
+    double re, im;
+    int32_t e;
+    uint32_t i;
+};
 template <class F> struct FsLav2ArgsT {
     uint32_t *out;
     const typename FsDev<F>::Z *zref; // prepared orbit
@@ -109,6 +116,13 @@ template <class F> struct FsLav2ArgsT {
     // view are sorted by it.  (The count alone no longer tells: since the AT loop's cycle search a pixel inside the set costs
     // what its cycle took to show, not what the iteration limit asks.)
     uint32_t *pixel_cost;
+    // (round 5, HDRFloat<double>) the AT iteration in a pass of its own (fsk_at_pass64): at_res = what PerformAT leaves per pixel
+    // (buffer geometry of the iteration buffer) -- written by that pass, read by the frame's kernel INSTEAD of iterating;
+    // at_cost (the pass only): every pixel's own AT iterations, recorded for the pass's order.  Why two passes: the AT loop reads
+    // no memory, so its lanes can be grouped by cost alone, while the LA stages and the perturbation steps want neighbours
+    // (table records, orbit entries) -- one launch cannot have both orders.
+    struct FsAtRes *at_res;
+    uint32_t *at_cost;
     // IterType = uint64_t POSITIONS (the waypoint-resident kernel with 64-bit counters, fsk_lav2_seq `wide`): high words of
     // the orbit's uncompressed length, of its period and of the AT step length; la_u64 = 1: `las` holds the reference's
     // uint64_t records (fs_la_hdr32_u64 / fs_la_hdr64_u64: 64-bit StepLength / NextStageLAIndex) instead of the narrowed ones
@@ -343,6 +357,7 @@ void fsk_tile_order_by_cost(const uint32_t *cost, uint32_t n_tiles, uint32_t *tm
 uint32_t fsk_lav2_hdr32_slots(const FsFrame &f);
 void fsk_lav2_hdr32(const FsLav2Args32 &A, int mode, bool stats, int variant, hipStream_t s);
 void fsk_lav2_hdr64(const FsLav2ArgsT<double> &A, int mode, bool stats, hipStream_t s);
+void fsk_at_pass64(const FsLav2ArgsT<double> &A, hipStream_t s); // A.at_res (out), A.at_cost (out, optional), A.pixel_order (optional)
 // IterType = uint64_t with 64-bit iteration counting (iteration caps of 2^32 and above): the literal kernel instantiated
 // with a 64-bit counter; needs a uint64_t iteration buffer (frame.iter_u64)
 void fsk_lav2_wide(const FsLav2Args32 *A32, const FsLav2ArgsT<double> *A64, int mode, bool stats, hipStream_t s);

@@ -304,7 +304,18 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
         hcplx<F> DeltaSubN = hc_from_native<F>(F(0), F(0)); // {0,0}: zero with exponent 0 (Fractal.cpp:2565)
         IterT iterations = 0;
 
-        if (Mode != FS_MODE_PO) {
+        bool at_done = false;
+        if constexpr (Mode != FS_MODE_PO && std::is_same<F, double>::value && sizeof(IterT) == 4 && !kSeq) {
+            if (A.at_res) { // PerformAT ran in its own pass (fsk_at_pass64): its result instead of the iteration
+                const FsAtRes ar = A.at_res[(size_t)L * A.frame.rounded_width + X];
+                at_done = true;
+                if (ar.i != 0xFFFFFFFFu) {
+                    DeltaSubN = hcplx<F>{ar.re, ar.im, ar.e};
+                    iterations = (IterT)ar.i * (IterT)A.at.StepLength;
+                }
+            }
+        }
+        if (Mode != FS_MODE_PO && !at_done) {
             if (A.la_valid && A.use_at && hr_cmp_pos(hc_cheb(DeltaSub0), ldr(A.at.ThresholdC)) <= 0) {
                 const IterT at_step = kWidePos ? (IterT)(((uint64_t)A.at_step_hi << 32) | A.at.StepLength) : (IterT)A.at.StepLength;
                 const IterT ATMaxIt = n_iterations / at_step;
@@ -4204,6 +4215,48 @@ void fsk_decompress_orbit_hdr32(const fs_orbit_hdr32_rc *wp, uint64_t n_wp, uint
 void fsk_prepare_orbit_hdr64(const fs_orbit_hdr64 *in, FsZ64 *out, uint64_t n, hipStream_t s)
 {
     hipLaunchKernelGGL(k_prepare_orbit_hdr64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n);
+}
+
+// PerformAT of every pixel in a pass of its own (see FsLav2ArgsT::at_res): the same pixel delta, the same isValid test, the same
+// at_perform and the same dz = z * InvZCoeff as k_lav2_lit<double> -- stored instead of used.
+__global__ void __launch_bounds__(256) k_at_pass64(FsLav2ArgsT<double> A)
+{
+    using F = double;
+    uint32_t X, L;
+    if (A.pixel_order)
+        ordered_pixel(A.frame, A.pixel_order, X, L);
+    else
+        tile_pixel(X, L);
+    const bool in_buffer = X < A.frame.width && L < A.frame.local_rows;
+    const uint32_t Y = in_buffer ? global_row(A.frame, L) : 0xFFFFFFFFu;
+    if (!(in_buffer && Y < A.frame.height))
+        return;
+    hreal<F> deltaReal, deltaImaginary;
+    pixel_delta<F>(A.coords, X, Y, deltaReal, deltaImaginary);
+    const hcplx<F> DeltaSub0 = hc_from_hr(deltaReal, deltaImaginary);
+    FsAtRes out{0.0, 0.0, 0, 0xFFFFFFFFu};
+    uint32_t own = 0;
+    if (A.la_valid && A.use_at && hr_cmp_pos(hc_cheb(DeltaSub0), ldr(A.at.ThresholdC)) <= 0) {
+        const uint32_t ATMaxIt = A.n_iterations / A.at.StepLength;
+        hcplx<F> c = hc_add(hc_mul(DeltaSub0, ldc(A.at.CCoeff)), ldc(A.at.RefC));
+        hc_reduce(c);
+        hcplx<F> z;
+        uint32_t i, i_exec = 0, i_own = 0;
+        at_perform<F, uint32_t>(c, ldr(A.at.SqrEscapeRadius), ATMaxIt, z, i, &i_exec, &i_own);
+        hcplx<F> dz = hc_mul(z, ldc(A.at.InvZCoeff));
+        hc_reduce(dz);
+        out = FsAtRes{dz.re, dz.im, dz.e, i};
+        own = i_own;
+    }
+    const size_t idx = (size_t)L * A.frame.rounded_width + X;
+    A.at_res[idx] = out;
+    if (A.at_cost)
+        A.at_cost[idx] = own;
+}
+
+void fsk_at_pass64(const FsLav2ArgsT<double> &A, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_at_pass64, tile_grid(A.frame), dim3(256), 0, s, A);
 }
 
 void fsk_lav2_hdr64(const FsLav2ArgsT<double> &A, int mode, bool stats, hipStream_t s)

@@ -83,19 +83,26 @@ struct fs_renderer {
     bool last_frame_ordered = false; // the last fs_render_lav2 launch used a recorded order (fs_last_frame_tile_ordered)
     // "pixels in the order of the previous frame's counts" (kernels_order.hip; HDRFloat<double> and HDRFloat<CudaDblflt> LAv2):
     // the order, the sort's work memory, and what the order was made from
+    // HDRFloat<double> LAv2: PerformAT in a pass of its own (fsk_at_pass64) with its own pixel order -- its results, the AT
+    // iterations every pixel needs by itself (recorded by the first frame of a view), and the order made from them
+    FsAtRes *at_res = nullptr;
+    uint32_t *at_cost = nullptr, *at_order = nullptr;
+    size_t at_cap = 0;
+    bool at_order_valid = false;
     uint32_t *pix_cost = nullptr; // per-pixel cost the unordered frame of a view records; what the order is sorted by
     size_t pix_cost_cap = 0;
     uint32_t *pix_order = nullptr, *pix_work = nullptr;
     void *pix_temp = nullptr;
     size_t pix_cap = 0, pix_temp_bytes = 0;
     bool pix_valid = false;
+    bool pix_seen = false; // the last unordered frame's key (pix_seen_key): an order is only made for a view that comes twice
     struct PixKey {
         uint32_t rounded_width, local_rows, band_first, band_rows, band_stride;
         int type_tag, mode, parity;
         uint64_t orbit_gen, orbit_epoch, n_iterations;
         unsigned char coords[64];
         bool operator==(const PixKey &o) const { return memcmp(this, &o, sizeof(*this)) == 0; }
-    } pix_key{};
+    } pix_key{}, pix_seen_key{};
     bool last_launch_wide = false;   // the last render launched a 64-bit counting kernel: those carry no step counters
     bool stats_on = false;
     int variant = FS_VARIANT_TUNED;
@@ -715,6 +722,13 @@ void free_all(fs_renderer *r)
     (void)r_free(r, r->pix_cost);
     r->pix_cost = nullptr;
     r->pix_cost_cap = 0;
+    (void)r_free(r, r->at_res);
+    (void)r_free(r, r->at_cost);
+    (void)r_free(r, r->at_order);
+    r->at_res = nullptr;
+    r->at_cost = r->at_order = nullptr;
+    r->at_cap = 0;
+    r->at_order_valid = false;
     (void)r_free(r, r->pix_order);
     (void)r_free(r, r->pix_work);
     (void)r_free(r, r->pix_temp);
@@ -2149,6 +2163,19 @@ static const uint32_t *pix_order_for(fs_renderer *r, const FsFrame &f, const fs_
     return r->pix_order;
 }
 
+// An order costs a sort (two for HDRFloat<double>) and is worth it only for a view that is rendered again: a viewer that zooms
+// changes the coordinates with every frame and would pay for sorts it never uses.  So the first unordered frame of a key only
+// leaves its key behind; the second one records and sorts; the third and later ones run ordered.  Returns whether THIS unordered
+// frame is such a second one.
+static bool pix_second_sighting(fs_renderer *r, const FsFrame &f, const fs_renderer::PixKey &key)
+{
+    const bool wanted = pix_order_wanted(r, f);
+    const bool again = wanted && r->pix_seen && r->pix_seen_key == key;
+    r->pix_seen = wanted;
+    r->pix_seen_key = key;
+    return again;
+}
+
 // The cost record of a frame that runs WITHOUT an order (the first of a view): a zeroed buffer in the iteration buffer's geometry
 // that the kernel fills pixel by pixel (padding stays 0 and sorts last), or nullptr (no order wanted, no memory).
 static uint32_t *pix_cost_for(fs_renderer *r, const FsFrame &f, bool frame_is_ordered)
@@ -2363,14 +2390,15 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
         }
         const fs_renderer::PixKey pk = pix_key_of(r, A.frame, type_tag, mode, 0, coords, sizeof(A.coords), n_iterations);
         A.pixel_order = r->orbit_seq ? nullptr : pix_order_for(r, A.frame, pk);
-        A.pixel_cost = r->orbit_seq ? nullptr : pix_cost_for(r, A.frame, A.pixel_order != nullptr);
+        const bool second = !r->orbit_seq && A.pixel_order == nullptr && pix_second_sighting(r, A.frame, pk);
+        A.pixel_cost = second ? pix_cost_for(r, A.frame, false) : nullptr;
         {
             TimedLaunch t(r);
             fsk_lav2_2x32(A, mode == FS_LAV2_FULL ? FS_MODE_FULL : (mode == FS_LAV2_PO ? FS_MODE_PO : FS_MODE_LAO),
                           r->stats_on, r->compute);
         }
-        if (!r->orbit_seq)
-            pix_order_after(r, A.frame, pk, A.pixel_order != nullptr, A.pixel_cost);
+        if (second)
+            pix_order_after(r, A.frame, pk, false, A.pixel_cost);
         return (uint32_t)hipGetLastError();
     }
     if (mode == FS_LAV2_PO && parity == FS_PARITY_CPU) {
@@ -2447,14 +2475,71 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
         A.at = r->at64;
         const fs_renderer::PixKey pk = pix_key_of(r, A.frame, type_tag, mode, parity, coords, 4 * sizeof(fs_real_hdr64), n_iterations);
         A.pixel_order = pix_order_for(r, A.frame, pk);
+        // PerformAT in a pass of its own, in the order of the AT iterations every pixel needs by itself (recorded by the view's
+        // first frame): the AT loop reads no memory, so its waves can be made of pixels from anywhere -- equal work per wave --
+        // while the frame's kernel keeps the order that keeps neighbours together (below).
+        static const bool at_split_off = [] { const char *e = getenv("FSMI355_AT_IN_KERNEL"); return e && e[0] == '1'; }();
+        const bool second = A.pixel_order == nullptr && pix_second_sighting(r, A.frame, pk);
+        bool at_split = !at_split_off && mode == FS_LAV2_FULL && A.use_at && A.la_valid && pix_order_wanted(r, A.frame) &&
+                        (A.pixel_order != nullptr || second); // (a view's first frame: one kernel, nothing recorded)
+        const bool at_warm = at_split && A.pixel_order != nullptr && r->at_order_valid; // (the two orders share their key)
+        if (at_split) {
+            const size_t n = (size_t)A.frame.rounded_width * ((A.frame.local_rows + 7u) & ~7u);
+            if (r->at_cap < n) {
+                (void)r_free(r, r->at_res);
+                (void)r_free(r, r->at_cost);
+                (void)r_free(r, r->at_order);
+                r->at_res = nullptr;
+                r->at_cost = r->at_order = nullptr;
+                r->at_cap = 0;
+                r->at_order_valid = false;
+                if (r_alloc(r, (void **)&r->at_res, n * sizeof(FsAtRes), kFrame) != hipSuccess ||
+                    r_alloc(r, (void **)&r->at_cost, n * sizeof(uint32_t), kFrame) != hipSuccess ||
+                    r_alloc(r, (void **)&r->at_order, n * sizeof(uint32_t), kFrame) != hipSuccess) {
+                    (void)hipGetLastError(); // no memory for it: PerformAT stays inside the frame's kernel
+                    (void)r_free(r, r->at_res);
+                    (void)r_free(r, r->at_cost);
+                    (void)r_free(r, r->at_order);
+                    r->at_res = nullptr;
+                    r->at_cost = r->at_order = nullptr;
+                    at_split = false;
+                } else {
+                    r->at_cap = n;
+                }
+            }
+        }
         // (sorted by COUNT, not by a recorded cost as the 2x32 frames are: this kernel's steps are cheap enough for the loads of
         // a wave whose lanes are scattered over the frame to cost more than the idle lanes they save -- 81 ms with the cost as
         // the key, 68 with its binades, 53 with the counts, which keep the pixels inside the set side by side: DESIGN.md 7)
         {
             TimedLaunch t(r);
+            if (at_split) {
+                const uint32_t n = A.frame.rounded_width * ((A.frame.local_rows + 7u) & ~7u);
+                FsLav2ArgsT<double> P = A;
+                P.at_res = r->at_res;
+                if (at_warm) {
+                    P.pixel_order = r->at_order;
+                } else {
+                    P.pixel_order = nullptr;
+                    P.at_cost = r->at_cost;
+                    FS_TRY(hipMemsetAsync(r->at_cost, 0, (size_t)n * sizeof(uint32_t), r->compute));
+                    r->at_order_valid = false;
+                }
+                fsk_at_pass64(P, r->compute);
+                A.at_res = r->at_res;
+            }
             fsk_lav2_hdr64(A, kmode, r->stats_on, r->compute);
         }
-        pix_order_after(r, A.frame, pk, A.pixel_order != nullptr);
+        if (second)
+            pix_order_after(r, A.frame, pk, false);
+        if (at_split && !at_warm && r->pix_valid && r->pix_work && r->pix_temp) {
+            // the AT pass's own order, from the costs it has just recorded (the sort's work memory is the pixel order's)
+            const uint32_t n = A.frame.rounded_width * ((A.frame.local_rows + 7u) & ~7u);
+            if (fsk_pixel_order_build(r->at_cost, n, r->pix_work, r->at_order, r->pix_temp, r->pix_temp_bytes, r->compute) == hipSuccess)
+                r->at_order_valid = true;
+            else
+                (void)hipGetLastError();
+        }
     }
     return (uint32_t)hipGetLastError();
 }
@@ -3067,6 +3152,8 @@ uint32_t fs_forget_tile_costs(fs_renderer *r)
     r->lav2_cost_valid = false;
     r->po_order_valid = false;
     r->pix_valid = false;
+    r->pix_seen = false;
+    r->at_order_valid = false;
     return 0;
 }
 
