@@ -535,6 +535,10 @@ def main():
     # spares a pixel inside the set most of the iterations the limit asks of it -- same state, same count, same frame).  The
     # roofline prices executed work; at_iterations_per_launch stays what the reference's loop would run.
     at_iters_executed = float(st.get("careful_steps", 0)) if (wl in ("c4_hdr64", "c4_2x32") and st.get("careful_steps")) else at_iters
+    if wl == "c4_hdr64" and tile_order_on and st.get("scaled_steps"):
+        # the timed frames run PerformAT in a pass of its own, whose lanes are grouped by what each pixel needs by itself
+        # (statistics word 6 of the counting launch, which iterates inside the frame's kernel and waits for the wave's slowest)
+        at_iters_executed = float(st["scaled_steps"])
     lane_slots = st["lane_slots"]
     b_main = state["last"]
     checksum = int(host_np[b_main][:H, :W].astype(np.uint64).sum()) if rank == 0 else None

@@ -291,6 +291,7 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
         tile_pixel(X, L);
     uint64_t c_at = 0, c_la = 0, c_pt = 0, c_px = 0, c_at_exec = 0; // (c_at_exec: AT iterations actually run -- the cycle search of at_perform spares the rest)
     uint32_t px_cost = 0; // AT iterations this pixel ran (FsLav2ArgsT::pixel_cost)
+    uint64_t c_at_own = 0; // AT iterations this pixel needs by itself (what the AT pass of its own runs for it: statistics word 6)
     const bool in_buffer = X < A.frame.width && L < A.frame.local_rows;
     const uint32_t Y = in_buffer ? global_row(A.frame, L) : 0xFFFFFFFFu;
     const bool live = in_buffer && Y < A.frame.height;
@@ -344,6 +345,7 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
                 if (kStats) {
                     c_at = i;
                     c_at_exec = kFastAT ? (uint64_t)i_exec : (uint64_t)i;
+                    c_at_own = kFastAT ? (uint64_t)i_own : (uint64_t)i;
                 }
             }
         }
@@ -488,8 +490,13 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
         uint64_t e = c_at_exec;
         for (int off = 32; off > 0; off >>= 1)
             e += __shfl_down(e, off);
-        if ((threadIdx.x & 63) == 0)
+        uint64_t o = c_at_own;
+        for (int off = 32; off > 0; off >>= 1)
+            o += __shfl_down(o, off);
+        if ((threadIdx.x & 63) == 0) {
             atomicAdd((unsigned long long *)&A.stats[5], (unsigned long long)e);
+            atomicAdd((unsigned long long *)&A.stats[6], (unsigned long long)o);
+        }
     }
 }
 

@@ -36,7 +36,9 @@ def main():
             continue
         group = os.path.basename(d)[len("pmc_%s_" % a.tag):]
         rows = []
-        for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+        # (gpurun merges every call's files into the same directory: only the NEWEST run's counters are this kernel's)
+        files = sorted(glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)
+        for f in files[-1:]:
             with open(f) as fh:
                 rd = csv.DictReader(fh)
                 for row in rd:

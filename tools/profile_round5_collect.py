@@ -32,8 +32,8 @@ def main():
         d = json.loads(open(line).read().strip().splitlines()[-1])
         shutil.copy(line, os.path.join(out, "%s_%s_under_rocprof_bench.json" % (tag, wl)))
         stats = glob.glob(os.path.join(ROOT, "gpurun_out", "prof_%s_%s" % (tag, wl), "**", "*kernel_stats.csv"), recursive=True)
-        if stats:
-            shutil.copy(stats[0], os.path.join(out, "%s_%s_kernel_stats.csv" % (tag, wl)))
+        if stats:  # (gpurun merges every call's files into the same directory: the newest run is the one the bench line is from)
+            shutil.copy(max(stats, key=os.path.getmtime), os.path.join(out, "%s_%s_kernel_stats.csv" % (tag, wl)))
         key = d["config"]["workload"]
         alg = d["roofline"].get("algorithmic_bytes")
         if alg is None:  # compulsory traffic of a VALU-bound frame: inputs once + the iteration buffer once
