@@ -319,7 +319,8 @@ uint32_t fs_kernel_ms_history(const fs_renderer *r, float *ms_out, uint32_t n);
  *                         short tiles beside it (never-escaping waves that share a CU slow each other down) --
  *                         which wave renders which tile changes no pixel.
  *                         The same switch keeps the HDRFloat<double> / HDRFloat<CudaDblflt> fs_render_lav2 frames in the tile
- *                         mapping: by default, from the second frame of a view on (same geometry, row bands, orbit, coordinates,
+ *                         mapping: by default, from the third frame of a view on (the first runs as it is, the second records and
+ *                         sorts -- a view that is shown once pays for no sort; a view = same geometry, row bands, orbit, coordinates,
  *                         iteration limit, mode), lane s of the launch renders the pixel that ranked s-th in the previous
  *                         frame -- by iteration count (HDRFloat<double>) or by the cost that frame recorded per pixel, its own AT
  *                         iterations above its perturbation steps (HDRFloat<CudaDblflt>); a device radix sort, once per view;
