@@ -95,6 +95,10 @@ __device__ __forceinline__ void at_perform(const hcplx<F> c, const hreal<F> esc,
                 uint64_t pending = __builtin_amdgcn_ballot_w64(true);       // lanes still iterating (a lane mask, scalar)
                 F xre = re, xim = im, xm = thr;
                 IterT xi = ATMaxIt;
+                // (cycle search of FS_AT_LOOP: the kept state as bit patterns -- all ones is a NaN no state equals)
+                constexpr uint32_t kAtLoopChunk = 128u;
+                typename fbits<F>::U g_sre = ~(typename fbits<F>::U)0, g_sim = ~(typename fbits<F>::U)0;
+                IterT g_sit = 0, g_snext = (IterT)kAtLoopChunk, g_cyc_p = 0, g_cyc_at = 0;
 #define FS_AT_LOOP(SCALE)                                                                                           \
     for (;;) {                                                                                                      \
         const F rr = re * re, ii = im * im;                                                                         \
@@ -115,6 +119,31 @@ __device__ __forceinline__ void at_perform(const hcplx<F> c, const hreal<F> esc,
             if (__builtin_amdgcn_inverse_ballot_w64(pending))                                                       \
                 xre = re, xim = im, xi = ATMaxIt; /* took its last iteration (xm stays normal: not literal) */      \
             break;                                                                                                  \
+        }                                                                                                           \
+        if ((it & (IterT)(kAtLoopChunk - 1u)) == 0) { /* the cycle search (see the hand-written loop below) */       \
+            if (g_cyc_p == 0) {                                                                                     \
+                if (to_bits<F>(re) == g_sre && to_bits<F>(im) == g_sim) {                                           \
+                    g_cyc_p = it - g_sit;                                                                           \
+                    g_cyc_at = it;                                                                                  \
+                } else if (it >= g_snext) {                                                                         \
+                    g_sre = to_bits<F>(re), g_sim = to_bits<F>(im), g_sit = it, g_snext = it + it;                   \
+                }                                                                                                   \
+            }                                                                                                       \
+            if ((__builtin_amdgcn_ballot_w64(g_cyc_p == 0) & pending) == 0ull) {                                    \
+                /* every lane still iterating is on its cycle: each walks its remainder, in this loop's arithmetic */ \
+                if (__builtin_amdgcn_inverse_ballot_w64(pending)) {                                                 \
+                    IterT r_ = (ATMaxIt - it) % g_cyc_p;                                                            \
+                    skipped = ATMaxIt - it - r_;                                                                    \
+                    own = g_cyc_at + (ATMaxIt - g_cyc_at) % g_cyc_p;                                                \
+                    for (; r_ != 0; r_--) {                                                                         \
+                        const F rr_ = re * re, ii_ = im * im, ri_ = re * im;                                        \
+                        re = (rr_ - ii_) SCALE + cre;                                                               \
+                        im = (ri_ + ri_) SCALE + cim;                                                               \
+                    }                                                                                               \
+                    xre = re, xim = im, xi = ATMaxIt;                                                               \
+                }                                                                                                   \
+                break;                                                                                              \
+            }                                                                                                       \
         }                                                                                                           \
     }
                 if constexpr (sizeof(F) == 8) {
