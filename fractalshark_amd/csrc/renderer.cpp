@@ -2480,7 +2480,7 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
         // while the frame's kernel keeps the order that keeps neighbours together (below).
         static const bool at_split_off = [] { const char *e = getenv("FSMI355_AT_IN_KERNEL"); return e && e[0] == '1'; }();
         const bool second = A.pixel_order == nullptr && pix_second_sighting(r, A.frame, pk);
-        bool at_split = !at_split_off && mode == FS_LAV2_FULL && A.use_at && A.la_valid && pix_order_wanted(r, A.frame) &&
+        bool at_split = !at_split_off && mode != FS_LAV2_PO && A.use_at && A.la_valid && pix_order_wanted(r, A.frame) &&
                         (A.pixel_order != nullptr || second); // (a view's first frame: one kernel, nothing recorded)
         const bool at_warm = at_split && A.pixel_order != nullptr && r->at_order_valid; // (the two orders share their key)
         if (at_split) {
