@@ -89,7 +89,7 @@ def _render_flags():
         extra.append("-DFS_FD16_SERIAL")
     if os.environ.get("FS_2X32_PROBE") == "1":  # counts the 2x32 perturbation loop's literal steps (statistics word 12)
         extra.append("-DFS_2X32_PROBE")
-    for name in ("FS_FL_EVERY", "FS_FL_SHIFT", "FS_FL_FLOOR_EXP", "FS_HOT_RUN_STEPS", "FS_PO_CHUNK"):  # A/B: form and scale of the scaled runs' floor tests (kernels.hip)
+    for name in ("FS_FL_EVERY", "FS_FL_SHIFT", "FS_FL_FLOOR_EXP", "FS_HOT_RUN_STEPS", "FS_PO_CHUNK", "FS_AT_CYCLE_CHUNK"):  # A/B: form and scale of the scaled runs' floor tests (kernels.hip)
         if os.environ.get(name):
             extra.append("-D%s=%d" % (name, int(os.environ[name])))
     if os.environ.get("FS_SCALED_CHUNK"):  # tuning experiments only

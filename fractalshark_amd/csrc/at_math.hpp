@@ -96,7 +96,7 @@ __device__ __forceinline__ void at_perform(const hcplx<F> c, const hreal<F> esc,
                 F xre = re, xim = im, xm = thr;
                 IterT xi = ATMaxIt;
                 // (cycle search of FS_AT_LOOP: the kept state as bit patterns -- all ones is a NaN no state equals)
-                constexpr uint32_t kAtLoopChunk = 128u;
+                constexpr uint32_t kAtLoopChunk = 16u;
                 typename fbits<F>::U g_sre = ~(typename fbits<F>::U)0, g_sim = ~(typename fbits<F>::U)0;
                 IterT g_sit = 0, g_snext = (IterT)kAtLoopChunk, g_cyc_p = 0, g_cyc_at = 0;
 #define FS_AT_LOOP(SCALE)                                                                                           \
@@ -167,10 +167,13 @@ __device__ __forceinline__ void at_perform(const hcplx<F> c, const hreal<F> esc,
                         // attracting cycle and, in binary64, locks into it -- View 14: after 320 iterations (median; 9 267 for
                         // the slowest percent) of the 18 402 the iteration limit asks of it, and those pixels are 9 % of the
                         // frame and 97 % of its AT iterations (tools/at_cycle_potential.py).  Brent's scheme, sampled where the
-                        // statement's budget ends (every kAtCycleChunk iterations): compare with a kept state, keep a new one
+                        // statement's budget ends (every kAtCycleChunk = 16 iterations): compare with a kept state, keep a new one
                         // at doubling distances.  When every lane still iterating has found its cycle the wave leaves the loop
                         // and each lane walks its remainder.  Same states, same iteration count, same results.
-                        constexpr uint32_t kAtCycleChunk = 128u;
+#ifndef FS_AT_CYCLE_CHUNK
+#define FS_AT_CYCLE_CHUNK 16 /* measured on C4 (ms per frame): 8: 46.0, 16: 45.8, 32: 46.1, 64: 46.7, 128: 48.1, 256: 51.3 */
+#endif
+                        constexpr uint32_t kAtCycleChunk = FS_AT_CYCLE_CHUNK;
                         uint64_t s_re = ~0ull, s_im = ~0ull; // the kept state (bit patterns; all ones = a NaN no state equals)
                         IterT s_it = 0, s_next = (IterT)kAtCycleChunk, cyc_p = 0, cyc_at = 0; // cyc_p != 0: this lane has found its cycle (at iteration cyc_at)
                         bool all_cyclic = false;

@@ -234,7 +234,10 @@ __global__ void __launch_bounds__(256) k_lav2_2x32(FsLav2Args2x32 A)
                         // kAtCycleChunk, against a state kept at doubling distances -- means the lane will go round that
                         // cycle for good: it cannot escape, and its state after ATMaxIt iterations is the state
                         // (ATMaxIt - i) mod P iterations further on.  The lane's loop limit drops to exactly that many.
-                        constexpr uint32_t kAtCycleChunk = 128u;
+#ifndef FS_AT_CYCLE_CHUNK
+#define FS_AT_CYCLE_CHUNK 8 /* measured on C4 as specified (ms per frame): 8: 198.8, 16: 200.0, 32: 202.4, 128: 219.2 */
+#endif
+                        constexpr uint32_t kAtCycleChunk = FS_AT_CYCLE_CHUNK;
                         IterT lim = ATMaxIt;      // this lane's loop limit: ATMaxIt, or where its remainder round the cycle ends
                         IterT s_it = 0, s_next = (IterT)kAtCycleChunk;
                         df32x2 s_zz(df32(__builtin_nanf(""), 0.0f), df32(0.0f, 0.0f)); // the kept state (a NaN equals nothing)
