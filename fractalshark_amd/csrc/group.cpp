@@ -315,6 +315,12 @@ uint32_t fs_group_init_memory(fs_group *g, uint32_t w, uint32_t h, uint32_t anti
         }
         FSG_TRY(fs_set_external_iter_buffer(g->members[r], buf, sb));
     }
+    // The clears above run on the devices' default streams, which the members' (non-blocking) streams do not wait for: a clear
+    // that is still pending could land on top of what the first frame's kernels write.  One wait per geometry.
+    for (uint32_t r = 0; r < world; r++) {
+        FSG_TRY(hipSetDevice(g->devices[r]));
+        FSG_TRY(hipDeviceSynchronize());
+    }
     return 0;
 }
 
@@ -440,6 +446,10 @@ static uint32_t group_current_progressive(fs_group *g, uint64_t n_iterations, vo
         FSG_TRY(hipMemset(g->prog_frame, 0, frame_bytes));
         FSG_TRY(hipMalloc((void **)&g->prog_colors, fs_color_buffer_elements(g->members[0]) * sizeof(fs_color16)));
         FSG_TRY(hipMalloc((void **)&g->prog_reduction, sizeof(fs_reduction)));
+        // (the two clears run on the default stream, which the display streams do not wait for: without this wait they could
+        // land on top of the snapshot the copies below assemble -- a first snapshot that came back partly zero, once in a few
+        // runs of the whole test suite)
+        FSG_TRY(hipStreamSynchronize(nullptr));
     }
     // member 0 renders straight into slot 0 of the set in rotation
     FSG_TRY(hipMemcpyAsync(g->prog_gathered, g->gathered[g->cur], sb, hipMemcpyDeviceToDevice, d0));
