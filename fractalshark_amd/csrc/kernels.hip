@@ -800,6 +800,68 @@ constexpr int kFloorBits = (127 - FS_FL_FLOOR_EXP) << 23;
           "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s66", "vcc",  \
           "scc")
 
+// The same loop with the block test on WAVE-UNIFORM thresholds (round 5): the kernel issues one vector instruction per SIMD
+// every four cycles and nothing else, and the block test was five of them per four steps (max|w|, max with max|dc|, + the lane's
+// scale, the compare, H's compare).  Both sides of it that are not the state are made scalar, each in the safe direction:
+//   max|dc| 2^E is the pixel's true max|dc|, a constant: its largest value over the wave (`sdc`, made once per tile) is compared
+//     with the block bound on the scalar unit;
+//   bits(max|w|) + Esh <= bound holds in every lane when bits(max|w|) <= bound - (the LARGEST Esh of the running lanes: `eshm`,
+//     made once per run by a few votes);  H is bits(max|w|) <= bits(2^14);
+// so a block's test is  bits(max|w|) <= T,  T = min(bound - eshm, bits(2^14)), or "never" when sdc > bound: five scalar
+// instructions, then max|w| and ONE compare on the vector unit.  (bound - eshm can only overflow upwards -- the "never" bound,
+// the most negative integer, is replaced by -2^30 first -- and an overflow means T = H.)  A wave whose lanes' scales are k binades
+// apart tests its lower lanes against a bound 2^k tighter than theirs: such a block takes the tested path, nothing else changes.
+#define FS_BT_T(BW)                                                                                                 \
+    "s_cmp_gt_i32 %[sdc], " BW "\n\t"                                                                               \
+    "s_cselect_b32 %[t], 0xc0000000, " BW "\n\t"                                                                    \
+    "s_sub_i32 %[t], %[t], %[eshm]\n\t"                                                                             \
+    "s_cselect_b32 %[t], 0x46800000, %[t]\n\t"                                                                      \
+    "s_min_i32 %[t], %[t], 0x46800000\n\t"
+#define FS_BT_V "v_cmp_lt_i32_e32 vcc, %[t], v60\n\t"
+#define FS_FAST_LOOP_FDU(PF)                                                                                        \
+    asm volatile(                                                                                                   \
+        "v_mov_b32_e32 v61, 0x7f800000\n\t" FS_BT_T("s67") FS_BT_V                                                  \
+        ".Lfu_loop_%=:\n\t" /* eight steps left?  the first block's verdict (taken where max|w| was made) */         \
+        "s_cmp_gt_u32 %[off], %[lim8]\n\t"                                                                          \
+        "s_cbranch_scc1 .Lfu_out_%=\n\t"                                                                            \
+        "s_cbranch_vccnz .Lfu_out_%=\n\t" /* steps 1 .. 4 */                                                        \
+        FS_PK_F(FS_R0, "s[64:65]")                                                                                  \
+        "s_load_dwordx16 s[36:51], s[68:69], %[off]\n\t"                                                            \
+        "s_load_dwordx16 s[52:67], s[68:69], %[off] offset:0x40\n\t"                                                \
+        FS_PK_MA(FS_R0) FS_PK_MB(FS_R0) FS_PK_P FS_PK_A(FS_R1)                                                      \
+        "s_waitcnt lgkmcnt(0)\n\t" PF FS_BT_T("s51")                                                                \
+        FS_PK_F(FS_R1, "s[36:37]") FS_FL_ACC("v50", "v51") FS_PK_MA(FS_R1) FS_PK_MB(FS_R1) FS_PK_P FS_PK_A(FS_R2)   \
+        FS_PK_F(FS_R2, "s[40:41]") FS_FL_ACC("v52", "v53") FS_PK_MA(FS_R2) FS_PK_MB(FS_R2) FS_PK_P FS_PK_A(FS_R3)   \
+        FS_PK_F(FS_R3, "s[44:45]") FS_FL_ACC("v54", "v55") FS_PK_MA(FS_R3) FS_PK_MB(FS_R3) FS_PK_P FS_PK_A(FS_R0)   \
+        /* step 5 + w4's floor part and max; the second block's verdict in step 6, before anything of block 2 is counted */ \
+        FS_PK_F(FS_R0, "s[48:49]") FS_FL_ACC("v48", "v49") FS_PK_MA(FS_R0) FS_T_X("v48", "v49") FS_PK_MB(FS_R0)     \
+        FS_PK_P FS_PK_A(FS_R1)                                                                                      \
+        FS_PK_F(FS_R1, "s[52:53]") FS_BT_V FS_PK_MA(FS_R1) FS_PK_MB(FS_R1) FS_PK_P                                  \
+        "s_cbranch_vccnz .Lfu_blk_%=\n\t" FS_PK_A(FS_R2)                                                            \
+        FS_PK_F(FS_R2, "s[56:57]") FS_FL_ACC("v50", "v51") FS_PK_MA(FS_R2) FS_FL_ACC("v52", "v53") FS_PK_MB(FS_R2)  \
+        FS_PK_P FS_PK_A(FS_R3)                                                                                      \
+        FS_PK_F(FS_R3, "s[60:61]") FS_FL_ACC("v54", "v55") FS_PK_MA(FS_R3) FS_PK_MB(FS_R3) FS_PK_P FS_PK_A(FS_R0)   \
+        "s_add_u32 %[off], %[off], 0x80\n\t" FS_BT_T("s67")                                                         \
+        FS_T_X("v48", "v49") FS_FL_ACC("v48", "v49") FS_BT_V "s_branch .Lfu_loop_%=\n"                              \
+        ".Lfu_blk_%=:\n\t" /* the second block needs its bound tests (or H): the state is w4 in v[48:49] */         \
+        "s_mov_b64 s[64:65], s[48:49]\n\t"                                                                          \
+        "s_mov_b32 s67, s51\n\t"                                                                                    \
+        "s_add_u32 %[off], %[off], 0x40\n"                                                                          \
+        ".Lfu_out_%=:\n\t" /* the verdict over every state of this invocation */                                    \
+        "s_mov_b32 %[st], 0\n\t" FS_FL_C                                                                            \
+        "s_cbranch_vccz .Lfu_end_%=\n\t"                                                                            \
+        "s_mov_b32 %[st], 3\n"                                                                                      \
+        ".Lfu_end_%=:\n\t"                                                                                          \
+        "s_waitcnt lgkmcnt(0)"                                                                                      \
+        : "+{v[48:49]}"(wv), "={v[50:51]}"(r1), "={v[52:53]}"(r2), "={v[54:55]}"(r3), "={v[56:57]}"(ts_),           \
+          "={v[58:59]}"(ta_), "+{v60}"(mxS), "={v61}"(tn_), [t] "=&s"(bt_t_), [st] "=&s"(st),                       \
+          "+{s67}"(pwi), "+{s[64:65]}"(zS), [off] "+s"(off), [pf] "=&s"(pf_), [pg] "=&s"(pg_), [ph] "=&s"(ph_)      \
+        : [se] "v"(sE2), [dc] "v"(dcs), [eshm] "s"(Esh_cap), [sdc] "s"(sdc_bits), [lim8] "s"(lim8),                 \
+          "{s[68:69]}"(zpb), [flr] "s"(kFloorBits)                                                                  \
+        : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50",  \
+          "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s66", "vcc",  \
+          "scc")
+
 // The untested body with the deferred verdict, SIXTEEN steps per body (round 4).  A wave that is alone on its SIMD -- the
 // never-escaping pixels that decide C2's frame time, the last waves of a rank of an N-GPU split -- pays one L2 round trip per
 // body: scalar loads return out of order, so the entries of a body can only be waited for all together, and the loads that
@@ -1128,6 +1190,24 @@ __device__ __forceinline__ uint32_t scaled_run_length_po(uint32_t left)
 // kGpuStage: the LA stage-validity test in the direction of the reference's GPU twin (FS_PARITY_CPU_GPUSTAGE) instead of
 // the CPU function's (FS_PARITY_CPU) -- a template parameter so that the two parity modes are two kernels (they do very
 // different work per frame, and a kernel trace then lists them separately).
+// An upper bound, wave-uniform, of v over the ACTIVE lanes -- the largest value itself when a vote or two find it (the values of
+// a wave's lanes, scales and dc, are a few binades apart at most), at most a few binades above it otherwise: each further trip
+// adds a growing slack (1, 2, 4 ... binades of a binary32 bit pattern), so the loop ends after nine trips at the latest whatever the
+// lanes hold.  Votes instead of a reduction: nothing is written under a widened EXEC.  v <= 0x7f800000.
+static __device__ __forceinline__ int wave_upper_bound_i32(int v)
+{
+    int m = __builtin_amdgcn_readfirstlane(v);
+    int slack = 0;
+    for (;;) {
+        const uint64_t above = __builtin_amdgcn_ballot_w64(v > m);
+        if (above == 0ull)
+            return m;
+        const long long next = (long long)__builtin_amdgcn_readlane(v, (int)__builtin_ctzll(above)) + slack;
+        m = next > 0x7f800000ll ? 0x7f800000 : (int)next;
+        slack = slack != 0 ? (slack < (64 << 23) ? slack * 2 : slack) : (1 << 23);
+    }
+}
+
 template <int Mode, bool kStats, bool kScaled, bool kLds = false, bool kGpuStage = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) k_lav2_hdr32_fast(FsLav2Args32 A)
 {
@@ -1185,6 +1265,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
     uint32_t c_blk_free = 0, c_blk_tested = 0; // 4-step blocks of the scalar-cache scaled path without / with bound tests (per wave)
 #ifdef FS_PROFILE_CYCLES
     uint64_t cyc_loop = 0, cyc_run = 0, cyc_body = 0, cyc_t0 = 0, cyc_t1 = 0, cyc_t2 = 0;
+    uint64_t cyc_asm = 0, cyc_tested = 0, cyc_hot = 0, cyc_t3 = 0, cyc_t4 = 0, cyc_t5 = 0, wall_loop = 0, wall_t0 = 0;
 #define FS_CYC(stmt) do { if (kStats) { stmt; } } while (0)
 #else
 #define FS_CYC(stmt) do { } while (0)
@@ -1301,6 +1382,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
                     (volatile __attribute__((address_space(3))) float *)s_dcp + (wave_in_block * 64u + lane_s) * 3u;
                 pd[0] = dc.re, pd[1] = dc.im, pd[2] = __int_as_float(dc.e);
             }
+            // the largest true max|dc| of the wave's pixels as a binary32 bit pattern, never below the true value (2^-126 for
+            // anything smaller, +inf beyond the range): the dc half of the block test, FS_FAST_LOOP_FDU
+            int sdc_bits;
+            {
+                const float mdc = __builtin_fmaxf(__builtin_fabsf(dc.re), __builtin_fabsf(dc.im));
+                const int de = dc.e < -400 ? -400 : (dc.e > 400 ? 400 : dc.e);
+                const int lane_bits = mdc > 0.0f ? __float_as_int(__builtin_fmaxf(__builtin_amdgcn_ldexpf(mdc, de), 0x1p-126f))
+                                                 : (mdc == 0.0f ? 0 : 0x7f800000);
+                sdc_bits = wave_upper_bound_i32(lane_bits);
+            }
             // (each use site reads dc back: FS_LOAD_DC declares dcm / dce in its scope)
 #define FS_LOAD_DC()                                                                                                \
     f2 dcm;                                                                                                         \
@@ -1329,6 +1420,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
             const float4 *__restrict__ zq = A.zq;
             const float4 *__restrict__ zs = A.zs;
             FS_CYC(cyc_t0 = __builtin_readcyclecounter());
+            FS_CYC(wall_t0 = wall_clock64());
             uint32_t sc_skip = 0, sc_penalty = 0; // (wave-uniform) back-off of the scaled-run attempts, see below
             bool fl_per_trip = false; // (wave-uniform) the next run attempt uses the per-trip floor verdicts (FS_FAST_LOOP_FD)
             while (running) {
@@ -1376,6 +1468,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
                     // decides.  The run also ends when every lane has cooled down (its arrival passes the bound test
                     // again: the fast paths resume) and after kHotRunSteps steps (the scale is re-centred).
                     bool hot_progress = false, hot_cold = false;
+                    FS_CYC(cyc_t5 = __builtin_readcyclecounter());
                     {
                         FS_LOAD_DC()
                         const int E = dze + kScaleShift;
@@ -1493,6 +1586,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
                             }
                         }
                     }
+                    FS_CYC(cyc_hot += __builtin_readcyclecounter() - cyc_t5);
                     if (__builtin_amdgcn_ballot_w64(hot_progress) != 0ull) { // (wave-uniform: a lane that is done has progressed)
                         if (hot_cold)
                             sc_skip = 0u, sc_penalty = 0u;
@@ -1707,6 +1801,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
                             // it stops after four when the second block needs its bound tests).  Blocks that need them run
                             // the tested C++ form, four steps at a time.
                             const int imdc = __float_as_int(__builtin_fmaxf(__builtin_fabsf(dcs.x), __builtin_fabsf(dcs.y)));
+                            // (FS_FAST_LOOP_FDU) the largest scale shift of the running lanes
+                            const int Esh_cap = wave_upper_bound_i32(Esh);
                             float mxS = mx0 * __builtin_amdgcn_ldexpf(1.0f, -kScaleShift);
                             int pwi = __builtin_amdgcn_readfirstlane(__float_as_int(e0.w));
                             // (all lanes sit at the same entry here: 2Z of the entry the state is at lives in scalar registers)
@@ -1721,8 +1817,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
 #ifdef FS_VERIFY_BLOCK_BOUND
                                 // VERIFICATION BUILD (tools/block_bound_check.py): every block runs the tested form, and a block
                                 // whose block test passes while one of its four arrivals fails its own bound test is counted
+#ifdef FS_FD_LANE_BOUND
                                 const int vg_ = __float_as_int(mxS) > imdc ? __float_as_int(mxS) : imdc;
                                 const bool bt_pass = __builtin_amdgcn_ballot_w64(vg_ + Esh > pwi) == 0ull;
+#else
+                                // (the block test of FS_FAST_LOOP_FDU, restated)
+                                const long long bt_a = sdc_bits > pwi ? -(1ll << 30) : (long long)pwi;
+                                const long long bt_d = bt_a - (long long)Esh_cap;
+                                const int bt_thr = bt_d > 0x46800000ll ? 0x46800000 : (int)bt_d;
+                                const bool bt_pass = __builtin_amdgcn_ballot_w64(__float_as_int(mxS) > bt_thr) == 0ull;
+#endif
                                 if (kStats && bt_pass)
                                     c_blk_free++;
 #else
@@ -1735,16 +1839,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
                                     uint64_t xacc_ = 0; // (verification build: lanes whose first state of a trip was below 2^-56)
                                     float tn_, tl_;
                                     uint64_t msk_;
-                                    int st, ebo, pf_, pg_, ph_;
+                                    int st, ebo, pf_, pg_, ph_, bt_t_;
                                     const uint32_t c_in = cs;
                                     uint32_t off = cs << 4;
+                                    FS_CYC(cyc_t3 = __builtin_readcyclecounter());
 #if FS_FL_EVERY && !defined(FS_VERIFY_FLOOR)
                                     if (!fl_per_trip) {
                                         {
                                             // (the 16-step body of k_perturb_scalar, FS_FAST_LOOP_FD16, measures 2 % slower here --
                                             // 47.8 - 48.1 against 46.6 - 47.0 ms at N = 1, 6.79 against 6.70 ms on the slowest of
                                             // eight emulated ranks: with seven waves per SIMD the round trip it halves is hidden)
+#ifdef FS_FD_LANE_BOUND /* A/B: round 4's per-lane block test (five vector instructions per block) */
                                             FS_FAST_LOOP_FD(FS_PF_NONE, FS_BT_DC_MAX, FS_BT_DC_ADD, FS_BT_H_CMP, FS_BT_H_OR);
+#else
+                                            FS_FAST_LOOP_FDU(FS_PF_NONE);
+#endif
                                         }
                                         ebo = 0;
                                     } else
@@ -1756,6 +1865,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
                                     if (kStats && xacc_ != 0ull)
                                         c_blk_violation++;
 #endif
+                                    FS_CYC(cyc_asm += __builtin_readcyclecounter() - cyc_t3);
                                     st = __builtin_amdgcn_readfirstlane(st); // (asm results count as divergent)
                                     zS = (f2){__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(zS.x))),
                                               __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(zS.y)))};
@@ -1795,6 +1905,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
                                 // takes any dword-aligned address)
                                 if (kStats)
                                     c_blk_tested++;
+                                FS_CYC(cyc_t4 = __builtin_readcyclecounter());
                                 typedef float f16 __attribute__((ext_vector_type(16)));
                                 f16 U;
                                 asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(U) : "s"(zpb + cs));
@@ -1841,6 +1952,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
                                 }
                                 cs += 4;
                                 wv = w4, mxS = mx_d, zS = (f2){ud.x, ud.y}, pwi = __float_as_int(ud.w);
+                                FS_CYC(cyc_tested += __builtin_readcyclecounter() - cyc_t4);
                                 if (cs >= rl) {
                                     c = cs, wO = wv, failed = false;
                                     break;
@@ -2185,6 +2297,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
                 }
             }
             FS_CYC(cyc_loop += __builtin_readcyclecounter() - cyc_t0);
+            FS_CYC(wall_loop += wall_clock64() - wall_t0);
             {
                 uint32_t lane_e;
                 asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
@@ -2237,6 +2350,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
             atomicAdd((unsigned long long *)&A.stats[0], (unsigned long long)cyc_loop);
             atomicAdd((unsigned long long *)&A.stats[1], (unsigned long long)cyc_run);
             atomicAdd((unsigned long long *)&A.stats[3], (unsigned long long)cyc_body);
+            atomicAdd((unsigned long long *)&A.stats[24], (unsigned long long)cyc_asm);
+            atomicAdd((unsigned long long *)&A.stats[25], (unsigned long long)cyc_tested);
+            atomicAdd((unsigned long long *)&A.stats[26], (unsigned long long)cyc_hot);
+            atomicAdd((unsigned long long *)&A.stats[27], (unsigned long long)wall_loop); // 100 MHz ticks
         }
         c_at = c_la = c_px = 0;
     }

@@ -26,10 +26,18 @@ for name, bands, waves in (("full", None, 3840 * 2160 // 64), ("band135", (135 *
         assert r.RenderPerturbLAv2(None, None, None, *co, v.num_iterations, T=T_HDR32, Mode=LAV2_FULL, parity=PARITY_CPU) == 0
         assert r.SyncComputeStream() == 0
     s = r.read_step_count()
+    import ctypes as C
+    raw = (C.c_uint64 * 32)()
+    assert r._lib.fs_read_stats_raw(r._h, raw, 32) == 0
     loop, run, body = s["at_iterations"], s["la_steps"], s["pixels"]
     print(json.dumps({"case": name, "kernel_ms": round(r.last_kernel_ms(), 3), "waves": waves,
                       "cyc_loop_per_wave": loop // waves, "cyc_run_block_per_wave": run // waves,
                       "cyc_bodies_per_wave": body // waves, "cyc_outside_run_block": (loop - run) // waves,
                       "cyc_entry_exit": (run - body) // waves,
+                      "cyc_hand_written_statement": raw[24] // waves, "cyc_tested_blocks": raw[25] // waves, "cyc_hot_runs": raw[26] // waves,
+                      "tested_blocks_per_wave": raw[9] / waves, "untested_blocks_per_wave": raw[8] / waves,
+                      "run_entries_per_wave": raw[12] / waves, "runs_started_per_wave": raw[13] / waves,
+                      "careful_passes_per_wave": raw[10] / waves,
+                      "shader_clock_ghz_in_the_loop": round(loop / max(1, raw[27]) * 0.1, 3),
                       "steps_per_wave_lane": s["perturb_steps"] // (waves * 64), "scaled_lane_steps": s["scaled_steps"],
                       "runs_per_wave": s["scaled_runs"] / waves, "careful_per_wave_lane": s["careful_steps"] / waves / 64}), flush=True)
