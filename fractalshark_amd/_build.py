@@ -85,11 +85,13 @@ def _render_flags():
         extra.append("-DFS_VERIFY_FLOOR")
     if os.environ.get("FS_BLA_FAST_PROBE") == "1":  # tools/bla_fast_check.py: how often the hand-written BLA loop is left (statistics words 20..23)
         extra.append("-DFS_BLA_FAST_PROBE")
+    if os.environ.get("FS_FD_LANE_BOUND") == "1":  # A/B: round 4's per-lane block test in C3's untested loop
+        extra.append("-DFS_FD_LANE_BOUND")
     if os.environ.get("FS_FD16_SERIAL") == "1":  # A/B: round 4's 16-step body (wait right behind the request) instead of the pipelined one
         extra.append("-DFS_FD16_SERIAL")
     if os.environ.get("FS_2X32_PROBE") == "1":  # counts the 2x32 perturbation loop's literal steps (statistics word 12)
         extra.append("-DFS_2X32_PROBE")
-    for name in ("FS_FL_EVERY", "FS_FL_SHIFT", "FS_FL_FLOOR_EXP", "FS_HOT_RUN_STEPS", "FS_PO_CHUNK", "FS_AT_CYCLE_CHUNK"):  # A/B: form and scale of the scaled runs' floor tests (kernels.hip)
+    for name in ("FS_FL_EVERY", "FS_FL_SHIFT", "FS_FL_FLOOR_EXP", "FS_HOT_RUN_STEPS", "FS_PO_CHUNK", "FS_AT_CYCLE_CHUNK", "FS_HOT_AFTER_FAIL"):  # A/B: form and scale of the scaled runs' floor tests (kernels.hip)
         if os.environ.get(name):
             extra.append("-D%s=%d" % (name, int(os.environ[name])))
     if os.environ.get("FS_SCALED_CHUNK"):  # tuning experiments only

@@ -39,6 +39,24 @@ __device__ __forceinline__ hcplx64 zref_at(const FsZ64 *__restrict__ z, uint32_t
 }
 
 // Pixel -> delta c, Fractal.cpp:2553-2562 (== 2272-2281): `dx * (float)x` goes through HDRFloat(T mant).
+
+// max / min of two magnitudes as ONE instruction (source modifiers).  Written as fmaxf(fabsf(a), fabsf(b)) the compiler first
+// canonicalises each operand (v_max_f32 |a|, |a| -- quieting a signalling NaN no arithmetic of this file can produce): three
+// instructions instead of one at every run entry, run exit and tested step.  A quiet NaN in one operand returns the other, as
+// fmaxf / fminf do.
+static __device__ __forceinline__ float fs_max_abs(float a, float b)
+{
+    float r;
+    asm("v_max_f32_e64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+static __device__ __forceinline__ float fs_min_abs(float a, float b)
+{
+    float r;
+    asm("v_min_f32_e64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 template <class F>
 __device__ __forceinline__ void pixel_delta(const FsCoordsT<F> &c, uint32_t x, uint32_t y, hreal<F> &dRe, hreal<F> &dIm)
 {
@@ -76,8 +94,8 @@ __global__ void k_prepare_orbit_hdr32(const fs_orbit_hdr32 *__restrict__ in, flo
 __device__ __forceinline__ float scaled_bound(const float4 v)
 {
     const int e = __float_as_int(v.z);
-    const float hi = __builtin_fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y));
-    const float lo = __builtin_fminf(__builtin_fabsf(v.x), __builtin_fabsf(v.y));
+    const float hi = fs_max_abs(v.x, v.y);
+    const float lo = fs_min_abs(v.x, v.y);
     const float zmax = __builtin_amdgcn_ldexpf(hi, e < -200 ? -200 : (e > 100 ? 100 : e));
     const bool usable = zmax >= 0x1p-40f && zmax < 5.6f && lo >= hi * 0x1p-40f;
     return usable ? zmax * 0x1p-2f : -0.0f;
@@ -113,7 +131,7 @@ __device__ __forceinline__ float scaled_block_bound(const float4 *__restrict__ z
         // growth of the step that leaves entry j + k
         const float4 v = zref[j + k < n ? j + k : n - 1];
         const int e = __float_as_int(v.z);
-        const float m = __builtin_amdgcn_ldexpf(__builtin_fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)),
+        const float m = __builtin_amdgcn_ldexpf(fs_max_abs(v.x, v.y),
                                                e < -200 ? -200 : (e > 100 ? 100 : e));
         ok = ok && m < 5.6f; // (a state never sits at an entry this large: its own bound is "never")
         grow *= (4.0f * m + 3.8f) * (1.0f + 0x1p-10f);
@@ -520,7 +538,7 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
     asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(p_##T) : "v"(pa_##T), "v"(pb_##T));              \
     NW_ = p_##T + dcs;
 #define FS_STEP_BOUND(NW_, T, V, EB)                                                                                \
-    const float mx_##T = __builtin_fmaxf(__builtin_fabsf(NW_.x), __builtin_fabsf(NW_.y));                           \
+    const float mx_##T = fs_max_abs(NW_.x, NW_.y);                           \
     V |= __builtin_amdgcn_ballot_w64(__float_as_int(mx_##T) + Esh > __float_as_int(EB));
 // One scaled step with its acceptance tests, and the per-lane entry load of the runs whose lanes sit at different orbit
 // positions: shared by k_lav2_hdr32_fast and the perturbation-only float path of k_perturb_scalar (one definition; round 4 had
@@ -532,7 +550,7 @@ __global__ void __launch_bounds__(256) k_lav2_lit(FsLav2ArgsT<F> A)
     f2 p_##T;                                                                                                       \
     asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(p_##T) : "v"(pa_##T), "v"(pb_##T));              \
     NW_ = p_##T + dcs;                                                                                              \
-    float mx_##T = __builtin_fmaxf(__builtin_fabsf(NW_.x), __builtin_fabsf(NW_.y));                                 \
+    float mx_##T = fs_max_abs(NW_.x, NW_.y);                                 \
     AFTER_ARITH;                                                                                                    \
     NZ_ = (f2){EX, EY};                                                                                             \
     V |= __builtin_amdgcn_ballot_w64(__float_as_int(mx_##T) + Esh > __float_as_int(EB));                            \
@@ -645,10 +663,10 @@ constexpr int kFloorBits = (127 - FS_FL_FLOOR_EXP) << 23;
 #define FS_FL_C "v_cmp_gt_f32_e32 vcc, %[flr], v61\n\t"   /* floor > the smallest part tested */
 #define FS_FL_H "v_cmp_lt_f32_e32 vcc, 0x46800000, v60\n\t"   /* 2^14 < max|w| at a block's first state */
 #define FS_STEP_FLOOR(NW_, V)                                                                                       \
-    V |= __builtin_amdgcn_ballot_w64(!(__builtin_fminf(__builtin_fabsf(NW_.x), __builtin_fabsf(NW_.y)) >= FS_FL_FLOOR));
+    V |= __builtin_amdgcn_ballot_w64(!(fs_min_abs(NW_.x, NW_.y) >= FS_FL_FLOOR));
 #if defined(FS_VERIFY_FLOOR)
 #define FS_STEP_FLOOR_FIRST(NW_, V)                                                                                 \
-    if (kStats && __builtin_amdgcn_ballot_w64(!(__builtin_fminf(__builtin_fabsf(NW_.x), __builtin_fabsf(NW_.y)) >= 0x1p-56f)) != 0ull) \
+    if (kStats && __builtin_amdgcn_ballot_w64(!(fs_min_abs(NW_.x, NW_.y) >= 0x1p-56f)) != 0ull) \
         c_blk_violation++;
 #elif FS_FL_EVERY
 #define FS_STEP_FLOOR_FIRST(NW_, V) FS_STEP_FLOOR(NW_, V)
@@ -1146,6 +1164,9 @@ constexpr uint32_t kScaledBackoffCap = FS_BACKOFF_CAP;
 #define FS_HOT_RUN_STEPS 64 /* measured on C3 (kernel ms): 8: 50.2, 16: 49.75, 32: 49.7, 64: 49.5, 128 .. 1024: 49.5 - 49.6 */
 #endif
 constexpr uint32_t kHotRunSteps = FS_HOT_RUN_STEPS;
+#ifndef FS_HOT_AFTER_FAIL
+#define FS_HOT_AFTER_FAIL 0 /* A/B, measured neutral on C3 (43.80 against 43.85 ms): 1 = the step a run failed on goes to a hot run before the careful step */
+#endif
 
 __device__ __forceinline__ uint32_t scaled_run_length(uint32_t left)
 {
@@ -1386,7 +1407,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
             // anything smaller, +inf beyond the range): the dc half of the block test, FS_FAST_LOOP_FDU
             int sdc_bits;
             {
-                const float mdc = __builtin_fmaxf(__builtin_fabsf(dc.re), __builtin_fabsf(dc.im));
+                const float mdc = fs_max_abs(dc.re, dc.im);
                 const int de = dc.e < -400 ? -400 : (dc.e > 400 ? 400 : dc.e);
                 const int lane_bits = mdc > 0.0f ? __float_as_int(__builtin_fmaxf(__builtin_amdgcn_ldexpf(mdc, de), 0x1p-126f))
                                                  : (mdc == 0.0f ? 0 : 0x7f800000);
@@ -1422,6 +1443,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
             FS_CYC(cyc_t0 = __builtin_readcyclecounter());
             FS_CYC(wall_t0 = wall_clock64());
             uint32_t sc_skip = 0, sc_penalty = 0; // (wave-uniform) back-off of the scaled-run attempts, see below
+            bool hot_next = false; // (wave-uniform) the step a scaled run has just failed on goes to a hot run first (FS_HOT_AFTER_FAIL)
             bool fl_per_trip = false; // (wave-uniform) the next run attempt uses the per-trip floor verdicts (FS_FAST_LOOP_FD)
             while (running) {
                 // ---- run of "scaled" quiet steps.  HDRFloat addition and multiplication are the correctly rounded binary32
@@ -1444,7 +1466,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
                 // sits >= 2^80 below everything that result is made of.
                 // Anything else leaves the state of the last accepted step to the exponent-tracking loop below.
                 bool sc_stopped = false; // a scaled run ended on a step it could not take: that step goes to the careful path
-                if (kScaled && sc_skip != 0u) {
+                if (kScaled && (sc_skip != 0u || hot_next)) {
+                    hot_next = false;
                     // back-off: the last run attempts of this wave ended before their first step (a lane sits where dz is not
                     // small against the orbit -- near its escape, or between two near-zero orbit values): an attempt costs an
                     // entry, a trip and an exit, so a few careful steps are taken before the next one
@@ -1477,8 +1500,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
                         const int dsh = dce - E;
                         const f2 dcs = {__builtin_amdgcn_ldexpf(dcm.x, dsh), __builtin_amdgcn_ldexpf(dcm.y, dsh)};
                         const float4 e0 = zs[ref];
-                        const float mx0 = __builtin_fmaxf(__builtin_fabsf(dzm.x), __builtin_fabsf(dzm.y));
-                        const float mn0 = __builtin_fminf(__builtin_fabsf(dzm.x), __builtin_fabsf(dzm.y));
+                        const float mx0 = fs_max_abs(dzm.x, dzm.y);
+                        const float mn0 = fs_min_abs(dzm.x, dzm.y);
                         const bool start_ok = scaled_startable(e0) && mn0 >= FS_FL_FLOOR * __builtin_amdgcn_ldexpf(1.0f, kScaleShift) &&
                                               mx0 >= 1.0f && mx0 < 2.0f && dsh <= 30 - kScaleShift;
                         if (__builtin_amdgcn_ballot_w64(!start_ok) == 0ull) {
@@ -1537,8 +1560,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
                                 f2 wz = q_;
                                 if (__builtin_amdgcn_ballot_w64(live && reb) != 0ull) {
                                     wz = (f2){__builtin_amdgcn_ldexpf(zt.x, -E), __builtin_amdgcn_ldexpf(zt.y, -E)};
-                                    const float mxz = __builtin_fmaxf(__builtin_fabsf(wz.x), __builtin_fabsf(wz.y));
-                                    const float mnz = __builtin_fminf(__builtin_fabsf(wz.x), __builtin_fabsf(wz.y));
+                                    const float mxz = fs_max_abs(wz.x, wz.y);
+                                    const float mnz = fs_min_abs(wz.x, wz.y);
                                     valid = valid && (!reb || (mnz >= FS_FL_FLOOR && mxz < FS_FL_HIGH_TRIP));
                                 }
                                 if (__builtin_amdgcn_ballot_w64(live && !valid) != 0ull)
@@ -1579,7 +1602,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
                                 // back to the reduced form (exact; every accepted state has two non-zero parts) -- also for a
                                 // lane that took no step: its w is dz 2^-E still, and rebuilding dz, its exponent and the orbit
                                 // value from it means that none of the three has to stay in a register across the run
-                                const float mxw = __builtin_fmaxf(__builtin_fabsf(w.x), __builtin_fabsf(w.y));
+                                const float mxw = fs_max_abs(w.x, w.y);
                                 const int k = (int)((uint32_t)__float_as_int(mxw) >> 23) - 127;
                                 dzm = (f2){__builtin_amdgcn_ldexpf(w.x, -k), __builtin_amdgcn_ldexpf(w.y, -k)};
                                 dze = E + k;
@@ -1592,7 +1615,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
                             sc_skip = 0u, sc_penalty = 0u;
                         continue;
                     }
-                    sc_skip--;
+                    if (sc_skip != 0u)
+                        sc_skip--;
                     sc_stopped = true;
                     was_skip = true;
                 } else if (kScaled) {
@@ -1606,8 +1630,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
                         FS_LOAD_DC()
                         const int dsh = dce - E;
                         const f2 dcs = {__builtin_amdgcn_ldexpf(dcm.x, dsh), __builtin_amdgcn_ldexpf(dcm.y, dsh)};
-                        const float mx0 = __builtin_fmaxf(__builtin_fabsf(dzm.x), __builtin_fabsf(dzm.y));
-                        const float mn0 = __builtin_fminf(__builtin_fabsf(dzm.x), __builtin_fabsf(dzm.y));
+                        const float mx0 = fs_max_abs(dzm.x, dzm.y);
+                        const float mn0 = fs_min_abs(dzm.x, dzm.y);
                         const uint32_t left_ref = ref + 1 < MaxRefIteration ? MaxRefIteration - 1 - ref : 0u;
                         const uint32_t left_it = n_iterations - 1 - iterations;
                         const uint32_t left = left_ref < left_it ? left_ref : left_it;
@@ -1652,7 +1676,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
                         // (a near-zero orbit entry otherwise costs two careful steps and two run entries when it sits second).
 #define FS_TRIP_FAILED(T, NW_, EB, WSTART)                                                                         \
     {                                                                                                               \
-        const float mn_s = __builtin_fminf(__builtin_fabsf(NW_.x), __builtin_fabsf(NW_.y));                         \
+        const float mn_s = fs_min_abs(NW_.x, NW_.y);                         \
         const uint64_t bad_s =                                                                                      \
             __builtin_amdgcn_ballot_w64(__float_as_int(mx_##T) + Esh > __float_as_int(EB)) |                        \
             __builtin_amdgcn_ballot_w64(!(mn_s >= FS_FL_FLOOR));                                                    \
@@ -1666,8 +1690,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
     }
 #define FS_TRIP_FAILED_NB(T, NW_, EB, WSTART)                                                                      \
     {                                                                                                               \
-        const float mx_s = __builtin_fmaxf(__builtin_fabsf(NW_.x), __builtin_fabsf(NW_.y));                         \
-        const float mn_s = __builtin_fminf(__builtin_fabsf(NW_.x), __builtin_fabsf(NW_.y));                         \
+        const float mx_s = fs_max_abs(NW_.x, NW_.y);                         \
+        const float mn_s = fs_min_abs(NW_.x, NW_.y);                         \
         const uint64_t bad_s =                                                                                      \
             __builtin_amdgcn_ballot_w64(__float_as_int(mx_s) + Esh > __float_as_int(EB)) |                        \
             __builtin_amdgcn_ballot_w64(!(mn_s >= FS_FL_FLOOR));                                                  \
@@ -1800,7 +1824,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
                             // happens, and the block runs without them -- as the hand-scheduled body below (eight steps;
                             // it stops after four when the second block needs its bound tests).  Blocks that need them run
                             // the tested C++ form, four steps at a time.
-                            const int imdc = __float_as_int(__builtin_fmaxf(__builtin_fabsf(dcs.x), __builtin_fabsf(dcs.y)));
+#if defined(FS_FD_LANE_BOUND) || defined(FS_VERIFY_BLOCK_BOUND) || defined(FS_VERIFY_FLOOR) || !FS_FL_EVERY
+                            const int imdc = __float_as_int(fs_max_abs(dcs.x, dcs.y));
+#endif
                             // (FS_FAST_LOOP_FDU) the largest scale shift of the running lanes
                             const int Esh_cap = wave_upper_bound_i32(Esh);
                             float mxS = mx0 * __builtin_amdgcn_ldexpf(1.0f, -kScaleShift);
@@ -1859,6 +1885,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
                                     } else
 #endif
                                     {
+#if !(defined(FS_FD_LANE_BOUND) || defined(FS_VERIFY_BLOCK_BOUND) || defined(FS_VERIFY_FLOOR) || !FS_FL_EVERY)
+                                        // (max|dc| in the run's scale: only this loop's per-lane block test reads it)
+                                        const int imdc = __float_as_int(fs_max_abs(dcs.x, dcs.y));
+#endif
                                         FS_FAST_LOOP_FL(FS_PF_NONE);
                                     }
 #ifdef FS_VERIFY_FLOOR
@@ -2026,7 +2056,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
                         // ends with means that none of them has to survive the run in a register (round 4: with the hot runs
                         // the allocator had spilled them to scratch around every run)
                         {
-                            const float mxw = __builtin_fmaxf(__builtin_fabsf(wO.x), __builtin_fabsf(wO.y));
+                            const float mxw = fs_max_abs(wO.x, wO.y);
                             const int k = (int)((uint32_t)__float_as_int(mxw) >> 23) - 127;
                             dzm = (f2){__builtin_amdgcn_ldexpf(wO.x, -k), __builtin_amdgcn_ldexpf(wO.y, -k)};
                             dze = E + k;
@@ -2043,6 +2073,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
                         }
                         if (failed) {
                             sc_stopped = true;
+                            hot_next = FS_HOT_AFTER_FAIL != 0;
                             if (c == 0u) {
                                 sc_penalty = sc_penalty < kScaledBackoffCap ? sc_penalty + 1u : kScaledBackoffCap;
                                 sc_skip = sc_penalty;
@@ -2053,6 +2084,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
                         }
                     }
                     FS_CYC(cyc_run += __builtin_readcyclecounter() - cyc_t1);
+                    // The step the run failed on: a hot run takes it (per lane, exit tests exact, 32 vector instructions) where it
+                    // can -- 70 of a wave's 97 careful passes (130 vector instructions each, and a run entry behind every one)
+                    // found that nothing happens at such a step -- and the careful step below where it cannot.
+                    if (hot_next)
+                        continue;
                 }
                 // ---- run of "quiet" steps: when dz is at least 2^4 below the orbit value and the orbit value is < 8,
                 // neither exit test can fire and z itself is not needed:
@@ -2098,7 +2134,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
     const float m2_##VIOL = __int_as_float((imax(imin(nd2_##VIOL, 111), -9) << 23) + (9 << 23));                    \
     const f2 q_##VIOL = p_##VIOL + dcm128 * m2_##VIOL;                                                              \
     const int fmax_##VIOL =                                                                                         \
-        __float_as_int(__builtin_fmaxf(__builtin_fabsf(q_##VIOL.x), __builtin_fabsf(q_##VIOL.y))) >> 23;            \
+        __float_as_int(fs_max_abs(q_##VIOL.x, q_##VIOL.y)) >> 23;            \
     NDZE = pe_##VIOL + fmax_##VIOL - 11; /* pe + fmax - 127 */                                                      \
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(ent_##VIOL));                                                          \
     NSC = __float_as_int(ent_##VIOL.z);                                                                             \
@@ -3129,8 +3165,8 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                     const int dshx = DeltaSub0X.e - E, dshy = DeltaSub0Y.e - E;
                     const f2 dcs = {__builtin_amdgcn_ldexpf(DeltaSub0X.m, imax(imin(dshx, 100), -200)),
                                     __builtin_amdgcn_ldexpf(DeltaSub0Y.m, imax(imin(dshy, 100), -200))};
-                    const float mx0 = __builtin_fmaxf(__builtin_fabsf(dzs.x), __builtin_fabsf(dzs.y));
-                    const float mn0 = __builtin_fminf(__builtin_fabsf(dzs.x), __builtin_fabsf(dzs.y));
+                    const float mx0 = fs_max_abs(dzs.x, dzs.y);
+                    const float mn0 = fs_min_abs(dzs.x, dzs.y);
                     const uint32_t left_ref = RefIteration + 1 < MaxRefS ? MaxRefS - 1 - RefIteration : 0u;
                     const uint32_t left_it = n_iterations - 1 - iter; // iter < n_iterations here
                     const uint32_t left = left_ref < left_it ? left_ref : left_it;
@@ -3157,7 +3193,7 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
                         // blocks with their bound tests where the block test fails.  A failed trip ends the run at its start
                         // state (keeping its first step loses here, see above).
                         const float4 *zpu = zs + ref_u + 1;
-                        const int imdc = __float_as_int(__builtin_fmaxf(__builtin_fabsf(dcs.x), __builtin_fabsf(dcs.y)));
+                        const int imdc = __float_as_int(fs_max_abs(dcs.x, dcs.y));
                         float mxS = mx0 * __builtin_amdgcn_ldexpf(1.0f, -kScaleShift);
                         int pwi = __builtin_amdgcn_readfirstlane(__float_as_int(e0.w));
                         f2 zS = {__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(e0.x))),
@@ -3462,8 +3498,8 @@ __global__ void __launch_bounds__(256) k_perturb_scalar(FsBlaArgsT<F> A)
     const int sN_ = __float_as_int(ent_.z);                                                                         \
     const int aXn_ = nxe_ + sN_, aYn_ = nye_ + sN_;                                                                 \
     const int hi_ = imax(imax(imax(aXn_, aYn_), cx_), cy_);                                                         \
-    const float tiny_ = __builtin_fminf(__builtin_fminf(__builtin_fabsf(T_.x), __builtin_fabsf(T_.y)),              \
-                                        __builtin_fminf(__builtin_fabsf(N_.x), __builtin_fabsf(N_.y)));             \
+    const float tiny_ = __builtin_fminf(fs_min_abs(T_.x, T_.y),              \
+                                        fs_min_abs(N_.x, N_.y));             \
     const uint64_t VIOL = __builtin_amdgcn_ballot_w64(imin(fx_, fy_) < 1) | __builtin_amdgcn_ballot_w64(hi_ > 111) | \
                           __builtin_amdgcn_ballot_w64(!(tiny_ > 0.0f))
 #define FS_SQ_COMMIT(ent_)                                                                                          \
