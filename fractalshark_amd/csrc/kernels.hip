@@ -1239,7 +1239,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
     // dc of the wave's pixels (two mantissas, one exponent): constant over the perturbation loop and needed only where a run or
     // a careful step starts, it is read back from here there instead of holding three registers across the loops (with the
     // hot runs of round 4 the register allocator had none left and spilled to scratch -- 180 MB of writes per frame)
-    __shared__ float s_dcp[3 * 256];
+    __shared__ float4 s_dcp[256]; // (16 bytes per lane: one shift for the address, ONE 12-byte LDS read for the three words)
     // ... and the state a scaled run starts from (dz's mantissas), needed again only when a run is repeated with the per-trip
     // verdicts: parked here for the run instead of held in two registers across it
     __shared__ float s_dzp[2 * 256];
@@ -1284,6 +1284,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
     uint32_t c_blk_violation = 0; // (verification build) blocks that passed the block test and failed a bound test: must stay 0
     uint32_t c_pass = 0, c_generic = 0; // careful passes of the wave / those that took the generic step
     uint32_t c_blk_free = 0, c_blk_tested = 0; // 4-step blocks of the scalar-cache scaled path without / with bound tests (per wave)
+    uint32_t c_lane_steps = 0, c_lane_runs = 0; // (counting build) wave-steps / runs taken on the per-lane entry path of the scaled runs
 #ifdef FS_PROFILE_CYCLES
     uint64_t cyc_loop = 0, cyc_run = 0, cyc_body = 0, cyc_t0 = 0, cyc_t1 = 0, cyc_t2 = 0;
     uint64_t cyc_asm = 0, cyc_tested = 0, cyc_hot = 0, cyc_t3 = 0, cyc_t4 = 0, cyc_t5 = 0, wall_loop = 0, wall_t0 = 0;
@@ -1400,7 +1401,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
                 uint32_t lane_s;
                 asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_s));
                 volatile __attribute__((address_space(3))) float *pd =
-                    (volatile __attribute__((address_space(3))) float *)s_dcp + (wave_in_block * 64u + lane_s) * 3u;
+                    (volatile __attribute__((address_space(3))) float *)s_dcp + (wave_in_block * 64u + lane_s) * 4u;
                 pd[0] = dc.re, pd[1] = dc.im, pd[2] = __int_as_float(dc.e);
             }
             // the largest true max|dc| of the wave's pixels as a binary32 bit pattern, never below the true value (2^-126 for
@@ -1420,10 +1421,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
     {                                                                                                               \
         uint32_t lane_d;                                                                                            \
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_d));             \
-        const volatile __attribute__((address_space(3))) float *pd_ =                                               \
-            (const volatile __attribute__((address_space(3))) float *)s_dcp + (wave_in_block * 64u + lane_d) * 3u;  \
-        dcm = (f2){pd_[0], pd_[1]};                                                                                 \
-        dce = __float_as_int(pd_[2]);                                                                               \
+        const uint32_t dc_addr_ = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float4 *)s_dcp +          \
+                                  ((wave_in_block * 64u + lane_d) << 4);                                            \
+        typedef float f3l_ __attribute__((ext_vector_type(3)));                                                     \
+        f3l_ dc3_;                                                                                                  \
+        asm volatile("ds_read_b96 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(dc3_) : "v"(dc_addr_) : "memory");       \
+        dcm = (f2){dc3_.x, dc3_.y};                                                                                 \
+        dce = __float_as_int(dc3_.z);                                                                               \
     }
             // (the orbit value the pixel is at is read where a quiet run or a careful step starts -- zq / zr [ref] -- instead of
             // being carried in registers across the runs)
@@ -2035,6 +2039,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
                             }
                             // a run that ends in its first trip leaves the loads of the second in flight: they land before anything else happens
                             asm volatile("s_waitcnt vmcnt(0) ; scaled run, loop exit" ::"v"(ent_a), "v"(ent_b), "v"(ent_c_), "v"(ent_d));
+                            if (kStats) {
+                                c_lane_steps += c;
+                                c_lane_runs++;
+                            }
                         }
 #undef FS_TRIP_FAILED
 #undef FS_TRIP_FAILED_NB
@@ -2411,6 +2419,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
             c_wentry = we > c_wentry ? we : c_wentry;
             c_wstart = ws > c_wstart ? ws : c_wstart;
             c_wshort = wh > c_wshort ? wh : c_wshort;
+            const uint32_t ls = __shfl_down(c_lane_steps, off), lr = __shfl_down(c_lane_runs, off);
+            c_lane_steps = ls > c_lane_steps ? ls : c_lane_steps;
+            c_lane_runs = lr > c_lane_runs ? lr : c_lane_runs;
             const uint32_t bv = __shfl_down(c_blk_violation, off);
             c_blk_violation = bv > c_blk_violation ? bv : c_blk_violation;
             for (int i = 0; i < 4; i++) {
@@ -2436,6 +2447,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
                 atomicAdd((unsigned long long *)&A.stats[16 + i], (unsigned long long)c_why[i]);
                 atomicAdd((unsigned long long *)&A.stats[20 + i], (unsigned long long)c_nz[i]);
             }
+            atomicAdd((unsigned long long *)&A.stats[28], (unsigned long long)c_lane_steps);
+            atomicAdd((unsigned long long *)&A.stats[29], (unsigned long long)c_lane_runs);
         }
     }
 }

@@ -48,6 +48,7 @@ for w, h in ((480, 270), (960, 540), (1920, 1080), (3840, 2160)):
                                                                    "such_an_entry_and_nothing_happens": round(raw[21] / (w * h / 64), 1),
                                                                    "another_entry_and_nothing_happens": round(raw[22] / (w * h / 64), 1),
                                                                    "as_a_back_off_wait": round(raw[23] / (w * h / 64), 1)},
+                          "per_lane_entry_path": {"wave_steps_per_wave": round(raw[28] / (w * h / 64), 1), "runs_per_wave": round(raw[29] / (w * h / 64), 1)},
                           "generic_step_share_of_passes": round(raw[11] / max(1, raw[10]), 4),
                           "lane_utilisation": round(st["perturb_steps"] / max(1, st["lane_slots"]), 4)}), flush=True)
 r.set_kernel_variant(0)
