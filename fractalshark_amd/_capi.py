@@ -138,6 +138,7 @@ def render_lib():
     _decl(lib, "fs_read_step_count", u32, [vp, vp])
     _decl(lib, "fs_time_render_current", u32, [vp, u64, u32, vp])
     _decl(lib, "fs_read_stats_raw", u32, [vp, vp, u64])
+    _decl(lib, "fs_test_block_threshold", u32, [vp, vp, vp, vp, vp, u32])
     _decl(lib, "fs_build_la", u32, [vp, C.c_int, vp, C.c_int])
     _decl(lib, "fs_build_la_mt", u32, [vp, C.c_int, vp, C.c_int, C.c_int])
     _decl(lib, "fs_la_counts", u32, [vp, vp, vp, vp, vp])
@@ -180,7 +181,7 @@ RENDER_SYMBOLS = [
     "fs_render_direct_lp", "fs_clear",
     "fs_render_current", "fs_sync_compute", "fs_compute_stream", "fs_sync_display", "fs_query_compute", "fs_enqueue_done_callback",
     "fs_host_fallback_bytes", "fs_idle_device_bytes", "fs_release_idle_device_memory", "fs_set_compressed_orbit_mode", "fs_orbit_device_bytes", "fs_get_width", "fs_get_height", "fs_last_kernel_ms", "fs_set_kernel_variant", "fs_kernel_ms_history", "fs_forget_tile_costs", "fs_last_frame_tile_ordered", "fs_read_tile_costs", "fs_read_tile_order", "fs_seq_cursor_probe", "fs_enable_step_count", "fs_read_step_count",
-    "fs_time_render_current", "fs_read_stats_raw", "fs_build_la", "fs_build_la_mt", "fs_la_counts", "fs_read_la",
+    "fs_time_render_current", "fs_read_stats_raw", "fs_test_block_threshold", "fs_build_la", "fs_build_la_mt", "fs_la_counts", "fs_read_la",
     "fs_group_create", "fs_group_destroy", "fs_group_size", "fs_group_transport", "fs_group_renderer", "fs_group_init_memory",
     "fs_group_upload_orbit", "fs_group_upload_orbit_compressed", "fs_group_upload_la", "fs_group_upload_bla",
     "fs_group_upload_orbit_scaled", "fs_group_render_lav2", "fs_group_render_bla", "fs_group_render_scaled",

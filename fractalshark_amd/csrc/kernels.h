@@ -447,3 +447,5 @@ template <class F>
 void fsk_la_at(const void *las, const uint32_t *stage_la_index, uint32_t stage_count, const void *radius,
                int use_small_exponents, void *at_out, uint32_t *use_at, hipStream_t s);
 void fsk_la_pack(bool is64, const void *in, void *out, uint32_t n, hipStream_t s);
+// test hook: FS_FAST_LOOP_FDU's block threshold for n (bound, largest scale shift, largest max|dc|) triples (device arrays)
+void fsk_test_block_threshold(const int *bw, const int *eshm, const int *sdc, int *t_out, uint32_t n, hipStream_t s);

@@ -825,16 +825,19 @@ constexpr int kFloorBits = (127 - FS_FL_FLOOR_EXP) << 23;
 //     with the block bound on the scalar unit;
 //   bits(max|w|) + Esh <= bound holds in every lane when bits(max|w|) <= bound - (the LARGEST Esh of the running lanes: `eshm`,
 //     made once per run by a few votes);  H is bits(max|w|) <= bits(2^14);
-// so a block's test is  bits(max|w|) <= T,  T = min(bound - eshm, bits(2^14)), or "never" when sdc > bound: five scalar
-// instructions, then max|w| and ONE compare on the vector unit.  (bound - eshm can only overflow upwards -- the "never" bound,
-// the most negative integer, is replaced by -2^30 first -- and an overflow means T = H.)  A wave whose lanes' scales are k binades
+// so a block's test is  bits(max|w|) <= T,  T = min(bound - eshm, bits(2^14)), or -1 ("never") when sdc > bound -- which the
+// "never" bound, the most negative integer, always is: five scalar instructions, then max|w| and ONE compare on the vector unit.
+// (For a usable bound, >= 0, the difference can only overflow upwards, and an overflow means T = H; what the first three
+// instructions make of the "never" bound is overwritten.  The first form of this macro replaced that bound by -2^30 and
+// subtracted: positive again under a scale shift below -2^30, i.e. for |dz| < 2^-152 -- tools/block_bound_check.py counted 24 150
+// such blocks among 3.6e9 on the deep views 11, 14 and 19, none on View 5.)  A wave whose lanes' scales are k binades
 // apart tests its lower lanes against a bound 2^k tighter than theirs: such a block takes the tested path, nothing else changes.
 #define FS_BT_T(BW)                                                                                                 \
-    "s_cmp_gt_i32 %[sdc], " BW "\n\t"                                                                               \
-    "s_cselect_b32 %[t], 0xc0000000, " BW "\n\t"                                                                    \
-    "s_sub_i32 %[t], %[t], %[eshm]\n\t"                                                                             \
+    "s_sub_i32 %[t], " BW ", %[eshm]\n\t"                                                                           \
     "s_cselect_b32 %[t], 0x46800000, %[t]\n\t"                                                                      \
-    "s_min_i32 %[t], %[t], 0x46800000\n\t"
+    "s_min_i32 %[t], %[t], 0x46800000\n\t"                                                                          \
+    "s_cmp_gt_i32 %[sdc], " BW "\n\t"                                                                               \
+    "s_cselect_b32 %[t], -1, %[t]\n\t"
 #define FS_BT_V "v_cmp_lt_i32_e32 vcc, %[t], v60\n\t"
 #define FS_FAST_LOOP_FDU(PF)                                                                                        \
     asm volatile(                                                                                                   \
@@ -1071,6 +1074,29 @@ constexpr int kFloorBits = (127 - FS_FL_FLOOR_EXP) << 23;
         : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50",  \
           "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65",  \
           "s72", "s73", "s74", "vcc", "scc")
+
+// ------------------------------------------------------------------------------------------------
+// Test hook (fs_test_block_threshold): the wave-uniform block threshold T of FS_FAST_LOOP_FDU, evaluated by the very macro the loop
+// uses (FS_BT_T), one case per wave -- so that tests/test_gpu_block_threshold.py can hold it against its definition at the corners
+// ("never" bounds under scale shifts of either sign and any size, overflow, max|dc| above the bound).
+__global__ void k_test_block_threshold(const int *__restrict__ bw, const int *__restrict__ eshm, const int *__restrict__ sdc,
+                                       int *__restrict__ t_out, uint32_t n)
+{
+    const uint32_t i = blockIdx.x;
+    if (i >= n)
+        return;
+    const int b = __builtin_amdgcn_readfirstlane(bw[i]), e = __builtin_amdgcn_readfirstlane(eshm[i]),
+              d = __builtin_amdgcn_readfirstlane(sdc[i]);
+    int t;
+    asm volatile("s_mov_b32 s67, %[b]\n\t" FS_BT_T("s67") : [t] "=&s"(t) : [b] "s"(b), [eshm] "s"(e), [sdc] "s"(d) : "s67", "scc");
+    if (threadIdx.x == 0)
+        t_out[i] = t;
+}
+
+void fsk_test_block_threshold(const int *bw, const int *eshm, const int *sdc, int *t_out, uint32_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_test_block_threshold, dim3(n), dim3(64), 0, s, bw, eshm, sdc, t_out, n);
+}
 
 // ------------------------------------------------------------------------------------------------
 // LAv2, T = HDRFloat<float>: tuned perturbation loop.  Same prologue (AT + LA stages) and the same results, bit for
@@ -1852,9 +1878,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
                                 const bool bt_pass = __builtin_amdgcn_ballot_w64(vg_ + Esh > pwi) == 0ull;
 #else
                                 // (the block test of FS_FAST_LOOP_FDU, restated)
-                                const long long bt_a = sdc_bits > pwi ? -(1ll << 30) : (long long)pwi;
-                                const long long bt_d = bt_a - (long long)Esh_cap;
-                                const int bt_thr = bt_d > 0x46800000ll ? 0x46800000 : (int)bt_d;
+                                const long long bt_d = (long long)pwi - (long long)Esh_cap;
+                                const int bt_thr = sdc_bits > pwi ? -1 : (bt_d > 0x46800000ll ? 0x46800000 : (int)bt_d);
                                 const bool bt_pass = __builtin_amdgcn_ballot_w64(__float_as_int(mxS) > bt_thr) == 0ull;
 #endif
                                 if (kStats && bt_pass)

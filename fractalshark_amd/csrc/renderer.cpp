@@ -3217,6 +3217,33 @@ uint32_t fs_enable_step_count(fs_renderer *r, int enable)
     return 0;
 }
 
+uint32_t fs_test_block_threshold(fs_renderer *r, const int32_t *bound_bits, const int32_t *scale_shift, const int32_t *dc_bits,
+                                 int32_t *threshold_out, uint32_t n)
+{
+    if (!r || !bound_bits || !scale_shift || !dc_bits || !threshold_out)
+        return (uint32_t)hipErrorInvalidValue;
+    if (n == 0)
+        return 0;
+    FS_TRY(hipSetDevice(r->device));
+    int *d = nullptr;
+    FS_TRY(hipMalloc((void **)&d, (size_t)n * 4 * sizeof(int)));
+    uint32_t rc = (uint32_t)hipMemcpy(d, bound_bits, n * sizeof(int), hipMemcpyHostToDevice);
+    if (!rc)
+        rc = (uint32_t)hipMemcpy(d + n, scale_shift, n * sizeof(int), hipMemcpyHostToDevice);
+    if (!rc)
+        rc = (uint32_t)hipMemcpy(d + 2 * (size_t)n, dc_bits, n * sizeof(int), hipMemcpyHostToDevice);
+    if (!rc) {
+        fsk_test_block_threshold(d, d + n, d + 2 * (size_t)n, d + 3 * (size_t)n, n, r->compute);
+        rc = (uint32_t)hipGetLastError();
+    }
+    if (!rc)
+        rc = (uint32_t)hipStreamSynchronize(r->compute);
+    if (!rc)
+        rc = (uint32_t)hipMemcpy(threshold_out, d + 3 * (size_t)n, n * sizeof(int), hipMemcpyDeviceToHost);
+    hipFree(d);
+    return rc;
+}
+
 uint32_t fs_read_stats_raw(fs_renderer *r, uint64_t *out, uint64_t max_words)
 {
     if (uint32_t e = use_device(r))

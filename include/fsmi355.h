@@ -362,6 +362,12 @@ uint32_t fs_read_step_count(fs_renderer *r, uint64_t counts[8]);
 /* The whole statistics buffer (measurement builds append per-wave trace records behind the 8 counters: library built
  * with FS_TRACE_WAVES=1 and FSMI355_TRACE_WAVES=<max waves> in the environment; tools/wave_trace.py). */
 uint32_t fs_read_stats_raw(fs_renderer *r, uint64_t *out, uint64_t max_words);
+/* Test hook: the wave-uniform block threshold of the tuned HDRFloat<float> LAv2 loop (csrc/kernels.hip, FS_FAST_LOOP_FDU), evaluated on
+ * the device by the macro the loop itself uses, for n triples (block bound as a binary32 bit pattern -- 0x80000000 = "never" --, largest
+ * scale shift of the running lanes, largest max|dc| as a bit pattern): threshold_out[i] = -1 when dc_bits > bound_bits, else
+ * min(bound_bits - scale_shift, 0x46800000) without wrap-around.  Host arrays.  tests/test_gpu_block_threshold.py. */
+uint32_t fs_test_block_threshold(fs_renderer *r, const int32_t *bound_bits, const int32_t *scale_shift, const int32_t *dc_bits,
+                                 int32_t *threshold_out, uint32_t n);
 /* Average duration (HIP events on the compute stream, `repeats` back-to-back launches, no D2H) of the two RenderCurrent
  * kernels over the current iteration buffer: ms_out[0] = antialias + palette, ms_out[1] = min / max / sum.  Needs a
  * palette (fs_init_memory) and the whole frame on this renderer.  tools/bench_render_current.py turns them into GB/s. */
