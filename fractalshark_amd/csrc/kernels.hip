@@ -1239,8 +1239,8 @@ __device__ __forceinline__ uint32_t scaled_run_length_po(uint32_t left)
 // different work per frame, and a kernel trace then lists them separately).
 // An upper bound, wave-uniform, of v over the ACTIVE lanes -- the largest value itself when a vote or two find it (the values of
 // a wave's lanes, scales and dc, are a few binades apart at most), at most a few binades above it otherwise: each further trip
-// adds a growing slack (1, 2, 4 ... binades of a binary32 bit pattern), so the loop ends after nine trips at the latest whatever the
-// lanes hold.  Votes instead of a reduction: nothing is written under a widened EXEC.  v <= 0x7f800000.
+// adds a growing slack (1, 2, 4 ... 64 binades of a binary32 bit pattern), so the loop ends after a dozen trips at the latest whatever
+// the lanes hold.  Votes instead of a reduction: nothing is written under a widened EXEC.  v <= 0x7f800000.
 static __device__ __forceinline__ int wave_upper_bound_i32(int v)
 {
     int m = __builtin_amdgcn_readfirstlane(v);
