@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark: Mpix/s of the iteration buffer, View #5 at 3840x2160, HDRx32 LAv2.
 
-  python bench.py --gpus N --steps K --warmup W [--workload c3_lav2|c2_po|c5_bla|c4_hdr64|c4_2x32|c4_scaled]
+  python bench.py --gpus N --steps K --warmup W [--workload c3_lav2|c1_direct|c2_po|c5_bla|c4_hdr64|c4_2x32|c4_scaled]
+                  [--host-path gather|direct]
 
 N > 1 is one rank per GPU under torch.distributed (backend "nccl" = RCCL).  When bench.py is started WITHOUT a launcher
 (no WORLD_SIZE / RANK in the environment) and --gpus N > 1, it starts `python -m torch.distributed.run --nnodes=1
@@ -44,13 +45,15 @@ PEAK_FP32_VECTOR_TFLOPS = 157.3
 PEAK_FP64_VECTOR_TFLOPS = 78.6
 PEAK_HBM_GBS = 8000.0
 FLOP_PER_BLA_JUMP = 22
-TRAFFIC_FILE = "r05_traffic.json"  # profiles/: PMC passes of THIS round's kernels (tools/profile_round5.sh + _collect.py)
+FLOP_PER_DIRECT_ITERATION = 8  # z*z + c in binary64 with |z|^2: 4 multiplications + 4 additions (Fractal.cpp:2148-2183)
+TRAFFIC_FILE = "r06_traffic.json"  # profiles/: PMC passes of THIS round's kernels (tools/profile_round6.sh + _collect.py)
 
 WORKLOADS = {  # name: (view, width, height, tag in config.workload, dominant kernel)
     "c3_lav2": (5, 3840, 2160, "hdrx32_lav2_full", "k_lav2_hdr32_fast"),
-    "c2_po": (5, 1920, 1080, "hdrx32_po", "k_perturb_scalar"),
-    "c5_bla": (19, 7680, 4320, "hdrx32_bla", "k_perturb_scalar"),
-    "c4_hdr64": (14, 3840, 2160, "hdrx64_lav2_full_aa4", "k_lav2_lit<double>"),
+    "c1_direct": (0, 1024, 768, "f64_direct", "k_direct_f64"),
+    "c2_po": (5, 1920, 1080, "hdrx32_po", "k_perturb_scalar<float, false>"),
+    "c5_bla": (19, 7680, 4320, "hdrx32_bla", "k_bla_hdr32_fast"),
+    "c4_hdr64": (14, 3840, 2160, "hdrx64_lav2_full_aa4", "k_at_pass64 + k_lav2_lit<double>"),
     "c4_2x32": (14, 3840, 2160, "hdrx2x32_lav2_full_aa4", "k_lav2_2x32"),
     "c4_scaled": (14, 3840, 2160, "hdrx32_scaled_aa1_itercap", "k_scaled_hdr32_fast"),
 }
@@ -121,7 +124,17 @@ def make_inputs(wl, view_id=-1, width=0, height=0, iter_cap=0, parity=None):
     is2x32 = wl == "c4_2x32"
     is_scaled = wl == "c4_scaled"
     is64 = wl in ("c4_hdr64", "c4_2x32")  # the 2x32 inputs are derived from the HDRFloat<double> ones
+    is_direct = wl == "c1_direct"
     view = inputs.View.builtin(view_id, width, height, antialiasing=None if is64 else 1)
+    if is_direct:
+        # BASELINE config C1: no reference orbit, no table -- CalcCpuHDR<uint32_t,double,double> iterates every pixel itself
+        AA = view.antialiasing
+        co = view.coords_direct_f64(AA)
+        return {"workload": wl, "view_id": view_id, "width": width, "height": height, "parity": parity or "cpu", "is_lav2": False,
+                "is2x32": False, "is_scaled": False, "is64": False, "is_direct": True, "view": view, "orbit": None, "la": None,
+                "orbit2": None, "la2": None, "bla": None, "AA": AA, "W": view.width * AA, "H": view.height * AA,
+                "n_iter": iter_cap if iter_cap > 0 else view.num_iterations, "coords_arr": co, "coords": None,
+                "key": "view%d_%dx%d_%s" % (view_id, view.width * AA, view.height * AA, WORKLOADS[wl][3])}
     orbit = inputs.Orbit(view, is64=is64)
     la = inputs.LATable(orbit, host_threads=max(2, effective_cpus()), use_small_exponents=is2x32) if is_lav2 else None
     orbit2 = inputs.Orbit2x32(orbit) if is2x32 else None
@@ -140,7 +153,7 @@ def make_inputs(wl, view_id=-1, width=0, height=0, iter_cap=0, parity=None):
         coords_arr = view.coords_perturb(orbit)
         coords = [(float(c["m"]), int(c["e"])) for c in coords_arr]
     return {"workload": wl, "view_id": view_id, "width": width, "height": height, "parity": parity, "is_lav2": is_lav2,
-            "is2x32": is2x32, "is_scaled": is_scaled, "is64": is64, "view": view, "orbit": orbit, "la": la, "orbit2": orbit2,
+            "is2x32": is2x32, "is_scaled": is_scaled, "is64": is64, "is_direct": False, "view": view, "orbit": orbit, "la": la, "orbit2": orbit2,
             "la2": la2, "bla": bla, "AA": AA, "W": view.width * AA, "H": view.height * AA, "n_iter": n_iter,
             "coords_arr": coords_arr, "coords": coords,
             "key": "view%d_%dx%d_%s" % (view_id, view.width * AA, view.height * AA, WORKLOADS[wl][3])}
@@ -191,6 +204,12 @@ def parse():
     ap.add_argument("--share-device", action="store_true",
                     help="every rank uses device 0 (tests on a one-GPU box; needs --dist-backend gloo: RCCL refuses two ranks "
                          "on one device)")
+    ap.add_argument("--host-path", choices=["gather", "direct"], default="gather",
+                    help="N > 1: how the frame reaches host memory.  gather (default) = the slices go to rank 0 (RCCL over xGMI), one "
+                         "kernel restores row order, ONE copy over rank 0's PCIe link.  direct = every rank copies its own bands "
+                         "straight to their rows of a shared, page-locked frame (POSIX shared memory registered in every rank; "
+                         "fs_copy_bands_to_host: one 2-D copy per rank, destination pitch = band stride) over ITS OWN link -- no "
+                         "gather, no re-order kernel, N links instead of one.  Same frame either way")
     ap.add_argument("--no-build", action="store_true",
                     help="never spawn a compiler (same as FS_NO_BUILD=1): required under rocprofv3, see tools/pmc_passes.sh")
     return ap.parse_args()
@@ -257,7 +276,7 @@ def main():
     import numpy as np
     import torch
 
-    from fractalshark_amd import (GPURenderer, LAV2_FULL, PARITY_CPU, PARITY_CPU_GPUSTAGE, T_HDR2X32, T_HDR32, T_HDR64,
+    from fractalshark_amd import (GPURenderer, LAV2_FULL, PARITY_CPU, PARITY_CPU_GPUSTAGE, T_F64, T_HDR2X32, T_HDR32, T_HDR64,
                                   _build, inputs, tiling)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -307,6 +326,7 @@ def main():
     t_inputs = time.time() - t0
     args.view, args.width, args.height, args.parity = inp["view_id"], inp["width"], inp["height"], inp["parity"]
     is_lav2, is2x32, is_scaled, is64 = inp["is_lav2"], inp["is2x32"], inp["is_scaled"], inp["is64"]
+    is_direct = inp["is_direct"]
     inp_default_parity = "cpu_gpustage" if wl == "c4_hdr64" else "cpu"  # (the parity the profiles were taken in)
     view, orbit, la, orbit2, la2, bla = inp["view"], inp["orbit"], inp["la"], inp["orbit2"], inp["la2"], inp["bla"]
     AA, W, H, n_iter = inp["AA"], inp["W"], inp["H"], inp["n_iter"]
@@ -330,6 +350,8 @@ def main():
         assert r.InitializePerturb(1, orbit2, 0, None, la2) == 0
     elif is_lav2:
         assert r.InitializePerturb(1, orbit, 0, None, la) == 0
+    elif is_direct:
+        pass  # (no inputs beyond the coordinates)
     elif is_scaled:
         # the reference re-uploads both PerturbExtras::Bad orbits inside every RenderPerturbBLAScaled call
         # (GPU_Render.cu:1324-1345); here once, outside the timed region (inputs resident in HBM)
@@ -369,10 +391,36 @@ def main():
         local_rows = rows_padded
     local = [torch.zeros((local_rows, rw), dtype=torch.int32, device="cuda") for _ in range(NB)]
     local_bytes = local[0].numel() * local[0].element_size()
-    host_t = [torch.zeros((rows_padded, rw), dtype=torch.int32, pin_memory=True) for _ in range(NB)] if rank == 0 else None
-    host_np = [t.numpy().view(np.uint32) for t in host_t] if rank == 0 else None
+    direct_path = distributed and args.host_path == "direct"
+    shm_files = shm_maps = flags = None
+    host_ptr = None
+    if direct_path:
+        # The frame lives in POSIX shared memory that EVERY rank maps and page-locks (fs_host_register = hipHostRegister, portable):
+        # rank r's copy engine writes rank r's bands into it over rank r's own PCIe link.  One small shared array of frame
+        # counters tells rank 0 (the consumer) when every rank's bands of a frame have landed.
+        names = [None]
+        if rank == 0:
+            names = ["/dev/shm/fsmi355_bench_%d" % os.getpid()]
+            with open(names[0], "wb") as f:
+                f.truncate(NB * rows_padded * rw * 4 + 4096)
+        dist.broadcast_object_list(names, src=0)
+        shm_files = names
+        mm = np.memmap(names[0], dtype=np.uint8, mode="r+")
+        shm_maps = mm
+        assert lib.fs_host_register(mm.ctypes.data, mm.nbytes) == 0, "hipHostRegister of the shared frame failed"
+        frame_bytes = rows_padded * rw * 4
+        host_np = [mm[b * frame_bytes:(b + 1) * frame_bytes].view(np.uint32).reshape(rows_padded, rw) for b in range(NB)]
+        host_ptr = [mm.ctypes.data + b * frame_bytes for b in range(NB)]
+        flags = mm[NB * frame_bytes:NB * frame_bytes + 4096].view(np.int64)  # flags[r] = frames of rank r that are in the host frame
+        host_t = None
+        dist.barrier()
+    else:
+        host_t = [torch.zeros((rows_padded, rw), dtype=torch.int32, pin_memory=True) for _ in range(NB)] if rank == 0 else None
+        host_np = [t.numpy().view(np.uint32) for t in host_t] if rank == 0 else None
     gathered = frame_dev = frame_index = stage = None
-    if host_staged:
+    if direct_path:
+        pass  # (no gather buffers at all)
+    elif host_staged:
         stage = torch.zeros((local_rows, rw), dtype=torch.int32, pin_memory=True)
         if rank == 0:
             gathered = [torch.empty((world * local_rows, rw), dtype=torch.int32)]
@@ -389,6 +437,7 @@ def main():
     ev_host = [torch.cuda.Event() for _ in range(NB)]      # host[b] holds the frame
     used = [False] * NB
     state = {"k": 0, "last": None}
+    seq_of = [0] * NB  # direct path: the frame number (1, 2, ...) buffer b holds
 
     def enqueue_frame(par):
         """Launch one frame and everything behind it (asynchronous).  Returns the buffer index it lands in."""
@@ -399,6 +448,8 @@ def main():
         assert r.SetExternalIterBuffer(local[b].data_ptr(), local_bytes) == 0
         if is_lav2:
             e = r.RenderPerturbLAv2(None, None, None, *coords, n_iter, T=T_TAG, Mode=LAV2_FULL, parity=par)
+        elif is_direct:
+            e = lib.fs_render_direct(r._h, T_F64, coords_arr.ctypes.data, n_iter)
         elif is_scaled:
             e = lib.fs_render_scaled(r._h, T_HDR32, coords_arr.ctypes.data, n_iter)
         else:
@@ -406,6 +457,17 @@ def main():
         assert e == 0, GPURenderer.ConvertErrorToString(e)
         ev_render[b].record(render_stream)
         src = local[b]
+        if direct_path:
+            # every rank: its own bands -> their rows of the shared frame, on its copy stream behind its kernel
+            copy_stream.wait_event(ev_render[b])
+            e = r.CopyBandsToHost(host_ptr[b], local[b].data_ptr(), copy_stream.cuda_stream)
+            assert e == 0, GPURenderer.ConvertErrorToString(e)
+            ev_host[b].record(copy_stream)
+            ev_consumed[b].record(copy_stream)
+            used[b] = True
+            state["last"] = b
+            seq_of[b] = state["k"]
+            return b
         if host_staged:
             # the same exchange through host memory: wait for the kernel, slice -> page-locked host, gloo gather, rank 0 puts
             # the rows in order straight into the frame's host buffer.  Blocking: frames do not overlap in this mode
@@ -446,6 +508,13 @@ def main():
 
     def wait_frame(b):
         """Host waits until frame in buffer b is where it has to be (rank 0: in host memory)."""
+        if direct_path:
+            ev_host[b].synchronize()      # my bands are in the shared frame ...
+            flags[rank] = seq_of[b]
+            if rank == 0:                 # ... and the consumer waits for everybody's
+                while int(flags[:world].min()) < seq_of[b]:
+                    pass
+            return
         (ev_host[b] if rank == 0 else ev_consumed[b]).synchronize()
 
     def one_frame(par):
@@ -466,14 +535,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    def timed(par):
+    def timed(par, cold=False):
         """EXACTLY args.steps frames between barrier + synchronize on both sides, pipelined: while frame k's slices are
         gathered and copied out, frame k+1's kernel runs; the host waits for frame k-1's host buffer before it launches
-        frame k+1.  -> (seconds, max over ranks; kernel ms of this rank's frames)"""
+        frame k+1.  cold: every frame is the FIRST frame of its view (whatever the renderer recorded is dropped before each
+        launch -- a viewer that zooms changes the coordinates with every frame).
+        -> (seconds, max over ranks; kernel ms of this rank's frames)"""
         barrier_sync()
         t0 = time.perf_counter()
         prev = None
         for _ in range(args.steps):
+            if cold:
+                r.forget_tile_costs()
             b = enqueue_frame(par)
             if prev is not None:
                 wait_frame(prev)
@@ -526,16 +599,36 @@ def main():
             one_frame(parity)
     # the frame the steady state starts from: a frame in natural order has run (count_steps), its recorded costs order the
     # frames that follow ("warm": every timed frame, like every frame after the first of a real sequence of frames)
-    elapsed, kernel_ms = timed(parity)
+    # HDRFloat<double> / <CudaDblflt> (advisor, round 5): their pixel order is keyed by the view's COORDINATES, so it only exists
+    # for a view that is rendered three times; a viewer that zooms never sees it.  `value` of these two workloads is therefore
+    # the COLD figure -- every timed frame a first frame -- and the warm one is reported beside it (value_warm).  The
+    # HDRFloat<float> tile costs are keyed without the coordinates and do carry over from frame to frame of a zoom: warm.
+    cold_headline = wl in ("c4_hdr64", "c4_2x32") and tile_order_on
+    elapsed_warm = kernel_ms_warm = None
+    if cold_headline:
+        elapsed_warm, kernel_ms_warm = timed(parity)
+        warm_split = r.kernel_ms_split_history(min(args.steps, 64))
+        elapsed, kernel_ms = timed(parity, cold=True)
+        kernel_split = r.kernel_ms_split_history(min(args.steps, 64))
+        for _ in range(3):  # (leave the renderer warm again for the latency figures below)
+            if r.last_frame_tile_ordered():
+                break
+            one_frame(parity)
+    else:
+        elapsed, kernel_ms = timed(parity)
+        kernel_split = r.kernel_ms_split_history(min(args.steps, 64))
+        warm_split = None
     avg_kernel_ms = max_over_ranks(sum(kernel_ms) / len(kernel_ms))
     is_po = wl == "c2_po"
     ordered_frames = bool(r.last_frame_tile_ordered()) if (is_lav2 or is_po) else False
+    if cold_headline:
+        ordered_frames = True  # (the warm frames above were; the latency figures below measure both)
     perturb_steps, at_iters, la_steps = float(st["perturb_steps"]), float(st["at_iterations"]), float(st["la_steps"])
     # HDRFloat<double> / <CudaDblflt> LAv2: the AT iterations the launch actually RAN (statistics word 5 of k_lav2_lit / k_lav2_2x32: the AT loop's cycle search
     # spares a pixel inside the set most of the iterations the limit asks of it -- same state, same count, same frame).  The
     # roofline prices executed work; at_iterations_per_launch stays what the reference's loop would run.
     at_iters_executed = float(st.get("careful_steps", 0)) if (wl in ("c4_hdr64", "c4_2x32") and st.get("careful_steps")) else at_iters
-    if wl == "c4_hdr64" and tile_order_on and st.get("scaled_steps"):
+    if wl == "c4_hdr64" and tile_order_on and not cold_headline and st.get("scaled_steps"):
         # the timed frames run PerformAT in a pass of its own, whose lanes are grouped by what each pixel needs by itself
         # (statistics word 6 of the counting launch, which iterates inside the frame's kernel and waits for the wave's slowest)
         at_iters_executed = float(st["scaled_steps"])
@@ -606,7 +699,7 @@ def main():
         # rows per host thread chosen per workload so that the sample is about 10 s of CPU work on the box's 16 threads (the
         # GPU part of the default run is ~2 s: a longer CPU leg hides it from a utilisation sampler); at N > 1 the same
         # check runs on rank 0 with one row per thread: the line of an N-GPU run carries its own parity verdict
-        per_thread = {"c3_lav2": 2, "c2_po": 1, "c5_bla": 12, "c4_hdr64": 24, "c4_2x32": 3, "c4_scaled": 2}[wl]
+        per_thread = {"c1_direct": 96, "c3_lav2": 2, "c2_po": 1, "c5_bla": 12, "c4_hdr64": 24, "c4_2x32": 3, "c4_scaled": 2}[wl]
         if distributed:
             per_thread = 1
         nrows = max(1, min(args.cpu_sample_rows if args.cpu_sample_rows > 0 else per_thread * threads, H))
@@ -632,7 +725,7 @@ def main():
 
         ref, cpu_t = cpu_run(0 if args.parity == "cpu" else 1)
         parity_rows_ok = all(np.array_equal(frame_main[y], ref[y]) for y in rows)
-        twin = {"c3_lav2": "Cpu32PerturbedBLAV2HDR", "c4_hdr64": "Cpu64PerturbedBLAV2HDR",
+        twin = {"c1_direct": "Cpu64 (CalcCpuHDR<uint32_t,double,double>)", "c3_lav2": "Cpu32PerturbedBLAV2HDR", "c4_hdr64": "Cpu64PerturbedBLAV2HDR",
                 "c2_po": "Cpu32PerturbedBLAHDR (single-step branch)",
                 "c5_bla": "Cpu32PerturbedBLAHDR"}.get(wl, "the CUDA kernel (no CPU twin exists)")
         if not distributed:  # (a reported baseline at N = 1 only; at N > 1 the rows are the line's parity check)
@@ -675,13 +768,15 @@ def main():
             # scaled kernel counters: [0] rescales, [1] full-precision (HDRFloat) steps, [2] binary32 steps; every step is
             # the 18-flop perturbation step of SURVEY 8(d)
             flops = (perturb_steps + la_steps) * FLOP_PER_STEP
+        elif is_direct:
+            flops = perturb_steps * FLOP_PER_DIRECT_ITERATION  # (the direct kernel counts its iterations in the step counter)
         elif wl == "c5_bla":
             # a BLA jump = dz' = A dz + B dc (two complex products, 6 flop each, + one complex sum, 2), z = Z + dz' (2),
             # |z|^2 (3), |dz'|^2 (3) = 22 flop; the kernel's la_steps counter holds the jumps
             flops = perturb_steps * FLOP_PER_STEP + la_steps * FLOP_PER_BLA_JUMP
         else:
             flops = perturb_steps * FLOP_PER_STEP
-        peak = PEAK_FP64_VECTOR_TFLOPS if (is64 and not is2x32) else PEAK_FP32_VECTOR_TFLOPS
+        peak = PEAK_FP64_VECTOR_TFLOPS if ((is64 and not is2x32) or is_direct) else PEAK_FP32_VECTOR_TFLOPS
         achieved = flops / (avg_kernel_ms * 1e-3) / 1e12
         roof = {"bound": "valu", "achieved": round(achieved, 4), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 5), "traffic": traffic}
@@ -699,7 +794,7 @@ def main():
             # prepared orbit once, the table once, the iteration buffer written once) / kernel time against 8 TB/s, with the
             # counter bytes beside it (`traffic`; traffic >> algorithmic = re-reads from L2 misses).  The vector-issue view
             # of the same launch is kept under "valu".
-            alg_bytes = orbit.count * 16 + sum(bla.sizes()) * 44 + rows_padded * rw * 4
+            alg_bytes = orbit.count * 16 + sum(bla.sizes()) * 44 + rows_padded * rw * 4  # (orbit + table + iteration buffer, once each)
             gbs = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": round(gbs, 3), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(gbs / PEAK_HBM_GBS, 6), "traffic": traffic, "algorithmic_bytes": alg_bytes,
@@ -714,19 +809,39 @@ def main():
             else "Mpix/s (iteration buffer), " + wl,
             "value": round(value, 4), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "2xf32+i32exp" if is2x32 else ("f64+i32exp" if is64 else "f32+i32exp"),
+            # a view's FIRST frame beside the sustained figure (frame_timing.latency_ms_cold: one frame, launch -> host, nothing
+            # overlapped, nothing recorded by an earlier frame); for the two workloads whose `value` is cold already, the warm
+            # sustained figure and its kernel time
+            "value_cold": (round(value, 4) if cold_headline else
+                           frame_timing["value_cold"] if frame_timing else None),
+            "value_warm": round(W * H * args.steps / elapsed_warm / 1e6, 4) if cold_headline else round(value, 4),
+            "kernel_ms_warm": (round(sum(kernel_ms_warm) / len(kernel_ms_warm), 3) if cold_headline else round(avg_kernel_ms, 3)),
+            "kernel_parts_ms_warm": ({"k_at_pass64": round(sum(warm_split[0]) / len(warm_split[0]), 3),
+                                      "k_lav2_lit<double>": round(sum(warm_split[1]) / len(warm_split[1]), 3)}
+                                     if cold_headline and wl == "c4_hdr64" and any(warm_split[0]) else None),
+            "vs_baseline": None,
+            "dtype": "2xf32+i32exp" if is2x32 else ("f64+i32exp" if is64 else ("f64" if is_direct else "f32+i32exp")),
             "data": "built-in view %d of the reference (deterministic: no dataset or randomness on this path)" % args.view,
             "window": "kernel launch -> iteration buffer in (page-locked) host memory, SURVEY.md 8(d); K frames back to back "
                       "(sustained, see frame_timing for the latency of one frame)",
             "config": {"workload": "view%d_%dx%d_%s" % (args.view, W, H, wl_tag),
-                       "parity": args.parity, "kernel_variant": args.variant or "tuned", "n_iterations": n_iter, "orbit_entries": orbit.count,
+                       "parity": args.parity, "kernel_variant": args.variant or "tuned", "n_iterations": n_iter,
+                       "orbit_entries": orbit.count if orbit is not None else 0,
+                       "host_path": ("one device" if not distributed else args.host_path),
+                       "frames": ("cold: every timed frame is the first frame of its view (fs_forget_tile_costs before each launch)"
+                                  if cold_headline else "warm: frames of one view back to back (value_cold = a view's first frame)"),
                        "la_records": la.count if la else 0, "la_stages": la.stage_count if la else 0,
                        "bla_levels": bla.num_levels if bla else 0, "tiling": "rows/8-row bands interleaved x%d" % world,
-                       "exchange": ("none" if not distributed else "gloo gather through host memory (functional path)" if host_staged
+                       "exchange": ("none" if not distributed else
+                                    "none on the data path: every rank copies its bands to the shared host frame over its own PCIe link"
+                                    if direct_path else "gloo gather through host memory (functional path)" if host_staged
                                     else "RCCL gather to rank 0 on the device"),
                        "host_input_build_s": round(t_inputs, 3), "la_build_on_device_ms": la_device_ms},
             "roofline": {**roof,
                          "kernel": wl_kernel, "kernel_ms": round(avg_kernel_ms, 3),
+                         "kernel_parts_ms": ({"k_at_pass64": round(sum(kernel_split[0]) / len(kernel_split[0]), 3),
+                                              "k_lav2_lit<double>": round(sum(kernel_split[1]) / len(kernel_split[1]), 3)}
+                                             if wl == "c4_hdr64" and any(kernel_split[0]) else None),
                          "pixel_steps_per_launch": perturb_steps, "at_iterations_per_launch": at_iters,
                          "la_steps_per_launch": la_steps, "flop_per_pixel_step": FLOP_PER_STEP,
                          "careful_step_fraction_rank0": round(st.get("careful_steps", 0) / max(1.0, perturb_steps), 5)
@@ -747,6 +862,16 @@ def main():
             "device_resident_mpix_s": round(W * H / avg_kernel_ms / 1e3, 4),
         }
         result_line = json.dumps(out)
+    if direct_path:
+        torch.cuda.synchronize()
+        dist.barrier()
+        lib.fs_host_unregister(shm_maps.ctypes.data)
+        host_np = host_ptr = flags = None
+        if rank == 0:
+            try:
+                os.unlink(shm_files[0])
+            except OSError:
+                pass
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

@@ -68,7 +68,7 @@ def _render_units():
 
 def _render_headers():
     return sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hpp")) +
-                  [os.path.join(ROOT, "include", f) for f in ("fsmi355.h", "fs_layout.h")])
+                  [os.path.join(ROOT, "include", f) for f in ("fsmi355.h", "fsmi355_internal.h", "fs_layout.h")])
 
 
 def _render_flags():

@@ -129,6 +129,7 @@ def render_lib():
     _decl(lib, "fs_last_kernel_ms", C.c_float, [vp])
     _decl(lib, "fs_set_kernel_variant", u32, [vp, C.c_int])
     _decl(lib, "fs_kernel_ms_history", u32, [vp, vp, u32])
+    _decl(lib, "fs_kernel_ms_split_history", u32, [vp, vp, vp, u32])
     _decl(lib, "fs_forget_tile_costs", u32, [vp])
     _decl(lib, "fs_last_frame_tile_ordered", C.c_int, [vp])
     _decl(lib, "fs_read_tile_costs", u32, [vp, vp, u64, vp])
@@ -169,6 +170,11 @@ def render_lib():
     _decl(lib, "fs_group_wait_current", u32, [vp, u32])
     _decl(lib, "fs_group_gather_ms", C.c_float, [vp])
     _decl(lib, "fs_group_plan", None, [u32, u32, u32, u32, vp, vp, vp])
+    _decl(lib, "fs_group_set_host_path", u32, [vp, C.c_int])
+    _decl(lib, "fs_group_host_path", C.c_int, [vp])
+    _decl(lib, "fs_copy_bands_to_host", u32, [vp, vp, vp, vp])
+    _decl(lib, "fs_host_register", u32, [vp, u64])
+    _decl(lib, "fs_host_unregister", u32, [vp])
     _render = lib
     return lib
 
@@ -180,14 +186,14 @@ RENDER_SYMBOLS = [
     "fs_render_scaled", "fs_build_bla", "fs_bla_num_levels", "fs_bla_lm2", "fs_bla_level_size", "fs_read_bla_level",
     "fs_render_direct_lp", "fs_clear",
     "fs_render_current", "fs_sync_compute", "fs_compute_stream", "fs_sync_display", "fs_query_compute", "fs_enqueue_done_callback",
-    "fs_host_fallback_bytes", "fs_idle_device_bytes", "fs_release_idle_device_memory", "fs_set_compressed_orbit_mode", "fs_orbit_device_bytes", "fs_get_width", "fs_get_height", "fs_last_kernel_ms", "fs_set_kernel_variant", "fs_kernel_ms_history", "fs_forget_tile_costs", "fs_last_frame_tile_ordered", "fs_read_tile_costs", "fs_read_tile_order", "fs_seq_cursor_probe", "fs_enable_step_count", "fs_read_step_count",
+    "fs_host_fallback_bytes", "fs_idle_device_bytes", "fs_release_idle_device_memory", "fs_set_compressed_orbit_mode", "fs_orbit_device_bytes", "fs_get_width", "fs_get_height", "fs_last_kernel_ms", "fs_set_kernel_variant", "fs_kernel_ms_history", "fs_kernel_ms_split_history", "fs_forget_tile_costs", "fs_last_frame_tile_ordered", "fs_read_tile_costs", "fs_read_tile_order", "fs_seq_cursor_probe", "fs_enable_step_count", "fs_read_step_count",
     "fs_time_render_current", "fs_read_stats_raw", "fs_test_block_threshold", "fs_build_la", "fs_build_la_mt", "fs_la_counts", "fs_read_la",
     "fs_group_create", "fs_group_destroy", "fs_group_size", "fs_group_transport", "fs_group_renderer", "fs_group_init_memory",
     "fs_group_upload_orbit", "fs_group_upload_orbit_compressed", "fs_group_upload_la", "fs_group_upload_bla",
     "fs_group_upload_orbit_scaled", "fs_group_render_lav2", "fs_group_render_bla", "fs_group_render_scaled",
     "fs_group_render_direct", "fs_group_clear", "fs_group_render_current", "fs_group_render_current_colors", "fs_group_sync_display", "fs_display_stream", "fs_colorize_frame",
     "fs_color_buffer_elements", "fs_group_sync", "fs_group_wait_current", "fs_group_gather_ms",
-    "fs_group_plan",
+    "fs_group_plan", "fs_group_set_host_path", "fs_group_host_path", "fs_copy_bands_to_host", "fs_host_register", "fs_host_unregister",
 ]
 
 

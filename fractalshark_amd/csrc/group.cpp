@@ -25,7 +25,7 @@
 #include <new>
 #include <vector>
 
-#include "../../include/fsmi355.h"
+#include "../../include/fsmi355_internal.h"
 #include "kernels.h"
 
 namespace {
@@ -81,8 +81,16 @@ struct fs_group {
     std::vector<int> devices;
     std::vector<fs_renderer *> members;
     std::vector<void *> comms;     // ncclComm_t per member (RCCL transport)
-    std::vector<void *> slices;    // per member: its slice buffer on its own device (external iteration buffer)
+    // per member r >= 1: its slice buffers on its own device (the external iteration buffer of the frame in set b is
+    // slices[b][r]; member 0 renders straight into gather slot 0 of the set).  Two, in rotation with the sets: under the direct host
+    // path a slice is still being copied to the host over the member's own link while the member renders its next frame.
+    std::vector<void *> slices[2];
     int transport = 0;
+    int host_path = 0;                      // 0 = whole frame through device 0 (gather), 1 = every member copies its own bands
+    std::vector<hipStream_t> copy_streams;  // direct host path: one per member, on its device
+    std::vector<hipEvent_t> ev_kernel;      // per member: its kernel of the frame being delivered has finished
+    std::vector<hipEvent_t> ev_copied[2];   // per set, per member: its bands of the set's frame are in the caller's host buffer
+    std::vector<char> copied_recorded[2];
     uint32_t width = 0, height = 0, band = 8, iter_bytes = 4, rounded_width = 0, max_rows = 0;
     // Two frames can be in flight: while frame k is received, put in row order, reduced and copied to the
     // host on device 0's POST stream, the members render frame k+1.  Everything frame k's post-processing reads or writes
@@ -175,12 +183,18 @@ static void group_free_buffers(fs_group *g)
     if (g->prog_gathered) // a progressive snapshot may still be copying out of the slices on the display streams
         for (fs_renderer *m : g->members)
             (void)fs_sync_display(m);
-    for (size_t i = 0; i < g->slices.size(); i++)
-        if (g->slices[i] && hipSetDevice(g->devices[i]) == hipSuccess) {
-            (void)fs_set_external_iter_buffer(g->members[i], nullptr, 0);
-            (void)hipFree(g->slices[i]);
-        }
-    g->slices.clear();
+    for (size_t i = 0; i < g->copy_streams.size(); i++) // (a direct copy may still be reading a slice)
+        if (g->copy_streams[i] && hipSetDevice(g->devices[i]) == hipSuccess)
+            (void)hipStreamSynchronize(g->copy_streams[i]);
+    for (int b = 0; b < 2; b++) {
+        for (size_t i = 0; i < g->slices[b].size(); i++)
+            if (g->slices[b][i] && hipSetDevice(g->devices[i]) == hipSuccess) {
+                (void)fs_set_external_iter_buffer(g->members[i], nullptr, 0);
+                (void)hipFree(g->slices[b][i]);
+            }
+        g->slices[b].clear();
+        std::fill(g->copied_recorded[b].begin(), g->copied_recorded[b].end(), 0);
+    }
     // member 0 renders straight into its gather slot (no slice of its own): detach it before that memory goes away
     if (g->gathered[0] && !g->members.empty())
         (void)fs_set_external_iter_buffer(g->members[0], nullptr, 0);
@@ -233,6 +247,16 @@ void fs_group_destroy(fs_group *g)
     }
     if (g->post && !g->devices.empty() && hipSetDevice(g->devices[0]) == hipSuccess)
         (void)hipStreamDestroy(g->post);
+    for (size_t i = 0; i < g->copy_streams.size(); i++)
+        if (hipSetDevice(g->devices[i]) == hipSuccess) {
+            if (g->copy_streams[i])
+                (void)hipStreamDestroy(g->copy_streams[i]);
+            if (i < g->ev_kernel.size() && g->ev_kernel[i])
+                (void)hipEventDestroy(g->ev_kernel[i]);
+            for (int b = 0; b < 2; b++)
+                if (i < g->ev_copied[b].size() && g->ev_copied[b][i])
+                    (void)hipEventDestroy(g->ev_copied[b][i]);
+        }
     for (void *c : g->comms)
         if (c)
             rccl().CommDestroy(c);
@@ -302,16 +326,21 @@ uint32_t fs_group_init_memory(fs_group *g, uint32_t w, uint32_t h, uint32_t anti
     }
     g->cur = 0;
     // every member renders into a slice buffer of the common (padded) size; member 0 straight into its gather slot
-    g->slices.assign(world, nullptr);
+    for (int b = 0; b < 2; b++) {
+        g->slices[b].assign(world, nullptr);
+        g->copied_recorded[b].assign(world, 0);
+    }
     for (uint32_t r = 0; r < world; r++) {
         void *buf = nullptr;
         if (r == 0) {
             buf = g->gathered[0];
         } else {
             FSG_TRY(hipSetDevice(g->devices[r]));
-            FSG_TRY(hipMalloc(&buf, sb));
-            FSG_TRY(hipMemset(buf, 0, sb));
-            g->slices[r] = buf;
+            for (int b = 1; b >= 0; b--) {
+                FSG_TRY(hipMalloc(&buf, sb));
+                FSG_TRY(hipMemset(buf, 0, sb));
+                g->slices[b][r] = buf;
+            }
         }
         FSG_TRY(fs_set_external_iter_buffer(g->members[r], buf, sb));
     }
@@ -456,7 +485,7 @@ static uint32_t group_current_progressive(fs_group *g, uint64_t n_iterations, vo
     for (uint32_t r = 1; r < world; r++) {
         hipStream_t dr = (hipStream_t)fs_display_stream(g->members[r]);
         FSG_TRY(hipSetDevice(g->devices[r]));
-        FSG_TRY(hipMemcpyPeerAsync((char *)g->prog_gathered + sb * r, g->devices[0], g->slices[r], g->devices[r], sb, dr));
+        FSG_TRY(hipMemcpyPeerAsync((char *)g->prog_gathered + sb * r, g->devices[0], g->slices[g->cur][r], g->devices[r], sb, dr));
         hipEvent_t done;
         FSG_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
         FSG_TRY(hipEventRecord(done, dr));
@@ -494,6 +523,52 @@ uint32_t fs_group_render_current(fs_group *g, uint64_t n_iterations, void *iter_
     return fs_group_render_current_colors(g, n_iterations, iter_buffer, nullptr, reduction, 0);
 }
 
+// The direct host path (round 6).  The gather funnels the whole frame through device 0 and its ONE PCIe link -- 531 MB = 9.5 ms per
+// frame at BASELINE's 8-GPU configuration against a 5.9-ms kernel per member.  Here every member copies its own bands straight to
+// their rows of the caller's frame over its OWN link (fs_copy_bands_to_host: one 2-D copy, destination pitch = band stride), on a copy
+// stream of its own behind its kernel, while it already renders the next frame into its other slice.  What still needs the frame
+// on one device -- colours, min / max / sum -- keeps the gather (66 MB of Color16 instead of 531 MB of counts at that configuration).
+static uint32_t group_direct_copies(fs_group *g, int b, void *iter_buffer, hipStream_t p0)
+{
+    const uint32_t world = (uint32_t)g->members.size();
+    if (g->copy_streams.size() != world) { // first use: one copy stream and three events per member, on its device
+        g->copy_streams.assign(world, nullptr);
+        g->ev_kernel.assign(world, nullptr);
+        for (int k = 0; k < 2; k++)
+            g->ev_copied[k].assign(world, nullptr);
+        for (uint32_t r = 0; r < world; r++) {
+            FSG_TRY(hipSetDevice(g->devices[r]));
+            FSG_TRY(hipStreamCreateWithFlags(&g->copy_streams[r], hipStreamNonBlocking));
+            FSG_TRY(hipEventCreateWithFlags(&g->ev_kernel[r], hipEventDisableTiming));
+            for (int k = 0; k < 2; k++)
+                FSG_TRY(hipEventCreateWithFlags(&g->ev_copied[k][r], hipEventDisableTiming));
+        }
+    }
+    for (uint32_t r = 0; r < world; r++) {
+        const void *src = r == 0 ? g->gathered[b] : g->slices[b][r];
+        FSG_TRY(hipSetDevice(g->devices[r]));
+        FSG_TRY(hipEventRecord(g->ev_kernel[r], (hipStream_t)fs_compute_stream(g->members[r])));
+        FSG_TRY(hipStreamWaitEvent(g->copy_streams[r], g->ev_kernel[r], 0));
+        FSG_TRY(fs_copy_bands_to_host(g->members[r], src, iter_buffer, g->copy_streams[r]));
+        FSG_TRY(hipEventRecord(g->ev_copied[b][r], g->copy_streams[r]));
+        g->copied_recorded[b][r] = 1;
+    }
+    // "the frame is in the caller's buffer" (ev_done) = every member's copy has landed: the post stream collects them
+    FSG_TRY(hipSetDevice(g->devices[0]));
+    for (uint32_t r = 0; r < world; r++)
+        FSG_TRY(hipStreamWaitEvent(p0, g->ev_copied[b][r], 0));
+    return 0;
+}
+
+uint32_t fs_group_set_host_path(fs_group *g, int host_path)
+{
+    if (host_path != 0 && host_path != 1)
+        return (uint32_t)hipErrorInvalidValue;
+    g->host_path = host_path;
+    return 0;
+}
+int fs_group_host_path(const fs_group *g) { return g->host_path; }
+
 uint32_t fs_group_render_current_colors(fs_group *g, uint64_t n_iterations, void *iter_buffer, fs_color16 *color_buffer,
                                         fs_reduction *reduction, int progressive)
 {
@@ -508,12 +583,17 @@ uint32_t fs_group_render_current_colors(fs_group *g, uint64_t n_iterations, void
     void *const frame = g->frame[b];
     hipStream_t s0 = (hipStream_t)fs_compute_stream(g->members[0]);
     hipStream_t p0 = g->post;
+    const bool direct = g->host_path == 1 && iter_buffer != nullptr;
+    // under the direct path the frame is only brought together on device 0 when something needs it there
+    const bool need_gather = !direct || color_buffer != nullptr || reduction != nullptr;
     FSG_TRY(hipSetDevice(g->devices[0]));
     // member 0's slice is in slot 0 once its kernel has finished
     FSG_TRY(hipEventRecord(g->ev_rendered[b], s0));
     FSG_TRY(hipStreamWaitEvent(p0, g->ev_rendered[b], 0));
     FSG_TRY(hipEventRecord(g->ev_a, p0));
-    if (world > 1 && g->transport == 0) {
+    if (direct)
+        FSG_TRY(group_direct_copies(g, b, iter_buffer, p0));
+    if (need_gather && world > 1 && g->transport == 0) {
         Rccl &q = rccl();
         if (q.GroupStart() != 0)
             return FS_ERR_7;
@@ -523,11 +603,11 @@ uint32_t fs_group_render_current_colors(fs_group *g, uint64_t n_iterations, void
             // rank 0 receives slice r on the post stream -- behind the k_gather_rows that last read this set's slots (same
             // stream), so a slot is never overwritten while it is still being read; rank r sends behind ITS kernel
             ok = q.Recv((char *)gathered + sb * r, sb, kNcclUint8, (int)r, g->comms[0], p0) == 0 &&
-                 q.Send(g->slices[r], sb, kNcclUint8, 0, g->comms[r], (hipStream_t)fs_compute_stream(g->members[r])) == 0;
+                 q.Send(g->slices[b][r], sb, kNcclUint8, 0, g->comms[r], (hipStream_t)fs_compute_stream(g->members[r])) == 0;
         }
         if (q.GroupEnd() != 0 || !ok)
             return FS_ERR_7;
-    } else if (world > 1) {
+    } else if (need_gather && world > 1) {
         for (uint32_t r = 1; r < world; r++) {
             // the copy runs on the SENDER's stream (ordered behind its kernel); the post stream then waits for it on the
             // device.  The copy writes gather slot r of this set, which the k_gather_rows of the frame that used the set
@@ -536,7 +616,7 @@ uint32_t fs_group_render_current_colors(fs_group *g, uint64_t n_iterations, void
             hipStream_t sr = (hipStream_t)fs_compute_stream(g->members[r]);
             FSG_TRY(hipSetDevice(g->devices[r]));
             FSG_TRY(hipStreamWaitEvent(sr, g->ev_consumed[b], 0));
-            FSG_TRY(hipMemcpyPeerAsync((char *)gathered + sb * r, g->devices[0], g->slices[r], g->devices[r], sb, sr));
+            FSG_TRY(hipMemcpyPeerAsync((char *)gathered + sb * r, g->devices[0], g->slices[b][r], g->devices[r], sb, sr));
             hipEvent_t done;
             FSG_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
             FSG_TRY(hipEventRecord(done, sr));
@@ -546,8 +626,10 @@ uint32_t fs_group_render_current_colors(fs_group *g, uint64_t n_iterations, void
         }
     }
     FSG_TRY(hipSetDevice(g->devices[0]));
-    fsk_gather_rows(gathered, frame, g->index, g->rounded_width * g->iter_bytes, g->height, p0);
-    FSG_TRY(hipGetLastError());
+    if (need_gather) {
+        fsk_gather_rows(gathered, frame, g->index, g->rounded_width * g->iter_bytes, g->height, p0);
+        FSG_TRY(hipGetLastError());
+    }
     FSG_TRY(hipEventRecord(g->ev_consumed[b], p0)); // this set's gather slots may be written again
     FSG_TRY(hipEventRecord(g->ev_b, p0));
     // colours of the whole frame (antialias + palette) on device 0, behind the row order: member 0 holds the palette and the
@@ -561,17 +643,26 @@ uint32_t fs_group_render_current_colors(fs_group *g, uint64_t n_iterations, void
         FSG_TRY(hipGetLastError());
         FSG_TRY(hipMemcpyAsync(reduction, g->reduction, sizeof(fs_reduction), hipMemcpyDefault, p0));
     }
-    if (iter_buffer) {
+    if (iter_buffer && !direct) {
         const size_t frame_rows = ((size_t)g->height + 7u) / 8u * 8u;
         FSG_TRY(hipMemcpyAsync(iter_buffer, frame, frame_rows * g->rounded_width * g->iter_bytes, hipMemcpyDefault, p0));
     }
     FSG_TRY(hipEventRecord(g->ev_done[b], p0));
     g->frames_posted++;
     // the next frame lands in the other set: member 0 renders into ITS slot 0 -- once the frame that used that set last has
-    // been put in row order (its gather slots are free then)
+    // been put in row order (its gather slots are free then) -- and every other member into its other slice -- once the direct
+    // copy of the frame that used it last has left it (a gather reads a slice on the member's own compute stream: in order)
     g->cur = (b + 1) % fs_group::kSets;
     FSG_TRY(hipStreamWaitEvent(s0, g->ev_consumed[g->cur], 0));
+    if (!g->copied_recorded[g->cur].empty() && g->copied_recorded[g->cur][0])
+        FSG_TRY(hipStreamWaitEvent(s0, g->ev_copied[g->cur][0], 0));
     FSG_TRY(fs_set_external_iter_buffer(g->members[0], g->gathered[g->cur], sb));
+    for (uint32_t r = 1; r < world; r++) {
+        FSG_TRY(hipSetDevice(g->devices[r]));
+        if (g->copied_recorded[g->cur][r])
+            FSG_TRY(hipStreamWaitEvent((hipStream_t)fs_compute_stream(g->members[r]), g->ev_copied[g->cur][r], 0));
+        FSG_TRY(fs_set_external_iter_buffer(g->members[r], g->slices[g->cur][r], sb));
+    }
     return 0;
 }
 

@@ -16,7 +16,7 @@
 #include <new>
 #include <vector>
 
-#include "../../include/fsmi355.h"
+#include "../../include/fsmi355_internal.h"
 #include "kernels.h"
 #include "la_math.hpp"
 
@@ -35,6 +35,10 @@ struct fs_renderer {
     // fs_kernel_ms_history the last few (frames that are in flight together, e.g. a pipelined bench loop, each keep theirs)
     static constexpr uint32_t kTimingRing = 64;
     hipEvent_t ev_start[kTimingRing] = {}, ev_stop[kTimingRing] = {};
+    // a frame made of two kernels (HDRFloat<double> LAv2: the AT pass, then the frame's kernel) also records where the first one
+    // ended (fs_kernel_ms_split_history); created on first use
+    hipEvent_t ev_mid[kTimingRing] = {};
+    bool mid_valid[kTimingRing] = {};
     uint64_t timed_launches = 0; // launches recorded so far; launch i uses pair i % kTimingRing
 
     // geometry
@@ -88,7 +92,7 @@ struct fs_renderer {
     FsAtRes *at_res = nullptr;
     uint32_t *at_cost = nullptr, *at_order = nullptr;
     size_t at_cap = 0;
-    bool at_order_valid = false;
+    bool at_order_valid = false; // ... for at_key (set where at_order is built: the order is a permutation of THAT key's buffer)
     uint32_t *pix_cost = nullptr; // per-pixel cost the unordered frame of a view records; what the order is sorted by
     size_t pix_cost_cap = 0;
     uint32_t *pix_order = nullptr, *pix_work = nullptr;
@@ -102,7 +106,8 @@ struct fs_renderer {
         uint64_t orbit_gen, orbit_epoch, n_iterations;
         unsigned char coords[64];
         bool operator==(const PixKey &o) const { return memcmp(this, &o, sizeof(*this)) == 0; }
-    } pix_key{}, pix_seen_key{};
+    } pix_key{}, pix_seen_key{}, at_key{};
+    bool lav2_last_ordered = false; // the last launch was an HDRFloat<float> frame in its recorded TILE order (fs_read_tile_order)
     bool last_launch_wide = false;   // the last render launched a 64-bit counting kernel: those carry no step counters
     bool stats_on = false;
     int variant = FS_VARIANT_TUNED;
@@ -765,10 +770,25 @@ struct TimedLaunch {
     fs_renderer *r;
     explicit TimedLaunch(fs_renderer *rr) : r(rr)
     {
-        if (r->ev_start[0])
+        if (r->ev_start[0]) {
             hipEventRecord(r->ev_start[r->timed_launches % fs_renderer::kTimingRing], r->compute);
+            r->mid_valid[r->timed_launches % fs_renderer::kTimingRing] = false;
+        }
         if (r->stats_on && r->stats)
             hipMemsetAsync(r->stats, 0, (r->stats_words == 32 ? 32 : 8) * sizeof(uint64_t), r->compute);
+    }
+    void mid() // between the two kernels of a two-kernel frame
+    {
+        if (!r->ev_start[0])
+            return;
+        const uint32_t i = (uint32_t)(r->timed_launches % fs_renderer::kTimingRing);
+        if (!r->ev_mid[i] && hipEventCreate(&r->ev_mid[i]) != hipSuccess) {
+            (void)hipGetLastError();
+            r->ev_mid[i] = nullptr;
+            return;
+        }
+        if (hipEventRecord(r->ev_mid[i], r->compute) == hipSuccess)
+            r->mid_valid[i] = true;
     }
     ~TimedLaunch()
     {
@@ -879,6 +899,8 @@ void fs_destroy(fs_renderer *r)
                 hipEventDestroy(r->ev_start[i]);
             if (r->ev_stop[i])
                 hipEventDestroy(r->ev_stop[i]);
+            if (r->ev_mid[i])
+                hipEventDestroy(r->ev_mid[i]);
         }
         if (r->compute)
             hipStreamDestroy(r->compute);
@@ -1083,6 +1105,48 @@ uint32_t fs_set_external_iter_buffer(fs_renderer *r, void *device_ptr, uint64_t 
 }
 
 void *fs_device_iter_buffer(const fs_renderer *r) { return r->iters(); }
+
+// The renderer's bands -> their rows of a WHOLE-FRAME host buffer, over THIS device's own PCIe link (round 6; the sharded
+// read-back of the row-tiled frame: GPURenderer::ExtractItersAndColors, GPU_Render.cu:1760-1805, copies N_cu counts per frame
+// through one device).  The local buffer holds the owned bands back to back and band k belongs at frame row
+// band_first + k * band_stride: ONE two-dimensional copy whose "row" is a whole band (band_rows x pitch bytes) and whose
+// destination pitch is the band stride, so the rows land in frame order and nothing has to restore it; a last, shorter band
+// goes by itself.
+uint32_t fs_copy_bands_to_host(fs_renderer *r, const void *device_iters, void *host_frame, void *stream)
+{
+    if (uint32_t e = use_device(r))
+        return e;
+    if (!r->memory_initialized() || !host_frame)
+        return host_frame ? 0u : (uint32_t)hipErrorInvalidValue;
+    if (r->local_rows == 0)
+        return 0;
+    const char *src = (const char *)(device_iters ? device_iters : r->iters());
+    hipStream_t s = stream ? (hipStream_t)stream : r->compute;
+    const size_t pitch = (size_t)r->w_block * 16u * r->iter_bytes;
+    const uint64_t H = r->height, first = r->band_first, rows = r->band_rows, stride = r->band_stride;
+    uint64_t full = 0; // bands that lie wholly inside the frame
+    if (first + rows <= H)
+        full = (H - rows - first) / stride + 1u;
+    char *dst = (char *)host_frame + first * pitch;
+    if (full == 1u || (full > 1u && stride == rows)) {
+        FS_TRY(hipMemcpyAsync(dst, src, full * rows * pitch, hipMemcpyDeviceToHost, s));
+    } else if (full > 1u) {
+        FS_TRY(hipMemcpy2DAsync(dst, stride * pitch, src, rows * pitch, rows * pitch, full, hipMemcpyDeviceToHost, s));
+    }
+    const uint64_t tail_start = first + full * stride;
+    if (tail_start < H) { // the last band is cut by the frame's edge
+        const uint64_t tail_rows = (tail_start + rows < H ? tail_start + rows : H) - tail_start;
+        FS_TRY(hipMemcpyAsync((char *)host_frame + tail_start * pitch, src + full * rows * pitch, tail_rows * pitch,
+                              hipMemcpyDeviceToHost, s));
+    }
+    return 0;
+}
+
+uint32_t fs_host_register(void *host_ptr, uint64_t bytes)
+{
+    return (uint32_t)hipHostRegister(host_ptr, (size_t)bytes, hipHostRegisterPortable);
+}
+uint32_t fs_host_unregister(void *host_ptr) { return (uint32_t)hipHostUnregister(host_ptr); }
 uint32_t fs_rounded_width(const fs_renderer *r) { return r->w_block * 16u; }
 
 // FNV-1a over the size, the period and up to 4096 evenly spread 8-byte words of an orbit's entries (never 0)
@@ -2247,6 +2311,8 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
         return 0; // GPU_Render.cu:1007-1009
     if (r->local_rows == 0)
         return 0; // this renderer owns no row of the frame (a rank beyond the last band)
+    r->last_frame_ordered = false; // (every path below that uses a recorded order says so itself)
+    r->lav2_last_ordered = false;
     const bool plain = type_tag == FS_T_F32 || type_tag == FS_T_F64 || type_tag == FS_T_2X32;
     // iteration caps of 2^32 and above need IterType = uint64_t (an 8-byte buffer): every type then runs an instantiation
     // of its kernel that counts in 64 bits (the literal one for HDRFloat<float|double>)
@@ -2464,6 +2530,7 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
         if (A.tile_order) {
             fsk_tile_order_by_cost(r->lav2_cost, n_tiles, r->lav2_sort_tmp, r->lav2_order, n_slots, r->compute);
             r->last_frame_ordered = true;
+            r->lav2_last_ordered = true;
         }
         TimedLaunch t(r);
         fsk_lav2_hdr32(A, kmode, r->stats_on, r->variant, r->compute);
@@ -2479,10 +2546,14 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
         // first frame): the AT loop reads no memory, so its waves can be made of pixels from anywhere -- equal work per wave --
         // while the frame's kernel keeps the order that keeps neighbours together (below).
         static const bool at_split_off = [] { const char *e = getenv("FSMI355_AT_IN_KERNEL"); return e && e[0] == '1'; }();
+        // (A/B: FSMI355_AT_SPLIT_COLD=0 keeps round 5's first frame of a view -- ONE kernel that iterates PerformAT itself)
+        static const bool at_split_cold = [] { const char *e = getenv("FSMI355_AT_SPLIT_COLD"); return !(e && e[0] == '0'); }();
         const bool second = A.pixel_order == nullptr && pix_second_sighting(r, A.frame, pk);
+        // Round 6: the pass of its own in EVERY frame, the first of a view included -- it needs no order to exist (natural order,
+        // nothing recorded), its waves hold 64 pixels of one 8 x 8 tile, and the frame's kernel behind it no longer waits for the
+        // slowest AT lane of each wave before its LA stages begin.
         bool at_split = !at_split_off && mode != FS_LAV2_PO && A.use_at && A.la_valid && pix_order_wanted(r, A.frame) &&
-                        (A.pixel_order != nullptr || second); // (a view's first frame: one kernel, nothing recorded)
-        const bool at_warm = at_split && A.pixel_order != nullptr && r->at_order_valid; // (the two orders share their key)
+                        (at_split_cold || A.pixel_order != nullptr || second);
         if (at_split) {
             const size_t n = (size_t)A.frame.rounded_width * ((A.frame.local_rows + 7u) & ~7u);
             if (r->at_cap < n) {
@@ -2508,6 +2579,10 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
                 }
             }
         }
+        // (the AT order has a key of its own: it is a permutation of the buffer it was recorded on, and pix_order can be rebuilt
+        // -- other row bands, a table without AT in between -- without it)
+        const bool at_warm = at_split && r->at_order_valid && r->at_key == pk;
+        const bool at_record = at_split && !at_warm && (second || A.pixel_order != nullptr);
         // (sorted by COUNT, not by a recorded cost as the 2x32 frames are: this kernel's steps are cheap enough for the loads of
         // a wave whose lanes are scattered over the frame to cost more than the idle lanes they save -- 81 ms with the cost as
         // the key, 68 with its binades, 53 with the counts, which keep the pixels inside the set side by side: DESIGN.md 7)
@@ -2521,23 +2596,28 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
                     P.pixel_order = r->at_order;
                 } else {
                     P.pixel_order = nullptr;
-                    P.at_cost = r->at_cost;
-                    FS_TRY(hipMemsetAsync(r->at_cost, 0, (size_t)n * sizeof(uint32_t), r->compute));
+                    if (at_record) { // (a view's first frame records nothing: a viewer that zooms never uses it)
+                        P.at_cost = r->at_cost;
+                        FS_TRY(hipMemsetAsync(r->at_cost, 0, (size_t)n * sizeof(uint32_t), r->compute));
+                    }
                     r->at_order_valid = false;
                 }
                 fsk_at_pass64(P, r->compute);
+                t.mid();
                 A.at_res = r->at_res;
             }
             fsk_lav2_hdr64(A, kmode, r->stats_on, r->compute);
         }
         if (second)
             pix_order_after(r, A.frame, pk, false);
-        if (at_split && !at_warm && r->pix_valid && r->pix_work && r->pix_temp) {
+        const uint32_t n_buf = A.frame.rounded_width * ((A.frame.local_rows + 7u) & ~7u);
+        if (at_split && at_record && r->pix_valid && r->pix_work && r->pix_temp && r->pix_cap >= n_buf) {
             // the AT pass's own order, from the costs it has just recorded (the sort's work memory is the pixel order's)
-            const uint32_t n = A.frame.rounded_width * ((A.frame.local_rows + 7u) & ~7u);
-            if (fsk_pixel_order_build(r->at_cost, n, r->pix_work, r->at_order, r->pix_temp, r->pix_temp_bytes, r->compute) == hipSuccess)
+            const uint32_t n = n_buf;
+            if (fsk_pixel_order_build(r->at_cost, n, r->pix_work, r->at_order, r->pix_temp, r->pix_temp_bytes, r->compute) == hipSuccess) {
                 r->at_order_valid = true;
-            else
+                r->at_key = pk;
+            } else
                 (void)hipGetLastError();
         }
     }
@@ -3136,6 +3216,23 @@ uint32_t fs_kernel_ms_history(const fs_renderer *r, float *ms_out, uint32_t n)
     return 0;
 }
 
+uint32_t fs_kernel_ms_split_history(const fs_renderer *r, float *first_ms, float *second_ms, uint32_t n)
+{
+    if (n > fs_renderer::kTimingRing || n > r->timed_launches)
+        return (uint32_t)hipErrorInvalidValue;
+    for (uint32_t k = 0; k < n; k++) {
+        const uint32_t i = (uint32_t)((r->timed_launches - n + k) % fs_renderer::kTimingRing);
+        if (r->mid_valid[i] && r->ev_mid[i]) {
+            FS_TRY(hipEventElapsedTime(&first_ms[k], r->ev_start[i], r->ev_mid[i]));
+            FS_TRY(hipEventElapsedTime(&second_ms[k], r->ev_mid[i], r->ev_stop[i]));
+        } else {
+            first_ms[k] = 0.0f;
+            FS_TRY(hipEventElapsedTime(&second_ms[k], r->ev_start[i], r->ev_stop[i]));
+        }
+    }
+    return 0;
+}
+
 uint32_t fs_set_kernel_variant(fs_renderer *r, int variant)
 {
     const int base = variant & FS_VARIANT_BASE_MASK, flags = variant & ~FS_VARIANT_BASE_MASK;
@@ -3202,7 +3299,7 @@ uint32_t fs_read_tile_order(fs_renderer *r, uint32_t *out, uint64_t max_words)
 {
     if (uint32_t e = use_device(r))
         return e;
-    if (!r->lav2_order || !r->last_frame_ordered)
+    if (!r->lav2_order || !r->lav2_last_ordered)
         return FS_ERR_6;
     const uint64_t n = (uint64_t)((r->lav2_cost_key.width + 7u) / 8u) * ((r->lav2_cost_key.local_rows + 7u) / 8u);
     const uint64_t m = n < max_words ? n : max_words;

@@ -85,6 +85,11 @@ class GPURenderer:
     def SetExternalIterBuffer(self, device_ptr, capacity_bytes=0):
         return self._lib.fs_set_external_iter_buffer(self._h, device_ptr, int(capacity_bytes))
 
+    def CopyBandsToHost(self, host_frame_ptr, device_iters=None, stream=None):
+        """fs_copy_bands_to_host: this renderer's row bands -> their rows of a whole-frame host buffer (raw pointer), over
+        this device's own PCIe link, asynchronously on `stream` (raw hipStream_t; None = the compute stream)."""
+        return self._lib.fs_copy_bands_to_host(self._h, device_iters, host_frame_ptr, stream)
+
     def GetWidth(self):
         return self._lib.fs_get_width(self._h)
 
@@ -341,6 +346,15 @@ class GPURenderer:
             raise RuntimeError("fs_kernel_ms_history: %s" % self.ConvertErrorToString(err))
         return [float(x) for x in out]
 
+    def kernel_ms_split_history(self, n):
+        """(first, second) kernel durations of the last n launches: a two-kernel frame (HDRFloat<double> LAv2: AT pass, then the
+        frame's kernel) split where the first ended; first = 0 for one-kernel frames."""
+        a, b = (C.c_float * int(n))(), (C.c_float * int(n))()
+        err = self._lib.fs_kernel_ms_split_history(self._h, a, b, int(n))
+        if err:
+            raise RuntimeError("fs_kernel_ms_split_history: %s" % self.ConvertErrorToString(err))
+        return [float(x) for x in a], [float(x) for x in b]
+
     def set_kernel_variant(self, literal=False, lds_orbit=False, refill=False, wide_counters=False,
                            natural_tile_order=False, bla_pool=False):
         """False / 0 (default): tuned loops; True / 1: literal transcription; 2: tuned loops without the scaled runs
@@ -485,6 +499,10 @@ class GPURendererGroup:
 
     def SyncDisplay(self):
         return self._lib.fs_group_sync_display(self._h)
+
+    def SetHostPath(self, direct):
+        """fs_group_set_host_path: False = gather through device 0, True = every member copies its own bands to the host."""
+        return self._lib.fs_group_set_host_path(self._h, 1 if direct else 0)
 
     def WaitCurrent(self, frames_back=0):
         """Host waits for the RenderCurrent issued `frames_back` calls ago (0 = latest, 1 = the one before): two frames may

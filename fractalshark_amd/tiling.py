@@ -85,3 +85,27 @@ def gather_frame(local, gathered, frame_index, rank, world):
     if rank != 0:
         return None
     return gathered.index_select(0, frame_index)
+
+
+def band_copy_plan(height, rank, world, band=8):
+    """The direct host path (round 6): the copies that take `rank`'s local buffer (its bands back to back) to their rows of a
+    whole-frame host buffer, as fs_copy_bands_to_host (csrc/renderer.cpp) issues them -- in ROWS:
+    {"dst_row", "dst_pitch_rows", "src_pitch_rows", "rows_per_band", "bands"} = ONE two-dimensional copy whose element is a whole
+    band (bands that lie wholly inside the frame), and {"tail_dst_row", "tail_src_row", "tail_rows"} = the last band when the
+    frame's edge cuts it (tail_rows = 0: none).  Pure host arithmetic (CPU tests; bench.py's ranks call the C function)."""
+    first, stride = rank * band, world * band
+    full = (height - band - first) // stride + 1 if first + band <= height else 0
+    tail_start = first + full * stride
+    tail_rows = max(0, min(tail_start + band, height) - tail_start) if tail_start < height else 0
+    return {"dst_row": first, "dst_pitch_rows": stride, "src_pitch_rows": band, "rows_per_band": band, "bands": full,
+            "tail_dst_row": tail_start, "tail_src_row": full * band, "tail_rows": tail_rows}
+
+
+def apply_band_copy_plan(local, frame, plan):
+    """numpy stand-in for the copy engine (tests): executes band_copy_plan on host arrays -- local [rows, W] -> frame [H, W]."""
+    for k in range(plan["bands"]):
+        d, s = plan["dst_row"] + k * plan["dst_pitch_rows"], k * plan["src_pitch_rows"]
+        frame[d:d + plan["rows_per_band"]] = local[s:s + plan["rows_per_band"]]
+    if plan["tail_rows"]:
+        frame[plan["tail_dst_row"]:plan["tail_dst_row"] + plan["tail_rows"]] = \
+            local[plan["tail_src_row"]:plan["tail_src_row"] + plan["tail_rows"]]

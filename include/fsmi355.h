@@ -13,6 +13,10 @@
  *   - "memory not initialised" makes render calls return 0 without doing anything (GPU_Render.cu:564-566).
  *
  * Record layouts: fs_layout.h.  Type tags select the numeric type T of the reference templates.
+ *
+ * This header is the whole interface a FractalShark maintainer binds: what gpu_render_shim.hpp forwards to, the device-side
+ * table builders, and the multi-GPU group.  Measurement hooks, A/B switches and test read-backs the library also exports
+ * (bench.py, tests/, tools/) are declared in fsmi355_internal.h and are not part of the drop-in boundary.
  */
 #ifndef FSMI355_H
 #define FSMI355_H
@@ -114,6 +118,19 @@ uint32_t fs_local_rows(const fs_renderer *r);
 uint32_t fs_set_external_iter_buffer(fs_renderer *r, void *device_ptr, uint64_t capacity_bytes);
 void *fs_device_iter_buffer(const fs_renderer *r);
 uint32_t fs_rounded_width(const fs_renderer *r);
+/* The sharded read-back of a row-tiled frame (this project's addition; the reference copies the whole iteration buffer through
+ * its one device, GPURenderer::ExtractItersAndColors, GPU_Render.cu:1760-1805): the renderer's owned bands go straight to THEIR
+ * rows of a whole-frame host buffer -- rows in frame order, row pitch = fs_rounded_width() x sizeof(IterType), (height padded to
+ * 8) rows -- over this device's own PCIe link: one two-dimensional copy whose destination pitch is the band stride, so nothing has
+ * to restore row order afterwards and no frame funnels through device 0.  device_iters = the buffer the frame was rendered into
+ * (NULL = the renderer's current iteration buffer); stream = a hipStream_t of this device (NULL = the compute stream: behind the
+ * kernel).  host_frame should be page-locked for every device that writes into it (hipHostMalloc with hipHostMallocPortable, or
+ * fs_host_register -- e.g. a POSIX shared-memory frame that several rank processes fill); pageable memory works, synchronously.
+ * Asynchronous.  Without row bands it is the plain copy of the whole padded buffer. */
+uint32_t fs_copy_bands_to_host(fs_renderer *r, const void *device_iters, void *host_frame, void *stream);
+/* hipHostRegister (portable: usable by every device of the process) / hipHostUnregister of caller-owned host memory. */
+uint32_t fs_host_register(void *host_ptr, uint64_t bytes);
+uint32_t fs_host_unregister(void *host_ptr);
 
 /* GPURenderer::InitializePerturb<IterType,T1,SubType,PExtras,T2> (GPU_Render.cu:431-501), split in two:
  * orbit upload (GPUPerturbSingleResults ctor, Perturb.cuh:20-80) ... */
@@ -164,12 +181,6 @@ uint32_t fs_upload_bla(fs_renderer *r, int type_tag, const void *const *levels, 
  * (fs_real_hdr32 / fs_real_hdr64, PerturbationResults::GetMaxRadius, Fractal.cpp:2739-2740).  Asynchronous on the compute
  * stream.  The reference rebuilds this table on the CPU and copies it over PCIe on every BLA render. */
 uint32_t fs_build_bla(fs_renderer *r, int type_tag, const void *bla_size);
-/* Table geometry / contents after fs_build_bla or fs_upload_bla (tests, tools): number of levels (m_B.size()), m_LM2,
- * records per level; fs_read_bla_level copies one level to the host (synchronises the compute stream). */
-int32_t fs_bla_num_levels(const fs_renderer *r);
-int32_t fs_bla_lm2(const fs_renderer *r);
-uint64_t fs_bla_level_size(const fs_renderer *r, int32_t level);
-uint32_t fs_read_bla_level(fs_renderer *r, int32_t level, void *out, uint64_t max_records);
 
 /* LAReference::GenerateApproximationData (FractalSharkLib/LAReference.cpp:971-1013: CreateLAFromOrbit :28-210,
  * CreateNewLAStage :774-966, CreateATFromLA :1050-1074) executed on the DEVICE instead of the host: builds the LAv2 table
@@ -182,7 +193,7 @@ uint32_t fs_read_bla_level(fs_renderer *r, int32_t level, void *out, uint64_t ma
  * LAReference.h:56) in which no period is found gets the reference's two records and a table that is not valid (:135-140,
  * :1002-1005; fs_la_counts reports is_valid 0 and the kernels ignore the table); one in which periods are found gets its
  * normal small table.  FS_ERR_UNSUPPORTED (use fs_upload_la): an orbit of fewer than three entries, a first step whose ZCoeff
- * is zero.  Synchronous.  fs_la_counts / fs_read_la read the installed table back (tests, tools). */
+ * is zero.  Synchronous.  (fs_la_counts / fs_read_la of fsmi355_internal.h read the installed table back: tests, tools.) */
 uint32_t fs_build_la(fs_renderer *r, int type_tag, const void *max_radius, int use_small_exponents);
 /* ... and with stage 0 as LAReference::CreateLAFromOrbitMT (LAReference.cpp:215-770) builds it on a host with `host_threads`
  * hardware threads (std::thread::hardware_concurrency(), :236-240): ThreadCount = min(maxRefIteration / 50000, host_threads)
@@ -193,8 +204,6 @@ uint32_t fs_build_la(fs_renderer *r, int type_tag, const void *max_radius, int u
  * fs_build_la.  The device computes next() for every state of the scan and the 2 (ThreadCount - 1) uncapped first detections;
  * the host walks the chains (indices only: 8 bytes per orbit entry come back once) and stitches; the device folds the records. */
 uint32_t fs_build_la_mt(fs_renderer *r, int type_tag, const void *max_radius, int use_small_exponents, int host_threads);
-uint32_t fs_la_counts(const fs_renderer *r, uint32_t *n_las, uint32_t *n_stages, int *use_at, int *is_valid);
-uint32_t fs_read_la(fs_renderer *r, void *las_out, uint32_t max_las, void *stages_out, uint32_t max_stages, void *at_out);
 
 /* GPURenderer::RenderPerturbLAv2<IterType,T,SubType,Mode,PExtras> (GPU_Render.cu:995-1188) for all six numeric types of
  * its instantiation list (:1204-1300): FS_T_HDR32 / FS_T_HDR64 / FS_T_HDR2X32 (GpuHDRx32 / x64 / x2x32 PerturbedLAv2*)
@@ -287,92 +296,6 @@ uint64_t fs_release_idle_device_memory(int device);
 uint32_t fs_get_width(const fs_renderer *r);
 uint32_t fs_get_height(const fs_renderer *r);
 
-/* Measurement hooks (this project's addition; bench.py / profiles).
- * fs_last_kernel_ms: duration of the most recent iteration-kernel launch measured with HIP events on the
- * compute stream (valid after fs_sync_compute).
- * fs_enable_step_count: when on, iteration kernels also accumulate the executed work per launch:
- * counts[0] = AT iterations, [1] = LA steps, [2] = perturbation steps, [3] = pixels,
- * [4] = lane slots occupied in the perturbation loop (64 x longest lane, summed over waves),
- * [5] = perturbation steps that went through the careful (exit-tested) path of the tuned LAv2 loop, [6] = steps taken in
- * its scaled runs, [7] = scaled runs started (both per lane). */
-float fs_last_kernel_ms(const fs_renderer *r);
-/* The durations of the last n (<= 64) iteration-kernel launches, oldest first (each launch keeps its own pair of HIP
- * events, so frames that were in flight together can be read after the fact); valid after fs_sync_compute. */
-uint32_t fs_kernel_ms_history(const fs_renderer *r, float *ms_out, uint32_t n);
-/* Low byte: 0 (default) = tuned iteration loops; 1 = literal operation-by-operation transcription of the CPU function;
- * 2 = tuned loops without the scaled runs of the HDRFloat<float> LAv2 kernel (slower; kept as in-library A/B references
- * for the tuned loops -- results are identical).  ORed with A/B flags, both off by default because they measure slower
- * (DESIGN.md 4.3 / 5.2), both bit-identical to the default and under test (tests/test_gpu_variants.py):
- *   FS_VARIANT_LDS_ORBIT  the scaled runs of the tuned HDRFloat<float> LAv2 kernel take their orbit entries through LDS
- *                         (LDS-DMA double buffer per wave) instead of the scalar cache;
- *   FS_VARIANT_REFILL     the HDRFloat<float|double> BLA kernel runs as a persistent launch whose waves refill finished
- *                         lanes from a frame-wide pixel queue (wave-ballot compaction).
- * Unknown values: hipErrorInvalidValue, the selection stays as it was.
- *   FS_VARIANT_WIDE_COUNTERS  (test switch) every entry point launches the instantiation of its kernel that counts
- *                         iterations in 64 bits -- the ones an iteration cap of 2^32 or above selects -- whatever the cap is:
- *                         lets the 64-bit kernels be compared with the CPU functions at caps a test can afford.
- *   FS_VARIANT_NATURAL_TILE_ORDER  fs_render_bla without BLA (perturbation only, HDRFloat<float>) and the tuned
- *                         HDRFloat<float> fs_render_lav2 (self-recorded order, see fs_forget_tile_costs) launch a frame's 8 x 8
- *                         tiles in their natural order.  Default for frames with an iteration limit of 2^18 or more and
- *                         at least 4096 tiles: the tiles that hold long-running pixels first (a probe launch runs every
- *                         tile's centre pixel for n_iterations / 32 steps), ONE to a workgroup with three
- *                         short tiles beside it (never-escaping waves that share a CU slow each other down) --
- *                         which wave renders which tile changes no pixel.
- *                         The same switch keeps the HDRFloat<double> / HDRFloat<CudaDblflt> fs_render_lav2 frames in the tile
- *                         mapping: by default, from the third frame of a view on (the first runs as it is, the second records and
- *                         sorts -- a view that is shown once pays for no sort; a view = same geometry, row bands, orbit, coordinates,
- *                         iteration limit, mode), lane s of the launch renders the pixel that ranked s-th in the previous
- *                         frame -- by iteration count (HDRFloat<double>) or by the cost that frame recorded per pixel, its own AT
- *                         iterations above its perturbation steps (HDRFloat<CudaDblflt>); a device radix sort, once per view;
- *                         frames of 2^20 elements and more -- so that the lanes of a wave run equally long.  Which lane renders
- *                         which pixel changes no pixel.
- *   FS_VARIANT_BLA_POOL   the hand-written HDRFloat<float> BLA kernel (the default of fs_render_bla with a table) re-packs the
- *                         running pixels of a workgroup's four waves into as few waves as possible every 32 trips (LDS exchange).
- *                         A/B, off by default: measured slower; results identical.
- */
-enum { FS_VARIANT_LDS_ORBIT = 0x100, FS_VARIANT_REFILL = 0x200, FS_VARIANT_WIDE_COUNTERS = 0x400,
-       FS_VARIANT_NATURAL_TILE_ORDER = 0x800, FS_VARIANT_BLA_POOL = 0x1000 };
-uint32_t fs_set_kernel_variant(fs_renderer *r, int variant);
-/* Longest tiles first, self-recorded (this project's addition).  Every fs_render_lav2 frame of the tuned
- * HDRFloat<float> kernel records one cost word per 8 x 8 tile (its longest lane's step count); the next frame with the
- * same geometry, row bands and orbit generation is launched in descending cost order -- "warm".  The first frame, a frame
- * after any of those changed or after fs_forget_tile_costs, and every frame under FS_VARIANT_NATURAL_TILE_ORDER run in
- * natural order -- "cold".  The order changes which wave renders which tile, never a pixel.
- * fs_render_bla's probe order (FS_VARIANT_NATURAL_TILE_ORDER above) is kept the same way: a frame with the same geometry, row
- * bands, orbit (generation, or for generation 0 a sampled fingerprint of the entries -- RenderPerturbBLA re-uploads per call),
- * coordinates and iteration limit as the one before reuses the order and skips the probe launch; fs_forget_tile_costs drops it
- * -- and the pixel order of the HDRFloat<double> / HDRFloat<CudaDblflt> LAv2 frames (FS_VARIANT_NATURAL_TILE_ORDER above).
- * fs_last_frame_tile_ordered: 1 when the most recent fs_render_lav2 launch used a recorded order / the most recent
- * perturbation-only fs_render_bla launch reused its probe order.
- * fs_read_tile_costs: the costs the last frame recorded (row-major tiles of the LOCAL buffer, (width + 7) / 8 per row);
- * *n_tiles = their number; out may be NULL.  FractalSharkError 10006 when nothing has been recorded. */
-uint32_t fs_forget_tile_costs(fs_renderer *r);
-int fs_last_frame_tile_ordered(fs_renderer *r);
-uint32_t fs_read_tile_costs(fs_renderer *r, uint32_t *out, uint64_t max_words, uint64_t *n_tiles);
-/* Test hook for the waypoint-resident orbit (fs_set_compressed_orbit_mode(1), HDRFloat<float | double>): one lane's
- * decompression cursor -- with 32-bit positions, or the 64-bit ones the wide kernel uses -- seeks to orbit index `start`
- * and walks n entries on; out[k] = the orbit value at start + k as {float re, im; int32 e} (12 B) or
- * {double re, im; int32 e; pad} (24 B).  Indices of 2^32 and above need wide_positions = 1. */
-uint32_t fs_seq_cursor_probe(fs_renderer *r, int wide_positions, uint64_t start, uint32_t n, void *out);
-/* The launch order of the most recent frame when it was an ordered one (its first n_tiles words: a permutation of the tile
- * numbers, highest cost class first); 10006 otherwise.  For tests. */
-uint32_t fs_read_tile_order(fs_renderer *r, uint32_t *out, uint64_t max_words);
-uint32_t fs_enable_step_count(fs_renderer *r, int enable);
-uint32_t fs_read_step_count(fs_renderer *r, uint64_t counts[8]);
-/* The whole statistics buffer (measurement builds append per-wave trace records behind the 8 counters: library built
- * with FS_TRACE_WAVES=1 and FSMI355_TRACE_WAVES=<max waves> in the environment; tools/wave_trace.py). */
-uint32_t fs_read_stats_raw(fs_renderer *r, uint64_t *out, uint64_t max_words);
-/* Test hook: the wave-uniform block threshold of the tuned HDRFloat<float> LAv2 loop (csrc/kernels.hip, FS_FAST_LOOP_FDU), evaluated on
- * the device by the macro the loop itself uses, for n triples (block bound as a binary32 bit pattern -- 0x80000000 = "never" --, largest
- * scale shift of the running lanes, largest max|dc| as a bit pattern): threshold_out[i] = -1 when dc_bits > bound_bits, else
- * min(bound_bits - scale_shift, 0x46800000) without wrap-around.  Host arrays.  tests/test_gpu_block_threshold.py. */
-uint32_t fs_test_block_threshold(fs_renderer *r, const int32_t *bound_bits, const int32_t *scale_shift, const int32_t *dc_bits,
-                                 int32_t *threshold_out, uint32_t n);
-/* Average duration (HIP events on the compute stream, `repeats` back-to-back launches, no D2H) of the two RenderCurrent
- * kernels over the current iteration buffer: ms_out[0] = antialias + palette, ms_out[1] = min / max / sum.  Needs a
- * palette (fs_init_memory) and the whole frame on this renderer.  tools/bench_render_current.py turns them into GB/s. */
-uint32_t fs_time_render_current(fs_renderer *r, uint64_t n_iterations, uint32_t repeats, float ms_out[2]);
-
 /* ---- Multi-GPU: one frame row-tiled over the GPUs of one node, gathered over xGMI with RCCL (this project's addition;
  * the reference is single-device, GPU_Render.cu:113).  A group = one fs_renderer per device inside ONE process (the C++
  * drop-in of INTEGRATION.md is one process), RCCL communicators from ncclCommInitAll.  Rank r renders the 8-row bands
@@ -420,6 +343,15 @@ uint32_t fs_group_render_current(fs_group *g, uint64_t n_iterations, void *iter_
  * for it. */
 uint32_t fs_group_render_current_colors(fs_group *g, uint64_t n_iterations, void *iter_buffer, fs_color16 *color_buffer,
                                         fs_reduction *reduction, int progressive);
+/* Where the iteration buffer of fs_group_render_current[_colors] travels (round 6).  0 (default) = gather: the slices go to device 0
+ * over xGMI, one kernel restores row order, ONE copy brings the whole frame to the host over device 0's PCIe link.  1 = direct: every
+ * member copies its own bands straight to their rows of iter_buffer over ITS OWN link (fs_copy_bands_to_host, on a copy stream of its
+ * own behind its kernel, while it renders the next frame into its second slice) -- N links instead of one, no re-order kernel; the
+ * gather then only runs when color_buffer or reduction is asked for (they need the frame on one device), and the frame itself no
+ * longer crosses device 0's link.  iter_buffer should be page-locked and portable (hipHostMalloc(hipHostMallocPortable) /
+ * fs_host_register).  Same frames either way (tests/test_gpu_group.py). */
+uint32_t fs_group_set_host_path(fs_group *g, int host_path);
+int fs_group_host_path(const fs_group *g);
 uint32_t fs_group_sync_display(fs_group *g);
 uint32_t fs_group_sync(fs_group *g);
 /* Two frames may be in flight: fs_group_render_current runs on a stream of its own on device 0 (receive, row order,
@@ -430,8 +362,6 @@ uint32_t fs_group_sync(fs_group *g);
  * The caller owns the host buffers: one per frame in flight.  (After fs_group_render_current member 0's own iteration
  * buffer is the OTHER set's slot: per-renderer colour output of a frame is taken before that call.) */
 uint32_t fs_group_wait_current(fs_group *g, uint32_t frames_back);
-/* Duration of the last gather + reassembly on device 0 (HIP events; synchronises device 0's post stream). */
-float fs_group_gather_ms(fs_group *g);
 /* The tiler's plan as a pure host function (tests; equals fractalshark_amd/tiling.py): rows rank `rank` owns, the
  * common padded slice height, and frame_index[y] = row of the gathered buffer (N slices back to back) that holds frame
  * row y.  Any output pointer may be NULL. */

@@ -133,6 +133,9 @@ def workload_rows(inp, y0, y1, threads=8, stage_test=None, row_step=1):
     view, orbit, aa, n = inp["view"], inp["orbit"], inp["AA"], inp["n_iter"]
     set_row_step(row_step)
     try:
+        if inp.get("is_direct"):
+            # (Fractal.cpp:2096-2206; direct_f64 renders every row of [y0, y1): a one-second frame, no row step)
+            return direct_f64(view, aa=aa, rows=(y0, y1), threads=threads)
         if inp["is2x32"]:
             return gpu_lav2_2x32(view, inp["orbit2"], inp["la2"], aa=aa, rows=(y0, y1), threads=threads, n_iterations=n)
         if inp["is_lav2"]:

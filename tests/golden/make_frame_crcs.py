@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Whole BASELINE frames as the CPU ORACLE renders them -> tests/golden/frame_crcs.json (build container, CPU only, hours).
 
-For every bench workload (bench.WORKLOADS: C3 and its GPU-stage-test secondary, C2, C5, C4 in its three forms) this renders the
+For every bench workload (bench.WORKLOADS: C1, C3 and its GPU-stage-test secondary, C2, C5, C4 in its three forms) this renders the
 WHOLE frame with the oracle (tests/_oracle.workload_rows: the same dispatch bench.py's cpu_baseline leg uses, on the inputs
 bench.make_inputs builds) and records, per `workload|parity|iteration cap`:
 
@@ -33,7 +33,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 OUT = os.path.join(HERE, "frame_crcs.json")
 # cheapest first (so that an interrupted run has the most frames): (workload, parity)
-JOBS = [("c5_bla", "cpu"), ("c3_lav2", "cpu_gpustage"), ("c4_scaled", "cpu"), ("c4_hdr64", "cpu_gpustage"),
+JOBS = [("c1_direct", "cpu"), ("c5_bla", "cpu"), ("c3_lav2", "cpu_gpustage"), ("c4_scaled", "cpu"), ("c4_hdr64", "cpu_gpustage"),
         ("c3_lav2", "cpu"), ("c4_2x32", "cpu"), ("c2_po", "cpu")]
 BANDS = 32
 
@@ -100,7 +100,8 @@ def main():
             print("  %s rows %d..%d  %.1f s (total %.0f s)" % (wl, y0, y1, time.time() - t1, st["seconds"]), flush=True)
         table[key] = {"crc32": "%08x" % st["crc"], "sum": int(st["sum"]), "width": W, "height": H, "band_rows": br,
                       "band_crc32": ["%08x" % c for c in st["bands"]], "source": "oracle",
-                      "oracle_function": ("gpu_lav2_2x32 (restated CUDA kernel, parity unpinned)" if inp["is2x32"] else
+                      "oracle_function": ("direct_f64 (CalcCpuHDR<uint32_t,double,double>)" if inp.get("is_direct") else
+                                          "gpu_lav2_2x32 (restated CUDA kernel, parity unpinned)" if inp["is2x32"] else
                                           "gpu_scaled_hdr32 (restated CUDA kernel, parity unpinned)" if inp["is_scaled"] else
                                           "lav2_hdr%d stage_test=%d" % (64 if inp["is64"] else 32, 0 if parity == "cpu" else 1)
                                           if inp["is_lav2"] else "bla_hdr32" + ("" if inp["bla"] is not None else " (no table)")),

@@ -1,4 +1,5 @@
-"""CPU-only: the C-ABI library builds for gfx950, loads, and exports every symbol include/fsmi355.h declares."""
+"""CPU-only: the C-ABI library builds for gfx950, loads, and exports every symbol include/fsmi355.h (the drop-in boundary) and
+include/fsmi355_internal.h (measurement hooks, A/B switches, test read-backs) declare."""
 import ctypes as C
 import os
 import re
@@ -16,11 +17,26 @@ def _declared(header, prefix):
 
 def test_render_lib_exports_every_declared_symbol(native_libs):
     lib = C.CDLL(native_libs.LIB_RENDER)
-    names = [n for n in _declared("fsmi355.h", "fs_") if n != "fs_done_cb"]
-    assert len(names) >= 25
-    for n in names:
+    public = [n for n in _declared("fsmi355.h", "fs_") if n != "fs_done_cb"]
+    internal = _declared("fsmi355_internal.h", "fs_")
+    assert len(public) >= 25 and not set(public) & set(internal)
+    for n in public + internal:
         assert hasattr(lib, n), n
-    assert sorted(names) == sorted(_capi.RENDER_SYMBOLS)
+    assert sorted(public + internal) == sorted(_capi.RENDER_SYMBOLS)
+
+
+def test_the_boundary_header_carries_no_laboratory():
+    """include/fsmi355.h is what a FractalShark maintainer binds: every probe, A/B switch and statistics read-back lives in
+    fsmi355_internal.h, and the reference-language host side (csrc/gpu_render_shim.hpp) needs the public header only."""
+    public = set(_declared("fsmi355.h", "fs_"))
+    for probe in ("fs_test_block_threshold", "fs_seq_cursor_probe", "fs_read_stats_raw", "fs_time_render_current",
+                  "fs_read_tile_order", "fs_set_kernel_variant", "fs_enable_step_count", "fs_read_step_count",
+                  "fs_kernel_ms_history", "fs_last_kernel_ms", "fs_read_tile_costs", "fs_forget_tile_costs"):
+        assert probe not in public, probe
+    shim = open(os.path.join(ROOT, "fractalshark_amd", "csrc", "gpu_render_shim.hpp")).read()
+    assert "fsmi355_internal.h" not in shim
+    used = set(re.findall(r"\b(fs_[a-z_0-9]+)\s*\(", re.sub(r"//.*", "", shim)))
+    assert used and used <= public, sorted(used - public)
 
 
 def test_inputs_lib_exports_every_declared_symbol(native_libs):

@@ -85,3 +85,37 @@ def test_rank_processes_sharing_the_device_run_the_whole_of_main(single, ranks):
     assert d["cpu_baseline"] is None
     assert d["roofline"]["pixel_steps_per_launch"] == single["roofline"]["pixel_steps_per_launch"]
     assert d["roofline"]["at_iterations_per_launch"] == single["roofline"]["at_iterations_per_launch"]
+
+
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_direct_host_path_rank_processes_fill_one_shared_frame(single, ranks):
+    """--host-path direct (round 6): no gather -- every rank process copies its own bands (fs_copy_bands_to_host) into ONE frame in
+    POSIX shared memory that all ranks have page-locked, rank 0 reads the frame when every rank's counter says its bands have
+    landed.  Same frame (checksum and CRC-32) as the one-GPU run, oracle rows bit-exact, summed step counts."""
+    d = _run(["--gpus", str(ranks), "--dist-backend", "gloo", "--share-device", "--host-path", "direct"], timeout=1500)
+    assert d["n_gpus"] == ranks
+    assert d["config"]["host_path"] == "direct" and d["config"]["exchange"].startswith("none on the data path")
+    assert d["frame_checksum"] == single["frame_checksum"]
+    assert d["frame_crc32"] == single["frame_crc32"]
+    assert d["cpu_sample_rows_bit_exact"] is True
+    assert d["roofline"]["pixel_steps_per_launch"] == single["roofline"]["pixel_steps_per_launch"]
+
+
+def test_direct_host_path_forced_process_group_one_rank(single):
+    d = _run(["--host-path", "direct"], {"FS_FORCE_DIST": "1", "MASTER_PORT": "29549"})
+    assert d["frame_crc32"] == single["frame_crc32"] and d["cpu_sample_rows_bit_exact"] is True
+
+
+def test_c1_direct_line(native_libs):
+    """BASELINE config C1 (View 0 1024x768, CalcCpuHDR<uint32_t,double,double>) has a bench line: the whole frame == the oracle's
+    frame rendered in the same run and == the committed oracle CRC."""
+    env = dict(os.environ)
+    env["FS_NO_BUILD"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c1_direct", "--steps", "3", "--warmup", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    d = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.strip()][-1])
+    assert d["config"]["workload"] == "view0_1024x768_f64_direct" and d["dtype"] == "f64"
+    assert d["cpu_sample_rows_bit_exact"] is True and d["frame_crc32_equals_oracle_frame"] is True
+    assert d["roofline"]["kernel"] == "k_direct_f64" and d["roofline"]["frac"] > 0
+    assert d["cpu_baseline"]["value"] > 0

@@ -3,7 +3,7 @@ to the host): the WHOLE frame must equal the frame the CPU oracle renders -- CRC
 counts against tests/golden/frame_crcs.json, which tests/golden/make_frame_crcs.py wrote in the build container from full
 oracle frames (hours of CPU, no GPU involved; the reference's own pattern: TestRenderGoldens.cpp:84-97 pins whole frames by a
 CRC) -- and a few rows of the same frame, spread over its height, must equal the oracle bit for bit in the same run.
-C3 3840x2160, C2 1920x1080, C5 7680x4320, C4 15360x8640 in its three forms.  One frame buffer of C4 is 531 MB; the oracle's
+C1 1024x768 (the direct binary64 kernel; the oracle's whole frame in the same run), C3 3840x2160, C2 1920x1080, C5 7680x4320, C4 15360x8640 in its three forms.  One frame buffer of C4 is 531 MB; the oracle's
 share of a test run is bounded by --cpu-sample-rows."""
 import json
 import os
@@ -32,6 +32,7 @@ def _bench(workload, rows, timeout=1500):
 
 
 @pytest.mark.parametrize("workload,rows,name", [
+    ("c1_direct", 768, "view0_1024x768_f64_direct"),
     ("c3_lav2", 8, "view5_3840x2160_hdrx32_lav2_full"),
     ("c2_po", 2, "view5_1920x1080_hdrx32_po"),
     ("c5_bla", 4, "view19_7680x4320_hdrx32_bla"),

@@ -327,3 +327,99 @@ def test_group_reinitialised_after_an_odd_number_of_frames(native_libs):
         assert np.array_equal(host[(len(order) - 1) % 2], refs[(len(order) - 1) % 2])
     finally:
         g.close()
+
+
+# ---- round 6: the direct host path (every member copies its own bands to the host over its own link)
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+@pytest.mark.parametrize("w,h", [(64, 36), (100, 75), (320, 180)])
+def test_direct_host_path_frame_equals_gather_path(native_libs, world, w, h):
+    """fs_group_set_host_path(1): the frame every member copies band by band into the caller's buffer (one 2-D copy per member, a
+    cut last band by itself) equals the gathered frame, padding included, with and without the reduction (which keeps its
+    gather) -- heights that are and are not multiples of the band, worlds that leave some members without a band."""
+    v = inputs.View.builtin(5, w, h)
+    ob = inputs.Orbit(v)
+    la = inputs.LATable(ob)
+    dx, dy, cx, cy = _pairs(v.coords_perturb_hdr32(ob))
+    n = v.num_iterations
+    ref, = _single_frames(v, ob, la, [PARITY_CPU_GPUSTAGE])
+    g = GPURendererGroup([0] * world)
+    assert g.InitializeMemory(w, h, 1) == 0
+    assert g.InitializePerturb(1, ob, la) == 0
+    assert g.SetHostPath(True) == 0
+    for with_reduction in (False, True, False):
+        assert g.RenderPerturbLAv2(dx, dy, cx, cy, n, Mode=LAV2_FULL, parity=PARITY_CPU_GPUSTAGE) == 0
+        out = g.new_iter_buffer()
+        out[:] = 0xDEADBEEF
+        red = _capi.Reduction()
+        assert g.RenderCurrent(n, out, red if with_reduction else None) == 0
+        assert g.Sync() == 0
+        assert np.array_equal(out[:h], ref[:h])
+        if with_reduction:
+            assert red.Sum == int(ref[:h, :w].astype(np.uint64).sum())
+    g.close()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_direct_host_path_pipelined_two_frames_in_flight(native_libs, world):
+    """The pipelined loop under the direct path: a member renders frame k+1 into its other slice while its copy of frame k is
+    still leaving the first one; wait_current(1) returns when EVERY member's bands of frame k-1 are in that frame's host buffer.
+    Alternating results, colours asked for on some frames (gather + direct copies side by side)."""
+    w, h = 960, 544
+    v = inputs.View.builtin(5, w, h)
+    ob = inputs.Orbit(v)
+    la = inputs.LATable(ob)
+    dx, dy, cx, cy = _pairs(v.coords_perturb_hdr32(ob))
+    order = [PARITY_CPU, PARITY_CPU_GPUSTAGE] * 5
+    refs = _single_frames(v, ob, la, order[:2])
+    g = GPURendererGroup([0] * world)
+    assert g.InitializeMemory(w, h, 1) == 0
+    assert g.InitializePerturb(1, ob, la) == 0
+    assert g.SetHostPath(True) == 0
+    host = [g.new_iter_buffer() for _ in range(2)]
+    reds = [_capi.Reduction(), _capi.Reduction()]
+    for k, parity in enumerate(order):
+        assert g.RenderPerturbLAv2(dx, dy, cx, cy, v.num_iterations, Mode=LAV2_FULL, parity=parity) == 0
+        host[k % 2][:] = 0
+        assert g.RenderCurrent(v.num_iterations, host[k % 2], reds[k % 2] if k % 3 == 0 else None) == 0
+        assert g.WaitCurrent(1) == 0
+        if k >= 1:
+            assert np.array_equal(host[(k - 1) % 2][:h], refs[(k - 1) % 2][:h]), k - 1
+            if (k - 1) % 3 == 0:
+                assert reds[(k - 1) % 2].Sum == int(refs[(k - 1) % 2][:h, :w].astype(np.uint64).sum())
+    assert g.WaitCurrent(0) == 0
+    assert np.array_equal(host[(len(order) - 1) % 2][:h], refs[(len(order) - 1) % 2][:h])
+    assert g.Sync() == 0
+    g.close()
+
+
+@pytest.mark.parametrize("aa,world", [(1, 3), (3, 2)])
+def test_copy_bands_to_host_of_one_renderer(native_libs, aa, world):
+    """fs_copy_bands_to_host on plain renderers with row bands (what a rank process of bench.py --host-path direct calls): `world`
+    renderers with interleaved bands (24-row bands for antialiasing 3) fill ONE host frame that equals the single-renderer frame."""
+    from fractalshark_amd import tiling
+    w, h = 96 * aa, 60 * aa
+    v = inputs.View.builtin(5, w // aa, h // aa, antialiasing=aa)
+    ob = inputs.Orbit(v)
+    la = inputs.LATable(ob)
+    dx, dy, cx, cy = _pairs(v.coords_perturb_hdr32(ob))
+    r = GPURenderer(0)
+    assert r.InitializeMemory(w, h, aa, None, 0, 0, 0, False) == 0
+    assert r.InitializePerturb(1, ob, 0, None, la) == 0
+    assert r.RenderPerturbLAv2(None, None, None, dx, dy, cx, cy, v.num_iterations, Mode=LAV2_FULL, parity=PARITY_CPU) == 0
+    ref = r.new_iter_buffer()
+    assert r.RenderCurrent(v.num_iterations, ref) == 0
+    assert r.SyncComputeStream() == 0
+    whole = np.full_like(ref, 0xFFFFFFFF)
+    assert r.CopyBandsToHost(whole.ctypes.data) == 0  # without bands: the plain copy of the whole buffer
+    assert r.SyncComputeStream() == 0
+    assert np.array_equal(whole, ref)
+    band = tiling.band_height(aa)
+    frame = np.full_like(ref, 0xFFFFFFFF)
+    for k in range(world):
+        assert r.SetRowBands(k * band, band, world * band) == 0
+        assert r.RenderPerturbLAv2(None, None, None, dx, dy, cx, cy, v.num_iterations, Mode=LAV2_FULL, parity=PARITY_CPU) == 0
+        assert r.CopyBandsToHost(frame.ctypes.data) == 0
+        assert r.SyncComputeStream() == 0
+    assert np.array_equal(frame[:h], ref[:h])
+    r.close()

@@ -116,3 +116,47 @@ def test_2x32_frames_in_count_order_are_the_first_frame(renderer, native_libs):
     assert np.array_equal(first, second) and np.array_equal(first, mid)
     ref = _oracle.gpu_lav2_2x32(v, o2, la2, rows=(500, 504))
     assert np.array_equal(second[500:504], ref[500:504])
+
+
+def test_at_order_is_not_trusted_across_row_bands_and_tables(renderer, native_libs):
+    """Advisor finding of round 5: the AT pass's order had no key of its own.  Build it for a whole 2048 x 1536 frame, shrink the
+    row bands, render the new view's first frames with a table WITHOUT an AT (so the pixel order is rebuilt for the smaller buffer
+    while the AT order is not), then upload the table with its AT again: the next frame must not run the AT pass in the old, larger
+    permutation (pixels without an AT result then kept stale ones).  Every frame == the first frame of its configuration."""
+    import ctypes as C
+    r = renderer
+    v = inputs.View.builtin(14, 2048, 1536, antialiasing=1)
+    ob = inputs.Orbit(v, is64=True)
+    la = inputs.LATable(ob)
+    assert la.use_at
+    co = _pairs(v.coords_perturb(ob))
+    n = v.num_iterations
+    lib = r._lib
+
+    def upload_la(use_at):
+        return lib.fs_upload_la(r._h, 0, T_HDR64, 4, la.las_ptr, la.count, la.stages_ptr, la.stage_count, 1, 1 if use_at else 0,
+                                C.addressof(la.at))
+
+    assert r.InitializeMemory(2048, 1536, 1, None, 0, 0, 0, False) == 0
+    assert r.InitializePerturb(1, ob, 0, None, la) == 0
+    assert r.forget_tile_costs() == 0
+    whole = [_frame(r, co, n, T_HDR64, PARITY_CPU_GPUSTAGE) for _ in range(4)]
+    assert [o for _, o in whole] == [False, False, True, True]
+    assert all(np.array_equal(whole[0][0], f) for f, _ in whole)
+    # the second of two ranks; a poisoned iteration buffer would show a pixel the frame's kernel skipped
+    assert r.SetRowBands(8, 8, 16) == 0
+    assert upload_la(False) == 0
+    no_at = [_frame(r, co, n, T_HDR64, PARITY_CPU_GPUSTAGE) for _ in range(3)]
+    assert [o for _, o in no_at] == [False, False, True]
+    assert upload_la(True) == 0
+    with_at = [_frame(r, co, n, T_HDR64, PARITY_CPU_GPUSTAGE) for _ in range(3)]
+    assert r.forget_tile_costs() == 0
+    fresh, _ = _frame(r, co, n, T_HDR64, PARITY_CPU_GPUSTAGE)
+    for f, _ in with_at:
+        assert np.array_equal(f, fresh)
+    # the banded frame's rows are the whole frame's rows 8..15, 24..31, ...
+    assert np.array_equal(fresh[0:8, :2048], whole[0][0][8:16, :2048])
+    assert np.array_equal(fresh[8:16, :2048], whole[0][0][24:32, :2048])
+    # (without AT the same pixels come out of the LA stages alone -- another arithmetic: only checked against itself)
+    assert all(np.array_equal(no_at[0][0], f) for f, _ in no_at)
+    assert r.SetRowBands(0, 0, 0) == 0
