@@ -82,6 +82,10 @@ def render_lib():
         return _render
     # FSMI355_LIB: another build of the same library (A/B measurements against other build flags; tools/c2_ab.py)
     path = os.environ.get("FSMI355_LIB") or _build.LIB_RENDER
+    if os.environ.get("FSMI355_LIB"):
+        # (advisor, round 5: an override has no stamp check -- at least say which build is being measured)
+        import sys
+        print("fractalshark_amd: FSMI355_LIB overrides the in-tree library: %s" % path, file=sys.stderr)
     if not os.path.exists(path):
         raise RuntimeError("libfsmi355.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'`"
                            % path)

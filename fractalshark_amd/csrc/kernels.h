@@ -396,7 +396,8 @@ void fsk_bla_hdr32_fast(const FsBlaArgs32 &A, bool pool, hipStream_t s);
 // pixel order from a frame's counts (kernels_order.hip): n = elements of the iteration buffer; work = 2 n words; order = n words
 size_t fsk_pixel_order_temp_bytes(uint32_t n);
 hipError_t fsk_pixel_order_build(const uint32_t *counts, uint32_t n, uint32_t *work, uint32_t *order, void *temp, size_t temp_bytes,
-                                 hipStream_t s);
+                                 hipStream_t s, int key_bits = 32);
+void fsk_lav2_hdr64_fast(const FsLav2ArgsT<double> &A, int mode, bool stats, hipStream_t s); // kernels_hdr64.hip
 void fsk_perturb_scalar_hdr64(const FsBlaArgsT<double> &A, bool use_bla, bool stats, int variant, hipStream_t s);
 void fsk_perturb_bla_f64(const FsBlaArgsF64 &A, bool use_bla, bool stats, hipStream_t s);
 void fsk_direct_hdr32(const FsDirectHdrArgsT<float> &A, fs::hreal<float> minX, fs::hreal<float> dx, bool stats, hipStream_t s);

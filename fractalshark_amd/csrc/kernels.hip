@@ -15,30 +15,11 @@
 #include "kernels.h"
 #include <cstdlib>
 #include "kernel_common.hpp"
+#include "lav2_common.hpp"
 
 using namespace fs;
 
 namespace {
-
-__device__ __forceinline__ hreal32 ldr(const fs_real_hdr32 &r) { return hreal32{r.m, r.e}; }
-__device__ __forceinline__ hcplx32 ldc(const fs_cplx_hdr32 &c) { return hcplx32{c.re, c.im, c.e}; }
-__device__ __forceinline__ hreal64 ldr(const fs_real_hdr64 &r) { return hreal64{r.m, r.e}; }
-__device__ __forceinline__ hcplx64 ldc(const fs_cplx_hdr64 &c) { return hcplx64{c.re, c.im, c.e}; }
-
-// Reference-orbit entry in device form: PerturbationResults::GetComplex (PerturbationResults.h:174-185)
-// builds HDRFloatComplex{x, y} on *every* access; it is a pure function of the entry, so it is evaluated
-// once here.  .w is unused padding so one access is one 16-byte load.
-__device__ __forceinline__ hcplx32 zref_at(const float4 *__restrict__ z, uint32_t i)
-{
-    const float4 v = z[i];
-    return hcplx32{v.x, v.y, __float_as_int(v.z)};
-}
-__device__ __forceinline__ hcplx64 zref_at(const FsZ64 *__restrict__ z, uint32_t i)
-{
-    return hcplx64{z[i].re, z[i].im, z[i].e};
-}
-
-// Pixel -> delta c, Fractal.cpp:2553-2562 (== 2272-2281): `dx * (float)x` goes through HDRFloat(T mant).
 
 // max / min of two magnitudes as ONE instruction (source modifiers).  Written as fmaxf(fabsf(a), fabsf(b)) the compiler first
 // canonicalises each operand (v_max_f32 |a|, |a| -- quieting a signalling NaN no arithmetic of this file can produce): three
@@ -55,21 +36,6 @@ static __device__ __forceinline__ float fs_min_abs(float a, float b)
     float r;
     asm("v_min_f32_e64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
     return r;
-}
-
-template <class F>
-__device__ __forceinline__ void pixel_delta(const FsCoordsT<F> &c, uint32_t x, uint32_t y, hreal<F> &dRe, hreal<F> &dIm)
-{
-    hreal<F> a = hr_mul(c.dx, hr_from_mant<F>((F)x)); // `dx * (SubType)x`
-    hr_reduce(a);
-    a = hr_sub(a, c.centerX);
-    hreal<F> b = hr_mul(hr_neg(c.dy), hr_from_mant<F>((F)y));
-    hr_reduce(b);
-    b = hr_sub(b, c.centerY);
-    hr_reduce(a);
-    hr_reduce(b);
-    dRe = a;
-    dIm = b;
 }
 
 } // namespace
@@ -4450,6 +4416,8 @@ __global__ void __launch_bounds__(256) k_at_pass64(FsLav2ArgsT<double> A)
     A.at_res[idx] = out;
     if (A.at_cost)
         A.at_cost[idx] = own;
+    if (A.pixel_cost) // the frame's own order (round 6): the AT iteration count is the leading part of the pixel's final count
+        A.pixel_cost[idx] = out.i == 0xFFFFFFFFu ? 0u : out.i;
 }
 
 void fsk_at_pass64(const FsLav2ArgsT<double> &A, hipStream_t s)

@@ -1,0 +1,319 @@
+// kernels_hdr64.hip -- LAv2 for T = HDRFloat<double>, the production kernel (round 6): k_lav2_hdr64.
+//
+// CPU twin: Fractal::CalcCpuPerturbationFractalLAV2<uint32_t,double,Disable> (Fractal.cpp:2545-2678) with
+// LAReference::getLA / isLAStageInvalid (LAReference.cpp:1076-1134), LAInfoDeep::Prepare / Evaluate (LAInfoDeep.h:395-420),
+// ATInfo::PerformAT (ATInfo.h:155-188).  Replaces mandel_1xHDR_float_perturb_lav2 as instantiated for HDRFloat<double>
+// (FractalSharkGpuLib/LAKernel.cuh:3-315, GPU_Render.cu:1152-1185).  k_lav2_lit<double> (kernels.hip) stays as the
+// operation-by-operation A/B reference (FS_VARIANT_LITERAL) and serves the 64-bit counters and the waypoint-resident orbit.
+//
+// What is different from the literal kernel -- the VALUES of every state are the literal ones, bit for bit except the sign of a
+// zero part (below); what changes is how the HDRFloatComplex operations are carried out on a 64-lane wave:
+//
+//  * HDRFloatComplex::plus_mutable (HDRFloatComplex.h:219-247) is a four-armed function of the exponent gap d = a.e - b.e:
+//    a alone (d >= 120), a + b 2^-d, a 2^d + b, b alone (d <= -120).  Compiled literally every add is four divergent arms with their
+//    EXEC bookkeeping -- 50 scalar instructions per step went there (SQ_INSTS_SALU 1.29e10 against SQ_INSTS_VALU 2.45e10, round 5).
+//    Here: ONE vote on the sign of d.  The two operands are named hi (the larger exponent) and lo, and the sum is
+//        hi + ldexp(lo, -(hi.e - lo.e))   with the shift forced to -4000 (ldexp -> +-0) where the gap is 120 or more,
+//    the same IEEE operations as the arm the literal code takes: 2^-d is an exact power of two inside the normal range, so the
+//    product b 2^-d and ldexp(b, -d) are the same correctly rounded value (also where it is subnormal); the addition commutes; an
+//    addend of +-0 leaves hi as it is.  A wave whose lanes agree on the sign of d (they almost always do: profiles/r06_hdr64_*)
+//    runs that one sequence; a mixed wave first selects hi / lo per lane (eight 32-bit selects) and runs the same sequence.
+//    Sign of zero: "hi alone" in the literal code returns hi's bits, here hi + (+-0): a -0.0 part of hi can come out as +0.0.
+//    No operation of this kernel tells the two apart -- every comparison treats them as equal, fabs and the exponent field
+//    ignore the sign, products and sums with a non-zero operand are unaffected, and a zero part stays a zero part -- so by
+//    induction every later state differs at most in the signs of its zero parts and every test (thresholds, rebase, escape)
+//    has the literal outcome; the iteration count is what the literal kernel writes.
+//  * HDRFloatComplex::Reduce (HDRFloatComplex.h:473-510): multiplier(-d) is the exact power of two 2^-d whenever the larger
+//    biased exponent field is in [1, 2045]; ldexp(part, -d) is then the literal product.  A wave with a lane outside that range
+//    (both parts zero or subnormal, an infinity) takes the literal function.
+//  * The norm tests (Reduce + compareToBothPositiveReduced on a squared norm, HDRFloat.h:1150-1167): for operands that are normal
+//    numbers the lexicographic compare of (exponent, mantissa in [1, 2)) IS the comparison of the real values m 2^e, and
+//    ldexp(n1, e1 - e2) < n2 decides that exactly (the shifted value is exact where it is normal; where it overflows or falls
+//    below the normal range the order is already decided by the exponents, and n2 >= 2^-1000 keeps a subnormal rounding away from
+//    it).  A wave with a lane whose operand is not >= 2^-1000 (zero, subnormal, NaN) takes the literal tests.
+//  * Records are requested one step ahead: the orbit entry / LA record a step arrives at is the one the next step leaves from.
+//
+// Verified against: the CPU oracle's whole C4 frame (tests/golden/frame_crcs.json, CRC ff3b12fe), the reference's golden CRC-64s
+// of Views 5 / 14 in HDRFloat<double> (tests/test_gpu_goldens.py), the literal kernel on every built-in view
+// (tests/test_gpu_hdr64_fast.py), sampled oracle rows in every bench line.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fs_layout.h"
+#include "hdr_math.hpp"
+#include "at_math.hpp"
+#include "kernels.h"
+#include "kernel_common.hpp"
+#include "lav2_common.hpp"
+
+using namespace fs;
+
+namespace {
+
+using C64 = hcplx64;
+using R64 = hreal64;
+
+__device__ __forceinline__ uint32_t hi_word(double v) { return (uint32_t)(__builtin_bit_cast(uint64_t, v) >> 32); }
+__device__ __forceinline__ uint32_t exp_field64(double v) { return (hi_word(v) >> 20) & 0x7FFu; }
+
+// hi + lo where hi.e >= lo.e in every lane that takes part: arms "a alone" and "a + b 2^-d" of plus_mutable
+__device__ __forceinline__ C64 add_hi_lo(C64 hi, const C64 lo)
+{
+    const int nd = lo.e - hi.e; // <= 0
+    const int n = nd > -kExpDiffIgnored ? nd : -4000;
+    hi.re = hi.re + __builtin_ldexp(lo.re, n);
+    hi.im = hi.im + __builtin_ldexp(lo.im, n);
+    return hi;
+}
+
+// HDRFloatComplex::plus_mutable, one vote on the direction of the exponent gap (see the head of this file).
+// FS_H64_ADD (A/B builds, tools/build_variant.py): 0 = the vote as plain C++ (the compiler sinks the three arms' common tail into
+// one sequence behind operand copies); 1 = the arms kept apart (an empty asm with a different comment ends each: nothing to merge);
+// 2 = no vote, the per-lane operand select always.
+#ifndef FS_H64_ADD
+#define FS_H64_ADD 1
+#endif
+__device__ __forceinline__ C64 hc_add_w(const C64 a, const C64 b)
+{
+    const bool lt = a.e < b.e;
+#if FS_H64_ADD != 2
+    const uint64_t m = __builtin_amdgcn_ballot_w64(lt);
+    if (m == 0ull) {
+        C64 r = add_hi_lo(a, b);
+#if FS_H64_ADD == 1
+        asm volatile("; hc_add_w: every lane a.e >= b.e" : "+v"(r.re), "+v"(r.im));
+#endif
+        return r;
+    }
+    if (m == __builtin_amdgcn_ballot_w64(true)) {
+        C64 r = add_hi_lo(b, a);
+#if FS_H64_ADD == 1
+        asm volatile("; hc_add_w: every lane a.e < b.e" : "+v"(r.re), "+v"(r.im));
+#endif
+        return r;
+    }
+#endif
+    C64 hi, lo;
+    hi.re = lt ? b.re : a.re, hi.im = lt ? b.im : a.im, hi.e = lt ? b.e : a.e;
+    lo.re = lt ? a.re : b.re, lo.im = lt ? a.im : b.im, lo.e = lt ? a.e : b.e;
+    return add_hi_lo(hi, lo);
+}
+
+// HDRFloatComplex::Reduce
+__device__ __forceinline__ void hc_reduce_w(C64 &a)
+{
+    const uint32_t fr = exp_field64(a.re), fi = exp_field64(a.im);
+    const uint32_t m = fr > fi ? fr : fi;
+    if (__builtin_amdgcn_ballot_w64(m - 1u >= 2045u) != 0ull) { // a zero / subnormal pair or an infinity in some lane
+        hc_reduce(a);
+        return;
+    }
+    const int d = (int)m - 1023;
+    a.re = __builtin_ldexp(a.re, -d);
+    a.im = __builtin_ldexp(a.im, -d);
+    a.e += d;
+}
+
+// hr_cmp_pos(hr_reduced({n1, e1}), hr_reduced({n2, e2})) < 0 for two non-negative mantissas, exactly
+__device__ __forceinline__ bool norm_less_w(double n1, int e1, double n2, int e2)
+{
+    const bool odd = !(n1 >= 0x1p-1000) || !(n2 >= 0x1p-1000);
+    if (__builtin_amdgcn_ballot_w64(odd) != 0ull)
+        return hr_cmp_pos(hr_reduced(R64{n1, e1}), hr_reduced(R64{n2, e2})) < 0;
+    int k = e1 - e2;
+    k = k < -4000 ? -4000 : (k > 4000 ? 4000 : k);
+    return __builtin_ldexp(n1, k) < n2;
+}
+
+// Statistics words of the counting build (fs_read_step_count / tools): [8] steps whose adds ran the mixed (select) form, [9] wave
+// steps of the perturbation loop, [10] wave steps of the LA loop
+template <int Mode, bool kStats> __global__ void __launch_bounds__(256) k_lav2_hdr64(FsLav2ArgsT<double> A)
+{
+    using F = double;
+    using LaRec = fs_la_hdr64_u32;
+    uint32_t X, L;
+    if (A.pixel_order)
+        ordered_pixel(A.frame, A.pixel_order, X, L);
+    else
+        tile_pixel(X, L);
+    uint64_t c_at = 0, c_la = 0, c_pt = 0, c_px = 0, c_at_exec = 0, c_at_own = 0;
+    uint32_t px_cost = 0;
+    const bool in_buffer = X < A.frame.width && L < A.frame.local_rows;
+    const uint32_t Y = in_buffer ? global_row(A.frame, L) : 0xFFFFFFFFu;
+    const bool live = in_buffer && Y < A.frame.height;
+    if (live) {
+        c_px = 1;
+        const uint32_t n_iterations = A.n_iterations;
+        R64 deltaReal, deltaImaginary;
+        pixel_delta<F>(A.coords, X, Y, deltaReal, deltaImaginary);
+        const C64 dc = hc_from_hr(deltaReal, deltaImaginary);
+        C64 dz = hc_from_native<F>(F(0), F(0)); // {0,0}: zero with exponent 0 (Fractal.cpp:2565)
+        uint32_t iterations = 0;
+
+        bool at_done = false;
+        if constexpr (Mode != FS_MODE_PO) {
+            if (A.at_res) { // PerformAT ran in its own pass (fsk_at_pass64): its result instead of the iteration
+                const FsAtRes ar = A.at_res[(size_t)L * A.frame.rounded_width + X];
+                at_done = true;
+                if (ar.i != 0xFFFFFFFFu) {
+                    dz = C64{ar.re, ar.im, ar.e};
+                    iterations = ar.i * A.at.StepLength;
+                }
+            }
+        }
+        if (Mode != FS_MODE_PO && !at_done) {
+            if (A.la_valid && A.use_at && hr_cmp_pos(hc_cheb(dc), ldr(A.at.ThresholdC)) <= 0) {
+                const uint32_t at_step = A.at.StepLength;
+                const uint32_t ATMaxIt = n_iterations / at_step;
+                C64 c = hc_add(hc_mul(dc, ldc(A.at.CCoeff)), ldc(A.at.RefC));
+                hc_reduce(c);
+                C64 z;
+                uint32_t i, i_exec = 0, i_own = 0;
+                at_perform<F, uint32_t>(c, ldr(A.at.SqrEscapeRadius), ATMaxIt, z, i, &i_exec, &i_own);
+                px_cost = i_own > 0xFFFFFu ? 0xFFFFFu : i_own;
+                C64 d0 = hc_mul(z, ldc(A.at.InvZCoeff));
+                hc_reduce(d0);
+                dz = d0;
+                iterations = i * at_step;
+                if (kStats)
+                    c_at = i, c_at_exec = i_exec, c_at_own = i_own;
+            }
+        }
+
+        uint32_t RefIteration = 0;
+        const uint32_t MaxRefIteration = A.orbit_count - 1;
+        const uint32_t period = A.period;
+        if (iterations != 0 && !(RefIteration < MaxRefIteration) && period != 0)
+            RefIteration = RefIteration % period; // (Fractal.cpp:2590-2591)
+
+        if (Mode != FS_MODE_PO) {
+            uint32_t CurrentLAStage = A.la_valid ? A.stage_count : 0;
+            const R64 dcCheb = hc_cheb(dc);
+            while (CurrentLAStage > 0) {
+                CurrentLAStage--;
+                const uint32_t LAIndex = A.stages[CurrentLAStage].LAIndex;
+                {
+                    const int cmp = hr_cmp_pos(dcCheb, ldr(A.las[LAIndex].LAThresholdC));
+                    const bool invalid = A.parity == FS_PARITY_LITERAL ? (cmp < 0) : (cmp >= 0);
+                    if (invalid)
+                        continue;
+                }
+                const uint32_t MacroItCount = A.stages[CurrentLAStage].MacroItCount;
+                const LaRec *__restrict__ base = A.las + LAIndex;
+                uint32_t j = RefIteration;
+                // The Ref of record j + 1, read for the rebase test of step j, is the Ref step j + 1 starts from: it travels in
+                // RefJ; the rest of record j (coefficients, threshold, lengths) is requested while step j - 1 still computes.
+                C64 RefJ = hc_zero<F>();
+                if (iterations < n_iterations)
+                    RefJ = ldc(base[j].Ref);
+                while (iterations < n_iterations) {
+                    const LaRec *__restrict__ LAj = base + j;
+                    const uint32_t l = LAj->StepLength;
+                    const C64 ZCoeff = ldc(LAj->ZCoeff), CCoeff = ldc(LAj->CCoeff);
+                    const R64 thr = ldr(LAj->LAThreshold);
+                    const C64 RefN = ldc(LAj[1].Ref);
+                    bool unusable = true;
+                    C64 newDz = hc_zero<F>();
+                    if (iterations + l <= n_iterations) {
+                        newDz = hc_mul(dz, hc_add_w(hc_mul2(RefJ), dz));
+                        hc_reduce_w(newDz);
+                        unusable = hr_cmp_pos(hc_cheb(newDz), thr) >= 0;
+                    }
+                    if (unusable) {
+                        RefIteration = LAj->NextStageLAIndex;
+                        break;
+                    }
+                    iterations += l;
+                    if (kStats)
+                        c_la++;
+                    dz = hc_add_w(hc_mul(newDz, ZCoeff), hc_mul(dc, CCoeff));
+                    const C64 complex0 = hc_add_w(RefN, dz);
+                    j++;
+                    const R64 c0 = hc_cheb(complex0), c1 = hc_cheb(dz);
+                    if (norm_less_w(c0.m, c0.e, c1.m, c1.e) || j >= MacroItCount) {
+                        dz = complex0;
+                        j = 0;
+                        RefJ = ldc(base[0].Ref);
+                    } else {
+                        RefJ = RefN;
+                    }
+                }
+                if (iterations >= n_iterations)
+                    break;
+            }
+        }
+
+        const uint32_t it_la = iterations;
+        if (Mode != FS_MODE_LAO) {
+            const FsZ64 *__restrict__ zr = A.zref;
+            C64 Zhere = hc_zero<F>();
+            if (iterations < n_iterations)
+                Zhere = zref_at(zr, RefIteration);
+            // (as in the literal kernel: one orbit load per step, not two; Reduce(z) before |z|^2 only re-labels z)
+            for (; iterations < n_iterations; iterations++) {
+                const C64 Znext = zref_at(zr, RefIteration + 1u);
+                const C64 cur = hc_add_w(hc_mul2(Zhere), dz);
+                C64 q = hc_add_w(hc_mul(dz, cur), dc);
+                hc_reduce_w(q);
+                dz = q;
+                if (kStats)
+                    c_pt++;
+                RefIteration++;
+                C64 complex0 = hc_add_w(Znext, dz);
+                const double n1 = complex0.re * complex0.re + complex0.im * complex0.im;
+                const double n2 = dz.re * dz.re + dz.im * dz.im;
+                // |z|^2 > 256 = {1.0, 8}: the same exact value comparison against the constant
+                if (norm_less_w(1.0, 8, n1, complex0.e << 1))
+                    break;
+                Zhere = Znext;
+                if (norm_less_w(n1, complex0.e << 1, n2, dz.e << 1) || RefIteration >= MaxRefIteration) {
+                    hc_reduce_w(complex0);
+                    dz = complex0;
+                    RefIteration = 0;
+                    Zhere = zref_at(zr, 0u);
+                }
+            }
+        }
+        store_iter(A.out, A.frame, L, X, iterations);
+        if (A.pixel_cost) {
+            const uint64_t pt = (uint64_t)(iterations - it_la);
+            A.pixel_cost[(size_t)L * A.frame.rounded_width + X] = (px_cost << 12) | (pt > 0xFFFull ? 0xFFFu : (uint32_t)pt);
+        }
+    }
+    if (kStats) {
+        add_stats(A.stats, c_at, c_la, c_pt, c_px);
+        uint64_t e = c_at_exec;
+        for (int off = 32; off > 0; off >>= 1)
+            e += __shfl_down(e, off);
+        uint64_t o = c_at_own;
+        for (int off = 32; off > 0; off >>= 1)
+            o += __shfl_down(o, off);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd((unsigned long long *)&A.stats[5], (unsigned long long)e);
+            atomicAdd((unsigned long long *)&A.stats[6], (unsigned long long)o);
+        }
+    }
+}
+
+dim3 tile_grid64(const FsFrame &f) { return dim3((f.width + 31) / 32, (f.local_rows + 7) / 8, 1); } // tile_pixel()
+
+} // namespace
+
+void fsk_lav2_hdr64_fast(const FsLav2ArgsT<double> &A, int mode, bool stats, hipStream_t s)
+{
+    const dim3 g = tile_grid64(A.frame), b(256);
+#define FS_LAUNCH64F(M)                                                                                             \
+    do {                                                                                                            \
+        if (stats)                                                                                                  \
+            hipLaunchKernelGGL((k_lav2_hdr64<M, true>), g, b, 0, s, A);                                             \
+        else                                                                                                        \
+            hipLaunchKernelGGL((k_lav2_hdr64<M, false>), g, b, 0, s, A);                                            \
+    } while (0)
+    if (mode == FS_MODE_FULL)
+        FS_LAUNCH64F(FS_MODE_FULL);
+    else if (mode == FS_MODE_PO)
+        FS_LAUNCH64F(FS_MODE_PO);
+    else
+        FS_LAUNCH64F(FS_MODE_LAO);
+#undef FS_LAUNCH64F
+}

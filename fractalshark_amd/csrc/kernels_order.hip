@@ -32,10 +32,12 @@ size_t fsk_pixel_order_temp_bytes(uint32_t n)
 }
 
 // counts: the iteration buffer (uint32, n elements incl. padding); work: 2 n words (sorted keys, identity); order: n words out.
+// key_bits: the keys are known to be below 2^key_bits (32 = anything): the sort only passes over those bits.
 hipError_t fsk_pixel_order_build(const uint32_t *counts, uint32_t n, uint32_t *work, uint32_t *order, void *temp, size_t temp_bytes,
-                                 hipStream_t s)
+                                 hipStream_t s, int key_bits)
 {
     uint32_t *keys_out = work, *iota = work + n;
     hipLaunchKernelGGL(k_iota, dim3((n + 255u) / 256u), dim3(256), 0, s, iota, n);
-    return hipcub::DeviceRadixSort::SortPairsDescending(temp, temp_bytes, counts, keys_out, (const uint32_t *)iota, order, (int)n, 0, 32, s);
+    return hipcub::DeviceRadixSort::SortPairsDescending(temp, temp_bytes, counts, keys_out, (const uint32_t *)iota, order, (int)n, 0,
+                                                       key_bits > 0 && key_bits < 32 ? key_bits : 32, s);
 }

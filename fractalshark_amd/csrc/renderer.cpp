@@ -1124,6 +1124,8 @@ uint32_t fs_copy_bands_to_host(fs_renderer *r, const void *device_iters, void *h
     hipStream_t s = stream ? (hipStream_t)stream : r->compute;
     const size_t pitch = (size_t)r->w_block * 16u * r->iter_bytes;
     const uint64_t H = r->height, first = r->band_first, rows = r->band_rows, stride = r->band_stride;
+    if (first == 0 && rows >= H) // no banding: the whole padded buffer, as fs_render_current copies it
+        return (uint32_t)hipMemcpyAsync(host_frame, src, (size_t)r->local_rows_padded * pitch, hipMemcpyDeviceToHost, s);
     uint64_t full = 0; // bands that lie wholly inside the frame
     if (first + rows <= H)
         full = (H - rows - first) / stride + 1u;
@@ -2264,38 +2266,47 @@ static uint32_t *pix_cost_for(fs_renderer *r, const FsFrame &f, bool frame_is_or
     return r->pix_cost;
 }
 
-static void pix_order_after(fs_renderer *r, const FsFrame &f, const fs_renderer::PixKey &key, bool frame_was_ordered,
-                            const uint32_t *cost = nullptr)
+// order / work / temp buffers of the pixel sort for n elements; false = no memory (frames keep the tile mapping)
+static bool pix_buffers(fs_renderer *r, uint32_t n)
 {
-    if (frame_was_ordered || !pix_order_wanted(r, f))
-        return; // (an ordered frame's buffer equals the one the order was made from: nothing new to learn)
-    const uint32_t n = f.rounded_width * ((f.local_rows + 7u) & ~7u);
+    if (r->pix_cap >= n)
+        return true;
+    (void)r_free(r, r->pix_order);
+    (void)r_free(r, r->pix_work);
+    (void)r_free(r, r->pix_temp);
+    r->pix_order = r->pix_work = nullptr;
+    r->pix_temp = nullptr;
+    r->pix_cap = 0;
     r->pix_valid = false;
-    if (r->pix_cap < n) {
+    const size_t tb = fsk_pixel_order_temp_bytes(n);
+    if (r_alloc(r, (void **)&r->pix_order, (size_t)n * sizeof(uint32_t), kFrame) != hipSuccess ||
+        r_alloc(r, (void **)&r->pix_work, (size_t)n * 2 * sizeof(uint32_t), kFrame) != hipSuccess ||
+        r_alloc(r, &r->pix_temp, tb ? tb : 16, kFrame) != hipSuccess) {
+        (void)hipGetLastError();
         (void)r_free(r, r->pix_order);
         (void)r_free(r, r->pix_work);
         (void)r_free(r, r->pix_temp);
         r->pix_order = r->pix_work = nullptr;
         r->pix_temp = nullptr;
-        r->pix_cap = 0;
-        const size_t tb = fsk_pixel_order_temp_bytes(n);
-        if (r_alloc(r, (void **)&r->pix_order, (size_t)n * sizeof(uint32_t), kFrame) != hipSuccess ||
-            r_alloc(r, (void **)&r->pix_work, (size_t)n * 2 * sizeof(uint32_t), kFrame) != hipSuccess ||
-            r_alloc(r, &r->pix_temp, tb ? tb : 16, kFrame) != hipSuccess) {
-            (void)hipGetLastError(); // no memory for it: frames keep the tile mapping
-            (void)r_free(r, r->pix_order);
-            (void)r_free(r, r->pix_work);
-            (void)r_free(r, r->pix_temp);
-            r->pix_order = r->pix_work = nullptr;
-            r->pix_temp = nullptr;
-            return;
-        }
-        r->pix_cap = n;
-        r->pix_temp_bytes = tb;
+        return false;
     }
+    r->pix_cap = n;
+    r->pix_temp_bytes = tb;
+    return true;
+}
+
+static void pix_order_after(fs_renderer *r, const FsFrame &f, const fs_renderer::PixKey &key, bool frame_was_ordered,
+                            const uint32_t *cost = nullptr, int key_bits = 32)
+{
+    if (frame_was_ordered || !pix_order_wanted(r, f))
+        return; // (an ordered frame's buffer equals the one the order was made from: nothing new to learn)
+    const uint32_t n = f.rounded_width * ((f.local_rows + 7u) & ~7u);
+    r->pix_valid = false;
+    if (!pix_buffers(r, n))
+        return;
     // sorted by the cost the frame recorded (round 5) -- or, without a record, by the counts as before
-    if (fsk_pixel_order_build(cost ? cost : (const uint32_t *)r->iters(), n, r->pix_work, r->pix_order, r->pix_temp, r->pix_temp_bytes, r->compute) !=
-        hipSuccess) {
+    if (fsk_pixel_order_build(cost ? cost : (const uint32_t *)r->iters(), n, r->pix_work, r->pix_order, r->pix_temp, r->pix_temp_bytes,
+                              r->compute, key_bits) != hipSuccess) {
         (void)hipGetLastError();
         return;
     }
@@ -2583,6 +2594,10 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
         // -- other row bands, a table without AT in between -- without it)
         const bool at_warm = at_split && r->at_order_valid && r->at_key == pk;
         const bool at_record = at_split && !at_warm && (second || A.pixel_order != nullptr);
+        // (A/B: FSMI355_C4_INFRAME_ORDER=0 keeps the first frame of a view in the tile mapping)
+        static const bool inframe_on = [] { const char *e = getenv("FSMI355_C4_INFRAME_ORDER"); return !(e && e[0] == '0'); }();
+        const bool inframe = inframe_on && at_split && A.pixel_order == nullptr;
+        bool inframe_done = false;
         // (sorted by COUNT, not by a recorded cost as the 2x32 frames are: this kernel's steps are cheap enough for the loads of
         // a wave whose lanes are scattered over the frame to cost more than the idle lanes they save -- 81 ms with the cost as
         // the key, 68 with its binades, 53 with the counts, which keep the pixels inside the set side by side: DESIGN.md 7)
@@ -2602,13 +2617,41 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
                     }
                     r->at_order_valid = false;
                 }
+                // In-frame order (round 6): a frame without an order makes its own from the AT pass it has just run -- the AT
+                // iteration count is the leading part of a pixel's final count (count = AT iterations x step length + LA steps +
+                // perturbation steps), so sorting by it groups the pixels as the previous frame's counts would, with nothing
+                // needed from an earlier frame.  key_bits: ATMaxIt bounds the key.
+                uint32_t *key = inframe && pix_buffers(r, n) ? pix_cost_for(r, A.frame, false) : nullptr;
+                P.pixel_cost = key;
                 fsk_at_pass64(P, r->compute);
                 t.mid();
                 A.at_res = r->at_res;
+                if (key) {
+                    uint64_t at_max = A.at.StepLength ? n_iterations / A.at.StepLength : 0;
+                    int bits = 1;
+                    while (bits < 32 && (at_max >> bits) != 0)
+                        bits++;
+                    if (fsk_pixel_order_build(key, n, r->pix_work, r->pix_order, r->pix_temp, r->pix_temp_bytes, r->compute,
+                                              bits) == hipSuccess) {
+                        r->pix_key = pk;
+                        r->pix_valid = true;
+                        A.pixel_order = r->pix_order;
+                        inframe_done = true;
+                        r->last_frame_ordered = true;
+                    } else {
+                        (void)hipGetLastError();
+                    }
+                }
             }
-            fsk_lav2_hdr64(A, kmode, r->stats_on, r->compute);
+            // the production kernel (kernels_hdr64.hip); FS_VARIANT_LITERAL keeps the operation-by-operation one for A/B
+            // (FSMI355_HDR64_LITERAL=1: the literal kernel with the same orders and the same AT pass -- the A/B of the kernel alone)
+            static const bool lit_env = [] { const char *e = getenv("FSMI355_HDR64_LITERAL"); return e && e[0] == '1'; }();
+            if (lit_env || (r->variant & FS_VARIANT_BASE_MASK) == FS_VARIANT_LITERAL)
+                fsk_lav2_hdr64(A, kmode, r->stats_on, r->compute);
+            else
+                fsk_lav2_hdr64_fast(A, kmode, r->stats_on, r->compute);
         }
-        if (second)
+        if (second && !inframe_done)
             pix_order_after(r, A.frame, pk, false);
         const uint32_t n_buf = A.frame.rounded_width * ((A.frame.local_rows + 7u) & ~7u);
         if (at_split && at_record && r->pix_valid && r->pix_work && r->pix_temp && r->pix_cap >= n_buf) {

@@ -126,7 +126,8 @@ uint32_t fs_rounded_width(const fs_renderer *r);
  * (NULL = the renderer's current iteration buffer); stream = a hipStream_t of this device (NULL = the compute stream: behind the
  * kernel).  host_frame should be page-locked for every device that writes into it (hipHostMalloc with hipHostMallocPortable, or
  * fs_host_register -- e.g. a POSIX shared-memory frame that several rank processes fill); pageable memory works, synchronously.
- * Asynchronous.  Without row bands it is the plain copy of the whole padded buffer. */
+ * Asynchronous.  Rows at and beyond the frame's height (the padding to 8) are only written without row bands, where the call is
+ * the plain copy of the whole padded buffer. */
 uint32_t fs_copy_bands_to_host(fs_renderer *r, const void *device_iters, void *host_frame, void *stream);
 /* hipHostRegister (portable: usable by every device of the process) / hipHostUnregister of caller-owned host memory. */
 uint32_t fs_host_register(void *host_ptr, uint64_t bytes);
