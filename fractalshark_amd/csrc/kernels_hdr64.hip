@@ -99,30 +99,73 @@ __device__ __forceinline__ C64 hc_add_w(const C64 a, const C64 b)
     return add_hi_lo(hi, lo);
 }
 
-// HDRFloatComplex::Reduce
+// max(|a|, |b|) as ONE instruction (source modifiers; the C++ form first canonicalises each operand)
+__device__ __forceinline__ double max_abs64(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// HDRFloatComplex::Reduce.  The larger biased exponent field of the two parts is the field of max(|re|, |im|) whenever that
+// is a normal number: one v_max_f64 with |.| modifiers, one class test (the vote: a zero / subnormal pair or an infinity in some
+// lane sends the wave through the literal function), v_frexp_exp for the field, two ldexp.
 __device__ __forceinline__ void hc_reduce_w(C64 &a)
 {
-    const uint32_t fr = exp_field64(a.re), fi = exp_field64(a.im);
-    const uint32_t m = fr > fi ? fr : fi;
-    if (__builtin_amdgcn_ballot_w64(m - 1u >= 2045u) != 0ull) { // a zero / subnormal pair or an infinity in some lane
+    const double m = max_abs64(a.re, a.im);
+    if (__builtin_amdgcn_ballot_w64(!__builtin_amdgcn_class(m, 0x100 /* +normal */)) != 0ull) {
         hc_reduce(a);
         return;
     }
-    const int d = (int)m - 1023;
-    a.re = __builtin_ldexp(a.re, -d);
-    a.im = __builtin_ldexp(a.im, -d);
-    a.e += d;
+    const int x = __builtin_amdgcn_frexp_exp(m); // m = f 2^x, f in [0.5, 1): biased field - 1022, so d = x - 1
+    a.re = __builtin_ldexp(a.re, 1 - x);
+    a.im = __builtin_ldexp(a.im, 1 - x);
+    a.e += x - 1;
 }
 
-// hr_cmp_pos(hr_reduced({n1, e1}), hr_reduced({n2, e2})) < 0 for two non-negative mantissas, exactly
-__device__ __forceinline__ bool norm_less_w(double n1, int e1, double n2, int e2)
+// The two tests of a perturbation step on squared norms n1 2^e1 (|Z + dz|^2) and n2 2^e2 (|dz|^2), both as
+// hr_cmp_pos(hr_reduced(.), hr_reduced(.)): escaped = 256 < first, rebase = first < second.  ONE vote for both: every operand a
+// normal number well inside the range (>= 2^-1000) -- then the compares are value compares and ldexp carries them out exactly (see
+// the head of this file; ldexp takes any int32 shift and saturates to 0 / inf, which is the order the exponents already decide).
+__device__ __forceinline__ void step_tests_w(double n1, int e1, double n2, int e2, bool &escaped, bool &rebase)
 {
-    const bool odd = !(n1 >= 0x1p-1000) || !(n2 >= 0x1p-1000);
-    if (__builtin_amdgcn_ballot_w64(odd) != 0ull)
-        return hr_cmp_pos(hr_reduced(R64{n1, e1}), hr_reduced(R64{n2, e2})) < 0;
-    int k = e1 - e2;
-    k = k < -4000 ? -4000 : (k > 4000 ? 4000 : k);
-    return __builtin_ldexp(n1, k) < n2;
+    double lo;
+    asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(n1), "v"(n2));
+    if (__builtin_amdgcn_ballot_w64(!(lo >= 0x1p-1000)) != 0ull) {
+        const R64 N1 = hr_reduced(R64{n1, e1}), N2 = hr_reduced(R64{n2, e2});
+        escaped = hr_cmp_pos(N1, R64{1.0, 8}) > 0;
+        rebase = hr_cmp_pos(N1, N2) < 0;
+        return;
+    }
+    escaped = __builtin_ldexp(n1, e1) > 256.0;
+    rebase = __builtin_ldexp(n1, e1 - e2) < n2;
+}
+
+// hr_cmp_pos(hr_reduced({m1, e1}), hr_reduced({m2, e2})) < 0 for two non-negative mantissas (the LA loop's rebase test on
+// Chebyshev norms), the same way
+__device__ __forceinline__ bool less_w(double m1, int e1, double m2, int e2)
+{
+    double lo;
+    asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(m1), "v"(m2));
+    if (__builtin_amdgcn_ballot_w64(!(lo >= 0x1p-1000)) != 0ull)
+        return hr_cmp_pos(hr_reduced(R64{m1, e1}), hr_reduced(R64{m2, e2})) < 0;
+    return __builtin_ldexp(m1, e1 - e2) < m2;
+}
+
+__device__ __forceinline__ const fs_la_hdr64_u32 *la_at_off(const fs_la_hdr64_u32 *__restrict__ las, uint32_t byte_off)
+{
+    return (const fs_la_hdr64_u32 *)((const char *)las + byte_off);
+}
+
+// HDRFloatComplex::chebychevNorm's mantissa
+__device__ __forceinline__ double cheb64(const C64 a) { return max_abs64(a.re, a.im); }
+
+// records by a 32-bit BYTE offset from a wave-uniform base (one scalar base + one vector offset per load; the host only launches
+// this kernel when the orbit and the table stay below 4 GB, renderer.cpp)
+__device__ __forceinline__ C64 z_at_off(const FsZ64 *__restrict__ z, uint32_t byte_off)
+{
+    const FsZ64 *p = (const FsZ64 *)((const char *)z + byte_off);
+    return C64{p->re, p->im, p->e};
 }
 
 // Statistics words of the counting build (fs_read_step_count / tools): [8] steps whose adds ran the mixed (select) form, [9] wave
@@ -199,15 +242,15 @@ template <int Mode, bool kStats> __global__ void __launch_bounds__(256) k_lav2_h
                         continue;
                 }
                 const uint32_t MacroItCount = A.stages[CurrentLAStage].MacroItCount;
-                const LaRec *__restrict__ base = A.las + LAIndex;
+                const uint32_t base_off = LAIndex * (uint32_t)sizeof(LaRec); // byte offset of the stage's first record
                 uint32_t j = RefIteration;
                 // The Ref of record j + 1, read for the rebase test of step j, is the Ref step j + 1 starts from: it travels in
                 // RefJ; the rest of record j (coefficients, threshold, lengths) is requested while step j - 1 still computes.
                 C64 RefJ = hc_zero<F>();
                 if (iterations < n_iterations)
-                    RefJ = ldc(base[j].Ref);
+                    RefJ = ldc(la_at_off(A.las, base_off + j * (uint32_t)sizeof(LaRec))->Ref);
                 while (iterations < n_iterations) {
-                    const LaRec *__restrict__ LAj = base + j;
+                    const LaRec *__restrict__ LAj = la_at_off(A.las, base_off + j * (uint32_t)sizeof(LaRec));
                     const uint32_t l = LAj->StepLength;
                     const C64 ZCoeff = ldc(LAj->ZCoeff), CCoeff = ldc(LAj->CCoeff);
                     const R64 thr = ldr(LAj->LAThreshold);
@@ -215,9 +258,9 @@ template <int Mode, bool kStats> __global__ void __launch_bounds__(256) k_lav2_h
                     bool unusable = true;
                     C64 newDz = hc_zero<F>();
                     if (iterations + l <= n_iterations) {
-                        newDz = hc_mul(dz, hc_add_w(hc_mul2(RefJ), dz));
+                        newDz = hc_mul(dz, hc_add_w(C64{RefJ.re, RefJ.im, clamp_exp(RefJ.e + 1)}, dz));
                         hc_reduce_w(newDz);
-                        unusable = hr_cmp_pos(hc_cheb(newDz), thr) >= 0;
+                        unusable = hr_cmp_pos(R64{cheb64(newDz), newDz.e}, thr) >= 0;
                     }
                     if (unusable) {
                         RefIteration = LAj->NextStageLAIndex;
@@ -229,11 +272,10 @@ template <int Mode, bool kStats> __global__ void __launch_bounds__(256) k_lav2_h
                     dz = hc_add_w(hc_mul(newDz, ZCoeff), hc_mul(dc, CCoeff));
                     const C64 complex0 = hc_add_w(RefN, dz);
                     j++;
-                    const R64 c0 = hc_cheb(complex0), c1 = hc_cheb(dz);
-                    if (norm_less_w(c0.m, c0.e, c1.m, c1.e) || j >= MacroItCount) {
+                    if (less_w(cheb64(complex0), complex0.e, cheb64(dz), dz.e) || j >= MacroItCount) {
                         dz = complex0;
                         j = 0;
-                        RefJ = ldc(base[0].Ref);
+                        RefJ = ldc(la_at_off(A.las, base_off)->Ref);
                     } else {
                         RefJ = RefN;
                     }
@@ -247,12 +289,14 @@ template <int Mode, bool kStats> __global__ void __launch_bounds__(256) k_lav2_h
         if (Mode != FS_MODE_LAO) {
             const FsZ64 *__restrict__ zr = A.zref;
             C64 Zhere = hc_zero<F>();
+            uint32_t zoff = RefIteration * (uint32_t)sizeof(FsZ64); // byte offset of the entry the step leaves from
             if (iterations < n_iterations)
-                Zhere = zref_at(zr, RefIteration);
+                Zhere = z_at_off(zr, zoff);
             // (as in the literal kernel: one orbit load per step, not two; Reduce(z) before |z|^2 only re-labels z)
             for (; iterations < n_iterations; iterations++) {
-                const C64 Znext = zref_at(zr, RefIteration + 1u);
-                const C64 cur = hc_add_w(hc_mul2(Zhere), dz);
+                zoff += (uint32_t)sizeof(FsZ64);
+                const C64 Znext = z_at_off(zr, zoff);
+                const C64 cur = hc_add_w(C64{Zhere.re, Zhere.im, Zhere.e + 1}, dz); // (hc_mul2: x * 1.0 is x; e + 1 needs no clamp)
                 C64 q = hc_add_w(hc_mul(dz, cur), dc);
                 hc_reduce_w(q);
                 dz = q;
@@ -262,15 +306,17 @@ template <int Mode, bool kStats> __global__ void __launch_bounds__(256) k_lav2_h
                 C64 complex0 = hc_add_w(Znext, dz);
                 const double n1 = complex0.re * complex0.re + complex0.im * complex0.im;
                 const double n2 = dz.re * dz.re + dz.im * dz.im;
-                // |z|^2 > 256 = {1.0, 8}: the same exact value comparison against the constant
-                if (norm_less_w(1.0, 8, n1, complex0.e << 1))
+                bool escaped, rebase;
+                step_tests_w(n1, complex0.e << 1, n2, dz.e << 1, escaped, rebase);
+                if (escaped)
                     break;
                 Zhere = Znext;
-                if (norm_less_w(n1, complex0.e << 1, n2, dz.e << 1) || RefIteration >= MaxRefIteration) {
+                if (rebase || RefIteration >= MaxRefIteration) {
                     hc_reduce_w(complex0);
                     dz = complex0;
                     RefIteration = 0;
-                    Zhere = zref_at(zr, 0u);
+                    zoff = 0;
+                    Zhere = z_at_off(zr, 0u);
                 }
             }
         }

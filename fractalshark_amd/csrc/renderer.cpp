@@ -2594,8 +2594,10 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
         // -- other row bands, a table without AT in between -- without it)
         const bool at_warm = at_split && r->at_order_valid && r->at_key == pk;
         const bool at_record = at_split && !at_warm && (second || A.pixel_order != nullptr);
-        // (A/B: FSMI355_C4_INFRAME_ORDER=0 keeps the first frame of a view in the tile mapping)
-        static const bool inframe_on = [] { const char *e = getenv("FSMI355_C4_INFRAME_ORDER"); return !(e && e[0] == '0'); }();
+        // (A/B, off: FSMI355_C4_INFRAME_ORDER=1 sorts the first frame of a view by its own AT iteration counts -- measured in round 6:
+        // the frame's kernel then takes 54 ms against 49.6 in the tile mapping and 35 in the order of the previous frame's COUNTS;
+        // what the count order knows and the AT count does not is how long a pixel's LA and perturbation phases are)
+        static const bool inframe_on = [] { const char *e = getenv("FSMI355_C4_INFRAME_ORDER"); return e && e[0] == '1'; }();
         const bool inframe = inframe_on && at_split && A.pixel_order == nullptr;
         bool inframe_done = false;
         // (sorted by COUNT, not by a recorded cost as the 2x32 frames are: this kernel's steps are cheap enough for the loads of
@@ -2646,7 +2648,10 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
             // the production kernel (kernels_hdr64.hip); FS_VARIANT_LITERAL keeps the operation-by-operation one for A/B
             // (FSMI355_HDR64_LITERAL=1: the literal kernel with the same orders and the same AT pass -- the A/B of the kernel alone)
             static const bool lit_env = [] { const char *e = getenv("FSMI355_HDR64_LITERAL"); return e && e[0] == '1'; }();
-            if (lit_env || (r->variant & FS_VARIANT_BASE_MASK) == FS_VARIANT_LITERAL)
+            // (k_lav2_hdr64 addresses its records with 32-bit byte offsets: an orbit or a table of 4 GB and more stays with the literal kernel)
+            const bool small = (uint64_t)A.orbit_count * sizeof(FsZ64) < 0xFFFFFF00ull &&
+                               (uint64_t)r->n_las * sizeof(fs_la_hdr64_u32) < 0xFFFFFF00ull;
+            if (lit_env || !small || (r->variant & FS_VARIANT_BASE_MASK) == FS_VARIANT_LITERAL)
                 fsk_lav2_hdr64(A, kmode, r->stats_on, r->compute);
             else
                 fsk_lav2_hdr64_fast(A, kmode, r->stats_on, r->compute);
