@@ -12,13 +12,14 @@
 //  * HDRFloatComplex::plus_mutable (HDRFloatComplex.h:219-247) is a four-armed function of the exponent gap d = a.e - b.e:
 //    a alone (d >= 120), a + b 2^-d, a 2^d + b, b alone (d <= -120).  Compiled literally every add is four divergent arms with their
 //    EXEC bookkeeping -- 50 scalar instructions per step went there (SQ_INSTS_SALU 1.29e10 against SQ_INSTS_VALU 2.45e10, round 5).
-//    Here: ONE vote on the sign of d.  The two operands are named hi (the larger exponent) and lo, and the sum is
-//        hi + ldexp(lo, -(hi.e - lo.e))   with the shift forced to -4000 (ldexp -> +-0) where the gap is 120 or more,
-//    the same IEEE operations as the arm the literal code takes: 2^-d is an exact power of two inside the normal range, so the
-//    product b 2^-d and ldexp(b, -d) are the same correctly rounded value (also where it is subnormal); the addition commutes; an
-//    addend of +-0 leaves hi as it is.  A wave whose lanes agree on the sign of d (they almost always do: profiles/r06_hdr64_*)
-//    runs that one sequence; a mixed wave first selects hi / lo per lane (eight 32-bit selects) and runs the same sequence.
-//    Sign of zero: "hi alone" in the literal code returns hi's bits, here hi + (+-0): a -0.0 part of hi can come out as +0.0.
+//    Here: votes on the gap.  A wave whose lanes all take the SAME arm -- nearly every wave: its lanes hold neighbouring pixels
+//    at the same phase of their orbits -- runs that arm alone: "a alone" / "b alone" return the operand as it is, and the two
+//    sums are  hi + ldexp(lo, -gap)  -- the same IEEE operations as the literal arm: 2^-gap is an exact power of two inside the
+//    normal range, so the product lo 2^-gap and ldexp(lo, -gap) are the same correctly rounded value (also where it is
+//    subnormal), and the addition commutes.  A mixed wave selects hi / lo per lane (eight 32-bit selects) and runs the same sum
+//    with the shift forced to -4000 (ldexp -> +-0, which leaves hi as it is) in the lanes whose gap is 120 or more.
+//    Sign of zero (mixed waves only): "hi alone" in the literal code returns hi's bits, there hi + (+-0): a -0.0 part of hi can
+//    come out as +0.0.
 //    No operation of this kernel tells the two apart -- every comparison treats them as equal, fabs and the exponent field
 //    ignore the sign, products and sums with a non-zero operand are unaffected, and a zero part stays a zero part -- so by
 //    induction every later state differs at most in the signs of its zero parts and every test (thresholds, rebase, escape)
@@ -66,33 +67,34 @@ __device__ __forceinline__ C64 add_hi_lo(C64 hi, const C64 lo)
     return hi;
 }
 
-// HDRFloatComplex::plus_mutable, one vote on the direction of the exponent gap (see the head of this file).
-// FS_H64_ADD (A/B builds, tools/build_variant.py): 0 = the vote as plain C++ (the compiler sinks the three arms' common tail into
-// one sequence behind operand copies); 1 = the arms kept apart (an empty asm with a different comment ends each: nothing to merge);
-// 2 = no vote, the per-lane operand select always.
-#ifndef FS_H64_ADD
-#define FS_H64_ADD 1
-#endif
-__device__ __forceinline__ C64 hc_add_w(const C64 a, const C64 b)
+// HDRFloatComplex::plus_mutable by votes on the exponent gap (see the head of this file).  nd = b.e - a.e decides the arm of the
+// literal function: (-120, 0] a + b 2^nd; [1, 119] a 2^-nd + b; <= -120 a alone; >= 120 b alone.  A wave whose lanes agree on the arm
+// -- nearly every wave: the lanes hold neighbouring pixels at the same phase -- runs that arm alone: five instructions (or none)
+// instead of the four-way divergent function; each arm ends in an empty asm with its own comment so that the compiler keeps the
+// arms apart (it would otherwise sink their common tail into one sequence behind operand copies).  kFirst: which agreement is
+// asked for first -- 0: the sum with a on top (2 Z + dz, Z + dz), 1: a alone (dz (2 Z + dz) + dc at a deep zoom, where dc is
+// hundreds of binades below everything else).  Mixed waves: per-lane operand select, then the same sum with the gap clamped.
+template <int kFirst = 0> __device__ __forceinline__ C64 hc_add_w(const C64 a, const C64 b)
 {
-    const bool lt = a.e < b.e;
-#if FS_H64_ADD != 2
-    const uint64_t m = __builtin_amdgcn_ballot_w64(lt);
-    if (m == 0ull) {
-        C64 r = add_hi_lo(a, b);
-#if FS_H64_ADD == 1
-        asm volatile("; hc_add_w: every lane a.e >= b.e" : "+v"(r.re), "+v"(r.im));
-#endif
+    const int nd = b.e - a.e;
+    const uint64_t all = __builtin_amdgcn_ballot_w64(true);
+    if (kFirst == 1 && __builtin_amdgcn_ballot_w64(nd <= -kExpDiffIgnored) == all)
+        return a;
+    if (__builtin_amdgcn_ballot_w64((uint32_t)(nd + (kExpDiffIgnored - 1)) < (uint32_t)kExpDiffIgnored) == all) {
+        C64 r{a.re + __builtin_ldexp(b.re, nd), a.im + __builtin_ldexp(b.im, nd), a.e};
+        asm volatile("; hc_add_w: a + b 2^nd" : "+v"(r.re), "+v"(r.im));
         return r;
     }
-    if (m == __builtin_amdgcn_ballot_w64(true)) {
-        C64 r = add_hi_lo(b, a);
-#if FS_H64_ADD == 1
-        asm volatile("; hc_add_w: every lane a.e < b.e" : "+v"(r.re), "+v"(r.im));
-#endif
+    if (__builtin_amdgcn_ballot_w64((uint32_t)(nd - 1) < (uint32_t)(kExpDiffIgnored - 1)) == all) {
+        C64 r{b.re + __builtin_ldexp(a.re, -nd), b.im + __builtin_ldexp(a.im, -nd), b.e};
+        asm volatile("; hc_add_w: a 2^-nd + b" : "+v"(r.re), "+v"(r.im));
         return r;
     }
-#endif
+    if (kFirst != 1 && __builtin_amdgcn_ballot_w64(nd <= -kExpDiffIgnored) == all)
+        return a;
+    if (__builtin_amdgcn_ballot_w64(nd >= kExpDiffIgnored) == all)
+        return b;
+    const bool lt = nd > 0; // a.e < b.e
     C64 hi, lo;
     hi.re = lt ? b.re : a.re, hi.im = lt ? b.im : a.im, hi.e = lt ? b.e : a.e;
     lo.re = lt ? a.re : b.re, lo.im = lt ? a.im : b.im, lo.e = lt ? a.e : b.e;
@@ -170,7 +172,19 @@ __device__ __forceinline__ C64 z_at_off(const FsZ64 *__restrict__ z, uint32_t by
 
 // Statistics words of the counting build (fs_read_step_count / tools): [8] steps whose adds ran the mixed (select) form, [9] wave
 // steps of the perturbation loop, [10] wave steps of the LA loop
-template <int Mode, bool kStats> __global__ void __launch_bounds__(256) k_lav2_hdr64(FsLav2ArgsT<double> A)
+// FS_H64_WAVES (A/B builds): 8 = the register allocator is held to 64 registers (8 waves per SIMD; it spills three or four dwords),
+// 0 = left alone (67 registers, 7 waves)
+#ifndef FS_H64_WAVES
+#define FS_H64_WAVES 8
+#endif
+#if FS_H64_WAVES == 8
+#define FS_H64_OCCUPANCY __attribute__((amdgpu_waves_per_eu(8, 8)))
+#else
+#define FS_H64_OCCUPANCY
+#endif
+// kAtInKernel: PerformAT is iterated here (at_perform; frames without the AT pass of their own) -- false: its results come from
+// A.at_res (fsk_at_pass64), and the instantiation carries neither the loop nor its registers
+template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_bounds__(256) FS_H64_OCCUPANCY k_lav2_hdr64(FsLav2ArgsT<double> A)
 {
     using F = double;
     using LaRec = fs_la_hdr64_u32;
@@ -193,18 +207,15 @@ template <int Mode, bool kStats> __global__ void __launch_bounds__(256) k_lav2_h
         C64 dz = hc_from_native<F>(F(0), F(0)); // {0,0}: zero with exponent 0 (Fractal.cpp:2565)
         uint32_t iterations = 0;
 
-        bool at_done = false;
-        if constexpr (Mode != FS_MODE_PO) {
-            if (A.at_res) { // PerformAT ran in its own pass (fsk_at_pass64): its result instead of the iteration
-                const FsAtRes ar = A.at_res[(size_t)L * A.frame.rounded_width + X];
-                at_done = true;
-                if (ar.i != 0xFFFFFFFFu) {
-                    dz = C64{ar.re, ar.im, ar.e};
-                    iterations = ar.i * A.at.StepLength;
-                }
+        if constexpr (Mode != FS_MODE_PO && !kAtInKernel) {
+            // PerformAT ran in its own pass (fsk_at_pass64): its result instead of the iteration
+            const FsAtRes ar = A.at_res[(size_t)L * A.frame.rounded_width + X];
+            if (ar.i != 0xFFFFFFFFu) {
+                dz = C64{ar.re, ar.im, ar.e};
+                iterations = ar.i * A.at.StepLength;
             }
         }
-        if (Mode != FS_MODE_PO && !at_done) {
+        if constexpr (Mode != FS_MODE_PO && kAtInKernel) {
             if (A.la_valid && A.use_at && hr_cmp_pos(hc_cheb(dc), ldr(A.at.ThresholdC)) <= 0) {
                 const uint32_t at_step = A.at.StepLength;
                 const uint32_t ATMaxIt = n_iterations / at_step;
@@ -223,6 +234,7 @@ template <int Mode, bool kStats> __global__ void __launch_bounds__(256) k_lav2_h
             }
         }
 
+        uint32_t n_la = 0; // LA steps of this pixel (the frame's own cost record, FsLav2ArgsT::pixel_cost)
         uint32_t RefIteration = 0;
         const uint32_t MaxRefIteration = A.orbit_count - 1;
         const uint32_t period = A.period;
@@ -267,8 +279,7 @@ template <int Mode, bool kStats> __global__ void __launch_bounds__(256) k_lav2_h
                         break;
                     }
                     iterations += l;
-                    if (kStats)
-                        c_la++;
+                    n_la++;
                     dz = hc_add_w(hc_mul(newDz, ZCoeff), hc_mul(dc, CCoeff));
                     const C64 complex0 = hc_add_w(RefN, dz);
                     j++;
@@ -297,7 +308,7 @@ template <int Mode, bool kStats> __global__ void __launch_bounds__(256) k_lav2_h
                 zoff += (uint32_t)sizeof(FsZ64);
                 const C64 Znext = z_at_off(zr, zoff);
                 const C64 cur = hc_add_w(C64{Zhere.re, Zhere.im, Zhere.e + 1}, dz); // (hc_mul2: x * 1.0 is x; e + 1 needs no clamp)
-                C64 q = hc_add_w(hc_mul(dz, cur), dc);
+                C64 q = hc_add_w<1>(hc_mul(dz, cur), dc);
                 hc_reduce_w(q);
                 dz = q;
                 if (kStats)
@@ -321,9 +332,16 @@ template <int Mode, bool kStats> __global__ void __launch_bounds__(256) k_lav2_h
             }
         }
         store_iter(A.out, A.frame, L, X, iterations);
+        if (kStats)
+            c_la = n_la;
         if (A.pixel_cost) {
-            const uint64_t pt = (uint64_t)(iterations - it_la);
-            A.pixel_cost[(size_t)L * A.frame.rounded_width + X] = (px_cost << 12) | (pt > 0xFFFull ? 0xFFFu : (uint32_t)pt);
+            // What this pixel cost THIS kernel: its LA steps and its perturbation steps (PerformAT runs in a pass of its own).  Few
+            // distinct values, so the sort that follows leaves pixels of equal cost in buffer order -- neighbours stay together.
+            // (with PerformAT inside the kernel -- no AT pass -- the round-5 key: AT iterations above perturbation steps)
+            const uint32_t pt = iterations - it_la;
+            const uint32_t steps = n_la + pt;
+            A.pixel_cost[(size_t)L * A.frame.rounded_width + X] =
+                !kAtInKernel ? (steps > 0xFFFFu ? 0xFFFFu : steps) : ((px_cost << 12) | (pt > 0xFFFu ? 0xFFFu : pt));
         }
     }
     if (kStats) {
@@ -350,10 +368,17 @@ void fsk_lav2_hdr64_fast(const FsLav2ArgsT<double> &A, int mode, bool stats, hip
     const dim3 g = tile_grid64(A.frame), b(256);
 #define FS_LAUNCH64F(M)                                                                                             \
     do {                                                                                                            \
-        if (stats)                                                                                                  \
-            hipLaunchKernelGGL((k_lav2_hdr64<M, true>), g, b, 0, s, A);                                             \
-        else                                                                                                        \
-            hipLaunchKernelGGL((k_lav2_hdr64<M, false>), g, b, 0, s, A);                                            \
+        if (A.at_res && (M) != FS_MODE_PO) {                                                                        \
+            if (stats)                                                                                              \
+                hipLaunchKernelGGL((k_lav2_hdr64<M, true, false>), g, b, 0, s, A);                                  \
+            else                                                                                                    \
+                hipLaunchKernelGGL((k_lav2_hdr64<M, false, false>), g, b, 0, s, A);                                 \
+        } else {                                                                                                    \
+            if (stats)                                                                                              \
+                hipLaunchKernelGGL((k_lav2_hdr64<M, true, true>), g, b, 0, s, A);                                   \
+            else                                                                                                    \
+                hipLaunchKernelGGL((k_lav2_hdr64<M, false, true>), g, b, 0, s, A);                                  \
+        }                                                                                                           \
     } while (0)
     if (mode == FS_MODE_FULL)
         FS_LAUNCH64F(FS_MODE_FULL);

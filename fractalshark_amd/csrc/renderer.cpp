@@ -2557,12 +2557,12 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
         // first frame): the AT loop reads no memory, so its waves can be made of pixels from anywhere -- equal work per wave --
         // while the frame's kernel keeps the order that keeps neighbours together (below).
         static const bool at_split_off = [] { const char *e = getenv("FSMI355_AT_IN_KERNEL"); return e && e[0] == '1'; }();
-        // (A/B: FSMI355_AT_SPLIT_COLD=0 keeps round 5's first frame of a view -- ONE kernel that iterates PerformAT itself)
-        static const bool at_split_cold = [] { const char *e = getenv("FSMI355_AT_SPLIT_COLD"); return !(e && e[0] == '0'); }();
+        // (A/B, off: FSMI355_AT_SPLIT_COLD=1 runs the pass of its own in the first frame of a view too -- natural order, nothing
+        // recorded.  Measured in round 6: AT pass 13.5 ms + the frame's kernel in the tile mapping 48.7 = 62.3 ms against 55.9 ms for the
+        // ONE kernel that iterates PerformAT itself: without an order the pass's waves wait for their slowest pixel just as the
+        // kernel's do, and the frame's kernel gains nothing from lanes that arrive together)
+        static const bool at_split_cold = [] { const char *e = getenv("FSMI355_AT_SPLIT_COLD"); return e && e[0] == '1'; }();
         const bool second = A.pixel_order == nullptr && pix_second_sighting(r, A.frame, pk);
-        // Round 6: the pass of its own in EVERY frame, the first of a view included -- it needs no order to exist (natural order,
-        // nothing recorded), its waves hold 64 pixels of one 8 x 8 tile, and the frame's kernel behind it no longer waits for the
-        // slowest AT lane of each wave before its LA stages begin.
         bool at_split = !at_split_off && mode != FS_LAV2_PO && A.use_at && A.la_valid && pix_order_wanted(r, A.frame) &&
                         (at_split_cold || A.pixel_order != nullptr || second);
         if (at_split) {
@@ -2603,6 +2603,14 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
         // (sorted by COUNT, not by a recorded cost as the 2x32 frames are: this kernel's steps are cheap enough for the loads of
         // a wave whose lanes are scattered over the frame to cost more than the idle lanes they save -- 81 ms with the cost as
         // the key, 68 with its binades, 53 with the counts, which keep the pixels inside the set side by side: DESIGN.md 7)
+        // The order's key (A/B, FSMI355_C4_ORDER_KEY=cost): the previous frame's COUNTS (default), or what the pixels cost the frame's
+        // kernel in that frame -- LA steps + perturbation steps, recorded by the second frame of the view
+        static const bool key_cost = [] { const char *e = getenv("FSMI355_C4_ORDER_KEY"); return e && e[0] == 'c' && e[1] == 'o' && e[2] == 's'; }();
+        uint32_t *cost_key = nullptr;
+        if (key_cost && second && at_split) {
+            cost_key = pix_cost_for(r, A.frame, false);
+            A.pixel_cost = cost_key;
+        }
         {
             TimedLaunch t(r);
             if (at_split) {
@@ -2657,7 +2665,7 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
                 fsk_lav2_hdr64_fast(A, kmode, r->stats_on, r->compute);
         }
         if (second && !inframe_done)
-            pix_order_after(r, A.frame, pk, false);
+            pix_order_after(r, A.frame, pk, false, cost_key, cost_key ? 16 : 32);
         const uint32_t n_buf = A.frame.rounded_width * ((A.frame.local_rows + 7u) & ~7u);
         if (at_split && at_record && r->pix_valid && r->pix_work && r->pix_temp && r->pix_cap >= n_buf) {
             // the AT pass's own order, from the costs it has just recorded (the sort's work memory is the pixel order's)
