@@ -105,6 +105,55 @@ def _render_flags():
 _UNIT_FLAGS = {"kernels_scaled.hip": ["-fno-slp-vectorize"]}
 
 
+# Units whose DEVICE code goes through tools/asm_peephole.py between the compiler and the assembler (v_cndmask_b32_e32 -> _e64).
+# EMPTY: back to back the 32-bit encoding of the select issues five times slower than the 64-bit one on gfx950
+# (profiles/r06_valu_issue_rates_f64.jsonl), but in a kernel -- k_lav2_hdr64, 838 selects rewritten, same box -- the frame time did not
+# move (33.33 against 33.28 ms, profiles/r06_c4_hdr64_kernel_ab_same_box.jsonl): the selects of real code are not back to back.  The
+# step stays for A/B builds (FS_PEEPHOLE_UNITS=kernels_x.hip,... in the environment of tools/build_variant.py).
+PEEPHOLE_TOOL = os.path.join(ROOT, "tools", "asm_peephole.py")
+_PEEPHOLE_UNITS = set(u for u in os.environ.get("FS_PEEPHOLE_UNITS", "").split(",") if u)
+LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+
+
+def _peephole_state():
+    return "peephole:" + (",".join(sorted(_PEEPHOLE_UNITS)) if os.environ.get("FS_PEEPHOLE", "1") != "0" else "off")
+
+
+def _peephole_on(src):
+    return src.endswith(".hip") and os.path.basename(src) in _PEEPHOLE_UNITS and os.environ.get("FS_PEEPHOLE", "1") != "0"
+
+
+def compile_one(hipcc, src, obj, flags, peephole):
+    """One translation unit -> object.  Plain: hipcc -c.  With the peephole: the driver's own steps taken apart -- device code to
+    assembly, the rewrite, assembler, lld (code object), clang-offload-bundler (fat binary), then the host pass with that binary."""
+    # renderer.cpp / group.cpp are host-only C++ that include HIP runtime headers: compiled by hipcc as HIP so
+    # that <hip/hip_runtime.h> types (float4, hipStream_t) match the kernels' launchers
+    lang = [] if src.endswith(".hip") else ["-x", "hip"]
+    if not peephole:
+        _run([hipcc, *flags, "-c", *lang, src, "-o", obj])
+        return
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fs_asm_peephole", PEEPHOLE_TOOL)
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    base = obj[:-2] if obj.endswith(".o") else obj
+    asm, asm2, dev, hsaco, fb = base + ".dev.s", base + ".dev.pp.s", base + ".dev.o", base + ".hsaco", base + ".hipfb"
+    _run([hipcc, *flags, "--cuda-device-only", "-S", *lang, src, "-o", asm])
+    text, n = tool.rewrite(open(asm).read())
+    open(asm2, "w").write(text)
+    _run([os.path.join(LLVM_BIN, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", asm2, "-o", dev])
+    _run([os.path.join(LLVM_BIN, "lld"), "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared", "-o", hsaco, dev])
+    _run([os.path.join(LLVM_BIN, "clang-offload-bundler"), "-type=o", "-bundle-align=4096",
+          "-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950", "-input=/dev/null", "-input=" + hsaco,
+          "-output=" + fb])
+    _run([hipcc, *flags, "--cuda-host-only", "-Xclang", "-fcuda-include-gpubinary", "-Xclang", fb, "-c", *lang, src, "-o", obj])
+    for f in (asm, dev, hsaco, fb):  # (the rewritten assembly stays next to the object: what was assembled can be read)
+        try:
+            os.remove(f)
+        except OSError:
+            pass
+
+
 def _inputs_sources():
     return [os.path.join(HOST, "refinputs.cpp"), os.path.join(CSRC, "hdr_math.hpp"), os.path.join(CSRC, "la_math.hpp"),
             os.path.join(CSRC, "df32_math.hpp"), os.path.join(CSRC, "bla_math.hpp"),
@@ -117,7 +166,8 @@ _INPUTS_FLAGS = ["-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 def up_to_date():
     """True when both libraries exist and were built from the current sources (no compiler is started)."""
     units = [u for u in _render_units() if os.path.exists(u)]
-    return (_stamp_ok(LIB_RENDER, _digest(units + _render_headers(), _render_flags() + [repr(sorted(_UNIT_FLAGS.items()))])) and
+    return (_stamp_ok(LIB_RENDER, _digest(units + _render_headers() + [PEEPHOLE_TOOL],
+                                          _render_flags() + [repr(sorted(_UNIT_FLAGS.items())), _peephole_state()])) and
             _stamp_ok(LIB_INPUTS, _digest(_inputs_sources(), _INPUTS_FLAGS)))
 
 
@@ -125,7 +175,7 @@ def build_render(force=False):
     units = [u for u in _render_units() if os.path.exists(u)]
     headers = _render_headers()
     flags = _render_flags()
-    digest = _digest(units + headers, flags + [repr(sorted(_UNIT_FLAGS.items()))])
+    digest = _digest(units + headers + [PEEPHOLE_TOOL], flags + [repr(sorted(_UNIT_FLAGS.items())), _peephole_state()])
     if not force and _stamp_ok(LIB_RENDER, digest):
         return LIB_RENDER
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -135,12 +185,10 @@ def build_render(force=False):
     def compile_unit(src):
         obj = os.path.join(OBJ, os.path.basename(src) + ".o")
         unit_flags = _UNIT_FLAGS.get(os.path.basename(src), [])
-        d = _digest([src], [hdr_digest, *unit_flags])
+        peep = _peephole_on(src)
+        d = _digest([src] + ([PEEPHOLE_TOOL] if peep else []), [hdr_digest, *unit_flags, "peephole" if peep else ""])
         if force or not _stamp_ok(obj, d):
-            # renderer.cpp / group.cpp are host-only C++ that include HIP runtime headers: compiled by hipcc as HIP so
-            # that <hip/hip_runtime.h> types (float4, hipStream_t) match the kernels' launchers
-            lang = [] if src.endswith(".hip") else ["-x", "hip"]
-            _run([hipcc, *flags, *unit_flags, "-c", *lang, src, "-o", obj])
+            compile_one(hipcc, src, obj, [*flags, *unit_flags], peep)
             _write_stamp(obj, d)
         return obj
 

@@ -74,6 +74,30 @@ __device__ __forceinline__ C64 add_hi_lo(C64 hi, const C64 lo)
 // arms apart (it would otherwise sink their common tail into one sequence behind operand copies).  kFirst: which agreement is
 // asked for first -- 0: the sum with a on top (2 Z + dz, Z + dz), 1: a alone (dz (2 Z + dz) + dc at a deep zoom, where dc is
 // hundreds of binades below everything else).  Mixed waves: per-lane operand select, then the same sum with the gap clamped.
+#ifndef FS_H64_ADDV
+#define FS_H64_ADDV 2 /* 2 = one vote on the SIGN of the gap, the sum with the shift clamped in every arm; 3 = votes on the ARM (a alone / a + b 2^nd / ...), no clamp in the agreed arms: 33.85 against 33.38 ms on one box (profiles/r06f_*), off */
+#endif
+#if FS_H64_ADDV == 2
+template <int kFirst = 0> __device__ __forceinline__ C64 hc_add_w(const C64 a, const C64 b)
+{
+    const bool lt = a.e < b.e;
+    const uint64_t m = __builtin_amdgcn_ballot_w64(lt);
+    if (m == 0ull) {
+        C64 r = add_hi_lo(a, b);
+        asm volatile("; hc_add_w: every lane a.e >= b.e" : "+v"(r.re), "+v"(r.im));
+        return r;
+    }
+    if (m == __builtin_amdgcn_ballot_w64(true)) {
+        C64 r = add_hi_lo(b, a);
+        asm volatile("; hc_add_w: every lane a.e < b.e" : "+v"(r.re), "+v"(r.im));
+        return r;
+    }
+    C64 hi, lo;
+    hi.re = lt ? b.re : a.re, hi.im = lt ? b.im : a.im, hi.e = lt ? b.e : a.e;
+    lo.re = lt ? a.re : b.re, lo.im = lt ? a.im : b.im, lo.e = lt ? a.e : b.e;
+    return add_hi_lo(hi, lo);
+}
+#else
 template <int kFirst = 0> __device__ __forceinline__ C64 hc_add_w(const C64 a, const C64 b)
 {
     const int nd = b.e - a.e;
@@ -100,6 +124,7 @@ template <int kFirst = 0> __device__ __forceinline__ C64 hc_add_w(const C64 a, c
     lo.re = lt ? a.re : b.re, lo.im = lt ? a.im : b.im, lo.e = lt ? a.e : b.e;
     return add_hi_lo(hi, lo);
 }
+#endif
 
 // max(|a|, |b|) as ONE instruction (source modifiers; the C++ form first canonicalises each operand)
 __device__ __forceinline__ double max_abs64(double a, double b)
@@ -234,6 +259,21 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
             }
         }
 
+        // counting build: how the waves' lanes agree (statistics words 8..15, tools/c4_arm_probe.py) -- wave steps of the perturbation
+        // loop [8], of them with lanes on different arms of the add 2Z + dz [9], dz t + dc [10], Z + dz [11], with a rebasing lane [12];
+        // wave steps of the LA loop [13], of them with lanes on different arms in any of its three adds [14], with a rebasing lane [15]
+        uint32_t w_pt = 0, w_mixA = 0, w_mixB = 0, w_mixC = 0, w_reb = 0, w_la = 0, w_lamix = 0, w_lareb = 0;
+        auto arm_of = [](const C64 a, const C64 b) {
+            const int nd = b.e - a.e;
+            return nd <= -kExpDiffIgnored ? 0 : (nd <= 0 ? 1 : (nd < kExpDiffIgnored ? 2 : 3));
+        };
+        auto mixed = [](int arm) {
+            const uint64_t all = __builtin_amdgcn_ballot_w64(true);
+            bool same = false;
+            for (int k = 0; k < 4; k++)
+                same = same || __builtin_amdgcn_ballot_w64(arm == k) == all;
+            return same ? 0u : 1u;
+        };
         uint32_t n_la = 0; // LA steps of this pixel (the frame's own cost record, FsLav2ArgsT::pixel_cost)
         uint32_t RefIteration = 0;
         const uint32_t MaxRefIteration = A.orbit_count - 1;
@@ -269,7 +309,11 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
                     const C64 RefN = ldc(LAj[1].Ref);
                     bool unusable = true;
                     C64 newDz = hc_zero<F>();
+                    if (kStats)
+                        w_la++;
                     if (iterations + l <= n_iterations) {
+                        if (kStats)
+                            w_lamix |= mixed(arm_of(C64{RefJ.re, RefJ.im, clamp_exp(RefJ.e + 1)}, dz)) << 8;
                         newDz = hc_mul(dz, hc_add_w(C64{RefJ.re, RefJ.im, clamp_exp(RefJ.e + 1)}, dz));
                         hc_reduce_w(newDz);
                         unusable = hr_cmp_pos(R64{cheb64(newDz), newDz.e}, thr) >= 0;
@@ -280,10 +324,19 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
                     }
                     iterations += l;
                     n_la++;
+                    if (kStats)
+                        w_lamix |= mixed(arm_of(hc_mul(newDz, ZCoeff), hc_mul(dc, CCoeff))) << 8;
                     dz = hc_add_w(hc_mul(newDz, ZCoeff), hc_mul(dc, CCoeff));
+                    if (kStats) {
+                        w_lamix |= mixed(arm_of(RefN, dz)) << 8;
+                        w_lamix = (w_lamix & 0xFFu) + (w_lamix >> 8 ? 1u : 0u); // (low byte... a count: one per wave step with any mixed add)
+                    }
                     const C64 complex0 = hc_add_w(RefN, dz);
                     j++;
-                    if (less_w(cheb64(complex0), complex0.e, cheb64(dz), dz.e) || j >= MacroItCount) {
+                    const bool la_rebase = less_w(cheb64(complex0), complex0.e, cheb64(dz), dz.e) || j >= MacroItCount;
+                    if (kStats)
+                        w_lareb += __builtin_amdgcn_ballot_w64(la_rebase) != 0ull ? 1u : 0u;
+                    if (la_rebase) {
                         dz = complex0;
                         j = 0;
                         RefJ = ldc(la_at_off(A.las, base_off)->Ref);
@@ -307,13 +360,21 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
             for (; iterations < n_iterations; iterations++) {
                 zoff += (uint32_t)sizeof(FsZ64);
                 const C64 Znext = z_at_off(zr, zoff);
+                if (kStats) {
+                    w_pt++;
+                    w_mixA += mixed(arm_of(C64{Zhere.re, Zhere.im, Zhere.e + 1}, dz));
+                }
                 const C64 cur = hc_add_w(C64{Zhere.re, Zhere.im, Zhere.e + 1}, dz); // (hc_mul2: x * 1.0 is x; e + 1 needs no clamp)
+                if (kStats)
+                    w_mixB += mixed(arm_of(hc_mul(dz, cur), dc));
                 C64 q = hc_add_w<1>(hc_mul(dz, cur), dc);
                 hc_reduce_w(q);
                 dz = q;
                 if (kStats)
                     c_pt++;
                 RefIteration++;
+                if (kStats)
+                    w_mixC += mixed(arm_of(Znext, dz));
                 C64 complex0 = hc_add_w(Znext, dz);
                 const double n1 = complex0.re * complex0.re + complex0.im * complex0.im;
                 const double n2 = dz.re * dz.re + dz.im * dz.im;
@@ -322,6 +383,8 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
                 if (escaped)
                     break;
                 Zhere = Znext;
+                if (kStats)
+                    w_reb += __builtin_amdgcn_ballot_w64(rebase || RefIteration >= MaxRefIteration) != 0ull ? 1u : 0u;
                 if (rebase || RefIteration >= MaxRefIteration) {
                     hc_reduce_w(complex0);
                     dz = complex0;
@@ -332,8 +395,17 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
             }
         }
         store_iter(A.out, A.frame, L, X, iterations);
-        if (kStats)
+        if (kStats) {
             c_la = n_la;
+            // one tally per wave: every lane that took part in a wave step counted it, so the first active lane's counters are the
+            // wave's for the steps it was in -- the longest lane's would be better; the first lane's are a sample, stated as such
+            if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) ==
+                (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) {
+                const uint32_t v[8] = {w_pt, w_mixA, w_mixB, w_mixC, w_reb, w_la, w_lamix, w_lareb};
+                for (int k = 0; k < 8; k++)
+                    atomicAdd((unsigned long long *)&A.stats[8 + k], (unsigned long long)v[k]);
+            }
+        }
         if (A.pixel_cost) {
             // What this pixel cost THIS kernel: its LA steps and its perturbation steps (PerformAT runs in a pass of its own).  Few
             // distinct values, so the sort that follows leaves pixels of equal cost in buffer order -- neighbours stay together.

@@ -2216,7 +2216,9 @@ static fs_renderer::PixKey pix_key_of(fs_renderer *r, const FsFrame &f, int type
 static bool pix_order_wanted(fs_renderer *r, const FsFrame &f)
 {
     const uint64_t n = (uint64_t)f.rounded_width * ((f.local_rows + 7u) & ~7u);
-    return r->iter_bytes == 4 && f.wide == 0u && !r->stats_on && n >= kPixOrderMinPixels && n < 0x7FFFFFFFull &&
+    // (FSMI355_STATS_KEEP_ORDER=1: a counting launch keeps the recorded order -- tools/c4_arm_probe.py counts what the ORDERED waves do)
+    static const bool stats_keep = [] { const char *e = getenv("FSMI355_STATS_KEEP_ORDER"); return e && e[0] == '1'; }();
+    return r->iter_bytes == 4 && f.wide == 0u && (!r->stats_on || stats_keep) && n >= kPixOrderMinPixels && n < 0x7FFFFFFFull &&
            (r->variant & FS_VARIANT_FLAG_NATURAL_ORDER) == 0 && (r->variant & FS_VARIANT_BASE_MASK) == FS_VARIANT_TUNED;
 }
 

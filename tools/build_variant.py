@@ -16,7 +16,10 @@ from fractalshark_amd import _build  # noqa: E402
 
 def main():
     name, units, defs = sys.argv[1], sys.argv[2].split(","), sys.argv[3:]
-    _build.build_render()  # the product objects the variant links with
+    # the product objects the variant links with: built by the product's own recipe (never under the variant's environment --
+    # FS_PEEPHOLE=0 for an A/B of the peephole would otherwise rebuild the PRODUCT without it)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("FS_")}  # (FS_PEEPHOLE_UNITS, FS_VERIFY_* ... belong to the variant)
+    subprocess.run([sys.executable, "-c", "from fractalshark_amd import _build; _build.build_render()"], check=True, env=env, cwd=ROOT)
     out_dir = os.path.join(ROOT, "build", "ab", name)
     os.makedirs(out_dir, exist_ok=True)
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -25,9 +28,8 @@ def main():
         base = os.path.basename(src)
         if base in units:
             obj = os.path.join(out_dir, base + ".o")
-            lang = [] if src.endswith(".hip") else ["-x", "hip"]
-            cmd = [hipcc, *_build._render_flags(), *_build._UNIT_FLAGS.get(base, []), *defs, "-c", *lang, src, "-o", obj]
-            subprocess.run(cmd, check=True)
+            _build.compile_one(hipcc, src, obj, [*_build._render_flags(), *_build._UNIT_FLAGS.get(base, []), *defs],
+                               _build._peephole_on(src))
         else:
             obj = os.path.join(_build.OBJ, base + ".o")
         objs.append(obj)

@@ -49,6 +49,15 @@ KERNEL(k_cnd_cmp, "v_cmp_lt_i32_e32 vcc, v20, v21\n v_cndmask_b32_e32 v30, v10, 
 KERNEL(k_cnd64, "v_cndmask_b32_e64 v30, v10, v12, s[20:21]\n v_cndmask_b32_e64 v31, v11, v13, s[20:21]\n v_cndmask_b32_e64 v32, v14, v16, s[22:23]\n"
                 "v_cndmask_b32_e64 v33, v15, v17, s[22:23]\n v_cndmask_b32_e64 v34, v12, v10, s[24:25]\n v_cndmask_b32_e64 v35, v13, v11, s[24:25]\n"
                 "v_cndmask_b32_e64 v36, v16, v14, s[26:27]\n v_cndmask_b32_e64 v37, v17, v15, s[26:27]")
+KERNEL(k_cnd64vcc, "v_cndmask_b32_e64 v30, v10, v12, vcc\n v_cndmask_b32_e64 v31, v11, v13, vcc\n v_cndmask_b32_e64 v32, v14, v16, vcc\n"
+                   "v_cndmask_b32_e64 v33, v15, v17, vcc\n v_cndmask_b32_e64 v34, v12, v10, vcc\n v_cndmask_b32_e64 v35, v13, v11, vcc\n"
+                   "v_cndmask_b32_e64 v36, v16, v14, vcc\n v_cndmask_b32_e64 v37, v17, v15, vcc")
+KERNEL(k_cnd32i, "v_cndmask_b32_e32 v30, v20, v21, vcc\n v_cndmask_b32_e32 v31, v21, v22, vcc\n v_cndmask_b32_e32 v32, v22, v23, vcc\n"
+                 "v_cndmask_b32_e32 v33, v23, v20, vcc\n v_cndmask_b32_e32 v34, v20, v22, vcc\n v_cndmask_b32_e32 v35, v21, v23, vcc\n"
+                 "v_cndmask_b32_e32 v36, v22, v20, vcc\n v_cndmask_b32_e32 v37, v23, v21, vcc")
+KERNEL(k_addc, "v_add_co_u32_e32 v30, vcc, v20, v21\n v_addc_co_u32_e32 v31, vcc, v21, v22, vcc\n v_add_co_u32_e32 v32, vcc, v22, v23\n"
+               "v_addc_co_u32_e32 v33, vcc, v23, v20, vcc\n v_add_co_u32_e32 v34, vcc, v20, v22\n v_addc_co_u32_e32 v35, vcc, v21, v23, vcc\n"
+               "v_add_co_u32_e32 v36, vcc, v22, v20\n v_addc_co_u32_e32 v37, vcc, v23, v21, vcc")
 KERNEL(k_clamp3, "v_add_u32_e32 v30, 0x77, v20\n v_ashrrev_i32_e32 v30, 31, v30\n v_lshl_add_u32 v31, v30, 12, v20\n v_add_u32_e32 v32, 0x77, v21\n"
                  "v_ashrrev_i32_e32 v32, 31, v32\n v_lshl_add_u32 v33, v32, 12, v21\n v_med3_i32 v34, v20, v21, v22\n v_min_i32_e32 v35, v22, v23")
 KERNEL(k_int, "v_sub_u32_e32 v30, v20, v21\n v_max_i32_e32 v31, v21, v22\n v_bfe_u32 v32, v11, 20, 11\n v_bfe_u32 v33, v13, 20, 11\n"
@@ -92,6 +101,9 @@ int main()
     run("v_cndmask_b32_e32 (vcc)", k_cnd);
     run("v_cmp_lt_i32 vcc + 7 v_cndmask_b32_e32 (vcc)", k_cnd_cmp);
     run("v_cndmask_b32_e64 (sgpr pair)", k_cnd64);
+    run("v_cndmask_b32_e64 (vcc as the mask)", k_cnd64vcc);
+    run("v_cndmask_b32_e32 (vcc), integer-register sources", k_cnd32i);
+    run("v_add_co_u32 / v_addc_co_u32 (vcc)", k_addc);
     run("add, ashrrev, lshl_add x2, med3_i32, min_i32", k_clamp3);
     run("sub, max_i32, bfe x2, cmp_i32, add3, max_u32, lshlrev", k_int);
     run("v_frexp_exp_i32_f64 / v_frexp_mant_f64", k_frexp);
