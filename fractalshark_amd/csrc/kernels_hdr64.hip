@@ -74,6 +74,10 @@ __device__ __forceinline__ C64 add_hi_lo(C64 hi, const C64 lo)
 // arms apart (it would otherwise sink their common tail into one sequence behind operand copies).  kFirst: which agreement is
 // asked for first -- 0: the sum with a on top (2 Z + dz, Z + dz), 1: a alone (dz (2 Z + dz) + dc at a deep zoom, where dc is
 // hundreds of binades below everything else).  Mixed waves: per-lane operand select, then the same sum with the gap clamped.
+#ifndef FS_H64_LA_PIPE
+#define FS_H64_LA_PIPE 1 /* the LA loop's step length travels one step ahead (0: A/B -- 33.74 against 32.41 ms; record j + 2's Ref and length two
+                            steps ahead as well: 36.5 ms with 8 waves and spills, 33.7 with 7 -- not kept) */
+#endif
 #ifndef FS_H64_ADDV
 #define FS_H64_ADDV 2 /* 2 = one vote on the SIGN of the gap, the sum with the shift clamped in every arm; 3 = votes on the ARM (a alone / a + b 2^nd / ...), no clamp in the agreed arms: 33.85 against 33.38 ms on one box (profiles/r06f_*), off */
 #endif
@@ -298,28 +302,37 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
                 uint32_t j = RefIteration;
                 // The Ref of record j + 1, read for the rebase test of step j, is the Ref step j + 1 starts from: it travels in
                 // RefJ; the rest of record j (coefficients, threshold, lengths) is requested while step j - 1 still computes.
+                // ... and so does its step length, which decides first whether the step may be taken at all: a step that had to wait
+                // for its own record's length before it could ask for the coefficients made two round trips to the cache.
                 C64 RefJ = hc_zero<F>();
-                if (iterations < n_iterations)
-                    RefJ = ldc(la_at_off(A.las, base_off + j * (uint32_t)sizeof(LaRec))->Ref);
+                uint32_t l = 0;
+                if (iterations < n_iterations) {
+                    const LaRec *__restrict__ first = la_at_off(A.las, base_off + j * (uint32_t)sizeof(LaRec));
+                    RefJ = ldc(first->Ref);
+                    l = first->StepLength;
+                }
                 while (iterations < n_iterations) {
                     const LaRec *__restrict__ LAj = la_at_off(A.las, base_off + j * (uint32_t)sizeof(LaRec));
-                    const uint32_t l = LAj->StepLength;
+#if !FS_H64_LA_PIPE
+                    l = LAj->StepLength; // (A/B: the step waits for its own record's length first, as the literal kernel does)
+#endif
+                    const uint32_t next_stage = LAj->NextStageLAIndex;
                     const C64 ZCoeff = ldc(LAj->ZCoeff), CCoeff = ldc(LAj->CCoeff);
                     const R64 thr = ldr(LAj->LAThreshold);
                     const C64 RefN = ldc(LAj[1].Ref);
-                    bool unusable = true;
-                    C64 newDz = hc_zero<F>();
+                    const uint32_t l_next = LAj[1].StepLength;
                     if (kStats)
                         w_la++;
-                    if (iterations + l <= n_iterations) {
-                        if (kStats)
-                            w_lamix |= mixed(arm_of(C64{RefJ.re, RefJ.im, clamp_exp(RefJ.e + 1)}, dz)) << 8;
-                        newDz = hc_mul(dz, hc_add_w(C64{RefJ.re, RefJ.im, clamp_exp(RefJ.e + 1)}, dz));
-                        hc_reduce_w(newDz);
-                        unusable = hr_cmp_pos(R64{cheb64(newDz), newDz.e}, thr) >= 0;
+                    if (iterations + l > n_iterations) { // the step would pass the iteration limit: unusable
+                        RefIteration = next_stage;
+                        break;
                     }
-                    if (unusable) {
-                        RefIteration = LAj->NextStageLAIndex;
+                    if (kStats)
+                        w_lamix |= mixed(arm_of(C64{RefJ.re, RefJ.im, clamp_exp(RefJ.e + 1)}, dz)) << 8;
+                    C64 newDz = hc_mul(dz, hc_add_w(C64{RefJ.re, RefJ.im, clamp_exp(RefJ.e + 1)}, dz));
+                    hc_reduce_w(newDz);
+                    if (hr_cmp_pos(R64{cheb64(newDz), newDz.e}, thr) >= 0) { // LAInfoDeep::Prepare's unusable
+                        RefIteration = next_stage;
                         break;
                     }
                     iterations += l;
@@ -340,8 +353,10 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
                         dz = complex0;
                         j = 0;
                         RefJ = ldc(la_at_off(A.las, base_off)->Ref);
+                        l = la_at_off(A.las, base_off)->StepLength;
                     } else {
                         RefJ = RefN;
+                        l = l_next;
                     }
                 }
                 if (iterations >= n_iterations)
