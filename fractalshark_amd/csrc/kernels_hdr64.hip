@@ -199,6 +199,36 @@ __device__ __forceinline__ C64 z_at_off(const FsZ64 *__restrict__ z, uint32_t by
     return C64{p->re, p->im, p->e};
 }
 
+// Lane -> pixel under a recorded order, XCD-aware.  The hardware hands workgroup b to XCD b mod 8, each XCD with an L2 of its own; in
+// plain launch order eight NEIGHBOURING workgroups -- whose pixels, adjacent in the count order, walk the same LA records -- land on
+// eight different L2s and every L2 sees the whole 15-MB table.  Here XCD x takes runs of FS_H64_XCD_RUN consecutive positions of the
+// order (virtual workgroup v = group * 8 R + x * R + r for the r-th workgroup the XCD receives in the group), so the workgroups that
+// share records share an L2, while every XCD still gets an even share of every stretch of the order.
+#ifndef FS_H64_XCD_RUN
+#define FS_H64_XCD_RUN 0
+#endif
+__device__ __forceinline__ void ordered_pixel_xcd(const FsFrame &f, const uint32_t *__restrict__ order, uint32_t &X, uint32_t &L)
+{
+    uint32_t b = blockIdx.y * gridDim.x + blockIdx.x;
+#if FS_H64_XCD_RUN > 0
+    constexpr uint32_t R = FS_H64_XCD_RUN, G = 8u * R;
+    const uint32_t nb = gridDim.x * gridDim.y;
+    if (b < nb / G * G) {
+        const uint32_t g = b / G, w = b % G;
+        b = g * G + (w % 8u) * R + w / 8u;
+    }
+#endif
+    const uint32_t slot = b * blockDim.x + threadIdx.x;
+    const uint32_t n = f.rounded_width * ((f.local_rows + 7u) & ~7u);
+    if (slot < n) {
+        const uint32_t id = order[slot];
+        L = id / f.rounded_width;
+        X = id - L * f.rounded_width;
+    } else {
+        X = 0xFFFFFFFFu, L = 0xFFFFFFFFu;
+    }
+}
+
 // Statistics words of the counting build (fs_read_step_count / tools): [8] steps whose adds ran the mixed (select) form, [9] wave
 // steps of the perturbation loop, [10] wave steps of the LA loop
 // FS_H64_WAVES (A/B builds): 8 = the register allocator is held to 64 registers (8 waves per SIMD; it spills three or four dwords),
@@ -219,7 +249,7 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
     using LaRec = fs_la_hdr64_u32;
     uint32_t X, L;
     if (A.pixel_order)
-        ordered_pixel(A.frame, A.pixel_order, X, L);
+        ordered_pixel_xcd(A.frame, A.pixel_order, X, L);
     else
         tile_pixel(X, L);
     uint64_t c_at = 0, c_la = 0, c_pt = 0, c_px = 0, c_at_exec = 0, c_at_own = 0;
@@ -304,36 +334,34 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
                 // RefJ; the rest of record j (coefficients, threshold, lengths) is requested while step j - 1 still computes.
                 // ... and so does its step length, which decides first whether the step may be taken at all: a step that had to wait
                 // for its own record's length before it could ask for the coefficients made two round trips to the cache.
-                C64 RefJ = hc_zero<F>();
-                uint32_t l = 0;
-                if (iterations < n_iterations) {
-                    const LaRec *__restrict__ first = la_at_off(A.las, base_off + j * (uint32_t)sizeof(LaRec));
-                    RefJ = ldc(first->Ref);
-                    l = first->StepLength;
-                }
-                while (iterations < n_iterations) {
+                // One LA step: leaves from record j with its Ref in RJ and its step length in lJ (both read one step ahead), reads the
+                // rest of record j and, into RN / lN, the Ref and length of record j + 1.  The loop calls it twice per trip with the two
+                // register sets' roles exchanged (no copies).  -> true: the stage is left (RefIteration set).
+                auto la_step = [&](const C64 &RJ, const uint32_t &lJ, C64 &RN, uint32_t &lN) __attribute__((always_inline)) -> bool {
                     const LaRec *__restrict__ LAj = la_at_off(A.las, base_off + j * (uint32_t)sizeof(LaRec));
 #if !FS_H64_LA_PIPE
-                    l = LAj->StepLength; // (A/B: the step waits for its own record's length first, as the literal kernel does)
+                    const uint32_t l = LAj->StepLength; // (A/B: the step waits for its own record's length first, as the literal kernel does)
+#else
+                    const uint32_t l = lJ;
 #endif
                     const uint32_t next_stage = LAj->NextStageLAIndex;
                     const C64 ZCoeff = ldc(LAj->ZCoeff), CCoeff = ldc(LAj->CCoeff);
                     const R64 thr = ldr(LAj->LAThreshold);
-                    const C64 RefN = ldc(LAj[1].Ref);
-                    const uint32_t l_next = LAj[1].StepLength;
+                    RN = ldc(LAj[1].Ref);
+                    lN = LAj[1].StepLength;
                     if (kStats)
                         w_la++;
                     if (iterations + l > n_iterations) { // the step would pass the iteration limit: unusable
                         RefIteration = next_stage;
-                        break;
+                        return true;
                     }
                     if (kStats)
-                        w_lamix |= mixed(arm_of(C64{RefJ.re, RefJ.im, clamp_exp(RefJ.e + 1)}, dz)) << 8;
-                    C64 newDz = hc_mul(dz, hc_add_w(C64{RefJ.re, RefJ.im, clamp_exp(RefJ.e + 1)}, dz));
+                        w_lamix |= mixed(arm_of(C64{RJ.re, RJ.im, clamp_exp(RJ.e + 1)}, dz)) << 8;
+                    C64 newDz = hc_mul(dz, hc_add_w(C64{RJ.re, RJ.im, clamp_exp(RJ.e + 1)}, dz));
                     hc_reduce_w(newDz);
                     if (hr_cmp_pos(R64{cheb64(newDz), newDz.e}, thr) >= 0) { // LAInfoDeep::Prepare's unusable
                         RefIteration = next_stage;
-                        break;
+                        return true;
                     }
                     iterations += l;
                     n_la++;
@@ -341,10 +369,10 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
                         w_lamix |= mixed(arm_of(hc_mul(newDz, ZCoeff), hc_mul(dc, CCoeff))) << 8;
                     dz = hc_add_w(hc_mul(newDz, ZCoeff), hc_mul(dc, CCoeff));
                     if (kStats) {
-                        w_lamix |= mixed(arm_of(RefN, dz)) << 8;
-                        w_lamix = (w_lamix & 0xFFu) + (w_lamix >> 8 ? 1u : 0u); // (low byte... a count: one per wave step with any mixed add)
+                        w_lamix |= mixed(arm_of(RN, dz)) << 8;
+                        w_lamix = (w_lamix & 0xFFu) + (w_lamix >> 8 ? 1u : 0u); // (one per wave step with any mixed add)
                     }
-                    const C64 complex0 = hc_add_w(RefN, dz);
+                    const C64 complex0 = hc_add_w(RN, dz);
                     j++;
                     const bool la_rebase = less_w(cheb64(complex0), complex0.e, cheb64(dz), dz.e) || j >= MacroItCount;
                     if (kStats)
@@ -352,12 +380,25 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
                     if (la_rebase) {
                         dz = complex0;
                         j = 0;
-                        RefJ = ldc(la_at_off(A.las, base_off)->Ref);
-                        l = la_at_off(A.las, base_off)->StepLength;
-                    } else {
-                        RefJ = RefN;
-                        l = l_next;
+                        RN = ldc(la_at_off(A.las, base_off)->Ref);
+                        lN = la_at_off(A.las, base_off)->StepLength;
                     }
+                    return false;
+                };
+                C64 RefA = hc_zero<F>(), RefB = hc_zero<F>();
+                uint32_t lA = 0, lB = 0;
+                if (iterations < n_iterations) {
+                    const LaRec *__restrict__ first = la_at_off(A.las, base_off + j * (uint32_t)sizeof(LaRec));
+                    RefA = ldc(first->Ref);
+                    lA = first->StepLength;
+                }
+                while (iterations < n_iterations) {
+                    if (la_step(RefA, lA, RefB, lB))
+                        break;
+                    if (!(iterations < n_iterations))
+                        break;
+                    if (la_step(RefB, lB, RefA, lA))
+                        break;
                 }
                 if (iterations >= n_iterations)
                     break;
@@ -367,19 +408,20 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
         const uint32_t it_la = iterations;
         if (Mode != FS_MODE_LAO) {
             const FsZ64 *__restrict__ zr = A.zref;
-            C64 Zhere = hc_zero<F>();
             uint32_t zoff = RefIteration * (uint32_t)sizeof(FsZ64); // byte offset of the entry the step leaves from
-            if (iterations < n_iterations)
-                Zhere = z_at_off(zr, zoff);
-            // (as in the literal kernel: one orbit load per step, not two; Reduce(z) before |z|^2 only re-labels z)
-            for (; iterations < n_iterations; iterations++) {
+            const uint32_t max_off = MaxRefIteration * (uint32_t)sizeof(FsZ64);
+            // One step: leaves from the entry in ZH, arrives at the entry it loads into ZN.  The loop below calls it twice per trip
+            // with the two registers' roles exchanged, so that "the entry a step arrives at is the entry the next one leaves from"
+            // costs no copy.  (As in the literal kernel: one orbit load per step, not two; Reduce(z) before |z|^2 only re-labels z.)
+            // -> true: this lane's pixel has escaped.
+            auto pt_step = [&](const C64 &ZH, C64 &ZN) __attribute__((always_inline)) -> bool {
                 zoff += (uint32_t)sizeof(FsZ64);
-                const C64 Znext = z_at_off(zr, zoff);
+                ZN = z_at_off(zr, zoff);
                 if (kStats) {
                     w_pt++;
-                    w_mixA += mixed(arm_of(C64{Zhere.re, Zhere.im, Zhere.e + 1}, dz));
+                    w_mixA += mixed(arm_of(C64{ZH.re, ZH.im, ZH.e + 1}, dz));
                 }
-                const C64 cur = hc_add_w(C64{Zhere.re, Zhere.im, Zhere.e + 1}, dz); // (hc_mul2: x * 1.0 is x; e + 1 needs no clamp)
+                const C64 cur = hc_add_w(C64{ZH.re, ZH.im, ZH.e + 1}, dz); // (hc_mul2: x * 1.0 is x; e + 1 needs no clamp)
                 if (kStats)
                     w_mixB += mixed(arm_of(hc_mul(dz, cur), dc));
                 C64 q = hc_add_w<1>(hc_mul(dz, cur), dc);
@@ -387,26 +429,38 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
                 dz = q;
                 if (kStats)
                     c_pt++;
-                RefIteration++;
                 if (kStats)
-                    w_mixC += mixed(arm_of(Znext, dz));
-                C64 complex0 = hc_add_w(Znext, dz);
+                    w_mixC += mixed(arm_of(ZN, dz));
+                C64 complex0 = hc_add_w(ZN, dz);
                 const double n1 = complex0.re * complex0.re + complex0.im * complex0.im;
                 const double n2 = dz.re * dz.re + dz.im * dz.im;
                 bool escaped, rebase;
                 step_tests_w(n1, complex0.e << 1, n2, dz.e << 1, escaped, rebase);
                 if (escaped)
-                    break;
-                Zhere = Znext;
+                    return true;
+                rebase = rebase || zoff >= max_off; // (RefIteration >= MaxRefIteration)
                 if (kStats)
-                    w_reb += __builtin_amdgcn_ballot_w64(rebase || RefIteration >= MaxRefIteration) != 0ull ? 1u : 0u;
-                if (rebase || RefIteration >= MaxRefIteration) {
+                    w_reb += __builtin_amdgcn_ballot_w64(rebase) != 0ull ? 1u : 0u;
+                if (rebase) {
                     hc_reduce_w(complex0);
                     dz = complex0;
-                    RefIteration = 0;
                     zoff = 0;
-                    Zhere = z_at_off(zr, 0u);
+                    ZN = z_at_off(zr, 0u);
                 }
+                return false;
+            };
+            C64 ZA = hc_zero<F>(), ZB = hc_zero<F>();
+            if (iterations < n_iterations)
+                ZA = z_at_off(zr, zoff);
+            while (iterations < n_iterations) {
+                if (pt_step(ZA, ZB))
+                    break;
+                iterations++;
+                if (!(iterations < n_iterations))
+                    break;
+                if (pt_step(ZB, ZA))
+                    break;
+                iterations++;
             }
         }
         store_iter(A.out, A.frame, L, X, iterations);
