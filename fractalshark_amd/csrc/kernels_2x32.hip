@@ -331,34 +331,59 @@ __global__ void __launch_bounds__(256) k_lav2_2x32(FsLav2Args2x32 A)
                     continue;
                 const uint32_t MacroItCount = A.stages[CurrentLAStage].MacroItCount;
                 uint32_t j = RefIteration;
-                while (iter < n_iterations) {
+                // (round 6, as k_lav2_hdr64) The Ref and the step length of record j are read ONE STEP AHEAD -- record j + 1's Ref is
+                // read by step j anyway, for its rebase test, and the length decides first whether the step may be taken: a step that
+                // waits for its own record's length before it asks for the coefficients makes two round trips to the cache.  Two steps
+                // per trip with the two register sets' roles exchanged: nothing is copied.  -> true: the stage is left.
+                auto la_step = [&](const HC &RJ, const uint32_t &lJ, HC &RN, uint32_t &lN) __attribute__((always_inline)) -> bool {
                     const fs_la_2x32_u32 *LAj = &A.las[LAIndex + j]; // getLA, GPU_LAReference.h:271-303
-                    const uint32_t l = LAj->StepLength;
-                    bool unusable = true;
-                    HC newDz = hc_zero<df32>();
-                    if (iter + l <= n_iterations) {
-                        // Prepare, GPU_LAInfoDeep.h:90-106
-                        newDz = hc_mul_pk(DeltaSubN, hc_add_pk(hc_mul2_pk(ldc(LAj->Ref)), DeltaSubN));
-                        hc_reduce(newDz);
-                        unusable = hr_cmp_pos(hc_cheb(newDz), ldr(LAj->LAThreshold)) >= 0;
+                    const uint32_t l = lJ;
+                    const uint32_t next_stage = LAj->NextStageLAIndex;
+                    const HC ZCoeff = ldc(LAj->ZCoeff), CCoeff = ldc(LAj->CCoeff);
+                    const HR thr = ldr(LAj->LAThreshold);
+                    RN = ldc(LAj[1].Ref);
+                    lN = LAj[1].StepLength;
+                    if (iter + l > n_iterations) { // the step would pass the iteration limit: unusable
+                        RefIteration = next_stage;
+                        return true;
                     }
-                    if (unusable) {
-                        RefIteration = LAj->NextStageLAIndex;
-                        break;
+                    // Prepare, GPU_LAInfoDeep.h:90-106
+                    HC newDz = hc_mul_pk(DeltaSubN, hc_add_pk(hc_mul2_pk(RJ), DeltaSubN));
+                    hc_reduce(newDz);
+                    if (hr_cmp_pos(hc_cheb(newDz), thr) >= 0) {
+                        RefIteration = next_stage;
+                        return true;
                     }
                     iter += l;
                     if (kStats)
                         c_la++;
                     // Evaluate GPU_LAInfoDeep.h:120-124, getZ LAstep.h:181-185
-                    DeltaSubN = hc_add_pk(hc_mul_pk(newDz, ldc(LAj->ZCoeff)), hc_mul_pk(DeltaSub0, ldc(LAj->CCoeff)));
-                    const HC complex0 = hc_add_pk(ldc(LAj[1].Ref), DeltaSubN);
+                    DeltaSubN = hc_add_pk(hc_mul_pk(newDz, ZCoeff), hc_mul_pk(DeltaSub0, CCoeff));
+                    const HC complex0 = hc_add_pk(RN, DeltaSubN);
                     j++;
                     const HR lhs = hr_reduced(hc_cheb(complex0));
                     const HR rhs = hr_reduced(hc_cheb(DeltaSubN));
                     if (hr_cmp_pos(lhs, rhs) < 0 || j >= MacroItCount) {
                         DeltaSubN = complex0;
                         j = 0;
+                        RN = ldc(A.las[LAIndex].Ref);
+                        lN = A.las[LAIndex].StepLength;
                     }
+                    return false;
+                };
+                HC RefA = hc_zero<df32>(), RefB = hc_zero<df32>();
+                uint32_t lA = 0, lB = 0;
+                if (iter < n_iterations) {
+                    RefA = ldc(A.las[LAIndex + j].Ref);
+                    lA = A.las[LAIndex + j].StepLength;
+                }
+                while (iter < n_iterations) {
+                    if (la_step(RefA, lA, RefB, lB))
+                        break;
+                    if (!(iter < n_iterations))
+                        break;
+                    if (la_step(RefB, lB, RefA, lA))
+                        break;
                 }
                 if (iter >= n_iterations)
                     break;
