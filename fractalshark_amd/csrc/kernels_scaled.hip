@@ -220,60 +220,40 @@ __device__ __forceinline__ uint32_t scaled_run(const fs_orbit_f32_bad *__restric
     float mx_##T = __builtin_fmaxf(__builtin_fabsf(N.x), __builtin_fabsf(N.y));                                      \
     WAIT;                                                                                                            \
     const bool ok_##T = mx_##T * s <= ent_##T.y && mx_##T < 0x1p24f;
-    // (round 6) Two sets of four entries, in rotation: a body requests the NEXT body's four entries before it consumes its own, which
-    // were requested one body ago -- a wave no longer waits for a round trip to the cache once per four steps.  The loop is two
-    // bodies per trip with the sets' roles exchanged (no copies).  Loads complete in order, so with the next body's four requests
-    // behind them this body's entries are there at vmcnt 7, 6, 5, 4.  (The orbit is padded by eight entries: a run never arrives
-    // at the last entry, so the furthest request is at count + 6.)
     f4 ent_a, ent_b, ent_c, ent_d; // {bad, bound, x, y}
-    f4 ent_e, ent_f, ent_g, ent_h;
-    // The entry values of the run's first step come from a load the compiler knows about; it would wait for it where they are first
-    // used -- inside the loop, behind the body's requests.  Used here, the wait stays outside the loop.
-    asm volatile("; scaled_run: entry values ready" : "+v"(e), "+v"(o));
-    FS_SC_LOAD("0", a, o.x)
-    FS_SC_LOAD("16", b, o.x)
-    FS_SC_LOAD("32", c, o.x)
-    FS_SC_LOAD("48", d, o.x)
-#define FS_SC_BODY(A_, B_, C_, D_, NA_, NB_, NC_, ND_)                                                              \
-    FS_SC_LOAD("64", NA_, o.x)                                                                                      \
-    FS_SC_LOAD("80", NB_, o.x)                                                                                      \
-    FS_SC_LOAD("96", NC_, o.x)                                                                                      \
-    FS_SC_LOAD("112", ND_, o.x)                                                                                     \
-    {                                                                                                               \
-        FS_SC_STEP(o, e, n1, A_, asm volatile("s_waitcnt vmcnt(7)" : "+v"(ent_##A_), "+v"(mx_##A_)))                  \
-        if (__builtin_amdgcn_ballot_w64(!ok_##A_) != 0ull)                                                          \
-            break;                                                                                                  \
-        const f2 e1 = {ent_##A_.z, ent_##A_.w};                                                                     \
-        FS_SC_STEP(n1, e1, n2, B_, asm volatile("s_waitcnt vmcnt(6)" : "+v"(ent_##B_), "+v"(mx_##B_)))                \
-        if (__builtin_amdgcn_ballot_w64(!ok_##B_) != 0ull) {                                                        \
-            o = n1, e = e1, c += 1;                                                                                 \
-            break;                                                                                                  \
-        }                                                                                                           \
-        const f2 e2 = {ent_##B_.z, ent_##B_.w};                                                                     \
-        FS_SC_STEP(n2, e2, n3, C_, asm volatile("s_waitcnt vmcnt(5)" : "+v"(ent_##C_), "+v"(mx_##C_)))                \
-        if (__builtin_amdgcn_ballot_w64(!ok_##C_) != 0ull) {                                                        \
-            o = n2, e = e2, c += 2;                                                                                 \
-            break;                                                                                                  \
-        }                                                                                                           \
-        const f2 e3 = {ent_##C_.z, ent_##C_.w};                                                                     \
-        FS_SC_STEP(n3, e3, n4, D_, asm volatile("s_waitcnt vmcnt(4)" : "+v"(ent_##D_), "+v"(mx_##D_)))                \
-        if (__builtin_amdgcn_ballot_w64(!ok_##D_) != 0ull) {                                                        \
-            o = n3, e = e3, c += 3;                                                                                 \
-            break;                                                                                                  \
-        }                                                                                                           \
-        o = n4, e = (f2){ent_##D_.z, ent_##D_.w}, c += 4;                                                           \
-        zp += 4;                                                                                                    \
-        if (c >= run_len)                                                                                           \
-            break;                                                                                                  \
-    }
     for (;;) {
-        FS_SC_BODY(a, b, c, d, e, f, g, h)
-        FS_SC_BODY(e, f, g, h, a, b, c, d)
+        FS_SC_LOAD("0", a, o.x)
+        FS_SC_LOAD("16", b, o.x)
+        FS_SC_LOAD("32", c, o.x)
+        FS_SC_LOAD("48", d, o.x)
+        FS_SC_STEP(o, e, n1, a, asm volatile("s_waitcnt vmcnt(3)" : "+v"(ent_a), "+v"(mx_a)))
+        if (__builtin_amdgcn_ballot_w64(!ok_a) != 0ull)
+            break;
+        const f2 e1 = {ent_a.z, ent_a.w};
+        FS_SC_STEP(n1, e1, n2, b, asm volatile("s_waitcnt vmcnt(2)" : "+v"(ent_b), "+v"(mx_b)))
+        if (__builtin_amdgcn_ballot_w64(!ok_b) != 0ull) {
+            o = n1, e = e1, c += 1;
+            break;
+        }
+        const f2 e2 = {ent_b.z, ent_b.w};
+        FS_SC_STEP(n2, e2, n3, c, asm volatile("s_waitcnt vmcnt(1)" : "+v"(ent_c), "+v"(mx_c)))
+        if (__builtin_amdgcn_ballot_w64(!ok_c) != 0ull) {
+            o = n2, e = e2, c += 2;
+            break;
+        }
+        const f2 e3 = {ent_c.z, ent_c.w};
+        FS_SC_STEP(n3, e3, n4, d, asm volatile("s_waitcnt vmcnt(0)" : "+v"(ent_d), "+v"(mx_d)))
+        if (__builtin_amdgcn_ballot_w64(!ok_d) != 0ull) {
+            o = n3, e = e3, c += 3;
+            break;
+        }
+        o = n4, e = (f2){ent_d.z, ent_d.w}, c += 4;
+        zp += 4;
+        if (c >= run_len)
+            break;
     }
-#undef FS_SC_BODY
     // a run that ends early leaves loads in flight: they land before anything else happens
-    asm volatile("s_waitcnt vmcnt(0) ; scaled-kernel run, loop exit" ::"v"(ent_a), "v"(ent_b), "v"(ent_c), "v"(ent_d), "v"(ent_e),
-                 "v"(ent_f), "v"(ent_g), "v"(ent_h));
+    asm volatile("s_waitcnt vmcnt(0) ; scaled-kernel run, loop exit" ::"v"(ent_a), "v"(ent_b), "v"(ent_c), "v"(ent_d));
 #undef FS_SC_STEP
 #undef FS_SC_LOAD
     wX = o.x, wY = o.y, cfx = e.x, cfy = e.y;
