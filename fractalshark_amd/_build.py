@@ -77,7 +77,7 @@ def _render_flags():
     extra = ["-DFS_PROFILE_CYCLES"] if os.environ.get("FS_PROFILE_CYCLES") == "1" else []
     if os.environ.get("FS_VERIFY_BLOCK_BOUND") == "1":  # tools/block_bound_check.py: the untested loop off, violations counted
         extra.append("-DFS_VERIFY_BLOCK_BOUND")
-    if os.environ.get("FS_BACKOFF_CAP"):  # A/B: back-off cap of the scaled-run attempts (kernels.hip; 0 = off)
+    if os.environ.get("FS_BACKOFF_CAP"):  # A/B: back-off cap of the scaled-run attempts (scaled_runs.hpp; 0 = off)
         extra.append("-DFS_BACKOFF_CAP=%d" % int(os.environ["FS_BACKOFF_CAP"]))
     if os.environ.get("FS_TRACE_WAVES") == "1":  # tools/wave_trace.py: per-wave start / end / SIMD records
         extra.append("-DFS_TRACE_WAVES")

@@ -1,4 +1,4 @@
-// kernel_common.hpp -- small device helpers shared by the kernel translation units (kernels.hip, kernels_2x32.hip).
+// kernel_common.hpp -- small device helpers shared by the kernel translation units (kernels*.hip).
 #pragma once
 
 #include <hip/hip_runtime.h>

@@ -1,4 +1,4 @@
-// kernels.h -- argument blocks and launch entry points shared by renderer.cpp (host) and kernels.hip.
+// kernels.h -- argument blocks and launch entry points shared by renderer.cpp (host) and the kernel translation units (kernels*.hip).
 // Kernel arguments are plain PODs passed by value (well under the 4 KB kernarg limit), instead of the
 // reference's by-value copies of non-trivial classes (GPUPerturbSingleResults, GPU_LAReference incl. ATInfo,
 // GPU_BLAS -- SURVEY.md appendix B).
@@ -397,6 +397,7 @@ void fsk_bla_hdr32_fast(const FsBlaArgs32 &A, bool pool, hipStream_t s);
 size_t fsk_pixel_order_temp_bytes(uint32_t n);
 hipError_t fsk_pixel_order_build(const uint32_t *counts, uint32_t n, uint32_t *work, uint32_t *order, void *temp, size_t temp_bytes,
                                  hipStream_t s, int key_bits = 32);
+void fsk_lav2_lit32(const FsLav2Args32 &A, int mode, bool stats, dim3 g, dim3 b, hipStream_t s); // kernels.hip
 void fsk_lav2_hdr64_fast(const FsLav2ArgsT<double> &A, int mode, bool stats, hipStream_t s); // kernels_hdr64.hip
 void fsk_perturb_scalar_hdr64(const FsBlaArgsT<double> &A, bool use_bla, bool stats, int variant, hipStream_t s);
 void fsk_perturb_bla_f64(const FsBlaArgsF64 &A, bool use_bla, bool stats, hipStream_t s);

@@ -1,7 +1,7 @@
 // kernels_bla_fast.hip -- the HDRFloat<float> perturbation + BLA kernel (GpuHDRx32PerturbedBLA <-> Cpu32PerturbedBLAHDR,
 // Fractal.cpp:2266-2470; BLAKernels.cuh:193-434; BLAS::LookupBackwards, BLAS.cpp:256-310) with its hot loop written by hand.
 //
-// Round 5.  The compiled kernel (k_perturb_scalar<float, kBla, kNat>, kernels.hip) issues 329 vector and 133 scalar
+// Round 5.  The compiled kernel (k_perturb_scalar<float, kBla, kNat>, kernels_perturb.hip) issues 329 vector and 133 scalar
 // instructions per outer trip of a wave on C5 (rocprofv3, profiles/r05a_c5_*) and is bound by vector issue; a third of
 // them are the structurizer's copies between the exits of its two nested loops, exponent alignment through factor +
 // multiply, votes lowered to v_cndmask + v_cmp, and 64-bit level pointers.  Here the per-pixel state lives in sixteen named
@@ -11,7 +11,7 @@
 //            the walk's first element, its level}; one compare; ladder rounds of two 16-byte loads and four 64-bit compares.
 //            The table is numbered like a binary heap -- element ix of level L sits at 2^(H - L) + ix -- so the element one
 //            level down is at twice the position: no level offsets, no LDS, no count-trailing-zeros per lookup.
-//   jump     BLA::getValue in the alignment-free form of kernels.hip (every product scaled to the maximum of the four
+//   jump     BLA::getValue in the alignment-free form of kernels_perturb.hip (every product scaled to the maximum of the four
 //            exponents with v_ldexp_f32 on the product itself), the quiet form only (both parts of the new dz four binades
 //            below the orbit value it arrives at: 99.95 % of C5's jumps, profiles/r05c_c5_actions.json); what a record must
 //            satisfy for it is decided when the table is made and poisons the record's arrival exponent.
@@ -154,7 +154,7 @@ __device__ __forceinline__ hcplx32 zref_entry(const float4 *__restrict__ z, uint
     return hcplx32{v.x, v.y, __float_as_int(v.z)};
 }
 
-// BLAS::LookupBackwards on the native table (kernels.hip bla_lookup_native, per lane, without its wave votes): position or ~0u.
+// BLAS::LookupBackwards on the native table (kernels_perturb.hip bla_lookup_native, per lane, without its wave votes): position or ~0u.
 __device__ __forceinline__ uint32_t lookup_literal(const FsBlaArgsT<float> &A, uint32_t m, hreal32 z2)
 {
     if (m == 0u)
@@ -667,7 +667,7 @@ template <bool kPool> __global__ void __launch_bounds__(256) k_bla_hdr32_fast(Fs
     uint32_t ref = 0, iter = 0;
     if (have) {
         hreal32 a, b;
-        // Pixel -> delta c, Fractal.cpp:2272-2281 (kernels.hip pixel_delta)
+        // Pixel -> delta c, Fractal.cpp:2272-2281 (lav2_common.hpp pixel_delta)
         a = hr_mul(A.coords.dx, hr_from_mant<float>((float)X));
         hr_reduce(a);
         a = hr_sub(a, A.coords.centerX);

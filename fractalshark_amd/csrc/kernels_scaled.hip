@@ -32,7 +32,7 @@ __device__ __forceinline__ H orb_x(const fs_orbit_hdr32_bad *__restrict__ o, uin
 __device__ __forceinline__ H orb_y(const fs_orbit_hdr32_bad *__restrict__ o, uint32_t i) { return H{o[i].my, o[i].ey}; }
 
 // steps of the next run of the tuned kernel: 256 / 64 / 16, the most that every running lane still has before its
-// iteration limit (three votes per run instead of a counter per step; the same scheme as scaled_run_length in kernels.hip)
+// iteration limit (three votes per run instead of a counter per step; the same scheme as scaled_run_length in scaled_runs.hpp)
 __device__ __forceinline__ uint32_t scaled_run_length_dev(uint32_t left)
 {
     if (__builtin_amdgcn_ballot_w64(left < 256u) == 0ull)
@@ -279,7 +279,7 @@ __device__ __forceinline__ uint32_t scaled_run(const fs_orbit_f32_bad *__restric
 // A run of such steps is wave-voted: it continues while EVERY running lane passes, the step that fails is dropped for the
 // whole wave and every lane takes one step through the literal code, which decides exactly.  Lanes whose iteration limit
 // is near are kept out of the runs by a vote on the steps left (runs of 256 / 64 / 16 steps, scaled_run_length in
-// kernels.hip does the same).  The entry of a step is one 16-byte load per lane, requested four steps ahead from a
+// scaled_runs.hpp does the same).  The entry of a step is one 16-byte load per lane, requested four steps ahead from a
 // wave-uniform base plus a per-lane byte offset that is fixed for the run.  (Entries through the scalar cache when the lanes
 // share their orbit position, which pays in k_lav2_hdr32_fast, does not here: 325 vs 315 ms on View 14, whose runs
 // average 37 steps -- profiles/patches/r02_t_*.)

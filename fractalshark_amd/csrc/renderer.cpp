@@ -60,7 +60,7 @@ struct fs_renderer {
     uint64_t *stats = nullptr;
     size_t stats_words = 32;
 
-    uint32_t *queue = nullptr; // pixel counter of the persistent launches (kernels.hip, k_perturb_scalar)
+    uint32_t *queue = nullptr; // pixel counter of the persistent launches (kernels_perturb.hip, k_perturb_scalar)
     uint32_t *tile_probe = nullptr, *tile_order = nullptr; // "long tiles first" (fs_render_bla): probe counts, launch order
     size_t tile_probe_cap = 0, tile_order_cap = 0;           // in elements
     // "longest tiles first" of the tuned LAv2 kernel (fs_render_lav2): the costs the last frame recorded per 8 x 8 tile, the

@@ -1,4 +1,4 @@
-"""The wave-uniform block threshold of the tuned HDRFloat<float> LAv2 loop (FS_BT_T in csrc/kernels.hip), evaluated on the device by
+"""The wave-uniform block threshold of the tuned HDRFloat<float> LAv2 loop (FS_BT_T in csrc/scaled_runs.hpp), evaluated on the device by
 the loop's own macro and held against its definition:  T = -1 ("never") when the wave's largest max|dc| exceeds the block bound --
 which a "never" bound, the most negative integer, always is -- and min(bound - largest scale shift, bits(2^14)) otherwise, without
 wrap-around.  The first form of the macro replaced the "never" bound by -2^30 before subtracting: positive again for scale shifts

@@ -1,5 +1,5 @@
 """The hand-scheduled loops of the tuned kernels name physical registers inside one `asm` statement (FS_FAST_LOOP,
-FS_FAST_LOOP_FL, FS_FAST_LOOP_FD in csrc/kernels.hip).  tools/check_asm_registers.py finds every such loop in the BUILT gfx950
+FS_FAST_LOOP_FL, FS_FAST_LOOP_FD in csrc/scaled_runs.hpp).  tools/check_asm_registers.py finds every such loop in the BUILT gfx950
 code and proves, with a liveness analysis over the function's control-flow graph, that none of the loop's scratch registers
 (v[56:59], v61, v62, s[36:63], s66) is live on the loop's exits -- i.e. the compiler keeps no value of its own in them across
 the statement -- and that the loop writes no vector register it does not name.  CPU only: it inspects the library."""
