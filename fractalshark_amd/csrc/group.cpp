@@ -169,8 +169,16 @@ fs_group *fs_group_create(const int *devices, int n_devices, int transport)
     if (g->transport == 0) {
         Rccl &q = rccl();
         g->comms.assign((size_t)n_devices, nullptr);
+        // (advisor, round 5) The dmabuf-IPC switch only works when it was in the environment BEFORE the ROCm runtime came up: the
+        // constructor above sets it when this library is loaded, which is too late in a process that made a HIP call first (or
+        // imported torch first).  Say so instead of failing later with "invalid argument".
+        const char *ipc = getenv("HSA_ENABLE_IPC_MODE_LEGACY");
+        if (!ipc || strcmp(ipc, "0") != 0)
+            fprintf(stderr, "fsmi355: HSA_ENABLE_IPC_MODE_LEGACY is %s: RCCL between the group's devices needs it to be 0 in the environment "
+                            "before the first HIP call of the process (load libfsmi355 first, or export it)\n", ipc ? ipc : "unset");
         if (!q.ok || q.CommInitAll(g->comms.data(), n_devices, devices) != 0) {
-            fprintf(stderr, "fsmi355: RCCL unavailable or ncclCommInitAll failed; the group falls back to peer copies\n");
+            fprintf(stderr, "fsmi355: RCCL unavailable or ncclCommInitAll failed (if the log above it says hipIpcGetMemHandle: invalid argument, "
+                            "HSA_ENABLE_IPC_MODE_LEGACY=0 was not in the environment when the ROCm runtime came up); the group falls back to peer copies\n");
             g->comms.clear();
             g->transport = 1;
         }

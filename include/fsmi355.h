@@ -302,7 +302,9 @@ uint32_t fs_get_height(const fs_renderer *r);
  * drop-in of INTEGRATION.md is one process), RCCL communicators from ncclCommInitAll.  Rank r renders the 8-row bands
  * k*N + r (24-row bands for antialiasing 3) with the global-row delta-c mapping of fs_set_row_bands; slices are sent to
  * device 0 with ncclSend / ncclRecv in one ncclGroup on the members' compute streams, one kernel restores row order.
- * transport: 0 = RCCL (resolved with dlopen at first use; falls back to 1 with a message on stderr if unavailable),
+ * transport: 0 = RCCL (resolved with dlopen at first use; falls back to 1 with a message on stderr if unavailable; on hosts that only
+ * support dmabuf IPC -- this pool -- HSA_ENABLE_IPC_MODE_LEGACY=0 must be in the environment before the process's FIRST HIP call: the
+ * library sets it when it is loaded unless the host chose a value, so load it before anything touches HIP, or export the variable),
  * 1 = hipMemcpyPeerAsync (also chosen automatically when members share a device, e.g. tests on a one-GPU box).
  * Every fs_group_* upload / render call is the fs_* call of the same name applied to every member; renders are
  * asynchronous.  fs_group_render_current = gather + row reassembly + min / max / sum + D2H of the padded iteration buffer
