@@ -8,7 +8,7 @@ out=gpurun_out/${tag}_all.jsonl
 : > $out
 python3 bench.py --no-build >> $out 2>/dev/null
 for wl in c1_direct c2_po c5_bla c4_hdr64 c4_2x32 c4_scaled; do
-  python3 bench.py --no-build --workload $wl --steps 3 --warmup 1 --no-secondary >> $out 2>/dev/null
+  python3 bench.py --no-build --workload $wl --steps 10 --warmup 1 --no-secondary >> $out 2>/dev/null
 done
 python3 - <<PY
 import json
