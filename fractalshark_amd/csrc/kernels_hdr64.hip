@@ -38,6 +38,7 @@
 // of Views 5 / 14 in HDRFloat<double> (tests/test_gpu_goldens.py), the literal kernel on every built-in view
 // (tests/test_gpu_hdr64_fast.py), sampled oracle rows in every bench line.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 #include "../../include/fs_layout.h"
@@ -79,6 +80,9 @@ __device__ __forceinline__ C64 add_hi_lo(C64 hi, const C64 lo)
                            SLOWER than the compiled loop on one box: frame kernel 34.65 against 31.77 ms, first frame 59.5 against 55.3
                            (profiles/r06r_c4_hand_written_pt_loop_ab.jsonl): it commits a step with seven moves and walks the rebase
                            block with EXEC = 0, where the compiled loop exchanges register roles over two steps */
+#endif
+#ifndef FS_H64_LA_SCALAR
+#define FS_H64_LA_SCALAR 1 /* LA records through the scalar cache where the wave's lanes agree on the record (0: A/B) */
 #endif
 #ifndef FS_H64_LA_PIPE
 #define FS_H64_LA_PIPE 1 /* the LA loop's step length travels one step ahead (0: A/B -- 33.74 against 32.41 ms; record j + 2's Ref and length two
@@ -303,6 +307,19 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
         // loop [8], of them with lanes on different arms of the add 2Z + dz [9], dz t + dc [10], Z + dz [11], with a rebasing lane [12];
         // wave steps of the LA loop [13], of them with lanes on different arms in any of its three adds [14], with a rebasing lane [15]
         uint32_t w_pt = 0, w_mixA = 0, w_mixB = 0, w_mixC = 0, w_reb = 0, w_la = 0, w_lamix = 0, w_lareb = 0;
+        // ... and how their ADDRESSES agree (words 16..19): LA wave steps whose lanes all read the same record [16], the number of
+        // distinct records summed over the LA wave steps [17]; the same two for the orbit entry of the perturbation steps [18], [19]
+        uint32_t w_launi = 0, w_ladist = 0, w_ptuni = 0, w_ptdist = 0;
+        auto distinct = [](uint32_t v) {
+            uint64_t m = __builtin_amdgcn_ballot_w64(true);
+            uint32_t n = 0;
+            while (m != 0ull) {
+                const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_ctzll(m));
+                m &= ~__builtin_amdgcn_ballot_w64(v == f);
+                n++;
+            }
+            return n;
+        };
         auto arm_of = [](const C64 a, const C64 b) {
             const int nd = b.e - a.e;
             return nd <= -kExpDiffIgnored ? 0 : (nd <= 0 ? 1 : (nd < kExpDiffIgnored ? 2 : 3));
@@ -343,20 +360,38 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
                 // One LA step: leaves from record j with its Ref in RJ and its step length in lJ (both read one step ahead), reads the
                 // rest of record j and, into RN / lN, the Ref and length of record j + 1.  The loop calls it twice per trip with the two
                 // register sets' roles exchanged (no copies).  -> true: the stage is left (RefIteration set).
-                auto la_step = [&](const C64 &RJ, const uint32_t &lJ, C64 &RN, uint32_t &lN) __attribute__((always_inline)) -> bool {
-                    const LaRec *__restrict__ LAj = la_at_off(A.las, base_off + j * (uint32_t)sizeof(LaRec));
+                // (round 6) ... and from the SCALAR cache when the wave's lanes all stand at the same record -- 96.5 % of the LA wave
+                // steps of C4's frame in the count order, 76 % in the tile mapping (tools/c4_arm_probe.py): the eleven vector loads of
+                // a step cost the CU's one texture-address unit >= 4 cycles each whatever their lanes read, and with four SIMDs
+                // behind it that unit, not the vector ALU, set the pace of this loop (TCP_TOTAL_CACHE_ACCESSES 1.7e10 per frame = 0.87
+                // per CU cycle).  kUni: the record is read through a constant-address-space pointer at a wave-uniform offset
+                // (s_load), its fields are scalar operands of the same operations, and RJ / lJ are not needed (Ref and length of
+                // record j are in the record itself).
+                auto la_body = [&](auto LAj, auto uni, const C64 &RJ_in, const uint32_t &lJ_in, C64 &RN, uint32_t &lN)
+                                   __attribute__((always_inline)) -> bool {
+                    constexpr bool kUni = decltype(uni)::value;
+#define FS_LDC(P, F) C64{(P)->F.re, (P)->F.im, (P)->F.e}
+#define FS_LDR(P, F) R64{(P)->F.m, (P)->F.e}
 #if !FS_H64_LA_PIPE
                     const uint32_t l = LAj->StepLength; // (A/B: the step waits for its own record's length first, as the literal kernel does)
+                    const C64 RJ = RJ_in;
 #else
-                    const uint32_t l = lJ;
+                    const uint32_t l = kUni ? LAj->StepLength : lJ_in;
+                    const C64 RJ = kUni ? FS_LDC(LAj, Ref) : RJ_in;
 #endif
                     const uint32_t next_stage = LAj->NextStageLAIndex;
-                    const C64 ZCoeff = ldc(LAj->ZCoeff), CCoeff = ldc(LAj->CCoeff);
-                    const R64 thr = ldr(LAj->LAThreshold);
-                    RN = ldc(LAj[1].Ref);
+                    const C64 ZCoeff = FS_LDC(LAj, ZCoeff), CCoeff = FS_LDC(LAj, CCoeff);
+                    const R64 thr = FS_LDR(LAj, LAThreshold);
+                    RN = FS_LDC(LAj + 1, Ref);
                     lN = LAj[1].StepLength;
-                    if (kStats)
+#undef FS_LDC
+#undef FS_LDR
+                    if (kStats) {
                         w_la++;
+                        const uint32_t nd_ = distinct(j);
+                        w_ladist += nd_;
+                        w_launi += nd_ == 1u ? 1u : 0u;
+                    }
                     if (iterations + l > n_iterations) { // the step would pass the iteration limit: unusable
                         RefIteration = next_stage;
                         return true;
@@ -390,6 +425,17 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
                         lN = la_at_off(A.las, base_off)->StepLength;
                     }
                     return false;
+                };
+                auto la_step = [&](const C64 &RJ, const uint32_t &lJ, C64 &RN, uint32_t &lN) __attribute__((always_inline)) -> bool {
+                    const uint32_t off = base_off + j * (uint32_t)sizeof(LaRec);
+#if FS_H64_LA_SCALAR
+                    const uint32_t uoff = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
+                    if (__builtin_amdgcn_ballot_w64(off == uoff) == __builtin_amdgcn_ballot_w64(true)) {
+                        typedef const __attribute__((address_space(4))) LaRec *CRec;
+                        return la_body((CRec)((uintptr_t)A.las + uoff), std::true_type{}, RJ, lJ, RN, lN);
+                    }
+#endif
+                    return la_body(la_at_off(A.las, off), std::false_type{}, RJ, lJ, RN, lN);
                 };
                 C64 RefA = hc_zero<F>(), RefB = hc_zero<F>();
                 uint32_t lA = 0, lB = 0;
@@ -425,6 +471,9 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
                 ZN = z_at_off(zr, zoff);
                 if (kStats) {
                     w_pt++;
+                    const uint32_t nd_ = distinct(zoff);
+                    w_ptdist += nd_;
+                    w_ptuni += nd_ == 1u ? 1u : 0u;
                     w_mixA += mixed(arm_of(C64{ZH.re, ZH.im, ZH.e + 1}, dz));
                 }
                 const C64 cur = hc_add_w(C64{ZH.re, ZH.im, ZH.e + 1}, dz); // (hc_mul2: x * 1.0 is x; e + 1 needs no clamp)
@@ -689,8 +738,8 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
             // wave's for the steps it was in -- the longest lane's would be better; the first lane's are a sample, stated as such
             if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) ==
                 (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) {
-                const uint32_t v[8] = {w_pt, w_mixA, w_mixB, w_mixC, w_reb, w_la, w_lamix, w_lareb};
-                for (int k = 0; k < 8; k++)
+                const uint32_t v[12] = {w_pt, w_mixA, w_mixB, w_mixC, w_reb, w_la, w_lamix, w_lareb, w_launi, w_ladist, w_ptuni, w_ptdist};
+                for (int k = 0; k < 12; k++)
                     atomicAdd((unsigned long long *)&A.stats[8 + k], (unsigned long long)v[k]);
             }
         }

@@ -36,7 +36,8 @@ def frame(stats):
 
 
 names = ["pt_wave_steps", "pt_mixed_2Z+dz", "pt_mixed_dz*t+dc", "pt_mixed_Z+dz", "pt_steps_with_a_rebasing_lane",
-         "la_wave_steps", "la_steps_with_a_mixed_add", "la_steps_with_a_rebasing_lane"]
+         "la_wave_steps", "la_steps_with_a_mixed_add", "la_steps_with_a_rebasing_lane",
+         "la_steps_all_lanes_one_record", "la_distinct_records_summed", "pt_steps_all_lanes_one_entry", "pt_distinct_entries_summed"]
 for label, warm in (("tile mapping (first frame)", 0), ("count order (third frame on)", 3)):
     r.forget_tile_costs()
     for _ in range(warm):
@@ -45,7 +46,9 @@ for label, warm in (("tile mapping (first frame)", 0), ("count order (third fram
     d = {"frame": label, "ordered": ordered, "W": W, "H": H, "perturb_lane_steps": raw[2], "la_lane_steps": raw[1],
          "lane_slots_pt": raw[4]}
     d.update({n: raw[8 + k] for k, n in enumerate(names)})
+    if raw[13]:
+        d["la_distinct_records_per_wave_step"] = round(raw[17] / raw[13], 2)
     if raw[8]:
-        d["pt_lanes_per_wave_step"] = round(raw[2] / raw[8], 1) if raw[8] else None
+        d["pt_distinct_entries_per_wave_step"] = round(raw[19] / raw[8], 2)
     print(json.dumps(d), flush=True)
 r.close()
