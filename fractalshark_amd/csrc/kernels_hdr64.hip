@@ -38,6 +38,7 @@
 // of Views 5 / 14 in HDRFloat<double> (tests/test_gpu_goldens.py), the literal kernel on every built-in view
 // (tests/test_gpu_hdr64_fast.py), sampled oracle rows in every bench line.
 #include <hip/hip_runtime.h>
+#include <cstddef>
 #include <type_traits>
 #include <stdint.h>
 
@@ -47,6 +48,7 @@
 #include "kernels.h"
 #include "kernel_common.hpp"
 #include "lav2_common.hpp"
+#include "la_step_asm.hpp"
 
 using namespace fs;
 
@@ -80,6 +82,12 @@ __device__ __forceinline__ C64 add_hi_lo(C64 hi, const C64 lo)
                            SLOWER than the compiled loop on one box: frame kernel 34.65 against 31.77 ms, first frame 59.5 against 55.3
                            (profiles/r06r_c4_hand_written_pt_loop_ab.jsonl): it commits a step with seven moves and walks the rebase
                            block with EXEC = 0, where the compiled loop exchanges register roles over two steps */
+#endif
+#ifndef FS_H64_LA_ASM
+#define FS_H64_LA_ASM 1 /* the LA steps of a wave whose lanes stand at one record by hand (la_step_asm.hpp); 0: the compiled loop, A/B */
+#endif
+#ifndef FS_H64_LA_ASM_DEBUG
+#define FS_H64_LA_ASM_DEBUG 0 /* 1 (probe build): the counting instantiation runs the statement too and tallies its exits by status in statistics words 20..23 */
 #endif
 #ifndef FS_H64_LA_SCALAR
 #define FS_H64_LA_SCALAR 1 /* LA records through the scalar cache where the wave's lanes agree on the record (0: A/B) */
@@ -257,6 +265,10 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
 {
     using F = double;
     using LaRec = fs_la_hdr64_u32;
+    static_assert(sizeof(LaRec) == 128 && offsetof(LaRec, Ref) == 0 && offsetof(LaRec, ZCoeff) == 24 && offsetof(LaRec, CCoeff) == 48 &&
+                      offsetof(LaRec, LAThreshold) == 72 && offsetof(LaRec, StepLength) == 120 && offsetof(LaRec, NextStageLAIndex) == 124 &&
+                      offsetof(fs_cplx_hdr64, im) == 8 && offsetof(fs_cplx_hdr64, e) == 16 && offsetof(fs_real_hdr64, e) == 8,
+                  "la_step_asm.hpp reads the record by these offsets");
     uint32_t X, L;
     if (A.pixel_order)
         ordered_pixel_xcd(A.frame, A.pixel_order, X, L);
@@ -388,7 +400,7 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
 #undef FS_LDR
                     if (kStats) {
                         w_la++;
-                        const uint32_t nd_ = distinct(j);
+                        const uint32_t nd_ = distinct(base_off + j * (uint32_t)sizeof(LaRec));
                         w_ladist += nd_;
                         w_launi += nd_ == 1u ? 1u : 0u;
                     }
@@ -437,6 +449,59 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
 #endif
                     return la_body(la_at_off(A.las, off), std::false_type{}, RJ, lJ, RN, lN);
                 };
+#if FS_H64_LA_ASM
+                // (frames in a recorded order only -- kAtInKernel is the first frame of a view, in the tile mapping, where a quarter of
+                // the LA steps have lanes at different records and every one of them would leave the statement for a compiled step and
+                // come back: 54.8 against 52.3 ms)
+                if constexpr ((!kStats || FS_H64_LA_ASM_DEBUG) && !kAtInKernel) {
+                    // the hand-written loop for the steps whose lanes stand at one record (la_step_asm.hpp); what it hands back --
+                    // lanes at different records, a product that Reduce's fast form does not cover, a norm below 2^-1000 in the
+                    // rebase test -- takes ONE compiled step (or its rebase test) and goes back in
+                    while (iterations < n_iterations) {
+                        double yr, yi, t0, t1, t2, t3, t4, t5;
+                        int ye, i0, i1, i2, i3, i4, i5;
+                        uint32_t st, so, sa;
+                        uint64_t run, leftm, sx, m0, m1;
+                        asm volatile(FS_LA_UNIFORM_LOOP
+                                     : [xr] "+v"(dz.re), [xi] "+v"(dz.im), [xe] "+v"(dz.e), [j] "+v"(j), [it] "+v"(iterations), [nla] "+v"(n_la),
+                                       [refit] "+v"(RefIteration), [yr] "=&v"(yr), [yi] "=&v"(yi), [ye] "=&v"(ye), [t0] "=&v"(t0),
+                                       [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [i0] "=&v"(i0),
+                                       [i1] "=&v"(i1), [i2] "=&v"(i2), [i3] "=&v"(i3), [i4] "=&v"(i4), [i5] "=&v"(i5), [st] "=&s"(st),
+                                       [run] "=&s"(run), [left] "=&s"(leftm), [sx] "=&s"(sx), [so] "=&s"(so), [sa] "=&s"(sa), [m0] "=&s"(m0), [m1] "=&s"(m1)
+                                     : [dcr] "v"(dc.re), [dci] "v"(dc.im), [dce] "v"(dc.e), [boff] "v"(base_off), [macro] "v"(MacroItCount), [m4k] "v"(-4000),
+                                       [las] "s"(A.las), [nit] "s"(n_iterations), [cls] "s"(0x100), [tiny] "s"(0x1p-1000)
+                                     : "vcc", "scc", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48",
+                                       "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s64", "s65",
+                                       "s66", "s67", "s68", "s69", "s70", "s71");
+#if FS_H64_LA_ASM_DEBUG
+                        if (kStats && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) ==
+                                          (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true)))
+                            atomicAdd((unsigned long long *)&A.stats[20 + st], 1ull); // exits of the statement by status
+#endif
+                        if (__builtin_amdgcn_inverse_ballot_w64(leftm))
+                            break; // this lane has left the stage (RefIteration is the record's NextStageLAIndex)
+                        if (!(iterations < n_iterations))
+                            break;
+                        const LaRec *__restrict__ LAj = la_at_off(A.las, base_off + j * (uint32_t)sizeof(LaRec));
+                        if (st == 2u) { // dz' and j + 1 are in place: complex0, the rebase test and its consequence
+                            const C64 complex0 = hc_add_w(ldc(LAj->Ref), dz);
+                            if (less_w(cheb64(complex0), complex0.e, cheb64(dz), dz.e) || j >= MacroItCount) {
+                                dz = complex0;
+                                j = 0;
+                            }
+                        } else {
+                            // one compiled step with vector loads (it reads its own record whole: handing Ref and length on
+                            // from step to step, as the compiled loop does, costs more registers than this kernel has next to the
+                            // statement's -- 37.9 against 30.0 ms with spills in the loop)
+                            C64 RNv;
+                            uint32_t lNv;
+                            if (la_body(LAj, std::false_type{}, ldc(LAj->Ref), LAj->StepLength, RNv, lNv))
+                                break;
+                        }
+                    }
+                } else
+#endif
+                {
                 C64 RefA = hc_zero<F>(), RefB = hc_zero<F>();
                 uint32_t lA = 0, lB = 0;
                 if (iterations < n_iterations) {
@@ -451,6 +516,7 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
                         break;
                     if (la_step(RefB, lB, RefA, lA))
                         break;
+                }
                 }
                 if (iterations >= n_iterations)
                     break;

@@ -46,6 +46,8 @@ for label, warm in (("tile mapping (first frame)", 0), ("count order (third fram
     d = {"frame": label, "ordered": ordered, "W": W, "H": H, "perturb_lane_steps": raw[2], "la_lane_steps": raw[1],
          "lane_slots_pt": raw[4]}
     d.update({n: raw[8 + k] for k, n in enumerate(names)})
+    if any(raw[20:24]):
+        d["la_statement_exits_by_status"] = raw[20:24]
     if raw[13]:
         d["la_distinct_records_per_wave_step"] = round(raw[17] / raw[13], 2)
     if raw[8]:
