@@ -49,6 +49,7 @@
 #include "kernel_common.hpp"
 #include "lav2_common.hpp"
 #include "la_step_asm.hpp"
+#include "pt_step_asm.hpp"
 
 using namespace fs;
 
@@ -78,10 +79,9 @@ __device__ __forceinline__ C64 add_hi_lo(C64 hi, const C64 lo)
 // asked for first -- 0: the sum with a on top (2 Z + dz, Z + dz), 1: a alone (dz (2 Z + dz) + dc at a deep zoom, where dc is
 // hundreds of binades below everything else).  Mixed waves: per-lane operand select, then the same sum with the gap clamped.
 #ifndef FS_H64_PT_ASM
-#define FS_H64_PT_ASM 0 /* 1 (A/B build, with FS_H64_WAVES=0): the perturbation loop as one hand-written statement.  Bit-exact, and
-                           SLOWER than the compiled loop on one box: frame kernel 34.65 against 31.77 ms, first frame 59.5 against 55.3
-                           (profiles/r06r_c4_hand_written_pt_loop_ab.jsonl): it commits a step with seven moves and walks the rebase
-                           block with EXEC = 0, where the compiled loop exchanges register roles over two steps */
+#define FS_H64_PT_ASM 1 /* the perturbation steps of the ordered frames by hand (pt_step_asm.hpp); 0: the compiled loop, A/B.  (A first version
+                           -- named registers, seven waves, the step committed with seven moves -- was slower than the compiled loop: 34.65
+                           against 31.77 ms, profiles/r06r_c4_hand_written_pt_loop_ab.jsonl) */
 #endif
 #ifndef FS_H64_LA_ASM
 #define FS_H64_LA_ASM 1 /* the LA steps of a wave whose lanes stand at one record by hand (la_step_asm.hpp); 0: the compiled loop, A/B */
@@ -252,7 +252,7 @@ __device__ __forceinline__ void ordered_pixel_xcd(const FsFrame &f, const uint32
 // FS_H64_WAVES (A/B builds): 8 = the register allocator is held to 64 registers (8 waves per SIMD; it spills three or four dwords),
 // 0 = left alone (67 registers, 7 waves)
 #ifndef FS_H64_WAVES
-#define FS_H64_WAVES 8 /* (the hand-written perturbation loop, FS_H64_PT_ASM=1, needs 0: its named registers v40..v64 take the 72 of 7 waves) */
+#define FS_H64_WAVES 8
 #endif
 #if FS_H64_WAVES == 8
 #define FS_H64_OCCUPANCY __attribute__((amdgpu_waves_per_eu(8, 8)))
@@ -574,16 +574,9 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
             if (iterations < n_iterations)
                 ZA = z_at_off(zr, zoff);
 #if FS_H64_PT_ASM
-            if constexpr (!kStats) {
-                // ---- the perturbation loop by hand (round 6).  The kernel is its vector-instruction count, and the
-                // compiled step issues ~80 of them for the ~30 binary64 operations it needs.  One statement holds the step for the wave
-                // whose lanes agree -- 2Z + dz and Z + dz with the orbit value on top (or, out of line, the general sum
-                // ldexp(a, sa) + ldexp(b, sb) for a wave whose lanes do not agree), dc hundreds of binades below dz (dz t + dc is dz t),
-                // Reduce and the norm tests on normal numbers -- escape (the lane leaves the running mask with its count), the
-                // iteration cap, and the rebase under EXEC.  Same operations in the same order as pt_step above (which is the same
-                // as the literal kernel's): each check that fails for ANY running lane leaves the statement before anything of
-                // the step is committed, with status 1, and the wave takes that one step through pt_step.
-                // Registers: v[40:64] and s[40:55] are the statement's own (clobbered); the per-pixel state travels in operands.
+            if constexpr ((!kStats || FS_H64_LA_ASM_DEBUG) && !kAtInKernel) {
+                // ---- the perturbation loop by hand (pt_step_asm.hpp) for the frames in a recorded order; what the statement hands
+                // back takes one compiled step (status 1, 3) or the compiled tests of the step it has computed (status 2)
                 const uint32_t z0re_lo = __builtin_amdgcn_readfirstlane((int)(uint32_t)__builtin_bit_cast(uint64_t, zr[0].re));
                 const uint32_t z0re_hi = __builtin_amdgcn_readfirstlane((int)(uint32_t)(__builtin_bit_cast(uint64_t, zr[0].re) >> 32));
                 const uint32_t z0im_lo = __builtin_amdgcn_readfirstlane((int)(uint32_t)__builtin_bit_cast(uint64_t, zr[0].im));
@@ -592,189 +585,49 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
                 const uint64_t z0re = ((uint64_t)z0re_hi << 32) | z0re_lo, z0im = ((uint64_t)z0im_hi << 32) | z0im_lo;
                 bool running = iterations < n_iterations;
                 uint64_t run = __builtin_amdgcn_ballot_w64(running);
-                const double c256 = 256.0, ctiny = 0x1p-1000;
-                const uint32_t cls_normal = 0x100u; // +normal
                 while (run != 0ull) {
-                    int st;
-                    asm volatile(
-                        "s_mov_b64 s[40:41], exec\n\t"
-                        "s_mov_b64 exec, %[run]\n"
-                        ".Lh64pt_top_%=:\n\t"
-                        "global_load_dwordx2 v[60:61], %[zoff], %[zb] offset:32\n\t"
-                        "global_load_dwordx2 v[62:63], %[zoff], %[zb] offset:40\n\t"
-                        "global_load_dword v64, %[zoff], %[zb] offset:48\n\t"
-                        /* A: cur = 2 Z + dz -> v[40:41], v[42:43], exponent v54 */
-                        "v_add_u32_e32 v54, 1, %[zhe]\n\t"
-                        "v_sub_u32_e32 v55, %[dze], v54\n\t"
-                        "v_add_u32_e32 v56, 0x77, v55\n\t"
-                        "v_cmp_gt_u32_e32 vcc, 0x78, v56\n\t" /* gap in (-120, 0]: the orbit value on top */
-                        "s_xor_b64 s[42:43], vcc, exec\n\t"
-                        "s_cbranch_scc1 .Lh64pt_Agen_%=\n\t"
-                        "v_ldexp_f64 v[40:41], %[dzr], v55\n\t"
-                        "v_ldexp_f64 v[42:43], %[dzi], v55\n\t"
-                        "v_add_f64 v[40:41], %[zhr], v[40:41]\n\t"
-                        "v_add_f64 v[42:43], %[zhi], v[42:43]\n"
-                        ".Lh64pt_Adone_%=:\n\t"
-                        /* p = dz * cur -> v[44:45], v[46:47], exponent v55 */
-                        "v_mul_f64 v[44:45], %[dzr], v[40:41]\n\t"
-                        "v_mul_f64 v[48:49], %[dzi], v[42:43]\n\t"
-                        "v_mul_f64 v[46:47], %[dzr], v[42:43]\n\t"
-                        "v_mul_f64 v[50:51], %[dzi], v[40:41]\n\t"
-                        "v_add_f64 v[44:45], v[44:45], -v[48:49]\n\t"
-                        "v_add_f64 v[46:47], v[46:47], v[50:51]\n\t"
-                        "v_add_u32_e32 v55, %[dze], v54\n\t"
-                        "v_max_i32_e32 v55, 0xf0000000, v55\n\t"
-                        /* q = p + dc: dc alone is dropped when it is 120 binades and more below p (every lane), else the compiled step */
-                        "v_sub_u32_e32 v56, %[dce], v55\n\t"
-                        "v_cmp_ge_i32_e32 vcc, 0xffffff88, v56\n\t"
-                        "s_xor_b64 s[42:43], vcc, exec\n\t"
-                        "s_cbranch_scc1 .Lh64pt_leave1_%=\n\t"
-                        /* Reduce(q): normal max part in every lane */
-                        "v_max_f64 v[48:49], |v[44:45]|, |v[46:47]|\n\t"
-                        "v_cmp_class_f64_e64 vcc, v[48:49], %[cls]\n\t"
-                        "s_xor_b64 s[42:43], vcc, exec\n\t"
-                        "s_cbranch_scc1 .Lh64pt_leave1_%=\n\t"
-                        "v_frexp_exp_i32_f64_e32 v56, v[48:49]\n\t"
-                        "v_sub_u32_e32 v57, 1, v56\n\t"
-                        "v_ldexp_f64 v[44:45], v[44:45], v57\n\t"
-                        "v_ldexp_f64 v[46:47], v[46:47], v57\n\t"
-                        "v_add3_u32 v55, v55, v56, -1\n\t" /* new dz: v[44:45], v[46:47], exponent v55 */
-                        /* c0 = Z' + dz' -> v[40:41], v[42:43], exponent v58 */
-                        "s_waitcnt vmcnt(0)\n\t"
-                        "v_sub_u32_e32 v56, v55, v64\n\t"
-                        "v_add_u32_e32 v57, 0x77, v56\n\t"
-                        "v_cmp_gt_u32_e32 vcc, 0x78, v57\n\t"
-                        "s_xor_b64 s[42:43], vcc, exec\n\t"
-                        "s_cbranch_scc1 .Lh64pt_Cgen_%=\n\t"
-                        "v_ldexp_f64 v[40:41], v[44:45], v56\n\t"
-                        "v_ldexp_f64 v[42:43], v[46:47], v56\n\t"
-                        "v_add_f64 v[40:41], v[60:61], v[40:41]\n\t"
-                        "v_add_f64 v[42:43], v[62:63], v[42:43]\n\t"
-                        "v_mov_b32_e32 v58, v64\n"
-                        ".Lh64pt_Cdone_%=:\n\t"
-                        /* n1 = |c0|^2 -> v[48:49], n2 = |dz'|^2 -> v[50:51]; both normal (>= 2^-1000) in every lane */
-                        "v_mul_f64 v[48:49], v[40:41], v[40:41]\n\t"
-                        "v_mul_f64 v[52:53], v[42:43], v[42:43]\n\t"
-                        "v_add_f64 v[48:49], v[48:49], v[52:53]\n\t"
-                        "v_mul_f64 v[50:51], v[44:45], v[44:45]\n\t"
-                        "v_mul_f64 v[52:53], v[46:47], v[46:47]\n\t"
-                        "v_add_f64 v[50:51], v[50:51], v[52:53]\n\t"
-                        "v_min_f64 v[52:53], v[48:49], v[50:51]\n\t"
-                        "v_cmp_le_f64_e32 vcc, %[tiny], v[52:53]\n\t"
-                        "s_xor_b64 s[42:43], vcc, exec\n\t"
-                        "s_cbranch_scc1 .Lh64pt_leave1_%=\n\t"
-                        "v_lshlrev_b32_e32 v56, 1, v58\n\t"
-                        "v_ldexp_f64 v[52:53], v[48:49], v56\n\t"
-                        "v_cmp_lt_f64_e64 s[44:45], %[c256], v[52:53]\n\t" /* escaped */
-                        "v_sub_u32_e32 v56, v58, v55\n\t"
-                        "v_lshlrev_b32_e32 v56, 1, v56\n\t"
-                        "v_ldexp_f64 v[52:53], v[48:49], v56\n\t"
-                        "v_cmp_lt_f64_e64 s[46:47], v[52:53], v[50:51]\n\t" /* |z|^2 < |dz|^2 */
-                        "v_add_u32_e32 v57, 32, %[zoff]\n\t"
-                        "v_cmp_le_u32_e64 s[48:49], %[maxoff], v57\n\t" /* arrived at the orbit's last entry */
-                        "s_or_b64 s[46:47], s[46:47], s[48:49]\n\t"
-                        "s_andn2_b64 s[46:47], s[46:47], s[44:45]\n\t" /* rebasing lanes (an escaped lane does not rebase) */
-                        "s_and_b64 s[46:47], s[46:47], exec\n\t"
-                        "s_cbranch_scc0 .Lh64pt_commit_%=\n\t"
-                        /* rebase: dz = Reduce(c0) for the lanes in s[46:47] -> v[48:49], v[50:51], exponent v59 */
-                        "s_mov_b64 s[50:51], exec\n\t"
-                        "s_mov_b64 exec, s[46:47]\n\t"
-                        "v_max_f64 v[52:53], |v[40:41]|, |v[42:43]|\n\t"
-                        "v_cmp_class_f64_e64 vcc, v[52:53], %[cls]\n\t"
-                        "s_xor_b64 s[42:43], vcc, exec\n\t"
-                        "s_mov_b64 exec, s[50:51]\n\t"
-                        "s_cbranch_scc1 .Lh64pt_leave1_%=\n\t"
-                        "s_mov_b64 exec, s[46:47]\n\t"
-                        "v_frexp_exp_i32_f64_e32 v56, v[52:53]\n\t"
-                        "v_sub_u32_e32 v59, 1, v56\n\t"
-                        "v_ldexp_f64 v[48:49], v[40:41], v59\n\t"
-                        "v_ldexp_f64 v[50:51], v[42:43], v59\n\t"
-                        "v_add3_u32 v59, v58, v56, -1\n\t"
-                        "s_mov_b64 exec, s[50:51]\n"
-                        ".Lh64pt_commit_%=:\n\t"
-                        /* commit: the step is taken */
-                        "v_mov_b64_e32 %[dzr], v[44:45]\n\t"
-                        "v_mov_b64_e32 %[dzi], v[46:47]\n\t"
-                        "v_mov_b32_e32 %[dze], v55\n\t"
-                        "v_mov_b64_e32 %[zhr], v[60:61]\n\t"
-                        "v_mov_b64_e32 %[zhi], v[62:63]\n\t"
-                        "v_mov_b32_e32 %[zhe], v64\n\t"
-                        "v_mov_b32_e32 %[zoff], v57\n\t"
-                        "s_mov_b64 s[50:51], exec\n\t"
-                        "s_mov_b64 exec, s[46:47]\n\t" /* (no lanes: the moves below do nothing) */
-                        "v_mov_b64_e32 %[dzr], v[48:49]\n\t"
-                        "v_mov_b64_e32 %[dzi], v[50:51]\n\t"
-                        "v_mov_b32_e32 %[dze], v59\n\t"
-                        "v_mov_b64_e32 %[zhr], %[z0re]\n\t"
-                        "v_mov_b64_e32 %[zhi], %[z0im]\n\t"
-                        "v_mov_b32_e32 %[zhe], %[z0e]\n\t"
-                        "v_mov_b32_e32 %[zoff], 0\n\t"
-                        "s_andn2_b64 exec, s[50:51], s[44:45]\n\t" /* escaped lanes leave with their count */
-                        "v_add_u32_e32 %[iter], 1, %[iter]\n\t"
-                        "v_cmp_gt_u32_e32 vcc, %[niter], %[iter]\n\t" /* lanes at the cap leave with it */
-                        "s_and_b64 exec, exec, vcc\n\t"
-                        "s_cbranch_execnz .Lh64pt_top_%=\n\t"
-                        "s_mov_b64 %[run], 0\n\t"
-                        "s_mov_b32 %[st], 0\n\t"
-                        "s_branch .Lh64pt_out_%=\n"
-                        /* the general sum for 2 Z + dz: ldexp(a, sa) + ldexp(b, sb), shifts of 120 and more make the operand vanish */
-                        ".Lh64pt_Agen_%=:\n\t"
-                        "v_max_i32_e32 v56, v54, %[dze]\n\t"
-                        "v_sub_u32_e32 v57, v54, v56\n\t"
-                        "v_sub_u32_e32 v58, %[dze], v56\n\t"
-                        "v_mov_b32_e32 v59, 0xfffff060\n\t" /* -4000 */
-                        "v_cmp_lt_i32_e32 vcc, 0xffffff88, v57\n\t"
-                        "s_nop 1\n\t" /* (a VALU write of vcc is two wait states from a VALU read of it as a mask: the compiler's hazard pass does not see inside) */
-                        "v_cndmask_b32_e32 v57, v59, v57, vcc\n\t"
-                        "v_cmp_lt_i32_e32 vcc, 0xffffff88, v58\n\t"
-                        "s_nop 1\n\t"
-                        "v_cndmask_b32_e32 v58, v59, v58, vcc\n\t"
-                        "v_ldexp_f64 v[40:41], %[zhr], v57\n\t"
-                        "v_ldexp_f64 v[42:43], %[zhi], v57\n\t"
-                        "v_ldexp_f64 v[44:45], %[dzr], v58\n\t"
-                        "v_ldexp_f64 v[46:47], %[dzi], v58\n\t"
-                        "v_add_f64 v[40:41], v[40:41], v[44:45]\n\t"
-                        "v_add_f64 v[42:43], v[42:43], v[46:47]\n\t"
-                        "v_mov_b32_e32 v54, v56\n\t"
-                        "s_branch .Lh64pt_Adone_%=\n"
-                        /* ... and for Z' + dz' */
-                        ".Lh64pt_Cgen_%=:\n\t"
-                        "v_max_i32_e32 v58, v64, v55\n\t"
-                        "v_sub_u32_e32 v56, v64, v58\n\t"
-                        "v_sub_u32_e32 v57, v55, v58\n\t"
-                        "v_mov_b32_e32 v59, 0xfffff060\n\t" /* -4000 */
-                        "v_cmp_lt_i32_e32 vcc, 0xffffff88, v56\n\t"
-                        "s_nop 1\n\t"
-                        "v_cndmask_b32_e32 v56, v59, v56, vcc\n\t"
-                        "v_cmp_lt_i32_e32 vcc, 0xffffff88, v57\n\t"
-                        "s_nop 1\n\t"
-                        "v_cndmask_b32_e32 v57, v59, v57, vcc\n\t"
-                        "v_ldexp_f64 v[40:41], v[60:61], v56\n\t"
-                        "v_ldexp_f64 v[42:43], v[62:63], v56\n\t"
-                        "v_ldexp_f64 v[48:49], v[44:45], v57\n\t"
-                        "v_ldexp_f64 v[50:51], v[46:47], v57\n\t"
-                        "v_add_f64 v[40:41], v[40:41], v[48:49]\n\t"
-                        "v_add_f64 v[42:43], v[42:43], v[50:51]\n\t"
-                        "s_branch .Lh64pt_Cdone_%=\n"
-                        /* nothing of this step has been committed: the compiled step takes it */
-                        ".Lh64pt_leave1_%=:\n\t"
-                        "s_waitcnt vmcnt(0)\n\t"
-                        "s_mov_b64 %[run], exec\n\t"
-                        "s_mov_b32 %[st], 1\n"
-                        ".Lh64pt_out_%=:\n\t"
-                        "s_mov_b64 exec, s[40:41]"
-                        : [dzr] "+v"(dz.re), [dzi] "+v"(dz.im), [dze] "+v"(dz.e), [zhr] "+v"(ZA.re), [zhi] "+v"(ZA.im), [zhe] "+v"(ZA.e),
-                          [zoff] "+v"(zoff), [iter] "+v"(iterations), [run] "+s"(run), [st] "=&s"(st)
-                        : [dce] "v"(dc.e), [zb] "s"(zr), [niter] "s"(n_iterations), [maxoff] "s"(max_off), [cls] "s"(cls_normal),
-                          [tiny] "s"(ctiny), [c256] "s"(c256), [z0re] "s"(z0re), [z0im] "s"(z0im), [z0e] "s"(z0e)
-                        : "vcc", "scc", "memory", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "v40",
-                          "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56",
-                          "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64");
-                    running = __builtin_amdgcn_inverse_ballot_w64(run);
-                    if (st == 0)
+                    double yr, yi, qr, qi, t0, t1, t2, t3, t4;
+                    int ye, qe, i0, i1, i2, i3;
+                    uint32_t st;
+                    uint64_t sx, mesc, mreb, mend;
+                    asm volatile(FS_PT_LOOP
+                                 : [xr] "+v"(dz.re), [xi] "+v"(dz.im), [xe] "+v"(dz.e), [pr] "+v"(ZA.re), [pi] "+v"(ZA.im), [pe] "+v"(ZA.e),
+                                   [zoff] "+v"(zoff), [iter] "+v"(iterations), [run] "+s"(run), [yr] "=&v"(yr), [yi] "=&v"(yi), [ye] "=&v"(ye),
+                                   [qr] "=&v"(qr), [qi] "=&v"(qi), [qe] "=&v"(qe), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
+                                   [t3] "=&v"(t3), [t4] "=&v"(t4), [i0] "=&v"(i0), [i1] "=&v"(i1), [i2] "=&v"(i2), [i3] "=&v"(i3),
+                                   [st] "=&s"(st), [sx] "=&s"(sx), [mesc] "=&s"(mesc), [mreb] "=&s"(mreb), [mend] "=&s"(mend)
+                                 : [dce] "v"(dc.e), [m4k] "v"(-4000), [zb] "s"(zr), [niter] "s"(n_iterations), [maxoff] "s"(max_off),
+                                   [cls] "s"(0x100), [tiny] "s"(0x1p-1000), [c256] "s"(256.0), [z0re] "s"(z0re), [z0im] "s"(z0im), [z0e] "s"(z0e)
+                                 : "vcc", "scc", "memory");
+#if FS_H64_LA_ASM_DEBUG
+                    if (kStats && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) ==
+                                      (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true)))
+                        atomicAdd((unsigned long long *)&A.stats[24 + st], 1ull); // exits of the statement by status
+#endif
+                    if (st == 0u)
                         break;
-                    if (running) { // one step through the compiled code for every lane still running
-                        if (pt_step(ZA, ZB)) {
+                    running = __builtin_amdgcn_inverse_ballot_w64(run);
+                    if (running) {
+                        if (st == 2u) { // dz' and the entry it arrives at are in place: the tests, the rebase, the count
+                            zoff += (uint32_t)sizeof(FsZ64);
+                            C64 complex0 = hc_add_w(ZA, dz);
+                            const double n1 = complex0.re * complex0.re + complex0.im * complex0.im;
+                            const double n2 = dz.re * dz.re + dz.im * dz.im;
+                            bool escaped, rebase;
+                            step_tests_w(n1, complex0.e << 1, n2, dz.e << 1, escaped, rebase);
+                            if (escaped) {
+                                running = false;
+                            } else {
+                                if (rebase || zoff >= max_off) {
+                                    hc_reduce_w(complex0);
+                                    dz = complex0;
+                                    zoff = 0;
+                                    ZA = z_at_off(zr, 0u);
+                                }
+                                iterations++;
+                                running = iterations < n_iterations;
+                            }
+                        } else if (pt_step(ZA, ZB)) { // one step through the compiled code for every lane still running
                             running = false;
                         } else {
                             iterations++;

@@ -48,6 +48,8 @@ for label, warm in (("tile mapping (first frame)", 0), ("count order (third fram
     d.update({n: raw[8 + k] for k, n in enumerate(names)})
     if any(raw[20:24]):
         d["la_statement_exits_by_status"] = raw[20:24]
+    if any(raw[24:28]):
+        d["pt_statement_exits_by_status"] = raw[24:28]
     if raw[13]:
         d["la_distinct_records_per_wave_step"] = round(raw[17] / raw[13], 2)
     if raw[8]:
