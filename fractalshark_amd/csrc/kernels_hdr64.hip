@@ -48,6 +48,10 @@
 #include "kernels.h"
 #include "kernel_common.hpp"
 #include "lav2_common.hpp"
+#ifndef FS_H64_LA_ASM_DEBUG
+#define FS_H64_LA_ASM_DEBUG 0 /* 1 (probe build): the counting instantiation runs the hand-written statements too and tallies their exits by
+                                 status (statistics words 20..23 LA, 24..27 perturbation) and their half-steps / general sums (28..35) */
+#endif
 #include "la_step_asm.hpp"
 #include "pt_step_asm.hpp"
 
@@ -85,9 +89,6 @@ __device__ __forceinline__ C64 add_hi_lo(C64 hi, const C64 lo)
 #endif
 #ifndef FS_H64_LA_ASM
 #define FS_H64_LA_ASM 1 /* the LA steps of a wave whose lanes stand at one record by hand (la_step_asm.hpp); 0: the compiled loop, A/B */
-#endif
-#ifndef FS_H64_LA_ASM_DEBUG
-#define FS_H64_LA_ASM_DEBUG 0 /* 1 (probe build): the counting instantiation runs the statement too and tallies its exits by status in statistics words 20..23 */
 #endif
 #ifndef FS_H64_LA_SCALAR
 #define FS_H64_LA_SCALAR 1 /* LA records through the scalar cache where the wave's lanes agree on the record (0: A/B) */
@@ -322,6 +323,11 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
         // ... and how their ADDRESSES agree (words 16..19): LA wave steps whose lanes all read the same record [16], the number of
         // distinct records summed over the LA wave steps [17]; the same two for the orbit entry of the perturbation steps [18], [19]
         uint32_t w_launi = 0, w_ladist = 0, w_ptuni = 0, w_ptdist = 0;
+        // ... and on which ARM they agree (words 28..39, the counting build without FS_H64_LA_ASM_DEBUG): wave steps with every lane on
+        // "a alone" / "a + b 2^nd" for 2 Ref + dz [28, 29], a alone / a on top / b on top / b alone for newDz ZCoeff + dc CCoeff [30..33],
+        // a alone / a on top for next Ref + dz' [34, 35], for 2 Z + dz [36, 37] and for Z' + dz' [38, 39]
+        uint32_t w_arm[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        auto all_on = [](int arm, int k) { return __builtin_amdgcn_ballot_w64(arm == k) == __builtin_amdgcn_ballot_w64(true) ? 1u : 0u; };
         auto distinct = [](uint32_t v) {
             uint64_t m = __builtin_amdgcn_ballot_w64(true);
             uint32_t n = 0;
@@ -408,8 +414,11 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
                         RefIteration = next_stage;
                         return true;
                     }
-                    if (kStats)
-                        w_lamix |= mixed(arm_of(C64{RJ.re, RJ.im, clamp_exp(RJ.e + 1)}, dz)) << 8;
+                    if (kStats) {
+                        const int arm = arm_of(C64{RJ.re, RJ.im, clamp_exp(RJ.e + 1)}, dz);
+                        w_lamix |= mixed(arm) << 8;
+                        w_arm[0] += all_on(arm, 0), w_arm[1] += all_on(arm, 1);
+                    }
                     C64 newDz = hc_mul(dz, hc_add_w(C64{RJ.re, RJ.im, clamp_exp(RJ.e + 1)}, dz));
                     hc_reduce_w(newDz);
                     if (hr_cmp_pos(R64{cheb64(newDz), newDz.e}, thr) >= 0) { // LAInfoDeep::Prepare's unusable
@@ -418,11 +427,17 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
                     }
                     iterations += l;
                     n_la++;
-                    if (kStats)
-                        w_lamix |= mixed(arm_of(hc_mul(newDz, ZCoeff), hc_mul(dc, CCoeff))) << 8;
+                    if (kStats) {
+                        const int arm = arm_of(hc_mul(newDz, ZCoeff), hc_mul(dc, CCoeff));
+                        w_lamix |= mixed(arm) << 8;
+                        for (int k = 0; k < 4; k++)
+                            w_arm[2 + k] += all_on(arm, k);
+                    }
                     dz = hc_add_w(hc_mul(newDz, ZCoeff), hc_mul(dc, CCoeff));
                     if (kStats) {
-                        w_lamix |= mixed(arm_of(RN, dz)) << 8;
+                        const int arm = arm_of(RN, dz);
+                        w_arm[6] += all_on(arm, 0), w_arm[7] += all_on(arm, 1);
+                        w_lamix |= mixed(arm) << 8;
                         w_lamix = (w_lamix & 0xFFu) + (w_lamix >> 8 ? 1u : 0u); // (one per wave step with any mixed add)
                     }
                     const C64 complex0 = hc_add_w(RN, dz);
@@ -462,12 +477,18 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
                         int ye, i0, i1, i2, i3, i4, i5;
                         uint32_t st, so, sa;
                         uint64_t run, leftm, sx, m0, m1;
+#if FS_H64_LA_ASM_DEBUG
+                        uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+#define FS_DBG_CNT_OPS , [c0] "+s"(c0), [c1] "+s"(c1), [c2] "+s"(c2), [c3] "+s"(c3)
+#else
+#define FS_DBG_CNT_OPS
+#endif
                         asm volatile(FS_LA_UNIFORM_LOOP
                                      : [xr] "+v"(dz.re), [xi] "+v"(dz.im), [xe] "+v"(dz.e), [j] "+v"(j), [it] "+v"(iterations), [nla] "+v"(n_la),
                                        [refit] "+v"(RefIteration), [yr] "=&v"(yr), [yi] "=&v"(yi), [ye] "=&v"(ye), [t0] "=&v"(t0),
                                        [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [i0] "=&v"(i0),
                                        [i1] "=&v"(i1), [i2] "=&v"(i2), [i3] "=&v"(i3), [i4] "=&v"(i4), [i5] "=&v"(i5), [st] "=&s"(st),
-                                       [run] "=&s"(run), [left] "=&s"(leftm), [sx] "=&s"(sx), [so] "=&s"(so), [sa] "=&s"(sa), [m0] "=&s"(m0), [m1] "=&s"(m1)
+                                       [run] "=&s"(run), [left] "=&s"(leftm), [sx] "=&s"(sx), [so] "=&s"(so), [sa] "=&s"(sa), [m0] "=&s"(m0), [m1] "=&s"(m1) FS_DBG_CNT_OPS
                                      : [dcr] "v"(dc.re), [dci] "v"(dc.im), [dce] "v"(dc.e), [boff] "v"(base_off), [macro] "v"(MacroItCount), [m4k] "v"(-4000),
                                        [las] "s"(A.las), [nit] "s"(n_iterations), [cls] "s"(0x100), [tiny] "s"(0x1p-1000)
                                      : "vcc", "scc", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48",
@@ -476,7 +497,13 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
 #if FS_H64_LA_ASM_DEBUG
                         if (kStats && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) ==
                                           (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true)))
+                        {
                             atomicAdd((unsigned long long *)&A.stats[20 + st], 1ull); // exits of the statement by status
+                            atomicAdd((unsigned long long *)&A.stats[28], (unsigned long long)c0); // half-steps begun
+                            atomicAdd((unsigned long long *)&A.stats[29], (unsigned long long)c1); // general sums: 2 Ref + dz
+                            atomicAdd((unsigned long long *)&A.stats[30], (unsigned long long)c2); // newDz ZCoeff + dc CCoeff
+                            atomicAdd((unsigned long long *)&A.stats[31], (unsigned long long)c3); // next Ref + dz'
+                        }
 #endif
                         if (__builtin_amdgcn_inverse_ballot_w64(leftm))
                             break; // this lane has left the stage (RefIteration is the record's NextStageLAIndex)
@@ -540,7 +567,9 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
                     const uint32_t nd_ = distinct(zoff);
                     w_ptdist += nd_;
                     w_ptuni += nd_ == 1u ? 1u : 0u;
-                    w_mixA += mixed(arm_of(C64{ZH.re, ZH.im, ZH.e + 1}, dz));
+                    const int arm = arm_of(C64{ZH.re, ZH.im, ZH.e + 1}, dz);
+                    w_mixA += mixed(arm);
+                    w_arm[8] += all_on(arm, 0), w_arm[9] += all_on(arm, 1);
                 }
                 const C64 cur = hc_add_w(C64{ZH.re, ZH.im, ZH.e + 1}, dz); // (hc_mul2: x * 1.0 is x; e + 1 needs no clamp)
                 if (kStats)
@@ -550,8 +579,11 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
                 dz = q;
                 if (kStats)
                     c_pt++;
-                if (kStats)
-                    w_mixC += mixed(arm_of(ZN, dz));
+                if (kStats) {
+                    const int arm = arm_of(ZN, dz);
+                    w_mixC += mixed(arm);
+                    w_arm[10] += all_on(arm, 0), w_arm[11] += all_on(arm, 1);
+                }
                 C64 complex0 = hc_add_w(ZN, dz);
                 const double n1 = complex0.re * complex0.re + complex0.im * complex0.im;
                 const double n2 = dz.re * dz.re + dz.im * dz.im;
@@ -590,19 +622,28 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
                     int ye, qe, i0, i1, i2, i3;
                     uint32_t st;
                     uint64_t sx, mesc, mreb, mend;
+#if FS_H64_LA_ASM_DEBUG
+                    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+#endif
                     asm volatile(FS_PT_LOOP
                                  : [xr] "+v"(dz.re), [xi] "+v"(dz.im), [xe] "+v"(dz.e), [pr] "+v"(ZA.re), [pi] "+v"(ZA.im), [pe] "+v"(ZA.e),
                                    [zoff] "+v"(zoff), [iter] "+v"(iterations), [run] "+s"(run), [yr] "=&v"(yr), [yi] "=&v"(yi), [ye] "=&v"(ye),
                                    [qr] "=&v"(qr), [qi] "=&v"(qi), [qe] "=&v"(qe), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
                                    [t3] "=&v"(t3), [t4] "=&v"(t4), [i0] "=&v"(i0), [i1] "=&v"(i1), [i2] "=&v"(i2), [i3] "=&v"(i3),
-                                   [st] "=&s"(st), [sx] "=&s"(sx), [mesc] "=&s"(mesc), [mreb] "=&s"(mreb), [mend] "=&s"(mend)
+                                   [st] "=&s"(st), [sx] "=&s"(sx), [mesc] "=&s"(mesc), [mreb] "=&s"(mreb), [mend] "=&s"(mend) FS_DBG_CNT_OPS
                                  : [dce] "v"(dc.e), [m4k] "v"(-4000), [zb] "s"(zr), [niter] "s"(n_iterations), [maxoff] "s"(max_off),
                                    [cls] "s"(0x100), [tiny] "s"(0x1p-1000), [c256] "s"(256.0), [z0re] "s"(z0re), [z0im] "s"(z0im), [z0e] "s"(z0e)
                                  : "vcc", "scc", "memory");
 #if FS_H64_LA_ASM_DEBUG
                     if (kStats && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) ==
                                       (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true)))
+                    {
                         atomicAdd((unsigned long long *)&A.stats[24 + st], 1ull); // exits of the statement by status
+                        atomicAdd((unsigned long long *)&A.stats[32], (unsigned long long)c0); // half-steps begun
+                        atomicAdd((unsigned long long *)&A.stats[33], (unsigned long long)c1); // general sums: 2 Z + dz
+                        atomicAdd((unsigned long long *)&A.stats[34], (unsigned long long)c2); // steps with a rebasing lane
+                        atomicAdd((unsigned long long *)&A.stats[35], (unsigned long long)c3); // general sums: Z' + dz'
+                    }
 #endif
                     if (st == 0u)
                         break;
@@ -660,6 +701,9 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
                 const uint32_t v[12] = {w_pt, w_mixA, w_mixB, w_mixC, w_reb, w_la, w_lamix, w_lareb, w_launi, w_ladist, w_ptuni, w_ptdist};
                 for (int k = 0; k < 12; k++)
                     atomicAdd((unsigned long long *)&A.stats[8 + k], (unsigned long long)v[k]);
+                if (!FS_H64_LA_ASM_DEBUG)
+                    for (int k = 0; k < 12; k++)
+                        atomicAdd((unsigned long long *)&A.stats[28 + k], (unsigned long long)w_arm[k]);
             }
         }
         if (A.pixel_cost) {

@@ -21,6 +21,13 @@
 //   operands: sx EXEC at entry, so record offset, m0 / m1 masks, sa exponent of 2 Ref
 #pragma once
 
+// (probe build, FS_H64_LA_ASM_DEBUG: tallies of the half-steps begun and of the general sums taken, in scalar registers)
+#if FS_H64_LA_ASM_DEBUG
+#define FS_ASM_CNT(N) "s_add_u32 %[c" #N "], %[c" #N "], 1\n\t"
+#else
+#define FS_ASM_CNT(N) ""
+#endif
+
 // HDRFloatComplex::plus_mutable for operands whose lanes do NOT agree on the arm: hi + lo 2^(lo.e - hi.e), the shift replaced by
 // -4000 (m4k, a vector register: a literal and VCC are one constant-bus operand too many; the addend becomes a zero) from a gap of 120 on -- ldexp(a, sa) + ldexp(b, sb) with sa / sb = e - max(e_a, e_b), one of them 0.
 // AR/AI/AE: first operand (scalar or vector), BR/BI/BE vector; OR/OI <- sum, OE <- its exponent; SA/SB, TA/TB scratch.
@@ -59,7 +66,7 @@
     "s_load_dwordx8 s[52:59], %[las], %[so] offset:0x40\n\t"                                                          \
     "s_load_dwordx2 s[60:61], %[las], %[so] offset:0x78\n\t"                                                          \
     "s_load_dwordx8 s[64:71], %[las], %[so] offset:0x80\n\t"                                                          \
-    "s_waitcnt lgkmcnt(0)\n\t"                                                                                      \
+    "s_waitcnt lgkmcnt(0)\n\t" FS_ASM_CNT(0)                                                                        \
     /* (1) the step would pass the iteration limit: the lane leaves the stage */                                    \
     "v_add_u32_e32 %[i1], s60, %[it]\n\t"                                                                           \
     "v_cmp_ge_u32_e32 vcc, %[nit], %[i1]\n\t"                                                                       \
@@ -72,27 +79,22 @@
     "s_mov_b64 exec, %[m0]\n\t"                                                                                  \
     "s_cbranch_execz .Lla_done%=\n\t"                                                                               \
     ".Lla_1ok" S "%=:\n\t"                                                                                          \
-    /* (2) cur = 2 Ref + dz: every lane with 2 Ref on top and the gap below 120, or the general sum */            \
-    "s_max_i32 %[sa], s40, 0xefffffff\n\t"                                                                            \
-    "s_add_i32 %[sa], %[sa], 1\n\t"                                                                                     \
-    "v_subrev_u32_e32 %[i2], %[sa], " DIe "\n\t"                                                                      \
-    "v_add_u32_e32 %[i3], 0x77, %[i2]\n\t"                                                                          \
-    "v_cmp_gt_u32_e32 vcc, 0x78, %[i3]\n\t"                                                                         \
+    /* (2), (3) p = dz (2 Ref + dz).  First the arm most steps of a deep zoom take: dz 120 binades and more below 2 Ref in every lane */ \
+    /* (cur IS 2 Ref: the record's own values are the operands); then 2 Ref on top with the gap below 120; then the general sum */ \
+    "s_max_i32 %[sa], s40, 0xefffffff\n\t"                                                                          \
+    "s_add_i32 %[sa], %[sa], 1\n\t"                                                                                 \
+    "v_subrev_u32_e32 %[i2], %[sa], " DIe "\n\t"                                                                    \
+    "v_cmp_ge_i32_e32 vcc, 0xffffff88, %[i2]\n\t"                                                                   \
     "s_cmp_lg_u64 vcc, exec\n\t"                                                                                    \
-    "s_cbranch_scc1 .Lla_Agen" S "%=\n\t"                                                                           \
-    "v_ldexp_f64 %[t0], " DIr ", %[i2]\n\t"                                                                         \
-    "v_ldexp_f64 %[t1], " DIi ", %[i2]\n\t"                                                                         \
-    "v_add_f64 %[t0], s[36:37], %[t0]\n\t"                                                                          \
-    "v_add_f64 %[t1], s[38:39], %[t1]\n\t"                                                                          \
-    "v_add_u32_e32 %[i2], %[sa], " DIe "\n\t"                                                                         \
-    ".Lla_Aback" S "%=:\n\t"                                                                                        \
-    /* (3) p = dz cur, exponent clamped */                                                                          \
-    "v_mul_f64 %[t2], " DIr ", %[t0]\n\t"                                                                           \
-    "v_mul_f64 %[t3], " DIi ", %[t1]\n\t"                                                                           \
+    "s_cbranch_scc1 .Lla_Aother" S "%=\n\t"                                                                         \
+    "v_mul_f64 %[t2], " DIr ", s[36:37]\n\t"                                                                        \
+    "v_mul_f64 %[t3], " DIi ", s[38:39]\n\t"                                                                        \
     "v_add_f64 %[t2], %[t2], -%[t3]\n\t"                                                                            \
-    "v_mul_f64 %[t3], " DIr ", %[t1]\n\t"                                                                           \
-    "v_mul_f64 %[t4], " DIi ", %[t0]\n\t"                                                                           \
+    "v_mul_f64 %[t3], " DIr ", s[38:39]\n\t"                                                                        \
+    "v_mul_f64 %[t4], " DIi ", s[36:37]\n\t"                                                                        \
     "v_add_f64 %[t3], %[t3], %[t4]\n\t"                                                                             \
+    "v_add_u32_e32 %[i2], %[sa], " DIe "\n\t"                                                                       \
+    ".Lla_Amulled" S "%=:\n\t"                                                                                      \
     "v_max_i32_e32 %[i2], 0xf0000000, %[i2]\n\t"                                                                    \
     /* (4) Reduce: max(|re|, |im|) a normal number in every lane, or the compiled step takes over */               \
     "v_max_f64 %[t4], |%[t2]|, |%[t3]|\n\t"                                                                         \
@@ -122,44 +124,31 @@
     /* (6) the step is taken */                                                                                     \
     "v_mov_b32_e32 %[it], %[i1]\n\t"                                                                                \
     "v_add_u32_e32 %[nla], 1, %[nla]\n\t"                                                                           \
-    /* (7) dz' = newDz ZCoeff + dc CCoeff */                                                                        \
-    "v_mul_f64 %[t0], %[t2], s[42:43]\n\t"                                                                          \
-    "v_mul_f64 %[t1], %[t3], s[44:45]\n\t"                                                                          \
-    "v_add_f64 %[t0], %[t0], -%[t1]\n\t"                                                                            \
-    "v_mul_f64 %[t1], %[t2], s[44:45]\n\t"                                                                          \
-    "v_mul_f64 %[t5], %[t3], s[42:43]\n\t"                                                                          \
-    "v_add_f64 %[t1], %[t1], %[t5]\n\t"                                                                             \
+    /* (7) dz' = newDz ZCoeff + dc CCoeff: the exponents first -- with dc CCoeff 120 binades and more below in every lane (nine */ \
+    /* steps of ten at C4's zoom) the second product is never formed */                                             \
     "v_add_u32_e32 %[i2], s46, %[i2]\n\t"                                                                           \
     "v_max_i32_e32 %[i2], 0xf0000000, %[i2]\n\t"                                                                    \
-    "v_mul_f64 %[t2], %[dcr], s[48:49]\n\t"                                                                         \
-    "v_mul_f64 %[t3], %[dci], s[50:51]\n\t"                                                                         \
-    "v_add_f64 %[t2], %[t2], -%[t3]\n\t"                                                                            \
-    "v_mul_f64 %[t3], %[dcr], s[50:51]\n\t"                                                                         \
-    "v_mul_f64 %[t5], %[dci], s[48:49]\n\t"                                                                         \
-    "v_add_f64 %[t3], %[t3], %[t5]\n\t"                                                                             \
     "v_add_u32_e32 %[i3], s52, %[dce]\n\t"                                                                          \
     "v_max_i32_e32 %[i3], 0xf0000000, %[i3]\n\t"                                                                    \
     "v_sub_u32_e32 %[i4], %[i3], %[i2]\n\t"                                                                         \
-    "v_add_u32_e32 %[i5], 0x77, %[i4]\n\t"                                                                          \
-    "v_cmp_gt_u32_e32 vcc, 0x78, %[i5]\n\t"                                                                         \
+    "v_cmp_ge_i32_e32 vcc, 0xffffff88, %[i4]\n\t"                                                                   \
     "s_cmp_lg_u64 vcc, exec\n\t"                                                                                    \
-    "s_cbranch_scc1 .Lla_Sgen" S "%=\n\t"                                                                           \
-    "v_ldexp_f64 %[t2], %[t2], %[i4]\n\t"                                                                           \
-    "v_ldexp_f64 %[t3], %[t3], %[i4]\n\t"                                                                           \
-    "v_add_f64 " DOr ", %[t0], %[t2]\n\t"                                                                           \
-    "v_add_f64 " DOi ", %[t1], %[t3]\n\t"                                                                           \
+    "s_cbranch_scc1 .Lla_Sother" S "%=\n\t"                                                                         \
+    "v_mul_f64 " DOr ", %[t2], s[42:43]\n\t"                                                                        \
+    "v_mul_f64 %[t0], %[t3], s[44:45]\n\t"                                                                          \
+    "v_add_f64 " DOr ", " DOr ", -%[t0]\n\t"                                                                        \
+    "v_mul_f64 " DOi ", %[t2], s[44:45]\n\t"                                                                        \
+    "v_mul_f64 %[t0], %[t3], s[42:43]\n\t"                                                                          \
+    "v_add_f64 " DOi ", " DOi ", %[t0]\n\t"                                                                         \
     "v_mov_b32_e32 " DOe ", %[i2]\n\t"                                                                              \
     ".Lla_Sback" S "%=:\n\t"                                                                                        \
-    /* (8) complex0 = next Ref + dz'; i4 <- complex0.e - dz'.e */                                                   \
+    /* (8) complex0 = next Ref + dz'; i4 <- complex0.e - dz'.e.  dz' 120 binades and more below in every lane: the next Ref itself */ \
     "v_subrev_u32_e32 %[i4], s68, " DOe "\n\t"                                                                      \
-    "v_add_u32_e32 %[i5], 0x77, %[i4]\n\t"                                                                          \
-    "v_cmp_gt_u32_e32 vcc, 0x78, %[i5]\n\t"                                                                         \
+    "v_cmp_ge_i32_e32 vcc, 0xffffff88, %[i4]\n\t"                                                                   \
     "s_cmp_lg_u64 vcc, exec\n\t"                                                                                    \
-    "s_cbranch_scc1 .Lla_Cgen" S "%=\n\t"                                                                           \
-    "v_ldexp_f64 %[t0], " DOr ", %[i4]\n\t"                                                                         \
-    "v_ldexp_f64 %[t1], " DOi ", %[i4]\n\t"                                                                         \
-    "v_add_f64 %[t0], s[64:65], %[t0]\n\t"                                                                          \
-    "v_add_f64 %[t1], s[66:67], %[t1]\n\t"                                                                          \
+    "s_cbranch_scc1 .Lla_Cother" S "%=\n\t"                                                                         \
+    "v_mov_b64_e32 %[t0], s[64:65]\n\t"                                                                             \
+    "v_mov_b64_e32 %[t1], s[66:67]\n\t"                                                                             \
     "v_sub_u32_e32 %[i4], 0, %[i4]\n\t"                                                                             \
     ".Lla_Cback" S "%=:\n\t"                                                                                        \
     /* (9) j + 1; rebase: |complex0| < |dz'| (Chebyshev norms, both above 2^-1000 or the compiled test decides) or the stage's end */ \
@@ -194,15 +183,67 @@
     "s_cbranch_execz .Lla_done%=\n\t"                                                                               \
     "s_branch .Lla_next" S "%=\n\t"                                                                                 \
     /* ---- out of line: the general sums */                                                                        \
-    ".Lla_Agen" S "%=:\n\t"                                                                                         \
-    "v_mov_b32_e32 %[i5], %[sa]\n\t"                                                                                  \
+    ".Lla_Aother" S "%=:\n\t"                                                                                       \
+    "v_add_u32_e32 %[i3], 0x77, %[i2]\n\t"                                                                          \
+    "v_cmp_gt_u32_e32 vcc, 0x78, %[i3]\n\t"                                                                         \
+    "s_cmp_lg_u64 vcc, exec\n\t"                                                                                    \
+    "s_cbranch_scc1 .Lla_Agen" S "%=\n\t"                                                                           \
+    "v_ldexp_f64 %[t0], " DIr ", %[i2]\n\t"                                                                         \
+    "v_ldexp_f64 %[t1], " DIi ", %[i2]\n\t"                                                                         \
+    "v_add_f64 %[t0], s[36:37], %[t0]\n\t"                                                                          \
+    "v_add_f64 %[t1], s[38:39], %[t1]\n\t"                                                                          \
+    "v_add_u32_e32 %[i2], %[sa], " DIe "\n\t"                                                                       \
+    ".Lla_Amul" S "%=:\n\t"                                                                                         \
+    "v_mul_f64 %[t2], " DIr ", %[t0]\n\t"                                                                           \
+    "v_mul_f64 %[t3], " DIi ", %[t1]\n\t"                                                                           \
+    "v_add_f64 %[t2], %[t2], -%[t3]\n\t"                                                                            \
+    "v_mul_f64 %[t3], " DIr ", %[t1]\n\t"                                                                           \
+    "v_mul_f64 %[t4], " DIi ", %[t0]\n\t"                                                                           \
+    "v_add_f64 %[t3], %[t3], %[t4]\n\t"                                                                             \
+    "s_branch .Lla_Amulled" S "%=\n\t"                                                                              \
+    ".Lla_Agen" S "%=:\n\t" FS_ASM_CNT(1)                                                                           \
+    "v_mov_b32_e32 %[i5], %[sa]\n\t"                                                                                \
     FS_LA_GENADD("s[36:37]", "s[38:39]", "%[i5]", DIr, DIi, DIe, "%[t0]", "%[t1]", "%[i3]", "%[i4]", "%[i2]", "%[t4]", "%[t5]") \
     "v_add_u32_e32 %[i2], %[i3], " DIe "\n\t"                                                                       \
-    "s_branch .Lla_Aback" S "%=\n\t"                                                                                \
-    ".Lla_Sgen" S "%=:\n\t"                                                                                         \
+    "s_branch .Lla_Amul" S "%=\n\t"                                                                                 \
+    ".Lla_Sother" S "%=:\n\t"                                                                                       \
+    "v_mul_f64 %[t0], %[t2], s[42:43]\n\t"                                                                          \
+    "v_mul_f64 %[t1], %[t3], s[44:45]\n\t"                                                                          \
+    "v_add_f64 %[t0], %[t0], -%[t1]\n\t"                                                                            \
+    "v_mul_f64 %[t1], %[t2], s[44:45]\n\t"                                                                          \
+    "v_mul_f64 %[t5], %[t3], s[42:43]\n\t"                                                                          \
+    "v_add_f64 %[t1], %[t1], %[t5]\n\t"                                                                             \
+    "v_mul_f64 %[t2], %[dcr], s[48:49]\n\t"                                                                         \
+    "v_mul_f64 %[t3], %[dci], s[50:51]\n\t"                                                                         \
+    "v_add_f64 %[t2], %[t2], -%[t3]\n\t"                                                                            \
+    "v_mul_f64 %[t3], %[dcr], s[50:51]\n\t"                                                                         \
+    "v_mul_f64 %[t5], %[dci], s[48:49]\n\t"                                                                         \
+    "v_add_f64 %[t3], %[t3], %[t5]\n\t"                                                                             \
+    "v_add_u32_e32 %[i5], 0x77, %[i4]\n\t"                                                                          \
+    "v_cmp_gt_u32_e32 vcc, 0x78, %[i5]\n\t"                                                                         \
+    "s_cmp_lg_u64 vcc, exec\n\t"                                                                                    \
+    "s_cbranch_scc1 .Lla_Sgen" S "%=\n\t"                                                                           \
+    "v_ldexp_f64 %[t2], %[t2], %[i4]\n\t"                                                                           \
+    "v_ldexp_f64 %[t3], %[t3], %[i4]\n\t"                                                                           \
+    "v_add_f64 " DOr ", %[t0], %[t2]\n\t"                                                                           \
+    "v_add_f64 " DOi ", %[t1], %[t3]\n\t"                                                                           \
+    "v_mov_b32_e32 " DOe ", %[i2]\n\t"                                                                              \
+    "s_branch .Lla_Sback" S "%=\n\t"                                                                                \
+    ".Lla_Sgen" S "%=:\n\t" FS_ASM_CNT(2)                                                                           \
     FS_LA_GENADD("%[t0]", "%[t1]", "%[i2]", "%[t2]", "%[t3]", "%[i3]", DOr, DOi, DOe, "%[i4]", "%[i5]", "%[t4]", "%[t5]") \
     "s_branch .Lla_Sback" S "%=\n\t"                                                                                \
-    ".Lla_Cgen" S "%=:\n\t"                                                                                         \
+    ".Lla_Cother" S "%=:\n\t"                                                                                       \
+    "v_add_u32_e32 %[i5], 0x77, %[i4]\n\t"                                                                          \
+    "v_cmp_gt_u32_e32 vcc, 0x78, %[i5]\n\t"                                                                         \
+    "s_cmp_lg_u64 vcc, exec\n\t"                                                                                    \
+    "s_cbranch_scc1 .Lla_Cgen" S "%=\n\t"                                                                           \
+    "v_ldexp_f64 %[t0], " DOr ", %[i4]\n\t"                                                                         \
+    "v_ldexp_f64 %[t1], " DOi ", %[i4]\n\t"                                                                         \
+    "v_add_f64 %[t0], s[64:65], %[t0]\n\t"                                                                          \
+    "v_add_f64 %[t1], s[66:67], %[t1]\n\t"                                                                          \
+    "v_sub_u32_e32 %[i4], 0, %[i4]\n\t"                                                                             \
+    "s_branch .Lla_Cback" S "%=\n\t"                                                                                \
+    ".Lla_Cgen" S "%=:\n\t" FS_ASM_CNT(3)                                                                           \
     "v_mov_b32_e32 %[i5], s68\n\t"                                                                                  \
     FS_LA_GENADD("s[64:65]", "s[66:67]", "%[i5]", DOr, DOi, DOe, "%[t0]", "%[t1]", "%[i3]", "%[i4]", "%[i2]", "%[t4]", "%[t5]") \
     "v_sub_u32_e32 %[i4], %[i3], " DOe "\n\t"                                                                       \

@@ -24,7 +24,7 @@
     ".Lpt_top" S "%=:\n\t"                                                                                          \
     "global_load_dwordx2 " ZNr ", %[zoff], %[zb] offset:32\n\t"                                                     \
     "global_load_dwordx2 " ZNi ", %[zoff], %[zb] offset:40\n\t"                                                     \
-    "global_load_dword " ZNe ", %[zoff], %[zb] offset:48\n\t"                                                       \
+    "global_load_dword " ZNe ", %[zoff], %[zb] offset:48\n\t" FS_ASM_CNT(0)                                         \
     /* cur = 2 Z + dz */                                                                                            \
     "v_add_u32_e32 %[i0], 1, " ZHe "\n\t"                                                                           \
     "v_sub_u32_e32 %[i1], " DIe ", %[i0]\n\t"                                                                       \
@@ -96,7 +96,7 @@
     "s_or_b64 %[mreb], %[mreb], %[mend]\n\t"                                                                        \
     "s_andn2_b64 %[mreb], %[mreb], %[mesc]\n\t" /* (an escaped lane does not rebase) */                            \
     "s_and_b64 %[mreb], %[mreb], exec\n\t"                                                                          \
-    "s_cbranch_scc0 .Lpt_noreb" S "%=\n\t"                                                                          \
+    "s_cbranch_scc0 .Lpt_noreb" S "%=\n\t" FS_ASM_CNT(2)                                                            \
     /* rebase: dz' = Reduce(complex0), the orbit from its first entry */                                            \
     "s_mov_b64 %[mend], exec\n\t"                                                                                   \
     "s_mov_b64 exec, %[mreb]\n\t"                                                                                   \
@@ -126,11 +126,11 @@
     "s_cbranch_execz .Lpt_done%=\n\t"                                                                               \
     "s_branch .Lpt_next" S "%=\n\t"                                                                                 \
     /* ---- out of line: the general sums */                                                                        \
-    ".Lpt_Agen" S "%=:\n\t"                                                                                         \
+    ".Lpt_Agen" S "%=:\n\t" FS_ASM_CNT(1)                                                                           \
     FS_LA_GENADD(ZHr, ZHi, "%[i0]", DIr, DIi, DIe, "%[t0]", "%[t1]", "%[i3]", "%[i1]", "%[i2]", "%[t2]", "%[t3]")   \
     "v_add_u32_e32 %[i1], " DIe ", %[i3]\n\t"                                                                       \
     "s_branch .Lpt_Aback" S "%=\n\t"                                                                                \
-    ".Lpt_Cgen" S "%=:\n\t"                                                                                         \
+    ".Lpt_Cgen" S "%=:\n\t" FS_ASM_CNT(3)                                                                           \
     FS_LA_GENADD(ZNr, ZNi, ZNe, DOr, DOi, DOe, "%[t0]", "%[t1]", "%[i0]", "%[i1]", "%[i2]", "%[t2]", "%[t3]")       \
     "v_lshlrev_b32_e32 %[i2], 1, %[i0]\n\t"                                                                         \
     "v_sub_u32_e32 %[i3], %[i0], " DOe "\n\t"                                                                       \

@@ -58,7 +58,7 @@ struct fs_renderer {
     fs_color16 *colors = nullptr;
     fs_reduction *reduction = nullptr;
     uint64_t *stats = nullptr;
-    size_t stats_words = 32;
+    size_t stats_words = 40;
 
     uint32_t *queue = nullptr; // pixel counter of the persistent launches (kernels_perturb.hip, k_perturb_scalar)
     uint32_t *tile_probe = nullptr, *tile_order = nullptr; // "long tiles first" (fs_render_bla): probe counts, launch order
@@ -775,7 +775,7 @@ struct TimedLaunch {
             r->mid_valid[r->timed_launches % fs_renderer::kTimingRing] = false;
         }
         if (r->stats_on && r->stats)
-            hipMemsetAsync(r->stats, 0, (r->stats_words == 32 ? 32 : 8) * sizeof(uint64_t), r->compute);
+            hipMemsetAsync(r->stats, 0, (r->stats_words == 40 ? 40 : 8) * sizeof(uint64_t), r->compute);
     }
     void mid() // between the two kernels of a two-kernel frame
     {
@@ -1047,7 +1047,7 @@ uint32_t fs_init_memory(fs_renderer *r, uint32_t w, uint32_t h, uint32_t antiali
         // 8 counters; a measurement build (FS_TRACE_WAVES) appends four words per wave of the largest frame it will see
         // (words 16..27: per-phase cycle counters of the FS_PROFILE_CYCLES build of the BLA kernel, tools/c5_phase_probe.py;
         // the two measurement builds are not combined)
-        r->stats_words = 32;
+        r->stats_words = 40; // (words 28..39: the probe build of k_lav2_hdr64's hand-written loops, tools/c4_arm_probe.py)
         if (const char *e = getenv("FSMI355_TRACE_WAVES"))
             r->stats_words = 16 + 4 * (size_t)atoll(e);
         FS_TRY(r_alloc(r, (void **)&r->stats, r->stats_words * sizeof(uint64_t), kFrame));

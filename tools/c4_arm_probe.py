@@ -29,9 +29,9 @@ def frame(stats):
     r.enable_step_count(stats)
     assert r.RenderPerturbLAv2(None, None, None, *inp["coords"], inp["n_iter"], T=T_HDR64, Mode=LAV2_FULL, parity=PARITY_CPU_GPUSTAGE) == 0
     assert r.SyncComputeStream() == 0
-    raw = (C.c_uint64 * 32)()
+    raw = (C.c_uint64 * 40)()
     if stats:
-        assert r._lib.fs_read_stats_raw(r._h, raw, 32) == 0
+        assert r._lib.fs_read_stats_raw(r._h, raw, 40) == 0
     return list(raw), bool(r.last_frame_tile_ordered()), r.last_kernel_ms()
 
 
@@ -50,6 +50,13 @@ for label, warm in (("tile mapping (first frame)", 0), ("count order (third fram
         d["la_statement_exits_by_status"] = raw[20:24]
     if any(raw[24:28]):
         d["pt_statement_exits_by_status"] = raw[24:28]
+    if any(raw[20:28]):  # the probe build (FS_H64_LA_ASM_DEBUG=1)
+        d["la_statement_half_steps_and_general_sums_A_S_C"] = raw[28:32]
+        d["pt_statement_half_steps_generalA_rebasing_generalC"] = raw[32:36]
+    else:
+        d["all_lanes_on_arm"] = {"la 2Ref+dz [a alone, a on top]": raw[28:30], "la newDz ZCoeff + dc CCoeff [a alone, a on top, b on top, b alone]": raw[30:34],
+                                 "la nextRef+dz' [a alone, a on top]": raw[34:36], "pt 2Z+dz [a alone, a on top]": raw[36:38],
+                                 "pt Z'+dz' [a alone, a on top]": raw[38:40]}
     if raw[13]:
         d["la_distinct_records_per_wave_step"] = round(raw[17] / raw[13], 2)
     if raw[8]:
