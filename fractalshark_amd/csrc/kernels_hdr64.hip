@@ -90,6 +90,9 @@ __device__ __forceinline__ C64 add_hi_lo(C64 hi, const C64 lo)
 #ifndef FS_H64_LA_ASM
 #define FS_H64_LA_ASM 1 /* the LA steps of a wave whose lanes stand at one record by hand (la_step_asm.hpp); 0: the compiled loop, A/B */
 #endif
+#ifndef FS_H64_ASM_COLD
+#define FS_H64_ASM_COLD 1 /* the first frame of a view runs the hand-written loops too (0: A/B -- 52.6 against 50.6 ms once the statements had their "alone" arms; 54.8 against 52.3 before) */
+#endif
 #ifndef FS_H64_LA_SCALAR
 #define FS_H64_LA_SCALAR 1 /* LA records through the scalar cache where the wave's lanes agree on the record (0: A/B) */
 #endif
@@ -385,6 +388,12 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
                 // per CU cycle).  kUni: the record is read through a constant-address-space pointer at a wave-uniform offset
                 // (s_load), its fields are scalar operands of the same operations, and RJ / lJ are not needed (Ref and length of
                 // record j are in the record itself).
+                // a + b where b is usually 120 binades and more below a in every lane of the wave (dz against an orbit value at a deep zoom)
+                auto add_a_first = [](const C64 a, const C64 b) __attribute__((always_inline)) {
+                    if (__builtin_amdgcn_ballot_w64(b.e - a.e <= -kExpDiffIgnored) == __builtin_amdgcn_ballot_w64(true))
+                        return a;
+                    return hc_add_w(a, b);
+                };
                 auto la_body = [&](auto LAj, auto uni, const C64 &RJ_in, const uint32_t &lJ_in, C64 &RN, uint32_t &lN)
                                    __attribute__((always_inline)) -> bool {
                     constexpr bool kUni = decltype(uni)::value;
@@ -419,7 +428,7 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
                         w_lamix |= mixed(arm) << 8;
                         w_arm[0] += all_on(arm, 0), w_arm[1] += all_on(arm, 1);
                     }
-                    C64 newDz = hc_mul(dz, hc_add_w(C64{RJ.re, RJ.im, clamp_exp(RJ.e + 1)}, dz));
+                    C64 newDz = hc_mul(dz, add_a_first(C64{RJ.re, RJ.im, clamp_exp(RJ.e + 1)}, dz));
                     hc_reduce_w(newDz);
                     if (hr_cmp_pos(R64{cheb64(newDz), newDz.e}, thr) >= 0) { // LAInfoDeep::Prepare's unusable
                         RefIteration = next_stage;
@@ -433,14 +442,20 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
                         for (int k = 0; k < 4; k++)
                             w_arm[2 + k] += all_on(arm, k);
                     }
-                    dz = hc_add_w(hc_mul(newDz, ZCoeff), hc_mul(dc, CCoeff));
+                    // (dc CCoeff 120 binades and more below newDz ZCoeff in every lane -- nine steps of ten at C4's zoom: plus_mutable returns
+                    // its first operand, and the second product need not be formed)
+                    if (__builtin_amdgcn_ballot_w64(clamp_exp(dc.e + CCoeff.e) - clamp_exp(newDz.e + ZCoeff.e) <= -kExpDiffIgnored) ==
+                        __builtin_amdgcn_ballot_w64(true))
+                        dz = hc_mul(newDz, ZCoeff);
+                    else
+                        dz = hc_add_w(hc_mul(newDz, ZCoeff), hc_mul(dc, CCoeff));
                     if (kStats) {
                         const int arm = arm_of(RN, dz);
                         w_arm[6] += all_on(arm, 0), w_arm[7] += all_on(arm, 1);
                         w_lamix |= mixed(arm) << 8;
                         w_lamix = (w_lamix & 0xFFu) + (w_lamix >> 8 ? 1u : 0u); // (one per wave step with any mixed add)
                     }
-                    const C64 complex0 = hc_add_w(RN, dz);
+                    const C64 complex0 = add_a_first(RN, dz);
                     j++;
                     const bool la_rebase = less_w(cheb64(complex0), complex0.e, cheb64(dz), dz.e) || j >= MacroItCount;
                     if (kStats)
@@ -468,7 +483,7 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
                 // (frames in a recorded order only -- kAtInKernel is the first frame of a view, in the tile mapping, where a quarter of
                 // the LA steps have lanes at different records and every one of them would leave the statement for a compiled step and
                 // come back: 54.8 against 52.3 ms)
-                if constexpr ((!kStats || FS_H64_LA_ASM_DEBUG) && !kAtInKernel) {
+                if constexpr ((!kStats || FS_H64_LA_ASM_DEBUG) && (!kAtInKernel || FS_H64_ASM_COLD)) {
                     // the hand-written loop for the steps whose lanes stand at one record (la_step_asm.hpp); what it hands back --
                     // lanes at different records, a product that Reduce's fast form does not cover, a norm below 2^-1000 in the
                     // rebase test -- takes ONE compiled step (or its rebase test) and goes back in
@@ -606,7 +621,7 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
             if (iterations < n_iterations)
                 ZA = z_at_off(zr, zoff);
 #if FS_H64_PT_ASM
-            if constexpr ((!kStats || FS_H64_LA_ASM_DEBUG) && !kAtInKernel) {
+            if constexpr ((!kStats || FS_H64_LA_ASM_DEBUG) && (!kAtInKernel || FS_H64_ASM_COLD)) {
                 // ---- the perturbation loop by hand (pt_step_asm.hpp) for the frames in a recorded order; what the statement hands
                 // back takes one compiled step (status 1, 3) or the compiled tests of the step it has computed (status 2)
                 const uint32_t z0re_lo = __builtin_amdgcn_readfirstlane((int)(uint32_t)__builtin_bit_cast(uint64_t, zr[0].re));
