@@ -633,22 +633,21 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
                 bool running = iterations < n_iterations;
                 uint64_t run = __builtin_amdgcn_ballot_w64(running);
                 while (run != 0ull) {
-                    double yr, yi, qr, qi, t0, t1, t2, t3, t4;
-                    int ye, qe, i0, i1, i2, i3;
+                    double yr, yi, t0, t1, t2, t3, t4;
+                    int ye, i0, i1, i2, i3;
                     uint32_t st;
                     uint64_t sx, mesc, mreb, mend;
 #if FS_H64_LA_ASM_DEBUG
                     uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
 #endif
                     asm volatile(FS_PT_LOOP
-                                 : [xr] "+v"(dz.re), [xi] "+v"(dz.im), [xe] "+v"(dz.e), [pr] "+v"(ZA.re), [pi] "+v"(ZA.im), [pe] "+v"(ZA.e),
-                                   [zoff] "+v"(zoff), [iter] "+v"(iterations), [run] "+s"(run), [yr] "=&v"(yr), [yi] "=&v"(yi), [ye] "=&v"(ye),
-                                   [qr] "=&v"(qr), [qi] "=&v"(qi), [qe] "=&v"(qe), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
+                                 : [xr] "+v"(dz.re), [xi] "+v"(dz.im), [xe] "+v"(dz.e), [zoff] "+v"(zoff), [iter] "+v"(iterations),
+                                   [run] "+s"(run), [yr] "=&v"(yr), [yi] "=&v"(yi), [ye] "=&v"(ye), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
                                    [t3] "=&v"(t3), [t4] "=&v"(t4), [i0] "=&v"(i0), [i1] "=&v"(i1), [i2] "=&v"(i2), [i3] "=&v"(i3),
                                    [st] "=&s"(st), [sx] "=&s"(sx), [mesc] "=&s"(mesc), [mreb] "=&s"(mreb), [mend] "=&s"(mend) FS_DBG_CNT_OPS
                                  : [dce] "v"(dc.e), [m4k] "v"(-4000), [zb] "s"(zr), [niter] "s"(n_iterations), [maxoff] "s"(max_off),
                                    [cls] "s"(0x100), [tiny] "s"(0x1p-1000), [c256] "s"(256.0), [z0re] "s"(z0re), [z0im] "s"(z0im), [z0e] "s"(z0e)
-                                 : "vcc", "scc", "memory");
+                                 : "vcc", "scc", "memory", "v52", "v53", "v54", "v55", "v56", "v58", "v59", "v60", "v61", "v62");
 #if FS_H64_LA_ASM_DEBUG
                     if (kStats && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) ==
                                       (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true)))
@@ -664,8 +663,9 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
                         break;
                     running = __builtin_amdgcn_inverse_ballot_w64(run);
                     if (running) {
-                        if (st == 2u) { // dz' and the entry it arrives at are in place: the tests, the rebase, the count
+                        if (st == 2u) { // dz' is in place: the tests, the rebase, the count
                             zoff += (uint32_t)sizeof(FsZ64);
+                            ZA = z_at_off(zr, zoff);
                             C64 complex0 = hc_add_w(ZA, dz);
                             const double n1 = complex0.re * complex0.re + complex0.im * complex0.im;
                             const double n2 = dz.re * dz.re + dz.im * dz.im;
@@ -683,7 +683,7 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
                                 iterations++;
                                 running = iterations < n_iterations;
                             }
-                        } else if (pt_step(ZA, ZB)) { // one step through the compiled code for every lane still running
+                        } else if (ZA = z_at_off(zr, zoff), pt_step(ZA, ZB)) { // one step through the compiled code for every lane still running
                             running = false;
                         } else {
                             iterations++;

@@ -9,21 +9,22 @@
 // What is done here is the step of a wave whose lanes agree: 2 Z + dz and Z' + dz' with the orbit value on top (or, out of line, the
 // general sum), dc 120 binades and more below dz (2 Z + dz) in every lane (dz t + dc IS dz t), Reduce on normal numbers, both squared
 // norms above 2^-1000.  Anything else leaves the statement: status 1 / 3 before the step has changed anything (one compiled step
-// follows), status 2 with dz' in X and the entry the step arrives at in P, zoff and the count as they were (the compiled code does
+// follows), status 2 with dz' in X, zoff and the count as they were (the compiled code does
 // the tests, the rebase and the count).  Status 0: every lane has escaped or reached the cap.
 #pragma once
 
 #include "la_step_asm.hpp" /* FS_LA_GENADD */
 
 #define FS_PT_COPY_YX "v_mov_b64_e32 %[xr], %[yr]\n\tv_mov_b64_e32 %[xi], %[yi]\n\tv_mov_b32_e32 %[xe], %[ye]\n\t"
-#define FS_PT_COPY_QP "v_mov_b64_e32 %[pr], %[qr]\n\tv_mov_b64_e32 %[pi], %[qi]\n\tv_mov_b32_e32 %[pe], %[qe]\n\t"
+// The orbit entries live in NAMED registers -- P = v[52:56], Q = v[58:62] (tuples start on even registers): one 16-byte load and one 4-byte load per entry need four
+// consecutive registers, which operands cannot promise -- and do not cross the statement's boundary: it loads the entry at zoff when
+// it starts, and the compiled code that follows an exit reads the entry it needs itself.
 
 // One half-step.  S: label suffix; DI*: dz in; DO*: dz out; ZH*: the entry the step leaves from; ZN*: the entry it arrives at (loaded
 // here); CPI: copies for an exit BEFORE the step (input sets back to X / P), CPO: copies for the status-2 exit (output sets to X / P).
-#define FS_PT_HALF(S, DIr, DIi, DIe, DOr, DOi, DOe, ZHr, ZHi, ZHe, ZNr, ZNi, ZNe, CPI, CPO)                         \
+#define FS_PT_HALF(S, DIr, DIi, DIe, DOr, DOi, DOe, ZHr, ZHi, ZHe, ZN4, ZNr, ZNi, ZNe, CPI, CPO)                         \
     ".Lpt_top" S "%=:\n\t"                                                                                          \
-    "global_load_dwordx2 " ZNr ", %[zoff], %[zb] offset:32\n\t"                                                     \
-    "global_load_dwordx2 " ZNi ", %[zoff], %[zb] offset:40\n\t"                                                     \
+    "global_load_dwordx4 " ZN4 ", %[zoff], %[zb] offset:32\n\t"                                                     \
     "global_load_dword " ZNe ", %[zoff], %[zb] offset:48\n\t" FS_ASM_CNT(0)                                         \
     /* cur = 2 Z + dz */                                                                                            \
     "v_add_u32_e32 %[i0], 1, " ZHe "\n\t"                                                                           \
@@ -151,10 +152,13 @@
 #define FS_PT_LOOP                                                                                                  \
     "s_mov_b64 %[sx], exec\n\t"                                                                                     \
     "s_mov_b64 exec, %[run]\n\t"                                                                                    \
-    FS_PT_HALF("A", "%[xr]", "%[xi]", "%[xe]", "%[yr]", "%[yi]", "%[ye]", "%[pr]", "%[pi]", "%[pe]", "%[qr]", "%[qi]", "%[qe]", "", \
-               FS_PT_COPY_YX FS_PT_COPY_QP)                                                                         \
-    FS_PT_HALF("B", "%[yr]", "%[yi]", "%[ye]", "%[xr]", "%[xi]", "%[xe]", "%[qr]", "%[qi]", "%[qe]", "%[pr]", "%[pi]", "%[pe]",     \
-               FS_PT_COPY_YX FS_PT_COPY_QP, "")                                                                     \
+    "global_load_dwordx4 v[52:55], %[zoff], %[zb]\n\t"                                                              \
+    "global_load_dword v56, %[zoff], %[zb] offset:16\n\t"                                                           \
+    "s_waitcnt vmcnt(0)\n\t"                                                                                        \
+    FS_PT_HALF("A", "%[xr]", "%[xi]", "%[xe]", "%[yr]", "%[yi]", "%[ye]", "v[52:53]", "v[54:55]", "v56", "v[58:61]", "v[58:59]",   \
+               "v[60:61]", "v62", "", FS_PT_COPY_YX)                                                                \
+    FS_PT_HALF("B", "%[yr]", "%[yi]", "%[ye]", "%[xr]", "%[xi]", "%[xe]", "v[58:59]", "v[60:61]", "v62", "v[52:55]", "v[52:53]",   \
+               "v[54:55]", "v56", FS_PT_COPY_YX, "")                                                                \
     "s_branch .Lpt_topA%=\n\t"                                                                                      \
     ".Lpt_leave1%=:\n\t"                                                                                            \
     "s_mov_b32 %[st], 1\n\t"                                                                                        \

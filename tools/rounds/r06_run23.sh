@@ -3,7 +3,7 @@
 # AT pass and the frame's kernel, with the first frame split into the same two launches (FSMI355_AT_SPLIT_COLD=1)
 set -u
 cd "$(dirname "$0")/../.."
-export FS_NO_BUILD=1 TMPDIR=/tmp FSMI355_AT_SPLIT_COLD=1
+export FS_NO_BUILD=1 TMPDIR=/tmp FSMI355_AT_SPLIT_COLD=${SPLIT:-1}
 O=gpurun_out/r06s
 mkdir -p $O
 i=0
