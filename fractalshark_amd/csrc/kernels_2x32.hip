@@ -358,7 +358,13 @@ __global__ void __launch_bounds__(256) k_lav2_2x32(FsLav2Args2x32 A)
                     if (kStats)
                         c_la++;
                     // Evaluate GPU_LAInfoDeep.h:120-124, getZ LAstep.h:181-185
-                    DeltaSubN = hc_add_pk(hc_mul_pk(newDz, ZCoeff), hc_mul_pk(DeltaSub0, CCoeff));
+                    // (round 6: dc CCoeff 120 binades and more below newDz ZCoeff in every lane of the wave -- nine LA steps of ten at
+                    // C4's zoom, tools/c4_arm_probe.py -- plus_mutable returns its first operand: the second product is not formed)
+                    if (__builtin_amdgcn_ballot_w64(clamp_exp(newDz.e + ZCoeff.e) - clamp_exp(DeltaSub0.e + CCoeff.e) >= kExpDiffIgnored) ==
+                        __builtin_amdgcn_ballot_w64(true))
+                        DeltaSubN = hc_mul_pk(newDz, ZCoeff);
+                    else
+                        DeltaSubN = hc_add_pk(hc_mul_pk(newDz, ZCoeff), hc_mul_pk(DeltaSub0, CCoeff));
                     const HC complex0 = hc_add_pk(RN, DeltaSubN);
                     j++;
                     const HR lhs = hr_reduced(hc_cheb(complex0));

@@ -174,7 +174,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
                     la_cost += 8u;
                     if (kStats)
                         c_la++;
-                    DeltaSubN = hc_add(hc_mul(newDz, ldc(LAj->ZCoeff)), hc_mul(DeltaSub0, ldc(LAj->CCoeff)));
+                    // (round 6, as in k_lav2_hdr64: with dc CCoeff 120 binades and more below newDz ZCoeff in every lane of the wave
+                    // plus_mutable returns its first operand, and the second product is not formed)
+                    if (__builtin_amdgcn_ballot_w64(fs::clamp_exp(newDz.e + LAj->ZCoeff.e) - fs::clamp_exp(DeltaSub0.e + LAj->CCoeff.e) >=
+                                                    fs::kExpDiffIgnored) == __builtin_amdgcn_ballot_w64(true))
+                        DeltaSubN = hc_mul(newDz, ldc(LAj->ZCoeff));
+                    else
+                        DeltaSubN = hc_add(hc_mul(newDz, ldc(LAj->ZCoeff)), hc_mul(DeltaSub0, ldc(LAj->CCoeff)));
                     const hcplx32 RefN = ldc(LAj[1].Ref);
                     const hcplx32 complex0 = hc_add(RefN, DeltaSubN);
                     j++;
