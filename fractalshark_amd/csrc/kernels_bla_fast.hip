@@ -282,8 +282,11 @@ __device__ __forceinline__ bool step_literal(const FsBlaArgsT<float> &A, PixelSt
 #ifdef FS_BLA_FAST_PROBE
 #define FS_CNT(R) "s_add_u32 " R ", " R ", 1\n\t"
 #define FS_LANE_STEP "v_add_u32_e32 v48, 1, v48\n\t" /* steps this lane has taken (written out INSTEAD of the count) */
-#define FS_CNT_ZERO "s_mov_b32 s58, 0\n\ts_mov_b32 s59, 0\n\ts_mov_b32 s60, 0\n\ts_mov_b32 s61, 0\n\ts_mov_b32 s62, 0\n\ts_mov_b32 s63, 0\n\ts_mov_b32 s64, 0\n\t"
+#define FS_CNT_ZERO "s_mov_b32 s58, 0\n\ts_mov_b32 s59, 0\n\ts_mov_b32 s60, 0\n\ts_mov_b32 s61, 0\n\ts_mov_b32 s62, 0\n\ts_mov_b32 s63, 0\n\ts_mov_b32 s64, 0\n\ts_mov_b32 s65, 0\n\ts_mov_b32 s66, 0\n\t"
+// (round 6) passes whose lanes all hold the same value in V -- do the lanes of a pass read ONE orbit entry / ONE table record?
+#define FS_UNI(V, R) "v_readfirstlane_b32 s67, " V "\n\ts_nop 1\n\tv_cmp_eq_u32_e32 vcc, s67, " V "\n\ts_cmp_eq_u64 vcc, exec\n\ts_cselect_b32 s67, 1, 0\n\ts_add_u32 " R ", " R ", s67\n\t"
 #else
+#define FS_UNI(V, R) ""
 #define FS_CNT(R) ""
 #define FS_LANE_STEP ""
 #define FS_CNT_ZERO ""
@@ -360,7 +363,7 @@ __device__ __forceinline__ bool step_literal(const FsBlaArgsT<float> &A, PixelSt
     "s_andn2_b64 exec, vcc, s[42:43]\n\t"                                                                               \
     "s_cbranch_scc1 .Lbf_round_%=\n\t"                                                                                  \
     "s_mov_b64 exec, s[44:45]\n\t"                                                                                      \
-    "s_cbranch_execz .Lbf_step_%=\n\t" FS_CNT("s61")                                                                    \
+    "s_cbranch_execz .Lbf_step_%=\n\t" FS_CNT("s61") FS_UNI("v24", "s66")                                              \
     /* ---------------- jump: lanes that found an element (position v20) */                                             \
     "v_mul_u32_u24_e32 v16, 48, v24\n\t"                                                                                \
     "global_load_dwordx4 v[30:33], v16, %[hrec] offset:32\n\t" /* Z.re, Z.im, Z.exp (poisoned: not quiet), l */          \
@@ -457,7 +460,7 @@ __device__ __forceinline__ bool step_literal(const FsBlaArgsT<float> &A, PixelSt
     "s_mov_b64 exec, %[R]\n\t"                                                                                          \
     "s_waitcnt vmcnt(0)\n\t"                    /* (a requested Q that no lookup consumed) */                           \
     "s_mov_b32 s57, 0\n\t"                                                                                              \
-    "v_lshl_add_u32 v16, v8, 4, 16\n\t" FS_CNT("s62") FS_LANE_STEP                                                                                 \
+    "v_lshl_add_u32 v16, v8, 4, 16\n\t" FS_CNT("s62") FS_LANE_STEP FS_UNI("v8", "s65")                                                                                 \
     "global_load_dwordx4 v[18:21], v16, %[zb]\n\t" /* the entry the step arrives at: re, im, exponent, quiet bound */    \
     "v_add_u32_e32 v17, 1, v14\n\t"                                                                                     \
     "v_max3_i32 v42, v17, v2, v3\n\t"           /* T = 2Z + dz under eT */                                              \
@@ -691,7 +694,7 @@ template <bool kPool> __global__ void __launch_bounds__(256) k_bla_hdr32_fast(Fs
 #ifdef FS_BLA_FAST_PROBE
     uint32_t n_enter = 0, n_slow_step = 0, n_slow_lk = 0; // (measurement build: how often the statement is left, per wave)
     uint32_t lane_steps = 0;
-    uint32_t pc[7] = {0, 0, 0, 0, 0, 0, 0}, pacc[7] = {0, 0, 0, 0, 0, 0, 0}; // passes: lookup, pre-test, ladder round, jump, step, step with z, rebase
+    uint32_t pc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, pacc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; // passes: lookup, pre-test, ladder round, jump, step, step with z, rebase
 #endif
     while (kPool || R != 0ull) {
         uint32_t st = 0;
@@ -705,20 +708,20 @@ template <bool kPool> __global__ void __launch_bounds__(256) k_bla_hdr32_fast(Fs
                        "+{v7}"(cYe), "+{v8}"(ref), "+{v9}"(iter), "+{v10}"(dnm), "+{v11}"(dne), "+{v12}"(Zre), "+{v13}"(Zim),
                        "+{v14}"(Ze), "+{v15}"(cemin), [R] "+s"(R), [J] "+s"(J), [st] "=&s"(st), [M] "=&s"(M), [bud] "+s"(budget)
 #ifdef FS_BLA_FAST_PROBE
-                       , "+{v48}"(lane_steps), "={s58}"(pc[0]), "={s59}"(pc[1]), "={s60}"(pc[2]), "={s61}"(pc[3]), "={s62}"(pc[4]), "={s63}"(pc[5]), "={s64}"(pc[6])
+                       , "+{v48}"(lane_steps), "={s58}"(pc[0]), "={s59}"(pc[1]), "={s60}"(pc[2]), "={s61}"(pc[3]), "={s62}"(pc[4]), "={s63}"(pc[5]), "={s64}"(pc[6]), "={s65}"(pc[7]), "={s66}"(pc[8])
 #endif
                      : [mode] "s"(__builtin_amdgcn_readfirstlane((int)mode)), [zb] "s"(A.zb), [hq] "s"(A.hq), [hlad] "s"(A.hlad), [hrec] "s"(A.hrec),
                        [n] "s"(n_iterations), [cm1] "s"(count - 1u)
                      : "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30",
                        "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45",
                        "v46", "v47", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48",
-                       "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "vcc", "scc", "memory");
+                       "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s67", "vcc", "scc", "memory");
         st = (uint32_t)__builtin_amdgcn_readfirstlane((int)st);
         R = uniform64(R), J = uniform64(J);
         budget = (uint32_t)__builtin_amdgcn_readfirstlane((int)budget);
 #ifdef FS_BLA_FAST_PROBE
         n_enter++;
-        for (int i = 0; i < 7; i++)
+        for (int i = 0; i < 9; i++)
             pacc[i] += (uint32_t)__builtin_amdgcn_readfirstlane((int)pc[i]);
         n_slow_step += st == 1u;
         n_slow_lk += st == 2u;
@@ -817,7 +820,7 @@ template <bool kPool> __global__ void __launch_bounds__(256) k_bla_hdr32_fast(Fs
         atomicAdd((unsigned long long *)&A.stats[21], (unsigned long long)n_slow_step);
         atomicAdd((unsigned long long *)&A.stats[22], (unsigned long long)n_slow_lk);
         atomicAdd((unsigned long long *)&A.stats[23], 1ull);
-        for (int i = 0; i < 7; i++)
+        for (int i = 0; i < 9; i++) // (words 31, 32: step passes with all lanes at one orbit entry, jump passes with all lanes at one record)
             atomicAdd((unsigned long long *)&A.stats[24 + i], (unsigned long long)pacc[i]);
     }
 #endif

@@ -37,9 +37,11 @@ def run(view, w, h, oracle):
         out[name] = (buf, min(ms))
     if os.environ.get("FS_BLA_FAST_PROBE") == "1":
         import ctypes as C
-        raw = (C.c_uint64 * 32)()
-        assert lib.fs_read_stats_raw(r._h, raw, 32) == 0
+        raw = (C.c_uint64 * 40)()
+        assert lib.fs_read_stats_raw(r._h, raw, 40) == 0
         e, ss, sl, wv = list(raw)[20:24]
+        print("  step passes with every lane at ONE orbit entry: %.3f of %d; jump passes with every lane at ONE record: %.3f of %d"
+              % (raw[31] / max(1, raw[28]), raw[28], raw[32] / max(1, raw[27]), raw[27]), flush=True)
         print("  passes per wave: " + ", ".join("%s %.1f" % (k, x / max(1, wv)) for k, x in zip(
             ["lookup", "pre-test", "ladder round", "jump", "step", "step with z", "rebase"], list(raw)[24:31])), flush=True)
         print("  probe (all asm launches): statement entered %.1f times per wave, literal step %.2f, literal lookup round %.2f"
