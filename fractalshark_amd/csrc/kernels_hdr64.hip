@@ -90,6 +90,10 @@ __device__ __forceinline__ C64 add_hi_lo(C64 hi, const C64 lo)
 #ifndef FS_H64_LA_ASM
 #define FS_H64_LA_ASM 1 /* the LA steps of a wave whose lanes stand at one record by hand (la_step_asm.hpp); 0: the compiled loop, A/B */
 #endif
+#ifndef FS_H64_ASM_TINY
+#define FS_H64_ASM_TINY 0x1p-1000 /* what the hand-written statements take for "a norm the value compare cannot be trusted with".  (Test build: 1e300 -- EVERY
+                                     step then leaves its statement with status 2, the one exit no view reaches by itself, and the frames must not change.) */
+#endif
 #ifndef FS_H64_ASM_COLD
 #define FS_H64_ASM_COLD 1 /* the first frame of a view runs the hand-written loops too (0: A/B -- 52.6 against 50.6 ms once the statements had their "alone" arms; 54.8 against 52.3 before) */
 #endif
@@ -505,7 +509,7 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
                                        [i1] "=&v"(i1), [i2] "=&v"(i2), [i3] "=&v"(i3), [i4] "=&v"(i4), [i5] "=&v"(i5), [st] "=&s"(st),
                                        [run] "=&s"(run), [left] "=&s"(leftm), [sx] "=&s"(sx), [so] "=&s"(so), [sa] "=&s"(sa), [m0] "=&s"(m0), [m1] "=&s"(m1) FS_DBG_CNT_OPS
                                      : [dcr] "v"(dc.re), [dci] "v"(dc.im), [dce] "v"(dc.e), [boff] "v"(base_off), [macro] "v"(MacroItCount), [m4k] "v"(-4000),
-                                       [las] "s"(A.las), [nit] "s"(n_iterations), [cls] "s"(0x100), [tiny] "s"(0x1p-1000)
+                                       [las] "s"(A.las), [nit] "s"(n_iterations), [cls] "s"(0x100), [tiny] "s"(FS_H64_ASM_TINY)
                                      : "vcc", "scc", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48",
                                        "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s64", "s65",
                                        "s66", "s67", "s68", "s69", "s70", "s71");
@@ -645,8 +649,8 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
                                    [run] "+s"(run), [yr] "=&v"(yr), [yi] "=&v"(yi), [ye] "=&v"(ye), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
                                    [t3] "=&v"(t3), [t4] "=&v"(t4), [i0] "=&v"(i0), [i1] "=&v"(i1), [i2] "=&v"(i2), [i3] "=&v"(i3),
                                    [st] "=&s"(st), [sx] "=&s"(sx), [mesc] "=&s"(mesc), [mreb] "=&s"(mreb), [mend] "=&s"(mend) FS_DBG_CNT_OPS
-                                 : [dce] "v"(dc.e), [m4k] "v"(-4000), [zb] "s"(zr), [niter] "s"(n_iterations), [maxoff] "s"(max_off),
-                                   [cls] "s"(0x100), [tiny] "s"(0x1p-1000), [c256] "s"(256.0), [z0re] "s"(z0re), [z0im] "s"(z0im), [z0e] "s"(z0e)
+                                 : [dcr] "v"(dc.re), [dci] "v"(dc.im), [dce] "v"(dc.e), [m4k] "v"(-4000), [zb] "s"(zr), [niter] "s"(n_iterations),
+                                   [maxoff] "s"(max_off), [cls] "s"(0x100), [tiny] "s"(FS_H64_ASM_TINY), [c256] "s"(256.0), [z0re] "s"(z0re), [z0im] "s"(z0im), [z0e] "s"(z0e)
                                  : "vcc", "scc", "memory", "v52", "v53", "v54", "v55", "v56", "v58", "v59", "v60", "v61", "v62");
 #if FS_H64_LA_ASM_DEBUG
                     if (kStats && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) ==

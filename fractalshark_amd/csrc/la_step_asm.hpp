@@ -54,14 +54,14 @@
 // One half-step.  S: label suffix; DIr/DIi/DIe the set dz is read from, DOr/DOi/DOe the set dz' is written to; CPI: FS_LA_COPY_YX when
 // the INPUT set is Y (a lane that stops before dz' keeps dz: it has to be in X), CPO: FS_LA_COPY_YX when the OUTPUT set is Y.
 #define FS_LA_HALF(S, DIr, DIi, DIe, DOr, DOi, DOe, CPI, CPO)                                                       \
-    ".Lla_top" S "%=:\n\t"                                                                                          \
+    ".Lla_top" S "_%=:\n\t"                                                                                          \
     "v_lshl_add_u32 %[i0], %[j], 7, %[boff]\n\t"                                                                    \
     "s_nop 0\n\t" /* gfx940+: a readlane of a register the previous vector instruction wrote needs one wait state */ \
     "v_readfirstlane_b32 %[so], %[i0]\n\t"                                                                            \
     "s_nop 1\n\t"                                                                                                   \
     "v_cmp_eq_u32_e32 vcc, %[so], %[i0]\n\t"                                                                          \
     "s_cmp_lg_u64 vcc, exec\n\t"                                                                                    \
-    "s_cbranch_scc1 .Lla_leave1" S "%=\n\t"                                                                         \
+    "s_cbranch_scc1 .Lla_leave1" S "_%=\n\t"                                                                         \
     "s_load_dwordx16 s[36:51], %[las], %[so]\n\t"                                                                     \
     "s_load_dwordx8 s[52:59], %[las], %[so] offset:0x40\n\t"                                                          \
     "s_load_dwordx2 s[60:61], %[las], %[so] offset:0x78\n\t"                                                          \
@@ -72,13 +72,13 @@
     "v_cmp_ge_u32_e32 vcc, %[nit], %[i1]\n\t"                                                                       \
     "s_and_b64 %[m0], vcc, exec\n\t"                                                                             \
     "s_xor_b64 %[m1], %[m0], exec\n\t"                                                                        \
-    "s_cbranch_scc0 .Lla_1ok" S "%=\n\t"                                                                            \
+    "s_cbranch_scc0 .Lla_1ok" S "_%=\n\t"                                                                            \
     "s_mov_b64 exec, %[m1]\n\t"                                                                                  \
     "v_mov_b32_e32 %[refit], s61\n\t" CPI                                                                           \
     "s_or_b64 %[left], %[left], %[m1]\n\t"                                                                       \
     "s_mov_b64 exec, %[m0]\n\t"                                                                                  \
-    "s_cbranch_execz .Lla_done%=\n\t"                                                                               \
-    ".Lla_1ok" S "%=:\n\t"                                                                                          \
+    "s_cbranch_execz .Lla_done_%=\n\t"                                                                               \
+    ".Lla_1ok" S "_%=:\n\t"                                                                                          \
     /* (2), (3) p = dz (2 Ref + dz).  First the arm most steps of a deep zoom take: dz 120 binades and more below 2 Ref in every lane */ \
     /* (cur IS 2 Ref: the record's own values are the operands); then 2 Ref on top with the gap below 120; then the general sum */ \
     "s_max_i32 %[sa], s40, 0xefffffff\n\t"                                                                          \
@@ -86,7 +86,7 @@
     "v_subrev_u32_e32 %[i2], %[sa], " DIe "\n\t"                                                                    \
     "v_cmp_ge_i32_e32 vcc, 0xffffff88, %[i2]\n\t"                                                                   \
     "s_cmp_lg_u64 vcc, exec\n\t"                                                                                    \
-    "s_cbranch_scc1 .Lla_Aother" S "%=\n\t"                                                                         \
+    "s_cbranch_scc1 .Lla_Aother" S "_%=\n\t"                                                                         \
     "v_mul_f64 %[t2], " DIr ", s[36:37]\n\t"                                                                        \
     "v_mul_f64 %[t3], " DIi ", s[38:39]\n\t"                                                                        \
     "v_add_f64 %[t2], %[t2], -%[t3]\n\t"                                                                            \
@@ -94,13 +94,13 @@
     "v_mul_f64 %[t4], " DIi ", s[36:37]\n\t"                                                                        \
     "v_add_f64 %[t3], %[t3], %[t4]\n\t"                                                                             \
     "v_add_u32_e32 %[i2], %[sa], " DIe "\n\t"                                                                       \
-    ".Lla_Amulled" S "%=:\n\t"                                                                                      \
+    ".Lla_Amulled" S "_%=:\n\t"                                                                                      \
     "v_max_i32_e32 %[i2], 0xf0000000, %[i2]\n\t"                                                                    \
     /* (4) Reduce: max(|re|, |im|) a normal number in every lane, or the compiled step takes over */               \
     "v_max_f64 %[t4], |%[t2]|, |%[t3]|\n\t"                                                                         \
     "v_cmp_class_f64_e64 vcc, %[t4], %[cls]\n\t"                                                                    \
     "s_cmp_lg_u64 vcc, exec\n\t"                                                                                    \
-    "s_cbranch_scc1 .Lla_leave3" S "%=\n\t"                                                                         \
+    "s_cbranch_scc1 .Lla_leave3" S "_%=\n\t"                                                                         \
     "v_frexp_exp_i32_f64_e32 %[i3], %[t4]\n\t"                                                                      \
     "v_sub_u32_e32 %[i4], 1, %[i3]\n\t"                                                                             \
     "v_ldexp_f64 %[t2], %[t2], %[i4]\n\t"                                                                           \
@@ -114,13 +114,13 @@
     "s_and_b64 %[m1], %[m1], vcc\n\t"                                                                         \
     "s_or_b64 %[m0], %[m0], %[m1]\n\t"                                                                     \
     "s_xor_b64 %[m1], %[m0], exec\n\t"                                                                        \
-    "s_cbranch_scc0 .Lla_5ok" S "%=\n\t"                                                                            \
+    "s_cbranch_scc0 .Lla_5ok" S "_%=\n\t"                                                                            \
     "s_mov_b64 exec, %[m1]\n\t"                                                                                  \
     "v_mov_b32_e32 %[refit], s61\n\t" CPI                                                                           \
     "s_or_b64 %[left], %[left], %[m1]\n\t"                                                                       \
     "s_mov_b64 exec, %[m0]\n\t"                                                                                  \
-    "s_cbranch_execz .Lla_done%=\n\t"                                                                               \
-    ".Lla_5ok" S "%=:\n\t"                                                                                          \
+    "s_cbranch_execz .Lla_done_%=\n\t"                                                                               \
+    ".Lla_5ok" S "_%=:\n\t"                                                                                          \
     /* (6) the step is taken */                                                                                     \
     "v_mov_b32_e32 %[it], %[i1]\n\t"                                                                                \
     "v_add_u32_e32 %[nla], 1, %[nla]\n\t"                                                                           \
@@ -133,7 +133,7 @@
     "v_sub_u32_e32 %[i4], %[i3], %[i2]\n\t"                                                                         \
     "v_cmp_ge_i32_e32 vcc, 0xffffff88, %[i4]\n\t"                                                                   \
     "s_cmp_lg_u64 vcc, exec\n\t"                                                                                    \
-    "s_cbranch_scc1 .Lla_Sother" S "%=\n\t"                                                                         \
+    "s_cbranch_scc1 .Lla_Sother" S "_%=\n\t"                                                                         \
     "v_mul_f64 " DOr ", %[t2], s[42:43]\n\t"                                                                        \
     "v_mul_f64 %[t0], %[t3], s[44:45]\n\t"                                                                          \
     "v_add_f64 " DOr ", " DOr ", -%[t0]\n\t"                                                                        \
@@ -141,16 +141,16 @@
     "v_mul_f64 %[t0], %[t3], s[42:43]\n\t"                                                                          \
     "v_add_f64 " DOi ", " DOi ", %[t0]\n\t"                                                                         \
     "v_mov_b32_e32 " DOe ", %[i2]\n\t"                                                                              \
-    ".Lla_Sback" S "%=:\n\t"                                                                                        \
+    ".Lla_Sback" S "_%=:\n\t"                                                                                        \
     /* (8) complex0 = next Ref + dz'; i4 <- complex0.e - dz'.e.  dz' 120 binades and more below in every lane: the next Ref itself */ \
     "v_subrev_u32_e32 %[i4], s68, " DOe "\n\t"                                                                      \
     "v_cmp_ge_i32_e32 vcc, 0xffffff88, %[i4]\n\t"                                                                   \
     "s_cmp_lg_u64 vcc, exec\n\t"                                                                                    \
-    "s_cbranch_scc1 .Lla_Cother" S "%=\n\t"                                                                         \
+    "s_cbranch_scc1 .Lla_Cother" S "_%=\n\t"                                                                         \
     "v_mov_b64_e32 %[t0], s[64:65]\n\t"                                                                             \
     "v_mov_b64_e32 %[t1], s[66:67]\n\t"                                                                             \
     "v_sub_u32_e32 %[i4], 0, %[i4]\n\t"                                                                             \
-    ".Lla_Cback" S "%=:\n\t"                                                                                        \
+    ".Lla_Cback" S "_%=:\n\t"                                                                                        \
     /* (9) j + 1; rebase: |complex0| < |dz'| (Chebyshev norms, both above 2^-1000 or the compiled test decides) or the stage's end */ \
     "v_add_u32_e32 %[j], 1, %[j]\n\t"                                                                               \
     "v_max_f64 %[t2], |%[t0]|, |%[t1]|\n\t"                                                                         \
@@ -158,13 +158,13 @@
     "v_min_f64 %[t4], %[t2], %[t3]\n\t"                                                                             \
     "v_cmp_le_f64_e32 vcc, %[tiny], %[t4]\n\t"                                                                      \
     "s_cmp_lg_u64 vcc, exec\n\t"                                                                                    \
-    "s_cbranch_scc1 .Lla_leave2" S "%=\n\t"                                                                         \
+    "s_cbranch_scc1 .Lla_leave2" S "_%=\n\t"                                                                         \
     "v_ldexp_f64 %[t2], %[t2], %[i4]\n\t"                                                                           \
     "v_cmp_lt_f64_e32 vcc, %[t2], %[t3]\n\t"                                                                        \
     "v_cmp_ge_u32_e64 %[m0], %[j], %[macro]\n\t"                                                                 \
     "s_or_b64 %[m0], %[m0], vcc\n\t"                                                                          \
     "s_and_b64 %[m0], %[m0], exec\n\t"                                                                        \
-    "s_cbranch_scc0 .Lla_noreb" S "%=\n\t"                                                                          \
+    "s_cbranch_scc0 .Lla_noreb" S "_%=\n\t"                                                                          \
     "s_mov_b64 %[m1], exec\n\t"                                                                                  \
     "s_mov_b64 exec, %[m0]\n\t"                                                                                  \
     "v_mov_b64_e32 " DOr ", %[t0]\n\t"                                                                              \
@@ -172,41 +172,41 @@
     "v_add_u32_e32 " DOe ", " DOe ", %[i4]\n\t"                                                                     \
     "v_mov_b32_e32 %[j], 0\n\t"                                                                                     \
     "s_mov_b64 exec, %[m1]\n\t"                                                                                  \
-    ".Lla_noreb" S "%=:\n\t"                                                                                        \
+    ".Lla_noreb" S "_%=:\n\t"                                                                                        \
     /* (10) lanes at the iteration cap stop here (dz' has to be in X) */                                            \
     "v_cmp_gt_u32_e32 vcc, %[nit], %[it]\n\t"                                                                       \
     "s_and_b64 %[m0], vcc, exec\n\t"                                                                             \
     "s_xor_b64 %[m1], %[m0], exec\n\t"                                                                        \
-    "s_cbranch_scc0 .Lla_next" S "%=\n\t"                                                                           \
+    "s_cbranch_scc0 .Lla_next" S "_%=\n\t"                                                                           \
     "s_mov_b64 exec, %[m1]\n\t" CPO                                                                              \
     "s_mov_b64 exec, %[m0]\n\t"                                                                                  \
-    "s_cbranch_execz .Lla_done%=\n\t"                                                                               \
-    "s_branch .Lla_next" S "%=\n\t"                                                                                 \
+    "s_cbranch_execz .Lla_done_%=\n\t"                                                                               \
+    "s_branch .Lla_next" S "_%=\n\t"                                                                                 \
     /* ---- out of line: the general sums */                                                                        \
-    ".Lla_Aother" S "%=:\n\t"                                                                                       \
+    ".Lla_Aother" S "_%=:\n\t"                                                                                       \
     "v_add_u32_e32 %[i3], 0x77, %[i2]\n\t"                                                                          \
     "v_cmp_gt_u32_e32 vcc, 0x78, %[i3]\n\t"                                                                         \
     "s_cmp_lg_u64 vcc, exec\n\t"                                                                                    \
-    "s_cbranch_scc1 .Lla_Agen" S "%=\n\t"                                                                           \
+    "s_cbranch_scc1 .Lla_Agen" S "_%=\n\t"                                                                           \
     "v_ldexp_f64 %[t0], " DIr ", %[i2]\n\t"                                                                         \
     "v_ldexp_f64 %[t1], " DIi ", %[i2]\n\t"                                                                         \
     "v_add_f64 %[t0], s[36:37], %[t0]\n\t"                                                                          \
     "v_add_f64 %[t1], s[38:39], %[t1]\n\t"                                                                          \
     "v_add_u32_e32 %[i2], %[sa], " DIe "\n\t"                                                                       \
-    ".Lla_Amul" S "%=:\n\t"                                                                                         \
+    ".Lla_Amul" S "_%=:\n\t"                                                                                         \
     "v_mul_f64 %[t2], " DIr ", %[t0]\n\t"                                                                           \
     "v_mul_f64 %[t3], " DIi ", %[t1]\n\t"                                                                           \
     "v_add_f64 %[t2], %[t2], -%[t3]\n\t"                                                                            \
     "v_mul_f64 %[t3], " DIr ", %[t1]\n\t"                                                                           \
     "v_mul_f64 %[t4], " DIi ", %[t0]\n\t"                                                                           \
     "v_add_f64 %[t3], %[t3], %[t4]\n\t"                                                                             \
-    "s_branch .Lla_Amulled" S "%=\n\t"                                                                              \
-    ".Lla_Agen" S "%=:\n\t" FS_ASM_CNT(1)                                                                           \
+    "s_branch .Lla_Amulled" S "_%=\n\t"                                                                              \
+    ".Lla_Agen" S "_%=:\n\t" FS_ASM_CNT(1)                                                                           \
     "v_mov_b32_e32 %[i5], %[sa]\n\t"                                                                                \
     FS_LA_GENADD("s[36:37]", "s[38:39]", "%[i5]", DIr, DIi, DIe, "%[t0]", "%[t1]", "%[i3]", "%[i4]", "%[i2]", "%[t4]", "%[t5]") \
     "v_add_u32_e32 %[i2], %[i3], " DIe "\n\t"                                                                       \
-    "s_branch .Lla_Amul" S "%=\n\t"                                                                                 \
-    ".Lla_Sother" S "%=:\n\t"                                                                                       \
+    "s_branch .Lla_Amul" S "_%=\n\t"                                                                                 \
+    ".Lla_Sother" S "_%=:\n\t"                                                                                       \
     "v_mul_f64 %[t0], %[t2], s[42:43]\n\t"                                                                          \
     "v_mul_f64 %[t1], %[t3], s[44:45]\n\t"                                                                          \
     "v_add_f64 %[t0], %[t0], -%[t1]\n\t"                                                                            \
@@ -222,40 +222,40 @@
     "v_add_u32_e32 %[i5], 0x77, %[i4]\n\t"                                                                          \
     "v_cmp_gt_u32_e32 vcc, 0x78, %[i5]\n\t"                                                                         \
     "s_cmp_lg_u64 vcc, exec\n\t"                                                                                    \
-    "s_cbranch_scc1 .Lla_Sgen" S "%=\n\t"                                                                           \
+    "s_cbranch_scc1 .Lla_Sgen" S "_%=\n\t"                                                                           \
     "v_ldexp_f64 %[t2], %[t2], %[i4]\n\t"                                                                           \
     "v_ldexp_f64 %[t3], %[t3], %[i4]\n\t"                                                                           \
     "v_add_f64 " DOr ", %[t0], %[t2]\n\t"                                                                           \
     "v_add_f64 " DOi ", %[t1], %[t3]\n\t"                                                                           \
     "v_mov_b32_e32 " DOe ", %[i2]\n\t"                                                                              \
-    "s_branch .Lla_Sback" S "%=\n\t"                                                                                \
-    ".Lla_Sgen" S "%=:\n\t" FS_ASM_CNT(2)                                                                           \
+    "s_branch .Lla_Sback" S "_%=\n\t"                                                                                \
+    ".Lla_Sgen" S "_%=:\n\t" FS_ASM_CNT(2)                                                                           \
     FS_LA_GENADD("%[t0]", "%[t1]", "%[i2]", "%[t2]", "%[t3]", "%[i3]", DOr, DOi, DOe, "%[i4]", "%[i5]", "%[t4]", "%[t5]") \
-    "s_branch .Lla_Sback" S "%=\n\t"                                                                                \
-    ".Lla_Cother" S "%=:\n\t"                                                                                       \
+    "s_branch .Lla_Sback" S "_%=\n\t"                                                                                \
+    ".Lla_Cother" S "_%=:\n\t"                                                                                       \
     "v_add_u32_e32 %[i5], 0x77, %[i4]\n\t"                                                                          \
     "v_cmp_gt_u32_e32 vcc, 0x78, %[i5]\n\t"                                                                         \
     "s_cmp_lg_u64 vcc, exec\n\t"                                                                                    \
-    "s_cbranch_scc1 .Lla_Cgen" S "%=\n\t"                                                                           \
+    "s_cbranch_scc1 .Lla_Cgen" S "_%=\n\t"                                                                           \
     "v_ldexp_f64 %[t0], " DOr ", %[i4]\n\t"                                                                         \
     "v_ldexp_f64 %[t1], " DOi ", %[i4]\n\t"                                                                         \
     "v_add_f64 %[t0], s[64:65], %[t0]\n\t"                                                                          \
     "v_add_f64 %[t1], s[66:67], %[t1]\n\t"                                                                          \
     "v_sub_u32_e32 %[i4], 0, %[i4]\n\t"                                                                             \
-    "s_branch .Lla_Cback" S "%=\n\t"                                                                                \
-    ".Lla_Cgen" S "%=:\n\t" FS_ASM_CNT(3)                                                                           \
+    "s_branch .Lla_Cback" S "_%=\n\t"                                                                                \
+    ".Lla_Cgen" S "_%=:\n\t" FS_ASM_CNT(3)                                                                           \
     "v_mov_b32_e32 %[i5], s68\n\t"                                                                                  \
     FS_LA_GENADD("s[64:65]", "s[66:67]", "%[i5]", DOr, DOi, DOe, "%[t0]", "%[t1]", "%[i3]", "%[i4]", "%[i2]", "%[t4]", "%[t5]") \
     "v_sub_u32_e32 %[i4], %[i3], " DOe "\n\t"                                                                       \
-    "s_branch .Lla_Cback" S "%=\n\t"                                                                                \
+    "s_branch .Lla_Cback" S "_%=\n\t"                                                                                \
     /* ---- out of line: the exits of this half */                                                                  \
-    ".Lla_leave1" S "%=:\n\t" CPI                                                                                   \
-    "s_branch .Lla_leave1%=\n\t"                                                                                    \
-    ".Lla_leave3" S "%=:\n\t" CPI                                                                                   \
-    "s_branch .Lla_leave3%=\n\t"                                                                                    \
-    ".Lla_leave2" S "%=:\n\t" CPO                                                                                   \
-    "s_branch .Lla_leave2%=\n\t"                                                                                    \
-    ".Lla_next" S "%=:\n\t"
+    ".Lla_leave1" S "_%=:\n\t" CPI                                                                                   \
+    "s_branch .Lla_leave1_%=\n\t"                                                                                    \
+    ".Lla_leave3" S "_%=:\n\t" CPI                                                                                   \
+    "s_branch .Lla_leave3_%=\n\t"                                                                                    \
+    ".Lla_leave2" S "_%=:\n\t" CPO                                                                                   \
+    "s_branch .Lla_leave2_%=\n\t"                                                                                    \
+    ".Lla_next" S "_%=:\n\t"
 
 // The statement.  (Half B's ".Lla_next" falls through to the loop's back edge.)
 #define FS_LA_UNIFORM_LOOP                                                                                          \
@@ -263,21 +263,21 @@
     "s_mov_b64 %[left], 0\n\t"                                                                                      \
     FS_LA_HALF("A", "%[xr]", "%[xi]", "%[xe]", "%[yr]", "%[yi]", "%[ye]", "", FS_LA_COPY_YX)                       \
     FS_LA_HALF("B", "%[yr]", "%[yi]", "%[ye]", "%[xr]", "%[xi]", "%[xe]", FS_LA_COPY_YX, "")                       \
-    "s_branch .Lla_topA%=\n\t"                                                                                      \
-    ".Lla_leave1%=:\n\t"                                                                                            \
+    "s_branch .Lla_topA_%=\n\t"                                                                                      \
+    ".Lla_leave1_%=:\n\t"                                                                                            \
     "s_mov_b32 %[st], 1\n\t"                                                                                        \
     "s_mov_b64 %[run], exec\n\t"                                                                                    \
-    "s_branch .Lla_out%=\n\t"                                                                                       \
-    ".Lla_leave3%=:\n\t"                                                                                            \
+    "s_branch .Lla_out_%=\n\t"                                                                                       \
+    ".Lla_leave3_%=:\n\t"                                                                                            \
     "s_mov_b32 %[st], 3\n\t"                                                                                        \
     "s_mov_b64 %[run], exec\n\t"                                                                                    \
-    "s_branch .Lla_out%=\n\t"                                                                                       \
-    ".Lla_leave2%=:\n\t"                                                                                            \
+    "s_branch .Lla_out_%=\n\t"                                                                                       \
+    ".Lla_leave2_%=:\n\t"                                                                                            \
     "s_mov_b32 %[st], 2\n\t"                                                                                        \
     "s_mov_b64 %[run], exec\n\t"                                                                                    \
-    "s_branch .Lla_out%=\n\t"                                                                                       \
-    ".Lla_done%=:\n\t"                                                                                              \
+    "s_branch .Lla_out_%=\n\t"                                                                                       \
+    ".Lla_done_%=:\n\t"                                                                                              \
     "s_mov_b32 %[st], 0\n\t"                                                                                        \
     "s_mov_b64 %[run], 0\n\t"                                                                                       \
-    ".Lla_out%=:\n\t"                                                                                               \
+    ".Lla_out_%=:\n\t"                                                                                               \
     "s_mov_b64 exec, %[sx]\n\t"
