@@ -219,3 +219,23 @@ def build_all(force=False):
 
 if __name__ == "__main__":
     print(build_all(force=True))
+
+
+def status2_test_variant():
+    """build/ab/libfsmi355_h64st2.so: the library with k_lav2_hdr64's hand-written statements taking their rarest exit (status 2) on
+    EVERY step (-DFS_H64_ASM_TINY=1e300) -- what tests/test_gpu_hdr64_statement_exits.py renders with.  Built by tools/build_variant.py
+    when its content stamp does not match the sources; returns the path."""
+    import sys
+    defs = ["-DFS_H64_ASM_TINY=1e300"]
+    lib = os.path.join(ROOT, "build", "ab", "libfsmi355_h64st2.so")
+    stamp = lib + ".stamp"  # (by content, as the product's own stamp: file times mean nothing on a freshly copied tree)
+    digest = _digest(_render_units() + _render_headers(), _render_flags() + defs)
+    if not os.path.exists(lib) or not os.path.exists(stamp) or open(stamp).read().strip() != digest:
+        env = {k: v for k, v in os.environ.items() if k != "FSMI355_LIB"}
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "build_variant.py"), "h64st2", "kernels_hdr64.hip", *defs], cwd=ROOT,
+                           env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if p.returncode != 0:
+            raise RuntimeError("build of the status-2 test variant failed:\n" + p.stdout[-3000:])
+        with open(stamp, "w") as f:
+            f.write(digest + "\n")
+    return lib
