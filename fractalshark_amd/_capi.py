@@ -136,6 +136,7 @@ def render_lib():
     _decl(lib, "fs_kernel_ms_split_history", u32, [vp, vp, vp, u32])
     _decl(lib, "fs_forget_tile_costs", u32, [vp])
     _decl(lib, "fs_last_frame_tile_ordered", C.c_int, [vp])
+    _decl(lib, "fs_last_frame_sampled_tile_order", C.c_int, [vp])
     _decl(lib, "fs_read_tile_costs", u32, [vp, vp, u64, vp])
     _decl(lib, "fs_read_tile_order", u32, [vp, vp, u64])
     _decl(lib, "fs_seq_cursor_probe", u32, [vp, C.c_int, u64, u32, vp])
@@ -190,7 +191,7 @@ RENDER_SYMBOLS = [
     "fs_render_scaled", "fs_build_bla", "fs_bla_num_levels", "fs_bla_lm2", "fs_bla_level_size", "fs_read_bla_level",
     "fs_render_direct_lp", "fs_clear",
     "fs_render_current", "fs_sync_compute", "fs_compute_stream", "fs_sync_display", "fs_query_compute", "fs_enqueue_done_callback",
-    "fs_host_fallback_bytes", "fs_idle_device_bytes", "fs_release_idle_device_memory", "fs_set_compressed_orbit_mode", "fs_orbit_device_bytes", "fs_get_width", "fs_get_height", "fs_last_kernel_ms", "fs_set_kernel_variant", "fs_kernel_ms_history", "fs_kernel_ms_split_history", "fs_forget_tile_costs", "fs_last_frame_tile_ordered", "fs_read_tile_costs", "fs_read_tile_order", "fs_seq_cursor_probe", "fs_enable_step_count", "fs_read_step_count",
+    "fs_host_fallback_bytes", "fs_idle_device_bytes", "fs_release_idle_device_memory", "fs_set_compressed_orbit_mode", "fs_orbit_device_bytes", "fs_get_width", "fs_get_height", "fs_last_kernel_ms", "fs_set_kernel_variant", "fs_kernel_ms_history", "fs_kernel_ms_split_history", "fs_forget_tile_costs", "fs_last_frame_tile_ordered", "fs_last_frame_sampled_tile_order", "fs_read_tile_costs", "fs_read_tile_order", "fs_seq_cursor_probe", "fs_enable_step_count", "fs_read_step_count",
     "fs_time_render_current", "fs_read_stats_raw", "fs_test_block_threshold", "fs_build_la", "fs_build_la_mt", "fs_la_counts", "fs_read_la",
     "fs_group_create", "fs_group_destroy", "fs_group_size", "fs_group_transport", "fs_group_renderer", "fs_group_init_memory",
     "fs_group_upload_orbit", "fs_group_upload_orbit_compressed", "fs_group_upload_la", "fs_group_upload_bla",

@@ -22,8 +22,32 @@ __device__ __forceinline__ uint32_t global_row(const FsFrame &f, uint32_t L)
 __device__ __forceinline__ void tile_pixel(uint32_t &X, uint32_t &L)
 {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    X = (blockIdx.x * (blockDim.x >> 6) + wave) * 8u + (lane & 7u);
-    L = blockIdx.y * 8u + (lane >> 3);
+#ifdef FS_TILE_STRIDE
+    // (A/B build, round 6: workgroups take the tile blocks in a strided order -- block v of the launch renders block v * FS_TILE_STRIDE mod N --
+    // so that a region of long pixels is spread over the launch instead of ending it)
+    const uint32_t nb = gridDim.x * gridDim.y;
+    const uint32_t v = (uint32_t)(((uint64_t)(blockIdx.y * gridDim.x + blockIdx.x) * (uint64_t)(FS_TILE_STRIDE)) % nb);
+    const uint32_t bx = v % gridDim.x, by = v / gridDim.x;
+#else
+    const uint32_t bx = blockIdx.x, by = blockIdx.y;
+#endif
+    X = (bx * (blockDim.x >> 6) + wave) * 8u + (lane & 7u);
+    L = by * 8u + (lane >> 3);
+}
+
+// ... or the tile a tile order names for this wave (FsLav2ArgsT::tile_order: row-major tile number of the local buffer, all ones = none)
+__device__ __forceinline__ void ordered_tile_pixel(const uint32_t *__restrict__ order, uint32_t tiles_x, uint32_t &X, uint32_t &L)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t w = (blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)order[w]);
+    if (tile != 0xFFFFFFFFu) {
+        const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        X = tx * 8u + (lane & 7u);
+        L = ty * 8u + (lane >> 3);
+    } else {
+        X = 0xFFFFFFFFu, L = 0xFFFFFFFFu;
+    }
 }
 
 // ... or, with a recorded pixel order (kernels_order.hip): lane s of the launch takes element order[s] of the local iteration

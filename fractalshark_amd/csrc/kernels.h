@@ -252,6 +252,8 @@ struct FsLav2Args2x32 {
     fs_real_2x32 cxLow, cyLow;
     const uint32_t *pixel_order; // see FsLav2ArgsT
     uint32_t *pixel_cost;        // see FsLav2ArgsT
+    const uint32_t *tile_order;  // see FsLav2ArgsT (round 6: the first frame of a view, kernels_tile_sample.hip)
+    uint32_t tiles_x;
 };
 
 // Non-HDR LAv2 (Gpu1x32 / Gpu1x64 / Gpu2x32 PerturbedLAv2*): records in the reference layouts of the selected type
@@ -394,6 +396,20 @@ void fsk_bla_make_heap(const FsBlaRec *rec, const int4 *lad, const long long *km
                        int4 *hlad, int4 *hq, float4 *zb, hipStream_t s);
 void fsk_bla_hdr32_fast(const FsBlaArgs32 &A, bool pool, hipStream_t s);
 // pixel order from a frame's counts (kernels_order.hip): n = elements of the iteration buffer; work = 2 n words; order = n words
+// An order for a view's FIRST frame (kernels_tile_sample.hip): PerformAT's loop for one pixel per 8 x 8 tile, in binary64.
+struct FsTileSampleArgs {
+    FsFrame frame;
+    FsCoordsT<double> coords;
+    fs::hreal<double> ThresholdC, SqrEscapeRadius;
+    fs::hcplx<double> RefC, CCoeff;
+    uint32_t StepLength;
+    uint32_t n_iterations;
+    uint32_t tiles_x, tiles_y; // tiles of the local buffer, row-major; n_slots >= tiles_x * tiles_y: waves of the frame's launch
+    uint32_t n_slots;
+    uint32_t *cost; // [n_slots] out: the sampled pixel's own AT iterations + 1, 0 = no AT step (or no tile)
+};
+void fsk_at_tile_sample64(const FsTileSampleArgs &A, hipStream_t s);
+void fsk_tile_order_finish(uint32_t *order, uint32_t n_slots, uint32_t n_tiles, hipStream_t s);
 size_t fsk_pixel_order_temp_bytes(uint32_t n);
 hipError_t fsk_pixel_order_build(const uint32_t *counts, uint32_t n, uint32_t *work, uint32_t *order, void *temp, size_t temp_bytes,
                                  hipStream_t s, int key_bits = 32);

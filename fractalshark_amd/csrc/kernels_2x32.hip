@@ -175,6 +175,8 @@ __global__ void __launch_bounds__(256) k_lav2_2x32(FsLav2Args2x32 A)
     uint32_t X, L;
     if (A.pixel_order)
         ordered_pixel(A.frame, A.pixel_order, X, L);
+    else if (A.tile_order) // (a first frame: tiles in the order of a sampled PerformAT count, kernels_tile_sample.hip)
+        ordered_tile_pixel(A.tile_order, A.tiles_x, X, L);
     else
         tile_pixel(X, L);
     uint64_t c_at = 0, c_la = 0, c_pt = 0, c_px = 0, c_at_skipped = 0; // (c_at_skipped: AT iterations the cycle search spared this lane)

@@ -107,6 +107,12 @@ struct fs_renderer {
         unsigned char coords[64];
         bool operator==(const PixKey &o) const { return memcmp(this, &o, sizeof(*this)) == 0; }
     } pix_key{}, pix_seen_key{}, at_key{};
+    // (round 6) an order for a view's FIRST frame: tiles by a sampled PerformAT count (kernels_tile_sample.hip)
+    uint32_t *cold_cost = nullptr, *cold_order = nullptr, *cold_work = nullptr;
+    void *cold_temp = nullptr;
+    size_t cold_temp_bytes = 0;
+    uint32_t cold_cap = 0;
+    bool last_cold_ordered = false; // (fs_last_frame_sampled_tile_order)
     bool lav2_last_ordered = false; // the last launch was an HDRFloat<float> frame in its recorded TILE order (fs_read_tile_order)
     bool last_launch_wide = false;   // the last render launched a 64-bit counting kernel: those carry no step counters
     bool stats_on = false;
@@ -741,6 +747,13 @@ void free_all(fs_renderer *r)
     r->pix_temp = nullptr;
     r->pix_cap = 0;
     r->pix_valid = false;
+    (void)r_free(r, r->cold_cost);
+    (void)r_free(r, r->cold_order);
+    (void)r_free(r, r->cold_work);
+    (void)r_free(r, r->cold_temp);
+    r->cold_cost = r->cold_order = r->cold_work = nullptr;
+    r->cold_temp = nullptr;
+    r->cold_cap = 0;
     r->lav2_cost = r->lav2_order = r->lav2_sort_tmp = nullptr;
     r->lav2_cost_cap = r->lav2_order_cap = 0;
     r->lav2_cost_valid = false;
@@ -2316,6 +2329,53 @@ static void pix_order_after(fs_renderer *r, const FsFrame &f, const fs_renderer:
     r->pix_valid = true;
 }
 
+// The tile order of a view's first frame (kernels_tile_sample.hip): S carries the frame, the coordinates and the AT record's values in
+// binary64; -> order[n_slots] on the device (wave w of the frame's launch renders tile order[w]), or nullptr: not wanted (small frames,
+// 64-bit buffers, A/B switch FSMI355_COLD_TILE_ORDER=0, FS_VARIANT_NATURAL_TILE_ORDER), no memory.  Queued on the compute stream.
+static const uint32_t *cold_tile_order(fs_renderer *r, FsTileSampleArgs &S)
+{
+    static const bool off = [] { const char *e = getenv("FSMI355_COLD_TILE_ORDER"); return e && e[0] == '0'; }();
+    if (off || !pix_order_wanted(r, S.frame) || S.StepLength == 0u)
+        return nullptr;
+    S.tiles_x = (S.frame.width + 7u) / 8u, S.tiles_y = (S.frame.local_rows + 7u) / 8u;
+    S.n_slots = ((S.frame.width + 31u) / 32u) * S.tiles_y * 4u; // waves of the frame's launch (tile_grid: 4 tiles per workgroup)
+    if (r->cold_cap < S.n_slots) {
+        (void)r_free(r, r->cold_cost);
+        (void)r_free(r, r->cold_order);
+        (void)r_free(r, r->cold_work);
+        (void)r_free(r, r->cold_temp);
+        r->cold_cost = r->cold_order = r->cold_work = nullptr;
+        r->cold_temp = nullptr;
+        r->cold_cap = 0;
+        const size_t tb = fsk_pixel_order_temp_bytes(S.n_slots);
+        if (r_alloc(r, (void **)&r->cold_cost, (size_t)S.n_slots * sizeof(uint32_t), kFrame) != hipSuccess ||
+            r_alloc(r, (void **)&r->cold_order, (size_t)S.n_slots * sizeof(uint32_t), kFrame) != hipSuccess ||
+            r_alloc(r, (void **)&r->cold_work, (size_t)S.n_slots * 2 * sizeof(uint32_t), kFrame) != hipSuccess ||
+            r_alloc(r, &r->cold_temp, tb ? tb : 16, kFrame) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)r_free(r, r->cold_cost);
+            (void)r_free(r, r->cold_order);
+            (void)r_free(r, r->cold_work);
+            (void)r_free(r, r->cold_temp);
+            r->cold_cost = r->cold_order = r->cold_work = nullptr;
+            r->cold_temp = nullptr;
+            return nullptr;
+        }
+        r->cold_cap = S.n_slots;
+        r->cold_temp_bytes = tb;
+    }
+    S.cost = r->cold_cost;
+    fsk_at_tile_sample64(S, r->compute);
+    if (fsk_pixel_order_build(r->cold_cost, S.n_slots, r->cold_work, r->cold_order, r->cold_temp, r->cold_temp_bytes, r->compute, 32) !=
+        hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    fsk_tile_order_finish(r->cold_order, S.n_slots, S.tiles_x * S.tiles_y, r->compute);
+    r->last_cold_ordered = true;
+    return r->cold_order;
+}
+
 uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, const void *coords, uint64_t n_iterations)
 {
     if (uint32_t e = use_device(r))
@@ -2326,6 +2386,7 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
         return 0; // this renderer owns no row of the frame (a rank beyond the last band)
     r->last_frame_ordered = false; // (every path below that uses a recorded order says so itself)
     r->lav2_last_ordered = false;
+    r->last_cold_ordered = false;
     const bool plain = type_tag == FS_T_F32 || type_tag == FS_T_F64 || type_tag == FS_T_2X32;
     // iteration caps of 2^32 and above need IterType = uint64_t (an 8-byte buffer): every type then runs an instantiation
     // of its kernel that counts in 64 bits (the literal one for HDRFloat<float|double>)
@@ -2473,6 +2534,22 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
         A.pixel_cost = second ? pix_cost_for(r, A.frame, false) : nullptr;
         {
             TimedLaunch t(r);
+            if (!r->orbit_seq && A.pixel_order == nullptr && !second && mode != FS_LAV2_PO && A.use_at && A.la_valid) {
+                // a view's first frame: tiles in the order of a sampled PerformAT count (the record's values in binary64: head + tail, exact)
+                auto R = [](const fs_real_2x32 &x) { return fs::hreal<double>{(double)x.head + (double)x.tail, x.e}; };
+                auto Cx = [](const fs_cplx_2x32 &c) {
+                    return fs::hcplx<double>{(double)c.re_head + (double)c.re_tail, (double)c.im_head + (double)c.im_tail, c.e};
+                };
+                FsTileSampleArgs S;
+                memset(&S, 0, sizeof(S));
+                S.frame = A.frame;
+                S.coords = FsCoordsT<double>{R(A.coords[0]), R(A.coords[1]), R(A.coords[2]), R(A.coords[3])};
+                S.ThresholdC = R(A.at.ThresholdC), S.SqrEscapeRadius = R(A.at.SqrEscapeRadius);
+                S.RefC = Cx(A.at.RefC), S.CCoeff = Cx(A.at.CCoeff);
+                S.StepLength = A.at.StepLength, S.n_iterations = A.n_iterations;
+                A.tile_order = cold_tile_order(r, S);
+                A.tiles_x = S.tiles_x;
+            }
             fsk_lav2_2x32(A, mode == FS_LAV2_FULL ? FS_MODE_FULL : (mode == FS_LAV2_PO ? FS_MODE_PO : FS_MODE_LAO),
                           r->stats_on, r->compute);
         }
@@ -2654,6 +2731,20 @@ uint32_t fs_render_lav2(fs_renderer *r, int type_tag, int mode, int parity, cons
                         (void)hipGetLastError();
                     }
                 }
+            }
+            if (A.pixel_order == nullptr && !second && !at_split && mode != FS_LAV2_PO && A.use_at && A.la_valid) {
+                // a view's first frame: tiles in the order of a sampled PerformAT count (kernels_tile_sample.hip)
+                FsTileSampleArgs S;
+                memset(&S, 0, sizeof(S));
+                S.frame = A.frame;
+                S.coords = A.coords;
+                S.ThresholdC = fs::hreal<double>{A.at.ThresholdC.m, A.at.ThresholdC.e};
+                S.SqrEscapeRadius = fs::hreal<double>{A.at.SqrEscapeRadius.m, A.at.SqrEscapeRadius.e};
+                S.RefC = fs::hcplx<double>{A.at.RefC.re, A.at.RefC.im, A.at.RefC.e};
+                S.CCoeff = fs::hcplx<double>{A.at.CCoeff.re, A.at.CCoeff.im, A.at.CCoeff.e};
+                S.StepLength = A.at.StepLength, S.n_iterations = A.n_iterations;
+                A.tile_order = cold_tile_order(r, S);
+                A.tiles_x = S.tiles_x;
             }
             // the production kernel (kernels_hdr64.hip); FS_VARIANT_LITERAL keeps the operation-by-operation one for A/B
             // (FSMI355_HDR64_LITERAL=1: the literal kernel with the same orders and the same AT pass -- the A/B of the kernel alone)
@@ -3313,6 +3404,7 @@ uint32_t fs_forget_tile_costs(fs_renderer *r)
 }
 
 int fs_last_frame_tile_ordered(fs_renderer *r) { return r->last_frame_ordered ? 1 : 0; }
+int fs_last_frame_sampled_tile_order(fs_renderer *r) { return r->last_cold_ordered ? 1 : 0; }
 
 uint32_t fs_read_tile_costs(fs_renderer *r, uint32_t *out, uint64_t max_words, uint64_t *n_tiles)
 {

@@ -374,6 +374,10 @@ class GPURenderer:
     def last_frame_tile_ordered(self):
         return bool(self._lib.fs_last_frame_tile_ordered(self._h))
 
+    def last_frame_sampled_tile_order(self):
+        """The last LAv2 frame was a view's first frame with its tiles in the order of a sampled PerformAT count (round 6)."""
+        return bool(self._lib.fs_last_frame_sampled_tile_order(self._h))
+
     def read_tile_costs(self):
         """Costs the last tuned LAv2 frame recorded, one per 8 x 8 tile of the local buffer (row-major), or None."""
         n = C.c_uint64(0)

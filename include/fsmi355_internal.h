@@ -74,10 +74,14 @@ uint32_t fs_set_kernel_variant(fs_renderer *r, int variant);
  * -- and the pixel order of the HDRFloat<double> / HDRFloat<CudaDblflt> LAv2 frames (FS_VARIANT_NATURAL_TILE_ORDER above).
  * fs_last_frame_tile_ordered: 1 when the most recent fs_render_lav2 launch used a recorded order / the most recent
  * perturbation-only fs_render_bla launch reused its probe order.
+ * fs_last_frame_sampled_tile_order (round 6): 1 when the most recent fs_render_lav2 launch was a view's FIRST frame of the
+ * HDRFloat<double> / HDRFloat<CudaDblflt> kernels with its tiles in the order of a sampled PerformAT count
+ * (csrc/kernels_tile_sample.hip; A/B switch: environment FSMI355_COLD_TILE_ORDER=0, FS_VARIANT_NATURAL_TILE_ORDER).
  * fs_read_tile_costs: the costs the last frame recorded (row-major tiles of the LOCAL buffer, (width + 7) / 8 per row);
  * *n_tiles = their number; out may be NULL.  FractalSharkError 10006 when nothing has been recorded. */
 uint32_t fs_forget_tile_costs(fs_renderer *r);
 int fs_last_frame_tile_ordered(fs_renderer *r);
+int fs_last_frame_sampled_tile_order(fs_renderer *r);
 uint32_t fs_read_tile_costs(fs_renderer *r, uint32_t *out, uint64_t max_words, uint64_t *n_tiles);
 /* Test hook for the waypoint-resident orbit (fs_set_compressed_orbit_mode(1), HDRFloat<float | double>): one lane's
  * decompression cursor -- with 32-bit positions, or the 64-bit ones the wide kernel uses -- seeks to orbit index `start`

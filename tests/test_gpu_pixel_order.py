@@ -30,10 +30,15 @@ def renderer(native_libs):
 def _frame(r, co, n, T, parity):
     assert r.ClearMemory() == 0
     assert r.RenderPerturbLAv2(None, None, None, *co, n, T=T, Mode=LAV2_FULL, parity=parity) == 0
+    sampled = r.last_frame_sampled_tile_order()
     out = r.new_iter_buffer()
     assert r.RenderCurrent(n, out) == 0
     assert r.SyncComputeStream() == 0
+    _frame.sampled.append(sampled)
     return out, r.last_frame_tile_ordered()
+
+
+_frame.sampled = []  # (per frame: was it a first frame launched in the order of a sampled PerformAT count, kernels_tile_sample.hip)
 
 
 @pytest.mark.parametrize("view_n,parity,st", [(14, PARITY_CPU_GPUSTAGE, 1), (5, PARITY_CPU, 0)])
@@ -49,10 +54,13 @@ def test_hdr64_frames_in_count_order_are_the_first_frame(renderer, native_libs, 
     assert r.forget_tile_costs() == 0
     # an order is made for a view that comes twice: the first frame runs as it is, the second records and sorts, the third and
     # later ones run ordered
+    del _frame.sampled[:]
     first, ordered0 = _frame(r, co, n, T_HDR64, parity)
     second, ordered1 = _frame(r, co, n, T_HDR64, parity)
     third, ordered2 = _frame(r, co, n, T_HDR64, parity)
     fourth, ordered3 = _frame(r, co, n, T_HDR64, parity)
+    # (round 6) the view's FIRST frame runs its tiles in the order of a sampled PerformAT count when the table has an AT; the later ones do not
+    assert _frame.sampled[1:] == [False, False, False] and _frame.sampled[0] == bool(la.use_at)
     # (round 6: a frame whose table has an AT makes its own order from the AT pass -- ordered from the first frame on)
     inframe = False  # (FSMI355_C4_INFRAME_ORDER=1, an A/B that is off: DESIGN.md 7)
     assert (ordered0, ordered1, ordered2, ordered3) == ((True, True, True, True) if inframe else (False, False, True, True))
@@ -73,7 +81,9 @@ def test_hdr64_frames_in_count_order_are_the_first_frame(renderer, native_libs, 
     assert (oa, ob_, ob2) == ((True, True, True) if inframe else (False, False, True)) and np.array_equal(a, b) and np.array_equal(a, b2)
     # the A/B switch and fs_forget_tile_costs
     assert r.set_kernel_variant(0, natural_tile_order=True) == 0
+    del _frame.sampled[:]
     c, oc = _frame(r, co2, n, T_HDR64, parity)
+    assert _frame.sampled == [False]  # (FS_VARIANT_NATURAL_TILE_ORDER: the tile mapping's own order, no sampled one either)
     assert r.set_kernel_variant(0) == 0
     assert oc is False and np.array_equal(c, a)
     assert r.forget_tile_costs() == 0
@@ -111,10 +121,12 @@ def test_2x32_frames_in_count_order_are_the_first_frame(renderer, native_libs):
     assert r.InitializeMemory(W, H, 1, None, 0, 0, 0, False) == 0
     assert r.InitializePerturb(1, o2, 0, None, la2) == 0
     assert r.forget_tile_costs() == 0
+    del _frame.sampled[:]
     first, o0 = _frame(r, co, v.num_iterations, T_HDR2X32, PARITY_CPU)
     mid, om = _frame(r, co, v.num_iterations, T_HDR2X32, PARITY_CPU)
     second, o1 = _frame(r, co, v.num_iterations, T_HDR2X32, PARITY_CPU)
     assert (o0, om, o1) == (False, False, True)
+    assert _frame.sampled == [True, False, False]  # (the first frame: tiles in the order of a sampled PerformAT count)
     assert np.array_equal(first, second) and np.array_equal(first, mid)
     ref = _oracle.gpu_lav2_2x32(v, o2, la2, rows=(500, 504))
     assert np.array_equal(second[500:504], ref[500:504])
