@@ -293,11 +293,28 @@ __device__ __forceinline__ bool step_literal(const FsBlaArgsT<float> &A, PixelSt
 #endif
 // Q[(m - 1) / 4] into v[22:33] for the lanes that have just arrived at an index m = 1 (mod 4) -- the only ones whose next
 // lookup can find anything; s57 = "requested" (the lookup then only waits).  48 bytes per record: (m - 1) * 12.
+// (round 6: FS_BLA_Q_SPLIT -- the kernel keeps the CU's texture-address unit at 0.88 accesses per cycle, and three lookups of five end at the first
+// key test: the record's first 16 bytes -- key, position, level -- are read ahead, the 32 bytes of ladder keys only by the lanes that pass)
+#ifndef FS_BLA_Q_SPLIT
+#define FS_BLA_Q_SPLIT 0 /* (A/B build; measured on C5: 133.8 against 133.5 ms -- the second round trip of the lanes that pass costs what the unread bytes saved) */
+#endif
+#if FS_BLA_Q_SPLIT
+#define FS_Q_LOADS                                                                                                      \
+    "v_mad_u32_u24 v16, v8, 12, -12\n\t"                                                                               \
+    "global_load_dwordx4 v[22:25], v16, %[hq]\n\t"
+#define FS_Q_LOADS_REST                                                                                                 \
+    "v_mad_u32_u24 v16, v8, 12, -12\n\t"                                                                               \
+    "global_load_dwordx4 v[26:29], v16, %[hq] offset:16\n\t"                                                            \
+    "global_load_dwordx4 v[30:33], v16, %[hq] offset:32\n\t"                                                            \
+    "s_waitcnt vmcnt(0)\n\t"
+#else
 #define FS_Q_LOADS                                                                                                      \
     "v_mad_u32_u24 v16, v8, 12, -12\n\t"                                                                               \
     "global_load_dwordx4 v[22:25], v16, %[hq]\n\t"                                                                      \
     "global_load_dwordx4 v[26:29], v16, %[hq] offset:16\n\t"                                                            \
     "global_load_dwordx4 v[30:33], v16, %[hq] offset:32\n\t"
+#define FS_Q_LOADS_REST ""
+#endif
 #define FS_Q_PREFETCH(N)                                                                                                \
     "v_and_b32_e32 v16, 3, v8\n\t"                                                                                      \
     "v_cmp_eq_u32_e32 vcc, 1, v16\n\t"                                                                                  \
@@ -334,7 +351,7 @@ __device__ __forceinline__ bool step_literal(const FsBlaArgsT<float> &A, PixelSt
     "s_waitcnt vmcnt(0)\n\t"                                                                                            \
     "v_cmp_lt_i64_e32 vcc, v[10:11], v[22:23]\n\t"                                                                      \
     "s_and_b64 exec, exec, vcc\n\t"                                                                                     \
-    "s_cbranch_scc0 .Lbf_step_%=\n\t"                                                                                   \
+    "s_cbranch_scc0 .Lbf_step_%=\n\t" FS_Q_LOADS_REST                                                                   \
     "v_cmp_eq_u32_e32 vcc, 0, v25\n\t"                                                                                  \
     "s_cbranch_vccnz .Lbf_slowlk_%=\n\t"                                                                                \
     "s_branch .Lbf_cmp_%=\n"                     /* (the first round's keys came with Q) */                            \
