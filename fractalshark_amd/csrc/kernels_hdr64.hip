@@ -90,6 +90,9 @@ __device__ __forceinline__ C64 add_hi_lo(C64 hi, const C64 lo)
 #ifndef FS_H64_LA_ASM
 #define FS_H64_LA_ASM 1 /* the LA steps of a wave whose lanes stand at one record by hand (la_step_asm.hpp); 0: the compiled loop, A/B */
 #endif
+#ifndef FS_H64_STAGE_SCALAR
+#define FS_H64_STAGE_SCALAR 1 /* the stage's words and its first record's threshold through the scalar cache (0: A/B) */
+#endif
 #ifndef FS_H64_ASM_TINY
 #define FS_H64_ASM_TINY 0x1p-1000 /* what the hand-written statements take for "a norm the value compare cannot be trusted with".  (Test build: 1e300 -- EVERY
                                      step then leaves its statement with status 2, the one exit no view reaches by itself, and the frames must not change.) */
@@ -370,6 +373,23 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
             const R64 dcCheb = hc_cheb(dc);
             while (CurrentLAStage > 0) {
                 CurrentLAStage--;
+#if FS_H64_STAGE_SCALAR
+                // (the stage number is the same in every lane that is still in this loop -- they all count down from stage_count, one per
+                // trip -- which the compiler cannot see behind the loop's divergent exits: said explicitly, the stage's two words and its
+                // first record's LAThresholdC come through the scalar cache instead of three dependent vector loads)
+                typedef const __attribute__((address_space(4))) fs_la_stage_u32 *CStage;
+                typedef const __attribute__((address_space(4))) LaRec *CRec0;
+                const CStage sp = (CStage)(uintptr_t)A.stages + (uint32_t)__builtin_amdgcn_readfirstlane((int)CurrentLAStage);
+                const uint32_t LAIndex = sp->LAIndex;
+                {
+                    const CRec0 r0 = (CRec0)(uintptr_t)A.las + LAIndex;
+                    const int cmp = hr_cmp_pos(dcCheb, R64{r0->LAThresholdC.m, r0->LAThresholdC.e});
+                    const bool invalid = A.parity == FS_PARITY_LITERAL ? (cmp < 0) : (cmp >= 0);
+                    if (invalid)
+                        continue;
+                }
+                const uint32_t MacroItCount = sp->MacroItCount;
+#else
                 const uint32_t LAIndex = A.stages[CurrentLAStage].LAIndex;
                 {
                     const int cmp = hr_cmp_pos(dcCheb, ldr(A.las[LAIndex].LAThresholdC));
@@ -378,6 +398,7 @@ template <int Mode, bool kStats, bool kAtInKernel> __global__ void __launch_boun
                         continue;
                 }
                 const uint32_t MacroItCount = A.stages[CurrentLAStage].MacroItCount;
+#endif
                 const uint32_t base_off = LAIndex * (uint32_t)sizeof(LaRec); // byte offset of the stage's first record
                 uint32_t j = RefIteration;
                 // The Ref of record j + 1, read for the rebase test of step j, is the Ref step j + 1 starts from: it travels in
